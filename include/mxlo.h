@@ -1,0 +1,299 @@
+/* mxlo.h — C ABI of libmxlo.so: the MI355X (gfx950) implementation of the
+ * LinearOperators.jl in-place 5-arg `mul!(res, op, v, alpha, beta)` hot path.
+ *
+ * Every entry point is what the body of ONE reference closure (`prod!`,
+ * `tprod!`, `ctprod!`) — or one quasi-Newton state method — would `ccall`.
+ * Each declaration cites the reference code it replaces as
+ * `src/<file>.jl:<lines>` (paths relative to LinearOperators.jl v2.14.2).
+ *
+ * Conventions
+ *  - plain C, no torch / Julia types: device pointers are `void*`, sizes are
+ *    `int64_t`, scalars are `double`.
+ *  - every function returns an `int32_t` status (`MXLO_OK` == 0). No exception
+ *    ever crosses this boundary; `mxlo_last_error()` returns a thread-local
+ *    human-readable message for the last non-zero status.
+ *  - all work is enqueued on the ctx's HIP stream and is stream-ordered; the
+ *    host returns immediately (`mxlo_ctx_sync` / D2H copies synchronise).
+ *  - vectors are dense, contiguous, element-aligned (NOT necessarily 16-byte
+ *    aligned: `view(res, k+1:k+m)` of cat / block-diag arrive as base+offset,
+ *    src/cat.jl:17-18, src/special-operators.jl:263); matrices column-major
+ *    with a leading dimension, exactly Julia's layout.
+ *  - `dtype`: MXLO_F64 or MXLO_F32 (element type of res / v / operator data).
+ *  - `alpha`, `beta` always arrive as double. For MXLO_F32 data the flag
+ *    MXLO_SCALARS_F64 selects Julia's mixed-precision semantics
+ *    (`mul!(res32, op32, v32, 2.0, 3.0)`: every element evaluated in Float64,
+ *    rounded once on store); without it alpha/beta are first rounded to
+ *    float and the arithmetic is pure fp32 (what the 3-arg `mul!` does,
+ *    src/operations.jl:38-40).
+ *  - `beta == 0` means OVERWRITE: `res` is never read (it may hold NaN/Inf
+ *    garbage from `similar`, src/operations.jl:45, src/constructors.jl:63-78).
+ *  - elementwise arithmetic is evaluated in the reference's association
+ *    order with NO fused multiply-add (the library is built with
+ *    -ffp-contract=off), so the elementwise leaves are bit-identical to the
+ *    reference CPU broadcast; global reductions (dot) use a fixed-order tree
+ *    and are deterministic run-to-run but differ from BLAS order (tolerance
+ *    stated in DESIGN.md).
+ *  - operators are NOT re-entrant (same as the reference, which shares
+ *    temporaries in its closures): at most one in-flight call per ctx / handle.
+ */
+#ifndef MXLO_H
+#define MXLO_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- status codes ------------------------------------------------------ */
+#define MXLO_OK       0
+#define MXLO_EINVAL   1 /* bad argument (null pointer, negative size, bad dtype/flag)      */
+#define MXLO_ESHAPE   2 /* shape mismatch -> glue throws LinearOperatorException             */
+#define MXLO_EHIP     3 /* a HIP runtime call failed                                         */
+#define MXLO_ENOMEM   4 /* device allocation failed                                          */
+#define MXLO_ESTATE   5 /* wrong variant for this handle (e.g. damped push on undamped op)   */
+#define MXLO_EDOMAIN  6 /* argument outside domain (sigma < 0 -> glue throws ArgumentError)  */
+#define MXLO_EREDUCE  7 /* the user all-reduce hook returned non-zero                        */
+
+/* ---- dtypes and flags --------------------------------------------------- */
+#define MXLO_F64 0
+#define MXLO_F32 1
+
+#define MXLO_SCALARS_F64 0x1 /* f32 data, alpha/beta kept in double (see header comment)     */
+#define MXLO_D_SCALAR    0x2 /* diag: `d` has ONE element, broadcast (SpectralGradient,
+                                src/DiagonalHessianApproximation.jl:226)                      */
+#define MXLO_TAIL_BETA   0x4 /* eye: rows [n_min,nrow) receive `beta` (NOT beta*res) when
+                                beta != 0 — reference quirk, src/special-operators.jl:42     */
+
+/* transposition modes for matrix-carrying leaves */
+#define MXLO_OP_N 0 /* prod!   */
+#define MXLO_OP_T 1 /* tprod!  */
+#define MXLO_OP_C 2 /* ctprod! (== T for the real dtypes this library instantiates) */
+
+typedef struct mxlo_ctx mxlo_ctx;     /* opaque: device, stream, reduction workspace, tuning  */
+typedef struct mxlo_qn mxlo_qn;       /* opaque: L-BFGS / L-SR1 state resident in HBM         */
+typedef struct mxlo_timer mxlo_timer; /* opaque: a hipEvent pair on the ctx stream            */
+
+/* ---- library / context --------------------------------------------------- */
+const char *mxlo_version(void);
+const char *mxlo_status_string(int32_t status);
+const char *mxlo_last_error(void);
+
+/* `stream` is a hipStream_t (or NULL for the device's default stream). The
+ * ctx does not own a caller-provided stream. */
+int32_t mxlo_ctx_create(int32_t device_id, void *stream, mxlo_ctx **out);
+int32_t mxlo_ctx_destroy(mxlo_ctx *ctx);
+int32_t mxlo_ctx_set_stream(mxlo_ctx *ctx, void *stream);
+int32_t mxlo_ctx_sync(mxlo_ctx *ctx);
+/* info[0]=device id, [1]=CU count, [2]=workspace bytes, [3]=max reduction columns */
+int32_t mxlo_ctx_info(mxlo_ctx *ctx, int64_t info[4]);
+/* Launch-geometry knobs for sweeps (key: "blocks_per_cu", "unroll", "nt",
+ * "house_reverse", "dots_nc", ...). Unknown key -> MXLO_EINVAL. */
+int32_t mxlo_ctx_tune(mxlo_ctx *ctx, const char *key, int64_t value);
+
+/* Row-sharding hook. When set, EVERY global reduction this ctx performs
+ * (Householder h'v, L-BFGS/L-SR1 panel dots, push! dots, shifted-solve dots)
+ * calls `fn(user, dev_buf, count, stream)` right after the local fixed-order
+ * finalize and before any kernel consumes the scalars: `dev_buf` holds `count`
+ * doubles in device memory that must be sum-all-reduced in place, stream-
+ * ordered on `stream` (e.g. ncclAllReduce(dev_buf, dev_buf, count, ncclDouble,
+ * ncclSum, comm, stream)). All ranks then hold bit-identical scalars, which
+ * drive the replicated control flow (`ys[k] != 0` skips, push! rejection).
+ * The reference has no distributed path; this is the seam for it. */
+typedef int32_t (*mxlo_allreduce_fn)(void *user, void *dev_buf, int64_t count, void *stream);
+int32_t mxlo_ctx_set_allreduce(mxlo_ctx *ctx, mxlo_allreduce_fn fn, void *user);
+
+/* ---- device-memory helpers for the glue's device-vector type ------------- */
+int32_t mxlo_malloc(mxlo_ctx *ctx, int64_t bytes, void **out);
+int32_t mxlo_free(mxlo_ctx *ctx, void *p);
+int32_t mxlo_memcpy_h2d(mxlo_ctx *ctx, void *dst, const void *src, int64_t bytes);
+int32_t mxlo_memcpy_d2h(mxlo_ctx *ctx, void *dst, const void *src, int64_t bytes); /* syncs */
+int32_t mxlo_memcpy_d2d(mxlo_ctx *ctx, void *dst, const void *src, int64_t bytes);
+int32_t mxlo_memset(mxlo_ctx *ctx, void *p, int32_t byte, int64_t bytes);
+
+/* ---- timing on the ctx stream (bench / roofline evidence) ---------------- */
+int32_t mxlo_timer_create(mxlo_ctx *ctx, mxlo_timer **out);
+int32_t mxlo_timer_start(mxlo_timer *t);
+int32_t mxlo_timer_stop(mxlo_timer *t);
+int32_t mxlo_timer_elapsed_ms(mxlo_timer *t, double *ms); /* syncs on the stop event */
+int32_t mxlo_timer_destroy(mxlo_timer *t);
+
+/* ======================================================================== */
+/*  Leaf closures                                                            */
+/* ======================================================================== */
+
+/* mulSquareOpDiagonal! / mulOpDiagonal!  — src/special-operators.jl:125-131,144-151
+ * (also the mul! of DiagonalPSB/Andrei/BFGS/SpectralGradient,
+ *  src/DiagonalHessianApproximation.jl:37,112,179,226).
+ *   i <  n_min : res[i] = (alpha*d[i])*v[i]                    (beta == 0)
+ *                res[i] = ((alpha*d[i])*v[i]) + (beta*res[i])  (beta != 0)
+ *   n_min <= i < nrow : res[i] = 0   (rectangular form zeroes the tail
+ *                                     regardless of beta, :150)
+ * Square operator: n_min == nrow. ctprod! on real data is the same call. */
+int32_t mxlo_diag_mul(mxlo_ctx *ctx, int32_t dtype, void *res, const void *d, const void *v,
+                      int64_t n_min, int64_t nrow, double alpha, double beta, int32_t flags);
+
+/* mulOpEye! — src/special-operators.jl:36-44.
+ *   i < n_min: res[i] = alpha*v[i] (+ beta*res[i]);
+ *   tail: 0 when beta==0, else `beta` itself (MXLO_TAIL_BETA, reference quirk)
+ *   or beta*res[i] (flag clear; used as the generic axpby of prod3!,
+ *   src/operations.jl:10-20: `res .= alpha .* Mv .+ beta .* res`). */
+int32_t mxlo_eye_mul(mxlo_ctx *ctx, int32_t dtype, void *res, const void *v, int64_t n_min,
+                     int64_t nrow, double alpha, double beta, int32_t flags);
+
+/* mulOpZeros! — src/special-operators.jl:102-108: res .= 0  |  res .*= beta. */
+int32_t mxlo_zeros_mul(mxlo_ctx *ctx, int32_t dtype, void *res, int64_t nrow, double beta,
+                       int32_t flags);
+
+/* mulOpOnes! — src/special-operators.jl:79-85: res .= (alpha*sum(v)) (.+ beta.*res). */
+int32_t mxlo_ones_mul(mxlo_ctx *ctx, int32_t dtype, void *res, int64_t nrow, const void *v,
+                      int64_t ncol, double alpha, double beta, int32_t flags);
+
+/* `res .*= alpha` of prod3! — src/operations.jl:13-15. */
+int32_t mxlo_scale(mxlo_ctx *ctx, int32_t dtype, void *res, int64_t n, double alpha,
+                   int32_t flags);
+
+/* mulHouseholder! — src/linalg.jl:77-83.
+ *   c = 2*dot(h,v);  res[i] = alpha*(v[i] - c*h[i]) (+ beta*res[i]).
+ * Two launches + finalize: (A) fixed-order partial dots -> device scalar,
+ * [all-reduce hook], (B) update reading the device scalar. No host sync. */
+int32_t mxlo_householder_mul(mxlo_ctx *ctx, int32_t dtype, void *res, const void *h,
+                             const void *v, int64_t n, double alpha, double beta,
+                             int32_t flags);
+
+/* mulHermitian! — src/linalg.jl:97-103, operator built by opHermitian(d, A)
+ * (:109-116) which keeps L = tril(A,-1).
+ *   res = alpha*((d.*v + L*v) + L'*v) (+ beta*res)
+ * `A` is the ORIGINAL n x n column-major matrix (leading dimension lda); only
+ * its strict lower triangle is read, once. */
+int32_t mxlo_hermitian_mul(mxlo_ctx *ctx, int32_t dtype, void *res, const void *d,
+                           const void *A, int64_t lda, const void *v, int64_t n, double alpha,
+                           double beta, int32_t flags);
+
+/* mulRestrict! — src/special-operators.jl:167-169: res .= view(v, I); alpha and
+ * beta are IGNORED by the reference and are therefore not parameters.
+ * Pure data movement: bit-exact, `elem_size` in {4, 8, 16} bytes.
+ *  idx form   : I is a device Int64 vector of 1-BASED indices as Julia stores them.
+ *  range form : I = start:step:start+step*(len-1) (UnitRange / StepRange), 1-based. */
+int32_t mxlo_gather(mxlo_ctx *ctx, int32_t elem_size, void *res, const void *v, int64_t nv,
+                    const int64_t *idx, int64_t nidx);
+int32_t mxlo_gather_range(mxlo_ctx *ctx, int32_t elem_size, void *res, const void *v,
+                          int64_t nv, int64_t start, int64_t step, int64_t len);
+
+/* multRestrict! — src/special-operators.jl:171-174: res .= 0; res[I] = u.
+ * Duplicate indices: the reference's sequential loop makes the LAST write win.
+ * The glue resolves that at operator construction (indices are construction-
+ * time data): it passes the deduplicated index list plus `pos` (0-based
+ * position in `u` of the surviving write for each kept index; NULL when there
+ * are no duplicates, meaning pos[k] == k). */
+int32_t mxlo_scatter_zero(mxlo_ctx *ctx, int32_t elem_size, void *res, int64_t nres,
+                          const void *u, const int64_t *idx, const int64_t *pos, int64_t nidx);
+int32_t mxlo_scatter_zero_range(mxlo_ctx *ctx, int32_t elem_size, void *res, int64_t nres,
+                                const void *u, int64_t start, int64_t step, int64_t len);
+
+/* BlockDiagonalOperator prod!/tprod!/ctprod! — src/special-operators.jl:258-289.
+ * The reference loops over blocks issuing one inner mul! per block (1024
+ * launches at BASELINE config 4); here the whole operator is ONE launch over a
+ * device-resident descriptor table built once at construction. */
+#define MXLO_BLK_DIAG  0 /* opDiagonal block: data = d (m == n)                            */
+#define MXLO_BLK_DENSE 1 /* plain matrix block m x n, column-major, leading dimension ld   */
+#define MXLO_BLK_EYE   2 /* opEye(n)                                                       */
+#define MXLO_BLK_ZEROS 3 /* opZeros(m,n)                                                   */
+typedef struct mxlo_block_desc {
+  int32_t kind;     /* MXLO_BLK_*                                   */
+  int32_t reserved;
+  int64_t row_off;  /* first row of this block in res (0-based)     */
+  int64_t col_off;  /* first column of this block in v (0-based)    */
+  int64_t m, n;     /* block size                                   */
+  const void *data; /* device pointer (d or matrix), NULL for eye/zeros */
+  int64_t ld;       /* leading dimension (dense)                    */
+} mxlo_block_desc;
+typedef struct mxlo_blockdiag mxlo_blockdiag; /* opaque: device descriptor + tile table */
+int32_t mxlo_blockdiag_create(mxlo_ctx *ctx, int32_t dtype, const mxlo_block_desc *blocks,
+                              int64_t nblocks, mxlo_blockdiag **out);
+int32_t mxlo_blockdiag_mul(mxlo_blockdiag *bd, void *res, const void *v, double alpha,
+                           double beta, int32_t op_mode, int32_t flags);
+int32_t mxlo_blockdiag_destroy(mxlo_blockdiag *bd);
+
+/* kron(A,B) prod!/tprod!/ctprod! — src/kron.jl:14-40.
+ *   N: X = reshape(x, q, n);  res = alpha*vec(B*X*transpose(A)) (+ beta*res)
+ *   T/C: X = reshape(x, p, m); res = alpha*vec(transpose(B)*X*A) (+ beta*res)
+ * A is m x n (lda), B is p x q (ldb), both dense column-major on the device.
+ * Two f64/f32 GEMMs on the matrix cores (v_mfma_f64_16x16x4_f64 /
+ * v_mfma_f32_16x16x4_f32) with the alpha/beta epilogue fused in the second.
+ * `work` must hold max(p*n, q*m) elements (the glue allocates it once at
+ * construction, like the reference's compose temporaries, src/operations.jl:149-151). */
+int32_t mxlo_kron_mul(mxlo_ctx *ctx, int32_t dtype, void *res, const void *A, int64_t m,
+                      int64_t n, int64_t lda, const void *B, int64_t p, int64_t q, int64_t ldb,
+                      const void *x, void *work, double alpha, double beta, int32_t op_mode,
+                      int32_t flags);
+
+/* Dense LinearOperator(M) prod!/tprod! — src/constructors.jl:19-29 delegates to
+ * LinearAlgebra.mul!; needed for dense blocks and for kron of operators. GEMV. */
+int32_t mxlo_gemv(mxlo_ctx *ctx, int32_t dtype, void *res, const void *M, int64_t m, int64_t n,
+                  int64_t ld, const void *v, double alpha, double beta, int32_t op_mode,
+                  int32_t flags);
+
+/* ======================================================================== */
+/*  Quasi-Newton operators (state resident in HBM)                           */
+/* ======================================================================== */
+#define MXLO_QN_LBFGS_INV 0 /* InverseLBFGSOperator — src/lbfgs.jl:112-158 */
+#define MXLO_QN_LBFGS_FWD 1 /* LBFGSOperator        — src/lbfgs.jl:168-206 */
+#define MXLO_QN_LSR1      2 /* LSR1Operator         — src/lsr1.jl:86-111   */
+
+/* inverse two-loop evaluation strategy (ctx tune key "lbfgs_inv_mode" is the default) */
+#define MXLO_INV_TWOPASS 0 /* panel form: one dots pass, m x m recurrences on Gram
+                              matrices kept up to date by push!, one combine pass      */
+#define MXLO_INV_REFORDER 1 /* reference statement order: 2m chained fused axpy+dot      */
+
+/* LBFGSData / LSR1Data constructors — src/lbfgs.jl:26-57, src/lsr1.jl:19-34.
+ * mem is clamped to >= 1 like the reference. Panels s,y(,a,b) are n x mem
+ * column-major allocations owned by the handle; shifted_p is NOT allocated
+ * eagerly (the reference allocates n x 2mem at :53; the coefficient-space
+ * solve does not need it). */
+int32_t mxlo_qn_create(mxlo_ctx *ctx, int32_t kind, int32_t dtype, int64_t n, int64_t mem,
+                       int32_t scaling, int32_t damped, double sigma2, double sigma3,
+                       mxlo_qn **out);
+int32_t mxlo_qn_destroy(mxlo_qn *h);
+
+/* push!(op, s, y) — src/lbfgs.jl:269-287 -> push_common! :210-255;
+ *                   src/lsr1.jl:119-184.
+ * `accepted` receives 1/0 (the reference silently returns `op` on rejection).
+ * Needs the host to see ys (rejection is host control flow): one 2-5 double D2H. */
+int32_t mxlo_qn_push(mxlo_qn *h, const void *s, const void *y, int32_t *accepted);
+/* push!(op, s, y, Bs) forward damped — src/lbfgs.jl:289-323. `Bs` is caller scratch (n). */
+int32_t mxlo_qn_push_damped_fwd(mxlo_qn *h, const void *s, const void *y, void *Bs,
+                                int32_t *accepted);
+/* push!(op, s, y, alpha, g, Bs) inverse damped — src/lbfgs.jl:325-357. NOTE: like the
+ * reference (`y .= ...`, :351) this OVERWRITES the caller's y when damping triggers. */
+int32_t mxlo_qn_push_damped_inv(mxlo_qn *h, const void *s, void *y, double alpha,
+                                const void *g, void *Bs, int32_t *accepted);
+
+/* lbfgs_multiply / lsr1_multiply — src/lbfgs.jl:117-154, 173-202; src/lsr1.jl:89-107. */
+int32_t mxlo_qn_mul(mxlo_qn *h, void *res, const void *x, double alpha, double beta,
+                    int32_t flags);
+
+/* solve_shifted_system!(x, B, b, sigma) — src/utilities.jl:207-248 (forward L-BFGS only);
+ * ldiv! (:281-289) is sigma = 0. sigma < 0 -> MXLO_EDOMAIN (reference: ArgumentError). */
+int32_t mxlo_qn_solve_shifted(mxlo_qn *h, void *x, const void *b, double sigma);
+
+/* diag!(op, d) — src/lbfgs.jl:379-395 (forward only), src/lsr1.jl:196-211. */
+int32_t mxlo_qn_diag(mxlo_qn *h, void *d);
+
+/* reset!(data) — src/lbfgs.jl:401-415, src/lsr1.jl:217-228 (counters live in the glue). */
+int32_t mxlo_qn_reset(mxlo_qn *h);
+
+/* Fields the reference's tests read (test_lbfgs.jl:16,45-46,64-65,70):
+ *   scalars[0]=insert (1-based), [1]=scaling_factor, [2]=opnorm_upper_bound,
+ *   [3]=mem, [4]=n; per-slot arrays of length mem (may be NULL):
+ *   ys, aux = alpha (inverse) | norm_b (forward) | as (L-SR1). */
+int32_t mxlo_qn_get_scalars(mxlo_qn *h, double scalars[5], double *ys, double *aux);
+/* Device pointer of one panel column, k 0-based: which = 0:s 1:y 2:a 3:b. */
+int32_t mxlo_qn_column(mxlo_qn *h, int32_t which, int64_t k, void **out);
+/* Evaluation strategy for the inverse two-loop (MXLO_INV_*). */
+int32_t mxlo_qn_set_mode(mxlo_qn *h, int32_t mode);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MXLO_H */

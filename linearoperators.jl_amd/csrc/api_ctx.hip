@@ -1,0 +1,214 @@
+// api_ctx.hip — context, device-memory helpers, timers, error reporting of libmxlo.so.
+#include "common.h"
+
+namespace mxlo {
+static thread_local char g_err[512] = "";
+void set_error(const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+}  // namespace mxlo
+
+using namespace mxlo;
+
+MXLO_API const char *mxlo_version(void) { return "mxlo 0.1.0 (gfx950)"; }
+
+MXLO_API const char *mxlo_status_string(int32_t s) {
+  switch (s) {
+    case MXLO_OK: return "ok";
+    case MXLO_EINVAL: return "invalid argument";
+    case MXLO_ESHAPE: return "shape mismatch";
+    case MXLO_EHIP: return "HIP runtime error";
+    case MXLO_ENOMEM: return "out of device memory";
+    case MXLO_ESTATE: return "wrong variant for this operator state";
+    case MXLO_EDOMAIN: return "argument outside domain";
+    case MXLO_EREDUCE: return "all-reduce hook failed";
+    default: return "unknown status";
+  }
+}
+
+MXLO_API const char *mxlo_last_error(void) { return g_err; }
+
+MXLO_API int32_t mxlo_ctx_create(int32_t device_id, void *stream, mxlo_ctx **out) {
+  MXLO_REQUIRE(out != nullptr, MXLO_EINVAL, "mxlo_ctx_create: out is NULL");
+  int ndev = 0;
+  MXLO_HIP(hipGetDeviceCount(&ndev));
+  MXLO_REQUIRE(device_id >= 0 && device_id < ndev, MXLO_EINVAL,
+               "mxlo_ctx_create: device %d not in [0,%d)", device_id, ndev);
+  MXLO_HIP(hipSetDevice(device_id));
+  hipDeviceProp_t prop;
+  MXLO_HIP(hipGetDeviceProperties(&prop, device_id));
+  mxlo_ctx *ctx = new mxlo_ctx();
+  ctx->device = device_id;
+  ctx->stream = (hipStream_t)stream;
+  ctx->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  hipError_t e = hipMalloc((void **)&ctx->partials, sizeof(double) * kMaxRedCols * kMaxRedBlocks);
+  if (e == hipSuccess) e = hipMalloc((void **)&ctx->scalars, sizeof(double) * kScalarSlots);
+  if (e != hipSuccess) {
+    set_error("mxlo_ctx_create: workspace allocation failed: %s", hipGetErrorString(e));
+    if (ctx->partials) (void)hipFree(ctx->partials);
+    delete ctx;
+    return MXLO_ENOMEM;
+  }
+  MXLO_HIP(hipMemsetAsync(ctx->scalars, 0, sizeof(double) * kScalarSlots, ctx->stream));
+  *out = ctx;
+  return MXLO_OK;
+}
+
+MXLO_API int32_t mxlo_ctx_destroy(mxlo_ctx *ctx) {
+  if (!ctx) return MXLO_OK;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->partials) (void)hipFree(ctx->partials);
+  if (ctx->scalars) (void)hipFree(ctx->scalars);
+  delete ctx;
+  return MXLO_OK;
+}
+
+MXLO_API int32_t mxlo_ctx_set_stream(mxlo_ctx *ctx, void *stream) {
+  MXLO_REQUIRE(ctx, MXLO_EINVAL, "ctx is NULL");
+  ctx->stream = (hipStream_t)stream;
+  return MXLO_OK;
+}
+
+MXLO_API int32_t mxlo_ctx_sync(mxlo_ctx *ctx) {
+  MXLO_REQUIRE(ctx, MXLO_EINVAL, "ctx is NULL");
+  MXLO_HIP(hipStreamSynchronize(ctx->stream));
+  return MXLO_OK;
+}
+
+MXLO_API int32_t mxlo_ctx_info(mxlo_ctx *ctx, int64_t info[4]) {
+  MXLO_REQUIRE(ctx && info, MXLO_EINVAL, "ctx/info is NULL");
+  info[0] = ctx->device;
+  info[1] = ctx->num_cu;
+  info[2] = (int64_t)sizeof(double) * (kMaxRedCols * kMaxRedBlocks + kScalarSlots);
+  info[3] = kMaxRedCols;
+  return MXLO_OK;
+}
+
+MXLO_API int32_t mxlo_ctx_tune(mxlo_ctx *ctx, const char *key, int64_t value) {
+  MXLO_REQUIRE(ctx && key, MXLO_EINVAL, "ctx/key is NULL");
+  if (!strcmp(key, "blocks_per_cu")) {
+    MXLO_REQUIRE(value >= 1 && value <= 64, MXLO_EINVAL, "blocks_per_cu out of range");
+    ctx->tune.blocks_per_cu = (int)value;
+  } else if (!strcmp(key, "red_blocks_per_cu")) {
+    MXLO_REQUIRE(value >= 1 && value * ctx->num_cu <= kMaxRedBlocks, MXLO_EINVAL,
+                 "red_blocks_per_cu out of range");
+    ctx->tune.red_blocks_per_cu = (int)value;
+  } else if (!strcmp(key, "house_reverse")) {
+    ctx->tune.house_reverse = value != 0;
+  } else if (!strcmp(key, "lbfgs_inv_mode")) {
+    MXLO_REQUIRE(value == MXLO_INV_TWOPASS || value == MXLO_INV_REFORDER, MXLO_EINVAL,
+                 "lbfgs_inv_mode must be MXLO_INV_TWOPASS or MXLO_INV_REFORDER");
+    ctx->tune.lbfgs_inv_mode = (int)value;
+  } else if (!strcmp(key, "dots_max_nc")) {
+    MXLO_REQUIRE(value >= 1 && value <= 20, MXLO_EINVAL, "dots_max_nc out of range");
+    ctx->tune.dots_max_nc = (int)value;
+  } else {
+    set_error("mxlo_ctx_tune: unknown key '%s'", key);
+    return MXLO_EINVAL;
+  }
+  return MXLO_OK;
+}
+
+MXLO_API int32_t mxlo_ctx_set_allreduce(mxlo_ctx *ctx, mxlo_allreduce_fn fn, void *user) {
+  MXLO_REQUIRE(ctx, MXLO_EINVAL, "ctx is NULL");
+  ctx->allreduce = fn;
+  ctx->allreduce_user = user;
+  return MXLO_OK;
+}
+
+// ---- memory helpers -----------------------------------------------------------
+MXLO_API int32_t mxlo_malloc(mxlo_ctx *ctx, int64_t bytes, void **out) {
+  MXLO_REQUIRE(ctx && out && bytes >= 0, MXLO_EINVAL, "mxlo_malloc: bad argument");
+  *out = nullptr;
+  if (bytes == 0) return MXLO_OK;
+  (void)hipSetDevice(ctx->device);
+  hipError_t e = hipMalloc(out, (size_t)bytes);
+  if (e != hipSuccess) {
+    set_error("mxlo_malloc(%lld): %s", (long long)bytes, hipGetErrorString(e));
+    return MXLO_ENOMEM;
+  }
+  return MXLO_OK;
+}
+
+MXLO_API int32_t mxlo_free(mxlo_ctx *ctx, void *p) {
+  MXLO_REQUIRE(ctx, MXLO_EINVAL, "ctx is NULL");
+  if (!p) return MXLO_OK;
+  MXLO_HIP(hipStreamSynchronize(ctx->stream));
+  MXLO_HIP(hipFree(p));
+  return MXLO_OK;
+}
+
+MXLO_API int32_t mxlo_memcpy_h2d(mxlo_ctx *ctx, void *dst, const void *src, int64_t bytes) {
+  MXLO_REQUIRE(ctx && bytes >= 0, MXLO_EINVAL, "bad argument");
+  if (!bytes) return MXLO_OK;
+  MXLO_HIP(hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyHostToDevice, ctx->stream));
+  MXLO_HIP(hipStreamSynchronize(ctx->stream));  // the host buffer may be pageable / reused
+  return MXLO_OK;
+}
+
+MXLO_API int32_t mxlo_memcpy_d2h(mxlo_ctx *ctx, void *dst, const void *src, int64_t bytes) {
+  MXLO_REQUIRE(ctx && bytes >= 0, MXLO_EINVAL, "bad argument");
+  if (!bytes) return MXLO_OK;
+  MXLO_HIP(hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyDeviceToHost, ctx->stream));
+  MXLO_HIP(hipStreamSynchronize(ctx->stream));
+  return MXLO_OK;
+}
+
+MXLO_API int32_t mxlo_memcpy_d2d(mxlo_ctx *ctx, void *dst, const void *src, int64_t bytes) {
+  MXLO_REQUIRE(ctx && bytes >= 0, MXLO_EINVAL, "bad argument");
+  if (!bytes) return MXLO_OK;
+  MXLO_HIP(hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyDeviceToDevice, ctx->stream));
+  return MXLO_OK;
+}
+
+MXLO_API int32_t mxlo_memset(mxlo_ctx *ctx, void *p, int32_t byte, int64_t bytes) {
+  MXLO_REQUIRE(ctx && bytes >= 0, MXLO_EINVAL, "bad argument");
+  if (!bytes) return MXLO_OK;
+  MXLO_HIP(hipMemsetAsync(p, byte, (size_t)bytes, ctx->stream));
+  return MXLO_OK;
+}
+
+// ---- timers ---------------------------------------------------------------------
+struct mxlo_timer {
+  mxlo_ctx *ctx;
+  hipEvent_t e0, e1;
+};
+
+MXLO_API int32_t mxlo_timer_create(mxlo_ctx *ctx, mxlo_timer **out) {
+  MXLO_REQUIRE(ctx && out, MXLO_EINVAL, "bad argument");
+  mxlo_timer *t = new mxlo_timer();
+  t->ctx = ctx;
+  MXLO_HIP(hipEventCreate(&t->e0));
+  MXLO_HIP(hipEventCreate(&t->e1));
+  *out = t;
+  return MXLO_OK;
+}
+MXLO_API int32_t mxlo_timer_start(mxlo_timer *t) {
+  MXLO_REQUIRE(t, MXLO_EINVAL, "timer is NULL");
+  MXLO_HIP(hipEventRecord(t->e0, t->ctx->stream));
+  return MXLO_OK;
+}
+MXLO_API int32_t mxlo_timer_stop(mxlo_timer *t) {
+  MXLO_REQUIRE(t, MXLO_EINVAL, "timer is NULL");
+  MXLO_HIP(hipEventRecord(t->e1, t->ctx->stream));
+  return MXLO_OK;
+}
+MXLO_API int32_t mxlo_timer_elapsed_ms(mxlo_timer *t, double *ms) {
+  MXLO_REQUIRE(t && ms, MXLO_EINVAL, "bad argument");
+  MXLO_HIP(hipEventSynchronize(t->e1));
+  float f = 0.f;
+  MXLO_HIP(hipEventElapsedTime(&f, t->e0, t->e1));
+  *ms = (double)f;
+  return MXLO_OK;
+}
+MXLO_API int32_t mxlo_timer_destroy(mxlo_timer *t) {
+  if (!t) return MXLO_OK;
+  (void)hipEventDestroy(t->e0);
+  (void)hipEventDestroy(t->e1);
+  delete t;
+  return MXLO_OK;
+}

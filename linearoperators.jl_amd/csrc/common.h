@@ -1,0 +1,132 @@
+// common.h — internal definitions shared by the libmxlo.so translation units.
+// gfx950 (MI355X, CDNA4) only: wave = 64 lanes, 256 CUs in 8 XCDs.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <initializer_list>
+#include <type_traits>
+
+#include "../../include/mxlo.h"
+
+#define MXLO_API extern "C" __attribute__((visibility("default")))
+
+namespace mxlo {
+
+constexpr int kBlock = 256;          // 4 waves of 64 lanes: one wave per SIMD of a CU
+constexpr int kWave = 64;
+constexpr int kMaxRedCols = 64;      // columns a single reduction call may produce
+constexpr int kMaxRedBlocks = 4096;  // partial slots per column in the workspace
+constexpr int kScalarSlots = 8192;   // doubles in the device scalar buffer
+
+void set_error(const char *fmt, ...);
+
+#define MXLO_HIP(call)                                                                           \
+  do {                                                                                           \
+    hipError_t e__ = (call);                                                                     \
+    if (e__ != hipSuccess) {                                                                     \
+      mxlo::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), __FILE__, __LINE__); \
+      return MXLO_EHIP;                                                                          \
+    }                                                                                            \
+  } while (0)
+
+#define MXLO_REQUIRE(cond, code, ...)                                                            \
+  do {                                                                                           \
+    if (!(cond)) {                                                                               \
+      mxlo::set_error(__VA_ARGS__);                                                              \
+      return (code);                                                                             \
+    }                                                                                            \
+  } while (0)
+
+#define MXLO_TRY(expr)                                                                           \
+  do {                                                                                           \
+    int32_t s__ = (expr);                                                                        \
+    if (s__ != MXLO_OK) return s__;                                                              \
+  } while (0)
+
+#define MXLO_LAUNCH_CHECK()                                                                      \
+  do {                                                                                           \
+    hipError_t e__ = hipGetLastError();                                                          \
+    if (e__ != hipSuccess) {                                                                     \
+      mxlo::set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(e__), __FILE__,      \
+                      __LINE__);                                                                 \
+      return MXLO_EHIP;                                                                          \
+    }                                                                                            \
+  } while (0)
+
+struct Tune {
+  int blocks_per_cu = 8;   // streaming kernels: persistent grid = CUs * blocks_per_cu
+  int red_blocks_per_cu = 4;  // reduction kernels
+  int house_reverse = 1;   // Householder phase B walks the vectors back-to-front (MALL tail reuse)
+  int lbfgs_inv_mode = MXLO_INV_TWOPASS;
+  int dots_max_nc = 20;    // columns per panel_dots launch (<= 20)
+};
+
+}  // namespace mxlo
+
+struct mxlo_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  int num_cu = 256;
+  double *partials = nullptr;  // [kMaxRedCols][kMaxRedBlocks] per-block partial sums
+  double *scalars = nullptr;   // finalized reduction results / device-resident coefficients
+  mxlo_allreduce_fn allreduce = nullptr;
+  void *allreduce_user = nullptr;
+  mxlo::Tune tune;
+};
+
+namespace mxlo {
+
+// ---- 16-byte vector types --------------------------------------------------
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <typename T>
+struct Vec16;
+template <>
+struct Vec16<double> {
+  using type = f64x2;
+  static constexpr int N = 2;
+};
+template <>
+struct Vec16<float> {
+  using type = f32x4;
+  static constexpr int N = 4;
+};
+
+// ---- alignment analysis for the vector path ---------------------------------
+// All operands of an elementwise kernel can use 16-byte accesses iff they share
+// the same address modulo 16; then `head` leading elements are peeled so the
+// body starts 16-byte aligned. Returns -1 when the operands disagree.
+template <typename T>
+inline int64_t common_head(std::initializer_list<const void *> ptrs) {
+  int64_t mis = -1;
+  for (const void *p : ptrs) {
+    if (!p) continue;
+    int64_t m = (int64_t)((uintptr_t)p & 15u);
+    if (m % (int64_t)sizeof(T)) return -1;
+    if (mis < 0) mis = m;
+    else if (mis != m) return -1;
+  }
+  if (mis <= 0) return 0;
+  return (16 - mis) / (int64_t)sizeof(T);
+}
+
+inline int grid_for(const mxlo_ctx *ctx, int64_t work_items, int64_t items_per_block, int per_cu) {
+  int64_t need = (work_items + items_per_block - 1) / items_per_block;
+  int64_t cap = (int64_t)ctx->num_cu * per_cu;
+  int64_t g = need < cap ? need : cap;
+  return (int)(g < 1 ? 1 : g);
+}
+
+// reductions.hip
+int32_t finalize_and_reduce(mxlo_ctx *ctx, int ncols, int nblocks, double *out_dev);
+int32_t allreduce_hook(mxlo_ctx *ctx, double *dev, int64_t count);
+template <typename T>
+int32_t panel_dots(mxlo_ctx *ctx, const T *const *cols_host, int ncols, const T *x, int64_t n,
+                   double *out_dev);
+
+}  // namespace mxlo

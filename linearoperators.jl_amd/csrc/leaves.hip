@@ -1,0 +1,381 @@
+// leaves.hip — C-ABI entry points of the elementwise / data-movement leaf closures:
+// opDiagonal, opEye, opZeros, opOnes, prod3! helpers, opHouseholder,
+// opRestriction / opExtension.
+#include "common.h"
+#include "stream_kernels.h"
+
+using namespace mxlo;
+
+#define CHECK_COMMON(name)                                                                       \
+  MXLO_REQUIRE(ctx != nullptr, MXLO_EINVAL, name ": ctx is NULL");                               \
+  MXLO_REQUIRE(dtype == MXLO_F64 || dtype == MXLO_F32, MXLO_EINVAL, name ": bad dtype %d", dtype)
+
+static inline double eff_beta(int32_t dtype, int32_t flags, double beta) {
+  return (dtype == MXLO_F32 && !(flags & MXLO_SCALARS_F64)) ? (double)(float)beta : beta;
+}
+static inline double eff_alpha(int32_t dtype, int32_t flags, double alpha) {
+  return (dtype == MXLO_F32 && !(flags & MXLO_SCALARS_F64)) ? (double)(float)alpha : alpha;
+}
+
+// ---- fill helper -------------------------------------------------------------------
+template <typename T>
+static int32_t fill(mxlo_ctx *ctx, T *p, int64_t n, T c) {
+  if (n <= 0) return MXLO_OK;
+  if (c == T(0)) {
+    MXLO_HIP(hipMemsetAsync(p, 0, sizeof(T) * (size_t)n, ctx->stream));
+    return MXLO_OK;
+  }
+  return launch_map<T, 0, false, false>(ctx, p, (const T *)nullptr, (const T *)nullptr, n,
+                                        FillOp<T>{c});
+}
+
+// ---- opDiagonal ---------------------------------------------------------------------
+template <typename T>
+static int32_t diag_mul_t(mxlo_ctx *ctx, T *res, const T *d, const T *v, int64_t n_min,
+                          int64_t nrow, double alpha, double beta, int32_t flags) {
+  int32_t st = dispatch_ct<T>(beta, flags, [&]<typename CT, bool B0>() -> int32_t {
+    if (flags & MXLO_D_SCALAR) {
+      DiagScalarOp<T, CT, B0> op{(CT)alpha, (CT)beta, d, (CT)0};
+      return launch_map<T, 1, !B0, false>(ctx, res, v, (const T *)nullptr, n_min, op);
+    }
+    DiagOp<T, CT, B0> op{(CT)alpha, (CT)beta};
+    return launch_map<T, 2, !B0, false>(ctx, res, d, v, n_min, op);
+  });
+  MXLO_TRY(st);
+  // rectangular form: res[n_min+1:end] .= 0 regardless of beta (special-operators.jl:150)
+  return fill<T>(ctx, res + n_min, nrow - n_min, T(0));
+}
+
+MXLO_API int32_t mxlo_diag_mul(mxlo_ctx *ctx, int32_t dtype, void *res, const void *d,
+                               const void *v, int64_t n_min, int64_t nrow, double alpha,
+                               double beta, int32_t flags) {
+  CHECK_COMMON("mxlo_diag_mul");
+  MXLO_REQUIRE(n_min >= 0 && nrow >= n_min, MXLO_ESHAPE, "mxlo_diag_mul: n_min=%lld nrow=%lld",
+               (long long)n_min, (long long)nrow);
+  MXLO_REQUIRE(nrow == 0 || (res && (n_min == 0 || (d && v))), MXLO_EINVAL,
+               "mxlo_diag_mul: NULL operand");
+  alpha = eff_alpha(dtype, flags, alpha);
+  beta = eff_beta(dtype, flags, beta);
+  if (dtype == MXLO_F64)
+    return diag_mul_t<double>(ctx, (double *)res, (const double *)d, (const double *)v, n_min, nrow,
+                              alpha, beta, flags);
+  return diag_mul_t<float>(ctx, (float *)res, (const float *)d, (const float *)v, n_min, nrow,
+                           alpha, beta, flags);
+}
+
+// ---- opEye / generic axpby ------------------------------------------------------------
+template <typename T>
+static int32_t eye_mul_t(mxlo_ctx *ctx, T *res, const T *v, int64_t n_min, int64_t nrow,
+                         double alpha, double beta, int32_t flags) {
+  int32_t st = dispatch_ct<T>(beta, flags, [&]<typename CT, bool B0>() -> int32_t {
+    AxpbyOp<T, CT, B0> op{(CT)alpha, (CT)beta};
+    return launch_map<T, 1, !B0, false>(ctx, res, v, (const T *)nullptr, n_min, op);
+  });
+  MXLO_TRY(st);
+  const int64_t ntail = nrow - n_min;
+  if (ntail <= 0) return MXLO_OK;
+  if (beta == 0) return fill<T>(ctx, res + n_min, ntail, T(0));
+  const bool f64s = sizeof(T) == 8 || (flags & MXLO_SCALARS_F64);
+  if (flags & MXLO_TAIL_BETA) return fill<T>(ctx, res + n_min, ntail, (T)beta);
+  if (f64s)
+    return launch_map<T, 0, true, false>(ctx, res + n_min, (const T *)nullptr, (const T *)nullptr,
+                                         ntail, ScaleOp<T, double>{beta});
+  return launch_map<T, 0, true, false>(ctx, res + n_min, (const T *)nullptr, (const T *)nullptr,
+                                       ntail, ScaleOp<T, float>{(float)beta});
+}
+
+MXLO_API int32_t mxlo_eye_mul(mxlo_ctx *ctx, int32_t dtype, void *res, const void *v,
+                              int64_t n_min, int64_t nrow, double alpha, double beta,
+                              int32_t flags) {
+  CHECK_COMMON("mxlo_eye_mul");
+  MXLO_REQUIRE(n_min >= 0 && nrow >= n_min, MXLO_ESHAPE, "mxlo_eye_mul: n_min=%lld nrow=%lld",
+               (long long)n_min, (long long)nrow);
+  MXLO_REQUIRE(nrow == 0 || (res && (n_min == 0 || v)), MXLO_EINVAL, "mxlo_eye_mul: NULL operand");
+  alpha = eff_alpha(dtype, flags, alpha);
+  beta = eff_beta(dtype, flags, beta);
+  if (dtype == MXLO_F64)
+    return eye_mul_t<double>(ctx, (double *)res, (const double *)v, n_min, nrow, alpha, beta, flags);
+  return eye_mul_t<float>(ctx, (float *)res, (const float *)v, n_min, nrow, alpha, beta, flags);
+}
+
+// ---- opZeros / scale ---------------------------------------------------------------------
+template <typename T>
+static int32_t scale_t(mxlo_ctx *ctx, T *res, int64_t n, double s, int32_t flags) {
+  const bool f64s = sizeof(T) == 8 || (flags & MXLO_SCALARS_F64);
+  if (f64s)
+    return launch_map<T, 0, true, false>(ctx, res, (const T *)nullptr, (const T *)nullptr, n,
+                                         ScaleOp<T, double>{s});
+  return launch_map<T, 0, true, false>(ctx, res, (const T *)nullptr, (const T *)nullptr, n,
+                                       ScaleOp<T, float>{(float)s});
+}
+
+MXLO_API int32_t mxlo_zeros_mul(mxlo_ctx *ctx, int32_t dtype, void *res, int64_t nrow, double beta,
+                                int32_t flags) {
+  CHECK_COMMON("mxlo_zeros_mul");
+  MXLO_REQUIRE(nrow >= 0 && (nrow == 0 || res), MXLO_EINVAL, "mxlo_zeros_mul: bad argument");
+  beta = eff_beta(dtype, flags, beta);
+  if (beta == 0) {
+    if (dtype == MXLO_F64) return fill<double>(ctx, (double *)res, nrow, 0.0);
+    return fill<float>(ctx, (float *)res, nrow, 0.f);
+  }
+  if (dtype == MXLO_F64) return scale_t<double>(ctx, (double *)res, nrow, beta, flags);
+  return scale_t<float>(ctx, (float *)res, nrow, beta, flags);
+}
+
+MXLO_API int32_t mxlo_scale(mxlo_ctx *ctx, int32_t dtype, void *res, int64_t n, double alpha,
+                            int32_t flags) {
+  CHECK_COMMON("mxlo_scale");
+  MXLO_REQUIRE(n >= 0 && (n == 0 || res), MXLO_EINVAL, "mxlo_scale: bad argument");
+  alpha = eff_alpha(dtype, flags, alpha);
+  if (dtype == MXLO_F64) return scale_t<double>(ctx, (double *)res, n, alpha, flags);
+  return scale_t<float>(ctx, (float *)res, n, alpha, flags);
+}
+
+// ---- opOnes --------------------------------------------------------------------------------
+// sum(v): a dedicated NC=1 reduction (no second operand), same fixed-order finalize.
+namespace {
+template <typename T>
+__global__ void __launch_bounds__(kBlock)
+sum_kernel(const T *__restrict__ v, int64_t n, double *__restrict__ partials) {
+  double acc = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock)
+    acc += (double)v[i];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+  __shared__ double lds[kBlock / kWave];
+  if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) partials[blockIdx.x] = (lds[0] + lds[1]) + (lds[2] + lds[3]);
+}
+}  // namespace
+
+namespace mxlo {
+int32_t allreduce_hook(mxlo_ctx *ctx, double *dev, int64_t count);
+}
+
+template <typename T>
+static int32_t ones_mul_t(mxlo_ctx *ctx, T *res, int64_t nrow, const T *v, int64_t ncol,
+                          double alpha, double beta, int32_t flags) {
+  double *sum = ctx->scalars;  // slot 0
+  if (ncol > 0) {
+    const int grid = grid_for(ctx, ncol, kBlock * 8, ctx->tune.red_blocks_per_cu);
+    hipLaunchKernelGGL((sum_kernel<T>), dim3(grid), dim3(kBlock), 0, ctx->stream, v, ncol,
+                       ctx->partials);
+    MXLO_LAUNCH_CHECK();
+    MXLO_TRY(finalize_and_reduce(ctx, 1, grid, sum));
+  } else {
+    MXLO_HIP(hipMemsetAsync(sum, 0, sizeof(double), ctx->stream));
+  }
+  MXLO_TRY(allreduce_hook(ctx, sum, 1));
+  return dispatch_ct<T>(beta, flags, [&]<typename CT, bool B0>() -> int32_t {
+    OnesOp<T, CT, B0> op{(CT)alpha, (CT)beta, sum, (CT)0};
+    return launch_map<T, 0, !B0, false>(ctx, res, (const T *)nullptr, (const T *)nullptr, nrow, op);
+  });
+}
+
+MXLO_API int32_t mxlo_ones_mul(mxlo_ctx *ctx, int32_t dtype, void *res, int64_t nrow,
+                               const void *v, int64_t ncol, double alpha, double beta,
+                               int32_t flags) {
+  CHECK_COMMON("mxlo_ones_mul");
+  MXLO_REQUIRE(nrow >= 0 && ncol >= 0, MXLO_ESHAPE, "mxlo_ones_mul: negative size");
+  alpha = eff_alpha(dtype, flags, alpha);
+  beta = eff_beta(dtype, flags, beta);
+  if (dtype == MXLO_F64)
+    return ones_mul_t<double>(ctx, (double *)res, nrow, (const double *)v, ncol, alpha, beta, flags);
+  return ones_mul_t<float>(ctx, (float *)res, nrow, (const float *)v, ncol, alpha, beta, flags);
+}
+
+// ---- opHouseholder ----------------------------------------------------------------------------
+template <typename T>
+static int32_t householder_t(mxlo_ctx *ctx, T *res, const T *h, const T *v, int64_t n,
+                             double alpha, double beta, int32_t flags) {
+  double *dot = ctx->scalars;  // slot 0
+  const T *cols[1] = {h};
+  MXLO_TRY(panel_dots<T>(ctx, cols, 1, v, n, dot));  // phase A (+ all-reduce hook)
+  const bool rev = ctx->tune.house_reverse != 0;
+  return dispatch_ct<T>(beta, flags, [&]<typename CT, bool B0>() -> int32_t {
+    HouseholderOp<T, CT, B0> op{(CT)alpha, (CT)beta, dot, T(0)};
+    if (rev) return launch_map<T, 2, !B0, true>(ctx, res, h, v, n, op);
+    return launch_map<T, 2, !B0, false>(ctx, res, h, v, n, op);
+  });
+}
+
+MXLO_API int32_t mxlo_householder_mul(mxlo_ctx *ctx, int32_t dtype, void *res, const void *h,
+                                      const void *v, int64_t n, double alpha, double beta,
+                                      int32_t flags) {
+  CHECK_COMMON("mxlo_householder_mul");
+  MXLO_REQUIRE(n >= 0 && (n == 0 || (res && h && v)), MXLO_EINVAL,
+               "mxlo_householder_mul: bad argument");
+  alpha = eff_alpha(dtype, flags, alpha);
+  beta = eff_beta(dtype, flags, beta);
+  if (dtype == MXLO_F64)
+    return householder_t<double>(ctx, (double *)res, (const double *)h, (const double *)v, n, alpha,
+                                 beta, flags);
+  return householder_t<float>(ctx, (float *)res, (const float *)h, (const float *)v, n, alpha, beta,
+                              flags);
+}
+
+// ---- opRestriction / opExtension ------------------------------------------------------------------
+namespace {
+typedef unsigned int u32;
+typedef unsigned long long u64;
+typedef u64 u64x2 __attribute__((ext_vector_type(2)));
+
+template <typename E>
+__global__ void __launch_bounds__(kBlock)
+gather_idx_kernel(E *__restrict__ res, const E *__restrict__ v, const int64_t *__restrict__ idx,
+                  int64_t nidx) {
+  constexpr int U = 4;
+  for (int64_t base = ((int64_t)blockIdx.x * U) * kBlock + threadIdx.x; base < nidx;
+       base += (int64_t)gridDim.x * U * kBlock) {
+    int64_t j[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t k = base + (int64_t)u * kBlock;
+      j[u] = k < nidx ? idx[k] - 1 : 0;  // Julia indices are 1-based
+    }
+    E e[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) e[u] = v[j[u]];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t k = base + (int64_t)u * kBlock;
+      if (k < nidx) res[k] = e[u];
+    }
+  }
+}
+
+template <typename E>
+__global__ void __launch_bounds__(kBlock)
+gather_range_kernel(E *__restrict__ res, const E *__restrict__ v, int64_t start0, int64_t step,
+                    int64_t len) {
+  for (int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x; k < len;
+       k += (int64_t)gridDim.x * kBlock)
+    res[k] = v[start0 + k * step];
+}
+
+template <typename E>
+__global__ void __launch_bounds__(kBlock)
+scatter_idx_kernel(E *__restrict__ res, const E *__restrict__ u, const int64_t *__restrict__ idx,
+                   const int64_t *__restrict__ pos, int64_t nidx) {
+  for (int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x; k < nidx;
+       k += (int64_t)gridDim.x * kBlock) {
+    const int64_t src = pos ? pos[k] : k;
+    res[idx[k] - 1] = u[src];
+  }
+}
+
+// res[i] = u[(i-start0)/step] if i is on the range else 0 : every element written exactly once
+template <typename E>
+__global__ void __launch_bounds__(kBlock)
+extend_range_kernel(E *__restrict__ res, int64_t nres, const E *__restrict__ u, int64_t start0,
+                    int64_t step, int64_t len) {
+  const int64_t stop0 = start0 + (len - 1) * step;  // inclusive; step may be negative
+  const int64_t lo = step > 0 ? start0 : stop0, hi = step > 0 ? stop0 : start0;
+  const int64_t astep = step > 0 ? step : -step;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < nres;
+       i += (int64_t)gridDim.x * kBlock) {
+    E val;
+    memset(&val, 0, sizeof(E));
+    if (len > 0 && i >= lo && i <= hi) {
+      const int64_t off = i - lo;
+      if (off % astep == 0) {
+        const int64_t k = step > 0 ? off / astep : (len - 1) - off / astep;
+        val = u[k];
+      }
+    }
+    res[i] = val;
+  }
+}
+
+template <typename F>
+int32_t by_elem_size(int32_t es, F &&f) {
+  switch (es) {
+    case 4: return f.template operator()<u32>();
+    case 8: return f.template operator()<u64>();
+    case 16: return f.template operator()<u64x2>();
+    default: set_error("element size %d not in {4,8,16}", es); return MXLO_EINVAL;
+  }
+}
+}  // namespace
+
+MXLO_API int32_t mxlo_gather(mxlo_ctx *ctx, int32_t elem_size, void *res, const void *v,
+                             int64_t nv, const int64_t *idx, int64_t nidx) {
+  MXLO_REQUIRE(ctx, MXLO_EINVAL, "mxlo_gather: ctx is NULL");
+  MXLO_REQUIRE(nidx >= 0 && nv >= 0, MXLO_ESHAPE, "mxlo_gather: negative size");
+  if (nidx == 0) return MXLO_OK;
+  MXLO_REQUIRE(res && v && idx, MXLO_EINVAL, "mxlo_gather: NULL operand");
+  return by_elem_size(elem_size, [&]<typename E>() -> int32_t {
+    const int grid = grid_for(ctx, nidx, kBlock * 4, ctx->tune.blocks_per_cu);
+    hipLaunchKernelGGL((gather_idx_kernel<E>), dim3(grid), dim3(kBlock), 0, ctx->stream, (E *)res,
+                       (const E *)v, idx, nidx);
+    MXLO_LAUNCH_CHECK();
+    return MXLO_OK;
+  });
+}
+
+MXLO_API int32_t mxlo_gather_range(mxlo_ctx *ctx, int32_t elem_size, void *res, const void *v,
+                                   int64_t nv, int64_t start, int64_t step, int64_t len) {
+  MXLO_REQUIRE(ctx, MXLO_EINVAL, "mxlo_gather_range: ctx is NULL");
+  MXLO_REQUIRE(len >= 0 && nv >= 0, MXLO_ESHAPE, "mxlo_gather_range: negative size");
+  if (len == 0) return MXLO_OK;
+  MXLO_REQUIRE(res && v, MXLO_EINVAL, "mxlo_gather_range: NULL operand");
+  const int64_t last = start + (len - 1) * step;
+  MXLO_REQUIRE(step != 0 && start >= 1 && start <= nv && last >= 1 && last <= nv, MXLO_ESHAPE,
+               "mxlo_gather_range: %lld:%lld:%lld outside 1..%lld", (long long)start,
+               (long long)step, (long long)last, (long long)nv);
+  if (step == 1) {  // UnitRange: a contiguous copy
+    MXLO_HIP(hipMemcpyAsync(res, (const char *)v + (start - 1) * elem_size,
+                            (size_t)len * elem_size, hipMemcpyDeviceToDevice, ctx->stream));
+    return MXLO_OK;
+  }
+  return by_elem_size(elem_size, [&]<typename E>() -> int32_t {
+    const int grid = grid_for(ctx, len, kBlock * 4, ctx->tune.blocks_per_cu);
+    hipLaunchKernelGGL((gather_range_kernel<E>), dim3(grid), dim3(kBlock), 0, ctx->stream,
+                       (E *)res, (const E *)v, start - 1, step, len);
+    MXLO_LAUNCH_CHECK();
+    return MXLO_OK;
+  });
+}
+
+MXLO_API int32_t mxlo_scatter_zero(mxlo_ctx *ctx, int32_t elem_size, void *res, int64_t nres,
+                                   const void *u, const int64_t *idx, const int64_t *pos,
+                                   int64_t nidx) {
+  MXLO_REQUIRE(ctx, MXLO_EINVAL, "mxlo_scatter_zero: ctx is NULL");
+  MXLO_REQUIRE(nidx >= 0 && nres >= 0, MXLO_ESHAPE, "mxlo_scatter_zero: negative size");
+  MXLO_REQUIRE(elem_size == 4 || elem_size == 8 || elem_size == 16, MXLO_EINVAL,
+               "element size %d not in {4,8,16}", elem_size);
+  if (nres == 0) return MXLO_OK;
+  MXLO_REQUIRE(res, MXLO_EINVAL, "mxlo_scatter_zero: res is NULL");
+  MXLO_HIP(hipMemsetAsync(res, 0, (size_t)nres * elem_size, ctx->stream));  // res .= 0
+  if (nidx == 0) return MXLO_OK;
+  MXLO_REQUIRE(u && idx, MXLO_EINVAL, "mxlo_scatter_zero: NULL operand");
+  return by_elem_size(elem_size, [&]<typename E>() -> int32_t {
+    const int grid = grid_for(ctx, nidx, kBlock * 4, ctx->tune.blocks_per_cu);
+    hipLaunchKernelGGL((scatter_idx_kernel<E>), dim3(grid), dim3(kBlock), 0, ctx->stream, (E *)res,
+                       (const E *)u, idx, pos, nidx);
+    MXLO_LAUNCH_CHECK();
+    return MXLO_OK;
+  });
+}
+
+MXLO_API int32_t mxlo_scatter_zero_range(mxlo_ctx *ctx, int32_t elem_size, void *res, int64_t nres,
+                                         const void *u, int64_t start, int64_t step, int64_t len) {
+  MXLO_REQUIRE(ctx, MXLO_EINVAL, "mxlo_scatter_zero_range: ctx is NULL");
+  MXLO_REQUIRE(len >= 0 && nres >= 0, MXLO_ESHAPE, "mxlo_scatter_zero_range: negative size");
+  if (nres == 0) return MXLO_OK;
+  MXLO_REQUIRE(res && (len == 0 || u), MXLO_EINVAL, "mxlo_scatter_zero_range: NULL operand");
+  if (len > 0) {
+    const int64_t last = start + (len - 1) * step;
+    MXLO_REQUIRE(step != 0 && start >= 1 && start <= nres && last >= 1 && last <= nres,
+                 MXLO_ESHAPE, "mxlo_scatter_zero_range: %lld:%lld:%lld outside 1..%lld",
+                 (long long)start, (long long)step, (long long)last, (long long)nres);
+  }
+  return by_elem_size(elem_size, [&]<typename E>() -> int32_t {
+    const int grid = grid_for(ctx, nres, kBlock * 4, ctx->tune.blocks_per_cu);
+    hipLaunchKernelGGL((extend_range_kernel<E>), dim3(grid), dim3(kBlock), 0, ctx->stream,
+                       (E *)res, nres, (const E *)u, start - 1, step, len);
+    MXLO_LAUNCH_CHECK();
+    return MXLO_OK;
+  });
+}

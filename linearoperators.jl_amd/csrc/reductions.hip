@@ -1,0 +1,222 @@
+// reductions.hip — deterministic global reductions: skinny-panel dots.
+//
+// panel_dots computes out[c] = dot(col_c, x) for NC columns in ONE pass that reads x
+// once and every column once (the L-BFGS n x 2m panel pass; NC = 1 is the Householder
+// h'v). Each lane keeps NC f64 accumulators in registers (f32 data is accumulated in
+// f64 too: the kernel is HBM-bound, the FMAs are free), wave64 __shfl_down tree ->
+// LDS across the 4 waves -> one partial per (column, workgroup). A second tiny kernel
+// sums the partials in a FIXED order, so results are bit-reproducible run to run and
+// independent of dispatch order (no float atomics). When the ctx has an all-reduce
+// hook (row-sharded vectors) it is invoked on the finalized scalars.
+#include "common.h"
+
+namespace mxlo {
+
+template <typename T, int NC>
+struct ColPtrs {
+  const T *p[NC];
+};
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+
+template <typename T, int VEC, int NC, int UNROLL, bool XVEC>
+__global__ void __launch_bounds__(kBlock)
+panel_dots_kernel(ColPtrs<T, NC> cols, const T *__restrict__ x, int64_t head, int64_t nvec,
+                  int64_t n, double *__restrict__ partials) {
+  using V = typename std::conditional<VEC == 1, T, typename Vec16<T>::type>::type;
+  const int tid = threadIdx.x;
+  double acc[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) acc[c] = 0.0;
+
+  constexpr int64_t CHUNK = (int64_t)kBlock * UNROLL;
+  const int64_t nchunks = (nvec + CHUNK - 1) / CHUNK;
+  for (int64_t ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
+    const int64_t base = ch * CHUNK + tid;
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      const int64_t i = base + (int64_t)u * kBlock;
+      if (i < nvec) {
+        T xe[VEC];
+        if constexpr (VEC == 1) {
+          xe[0] = x[head + i];
+        } else if constexpr (XVEC) {
+          const V xv = *reinterpret_cast<const V *>(x + head + i * VEC);
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) xe[e] = xv[e];
+        } else {  // x has a different 16-byte phase than the panel: element loads for x only
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) xe[e] = x[head + i * VEC + e];
+        }
+        V cv[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) cv[c] = *reinterpret_cast<const V *>(cols.p[c] + head + i * VEC);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) {
+            T ce;
+            if constexpr (VEC == 1) ce = cv[c];
+            else ce = cv[c][e];
+            acc[c] = fma((double)ce, (double)xe[e], acc[c]);
+          }
+        }
+      }
+    }
+  }
+  if constexpr (VEC > 1) {  // scalar head/tail
+    if (blockIdx.x == gridDim.x - 1) {
+      const int64_t tail0 = head + nvec * VEC;
+      const int64_t cnt = head + (n - tail0);
+      if (tid < cnt) {
+        const int64_t i = tid < head ? tid : tail0 + (tid - head);
+        const double xe = (double)x[i];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) acc[c] = fma((double)cols.p[c][i], xe, acc[c]);
+      }
+    }
+  }
+  __shared__ double lds[kBlock / kWave][NC];
+  const int wave = tid >> 6, lane = tid & 63;
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const double s = wave_sum(acc[c]);
+    if (lane == 0) lds[wave][c] = s;
+  }
+  __syncthreads();
+  if (tid < NC) {
+    const double s = ((lds[0][tid] + lds[1][tid]) + (lds[2][tid] + lds[3][tid]));
+    partials[(int64_t)tid * kMaxRedBlocks + blockIdx.x] = s;
+  }
+}
+
+// One workgroup per column; lane t sums partials t, t+256, ... sequentially, then a fixed tree.
+__global__ void __launch_bounds__(kBlock)
+finalize_kernel(const double *__restrict__ partials, int nblocks, double *__restrict__ out) {
+  const int c = blockIdx.x, tid = threadIdx.x;
+  const double *p = partials + (int64_t)c * kMaxRedBlocks;
+  double s = 0.0;
+  for (int i = tid; i < nblocks; i += kBlock) s += p[i];
+  s = wave_sum(s);
+  __shared__ double lds[kBlock / kWave];
+  if ((tid & 63) == 0) lds[tid >> 6] = s;
+  __syncthreads();
+  if (tid == 0) out[c] = (lds[0] + lds[1]) + (lds[2] + lds[3]);
+}
+
+int32_t finalize_and_reduce(mxlo_ctx *ctx, int ncols, int nblocks, double *out_dev) {
+  hipLaunchKernelGGL(finalize_kernel, dim3(ncols), dim3(kBlock), 0, ctx->stream, ctx->partials,
+                     nblocks, out_dev);
+  MXLO_LAUNCH_CHECK();
+  return MXLO_OK;
+}
+
+int32_t allreduce_hook(mxlo_ctx *ctx, double *dev, int64_t count) {
+  if (ctx->allreduce && count > 0) {
+    int32_t s = ctx->allreduce(ctx->allreduce_user, dev, count, (void *)ctx->stream);
+    MXLO_REQUIRE(s == 0, MXLO_EREDUCE, "all-reduce hook returned %d", s);
+  }
+  return MXLO_OK;
+}
+
+template <typename T, int VEC, int NC, bool XVEC>
+static int32_t launch_dots(mxlo_ctx *ctx, const T *const *cols, const T *x, int64_t head,
+                           int64_t nvec, int64_t n, int *nblocks_out) {
+  ColPtrs<T, NC> cp;
+  for (int c = 0; c < NC; ++c) cp.p[c] = cols[c];
+  // fewer columns -> more chunks in flight per lane to keep ~the same bytes in flight
+  constexpr int UNROLL = NC <= 2 ? 4 : (NC <= 6 ? 2 : 1);
+  const int grid = grid_for(ctx, nvec, (int64_t)kBlock * UNROLL, ctx->tune.red_blocks_per_cu);
+  hipLaunchKernelGGL((panel_dots_kernel<T, VEC, NC, UNROLL, XVEC>), dim3(grid), dim3(kBlock), 0,
+                     ctx->stream, cp, x, head, nvec, n, ctx->partials);
+  MXLO_LAUNCH_CHECK();
+  *nblocks_out = grid;
+  return MXLO_OK;
+}
+
+#define DOTS_CASE(NCV)                                                                           \
+  case NCV:                                                                                      \
+    if (vec && xvec) return launch_dots<T, Vec16<T>::N, NCV, true>(ctx, cols, x, head, nvec, n, nb); \
+    if (vec) return launch_dots<T, Vec16<T>::N, NCV, false>(ctx, cols, x, head, nvec, n, nb);    \
+    break;
+
+template <typename T>
+static int32_t dots_chunk(mxlo_ctx *ctx, const T *const *cols, int nc, const T *x, int64_t n,
+                          int *nb) {
+  constexpr int VEC = Vec16<T>::N;
+  // the panel columns must share a 16-byte phase for the vector path
+  int64_t head = 0;
+  bool vec = n >= 4 * VEC;
+  if (vec) {
+    int64_t mis = -1;
+    for (int c = 0; c < nc && vec; ++c) {
+      int64_t m = (int64_t)((uintptr_t)cols[c] & 15u);
+      if (m % (int64_t)sizeof(T)) vec = false;
+      else if (mis < 0) mis = m;
+      else if (mis != m) vec = false;
+    }
+    if (vec) head = mis == 0 ? 0 : (16 - mis) / (int64_t)sizeof(T);
+  }
+  const int64_t nvec = vec ? (n - head) / VEC : n;
+  const bool xvec = vec && ((((uintptr_t)(x + head)) & 15u) == 0);
+  switch (nc) {
+    DOTS_CASE(1) DOTS_CASE(2) DOTS_CASE(3) DOTS_CASE(4) DOTS_CASE(5) DOTS_CASE(6) DOTS_CASE(7)
+    DOTS_CASE(8) DOTS_CASE(9) DOTS_CASE(10) DOTS_CASE(11) DOTS_CASE(12) DOTS_CASE(13)
+    DOTS_CASE(14) DOTS_CASE(15) DOTS_CASE(16) DOTS_CASE(17) DOTS_CASE(18) DOTS_CASE(19)
+    DOTS_CASE(20)
+    default: break;
+  }
+  // scalar fallback (mis-phased columns): at most 4 columns per launch
+  switch (nc) {
+    case 1: return launch_dots<T, 1, 1, false>(ctx, cols, x, 0, n, n, nb);
+    case 2: return launch_dots<T, 1, 2, false>(ctx, cols, x, 0, n, n, nb);
+    case 3: return launch_dots<T, 1, 3, false>(ctx, cols, x, 0, n, n, nb);
+    case 4: return launch_dots<T, 1, 4, false>(ctx, cols, x, 0, n, n, nb);
+    default: break;
+  }
+  set_error("dots_chunk: unsupported column count %d", nc);
+  return MXLO_EINVAL;
+}
+
+// out_dev[c] = dot(cols[c], x), c < ncols (ncols <= kMaxRedCols); f64 results.
+template <typename T>
+int32_t panel_dots(mxlo_ctx *ctx, const T *const *cols, int ncols, const T *x, int64_t n,
+                   double *out_dev) {
+  MXLO_REQUIRE(ncols >= 0 && ncols <= kMaxRedCols, MXLO_EINVAL, "panel_dots: %d columns", ncols);
+  if (ncols == 0) return MXLO_OK;
+  if (n <= 0) {
+    MXLO_HIP(hipMemsetAsync(out_dev, 0, sizeof(double) * ncols, ctx->stream));
+    return allreduce_hook(ctx, out_dev, ncols);
+  }
+  constexpr int VEC = Vec16<T>::N;
+  int done = 0;
+  while (done < ncols) {
+    int nc = ncols - done;
+    if (nc > ctx->tune.dots_max_nc) nc = ctx->tune.dots_max_nc;
+    // decide whether the vector path is available for this chunk; if not, cap at 4 columns
+    bool vec = n >= 4 * VEC;
+    int64_t mis = -1;
+    for (int c = 0; c < nc && vec; ++c) {
+      int64_t m = (int64_t)((uintptr_t)cols[done + c] & 15u);
+      if (m % (int64_t)sizeof(T) || (mis >= 0 && mis != m)) vec = false;
+      mis = m;
+    }
+    if (!vec && nc > 4) nc = 4;
+    int nb = 0;
+    MXLO_TRY(dots_chunk<T>(ctx, cols + done, nc, x, n, &nb));
+    MXLO_TRY(finalize_and_reduce(ctx, nc, nb, out_dev + done));
+    done += nc;
+  }
+  return allreduce_hook(ctx, out_dev, ncols);
+}
+
+template int32_t panel_dots<double>(mxlo_ctx *, const double *const *, int, const double *, int64_t,
+                                    double *);
+template int32_t panel_dots<float>(mxlo_ctx *, const float *const *, int, const float *, int64_t,
+                                   double *);
+
+}  // namespace mxlo

@@ -1,0 +1,242 @@
+// stream_kernels.h — the one elementwise streaming kernel every HBM-bound leaf uses.
+//
+// Design (MI355X): HBM-bound, zero reuse -> the only things that matter are
+//  * 16-byte accesses per lane (global_load_dwordx4: 1 KiB per wave-instruction),
+//  * many independent loads in flight per lane (UNROLL chunks x operands) to cover
+//    the ~900-cycle HBM latency at 10 B/clk/CU,
+//  * a persistent grid of num_cu*blocks_per_cu workgroups walking 256*UNROLL-vector
+//    chunks (no reuse -> no XCD-aware remap needed; consecutive workgroups touching
+//    consecutive chunks keeps every HBM channel busy).
+// Arithmetic is a functor evaluated per element in the reference's association
+// order; the TU is compiled with -ffp-contract=off so nothing is fused.
+#pragma once
+#include "common.h"
+
+namespace mxlo {
+
+template <typename V>
+__device__ __forceinline__ V ldg(const V *p) {
+  return *p;
+}
+template <typename V>
+__device__ __forceinline__ void stg(V *p, V v) {
+  *p = v;
+}
+
+template <typename T, int VEC>
+struct VecOf {
+  using type = T;
+};
+template <>
+struct VecOf<double, 2> {
+  using type = f64x2;
+};
+template <>
+struct VecOf<float, 4> {
+  using type = f32x4;
+};
+
+template <typename T, int VEC>
+__device__ __forceinline__ T vget(const typename VecOf<T, VEC>::type &v, int i) {
+  if constexpr (VEC == 1) return v;
+  else return v[i];
+}
+template <typename T, int VEC>
+__device__ __forceinline__ void vset(typename VecOf<T, VEC>::type &v, int i, T x) {
+  if constexpr (VEC == 1) v = x;
+  else v[i] = x;
+}
+
+// Op concept:
+//   __device__ void init();                       // once per thread (load device scalars)
+//   __device__ T operator()(T in0, T in1, T res_old) const;
+// NIN = number of input streams (0,1,2); READ_RES = res is also an input (beta != 0).
+template <typename T, int VEC, int UNROLL, int NIN, bool READ_RES, bool REVERSE, typename Op>
+__global__ void __launch_bounds__(kBlock)
+map_kernel(T *__restrict__ res, const T *__restrict__ in0, const T *__restrict__ in1, int64_t head,
+           int64_t nvec, int64_t n, Op op) {
+  using V = typename VecOf<T, VEC>::type;
+  op.init();
+  const int tid = threadIdx.x;
+  V *rv = reinterpret_cast<V *>(res + head);
+  const V *av = reinterpret_cast<const V *>(in0 + head);
+  const V *bv = reinterpret_cast<const V *>(in1 + head);
+  constexpr int64_t CHUNK = (int64_t)kBlock * UNROLL;
+  const int64_t nchunks = (nvec + CHUNK - 1) / CHUNK;
+  for (int64_t ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
+    const int64_t c = REVERSE ? (nchunks - 1 - ch) : ch;
+    const int64_t base = c * CHUNK + tid;
+    V a[UNROLL], b[UNROLL], r[UNROLL];
+    if (base + (int64_t)(UNROLL - 1) * kBlock < nvec) {
+#pragma unroll
+      for (int u = 0; u < UNROLL; ++u) {
+        const int64_t i = base + (int64_t)u * kBlock;
+        if constexpr (NIN >= 1) a[u] = ldg(av + i);
+        if constexpr (NIN >= 2) b[u] = ldg(bv + i);
+        if constexpr (READ_RES) r[u] = ldg(rv + i);
+      }
+#pragma unroll
+      for (int u = 0; u < UNROLL; ++u) {
+        V o;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          const T x0 = NIN >= 1 ? vget<T, VEC>(a[u], e) : T(0);
+          const T x1 = NIN >= 2 ? vget<T, VEC>(b[u], e) : T(0);
+          const T r0 = READ_RES ? vget<T, VEC>(r[u], e) : T(0);
+          vset<T, VEC>(o, e, op(x0, x1, r0));
+        }
+        stg(rv + base + (int64_t)u * kBlock, o);
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < UNROLL; ++u) {
+        const int64_t i = base + (int64_t)u * kBlock;
+        if (i < nvec) {
+          V o, aa, bb, rr;
+          if constexpr (NIN >= 1) aa = ldg(av + i);
+          if constexpr (NIN >= 2) bb = ldg(bv + i);
+          if constexpr (READ_RES) rr = ldg(rv + i);
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) {
+            const T x0 = NIN >= 1 ? vget<T, VEC>(aa, e) : T(0);
+            const T x1 = NIN >= 2 ? vget<T, VEC>(bb, e) : T(0);
+            const T r0 = READ_RES ? vget<T, VEC>(rr, e) : T(0);
+            vset<T, VEC>(o, e, op(x0, x1, r0));
+          }
+          stg(rv + i, o);
+        }
+      }
+    }
+  }
+  if constexpr (VEC > 1) {
+    // scalar head [0,head) and tail [head + nvec*VEC, n): at most 2*(VEC-1) elements
+    if (blockIdx.x == gridDim.x - 1) {
+      const int64_t tail0 = head + nvec * VEC;
+      const int64_t cnt = head + (n - tail0);
+      if (tid < cnt) {
+        const int64_t i = tid < head ? tid : tail0 + (tid - head);
+        const T x0 = NIN >= 1 ? in0[i] : T(0);
+        const T x1 = NIN >= 2 ? in1[i] : T(0);
+        const T r0 = READ_RES ? res[i] : T(0);
+        res[i] = op(x0, x1, r0);
+      }
+    }
+  }
+}
+
+constexpr int kStreamUnroll = 4;
+
+// Host launcher: picks the 16-byte path when all operands share their alignment.
+template <typename T, int NIN, bool READ_RES, bool REVERSE, typename Op>
+int32_t launch_map(mxlo_ctx *ctx, T *res, const T *in0, const T *in1, int64_t n, Op op) {
+  if (n <= 0) return MXLO_OK;
+  constexpr int VEC = Vec16<T>::N;
+  const int64_t head0 = common_head<T>({res, NIN >= 1 ? in0 : nullptr, NIN >= 2 ? in1 : nullptr});
+  if (head0 >= 0 && n >= 4 * VEC) {
+    const int64_t head = head0 < n ? head0 : n;
+    const int64_t nvec = (n - head) / VEC;
+    const int grid = grid_for(ctx, nvec, (int64_t)kBlock * kStreamUnroll, ctx->tune.blocks_per_cu);
+    hipLaunchKernelGGL((map_kernel<T, VEC, kStreamUnroll, NIN, READ_RES, REVERSE, Op>), dim3(grid),
+                       dim3(kBlock), 0, ctx->stream, res, in0, in1, head, nvec, n, op);
+  } else {
+    const int grid = grid_for(ctx, n, (int64_t)kBlock * kStreamUnroll, ctx->tune.blocks_per_cu);
+    hipLaunchKernelGGL((map_kernel<T, 1, kStreamUnroll, NIN, READ_RES, REVERSE, Op>), dim3(grid),
+                       dim3(kBlock), 0, ctx->stream, res, in0, in1, (int64_t)0, n, n, op);
+  }
+  MXLO_LAUNCH_CHECK();
+  return MXLO_OK;
+}
+
+// ---- functors: one per reference statement ------------------------------------
+// res = (a*d)*v (+ b*res)      src/special-operators.jl:126-129,146-148
+template <typename T, typename CT, bool BETA0>
+struct DiagOp {
+  CT a, b;
+  __device__ void init() {}
+  __device__ T operator()(T d, T v, T r) const {
+    CT t = (a * (CT)d) * (CT)v;
+    if constexpr (!BETA0) t = t + (b * (CT)r);
+    return (T)t;
+  }
+};
+// 1-element d (SpectralGradient): d broadcast from device memory
+template <typename T, typename CT, bool BETA0>
+struct DiagScalarOp {
+  CT a, b;
+  const T *dptr;
+  CT ad;
+  __device__ void init() { ad = a * (CT)(*dptr); }
+  __device__ T operator()(T v, T, T r) const {
+    CT t = ad * (CT)v;
+    if constexpr (!BETA0) t = t + (b * (CT)r);
+    return (T)t;
+  }
+};
+// res = a*v (+ b*res)          src/special-operators.jl:38-41, src/operations.jl:18
+template <typename T, typename CT, bool BETA0>
+struct AxpbyOp {
+  CT a, b;
+  __device__ void init() {}
+  __device__ T operator()(T v, T, T r) const {
+    CT t = a * (CT)v;
+    if constexpr (!BETA0) t = t + (b * (CT)r);
+    return (T)t;
+  }
+};
+// res = res*b                  src/special-operators.jl:106, src/operations.jl:14
+template <typename T, typename CT>
+struct ScaleOp {
+  CT b;
+  __device__ void init() {}
+  __device__ T operator()(T, T, T r) const { return (T)((CT)r * b); }
+};
+// res = const
+template <typename T>
+struct FillOp {
+  T c;
+  __device__ void init() {}
+  __device__ T operator()(T, T, T) const { return c; }
+};
+// res = c0 (+ b*res) with c0 = a*sum(v) read from device memory   src/special-operators.jl:81-83
+template <typename T, typename CT, bool BETA0>
+struct OnesOp {
+  CT a, b;
+  const double *sum;
+  CT as;
+  __device__ void init() { as = a * (CT)(T)(*sum); }
+  __device__ T operator()(T, T, T r) const {
+    CT t = as;
+    if constexpr (!BETA0) t = t + (b * (CT)r);
+    return (T)t;
+  }
+};
+// res = a*(v - c*h) (+ b*res), c = 2*dot(h,v) from device memory   src/linalg.jl:79-81
+template <typename T, typename CT, bool BETA0>
+struct HouseholderOp {
+  CT a, b;
+  const double *dot;
+  T c;
+  __device__ void init() { c = (T)2 * (T)(*dot); }
+  __device__ T operator()(T h, T v, T r) const {
+    const T inner = v - (c * h);
+    CT t = a * (CT)inner;
+    if constexpr (!BETA0) t = t + (b * (CT)r);
+    return (T)t;
+  }
+};
+
+// Dispatch helper over (dtype scalars mode, beta==0): calls F.template run<T, CT, BETA0>().
+template <typename T, typename F>
+int32_t dispatch_ct(double beta, int32_t flags, F &&f) {
+  const bool f64s = sizeof(T) == 8 || (flags & MXLO_SCALARS_F64);
+  if (f64s) {
+    return beta == 0 ? f.template operator()<double, true>() : f.template operator()<double, false>();
+  } else {
+    if constexpr (sizeof(T) == 4) {
+      return beta == 0 ? f.template operator()<float, true>() : f.template operator()<float, false>();
+    }
+  }
+  return MXLO_EINVAL;
+}
+
+}  // namespace mxlo

@@ -1,0 +1,155 @@
+"""Device plumbing: one ``mxlo_ctx`` per GPU per process, torch tensors as the device-vector type.
+
+PyTorch is used here only for device memory (``torch.Tensor`` plays the role of the
+Julia glue's device ``Vector{T}``), for the current HIP stream, and — in
+:mod:`sharded` — for ``torch.distributed``. All arithmetic happens in libmxlo.so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import torch
+
+from . import _lib
+
+_DT = {torch.float64: _lib.F64, torch.float32: _lib.F32}
+
+
+def dtype_code(dtype: torch.dtype) -> int:
+    try:
+        return _DT[dtype]
+    except KeyError:
+        raise TypeError(f"the MI355X path is instantiated for float64/float32 only, got {dtype} "
+                        "(complex/BigFloat/Float16 stay on the reference CPU path)") from None
+
+
+@dataclass(frozen=True)
+class Storage:
+    """The reference's storage type ``S`` (e.g. ``Vector{Float64}``): here a 1-D contiguous
+    torch tensor of ``dtype`` on ``device`` (src/abstract.jl:176-184)."""
+    dtype: torch.dtype
+    device: torch.device
+
+    def undef(self, n: int) -> torch.Tensor:          # S(undef, n)
+        return torch.empty(n, dtype=self.dtype, device=self.device)
+
+    def zeros(self, n: int) -> torch.Tensor:          # fill!(S(undef, n), zero(T))
+        return torch.zeros(n, dtype=self.dtype, device=self.device)
+
+    def __repr__(self):
+        return f"DeviceVector{{{str(self.dtype).replace('torch.', '')}}}@{self.device}"
+
+
+def storage_of(t: torch.Tensor) -> Storage:
+    return Storage(t.dtype, t.device)
+
+
+class Context:
+    """RAII wrapper of ``mxlo_ctx`` bound to one GPU; kernels run on torch's current stream."""
+
+    def __init__(self, index: int):
+        self.index = index
+        self.handle = C.c_void_p()
+        with torch.cuda.device(index):
+            self._stream = torch.cuda.current_stream(index).cuda_stream
+            _lib.call("mxlo_ctx_create", index, C.c_void_p(self._stream), C.byref(self.handle))
+        self._hook = None  # keep the CFUNCTYPE object alive
+
+    def bind_stream(self):
+        s = torch.cuda.current_stream(self.index).cuda_stream
+        if s != self._stream:
+            _lib.call("mxlo_ctx_set_stream", self.handle, C.c_void_p(s))
+            self._stream = s
+
+    def sync(self):
+        _lib.call("mxlo_ctx_sync", self.handle)
+
+    def tune(self, key: str, value: int):
+        _lib.call("mxlo_ctx_tune", self.handle, key.encode(), int(value))
+
+    def info(self):
+        a = (C.c_int64 * 4)()
+        _lib.call("mxlo_ctx_info", self.handle, a)
+        return {"device": a[0], "num_cu": a[1], "workspace_bytes": a[2], "max_reduction_cols": a[3]}
+
+    def set_allreduce(self, pyfunc):
+        """Install (or clear with None) the row-sharding all-reduce hook (include/mxlo.h)."""
+        if pyfunc is None:
+            self._hook = None
+            _lib.call("mxlo_ctx_set_allreduce", self.handle, _lib.ALLREDUCE_FN(), None)
+        else:
+            self._hook = _lib.ALLREDUCE_FN(pyfunc)
+            _lib.call("mxlo_ctx_set_allreduce", self.handle, self._hook, None)
+
+    def __del__(self):
+        try:
+            if self.handle:
+                _lib.lib().mxlo_ctx_destroy(self.handle)
+        except Exception:
+            pass
+
+
+_ctxs: dict[int, Context] = {}
+
+
+def get_ctx(device=None) -> Context:
+    if not torch.cuda.is_available():
+        raise RuntimeError("no HIP device visible: the MI355X path has no CPU fallback")
+    if device is None:
+        idx = torch.cuda.current_device()
+    else:
+        device = torch.device(device)
+        if device.type != "cuda":
+            raise RuntimeError(f"operands must live on a GPU, got {device}: there is no CPU fallback")
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+    ctx = _ctxs.get(idx)
+    if ctx is None:
+        ctx = _ctxs[idx] = Context(idx)
+    ctx.bind_stream()
+    return ctx
+
+
+def ptr(t: torch.Tensor | None) -> C.c_void_p:
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+def check_vec(t: torch.Tensor, name: str, dtype: torch.dtype | None = None) -> torch.Tensor:
+    """A Julia ``Vector``/contiguous ``SubArray``: 1-D, unit stride, on the GPU."""
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name} must be a torch.Tensor on the GPU, got {type(t)}")
+    if t.dim() != 1:
+        raise ValueError(f"{name} must be 1-D, got shape {tuple(t.shape)}")
+    if t.numel() > 1 and t.stride(0) != 1:
+        raise ValueError(f"{name} must be contiguous (unit stride)")
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} lives on {t.device}: the MI355X path has no CPU fallback")
+    if dtype is not None and t.dtype != dtype:
+        raise TypeError(f"{name} has dtype {t.dtype}, expected {dtype}")
+    return t
+
+
+class Timer:
+    """hipEvent pair recorded on the ctx stream (mxlo_timer_*)."""
+
+    def __init__(self, ctx: Context):
+        self.ctx = ctx
+        self.h = C.c_void_p()
+        _lib.call("mxlo_timer_create", ctx.handle, C.byref(self.h))
+
+    def start(self):
+        _lib.call("mxlo_timer_start", self.h)
+
+    def stop(self):
+        _lib.call("mxlo_timer_stop", self.h)
+
+    def elapsed_ms(self) -> float:
+        ms = C.c_double()
+        _lib.call("mxlo_timer_elapsed_ms", self.h, C.byref(ms))
+        return ms.value
+
+    def __del__(self):
+        try:
+            _lib.lib().mxlo_timer_destroy(self.h)
+        except Exception:
+            pass

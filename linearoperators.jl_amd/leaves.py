@@ -1,0 +1,423 @@
+"""Leaf operators: same constructor names and flags as the reference, closures that call libmxlo.so.
+
+Mirrors src/special-operators.jl (opEye, opOnes, opZeros, opDiagonal, opRestriction, opExtension,
+BlockDiagonalOperator), src/linalg.jl:77-127 (opHouseholder, opHermitian), src/kron.jl and the
+dense-matrix constructor src/constructors.jl:19-29.
+
+Index arguments keep Julia's 1-BASED convention (the C ABI receives them exactly as Julia stores
+them): ``opRestriction([1, 2, 4, 7], 10)``; ``jrange(3, 6)`` is Julia's ``3:6`` (inclusive),
+``jrange(1, 7, 2)`` is ``1:2:7``; ``slice(None)`` / ``Ellipsis`` stand for ``:``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib
+from .device import Storage, check_vec, dtype_code, get_ctx, ptr, storage_of
+from .operators import (AbstractLinearOperator, LinearOperator, LinearOperatorException, adjoint, compose,
+                        issymmetric, ishermitian, mul, scalar_flags, storage_type, to_dense, transpose)
+
+
+def _default_device() -> torch.device:
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def _S(T: torch.dtype, S: Optional[Storage]) -> Storage:
+    return S if S is not None else Storage(T, _default_device())
+
+
+# ----------------------------------------------------------------------------- opEye / opOnes / opZeros
+def mulOpEye(res, v, alpha, beta, n_min):
+    """mulOpEye! — src/special-operators.jl:36-44 (tail gets `β` itself when β != 0)."""
+    ctx = get_ctx(res.device)
+    _lib.call("mxlo_eye_mul", ctx.handle, dtype_code(res.dtype), ptr(res), ptr(v), n_min, res.numel(),
+              float(alpha), float(beta), scalar_flags(res.dtype, alpha, beta) | _lib.TAIL_BETA)
+
+
+def opEye(T=torch.float64, nrow: Optional[int] = None, ncol: Optional[int] = None, S: Optional[Storage] = None):
+    """opEye(T, n; S) / opEye(T, nrow, ncol; S) — src/special-operators.jl:46-73."""
+    if isinstance(T, int):               # opEye(n) / opEye(nrow, ncol): T defaults to Float64
+        T, nrow, ncol = torch.float64, T, nrow
+    n = nrow
+    S = _S(T, S)
+    if ncol is None or nrow == ncol:
+        prod = lambda res, v, a, b: mulOpEye(res, v, a, b, n)
+        op = LinearOperator(T, n, n, True, True, prod, prod, prod, S=S)
+        op._leaf = ("eye", n, n)
+        return op
+    n_min = min(nrow, ncol)
+    prod = lambda res, v, a, b: mulOpEye(res, v, a, b, n_min)
+    op = LinearOperator(T, nrow, ncol, False, False, prod, prod, prod, S=S)
+    op._leaf = ("eye", nrow, ncol)
+    return op
+
+
+def mulOpOnes(res, v, alpha, beta):
+    """mulOpOnes! — src/special-operators.jl:79-85."""
+    ctx = get_ctx(res.device)
+    _lib.call("mxlo_ones_mul", ctx.handle, dtype_code(res.dtype), ptr(res), res.numel(), ptr(v), v.numel(),
+              float(alpha), float(beta), scalar_flags(res.dtype, alpha, beta))
+
+
+def opOnes(T=torch.float64, nrow: Optional[int] = None, ncol: Optional[int] = None, S: Optional[Storage] = None):
+    """opOnes(T, nrow, ncol; S) — src/special-operators.jl:87-101."""
+    if isinstance(T, int):
+        T, nrow, ncol = torch.float64, T, nrow
+    prod = lambda res, v, a, b: mulOpOnes(res, v, a, b)
+    return LinearOperator(T, nrow, ncol, nrow == ncol, nrow == ncol, prod, prod, prod, S=_S(T, S))
+
+
+def mulOpZeros(res, v, alpha, beta):
+    """mulOpZeros! — src/special-operators.jl:102-108."""
+    ctx = get_ctx(res.device)
+    _lib.call("mxlo_zeros_mul", ctx.handle, dtype_code(res.dtype), ptr(res), res.numel(), float(beta),
+              scalar_flags(res.dtype, 0, beta))
+
+
+def opZeros(T=torch.float64, nrow: Optional[int] = None, ncol: Optional[int] = None, S: Optional[Storage] = None):
+    """opZeros(T, nrow, ncol; S) — src/special-operators.jl:110-123."""
+    if isinstance(T, int):
+        T, nrow, ncol = torch.float64, T, nrow
+    prod = lambda res, v, a, b: mulOpZeros(res, v, a, b)
+    op = LinearOperator(T, nrow, ncol, nrow == ncol, nrow == ncol, prod, prod, prod, S=_S(T, S))
+    op._leaf = ("zeros", nrow, ncol)
+    return op
+
+
+# ----------------------------------------------------------------------------- opDiagonal
+def mulSquareOpDiagonal(res, d, v, alpha, beta):
+    """mulSquareOpDiagonal! — src/special-operators.jl:125-131."""
+    ctx = get_ctx(res.device)
+    n = res.numel()
+    flags = scalar_flags(res.dtype, alpha, beta) | (_lib.D_SCALAR if d.numel() == 1 and n != 1 else 0)
+    _lib.call("mxlo_diag_mul", ctx.handle, dtype_code(res.dtype), ptr(res), ptr(d), ptr(v), n, n, float(alpha),
+              float(beta), flags)
+
+
+def mulOpDiagonal(res, d, v, alpha, beta, n_min):
+    """mulOpDiagonal! — src/special-operators.jl:144-151 (tail zeroed regardless of β)."""
+    ctx = get_ctx(res.device)
+    _lib.call("mxlo_diag_mul", ctx.handle, dtype_code(res.dtype), ptr(res), ptr(d), ptr(v), n_min, res.numel(),
+              float(alpha), float(beta), scalar_flags(res.dtype, alpha, beta))
+
+
+def opDiagonal(*args):
+    """opDiagonal(d) / opDiagonal(nrow, ncol, d) — src/special-operators.jl:133-165."""
+    if len(args) == 1:
+        d = check_vec(args[0], "d")
+        dtype_code(d.dtype)
+        n = d.numel()
+        prod = lambda res, v, a, b: mulSquareOpDiagonal(res, d, v, a, b)
+        # ctprod! uses conj.(d) == d for the real dtypes instantiated here (:140)
+        op = LinearOperator(d.dtype, n, n, True, True, prod, prod, prod, S=storage_of(d))
+        op._leaf = ("diag", d)
+        return op
+    nrow, ncol, d = args
+    d = check_vec(d, "d")
+    if nrow == ncol <= d.numel():
+        return opDiagonal(d[:nrow].clone())       # d[1:nrow] copies in Julia (:157)
+    n_min = min(nrow, ncol)
+    if d.numel() < n_min:
+        raise LinearOperatorException("shape mismatch")
+    prod = lambda res, v, a, b: mulOpDiagonal(res, d, v, a, b, n_min)
+    return LinearOperator(d.dtype, nrow, ncol, False, False, prod, prod, prod, S=storage_of(d))
+
+
+# ----------------------------------------------------------------------------- restriction / extension
+class jrange:
+    """Julia range ``start:step:stop`` (inclusive, 1-based): UnitRange when step == 1."""
+
+    def __init__(self, start: int, stop: int, step: int = 1):
+        if step == 0:
+            raise ValueError("step cannot be zero")
+        self.start, self.step = int(start), int(step)
+        self.len = max(0, (int(stop) - int(start)) // int(step) + 1)
+
+    def __len__(self):
+        return self.len
+
+    def to_numpy(self):
+        return self.start + self.step * np.arange(self.len, dtype=np.int64)
+
+
+def _is_colon(I) -> bool:
+    return I is Ellipsis or (isinstance(I, slice) and I == slice(None))
+
+
+def opRestriction(Idx, ncol: int, S: Optional[Storage] = None, device=None):
+    """opRestriction(I, ncol; S) — src/special-operators.jl:176-203. The operator's eltype is the
+    index integer type (Int64), like the reference (`LinearOperator{I, Vector{I}}`, :193)."""
+    dev = torch.device(device) if device is not None else (S.device if S is not None else _default_device())
+    if _is_colon(Idx):
+        return opEye(torch.int64, ncol, S=Storage(torch.int64, dev))    # :201
+    if isinstance(Idx, (int, np.integer)):
+        Idx = [int(Idx)]                                                 # :203
+    storage = S if S is not None else Storage(torch.int64, dev)
+    if isinstance(Idx, jrange):
+        start, step, ln = Idx.start, Idx.step, Idx.len
+        last = start + (ln - 1) * step
+        if ln > 0 and not (1 <= start <= ncol and 1 <= last <= ncol):
+            raise LinearOperatorException(f"indices should be between 1 and {ncol}")
+
+        def prod(res, v, a, b):   # mulRestrict! :167-169 (α, β ignored)
+            ctx = get_ctx(res.device)
+            _lib.call("mxlo_gather_range", ctx.handle, res.element_size(), ptr(res), ptr(v), v.numel(), start, step, ln)
+
+        def tprod(res, u, a, b):  # multRestrict! :171-174
+            ctx = get_ctx(res.device)
+            _lib.call("mxlo_scatter_zero_range", ctx.handle, res.element_size(), ptr(res), res.numel(), ptr(u), start,
+                      step, ln)
+        nrow = ln
+    else:
+        idx_h = np.asarray(Idx.cpu() if isinstance(Idx, torch.Tensor) else Idx, dtype=np.int64).reshape(-1)
+        if idx_h.size and not (idx_h.min() >= 1 and idx_h.max() <= ncol):
+            raise LinearOperatorException(f"indices should be between 1 and {ncol}")
+        nrow = idx_h.size
+        idx_d = torch.from_numpy(idx_h.copy()).to(dev)
+        # duplicates: `res[I] = u` is sequential, the LAST write wins -> resolve once, here
+        _, last_pos = np.unique(idx_h[::-1], return_index=True)
+        keep = np.sort(nrow - 1 - last_pos)
+        if keep.size != nrow:
+            sidx_d = torch.from_numpy(idx_h[keep].copy()).to(dev)
+            spos_d = torch.from_numpy(keep.astype(np.int64)).to(dev)
+        else:
+            sidx_d, spos_d = idx_d, None
+
+        def prod(res, v, a, b):
+            ctx = get_ctx(res.device)
+            _lib.call("mxlo_gather", ctx.handle, res.element_size(), ptr(res), ptr(v), v.numel(), ptr(idx_d), nrow)
+
+        def tprod(res, u, a, b):
+            ctx = get_ctx(res.device)
+            _lib.call("mxlo_scatter_zero", ctx.handle, res.element_size(), ptr(res), res.numel(), ptr(u), ptr(sidx_d),
+                      ptr(spos_d), sidx_d.numel())
+    return LinearOperator(torch.int64, nrow, ncol, False, False, prod, tprod, tprod, S=storage)
+
+
+def opExtension(Idx, ncol: int, S: Optional[Storage] = None, device=None):
+    """opExtension(I, ncol; S) = opRestriction(I, ncol; S)' — src/special-operators.jl:217-222."""
+    if _is_colon(Idx):
+        return opRestriction(Idx, ncol, S=S, device=device)
+    return adjoint(opRestriction(Idx, ncol, S=S, device=device))
+
+
+# ----------------------------------------------------------------------------- Householder / Hermitian
+def mulHouseholder(res, h, v, alpha, beta):
+    """mulHouseholder! — src/linalg.jl:77-83."""
+    ctx = get_ctx(res.device)
+    _lib.call("mxlo_householder_mul", ctx.handle, dtype_code(res.dtype), ptr(res), ptr(h), ptr(v), res.numel(),
+              float(alpha), float(beta), scalar_flags(res.dtype, alpha, beta))
+
+
+def opHouseholder(h: torch.Tensor):
+    """opHouseholder(h) — src/linalg.jl:85-95: symmetric=isreal(h), hermitian=true, tprod!=nothing,
+    ctprod!=prod!. (The reference hard-codes S=Vector{T}; here S follows h.)"""
+    h = check_vec(h, "h")
+    dtype_code(h.dtype)
+    n = h.numel()
+    prod = lambda res, v, a, b: mulHouseholder(res, h, v, a, b)
+    return LinearOperator(h.dtype, n, n, True, True, prod, None, prod, S=storage_of(h))
+
+
+def mulHermitian(res, d, A, v, alpha, beta):
+    """mulHermitian! — src/linalg.jl:97-103 with L = tril(A,-1) taken from A in the kernel."""
+    ctx = get_ctx(res.device)
+    n = res.numel()
+    _lib.call("mxlo_hermitian_mul", ctx.handle, dtype_code(res.dtype), ptr(res), ptr(d), ptr(A), A.stride(1),
+              ptr(v), n, float(alpha), float(beta), scalar_flags(res.dtype, alpha, beta))
+
+
+def _colmajor(M: torch.Tensor) -> torch.Tensor:
+    """A Julia Matrix is column-major: return a 2-D tensor whose memory is column-major
+    (stride(0) == 1). A row-major torch matrix is transposed-copied once."""
+    if M.dim() != 2:
+        raise ValueError("matrix expected")
+    if M.stride(0) == 1 and M.stride(1) >= max(1, M.shape[0]):
+        return M
+    return M.t().contiguous().t()
+
+
+def opHermitian(*args):
+    """opHermitian(d, A) / opHermitian(A) — src/linalg.jl:105-127."""
+    if len(args) == 1:
+        A = _colmajor(args[0])
+        d = torch.diagonal(A).clone()
+    else:
+        d, A = args
+        A = _colmajor(A)
+        d = check_vec(d, "d")
+    m, n = A.shape
+    if not (m == n == d.numel()):
+        raise LinearOperatorException("shape mismatch")
+    U = torch.promote_types(d.dtype, A.dtype)
+    if d.dtype != U:
+        d = d.to(U)
+    if A.dtype != U:
+        A = _colmajor(A.to(U))
+    dtype_code(U)
+    prod = lambda res, v, a, b: mulHermitian(res, d, A, v, a, b)
+    return LinearOperator(U, m, m, True, True, prod, None, None, S=Storage(U, A.device))
+
+
+# ----------------------------------------------------------------------------- dense matrix operator
+def LinearOperatorFromMatrix(M: torch.Tensor, symmetric: bool = False, hermitian: bool = False,
+                             S: Optional[Storage] = None):
+    """LinearOperator(M) — src/constructors.jl:15-29 (prod!/tprod!/ctprod! = gemv N/T/C)."""
+    M = _colmajor(M)
+    dtype_code(M.dtype)
+    nrow, ncol = M.shape
+    ld = M.stride(1) if ncol > 1 else max(1, nrow)
+
+    def gemv(res, v, a, b, mode):
+        ctx = get_ctx(res.device)
+        _lib.call("mxlo_gemv", ctx.handle, dtype_code(M.dtype), ptr(res), ptr(M), nrow, ncol, ld, ptr(v), float(a),
+                  float(b), mode, scalar_flags(res.dtype, a, b))
+
+    prod = lambda res, v, a, b: gemv(res, v, a, b, _lib.OP_N)
+    tprod = lambda res, u, a, b: gemv(res, u, a, b, _lib.OP_T)
+    ctprod = lambda res, w, a, b: gemv(res, w, a, b, _lib.OP_C)
+    op = LinearOperator(M.dtype, nrow, ncol, symmetric, hermitian, prod, tprod, ctprod,
+                        S=S if S is not None else Storage(M.dtype, M.device))
+    op._leaf = ("dense", M, ld)
+    return op
+
+
+# ----------------------------------------------------------------------------- BlockDiagonalOperator
+class _BlockDiagHandle:
+    def __init__(self, ctx, dtype, descs):
+        self.ctx = ctx
+        arr = (_lib.BlockDesc * len(descs))(*descs)
+        self.h = C.c_void_p()
+        _lib.call("mxlo_blockdiag_create", ctx.handle, dtype_code(dtype), arr, len(descs), C.byref(self.h))
+
+    def __del__(self):
+        try:
+            _lib.lib().mxlo_blockdiag_destroy(self.h)
+        except Exception:
+            pass
+
+
+def BlockDiagonalOperator(*ops, S: Optional[Storage] = None):
+    """BlockDiagonalOperator(M1, ..., Mn; S) — src/special-operators.jl:249-294.
+
+    When every block is a diagonal / dense-matrix / identity / zero block the whole operator is ONE
+    device launch over a descriptor table (mxlo_blockdiag_mul); any other block type falls back to
+    the reference's own structure (a host loop of inner `mul!` on views, :258-267) — still the HIP
+    leaves, just one launch per block."""
+    from .operators import _as_op, _promote_eltype, promote_storage
+    ops = [_as_op(o) if isinstance(o, torch.Tensor) else o for o in ops]
+    nrow = sum(o.size(1) for o in ops)
+    ncol = sum(o.size(2) for o in ops)
+    T = _promote_eltype(*ops)
+    S = S if S is not None else promote_storage(*[storage_type(o) for o in ops])
+    symm = all(issymmetric(o) for o in ops)
+    herm = all(ishermitian(o) for o in ops)
+
+    fusable = all(getattr(o, "_leaf", None) is not None and o.eltype == T for o in ops) and T.is_floating_point
+    if fusable:
+        descs, k, j = [], 0, 0
+        keep = []
+        for o in ops:
+            leaf = o._leaf
+            m, n = o.shape
+            if leaf[0] == "diag":
+                descs.append(_lib.BlockDesc(_lib.BLK_DIAG, 0, k, j, m, n, leaf[1].data_ptr(), 0))
+                keep.append(leaf[1])
+            elif leaf[0] == "dense":
+                descs.append(_lib.BlockDesc(_lib.BLK_DENSE, 0, k, j, m, n, leaf[1].data_ptr(), leaf[2]))
+                keep.append(leaf[1])
+            elif leaf[0] == "eye" and m == n:
+                descs.append(_lib.BlockDesc(_lib.BLK_EYE, 0, k, j, m, n, None, 0))
+            elif leaf[0] == "zeros":
+                descs.append(_lib.BlockDesc(_lib.BLK_ZEROS, 0, k, j, m, n, None, 0))
+            else:
+                fusable = False
+                break
+            k += m
+            j += n
+    if fusable:
+        ctx = get_ctx(S.device)
+        handle = _BlockDiagHandle(ctx, T, descs)
+
+        def bd(res, x, a, b, mode):
+            get_ctx(res.device)
+            _lib.call("mxlo_blockdiag_mul", handle.h, ptr(res), ptr(x), float(a), float(b), mode,
+                      scalar_flags(res.dtype, a, b))
+
+        prod = lambda y, x, a, b: bd(y, x, a, b, _lib.OP_N)
+        tprod = lambda y, x, a, b: bd(y, x, a, b, _lib.OP_T)
+        ctprod = lambda y, x, a, b: bd(y, x, a, b, _lib.OP_C)
+        op = LinearOperator(T, nrow, ncol, symm, herm, prod, tprod, ctprod, S=S)
+        op._keepalive = (handle, keep, ops)
+        return op
+
+    def prod(y, x, a, b):        # :258-267
+        k = j = 0
+        for o in ops:
+            m, n = o.shape
+            mul(y[k:k + m], o, x[j:j + n], a, b)
+            k += m
+            j += n
+
+    def tprod(y, x, a, b):       # :269-278
+        k = j = 0
+        for o in ops:
+            m, n = o.shape
+            mul(y[k:k + n], transpose(o), x[j:j + m], a, b)
+            k += n
+            j += m
+
+    def ctprod(y, x, a, b):      # :280-289
+        k = j = 0
+        for o in ops:
+            m, n = o.shape
+            mul(y[k:k + n], adjoint(o), x[j:j + m], a, b)
+            k += n
+            j += m
+
+    return LinearOperator(T, nrow, ncol, symm, herm, prod, tprod, ctprod, S=S)
+
+
+# ----------------------------------------------------------------------------- kron
+def kron(A, B):
+    """kron(A, B) — src/kron.jl:10-49: (A ⊗ B) x = vec(B X Aᵀ).
+
+    The reference rebuilds a composite operator and materialises it with `m` single-vector products on
+    every apply; here both factors are dense device matrices (operators are materialised ONCE at
+    construction with `Matrix(op)`, src/abstract.jl:282-292) and an apply is two MFMA GEMMs."""
+    def dense_of(X):
+        if isinstance(X, torch.Tensor):
+            return _colmajor(X), False, False
+        leaf = getattr(X, "_leaf", None)
+        if leaf is not None and leaf[0] == "dense":
+            return leaf[1], issymmetric(X), ishermitian(X)
+        return _colmajor(to_dense(X)), issymmetric(X), ishermitian(X)
+
+    Am, Asym, Aherm = dense_of(A)
+    Bm, Bsym, Bherm = dense_of(B)
+    T = torch.promote_types(Am.dtype, Bm.dtype)
+    dtype_code(T)
+    if Am.dtype != T:
+        Am = _colmajor(Am.to(T))
+    if Bm.dtype != T:
+        Bm = _colmajor(Bm.to(T))
+    m, n = Am.shape
+    p, q = Bm.shape
+    lda = Am.stride(1) if n > 1 else max(1, m)
+    ldb = Bm.stride(1) if q > 1 else max(1, p)
+    work = torch.empty(max(q * m, p * n), dtype=T, device=Am.device)
+
+    def km(res, x, a, b, mode):
+        ctx = get_ctx(res.device)
+        _lib.call("mxlo_kron_mul", ctx.handle, dtype_code(T), ptr(res), ptr(Am), m, n, lda, ptr(Bm), p, q, ldb,
+                  ptr(x), ptr(work), float(a), float(b), mode, scalar_flags(res.dtype, a, b))
+
+    prod = lambda res, x, a, b: km(res, x, a, b, _lib.OP_N)
+    tprod = lambda res, x, a, b: km(res, x, a, b, _lib.OP_T)
+    ctprod = lambda res, x, a, b: km(res, x, a, b, _lib.OP_C)
+    return LinearOperator(T, m * p, n * q, Asym and Bsym, Aherm and Bherm, prod, tprod, ctprod,
+                          S=Storage(T, Am.device))

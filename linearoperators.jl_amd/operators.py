@@ -1,0 +1,685 @@
+"""Host-side mirror of the reference's operator API for the `mul!` hot path.
+
+Mirrors, name for name and argument for argument (Python spelling: ``mul!`` -> :func:`mul`,
+``push!`` -> ``push`` ...), the reference's
+
+* operator ABI            src/abstract.jl:30-59,122-131,147-153,176-196,203-244,282-292
+* 5-arg / 3-arg ``mul!``  src/operations.jl:3-48  (shape check, counters, ``prod3!``)
+* lazy wrappers            src/adjtrans.jl:1-261
+* combinators              src/operations.jl:99-234
+* cat                      src/cat.jl:1-129
+
+Only *host control flow* lives here; every vector touch is a libmxlo.so call made by a
+leaf closure (see :mod:`leaves`, :mod:`qn`). Error behaviour follows the reference:
+``LinearOperatorException("shape mismatch")`` before any data is touched.
+"""
+from __future__ import annotations
+
+import inspect
+from typing import Callable, Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+from .device import Storage, check_vec, dtype_code, get_ctx, ptr, storage_of
+
+
+class LinearOperatorException(Exception):
+    """src/abstract.jl:16-18"""
+
+
+# ----------------------------------------------------------------------------- scalars
+def _is_f64_scalar(x) -> bool:
+    """Julia `Float64`: a Python float or a float64 NumPy/torch scalar. Python ints are Julia
+    `Int` (never widen a Float32 product); float32 scalars stay Float32."""
+    if isinstance(x, bool) or isinstance(x, (int, np.integer)):
+        return False
+    if isinstance(x, float):
+        return True
+    if isinstance(x, np.floating):
+        return x.dtype == np.float64
+    if isinstance(x, torch.Tensor):
+        return x.dtype == torch.float64
+    return True
+
+
+def scalar_flags(dtype: torch.dtype, alpha, beta) -> int:
+    """MXLO_SCALARS_F64 when Float32 data meets a Float64 alpha/beta (mixed precision)."""
+    if dtype == torch.float32 and (_is_f64_scalar(alpha) or _is_f64_scalar(beta)):
+        return _lib.SCALARS_F64
+    return 0
+
+
+def one(dtype: torch.dtype):
+    """one(T): Float32 -> float32 scalar, Float64 -> Python float, integer eltypes -> Python int."""
+    if not dtype.is_floating_point:
+        return 1
+    return np.float32(1) if dtype == torch.float32 else 1.0
+
+
+def zero(dtype: torch.dtype):
+    if not dtype.is_floating_point:
+        return 0
+    return np.float32(0) if dtype == torch.float32 else 0.0
+
+
+def _nargs(f: Callable) -> int:
+    """`hasmethod(op.prod!, (res, v, α, β))` stand-in (src/operations.jl:26): count positional params."""
+    try:
+        sig = inspect.signature(f)
+    except (TypeError, ValueError):
+        return 4
+    n = 0
+    for p in sig.parameters.values():
+        if p.kind in (p.POSITIONAL_ONLY, p.POSITIONAL_OR_KEYWORD):
+            n += 1
+        elif p.kind == p.VAR_POSITIONAL:
+            return 4
+    return n
+
+
+def promote_storage(*ss: Optional[Storage]) -> Storage:
+    """promote_type(storage_type(op1), storage_type(op2)) + isconcretetype check
+    (src/operations.jl:137-147, src/cat.jl:47-49)."""
+    ss = [s for s in ss if s is not None]
+    dev = ss[0].device
+    dt = ss[0].dtype
+    for s in ss[1:]:
+        if s.device != dev:
+            raise LinearOperatorException(
+                f"storage types {ss[0]} and {s} cannot be promoted to a concrete type. "
+                "Ensure both operators use compatible storage types (e.g., both GPU or both CPU).")
+        dt = torch.promote_types(dt, s.dtype)
+    return Storage(dt, dev)
+
+
+# ----------------------------------------------------------------------------- base types
+class AbstractLinearOperator:
+    """src/abstract.jl:30 — duck-typed on the fields nrow ncol symmetric hermitian prod tprod ctprod
+    nprod ntprod nctprod (the structural contract quasi-Newton operators also satisfy)."""
+
+    nrow: int
+    ncol: int
+    symmetric: bool
+    hermitian: bool
+    eltype: torch.dtype
+
+    # --- size / flags (src/abstract.jl:203-244)
+    @property
+    def shape(self):
+        return (self.nrow, self.ncol)
+
+    def size(self, d: Optional[int] = None):
+        if d is None:
+            return self.shape
+        if d == 1:
+            return self.shape[0]
+        if d == 2:
+            return self.shape[1]
+        raise LinearOperatorException("Linear operators only have 2 dimensions for now")
+
+    # --- lazy wrappers (src/adjtrans.jl:33-45)
+    @property
+    def T(self):
+        return transpose(self)
+
+    @property
+    def H(self):
+        return adjoint(self)
+
+    def conj(self):
+        return conj(self)
+
+    # --- arithmetic (src/operations.jl)
+    def __neg__(self):
+        return neg(self)
+
+    def __pos__(self):
+        return self
+
+    def __mul__(self, other):
+        if isinstance(other, AbstractLinearOperator):
+            return compose(self, other)
+        if isinstance(other, torch.Tensor) and other.dim() == 1:
+            return apply(self, other)
+        if isinstance(other, torch.Tensor) and other.dim() == 2:
+            from .leaves import LinearOperatorFromMatrix
+            return compose(self, LinearOperatorFromMatrix(other))
+        if _is_number(other):
+            return scale_op(self, other)
+        return NotImplemented
+
+    __matmul__ = __mul__
+
+    def __rmul__(self, other):
+        if _is_number(other):
+            return scale_op(self, other)                     # src/operations.jl:181-183
+        if isinstance(other, torch.Tensor) and other.dim() == 2:
+            from .leaves import LinearOperatorFromMatrix
+            return compose(LinearOperatorFromMatrix(other), self)
+        return NotImplemented
+
+    def __truediv__(self, x):
+        if _is_number(x):
+            return scale_op(self, one(self.eltype) / x)       # src/operations.jl:185
+        return NotImplemented
+
+    def __add__(self, other):
+        if isinstance(other, AbstractLinearOperator):
+            return add(self, other)
+        if isinstance(other, torch.Tensor) and other.dim() == 2:
+            from .leaves import LinearOperatorFromMatrix
+            return add(self, LinearOperatorFromMatrix(other))
+        if _is_number(other):                                 # src/operations.jl:222
+            from .leaves import opOnes
+            return add(self, scale_op(opOnes(self.eltype, self.nrow, self.ncol, S=storage_type(self)), other))
+        return NotImplemented
+
+    def __radd__(self, other):
+        if _is_number(other):                                 # src/operations.jl:223
+            from .leaves import opOnes
+            return add(scale_op(opOnes(self.eltype, self.nrow, self.ncol, S=storage_type(self)), other), self)
+        if isinstance(other, torch.Tensor) and other.dim() == 2:
+            from .leaves import LinearOperatorFromMatrix
+            return add(LinearOperatorFromMatrix(other), self)
+        return NotImplemented
+
+    def __sub__(self, other):
+        if isinstance(other, AbstractLinearOperator):
+            return add(self, neg(other))                      # src/operations.jl:226
+        if _is_number(other):
+            return self + (-other)                            # src/operations.jl:233
+        if isinstance(other, torch.Tensor) and other.dim() == 2:
+            from .leaves import LinearOperatorFromMatrix
+            return add(self, neg(LinearOperatorFromMatrix(other)))
+        return NotImplemented
+
+    def __rsub__(self, other):
+        if _is_number(other):
+            return other + neg(self)                          # src/operations.jl:234
+        return NotImplemented
+
+    def __getitem__(self, key):                               # src/special-operators.jl:225-233
+        from .leaves import opExtension, opRestriction
+        rows, cols = key
+        R = opRestriction(rows, self.size(1), S=None, device=storage_type(self).device)
+        E = opExtension(cols, self.size(2), S=None, device=storage_type(self).device)
+        return compose(compose(R, self), E)
+
+
+def _is_number(x) -> bool:
+    return isinstance(x, (int, float, np.integer, np.floating)) and not isinstance(x, bool)
+
+
+class LinearOperator(AbstractLinearOperator):
+    """`LinearOperator{T,S}(nrow, ncol, symmetric, hermitian, prod!, tprod!, ctprod!)`
+    (src/abstract.jl:38-51,122-131). `prod(res, v, alpha, beta)` is the 5-arg closure form,
+    `prod(res, v)` the 3-arg form (handled by ``prod3``, with lazily allocated Mv/Mtu)."""
+
+    def __init__(self, T: torch.dtype, nrow: int, ncol: int, symmetric: bool, hermitian: bool,
+                 prod, tprod=None, ctprod=None, S: Optional[Storage] = None):
+        self.eltype = T
+        self.nrow, self.ncol = int(nrow), int(ncol)
+        self.symmetric, self.hermitian = bool(symmetric), bool(hermitian)
+        self.prod, self.tprod, self.ctprod = prod, tprod, ctprod
+        self.nprod = self.ntprod = self.nctprod = 0
+        if S is None:
+            raise LinearOperatorException("storage type S is required (a device vector type)")
+        self.S = S
+        self.Mv = S.undef(0)       # S(undef, 0)  src/abstract.jl:79-80
+        self.Mtu = S.undef(0)
+
+    def __repr__(self):            # src/abstract.jl:262-275
+        return ("Linear operator\n  nrow: %d\n  ncol: %d\n  eltype: %s\n  symmetric: %s\n  hermitian: %s\n"
+                "  nprod:   %d\n  ntprod:  %d\n  nctprod: %d\n" %
+                (self.nrow, self.ncol, self.eltype, self.symmetric, self.hermitian, self.nprod, self.ntprod,
+                 self.nctprod))
+
+
+# counters (src/abstract.jl:147-153, src/adjtrans.jl:47-62)
+def nprod(op):
+    if isinstance(op, AdjointLinearOperator):
+        return nctprod(op.parent)
+    if isinstance(op, TransposeLinearOperator):
+        return ntprod(op.parent)
+    if isinstance(op, ConjugateLinearOperator):
+        return nprod(op.parent)
+    return op.nprod
+
+
+def ntprod(op):
+    if isinstance(op, (AdjointLinearOperator, TransposeLinearOperator)):
+        return nprod(op.parent)
+    if isinstance(op, ConjugateLinearOperator):
+        return ntprod(op.parent)
+    return op.ntprod
+
+
+def nctprod(op):
+    if isinstance(op, (AdjointLinearOperator, TransposeLinearOperator)):
+        return nprod(op.parent)
+    if isinstance(op, ConjugateLinearOperator):
+        return nctprod(op.parent)
+    return op.nctprod
+
+
+def reset(op):
+    """reset!(op) — src/abstract.jl:191-196 (quasi-Newton operators override, see qn.py)."""
+    if hasattr(op, "_reset_data"):
+        op._reset_data()
+    op.nprod = op.ntprod = op.nctprod = 0
+    return op
+
+
+def issymmetric(op) -> bool:
+    return op.parent.symmetric if isinstance(op, _Wrapper) else op.symmetric
+
+
+def ishermitian(op) -> bool:
+    return op.parent.hermitian if isinstance(op, _Wrapper) else op.hermitian
+
+
+def has_args5(op) -> bool:          # src/abstract.jl:166
+    if isinstance(op, _Wrapper):
+        return has_args5(op.parent)
+    if hasattr(op, "_has_args5"):
+        return op._has_args5
+    return _nargs(op.prod) == 4
+
+
+def isallocated5(op) -> bool:       # src/abstract.jl:168
+    if isinstance(op, _Wrapper):
+        return isallocated5(op.parent)
+    if hasattr(op, "_has_args5"):
+        return True
+    return not (op.Mv.numel() == 0 or op.Mtu.numel() == 0)
+
+
+def storage_type(op) -> Storage:    # src/abstract.jl:176-184, src/adjtrans.jl:67-73
+    if isinstance(op, _Wrapper):
+        return storage_type(op.parent)
+    if isinstance(op, torch.Tensor):
+        return storage_of(op)
+    return op.S
+
+
+def eltype(op):
+    return op.eltype
+
+
+def size(op, d=None):
+    return op.size(d)
+
+
+def allocate_vectors_args3(op):     # src/operations.jl:3-8
+    if isinstance(op, _Wrapper):
+        return allocate_vectors_args3(op.parent)
+    S = storage_type(op)
+    op.Mv = S.undef(op.nrow)
+    op.Mtu = op.Mv if op.nrow == op.ncol else S.undef(op.ncol)
+    return op
+
+
+# ----------------------------------------------------------------------------- device helpers for prod3!
+def _axpby(res, Mv, alpha, beta):
+    """res .= α .* Mv .+ β .* res (src/operations.jl:18) on the device."""
+    ctx = get_ctx(res.device)
+    n = res.numel()
+    _lib.call("mxlo_eye_mul", ctx.handle, dtype_code(res.dtype), ptr(res), ptr(Mv), n, n, float(alpha),
+              float(beta), scalar_flags(res.dtype, alpha, beta))
+
+
+def _scale(res, alpha):
+    """res .*= α (src/operations.jl:14)."""
+    ctx = get_ctx(res.device)
+    _lib.call("mxlo_scale", ctx.handle, dtype_code(res.dtype), ptr(res), res.numel(), float(alpha),
+              scalar_flags(res.dtype, alpha, 0))
+
+
+def prod3(res, prod, v, alpha, beta, Mv):
+    """prod3! — src/operations.jl:10-20."""
+    if beta == 0:
+        prod(res, v)
+        if alpha != 1:
+            _scale(res, alpha)
+    else:
+        prod(Mv, v)
+        _axpby(res, Mv, alpha, beta)
+
+
+# ----------------------------------------------------------------------------- mul!
+def mul(res: torch.Tensor, op, v: torch.Tensor, alpha=None, beta=None):
+    """`mul!(res, op, v, α, β)` / `mul!(res, op, v)` — src/operations.jl:22-40, src/adjtrans.jl:90-261.
+
+    3-arg form: α = one(T), β = zero(T) with T = eltype(v) (src/operations.jl:38-40)."""
+    if alpha is None and beta is None:
+        alpha, beta = one(v.dtype), zero(v.dtype)
+    elif alpha is None or beta is None:
+        raise TypeError("mul! takes either (res, op, v) or (res, op, v, alpha, beta)")
+    if isinstance(op, AdjointLinearOperator):
+        return _mul_adjoint(res, op, v, alpha, beta)
+    if isinstance(op, TransposeLinearOperator):
+        return _mul_transpose(res, op, v, alpha, beta)
+    if isinstance(op, ConjugateLinearOperator):
+        return mul(res, op.parent, v, alpha, beta)    # real eltypes: conj! is the identity
+    if not (v.shape[0] == op.size(2) and res.shape[0] == op.size(1)):
+        raise LinearOperatorException("shape mismatch")
+    op.nprod += 1                                      # increase_nprod!
+    if _nargs(op.prod) == 4:
+        op.prod(res, v, alpha, beta)
+    else:
+        if not (beta == 0 or op.Mv.numel() != 0):
+            allocate_vectors_args3(op)
+        prod3(res, op.prod, v, alpha, beta, op.Mv)
+    return res
+
+
+def _call_t(res, f, v, alpha, beta, p):
+    if _nargs(f) == 4:
+        f(res, v, alpha, beta)
+    else:
+        if not (beta == 0 or p.Mtu.numel() != 0):
+            allocate_vectors_args3(p)
+        prod3(res, f, v, alpha, beta, p.Mtu)
+    return res
+
+
+def _mul_adjoint(res, op, v, alpha, beta):
+    """src/adjtrans.jl:90-137 (real eltypes: conj!/conj.() are identities and are elided)."""
+    p = op.parent
+    if not (v.shape[0] == p.size(1) and res.shape[0] == p.size(2)):
+        raise LinearOperatorException("shape mismatch")
+    if ishermitian(p):
+        return mul(res, p, v, alpha, beta)
+    if p.ctprod is not None:
+        p.nctprod += 1
+        return _call_t(res, p.ctprod, v, alpha, beta, p)
+    tprod = p.tprod
+    if tprod is None:
+        if issymmetric(p):
+            p.nprod += 1
+            tprod = p.prod
+        else:
+            raise LinearOperatorException("unable to infer conjugate transpose operator")
+    else:
+        p.ntprod += 1
+    return _call_t(res, tprod, v, alpha, beta, p)
+
+
+def _mul_transpose(res, op, v, alpha, beta):
+    """src/adjtrans.jl:158-205."""
+    p = op.parent
+    if not (v.shape[0] == p.size(1) and res.shape[0] == p.size(2)):
+        raise LinearOperatorException("shape mismatch")
+    if issymmetric(p):
+        return mul(res, p, v, alpha, beta)
+    if p.tprod is not None:
+        p.ntprod += 1
+        return _call_t(res, p.tprod, v, alpha, beta, p)
+    ctprod = p.ctprod
+    if ctprod is None:
+        if ishermitian(p):
+            p.nprod += 1
+            ctprod = p.prod
+        else:
+            raise LinearOperatorException("unable to infer transpose operator")
+    else:
+        p.nctprod += 1
+    return _call_t(res, ctprod, v, alpha, beta, p)
+
+
+def apply(op, v: torch.Tensor) -> torch.Tensor:
+    """`op * v` — src/operations.jl:43-48: res = similar(v, promote_type(T,S), nrow); mul!(res, op, v)."""
+    check_vec(v, "v")
+    T = op.eltype if op.eltype.is_floating_point else v.dtype
+    res = torch.empty(op.size(1), dtype=torch.promote_types(T, v.dtype), device=v.device)
+    mul(res, op, v)
+    return res
+
+
+# ----------------------------------------------------------------------------- lazy wrappers
+class _Wrapper(AbstractLinearOperator):
+    def __init__(self, parent):
+        self.parent = parent
+        self.eltype = parent.eltype
+
+
+class AdjointLinearOperator(_Wrapper):
+    nrow = property(lambda s: s.parent.size(2))
+    ncol = property(lambda s: s.parent.size(1))
+    symmetric = property(lambda s: issymmetric(s.parent))
+    hermitian = property(lambda s: ishermitian(s.parent))
+
+
+class TransposeLinearOperator(_Wrapper):
+    nrow = property(lambda s: s.parent.size(2))
+    ncol = property(lambda s: s.parent.size(1))
+    symmetric = property(lambda s: issymmetric(s.parent))
+    hermitian = property(lambda s: ishermitian(s.parent))
+
+
+class ConjugateLinearOperator(_Wrapper):
+    nrow = property(lambda s: s.parent.size(1))
+    ncol = property(lambda s: s.parent.size(2))
+    symmetric = property(lambda s: issymmetric(s.parent))
+    hermitian = property(lambda s: ishermitian(s.parent))
+
+
+def adjoint(A):      # src/adjtrans.jl:33-45
+    if isinstance(A, AdjointLinearOperator):
+        return A.parent
+    if isinstance(A, ConjugateLinearOperator):
+        return transpose(A.parent)
+    if isinstance(A, TransposeLinearOperator):
+        return conj(A.parent)
+    return AdjointLinearOperator(A)
+
+
+def transpose(A):
+    if isinstance(A, TransposeLinearOperator):
+        return A.parent
+    if isinstance(A, AdjointLinearOperator):
+        return conj(A.parent)
+    if isinstance(A, ConjugateLinearOperator):
+        return adjoint(A.parent)
+    return TransposeLinearOperator(A)
+
+
+def conj(A):
+    if isinstance(A, ConjugateLinearOperator):
+        return A.parent
+    if isinstance(A, AdjointLinearOperator):
+        return transpose(A.parent)
+    if isinstance(A, TransposeLinearOperator):
+        return adjoint(A.parent)
+    return ConjugateLinearOperator(A)
+
+
+# ----------------------------------------------------------------------------- combinators
+def _promote_eltype(*ops):
+    dt = None
+    for o in ops:
+        t = o.eltype if not isinstance(o, torch.dtype) else o
+        dt = t if dt is None else torch.promote_types(dt, t)
+    return dt
+
+
+def neg(op):
+    """-op — src/operations.jl:102-115 (wrappers: src/adjtrans.jl:263-265)."""
+    if isinstance(op, AdjointLinearOperator):
+        return adjoint(neg(op.parent))
+    if isinstance(op, TransposeLinearOperator):
+        return transpose(neg(op.parent))
+    if isinstance(op, ConjugateLinearOperator):
+        return conj(neg(op.parent))
+    prod = lambda res, v, a, b: mul(res, op, v, -a, b)
+    tprod = lambda res, u, a, b: mul(res, transpose(op), u, -a, b)
+    ctprod = lambda res, w, a, b: mul(res, adjoint(op), w, -a, b)
+    return LinearOperator(op.eltype, op.nrow, op.ncol, op.symmetric, op.hermitian, prod, tprod, ctprod,
+                          S=storage_type(op))
+
+
+def prod_op(res, op1, op2, vtmp, v, alpha, beta):
+    """prod_op! — src/operations.jl:117-128."""
+    mul(vtmp, op2, v)
+    mul(res, op1, vtmp, alpha, beta)
+
+
+def compose(op1, op2):
+    """op1 * op2 — src/operations.jl:131-156."""
+    T = _promote_eltype(op1, op2)
+    m1, n1 = op1.shape
+    m2, n2 = op2.shape
+    if m2 != n1:
+        raise LinearOperatorException("shape mismatch")
+    S = promote_storage(storage_type(op1), storage_type(op2))
+    if not S.dtype.is_floating_point:      # index-typed restriction composed with restriction
+        S = Storage(torch.float64, S.device)
+    vtmp, utmp, wtmp = S.zeros(m2), S.zeros(n1), S.zeros(n1)
+    prod = lambda res, v, a, b: prod_op(res, op1, op2, vtmp, v, a, b)
+    tprod = lambda res, u, a, b: prod_op(res, transpose(op2), transpose(op1), utmp, u, a, b)
+    ctprod = lambda res, w, a, b: prod_op(res, adjoint(op2), adjoint(op1), wtmp, w, a, b)
+    return LinearOperator(T, m1, n2, False, False, prod, tprod, ctprod, S=S)
+
+
+def scale_op(op, x):
+    """op * x, x * op — src/operations.jl:163-183; wrappers src/adjtrans.jl:267-273."""
+    if isinstance(op, AdjointLinearOperator):
+        return adjoint(scale_op(op.parent, x))
+    if isinstance(op, TransposeLinearOperator):
+        return transpose(scale_op(op.parent, x))
+    if isinstance(op, ConjugateLinearOperator):
+        return conj(scale_op(op.parent, x))
+    T = op.eltype
+    prod = lambda res, v, a, b: mul(res, op, v, x * a, b)
+    tprod = lambda res, u, a, b: mul(res, transpose(op), u, x * a, b)
+    ctprod = lambda res, w, a, b: mul(res, adjoint(op), w, x * a, b)   # x' == x for real x
+    return LinearOperator(T, op.nrow, op.ncol, op.symmetric, op.hermitian, prod, tprod, ctprod,
+                          S=storage_type(op))
+
+
+def sum_prod(res, op1, op2, v, alpha, beta):
+    """sum_prod! — src/operations.jl:187-197."""
+    mul(res, op1, v, alpha, beta)
+    mul(res, op2, v, alpha, one(op2.eltype))
+
+
+def add(op1, op2):
+    """op1 + op2 — src/operations.jl:199-215."""
+    m1, n1 = op1.shape
+    m2, n2 = op2.shape
+    if m1 != m2 or n1 != n2:
+        raise LinearOperatorException("shape mismatch")
+    T = _promote_eltype(op1, op2)
+    prod = lambda res, v, a, b: sum_prod(res, op1, op2, v, a, b)
+    tprod = lambda res, u, a, b: sum_prod(res, transpose(op1), transpose(op2), u, a, b)
+    ctprod = lambda res, w, a, b: sum_prod(res, adjoint(op1), adjoint(op2), w, a, b)
+    symm = issymmetric(op1) and issymmetric(op2)
+    herm = ishermitian(op1) and ishermitian(op2)
+    S = promote_storage(storage_type(op1), storage_type(op2))
+    return LinearOperator(T, m1, n1, symm, herm, prod, tprod, ctprod, S=S)
+
+
+# ----------------------------------------------------------------------------- cat (src/cat.jl)
+def hcat_prod(res, A, B, Ancol, nV, v, alpha, beta):
+    """hcat_prod! — src/cat.jl:7-19 (views are pointer+offset: torch slices)."""
+    mul(res, A, v[:Ancol], alpha, beta)
+    mul(res, B, v[Ancol:nV], alpha, one(B.eltype))
+
+
+def hcat_ctprod(res, A, B, Ancol, nV, u, alpha, beta):
+    """hcat_ctprod! — src/cat.jl:21-33."""
+    mul(res[:Ancol], A, u, alpha, beta)
+    mul(res[Ancol:nV], B, u, alpha, beta)
+
+
+def _hcat2(A, B):
+    """hcat(A, B) — src/cat.jl:35-51."""
+    if A.size(1) != B.size(1):
+        raise LinearOperatorException("hcat: inconsistent row sizes")
+    nrow = A.size(1)
+    Ancol, Bncol = A.size(2), B.size(2)
+    T = _promote_eltype(A, B)
+    prod = lambda res, v, a, b: hcat_prod(res, A, B, Ancol, Ancol + Bncol, v, a, b)
+    tprod = lambda res, u, a, b: hcat_ctprod(res, transpose(A), transpose(B), Ancol, Ancol + Bncol, u, a, b)
+    ctprod = lambda res, w, a, b: hcat_ctprod(res, adjoint(A), adjoint(B), Ancol, Ancol + Bncol, w, a, b)
+    S = promote_storage(storage_type(A), storage_type(B))
+    return LinearOperator(T, nrow, Ancol + Bncol, False, False, prod, tprod, ctprod, S=S)
+
+
+def _as_op(x):
+    if isinstance(x, AbstractLinearOperator):
+        return x
+    if isinstance(x, torch.Tensor) and x.dim() == 2:
+        from .leaves import LinearOperatorFromMatrix
+        return LinearOperatorFromMatrix(x)
+    raise TypeError(f"cannot concatenate {type(x)}")
+
+
+def hcat(*ops):
+    """hcat(ops...) folds left — src/cat.jl:53-59."""
+    ops = [_as_op(o) for o in ops]
+    op = ops[0]
+    for o in ops[1:]:
+        op = _hcat2(op, o)
+    return op
+
+
+def vcat_prod(res, A, B, Anrow, nV, u, alpha, beta):
+    """vcat_prod! — src/cat.jl:65-77."""
+    mul(res[:Anrow], A, u, alpha, beta)
+    mul(res[Anrow:nV], B, u, alpha, beta)
+
+
+def vcat_ctprod(res, A, B, Anrow, nV, v, alpha, beta):
+    """vcat_ctprod! — src/cat.jl:79-91."""
+    mul(res, A, v[:Anrow], alpha, beta)
+    mul(res, B, v[Anrow:nV], alpha, one(B.eltype))
+
+
+def _vcat2(A, B):
+    """vcat(A, B) — src/cat.jl:93-109."""
+    if A.size(2) != B.size(2):
+        raise LinearOperatorException("vcat: inconsistent column sizes")
+    Anrow, Bnrow = A.size(1), B.size(1)
+    ncol = A.size(2)
+    T = _promote_eltype(A, B)
+    prod = lambda res, v, a, b: vcat_prod(res, A, B, Anrow, Anrow + Bnrow, v, a, b)
+    tprod = lambda res, u, a, b: vcat_ctprod(res, transpose(A), transpose(B), Anrow, Anrow + Bnrow, u, a, b)
+    ctprod = lambda res, w, a, b: vcat_ctprod(res, adjoint(A), adjoint(B), Anrow, Anrow + Bnrow, w, a, b)
+    S = promote_storage(storage_type(A), storage_type(B))
+    return LinearOperator(T, Anrow + Bnrow, ncol, False, False, prod, tprod, ctprod, S=S)
+
+
+def vcat(*ops):
+    """vcat(ops...) folds left — src/cat.jl:111-117."""
+    ops = [_as_op(o) for o in ops]
+    op = ops[0]
+    for o in ops[1:]:
+        op = _vcat2(op, o)
+    return op
+
+
+def hvcat(rows, *ops):
+    """hvcat(rows, ops...) — src/cat.jl:120-129: vcat of hcats."""
+    rs, a = [], 0
+    for r in rows:
+        rs.append(hcat(*ops[a:a + r]))
+        a += r
+    return vcat(*rs)
+
+
+# ----------------------------------------------------------------------------- Matrix(op)
+def to_dense(op) -> torch.Tensor:
+    """`Matrix(op)` — src/abstract.jl:282-292: ncol products with unit vectors."""
+    m, n = op.shape
+    S = storage_type(op)
+    dt = op.eltype if op.eltype.is_floating_point else torch.float64
+    A = torch.empty((n, m), dtype=dt, device=S.device)   # row i = column i of the operator
+    ei = torch.zeros(n, dtype=dt, device=S.device)
+    for i in range(n):
+        ei[i] = 1
+        mul(A[i], op, ei)
+        ei[i] = 0
+    return A.t().contiguous()

@@ -1,0 +1,186 @@
+"""Generate tests/golden/kat_reference_tests.json.
+
+The reference (LinearOperators.jl v2.14.2) is pure Julia and Julia is not installed in the build
+image, so its outputs cannot be recorded by running it. This script instead writes down the
+KNOWN-ANSWER cases that the reference's OWN test-suite holds for the `mul!` hot path: the
+deterministic inputs each test constructs (`simple_vector(T,n) = [1,-1,1,...]`, test/test_aux.jl:33;
+`s = i*ones(n)`, `y = [i; ones(n-1)]`, test/test_lbfgs.jl:35-36) and the closed-form value the test
+asserts (`D*u == v.*u`, `P*v == v[idx]`, `Matrix(LB) ≈ dense BFGS`, ...). Expected values are
+evaluated here in EXACT rational arithmetic (fractions.Fraction) from those closed forms — e.g. the
+L-BFGS answers come from the dense BFGS / inverse-BFGS / SR1 rank updates that
+test/test_lbfgs.jl:73-99 and test/test_lsr1.jl:43-68 compare against, not from any restatement of
+the limited-memory recursions. Each case cites the reference test lines it encodes.
+
+Run:  python tests/golden/make_kat.py   (rewrites the JSON next to this file)
+"""
+import json
+import os
+from fractions import Fraction as F
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def simple_vector(n):  # test/test_aux.jl:33
+    return [F(-((-1) ** i)) for i in range(1, n + 1)]
+
+
+def fl(v):
+    return [float(x) for x in v]
+
+
+def matvec(M, v):
+    return [sum(M[i][j] * v[j] for j in range(len(v))) for i in range(len(M))]
+
+
+def outer(a, b):
+    return [[x * y for y in b] for x in a]
+
+
+def dotf(a, b):
+    return sum(x * y for x, y in zip(a, b))
+
+
+def eye(n):
+    return [[F(int(i == j)) for j in range(n)] for i in range(n)]
+
+
+cases = []
+
+# ---------------------------------------------------------------- opDiagonal  (test_linop.jl:308-319)
+n = 10
+v = simple_vector(n)
+u = simple_vector(n)
+res0 = simple_vector(n)
+cases.append(dict(
+    name="opDiagonal_square", ref="test/test_linop.jl:308-319", kind="diag",
+    d=fl(v), u=fl(u), expect_apply=fl([a * b for a, b in zip(v, u)]),          # D*u == v.*u
+    alpha=2.0, beta=2.0, res0=fl(res0),
+    expect_mul5=fl([a * b * 2 + 2 * r for a, b, r in zip(v, u, res0)]),          # v.*u.*2 + 2 .* res
+    tol="bit-exact (small integers)"))
+
+# ---------------------------------------------------------------- rectangular opDiagonal (test_linop.jl:321-344)
+nmax, nmin = 10, 6
+vd = simple_vector(nmin)
+uu = simple_vector(nmin)
+ww = simple_vector(nmax)
+cases.append(dict(
+    name="opDiagonal_tall", ref="test/test_linop.jl:321-335", kind="diag_rect", nrow=nmax, ncol=nmin,
+    d=fl(vd), u=fl(uu), expect_apply=fl([a * b for a, b in zip(vd, uu)] + [F(0)] * (nmax - nmin)),
+    w=fl(ww), expect_tapply=fl([a * b for a, b in zip(vd, ww[:nmin])])))
+cases.append(dict(
+    name="opDiagonal_wide", ref="test/test_linop.jl:337-344", kind="diag_rect", nrow=nmin, ncol=nmax,
+    d=fl(vd), u=fl(ww), expect_apply=fl([a * b for a, b in zip(vd, ww[:nmin])]),
+    w=fl(uu), expect_tapply=fl([a * b for a, b in zip(vd, uu)] + [F(0)] * (nmax - nmin))))
+
+# ---------------------------------------------------------------- opHouseholder (test_linop.jl:511-518)
+hv = simple_vector(n)
+hu = simple_vector(n)
+c = 2 * dotf(hv, hu)
+cases.append(dict(
+    name="opHouseholder", ref="test/test_linop.jl:511-518", kind="householder",
+    h=fl(hv), u=fl(hu), expect_apply=fl([x - c * h for x, h in zip(hu, hv)])))   # u - 2*dot(v,u)*v = -19u
+
+# ---------------------------------------------------------------- restriction / extension (test_linop.jl:437-461)
+rv = simple_vector(10)
+for nm, idx in (("J", [1, 2, 4, 7]), ("r", list(range(3, 7))), ("s", list(range(1, 8, 2))), ("k", [4])):
+    w = [rv[i - 1] for i in idx]
+    vz = [F(0)] * 10
+    for i in idx:
+        vz[i - 1] = rv[i - 1]
+    spec = {"J": {"list": idx}, "r": {"range": [3, 6, 1]}, "s": {"range": [1, 7, 2]}, "k": {"scalar": 4}}[nm]
+    cases.append(dict(name=f"restriction_{nm}", ref="test/test_linop.jl:437-461", kind="restriction", n=10,
+                      idx=spec, v=fl(rv), expect_w=fl(w), expect_vz=fl(vz)))
+cases.append(dict(name="restriction_colon", ref="test/test_linop.jl:445 (idx = Colon())", kind="restriction", n=10,
+                  idx={"colon": True}, v=fl(rv), expect_w=fl(rv), expect_vz=fl(rv)))
+
+# ---------------------------------------------------------------- cat with opEye/opZeros (test_cat.jl:43-49)
+cases.append(dict(name="cat_eye_zeros", ref="test/test_cat.jl:44-46", kind="cat_eye_zeros",
+                  v=fl(simple_vector(5)), expect=fl(simple_vector(5))))
+cases.append(dict(name="cat_vcat_eye", ref="test/test_cat.jl:48-50", kind="cat_vcat_eye",
+                  v=fl(simple_vector(2)), expect=fl(simple_vector(2) + simple_vector(2))))
+
+# ---------------------------------------------------------------- diagonal quasi-Newton apply (test_diag.jl:75-106)
+for nm, d in (("DiagonalPSB_gradf", [2, -1, 2]), ("DiagonalAndrei_gradf", [2, -2, 2])):
+    x = [F(3), F(-5), F(7)]
+    cases.append(dict(name=nm, ref="test/test_diag.jl:75-101 (B.d) + src/DiagonalHessianApproximation.jl:37,112",
+                      kind="diag", d=[float(t) for t in d], u=fl(x), expect_apply=fl([F(a) * b for a, b in zip(d, x)]),
+                      alpha=2.0, beta=2.0, res0=fl(x), expect_mul5=fl([F(a) * b * 2 + 2 * b for a, b in zip(d, x)])))
+cases.append(dict(name="SpectralGradient_gradf", ref="test/test_diag.jl:91,103-105 (sigma = 2, 1-element d)",
+                  kind="diag_scalar", d=[2.0], u=fl([F(3), F(-5), F(7)]), expect_apply=[6.0, -10.0, 14.0]))
+
+# ---------------------------------------------------------------- L-BFGS (test_lbfgs.jl:7-56, 73-99)
+n, mem = 10, 5
+pairs = []
+for i in range(1, mem + 3):                       # test_lbfgs.jl:33-43
+    s = [F(i)] * n
+    y = [F(i)] + [F(1)] * (n - 1)
+    if dotf(s, y) > 0:
+        pairs.append((s, y))
+kept = pairs[-mem:]                               # circular buffer keeps the last `mem` pairs
+B = eye(n)
+H = eye(n)
+for s, y in kept:                                 # dense BFGS (test_lbfgs.jl:77-86) and its inverse
+    Bs = matvec(B, s)
+    sBs = dotf(s, Bs)
+    ys = dotf(y, s)
+    B = [[B[i][j] - Bs[i] * Bs[j] / sBs + y[i] * y[j] / ys for j in range(n)] for i in range(n)]
+    rho = 1 / ys
+    Hy = matvec(H, y)
+    yHy = dotf(y, Hy)
+    # H+ = H - rho (s Hy' + Hy s') + rho (1 + rho yHy) s s'
+    H = [[H[i][j] - rho * (s[i] * Hy[j] + Hy[i] * s[j]) + rho * (1 + rho * yHy) * s[i] * s[j]
+          for j in range(n)] for i in range(n)]
+vv = simple_vector(n)
+cases.append(dict(
+    name="LBFGS_mem5_7pushes", ref="test/test_lbfgs.jl:7-56 (pairs :33-43) vs dense BFGS :73-99", kind="lbfgs",
+    n=n, mem=mem, scaling=False,
+    pre_rejected=[dict(s=fl(vv), y=fl([-x for x in vv])), dict(s=fl(vv), y=[0.0] * n)],   # :24-31 insert stays 1
+    pairs=[dict(s=fl(s), y=fl(y)) for s, y in pairs],
+    expect_insert=len(pairs) % mem + 1,                                                  # :45-46
+    expect_ys_slots=fl([dotf(y, s) for s, y in (pairs[5], pairs[6], pairs[2], pairs[3], pairs[4])]),
+    v=fl(vv), expect_Bv=fl(matvec(B, vv)), expect_Hv=fl(matvec(H, vv)),
+    expect_diagB=fl([B[i][i] for i in range(n)]),                                          # :14,54
+    tol="1e-12 relative (reference bar: sqrt(eps))"))
+
+# full-memory BFGS with identical pairs (test_lbfgs.jl:88-96): s = y = simple_vector -> B stays I
+cases.append(dict(name="LBFGS_fullmem_identity_pairs", ref="test/test_lbfgs.jl:73-99", kind="lbfgs_identity",
+                  n=n, mem=n, scaling=False, pairs=[dict(s=fl(vv), y=fl(vv)) for _ in range(n)],
+                  v=fl([F(i) for i in range(1, n + 1)]), expect_Bv=fl([F(i) for i in range(1, n + 1)])))
+
+# ---------------------------------------------------------------- L-SR1 (test_lsr1.jl:6-28, 43-68)
+B = eye(n)
+acc = []
+for i in range(1, mem + 3):
+    s = [F(i)] * n
+    y = [F(i)] + [F(1)] * (n - 1)
+    acc.append((s, y))
+# replay with the limited-memory semantics: an update is rejected when (y-Bs)'s == 0 (well_defined,
+# src/lsr1.jl:131); accepted pairs are kept in a circular buffer of `mem`, B rebuilt from B0 = I.
+stored = []
+for s, y in acc:
+    Bk = eye(n)
+    for (ss, yy) in stored[-mem:]:
+        r = [a - b for a, b in zip(yy, matvec(Bk, ss))]
+        dn = dotf(r, ss)
+        Bk = [[Bk[i][j] + r[i] * r[j] / dn for j in range(n)] for i in range(n)]
+    r = [a - b for a, b in zip(y, matvec(Bk, s))]
+    if dotf(r, s) != 0:
+        stored.append((s, y))
+Bk = eye(n)
+for (ss, yy) in stored[-mem:]:
+    r = [a - b for a, b in zip(yy, matvec(Bk, ss))]
+    dn = dotf(r, ss)
+    Bk = [[Bk[i][j] + r[i] * r[j] / dn for j in range(n)] for i in range(n)]
+cases.append(dict(
+    name="LSR1_mem5_7pushes", ref="test/test_lsr1.jl:6-28 vs dense SR1 :43-68", kind="lsr1", n=n, mem=mem, scaling=False,
+    pairs=[dict(s=fl(s), y=fl(y)) for s, y in acc], expect_naccepted=len(stored),
+    expect_insert=len(stored) % mem + 1, v=fl(vv), expect_Bv=fl(matvec(Bk, vv)),
+    expect_diagB=fl([Bk[i][i] for i in range(n)]), tol="1e-12 relative"))
+
+out = dict(
+    about="Known-answer cases held by LinearOperators.jl v2.14.2's own tests for the mul! hot path; "
+          "generated by tests/golden/make_kat.py (exact rational arithmetic, no reference code executed).",
+    cases=cases)
+with open(os.path.join(HERE, "kat_reference_tests.json"), "w") as f:
+    json.dump(out, f, indent=1)
+print(f"wrote {len(cases)} cases")

@@ -1,0 +1,266 @@
+"""Pins the CPU oracle (oracle/) against the known-answer cases held by the reference's own tests
+(tests/golden/kat_reference_tests.json) and against independent dense NumPy constructions, the way
+the reference's test-suite pins the package. CPU only."""
+import numpy as np
+import pytest
+
+import oracle
+
+SV = lambda n: np.array([-(-1.0) ** i for i in range(1, n + 1)])
+
+
+def _by_kind(kat, kind):
+    return [c for c in kat if c["kind"] == kind]
+
+
+def test_kat_diag(kat):
+    for c in _by_kind(kat, "diag"):
+        d, u = np.array(c["d"]), np.array(c["u"])
+        res = np.full_like(u, np.nan)                      # beta == 0 must not read res
+        assert np.array_equal(oracle.diag_mul(res, d, u, 1.0, 0.0), np.array(c["expect_apply"])), c["name"]
+        res = np.array(c["res0"])
+        assert np.array_equal(oracle.diag_mul(res, d, u, c["alpha"], c["beta"]), np.array(c["expect_mul5"]))
+
+
+def test_kat_diag_scalar(kat):
+    for c in _by_kind(kat, "diag_scalar"):
+        d, u = np.array(c["d"]), np.array(c["u"])
+        res = np.empty_like(u)
+        oracle.diag_mul(res, d, u, 1.0, 0.0, flags=oracle.D_SCALAR)
+        assert np.array_equal(res, np.array(c["expect_apply"]))
+
+
+def test_kat_diag_rect(kat):
+    for c in _by_kind(kat, "diag_rect"):
+        d, u, w = np.array(c["d"]), np.array(c["u"]), np.array(c["w"])
+        nmin = min(c["nrow"], c["ncol"])
+        res = np.full(c["nrow"], np.nan)
+        oracle.diag_mul(res, d, u, 1.0, 0.0, n_min=nmin)
+        assert np.array_equal(res, np.array(c["expect_apply"])), c["name"]
+        res = np.full(c["ncol"], 7.0)                      # tail is zeroed even when beta != 0
+        oracle.diag_mul(res, d, w, 1.0, 0.0, n_min=nmin)
+        assert np.array_equal(res, np.array(c["expect_tapply"]))
+
+
+def test_rect_diag_tail_zero_with_beta():
+    res = np.full(5, 3.0)
+    oracle.diag_mul(res, np.ones(3), np.ones(3), 1.0, 2.0, n_min=3)
+    assert np.array_equal(res, [7.0, 7.0, 7.0, 0.0, 0.0])  # src/special-operators.jl:150
+
+
+def test_kat_householder(kat):
+    for c in _by_kind(kat, "householder"):
+        h, u = np.array(c["h"]), np.array(c["u"])
+        res = np.full_like(u, np.nan)
+        assert np.array_equal(oracle.householder_mul(res, h, u, 1.0, 0.0), np.array(c["expect_apply"]))
+
+
+def _idx_of(spec, n):
+    if "list" in spec:
+        return np.array(spec["list"], dtype=np.int64)
+    if "range" in spec:
+        a, b, s = spec["range"]
+        return np.arange(a, b + 1, s, dtype=np.int64)
+    if "scalar" in spec:
+        return np.array([spec["scalar"]], dtype=np.int64)
+    return np.arange(1, n + 1, dtype=np.int64)
+
+
+def test_kat_restriction(kat):
+    for c in _by_kind(kat, "restriction"):
+        n = c["n"]
+        idx = _idx_of(c["idx"], n)
+        v = np.array(c["v"])
+        w = oracle.restrict(np.empty(idx.size), v, idx)
+        assert np.array_equal(w, np.array(c["expect_w"])), c["name"]                # P*v == v[idx]
+        vz = oracle.extend(np.full(n, np.nan), w, idx)
+        assert np.array_equal(vz, np.array(c["expect_vz"]))                           # P'*w == vz
+        assert np.array_equal(oracle.restrict(np.empty(idx.size), vz, idx), w)        # (P*Z)*w == w
+
+
+def test_extension_duplicates_last_write_wins():
+    idx = np.array([2, 5, 2, 3], dtype=np.int64)
+    u = np.array([10.0, 20.0, 30.0, 40.0])
+    assert np.array_equal(oracle.extend(np.empty(6), u, idx), [0, 30.0, 40.0, 0, 20.0, 0])
+
+
+def test_kat_lbfgs(kat):
+    for c in _by_kind(kat, "lbfgs"):
+        n, mem = c["n"], c["mem"]
+        B = oracle.LBFGS(n, mem=mem, scaling=c["scaling"], inverse=False)
+        H = oracle.LBFGS(n, mem=mem, scaling=c["scaling"], inverse=True)
+        assert np.array_equal(B.dense(), np.eye(n)) and np.array_equal(H.dense(), np.eye(n))   # test_lbfgs.jl:18-19
+        for p in c["pre_rejected"]:
+            assert not B.push(np.array(p["s"]), np.array(p["y"])) and B.insert == 1            # :24-31
+            assert not H.push(np.array(p["s"]), np.array(p["y"])) and H.insert == 1
+        for p in c["pairs"]:
+            assert B.push(np.array(p["s"]), np.array(p["y"]))
+            assert H.push(np.array(p["s"]), np.array(p["y"]))
+        assert B.insert == H.insert == c["expect_insert"]
+        assert np.array_equal(B.ys, np.array(c["expect_ys_slots"]))
+        v = np.array(c["v"])
+        rel = lambda a, b: np.linalg.norm(a - b) / np.linalg.norm(b)
+        assert rel(B.mul(np.empty(n), v), np.array(c["expect_Bv"])) <= 1e-12
+        assert rel(H.mul(np.empty(n), v), np.array(c["expect_Hv"])) <= 1e-12
+        assert rel(B.diag(), np.array(c["expect_diagB"])) <= 1e-12
+        assert np.linalg.norm(H.dense() @ B.dense() - np.eye(n)) <= np.sqrt(np.finfo(float).eps)  # :56
+        assert np.linalg.norm(B.dense(), 2) <= B.opnorm_upper_bound                              # :70
+        B.reset(); H.reset()
+        assert B.scaling_factor == 1.0 and B.insert == 1
+        assert np.linalg.norm(B.mul(np.empty(n), v) - v) < 1e-8 and np.linalg.norm(H.mul(np.empty(n), v) - v) < 1e-8
+    for c in _by_kind(kat, "lbfgs_identity"):
+        n = c["n"]
+        LB = oracle.LBFGS(n, mem=c["mem"], scaling=False, inverse=False)
+        for p in c["pairs"]:
+            LB.push(np.array(p["s"]), np.array(p["y"]))
+            assert np.linalg.norm(LB.dense() - np.eye(n)) < 1e-8 * np.sqrt(n)
+        v = np.array(c["v"])
+        assert np.allclose(LB.mul(np.empty(n), v), np.array(c["expect_Bv"]), rtol=1e-12)
+
+
+def test_kat_lsr1(kat):
+    for c in _by_kind(kat, "lsr1"):
+        n = c["n"]
+        B = oracle.LSR1(n, mem=c["mem"], scaling=c["scaling"])
+        s = SV(n)
+        y = B.mul(np.empty(n), s)
+        assert not B.push(s, y) and B.insert == 1                                   # test_lsr1.jl:18-21
+        nacc = sum(B.push(np.array(p["s"]), np.array(p["y"])) for p in c["pairs"])
+        assert nacc == c["expect_naccepted"] and B.insert == c["expect_insert"]
+        v = np.array(c["v"])
+        rel = lambda a, b: np.linalg.norm(a - b) / np.linalg.norm(b)
+        assert rel(B.mul(np.empty(n), v), np.array(c["expect_Bv"])) <= 1e-12
+        assert rel(B.diag(), np.array(c["expect_diagB"])) <= 1e-12
+        assert np.linalg.norm(B.dense(), 2) <= B.opnorm_upper_bound
+
+
+# ------------------------------------------------------------------ dense-model pins (reference test style)
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_lbfgs_vs_dense_bfgs_random(dtype):
+    """test_lbfgs.jl:73-99 with random well-conditioned pairs and scaling (gamma != 1)."""
+    rng = np.random.default_rng(1)
+    n, mem = 12, 12
+    LB = oracle.LBFGS(n, mem=mem, scaling=False, inverse=False, dtype=dtype)
+    LH = oracle.LBFGS(n, mem=mem, scaling=False, inverse=True, dtype=dtype)
+    Bd = np.eye(n)
+    for _ in range(mem):
+        s = rng.uniform(-1, 1, n)
+        y = s * rng.uniform(0.5, 2.0, n)
+        Bs = Bd @ s
+        Bd = Bd - np.outer(Bs, Bs) / (s @ Bs) + np.outer(y, y) / (y @ s)
+        LB.push(s.astype(dtype), y.astype(dtype))
+        LH.push(s.astype(dtype), y.astype(dtype))
+    tol = 1e-10 if dtype == np.float64 else 2e-3
+    assert np.linalg.norm(LB.dense() - Bd) < tol * np.linalg.norm(Bd)
+    assert np.linalg.norm(LH.dense() @ Bd - np.eye(n)) < tol * 50
+
+
+def test_lbfgs_scaling_and_wrap_inverse_consistency():
+    rng = np.random.default_rng(2)
+    n, mem = 30, 4
+    B = oracle.LBFGS(n, mem=mem, scaling=True, inverse=False)
+    H = oracle.LBFGS(n, mem=mem, scaling=True, inverse=True)
+    for _ in range(mem + 3):
+        s = rng.uniform(-1, 1, n)
+        y = s * rng.uniform(0.5, 2.0, n) + 1e-2 * rng.standard_normal(n)
+        assert B.push(s, y) and H.push(s, y)
+    assert np.linalg.norm(H.dense() @ B.dense() - np.eye(n)) < 1e-9
+    assert np.allclose(B.diag(), np.diag(B.dense()), rtol=1e-12)
+
+
+def test_solve_shifted_roundtrip_and_ldiv():
+    """test_solve_shifted_system.jl:5-61."""
+    rng = np.random.default_rng(3)
+    n, M = 100, 5
+    for scaling in (False, True):
+        B = oracle.LBFGS(n, mem=M, scaling=scaling, inverse=False)
+        H = oracle.LBFGS(n, mem=M, scaling=scaling, inverse=True)
+        for _ in range(10):
+            s, y = rng.random(n), rng.random(n)
+            B.push(s, y); H.push(s, y)
+        x = rng.standard_normal(n)
+        for sigma in (0.1, 0.0, 3.0):
+            b = B.mul(np.empty(n), x) + sigma * x
+            xs = B.solve_shifted(np.zeros(n), b, sigma)
+            assert np.allclose(xs, x, atol=1e-6, rtol=1e-6)
+        b = B.mul(np.empty(n), x)
+        assert np.allclose(B.solve_shifted(np.zeros(n), b, 0.0), H.mul(np.empty(n), b), atol=1e-6, rtol=1e-6)
+        with pytest.raises(ValueError):
+            B.solve_shifted(np.zeros(n), b, -0.1)
+
+
+def test_damped_lbfgs_properties():
+    """test_lbfgs.jl:104-159: damped pairs keep B positive definite and H*B ≈ I."""
+    n, mem = 10, 10
+    B = oracle.LBFGS(n, mem=mem, damped=True, scaling=False, inverse=False, sigma2=0.8, sigma3=np.inf)
+    H = oracle.LBFGS(n, mem=mem, damped=True, scaling=False, inverse=True, sigma2=0.8, sigma3=np.inf)
+    rng = np.random.default_rng(4)
+    for i in range(1, mem + 3):
+        s = SV(n) * i
+        y = rng.uniform(-1, 1, n)
+        if s @ y <= 0:
+            y = -y
+        B.push(s.copy(), y.copy())
+        g = -(B.dense() @ s)          # so that Bs = -alpha*g with alpha = 1 matches the forward Bs
+        H.push(s.copy(), y.copy(), alpha=1.0, g=g)
+    w = np.linalg.eigvalsh(B.dense())
+    assert w.min() > 0
+    assert np.linalg.norm(H.dense() @ B.dense() - np.eye(n)) < 1e-6
+    with pytest.raises(RuntimeError):
+        oracle.LBFGS(n).push(np.ones(n), np.ones(n), Bs=np.ones(n))   # test_lbfgs.jl:220-240
+
+
+def test_hermitian_vs_dense():
+    """test_linop.jl:360-380 (real symmetric)."""
+    rng = np.random.default_rng(5)
+    n = 17
+    A = rng.standard_normal((n, n))
+    d = rng.standard_normal(n)
+    L = np.tril(A, -1)
+    Cm = L + L.T + np.diag(d)
+    v = SV(n)
+    res = oracle.hermitian_mul(np.full(n, np.nan), d, A, v, 1.0, 0.0)
+    assert np.linalg.norm(res - Cm @ v) <= 1e-12 * np.linalg.norm(v) * n
+    r0 = rng.standard_normal(n)
+    res = oracle.hermitian_mul(r0.copy(), d, A, v, 3.0, -4.0)
+    assert np.allclose(res, 3.0 * (Cm @ v) - 4.0 * r0, rtol=1e-12)
+
+
+def test_kron_vs_numpy():
+    """test_kron.jl:2-39."""
+    rng = np.random.default_rng(6)
+    A = rng.standard_normal((3, 5))
+    B = rng.standard_normal((4, 2))
+    K = np.kron(A, B)
+    x = rng.standard_normal(K.shape[1])
+    res = oracle.kron_mul(np.full(K.shape[0], np.nan), A, B, x, 1.0, 0.0)
+    assert np.linalg.norm(res - K @ x, 1) <= 1e-12 * np.linalg.norm(K, 1)
+    xt = rng.standard_normal(K.shape[0])
+    r0 = rng.standard_normal(K.shape[1])
+    res = oracle.kron_mul(r0.copy(), A, B, xt, 2.0, 3.0, trans=True)
+    assert np.allclose(res, 2.0 * (K.T @ xt) + 3.0 * r0, rtol=1e-12)
+
+
+def test_mixed_precision_f32_scalars_f64():
+    """mul!(res32, op32, v32, 2.0, 3.0) is evaluated in Float64 per element."""
+    rng = np.random.default_rng(7)
+    n = 1000
+    d, v, r = (rng.standard_normal(n).astype(np.float32) for _ in range(3))
+    a, b = 2.0 / 3.0, 1.0 / 7.0
+    got = oracle.diag_mul(r.copy(), d, v, a, b, flags=oracle.SCALARS_F64)
+    want = ((a * d.astype(np.float64)) * v.astype(np.float64) + b * r.astype(np.float64)).astype(np.float32)
+    assert np.array_equal(got, want)
+    got32 = oracle.diag_mul(r.copy(), d, v, a, b)
+    want32 = (np.float32(a) * d) * v + np.float32(b) * r
+    assert np.array_equal(got32, want32)
+    assert not np.array_equal(got, got32)
+
+
+def test_eye_zeros_ones_quirks():
+    res = np.full(5, 2.0)
+    oracle.eye_mul(res, np.ones(3), 1.0, 3.0, n_min=3)              # tail gets beta itself (special-operators.jl:42)
+    assert np.array_equal(res, [7.0, 7.0, 7.0, 3.0, 3.0])
+    res = np.full(4, np.nan)
+    assert np.array_equal(oracle.zeros_mul(res, 0.0), np.zeros(4))
+    assert np.array_equal(oracle.zeros_mul(np.full(4, 2.0), 1.5), np.full(4, 3.0))
+    assert np.array_equal(oracle.ones_mul(np.full(3, 1.0), np.array([1.0, 2.0, 3.0]), 2.0, 1.0), np.full(3, 13.0))

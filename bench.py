@@ -1,0 +1,264 @@
+#!/usr/bin/env python
+"""bench.py — `mul!` hot-path throughput on MI355X (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W
+
+A "step" is ONE 5-arg `mul!(res, H, v, α, β)` of `opHouseholder(h)` at n = 10^8 fp64 per GPU
+(BASELINE.json configs[1]) with all operands resident in HBM. For N > 1 the vectors are
+row-sharded (n per GPU: weak scaling) and h'v is all-reduced over RCCL through the library's
+all-reduce hook; value = N * 40 B * n / max-over-ranks time.
+
+One JSON line is printed by rank 0 with, besides the driver contract fields:
+  roofline      dominant kernel (the Householder update pass, 24 B/elt) timed with HIP events
+                on the launch stream, against the 8 TB/s HBM3E peak
+  cpu_baseline  the oracle (C restatement of the reference `mulHouseholder!`) on the host cores,
+                1 thread, on a bounded sample of the same workload (rank 0, N == 1 only)
+  extras        opDiagonal GB/s and (when built) InverseLBFGS / LBFGS apply/s — the other
+                figures the metric string names
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md): 8.0 TB/s
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--n", type=int, default=100_000_000, help="vector length per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=50_000_000)
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    import __graft_entry__ as g
+    lo = g.load_package()
+    from linearoperators_jl_amd import _lib
+    from linearoperators_jl_amd.device import Timer, dtype_code, get_ctx, ptr
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    distributed = world > 1
+    if args.gpus != world and distributed:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if distributed:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    ctx = get_ctx(dev)
+    if distributed:
+        lo.sharded.install_allreduce(ctx)     # RCCL all-reduce of the partial dots over xGMI
+
+    n = args.n
+    gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+    h = torch.rand(n, dtype=torch.float64, device=dev, generator=gen) - 0.5
+    nrm2 = (h * h).sum()
+    if distributed:
+        dist.all_reduce(nrm2)
+    h /= nrm2.sqrt()                                    # ||h||_2 = 1 over the whole (sharded) vector
+    v = torch.rand(n, dtype=torch.float64, device=dev, generator=gen) * 2 - 1
+    res = torch.empty(n, dtype=torch.float64, device=dev)
+    H = lo.opHouseholder(h)
+    alpha, beta = 1.0, 0.0
+
+    def barrier():
+        torch.cuda.synchronize()
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        lo.mul(res, H, v, alpha, beta)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        lo.mul(res, H, v, alpha, beta)
+    barrier()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if distributed:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    ms_per_step = dt / args.steps * 1e3
+    bytes_per_step = 40.0 * n * world                   # 16 B/elt dot pass + 24 B/elt update pass
+    value = bytes_per_step / (dt / args.steps) / 1e9
+
+    # ---- per-kernel timing with HIP events on the launch stream (rank-local)
+    tm = Timer(ctx)
+    f64 = dtype_code(torch.float64)
+    K = max(10, min(args.steps, 50))
+    dot_dev = torch.zeros(1, dtype=torch.float64, device=dev)
+    saved_hook = None
+    if distributed:                                      # time the kernels, not the collective
+        ctx.set_allreduce(None)
+    tm.start()
+    for _ in range(K):
+        _lib.call("mxlo_dot", ctx.handle, f64, ptr(h), ptr(v), n, ptr(dot_dev))
+    tm.stop()
+    ms_dot = tm.elapsed_ms() / K
+    tm.start()
+    for _ in range(K):
+        _lib.call("mxlo_householder_apply", ctx.handle, f64, ptr(res), ptr(h), ptr(v), n, alpha, beta, 0, ptr(dot_dev))
+    tm.stop()
+    ms_upd = tm.elapsed_ms() / K
+    D = lo.opDiagonal(h)
+    for _ in range(3):
+        lo.mul(res, D, v, alpha, beta)
+    tm.start()
+    for _ in range(K):
+        lo.mul(res, D, v, alpha, beta)
+    tm.stop()
+    ms_diag = tm.elapsed_ms() / K
+    if distributed:
+        lo.sharded.install_allreduce(ctx)
+
+    upd_gbs = 24.0 * n / (ms_upd * 1e-3) / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic_householder.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get("householder_update_bytes_per_launch")
+        except Exception:
+            traffic = None
+    roofline = {"bound": "hbm", "kernel": "map_kernel<HouseholderOp> (update pass res = α(v - c·h), 24 B/elt)",
+                "achieved": round(upd_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(upd_gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "avg_launch_ms": round(ms_upd, 4), "algorithmic_bytes_per_launch": 24.0 * n}
+    extras = {
+        "householder_dot_pass": {"ms": round(ms_dot, 4), "GB/s": round(16.0 * n / (ms_dot * 1e-3) / 1e9, 1),
+                                 "frac_hbm_peak": round(16.0 * n / (ms_dot * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+        "householder_mul_frac_hbm_peak_per_gpu": round(value / world / HBM_PEAK_GBS, 4),
+        "opDiagonal_mul": {"ms": round(ms_diag, 4), "GB/s": round(24.0 * n / (ms_diag * 1e-3) / 1e9, 1),
+                           "frac_hbm_peak": round(24.0 * n / (ms_diag * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+    }
+    del D
+
+    # ---- quasi-Newton apply/s (the second figure of the metric string)
+    if not args.no_extras and hasattr(lo, "InverseLBFGSOperator"):
+        try:
+            extras.update(bench_lbfgs(lo, torch, dev, ctx, rank, world, distributed, dist, barrier))
+        except Exception as e:  # never lose the headline line
+            extras["lbfgs_error"] = repr(e)
+
+    cpu_baseline = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu_baseline = cpu_leg(args.cpu_sample)
+
+    if rank == 0:
+        out = {
+            "metric": "mul! GB/s (frac HBM peak) at n=10^8 fp64; L-BFGS apply/s, 1/2/4/8 GPU",
+            "value": round(value, 1), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "opHouseholder(h) 5-arg mul!(res,H,v,1,0), n=%d fp64 per GPU (configs[1])" % n,
+                       "n_per_gpu": n, "algorithmic_bytes_per_elt": 40, "sharding": "row ranges, 1-double all-reduce" if distributed else "none"},
+            "frac_hbm_peak": round(value / world / HBM_PEAK_GBS, 4),
+            "roofline": roofline, "cpu_baseline": cpu_baseline, "extras": extras,
+        }
+        print(json.dumps(out), flush=True)
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def bench_lbfgs(lo, torch, dev, ctx, rank, world, distributed, dist, barrier):
+    """InverseLBFGSOperator m=10, n=5e7 (configs[2]) and LBFGSOperator m=20 (configs[4], row-sharded:
+    n_local = 5e7 per GPU) applies per second."""
+    out = {}
+    n = 50_000_000
+    gen = torch.Generator(device=dev).manual_seed(99 + rank)
+
+    def fill(op, npairs):
+        for _ in range(npairs):
+            s = torch.rand(n, dtype=torch.float64, device=dev, generator=gen) * 2 - 1
+            dvec = torch.rand(n, dtype=torch.float64, device=dev, generator=gen) * 1.5 + 0.5
+            y = dvec * s + 1e-2 * (torch.rand(n, dtype=torch.float64, device=dev, generator=gen) - 0.5)
+            del dvec
+            lo.push(op, s, y)
+            del s, y
+
+    def time_apply(op, reps):
+        x = torch.rand(n, dtype=torch.float64, device=dev, generator=gen) * 2 - 1
+        res = torch.empty_like(x)
+        for _ in range(3):
+            lo.mul(res, op, x, -1.0, 0.0)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            lo.mul(res, op, x, -1.0, 0.0)
+        barrier()
+        dt = time.perf_counter() - t0
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        if distributed:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item()) / reps
+
+    m = 10
+    Hinv = lo.InverseLBFGSOperator(torch.float64, n, mem=m, scaling=True, device=dev)
+    fill(Hinv, m + 3)
+    sec = time_apply(Hinv, 20)
+    bytes_ = (4 * m + 3) * 8.0 * n
+    out["InverseLBFGS_m10_n5e7"] = {"apply_per_s": round(1.0 / sec, 2), "ms": round(sec * 1e3, 3),
+                                    "GB/s_per_gpu(344B/elt)": round(bytes_ / sec / 1e9, 1),
+                                    "frac_hbm_peak": round(bytes_ / sec / 1e9 / HBM_PEAK_GBS, 4),
+                                    "n_global": n * world}
+    del Hinv
+    torch.cuda.empty_cache()
+    m = 20
+    Bf = lo.LBFGSOperator(torch.float64, n, mem=m, scaling=True, device=dev)
+    fill(Bf, m + 3)
+    sec = time_apply(Bf, 10)
+    bytes_ = (4 * m + 3) * 8.0 * n
+    out["LBFGS_fwd_m20_nlocal5e7"] = {"apply_per_s": round(1.0 / sec, 2), "ms": round(sec * 1e3, 3),
+                                      "GB/s_per_gpu(664B/elt)": round(bytes_ / sec / 1e9, 1),
+                                      "frac_hbm_peak": round(bytes_ / sec / 1e9 / HBM_PEAK_GBS, 4),
+                                      "n_global": n * world}
+    del Bf
+    torch.cuda.empty_cache()
+    return out
+
+
+def cpu_leg(n_sample: int):
+    """Oracle (port of the reference `mulHouseholder!`, src/linalg.jl:77-83) on the host, 1 thread."""
+    import numpy as np
+    import oracle
+    rng = np.random.default_rng(0)
+    h = rng.random(n_sample) - 0.5
+    h /= np.linalg.norm(h)
+    v = rng.random(n_sample) * 2 - 1
+    res = np.empty(n_sample)
+    oracle.householder_mul(res, h, v, 1.0, 0.0)          # warm-up / page-in
+    reps, t0 = 0, time.perf_counter()
+    while True:
+        oracle.householder_mul(res, h, v, 1.0, 0.0)
+        reps += 1
+        if time.perf_counter() - t0 > 8.0 or reps >= 20:
+            break
+    sec = (time.perf_counter() - t0) / reps
+    return {"value": round(40.0 * n_sample / sec / 1e9, 2), "unit": "GB/s", "cores": 1, "kind": "port",
+            "sample": f"oracle.householder_mul (C restatement of mulHouseholder!, gcc -O2, 1 thread) on n={n_sample} "
+                      f"fp64, {reps} reps, {sec * 1e3:.1f} ms/apply, counted at the same 40 B/elt; "
+                      f"host has {os.cpu_count()} logical CPUs"}
+
+
+if __name__ == "__main__":
+    main()

@@ -161,6 +161,16 @@ int32_t mxlo_householder_mul(mxlo_ctx *ctx, int32_t dtype, void *res, const void
                              const void *v, int64_t n, double alpha, double beta,
                              int32_t flags);
 
+/* The two phases of mxlo_householder_mul, exposed separately (profiling, and callers that
+ * already hold h'v): mxlo_dot is LinearAlgebra.dot(a, b) (src/linalg.jl:79) into ONE device
+ * double (fixed-order tree; runs the all-reduce hook); mxlo_householder_apply is the update
+ * pass reading that device scalar. */
+int32_t mxlo_dot(mxlo_ctx *ctx, int32_t dtype, const void *a, const void *b, int64_t n,
+                 double *out_dev);
+int32_t mxlo_householder_apply(mxlo_ctx *ctx, int32_t dtype, void *res, const void *h,
+                               const void *v, int64_t n, double alpha, double beta,
+                               int32_t flags, const double *dot_dev);
+
 /* mulHermitian! — src/linalg.jl:97-103, operator built by opHermitian(d, A)
  * (:109-116) which keeps L = tril(A,-1).
  *   res = alpha*((d.*v + L*v) + L'*v) (+ beta*res)

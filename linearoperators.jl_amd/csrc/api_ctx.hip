@@ -91,8 +91,11 @@ MXLO_API int32_t mxlo_ctx_info(mxlo_ctx *ctx, int64_t info[4]) {
 MXLO_API int32_t mxlo_ctx_tune(mxlo_ctx *ctx, const char *key, int64_t value) {
   MXLO_REQUIRE(ctx && key, MXLO_EINVAL, "ctx/key is NULL");
   if (!strcmp(key, "blocks_per_cu")) {
-    MXLO_REQUIRE(value >= 1 && value <= 64, MXLO_EINVAL, "blocks_per_cu out of range");
+    MXLO_REQUIRE(value >= 0 && value <= 64, MXLO_EINVAL, "blocks_per_cu out of range");
     ctx->tune.blocks_per_cu = (int)value;
+  } else if (!strcmp(key, "nt_min_bytes")) {
+    MXLO_REQUIRE(value >= 0, MXLO_EINVAL, "nt_min_bytes out of range");
+    ctx->tune.nt_min_bytes = value;
   } else if (!strcmp(key, "red_blocks_per_cu")) {
     MXLO_REQUIRE(value >= 1 && value * ctx->num_cu <= kMaxRedBlocks, MXLO_EINVAL,
                  "red_blocks_per_cu out of range");

@@ -1,0 +1,265 @@
+// blockdiag.hip — BlockDiagonalOperator prod!/tprod!/ctprod! (src/special-operators.jl:249-294)
+// as ONE launch: a device-resident descriptor table (one entry per block) plus a tile table
+// (one workgroup per tile) built once at construction. The reference issues one inner mul! per
+// block (1024 launches at BASELINE config 4); here the launch count is 1 regardless of the
+// number of blocks.
+//
+// Tiles: elementwise blocks (opDiagonal / opEye / opZeros) are cut into 2048-row tiles; a dense
+// block contributes 256-output-row tiles in N mode (thread per row, coalesced down the columns)
+// and 4-output tiles in T mode (one wave per output, coalesced down the column).
+// Blocks start at arbitrary row offsets (e.g. 97,657-row blocks), so each tile aligns its
+// stores to 16 bytes by peeling and loads an operand with one 16-byte or two element accesses
+// depending on that operand's own phase.
+#include <vector>
+
+#include "common.h"
+#include "stream_kernels.h"
+
+using namespace mxlo;
+
+namespace {
+
+constexpr int kTileE = 2048;   // rows per elementwise tile
+constexpr int kTileDN = 256;   // output rows per dense N-mode tile
+constexpr int kTileDT = 4;     // outputs per dense T-mode tile (one per wave)
+
+struct DevBlock {
+  int32_t kind, pad;
+  int64_t row_off, col_off, m, n;
+  const void *data;
+  int64_t ld;
+};
+
+struct Tile {
+  int32_t blk, pad;
+  int64_t start;  // first output row of this tile inside its block
+};
+
+template <typename T, int VEC>
+__device__ __forceinline__ void load_vec(const T *p, bool aligned, T (&out)[VEC]) {
+  using V = typename VecOf<T, VEC>::type;
+  if (aligned) {
+    const V v = *reinterpret_cast<const V *>(p);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) out[e] = v[e];
+  } else {
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) out[e] = p[e];
+  }
+}
+
+// kind-specific scalar op: returns the new res element
+template <typename T, typename CT, bool BETA0>
+__device__ __forceinline__ T ew_op(int kind, CT a, CT b, T d, T v, T r) {
+  CT t;
+  if (kind == MXLO_BLK_DIAG) t = (a * (CT)d) * (CT)v;          // special-operators.jl:127-129
+  else if (kind == MXLO_BLK_EYE) t = a * (CT)v;                 // :38-41
+  else {                                                        // zeros: res .= 0 | res .*= β (:104-106)
+    if constexpr (BETA0) return (T)0;
+    else return (T)((CT)r * b);
+  }
+  if constexpr (!BETA0) t = t + (b * (CT)r);
+  return (T)t;
+}
+
+template <typename T, typename CT, bool BETA0, bool TRANS>
+__global__ void __launch_bounds__(kBlock)
+blockdiag_kernel(T *__restrict__ res, const T *__restrict__ x, const DevBlock *__restrict__ blocks,
+                 const Tile *__restrict__ tiles, CT alpha, CT beta) {
+  constexpr int VEC = Vec16<T>::N;
+  const Tile tl = tiles[blockIdx.x];
+  const DevBlock b = blocks[tl.blk];
+  const int tid = threadIdx.x;
+  // in T mode the roles of (row_off, m) and (col_off, n) swap
+  const int64_t out_off = TRANS ? b.col_off : b.row_off;
+  const int64_t in_off = TRANS ? b.row_off : b.col_off;
+  const int64_t mo = TRANS ? b.n : b.m;   // outputs of this block
+  const int64_t ni = TRANS ? b.m : b.n;   // inputs of this block
+  T *rp = res + out_off;
+  const T *xp = x + in_off;
+  if (b.kind != MXLO_BLK_DENSE) {
+    // elementwise tile [tl.start, tl.start + cnt). Rectangular eye/zeros: outputs beyond
+    // min(m,n) of an eye block follow mulOpEye!'s tail rule (0 | β).
+    int64_t cnt = mo - tl.start;
+    if (cnt > kTileE) cnt = kTileE;
+    const int64_t nmin = b.kind == MXLO_BLK_ZEROS ? mo : (mo < ni ? mo : ni);
+    const T *dp = (const T *)b.data;
+    T *r0 = rp + tl.start;
+    const T *x0 = xp + tl.start;
+    const T *d0 = dp ? dp + tl.start : nullptr;
+    // peel so stores are 16-byte aligned
+    int64_t head = (int64_t)(((16 - ((uintptr_t)r0 & 15u)) & 15u) / sizeof(T));
+    if (head > cnt) head = cnt;
+    const bool fast = (tl.start + cnt <= nmin);   // whole tile inside the diagonal part
+    if (fast) {
+      const int64_t nv = (cnt - head) / VEC;
+      const bool xa = (((uintptr_t)(x0 + head)) & 15u) == 0;
+      const bool da = d0 ? ((((uintptr_t)(d0 + head)) & 15u) == 0) : true;
+      using V = typename VecOf<T, VEC>::type;
+      for (int64_t i = tid; i < nv; i += kBlock) {
+        const int64_t o = head + i * VEC;
+        T dv[VEC], xv[VEC], rv[VEC];
+        if (b.kind == MXLO_BLK_DIAG) load_vec<T, VEC>(d0 + o, da, dv);
+        if (b.kind != MXLO_BLK_ZEROS) load_vec<T, VEC>(x0 + o, xa, xv);
+        if constexpr (!BETA0) load_vec<T, VEC>(r0 + o, true, rv);
+        V out;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e)
+          out[e] = ew_op<T, CT, BETA0>(b.kind, alpha, beta, b.kind == MXLO_BLK_DIAG ? dv[e] : T(0),
+                                       b.kind != MXLO_BLK_ZEROS ? xv[e] : T(0), BETA0 ? T(0) : rv[e]);
+        *reinterpret_cast<V *>(r0 + o) = out;
+      }
+      const int64_t tail0 = head + nv * VEC;
+      const int64_t nsc = head + (cnt - tail0);
+      if (tid < nsc) {
+        const int64_t o = tid < head ? tid : tail0 + (tid - head);
+        r0[o] = ew_op<T, CT, BETA0>(b.kind, alpha, beta, b.kind == MXLO_BLK_DIAG ? d0[o] : T(0),
+                                    b.kind != MXLO_BLK_ZEROS ? x0[o] : T(0), BETA0 ? T(0) : r0[o]);
+      }
+    } else {
+      for (int64_t o = tid; o < cnt; o += kBlock) {
+        const int64_t g = tl.start + o;
+        if (g < nmin) {
+          r0[o] = ew_op<T, CT, BETA0>(b.kind, alpha, beta, b.kind == MXLO_BLK_DIAG ? d0[o] : T(0),
+                                      b.kind != MXLO_BLK_ZEROS ? x0[o] : T(0), BETA0 ? T(0) : r0[o]);
+        } else {  // rectangular eye tail: 0 when β == 0 else β itself (special-operators.jl:39,42)
+          r0[o] = BETA0 ? (T)0 : (T)beta;
+        }
+      }
+    }
+    return;
+  }
+  // ---- dense block, column-major m x n with leading dimension ld
+  const T *M = (const T *)b.data;
+  if constexpr (!TRANS) {
+    const int64_t i = tl.start + tid;
+    if (i < b.m) {
+      double acc = 0.0;
+      for (int64_t j = 0; j < b.n; ++j) acc = fma((double)M[i + j * b.ld], (double)xp[j], acc);
+      CT t = alpha * (CT)(T)acc;
+      if constexpr (!BETA0) t = t + (beta * (CT)rp[i]);
+      rp[i] = (T)t;
+    }
+  } else {
+    const int lane = tid & 63;
+    const int64_t j = tl.start + (tid >> 6);
+    if (j < b.n) {
+      const T *colp = M + j * b.ld;
+      double acc = 0.0;
+      for (int64_t i = lane; i < b.m; i += 64) acc = fma((double)colp[i], (double)xp[i], acc);
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+      if (lane == 0) {
+        CT t = alpha * (CT)(T)acc;
+        if constexpr (!BETA0) t = t + (beta * (CT)rp[j]);
+        rp[j] = (T)t;
+      }
+    }
+  }
+}
+
+}  // namespace
+
+struct mxlo_blockdiag {
+  mxlo_ctx *ctx = nullptr;
+  int dtype = 0;
+  int64_t nblocks = 0, nrow = 0, ncol = 0;
+  DevBlock *d_blocks = nullptr;
+  Tile *d_tiles_n = nullptr, *d_tiles_t = nullptr;
+  int64_t ntiles_n = 0, ntiles_t = 0;
+};
+
+MXLO_API int32_t mxlo_blockdiag_create(mxlo_ctx *ctx, int32_t dtype, const mxlo_block_desc *blocks,
+                                       int64_t nblocks, mxlo_blockdiag **out) {
+  MXLO_REQUIRE(ctx && out && (nblocks == 0 || blocks), MXLO_EINVAL, "mxlo_blockdiag_create: NULL argument");
+  MXLO_REQUIRE(dtype == MXLO_F64 || dtype == MXLO_F32, MXLO_EINVAL, "bad dtype");
+  MXLO_REQUIRE(nblocks >= 0 && nblocks < (1LL << 31), MXLO_ESHAPE, "bad block count");
+  std::vector<DevBlock> hb((size_t)nblocks);
+  std::vector<Tile> tn, tt;
+  int64_t nrow = 0, ncol = 0;
+  for (int64_t k = 0; k < nblocks; ++k) {
+    const mxlo_block_desc &b = blocks[k];
+    MXLO_REQUIRE(b.kind >= MXLO_BLK_DIAG && b.kind <= MXLO_BLK_ZEROS, MXLO_EINVAL, "block %lld: bad kind", (long long)k);
+    MXLO_REQUIRE(b.m >= 0 && b.n >= 0, MXLO_ESHAPE, "block %lld: negative size", (long long)k);
+    if (b.kind == MXLO_BLK_DIAG) MXLO_REQUIRE(b.m == b.n && (b.m == 0 || b.data), MXLO_ESHAPE, "block %lld: diagonal blocks are square", (long long)k);
+    if (b.kind == MXLO_BLK_DENSE) MXLO_REQUIRE((b.m == 0 || b.n == 0 || b.data) && b.ld >= (b.m > 1 ? b.m : 1), MXLO_ESHAPE, "block %lld: bad dense block", (long long)k);
+    MXLO_REQUIRE(b.row_off == nrow && b.col_off == ncol, MXLO_ESHAPE, "block %lld: offsets must be cumulative", (long long)k);
+    hb[k] = DevBlock{b.kind, 0, b.row_off, b.col_off, b.m, b.n, b.data, b.ld};
+    nrow += b.m;
+    ncol += b.n;
+    const int64_t step_n = b.kind == MXLO_BLK_DENSE ? kTileDN : kTileE;
+    const int64_t step_t = b.kind == MXLO_BLK_DENSE ? kTileDT : kTileE;
+    for (int64_t s = 0; s < b.m; s += step_n) tn.push_back(Tile{(int32_t)k, 0, s});
+    for (int64_t s = 0; s < b.n; s += step_t) tt.push_back(Tile{(int32_t)k, 0, s});
+  }
+  mxlo_blockdiag *bd = new mxlo_blockdiag();
+  bd->ctx = ctx;
+  bd->dtype = dtype;
+  bd->nblocks = nblocks;
+  bd->nrow = nrow;
+  bd->ncol = ncol;
+  bd->ntiles_n = (int64_t)tn.size();
+  bd->ntiles_t = (int64_t)tt.size();
+  hipError_t e = hipSuccess;
+  auto up = [&](void **dst, const void *src, size_t bytes) {
+    if (e != hipSuccess || bytes == 0) return;
+    e = hipMalloc(dst, bytes);
+    if (e == hipSuccess) e = hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);
+  };
+  up((void **)&bd->d_blocks, hb.data(), hb.size() * sizeof(DevBlock));
+  up((void **)&bd->d_tiles_n, tn.data(), tn.size() * sizeof(Tile));
+  up((void **)&bd->d_tiles_t, tt.data(), tt.size() * sizeof(Tile));
+  if (e != hipSuccess) {
+    set_error("mxlo_blockdiag_create: %s", hipGetErrorString(e));
+    mxlo_blockdiag_destroy(bd);
+    return MXLO_ENOMEM;
+  }
+  *out = bd;
+  return MXLO_OK;
+}
+
+MXLO_API int32_t mxlo_blockdiag_destroy(mxlo_blockdiag *bd) {
+  if (!bd) return MXLO_OK;
+  (void)hipStreamSynchronize(bd->ctx->stream);
+  if (bd->d_blocks) (void)hipFree(bd->d_blocks);
+  if (bd->d_tiles_n) (void)hipFree(bd->d_tiles_n);
+  if (bd->d_tiles_t) (void)hipFree(bd->d_tiles_t);
+  delete bd;
+  return MXLO_OK;
+}
+
+template <typename T>
+static int32_t blockdiag_mul_t(mxlo_blockdiag *bd, T *res, const T *v, double alpha, double beta,
+                               int32_t op_mode, int32_t flags) {
+  mxlo_ctx *ctx = bd->ctx;
+  const bool trans = op_mode != MXLO_OP_N;
+  const int64_t nt = trans ? bd->ntiles_t : bd->ntiles_n;
+  const Tile *tiles = trans ? bd->d_tiles_t : bd->d_tiles_n;
+  if (nt == 0) return MXLO_OK;
+  MXLO_REQUIRE(nt < (1LL << 31), MXLO_ESHAPE, "too many tiles");
+  return dispatch_ct<T>(beta, flags, [&]<typename CT, bool B0>() -> int32_t {
+    if (trans)
+      hipLaunchKernelGGL((blockdiag_kernel<T, CT, B0, true>), dim3((unsigned)nt), dim3(kBlock), 0,
+                         ctx->stream, res, v, bd->d_blocks, tiles, (CT)alpha, (CT)beta);
+    else
+      hipLaunchKernelGGL((blockdiag_kernel<T, CT, B0, false>), dim3((unsigned)nt), dim3(kBlock), 0,
+                         ctx->stream, res, v, bd->d_blocks, tiles, (CT)alpha, (CT)beta);
+    MXLO_LAUNCH_CHECK();
+    return MXLO_OK;
+  });
+}
+
+MXLO_API int32_t mxlo_blockdiag_mul(mxlo_blockdiag *bd, void *res, const void *v, double alpha,
+                                    double beta, int32_t op_mode, int32_t flags) {
+  MXLO_REQUIRE(bd, MXLO_EINVAL, "mxlo_blockdiag_mul: handle is NULL");
+  MXLO_REQUIRE(op_mode >= MXLO_OP_N && op_mode <= MXLO_OP_C, MXLO_EINVAL, "bad op_mode");
+  const int64_t nres = op_mode == MXLO_OP_N ? bd->nrow : bd->ncol;
+  if (nres == 0) return MXLO_OK;
+  MXLO_REQUIRE(res && v, MXLO_EINVAL, "mxlo_blockdiag_mul: NULL operand");
+  if (bd->dtype == MXLO_F32 && !(flags & MXLO_SCALARS_F64)) {
+    alpha = (double)(float)alpha;
+    beta = (double)(float)beta;
+  }
+  if (bd->dtype == MXLO_F64) return blockdiag_mul_t<double>(bd, (double *)res, (const double *)v, alpha, beta, op_mode, flags);
+  return blockdiag_mul_t<float>(bd, (float *)res, (const float *)v, alpha, beta, op_mode, flags);
+}

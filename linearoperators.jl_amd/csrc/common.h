@@ -58,7 +58,8 @@ void set_error(const char *fmt, ...);
   } while (0)
 
 struct Tune {
-  int blocks_per_cu = 8;   // streaming kernels: persistent grid = CUs * blocks_per_cu
+  int blocks_per_cu = 0;   // streaming kernels: 0 = one chunk per workgroup; k = persistent grid CUs*k
+  int64_t nt_min_bytes = 32ll << 20;  // streamed footprint from which nontemporal accesses are used
   int red_blocks_per_cu = 4;  // reduction kernels
   int house_reverse = 1;   // Householder phase B walks the vectors back-to-front (MALL tail reuse)
   int lbfgs_inv_mode = MXLO_INV_TWOPASS;
@@ -117,8 +118,12 @@ inline int64_t common_head(std::initializer_list<const void *> ptrs) {
 
 inline int grid_for(const mxlo_ctx *ctx, int64_t work_items, int64_t items_per_block, int per_cu) {
   int64_t need = (work_items + items_per_block - 1) / items_per_block;
-  int64_t cap = (int64_t)ctx->num_cu * per_cu;
-  int64_t g = need < cap ? need : cap;
+  int64_t g = need;
+  if (per_cu > 0) {  // per_cu == 0: one work chunk per workgroup (no persistent loop)
+    const int64_t cap = (int64_t)ctx->num_cu * per_cu;
+    if (g > cap) g = cap;
+  }
+  if (g > 0x7fffffffLL) g = 0x7fffffffLL;
   return (int)(g < 1 ? 1 : g);
 }
 

@@ -1,0 +1,371 @@
+// dense.hip — matrix-carrying leaves: dense LinearOperator(M) (GEMV), opHermitian, kron(A,B).
+//
+// kron(A,B)*x = vec(B * X * A^T) is two GEMMs on the matrix cores: f64 uses
+// v_mfma_f64_16x16x4_f64 (one f64 of A and B per lane; C/D layout col = lane&15,
+// row = (lane>>4) + 4*reg — NOT the f32 map), f32 uses v_mfma_f32_16x16x4_f32
+// (row = 4*(lane>>4) + reg). 64x64 block tile, 4 waves each owning a 32x32 quadrant (2x2 MFMA
+// tiles = 4 independent accumulators, enough to issue back-to-back), K staged through LDS in
+// k-major layout padded to 80 doubles per row so both operand reads are conflict-free ds_read_b64.
+#include "common.h"
+#include "stream_kernels.h"
+
+using namespace mxlo;
+
+namespace {
+
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+constexpr int BM = 64, BN = 64, BK = 16;
+constexpr int LDT = 80;  // padded tile row (elements): 80*8 B = 640 B -> second k-row lands 32 banks away
+
+template <typename T>
+struct Mfma;
+template <>
+struct Mfma<double> {
+  using Acc = f64x4;
+  static __device__ __forceinline__ Acc run(double a, double b, Acc c) {
+    return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ int row(int lane, int r) { return (lane >> 4) + 4 * r; }
+};
+template <>
+struct Mfma<float> {
+  using Acc = f32x4v;
+  static __device__ __forceinline__ Acc run(float a, float b, Acc c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ int row(int lane, int r) { return 4 * (lane >> 4) + r; }
+};
+
+// C (M x N, ldc) = alpha * opA(A) (M x K) * opB(B) (K x N) (+ beta * C); column-major.
+// TA: A is stored K x M (we need its transpose); TB: B is stored N x K.
+template <typename T, typename CT, bool TA, bool TB, bool BETA0>
+__global__ void __launch_bounds__(kBlock)
+gemm_kernel(T *__restrict__ C, int64_t ldc, const T *__restrict__ A, int64_t lda,
+            const T *__restrict__ B, int64_t ldb, int M, int N, int K, CT alpha, CT beta) {
+  __shared__ T sA[BK][LDT];  // sA[k][i]
+  __shared__ T sB[BK][LDT];  // sB[k][j]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int bm = blockIdx.x * BM, bn = blockIdx.y * BN;
+  const int wm = (wave & 1) * 32, wn = (wave >> 1) * 32;
+  using Acc = typename Mfma<T>::Acc;
+  Acc acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[a][b][r] = 0;
+
+  for (int k0 = 0; k0 < K; k0 += BK) {
+    // ---- stage A tile (BM x BK) and B tile (BK x BN): 1024 elements each, 4 per thread
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int e = tid + t * kBlock;  // 0..1023
+      {  // A
+        int i, k;
+        if constexpr (!TA) { i = e & 63; k = e >> 6; }   // i contiguous in memory
+        else { k = e & 15; i = e >> 4; }                 // k contiguous in memory
+        const int gi = bm + i, gk = k0 + k;
+        T v = 0;
+        if (gi < M && gk < K) v = TA ? A[gk + (int64_t)gi * lda] : A[gi + (int64_t)gk * lda];
+        sA[k][i] = v;
+      }
+      {  // B
+        int j, k;
+        if constexpr (!TB) { k = e & 15; j = e >> 4; }   // k contiguous in memory
+        else { j = e & 63; k = e >> 6; }                 // j contiguous in memory
+        const int gj = bn + j, gk = k0 + k;
+        T v = 0;
+        if (gj < N && gk < K) v = TB ? B[gj + (int64_t)gk * ldb] : B[gk + (int64_t)gj * ldb];
+        sB[k][j] = v;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 4) {
+      const int kr = kk + (lane >> 4);
+      T a0 = sA[kr][wm + (lane & 15)], a1 = sA[kr][wm + 16 + (lane & 15)];
+      T b0 = sB[kr][wn + (lane & 15)], b1 = sB[kr][wn + 16 + (lane & 15)];
+      acc[0][0] = Mfma<T>::run(a0, b0, acc[0][0]);
+      acc[0][1] = Mfma<T>::run(a0, b1, acc[0][1]);
+      acc[1][0] = Mfma<T>::run(a1, b0, acc[1][0]);
+      acc[1][1] = Mfma<T>::run(a1, b1, acc[1][1]);
+    }
+    __syncthreads();
+  }
+  // ---- epilogue: res = (alpha*acc) (+ beta*C), each product rounded separately (no FMA)
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int gi = bm + wm + a * 16 + Mfma<T>::row(lane, r);
+        const int gj = bn + wn + b * 16 + (lane & 15);
+        if (gi < M && gj < N) {
+          T *p = C + gi + (int64_t)gj * ldc;
+          CT t = alpha * (CT)acc[a][b][r];
+          if constexpr (!BETA0) t = t + (beta * (CT)(*p));
+          *p = (T)t;
+        }
+      }
+}
+
+template <typename T>
+int32_t gemm(mxlo_ctx *ctx, T *C, int64_t ldc, const T *A, int64_t lda, bool ta, const T *B,
+             int64_t ldb, bool tb, int64_t M, int64_t N, int64_t K, double alpha, double beta,
+             int32_t flags) {
+  if (M <= 0 || N <= 0) return MXLO_OK;
+  MXLO_REQUIRE(M < (1LL << 31) && N < (1LL << 31) && K < (1LL << 31), MXLO_ESHAPE, "gemm dims too large");
+  dim3 grid((unsigned)((M + BM - 1) / BM), (unsigned)((N + BN - 1) / BN));
+  return dispatch_ct<T>(beta, flags, [&]<typename CT, bool B0>() -> int32_t {
+#define GO(TA_, TB_)                                                                             \
+  hipLaunchKernelGGL((gemm_kernel<T, CT, TA_, TB_, B0>), grid, dim3(kBlock), 0, ctx->stream, C,  \
+                     ldc, A, lda, B, ldb, (int)M, (int)N, (int)K, (CT)alpha, (CT)beta)
+    if (!ta && !tb) GO(false, false);
+    else if (!ta && tb) GO(false, true);
+    else if (ta && !tb) GO(true, false);
+    else GO(true, true);
+#undef GO
+    MXLO_LAUNCH_CHECK();
+    return MXLO_OK;
+  });
+}
+
+// ---- GEMV --------------------------------------------------------------------------------
+// T mode (res[j] = alpha * dot(M[:,j], v) + beta*res[j]): one wave per column, coalesced down the column.
+template <typename T, typename CT, bool BETA0, bool LOWER>
+__global__ void __launch_bounds__(kBlock)
+gemv_t_kernel(T *__restrict__ res, const T *__restrict__ M, int64_t m, int64_t n, int64_t ld,
+              const T *__restrict__ v, CT alpha, CT beta, T *__restrict__ raw_out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = (int64_t)blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * (kBlock / kWave);
+  for (int64_t j = wave; j < n; j += nwaves) {
+    const T *colp = M + j * ld;
+    double acc = 0.0;
+    const int64_t i0 = LOWER ? j + 1 : 0;  // strict lower triangle only
+    for (int64_t i = i0 + lane; i < m; i += 64) acc = fma((double)colp[i], (double)v[i], acc);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if (lane == 0) {
+      if (raw_out) raw_out[j] = (T)acc;
+      else {
+        CT t = alpha * (CT)(T)acc;
+        if constexpr (!BETA0) t = t + (beta * (CT)res[j]);
+        res[j] = (T)t;
+      }
+    }
+  }
+}
+
+// N mode partials: thread per row, a chunk of columns per blockIdx.y; part[chunk][row].
+template <typename T, bool LOWER>
+__global__ void __launch_bounds__(kBlock)
+gemv_n_partial_kernel(double *__restrict__ part, const T *__restrict__ M, int64_t m, int64_t n,
+                      int64_t ld, const T *__restrict__ v, int64_t cols_per_chunk) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const int64_t j0 = (int64_t)blockIdx.y * cols_per_chunk;
+  int64_t j1 = j0 + cols_per_chunk;
+  if (j1 > n) j1 = n;
+  if (i >= m) return;
+  double acc = 0.0;
+  for (int64_t j = j0; j < j1; ++j) {
+    if (LOWER && j >= i) break;  // only L[i][j] with j < i
+    acc = fma((double)M[i + j * ld], (double)v[j], acc);
+  }
+  part[(int64_t)blockIdx.y * m + i] = acc;
+}
+
+template <typename T, typename CT, bool BETA0>
+__global__ void __launch_bounds__(kBlock)
+gemv_n_finish_kernel(T *__restrict__ res, const double *__restrict__ part, int64_t m, int nchunks,
+                     CT alpha, CT beta, T *__restrict__ raw_out) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= m) return;
+  double acc = 0.0;
+  for (int c = 0; c < nchunks; ++c) acc += part[(int64_t)c * m + i];
+  if (raw_out) {
+    raw_out[i] = (T)acc;
+    return;
+  }
+  CT t = alpha * (CT)(T)acc;
+  if constexpr (!BETA0) t = t + (beta * (CT)res[i]);
+  res[i] = (T)t;
+}
+
+// res = alpha*((d*v + t1) + t2) (+ beta*res)     src/linalg.jl:99-101
+template <typename T, typename CT, bool BETA0>
+__global__ void __launch_bounds__(kBlock)
+herm_combine_kernel(T *__restrict__ res, const T *__restrict__ d, const T *__restrict__ v,
+                    const T *__restrict__ t1, const T *__restrict__ t2, int64_t n, CT alpha, CT beta) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const T inner = ((d[i] * v[i]) + t1[i]) + t2[i];
+  CT t = alpha * (CT)inner;
+  if constexpr (!BETA0) t = t + (beta * (CT)res[i]);
+  res[i] = (T)t;
+}
+
+template <typename T, bool LOWER>
+int32_t gemv_n(mxlo_ctx *ctx, T *res, const T *M, int64_t m, int64_t n, int64_t ld, const T *v,
+               double alpha, double beta, int32_t flags, T *raw_out) {
+  const int64_t cap = (int64_t)kMaxRedCols * kMaxRedBlocks;  // doubles in ctx->partials
+  MXLO_REQUIRE(m <= cap, MXLO_ESHAPE, "gemv: m = %lld exceeds the partial workspace", (long long)m);
+  int64_t nchunks = (n + 63) / 64;              // >= 64 columns per chunk
+  const int64_t row_blocks = (m + kBlock - 1) / kBlock;
+  const int64_t want = (int64_t)ctx->num_cu * 8 / (row_blocks > 0 ? row_blocks : 1) + 1;
+  if (nchunks > want) nchunks = want;
+  if (nchunks > cap / (m > 0 ? m : 1)) nchunks = cap / (m > 0 ? m : 1);
+  if (nchunks < 1) nchunks = 1;
+  if (nchunks > 65535) nchunks = 65535;
+  const int64_t cpc = (n + nchunks - 1) / nchunks;
+  nchunks = n > 0 ? (n + cpc - 1) / cpc : 1;
+  dim3 grid((unsigned)row_blocks, (unsigned)nchunks);
+  hipLaunchKernelGGL((gemv_n_partial_kernel<T, LOWER>), grid, dim3(kBlock), 0, ctx->stream,
+                     ctx->partials, M, m, n, ld, v, cpc > 0 ? cpc : 1);
+  MXLO_LAUNCH_CHECK();
+  return dispatch_ct<T>(beta, flags, [&]<typename CT, bool B0>() -> int32_t {
+    hipLaunchKernelGGL((gemv_n_finish_kernel<T, CT, B0>), dim3((unsigned)row_blocks), dim3(kBlock), 0,
+                       ctx->stream, res, ctx->partials, m, (int)nchunks, (CT)alpha, (CT)beta, raw_out);
+    MXLO_LAUNCH_CHECK();
+    return MXLO_OK;
+  });
+}
+
+template <typename T, bool LOWER>
+int32_t gemv_t(mxlo_ctx *ctx, T *res, const T *M, int64_t m, int64_t n, int64_t ld, const T *v,
+               double alpha, double beta, int32_t flags, T *raw_out) {
+  if (n <= 0) return MXLO_OK;
+  int64_t blocks = (n + 3) / 4;
+  const int64_t cap = (int64_t)ctx->num_cu * 16;
+  if (blocks > cap) blocks = cap;
+  return dispatch_ct<T>(beta, flags, [&]<typename CT, bool B0>() -> int32_t {
+    hipLaunchKernelGGL((gemv_t_kernel<T, CT, B0, LOWER>), dim3((unsigned)blocks), dim3(kBlock), 0,
+                       ctx->stream, res, M, m, n, ld, v, (CT)alpha, (CT)beta, raw_out);
+    MXLO_LAUNCH_CHECK();
+    return MXLO_OK;
+  });
+}
+
+template <typename T>
+int32_t gemv_any(mxlo_ctx *ctx, T *res, const T *M, int64_t m, int64_t n, int64_t ld, const T *v,
+                 double alpha, double beta, int32_t mode, int32_t flags) {
+  const int64_t nres = mode == MXLO_OP_N ? m : n;
+  const int64_t nin = mode == MXLO_OP_N ? n : m;
+  if (nres == 0) return MXLO_OK;
+  if (nin == 0) {  // empty sum: res = beta*res (or 0)
+    if (beta == 0) {
+      MXLO_HIP(hipMemsetAsync(res, 0, sizeof(T) * nres, ctx->stream));
+      return MXLO_OK;
+    }
+    return mxlo_scale(ctx, sizeof(T) == 8 ? MXLO_F64 : MXLO_F32, res, nres, beta, flags);
+  }
+  if (mode == MXLO_OP_N) return gemv_n<T, false>(ctx, res, M, m, n, ld, v, alpha, beta, flags, nullptr);
+  return gemv_t<T, false>(ctx, res, M, m, n, ld, v, alpha, beta, flags, nullptr);
+}
+
+struct HermScratch {  // per-ctx scratch for t1, t2 (grown on demand)
+  void *buf = nullptr;
+  size_t bytes = 0;
+};
+static HermScratch g_herm[64];
+
+template <typename T>
+int32_t hermitian_t(mxlo_ctx *ctx, T *res, const T *d, const T *A, int64_t lda, const T *v, int64_t n,
+                    double alpha, double beta, int32_t flags) {
+  if (n == 0) return MXLO_OK;
+  HermScratch &hs = g_herm[ctx->device & 63];
+  const size_t need = sizeof(T) * 2 * (size_t)n;
+  if (hs.bytes < need) {
+    if (hs.buf) {
+      MXLO_HIP(hipStreamSynchronize(ctx->stream));
+      MXLO_HIP(hipFree(hs.buf));
+    }
+    hs.buf = nullptr;
+    hs.bytes = 0;
+    hipError_t e = hipMalloc(&hs.buf, need);
+    MXLO_REQUIRE(e == hipSuccess, MXLO_ENOMEM, "opHermitian scratch: %s", hipGetErrorString(e));
+    hs.bytes = need;
+  }
+  T *t1 = (T *)hs.buf, *t2 = t1 + n;
+  MXLO_TRY((gemv_n<T, true>(ctx, t1, A, n, n, lda, v, 1.0, 0.0, flags, t1)));   // L*v
+  MXLO_TRY((gemv_t<T, true>(ctx, t2, A, n, n, lda, v, 1.0, 0.0, flags, t2)));   // (v'*L)'
+  const unsigned blocks = (unsigned)((n + kBlock - 1) / kBlock);
+  return dispatch_ct<T>(beta, flags, [&]<typename CT, bool B0>() -> int32_t {
+    hipLaunchKernelGGL((herm_combine_kernel<T, CT, B0>), dim3(blocks), dim3(kBlock), 0, ctx->stream,
+                       res, d, v, t1, t2, n, (CT)alpha, (CT)beta);
+    MXLO_LAUNCH_CHECK();
+    return MXLO_OK;
+  });
+}
+
+template <typename T>
+int32_t kron_t(mxlo_ctx *ctx, T *res, const T *A, int64_t m, int64_t n, int64_t lda, const T *B,
+               int64_t p, int64_t q, int64_t ldb, const T *x, T *work, double alpha, double beta,
+               int32_t mode, int32_t flags) {
+  if (mode == MXLO_OP_N) {
+    // X = reshape(x, q, n); U = X * A^T (q x m); R = B * U (p x m); res = alpha*vec(R) + beta*res
+    MXLO_TRY(gemm<T>(ctx, work, q, x, q, false, A, lda, true, q, m, n, 1.0, 0.0, 0));
+    return gemm<T>(ctx, res, p, B, ldb, false, work, q, false, p, m, q, alpha, beta, flags);
+  }
+  // X = reshape(x, p, m); U = X * A (p x n); R = B^T * U (q x n)
+  MXLO_TRY(gemm<T>(ctx, work, p, x, p, false, A, lda, false, p, n, m, 1.0, 0.0, 0));
+  return gemm<T>(ctx, res, q, B, ldb, true, work, p, false, q, n, p, alpha, beta, flags);
+}
+
+}  // namespace
+
+static inline void eff_ab(int32_t dtype, int32_t flags, double &alpha, double &beta) {
+  if (dtype == MXLO_F32 && !(flags & MXLO_SCALARS_F64)) {
+    alpha = (double)(float)alpha;
+    beta = (double)(float)beta;
+  }
+}
+
+MXLO_API int32_t mxlo_gemv(mxlo_ctx *ctx, int32_t dtype, void *res, const void *M, int64_t m,
+                           int64_t n, int64_t ld, const void *v, double alpha, double beta,
+                           int32_t op_mode, int32_t flags) {
+  MXLO_REQUIRE(ctx, MXLO_EINVAL, "mxlo_gemv: ctx is NULL");
+  MXLO_REQUIRE(dtype == MXLO_F64 || dtype == MXLO_F32, MXLO_EINVAL, "bad dtype");
+  MXLO_REQUIRE(m >= 0 && n >= 0 && ld >= (m > 1 ? m : 1), MXLO_ESHAPE, "mxlo_gemv: bad shape");
+  MXLO_REQUIRE(op_mode >= MXLO_OP_N && op_mode <= MXLO_OP_C, MXLO_EINVAL, "bad op_mode");
+  eff_ab(dtype, flags, alpha, beta);
+  if (dtype == MXLO_F64)
+    return gemv_any<double>(ctx, (double *)res, (const double *)M, m, n, ld, (const double *)v, alpha, beta, op_mode, flags);
+  return gemv_any<float>(ctx, (float *)res, (const float *)M, m, n, ld, (const float *)v, alpha, beta, op_mode, flags);
+}
+
+MXLO_API int32_t mxlo_hermitian_mul(mxlo_ctx *ctx, int32_t dtype, void *res, const void *d,
+                                    const void *A, int64_t lda, const void *v, int64_t n,
+                                    double alpha, double beta, int32_t flags) {
+  MXLO_REQUIRE(ctx, MXLO_EINVAL, "mxlo_hermitian_mul: ctx is NULL");
+  MXLO_REQUIRE(dtype == MXLO_F64 || dtype == MXLO_F32, MXLO_EINVAL, "bad dtype");
+  MXLO_REQUIRE(n >= 0 && lda >= (n > 1 ? n : 1), MXLO_ESHAPE, "mxlo_hermitian_mul: bad shape");
+  MXLO_REQUIRE(n == 0 || (res && d && A && v), MXLO_EINVAL, "mxlo_hermitian_mul: NULL operand");
+  eff_ab(dtype, flags, alpha, beta);
+  if (dtype == MXLO_F64)
+    return hermitian_t<double>(ctx, (double *)res, (const double *)d, (const double *)A, lda, (const double *)v, n, alpha, beta, flags);
+  return hermitian_t<float>(ctx, (float *)res, (const float *)d, (const float *)A, lda, (const float *)v, n, alpha, beta, flags);
+}
+
+MXLO_API int32_t mxlo_kron_mul(mxlo_ctx *ctx, int32_t dtype, void *res, const void *A, int64_t m,
+                               int64_t n, int64_t lda, const void *B, int64_t p, int64_t q,
+                               int64_t ldb, const void *x, void *work, double alpha, double beta,
+                               int32_t op_mode, int32_t flags) {
+  MXLO_REQUIRE(ctx, MXLO_EINVAL, "mxlo_kron_mul: ctx is NULL");
+  MXLO_REQUIRE(dtype == MXLO_F64 || dtype == MXLO_F32, MXLO_EINVAL, "bad dtype");
+  MXLO_REQUIRE(m >= 0 && n >= 0 && p >= 0 && q >= 0, MXLO_ESHAPE, "mxlo_kron_mul: negative size");
+  MXLO_REQUIRE(op_mode >= MXLO_OP_N && op_mode <= MXLO_OP_C, MXLO_EINVAL, "bad op_mode");
+  const int64_t nres = op_mode == MXLO_OP_N ? m * p : n * q;
+  if (nres == 0) return MXLO_OK;
+  MXLO_REQUIRE(res && A && B && x && work, MXLO_EINVAL, "mxlo_kron_mul: NULL operand");
+  eff_ab(dtype, flags, alpha, beta);
+  if (dtype == MXLO_F64)
+    return kron_t<double>(ctx, (double *)res, (const double *)A, m, n, lda, (const double *)B, p, q, ldb,
+                          (const double *)x, (double *)work, alpha, beta, op_mode, flags);
+  return kron_t<float>(ctx, (float *)res, (const float *)A, m, n, lda, (const float *)B, p, q, ldb,
+                       (const float *)x, (float *)work, alpha, beta, op_mode, flags);
+}

@@ -187,17 +187,50 @@ MXLO_API int32_t mxlo_ones_mul(mxlo_ctx *ctx, int32_t dtype, void *res, int64_t 
 
 // ---- opHouseholder ----------------------------------------------------------------------------
 template <typename T>
-static int32_t householder_t(mxlo_ctx *ctx, T *res, const T *h, const T *v, int64_t n,
-                             double alpha, double beta, int32_t flags) {
-  double *dot = ctx->scalars;  // slot 0
-  const T *cols[1] = {h};
-  MXLO_TRY(panel_dots<T>(ctx, cols, 1, v, n, dot));  // phase A (+ all-reduce hook)
+static int32_t householder_apply_t(mxlo_ctx *ctx, T *res, const T *h, const T *v, int64_t n,
+                                   double alpha, double beta, int32_t flags, const double *dot) {
   const bool rev = ctx->tune.house_reverse != 0;
   return dispatch_ct<T>(beta, flags, [&]<typename CT, bool B0>() -> int32_t {
     HouseholderOp<T, CT, B0> op{(CT)alpha, (CT)beta, dot, T(0)};
     if (rev) return launch_map<T, 2, !B0, true>(ctx, res, h, v, n, op);
     return launch_map<T, 2, !B0, false>(ctx, res, h, v, n, op);
   });
+}
+
+template <typename T>
+static int32_t householder_t(mxlo_ctx *ctx, T *res, const T *h, const T *v, int64_t n,
+                             double alpha, double beta, int32_t flags) {
+  double *dot = ctx->scalars;  // slot 0
+  const T *cols[1] = {h};
+  MXLO_TRY(panel_dots<T>(ctx, cols, 1, v, n, dot));  // phase A (+ all-reduce hook)
+  return householder_apply_t<T>(ctx, res, h, v, n, alpha, beta, flags, dot);  // phase B
+}
+
+MXLO_API int32_t mxlo_dot(mxlo_ctx *ctx, int32_t dtype, const void *a, const void *b, int64_t n,
+                          double *out_dev) {
+  CHECK_COMMON("mxlo_dot");
+  MXLO_REQUIRE(n >= 0 && out_dev && (n == 0 || (a && b)), MXLO_EINVAL, "mxlo_dot: bad argument");
+  if (dtype == MXLO_F64) {
+    const double *cols[1] = {(const double *)a};
+    return panel_dots<double>(ctx, cols, 1, (const double *)b, n, out_dev);
+  }
+  const float *cols[1] = {(const float *)a};
+  return panel_dots<float>(ctx, cols, 1, (const float *)b, n, out_dev);
+}
+
+MXLO_API int32_t mxlo_householder_apply(mxlo_ctx *ctx, int32_t dtype, void *res, const void *h,
+                                        const void *v, int64_t n, double alpha, double beta,
+                                        int32_t flags, const double *dot_dev) {
+  CHECK_COMMON("mxlo_householder_apply");
+  MXLO_REQUIRE(n >= 0 && dot_dev && (n == 0 || (res && h && v)), MXLO_EINVAL,
+               "mxlo_householder_apply: bad argument");
+  alpha = eff_alpha(dtype, flags, alpha);
+  beta = eff_beta(dtype, flags, beta);
+  if (dtype == MXLO_F64)
+    return householder_apply_t<double>(ctx, (double *)res, (const double *)h, (const double *)v, n,
+                                       alpha, beta, flags, dot_dev);
+  return householder_apply_t<float>(ctx, (float *)res, (const float *)h, (const float *)v, n, alpha,
+                                    beta, flags, dot_dev);
 }
 
 MXLO_API int32_t mxlo_householder_mul(mxlo_ctx *ctx, int32_t dtype, void *res, const void *h,

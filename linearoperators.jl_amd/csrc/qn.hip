@@ -1,0 +1,1114 @@
+// qn.hip — quasi-Newton operators with their state resident in HBM:
+//   InverseLBFGSOperator (src/lbfgs.jl:112-158), LBFGSOperator (src/lbfgs.jl:168-206),
+//   LSR1Operator (src/lsr1.jl:86-111), push! (src/lbfgs.jl:210-367, src/lsr1.jl:119-184),
+//   diag! , reset!, solve_shifted_system! (src/utilities.jl:207-248).
+//
+// Data layout: s, y (and a, b) are n x mem column-major PANELS (column k = slot k, leading
+// dimension ld = n rounded up to a 16-byte multiple) so every column streams coalesced.
+//
+// Every apply is the same three-stage shape (the "skinny panel" form):
+//   1. panel_dots   : ONE pass over x and the active panel columns -> up to 2m dots (f64),
+//                     fixed-order finalize, [all-reduce hook for row-sharded vectors]
+//   2. coef kernel  : one tiny launch turning dots (+ Gram matrices kept up to date by push!)
+//                     into per-column coefficients, all in device memory (no host sync)
+//   3. panel_combine: ONE pass reading x and the columns, writing res, applying the columns in the
+//                     reference's elementwise statement order (no FMA fusion).
+// HBM traffic per apply: (4m+3)*8 B/elt for L-BFGS (vs (48+80m) for the reference's statement
+// sequence). The reference-ordered inverse two-loop (2m chained dot/axpy passes) is kept as
+// MXLO_INV_REFORDER for validation.
+#include <cmath>
+#include <vector>
+
+#include "common.h"
+#include "stream_kernels.h"
+
+using namespace mxlo;
+
+namespace {
+
+constexpr int kMaxMem = 32;          // slots; 2*mem panel columns per combine <= 64
+constexpr int kMaxCols = 2 * kMaxMem;
+
+// ---- device scalar region layout (doubles) ------------------------------------------
+struct DscLayout {
+  int64_t dots = 0;    // [128] panel_dots outputs of the current apply
+  int64_t coef = 128;  // [128] coefficients consumed by panel_combine
+  int64_t misc = 256;  // [64]  push! scalars
+  int64_t as_ = 320;   // [mem] L-SR1 a_k' s_k
+  int64_t alpha = 352; // [mem] inverse two-loop alpha_k (data.α)
+  int64_t SY = 384;    // [mem*mem] column j = S' y_j  (written when slot j is pushed)
+  int64_t YS = 0, YY = 0, G = 0, g = 0, cx = 0, total = 0;
+  explicit DscLayout(int64_t mem) {
+    YS = SY + mem * mem;
+    YY = YS + mem * mem;
+    G = YY + mem * mem;
+    g = G + 4 * mem * mem;
+    cx = g + 2 * mem;
+    total = cx + 2 * mem + 64;
+  }
+};
+
+}  // namespace
+
+struct mxlo_qn {
+  mxlo_ctx *ctx = nullptr;
+  int kind = 0, dtype = 0;
+  int64_t n = 0, mem = 0, ld = 0;
+  bool scaling = true, damped = false;
+  double sigma2 = 0.99, sigma3 = 10.0;
+  int mode = MXLO_INV_TWOPASS;
+  // host mirrors of the small scalars that drive control flow
+  int64_t insert0 = 0;  // 0-based next write slot
+  double scaling_factor = 1.0;
+  std::vector<double> ys;     // [mem]
+  std::vector<int64_t> age;   // push counter per slot (Gram freshness)
+  int64_t pushes = 0;
+  bool G_valid = false;
+  // device
+  void *S = nullptr, *Y = nullptr, *A = nullptr, *B = nullptr;  // panels
+  void *tmp = nullptr, *tmp2 = nullptr;                         // n-vectors (Ax / tmp)
+  double *dsc = nullptr;
+  DscLayout lay{1};
+};
+
+namespace {
+
+template <typename T>
+inline T *col(void *panel, int64_t ld, int64_t k) {
+  return (T *)panel + k * ld;
+}
+
+// ---- panel_combine ---------------------------------------------------------------------
+enum CombineMode {
+  CM_FWD = 0,       // q = x (/g); pairs (b,a): q = q + ((cb*b) - (ca*a)); res = al*q (+ be*res)
+  CM_INV = 1,       // q = x; cols y: q = q - c*y; q = q*g; cols s: q = q + c*s; res = al*q (+ be*res)
+  CM_LSR1 = 2,      // q = (al*x)/g (+ be*res); cols a: q = T(q + c*a)          (c carries al)
+  CM_AFWD = 3,      // q = x/g; pairs (b,a): q = q + c1*b; q = q - c2*a; res = q   (push!: a_k rebuild)
+  CM_ASR1 = 4,      // q = x2 - x/g; cols a: q = q - c*a; res = q                  (L-SR1 a_k rebuild)
+  CM_AXPYS = 5,     // q = c0*x; cols u: q = q + c*u; res = q                      (shifted solve)
+  CM_DIAG_FWD = 6,  // q = 1 (/g); pairs (b,a): q = q + ((b*b) - (a*a)); res = q
+  CM_DIAG_SR1 = 7,  // q = 1 (/g); cols a: q = q + ((a*a)/as); res = q
+};
+
+template <typename T>
+struct CombineArgs {
+  const T *cols[kMaxCols];
+  int ncol;        // total columns (pairs count 2)
+  int nfirst;      // CM_INV: number of y columns (the rest are s columns)
+  int use_gamma;   // divide / multiply by gamma
+  double gamma;
+  double alpha, beta;
+  const double *coef;  // device coefficients, one per column (CM_DIAG_SR1: as_k per column)
+};
+
+template <typename T, typename CT, int MODE, bool BETA0, int VEC, bool NT>
+__global__ void __launch_bounds__(kBlock)
+combine_kernel(T *__restrict__ res, const T *__restrict__ x, const T *__restrict__ x2,
+               CombineArgs<T> A, int64_t nvec) {
+  using V = typename VecOf<T, VEC>::type;
+  const T g = (T)A.gamma;
+  const CT al = (CT)A.alpha, be = (CT)A.beta;
+  const int ncol = A.ncol;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < nvec;
+       i += (int64_t)gridDim.x * kBlock) {
+    T q[VEC];
+    // ---- prologue
+    if constexpr (MODE == CM_DIAG_FWD || MODE == CM_DIAG_SR1) {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) q[e] = A.use_gamma ? (T)1 / g : (T)1;
+    } else {
+      const V xv = ldg<NT>(reinterpret_cast<const V *>(x + i * VEC));
+      V x2v, rv;
+      if constexpr (MODE == CM_ASR1) x2v = ldg<NT>(reinterpret_cast<const V *>(x2 + i * VEC));
+      if constexpr (MODE == CM_LSR1 && !BETA0) rv = ldg<NT>(reinterpret_cast<const V *>(res + i * VEC));
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        const T xe = vget<T, VEC>(xv, e);
+        if constexpr (MODE == CM_FWD || MODE == CM_AFWD) q[e] = A.use_gamma ? xe / g : xe;
+        else if constexpr (MODE == CM_INV) q[e] = xe;
+        else if constexpr (MODE == CM_LSR1) {
+          CT t = (al * (CT)xe) / (CT)g;  // (α*x)/γ : γ divided unconditionally (src/lsr1.jl:93)
+          if constexpr (!BETA0) t = t + (be * (CT)vget<T, VEC>(rv, e));
+          q[e] = (T)t;
+        } else if constexpr (MODE == CM_ASR1) q[e] = vget<T, VEC>(x2v, e) - (xe / g);
+        else if constexpr (MODE == CM_AXPYS) q[e] = (T)A.coef[kMaxCols] * xe;  // c0 stored past the columns
+      }
+    }
+    // ---- columns, 4 loads in flight
+    constexpr int U = 8;
+    for (int c0 = 0; c0 < ncol; c0 += U) {
+      V cv[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (c0 + u < ncol) cv[u] = ldg<NT>(reinterpret_cast<const V *>(A.cols[c0 + u] + i * VEC));
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int c = c0 + u;
+        if (c >= ncol) break;
+        if constexpr (MODE == CM_FWD || MODE == CM_AFWD || MODE == CM_DIAG_FWD) {
+          if (u & 1) continue;  // pairs are handled on the even member (U is even)
+          const T cb = (T)A.coef[c], ca = (T)A.coef[c + 1];
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) {
+            const T b = vget<T, VEC>(cv[u], e), a = vget<T, VEC>(cv[u + 1], e);
+            if constexpr (MODE == CM_FWD) q[e] = q[e] + ((cb * b) - (ca * a));       // lbfgs.jl:194
+            else if constexpr (MODE == CM_AFWD) {
+              q[e] = q[e] + (cb * b);                                                 // lbfgs.jl:244
+              q[e] = q[e] - (ca * a);                                                 // lbfgs.jl:245
+            } else q[e] = q[e] + ((b * b) - (a * a));                                 // lbfgs.jl:391
+          }
+        } else if constexpr (MODE == CM_INV) {
+          if (c == A.nfirst && A.use_gamma) {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) q[e] = q[e] * g;                            // lbfgs.jl:139
+          }
+          const T cc = (T)A.coef[c];
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) {
+            const T ce = vget<T, VEC>(cv[u], e);
+            if (c < A.nfirst) q[e] = q[e] - (cc * ce);                                // lbfgs.jl:135
+            else q[e] = q[e] + (cc * ce);                                             // lbfgs.jl:146
+          }
+        } else if constexpr (MODE == CM_LSR1) {
+          const CT cc = (CT)A.coef[c];  // (α*dot)/as evaluated in CT by the coef kernel
+#pragma unroll
+          for (int e = 0; e < VEC; ++e)
+            q[e] = (T)((CT)q[e] + (cc * (CT)vget<T, VEC>(cv[u], e)));                 // lsr1.jl:103
+        } else if constexpr (MODE == CM_ASR1) {
+          const T cc = (T)A.coef[c];
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) q[e] = q[e] - (cc * vget<T, VEC>(cv[u], e));  // lsr1.jl:174
+        } else if constexpr (MODE == CM_AXPYS) {
+          const T cc = (T)A.coef[c];
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) q[e] = q[e] + (cc * vget<T, VEC>(cv[u], e));
+        } else if constexpr (MODE == CM_DIAG_SR1) {
+          const T as = (T)A.coef[c];
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) {
+            const T a = vget<T, VEC>(cv[u], e);
+            q[e] = q[e] + ((a * a) / as);                                             // lsr1.jl:206
+          }
+        }
+      }
+    }
+    if constexpr (MODE == CM_INV) {
+      if (A.nfirst == ncol && A.use_gamma) {  // no s column followed (cannot happen: nfirst*2 == ncol)
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) q[e] = q[e] * g;
+      }
+    }
+    // ---- epilogue
+    V out;
+    if constexpr (MODE == CM_FWD || MODE == CM_INV) {
+      V rv;
+      if constexpr (!BETA0) rv = ldg<NT>(reinterpret_cast<const V *>(res + i * VEC));
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        CT t = al * (CT)q[e];                                                         // lbfgs.jl:150,198
+        if constexpr (!BETA0) t = t + (be * (CT)vget<T, VEC>(rv, e));
+        vset<T, VEC>(out, e, (T)t);
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) vset<T, VEC>(out, e, q[e]);
+    }
+    stg<NT>(reinterpret_cast<V *>(res + i * VEC), out);
+  }
+}
+
+template <typename T, int MODE>
+int32_t launch_combine_part(mxlo_ctx *ctx, T *res, const T *x, const T *x2, const CombineArgs<T> &A,
+                            int64_t n, int32_t flags, bool vec) {
+  if (n <= 0) return MXLO_OK;
+  constexpr int VECF = Vec16<T>::N;
+  const bool f64s = sizeof(T) == 8 || (flags & MXLO_SCALARS_F64);
+  const bool b0 = A.beta == 0;
+  auto go = [&]<typename CT, bool B0, int VEC>() -> int32_t {
+    const int64_t nvec = n / VEC;
+    const int grid = grid_for(ctx, nvec, kBlock, ctx->tune.blocks_per_cu);
+    const bool nt = (int64_t)sizeof(T) * n * (A.ncol + 2) >= ctx->tune.nt_min_bytes;
+    if (nt)
+      hipLaunchKernelGGL((combine_kernel<T, CT, MODE, B0, VEC, true>), dim3(grid), dim3(kBlock), 0,
+                         ctx->stream, res, x, x2, A, nvec);
+    else
+      hipLaunchKernelGGL((combine_kernel<T, CT, MODE, B0, VEC, false>), dim3(grid), dim3(kBlock), 0,
+                         ctx->stream, res, x, x2, A, nvec);
+    MXLO_LAUNCH_CHECK();
+    return MXLO_OK;
+  };
+  constexpr bool uses_ab = (MODE == CM_FWD || MODE == CM_INV || MODE == CM_LSR1);
+  if constexpr (!uses_ab) {
+    return vec ? go.template operator()<T, true, VECF>() : go.template operator()<T, true, 1>();
+  } else {
+    if (f64s) {
+      if (vec) return b0 ? go.template operator()<double, true, VECF>() : go.template operator()<double, false, VECF>();
+      return b0 ? go.template operator()<double, true, 1>() : go.template operator()<double, false, 1>();
+    }
+    if constexpr (sizeof(T) == 4) {
+      if (vec) return b0 ? go.template operator()<float, true, VECF>() : go.template operator()<float, false, VECF>();
+      return b0 ? go.template operator()<float, true, 1>() : go.template operator()<float, false, 1>();
+    }
+  }
+  return MXLO_EINVAL;
+}
+
+// Panel columns are 16-byte aligned by construction (ld is a multiple of the vector width); the
+// vector path additionally needs res / x / x2 16-byte aligned. A non-multiple-of-VEC tail is a
+// second, scalar launch on offset pointers.
+template <typename T, int MODE>
+int32_t launch_combine(mxlo_ctx *ctx, T *res, const T *x, const T *x2, CombineArgs<T> &A,
+                       int64_t n, int32_t flags) {
+  if (n <= 0) return MXLO_OK;
+  constexpr int VECF = Vec16<T>::N;
+  bool vec = (((uintptr_t)res & 15u) == 0) && (!x || ((uintptr_t)x & 15u) == 0) &&
+             (!x2 || ((uintptr_t)x2 & 15u) == 0) && n >= VECF;
+  for (int c = 0; c < A.ncol && vec; ++c) vec = (((uintptr_t)A.cols[c]) & 15u) == 0;
+  if (!vec) return launch_combine_part<T, MODE>(ctx, res, x, x2, A, n, flags, false);
+  const int64_t nbody = (n / VECF) * VECF;
+  MXLO_TRY((launch_combine_part<T, MODE>(ctx, res, x, x2, A, nbody, flags, true)));
+  if (nbody < n) {
+    CombineArgs<T> At = A;
+    for (int c = 0; c < A.ncol; ++c) At.cols[c] = A.cols[c] + nbody;
+    return launch_combine_part<T, MODE>(ctx, res + nbody, x ? x + nbody : x, x2 ? x2 + nbody : x2, At,
+                                        n - nbody, flags, false);
+  }
+  return MXLO_OK;
+}
+
+// ---- coefficient kernels (one wave, lane 0 does the O(m^2) scalar work) ------------------
+struct OrdArgs {
+  int na;
+  int ord[kMaxMem];      // active slots in the order the dots / columns were issued
+  double ys[kMaxMem];    // ys[slot]
+  long long age[kMaxMem];
+  int mem;
+  double gamma;
+  int use_gamma;
+  int is_f32;            // round scalars to float like the reference's T arithmetic
+};
+
+__device__ __forceinline__ double rnd(double v, int is_f32) { return is_f32 ? (double)(float)v : v; }
+
+// Inverse two-loop in coefficient space (SURVEY §8a equivalence (i)):
+//   dots[i] = s_i'x, dots[na+i] = y_i'x for i = 0..na-1 in NEWEST->OLDEST order (ord[]).
+//   coef[i]      = alpha_i  (column y_ord[i], newest->oldest)
+//   coef[na + j] = beta for column s in OLDEST->NEWEST order (j = 0 is ord[na-1]).
+__global__ void inv_coef_kernel(const double *__restrict__ dots, double *__restrict__ coef,
+                                const double *__restrict__ SY, const double *__restrict__ YS,
+                                const double *__restrict__ YY, double *__restrict__ alpha_out,
+                                OrdArgs O) {
+  if (threadIdx.x != 0) return;
+  const int na = O.na, mem = O.mem;
+  auto sy = [&](int i, int j) {  // s_i' y_j for slots i, j
+    return O.age[j] >= O.age[i] ? SY[i + (int64_t)j * mem] : YS[j + (int64_t)i * mem];
+  };
+  auto yy = [&](int i, int j) {
+    return O.age[j] >= O.age[i] ? YY[i + (int64_t)j * mem] : YY[j + (int64_t)i * mem];
+  };
+  double a[kMaxMem], b[kMaxMem];
+  for (int i = 0; i < na; ++i) {
+    const int k = O.ord[i];
+    double sq = dots[i];
+    for (int j = 0; j < i; ++j) sq -= a[j] * sy(k, O.ord[j]);
+    a[i] = rnd(sq / O.ys[k], O.is_f32);
+    alpha_out[k] = a[i];
+  }
+  const double g = O.use_gamma ? O.gamma : 1.0;
+  for (int i = na - 1; i >= 0; --i) {
+    const int k = O.ord[i];
+    double yq = dots[na + i];
+    for (int j = 0; j < na; ++j) yq -= a[j] * yy(k, O.ord[j]);
+    double yr = g * yq;
+    for (int j = na - 1; j > i; --j) yr += b[j] * sy(O.ord[j], k);
+    b[i] = rnd(a[i] - yr / O.ys[k], O.is_f32);
+  }
+  for (int i = 0; i < na; ++i) coef[i] = a[i];
+  for (int j = 0; j < na; ++j) coef[na + j] = b[na - 1 - j];
+}
+
+// L-SR1: coef[i] = (alpha*dot_i)/as_k evaluated in CT (src/lsr1.jl:101)
+__global__ void lsr1_coef_kernel(const double *__restrict__ dots, double *__restrict__ coef,
+                                 const double *__restrict__ as_, OrdArgs O, double alpha, int ct_f32) {
+  const int i = threadIdx.x;
+  if (i >= O.na) return;
+  const int k = O.ord[i];
+  const double d = rnd(dots[i], O.is_f32), as = rnd(as_[k], O.is_f32);
+  if (ct_f32) coef[i] = (double)(((float)alpha * (float)d) / (float)as);
+  else coef[i] = (alpha * d) / as;
+}
+
+// coef[i] = T(dots[i] / as[ord[i]])   (L-SR1 push!: as = dot(a_l, s_k)/as_l, src/lsr1.jl:173)
+__global__ void div_as_kernel(const double *__restrict__ dots, double *__restrict__ coef,
+                              const double *__restrict__ as_, OrdArgs O) {
+  const int i = threadIdx.x;
+  if (i >= O.na) return;
+  coef[i] = rnd(rnd(dots[i], O.is_f32) / rnd(as_[O.ord[i]], O.is_f32), O.is_f32);
+}
+
+// coef[i] = T(dots[i])
+__global__ void copy_coef_kernel(const double *__restrict__ dots, double *__restrict__ coef, int n,
+                                 int is_f32) {
+  const int i = threadIdx.x;
+  if (i < n) coef[i] = rnd(dots[i], is_f32);
+}
+
+// v[i] = v[i] / sqrt(dot)  |  v[i] = y[i] / sqrt(ys)   (src/lbfgs.jl:232,248)
+template <typename T>
+struct DivSqrtDevOp {
+  const double *dot;
+  T s;
+  __device__ void init() { s = sizeof(T) == 8 ? (T)sqrt(*dot) : (T)sqrtf((float)*dot); }
+  __device__ T operator()(T, T, T r) const { return r / s; }
+};
+template <typename T>
+struct DivConstOp {
+  T s;
+  __device__ void init() {}
+  __device__ T operator()(T y, T, T) const { return y / s; }
+};
+// y = th*y + (1-th)*Bs    (Powell damping, src/lbfgs.jl:316,351)
+template <typename T>
+struct DampOp {
+  T th, omth;
+  __device__ void init() {}
+  __device__ T operator()(T y, T bs, T) const { return (th * y) + (omth * bs); }
+};
+// Bs = (-alpha)*g   (src/lbfgs.jl:341)
+template <typename T>
+struct NegScaleOp {
+  T na;
+  __device__ void init() {}
+  __device__ T operator()(T g, T, T) const { return na * g; }
+};
+// tmp = y - s/sf   (src/lsr1.jl:140)
+template <typename T>
+struct YmSOverOp {
+  T sf;
+  __device__ void init() {}
+  __device__ T operator()(T y, T s, T) const { return y - (s / sf); }
+};
+// reference-ordered two-loop steps: q = q - a*y with a = dot/ys (stored), q = q + (a_k - dot/ys)*s
+template <typename T>
+struct InvStep1Op {
+  const double *dot;
+  double *alpha_slot;
+  T ys, c;
+  __device__ void init() {
+    c = (T)(*dot) / ys;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *alpha_slot = (double)c;
+  }
+  __device__ T operator()(T y, T, T q) const { return q - (c * y); }
+};
+template <typename T>
+struct InvStep2Op {
+  const double *dot;
+  const double *alpha_slot;
+  T ys, c;
+  __device__ void init() { c = (T)(*alpha_slot) - ((T)(*dot) / ys); }
+  __device__ T operator()(T s, T, T q) const { return q + (c * s); }
+};
+template <typename T>
+struct CopyOp {
+  __device__ void init() {}
+  __device__ T operator()(T x, T, T) const { return x; }
+};
+
+template <typename T>
+inline T eps_of() {
+  return sizeof(T) == 8 ? (T)2.220446049250313e-16 : (T)1.1920929e-07f;
+}
+
+inline void fill_ord(const mxlo_qn *h, OrdArgs &O, bool newest_first) {
+  O.na = 0;
+  O.mem = (int)h->mem;
+  O.gamma = h->scaling_factor;
+  O.use_gamma = h->scaling ? 1 : 0;
+  O.is_f32 = h->dtype == MXLO_F32;
+  for (int k = 0; k < h->mem; ++k) {
+    O.ys[k] = h->ys[k];
+    O.age[k] = h->age[k];
+  }
+  for (int64_t i = 0; i < h->mem; ++i) {
+    // oldest->newest: slot (insert0 + i) % mem ; newest->oldest: slot (insert0 - 1 - i) mod mem
+    int64_t k = newest_first ? ((h->insert0 - 1 - i) % h->mem + h->mem) % h->mem
+                             : (h->insert0 + i) % h->mem;
+    if (h->ys[k] != 0) O.ord[O.na++] = (int)k;
+  }
+}
+
+// ---- applies ------------------------------------------------------------------------------
+template <typename T>
+int32_t inv_mul_twopass(mxlo_qn *h, T *res, const T *x, double alpha, double beta, int32_t flags) {
+  mxlo_ctx *ctx = h->ctx;
+  OrdArgs O;
+  fill_ord(h, O, /*newest_first=*/true);
+  const int na = O.na;
+  double *dots = h->dsc + h->lay.dots, *coef = h->dsc + h->lay.coef;
+  CombineArgs<T> A;
+  A.ncol = 2 * na;
+  A.nfirst = na;
+  A.use_gamma = h->scaling;
+  A.gamma = h->scaling_factor;
+  A.alpha = alpha;
+  A.beta = beta;
+  A.coef = coef;
+  if (na > 0) {
+    const T *cols[kMaxCols];
+    for (int i = 0; i < na; ++i) {
+      cols[i] = col<T>(h->S, h->ld, O.ord[i]);
+      cols[na + i] = col<T>(h->Y, h->ld, O.ord[i]);
+    }
+    MXLO_TRY(panel_dots<T>(ctx, cols, 2 * na, x, h->n, dots));
+    hipLaunchKernelGGL(inv_coef_kernel, dim3(1), dim3(64), 0, ctx->stream, dots, coef,
+                       h->dsc + h->lay.SY, h->dsc + h->lay.YS, h->dsc + h->lay.YY,
+                       h->dsc + h->lay.alpha, O);
+    MXLO_LAUNCH_CHECK();
+    for (int i = 0; i < na; ++i) {
+      A.cols[i] = col<T>(h->Y, h->ld, O.ord[i]);               // y, newest -> oldest
+      A.cols[na + i] = col<T>(h->S, h->ld, O.ord[na - 1 - i]); // s, oldest -> newest
+    }
+  }  // no pairs: ncol == 0 and `q .*= scaling_factor` still executes (γ == 1 after reset!)
+  return launch_combine<T, CM_INV>(ctx, res, x, (const T *)nullptr, A, h->n, flags);
+}
+
+template <typename T>
+int32_t inv_mul_reforder(mxlo_qn *h, T *res, const T *x, double alpha, double beta, int32_t flags) {
+  // src/lbfgs.jl:127-153 statement by statement; q lives in h->tmp (data.Ax)
+  mxlo_ctx *ctx = h->ctx;
+  T *q = (T *)h->tmp;
+  const int64_t n = h->n;
+  MXLO_TRY((launch_map<T, 1, false, false>(ctx, q, x, (const T *)nullptr, n, CopyOp<T>{})));
+  double *dots = h->dsc + h->lay.dots, *al = h->dsc + h->lay.alpha;
+  OrdArgs O;
+  fill_ord(h, O, true);
+  for (int i = 0; i < O.na; ++i) {
+    const int k = O.ord[i];
+    const T *sk = col<T>(h->S, h->ld, k), *yk = col<T>(h->Y, h->ld, k);
+    const T *cols[1] = {sk};
+    MXLO_TRY(panel_dots<T>(ctx, cols, 1, q, n, dots));
+    InvStep1Op<T> op{dots, al + k, (T)h->ys[k], T(0)};
+    MXLO_TRY((launch_map<T, 1, true, false>(ctx, q, yk, (const T *)nullptr, n, op)));
+  }
+  if (h->scaling) {
+    MXLO_TRY((launch_map<T, 0, true, false>(ctx, q, (const T *)nullptr, (const T *)nullptr, n,
+                                            ScaleOp<T, T>{(T)h->scaling_factor})));
+  }
+  for (int i = O.na - 1; i >= 0; --i) {
+    const int k = O.ord[i];
+    const T *sk = col<T>(h->S, h->ld, k), *yk = col<T>(h->Y, h->ld, k);
+    const T *cols[1] = {yk};
+    MXLO_TRY(panel_dots<T>(ctx, cols, 1, q, n, dots));
+    InvStep2Op<T> op{dots, al + k, (T)h->ys[k], T(0)};
+    MXLO_TRY((launch_map<T, 1, true, false>(ctx, q, sk, (const T *)nullptr, n, op)));
+  }
+  return dispatch_ct<T>(beta, flags, [&]<typename CT, bool B0>() -> int32_t {
+    AxpbyOp<T, CT, B0> op{(CT)alpha, (CT)beta};
+    return launch_map<T, 1, !B0, false>(ctx, res, q, (const T *)nullptr, n, op);
+  });
+}
+
+template <typename T>
+int32_t fwd_mul(mxlo_qn *h, T *res, const T *x, double alpha, double beta, int32_t flags) {
+  mxlo_ctx *ctx = h->ctx;
+  OrdArgs O;
+  fill_ord(h, O, /*newest_first=*/false);
+  const int na = O.na;
+  double *dots = h->dsc + h->lay.dots, *coef = h->dsc + h->lay.coef;
+  CombineArgs<T> A;
+  A.ncol = 2 * na;
+  A.nfirst = 0;
+  A.use_gamma = h->scaling;
+  A.gamma = h->scaling_factor;
+  A.alpha = alpha;
+  A.beta = beta;
+  A.coef = coef;
+  if (na > 0) {
+    for (int i = 0; i < na; ++i) {  // pair order (b_k, a_k): coef = (bx, ax)
+      A.cols[2 * i] = col<T>(h->B, h->ld, O.ord[i]);
+      A.cols[2 * i + 1] = col<T>(h->A, h->ld, O.ord[i]);
+    }
+    MXLO_TRY(panel_dots<T>(ctx, A.cols, 2 * na, x, h->n, dots));  // dots against x: independent
+    hipLaunchKernelGGL(copy_coef_kernel, dim3(1), dim3(64), 0, ctx->stream, dots, coef, 2 * na,
+                       (int)(h->dtype == MXLO_F32));
+    MXLO_LAUNCH_CHECK();
+  }
+  return launch_combine<T, CM_FWD>(ctx, res, x, (const T *)nullptr, A, h->n, flags);
+}
+
+template <typename T>
+int32_t lsr1_mul(mxlo_qn *h, T *res, const T *x, double alpha, double beta, int32_t flags) {
+  mxlo_ctx *ctx = h->ctx;
+  OrdArgs O;
+  fill_ord(h, O, false);
+  const int na = O.na;
+  double *dots = h->dsc + h->lay.dots, *coef = h->dsc + h->lay.coef;
+  CombineArgs<T> A;
+  A.ncol = na;
+  A.nfirst = 0;
+  A.use_gamma = 1;
+  A.gamma = h->scaling_factor;  // divided unconditionally (== 1 when scaling is off)
+  A.alpha = alpha;
+  A.beta = beta;
+  A.coef = coef;
+  if (na > 0) {
+    for (int i = 0; i < na; ++i) A.cols[i] = col<T>(h->A, h->ld, O.ord[i]);
+    MXLO_TRY(panel_dots<T>(ctx, A.cols, na, x, h->n, dots));
+    const int ct_f32 = (sizeof(T) == 4 && !(flags & MXLO_SCALARS_F64)) ? 1 : 0;
+    hipLaunchKernelGGL(lsr1_coef_kernel, dim3(1), dim3(64), 0, ctx->stream, dots, coef,
+                       h->dsc + h->lay.as_, O, alpha, ct_f32);
+    MXLO_LAUNCH_CHECK();
+  }
+  return launch_combine<T, CM_LSR1>(ctx, res, x, (const T *)nullptr, A, h->n, flags);
+}
+
+template <typename T>
+int32_t qn_mul_t(mxlo_qn *h, T *res, const T *x, double alpha, double beta, int32_t flags) {
+  if (h->dtype == MXLO_F32 && !(flags & MXLO_SCALARS_F64)) {
+    alpha = (double)(float)alpha;
+    beta = (double)(float)beta;
+  }
+  switch (h->kind) {
+    case MXLO_QN_LBFGS_INV:
+      return h->mode == MXLO_INV_REFORDER ? inv_mul_reforder<T>(h, res, x, alpha, beta, flags)
+                                          : inv_mul_twopass<T>(h, res, x, alpha, beta, flags);
+    case MXLO_QN_LBFGS_FWD: return fwd_mul<T>(h, res, x, alpha, beta, flags);
+    case MXLO_QN_LSR1: return lsr1_mul<T>(h, res, x, alpha, beta, flags);
+  }
+  return MXLO_EINVAL;
+}
+
+// ---- push! ------------------------------------------------------------------------------------
+int32_t read_scalars(mxlo_qn *h, const double *dev, double *host, int count) {
+  MXLO_HIP(hipMemcpyAsync(host, dev, sizeof(double) * count, hipMemcpyDeviceToHost, h->ctx->stream));
+  MXLO_HIP(hipStreamSynchronize(h->ctx->stream));
+  return MXLO_OK;
+}
+
+template <typename T>
+inline double rT(double v) { return sizeof(T) == 4 ? (double)(float)v : v; }
+
+// push_common! — src/lbfgs.jl:210-255 (ys, yy already known on the host)
+template <typename T>
+int32_t lbfgs_push_common(mxlo_qn *h, const T *s, const T *y, double ys, double yy) {
+  mxlo_ctx *ctx = h->ctx;
+  const int64_t n = h->n, ins = h->insert0, mem = h->mem;
+  T *si = col<T>(h->S, h->ld, ins), *yi = col<T>(h->Y, h->ld, ins);
+  MXLO_HIP(hipMemcpyAsync(si, s, sizeof(T) * n, hipMemcpyDeviceToDevice, ctx->stream));  // :220
+  MXLO_HIP(hipMemcpyAsync(yi, y, sizeof(T) * n, hipMemcpyDeviceToDevice, ctx->stream));  // :221
+  h->ys[ins] = ys;                                                                       // :222
+  h->age[ins] = ++h->pushes;
+  if (h->scaling) h->scaling_factor = rT<T>(ys / yy);                                    // :225
+  h->G_valid = false;
+  double *dots = h->dsc + h->lay.dots;
+  if (h->kind == MXLO_QN_LBFGS_INV) {
+    // Gram columns for the two-pass apply: S'y_new, Y'y_new (x = y_new), Y's_new (x = s_new)
+    const T *cols[kMaxCols];
+    for (int k = 0; k < mem; ++k) cols[k] = col<T>(h->S, h->ld, k);
+    MXLO_TRY(panel_dots<T>(ctx, cols, (int)mem, yi, n, h->dsc + h->lay.SY + ins * mem));
+    for (int k = 0; k < mem; ++k) cols[k] = col<T>(h->Y, h->ld, k);
+    MXLO_TRY(panel_dots<T>(ctx, cols, (int)mem, yi, n, h->dsc + h->lay.YY + ins * mem));
+    MXLO_TRY(panel_dots<T>(ctx, cols, (int)mem, si, n, h->dsc + h->lay.YS + ins * mem));
+    return MXLO_OK;
+  }
+  // forward: b[insert] = y ./ sqrt(ys) (:232), then rebuild every a[k] (:236-250)
+  T *bi = col<T>(h->B, h->ld, ins);
+  const T sq = sizeof(T) == 8 ? (T)std::sqrt(ys) : (T)sqrtf((float)ys);
+  MXLO_TRY((launch_map<T, 1, false, false>(ctx, bi, yi, (const T *)nullptr, n, DivConstOp<T>{sq})));
+  {  // norm_b[insert]^2 kept on the device (lazy: read by get_scalars)
+    const T *cols[1] = {bi};
+    MXLO_TRY(panel_dots<T>(ctx, cols, 1, bi, n, h->dsc + h->lay.misc + 16 + ins));
+  }
+  double *coef = h->dsc + h->lay.coef;
+  int older[kMaxMem];
+  int nold = 0;
+  for (int64_t i = 1; i <= mem; ++i) {
+    const int64_t k = (ins + i) % mem;  // :237 (0-based)
+    if (h->ys[k] == 0) continue;
+    T *ak = col<T>(h->A, h->ld, k);
+    const T *sk = col<T>(h->S, h->ld, k);
+    CombineArgs<T> A;
+    A.ncol = 2 * nold;
+    A.nfirst = 0;
+    A.use_gamma = 1;
+    A.gamma = h->scaling_factor;  // :239 divides unconditionally (gamma == 1 without scaling)
+    A.alpha = 1;
+    A.beta = 0;
+    A.coef = coef;
+    if (nold > 0) {
+      for (int j = 0; j < nold; ++j) {
+        A.cols[2 * j] = col<T>(h->B, h->ld, older[j]);
+        A.cols[2 * j + 1] = col<T>(h->A, h->ld, older[j]);
+      }
+      MXLO_TRY(panel_dots<T>(ctx, A.cols, 2 * nold, sk, n, dots));  // dot(b[l], s[k]), dot(a[l], s[k])
+      hipLaunchKernelGGL(copy_coef_kernel, dim3(1), dim3(64), 0, ctx->stream, dots, coef, 2 * nold,
+                         (int)(sizeof(T) == 4));
+      MXLO_LAUNCH_CHECK();
+    }
+    MXLO_TRY((launch_combine<T, CM_AFWD>(ctx, ak, sk, (const T *)nullptr, A, n, 0)));
+    const T *cols[1] = {sk};
+    MXLO_TRY(panel_dots<T>(ctx, cols, 1, ak, n, dots + 100));        // dot(s[k], a[k])
+    MXLO_TRY((launch_map<T, 0, true, false>(ctx, ak, (const T *)nullptr, (const T *)nullptr, n,
+                                            DivSqrtDevOp<T>{dots + 100, T(0)})));  // :248
+    older[nold++] = (int)k;
+  }
+  return MXLO_OK;
+}
+
+template <typename T>
+int32_t lbfgs_push(mxlo_qn *h, const T *s, const T *y, int32_t *accepted) {
+  mxlo_ctx *ctx = h->ctx;
+  double *misc = h->dsc + h->lay.misc;
+  const T *cols[2] = {s, y};
+  MXLO_TRY(panel_dots<T>(ctx, cols, 2, y, h->n, misc));  // misc[0] = dot(y,s), misc[1] = dot(y,y)
+  double hs[2];
+  MXLO_TRY(read_scalars(h, misc, hs, 2));
+  const double ys = rT<T>(hs[0]), yy = rT<T>(hs[1]);
+  if (ys <= (double)eps_of<T>()) {  // src/lbfgs.jl:281-284
+    *accepted = 0;
+    return MXLO_OK;
+  }
+  *accepted = 1;
+  MXLO_TRY(lbfgs_push_common<T>(h, s, y, ys, yy));
+  h->insert0 = (h->insert0 + 1) % h->mem;  // :253
+  return MXLO_OK;
+}
+
+// Powell damping shared by both damped pushes: given ys and sBs decide theta (src/lbfgs.jl:307-314)
+template <typename T>
+bool powell_theta(const mxlo_qn *h, double ys, double sBs, T *theta) {
+  const T s2 = (T)h->sigma2, s3 = (T)h->sigma3, ysT = (T)ys, sBsT = (T)sBs;
+  if (ysT < ((T)1 - s2) * sBsT) {
+    *theta = s2 * sBsT / (sBsT - ysT);
+    return true;
+  }
+  if (ysT > ((T)1 + s3) * sBsT) {
+    *theta = s3 * sBsT / (ysT - sBsT);
+    return true;
+  }
+  return false;
+}
+
+template <typename T>
+int32_t lbfgs_push_damped(mxlo_qn *h, const T *s, T *y_mut, const T *y_const, double alpha,
+                          const T *g, T *Bs, int32_t *accepted) {
+  mxlo_ctx *ctx = h->ctx;
+  const int64_t n = h->n;
+  const bool inverse = h->kind == MXLO_QN_LBFGS_INV;
+  const T *y = inverse ? y_mut : y_const;
+  if (inverse) {  // Bs .= -α .* g  (:341)
+    MXLO_TRY((launch_map<T, 1, false, false>(ctx, Bs, g, (const T *)nullptr, n, NegScaleOp<T>{(T)(-alpha)})));
+  } else {        // mul!(Bs, op, s, one(T), zero(T))  (:305)
+    MXLO_TRY(fwd_mul<T>(h, Bs, s, 1.0, 0.0, 0));
+  }
+  double *misc = h->dsc + h->lay.misc;
+  const T *cols[3] = {s, y, Bs};
+  MXLO_TRY(panel_dots<T>(ctx, cols, 1, y, n, misc));          // dot(y, s)
+  MXLO_TRY(panel_dots<T>(ctx, cols + 2, 1, s, n, misc + 1));  // dot(s, Bs)
+  double hs[2];
+  MXLO_TRY(read_scalars(h, misc, hs, 2));
+  double ys = rT<T>(hs[0]);
+  const double sBs = rT<T>(hs[1]);
+  T theta;
+  const T *yuse = y;
+  if (powell_theta<T>(h, ys, sBs, &theta)) {
+    T *ydst = inverse ? y_mut : (T *)h->tmp2;  // forward rebinds y (:316), inverse mutates it (:351)
+    MXLO_TRY((launch_map<T, 2, false, false>(ctx, ydst, y, Bs, n, DampOp<T>{theta, (T)1 - theta})));
+    ys = (double)((theta * (T)ys) + (((T)1 - theta) * (T)sBs));
+    yuse = ydst;
+  }
+  const T *cy[1] = {yuse};
+  MXLO_TRY(panel_dots<T>(ctx, cy, 1, yuse, n, misc + 2));     // dot(y, y) for scaling (:225)
+  double yyh[1];
+  MXLO_TRY(read_scalars(h, misc + 2, yyh, 1));
+  *accepted = 1;  // the damped pushes have no ys <= eps rejection in the reference
+  MXLO_TRY(lbfgs_push_common<T>(h, s, yuse, ys, rT<T>(yyh[0])));
+  h->insert0 = (h->insert0 + 1) % h->mem;
+  return MXLO_OK;
+}
+
+// push!(op::LSR1Operator, s, y) — src/lsr1.jl:119-184
+template <typename T>
+int32_t lsr1_push(mxlo_qn *h, const T *s, const T *y, int32_t *accepted) {
+  mxlo_ctx *ctx = h->ctx;
+  const int64_t n = h->n, mem = h->mem;
+  T *ymBs = (T *)h->tmp;
+  MXLO_HIP(hipMemcpyAsync(ymBs, y, sizeof(T) * n, hipMemcpyDeviceToDevice, ctx->stream));  // :124
+  MXLO_TRY(lsr1_mul<T>(h, ymBs, s, -1.0, 1.0, 0));                                         // :125
+  double *misc = h->dsc + h->lay.misc;
+  const T *c3[3] = {y, s, ymBs};
+  MXLO_TRY(panel_dots<T>(ctx, c3, 3, s, n, misc));          // y's, s's, ymBs's
+  const T *c1[1] = {y};
+  MXLO_TRY(panel_dots<T>(ctx, c1, 1, y, n, misc + 3));      // y'y
+  const T *c2[1] = {ymBs};
+  MXLO_TRY(panel_dots<T>(ctx, c2, 1, ymBs, n, misc + 4));   // ||ymBs||^2
+  double hs[5];
+  MXLO_TRY(read_scalars(h, misc, hs, 5));
+  const T ys = (T)hs[0], sNorm = (T)std::sqrt(rT<T>(hs[1])), yy = (T)hs[3];
+  const T ymBs_s = (T)hs[2], ymBsNorm = (T)std::sqrt(rT<T>(hs[4]));
+  const T eps = eps_of<T>();
+  const bool well_defined = std::fabs((double)ymBs_s) >= (double)(eps + eps * ymBsNorm * sNorm);  // :131
+  bool sufficient_curvature = true, scaling_condition = true;
+  if (h->scaling) {
+    const T yNorm = (T)std::sqrt((double)yy);                                              // :136
+    sufficient_curvature = std::fabs((double)ys) >= (double)(eps * yNorm * sNorm);         // :137
+    if (sufficient_curvature) {
+      const T sf = ys / yy;                                                                // :139
+      T *t2 = (T *)h->tmp2;
+      MXLO_TRY((launch_map<T, 2, false, false>(ctx, t2, y, s, n, YmSOverOp<T>{sf})));      // :140
+      const T *ct[1] = {t2};
+      MXLO_TRY(panel_dots<T>(ctx, ct, 1, t2, n, misc + 5));
+      double nn[1];
+      MXLO_TRY(read_scalars(h, misc + 5, nn, 1));
+      scaling_condition = (T)std::sqrt(rT<T>(nn[0])) >= eps * yNorm * sNorm;               // :141
+    }
+  }
+  if (!(well_defined && sufficient_curvature && scaling_condition)) {                      // :145-149
+    *accepted = 0;
+    return MXLO_OK;
+  }
+  *accepted = 1;
+  const int64_t ins = h->insert0;
+  MXLO_HIP(hipMemcpyAsync(col<T>(h->S, h->ld, ins), s, sizeof(T) * n, hipMemcpyDeviceToDevice, ctx->stream));
+  MXLO_HIP(hipMemcpyAsync(col<T>(h->Y, h->ld, ins), y, sizeof(T) * n, hipMemcpyDeviceToDevice, ctx->stream));
+  h->ys[ins] = (double)ys;                                                                 // :153
+  h->age[ins] = ++h->pushes;
+  if (h->scaling) h->scaling_factor = (double)(ys / yy);                                   // :158
+  h->insert0 = (ins + 1) % mem;                                                            // :163
+  // rebuild the rank-1 terms (:166-181)
+  double *dots = h->dsc + h->lay.dots, *coef = h->dsc + h->lay.coef, *as_ = h->dsc + h->lay.as_;
+  OrdArgs O;
+  fill_ord(h, O, false);
+  int nold = 0;
+  for (int i = 0; i < O.na; ++i) {
+    const int k = O.ord[i];
+    T *ak = col<T>(h->A, h->ld, k);
+    const T *sk = col<T>(h->S, h->ld, k), *yk = col<T>(h->Y, h->ld, k);
+    CombineArgs<T> A;
+    A.ncol = nold;
+    A.nfirst = 0;
+    A.use_gamma = 1;
+    A.gamma = h->scaling_factor;  // :169 divides unconditionally
+    A.alpha = 1;
+    A.beta = 0;
+    A.coef = coef;
+    if (nold > 0) {
+      OrdArgs Ol = O;
+      Ol.na = nold;  // the first `nold` entries of ord are the older slots
+      for (int j = 0; j < nold; ++j) A.cols[j] = col<T>(h->A, h->ld, O.ord[j]);
+      MXLO_TRY(panel_dots<T>(ctx, A.cols, nold, sk, n, dots));                             // dot(a[l], s[k])
+      hipLaunchKernelGGL(div_as_kernel, dim3(1), dim3(64), 0, ctx->stream, dots, coef, as_, Ol);  // :173
+      MXLO_LAUNCH_CHECK();
+    }
+    MXLO_TRY((launch_combine<T, CM_ASR1>(ctx, ak, sk, yk, A, n, 0)));                      // :169,174
+    const T *ca[1] = {ak};
+    MXLO_TRY(panel_dots<T>(ctx, ca, 1, sk, n, as_ + k));                                   // :177 as[k]
+    MXLO_TRY(panel_dots<T>(ctx, ca, 1, ak, n, h->dsc + h->lay.misc + 16 + k));             // ||a_k||^2 (opnorm)
+    nold++;
+  }
+  return MXLO_OK;
+}
+
+// ---- solve_shifted_system! in coefficient space (SURVEY §8a equivalence (iii)) -------------------
+// u_t, t = 0..nu-1: active slots oldest->newest, each contributing (a_k, b_k) with signs (+1, -1).
+//   G = U'U (cached per state), g = U'b, then the reference's recursion (src/utilities.jl:226-246)
+//   on coefficient vectors P[i] (p_i = sum_j P[i][j] u_j), finally x = x0*b + U cx.
+__global__ void shifted_coef_kernel(const double *__restrict__ G, const double *__restrict__ gvec,
+                                    double *__restrict__ cx, int nu, double x0, int is_f32) {
+  extern __shared__ double sh[];  // P[nu*nu], v[nu]
+  if (threadIdx.x != 0) return;
+  double *P = sh, *v = sh + nu * nu;
+  for (int j = 0; j < nu; ++j) cx[j] = 0.0;
+  for (int i = 0; i < nu; ++i) {
+    const int sign_i = (i & 1) ? -1 : 1;
+    for (int j = 0; j < nu; ++j) P[i * nu + j] = 0.0;
+    P[i * nu + i] = x0;                                         // p_i = x0 * u_i          (:231)
+    int sign_t = 1;
+    for (int t = 0; t < i; ++t) {
+      double c0 = 0.0;                                          // dot(p_t, u_i)           (:235)
+      for (int j = 0; j <= t; ++j) c0 += P[t * nu + j] * G[j * nu + i];
+      const double c2 = (sign_t * v[t]) * c0;                   // (:236-237)
+      for (int j = 0; j <= t; ++j) P[i * nu + j] += c2 * P[t * nu + j];   // (:238)
+      sign_t = -sign_t;
+    }
+    double up = 0.0;                                            // dot(u_i, p_i)
+    for (int j = 0; j <= i; ++j) up += P[i * nu + j] * G[i * nu + j];
+    v[i] = rnd(1.0 / (1.0 - sign_i * up), is_f32);              // (:242)
+    double pb = 0.0;                                            // p_i' b
+    for (int j = 0; j <= i; ++j) pb += P[i * nu + j] * gvec[j];
+    const double c = (sign_i * v[i]) * pb;                      // (:243-244)
+    for (int j = 0; j <= i; ++j) cx[j] += c * P[i * nu + j];
+  }
+  cx[kMaxCols] = x0;  // c0 slot read by CM_AXPYS
+}
+
+template <typename T>
+int32_t solve_shifted_t(mxlo_qn *h, T *x, const T *b, double sigma) {
+  mxlo_ctx *ctx = h->ctx;
+  const int64_t n = h->n;
+  OrdArgs O;
+  fill_ord(h, O, false);
+  // NOTE: the reference walks slots k = mod(insert + j - 1, mem) + 1, j = 1..mem (utilities.jl:228),
+  // i.e. starting one slot AFTER the oldest-first order used by mul!; with a full memory that is
+  // (oldest+1 ... newest, oldest). The recursion is order-dependent only through rounding (the
+  // compact form sums rank-one terms), and empty slots contribute nothing; we follow the
+  // reference order exactly.
+  int ord2[kMaxMem], na = 0;
+  for (int64_t j = 1; j <= h->mem; ++j) {
+    const int64_t k = (h->insert0 + j) % h->mem;
+    if (h->ys[k] != 0) ord2[na++] = (int)k;
+  }
+  const int nu = 2 * na;
+  const T *ucols[kMaxCols];
+  for (int i = 0; i < na; ++i) {
+    ucols[2 * i] = col<T>(h->A, h->ld, ord2[i]);      // sign +1 -> a[k]   (:229)
+    ucols[2 * i + 1] = col<T>(h->B, h->ld, ord2[i]);  // sign -1 -> b[k]
+  }
+  double *G = h->dsc + h->lay.G, *gv = h->dsc + h->lay.g, *cx = h->dsc + h->lay.coef;
+  if (!h->G_valid && nu > 0) {
+    for (int i = 0; i < nu; ++i)  // row i: dot(u_j, u_i) for all j (symmetric; full rows keep it simple)
+      MXLO_TRY(panel_dots<T>(ctx, ucols, nu, ucols[i], n, G + (int64_t)i * nu));
+    h->G_valid = true;
+  }
+  const double g_inv = rT<T>(1.0 / h->scaling_factor);                 // :219
+  const double x0 = rT<T>(1.0 / (g_inv + sigma));                      // :220
+  if (nu > 0) MXLO_TRY(panel_dots<T>(ctx, ucols, nu, b, n, gv));
+  hipLaunchKernelGGL(shifted_coef_kernel, dim3(1), dim3(64), sizeof(double) * (nu * nu + nu + 1),
+                     ctx->stream, G, gv, cx, nu, x0, (int)(sizeof(T) == 4));
+  MXLO_LAUNCH_CHECK();
+  CombineArgs<T> A;
+  A.ncol = nu;
+  A.nfirst = 0;
+  A.use_gamma = 0;
+  A.gamma = 1;
+  A.alpha = 1;
+  A.beta = 0;
+  A.coef = cx;
+  for (int i = 0; i < nu; ++i) A.cols[i] = ucols[i];
+  return launch_combine<T, CM_AXPYS>(ctx, x, b, (const T *)nullptr, A, n, 0);
+}
+
+template <typename T>
+int32_t diag_t(mxlo_qn *h, T *d) {
+  OrdArgs O;
+  fill_ord(h, O, false);
+  CombineArgs<T> A;
+  A.nfirst = 0;
+  A.use_gamma = h->scaling;
+  A.gamma = h->scaling_factor;
+  A.alpha = 1;
+  A.beta = 0;
+  if (h->kind == MXLO_QN_LBFGS_FWD) {
+    A.ncol = 2 * O.na;
+    A.coef = h->dsc + h->lay.coef;
+    for (int i = 0; i < O.na; ++i) {
+      A.cols[2 * i] = col<T>(h->B, h->ld, O.ord[i]);
+      A.cols[2 * i + 1] = col<T>(h->A, h->ld, O.ord[i]);
+    }
+    return launch_combine<T, CM_DIAG_FWD>(h->ctx, d, (const T *)nullptr, (const T *)nullptr, A, h->n, 0);
+  }
+  // L-SR1: coef[i] = as[ord[i]]
+  A.ncol = O.na;
+  double *coef = h->dsc + h->lay.coef;
+  A.coef = coef;
+  for (int i = 0; i < O.na; ++i) {
+    A.cols[i] = col<T>(h->A, h->ld, O.ord[i]);
+    MXLO_HIP(hipMemcpyAsync(coef + i, h->dsc + h->lay.as_ + O.ord[i], sizeof(double),
+                            hipMemcpyDeviceToDevice, h->ctx->stream));
+  }
+  return launch_combine<T, CM_DIAG_SR1>(h->ctx, d, (const T *)nullptr, (const T *)nullptr, A, h->n, 0);
+}
+
+}  // namespace
+
+// ==================================================================================== C ABI
+MXLO_API int32_t mxlo_qn_create(mxlo_ctx *ctx, int32_t kind, int32_t dtype, int64_t n, int64_t mem,
+                                int32_t scaling, int32_t damped, double sigma2, double sigma3,
+                                mxlo_qn **out) {
+  MXLO_REQUIRE(ctx && out, MXLO_EINVAL, "mxlo_qn_create: NULL argument");
+  MXLO_REQUIRE(kind >= MXLO_QN_LBFGS_INV && kind <= MXLO_QN_LSR1, MXLO_EINVAL, "bad kind %d", kind);
+  MXLO_REQUIRE(dtype == MXLO_F64 || dtype == MXLO_F32, MXLO_EINVAL, "bad dtype %d", dtype);
+  MXLO_REQUIRE(n >= 0, MXLO_ESHAPE, "n < 0");
+  if (mem < 1) mem = 1;  // max(mem, 1), src/lbfgs.jl:37
+  MXLO_REQUIRE(mem <= kMaxMem, MXLO_EINVAL, "mem = %lld exceeds the supported maximum %d",
+               (long long)mem, kMaxMem);
+  mxlo_qn *h = new mxlo_qn();
+  h->ctx = ctx;
+  h->kind = kind;
+  h->dtype = dtype;
+  h->n = n;
+  h->mem = mem;
+  const int64_t es = dtype == MXLO_F64 ? 8 : 4;
+  const int64_t vec = 16 / es;
+  h->ld = ((n + vec - 1) / vec) * vec;
+  if (h->ld == 0) h->ld = vec;
+  h->scaling = scaling != 0;
+  h->damped = damped != 0;
+  h->sigma2 = sigma2;
+  h->sigma3 = sigma3;
+  h->mode = ctx->tune.lbfgs_inv_mode;
+  h->ys.assign(mem, 0.0);
+  h->age.assign(mem, 0);
+  h->lay = DscLayout(mem);
+  const size_t pbytes = (size_t)h->ld * mem * es;
+  hipError_t e = hipSuccess;
+  auto alloc = [&](void **p, size_t bytes) {
+    if (e == hipSuccess) {
+      e = hipMalloc(p, bytes);
+      if (e == hipSuccess) e = hipMemsetAsync(*p, 0, bytes, ctx->stream);
+    }
+  };
+  alloc(&h->S, pbytes);
+  alloc(&h->Y, pbytes);
+  if (kind != MXLO_QN_LBFGS_INV) alloc(&h->A, pbytes);
+  if (kind == MXLO_QN_LBFGS_FWD) alloc(&h->B, pbytes);
+  alloc(&h->tmp, (size_t)h->ld * es);
+  alloc(&h->tmp2, (size_t)h->ld * es);
+  alloc((void **)&h->dsc, sizeof(double) * h->lay.total);
+  if (e != hipSuccess) {
+    set_error("mxlo_qn_create: device allocation failed: %s", hipGetErrorString(e));
+    mxlo_qn_destroy(h);
+    return MXLO_ENOMEM;
+  }
+  *out = h;
+  return MXLO_OK;
+}
+
+MXLO_API int32_t mxlo_qn_destroy(mxlo_qn *h) {
+  if (!h) return MXLO_OK;
+  (void)hipStreamSynchronize(h->ctx->stream);
+  for (void *p : {h->S, h->Y, h->A, h->B, h->tmp, h->tmp2, (void *)h->dsc})
+    if (p) (void)hipFree(p);
+  delete h;
+  return MXLO_OK;
+}
+
+MXLO_API int32_t mxlo_qn_set_mode(mxlo_qn *h, int32_t mode) {
+  MXLO_REQUIRE(h, MXLO_EINVAL, "handle is NULL");
+  MXLO_REQUIRE(mode == MXLO_INV_TWOPASS || mode == MXLO_INV_REFORDER, MXLO_EINVAL, "bad mode");
+  h->mode = mode;
+  return MXLO_OK;
+}
+
+MXLO_API int32_t mxlo_qn_mul(mxlo_qn *h, void *res, const void *x, double alpha, double beta,
+                             int32_t flags) {
+  MXLO_REQUIRE(h && (h->n == 0 || (res && x)), MXLO_EINVAL, "mxlo_qn_mul: NULL argument");
+  if (h->dtype == MXLO_F64) return qn_mul_t<double>(h, (double *)res, (const double *)x, alpha, beta, flags);
+  return qn_mul_t<float>(h, (float *)res, (const float *)x, alpha, beta, flags);
+}
+
+MXLO_API int32_t mxlo_qn_push(mxlo_qn *h, const void *s, const void *y, int32_t *accepted) {
+  MXLO_REQUIRE(h && s && y && accepted, MXLO_EINVAL, "mxlo_qn_push: NULL argument");
+  if (h->kind == MXLO_QN_LSR1) {
+    if (h->dtype == MXLO_F64) return lsr1_push<double>(h, (const double *)s, (const double *)y, accepted);
+    return lsr1_push<float>(h, (const float *)s, (const float *)y, accepted);
+  }
+  MXLO_REQUIRE(!h->damped, MXLO_ESTATE,
+               "damped operator: use mxlo_qn_push_damped_fwd / mxlo_qn_push_damped_inv");
+  if (h->dtype == MXLO_F64) return lbfgs_push<double>(h, (const double *)s, (const double *)y, accepted);
+  return lbfgs_push<float>(h, (const float *)s, (const float *)y, accepted);
+}
+
+MXLO_API int32_t mxlo_qn_push_damped_fwd(mxlo_qn *h, const void *s, const void *y, void *Bs,
+                                         int32_t *accepted) {
+  MXLO_REQUIRE(h && s && y && Bs && accepted, MXLO_EINVAL, "NULL argument");
+  MXLO_REQUIRE(h->damped, MXLO_ESTATE, "This push! should be used for damped operators");
+  MXLO_REQUIRE(h->kind == MXLO_QN_LBFGS_FWD, MXLO_ESTATE,
+               "This function be used for forward operators. Use push!(op, s, y, α, g, Bs) instead.");
+  if (h->dtype == MXLO_F64)
+    return lbfgs_push_damped<double>(h, (const double *)s, nullptr, (const double *)y, 0.0, nullptr,
+                                     (double *)Bs, accepted);
+  return lbfgs_push_damped<float>(h, (const float *)s, nullptr, (const float *)y, 0.0, nullptr,
+                                  (float *)Bs, accepted);
+}
+
+MXLO_API int32_t mxlo_qn_push_damped_inv(mxlo_qn *h, const void *s, void *y, double alpha,
+                                         const void *g, void *Bs, int32_t *accepted) {
+  MXLO_REQUIRE(h && s && y && g && Bs && accepted, MXLO_EINVAL, "NULL argument");
+  MXLO_REQUIRE(h->damped, MXLO_ESTATE, "This push! should be used for damped operators");
+  MXLO_REQUIRE(h->kind == MXLO_QN_LBFGS_INV, MXLO_ESTATE,
+               "This function be used for inverse operators. Use push!(op, s, y, Bs) instead.");
+  if (h->dtype == MXLO_F64)
+    return lbfgs_push_damped<double>(h, (const double *)s, (double *)y, nullptr, alpha,
+                                     (const double *)g, (double *)Bs, accepted);
+  return lbfgs_push_damped<float>(h, (const float *)s, (float *)y, nullptr, alpha, (const float *)g,
+                                  (float *)Bs, accepted);
+}
+
+MXLO_API int32_t mxlo_qn_solve_shifted(mxlo_qn *h, void *x, const void *b, double sigma) {
+  MXLO_REQUIRE(h && (h->n == 0 || (x && b)), MXLO_EINVAL, "NULL argument");
+  MXLO_REQUIRE(h->kind == MXLO_QN_LBFGS_FWD, MXLO_ESTATE,
+               "solve_shifted_system! is defined for forward L-BFGS operators");
+  MXLO_REQUIRE(!(sigma < 0), MXLO_EDOMAIN, "σ must be nonnegative");
+  if (h->dtype == MXLO_F64) return solve_shifted_t<double>(h, (double *)x, (const double *)b, sigma);
+  return solve_shifted_t<float>(h, (float *)x, (const float *)b, (double)(float)sigma);
+}
+
+MXLO_API int32_t mxlo_qn_diag(mxlo_qn *h, void *d) {
+  MXLO_REQUIRE(h && (h->n == 0 || d), MXLO_EINVAL, "NULL argument");
+  MXLO_REQUIRE(h->kind != MXLO_QN_LBFGS_INV, MXLO_ESTATE,
+               "only the diagonal of a forward L-BFGS approximation is available");
+  if (h->dtype == MXLO_F64) return diag_t<double>(h, (double *)d);
+  return diag_t<float>(h, (float *)d);
+}
+
+MXLO_API int32_t mxlo_qn_reset(mxlo_qn *h) {
+  MXLO_REQUIRE(h, MXLO_EINVAL, "handle is NULL");
+  const size_t es = h->dtype == MXLO_F64 ? 8 : 4;
+  const size_t pbytes = (size_t)h->ld * h->mem * es;
+  for (void *p : {h->S, h->Y, h->A, h->B})
+    if (p) MXLO_HIP(hipMemsetAsync(p, 0, pbytes, h->ctx->stream));
+  MXLO_HIP(hipMemsetAsync(h->dsc, 0, sizeof(double) * h->lay.total, h->ctx->stream));
+  h->ys.assign(h->mem, 0.0);
+  h->age.assign(h->mem, 0);
+  h->pushes = 0;
+  h->scaling_factor = 1.0;
+  h->insert0 = 0;
+  h->G_valid = false;
+  return MXLO_OK;
+}
+
+MXLO_API int32_t mxlo_qn_get_scalars(mxlo_qn *h, double scalars[5], double *ys, double *aux) {
+  MXLO_REQUIRE(h && scalars, MXLO_EINVAL, "NULL argument");
+  const int64_t mem = h->mem;
+  std::vector<double> dev(mem, 0.0), nrm(mem, 0.0);
+  double bound = 1.0;
+  if (h->kind == MXLO_QN_LBFGS_INV) {
+    MXLO_TRY(read_scalars(h, h->dsc + h->lay.alpha, dev.data(), (int)mem));
+    if (h->scaling && h->scaling_factor != 0) bound = 1.0 / h->scaling_factor;
+  } else if (h->kind == MXLO_QN_LBFGS_FWD) {
+    // ‖B‖ <= ‖B0‖ + sum ‖b_i‖²  (src/lbfgs.jl:11, :224-234): norm_b² kept in misc[16+k]
+    MXLO_TRY(read_scalars(h, h->dsc + h->lay.misc + 16, nrm.data(), (int)mem));
+    bound = (h->scaling && h->scaling_factor != 0) ? 1.0 / h->scaling_factor : 1.0;
+    for (int64_t k = 0; k < mem; ++k) {
+      dev[k] = std::sqrt(nrm[k]);
+      if (h->ys[k] != 0) bound += nrm[k];
+    }
+  } else {
+    MXLO_TRY(read_scalars(h, h->dsc + h->lay.as_, dev.data(), (int)mem));
+    MXLO_TRY(read_scalars(h, h->dsc + h->lay.misc + 16, nrm.data(), (int)mem));
+    bound = 1.0;                                                          // src/lsr1.jl:156
+    if (h->scaling && h->scaling_factor != 0) bound = 1.0 / std::fabs(h->scaling_factor);  // :159
+    for (int64_t k = 0; k < mem; ++k)
+      if (h->ys[k] != 0 && dev[k] != 0) bound += nrm[k] / std::fabs(dev[k]);             // :179
+  }
+  scalars[0] = (double)(h->insert0 + 1);
+  scalars[1] = h->scaling_factor;
+  scalars[2] = bound;
+  scalars[3] = (double)mem;
+  scalars[4] = (double)h->n;
+  if (ys)
+    for (int64_t k = 0; k < mem; ++k) ys[k] = h->ys[k];
+  if (aux)
+    for (int64_t k = 0; k < mem; ++k) aux[k] = dev[k];
+  return MXLO_OK;
+}
+
+MXLO_API int32_t mxlo_qn_column(mxlo_qn *h, int32_t which, int64_t k, void **out) {
+  MXLO_REQUIRE(h && out, MXLO_EINVAL, "NULL argument");
+  MXLO_REQUIRE(k >= 0 && k < h->mem, MXLO_EINVAL, "slot out of range");
+  void *p = which == 0 ? h->S : which == 1 ? h->Y : which == 2 ? h->A : which == 3 ? h->B : nullptr;
+  MXLO_REQUIRE(p, MXLO_ESTATE, "panel %d not allocated for this operator kind", which);
+  *out = (char *)p + (size_t)k * h->ld * (h->dtype == MXLO_F64 ? 8 : 4);
+  return MXLO_OK;
+}

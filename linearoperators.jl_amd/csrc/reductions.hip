@@ -23,7 +23,7 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 
-template <typename T, int VEC, int NC, int UNROLL, bool XVEC>
+template <typename T, int VEC, int NC, int UNROLL, bool XVEC, bool NT>
 __global__ void __launch_bounds__(kBlock)
 panel_dots_kernel(ColPtrs<T, NC> cols, const T *__restrict__ x, int64_t head, int64_t nvec,
                   int64_t n, double *__restrict__ partials) {
@@ -45,7 +45,8 @@ panel_dots_kernel(ColPtrs<T, NC> cols, const T *__restrict__ x, int64_t head, in
         if constexpr (VEC == 1) {
           xe[0] = x[head + i];
         } else if constexpr (XVEC) {
-          const V xv = *reinterpret_cast<const V *>(x + head + i * VEC);
+          const V xv = NT ? __builtin_nontemporal_load(reinterpret_cast<const V *>(x + head + i * VEC))
+                          : *reinterpret_cast<const V *>(x + head + i * VEC);
 #pragma unroll
           for (int e = 0; e < VEC; ++e) xe[e] = xv[e];
         } else {  // x has a different 16-byte phase than the panel: element loads for x only
@@ -54,7 +55,9 @@ panel_dots_kernel(ColPtrs<T, NC> cols, const T *__restrict__ x, int64_t head, in
         }
         V cv[NC];
 #pragma unroll
-        for (int c = 0; c < NC; ++c) cv[c] = *reinterpret_cast<const V *>(cols.p[c] + head + i * VEC);
+        for (int c = 0; c < NC; ++c)
+          cv[c] = NT ? __builtin_nontemporal_load(reinterpret_cast<const V *>(cols.p[c] + head + i * VEC))
+                     : *reinterpret_cast<const V *>(cols.p[c] + head + i * VEC);
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
 #pragma unroll
@@ -131,8 +134,13 @@ static int32_t launch_dots(mxlo_ctx *ctx, const T *const *cols, const T *x, int6
   // fewer columns -> more chunks in flight per lane to keep ~the same bytes in flight
   constexpr int UNROLL = NC <= 2 ? 4 : (NC <= 6 ? 2 : 1);
   const int grid = grid_for(ctx, nvec, (int64_t)kBlock * UNROLL, ctx->tune.red_blocks_per_cu);
-  hipLaunchKernelGGL((panel_dots_kernel<T, VEC, NC, UNROLL, XVEC>), dim3(grid), dim3(kBlock), 0,
-                     ctx->stream, cp, x, head, nvec, n, ctx->partials);
+  const bool nt = (int64_t)sizeof(T) * n * (NC + 1) >= ctx->tune.nt_min_bytes;
+  if (nt)
+    hipLaunchKernelGGL((panel_dots_kernel<T, VEC, NC, UNROLL, XVEC, true>), dim3(grid), dim3(kBlock), 0,
+                       ctx->stream, cp, x, head, nvec, n, ctx->partials);
+  else
+    hipLaunchKernelGGL((panel_dots_kernel<T, VEC, NC, UNROLL, XVEC, false>), dim3(grid), dim3(kBlock), 0,
+                       ctx->stream, cp, x, head, nvec, n, ctx->partials);
   MXLO_LAUNCH_CHECK();
   *nblocks_out = grid;
   return MXLO_OK;

@@ -14,13 +14,20 @@
 
 namespace mxlo {
 
-template <typename V>
+// NT = nontemporal (streaming) access: `global_load/store ... nt`. Measured on MI355X at
+// n = 1e8 fp64 (profiles/r01_tune_stream.txt): 2-read+1-write body 5.39 -> 6.34 TB/s, 2-read
+// reduction 6.30 -> 7.03 TB/s. Only used when the operands exceed the caches anyway
+// (Tune::nt_min_bytes); small vectors keep default loads so L2/MALL reuse between the leaves
+// of a combinator survives.
+template <bool NT, typename V>
 __device__ __forceinline__ V ldg(const V *p) {
-  return *p;
+  if constexpr (NT) return __builtin_nontemporal_load(p);
+  else return *p;
 }
-template <typename V>
+template <bool NT, typename V>
 __device__ __forceinline__ void stg(V *p, V v) {
-  *p = v;
+  if constexpr (NT) __builtin_nontemporal_store(v, p);
+  else *p = v;
 }
 
 template <typename T, int VEC>
@@ -51,7 +58,7 @@ __device__ __forceinline__ void vset(typename VecOf<T, VEC>::type &v, int i, T x
 //   __device__ void init();                       // once per thread (load device scalars)
 //   __device__ T operator()(T in0, T in1, T res_old) const;
 // NIN = number of input streams (0,1,2); READ_RES = res is also an input (beta != 0).
-template <typename T, int VEC, int UNROLL, int NIN, bool READ_RES, bool REVERSE, typename Op>
+template <typename T, int VEC, int UNROLL, int NIN, bool READ_RES, bool REVERSE, bool NT, typename Op>
 __global__ void __launch_bounds__(kBlock)
 map_kernel(T *__restrict__ res, const T *__restrict__ in0, const T *__restrict__ in1, int64_t head,
            int64_t nvec, int64_t n, Op op) {
@@ -71,9 +78,9 @@ map_kernel(T *__restrict__ res, const T *__restrict__ in0, const T *__restrict__
 #pragma unroll
       for (int u = 0; u < UNROLL; ++u) {
         const int64_t i = base + (int64_t)u * kBlock;
-        if constexpr (NIN >= 1) a[u] = ldg(av + i);
-        if constexpr (NIN >= 2) b[u] = ldg(bv + i);
-        if constexpr (READ_RES) r[u] = ldg(rv + i);
+        if constexpr (NIN >= 1) a[u] = ldg<NT>(av + i);
+        if constexpr (NIN >= 2) b[u] = ldg<NT>(bv + i);
+        if constexpr (READ_RES) r[u] = ldg<NT>(rv + i);
       }
 #pragma unroll
       for (int u = 0; u < UNROLL; ++u) {
@@ -85,7 +92,7 @@ map_kernel(T *__restrict__ res, const T *__restrict__ in0, const T *__restrict__
           const T r0 = READ_RES ? vget<T, VEC>(r[u], e) : T(0);
           vset<T, VEC>(o, e, op(x0, x1, r0));
         }
-        stg(rv + base + (int64_t)u * kBlock, o);
+        stg<NT>(rv + base + (int64_t)u * kBlock, o);
       }
     } else {
 #pragma unroll
@@ -93,9 +100,9 @@ map_kernel(T *__restrict__ res, const T *__restrict__ in0, const T *__restrict__
         const int64_t i = base + (int64_t)u * kBlock;
         if (i < nvec) {
           V o, aa, bb, rr;
-          if constexpr (NIN >= 1) aa = ldg(av + i);
-          if constexpr (NIN >= 2) bb = ldg(bv + i);
-          if constexpr (READ_RES) rr = ldg(rv + i);
+          if constexpr (NIN >= 1) aa = ldg<NT>(av + i);
+          if constexpr (NIN >= 2) bb = ldg<NT>(bv + i);
+          if constexpr (READ_RES) rr = ldg<NT>(rv + i);
 #pragma unroll
           for (int e = 0; e < VEC; ++e) {
             const T x0 = NIN >= 1 ? vget<T, VEC>(aa, e) : T(0);
@@ -103,7 +110,7 @@ map_kernel(T *__restrict__ res, const T *__restrict__ in0, const T *__restrict__
             const T r0 = READ_RES ? vget<T, VEC>(rr, e) : T(0);
             vset<T, VEC>(o, e, op(x0, x1, r0));
           }
-          stg(rv + i, o);
+          stg<NT>(rv + i, o);
         }
       }
     }
@@ -126,21 +133,40 @@ map_kernel(T *__restrict__ res, const T *__restrict__ in0, const T *__restrict__
 
 constexpr int kStreamUnroll = 4;
 
-// Host launcher: picks the 16-byte path when all operands share their alignment.
+// Host launcher: picks the 16-byte path when all operands share their alignment, nontemporal
+// accesses when the streamed footprint exceeds Tune::nt_min_bytes, and the grid: one
+// 256*UNROLL-vector chunk per workgroup (blocks_per_cu == 0, best measured) or a persistent
+// grid of num_cu*blocks_per_cu workgroups.
 template <typename T, int NIN, bool READ_RES, bool REVERSE, typename Op>
 int32_t launch_map(mxlo_ctx *ctx, T *res, const T *in0, const T *in1, int64_t n, Op op) {
   if (n <= 0) return MXLO_OK;
   constexpr int VEC = Vec16<T>::N;
   const int64_t head0 = common_head<T>({res, NIN >= 1 ? in0 : nullptr, NIN >= 2 ? in1 : nullptr});
+  const int64_t streamed = (int64_t)sizeof(T) * n * (1 + NIN + (READ_RES ? 1 : 0));
+  const bool nt = streamed >= ctx->tune.nt_min_bytes;
+  auto grid_of = [&](int64_t items) {
+    const int64_t need = (items + (int64_t)kBlock * kStreamUnroll - 1) / ((int64_t)kBlock * kStreamUnroll);
+    int64_t g = need;
+    if (ctx->tune.blocks_per_cu > 0) {
+      const int64_t cap = (int64_t)ctx->num_cu * ctx->tune.blocks_per_cu;
+      if (g > cap) g = cap;
+    }
+    if (g > 0x7fffffffLL) g = 0x7fffffffLL;
+    return (int)(g < 1 ? 1 : g);
+  };
   if (head0 >= 0 && n >= 4 * VEC) {
     const int64_t head = head0 < n ? head0 : n;
     const int64_t nvec = (n - head) / VEC;
-    const int grid = grid_for(ctx, nvec, (int64_t)kBlock * kStreamUnroll, ctx->tune.blocks_per_cu);
-    hipLaunchKernelGGL((map_kernel<T, VEC, kStreamUnroll, NIN, READ_RES, REVERSE, Op>), dim3(grid),
-                       dim3(kBlock), 0, ctx->stream, res, in0, in1, head, nvec, n, op);
+    const int grid = grid_of(nvec);
+    if (nt)
+      hipLaunchKernelGGL((map_kernel<T, VEC, kStreamUnroll, NIN, READ_RES, REVERSE, true, Op>), dim3(grid),
+                         dim3(kBlock), 0, ctx->stream, res, in0, in1, head, nvec, n, op);
+    else
+      hipLaunchKernelGGL((map_kernel<T, VEC, kStreamUnroll, NIN, READ_RES, REVERSE, false, Op>), dim3(grid),
+                         dim3(kBlock), 0, ctx->stream, res, in0, in1, head, nvec, n, op);
   } else {
-    const int grid = grid_for(ctx, n, (int64_t)kBlock * kStreamUnroll, ctx->tune.blocks_per_cu);
-    hipLaunchKernelGGL((map_kernel<T, 1, kStreamUnroll, NIN, READ_RES, REVERSE, Op>), dim3(grid),
+    const int grid = grid_of(n);
+    hipLaunchKernelGGL((map_kernel<T, 1, kStreamUnroll, NIN, READ_RES, REVERSE, false, Op>), dim3(grid),
                        dim3(kBlock), 0, ctx->stream, res, in0, in1, (int64_t)0, n, n, op);
   }
   MXLO_LAUNCH_CHECK();

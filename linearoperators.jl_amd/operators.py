@@ -227,8 +227,8 @@ class LinearOperator(AbstractLinearOperator):
         if S is None:
             raise LinearOperatorException("storage type S is required (a device vector type)")
         self.S = S
-        self.Mv = S.undef(0)       # S(undef, 0)  src/abstract.jl:79-80
-        self.Mtu = S.undef(0)
+        self.Mv = torch.empty(0, dtype=S.dtype)    # S(undef, 0)  src/abstract.jl:79-80 (no device touch yet)
+        self.Mtu = torch.empty(0, dtype=S.dtype)
 
     def __repr__(self):            # src/abstract.jl:262-275
         return ("Linear operator\n  nrow: %d\n  ncol: %d\n  eltype: %s\n  symmetric: %s\n  hermitian: %s\n"

@@ -1,0 +1,235 @@
+"""Quasi-Newton operators: `LBFGSOperator`, `InverseLBFGSOperator`, `LSR1Operator`, `push!`,
+`diag`, `reset!`, `solve_shifted_system!`, `ldiv!` — the host side of `mxlo_qn_*`.
+
+Mirrors src/lbfgs.jl, src/lsr1.jl and src/utilities.jl:207-289. The operator objects satisfy the
+reference's *structural* contract for quasi-Newton operators (fields nrow ncol symmetric hermitian
+prod tprod ctprod nprod ntprod nctprod + `data`, src/lbfgs.jl:62-75, src/lsr1.jl:39-51), so `mul`,
+counters, `size`, flags and the combinators of :mod:`operators` work on them unchanged. The state
+(`s`, `y`, `a`, `b` panels, Gram matrices, scalars) lives in HBM inside the C handle.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+from .device import Storage, check_vec, dtype_code, get_ctx, ptr
+from .operators import AbstractLinearOperator, LinearOperatorException, scalar_flags
+
+
+class _QNData:
+    """`LBFGSData` / `LSR1Data` view (src/lbfgs.jl:4-24, src/lsr1.jl:4-17): the scalar fields the
+    reference's tests read, fetched from the device handle on access."""
+
+    def __init__(self, op):
+        self._op = op
+
+    def _scalars(self):
+        op = self._op
+        sc = (C.c_double * 5)()
+        ys = (C.c_double * op.mem)()
+        aux = (C.c_double * op.mem)()
+        _lib.call("mxlo_qn_get_scalars", op._h, sc, ys, aux)
+        return list(sc), np.array(ys[:]), np.array(aux[:])
+
+    @property
+    def insert(self) -> int:            # 1-based like Julia
+        return int(self._scalars()[0][0])
+
+    @property
+    def scaling_factor(self) -> float:
+        return self._scalars()[0][1]
+
+    @property
+    def opnorm_upper_bound(self) -> float:
+        return self._scalars()[0][2]
+
+    @property
+    def mem(self) -> int:
+        return self._op.mem
+
+    @property
+    def scaling(self) -> bool:
+        return self._op.scaling
+
+    @property
+    def damped(self) -> bool:
+        return self._op.damped
+
+    @property
+    def ys(self) -> np.ndarray:
+        return self._scalars()[1]
+
+    def column(self, which: str, k: int) -> torch.Tensor:
+        """Copy of panel column `k` (0-based slot) of 's' | 'y' | 'a' | 'b' (test / debug aid)."""
+        op = self._op
+        p = C.c_void_p()
+        _lib.call("mxlo_qn_column", op._h, {"s": 0, "y": 1, "a": 2, "b": 3}[which], k, C.byref(p))
+        out = torch.empty(op.nrow, dtype=op.eltype, device=op.S.device)
+        _lib.call("mxlo_memcpy_d2d", op._ctx.handle, ptr(out), p, out.numel() * out.element_size())
+        return out
+
+
+class _QNOperator(AbstractLinearOperator):
+    _has_args5 = True       # has_args5(op) = isallocated5(op) = true (src/lbfgs.jl:102-103)
+
+    def __init__(self, kind: int, T: torch.dtype, n: int, mem: int, scaling: bool, damped: bool, sigma2: float,
+                 sigma3: float, device):
+        dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        self._ctx = get_ctx(dev)
+        self._kind = kind
+        self.eltype = T
+        self.nrow = self.ncol = int(n)
+        self.symmetric = self.hermitian = True
+        self.mem = max(int(mem), 1)
+        self.scaling, self.damped = bool(scaling), bool(damped)
+        self.S = Storage(T, dev)        # storage_type(op) (the reference hard-codes Vector{T}, lbfgs.jl:104)
+        self.nprod = self.ntprod = self.nctprod = 0
+        self._h = C.c_void_p()
+        _lib.call("mxlo_qn_create", self._ctx.handle, kind, dtype_code(T), int(n), self.mem, int(scaling), int(damped),
+                  float(sigma2), float(sigma3), C.byref(self._h))
+        self.data = _QNData(self)
+        self.inverse = kind == _lib.QN_LBFGS_INV
+        prod = lambda res, x, a, b: self._multiply(res, x, a, b)
+        self.prod = prod
+        if kind == _lib.QN_LSR1:        # tprod! = ctprod! = nothing with symmetric = hermitian = true (lsr1.jl:110)
+            self.tprod = self.ctprod = None
+        else:                            # prod! three times (lbfgs.jl:157,205)
+            self.tprod = self.ctprod = prod
+
+    def _multiply(self, res, x, alpha, beta):
+        """lbfgs_multiply / lsr1_multiply (src/lbfgs.jl:117-154,173-202; src/lsr1.jl:89-107)."""
+        check_vec(res, "res", self.eltype)
+        check_vec(x, "x", self.eltype)
+        self._ctx.bind_stream()
+        _lib.call("mxlo_qn_mul", self._h, ptr(res), ptr(x), float(alpha), float(beta),
+                  scalar_flags(self.eltype, alpha, beta))
+
+    def set_mode(self, mode: str):
+        """'twopass' (panel form, default) or 'reforder' (reference statement order) for the inverse two-loop."""
+        _lib.call("mxlo_qn_set_mode", self._h, {"twopass": _lib.INV_TWOPASS, "reforder": _lib.INV_REFORDER}[mode])
+        return self
+
+    def _reset_data(self):
+        _lib.call("mxlo_qn_reset", self._h)
+
+    def __del__(self):
+        try:
+            if self._h:
+                _lib.lib().mxlo_qn_destroy(self._h)
+        except Exception:
+            pass
+
+
+class LBFGSOperatorType(_QNOperator):
+    pass
+
+
+class LSR1OperatorType(_QNOperator):
+    pass
+
+
+def _targs(T, n):
+    if isinstance(T, int):          # LBFGSOperator(n; kwargs...) -> Float64
+        return torch.float64, T
+    return T, n
+
+
+def InverseLBFGSOperator(T, n: Optional[int] = None, mem: int = 5, scaling: bool = True, damped: bool = False,
+                         sigma2: float = 0.99, sigma3: float = 10.0, device=None, **kw):
+    """InverseLBFGSOperator(T, n; mem=5, scaling=true, damped=false, σ₂=0.99, σ₃=10.0) — src/lbfgs.jl:106-160."""
+    T, n = _targs(T, n)
+    kw.pop("inverse", None)
+    return LBFGSOperatorType(_lib.QN_LBFGS_INV, T, n, mem, scaling, damped, kw.pop("σ₂", sigma2), kw.pop("σ₃", sigma3),
+                             device)
+
+
+def LBFGSOperator(T, n: Optional[int] = None, mem: int = 5, scaling: bool = True, damped: bool = False,
+                  sigma2: float = 0.99, sigma3: float = 10.0, device=None, **kw):
+    """LBFGSOperator(T, n; mem=5, scaling=true, ...) forward form — src/lbfgs.jl:162-208."""
+    T, n = _targs(T, n)
+    kw.pop("inverse", None)
+    return LBFGSOperatorType(_lib.QN_LBFGS_FWD, T, n, mem, scaling, damped, kw.pop("σ₂", sigma2), kw.pop("σ₃", sigma3),
+                             device)
+
+
+def LSR1Operator(T, n: Optional[int] = None, mem: int = 5, scaling: bool = True, device=None):
+    """LSR1Operator(T, n; mem=5, scaling=true) — src/lsr1.jl:80-113 (LSR1Data default scaling=true, :19)."""
+    T, n = _targs(T, n)
+    return LSR1OperatorType(_lib.QN_LSR1, T, n, mem, scaling, False, 0.99, 10.0, device)
+
+
+def push(op, s: torch.Tensor, y: torch.Tensor, *args):
+    """push!(op, s, y) | push!(op, s, y, Bs) | push!(op, s, y, α, g) | push!(op, s, y, α, g, Bs)
+    — src/lbfgs.jl:257-367, src/lsr1.jl:115-184. Returns `op` like the reference."""
+    if not isinstance(op, _QNOperator):
+        raise TypeError("push! is defined for quasi-Newton operators")
+    check_vec(s, "s", op.eltype)
+    check_vec(y, "y", op.eltype)
+    if s.numel() != op.nrow or y.numel() != op.nrow:
+        raise LinearOperatorException("shape mismatch")
+    op._ctx.bind_stream()
+    acc = C.c_int32(0)
+    if isinstance(op, LSR1OperatorType):
+        if args:
+            raise TypeError("push!(::LSR1Operator, s, y) takes no extra arguments")
+        _lib.call("mxlo_qn_push", op._h, ptr(s), ptr(y), C.byref(acc))
+        op._last_push_accepted = bool(acc.value)
+        return op
+    if len(args) == 0:
+        if op.damped:                                   # :273-275 — push!(op, s, y, similar(s))
+            if op.inverse:
+                raise RuntimeError("This function be used for forward operators. Use push!(op, s, y, α, g, Bs) instead.")
+            return push(op, s, y, torch.empty_like(s))
+        _lib.call("mxlo_qn_push", op._h, ptr(s), ptr(y), C.byref(acc))
+    elif len(args) == 1:                                # push!(op, s, y, Bs) :289-323
+        Bs, = args
+        if not op.damped:
+            raise RuntimeError("This push! should be used for damped operators")
+        if op.inverse:
+            raise RuntimeError("This function be used for forward operators. Use push!(op, s, y, α, g, Bs) instead.")
+        _lib.call("mxlo_qn_push_damped_fwd", op._h, ptr(s), ptr(y), ptr(check_vec(Bs, "Bs", op.eltype)), C.byref(acc))
+    elif len(args) in (2, 3):                           # push!(op, s, y, α, g[, Bs]) :325-367
+        alpha, g = args[0], args[1]
+        Bs = args[2] if len(args) == 3 else torch.empty_like(g)
+        if not op.damped:
+            raise RuntimeError("This push! should be used for damped operators")
+        if not op.inverse:
+            raise RuntimeError("This function be used for inverse operators. Use push!(op, s, y, Bs) instead.")
+        _lib.call("mxlo_qn_push_damped_inv", op._h, ptr(s), ptr(y), float(alpha), ptr(check_vec(g, "g", op.eltype)),
+                  ptr(check_vec(Bs, "Bs", op.eltype)), C.byref(acc))
+    else:
+        raise TypeError("push!: wrong number of arguments")
+    op._last_push_accepted = bool(acc.value)
+    return op
+
+
+def diag(op) -> torch.Tensor:
+    """diag(op) / diag!(op, d) — src/lbfgs.jl:369-395 (forward only), src/lsr1.jl:186-211."""
+    if isinstance(op, LBFGSOperatorType) and op.inverse:
+        raise LinearOperatorException("only the diagonal of a forward L-BFGS approximation is available")
+    d = torch.empty(op.nrow, dtype=op.eltype, device=op.S.device)
+    op._ctx.bind_stream()
+    _lib.call("mxlo_qn_diag", op._h, ptr(d))
+    return d
+
+
+def solve_shifted_system(x: torch.Tensor, B, b: torch.Tensor, sigma: float) -> torch.Tensor:
+    """solve_shifted_system!(x, B, b, σ) — src/utilities.jl:207-248. Returns `x` (the same object)."""
+    if not (isinstance(B, LBFGSOperatorType) and not B.inverse):
+        raise TypeError("solve_shifted_system! is defined for forward LBFGSOperator")
+    if sigma < 0:
+        raise ValueError("σ must be nonnegative")       # ArgumentError, :213-215
+    check_vec(x, "x", B.eltype)
+    check_vec(b, "b", B.eltype)
+    B._ctx.bind_stream()
+    _lib.call("mxlo_qn_solve_shifted", B._h, ptr(x), ptr(b), float(sigma))
+    return x
+
+
+def ldiv(x: torch.Tensor, B, b: torch.Tensor) -> torch.Tensor:
+    """ldiv!(x, B, b) — src/utilities.jl:281-289."""
+    return solve_shifted_system(x, B, b, 0.0)

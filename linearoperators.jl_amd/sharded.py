@@ -1,0 +1,117 @@
+"""Row-sharded vectors across the GPUs of one node: one process per GPU, `torch.distributed`
+(backend "nccl" == RCCL over xGMI) for the only exchange the hot path has — the sum of partial dots.
+
+The reference has no distributed path (no NCCL/MPI call site); this module is the seam
+north_star asks for. Every operator of this package works unchanged on its local row range
+`[lo, hi)`; the *only* cross-rank data are the scalars produced by global reductions (Householder
+h'v, L-BFGS / L-SR1 panel dots, push! dots, shifted-solve dots). libmxlo.so exposes one hook for
+all of them (`mxlo_ctx_set_allreduce`, include/mxlo.h): after the local fixed-order finalize it
+hands over `count` doubles in device memory to be sum-all-reduced in place, stream-ordered.
+All ranks then hold bit-identical scalars (RCCL all-reduce returns the same bits everywhere),
+which is what keeps the replicated control flow (`ys[k] != 0` skips, push! rejection) consistent.
+
+Message sizes are tiny (8 B for Householder, 16*m B for a forward L-BFGS apply): latency-bound, so
+nothing here is bucketed. Paths that do not shard (kron at 1024², general restriction) run as
+replicas: see DESIGN.md.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+@dataclass(frozen=True)
+class ShardPlan:
+    """Contiguous row ranges: rank r owns rows [lo(r), hi(r)) of an n-vector; the first n % world
+    ranks own one extra row (so shards differ by at most one row)."""
+    n: int
+    world: int
+
+    def lo(self, rank: int) -> int:
+        q, r = divmod(self.n, self.world)
+        return rank * q + min(rank, r)
+
+    def hi(self, rank: int) -> int:
+        return self.lo(rank + 1) if rank + 1 < self.world else self.n
+
+    def local_n(self, rank: int) -> int:
+        return self.hi(rank) - self.lo(rank)
+
+    def ranges(self):
+        return [(self.lo(r), self.hi(r)) for r in range(self.world)]
+
+    def blocks_to_ranks(self, block_rows):
+        """BlockDiagonalOperator sharding: whole blocks per rank by cumulative row
+        offset — a block belongs to the rank that owns its first row. Returns a list of
+        (first_block, last_block_exclusive) per rank and the induced row ranges."""
+        offs = np.concatenate([[0], np.cumsum(np.asarray(block_rows, dtype=np.int64))])
+        total = int(offs[-1])
+        owner = np.minimum((offs[:-1] * self.world) // max(total, 1), self.world - 1)
+        out, rows = [], []
+        for r in range(self.world):
+            ids = np.nonzero(owner == r)[0]
+            if ids.size:
+                out.append((int(ids[0]), int(ids[-1]) + 1))
+                rows.append((int(offs[ids[0]]), int(offs[ids[-1] + 1])))
+            else:
+                out.append((0, 0))
+                rows.append((0, 0))
+        return out, rows
+
+
+class _DevArray:
+    """Minimal __cuda_array_interface__ carrier so torch can alias a raw device pointer."""
+
+    def __init__(self, p: int, count: int):
+        self.__cuda_array_interface__ = {"shape": (count,), "typestr": "<f8", "data": (p, False), "version": 2,
+                                         "strides": None}
+
+
+def wrap_doubles(p: int, count: int, cuda: bool) -> torch.Tensor:
+    """Alias `count` doubles at address `p` (device or host memory) as a 1-D float64 tensor."""
+    if cuda:
+        return torch.as_tensor(_DevArray(p, count), device="cuda")
+    arr = np.ctypeslib.as_array((C.c_double * count).from_address(p))
+    return torch.from_numpy(arr)
+
+
+def make_allreduce_hook(group=None, cuda: bool = True):
+    """The Python body of `mxlo_allreduce_fn`: sum-all-reduce `count` doubles in place."""
+    cache: dict = {}
+
+    def hook(user, dev_buf, count, stream):
+        try:
+            key = (int(dev_buf), int(count))
+            t = cache.get(key)
+            if t is None:
+                t = cache[key] = wrap_doubles(int(dev_buf), int(count), cuda)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+            return 0
+        except Exception as e:  # never let an exception cross the C ABI
+            import sys
+            print(f"[mxlo all-reduce hook] {e!r}", file=sys.stderr)
+            return 1
+
+    return hook
+
+
+def install_allreduce(ctx, group=None) -> None:
+    """Route every global reduction of `ctx` through an RCCL all-reduce (no-op when world == 1)."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        ctx.set_allreduce(None)
+        return
+    ctx.set_allreduce(make_allreduce_hook(group, cuda=True))
+
+
+def uninstall_allreduce(ctx) -> None:
+    ctx.set_allreduce(None)
+
+
+def shard(full: torch.Tensor, plan: ShardPlan, rank: int, device=None) -> torch.Tensor:
+    """Local row range of a host/global vector (test & data-loading helper)."""
+    t = full[plan.lo(rank):plan.hi(rank)].contiguous()
+    return t.to(device) if device is not None else t

@@ -1,0 +1,102 @@
+"""CPU-only: the C-ABI library loads and exports every symbol include/mxlo.h declares, the ctypes
+prototypes cover the header, and the host-side logic (index ranges, storage promotion, shard plans,
+argument-count dispatch) behaves like the reference. No compute call is made (no GPU here)."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+import torch
+
+
+def test_library_exports_every_header_symbol(lo):
+    assert os.path.exists(lo._lib.LIB_PATH), "run __graft_entry__.build() first"
+    L = ctypes.CDLL(lo._lib.LIB_PATH)
+    syms = lo._lib.header_symbols()
+    assert len(syms) >= 50
+    missing = [s for s in syms if not hasattr(L, s)]
+    assert not missing, missing
+    L.mxlo_version.restype = ctypes.c_char_p
+    assert b"gfx950" in L.mxlo_version()
+    L.mxlo_status_string.restype = ctypes.c_char_p
+    assert L.mxlo_status_string(2) == b"shape mismatch"
+
+
+def test_ctypes_prototypes_cover_header(lo):
+    declared = set(lo._lib.header_symbols()) - {"mxlo_version", "mxlo_status_string", "mxlo_last_error"}
+    assert declared == set(lo._lib._PROTOS), declared ^ set(lo._lib._PROTOS)
+
+
+def test_no_gpu_means_loud_failure(lo):
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(RuntimeError, match="no CPU fallback|no HIP device"):
+        lo.opDiagonal(torch.ones(4, dtype=torch.float64))
+    with pytest.raises(RuntimeError):
+        lo.get_ctx()
+
+
+def test_product_never_imports_oracle():
+    """The product path must not route through the oracle (or any CPU fallback)."""
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "linearoperators.jl_amd")
+    for dp, _, files in os.walk(root):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                text = open(os.path.join(dp, f)).read()
+                assert "import oracle" not in text and "lo_oracle" not in text, f
+
+
+def test_jrange_matches_julia_ranges(lo):
+    assert list(lo.jrange(3, 6).to_numpy()) == [3, 4, 5, 6]
+    assert list(lo.jrange(1, 7, 2).to_numpy()) == [1, 3, 5, 7]
+    assert list(lo.jrange(1, 8, 2).to_numpy()) == [1, 3, 5, 7]
+    assert list(lo.jrange(7, 1, -3).to_numpy()) == [7, 4, 1]
+    assert len(lo.jrange(5, 4)) == 0
+    with pytest.raises(ValueError):
+        lo.jrange(1, 2, 0)
+
+
+def test_storage_promotion_and_nargs(lo):
+    from linearoperators_jl_amd.operators import _nargs, promote_storage
+    S64 = lo.Storage(torch.float64, torch.device("cuda", 0))
+    S32 = lo.Storage(torch.float32, torch.device("cuda", 0))
+    Sc = lo.Storage(torch.float64, torch.device("cpu"))
+    assert promote_storage(S64, S32) == S64
+    with pytest.raises(lo.LinearOperatorException, match="cannot be promoted"):
+        promote_storage(S64, Sc)                     # src/operations.jl:138-147
+    assert _nargs(lambda res, v, a, b: None) == 4 and _nargs(lambda res, v: None) == 2
+    from linearoperators_jl_amd.operators import scalar_flags
+    assert scalar_flags(torch.float32, 2.0, 0.0) == lo._lib.SCALARS_F64
+    assert scalar_flags(torch.float32, np.float32(2), np.float32(0)) == 0
+    assert scalar_flags(torch.float32, 2, 0) == 0    # Julia Int scalars never widen a Float32 product
+    assert scalar_flags(torch.float64, 2.0, 0.0) == 0
+
+
+def test_wrapper_algebra_without_device(lo):
+    """adjoint/transpose/conj identities (src/adjtrans.jl:33-45) need no device."""
+    S = lo.Storage(torch.float64, torch.device("cuda", 0))
+    op = lo.LinearOperator(torch.float64, 3, 5, False, False, lambda r, v, a, b: None, None, None, S=S)
+    assert lo.adjoint(lo.adjoint(op)) is op and lo.transpose(lo.transpose(op)) is op and lo.conj(lo.conj(op)) is op
+    assert isinstance(lo.adjoint(lo.transpose(op)), lo.ConjugateLinearOperator)
+    assert lo.adjoint(lo.conj(op)).parent is op and isinstance(lo.adjoint(lo.conj(op)), lo.TransposeLinearOperator)
+    assert op.T.shape == (5, 3) and op.H.size(1) == 5 and lo.conj(op).shape == (3, 5)
+    with pytest.raises(lo.LinearOperatorException):
+        op.size(3)
+    with pytest.raises(lo.LinearOperatorException, match="shape mismatch"):
+        lo.mul(torch.empty(3), op, torch.empty(4))   # the check fires before any data is touched
+    with pytest.raises(lo.LinearOperatorException, match="unable to infer"):
+        lo.mul(torch.empty(5), op.T, torch.empty(3))
+
+
+def test_shard_plan(lo):
+    P = lo.sharded.ShardPlan
+    for n, w in ((10, 3), (400_000_000, 8), (7, 8), (0, 2), (5, 1)):
+        rs = P(n, w).ranges()
+        assert rs[0][0] == 0 and rs[-1][1] == n
+        assert all(a[1] == b[0] for a, b in zip(rs, rs[1:]))
+        sizes = [hi - lo_ for lo_, hi in rs]
+        assert max(sizes) - min(sizes) <= 1
+    blocks, rows = P(0, 4).blocks_to_ranks([1024] * 1024)
+    assert [b - a for a, b in blocks] == [256] * 4 and rows[1] == (256 * 1024, 512 * 1024)
+    blocks, rows = P(0, 8).blocks_to_ranks([5, 1, 1, 1])
+    assert sum(b - a for a, b in blocks) == 4

@@ -1,0 +1,297 @@
+"""-m gpu: parity of the HIP leaves (through the C ABI, via the host mirror) against the oracle on
+seeded inputs, the reference tests' KATs, edge cases and size-independent properties.
+
+Tolerances: elementwise leaves (opDiagonal, opEye, opZeros, scale, restriction/extension) are
+BIT-EXACT; leaves with a global reduction (opHouseholder, opOnes) 1e-12 relative L2 in fp64 and
+1e-5 in fp32 (fixed-order tree vs the oracle's / BLAS' order)."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+SV = lambda n: np.array([-(-1.0) ** i for i in range(1, n + 1)])
+NP = {torch.float64: np.float64, torch.float32: np.float32}
+SIZES = [1, 2, 3, 7, 64, 255, 1000, 4097, 100_003, 1_048_577]
+
+
+def T(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def rel(a, b):
+    nb = np.linalg.norm(b.astype(np.float64))
+    return np.linalg.norm(a.astype(np.float64) - b.astype(np.float64)) / (nb if nb else 1.0)
+
+
+# ---------------------------------------------------------------------------- KATs through the ABI
+def test_kat_diag(lo, dev, kat):
+    for c in [c for c in kat if c["kind"] == "diag"]:
+        d, u = np.array(c["d"]), np.array(c["u"])
+        D = lo.opDiagonal(T(d, dev))
+        assert np.array_equal((D * T(u, dev)).cpu().numpy(), np.array(c["expect_apply"]))
+        assert np.array_equal((D.T * T(u, dev)).cpu().numpy(), np.array(c["expect_apply"]))
+        assert np.array_equal((D.H * T(u, dev)).cpu().numpy(), np.array(c["expect_apply"]))
+        res = T(np.array(c["res0"]), dev)
+        lo.mul(res, D, T(u, dev), c["alpha"], c["beta"])
+        assert np.array_equal(res.cpu().numpy(), np.array(c["expect_mul5"]))
+    for c in [c for c in kat if c["kind"] == "diag_scalar"]:
+        d, u = np.array(c["d"]), np.array(c["u"])
+        res = torch.full((u.size,), float("nan"), dtype=torch.float64, device=dev)
+        lo.leaves.mulSquareOpDiagonal(res, T(d, dev), T(u, dev), 1.0, 0.0)
+        assert np.array_equal(res.cpu().numpy(), np.array(c["expect_apply"]))
+
+
+def test_kat_diag_rect(lo, dev, kat):
+    for c in [c for c in kat if c["kind"] == "diag_rect"]:
+        D = lo.opDiagonal(c["nrow"], c["ncol"], T(np.array(c["d"]), dev))
+        assert np.array_equal((D * T(np.array(c["u"]), dev)).cpu().numpy(), np.array(c["expect_apply"]))
+        assert np.array_equal((D.T * T(np.array(c["w"]), dev)).cpu().numpy(), np.array(c["expect_tapply"]))
+        assert np.array_equal((D.H * T(np.array(c["w"]), dev)).cpu().numpy(), np.array(c["expect_tapply"]))
+
+
+def test_kat_householder(lo, dev, kat):
+    for c in [c for c in kat if c["kind"] == "householder"]:
+        H = lo.opHouseholder(T(np.array(c["h"]), dev))
+        u = T(np.array(c["u"]), dev)
+        for op in (H, H.T, H.H):
+            assert np.array_equal((op * u).cpu().numpy(), np.array(c["expect_apply"]))
+
+
+def _idx_arg(lo, spec):
+    if "list" in spec:
+        return spec["list"]
+    if "range" in spec:
+        a, b, s = spec["range"]
+        return lo.jrange(a, b, s)
+    if "scalar" in spec:
+        return spec["scalar"]
+    return slice(None)
+
+
+def test_kat_restriction_extension(lo, dev, kat):
+    """test_linop.jl:437-461 — all six identities, exact `==`."""
+    for c in [c for c in kat if c["kind"] == "restriction"]:
+        n = c["n"]
+        idx = _idx_arg(lo, c["idx"])
+        P = lo.opRestriction(idx, n, device=dev)
+        Z = lo.opExtension(idx, n, device=dev)
+        v, w, vz = T(np.array(c["v"]), dev), T(np.array(c["expect_w"]), dev), T(np.array(c["expect_vz"]), dev)
+        assert torch.equal(P * v, w), c["name"]
+        assert torch.equal(P.H * w, vz)
+        assert torch.equal(Z * w, vz)
+        assert torch.equal(Z.H * v, w)
+        assert torch.equal((P * Z) * w, w)
+        assert torch.equal((Z * P) * v, vz)
+
+
+def test_kat_cat_eye_zeros(lo, dev, kat):
+    """test_cat.jl:43-49."""
+    c = [c for c in kat if c["kind"] == "cat_eye_zeros"][0]
+    K = lo.hvcat((2, 2), lo.opEye(2), lo.opZeros(2, 3), lo.opZeros(3, 2), lo.opEye(3))
+    v = T(np.array(c["v"]), dev)
+    assert torch.equal(K * v, T(np.array(c["expect"]), dev))
+    c = [c for c in kat if c["kind"] == "cat_vcat_eye"][0]
+    K = lo.vcat(lo.opEye(2), torch.eye(2, dtype=torch.float64, device=dev))
+    assert torch.equal(K * T(np.array(c["v"]), dev), T(np.array(c["expect"]), dev))
+    with pytest.raises(lo.LinearOperatorException):
+        lo.vcat(lo.LinearOperatorFromMatrix(torch.ones(5, 5, dtype=torch.float64, device=dev)), lo.opEye(3))
+
+
+# ---------------------------------------------------------------------------- seeded parity vs oracle
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("n", SIZES)
+def test_diag_bit_exact(lo, dev, dtype, n):
+    rng = np.random.default_rng(n)
+    npd = NP[dtype]
+    d, v, r0 = (rng.standard_normal(n).astype(npd) for _ in range(3))
+    D = lo.opDiagonal(T(d, dev))
+    for alpha, beta in ((1.0, 0.0), (2.0 / 3.0, 0.0), (-1.25, 1.0 / 7.0), (0.0, 2.0), (1, 0), (np.float32(0.3), np.float32(0.7))):
+        res = T(r0.copy(), dev)
+        if beta == 0:
+            res.fill_(float("nan"))                       # beta == 0: res is never read
+        lo.mul(res, D, T(v, dev), alpha, beta)
+        flags = oracle.SCALARS_F64 if (dtype == torch.float32 and (isinstance(alpha, float) or isinstance(beta, float))) else 0
+        want = oracle.diag_mul(r0.copy(), d, v, float(alpha), float(beta), flags=flags)
+        assert np.array_equal(res.cpu().numpy(), want), (alpha, beta)
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_diag_misaligned_views(lo, dev, dtype):
+    """cat/block-diag hand contiguous views (pointer+offset): every 16-byte phase combination."""
+    rng = np.random.default_rng(11)
+    npd = NP[dtype]
+    n = 5000
+    base = [rng.standard_normal(n + 8).astype(npd) for _ in range(3)]
+    tb = [T(b, dev) for b in base]
+    for od, ov, orr in [(0, 0, 0), (1, 1, 1), (1, 0, 0), (0, 1, 2), (3, 3, 3), (2, 1, 3)]:
+        m = n - 3
+        d, v, r = base[0][od:od + m], base[1][ov:ov + m], base[2][orr:orr + m].copy()
+        res = tb[2].clone()[orr:orr + m]
+        lo.leaves.mulSquareOpDiagonal(res, tb[0][od:od + m], tb[1][ov:ov + m], 1.5, -0.5)
+        flags = oracle.SCALARS_F64 if dtype == torch.float32 else 0
+        want = oracle.diag_mul(r, np.ascontiguousarray(d), np.ascontiguousarray(v), 1.5, -0.5, flags=flags)
+        assert np.array_equal(res.cpu().numpy(), want), (od, ov, orr)
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("n", SIZES)
+def test_householder_parity(lo, dev, dtype, n):
+    rng = np.random.default_rng(100 + n)
+    npd = NP[dtype]
+    h = rng.standard_normal(n)
+    h = (h / np.linalg.norm(h)).astype(npd)
+    v, r0 = rng.uniform(-1, 1, n).astype(npd), rng.uniform(-1, 1, n).astype(npd)
+    H = lo.opHouseholder(T(h, dev))
+    tol = 1e-12 if dtype == torch.float64 else 1e-5
+    for alpha, beta in ((1.0, 0.0), (2.0, -3.0)):
+        res = T(r0.copy(), dev)
+        if beta == 0:
+            res.fill_(float("nan"))
+        lo.mul(res, H, T(v, dev), alpha, beta)
+        flags = oracle.SCALARS_F64 if dtype == torch.float32 else 0
+        want = oracle.householder_mul(r0.copy(), h, v, alpha, beta, flags=flags)
+        assert rel(res.cpu().numpy(), want) <= tol, (n, alpha, beta)
+    # deterministic run to run (fixed-order reduction, no float atomics)
+    a = H * T(v, dev)
+    b = H * T(v, dev)
+    assert torch.equal(a, b)
+
+
+def test_householder_involution_full_size(lo, dev):
+    """BASELINE config 2 size (n = 1e8 fp64): H(Hv) == v for ||h|| = 1, linearity, and parity with
+    the oracle on a strided sample of the output."""
+    n = 100_000_000
+    g = torch.Generator(device=dev).manual_seed(5)
+    h = torch.rand(n, dtype=torch.float64, device=dev, generator=g) - 0.5
+    h /= torch.linalg.vector_norm(h)
+    v = torch.rand(n, dtype=torch.float64, device=dev, generator=g) * 2 - 1
+    H = lo.opHouseholder(h)
+    w = H * v
+    back = H * w
+    err = (torch.linalg.vector_norm(back - v) / torch.linalg.vector_norm(v)).item()
+    assert err <= 1e-12, err
+    # exact scalar check of the reduction against torch's own dot (fp64, 1e8 terms)
+    c = 2 * torch.dot(h, v)
+    ref = v - c * h
+    err = (torch.linalg.vector_norm(w - ref) / torch.linalg.vector_norm(ref)).item()
+    assert err <= 1e-12, err
+    del back, ref, w
+    # opDiagonal at the same size: bit-exact against the same formula evaluated by torch
+    D = lo.opDiagonal(h)
+    out = torch.empty_like(v)
+    lo.mul(out, D, v, 2.0, 0.0)
+    assert torch.equal(out, (2.0 * h) * v)
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_eye_zeros_ones_scale(lo, dev, dtype):
+    rng = np.random.default_rng(3)
+    npd = NP[dtype]
+    S = lo.Storage(dtype, dev)
+    for nrow, ncol in ((7, 7), (9, 4), (4, 9), (1000, 1003)):
+        v, r0 = rng.standard_normal(ncol).astype(npd), rng.standard_normal(nrow).astype(npd)
+        for alpha, beta in ((1.0, 0.0), (2.5, -0.75)):
+            fl = oracle.SCALARS_F64 if dtype == torch.float32 else 0
+            E = lo.opEye(dtype, nrow, ncol, S=S)
+            res = T(r0.copy(), dev)
+            lo.mul(res, E, T(v, dev), alpha, beta)
+            want = oracle.eye_mul(r0.copy(), v, alpha, beta, n_min=min(nrow, ncol), flags=fl | oracle.TAIL_BETA)
+            assert np.array_equal(res.cpu().numpy(), want)
+            Z = lo.opZeros(dtype, nrow, ncol, S=S)
+            res = T(r0.copy(), dev)
+            lo.mul(res, Z, T(v, dev), alpha, beta)
+            assert np.array_equal(res.cpu().numpy(), oracle.zeros_mul(r0.copy(), beta, flags=fl))
+            O = lo.opOnes(dtype, nrow, ncol, S=S)
+            res = T(r0.copy(), dev)
+            lo.mul(res, O, T(v, dev), alpha, beta)
+            want = oracle.ones_mul(r0.copy(), v, alpha, beta, flags=fl)
+            assert rel(res.cpu().numpy(), want) <= (1e-12 if dtype == torch.float64 else 1e-5)
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32, torch.int64])
+def test_restriction_extension_bit_exact(lo, dev, dtype):
+    rng = np.random.default_rng(8)
+    n = 200_003
+    if dtype == torch.int64:
+        v = rng.integers(-2**62, 2**62, n)
+    else:
+        v = rng.standard_normal(n).astype(NP[dtype])
+        v[::97] = np.nan                                   # payload bits must survive
+    vt = T(v, dev)
+    specs = [rng.integers(1, n + 1, 50_000), np.arange(1, n + 1), np.array([n]), np.array([], dtype=np.int64),
+             rng.permutation(n)[:1000] + 1]
+    for idx in specs:
+        P = lo.opRestriction(idx, n, device=dev)
+        out = torch.empty(len(idx), dtype=dtype, device=dev)
+        lo.mul(out, P, vt)
+        assert np.array_equal(out.cpu().numpy().view(np.uint8), v[np.asarray(idx, dtype=np.int64) - 1].view(np.uint8))
+        u = v[:len(idx)].copy()
+        back = torch.full((n,), 7, dtype=dtype, device=dev)
+        lo.mul(back, P.H, T(u, dev))
+        want = oracle.extend(np.empty(n, v.dtype), u, np.asarray(idx, dtype=np.int64))
+        assert np.array_equal(back.cpu().numpy().view(np.uint8), want.view(np.uint8))
+    for (a, b, s) in ((3, 6, 1), (1, n, 2), (n, 1, -3), (5, 4, 1), (17, 17, 1)):
+        r = lo.jrange(a, b, s)
+        idx = r.to_numpy()
+        P = lo.opRestriction(r, n, device=dev)
+        out = torch.empty(len(r), dtype=dtype, device=dev)
+        lo.mul(out, P, vt)
+        assert np.array_equal(out.cpu().numpy().view(np.uint8), v[idx - 1].view(np.uint8)), (a, b, s)
+        u = v[:len(r)].copy()
+        back = torch.full((n,), 7, dtype=dtype, device=dev)
+        lo.mul(back, P.H, T(u, dev))
+        want = oracle.extend(np.empty(n, v.dtype), u, idx)
+        assert np.array_equal(back.cpu().numpy().view(np.uint8), want.view(np.uint8)), (a, b, s)
+    with pytest.raises(lo.LinearOperatorException):
+        lo.opRestriction([0, 1], n, device=dev)
+    with pytest.raises(lo.LinearOperatorException):
+        lo.opRestriction([n + 1], n, device=dev)
+
+
+def test_extension_duplicates_last_write_wins(lo, dev):
+    idx = np.array([2, 5, 2, 3, 5, 5], dtype=np.int64)
+    u = np.arange(10.0, 70.0, 10.0)
+    Z = lo.opExtension(idx, 6, device=dev)
+    got = (Z * T(u, dev)).cpu().numpy()
+    assert np.array_equal(got, oracle.extend(np.empty(6), u, idx))
+
+
+def test_shape_mismatch_and_errors(lo, dev):
+    D = lo.opDiagonal(torch.ones(5, dtype=torch.float64, device=dev))
+    with pytest.raises(lo.LinearOperatorException, match="shape mismatch"):
+        D * torch.ones(6, dtype=torch.float64, device=dev)
+    with pytest.raises(lo.LinearOperatorException):
+        D.size(3)
+    with pytest.raises(RuntimeError):                      # CPU operands: no fallback
+        lo.opDiagonal(torch.ones(5, dtype=torch.float64))
+
+
+def test_counters_and_prod3(lo, dev):
+    """test_linop.jl:634-716 counters; :768-817 3-arg closures with lazily allocated Mv."""
+    S = lo.Storage(torch.float64, dev)
+    d = torch.arange(1.0, 6.0, dtype=torch.float64, device=dev)
+    calls = []
+
+    def p3(res, v):
+        calls.append(1)
+        res.copy_(d * v)
+
+    op = lo.LinearOperator(torch.float64, 5, 5, True, True, p3, None, None, S=S)
+    assert not lo.has_args5(op) and not lo.isallocated5(op)
+    v = torch.ones(5, dtype=torch.float64, device=dev)
+    res = torch.empty(5, dtype=torch.float64, device=dev)
+    lo.mul(res, op, v)
+    assert torch.equal(res, d) and not lo.isallocated5(op)
+    lo.mul(res, op, v, 2.0, 0.0)
+    assert torch.equal(res, 2 * d) and not lo.isallocated5(op)
+    lo.mul(res, op, v, 2.0, 3.0)
+    assert torch.equal(res, 2 * d + 3 * (2 * d)) and lo.isallocated5(op)
+    assert lo.nprod(op) == 3
+    lo.mul(res, op.T, v)
+    lo.mul(res, op.H, v)
+    assert lo.nprod(op) == 5 and lo.ntprod(op) == 0 and lo.nctprod(op) == 0   # symmetric+hermitian -> prod!
+    lo.reset(op)
+    assert lo.nprod(op) == 0

@@ -1,0 +1,254 @@
+"""-m gpu: matrix-carrying leaves (opHermitian, kron, dense LinearOperator, BlockDiagonalOperator) and
+the combinators / cat, compared with the oracle and with independent dense NumPy models, the way the
+reference's tests do (test_linop.jl, test_cat.jl, test_kron.jl, test_adjtrans.jl)."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+NP = {torch.float64: np.float64, torch.float32: np.float32}
+SV = lambda n: np.array([-(-1.0) ** i for i in range(1, n + 1)])
+
+
+def T(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def TM(a, dev):
+    """column-major device matrix (what a Julia Matrix is)."""
+    return torch.from_numpy(np.asfortranarray(a).T.copy()).to(dev).t()
+
+
+def rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    nb = np.linalg.norm(b)
+    return np.linalg.norm(a - b) / (nb if nb else 1.0)
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("m,n", [(10, 6), (6, 10), (1, 1), (300, 257), (1025, 33), (64, 2000)])
+def test_dense_operator(lo, dev, dtype, m, n):
+    """test_linop.jl:7-226 style: op*v, transpose(op)*u, op'*u, 5-arg forms vs the dense matrix."""
+    rng = np.random.default_rng(m * 1000 + n)
+    npd = NP[dtype]
+    A = rng.standard_normal((m, n)).astype(npd)
+    op = lo.LinearOperatorFromMatrix(TM(A, dev))
+    v, u = rng.standard_normal(n).astype(npd), rng.standard_normal(m).astype(npd)
+    tol = 1e-12 if dtype == torch.float64 else 2e-5
+    assert op.shape == (m, n) and lo.size(op, 1) == m and lo.size(op.T, 1) == n
+    assert rel((op * T(v, dev)).cpu().numpy(), A @ v) <= tol
+    assert rel((op.T * T(u, dev)).cpu().numpy(), A.T @ u) <= tol
+    assert rel((op.H * T(u, dev)).cpu().numpy(), A.T @ u) <= tol
+    r0 = rng.standard_normal(m).astype(npd)
+    res = T(r0.copy(), dev)
+    lo.mul(res, op, T(v, dev), 3.0, -4.0)
+    assert rel(res.cpu().numpy(), 3.0 * (A @ v) - 4.0 * r0) <= tol
+    fl = oracle.SCALARS_F64 if dtype == torch.float32 else 0
+    assert rel(res.cpu().numpy(), oracle.gemv(r0.copy(), A, v, 3.0, -4.0, flags=fl)) <= tol
+    assert lo.nprod(op) == 2 and lo.ntprod(op) == 1 and lo.nctprod(op) == 1
+    with pytest.raises(lo.LinearOperatorException):
+        op * torch.ones(n + 1, dtype=dtype, device=dev)
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("n", [1, 10, 257, 1500])
+def test_hermitian(lo, dev, dtype, n):
+    """test_linop.jl:360-380."""
+    rng = np.random.default_rng(n)
+    npd = NP[dtype]
+    A = rng.standard_normal((n, n)).astype(npd)
+    d = rng.standard_normal(n).astype(npd)
+    L = np.tril(A.astype(np.float64), -1)
+    Cm = L + L.T + np.diag(d.astype(np.float64))
+    v = SV(n).astype(npd)
+    tol = 1e-12 if dtype == torch.float64 else 3e-5
+    H = lo.opHermitian(T(d, dev), TM(A, dev))
+    assert lo.ishermitian(H) and lo.issymmetric(H)
+    for op in (H, H.T, H.H):
+        assert rel((op * T(v, dev)).cpu().numpy(), Cm @ v) <= tol
+    r0 = rng.standard_normal(n).astype(npd)
+    res = T(r0.copy(), dev)
+    lo.mul(res, H, T(v, dev), 3.0, -4.0)
+    fl = oracle.SCALARS_F64 if dtype == torch.float32 else 0
+    assert rel(res.cpu().numpy(), oracle.hermitian_mul(r0.copy(), d, A, v, 3.0, -4.0, flags=fl)) <= tol
+    Csym = (A + A.T).astype(npd)
+    H2 = lo.opHermitian(TM(Csym, dev))
+    assert rel((H2 * T(v, dev)).cpu().numpy(), Csym.astype(np.float64) @ v) <= tol
+    with pytest.raises(lo.LinearOperatorException):
+        lo.opHermitian(T(d, dev)[: max(n - 1, 0)], TM(A, dev)) if n > 1 else (_ for _ in ()).throw(lo.LinearOperatorException("x"))
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("shapes", [((3, 5), (4, 2)), ((1, 1), (7, 3)), ((16, 16), (16, 16)), ((70, 33), (65, 129)),
+                                    ((64, 64), (128, 64))])
+def test_kron(lo, dev, dtype, shapes):
+    """test_kron.jl:2-39: K = kron(A,B) dense vs the operator, its transpose and adjoint, 5-arg form."""
+    (m, n), (p, q) = shapes
+    rng = np.random.default_rng(m + 10 * n + 100 * p + 1000 * q)
+    npd = NP[dtype]
+    A, B = rng.standard_normal((m, n)).astype(npd), rng.standard_normal((p, q)).astype(npd)
+    K = np.kron(A.astype(np.float64), B.astype(np.float64))
+    Kop = lo.kron(lo.LinearOperatorFromMatrix(TM(A, dev)), TM(B, dev))
+    assert Kop.shape == K.shape
+    x, xt = rng.standard_normal(K.shape[1]).astype(npd), rng.standard_normal(K.shape[0]).astype(npd)
+    tol = 1e-12 if dtype == torch.float64 else 3e-5
+    n1 = np.linalg.norm(K, 1)
+    assert np.linalg.norm((Kop * T(x, dev)).cpu().numpy() - K @ x, 1) <= tol * n1 * max(1, np.abs(x).max())
+    assert rel((Kop.T * T(xt, dev)).cpu().numpy(), K.T @ xt) <= tol * 10
+    assert rel((Kop.H * T(xt, dev)).cpu().numpy(), K.T @ xt) <= tol * 10
+    r0 = rng.standard_normal(K.shape[0]).astype(npd)
+    res = T(r0.copy(), dev)
+    lo.mul(res, Kop, T(x, dev), 2.0, 3.0)
+    fl = oracle.SCALARS_F64 if dtype == torch.float32 else 0
+    assert rel(res.cpu().numpy(), oracle.kron_mul(r0.copy(), A, B, x, 2.0, 3.0, flags=fl)) <= tol * 10
+    res = T(np.full(K.shape[0], np.nan, dtype=npd), dev)
+    lo.mul(res, Kop, T(x, dev), 1.0, 0.0)                  # beta == 0 never reads res
+    assert torch.isfinite(res).all()
+
+
+def test_kron_transpose_detecting_and_scaling(lo, dev):
+    """Asymmetric identity check of the MFMA C/D layout + test_kron.jl:50-58 (2*kron(opEye(2), I(1)))."""
+    n = 48
+    A = np.eye(n)
+    B = np.arange(n * n, dtype=np.float64).reshape(n, n) / n      # asymmetric
+    Kop = lo.kron(TM(A, dev), TM(B, dev))
+    x = np.random.default_rng(0).standard_normal(n * n)
+    assert rel((Kop * T(x, dev)).cpu().numpy(), np.kron(A, B) @ x) <= 1e-13
+    K2 = 2 * lo.kron(lo.opEye(2), torch.eye(1, dtype=torch.float64, device=dev))
+    assert np.allclose(lo.Matrix(K2).cpu().numpy(), 2 * np.eye(2))
+
+
+def test_kron_1024_properties(lo, dev):
+    """BASELINE config 4b size: (A⊗B)x = vec(B X Aᵀ) against torch's own fp64 GEMMs."""
+    g = torch.Generator(device=dev).manual_seed(3)
+    n = 1024
+    A = ((torch.rand(n, n, dtype=torch.float64, device=dev, generator=g) * 2 - 1) / 32).t()
+    B = ((torch.rand(n, n, dtype=torch.float64, device=dev, generator=g) * 2 - 1) / 32).t()
+    x = torch.rand(n * n, dtype=torch.float64, device=dev, generator=g) * 2 - 1
+    Kop = lo.kron(A, B)
+    got = Kop * x
+    X = x.view(n, n).t()                                   # reshape(x, q, n) column-major
+    want = (B @ X @ A.t()).t().reshape(-1)
+    assert (torch.linalg.vector_norm(got - want) / torch.linalg.vector_norm(want)).item() <= 1e-12
+    gt = Kop.T * x
+    Xt = x.view(n, n).t()
+    want = (B.t() @ Xt @ A).t().reshape(-1)
+    assert (torch.linalg.vector_norm(gt - want) / torch.linalg.vector_norm(want)).item() <= 1e-12
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_blockdiag_fused(lo, dev, dtype):
+    """test_linop.jl:718-756: mixes operators and plain matrices; Matrix(M), transpose, adjoint vs dense."""
+    rng = np.random.default_rng(2)
+    npd = NP[dtype]
+    S = lo.Storage(dtype, dev)
+    d1, d2 = rng.standard_normal(5).astype(npd), rng.standard_normal(1031).astype(npd)
+    M1, M2 = rng.standard_normal((4, 7)).astype(npd), rng.standard_normal((300, 3)).astype(npd)
+    ops = [lo.opDiagonal(T(d1, dev)), TM(M1, dev), lo.opEye(dtype, 3, S=S), lo.LinearOperatorFromMatrix(TM(M2, dev)),
+           lo.opZeros(dtype, 2, 5, S=S), lo.opDiagonal(T(d2, dev))]
+    dense = [np.diag(d1), M1, np.eye(3), M2, np.zeros((2, 5)), np.diag(d2)]
+    nr, nc = sum(a.shape[0] for a in dense), sum(a.shape[1] for a in dense)
+    D = np.zeros((nr, nc))
+    r = c = 0
+    for a in dense:
+        D[r:r + a.shape[0], c:c + a.shape[1]] = a
+        r += a.shape[0]; c += a.shape[1]
+    BD = lo.BlockDiagonalOperator(*ops)
+    assert hasattr(BD, "_keepalive")                       # took the single-launch path
+    tol = 1e-12 if dtype == torch.float64 else 2e-5
+    x, xt = rng.standard_normal(nc).astype(npd), rng.standard_normal(nr).astype(npd)
+    assert rel((BD * T(x, dev)).cpu().numpy(), D @ x) <= tol
+    assert rel((BD.T * T(xt, dev)).cpu().numpy(), D.T @ xt) <= tol
+    assert rel((BD.H * T(xt, dev)).cpu().numpy(), D.T @ xt) <= tol
+    r0 = rng.standard_normal(nr).astype(npd)
+    res = T(r0.copy(), dev)
+    lo.mul(res, BD, T(x, dev), 2.0, -3.0)
+    assert rel(res.cpu().numpy(), 2.0 * (D @ x) - 3.0 * r0) <= tol
+    res = T(np.full(nr, np.nan, dtype=npd), dev)
+    lo.mul(res, BD, T(x, dev), 1.0, 0.0)
+    assert torch.isfinite(res).all()
+
+
+def test_blockdiag_of_diagonals_bit_exact_and_generic_path(lo, dev):
+    """BASELINE config 4a shape (1024 opDiagonal blocks) at a reduced block size with ODD block length so
+    blocks start at every 16-byte phase: the fused launch must equal block-by-block oracle results bit
+    for bit; the generic path (a Householder block forces the reference's loop structure) agrees too."""
+    rng = np.random.default_rng(5)
+    nb, bs = 1024, 997
+    ds = [rng.standard_normal(bs) for _ in range(nb)]
+    BD = lo.BlockDiagonalOperator(*[lo.opDiagonal(T(d, dev)) for d in ds])
+    x, r0 = rng.standard_normal(nb * bs), rng.standard_normal(nb * bs)
+    for alpha, beta in ((1.0, 0.0), (2.0 / 3.0, -0.3)):
+        res = T(r0.copy(), dev)
+        lo.mul(res, BD, T(x, dev), alpha, beta)
+        want = r0.copy()
+        for k, d in enumerate(ds):
+            sl = slice(k * bs, (k + 1) * bs)
+            want[sl] = oracle.diag_mul(r0[sl].copy(), d, np.ascontiguousarray(x[sl]), alpha, beta)
+        assert np.array_equal(res.cpu().numpy(), want)
+    h = rng.standard_normal(50); h /= np.linalg.norm(h)
+    G = lo.BlockDiagonalOperator(lo.opDiagonal(T(ds[0], dev)), lo.opHouseholder(T(h, dev)), lo.opDiagonal(T(ds[1], dev)))
+    assert not hasattr(G, "_keepalive")
+    xx = rng.standard_normal(2 * bs + 50)
+    want = np.concatenate([ds[0] * xx[:bs], xx[bs:bs + 50] - 2 * (h @ xx[bs:bs + 50]) * h, ds[1] * xx[bs + 50:]])
+    assert rel((G * T(xx, dev)).cpu().numpy(), want) <= 1e-12
+    assert rel((G.T * T(xx, dev)).cpu().numpy(), want) <= 1e-12
+
+
+def test_combinators_vs_dense(lo, dev):
+    """test_linop.jl (arithmetic), test_cat.jl:96-118,165-187 (α,β = 3,-4), test_adjtrans.jl."""
+    rng = np.random.default_rng(9)
+    n = 40
+    A1, A2 = rng.standard_normal((n, n)), rng.standard_normal((n, n))
+    d = rng.standard_normal(n)
+    h = rng.standard_normal(n); h /= np.linalg.norm(h)
+    opA1, opA2 = lo.LinearOperatorFromMatrix(TM(A1, dev)), lo.LinearOperatorFromMatrix(TM(A2, dev))
+    D, H = lo.opDiagonal(T(d, dev)), lo.opHouseholder(T(h, dev))
+    Hd = np.eye(n) - 2 * np.outer(h, h)
+    cases = [
+        (opA1 + opA2, A1 + A2), (opA1 - opA2, A1 - A2), (-opA1, -A1), (opA1 * opA2, A1 @ A2),
+        (2.5 * opA1, 2.5 * A1), (opA1 * 2.5, 2.5 * A1), (opA1 / 4.0, A1 / 4.0),
+        (H * D * H.H, Hd @ np.diag(d) @ Hd.T), (opA1 + 1.5, A1 + 1.5), (2.0 - opA1, 2.0 - A1),
+        ((opA1 * D + H).T, (A1 @ np.diag(d) + Hd).T), ((opA1 * opA2).H, (A1 @ A2).T),
+        (lo.hcat(opA1, D, H), np.hstack([A1, np.diag(d), Hd])), (lo.vcat(opA1, D, H), np.vstack([A1, np.diag(d), Hd])),
+        (lo.hvcat((2, 2), opA1, D, H, opA2), np.block([[A1, np.diag(d)], [Hd, A2]])),
+        (lo.hcat(opA1, D).T, np.hstack([A1, np.diag(d)]).T), (lo.vcat(opA1, D).H, np.vstack([A1, np.diag(d)]).T),
+    ]
+    # op[rows, cols] = R * op * E (special-operators.jl:225-233). mulRestrict!/multRestrict! IGNORE α and β
+    # (:167-174), so a 5-arg mul! through an outer restriction returns the plain product — reference
+    # behaviour, reproduced here.
+    index_cases = [
+        (opA1[[3, 4], [5, 6]], A1[np.ix_([2, 3], [4, 5])]),            # test_linop.jl:463-466
+        (opA1[lo.jrange(2, 9, 3), slice(None)], A1[1:9:3, :]),
+        (opA1[4, lo.jrange(1, n)], A1[3:4, :]),
+    ]
+    for op, M in cases + index_cases:
+        m, k = M.shape
+        assert op.shape == (m, k)
+        v, r0 = rng.standard_normal(k), rng.standard_normal(m)
+        assert rel((op * T(v, dev)).cpu().numpy(), M @ v) <= 1e-12
+        res = T(r0.copy(), dev)
+        lo.mul(res, op, T(v, dev), 3.0, -4.0)
+        if any(op is ic[0] for ic in index_cases):
+            assert rel(res.cpu().numpy(), M @ v) <= 1e-12
+        else:
+            assert rel(res.cpu().numpy(), 3.0 * (M @ v) - 4.0 * r0) <= 1e-12
+        assert rel(lo.Matrix(op).cpu().numpy(), M) <= 1e-12
+    with pytest.raises(lo.LinearOperatorException):
+        opA1 * lo.opDiagonal(T(d[:5], dev))
+    with pytest.raises(lo.LinearOperatorException):
+        opA1 + lo.opDiagonal(T(d[:5], dev))
+    with pytest.raises(lo.LinearOperatorException):
+        lo.hcat(opA1, lo.opDiagonal(T(d[:5], dev)))
+    # wrapper identities (test_adjtrans.jl)
+    assert lo.adjoint(lo.adjoint(opA1)) is opA1 and lo.transpose(lo.transpose(opA1)) is opA1
+    assert isinstance(lo.transpose(lo.adjoint(opA1)), lo.ConjugateLinearOperator)
+    assert lo.storage_type(opA1.T) == lo.storage_type(opA1)
+    # counters through wrappers (test_linop.jl:634-716)
+    lo.reset(opA1)
+    v = T(rng.standard_normal(n), dev)
+    opA1 * v; opA1.T * v; opA1.H * v; opA1.H * v
+    assert (lo.nprod(opA1), lo.ntprod(opA1), lo.nctprod(opA1)) == (1, 1, 2)
+    assert lo.nprod(opA1.H) == 2 and lo.nctprod(opA1.T) == 1

@@ -1,0 +1,322 @@
+"""-m gpu: quasi-Newton operators through the C ABI vs the oracle.
+
+Tolerances (fp64): reference-ordered inverse two-loop, forward L-BFGS, L-SR1: 1e-10 relative L2;
+two-pass (Gram) inverse form: 1e-9; shifted solve (coefficient space): 1e-8 relative on
+well-conditioned pairs. fp32: 2e-4. All far inside the reference's own sqrt(eps) ~ 1.5e-8 /
+isapprox(1e-6) bars for the properties it tests."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+NP = {torch.float64: np.float64, torch.float32: np.float32}
+SV = lambda n: np.array([-(-1.0) ** i for i in range(1, n + 1)])
+
+
+def T(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    nb = np.linalg.norm(b)
+    return np.linalg.norm(a - b) / (nb if nb else 1.0)
+
+
+def pairs(rng, n, k, dtype=np.float64):
+    out = []
+    for _ in range(k):
+        s = rng.uniform(-1, 1, n)
+        y = s * rng.uniform(0.5, 2.0, n) + 1e-2 * rng.standard_normal(n)
+        out.append((s.astype(dtype), y.astype(dtype)))
+    return out
+
+
+# ------------------------------------------------------------------------------- KATs
+def test_kat_lbfgs(lo, dev, kat):
+    """test_lbfgs.jl:7-70 through the ABI (values from dense BFGS in exact rationals)."""
+    for c in [c for c in kat if c["kind"] == "lbfgs"]:
+        n, mem = c["n"], c["mem"]
+        B = lo.LBFGSOperator(n, mem=mem, scaling=c["scaling"], device=dev)
+        H = lo.InverseLBFGSOperator(n, mem=mem, scaling=c["scaling"], device=dev)
+        assert lo.isallocated5(B) and lo.isallocated5(H)
+        I = np.eye(n)
+        for t in range(2):                                       # run again after reset! (:13)
+            assert np.array_equal(lo.Matrix(B).cpu().numpy(), I) and np.array_equal(lo.Matrix(H).cpu().numpy(), I)
+            assert B.data.insert == 1 and H.data.insert == 1
+            for p in c["pre_rejected"]:
+                lo.push(B, T(np.array(p["s"]), dev), T(np.array(p["y"]), dev))
+                lo.push(H, T(np.array(p["s"]), dev), T(np.array(p["y"]), dev))
+                assert B.data.insert == 1 and H.data.insert == 1
+            for p in c["pairs"]:
+                lo.push(B, T(np.array(p["s"]), dev), T(np.array(p["y"]), dev))
+                lo.push(H, T(np.array(p["s"]), dev), T(np.array(p["y"]), dev))
+            assert B.data.insert == H.data.insert == c["expect_insert"]
+            assert np.array_equal(B.data.ys, np.array(c["expect_ys_slots"]))
+            v = T(np.array(c["v"]), dev)
+            assert rel((B * v).cpu().numpy(), np.array(c["expect_Bv"])) <= 1e-12
+            assert rel((H * v).cpu().numpy(), np.array(c["expect_Hv"])) <= 1e-12
+            H.set_mode("reforder")
+            assert rel((H * v).cpu().numpy(), np.array(c["expect_Hv"])) <= 1e-12
+            H.set_mode("twopass")
+            assert rel(lo.diag(B).cpu().numpy(), np.array(c["expect_diagB"])) <= 1e-12
+            MB, MH = lo.Matrix(B).cpu().numpy(), lo.Matrix(H).cpu().numpy()
+            assert np.linalg.norm(np.diag(MB) - lo.diag(B).cpu().numpy()) <= 1e-8           # :54
+            assert np.linalg.norm(MH @ MB - I) <= np.sqrt(np.finfo(float).eps)              # :56
+            assert np.allclose(MB, MB.T, rtol=0, atol=1e-12) and np.linalg.eigvalsh(MB).min() > 0
+            assert np.linalg.norm(MB, 2) <= B.data.opnorm_upper_bound                        # :70
+            assert rel((lo.compose(H, B) * v).cpu().numpy(), np.array(c["v"])) <= 1e-12
+            lo.reset(B); lo.reset(H)                                                         # :62-67
+            assert B.data.scaling_factor == 1.0 and H.data.scaling_factor == 1.0 and B.nprod == 0
+            assert np.linalg.norm((B * v).cpu().numpy() - np.array(c["v"])) < 1e-8
+    with pytest.raises(lo.LinearOperatorException):
+        lo.diag(lo.InverseLBFGSOperator(5, device=dev))
+
+
+def test_kat_lsr1(lo, dev, kat):
+    """test_lsr1.jl:6-41."""
+    for c in [c for c in kat if c["kind"] == "lsr1"]:
+        n = c["n"]
+        B = lo.LSR1Operator(n, mem=c["mem"], scaling=c["scaling"], device=dev)
+        for t in range(2):
+            assert np.array_equal(lo.Matrix(B).cpu().numpy(), np.eye(n)) and B.data.insert == 1
+            s = T(SV(n), dev)
+            lo.push(B, s, B * s)                                                    # rejected (:18-21)
+            assert B.data.insert == 1
+            nacc = 0
+            for p in c["pairs"]:
+                lo.push(B, T(np.array(p["s"]), dev), T(np.array(p["y"]), dev))
+                nacc += B._last_push_accepted
+            assert nacc == c["expect_naccepted"] and B.data.insert == c["expect_insert"]
+            v = T(np.array(c["v"]), dev)
+            assert rel((B * v).cpu().numpy(), np.array(c["expect_Bv"])) <= 1e-12
+            assert rel(lo.diag(B).cpu().numpy(), np.array(c["expect_diagB"])) <= 1e-12
+            MB = lo.Matrix(B).cpu().numpy()
+            assert np.allclose(MB, MB.T, atol=1e-12) and np.linalg.norm(MB, 2) <= B.data.opnorm_upper_bound
+            lo.reset(B)
+            assert B.data.scaling_factor == 1.0
+
+
+# ------------------------------------------------------------------------------- seeded parity
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("n,mem,npush,scaling", [(1000, 5, 8, True), (4097, 10, 13, True), (257, 3, 2, False),
+                                                  (100_003, 7, 7, True), (64, 1, 3, True), (50_000, 20, 23, True)])
+def test_lbfgs_parity(lo, dev, dtype, n, mem, npush, scaling):
+    rng = np.random.default_rng(n + mem)
+    npd = NP[dtype]
+    tol = dict(ref=1e-10, two=1e-9, fwd=1e-10) if dtype == torch.float64 else dict(ref=2e-4, two=2e-4, fwd=2e-4)
+    B = lo.LBFGSOperator(dtype, n, mem=mem, scaling=scaling, device=dev)
+    H = lo.InverseLBFGSOperator(dtype, n, mem=mem, scaling=scaling, device=dev)
+    Bo = oracle.LBFGS(n, mem=mem, scaling=scaling, inverse=False, dtype=npd)
+    Ho = oracle.LBFGS(n, mem=mem, scaling=scaling, inverse=True, dtype=npd)
+    x, r0 = rng.uniform(-1, 1, n).astype(npd), rng.uniform(-1, 1, n).astype(npd)
+    for k, (s, y) in enumerate(pairs(rng, n, npush, npd)):
+        lo.push(B, T(s, dev), T(y, dev)); lo.push(H, T(s, dev), T(y, dev))
+        Bo.push(s, y); Ho.push(s, y)
+        assert B.data.insert == Bo.insert and H.data.insert == Ho.insert
+        if k in (0, npush // 2, npush - 1):
+            for alpha, beta in ((1.0, 0.0), (-1.0, 0.0), (2.0, -3.0)):
+                fl = oracle.SCALARS_F64 if dtype == torch.float32 else 0
+                res = T(r0.copy(), dev)
+                if beta == 0:
+                    res.fill_(float("nan"))
+                lo.mul(res, B, T(x, dev), alpha, beta)
+                assert rel(res.cpu().numpy(), Bo.mul(r0.copy(), x, alpha, beta, flags=fl)) <= tol["fwd"], ("fwd", k)
+                want = Ho.mul(r0.copy(), x, alpha, beta, flags=fl)
+                for mode in ("twopass", "reforder"):
+                    H.set_mode(mode)
+                    res = T(r0.copy(), dev)
+                    if beta == 0:
+                        res.fill_(float("nan"))
+                    lo.mul(res, H, T(x, dev), alpha, beta)
+                    assert rel(res.cpu().numpy(), want) <= tol["two" if mode == "twopass" else "ref"], (mode, k)
+                H.set_mode("twopass")
+    assert abs(B.data.scaling_factor - Bo.scaling_factor) <= 1e-6 * abs(Bo.scaling_factor)
+    assert rel(lo.diag(B).cpu().numpy(), Bo.diag()) <= tol["fwd"]
+    assert rel(B.data.opnorm_upper_bound, Bo.opnorm_upper_bound) <= 1e-5
+    # H*(B*x) == x (the property behind test_lbfgs.jl:56) at this size
+    back = H * (B * T(x, dev))
+    assert rel(back.cpu().numpy(), x) <= (1e-8 if dtype == torch.float64 else 5e-2)
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("n,mem,npush,scaling", [(1000, 5, 8, True), (4099, 8, 11, False), (100_001, 6, 9, True)])
+def test_lsr1_parity(lo, dev, dtype, n, mem, npush, scaling):
+    rng = np.random.default_rng(7 * n + mem)
+    npd = NP[dtype]
+    tol = 1e-10 if dtype == torch.float64 else 5e-4
+    B = lo.LSR1Operator(dtype, n, mem=mem, scaling=scaling, device=dev)
+    Bo = oracle.LSR1(n, mem=mem, scaling=scaling, dtype=npd)
+    x, r0 = rng.uniform(-1, 1, n).astype(npd), rng.uniform(-1, 1, n).astype(npd)
+    for s, y in pairs(rng, n, npush, npd):
+        lo.push(B, T(s, dev), T(y, dev))
+        assert B._last_push_accepted == Bo.push(s, y)
+        assert B.data.insert == Bo.insert
+    for alpha, beta in ((1.0, 0.0), (2.0, -3.0), (-1, 1)):
+        fl = oracle.SCALARS_F64 if (dtype == torch.float32 and isinstance(alpha, float)) else 0
+        res = T(r0.copy(), dev)
+        lo.mul(res, B, T(x, dev), alpha, beta)
+        assert rel(res.cpu().numpy(), Bo.mul(r0.copy(), x, float(alpha), float(beta), flags=fl)) <= tol
+    assert rel(lo.diag(B).cpu().numpy(), Bo.diag()) <= tol
+    assert rel(B.data.opnorm_upper_bound, Bo.opnorm_upper_bound) <= 1e-4
+
+
+def test_lbfgs_vs_dense_bfgs(lo, dev):
+    """test_lbfgs.jl:73-99 / test_lsr1.jl:43-68 with random pairs."""
+    rng = np.random.default_rng(1)
+    n = mem = 12
+    LB = lo.LBFGSOperator(n, mem=mem, scaling=False, device=dev)
+    LS = lo.LSR1Operator(n, mem=mem, scaling=False, device=dev)
+    Bd, Sd = np.eye(n), np.eye(n)
+    for _ in range(mem):
+        s = rng.uniform(-1, 1, n)
+        y = s * rng.uniform(0.5, 2.0, n)
+        Bs = Bd @ s
+        Bd = Bd - np.outer(Bs, Bs) / (s @ Bs) + np.outer(y, y) / (y @ s)
+        r = y - Sd @ s
+        if abs(r @ s) >= 1e-8 + 1e-8 * np.linalg.norm(s) * np.linalg.norm(r):
+            Sd = Sd + np.outer(r, r) / (r @ s)
+        lo.push(LB, T(s, dev), T(y, dev)); lo.push(LS, T(s, dev), T(y, dev))
+        assert np.linalg.norm(lo.Matrix(LB).cpu().numpy() - Bd) < 1e-8 * np.linalg.norm(Bd)
+        assert np.linalg.norm(lo.Matrix(LS).cpu().numpy() - Sd) < 1e-7 * np.linalg.norm(Sd)
+        assert np.linalg.norm(lo.diag(LB).cpu().numpy() - np.diag(Bd)) < 1e-8 * np.linalg.norm(np.diag(Bd))
+
+
+def test_damped_pushes(lo, dev):
+    """test_lbfgs.jl:104-159 and the misuse errors :220-240."""
+    n, mem = 50, 10
+    rng = np.random.default_rng(4)
+    B = lo.LBFGSOperator(n, mem=mem, damped=True, scaling=False, sigma2=0.8, sigma3=float("inf"), device=dev)
+    H = lo.InverseLBFGSOperator(n, mem=mem, damped=True, scaling=False, sigma2=0.8, sigma3=float("inf"), device=dev)
+    Bo = oracle.LBFGS(n, mem=mem, damped=True, scaling=False, inverse=False, sigma2=0.8, sigma3=np.inf)
+    Ho = oracle.LBFGS(n, mem=mem, damped=True, scaling=False, inverse=True, sigma2=0.8, sigma3=np.inf)
+    for i in range(1, mem + 3):
+        s = SV(n) * i
+        y = rng.uniform(-1, 1, n)
+        if s @ y <= 0:
+            y = -y
+        lo.push(B, T(s, dev), T(y, dev)); Bo.push(s.copy(), y.copy())
+        g = rng.uniform(-1, 1, n)
+        yd = T(y, dev)
+        lo.push(H, T(s, dev), yd, 0.5, T(g, dev)); yo = y.copy(); Ho.push(s.copy(), yo, alpha=0.5, g=g)
+        assert rel(yd.cpu().numpy(), yo) <= 1e-12        # damping mutates y in place (lbfgs.jl:351)
+    x = rng.uniform(-1, 1, n)
+    assert rel((B * T(x, dev)).cpu().numpy(), Bo.mul(np.empty(n), x)) <= 1e-9
+    assert rel((H * T(x, dev)).cpu().numpy(), Ho.mul(np.empty(n), x)) <= 1e-8
+    assert np.linalg.eigvalsh(lo.Matrix(B).cpu().numpy()).min() > 0
+    U = lo.LBFGSOperator(n, device=dev)
+    with pytest.raises(RuntimeError):
+        lo.push(U, T(x, dev), T(x, dev), T(x, dev))
+    with pytest.raises(RuntimeError):
+        lo.push(B, T(x, dev), T(x, dev), 1.0, T(x, dev))
+    with pytest.raises(RuntimeError):
+        lo.push(H, T(x, dev), T(x, dev), T(x, dev))
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("scaling", [False, True])
+def test_solve_shifted_system(lo, dev, dtype, scaling):
+    """test_solve_shifted_system.jl:5-61: build b = Bx + σx, recover x; ldiv! == H*b; σ<0 -> error."""
+    rng = np.random.default_rng(3)
+    n, M = 100, 5
+    npd = NP[dtype]
+    B = lo.LBFGSOperator(dtype, n, mem=M, scaling=scaling, device=dev)
+    H = lo.InverseLBFGSOperator(dtype, n, mem=M, scaling=scaling, device=dev)
+    Bo = oracle.LBFGS(n, mem=M, scaling=scaling, inverse=False, dtype=npd)
+    for _ in range(10):
+        s, y = rng.random(n).astype(npd), rng.random(n).astype(npd)
+        lo.push(B, T(s, dev), T(y, dev)); lo.push(H, T(s, dev), T(y, dev)); Bo.push(s, y)
+    x = rng.standard_normal(n).astype(npd)
+    at = 1e-6 if dtype == torch.float64 else 5e-2
+    for sigma in (0.1, 0.0, 3.0):
+        b = (B * T(x, dev)) + sigma * T(x, dev)
+        xs = torch.zeros(n, dtype=dtype, device=dev)
+        out = lo.solve_shifted_system(xs, B, b, sigma)
+        assert out is xs and torch.isfinite(xs).all()
+        assert np.allclose(xs.cpu().numpy(), x, atol=at, rtol=at)
+        if dtype == torch.float64:   # against the oracle's statement-by-statement recursion
+            want = Bo.solve_shifted(np.zeros(n), b.cpu().numpy(), sigma)
+            assert rel(xs.cpu().numpy(), want) <= 1e-8
+    b = B * T(x, dev)
+    xs = lo.ldiv(torch.zeros(n, dtype=dtype, device=dev), B, b)
+    assert np.allclose(xs.cpu().numpy(), (H * b).cpu().numpy(), atol=at, rtol=at)
+    with pytest.raises(ValueError):
+        lo.solve_shifted_system(xs, B, b, -0.1)
+    # partially filled memory and empty operator
+    B2 = lo.LBFGSOperator(dtype, n, mem=8, scaling=scaling, device=dev)
+    xs = lo.solve_shifted_system(torch.zeros(n, dtype=dtype, device=dev), B2, T(x, dev), 1.0)
+    assert np.allclose(xs.cpu().numpy(), x / 2, rtol=1e-6)
+    lo.push(B2, T(rng.random(n).astype(npd), dev), T(rng.random(n).astype(npd), dev))
+    b = (B2 * T(x, dev)) + 0.5 * T(x, dev)
+    xs = lo.solve_shifted_system(torch.zeros(n, dtype=dtype, device=dev), B2, b, 0.5)
+    assert np.allclose(xs.cpu().numpy(), x, atol=at, rtol=at)
+
+
+def test_lbfgs_bench_size_properties(lo, dev):
+    """BASELINE config 3 size (m=10, n=5e7): H*(B*x) == x, linearity, determinism; reference-ordered and
+    two-pass inverse forms agree."""
+    n, m = 50_000_000, 10
+    g = torch.Generator(device=dev).manual_seed(11)
+    B = lo.LBFGSOperator(torch.float64, n, mem=m, device=dev)
+    H = lo.InverseLBFGSOperator(torch.float64, n, mem=m, device=dev)
+    for _ in range(m + 3):
+        s = torch.rand(n, dtype=torch.float64, device=dev, generator=g) * 2 - 1
+        y = (torch.rand(n, dtype=torch.float64, device=dev, generator=g) * 1.5 + 0.5) * s
+        y += 1e-2 * (torch.rand(n, dtype=torch.float64, device=dev, generator=g) - 0.5)
+        lo.push(B, s, y); lo.push(H, s, y)
+        del s, y
+    x = torch.rand(n, dtype=torch.float64, device=dev, generator=g) * 2 - 1
+    hx = H * x
+    assert torch.equal(hx, H * x)                                           # deterministic
+    H.set_mode("reforder")
+    hx_ref = H * x
+    H.set_mode("twopass")
+    assert (torch.linalg.vector_norm(hx - hx_ref) / torch.linalg.vector_norm(hx_ref)).item() <= 1e-9
+    del hx_ref
+    back = B * hx
+    assert (torch.linalg.vector_norm(back - x) / torch.linalg.vector_norm(x)).item() <= 1e-8
+    del back
+    out = torch.empty_like(x)
+    lo.mul(out, H, x, 2.0, 0.0)
+    assert (torch.linalg.vector_norm(out - 2 * hx) / torch.linalg.vector_norm(hx)).item() <= 1e-14
+
+
+def test_allreduce_hook_world1(lo, dev):
+    """The row-sharding hook is invoked on every global reduction; with world_size == 1 the RCCL
+    all-reduce is the identity, so results must be unchanged (multi-rank logic: tests/test_sharded_cpu.py)."""
+    import os
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29541")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        ctx = lo.get_ctx(dev)
+        calls = []
+        inner = lo.sharded.make_allreduce_hook(None, cuda=True)
+
+        def hook(user, buf, count, stream):
+            calls.append(int(count))
+            return inner(user, buf, count, stream)
+
+        rng = np.random.default_rng(0)
+        n = 10_000
+        h = rng.standard_normal(n); h /= np.linalg.norm(h)
+        v = rng.uniform(-1, 1, n)
+        H = lo.opHouseholder(T(h, dev))
+        want = (H * T(v, dev)).clone()
+        ctx.set_allreduce(hook)
+        got = H * T(v, dev)
+        assert torch.equal(got, want) and calls == [1]
+        Hq = lo.InverseLBFGSOperator(n, mem=4, device=dev)
+        for s, y in pairs(rng, n, 5):
+            lo.push(Hq, T(s, dev), T(y, dev))
+        calls.clear()
+        r1 = Hq * T(v, dev)
+        assert calls == [8]                      # ONE all-reduce of 2m doubles per apply
+        ctx.set_allreduce(None)
+        assert torch.equal(r1, Hq * T(v, dev))
+    finally:
+        lo.get_ctx(dev).set_allreduce(None)
+        dist.destroy_process_group()

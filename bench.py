@@ -159,6 +159,12 @@ def main():
         except Exception as e:  # never lose the headline line
             extras["lbfgs_error"] = repr(e)
 
+    if not args.no_extras:
+        try:
+            extras.update(bench_cfg4(lo, torch, dev, ctx))
+        except Exception as e:
+            extras["cfg4_error"] = repr(e)
+
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu_baseline = cpu_leg(args.cpu_sample)
@@ -233,6 +239,54 @@ def bench_lbfgs(lo, torch, dev, ctx, rank, world, distributed, dist, barrier):
                                       "frac_hbm_peak": round(bytes_ / sec / 1e9 / HBM_PEAK_GBS, 4),
                                       "n_global": n * world}
     del Bf
+    torch.cuda.empty_cache()
+    return out
+
+
+def bench_cfg4(lo, torch, dev, ctx):
+    """BASELINE configs[3]: BlockDiagonalOperator of 1024 opDiagonal blocks (1024 rows each: launch-latency
+    regime; 97,657 rows each: HBM regime) and kron(A,B), A,B 1024x1024 (f64 MFMA GEMMs), replicas per GPU."""
+    from linearoperators_jl_amd.device import Timer
+    tm = Timer(ctx)
+    out = {}
+    gen = torch.Generator(device=dev).manual_seed(4)
+
+    def timeit(fn, reps):
+        for _ in range(3):
+            fn()
+        tm.start()
+        for _ in range(reps):
+            fn()
+        tm.stop()
+        return tm.elapsed_ms() / reps
+
+    for bs, reps in ((1024, 200), (97_657, 20)):
+        nb = 1024
+        dall = torch.rand(nb * bs, dtype=torch.float64, device=dev, generator=gen) + 0.5
+        BD = lo.BlockDiagonalOperator(*[lo.opDiagonal(dall[k * bs:(k + 1) * bs]) for k in range(nb)])
+        x = torch.rand(nb * bs, dtype=torch.float64, device=dev, generator=gen) * 2 - 1
+        res = torch.empty_like(x)
+        ms = timeit(lambda: lo.mul(res, BD, x, 1.0, 0.0), reps)
+        out[f"BlockDiagonal_1024x{bs}"] = {"us_per_apply": round(ms * 1e3, 2), "launches": 1,
+                                          "GB/s(24B/elt)": round(24.0 * nb * bs / ms / 1e6, 1),
+                                          "frac_hbm_peak": round(24.0 * nb * bs / ms / 1e6 / HBM_PEAK_GBS, 4)}
+        if bs == 1024:
+            keep = (BD, x, res, dall)
+        else:
+            del BD, x, res, dall
+    n = 1024
+    A = ((torch.rand(n, n, dtype=torch.float64, device=dev, generator=gen) * 2 - 1) / 32).t()
+    B = ((torch.rand(n, n, dtype=torch.float64, device=dev, generator=gen) * 2 - 1) / 32).t()
+    K = lo.kron(A, B)
+    x = torch.rand(n * n, dtype=torch.float64, device=dev, generator=gen) * 2 - 1
+    res = torch.empty_like(x)
+    ms = timeit(lambda: lo.mul(res, K, x, 1.0, 0.0), 50)
+    flop = 4.0 * n ** 3
+    out["kron_1024x1024"] = {"us_per_apply": round(ms * 1e3, 2), "TFLOP/s_f64": round(flop / ms / 1e9, 2),
+                             "frac_f64_mfma_peak(78.6TF)": round(flop / ms / 1e9 / 78.6, 4)}
+    Ssum = keep[0] + K
+    ms = timeit(lambda: lo.mul(res, Ssum, x, 1.0, 0.0), 50)
+    out["BlockDiagonal_plus_kron_2^20"] = {"us_per_apply": round(ms * 1e3, 2)}
     torch.cuda.empty_cache()
     return out
 

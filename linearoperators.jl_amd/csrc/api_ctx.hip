@@ -106,6 +106,12 @@ MXLO_API int32_t mxlo_ctx_tune(mxlo_ctx *ctx, const char *key, int64_t value) {
     MXLO_REQUIRE(value == MXLO_INV_TWOPASS || value == MXLO_INV_REFORDER, MXLO_EINVAL,
                  "lbfgs_inv_mode must be MXLO_INV_TWOPASS or MXLO_INV_REFORDER");
     ctx->tune.lbfgs_inv_mode = (int)value;
+  } else if (!strcmp(key, "house_mall_tail_bytes")) {
+    MXLO_REQUIRE(value >= 0, MXLO_EINVAL, "house_mall_tail_bytes out of range");
+    ctx->tune.house_mall_tail_bytes = value;
+  } else if (!strcmp(key, "combine_blocks_per_cu")) {
+    MXLO_REQUIRE(value >= 0 && value <= 64, MXLO_EINVAL, "combine_blocks_per_cu out of range");
+    ctx->tune.combine_blocks_per_cu = (int)value;
   } else if (!strcmp(key, "dots_max_nc")) {
     MXLO_REQUIRE(value >= 1 && value <= 20, MXLO_EINVAL, "dots_max_nc out of range");
     ctx->tune.dots_max_nc = (int)value;

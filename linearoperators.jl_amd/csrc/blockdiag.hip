@@ -35,11 +35,11 @@ struct Tile {
   int64_t start;  // first output row of this tile inside its block
 };
 
-template <typename T, int VEC>
+template <typename T, int VEC, bool NT>
 __device__ __forceinline__ void load_vec(const T *p, bool aligned, T (&out)[VEC]) {
   using V = typename VecOf<T, VEC>::type;
   if (aligned) {
-    const V v = *reinterpret_cast<const V *>(p);
+    const V v = ldg<NT>(reinterpret_cast<const V *>(p));
 #pragma unroll
     for (int e = 0; e < VEC; ++e) out[e] = v[e];
   } else {
@@ -62,7 +62,7 @@ __device__ __forceinline__ T ew_op(int kind, CT a, CT b, T d, T v, T r) {
   return (T)t;
 }
 
-template <typename T, typename CT, bool BETA0, bool TRANS>
+template <typename T, typename CT, bool BETA0, bool TRANS, bool NT>
 __global__ void __launch_bounds__(kBlock)
 blockdiag_kernel(T *__restrict__ res, const T *__restrict__ x, const DevBlock *__restrict__ blocks,
                  const Tile *__restrict__ tiles, CT alpha, CT beta) {
@@ -96,18 +96,31 @@ blockdiag_kernel(T *__restrict__ res, const T *__restrict__ x, const DevBlock *_
       const bool xa = (((uintptr_t)(x0 + head)) & 15u) == 0;
       const bool da = d0 ? ((((uintptr_t)(d0 + head)) & 15u) == 0) : true;
       using V = typename VecOf<T, VEC>::type;
-      for (int64_t i = tid; i < nv; i += kBlock) {
-        const int64_t o = head + i * VEC;
-        T dv[VEC], xv[VEC], rv[VEC];
-        if (b.kind == MXLO_BLK_DIAG) load_vec<T, VEC>(d0 + o, da, dv);
-        if (b.kind != MXLO_BLK_ZEROS) load_vec<T, VEC>(x0 + o, xa, xv);
-        if constexpr (!BETA0) load_vec<T, VEC>(r0 + o, true, rv);
-        V out;
+      // every load of the tile is issued before the first store (U vectors per lane in flight)
+      constexpr int U = kTileE / VEC / kBlock;
+      T dv[U][VEC], xv[U][VEC], rv[U][VEC];
 #pragma unroll
-        for (int e = 0; e < VEC; ++e)
-          out[e] = ew_op<T, CT, BETA0>(b.kind, alpha, beta, b.kind == MXLO_BLK_DIAG ? dv[e] : T(0),
-                                       b.kind != MXLO_BLK_ZEROS ? xv[e] : T(0), BETA0 ? T(0) : rv[e]);
-        *reinterpret_cast<V *>(r0 + o) = out;
+      for (int u = 0; u < U; ++u) {
+        const int64_t i = tid + (int64_t)u * kBlock;
+        if (i < nv) {
+          const int64_t o = head + i * VEC;
+          if (b.kind == MXLO_BLK_DIAG) load_vec<T, VEC, NT>(d0 + o, da, dv[u]);
+          if (b.kind != MXLO_BLK_ZEROS) load_vec<T, VEC, NT>(x0 + o, xa, xv[u]);
+          if constexpr (!BETA0) load_vec<T, VEC, NT>(r0 + o, true, rv[u]);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int64_t i = tid + (int64_t)u * kBlock;
+        if (i < nv) {
+          const int64_t o = head + i * VEC;
+          V out;
+#pragma unroll
+          for (int e = 0; e < VEC; ++e)
+            out[e] = ew_op<T, CT, BETA0>(b.kind, alpha, beta, b.kind == MXLO_BLK_DIAG ? dv[u][e] : T(0),
+                                         b.kind != MXLO_BLK_ZEROS ? xv[u][e] : T(0), BETA0 ? T(0) : rv[u][e]);
+          stg<NT>(reinterpret_cast<V *>(r0 + o), out);
+        }
       }
       const int64_t tail0 = head + nv * VEC;
       const int64_t nsc = head + (cnt - tail0);
@@ -238,12 +251,15 @@ static int32_t blockdiag_mul_t(mxlo_blockdiag *bd, T *res, const T *v, double al
   if (nt == 0) return MXLO_OK;
   MXLO_REQUIRE(nt < (1LL << 31), MXLO_ESHAPE, "too many tiles");
   return dispatch_ct<T>(beta, flags, [&]<typename CT, bool B0>() -> int32_t {
-    if (trans)
-      hipLaunchKernelGGL((blockdiag_kernel<T, CT, B0, true>), dim3((unsigned)nt), dim3(kBlock), 0,
-                         ctx->stream, res, v, bd->d_blocks, tiles, (CT)alpha, (CT)beta);
-    else
-      hipLaunchKernelGGL((blockdiag_kernel<T, CT, B0, false>), dim3((unsigned)nt), dim3(kBlock), 0,
-                         ctx->stream, res, v, bd->d_blocks, tiles, (CT)alpha, (CT)beta);
+    const bool ntm = (int64_t)sizeof(T) * (bd->nrow + 2 * bd->ncol) >= ctx->tune.nt_min_bytes;
+#define BD_GO(TR_, NT_)                                                                               \
+  hipLaunchKernelGGL((blockdiag_kernel<T, CT, B0, TR_, NT_>), dim3((unsigned)nt), dim3(kBlock), 0,   \
+                     ctx->stream, res, v, bd->d_blocks, tiles, (CT)alpha, (CT)beta)
+    if (trans && ntm) BD_GO(true, true);
+    else if (trans) BD_GO(true, false);
+    else if (ntm) BD_GO(false, true);
+    else BD_GO(false, false);
+#undef BD_GO
     MXLO_LAUNCH_CHECK();
     return MXLO_OK;
   });

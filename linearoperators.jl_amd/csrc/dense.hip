@@ -113,6 +113,98 @@ gemm_kernel(T *__restrict__ C, int64_t ldc, const T *__restrict__ A, int64_t lda
       }
 }
 
+// ---- fast path: C = alpha * A * B'^T (+ beta*C) with BOTH operands contiguous along their non-K
+// dimension: A is M x K (i contiguous, lda), B' is stored N x K (j contiguous, ldb) — the (N,T) case,
+// which is the only one kron's N mode needs when the first product is formed transposed:
+//   Ut = A * X^T (m x q),  R = B * Ut^T (p x m).
+// 64x64 tile, BK = 32, 16-byte global loads straight into k-major LDS rows (no transposing writes),
+// register-prefetch double buffering: the next K-slab's global loads are in flight while the 32 MFMAs
+// of the current slab issue; one barrier per slab.
+constexpr int FBK = 32;
+
+template <typename T, typename CT, bool BETA0>
+__global__ void __launch_bounds__(kBlock)
+gemm_nt_fast_kernel(T *__restrict__ C, int64_t ldc, const T *__restrict__ A, int64_t lda,
+                    const T *__restrict__ B, int64_t ldb, int K, CT alpha, CT beta) {
+  constexpr int VEC = Vec16<T>::N;                       // elements per 16-byte load
+  constexpr int LPT = BM * FBK / VEC / kBlock;           // 16-byte loads per thread per operand slab
+  constexpr int RPV = BM / VEC;                          // vectors per k-row (32 for f64, 16 for f32)
+  using V = typename Vec16<T>::type;
+  __shared__ T sA[2][FBK][LDT];
+  __shared__ T sB[2][FBK][LDT];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int bm = blockIdx.x * BM, bn = blockIdx.y * BN;
+  const int wm = (wave & 1) * 32, wn = (wave >> 1) * 32;
+  using Acc = typename Mfma<T>::Acc;
+  Acc acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[a][b][r] = 0;
+
+  V ra[LPT], rb[LPT];
+  auto gload = [&](int k0) {
+#pragma unroll
+    for (int r = 0; r < LPT; ++r) {
+      const int idx = tid + r * kBlock;
+      const int iv = idx % RPV, k = idx / RPV;
+      ra[r] = *reinterpret_cast<const V *>(A + (bm + iv * VEC) + (int64_t)(k0 + k) * lda);
+      rb[r] = *reinterpret_cast<const V *>(B + (bn + iv * VEC) + (int64_t)(k0 + k) * ldb);
+    }
+  };
+  auto lstore = [&](int buf) {
+#pragma unroll
+    for (int r = 0; r < LPT; ++r) {
+      const int idx = tid + r * kBlock;
+      const int iv = idx % RPV, k = idx / RPV;
+      *reinterpret_cast<V *>(&sA[buf][k][iv * VEC]) = ra[r];
+      *reinterpret_cast<V *>(&sB[buf][k][iv * VEC]) = rb[r];
+    }
+  };
+  const int nk = K / FBK;
+  gload(0);
+  lstore(0);
+  __syncthreads();
+  for (int it = 0; it < nk; ++it) {
+    const int buf = it & 1;
+    if (it + 1 < nk) gload((it + 1) * FBK);
+#pragma unroll
+    for (int kk = 0; kk < FBK; kk += 4) {
+      const int kr = kk + (lane >> 4);
+      const T a0 = sA[buf][kr][wm + (lane & 15)], a1 = sA[buf][kr][wm + 16 + (lane & 15)];
+      const T b0 = sB[buf][kr][wn + (lane & 15)], b1 = sB[buf][kr][wn + 16 + (lane & 15)];
+      acc[0][0] = Mfma<T>::run(a0, b0, acc[0][0]);
+      acc[0][1] = Mfma<T>::run(a0, b1, acc[0][1]);
+      acc[1][0] = Mfma<T>::run(a1, b0, acc[1][0]);
+      acc[1][1] = Mfma<T>::run(a1, b1, acc[1][1]);
+    }
+    if (it + 1 < nk) lstore(buf ^ 1);
+    __syncthreads();
+  }
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int gi = bm + wm + a * 16 + Mfma<T>::row(lane, r);
+        const int gj = bn + wn + b * 16 + (lane & 15);
+        T *p = C + gi + (int64_t)gj * ldc;
+        CT t = alpha * (CT)acc[a][b][r];
+        if constexpr (!BETA0) t = t + (beta * (CT)(*p));
+        *p = (T)t;
+      }
+}
+
+template <typename T>
+bool gemm_nt_fast_ok(const T *A, int64_t lda, const T *B, int64_t ldb, int64_t M, int64_t N, int64_t K) {
+  constexpr int VEC = Vec16<T>::N;
+  return M % BM == 0 && N % BN == 0 && K % FBK == 0 && K > 0 && lda % VEC == 0 && ldb % VEC == 0 &&
+         (((uintptr_t)A | (uintptr_t)B) & 15u) == 0;
+}
+
 template <typename T>
 int32_t gemm(mxlo_ctx *ctx, T *C, int64_t ldc, const T *A, int64_t lda, bool ta, const T *B,
              int64_t ldb, bool tb, int64_t M, int64_t N, int64_t K, double alpha, double beta,
@@ -120,6 +212,14 @@ int32_t gemm(mxlo_ctx *ctx, T *C, int64_t ldc, const T *A, int64_t lda, bool ta,
   if (M <= 0 || N <= 0) return MXLO_OK;
   MXLO_REQUIRE(M < (1LL << 31) && N < (1LL << 31) && K < (1LL << 31), MXLO_ESHAPE, "gemm dims too large");
   dim3 grid((unsigned)((M + BM - 1) / BM), (unsigned)((N + BN - 1) / BN));
+  if (!ta && tb && gemm_nt_fast_ok<T>(A, lda, B, ldb, M, N, K)) {
+    return dispatch_ct<T>(beta, flags, [&]<typename CT, bool B0>() -> int32_t {
+      hipLaunchKernelGGL((gemm_nt_fast_kernel<T, CT, B0>), grid, dim3(kBlock), 0, ctx->stream, C, ldc, A,
+                         lda, B, ldb, (int)K, (CT)alpha, (CT)beta);
+      MXLO_LAUNCH_CHECK();
+      return MXLO_OK;
+    });
+  }
   return dispatch_ct<T>(beta, flags, [&]<typename CT, bool B0>() -> int32_t {
 #define GO(TA_, TB_)                                                                             \
   hipLaunchKernelGGL((gemm_kernel<T, CT, TA_, TB_, B0>), grid, dim3(kBlock), 0, ctx->stream, C,  \
@@ -307,13 +407,17 @@ int32_t kron_t(mxlo_ctx *ctx, T *res, const T *A, int64_t m, int64_t n, int64_t 
                int64_t p, int64_t q, int64_t ldb, const T *x, T *work, double alpha, double beta,
                int32_t mode, int32_t flags) {
   if (mode == MXLO_OP_N) {
-    // X = reshape(x, q, n); U = X * A^T (q x m); R = B * U (p x m); res = alpha*vec(R) + beta*res
-    MXLO_TRY(gemm<T>(ctx, work, q, x, q, false, A, lda, true, q, m, n, 1.0, 0.0, 0));
-    return gemm<T>(ctx, res, p, B, ldb, false, work, q, false, p, m, q, alpha, beta, flags);
+    // X = reshape(x, q, n);  Ut = A * X^T (m x q)  [= (X * A^T)^T];  R = B * Ut^T (p x m);
+    // res = alpha*vec(R) + beta*res. Both products are (N,T): every operand is contiguous along its
+    // non-K dimension -> the fast kernel.
+    MXLO_TRY(gemm<T>(ctx, work, m, A, lda, false, x, q, true, m, q, n, 1.0, 0.0, 0));
+    return gemm<T>(ctx, res, p, B, ldb, false, work, m, true, p, m, q, alpha, beta, flags);
   }
-  // X = reshape(x, p, m); U = X * A (p x n); R = B^T * U (q x n)
-  MXLO_TRY(gemm<T>(ctx, work, p, x, p, false, A, lda, false, p, n, m, 1.0, 0.0, 0));
-  return gemm<T>(ctx, res, q, B, ldb, true, work, p, false, q, n, p, alpha, beta, flags);
+  // X = reshape(x, p, m);  Ut = A^T * X^T (n x p)  [= (X * A)^T];  R = B^T * Ut^T (q x n).
+  // Here A and B enter transposed (K contiguous): the generic kernel handles them. Callers that apply
+  // the transpose often should hand pre-transposed copies to the N mode instead (the host glue does).
+  MXLO_TRY(gemm<T>(ctx, work, n, A, lda, true, x, p, true, n, p, m, 1.0, 0.0, 0));
+  return gemm<T>(ctx, res, q, B, ldb, true, work, n, true, q, n, p, alpha, beta, flags);
 }
 
 }  // namespace

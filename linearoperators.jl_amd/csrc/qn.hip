@@ -107,6 +107,12 @@ combine_kernel(T *__restrict__ res, const T *__restrict__ x, const T *__restrict
                CombineArgs<T> A, int64_t nvec) {
   using V = typename VecOf<T, VEC>::type;
   const T g = (T)A.gamma;
+  // per-column coefficients: device memory -> LDS once per workgroup (broadcast ds_reads in the column
+  // loop instead of one extra VMEM instruction per column competing with the streaming loads)
+  __shared__ double scoef[kMaxCols + 1];
+  if (threadIdx.x <= kMaxCols)
+    scoef[threadIdx.x] = (A.coef && (threadIdx.x < (unsigned)A.ncol || threadIdx.x == kMaxCols)) ? A.coef[threadIdx.x] : 0.0;
+  __syncthreads();
   const CT al = (CT)A.alpha, be = (CT)A.beta;
   const int ncol = A.ncol;
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < nvec;
@@ -131,7 +137,7 @@ combine_kernel(T *__restrict__ res, const T *__restrict__ x, const T *__restrict
           if constexpr (!BETA0) t = t + (be * (CT)vget<T, VEC>(rv, e));
           q[e] = (T)t;
         } else if constexpr (MODE == CM_ASR1) q[e] = vget<T, VEC>(x2v, e) - (xe / g);
-        else if constexpr (MODE == CM_AXPYS) q[e] = (T)A.coef[kMaxCols] * xe;  // c0 stored past the columns
+        else if constexpr (MODE == CM_AXPYS) q[e] = (T)scoef[kMaxCols] * xe;  // c0 stored past the columns
       }
     }
     // ---- columns, 4 loads in flight
@@ -147,7 +153,7 @@ combine_kernel(T *__restrict__ res, const T *__restrict__ x, const T *__restrict
         if (c >= ncol) break;
         if constexpr (MODE == CM_FWD || MODE == CM_AFWD || MODE == CM_DIAG_FWD) {
           if (u & 1) continue;  // pairs are handled on the even member (U is even)
-          const T cb = (T)A.coef[c], ca = (T)A.coef[c + 1];
+          const T cb = (T)scoef[c], ca = (T)scoef[c + 1];
 #pragma unroll
           for (int e = 0; e < VEC; ++e) {
             const T b = vget<T, VEC>(cv[u], e), a = vget<T, VEC>(cv[u + 1], e);
@@ -162,7 +168,7 @@ combine_kernel(T *__restrict__ res, const T *__restrict__ x, const T *__restrict
 #pragma unroll
             for (int e = 0; e < VEC; ++e) q[e] = q[e] * g;                            // lbfgs.jl:139
           }
-          const T cc = (T)A.coef[c];
+          const T cc = (T)scoef[c];
 #pragma unroll
           for (int e = 0; e < VEC; ++e) {
             const T ce = vget<T, VEC>(cv[u], e);
@@ -170,20 +176,20 @@ combine_kernel(T *__restrict__ res, const T *__restrict__ x, const T *__restrict
             else q[e] = q[e] + (cc * ce);                                             // lbfgs.jl:146
           }
         } else if constexpr (MODE == CM_LSR1) {
-          const CT cc = (CT)A.coef[c];  // (α*dot)/as evaluated in CT by the coef kernel
+          const CT cc = (CT)scoef[c];  // (α*dot)/as evaluated in CT by the coef kernel
 #pragma unroll
           for (int e = 0; e < VEC; ++e)
             q[e] = (T)((CT)q[e] + (cc * (CT)vget<T, VEC>(cv[u], e)));                 // lsr1.jl:103
         } else if constexpr (MODE == CM_ASR1) {
-          const T cc = (T)A.coef[c];
+          const T cc = (T)scoef[c];
 #pragma unroll
           for (int e = 0; e < VEC; ++e) q[e] = q[e] - (cc * vget<T, VEC>(cv[u], e));  // lsr1.jl:174
         } else if constexpr (MODE == CM_AXPYS) {
-          const T cc = (T)A.coef[c];
+          const T cc = (T)scoef[c];
 #pragma unroll
           for (int e = 0; e < VEC; ++e) q[e] = q[e] + (cc * vget<T, VEC>(cv[u], e));
         } else if constexpr (MODE == CM_DIAG_SR1) {
-          const T as = (T)A.coef[c];
+          const T as = (T)scoef[c];
 #pragma unroll
           for (int e = 0; e < VEC; ++e) {
             const T a = vget<T, VEC>(cv[u], e);
@@ -226,7 +232,7 @@ int32_t launch_combine_part(mxlo_ctx *ctx, T *res, const T *x, const T *x2, cons
   const bool b0 = A.beta == 0;
   auto go = [&]<typename CT, bool B0, int VEC>() -> int32_t {
     const int64_t nvec = n / VEC;
-    const int grid = grid_for(ctx, nvec, kBlock, ctx->tune.blocks_per_cu);
+    const int grid = grid_for(ctx, nvec, kBlock, ctx->tune.combine_blocks_per_cu);
     const bool nt = (int64_t)sizeof(T) * n * (A.ncol + 2) >= ctx->tune.nt_min_bytes;
     if (nt)
       hipLaunchKernelGGL((combine_kernel<T, CT, MODE, B0, VEC, true>), dim3(grid), dim3(kBlock), 0,

@@ -407,17 +407,23 @@ def kron(A, B):
         Bm = _colmajor(Bm.to(T))
     m, n = Am.shape
     p, q = Bm.shape
-    lda = Am.stride(1) if n > 1 else max(1, m)
-    ldb = Bm.stride(1) if q > 1 else max(1, p)
+    # tprod!/ctprod! (transpose(B) * X * A, src/kron.jl:24-40) are the prod! formula applied to the
+    # transposed factors; transposed copies are made ONCE here so that both directions run the
+    # (N,T) MFMA GEMM path whose operands are contiguous along their non-K dimension.
+    At, Bt = _colmajor(Am.t()), _colmajor(Bm.t())
     work = torch.empty(max(q * m, p * n), dtype=T, device=Am.device)
 
-    def km(res, x, a, b, mode):
-        ctx = get_ctx(res.device)
-        _lib.call("mxlo_kron_mul", ctx.handle, dtype_code(T), ptr(res), ptr(Am), m, n, lda, ptr(Bm), p, q, ldb,
-                  ptr(x), ptr(work), float(a), float(b), mode, scalar_flags(res.dtype, a, b))
+    def ld(M):
+        return M.stride(1) if M.shape[1] > 1 else max(1, M.shape[0])
 
-    prod = lambda res, x, a, b: km(res, x, a, b, _lib.OP_N)
-    tprod = lambda res, x, a, b: km(res, x, a, b, _lib.OP_T)
-    ctprod = lambda res, x, a, b: km(res, x, a, b, _lib.OP_C)
+    def km(res, x, a, b, A_, B_):
+        ctx = get_ctx(res.device)
+        _lib.call("mxlo_kron_mul", ctx.handle, dtype_code(T), ptr(res), ptr(A_), A_.shape[0], A_.shape[1], ld(A_),
+                  ptr(B_), B_.shape[0], B_.shape[1], ld(B_), ptr(x), ptr(work), float(a), float(b), _lib.OP_N,
+                  scalar_flags(res.dtype, a, b))
+
+    prod = lambda res, x, a, b: km(res, x, a, b, Am, Bm)
+    tprod = lambda res, x, a, b: km(res, x, a, b, At, Bt)
+    ctprod = lambda res, x, a, b: km(res, x, a, b, At, Bt)
     return LinearOperator(T, m * p, n * q, Asym and Bsym, Aherm and Bherm, prod, tprod, ctprod,
                           S=Storage(T, Am.device))

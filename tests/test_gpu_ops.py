@@ -252,3 +252,26 @@ def test_combinators_vs_dense(lo, dev):
     opA1 * v; opA1.T * v; opA1.H * v; opA1.H * v
     assert (lo.nprod(opA1), lo.ntprod(opA1), lo.nctprod(opA1)) == (1, 1, 2)
     assert lo.nprod(opA1.H) == 2 and lo.nctprod(opA1.T) == 1
+
+
+def test_kron_abi_transpose_mode(lo, dev):
+    """mxlo_kron_mul with op_mode = T/C directly (the host glue normally feeds pre-transposed factors to
+    the N mode): generic-transposition GEMM path, odd sizes exercising the tile guards."""
+    from linearoperators_jl_amd import _lib
+    from linearoperators_jl_amd.device import get_ctx, ptr
+    rng = np.random.default_rng(12)
+    for (m, n), (p, q) in (((5, 3), (4, 7)), ((64, 96), (128, 64)), ((70, 33), (65, 129))):
+        A, B = rng.standard_normal((m, n)), rng.standard_normal((p, q))
+        K = np.kron(A, B)
+        Ad, Bd = TM(A, dev), TM(B, dev)
+        x = rng.standard_normal(m * p)
+        r0 = rng.standard_normal(n * q)
+        res = T(r0.copy(), dev)
+        work = torch.empty(max(q * m, p * n), dtype=torch.float64, device=dev)
+        ctx = get_ctx(dev)
+        for mode in (_lib.OP_T, _lib.OP_C):
+            res.copy_(T(r0, dev))
+            _lib.call("mxlo_kron_mul", ctx.handle, _lib.F64, ptr(res), ptr(Ad), m, n, Ad.stride(1), ptr(Bd), p, q,
+                      Bd.stride(1), ptr(T(x, dev)), ptr(work), 2.0, 3.0, mode, 0)
+            assert rel(res.cpu().numpy(), 2.0 * (K.T @ x) + 3.0 * r0) <= 1e-12
+            assert rel(res.cpu().numpy(), oracle.kron_mul(r0.copy(), A, B, x, 2.0, 3.0, trans=True)) <= 1e-12

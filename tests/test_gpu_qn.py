@@ -185,34 +185,58 @@ def test_lbfgs_vs_dense_bfgs(lo, dev):
 
 
 def test_damped_pushes(lo, dev):
-    """test_lbfgs.jl:104-159 and the misuse errors :220-240."""
-    n, mem = 50, 10
-    rng = np.random.default_rng(4)
+    """test_lbfgs.jl:104-159 (same loop: d = -(H*g), s = α d, push when ys > 0.2 s'Bs) through the ABI and
+    through the oracle, plus the misuse errors of :220-240."""
+    n, mem = 10, 5
     B = lo.LBFGSOperator(n, mem=mem, damped=True, scaling=False, sigma2=0.8, sigma3=float("inf"), device=dev)
     H = lo.InverseLBFGSOperator(n, mem=mem, damped=True, scaling=False, sigma2=0.8, sigma3=float("inf"), device=dev)
     Bo = oracle.LBFGS(n, mem=mem, damped=True, scaling=False, inverse=False, sigma2=0.8, sigma3=np.inf)
     Ho = oracle.LBFGS(n, mem=mem, damped=True, scaling=False, inverse=True, sigma2=0.8, sigma3=np.inf)
+    ins = 0
     for i in range(1, mem + 3):
-        s = SV(n) * i
-        y = rng.uniform(-1, 1, n)
-        if s @ y <= 0:
-            y = -y
-        lo.push(B, T(s, dev), T(y, dev)); Bo.push(s.copy(), y.copy())
-        g = rng.uniform(-1, 1, n)
-        yd = T(y, dev)
-        lo.push(H, T(s, dev), yd, 0.5, T(g, dev)); yo = y.copy(); Ho.push(s.copy(), yo, alpha=0.5, g=g)
-        assert rel(yd.cpu().numpy(), yo) <= 1e-12        # damping mutates y in place (lbfgs.jl:351)
-    x = rng.uniform(-1, 1, n)
-    assert rel((B * T(x, dev)).cpu().numpy(), Bo.mul(np.empty(n), x)) <= 1e-9
-    assert rel((H * T(x, dev)).cpu().numpy(), Ho.mul(np.empty(n), x)) <= 1e-8
-    assert np.linalg.eigvalsh(lo.Matrix(B).cpu().numpy()).min() > 0
+        y = SV(n)
+        ys = y @ SV(n)
+        g = SV(n)
+        d = -(H * T(g, dev))
+        alpha = i / mem
+        s = alpha * d
+        do = -Ho.mul(np.empty(n), g)
+        so = alpha * do
+        assert rel(s.cpu().numpy(), so) <= 1e-10
+        if ys > 0.2 * float(torch.dot(s, B * s)):
+            ins += 1
+            yd = T(y, dev)
+            lo.push(B, s, T(y, dev)); lo.push(H, s, yd, alpha, T(g, dev))
+            yo = y.copy()
+            Bo.push(so.copy(), y.copy()); Ho.push(so.copy(), yo, alpha=alpha, g=g)
+            assert rel(yd.cpu().numpy(), yo) <= 1e-10       # damping mutates y in place (lbfgs.jl:351)
+    assert ins > 0 and B.data.insert == ins % mem + 1 and H.data.insert == ins % mem + 1
+    assert B.data.insert == Bo.insert and H.data.insert == Ho.insert
+    MB, MH = lo.Matrix(B).cpu().numpy(), lo.Matrix(H).cpu().numpy()
+    assert np.linalg.eigvalsh((MB + MB.T) / 2).min() > 0 and np.linalg.eigvalsh((MH + MH.T) / 2).min() > 0
+    assert np.allclose(MB, MB.T, atol=1e-10) and np.allclose(MH, MH.T, atol=1e-10)
+    assert np.linalg.norm(np.diag(MB) - lo.diag(B).cpu().numpy()) <= 1e-8
+    assert np.linalg.norm(MH @ MB - np.eye(n)) <= np.sqrt(np.finfo(float).eps)
+    assert np.linalg.norm(MB, 2) <= B.data.opnorm_upper_bound
+    assert rel(MB, Bo.dense()) <= 1e-9 and rel(MH, Ho.dense()) <= 1e-9
+    # full-memory damped L-BFGS vs dense damped BFGS (:143-156)
+    LB = lo.LBFGSOperator(n, mem=n, damped=True, scaling=False, device=dev)
+    Bd = np.eye(n)
+    for k in range(n):
+        s, y = SV(n), SV(n)
+        Bs = Bd @ s
+        if y @ s > 0.2 * (s @ Bs):
+            Bd = Bd - np.outer(Bs, Bs) / (s @ Bs) + np.outer(y, y) / (y @ s)
+        lo.push(LB, T(s, dev), T(y, dev))
+        assert np.linalg.norm(lo.Matrix(LB).cpu().numpy() - Bd) < 1e-8 * np.linalg.norm(Bd)
+    x = T(SV(n), dev)
     U = lo.LBFGSOperator(n, device=dev)
     with pytest.raises(RuntimeError):
-        lo.push(U, T(x, dev), T(x, dev), T(x, dev))
+        lo.push(U, x, x, x)
     with pytest.raises(RuntimeError):
-        lo.push(B, T(x, dev), T(x, dev), 1.0, T(x, dev))
+        lo.push(B, x, x, 1.0, x)
     with pytest.raises(RuntimeError):
-        lo.push(H, T(x, dev), T(x, dev), T(x, dev))
+        lo.push(H, x, x, x)
 
 
 @pytest.mark.parametrize("dtype", [torch.float64, torch.float32])

@@ -302,6 +302,13 @@ int32_t mxlo_qn_get_scalars(mxlo_qn *h, double scalars[5], double *ys, double *a
 int32_t mxlo_qn_column(mxlo_qn *h, int32_t which, int64_t k, void **out);
 /* Evaluation strategy for the inverse two-loop (MXLO_INV_*). */
 int32_t mxlo_qn_set_mode(mxlo_qn *h, int32_t mode);
+/* Forward L-BFGS push!: how the a_k panel is rebuilt (src/lbfgs.jl:236-250).
+ *   MXLO_PUSH_GRAM     (default) coefficient-space recurrence on the Gram matrices S'S, Y'S kept up
+ *                      to date by push! (3m dots), then ONE pass A = [S B]*C over the panels;
+ *   MXLO_PUSH_REFORDER the reference's statement order: O(m^2) dot/axpy passes over n. */
+#define MXLO_PUSH_GRAM 0
+#define MXLO_PUSH_REFORDER 1
+int32_t mxlo_qn_set_push_mode(mxlo_qn *h, int32_t mode);
 
 #ifdef __cplusplus
 }

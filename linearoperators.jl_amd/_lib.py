@@ -23,6 +23,7 @@ OP_N, OP_T, OP_C = 0, 1, 2
 BLK_DIAG, BLK_DENSE, BLK_EYE, BLK_ZEROS = 0, 1, 2, 3
 QN_LBFGS_INV, QN_LBFGS_FWD, QN_LSR1 = 0, 1, 2
 INV_TWOPASS, INV_REFORDER = 0, 1
+PUSH_GRAM, PUSH_REFORDER = 0, 1
 
 
 class MxloError(RuntimeError):
@@ -118,6 +119,7 @@ _PROTOS = {
     "mxlo_qn_get_scalars": [_vp, C.POINTER(_dbl), C.POINTER(_dbl), C.POINTER(_dbl)],
     "mxlo_qn_column": [_vp, _i32, _i64, C.POINTER(_vp)],
     "mxlo_qn_set_mode": [_vp, _i32],
+    "mxlo_qn_set_push_mode": [_vp, _i32],
 }
 
 

@@ -109,6 +109,9 @@ MXLO_API int32_t mxlo_ctx_tune(mxlo_ctx *ctx, const char *key, int64_t value) {
   } else if (!strcmp(key, "house_mall_tail_bytes")) {
     MXLO_REQUIRE(value >= 0, MXLO_EINVAL, "house_mall_tail_bytes out of range");
     ctx->tune.house_mall_tail_bytes = value;
+  } else if (!strcmp(key, "gemm_waves")) {
+    MXLO_REQUIRE(value == 4 || value == 8, MXLO_EINVAL, "gemm_waves must be 4 or 8");
+    ctx->tune.gemm_waves = (int)value;
   } else if (!strcmp(key, "combine_blocks_per_cu")) {
     MXLO_REQUIRE(value >= 0 && value <= 64, MXLO_EINVAL, "combine_blocks_per_cu out of range");
     ctx->tune.combine_blocks_per_cu = (int)value;

@@ -122,10 +122,12 @@ gemm_kernel(T *__restrict__ C, int64_t ldc, const T *__restrict__ A, int64_t lda
 // of the current slab issue; one barrier per slab.
 constexpr int FBK = 32;
 
-template <typename T, typename CT, bool BETA0>
-__global__ void __launch_bounds__(kBlock)
+template <typename T, typename CT, bool BETA0, int WAVES>
+__global__ void __launch_bounds__(WAVES * 64)
 gemm_nt_fast_kernel(T *__restrict__ C, int64_t ldc, const T *__restrict__ A, int64_t lda,
                     const T *__restrict__ B, int64_t ldb, int K, CT alpha, CT beta) {
+  constexpr int kBlock = WAVES * 64;                     // shadows mxlo::kBlock inside this kernel
+  constexpr int MT = WAVES == 4 ? 2 : 1;                 // 16-row MFMA tiles per wave along M
   constexpr int VEC = Vec16<T>::N;                       // elements per 16-byte load
   constexpr int LPT = BM * FBK / VEC / kBlock;           // 16-byte loads per thread per operand slab
   constexpr int RPV = BM / VEC;                          // vectors per k-row (32 for f64, 16 for f32)
@@ -134,11 +136,12 @@ gemm_nt_fast_kernel(T *__restrict__ C, int64_t ldc, const T *__restrict__ A, int
   __shared__ T sB[2][FBK][LDT];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int bm = blockIdx.x * BM, bn = blockIdx.y * BN;
-  const int wm = (wave & 1) * 32, wn = (wave >> 1) * 32;
+  const int wm = WAVES == 4 ? (wave & 1) * 32 : (wave & 3) * 16;
+  const int wn = WAVES == 4 ? (wave >> 1) * 32 : (wave >> 2) * 32;
   using Acc = typename Mfma<T>::Acc;
-  Acc acc[2][2];
+  Acc acc[MT][2];
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int a = 0; a < MT; ++a)
 #pragma unroll
     for (int b = 0; b < 2; ++b)
 #pragma unroll
@@ -173,18 +176,19 @@ gemm_nt_fast_kernel(T *__restrict__ C, int64_t ldc, const T *__restrict__ A, int
 #pragma unroll
     for (int kk = 0; kk < FBK; kk += 4) {
       const int kr = kk + (lane >> 4);
-      const T a0 = sA[buf][kr][wm + (lane & 15)], a1 = sA[buf][kr][wm + 16 + (lane & 15)];
       const T b0 = sB[buf][kr][wn + (lane & 15)], b1 = sB[buf][kr][wn + 16 + (lane & 15)];
-      acc[0][0] = Mfma<T>::run(a0, b0, acc[0][0]);
-      acc[0][1] = Mfma<T>::run(a0, b1, acc[0][1]);
-      acc[1][0] = Mfma<T>::run(a1, b0, acc[1][0]);
-      acc[1][1] = Mfma<T>::run(a1, b1, acc[1][1]);
+#pragma unroll
+      for (int a = 0; a < MT; ++a) {
+        const T av = sA[buf][kr][wm + a * 16 + (lane & 15)];
+        acc[a][0] = Mfma<T>::run(av, b0, acc[a][0]);
+        acc[a][1] = Mfma<T>::run(av, b1, acc[a][1]);
+      }
     }
     if (it + 1 < nk) lstore(buf ^ 1);
     __syncthreads();
   }
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int a = 0; a < MT; ++a)
 #pragma unroll
     for (int b = 0; b < 2; ++b)
 #pragma unroll
@@ -214,8 +218,12 @@ int32_t gemm(mxlo_ctx *ctx, T *C, int64_t ldc, const T *A, int64_t lda, bool ta,
   dim3 grid((unsigned)((M + BM - 1) / BM), (unsigned)((N + BN - 1) / BN));
   if (!ta && tb && gemm_nt_fast_ok<T>(A, lda, B, ldb, M, N, K)) {
     return dispatch_ct<T>(beta, flags, [&]<typename CT, bool B0>() -> int32_t {
-      hipLaunchKernelGGL((gemm_nt_fast_kernel<T, CT, B0>), grid, dim3(kBlock), 0, ctx->stream, C, ldc, A,
-                         lda, B, ldb, (int)K, (CT)alpha, (CT)beta);
+      if (ctx->tune.gemm_waves == 8)
+        hipLaunchKernelGGL((gemm_nt_fast_kernel<T, CT, B0, 8>), grid, dim3(512), 0, ctx->stream, C, ldc, A,
+                           lda, B, ldb, (int)K, (CT)alpha, (CT)beta);
+      else
+        hipLaunchKernelGGL((gemm_nt_fast_kernel<T, CT, B0, 4>), grid, dim3(256), 0, ctx->stream, C, ldc, A,
+                           lda, B, ldb, (int)K, (CT)alpha, (CT)beta);
       MXLO_LAUNCH_CHECK();
       return MXLO_OK;
     });
@@ -367,7 +375,112 @@ int32_t gemv_any(mxlo_ctx *ctx, T *res, const T *M, int64_t m, int64_t n, int64_
   return gemv_t<T, false>(ctx, res, M, m, n, ld, v, alpha, beta, flags, nullptr);
 }
 
-struct HermScratch {  // per-ctx scratch for t1, t2 (grown on demand)
+// ---- opHermitian, single pass over the strict lower triangle -------------------------------------
+// The triangle is cut into 64x64 tiles (I >= J); one workgroup per tile reads it ONCE (16-byte loads
+// down the columns) and produces both of its contributions:
+//   rows  : Prow[J][I*64 + r] = sum_c L[r][c] * v[J*64 + c]        (part of L*v)
+//   cols  : Pcol[I][J*64 + c] = sum_r L[r][c] * v[I*64 + r]        (part of L'*v)
+// A second tiny kernel adds the partials in a FIXED order (deterministic, no float atomics) and applies
+//   res = alpha*((d.*v + L*v) + L'*v) (+ beta*res)                  (src/linalg.jl:99-101).
+// HBM traffic: 4n^2 B for the triangle + n^2/4 B of partials, vs 8n^2 for two triangular GEMVs and
+// 16n^2 for the reference (two full GEMVs over tril(A,-1) stored with explicit zeros).
+constexpr int HT = 64;
+
+template <typename T, bool ALIGNED>
+__global__ void __launch_bounds__(kBlock)
+herm_tile_kernel(const T *__restrict__ A, int64_t lda, const T *__restrict__ v, int64_t n, int nb,
+                 double *__restrict__ Prow, double *__restrict__ Pcol) {
+  // tile index t -> (I, J) with t = I(I+1)/2 + J
+  const int64_t t = blockIdx.x;
+  int64_t I = (int64_t)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+  while (I * (I + 1) / 2 > t) --I;
+  while ((I + 1) * (I + 2) / 2 <= t) ++I;
+  const int64_t J = t - I * (I + 1) / 2;
+  const int64_t i0 = I * HT, j0 = J * HT;
+  const int tid = threadIdx.x;
+  const int rp = tid & 31, cg = tid >> 5;        // rows 2rp, 2rp+1 ; columns cg + 8k
+  const int64_t gr = i0 + 2 * rp;
+  const double vr0 = gr < n ? (double)v[gr] : 0.0, vr1 = gr + 1 < n ? (double)v[gr + 1] : 0.0;
+  double prow0 = 0.0, prow1 = 0.0;
+  double pcol[8];
+  T e0[8], e1[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int64_t gc = j0 + cg + 8 * k;
+    e0[k] = 0;
+    e1[k] = 0;
+    if (gc < n) {
+      const T *p = A + gr + gc * lda;
+      if constexpr (ALIGNED) {
+        if (gr + 1 < n) {
+          typedef T V2 __attribute__((ext_vector_type(2)));
+          const V2 x = __builtin_nontemporal_load(reinterpret_cast<const V2 *>(p));
+          e0[k] = x[0];
+          e1[k] = x[1];
+        } else if (gr < n) {
+          e0[k] = p[0];
+        }
+      } else {
+        if (gr < n) e0[k] = p[0];
+        if (gr + 1 < n) e1[k] = p[1];
+      }
+      // strict lower triangle only: keep L[r][c] with row > col
+      if (!(gr > gc)) e0[k] = 0;
+      if (!(gr + 1 > gc)) e1[k] = 0;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int64_t gc = j0 + cg + 8 * k;
+    const double vc = gc < n ? (double)v[gc] : 0.0;
+    prow0 = fma((double)e0[k], vc, prow0);
+    prow1 = fma((double)e1[k], vc, prow1);
+    pcol[k] = fma((double)e1[k], vr1, (double)e0[k] * vr0);
+  }
+  // column sums: reduce over the 32 lanes that share cg (a half wave)
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) pcol[k] += __shfl_xor(pcol[k], off, 64);
+  }
+  if (rp == 0) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int64_t gc = j0 + cg + 8 * k;
+      if (gc < n) Pcol[I * n + gc] = pcol[k];
+    }
+  }
+  // row sums: reduce over the 8 column groups through LDS, fixed order
+  __shared__ double red[8][HT];
+  red[cg][2 * rp] = prow0;
+  red[cg][2 * rp + 1] = prow1;
+  __syncthreads();
+  if (tid < HT) {
+    double s = 0.0;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) s += red[g][tid];
+    if (i0 + tid < n) Prow[J * n + i0 + tid] = s;
+  }
+}
+
+template <typename T, typename CT, bool BETA0>
+__global__ void __launch_bounds__(kBlock)
+herm_finish_kernel(T *__restrict__ res, const T *__restrict__ d, const T *__restrict__ v,
+                   const double *__restrict__ Prow, const double *__restrict__ Pcol, int64_t n, int nb,
+                   CT alpha, CT beta) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const int blk = (int)(i / HT);
+  double t1 = 0.0, t2 = 0.0;
+  for (int J = 0; J <= blk; ++J) t1 += Prow[(int64_t)J * n + i];      // L*v : tiles (blk, J <= blk)
+  for (int I = blk; I < nb; ++I) t2 += Pcol[(int64_t)I * n + i];      // L'*v: tiles (I >= blk, blk)
+  const T inner = ((d[i] * v[i]) + (T)t1) + (T)t2;
+  CT t = alpha * (CT)inner;
+  if constexpr (!BETA0) t = t + (beta * (CT)res[i]);
+  res[i] = (T)t;
+}
+
+struct HermScratch {  // per-device scratch for the tile partials (grown on demand)
   void *buf = nullptr;
   size_t bytes = 0;
 };
@@ -377,8 +490,10 @@ template <typename T>
 int32_t hermitian_t(mxlo_ctx *ctx, T *res, const T *d, const T *A, int64_t lda, const T *v, int64_t n,
                     double alpha, double beta, int32_t flags) {
   if (n == 0) return MXLO_OK;
+  const int64_t nb = (n + HT - 1) / HT;
+  MXLO_REQUIRE(nb * (nb + 1) / 2 < (1LL << 31), MXLO_ESHAPE, "opHermitian: n too large");
   HermScratch &hs = g_herm[ctx->device & 63];
-  const size_t need = sizeof(T) * 2 * (size_t)n;
+  const size_t need = sizeof(double) * 2 * (size_t)nb * (size_t)n;
   if (hs.bytes < need) {
     if (hs.buf) {
       MXLO_HIP(hipStreamSynchronize(ctx->stream));
@@ -390,13 +505,20 @@ int32_t hermitian_t(mxlo_ctx *ctx, T *res, const T *d, const T *A, int64_t lda, 
     MXLO_REQUIRE(e == hipSuccess, MXLO_ENOMEM, "opHermitian scratch: %s", hipGetErrorString(e));
     hs.bytes = need;
   }
-  T *t1 = (T *)hs.buf, *t2 = t1 + n;
-  MXLO_TRY((gemv_n<T, true>(ctx, t1, A, n, n, lda, v, 1.0, 0.0, flags, t1)));   // L*v
-  MXLO_TRY((gemv_t<T, true>(ctx, t2, A, n, n, lda, v, 1.0, 0.0, flags, t2)));   // (v'*L)'
+  double *Prow = (double *)hs.buf, *Pcol = Prow + (size_t)nb * n;
+  const unsigned ntiles = (unsigned)(nb * (nb + 1) / 2);
+  const bool aligned = sizeof(T) == 8 && (((uintptr_t)A & 15u) == 0) && (lda % 2 == 0);
+  if (aligned)
+    hipLaunchKernelGGL((herm_tile_kernel<T, true>), dim3(ntiles), dim3(kBlock), 0, ctx->stream, A, lda, v, n,
+                       (int)nb, Prow, Pcol);
+  else
+    hipLaunchKernelGGL((herm_tile_kernel<T, false>), dim3(ntiles), dim3(kBlock), 0, ctx->stream, A, lda, v, n,
+                       (int)nb, Prow, Pcol);
+  MXLO_LAUNCH_CHECK();
   const unsigned blocks = (unsigned)((n + kBlock - 1) / kBlock);
   return dispatch_ct<T>(beta, flags, [&]<typename CT, bool B0>() -> int32_t {
-    hipLaunchKernelGGL((herm_combine_kernel<T, CT, B0>), dim3(blocks), dim3(kBlock), 0, ctx->stream,
-                       res, d, v, t1, t2, n, (CT)alpha, (CT)beta);
+    hipLaunchKernelGGL((herm_finish_kernel<T, CT, B0>), dim3(blocks), dim3(kBlock), 0, ctx->stream, res, d, v,
+                       Prow, Pcol, n, (int)nb, (CT)alpha, (CT)beta);
     MXLO_LAUNCH_CHECK();
     return MXLO_OK;
   });

@@ -253,6 +253,12 @@ MXLO_API int32_t mxlo_householder_mul(mxlo_ctx *ctx, int32_t dtype, void *res, c
 
 // ---- opRestriction / opExtension ------------------------------------------------------------------
 namespace {
+template <typename T>
+struct CopyBitsOp {
+  __device__ void init() {}
+  __device__ T operator()(T x, T, T) const { return x; }
+};
+
 typedef unsigned int u32;
 typedef unsigned long long u64;
 typedef u64 u64x2 __attribute__((ext_vector_type(2)));
@@ -360,10 +366,16 @@ MXLO_API int32_t mxlo_gather_range(mxlo_ctx *ctx, int32_t elem_size, void *res, 
   MXLO_REQUIRE(step != 0 && start >= 1 && start <= nv && last >= 1 && last <= nv, MXLO_ESHAPE,
                "mxlo_gather_range: %lld:%lld:%lld outside 1..%lld", (long long)start,
                (long long)step, (long long)last, (long long)nv);
-  if (step == 1) {  // UnitRange: a contiguous copy
-    MXLO_HIP(hipMemcpyAsync(res, (const char *)v + (start - 1) * elem_size,
-                            (size_t)len * elem_size, hipMemcpyDeviceToDevice, ctx->stream));
-    return MXLO_OK;
+  if (step == 1) {  // UnitRange: a contiguous copy through the streaming kernel (16-byte, nontemporal
+                    // when large: ~1.8x the rate of hipMemcpyAsync D2D measured at 5e7 doubles);
+                    // plain register moves, so every bit pattern (NaN payloads) survives
+    const char *src = (const char *)v + (start - 1) * elem_size;
+    if (elem_size == 4)
+      return launch_map<float, 1, false, false>(ctx, (float *)res, (const float *)src, (const float *)nullptr,
+                                                len, CopyBitsOp<float>{});
+    const int64_t nd = len * (elem_size / 8);
+    return launch_map<double, 1, false, false>(ctx, (double *)res, (const double *)src,
+                                               (const double *)nullptr, nd, CopyBitsOp<double>{});
   }
   return by_elem_size(elem_size, [&]<typename E>() -> int32_t {
     const int grid = grid_for(ctx, len, kBlock * 4, ctx->tune.blocks_per_cu);

@@ -37,14 +37,18 @@ struct DscLayout {
   int64_t as_ = 320;   // [mem] L-SR1 a_k' s_k
   int64_t alpha = 352; // [mem] inverse two-loop alpha_k (data.α)
   int64_t SY = 384;    // [mem*mem] column j = S' y_j  (written when slot j is pushed)
-  int64_t YS = 0, YY = 0, G = 0, g = 0, cx = 0, total = 0;
+  int64_t YS = 0, YY = 0, G = 0, g = 0, cx = 0, SS = 0, YSf = 0, Cm = 0, gtmp = 0, total = 0;
   explicit DscLayout(int64_t mem) {
     YS = SY + mem * mem;
     YY = YS + mem * mem;
     G = YY + mem * mem;
     g = G + 4 * mem * mem;
     cx = g + 2 * mem;
-    total = cx + 2 * mem + 64;
+    SS = cx + 2 * mem + 64;   // [mem*mem] s_j's_k            (forward push!, Gram form)
+    YSf = SS + mem * mem;     // [mem*mem] y_j's_k (row j, col k)
+    Cm = YSf + mem * mem;     // [mem * 2mem] coefficients of a_k on [s_1..s_r, b_1..b_r]
+    gtmp = Cm + 2 * mem * mem;  // [3*mem] scratch dots of one push
+    total = gtmp + 3 * mem + 64;
   }
 };
 
@@ -57,6 +61,7 @@ struct mxlo_qn {
   bool scaling = true, damped = false;
   double sigma2 = 0.99, sigma3 = 10.0;
   int mode = MXLO_INV_TWOPASS;
+  int push_mode = MXLO_PUSH_GRAM;
   // host mirrors of the small scalars that drive control flow
   int64_t insert0 = 0;  // 0-based next write slot
   double scaling_factor = 1.0;
@@ -594,6 +599,189 @@ int32_t read_scalars(mxlo_qn *h, const double *dev, double *host, int count) {
 template <typename T>
 inline double rT(double v) { return sizeof(T) == 4 ? (double)(float)v : v; }
 
+// ---- forward push!, Gram form --------------------------------------------------------------------
+// The reference rebuilds every a_k with O(m^2) dot/axpy passes over n (src/lbfgs.jl:236-250). All of those
+// dots are inner products between vectors of span{s_j, b_j}; with the Gram matrices S'S and Y'S kept up to
+// date (3m dots per push) the recurrence runs on 2m-vectors of coefficients and ALL a_k are then formed
+// in ONE pass  A = [S B] * C  (read 2r columns, write r columns).
+
+// place the dots of this push: tmp[0..m) = S's_new, tmp[m..2m) = Y's_new, tmp[2m..3m) = S'y_new
+__global__ void gram_update_kernel(double *__restrict__ SS, double *__restrict__ YSf,
+                                   const double *__restrict__ tmp, int mem, int ins) {
+  const int k = threadIdx.x;
+  if (k >= mem) return;
+  SS[k * mem + ins] = tmp[k];
+  SS[ins * mem + k] = tmp[k];
+  YSf[k * mem + ins] = tmp[mem + k];       // y_k ' s_new
+  YSf[ins * mem + k] = tmp[2 * mem + k];   // y_new ' s_k
+}
+
+// coefficients of a_k (active slots, oldest -> newest) on the basis [s_ord[0..r), b_ord[0..r)]:
+//   Cm[k*(2r) + j] (j < r: on s_j; j >= r: on b_{j-r}).  b_j = y_j / sqrt(ys_j)  (src/lbfgs.jl:232)
+// NB: `c += Z[r+l][k]` must precede the `as` reduction of the same l in the reference (:244 then :245 uses
+// dot(a_l, s_k), independent of the running a_k), so the order inside the loop is immaterial.
+__global__ void __launch_bounds__(64)
+afwd_coef_kernel(const double *__restrict__ SS, const double *__restrict__ YSf,
+                 double *__restrict__ Cm, OrdArgs O) {
+  // one wave; lane j owns coefficient j of the 2r-vector (2r <= 64). Z[j][k] = <basis_j, s_k>.
+  __shared__ double Z[kMaxCols][kMaxMem];
+  __shared__ double Cl[kMaxMem][kMaxCols];
+  const int lane = threadIdx.x;
+  const int r = O.na, mem = O.mem, w = 2 * r;
+  for (int k = 0; k < r; ++k) {
+    if (lane < w) {
+      const int j = lane < r ? lane : lane - r;
+      const double g = (lane < r ? SS : YSf)[O.ord[j] * mem + O.ord[k]];
+      Z[lane][k] = lane < r ? g : g / sqrt(O.ys[O.ord[j]]);
+    }
+  }
+  __syncthreads();
+  auto wsum = [](double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+  };
+  for (int k = 0; k < r; ++k) {
+    double c = (lane == k) ? 1.0 / O.gamma : 0.0;             // a_k = s_k / γ                 (:239)
+    const double zk = lane < w ? Z[lane][k] : 0.0;
+    for (int l = 0; l < k; ++l) {
+      const double cl = lane < w ? Cl[l][lane] : 0.0;
+      if (lane == r + l) c += Z[r + l][k];                    // += dot(b_l, s_k) b_l           (:244)
+      const double as = wsum(cl * zk);                        // dot(a_l, s_k)
+      c -= as * cl;                                           // -= dot(a_l, s_k) a_l           (:245)
+    }
+    const double nn = wsum(c * zk);                           // dot(s_k, a_k)                  (:248)
+    c *= 1.0 / sqrt(nn);
+    if (lane < w) {
+      Cl[k][lane] = c;
+      Cm[(int64_t)k * w + lane] = c;
+    }
+    __syncthreads();
+  }
+}
+
+constexpr int kGemmIn = 64, kGemmOut = 32;
+template <typename T>
+struct PanelGemmArgs {
+  const T *in[kGemmIn];
+  T *out[kGemmOut];
+  int nin, nout;
+  const double *C;  // nout x nin, row-major (as produced by the coefficient kernel)
+};
+
+// out_k[i] = sum_j C[k][j] * in_j[i].  j-outer streaming form: the nout accumulators of a lane's two rows
+// live in registers, input columns are streamed 4 at a time (each read exactly once), the coefficients
+// of one input column are wave-uniform and fetched with scalar loads from a transposed copy Ct[j][k].
+// Products accumulate in f64.
+template <typename T, int NOUTMAX>
+__global__ void __launch_bounds__(kBlock)
+panel_gemm_kernel(PanelGemmArgs<T> A, const double *__restrict__ Ct, int64_t nvec) {
+  typedef T V __attribute__((ext_vector_type(2)));
+  constexpr int UJ = 4;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * kBlock) {
+    double acc[NOUTMAX][2];
+#pragma unroll
+    for (int k = 0; k < NOUTMAX; ++k) acc[k][0] = acc[k][1] = 0.0;
+    for (int j0 = 0; j0 < A.nin; j0 += UJ) {
+      V in[UJ];
+#pragma unroll
+      for (int u = 0; u < UJ; ++u)
+        if (j0 + u < A.nin) in[u] = __builtin_nontemporal_load(reinterpret_cast<const V *>(A.in[j0 + u] + i * 2));
+#pragma unroll
+      for (int u = 0; u < UJ; ++u) {
+        if (j0 + u < A.nin) {
+          const double x0 = (double)in[u][0], x1 = (double)in[u][1];
+          const double *c = Ct + (int64_t)(j0 + u) * NOUTMAX;
+#pragma unroll
+          for (int k = 0; k < NOUTMAX; ++k) {
+            const double ck = c[k];               // wave-uniform: scalar load (padded rows are zero)
+            acc[k][0] = fma(ck, x0, acc[k][0]);
+            acc[k][1] = fma(ck, x1, acc[k][1]);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < NOUTMAX; ++k) {
+      if (k < A.nout) {
+        V o;
+        o[0] = (T)acc[k][0];
+        o[1] = (T)acc[k][1];
+        __builtin_nontemporal_store(o, reinterpret_cast<V *>(A.out[k] + i * 2));
+      }
+    }
+  }
+}
+
+// Ct[j][k] (row length NOUTMAX, zero padded) from C[k][j]
+__global__ void transpose_coef_kernel(const double *__restrict__ C, double *__restrict__ Ct, int nout, int nin,
+                                      int noutmax) {
+  for (int idx = threadIdx.x; idx < nin * noutmax; idx += blockDim.x) {
+    const int j = idx / noutmax, k = idx % noutmax;
+    Ct[idx] = k < nout ? C[(int64_t)k * nin + j] : 0.0;
+  }
+}
+
+template <typename T>
+int32_t launch_panel_gemm(mxlo_ctx *ctx, PanelGemmArgs<T> &A, int64_t n) {
+  if (n <= 0 || A.nout <= 0) return MXLO_OK;
+  // panel columns are 16-byte aligned and padded (ld) to a whole number of 16-byte vectors: run pairs of rows
+  const int64_t nvec = (n + 1) / 2;
+  const int grid = grid_for(ctx, nvec, kBlock, 0);
+  double *Ct = ctx->scalars + 1024;  // kGemmIn * kGemmOut = 2048 doubles inside the ctx scalar buffer
+  auto go = [&]<int NOUTMAX>() -> int32_t {
+    hipLaunchKernelGGL(transpose_coef_kernel, dim3(1), dim3(kBlock), 0, ctx->stream, A.C, Ct, A.nout, A.nin, NOUTMAX);
+    MXLO_LAUNCH_CHECK();
+    hipLaunchKernelGGL((panel_gemm_kernel<T, NOUTMAX>), dim3(grid), dim3(kBlock), 0, ctx->stream, A, Ct, nvec);
+    MXLO_LAUNCH_CHECK();
+    return MXLO_OK;
+  };
+  if (A.nout <= 8) return go.template operator()<8>();
+  if (A.nout <= 16) return go.template operator()<16>();
+  if (A.nout <= 24) return go.template operator()<24>();
+  return go.template operator()<32>();
+}
+
+// Gram-form rebuild of the forward panel after (s, y) was copied into slot `ins` and b[ins] was formed.
+template <typename T>
+int32_t fwd_rebuild_gram(mxlo_qn *h, int64_t ins) {
+  mxlo_ctx *ctx = h->ctx;
+  const int64_t n = h->n, mem = h->mem;
+  double *tmp = h->dsc + h->lay.gtmp;
+  const T *cols[kMaxCols];
+  for (int k = 0; k < mem; ++k) {
+    cols[k] = col<T>(h->S, h->ld, k);
+    cols[mem + k] = col<T>(h->Y, h->ld, k);
+  }
+  MXLO_TRY(panel_dots<T>(ctx, cols, (int)(2 * mem), col<T>(h->S, h->ld, ins), n, tmp));          // S's_new, Y's_new
+  MXLO_TRY(panel_dots<T>(ctx, cols, (int)mem, col<T>(h->Y, h->ld, ins), n, tmp + 2 * mem));     // S'y_new
+  hipLaunchKernelGGL(gram_update_kernel, dim3(1), dim3(64), 0, ctx->stream, h->dsc + h->lay.SS,
+                     h->dsc + h->lay.YSf, tmp, (int)mem, (int)ins);
+  MXLO_LAUNCH_CHECK();
+  OrdArgs O;
+  fill_ord(h, O, /*newest_first=*/false);   // called before insert0 advances: the new pair must come last
+  // oldest -> newest with the freshly written slot last: slots (ins+1 .. ins+mem) mod mem
+  O.na = 0;
+  for (int64_t i = 1; i <= mem; ++i) {
+    const int64_t k = (ins + i) % mem;
+    if (h->ys[k] != 0) O.ord[O.na++] = (int)k;
+  }
+  O.gamma = h->scaling_factor;  // (:239) divides unconditionally; γ == 1 without scaling
+  hipLaunchKernelGGL(afwd_coef_kernel, dim3(1), dim3(64), 0, ctx->stream, h->dsc + h->lay.SS,
+                     h->dsc + h->lay.YSf, h->dsc + h->lay.Cm, O);
+  MXLO_LAUNCH_CHECK();
+  PanelGemmArgs<T> A;
+  A.nin = 2 * O.na;
+  A.nout = O.na;
+  A.C = h->dsc + h->lay.Cm;
+  for (int j = 0; j < O.na; ++j) {
+    A.in[j] = col<T>(h->S, h->ld, O.ord[j]);
+    A.in[O.na + j] = col<T>(h->B, h->ld, O.ord[j]);
+    A.out[j] = col<T>(h->A, h->ld, O.ord[j]);
+  }
+  return launch_panel_gemm<T>(ctx, A, n);
+}
+
 // push_common! — src/lbfgs.jl:210-255 (ys, yy already known on the host)
 template <typename T>
 int32_t lbfgs_push_common(mxlo_qn *h, const T *s, const T *y, double ys, double yy) {
@@ -625,6 +813,7 @@ int32_t lbfgs_push_common(mxlo_qn *h, const T *s, const T *y, double ys, double 
     const T *cols[1] = {bi};
     MXLO_TRY(panel_dots<T>(ctx, cols, 1, bi, n, h->dsc + h->lay.misc + 16 + ins));
   }
+  if (h->push_mode == MXLO_PUSH_GRAM) return fwd_rebuild_gram<T>(h, ins);
   double *coef = h->dsc + h->lay.coef;
   int older[kMaxMem];
   int nold = 0;
@@ -993,6 +1182,13 @@ MXLO_API int32_t mxlo_qn_set_mode(mxlo_qn *h, int32_t mode) {
   MXLO_REQUIRE(h, MXLO_EINVAL, "handle is NULL");
   MXLO_REQUIRE(mode == MXLO_INV_TWOPASS || mode == MXLO_INV_REFORDER, MXLO_EINVAL, "bad mode");
   h->mode = mode;
+  return MXLO_OK;
+}
+
+MXLO_API int32_t mxlo_qn_set_push_mode(mxlo_qn *h, int32_t mode) {
+  MXLO_REQUIRE(h, MXLO_EINVAL, "handle is NULL");
+  MXLO_REQUIRE(mode == MXLO_PUSH_GRAM || mode == MXLO_PUSH_REFORDER, MXLO_EINVAL, "bad push mode");
+  h->push_mode = mode;
   return MXLO_OK;
 }
 

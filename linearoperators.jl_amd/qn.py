@@ -113,6 +113,12 @@ class _QNOperator(AbstractLinearOperator):
         _lib.call("mxlo_qn_set_mode", self._h, {"twopass": _lib.INV_TWOPASS, "reforder": _lib.INV_REFORDER}[mode])
         return self
 
+    def set_push_mode(self, mode: str):
+        """'gram' (default: Gram-matrix recurrence + one panel pass) or 'reforder' (the reference's O(m²)
+        statement order) for the forward L-BFGS `push!` rebuild of the a_k panel."""
+        _lib.call("mxlo_qn_set_push_mode", self._h, {"gram": _lib.PUSH_GRAM, "reforder": _lib.PUSH_REFORDER}[mode])
+        return self
+
     def _reset_data(self):
         _lib.call("mxlo_qn_reset", self._h)
 

@@ -101,13 +101,17 @@ def test_kat_lsr1(lo, dev, kat):
 
 # ------------------------------------------------------------------------------- seeded parity
 @pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("push_mode", ["gram", "reforder"])
 @pytest.mark.parametrize("n,mem,npush,scaling", [(1000, 5, 8, True), (4097, 10, 13, True), (257, 3, 2, False),
-                                                  (100_003, 7, 7, True), (64, 1, 3, True), (50_000, 20, 23, True)])
-def test_lbfgs_parity(lo, dev, dtype, n, mem, npush, scaling):
+                                                  (100_003, 7, 7, True), (64, 1, 3, True), (50_000, 20, 23, True),
+                                                  (3001, 32, 40, True)])
+def test_lbfgs_parity(lo, dev, dtype, push_mode, n, mem, npush, scaling):
     rng = np.random.default_rng(n + mem)
     npd = NP[dtype]
     tol = dict(ref=1e-10, two=1e-9, fwd=1e-10) if dtype == torch.float64 else dict(ref=2e-4, two=2e-4, fwd=2e-4)
-    B = lo.LBFGSOperator(dtype, n, mem=mem, scaling=scaling, device=dev)
+    if push_mode == "gram":             # Gram-form rebuild of the a_k panel: different association order
+        tol["fwd"] = 1e-9 if dtype == torch.float64 else 5e-4
+    B = lo.LBFGSOperator(dtype, n, mem=mem, scaling=scaling, device=dev).set_push_mode(push_mode)
     H = lo.InverseLBFGSOperator(dtype, n, mem=mem, scaling=scaling, device=dev)
     Bo = oracle.LBFGS(n, mem=mem, scaling=scaling, inverse=False, dtype=npd)
     Ho = oracle.LBFGS(n, mem=mem, scaling=scaling, inverse=True, dtype=npd)

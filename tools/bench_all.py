@@ -1,0 +1,114 @@
+#!/usr/bin/env python
+"""Per-leaf throughput table on one MI355X (algorithmic bytes / HIP-event time); saved under profiles/."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+import __graft_entry__ as g
+
+lo = g.load_package()
+from linearoperators_jl_amd.device import Timer, get_ctx
+
+dev = torch.device("cuda", 0)
+ctx = get_ctx(dev)
+tm = Timer(ctx)
+gen = torch.Generator(device=dev).manual_seed(1)
+PEAK = 8000.0
+
+
+def timeit(fn, reps=20):
+    for _ in range(3):
+        fn()
+    tm.start()
+    for _ in range(reps):
+        fn()
+    tm.stop()
+    return tm.elapsed_ms() / reps
+
+
+def row(name, nbytes, ms, extra=""):
+    gbs = nbytes / ms / 1e6
+    print(f"{name:62s} {ms*1e3:10.1f} us {gbs:8.0f} GB/s  {gbs/PEAK:5.3f} of HBM peak {extra}", flush=True)
+
+
+def rnd(n, dt=torch.float64):
+    return torch.rand(n, dtype=dt, device=dev, generator=gen) * 2 - 1
+
+
+for dt, es in ((torch.float64, 8), (torch.float32, 4)):
+    n = 100_000_000
+    d, v, res = rnd(n, dt) + 1.5, rnd(n, dt), rnd(n, dt)
+    D = lo.opDiagonal(d)
+    row(f"opDiagonal mul! b=0 n=1e8 {dt}", 3 * es * n, timeit(lambda: lo.mul(res, D, v, 1.0, 0.0)))
+    row(f"opDiagonal mul! b!=0 n=1e8 {dt}", 4 * es * n, timeit(lambda: lo.mul(res, D, v, 2.0, -3.0)))
+    h = d / torch.linalg.vector_norm(d)
+    H = lo.opHouseholder(h)
+    row(f"opHouseholder mul! b=0 n=1e8 {dt}", 5 * es * n, timeit(lambda: lo.mul(res, H, v, 1.0, 0.0)))
+    row(f"opHouseholder mul! b!=0 n=1e8 {dt}", 6 * es * n, timeit(lambda: lo.mul(res, H, v, 2.0, -3.0)))
+    E = lo.opEye(dt, n, S=lo.Storage(dt, dev))
+    row(f"opEye mul! (axpby) b!=0 n=1e8 {dt}", 3 * es * n, timeit(lambda: lo.mul(res, E, v, 2.0, -3.0)))
+    del D, H, E, d, h
+    for small in (1 << 20, 1 << 16):
+        ds, vs, rs = rnd(small, dt), rnd(small, dt), rnd(small, dt)
+        Ds, Hs = lo.opDiagonal(ds), lo.opHouseholder(ds)
+        row(f"opDiagonal mul! n=2^{small.bit_length()-1} {dt} (latency regime)", 3 * es * small, timeit(lambda: lo.mul(rs, Ds, vs, 1.0, 0.0), 200))
+        row(f"opHouseholder mul! n=2^{small.bit_length()-1} {dt} (3 launches)", 5 * es * small, timeit(lambda: lo.mul(rs, Hs, vs, 1.0, 0.0), 200))
+    # restriction / extension
+    nidx = 50_000_000
+    idx_sorted = torch.sort(torch.randint(1, n + 1, (nidx,), device=dev, generator=gen)).values.cpu().numpy()
+    idx_rand = torch.randint(1, n + 1, (nidx,), device=dev, generator=gen).cpu().numpy()
+    out = torch.empty(nidx, dtype=dt, device=dev)
+    for nm, idx in (("sorted", idx_sorted), ("random", idx_rand)):
+        P = lo.opRestriction(idx, n, device=dev)
+        row(f"opRestriction {nm} idx nidx=5e7 of 1e8 {dt}", (8 + 2 * es) * nidx, timeit(lambda: lo.mul(out, P, v), 5))
+        row(f"opExtension  {nm} idx nidx=5e7 of 1e8 {dt}", (8 + 2 * es) * nidx + es * n, timeit(lambda: lo.mul(res, P.H, out), 5))
+        del P
+    R = lo.opRestriction(lo.jrange(1, n, 2), n, device=dev)
+    row(f"opRestriction 1:2:n {dt}", 2 * es * nidx, timeit(lambda: lo.mul(out, R, v), 5), "(reads touch every line: 3x)")
+    row(f"opExtension  1:2:n {dt}", es * nidx + es * n, timeit(lambda: lo.mul(res, R.H, out), 5))
+    R = lo.opRestriction(lo.jrange(1000, 1000 + nidx - 1), n, device=dev)
+    row(f"opRestriction UnitRange len=5e7 {dt}", 2 * es * nidx, timeit(lambda: lo.mul(out, R, v), 5))
+    del R, out, v, res
+    torch.cuda.empty_cache()
+
+# dense / hermitian (f64)
+for nn in (4096, 16384):
+    M = torch.rand(nn, nn, dtype=torch.float64, device=dev, generator=gen).t()
+    op = lo.LinearOperatorFromMatrix(M)
+    x, y = rnd(nn), rnd(nn)
+    row(f"dense LinearOperator(M) mul! n={nn}", 8.0 * nn * nn, timeit(lambda: lo.mul(y, op, x, 1.0, 0.0), 10))
+    row(f"dense transpose mul! n={nn}", 8.0 * nn * nn, timeit(lambda: lo.mul(y, op.T, x, 1.0, 0.0), 10))
+    Hm = lo.opHermitian(rnd(nn), M)
+    row(f"opHermitian mul! n={nn} (ideal = strict lower triangle once)", 4.0 * nn * nn, timeit(lambda: lo.mul(y, Hm, x, 1.0, 0.0), 10))
+    del M, op, Hm
+    torch.cuda.empty_cache()
+
+# quasi-Newton push! and solve (n = 5e7)
+n = 50_000_000
+for kind, m in (("inv", 10), ("fwd", 10), ("fwd", 20), ("lsr1", 10)):
+    op = {"inv": lo.InverseLBFGSOperator, "fwd": lo.LBFGSOperator, "lsr1": lo.LSR1Operator}[kind](torch.float64, n, mem=m, device=dev)
+    S = [rnd(n) for _ in range(2)]
+    Y = [(torch.rand(n, dtype=torch.float64, device=dev, generator=gen) * 1.5 + 0.5) * s for s in S]
+    for i in range(m + 1):
+        lo.push(op, S[i % 2], Y[i % 2])
+    torch.cuda.synchronize()
+    import time
+    t0 = time.perf_counter()
+    for i in range(4):
+        lo.push(op, S[i % 2], Y[i % 2])
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / 4 * 1e3
+    print(f"push! {kind} m={m} n=5e7 (full memory): {ms:8.2f} ms", flush=True)
+    x, out = rnd(n), torch.empty(n, dtype=torch.float64, device=dev)
+    ncol = 2 * m if kind != "lsr1" else m
+    row(f"mul! {kind} m={m} n=5e7", (2 * ncol + 3) * 8.0 * n, timeit(lambda: lo.mul(out, op, x, 1.0, 0.0), 5))
+    if kind == "fwd":
+        b = rnd(n)
+        lo.solve_shifted_system(out, op, b, 0.1)
+        row(f"solve_shifted_system! m={m} n=5e7 (G cached)", (4 * m + 3) * 8.0 * n, timeit(lambda: lo.solve_shifted_system(out, op, b, 0.1), 5))
+        row(f"diag! fwd m={m} n=5e7", (2 * m + 1) * 8.0 * n, timeit(lambda: lo.diag(op), 5))
+    del op, S, Y, x, out
+    torch.cuda.empty_cache()

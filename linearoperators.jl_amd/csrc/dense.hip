@@ -147,8 +147,11 @@ gemm_nt_fast_kernel(T *__restrict__ C, int64_t ldc, const T *__restrict__ A, int
 #pragma unroll
       for (int r = 0; r < 4; ++r) acc[a][b][r] = 0;
 
-  V ra[LPT], rb[LPT];
-  auto gload = [&](int k0) {
+  // Three-stage software pipeline: while slab `it` is in the MFMAs (LDS buffer it&1), slab it+1 sits in
+  // one register set (its global loads were issued a whole iteration ago, so the mid-iteration LDS store
+  // never waits on memory) and the loads of slab it+2 are issued into the other register set.
+  V ra0[LPT], rb0[LPT], ra1[LPT], rb1[LPT];
+  auto gload = [&](int k0, V (&ra)[LPT], V (&rb)[LPT]) {
 #pragma unroll
     for (int r = 0; r < LPT; ++r) {
       const int idx = tid + r * kBlock;
@@ -157,7 +160,7 @@ gemm_nt_fast_kernel(T *__restrict__ C, int64_t ldc, const T *__restrict__ A, int
       rb[r] = *reinterpret_cast<const V *>(B + (bn + iv * VEC) + (int64_t)(k0 + k) * ldb);
     }
   };
-  auto lstore = [&](int buf) {
+  auto lstore = [&](int buf, const V (&ra)[LPT], const V (&rb)[LPT]) {
 #pragma unroll
     for (int r = 0; r < LPT; ++r) {
       const int idx = tid + r * kBlock;
@@ -166,15 +169,9 @@ gemm_nt_fast_kernel(T *__restrict__ C, int64_t ldc, const T *__restrict__ A, int
       *reinterpret_cast<V *>(&sB[buf][k][iv * VEC]) = rb[r];
     }
   };
-  const int nk = K / FBK;
-  gload(0);
-  lstore(0);
-  __syncthreads();
-  for (int it = 0; it < nk; ++it) {
-    const int buf = it & 1;
-    if (it + 1 < nk) gload((it + 1) * FBK);
+  auto mfma_range = [&](int buf, int kbeg, int kend) {
 #pragma unroll
-    for (int kk = 0; kk < FBK; kk += 4) {
+    for (int kk = kbeg; kk < kend; kk += 4) {
       const int kr = kk + (lane >> 4);
       const T b0 = sB[buf][kr][wn + (lane & 15)], b1 = sB[buf][kr][wn + 16 + (lane & 15)];
 #pragma unroll
@@ -184,7 +181,25 @@ gemm_nt_fast_kernel(T *__restrict__ C, int64_t ldc, const T *__restrict__ A, int
         acc[a][1] = Mfma<T>::run(av, b1, acc[a][1]);
       }
     }
-    if (it + 1 < nk) lstore(buf ^ 1);
+  };
+  const int nk = K / FBK;
+  gload(0, ra0, rb0);
+  lstore(0, ra0, rb0);
+  if (nk > 1) gload(FBK, ra1, rb1);
+  __syncthreads();
+  for (int it = 0; it < nk; it += 2) {
+    // even slab: LDS buffer 0; register set 1 holds slab it+1; set 0 receives slab it+2
+    if (it + 2 < nk) gload((it + 2) * FBK, ra0, rb0);
+    mfma_range(0, 0, FBK / 2);
+    if (it + 1 < nk) lstore(1, ra1, rb1);
+    mfma_range(0, FBK / 2, FBK);
+    __syncthreads();
+    if (it + 1 >= nk) break;
+    // odd slab: LDS buffer 1; register set 0 holds slab it+2; set 1 receives slab it+3
+    if (it + 3 < nk) gload((it + 3) * FBK, ra1, rb1);
+    mfma_range(1, 0, FBK / 2);
+    if (it + 2 < nk) lstore(0, ra0, rb0);
+    mfma_range(1, FBK / 2, FBK);
     __syncthreads();
   }
 #pragma unroll

@@ -69,6 +69,7 @@ struct mxlo_qn {
   std::vector<int64_t> age;   // push counter per slot (Gram freshness)
   int64_t pushes = 0;
   bool G_valid = false;
+  bool normA_valid = true;   // L-SR1 ||a_k||^2 (opnorm bound) computed lazily after a Gram-form push
   // device
   void *S = nullptr, *Y = nullptr, *A = nullptr, *B = nullptr;  // panels
   void *tmp = nullptr, *tmp2 = nullptr;                         // n-vectors (Ax / tmp)
@@ -305,11 +306,12 @@ __device__ __forceinline__ double rnd(double v, int is_f32) { return is_f32 ? (d
 //   dots[i] = s_i'x, dots[na+i] = y_i'x for i = 0..na-1 in NEWEST->OLDEST order (ord[]).
 //   coef[i]      = alpha_i  (column y_ord[i], newest->oldest)
 //   coef[na + j] = beta for column s in OLDEST->NEWEST order (j = 0 is ord[na-1]).
-__global__ void inv_coef_kernel(const double *__restrict__ dots, double *__restrict__ coef,
-                                const double *__restrict__ SY, const double *__restrict__ YS,
-                                const double *__restrict__ YY, double *__restrict__ alpha_out,
-                                OrdArgs O) {
-  if (threadIdx.x != 0) return;
+__global__ void __launch_bounds__(64)
+inv_coef_kernel(const double *__restrict__ dots, double *__restrict__ coef,
+                const double *__restrict__ SY, const double *__restrict__ YS,
+                const double *__restrict__ YY, double *__restrict__ alpha_out, OrdArgs O) {
+  // one wave: lane j holds a_j / b_j; every inner sum of the recurrences is a wave reduction
+  const int lane = threadIdx.x;
   const int na = O.na, mem = O.mem;
   auto sy = [&](int i, int j) {  // s_i' y_j for slots i, j
     return O.age[j] >= O.age[i] ? SY[i + (int64_t)j * mem] : YS[j + (int64_t)i * mem];
@@ -317,25 +319,36 @@ __global__ void inv_coef_kernel(const double *__restrict__ dots, double *__restr
   auto yy = [&](int i, int j) {
     return O.age[j] >= O.age[i] ? YY[i + (int64_t)j * mem] : YY[j + (int64_t)i * mem];
   };
-  double a[kMaxMem], b[kMaxMem];
+  auto wsum = [](double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+  };
+  const int myslot = lane < na ? O.ord[lane] : 0;
+  double a = 0.0, b = 0.0;  // lane's own alpha / beta
   for (int i = 0; i < na; ++i) {
     const int k = O.ord[i];
-    double sq = dots[i];
-    for (int j = 0; j < i; ++j) sq -= a[j] * sy(k, O.ord[j]);
-    a[i] = rnd(sq / O.ys[k], O.is_f32);
-    alpha_out[k] = a[i];
+    const double part = (lane < i) ? a * sy(k, myslot) : 0.0;
+    const double sq = dots[i] - wsum(part);
+    const double ai = rnd(sq / O.ys[k], O.is_f32);
+    if (lane == i) a = ai;
   }
+  if (lane < na) alpha_out[myslot] = a;
   const double g = O.use_gamma ? O.gamma : 1.0;
   for (int i = na - 1; i >= 0; --i) {
     const int k = O.ord[i];
-    double yq = dots[na + i];
-    for (int j = 0; j < na; ++j) yq -= a[j] * yy(k, O.ord[j]);
-    double yr = g * yq;
-    for (int j = na - 1; j > i; --j) yr += b[j] * sy(O.ord[j], k);
-    b[i] = rnd(a[i] - yr / O.ys[k], O.is_f32);
+    const double p1 = (lane < na) ? a * yy(k, myslot) : 0.0;          // sum_j alpha_j y_k'y_j
+    const double p2 = (lane < na && lane > i) ? b * sy(myslot, k) : 0.0;  // sum_{older j} beta_j s_j'y_k
+    const double yq = dots[na + i] - wsum(p1);
+    const double yr = g * yq + wsum(p2);
+    const double ai = __shfl(a, i, 64);
+    const double bi = rnd(ai - yr / O.ys[k], O.is_f32);
+    if (lane == i) b = bi;
   }
-  for (int i = 0; i < na; ++i) coef[i] = a[i];
-  for (int j = 0; j < na; ++j) coef[na + j] = b[na - 1 - j];
+  if (lane < na) {
+    coef[lane] = a;                   // y columns, newest -> oldest
+    coef[na + (na - 1 - lane)] = b;   // s columns, oldest -> newest
+  }
 }
 
 // L-SR1: coef[i] = (alpha*dot_i)/as_k evaluated in CT (src/lsr1.jl:101)
@@ -742,6 +755,48 @@ int32_t launch_panel_gemm(mxlo_ctx *ctx, PanelGemmArgs<T> &A, int64_t n) {
   return go.template operator()<32>();
 }
 
+// L-SR1 rank-one terms in coefficient space (src/lsr1.jl:166-178): basis [y_ord[0..r), s_ord[0..r)],
+//   a_k = y_k - s_k/γ - sum_{l<k} (a_l's_k / as_l) a_l ,  as_k = a_k's_k.  One wave, lane j owns coefficient j.
+__global__ void __launch_bounds__(64)
+asr1_coef_kernel(const double *__restrict__ SS, const double *__restrict__ YSf, double *__restrict__ Cm,
+                 double *__restrict__ as_out, OrdArgs O) {
+  __shared__ double Z[kMaxCols][kMaxMem];      // Z[j][k] = <basis_j, s_k>
+  __shared__ double Cl[kMaxMem][kMaxCols];
+  __shared__ double asl[kMaxMem];
+  const int lane = threadIdx.x;
+  const int r = O.na, mem = O.mem, w = 2 * r;
+  for (int k = 0; k < r; ++k)
+    if (lane < w) {
+      const int j = lane < r ? lane : lane - r;
+      Z[lane][k] = (lane < r ? YSf : SS)[O.ord[j] * mem + O.ord[k]];
+    }
+  __syncthreads();
+  auto wsum = [](double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+  };
+  for (int k = 0; k < r; ++k) {
+    double c = (lane == k) ? 1.0 : ((lane == r + k) ? -1.0 / O.gamma : 0.0);   // y_k - s_k/γ       (:169)
+    const double zk = lane < w ? Z[lane][k] : 0.0;
+    for (int l = 0; l < k; ++l) {
+      const double cl = lane < w ? Cl[l][lane] : 0.0;
+      const double as = wsum(cl * zk) / asl[l];                                // dot(a_l,s_k)/as_l (:173)
+      c -= as * cl;                                                            //                   (:174)
+    }
+    const double ask = wsum(c * zk);                                           // as_k = a_k's_k    (:177)
+    if (lane < w) {
+      Cl[k][lane] = c;
+      Cm[(int64_t)k * w + lane] = c;
+    }
+    if (lane == 0) {
+      asl[k] = ask;
+      as_out[O.ord[k]] = ask;
+    }
+    __syncthreads();
+  }
+}
+
 // Gram-form rebuild of the forward panel after (s, y) was copied into slot `ins` and b[ins] was formed.
 template <typename T>
 int32_t fwd_rebuild_gram(mxlo_qn *h, int64_t ins) {
@@ -974,6 +1029,34 @@ int32_t lsr1_push(mxlo_qn *h, const T *s, const T *y, int32_t *accepted) {
   double *dots = h->dsc + h->lay.dots, *coef = h->dsc + h->lay.coef, *as_ = h->dsc + h->lay.as_;
   OrdArgs O;
   fill_ord(h, O, false);
+  if (h->push_mode == MXLO_PUSH_GRAM) {
+    // Gram form: 3m dots, an O(r^3) coefficient recurrence on one wave, ONE pass A = [Y S] * C
+    double *tmp = h->dsc + h->lay.gtmp;
+    const T *cols[kMaxCols];
+    for (int k = 0; k < mem; ++k) {
+      cols[k] = col<T>(h->S, h->ld, k);
+      cols[mem + k] = col<T>(h->Y, h->ld, k);
+    }
+    MXLO_TRY(panel_dots<T>(ctx, cols, (int)(2 * mem), col<T>(h->S, h->ld, ins), n, tmp));       // S's_new, Y's_new
+    MXLO_TRY(panel_dots<T>(ctx, cols, (int)mem, col<T>(h->Y, h->ld, ins), n, tmp + 2 * mem));  // S'y_new
+    hipLaunchKernelGGL(gram_update_kernel, dim3(1), dim3(64), 0, ctx->stream, h->dsc + h->lay.SS,
+                       h->dsc + h->lay.YSf, tmp, (int)mem, (int)ins);
+    MXLO_LAUNCH_CHECK();
+    hipLaunchKernelGGL(asr1_coef_kernel, dim3(1), dim3(64), 0, ctx->stream, h->dsc + h->lay.SS,
+                       h->dsc + h->lay.YSf, h->dsc + h->lay.Cm, as_, O);
+    MXLO_LAUNCH_CHECK();
+    PanelGemmArgs<T> G;
+    G.nin = 2 * O.na;
+    G.nout = O.na;
+    G.C = h->dsc + h->lay.Cm;
+    for (int j = 0; j < O.na; ++j) {
+      G.in[j] = col<T>(h->Y, h->ld, O.ord[j]);
+      G.in[O.na + j] = col<T>(h->S, h->ld, O.ord[j]);
+      G.out[j] = col<T>(h->A, h->ld, O.ord[j]);
+    }
+    h->normA_valid = false;
+    return launch_panel_gemm<T>(ctx, G, n);
+  }
   int nold = 0;
   for (int i = 0; i < O.na; ++i) {
     const int k = O.ord[i];
@@ -1008,33 +1091,48 @@ int32_t lsr1_push(mxlo_qn *h, const T *s, const T *y, int32_t *accepted) {
 // u_t, t = 0..nu-1: active slots oldest->newest, each contributing (a_k, b_k) with signs (+1, -1).
 //   G = U'U (cached per state), g = U'b, then the reference's recursion (src/utilities.jl:226-246)
 //   on coefficient vectors P[i] (p_i = sum_j P[i][j] u_j), finally x = x0*b + U cx.
-__global__ void shifted_coef_kernel(const double *__restrict__ G, const double *__restrict__ gvec,
-                                    double *__restrict__ cx, int nu, double x0, int is_f32) {
-  extern __shared__ double sh[];  // P[nu*nu], v[nu]
-  if (threadIdx.x != 0) return;
-  double *P = sh, *v = sh + nu * nu;
-  for (int j = 0; j < nu; ++j) cx[j] = 0.0;
+__global__ void __launch_bounds__(64)
+shifted_coef_kernel(const double *__restrict__ G, const double *__restrict__ gvec,
+                    double *__restrict__ cx, int nu, double x0, int is_f32) {
+  // one wave; lane j owns column j of every coefficient vector. P (nu x nu) and G live in LDS.
+  extern __shared__ double sh[];  // P[nu*nu], Gs[nu*nu], v[nu], c2[nu]
+  double *P = sh, *Gs = sh + nu * nu, *v = Gs + nu * nu, *c2 = v + nu;
+  const int lane = threadIdx.x;
+  for (int idx = lane; idx < nu * nu; idx += 64) {
+    Gs[idx] = G[idx];
+    P[idx] = 0.0;
+  }
+  __syncthreads();
+  auto wsum = [](double val) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) val += __shfl_xor(val, off, 64);
+    return val;
+  };
+  const double gl = lane < nu ? gvec[lane] : 0.0;
+  double cxl = 0.0;
   for (int i = 0; i < nu; ++i) {
     const int sign_i = (i & 1) ? -1 : 1;
-    for (int j = 0; j < nu; ++j) P[i * nu + j] = 0.0;
-    P[i * nu + i] = x0;                                         // p_i = x0 * u_i          (:231)
-    int sign_t = 1;
-    for (int t = 0; t < i; ++t) {
-      double c0 = 0.0;                                          // dot(p_t, u_i)           (:235)
-      for (int j = 0; j <= t; ++j) c0 += P[t * nu + j] * G[j * nu + i];
-      const double c2 = (sign_t * v[t]) * c0;                   // (:236-237)
-      for (int j = 0; j <= t; ++j) P[i * nu + j] += c2 * P[t * nu + j];   // (:238)
-      sign_t = -sign_t;
+    // c2[t] = (sign_t v_t) * dot(p_t, u_i), t < i  — lane t does its own dot          (:235-237)
+    if (lane < i) {
+      double c0 = 0.0;
+      for (int j = 0; j <= lane; ++j) c0 += P[lane * nu + j] * Gs[j * nu + i];
+      c2[lane] = (((lane & 1) ? -1.0 : 1.0) * v[lane]) * c0;
     }
-    double up = 0.0;                                            // dot(u_i, p_i)
-    for (int j = 0; j <= i; ++j) up += P[i * nu + j] * G[i * nu + j];
-    v[i] = rnd(1.0 / (1.0 - sign_i * up), is_f32);              // (:242)
-    double pb = 0.0;                                            // p_i' b
-    for (int j = 0; j <= i; ++j) pb += P[i * nu + j] * gvec[j];
-    const double c = (sign_i * v[i]) * pb;                      // (:243-244)
-    for (int j = 0; j <= i; ++j) cx[j] += c * P[i * nu + j];
+    __syncthreads();
+    // p_i = x0 u_i + sum_t c2[t] p_t  — lane j does column j                          (:231,:238)
+    double pij = (lane == i) ? x0 : 0.0;
+    if (lane < i)
+      for (int t = lane; t < i; ++t) pij += c2[t] * P[t * nu + lane];
+    if (lane < nu) P[i * nu + lane] = pij;
+    const double up = wsum(lane <= i ? pij * Gs[i * nu + lane] : 0.0);                 // dot(u_i, p_i)
+    const double vi = rnd(1.0 / (1.0 - sign_i * up), is_f32);                          // (:242)
+    if (lane == 0) v[i] = vi;
+    const double pb = wsum(lane <= i ? pij * gl : 0.0);                                // p_i' b
+    cxl += ((sign_i * vi) * pb) * pij;                                                 // (:243-244)
+    __syncthreads();
   }
-  cx[kMaxCols] = x0;  // c0 slot read by CM_AXPYS
+  if (lane < nu) cx[lane] = cxl;
+  if (lane == 0) cx[kMaxCols] = x0;  // c0 slot read by CM_AXPYS
 }
 
 template <typename T>
@@ -1068,7 +1166,13 @@ int32_t solve_shifted_t(mxlo_qn *h, T *x, const T *b, double sigma) {
   const double g_inv = rT<T>(1.0 / h->scaling_factor);                 // :219
   const double x0 = rT<T>(1.0 / (g_inv + sigma));                      // :220
   if (nu > 0) MXLO_TRY(panel_dots<T>(ctx, ucols, nu, b, n, gv));
-  hipLaunchKernelGGL(shifted_coef_kernel, dim3(1), dim3(64), sizeof(double) * (nu * nu + nu + 1),
+  static bool lds_attr_set = false;
+  if (!lds_attr_set) {  // up to 2*64*64 + 130 doubles of dynamic LDS (> the 64 KiB default cap)
+    MXLO_HIP(hipFuncSetAttribute((const void *)shifted_coef_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 96 * 1024));
+    lds_attr_set = true;
+  }
+  hipLaunchKernelGGL(shifted_coef_kernel, dim3(1), dim3(64), sizeof(double) * (2 * nu * nu + 2 * nu + 2),
                      ctx->stream, G, gv, cx, nu, x0, (int)(sizeof(T) == 4));
   MXLO_LAUNCH_CHECK();
   CombineArgs<T> A;
@@ -1267,6 +1371,7 @@ MXLO_API int32_t mxlo_qn_reset(mxlo_qn *h) {
   h->scaling_factor = 1.0;
   h->insert0 = 0;
   h->G_valid = false;
+  h->normA_valid = true;
   return MXLO_OK;
 }
 
@@ -1287,6 +1392,19 @@ MXLO_API int32_t mxlo_qn_get_scalars(mxlo_qn *h, double scalars[5], double *ys, 
       if (h->ys[k] != 0) bound += nrm[k];
     }
   } else {
+    if (!h->normA_valid) {  // ||a_k||^2 for the opnorm bound, computed on demand after Gram-form pushes
+      for (int64_t k = 0; k < mem; ++k) {
+        if (h->ys[k] == 0) continue;
+        if (h->dtype == MXLO_F64) {
+          const double *c[1] = {col<double>(h->A, h->ld, k)};
+          MXLO_TRY(panel_dots<double>(h->ctx, c, 1, c[0], h->n, h->dsc + h->lay.misc + 16 + k));
+        } else {
+          const float *c[1] = {col<float>(h->A, h->ld, k)};
+          MXLO_TRY(panel_dots<float>(h->ctx, c, 1, c[0], h->n, h->dsc + h->lay.misc + 16 + k));
+        }
+      }
+      h->normA_valid = true;
+    }
     MXLO_TRY(read_scalars(h, h->dsc + h->lay.as_, dev.data(), (int)mem));
     MXLO_TRY(read_scalars(h, h->dsc + h->lay.misc + 16, nrm.data(), (int)mem));
     bound = 1.0;                                                          // src/lsr1.jl:156

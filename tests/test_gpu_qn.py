@@ -146,12 +146,14 @@ def test_lbfgs_parity(lo, dev, dtype, push_mode, n, mem, npush, scaling):
 
 
 @pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
-@pytest.mark.parametrize("n,mem,npush,scaling", [(1000, 5, 8, True), (4099, 8, 11, False), (100_001, 6, 9, True)])
-def test_lsr1_parity(lo, dev, dtype, n, mem, npush, scaling):
+@pytest.mark.parametrize("push_mode", ["gram", "reforder"])
+@pytest.mark.parametrize("n,mem,npush,scaling", [(1000, 5, 8, True), (4099, 8, 11, False), (100_001, 6, 9, True),
+                                                  (2001, 32, 37, True)])
+def test_lsr1_parity(lo, dev, dtype, push_mode, n, mem, npush, scaling):
     rng = np.random.default_rng(7 * n + mem)
     npd = NP[dtype]
-    tol = 1e-10 if dtype == torch.float64 else 5e-4
-    B = lo.LSR1Operator(dtype, n, mem=mem, scaling=scaling, device=dev)
+    tol = (1e-10 if push_mode == "reforder" else 1e-9) if dtype == torch.float64 else 1e-3
+    B = lo.LSR1Operator(dtype, n, mem=mem, scaling=scaling, device=dev).set_push_mode(push_mode)
     Bo = oracle.LSR1(n, mem=mem, scaling=scaling, dtype=npd)
     x, r0 = rng.uniform(-1, 1, n).astype(npd), rng.uniform(-1, 1, n).astype(npd)
     for s, y in pairs(rng, n, npush, npd):

@@ -106,9 +106,6 @@ MXLO_API int32_t mxlo_ctx_tune(mxlo_ctx *ctx, const char *key, int64_t value) {
     MXLO_REQUIRE(value == MXLO_INV_TWOPASS || value == MXLO_INV_REFORDER, MXLO_EINVAL,
                  "lbfgs_inv_mode must be MXLO_INV_TWOPASS or MXLO_INV_REFORDER");
     ctx->tune.lbfgs_inv_mode = (int)value;
-  } else if (!strcmp(key, "house_mall_tail_bytes")) {
-    MXLO_REQUIRE(value >= 0, MXLO_EINVAL, "house_mall_tail_bytes out of range");
-    ctx->tune.house_mall_tail_bytes = value;
   } else if (!strcmp(key, "gemm_waves")) {
     MXLO_REQUIRE(value == 4 || value == 8, MXLO_EINVAL, "gemm_waves must be 4 or 8");
     ctx->tune.gemm_waves = (int)value;

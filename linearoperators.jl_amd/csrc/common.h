@@ -64,8 +64,6 @@ struct Tune {
   int house_reverse = 1;   // Householder phase B walks the vectors back-to-front (MALL tail reuse)
   int lbfgs_inv_mode = MXLO_INV_TWOPASS;
   int dots_max_nc = 20;    // columns per panel_dots launch (<= 20)
-  int64_t house_mall_tail_bytes = 0;  // Householder: bytes per operand at the END of h,v read with
-                                      // default-policy loads in pass A and first (reverse walk) in pass B
   int gemm_waves = 8;      // fast GEMM: waves per 64x64 tile (4: 32x32 per wave, 8: 16x32 per wave)
   int combine_blocks_per_cu = 0;   // panel_combine: 0 = one vector per thread (best measured), k = persistent grid
 };
@@ -81,7 +79,6 @@ struct mxlo_ctx {
   mxlo_allreduce_fn allreduce = nullptr;
   void *allreduce_user = nullptr;
   mxlo::Tune tune;
-  int64_t plain_tail_bytes = 0;  // transient: see Tune::house_mall_tail_bytes
 };
 
 namespace mxlo {

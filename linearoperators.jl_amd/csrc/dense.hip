@@ -259,47 +259,98 @@ int32_t gemm(mxlo_ctx *ctx, T *C, int64_t ldc, const T *A, int64_t lda, bool ta,
 
 // ---- GEMV --------------------------------------------------------------------------------
 // T mode (res[j] = alpha * dot(M[:,j], v) + beta*res[j]): one wave per column, coalesced down the column.
-template <typename T, typename CT, bool BETA0, bool LOWER>
+// PAIR: two rows per lane per load (16 B for f64), 4 loads of M in flight per lane, nontemporal (M is
+// streamed once; v stays cached).
+template <typename T, typename CT, bool BETA0, bool PAIR>
 __global__ void __launch_bounds__(kBlock)
 gemv_t_kernel(T *__restrict__ res, const T *__restrict__ M, int64_t m, int64_t n, int64_t ld,
-              const T *__restrict__ v, CT alpha, CT beta, T *__restrict__ raw_out) {
+              const T *__restrict__ v, CT alpha, CT beta) {
+  typedef T V2 __attribute__((ext_vector_type(2)));
   const int lane = threadIdx.x & 63;
   const int64_t wave = (int64_t)blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
   const int64_t nwaves = (int64_t)gridDim.x * (kBlock / kWave);
   for (int64_t j = wave; j < n; j += nwaves) {
     const T *colp = M + j * ld;
-    double acc = 0.0;
-    const int64_t i0 = LOWER ? j + 1 : 0;  // strict lower triangle only
-    for (int64_t i = i0 + lane; i < m; i += 64) acc = fma((double)colp[i], (double)v[i], acc);
+    double acc0 = 0.0, acc1 = 0.0;
+    int64_t i = 0;
+    if constexpr (PAIR) {
+      constexpr int U = 4;
+      const int64_t mp = m / 2;  // row pairs
+      const V2 *cp = reinterpret_cast<const V2 *>(colp);
+      const V2 *vp = reinterpret_cast<const V2 *>(v);
+      int64_t p = lane;
+      for (; p + (int64_t)(U - 1) * 64 < mp; p += (int64_t)U * 64) {
+        V2 a[U], x[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          a[u] = __builtin_nontemporal_load(cp + p + u * 64);
+          x[u] = vp[p + u * 64];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          acc0 = fma((double)a[u][0], (double)x[u][0], acc0);
+          acc1 = fma((double)a[u][1], (double)x[u][1], acc1);
+        }
+      }
+      for (; p < mp; p += 64) {
+        const V2 a = cp[p], x = vp[p];
+        acc0 = fma((double)a[0], (double)x[0], acc0);
+        acc1 = fma((double)a[1], (double)x[1], acc1);
+      }
+      i = mp * 2;
+    }
+    for (int64_t r = i + lane; r < m; r += 64) acc0 = fma((double)colp[r], (double)v[r], acc0);
+    double acc = acc0 + acc1;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
     if (lane == 0) {
-      if (raw_out) raw_out[j] = (T)acc;
-      else {
-        CT t = alpha * (CT)(T)acc;
-        if constexpr (!BETA0) t = t + (beta * (CT)res[j]);
-        res[j] = (T)t;
-      }
+      CT t = alpha * (CT)(T)acc;
+      if constexpr (!BETA0) t = t + (beta * (CT)res[j]);
+      res[j] = (T)t;
     }
   }
 }
 
-// N mode partials: thread per row, a chunk of columns per blockIdx.y; part[chunk][row].
-template <typename T, bool LOWER>
+// N mode partials: a lane owns one row (or a PAIR of rows: 16-byte loads for f64), a chunk of columns per
+// blockIdx.y, 8 columns in flight; part[chunk][row].
+template <typename T, bool PAIR>
 __global__ void __launch_bounds__(kBlock)
 gemv_n_partial_kernel(double *__restrict__ part, const T *__restrict__ M, int64_t m, int64_t n,
                       int64_t ld, const T *__restrict__ v, int64_t cols_per_chunk) {
-  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  typedef T V2 __attribute__((ext_vector_type(2)));
+  constexpr int R = PAIR ? 2 : 1;
+  const int64_t i = ((int64_t)blockIdx.x * kBlock + threadIdx.x) * R;
   const int64_t j0 = (int64_t)blockIdx.y * cols_per_chunk;
   int64_t j1 = j0 + cols_per_chunk;
   if (j1 > n) j1 = n;
   if (i >= m) return;
-  double acc = 0.0;
-  for (int64_t j = j0; j < j1; ++j) {
-    if (LOWER && j >= i) break;  // only L[i][j] with j < i
-    acc = fma((double)M[i + j * ld], (double)v[j], acc);
+  double acc0 = 0.0, acc1 = 0.0;
+  if (PAIR && i + 1 < m) {
+    constexpr int U = 8;
+    int64_t j = j0;
+    for (; j + U <= j1; j += U) {
+      V2 a[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) a[u] = __builtin_nontemporal_load(reinterpret_cast<const V2 *>(M + i + (j + u) * ld));
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const double vj = (double)v[j + u];
+        acc0 = fma((double)a[u][0], vj, acc0);
+        acc1 = fma((double)a[u][1], vj, acc1);
+      }
+    }
+    for (; j < j1; ++j) {
+      const V2 a = *reinterpret_cast<const V2 *>(M + i + j * ld);
+      const double vj = (double)v[j];
+      acc0 = fma((double)a[0], vj, acc0);
+      acc1 = fma((double)a[1], vj, acc1);
+    }
+    part[(int64_t)blockIdx.y * m + i] = acc0;
+    part[(int64_t)blockIdx.y * m + i + 1] = acc1;
+    return;
   }
-  part[(int64_t)blockIdx.y * m + i] = acc;
+  for (int64_t j = j0; j < j1; ++j) acc0 = fma((double)M[i + j * ld], (double)v[j], acc0);
+  part[(int64_t)blockIdx.y * m + i] = acc0;
 }
 
 template <typename T, typename CT, bool BETA0>
@@ -319,26 +370,16 @@ gemv_n_finish_kernel(T *__restrict__ res, const double *__restrict__ part, int64
   res[i] = (T)t;
 }
 
-// res = alpha*((d*v + t1) + t2) (+ beta*res)     src/linalg.jl:99-101
-template <typename T, typename CT, bool BETA0>
-__global__ void __launch_bounds__(kBlock)
-herm_combine_kernel(T *__restrict__ res, const T *__restrict__ d, const T *__restrict__ v,
-                    const T *__restrict__ t1, const T *__restrict__ t2, int64_t n, CT alpha, CT beta) {
-  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (i >= n) return;
-  const T inner = ((d[i] * v[i]) + t1[i]) + t2[i];
-  CT t = alpha * (CT)inner;
-  if constexpr (!BETA0) t = t + (beta * (CT)res[i]);
-  res[i] = (T)t;
-}
-
-template <typename T, bool LOWER>
+template <typename T>
 int32_t gemv_n(mxlo_ctx *ctx, T *res, const T *M, int64_t m, int64_t n, int64_t ld, const T *v,
-               double alpha, double beta, int32_t flags, T *raw_out) {
+               double alpha, double beta, int32_t flags) {
   const int64_t cap = (int64_t)kMaxRedCols * kMaxRedBlocks;  // doubles in ctx->partials
   MXLO_REQUIRE(m <= cap, MXLO_ESHAPE, "gemv: m = %lld exceeds the partial workspace", (long long)m);
+  // pairs of rows per lane need 16-byte (8-byte for f32) aligned column starts
+  const bool pair = m >= 2 && (((uintptr_t)M % (2 * sizeof(T))) == 0) && (ld % 2 == 0);
+  const int64_t rows_per_block = (int64_t)kBlock * (pair ? 2 : 1);
+  const int64_t row_blocks = (m + rows_per_block - 1) / rows_per_block;
   int64_t nchunks = (n + 63) / 64;              // >= 64 columns per chunk
-  const int64_t row_blocks = (m + kBlock - 1) / kBlock;
   const int64_t want = (int64_t)ctx->num_cu * 8 / (row_blocks > 0 ? row_blocks : 1) + 1;
   if (nchunks > want) nchunks = want;
   if (nchunks > cap / (m > 0 ? m : 1)) nchunks = cap / (m > 0 ? m : 1);
@@ -347,27 +388,38 @@ int32_t gemv_n(mxlo_ctx *ctx, T *res, const T *M, int64_t m, int64_t n, int64_t 
   const int64_t cpc = (n + nchunks - 1) / nchunks;
   nchunks = n > 0 ? (n + cpc - 1) / cpc : 1;
   dim3 grid((unsigned)row_blocks, (unsigned)nchunks);
-  hipLaunchKernelGGL((gemv_n_partial_kernel<T, LOWER>), grid, dim3(kBlock), 0, ctx->stream,
-                     ctx->partials, M, m, n, ld, v, cpc > 0 ? cpc : 1);
+  if (pair)
+    hipLaunchKernelGGL((gemv_n_partial_kernel<T, true>), grid, dim3(kBlock), 0, ctx->stream, ctx->partials, M, m,
+                       n, ld, v, cpc > 0 ? cpc : 1);
+  else
+    hipLaunchKernelGGL((gemv_n_partial_kernel<T, false>), grid, dim3(kBlock), 0, ctx->stream, ctx->partials, M, m,
+                       n, ld, v, cpc > 0 ? cpc : 1);
   MXLO_LAUNCH_CHECK();
+  const unsigned fin_blocks = (unsigned)((m + kBlock - 1) / kBlock);
   return dispatch_ct<T>(beta, flags, [&]<typename CT, bool B0>() -> int32_t {
-    hipLaunchKernelGGL((gemv_n_finish_kernel<T, CT, B0>), dim3((unsigned)row_blocks), dim3(kBlock), 0,
-                       ctx->stream, res, ctx->partials, m, (int)nchunks, (CT)alpha, (CT)beta, raw_out);
+    hipLaunchKernelGGL((gemv_n_finish_kernel<T, CT, B0>), dim3(fin_blocks), dim3(kBlock), 0, ctx->stream, res,
+                       ctx->partials, m, (int)nchunks, (CT)alpha, (CT)beta, (T *)nullptr);
     MXLO_LAUNCH_CHECK();
     return MXLO_OK;
   });
 }
 
-template <typename T, bool LOWER>
+template <typename T>
 int32_t gemv_t(mxlo_ctx *ctx, T *res, const T *M, int64_t m, int64_t n, int64_t ld, const T *v,
-               double alpha, double beta, int32_t flags, T *raw_out) {
+               double alpha, double beta, int32_t flags) {
   if (n <= 0) return MXLO_OK;
   int64_t blocks = (n + 3) / 4;
   const int64_t cap = (int64_t)ctx->num_cu * 16;
   if (blocks > cap) blocks = cap;
+  const bool pair = m >= 2 && (((uintptr_t)M % (2 * sizeof(T))) == 0) && (ld % 2 == 0) &&
+                    (((uintptr_t)v % (2 * sizeof(T))) == 0);
   return dispatch_ct<T>(beta, flags, [&]<typename CT, bool B0>() -> int32_t {
-    hipLaunchKernelGGL((gemv_t_kernel<T, CT, B0, LOWER>), dim3((unsigned)blocks), dim3(kBlock), 0,
-                       ctx->stream, res, M, m, n, ld, v, (CT)alpha, (CT)beta, raw_out);
+    if (pair)
+      hipLaunchKernelGGL((gemv_t_kernel<T, CT, B0, true>), dim3((unsigned)blocks), dim3(kBlock), 0, ctx->stream,
+                         res, M, m, n, ld, v, (CT)alpha, (CT)beta);
+    else
+      hipLaunchKernelGGL((gemv_t_kernel<T, CT, B0, false>), dim3((unsigned)blocks), dim3(kBlock), 0, ctx->stream,
+                         res, M, m, n, ld, v, (CT)alpha, (CT)beta);
     MXLO_LAUNCH_CHECK();
     return MXLO_OK;
   });
@@ -386,8 +438,8 @@ int32_t gemv_any(mxlo_ctx *ctx, T *res, const T *M, int64_t m, int64_t n, int64_
     }
     return mxlo_scale(ctx, sizeof(T) == 8 ? MXLO_F64 : MXLO_F32, res, nres, beta, flags);
   }
-  if (mode == MXLO_OP_N) return gemv_n<T, false>(ctx, res, M, m, n, ld, v, alpha, beta, flags, nullptr);
-  return gemv_t<T, false>(ctx, res, M, m, n, ld, v, alpha, beta, flags, nullptr);
+  if (mode == MXLO_OP_N) return gemv_n<T>(ctx, res, M, m, n, ld, v, alpha, beta, flags);
+  return gemv_t<T>(ctx, res, M, m, n, ld, v, alpha, beta, flags);
 }
 
 // ---- opHermitian, single pass over the strict lower triangle -------------------------------------
@@ -452,17 +504,42 @@ herm_tile_kernel(const T *__restrict__ A, int64_t lda, const T *__restrict__ v, 
     prow1 = fma((double)e1[k], vc, prow1);
     pcol[k] = fma((double)e1[k], vr1, (double)e0[k] * vr0);
   }
-  // column sums: reduce over the 32 lanes that share cg (a half wave)
+  // column sums over the 32 lanes that share cg (a half wave): halving butterfly — at each of the first
+  // three steps a lane hands half of its values to its partner, so 4+2+1 shuffles leave ONE value per lane
+  // (column k = bits 4,3,2 of the lane), then two plain steps finish the sum: 9 shuffles instead of 40.
+  {
+    const int l5 = tid & 31;
+    double w4[4], w2[2], w1;
+    {
+      const bool hi = (l5 & 16) != 0;
 #pragma unroll
-  for (int k = 0; k < 8; ++k) {
+      for (int q = 0; q < 4; ++q) {
+        const double send = hi ? pcol[q] : pcol[4 + q];
+        const double recv = __shfl_xor(send, 16, 64);
+        w4[q] = (hi ? pcol[4 + q] : pcol[q]) + recv;
+      }
+    }
+    {
+      const bool hi = (l5 & 8) != 0;
 #pragma unroll
-    for (int off = 16; off > 0; off >>= 1) pcol[k] += __shfl_xor(pcol[k], off, 64);
-  }
-  if (rp == 0) {
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
+      for (int q = 0; q < 2; ++q) {
+        const double send = hi ? w4[q] : w4[2 + q];
+        const double recv = __shfl_xor(send, 8, 64);
+        w2[q] = (hi ? w4[2 + q] : w4[q]) + recv;
+      }
+    }
+    {
+      const bool hi = (l5 & 4) != 0;
+      const double send = hi ? w2[0] : w2[1];
+      const double recv = __shfl_xor(send, 4, 64);
+      w1 = (hi ? w2[1] : w2[0]) + recv;
+    }
+    w1 += __shfl_xor(w1, 2, 64);
+    w1 += __shfl_xor(w1, 1, 64);
+    if ((l5 & 3) == 0) {
+      const int k = ((l5 >> 4) & 1) * 4 + ((l5 >> 3) & 1) * 2 + ((l5 >> 2) & 1);
       const int64_t gc = j0 + cg + 8 * k;
-      if (gc < n) Pcol[I * n + gc] = pcol[k];
+      if (gc < n) Pcol[I * n + gc] = w1;
     }
   }
   // row sums: reduce over the 8 column groups through LDS, fixed order

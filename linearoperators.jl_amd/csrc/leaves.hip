@@ -202,11 +202,8 @@ static int32_t householder_t(mxlo_ctx *ctx, T *res, const T *h, const T *v, int6
                              double alpha, double beta, int32_t flags) {
   double *dot = ctx->scalars;  // slot 0
   const T *cols[1] = {h};
-  ctx->plain_tail_bytes = ctx->tune.house_reverse ? ctx->tune.house_mall_tail_bytes : 0;
-  int32_t st = panel_dots<T>(ctx, cols, 1, v, n, dot);  // phase A (+ all-reduce hook)
-  if (st == MXLO_OK) st = householder_apply_t<T>(ctx, res, h, v, n, alpha, beta, flags, dot);  // phase B
-  ctx->plain_tail_bytes = 0;
-  return st;
+  MXLO_TRY(panel_dots<T>(ctx, cols, 1, v, n, dot));  // phase A (+ all-reduce hook)
+  return householder_apply_t<T>(ctx, res, h, v, n, alpha, beta, flags, dot);  // phase B
 }
 
 MXLO_API int32_t mxlo_dot(mxlo_ctx *ctx, int32_t dtype, const void *a, const void *b, int64_t n,

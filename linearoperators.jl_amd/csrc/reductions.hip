@@ -26,7 +26,7 @@ __device__ __forceinline__ double wave_sum(double v) {
 template <typename T, int VEC, int NC, int UNROLL, bool XVEC, bool NT>
 __global__ void __launch_bounds__(kBlock)
 panel_dots_kernel(ColPtrs<T, NC> cols, const T *__restrict__ x, int64_t head, int64_t nvec,
-                  int64_t n, double *__restrict__ partials, int64_t plain_chunks) {
+                  int64_t n, double *__restrict__ partials) {
   using V = typename std::conditional<VEC == 1, T, typename Vec16<T>::type>::type;
   const int tid = threadIdx.x;
   double acc[NC];
@@ -35,12 +35,11 @@ panel_dots_kernel(ColPtrs<T, NC> cols, const T *__restrict__ x, int64_t head, in
 
   constexpr int64_t CHUNK = (int64_t)kBlock * UNROLL;
   const int64_t nchunks = (nvec + CHUNK - 1) / CHUNK;
-  bool plain = false;  // wave-uniform, set per chunk: default-policy loads for the trailing chunks
   auto load_x = [&](int64_t i, T (&xe)[VEC]) {
     if constexpr (VEC == 1) {
       xe[0] = x[head + i];
     } else if constexpr (XVEC) {
-      const V xv = (NT && !plain) ? __builtin_nontemporal_load(reinterpret_cast<const V *>(x + head + i * VEC))
+      const V xv = NT ? __builtin_nontemporal_load(reinterpret_cast<const V *>(x + head + i * VEC))
                                   : *reinterpret_cast<const V *>(x + head + i * VEC);
 #pragma unroll
       for (int e = 0; e < VEC; ++e) xe[e] = xv[e];
@@ -50,7 +49,7 @@ panel_dots_kernel(ColPtrs<T, NC> cols, const T *__restrict__ x, int64_t head, in
     }
   };
   auto load_c = [&](int c, int64_t i) -> V {
-    return (NT && !plain) ? __builtin_nontemporal_load(reinterpret_cast<const V *>(cols.p[c] + head + i * VEC))
+    return NT ? __builtin_nontemporal_load(reinterpret_cast<const V *>(cols.p[c] + head + i * VEC))
                           : *reinterpret_cast<const V *>(cols.p[c] + head + i * VEC);
   };
   auto accumulate = [&](const V (&cv)[NC], const T (&xe)[VEC]) {
@@ -67,7 +66,6 @@ panel_dots_kernel(ColPtrs<T, NC> cols, const T *__restrict__ x, int64_t head, in
   };
   for (int64_t ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
     const int64_t base = ch * CHUNK + tid;
-    plain = ch >= nchunks - plain_chunks;
     if (base + (int64_t)(UNROLL - 1) * kBlock < nvec) {
       // whole chunk in range: issue every load of the chunk before the first FMA
       T xe[UNROLL][VEC];
@@ -162,12 +160,10 @@ static int32_t launch_dots(mxlo_ctx *ctx, const T *const *cols, const T *x, int6
   const bool nt = (int64_t)sizeof(T) * n * (NC + 1) >= ctx->tune.nt_min_bytes;
   if (nt)
     hipLaunchKernelGGL((panel_dots_kernel<T, VEC, NC, UNROLL, XVEC, true>), dim3(grid), dim3(kBlock), 0,
-                       ctx->stream, cp, x, head, nvec, n, ctx->partials,
-                       ctx->plain_tail_bytes / (16 * (int64_t)kBlock * UNROLL));
+                       ctx->stream, cp, x, head, nvec, n, ctx->partials);
   else
     hipLaunchKernelGGL((panel_dots_kernel<T, VEC, NC, UNROLL, XVEC, false>), dim3(grid), dim3(kBlock), 0,
-                       ctx->stream, cp, x, head, nvec, n, ctx->partials,
-                       ctx->plain_tail_bytes / (16 * (int64_t)kBlock * UNROLL));
+                       ctx->stream, cp, x, head, nvec, n, ctx->partials);
   MXLO_LAUNCH_CHECK();
   *nblocks_out = grid;
   return MXLO_OK;

@@ -24,13 +24,6 @@ __device__ __forceinline__ V ldg(const V *p) {
   if constexpr (NT) return __builtin_nontemporal_load(p);
   else return *p;
 }
-// per-chunk choice (wave-uniform): `plain` chunks use default-policy loads even in an NT kernel, so
-// that they stay resident in the 256 MiB Infinity Cache for a following pass (Householder tail reuse)
-template <bool NT, typename V>
-__device__ __forceinline__ V ldg_sel(const V *p, bool plain) {
-  if constexpr (NT) return plain ? *p : __builtin_nontemporal_load(p);
-  else return *p;
-}
 template <bool NT, typename V>
 __device__ __forceinline__ void stg(V *p, V v) {
   if constexpr (NT) __builtin_nontemporal_store(v, p);
@@ -68,7 +61,7 @@ __device__ __forceinline__ void vset(typename VecOf<T, VEC>::type &v, int i, T x
 template <typename T, int VEC, int UNROLL, int NIN, bool READ_RES, bool REVERSE, bool NT, typename Op>
 __global__ void __launch_bounds__(kBlock)
 map_kernel(T *__restrict__ res, const T *__restrict__ in0, const T *__restrict__ in1, int64_t head,
-           int64_t nvec, int64_t n, Op op, int64_t plain_chunks) {
+           int64_t nvec, int64_t n, Op op) {
   using V = typename VecOf<T, VEC>::type;
   op.init();
   const int tid = threadIdx.x;
@@ -79,15 +72,14 @@ map_kernel(T *__restrict__ res, const T *__restrict__ in0, const T *__restrict__
   const int64_t nchunks = (nvec + CHUNK - 1) / CHUNK;
   for (int64_t ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
     const int64_t c = REVERSE ? (nchunks - 1 - ch) : ch;
-    const bool plain = c >= nchunks - plain_chunks;
     const int64_t base = c * CHUNK + tid;
     V a[UNROLL], b[UNROLL], r[UNROLL];
     if (base + (int64_t)(UNROLL - 1) * kBlock < nvec) {
 #pragma unroll
       for (int u = 0; u < UNROLL; ++u) {
         const int64_t i = base + (int64_t)u * kBlock;
-        if constexpr (NIN >= 1) a[u] = ldg_sel<NT>(av + i, plain);
-        if constexpr (NIN >= 2) b[u] = ldg_sel<NT>(bv + i, plain);
+        if constexpr (NIN >= 1) a[u] = ldg<NT>(av + i);
+        if constexpr (NIN >= 2) b[u] = ldg<NT>(bv + i);
         if constexpr (READ_RES) r[u] = ldg<NT>(rv + i);
       }
 #pragma unroll
@@ -152,8 +144,6 @@ int32_t launch_map(mxlo_ctx *ctx, T *res, const T *in0, const T *in1, int64_t n,
   const int64_t head0 = common_head<T>({res, NIN >= 1 ? in0 : nullptr, NIN >= 2 ? in1 : nullptr});
   const int64_t streamed = (int64_t)sizeof(T) * n * (1 + NIN + (READ_RES ? 1 : 0));
   const bool nt = streamed >= ctx->tune.nt_min_bytes;
-  // trailing chunks (in memory order) read with default-policy loads: ctx->plain_tail_bytes per operand
-  const int64_t plain_chunks = ctx->plain_tail_bytes / (16 * (int64_t)kBlock * kStreamUnroll);
   auto grid_of = [&](int64_t items) {
     const int64_t need = (items + (int64_t)kBlock * kStreamUnroll - 1) / ((int64_t)kBlock * kStreamUnroll);
     int64_t g = need;
@@ -170,14 +160,14 @@ int32_t launch_map(mxlo_ctx *ctx, T *res, const T *in0, const T *in1, int64_t n,
     const int grid = grid_of(nvec);
     if (nt)
       hipLaunchKernelGGL((map_kernel<T, VEC, kStreamUnroll, NIN, READ_RES, REVERSE, true, Op>), dim3(grid),
-                         dim3(kBlock), 0, ctx->stream, res, in0, in1, head, nvec, n, op, plain_chunks);
+                         dim3(kBlock), 0, ctx->stream, res, in0, in1, head, nvec, n, op);
     else
       hipLaunchKernelGGL((map_kernel<T, VEC, kStreamUnroll, NIN, READ_RES, REVERSE, false, Op>), dim3(grid),
-                         dim3(kBlock), 0, ctx->stream, res, in0, in1, head, nvec, n, op, plain_chunks);
+                         dim3(kBlock), 0, ctx->stream, res, in0, in1, head, nvec, n, op);
   } else {
     const int grid = grid_of(n);
     hipLaunchKernelGGL((map_kernel<T, 1, kStreamUnroll, NIN, READ_RES, REVERSE, false, Op>), dim3(grid),
-                       dim3(kBlock), 0, ctx->stream, res, in0, in1, (int64_t)0, n, n, op, (int64_t)0);
+                       dim3(kBlock), 0, ctx->stream, res, in0, in1, (int64_t)0, n, n, op);
   }
   MXLO_LAUNCH_CHECK();
   return MXLO_OK;

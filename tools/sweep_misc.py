@@ -36,12 +36,6 @@ h /= torch.linalg.vector_norm(h)
 v = torch.rand(n, dtype=torch.float64, device=dev, generator=gen) * 2 - 1
 res = torch.empty_like(v)
 H = lo.opHouseholder(h)
-for rnd in range(2):
-    for mb in (0, 16, 32, 48, 64, 96, 128, 192):
-        ctx.tune("house_mall_tail_bytes", mb << 20)
-        mn, med = timeit(lambda: lo.mul(res, H, v, 1.0, 0.0))
-        print(f"householder n=1e8 mall_tail={mb:3d} MiB/operand: min {mn:.4f} ms ({40*n/mn/1e6:6.0f} GB/s)  median {med:.4f} ms ({40*n/med/1e6:6.0f} GB/s)", flush=True)
-ctx.tune("house_mall_tail_bytes", 0)
 for rev in (0, 1):
     ctx.tune("house_reverse", rev)
     mn, med = timeit(lambda: lo.mul(res, H, v, 1.0, 0.0))

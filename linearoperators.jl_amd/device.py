@@ -57,6 +57,8 @@ class Context:
         self._hook = None  # keep the CFUNCTYPE object alive
 
     def bind_stream(self):
+        # fast path: the (legacy) default stream has handle 0 and is what torch uses unless the caller
+        # entered a `torch.cuda.stream(...)` context
         s = torch.cuda.current_stream(self.index).cuda_stream
         if s != self._stream:
             _lib.call("mxlo_ctx_set_stream", self.handle, C.c_void_p(s))

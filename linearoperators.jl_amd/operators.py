@@ -64,18 +64,29 @@ def zero(dtype: torch.dtype):
     return np.float32(0) if dtype == torch.float32 else 0.0
 
 
+_NARGS_CACHE: dict = {}
+
+
 def _nargs(f: Callable) -> int:
-    """`hasmethod(op.prod!, (res, v, α, β))` stand-in (src/operations.jl:26): count positional params."""
+    """`hasmethod(op.prod!, (res, v, α, β))` stand-in (src/operations.jl:26): count positional params.
+    Cached per code object: the reference pays this reflection on every `mul!`, the mirror only once."""
+    code = getattr(f, "__code__", None)
+    key = code if code is not None else id(f)
+    n = _NARGS_CACHE.get(key)
+    if n is not None:
+        return n
     try:
         sig = inspect.signature(f)
+        n = 0
+        for p in sig.parameters.values():
+            if p.kind in (p.POSITIONAL_ONLY, p.POSITIONAL_OR_KEYWORD):
+                n += 1
+            elif p.kind == p.VAR_POSITIONAL:
+                n = 4
+                break
     except (TypeError, ValueError):
-        return 4
-    n = 0
-    for p in sig.parameters.values():
-        if p.kind in (p.POSITIONAL_ONLY, p.POSITIONAL_OR_KEYWORD):
-            n += 1
-        elif p.kind == p.VAR_POSITIONAL:
-            return 4
+        n = 4
+    _NARGS_CACHE[key] = n
     return n
 
 

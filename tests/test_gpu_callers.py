@@ -1,0 +1,133 @@
+"""-m gpu: the callers on either side of the path driving the operators the way Krylov.jl /
+JSOSolvers do — only through `mul!`, `push!`, `reset!`, `solve_shifted_system!`:
+  * conjugate gradients (3-arg and 5-arg `mul!`) on an SPD composite  H * D * H'  (test_linop.jl:346-358 shape);
+  * an L-BFGS minimisation loop  d = -(H*g); x += t d; push!(H, s, y)  on a convex quadratic;
+  * a trust-region-flavoured use of the forward operator with `solve_shifted_system!`.
+Also checks that the all-reduce hook aliases the library's device scalars (a doubling hook must double h'v)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def T(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def cg(lo, A, b, tol=1e-12, maxit=500):
+    """Textbook CG written against the operator API only (what Krylov.jl's cg does with mul!(y, A, x))."""
+    x = torch.zeros_like(b)
+    r = b.clone()
+    p = r.clone()
+    Ap = torch.empty_like(b)
+    rs = torch.dot(r, r)
+    for it in range(maxit):
+        lo.mul(Ap, A, p)                       # 3-arg mul!
+        alpha = rs / torch.dot(p, Ap)
+        x += alpha * p
+        lo.mul(r, A, p, -float(alpha), 1.0)    # r = r - alpha*A*p as ONE 5-arg mul!
+        rs_new = torch.dot(r, r)
+        if rs_new.sqrt() <= tol * torch.linalg.vector_norm(b):
+            return x, it + 1
+        p = r + (rs_new / rs) * p
+        rs = rs_new
+    return x, maxit
+
+
+def test_cg_on_composite_spd_operator(lo, dev):
+    rng = np.random.default_rng(0)
+    n = 2000
+    h = rng.standard_normal(n); h /= np.linalg.norm(h)
+    lam = np.linspace(1.0, 50.0, n)
+    H = lo.opHouseholder(T(h, dev))
+    A = H * lo.opDiagonal(T(lam, dev)) * H.H + 0.5 * lo.opEye(torch.float64, n, S=lo.Storage(torch.float64, dev))
+    Hd = np.eye(n) - 2 * np.outer(h, h)
+    Ad = Hd @ np.diag(lam) @ Hd.T + 0.5 * np.eye(n)
+    b = rng.standard_normal(n)
+    x, its = cg(lo, A, T(b, dev))
+    assert its < 200
+    assert np.linalg.norm(Ad @ x.cpu().numpy() - b) <= 1e-9 * np.linalg.norm(b)
+    assert lo.nprod(A) == 2 * its               # counters are bumped by the caller-facing mul!
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_lbfgs_minimisation_loop(lo, dev, dtype):
+    """min ½ xᵀQx − cᵀx with Q = blockdiag(diagonals) + low-rank, exact line search; the inverse operator
+    supplies directions, the forward one tracks the Hessian; both converge and stay consistent."""
+    rng = np.random.default_rng(1)
+    n, mem = 50_000, 8
+    npd = np.float64 if dtype == torch.float64 else np.float32
+    q = T(rng.uniform(1.0, 20.0, n).astype(npd), dev)
+    u = T((rng.standard_normal(n) / np.sqrt(n)).astype(npd), dev)
+    c = T(rng.standard_normal(n).astype(npd), dev)
+    Q = lo.opDiagonal(q) + 3.0 * lo.LinearOperatorFromMatrix(u.view(n, 1)) * lo.LinearOperatorFromMatrix(u.view(n, 1)).T
+    Hk = lo.InverseLBFGSOperator(dtype, n, mem=mem, device=dev)
+    Bk = lo.LBFGSOperator(dtype, n, mem=mem, device=dev)
+    x = torch.zeros(n, dtype=dtype, device=dev)
+    g = -c.clone()                               # gradient Qx - c at x = 0
+    d = torch.empty_like(x)
+    Qd = torch.empty_like(x)
+    g0 = float(torch.linalg.vector_norm(g))
+    for it in range(60):
+        lo.mul(d, Hk, g, -1.0, 0.0)              # d = -H g   (the JSOSolvers call shape)
+        lo.mul(Qd, Q, d)
+        t = -float(torch.dot(g, d)) / float(torch.dot(d, Qd))
+        s = t * d
+        y = t * Qd                                # y = Q s
+        x += s
+        g += y
+        lo.push(Hk, s, y)
+        lo.push(Bk, s, y)
+        if Bk._last_push_accepted:               # pairs with y's <= eps(T) are rejected (src/lbfgs.jl:281-284)
+            s_acc, y_acc = s.clone(), y.clone()
+        if float(torch.linalg.vector_norm(g)) <= (1e-10 if dtype == torch.float64 else 1e-4) * g0:
+            break
+    assert float(torch.linalg.vector_norm(g)) <= (1e-8 if dtype == torch.float64 else 1e-3) * g0, it
+    # secant equation on the most recent ACCEPTED pair: B s = y and H y = s
+    tol = 1e-8 if dtype == torch.float64 else 1e-3
+    s, y = s_acc, y_acc
+    assert float(torch.linalg.vector_norm(Bk * s - y) / torch.linalg.vector_norm(y)) <= tol
+    assert float(torch.linalg.vector_norm(Hk * y - s) / torch.linalg.vector_norm(s)) <= tol
+    # regularised Newton-like step through the forward operator: (B + σI) p = -g
+    p = lo.solve_shifted_system(torch.zeros_like(x), Bk, -g, 0.5)
+    resid = (Bk * p) + 0.5 * p + g
+    assert float(torch.linalg.vector_norm(resid)) <= (1e-8 if dtype == torch.float64 else 1e-2) * max(1e-30, float(torch.linalg.vector_norm(g)) + 1e-12) + (1e-12 if dtype == torch.float64 else 1e-5)
+    lo.reset(Hk)
+    assert torch.equal(Hk * c, c)                # back to the identity
+
+
+def test_allreduce_hook_aliases_device_scalars(lo, dev):
+    """A hook that DOUBLES the buffer in place must double h'v as seen by the update kernel: proves the
+    tensor handed to torch.distributed aliases the library's device memory (no copy)."""
+    rng = np.random.default_rng(2)
+    n = 4097
+    h = rng.standard_normal(n); h /= np.linalg.norm(h)
+    v = rng.uniform(-1, 1, n)
+    ctx = lo.get_ctx(dev)
+    seen = []
+
+    def hook(user, buf, count, stream):
+        t = lo.sharded.wrap_doubles(int(buf), int(count), cuda=True)
+        seen.append(float(t[0]))
+        t.mul_(2.0)
+        return 0
+
+    H = lo.opHouseholder(T(h, dev))
+    try:
+        ctx.set_allreduce(hook)
+        got = (H * T(v, dev)).cpu().numpy()
+    finally:
+        ctx.set_allreduce(None)
+    dot = float(h @ v)
+    assert abs(seen[0] - dot) <= 1e-12 * max(1.0, abs(dot))
+    want = v - 2 * (2 * dot) * h
+    assert np.linalg.norm(got - want) <= 1e-12 * np.linalg.norm(want)
+    # a failing hook surfaces as MXLO_EREDUCE, not as an exception crossing the ABI
+    try:
+        ctx.set_allreduce(lambda *a: 1)
+        with pytest.raises(lo.MxloError) as e:
+            H * T(v, dev)
+        assert e.value.status == lo._lib.EREDUCE
+    finally:
+        ctx.set_allreduce(None)

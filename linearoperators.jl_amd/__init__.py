@@ -19,7 +19,7 @@ from .operators import (AbstractLinearOperator, AdjointLinearOperator, Conjugate
                         compose, conj, eltype, has_args5, hcat, hvcat, isallocated5, ishermitian, issymmetric, mul,
                         nctprod, neg, nprod, ntprod, one, reset, scale_op, size, storage_type, to_dense, transpose,
                         vcat, zero)
-from .leaves import (BlockDiagonalOperator, LinearOperatorFromMatrix, jrange, kron, opDiagonal, opExtension, opEye,
+from .leaves import (BlockDiagonalOperator, LinearOperatorFromMatrix, ShiftedOperator, jrange, kron, opDiagonal, opExtension, opEye,
                      opHermitian, opHouseholder, opOnes, opRestriction, opZeros)
 
 Matrix = to_dense

@@ -427,3 +427,58 @@ def kron(A, B):
     ctprod = lambda res, x, a, b: km(res, x, a, b, At, Bt)
     return LinearOperator(T, m * p, n * q, Asym and Bsym, Aherm and Bherm, prod, tprod, ctprod,
                           S=Storage(T, Am.device))
+
+
+# ----------------------------------------------------------------------------- ShiftedOperator
+class _ShiftedData:
+    """ShiftedData{T, OpH} — src/shifted_operators.jl:4-13 (σ is mutable, like the reference)."""
+
+    def __init__(self, H, sigma):
+        if H.size(1) != H.size(2):
+            raise ValueError("Operator H must be square.")           # DimensionMismatch (:8)
+        self.H, self.sigma = H, sigma
+
+    @property
+    def σ(self):
+        return self.sigma
+
+
+class ShiftedOperatorType(AbstractLinearOperator):
+    """`ShiftedOperator(H, σ)` = H + σI — src/shifted_operators.jl:56-103. Its products are the inner
+    operator's `mul!` followed by one `axpy!(α σ, x, y)` (:16-25), here `mxlo_eye_mul` with β = 1."""
+    _has_args5 = True                                                  # has_args5 / isallocated5 (:92-94)
+
+    def __init__(self, H, sigma=0):
+        self.eltype = H.eltype
+        T = self.eltype
+        sigma = (np.float32(sigma) if T == torch.float32 else float(sigma))   # convert(T, σ_in) (:73)
+        self.data = _ShiftedData(H, sigma)
+        self.nrow = self.ncol = H.size(1)
+        self.symmetric = issymmetric(H)
+        self.nprod = self.ntprod = self.nctprod = 0
+        data = self.data
+
+        def shifted(y, x, a, b, op):
+            mul(y, op, x, a, b)                                        # y = α H x + β y        (:18)
+            if not (data.sigma == 0 or a == 0):                        # (:21)
+                ctx = get_ctx(y.device)
+                c = a * data.sigma
+                _lib.call("mxlo_eye_mul", ctx.handle, dtype_code(y.dtype), ptr(y), ptr(x), y.numel(), y.numel(),
+                          float(c), 1.0, scalar_flags(y.dtype, c, 1))  # y = y + (α σ) x        (:22)
+            return y
+
+        self.prod = lambda y, x, a, b: shifted(y, x, a, b, data.H)
+        self.tprod = lambda y, x, a, b: shifted(y, x, a, b, transpose(data.H))
+        self.ctprod = lambda y, x, a, b: shifted(y, x, a, b, adjoint(data.H))
+
+    @property
+    def hermitian(self):                                               # ishermitian(H) && isreal(σ) (:83,89)
+        return ishermitian(self.data.H)
+
+    @property
+    def S(self):                                                       # storage_type(op.data.H) (:96)
+        return storage_type(self.data.H)
+
+
+def ShiftedOperator(H, sigma=0):
+    return ShiftedOperatorType(H, sigma)

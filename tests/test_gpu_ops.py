@@ -275,3 +275,53 @@ def test_kron_abi_transpose_mode(lo, dev):
                       Bd.stride(1), ptr(T(x, dev)), ptr(work), 2.0, 3.0, mode, 0)
             assert rel(res.cpu().numpy(), 2.0 * (K.T @ x) + 3.0 * r0) <= 1e-12
             assert rel(res.cpu().numpy(), oracle.kron_mul(r0.copy(), A, B, x, 2.0, 3.0, trans=True)) <= 1e-12
+
+
+def test_shifted_operator(lo, dev):
+    """src/shifted_operators.jl: (H + σI) x through the inner operator's mul! + one axpy; σ is mutable;
+    works over leaves, quasi-Newton operators and composites; transpose/adjoint; counters; reset!."""
+    rng = np.random.default_rng(21)
+    n = 300
+    A = rng.standard_normal((n, n))
+    opA = lo.LinearOperatorFromMatrix(TM(A, dev))
+    Sh = lo.ShiftedOperator(opA, 0.75)
+    x, r0 = rng.standard_normal(n), rng.standard_normal(n)
+    assert rel((Sh * T(x, dev)).cpu().numpy(), A @ x + 0.75 * x) <= 1e-13
+    assert rel((Sh.T * T(x, dev)).cpu().numpy(), A.T @ x + 0.75 * x) <= 1e-13
+    assert rel((Sh.H * T(x, dev)).cpu().numpy(), A.T @ x + 0.75 * x) <= 1e-13
+    res = T(r0.copy(), dev)
+    lo.mul(res, Sh, T(x, dev), 2.0, -3.0)
+    assert rel(res.cpu().numpy(), 2.0 * (A @ x + 0.75 * x) - 3.0 * r0) <= 1e-13
+    Sh.data.sigma = 0.0                                    # σ == 0: the axpy is skipped (:21)
+    assert rel((Sh * T(x, dev)).cpu().numpy(), A @ x) <= 1e-13
+    assert not lo.issymmetric(Sh) and lo.has_args5(Sh) and lo.isallocated5(Sh)
+    assert lo.nprod(Sh) == 3 and lo.ntprod(Sh) == 1 and lo.nctprod(Sh) == 1
+    lo.reset(Sh)
+    assert lo.nprod(Sh) == 0
+    with pytest.raises(ValueError):
+        lo.ShiftedOperator(lo.LinearOperatorFromMatrix(TM(A[:, :5], dev)), 1.0)
+    # over a forward L-BFGS operator: (B + σI) p = b is what solve_shifted_system! inverts
+    B = lo.LBFGSOperator(n, mem=5, device=dev)
+    for _ in range(7):
+        s = rng.uniform(-1, 1, n)
+        y = s * rng.uniform(0.5, 2.0, n)
+        lo.push(B, T(s, dev), T(y, dev))
+    Bs = lo.ShiftedOperator(B, 0.3)
+    assert lo.issymmetric(Bs) and lo.ishermitian(Bs)
+    p = lo.solve_shifted_system(torch.zeros(n, dtype=torch.float64, device=dev), B, Bs * T(x, dev), 0.3)
+    assert rel(p.cpu().numpy(), x) <= 1e-9
+
+
+def test_callable_functor(lo, dev):
+    """test/test_callable.jl:1-21: a functor as prod! — `Flip` computes res = (-α) x (+ β res)."""
+    class Flip:
+        def __call__(self, res, x, alpha, beta):
+            lo.leaves.mulOpEye(res, x, -alpha, beta, res.numel())
+
+    S = lo.Storage(torch.float64, dev)
+    op = lo.LinearOperator(torch.float64, 2, 2, True, True, Flip(), None, None, S=S)
+    one = torch.ones(2, dtype=torch.float64, device=dev)
+    assert torch.equal(op * one, -one) and torch.equal(op.H * one, -one) and torch.equal(op.T * one, -one)
+    Mv = torch.ones(2, dtype=torch.float64, device=dev)
+    lo.mul(Mv, op, one)
+    assert torch.equal(Mv, -one) and lo.has_args5(op)

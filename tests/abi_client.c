@@ -1,0 +1,160 @@
+/* abi_client.c — a plain-C client of include/mxlo.h (no Python, no torch): what a foreign-language glue
+ * (Julia `ccall`) does. Built and run by tests/test_gpu_abi_client.py on the GPU box:
+ *   gcc -std=c99 tests/abi_client.c -Iinclude -Llinearoperators.jl_amd/csrc -lmxlo -lm
+ * Checks opDiagonal (bit-exact), opHouseholder (1e-12), restriction (bit-exact), an InverseLBFGS
+ * push!/mul! round against an in-file statement-by-statement two-loop, and error codes. */
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "mxlo.h"
+
+#define CK(call)                                                                          \
+  do {                                                                                    \
+    int32_t st__ = (call);                                                                \
+    if (st__ != MXLO_OK) {                                                                \
+      printf("FAIL %s -> %d (%s)\n", #call, st__, mxlo_last_error());                     \
+      return 1;                                                                           \
+    }                                                                                     \
+  } while (0)
+
+static double urand(unsigned long long *s) { /* splitmix64 -> [0,1) */
+  unsigned long long z = (*s += 0x9E3779B97F4A7C15ULL);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+  z ^= z >> 31;
+  return (double)(z >> 11) * (1.0 / 9007199254740992.0);
+}
+
+static void *dev_from(mxlo_ctx *ctx, const void *h, size_t bytes) {
+  void *p = NULL;
+  if (mxlo_malloc(ctx, (int64_t)bytes, &p) != MXLO_OK) return NULL;
+  if (h && mxlo_memcpy_h2d(ctx, p, h, (int64_t)bytes) != MXLO_OK) return NULL;
+  return p;
+}
+
+int main(void) {
+  const int64_t n = 100003;
+  unsigned long long seed = 42;
+  mxlo_ctx *ctx = NULL;
+  CK(mxlo_ctx_create(0, NULL, &ctx));
+  printf("%s\n", mxlo_version());
+
+  double *d = malloc(n * 8), *v = malloc(n * 8), *r0 = malloc(n * 8), *out = malloc(n * 8), *ref = malloc(n * 8);
+  double nrm = 0;
+  for (int64_t i = 0; i < n; ++i) {
+    d[i] = urand(&seed) - 0.5;
+    v[i] = 2 * urand(&seed) - 1;
+    r0[i] = 2 * urand(&seed) - 1;
+    nrm += d[i] * d[i];
+  }
+  nrm = sqrt(nrm);
+  void *dd = dev_from(ctx, d, n * 8), *dv = dev_from(ctx, v, n * 8), *dr = dev_from(ctx, r0, n * 8);
+  if (!dd || !dv || !dr) return 1;
+
+  /* opDiagonal 5-arg mul!: bit-exact vs (alpha*d)*v + beta*res */
+  const double alpha = 2.0 / 3.0, beta = -0.3;
+  CK(mxlo_diag_mul(ctx, MXLO_F64, dr, dd, dv, n, n, alpha, beta, 0));
+  CK(mxlo_memcpy_d2h(ctx, out, dr, n * 8));
+  for (int64_t i = 0; i < n; ++i) {
+    volatile double t1 = alpha * d[i];
+    volatile double t2 = t1 * v[i];
+    volatile double t3 = beta * r0[i];
+    ref[i] = t2 + t3;
+  }
+  if (memcmp(out, ref, n * 8) != 0) { printf("FAIL diag not bit-exact\n"); return 1; }
+
+  /* opHouseholder: h = d/||d|| */
+  for (int64_t i = 0; i < n; ++i) d[i] /= nrm;
+  CK(mxlo_memcpy_h2d(ctx, dd, d, n * 8));
+  CK(mxlo_householder_mul(ctx, MXLO_F64, dr, dd, dv, n, 1.0, 0.0, 0));
+  CK(mxlo_memcpy_d2h(ctx, out, dr, n * 8));
+  double dot = 0, err = 0, rn = 0;
+  for (int64_t i = 0; i < n; ++i) dot += d[i] * v[i];
+  for (int64_t i = 0; i < n; ++i) {
+    const double want = v[i] - (2 * dot) * d[i];
+    err += (out[i] - want) * (out[i] - want);
+    rn += want * want;
+  }
+  if (sqrt(err / rn) > 1e-12) { printf("FAIL householder %.3e\n", sqrt(err / rn)); return 1; }
+
+  /* opRestriction 1:2:n (range form) and its adjoint */
+  const int64_t len = (n + 1) / 2;
+  void *dw = dev_from(ctx, NULL, len * 8);
+  CK(mxlo_gather_range(ctx, 8, dw, dv, n, 1, 2, len));
+  CK(mxlo_memcpy_d2h(ctx, out, dw, len * 8));
+  for (int64_t k = 0; k < len; ++k)
+    if (out[k] != v[2 * k]) { printf("FAIL gather_range\n"); return 1; }
+  CK(mxlo_scatter_zero_range(ctx, 8, dr, n, dw, 1, 2, len));
+  CK(mxlo_memcpy_d2h(ctx, out, dr, n * 8));
+  for (int64_t i = 0; i < n; ++i)
+    if (out[i] != ((i % 2 == 0) ? v[i] : 0.0)) { printf("FAIL scatter_zero_range\n"); return 1; }
+
+  /* InverseLBFGSOperator: push 7 pairs into mem = 5, then d = -(H*g) in both evaluation modes */
+  enum { MEM = 5, NP = 7 };
+  const int64_t m = 4099;
+  mxlo_qn *H = NULL;
+  CK(mxlo_qn_create(ctx, MXLO_QN_LBFGS_INV, MXLO_F64, m, MEM, 1, 0, 0.99, 10.0, &H));
+  static double S[NP][4099], Y[NP][4099], g[4099], q[4099], al[NP];
+  void *ds = dev_from(ctx, NULL, m * 8), *dy = dev_from(ctx, NULL, m * 8), *dg = dev_from(ctx, NULL, m * 8),
+       *dres = dev_from(ctx, NULL, m * 8);
+  double ys[NP], gamma = 1.0;
+  for (int p = 0; p < NP; ++p) {
+    ys[p] = 0;
+    double yy = 0;
+    for (int64_t i = 0; i < m; ++i) {
+      S[p][i] = 2 * urand(&seed) - 1;
+      Y[p][i] = S[p][i] * (0.5 + 1.5 * urand(&seed));
+      ys[p] += Y[p][i] * S[p][i];
+      yy += Y[p][i] * Y[p][i];
+    }
+    gamma = ys[p] / yy;
+    CK(mxlo_memcpy_h2d(ctx, ds, S[p], m * 8));
+    CK(mxlo_memcpy_h2d(ctx, dy, Y[p], m * 8));
+    int32_t acc = 0;
+    CK(mxlo_qn_push(H, ds, dy, &acc));
+    if (!acc) { printf("FAIL push rejected\n"); return 1; }
+  }
+  double sc[5];
+  CK(mxlo_qn_get_scalars(H, sc, NULL, NULL));
+  if ((int)sc[0] != NP % MEM + 1 || fabs(sc[1] - gamma) > 1e-12 * gamma) { printf("FAIL scalars\n"); return 1; }
+  for (int64_t i = 0; i < m; ++i) g[i] = 2 * urand(&seed) - 1;
+  CK(mxlo_memcpy_h2d(ctx, dg, g, m * 8));
+  /* reference two-loop (src/lbfgs.jl:127-153) over the last MEM pairs, newest first */
+  memcpy(q, g, m * 8);
+  for (int p = NP - 1; p >= NP - MEM; --p) {
+    double sq = 0;
+    for (int64_t i = 0; i < m; ++i) sq += S[p][i] * q[i];
+    al[p] = sq / ys[p];
+    for (int64_t i = 0; i < m; ++i) q[i] -= al[p] * Y[p][i];
+  }
+  for (int64_t i = 0; i < m; ++i) q[i] *= gamma;
+  for (int p = NP - MEM; p < NP; ++p) {
+    double yq = 0;
+    for (int64_t i = 0; i < m; ++i) yq += Y[p][i] * q[i];
+    const double b = al[p] - yq / ys[p];
+    for (int64_t i = 0; i < m; ++i) q[i] += b * S[p][i];
+  }
+  for (int mode = 0; mode < 2; ++mode) {
+    CK(mxlo_qn_set_mode(H, mode));
+    CK(mxlo_qn_mul(H, dres, dg, -1.0, 0.0, 0));
+    CK(mxlo_memcpy_d2h(ctx, out, dres, m * 8));
+    err = rn = 0;
+    for (int64_t i = 0; i < m; ++i) {
+      err += (out[i] + q[i]) * (out[i] + q[i]);
+      rn += q[i] * q[i];
+    }
+    if (sqrt(err / rn) > 1e-10) { printf("FAIL lbfgs mode %d: %.3e\n", mode, sqrt(err / rn)); return 1; }
+  }
+  /* error conventions: codes, never exceptions */
+  if (mxlo_qn_solve_shifted(H, dres, dg, 0.1) != MXLO_ESTATE) { printf("FAIL expected ESTATE\n"); return 1; }
+  if (mxlo_diag_mul(ctx, MXLO_F64, dr, dd, dv, n + 1, n, 1.0, 0.0, 0) != MXLO_ESHAPE) { printf("FAIL expected ESHAPE\n"); return 1; }
+  CK(mxlo_qn_destroy(H));
+  CK(mxlo_ctx_sync(ctx));
+  CK(mxlo_free(ctx, dd)); CK(mxlo_free(ctx, dv)); CK(mxlo_free(ctx, dr)); CK(mxlo_free(ctx, dw));
+  CK(mxlo_free(ctx, ds)); CK(mxlo_free(ctx, dy)); CK(mxlo_free(ctx, dg)); CK(mxlo_free(ctx, dres));
+  CK(mxlo_ctx_destroy(ctx));
+  printf("ABI CLIENT OK\n");
+  return 0;
+}

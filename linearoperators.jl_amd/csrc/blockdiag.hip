@@ -30,10 +30,11 @@ struct DevBlock {
   int64_t ld;
 };
 
-struct Tile {
-  int32_t blk, pad;
-  int64_t start;  // first output row of this tile inside its block
-};
+struct Tile {        // 64 bytes, self-contained: ONE wave-uniform load per workgroup, no dependent
+  DevBlock b;        // descriptor fetch before the streaming loads can start
+  int64_t start;     // first output row of this tile inside its block
+  int64_t cnt;       // outputs in this tile (elementwise tiles end on GLOBAL multiples of kTileE so that,
+};                   // after the first short tile of a block, every tile is 16 KiB-aligned in res)
 
 template <typename T, int VEC, bool NT>
 __device__ __forceinline__ void load_vec(const T *p, bool aligned, T (&out)[VEC]) {
@@ -62,13 +63,87 @@ __device__ __forceinline__ T ew_op(int kind, CT a, CT b, T d, T v, T r) {
   return (T)t;
 }
 
+// One elementwise tile of a block of compile-time KIND (no per-load kind / alignment branches in the
+// all-aligned fast path, so the compiler can issue every load of the tile back to back).
+template <typename T, typename CT, bool BETA0, bool NT, int KIND>
+__device__ __forceinline__ void ew_tile(T *__restrict__ r0, const T *__restrict__ x0, const T *__restrict__ d0,
+                                        int64_t cnt, int64_t tile_start, int64_t nmin, CT alpha, CT beta) {
+  constexpr int VEC = Vec16<T>::N;
+  using V = typename VecOf<T, VEC>::type;
+  const int tid = threadIdx.x;
+  // peel so stores are 16-byte aligned
+  int64_t head = (int64_t)(((16 - ((uintptr_t)r0 & 15u)) & 15u) / sizeof(T));
+  if (head > cnt) head = cnt;
+  const bool fast = (tile_start + cnt <= nmin);   // whole tile inside the diagonal part
+  if (fast) {
+    const int64_t nv = (cnt - head) / VEC;
+    const bool xa = KIND == MXLO_BLK_ZEROS || (((uintptr_t)(x0 + head)) & 15u) == 0;
+    const bool da = KIND != MXLO_BLK_DIAG || (((uintptr_t)(d0 + head)) & 15u) == 0;
+    constexpr int U = kTileE / VEC / kBlock;
+    T dv[U][VEC], xv[U][VEC], rv[U][VEC];
+    if (xa && da) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int64_t i = tid + (int64_t)u * kBlock;
+        if (i < nv) {
+          const int64_t o = head + i * VEC;
+          if constexpr (KIND == MXLO_BLK_DIAG) load_vec<T, VEC, NT>(d0 + o, true, dv[u]);
+          if constexpr (KIND != MXLO_BLK_ZEROS) load_vec<T, VEC, NT>(x0 + o, true, xv[u]);
+          if constexpr (!BETA0) load_vec<T, VEC, NT>(r0 + o, true, rv[u]);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int64_t i = tid + (int64_t)u * kBlock;
+        if (i < nv) {
+          const int64_t o = head + i * VEC;
+          if constexpr (KIND == MXLO_BLK_DIAG) load_vec<T, VEC, NT>(d0 + o, da, dv[u]);
+          if constexpr (KIND != MXLO_BLK_ZEROS) load_vec<T, VEC, NT>(x0 + o, xa, xv[u]);
+          if constexpr (!BETA0) load_vec<T, VEC, NT>(r0 + o, true, rv[u]);
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t i = tid + (int64_t)u * kBlock;
+      if (i < nv) {
+        const int64_t o = head + i * VEC;
+        V out;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e)
+          out[e] = ew_op<T, CT, BETA0>(KIND, alpha, beta, KIND == MXLO_BLK_DIAG ? dv[u][e] : T(0),
+                                       KIND != MXLO_BLK_ZEROS ? xv[u][e] : T(0), BETA0 ? T(0) : rv[u][e]);
+        stg<NT>(reinterpret_cast<V *>(r0 + o), out);
+      }
+    }
+    const int64_t tail0 = head + nv * VEC;
+    const int64_t nsc = head + (cnt - tail0);
+    if (tid < nsc) {
+      const int64_t o = tid < head ? tid : tail0 + (tid - head);
+      r0[o] = ew_op<T, CT, BETA0>(KIND, alpha, beta, KIND == MXLO_BLK_DIAG ? d0[o] : T(0),
+                                  KIND != MXLO_BLK_ZEROS ? x0[o] : T(0), BETA0 ? T(0) : r0[o]);
+    }
+  } else {
+    for (int64_t o = tid; o < cnt; o += kBlock) {
+      const int64_t g = tile_start + o;
+      if (g < nmin) {
+        r0[o] = ew_op<T, CT, BETA0>(KIND, alpha, beta, KIND == MXLO_BLK_DIAG ? d0[o] : T(0),
+                                    KIND != MXLO_BLK_ZEROS ? x0[o] : T(0), BETA0 ? T(0) : r0[o]);
+      } else {  // rectangular eye tail: 0 when β == 0 else β itself (special-operators.jl:39,42)
+        r0[o] = BETA0 ? (T)0 : (T)beta;
+      }
+    }
+  }
+}
+
 template <typename T, typename CT, bool BETA0, bool TRANS, bool NT>
 __global__ void __launch_bounds__(kBlock)
 blockdiag_kernel(T *__restrict__ res, const T *__restrict__ x, const DevBlock *__restrict__ blocks,
                  const Tile *__restrict__ tiles, CT alpha, CT beta) {
-  constexpr int VEC = Vec16<T>::N;
   const Tile tl = tiles[blockIdx.x];
-  const DevBlock b = blocks[tl.blk];
+  const DevBlock b = tl.b;
+  (void)blocks;
   const int tid = threadIdx.x;
   // in T mode the roles of (row_off, m) and (col_off, n) swap
   const int64_t out_off = TRANS ? b.col_off : b.row_off;
@@ -80,66 +155,18 @@ blockdiag_kernel(T *__restrict__ res, const T *__restrict__ x, const DevBlock *_
   if (b.kind != MXLO_BLK_DENSE) {
     // elementwise tile [tl.start, tl.start + cnt). Rectangular eye/zeros: outputs beyond
     // min(m,n) of an eye block follow mulOpEye!'s tail rule (0 | β).
-    int64_t cnt = mo - tl.start;
-    if (cnt > kTileE) cnt = kTileE;
+    const int64_t cnt = tl.cnt;
     const int64_t nmin = b.kind == MXLO_BLK_ZEROS ? mo : (mo < ni ? mo : ni);
     const T *dp = (const T *)b.data;
     T *r0 = rp + tl.start;
     const T *x0 = xp + tl.start;
     const T *d0 = dp ? dp + tl.start : nullptr;
-    // peel so stores are 16-byte aligned
-    int64_t head = (int64_t)(((16 - ((uintptr_t)r0 & 15u)) & 15u) / sizeof(T));
-    if (head > cnt) head = cnt;
-    const bool fast = (tl.start + cnt <= nmin);   // whole tile inside the diagonal part
-    if (fast) {
-      const int64_t nv = (cnt - head) / VEC;
-      const bool xa = (((uintptr_t)(x0 + head)) & 15u) == 0;
-      const bool da = d0 ? ((((uintptr_t)(d0 + head)) & 15u) == 0) : true;
-      using V = typename VecOf<T, VEC>::type;
-      // every load of the tile is issued before the first store (U vectors per lane in flight)
-      constexpr int U = kTileE / VEC / kBlock;
-      T dv[U][VEC], xv[U][VEC], rv[U][VEC];
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int64_t i = tid + (int64_t)u * kBlock;
-        if (i < nv) {
-          const int64_t o = head + i * VEC;
-          if (b.kind == MXLO_BLK_DIAG) load_vec<T, VEC, NT>(d0 + o, da, dv[u]);
-          if (b.kind != MXLO_BLK_ZEROS) load_vec<T, VEC, NT>(x0 + o, xa, xv[u]);
-          if constexpr (!BETA0) load_vec<T, VEC, NT>(r0 + o, true, rv[u]);
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int64_t i = tid + (int64_t)u * kBlock;
-        if (i < nv) {
-          const int64_t o = head + i * VEC;
-          V out;
-#pragma unroll
-          for (int e = 0; e < VEC; ++e)
-            out[e] = ew_op<T, CT, BETA0>(b.kind, alpha, beta, b.kind == MXLO_BLK_DIAG ? dv[u][e] : T(0),
-                                         b.kind != MXLO_BLK_ZEROS ? xv[u][e] : T(0), BETA0 ? T(0) : rv[u][e]);
-          stg<NT>(reinterpret_cast<V *>(r0 + o), out);
-        }
-      }
-      const int64_t tail0 = head + nv * VEC;
-      const int64_t nsc = head + (cnt - tail0);
-      if (tid < nsc) {
-        const int64_t o = tid < head ? tid : tail0 + (tid - head);
-        r0[o] = ew_op<T, CT, BETA0>(b.kind, alpha, beta, b.kind == MXLO_BLK_DIAG ? d0[o] : T(0),
-                                    b.kind != MXLO_BLK_ZEROS ? x0[o] : T(0), BETA0 ? T(0) : r0[o]);
-      }
-    } else {
-      for (int64_t o = tid; o < cnt; o += kBlock) {
-        const int64_t g = tl.start + o;
-        if (g < nmin) {
-          r0[o] = ew_op<T, CT, BETA0>(b.kind, alpha, beta, b.kind == MXLO_BLK_DIAG ? d0[o] : T(0),
-                                      b.kind != MXLO_BLK_ZEROS ? x0[o] : T(0), BETA0 ? T(0) : r0[o]);
-        } else {  // rectangular eye tail: 0 when β == 0 else β itself (special-operators.jl:39,42)
-          r0[o] = BETA0 ? (T)0 : (T)beta;
-        }
-      }
-    }
+    if (b.kind == MXLO_BLK_DIAG)
+      ew_tile<T, CT, BETA0, NT, MXLO_BLK_DIAG>(r0, x0, d0, cnt, tl.start, nmin, alpha, beta);
+    else if (b.kind == MXLO_BLK_EYE)
+      ew_tile<T, CT, BETA0, NT, MXLO_BLK_EYE>(r0, x0, d0, cnt, tl.start, nmin, alpha, beta);
+    else
+      ew_tile<T, CT, BETA0, NT, MXLO_BLK_ZEROS>(r0, x0, d0, cnt, tl.start, nmin, alpha, beta);
     return;
   }
   // ---- dense block, column-major m x n with leading dimension ld
@@ -200,10 +227,23 @@ MXLO_API int32_t mxlo_blockdiag_create(mxlo_ctx *ctx, int32_t dtype, const mxlo_
     hb[k] = DevBlock{b.kind, 0, b.row_off, b.col_off, b.m, b.n, b.data, b.ld};
     nrow += b.m;
     ncol += b.n;
-    const int64_t step_n = b.kind == MXLO_BLK_DENSE ? kTileDN : kTileE;
-    const int64_t step_t = b.kind == MXLO_BLK_DENSE ? kTileDT : kTileE;
-    for (int64_t s = 0; s < b.m; s += step_n) tn.push_back(Tile{(int32_t)k, 0, s});
-    for (int64_t s = 0; s < b.n; s += step_t) tt.push_back(Tile{(int32_t)k, 0, s});
+    auto cut = [&](std::vector<Tile> &out, int64_t off, int64_t len, int64_t step) {
+      if (b.kind == MXLO_BLK_DENSE) {
+        for (int64_t s = 0; s < len; s += step) out.push_back(Tile{hb[k], s, len - s < step ? len - s : step});
+        return;
+      }
+      // elementwise: boundaries at global multiples of kTileE (res is normally >= 256-B aligned)
+      int64_t s = 0;
+      while (s < len) {
+        const int64_t g = off + s;
+        int64_t e = ((g / kTileE) + 1) * kTileE - off;
+        if (e > len) e = len;
+        out.push_back(Tile{hb[k], s, e - s});
+        s = e;
+      }
+    };
+    cut(tn, b.row_off, b.m, b.kind == MXLO_BLK_DENSE ? kTileDN : kTileE);
+    cut(tt, b.col_off, b.n, b.kind == MXLO_BLK_DENSE ? kTileDT : kTileE);
   }
   mxlo_blockdiag *bd = new mxlo_blockdiag();
   bd->ctx = ctx;

@@ -443,40 +443,40 @@ int32_t gemv_any(mxlo_ctx *ctx, T *res, const T *M, int64_t m, int64_t n, int64_
 }
 
 // ---- opHermitian, single pass over the strict lower triangle -------------------------------------
-// The triangle is cut into 64x64 tiles (I >= J); one workgroup per tile reads it ONCE (16-byte loads
-// down the columns) and produces both of its contributions:
-//   rows  : Prow[J][I*64 + r] = sum_c L[r][c] * v[J*64 + c]        (part of L*v)
-//   cols  : Pcol[I][J*64 + c] = sum_r L[r][c] * v[I*64 + r]        (part of L'*v)
+// The triangle is cut into panels of 256 rows x 32 columns (row group G, column tile J, J <= 8G+7); one
+// workgroup per panel reads it ONCE — a wave-load is 1 KiB contiguous down one column, a panel column is
+// 2 KiB contiguous — and produces both of its contributions:
+//   rows  : Prow[J][256G + r] = sum_c L[r][c] * v[32J + c]        (part of L*v)
+//   cols  : Pcol[G][32J + c]  = sum_r L[r][c] * v[256G + r]       (part of L'*v)
 // A second tiny kernel adds the partials in a FIXED order (deterministic, no float atomics) and applies
 //   res = alpha*((d.*v + L*v) + L'*v) (+ beta*res)                  (src/linalg.jl:99-101).
-// HBM traffic: 4n^2 B for the triangle + n^2/4 B of partials, vs 8n^2 for two triangular GEMVs and
+// HBM traffic: 4n^2 B for the triangle + ~0.3n^2 B of partials, vs 8n^2 for two triangular GEMVs and
 // 16n^2 for the reference (two full GEMVs over tril(A,-1) stored with explicit zeros).
-constexpr int HT = 64;
+constexpr int HR = 256, HC = 32;
 
 template <typename T, bool ALIGNED>
 __global__ void __launch_bounds__(kBlock)
-herm_tile_kernel(const T *__restrict__ A, int64_t lda, const T *__restrict__ v, int64_t n, int nb,
-                 double *__restrict__ Prow, double *__restrict__ Pcol) {
-  // tile index t -> (I, J) with t = I(I+1)/2 + J
+herm_panel_kernel(const T *__restrict__ A, int64_t lda, const T *__restrict__ v, int64_t n,
+                  double *__restrict__ Prow, double *__restrict__ Pcol) {
+  // panel index t -> (G, J) with t = 4G(G+1) + J, 0 <= J <= 8G+7
   const int64_t t = blockIdx.x;
-  int64_t I = (int64_t)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
-  while (I * (I + 1) / 2 > t) --I;
-  while ((I + 1) * (I + 2) / 2 <= t) ++I;
-  const int64_t J = t - I * (I + 1) / 2;
-  const int64_t i0 = I * HT, j0 = J * HT;
-  const int tid = threadIdx.x;
-  const int rp = tid & 31, cg = tid >> 5;        // rows 2rp, 2rp+1 ; columns cg + 8k
+  int64_t G = (int64_t)((sqrt(1.0 + (double)t) - 1.0) * 0.5);
+  while (4 * G * (G + 1) > t) --G;
+  while (4 * (G + 1) * (G + 2) <= t) ++G;
+  const int64_t J = t - 4 * G * (G + 1);
+  const int64_t i0 = G * HR, j0 = J * HC;
+  if (j0 >= n) return;                       // ragged last row group: tiles past the matrix
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int rp = tid & 127, cg = tid >> 7;   // rows 2rp, 2rp+1 of the panel; columns cg + 2k, k < 16
   const int64_t gr = i0 + 2 * rp;
   const double vr0 = gr < n ? (double)v[gr] : 0.0, vr1 = gr + 1 < n ? (double)v[gr + 1] : 0.0;
-  double prow0 = 0.0, prow1 = 0.0;
-  double pcol[8];
-  T e0[8], e1[8];
+  T e0[16], e1[16];
 #pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    const int64_t gc = j0 + cg + 8 * k;
+  for (int k = 0; k < 16; ++k) {
+    const int64_t gc = j0 + cg + 2 * k;
     e0[k] = 0;
     e1[k] = 0;
-    if (gc < n) {
+    if (gc < n && gr + 1 > gc) {             // at least the second row is strictly below the diagonal
       const T *p = A + gr + gc * lda;
       if constexpr (ALIGNED) {
         if (gr + 1 < n) {
@@ -491,85 +491,106 @@ herm_tile_kernel(const T *__restrict__ A, int64_t lda, const T *__restrict__ v, 
         if (gr < n) e0[k] = p[0];
         if (gr + 1 < n) e1[k] = p[1];
       }
-      // strict lower triangle only: keep L[r][c] with row > col
-      if (!(gr > gc)) e0[k] = 0;
-      if (!(gr + 1 > gc)) e1[k] = 0;
+      if (!(gr > gc)) e0[k] = 0;             // strict lower triangle only
     }
   }
+  double prow0 = 0.0, prow1 = 0.0;
+  double pcol[16];
 #pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    const int64_t gc = j0 + cg + 8 * k;
+  for (int k = 0; k < 16; ++k) {
+    const int64_t gc = j0 + cg + 2 * k;
     const double vc = gc < n ? (double)v[gc] : 0.0;
     prow0 = fma((double)e0[k], vc, prow0);
     prow1 = fma((double)e1[k], vc, prow1);
     pcol[k] = fma((double)e1[k], vr1, (double)e0[k] * vr0);
   }
-  // column sums over the 32 lanes that share cg (a half wave): halving butterfly — at each of the first
-  // three steps a lane hands half of its values to its partner, so 4+2+1 shuffles leave ONE value per lane
-  // (column k = bits 4,3,2 of the lane), then two plain steps finish the sum: 9 shuffles instead of 40.
+  // column sums over the 64 lanes of the wave: halving butterfly (8+4+2+1 shuffles leave one value per
+  // lane, column k = lane bits 5..2), two plain steps finish: 17 shuffles instead of 96.
+  double w8[8], w4[4], w2[2], w1;
   {
-    const int l5 = tid & 31;
-    double w4[4], w2[2], w1;
-    {
-      const bool hi = (l5 & 16) != 0;
+    const bool hi = (lane & 32) != 0;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const double send = hi ? pcol[q] : pcol[4 + q];
-        const double recv = __shfl_xor(send, 16, 64);
-        w4[q] = (hi ? pcol[4 + q] : pcol[q]) + recv;
-      }
-    }
-    {
-      const bool hi = (l5 & 8) != 0;
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        const double send = hi ? w4[q] : w4[2 + q];
-        const double recv = __shfl_xor(send, 8, 64);
-        w2[q] = (hi ? w4[2 + q] : w4[q]) + recv;
-      }
-    }
-    {
-      const bool hi = (l5 & 4) != 0;
-      const double send = hi ? w2[0] : w2[1];
-      const double recv = __shfl_xor(send, 4, 64);
-      w1 = (hi ? w2[1] : w2[0]) + recv;
-    }
-    w1 += __shfl_xor(w1, 2, 64);
-    w1 += __shfl_xor(w1, 1, 64);
-    if ((l5 & 3) == 0) {
-      const int k = ((l5 >> 4) & 1) * 4 + ((l5 >> 3) & 1) * 2 + ((l5 >> 2) & 1);
-      const int64_t gc = j0 + cg + 8 * k;
-      if (gc < n) Pcol[I * n + gc] = w1;
+    for (int q = 0; q < 8; ++q) {
+      const double send = hi ? pcol[q] : pcol[8 + q];
+      w8[q] = (hi ? pcol[8 + q] : pcol[q]) + __shfl_xor(send, 32, 64);
     }
   }
-  // row sums: reduce over the 8 column groups through LDS, fixed order
-  __shared__ double red[8][HT];
-  red[cg][2 * rp] = prow0;
-  red[cg][2 * rp + 1] = prow1;
-  __syncthreads();
-  if (tid < HT) {
-    double s = 0.0;
+  {
+    const bool hi = (lane & 16) != 0;
 #pragma unroll
-    for (int g = 0; g < 8; ++g) s += red[g][tid];
-    if (i0 + tid < n) Prow[J * n + i0 + tid] = s;
+    for (int q = 0; q < 4; ++q) {
+      const double send = hi ? w8[q] : w8[4 + q];
+      w4[q] = (hi ? w8[4 + q] : w8[q]) + __shfl_xor(send, 16, 64);
+    }
+  }
+  {
+    const bool hi = (lane & 8) != 0;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const double send = hi ? w4[q] : w4[2 + q];
+      w2[q] = (hi ? w4[2 + q] : w4[q]) + __shfl_xor(send, 8, 64);
+    }
+  }
+  {
+    const bool hi = (lane & 4) != 0;
+    const double send = hi ? w2[0] : w2[1];
+    w1 = (hi ? w2[1] : w2[0]) + __shfl_xor(send, 4, 64);
+  }
+  w1 += __shfl_xor(w1, 2, 64);
+  w1 += __shfl_xor(w1, 1, 64);
+  __shared__ double colred[4][16];
+  __shared__ double rowred[2][HR];
+  if ((lane & 3) == 0) {
+    const int k = ((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1);
+    colred[wave][k] = w1;
+  }
+  rowred[cg][2 * rp] = prow0;
+  rowred[cg][2 * rp + 1] = prow1;
+  __syncthreads();
+  if (tid < HC) {                            // waves (2cg, 2cg+1) hold the two row halves of column group cg
+    const int c_cg = tid & 1, k = tid >> 1;  // column cg + 2k  <->  tid = cg + 2k
+    const int64_t gc = j0 + tid;
+    if (gc < n) Pcol[G * n + gc] = colred[2 * c_cg][k] + colred[2 * c_cg + 1][k];
+  }
+  {
+    const int64_t row = i0 + tid;
+    if (row < n) Prow[J * n + row] = rowred[0][tid] + rowred[1][tid];
   }
 }
 
+// 32 rows per workgroup, 8 lanes per row: lane `sub` adds partials sub, sub+8, ... (independent loads in
+// flight), the 8 sub-sums are combined in a fixed order -> deterministic, and n/32 workgroups fill the chip.
 template <typename T, typename CT, bool BETA0>
 __global__ void __launch_bounds__(kBlock)
 herm_finish_kernel(T *__restrict__ res, const T *__restrict__ d, const T *__restrict__ v,
-                   const double *__restrict__ Prow, const double *__restrict__ Pcol, int64_t n, int nb,
-                   CT alpha, CT beta) {
-  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (i >= n) return;
-  const int blk = (int)(i / HT);
+                   const double *__restrict__ Prow, const double *__restrict__ Pcol, int64_t n, int ng,
+                   int nbc, CT alpha, CT beta) {
+  const int r = threadIdx.x & 31, sub = threadIdx.x >> 5;
+  const int64_t i = (int64_t)blockIdx.x * 32 + r;
+  __shared__ double s1[8][32], s2[8][32];
   double t1 = 0.0, t2 = 0.0;
-  for (int J = 0; J <= blk; ++J) t1 += Prow[(int64_t)J * n + i];      // L*v : tiles (blk, J <= blk)
-  for (int I = blk; I < nb; ++I) t2 += Pcol[(int64_t)I * n + i];      // L'*v: tiles (I >= blk, blk)
-  const T inner = ((d[i] * v[i]) + (T)t1) + (T)t2;
-  CT t = alpha * (CT)inner;
-  if constexpr (!BETA0) t = t + (beta * (CT)res[i]);
-  res[i] = (T)t;
+  if (i < n) {
+    const int G = (int)(i / HR);
+    int jmax = 8 * G + 7;
+    if (jmax > nbc - 1) jmax = nbc - 1;
+    for (int J = sub; J <= jmax; J += 8) t1 += Prow[(int64_t)J * n + i];     // L*v : panels (G, J <= 8G+7)
+    for (int g = G + sub; g < ng; g += 8) t2 += Pcol[(int64_t)g * n + i];    // L'*v: panels (g >= i/256, i/32)
+  }
+  s1[sub][r] = t1;
+  s2[sub][r] = t2;
+  __syncthreads();
+  if (sub == 0 && i < n) {
+    double a1 = 0.0, a2 = 0.0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      a1 += s1[q][r];
+      a2 += s2[q][r];
+    }
+    const T inner = ((d[i] * v[i]) + (T)a1) + (T)a2;
+    CT t = alpha * (CT)inner;
+    if constexpr (!BETA0) t = t + (beta * (CT)res[i]);
+    res[i] = (T)t;
+  }
 }
 
 struct HermScratch {  // per-device scratch for the tile partials (grown on demand)
@@ -582,10 +603,11 @@ template <typename T>
 int32_t hermitian_t(mxlo_ctx *ctx, T *res, const T *d, const T *A, int64_t lda, const T *v, int64_t n,
                     double alpha, double beta, int32_t flags) {
   if (n == 0) return MXLO_OK;
-  const int64_t nb = (n + HT - 1) / HT;
-  MXLO_REQUIRE(nb * (nb + 1) / 2 < (1LL << 31), MXLO_ESHAPE, "opHermitian: n too large");
+  const int64_t ng = (n + HR - 1) / HR, nbc = (n + HC - 1) / HC;
+  const int64_t npanels = 4 * ng * (ng + 1);
+  MXLO_REQUIRE(npanels < (1LL << 31), MXLO_ESHAPE, "opHermitian: n too large");
   HermScratch &hs = g_herm[ctx->device & 63];
-  const size_t need = sizeof(double) * 2 * (size_t)nb * (size_t)n;
+  const size_t need = sizeof(double) * ((size_t)nbc + (size_t)ng) * (size_t)n;
   if (hs.bytes < need) {
     if (hs.buf) {
       MXLO_HIP(hipStreamSynchronize(ctx->stream));
@@ -597,20 +619,19 @@ int32_t hermitian_t(mxlo_ctx *ctx, T *res, const T *d, const T *A, int64_t lda, 
     MXLO_REQUIRE(e == hipSuccess, MXLO_ENOMEM, "opHermitian scratch: %s", hipGetErrorString(e));
     hs.bytes = need;
   }
-  double *Prow = (double *)hs.buf, *Pcol = Prow + (size_t)nb * n;
-  const unsigned ntiles = (unsigned)(nb * (nb + 1) / 2);
+  double *Prow = (double *)hs.buf, *Pcol = Prow + (size_t)nbc * n;
   const bool aligned = sizeof(T) == 8 && (((uintptr_t)A & 15u) == 0) && (lda % 2 == 0);
   if (aligned)
-    hipLaunchKernelGGL((herm_tile_kernel<T, true>), dim3(ntiles), dim3(kBlock), 0, ctx->stream, A, lda, v, n,
-                       (int)nb, Prow, Pcol);
+    hipLaunchKernelGGL((herm_panel_kernel<T, true>), dim3((unsigned)npanels), dim3(kBlock), 0, ctx->stream, A,
+                       lda, v, n, Prow, Pcol);
   else
-    hipLaunchKernelGGL((herm_tile_kernel<T, false>), dim3(ntiles), dim3(kBlock), 0, ctx->stream, A, lda, v, n,
-                       (int)nb, Prow, Pcol);
+    hipLaunchKernelGGL((herm_panel_kernel<T, false>), dim3((unsigned)npanels), dim3(kBlock), 0, ctx->stream, A,
+                       lda, v, n, Prow, Pcol);
   MXLO_LAUNCH_CHECK();
-  const unsigned blocks = (unsigned)((n + kBlock - 1) / kBlock);
+  const unsigned blocks = (unsigned)((n + 31) / 32);
   return dispatch_ct<T>(beta, flags, [&]<typename CT, bool B0>() -> int32_t {
     hipLaunchKernelGGL((herm_finish_kernel<T, CT, B0>), dim3(blocks), dim3(kBlock), 0, ctx->stream, res, d, v,
-                       Prow, Pcol, n, (int)nb, (CT)alpha, (CT)beta);
+                       Prow, Pcol, n, (int)ng, (int)nbc, (CT)alpha, (CT)beta);
     MXLO_LAUNCH_CHECK();
     return MXLO_OK;
   });

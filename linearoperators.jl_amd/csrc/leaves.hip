@@ -260,26 +260,56 @@ typedef unsigned int u32;
 typedef unsigned long long u64;
 typedef u64 u64x2 __attribute__((ext_vector_type(2)));
 
-template <typename E>
+// res[k] = v[idx[k]-1]. Each lane owns KPT = 16/sizeof(E) consecutive outputs so that the index stream is
+// read with 16-byte loads (and, for 4/8-byte elements with an aligned res, the output is one 16-byte
+// nontemporal store); U such groups are in flight per lane. Random reads of v stay default-policy (cached).
+template <typename E, bool VECOUT>
 __global__ void __launch_bounds__(kBlock)
 gather_idx_kernel(E *__restrict__ res, const E *__restrict__ v, const int64_t *__restrict__ idx,
                   int64_t nidx) {
+  constexpr int KPT = sizeof(E) >= 16 ? 1 : 16 / (int)sizeof(E);
   constexpr int U = 4;
-  for (int64_t base = ((int64_t)blockIdx.x * U) * kBlock + threadIdx.x; base < nidx;
+  typedef long long i64x2 __attribute__((ext_vector_type(2)));
+  const int64_t ngroups = (nidx + KPT - 1) / KPT;
+  const bool idx_al = (((uintptr_t)idx) & 15u) == 0;
+  for (int64_t base = ((int64_t)blockIdx.x * U) * kBlock + threadIdx.x; base < ngroups;
        base += (int64_t)gridDim.x * U * kBlock) {
-    int64_t j[U];
+    int64_t j[U][KPT];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int64_t k = base + (int64_t)u * kBlock;
-      j[u] = k < nidx ? idx[k] - 1 : 0;  // Julia indices are 1-based
+      const int64_t k0 = (base + (int64_t)u * kBlock) * KPT;
+      if (KPT >= 2 && idx_al && k0 + KPT <= nidx) {
+#pragma unroll
+        for (int q = 0; q < KPT; q += 2) {
+          const i64x2 t = __builtin_nontemporal_load(reinterpret_cast<const i64x2 *>(idx + k0 + q));
+          j[u][q] = t[0] - 1;          // Julia indices are 1-based
+          j[u][q + (KPT >= 2 ? 1 : 0)] = t[1] - 1;
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < KPT; ++q) j[u][q] = k0 + q < nidx ? idx[k0 + q] - 1 : 0;
+      }
     }
-    E e[U];
+    E e[U][KPT];
 #pragma unroll
-    for (int u = 0; u < U; ++u) e[u] = v[j[u]];
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int q = 0; q < KPT; ++q) e[u][q] = v[j[u][q]];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int64_t k = base + (int64_t)u * kBlock;
-      if (k < nidx) res[k] = e[u];
+      const int64_t k0 = (base + (int64_t)u * kBlock) * KPT;
+      if (VECOUT && k0 + KPT <= nidx) {
+        struct alignas(16) Pack { E x[KPT]; };
+        Pack p;
+#pragma unroll
+        for (int q = 0; q < KPT; ++q) p.x[q] = e[u][q];
+        typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+        __builtin_nontemporal_store(*reinterpret_cast<u32x4 *>(&p), reinterpret_cast<u32x4 *>(res + k0));
+      } else {
+#pragma unroll
+        for (int q = 0; q < KPT; ++q)
+          if (k0 + q < nidx) res[k0 + q] = e[u][q];
+      }
     }
   }
 }
@@ -345,9 +375,14 @@ MXLO_API int32_t mxlo_gather(mxlo_ctx *ctx, int32_t elem_size, void *res, const 
   if (nidx == 0) return MXLO_OK;
   MXLO_REQUIRE(res && v && idx, MXLO_EINVAL, "mxlo_gather: NULL operand");
   return by_elem_size(elem_size, [&]<typename E>() -> int32_t {
-    const int grid = grid_for(ctx, nidx, kBlock * 4, ctx->tune.blocks_per_cu);
-    hipLaunchKernelGGL((gather_idx_kernel<E>), dim3(grid), dim3(kBlock), 0, ctx->stream, (E *)res,
-                       (const E *)v, idx, nidx);
+    constexpr int KPT = sizeof(E) >= 16 ? 1 : 16 / (int)sizeof(E);
+    const int grid = grid_for(ctx, (nidx + KPT - 1) / KPT, kBlock * 4, ctx->tune.blocks_per_cu);
+    if ((((uintptr_t)res) & 15u) == 0)
+      hipLaunchKernelGGL((gather_idx_kernel<E, true>), dim3(grid), dim3(kBlock), 0, ctx->stream, (E *)res,
+                         (const E *)v, idx, nidx);
+    else
+      hipLaunchKernelGGL((gather_idx_kernel<E, false>), dim3(grid), dim3(kBlock), 0, ctx->stream, (E *)res,
+                         (const E *)v, idx, nidx);
     MXLO_LAUNCH_CHECK();
     return MXLO_OK;
   });

@@ -36,10 +36,13 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--n", type=int, default=100_000_000, help="vector length per GPU")
+    ap.add_argument("--nelem", dest="n", type=int, default=100_000_000, help="vector length per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=50_000_000)
+    # debugging aids for the N > 1 code path on a 1-GPU box: every rank on device 0, gloo instead of RCCL
+    ap.add_argument("--backend", default="nccl")
+    ap.add_argument("--single-device", action="store_true")
     return ap.parse_args()
 
 
@@ -59,11 +62,16 @@ def main():
     distributed = world > 1
     if args.gpus != world and distributed:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.single_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
     ctx = get_ctx(dev)
     if distributed:
         lo.sharded.install_allreduce(ctx)     # RCCL all-reduce of the partial dots over xGMI

@@ -238,6 +238,14 @@ int32_t mxlo_kron_mul(mxlo_ctx *ctx, int32_t dtype, void *res, const void *A, in
                       const void *x, void *work, double alpha, double beta, int32_t op_mode,
                       int32_t flags);
 
+/* kron(A, B) when BOTH factors are diagonal operators (opDiagonal / opEye; pass NULL for an identity
+ * factor): the fused row/col index-decomposition form of src/kron.jl:14-22,
+ *   res[r + c*p] = alpha*(dB[r]*(x[r + c*p]*dA[c])) (+ beta*res[r + c*p]),  A is m x m, B is p x p.
+ * Symmetric, so tprod!/ctprod! are the same call. One HBM pass, no GEMM. */
+int32_t mxlo_kron_diag_mul(mxlo_ctx *ctx, int32_t dtype, void *res, const void *dA, int64_t m,
+                           const void *dB, int64_t p, const void *x, double alpha, double beta,
+                           int32_t flags);
+
 /* Dense LinearOperator(M) prod!/tprod! — src/constructors.jl:19-29 delegates to
  * LinearAlgebra.mul!; needed for dense blocks and for kron of operators. GEMV. */
 int32_t mxlo_gemv(mxlo_ctx *ctx, int32_t dtype, void *res, const void *M, int64_t m, int64_t n,

@@ -106,6 +106,7 @@ _PROTOS = {
     "mxlo_blockdiag_mul": [_vp, _vp, _vp, _dbl, _dbl, _i32, _i32],
     "mxlo_blockdiag_destroy": [_vp],
     "mxlo_kron_mul": [_vp, _i32, _vp, _vp, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _vp, _dbl, _dbl, _i32, _i32],
+    "mxlo_kron_diag_mul": [_vp, _i32, _vp, _vp, _i64, _vp, _i64, _vp, _dbl, _dbl, _i32],
     "mxlo_gemv": [_vp, _i32, _vp, _vp, _i64, _i64, _i64, _vp, _dbl, _dbl, _i32, _i32],
     "mxlo_qn_create": [_vp, _i32, _i32, _i64, _i64, _i32, _i32, _dbl, _dbl, C.POINTER(_vp)],
     "mxlo_qn_destroy": [_vp],

@@ -459,3 +459,67 @@ MXLO_API int32_t mxlo_scatter_zero_range(mxlo_ctx *ctx, int32_t elem_size, void 
     return MXLO_OK;
   });
 }
+
+
+// ---- kron of two diagonal / identity factors: fused row/col index decomposition ------------------------
+// kron(A, B) with A = Diagonal(dA) (m x m) and B = Diagonal(dB) (p x p) (either may be the identity):
+//   X = reshape(x, p, m);  (B * X * transpose(A))[r, c] = dB[r] * (X[r, c] * dA[c])      (src/kron.jl:14-22)
+//   res[r + c*p] = alpha * that (+ beta * res[r + c*p])
+// Output index i decomposes as (r, c) = (i % p, i / p); blockIdx.y walks c so no integer division is
+// needed in the lanes. HBM-bound: 16 B/elt (+8 when beta != 0) plus the two small diagonals (cached).
+namespace {
+template <typename T, typename CT, bool BETA0>
+__global__ void __launch_bounds__(kBlock)
+kron_diag_kernel(T *__restrict__ res, const T *__restrict__ dA, const T *__restrict__ dB,
+                 const T *__restrict__ x, int64_t p, int64_t m, CT alpha, CT beta) {
+  for (int64_t c = blockIdx.y; c < m; c += gridDim.y) {
+    const T ac = dA ? dA[c] : T(1);
+    T *rc = res + c * p;
+    const T *xc = x + c * p;
+    for (int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x; r < p; r += (int64_t)gridDim.x * kBlock) {
+      const T br = dB ? dB[r] : T(1);
+      const T inner = br * (xc[r] * ac);
+      CT t = alpha * (CT)inner;
+      if constexpr (!BETA0) t = t + (beta * (CT)rc[r]);
+      rc[r] = (T)t;
+    }
+  }
+}
+
+template <typename T>
+int32_t kron_diag_t(mxlo_ctx *ctx, T *res, const T *dA, int64_t m, const T *dB, int64_t p, const T *x,
+                    double alpha, double beta, int32_t flags) {
+  if (m <= 0 || p <= 0) return MXLO_OK;
+  int64_t gx = (p + kBlock - 1) / kBlock;
+  if (gx > 1024) gx = 1024;
+  int64_t gy = m < 65535 ? m : 65535;
+  // keep the grid around 16 workgroups per CU
+  const int64_t cap = (int64_t)ctx->num_cu * 16;
+  if (gx * gy > cap) {
+    gy = cap / gx;
+    if (gy < 1) gy = 1;
+  }
+  return dispatch_ct<T>(beta, flags, [&]<typename CT, bool B0>() -> int32_t {
+    hipLaunchKernelGGL((kron_diag_kernel<T, CT, B0>), dim3((unsigned)gx, (unsigned)gy), dim3(kBlock), 0,
+                       ctx->stream, res, dA, dB, x, p, m, (CT)alpha, (CT)beta);
+    MXLO_LAUNCH_CHECK();
+    return MXLO_OK;
+  });
+}
+}  // namespace
+
+MXLO_API int32_t mxlo_kron_diag_mul(mxlo_ctx *ctx, int32_t dtype, void *res, const void *dA, int64_t m,
+                                    const void *dB, int64_t p, const void *x, double alpha, double beta,
+                                    int32_t flags) {
+  CHECK_COMMON("mxlo_kron_diag_mul");
+  MXLO_REQUIRE(m >= 0 && p >= 0, MXLO_ESHAPE, "mxlo_kron_diag_mul: negative size");
+  if (m == 0 || p == 0) return MXLO_OK;
+  MXLO_REQUIRE(res && x, MXLO_EINVAL, "mxlo_kron_diag_mul: NULL operand");
+  alpha = eff_alpha(dtype, flags, alpha);
+  beta = eff_beta(dtype, flags, beta);
+  if (dtype == MXLO_F64)
+    return kron_diag_t<double>(ctx, (double *)res, (const double *)dA, m, (const double *)dB, p,
+                               (const double *)x, alpha, beta, flags);
+  return kron_diag_t<float>(ctx, (float *)res, (const float *)dA, m, (const float *)dB, p, (const float *)x,
+                            alpha, beta, flags);
+}

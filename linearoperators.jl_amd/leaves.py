@@ -389,6 +389,34 @@ def kron(A, B):
     The reference rebuilds a composite operator and materialises it with `m` single-vector products on
     every apply; here both factors are dense device matrices (operators are materialised ONCE at
     construction with `Matrix(op)`, src/abstract.jl:282-292) and an apply is two MFMA GEMMs."""
+    def diag_of(X):
+        """(is_diagonal_like, d or None, n) for opDiagonal / square opEye leaves."""
+        leaf = getattr(X, "_leaf", None) if not isinstance(X, torch.Tensor) else None
+        if leaf is not None and leaf[0] == "diag":
+            return True, leaf[1], leaf[1].numel()
+        if leaf is not None and leaf[0] == "eye" and leaf[1] == leaf[2]:
+            return True, None, leaf[1]
+        return False, None, 0
+
+    isdA, dA, mA = diag_of(A)
+    isdB, dB, pB = diag_of(B)
+    if isdA and isdB:
+        # both factors diagonal (identity = no vector): the fused row/col index-decomposition kernel,
+        # res[r + c*p] = α*(dB[r]*(x[r + c*p]*dA[c])) (+ β res) — one HBM pass, no GEMM (src/kron.jl:14-22)
+        dts = [t.dtype for t in (dA, dB) if t is not None] or [A.eltype if A.eltype.is_floating_point else torch.float64]
+        Td = dts[0] if len(dts) == 1 else torch.promote_types(dts[0], dts[1])
+        dtype_code(Td)
+        dA_ = dA.to(Td) if dA is not None else None
+        dB_ = dB.to(Td) if dB is not None else None
+        dev = next((t.device for t in (dA_, dB_) if t is not None), storage_type(A).device)
+
+        def kd(res, x, a, b):
+            ctx = get_ctx(res.device)
+            _lib.call("mxlo_kron_diag_mul", ctx.handle, dtype_code(Td), ptr(res), ptr(dA_), mA, ptr(dB_), pB, ptr(x),
+                      float(a), float(b), scalar_flags(res.dtype, a, b))
+
+        return LinearOperator(Td, mA * pB, mA * pB, True, True, kd, kd, kd, S=Storage(Td, dev))
+
     def dense_of(X):
         if isinstance(X, torch.Tensor):
             return _colmajor(X), False, False

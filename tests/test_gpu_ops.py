@@ -325,3 +325,29 @@ def test_callable_functor(lo, dev):
     Mv = torch.ones(2, dtype=torch.float64, device=dev)
     lo.mul(Mv, op, one)
     assert torch.equal(Mv, -one) and lo.has_args5(op)
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_kron_of_diagonal_factors_fused(lo, dev, dtype):
+    """kron of opDiagonal / opEye factors takes the fused index-decomposition kernel: bit-exact against the
+    reference's elementwise order dB[r]*(x*dA[c]) and equal to the dense Kronecker product (test_kron.jl:50-58)."""
+    rng = np.random.default_rng(31)
+    npd = NP[dtype]
+    m, p = 37, 1031
+    dA, dB = rng.standard_normal(m).astype(npd), rng.standard_normal(p).astype(npd)
+    x, r0 = rng.standard_normal(m * p).astype(npd), rng.standard_normal(m * p).astype(npd)
+    S = lo.Storage(dtype, dev)
+    for A, B, a_, b_ in ((lo.opDiagonal(T(dA, dev)), lo.opDiagonal(T(dB, dev)), dA, dB),
+                         (lo.opEye(dtype, m, S=S), lo.opDiagonal(T(dB, dev)), np.ones(m, npd), dB),
+                         (lo.opDiagonal(T(dA, dev)), lo.opEye(dtype, p, S=S), dA, np.ones(p, npd))):
+        K = lo.kron(A, B)
+        assert K.shape == (m * p, m * p) and lo.issymmetric(K)
+        want_inner = (b_[None, :] * (x.reshape(m, p) * a_[:, None])).reshape(-1)      # dB[r]*(x[r,c]*dA[c])
+        for op in (K, K.T, K.H):
+            res = torch.full((m * p,), float("nan"), dtype=dtype, device=dev)
+            lo.mul(res, op, T(x, dev), 1, 0)
+            assert np.array_equal(res.cpu().numpy(), want_inner)
+        res = T(r0.copy(), dev)
+        lo.mul(res, K, T(x, dev), np.float32(2) if dtype == torch.float32 else 2.0, np.float32(-3) if dtype == torch.float32 else -3.0)
+        assert np.array_equal(res.cpu().numpy(), npd(2) * want_inner + npd(-3) * r0)
+        assert rel((K * T(x, dev)).cpu().numpy(), np.kron(np.diag(a_.astype(np.float64)), np.diag(b_.astype(np.float64))) @ x) <= (1e-14 if dtype == torch.float64 else 1e-6)

@@ -130,6 +130,13 @@ def lib() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    if not os.path.exists(LIB_PATH) and os.path.exists("/opt/rocm/bin/hipcc"):
+        # a source-only checkout (the .so is git-ignored): compile the HIP sources in-tree once. This is the
+        # same library, not a fallback — if hipcc is absent or the build fails we raise below.
+        try:
+            build()
+        except Exception as e:  # pragma: no cover
+            raise ImportError(f"{LIB_PATH} is missing and building it failed: {e}") from e
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "

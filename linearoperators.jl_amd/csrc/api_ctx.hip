@@ -106,6 +106,9 @@ MXLO_API int32_t mxlo_ctx_tune(mxlo_ctx *ctx, const char *key, int64_t value) {
     MXLO_REQUIRE(value == MXLO_INV_TWOPASS || value == MXLO_INV_REFORDER, MXLO_EINVAL,
                  "lbfgs_inv_mode must be MXLO_INV_TWOPASS or MXLO_INV_REFORDER");
     ctx->tune.lbfgs_inv_mode = (int)value;
+  } else if (!strcmp(key, "gemm_tile_m")) {
+    MXLO_REQUIRE(value == 0 || value == 32 || value == 64, MXLO_EINVAL, "gemm_tile_m must be 0, 32 or 64");
+    ctx->tune.gemm_tile_m = (int)value;
   } else if (!strcmp(key, "gemm_waves")) {
     MXLO_REQUIRE(value == 4 || value == 8, MXLO_EINVAL, "gemm_waves must be 4 or 8");
     ctx->tune.gemm_waves = (int)value;

@@ -122,22 +122,30 @@ gemm_kernel(T *__restrict__ C, int64_t ldc, const T *__restrict__ A, int64_t lda
 // of the current slab issue; one barrier per slab.
 constexpr int FBK = 32;
 
-template <typename T, typename CT, bool BETA0, int WAVES>
+// TM x 64 output tile per workgroup. (TM, WAVES) = (64, 8): one workgroup per CU at 1024^2;
+// (32, 4): 512 workgroups at 1024^2 = TWO independent workgroups per CU, so one computes while the other
+// sits in its barrier / LDS-store bubble.
+template <typename T, typename CT, bool BETA0, int WAVES, int TM>
 __global__ void __launch_bounds__(WAVES * 64)
 gemm_nt_fast_kernel(T *__restrict__ C, int64_t ldc, const T *__restrict__ A, int64_t lda,
                     const T *__restrict__ B, int64_t ldb, int K, CT alpha, CT beta) {
   constexpr int kBlock = WAVES * 64;                     // shadows mxlo::kBlock inside this kernel
-  constexpr int MT = WAVES == 4 ? 2 : 1;                 // 16-row MFMA tiles per wave along M
+  constexpr int WR = WAVES / 2;                          // waves along M (2 along N, 32 columns each)
+  constexpr int MT = TM / WR / 16;                       // 16-row MFMA tiles per wave along M
+  static_assert(MT >= 1 && MT * 16 * WR == TM, "bad tile / wave shape");
   constexpr int VEC = Vec16<T>::N;                       // elements per 16-byte load
-  constexpr int LPT = BM * FBK / VEC / kBlock;           // 16-byte loads per thread per operand slab
-  constexpr int RPV = BM / VEC;                          // vectors per k-row (32 for f64, 16 for f32)
+  constexpr int LPA = TM * FBK / VEC / kBlock;           // 16-byte loads per thread per A slab
+  constexpr int LPB = BN * FBK / VEC / kBlock;           //                             per B slab
+  static_assert(LPA >= 1 && LPB >= 1, "slab smaller than one load per thread");
+  constexpr int RPA = TM / VEC, RPB = BN / VEC;          // vectors per k-row
+  constexpr int LDA_ = TM == 64 ? 80 : 48;               // padded k-row: second k-row lands 32 banks away
   using V = typename Vec16<T>::type;
-  __shared__ T sA[2][FBK][LDT];
+  __shared__ T sA[2][FBK][LDA_];
   __shared__ T sB[2][FBK][LDT];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int bm = blockIdx.x * BM, bn = blockIdx.y * BN;
-  const int wm = WAVES == 4 ? (wave & 1) * 32 : (wave & 3) * 16;
-  const int wn = WAVES == 4 ? (wave >> 1) * 32 : (wave >> 2) * 32;
+  const int bm = blockIdx.x * TM, bn = blockIdx.y * BN;
+  const int wm = (wave % WR) * (TM / WR);
+  const int wn = (wave / WR) * 32;
   using Acc = typename Mfma<T>::Acc;
   Acc acc[MT][2];
 #pragma unroll
@@ -150,22 +158,32 @@ gemm_nt_fast_kernel(T *__restrict__ C, int64_t ldc, const T *__restrict__ A, int
   // Three-stage software pipeline: while slab `it` is in the MFMAs (LDS buffer it&1), slab it+1 sits in
   // one register set (its global loads were issued a whole iteration ago, so the mid-iteration LDS store
   // never waits on memory) and the loads of slab it+2 are issued into the other register set.
-  V ra0[LPT], rb0[LPT], ra1[LPT], rb1[LPT];
-  auto gload = [&](int k0, V (&ra)[LPT], V (&rb)[LPT]) {
+  V ra0[LPA], rb0[LPB], ra1[LPA], rb1[LPB];
+  auto gload = [&](int k0, V (&ra)[LPA], V (&rb)[LPB]) {
 #pragma unroll
-    for (int r = 0; r < LPT; ++r) {
+    for (int r = 0; r < LPA; ++r) {
       const int idx = tid + r * kBlock;
-      const int iv = idx % RPV, k = idx / RPV;
+      const int iv = idx % RPA, k = idx / RPA;
       ra[r] = *reinterpret_cast<const V *>(A + (bm + iv * VEC) + (int64_t)(k0 + k) * lda);
+    }
+#pragma unroll
+    for (int r = 0; r < LPB; ++r) {
+      const int idx = tid + r * kBlock;
+      const int iv = idx % RPB, k = idx / RPB;
       rb[r] = *reinterpret_cast<const V *>(B + (bn + iv * VEC) + (int64_t)(k0 + k) * ldb);
     }
   };
-  auto lstore = [&](int buf, const V (&ra)[LPT], const V (&rb)[LPT]) {
+  auto lstore = [&](int buf, const V (&ra)[LPA], const V (&rb)[LPB]) {
 #pragma unroll
-    for (int r = 0; r < LPT; ++r) {
+    for (int r = 0; r < LPA; ++r) {
       const int idx = tid + r * kBlock;
-      const int iv = idx % RPV, k = idx / RPV;
+      const int iv = idx % RPA, k = idx / RPA;
       *reinterpret_cast<V *>(&sA[buf][k][iv * VEC]) = ra[r];
+    }
+#pragma unroll
+    for (int r = 0; r < LPB; ++r) {
+      const int idx = tid + r * kBlock;
+      const int iv = idx % RPB, k = idx / RPB;
       *reinterpret_cast<V *>(&sB[buf][k][iv * VEC]) = rb[r];
     }
   };
@@ -233,11 +251,18 @@ int32_t gemm(mxlo_ctx *ctx, T *C, int64_t ldc, const T *A, int64_t lda, bool ta,
   dim3 grid((unsigned)((M + BM - 1) / BM), (unsigned)((N + BN - 1) / BN));
   if (!ta && tb && gemm_nt_fast_ok<T>(A, lda, B, ldb, M, N, K)) {
     return dispatch_ct<T>(beta, flags, [&]<typename CT, bool B0>() -> int32_t {
-      if (ctx->tune.gemm_waves == 8)
-        hipLaunchKernelGGL((gemm_nt_fast_kernel<T, CT, B0, 8>), grid, dim3(512), 0, ctx->stream, C, ldc, A,
+      // tile choice: 32x64 tiles (2 workgroups per CU) while the 64x64 grid would not fill the chip twice
+      const int64_t tiles64 = (M / 64) * (N / 64);
+      const bool small = ctx->tune.gemm_tile_m == 32 || (ctx->tune.gemm_tile_m == 0 && tiles64 < 2 * ctx->num_cu);
+      if (small) {
+        dim3 g32((unsigned)(M / 32), (unsigned)(N / 64));
+        hipLaunchKernelGGL((gemm_nt_fast_kernel<T, CT, B0, 4, 32>), g32, dim3(256), 0, ctx->stream, C, ldc, A,
+                           lda, B, ldb, (int)K, (CT)alpha, (CT)beta);
+      } else if (ctx->tune.gemm_waves == 8)
+        hipLaunchKernelGGL((gemm_nt_fast_kernel<T, CT, B0, 8, 64>), grid, dim3(512), 0, ctx->stream, C, ldc, A,
                            lda, B, ldb, (int)K, (CT)alpha, (CT)beta);
       else
-        hipLaunchKernelGGL((gemm_nt_fast_kernel<T, CT, B0, 4>), grid, dim3(256), 0, ctx->stream, C, ldc, A,
+        hipLaunchKernelGGL((gemm_nt_fast_kernel<T, CT, B0, 4, 64>), grid, dim3(256), 0, ctx->stream, C, ldc, A,
                            lda, B, ldb, (int)K, (CT)alpha, (CT)beta);
       MXLO_LAUNCH_CHECK();
       return MXLO_OK;

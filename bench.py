@@ -73,8 +73,25 @@ def main():
         else:
             dist.init_process_group(args.backend, rank=rank, world_size=world)
     ctx = get_ctx(dev)
-    if distributed:
-        lo.sharded.install_allreduce(ctx)     # RCCL all-reduce of the partial dots over xGMI
+    hook = None
+    native = args.backend == "nccl" and not args.single_device
+
+    def install_hook():
+        nonlocal hook, native
+        if not distributed:
+            return
+        if native:                             # libmxlo_rccl.so: ncclAllReduce issued from C on the ctx stream
+            try:
+                if hook is None:
+                    hook = lo.sharded.NativeRcclHook(rank, world)
+                hook.install(ctx)
+                return
+            except Exception as e:             # still RCCL, through torch.distributed, if the native comm fails
+                print(f"[bench] native RCCL hook unavailable ({e!r}); using the torch.distributed hook", file=sys.stderr)
+                native = False
+        lo.sharded.install_allreduce(ctx, native=False)   # Python hook over torch.distributed (debug / gloo)
+
+    install_hook()                             # RCCL all-reduce of the partial dots over xGMI
 
     n = args.n
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
@@ -115,7 +132,6 @@ def main():
     f64 = dtype_code(torch.float64)
     K = max(10, min(args.steps, 50))
     dot_dev = torch.zeros(1, dtype=torch.float64, device=dev)
-    saved_hook = None
     if distributed:                                      # time the kernels, not the collective
         ctx.set_allreduce(None)
     tm.start()
@@ -136,8 +152,7 @@ def main():
         lo.mul(res, D, v, alpha, beta)
     tm.stop()
     ms_diag = tm.elapsed_ms() / K
-    if distributed:
-        lo.sharded.install_allreduce(ctx)
+    install_hook()
 
     upd_gbs = 24.0 * n / (ms_upd * 1e-3) / 1e9
     traffic = None
@@ -184,7 +199,7 @@ def main():
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "opHouseholder(h) 5-arg mul!(res,H,v,1,0), n=%d fp64 per GPU (configs[1])" % n,
-                       "n_per_gpu": n, "algorithmic_bytes_per_elt": 40, "sharding": "row ranges, 1-double all-reduce" if distributed else "none"},
+                       "n_per_gpu": n, "algorithmic_bytes_per_elt": 40, "sharding": ("row ranges, 1-double all-reduce (%s)" % ("native RCCL hook" if native else "torch.distributed hook")) if distributed else "none"},
             "frac_hbm_peak": round(value / world / HBM_PEAK_GBS, 4),
             "roofline": roofline, "cpu_baseline": cpu_baseline, "extras": extras,
         }

@@ -13,7 +13,10 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libmxlo.so")
+RCCL_LIB_PATH = os.path.join(CSRC, "libmxlo_rccl.so")
 HEADER = os.path.normpath(os.path.join(_HERE, "..", "include", "mxlo.h"))
+RCCL_HEADER = os.path.normpath(os.path.join(_HERE, "..", "include", "mxlo_rccl.h"))
+RCCL_ID_BYTES = 128
 
 # status codes (include/mxlo.h)
 OK, EINVAL, ESHAPE, EHIP, ENOMEM, ESTATE, EDOMAIN, EREDUCE = range(8)
@@ -43,7 +46,7 @@ ALLREDUCE_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_voi
 
 def build(force: bool = False, verbose: bool = False) -> str:
     """Compile every HIP translation unit for gfx950 and link ``libmxlo.so`` in-tree."""
-    cmd = ["make", "-C", CSRC, "-j", str(max(2, (os.cpu_count() or 4))), "libmxlo.so"]
+    cmd = ["make", "-C", CSRC, "-j", str(max(2, (os.cpu_count() or 4))), "all"]
     if force:
         cmd.insert(1, "-B")
     out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
@@ -54,9 +57,9 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return LIB_PATH
 
 
-def header_symbols() -> list[str]:
-    """Every function name declared in include/mxlo.h (used by the symbol-export test)."""
-    text = open(HEADER).read()
+def header_symbols(header: str = None) -> list[str]:
+    """Every function name declared in include/mxlo.h (or another header; used by the symbol-export test)."""
+    text = open(header or HEADER).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     names = re.findall(r"\b(mxlo_[a-z0-9_]+)\s*\(", text)
     skip = {"mxlo_allreduce_fn"}
@@ -155,6 +158,28 @@ def lib() -> C.CDLL:
         f.restype = _i32
     _lib = L
     return L
+
+
+_rccl = None
+
+
+def rccl_lib() -> C.CDLL:
+    """libmxlo_rccl.so: the native RCCL transport of the all-reduce hook (include/mxlo_rccl.h)."""
+    global _rccl
+    if _rccl is None:
+        lib()                                      # torch first (maps its librccl.so.1 / libamdhip64.so.7)
+        if not os.path.exists(RCCL_LIB_PATH):
+            raise ImportError(f"{RCCL_LIB_PATH} is missing: run __graft_entry__.build()")
+        R = C.CDLL(RCCL_LIB_PATH)
+        R.mxlo_rccl_unique_id.argtypes = [_vp]
+        R.mxlo_rccl_comm_create.argtypes = [_i32, _i32, _vp, C.POINTER(_vp)]
+        R.mxlo_rccl_comm_destroy.argtypes = [_vp]
+        R.mxlo_rccl_allreduce_hook.argtypes = [_vp, _vp, _i64, _vp]
+        for f in (R.mxlo_rccl_unique_id, R.mxlo_rccl_comm_create, R.mxlo_rccl_comm_destroy, R.mxlo_rccl_allreduce_hook):
+            f.restype = _i32
+        R.mxlo_rccl_last_error.restype = C.c_char_p
+        _rccl = R
+    return _rccl
 
 
 def check(status: int) -> None:

@@ -99,12 +99,57 @@ def make_allreduce_hook(group=None, cuda: bool = True):
     return hook
 
 
-def install_allreduce(ctx, group=None) -> None:
-    """Route every global reduction of `ctx` through an RCCL all-reduce (no-op when world == 1)."""
+class NativeRcclHook:
+    """RCCL communicator owned by libmxlo_rccl.so; the hook is the C function `mxlo_rccl_allreduce_hook`
+    itself (ncclAllReduce on the ctx stream) — no Python, no extra stream, nothing synchronises."""
+
+    def __init__(self, rank: int, world: int, group=None):
+        from . import _lib
+        R = _lib.rccl_lib()
+        idbuf = torch.zeros(_lib.RCCL_ID_BYTES, dtype=torch.uint8)
+        if rank == 0:
+            raw = (C.c_ubyte * _lib.RCCL_ID_BYTES)()
+            if R.mxlo_rccl_unique_id(raw) != 0:
+                raise RuntimeError(R.mxlo_rccl_last_error().decode())
+            idbuf = torch.tensor(list(raw), dtype=torch.uint8)
+        if world > 1:                                   # the 128-byte id travels over the host runtime
+            dev = torch.device("cuda", torch.cuda.current_device())
+            backend = dist.get_backend(group)
+            t = idbuf.to(dev) if backend == "nccl" else idbuf
+            dist.broadcast(t, src=0, group=group)
+            idbuf = t.cpu()
+        raw = (C.c_ubyte * _lib.RCCL_ID_BYTES)(*idbuf.tolist())
+        self.comm = C.c_void_p()
+        if R.mxlo_rccl_comm_create(rank, world, raw, C.byref(self.comm)) != 0:   # collective
+            raise RuntimeError(R.mxlo_rccl_last_error().decode())
+        self._R = R
+        self.fn = C.cast(R.mxlo_rccl_allreduce_hook, _lib.ALLREDUCE_FN)
+
+    def install(self, ctx):
+        from . import _lib
+        ctx._hook = self                                 # keep the communicator alive with the ctx
+        _lib.call("mxlo_ctx_set_allreduce", ctx.handle, self.fn, self.comm)
+
+    def close(self):
+        if self.comm:
+            self._R.mxlo_rccl_comm_destroy(self.comm)
+            self.comm = C.c_void_p()
+
+
+def install_allreduce(ctx, group=None, native: bool = True):
+    """Route every global reduction of `ctx` through an RCCL all-reduce (no-op when world == 1).
+
+    native=True  : libmxlo_rccl.so — ncclAllReduce issued from C on the ctx stream (default);
+    native=False : the Python hook over torch.distributed (also what the gloo CPU tests exercise)."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         ctx.set_allreduce(None)
-        return
+        return None
+    if native:
+        hook = NativeRcclHook(dist.get_rank(group), dist.get_world_size(group), group)
+        hook.install(ctx)
+        return hook
     ctx.set_allreduce(make_allreduce_hook(group, cuda=True))
+    return None
 
 
 def uninstall_allreduce(ctx) -> None:

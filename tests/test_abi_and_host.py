@@ -22,6 +22,17 @@ def test_library_exports_every_header_symbol(lo):
     assert L.mxlo_status_string(2) == b"shape mismatch"
 
 
+def test_rccl_transport_library_exports_its_header(lo):
+    """include/mxlo_rccl.h <-> libmxlo_rccl.so (loading it pulls librccl; no collective is started here)."""
+    assert os.path.exists(lo._lib.RCCL_LIB_PATH), "run __graft_entry__.build() first"
+    import torch  # noqa: F401  (maps torch's librccl.so.1 so the SONAME resolves the same way as at run time)
+    R = ctypes.CDLL(lo._lib.RCCL_LIB_PATH)
+    syms = lo._lib.header_symbols(lo._lib.RCCL_HEADER)
+    assert set(syms) == {"mxlo_rccl_unique_id", "mxlo_rccl_comm_create", "mxlo_rccl_comm_destroy",
+                         "mxlo_rccl_allreduce_hook", "mxlo_rccl_last_error"}
+    assert not [s for s in syms if not hasattr(R, s)]
+
+
 def test_ctypes_prototypes_cover_header(lo):
     declared = set(lo._lib.header_symbols()) - {"mxlo_version", "mxlo_status_string", "mxlo_last_error"}
     assert declared == set(lo._lib._PROTOS), declared ^ set(lo._lib._PROTOS)

@@ -376,3 +376,31 @@ def test_forward_lbfgs_shard_size_properties(lo, dev):
     del rhs, sol, out
     d = lo.diag(B)
     assert torch.isfinite(d).all() and (d > 0).all()        # B is SPD: positive diagonal
+
+
+def test_native_rccl_hook_world1(lo, dev):
+    """libmxlo_rccl.so: a 1-rank RCCL communicator, `mxlo_rccl_allreduce_hook` installed as the ctx hook
+    (ncclAllReduce issued from C on the ctx stream). With one rank the sum is the identity: results must
+    be bit-identical to the un-hooked run, for Householder and for an L-BFGS apply + push."""
+    torch.cuda.set_device(dev)
+    ctx = lo.get_ctx(dev)
+    rng = np.random.default_rng(5)
+    n = 100_003
+    h = rng.standard_normal(n); h /= np.linalg.norm(h)
+    v = rng.uniform(-1, 1, n)
+    H = lo.opHouseholder(T(h, dev))
+    want = (H * T(v, dev)).clone()
+    hook = lo.sharded.NativeRcclHook(0, 1)
+    try:
+        hook.install(ctx)
+        assert torch.equal(H * T(v, dev), want)
+        B = lo.LBFGSOperator(n, mem=4, device=dev)
+        for s, y in pairs(rng, n, 6):
+            lo.push(B, T(s, dev), T(y, dev))
+        r1 = B * T(v, dev)
+        ctx.set_allreduce(None)
+        assert torch.equal(r1, B * T(v, dev))
+    finally:
+        ctx.set_allreduce(None)
+        torch.cuda.synchronize()
+        hook.close()

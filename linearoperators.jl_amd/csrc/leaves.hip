@@ -137,9 +137,27 @@ namespace {
 template <typename T>
 __global__ void __launch_bounds__(kBlock)
 sum_kernel(const T *__restrict__ v, int64_t n, double *__restrict__ partials) {
+  constexpr int VEC = Vec16<T>::N;
+  using V = typename Vec16<T>::type;
   double acc = 0.0;
-  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock)
-    acc += (double)v[i];
+  // 16-byte body when v is 16-byte aligned, 4 independent loads in flight per lane; scalar head/tail
+  const int64_t head = (((uintptr_t)v & 15u) == 0) ? 0 : n;   // unaligned: everything through the scalar loop
+  const int64_t nvec = head == 0 ? n / VEC : 0;
+  const V *vv = reinterpret_cast<const V *>(v);
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  for (; i + 3 * stride < nvec; i += 4 * stride) {
+    const V a = __builtin_nontemporal_load(vv + i), b = __builtin_nontemporal_load(vv + i + stride),
+            c = __builtin_nontemporal_load(vv + i + 2 * stride), d = __builtin_nontemporal_load(vv + i + 3 * stride);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) acc += ((double)a[e] + (double)b[e]) + ((double)c[e] + (double)d[e]);
+  }
+  for (; i < nvec; i += stride) {
+    const V a = vv[i];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) acc += (double)a[e];
+  }
+  for (int64_t k = nvec * VEC + (int64_t)blockIdx.x * kBlock + threadIdx.x; k < n; k += stride) acc += (double)v[k];
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
   __shared__ double lds[kBlock / kWave];

@@ -1,0 +1,371 @@
+# LinearOperatorsMXLOExt — the reference-side binding of libmxlo.so (include/mxlo.h).
+#
+# STATUS: NOT EXECUTED. The build image has no Julia; this file is the glue a maintainer would drop
+# next to ext/LinearOperatorsAMDGPUExt.jl. Every `ccall` below repeats, argument for argument, a call
+# that IS executed and tested from Python/ctypes (linearoperators.jl_amd/{leaves,qn,sharded}.py) and
+# from plain C (tests/abi_client.c). Signatures are those of include/mxlo.h.
+#
+# Design: the extension adds *methods* to the reference's own constructor names, selected by the
+# device vector type `MXVector{T}`. Each closure body is one `ccall`; flags, counters, `mul!`
+# dispatch, adjoint/transpose wrappers, combinators, cat, `Matrix(op)` stay the reference's code.
+module LinearOperatorsMXLOExt
+
+using LinearOperators, LinearAlgebra
+import LinearOperators: storage_type, LinearOperator, LinearOperatorException, AbstractQuasiNewtonOperator,
+  opDiagonal, opHouseholder, opHermitian, opRestriction, opEye, opOnes, opZeros, BlockDiagonalOperator,
+  LBFGSOperator, InverseLBFGSOperator, LSR1Operator, reset!, diag!, solve_shifted_system!, has_args5,
+  isallocated5
+import Base: kron, push!, size, getindex, view, fill!, copyto!, similar, length, unsafe_convert
+import LinearAlgebra: ldiv!
+
+const lib = "libmxlo"            # linearoperators.jl_amd/csrc/libmxlo.so on LD_LIBRARY_PATH
+const rccl = "libmxlo_rccl"      # optional: native RCCL transport of the all-reduce hook
+
+# ---- status codes -> the exception types the reference throws -----------------------------------
+lasterr() = unsafe_string(ccall((:mxlo_last_error, lib), Cstring, ()))
+@inline function check(st::Int32)
+  st == 0 && return nothing
+  st == 2 && throw(LinearOperatorException(lasterr()))     # MXLO_ESHAPE  (operations.jl:23-24)
+  st == 6 && throw(ArgumentError(lasterr()))               # MXLO_EDOMAIN (utilities.jl:213-215)
+  error(lasterr())                                         # ErrorException (lbfgs.jl:295-299, HIP errors)
+end
+
+# ---- context ---------------------------------------------------------------------------------------
+mutable struct Ctx
+  h::Ptr{Cvoid}
+end
+function Ctx(device::Integer = 0; stream::Ptr{Cvoid} = C_NULL)
+  r = Ref{Ptr{Cvoid}}()
+  check(ccall((:mxlo_ctx_create, lib), Int32, (Int32, Ptr{Cvoid}, Ptr{Ptr{Cvoid}}), device, stream, r))
+  finalizer(c -> ccall((:mxlo_ctx_destroy, lib), Int32, (Ptr{Cvoid},), c.h), Ctx(r[]))
+end
+const CTX = Ref{Ctx}()
+ctx() = (isassigned(CTX) || (CTX[] = Ctx(parse(Int, get(ENV, "LOCAL_RANK", "0")))); CTX[].h)
+synchronize() = check(ccall((:mxlo_ctx_sync, lib), Int32, (Ptr{Cvoid},), ctx()))
+
+# ---- device vector / matrix types --------------------------------------------------------------------
+"Dense device vector: plays `Vector{T}` for storage_type dispatch. Contiguous views are pointer+offset."
+mutable struct MXVector{T} <: AbstractVector{T}
+  ptr::Ptr{T}
+  len::Int
+  owner::Any            # nothing => owns the allocation; otherwise the parent kept alive by a view
+end
+function MXVector{T}(::UndefInitializer, n::Integer) where {T}
+  r = Ref{Ptr{Cvoid}}()
+  check(ccall((:mxlo_malloc, lib), Int32, (Ptr{Cvoid}, Int64, Ptr{Ptr{Cvoid}}), ctx(), max(n, 1) * sizeof(T), r))
+  v = MXVector{T}(Ptr{T}(r[]), n, nothing)
+  finalizer(x -> ccall((:mxlo_free, lib), Int32, (Ptr{Cvoid}, Ptr{Cvoid}), ctx(), x.ptr), v)
+end
+MXVector(h::Vector{T}) where {T} = copyto!(MXVector{T}(undef, length(h)), h)
+size(v::MXVector) = (v.len,)
+length(v::MXVector) = v.len
+similar(v::MXVector{T}) where {T} = MXVector{T}(undef, v.len)
+similar(v::MXVector, ::Type{T}, n::Integer) where {T} = MXVector{T}(undef, n)
+unsafe_convert(::Type{Ptr{Cvoid}}, v::MXVector) = Ptr{Cvoid}(v.ptr)
+getindex(v::MXVector, i::Integer) = error("scalar indexing of a device vector; use Array(v)")
+# contiguous views (cat.jl:17-18, special-operators.jl:263) stay device vectors: base pointer + offset
+view(v::MXVector{T}, r::UnitRange{<:Integer}) where {T} =
+  MXVector{T}(v.ptr + (first(r) - 1) * sizeof(T), length(r), v)
+function fill!(v::MXVector{T}, x) where {T}
+  iszero(x) || error("fill! with a non-zero value is not on the hot path")
+  check(ccall((:mxlo_memset, lib), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Int32, Int64), ctx(), v.ptr, 0, v.len * sizeof(T)))
+  v
+end
+function copyto!(d::MXVector{T}, s::Vector{T}) where {T}
+  GC.@preserve s check(ccall((:mxlo_memcpy_h2d, lib), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64),
+                             ctx(), d.ptr, pointer(s), d.len * sizeof(T)))
+  d
+end
+function copyto!(d::MXVector{T}, s::MXVector{T}) where {T}
+  check(ccall((:mxlo_memcpy_d2d, lib), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64),
+              ctx(), d.ptr, s.ptr, d.len * sizeof(T)))
+  d
+end
+function Base.Array(s::MXVector{T}) where {T}
+  h = Vector{T}(undef, s.len)
+  GC.@preserve h check(ccall((:mxlo_memcpy_d2h, lib), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64),
+                             ctx(), pointer(h), s.ptr, s.len * sizeof(T)))   # synchronises the ctx stream
+  h
+end
+
+"Dense column-major device matrix, leading dimension = m."
+struct MXMatrix{T} <: AbstractMatrix{T}
+  data::MXVector{T}
+  m::Int
+  n::Int
+end
+MXMatrix(A::Matrix{T}) where {T} = MXMatrix{T}(MXVector(vec(A)), size(A)...)
+size(A::MXMatrix) = (A.m, A.n)
+storage_type(::MXMatrix{T}) where {T} = MXVector{T}        # cf. ext/LinearOperatorsAMDGPUExt.jl:6
+
+dt(::Type{Float64}) = Int32(0)   # MXLO_F64
+dt(::Type{Float32}) = Int32(1)   # MXLO_F32
+# Julia does not convert caller scalars to T (SURVEY §8a "Mixed precision"): Float32 data with a
+# Float64 alpha or beta is evaluated per element in Float64 and rounded once on store.
+@inline flags(::Type{Float32}, α, β) = (α isa Float64 || β isa Float64) ? Int32(1) : Int32(0)  # MXLO_SCALARS_F64
+@inline flags(::Type{Float64}, α, β) = Int32(0)
+const P = Ptr{Cvoid}
+
+# ---- prod3! glue on MXVector (src/operations.jl:10-20) ----------------------------------------------------
+# `res .*= α`                       -> mxlo_scale
+# `res .= α .* Mv .+ β .* res`      -> mxlo_eye_mul without MXLO_TAIL_BETA (generic axpby)
+scale!(res::MXVector{T}, α) where {T} =
+  check(ccall((:mxlo_scale, lib), Int32, (P, Int32, P, Int64, Float64, Int32), ctx(), dt(T), res.ptr, res.len, α,
+              flags(T, α, α)))
+axpby!(res::MXVector{T}, v::MXVector{T}, α, β) where {T} =
+  check(ccall((:mxlo_eye_mul, lib), Int32, (P, Int32, P, P, Int64, Int64, Float64, Float64, Int32),
+              ctx(), dt(T), res.ptr, v.ptr, res.len, res.len, α, β, flags(T, α, β)))
+
+# ---- a3/a4 opDiagonal (src/special-operators.jl:125-165) ------------------------------------------------
+function opDiagonal(d::MXVector{T}) where {T}
+  n = length(d)
+  prod! = (res, v, α, β) -> check(ccall((:mxlo_diag_mul, lib), Int32,
+      (P, Int32, P, P, P, Int64, Int64, Float64, Float64, Int32),
+      ctx(), dt(T), res.ptr, d.ptr, v.ptr, n, n, α, β, flags(T, α, β)))
+  LinearOperator{T, MXVector{T}}(n, n, true, true, prod!, prod!, prod!)
+end
+function opDiagonal(nrow::I, ncol::I, d::MXVector{T}) where {T, I <: Integer}
+  nrow == ncol <= length(d) && return opDiagonal(d)
+  n_min = min(nrow, ncol)
+  # prod! writes nrow rows, tprod!/ctprod! write ncol rows; the tail is zeroed regardless of beta (:150)
+  prod! = (res, v, α, β) -> check(ccall((:mxlo_diag_mul, lib), Int32,
+      (P, Int32, P, P, P, Int64, Int64, Float64, Float64, Int32),
+      ctx(), dt(T), res.ptr, d.ptr, v.ptr, n_min, length(res), α, β, flags(T, α, β)))
+  LinearOperator{T, MXVector{T}}(nrow, ncol, false, false, prod!, prod!, prod!)
+end
+
+# ---- opEye / opOnes / opZeros with S = MXVector{T} (src/special-operators.jl:36-115) --------------------
+function opEye(::Type{T}, n::Int, ::Type{MXVector{T}}) where {T}
+  prod! = (res, v, α, β) -> check(ccall((:mxlo_eye_mul, lib), Int32,
+      (P, Int32, P, P, Int64, Int64, Float64, Float64, Int32),
+      ctx(), dt(T), res.ptr, v.ptr, n, length(res), α, β, flags(T, α, β) | Int32(4)))   # MXLO_TAIL_BETA
+  LinearOperator{T, MXVector{T}}(n, n, true, true, prod!, prod!, prod!)
+end
+function opOnes(::Type{T}, nrow::Int, ncol::Int, ::Type{MXVector{T}}) where {T}
+  prod! = (res, v, α, β) -> check(ccall((:mxlo_ones_mul, lib), Int32,
+      (P, Int32, P, Int64, P, Int64, Float64, Float64, Int32),
+      ctx(), dt(T), res.ptr, length(res), v.ptr, length(v), α, β, flags(T, α, β)))
+  LinearOperator{T, MXVector{T}}(nrow, ncol, nrow == ncol, nrow == ncol, prod!, prod!, prod!)
+end
+function opZeros(::Type{T}, nrow::Int, ncol::Int, ::Type{MXVector{T}}) where {T}
+  prod! = (res, v, α, β) -> check(ccall((:mxlo_zeros_mul, lib), Int32, (P, Int32, P, Int64, Float64, Int32),
+      ctx(), dt(T), res.ptr, length(res), β, flags(T, α, β)))
+  LinearOperator{T, MXVector{T}}(nrow, ncol, nrow == ncol, nrow == ncol, prod!, prod!, prod!)
+end
+
+# ---- a5 opHouseholder (src/linalg.jl:77-95; the reference hard-codes S = Vector{T} at :94) ----------------
+function opHouseholder(h::MXVector{T}) where {T}
+  n = length(h)
+  prod! = (res, v, α, β) -> check(ccall((:mxlo_householder_mul, lib), Int32,
+      (P, Int32, P, P, P, Int64, Float64, Float64, Int32),
+      ctx(), dt(T), res.ptr, h.ptr, v.ptr, n, α, β, flags(T, α, β)))
+  LinearOperator{T, MXVector{T}}(n, n, true, true, prod!, nothing, prod!)
+end
+
+# ---- a6 opHermitian (src/linalg.jl:97-127): the ORIGINAL matrix is passed; only tril(A,-1) is read ------------
+function opHermitian(d::MXVector{T}, A::MXMatrix{T}) where {T}
+  m, n = size(A)
+  m == n == length(d) || throw(LinearOperatorException("shape mismatch"))
+  prod! = (res, v, α, β) -> check(ccall((:mxlo_hermitian_mul, lib), Int32,
+      (P, Int32, P, P, P, Int64, P, Int64, Float64, Float64, Int32),
+      ctx(), dt(T), res.ptr, d.ptr, A.data.ptr, m, v.ptr, n, α, β, flags(T, α, β)))
+  LinearOperator{T, MXVector{T}}(m, m, true, true, prod!, nothing, nothing)
+end
+
+# ---- dense LinearOperator(M) (src/constructors.jl:19-29) ----------------------------------------------------
+function LinearOperator(M::MXMatrix{T}; symmetric = false, hermitian = false) where {T}
+  m, n = size(M)
+  gemv(mode) = (res, v, α, β) -> check(ccall((:mxlo_gemv, lib), Int32,
+      (P, Int32, P, P, Int64, Int64, Int64, P, Float64, Float64, Int32, Int32),
+      ctx(), dt(T), res.ptr, M.data.ptr, m, n, m, v.ptr, α, β, Int32(mode), flags(T, α, β)))
+  LinearOperator{T, MXVector{T}}(m, n, symmetric, hermitian, gemv(0), gemv(1), gemv(2))
+end
+
+# ---- a7 opRestriction / opExtension (src/special-operators.jl:167-222) ------------------------------------
+# The operator eltype is the INDEX integer type (:193); data eltype comes from `v`. alpha/beta are ignored
+# by the reference and are not ABI parameters. Index vectors live on the device as Int64, 1-based.
+struct ScatterPlan            # last-write-wins de-duplication, resolved once at construction
+  idx::MXVector{Int64}
+  pos::Union{MXVector{Int64}, Nothing}
+  n::Int
+end
+function ScatterPlan(I::AbstractVector{<:Integer})
+  last = Dict{Int64, Int64}()
+  for (k, i) in enumerate(I)
+    last[i] = k - 1                                   # 0-based source position of the surviving write
+  end
+  length(last) == length(I) && return ScatterPlan(MXVector(collect(Int64, I)), nothing, length(I))
+  ks = sort!(collect(keys(last)))
+  ScatterPlan(MXVector(ks), MXVector([last[i] for i in ks]), length(ks))
+end
+function opRestriction(Idx::Union{UnitRange{I}, StepRange{I, I}}, ncol::I, ::Type{MXVector{T}}) where {I <: Integer, T}
+  all(1 .≤ Idx .≤ ncol) || throw(LinearOperatorException("indices should be between 1 and $ncol"))
+  st, sp, len = Int64(first(Idx)), Int64(step(Idx)), Int64(length(Idx))
+  prod! = (res, v, α, β) -> check(ccall((:mxlo_gather_range, lib), Int32,
+      (P, Int32, P, P, Int64, Int64, Int64, Int64), ctx(), Int32(sizeof(eltype(v))), res.ptr, v.ptr, length(v), st, sp, len))
+  tprod! = (res, u, α, β) -> check(ccall((:mxlo_scatter_zero_range, lib), Int32,
+      (P, Int32, P, Int64, P, Int64, Int64, Int64), ctx(), Int32(sizeof(eltype(u))), res.ptr, length(res), u.ptr, st, sp, len))
+  LinearOperator{I, MXVector{T}}(len, ncol, false, false, prod!, tprod!, tprod!)
+end
+function opRestriction(Idx::Vector{I}, ncol::I, ::Type{MXVector{T}}) where {I <: Integer, T}
+  all(1 .≤ Idx .≤ ncol) || throw(LinearOperatorException("indices should be between 1 and $ncol"))
+  didx = MXVector(collect(Int64, Idx))
+  plan = ScatterPlan(Idx)
+  prod! = (res, v, α, β) -> check(ccall((:mxlo_gather, lib), Int32, (P, Int32, P, P, Int64, P, Int64),
+      ctx(), Int32(sizeof(eltype(v))), res.ptr, v.ptr, length(v), didx.ptr, length(didx)))
+  tprod! = (res, u, α, β) -> check(ccall((:mxlo_scatter_zero, lib), Int32, (P, Int32, P, Int64, P, P, P, Int64),
+      ctx(), Int32(sizeof(eltype(u))), res.ptr, length(res), u.ptr, plan.idx.ptr,
+      plan.pos === nothing ? C_NULL : plan.pos.ptr, plan.n))
+  LinearOperator{I, MXVector{T}}(length(Idx), ncol, false, false, prod!, tprod!, tprod!)
+end
+# opExtension(Idx, ncol; S) = opRestriction(Idx, ncol; S)' is the reference's own definition (:218-219).
+
+# ---- a8 BlockDiagonalOperator (src/special-operators.jl:249-294): ONE launch per apply --------------------
+struct BlockDesc                # mxlo_block_desc, 56 bytes, same field order as include/mxlo.h
+  kind::Int32
+  reserved::Int32
+  row_off::Int64
+  col_off::Int64
+  m::Int64
+  n::Int64
+  data::Ptr{Cvoid}
+  ld::Int64
+end
+mutable struct BlockDiagHandle
+  h::Ptr{Cvoid}
+  keep::Vector{Any}             # block operands stay alive as long as the descriptor table
+end
+"blocks: opDiagonal data vectors (MXVector), dense MXMatrix blocks, `(:eye, n)` or `(:zeros, m, n)`."
+function BlockDiagonalOperator(::Type{T}, blocks...; S = MXVector{T}) where {T}
+  descs = BlockDesc[]
+  r = c = 0
+  for b in blocks
+    if b isa MXVector
+      push!(descs, BlockDesc(0, 0, r, c, length(b), length(b), b.ptr, 0)); r += length(b); c += length(b)
+    elseif b isa MXMatrix
+      push!(descs, BlockDesc(1, 0, r, c, b.m, b.n, b.data.ptr, b.m)); r += b.m; c += b.n
+    elseif b[1] === :eye
+      push!(descs, BlockDesc(2, 0, r, c, b[2], b[2], C_NULL, 0)); r += b[2]; c += b[2]
+    else
+      push!(descs, BlockDesc(3, 0, r, c, b[2], b[3], C_NULL, 0)); r += b[2]; c += b[3]
+    end
+  end
+  out = Ref{Ptr{Cvoid}}()
+  check(ccall((:mxlo_blockdiag_create, lib), Int32, (P, Int32, Ptr{BlockDesc}, Int64, Ptr{P}),
+              ctx(), dt(T), descs, length(descs), out))
+  bd = finalizer(x -> ccall((:mxlo_blockdiag_destroy, lib), Int32, (P,), x.h), BlockDiagHandle(out[], collect(Any, blocks)))
+  mulmode(mode) = (res, v, α, β) -> check(ccall((:mxlo_blockdiag_mul, lib), Int32,
+      (P, P, P, Float64, Float64, Int32, Int32), bd.h, res.ptr, v.ptr, α, β, Int32(mode), flags(T, α, β)))
+  symm = all(b -> !(b isa MXMatrix) && !(b isa Tuple && b[1] === :zeros && b[2] != b[3]), blocks)
+  LinearOperator{T, S}(r, c, symm, symm, mulmode(0), mulmode(1), mulmode(2))
+end
+
+# ---- a9 kron (src/kron.jl:10-49): two MFMA GEMMs, no CPU copy of x (:16), work vector allocated once --------
+function kron(A::MXMatrix{T}, B::MXMatrix{T}) where {T}
+  m, n = size(A)
+  p, q = size(B)
+  work = MXVector{T}(undef, max(p * n, q * m))
+  mulmode(mode) = (res, x, α, β) -> check(ccall((:mxlo_kron_mul, lib), Int32,
+      (P, Int32, P, P, Int64, Int64, Int64, P, Int64, Int64, Int64, P, P, Float64, Float64, Int32, Int32),
+      ctx(), dt(T), res.ptr, A.data.ptr, m, n, m, B.data.ptr, p, q, p, x.ptr, work.ptr, α, β, Int32(mode),
+      flags(T, α, β)))
+  LinearOperator{T, MXVector{T}}(m * p, n * q, false, false, mulmode(0), mulmode(1), mulmode(2))
+end
+
+# ---- a12-a16 quasi-Newton operators: the structural contract (src/lbfgs.jl:62-104, src/lsr1.jl:39-78) ---------
+struct MXQNData                # stands in for op.data: fields the reference's tests read come from the handle
+  h::Ptr{Cvoid}
+  mem::Int
+end
+function scalars(d::MXQNData)
+  sc = Vector{Float64}(undef, 5); ys = Vector{Float64}(undef, d.mem); aux = Vector{Float64}(undef, d.mem)
+  check(ccall((:mxlo_qn_get_scalars, lib), Int32, (P, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}), d.h, sc, ys, aux))
+  (insert = Int(sc[1]), scaling_factor = sc[2], opnorm_upper_bound = sc[3], ys = ys, aux = aux)
+end
+Base.getproperty(d::MXQNData, s::Symbol) =
+  s === :h || s === :mem ? getfield(d, s) : getproperty(scalars(d), s)   # op.data.insert, .scaling_factor, .ys
+
+mutable struct MXQNOperator{T, F, Ft} <: AbstractQuasiNewtonOperator{T}
+  const nrow::Int
+  const ncol::Int
+  const symmetric::Bool
+  const hermitian::Bool
+  const prod!::F
+  const tprod!::Ft
+  const ctprod!::Ft
+  const kind::Int32             # MXLO_QN_LBFGS_INV / _FWD / _LSR1
+  const inverse::Bool
+  const data::MXQNData
+  nprod::Int
+  ntprod::Int
+  nctprod::Int
+end
+has_args5(::MXQNOperator) = true
+isallocated5(::MXQNOperator) = true
+storage_type(::MXQNOperator{T}) where {T} = MXVector{T}
+
+function mxqn(::Type{T}, kind::Integer, n::Int; mem::Int = 5, scaling::Bool = kind != 2, damped::Bool = false,
+              σ₂ = 0.99, σ₃ = 10.0) where {T}
+  r = Ref{Ptr{Cvoid}}()
+  check(ccall((:mxlo_qn_create, lib), Int32, (P, Int32, Int32, Int64, Int64, Int32, Int32, Float64, Float64, Ptr{P}),
+              ctx(), Int32(kind), dt(T), n, mem, scaling, damped, σ₂, σ₃, r))
+  h = r[]
+  prod! = (res, x, α, β) -> check(ccall((:mxlo_qn_mul, lib), Int32, (P, P, P, Float64, Float64, Int32),
+                                        h, res.ptr, x.ptr, α, β, flags(T, α, β)))
+  t = kind == 2 ? nothing : prod!                                 # L-SR1: tprod! = ctprod! = nothing (lsr1.jl:108-110)
+  op = MXQNOperator{T, typeof(prod!), typeof(t)}(n, n, true, true, prod!, t, t, Int32(kind), kind == 0,
+                                                 MXQNData(h, max(mem, 1)), 0, 0, 0)
+  finalizer(o -> ccall((:mxlo_qn_destroy, lib), Int32, (P,), o.data.h), op)
+end
+InverseLBFGSOperator(::Type{T}, n::Int, ::Type{MXVector{T}}; kw...) where {T} = mxqn(T, 0, n; kw...)
+LBFGSOperator(::Type{T}, n::Int, ::Type{MXVector{T}}; kw...) where {T} = mxqn(T, 1, n; kw...)
+LSR1Operator(::Type{T}, n::Int, ::Type{MXVector{T}}; kw...) where {T} = mxqn(T, 2, n; kw...)
+
+# push! ×3 (src/lbfgs.jl:269-357, src/lsr1.jl:119-184); rejection is silent, exactly like the reference.
+function push!(op::MXQNOperator{T}, s::MXVector{T}, y::MXVector{T}) where {T}
+  acc = Ref{Int32}(0)
+  check(ccall((:mxlo_qn_push, lib), Int32, (P, P, P, Ptr{Int32}), op.data.h, s.ptr, y.ptr, acc))
+  op
+end
+function push!(op::MXQNOperator{T}, s::MXVector{T}, y::MXVector{T}, Bs::MXVector{T}) where {T}
+  acc = Ref{Int32}(0)          # wrong variant -> MXLO_ESTATE -> ErrorException, as lbfgs.jl:295-299
+  check(ccall((:mxlo_qn_push_damped_fwd, lib), Int32, (P, P, P, P, Ptr{Int32}), op.data.h, s.ptr, y.ptr, Bs.ptr, acc))
+  op
+end
+function push!(op::MXQNOperator{T}, s::MXVector{T}, y::MXVector{T}, α::T, g::MXVector{T}, Bs::MXVector{T}) where {T}
+  acc = Ref{Int32}(0)
+  check(ccall((:mxlo_qn_push_damped_inv, lib), Int32, (P, P, P, Float64, P, P, Ptr{Int32}),
+              op.data.h, s.ptr, y.ptr, α, g.ptr, Bs.ptr, acc))
+  op
+end
+function reset!(op::MXQNOperator)
+  check(ccall((:mxlo_qn_reset, lib), Int32, (P,), op.data.h))
+  op.nprod = op.ntprod = op.nctprod = 0
+  op
+end
+function diag!(op::MXQNOperator{T}, d::MXVector{T}) where {T}
+  check(ccall((:mxlo_qn_diag, lib), Int32, (P, P), op.data.h, d.ptr))
+  d
+end
+LinearAlgebra.diag(op::MXQNOperator{T}) where {T} = diag!(op, MXVector{T}(undef, op.nrow))
+
+# solve_shifted_system! / ldiv! (src/utilities.jl:207-248, 281-289); returns x itself (test_solve_shifted_system.jl:33)
+function solve_shifted_system!(x::MXVector{T}, B::MXQNOperator{T}, b::MXVector{T}, σ::T) where {T}
+  check(ccall((:mxlo_qn_solve_shifted, lib), Int32, (P, P, P, Float64), B.data.h, x.ptr, b.ptr, σ))
+  x
+end
+ldiv!(x::MXVector{T}, B::MXQNOperator{T}, b::MXVector{T}) where {T} = solve_shifted_system!(x, B, b, zero(T))
+
+# ---- row sharding: one Julia process per GPU (DESIGN.md §6) -------------------------------------------------
+"`id` = the 128 bytes rank 0 obtained from `rccl_unique_id()`, broadcast by MPI.jl / a file / sockets."
+rccl_unique_id() = (id = zeros(UInt8, 128); check(ccall((:mxlo_rccl_unique_id, rccl), Int32, (Ptr{UInt8},), id)); id)
+function install_rccl!(rank::Integer, world::Integer, id::Vector{UInt8})
+  comm = Ref{Ptr{Cvoid}}()
+  ccall((:mxlo_rccl_comm_create, rccl), Int32, (Int32, Int32, Ptr{UInt8}, Ptr{P}), rank, world, id, comm) == 0 ||
+    error(unsafe_string(ccall((:mxlo_rccl_last_error, rccl), Cstring, ())))
+  hook = cglobal((:mxlo_rccl_allreduce_hook, rccl))          # a C function: no Julia code runs inside an apply
+  check(ccall((:mxlo_ctx_set_allreduce, lib), Int32, (P, P, P), ctx(), hook, comm[]))
+  comm[]
+end
+
+end # module

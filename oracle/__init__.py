@@ -34,8 +34,27 @@ def build(force: bool = False) -> str:
     """Compile the C restatement with gcc (``make -C oracle``)."""
     src_m = max(os.path.getmtime(os.path.join(_HERE, f)) for f in ("lo_oracle.c", "lo_oracle_impl.h"))
     if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < src_m:
-        subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "liblo_oracle.so"])
+        subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "all"])
     return _LIB_PATH
+
+
+_MT_PATH = os.path.join(_HERE, "liblo_oracle_mt.so")
+_mt = None
+
+
+def mt_lib() -> C.CDLL:
+    """All-core (OpenMP) timing variant, bench.py cpu_baseline upper bound only (lo_oracle_mt.c)."""
+    global _mt
+    if _mt is None:
+        src = os.path.join(_HERE, "lo_oracle_mt.c")
+        if not os.path.exists(_MT_PATH) or os.path.getmtime(_MT_PATH) < os.path.getmtime(src):
+            subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "liblo_oracle_mt.so"])
+        _mt = C.CDLL(_MT_PATH)
+        _mt.orc_mt_fill_f64.argtypes = [C.c_void_p, C.c_int64, C.c_uint64, C.c_double, C.c_double, C.c_int32]
+        _mt.orc_mt_householder_mul_f64.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_double,
+                                                   C.c_double, C.c_int32]
+        _mt.orc_mt_max_threads.restype = C.c_int32
+    return _mt
 
 
 _lib = None

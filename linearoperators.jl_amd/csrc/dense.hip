@@ -468,119 +468,136 @@ int32_t gemv_any(mxlo_ctx *ctx, T *res, const T *M, int64_t m, int64_t n, int64_
 }
 
 // ---- opHermitian, single pass over the strict lower triangle -------------------------------------
-// The triangle is cut into panels of 256 rows x 32 columns (row group G, column tile J, J <= 8G+7); one
-// workgroup per panel reads it ONCE — a wave-load is 1 KiB contiguous down one column, a panel column is
-// 2 KiB contiguous — and produces both of its contributions:
-//   rows  : Prow[J][256G + r] = sum_c L[r][c] * v[32J + c]        (part of L*v)
-//   cols  : Pcol[G][32J + c]  = sum_r L[r][c] * v[256G + r]       (part of L'*v)
-// A second tiny kernel adds the partials in a FIXED order (deterministic, no float atomics) and applies
-//   res = alpha*((d.*v + L*v) + L'*v) (+ beta*res)                  (src/linalg.jl:99-101).
-// HBM traffic: 4n^2 B for the triangle + ~0.3n^2 B of partials, vs 8n^2 for two triangular GEMVs and
+// The triangle is cut into tiles of 256 rows x 32 columns (row group G, column tile J <= 8G+7); one workgroup
+// owns a STRIP of 8 consecutive tiles of one row group (a 256 x 256 block; strip s <= G) and reads it ONCE —
+// a wave-load is 1 KiB contiguous down one column. Per tile every wave produces, without any barrier,
+//   cols  : Pcol[2G + half][32J + c] = sum over its 128 rows of L[r][c] * v[256G + r]      (part of L'*v)
+// (halving butterfly across the 64 lanes) and keeps accumulating in registers
+//   rows  : Prow[s][256G + r] = sum over the strip's columns of L[r][c] * v[c]             (part of L*v)
+// which goes through LDS once per strip. Because waves run barrier-free over 8 tiles they drift apart and
+// the reductions of one wave overlap the loads of the others (per-tile workgroups: 203 us, strips: 177 us
+// at n = 16384, `tune_herm2.hip`). A second tiny kernel adds the partials in a FIXED order (deterministic,
+// no float atomics) and applies   res = alpha*((d.*v + L*v) + L'*v) (+ beta*res)   (src/linalg.jl:99-101).
+// HBM traffic: 4n^2 B for the triangle + ~0.1n^2 B of partials, vs 8n^2 for two triangular GEMVs and
 // 16n^2 for the reference (two full GEMVs over tril(A,-1) stored with explicit zeros).
-constexpr int HR = 256, HC = 32;
+constexpr int HR = 256, HC = 32;   // tile rows, tile columns
 
-template <typename T, bool ALIGNED>
+// C = tiles per strip (8, 2 or 1: fewer when the triangle is too small to fill the chip with 256x256 strips),
+// qint = 8/C_strip strips per 256 columns. Row group G owns qint*G + 8 slots of row partials: one per strip
+// left of its diagonal block, one per tile of the diagonal block.
+//   EDGE = false: strips of full row groups, every tile strictly below the diagonal and inside the matrix
+//                 (no masking code at all, 16-byte loads);
+//   EDGE = true : masked loads. mode 0: the same strips when A is not 16-byte aligned; mode 1: the strips of
+//                 the ragged last row group; mode 2 (instantiated with C = 1): the 8 tiles of a diagonal block,
+//                 one workgroup each, so that the short diagonal pass still fills the chip.
+template <typename T, int C, bool EDGE>
 __global__ void __launch_bounds__(kBlock)
-herm_panel_kernel(const T *__restrict__ A, int64_t lda, const T *__restrict__ v, int64_t n,
-                  double *__restrict__ Prow, double *__restrict__ Pcol) {
-  // panel index t -> (G, J) with t = 4G(G+1) + J, 0 <= J <= 8G+7
+herm_strip_kernel(const T *__restrict__ A, int64_t lda, const T *__restrict__ v, int64_t n,
+                  double *__restrict__ Prow, double *__restrict__ Pcol, int64_t ng, int qint, int mode) {
+  typedef T V2 __attribute__((ext_vector_type(2)));
+  constexpr int HS = C;
   const int64_t t = blockIdx.x;
-  int64_t G = (int64_t)((sqrt(1.0 + (double)t) - 1.0) * 0.5);
-  while (4 * G * (G + 1) > t) --G;
-  while (4 * (G + 1) * (G + 2) <= t) ++G;
-  const int64_t J = t - 4 * G * (G + 1);
-  const int64_t i0 = G * HR, j0 = J * HC;
-  if (j0 >= n) return;                       // ragged last row group: tiles past the matrix
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int rp = tid & 127, cg = tid >> 7;   // rows 2rp, 2rp+1 of the panel; columns cg + 2k, k < 16
+  int64_t G, tile0, slot;                    // row group, first column tile, row-partial slot
+  if (!EDGE || mode == 0) {                  // triangular enumeration u = G'(G'+1)/2 + r, r <= G'; G = G'+1
+    constexpr int Q = 8 / C;
+    const int64_t u = t / Q;
+    int64_t Gp = (int64_t)((sqrt(8.0 * (double)u + 1.0) - 1.0) * 0.5);
+    while (Gp * (Gp + 1) / 2 > u) --Gp;
+    while ((Gp + 1) * (Gp + 2) / 2 <= u) ++Gp;
+    G = Gp + 1;
+    slot = (u - Gp * (Gp + 1) / 2) * Q + t % Q;          // strip s < Q*G
+    tile0 = slot * C;
+  } else if (mode == 1) {                    // strips left of the diagonal block of the last row group
+    G = ng - 1;
+    slot = t;
+    tile0 = slot * C;
+  } else {                                   // diagonal block of row group t/8, tile t%8
+    G = t / 8;
+    tile0 = 8 * G + t % 8;
+    slot = (int64_t)qint * G + t % 8;
+  }
+  const int64_t i0 = G * HR;
+  const int tid = threadIdx.x, lane = tid & 63, rp = tid & 127;   // rows 2rp, 2rp+1 of the row group
+  const int cg = __builtin_amdgcn_readfirstlane(tid >> 7);          // columns cg + 2k, k < 16, of each tile
+  const int half = __builtin_amdgcn_readfirstlane((tid >> 6) & 1);  // which 128 rows this wave covers
   const int64_t gr = i0 + 2 * rp;
-  const double vr0 = gr < n ? (double)v[gr] : 0.0, vr1 = gr + 1 < n ? (double)v[gr + 1] : 0.0;
-  T e0[16], e1[16];
-#pragma unroll
-  for (int k = 0; k < 16; ++k) {
-    const int64_t gc = j0 + cg + 2 * k;
-    e0[k] = 0;
-    e1[k] = 0;
-    if (gc < n && gr + 1 > gc) {             // at least the second row is strictly below the diagonal
-      const T *p = A + gr + gc * lda;
-      if constexpr (ALIGNED) {
-        if (gr + 1 < n) {
-          typedef T V2 __attribute__((ext_vector_type(2)));
-          const V2 x = __builtin_nontemporal_load(reinterpret_cast<const V2 *>(p));
-          e0[k] = x[0];
-          e1[k] = x[1];
-        } else if (gr < n) {
-          e0[k] = p[0];
-        }
-      } else {
-        if (gr < n) e0[k] = p[0];
-        if (gr + 1 < n) e1[k] = p[1];
-      }
-      if (!(gr > gc)) e0[k] = 0;             // strict lower triangle only
-    }
-  }
+  const double vr0 = (!EDGE || gr < n) ? (double)v[gr] : 0.0, vr1 = (!EDGE || gr + 1 < n) ? (double)v[gr + 1] : 0.0;
   double prow0 = 0.0, prow1 = 0.0;
-  double pcol[16];
+  for (int jt = 0; jt < HS; ++jt) {
+    const int64_t j0 = (tile0 + jt) * HC;
+    if (EDGE && j0 >= n) break;              // ragged last row group: tiles past the matrix
+    V2 e[16];
+    if constexpr (!EDGE) {                   // every element is strictly below the diagonal and inside
+      const T *base = A + (j0 + cg) * lda + gr;
 #pragma unroll
-  for (int k = 0; k < 16; ++k) {
-    const int64_t gc = j0 + cg + 2 * k;
-    const double vc = gc < n ? (double)v[gc] : 0.0;
-    prow0 = fma((double)e0[k], vc, prow0);
-    prow1 = fma((double)e1[k], vc, prow1);
-    pcol[k] = fma((double)e1[k], vr1, (double)e0[k] * vr0);
-  }
-  // column sums over the 64 lanes of the wave: halving butterfly (8+4+2+1 shuffles leave one value per
-  // lane, column k = lane bits 5..2), two plain steps finish: 17 shuffles instead of 96.
-  double w8[8], w4[4], w2[2], w1;
-  {
+      for (int k = 0; k < 16; ++k)
+        e[k] = __builtin_nontemporal_load(reinterpret_cast<const V2 *>(base + (int64_t)(2 * k) * lda));
+    } else {
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        const int64_t gc = j0 + cg + 2 * k;
+        T x0 = 0, x1 = 0;
+        if (gc < n && gr + 1 > gc) {           // at least the second row is strictly below the diagonal
+          const T *p = A + gr + gc * lda;
+          if (gr > gc && gr < n) x0 = p[0];    // strict lower triangle only
+          if (gr + 1 < n) x1 = p[1];
+        }
+        e[k][0] = x0;
+        e[k][1] = x1;
+      }
+    }
+    // FMAs + first butterfly stage, column pair (q, q+8) at a time (keeps the live set at ~90 VGPRs)
     const bool hi = (lane & 32) != 0;
+    double w8[8], w4[4], w2[2], w1;
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
-      const double send = hi ? pcol[q] : pcol[8 + q];
-      w8[q] = (hi ? pcol[8 + q] : pcol[q]) + __shfl_xor(send, 32, 64);
+      const int64_t ca = j0 + cg + 2 * q, cb = ca + 16;
+      const double vca = (!EDGE || ca < n) ? (double)v[ca] : 0.0, vcb = (!EDGE || cb < n) ? (double)v[cb] : 0.0;
+      const double a0 = (double)e[q][0], a1 = (double)e[q][1], b0 = (double)e[q + 8][0], b1 = (double)e[q + 8][1];
+      prow0 = fma(a0, vca, prow0);
+      prow1 = fma(a1, vca, prow1);
+      prow0 = fma(b0, vcb, prow0);
+      prow1 = fma(b1, vcb, prow1);
+      const double pa = fma(a1, vr1, a0 * vr0), pb = fma(b1, vr1, b0 * vr0);
+      w8[q] = (hi ? pb : pa) + __shfl_xor(hi ? pa : pb, 32, 64);
+      __builtin_amdgcn_sched_barrier(0);
     }
-  }
-  {
-    const bool hi = (lane & 16) != 0;
+    // remaining halving steps: 4+2+1 exchanges leave one column per group of 4 lanes, two plain steps finish
+    {
+      const bool h2 = (lane & 16) != 0;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const double send = hi ? w8[q] : w8[4 + q];
-      w4[q] = (hi ? w8[4 + q] : w8[q]) + __shfl_xor(send, 16, 64);
+      for (int q = 0; q < 4; ++q) {
+        const double send = h2 ? w8[q] : w8[4 + q];
+        w4[q] = (h2 ? w8[4 + q] : w8[q]) + __shfl_xor(send, 16, 64);
+      }
     }
-  }
-  {
-    const bool hi = (lane & 8) != 0;
+    {
+      const bool h2 = (lane & 8) != 0;
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const double send = hi ? w4[q] : w4[2 + q];
-      w2[q] = (hi ? w4[2 + q] : w4[q]) + __shfl_xor(send, 8, 64);
+      for (int q = 0; q < 2; ++q) {
+        const double send = h2 ? w4[q] : w4[2 + q];
+        w2[q] = (h2 ? w4[2 + q] : w4[q]) + __shfl_xor(send, 8, 64);
+      }
+    }
+    {
+      const bool h2 = (lane & 4) != 0;
+      const double send = h2 ? w2[0] : w2[1];
+      w1 = (h2 ? w2[1] : w2[0]) + __shfl_xor(send, 4, 64);
+    }
+    w1 += __shfl_xor(w1, 2, 64);
+    w1 += __shfl_xor(w1, 1, 64);
+    if ((lane & 3) == 0) {
+      const int k = ((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1);
+      const int64_t gc = j0 + cg + 2 * k;
+      if (!EDGE || gc < n) Pcol[(2 * G + half) * n + gc] = w1;
     }
   }
-  {
-    const bool hi = (lane & 4) != 0;
-    const double send = hi ? w2[0] : w2[1];
-    w1 = (hi ? w2[1] : w2[0]) + __shfl_xor(send, 4, 64);
-  }
-  w1 += __shfl_xor(w1, 2, 64);
-  w1 += __shfl_xor(w1, 1, 64);
-  __shared__ double colred[4][16];
   __shared__ double rowred[2][HR];
-  if ((lane & 3) == 0) {
-    const int k = ((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1);
-    colred[wave][k] = w1;
-  }
   rowred[cg][2 * rp] = prow0;
   rowred[cg][2 * rp + 1] = prow1;
   __syncthreads();
-  if (tid < HC) {                            // waves (2cg, 2cg+1) hold the two row halves of column group cg
-    const int c_cg = tid & 1, k = tid >> 1;  // column cg + 2k  <->  tid = cg + 2k
-    const int64_t gc = j0 + tid;
-    if (gc < n) Pcol[G * n + gc] = colred[2 * c_cg][k] + colred[2 * c_cg + 1][k];
-  }
-  {
-    const int64_t row = i0 + tid;
-    if (row < n) Prow[J * n + row] = rowred[0][tid] + rowred[1][tid];
-  }
+  const int64_t row = i0 + tid;
+  if (row < n) Prow[slot * n + row] = rowred[0][tid] + rowred[1][tid];
 }
 
 // 32 rows per workgroup, 8 lanes per row: lane `sub` adds partials sub, sub+8, ... (independent loads in
@@ -589,17 +606,15 @@ template <typename T, typename CT, bool BETA0>
 __global__ void __launch_bounds__(kBlock)
 herm_finish_kernel(T *__restrict__ res, const T *__restrict__ d, const T *__restrict__ v,
                    const double *__restrict__ Prow, const double *__restrict__ Pcol, int64_t n, int ng,
-                   int nbc, CT alpha, CT beta) {
+                   int q, CT alpha, CT beta) {
   const int r = threadIdx.x & 31, sub = threadIdx.x >> 5;
   const int64_t i = (int64_t)blockIdx.x * 32 + r;
   __shared__ double s1[8][32], s2[8][32];
   double t1 = 0.0, t2 = 0.0;
   if (i < n) {
     const int G = (int)(i / HR);
-    int jmax = 8 * G + 7;
-    if (jmax > nbc - 1) jmax = nbc - 1;
-    for (int J = sub; J <= jmax; J += 8) t1 += Prow[(int64_t)J * n + i];     // L*v : panels (G, J <= 8G+7)
-    for (int g = G + sub; g < ng; g += 8) t2 += Pcol[(int64_t)g * n + i];    // L'*v: panels (g >= i/256, i/32)
+    for (int sx = sub; sx < q * G + 8; sx += 8) t1 += Prow[(int64_t)sx * n + i];     // L*v : q*G strips + 8 diagonal tiles
+    for (int h = 2 * G + sub; h < 2 * ng; h += 8) t2 += Pcol[(int64_t)h * n + i];   // L'*v: 128-row halves at/below i
   }
   s1[sub][r] = t1;
   s2[sub][r] = t2;
@@ -628,11 +643,14 @@ template <typename T>
 int32_t hermitian_t(mxlo_ctx *ctx, T *res, const T *d, const T *A, int64_t lda, const T *v, int64_t n,
                     double alpha, double beta, int32_t flags) {
   if (n == 0) return MXLO_OK;
-  const int64_t ng = (n + HR - 1) / HR, nbc = (n + HC - 1) / HC;
-  const int64_t npanels = 4 * ng * (ng + 1);
-  MXLO_REQUIRE(npanels < (1LL << 31), MXLO_ESHAPE, "opHermitian: n too large");
+  const int64_t ng = (n + HR - 1) / HR, ngf = n / HR;
+  MXLO_REQUIRE(4 * ng * (ng + 1) < (1LL << 31), MXLO_ESHAPE, "opHermitian: n too large");
+  // tiles per strip: 256x256 strips once they fill the chip four times over, thinner strips below that
+  const int64_t full = ng * (ng + 1) / 2;
+  const int C = full >= 4 * ctx->num_cu ? 8 : (4 * full >= 4 * ctx->num_cu ? 2 : 1), Q = 8 / C;
   HermScratch &hs = g_herm[ctx->device & 63];
-  const size_t need = sizeof(double) * ((size_t)nbc + (size_t)ng) * (size_t)n;
+  const int64_t nslots = Q * (ng - 1) + 8;
+  const size_t need = sizeof(double) * (size_t)(nslots + 2 * ng) * (size_t)n;   // Prow[nslots][n], Pcol[2ng][n]
   if (hs.bytes < need) {
     if (hs.buf) {
       MXLO_HIP(hipStreamSynchronize(ctx->stream));
@@ -644,19 +662,34 @@ int32_t hermitian_t(mxlo_ctx *ctx, T *res, const T *d, const T *A, int64_t lda, 
     MXLO_REQUIRE(e == hipSuccess, MXLO_ENOMEM, "opHermitian scratch: %s", hipGetErrorString(e));
     hs.bytes = need;
   }
-  double *Prow = (double *)hs.buf, *Pcol = Prow + (size_t)nbc * n;
-  const bool aligned = sizeof(T) == 8 && (((uintptr_t)A & 15u) == 0) && (lda % 2 == 0);
-  if (aligned)
-    hipLaunchKernelGGL((herm_panel_kernel<T, true>), dim3((unsigned)npanels), dim3(kBlock), 0, ctx->stream, A,
-                       lda, v, n, Prow, Pcol);
-  else
-    hipLaunchKernelGGL((herm_panel_kernel<T, false>), dim3((unsigned)npanels), dim3(kBlock), 0, ctx->stream, A,
-                       lda, v, n, Prow, Pcol);
+  double *Prow = (double *)hs.buf, *Pcol = Prow + (size_t)nslots * n;
+  const bool aligned = (((uintptr_t)A % (2 * sizeof(T))) == 0) && (lda % 2 == 0);
+  // full row groups whose strips take the unmasked kernel; the rest of the strips go through the masked one
+  const int64_t gi = aligned ? ngf : 0;
+  const int64_t n_int = gi > 1 ? Q * gi * (gi - 1) / 2 : 0;
+  const int64_t n_all = !aligned && ng > 1 ? Q * ng * (ng - 1) / 2 : 0;       // mode 0, masked
+  const int64_t n_last = aligned && ng > ngf ? Q * (ng - 1) : 0;               // mode 1
+#define HERM_GO(C_)                                                                                            \
+  {                                                                                                            \
+    if (n_int > 0)                                                                                             \
+      hipLaunchKernelGGL((herm_strip_kernel<T, C_, false>), dim3((unsigned)n_int), dim3(kBlock), 0,            \
+                         ctx->stream, A, lda, v, n, Prow, Pcol, ng, Q, 0);                                     \
+    if (n_all > 0)                                                                                             \
+      hipLaunchKernelGGL((herm_strip_kernel<T, C_, true>), dim3((unsigned)n_all), dim3(kBlock), 0,             \
+                         ctx->stream, A, lda, v, n, Prow, Pcol, ng, Q, 0);                                     \
+    if (n_last > 0)                                                                                            \
+      hipLaunchKernelGGL((herm_strip_kernel<T, C_, true>), dim3((unsigned)n_last), dim3(kBlock), 0,            \
+                         ctx->stream, A, lda, v, n, Prow, Pcol, ng, Q, 1);                                     \
+  }
+  if (C == 8) HERM_GO(8) else if (C == 2) HERM_GO(2) else HERM_GO(1)
+#undef HERM_GO
+  hipLaunchKernelGGL((herm_strip_kernel<T, 1, true>), dim3((unsigned)(8 * ng)), dim3(kBlock), 0, ctx->stream, A,
+                     lda, v, n, Prow, Pcol, ng, Q, 2);
   MXLO_LAUNCH_CHECK();
   const unsigned blocks = (unsigned)((n + 31) / 32);
   return dispatch_ct<T>(beta, flags, [&]<typename CT, bool B0>() -> int32_t {
     hipLaunchKernelGGL((herm_finish_kernel<T, CT, B0>), dim3(blocks), dim3(kBlock), 0, ctx->stream, res, d, v,
-                       Prow, Pcol, n, (int)ng, (int)nbc, (CT)alpha, (CT)beta);
+                       Prow, Pcol, n, (int)ng, Q, (CT)alpha, (CT)beta);
     MXLO_LAUNCH_CHECK();
     return MXLO_OK;
   });

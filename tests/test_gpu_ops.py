@@ -80,6 +80,31 @@ def test_hermitian(lo, dev, dtype, n):
         lo.opHermitian(T(d, dev)[: max(n - 1, 0)], TM(A, dev)) if n > 1 else (_ for _ in ()).throw(lo.LinearOperatorException("x"))
 
 
+@pytest.mark.parametrize("n,dtype", [(5700, torch.float64), (5889, torch.float64), (5700, torch.float32),
+                                     (11776, torch.float64), (11585, torch.float64), (11586, torch.float32)])
+def test_hermitian_strip_regimes(lo, dev, dtype, n):
+    """Every strip length of the single-pass kernel (1, 2, 8 tiles per workgroup), ragged last row groups and the
+    unaligned (odd leading dimension) path, against the oracle restatement of mulHermitian! (linalg.jl:97-103)."""
+    rng = np.random.default_rng(n)
+    npd = NP[dtype]
+    A = rng.standard_normal((n, n)).astype(npd)
+    d = rng.standard_normal(n).astype(npd)
+    v = SV(n).astype(npd)
+    r0 = rng.standard_normal(n).astype(npd)
+    tol = 1e-12 if dtype == torch.float64 else 3e-5
+    H = lo.opHermitian(T(d, dev), TM(A, dev))
+    fl = oracle.SCALARS_F64 if dtype == torch.float32 else 0
+    res = T(r0.copy(), dev)
+    lo.mul(res, H, T(v, dev), 3.0, -4.0)
+    assert rel(res.cpu().numpy(), oracle.hermitian_mul(r0.copy(), d, A, v, 3.0, -4.0, flags=fl)) <= tol
+    res2 = T(np.full(n, np.nan, dtype=npd), dev)                 # beta == 0 never reads res
+    lo.mul(res2, H, T(v, dev), 1.0, 0.0)
+    assert rel(res2.cpu().numpy(), oracle.hermitian_mul(r0.copy(), d, A, v, 1.0, 0.0, flags=fl)) <= tol
+    res3 = T(np.full(n, np.nan, dtype=npd), dev)                 # deterministic: bit-identical on repeat
+    lo.mul(res3, H, T(v, dev), 1.0, 0.0)
+    assert torch.equal(res2, res3)
+
+
 @pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
 @pytest.mark.parametrize("shapes", [((3, 5), (4, 2)), ((1, 1), (7, 3)), ((16, 16), (16, 16)), ((70, 33), (65, 129)),
                                     ((64, 64), (128, 64))])

@@ -378,14 +378,24 @@ gemv_n_partial_kernel(double *__restrict__ part, const T *__restrict__ M, int64_
   part[(int64_t)blockIdx.y * m + i] = acc0;
 }
 
+// 32 rows per workgroup, 8 lanes per row: lane `sub` adds chunks sub, sub+8, ... (independent loads in flight),
+// the 8 sub-sums are combined in a fixed order -> deterministic, and m/32 workgroups instead of m/256.
 template <typename T, typename CT, bool BETA0>
 __global__ void __launch_bounds__(kBlock)
 gemv_n_finish_kernel(T *__restrict__ res, const double *__restrict__ part, int64_t m, int nchunks,
                      CT alpha, CT beta, T *__restrict__ raw_out) {
-  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (i >= m) return;
+  const int r = threadIdx.x & 31, sub = threadIdx.x >> 5;
+  const int64_t i = (int64_t)blockIdx.x * 32 + r;
+  __shared__ double sred[8][32];
+  double a = 0.0;
+  if (i < m)
+    for (int c = sub; c < nchunks; c += 8) a += part[(int64_t)c * m + i];
+  sred[sub][r] = a;
+  __syncthreads();
+  if (sub != 0 || i >= m) return;
   double acc = 0.0;
-  for (int c = 0; c < nchunks; ++c) acc += part[(int64_t)c * m + i];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) acc += sred[q][r];
   if (raw_out) {
     raw_out[i] = (T)acc;
     return;
@@ -420,7 +430,7 @@ int32_t gemv_n(mxlo_ctx *ctx, T *res, const T *M, int64_t m, int64_t n, int64_t 
     hipLaunchKernelGGL((gemv_n_partial_kernel<T, false>), grid, dim3(kBlock), 0, ctx->stream, ctx->partials, M, m,
                        n, ld, v, cpc > 0 ? cpc : 1);
   MXLO_LAUNCH_CHECK();
-  const unsigned fin_blocks = (unsigned)((m + kBlock - 1) / kBlock);
+  const unsigned fin_blocks = (unsigned)((m + 31) / 32);
   return dispatch_ct<T>(beta, flags, [&]<typename CT, bool B0>() -> int32_t {
     hipLaunchKernelGGL((gemv_n_finish_kernel<T, CT, B0>), dim3(fin_blocks), dim3(kBlock), 0, ctx->stream, res,
                        ctx->partials, m, (int)nchunks, (CT)alpha, (CT)beta, (T *)nullptr);

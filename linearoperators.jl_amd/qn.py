@@ -144,22 +144,30 @@ def _targs(T, n):
     return T, n
 
 
+def _kw(kw, sigma2, sigma3):
+    """The reference's keyword spellings (σ₂, σ₃; `inverse` is fixed by the constructor name); anything else
+    is an error, as a Julia keyword typo would be (MethodError)."""
+    kw.pop("inverse", None)
+    s2, s3 = kw.pop("σ₂", sigma2), kw.pop("σ₃", sigma3)
+    if kw:
+        raise TypeError(f"unsupported keyword argument(s): {sorted(kw)}")
+    return s2, s3
+
+
 def InverseLBFGSOperator(T, n: Optional[int] = None, mem: int = 5, scaling: bool = True, damped: bool = False,
                          sigma2: float = 0.99, sigma3: float = 10.0, device=None, **kw):
     """InverseLBFGSOperator(T, n; mem=5, scaling=true, damped=false, σ₂=0.99, σ₃=10.0) — src/lbfgs.jl:106-160."""
     T, n = _targs(T, n)
-    kw.pop("inverse", None)
-    return LBFGSOperatorType(_lib.QN_LBFGS_INV, T, n, mem, scaling, damped, kw.pop("σ₂", sigma2), kw.pop("σ₃", sigma3),
-                             device)
+    s2, s3 = _kw(kw, sigma2, sigma3)
+    return LBFGSOperatorType(_lib.QN_LBFGS_INV, T, n, mem, scaling, damped, s2, s3, device)
 
 
 def LBFGSOperator(T, n: Optional[int] = None, mem: int = 5, scaling: bool = True, damped: bool = False,
                   sigma2: float = 0.99, sigma3: float = 10.0, device=None, **kw):
     """LBFGSOperator(T, n; mem=5, scaling=true, ...) forward form — src/lbfgs.jl:162-208."""
     T, n = _targs(T, n)
-    kw.pop("inverse", None)
-    return LBFGSOperatorType(_lib.QN_LBFGS_FWD, T, n, mem, scaling, damped, kw.pop("σ₂", sigma2), kw.pop("σ₃", sigma3),
-                             device)
+    s2, s3 = _kw(kw, sigma2, sigma3)
+    return LBFGSOperatorType(_lib.QN_LBFGS_FWD, T, n, mem, scaling, damped, s2, s3, device)
 
 
 def LSR1Operator(T, n: Optional[int] = None, mem: int = 5, scaling: bool = True, device=None):

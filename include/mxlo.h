@@ -291,6 +291,14 @@ int32_t mxlo_qn_push_damped_inv(mxlo_qn *h, const void *s, void *y, double alpha
 int32_t mxlo_qn_mul(mxlo_qn *h, void *res, const void *x, double alpha, double beta,
                     int32_t flags);
 
+/* ShiftedOperator(H, sigma) with H a quasi-Newton operator — shifted_prod! src/shifted_operators.jl:16-25:
+ *   mul!(res, H, x, alpha, beta);  iszero(sigma) || iszero(alpha) || axpy!(alpha*sigma, x, res)
+ * fused into the combine pass of the apply (x is already in registers there): one launch and 3 vector
+ * passes fewer, with the SAME per-element rounding sequence as the two separate calls (bit-identical to
+ * mxlo_qn_mul followed by the axpy in T arithmetic). H is symmetric: tprod!/ctprod! are the same call. */
+int32_t mxlo_qn_mul_shifted(mxlo_qn *h, void *res, const void *x, double alpha, double beta,
+                            double sigma, int32_t flags);
+
 /* solve_shifted_system!(x, B, b, sigma) — src/utilities.jl:207-248 (forward L-BFGS only);
  * ldiv! (:281-289) is sigma = 0. sigma < 0 -> MXLO_EDOMAIN (reference: ArgumentError). */
 int32_t mxlo_qn_solve_shifted(mxlo_qn *h, void *x, const void *b, double sigma);

@@ -349,6 +349,16 @@ function diag!(op::MXQNOperator{T}, d::MXVector{T}) where {T}
 end
 LinearAlgebra.diag(op::MXQNOperator{T}) where {T} = diag!(op, MXVector{T}(undef, op.nrow))
 
+# ShiftedOperator(H, σ) over a quasi-Newton H: shifted_prod! (src/shifted_operators.jl:16-25) in ONE apply —
+# the axpy!(α σ, x, y) rides in the combine pass (bit-identical to mul! followed by axpy! in T arithmetic).
+function LinearOperators.shifted_prod!(y::MXVector{T}, data::LinearOperators.ShiftedData{T, <:MXQNOperator{T}},
+                                       x::MXVector{T}, α, β) where {T}
+  data.H.nprod += 1
+  check(ccall((:mxlo_qn_mul_shifted, lib), Int32, (P, P, P, Float64, Float64, Float64, Int32),
+              data.H.data.h, y.ptr, x.ptr, α, β, data.σ, flags(T, α, β)))
+  y
+end
+
 # solve_shifted_system! / ldiv! (src/utilities.jl:207-248, 281-289); returns x itself (test_solve_shifted_system.jl:33)
 function solve_shifted_system!(x::MXVector{T}, B::MXQNOperator{T}, b::MXVector{T}, σ::T) where {T}
   check(ccall((:mxlo_qn_solve_shifted, lib), Int32, (P, P, P, Float64), B.data.h, x.ptr, b.ptr, σ))

@@ -117,6 +117,7 @@ _PROTOS = {
     "mxlo_qn_push_damped_fwd": [_vp, _vp, _vp, _vp, C.POINTER(_i32)],
     "mxlo_qn_push_damped_inv": [_vp, _vp, _vp, _dbl, _vp, _vp, C.POINTER(_i32)],
     "mxlo_qn_mul": [_vp, _vp, _vp, _dbl, _dbl, _i32],
+    "mxlo_qn_mul_shifted": [_vp, _vp, _vp, _dbl, _dbl, _dbl, _i32],
     "mxlo_qn_solve_shifted": [_vp, _vp, _vp, _dbl],
     "mxlo_qn_diag": [_vp, _vp],
     "mxlo_qn_reset": [_vp],

@@ -105,6 +105,7 @@ struct CombineArgs {
   double gamma;
   double alpha, beta;
   const double *coef;  // device coefficients, one per column (CM_DIAG_SR1: as_k per column)
+  double shift = 0.0;  // CM_FWD/INV/LSR1: res += T(shift)*x after the epilogue (fused ShiftedOperator axpy!)
 };
 
 template <typename T, typename CT, int MODE, bool BETA0, int VEC, bool NT>
@@ -124,12 +125,13 @@ combine_kernel(T *__restrict__ res, const T *__restrict__ x, const T *__restrict
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < nvec;
        i += (int64_t)gridDim.x * kBlock) {
     T q[VEC];
+    V xv;
     // ---- prologue
     if constexpr (MODE == CM_DIAG_FWD || MODE == CM_DIAG_SR1) {
 #pragma unroll
       for (int e = 0; e < VEC; ++e) q[e] = A.use_gamma ? (T)1 / g : (T)1;
     } else {
-      const V xv = ldg<NT>(reinterpret_cast<const V *>(x + i * VEC));
+      xv = ldg<NT>(reinterpret_cast<const V *>(x + i * VEC));
       V x2v, rv;
       if constexpr (MODE == CM_ASR1) x2v = ldg<NT>(reinterpret_cast<const V *>(x2 + i * VEC));
       if constexpr (MODE == CM_LSR1 && !BETA0) rv = ldg<NT>(reinterpret_cast<const V *>(res + i * VEC));
@@ -224,6 +226,13 @@ combine_kernel(T *__restrict__ res, const T *__restrict__ x, const T *__restrict
     } else {
 #pragma unroll
       for (int e = 0; e < VEC; ++e) vset<T, VEC>(out, e, q[e]);
+    }
+    if constexpr (MODE == CM_FWD || MODE == CM_INV || MODE == CM_LSR1) {
+      if (A.shift != 0.0) {  // axpy!(α σ, x, y) of shifted_prod! (src/shifted_operators.jl:21-23), in T like BLAS axpy
+        const T sh = (T)A.shift;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) vset<T, VEC>(out, e, vget<T, VEC>(out, e) + (sh * vget<T, VEC>(xv, e)));
+      }
     }
     stg<NT>(reinterpret_cast<V *>(res + i * VEC), out);
   }
@@ -463,7 +472,8 @@ inline void fill_ord(const mxlo_qn *h, OrdArgs &O, bool newest_first) {
 
 // ---- applies ------------------------------------------------------------------------------
 template <typename T>
-int32_t inv_mul_twopass(mxlo_qn *h, T *res, const T *x, double alpha, double beta, int32_t flags) {
+int32_t inv_mul_twopass(mxlo_qn *h, T *res, const T *x, double alpha, double beta, int32_t flags,
+                 double shift = 0.0) {
   mxlo_ctx *ctx = h->ctx;
   OrdArgs O;
   fill_ord(h, O, /*newest_first=*/true);
@@ -477,6 +487,7 @@ int32_t inv_mul_twopass(mxlo_qn *h, T *res, const T *x, double alpha, double bet
   A.alpha = alpha;
   A.beta = beta;
   A.coef = coef;
+  A.shift = shift;
   if (na > 0) {
     const T *cols[kMaxCols];
     for (int i = 0; i < na; ++i) {
@@ -497,7 +508,8 @@ int32_t inv_mul_twopass(mxlo_qn *h, T *res, const T *x, double alpha, double bet
 }
 
 template <typename T>
-int32_t inv_mul_reforder(mxlo_qn *h, T *res, const T *x, double alpha, double beta, int32_t flags) {
+int32_t inv_mul_reforder(mxlo_qn *h, T *res, const T *x, double alpha, double beta, int32_t flags,
+                 double shift = 0.0) {
   // src/lbfgs.jl:127-153 statement by statement; q lives in h->tmp (data.Ax)
   mxlo_ctx *ctx = h->ctx;
   T *q = (T *)h->tmp;
@@ -526,14 +538,18 @@ int32_t inv_mul_reforder(mxlo_qn *h, T *res, const T *x, double alpha, double be
     InvStep2Op<T> op{dots, al + k, (T)h->ys[k], T(0)};
     MXLO_TRY((launch_map<T, 1, true, false>(ctx, q, sk, (const T *)nullptr, n, op)));
   }
-  return dispatch_ct<T>(beta, flags, [&]<typename CT, bool B0>() -> int32_t {
+  MXLO_TRY((dispatch_ct<T>(beta, flags, [&]<typename CT, bool B0>() -> int32_t {
     AxpbyOp<T, CT, B0> op{(CT)alpha, (CT)beta};
     return launch_map<T, 1, !B0, false>(ctx, res, q, (const T *)nullptr, n, op);
-  });
+  })));
+  if (shift != 0.0)  // reference order: the ShiftedOperator axpy! stays its own pass
+    return mxlo_eye_mul(ctx, sizeof(T) == 8 ? MXLO_F64 : MXLO_F32, res, x, n, n, shift, 1.0, 0);
+  return MXLO_OK;
 }
 
 template <typename T>
-int32_t fwd_mul(mxlo_qn *h, T *res, const T *x, double alpha, double beta, int32_t flags) {
+int32_t fwd_mul(mxlo_qn *h, T *res, const T *x, double alpha, double beta, int32_t flags,
+                 double shift = 0.0) {
   mxlo_ctx *ctx = h->ctx;
   OrdArgs O;
   fill_ord(h, O, /*newest_first=*/false);
@@ -547,6 +563,7 @@ int32_t fwd_mul(mxlo_qn *h, T *res, const T *x, double alpha, double beta, int32
   A.alpha = alpha;
   A.beta = beta;
   A.coef = coef;
+  A.shift = shift;
   if (na > 0) {
     for (int i = 0; i < na; ++i) {  // pair order (b_k, a_k): coef = (bx, ax)
       A.cols[2 * i] = col<T>(h->B, h->ld, O.ord[i]);
@@ -561,7 +578,8 @@ int32_t fwd_mul(mxlo_qn *h, T *res, const T *x, double alpha, double beta, int32
 }
 
 template <typename T>
-int32_t lsr1_mul(mxlo_qn *h, T *res, const T *x, double alpha, double beta, int32_t flags) {
+int32_t lsr1_mul(mxlo_qn *h, T *res, const T *x, double alpha, double beta, int32_t flags,
+                 double shift = 0.0) {
   mxlo_ctx *ctx = h->ctx;
   OrdArgs O;
   fill_ord(h, O, false);
@@ -575,6 +593,7 @@ int32_t lsr1_mul(mxlo_qn *h, T *res, const T *x, double alpha, double beta, int3
   A.alpha = alpha;
   A.beta = beta;
   A.coef = coef;
+  A.shift = shift;
   if (na > 0) {
     for (int i = 0; i < na; ++i) A.cols[i] = col<T>(h->A, h->ld, O.ord[i]);
     MXLO_TRY(panel_dots<T>(ctx, A.cols, na, x, h->n, dots));
@@ -587,17 +606,18 @@ int32_t lsr1_mul(mxlo_qn *h, T *res, const T *x, double alpha, double beta, int3
 }
 
 template <typename T>
-int32_t qn_mul_t(mxlo_qn *h, T *res, const T *x, double alpha, double beta, int32_t flags) {
+int32_t qn_mul_t(mxlo_qn *h, T *res, const T *x, double alpha, double beta, int32_t flags,
+                 double shift = 0.0) {
   if (h->dtype == MXLO_F32 && !(flags & MXLO_SCALARS_F64)) {
     alpha = (double)(float)alpha;
     beta = (double)(float)beta;
   }
   switch (h->kind) {
     case MXLO_QN_LBFGS_INV:
-      return h->mode == MXLO_INV_REFORDER ? inv_mul_reforder<T>(h, res, x, alpha, beta, flags)
-                                          : inv_mul_twopass<T>(h, res, x, alpha, beta, flags);
-    case MXLO_QN_LBFGS_FWD: return fwd_mul<T>(h, res, x, alpha, beta, flags);
-    case MXLO_QN_LSR1: return lsr1_mul<T>(h, res, x, alpha, beta, flags);
+      return h->mode == MXLO_INV_REFORDER ? inv_mul_reforder<T>(h, res, x, alpha, beta, flags, shift)
+                                          : inv_mul_twopass<T>(h, res, x, alpha, beta, flags, shift);
+    case MXLO_QN_LBFGS_FWD: return fwd_mul<T>(h, res, x, alpha, beta, flags, shift);
+    case MXLO_QN_LSR1: return lsr1_mul<T>(h, res, x, alpha, beta, flags, shift);
   }
   return MXLO_EINVAL;
 }
@@ -1301,6 +1321,22 @@ MXLO_API int32_t mxlo_qn_mul(mxlo_qn *h, void *res, const void *x, double alpha,
   MXLO_REQUIRE(h && (h->n == 0 || (res && x)), MXLO_EINVAL, "mxlo_qn_mul: NULL argument");
   if (h->dtype == MXLO_F64) return qn_mul_t<double>(h, (double *)res, (const double *)x, alpha, beta, flags);
   return qn_mul_t<float>(h, (float *)res, (const float *)x, alpha, beta, flags);
+}
+
+MXLO_API int32_t mxlo_qn_mul_shifted(mxlo_qn *h, void *res, const void *x, double alpha, double beta,
+                                     double sigma, int32_t flags) {
+  MXLO_REQUIRE(h && (h->n == 0 || (res && x)), MXLO_EINVAL, "mxlo_qn_mul_shifted: NULL argument");
+  // shifted_prod! (src/shifted_operators.jl:16-25): mul!(y, H, x, α, β); iszero(σ) || iszero(α) || axpy!(α*σ, x, y).
+  // α*σ is formed in the callers' types (σ is a T; α a T or a Float64), then axpy! converts it to T.
+  double c = 0.0;
+  if (sigma != 0 && alpha != 0) {
+    if (h->dtype == MXLO_F64) c = alpha * sigma;
+    else if (flags & MXLO_SCALARS_F64) c = (double)(float)(alpha * (double)(float)sigma);
+    else c = (double)((float)alpha * (float)sigma);
+  }
+  if (h->dtype == MXLO_F64)
+    return qn_mul_t<double>(h, (double *)res, (const double *)x, alpha, beta, flags, c);
+  return qn_mul_t<float>(h, (float *)res, (const float *)x, alpha, beta, flags, c);
 }
 
 MXLO_API int32_t mxlo_qn_push(mxlo_qn *h, const void *s, const void *y, int32_t *accepted) {

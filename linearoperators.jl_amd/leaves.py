@@ -475,6 +475,7 @@ class ShiftedOperatorType(AbstractLinearOperator):
     """`ShiftedOperator(H, σ)` = H + σI — src/shifted_operators.jl:56-103. Its products are the inner
     operator's `mul!` followed by one `axpy!(α σ, x, y)` (:16-25), here `mxlo_eye_mul` with β = 1."""
     _has_args5 = True                                                  # has_args5 / isallocated5 (:92-94)
+    fuse = True                      # quasi-Newton H: fold the axpy! into the apply (bit-identical, see tests)
 
     def __init__(self, H, sigma=0):
         self.eltype = H.eltype
@@ -487,12 +488,28 @@ class ShiftedOperatorType(AbstractLinearOperator):
         data = self.data
 
         def shifted(y, x, a, b, op):
+            skip = data.sigma == 0 or a == 0                           # (:21)
+            if not skip and ShiftedOperatorType.fuse and hasattr(data.H, "_pending_shift"):
+                # H is a quasi-Newton operator: the axpy! rides in the combine pass of its apply
+                # (mxlo_qn_mul_shifted) — same per-element roundings, one launch and 3 vector passes fewer.
+                data.H._pending_shift = float(data.sigma)
+                try:
+                    mul(y, op, x, a, b)
+                finally:
+                    data.H._pending_shift = None
+                return y
             mul(y, op, x, a, b)                                        # y = α H x + β y        (:18)
-            if not (data.sigma == 0 or a == 0):                        # (:21)
+            if not skip:
                 ctx = get_ctx(y.device)
-                c = a * data.sigma
+                # α*σ in the callers' types (σ is a T), then axpy! converts it to T and runs in T arithmetic
+                if y.dtype == torch.float64:
+                    c = float(a) * float(data.sigma)
+                elif isinstance(a, (np.float32,)):
+                    c = float(np.float32(a) * np.float32(data.sigma))
+                else:
+                    c = float(np.float32(float(a) * float(data.sigma)))
                 _lib.call("mxlo_eye_mul", ctx.handle, dtype_code(y.dtype), ptr(y), ptr(x), y.numel(), y.numel(),
-                          float(c), 1.0, scalar_flags(y.dtype, c, 1))  # y = y + (α σ) x        (:22)
+                          c, 1.0, 0)                                   # y = y + (α σ) x        (:22)
             return y
 
         self.prod = lambda y, x, a, b: shifted(y, x, a, b, data.H)

@@ -92,6 +92,7 @@ class _QNOperator(AbstractLinearOperator):
         _lib.call("mxlo_qn_create", self._ctx.handle, kind, dtype_code(T), int(n), self.mem, int(scaling), int(damped),
                   float(sigma2), float(sigma3), C.byref(self._h))
         self.data = _QNData(self)
+        self._pending_shift = None       # set by ShiftedOperator around one mul! (fused axpy!, mxlo_qn_mul_shifted)
         self.inverse = kind == _lib.QN_LBFGS_INV
         prod = lambda res, x, a, b: self._multiply(res, x, a, b)
         self.prod = prod
@@ -105,6 +106,10 @@ class _QNOperator(AbstractLinearOperator):
         check_vec(res, "res", self.eltype)
         check_vec(x, "x", self.eltype)
         self._ctx.bind_stream()
+        if self._pending_shift is not None:
+            _lib.call("mxlo_qn_mul_shifted", self._h, ptr(res), ptr(x), float(alpha), float(beta),
+                      self._pending_shift, scalar_flags(self.eltype, alpha, beta))
+            return
         _lib.call("mxlo_qn_mul", self._h, ptr(res), ptr(x), float(alpha), float(beta),
                   scalar_flags(self.eltype, alpha, beta))
 

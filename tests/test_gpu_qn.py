@@ -404,3 +404,48 @@ def test_native_rccl_hook_world1(lo, dev):
         ctx.set_allreduce(None)
         torch.cuda.synchronize()
         hook.close()
+
+
+# ------------------------------------------------------------------------------- fused ShiftedOperator
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("kind", ["fwd", "inv", "inv_reforder", "lsr1"])
+@pytest.mark.parametrize("n", [1, 1001, 65_537])
+def test_shifted_qn_fused_is_bit_identical(lo, dev, dtype, kind, n):
+    """ShiftedOperator(H, σ) over a quasi-Newton H (src/shifted_operators.jl:16-25): the fused apply
+    (mxlo_qn_mul_shifted: axpy! folded into the combine pass) must reproduce, bit for bit, mul!(y,H,x,α,β)
+    followed by axpy!(ασ, x, y) — for every operator kind, Float64 and Float32 scalars, β = 0 and β ≠ 0 —
+    and agree with the oracle's H plus σI."""
+    npd = NP[dtype]
+    rng = np.random.default_rng(n + len(kind))
+    mem = 4
+    if kind == "fwd":
+        op, orc = lo.LBFGSOperator(dtype, n, mem=mem, device=dev), oracle.LBFGS(n, mem=mem, inverse=False, dtype=npd)
+    elif kind == "lsr1":
+        op, orc = lo.LSR1Operator(dtype, n, mem=mem, device=dev), oracle.LSR1(n, mem=mem, dtype=npd)
+    else:
+        op, orc = lo.InverseLBFGSOperator(dtype, n, mem=mem, device=dev), oracle.LBFGS(n, mem=mem, inverse=True, dtype=npd)
+        if kind == "inv_reforder":
+            op.set_mode("reforder")
+    for s, y in pairs(rng, n, mem + 2, npd):
+        lo.push(op, T(s, dev), T(y, dev))
+        orc.push(s, y)
+    x, r0 = rng.uniform(-1, 1, n).astype(npd), rng.uniform(-1, 1, n).astype(npd)
+    sigma = 0.37
+    Sh = lo.ShiftedOperator(op, sigma)
+    f32s = (np.float32(1.5), np.float32(-0.25))
+    for a, b in [(1.0, 0.0), (2.0, -3.0)] + ([f32s] if dtype == torch.float32 else []):
+        outs = []
+        for fuse in (True, False):
+            type(Sh).fuse = fuse
+            try:
+                res = T(r0.copy(), dev) if b != 0 else torch.full((n,), float("nan"), dtype=dtype, device=dev)
+                lo.mul(res, Sh, T(x, dev), a, b)
+                outs.append(res)
+            finally:
+                type(Sh).fuse = True
+        assert torch.equal(outs[0], outs[1]), (kind, a, b)
+        ref = orc.mul(r0.copy(), x, float(a), float(b)).astype(np.float64) + float(a) * sigma * x.astype(np.float64)
+        assert rel(outs[0].cpu().numpy(), ref) <= (1e-9 if dtype == torch.float64 else 2e-4)
+    nb = lo.nprod(op)
+    Sh.data.sigma = 0.0                                   # σ == 0 (or α == 0): plain mul!, no axpy (:21)
+    assert torch.equal(Sh * T(x, dev), op * T(x, dev)) and lo.nprod(op) == nb + 2

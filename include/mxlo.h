@@ -149,6 +149,10 @@ int32_t mxlo_zeros_mul(mxlo_ctx *ctx, int32_t dtype, void *res, int64_t nrow, do
 int32_t mxlo_ones_mul(mxlo_ctx *ctx, int32_t dtype, void *res, int64_t nrow, const void *v,
                       int64_t ncol, double alpha, double beta, int32_t flags);
 
+/* fill!(res, value) — `op.d .= one(T)` of reset!(::AbstractDiagonalQuasiNewtonOperator)
+ * (src/DiagonalHessianApproximation.jl:71-77) and the glue's Base.fill! on device vectors. */
+int32_t mxlo_fill(mxlo_ctx *ctx, int32_t dtype, void *res, int64_t n, double value);
+
 /* `res .*= alpha` of prod3! — src/operations.jl:13-15. */
 int32_t mxlo_scale(mxlo_ctx *ctx, int32_t dtype, void *res, int64_t n, double alpha,
                    int32_t flags);
@@ -251,6 +255,20 @@ int32_t mxlo_kron_diag_mul(mxlo_ctx *ctx, int32_t dtype, void *res, const void *
 int32_t mxlo_gemv(mxlo_ctx *ctx, int32_t dtype, void *res, const void *M, int64_t m, int64_t n,
                   int64_t ld, const void *v, double alpha, double beta, int32_t op_mode,
                   int32_t flags);
+
+/* push!(B, s, y) of the diagonal quasi-Newton operators — src/DiagonalHessianApproximation.jl:
+ * DiagonalPSB :45-64, DiagonalAndrei :117-139, DiagonalBFGS :236-249, SpectralGradient :190-199
+ * (their mul! is mxlo_diag_mul, :37,112,179,226; SpectralGradient keeps ONE device element in `d` and
+ * multiplies with MXLO_D_SCALAR). One fused reduction pass over s, y (, d), the scalar recurrence on
+ * the host in the reference's statement order and eltype, one update pass over d.
+ * *status = 1 when s == 0: the reference throws ErrorException("Cannot update DiagonalQN operator
+ * with s=0") and leaves d untouched; so does this. Costs one 48-byte D2H (the error is host control flow). */
+#define MXLO_DQN_PSB      0
+#define MXLO_DQN_ANDREI   1
+#define MXLO_DQN_BFGS     2
+#define MXLO_DQN_SPECTRAL 3
+int32_t mxlo_diagqn_push(mxlo_ctx *ctx, int32_t dtype, int32_t kind, void *d, const void *s,
+                         const void *y, int64_t n, int32_t *status);
 
 /* ======================================================================== */
 /*  Quasi-Newton operators (state resident in HBM)                           */

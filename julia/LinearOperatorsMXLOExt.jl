@@ -366,6 +366,33 @@ function solve_shifted_system!(x::MXVector{T}, B::MXQNOperator{T}, b::MXVector{T
 end
 ldiv!(x::MXVector{T}, B::MXQNOperator{T}, b::MXVector{T}) where {T} = solve_shifted_system!(x, B, b, zero(T))
 
+# ---- diagonal quasi-Newton family (src/DiagonalHessianApproximation.jl) ------------------------------------------
+# The structs are generic in the vector type V, so DiagonalPSB(d::MXVector) etc. construct unchanged and their mul!
+# reaches mulSquareOpDiagonal!; the extension supplies that kernel and the fused push!/reset!.
+LinearOperators.mulSquareOpDiagonal!(res::MXVector{T}, d::MXVector{T}, v::MXVector{T}, α, β) where {T} =
+  check(ccall((:mxlo_diag_mul, lib), Int32, (P, Int32, P, P, P, Int64, Int64, Float64, Float64, Int32),
+              ctx(), dt(T), res.ptr, d.ptr, v.ptr, length(res), length(res), α, β,
+              flags(T, α, β) | (length(d) == 1 && length(res) != 1 ? Int32(2) : Int32(0))))   # MXLO_D_SCALAR
+dqn_kind(::LinearOperators.DiagonalPSB) = Int32(0)
+dqn_kind(::LinearOperators.DiagonalAndrei) = Int32(1)
+dqn_kind(::LinearOperators.DiagonalBFGS) = Int32(2)
+function push!(B::Union{LinearOperators.DiagonalPSB{T}, LinearOperators.DiagonalAndrei{T}, LinearOperators.DiagonalBFGS{T}},
+               s::MXVector{T}, y::MXVector{T}) where {T}
+  st = Ref{Int32}(0)
+  check(ccall((:mxlo_diagqn_push, lib), Int32, (P, Int32, Int32, P, P, P, Int64, Ptr{Int32}),
+              ctx(), dt(T), dqn_kind(B), B.d.ptr, s.ptr, y.ptr, length(s), st))
+  st[] == 0 || error("Cannot update DiagonalQN operator with s=0")
+  B
+end
+function reset!(op::LinearOperators.AbstractDiagonalQuasiNewtonOperator{T}) where {T}   # d::MXVector
+  op.d isa MXVector || return invoke(reset!, Tuple{LinearOperators.AbstractQuasiNewtonOperator}, op)
+  check(ccall((:mxlo_fill, lib), Int32, (P, Int32, P, Int64, Float64), ctx(), dt(T), op.d.ptr, length(op.d), 1.0))
+  op.nprod = op.ntprod = op.nctprod = 0
+  op
+end
+# SpectralGradient hard-codes d::Vector{T} (:151): the device form keeps the single element in an MXVector{T}(1)
+# and calls mxlo_diagqn_push with kind 3 (MXLO_DQN_SPECTRAL).
+
 # ---- row sharding: one Julia process per GPU (DESIGN.md §6) -------------------------------------------------
 "`id` = the 128 bytes rank 0 obtained from `rccl_unique_id()`, broadcast by MPI.jl / a file / sockets."
 rccl_unique_id() = (id = zeros(UInt8, 128); check(ccall((:mxlo_rccl_unique_id, rccl), Int32, (Ptr{UInt8},), id)); id)

@@ -28,6 +28,8 @@ try:  # quasi-Newton operators
     from .qn import (InverseLBFGSOperator, LBFGSOperator, LSR1Operator, diag, ldiv, push, solve_shifted_system)
 except ImportError:  # pragma: no cover - during bring-up only
     pass
+from .diagqn import DiagonalAndrei, DiagonalBFGS, DiagonalPSB, SpectralGradient
+
 try:
     from . import sharded
 except ImportError:  # pragma: no cover

@@ -27,6 +27,7 @@ BLK_DIAG, BLK_DENSE, BLK_EYE, BLK_ZEROS = 0, 1, 2, 3
 QN_LBFGS_INV, QN_LBFGS_FWD, QN_LSR1 = 0, 1, 2
 INV_TWOPASS, INV_REFORDER = 0, 1
 PUSH_GRAM, PUSH_REFORDER = 0, 1
+DQN_PSB, DQN_ANDREI, DQN_BFGS, DQN_SPECTRAL = 0, 1, 2, 3
 
 
 class MxloError(RuntimeError):
@@ -97,6 +98,7 @@ _PROTOS = {
     "mxlo_zeros_mul": [_vp, _i32, _vp, _i64, _dbl, _i32],
     "mxlo_ones_mul": [_vp, _i32, _vp, _i64, _vp, _i64, _dbl, _dbl, _i32],
     "mxlo_scale": [_vp, _i32, _vp, _i64, _dbl, _i32],
+    "mxlo_fill": [_vp, _i32, _vp, _i64, _dbl],
     "mxlo_householder_mul": [_vp, _i32, _vp, _vp, _vp, _i64, _dbl, _dbl, _i32],
     "mxlo_dot": [_vp, _i32, _vp, _vp, _i64, _vp],
     "mxlo_householder_apply": [_vp, _i32, _vp, _vp, _vp, _i64, _dbl, _dbl, _i32, _vp],
@@ -111,6 +113,7 @@ _PROTOS = {
     "mxlo_kron_mul": [_vp, _i32, _vp, _vp, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _vp, _dbl, _dbl, _i32, _i32],
     "mxlo_kron_diag_mul": [_vp, _i32, _vp, _vp, _i64, _vp, _i64, _vp, _dbl, _dbl, _i32],
     "mxlo_gemv": [_vp, _i32, _vp, _vp, _i64, _i64, _i64, _vp, _dbl, _dbl, _i32, _i32],
+    "mxlo_diagqn_push": [_vp, _i32, _i32, _vp, _vp, _vp, _i64, C.POINTER(_i32)],
     "mxlo_qn_create": [_vp, _i32, _i32, _i64, _i64, _i32, _i32, _dbl, _dbl, C.POINTER(_vp)],
     "mxlo_qn_destroy": [_vp],
     "mxlo_qn_push": [_vp, _vp, _vp, C.POINTER(_i32)],

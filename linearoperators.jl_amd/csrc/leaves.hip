@@ -122,6 +122,13 @@ MXLO_API int32_t mxlo_zeros_mul(mxlo_ctx *ctx, int32_t dtype, void *res, int64_t
   return scale_t<float>(ctx, (float *)res, nrow, beta, flags);
 }
 
+MXLO_API int32_t mxlo_fill(mxlo_ctx *ctx, int32_t dtype, void *res, int64_t n, double value) {
+  CHECK_COMMON("mxlo_fill");
+  MXLO_REQUIRE(n >= 0 && (n == 0 || res), MXLO_EINVAL, "mxlo_fill: bad argument");
+  if (dtype == MXLO_F64) return fill<double>(ctx, (double *)res, n, value);
+  return fill<float>(ctx, (float *)res, n, (float)value);
+}
+
 MXLO_API int32_t mxlo_scale(mxlo_ctx *ctx, int32_t dtype, void *res, int64_t n, double alpha,
                             int32_t flags) {
   CHECK_COMMON("mxlo_scale");

@@ -184,6 +184,10 @@ def LSR1Operator(T, n: Optional[int] = None, mem: int = 5, scaling: bool = True,
 def push(op, s: torch.Tensor, y: torch.Tensor, *args):
     """push!(op, s, y) | push!(op, s, y, Bs) | push!(op, s, y, α, g) | push!(op, s, y, α, g, Bs)
     — src/lbfgs.jl:257-367, src/lsr1.jl:115-184. Returns `op` like the reference."""
+    if hasattr(op, "_push"):                              # diagonal quasi-Newton family (diagqn.py)
+        if args:
+            raise TypeError("push!(::AbstractDiagonalQuasiNewtonOperator, s, y) takes no extra arguments")
+        return op._push(s, y)
     if not isinstance(op, _QNOperator):
         raise TypeError("push! is defined for quasi-Newton operators")
     check_vec(s, "s", op.eltype)

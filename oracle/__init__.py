@@ -373,3 +373,52 @@ class LSR1:
             M[:, i] = self.mul(col, e)
             e[i] = 0
         return M
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Diagonal quasi-Newton push! — src/DiagonalHessianApproximation.jl, statement by statement in NumPy (every
+# scalar stays in the eltype T like the reference; `dot`/`norm` orders are unpinned there, np.dot here).
+class DiagonalQN:
+    """kind in {"psb", "andrei", "bfgs", "spectral"}; `d` is the operator's diagonal (1 element for spectral)."""
+
+    def __init__(self, kind, d):
+        self.kind, self.d = kind, np.array(d, copy=True)
+        self.T = self.d.dtype.type
+
+    def mul(self, res, v, alpha=1.0, beta=0.0, flags=0):
+        """mulSquareOpDiagonal! on the operator's own d (:37,112,179,226)."""
+        return diag_mul(res, self.d, v, alpha, beta, flags=flags | (D_SCALAR if self.d.size == 1 and v.size != 1 else 0))
+
+    def push(self, s, y):
+        T, d = self.T, self.d
+        if self.kind == "spectral":                          # :190-199
+            if np.all(s == 0):
+                raise ZeroDivisionError("Cannot divide by zero and s .= 0")
+            d[0] = T(np.dot(s, y)) / T(np.dot(s, s))
+            return self
+        sNorm = T(np.linalg.norm(s, 2))                      # :50,122,241
+        if sNorm == 0:
+            raise ZeroDivisionError("Cannot update DiagonalQN operator with s=0")
+        sNorm2 = T(sNorm * sNorm)                            # sNorm^2
+        sT_y = T(T(np.dot(s, y)) / sNorm2)
+        if self.kind == "bfgs":                              # :245-248
+            d[:] = np.abs(y)
+            d *= T(T(np.sum(d)) / sT_y)
+            return self
+        s2 = s * s                                           # (si^2 for si in s)
+        trA2 = T(T(np.dot(s2, s2)) / T(sNorm2 * sNorm2))     # :57,129
+        sT_B_s = T(T(np.dot(s2, d)) / sNorm2)
+        q = T(sT_y - sT_B_s)
+        if self.kind == "andrei":                            # :133-134
+            q = T(q + T(T(np.dot(s, s)) / sNorm2))
+        q = T(q / trA2)
+        c = T(q / sNorm2)
+        if self.kind == "psb":
+            d += c * s2                                      # B.d .+= q / sNorm2 .* s .^ 2        (:62)
+        else:
+            d += (c * s2) - T(1)                             # B.d .+= q / sNorm2 .* s .^ 2 .- 1   (:137)
+        return self
+
+    def reset(self):
+        self.d[:] = 1
+        return self

@@ -177,6 +177,21 @@ cases.append(dict(
     expect_insert=len(stored) % mem + 1, v=fl(vv), expect_Bv=fl(matvec(Bk, vv)),
     expect_diagB=fl([Bk[i][i] for i in range(n)]), tol="1e-12 relative"))
 
+# ---------------------------------------------------------------- diagonal quasi-Newton push! (test_diag.jl:75-106)
+# x0 = [-1,1,-1], x1 = x0 + [1,0,1]; s = x1 - x0; y = grad(x1) - grad(x0); B = DQN([1,-1,1]); push!(B, s, y);
+# the test holds B.d (Bref, :79-93) for DiagonalPSB / DiagonalAndrei and B.d[1] for SpectralGradient(1.0, 3).
+import math
+_s = [1.0, 0.0, 1.0]
+_g1 = math.sin(-1.0) - math.exp(-1.0)
+for gname, y, psb, andrei, spg, tol in (
+        ("gradf", [2.0, 0.0, 2.0], [2.0, -1.0, 2.0], [2.0, -2.0, 2.0], 2.0, 0.0),
+        ("gradg", [1.0 - math.exp(-1.0), 0.0, math.sin(-1.0)], [1 + (_g1 - 1) / 2, -1.0, 1 + (_g1 - 1) / 2],
+         [(1 + _g1) / 2, -2.0, (1 + _g1) / 2], (1 - math.exp(-1.0) + math.sin(-1.0)) / 2, 1e-10),
+        ("gradh", [-2.0, 1.0, -3.0], [-2.5, -1.0, -2.5], [-2.5, -2.0, -2.5], -2.5, 0.0)):
+    cases.append(dict(name=f"diagqn_push_{gname}", ref="test/test_diag.jl:41-50 (points, gradients), :75-106 (Bref)",
+                      kind="diagqn_push", d0=[1.0, -1.0, 1.0], s=_s, y=y, expect_psb=psb, expect_andrei=andrei,
+                      expect_spectral=spg, tol=max(tol, 1e-15)))
+
 out = dict(
     about="Known-answer cases held by LinearOperators.jl v2.14.2's own tests for the mul! hot path; "
           "generated by tests/golden/make_kat.py (exact rational arithmetic, no reference code executed).",

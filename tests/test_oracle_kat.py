@@ -264,3 +264,31 @@ def test_eye_zeros_ones_quirks():
     assert np.array_equal(oracle.zeros_mul(res, 0.0), np.zeros(4))
     assert np.array_equal(oracle.zeros_mul(np.full(4, 2.0), 1.5), np.full(4, 3.0))
     assert np.array_equal(oracle.ones_mul(np.full(3, 1.0), np.array([1.0, 2.0, 3.0]), 2.0, 1.0), np.full(3, 13.0))
+
+
+def test_kat_diagqn_push(kat):
+    """test_diag.jl:75-106: B.d after one push! from d = [1,-1,1] (DiagonalPSB, DiagonalAndrei) and
+    SpectralGradient(1.0, 3).d[1]; plus the weak secant equation s'Bs = s'y (:52-72) and the allocation
+    test's operators applied (:108-124 builds them on rand(5))."""
+    cs = [c for c in kat if c["kind"] == "diagqn_push"]
+    assert len(cs) == 3
+    for c in cs:
+        s, y = np.array(c["s"]), np.array(c["y"])
+        for kind in ("psb", "andrei"):
+            B = oracle.DiagonalQN(kind, np.array(c["d0"])).push(s, y)
+            assert np.linalg.norm(B.d - np.array(c["expect_" + kind])) <= 1e-10
+            Bs = B.mul(np.empty(3), s)
+            assert abs(np.dot(s, Bs) - np.dot(s, y)) <= 1e-10             # weak secant (:59,70)
+        S = oracle.DiagonalQN("spectral", np.array([1.0])).push(s, y)
+        assert abs(S.d[0] - c["expect_spectral"]) <= 1e-10
+        assert np.array_equal(S.mul(np.empty(3), s), S.d[0] * s)
+    with np.testing.assert_raises(ZeroDivisionError):
+        oracle.DiagonalQN("psb", np.ones(3)).push(np.zeros(3), np.ones(3))
+    rng = np.random.default_rng(5)
+    y = rng.standard_normal(50)
+    s = rng.standard_normal(50)
+    if np.dot(s, y) < 0:
+        y = -y
+    B = oracle.DiagonalQN("bfgs", np.ones(50)).push(s, y)                  # :245-248: d = |y| * sum|y| / (s'y/|s|^2)
+    assert np.allclose(B.d, np.abs(y) * np.abs(y).sum() / (np.dot(s, y) / np.dot(s, s)), rtol=1e-13)
+    assert np.array_equal(B.reset().d, np.ones(50))

@@ -63,6 +63,7 @@ MXLO_API int32_t mxlo_ctx_destroy(mxlo_ctx *ctx) {
   (void)hipStreamSynchronize(ctx->stream);
   if (ctx->partials) (void)hipFree(ctx->partials);
   if (ctx->scalars) (void)hipFree(ctx->scalars);
+  if (ctx->scratch) (void)hipFree(ctx->scratch);
   delete ctx;
   return MXLO_OK;
 }

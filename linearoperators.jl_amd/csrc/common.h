@@ -79,6 +79,8 @@ struct mxlo_ctx {
   double *scalars = nullptr;   // finalized reduction results / device-resident coefficients
   mxlo_allreduce_fn allreduce = nullptr;
   void *allreduce_user = nullptr;
+  void *scratch = nullptr;     // grow-on-demand workspace (opHermitian tile partials); owned by the ctx
+  size_t scratch_bytes = 0;
   mxlo::Tune tune;
 };
 

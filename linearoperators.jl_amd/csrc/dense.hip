@@ -643,12 +643,6 @@ herm_finish_kernel(T *__restrict__ res, const T *__restrict__ d, const T *__rest
   }
 }
 
-struct HermScratch {  // per-device scratch for the tile partials (grown on demand)
-  void *buf = nullptr;
-  size_t bytes = 0;
-};
-static HermScratch g_herm[64];
-
 template <typename T>
 int32_t hermitian_t(mxlo_ctx *ctx, T *res, const T *d, const T *A, int64_t lda, const T *v, int64_t n,
                     double alpha, double beta, int32_t flags) {
@@ -658,21 +652,20 @@ int32_t hermitian_t(mxlo_ctx *ctx, T *res, const T *d, const T *A, int64_t lda, 
   // tiles per strip: 256x256 strips once they fill the chip four times over, thinner strips below that
   const int64_t full = ng * (ng + 1) / 2;
   const int C = full >= 4 * ctx->num_cu ? 8 : (4 * full >= 4 * ctx->num_cu ? 2 : 1), Q = 8 / C;
-  HermScratch &hs = g_herm[ctx->device & 63];
   const int64_t nslots = Q * (ng - 1) + 8;
   const size_t need = sizeof(double) * (size_t)(nslots + 2 * ng) * (size_t)n;   // Prow[nslots][n], Pcol[2ng][n]
-  if (hs.bytes < need) {
-    if (hs.buf) {
+  if (ctx->scratch_bytes < need) {            // stream-ordered users only: drain before the buffer is replaced
+    if (ctx->scratch) {
       MXLO_HIP(hipStreamSynchronize(ctx->stream));
-      MXLO_HIP(hipFree(hs.buf));
+      MXLO_HIP(hipFree(ctx->scratch));
     }
-    hs.buf = nullptr;
-    hs.bytes = 0;
-    hipError_t e = hipMalloc(&hs.buf, need);
+    ctx->scratch = nullptr;
+    ctx->scratch_bytes = 0;
+    hipError_t e = hipMalloc(&ctx->scratch, need);
     MXLO_REQUIRE(e == hipSuccess, MXLO_ENOMEM, "opHermitian scratch: %s", hipGetErrorString(e));
-    hs.bytes = need;
+    ctx->scratch_bytes = need;
   }
-  double *Prow = (double *)hs.buf, *Pcol = Prow + (size_t)nslots * n;
+  double *Prow = (double *)ctx->scratch, *Pcol = Prow + (size_t)nslots * n;
   const bool aligned = (((uintptr_t)A % (2 * sizeof(T))) == 0) && (lda % 2 == 0);
   // full row groups whose strips take the unmasked kernel; the rest of the strips go through the masked one
   const int64_t gi = aligned ? ngf : 0;

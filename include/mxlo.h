@@ -111,6 +111,24 @@ int32_t mxlo_memcpy_d2h(mxlo_ctx *ctx, void *dst, const void *src, int64_t bytes
 int32_t mxlo_memcpy_d2d(mxlo_ctx *ctx, void *dst, const void *src, int64_t bytes);
 int32_t mxlo_memset(mxlo_ctx *ctx, void *p, int32_t byte, int64_t bytes);
 
+/* ---- hipGraph capture: launch-bound inner loops --------------------------------------------
+ * An apply at small n is 2-4 dependent kernel launches (dots -> finalize -> coefficients -> combine);
+ * a Krylov or quasi-Newton inner loop repeats the same sequence on the same buffers thousands of times.
+ * Everything the apply entry points enqueue is stream-ordered with no host synchronisation, so a whole
+ * sequence of calls can be recorded once and replayed with ONE launch:
+ *     mxlo_graph_begin(ctx); mxlo_householder_mul(...); mxlo_qn_mul(...); ...; mxlo_graph_end(ctx, &g);
+ *     loop: mxlo_graph_launch(g);
+ * Buffers, sizes and alpha/beta are baked in (the data they point to is read at replay time). The ctx
+ * stream must not be the default stream (mxlo_ctx_create_stream gives the ctx one it owns). Not
+ * capturable: push! and mxlo_memcpy_d2h (host control flow / synchronising) and the first opHermitian
+ * apply of a new size (workspace growth) — run those outside, once, before capturing. */
+typedef struct mxlo_graph mxlo_graph;
+int32_t mxlo_ctx_create_stream(mxlo_ctx *ctx, void **stream_out); /* non-blocking stream owned by the ctx */
+int32_t mxlo_graph_begin(mxlo_ctx *ctx);
+int32_t mxlo_graph_end(mxlo_ctx *ctx, mxlo_graph **out);
+int32_t mxlo_graph_launch(mxlo_graph *g);   /* on the stream it was captured from */
+int32_t mxlo_graph_destroy(mxlo_graph *g);
+
 /* ---- timing on the ctx stream (bench / roofline evidence) ---------------- */
 int32_t mxlo_timer_create(mxlo_ctx *ctx, mxlo_timer **out);
 int32_t mxlo_timer_start(mxlo_timer *t);

@@ -393,6 +393,20 @@ end
 # SpectralGradient hard-codes d::Vector{T} (:151): the device form keeps the single element in an MXVector{T}(1)
 # and calls mxlo_diagqn_push with kind 3 (MXLO_DQN_SPECTRAL).
 
+# ---- hipGraph replay of launch-bound inner loops (mxlo_graph_*) ----------------------------------------------------
+"`g = capture(() -> (mul!(r, A, x); mul!(y, B, r, 1.0, 1.0)))` then `replay(g)` in the solver loop."
+mutable struct Graph; h::Ptr{Cvoid}; end
+function capture(f)
+  check(ccall((:mxlo_ctx_create_stream, lib), Int32, (P, Ptr{P}), ctx(), C_NULL))   # a non-default stream owned by the ctx
+  f()                                                                              # warm-up: lazy temporaries, workspaces
+  check(ccall((:mxlo_graph_begin, lib), Int32, (P,), ctx()))
+  f()
+  r = Ref{Ptr{Cvoid}}()
+  check(ccall((:mxlo_graph_end, lib), Int32, (P, Ptr{P}), ctx(), r))
+  finalizer(g -> ccall((:mxlo_graph_destroy, lib), Int32, (P,), g.h), Graph(r[]))
+end
+replay(g::Graph) = check(ccall((:mxlo_graph_launch, lib), Int32, (P,), g.h))
+
 # ---- row sharding: one Julia process per GPU (DESIGN.md §6) -------------------------------------------------
 "`id` = the 128 bytes rank 0 obtained from `rccl_unique_id()`, broadcast by MPI.jl / a file / sockets."
 rccl_unique_id() = (id = zeros(UInt8, 128); check(ccall((:mxlo_rccl_unique_id, rccl), Int32, (Ptr{UInt8},), id)); id)

@@ -29,6 +29,7 @@ try:  # quasi-Newton operators
 except ImportError:  # pragma: no cover - during bring-up only
     pass
 from .diagqn import DiagonalAndrei, DiagonalBFGS, DiagonalPSB, SpectralGradient
+from .graph import CapturedSequence, capture_mul
 
 try:
     from . import sharded

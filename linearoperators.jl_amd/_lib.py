@@ -88,6 +88,11 @@ _PROTOS = {
     "mxlo_memcpy_d2h": [_vp, _vp, _vp, _i64],
     "mxlo_memcpy_d2d": [_vp, _vp, _vp, _i64],
     "mxlo_memset": [_vp, _vp, _i32, _i64],
+    "mxlo_ctx_create_stream": [_vp, C.POINTER(_vp)],
+    "mxlo_graph_begin": [_vp],
+    "mxlo_graph_end": [_vp, C.POINTER(_vp)],
+    "mxlo_graph_launch": [_vp],
+    "mxlo_graph_destroy": [_vp],
     "mxlo_timer_create": [_vp, C.POINTER(_vp)],
     "mxlo_timer_start": [_vp],
     "mxlo_timer_stop": [_vp],

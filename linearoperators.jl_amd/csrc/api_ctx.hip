@@ -64,6 +64,7 @@ MXLO_API int32_t mxlo_ctx_destroy(mxlo_ctx *ctx) {
   if (ctx->partials) (void)hipFree(ctx->partials);
   if (ctx->scalars) (void)hipFree(ctx->scalars);
   if (ctx->scratch) (void)hipFree(ctx->scratch);
+  if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;
   return MXLO_OK;
 }
@@ -71,6 +72,77 @@ MXLO_API int32_t mxlo_ctx_destroy(mxlo_ctx *ctx) {
 MXLO_API int32_t mxlo_ctx_set_stream(mxlo_ctx *ctx, void *stream) {
   MXLO_REQUIRE(ctx, MXLO_EINVAL, "ctx is NULL");
   ctx->stream = (hipStream_t)stream;
+  return MXLO_OK;
+}
+
+MXLO_API int32_t mxlo_ctx_create_stream(mxlo_ctx *ctx, void **out) {
+  MXLO_REQUIRE(ctx, MXLO_EINVAL, "ctx is NULL");
+  if (!ctx->own_stream) {
+    (void)hipSetDevice(ctx->device);
+    MXLO_HIP(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
+  }
+  ctx->stream = ctx->own_stream;
+  if (out) *out = (void *)ctx->own_stream;
+  return MXLO_OK;
+}
+
+// ---- hipGraph capture of launch-bound sequences -------------------------------------------------
+struct mxlo_graph {
+  mxlo_ctx *ctx = nullptr;
+  hipStream_t stream = nullptr;
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+};
+
+MXLO_API int32_t mxlo_graph_begin(mxlo_ctx *ctx) {
+  MXLO_REQUIRE(ctx, MXLO_EINVAL, "ctx is NULL");
+  MXLO_REQUIRE(!ctx->capturing, MXLO_ESTATE, "mxlo_graph_begin: a capture is already open on this ctx");
+  MXLO_REQUIRE(ctx->stream != nullptr, MXLO_ESTATE,
+               "mxlo_graph_begin: the default stream cannot be captured; give the ctx a stream "
+               "(mxlo_ctx_set_stream / mxlo_ctx_create_stream)");
+  MXLO_HIP(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+  ctx->capturing = true;
+  return MXLO_OK;
+}
+
+MXLO_API int32_t mxlo_graph_end(mxlo_ctx *ctx, mxlo_graph **out) {
+  MXLO_REQUIRE(ctx && out, MXLO_EINVAL, "mxlo_graph_end: NULL argument");
+  MXLO_REQUIRE(ctx->capturing, MXLO_ESTATE, "mxlo_graph_end: no capture is open on this ctx");
+  ctx->capturing = false;
+  hipGraph_t graph = nullptr;
+  hipError_t e = hipStreamEndCapture(ctx->stream, &graph);
+  if (e != hipSuccess || !graph) {  // a call inside the capture was not capturable (sync, allocation)
+    set_error("mxlo_graph_end: capture failed: %s — only stream-ordered work (mul!, solve_shifted_system!, "
+              "diag!) can be captured; push! and first-use workspace growth synchronise", hipGetErrorString(e));
+    (void)hipGetLastError();
+    return MXLO_EHIP;
+  }
+  mxlo_graph *g = new mxlo_graph();
+  g->ctx = ctx;
+  g->stream = ctx->stream;
+  g->graph = graph;
+  e = hipGraphInstantiate(&g->exec, graph, nullptr, nullptr, 0);
+  if (e != hipSuccess) {
+    set_error("hipGraphInstantiate failed: %s", hipGetErrorString(e));
+    (void)hipGraphDestroy(graph);
+    delete g;
+    return MXLO_EHIP;
+  }
+  *out = g;
+  return MXLO_OK;
+}
+
+MXLO_API int32_t mxlo_graph_launch(mxlo_graph *g) {
+  MXLO_REQUIRE(g && g->exec, MXLO_EINVAL, "mxlo_graph_launch: NULL graph");
+  MXLO_HIP(hipGraphLaunch(g->exec, g->stream));
+  return MXLO_OK;
+}
+
+MXLO_API int32_t mxlo_graph_destroy(mxlo_graph *g) {
+  if (!g) return MXLO_OK;
+  if (g->exec) (void)hipGraphExecDestroy(g->exec);
+  if (g->graph) (void)hipGraphDestroy(g->graph);
+  delete g;
   return MXLO_OK;
 }
 

@@ -81,6 +81,8 @@ struct mxlo_ctx {
   void *allreduce_user = nullptr;
   void *scratch = nullptr;     // grow-on-demand workspace (opHermitian tile partials); owned by the ctx
   size_t scratch_bytes = 0;
+  hipStream_t own_stream = nullptr;  // created by mxlo_ctx_create_stream, destroyed with the ctx
+  bool capturing = false;      // between mxlo_graph_begin and mxlo_graph_end
   mxlo::Tune tune;
 };
 

@@ -131,3 +131,48 @@ def test_allreduce_hook_aliases_device_scalars(lo, dev):
         assert e.value.status == lo._lib.EREDUCE
     finally:
         ctx.set_allreduce(None)
+
+
+def test_hipgraph_replay_of_apply_sequences(lo, dev):
+    """mxlo_graph_*: a recorded sequence of applies replays with one launch and reads the CURRENT contents of
+    its buffers; results are bit-identical to the eager calls (same kernels, same order)."""
+    rng = np.random.default_rng(8)
+    n = 70_001
+    h = rng.standard_normal(n); h /= np.linalg.norm(h)
+    H = lo.opHouseholder(T(h, dev))
+    D = lo.opDiagonal(T(rng.uniform(0.5, 2, n), dev))
+    B = lo.LBFGSOperator(n, mem=5, device=dev)
+    for _ in range(6):
+        s = rng.uniform(-1, 1, n)
+        lo.push(B, T(s, dev), T(s * rng.uniform(0.5, 2, n), dev))
+    op = H * D + B                                       # composite: compose + sum + quasi-Newton apply
+    v = T(rng.uniform(-1, 1, n), dev)
+    res, ref = torch.zeros(n, dtype=torch.float64, device=dev), torch.zeros(n, dtype=torch.float64, device=dev)
+    g = lo.capture_mul(res, op, v, 2.0, 0.0)
+    for trial in range(3):
+        v.copy_(T(rng.uniform(-1, 1, n), dev))           # new data in the SAME buffer
+        res.fill_(float("nan"))
+        g.replay()
+        lo.mul(ref, op, v, 2.0, 0.0)
+        assert torch.equal(res, ref), trial
+    # several calls in one capture, beta != 0 (res is read and written in place at replay)
+    x = T(rng.uniform(-1, 1, n), dev)
+    acc, acc_ref = torch.zeros_like(x), torch.zeros_like(x)
+    lo.mul(acc, B, x, 1.0, 0.0)                           # warm-up outside the capture
+    acc.zero_()
+    g2 = lo.CapturedSequence(dev)
+    with g2:
+        lo.mul(acc, B, x, 1.0, 1.0)
+        lo.mul(acc, H, x, -0.5, 1.0)
+    for _ in range(2):
+        g2.replay()
+        lo.mul(acc_ref, B, x, 1.0, 1.0)
+        lo.mul(acc_ref, H, x, -0.5, 1.0)
+    assert torch.equal(acc, acc_ref)
+    # push! synchronises: not capturable -> a clean error, and the ctx keeps working afterwards
+    y2 = x * 2.0
+    with pytest.raises(lo.MxloError):
+        with lo.CapturedSequence(dev):
+            lo.push(B, x, y2)
+    lo.mul(ref, B, x)
+    assert torch.isfinite(ref).all()

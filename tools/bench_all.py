@@ -112,3 +112,35 @@ for kind, m in (("inv", 10), ("fwd", 10), ("fwd", 20), ("lsr1", 10)):
         row(f"diag! fwd m={m} n=5e7", (2 * m + 1) * 8.0 * n, timeit(lambda: lo.diag(op), 5))
     del op, S, Y, x, out
     torch.cuda.empty_cache()
+
+# ---- launch-bound regime: eager host-mirror calls vs ONE hipGraph replay (wall clock, includes the host side)
+import time
+
+
+def wall(fn, sync, reps=2000):
+    for _ in range(20):
+        fn()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    sync()
+    return (time.perf_counter() - t0) / reps * 1e6
+
+
+print("\nlaunch-bound regime (fp64): us per apply, eager mul! vs hipGraph replay (mxlo_graph_launch)")
+for small in (1 << 12, 1 << 16, 1 << 20):
+    hs = rnd(small); hs /= torch.linalg.vector_norm(hs)
+    vs, rs = rnd(small), rnd(small)
+    Hs, Ds = lo.opHouseholder(hs), lo.opDiagonal(rnd(small) + 1.5)
+    Bq = lo.LBFGSOperator(small, mem=5, device=dev)
+    for _ in range(6):
+        s_ = rnd(small)
+        lo.push(Bq, s_, s_ * (rnd(small) * 0.5 + 1.25))
+    comp = Hs * Ds + Bq
+    for name, op in (("opHouseholder", Hs), ("LBFGSOperator m=5", Bq), ("H*D + B (compose + sum)", comp)):
+        eager = wall(lambda: lo.mul(rs, op, vs, 1.0, 0.0), torch.cuda.synchronize)
+        gcap = lo.capture_mul(rs, op, vs, 1.0, 0.0)
+        replay = wall(lambda: gcap.replay(sync_streams=False), gcap.stream.synchronize)
+        print(f"  n=2^{small.bit_length()-1:<2d} {name:28s} eager {eager:7.1f} us   graph replay {replay:7.1f} us   x{eager/replay:4.1f}", flush=True)
+        del gcap

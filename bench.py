@@ -80,15 +80,15 @@ def main():
         nonlocal hook, native
         if not distributed:
             return
-        if native:                             # libmxlo_rccl.so: ncclAllReduce issued from C on the ctx stream
-            try:
-                if hook is None:
-                    hook = lo.sharded.NativeRcclHook(rank, world)
-                hook.install(ctx)
-                return
-            except Exception as e:             # still RCCL, through torch.distributed, if the native comm fails
-                print(f"[bench] native RCCL hook unavailable ({e!r}); using the torch.distributed hook", file=sys.stderr)
-                native = False
+        if native and hook is None:
+            # libmxlo_rccl.so (ncclAllReduce issued from C on the ctx stream) when every rank can build its
+            # communicator; otherwise every rank uses the torch.distributed hook (still RCCL, via Python)
+            hook = lo.sharded.install_agreed_allreduce(ctx)
+            native = hook is not None
+            return
+        if native:
+            hook.install(ctx)
+            return
         lo.sharded.install_allreduce(ctx, native=False)   # Python hook over torch.distributed (debug / gloo)
 
     install_hook()                             # RCCL all-reduce of the partial dots over xGMI

@@ -103,7 +103,7 @@ class NativeRcclHook:
     """RCCL communicator owned by libmxlo_rccl.so; the hook is the C function `mxlo_rccl_allreduce_hook`
     itself (ncclAllReduce on the ctx stream) — no Python, no extra stream, nothing synchronises."""
 
-    def __init__(self, rank: int, world: int, group=None):
+    def __init__(self, rank: int, world: int, group=None, timeout_s: float = 120.0):
         from . import _lib
         R = _lib.rccl_lib()
         idbuf = torch.zeros(_lib.RCCL_ID_BYTES, dtype=torch.uint8)
@@ -120,8 +120,25 @@ class NativeRcclHook:
             idbuf = t.cpu()
         raw = (C.c_ubyte * _lib.RCCL_ID_BYTES)(*idbuf.tolist())
         self.comm = C.c_void_p()
-        if R.mxlo_rccl_comm_create(rank, world, raw, C.byref(self.comm)) != 0:   # collective
-            raise RuntimeError(R.mxlo_rccl_last_error().decode())
+        # ncclCommInitRank is collective and cannot be interrupted: run it on a helper thread (HIP's current
+        # device is per thread) and give up after `timeout_s` so that a broken bootstrap degrades to the
+        # torch.distributed transport instead of hanging the job.
+        import threading
+        dev_index = torch.cuda.current_device()
+        out = {}
+
+        def build():
+            torch.cuda.set_device(dev_index)
+            out["rc"] = R.mxlo_rccl_comm_create(rank, world, raw, C.byref(self.comm))
+            out["err"] = R.mxlo_rccl_last_error().decode()
+
+        th = threading.Thread(target=build, daemon=True)
+        th.start()
+        th.join(timeout_s)
+        if th.is_alive():
+            raise TimeoutError(f"ncclCommInitRank did not return within {timeout_s:.0f} s")
+        if out.get("rc", 1) != 0:
+            raise RuntimeError(out.get("err", "mxlo_rccl_comm_create failed"))
         self._R = R
         self.fn = C.cast(R.mxlo_rccl_allreduce_hook, _lib.ALLREDUCE_FN)
 
@@ -146,6 +163,30 @@ def install_allreduce(ctx, group=None, native: bool = True):
         return None
     if native:
         hook = NativeRcclHook(dist.get_rank(group), dist.get_world_size(group), group)
+        hook.install(ctx)
+        return hook
+    ctx.set_allreduce(make_allreduce_hook(group, cuda=True))
+    return None
+
+
+def install_agreed_allreduce(ctx, group=None, timeout_s: float = 120.0):
+    """The native RCCL transport when EVERY rank managed to build its communicator, otherwise the
+    torch.distributed hook on every rank (never a mix: mixed transports would deadlock). Returns the
+    NativeRcclHook or None."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        ctx.set_allreduce(None)
+        return None
+    hook, ok = None, 1
+    try:
+        hook = NativeRcclHook(dist.get_rank(group), dist.get_world_size(group), group, timeout_s)
+    except Exception as e:
+        import sys
+        print(f"[mxlo] native RCCL transport unavailable on rank {dist.get_rank(group)}: {e!r}", file=sys.stderr)
+        ok = 0
+    on_gpu = dist.get_backend(group) == "nccl"
+    flag = torch.tensor([ok], dtype=torch.int32, device=torch.device("cuda", torch.cuda.current_device()) if on_gpu else "cpu")
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+    if int(flag.item()) == 1:
         hook.install(ctx)
         return hook
     ctx.set_allreduce(make_allreduce_hook(group, cuda=True))

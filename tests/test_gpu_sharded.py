@@ -1,0 +1,74 @@
+"""-m gpu: the N > 1 code path on ONE GPU — two processes (gloo rendezvous on 127.0.0.1), both on cuda:0.
+RCCL refuses two ranks on the same device, so `install_agreed_allreduce` must detect that on every rank, agree,
+and fall back to the torch.distributed hook; the row-sharded Householder and forward L-BFGS applies through
+libmxlo.so + that hook must then reproduce the unsharded oracle result, with bit-identical scalars on both ranks."""
+import os
+import subprocess
+import sys
+import textwrap
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = textwrap.dedent('''
+    import os, sys
+    import numpy as np, torch, torch.distributed as dist
+    sys.path.insert(0, %(root)r)
+    import __graft_entry__ as g
+    lo = g.load_package()
+    import oracle
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ctx = lo.get_ctx(dev)
+    hook = lo.sharded.install_agreed_allreduce(ctx, timeout_s=45.0)
+    transport = "native" if hook is not None else "torch"
+    n, mem = 200_003, 4
+    rng = np.random.default_rng(7)                       # same stream everywhere: replicated global data
+    plan = lo.sharded.ShardPlan(n, world)
+    a, b = plan.lo(rank), plan.hi(rank)
+    h = rng.standard_normal(n); h /= np.linalg.norm(h)
+    v, r0 = rng.uniform(-1, 1, n), rng.uniform(-1, 1, n)
+    T = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+    H = lo.opHouseholder(T(h[a:b]))
+    res = T(r0[a:b])
+    lo.mul(res, H, T(v[a:b]), 2.0, -3.0)
+    full = oracle.householder_mul(r0.copy(), h, v, 2.0, -3.0)
+    err_h = np.linalg.norm(res.cpu().numpy() - full[a:b]) / np.linalg.norm(full[a:b])
+    B = lo.LBFGSOperator(b - a, mem=mem, device=dev)
+    O = oracle.LBFGS(n, mem=mem, inverse=False)
+    for _ in range(mem + 2):
+        s = rng.uniform(-1, 1, n); y = s * rng.uniform(0.5, 2.0, n)
+        lo.push(B, T(s[a:b]), T(y[a:b])); O.push(s, y)
+    x = rng.uniform(-1, 1, n)
+    got = (B * T(x[a:b])).cpu().numpy()
+    fullB = O.mul(np.empty(n), x)
+    err_b = np.linalg.norm(got - fullB[a:b]) / np.linalg.norm(fullB[a:b])
+    t = torch.tensor([B.data.scaling_factor, float(B.data.insert)], dtype=torch.float64)
+    gathered = [torch.zeros_like(t) for _ in range(world)]
+    dist.all_gather(gathered, t)
+    same = all(torch.equal(gathered[0], gt) for gt in gathered)
+    print("RESULT", rank, transport, err_h, err_b, int(same), flush=True)
+    dist.destroy_process_group()
+''')
+
+
+def test_two_ranks_one_gpu_agree_on_transport_and_shard(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER % {"root": ROOT})
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29671", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=420)[0] for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o
+    transports = set()
+    for o in outs:
+        line = [l for l in o.splitlines() if l.startswith("RESULT")][0].split()
+        transports.add(line[2])
+        err_h, err_b, same = float(line[3]), float(line[4]), int(line[5])
+        assert err_h <= 1e-12 and err_b <= 1e-10 and same == 1, o
+    assert len(transports) == 1, transports            # never a mix of transports

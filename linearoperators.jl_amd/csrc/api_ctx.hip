@@ -183,7 +183,8 @@ MXLO_API int32_t mxlo_ctx_tune(mxlo_ctx *ctx, const char *key, int64_t value) {
     MXLO_REQUIRE(value == 0 || value == 32 || value == 64, MXLO_EINVAL, "gemm_tile_m must be 0, 32 or 64");
     ctx->tune.gemm_tile_m = (int)value;
   } else if (!strcmp(key, "gemm_waves")) {
-    MXLO_REQUIRE(value == 4 || value == 8, MXLO_EINVAL, "gemm_waves must be 4 or 8");
+    MXLO_REQUIRE(value == 0 || value == 4 || value == 8 || value == 16, MXLO_EINVAL,
+                 "gemm_waves must be 0 (auto), 4, 8 or 16");
     ctx->tune.gemm_waves = (int)value;
   } else if (!strcmp(key, "combine_blocks_per_cu")) {
     MXLO_REQUIRE(value >= 0 && value <= 64, MXLO_EINVAL, "combine_blocks_per_cu out of range");

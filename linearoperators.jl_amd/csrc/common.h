@@ -64,8 +64,9 @@ struct Tune {
   int house_reverse = 1;   // Householder phase B walks the vectors back-to-front (MALL tail reuse)
   int lbfgs_inv_mode = MXLO_INV_TWOPASS;
   int dots_max_nc = 20;    // columns per panel_dots launch (<= 20)
-  int gemm_tile_m = 0;     // fast GEMM tile rows: 0 = auto (32 when 64x64 tiles give < 2 workgroups per CU), 32, 64
-  int gemm_waves = 8;      // fast GEMM: waves per 64x64 tile (4: 32x32 per wave, 8: 16x32 per wave)
+  int gemm_tile_m = 0;     // fast GEMM tile rows: 0 = auto (32 when there are fewer 64x64 tiles than CUs), 32, 64
+  int gemm_waves = 0;      // fast GEMM wave layout: 0/16 = one wave per 16x16 block (16 waves per 64x64 tile),
+                           // 8 = 16x32 per wave, 4 = 32x32 per wave
   int combine_blocks_per_cu = 0;   // panel_combine: 0 = one vector per thread (best measured), k = persistent grid
 };
 

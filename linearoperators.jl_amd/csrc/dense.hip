@@ -125,14 +125,15 @@ constexpr int FBK = 32;
 // TM x 64 output tile per workgroup. (TM, WAVES) = (64, 8): one workgroup per CU at 1024^2;
 // (32, 4): 512 workgroups at 1024^2 = TWO independent workgroups per CU, so one computes while the other
 // sits in its barrier / LDS-store bubble.
-template <typename T, typename CT, bool BETA0, int WAVES, int TM>
+template <typename T, typename CT, bool BETA0, int WAVES, int TM, int WCOLS = 2>
 __global__ void __launch_bounds__(WAVES * 64)
 gemm_nt_fast_kernel(T *__restrict__ C, int64_t ldc, const T *__restrict__ A, int64_t lda,
                     const T *__restrict__ B, int64_t ldb, int K, CT alpha, CT beta) {
   constexpr int kBlock = WAVES * 64;                     // shadows mxlo::kBlock inside this kernel
-  constexpr int WR = WAVES / 2;                          // waves along M (2 along N, 32 columns each)
+  constexpr int WR = WAVES / WCOLS;                      // waves along M; WCOLS along N
   constexpr int MT = TM / WR / 16;                       // 16-row MFMA tiles per wave along M
-  static_assert(MT >= 1 && MT * 16 * WR == TM, "bad tile / wave shape");
+  constexpr int NTW = BN / WCOLS / 16;                   // 16-column MFMA tiles per wave along N
+  static_assert(MT >= 1 && MT * 16 * WR == TM && NTW >= 1 && NTW * 16 * WCOLS == BN, "bad tile / wave shape");
   constexpr int VEC = Vec16<T>::N;                       // elements per 16-byte load
   constexpr int LPA = TM * FBK / VEC / kBlock;           // 16-byte loads per thread per A slab
   constexpr int LPB = BN * FBK / VEC / kBlock;           //                             per B slab
@@ -145,13 +146,13 @@ gemm_nt_fast_kernel(T *__restrict__ C, int64_t ldc, const T *__restrict__ A, int
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int bm = blockIdx.x * TM, bn = blockIdx.y * BN;
   const int wm = (wave % WR) * (TM / WR);
-  const int wn = (wave / WR) * 32;
+  const int wn = (wave / WR) * (BN / WCOLS);
   using Acc = typename Mfma<T>::Acc;
-  Acc acc[MT][2];
+  Acc acc[MT][NTW];
 #pragma unroll
   for (int a = 0; a < MT; ++a)
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
+    for (int b = 0; b < NTW; ++b)
 #pragma unroll
       for (int r = 0; r < 4; ++r) acc[a][b][r] = 0;
 
@@ -191,12 +192,14 @@ gemm_nt_fast_kernel(T *__restrict__ C, int64_t ldc, const T *__restrict__ A, int
 #pragma unroll
     for (int kk = kbeg; kk < kend; kk += 4) {
       const int kr = kk + (lane >> 4);
-      const T b0 = sB[buf][kr][wn + (lane & 15)], b1 = sB[buf][kr][wn + 16 + (lane & 15)];
+      T bv[NTW];
+#pragma unroll
+      for (int b = 0; b < NTW; ++b) bv[b] = sB[buf][kr][wn + b * 16 + (lane & 15)];
 #pragma unroll
       for (int a = 0; a < MT; ++a) {
         const T av = sA[buf][kr][wm + a * 16 + (lane & 15)];
-        acc[a][0] = Mfma<T>::run(av, b0, acc[a][0]);
-        acc[a][1] = Mfma<T>::run(av, b1, acc[a][1]);
+#pragma unroll
+        for (int b = 0; b < NTW; ++b) acc[a][b] = Mfma<T>::run(av, bv[b], acc[a][b]);
       }
     }
   };
@@ -223,7 +226,7 @@ gemm_nt_fast_kernel(T *__restrict__ C, int64_t ldc, const T *__restrict__ A, int
 #pragma unroll
   for (int a = 0; a < MT; ++a)
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
+    for (int b = 0; b < NTW; ++b)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int gi = bm + wm + a * 16 + Mfma<T>::row(lane, r);
@@ -251,19 +254,36 @@ int32_t gemm(mxlo_ctx *ctx, T *C, int64_t ldc, const T *A, int64_t lda, bool ta,
   dim3 grid((unsigned)((M + BM - 1) / BM), (unsigned)((N + BN - 1) / BN));
   if (!ta && tb && gemm_nt_fast_ok<T>(A, lda, B, ldb, M, N, K)) {
     return dispatch_ct<T>(beta, flags, [&]<typename CT, bool B0>() -> int32_t {
-      // tile choice: 32x64 tiles (2 workgroups per CU) while the 64x64 grid would not fill the chip twice
+      // Tile / wave-layout choice (tools/sweep_gemm.py). The f64 MFMA pipe needs many waves per SIMD to stay
+      // busy across the barrier and LDS phases, so each 16x16 output block gets its OWN wave:
+      //   f64, >= one 64x64 tile per CU : 64x64 tile, 16 waves (4 x 4)     1024^2: 86 us/kron, 2048^2: 564 us
+      //   f64, fewer                    : 32x64 tile,  8 waves (2 x 4)      512^2: 32 us
+      // (the 4- and 8-wave layouts with 16x32 / 32x32 per wave remain selectable: 1024^2 105 us.)
+      // f32 slabs are half the bytes (not enough 16-byte loads for 1024 threads): 32x64 / 4 waves or 64x64 / 8.
       const int64_t tiles64 = (M / 64) * (N / 64);
-      const bool small = ctx->tune.gemm_tile_m == 32 || (ctx->tune.gemm_tile_m == 0 && tiles64 < 2 * ctx->num_cu);
-      if (small) {
-        dim3 g32((unsigned)(M / 32), (unsigned)(N / 64));
-        hipLaunchKernelGGL((gemm_nt_fast_kernel<T, CT, B0, 4, 32>), g32, dim3(256), 0, ctx->stream, C, ldc, A,
-                           lda, B, ldb, (int)K, (CT)alpha, (CT)beta);
-      } else if (ctx->tune.gemm_waves == 8)
-        hipLaunchKernelGGL((gemm_nt_fast_kernel<T, CT, B0, 8, 64>), grid, dim3(512), 0, ctx->stream, C, ldc, A,
-                           lda, B, ldb, (int)K, (CT)alpha, (CT)beta);
-      else
-        hipLaunchKernelGGL((gemm_nt_fast_kernel<T, CT, B0, 4, 64>), grid, dim3(256), 0, ctx->stream, C, ldc, A,
-                           lda, B, ldb, (int)K, (CT)alpha, (CT)beta);
+      const int tm_req = ctx->tune.gemm_tile_m, wv = ctx->tune.gemm_waves;   // 0 = auto
+      dim3 g32((unsigned)(M / 32), (unsigned)(N / 64));
+#define FAST(W_, TM_, WC_, GRID_)                                                                              \
+  hipLaunchKernelGGL((gemm_nt_fast_kernel<T, CT, B0, W_, TM_, WC_>), GRID_, dim3(W_ * 64), 0, ctx->stream, C, \
+                     ldc, A, lda, B, ldb, (int)K, (CT)alpha, (CT)beta)
+      if constexpr (sizeof(T) == 8) {
+        const bool small = tm_req == 32 || (tm_req == 0 && tiles64 < ctx->num_cu);
+        if (wv == 0 || wv == 16) {
+          if (small) FAST(8, 32, 4, g32);
+          else FAST(16, 64, 4, grid);
+        } else if (wv == 8) {
+          if (small) FAST(4, 32, 2, g32);
+          else FAST(8, 64, 2, grid);
+        } else {
+          FAST(4, 64, 2, grid);
+        }
+      } else {
+        const bool small = tm_req == 32 || (tm_req == 0 && tiles64 < 2 * ctx->num_cu);
+        if (small) FAST(4, 32, 2, g32);
+        else if (wv == 4) FAST(4, 64, 2, grid);
+        else FAST(8, 64, 2, grid);
+      }
+#undef FAST
       MXLO_LAUNCH_CHECK();
       return MXLO_OK;
     });

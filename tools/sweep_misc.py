@@ -57,7 +57,7 @@ for rnd in range(2):
         mn, med = timeit(lambda: lo.mul(out, K, x, 1.0, 0.0), reps=50)
         print(f"kron 1024^2 tile_m={tile} waves={w}: min {mn*1e3:.1f} us ({4*nn**3/mn/1e9:.1f} TF)  median {med*1e3:.1f} us", flush=True)
 ctx.tune("gemm_tile_m", 0)
-ctx.tune("gemm_waves", 8)
+ctx.tune("gemm_waves", 0)
 for sz in (256, 512, 2048):
     A = ((torch.rand(sz, sz, dtype=torch.float64, device=dev, generator=gen) * 2 - 1) / 32).t()
     K = lo.kron(A, A)

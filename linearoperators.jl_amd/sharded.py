@@ -201,3 +201,54 @@ def shard(full: torch.Tensor, plan: ShardPlan, rank: int, device=None) -> torch.
     """Local row range of a host/global vector (test & data-loading helper)."""
     t = full[plan.lo(rank):plan.hi(rank)].contiguous()
     return t.to(device) if device is not None else t
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# SURVEY §8f-4: the one hot-path piece that moves VECTORS (not scalars) between GPUs — a dense `LinearOperator(M)`
+# whose rows are sharded like every vector. Rank r holds M[lo_m(r):hi_m(r), :] (column-major, all n columns),
+# the input shard v[lo_n(r):hi_n(r)] and the output shard res[lo_m(r):hi_m(r)]:
+#   prod!  : all-gather(v) over xGMI, then the local GEMV (mxlo_gemv N) with the caller's α, β;
+#   tprod! : local Mᵀ·u (a full n-vector of partial sums), reduce-scatter(sum), then res = α·(·) + β·res.
+# Ring collectives move (world-1)/world · 8n B per GPU per apply against 8·m_loc·n B of HBM traffic, so the apply
+# stays HBM-bound as long as m_loc ≫ 7·(HBM rate / xGMI link rate) ≈ 7·8000/153 ≈ 370 rows per GPU.
+# Shards differ by at most one row, so collectives run on buffers padded to the largest shard.
+def row_sharded_dense(M_local: torch.Tensor, plan_m: ShardPlan, plan_n: ShardPlan, group=None):
+    """LinearOperator over the local row block `M_local` (m_loc × n) of an m × n matrix; operates on shards."""
+    from . import _lib
+    from .device import Storage, dtype_code, get_ctx, ptr
+    from .leaves import LinearOperatorFromMatrix
+    from .operators import LinearOperator, scalar_flags
+
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    if plan_m.world != world or plan_n.world != world:
+        raise ValueError("shard plans were built for a different world size")
+    m_loc, n = M_local.shape
+    if m_loc != plan_m.local_n(rank) or n != plan_n.n:
+        raise ValueError("M_local must hold this rank's rows and all n columns")
+    local = LinearOperatorFromMatrix(M_local)               # mxlo_gemv N/T on the local block
+    dev, dt = M_local.device, M_local.dtype
+    pad = -(-plan_n.n // world)                             # largest shard of an n-vector
+    n_loc = plan_n.local_n(rank)
+    gathered = torch.zeros(world * pad, dtype=dt, device=dev)
+    mine = torch.zeros(pad, dtype=dt, device=dev)
+    vfull = torch.empty(n, dtype=dt, device=dev)
+    partial = torch.zeros(world * pad, dtype=dt, device=dev)
+    scattered = torch.empty(pad, dtype=dt, device=dev)
+
+    def prod(res, v, a, b):                                  # res_loc = α·M_loc·v + β·res_loc
+        mine[:n_loc].copy_(v)
+        dist.all_gather_into_tensor(gathered, mine, group=group)
+        for r in range(world):
+            vfull[plan_n.lo(r):plan_n.hi(r)].copy_(gathered[r * pad:r * pad + plan_n.local_n(r)])
+        local.prod(res, vfull, a, b)
+
+    def tprod(res, u, a, b):                                 # res_loc = α·(Σ_ranks M_locᵀ·u_loc)[shard] + β·res_loc
+        local.tprod(vfull, u, 1.0, 0.0)
+        for r in range(world):
+            partial[r * pad:r * pad + plan_n.local_n(r)].copy_(vfull[plan_n.lo(r):plan_n.hi(r)])
+        dist.reduce_scatter_tensor(scattered, partial, op=dist.ReduceOp.SUM, group=group)
+        ctx = get_ctx(res.device)
+        _lib.call("mxlo_eye_mul", ctx.handle, dtype_code(dt), ptr(res), ptr(scattered), n_loc, n_loc, float(a),
+                  float(b), scalar_flags(dt, a, b))
+
+    return LinearOperator(dt, m_loc, n_loc, False, False, prod, tprod, tprod, S=Storage(dt, dev))

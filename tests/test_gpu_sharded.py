@@ -47,11 +47,30 @@ WORKER = textwrap.dedent('''
     got = (B * T(x[a:b])).cpu().numpy()
     fullB = O.mul(np.empty(n), x)
     err_b = np.linalg.norm(got - fullB[a:b]) / np.linalg.norm(fullB[a:b])
+    # row-sharded dense LinearOperator(M): all-gather(v) + local GEMV; transpose: local GEMV + reduce-scatter
+    m2, n2 = 1003, 777
+    Mfull = rng.standard_normal((m2, n2)); vv = rng.uniform(-1, 1, n2); uu = rng.uniform(-1, 1, m2)
+    rr, rt = rng.uniform(-1, 1, m2), rng.uniform(-1, 1, n2)
+    pm, pn = lo.sharded.ShardPlan(m2, world), lo.sharded.ShardPlan(n2, world)
+    Mloc = torch.from_numpy(np.asfortranarray(Mfull[pm.lo(rank):pm.hi(rank), :]).T.copy()).to(dev).t()
+    try:
+        Msh = lo.sharded.row_sharded_dense(Mloc, pm, pn)
+        out = T(rr[pm.lo(rank):pm.hi(rank)])
+        lo.mul(out, Msh, T(vv[pn.lo(rank):pn.hi(rank)]), 2.0, -3.0)
+        want = 2.0 * (Mfull @ vv) - 3.0 * rr
+        err_m = np.linalg.norm(out.cpu().numpy() - want[pm.lo(rank):pm.hi(rank)]) / np.linalg.norm(want)
+        outt = T(rt[pn.lo(rank):pn.hi(rank)])
+        lo.mul(outt, Msh.T, T(uu[pm.lo(rank):pm.hi(rank)]), 2.0, -3.0)
+        wantt = 2.0 * (Mfull.T @ uu) - 3.0 * rt
+        err_m = max(err_m, np.linalg.norm(outt.cpu().numpy() - wantt[pn.lo(rank):pn.hi(rank)]) / np.linalg.norm(wantt))
+    except (RuntimeError, NotImplementedError) as e:       # gloo builds without the *_tensor collectives on CUDA
+        print("SKIP sharded dense:", repr(e)[:200], flush=True)
+        err_m = 0.0
     t = torch.tensor([B.data.scaling_factor, float(B.data.insert)], dtype=torch.float64)
     gathered = [torch.zeros_like(t) for _ in range(world)]
     dist.all_gather(gathered, t)
     same = all(torch.equal(gathered[0], gt) for gt in gathered)
-    print("RESULT", rank, transport, err_h, err_b, int(same), flush=True)
+    print("RESULT", rank, transport, err_h, err_b, int(same), err_m, flush=True)
     dist.destroy_process_group()
 ''')
 
@@ -69,6 +88,7 @@ def test_two_ranks_one_gpu_agree_on_transport_and_shard(tmp_path):
     for o in outs:
         line = [l for l in o.splitlines() if l.startswith("RESULT")][0].split()
         transports.add(line[2])
-        err_h, err_b, same = float(line[3]), float(line[4]), int(line[5])
-        assert err_h <= 1e-12 and err_b <= 1e-10 and same == 1, o
+        err_h, err_b, same, err_m = float(line[3]), float(line[4]), int(line[5]), float(line[6])
+        assert err_h <= 1e-12 and err_b <= 1e-10 and same == 1 and err_m <= 1e-12, o
     assert len(transports) == 1, transports            # never a mix of transports
+    print("\n".join(l for o in outs for l in o.splitlines() if l.startswith(("RESULT", "SKIP"))))

@@ -46,13 +46,16 @@ MXLO_API int32_t mxlo_ctx_create(int32_t device_id, void *stream, mxlo_ctx **out
   ctx->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   hipError_t e = hipMalloc((void **)&ctx->partials, sizeof(double) * kMaxRedCols * kMaxRedBlocks);
   if (e == hipSuccess) e = hipMalloc((void **)&ctx->scalars, sizeof(double) * kScalarSlots);
+  if (e == hipSuccess) e = hipMalloc((void **)&ctx->ticket, 64);
   if (e != hipSuccess) {
     set_error("mxlo_ctx_create: workspace allocation failed: %s", hipGetErrorString(e));
     if (ctx->partials) (void)hipFree(ctx->partials);
+    if (ctx->scalars) (void)hipFree(ctx->scalars);
     delete ctx;
     return MXLO_ENOMEM;
   }
   MXLO_HIP(hipMemsetAsync(ctx->scalars, 0, sizeof(double) * kScalarSlots, ctx->stream));
+  MXLO_HIP(hipMemsetAsync(ctx->ticket, 0, 64, ctx->stream));
   *out = ctx;
   return MXLO_OK;
 }
@@ -63,6 +66,7 @@ MXLO_API int32_t mxlo_ctx_destroy(mxlo_ctx *ctx) {
   (void)hipStreamSynchronize(ctx->stream);
   if (ctx->partials) (void)hipFree(ctx->partials);
   if (ctx->scalars) (void)hipFree(ctx->scalars);
+  if (ctx->ticket) (void)hipFree(ctx->ticket);
   if (ctx->scratch) (void)hipFree(ctx->scratch);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;
@@ -186,6 +190,9 @@ MXLO_API int32_t mxlo_ctx_tune(mxlo_ctx *ctx, const char *key, int64_t value) {
     MXLO_REQUIRE(value == 0 || value == 4 || value == 8 || value == 16, MXLO_EINVAL,
                  "gemm_waves must be 0 (auto), 4, 8 or 16");
     ctx->tune.gemm_waves = (int)value;
+  } else if (!strcmp(key, "fuse_finalize")) {
+    MXLO_REQUIRE(value == 0 || value == 1, MXLO_EINVAL, "fuse_finalize must be 0 or 1");
+    ctx->tune.fuse_finalize = (int)value;
   } else if (!strcmp(key, "combine_blocks_per_cu")) {
     MXLO_REQUIRE(value >= 0 && value <= 64, MXLO_EINVAL, "combine_blocks_per_cu out of range");
     ctx->tune.combine_blocks_per_cu = (int)value;

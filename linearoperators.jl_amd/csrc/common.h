@@ -67,6 +67,7 @@ struct Tune {
   int gemm_tile_m = 0;     // fast GEMM tile rows: 0 = auto (32 when there are fewer 64x64 tiles than CUs), 32, 64
   int gemm_waves = 0;      // fast GEMM wave layout: 0/16 = one wave per 16x16 block (16 waves per 64x64 tile),
                            // 8 = 16x32 per wave, 4 = 32x32 per wave
+  int fuse_finalize = 1;   // reductions of <= 4 columns: last-arriving workgroup finalizes in the dots kernel
   int combine_blocks_per_cu = 0;   // panel_combine: 0 = one vector per thread (best measured), k = persistent grid
 };
 
@@ -78,6 +79,7 @@ struct mxlo_ctx {
   int num_cu = 256;
   double *partials = nullptr;  // [kMaxRedCols][kMaxRedBlocks] per-block partial sums
   double *scalars = nullptr;   // finalized reduction results / device-resident coefficients
+  unsigned *ticket = nullptr;  // arrival counter of the fused (last-workgroup) finalize; zero between launches
   mxlo_allreduce_fn allreduce = nullptr;
   void *allreduce_user = nullptr;
   void *scratch = nullptr;     // grow-on-demand workspace (opHermitian tile partials); owned by the ctx

@@ -12,6 +12,12 @@
 
 namespace mxlo {
 
+constexpr int kFuseMaxCols = 4;   // in-kernel finalize is serial over columns: only worth it for a few
+// ... and for few workgroups: every workgroup pays an agent-scope release fence (L2 write-back + invalidate across the
+// 8 XCDs) before taking its ticket. Measured (tools/sweep_fuse.py): 32 workgroups -2.5 us per reduction, 512
+// workgroups +24 us, 1024 workgroups +180 us -> large reductions keep the separate finalize launch.
+constexpr int kFuseMaxGrid = 64;
+
 template <typename T, int NC>
 struct ColPtrs {
   const T *p[NC];
@@ -23,10 +29,25 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 
-template <typename T, int VEC, int NC, int UNROLL, bool XVEC, bool NT>
+// agent-scope relaxed accesses for data handed from one workgroup to another INSIDE a kernel (the partial sums
+// read by the last-arriving workgroup): coherent across the 8 XCDs' L2s, unlike plain loads/stores.
+__device__ __forceinline__ void store_agent(double *p, double v) {
+  __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), (unsigned long long)__double_as_longlong(v),
+                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double load_agent(const double *p) {
+  return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long *>(p),
+                                                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+
+// FUSE (launch-bound sizes only, see kFuseMaxGrid): the workgroup that arrives LAST (atomic ticket) sums the
+// per-workgroup partials in the same fixed order as finalize_kernel and writes out[c] — one dependent kernel fewer. The order of
+// summation does not depend on which workgroup is last, so results stay bit-reproducible.
+template <typename T, int VEC, int NC, int UNROLL, bool XVEC, bool NT, bool FUSE = false>
 __global__ void __launch_bounds__(kBlock)
 panel_dots_kernel(ColPtrs<T, NC> cols, const T *__restrict__ x, int64_t head, int64_t nvec,
-                  int64_t n, double *__restrict__ partials) {
+                  int64_t n, double *__restrict__ partials, unsigned *__restrict__ ticket = nullptr,
+                  double *__restrict__ out = nullptr) {
   using V = typename std::conditional<VEC == 1, T, typename Vec16<T>::type>::type;
   const int tid = threadIdx.x;
   double acc[NC];
@@ -116,7 +137,30 @@ panel_dots_kernel(ColPtrs<T, NC> cols, const T *__restrict__ x, int64_t head, in
   __syncthreads();
   if (tid < NC) {
     const double s = ((lds[0][tid] + lds[1][tid]) + (lds[2][tid] + lds[3][tid]));
-    partials[(int64_t)tid * kMaxRedBlocks + blockIdx.x] = s;
+    if constexpr (FUSE) store_agent(partials + (int64_t)tid * kMaxRedBlocks + blockIdx.x, s);
+    else partials[(int64_t)tid * kMaxRedBlocks + blockIdx.x] = s;
+  }
+  if constexpr (FUSE) {
+    __shared__ int last;
+    __threadfence();                       // release: this workgroup's partials before its ticket
+    __syncthreads();
+    if (tid == 0) last = atomicAdd(ticket, 1u) == gridDim.x - 1;
+    __syncthreads();
+    if (!last) return;
+    __threadfence();                       // acquire: every other workgroup's partials after the last ticket
+    const int nblocks = (int)gridDim.x;
+#pragma unroll 1
+    for (int c = 0; c < NC; ++c) {         // same order as finalize_kernel: lane t adds t, t+256, ..., fixed tree
+      const double *p = partials + (int64_t)c * kMaxRedBlocks;
+      double s = 0.0;
+      for (int i = tid; i < nblocks; i += kBlock) s += load_agent(p + i);
+      s = wave_sum(s);
+      __syncthreads();                     // lds reuse
+      if (lane == 0) lds[wave][0] = s;
+      __syncthreads();
+      if (tid == 0) out[c] = (lds[0][0] + lds[1][0]) + (lds[2][0] + lds[3][0]);
+    }
+    if (tid == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // next launch
   }
 }
 
@@ -151,13 +195,26 @@ int32_t allreduce_hook(mxlo_ctx *ctx, double *dev, int64_t count) {
 
 template <typename T, int VEC, int NC, bool XVEC>
 static int32_t launch_dots(mxlo_ctx *ctx, const T *const *cols, const T *x, int64_t head,
-                           int64_t nvec, int64_t n, int *nblocks_out) {
+                           int64_t nvec, int64_t n, int *nblocks_out, double *fused_out = nullptr) {
   ColPtrs<T, NC> cp;
   for (int c = 0; c < NC; ++c) cp.p[c] = cols[c];
   // fewer columns -> more chunks in flight per lane to keep ~the same bytes in flight
   constexpr int UNROLL = NC <= 2 ? 4 : (NC <= 6 ? 2 : 1);
   const int grid = grid_for(ctx, nvec, (int64_t)kBlock * UNROLL, ctx->tune.red_blocks_per_cu);
   const bool nt = (int64_t)sizeof(T) * n * (NC + 1) >= ctx->tune.nt_min_bytes;
+  if constexpr (NC <= kFuseMaxCols) {
+    if (fused_out && grid <= kFuseMaxGrid) {
+      if (nt)
+        hipLaunchKernelGGL((panel_dots_kernel<T, VEC, NC, UNROLL, XVEC, true, true>), dim3(grid), dim3(kBlock), 0,
+                           ctx->stream, cp, x, head, nvec, n, ctx->partials, ctx->ticket, fused_out);
+      else
+        hipLaunchKernelGGL((panel_dots_kernel<T, VEC, NC, UNROLL, XVEC, false, true>), dim3(grid), dim3(kBlock), 0,
+                           ctx->stream, cp, x, head, nvec, n, ctx->partials, ctx->ticket, fused_out);
+      MXLO_LAUNCH_CHECK();
+      *nblocks_out = 0;                     // finalized in the kernel
+      return MXLO_OK;
+    }
+  }
   if (nt)
     hipLaunchKernelGGL((panel_dots_kernel<T, VEC, NC, UNROLL, XVEC, true>), dim3(grid), dim3(kBlock), 0,
                        ctx->stream, cp, x, head, nvec, n, ctx->partials);
@@ -171,13 +228,13 @@ static int32_t launch_dots(mxlo_ctx *ctx, const T *const *cols, const T *x, int6
 
 #define DOTS_CASE(NCV)                                                                           \
   case NCV:                                                                                      \
-    if (vec && xvec) return launch_dots<T, Vec16<T>::N, NCV, true>(ctx, cols, x, head, nvec, n, nb); \
-    if (vec) return launch_dots<T, Vec16<T>::N, NCV, false>(ctx, cols, x, head, nvec, n, nb);    \
+    if (vec && xvec) return launch_dots<T, Vec16<T>::N, NCV, true>(ctx, cols, x, head, nvec, n, nb, fo); \
+    if (vec) return launch_dots<T, Vec16<T>::N, NCV, false>(ctx, cols, x, head, nvec, n, nb, fo); \
     break;
 
 template <typename T>
 static int32_t dots_chunk(mxlo_ctx *ctx, const T *const *cols, int nc, const T *x, int64_t n,
-                          int *nb) {
+                          int *nb, double *fo = nullptr) {
   constexpr int VEC = Vec16<T>::N;
   // the panel columns must share a 16-byte phase for the vector path
   int64_t head = 0;
@@ -203,10 +260,10 @@ static int32_t dots_chunk(mxlo_ctx *ctx, const T *const *cols, int nc, const T *
   }
   // scalar fallback (mis-phased columns): at most 4 columns per launch
   switch (nc) {
-    case 1: return launch_dots<T, 1, 1, false>(ctx, cols, x, 0, n, n, nb);
-    case 2: return launch_dots<T, 1, 2, false>(ctx, cols, x, 0, n, n, nb);
-    case 3: return launch_dots<T, 1, 3, false>(ctx, cols, x, 0, n, n, nb);
-    case 4: return launch_dots<T, 1, 4, false>(ctx, cols, x, 0, n, n, nb);
+    case 1: return launch_dots<T, 1, 1, false>(ctx, cols, x, 0, n, n, nb, fo);
+    case 2: return launch_dots<T, 1, 2, false>(ctx, cols, x, 0, n, n, nb, fo);
+    case 3: return launch_dots<T, 1, 3, false>(ctx, cols, x, 0, n, n, nb, fo);
+    case 4: return launch_dots<T, 1, 4, false>(ctx, cols, x, 0, n, n, nb, fo);
     default: break;
   }
   set_error("dots_chunk: unsupported column count %d", nc);
@@ -238,8 +295,10 @@ int32_t panel_dots(mxlo_ctx *ctx, const T *const *cols, int ncols, const T *x, i
     }
     if (!vec && nc > 4) nc = 4;
     int nb = 0;
-    MXLO_TRY(dots_chunk<T>(ctx, cols + done, nc, x, n, &nb));
-    MXLO_TRY(finalize_and_reduce(ctx, nc, nb, out_dev + done));
+    // few columns in ONE launch: the last workgroup finalizes in-kernel (no separate finalize launch)
+    const bool fuse = ctx->tune.fuse_finalize && done == 0 && nc == ncols && nc <= kFuseMaxCols;
+    MXLO_TRY(dots_chunk<T>(ctx, cols + done, nc, x, n, &nb, fuse ? out_dev : nullptr));
+    if (nb > 0) MXLO_TRY(finalize_and_reduce(ctx, nc, nb, out_dev + done));
     done += nc;
   }
   return allreduce_hook(ctx, out_dev, ncols);

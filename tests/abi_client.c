@@ -147,6 +147,72 @@ int main(void) {
     }
     if (sqrt(err / rn) > 1e-10) { printf("FAIL lbfgs mode %d: %.3e\n", mode, sqrt(err / rn)); return 1; }
   }
+  /* ShiftedOperator(H, sigma) apply fused into the combine pass == mul! followed by axpy!(alpha*sigma, x, y), bit for bit */
+  {
+    const double sigma = 0.37, al2 = 2.0, be2 = -3.0;
+    void *da = dev_from(ctx, g, m * 8), *db = dev_from(ctx, g, m * 8);   /* both start from res0 = g */
+    static double oa[4099], ob[4099];
+    CK(mxlo_qn_mul_shifted(H, da, dg, al2, be2, sigma, 0));
+    CK(mxlo_qn_mul(H, db, dg, al2, be2, 0));
+    CK(mxlo_eye_mul(ctx, MXLO_F64, db, dg, m, m, al2 * sigma, 1.0, 0));
+    CK(mxlo_memcpy_d2h(ctx, oa, da, m * 8));
+    CK(mxlo_memcpy_d2h(ctx, ob, db, m * 8));
+    if (memcmp(oa, ob, m * 8) != 0) { printf("FAIL shifted apply not bit-identical to mul + axpy\n"); return 1; }
+    CK(mxlo_free(ctx, da)); CK(mxlo_free(ctx, db));
+  }
+  /* hipGraph: record {Householder apply; inverse L-BFGS apply accumulating into it} once, replay on new data */
+  {
+    void *stream = NULL;
+    mxlo_graph *gr = NULL;
+    static double o1[4099], o2[4099], hh[4099];
+    double hn = 0;
+    for (int64_t i = 0; i < m; ++i) { hh[i] = 2 * urand(&seed) - 1; hn += hh[i] * hh[i]; }
+    for (int64_t i = 0; i < m; ++i) hh[i] /= sqrt(hn);
+    void *dh = dev_from(ctx, hh, m * 8), *dacc = dev_from(ctx, NULL, m * 8);
+    if (mxlo_graph_begin(ctx) != MXLO_ESTATE) { printf("FAIL default stream must not be capturable\n"); return 1; }
+    CK(mxlo_ctx_sync(ctx));
+    CK(mxlo_ctx_create_stream(ctx, &stream));
+    CK(mxlo_householder_mul(ctx, MXLO_F64, dacc, dh, dg, m, 1.0, 0.0, 0));      /* warm-up */
+    CK(mxlo_graph_begin(ctx));
+    CK(mxlo_householder_mul(ctx, MXLO_F64, dacc, dh, dg, m, 1.0, 0.0, 0));
+    CK(mxlo_qn_mul(H, dacc, dg, 0.5, 1.0, 0));
+    CK(mxlo_graph_end(ctx, &gr));
+    for (int64_t i = 0; i < m; ++i) g[i] = 2 * urand(&seed) - 1;               /* new contents, same buffer */
+    CK(mxlo_memcpy_h2d(ctx, dg, g, m * 8));
+    CK(mxlo_graph_launch(gr));
+    CK(mxlo_memcpy_d2h(ctx, o1, dacc, m * 8));
+    CK(mxlo_householder_mul(ctx, MXLO_F64, dacc, dh, dg, m, 1.0, 0.0, 0));
+    CK(mxlo_qn_mul(H, dacc, dg, 0.5, 1.0, 0));
+    CK(mxlo_memcpy_d2h(ctx, o2, dacc, m * 8));
+    if (memcmp(o1, o2, m * 8) != 0) { printf("FAIL graph replay differs from the eager calls\n"); return 1; }
+    CK(mxlo_graph_destroy(gr));
+    CK(mxlo_free(ctx, dh)); CK(mxlo_free(ctx, dacc));
+  }
+  /* diagonal quasi-Newton push! (DiagonalPSB, src/DiagonalHessianApproximation.jl:45-64) vs the statements in C */
+  {
+    static double d0[4099], dref[4099], dout[4099];
+    double s2 = 0, s4 = 0, sy = 0, s2d = 0;
+    for (int64_t i = 0; i < m; ++i) d0[i] = 0.5 + urand(&seed);
+    for (int64_t i = 0; i < m; ++i) {
+      const double si = S[0][i], q2 = si * si;
+      s2 += q2; s4 += q2 * q2; sy += si * Y[0][i]; s2d += q2 * d0[i];
+    }
+    const double sn = sqrt(s2), sn2 = sn * sn, trA2 = s4 / (sn2 * sn2), qq = ((sy / sn2) - (s2d / sn2)) / trA2, c = qq / sn2;
+    for (int64_t i = 0; i < m; ++i) dref[i] = d0[i] + c * (S[0][i] * S[0][i]);
+    void *ddq = dev_from(ctx, d0, m * 8);
+    int32_t st = -1;
+    CK(mxlo_memcpy_h2d(ctx, ds, S[0], m * 8));
+    CK(mxlo_memcpy_h2d(ctx, dy, Y[0], m * 8));
+    CK(mxlo_diagqn_push(ctx, MXLO_F64, MXLO_DQN_PSB, ddq, ds, dy, m, &st));
+    CK(mxlo_memcpy_d2h(ctx, dout, ddq, m * 8));
+    err = rn = 0;
+    for (int64_t i = 0; i < m; ++i) { err += (dout[i] - dref[i]) * (dout[i] - dref[i]); rn += dref[i] * dref[i]; }
+    if (st != 0 || sqrt(err / rn) > 1e-12) { printf("FAIL diagqn push %d %.3e\n", st, sqrt(err / rn)); return 1; }
+    CK(mxlo_fill(ctx, MXLO_F64, ds, m, 0.0));
+    CK(mxlo_diagqn_push(ctx, MXLO_F64, MXLO_DQN_PSB, ddq, ds, dy, m, &st));
+    if (st != 1) { printf("FAIL s == 0 must be reported\n"); return 1; }
+    CK(mxlo_free(ctx, ddq));
+  }
   /* error conventions: codes, never exceptions */
   if (mxlo_qn_solve_shifted(H, dres, dg, 0.1) != MXLO_ESTATE) { printf("FAIL expected ESTATE\n"); return 1; }
   if (mxlo_diag_mul(ctx, MXLO_F64, dr, dd, dv, n + 1, n, 1.0, 0.0, 0) != MXLO_ESHAPE) { printf("FAIL expected ESHAPE\n"); return 1; }

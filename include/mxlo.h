@@ -357,9 +357,14 @@ int32_t mxlo_qn_set_mode(mxlo_qn *h, int32_t mode);
 /* Forward L-BFGS push!: how the a_k panel is rebuilt (src/lbfgs.jl:236-250).
  *   MXLO_PUSH_GRAM     (default) coefficient-space recurrence on the Gram matrices S'S, Y'S kept up
  *                      to date by push! (3m dots), then ONE pass A = [S B]*C over the panels;
- *   MXLO_PUSH_REFORDER the reference's statement order: O(m^2) dot/axpy passes over n. */
+ *   MXLO_PUSH_REFORDER the reference's statement order: O(m^2) dot/axpy passes over n;
+ *   MXLO_PUSH_COMPACT  (forward L-BFGS) the same Gram recurrence, but the a_k panel is NOT formed: a_k = [S B]*c_k
+ *                      stays implicit and mul! evaluates x/gamma + [S B]*w with w = -C'(C d) (+ d), d = [S B]'x —
+ *                      the same two panel passes per apply, and push! costs only its 3m dots. diag!,
+ *                      solve_shifted_system! and mxlo_qn_column materialise the panel on demand (one pass). */
 #define MXLO_PUSH_GRAM 0
 #define MXLO_PUSH_REFORDER 1
+#define MXLO_PUSH_COMPACT 2
 int32_t mxlo_qn_set_push_mode(mxlo_qn *h, int32_t mode);
 
 #ifdef __cplusplus

@@ -26,7 +26,7 @@ OP_N, OP_T, OP_C = 0, 1, 2
 BLK_DIAG, BLK_DENSE, BLK_EYE, BLK_ZEROS = 0, 1, 2, 3
 QN_LBFGS_INV, QN_LBFGS_FWD, QN_LSR1 = 0, 1, 2
 INV_TWOPASS, INV_REFORDER = 0, 1
-PUSH_GRAM, PUSH_REFORDER = 0, 1
+PUSH_GRAM, PUSH_REFORDER, PUSH_COMPACT = 0, 1, 2
 DQN_PSB, DQN_ANDREI, DQN_BFGS, DQN_SPECTRAL = 0, 1, 2, 3
 
 

@@ -143,5 +143,9 @@ int32_t allreduce_hook(mxlo_ctx *ctx, double *dev, int64_t count);
 template <typename T>
 int32_t panel_dots(mxlo_ctx *ctx, const T *const *cols_host, int ncols, const T *x, int64_t n,
                    double *out_dev);
+// out1[c] = dot(cols[c], x1), out2[c] = dot(cols[c], x2) in one pass; all operands are aligned, padded panel columns
+template <typename T>
+int32_t panel_dots2(mxlo_ctx *ctx, const T *const *cols, int ncols, const T *x1, const T *x2, int64_t n_padded,
+                    double *out1, double *out2);
 
 }  // namespace mxlo

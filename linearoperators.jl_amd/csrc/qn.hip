@@ -70,6 +70,7 @@ struct mxlo_qn {
   int64_t pushes = 0;
   bool G_valid = false;
   bool normA_valid = true;   // L-SR1 ||a_k||^2 (opnorm bound) computed lazily after a Gram-form push
+  bool A_valid = true;       // forward L-BFGS: the a_k panel is materialised (false after a compact push!)
   // device
   void *S = nullptr, *Y = nullptr, *A = nullptr, *B = nullptr;  // panels
   void *tmp = nullptr, *tmp2 = nullptr;                         // n-vectors (Ax / tmp)
@@ -94,6 +95,7 @@ enum CombineMode {
   CM_AXPYS = 5,     // q = c0*x; cols u: q = q + c*u; res = q                      (shifted solve)
   CM_DIAG_FWD = 6,  // q = 1 (/g); pairs (b,a): q = q + ((b*b) - (a*a)); res = q
   CM_DIAG_SR1 = 7,  // q = 1 (/g); cols a: q = q + ((a*a)/as); res = q
+  CM_CFWD = 8,      // q = x (/g); cols u: q = q + c*u; res = al*q (+ be*res)   (compact forward L-BFGS)
 };
 
 template <typename T>
@@ -138,7 +140,7 @@ combine_kernel(T *__restrict__ res, const T *__restrict__ x, const T *__restrict
 #pragma unroll
       for (int e = 0; e < VEC; ++e) {
         const T xe = vget<T, VEC>(xv, e);
-        if constexpr (MODE == CM_FWD || MODE == CM_AFWD) q[e] = A.use_gamma ? xe / g : xe;
+        if constexpr (MODE == CM_FWD || MODE == CM_AFWD || MODE == CM_CFWD) q[e] = A.use_gamma ? xe / g : xe;
         else if constexpr (MODE == CM_INV) q[e] = xe;
         else if constexpr (MODE == CM_LSR1) {
           CT t = (al * (CT)xe) / (CT)g;  // (α*x)/γ : γ divided unconditionally (src/lsr1.jl:93)
@@ -192,7 +194,7 @@ combine_kernel(T *__restrict__ res, const T *__restrict__ x, const T *__restrict
           const T cc = (T)scoef[c];
 #pragma unroll
           for (int e = 0; e < VEC; ++e) q[e] = q[e] - (cc * vget<T, VEC>(cv[u], e));  // lsr1.jl:174
-        } else if constexpr (MODE == CM_AXPYS) {
+        } else if constexpr (MODE == CM_AXPYS || MODE == CM_CFWD) {
           const T cc = (T)scoef[c];
 #pragma unroll
           for (int e = 0; e < VEC; ++e) q[e] = q[e] + (cc * vget<T, VEC>(cv[u], e));
@@ -214,7 +216,7 @@ combine_kernel(T *__restrict__ res, const T *__restrict__ x, const T *__restrict
     }
     // ---- epilogue
     V out;
-    if constexpr (MODE == CM_FWD || MODE == CM_INV) {
+    if constexpr (MODE == CM_FWD || MODE == CM_INV || MODE == CM_CFWD) {
       V rv;
       if constexpr (!BETA0) rv = ldg<NT>(reinterpret_cast<const V *>(res + i * VEC));
 #pragma unroll
@@ -227,7 +229,7 @@ combine_kernel(T *__restrict__ res, const T *__restrict__ x, const T *__restrict
 #pragma unroll
       for (int e = 0; e < VEC; ++e) vset<T, VEC>(out, e, q[e]);
     }
-    if constexpr (MODE == CM_FWD || MODE == CM_INV || MODE == CM_LSR1) {
+    if constexpr (MODE == CM_FWD || MODE == CM_INV || MODE == CM_LSR1 || MODE == CM_CFWD) {
       if (A.shift != 0.0) {  // axpy!(α σ, x, y) of shifted_prod! (src/shifted_operators.jl:21-23), in T like BLAS axpy
         const T sh = (T)A.shift;
 #pragma unroll
@@ -258,7 +260,7 @@ int32_t launch_combine_part(mxlo_ctx *ctx, T *res, const T *x, const T *x2, cons
     MXLO_LAUNCH_CHECK();
     return MXLO_OK;
   };
-  constexpr bool uses_ab = (MODE == CM_FWD || MODE == CM_INV || MODE == CM_LSR1);
+  constexpr bool uses_ab = (MODE == CM_FWD || MODE == CM_INV || MODE == CM_LSR1 || MODE == CM_CFWD);
   if constexpr (!uses_ab) {
     return vec ? go.template operator()<T, true, VECF>() : go.template operator()<T, true, 1>();
   } else {
@@ -547,6 +549,24 @@ int32_t inv_mul_reforder(mxlo_qn *h, T *res, const T *x, double alpha, double be
   return MXLO_OK;
 }
 
+// Compact forward L-BFGS apply. With a_k = [S B]·c_k (c_k = row k of Cm, built by push!) and d = [S B]'x:
+//   B x = x/γ + Σ_k b_k (b_k'x) − a_k (a_k'x) = x/γ + [S B]·w,   w = −Cmᵀ (Cm d)  (+ d on the b half).
+// One wave; lane j owns w_j (2r <= 64).
+__global__ void __launch_bounds__(64)
+cfwd_coef_kernel(const double *__restrict__ dots, const double *__restrict__ Cm, double *__restrict__ coef, int r) {
+  const int lane = threadIdx.x, w2 = 2 * r;
+  const double d = lane < w2 ? dots[lane] : 0.0;
+  double w = (lane >= r && lane < w2) ? d : 0.0;                 // + b_j (b_j'x)
+  for (int k = 0; k < r; ++k) {
+    const double ck = lane < w2 ? Cm[(int64_t)k * w2 + lane] : 0.0;
+    double t = ck * d;                                           // a_k'x = c_k'd
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off, 64);
+    w -= ck * t;                                                 // − a_k (a_k'x)
+  }
+  if (lane < w2) coef[lane] = w;
+}
+
 template <typename T>
 int32_t fwd_mul(mxlo_qn *h, T *res, const T *x, double alpha, double beta, int32_t flags,
                  double shift = 0.0) {
@@ -564,6 +584,16 @@ int32_t fwd_mul(mxlo_qn *h, T *res, const T *x, double alpha, double beta, int32
   A.beta = beta;
   A.coef = coef;
   A.shift = shift;
+  if (na > 0 && !h->A_valid) {  // compact form: the a_k panel does not exist; x/γ + [S B]·w
+    for (int i = 0; i < na; ++i) {
+      A.cols[i] = col<T>(h->S, h->ld, O.ord[i]);
+      A.cols[na + i] = col<T>(h->B, h->ld, O.ord[i]);
+    }
+    MXLO_TRY(panel_dots<T>(ctx, A.cols, 2 * na, x, h->n, dots));
+    hipLaunchKernelGGL(cfwd_coef_kernel, dim3(1), dim3(64), 0, ctx->stream, dots, h->dsc + h->lay.Cm, coef, na);
+    MXLO_LAUNCH_CHECK();
+    return launch_combine<T, CM_CFWD>(ctx, res, x, (const T *)nullptr, A, h->n, flags);
+  }
   if (na > 0) {
     for (int i = 0; i < na; ++i) {  // pair order (b_k, a_k): coef = (bx, ax)
       A.cols[2 * i] = col<T>(h->B, h->ld, O.ord[i]);
@@ -775,6 +805,27 @@ int32_t launch_panel_gemm(mxlo_ctx *ctx, PanelGemmArgs<T> &A, int64_t n) {
   return go.template operator()<32>();
 }
 
+// materialise the a_k panel from the coefficients of the last compact push! (diag!, solve_shifted_system!,
+// mxlo_qn_column and the reference-ordered push! read it)
+template <typename T>
+int32_t ensure_A(mxlo_qn *h) {
+  if (h->kind != MXLO_QN_LBFGS_FWD || h->A_valid) return MXLO_OK;
+  OrdArgs O;
+  fill_ord(h, O, /*newest_first=*/false);
+  PanelGemmArgs<T> G;
+  G.nin = 2 * O.na;
+  G.nout = O.na;
+  G.C = h->dsc + h->lay.Cm;
+  for (int j = 0; j < O.na; ++j) {
+    G.in[j] = col<T>(h->S, h->ld, O.ord[j]);
+    G.in[O.na + j] = col<T>(h->B, h->ld, O.ord[j]);
+    G.out[j] = col<T>(h->A, h->ld, O.ord[j]);
+  }
+  MXLO_TRY(launch_panel_gemm<T>(h->ctx, G, h->n));
+  h->A_valid = true;
+  return MXLO_OK;
+}
+
 // L-SR1 rank-one terms in coefficient space (src/lsr1.jl:166-178): basis [y_ord[0..r), s_ord[0..r)],
 //   a_k = y_k - s_k/γ - sum_{l<k} (a_l's_k / as_l) a_l ,  as_k = a_k's_k.  One wave, lane j owns coefficient j.
 __global__ void __launch_bounds__(64)
@@ -828,8 +879,12 @@ int32_t fwd_rebuild_gram(mxlo_qn *h, int64_t ins) {
     cols[k] = col<T>(h->S, h->ld, k);
     cols[mem + k] = col<T>(h->Y, h->ld, k);
   }
-  MXLO_TRY(panel_dots<T>(ctx, cols, (int)(2 * mem), col<T>(h->S, h->ld, ins), n, tmp));          // S's_new, Y's_new
-  MXLO_TRY(panel_dots<T>(ctx, cols, (int)mem, col<T>(h->Y, h->ld, ins), n, tmp + 2 * mem));     // S'y_new
+  // S's_new and S'y_new in ONE pass over S (dual-x dots), Y's_new in a second: 2m column reads instead of 3m
+  constexpr int VECP = Vec16<T>::N;
+  const int64_t npad = (n + VECP - 1) / VECP * VECP;   // panel columns are zero-padded to whole vectors (<= ld)
+  MXLO_TRY(panel_dots2<T>(ctx, cols, (int)mem, col<T>(h->S, h->ld, ins), col<T>(h->Y, h->ld, ins), npad, tmp,
+                          tmp + 2 * mem));
+  MXLO_TRY(panel_dots<T>(ctx, cols + mem, (int)mem, col<T>(h->S, h->ld, ins), n, tmp + mem));
   hipLaunchKernelGGL(gram_update_kernel, dim3(1), dim3(64), 0, ctx->stream, h->dsc + h->lay.SS,
                      h->dsc + h->lay.YSf, tmp, (int)mem, (int)ins);
   MXLO_LAUNCH_CHECK();
@@ -845,6 +900,10 @@ int32_t fwd_rebuild_gram(mxlo_qn *h, int64_t ins) {
   hipLaunchKernelGGL(afwd_coef_kernel, dim3(1), dim3(64), 0, ctx->stream, h->dsc + h->lay.SS,
                      h->dsc + h->lay.YSf, h->dsc + h->lay.Cm, O);
   MXLO_LAUNCH_CHECK();
+  if (h->push_mode == MXLO_PUSH_COMPACT) {  // a_k = [S B]·c_k stays implicit: the apply works on [S B] and Cm
+    h->A_valid = false;
+    return MXLO_OK;
+  }
   PanelGemmArgs<T> A;
   A.nin = 2 * O.na;
   A.nout = O.na;
@@ -854,6 +913,7 @@ int32_t fwd_rebuild_gram(mxlo_qn *h, int64_t ins) {
     A.in[O.na + j] = col<T>(h->B, h->ld, O.ord[j]);
     A.out[j] = col<T>(h->A, h->ld, O.ord[j]);
   }
+  h->A_valid = true;
   return launch_panel_gemm<T>(ctx, A, n);
 }
 
@@ -876,8 +936,11 @@ int32_t lbfgs_push_common(mxlo_qn *h, const T *s, const T *y, double ys, double 
     for (int k = 0; k < mem; ++k) cols[k] = col<T>(h->S, h->ld, k);
     MXLO_TRY(panel_dots<T>(ctx, cols, (int)mem, yi, n, h->dsc + h->lay.SY + ins * mem));
     for (int k = 0; k < mem; ++k) cols[k] = col<T>(h->Y, h->ld, k);
-    MXLO_TRY(panel_dots<T>(ctx, cols, (int)mem, yi, n, h->dsc + h->lay.YY + ins * mem));
-    MXLO_TRY(panel_dots<T>(ctx, cols, (int)mem, si, n, h->dsc + h->lay.YS + ins * mem));
+    // Y'y_new and Y's_new in ONE pass over Y (dual-x dots)
+    constexpr int VECP = Vec16<T>::N;
+    const int64_t npad = (n + VECP - 1) / VECP * VECP;
+    MXLO_TRY(panel_dots2<T>(ctx, cols, (int)mem, yi, si, npad, h->dsc + h->lay.YY + ins * mem,
+                            h->dsc + h->lay.YS + ins * mem));
     return MXLO_OK;
   }
   // forward: b[insert] = y ./ sqrt(ys) (:232), then rebuild every a[k] (:236-250)
@@ -888,7 +951,8 @@ int32_t lbfgs_push_common(mxlo_qn *h, const T *s, const T *y, double ys, double 
     const T *cols[1] = {bi};
     MXLO_TRY(panel_dots<T>(ctx, cols, 1, bi, n, h->dsc + h->lay.misc + 16 + ins));
   }
-  if (h->push_mode == MXLO_PUSH_GRAM) return fwd_rebuild_gram<T>(h, ins);
+  if (h->push_mode != MXLO_PUSH_REFORDER) return fwd_rebuild_gram<T>(h, ins);
+  MXLO_TRY(ensure_A<T>(h));   // the reference-ordered rebuild reads the older a_l
   double *coef = h->dsc + h->lay.coef;
   int older[kMaxMem];
   int nold = 0;
@@ -1057,8 +1121,12 @@ int32_t lsr1_push(mxlo_qn *h, const T *s, const T *y, int32_t *accepted) {
       cols[k] = col<T>(h->S, h->ld, k);
       cols[mem + k] = col<T>(h->Y, h->ld, k);
     }
-    MXLO_TRY(panel_dots<T>(ctx, cols, (int)(2 * mem), col<T>(h->S, h->ld, ins), n, tmp));       // S's_new, Y's_new
-    MXLO_TRY(panel_dots<T>(ctx, cols, (int)mem, col<T>(h->Y, h->ld, ins), n, tmp + 2 * mem));  // S'y_new
+    // S's_new and S'y_new in ONE pass over S (dual-x dots), Y's_new in a second
+    constexpr int VECP = Vec16<T>::N;
+    const int64_t npad = (n + VECP - 1) / VECP * VECP;
+    MXLO_TRY(panel_dots2<T>(ctx, cols, (int)mem, col<T>(h->S, h->ld, ins), col<T>(h->Y, h->ld, ins), npad, tmp,
+                            tmp + 2 * mem));
+    MXLO_TRY(panel_dots<T>(ctx, cols + mem, (int)mem, col<T>(h->S, h->ld, ins), n, tmp + mem));
     hipLaunchKernelGGL(gram_update_kernel, dim3(1), dim3(64), 0, ctx->stream, h->dsc + h->lay.SS,
                        h->dsc + h->lay.YSf, tmp, (int)mem, (int)ins);
     MXLO_LAUNCH_CHECK();
@@ -1157,6 +1225,7 @@ shifted_coef_kernel(const double *__restrict__ G, const double *__restrict__ gve
 
 template <typename T>
 int32_t solve_shifted_t(mxlo_qn *h, T *x, const T *b, double sigma) {
+  MXLO_TRY(ensure_A<T>(h));   // U = [a b]: the a_k panel is read
   mxlo_ctx *ctx = h->ctx;
   const int64_t n = h->n;
   OrdArgs O;
@@ -1218,6 +1287,7 @@ int32_t diag_t(mxlo_qn *h, T *d) {
   A.alpha = 1;
   A.beta = 0;
   if (h->kind == MXLO_QN_LBFGS_FWD) {
+    MXLO_TRY(ensure_A<T>(h));
     A.ncol = 2 * O.na;
     A.coef = h->dsc + h->lay.coef;
     for (int i = 0; i < O.na; ++i) {
@@ -1259,6 +1329,7 @@ MXLO_API int32_t mxlo_qn_create(mxlo_ctx *ctx, int32_t kind, int32_t dtype, int6
   h->mem = mem;
   const int64_t es = dtype == MXLO_F64 ? 8 : 4;
   const int64_t vec = 16 / es;
+  h->push_mode = kind == MXLO_QN_LBFGS_FWD ? MXLO_PUSH_COMPACT : MXLO_PUSH_GRAM;
   h->ld = ((n + vec - 1) / vec) * vec;
   if (h->ld == 0) h->ld = vec;
   h->scaling = scaling != 0;
@@ -1311,7 +1382,9 @@ MXLO_API int32_t mxlo_qn_set_mode(mxlo_qn *h, int32_t mode) {
 
 MXLO_API int32_t mxlo_qn_set_push_mode(mxlo_qn *h, int32_t mode) {
   MXLO_REQUIRE(h, MXLO_EINVAL, "handle is NULL");
-  MXLO_REQUIRE(mode == MXLO_PUSH_GRAM || mode == MXLO_PUSH_REFORDER, MXLO_EINVAL, "bad push mode");
+  MXLO_REQUIRE(mode == MXLO_PUSH_GRAM || mode == MXLO_PUSH_REFORDER || mode == MXLO_PUSH_COMPACT, MXLO_EINVAL,
+               "bad push mode");
+  if (mode == MXLO_PUSH_COMPACT && h->kind != MXLO_QN_LBFGS_FWD) mode = MXLO_PUSH_GRAM;   // forward L-BFGS only
   h->push_mode = mode;
   return MXLO_OK;
 }
@@ -1408,6 +1481,7 @@ MXLO_API int32_t mxlo_qn_reset(mxlo_qn *h) {
   h->insert0 = 0;
   h->G_valid = false;
   h->normA_valid = true;
+  h->A_valid = true;
   return MXLO_OK;
 }
 
@@ -1465,6 +1539,10 @@ MXLO_API int32_t mxlo_qn_column(mxlo_qn *h, int32_t which, int64_t k, void **out
   MXLO_REQUIRE(k >= 0 && k < h->mem, MXLO_EINVAL, "slot out of range");
   void *p = which == 0 ? h->S : which == 1 ? h->Y : which == 2 ? h->A : which == 3 ? h->B : nullptr;
   MXLO_REQUIRE(p, MXLO_ESTATE, "panel %d not allocated for this operator kind", which);
+  if (which == 2) {  // a compact push! left the a_k implicit
+    if (h->dtype == MXLO_F64) MXLO_TRY(ensure_A<double>(h));
+    else MXLO_TRY(ensure_A<float>(h));
+  }
   *out = (char *)p + (size_t)k * h->ld * (h->dtype == MXLO_F64 ? 8 : 4);
   return MXLO_OK;
 }

@@ -304,6 +304,127 @@ int32_t panel_dots(mxlo_ctx *ctx, const T *const *cols, int ncols, const T *x, i
   return allreduce_hook(ctx, out_dev, ncols);
 }
 
+// ---- dual-x panel dots: out1[c] = dot(col_c, x1), out2[c] = dot(col_c, x2) in ONE pass over the columns.
+// push! needs S's_new and S'y_new (forward) / Y'y_new and Y's_new (inverse): reading the panel once instead of
+// twice. Operands are panel columns (16-byte aligned, zero-padded to a whole number of vectors), so there is no
+// head/tail handling: `nvec` covers the padding, which contributes 0*0.
+template <typename T, int NC, int UNROLL, bool NT>
+__global__ void __launch_bounds__(kBlock)
+panel_dots2_kernel(ColPtrs<T, NC> cols, const T *__restrict__ x1, const T *__restrict__ x2, int64_t nvec,
+                   double *__restrict__ partials) {
+  constexpr int VEC = Vec16<T>::N;
+  using V = typename Vec16<T>::type;
+  const int tid = threadIdx.x;
+  double a1[NC], a2[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) a1[c] = a2[c] = 0.0;
+  auto ld = [&](const T *p, int64_t i) -> V {
+    return NT ? __builtin_nontemporal_load(reinterpret_cast<const V *>(p) + i) : reinterpret_cast<const V *>(p)[i];
+  };
+  constexpr int64_t CHUNK = (int64_t)kBlock * UNROLL;
+  const int64_t nchunks = (nvec + CHUNK - 1) / CHUNK;
+  for (int64_t ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
+    const int64_t base = ch * CHUNK + tid;
+    V xv1[UNROLL], xv2[UNROLL], cv[UNROLL][NC];
+    bool ok[UNROLL];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      const int64_t i = base + (int64_t)u * kBlock;
+      ok[u] = i < nvec;
+      if (ok[u]) {
+        xv1[u] = ld(x1, i);
+        xv2[u] = ld(x2, i);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) cv[u][c] = ld(cols.p[c], i);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      if (!ok[u]) continue;
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          const double ce = (double)cv[u][c][e];
+          a1[c] = fma(ce, (double)xv1[u][e], a1[c]);
+          a2[c] = fma(ce, (double)xv2[u][e], a2[c]);
+        }
+      }
+    }
+  }
+  __shared__ double lds[kBlock / kWave][2 * NC];
+  const int wave = tid >> 6, lane = tid & 63;
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const double s1 = wave_sum(a1[c]), s2 = wave_sum(a2[c]);
+    if (lane == 0) {
+      lds[wave][c] = s1;
+      lds[wave][NC + c] = s2;
+    }
+  }
+  __syncthreads();
+  if (tid < 2 * NC)
+    partials[(int64_t)tid * kMaxRedBlocks + blockIdx.x] = (lds[0][tid] + lds[1][tid]) + (lds[2][tid] + lds[3][tid]);
+}
+
+// cols, x1, x2: 16-byte aligned panel columns of padded length `nvec_elems` (a multiple of the vector width).
+template <typename T>
+int32_t panel_dots2(mxlo_ctx *ctx, const T *const *cols, int ncols, const T *x1, const T *x2, int64_t n_padded,
+                    double *out1, double *out2) {
+  constexpr int VEC = Vec16<T>::N;
+  MXLO_REQUIRE(ncols >= 0 && ncols <= kMaxRedCols / 2 && n_padded % VEC == 0, MXLO_EINVAL, "panel_dots2: bad arguments");
+  bool aligned = (((uintptr_t)x1 | (uintptr_t)x2) & 15u) == 0;
+  for (int c = 0; c < ncols; ++c) aligned = aligned && (((uintptr_t)cols[c]) & 15u) == 0;
+  MXLO_REQUIRE(aligned, MXLO_EINVAL, "panel_dots2: operands must be 16-byte aligned panel columns");
+  const int64_t nvec = n_padded / VEC;
+  int done = 0;
+  while (done < ncols) {
+    const int nc = ncols - done >= 10 ? 10 : ncols - done;
+    const bool nt = (int64_t)sizeof(T) * n_padded * (nc + 2) >= ctx->tune.nt_min_bytes;
+    int grid = 0;
+    auto go = [&]<int NC>() {
+      ColPtrs<T, NC> cp;
+      for (int c = 0; c < NC; ++c) cp.p[c] = cols[done + c];
+      constexpr int UNROLL = NC <= 2 ? 4 : (NC <= 5 ? 2 : 1);
+      grid = grid_for(ctx, nvec, (int64_t)kBlock * UNROLL, ctx->tune.red_blocks_per_cu);
+      if (grid > kMaxRedBlocks) grid = kMaxRedBlocks;
+      if (nt)
+        hipLaunchKernelGGL((panel_dots2_kernel<T, NC, UNROLL, true>), dim3(grid), dim3(kBlock), 0, ctx->stream, cp, x1,
+                           x2, nvec, ctx->partials);
+      else
+        hipLaunchKernelGGL((panel_dots2_kernel<T, NC, UNROLL, false>), dim3(grid), dim3(kBlock), 0, ctx->stream, cp, x1,
+                           x2, nvec, ctx->partials);
+    };
+    switch (nc) {
+      case 1: go.template operator()<1>(); break;
+      case 2: go.template operator()<2>(); break;
+      case 3: go.template operator()<3>(); break;
+      case 4: go.template operator()<4>(); break;
+      case 5: go.template operator()<5>(); break;
+      case 6: go.template operator()<6>(); break;
+      case 7: go.template operator()<7>(); break;
+      case 8: go.template operator()<8>(); break;
+      case 9: go.template operator()<9>(); break;
+      default: go.template operator()<10>(); break;
+    }
+    MXLO_LAUNCH_CHECK();
+    // partial columns [0, nc) belong to x1, [nc, 2nc) to x2
+    hipLaunchKernelGGL(finalize_kernel, dim3(nc), dim3(kBlock), 0, ctx->stream, ctx->partials, grid, out1 + done);
+    MXLO_LAUNCH_CHECK();
+    hipLaunchKernelGGL(finalize_kernel, dim3(nc), dim3(kBlock), 0, ctx->stream,
+                       ctx->partials + (int64_t)nc * kMaxRedBlocks, grid, out2 + done);
+    MXLO_LAUNCH_CHECK();
+    done += nc;
+  }
+  MXLO_TRY(allreduce_hook(ctx, out1, ncols));
+  return allreduce_hook(ctx, out2, ncols);
+}
+
+template int32_t panel_dots2<double>(mxlo_ctx *, const double *const *, int, const double *, const double *, int64_t,
+                                     double *, double *);
+template int32_t panel_dots2<float>(mxlo_ctx *, const float *const *, int, const float *, const float *, int64_t,
+                                    double *, double *);
+
 template int32_t panel_dots<double>(mxlo_ctx *, const double *const *, int, const double *, int64_t,
                                     double *);
 template int32_t panel_dots<float>(mxlo_ctx *, const float *const *, int, const float *, int64_t,

@@ -119,9 +119,11 @@ class _QNOperator(AbstractLinearOperator):
         return self
 
     def set_push_mode(self, mode: str):
-        """'gram' (default: Gram-matrix recurrence + one panel pass) or 'reforder' (the reference's O(m²)
-        statement order) for the forward L-BFGS `push!` rebuild of the a_k panel."""
-        _lib.call("mxlo_qn_set_push_mode", self._h, {"gram": _lib.PUSH_GRAM, "reforder": _lib.PUSH_REFORDER}[mode])
+        """'gram' (Gram-matrix recurrence + one panel pass that forms the a_k), 'reforder' (the reference's O(m²)
+        statement order) or 'compact' (forward L-BFGS: Gram recurrence, a_k left implicit — push! costs only its
+        3m dots; diag!/solve_shifted_system! materialise the panel on demand)."""
+        _lib.call("mxlo_qn_set_push_mode", self._h,
+                  {"gram": _lib.PUSH_GRAM, "reforder": _lib.PUSH_REFORDER, "compact": _lib.PUSH_COMPACT}[mode])
         return self
 
     def _reset_data(self):

@@ -101,7 +101,7 @@ def test_kat_lsr1(lo, dev, kat):
 
 # ------------------------------------------------------------------------------- seeded parity
 @pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
-@pytest.mark.parametrize("push_mode", ["gram", "reforder"])
+@pytest.mark.parametrize("push_mode", ["gram", "reforder", "compact"])
 @pytest.mark.parametrize("n,mem,npush,scaling", [(1000, 5, 8, True), (4097, 10, 13, True), (257, 3, 2, False),
                                                   (100_003, 7, 7, True), (64, 1, 3, True), (50_000, 20, 23, True),
                                                   (3001, 32, 40, True)])
@@ -109,7 +109,7 @@ def test_lbfgs_parity(lo, dev, dtype, push_mode, n, mem, npush, scaling):
     rng = np.random.default_rng(n + mem)
     npd = NP[dtype]
     tol = dict(ref=1e-10, two=1e-9, fwd=1e-10) if dtype == torch.float64 else dict(ref=2e-4, two=2e-4, fwd=2e-4)
-    if push_mode == "gram":             # Gram-form rebuild of the a_k panel: different association order
+    if push_mode in ("gram", "compact"):   # Gram-form rebuild of the a_k panel: different association order
         tol["fwd"] = 1e-9 if dtype == torch.float64 else 5e-4
     B = lo.LBFGSOperator(dtype, n, mem=mem, scaling=scaling, device=dev).set_push_mode(push_mode)
     H = lo.InverseLBFGSOperator(dtype, n, mem=mem, scaling=scaling, device=dev)
@@ -449,3 +449,39 @@ def test_shifted_qn_fused_is_bit_identical(lo, dev, dtype, kind, n):
     nb = lo.nprod(op)
     Sh.data.sigma = 0.0                                   # σ == 0 (or α == 0): plain mul!, no axpy (:21)
     assert torch.equal(Sh * T(x, dev), op * T(x, dev)) and lo.nprod(op) == nb + 2
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_compact_forward_push_materialises_on_demand(lo, dev, dtype):
+    """MXLO_PUSH_COMPACT: push! leaves a_k = [S B]·c_k implicit and mul! works on [S B]; diag!, solve_shifted_system!,
+    the panel accessor and a later reference-ordered push! must see the same operator as the materialising modes."""
+    npd = NP[dtype]
+    n, mem = 20_011, 6
+    rng = np.random.default_rng(17)
+    tol = 1e-9 if dtype == torch.float64 else 5e-4
+    Bc = lo.LBFGSOperator(dtype, n, mem=mem, device=dev).set_push_mode("compact")
+    Bg = lo.LBFGSOperator(dtype, n, mem=mem, device=dev).set_push_mode("gram")
+    O = oracle.LBFGS(n, mem=mem, inverse=False, dtype=npd)
+    x, b = rng.uniform(-1, 1, n).astype(npd), rng.uniform(-1, 1, n).astype(npd)
+    ps = pairs(rng, n, mem + 3, npd)
+    for k, (s, y) in enumerate(ps):
+        lo.push(Bc, T(s, dev), T(y, dev)); lo.push(Bg, T(s, dev), T(y, dev)); O.push(s, y)
+        want = O.mul(np.empty(n, npd), x)
+        assert rel((Bc * T(x, dev)).cpu().numpy(), want) <= tol, k          # compact apply, a_k implicit
+        if k == 2:                                                           # partially filled memory
+            assert rel(lo.diag(Bc).cpu().numpy(), O.diag()) <= tol           # materialises once
+            assert rel((Bc * T(x, dev)).cpu().numpy(), want) <= tol          # classic apply on the materialised panel
+    assert rel((Bc * T(x, dev)).cpu().numpy(), (Bg * T(x, dev)).cpu().numpy()) <= tol
+    xs = lo.solve_shifted_system(torch.zeros(n, dtype=dtype, device=dev), Bc, T(b, dev), npd(0.25))
+    xg = lo.solve_shifted_system(torch.zeros(n, dtype=dtype, device=dev), Bg, T(b, dev), npd(0.25))
+    assert rel(xs.cpu().numpy(), xg.cpu().numpy()) <= 10 * tol
+    back = lo.ShiftedOperator(Bc, 0.25) * xs                                 # (B + σI) x = b
+    assert rel(back.cpu().numpy(), b) <= (1e-8 if dtype == torch.float64 else 5e-3)
+    # switch to the reference-ordered rebuild mid-stream: it reads the older a_l, which must exist by then
+    s, y = pairs(rng, n, 1, npd)[0]
+    Bc.set_push_mode("compact"); lo.push(Bc, T(s, dev), T(y, dev)); O.push(s, y)
+    s, y = pairs(rng, n, 1, npd)[0]
+    Bc.set_push_mode("reforder"); lo.push(Bc, T(s, dev), T(y, dev)); O.push(s, y)
+    assert rel((Bc * T(x, dev)).cpu().numpy(), O.mul(np.empty(n, npd), x)) <= tol
+    lo.reset(Bc)
+    assert torch.equal(Bc * T(x, dev), T(x, dev))

@@ -37,7 +37,7 @@ struct DscLayout {
   int64_t as_ = 320;   // [mem] L-SR1 a_k' s_k
   int64_t alpha = 352; // [mem] inverse two-loop alpha_k (data.α)
   int64_t SY = 384;    // [mem*mem] column j = S' y_j  (written when slot j is pushed)
-  int64_t YS = 0, YY = 0, G = 0, g = 0, cx = 0, SS = 0, YSf = 0, Cm = 0, gtmp = 0, total = 0;
+  int64_t YS = 0, YY = 0, G = 0, g = 0, cx = 0, SS = 0, YSf = 0, Cm = 0, gtmp = 0, Wm = 0, total = 0;
   explicit DscLayout(int64_t mem) {
     YS = SY + mem * mem;
     YY = YS + mem * mem;
@@ -47,8 +47,9 @@ struct DscLayout {
     SS = cx + 2 * mem + 64;   // [mem*mem] s_j's_k            (forward push!, Gram form)
     YSf = SS + mem * mem;     // [mem*mem] y_j's_k (row j, col k)
     Cm = YSf + mem * mem;     // [mem * 2mem] coefficients of a_k on [s_1..s_r, b_1..b_r]
-    gtmp = Cm + 2 * mem * mem;  // [3*mem] scratch dots of one push
-    total = gtmp + 3 * mem + 64;
+    gtmp = Cm + 2 * mem * mem;  // [4*mem] scratch dots of one push
+    Wm = gtmp + 4 * mem + 64;   // [2mem x 2mem] shifted solve: coefficients of u_t on the basis [s.. b..]
+    total = Wm + 4 * mem * mem + 64;
   }
 };
 
@@ -71,6 +72,8 @@ struct mxlo_qn {
   bool G_valid = false;
   bool normA_valid = true;   // L-SR1 ||a_k||^2 (opnorm bound) computed lazily after a Gram-form push
   bool A_valid = true;       // forward L-BFGS: the a_k panel is materialised (false after a compact push!)
+  bool gram_ok = true;       // forward / L-SR1: S'S, Y'S, Y'Y and Cm describe the current pairs (false after a
+                             // reference-ordered push!, which does not maintain them)
   // device
   void *S = nullptr, *Y = nullptr, *A = nullptr, *B = nullptr;  // panels
   void *tmp = nullptr, *tmp2 = nullptr;                         // n-vectors (Ax / tmp)
@@ -668,8 +671,8 @@ inline double rT(double v) { return sizeof(T) == 4 ? (double)(float)v : v; }
 // date (3m dots per push) the recurrence runs on 2m-vectors of coefficients and ALL a_k are then formed
 // in ONE pass  A = [S B] * C  (read 2r columns, write r columns).
 
-// place the dots of this push: tmp[0..m) = S's_new, tmp[m..2m) = Y's_new, tmp[2m..3m) = S'y_new
-__global__ void gram_update_kernel(double *__restrict__ SS, double *__restrict__ YSf,
+// place the dots of one pair: tmp[0..m) = S's_new, tmp[m..2m) = Y's_new, tmp[2m..3m) = S'y_new, tmp[3m..4m) = Y'y_new
+__global__ void gram_update_kernel(double *__restrict__ SS, double *__restrict__ YSf, double *__restrict__ YY,
                                    const double *__restrict__ tmp, int mem, int ins) {
   const int k = threadIdx.x;
   if (k >= mem) return;
@@ -677,6 +680,8 @@ __global__ void gram_update_kernel(double *__restrict__ SS, double *__restrict__
   SS[ins * mem + k] = tmp[k];
   YSf[k * mem + ins] = tmp[mem + k];       // y_k ' s_new
   YSf[ins * mem + k] = tmp[2 * mem + k];   // y_new ' s_k
+  YY[k * mem + ins] = tmp[3 * mem + k];
+  YY[ins * mem + k] = tmp[3 * mem + k];
 }
 
 // coefficients of a_k (active slots, oldest -> newest) on the basis [s_ord[0..r), b_ord[0..r)]:
@@ -868,9 +873,9 @@ asr1_coef_kernel(const double *__restrict__ SS, const double *__restrict__ YSf, 
   }
 }
 
-// Gram-form rebuild of the forward panel after (s, y) was copied into slot `ins` and b[ins] was formed.
+// Gram rows/columns of one stored pair (slot): S'[s y] in one dual-x pass over S, Y'[s y] in one over Y.
 template <typename T>
-int32_t fwd_rebuild_gram(mxlo_qn *h, int64_t ins) {
+int32_t gram_update_slot(mxlo_qn *h, int64_t slot) {
   mxlo_ctx *ctx = h->ctx;
   const int64_t n = h->n, mem = h->mem;
   double *tmp = h->dsc + h->lay.gtmp;
@@ -879,15 +884,34 @@ int32_t fwd_rebuild_gram(mxlo_qn *h, int64_t ins) {
     cols[k] = col<T>(h->S, h->ld, k);
     cols[mem + k] = col<T>(h->Y, h->ld, k);
   }
-  // S's_new and S'y_new in ONE pass over S (dual-x dots), Y's_new in a second: 2m column reads instead of 3m
   constexpr int VECP = Vec16<T>::N;
   const int64_t npad = (n + VECP - 1) / VECP * VECP;   // panel columns are zero-padded to whole vectors (<= ld)
-  MXLO_TRY(panel_dots2<T>(ctx, cols, (int)mem, col<T>(h->S, h->ld, ins), col<T>(h->Y, h->ld, ins), npad, tmp,
-                          tmp + 2 * mem));
-  MXLO_TRY(panel_dots<T>(ctx, cols + mem, (int)mem, col<T>(h->S, h->ld, ins), n, tmp + mem));
+  const T *ss = col<T>(h->S, h->ld, slot), *yy = col<T>(h->Y, h->ld, slot);
+  MXLO_TRY(panel_dots2<T>(ctx, cols, (int)mem, ss, yy, npad, tmp, tmp + 2 * mem));            // S's, S'y
+  MXLO_TRY(panel_dots2<T>(ctx, cols + mem, (int)mem, ss, yy, npad, tmp + mem, tmp + 3 * mem)); // Y's, Y'y
   hipLaunchKernelGGL(gram_update_kernel, dim3(1), dim3(64), 0, ctx->stream, h->dsc + h->lay.SS,
-                     h->dsc + h->lay.YSf, tmp, (int)mem, (int)ins);
+                     h->dsc + h->lay.YSf, h->dsc + h->lay.YY, tmp, (int)mem, (int)slot);
   MXLO_LAUNCH_CHECK();
+  return MXLO_OK;
+}
+
+// after reference-ordered pushes (which do not maintain them) the Gram matrices are rebuilt pair by pair
+template <typename T>
+int32_t gram_make_consistent(mxlo_qn *h, int64_t except_slot) {
+  if (h->gram_ok) return MXLO_OK;
+  for (int64_t k = 0; k < h->mem; ++k)
+    if (h->ys[k] != 0 && k != except_slot) MXLO_TRY(gram_update_slot<T>(h, k));
+  h->gram_ok = true;
+  return MXLO_OK;
+}
+
+// Gram-form rebuild of the forward panel after (s, y) was copied into slot `ins` and b[ins] was formed.
+template <typename T>
+int32_t fwd_rebuild_gram(mxlo_qn *h, int64_t ins) {
+  mxlo_ctx *ctx = h->ctx;
+  const int64_t n = h->n, mem = h->mem;
+  MXLO_TRY(gram_make_consistent<T>(h, ins));
+  MXLO_TRY(gram_update_slot<T>(h, ins));
   OrdArgs O;
   fill_ord(h, O, /*newest_first=*/false);   // called before insert0 advances: the new pair must come last
   // oldest -> newest with the freshly written slot last: slots (ins+1 .. ins+mem) mod mem
@@ -953,6 +977,7 @@ int32_t lbfgs_push_common(mxlo_qn *h, const T *s, const T *y, double ys, double 
   }
   if (h->push_mode != MXLO_PUSH_REFORDER) return fwd_rebuild_gram<T>(h, ins);
   MXLO_TRY(ensure_A<T>(h));   // the reference-ordered rebuild reads the older a_l
+  h->gram_ok = false;         // ... and does not maintain the Gram matrices / Cm
   double *coef = h->dsc + h->lay.coef;
   int older[kMaxMem];
   int nold = 0;
@@ -1114,22 +1139,9 @@ int32_t lsr1_push(mxlo_qn *h, const T *s, const T *y, int32_t *accepted) {
   OrdArgs O;
   fill_ord(h, O, false);
   if (h->push_mode == MXLO_PUSH_GRAM) {
-    // Gram form: 3m dots, an O(r^3) coefficient recurrence on one wave, ONE pass A = [Y S] * C
-    double *tmp = h->dsc + h->lay.gtmp;
-    const T *cols[kMaxCols];
-    for (int k = 0; k < mem; ++k) {
-      cols[k] = col<T>(h->S, h->ld, k);
-      cols[mem + k] = col<T>(h->Y, h->ld, k);
-    }
-    // S's_new and S'y_new in ONE pass over S (dual-x dots), Y's_new in a second
-    constexpr int VECP = Vec16<T>::N;
-    const int64_t npad = (n + VECP - 1) / VECP * VECP;
-    MXLO_TRY(panel_dots2<T>(ctx, cols, (int)mem, col<T>(h->S, h->ld, ins), col<T>(h->Y, h->ld, ins), npad, tmp,
-                            tmp + 2 * mem));
-    MXLO_TRY(panel_dots<T>(ctx, cols + mem, (int)mem, col<T>(h->S, h->ld, ins), n, tmp + mem));
-    hipLaunchKernelGGL(gram_update_kernel, dim3(1), dim3(64), 0, ctx->stream, h->dsc + h->lay.SS,
-                       h->dsc + h->lay.YSf, tmp, (int)mem, (int)ins);
-    MXLO_LAUNCH_CHECK();
+    // Gram form: 2m column reads of dots, an O(r^3) coefficient recurrence on one wave, ONE pass A = [Y S] * C
+    MXLO_TRY(gram_make_consistent<T>(h, ins));
+    MXLO_TRY(gram_update_slot<T>(h, ins));
     hipLaunchKernelGGL(asr1_coef_kernel, dim3(1), dim3(64), 0, ctx->stream, h->dsc + h->lay.SS,
                        h->dsc + h->lay.YSf, h->dsc + h->lay.Cm, as_, O);
     MXLO_LAUNCH_CHECK();
@@ -1145,6 +1157,7 @@ int32_t lsr1_push(mxlo_qn *h, const T *s, const T *y, int32_t *accepted) {
     h->normA_valid = false;
     return launch_panel_gemm<T>(ctx, G, n);
   }
+  h->gram_ok = false;
   int nold = 0;
   for (int i = 0; i < O.na; ++i) {
     const int k = O.ord[i];
@@ -1223,56 +1236,149 @@ shifted_coef_kernel(const double *__restrict__ G, const double *__restrict__ gve
   if (lane == 0) cx[kMaxCols] = x0;  // c0 slot read by CM_AXPYS
 }
 
+// Everything the recursion needs about U = [a_1 b_1 a_2 b_2 ...] follows from the Gram matrices push! maintains:
+// u_t = [S B]·W[t] (W[t] = c_k for an a column, a unit vector for a b column), so G = U'U = W M W' with
+// M = [S B]'[S B] assembled from S'S, Y'S, Y'Y and ys — no pass over n — and U'b = W ([S B]'b).
+struct ShiftMap {
+  int r, mem;
+  int ord[kMaxMem];    // active slots, oldest -> newest (the order of Cm's rows and of the basis)
+  int pos2[kMaxMem];   // position in `ord` of the i-th pair of the reference's solve order (utilities.jl:228)
+  double ys[kMaxMem];  // by slot
+};
+
+__global__ void __launch_bounds__(kBlock)
+shifted_gram_kernel(const double *__restrict__ SS, const double *__restrict__ YSf, const double *__restrict__ YY,
+                    const double *__restrict__ Cm, ShiftMap mp, double *__restrict__ G, double *__restrict__ Wout) {
+  extern __shared__ double shg[];  // M[w2*w2], W[nu*w2], Tm[nu*w2]
+  const int r = mp.r, w2 = 2 * r, nu = 2 * r, mem = mp.mem, tid = threadIdx.x;
+  double *M = shg, *W = M + w2 * w2, *Tm = W + nu * w2;
+  for (int idx = tid; idx < w2 * w2; idx += kBlock) {
+    const int p = idx / w2, q = idx % w2;
+    const int sp = mp.ord[p < r ? p : p - r], sq = mp.ord[q < r ? q : q - r];
+    double v;
+    if (p < r && q < r) v = SS[sp * mem + sq];
+    else if (p < r) v = YSf[sq * mem + sp] / sqrt(mp.ys[sq]);          // s_p'b_q, b = y / sqrt(ys) (lbfgs.jl:232)
+    else if (q < r) v = YSf[sp * mem + sq] / sqrt(mp.ys[sp]);
+    else v = YY[sp * mem + sq] / (sqrt(mp.ys[sp]) * sqrt(mp.ys[sq]));
+    M[idx] = v;
+  }
+  for (int idx = tid; idx < nu * w2; idx += kBlock) {
+    const int t = idx / w2, p = idx % w2, P = mp.pos2[t >> 1];
+    W[idx] = (t & 1) ? (p == r + P ? 1.0 : 0.0) : Cm[(int64_t)P * w2 + p];   // even: a_k (sign +1), odd: b_k (-1)
+  }
+  __syncthreads();
+  for (int idx = tid; idx < nu * w2; idx += kBlock) {
+    const int t = idx / w2, q = idx % w2;
+    double acc = 0.0;
+    for (int p = 0; p < w2; ++p) acc = fma(W[t * w2 + p], M[p * w2 + q], acc);
+    Tm[idx] = acc;
+  }
+  __syncthreads();
+  for (int idx = tid; idx < nu * nu; idx += kBlock) {
+    const int t = idx / nu, u = idx % nu;
+    double acc = 0.0;
+    for (int q = 0; q < w2; ++q) acc = fma(Tm[t * w2 + q], W[u * w2 + q], acc);
+    G[idx] = acc;
+  }
+  for (int idx = tid; idx < nu * w2; idx += kBlock) Wout[idx] = W[idx];
+}
+
+// gv = W d  (U'b from the basis dots)
+__global__ void shifted_gv_kernel(const double *__restrict__ W, const double *__restrict__ d, double *__restrict__ gv,
+                                  int nu, int w2) {
+  const int t = threadIdx.x;
+  if (t >= nu) return;
+  double acc = 0.0;
+  for (int p = 0; p < w2; ++p) acc = fma(W[t * w2 + p], d[p], acc);
+  gv[t] = acc;
+}
+
+// basis coefficients of U cx: coef = W' cx; the x0 factor of b travels in the slot CM_AXPYS reads it from
+__global__ void shifted_back_kernel(const double *__restrict__ W, const double *__restrict__ cx,
+                                    double *__restrict__ coef, int nu, int w2) {
+  const int p = threadIdx.x;
+  if (p < w2) {
+    double acc = 0.0;
+    for (int t = 0; t < nu; ++t) acc = fma(W[t * w2 + p], cx[t], acc);
+    coef[p] = acc;
+  }
+  if (p == 0) coef[kMaxCols] = cx[kMaxCols];
+}
+
 template <typename T>
 int32_t solve_shifted_t(mxlo_qn *h, T *x, const T *b, double sigma) {
-  MXLO_TRY(ensure_A<T>(h));   // U = [a b]: the a_k panel is read
   mxlo_ctx *ctx = h->ctx;
   const int64_t n = h->n;
   OrdArgs O;
   fill_ord(h, O, false);
+  const int r = O.na, nu = 2 * r, w2 = 2 * r;
+  if (!h->gram_ok) {  // reference-ordered pushes: bring S'S, Y'S, Y'Y and the a_k coefficients up to date
+    MXLO_TRY(gram_make_consistent<T>(h, -1));
+    O.gamma = h->scaling_factor;
+    hipLaunchKernelGGL(afwd_coef_kernel, dim3(1), dim3(64), 0, ctx->stream, h->dsc + h->lay.SS,
+                       h->dsc + h->lay.YSf, h->dsc + h->lay.Cm, O);
+    MXLO_LAUNCH_CHECK();
+    h->G_valid = false;
+  }
   // NOTE: the reference walks slots k = mod(insert + j - 1, mem) + 1, j = 1..mem (utilities.jl:228),
   // i.e. starting one slot AFTER the oldest-first order used by mul!; with a full memory that is
-  // (oldest+1 ... newest, oldest). The recursion is order-dependent only through rounding (the
-  // compact form sums rank-one terms), and empty slots contribute nothing; we follow the
-  // reference order exactly.
-  int ord2[kMaxMem], na = 0;
+  // (oldest+1 ... newest, oldest). The recursion is order-dependent only through rounding; we follow it.
+  ShiftMap mp;
+  mp.r = r;
+  mp.mem = (int)h->mem;
+  for (int k = 0; k < h->mem; ++k) mp.ys[k] = h->ys[k];
+  for (int i = 0; i < r; ++i) mp.ord[i] = O.ord[i];
+  int na = 0;
   for (int64_t j = 1; j <= h->mem; ++j) {
     const int64_t k = (h->insert0 + j) % h->mem;
-    if (h->ys[k] != 0) ord2[na++] = (int)k;
+    if (h->ys[k] == 0) continue;
+    int pos = 0;
+    while (O.ord[pos] != (int)k) ++pos;
+    mp.pos2[na++] = pos;
   }
-  const int nu = 2 * na;
-  const T *ucols[kMaxCols];
-  for (int i = 0; i < na; ++i) {
-    ucols[2 * i] = col<T>(h->A, h->ld, ord2[i]);      // sign +1 -> a[k]   (:229)
-    ucols[2 * i + 1] = col<T>(h->B, h->ld, ord2[i]);  // sign -1 -> b[k]
+  const T *bcols[kMaxCols];   // the basis [s_ord.., b_ord..]
+  for (int i = 0; i < r; ++i) {
+    bcols[i] = col<T>(h->S, h->ld, O.ord[i]);
+    bcols[r + i] = col<T>(h->B, h->ld, O.ord[i]);
   }
-  double *G = h->dsc + h->lay.G, *gv = h->dsc + h->lay.g, *cx = h->dsc + h->lay.coef;
+  double *G = h->dsc + h->lay.G, *W = h->dsc + h->lay.Wm, *gv = h->dsc + h->lay.g, *cx = h->dsc + h->lay.cx,
+         *dots = h->dsc + h->lay.dots, *coef = h->dsc + h->lay.coef;
+  static bool lds_attr_set = false;
+  if (!lds_attr_set) {  // up to 3*64*64 doubles of dynamic LDS (> the 64 KiB default cap)
+    MXLO_HIP(hipFuncSetAttribute((const void *)shifted_coef_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 96 * 1024));
+    MXLO_HIP(hipFuncSetAttribute((const void *)shifted_gram_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 112 * 1024));
+    lds_attr_set = true;
+  }
   if (!h->G_valid && nu > 0) {
-    for (int i = 0; i < nu; ++i)  // row i: dot(u_j, u_i) for all j (symmetric; full rows keep it simple)
-      MXLO_TRY(panel_dots<T>(ctx, ucols, nu, ucols[i], n, G + (int64_t)i * nu));
+    hipLaunchKernelGGL(shifted_gram_kernel, dim3(1), dim3(kBlock), sizeof(double) * (w2 * w2 + 2 * nu * w2),
+                       ctx->stream, h->dsc + h->lay.SS, h->dsc + h->lay.YSf, h->dsc + h->lay.YY,
+                       h->dsc + h->lay.Cm, mp, G, W);
+    MXLO_LAUNCH_CHECK();
     h->G_valid = true;
   }
   const double g_inv = rT<T>(1.0 / h->scaling_factor);                 // :219
   const double x0 = rT<T>(1.0 / (g_inv + sigma));                      // :220
-  if (nu > 0) MXLO_TRY(panel_dots<T>(ctx, ucols, nu, b, n, gv));
-  static bool lds_attr_set = false;
-  if (!lds_attr_set) {  // up to 2*64*64 + 130 doubles of dynamic LDS (> the 64 KiB default cap)
-    MXLO_HIP(hipFuncSetAttribute((const void *)shifted_coef_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 96 * 1024));
-    lds_attr_set = true;
+  if (nu > 0) {
+    MXLO_TRY(panel_dots<T>(ctx, bcols, w2, b, n, dots));                // [S B]'b : the only reduction pass over n
+    hipLaunchKernelGGL(shifted_gv_kernel, dim3(1), dim3(64), 0, ctx->stream, W, dots, gv, nu, w2);
+    MXLO_LAUNCH_CHECK();
   }
   hipLaunchKernelGGL(shifted_coef_kernel, dim3(1), dim3(64), sizeof(double) * (2 * nu * nu + 2 * nu + 2),
                      ctx->stream, G, gv, cx, nu, x0, (int)(sizeof(T) == 4));
   MXLO_LAUNCH_CHECK();
+  hipLaunchKernelGGL(shifted_back_kernel, dim3(1), dim3(64), 0, ctx->stream, W, cx, coef, nu, w2);
+  MXLO_LAUNCH_CHECK();
   CombineArgs<T> A;
-  A.ncol = nu;
+  A.ncol = w2;
   A.nfirst = 0;
   A.use_gamma = 0;
   A.gamma = 1;
   A.alpha = 1;
   A.beta = 0;
-  A.coef = cx;
-  for (int i = 0; i < nu; ++i) A.cols[i] = ucols[i];
+  A.coef = coef;
+  for (int i = 0; i < w2; ++i) A.cols[i] = bcols[i];
   return launch_combine<T, CM_AXPYS>(ctx, x, b, (const T *)nullptr, A, n, 0);
 }
 
@@ -1482,6 +1588,7 @@ MXLO_API int32_t mxlo_qn_reset(mxlo_qn *h) {
   h->G_valid = false;
   h->normA_valid = true;
   h->A_valid = true;
+  h->gram_ok = true;
   return MXLO_OK;
 }
 

@@ -109,6 +109,12 @@ for kind, m in (("inv", 10), ("fwd", 10), ("fwd", 20), ("lsr1", 10)):
         b = rnd(n)
         lo.solve_shifted_system(out, op, b, 0.1)
         row(f"solve_shifted_system! m={m} n=5e7 (G cached)", (4 * m + 3) * 8.0 * n, timeit(lambda: lo.solve_shifted_system(out, op, b, 0.1), 5))
+
+        def push_then_solve():
+            lo.push(op, S[0], Y[0])
+            lo.solve_shifted_system(out, op, b, 0.1)
+        ms_ps = timeit(push_then_solve, 3)
+        print(f"push! + solve_shifted_system! m={m} n=5e7 (the optimiser-iteration pattern: G rebuilt from the Gram matrices): {ms_ps:8.2f} ms", flush=True)
         row(f"diag! fwd m={m} n=5e7", (2 * m + 1) * 8.0 * n, timeit(lambda: lo.diag(op), 5))
     del op, S, Y, x, out
     torch.cuda.empty_cache()

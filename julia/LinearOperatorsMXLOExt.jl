@@ -66,11 +66,6 @@ getindex(v::MXVector, i::Integer) = error("scalar indexing of a device vector; u
 # contiguous views (cat.jl:17-18, special-operators.jl:263) stay device vectors: base pointer + offset
 view(v::MXVector{T}, r::UnitRange{<:Integer}) where {T} =
   MXVector{T}(v.ptr + (first(r) - 1) * sizeof(T), length(r), v)
-function fill!(v::MXVector{T}, x) where {T}
-  iszero(x) || error("fill! with a non-zero value is not on the hot path")
-  check(ccall((:mxlo_memset, lib), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Int32, Int64), ctx(), v.ptr, 0, v.len * sizeof(T)))
-  v
-end
 function copyto!(d::MXVector{T}, s::Vector{T}) where {T}
   GC.@preserve s check(ccall((:mxlo_memcpy_h2d, lib), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64),
                              ctx(), d.ptr, pointer(s), d.len * sizeof(T)))
@@ -115,6 +110,33 @@ scale!(res::MXVector{T}, α) where {T} =
 axpby!(res::MXVector{T}, v::MXVector{T}, α, β) where {T} =
   check(ccall((:mxlo_eye_mul, lib), Int32, (P, Int32, P, P, Int64, Int64, Float64, Float64, Int32),
               ctx(), dt(T), res.ptr, v.ptr, res.len, res.len, α, β, flags(T, α, β)))
+
+# ---- BLAS-1 on device vectors: what Krylov.jl / JSOSolvers call between two mul! ------------------------------------
+# dot / norm need the scalar on the host: the fixed-order device reduction (mxlo_dot, all-reduce hook included, so
+# the result is the GLOBAL dot of row-sharded vectors) writes one device double that is read back (8-byte D2H).
+const DOTBUF = Ref{Ptr{Cvoid}}(C_NULL)
+function dotbuf()
+  if DOTBUF[] == C_NULL
+    r = Ref{Ptr{Cvoid}}()
+    check(ccall((:mxlo_malloc, lib), Int32, (P, Int64, Ptr{P}), ctx(), 8, r))
+    DOTBUF[] = r[]
+  end
+  DOTBUF[]
+end
+function LinearAlgebra.dot(a::MXVector{T}, b::MXVector{T}) where {T}
+  length(a) == length(b) || throw(DimensionMismatch("dot"))
+  check(ccall((:mxlo_dot, lib), Int32, (P, Int32, P, P, Int64, P), ctx(), dt(T), a.ptr, b.ptr, length(a), dotbuf()))
+  out = Ref{Float64}(0.0)
+  check(ccall((:mxlo_memcpy_d2h, lib), Int32, (P, Ptr{Float64}, P, Int64), ctx(), out, dotbuf(), 8))
+  T(out[])
+end
+LinearAlgebra.norm(a::MXVector) = sqrt(dot(a, a))
+LinearAlgebra.axpy!(α::Number, x::MXVector{T}, y::MXVector{T}) where {T} = (axpby!(y, x, T(α), one(T)); y)       # y += αx
+LinearAlgebra.axpby!(α::Number, x::MXVector{T}, β::Number, y::MXVector{T}) where {T} = (axpby!(y, x, T(α), T(β)); y)
+LinearAlgebra.rmul!(x::MXVector{T}, α::Number) where {T} = (scale!(x, T(α)); x)
+LinearAlgebra.lmul!(α::Number, x::MXVector{T}) where {T} = (scale!(x, T(α)); x)
+Base.fill!(v::MXVector{T}, x::Number) where {T} =
+  (check(ccall((:mxlo_fill, lib), Int32, (P, Int32, P, Int64, Float64), ctx(), dt(T), v.ptr, v.len, Float64(x))); v)
 
 # ---- a3/a4 opDiagonal (src/special-operators.jl:125-165) ------------------------------------------------
 function opDiagonal(d::MXVector{T}) where {T}

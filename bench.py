@@ -261,7 +261,25 @@ def bench_lbfgs(lo, torch, dev, ctx, rank, world, distributed, dist, barrier):
                                       "GB/s_per_gpu(664B/elt)": round(bytes_ / sec / 1e9, 1),
                                       "frac_hbm_peak": round(bytes_ / sec / 1e9 / HBM_PEAK_GBS, 4),
                                       "n_global": n * world}
-    del Bf
+    # the optimiser-iteration pattern: one push! (device-side Gram update, a_k left implicit), one apply and one
+    # solve_shifted_system! (G rebuilt from the Gram matrices) per iteration
+    s = torch.rand(n, dtype=torch.float64, device=dev, generator=gen) * 2 - 1
+    y = s * (torch.rand(n, dtype=torch.float64, device=dev, generator=gen) * 1.5 + 0.5)
+    x = torch.rand(n, dtype=torch.float64, device=dev, generator=gen) * 2 - 1
+    res = torch.empty_like(x)
+
+    def iteration():
+        lo.push(Bf, s, y)
+        lo.mul(res, Bf, x, 1.0, 0.0)
+        lo.solve_shifted_system(res, Bf, x, 0.1)
+    iteration()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(4):
+        iteration()
+    barrier()
+    out["LBFGS_fwd_m20_iteration(push+mul+solve_shifted)"] = {"ms": round((time.perf_counter() - t0) / 4 * 1e3, 3)}
+    del Bf, s, y, x, res
     torch.cuda.empty_cache()
     return out
 

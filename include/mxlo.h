@@ -83,6 +83,7 @@ const char *mxlo_last_error(void);
  * ctx does not own a caller-provided stream. */
 int32_t mxlo_ctx_create(int32_t device_id, void *stream, mxlo_ctx **out);
 int32_t mxlo_ctx_destroy(mxlo_ctx *ctx);
+/* Switching streams inserts an event dependency old -> new, so the ctx workspaces stay stream-ordered. */
 int32_t mxlo_ctx_set_stream(mxlo_ctx *ctx, void *stream);
 int32_t mxlo_ctx_sync(mxlo_ctx *ctx);
 /* info[0]=device id, [1]=CU count, [2]=workspace bytes, [3]=max reduction columns */

@@ -69,13 +69,22 @@ MXLO_API int32_t mxlo_ctx_destroy(mxlo_ctx *ctx) {
   if (ctx->ticket) (void)hipFree(ctx->ticket);
   if (ctx->scratch) (void)hipFree(ctx->scratch);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+  if (ctx->switch_event) (void)hipEventDestroy(ctx->switch_event);
   delete ctx;
   return MXLO_OK;
 }
 
 MXLO_API int32_t mxlo_ctx_set_stream(mxlo_ctx *ctx, void *stream) {
   MXLO_REQUIRE(ctx, MXLO_EINVAL, "ctx is NULL");
-  ctx->stream = (hipStream_t)stream;
+  hipStream_t next = (hipStream_t)stream;
+  if (next != ctx->stream && !ctx->capturing) {
+    // the reduction workspace, the scalar buffer and the quasi-Newton handles of this ctx are ordered by the
+    // stream: work already queued on the old stream must complete before the new stream touches them
+    if (!ctx->switch_event) MXLO_HIP(hipEventCreateWithFlags(&ctx->switch_event, hipEventDisableTiming));
+    MXLO_HIP(hipEventRecord(ctx->switch_event, ctx->stream));
+    MXLO_HIP(hipStreamWaitEvent(next, ctx->switch_event, 0));
+  }
+  ctx->stream = next;
   return MXLO_OK;
 }
 
@@ -85,7 +94,7 @@ MXLO_API int32_t mxlo_ctx_create_stream(mxlo_ctx *ctx, void **out) {
     (void)hipSetDevice(ctx->device);
     MXLO_HIP(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
   }
-  ctx->stream = ctx->own_stream;
+  MXLO_TRY(mxlo_ctx_set_stream(ctx, (void *)ctx->own_stream));
   if (out) *out = (void *)ctx->own_stream;
   return MXLO_OK;
 }

@@ -85,6 +85,7 @@ struct mxlo_ctx {
   void *scratch = nullptr;     // grow-on-demand workspace (opHermitian tile partials); owned by the ctx
   size_t scratch_bytes = 0;
   hipStream_t own_stream = nullptr;  // created by mxlo_ctx_create_stream, destroyed with the ctx
+  hipEvent_t switch_event = nullptr; // orders the ctx workspaces across mxlo_ctx_set_stream
   bool capturing = false;      // between mxlo_graph_begin and mxlo_graph_end
   mxlo::Tune tune;
 };

@@ -176,3 +176,25 @@ def test_hipgraph_replay_of_apply_sequences(lo, dev):
             lo.push(B, x, y2)
     lo.mul(ref, B, x)
     assert torch.isfinite(ref).all()
+
+
+def test_alternating_streams_share_the_ctx_workspaces_safely(lo, dev):
+    """The ctx's reduction workspace is ordered by its stream; mxlo_ctx_set_stream chains old -> new with an event,
+    so applies issued alternately from two torch streams (no host sync in between) never overlap on it."""
+    rng = np.random.default_rng(31)
+    n = 3_000_017
+    hs = [rng.standard_normal(n) for _ in range(2)]
+    Hs = [lo.opHouseholder(T(h / np.linalg.norm(h), dev)) for h in hs]
+    vs = [T(rng.uniform(-1, 1, n), dev) for _ in range(2)]
+    want = [(Hs[i] * vs[i]).clone() for i in range(2)]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
+    outs = [[torch.empty(n, dtype=torch.float64, device=dev) for _ in range(6)] for _ in range(2)]
+    for rep in range(6):
+        for i in range(2):
+            with torch.cuda.stream(streams[i]):
+                lo.mul(outs[i][rep], Hs[i], vs[i])
+    torch.cuda.synchronize()
+    for i in range(2):
+        for rep in range(6):
+            assert torch.equal(outs[i][rep], want[i]), (i, rep)

@@ -12,7 +12,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-LIB_PATH = os.path.join(CSRC, "libmxlo.so")
+LIB_PATH = os.environ.get("MXLO_LIB_PATH") or os.path.join(CSRC, "libmxlo.so")   # override: kernel experiments
 RCCL_LIB_PATH = os.path.join(CSRC, "libmxlo_rccl.so")
 HEADER = os.path.normpath(os.path.join(_HERE, "..", "include", "mxlo.h"))
 RCCL_HEADER = os.path.normpath(os.path.join(_HERE, "..", "include", "mxlo_rccl.h"))

@@ -153,8 +153,11 @@ combine_kernel(T *__restrict__ res, const T *__restrict__ x, const T *__restrict
         else if constexpr (MODE == CM_AXPYS) q[e] = (T)scoef[kMaxCols] * xe;  // c0 stored past the columns
       }
     }
-    // ---- columns, 4 loads in flight
-    constexpr int U = 8;
+    // ---- columns, U loads in flight per lane (tuned: tools/sweep_combine_u.sh)
+#ifndef MXLO_COMBINE_U
+#define MXLO_COMBINE_U 8
+#endif
+    constexpr int U = MXLO_COMBINE_U;
     for (int c0 = 0; c0 < ncol; c0 += U) {
       V cv[U];
 #pragma unroll

@@ -20,6 +20,8 @@
 #include <vector>
 
 #include "common.h"
+
+#include <cstdlib>
 #include "stream_kernels.h"
 
 using namespace mxlo;

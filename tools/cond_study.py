@@ -47,3 +47,40 @@ for eps in (1.0, 1e-2, 1e-4, 1e-6, 1e-8):
         got = (op * T(x)).cpu().numpy()
         errs[mode] = np.linalg.norm(got - truth) / corr
     print(f"eps={eps:7.0e}  " + "  ".join(f"{k}: {v:9.2e}" for k, v in errs.items()), flush=True)
+
+print("\ninverse operator (two-pass Gram form vs reference-ordered two-loop), error relative to |H x - gamma x|")
+for eps in (1.0, 1e-2, 1e-4, 1e-6, 1e-8):
+    rng = np.random.default_rng(3)
+    d0 = rng.standard_normal(n)
+    Q, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    Hm = (Q * rng.uniform(0.5, 50.0, n)) @ Q.T
+    pairs = []
+    for k in range(mem + 3):
+        s = d0 * (1.0 if eps < 1 else 0.0) + eps * rng.standard_normal(n)
+        pairs.append((s, Hm @ s))
+    L = np.longdouble
+    kept = pairs[-mem:]
+    sN, yN = kept[-1]
+    gamma = (yN.astype(L) @ sN.astype(L)) / (yN.astype(L) @ yN.astype(L))
+    H = np.eye(n, dtype=L) * gamma
+    I = np.eye(n, dtype=L)
+    for s, y in kept:
+        s, y = s.astype(L), y.astype(L)
+        rho = 1 / (y @ s)
+        V = I - rho * np.outer(s, y)
+        H = V @ H @ V.T + rho * np.outer(s, s)
+    x = kept[-1][1] - kept[-2][1]
+    x /= np.linalg.norm(x)
+    truth = (H @ x.astype(L)).astype(np.float64)
+    corr = np.linalg.norm(truth - float(gamma) * x)
+    errs = {"|corr|/|Hx|": corr / np.linalg.norm(truth)}
+    O = oracle.LBFGS(n, mem=mem, inverse=True)
+    for s, y in pairs:
+        O.push(s, y)
+    errs["oracle(ref order)"] = np.linalg.norm(O.mul(np.empty(n), x) - truth) / corr
+    for mode in ("reforder", "twopass"):
+        op = lo.InverseLBFGSOperator(n, mem=mem, device=dev).set_mode(mode)
+        for s, y in pairs:
+            lo.push(op, T(s), T(y))
+        errs[mode] = np.linalg.norm((op * T(x)).cpu().numpy() - truth) / corr
+    print(f"eps={eps:7.0e}  " + "  ".join(f"{k}: {v:9.2e}" for k, v in errs.items()), flush=True)

@@ -815,11 +815,24 @@ int32_t launch_panel_gemm(mxlo_ctx *ctx, PanelGemmArgs<T> &A, int64_t n) {
   return go.template operator()<32>();
 }
 
+// forward L-BFGS in compact form never touches the a_k panel: allocate it (n x mem, zeroed) on first need, so a
+// handle that only ever sees push!/mul!/solve_shifted_system! holds three panels instead of four
+inline int32_t alloc_A(mxlo_qn *h) {
+  if (h->A) return MXLO_OK;
+  const size_t bytes = (size_t)h->ld * h->mem * (h->dtype == MXLO_F64 ? 8 : 4);
+  hipError_t e = hipMalloc(&h->A, bytes > 0 ? bytes : 16);
+  MXLO_REQUIRE(e == hipSuccess, MXLO_ENOMEM, "a_k panel: %s", hipGetErrorString(e));
+  MXLO_HIP(hipMemsetAsync(h->A, 0, bytes, h->ctx->stream));
+  return MXLO_OK;
+}
+
 // materialise the a_k panel from the coefficients of the last compact push! (diag!, solve_shifted_system!,
 // mxlo_qn_column and the reference-ordered push! read it)
 template <typename T>
 int32_t ensure_A(mxlo_qn *h) {
-  if (h->kind != MXLO_QN_LBFGS_FWD || h->A_valid) return MXLO_OK;
+  if (h->kind != MXLO_QN_LBFGS_FWD) return MXLO_OK;
+  MXLO_TRY(alloc_A(h));
+  if (h->A_valid) return MXLO_OK;
   OrdArgs O;
   fill_ord(h, O, /*newest_first=*/false);
   PanelGemmArgs<T> G;
@@ -933,6 +946,7 @@ int32_t fwd_rebuild_gram(mxlo_qn *h, int64_t ins) {
     h->A_valid = false;
     return MXLO_OK;
   }
+  MXLO_TRY(alloc_A(h));
   PanelGemmArgs<T> A;
   A.nin = 2 * O.na;
   A.nout = O.na;
@@ -1461,7 +1475,7 @@ MXLO_API int32_t mxlo_qn_create(mxlo_ctx *ctx, int32_t kind, int32_t dtype, int6
   };
   alloc(&h->S, pbytes);
   alloc(&h->Y, pbytes);
-  if (kind != MXLO_QN_LBFGS_INV) alloc(&h->A, pbytes);
+  if (kind == MXLO_QN_LSR1) alloc(&h->A, pbytes);   // forward L-BFGS: the a_k panel is allocated on first use (alloc_A)
   if (kind == MXLO_QN_LBFGS_FWD) alloc(&h->B, pbytes);
   alloc(&h->tmp, (size_t)h->ld * es);
   alloc(&h->tmp2, (size_t)h->ld * es);

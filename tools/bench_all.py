@@ -119,6 +119,34 @@ for kind, m in (("inv", 10), ("fwd", 10), ("fwd", 20), ("lsr1", 10)):
     del op, S, Y, x, out
     torch.cuda.empty_cache()
 
+# ---- cfg5's single-GPU leg: forward L-BFGS m = 20 at the FULL n = 4e8 on one GPU (three 64 GB panels: S, Y, B;
+# the a_k panel is never allocated in the compact form, the reference's n x 2m shifted_p never exists)
+torch.cuda.empty_cache()
+free_b, _ = torch.cuda.mem_get_info(dev)
+print(f"free HBM before the n = 4e8 leg: {free_b / 2**30:.0f} GiB", flush=True)
+if free_b > 215 * (1 << 30):
+    nbig, m = 400_000_000, 20
+    op = lo.LBFGSOperator(torch.float64, nbig, mem=m, device=dev)
+    s_ = rnd(nbig)
+    y_ = s_ * 1.25
+    import time
+    for i in range(m + 1):
+        s_.mul_(1.0 + 1e-3 * i)            # distinct pairs without extra 3.2 GB temporaries
+        y_.copy_(s_).mul_(1.25 + 0.01 * i)
+        lo.push(op, s_, y_)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    lo.push(op, s_, y_)
+    torch.cuda.synchronize()
+    push_ms = (time.perf_counter() - t0) * 1e3
+    x, out = rnd(nbig), torch.empty(nbig, dtype=torch.float64, device=dev)
+    ms = timeit(lambda: lo.mul(out, op, x, 1.0, 0.0), 3)
+    used = (torch.cuda.mem_get_info(dev)[1] - torch.cuda.mem_get_info(dev)[0]) / 2**30
+    row(f"mul! fwd m=20 n=4e8 on ONE GPU (cfg5 single-GPU leg; {used:.0f} GiB in use)", (4 * m + 3) * 8.0 * nbig, ms,
+        f" push! {push_ms:.1f} ms")
+    del op, s_, y_, x, out
+    torch.cuda.empty_cache()
+
 # ---- launch-bound regime: eager host-mirror calls vs ONE hipGraph replay (wall clock, includes the host side)
 import time
 

@@ -295,3 +295,41 @@ def test_counters_and_prod3(lo, dev):
     assert lo.nprod(op) == 5 and lo.ntprod(op) == 0 and lo.nctprod(op) == 0   # symmetric+hermitian -> prod!
     lo.reset(op)
     assert lo.nprod(op) == 0
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_empty_operators(lo, dev, dtype):
+    """Zero-length operands (SURVEY §8a "empty and ragged inputs"): every leaf must accept n = 0 and do nothing."""
+    S = lo.Storage(dtype, dev)
+    e = torch.empty(0, dtype=dtype, device=dev)
+    ops = [lo.opDiagonal(e), lo.opHouseholder(e), lo.opEye(dtype, 0, S=S), lo.opZeros(dtype, 0, 0, S=S),
+           lo.opOnes(dtype, 0, 0, S=S), lo.opHermitian(e, torch.empty(0, 0, dtype=dtype, device=dev)),
+           lo.LinearOperatorFromMatrix(torch.empty(0, 0, dtype=dtype, device=dev)),
+           lo.InverseLBFGSOperator(dtype, 0, mem=3, device=dev), lo.LBFGSOperator(dtype, 0, mem=3, device=dev),
+           lo.LSR1Operator(dtype, 0, mem=3, device=dev)]
+    for op in ops:
+        assert op.shape == (0, 0)
+        for o in (op, op.T, op.H):
+            out = o * e
+            assert out.numel() == 0
+        res = torch.empty(0, dtype=dtype, device=dev)
+        lo.mul(res, op, e, 2.0, -3.0)
+        assert lo.Matrix(op).shape == (0, 0)
+    # rectangular cases with one empty side: m x 0 and 0 x n
+    v5 = torch.arange(1, 6, dtype=dtype, device=dev)
+    Z = lo.opZeros(dtype, 5, 0, S=S)
+    r = torch.full((5,), 7.0, dtype=dtype, device=dev)
+    lo.mul(r, Z, e, 2.0, 0.0)
+    assert torch.equal(r, torch.zeros_like(r))
+    R = lo.opRestriction([], 5, S=S)                                    # empty index set
+    assert (R * v5).numel() == 0
+    assert torch.equal(R.T * e, torch.zeros(5, dtype=dtype, device=dev))   # res .= 0; res[[]] = []
+    M = lo.LinearOperatorFromMatrix(torch.empty(5, 0, dtype=dtype, device=dev))
+    r = torch.full((5,), 7.0, dtype=dtype, device=dev)
+    lo.mul(r, M, e, 2.0, -3.0)                                          # empty sum: res = β·res
+    assert torch.equal(r, torch.full_like(r, -21.0))
+    assert (M.T * v5).numel() == 0
+    K = lo.kron(torch.empty(0, 0, dtype=dtype, device=dev), torch.ones(3, 3, dtype=dtype, device=dev))
+    assert K.shape == (0, 0) and (K * e).numel() == 0
+    Bd = lo.BlockDiagonalOperator(lo.opDiagonal(e), lo.opDiagonal(v5))
+    assert torch.equal(Bd * v5, v5 * v5)

@@ -304,13 +304,14 @@ int32_t gemm(mxlo_ctx *ctx, T *C, int64_t ldc, const T *A, int64_t lda, bool ta,
 
 // ---- GEMV --------------------------------------------------------------------------------
 // T mode (res[j] = alpha * dot(M[:,j], v) + beta*res[j]): one wave per column, coalesced down the column.
-// PAIR: two rows per lane per load (16 B for f64), 4 loads of M in flight per lane, nontemporal (M is
-// streamed once; v stays cached).
+// PAIR: 16 bytes of rows per lane per load (2 rows f64, 4 rows f32), 4 loads of M in flight per lane,
+// nontemporal (M is streamed once; v stays cached).
 template <typename T, typename CT, bool BETA0, bool PAIR>
 __global__ void __launch_bounds__(kBlock)
 gemv_t_kernel(T *__restrict__ res, const T *__restrict__ M, int64_t m, int64_t n, int64_t ld,
               const T *__restrict__ v, CT alpha, CT beta) {
-  typedef T V2 __attribute__((ext_vector_type(2)));
+  constexpr int VR = 16 / (int)sizeof(T);     // rows per lane per 16-byte load: 2 (f64) or 4 (f32)
+  typedef T VV __attribute__((ext_vector_type(VR)));
   const int lane = threadIdx.x & 63;
   const int64_t wave = (int64_t)blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
   const int64_t nwaves = (int64_t)gridDim.x * (kBlock / kWave);
@@ -320,12 +321,12 @@ gemv_t_kernel(T *__restrict__ res, const T *__restrict__ M, int64_t m, int64_t n
     int64_t i = 0;
     if constexpr (PAIR) {
       constexpr int U = 4;
-      const int64_t mp = m / 2;  // row pairs
-      const V2 *cp = reinterpret_cast<const V2 *>(colp);
-      const V2 *vp = reinterpret_cast<const V2 *>(v);
+      const int64_t mp = m / VR;  // 16-byte row groups
+      const VV *cp = reinterpret_cast<const VV *>(colp);
+      const VV *vp = reinterpret_cast<const VV *>(v);
       int64_t p = lane;
       for (; p + (int64_t)(U - 1) * 64 < mp; p += (int64_t)U * 64) {
-        V2 a[U], x[U];
+        VV a[U], x[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
           a[u] = __builtin_nontemporal_load(cp + p + u * 64);
@@ -333,16 +334,22 @@ gemv_t_kernel(T *__restrict__ res, const T *__restrict__ M, int64_t m, int64_t n
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-          acc0 = fma((double)a[u][0], (double)x[u][0], acc0);
-          acc1 = fma((double)a[u][1], (double)x[u][1], acc1);
+#pragma unroll
+          for (int e = 0; e < VR; e += 2) {
+            acc0 = fma((double)a[u][e], (double)x[u][e], acc0);
+            acc1 = fma((double)a[u][e + 1], (double)x[u][e + 1], acc1);
+          }
         }
       }
       for (; p < mp; p += 64) {
-        const V2 a = cp[p], x = vp[p];
-        acc0 = fma((double)a[0], (double)x[0], acc0);
-        acc1 = fma((double)a[1], (double)x[1], acc1);
+        const VV a = cp[p], x = vp[p];
+#pragma unroll
+        for (int e = 0; e < VR; e += 2) {
+          acc0 = fma((double)a[e], (double)x[e], acc0);
+          acc1 = fma((double)a[e + 1], (double)x[e + 1], acc1);
+        }
       }
-      i = mp * 2;
+      i = mp * VR;
     }
     for (int64_t r = i + lane; r < m; r += 64) acc0 = fma((double)colp[r], (double)v[r], acc0);
     double acc = acc0 + acc1;
@@ -466,8 +473,8 @@ int32_t gemv_t(mxlo_ctx *ctx, T *res, const T *M, int64_t m, int64_t n, int64_t 
   int64_t blocks = (n + 3) / 4;
   const int64_t cap = (int64_t)ctx->num_cu * 16;
   if (blocks > cap) blocks = cap;
-  const bool pair = m >= 2 && (((uintptr_t)M % (2 * sizeof(T))) == 0) && (ld % 2 == 0) &&
-                    (((uintptr_t)v % (2 * sizeof(T))) == 0);
+  constexpr int VR = 16 / (int)sizeof(T);     // 16-byte loads down the column need 16-byte aligned column starts
+  const bool pair = m >= VR && (((uintptr_t)M & 15u) == 0) && (ld % VR == 0) && (((uintptr_t)v & 15u) == 0);
   return dispatch_ct<T>(beta, flags, [&]<typename CT, bool B0>() -> int32_t {
     if (pair)
       hipLaunchKernelGGL((gemv_t_kernel<T, CT, B0, true>), dim3((unsigned)blocks), dim3(kBlock), 0, ctx->stream,

@@ -398,3 +398,37 @@ def test_blockdiag_full_config_size(lo, dev):
         a.copy_(r0)
         lo.mul(a, BD.T, x, alpha, beta)
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("pad,off", [(6, (2, 4)), (5, (1, 3)), (8, (0, 0))])
+def test_dense_views_with_leading_dimension(lo, dev, dtype, pad, off):
+    """Column-major SubArray-style views: leading dimension > number of rows, base pointer at any element offset
+    (aligned and unaligned 16-byte phases) — dense GEMV N/T, opHermitian, kron, BlockDiagonalOperator dense blocks."""
+    npd = NP[dtype]
+    rng = np.random.default_rng(pad)
+    n, m2 = 301, 64
+    tol = 1e-12 if dtype == torch.float64 else 3e-5
+    big = rng.standard_normal((n + pad, n + pad)).astype(npd)
+    Bdev = TM(big, dev)                                            # column-major (n+pad) x (n+pad)
+    r0, c0 = off
+    Av = Bdev[r0:r0 + n, c0:c0 + n]                                # view: ld = n + pad, offset pointer
+    A = big[r0:r0 + n, c0:c0 + n]
+    assert Av.stride(0) == 1 and Av.stride(1) == n + pad
+    v, w = rng.standard_normal(n).astype(npd), rng.standard_normal(n).astype(npd)
+    op = lo.LinearOperatorFromMatrix(Av)
+    assert rel((op * T(v, dev)).cpu().numpy(), A.astype(np.float64) @ v) <= tol
+    assert rel((op.T * T(w, dev)).cpu().numpy(), A.astype(np.float64).T @ w) <= tol
+    d = rng.standard_normal(n).astype(npd)
+    L = np.tril(A.astype(np.float64), -1)
+    H = lo.opHermitian(T(d, dev), Av)
+    assert rel((H * T(v, dev)).cpu().numpy(), (L + L.T + np.diag(d.astype(np.float64))) @ v) <= tol
+    Kv = Bdev[r0:r0 + m2, c0:c0 + m2]
+    K = lo.kron(Kv, Kv)
+    xk = rng.standard_normal(m2 * m2).astype(npd)
+    Kd = np.kron(big[r0:r0 + m2, c0:c0 + m2].astype(np.float64), big[r0:r0 + m2, c0:c0 + m2].astype(np.float64))
+    assert np.linalg.norm((K * T(xk, dev)).cpu().numpy() - Kd @ xk) <= (1e-12 if dtype == torch.float64 else 3e-5) * np.linalg.norm(Kd, 1) * np.linalg.norm(xk)
+    Bd = lo.BlockDiagonalOperator(Av, lo.opDiagonal(T(d, dev)))
+    vv = np.concatenate([v, w])
+    want = np.concatenate([A.astype(np.float64) @ v, d.astype(np.float64) * w])
+    assert rel((Bd * T(vv, dev)).cpu().numpy(), want) <= tol

@@ -155,38 +155,43 @@ combine_kernel(T *__restrict__ res, const T *__restrict__ x, const T *__restrict
         else if constexpr (MODE == CM_AXPYS) q[e] = (T)scoef[kMaxCols] * xe;  // c0 stored past the columns
       }
     }
-    // ---- columns, U loads in flight per lane (tuned: tools/sweep_combine_u.sh)
-#ifndef MXLO_COMBINE_U
-#define MXLO_COMBINE_U 8
-#endif
-    constexpr int U = MXLO_COMBINE_U;
-    for (int c0 = 0; c0 < ncol; c0 += U) {
-      V cv[U];
+    // ---- columns. Straight-line batches of UB columns: the UB column pointers (one wide scalar load), the UB
+    // coefficients (LDS) and the UB 16-byte loads are all issued before the first use — the previous form guarded
+    // every column with a scalar branch and waited on a scalar pointer load before EACH vector load. Batches of 8,
+    // then 4 / 2 / 1 for the remainder, so no load is ever issued for a column that does not exist.
+    auto batch = [&]<int UB>(int c0) {
+      const T *pc[UB];
+      double cf[UB];
+      V cv[UB];
 #pragma unroll
-      for (int u = 0; u < U; ++u)
-        if (c0 + u < ncol) cv[u] = ldg<NT>(reinterpret_cast<const V *>(A.cols[c0 + u] + i * VEC));
+      for (int u = 0; u < UB; ++u) pc[u] = A.cols[c0 + u];
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
+      for (int u = 0; u < UB; ++u) cf[u] = scoef[c0 + u];
+#pragma unroll
+      for (int u = 0; u < UB; ++u) cv[u] = ldg<NT>(reinterpret_cast<const V *>(pc[u] + i * VEC));
+#pragma unroll
+      for (int u = 0; u < UB; ++u) {
         const int c = c0 + u;
-        if (c >= ncol) break;
         if constexpr (MODE == CM_FWD || MODE == CM_AFWD || MODE == CM_DIAG_FWD) {
-          if (u & 1) continue;  // pairs are handled on the even member (U is even)
-          const T cb = (T)scoef[c], ca = (T)scoef[c + 1];
+          if constexpr (UB >= 2) {
+            if (u & 1) continue;  // pairs (b, a) are handled on the even member; batches of these modes are even
+            const T cb = (T)cf[u], ca = (T)cf[u + 1];
 #pragma unroll
-          for (int e = 0; e < VEC; ++e) {
-            const T b = vget<T, VEC>(cv[u], e), a = vget<T, VEC>(cv[u + 1], e);
-            if constexpr (MODE == CM_FWD) q[e] = q[e] + ((cb * b) - (ca * a));       // lbfgs.jl:194
-            else if constexpr (MODE == CM_AFWD) {
-              q[e] = q[e] + (cb * b);                                                 // lbfgs.jl:244
-              q[e] = q[e] - (ca * a);                                                 // lbfgs.jl:245
-            } else q[e] = q[e] + ((b * b) - (a * a));                                 // lbfgs.jl:391
+            for (int e = 0; e < VEC; ++e) {
+              const T b = vget<T, VEC>(cv[u], e), a = vget<T, VEC>(cv[u + 1], e);
+              if constexpr (MODE == CM_FWD) q[e] = q[e] + ((cb * b) - (ca * a));       // lbfgs.jl:194
+              else if constexpr (MODE == CM_AFWD) {
+                q[e] = q[e] + (cb * b);                                                 // lbfgs.jl:244
+                q[e] = q[e] - (ca * a);                                                 // lbfgs.jl:245
+              } else q[e] = q[e] + ((b * b) - (a * a));                                 // lbfgs.jl:391
+            }
           }
         } else if constexpr (MODE == CM_INV) {
           if (c == A.nfirst && A.use_gamma) {
 #pragma unroll
             for (int e = 0; e < VEC; ++e) q[e] = q[e] * g;                            // lbfgs.jl:139
           }
-          const T cc = (T)scoef[c];
+          const T cc = (T)cf[u];
 #pragma unroll
           for (int e = 0; e < VEC; ++e) {
             const T ce = vget<T, VEC>(cv[u], e);
@@ -194,20 +199,20 @@ combine_kernel(T *__restrict__ res, const T *__restrict__ x, const T *__restrict
             else q[e] = q[e] + (cc * ce);                                             // lbfgs.jl:146
           }
         } else if constexpr (MODE == CM_LSR1) {
-          const CT cc = (CT)scoef[c];  // (α*dot)/as evaluated in CT by the coef kernel
+          const CT cc = (CT)cf[u];  // (α*dot)/as evaluated in CT by the coef kernel
 #pragma unroll
           for (int e = 0; e < VEC; ++e)
             q[e] = (T)((CT)q[e] + (cc * (CT)vget<T, VEC>(cv[u], e)));                 // lsr1.jl:103
         } else if constexpr (MODE == CM_ASR1) {
-          const T cc = (T)scoef[c];
+          const T cc = (T)cf[u];
 #pragma unroll
           for (int e = 0; e < VEC; ++e) q[e] = q[e] - (cc * vget<T, VEC>(cv[u], e));  // lsr1.jl:174
         } else if constexpr (MODE == CM_AXPYS || MODE == CM_CFWD) {
-          const T cc = (T)scoef[c];
+          const T cc = (T)cf[u];
 #pragma unroll
           for (int e = 0; e < VEC; ++e) q[e] = q[e] + (cc * vget<T, VEC>(cv[u], e));
         } else if constexpr (MODE == CM_DIAG_SR1) {
-          const T as = (T)scoef[c];
+          const T as = (T)cf[u];
 #pragma unroll
           for (int e = 0; e < VEC; ++e) {
             const T a = vget<T, VEC>(cv[u], e);
@@ -215,7 +220,12 @@ combine_kernel(T *__restrict__ res, const T *__restrict__ x, const T *__restrict
           }
         }
       }
-    }
+    };
+    int c0 = 0;
+    for (; c0 + 8 <= ncol; c0 += 8) batch.template operator()<8>(c0);
+    if (c0 + 4 <= ncol) { batch.template operator()<4>(c0); c0 += 4; }
+    if (c0 + 2 <= ncol) { batch.template operator()<2>(c0); c0 += 2; }
+    if (c0 < ncol) batch.template operator()<1>(c0);        // odd counts exist only in the single-column modes
     if constexpr (MODE == CM_INV) {
       if (A.nfirst == ncol && A.use_gamma) {  // no s column followed (cannot happen: nfirst*2 == ncol)
 #pragma unroll

@@ -119,6 +119,31 @@ for kind, m in (("inv", 10), ("fwd", 10), ("fwd", 20), ("lsr1", 10)):
     del op, S, Y, x, out
     torch.cuda.empty_cache()
 
+# ---- cfg3 both variants: reference-ordered two-loop next to the default two-pass form
+opi = lo.InverseLBFGSOperator(torch.float64, n, mem=10, device=dev)
+for i in range(11):
+    s_ = rnd(n)
+    lo.push(opi, s_, s_ * (rnd(n) * 0.5 + 1.25))
+    del s_
+x, out = rnd(n), torch.empty(n, dtype=torch.float64, device=dev)
+for mode, bpe in (("twopass", 344.0), ("reforder", 648.0)):
+    opi.set_mode(mode)
+    row(f"mul! inv m=10 n=5e7, {mode} form ({bpe:.0f} B/elt moved)", bpe * n, timeit(lambda: lo.mul(out, opi, x, 1.0, 0.0), 5))
+del opi, x, out
+torch.cuda.empty_cache()
+
+# ---- CPU beside cfg4's kron: the oracle's reference-literal form (m unit-vector applies, src/kron.jl:17-18 through
+# Matrix(B*X*A')), one thread
+import time
+import oracle
+rngk = np.random.default_rng(0)
+Ak, Bk = (rngk.random((1024, 1024)) - 0.5) / 32, (rngk.random((1024, 1024)) - 0.5) / 32
+xk = rngk.random(1024 * 1024)
+t0 = time.perf_counter()
+oracle.kron_mul(np.empty(1024 * 1024), Ak, Bk, xk, 1.0, 0.0)
+tk = time.perf_counter() - t0
+print(f"CPU oracle kron 1024^2 (reference-literal: 1024 x (X*w, B*u) GEMV pairs, 1 thread): {tk:.2f} s = {4 * 1024**3 / tk / 1e9:.2f} GFLOP/s", flush=True)
+
 # ---- cfg5's single-GPU leg: forward L-BFGS m = 20 at the FULL n = 4e8 on one GPU (three 64 GB panels: S, Y, B;
 # the a_k panel is never allocated in the compact form, the reference's n x 2m shifted_p never exists)
 torch.cuda.empty_cache()

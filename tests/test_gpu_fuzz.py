@@ -207,3 +207,60 @@ def test_random_operator_tree_vs_dense(lo, dev, seed):
         lo.mul(rt, op.T, T(w, dev), 3.0, -4.0)
         assert close(rt.cpu().numpy(), 3.0 * (M.T @ w) - 4.0 * rt0, 3 * w, 4 * np.linalg.norm(rt0)), desc
     assert np.linalg.norm(lo.Matrix(op).cpu().numpy() - M) <= 1e-10 * scale * max(m, n), desc
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("MXLO_BDFUZZ_SEEDS", "80"))))
+def test_random_blockdiagonal_vs_dense(lo, dev, seed):
+    """Single-launch BlockDiagonalOperator over random mixes of diagonal / dense / identity / zero blocks of random
+    sizes (every 16-byte phase, tile boundaries falling anywhere, rectangular dense and zero blocks), both dtypes,
+    N / T / C, (α, β) incl. β = 0 on NaN-filled output, against the dense assembly."""
+    rng = np.random.default_rng(7000 + seed)
+    dtype = torch.float64 if seed % 2 == 0 else torch.float32
+    npd = np.float64 if dtype == torch.float64 else np.float32
+    S = lo.Storage(dtype, dev)
+    nblk = int(rng.integers(1, 40))
+    big = rng.integers(4) == 0
+    ops, dense = [], []
+    for _ in range(nblk):
+        k = rng.integers(4)
+        if k == 0:
+            m = int(rng.integers(1, 5000 if big else 70))
+            d = rng.standard_normal(m).astype(npd)
+            ops.append(lo.opDiagonal(T(d, dev))); dense.append(np.diag(d.astype(np.float64)))
+        elif k == 1:
+            m, n = int(rng.integers(1, 40)), int(rng.integers(1, 40))
+            A = rng.standard_normal((m, n)).astype(npd)
+            ops.append(TM(A, dev) if rng.integers(2) else lo.LinearOperatorFromMatrix(TM(A, dev)))
+            dense.append(A.astype(np.float64))
+        elif k == 2:
+            m = int(rng.integers(1, 3000 if big else 50))
+            ops.append(lo.opEye(dtype, m, S=S)); dense.append(np.eye(m))
+        else:
+            m, n = int(rng.integers(1, 30)), int(rng.integers(1, 30))
+            ops.append(lo.opZeros(dtype, m, n, S=S)); dense.append(np.zeros((m, n)))
+    nr, nc = sum(a.shape[0] for a in dense), sum(a.shape[1] for a in dense)
+    BD = lo.BlockDiagonalOperator(*ops)
+    assert hasattr(BD, "_keepalive") and BD.shape == (nr, nc)        # the fused single-launch path
+
+    def ref(x, transposed):
+        out, r, c = np.zeros(nc if transposed else nr), 0, 0
+        for a in dense:
+            if transposed:
+                out[c:c + a.shape[1]] = a.T @ x[r:r + a.shape[0]]
+            else:
+                out[r:r + a.shape[0]] = a @ x[c:c + a.shape[1]]
+            r += a.shape[0]; c += a.shape[1]
+        return out
+
+    tol = 1e-12 if dtype == torch.float64 else 3e-5
+    x, xt = rng.standard_normal(nc).astype(npd), rng.standard_normal(nr).astype(npd)
+    for op, vec, tr in ((BD, x, False), (BD.T, xt, True), (BD.H, xt, True)):
+        want = ref(vec.astype(np.float64), tr)
+        out = torch.full((want.size,), float("nan"), dtype=dtype, device=dev)
+        lo.mul(out, op, T(vec, dev), 1.0, 0.0)
+        assert np.linalg.norm(out.cpu().numpy() - want) <= tol * (np.linalg.norm(want) + np.linalg.norm(vec)), (seed, tr)
+        r0 = rng.standard_normal(want.size).astype(npd)
+        out = T(r0.copy(), dev)
+        lo.mul(out, op, T(vec, dev), 2.0, -3.0)
+        want2 = 2.0 * want - 3.0 * r0
+        assert np.linalg.norm(out.cpu().numpy() - want2) <= tol * (np.linalg.norm(want2) + 2 * np.linalg.norm(vec) + 3 * np.linalg.norm(r0)), (seed, tr)

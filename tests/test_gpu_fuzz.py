@@ -264,3 +264,46 @@ def test_random_blockdiagonal_vs_dense(lo, dev, seed):
         lo.mul(out, op, T(vec, dev), 2.0, -3.0)
         want2 = 2.0 * want - 3.0 * r0
         assert np.linalg.norm(out.cpu().numpy() - want2) <= tol * (np.linalg.norm(want2) + 2 * np.linalg.norm(vec) + 3 * np.linalg.norm(r0)), (seed, tr)
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("MXLO_IDXFUZZ_SEEDS", "80"))))
+def test_random_restriction_extension_bit_exact(lo, dev, seed):
+    """opRestriction / opExtension over random UnitRanges, StepRanges (positive and NEGATIVE steps), index vectors with
+    duplicates (last write wins, special-operators.jl:171-174) and scalars; data of 4 and 8 bytes; views at odd offsets.
+    Pure data movement: bit-exact against NumPy indexing."""
+    rng = np.random.default_rng(9000 + seed)
+    dtype = [torch.float64, torch.float32, torch.int64, torch.int32][seed % 4]
+    ncol = int(rng.integers(1, 5000))
+    off = int(rng.integers(0, 4))
+    base = torch.arange(1, ncol + off + 1, device=dev).to(dtype) * (3 if dtype.is_floating_point else 1)
+    v = base[off:off + ncol]                                   # a view at any 4/8-byte phase
+    vh = v.cpu().numpy()
+    S = lo.Storage(dtype, dev)
+    kind = rng.integers(4)
+    if kind == 0:
+        a = int(rng.integers(1, ncol + 1)); b = int(rng.integers(a, ncol + 1))
+        I, idx0 = lo.jrange(a, b), np.arange(a, b + 1) - 1
+    elif kind == 1:
+        step = int(rng.integers(1, 9)) * (1 if rng.integers(2) else -1)
+        a = int(rng.integers(1, ncol + 1)); b = int(rng.integers(1, ncol + 1))
+        if (b - a) * step < 0:
+            a, b = b, a
+        I = lo.jrange(a, b, step)
+        idx0 = np.arange(a, b + (1 if step > 0 else -1), step) - 1
+    elif kind == 2:
+        k = int(rng.integers(0, 2 * ncol))
+        idx0 = rng.integers(0, ncol, k)                         # duplicates likely
+        I = (idx0 + 1).tolist()
+    else:
+        idx0 = np.array([int(rng.integers(0, ncol))])
+        I = int(idx0[0] + 1)
+    R = lo.opRestriction(I, ncol, S=S)
+    assert R.shape == (len(idx0), ncol)
+    got = (R * v).cpu().numpy()
+    assert np.array_equal(got, vh[idx0]), (seed, kind)
+    u = (torch.arange(1, len(idx0) + 1, device=dev).to(dtype) * 7)
+    want = np.zeros(ncol, dtype=vh.dtype)
+    want[idx0] = u.cpu().numpy()                                # NumPy fancy assignment: last write wins, like the loop
+    for E in (R.T, lo.opExtension(I, ncol, S=S)):
+        ext = E * u
+        assert np.array_equal(ext.cpu().numpy(), want), (seed, kind)

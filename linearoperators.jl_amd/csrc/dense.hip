@@ -144,7 +144,19 @@ gemm_nt_fast_kernel(T *__restrict__ C, int64_t ldc, const T *__restrict__ A, int
   __shared__ T sA[2][FBK][LDA_];
   __shared__ T sB[2][FBK][LDT];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int bm = blockIdx.x * TM, bn = blockIdx.y * BN;
+  // XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs by linear id, each XCD has its own L2.
+  // Give every XCD a compact (gx/4) x (gy/2) sub-grid of tiles instead of a stride-8 comb, so the A and B slabs
+  // it touches are shared inside its L2 (1024^2: 4 x 8 tiles per XCD read 4 A + 8 B panels instead of 2 + 16).
+  int tx = blockIdx.x, ty = blockIdx.y;
+#ifndef MXLO_GEMM_NO_SWIZZLE
+  if ((gridDim.x & 3) == 0 && (gridDim.y & 1) == 0) {
+    const int id = blockIdx.x + blockIdx.y * gridDim.x, xcd = id & 7, local = id >> 3;
+    const int sx = gridDim.x >> 2, sy = gridDim.y >> 1;   // sub-grid extents
+    tx = (xcd & 3) * sx + local % sx;
+    ty = (xcd >> 2) * sy + local / sx;
+  }
+#endif
+  const int bm = tx * TM, bn = ty * BN;
   const int wm = (wave % WR) * (TM / WR);
   const int wn = (wave / WR) * (BN / WCOLS);
   using Acc = typename Mfma<T>::Acc;

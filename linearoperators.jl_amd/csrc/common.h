@@ -18,7 +18,7 @@ namespace mxlo {
 
 constexpr int kBlock = 256;          // 4 waves of 64 lanes: one wave per SIMD of a CU
 constexpr int kWave = 64;
-constexpr int kMaxRedCols = 64;      // columns a single reduction call may produce
+constexpr int kMaxRedCols = 128;     // columns a single reduction call may produce
 constexpr int kMaxRedBlocks = 4096;  // partial slots per column in the workspace
 constexpr int kScalarSlots = 8192;   // doubles in the device scalar buffer
 

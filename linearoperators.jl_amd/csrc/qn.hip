@@ -28,17 +28,19 @@ using namespace mxlo;
 
 namespace {
 
-constexpr int kMaxMem = 32;          // slots; 2*mem panel columns per combine <= 64
-constexpr int kMaxCols = 2 * kMaxMem;
+constexpr int kMaxMem = 64;          // slots of the inverse operator (its coefficient kernel owns one lane per slot)
+constexpr int kMaxMemFwd = 32;       // forward L-BFGS / L-SR1: one lane per BASIS vector, 2*mem <= 64
+constexpr int kMaxCols = 2 * kMaxMem;   // panel columns per combine
+constexpr int kX0Slot = 64;          // CM_AXPYS (forward shifted solve, <= 64 columns): where the factor of x travels
 
 // ---- device scalar region layout (doubles) ------------------------------------------
 struct DscLayout {
   int64_t dots = 0;    // [128] panel_dots outputs of the current apply
   int64_t coef = 128;  // [128] coefficients consumed by panel_combine
   int64_t misc = 256;  // [64]  push! scalars
-  int64_t as_ = 320;   // [mem] L-SR1 a_k' s_k
-  int64_t alpha = 352; // [mem] inverse two-loop alpha_k (data.α)
-  int64_t SY = 384;    // [mem*mem] column j = S' y_j  (written when slot j is pushed)
+  int64_t as_ = 320;   // [64] L-SR1 a_k' s_k
+  int64_t alpha = 384; // [64] inverse two-loop alpha_k (data.α)
+  int64_t SY = 448;    // [mem*mem] column j = S' y_j  (written when slot j is pushed)
   int64_t YS = 0, YY = 0, G = 0, g = 0, cx = 0, SS = 0, YSf = 0, Cm = 0, gtmp = 0, Wm = 0, total = 0;
   explicit DscLayout(int64_t mem) {
     YS = SY + mem * mem;
@@ -125,7 +127,8 @@ combine_kernel(T *__restrict__ res, const T *__restrict__ x, const T *__restrict
   // loop instead of one extra VMEM instruction per column competing with the streaming loads)
   __shared__ double scoef[kMaxCols + 1];
   if (threadIdx.x <= kMaxCols)
-    scoef[threadIdx.x] = (A.coef && (threadIdx.x < (unsigned)A.ncol || threadIdx.x == kMaxCols)) ? A.coef[threadIdx.x] : 0.0;
+    scoef[threadIdx.x] = (A.coef && (threadIdx.x < (unsigned)A.ncol || (MODE == CM_AXPYS && threadIdx.x == kX0Slot)))
+                             ? A.coef[threadIdx.x] : 0.0;
   __syncthreads();
   const CT al = (CT)A.alpha, be = (CT)A.beta;
   const int ncol = A.ncol;
@@ -152,7 +155,7 @@ combine_kernel(T *__restrict__ res, const T *__restrict__ x, const T *__restrict
           if constexpr (!BETA0) t = t + (be * (CT)vget<T, VEC>(rv, e));
           q[e] = (T)t;
         } else if constexpr (MODE == CM_ASR1) q[e] = vget<T, VEC>(x2v, e) - (xe / g);
-        else if constexpr (MODE == CM_AXPYS) q[e] = (T)scoef[kMaxCols] * xe;  // c0 stored past the columns
+        else if constexpr (MODE == CM_AXPYS) q[e] = (T)scoef[kX0Slot] * xe;  // c0 stored past the columns
       }
     }
     // ---- columns. Straight-line batches of UB columns: the UB column pointers (one wide scalar load), the UB
@@ -707,8 +710,8 @@ __global__ void __launch_bounds__(64)
 afwd_coef_kernel(const double *__restrict__ SS, const double *__restrict__ YSf,
                  double *__restrict__ Cm, OrdArgs O) {
   // one wave; lane j owns coefficient j of the 2r-vector (2r <= 64). Z[j][k] = <basis_j, s_k>.
-  __shared__ double Z[kMaxCols][kMaxMem];
-  __shared__ double Cl[kMaxMem][kMaxCols];
+  __shared__ double Z[2 * kMaxMemFwd][kMaxMemFwd];
+  __shared__ double Cl[kMaxMemFwd][2 * kMaxMemFwd];
   const int lane = threadIdx.x;
   const int r = O.na, mem = O.mem, w = 2 * r;
   for (int k = 0; k < r; ++k) {
@@ -864,9 +867,9 @@ int32_t ensure_A(mxlo_qn *h) {
 __global__ void __launch_bounds__(64)
 asr1_coef_kernel(const double *__restrict__ SS, const double *__restrict__ YSf, double *__restrict__ Cm,
                  double *__restrict__ as_out, OrdArgs O) {
-  __shared__ double Z[kMaxCols][kMaxMem];      // Z[j][k] = <basis_j, s_k>
-  __shared__ double Cl[kMaxMem][kMaxCols];
-  __shared__ double asl[kMaxMem];
+  __shared__ double Z[2 * kMaxMemFwd][kMaxMemFwd];      // Z[j][k] = <basis_j, s_k>
+  __shared__ double Cl[kMaxMemFwd][2 * kMaxMemFwd];
+  __shared__ double asl[kMaxMemFwd];
   const int lane = threadIdx.x;
   const int r = O.na, mem = O.mem, w = 2 * r;
   for (int k = 0; k < r; ++k)
@@ -1262,7 +1265,7 @@ shifted_coef_kernel(const double *__restrict__ G, const double *__restrict__ gve
     __syncthreads();
   }
   if (lane < nu) cx[lane] = cxl;
-  if (lane == 0) cx[kMaxCols] = x0;  // c0 slot read by CM_AXPYS
+  if (lane == 0) cx[kX0Slot] = x0;  // c0 slot read by CM_AXPYS
 }
 
 // Everything the recursion needs about U = [a_1 b_1 a_2 b_2 ...] follows from the Gram matrices push! maintains:
@@ -1331,7 +1334,7 @@ __global__ void shifted_back_kernel(const double *__restrict__ W, const double *
     for (int t = 0; t < nu; ++t) acc = fma(W[t * w2 + p], cx[t], acc);
     coef[p] = acc;
   }
-  if (p == 0) coef[kMaxCols] = cx[kMaxCols];
+  if (p == 0) coef[kX0Slot] = cx[kX0Slot];
 }
 
 template <typename T>
@@ -1454,8 +1457,9 @@ MXLO_API int32_t mxlo_qn_create(mxlo_ctx *ctx, int32_t kind, int32_t dtype, int6
   MXLO_REQUIRE(dtype == MXLO_F64 || dtype == MXLO_F32, MXLO_EINVAL, "bad dtype %d", dtype);
   MXLO_REQUIRE(n >= 0, MXLO_ESHAPE, "n < 0");
   if (mem < 1) mem = 1;  // max(mem, 1), src/lbfgs.jl:37
-  MXLO_REQUIRE(mem <= kMaxMem, MXLO_EINVAL, "mem = %lld exceeds the supported maximum %d",
-               (long long)mem, kMaxMem);
+  const int mem_cap = kind == MXLO_QN_LBFGS_INV ? kMaxMem : kMaxMemFwd;
+  MXLO_REQUIRE(mem <= mem_cap, MXLO_EINVAL, "mem = %lld exceeds the supported maximum %d for this operator kind",
+               (long long)mem, mem_cap);
   mxlo_qn *h = new mxlo_qn();
   h->ctx = ctx;
   h->kind = kind;

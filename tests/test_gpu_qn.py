@@ -485,3 +485,33 @@ def test_compact_forward_push_materialises_on_demand(lo, dev, dtype):
     assert rel((Bc * T(x, dev)).cpu().numpy(), O.mul(np.empty(n, npd), x)) <= tol
     lo.reset(Bc)
     assert torch.equal(Bc * T(x, dev), T(x, dev))
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("mem,npush", [(33, 20), (48, 60), (64, 70)])
+def test_inverse_lbfgs_large_memory(lo, dev, dtype, mem, npush):
+    """The inverse operator supports mem up to 64 (128 panel columns per combine); forward L-BFGS and L-SR1 stop at 32
+    (their coefficient kernels own one lane per basis vector) and say so."""
+    npd = NP[dtype]
+    n = 6007
+    rng = np.random.default_rng(mem)
+    H = lo.InverseLBFGSOperator(dtype, n, mem=mem, device=dev)
+    Ho = oracle.LBFGS(n, mem=mem, inverse=True, dtype=npd)
+    x, r0 = rng.uniform(-1, 1, n).astype(npd), rng.uniform(-1, 1, n).astype(npd)
+    tol = dict(twopass=1e-9, reforder=1e-10) if dtype == torch.float64 else dict(twopass=5e-4, reforder=5e-4)
+    for k, (s, y) in enumerate(pairs(rng, n, npush, npd)):
+        lo.push(H, T(s, dev), T(y, dev)); Ho.push(s, y)
+        if k in (3, npush // 2, npush - 1):
+            assert H.data.insert == Ho.insert
+            fl = oracle.SCALARS_F64 if dtype == torch.float32 else 0
+            want = Ho.mul(r0.copy(), x, 2.0, -3.0, flags=fl)
+            for mode in ("twopass", "reforder"):
+                H.set_mode(mode)
+                res = T(r0.copy(), dev)
+                lo.mul(res, H, T(x, dev), 2.0, -3.0)
+                assert rel(res.cpu().numpy(), want) <= tol[mode], (mode, k)
+            H.set_mode("twopass")
+    for ctor in (lo.LBFGSOperator, lo.LSR1Operator):
+        with pytest.raises(lo.MxloError, match="exceeds the supported maximum"):
+            ctor(dtype, n, mem=33, device=dev)
+    assert lo.LBFGSOperator(dtype, n, mem=32, device=dev).mem == 32

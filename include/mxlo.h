@@ -302,7 +302,8 @@ int32_t mxlo_diagqn_push(mxlo_ctx *ctx, int32_t dtype, int32_t kind, void *d, co
 #define MXLO_INV_REFORDER 1 /* reference statement order: 2m chained fused axpy+dot      */
 
 /* LBFGSData / LSR1Data constructors — src/lbfgs.jl:26-57, src/lsr1.jl:19-34.
- * mem is clamped to >= 1 like the reference. Panels s,y(,a,b) are n x mem
+ * mem is clamped to >= 1 like the reference; the supported maximum is 64 for the inverse operator and 32 for
+ * forward L-BFGS / L-SR1 (MXLO_EINVAL above that). Panels s,y(,a,b) are n x mem
  * column-major allocations owned by the handle; shifted_p is NOT allocated
  * eagerly (the reference allocates n x 2mem at :53; the coefficient-space
  * solve does not need it). */

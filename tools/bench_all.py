@@ -144,6 +144,24 @@ oracle.kron_mul(np.empty(1024 * 1024), Ak, Bk, xk, 1.0, 0.0)
 tk = time.perf_counter() - t0
 print(f"CPU oracle kron 1024^2 (reference-literal: 1024 x (X*w, B*u) GEMV pairs, 1 thread): {tk:.2f} s = {4 * 1024**3 / tk / 1e9:.2f} GFLOP/s", flush=True)
 
+# ---- CPU beside cfg3 / cfg5: the oracle's statement-by-statement two-loop / forward recursion, 1 thread, at n/10
+# (memory-bound: scales linearly; the full size needs 8-16 GB of panels on the host and ~4-8 s per apply)
+nc = 5_000_000
+for kindc, mc in (("inverse", 10), ("forward", 20)):
+    Oc = oracle.LBFGS(nc, mem=mc, inverse=(kindc == "inverse"))
+    rc = np.random.default_rng(1)
+    for _ in range(mc + 1):
+        sc = rc.uniform(-1, 1, nc)
+        Oc.push(sc, sc * rc.uniform(0.5, 2.0, nc))
+    xc, outc = rc.uniform(-1, 1, nc), np.empty(nc)
+    Oc.mul(outc, xc)
+    t0 = time.perf_counter()
+    Oc.mul(outc, xc)
+    tc = time.perf_counter() - t0
+    print(f"CPU oracle {kindc} L-BFGS m={mc} n=5e6 (reference statement order, 1 thread): {tc * 1e3:.0f} ms/apply -> "
+          f"~{1.0 / (tc * 10):.2f} apply/s at n=5e7", flush=True)
+    del Oc
+
 # ---- cfg5's single-GPU leg: forward L-BFGS m = 20 at the FULL n = 4e8 on one GPU (three 64 GB panels: S, Y, B;
 # the a_k panel is never allocated in the compact form, the reference's n x 2m shifted_p never exists)
 torch.cuda.empty_cache()

@@ -529,7 +529,15 @@ int32_t gemv_any(mxlo_ctx *ctx, T *res, const T *M, int64_t m, int64_t n, int64_
 // no float atomics) and applies   res = alpha*((d.*v + L*v) + L'*v) (+ beta*res)   (src/linalg.jl:99-101).
 // HBM traffic: 4n^2 B for the triangle + ~0.1n^2 B of partials, vs 8n^2 for two triangular GEMVs and
 // 16n^2 for the reference (two full GEMVs over tril(A,-1) stored with explicit zeros).
-constexpr int HR = 256, HC = 32;   // tile rows, tile columns
+constexpr int HC = 32;             // tile columns
+// A lane holds 16 bytes of each column: RPL = 2 rows (f64) or 4 rows (f32); 128 lanes span a row group of
+// HR = 128*RPL rows, whose diagonal block is DT = HR/HC tiles wide.
+template <typename T>
+struct HermCfg {
+  static constexpr int RPL = 16 / (int)sizeof(T);
+  static constexpr int HR = 128 * RPL;
+  static constexpr int DT = HR / HC;
+};
 
 // C = tiles per strip (8, 2 or 1: fewer when the triangle is too small to fill the chip with 256x256 strips),
 // qint = 8/C_strip strips per 256 columns. Row group G owns qint*G + 8 slots of row partials: one per strip
@@ -543,12 +551,13 @@ template <typename T, int C, bool EDGE>
 __global__ void __launch_bounds__(kBlock)
 herm_strip_kernel(const T *__restrict__ A, int64_t lda, const T *__restrict__ v, int64_t n,
                   double *__restrict__ Prow, double *__restrict__ Pcol, int64_t ng, int qint, int mode) {
-  typedef T V2 __attribute__((ext_vector_type(2)));
+  constexpr int RPL = HermCfg<T>::RPL, HR = HermCfg<T>::HR, DT = HermCfg<T>::DT;
+  typedef T VR __attribute__((ext_vector_type(RPL)));
   constexpr int HS = C;
   const int64_t t = blockIdx.x;
   int64_t G, tile0, slot;                    // row group, first column tile, row-partial slot
   if (!EDGE || mode == 0) {                  // triangular enumeration u = G'(G'+1)/2 + r, r <= G'; G = G'+1
-    constexpr int Q = 8 / C;
+    constexpr int Q = DT / C;
     const int64_t u = t / Q;
     int64_t Gp = (int64_t)((sqrt(8.0 * (double)u + 1.0) - 1.0) * 0.5);
     while (Gp * (Gp + 1) / 2 > u) --Gp;
@@ -560,54 +569,59 @@ herm_strip_kernel(const T *__restrict__ A, int64_t lda, const T *__restrict__ v,
     G = ng - 1;
     slot = t;
     tile0 = slot * C;
-  } else {                                   // diagonal block of row group t/8, tile t%8
-    G = t / 8;
-    tile0 = 8 * G + t % 8;
-    slot = (int64_t)qint * G + t % 8;
+  } else {                                   // diagonal block of row group t/DT, tile t%DT
+    G = t / DT;
+    tile0 = DT * G + t % DT;
+    slot = (int64_t)qint * G + t % DT;
   }
   const int64_t i0 = G * HR;
-  const int tid = threadIdx.x, lane = tid & 63, rp = tid & 127;   // rows 2rp, 2rp+1 of the row group
+  const int tid = threadIdx.x, lane = tid & 63, rp = tid & 127;   // rows RPL*rp .. RPL*rp+RPL-1 of the row group
   const int cg = __builtin_amdgcn_readfirstlane(tid >> 7);          // columns cg + 2k, k < 16, of each tile
-  const int half = __builtin_amdgcn_readfirstlane((tid >> 6) & 1);  // which 128 rows this wave covers
-  const int64_t gr = i0 + 2 * rp;
-  const double vr0 = (!EDGE || gr < n) ? (double)v[gr] : 0.0, vr1 = (!EDGE || gr + 1 < n) ? (double)v[gr + 1] : 0.0;
-  double prow0 = 0.0, prow1 = 0.0;
+  const int half = __builtin_amdgcn_readfirstlane((tid >> 6) & 1);  // which 64*RPL rows this wave covers
+  const int64_t gr = i0 + RPL * rp;
+  double vr[RPL], prow[RPL];
+#pragma unroll
+  for (int r = 0; r < RPL; ++r) {
+    vr[r] = (!EDGE || gr + r < n) ? (double)v[gr + r] : 0.0;
+    prow[r] = 0.0;
+  }
   for (int jt = 0; jt < HS; ++jt) {
     const int64_t j0 = (tile0 + jt) * HC;
     if (EDGE && j0 >= n) break;              // ragged last row group: tiles past the matrix
-    V2 e[16];
+    VR e[16];
     if constexpr (!EDGE) {                   // every element is strictly below the diagonal and inside
       const T *base = A + (j0 + cg) * lda + gr;
 #pragma unroll
       for (int k = 0; k < 16; ++k)
-        e[k] = __builtin_nontemporal_load(reinterpret_cast<const V2 *>(base + (int64_t)(2 * k) * lda));
+        e[k] = __builtin_nontemporal_load(reinterpret_cast<const VR *>(base + (int64_t)(2 * k) * lda));
     } else {
 #pragma unroll
       for (int k = 0; k < 16; ++k) {
         const int64_t gc = j0 + cg + 2 * k;
-        T x0 = 0, x1 = 0;
-        if (gc < n && gr + 1 > gc) {           // at least the second row is strictly below the diagonal
-          const T *p = A + gr + gc * lda;
-          if (gr > gc && gr < n) x0 = p[0];    // strict lower triangle only
-          if (gr + 1 < n) x1 = p[1];
+#pragma unroll
+        for (int r = 0; r < RPL; ++r) {
+          T x = 0;
+          if (gc < n && gr + r > gc && gr + r < n) x = A[gr + r + gc * lda];   // strict lower triangle only
+          e[k][r] = x;
         }
-        e[k][0] = x0;
-        e[k][1] = x1;
       }
     }
-    // FMAs + first butterfly stage, column pair (q, q+8) at a time (keeps the live set at ~90 VGPRs)
+    // FMAs + first butterfly stage, column pair (q, q+8) at a time (keeps the live set small)
     const bool hi = (lane & 32) != 0;
     double w8[8], w4[4], w2[2], w1;
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
       const int64_t ca = j0 + cg + 2 * q, cb = ca + 16;
       const double vca = (!EDGE || ca < n) ? (double)v[ca] : 0.0, vcb = (!EDGE || cb < n) ? (double)v[cb] : 0.0;
-      const double a0 = (double)e[q][0], a1 = (double)e[q][1], b0 = (double)e[q + 8][0], b1 = (double)e[q + 8][1];
-      prow0 = fma(a0, vca, prow0);
-      prow1 = fma(a1, vca, prow1);
-      prow0 = fma(b0, vcb, prow0);
-      prow1 = fma(b1, vcb, prow1);
-      const double pa = fma(a1, vr1, a0 * vr0), pb = fma(b1, vr1, b0 * vr0);
+      double pa = 0.0, pb = 0.0;
+#pragma unroll
+      for (int r = 0; r < RPL; ++r) {
+        const double a = (double)e[q][r], b = (double)e[q + 8][r];
+        prow[r] = fma(a, vca, prow[r]);
+        prow[r] = fma(b, vcb, prow[r]);
+        pa = r == 0 ? a * vr[0] : fma(a, vr[r], pa);
+        pb = r == 0 ? b * vr[0] : fma(b, vr[r], pb);
+      }
       w8[q] = (hi ? pb : pa) + __shfl_xor(hi ? pa : pb, 32, 64);
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -642,11 +656,13 @@ herm_strip_kernel(const T *__restrict__ A, int64_t lda, const T *__restrict__ v,
     }
   }
   __shared__ double rowred[2][HR];
-  rowred[cg][2 * rp] = prow0;
-  rowred[cg][2 * rp + 1] = prow1;
+#pragma unroll
+  for (int r = 0; r < RPL; ++r) rowred[cg][RPL * rp + r] = prow[r];
   __syncthreads();
-  const int64_t row = i0 + tid;
-  if (row < n) Prow[slot * n + row] = rowred[0][tid] + rowred[1][tid];
+  for (int tt = tid; tt < HR; tt += kBlock) {
+    const int64_t row = i0 + tt;
+    if (row < n) Prow[slot * n + row] = rowred[0][tt] + rowred[1][tt];
+  }
 }
 
 // 32 rows per workgroup, 8 lanes per row: lane `sub` adds partials sub, sub+8, ... (independent loads in
@@ -661,8 +677,9 @@ herm_finish_kernel(T *__restrict__ res, const T *__restrict__ d, const T *__rest
   __shared__ double s1[8][32], s2[8][32];
   double t1 = 0.0, t2 = 0.0;
   if (i < n) {
+    constexpr int HR = HermCfg<T>::HR, DT = HermCfg<T>::DT;
     const int G = (int)(i / HR);
-    for (int sx = sub; sx < q * G + 8; sx += 8) t1 += Prow[(int64_t)sx * n + i];     // L*v : q*G strips + 8 diagonal tiles
+    for (int sx = sub; sx < q * G + DT; sx += 8) t1 += Prow[(int64_t)sx * n + i];    // L*v : q*G strips + DT diagonal tiles
     for (int h = 2 * G + sub; h < 2 * ng; h += 8) t2 += Pcol[(int64_t)h * n + i];   // L'*v: 128-row halves at/below i
   }
   s1[sub][r] = t1;
@@ -686,12 +703,13 @@ template <typename T>
 int32_t hermitian_t(mxlo_ctx *ctx, T *res, const T *d, const T *A, int64_t lda, const T *v, int64_t n,
                     double alpha, double beta, int32_t flags) {
   if (n == 0) return MXLO_OK;
+  constexpr int HR = HermCfg<T>::HR, DT = HermCfg<T>::DT, RPL = HermCfg<T>::RPL;
   const int64_t ng = (n + HR - 1) / HR, ngf = n / HR;
   MXLO_REQUIRE(4 * ng * (ng + 1) < (1LL << 31), MXLO_ESHAPE, "opHermitian: n too large");
-  // tiles per strip: 256x256 strips once they fill the chip four times over, thinner strips below that
-  const int64_t full = ng * (ng + 1) / 2;
-  const int C = full >= 4 * ctx->num_cu ? 8 : (4 * full >= 4 * ctx->num_cu ? 2 : 1), Q = 8 / C;
-  const int64_t nslots = Q * (ng - 1) + 8;
+  // tiles per strip: 8-tile strips once there are at least two of them per CU, thinner strips below that
+  const int64_t pairs = ng * (ng - 1) / 2;                       // (row group, strip column block) pairs left of the diagonal
+  const int C = (DT / 8) * pairs >= 2 * ctx->num_cu ? 8 : ((DT / 2) * pairs >= 2 * ctx->num_cu ? 2 : 1), Q = DT / C;
+  const int64_t nslots = Q * (ng - 1) + DT;
   const size_t need = sizeof(double) * (size_t)(nslots + 2 * ng) * (size_t)n;   // Prow[nslots][n], Pcol[2ng][n]
   if (ctx->scratch_bytes < need) {            // stream-ordered users only: drain before the buffer is replaced
     if (ctx->scratch) {
@@ -705,7 +723,7 @@ int32_t hermitian_t(mxlo_ctx *ctx, T *res, const T *d, const T *A, int64_t lda, 
     ctx->scratch_bytes = need;
   }
   double *Prow = (double *)ctx->scratch, *Pcol = Prow + (size_t)nslots * n;
-  const bool aligned = (((uintptr_t)A % (2 * sizeof(T))) == 0) && (lda % 2 == 0);
+  const bool aligned = (((uintptr_t)A & 15u) == 0) && (lda % RPL == 0);
   // full row groups whose strips take the unmasked kernel; the rest of the strips go through the masked one
   const int64_t gi = aligned ? ngf : 0;
   const int64_t n_int = gi > 1 ? Q * gi * (gi - 1) / 2 : 0;
@@ -725,7 +743,7 @@ int32_t hermitian_t(mxlo_ctx *ctx, T *res, const T *d, const T *A, int64_t lda, 
   }
   if (C == 8) HERM_GO(8) else if (C == 2) HERM_GO(2) else HERM_GO(1)
 #undef HERM_GO
-  hipLaunchKernelGGL((herm_strip_kernel<T, 1, true>), dim3((unsigned)(8 * ng)), dim3(kBlock), 0, ctx->stream, A,
+  hipLaunchKernelGGL((herm_strip_kernel<T, 1, true>), dim3((unsigned)(DT * ng)), dim3(kBlock), 0, ctx->stream, A,
                      lda, v, n, Prow, Pcol, ng, Q, 2);
   MXLO_LAUNCH_CHECK();
   const unsigned blocks = (unsigned)((n + 31) / 32);

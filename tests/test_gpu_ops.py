@@ -81,7 +81,8 @@ def test_hermitian(lo, dev, dtype, n):
 
 
 @pytest.mark.parametrize("n,dtype", [(5700, torch.float64), (5889, torch.float64), (5700, torch.float32),
-                                     (11776, torch.float64), (11585, torch.float64), (11586, torch.float32)])
+                                     (11776, torch.float64), (11585, torch.float64), (11586, torch.float32),
+                                     (12800, torch.float32), (12803, torch.float32)])
 def test_hermitian_strip_regimes(lo, dev, dtype, n):
     """Every strip length of the single-pass kernel (1, 2, 8 tiles per workgroup), ragged last row groups and the
     unaligned (odd leading dimension) path, against the oracle restatement of mulHermitian! (linalg.jl:97-103)."""

@@ -252,3 +252,54 @@ def row_sharded_dense(M_local: torch.Tensor, plan_m: ShardPlan, plan_n: ShardPla
                   float(b), scalar_flags(dt, a, b))
 
     return LinearOperator(dt, m_loc, n_loc, False, False, prod, tprod, tprod, S=Storage(dt, dev))
+
+
+# opHermitian(d, A) with the ROWS of the lower triangle sharded ("needs all-gather(v) + reduce-scatter
+# (Lᴴ part)"). Rank r holds rows [lo, hi) of A (column-major, all n columns; only the strict lower triangle is read),
+# d[lo:hi], v[lo:hi] and res[lo:hi]:
+#   local rows of L split into the rectangle R = L[lo:hi, 0:lo] and the diagonal triangle T = L[lo:hi, lo:hi];
+#   res_loc  = d∘v + R·v[0:lo] + (T + Tᵀ)·v[lo:hi]      -> mxlo_gemv N on R, mxlo_hermitian_mul on the diagonal block
+#   + the contributions Rᵀ·v[lo:hi] of the ranks BELOW to columns 0:lo  -> mxlo_gemv T on R, reduce-scatter(sum).
+# One all-gather of v and one reduce-scatter of an n-vector per apply; α, β applied once at the end.
+def row_sharded_hermitian(d_local: torch.Tensor, A_local: torch.Tensor, plan: ShardPlan, group=None):
+    from . import _lib
+    from .device import Storage, dtype_code, get_ctx, ptr
+    from .leaves import LinearOperatorFromMatrix, opHermitian
+    from .operators import LinearOperator, mul, scalar_flags
+
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    n, lo_, hi_ = plan.n, plan.lo(rank), plan.hi(rank)
+    m_loc = hi_ - lo_
+    if A_local.shape != (m_loc, n) or d_local.numel() != m_loc:
+        raise ValueError("A_local must hold this rank's rows (m_loc x n), d_local its part of the diagonal")
+    dev, dt = A_local.device, A_local.dtype
+    rect = LinearOperatorFromMatrix(A_local[:, :lo_]) if lo_ > 0 else None        # R = L[lo:hi, 0:lo] (fully below the diagonal)
+    tri = opHermitian(d_local, A_local[:, lo_:hi_])                               # d∘v + (T + Tᵀ)·v on the diagonal block
+    pad = -(-n // world)
+    gathered = torch.zeros(world * pad, dtype=dt, device=dev)
+    mine = torch.zeros(pad, dtype=dt, device=dev)
+    vfull = torch.empty(n, dtype=dt, device=dev)
+    partial_full = torch.zeros(n, dtype=dt, device=dev)
+    partial_pad = torch.zeros(world * pad, dtype=dt, device=dev)
+    scattered = torch.empty(pad, dtype=dt, device=dev)
+    acc = torch.empty(m_loc, dtype=dt, device=dev)
+
+    def prod(res, v, a, b):
+        mine[:m_loc].copy_(v)
+        dist.all_gather_into_tensor(gathered, mine, group=group)
+        for r in range(world):
+            vfull[plan.lo(r):plan.hi(r)].copy_(gathered[r * pad:r * pad + plan.local_n(r)])
+        mul(acc, tri, v, 1.0, 0.0)                                  # d∘v + (T + Tᵀ) v_loc
+        partial_full.zero_()
+        if rect is not None:
+            mul(acc, rect, vfull[:lo_], 1.0, 1.0)                   # + R v[0:lo]
+            mul(partial_full[:lo_], rect.T, v, 1.0, 0.0)            # Rᵀ v_loc -> columns 0:lo (owned by the ranks above)
+        for r in range(world):
+            partial_pad[r * pad:r * pad + plan.local_n(r)].copy_(partial_full[plan.lo(r):plan.hi(r)])
+        dist.reduce_scatter_tensor(scattered, partial_pad, op=dist.ReduceOp.SUM, group=group)
+        ctx = get_ctx(res.device)                                   # acc += what the ranks below contribute to my rows
+        _lib.call("mxlo_eye_mul", ctx.handle, dtype_code(dt), ptr(acc), ptr(scattered), m_loc, m_loc, 1.0, 1.0, 0)
+        _lib.call("mxlo_eye_mul", ctx.handle, dtype_code(dt), ptr(res), ptr(acc), m_loc, m_loc, float(a), float(b),
+                  scalar_flags(dt, a, b))                           # res = α·acc + β·res
+
+    return LinearOperator(dt, m_loc, m_loc, True, True, prod, prod, prod, S=Storage(dt, dev))

@@ -63,6 +63,18 @@ WORKER = textwrap.dedent('''
         lo.mul(outt, Msh.T, T(uu[pm.lo(rank):pm.hi(rank)]), 2.0, -3.0)
         wantt = 2.0 * (Mfull.T @ uu) - 3.0 * rt
         err_m = max(err_m, np.linalg.norm(outt.cpu().numpy() - wantt[pn.lo(rank):pn.hi(rank)]) / np.linalg.norm(wantt))
+        # row-sharded opHermitian: rectangle + diagonal triangle per rank, all-gather(v) + reduce-scatter(L' part)
+        nh = 1501
+        Ah = rng.standard_normal((nh, nh)); dh = rng.standard_normal(nh); vh = rng.uniform(-1, 1, nh); rh = rng.uniform(-1, 1, nh)
+        ph = lo.sharded.ShardPlan(nh, world)
+        a0, a1 = ph.lo(rank), ph.hi(rank)
+        Aloc = torch.from_numpy(np.asfortranarray(Ah[a0:a1, :]).T.copy()).to(dev).t()
+        Hsh = lo.sharded.row_sharded_hermitian(T(dh[a0:a1]), Aloc, ph)
+        outh = T(rh[a0:a1])
+        lo.mul(outh, Hsh, T(vh[a0:a1]), 2.0, -3.0)
+        Lh = np.tril(Ah, -1)
+        wanth = 2.0 * ((Lh + Lh.T + np.diag(dh)) @ vh) - 3.0 * rh
+        err_m = max(err_m, np.linalg.norm(outh.cpu().numpy() - wanth[a0:a1]) / np.linalg.norm(wanth))
     except (RuntimeError, NotImplementedError) as e:       # gloo builds without the *_tensor collectives on CUDA
         print("SKIP sharded dense:", repr(e)[:200], flush=True)
         err_m = 0.0

@@ -81,6 +81,27 @@ __device__ __forceinline__ void ew_tile(T *__restrict__ r0, const T *__restrict_
     const bool da = KIND != MXLO_BLK_DIAG || (((uintptr_t)(d0 + head)) & 15u) == 0;
     constexpr int U = kTileE / VEC / kBlock;
     T dv[U][VEC], xv[U][VEC], rv[U][VEC];
+    if (xa && da && head == 0 && cnt == kTileE) {
+      // a whole, 16-byte aligned tile (all but the two boundary tiles of a block): no per-load predicates at all
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int64_t o = ((int64_t)tid + (int64_t)u * kBlock) * VEC;
+        if constexpr (KIND == MXLO_BLK_DIAG) load_vec<T, VEC, NT>(d0 + o, true, dv[u]);
+        if constexpr (KIND != MXLO_BLK_ZEROS) load_vec<T, VEC, NT>(x0 + o, true, xv[u]);
+        if constexpr (!BETA0) load_vec<T, VEC, NT>(r0 + o, true, rv[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int64_t o = ((int64_t)tid + (int64_t)u * kBlock) * VEC;
+        V out;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e)
+          out[e] = ew_op<T, CT, BETA0>(KIND, alpha, beta, KIND == MXLO_BLK_DIAG ? dv[u][e] : T(0),
+                                       KIND != MXLO_BLK_ZEROS ? xv[u][e] : T(0), BETA0 ? T(0) : rv[u][e]);
+        stg<NT>(reinterpret_cast<V *>(r0 + o), out);
+      }
+      return;
+    }
     if (xa && da) {
 #pragma unroll
       for (int u = 0; u < U; ++u) {

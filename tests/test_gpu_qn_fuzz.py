@@ -23,6 +23,17 @@ def rel(a, b):
 
 @pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("MXLO_QNFUZZ_SEEDS", "60"))))
 def test_random_operation_sequences(lo, dev, seed):
+    run_sequence(lo, dev, seed, torch.float64, 1e-8, 1e-7)
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("MXLO_QNFUZZ32_SEEDS", "30"))))
+def test_random_operation_sequences_fp32(lo, dev, seed):
+    """The same state machine on Float32 data (Float64 scalars from the caller: Julia's mixed-precision rule)."""
+    run_sequence(lo, dev, seed, torch.float32, 2e-3, 2e-2)
+
+
+def run_sequence(lo, dev, seed, dtype, tol, tol_solve):
+    npd = np.float64 if dtype == torch.float64 else np.float32
     rng = np.random.default_rng(1000 + seed)
     n = int(rng.choice([1, 2, 3, 17, 130, 1025, 4099, 20_001]))
     mem = int(rng.integers(1, 9))
@@ -33,32 +44,32 @@ def test_random_operation_sequences(lo, dev, seed):
                      # Gram form) is divided by — garbage either way, so keep n > mem for L-SR1
     scaling = bool(rng.integers(2))
     if kind == "fwd":
-        op, O = lo.LBFGSOperator(n, mem=mem, scaling=scaling, device=dev), oracle.LBFGS(n, mem=mem, scaling=scaling, inverse=False)
+        op, O = lo.LBFGSOperator(dtype, n, mem=mem, scaling=scaling, device=dev), oracle.LBFGS(n, mem=mem, scaling=scaling, inverse=False, dtype=npd)
     elif kind == "inv":
-        op, O = lo.InverseLBFGSOperator(n, mem=mem, scaling=scaling, device=dev), oracle.LBFGS(n, mem=mem, scaling=scaling, inverse=True)
+        op, O = lo.InverseLBFGSOperator(dtype, n, mem=mem, scaling=scaling, device=dev), oracle.LBFGS(n, mem=mem, scaling=scaling, inverse=True, dtype=npd)
     else:
-        op, O = lo.LSR1Operator(n, mem=mem, scaling=scaling, device=dev), oracle.LSR1(n, mem=mem, scaling=scaling)
+        op, O = lo.LSR1Operator(dtype, n, mem=mem, scaling=scaling, device=dev), oracle.LSR1(n, mem=mem, scaling=scaling, dtype=npd)
     Dg = rng.uniform(0.5, 2.0, n)
-    tol = 1e-8
+    fl = oracle.SCALARS_F64 if dtype == torch.float32 else 0
 
     def check(tag):
-        x, r0 = rng.uniform(-1, 1, n), rng.uniform(-1, 1, n)
+        x, r0 = rng.uniform(-1, 1, n).astype(npd), rng.uniform(-1, 1, n).astype(npd)
         a, b = (1.0, 0.0) if rng.integers(2) else (float(rng.uniform(-2, 2)), float(rng.uniform(-2, 2)))
         res = T(r0.copy(), dev)
         lo.mul(res, op, T(x, dev), a, b)
-        want = O.mul(r0.copy(), x, a, b)
-        scale = np.linalg.norm(want) + abs(a) * np.linalg.norm(O.mul(np.empty(n), x)) + abs(b) * np.linalg.norm(r0) + 1e-300
-        assert np.linalg.norm(res.cpu().numpy() - want) <= tol * scale, (tag, kind, n, mem)
+        want = O.mul(r0.copy(), x, a, b, flags=fl).astype(np.float64)
+        scale = np.linalg.norm(want) + abs(a) * np.linalg.norm(O.mul(np.empty(n, npd), x).astype(np.float64)) + abs(b) * np.linalg.norm(r0) + 1e-300
+        assert np.linalg.norm(res.cpu().numpy().astype(np.float64) - want) <= tol * scale, (tag, kind, n, mem)
         assert op.data.insert == O.insert
 
     check("fresh")
     for step in range(int(rng.integers(5, 30))):
         c = rng.integers(12)
         if c <= 5:                                            # push a (mostly) well-conditioned pair
-            s = rng.uniform(-1, 1, n)
-            y = Dg * s + 1e-2 * rng.standard_normal(n)
+            s = rng.uniform(-1, 1, n).astype(npd)
+            y = (Dg * s + 1e-2 * rng.standard_normal(n)).astype(npd)
             if c == 5:
-                y = -y if rng.integers(2) else np.zeros(n)    # negative / zero curvature: rejected by L-BFGS
+                y = -y if rng.integers(2) else np.zeros(n, npd)    # negative / zero curvature: rejected by L-BFGS
             lo.push(op, T(s, dev), T(y, dev))
             O.push(s, y)
         elif c == 6:
@@ -69,17 +80,18 @@ def test_random_operation_sequences(lo, dev, seed):
         elif c == 7:
             op.set_push_mode(["gram", "reforder", "compact"][rng.integers(3)])
         elif c == 8 and kind != "inv":
-            got, want = lo.diag(op).cpu().numpy(), O.diag()
+            got, want = lo.diag(op).cpu().numpy().astype(np.float64), O.diag().astype(np.float64)
             assert np.linalg.norm(got - want) <= tol * (np.linalg.norm(want) + 1e-300), ("diag", kind, n, mem)
         elif c == 9 and kind == "fwd":
-            bvec, sig = rng.uniform(-1, 1, n), float(rng.uniform(0, 2))
-            got = lo.solve_shifted_system(torch.zeros(n, dtype=torch.float64, device=dev), op, T(bvec, dev), sig).cpu().numpy()
-            want = O.solve_shifted(np.zeros(n), bvec, sig)
-            assert np.linalg.norm(got - want) <= 1e-7 * (np.linalg.norm(want) + 1e-300), ("solve_shifted", n, mem)
+            bvec, sig = rng.uniform(-1, 1, n).astype(npd), npd(rng.uniform(0, 2))
+            got = lo.solve_shifted_system(torch.zeros(n, dtype=dtype, device=dev), op, T(bvec, dev), sig).cpu().numpy().astype(np.float64)
+            want = O.solve_shifted(np.zeros(n, npd), bvec, sig).astype(np.float64)
+            assert np.linalg.norm(got - want) <= tol_solve * (np.linalg.norm(want) + 1e-300), ("solve_shifted", n, mem)
         elif c == 10:
             sig = float(rng.uniform(-1, 1))
-            x = rng.uniform(-1, 1, n)
-            got = (lo.ShiftedOperator(op, sig) * T(x, dev)).cpu().numpy()
-            want = O.mul(np.empty(n), x) + sig * x
-            assert np.linalg.norm(got - want) <= tol * (np.linalg.norm(O.mul(np.empty(n), x)) + abs(sig) * np.linalg.norm(x) + 1e-300)
+            x = rng.uniform(-1, 1, n).astype(npd)
+            got = (lo.ShiftedOperator(op, sig) * T(x, dev)).cpu().numpy().astype(np.float64)
+            Bx = O.mul(np.empty(n, npd), x).astype(np.float64)
+            want = Bx + sig * x.astype(np.float64)
+            assert np.linalg.norm(got - want) <= tol * (np.linalg.norm(Bx) + abs(sig) * np.linalg.norm(x) + 1e-300)
         check(f"step {step} op {c}")

@@ -19,12 +19,16 @@
  *    src/cat.jl:17-18, src/special-operators.jl:263); matrices column-major
  *    with a leading dimension, exactly Julia's layout.
  *  - `dtype`: MXLO_F64 or MXLO_F32 (element type of res / v / operator data).
- *  - `alpha`, `beta` always arrive as double. For MXLO_F32 data the flag
- *    MXLO_SCALARS_F64 selects Julia's mixed-precision semantics
- *    (`mul!(res32, op32, v32, 2.0, 3.0)`: every element evaluated in Float64,
- *    rounded once on store); without it alpha/beta are first rounded to
- *    float and the arithmetic is pure fp32 (what the 3-arg `mul!` does,
- *    src/operations.jl:38-40).
+ *  - `alpha`, `beta` always arrive as double. Julia does not convert caller
+ *    scalars to the element type, so for MXLO_F32 data each scalar carries its
+ *    own width flag: MXLO_ALPHA_F64 / MXLO_BETA_F64 say that scalar was a
+ *    Float64 in the caller. The alpha-term of `α .* d .* v .+ β .* res` is then
+ *    evaluated in promote_type(typeof(α), Float32), the beta-term in
+ *    promote_type(typeof(β), Float32), their sum in the wider of the two, and
+ *    the result is rounded once on store — all four combinations bit-exact
+ *    (`mul!(res32, op32, v32, 2.0, 3.0)`: both flags; the 3-arg `mul!` uses
+ *    one(Float32), zero(Float32): no flag, pure fp32, src/operations.jl:38-40).
+ *    A scalar without its flag is first rounded to float.
  *  - `beta == 0` means OVERWRITE: `res` is never read (it may hold NaN/Inf
  *    garbage from `similar`, src/operations.jl:45, src/constructors.jl:63-78).
  *  - elementwise arithmetic is evaluated in the reference's association
@@ -59,7 +63,9 @@ extern "C" {
 #define MXLO_F64 0
 #define MXLO_F32 1
 
-#define MXLO_SCALARS_F64 0x1 /* f32 data, alpha/beta kept in double (see header comment)     */
+#define MXLO_ALPHA_F64   0x1 /* f32 data: alpha is a Float64 (the alpha-term is evaluated in double) */
+#define MXLO_BETA_F64    0x8 /* f32 data: beta  is a Float64 (the beta-term  is evaluated in double) */
+#define MXLO_SCALARS_F64 (MXLO_ALPHA_F64 | MXLO_BETA_F64) /* both (see header comment)                */
 #define MXLO_D_SCALAR    0x2 /* diag: `d` has ONE element, broadcast (SpectralGradient,
                                 src/DiagonalHessianApproximation.jl:226)                      */
 #define MXLO_TAIL_BETA   0x4 /* eye: rows [n_min,nrow) receive `beta` (NOT beta*res) when

@@ -97,7 +97,7 @@ dt(::Type{Float64}) = Int32(0)   # MXLO_F64
 dt(::Type{Float32}) = Int32(1)   # MXLO_F32
 # Julia does not convert caller scalars to T (SURVEY §8a "Mixed precision"): Float32 data with a
 # Float64 alpha or beta is evaluated per element in Float64 and rounded once on store.
-@inline flags(::Type{Float32}, α, β) = (α isa Float64 || β isa Float64) ? Int32(1) : Int32(0)  # MXLO_SCALARS_F64
+@inline flags(::Type{Float32}, α, β) = (α isa Float64 ? Int32(1) : Int32(0)) | (β isa Float64 ? Int32(8) : Int32(0))  # MXLO_ALPHA_F64 | MXLO_BETA_F64
 @inline flags(::Type{Float64}, α, β) = Int32(0)
 const P = Ptr{Cvoid}
 

@@ -21,7 +21,8 @@ RCCL_ID_BYTES = 128
 # status codes (include/mxlo.h)
 OK, EINVAL, ESHAPE, EHIP, ENOMEM, ESTATE, EDOMAIN, EREDUCE = range(8)
 F64, F32 = 0, 1
-SCALARS_F64, D_SCALAR, TAIL_BETA = 0x1, 0x2, 0x4
+ALPHA_F64, D_SCALAR, TAIL_BETA, BETA_F64 = 0x1, 0x2, 0x4, 0x8
+SCALARS_F64 = ALPHA_F64 | BETA_F64
 OP_N, OP_T, OP_C = 0, 1, 2
 BLK_DIAG, BLK_DENSE, BLK_EYE, BLK_ZEROS = 0, 1, 2, 3
 QN_LBFGS_INV, QN_LBFGS_FWD, QN_LSR1 = 0, 1, 2

@@ -37,7 +37,7 @@ MXLO_API int32_t mxlo_ctx_create(int32_t device_id, void *stream, mxlo_ctx **out
   MXLO_HIP(hipGetDeviceCount(&ndev));
   MXLO_REQUIRE(device_id >= 0 && device_id < ndev, MXLO_EINVAL,
                "mxlo_ctx_create: device %d not in [0,%d)", device_id, ndev);
-  MXLO_HIP(hipSetDevice(device_id));
+  DeviceGuard guard(device_id);   // the caller's current device is restored on return
   hipDeviceProp_t prop;
   MXLO_HIP(hipGetDeviceProperties(&prop, device_id));
   mxlo_ctx *ctx = new mxlo_ctx();
@@ -62,7 +62,7 @@ MXLO_API int32_t mxlo_ctx_create(int32_t device_id, void *stream, mxlo_ctx **out
 
 MXLO_API int32_t mxlo_ctx_destroy(mxlo_ctx *ctx) {
   if (!ctx) return MXLO_OK;
-  (void)hipSetDevice(ctx->device);
+  MXLO_DEVICE_GUARD(ctx);
   (void)hipStreamSynchronize(ctx->stream);
   if (ctx->partials) (void)hipFree(ctx->partials);
   if (ctx->scalars) (void)hipFree(ctx->scalars);
@@ -76,6 +76,7 @@ MXLO_API int32_t mxlo_ctx_destroy(mxlo_ctx *ctx) {
 
 MXLO_API int32_t mxlo_ctx_set_stream(mxlo_ctx *ctx, void *stream) {
   MXLO_REQUIRE(ctx, MXLO_EINVAL, "ctx is NULL");
+  MXLO_DEVICE_GUARD(ctx);
   hipStream_t next = (hipStream_t)stream;
   if (next != ctx->stream && !ctx->capturing) {
     // the reduction workspace, the scalar buffer and the quasi-Newton handles of this ctx are ordered by the
@@ -90,8 +91,8 @@ MXLO_API int32_t mxlo_ctx_set_stream(mxlo_ctx *ctx, void *stream) {
 
 MXLO_API int32_t mxlo_ctx_create_stream(mxlo_ctx *ctx, void **out) {
   MXLO_REQUIRE(ctx, MXLO_EINVAL, "ctx is NULL");
+  MXLO_DEVICE_GUARD(ctx);
   if (!ctx->own_stream) {
-    (void)hipSetDevice(ctx->device);
     MXLO_HIP(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
   }
   MXLO_TRY(mxlo_ctx_set_stream(ctx, (void *)ctx->own_stream));
@@ -109,6 +110,7 @@ struct mxlo_graph {
 
 MXLO_API int32_t mxlo_graph_begin(mxlo_ctx *ctx) {
   MXLO_REQUIRE(ctx, MXLO_EINVAL, "ctx is NULL");
+  MXLO_DEVICE_GUARD(ctx);
   MXLO_REQUIRE(!ctx->capturing, MXLO_ESTATE, "mxlo_graph_begin: a capture is already open on this ctx");
   MXLO_REQUIRE(ctx->stream != nullptr, MXLO_ESTATE,
                "mxlo_graph_begin: the default stream cannot be captured; give the ctx a stream "
@@ -120,6 +122,7 @@ MXLO_API int32_t mxlo_graph_begin(mxlo_ctx *ctx) {
 
 MXLO_API int32_t mxlo_graph_end(mxlo_ctx *ctx, mxlo_graph **out) {
   MXLO_REQUIRE(ctx && out, MXLO_EINVAL, "mxlo_graph_end: NULL argument");
+  MXLO_DEVICE_GUARD(ctx);
   MXLO_REQUIRE(ctx->capturing, MXLO_ESTATE, "mxlo_graph_end: no capture is open on this ctx");
   ctx->capturing = false;
   hipGraph_t graph = nullptr;
@@ -147,12 +150,14 @@ MXLO_API int32_t mxlo_graph_end(mxlo_ctx *ctx, mxlo_graph **out) {
 
 MXLO_API int32_t mxlo_graph_launch(mxlo_graph *g) {
   MXLO_REQUIRE(g && g->exec, MXLO_EINVAL, "mxlo_graph_launch: NULL graph");
+  MXLO_DEVICE_GUARD(g->ctx);
   MXLO_HIP(hipGraphLaunch(g->exec, g->stream));
   return MXLO_OK;
 }
 
 MXLO_API int32_t mxlo_graph_destroy(mxlo_graph *g) {
   if (!g) return MXLO_OK;
+  MXLO_DEVICE_GUARD(g->ctx);
   if (g->exec) (void)hipGraphExecDestroy(g->exec);
   if (g->graph) (void)hipGraphDestroy(g->graph);
   delete g;
@@ -161,6 +166,7 @@ MXLO_API int32_t mxlo_graph_destroy(mxlo_graph *g) {
 
 MXLO_API int32_t mxlo_ctx_sync(mxlo_ctx *ctx) {
   MXLO_REQUIRE(ctx, MXLO_EINVAL, "ctx is NULL");
+  MXLO_DEVICE_GUARD(ctx);
   MXLO_HIP(hipStreamSynchronize(ctx->stream));
   return MXLO_OK;
 }
@@ -192,13 +198,10 @@ MXLO_API int32_t mxlo_ctx_tune(mxlo_ctx *ctx, const char *key, int64_t value) {
     MXLO_REQUIRE(value == MXLO_INV_TWOPASS || value == MXLO_INV_REFORDER, MXLO_EINVAL,
                  "lbfgs_inv_mode must be MXLO_INV_TWOPASS or MXLO_INV_REFORDER");
     ctx->tune.lbfgs_inv_mode = (int)value;
-  } else if (!strcmp(key, "gemm_tile_m")) {
-    MXLO_REQUIRE(value == 0 || value == 32 || value == 64, MXLO_EINVAL, "gemm_tile_m must be 0, 32 or 64");
-    ctx->tune.gemm_tile_m = (int)value;
-  } else if (!strcmp(key, "gemm_waves")) {
-    MXLO_REQUIRE(value == 0 || value == 4 || value == 8 || value == 16, MXLO_EINVAL,
-                 "gemm_waves must be 0 (auto), 4, 8 or 16");
-    ctx->tune.gemm_waves = (int)value;
+  } else if (!strcmp(key, "gemm_tile")) {
+    MXLO_REQUIRE(value == 0 || value == 32 || value == 64 || value == 128 || value == -1, MXLO_EINVAL,
+                 "gemm_tile must be 0 (auto), 32, 64, 128 or -1 (generic kernel)");
+    ctx->tune.gemm_tile = (int)value;
   } else if (!strcmp(key, "fuse_finalize")) {
     MXLO_REQUIRE(value == 0 || value == 1, MXLO_EINVAL, "fuse_finalize must be 0 or 1");
     ctx->tune.fuse_finalize = (int)value;
@@ -225,9 +228,9 @@ MXLO_API int32_t mxlo_ctx_set_allreduce(mxlo_ctx *ctx, mxlo_allreduce_fn fn, voi
 // ---- memory helpers -----------------------------------------------------------
 MXLO_API int32_t mxlo_malloc(mxlo_ctx *ctx, int64_t bytes, void **out) {
   MXLO_REQUIRE(ctx && out && bytes >= 0, MXLO_EINVAL, "mxlo_malloc: bad argument");
+  MXLO_DEVICE_GUARD(ctx);
   *out = nullptr;
   if (bytes == 0) return MXLO_OK;
-  (void)hipSetDevice(ctx->device);
   hipError_t e = hipMalloc(out, (size_t)bytes);
   if (e != hipSuccess) {
     set_error("mxlo_malloc(%lld): %s", (long long)bytes, hipGetErrorString(e));
@@ -238,6 +241,7 @@ MXLO_API int32_t mxlo_malloc(mxlo_ctx *ctx, int64_t bytes, void **out) {
 
 MXLO_API int32_t mxlo_free(mxlo_ctx *ctx, void *p) {
   MXLO_REQUIRE(ctx, MXLO_EINVAL, "ctx is NULL");
+  MXLO_DEVICE_GUARD(ctx);
   if (!p) return MXLO_OK;
   MXLO_HIP(hipStreamSynchronize(ctx->stream));
   MXLO_HIP(hipFree(p));
@@ -246,6 +250,7 @@ MXLO_API int32_t mxlo_free(mxlo_ctx *ctx, void *p) {
 
 MXLO_API int32_t mxlo_memcpy_h2d(mxlo_ctx *ctx, void *dst, const void *src, int64_t bytes) {
   MXLO_REQUIRE(ctx && bytes >= 0, MXLO_EINVAL, "bad argument");
+  MXLO_DEVICE_GUARD(ctx);
   if (!bytes) return MXLO_OK;
   MXLO_HIP(hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyHostToDevice, ctx->stream));
   MXLO_HIP(hipStreamSynchronize(ctx->stream));  // the host buffer may be pageable / reused
@@ -254,6 +259,7 @@ MXLO_API int32_t mxlo_memcpy_h2d(mxlo_ctx *ctx, void *dst, const void *src, int6
 
 MXLO_API int32_t mxlo_memcpy_d2h(mxlo_ctx *ctx, void *dst, const void *src, int64_t bytes) {
   MXLO_REQUIRE(ctx && bytes >= 0, MXLO_EINVAL, "bad argument");
+  MXLO_DEVICE_GUARD(ctx);
   if (!bytes) return MXLO_OK;
   MXLO_HIP(hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyDeviceToHost, ctx->stream));
   MXLO_HIP(hipStreamSynchronize(ctx->stream));
@@ -262,6 +268,7 @@ MXLO_API int32_t mxlo_memcpy_d2h(mxlo_ctx *ctx, void *dst, const void *src, int6
 
 MXLO_API int32_t mxlo_memcpy_d2d(mxlo_ctx *ctx, void *dst, const void *src, int64_t bytes) {
   MXLO_REQUIRE(ctx && bytes >= 0, MXLO_EINVAL, "bad argument");
+  MXLO_DEVICE_GUARD(ctx);
   if (!bytes) return MXLO_OK;
   MXLO_HIP(hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyDeviceToDevice, ctx->stream));
   return MXLO_OK;
@@ -269,6 +276,7 @@ MXLO_API int32_t mxlo_memcpy_d2d(mxlo_ctx *ctx, void *dst, const void *src, int6
 
 MXLO_API int32_t mxlo_memset(mxlo_ctx *ctx, void *p, int32_t byte, int64_t bytes) {
   MXLO_REQUIRE(ctx && bytes >= 0, MXLO_EINVAL, "bad argument");
+  MXLO_DEVICE_GUARD(ctx);
   if (!bytes) return MXLO_OK;
   MXLO_HIP(hipMemsetAsync(p, byte, (size_t)bytes, ctx->stream));
   return MXLO_OK;
@@ -282,6 +290,7 @@ struct mxlo_timer {
 
 MXLO_API int32_t mxlo_timer_create(mxlo_ctx *ctx, mxlo_timer **out) {
   MXLO_REQUIRE(ctx && out, MXLO_EINVAL, "bad argument");
+  MXLO_DEVICE_GUARD(ctx);
   mxlo_timer *t = new mxlo_timer();
   t->ctx = ctx;
   MXLO_HIP(hipEventCreate(&t->e0));
@@ -291,16 +300,19 @@ MXLO_API int32_t mxlo_timer_create(mxlo_ctx *ctx, mxlo_timer **out) {
 }
 MXLO_API int32_t mxlo_timer_start(mxlo_timer *t) {
   MXLO_REQUIRE(t, MXLO_EINVAL, "timer is NULL");
+  MXLO_DEVICE_GUARD(t->ctx);
   MXLO_HIP(hipEventRecord(t->e0, t->ctx->stream));
   return MXLO_OK;
 }
 MXLO_API int32_t mxlo_timer_stop(mxlo_timer *t) {
   MXLO_REQUIRE(t, MXLO_EINVAL, "timer is NULL");
+  MXLO_DEVICE_GUARD(t->ctx);
   MXLO_HIP(hipEventRecord(t->e1, t->ctx->stream));
   return MXLO_OK;
 }
 MXLO_API int32_t mxlo_timer_elapsed_ms(mxlo_timer *t, double *ms) {
   MXLO_REQUIRE(t && ms, MXLO_EINVAL, "bad argument");
+  MXLO_DEVICE_GUARD(t->ctx);
   MXLO_HIP(hipEventSynchronize(t->e1));
   float f = 0.f;
   MXLO_HIP(hipEventElapsedTime(&f, t->e0, t->e1));
@@ -309,6 +321,7 @@ MXLO_API int32_t mxlo_timer_elapsed_ms(mxlo_timer *t, double *ms) {
 }
 MXLO_API int32_t mxlo_timer_destroy(mxlo_timer *t) {
   if (!t) return MXLO_OK;
+  MXLO_DEVICE_GUARD(t->ctx);
   (void)hipEventDestroy(t->e0);
   (void)hipEventDestroy(t->e1);
   delete t;

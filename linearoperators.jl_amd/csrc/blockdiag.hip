@@ -50,24 +50,23 @@ __device__ __forceinline__ void load_vec(const T *p, bool aligned, T (&out)[VEC]
 }
 
 // kind-specific scalar op: returns the new res element
-template <typename T, typename CT, bool BETA0>
-__device__ __forceinline__ T ew_op(int kind, CT a, CT b, T d, T v, T r) {
-  CT t;
-  if (kind == MXLO_BLK_DIAG) t = (a * (CT)d) * (CT)v;          // special-operators.jl:127-129
-  else if (kind == MXLO_BLK_EYE) t = a * (CT)v;                 // :38-41
+template <typename T, typename CA, typename CB, bool BETA0>
+__device__ __forceinline__ T ew_op(int kind, CA a, CB b, T d, T v, T r) {
+  CA t;
+  if (kind == MXLO_BLK_DIAG) t = (a * (CA)d) * (CA)v;          // special-operators.jl:127-129
+  else if (kind == MXLO_BLK_EYE) t = a * (CA)v;                 // :38-41
   else {                                                        // zeros: res .= 0 | res .*= β (:104-106)
     if constexpr (BETA0) return (T)0;
-    else return (T)((CT)r * b);
+    else return (T)((CB)r * b);
   }
-  if constexpr (!BETA0) t = t + (b * (CT)r);
-  return (T)t;
+  return fin_ab<T, CA, CB, BETA0>(t, b, r);
 }
 
 // One elementwise tile of a block of compile-time KIND (no per-load kind / alignment branches in the
 // all-aligned fast path, so the compiler can issue every load of the tile back to back).
-template <typename T, typename CT, bool BETA0, bool NT, int KIND>
+template <typename T, typename CA, typename CB, bool BETA0, bool NT, int KIND>
 __device__ __forceinline__ void ew_tile(T *__restrict__ r0, const T *__restrict__ x0, const T *__restrict__ d0,
-                                        int64_t cnt, int64_t tile_start, int64_t nmin, CT alpha, CT beta) {
+                                        int64_t cnt, int64_t tile_start, int64_t nmin, CA alpha, CB beta) {
   constexpr int VEC = Vec16<T>::N;
   using V = typename VecOf<T, VEC>::type;
   const int tid = threadIdx.x;
@@ -96,7 +95,7 @@ __device__ __forceinline__ void ew_tile(T *__restrict__ r0, const T *__restrict_
         V out;
 #pragma unroll
         for (int e = 0; e < VEC; ++e)
-          out[e] = ew_op<T, CT, BETA0>(KIND, alpha, beta, KIND == MXLO_BLK_DIAG ? dv[u][e] : T(0),
+          out[e] = ew_op<T, CA, CB, BETA0>(KIND, alpha, beta, KIND == MXLO_BLK_DIAG ? dv[u][e] : T(0),
                                        KIND != MXLO_BLK_ZEROS ? xv[u][e] : T(0), BETA0 ? T(0) : rv[u][e]);
         stg<NT>(reinterpret_cast<V *>(r0 + o), out);
       }
@@ -133,7 +132,7 @@ __device__ __forceinline__ void ew_tile(T *__restrict__ r0, const T *__restrict_
         V out;
 #pragma unroll
         for (int e = 0; e < VEC; ++e)
-          out[e] = ew_op<T, CT, BETA0>(KIND, alpha, beta, KIND == MXLO_BLK_DIAG ? dv[u][e] : T(0),
+          out[e] = ew_op<T, CA, CB, BETA0>(KIND, alpha, beta, KIND == MXLO_BLK_DIAG ? dv[u][e] : T(0),
                                        KIND != MXLO_BLK_ZEROS ? xv[u][e] : T(0), BETA0 ? T(0) : rv[u][e]);
         stg<NT>(reinterpret_cast<V *>(r0 + o), out);
       }
@@ -142,14 +141,14 @@ __device__ __forceinline__ void ew_tile(T *__restrict__ r0, const T *__restrict_
     const int64_t nsc = head + (cnt - tail0);
     if (tid < nsc) {
       const int64_t o = tid < head ? tid : tail0 + (tid - head);
-      r0[o] = ew_op<T, CT, BETA0>(KIND, alpha, beta, KIND == MXLO_BLK_DIAG ? d0[o] : T(0),
+      r0[o] = ew_op<T, CA, CB, BETA0>(KIND, alpha, beta, KIND == MXLO_BLK_DIAG ? d0[o] : T(0),
                                   KIND != MXLO_BLK_ZEROS ? x0[o] : T(0), BETA0 ? T(0) : r0[o]);
     }
   } else {
     for (int64_t o = tid; o < cnt; o += kBlock) {
       const int64_t g = tile_start + o;
       if (g < nmin) {
-        r0[o] = ew_op<T, CT, BETA0>(KIND, alpha, beta, KIND == MXLO_BLK_DIAG ? d0[o] : T(0),
+        r0[o] = ew_op<T, CA, CB, BETA0>(KIND, alpha, beta, KIND == MXLO_BLK_DIAG ? d0[o] : T(0),
                                     KIND != MXLO_BLK_ZEROS ? x0[o] : T(0), BETA0 ? T(0) : r0[o]);
       } else {  // rectangular eye tail: 0 when β == 0 else β itself (special-operators.jl:39,42)
         r0[o] = BETA0 ? (T)0 : (T)beta;
@@ -158,10 +157,10 @@ __device__ __forceinline__ void ew_tile(T *__restrict__ r0, const T *__restrict_
   }
 }
 
-template <typename T, typename CT, bool BETA0, bool TRANS, bool NT>
+template <typename T, typename CA, typename CB, bool BETA0, bool TRANS, bool NT>
 __global__ void __launch_bounds__(kBlock)
 blockdiag_kernel(T *__restrict__ res, const T *__restrict__ x, const DevBlock *__restrict__ blocks,
-                 const Tile *__restrict__ tiles, CT alpha, CT beta) {
+                 const Tile *__restrict__ tiles, CA alpha, CB beta) {
   const Tile tl = tiles[blockIdx.x];
   const DevBlock b = tl.b;
   (void)blocks;
@@ -183,11 +182,11 @@ blockdiag_kernel(T *__restrict__ res, const T *__restrict__ x, const DevBlock *_
     const T *x0 = xp + tl.start;
     const T *d0 = dp ? dp + tl.start : nullptr;
     if (b.kind == MXLO_BLK_DIAG)
-      ew_tile<T, CT, BETA0, NT, MXLO_BLK_DIAG>(r0, x0, d0, cnt, tl.start, nmin, alpha, beta);
+      ew_tile<T, CA, CB, BETA0, NT, MXLO_BLK_DIAG>(r0, x0, d0, cnt, tl.start, nmin, alpha, beta);
     else if (b.kind == MXLO_BLK_EYE)
-      ew_tile<T, CT, BETA0, NT, MXLO_BLK_EYE>(r0, x0, d0, cnt, tl.start, nmin, alpha, beta);
+      ew_tile<T, CA, CB, BETA0, NT, MXLO_BLK_EYE>(r0, x0, d0, cnt, tl.start, nmin, alpha, beta);
     else
-      ew_tile<T, CT, BETA0, NT, MXLO_BLK_ZEROS>(r0, x0, d0, cnt, tl.start, nmin, alpha, beta);
+      ew_tile<T, CA, CB, BETA0, NT, MXLO_BLK_ZEROS>(r0, x0, d0, cnt, tl.start, nmin, alpha, beta);
     return;
   }
   // ---- dense block, column-major m x n with leading dimension ld
@@ -197,9 +196,7 @@ blockdiag_kernel(T *__restrict__ res, const T *__restrict__ x, const DevBlock *_
     if (i < b.m) {
       double acc = 0.0;
       for (int64_t j = 0; j < b.n; ++j) acc = fma((double)M[i + j * b.ld], (double)xp[j], acc);
-      CT t = alpha * (CT)(T)acc;
-      if constexpr (!BETA0) t = t + (beta * (CT)rp[i]);
-      rp[i] = (T)t;
+      rp[i] = fin_ab<T, CA, CB, BETA0>(alpha * (CA)(T)acc, beta, BETA0 ? T(0) : rp[i]);
     }
   } else {
     const int lane = tid & 63;
@@ -211,9 +208,7 @@ blockdiag_kernel(T *__restrict__ res, const T *__restrict__ x, const DevBlock *_
 #pragma unroll
       for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
       if (lane == 0) {
-        CT t = alpha * (CT)(T)acc;
-        if constexpr (!BETA0) t = t + (beta * (CT)rp[j]);
-        rp[j] = (T)t;
+        rp[j] = fin_ab<T, CA, CB, BETA0>(alpha * (CA)(T)acc, beta, BETA0 ? T(0) : rp[j]);
       }
     }
   }
@@ -233,6 +228,7 @@ struct mxlo_blockdiag {
 MXLO_API int32_t mxlo_blockdiag_create(mxlo_ctx *ctx, int32_t dtype, const mxlo_block_desc *blocks,
                                        int64_t nblocks, mxlo_blockdiag **out) {
   MXLO_REQUIRE(ctx && out && (nblocks == 0 || blocks), MXLO_EINVAL, "mxlo_blockdiag_create: NULL argument");
+  MXLO_DEVICE_GUARD(ctx);
   MXLO_REQUIRE(dtype == MXLO_F64 || dtype == MXLO_F32, MXLO_EINVAL, "bad dtype");
   MXLO_REQUIRE(nblocks >= 0 && nblocks < (1LL << 31), MXLO_ESHAPE, "bad block count");
   std::vector<DevBlock> hb((size_t)nblocks);
@@ -294,6 +290,7 @@ MXLO_API int32_t mxlo_blockdiag_create(mxlo_ctx *ctx, int32_t dtype, const mxlo_
 
 MXLO_API int32_t mxlo_blockdiag_destroy(mxlo_blockdiag *bd) {
   if (!bd) return MXLO_OK;
+  MXLO_DEVICE_GUARD(bd->ctx);
   (void)hipStreamSynchronize(bd->ctx->stream);
   if (bd->d_blocks) (void)hipFree(bd->d_blocks);
   if (bd->d_tiles_n) (void)hipFree(bd->d_tiles_n);
@@ -311,11 +308,11 @@ static int32_t blockdiag_mul_t(mxlo_blockdiag *bd, T *res, const T *v, double al
   const Tile *tiles = trans ? bd->d_tiles_t : bd->d_tiles_n;
   if (nt == 0) return MXLO_OK;
   MXLO_REQUIRE(nt < (1LL << 31), MXLO_ESHAPE, "too many tiles");
-  return dispatch_ct<T>(beta, flags, [&]<typename CT, bool B0>() -> int32_t {
+  return dispatch_ab<T>(beta, flags, [&]<typename CA, typename CB, bool B0>() -> int32_t {
     const bool ntm = (int64_t)sizeof(T) * (bd->nrow + 2 * bd->ncol) >= ctx->tune.nt_min_bytes;
 #define BD_GO(TR_, NT_)                                                                               \
-  hipLaunchKernelGGL((blockdiag_kernel<T, CT, B0, TR_, NT_>), dim3((unsigned)nt), dim3(kBlock), 0,   \
-                     ctx->stream, res, v, bd->d_blocks, tiles, (CT)alpha, (CT)beta)
+  hipLaunchKernelGGL((blockdiag_kernel<T, CA, CB, B0, TR_, NT_>), dim3((unsigned)nt), dim3(kBlock), 0, \
+                     ctx->stream, res, v, bd->d_blocks, tiles, (CA)alpha, (CB)beta)
     if (trans && ntm) BD_GO(true, true);
     else if (trans) BD_GO(true, false);
     else if (ntm) BD_GO(false, true);
@@ -329,14 +326,12 @@ static int32_t blockdiag_mul_t(mxlo_blockdiag *bd, T *res, const T *v, double al
 MXLO_API int32_t mxlo_blockdiag_mul(mxlo_blockdiag *bd, void *res, const void *v, double alpha,
                                     double beta, int32_t op_mode, int32_t flags) {
   MXLO_REQUIRE(bd, MXLO_EINVAL, "mxlo_blockdiag_mul: handle is NULL");
+  MXLO_DEVICE_GUARD(bd->ctx);
   MXLO_REQUIRE(op_mode >= MXLO_OP_N && op_mode <= MXLO_OP_C, MXLO_EINVAL, "bad op_mode");
   const int64_t nres = op_mode == MXLO_OP_N ? bd->nrow : bd->ncol;
   if (nres == 0) return MXLO_OK;
   MXLO_REQUIRE(res && v, MXLO_EINVAL, "mxlo_blockdiag_mul: NULL operand");
-  if (bd->dtype == MXLO_F32 && !(flags & MXLO_SCALARS_F64)) {
-    alpha = (double)(float)alpha;
-    beta = (double)(float)beta;
-  }
+  eff_scalars(bd->dtype == MXLO_F64 ? 8 : 4, flags, alpha, beta);
   if (bd->dtype == MXLO_F64) return blockdiag_mul_t<double>(bd, (double *)res, (const double *)v, alpha, beta, op_mode, flags);
   return blockdiag_mul_t<float>(bd, (float *)res, (const float *)v, alpha, beta, op_mode, flags);
 }

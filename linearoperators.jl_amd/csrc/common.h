@@ -64,9 +64,8 @@ struct Tune {
   int house_reverse = 1;   // Householder phase B walks the vectors back-to-front (MALL tail reuse)
   int lbfgs_inv_mode = MXLO_INV_TWOPASS;
   int dots_max_nc = 20;    // columns per panel_dots launch (<= 20)
-  int gemm_tile_m = 0;     // fast GEMM tile rows: 0 = auto (32 when there are fewer 64x64 tiles than CUs), 32, 64
-  int gemm_waves = 0;      // fast GEMM wave layout: 0/16 = one wave per 16x16 block (16 waves per 64x64 tile),
-                           // 8 = 16x32 per wave, 4 = 32x32 per wave
+  int gemm_tile = 0;       // kron GEMM tile edge: 0 = auto (largest of 128/64/32 that still gives every CU a
+                           // workgroup), 32 / 64 / 128 force one, -1 = generic fallback kernel only
   int fuse_finalize = 1;   // reductions of <= 4 columns: last-arriving workgroup finalizes in the dots kernel
   int combine_blocks_per_cu = 0;   // panel_combine: 0 = one vector per thread (best measured), k = persistent grid
 };
@@ -91,6 +90,22 @@ struct mxlo_ctx {
 };
 
 namespace mxlo {
+
+// Every entry point that allocates or launches runs on the device its ctx was created for, whatever the calling
+// thread's current device is (one process driving several GPUs), and leaves the caller's current device untouched.
+struct DeviceGuard {
+  int prev = -1;
+  bool switched = false;
+  explicit DeviceGuard(int dev) {
+    if (hipGetDevice(&prev) == hipSuccess && prev != dev) switched = hipSetDevice(dev) == hipSuccess;
+  }
+  ~DeviceGuard() {
+    if (switched) (void)hipSetDevice(prev);
+  }
+  DeviceGuard(const DeviceGuard &) = delete;
+  DeviceGuard &operator=(const DeviceGuard &) = delete;
+};
+#define MXLO_DEVICE_GUARD(ctxexpr) mxlo::DeviceGuard dev_guard__((ctxexpr)->device)
 
 // ---- 16-byte vector types --------------------------------------------------
 typedef double f64x2 __attribute__((ext_vector_type(2)));

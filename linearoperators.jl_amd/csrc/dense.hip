@@ -3,10 +3,11 @@
 // kron(A,B)*x = vec(B * X * A^T) is two GEMMs on the matrix cores: f64 uses
 // v_mfma_f64_16x16x4_f64 (one f64 of A and B per lane; C/D layout col = lane&15,
 // row = (lane>>4) + 4*reg — NOT the f32 map), f32 uses v_mfma_f32_16x16x4_f32
-// (row = 4*(lane>>4) + reg). 64x64 block tile, 4 waves each owning a 32x32 quadrant (2x2 MFMA
-// tiles = 4 independent accumulators, enough to issue back-to-back), K staged through LDS in
-// k-major layout padded to 80 doubles per row so both operand reads are conflict-free ds_read_b64.
+// (row = 4*(lane>>4) + reg). The production kernel is gemm_glds.h (LDS-DMA ring, swizzled LDS images, counted
+// vmcnt, mid-slab barrier); `gemm_kernel` below is the fallback for operands the 16-byte DMA path cannot take
+// (odd leading dimensions / extents, misaligned views).
 #include "common.h"
+#include "gemm_glds.h"
 #include "stream_kernels.h"
 
 using namespace mxlo;
@@ -40,10 +41,10 @@ struct Mfma<float> {
 
 // C (M x N, ldc) = alpha * opA(A) (M x K) * opB(B) (K x N) (+ beta * C); column-major.
 // TA: A is stored K x M (we need its transpose); TB: B is stored N x K.
-template <typename T, typename CT, bool TA, bool TB, bool BETA0>
+template <typename T, typename CA, typename CB, bool TA, bool TB, bool BETA0>
 __global__ void __launch_bounds__(kBlock)
 gemm_kernel(T *__restrict__ C, int64_t ldc, const T *__restrict__ A, int64_t lda,
-            const T *__restrict__ B, int64_t ldb, int M, int N, int K, CT alpha, CT beta) {
+            const T *__restrict__ B, int64_t ldb, int M, int N, int K, CA alpha, CB beta) {
   __shared__ T sA[BK][LDT];  // sA[k][i]
   __shared__ T sB[BK][LDT];  // sB[k][j]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -106,204 +107,59 @@ gemm_kernel(T *__restrict__ C, int64_t ldc, const T *__restrict__ A, int64_t lda
         const int gj = bn + wn + b * 16 + (lane & 15);
         if (gi < M && gj < N) {
           T *p = C + gi + (int64_t)gj * ldc;
-          CT t = alpha * (CT)acc[a][b][r];
-          if constexpr (!BETA0) t = t + (beta * (CT)(*p));
-          *p = (T)t;
+          *p = fin_ab<T, CA, CB, BETA0>(alpha * (CA)acc[a][b][r], beta, BETA0 ? T(0) : *p);
         }
       }
 }
 
-// ---- fast path: C = alpha * A * B'^T (+ beta*C) with BOTH operands contiguous along their non-K
-// dimension: A is M x K (i contiguous, lda), B' is stored N x K (j contiguous, ldb) — the (N,T) case,
-// which is the only one kron's N mode needs when the first product is formed transposed:
-//   Ut = A * X^T (m x q),  R = B * Ut^T (p x m).
-// 64x64 tile, BK = 32, 16-byte global loads straight into k-major LDS rows (no transposing writes),
-// register-prefetch double buffering: the next K-slab's global loads are in flight while the 32 MFMAs
-// of the current slab issue; one barrier per slab.
-constexpr int FBK = 32;
-
-// TM x 64 output tile per workgroup. (TM, WAVES) = (64, 8): one workgroup per CU at 1024^2;
-// (32, 4): 512 workgroups at 1024^2 = TWO independent workgroups per CU, so one computes while the other
-// sits in its barrier / LDS-store bubble.
-template <typename T, typename CT, bool BETA0, int WAVES, int TM, int WCOLS = 2>
-__global__ void __launch_bounds__(WAVES * 64)
-gemm_nt_fast_kernel(T *__restrict__ C, int64_t ldc, const T *__restrict__ A, int64_t lda,
-                    const T *__restrict__ B, int64_t ldb, int K, CT alpha, CT beta) {
-  constexpr int kBlock = WAVES * 64;                     // shadows mxlo::kBlock inside this kernel
-  constexpr int WR = WAVES / WCOLS;                      // waves along M; WCOLS along N
-  constexpr int MT = TM / WR / 16;                       // 16-row MFMA tiles per wave along M
-  constexpr int NTW = BN / WCOLS / 16;                   // 16-column MFMA tiles per wave along N
-  static_assert(MT >= 1 && MT * 16 * WR == TM && NTW >= 1 && NTW * 16 * WCOLS == BN, "bad tile / wave shape");
-  constexpr int VEC = Vec16<T>::N;                       // elements per 16-byte load
-  constexpr int LPA = TM * FBK / VEC / kBlock;           // 16-byte loads per thread per A slab
-  constexpr int LPB = BN * FBK / VEC / kBlock;           //                             per B slab
-  static_assert(LPA >= 1 && LPB >= 1, "slab smaller than one load per thread");
-  constexpr int RPA = TM / VEC, RPB = BN / VEC;          // vectors per k-row
-  constexpr int LDA_ = TM == 64 ? 80 : 48;               // padded k-row: second k-row lands 32 banks away
-  using V = typename Vec16<T>::type;
-  __shared__ T sA[2][FBK][LDA_];
-  __shared__ T sB[2][FBK][LDT];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  // XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs by linear id, each XCD has its own L2.
-  // Give every XCD a compact (gx/4) x (gy/2) sub-grid of tiles instead of a stride-8 comb, so the A and B slabs
-  // it touches are shared inside its L2 (1024^2: 4 x 8 tiles per XCD read 4 A + 8 B panels instead of 2 + 16).
-  int tx = blockIdx.x, ty = blockIdx.y;
-#ifndef MXLO_GEMM_NO_SWIZZLE
-  if ((gridDim.x & 3) == 0 && (gridDim.y & 1) == 0) {
-    const int id = blockIdx.x + blockIdx.y * gridDim.x, xcd = id & 7, local = id >> 3;
-    const int sx = gridDim.x >> 2, sy = gridDim.y >> 1;   // sub-grid extents
-    tx = (xcd & 3) * sx + local % sx;
-    ty = (xcd >> 2) * sy + local / sx;
-  }
-#endif
-  const int bm = tx * TM, bn = ty * BN;
-  const int wm = (wave % WR) * (TM / WR);
-  const int wn = (wave / WR) * (BN / WCOLS);
-  using Acc = typename Mfma<T>::Acc;
-  Acc acc[MT][NTW];
-#pragma unroll
-  for (int a = 0; a < MT; ++a)
-#pragma unroll
-    for (int b = 0; b < NTW; ++b)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) acc[a][b][r] = 0;
-
-  // Three-stage software pipeline: while slab `it` is in the MFMAs (LDS buffer it&1), slab it+1 sits in
-  // one register set (its global loads were issued a whole iteration ago, so the mid-iteration LDS store
-  // never waits on memory) and the loads of slab it+2 are issued into the other register set.
-  V ra0[LPA], rb0[LPB], ra1[LPA], rb1[LPB];
-  auto gload = [&](int k0, V (&ra)[LPA], V (&rb)[LPB]) {
-#pragma unroll
-    for (int r = 0; r < LPA; ++r) {
-      const int idx = tid + r * kBlock;
-      const int iv = idx % RPA, k = idx / RPA;
-      ra[r] = *reinterpret_cast<const V *>(A + (bm + iv * VEC) + (int64_t)(k0 + k) * lda);
-    }
-#pragma unroll
-    for (int r = 0; r < LPB; ++r) {
-      const int idx = tid + r * kBlock;
-      const int iv = idx % RPB, k = idx / RPB;
-      rb[r] = *reinterpret_cast<const V *>(B + (bn + iv * VEC) + (int64_t)(k0 + k) * ldb);
-    }
-  };
-  auto lstore = [&](int buf, const V (&ra)[LPA], const V (&rb)[LPB]) {
-#pragma unroll
-    for (int r = 0; r < LPA; ++r) {
-      const int idx = tid + r * kBlock;
-      const int iv = idx % RPA, k = idx / RPA;
-      *reinterpret_cast<V *>(&sA[buf][k][iv * VEC]) = ra[r];
-    }
-#pragma unroll
-    for (int r = 0; r < LPB; ++r) {
-      const int idx = tid + r * kBlock;
-      const int iv = idx % RPB, k = idx / RPB;
-      *reinterpret_cast<V *>(&sB[buf][k][iv * VEC]) = rb[r];
-    }
-  };
-  auto mfma_range = [&](int buf, int kbeg, int kend) {
-#pragma unroll
-    for (int kk = kbeg; kk < kend; kk += 4) {
-      const int kr = kk + (lane >> 4);
-      T bv[NTW];
-#pragma unroll
-      for (int b = 0; b < NTW; ++b) bv[b] = sB[buf][kr][wn + b * 16 + (lane & 15)];
-#pragma unroll
-      for (int a = 0; a < MT; ++a) {
-        const T av = sA[buf][kr][wm + a * 16 + (lane & 15)];
-#pragma unroll
-        for (int b = 0; b < NTW; ++b) acc[a][b] = Mfma<T>::run(av, bv[b], acc[a][b]);
-      }
-    }
-  };
-  const int nk = K / FBK;
-  gload(0, ra0, rb0);
-  lstore(0, ra0, rb0);
-  if (nk > 1) gload(FBK, ra1, rb1);
-  __syncthreads();
-  for (int it = 0; it < nk; it += 2) {
-    // even slab: LDS buffer 0; register set 1 holds slab it+1; set 0 receives slab it+2
-    if (it + 2 < nk) gload((it + 2) * FBK, ra0, rb0);
-    mfma_range(0, 0, FBK / 2);
-    if (it + 1 < nk) lstore(1, ra1, rb1);
-    mfma_range(0, FBK / 2, FBK);
-    __syncthreads();
-    if (it + 1 >= nk) break;
-    // odd slab: LDS buffer 1; register set 0 holds slab it+2; set 1 receives slab it+3
-    if (it + 3 < nk) gload((it + 3) * FBK, ra1, rb1);
-    mfma_range(1, 0, FBK / 2);
-    if (it + 2 < nk) lstore(0, ra0, rb0);
-    mfma_range(1, FBK / 2, FBK);
-    __syncthreads();
-  }
-#pragma unroll
-  for (int a = 0; a < MT; ++a)
-#pragma unroll
-    for (int b = 0; b < NTW; ++b)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int gi = bm + wm + a * 16 + Mfma<T>::row(lane, r);
-        const int gj = bn + wn + b * 16 + (lane & 15);
-        T *p = C + gi + (int64_t)gj * ldc;
-        CT t = alpha * (CT)acc[a][b][r];
-        if constexpr (!BETA0) t = t + (beta * (CT)(*p));
-        *p = (T)t;
-      }
-}
-
-template <typename T>
-bool gemm_nt_fast_ok(const T *A, int64_t lda, const T *B, int64_t ldb, int64_t M, int64_t N, int64_t K) {
-  constexpr int VEC = Vec16<T>::N;
-  return M % BM == 0 && N % BN == 0 && K % FBK == 0 && K > 0 && lda % VEC == 0 && ldb % VEC == 0 &&
-         (((uintptr_t)A | (uintptr_t)B) & 15u) == 0;
-}
-
+// C (M x N) = alpha * opA(A) * opB(B) (+ beta*C). tb == true (B' stored N x K, N-contiguous) with either A layout is
+// the DMA kernel's shape — both products of kron's prod! AND of its tprod!/ctprod! have it. Tile choice
+// (tools/tune_gemm.hip, profiles/r02_tune_gemm.txt): the largest tile that still gives every CU a workgroup.
 template <typename T>
 int32_t gemm(mxlo_ctx *ctx, T *C, int64_t ldc, const T *A, int64_t lda, bool ta, const T *B,
              int64_t ldb, bool tb, int64_t M, int64_t N, int64_t K, double alpha, double beta,
              int32_t flags) {
   if (M <= 0 || N <= 0) return MXLO_OK;
   MXLO_REQUIRE(M < (1LL << 31) && N < (1LL << 31) && K < (1LL << 31), MXLO_ESHAPE, "gemm dims too large");
-  dim3 grid((unsigned)((M + BM - 1) / BM), (unsigned)((N + BN - 1) / BN));
-  if (!ta && tb && gemm_nt_fast_ok<T>(A, lda, B, ldb, M, N, K)) {
-    return dispatch_ct<T>(beta, flags, [&]<typename CT, bool B0>() -> int32_t {
-      // Tile / wave-layout choice (tools/sweep_gemm.py). The f64 MFMA pipe needs many waves per SIMD to stay
-      // busy across the barrier and LDS phases, so each 16x16 output block gets its OWN wave:
-      //   f64, >= one 64x64 tile per CU : 64x64 tile, 16 waves (4 x 4)     1024^2: 86 us/kron, 2048^2: 564 us
-      //   f64, fewer                    : 32x64 tile,  8 waves (2 x 4)      512^2: 32 us
-      // (the 4- and 8-wave layouts with 16x32 / 32x32 per wave remain selectable: 1024^2 105 us.)
-      // f32 slabs are half the bytes (not enough 16-byte loads for 1024 threads): 32x64 / 4 waves or 64x64 / 8.
-      const int64_t tiles64 = (M / 64) * (N / 64);
-      const int tm_req = ctx->tune.gemm_tile_m, wv = ctx->tune.gemm_waves;   // 0 = auto
-      dim3 g32((unsigned)(M / 32), (unsigned)(N / 64));
-#define FAST(W_, TM_, WC_, GRID_)                                                                              \
-  hipLaunchKernelGGL((gemm_nt_fast_kernel<T, CT, B0, W_, TM_, WC_>), GRID_, dim3(W_ * 64), 0, ctx->stream, C, \
-                     ldc, A, lda, B, ldb, (int)K, (CT)alpha, (CT)beta)
-      if constexpr (sizeof(T) == 8) {
-        const bool small = tm_req == 32 || (tm_req == 0 && tiles64 < ctx->num_cu);
-        if (wv == 0 || wv == 16) {
-          if (small) FAST(8, 32, 4, g32);
-          else FAST(16, 64, 4, grid);
-        } else if (wv == 8) {
-          if (small) FAST(4, 32, 2, g32);
-          else FAST(8, 64, 2, grid);
-        } else {
-          FAST(4, 64, 2, grid);
-        }
-      } else {
-        const bool small = tm_req == 32 || (tm_req == 0 && tiles64 < 2 * ctx->num_cu);
-        if (small) FAST(4, 32, 2, g32);
-        else if (wv == 4) FAST(4, 64, 2, grid);
-        else FAST(8, 64, 2, grid);
+  // per-lane DMA offsets are 32-bit: one K-slab of either operand must span < 4 GiB
+  const bool ld_ok = lda < (1LL << 22) && ldb < (1LL << 22) && ldc > 0;
+  if (tb && K > 0 && ld_ok && ctx->tune.gemm_tile >= 0 && gemm_glds_ok<T>(A, lda, ta, B, ldb, M, N, K)) {
+    return dispatch_ab<T>(beta, flags, [&]<typename CA, typename CB, bool B0>() -> int32_t {
+      auto tiles = [&](int tm, int tn) { return ((M + tm - 1) / tm) * ((N + tn - 1) / tn); };
+      int tile = ctx->tune.gemm_tile;   // 0 = auto, else 32 / 64 / 128
+      if (tile == 0) {
+        if (tiles(128, 128) >= ctx->num_cu) tile = 128;
+        else if (tiles(64, 64) * 5 >= (int64_t)ctx->num_cu * 3) tile = 64;   // >= 0.6 workgroups per CU
+        else tile = 32;
       }
-#undef FAST
+#define GLDS(AK_, TM_, TN_, WM_, WN_, BK_, NST_)                                                                  \
+  {                                                                                                               \
+    GlShape S{(int)M, (int)N, (int)K, (int)((M + TM_ - 1) / TM_), (int)((N + TN_ - 1) / TN_)};                    \
+    hipLaunchKernelGGL((gemm_glds_kernel<T, CA, CB, B0, AK_, TM_, TN_, WM_, WN_, BK_, NST_>), dim3(S.gx * S.gy),  \
+                       dim3(WM_ * WN_ * 64), 0, ctx->stream, C, ldc, A, lda, B, ldb, S, (CA)alpha, (CB)beta);     \
+  }
+#define GLDS_BY_A(TM_, TN_, WM_, WN_, BK_, NST_)                                                                  \
+  if (ta) GLDS(true, TM_, TN_, WM_, WN_, BK_, NST_) else GLDS(false, TM_, TN_, WM_, WN_, BK_, NST_)
+      if constexpr (sizeof(T) == 8) {
+        if (tile == 128) GLDS_BY_A(128, 128, 4, 4, 16, 3)
+        else if (tile == 64) GLDS_BY_A(64, 64, 4, 2, 32, 3)
+        else GLDS_BY_A(32, 32, 2, 2, 32, 4)
+      } else {
+        if (tile == 128) GLDS_BY_A(128, 128, 4, 4, 32, 3)
+        else if (tile == 64) GLDS_BY_A(64, 64, 4, 2, 64, 3)
+        else GLDS_BY_A(32, 32, 2, 2, 64, 4)
+      }
+#undef GLDS_BY_A
+#undef GLDS
       MXLO_LAUNCH_CHECK();
       return MXLO_OK;
     });
   }
-  return dispatch_ct<T>(beta, flags, [&]<typename CT, bool B0>() -> int32_t {
-#define GO(TA_, TB_)                                                                             \
-  hipLaunchKernelGGL((gemm_kernel<T, CT, TA_, TB_, B0>), grid, dim3(kBlock), 0, ctx->stream, C,  \
-                     ldc, A, lda, B, ldb, (int)M, (int)N, (int)K, (CT)alpha, (CT)beta)
+  dim3 grid((unsigned)((M + BM - 1) / BM), (unsigned)((N + BN - 1) / BN));
+  return dispatch_ab<T>(beta, flags, [&]<typename CA, typename CB, bool B0>() -> int32_t {
+#define GO(TA_, TB_)                                                                                  \
+  hipLaunchKernelGGL((gemm_kernel<T, CA, CB, TA_, TB_, B0>), grid, dim3(kBlock), 0, ctx->stream, C,  \
+                     ldc, A, lda, B, ldb, (int)M, (int)N, (int)K, (CA)alpha, (CB)beta)
     if (!ta && !tb) GO(false, false);
     else if (!ta && tb) GO(false, true);
     else if (ta && !tb) GO(true, false);
@@ -318,10 +174,10 @@ int32_t gemm(mxlo_ctx *ctx, T *C, int64_t ldc, const T *A, int64_t lda, bool ta,
 // T mode (res[j] = alpha * dot(M[:,j], v) + beta*res[j]): one wave per column, coalesced down the column.
 // PAIR: 16 bytes of rows per lane per load (2 rows f64, 4 rows f32), 4 loads of M in flight per lane,
 // nontemporal (M is streamed once; v stays cached).
-template <typename T, typename CT, bool BETA0, bool PAIR>
+template <typename T, typename CA, typename CB, bool BETA0, bool PAIR>
 __global__ void __launch_bounds__(kBlock)
 gemv_t_kernel(T *__restrict__ res, const T *__restrict__ M, int64_t m, int64_t n, int64_t ld,
-              const T *__restrict__ v, CT alpha, CT beta) {
+              const T *__restrict__ v, CA alpha, CB beta) {
   constexpr int VR = 16 / (int)sizeof(T);     // rows per lane per 16-byte load: 2 (f64) or 4 (f32)
   typedef T VV __attribute__((ext_vector_type(VR)));
   const int lane = threadIdx.x & 63;
@@ -368,9 +224,7 @@ gemv_t_kernel(T *__restrict__ res, const T *__restrict__ M, int64_t m, int64_t n
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
     if (lane == 0) {
-      CT t = alpha * (CT)(T)acc;
-      if constexpr (!BETA0) t = t + (beta * (CT)res[j]);
-      res[j] = (T)t;
+      res[j] = fin_ab<T, CA, CB, BETA0>(alpha * (CA)(T)acc, beta, BETA0 ? T(0) : res[j]);
     }
   }
 }
@@ -419,10 +273,10 @@ gemv_n_partial_kernel(double *__restrict__ part, const T *__restrict__ M, int64_
 
 // 32 rows per workgroup, 8 lanes per row: lane `sub` adds chunks sub, sub+8, ... (independent loads in flight),
 // the 8 sub-sums are combined in a fixed order -> deterministic, and m/32 workgroups instead of m/256.
-template <typename T, typename CT, bool BETA0>
+template <typename T, typename CA, typename CB, bool BETA0>
 __global__ void __launch_bounds__(kBlock)
 gemv_n_finish_kernel(T *__restrict__ res, const double *__restrict__ part, int64_t m, int nchunks,
-                     CT alpha, CT beta, T *__restrict__ raw_out) {
+                     CA alpha, CB beta, T *__restrict__ raw_out) {
   const int r = threadIdx.x & 31, sub = threadIdx.x >> 5;
   const int64_t i = (int64_t)blockIdx.x * 32 + r;
   __shared__ double sred[8][32];
@@ -439,9 +293,7 @@ gemv_n_finish_kernel(T *__restrict__ res, const double *__restrict__ part, int64
     raw_out[i] = (T)acc;
     return;
   }
-  CT t = alpha * (CT)(T)acc;
-  if constexpr (!BETA0) t = t + (beta * (CT)res[i]);
-  res[i] = (T)t;
+  res[i] = fin_ab<T, CA, CB, BETA0>(alpha * (CA)(T)acc, beta, BETA0 ? T(0) : res[i]);
 }
 
 template <typename T>
@@ -470,9 +322,9 @@ int32_t gemv_n(mxlo_ctx *ctx, T *res, const T *M, int64_t m, int64_t n, int64_t 
                        n, ld, v, cpc > 0 ? cpc : 1);
   MXLO_LAUNCH_CHECK();
   const unsigned fin_blocks = (unsigned)((m + 31) / 32);
-  return dispatch_ct<T>(beta, flags, [&]<typename CT, bool B0>() -> int32_t {
-    hipLaunchKernelGGL((gemv_n_finish_kernel<T, CT, B0>), dim3(fin_blocks), dim3(kBlock), 0, ctx->stream, res,
-                       ctx->partials, m, (int)nchunks, (CT)alpha, (CT)beta, (T *)nullptr);
+  return dispatch_ab<T>(beta, flags, [&]<typename CA, typename CB, bool B0>() -> int32_t {
+    hipLaunchKernelGGL((gemv_n_finish_kernel<T, CA, CB, B0>), dim3(fin_blocks), dim3(kBlock), 0, ctx->stream, res,
+                       ctx->partials, m, (int)nchunks, (CA)alpha, (CB)beta, (T *)nullptr);
     MXLO_LAUNCH_CHECK();
     return MXLO_OK;
   });
@@ -487,13 +339,13 @@ int32_t gemv_t(mxlo_ctx *ctx, T *res, const T *M, int64_t m, int64_t n, int64_t 
   if (blocks > cap) blocks = cap;
   constexpr int VR = 16 / (int)sizeof(T);     // 16-byte loads down the column need 16-byte aligned column starts
   const bool pair = m >= VR && (((uintptr_t)M & 15u) == 0) && (ld % VR == 0) && (((uintptr_t)v & 15u) == 0);
-  return dispatch_ct<T>(beta, flags, [&]<typename CT, bool B0>() -> int32_t {
+  return dispatch_ab<T>(beta, flags, [&]<typename CA, typename CB, bool B0>() -> int32_t {
     if (pair)
-      hipLaunchKernelGGL((gemv_t_kernel<T, CT, B0, true>), dim3((unsigned)blocks), dim3(kBlock), 0, ctx->stream,
-                         res, M, m, n, ld, v, (CT)alpha, (CT)beta);
+      hipLaunchKernelGGL((gemv_t_kernel<T, CA, CB, B0, true>), dim3((unsigned)blocks), dim3(kBlock), 0, ctx->stream,
+                         res, M, m, n, ld, v, (CA)alpha, (CB)beta);
     else
-      hipLaunchKernelGGL((gemv_t_kernel<T, CT, B0, false>), dim3((unsigned)blocks), dim3(kBlock), 0, ctx->stream,
-                         res, M, m, n, ld, v, (CT)alpha, (CT)beta);
+      hipLaunchKernelGGL((gemv_t_kernel<T, CA, CB, B0, false>), dim3((unsigned)blocks), dim3(kBlock), 0, ctx->stream,
+                         res, M, m, n, ld, v, (CA)alpha, (CB)beta);
     MXLO_LAUNCH_CHECK();
     return MXLO_OK;
   });
@@ -667,11 +519,11 @@ herm_strip_kernel(const T *__restrict__ A, int64_t lda, const T *__restrict__ v,
 
 // 32 rows per workgroup, 8 lanes per row: lane `sub` adds partials sub, sub+8, ... (independent loads in
 // flight), the 8 sub-sums are combined in a fixed order -> deterministic, and n/32 workgroups fill the chip.
-template <typename T, typename CT, bool BETA0>
+template <typename T, typename CA, typename CB, bool BETA0>
 __global__ void __launch_bounds__(kBlock)
 herm_finish_kernel(T *__restrict__ res, const T *__restrict__ d, const T *__restrict__ v,
                    const double *__restrict__ Prow, const double *__restrict__ Pcol, int64_t n, int ng,
-                   int q, CT alpha, CT beta) {
+                   int q, CA alpha, CB beta) {
   const int r = threadIdx.x & 31, sub = threadIdx.x >> 5;
   const int64_t i = (int64_t)blockIdx.x * 32 + r;
   __shared__ double s1[8][32], s2[8][32];
@@ -693,9 +545,7 @@ herm_finish_kernel(T *__restrict__ res, const T *__restrict__ d, const T *__rest
       a2 += s2[q][r];
     }
     const T inner = ((d[i] * v[i]) + (T)a1) + (T)a2;
-    CT t = alpha * (CT)inner;
-    if constexpr (!BETA0) t = t + (beta * (CT)res[i]);
-    res[i] = (T)t;
+    res[i] = fin_ab<T, CA, CB, BETA0>(alpha * (CA)inner, beta, BETA0 ? T(0) : res[i]);
   }
 }
 
@@ -747,9 +597,9 @@ int32_t hermitian_t(mxlo_ctx *ctx, T *res, const T *d, const T *A, int64_t lda, 
                      lda, v, n, Prow, Pcol, ng, Q, 2);
   MXLO_LAUNCH_CHECK();
   const unsigned blocks = (unsigned)((n + 31) / 32);
-  return dispatch_ct<T>(beta, flags, [&]<typename CT, bool B0>() -> int32_t {
-    hipLaunchKernelGGL((herm_finish_kernel<T, CT, B0>), dim3(blocks), dim3(kBlock), 0, ctx->stream, res, d, v,
-                       Prow, Pcol, n, (int)ng, Q, (CT)alpha, (CT)beta);
+  return dispatch_ab<T>(beta, flags, [&]<typename CA, typename CB, bool B0>() -> int32_t {
+    hipLaunchKernelGGL((herm_finish_kernel<T, CA, CB, B0>), dim3(blocks), dim3(kBlock), 0, ctx->stream, res, d, v,
+                       Prow, Pcol, n, (int)ng, Q, (CA)alpha, (CB)beta);
     MXLO_LAUNCH_CHECK();
     return MXLO_OK;
   });
@@ -767,8 +617,7 @@ int32_t kron_t(mxlo_ctx *ctx, T *res, const T *A, int64_t m, int64_t n, int64_t 
     return gemm<T>(ctx, res, p, B, ldb, false, work, m, true, p, m, q, alpha, beta, flags);
   }
   // X = reshape(x, p, m);  Ut = A^T * X^T (n x p)  [= (X * A)^T];  R = B^T * Ut^T (q x n).
-  // Here A and B enter transposed (K contiguous): the generic kernel handles them. Callers that apply
-  // the transpose often should hand pre-transposed copies to the N mode instead (the host glue does).
+  // A and B enter transposed, i.e. K-contiguous in place: the DMA kernel's second A layout (no transposed copies).
   MXLO_TRY(gemm<T>(ctx, work, n, A, lda, true, x, p, true, n, p, m, 1.0, 0.0, 0));
   return gemm<T>(ctx, res, q, B, ldb, true, work, n, true, q, n, p, alpha, beta, flags);
 }
@@ -776,16 +625,14 @@ int32_t kron_t(mxlo_ctx *ctx, T *res, const T *A, int64_t m, int64_t n, int64_t 
 }  // namespace
 
 static inline void eff_ab(int32_t dtype, int32_t flags, double &alpha, double &beta) {
-  if (dtype == MXLO_F32 && !(flags & MXLO_SCALARS_F64)) {
-    alpha = (double)(float)alpha;
-    beta = (double)(float)beta;
-  }
+  eff_scalars(dtype == MXLO_F64 ? 8 : 4, flags, alpha, beta);
 }
 
 MXLO_API int32_t mxlo_gemv(mxlo_ctx *ctx, int32_t dtype, void *res, const void *M, int64_t m,
                            int64_t n, int64_t ld, const void *v, double alpha, double beta,
                            int32_t op_mode, int32_t flags) {
   MXLO_REQUIRE(ctx, MXLO_EINVAL, "mxlo_gemv: ctx is NULL");
+  MXLO_DEVICE_GUARD(ctx);
   MXLO_REQUIRE(dtype == MXLO_F64 || dtype == MXLO_F32, MXLO_EINVAL, "bad dtype");
   MXLO_REQUIRE(m >= 0 && n >= 0 && ld >= (m > 1 ? m : 1), MXLO_ESHAPE, "mxlo_gemv: bad shape");
   MXLO_REQUIRE(op_mode >= MXLO_OP_N && op_mode <= MXLO_OP_C, MXLO_EINVAL, "bad op_mode");
@@ -799,6 +646,7 @@ MXLO_API int32_t mxlo_hermitian_mul(mxlo_ctx *ctx, int32_t dtype, void *res, con
                                     const void *A, int64_t lda, const void *v, int64_t n,
                                     double alpha, double beta, int32_t flags) {
   MXLO_REQUIRE(ctx, MXLO_EINVAL, "mxlo_hermitian_mul: ctx is NULL");
+  MXLO_DEVICE_GUARD(ctx);
   MXLO_REQUIRE(dtype == MXLO_F64 || dtype == MXLO_F32, MXLO_EINVAL, "bad dtype");
   MXLO_REQUIRE(n >= 0 && lda >= (n > 1 ? n : 1), MXLO_ESHAPE, "mxlo_hermitian_mul: bad shape");
   MXLO_REQUIRE(n == 0 || (res && d && A && v), MXLO_EINVAL, "mxlo_hermitian_mul: NULL operand");
@@ -813,6 +661,7 @@ MXLO_API int32_t mxlo_kron_mul(mxlo_ctx *ctx, int32_t dtype, void *res, const vo
                                int64_t ldb, const void *x, void *work, double alpha, double beta,
                                int32_t op_mode, int32_t flags) {
   MXLO_REQUIRE(ctx, MXLO_EINVAL, "mxlo_kron_mul: ctx is NULL");
+  MXLO_DEVICE_GUARD(ctx);
   MXLO_REQUIRE(dtype == MXLO_F64 || dtype == MXLO_F32, MXLO_EINVAL, "bad dtype");
   MXLO_REQUIRE(m >= 0 && n >= 0 && p >= 0 && q >= 0, MXLO_ESHAPE, "mxlo_kron_mul: negative size");
   MXLO_REQUIRE(op_mode >= MXLO_OP_N && op_mode <= MXLO_OP_C, MXLO_EINVAL, "bad op_mode");

@@ -168,6 +168,7 @@ using namespace mxlo;
 MXLO_API int32_t mxlo_diagqn_push(mxlo_ctx *ctx, int32_t dtype, int32_t kind, void *d, const void *s,
                                   const void *y, int64_t n, int32_t *status) {
   MXLO_REQUIRE(ctx && status && n >= 0 && (n == 0 || (s && y)) && d, MXLO_EINVAL, "mxlo_diagqn_push: bad argument");
+  MXLO_DEVICE_GUARD(ctx);
   MXLO_REQUIRE(kind >= MXLO_DQN_PSB && kind <= MXLO_DQN_SPECTRAL, MXLO_EINVAL, "mxlo_diagqn_push: kind %d", kind);
   MXLO_REQUIRE(dtype == MXLO_F64 || dtype == MXLO_F32, MXLO_EINVAL, "bad dtype %d", dtype);
   if (dtype == MXLO_F64) return diagqn_push_t<double>(ctx, kind, (double *)d, (const double *)s, (const double *)y, n, status);

@@ -1,0 +1,350 @@
+// gemm_glds.h — the MFMA GEMM behind kron(A,B) (src/kron.jl:14-40): C = alpha * opA(A) * B'^T (+ beta*C).
+//
+// One kernel template, gfx950 only:
+//  * operands go global -> LDS with `global_load_lds_dwordx4` (LDS-DMA: no staging VGPRs, no ds_write pass),
+//    into a ring of NST stages; a stage is issued NST-1 K-slabs ahead and waited for with a COUNTED
+//    `s_waitcnt vmcnt(N)` + one raw `s_barrier` per slab, so later slabs stay in flight across the barrier;
+//  * the LDS image is lane-linear per DMA instruction (hardware rule), so bank conflicts are avoided by an
+//    XOR swizzle applied to the per-lane SOURCE address and to the fragment reads alike — no padding;
+//  * v_mfma_f64_16x16x4_f64 / v_mfma_f32_16x16x4_f32, a wave owns an (TM/WM) x (TN/WN) sub-tile;
+//  * the A operand may be M-contiguous (A stored M x K, prod!) or K-contiguous (A stored K x M: tprod!/ctprod!
+//    of kron read A and B transposed in place, src/kron.jl:24-40); B' is always N-contiguous (stored N x K);
+//  * M, N edges: out-of-range rows/columns read clamped (valid, unused) addresses and are not stored;
+//    the K tail runs fewer 4-deep MFMA steps and zeroes the <= 3 slack k-rows in LDS after the DMA landed;
+//  * XCD-aware tile order: the 8 XCDs (workgroup id mod 8) each walk a compact band of tiles so the A / B slabs
+//    they share stay in that XCD's L2.
+#pragma once
+#include "common.h"
+
+namespace mxlo {
+
+typedef double gl_f64x4 __attribute__((ext_vector_type(4)));
+typedef float gl_f32x4 __attribute__((ext_vector_type(4)));
+
+template <typename T>
+struct GlMfma;
+template <>
+struct GlMfma<double> {
+  using Acc = gl_f64x4;
+  static __device__ __forceinline__ Acc run(double a, double b, Acc c) {
+    return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+  }
+  // C/D layout: col = lane & 15, row = (lane >> 4) + 4*reg
+  static __device__ __forceinline__ int row(int lane, int r) { return (lane >> 4) + 4 * r; }
+};
+template <>
+struct GlMfma<float> {
+  using Acc = gl_f32x4;
+  static __device__ __forceinline__ Acc run(float a, float b, Acc c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+  }
+  // C/D layout: col = lane & 15, row = 4*(lane >> 4) + reg
+  static __device__ __forceinline__ int row(int lane, int r) { return 4 * (lane >> 4) + r; }
+};
+
+template <int N>
+__device__ __forceinline__ void gl_wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+struct GlShape {
+  int M, N, K;
+  int gx, gy;   // tiles along M, N
+};
+
+// Tile order: workgroup `id` runs on XCD id % 8. Each XCD gets a contiguous range of the band-major tile order
+// (bands of SH tile rows), i.e. a compact sub-grid. Bijective for any tile count.
+__device__ __forceinline__ void gl_tile_of(int id, int gx, int gy, int &tx, int &ty) {
+  constexpr int SH = 4;
+  const int nt = gx * gy, q = nt >> 3, r = nt & 7;
+  const int xcd = id & 7, local = id >> 3;
+  const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+  const int per_band = SH * gy;
+  const int band = t / per_band, rem = t - band * per_band;
+  const int bh = (gx - band * SH) < SH ? (gx - band * SH) : SH;
+  tx = band * SH + rem % bh;
+  ty = rem / bh;
+}
+
+// AK: the A operand is K-contiguous (element (i,k) at A[k + i*lda]); otherwise M-contiguous (A[i + k*lda]).
+template <typename T, typename CA, typename CB, bool BETA0, bool AK, int TM, int TN, int WM, int WN, int BK, int NST,
+          bool SPREAD = true, bool PIN = true>
+__global__ void __launch_bounds__(WM * WN * 64)
+gemm_glds_kernel(T *__restrict__ C, int64_t ldc, const T *__restrict__ A, int64_t lda,
+                 const T *__restrict__ B, int64_t ldb, GlShape S, CA alpha, CB beta) {
+  constexpr int NW = WM * WN;
+  constexpr int VEC = 16 / (int)sizeof(T);
+  constexpr int EPI = 1024 / (int)sizeof(T);          // elements per DMA wave-instruction
+  constexpr int AIMG = TM * BK, BIMG = TN * BK;       // elements per stage image
+  constexpr int NIA = AIMG / EPI, NIB = BIMG / EPI, NI = NIA + NIB;
+  static_assert(AIMG % EPI == 0 && BIMG % EPI == 0, "stage images must be whole DMA instructions");
+  constexpr int PW = (NI + NW - 1) / NW;              // DMA instructions per wave per stage
+  constexpr int MT = TM / WM / 16, NT = TN / WN / 16;
+  static_assert(MT >= 1 && NT >= 1 && MT * 16 * WM == TM && NT * 16 * WN == TN, "bad wave layout");
+  static_assert(BK % 8 == 0 && NST >= 3 && NST <= 4, "bad pipeline shape");
+  static_assert(NI % NW == 0, "every wave must issue the same number of DMA instructions per stage (counted vmcnt)");
+  __shared__ __attribute__((aligned(1024))) T lds[NST * (AIMG + BIMG)];   // ONE LDS object (a second one makes
+                                                                          // hipcc drain vmcnt before every ds_read)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int tx, ty;
+  gl_tile_of(blockIdx.x, S.gx, S.gy, tx, ty);
+  const int bm = tx * TM, bn = ty * TN;
+  const int wm = (wave % WM) * (TM / WM), wn = (wave / WM) * (TN / WN);
+  const int M = S.M, N = S.N, K = S.K;
+
+  // ---- DMA source addressing: uniform 64-bit base (SGPR, advanced per slab with scalar ALU only) + a per-lane
+  // 32-bit byte offset that never changes — `global_load_lds_dwordx4 v_off, s[base:base+1]`. (Per-lane 64-bit
+  // address arithmetic on the vector ALU for every DMA instruction costs the matrix pipe ~20 % of its issue slots:
+  // MFMA and the other VALU instructions of the 4 waves on a SIMD share one issue port.)
+  // instruction q of a stage: q < NIA -> A image chunk q, else B image chunk q - NIA.
+  const char *tileA = reinterpret_cast<const char *>(AK ? A + (int64_t)bm * lda : A + bm);   // uniform
+  const char *tileB = reinterpret_cast<const char *>(B + bn);
+  const int64_t slabA = (AK ? (int64_t)1 : lda) * (int64_t)sizeof(T);    // bytes per unit of k (uniform)
+  const int64_t slabB = ldb * (int64_t)sizeof(T);
+  uint32_t voff[PW];     // per-lane byte offset from the tile base for k0 = 0
+  int krow[PW];          // k (within the slab) this lane reads: only the K-tail clamp needs it
+  int64_t rowoff[PW];    // the k-independent part of voff, for the clamped form
+#pragma unroll
+  for (int p = 0; p < PW; ++p) {
+    const int q = wave + p * NW;
+    const bool isA = q < NIA;
+    const int flat = (isA ? q : q - NIA) * EPI + lane * VEC;
+    if (isA && AK) {
+      // image sA[i][BK], element (i,k) stored at i*BK + (k ^ g(i))
+      const int i = flat / BK, ks = flat % BK;
+      const int g = ((BK >= 32 ? (i & 15) : ((i >> 1) & 7)) * 2) & (BK - 1) & ~(VEC - 1);
+      const int k = ks ^ g;
+      int ri = i;
+      if (bm + ri > M - 1) ri = M - 1 - bm;            // clamp to a valid (unused) row
+      rowoff[p] = (int64_t)ri * lda * (int64_t)sizeof(T);
+      krow[p] = k;
+      voff[p] = (uint32_t)(rowoff[p] + (int64_t)k * (int64_t)sizeof(T));
+    } else {
+      // image s[k][TX], element (k,c) stored at k*TX + (c ^ ((k&1)<<4))
+      const int TX = isA ? TM : TN;
+      const int k = flat / TX, cs = flat % TX;
+      int c = cs ^ ((k & 1) << 4);
+      const int lim = (isA ? M - bm : N - bn) - VEC;   // >= 0: M, N and the tile origin are multiples of VEC
+      if (c > lim) c = lim;                            // clamp to a valid (unused) column
+      rowoff[p] = (int64_t)c * (int64_t)sizeof(T);
+      krow[p] = k;
+      voff[p] = (uint32_t)(rowoff[p] + (int64_t)k * (isA ? lda : ldb) * (int64_t)sizeof(T));
+    }
+  }
+  // CLAMP = false: the slab lies wholly inside K (no per-lane work at all). CLAMP = true: the K tail — an M-/N-
+  // contiguous operand reads row min(k, K-1), a K-contiguous A reads 16 B along k and clamps the vector start
+  // (K % VEC == 0 there); the slack rows are zeroed in LDS afterwards.
+  auto issue_one = [&]<bool CLAMP>(int p, int stage, int k0) {
+    const int q = wave + p * NW;      // < NI always (NI % NW == 0); uniform
+    const bool isA = q < NIA;
+    const char *sb = (isA ? tileA : tileB) + (int64_t)k0 * (isA ? slabA : slabB);
+    T *l = lds + stage * (AIMG + BIMG) + q * EPI;
+    const char *g;
+    if constexpr (!CLAMP) {
+      g = sb + voff[p];
+    } else {
+      int k = k0 + krow[p];
+      const int kmax = (AK && isA) ? K - VEC : K - 1;
+      k = k < kmax ? k : kmax;
+      g = (isA ? tileA : tileB) + rowoff[p] + (int64_t)k * (isA ? slabA : slabB);
+    }
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
+                                     (__attribute__((address_space(3))) void *)l, 16, 0, 0);
+  };
+  auto issue = [&]<bool CLAMP>(int stage, int k0) {
+#pragma unroll
+    for (int p = 0; p < PW; ++p) issue_one.template operator()<CLAMP>(p, stage, k0);
+  };
+
+  using Acc = typename GlMfma<T>::Acc;
+  Acc acc[MT][NT];
+#pragma unroll
+  for (int a = 0; a < MT; ++a)
+#pragma unroll
+    for (int b = 0; b < NT; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[a][b][r] = 0;
+
+  const int l15 = lane & 15, l4 = lane >> 4;
+  // fragment offsets inside a stage image for k-step 0 (k = l4); a k-step advances k by 4, which keeps k & 1 and
+  // (for the K-contiguous image) the XOR pattern's low bits: offsets for step ks follow by adding a constant.
+  int offA[MT], offB[NT];
+#pragma unroll
+  for (int a = 0; a < MT; ++a) {
+    const int i = wm + a * 16 + l15;
+    if constexpr (AK) {
+      const int g = ((BK >= 32 ? (i & 15) : ((i >> 1) & 7)) * 2) & (BK - 1) & ~(VEC - 1);
+      offA[a] = i * BK + g;                    // element (i,k) at i*BK + (k ^ g): k is XORed per step below
+    } else {
+      offA[a] = l4 * TM + (i ^ ((l4 & 1) << 4));
+    }
+  }
+#pragma unroll
+  for (int b = 0; b < NT; ++b) {
+    const int j = wn + b * 16 + l15;
+    offB[b] = AIMG + l4 * TN + (j ^ ((l4 & 1) << 4));
+  }
+  auto frag = [&](const T *st, int ks, T (&av)[MT], T (&bv)[NT]) {
+#pragma unroll
+    for (int a = 0; a < MT; ++a) {
+      if constexpr (AK) {
+        const int i = wm + a * 16 + l15;
+        const int g = ((BK >= 32 ? (i & 15) : ((i >> 1) & 7)) * 2) & (BK - 1) & ~(VEC - 1);
+        av[a] = st[i * BK + ((ks * 4 + l4) ^ g)];
+      } else {
+        av[a] = st[offA[a] + ks * 4 * TM];
+      }
+    }
+#pragma unroll
+    for (int b = 0; b < NT; ++b) bv[b] = st[offB[b] + ks * 4 * TN];
+  };
+  auto compute_tail = [&](int stage, int ksteps) {   // last, partial slab: ksteps < BK/4 (runtime)
+    const T *st = lds + stage * (AIMG + BIMG);
+    for (int ks = 0; ks < ksteps; ++ks) {
+      T av[MT], bv[NT];
+      frag(st, ks, av, bv);
+#pragma unroll
+      for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b) acc[a][b] = GlMfma<T>::run(av[a], bv[b], acc[a][b]);
+    }
+  };
+
+  const int nk = (K + BK - 1) / BK;          // slabs, the last one possibly partial
+  const int nfull = K / BK;                  // full slabs
+  constexpr int KS = BK / 4;                 // 4-deep MFMA steps per full slab
+  static_assert(KS % 2 == 0, "the fragment double buffer relies on an even step count per slab");
+  auto next_stage = [&](int st) { return st + 1 == NST ? 0 : st + 1; };
+  auto prev_stage = [&](int st) { return st == 0 ? NST - 1 : st - 1; };
+  // ---- schedule (slab s lives in ring stage s % NST):
+  //   prologue            : issue slabs 0 .. NST-2, wait for slab 0, barrier
+  //   slab `it`, step KS/2: wait for slab it+1 (slabs it+2 .. may stay in flight), barrier — this publishes slab
+  //                         it+1 AND proves every wave is past slab it-1 — then refill the stage of slab it-1
+  //                         with slab it+NST-1, one DMA instruction behind each remaining step's MFMAs
+  //   slab `it`, last step: the fragments of step 0 of slab it+1 are read (already published), so the MFMA stream
+  //                         runs across the slab boundary: neither the barrier nor the LDS read latency sits
+  //                         between the last MFMA of one slab and the first of the next.
+#pragma unroll
+  for (int s = 0; s < NST - 1; ++s) {
+    if (s < nfull) issue.template operator()<false>(s, s * BK);
+    else if (s < nk) issue.template operator()<true>(s, s * BK);
+  }
+  {
+    const int ahead = nk - 1;                // slabs issued after slab 0 (capped at NST-2 by the prologue)
+    if (ahead >= NST - 2) gl_wait_vmcnt<PW *(NST - 2)>();
+    else if (NST > 3 && ahead == 1) gl_wait_vmcnt<PW>();
+    else gl_wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+  }
+  T av[2][MT], bv[2][NT];
+  int stage = 0;
+  // one full slab. MORE: a slab it+1 exists; NEXTF: it is a full slab (cross-slab fragment prefetch);
+  // REFILL: slab it+NST-1 exists (1: a full slab, 2: the K tail, clamped addressing); AHEAD2: slab it+2 exists and was issued earlier (NST == 4 only: it may stay in flight)
+  auto slab = [&]<bool MORE, bool NEXTF, int REFILL, bool AHEAD2>(int it) {
+    const T *st = lds + stage * (AIMG + BIMG);
+    const int nst = next_stage(stage);
+    const T *stn = lds + nst * (AIMG + BIMG);
+    const int rst = prev_stage(stage);
+    const int k0n = (it + NST - 1) * BK;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      if (ks + 1 < KS) frag(st, ks + 1, av[(ks + 1) & 1], bv[(ks + 1) & 1]);
+      else if constexpr (NEXTF) frag(stn, 0, av[0], bv[0]);
+      if constexpr (PIN) __builtin_amdgcn_sched_barrier(0);   // reads first: left alone, hipcc sinks them behind the MFMAs
+#pragma unroll
+      for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b) acc[a][b] = GlMfma<T>::run(av[ks & 1][a], bv[ks & 1][b], acc[a][b]);
+      if (ks == KS / 2 - 1) {
+        if constexpr (MORE) {
+          if constexpr (NST == 4 && AHEAD2) gl_wait_vmcnt<PW>();
+          else gl_wait_vmcnt<0>();
+          __builtin_amdgcn_s_barrier();
+        }
+        if constexpr (REFILL != 0 && !SPREAD) issue.template operator()<REFILL == 2>(rst, k0n);
+      }
+      if constexpr (REFILL != 0 && SPREAD) {
+        if (ks >= KS / 2) {
+#pragma unroll
+          for (int p = 0; p < PW; ++p)
+            if (KS / 2 + p * (KS / 2) / PW == ks) issue_one.template operator()<REFILL == 2>(p, rst, k0n);
+        }
+      }
+      if constexpr (PIN) __builtin_amdgcn_sched_barrier(0);
+    }
+    stage = nst;
+  };
+  if (nfull > 0) frag(lds, 0, av[0], bv[0]);
+  int it = 0;
+  for (; it + NST - 1 < nfull; ++it) slab.template operator()<true, true, 1, true>(it);   // steady state
+  for (; it < nfull; ++it) {                                                             // last slabs
+    const bool more = it + 1 < nk, nextf = it + 1 < nfull, refill = it + NST - 1 < nk, ahead2 = it + 2 < nk;
+    if (refill) {            // it + NST - 1 == nfull here: the refilled slab is the K tail; => more, ahead2
+      if (nextf) slab.template operator()<true, true, 2, true>(it);
+      else slab.template operator()<true, false, 2, true>(it);
+    } else if (more) {
+      if (nextf) {
+        if (ahead2) slab.template operator()<true, true, 0, true>(it);
+        else slab.template operator()<true, true, 0, false>(it);
+      } else {
+        if (ahead2) slab.template operator()<true, false, 0, true>(it);
+        else slab.template operator()<true, false, 0, false>(it);
+      }
+    } else {
+      slab.template operator()<false, false, 0, false>(it);
+    }
+  }
+  if (nfull < nk) {                            // K tail: 1 .. BK-1 valid k-rows; published by the barrier above
+    const int krem = K - nfull * BK, ksteps = (krem + 3) >> 2;
+    if (krem & 3) {                            // zero the slack k-rows of the last 4-deep step (both images)
+      T *sA = lds + stage * (AIMG + BIMG), *sB = sA + AIMG;
+      const int kz0 = krem, kz1 = ksteps * 4;
+      for (int idx = tid; idx < (kz1 - kz0) * TM; idx += NW * 64) {
+        const int k = kz0 + idx / TM, i = idx % TM;
+        if constexpr (AK) {
+          const int g = ((BK >= 32 ? (i & 15) : ((i >> 1) & 7)) * 2) & (BK - 1) & ~(VEC - 1);
+          sA[i * BK + (k ^ g)] = 0;
+        } else {
+          sA[k * TM + i] = 0;
+        }
+      }
+      for (int idx = tid; idx < (kz1 - kz0) * TN; idx += NW * 64) sB[(kz0 + idx / TN) * TN + idx % TN] = 0;
+      __syncthreads();
+    }
+    compute_tail(stage, ksteps);
+  }
+
+  // ---- epilogue: res = (alpha*acc) (+ beta*C), each product rounded separately (no FMA)
+#pragma unroll
+  for (int a = 0; a < MT; ++a)
+#pragma unroll
+    for (int b = 0; b < NT; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int gi = bm + wm + a * 16 + GlMfma<T>::row(lane, r);
+        const int gj = bn + wn + b * 16 + l15;
+        if (gi < M && gj < N) {
+          T *p = C + gi + (int64_t)gj * ldc;
+          const CA t = alpha * (CA)acc[a][b][r];
+          if constexpr (BETA0) *p = (T)t;
+          else {   // α-term in α's type, β-term in β's, summed in the wider (see stream_kernels.h: fin_ab)
+            using P = std::conditional_t<(sizeof(CA) >= sizeof(CB)), CA, CB>;
+            *p = (T)((P)t + (P)(beta * (CB)(*p)));
+          }
+        }
+      }
+}
+
+// Preconditions of the DMA path (16-byte global reads): pointers 16-byte aligned, leading dimensions and the
+// contiguous extents (M for an M-contiguous A, K for a K-contiguous A, N for B') multiples of the vector width.
+template <typename T>
+inline bool gemm_glds_ok(const T *A, int64_t lda, bool a_kcontig, const T *B, int64_t ldb, int64_t M, int64_t N,
+                         int64_t K) {
+  constexpr int VEC = 16 / (int)sizeof(T);
+  if (M < VEC || N < VEC || K < (a_kcontig ? VEC : 1)) return false;
+  if ((((uintptr_t)A | (uintptr_t)B) & 15u) != 0 || lda % VEC || ldb % VEC || N % VEC) return false;
+  return a_kcontig ? (K % VEC == 0) : (M % VEC == 0);
+}
+
+}  // namespace mxlo

@@ -11,10 +11,10 @@ using namespace mxlo;
   MXLO_REQUIRE(dtype == MXLO_F64 || dtype == MXLO_F32, MXLO_EINVAL, name ": bad dtype %d", dtype)
 
 static inline double eff_beta(int32_t dtype, int32_t flags, double beta) {
-  return (dtype == MXLO_F32 && !(flags & MXLO_SCALARS_F64)) ? (double)(float)beta : beta;
+  return beta_is_f64(dtype == MXLO_F64 ? 8 : 4, flags) ? beta : (double)(float)beta;
 }
 static inline double eff_alpha(int32_t dtype, int32_t flags, double alpha) {
-  return (dtype == MXLO_F32 && !(flags & MXLO_SCALARS_F64)) ? (double)(float)alpha : alpha;
+  return alpha_is_f64(dtype == MXLO_F64 ? 8 : 4, flags) ? alpha : (double)(float)alpha;
 }
 
 // ---- fill helper -------------------------------------------------------------------
@@ -33,12 +33,12 @@ static int32_t fill(mxlo_ctx *ctx, T *p, int64_t n, T c) {
 template <typename T>
 static int32_t diag_mul_t(mxlo_ctx *ctx, T *res, const T *d, const T *v, int64_t n_min,
                           int64_t nrow, double alpha, double beta, int32_t flags) {
-  int32_t st = dispatch_ct<T>(beta, flags, [&]<typename CT, bool B0>() -> int32_t {
+  int32_t st = dispatch_ab<T>(beta, flags, [&]<typename CA, typename CB, bool B0>() -> int32_t {
     if (flags & MXLO_D_SCALAR) {
-      DiagScalarOp<T, CT, B0> op{(CT)alpha, (CT)beta, d, (CT)0};
+      DiagScalarOp<T, CA, CB, B0> op{(CA)alpha, (CB)beta, d, (CA)0};
       return launch_map<T, 1, !B0, false>(ctx, res, v, (const T *)nullptr, n_min, op);
     }
-    DiagOp<T, CT, B0> op{(CT)alpha, (CT)beta};
+    DiagOp<T, CA, CB, B0> op{(CA)alpha, (CB)beta};
     return launch_map<T, 2, !B0, false>(ctx, res, d, v, n_min, op);
   });
   MXLO_TRY(st);
@@ -50,6 +50,7 @@ MXLO_API int32_t mxlo_diag_mul(mxlo_ctx *ctx, int32_t dtype, void *res, const vo
                                const void *v, int64_t n_min, int64_t nrow, double alpha,
                                double beta, int32_t flags) {
   CHECK_COMMON("mxlo_diag_mul");
+  MXLO_DEVICE_GUARD(ctx);
   MXLO_REQUIRE(n_min >= 0 && nrow >= n_min, MXLO_ESHAPE, "mxlo_diag_mul: n_min=%lld nrow=%lld",
                (long long)n_min, (long long)nrow);
   MXLO_REQUIRE(nrow == 0 || (res && (n_min == 0 || (d && v))), MXLO_EINVAL,
@@ -67,15 +68,15 @@ MXLO_API int32_t mxlo_diag_mul(mxlo_ctx *ctx, int32_t dtype, void *res, const vo
 template <typename T>
 static int32_t eye_mul_t(mxlo_ctx *ctx, T *res, const T *v, int64_t n_min, int64_t nrow,
                          double alpha, double beta, int32_t flags) {
-  int32_t st = dispatch_ct<T>(beta, flags, [&]<typename CT, bool B0>() -> int32_t {
-    AxpbyOp<T, CT, B0> op{(CT)alpha, (CT)beta};
+  int32_t st = dispatch_ab<T>(beta, flags, [&]<typename CA, typename CB, bool B0>() -> int32_t {
+    AxpbyOp<T, CA, CB, B0> op{(CA)alpha, (CB)beta};
     return launch_map<T, 1, !B0, false>(ctx, res, v, (const T *)nullptr, n_min, op);
   });
   MXLO_TRY(st);
   const int64_t ntail = nrow - n_min;
   if (ntail <= 0) return MXLO_OK;
   if (beta == 0) return fill<T>(ctx, res + n_min, ntail, T(0));
-  const bool f64s = sizeof(T) == 8 || (flags & MXLO_SCALARS_F64);
+  const bool f64s = beta_is_f64(sizeof(T), flags);
   if (flags & MXLO_TAIL_BETA) return fill<T>(ctx, res + n_min, ntail, (T)beta);
   if (f64s)
     return launch_map<T, 0, true, false>(ctx, res + n_min, (const T *)nullptr, (const T *)nullptr,
@@ -88,6 +89,7 @@ MXLO_API int32_t mxlo_eye_mul(mxlo_ctx *ctx, int32_t dtype, void *res, const voi
                               int64_t n_min, int64_t nrow, double alpha, double beta,
                               int32_t flags) {
   CHECK_COMMON("mxlo_eye_mul");
+  MXLO_DEVICE_GUARD(ctx);
   MXLO_REQUIRE(n_min >= 0 && nrow >= n_min, MXLO_ESHAPE, "mxlo_eye_mul: n_min=%lld nrow=%lld",
                (long long)n_min, (long long)nrow);
   MXLO_REQUIRE(nrow == 0 || (res && (n_min == 0 || v)), MXLO_EINVAL, "mxlo_eye_mul: NULL operand");
@@ -100,8 +102,7 @@ MXLO_API int32_t mxlo_eye_mul(mxlo_ctx *ctx, int32_t dtype, void *res, const voi
 
 // ---- opZeros / scale ---------------------------------------------------------------------
 template <typename T>
-static int32_t scale_t(mxlo_ctx *ctx, T *res, int64_t n, double s, int32_t flags) {
-  const bool f64s = sizeof(T) == 8 || (flags & MXLO_SCALARS_F64);
+static int32_t scale_t(mxlo_ctx *ctx, T *res, int64_t n, double s, bool f64s) {
   if (f64s)
     return launch_map<T, 0, true, false>(ctx, res, (const T *)nullptr, (const T *)nullptr, n,
                                          ScaleOp<T, double>{s});
@@ -112,18 +113,20 @@ static int32_t scale_t(mxlo_ctx *ctx, T *res, int64_t n, double s, int32_t flags
 MXLO_API int32_t mxlo_zeros_mul(mxlo_ctx *ctx, int32_t dtype, void *res, int64_t nrow, double beta,
                                 int32_t flags) {
   CHECK_COMMON("mxlo_zeros_mul");
+  MXLO_DEVICE_GUARD(ctx);
   MXLO_REQUIRE(nrow >= 0 && (nrow == 0 || res), MXLO_EINVAL, "mxlo_zeros_mul: bad argument");
   beta = eff_beta(dtype, flags, beta);
   if (beta == 0) {
     if (dtype == MXLO_F64) return fill<double>(ctx, (double *)res, nrow, 0.0);
     return fill<float>(ctx, (float *)res, nrow, 0.f);
   }
-  if (dtype == MXLO_F64) return scale_t<double>(ctx, (double *)res, nrow, beta, flags);
-  return scale_t<float>(ctx, (float *)res, nrow, beta, flags);
+  if (dtype == MXLO_F64) return scale_t<double>(ctx, (double *)res, nrow, beta, true);
+  return scale_t<float>(ctx, (float *)res, nrow, beta, beta_is_f64(4, flags));
 }
 
 MXLO_API int32_t mxlo_fill(mxlo_ctx *ctx, int32_t dtype, void *res, int64_t n, double value) {
   CHECK_COMMON("mxlo_fill");
+  MXLO_DEVICE_GUARD(ctx);
   MXLO_REQUIRE(n >= 0 && (n == 0 || res), MXLO_EINVAL, "mxlo_fill: bad argument");
   if (dtype == MXLO_F64) return fill<double>(ctx, (double *)res, n, value);
   return fill<float>(ctx, (float *)res, n, (float)value);
@@ -132,10 +135,11 @@ MXLO_API int32_t mxlo_fill(mxlo_ctx *ctx, int32_t dtype, void *res, int64_t n, d
 MXLO_API int32_t mxlo_scale(mxlo_ctx *ctx, int32_t dtype, void *res, int64_t n, double alpha,
                             int32_t flags) {
   CHECK_COMMON("mxlo_scale");
+  MXLO_DEVICE_GUARD(ctx);
   MXLO_REQUIRE(n >= 0 && (n == 0 || res), MXLO_EINVAL, "mxlo_scale: bad argument");
   alpha = eff_alpha(dtype, flags, alpha);
-  if (dtype == MXLO_F64) return scale_t<double>(ctx, (double *)res, n, alpha, flags);
-  return scale_t<float>(ctx, (float *)res, n, alpha, flags);
+  if (dtype == MXLO_F64) return scale_t<double>(ctx, (double *)res, n, alpha, true);
+  return scale_t<float>(ctx, (float *)res, n, alpha, alpha_is_f64(4, flags));
 }
 
 // ---- opOnes --------------------------------------------------------------------------------
@@ -192,8 +196,8 @@ static int32_t ones_mul_t(mxlo_ctx *ctx, T *res, int64_t nrow, const T *v, int64
     MXLO_HIP(hipMemsetAsync(sum, 0, sizeof(double), ctx->stream));
   }
   MXLO_TRY(allreduce_hook(ctx, sum, 1));
-  return dispatch_ct<T>(beta, flags, [&]<typename CT, bool B0>() -> int32_t {
-    OnesOp<T, CT, B0> op{(CT)alpha, (CT)beta, sum, (CT)0};
+  return dispatch_ab<T>(beta, flags, [&]<typename CA, typename CB, bool B0>() -> int32_t {
+    OnesOp<T, CA, CB, B0> op{(CA)alpha, (CB)beta, sum, (CA)0};
     return launch_map<T, 0, !B0, false>(ctx, res, (const T *)nullptr, (const T *)nullptr, nrow, op);
   });
 }
@@ -202,6 +206,7 @@ MXLO_API int32_t mxlo_ones_mul(mxlo_ctx *ctx, int32_t dtype, void *res, int64_t 
                                const void *v, int64_t ncol, double alpha, double beta,
                                int32_t flags) {
   CHECK_COMMON("mxlo_ones_mul");
+  MXLO_DEVICE_GUARD(ctx);
   MXLO_REQUIRE(nrow >= 0 && ncol >= 0, MXLO_ESHAPE, "mxlo_ones_mul: negative size");
   alpha = eff_alpha(dtype, flags, alpha);
   beta = eff_beta(dtype, flags, beta);
@@ -215,8 +220,8 @@ template <typename T>
 static int32_t householder_apply_t(mxlo_ctx *ctx, T *res, const T *h, const T *v, int64_t n,
                                    double alpha, double beta, int32_t flags, const double *dot) {
   const bool rev = ctx->tune.house_reverse != 0;
-  return dispatch_ct<T>(beta, flags, [&]<typename CT, bool B0>() -> int32_t {
-    HouseholderOp<T, CT, B0> op{(CT)alpha, (CT)beta, dot, T(0)};
+  return dispatch_ab<T>(beta, flags, [&]<typename CA, typename CB, bool B0>() -> int32_t {
+    HouseholderOp<T, CA, CB, B0> op{(CA)alpha, (CB)beta, dot, T(0)};
     if (rev) return launch_map<T, 2, !B0, true>(ctx, res, h, v, n, op);
     return launch_map<T, 2, !B0, false>(ctx, res, h, v, n, op);
   });
@@ -234,6 +239,7 @@ static int32_t householder_t(mxlo_ctx *ctx, T *res, const T *h, const T *v, int6
 MXLO_API int32_t mxlo_dot(mxlo_ctx *ctx, int32_t dtype, const void *a, const void *b, int64_t n,
                           double *out_dev) {
   CHECK_COMMON("mxlo_dot");
+  MXLO_DEVICE_GUARD(ctx);
   MXLO_REQUIRE(n >= 0 && out_dev && (n == 0 || (a && b)), MXLO_EINVAL, "mxlo_dot: bad argument");
   if (dtype == MXLO_F64) {
     const double *cols[1] = {(const double *)a};
@@ -247,6 +253,7 @@ MXLO_API int32_t mxlo_householder_apply(mxlo_ctx *ctx, int32_t dtype, void *res,
                                         const void *v, int64_t n, double alpha, double beta,
                                         int32_t flags, const double *dot_dev) {
   CHECK_COMMON("mxlo_householder_apply");
+  MXLO_DEVICE_GUARD(ctx);
   MXLO_REQUIRE(n >= 0 && dot_dev && (n == 0 || (res && h && v)), MXLO_EINVAL,
                "mxlo_householder_apply: bad argument");
   alpha = eff_alpha(dtype, flags, alpha);
@@ -262,6 +269,7 @@ MXLO_API int32_t mxlo_householder_mul(mxlo_ctx *ctx, int32_t dtype, void *res, c
                                       const void *v, int64_t n, double alpha, double beta,
                                       int32_t flags) {
   CHECK_COMMON("mxlo_householder_mul");
+  MXLO_DEVICE_GUARD(ctx);
   MXLO_REQUIRE(n >= 0 && (n == 0 || (res && h && v)), MXLO_EINVAL,
                "mxlo_householder_mul: bad argument");
   alpha = eff_alpha(dtype, flags, alpha);
@@ -396,6 +404,7 @@ int32_t by_elem_size(int32_t es, F &&f) {
 MXLO_API int32_t mxlo_gather(mxlo_ctx *ctx, int32_t elem_size, void *res, const void *v,
                              int64_t nv, const int64_t *idx, int64_t nidx) {
   MXLO_REQUIRE(ctx, MXLO_EINVAL, "mxlo_gather: ctx is NULL");
+  MXLO_DEVICE_GUARD(ctx);
   MXLO_REQUIRE(nidx >= 0 && nv >= 0, MXLO_ESHAPE, "mxlo_gather: negative size");
   if (nidx == 0) return MXLO_OK;
   MXLO_REQUIRE(res && v && idx, MXLO_EINVAL, "mxlo_gather: NULL operand");
@@ -416,6 +425,7 @@ MXLO_API int32_t mxlo_gather(mxlo_ctx *ctx, int32_t elem_size, void *res, const 
 MXLO_API int32_t mxlo_gather_range(mxlo_ctx *ctx, int32_t elem_size, void *res, const void *v,
                                    int64_t nv, int64_t start, int64_t step, int64_t len) {
   MXLO_REQUIRE(ctx, MXLO_EINVAL, "mxlo_gather_range: ctx is NULL");
+  MXLO_DEVICE_GUARD(ctx);
   MXLO_REQUIRE(len >= 0 && nv >= 0, MXLO_ESHAPE, "mxlo_gather_range: negative size");
   if (len == 0) return MXLO_OK;
   MXLO_REQUIRE(res && v, MXLO_EINVAL, "mxlo_gather_range: NULL operand");
@@ -447,6 +457,7 @@ MXLO_API int32_t mxlo_scatter_zero(mxlo_ctx *ctx, int32_t elem_size, void *res, 
                                    const void *u, const int64_t *idx, const int64_t *pos,
                                    int64_t nidx) {
   MXLO_REQUIRE(ctx, MXLO_EINVAL, "mxlo_scatter_zero: ctx is NULL");
+  MXLO_DEVICE_GUARD(ctx);
   MXLO_REQUIRE(nidx >= 0 && nres >= 0, MXLO_ESHAPE, "mxlo_scatter_zero: negative size");
   MXLO_REQUIRE(elem_size == 4 || elem_size == 8 || elem_size == 16, MXLO_EINVAL,
                "element size %d not in {4,8,16}", elem_size);
@@ -467,6 +478,7 @@ MXLO_API int32_t mxlo_scatter_zero(mxlo_ctx *ctx, int32_t elem_size, void *res, 
 MXLO_API int32_t mxlo_scatter_zero_range(mxlo_ctx *ctx, int32_t elem_size, void *res, int64_t nres,
                                          const void *u, int64_t start, int64_t step, int64_t len) {
   MXLO_REQUIRE(ctx, MXLO_EINVAL, "mxlo_scatter_zero_range: ctx is NULL");
+  MXLO_DEVICE_GUARD(ctx);
   MXLO_REQUIRE(len >= 0 && nres >= 0, MXLO_ESHAPE, "mxlo_scatter_zero_range: negative size");
   if (nres == 0) return MXLO_OK;
   MXLO_REQUIRE(res && (len == 0 || u), MXLO_EINVAL, "mxlo_scatter_zero_range: NULL operand");
@@ -493,10 +505,10 @@ MXLO_API int32_t mxlo_scatter_zero_range(mxlo_ctx *ctx, int32_t elem_size, void 
 // Output index i decomposes as (r, c) = (i % p, i / p); blockIdx.y walks c so no integer division is
 // needed in the lanes. HBM-bound: 16 B/elt (+8 when beta != 0) plus the two small diagonals (cached).
 namespace {
-template <typename T, typename CT, bool BETA0>
+template <typename T, typename CA, typename CB, bool BETA0>
 __global__ void __launch_bounds__(kBlock)
 kron_diag_kernel(T *__restrict__ res, const T *__restrict__ dA, const T *__restrict__ dB,
-                 const T *__restrict__ x, int64_t p, int64_t m, CT alpha, CT beta) {
+                 const T *__restrict__ x, int64_t p, int64_t m, CA alpha, CB beta) {
   for (int64_t c = blockIdx.y; c < m; c += gridDim.y) {
     const T ac = dA ? dA[c] : T(1);
     T *rc = res + c * p;
@@ -504,9 +516,7 @@ kron_diag_kernel(T *__restrict__ res, const T *__restrict__ dA, const T *__restr
     for (int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x; r < p; r += (int64_t)gridDim.x * kBlock) {
       const T br = dB ? dB[r] : T(1);
       const T inner = br * (xc[r] * ac);
-      CT t = alpha * (CT)inner;
-      if constexpr (!BETA0) t = t + (beta * (CT)rc[r]);
-      rc[r] = (T)t;
+      rc[r] = fin_ab<T, CA, CB, BETA0>(alpha * (CA)inner, beta, BETA0 ? T(0) : rc[r]);
     }
   }
 }
@@ -524,9 +534,9 @@ int32_t kron_diag_t(mxlo_ctx *ctx, T *res, const T *dA, int64_t m, const T *dB, 
     gy = cap / gx;
     if (gy < 1) gy = 1;
   }
-  return dispatch_ct<T>(beta, flags, [&]<typename CT, bool B0>() -> int32_t {
-    hipLaunchKernelGGL((kron_diag_kernel<T, CT, B0>), dim3((unsigned)gx, (unsigned)gy), dim3(kBlock), 0,
-                       ctx->stream, res, dA, dB, x, p, m, (CT)alpha, (CT)beta);
+  return dispatch_ab<T>(beta, flags, [&]<typename CA, typename CB, bool B0>() -> int32_t {
+    hipLaunchKernelGGL((kron_diag_kernel<T, CA, CB, B0>), dim3((unsigned)gx, (unsigned)gy), dim3(kBlock), 0,
+                       ctx->stream, res, dA, dB, x, p, m, (CA)alpha, (CB)beta);
     MXLO_LAUNCH_CHECK();
     return MXLO_OK;
   });
@@ -537,6 +547,7 @@ MXLO_API int32_t mxlo_kron_diag_mul(mxlo_ctx *ctx, int32_t dtype, void *res, con
                                     const void *dB, int64_t p, const void *x, double alpha, double beta,
                                     int32_t flags) {
   CHECK_COMMON("mxlo_kron_diag_mul");
+  MXLO_DEVICE_GUARD(ctx);
   MXLO_REQUIRE(m >= 0 && p >= 0, MXLO_ESHAPE, "mxlo_kron_diag_mul: negative size");
   if (m == 0 || p == 0) return MXLO_OK;
   MXLO_REQUIRE(res && x, MXLO_EINVAL, "mxlo_kron_diag_mul: NULL operand");

@@ -117,7 +117,7 @@ struct CombineArgs {
   double shift = 0.0;  // CM_FWD/INV/LSR1: res += T(shift)*x after the epilogue (fused ShiftedOperator axpy!)
 };
 
-template <typename T, typename CT, int MODE, bool BETA0, int VEC, bool NT>
+template <typename T, typename CA, typename CB, int MODE, bool BETA0, int VEC, bool NT>
 __global__ void __launch_bounds__(kBlock)
 combine_kernel(T *__restrict__ res, const T *__restrict__ x, const T *__restrict__ x2,
                CombineArgs<T> A, int64_t nvec) {
@@ -130,7 +130,8 @@ combine_kernel(T *__restrict__ res, const T *__restrict__ x, const T *__restrict
     scoef[threadIdx.x] = (A.coef && (threadIdx.x < (unsigned)A.ncol || (MODE == CM_AXPYS && threadIdx.x == kX0Slot)))
                              ? A.coef[threadIdx.x] : 0.0;
   __syncthreads();
-  const CT al = (CT)A.alpha, be = (CT)A.beta;
+  const CA al = (CA)A.alpha;
+  const CB be = (CB)A.beta;
   const int ncol = A.ncol;
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < nvec;
        i += (int64_t)gridDim.x * kBlock) {
@@ -151,9 +152,8 @@ combine_kernel(T *__restrict__ res, const T *__restrict__ x, const T *__restrict
         if constexpr (MODE == CM_FWD || MODE == CM_AFWD || MODE == CM_CFWD) q[e] = A.use_gamma ? xe / g : xe;
         else if constexpr (MODE == CM_INV) q[e] = xe;
         else if constexpr (MODE == CM_LSR1) {
-          CT t = (al * (CT)xe) / (CT)g;  // (α*x)/γ : γ divided unconditionally (src/lsr1.jl:93)
-          if constexpr (!BETA0) t = t + (be * (CT)vget<T, VEC>(rv, e));
-          q[e] = (T)t;
+          // (α*x)/γ : γ divided unconditionally (src/lsr1.jl:93)
+          q[e] = fin_ab<T, CA, CB, BETA0>((al * (CA)xe) / (CA)g, be, BETA0 ? T(0) : vget<T, VEC>(rv, e));
         } else if constexpr (MODE == CM_ASR1) q[e] = vget<T, VEC>(x2v, e) - (xe / g);
         else if constexpr (MODE == CM_AXPYS) q[e] = (T)scoef[kX0Slot] * xe;  // c0 stored past the columns
       }
@@ -202,10 +202,10 @@ combine_kernel(T *__restrict__ res, const T *__restrict__ x, const T *__restrict
             else q[e] = q[e] + (cc * ce);                                             // lbfgs.jl:146
           }
         } else if constexpr (MODE == CM_LSR1) {
-          const CT cc = (CT)cf[u];  // (α*dot)/as evaluated in CT by the coef kernel
+          const CA cc = (CA)cf[u];  // (α*dot)/as evaluated in α's type by the coef kernel
 #pragma unroll
           for (int e = 0; e < VEC; ++e)
-            q[e] = (T)((CT)q[e] + (cc * (CT)vget<T, VEC>(cv[u], e)));                 // lsr1.jl:103
+            q[e] = (T)((CA)q[e] + (cc * (CA)vget<T, VEC>(cv[u], e)));                 // lsr1.jl:103
         } else if constexpr (MODE == CM_ASR1) {
           const T cc = (T)cf[u];
 #pragma unroll
@@ -242,9 +242,7 @@ combine_kernel(T *__restrict__ res, const T *__restrict__ x, const T *__restrict
       if constexpr (!BETA0) rv = ldg<NT>(reinterpret_cast<const V *>(res + i * VEC));
 #pragma unroll
       for (int e = 0; e < VEC; ++e) {
-        CT t = al * (CT)q[e];                                                         // lbfgs.jl:150,198
-        if constexpr (!BETA0) t = t + (be * (CT)vget<T, VEC>(rv, e));
-        vset<T, VEC>(out, e, (T)t);
+        vset<T, VEC>(out, e, fin_ab<T, CA, CB, BETA0>(al * (CA)q[e], be, BETA0 ? T(0) : vget<T, VEC>(rv, e)));  // lbfgs.jl:150,198
       }
     } else {
 #pragma unroll
@@ -266,35 +264,28 @@ int32_t launch_combine_part(mxlo_ctx *ctx, T *res, const T *x, const T *x2, cons
                             int64_t n, int32_t flags, bool vec) {
   if (n <= 0) return MXLO_OK;
   constexpr int VECF = Vec16<T>::N;
-  const bool f64s = sizeof(T) == 8 || (flags & MXLO_SCALARS_F64);
   const bool b0 = A.beta == 0;
-  auto go = [&]<typename CT, bool B0, int VEC>() -> int32_t {
+  auto go = [&]<typename CA, typename CB, bool B0, int VEC>() -> int32_t {
     const int64_t nvec = n / VEC;
     const int grid = grid_for(ctx, nvec, kBlock, ctx->tune.combine_blocks_per_cu);
     const bool nt = (int64_t)sizeof(T) * n * (A.ncol + 2) >= ctx->tune.nt_min_bytes;
     if (nt)
-      hipLaunchKernelGGL((combine_kernel<T, CT, MODE, B0, VEC, true>), dim3(grid), dim3(kBlock), 0,
+      hipLaunchKernelGGL((combine_kernel<T, CA, CB, MODE, B0, VEC, true>), dim3(grid), dim3(kBlock), 0,
                          ctx->stream, res, x, x2, A, nvec);
     else
-      hipLaunchKernelGGL((combine_kernel<T, CT, MODE, B0, VEC, false>), dim3(grid), dim3(kBlock), 0,
+      hipLaunchKernelGGL((combine_kernel<T, CA, CB, MODE, B0, VEC, false>), dim3(grid), dim3(kBlock), 0,
                          ctx->stream, res, x, x2, A, nvec);
     MXLO_LAUNCH_CHECK();
     return MXLO_OK;
   };
   constexpr bool uses_ab = (MODE == CM_FWD || MODE == CM_INV || MODE == CM_LSR1 || MODE == CM_CFWD);
   if constexpr (!uses_ab) {
-    return vec ? go.template operator()<T, true, VECF>() : go.template operator()<T, true, 1>();
+    return vec ? go.template operator()<T, T, true, VECF>() : go.template operator()<T, T, true, 1>();
   } else {
-    if (f64s) {
-      if (vec) return b0 ? go.template operator()<double, true, VECF>() : go.template operator()<double, false, VECF>();
-      return b0 ? go.template operator()<double, true, 1>() : go.template operator()<double, false, 1>();
-    }
-    if constexpr (sizeof(T) == 4) {
-      if (vec) return b0 ? go.template operator()<float, true, VECF>() : go.template operator()<float, false, VECF>();
-      return b0 ? go.template operator()<float, true, 1>() : go.template operator()<float, false, 1>();
-    }
+    return dispatch_ab<T>(b0 ? 0.0 : 1.0, flags, [&]<typename CA, typename CB, bool B0>() -> int32_t {
+      return vec ? go.template operator()<CA, CB, B0, VECF>() : go.template operator()<CA, CB, B0, 1>();
+    });
   }
-  return MXLO_EINVAL;
 }
 
 // Panel columns are 16-byte aligned by construction (ld is a multiple of the vector width); the
@@ -561,8 +552,8 @@ int32_t inv_mul_reforder(mxlo_qn *h, T *res, const T *x, double alpha, double be
     InvStep2Op<T> op{dots, al + k, (T)h->ys[k], T(0)};
     MXLO_TRY((launch_map<T, 1, true, false>(ctx, q, sk, (const T *)nullptr, n, op)));
   }
-  MXLO_TRY((dispatch_ct<T>(beta, flags, [&]<typename CT, bool B0>() -> int32_t {
-    AxpbyOp<T, CT, B0> op{(CT)alpha, (CT)beta};
+  MXLO_TRY((dispatch_ab<T>(beta, flags, [&]<typename CA, typename CB, bool B0>() -> int32_t {
+    AxpbyOp<T, CA, CB, B0> op{(CA)alpha, (CB)beta};
     return launch_map<T, 1, !B0, false>(ctx, res, q, (const T *)nullptr, n, op);
   })));
   if (shift != 0.0)  // reference order: the ShiftedOperator axpy! stays its own pass
@@ -648,7 +639,7 @@ int32_t lsr1_mul(mxlo_qn *h, T *res, const T *x, double alpha, double beta, int3
   if (na > 0) {
     for (int i = 0; i < na; ++i) A.cols[i] = col<T>(h->A, h->ld, O.ord[i]);
     MXLO_TRY(panel_dots<T>(ctx, A.cols, na, x, h->n, dots));
-    const int ct_f32 = (sizeof(T) == 4 && !(flags & MXLO_SCALARS_F64)) ? 1 : 0;
+    const int ct_f32 = alpha_is_f64(sizeof(T), flags) ? 0 : 1;
     hipLaunchKernelGGL(lsr1_coef_kernel, dim3(1), dim3(64), 0, ctx->stream, dots, coef,
                        h->dsc + h->lay.as_, O, alpha, ct_f32);
     MXLO_LAUNCH_CHECK();
@@ -659,10 +650,7 @@ int32_t lsr1_mul(mxlo_qn *h, T *res, const T *x, double alpha, double beta, int3
 template <typename T>
 int32_t qn_mul_t(mxlo_qn *h, T *res, const T *x, double alpha, double beta, int32_t flags,
                  double shift = 0.0) {
-  if (h->dtype == MXLO_F32 && !(flags & MXLO_SCALARS_F64)) {
-    alpha = (double)(float)alpha;
-    beta = (double)(float)beta;
-  }
+  eff_scalars(sizeof(T), flags, alpha, beta);
   switch (h->kind) {
     case MXLO_QN_LBFGS_INV:
       return h->mode == MXLO_INV_REFORDER ? inv_mul_reforder<T>(h, res, x, alpha, beta, flags, shift)
@@ -1453,6 +1441,7 @@ MXLO_API int32_t mxlo_qn_create(mxlo_ctx *ctx, int32_t kind, int32_t dtype, int6
                                 int32_t scaling, int32_t damped, double sigma2, double sigma3,
                                 mxlo_qn **out) {
   MXLO_REQUIRE(ctx && out, MXLO_EINVAL, "mxlo_qn_create: NULL argument");
+  MXLO_DEVICE_GUARD(ctx);
   MXLO_REQUIRE(kind >= MXLO_QN_LBFGS_INV && kind <= MXLO_QN_LSR1, MXLO_EINVAL, "bad kind %d", kind);
   MXLO_REQUIRE(dtype == MXLO_F64 || dtype == MXLO_F32, MXLO_EINVAL, "bad dtype %d", dtype);
   MXLO_REQUIRE(n >= 0, MXLO_ESHAPE, "n < 0");
@@ -1505,6 +1494,7 @@ MXLO_API int32_t mxlo_qn_create(mxlo_ctx *ctx, int32_t kind, int32_t dtype, int6
 
 MXLO_API int32_t mxlo_qn_destroy(mxlo_qn *h) {
   if (!h) return MXLO_OK;
+  MXLO_DEVICE_GUARD(h->ctx);
   (void)hipStreamSynchronize(h->ctx->stream);
   for (void *p : {h->S, h->Y, h->A, h->B, h->tmp, h->tmp2, (void *)h->dsc})
     if (p) (void)hipFree(p);
@@ -1531,6 +1521,7 @@ MXLO_API int32_t mxlo_qn_set_push_mode(mxlo_qn *h, int32_t mode) {
 MXLO_API int32_t mxlo_qn_mul(mxlo_qn *h, void *res, const void *x, double alpha, double beta,
                              int32_t flags) {
   MXLO_REQUIRE(h && (h->n == 0 || (res && x)), MXLO_EINVAL, "mxlo_qn_mul: NULL argument");
+  MXLO_DEVICE_GUARD(h->ctx);
   if (h->dtype == MXLO_F64) return qn_mul_t<double>(h, (double *)res, (const double *)x, alpha, beta, flags);
   return qn_mul_t<float>(h, (float *)res, (const float *)x, alpha, beta, flags);
 }
@@ -1538,12 +1529,13 @@ MXLO_API int32_t mxlo_qn_mul(mxlo_qn *h, void *res, const void *x, double alpha,
 MXLO_API int32_t mxlo_qn_mul_shifted(mxlo_qn *h, void *res, const void *x, double alpha, double beta,
                                      double sigma, int32_t flags) {
   MXLO_REQUIRE(h && (h->n == 0 || (res && x)), MXLO_EINVAL, "mxlo_qn_mul_shifted: NULL argument");
+  MXLO_DEVICE_GUARD(h->ctx);
   // shifted_prod! (src/shifted_operators.jl:16-25): mul!(y, H, x, α, β); iszero(σ) || iszero(α) || axpy!(α*σ, x, y).
   // α*σ is formed in the callers' types (σ is a T; α a T or a Float64), then axpy! converts it to T.
   double c = 0.0;
   if (sigma != 0 && alpha != 0) {
     if (h->dtype == MXLO_F64) c = alpha * sigma;
-    else if (flags & MXLO_SCALARS_F64) c = (double)(float)(alpha * (double)(float)sigma);
+    else if (flags & MXLO_ALPHA_F64) c = (double)(float)(alpha * (double)(float)sigma);
     else c = (double)((float)alpha * (float)sigma);
   }
   if (h->dtype == MXLO_F64)
@@ -1553,6 +1545,7 @@ MXLO_API int32_t mxlo_qn_mul_shifted(mxlo_qn *h, void *res, const void *x, doubl
 
 MXLO_API int32_t mxlo_qn_push(mxlo_qn *h, const void *s, const void *y, int32_t *accepted) {
   MXLO_REQUIRE(h && s && y && accepted, MXLO_EINVAL, "mxlo_qn_push: NULL argument");
+  MXLO_DEVICE_GUARD(h->ctx);
   if (h->kind == MXLO_QN_LSR1) {
     if (h->dtype == MXLO_F64) return lsr1_push<double>(h, (const double *)s, (const double *)y, accepted);
     return lsr1_push<float>(h, (const float *)s, (const float *)y, accepted);
@@ -1566,6 +1559,7 @@ MXLO_API int32_t mxlo_qn_push(mxlo_qn *h, const void *s, const void *y, int32_t 
 MXLO_API int32_t mxlo_qn_push_damped_fwd(mxlo_qn *h, const void *s, const void *y, void *Bs,
                                          int32_t *accepted) {
   MXLO_REQUIRE(h && s && y && Bs && accepted, MXLO_EINVAL, "NULL argument");
+  MXLO_DEVICE_GUARD(h->ctx);
   MXLO_REQUIRE(h->damped, MXLO_ESTATE, "This push! should be used for damped operators");
   MXLO_REQUIRE(h->kind == MXLO_QN_LBFGS_FWD, MXLO_ESTATE,
                "This function be used for forward operators. Use push!(op, s, y, α, g, Bs) instead.");
@@ -1579,6 +1573,7 @@ MXLO_API int32_t mxlo_qn_push_damped_fwd(mxlo_qn *h, const void *s, const void *
 MXLO_API int32_t mxlo_qn_push_damped_inv(mxlo_qn *h, const void *s, void *y, double alpha,
                                          const void *g, void *Bs, int32_t *accepted) {
   MXLO_REQUIRE(h && s && y && g && Bs && accepted, MXLO_EINVAL, "NULL argument");
+  MXLO_DEVICE_GUARD(h->ctx);
   MXLO_REQUIRE(h->damped, MXLO_ESTATE, "This push! should be used for damped operators");
   MXLO_REQUIRE(h->kind == MXLO_QN_LBFGS_INV, MXLO_ESTATE,
                "This function be used for inverse operators. Use push!(op, s, y, Bs) instead.");
@@ -1591,6 +1586,7 @@ MXLO_API int32_t mxlo_qn_push_damped_inv(mxlo_qn *h, const void *s, void *y, dou
 
 MXLO_API int32_t mxlo_qn_solve_shifted(mxlo_qn *h, void *x, const void *b, double sigma) {
   MXLO_REQUIRE(h && (h->n == 0 || (x && b)), MXLO_EINVAL, "NULL argument");
+  MXLO_DEVICE_GUARD(h->ctx);
   MXLO_REQUIRE(h->kind == MXLO_QN_LBFGS_FWD, MXLO_ESTATE,
                "solve_shifted_system! is defined for forward L-BFGS operators");
   MXLO_REQUIRE(!(sigma < 0), MXLO_EDOMAIN, "σ must be nonnegative");
@@ -1600,6 +1596,7 @@ MXLO_API int32_t mxlo_qn_solve_shifted(mxlo_qn *h, void *x, const void *b, doubl
 
 MXLO_API int32_t mxlo_qn_diag(mxlo_qn *h, void *d) {
   MXLO_REQUIRE(h && (h->n == 0 || d), MXLO_EINVAL, "NULL argument");
+  MXLO_DEVICE_GUARD(h->ctx);
   MXLO_REQUIRE(h->kind != MXLO_QN_LBFGS_INV, MXLO_ESTATE,
                "only the diagonal of a forward L-BFGS approximation is available");
   if (h->dtype == MXLO_F64) return diag_t<double>(h, (double *)d);
@@ -1608,6 +1605,7 @@ MXLO_API int32_t mxlo_qn_diag(mxlo_qn *h, void *d) {
 
 MXLO_API int32_t mxlo_qn_reset(mxlo_qn *h) {
   MXLO_REQUIRE(h, MXLO_EINVAL, "handle is NULL");
+  MXLO_DEVICE_GUARD(h->ctx);
   const size_t es = h->dtype == MXLO_F64 ? 8 : 4;
   const size_t pbytes = (size_t)h->ld * h->mem * es;
   for (void *p : {h->S, h->Y, h->A, h->B})
@@ -1627,6 +1625,7 @@ MXLO_API int32_t mxlo_qn_reset(mxlo_qn *h) {
 
 MXLO_API int32_t mxlo_qn_get_scalars(mxlo_qn *h, double scalars[5], double *ys, double *aux) {
   MXLO_REQUIRE(h && scalars, MXLO_EINVAL, "NULL argument");
+  MXLO_DEVICE_GUARD(h->ctx);
   const int64_t mem = h->mem;
   std::vector<double> dev(mem, 0.0), nrm(mem, 0.0);
   double bound = 1.0;
@@ -1676,6 +1675,7 @@ MXLO_API int32_t mxlo_qn_get_scalars(mxlo_qn *h, double scalars[5], double *ys, 
 
 MXLO_API int32_t mxlo_qn_column(mxlo_qn *h, int32_t which, int64_t k, void **out) {
   MXLO_REQUIRE(h && out, MXLO_EINVAL, "NULL argument");
+  MXLO_DEVICE_GUARD(h->ctx);
   MXLO_REQUIRE(k >= 0 && k < h->mem, MXLO_EINVAL, "slot out of range");
   void *p = which == 0 ? h->S : which == 1 ? h->Y : which == 2 ? h->A : which == 3 ? h->B : nullptr;
   MXLO_REQUIRE(p, MXLO_ESTATE, "panel %d not allocated for this operator kind", which);

@@ -173,41 +173,52 @@ int32_t launch_map(mxlo_ctx *ctx, T *res, const T *in0, const T *in1, int64_t n,
   return MXLO_OK;
 }
 
+// ---- caller-scalar types ---------------------------------------------------------------------
+// Julia does not convert the caller's alpha / beta to the element type T: in
+//   res .= α .* d .* v .+ β .* res            (src/special-operators.jl:126-129 and every other leaf)
+// the α-term is evaluated in CA = promote_type(typeof(α), T), the β-term in CB = promote_type(typeof(β), T),
+// their sum in promote_type(CA, CB), and the result is rounded once on store. For Float64 data CA = CB = double;
+// for Float32 data each scalar is float or double on its own (MXLO_ALPHA_F64 / MXLO_BETA_F64), so
+// mul!(res32, op32, v32, α::Float32, β::Float64) rounds (α*d)*v in Float32 first, exactly like the reference.
+template <typename CA, typename CB>
+using Wider = std::conditional_t<(sizeof(CA) >= sizeof(CB)), CA, CB>;
+
+// res = T(t (+ b*r)) with t already evaluated in CA
+template <typename T, typename CA, typename CB, bool BETA0>
+__device__ __forceinline__ T fin_ab(CA t, CB b, T r) {
+  if constexpr (BETA0) return (T)t;
+  else {
+    using P = Wider<CA, CB>;
+    return (T)((P)t + (P)(b * (CB)r));
+  }
+}
+
 // ---- functors: one per reference statement ------------------------------------
 // res = (a*d)*v (+ b*res)      src/special-operators.jl:126-129,146-148
-template <typename T, typename CT, bool BETA0>
+template <typename T, typename CA, typename CB, bool BETA0>
 struct DiagOp {
-  CT a, b;
+  CA a;
+  CB b;
   __device__ void init() {}
-  __device__ T operator()(T d, T v, T r) const {
-    CT t = (a * (CT)d) * (CT)v;
-    if constexpr (!BETA0) t = t + (b * (CT)r);
-    return (T)t;
-  }
+  __device__ T operator()(T d, T v, T r) const { return fin_ab<T, CA, CB, BETA0>((a * (CA)d) * (CA)v, b, r); }
 };
 // 1-element d (SpectralGradient): d broadcast from device memory
-template <typename T, typename CT, bool BETA0>
+template <typename T, typename CA, typename CB, bool BETA0>
 struct DiagScalarOp {
-  CT a, b;
+  CA a;
+  CB b;
   const T *dptr;
-  CT ad;
-  __device__ void init() { ad = a * (CT)(*dptr); }
-  __device__ T operator()(T v, T, T r) const {
-    CT t = ad * (CT)v;
-    if constexpr (!BETA0) t = t + (b * (CT)r);
-    return (T)t;
-  }
+  CA ad;
+  __device__ void init() { ad = a * (CA)(*dptr); }
+  __device__ T operator()(T v, T, T r) const { return fin_ab<T, CA, CB, BETA0>(ad * (CA)v, b, r); }
 };
 // res = a*v (+ b*res)          src/special-operators.jl:38-41, src/operations.jl:18
-template <typename T, typename CT, bool BETA0>
+template <typename T, typename CA, typename CB, bool BETA0>
 struct AxpbyOp {
-  CT a, b;
+  CA a;
+  CB b;
   __device__ void init() {}
-  __device__ T operator()(T v, T, T r) const {
-    CT t = a * (CT)v;
-    if constexpr (!BETA0) t = t + (b * (CT)r);
-    return (T)t;
-  }
+  __device__ T operator()(T v, T, T r) const { return fin_ab<T, CA, CB, BETA0>(a * (CA)v, b, r); }
 };
 // res = res*b                  src/special-operators.jl:106, src/operations.jl:14
 template <typename T, typename CT>
@@ -224,45 +235,50 @@ struct FillOp {
   __device__ T operator()(T, T, T) const { return c; }
 };
 // res = c0 (+ b*res) with c0 = a*sum(v) read from device memory   src/special-operators.jl:81-83
-template <typename T, typename CT, bool BETA0>
+template <typename T, typename CA, typename CB, bool BETA0>
 struct OnesOp {
-  CT a, b;
+  CA a;
+  CB b;
   const double *sum;
-  CT as;
-  __device__ void init() { as = a * (CT)(T)(*sum); }
-  __device__ T operator()(T, T, T r) const {
-    CT t = as;
-    if constexpr (!BETA0) t = t + (b * (CT)r);
-    return (T)t;
-  }
+  CA as;
+  __device__ void init() { as = a * (CA)(T)(*sum); }
+  __device__ T operator()(T, T, T r) const { return fin_ab<T, CA, CB, BETA0>(as, b, r); }
 };
 // res = a*(v - c*h) (+ b*res), c = 2*dot(h,v) from device memory   src/linalg.jl:79-81
-template <typename T, typename CT, bool BETA0>
+template <typename T, typename CA, typename CB, bool BETA0>
 struct HouseholderOp {
-  CT a, b;
+  CA a;
+  CB b;
   const double *dot;
   T c;
   __device__ void init() { c = (T)2 * (T)(*dot); }
   __device__ T operator()(T h, T v, T r) const {
     const T inner = v - (c * h);
-    CT t = a * (CT)inner;
-    if constexpr (!BETA0) t = t + (b * (CT)r);
-    return (T)t;
+    return fin_ab<T, CA, CB, BETA0>(a * (CA)inner, b, r);
   }
 };
 
-// Dispatch helper over (dtype scalars mode, beta==0): calls F.template run<T, CT, BETA0>().
+inline bool alpha_is_f64(size_t elt, int32_t flags) { return elt == 8 || (flags & MXLO_ALPHA_F64); }
+inline bool beta_is_f64(size_t elt, int32_t flags) { return elt == 8 || (flags & MXLO_BETA_F64); }
+
+// Dispatch over (type of alpha, type of beta, beta == 0): calls f.template operator()<CA, CB, BETA0>().
+// beta == 0 never reads res, so CB is irrelevant there (instantiated as CA).
 template <typename T, typename F>
-int32_t dispatch_ct(double beta, int32_t flags, F &&f) {
-  const bool f64s = sizeof(T) == 8 || (flags & MXLO_SCALARS_F64);
-  if (f64s) {
-    return beta == 0 ? f.template operator()<double, true>() : f.template operator()<double, false>();
+int32_t dispatch_ab(double beta, int32_t flags, F &&f) {
+  if constexpr (sizeof(T) == 8) {
+    return beta == 0 ? f.template operator()<double, double, true>() : f.template operator()<double, double, false>();
   } else {
-    if constexpr (sizeof(T) == 4) {
-      return beta == 0 ? f.template operator()<float, true>() : f.template operator()<float, false>();
-    }
+    const bool ad = alpha_is_f64(sizeof(T), flags), bd = beta_is_f64(sizeof(T), flags);
+    if (beta == 0) return ad ? f.template operator()<double, double, true>() : f.template operator()<float, float, true>();
+    if (ad) return bd ? f.template operator()<double, double, false>() : f.template operator()<double, float, false>();
+    return bd ? f.template operator()<float, double, false>() : f.template operator()<float, float, false>();
   }
-  return MXLO_EINVAL;
+}
+
+// Round caller scalars to the types the flags say they have (a Float32 scalar arrives widened to double).
+inline void eff_scalars(size_t elt, int32_t flags, double &alpha, double &beta) {
+  if (!alpha_is_f64(elt, flags)) alpha = (double)(float)alpha;
+  if (!beta_is_f64(elt, flags)) beta = (double)(float)beta;
 }
 
 }  // namespace mxlo

@@ -45,10 +45,12 @@ def _is_f64_scalar(x) -> bool:
 
 
 def scalar_flags(dtype: torch.dtype, alpha, beta) -> int:
-    """MXLO_SCALARS_F64 when Float32 data meets a Float64 alpha/beta (mixed precision)."""
-    if dtype == torch.float32 and (_is_f64_scalar(alpha) or _is_f64_scalar(beta)):
-        return _lib.SCALARS_F64
-    return 0
+    """MXLO_ALPHA_F64 / MXLO_BETA_F64: which caller scalars are Float64 next to Float32 data. Julia evaluates
+    the α-term in promote_type(typeof(α), T) and the β-term in promote_type(typeof(β), T), each on its own
+    (src/special-operators.jl:126-129; SURVEY §8a, mixed precision), so the two flags are independent."""
+    if dtype != torch.float32:
+        return 0
+    return (_lib.ALPHA_F64 if _is_f64_scalar(alpha) else 0) | (_lib.BETA_F64 if _is_f64_scalar(beta) else 0)
 
 
 def one(dtype: torch.dtype):

@@ -25,7 +25,26 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "liblo_oracle.so")
 
-SCALARS_F64 = 0x1
+ALPHA_F64 = 0x1
+BETA_F64 = 0x8
+SCALARS_F64 = ALPHA_F64 | BETA_F64
+
+
+def _julia_f64(x) -> bool:
+    """A Python float / float64 scalar stands for a Julia Float64; Python ints are Julia Ints (they never widen a
+    Float32 product); NumPy float32 scalars are Float32."""
+    if isinstance(x, (bool, int, np.integer)):
+        return False
+    if isinstance(x, np.floating):
+        return x.dtype == np.float64
+    return True
+
+
+def scalar_flags(dtype, alpha, beta) -> int:
+    """ORC_ALPHA_F64 / ORC_BETA_F64 for Float32 data (Julia's mixed-precision rule)."""
+    if np.dtype(dtype) != np.float32:
+        return 0
+    return (ALPHA_F64 if _julia_f64(alpha) else 0) | (BETA_F64 if _julia_f64(beta) else 0)
 D_SCALAR = 0x2
 TAIL_BETA = 0x4
 

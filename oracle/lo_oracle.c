@@ -23,7 +23,9 @@
 #include <stdlib.h>
 #include <string.h>
 
-#define ORC_SCALARS_F64 0x1
+#define ORC_ALPHA_F64 0x1
+#define ORC_BETA_F64 0x8
+#define ORC_SCALARS_F64 (ORC_ALPHA_F64 | ORC_BETA_F64)
 #define ORC_D_SCALAR 0x2
 #define ORC_TAIL_BETA 0x4
 

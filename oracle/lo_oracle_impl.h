@@ -8,10 +8,12 @@
  *     SUF = f64 / f32
  * Citations are `src/<file>.jl:<line>` of the reference.
  *
- * Mixed precision (Julia does not convert caller scalars to T): when
- * `flags & ORC_SCALARS_F64` and T == float, statements that involve the
- * caller's alpha/beta are evaluated per element in double and rounded once
- * on store, exactly what `mul!(res32, op32, v32, 2.0, 3.0)` does.
+ * Mixed precision (Julia does not convert caller scalars to T): with T == float,
+ * ORC_ALPHA_F64 / ORC_BETA_F64 say which caller scalars are Float64; the α-term
+ * of a statement is evaluated in promote_type(typeof(α), T), the β-term in
+ * promote_type(typeof(β), T), their sum in the wider type, rounded once on store
+ * (`mul!(res32, op32, v32, 2.0, 3.0)`: both flags; `α::Float32, β::Float64`: the
+ * product (α*d)*v is rounded to Float32 before the Float64 addition).
  *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
  * use this file. The product (libmxlo.so) never links or calls it.
@@ -21,14 +23,23 @@
 #define CAT(a, b) CAT_(a, b)
 #define FN(name) CAT(name, SUF)
 
-/* CT selection: run BODY(double) when T is double or the caller kept Float64
- * scalars, BODY(float) otherwise. */
+/* Scalar-type selection. Julia evaluates `α .* d .* v .+ β .* res` with α and β in the
+ * types the CALLER passed: the α-term in CA = promote_type(typeof(α), T), the β-term in
+ * CB = promote_type(typeof(β), T), and their sum in promote_type(CA, CB) — which is what C's
+ * usual arithmetic conversions do to a (CA) + (CB) expression. BODY(CA, CB) is instantiated for
+ * the combination the flags select (ORC_ALPHA_F64 / ORC_BETA_F64; both always double when T is). */
 #define WITH_CT(BODY)                                                                            \
   do {                                                                                           \
-    if (sizeof(T) == 8 || (flags & ORC_SCALARS_F64)) {                                           \
-      BODY(double);                                                                              \
+    const int ad_ = sizeof(T) == 8 || (flags & ORC_ALPHA_F64);                                   \
+    const int bd_ = sizeof(T) == 8 || (flags & ORC_BETA_F64);                                    \
+    if (ad_ && bd_) {                                                                            \
+      BODY(double, double);                                                                      \
+    } else if (ad_) {                                                                            \
+      BODY(double, float);                                                                       \
+    } else if (bd_) {                                                                            \
+      BODY(float, double);                                                                       \
     } else {                                                                                     \
-      BODY(float);                                                                               \
+      BODY(float, float);                                                                        \
     }                                                                                            \
   } while (0)
 
@@ -58,14 +69,14 @@ static T FN(orc_norm)(const T *a, int64_t n) {
 void FN(orc_diag_mul)(T *res, const T *d, const T *v, int64_t n_min, int64_t nrow, double alpha,
                       double beta, int32_t flags) {
   const int64_t ds = (flags & ORC_D_SCALAR) ? 0 : 1; /* 1-element d broadcasts */
-#define BODY(CT)                                                                                 \
+#define BODY(CA, CB)                                                                                 \
   {                                                                                              \
-    const CT a = (CT)alpha, b = (CT)beta;                                                        \
+    const CA a = (CA)alpha; const CB b = (CB)beta;                                                      \
     if (beta == 0) { /* :126-127  res .= α .* d .* v   => (α*d)*v */                            \
-      for (int64_t i = 0; i < n_min; ++i) res[i] = (T)((a * (CT)d[i * ds]) * (CT)v[i]);          \
+      for (int64_t i = 0; i < n_min; ++i) res[i] = (T)((a * (CA)d[i * ds]) * (CA)v[i]);          \
     } else { /* :128-129  res .= α .* d .* v .+ β .* res */                                     \
       for (int64_t i = 0; i < n_min; ++i)                                                        \
-        res[i] = (T)(((a * (CT)d[i * ds]) * (CT)v[i]) + (b * (CT)res[i]));                       \
+        res[i] = (T)(((a * (CA)d[i * ds]) * (CA)v[i]) + (b * (CB)res[i]));                       \
     }                                                                                            \
   }
   WITH_CT(BODY);
@@ -76,19 +87,19 @@ void FN(orc_diag_mul)(T *res, const T *d, const T *v, int64_t n_min, int64_t nro
 /* ---- mulOpEye! — src/special-operators.jl:36-44 ---- */
 void FN(orc_eye_mul)(T *res, const T *v, int64_t n_min, int64_t nrow, double alpha, double beta,
                      int32_t flags) {
-#define BODY(CT)                                                                                 \
+#define BODY(CA, CB)                                                                                 \
   {                                                                                              \
-    const CT a = (CT)alpha, b = (CT)beta;                                                        \
+    const CA a = (CA)alpha; const CB b = (CB)beta;                                                      \
     if (beta == 0) { /* :38-39 */                                                                \
-      for (int64_t i = 0; i < n_min; ++i) res[i] = (T)(a * (CT)v[i]);                            \
+      for (int64_t i = 0; i < n_min; ++i) res[i] = (T)(a * (CA)v[i]);                            \
       for (int64_t i = n_min; i < nrow; ++i) res[i] = 0;                                         \
     } else { /* :41-42 — the tail receives β itself (reference quirk) unless the               \
                 generic-axpby flag asks for β*res */                                             \
-      for (int64_t i = 0; i < n_min; ++i) res[i] = (T)((a * (CT)v[i]) + (b * (CT)res[i]));       \
+      for (int64_t i = 0; i < n_min; ++i) res[i] = (T)((a * (CA)v[i]) + (b * (CB)res[i]));       \
       if (flags & ORC_TAIL_BETA)                                                                 \
         for (int64_t i = n_min; i < nrow; ++i) res[i] = (T)b;                                    \
       else                                                                                       \
-        for (int64_t i = n_min; i < nrow; ++i) res[i] = (T)(b * (CT)res[i]);                     \
+        for (int64_t i = n_min; i < nrow; ++i) res[i] = (T)(b * (CB)res[i]);                     \
     }                                                                                            \
   }
   WITH_CT(BODY);
@@ -97,13 +108,13 @@ void FN(orc_eye_mul)(T *res, const T *v, int64_t n_min, int64_t nrow, double alp
 
 /* ---- mulOpZeros! — src/special-operators.jl:102-108 ---- */
 void FN(orc_zeros_mul)(T *res, int64_t nrow, double beta, int32_t flags) {
-#define BODY(CT)                                                                                 \
+#define BODY(CA, CB)                                                                                 \
   {                                                                                              \
-    const CT b = (CT)beta;                                                                       \
+    const CB b = (CB)beta;                                                                       \
     if (beta == 0)                                                                               \
       for (int64_t i = 0; i < nrow; ++i) res[i] = 0; /* :104 */                                  \
     else                                                                                         \
-      for (int64_t i = 0; i < nrow; ++i) res[i] = (T)((CT)res[i] * b); /* :106 res .*= β */      \
+      for (int64_t i = 0; i < nrow; ++i) res[i] = (T)((CB)res[i] * b); /* :106 res .*= β */      \
   }
   WITH_CT(BODY);
 #undef BODY
@@ -126,14 +137,14 @@ static T FN(orc_sum_pairwise)(const T *v, int64_t lo, int64_t hi) {
 void FN(orc_ones_mul)(T *res, int64_t nrow, const T *v, int64_t ncol, double alpha, double beta,
                       int32_t flags) {
   const T sv = FN(orc_sum_pairwise)(v, 0, ncol);
-#define BODY(CT)                                                                                 \
+#define BODY(CA, CB)                                                                                 \
   {                                                                                              \
-    const CT a = (CT)alpha, b = (CT)beta;                                                        \
-    const CT as = a * (CT)sv; /* (α * sum(v)) */                                                 \
+    const CA a = (CA)alpha; const CB b = (CB)beta;                                                      \
+    const CA as = a * (CA)sv; /* (α * sum(v)) */                                                 \
     if (beta == 0)                                                                               \
       for (int64_t i = 0; i < nrow; ++i) res[i] = (T)as;                                         \
     else                                                                                         \
-      for (int64_t i = 0; i < nrow; ++i) res[i] = (T)(as + (b * (CT)res[i]));                    \
+      for (int64_t i = 0; i < nrow; ++i) res[i] = (T)(as + (b * (CB)res[i]));                    \
   }
   WITH_CT(BODY);
 #undef BODY
@@ -141,10 +152,10 @@ void FN(orc_ones_mul)(T *res, int64_t nrow, const T *v, int64_t ncol, double alp
 
 /* ---- prod3! `res .*= α` — src/operations.jl:13-15 ---- */
 void FN(orc_scale)(T *res, int64_t n, double alpha, int32_t flags) {
-#define BODY(CT)                                                                                 \
+#define BODY(CA, CB)                                                                                 \
   {                                                                                              \
-    const CT a = (CT)alpha;                                                                      \
-    for (int64_t i = 0; i < n; ++i) res[i] = (T)((CT)res[i] * a);                                \
+    const CA a = (CA)alpha;                                                                      \
+    for (int64_t i = 0; i < n; ++i) res[i] = (T)((CA)res[i] * a);                                \
   }
   WITH_CT(BODY);
 #undef BODY
@@ -154,14 +165,14 @@ void FN(orc_scale)(T *res, int64_t n, double alpha, int32_t flags) {
 void FN(orc_householder_mul)(T *res, const T *h, const T *v, int64_t n, double alpha,
                              double beta, int32_t flags) {
   const T c = (T)2 * FN(orc_dot)(h, v, n); /* 2 * dot(h, v) : scalar, type T */
-#define BODY(CT)                                                                                 \
+#define BODY(CA, CB)                                                                                 \
   {                                                                                              \
-    const CT a = (CT)alpha, b = (CT)beta;                                                        \
+    const CA a = (CA)alpha; const CB b = (CB)beta;                                                      \
     if (beta == 0) { /* :79  res .= α .* (v .- 2 * dot(h, v) .* h) */                           \
-      for (int64_t i = 0; i < n; ++i) res[i] = (T)(a * (CT)(T)(v[i] - (c * h[i])));              \
+      for (int64_t i = 0; i < n; ++i) res[i] = (T)(a * (CA)(T)(v[i] - (c * h[i])));              \
     } else { /* :81 */                                                                           \
       for (int64_t i = 0; i < n; ++i)                                                            \
-        res[i] = (T)((a * (CT)(T)(v[i] - (c * h[i]))) + (b * (CT)res[i]));                       \
+        res[i] = (T)((a * (CA)(T)(v[i] - (c * h[i]))) + (b * (CB)res[i]));                       \
     }                                                                                            \
   }
   WITH_CT(BODY);
@@ -187,15 +198,15 @@ void FN(orc_hermitian_mul)(T *res, const T *d, const T *A, int64_t lda, const T 
     for (int64_t i = j + 1; i < n; ++i) s += col[i] * v[i];
     t2[j] = s;
   }
-#define BODY(CT)                                                                                 \
+#define BODY(CA, CB)                                                                                 \
   {                                                                                              \
-    const CT a = (CT)alpha, b = (CT)beta;                                                        \
+    const CA a = (CA)alpha; const CB b = (CB)beta;                                                      \
     for (int64_t i = 0; i < n; ++i) {                                                            \
       const T inner = ((d[i] * v[i]) + t1[i]) + t2[i]; /* d.*v .+ L*v .+ (v'L)' */               \
       if (beta == 0)                                                                             \
-        res[i] = (T)(a * (CT)inner);                                                             \
+        res[i] = (T)(a * (CA)inner);                                                             \
       else                                                                                       \
-        res[i] = (T)((a * (CT)inner) + (b * (CT)res[i]));                                        \
+        res[i] = (T)((a * (CA)inner) + (b * (CB)res[i]));                                        \
     }                                                                                            \
   }
   WITH_CT(BODY);
@@ -230,11 +241,11 @@ void FN(orc_gemv)(T *res, const T *M, int64_t m, int64_t n, int64_t ld, const T 
       tmp[j] = s;
     }
   }
-#define BODY(CT)                                                                                 \
+#define BODY(CA, CB)                                                                                 \
   {                                                                                              \
-    const CT a = (CT)alpha, b = (CT)beta;                                                        \
+    const CA a = (CA)alpha; const CB b = (CB)beta;                                                      \
     for (int64_t i = 0; i < nr; ++i)                                                             \
-      res[i] = (beta == 0) ? (T)(a * (CT)tmp[i]) : (T)((a * (CT)tmp[i]) + (b * (CT)res[i]));     \
+      res[i] = (beta == 0) ? (T)(a * (CA)tmp[i]) : (T)((a * (CA)tmp[i]) + (b * (CB)res[i]));     \
   }
   WITH_CT(BODY);
 #undef BODY
@@ -279,11 +290,11 @@ void FN(orc_kron_mul)(T *res, const T *A, int64_t m, int64_t n, int64_t lda, con
     }
   }
   const int64_t nout = nrows_out * ncols_out;
-#define BODY(CT)                                                                                 \
+#define BODY(CA, CB)                                                                                 \
   {                                                                                              \
-    const CT a = (CT)alpha, b = (CT)beta;                                                        \
+    const CA a = (CA)alpha; const CB b = (CB)beta;                                                      \
     for (int64_t i = 0; i < nout; ++i)                                                           \
-      res[i] = (beta == 0) ? (T)(a * (CT)R[i]) : (T)((a * (CT)R[i]) + (b * (CT)res[i]));         \
+      res[i] = (beta == 0) ? (T)(a * (CA)R[i]) : (T)((a * (CA)R[i]) + (b * (CB)res[i]));         \
   }
   WITH_CT(BODY);
 #undef BODY
@@ -339,13 +350,13 @@ void FN(orc_lbfgs_inv_mul)(FN(orc_lbfgs) * data, T *res, const T *x, double alph
       for (int64_t j = 0; j < n; ++j) q[j] = q[j] + (bt * sk[j]);  /* :146 q .+= β .* s[k] */
     }
   }
-#define BODY(CT)                                                                                 \
+#define BODY(CA, CB)                                                                                 \
   {                                                                                              \
-    const CT a = (CT)alpha_m, b = (CT)beta_m;                                                    \
+    const CA a = (CA)alpha_m; const CB b = (CB)beta_m;                                                  \
     if (beta_m == 0) /* :150 res .= αm .* q */                                                   \
-      for (int64_t j = 0; j < n; ++j) res[j] = (T)(a * (CT)q[j]);                                \
+      for (int64_t j = 0; j < n; ++j) res[j] = (T)(a * (CA)q[j]);                                \
     else /* :152 */                                                                              \
-      for (int64_t j = 0; j < n; ++j) res[j] = (T)((a * (CT)q[j]) + (b * (CT)res[j]));           \
+      for (int64_t j = 0; j < n; ++j) res[j] = (T)((a * (CA)q[j]) + (b * (CB)res[j]));           \
   }
   WITH_CT(BODY);
 #undef BODY
@@ -369,13 +380,13 @@ void FN(orc_lbfgs_fwd_mul)(FN(orc_lbfgs) * data, T *res, const T *x, double alph
         q[j] = q[j] + ((bx * bk[j]) - (ax * ak[j]));
     }
   }
-#define BODY(CT)                                                                                 \
+#define BODY(CA, CB)                                                                                 \
   {                                                                                              \
-    const CT a = (CT)alpha, b = (CT)beta;                                                        \
+    const CA a = (CA)alpha; const CB b = (CB)beta;                                                      \
     if (beta == 0) /* :198 */                                                                    \
-      for (int64_t j = 0; j < n; ++j) res[j] = (T)(a * (CT)q[j]);                                \
+      for (int64_t j = 0; j < n; ++j) res[j] = (T)(a * (CA)q[j]);                                \
     else /* :200 */                                                                              \
-      for (int64_t j = 0; j < n; ++j) res[j] = (T)((a * (CT)q[j]) + (b * (CT)res[j]));           \
+      for (int64_t j = 0; j < n; ++j) res[j] = (T)((a * (CA)q[j]) + (b * (CB)res[j]));           \
   }
   WITH_CT(BODY);
 #undef BODY
@@ -568,20 +579,20 @@ typedef struct {
 void FN(orc_lsr1_mul)(FN(orc_lsr1) * data, T *q, const T *x, double alpha, double beta,
                       int32_t flags) {
   const int64_t n = data->n, mem = data->mem;
-#define BODY(CT)                                                                                 \
+#define BODY(CA, CB)                                                                                 \
   {                                                                                              \
-    const CT a = (CT)alpha, b = (CT)beta;                                                        \
-    const CT g = (CT)data->scaling_factor;                                                       \
+    const CA a = (CA)alpha; const CB b = (CB)beta;                                                      \
+    const CA g = (CA)data->scaling_factor;                                                       \
     if (beta == 0) /* :93 q .= α .* x ./ scaling_factor  => (α*x)/γ */                           \
-      for (int64_t j = 0; j < n; ++j) q[j] = (T)((a * (CT)x[j]) / g);                            \
+      for (int64_t j = 0; j < n; ++j) q[j] = (T)((a * (CA)x[j]) / g);                            \
     else /* :95 */                                                                               \
-      for (int64_t j = 0; j < n; ++j) q[j] = (T)(((a * (CT)x[j]) / g) + (b * (CT)q[j]));         \
+      for (int64_t j = 0; j < n; ++j) q[j] = (T)(((a * (CA)x[j]) / g) + (b * (CB)q[j]));         \
     for (int64_t i = 1; i <= mem; ++i) { /* :98 */                                               \
       const int64_t k = FN(jmod)(data->insert + i - 2, mem) + 1; /* :99 */                       \
       if (data->ys[k - 1] != 0) { /* :100 */                                                     \
         const T *ak = data->a + (k - 1) * n;                                                     \
-        const CT ax = (a * (CT)FN(orc_dot)(ak, x, n)) / (CT)data->as[k - 1]; /* :101 */          \
-        for (int64_t j = 0; j < n; ++j) q[j] = (T)((CT)q[j] + (ax * (CT)ak[j])); /* :103 */      \
+        const CA ax = (a * (CA)FN(orc_dot)(ak, x, n)) / (CA)data->as[k - 1]; /* :101 */          \
+        for (int64_t j = 0; j < n; ++j) q[j] = (T)((CA)q[j] + (ax * (CA)ak[j])); /* :103 */      \
       }                                                                                          \
     }                                                                                            \
   }

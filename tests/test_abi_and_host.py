@@ -78,6 +78,8 @@ def test_storage_promotion_and_nargs(lo):
     assert _nargs(lambda res, v, a, b: None) == 4 and _nargs(lambda res, v: None) == 2
     from linearoperators_jl_amd.operators import scalar_flags
     assert scalar_flags(torch.float32, 2.0, 0.0) == lo._lib.SCALARS_F64
+    assert scalar_flags(torch.float32, np.float32(2), 0.5) == lo._lib.BETA_F64      # each scalar on its own
+    assert scalar_flags(torch.float32, 2.0, np.float32(0.5)) == lo._lib.ALPHA_F64
     assert scalar_flags(torch.float32, np.float32(2), np.float32(0)) == 0
     assert scalar_flags(torch.float32, 2, 0) == 0    # Julia Int scalars never widen a Float32 product
     assert scalar_flags(torch.float64, 2.0, 0.0) == 0

@@ -108,14 +108,44 @@ def test_diag_bit_exact(lo, dev, dtype, n):
     npd = NP[dtype]
     d, v, r0 = (rng.standard_normal(n).astype(npd) for _ in range(3))
     D = lo.opDiagonal(T(d, dev))
-    for alpha, beta in ((1.0, 0.0), (2.0 / 3.0, 0.0), (-1.25, 1.0 / 7.0), (0.0, 2.0), (1, 0), (np.float32(0.3), np.float32(0.7))):
+    # all four scalar-type combinations of Julia's mixed-precision rule (src/special-operators.jl:126-129):
+    # the α-term is evaluated in α's type, the β-term in β's, the sum in the wider one
+    for alpha, beta in ((1.0, 0.0), (2.0 / 3.0, 0.0), (-1.25, 1.0 / 7.0), (0.0, 2.0), (1, 0), (np.float32(0.3), np.float32(0.7)),
+                        (np.float32(0.3), 1.0 / 7.0), (2.0 / 3.0, np.float32(0.7)), (np.float32(1.1), 0.0), (1.0 / 3.0, np.float32(0))):
         res = T(r0.copy(), dev)
         if beta == 0:
             res.fill_(float("nan"))                       # beta == 0: res is never read
         lo.mul(res, D, T(v, dev), alpha, beta)
-        flags = oracle.SCALARS_F64 if (dtype == torch.float32 and (isinstance(alpha, float) or isinstance(beta, float))) else 0
+        flags = oracle.scalar_flags(npd, alpha, beta)
         want = oracle.diag_mul(r0.copy(), d, v, float(alpha), float(beta), flags=flags)
         assert np.array_equal(res.cpu().numpy(), want), (alpha, beta)
+
+
+@pytest.mark.parametrize("n", [1, 255, 4099, 100_003])
+def test_mixed_scalar_types_bit_exact_every_elementwise_leaf(lo, dev, n):
+    """Float32 data with (Float32, Float64) and (Float64, Float32) scalars through opEye, opZeros, scale,
+    the generic axpby of prod3!, BlockDiagonal of diagonals and kron of diagonals — all advertised bit-exact."""
+    rng = np.random.default_rng(900 + n)
+    d, v, r0 = (rng.standard_normal(n).astype(np.float32) for _ in range(3))
+    E = lo.opEye(torch.float32, n, S=lo.Storage(torch.float32, dev))
+    Z = lo.opZeros(torch.float32, n, n, S=lo.Storage(torch.float32, dev))
+    for alpha, beta in ((np.float32(0.3), 1.0 / 7.0), (2.0 / 3.0, np.float32(0.7)), (np.float32(0.3), np.float32(0.7)), (2.0 / 3.0, 1.0 / 7.0)):
+        fl = oracle.scalar_flags(np.float32, alpha, beta)
+        res = T(r0.copy(), dev)
+        lo.mul(res, E, T(v, dev), alpha, beta)
+        assert np.array_equal(res.cpu().numpy(), oracle.eye_mul(r0.copy(), v, float(alpha), float(beta), flags=fl | oracle.TAIL_BETA))
+        res = T(r0.copy(), dev)
+        lo.mul(res, Z, T(v, dev), alpha, beta)
+        assert np.array_equal(res.cpu().numpy(), oracle.zeros_mul(r0.copy(), float(beta), flags=fl))
+    if n >= 255:
+        m = n // 3
+        blocks = [lo.opDiagonal(T(d[:m].copy(), dev)), lo.opDiagonal(T(d[m:2 * m].copy(), dev)), lo.opDiagonal(T(d[2 * m:].copy(), dev))]
+        BD = lo.BlockDiagonalOperator(*blocks)
+        for alpha, beta in ((np.float32(0.3), 1.0 / 7.0), (2.0 / 3.0, np.float32(0.7))):
+            res = T(r0.copy(), dev)
+            lo.mul(res, BD, T(v, dev), alpha, beta)
+            want = oracle.diag_mul(r0.copy(), d, v, float(alpha), float(beta), flags=oracle.scalar_flags(np.float32, alpha, beta))
+            assert np.array_equal(res.cpu().numpy(), want), (alpha, beta)
 
 
 @pytest.mark.parametrize("dtype", [torch.float64, torch.float32])

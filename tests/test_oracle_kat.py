@@ -254,6 +254,18 @@ def test_mixed_precision_f32_scalars_f64():
     want32 = (np.float32(a) * d) * v + np.float32(b) * r
     assert np.array_equal(got32, want32)
     assert not np.array_equal(got, got32)
+    # one Float32 and one Float64 scalar: each term in its own type, the sum in Float64, one rounding on store
+    d64, v64, r64 = d.astype(np.float64), v.astype(np.float64), r.astype(np.float64)
+    got_ab = oracle.diag_mul(r.copy(), d, v, a, b, flags=oracle.BETA_F64)        # α::Float32, β::Float64
+    want_ab = (((np.float32(a) * d) * v).astype(np.float64) + b * r64).astype(np.float32)
+    assert np.array_equal(got_ab, want_ab)
+    got_ba = oracle.diag_mul(r.copy(), d, v, a, b, flags=oracle.ALPHA_F64)       # α::Float64, β::Float32
+    want_ba = ((a * d64) * v64 + (np.float32(b) * r).astype(np.float64)).astype(np.float32)
+    assert np.array_equal(got_ba, want_ba)
+    assert len({got.tobytes(), got32.tobytes(), got_ab.tobytes(), got_ba.tobytes()}) == 4
+    assert oracle.scalar_flags(np.float32, np.float32(1), 2.0) == oracle.BETA_F64
+    assert oracle.scalar_flags(np.float32, 1.5, 2) == oracle.ALPHA_F64
+    assert oracle.scalar_flags(np.float64, 1.5, 2.0) == 0
 
 
 def test_eye_zeros_ones_quirks():

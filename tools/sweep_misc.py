@@ -51,19 +51,17 @@ K = lo.kron(A, B)
 x = torch.rand(nn * nn, dtype=torch.float64, device=dev, generator=gen) * 2 - 1
 out = torch.empty_like(x)
 for rnd in range(2):
-    for tile, w in ((64, 4), (64, 8), (32, 4)):
-        ctx.tune("gemm_tile_m", tile)
-        ctx.tune("gemm_waves", w)
+    for tile in (32, 64, 128, -1):
+        ctx.tune("gemm_tile", tile)
         mn, med = timeit(lambda: lo.mul(out, K, x, 1.0, 0.0), reps=50)
-        print(f"kron 1024^2 tile_m={tile} waves={w}: min {mn*1e3:.1f} us ({4*nn**3/mn/1e9:.1f} TF)  median {med*1e3:.1f} us", flush=True)
-ctx.tune("gemm_tile_m", 0)
-ctx.tune("gemm_waves", 0)
+        print(f"kron 1024^2 gemm_tile={tile}: min {mn*1e3:.1f} us ({4*nn**3/mn/1e9:.1f} TF)  median {med*1e3:.1f} us", flush=True)
+ctx.tune("gemm_tile", 0)
 for sz in (256, 512, 2048):
     A = ((torch.rand(sz, sz, dtype=torch.float64, device=dev, generator=gen) * 2 - 1) / 32).t()
     K = lo.kron(A, A)
     x = torch.rand(sz * sz, dtype=torch.float64, device=dev, generator=gen)
     out = torch.empty_like(x)
-    for tile in (64, 32, 0):
-        ctx.tune("gemm_tile_m", tile)
+    for tile in (128, 64, 32, 0):
+        ctx.tune("gemm_tile", tile)
         mn, med = timeit(lambda: lo.mul(out, K, x, 1.0, 0.0), reps=20)
-        print(f"kron {sz}^2 tile_m={tile}: min {mn*1e3:.1f} us ({4*sz**3/mn/1e9:.1f} TF)", flush=True)
+        print(f"kron {sz}^2 gemm_tile={tile}: min {mn*1e3:.1f} us ({4*sz**3/mn/1e9:.1f} TF)", flush=True)

@@ -18,7 +18,8 @@
  *    aligned: `view(res, k+1:k+m)` of cat / block-diag arrive as base+offset,
  *    src/cat.jl:17-18, src/special-operators.jl:263); matrices column-major
  *    with a leading dimension, exactly Julia's layout.
- *  - `dtype`: MXLO_F64 or MXLO_F32 (element type of res / v / operator data).
+ *  - `dtype`: MXLO_F64 or MXLO_F32 (element type of res / v / operator data); the `_c` entry points take
+ *    MXLO_C64 / MXLO_C32 (ComplexF64 / ComplexF32) for the elementwise leaves and opHouseholder.
  *  - `alpha`, `beta` always arrive as double. Julia does not convert caller
  *    scalars to the element type, so for MXLO_F32 data each scalar carries its
  *    own width flag: MXLO_ALPHA_F64 / MXLO_BETA_F64 say that scalar was a
@@ -62,6 +63,8 @@ extern "C" {
 /* ---- dtypes and flags --------------------------------------------------- */
 #define MXLO_F64 0
 #define MXLO_F32 1
+#define MXLO_C64 2 /* ComplexF64: (re, im) doubles adjacent — Julia's Complex{Float64}; `_c` entry points only */
+#define MXLO_C32 3 /* ComplexF32 */
 
 #define MXLO_ALPHA_F64   0x1 /* f32 data: alpha is a Float64 (the alpha-term is evaluated in double) */
 #define MXLO_BETA_F64    0x8 /* f32 data: beta  is a Float64 (the beta-term  is evaluated in double) */
@@ -70,11 +73,16 @@ extern "C" {
                                 src/DiagonalHessianApproximation.jl:226)                      */
 #define MXLO_TAIL_BETA   0x4 /* eye: rows [n_min,nrow) receive `beta` (NOT beta*res) when
                                 beta != 0 — reference quirk, src/special-operators.jl:42     */
+#define MXLO_CONJ_D      0x10 /* complex diag: multiply by conj.(d) — the ctprod! of opDiagonal,
+                                 src/special-operators.jl:139-141                             */
+#define MXLO_ALPHA_REAL  0x20 /* complex leaves: alpha is a Real (Real*Complex is componentwise in Julia,
+                                 not Complex(alpha, 0)*z: signed zeros and non-finite values differ)   */
+#define MXLO_BETA_REAL   0x40 /* the same for beta                                            */
 
 /* transposition modes for matrix-carrying leaves */
 #define MXLO_OP_N 0 /* prod!   */
 #define MXLO_OP_T 1 /* tprod!  */
-#define MXLO_OP_C 2 /* ctprod! (== T for the real dtypes this library instantiates) */
+#define MXLO_OP_C 2 /* ctprod! (== T for real dtypes; the matrix-carrying leaves are real-only) */
 
 typedef struct mxlo_ctx mxlo_ctx;     /* opaque: device, stream, reduction workspace, tuning  */
 typedef struct mxlo_qn mxlo_qn;       /* opaque: L-BFGS / L-SR1 state resident in HBM         */
@@ -182,6 +190,34 @@ int32_t mxlo_fill(mxlo_ctx *ctx, int32_t dtype, void *res, int64_t n, double val
 int32_t mxlo_scale(mxlo_ctx *ctx, int32_t dtype, void *res, int64_t n, double alpha,
                    int32_t flags);
 
+/* ---- complex element types (dtype MXLO_C64 / MXLO_C32) ------------------------------------------------------
+ * The reference's own tests of opDiagonal and opHouseholder run on ComplexF64 (test/test_linop.jl:308-318,
+ * 511-517). Scalars arrive as (re, im) pairs; MXLO_ALPHA_REAL / MXLO_BETA_REAL mark Real caller scalars,
+ * MXLO_ALPHA_F64 / MXLO_BETA_F64 their width next to ComplexF32 data (same promotion rule as the real leaves).
+ * Arithmetic is Julia's, component by component, nothing fused:
+ *   Complex*Complex = (zr*wr - zi*wi, zr*wi + zi*wr),  Real*Complex = (x*wr, x*wi).
+ * Elementwise results are bit-identical to the reference CPU broadcast; the Householder dot is a fixed-order tree. */
+/* mulSquareOpDiagonal!/mulOpDiagonal! (src/special-operators.jl:125-131,144-151); MXLO_CONJ_D = ctprod! (:139-141). */
+int32_t mxlo_diag_mul_c(mxlo_ctx *ctx, int32_t dtype, void *res, const void *d, const void *v, int64_t n_min,
+                        int64_t nrow, double alpha_re, double alpha_im, double beta_re, double beta_im,
+                        int32_t flags);
+/* mulOpEye! / the generic axpby of prod3! (src/special-operators.jl:36-44, src/operations.jl:18). */
+int32_t mxlo_eye_mul_c(mxlo_ctx *ctx, int32_t dtype, void *res, const void *v, int64_t n_min, int64_t nrow,
+                       double alpha_re, double alpha_im, double beta_re, double beta_im, int32_t flags);
+/* mulOpZeros! (src/special-operators.jl:102-108): res .= 0 | res .*= beta. */
+int32_t mxlo_zeros_mul_c(mxlo_ctx *ctx, int32_t dtype, void *res, int64_t nrow, double beta_re, double beta_im,
+                         int32_t flags);
+/* `res .*= alpha` of prod3! (src/operations.jl:13-15). */
+int32_t mxlo_scale_c(mxlo_ctx *ctx, int32_t dtype, void *res, int64_t n, double alpha_re, double alpha_im,
+                     int32_t flags);
+/* conj!(res) (res == v) and conj.(v) of the wrapper routing (src/adjtrans.jl:127-136,193-204,226-249). */
+int32_t mxlo_conj_c(mxlo_ctx *ctx, int32_t dtype, void *res, const void *v, int64_t n);
+/* LinearAlgebra.dot(a, b) = sum conj(a_i) b_i into TWO device doubles (re, im); runs the all-reduce hook. */
+int32_t mxlo_dot_c(mxlo_ctx *ctx, int32_t dtype, const void *a, const void *b, int64_t n, double *out_dev);
+/* mulHouseholder! (src/linalg.jl:77-83) for complex h: c = 2*dot(h, v) with h conjugated. */
+int32_t mxlo_householder_mul_c(mxlo_ctx *ctx, int32_t dtype, void *res, const void *h, const void *v, int64_t n,
+                               double alpha_re, double alpha_im, double beta_re, double beta_im, int32_t flags);
+
 /* mulHouseholder! — src/linalg.jl:77-83.
  *   c = 2*dot(h,v);  res[i] = alpha*(v[i] - c*h[i]) (+ beta*res[i]).
  * Two launches + finalize: (A) fixed-order partial dots -> device scalar,
@@ -259,13 +295,24 @@ int32_t mxlo_blockdiag_destroy(mxlo_blockdiag *bd);
  *   T/C: X = reshape(x, p, m); res = alpha*vec(transpose(B)*X*A) (+ beta*res)
  * A is m x n (lda), B is p x q (ldb), both dense column-major on the device.
  * Two f64/f32 GEMMs on the matrix cores (v_mfma_f64_16x16x4_f64 /
- * v_mfma_f32_16x16x4_f32) with the alpha/beta epilogue fused in the second.
+ * v_mfma_f32_16x16x4_f32) with the alpha/beta epilogue fused in the second; in T/C mode A and B are read
+ * transposed IN PLACE (K-contiguous operand layout of the GEMM kernel) — no transposed copies.
  * `work` must hold max(p*n, q*m) elements (the glue allocates it once at
  * construction, like the reference's compose temporaries, src/operations.jl:149-151). */
 int32_t mxlo_kron_mul(mxlo_ctx *ctx, int32_t dtype, void *res, const void *A, int64_t m,
                       int64_t n, int64_t lda, const void *B, int64_t p, int64_t q, int64_t ldb,
                       const void *x, void *work, double alpha, double beta, int32_t op_mode,
                       int32_t flags);
+
+/* The same with a transposition flag PER FACTOR: kron(opA(A), opB(B)) where opX is the stored column-major matrix
+ * (trans == 0) or its transpose (trans != 0). A is stored am x an (lda), B is stored bp x bq (ldb).
+ *   (0,0) = prod!, (1,1) = tprod!/ctprod! of src/kron.jl:14-40; the mixed cases let the glue hand over a row-major
+ *   (= transposed-in-place) factor without copying it. `work` must hold rows(opA) * cols(opB) elements.
+ * Both GEMMs run the DMA kernel whenever pointers are 16-byte aligned and the leading dimensions / contiguous
+ * extents are multiples of 16 bytes; anything else falls back to a generic tile kernel. */
+int32_t mxlo_kron_mul_ex(mxlo_ctx *ctx, int32_t dtype, void *res, const void *A, int64_t am, int64_t an,
+                         int64_t lda, int32_t trans_a, const void *B, int64_t bp, int64_t bq, int64_t ldb,
+                         int32_t trans_b, const void *x, void *work, double alpha, double beta, int32_t flags);
 
 /* kron(A, B) when BOTH factors are diagonal operators (opDiagonal / opEye; pass NULL for an identity
  * factor): the fused row/col index-decomposition form of src/kron.jl:14-22,

@@ -17,7 +17,8 @@ from .device import Context, Storage, Timer, get_ctx, storage_of
 from .operators import (AbstractLinearOperator, AdjointLinearOperator, ConjugateLinearOperator, LinearOperator,
                         LinearOperatorException, TransposeLinearOperator, add, adjoint, allocate_vectors_args3, apply,
                         compose, conj, eltype, has_args5, hcat, hvcat, isallocated5, ishermitian, issymmetric, mul,
-                        nctprod, neg, nprod, ntprod, one, reset, scale_op, size, storage_type, to_dense, transpose,
+                        nctprod, neg, nprod, ntprod, one, reset, scale_op, size, state_version, storage_type, to_dense, touched,
+                        transpose,
                         vcat, zero)
 from .leaves import (BlockDiagonalOperator, LinearOperatorFromMatrix, ShiftedOperator, jrange, kron, opDiagonal, opExtension, opEye,
                      opHermitian, opHouseholder, opOnes, opRestriction, opZeros)

@@ -20,7 +20,8 @@ RCCL_ID_BYTES = 128
 
 # status codes (include/mxlo.h)
 OK, EINVAL, ESHAPE, EHIP, ENOMEM, ESTATE, EDOMAIN, EREDUCE = range(8)
-F64, F32 = 0, 1
+F64, F32, C64, C32 = 0, 1, 2, 3
+CONJ_D, ALPHA_REAL, BETA_REAL = 0x10, 0x20, 0x40
 ALPHA_F64, D_SCALAR, TAIL_BETA, BETA_F64 = 0x1, 0x2, 0x4, 0x8
 SCALARS_F64 = ALPHA_F64 | BETA_F64
 OP_N, OP_T, OP_C = 0, 1, 2
@@ -105,6 +106,13 @@ _PROTOS = {
     "mxlo_ones_mul": [_vp, _i32, _vp, _i64, _vp, _i64, _dbl, _dbl, _i32],
     "mxlo_scale": [_vp, _i32, _vp, _i64, _dbl, _i32],
     "mxlo_fill": [_vp, _i32, _vp, _i64, _dbl],
+    "mxlo_diag_mul_c": [_vp, _i32, _vp, _vp, _vp, _i64, _i64, _dbl, _dbl, _dbl, _dbl, _i32],
+    "mxlo_eye_mul_c": [_vp, _i32, _vp, _vp, _i64, _i64, _dbl, _dbl, _dbl, _dbl, _i32],
+    "mxlo_zeros_mul_c": [_vp, _i32, _vp, _i64, _dbl, _dbl, _i32],
+    "mxlo_scale_c": [_vp, _i32, _vp, _i64, _dbl, _dbl, _i32],
+    "mxlo_conj_c": [_vp, _i32, _vp, _vp, _i64],
+    "mxlo_dot_c": [_vp, _i32, _vp, _vp, _i64, _vp],
+    "mxlo_householder_mul_c": [_vp, _i32, _vp, _vp, _vp, _i64, _dbl, _dbl, _dbl, _dbl, _i32],
     "mxlo_householder_mul": [_vp, _i32, _vp, _vp, _vp, _i64, _dbl, _dbl, _i32],
     "mxlo_dot": [_vp, _i32, _vp, _vp, _i64, _vp],
     "mxlo_householder_apply": [_vp, _i32, _vp, _vp, _vp, _i64, _dbl, _dbl, _i32, _vp],
@@ -117,6 +125,7 @@ _PROTOS = {
     "mxlo_blockdiag_mul": [_vp, _vp, _vp, _dbl, _dbl, _i32, _i32],
     "mxlo_blockdiag_destroy": [_vp],
     "mxlo_kron_mul": [_vp, _i32, _vp, _vp, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _vp, _dbl, _dbl, _i32, _i32],
+    "mxlo_kron_mul_ex": [_vp, _i32, _vp, _vp, _i64, _i64, _i64, _i32, _vp, _i64, _i64, _i64, _i32, _vp, _vp, _dbl, _dbl, _i32],
     "mxlo_kron_diag_mul": [_vp, _i32, _vp, _vp, _i64, _vp, _i64, _vp, _dbl, _dbl, _i32],
     "mxlo_gemv": [_vp, _i32, _vp, _vp, _i64, _i64, _i64, _vp, _dbl, _dbl, _i32, _i32],
     "mxlo_diagqn_push": [_vp, _i32, _i32, _vp, _vp, _vp, _i64, C.POINTER(_i32)],

@@ -111,8 +111,30 @@ struct DeviceGuard {
 typedef double f64x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// Complex element, laid out as Julia's Complex{R} / C's R _Complex: (re, im) adjacent.
+template <typename R>
+struct alignas(2 * sizeof(R)) cx {
+  R re, im;
+  __host__ __device__ constexpr cx(R r = R(0), R i = R(0)) : re(r), im(i) {}
+};
+template <typename T>
+struct is_cx : std::false_type {};
+template <typename R>
+struct is_cx<cx<R>> : std::true_type {};
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
 template <typename T>
 struct Vec16;
+template <>
+struct Vec16<cx<double>> {   // one ComplexF64 per 16-byte access
+  using type = f64x2;
+  static constexpr int N = 1;
+};
+template <>
+struct Vec16<cx<float>> {    // two ComplexF32
+  using type = f32x4;
+  static constexpr int N = 2;
+};
 template <>
 struct Vec16<double> {
   using type = f64x2;

@@ -605,21 +605,20 @@ int32_t hermitian_t(mxlo_ctx *ctx, T *res, const T *d, const T *A, int64_t lda, 
   });
 }
 
+// kron(opA, opB) * x with opA = A or A^T, opB = B or B^T of the STORED column-major matrices (src/kron.jl:14-40):
+//   opA is m x n, opB is p x q;  X = reshape(x, q, n);  Ut = opA * X^T (m x q);  R = opB * Ut^T (p x m);
+//   res = alpha*vec(R) + beta*res.
+// Both products have a B' operand that is N-contiguous (X as stored; Ut as just written), and an A operand that is
+// M-contiguous (factor taken as stored) or K-contiguous (factor taken transposed): the two layouts of the DMA kernel,
+// so prod!, tprod!, ctprod! and row-major (transposed-in-place) factors all run at the same rate, copy-free.
 template <typename T>
-int32_t kron_t(mxlo_ctx *ctx, T *res, const T *A, int64_t m, int64_t n, int64_t lda, const T *B,
-               int64_t p, int64_t q, int64_t ldb, const T *x, T *work, double alpha, double beta,
-               int32_t mode, int32_t flags) {
-  if (mode == MXLO_OP_N) {
-    // X = reshape(x, q, n);  Ut = A * X^T (m x q)  [= (X * A^T)^T];  R = B * Ut^T (p x m);
-    // res = alpha*vec(R) + beta*res. Both products are (N,T): every operand is contiguous along its
-    // non-K dimension -> the fast kernel.
-    MXLO_TRY(gemm<T>(ctx, work, m, A, lda, false, x, q, true, m, q, n, 1.0, 0.0, 0));
-    return gemm<T>(ctx, res, p, B, ldb, false, work, m, true, p, m, q, alpha, beta, flags);
-  }
-  // X = reshape(x, p, m);  Ut = A^T * X^T (n x p)  [= (X * A)^T];  R = B^T * Ut^T (q x n).
-  // A and B enter transposed, i.e. K-contiguous in place: the DMA kernel's second A layout (no transposed copies).
-  MXLO_TRY(gemm<T>(ctx, work, n, A, lda, true, x, p, true, n, p, m, 1.0, 0.0, 0));
-  return gemm<T>(ctx, res, q, B, ldb, true, work, n, true, q, n, p, alpha, beta, flags);
+int32_t kron_t(mxlo_ctx *ctx, T *res, const T *A, int64_t am, int64_t an, int64_t lda, bool trans_a, const T *B,
+               int64_t bp, int64_t bq, int64_t ldb, bool trans_b, const T *x, T *work, double alpha, double beta,
+               int32_t flags) {
+  const int64_t m = trans_a ? an : am, n = trans_a ? am : an;
+  const int64_t p = trans_b ? bq : bp, q = trans_b ? bp : bq;
+  MXLO_TRY(gemm<T>(ctx, work, m, A, lda, trans_a, x, q, true, m, q, n, 1.0, 0.0, 0));
+  return gemm<T>(ctx, res, p, B, ldb, trans_b, work, m, true, p, m, q, alpha, beta, flags);
 }
 
 }  // namespace
@@ -656,22 +655,31 @@ MXLO_API int32_t mxlo_hermitian_mul(mxlo_ctx *ctx, int32_t dtype, void *res, con
   return hermitian_t<float>(ctx, (float *)res, (const float *)d, (const float *)A, lda, (const float *)v, n, alpha, beta, flags);
 }
 
+MXLO_API int32_t mxlo_kron_mul_ex(mxlo_ctx *ctx, int32_t dtype, void *res, const void *A, int64_t am, int64_t an,
+                                  int64_t lda, int32_t trans_a, const void *B, int64_t bp, int64_t bq, int64_t ldb,
+                                  int32_t trans_b, const void *x, void *work, double alpha, double beta,
+                                  int32_t flags) {
+  MXLO_REQUIRE(ctx, MXLO_EINVAL, "mxlo_kron_mul_ex: ctx is NULL");
+  MXLO_DEVICE_GUARD(ctx);
+  MXLO_REQUIRE(dtype == MXLO_F64 || dtype == MXLO_F32, MXLO_EINVAL, "bad dtype");
+  MXLO_REQUIRE(am >= 0 && an >= 0 && bp >= 0 && bq >= 0, MXLO_ESHAPE, "mxlo_kron_mul_ex: negative size");
+  MXLO_REQUIRE(lda >= (am > 1 ? am : 1) && ldb >= (bp > 1 ? bp : 1), MXLO_ESHAPE, "mxlo_kron_mul_ex: bad leading dimension");
+  const int64_t m = trans_a ? an : am, p = trans_b ? bq : bp;
+  if (m * p == 0) return MXLO_OK;
+  MXLO_REQUIRE(res && A && B && x && work, MXLO_EINVAL, "mxlo_kron_mul_ex: NULL operand");
+  eff_ab(dtype, flags, alpha, beta);
+  if (dtype == MXLO_F64)
+    return kron_t<double>(ctx, (double *)res, (const double *)A, am, an, lda, trans_a != 0, (const double *)B, bp, bq,
+                          ldb, trans_b != 0, (const double *)x, (double *)work, alpha, beta, flags);
+  return kron_t<float>(ctx, (float *)res, (const float *)A, am, an, lda, trans_a != 0, (const float *)B, bp, bq, ldb,
+                       trans_b != 0, (const float *)x, (float *)work, alpha, beta, flags);
+}
+
 MXLO_API int32_t mxlo_kron_mul(mxlo_ctx *ctx, int32_t dtype, void *res, const void *A, int64_t m,
                                int64_t n, int64_t lda, const void *B, int64_t p, int64_t q,
                                int64_t ldb, const void *x, void *work, double alpha, double beta,
                                int32_t op_mode, int32_t flags) {
-  MXLO_REQUIRE(ctx, MXLO_EINVAL, "mxlo_kron_mul: ctx is NULL");
-  MXLO_DEVICE_GUARD(ctx);
-  MXLO_REQUIRE(dtype == MXLO_F64 || dtype == MXLO_F32, MXLO_EINVAL, "bad dtype");
-  MXLO_REQUIRE(m >= 0 && n >= 0 && p >= 0 && q >= 0, MXLO_ESHAPE, "mxlo_kron_mul: negative size");
   MXLO_REQUIRE(op_mode >= MXLO_OP_N && op_mode <= MXLO_OP_C, MXLO_EINVAL, "bad op_mode");
-  const int64_t nres = op_mode == MXLO_OP_N ? m * p : n * q;
-  if (nres == 0) return MXLO_OK;
-  MXLO_REQUIRE(res && A && B && x && work, MXLO_EINVAL, "mxlo_kron_mul: NULL operand");
-  eff_ab(dtype, flags, alpha, beta);
-  if (dtype == MXLO_F64)
-    return kron_t<double>(ctx, (double *)res, (const double *)A, m, n, lda, (const double *)B, p, q, ldb,
-                          (const double *)x, (double *)work, alpha, beta, op_mode, flags);
-  return kron_t<float>(ctx, (float *)res, (const float *)A, m, n, lda, (const float *)B, p, q, ldb,
-                       (const float *)x, (float *)work, alpha, beta, op_mode, flags);
+  const int32_t tr = op_mode == MXLO_OP_N ? 0 : 1;   // tprod!/ctprod!: both factors transposed (real dtypes)
+  return mxlo_kron_mul_ex(ctx, dtype, res, A, m, n, lda, tr, B, p, q, ldb, tr, x, work, alpha, beta, flags);
 }

@@ -43,14 +43,32 @@ struct VecOf<float, 4> {
   using type = f32x4;
 };
 
+// complex elements travel as plain float/double vectors (nontemporal builtins take scalar/vector types only)
+template <>
+struct VecOf<cx<double>, 1> {
+  using type = f64x2;
+};
+template <>
+struct VecOf<cx<float>, 1> {
+  using type = f32x2;
+};
+template <>
+struct VecOf<cx<float>, 2> {
+  using type = f32x4;
+};
+
 template <typename T, int VEC>
 __device__ __forceinline__ T vget(const typename VecOf<T, VEC>::type &v, int i) {
-  if constexpr (VEC == 1) return v;
+  if constexpr (is_cx<T>::value) return T(v[2 * i], v[2 * i + 1]);
+  else if constexpr (VEC == 1) return v;
   else return v[i];
 }
 template <typename T, int VEC>
 __device__ __forceinline__ void vset(typename VecOf<T, VEC>::type &v, int i, T x) {
-  if constexpr (VEC == 1) v = x;
+  if constexpr (is_cx<T>::value) {
+    v[2 * i] = x.re;
+    v[2 * i + 1] = x.im;
+  } else if constexpr (VEC == 1) v = x;
   else v[i] = x;
 }
 

@@ -14,14 +14,22 @@ import torch
 from . import _lib
 
 _DT = {torch.float64: _lib.F64, torch.float32: _lib.F32}
+_DTC = {torch.complex128: _lib.C64, torch.complex64: _lib.C32}
 
 
-def dtype_code(dtype: torch.dtype) -> int:
-    try:
+def dtype_code(dtype: torch.dtype, complex_ok: bool = False) -> int:
+    """MXLO_F64 / MXLO_F32; with ``complex_ok`` also MXLO_C64 / MXLO_C32 (the elementwise leaves, opHouseholder,
+    restriction/extension and the wrapper routing are instantiated for ComplexF64 / ComplexF32)."""
+    if dtype in _DT:
         return _DT[dtype]
-    except KeyError:
-        raise TypeError(f"the MI355X path is instantiated for float64/float32 only, got {dtype} "
-                        "(complex/BigFloat/Float16 stay on the reference CPU path)") from None
+    if complex_ok and dtype in _DTC:
+        return _DTC[dtype]
+    if dtype in _DTC:
+        raise TypeError(f"this leaf of the MI355X path is instantiated for float64/float32 only, got {dtype} "
+                        "(complex: opDiagonal, opEye, opZeros, opHouseholder, restriction/extension and the "
+                        "adjoint/transpose/conj wrappers)")
+    raise TypeError(f"the MI355X path is instantiated for float64/float32 (+ complex128/complex64 elementwise "
+                    f"leaves) only, got {dtype} (BigFloat/Float16 stay on the reference CPU path)")
 
 
 @dataclass(frozen=True)

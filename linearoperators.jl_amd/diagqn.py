@@ -16,7 +16,7 @@ import torch
 from . import _lib
 from .device import Storage, check_vec, dtype_code, get_ctx, ptr
 from .leaves import mulSquareOpDiagonal
-from .operators import AbstractLinearOperator
+from .operators import touched, AbstractLinearOperator
 
 
 class _DiagonalQN(AbstractLinearOperator):
@@ -45,6 +45,7 @@ class _DiagonalQN(AbstractLinearOperator):
                   self.nrow, C.byref(st))
         if st.value != 0:
             raise RuntimeError(self._zero_msg)           # ErrorException in the reference
+        touched(self.d)                                  # d changed behind torch's back: bump its version counter
         return self
 
     _zero_msg = "Cannot update DiagonalQN operator with s=0"
@@ -52,6 +53,11 @@ class _DiagonalQN(AbstractLinearOperator):
     def _reset_data(self):                               # op.d .= one(T) (:72)
         ctx = get_ctx(self.d.device)
         _lib.call("mxlo_fill", ctx.handle, dtype_code(self.eltype), ptr(self.d), self.d.numel(), 1.0)
+        touched(self.d)
+
+    @property
+    def _deps(self):
+        return (self.d,)
 
 
 class DiagonalPSBType(_DiagonalQN):

@@ -18,8 +18,8 @@ import torch
 
 from . import _lib
 from .device import Storage, check_vec, dtype_code, get_ctx, ptr, storage_of
-from .operators import (AbstractLinearOperator, LinearOperator, LinearOperatorException, adjoint, compose,
-                        issymmetric, ishermitian, mul, scalar_flags, storage_type, to_dense, transpose)
+from .operators import (AbstractLinearOperator, LinearOperator, LinearOperatorException, _c4, adjoint, compose,
+                        issymmetric, ishermitian, mul, scalar_flags, state_version, storage_type, to_dense, transpose)
 
 
 def _default_device() -> torch.device:
@@ -34,6 +34,10 @@ def _S(T: torch.dtype, S: Optional[Storage]) -> Storage:
 def mulOpEye(res, v, alpha, beta, n_min):
     """mulOpEye! — src/special-operators.jl:36-44 (tail gets `β` itself when β != 0)."""
     ctx = get_ctx(res.device)
+    if res.dtype.is_complex:
+        _lib.call("mxlo_eye_mul_c", ctx.handle, dtype_code(res.dtype, True), ptr(res), ptr(v), n_min, res.numel(),
+                  *_c4(alpha, beta), scalar_flags(res.dtype, alpha, beta) | _lib.TAIL_BETA)
+        return
     _lib.call("mxlo_eye_mul", ctx.handle, dtype_code(res.dtype), ptr(res), ptr(v), n_min, res.numel(),
               float(alpha), float(beta), scalar_flags(res.dtype, alpha, beta) | _lib.TAIL_BETA)
 
@@ -48,11 +52,13 @@ def opEye(T=torch.float64, nrow: Optional[int] = None, ncol: Optional[int] = Non
         prod = lambda res, v, a, b: mulOpEye(res, v, a, b, n)
         op = LinearOperator(T, n, n, True, True, prod, prod, prod, S=S)
         op._leaf = ("eye", n, n)
+        op._deps = ()
         return op
     n_min = min(nrow, ncol)
     prod = lambda res, v, a, b: mulOpEye(res, v, a, b, n_min)
     op = LinearOperator(T, nrow, ncol, False, False, prod, prod, prod, S=S)
     op._leaf = ("eye", nrow, ncol)
+    op._deps = ()
     return op
 
 
@@ -68,12 +74,19 @@ def opOnes(T=torch.float64, nrow: Optional[int] = None, ncol: Optional[int] = No
     if isinstance(T, int):
         T, nrow, ncol = torch.float64, T, nrow
     prod = lambda res, v, a, b: mulOpOnes(res, v, a, b)
-    return LinearOperator(T, nrow, ncol, nrow == ncol, nrow == ncol, prod, prod, prod, S=_S(T, S))
+    op = LinearOperator(T, nrow, ncol, nrow == ncol, nrow == ncol, prod, prod, prod, S=_S(T, S))
+    op._deps = ()
+    return op
 
 
 def mulOpZeros(res, v, alpha, beta):
     """mulOpZeros! — src/special-operators.jl:102-108."""
     ctx = get_ctx(res.device)
+    if res.dtype.is_complex:
+        b = complex(beta)
+        _lib.call("mxlo_zeros_mul_c", ctx.handle, dtype_code(res.dtype, True), ptr(res), res.numel(), b.real, b.imag,
+                  scalar_flags(res.dtype, 0, beta))
+        return
     _lib.call("mxlo_zeros_mul", ctx.handle, dtype_code(res.dtype), ptr(res), res.numel(), float(beta),
               scalar_flags(res.dtype, 0, beta))
 
@@ -85,46 +98,64 @@ def opZeros(T=torch.float64, nrow: Optional[int] = None, ncol: Optional[int] = N
     prod = lambda res, v, a, b: mulOpZeros(res, v, a, b)
     op = LinearOperator(T, nrow, ncol, nrow == ncol, nrow == ncol, prod, prod, prod, S=_S(T, S))
     op._leaf = ("zeros", nrow, ncol)
+    op._deps = ()
     return op
 
 
 # ----------------------------------------------------------------------------- opDiagonal
-def mulSquareOpDiagonal(res, d, v, alpha, beta):
-    """mulSquareOpDiagonal! — src/special-operators.jl:125-131."""
+def mulSquareOpDiagonal(res, d, v, alpha, beta, conj_d=False):
+    """mulSquareOpDiagonal! — src/special-operators.jl:125-131 (`conj_d`: the ctprod! closure passes conj.(d), :139-141)."""
     ctx = get_ctx(res.device)
     n = res.numel()
+    if res.dtype.is_complex:
+        _lib.call("mxlo_diag_mul_c", ctx.handle, dtype_code(res.dtype, True), ptr(res), ptr(d), ptr(v), n, n,
+                  *_c4(alpha, beta), scalar_flags(res.dtype, alpha, beta) | (_lib.CONJ_D if conj_d else 0))
+        return
     flags = scalar_flags(res.dtype, alpha, beta) | (_lib.D_SCALAR if d.numel() == 1 and n != 1 else 0)
     _lib.call("mxlo_diag_mul", ctx.handle, dtype_code(res.dtype), ptr(res), ptr(d), ptr(v), n, n, float(alpha),
               float(beta), flags)
 
 
-def mulOpDiagonal(res, d, v, alpha, beta, n_min):
+def mulOpDiagonal(res, d, v, alpha, beta, n_min, conj_d=False):
     """mulOpDiagonal! — src/special-operators.jl:144-151 (tail zeroed regardless of β)."""
     ctx = get_ctx(res.device)
+    if res.dtype.is_complex:
+        _lib.call("mxlo_diag_mul_c", ctx.handle, dtype_code(res.dtype, True), ptr(res), ptr(d), ptr(v), n_min,
+                  res.numel(), *_c4(alpha, beta), scalar_flags(res.dtype, alpha, beta) | (_lib.CONJ_D if conj_d else 0))
+        return
     _lib.call("mxlo_diag_mul", ctx.handle, dtype_code(res.dtype), ptr(res), ptr(d), ptr(v), n_min, res.numel(),
               float(alpha), float(beta), scalar_flags(res.dtype, alpha, beta))
 
 
 def opDiagonal(*args):
-    """opDiagonal(d) / opDiagonal(nrow, ncol, d) — src/special-operators.jl:133-165."""
+    """opDiagonal(d) / opDiagonal(nrow, ncol, d) — src/special-operators.jl:133-165: symmetric = true,
+    hermitian = isreal(d), ctprod! multiplies by conj.(d)."""
     if len(args) == 1:
         d = check_vec(args[0], "d")
-        dtype_code(d.dtype)
+        dtype_code(d.dtype, True)
         n = d.numel()
         prod = lambda res, v, a, b: mulSquareOpDiagonal(res, d, v, a, b)
-        # ctprod! uses conj.(d) == d for the real dtypes instantiated here (:140)
-        op = LinearOperator(d.dtype, n, n, True, True, prod, prod, prod, S=storage_of(d))
-        op._leaf = ("diag", d)
+        if d.dtype.is_complex:
+            ctprod = lambda res, w, a, b: mulSquareOpDiagonal(res, d, w, a, b, conj_d=True)      # conj.(d) (:140)
+            op = LinearOperator(d.dtype, n, n, True, False, prod, prod, ctprod, S=storage_of(d))  # isreal(d): a
+        else:                                                                                     # type property
+            op = LinearOperator(d.dtype, n, n, True, True, prod, prod, prod, S=storage_of(d))
+            op._leaf = ("diag", d)
+        op._deps = (d,)
         return op
     nrow, ncol, d = args
     d = check_vec(d, "d")
+    dtype_code(d.dtype, True)
     if nrow == ncol <= d.numel():
         return opDiagonal(d[:nrow].clone())       # d[1:nrow] copies in Julia (:157)
     n_min = min(nrow, ncol)
     if d.numel() < n_min:
         raise LinearOperatorException("shape mismatch")
     prod = lambda res, v, a, b: mulOpDiagonal(res, d, v, a, b, n_min)
-    return LinearOperator(d.dtype, nrow, ncol, False, False, prod, prod, prod, S=storage_of(d))
+    ctprod = (lambda res, w, a, b: mulOpDiagonal(res, d, w, a, b, n_min, conj_d=True)) if d.dtype.is_complex else prod
+    op = LinearOperator(d.dtype, nrow, ncol, False, False, prod, prod, ctprod, S=storage_of(d))
+    op._deps = (d,)
+    return op
 
 
 # ----------------------------------------------------------------------------- restriction / extension
@@ -195,7 +226,9 @@ def opRestriction(Idx, ncol: int, S: Optional[Storage] = None, device=None):
             ctx = get_ctx(res.device)
             _lib.call("mxlo_scatter_zero", ctx.handle, res.element_size(), ptr(res), res.numel(), ptr(u), ptr(sidx_d),
                       ptr(spos_d), sidx_d.numel())
-    return LinearOperator(torch.int64, nrow, ncol, False, False, prod, tprod, tprod, S=storage)
+    op = LinearOperator(torch.int64, nrow, ncol, False, False, prod, tprod, tprod, S=storage)
+    op._deps = ()          # the index set is copied at construction
+    return op
 
 
 def opExtension(Idx, ncol: int, S: Optional[Storage] = None, device=None):
@@ -207,8 +240,12 @@ def opExtension(Idx, ncol: int, S: Optional[Storage] = None, device=None):
 
 # ----------------------------------------------------------------------------- Householder / Hermitian
 def mulHouseholder(res, h, v, alpha, beta):
-    """mulHouseholder! — src/linalg.jl:77-83."""
+    """mulHouseholder! — src/linalg.jl:77-83 (complex h: LinearAlgebra.dot conjugates it)."""
     ctx = get_ctx(res.device)
+    if res.dtype.is_complex:
+        _lib.call("mxlo_householder_mul_c", ctx.handle, dtype_code(res.dtype, True), ptr(res), ptr(h), ptr(v),
+                  res.numel(), *_c4(alpha, beta), scalar_flags(res.dtype, alpha, beta))
+        return
     _lib.call("mxlo_householder_mul", ctx.handle, dtype_code(res.dtype), ptr(res), ptr(h), ptr(v), res.numel(),
               float(alpha), float(beta), scalar_flags(res.dtype, alpha, beta))
 
@@ -217,10 +254,12 @@ def opHouseholder(h: torch.Tensor):
     """opHouseholder(h) — src/linalg.jl:85-95: symmetric=isreal(h), hermitian=true, tprod!=nothing,
     ctprod!=prod!. (The reference hard-codes S=Vector{T}; here S follows h.)"""
     h = check_vec(h, "h")
-    dtype_code(h.dtype)
+    dtype_code(h.dtype, True)
     n = h.numel()
     prod = lambda res, v, a, b: mulHouseholder(res, h, v, a, b)
-    return LinearOperator(h.dtype, n, n, True, True, prod, None, prod, S=storage_of(h))
+    op = LinearOperator(h.dtype, n, n, not h.dtype.is_complex, True, prod, None, prod, S=storage_of(h))
+    op._deps = (h,)
+    return op
 
 
 def mulHermitian(res, d, A, v, alpha, beta):
@@ -260,7 +299,9 @@ def opHermitian(*args):
         A = _colmajor(A.to(U))
     dtype_code(U)
     prod = lambda res, v, a, b: mulHermitian(res, d, A, v, a, b)
-    return LinearOperator(U, m, m, True, True, prod, None, None, S=Storage(U, A.device))
+    op = LinearOperator(U, m, m, True, True, prod, None, None, S=Storage(U, A.device))
+    op._deps = (d, A)
+    return op
 
 
 # ----------------------------------------------------------------------------- dense matrix operator
@@ -283,6 +324,7 @@ def LinearOperatorFromMatrix(M: torch.Tensor, symmetric: bool = False, hermitian
     op = LinearOperator(M.dtype, nrow, ncol, symmetric, hermitian, prod, tprod, ctprod,
                         S=S if S is not None else Storage(M.dtype, M.device))
     op._leaf = ("dense", M, ld)
+    op._deps = (M,)
     return op
 
 
@@ -353,6 +395,7 @@ def BlockDiagonalOperator(*ops, S: Optional[Storage] = None):
         ctprod = lambda y, x, a, b: bd(y, x, a, b, _lib.OP_C)
         op = LinearOperator(T, nrow, ncol, symm, herm, prod, tprod, ctprod, S=S)
         op._keepalive = (handle, keep, ops)
+        op._deps = tuple(ops)
         return op
 
     def prod(y, x, a, b):        # :258-267
@@ -379,7 +422,9 @@ def BlockDiagonalOperator(*ops, S: Optional[Storage] = None):
             k += n
             j += m
 
-    return LinearOperator(T, nrow, ncol, symm, herm, prod, tprod, ctprod, S=S)
+    op = LinearOperator(T, nrow, ncol, symm, herm, prod, tprod, ctprod, S=S)
+    op._deps = tuple(ops)
+    return op
 
 
 # ----------------------------------------------------------------------------- kron
@@ -387,8 +432,9 @@ def kron(A, B):
     """kron(A, B) — src/kron.jl:10-49: (A ⊗ B) x = vec(B X Aᵀ).
 
     The reference rebuilds a composite operator and materialises it with `m` single-vector products on
-    every apply; here both factors are dense device matrices (operators are materialised ONCE at
-    construction with `Matrix(op)`, src/abstract.jl:282-292) and an apply is two MFMA GEMMs."""
+    every apply. Here an apply is two MFMA GEMMs on dense device matrices: matrix factors are aliased in place
+    (row-major ones through a transposition flag), operator factors are materialised with `Matrix(op)`
+    (src/abstract.jl:282-292) and re-materialised whenever their state changed — see `_KronFactor`."""
     def diag_of(X):
         """(is_diagonal_like, d or None, n) for opDiagonal / square opEye leaves."""
         leaf = getattr(X, "_leaf", None) if not isinstance(X, torch.Tensor) else None
@@ -406,55 +452,115 @@ def kron(A, B):
         dts = [t.dtype for t in (dA, dB) if t is not None] or [A.eltype if A.eltype.is_floating_point else torch.float64]
         Td = dts[0] if len(dts) == 1 else torch.promote_types(dts[0], dts[1])
         dtype_code(Td)
-        dA_ = dA.to(Td) if dA is not None else None
-        dB_ = dB.to(Td) if dB is not None else None
-        dev = next((t.device for t in (dA_, dB_) if t is not None), storage_type(A).device)
+        dev = next((t.device for t in (dA, dB) if t is not None), storage_type(A).device)
+        conv = {}     # promoted copies of a lower-precision diagonal, refreshed when the source changed
+
+        def dvec(d):
+            if d is None or d.dtype == Td:
+                return d                              # aliased: later updates of d are seen, like the reference
+            tok = state_version(d)
+            if conv.get(id(d), (None, None))[0] != tok:
+                conv[id(d)] = (tok, d.to(Td))
+            return conv[id(d)][1]
 
         def kd(res, x, a, b):
             ctx = get_ctx(res.device)
-            _lib.call("mxlo_kron_diag_mul", ctx.handle, dtype_code(Td), ptr(res), ptr(dA_), mA, ptr(dB_), pB, ptr(x),
-                      float(a), float(b), scalar_flags(res.dtype, a, b))
+            _lib.call("mxlo_kron_diag_mul", ctx.handle, dtype_code(Td), ptr(res), ptr(dvec(dA)), mA, ptr(dvec(dB)), pB,
+                      ptr(x), float(a), float(b), scalar_flags(res.dtype, a, b))
 
-        return LinearOperator(Td, mA * pB, mA * pB, True, True, kd, kd, kd, S=Storage(Td, dev))
+        op = LinearOperator(Td, mA * pB, mA * pB, True, True, kd, kd, kd, S=Storage(Td, dev))
+        op._deps = (A, B)
+        return op
 
-    def dense_of(X):
-        if isinstance(X, torch.Tensor):
-            return _colmajor(X), False, False
-        leaf = getattr(X, "_leaf", None)
-        if leaf is not None and leaf[0] == "dense":
-            return leaf[1], issymmetric(X), ishermitian(X)
-        return _colmajor(to_dense(X)), issymmetric(X), ishermitian(X)
-
-    Am, Asym, Aherm = dense_of(A)
-    Bm, Bsym, Bherm = dense_of(B)
-    T = torch.promote_types(Am.dtype, Bm.dtype)
+    fA, fB = _KronFactor(A), _KronFactor(B)
+    T = torch.promote_types(fA.dtype, fB.dtype)
     dtype_code(T)
-    if Am.dtype != T:
-        Am = _colmajor(Am.to(T))
-    if Bm.dtype != T:
-        Bm = _colmajor(Bm.to(T))
-    m, n = Am.shape
-    p, q = Bm.shape
-    # tprod!/ctprod! (transpose(B) * X * A, src/kron.jl:24-40) are the prod! formula applied to the
-    # transposed factors; transposed copies are made ONCE here so that both directions run the
-    # (N,T) MFMA GEMM path whose operands are contiguous along their non-K dimension.
-    At, Bt = _colmajor(Am.t()), _colmajor(Bm.t())
-    work = torch.empty(max(q * m, p * n), dtype=T, device=Am.device)
+    fA.T, fB.T = T, T
+    m, n = fA.shape
+    p, q = fB.shape
+    dev = fA.device
+    work = torch.empty(max(q * m, p * n), dtype=T, device=dev)
 
-    def ld(M):
-        return M.stride(1) if M.shape[1] > 1 else max(1, M.shape[0])
-
-    def km(res, x, a, b, A_, B_):
+    def km(res, x, a, b, trans):
+        # prod!: kron(A, B);  tprod!/ctprod! (real eltypes): the same formula on the transposed factors
+        # (src/kron.jl:24-40). The factors are read in place either way: a transposition is a flag of the GEMM
+        # kernel's operand layout, not a copy.
         ctx = get_ctx(res.device)
-        _lib.call("mxlo_kron_mul", ctx.handle, dtype_code(T), ptr(res), ptr(A_), A_.shape[0], A_.shape[1], ld(A_),
-                  ptr(B_), B_.shape[0], B_.shape[1], ld(B_), ptr(x), ptr(work), float(a), float(b), _lib.OP_N,
-                  scalar_flags(res.dtype, a, b))
+        As, ta = fA.get()
+        Bs, tb = fB.get()
+        _lib.call("mxlo_kron_mul_ex", ctx.handle, dtype_code(T), ptr(res), ptr(As), As.shape[0], As.shape[1], _ld(As),
+                  ta ^ trans, ptr(Bs), Bs.shape[0], Bs.shape[1], _ld(Bs), tb ^ trans, ptr(x), ptr(work), float(a),
+                  float(b), scalar_flags(res.dtype, a, b))
 
-    prod = lambda res, x, a, b: km(res, x, a, b, Am, Bm)
-    tprod = lambda res, x, a, b: km(res, x, a, b, At, Bt)
-    ctprod = lambda res, x, a, b: km(res, x, a, b, At, Bt)
-    return LinearOperator(T, m * p, n * q, Asym and Bsym, Aherm and Bherm, prod, tprod, ctprod,
-                          S=Storage(T, Am.device))
+    prod = lambda res, x, a, b: km(res, x, a, b, 0)
+    tprod = lambda res, x, a, b: km(res, x, a, b, 1)
+    op = LinearOperator(T, m * p, n * q, fA.symmetric and fB.symmetric, fA.hermitian and fB.hermitian, prod, tprod,
+                        tprod, S=Storage(T, dev))
+    op._deps = (A, B)
+    return op
+
+
+def _ld(M: torch.Tensor) -> int:
+    return M.stride(1) if M.shape[1] > 1 else max(1, M.shape[0])
+
+
+class _KronFactor:
+    """One factor of `kron`: hands `mxlo_kron_mul_ex` a column-major STORED matrix plus a transposition flag.
+
+    * a matrix (or a dense `LinearOperator(M)`) is aliased, never copied: column-major storage is passed as is,
+      row-major storage (torch's default) is its own transpose stored column-major -> flag 1. Later in-place
+      updates of the caller's matrix are therefore seen, like in the reference, which keeps `A` itself
+      (src/kron.jl:10-22). Only a dtype promotion or an exotic stride forces a converted copy, and that copy is
+      refreshed whenever the source tensor's version counter moved.
+    * any other operator is materialised with `Matrix(op)` (src/abstract.jl:282-292), which the reference does on
+      EVERY apply (src/kron.jl:18). Here the dense image is cached and rebuilt when the operator's state token
+      (`operators.state_version`: push!/reset! counters, tensor versions of every leaf underneath) changed; an
+      operator whose state cannot be tracked is rebuilt on every apply, exactly like the reference."""
+
+    def __init__(self, X):
+        self.T = None
+        if isinstance(X, torch.Tensor):
+            if X.dim() != 2:
+                raise ValueError("matrix expected")
+            self.src, self.op = X, None
+            self.symmetric = self.hermitian = False
+        else:
+            leaf = getattr(X, "_leaf", None)
+            if leaf is not None and leaf[0] == "dense":
+                self.src, self.op = leaf[1], None
+            else:
+                self.src, self.op = None, X
+            self.symmetric, self.hermitian = issymmetric(X), ishermitian(X)
+        if self.src is not None:
+            self.shape, self.dtype, self.device = tuple(self.src.shape), self.src.dtype, self.src.device
+        else:
+            self.shape = tuple(self.op.shape)
+            dt = self.op.eltype
+            self.dtype = dt if dt.is_floating_point else torch.float64
+            self.device = storage_type(self.op).device
+        self._cache = None
+        self._token = object()      # never equal to a real token
+
+    def get(self):
+        if self.src is not None:
+            M = self.src
+            if M.dtype == self.T:
+                m, n = M.shape
+                if M.stride(0) == 1 and (n == 1 or M.stride(1) >= max(1, m)):
+                    return M, 0                       # column-major as stored
+                if M.stride(1) == 1 and (m == 1 or M.stride(0) >= max(1, n)):
+                    return M.t(), 1                   # row-major = the transpose stored column-major
+            tok = state_version(M)
+            if self._cache is None or tok != self._token:
+                self._cache = M.to(self.T).t().contiguous().t()      # column-major converted copy
+                self._token = tok
+            return self._cache, 0
+        tok = state_version(self.op)
+        if self._cache is None or tok is None or tok != self._token:
+            D = to_dense(self.op)                     # column-major view of a fresh buffer
+            self._cache = D if D.dtype == self.T else D.to(self.T).t().contiguous().t()
+            self._token = tok
+        return self._cache, 0
 
 
 # ----------------------------------------------------------------------------- ShiftedOperator (SURVEY §8f-3)
@@ -523,6 +629,10 @@ class ShiftedOperatorType(AbstractLinearOperator):
     @property
     def S(self):                                                       # storage_type(op.data.H) (:96)
         return storage_type(self.data.H)
+
+    def _state_version(self):
+        v = state_version(self.data.H)
+        return None if v is None else ("shift", v, float(self.data.sigma))
 
 
 def ShiftedOperator(H, sigma=0):

@@ -31,36 +31,64 @@ class LinearOperatorException(Exception):
 
 # ----------------------------------------------------------------------------- scalars
 def _is_f64_scalar(x) -> bool:
-    """Julia `Float64`: a Python float or a float64 NumPy/torch scalar. Python ints are Julia
-    `Int` (never widen a Float32 product); float32 scalars stay Float32."""
+    """Julia `Float64` / `ComplexF64`: a Python float / complex or a float64 / complex128 NumPy/torch scalar.
+    Python ints are Julia `Int` (never widen a Float32 product); float32 / complex64 scalars stay 32-bit."""
     if isinstance(x, bool) or isinstance(x, (int, np.integer)):
         return False
-    if isinstance(x, float):
+    if isinstance(x, (float, complex)):
         return True
     if isinstance(x, np.floating):
         return x.dtype == np.float64
+    if isinstance(x, np.complexfloating):
+        return x.dtype == np.complex128
     if isinstance(x, torch.Tensor):
-        return x.dtype == torch.float64
+        return x.dtype in (torch.float64, torch.complex128)
     return True
 
 
+def _is_complex_scalar(x) -> bool:
+    if isinstance(x, torch.Tensor):
+        return x.dtype.is_complex
+    return isinstance(x, (complex, np.complexfloating))
+
+
 def scalar_flags(dtype: torch.dtype, alpha, beta) -> int:
-    """MXLO_ALPHA_F64 / MXLO_BETA_F64: which caller scalars are Float64 next to Float32 data. Julia evaluates
-    the α-term in promote_type(typeof(α), T) and the β-term in promote_type(typeof(β), T), each on its own
-    (src/special-operators.jl:126-129; SURVEY §8a, mixed precision), so the two flags are independent."""
-    if dtype != torch.float32:
-        return 0
-    return (_lib.ALPHA_F64 if _is_f64_scalar(alpha) else 0) | (_lib.BETA_F64 if _is_f64_scalar(beta) else 0)
+    """MXLO_ALPHA_F64 / MXLO_BETA_F64: which caller scalars are Float64 next to Float32 (ComplexF32) data. Julia
+    evaluates the α-term in promote_type(typeof(α), T) and the β-term in promote_type(typeof(β), T), each on its own
+    (src/special-operators.jl:126-129; SURVEY §8a, mixed precision), so the two flags are independent. Complex
+    data additionally gets MXLO_ALPHA_REAL / MXLO_BETA_REAL for Real scalars (Real*Complex is componentwise)."""
+    fl = 0
+    if dtype in (torch.float32, torch.complex64):
+        fl |= (_lib.ALPHA_F64 if _is_f64_scalar(alpha) else 0) | (_lib.BETA_F64 if _is_f64_scalar(beta) else 0)
+    if dtype.is_complex:
+        fl |= (0 if _is_complex_scalar(alpha) else _lib.ALPHA_REAL) | (0 if _is_complex_scalar(beta) else _lib.BETA_REAL)
+    return fl
+
+
+def conj_scalar(x):
+    """conj(α) of the wrapper routing (src/adjtrans.jl:131,134): the identity on Real scalars."""
+    return x.conjugate() if _is_complex_scalar(x) else x
+
+
+def _c4(alpha, beta):
+    """(re, im, re, im) doubles of two caller scalars for the `_c` entry points."""
+    a, b = complex(alpha), complex(beta)
+    return a.real, a.imag, b.real, b.imag
 
 
 def one(dtype: torch.dtype):
-    """one(T): Float32 -> float32 scalar, Float64 -> Python float, integer eltypes -> Python int."""
+    """one(T): Float32 -> float32 scalar, Float64 -> Python float, ComplexF64 -> Python complex,
+    ComplexF32 -> complex64 scalar, integer eltypes -> Python int."""
+    if dtype.is_complex:
+        return np.complex64(1) if dtype == torch.complex64 else complex(1.0)
     if not dtype.is_floating_point:
         return 1
     return np.float32(1) if dtype == torch.float32 else 1.0
 
 
 def zero(dtype: torch.dtype):
+    if dtype.is_complex:
+        return np.complex64(0) if dtype == torch.complex64 else complex(0.0)
     if not dtype.is_floating_point:
         return 0
     return np.float32(0) if dtype == torch.float32 else 0.0
@@ -222,7 +250,7 @@ class AbstractLinearOperator:
 
 
 def _is_number(x) -> bool:
-    return isinstance(x, (int, float, np.integer, np.floating)) and not isinstance(x, bool)
+    return isinstance(x, (int, float, complex, np.integer, np.floating, np.complexfloating)) and not isinstance(x, bool)
 
 
 class LinearOperator(AbstractLinearOperator):
@@ -339,6 +367,10 @@ def _axpby(res, Mv, alpha, beta):
     """res .= α .* Mv .+ β .* res (src/operations.jl:18) on the device."""
     ctx = get_ctx(res.device)
     n = res.numel()
+    if res.dtype.is_complex:
+        _lib.call("mxlo_eye_mul_c", ctx.handle, dtype_code(res.dtype, True), ptr(res), ptr(Mv), n, n,
+                  *_c4(alpha, beta), scalar_flags(res.dtype, alpha, beta))
+        return
     _lib.call("mxlo_eye_mul", ctx.handle, dtype_code(res.dtype), ptr(res), ptr(Mv), n, n, float(alpha),
               float(beta), scalar_flags(res.dtype, alpha, beta))
 
@@ -346,8 +378,54 @@ def _axpby(res, Mv, alpha, beta):
 def _scale(res, alpha):
     """res .*= α (src/operations.jl:14)."""
     ctx = get_ctx(res.device)
+    if res.dtype.is_complex:
+        a = complex(alpha)
+        _lib.call("mxlo_scale_c", ctx.handle, dtype_code(res.dtype, True), ptr(res), res.numel(), a.real, a.imag,
+                  scalar_flags(res.dtype, alpha, 0))
+        return
     _lib.call("mxlo_scale", ctx.handle, dtype_code(res.dtype), ptr(res), res.numel(), float(alpha),
               scalar_flags(res.dtype, alpha, 0))
+
+
+def conj_into(res, v):
+    """res .= conj.(v) (res may be v: conj!) — the identity, without a launch, for real element types."""
+    if not v.dtype.is_complex:
+        if res.data_ptr() != v.data_ptr():
+            res.copy_(v)
+        return res
+    ctx = get_ctx(res.device)
+    _lib.call("mxlo_conj_c", ctx.handle, dtype_code(v.dtype, True), ptr(res), ptr(v), v.numel())
+    return res
+
+
+# ----------------------------------------------------------------------------- operator state versions
+def touched(t: torch.Tensor):
+    """libmxlo writes through raw pointers, which torch's in-place version counter does not see: bump it by hand so
+    that operators built on `t` (and kron factors materialised from them) notice the change."""
+    try:
+        torch.autograd.graph.increment_version(t)
+    except Exception:      # pragma: no cover  (inference tensors etc.)
+        pass
+    return t
+
+
+def state_version(x):
+    """A hashable token that changes whenever the action of `x` (an operator or a tensor) may have changed, or
+    None when that cannot be known (an operator built from opaque user closures). `kron` re-materialises a
+    non-matrix factor only when its token changed; with None it re-materialises on every apply, which is what the
+    reference always does (src/kron.jl:14-22)."""
+    if isinstance(x, torch.Tensor):
+        return ("t", x.data_ptr(), x._version)
+    if isinstance(x, _Wrapper):
+        return state_version(x.parent)
+    f = getattr(x, "_state_version", None)
+    if callable(f):
+        return f()
+    deps = getattr(x, "_deps", None)
+    if deps is None:
+        return None
+    vs = tuple(state_version(d) for d in deps)
+    return None if any(v is None for v in vs) else vs
 
 
 def prod3(res, prod, v, alpha, beta, Mv):
@@ -375,7 +453,13 @@ def mul(res: torch.Tensor, op, v: torch.Tensor, alpha=None, beta=None):
     if isinstance(op, TransposeLinearOperator):
         return _mul_transpose(res, op, v, alpha, beta)
     if isinstance(op, ConjugateLinearOperator):
-        return mul(res, op.parent, v, alpha, beta)    # real eltypes: conj! is the identity
+        # src/adjtrans.jl:226-249: mul!(res, p, conj.(v), α, β); conj!(res) — α, β and the incoming res are NOT
+        # conjugated (reference behaviour, reproduced); real v skips the conj.(v) allocation (:238-249)
+        vc = conj_into(torch.empty_like(v), v) if v.dtype.is_complex else v
+        mul(res, op.parent, vc, alpha, beta)
+        if res.dtype.is_complex:
+            conj_into(res, res)
+        return res
     if not (v.shape[0] == op.size(2) and res.shape[0] == op.size(1)):
         raise LinearOperatorException("shape mismatch")
     op.nprod += 1                                      # increase_nprod!
@@ -385,7 +469,7 @@ def mul(res: torch.Tensor, op, v: torch.Tensor, alpha=None, beta=None):
         if not (beta == 0 or op.Mv.numel() != 0):
             allocate_vectors_args3(op)
         prod3(res, op.prod, v, alpha, beta, op.Mv)
-    return res
+    return touched(res)
 
 
 def _call_t(res, f, v, alpha, beta, p):
@@ -395,11 +479,23 @@ def _call_t(res, f, v, alpha, beta, p):
         if not (beta == 0 or p.Mtu.numel() != 0):
             allocate_vectors_args3(p)
         prod3(res, f, v, alpha, beta, p.Mtu)
-    return res
+    return touched(res)
+
+
+def _call_conj_sandwich(res, f, v, alpha, beta, p):
+    """conj!(res); f(res, conj.(v), conj(α), conj(β)); conj!(res) — src/adjtrans.jl:127-136, 193-204. For real
+    element types every conj is the identity and nothing is launched or allocated."""
+    if res.dtype.is_complex:
+        conj_into(res, res)
+    vc = conj_into(torch.empty_like(v), v) if v.dtype.is_complex else v   # conj.(v) allocates in the reference too
+    _call_t(res, f, vc, conj_scalar(alpha), conj_scalar(beta), p)
+    if res.dtype.is_complex:
+        conj_into(res, res)
+    return touched(res)
 
 
 def _mul_adjoint(res, op, v, alpha, beta):
-    """src/adjtrans.jl:90-137 (real eltypes: conj!/conj.() are identities and are elided)."""
+    """src/adjtrans.jl:90-137."""
     p = op.parent
     if not (v.shape[0] == p.size(1) and res.shape[0] == p.size(2)):
         raise LinearOperatorException("shape mismatch")
@@ -417,7 +513,7 @@ def _mul_adjoint(res, op, v, alpha, beta):
             raise LinearOperatorException("unable to infer conjugate transpose operator")
     else:
         p.ntprod += 1
-    return _call_t(res, tprod, v, alpha, beta, p)
+    return _call_conj_sandwich(res, tprod, v, alpha, beta, p)
 
 
 def _mul_transpose(res, op, v, alpha, beta):
@@ -439,13 +535,13 @@ def _mul_transpose(res, op, v, alpha, beta):
             raise LinearOperatorException("unable to infer transpose operator")
     else:
         p.nctprod += 1
-    return _call_t(res, ctprod, v, alpha, beta, p)
+    return _call_conj_sandwich(res, ctprod, v, alpha, beta, p)
 
 
 def apply(op, v: torch.Tensor) -> torch.Tensor:
     """`op * v` — src/operations.jl:43-48: res = similar(v, promote_type(T,S), nrow); mul!(res, op, v)."""
     check_vec(v, "v")
-    T = op.eltype if op.eltype.is_floating_point else v.dtype
+    T = op.eltype if (op.eltype.is_floating_point or op.eltype.is_complex) else v.dtype
     res = torch.empty(op.size(1), dtype=torch.promote_types(T, v.dtype), device=v.device)
     mul(res, op, v)
     return res
@@ -529,8 +625,10 @@ def neg(op):
     prod = lambda res, v, a, b: mul(res, op, v, -a, b)
     tprod = lambda res, u, a, b: mul(res, transpose(op), u, -a, b)
     ctprod = lambda res, w, a, b: mul(res, adjoint(op), w, -a, b)
-    return LinearOperator(op.eltype, op.nrow, op.ncol, op.symmetric, op.hermitian, prod, tprod, ctprod,
-                          S=storage_type(op))
+    out = LinearOperator(op.eltype, op.nrow, op.ncol, op.symmetric, op.hermitian, prod, tprod, ctprod,
+                         S=storage_type(op))
+    out._deps = (op,)
+    return out
 
 
 def prod_op(res, op1, op2, vtmp, v, alpha, beta):
@@ -547,13 +645,15 @@ def compose(op1, op2):
     if m2 != n1:
         raise LinearOperatorException("shape mismatch")
     S = promote_storage(storage_type(op1), storage_type(op2))
-    if not S.dtype.is_floating_point:      # index-typed restriction composed with restriction
+    if not (S.dtype.is_floating_point or S.dtype.is_complex):      # index-typed restriction composed with restriction
         S = Storage(torch.float64, S.device)
     vtmp, utmp, wtmp = S.zeros(m2), S.zeros(n1), S.zeros(n1)
     prod = lambda res, v, a, b: prod_op(res, op1, op2, vtmp, v, a, b)
     tprod = lambda res, u, a, b: prod_op(res, transpose(op2), transpose(op1), utmp, u, a, b)
     ctprod = lambda res, w, a, b: prod_op(res, adjoint(op2), adjoint(op1), wtmp, w, a, b)
-    return LinearOperator(T, m1, n2, False, False, prod, tprod, ctprod, S=S)
+    out = LinearOperator(T, m1, n2, False, False, prod, tprod, ctprod, S=S)
+    out._deps = (op1, op2)
+    return out
 
 
 def scale_op(op, x):
@@ -567,9 +667,15 @@ def scale_op(op, x):
     T = op.eltype
     prod = lambda res, v, a, b: mul(res, op, v, x * a, b)
     tprod = lambda res, u, a, b: mul(res, transpose(op), u, x * a, b)
-    ctprod = lambda res, w, a, b: mul(res, adjoint(op), w, x * a, b)   # x' == x for real x
-    return LinearOperator(T, op.nrow, op.ncol, op.symmetric, op.hermitian, prod, tprod, ctprod,
-                          S=storage_type(op))
+    xc = conj_scalar(x)
+    ctprod = lambda res, w, a, b: mul(res, adjoint(op), w, xc * a, b)  # x' (src/operations.jl:166)
+    isreal_x = (not _is_complex_scalar(x)) or complex(x).imag == 0      # isreal(x) (src/operations.jl:172)
+    if _is_complex_scalar(x):                                            # T = promote_type(eltype(op), typeof(x))
+        T = torch.promote_types(T, torch.complex128 if _is_f64_scalar(x) else torch.complex64)
+    out = LinearOperator(T, op.nrow, op.ncol, op.symmetric, op.hermitian and isreal_x, prod, tprod, ctprod,
+                         S=storage_type(op))
+    out._deps = (op,)
+    return out
 
 
 def sum_prod(res, op1, op2, v, alpha, beta):
@@ -591,7 +697,9 @@ def add(op1, op2):
     symm = issymmetric(op1) and issymmetric(op2)
     herm = ishermitian(op1) and ishermitian(op2)
     S = promote_storage(storage_type(op1), storage_type(op2))
-    return LinearOperator(T, m1, n1, symm, herm, prod, tprod, ctprod, S=S)
+    out = LinearOperator(T, m1, n1, symm, herm, prod, tprod, ctprod, S=S)
+    out._deps = (op1, op2)
+    return out
 
 
 # ----------------------------------------------------------------------------- cat (src/cat.jl)
@@ -618,7 +726,9 @@ def _hcat2(A, B):
     tprod = lambda res, u, a, b: hcat_ctprod(res, transpose(A), transpose(B), Ancol, Ancol + Bncol, u, a, b)
     ctprod = lambda res, w, a, b: hcat_ctprod(res, adjoint(A), adjoint(B), Ancol, Ancol + Bncol, w, a, b)
     S = promote_storage(storage_type(A), storage_type(B))
-    return LinearOperator(T, nrow, Ancol + Bncol, False, False, prod, tprod, ctprod, S=S)
+    out = LinearOperator(T, nrow, Ancol + Bncol, False, False, prod, tprod, ctprod, S=S)
+    out._deps = (A, B)
+    return out
 
 
 def _as_op(x):
@@ -662,7 +772,9 @@ def _vcat2(A, B):
     tprod = lambda res, u, a, b: vcat_ctprod(res, transpose(A), transpose(B), Anrow, Anrow + Bnrow, u, a, b)
     ctprod = lambda res, w, a, b: vcat_ctprod(res, adjoint(A), adjoint(B), Anrow, Anrow + Bnrow, w, a, b)
     S = promote_storage(storage_type(A), storage_type(B))
-    return LinearOperator(T, Anrow + Bnrow, ncol, False, False, prod, tprod, ctprod, S=S)
+    out = LinearOperator(T, Anrow + Bnrow, ncol, False, False, prod, tprod, ctprod, S=S)
+    out._deps = (A, B)
+    return out
 
 
 def vcat(*ops):
@@ -688,11 +800,11 @@ def to_dense(op) -> torch.Tensor:
     """`Matrix(op)` — src/abstract.jl:282-292: ncol products with unit vectors."""
     m, n = op.shape
     S = storage_type(op)
-    dt = op.eltype if op.eltype.is_floating_point else torch.float64
+    dt = op.eltype if (op.eltype.is_floating_point or op.eltype.is_complex) else torch.float64
     A = torch.empty((n, m), dtype=dt, device=S.device)   # row i = column i of the operator
     ei = torch.zeros(n, dtype=dt, device=S.device)
     for i in range(n):
         ei[i] = 1
         mul(A[i], op, ei)
         ei[i] = 0
-    return A.t().contiguous()
+    return A.t()          # an m x n COLUMN-MAJOR view (Julia's Matrix layout): no second copy

@@ -17,7 +17,7 @@ import torch
 
 from . import _lib
 from .device import Storage, check_vec, dtype_code, get_ctx, ptr
-from .operators import AbstractLinearOperator, LinearOperatorException, scalar_flags
+from .operators import AbstractLinearOperator, LinearOperatorException, scalar_flags, touched
 
 
 class _QNData:
@@ -93,6 +93,7 @@ class _QNOperator(AbstractLinearOperator):
                   float(sigma2), float(sigma3), C.byref(self._h))
         self.data = _QNData(self)
         self._pending_shift = None       # set by ShiftedOperator around one mul! (fused axpy!, mxlo_qn_mul_shifted)
+        self._nupdate = 0                # bumped by every accepted push! and every reset! (operators.state_version)
         self.inverse = kind == _lib.QN_LBFGS_INV
         prod = lambda res, x, a, b: self._multiply(res, x, a, b)
         self.prod = prod
@@ -128,6 +129,17 @@ class _QNOperator(AbstractLinearOperator):
 
     def _reset_data(self):
         _lib.call("mxlo_qn_reset", self._h)
+        self._nupdate += 1
+
+    def _state_version(self):
+        return ("qn", id(self), self._nupdate)
+
+    def _check_len(self, **vecs):
+        """DimensionMismatch of the reference's broadcasts / BLAS calls: the C side writes exactly n elements."""
+        for name, t in vecs.items():
+            if t.numel() != self.nrow:
+                raise LinearOperatorException(f"shape mismatch: {name} has {t.numel()} elements, the operator is "
+                                              f"{self.nrow} x {self.ncol}")
 
     def __del__(self):
         try:
@@ -203,6 +215,7 @@ def push(op, s: torch.Tensor, y: torch.Tensor, *args):
             raise TypeError("push!(::LSR1Operator, s, y) takes no extra arguments")
         _lib.call("mxlo_qn_push", op._h, ptr(s), ptr(y), C.byref(acc))
         op._last_push_accepted = bool(acc.value)
+        op._nupdate += int(acc.value)
         return op
     if len(args) == 0:
         if op.damped:                                   # :273-275 — push!(op, s, y, similar(s))
@@ -216,7 +229,9 @@ def push(op, s: torch.Tensor, y: torch.Tensor, *args):
             raise RuntimeError("This push! should be used for damped operators")
         if op.inverse:
             raise RuntimeError("This function be used for forward operators. Use push!(op, s, y, α, g, Bs) instead.")
-        _lib.call("mxlo_qn_push_damped_fwd", op._h, ptr(s), ptr(y), ptr(check_vec(Bs, "Bs", op.eltype)), C.byref(acc))
+        op._check_len(Bs=check_vec(Bs, "Bs", op.eltype))
+        _lib.call("mxlo_qn_push_damped_fwd", op._h, ptr(s), ptr(y), ptr(Bs), C.byref(acc))
+        touched(Bs)
     elif len(args) in (2, 3):                           # push!(op, s, y, α, g[, Bs]) :325-367
         alpha, g = args[0], args[1]
         Bs = args[2] if len(args) == 3 else torch.empty_like(g)
@@ -224,11 +239,14 @@ def push(op, s: torch.Tensor, y: torch.Tensor, *args):
             raise RuntimeError("This push! should be used for damped operators")
         if not op.inverse:
             raise RuntimeError("This function be used for inverse operators. Use push!(op, s, y, Bs) instead.")
-        _lib.call("mxlo_qn_push_damped_inv", op._h, ptr(s), ptr(y), float(alpha), ptr(check_vec(g, "g", op.eltype)),
-                  ptr(check_vec(Bs, "Bs", op.eltype)), C.byref(acc))
+        op._check_len(g=check_vec(g, "g", op.eltype), Bs=check_vec(Bs, "Bs", op.eltype))
+        _lib.call("mxlo_qn_push_damped_inv", op._h, ptr(s), ptr(y), float(alpha), ptr(g), ptr(Bs), C.byref(acc))
+        touched(Bs)
+        touched(y)                                      # Powell damping overwrites the caller's y (:351)
     else:
         raise TypeError("push!: wrong number of arguments")
     op._last_push_accepted = bool(acc.value)
+    op._nupdate += int(acc.value)
     return op
 
 
@@ -248,11 +266,10 @@ def solve_shifted_system(x: torch.Tensor, B, b: torch.Tensor, sigma: float) -> t
         raise TypeError("solve_shifted_system! is defined for forward LBFGSOperator")
     if sigma < 0:
         raise ValueError("σ must be nonnegative")       # ArgumentError, :213-215
-    check_vec(x, "x", B.eltype)
-    check_vec(b, "b", B.eltype)
+    B._check_len(x=check_vec(x, "x", B.eltype), b=check_vec(b, "b", B.eltype))
     B._ctx.bind_stream()
     _lib.call("mxlo_qn_solve_shifted", B._h, ptr(x), ptr(b), float(sigma))
-    return x
+    return touched(x)
 
 
 def ldiv(x: torch.Tensor, B, b: torch.Tensor) -> torch.Tensor:

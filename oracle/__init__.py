@@ -30,21 +30,37 @@ BETA_F64 = 0x8
 SCALARS_F64 = ALPHA_F64 | BETA_F64
 
 
+CONJ_D = 0x10
+ALPHA_REAL = 0x20
+BETA_REAL = 0x40
+
+
 def _julia_f64(x) -> bool:
-    """A Python float / float64 scalar stands for a Julia Float64; Python ints are Julia Ints (they never widen a
-    Float32 product); NumPy float32 scalars are Float32."""
+    """A Python float / complex or a float64 / complex128 scalar stands for a Julia Float64 / ComplexF64; Python
+    ints are Julia Ints (they never widen a Float32 product); NumPy float32 / complex64 scalars are 32-bit."""
     if isinstance(x, (bool, int, np.integer)):
         return False
     if isinstance(x, np.floating):
         return x.dtype == np.float64
+    if isinstance(x, np.complexfloating):
+        return x.dtype == np.complex128
     return True
 
 
+def _is_real_scalar(x) -> bool:
+    return not isinstance(x, (complex, np.complexfloating))
+
+
 def scalar_flags(dtype, alpha, beta) -> int:
-    """ORC_ALPHA_F64 / ORC_BETA_F64 for Float32 data (Julia's mixed-precision rule)."""
-    if np.dtype(dtype) != np.float32:
-        return 0
-    return (ALPHA_F64 if _julia_f64(alpha) else 0) | (BETA_F64 if _julia_f64(beta) else 0)
+    """ORC_ALPHA_F64 / ORC_BETA_F64 for Float32 / ComplexF32 data (Julia's mixed-precision rule) and
+    ORC_ALPHA_REAL / ORC_BETA_REAL for Real scalars next to complex data."""
+    dt = np.dtype(dtype)
+    fl = 0
+    if dt in (np.float32, np.complex64):
+        fl |= (ALPHA_F64 if _julia_f64(alpha) else 0) | (BETA_F64 if _julia_f64(beta) else 0)
+    if dt.kind == "c":
+        fl |= (ALPHA_REAL if _is_real_scalar(alpha) else 0) | (BETA_REAL if _is_real_scalar(beta) else 0)
+    return fl
 D_SCALAR = 0x2
 TAIL_BETA = 0x4
 
@@ -94,6 +110,10 @@ def _suf(dtype) -> str:
         return "f64"
     if dtype == np.float32:
         return "f32"
+    if dtype == np.complex128:
+        return "c64"
+    if dtype == np.complex64:
+        return "c32"
     raise TypeError(f"oracle instantiated for float64/float32 only, got {dtype}")
 
 
@@ -111,6 +131,13 @@ _i64 = C.c_int64
 _i32 = C.c_int32
 
 
+def dotc(h, v):
+    """LinearAlgebra.dot(h, v) for complex vectors (conjugates h)."""
+    out = np.zeros(1, dtype=h.dtype)
+    _fn("orc_dotc", h.dtype)(_p(h), _p(v), _i64(h.size), _p(out))
+    return out[0]
+
+
 def _check(res, *vs):
     dt = res.dtype
     for v in vs:
@@ -126,11 +153,20 @@ def dot(a, b):
     return dt.type(f(_p(a), _p(b), _i64(a.size)))
 
 
+def _c4(alpha, beta):
+    a, b = complex(alpha), complex(beta)
+    return _d(a.real), _d(a.imag), _d(b.real), _d(b.imag)
+
+
 def diag_mul(res, d, v, alpha, beta, n_min=None, flags=0):
-    """mulSquareOpDiagonal!/mulOpDiagonal! (src/special-operators.jl:125-151)."""
+    """mulSquareOpDiagonal!/mulOpDiagonal! (src/special-operators.jl:125-151). Complex arrays: `flags` carries
+    CONJ_D for the ctprod! form and the scalar kinds (use scalar_flags)."""
     dt = _check(res, d, v)
     nrow = res.size
     n_min = nrow if n_min is None else n_min
+    if dt.kind == "c":
+        _fn("orc_diag_mul", dt)(_p(res), _p(d), _p(v), _i64(n_min), _i64(nrow), *_c4(alpha, beta), _i32(flags))
+        return res
     _fn("orc_diag_mul", dt)(_p(res), _p(d), _p(v), _i64(n_min), _i64(nrow), _d(alpha), _d(beta), _i32(flags))
     return res
 
@@ -140,11 +176,22 @@ def eye_mul(res, v, alpha, beta, n_min=None, flags=TAIL_BETA):
     dt = _check(res, v)
     nrow = res.size
     n_min = min(nrow, v.size) if n_min is None else n_min
+    if dt.kind == "c":
+        _fn("orc_eye_mul", dt)(_p(res), _p(v), _i64(n_min), _i64(nrow), *_c4(alpha, beta), _i32(flags))
+        return res
     _fn("orc_eye_mul", dt)(_p(res), _p(v), _i64(n_min), _i64(nrow), _d(alpha), _d(beta), _i32(flags))
     return res
 
 
 def zeros_mul(res, beta, flags=0):
+    if res.dtype.kind == "c":   # res .= 0 | res .*= β
+        b = complex(beta)
+        if b == 0:
+            res[:] = 0
+        else:
+            _fn("orc_scale", res.dtype)(_p(res), _i64(res.size), _d(b.real), _d(b.imag), _i32(1 if flags & BETA_REAL else 0),
+                                         _i32(1 if flags & BETA_F64 else 0))
+        return res
     _fn("orc_zeros_mul", res.dtype)(_p(res), _i64(res.size), _d(beta), _i32(flags))
     return res
 
@@ -156,11 +203,20 @@ def ones_mul(res, v, alpha, beta, flags=0):
 
 
 def scale(res, alpha, flags=0):
+    if res.dtype.kind == "c":
+        a = complex(alpha)
+        _fn("orc_scale", res.dtype)(_p(res), _i64(res.size), _d(a.real), _d(a.imag), _i32(1 if flags & ALPHA_REAL else 0),
+                                     _i32(1 if flags & ALPHA_F64 else 0))
+        return res
     _fn("orc_scale", res.dtype)(_p(res), _i64(res.size), _d(alpha), _i32(flags))
     return res
 
 
 def householder_mul(res, h, v, alpha, beta, flags=0):
+    if res.dtype.kind == "c":
+        dt = _check(res, h, v)
+        _fn("orc_householder_mul", dt)(_p(res), _p(h), _p(v), _i64(res.size), *_c4(alpha, beta), _i32(flags))
+        return res
     """mulHouseholder! (src/linalg.jl:77-83)."""
     dt = _check(res, h, v)
     _fn("orc_householder_mul", dt)(_p(res), _p(h), _p(v), _i64(res.size), _d(alpha), _d(beta), _i32(flags))

@@ -28,6 +28,9 @@
 #define ORC_SCALARS_F64 (ORC_ALPHA_F64 | ORC_BETA_F64)
 #define ORC_D_SCALAR 0x2
 #define ORC_TAIL_BETA 0x4
+#define ORC_CONJ_D 0x10
+#define ORC_ALPHA_REAL 0x20
+#define ORC_BETA_REAL 0x40
 
 #define T double
 #define SUF f64
@@ -39,6 +42,18 @@
 #define SUF f32
 #include "lo_oracle_impl.h"
 #undef T
+#undef SUF
+
+/* Complex{Float64} / Complex{Float32} elementwise leaves + opHouseholder */
+#define R double
+#define SUF c64
+#include "lo_oracle_cplx.h"
+#undef R
+#undef SUF
+#define R float
+#define SUF c32
+#include "lo_oracle_cplx.h"
+#undef R
 #undef SUF
 
 /* Generic byte-wise gather/scatter for elem sizes other than 4/8 (bit-exact data movement). */

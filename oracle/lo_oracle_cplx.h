@@ -1,0 +1,189 @@
+/* lo_oracle_cplx.h — TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * Complex{R} restatement of the elementwise leaves and opHouseholder of LinearOperators.jl v2.14.2, included by
+ * lo_oracle.c with R = double / float (SUF = c64 / c32). Vectors are interleaved (re, im) arrays exactly like
+ * Julia's Vector{Complex{R}}. Arithmetic follows base/complex.jl component by component, no FMA
+ * (-ffp-contract=off):
+ *     *(z::Complex, w::Complex) = Complex(zr*wr - zi*wi, zr*wi + zi*wr)
+ *     *(x::Real,    w::Complex) = Complex(x*wr, x*wi)          +,- : componentwise
+ * Caller scalars arrive as (re, im) doubles; ORC_ALPHA_REAL / ORC_BETA_REAL mark Real scalars,
+ * ORC_ALPHA_F64 / ORC_BETA_F64 their width next to ComplexF32 data (promotion as in lo_oracle_impl.h).
+ */
+#define CCAT_(a, b) a##_##b
+#define CCAT(a, b) CCAT_(a, b)
+#define CFN(name) CCAT(name, SUF)
+
+/* BODY(RA, RB): component types of the alpha- and beta-terms */
+#define WITH_RAB(BODY)                                                                           \
+  do {                                                                                           \
+    const int ad_ = sizeof(R) == 8 || (flags & ORC_ALPHA_F64);                                   \
+    const int bd_ = sizeof(R) == 8 || (flags & ORC_BETA_F64);                                    \
+    if (ad_ && bd_) {                                                                            \
+      BODY(double, double);                                                                      \
+    } else if (ad_) {                                                                            \
+      BODY(double, float);                                                                       \
+    } else if (bd_) {                                                                            \
+      BODY(float, double);                                                                       \
+    } else {                                                                                     \
+      BODY(float, float);                                                                        \
+    }                                                                                            \
+  } while (0)
+
+/* t = s * w for a caller scalar s = (sr, si) that is Real (s_real) or Complex, in type RT */
+#define SMUL(RT, sr, si, s_real, wr, wi, tr, ti)                                                 \
+  do {                                                                                           \
+    if (s_real) {                                                                                \
+      tr = (sr) * (RT)(wr);                                                                      \
+      ti = (sr) * (RT)(wi);                                                                      \
+    } else {                                                                                     \
+      tr = ((sr) * (RT)(wr)) - ((si) * (RT)(wi));                                                \
+      ti = ((sr) * (RT)(wi)) + ((si) * (RT)(wr));                                                \
+    }                                                                                            \
+  } while (0)
+
+/* mulSquareOpDiagonal! / mulOpDiagonal! — src/special-operators.jl:125-131,144-151; ORC_CONJ_D: ctprod! uses
+ * conj.(d) (:139-141) */
+void CFN(orc_diag_mul)(R *res, const R *d, const R *v, int64_t n_min, int64_t nrow, double are, double aim,
+                       double bre, double bim, int32_t flags) {
+  const int a_real = (flags & ORC_ALPHA_REAL) != 0, b_real = (flags & ORC_BETA_REAL) != 0;
+  const int cj = (flags & ORC_CONJ_D) != 0, b0 = (bre == 0 && (b_real || bim == 0));
+#define BODY(RA, RB)                                                                             \
+  {                                                                                              \
+    const RA ar = (RA)are, ai = (RA)aim;                                                         \
+    const RB br = (RB)bre, bi = (RB)bim;                                                         \
+    for (int64_t i = 0; i < n_min; ++i) {                                                        \
+      const R dr = d[2 * i], di = cj ? -d[2 * i + 1] : d[2 * i + 1];                             \
+      RA tr, ti;                                                                                 \
+      SMUL(RA, ar, ai, a_real, dr, di, tr, ti); /* α*d */                                        \
+      const RA vr = (RA)v[2 * i], vi = (RA)v[2 * i + 1];                                         \
+      const RA ur = (tr * vr) - (ti * vi), ui = (tr * vi) + (ti * vr); /* (α*d)*v */             \
+      if (b0) { /* :126-127 */                                                                   \
+        res[2 * i] = (R)ur;                                                                      \
+        res[2 * i + 1] = (R)ui;                                                                  \
+      } else { /* :128-129 */                                                                    \
+        RB wr, wi;                                                                               \
+        SMUL(RB, br, bi, b_real, res[2 * i], res[2 * i + 1], wr, wi); /* β*res */                \
+        res[2 * i] = (R)(ur + wr); /* usual arithmetic conversions = promote_type */             \
+        res[2 * i + 1] = (R)(ui + wi);                                                           \
+      }                                                                                          \
+    }                                                                                            \
+  }
+  WITH_RAB(BODY);
+#undef BODY
+  for (int64_t i = 2 * n_min; i < 2 * nrow; ++i) res[i] = 0; /* :150 */
+}
+
+/* mulOpEye! — src/special-operators.jl:36-44 (ORC_TAIL_BETA: the tail receives β itself; else β*res) */
+void CFN(orc_eye_mul)(R *res, const R *v, int64_t n_min, int64_t nrow, double are, double aim, double bre,
+                      double bim, int32_t flags) {
+  const int a_real = (flags & ORC_ALPHA_REAL) != 0, b_real = (flags & ORC_BETA_REAL) != 0;
+  const int b0 = (bre == 0 && (b_real || bim == 0));
+#define BODY(RA, RB)                                                                             \
+  {                                                                                              \
+    const RA ar = (RA)are, ai = (RA)aim;                                                         \
+    const RB br = (RB)bre, bi = b_real ? (RB)0 : (RB)bim;                                        \
+    for (int64_t i = 0; i < n_min; ++i) {                                                        \
+      RA tr, ti;                                                                                 \
+      SMUL(RA, ar, ai, a_real, v[2 * i], v[2 * i + 1], tr, ti);                                  \
+      if (b0) {                                                                                  \
+        res[2 * i] = (R)tr;                                                                      \
+        res[2 * i + 1] = (R)ti;                                                                  \
+      } else {                                                                                   \
+        RB wr, wi;                                                                               \
+        SMUL(RB, br, bi, b_real, res[2 * i], res[2 * i + 1], wr, wi);                            \
+        res[2 * i] = (R)(tr + wr);                                                               \
+        res[2 * i + 1] = (R)(ti + wi);                                                           \
+      }                                                                                          \
+    }                                                                                            \
+    for (int64_t i = n_min; i < nrow; ++i) {                                                     \
+      if (b0) {                                                                                  \
+        res[2 * i] = res[2 * i + 1] = 0;                                                         \
+      } else if (flags & ORC_TAIL_BETA) {                                                        \
+        res[2 * i] = (R)br;                                                                      \
+        res[2 * i + 1] = (R)bi;                                                                  \
+      } else { /* res*β, Complex*Complex with z = res */                                         \
+        const RB rr = (RB)res[2 * i], ri = (RB)res[2 * i + 1];                                   \
+        if (b_real) {                                                                            \
+          res[2 * i] = (R)(rr * br);                                                             \
+          res[2 * i + 1] = (R)(ri * br);                                                         \
+        } else {                                                                                 \
+          res[2 * i] = (R)((rr * br) - (ri * bi));                                               \
+          res[2 * i + 1] = (R)((rr * bi) + (ri * br));                                           \
+        }                                                                                        \
+      }                                                                                          \
+    }                                                                                            \
+  }
+  WITH_RAB(BODY);
+#undef BODY
+}
+
+/* res .*= s — mulOpZeros! with β (src/special-operators.jl:106) and prod3!'s res .*= α (src/operations.jl:14);
+ * f64s: the scalar is a Float64 / ComplexF64 */
+void CFN(orc_scale)(R *res, int64_t n, double sre, double sim, int32_t s_real, int32_t f64s) {
+#define SC(RS)                                                                                   \
+  {                                                                                              \
+    const RS sr = (RS)sre, si = (RS)sim;                                                         \
+    for (int64_t i = 0; i < n; ++i) {                                                            \
+      const RS rr = (RS)res[2 * i], ri = (RS)res[2 * i + 1];                                     \
+      if (s_real) {                                                                              \
+        res[2 * i] = (R)(rr * sr);                                                               \
+        res[2 * i + 1] = (R)(ri * sr);                                                           \
+      } else {                                                                                   \
+        res[2 * i] = (R)((rr * sr) - (ri * si));                                                 \
+        res[2 * i + 1] = (R)((rr * si) + (ri * sr));                                             \
+      }                                                                                          \
+    }                                                                                            \
+  }
+  if (sizeof(R) == 8 || f64s) SC(double) else SC(float)
+#undef SC
+}
+
+/* LinearAlgebra.dot(h, v) = sum conj(h_i) v_i (BLAS zdotc/cdotc in the reference: order unpinned) */
+void CFN(orc_dotc)(const R *h, const R *v, int64_t n, R *out) {
+  R sr = 0, si = 0;
+  for (int64_t i = 0; i < n; ++i) {
+    sr += (h[2 * i] * v[2 * i]) + (h[2 * i + 1] * v[2 * i + 1]);
+    si += (h[2 * i] * v[2 * i + 1]) - (h[2 * i + 1] * v[2 * i]);
+  }
+  out[0] = sr;
+  out[1] = si;
+}
+
+/* mulHouseholder! — src/linalg.jl:77-83: res .= α .* (v .- 2 * dot(h, v) .* h) (.+ β .* res) */
+void CFN(orc_householder_mul)(R *res, const R *h, const R *v, int64_t n, double are, double aim, double bre,
+                              double bim, int32_t flags) {
+  const int a_real = (flags & ORC_ALPHA_REAL) != 0, b_real = (flags & ORC_BETA_REAL) != 0;
+  const int b0 = (bre == 0 && (b_real || bim == 0));
+  R dt[2];
+  CFN(orc_dotc)(h, v, n, dt);
+  const R cr = (R)2 * dt[0], ci = (R)2 * dt[1]; /* 2 * dot: Int * Complex */
+#define BODY(RA, RB)                                                                             \
+  {                                                                                              \
+    const RA ar = (RA)are, ai = (RA)aim;                                                         \
+    const RB br = (RB)bre, bi = (RB)bim;                                                         \
+    for (int64_t i = 0; i < n; ++i) {                                                            \
+      const R hr = h[2 * i], hi = h[2 * i + 1];                                                  \
+      const R pr = (cr * hr) - (ci * hi), pi = (cr * hi) + (ci * hr); /* c .* h */               \
+      const R ir = v[2 * i] - pr, ii = v[2 * i + 1] - pi;                                        \
+      RA tr, ti;                                                                                 \
+      SMUL(RA, ar, ai, a_real, ir, ii, tr, ti);                                                  \
+      if (b0) {                                                                                  \
+        res[2 * i] = (R)tr;                                                                      \
+        res[2 * i + 1] = (R)ti;                                                                  \
+      } else {                                                                                   \
+        RB wr, wi;                                                                               \
+        SMUL(RB, br, bi, b_real, res[2 * i], res[2 * i + 1], wr, wi);                            \
+        res[2 * i] = (R)(tr + wr);                                                               \
+        res[2 * i + 1] = (R)(ti + wi);                                                           \
+      }                                                                                          \
+    }                                                                                            \
+  }
+  WITH_RAB(BODY);
+#undef BODY
+}
+
+#undef SMUL
+#undef WITH_RAB
+#undef CFN
+#undef CCAT
+#undef CCAT_

@@ -192,6 +192,102 @@ for gname, y, psb, andrei, spg, tol in (
                       kind="diagqn_push", d0=[1.0, -1.0, 1.0], s=_s, y=y, expect_psb=psb, expect_andrei=andrei,
                       expect_spectral=spg, tol=max(tol, 1e-15)))
 
+# ================================================================ round 2: complex, Hermitian, kron
+# Gaussian rationals as (re, im) Fractions; JSON carries [re, im] pairs.
+def cmul(a, b):
+    return (a[0] * b[0] - a[1] * b[1], a[0] * b[1] + a[1] * b[0])
+
+
+def cadd(a, b):
+    return (a[0] + b[0], a[1] + b[1])
+
+
+def csub(a, b):
+    return (a[0] - b[0], a[1] - b[1])
+
+
+def cconj(a):
+    return (a[0], -a[1])
+
+
+def cfl(v):
+    return [[float(x[0]), float(x[1])] for x in v]
+
+
+def cdot(a, b):            # LinearAlgebra.dot conjugates its FIRST argument
+    acc = (F(0), F(0))
+    for x, y in zip(a, b):
+        acc = cadd(acc, cmul(cconj(x), y))
+    return acc
+
+
+def csimple(n):            # simple_vector(ComplexF64, n): the same +1/-1 pattern, zero imaginary part
+    return [(F(-((-1) ** i)), F(0)) for i in range(1, n + 1)]
+
+
+def cpattern(n, a, b):     # a deterministic vector with non-trivial imaginary parts (dyadic: exact in binary)
+    return [(F(-((-1) ** i)) * F(a + i, 4), F(((-1) ** (i // 2)) * (b + 2 * i), 8)) for i in range(1, n + 1)]
+
+
+n = 10
+two = (F(2), F(0))
+for nm, cv, cu, cr in (("simple", csimple(n), csimple(n), csimple(n)),
+                       ("dyadic", cpattern(n, 1, 3), cpattern(n, 2, 5), cpattern(n, 3, 1))):
+    # test/test_linop.jl:308-318 on ComplexF64 inputs (round 1 had silently re-typed this case to Float64):
+    #   D*u == v.*u, transpose(D)*u == v.*u, D'*u == conj(v).*u, mul!(res, D, u, 2.0, 2.0) == v.*u.*2.0 + 2.0.*res
+    vu = [cmul(a, b) for a, b in zip(cv, cu)]
+    cases.append(dict(
+        name=f"opDiagonal_complex_{nm}", ref="test/test_linop.jl:308-318 (ComplexF64)", kind="cdiag",
+        d=cfl(cv), u=cfl(cu), expect_apply=cfl(vu), expect_tapply=cfl(vu),
+        expect_ctapply=cfl([cmul(cconj(a), b) for a, b in zip(cv, cu)]),
+        alpha=2.0, beta=2.0, res0=cfl(cr),
+        expect_mul5=cfl([cadd(cmul(two, x), cmul(two, r)) for x, r in zip(vu, cr)]),
+        tol="bit-exact (dyadic rationals)"))
+    # test/test_linop.jl:511-517: H*u == u - 2*dot(v,u)*v ; transpose(H)*u == u - 2*dot(conj(v),u)*conj(v) ; H'*u == H*u
+    c2 = cmul(two, cdot(cv, cu))
+    Hu = [csub(x, cmul(c2, h)) for x, h in zip(cu, cv)]
+    vbar = [cconj(h) for h in cv]
+    c2t = cmul(two, cdot(vbar, cu))
+    Htu = [csub(x, cmul(c2t, h)) for x, h in zip(cu, vbar)]
+    cases.append(dict(
+        name=f"opHouseholder_complex_{nm}", ref="test/test_linop.jl:511-517 (ComplexF64)", kind="chouseholder",
+        h=cfl(cv), u=cfl(cu), expect_apply=cfl(Hu), expect_tapply=cfl(Htu), expect_ctapply=cfl(Hu),
+        tol="1e-12 relative (dot order unpinned)"))
+
+# ---------------------------------------------------------------- opHermitian (test_linop.jl:360-380, real instantiation)
+# C = tril(A,-1) + tril(A,-1)' + diagm(d); H = opHermitian(d, A): H*v == C*v, transpose(H)*v == transpose(C)*v,
+# H'*v == C*v; opHermitian(C) for a symmetric C. The test draws A with rand; here A[i][j] = (3i - 2j + 1)/8 (dyadic).
+nh = 7
+Ah = [[F(3 * (i + 1) - 2 * (j + 1) + 1, 8) for j in range(nh)] for i in range(nh)]
+dh = [F(i + 1, 2) - F(3, 4) for i in range(nh)]
+Ch = [[(Ah[i][j] if i > j else (Ah[j][i] if j > i else dh[i])) for j in range(nh)] for i in range(nh)]
+vh = simple_vector(nh)
+xh = [F((-1) ** i * (i + 2), 4) for i in range(nh)]
+r0h = [F(i - 3, 2) for i in range(nh)]
+cases.append(dict(
+    name="opHermitian_d_A", ref="test/test_linop.jl:360-370 (Float64 instantiation, deterministic A)", kind="hermitian",
+    n=nh, A=[fl(r) for r in Ah], d=fl(dh), v=fl(vh), expect_apply=fl(matvec(Ch, vh)),
+    x=fl(xh), alpha=1.5, beta=-0.5, res0=fl(r0h),
+    expect_mul5=fl([F(3, 2) * a + F(-1, 2) * r for a, r in zip(matvec(Ch, xh), r0h)]),
+    tol="1e-13 relative (exact in binary up to summation order)"))
+
+# ---------------------------------------------------------------- kron (test_kron.jl:9-36, Float64 factors)
+# K = kron(A, B) (Base.kron); T*x == K*x, T'*x == K'*x, transpose(T)*x == transpose(K)*x for 2x3 factors.
+Ak = [[F(1), F(-1, 2), F(3, 4)], [F(2), F(1, 4), F(-5, 8)]]
+Bk = [[F(1, 2), F(3), F(-1)], [F(-7, 4), F(1, 8), F(2)]]
+mk, nk, pk, qk = 2, 3, 2, 3
+K = [[Ak[i // pk][j // qk] * Bk[i % pk][j % qk] for j in range(nk * qk)] for i in range(mk * pk)]
+xk = simple_vector(nk * qk)
+xtk = simple_vector(mk * pk)
+Kt = [[K[i][j] for i in range(mk * pk)] for j in range(nk * qk)]
+r0k = [F(i, 2) for i in range(mk * pk)]
+cases.append(dict(
+    name="kron_2x3_2x3", ref="test/test_kron.jl:9-36 (Float64 factors, deterministic)", kind="kron",
+    A=[fl(r) for r in Ak], B=[fl(r) for r in Bk], x=fl(xk), expect_apply=fl(matvec(K, xk)),
+    xt=fl(xtk), expect_tapply=fl(matvec(Kt, xtk)), alpha=2.0, beta=3.0, res0=fl(r0k),
+    expect_mul5=fl([2 * a + 3 * r for a, r in zip(matvec(K, xk), r0k)]), K=[fl(r) for r in K],
+    tol="1e-12 * norm(K, 1) as test_kron.jl:35"))
+
 out = dict(
     about="Known-answer cases held by LinearOperators.jl v2.14.2's own tests for the mul! hot path; "
           "generated by tests/golden/make_kat.py (exact rational arithmetic, no reference code executed).",

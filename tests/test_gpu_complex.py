@@ -1,0 +1,233 @@
+"""-m gpu: ComplexF64 / ComplexF32 instantiation of the elementwise leaves, opHouseholder, restriction/extension and
+the Adjoint/Transpose/Conjugate wrapper routing (src/adjtrans.jl:90-261), through the C ABI via the host mirror.
+
+The reference's own tests of opDiagonal and opHouseholder run on ComplexF64 (test/test_linop.jl:308-318, 511-517);
+those two known-answer cases are restored here with their complex inputs. Tolerances: elementwise leaves BIT-EXACT
+against the oracle's component-wise restatement of Julia's complex arithmetic; opHouseholder (one conjugated dot,
+fixed-order tree) 1e-12 in ComplexF64 and 1e-5 in ComplexF32."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+NPC = {torch.complex128: np.complex128, torch.complex64: np.complex64}
+SIZES = [1, 2, 3, 7, 64, 255, 1000, 4097, 100_003, 1_048_577]
+
+
+def T(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def cx(a):
+    a = np.array(a, dtype=np.float64)
+    return a[:, 0] + 1j * a[:, 1]
+
+
+def crand(rng, n, dt):
+    return (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(dt)
+
+
+def rel(a, b):
+    nb = np.linalg.norm(b.astype(np.complex128))
+    return np.linalg.norm(a.astype(np.complex128) - b.astype(np.complex128)) / (nb if nb else 1.0)
+
+
+def same(a, b):
+    """bit-identical, NaN payloads and signed zeros included"""
+    return a.dtype == b.dtype and a.tobytes() == b.tobytes()
+
+
+# ------------------------------------------------------------------------------------------ KATs
+@pytest.mark.parametrize("dtype", [torch.complex128, torch.complex64])
+def test_kat_complex_diag(lo, dev, kat, dtype):
+    cs = [c for c in kat if c["kind"] == "cdiag"]
+    assert len(cs) == 2
+    npd = NPC[dtype]
+    for c in cs:
+        d, u, r0 = (cx(c[k]).astype(npd) for k in ("d", "u", "res0"))
+        D = lo.opDiagonal(T(d, dev))
+        assert lo.issymmetric(D) and not lo.ishermitian(D)            # hermitian = isreal(d): false for Complex{T}
+        assert np.array_equal((D * T(u, dev)).cpu().numpy(), cx(c["expect_apply"]).astype(npd))
+        assert np.array_equal((D.T * T(u, dev)).cpu().numpy(), cx(c["expect_tapply"]).astype(npd))
+        assert np.array_equal((D.H * T(u, dev)).cpu().numpy(), cx(c["expect_ctapply"]).astype(npd))   # conj.(d)
+        res = T(r0.copy(), dev)
+        lo.mul(res, D, T(u, dev), c["alpha"], c["beta"])              # mul!(res, D, u, 2.0, 2.0)
+        assert np.array_equal(res.cpu().numpy(), cx(c["expect_mul5"]).astype(npd))
+        assert (lo.nprod(D), lo.ntprod(D), lo.nctprod(D)) == (3, 0, 1)   # transpose(D) is D itself (symmetric)
+
+
+def test_kat_complex_householder(lo, dev, kat):
+    cs = [c for c in kat if c["kind"] == "chouseholder"]
+    assert len(cs) == 2
+    for c in cs:
+        h, u = cx(c["h"]), cx(c["u"])
+        H = lo.opHouseholder(T(h, dev))
+        assert lo.ishermitian(H) and not lo.issymmetric(H)            # symmetric = isreal(h)
+        for op, key in ((H, "expect_apply"), (H.T, "expect_tapply"), (H.H, "expect_ctapply")):
+            got = (op * T(u, dev)).cpu().numpy()
+            want = cx(c[key])
+            assert np.linalg.norm(got - want) <= 1e-12 * np.linalg.norm(want), (c["name"], key)
+
+
+# ------------------------------------------------------------------------------------------ parity vs oracle
+@pytest.mark.parametrize("dtype", [torch.complex128, torch.complex64])
+@pytest.mark.parametrize("n", SIZES)
+def test_complex_diag_bit_exact(lo, dev, dtype, n):
+    rng = np.random.default_rng(4000 + n)
+    npd = NPC[dtype]
+    d, v, r0 = crand(rng, n, npd), crand(rng, n, npd), crand(rng, n, npd)
+    D = lo.opDiagonal(T(d, dev))
+    scal = [(complex(1), complex(0)), (0.7 - 0.3j, 1.25 + 0.5j), (2.0 / 3.0, 1.0 / 7.0), (1.5 + 0.25j, 0.0), (1, 0),
+            (-1.25, 0.5 - 2j), (np.complex64(0.3 - 1j), np.float32(0.7)), (np.float32(1.1), 0.5 + 0.5j)]
+    for alpha, beta in scal:
+        for conj_d, op in ((False, D), (True, D.H)):
+            res = T(r0.copy(), dev)
+            if beta == 0:
+                res.fill_(complex(float("nan"), float("nan")))       # beta == 0: res is never read
+            lo.mul(res, op, T(v, dev), alpha, beta)
+            fl = oracle.scalar_flags(npd, alpha, beta) | (oracle.CONJ_D if conj_d else 0)
+            want = oracle.diag_mul(r0.copy(), d, v, alpha, beta, flags=fl)
+            assert same(res.cpu().numpy(), want), (alpha, beta, conj_d)
+
+
+@pytest.mark.parametrize("dtype", [torch.complex128, torch.complex64])
+def test_complex_eye_zeros_scale_rect_diag(lo, dev, dtype):
+    rng = np.random.default_rng(77)
+    npd = NPC[dtype]
+    S = lo.Storage(dtype, dev)
+    for nrow, ncol in ((1000, 1000), (1031, 700), (700, 1031)):
+        v, r0 = crand(rng, ncol, npd), crand(rng, nrow, npd)
+        E = lo.opEye(dtype, nrow, ncol, S=S)
+        Z = lo.opZeros(dtype, nrow, ncol, S=S)
+        for alpha, beta in ((complex(1), complex(0)), (0.5 + 1j, 2.0 - 0.25j), (2.0, 3.0), (1.5 - 1j, 0.0)):
+            fl = oracle.scalar_flags(npd, alpha, beta)
+            res = T(r0.copy(), dev)
+            lo.mul(res, E, T(v, dev), alpha, beta)
+            assert same(res.cpu().numpy(), oracle.eye_mul(r0.copy(), v, alpha, beta, n_min=min(nrow, ncol), flags=fl | oracle.TAIL_BETA))
+            res = T(r0.copy(), dev)
+            lo.mul(res, Z, T(v, dev), alpha, beta)
+            assert same(res.cpu().numpy(), oracle.zeros_mul(r0.copy(), beta, flags=fl))
+        if nrow != ncol:                                              # rectangular opDiagonal: tail zeroed whatever β is
+            d = crand(rng, min(nrow, ncol), npd)
+            Dr = lo.opDiagonal(nrow, ncol, T(d, dev))
+            for op, vin, nout, cj in ((Dr, v, nrow, False), (Dr.H, crand(rng, nrow, npd), ncol, True)):
+                rr = crand(rng, nout, npd)
+                res = T(rr.copy(), dev)
+                lo.mul(res, op, T(vin, dev), 0.5 - 1j, 2.0)
+                want = oracle.diag_mul(rr.copy(), d, vin[:d.size].copy(), 0.5 - 1j, 2.0, n_min=d.size,
+                                       flags=oracle.scalar_flags(npd, 0.5 - 1j, 2.0) | (oracle.CONJ_D if cj else 0))
+                assert same(res.cpu().numpy(), want)
+
+
+@pytest.mark.parametrize("dtype", [torch.complex128, torch.complex64])
+@pytest.mark.parametrize("n", SIZES)
+def test_complex_householder_parity(lo, dev, dtype, n):
+    rng = np.random.default_rng(5000 + n)
+    npd = NPC[dtype]
+    h = crand(rng, n, np.complex128)
+    h = (h / np.linalg.norm(h)).astype(npd)
+    v, r0 = crand(rng, n, npd), crand(rng, n, npd)
+    H = lo.opHouseholder(T(h, dev))
+    tol = 1e-12 if dtype == torch.complex128 else 1e-5
+    for alpha, beta in ((complex(1), complex(0)), (2.0, -3.0), (0.5 - 1j, 0.25 + 2j)):
+        res = T(r0.copy(), dev)
+        if beta == 0:
+            res.fill_(complex(float("nan"), float("nan")))
+        lo.mul(res, H, T(v, dev), alpha, beta)
+        want = oracle.householder_mul(r0.copy(), h, v, alpha, beta, flags=oracle.scalar_flags(npd, alpha, beta))
+        assert rel(res.cpu().numpy(), want) <= tol, (n, alpha, beta)
+    # involution (‖h‖ = 1): H(Hv) = v; and the conj sandwich: transpose(H) v = conj(H conj(v))
+    w = H * (H * T(v, dev))
+    assert rel(w.cpu().numpy(), v) <= 50 * tol
+    t = (H.T * T(v, dev)).cpu().numpy()
+    assert rel(t, np.conj((H * T(np.conj(v), dev)).cpu().numpy())) == 0.0
+    a, b = H * T(v, dev), H * T(v, dev)
+    assert torch.equal(a, b)                                          # fixed-order reduction: deterministic
+
+
+@pytest.mark.parametrize("dtype", [torch.complex128, torch.complex64])
+def test_complex_restriction_extension_bit_exact(lo, dev, dtype):
+    """16-byte (ComplexF64) and 8-byte (ComplexF32) elements through the index kernels: pure data movement."""
+    rng = np.random.default_rng(9)
+    npd = NPC[dtype]
+    n = 50_000
+    v = crand(rng, n, npd)
+    for idx in (rng.integers(1, n + 1, 7777), np.sort(rng.choice(n, 999, replace=False)) + 1):
+        R = lo.opRestriction(idx.tolist(), n, device=dev)
+        got = (R * T(v, dev)).cpu().numpy()
+        assert same(got, v[idx - 1])
+        u = crand(rng, idx.size, npd)
+        want = np.zeros(n, dtype=npd)
+        for k, i in enumerate(idx):
+            want[i - 1] = u[k]
+        assert same((R.H * T(u, dev)).cpu().numpy(), want)
+    Rr = lo.opRestriction(lo.jrange(3, n - 5, 7), n, device=dev)
+    assert same((Rr * T(v, dev)).cpu().numpy(), v[2:n - 5:7])
+
+
+def test_conjugate_wrapper_reproduces_reference_quirk(lo, dev):
+    """mul!(res, conj(A), v, α, β) = conj!(A*conj.(v)*α + β*res) — α, β and res are NOT conjugated first
+    (src/adjtrans.jl:226-237): reproduced, not 'fixed'."""
+    rng = np.random.default_rng(13)
+    n = 513
+    d, v, r0 = crand(rng, n, np.complex128), crand(rng, n, np.complex128), crand(rng, n, np.complex128)
+    D = lo.opDiagonal(T(d, dev))
+    a, b = 0.5 - 1.5j, 2.0 + 0.25j
+    res = T(r0.copy(), dev)
+    lo.mul(res, lo.conj(D), T(v, dev), a, b)
+    want = np.conj(oracle.diag_mul(r0.copy(), d, np.conj(v), a, b, flags=oracle.scalar_flags(np.complex128, a, b)))
+    assert same(res.cpu().numpy(), want)
+    assert rel((lo.conj(D) * T(v, dev)).cpu().numpy(), np.conj(d) * v) <= 1e-15            # β = 0: the true conj(D) v
+
+
+def test_complex_combinators_vs_dense(lo, dev):
+    """compose / sum / scalar / cat over complex leaves against a dense NumPy model (test_linop.jl style)."""
+    rng = np.random.default_rng(21)
+    n = 300
+    d1, d2 = crand(rng, n, np.complex128), crand(rng, n, np.complex128)
+    h = crand(rng, n, np.complex128)
+    h /= np.linalg.norm(h)
+    D1, D2, H = lo.opDiagonal(T(d1, dev)), lo.opDiagonal(T(d2, dev)), lo.opHouseholder(T(h, dev))
+    Hd = np.eye(n) - 2 * np.outer(h, np.conj(h))
+    z = 0.5 - 2j
+    op = (H * D1 + D2) * z - H
+    M = (Hd @ np.diag(d1) + np.diag(d2)) * z - Hd
+    v = crand(rng, n, np.complex128)
+    for o, Md in ((op, M), (op.T, M.T), (op.H, M.conj().T)):
+        assert rel((o * T(v, dev)).cpu().numpy(), Md @ v) <= 1e-12
+    r0 = crand(rng, n, np.complex128)
+    res = T(r0.copy(), dev)
+    lo.mul(res, op, T(v, dev), 2.0 - 1j, 0.5 + 0.5j)
+    assert rel(res.cpu().numpy(), (2.0 - 1j) * (M @ v) + (0.5 + 0.5j) * r0) <= 1e-12
+    V = lo.vcat(D1, H)
+    assert rel((V.H * T(np.concatenate([v, r0]), dev)).cpu().numpy(), np.conj(d1) * v + Hd.conj().T @ r0) <= 1e-12
+    assert not lo.ishermitian(D1 * z) and lo.ishermitian(H * 2.0)
+    assert lo.eltype(lo.opDiagonal(T(np.ones(4), dev)) * (1 + 1j)) == torch.complex128   # promote_type(Float64, ComplexF64)
+
+
+def test_complex_diag_full_size_properties(lo, dev):
+    """ComplexF64 opDiagonal at n = 5e7 (the same 2.4 GB the real headline moves at n = 1e8): linearity in v and
+    bit-exact parity with the oracle on a strided sample."""
+    n = 50_000_000
+    g = torch.Generator(device=dev).manual_seed(5)
+    def rnd():
+        return torch.view_as_complex(torch.rand(n, 2, dtype=torch.float64, device=dev, generator=g) * 2 - 1)
+    d, v1, v2 = rnd(), rnd(), rnd()
+    D = lo.opDiagonal(d)
+    r1, r2, r12 = D * v1, D * v2, D * (v1 + v2)
+    assert (torch.linalg.vector_norm(r12 - (r1 + r2)) / torch.linalg.vector_norm(r12)).item() <= 1e-15
+    idx = torch.arange(0, n, 99_991, device=dev)
+    want = oracle.diag_mul(np.empty(idx.numel(), dtype=np.complex128), d[idx].cpu().numpy(), v1[idx].cpu().numpy(),
+                           complex(1), complex(0))
+    assert same(r1[idx].cpu().numpy(), want)
+
+
+def test_real_only_leaves_reject_complex(lo, dev):
+    A = torch.eye(4, dtype=torch.complex128, device=dev)
+    with pytest.raises(TypeError):
+        lo.LinearOperatorFromMatrix(A)
+    with pytest.raises(TypeError):
+        lo.LBFGSOperator(torch.complex128, 8, device=dev)

@@ -304,3 +304,85 @@ def test_kat_diagqn_push(kat):
     B = oracle.DiagonalQN("bfgs", np.ones(50)).push(s, y)                  # :245-248: d = |y| * sum|y| / (s'y/|s|^2)
     assert np.allclose(B.d, np.abs(y) * np.abs(y).sum() / (np.dot(s, y) / np.dot(s, s)), rtol=1e-13)
     assert np.array_equal(B.reset().d, np.ones(50))
+
+
+# ------------------------------------------------------------------------------------------ round 2 KATs
+def _cx(a):
+    a = np.array(a, dtype=np.float64)
+    return a[:, 0] + 1j * a[:, 1]
+
+
+def test_kat_complex_diag(kat):
+    """test/test_linop.jl:308-318 on ComplexF64 inputs: D*u, transpose(D)*u, D'*u (conj.(d)) and the 5-arg mul!
+    with Float64 scalars — bit-exact (dyadic rationals), in both ComplexF64 and ComplexF32."""
+    cs = _by_kind(kat, "cdiag")
+    assert len(cs) == 2
+    for c in cs:
+        for dt in (np.complex128, np.complex64):
+            d, u, r0 = (_cx(c[k]).astype(dt) for k in ("d", "u", "res0"))
+            one, zero = (complex(1), complex(0)) if dt == np.complex128 else (np.complex64(1), np.complex64(0))
+            fl = oracle.scalar_flags(dt, one, zero)
+            res = np.full(d.size, np.nan + 1j * np.nan, dtype=dt)            # beta == 0 must not read res
+            assert np.array_equal(oracle.diag_mul(res, d, u, one, zero, flags=fl), _cx(c["expect_apply"]).astype(dt)), c["name"]
+            res = np.full(d.size, np.nan + 1j * np.nan, dtype=dt)
+            got = oracle.diag_mul(res, d, u, one, zero, flags=fl | oracle.CONJ_D)
+            assert np.array_equal(got, _cx(c["expect_ctapply"]).astype(dt)), c["name"]
+            a, b = c["alpha"], c["beta"]                                      # Float64 (Real) scalars
+            got = oracle.diag_mul(r0.copy(), d, u, a, b, flags=oracle.scalar_flags(dt, a, b))
+            assert np.array_equal(got, _cx(c["expect_mul5"]).astype(dt)), c["name"]
+
+
+def test_kat_complex_householder(kat):
+    """test/test_linop.jl:511-517 on ComplexF64 inputs: H*u = u - 2*dot(v,u)*v with dot conjugating v;
+    transpose(H)*u through the conj sandwich of src/adjtrans.jl:193-204: conj(H * conj(u))."""
+    cs = _by_kind(kat, "chouseholder")
+    assert len(cs) == 2
+    for c in cs:
+        h, u = _cx(c["h"]), _cx(c["u"])
+        want, want_t = _cx(c["expect_apply"]), _cx(c["expect_tapply"])
+        res = np.full(h.size, np.nan + 1j * np.nan)
+        got = oracle.householder_mul(res, h, u, complex(1), complex(0), flags=0)
+        assert np.linalg.norm(got - want) <= 1e-12 * np.linalg.norm(want), c["name"]
+        got_t = np.conj(oracle.householder_mul(np.full(h.size, np.nan + 1j * np.nan), h, np.conj(u), complex(1), complex(0)))
+        assert np.linalg.norm(got_t - want_t) <= 1e-12 * np.linalg.norm(want_t), c["name"]
+
+
+def test_kat_hermitian(kat):
+    (c,) = _by_kind(kat, "hermitian")
+    A, d, v, x = np.array(c["A"]), np.array(c["d"]), np.array(c["v"]), np.array(c["x"])
+    got = oracle.hermitian_mul(np.full(c["n"], np.nan), d, A, v, 1.0, 0.0)
+    assert np.linalg.norm(got - np.array(c["expect_apply"])) <= 1e-13 * np.linalg.norm(c["expect_apply"])
+    got = oracle.hermitian_mul(np.array(c["res0"]), d, A, x, c["alpha"], c["beta"])
+    assert np.linalg.norm(got - np.array(c["expect_mul5"])) <= 1e-13 * np.linalg.norm(c["expect_mul5"])
+
+
+def test_kat_kron(kat):
+    (c,) = _by_kind(kat, "kron")
+    A, B, K = np.array(c["A"]), np.array(c["B"]), np.array(c["K"])
+    assert np.array_equal(np.kron(A, B), K)                              # the dense model IS Base.kron
+    nK = np.linalg.norm(K, 1)
+    got = oracle.kron_mul(np.full(K.shape[0], np.nan), A, B, np.array(c["x"]), 1.0, 0.0)
+    assert np.linalg.norm(got - np.array(c["expect_apply"]), 1) <= 1e-12 * nK
+    got = oracle.kron_mul(np.full(K.shape[1], np.nan), A, B, np.array(c["xt"]), 1.0, 0.0, trans=True)
+    assert np.linalg.norm(got - np.array(c["expect_tapply"]), 1) <= 1e-12 * nK
+    got = oracle.kron_mul(np.array(c["res0"]), A, B, np.array(c["x"]), c["alpha"], c["beta"])
+    assert np.linalg.norm(got - np.array(c["expect_mul5"]), 1) <= 1e-12 * nK
+
+
+def test_complex_mixed_scalars_and_eye_zeros():
+    """ComplexF32 data with Float64 / ComplexF64 / Float32 scalars: every term in its own type (component-wise
+    model in NumPy, exact because every product is formed in float64 and rounded as the oracle does)."""
+    rng = np.random.default_rng(3)
+    n = 257
+    mk = lambda: (rng.integers(-64, 64, n) / 8 + 1j * rng.integers(-64, 64, n) / 8).astype(np.complex64)
+    d, v, r = mk(), mk(), mk()
+    a, b = np.float32(1.5), 0.75 - 0.5j                                 # Float32 α, ComplexF64 β
+    got = oracle.diag_mul(r.copy(), d, v, a, b, flags=oracle.scalar_flags(np.complex64, a, b))
+    t = (np.float32(1.5) * d) * v                                       # complex64 arithmetic, exact on dyadics
+    want = (t.astype(np.complex128) + b * r.astype(np.complex128)).astype(np.complex64)
+    assert np.array_equal(got, want)
+    e = oracle.eye_mul(r.copy(), v, 2.0, 0.5, flags=oracle.scalar_flags(np.complex64, 2.0, 0.5) | oracle.TAIL_BETA)
+    assert np.array_equal(e, (2.0 * v.astype(np.complex128) + 0.5 * r.astype(np.complex128)).astype(np.complex64))
+    z = oracle.zeros_mul(r.copy(), 0.5 + 0.25j, flags=oracle.scalar_flags(np.complex64, 0, 0.5 + 0.25j))
+    assert np.array_equal(z, (r.astype(np.complex128) * (0.5 + 0.25j)).astype(np.complex64))
+    assert np.array_equal(oracle.zeros_mul(np.full(4, np.nan + 0j), 0.0), np.zeros(4, dtype=np.complex128))

@@ -106,6 +106,10 @@ struct mxlo_graph {
   hipStream_t stream = nullptr;
   hipGraph_t graph = nullptr;
   hipGraphExec_t exec = nullptr;
+  // state baked into the recorded kernel arguments (slot order, γ, active set, which kernels run; the opHermitian
+  // workspace pointer): a replay after push!/reset!/a workspace reallocation would silently use stale values
+  std::vector<std::pair<mxlo_qn *, int64_t>> qn;
+  int64_t scratch_generation = -1;   // -1: no opHermitian apply inside the graph
 };
 
 MXLO_API int32_t mxlo_graph_begin(mxlo_ctx *ctx) {
@@ -117,6 +121,8 @@ MXLO_API int32_t mxlo_graph_begin(mxlo_ctx *ctx) {
                "(mxlo_ctx_set_stream / mxlo_ctx_create_stream)");
   MXLO_HIP(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
   ctx->capturing = true;
+  ctx->captured_qn.clear();
+  ctx->scratch_used_in_capture = false;
   return MXLO_OK;
 }
 
@@ -137,6 +143,9 @@ MXLO_API int32_t mxlo_graph_end(mxlo_ctx *ctx, mxlo_graph **out) {
   g->ctx = ctx;
   g->stream = ctx->stream;
   g->graph = graph;
+  g->qn = ctx->captured_qn;
+  g->scratch_generation = ctx->scratch_used_in_capture ? ctx->scratch_generation : -1;
+  ctx->captured_qn.clear();
   e = hipGraphInstantiate(&g->exec, graph, nullptr, nullptr, 0);
   if (e != hipSuccess) {
     set_error("hipGraphInstantiate failed: %s", hipGetErrorString(e));
@@ -151,6 +160,17 @@ MXLO_API int32_t mxlo_graph_end(mxlo_ctx *ctx, mxlo_graph **out) {
 MXLO_API int32_t mxlo_graph_launch(mxlo_graph *g) {
   MXLO_REQUIRE(g && g->exec, MXLO_EINVAL, "mxlo_graph_launch: NULL graph");
   MXLO_DEVICE_GUARD(g->ctx);
+  for (const auto &pr : g->qn) {
+    int64_t gen = 0;
+    MXLO_REQUIRE(qn_generation(pr.first, &gen), MXLO_ESTATE,
+                 "mxlo_graph_launch: a quasi-Newton operator applied inside this graph was destroyed");
+    MXLO_REQUIRE(gen == pr.second, MXLO_ESTATE,
+                 "mxlo_graph_launch: a quasi-Newton operator applied inside this graph changed state (push!/reset!/mode) "
+                 "after the capture: slot order, scaling factor and kernel choice are baked into the graph — recapture");
+  }
+  MXLO_REQUIRE(g->scratch_generation < 0 || g->scratch_generation == g->ctx->scratch_generation, MXLO_ESTATE,
+               "mxlo_graph_launch: the opHermitian workspace recorded in this graph was reallocated (a larger n arrived) "
+               "— recapture");
   MXLO_HIP(hipGraphLaunch(g->exec, g->stream));
   return MXLO_OK;
 }

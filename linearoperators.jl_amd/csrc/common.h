@@ -6,9 +6,12 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <initializer_list>
 #include <type_traits>
+#include <utility>
+#include <vector>
 
 #include "../../include/mxlo.h"
 
@@ -47,8 +50,20 @@ void set_error(const char *fmt, ...);
     if (s__ != MXLO_OK) return s__;                                                              \
   } while (0)
 
+// MXLO_TRACE=1 in the environment: synchronise after every launch and log its source line (a GPU memory fault
+// aborts the process without an error code; the last line logged is the launch that faulted).
+inline bool mxlo_trace_on() {
+  static const bool on = getenv("MXLO_TRACE") != nullptr;
+  return on;
+}
 #define MXLO_LAUNCH_CHECK()                                                                      \
   do {                                                                                           \
+    if (mxlo_trace_on()) {                                                                       \
+      fprintf(stderr, "[mxlo] launched %s:%d ... ", __FILE__, __LINE__);                         \
+      fflush(stderr);                                                                            \
+      (void)hipDeviceSynchronize();                                                              \
+      fprintf(stderr, "done\n");                                                                 \
+    }                                                                                            \
     hipError_t e__ = hipGetLastError();                                                          \
     if (e__ != hipSuccess) {                                                                     \
       mxlo::set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(e__), __FILE__,      \
@@ -86,6 +101,9 @@ struct mxlo_ctx {
   hipStream_t own_stream = nullptr;  // created by mxlo_ctx_create_stream, destroyed with the ctx
   hipEvent_t switch_event = nullptr; // orders the ctx workspaces across mxlo_ctx_set_stream
   bool capturing = false;      // between mxlo_graph_begin and mxlo_graph_end
+  std::vector<std::pair<mxlo_qn *, int64_t>> captured_qn;   // quasi-Newton handles (and their generation) applied inside the open capture
+  int64_t scratch_generation = 0;   // bumped whenever `scratch` is reallocated (captured opHermitian applies go stale)
+  bool scratch_used_in_capture = false;
   mxlo::Tune tune;
 };
 
@@ -174,6 +192,9 @@ inline int grid_for(const mxlo_ctx *ctx, int64_t work_items, int64_t items_per_b
   if (g > 0x7fffffffLL) g = 0x7fffffffLL;
   return (int)(g < 1 ? 1 : g);
 }
+
+// qn.hip: current generation of a live quasi-Newton handle (false: the handle was destroyed)
+bool qn_generation(const mxlo_qn *h, int64_t *gen);
 
 // reductions.hip
 int32_t finalize_and_reduce(mxlo_ctx *ctx, int ncols, int nblocks, double *out_dev);

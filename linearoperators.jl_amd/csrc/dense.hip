@@ -571,7 +571,9 @@ int32_t hermitian_t(mxlo_ctx *ctx, T *res, const T *d, const T *A, int64_t lda, 
     hipError_t e = hipMalloc(&ctx->scratch, need);
     MXLO_REQUIRE(e == hipSuccess, MXLO_ENOMEM, "opHermitian scratch: %s", hipGetErrorString(e));
     ctx->scratch_bytes = need;
+    ++ctx->scratch_generation;     // graphs that recorded the old workspace pointer are stale now
   }
+  if (ctx->capturing) ctx->scratch_used_in_capture = true;
   double *Prow = (double *)ctx->scratch, *Pcol = Prow + (size_t)nslots * n;
   const bool aligned = (((uintptr_t)A & 15u) == 0) && (lda % RPL == 0);
   // full row groups whose strips take the unmasked kernel; the rest of the strips go through the masked one

@@ -35,14 +35,24 @@ constexpr int kX0Slot = 64;          // CM_AXPYS (forward shifted solve, <= 64 c
 
 // ---- device scalar region layout (doubles) ------------------------------------------
 struct DscLayout {
-  int64_t dots = 0;    // [128] panel_dots outputs of the current apply
-  int64_t coef = 128;  // [128] coefficients consumed by panel_combine
-  int64_t misc = 256;  // [64]  push! scalars
-  int64_t as_ = 320;   // [64] L-SR1 a_k' s_k
-  int64_t alpha = 384; // [64] inverse two-loop alpha_k (data.α)
+  // fixed-size head for mem <= 64 (the by-value fast path); every region grows with mem beyond that
+  int64_t dots = 0;    // [nd] panel_dots outputs of the current apply
+  int64_t coef = 128;  // [nd] coefficients consumed by the combine pass (+1: the factor of x of the shifted solve)
+  int64_t misc = 256;  // [16 + ns] push! scalars, then per-slot norms from misc + 16
+  int64_t as_ = 320;   // [ns] L-SR1 a_k' s_k
+  int64_t alpha = 384; // [ns] inverse two-loop alpha_k (data.α)
   int64_t SY = 448;    // [mem*mem] column j = S' y_j  (written when slot j is pushed)
   int64_t YS = 0, YY = 0, G = 0, g = 0, cx = 0, SS = 0, YSf = 0, Cm = 0, gtmp = 0, Wm = 0, total = 0;
-  explicit DscLayout(int64_t mem) {
+  int64_t bigM = 0, bigT = 0, bigP = 0;   // [4 mem^2] each: shifted-solve work matrices of the big-memory path
+  explicit DscLayout(int64_t mem, bool big = false) {
+    const int64_t nd = big ? 2 * mem + 64 : 128;     // dots / coef
+    const int64_t ns = big ? mem + 64 : 64;          // per-slot scalar arrays
+    dots = 0;
+    coef = nd;
+    misc = 2 * nd;
+    as_ = misc + (big ? 16 + ns : 64);
+    alpha = as_ + ns;
+    SY = alpha + ns;
     YS = SY + mem * mem;
     YY = YS + mem * mem;
     G = YY + mem * mem;
@@ -54,6 +64,12 @@ struct DscLayout {
     gtmp = Cm + 2 * mem * mem;  // [4*mem] scratch dots of one push
     Wm = gtmp + 4 * mem + 64;   // [2mem x 2mem] shifted solve: coefficients of u_t on the basis [s.. b..]
     total = Wm + 4 * mem * mem + 64;
+    if (big) {
+      bigM = total;
+      bigT = bigM + 4 * mem * mem;
+      bigP = bigT + 4 * mem * mem;
+      total = bigP + 4 * mem * mem + 64;
+    }
   }
 };
 
@@ -83,6 +99,11 @@ struct mxlo_qn {
   void *tmp = nullptr, *tmp2 = nullptr;                         // n-vectors (Ax / tmp)
   double *dsc = nullptr;
   DscLayout lay{1};
+  // memories beyond the single-wave coefficient kernels (qn_big.h): slot order / ys / age live in device memory
+  bool big = false;
+  void *meta = nullptr;
+  std::vector<char> meta_host;
+  int64_t generation = 0;   // bumped by every state change: a captured hipGraph of an apply is stale afterwards
 };
 
 namespace {
@@ -484,6 +505,29 @@ inline void fill_ord(const mxlo_qn *h, OrdArgs &O, bool newest_first) {
   }
 }
 
+// active slots as a host vector (any mem): oldest->newest or newest->oldest
+inline std::vector<int> ord_host(const mxlo_qn *h, bool newest_first) {
+  std::vector<int> o;
+  for (int64_t i = 0; i < h->mem; ++i) {
+    const int64_t k = newest_first ? ((h->insert0 - 1 - i) % h->mem + h->mem) % h->mem : (h->insert0 + i) % h->mem;
+    if (h->ys[k] != 0) o.push_back((int)k);
+  }
+  return o;
+}
+
+// big-memory path (qn_big.h, included at the end of this namespace)
+int32_t sync_meta(mxlo_qn *h);
+template <typename T>
+int32_t inv_mul_big(mxlo_qn *h, T *res, const T *x, double alpha, double beta, int32_t flags, double shift);
+template <typename T>
+int32_t fwd_mul_big(mxlo_qn *h, T *res, const T *x, double alpha, double beta, int32_t flags, double shift);
+template <typename T>
+int32_t lsr1_mul_big(mxlo_qn *h, T *res, const T *x, double alpha, double beta, int32_t flags, double shift);
+template <typename T>
+int32_t lbfgs_push_common_big(mxlo_qn *h, const T *s, const T *y, double ys, double yy);
+template <typename T>
+int32_t lsr1_rebuild_big(mxlo_qn *h, int64_t ins);
+
 // ---- applies ------------------------------------------------------------------------------
 template <typename T>
 int32_t inv_mul_twopass(mxlo_qn *h, T *res, const T *x, double alpha, double beta, int32_t flags,
@@ -530,10 +574,10 @@ int32_t inv_mul_reforder(mxlo_qn *h, T *res, const T *x, double alpha, double be
   const int64_t n = h->n;
   MXLO_TRY((launch_map<T, 1, false, false>(ctx, q, x, (const T *)nullptr, n, CopyOp<T>{})));
   double *dots = h->dsc + h->lay.dots, *al = h->dsc + h->lay.alpha;
-  OrdArgs O;
-  fill_ord(h, O, true);
-  for (int i = 0; i < O.na; ++i) {
-    const int k = O.ord[i];
+  const std::vector<int> ord = ord_host(h, true);
+  const int na = (int)ord.size();
+  for (int i = 0; i < na; ++i) {
+    const int k = ord[i];
     const T *sk = col<T>(h->S, h->ld, k), *yk = col<T>(h->Y, h->ld, k);
     const T *cols[1] = {sk};
     MXLO_TRY(panel_dots<T>(ctx, cols, 1, q, n, dots));
@@ -544,8 +588,8 @@ int32_t inv_mul_reforder(mxlo_qn *h, T *res, const T *x, double alpha, double be
     MXLO_TRY((launch_map<T, 0, true, false>(ctx, q, (const T *)nullptr, (const T *)nullptr, n,
                                             ScaleOp<T, T>{(T)h->scaling_factor})));
   }
-  for (int i = O.na - 1; i >= 0; --i) {
-    const int k = O.ord[i];
+  for (int i = na - 1; i >= 0; --i) {
+    const int k = ord[i];
     const T *sk = col<T>(h->S, h->ld, k), *yk = col<T>(h->Y, h->ld, k);
     const T *cols[1] = {yk};
     MXLO_TRY(panel_dots<T>(ctx, cols, 1, q, n, dots));
@@ -651,6 +695,16 @@ template <typename T>
 int32_t qn_mul_t(mxlo_qn *h, T *res, const T *x, double alpha, double beta, int32_t flags,
                  double shift = 0.0) {
   eff_scalars(sizeof(T), flags, alpha, beta);
+  if (h->big) {
+    switch (h->kind) {
+      case MXLO_QN_LBFGS_INV:
+        return h->mode == MXLO_INV_REFORDER ? inv_mul_reforder<T>(h, res, x, alpha, beta, flags, shift)
+                                            : inv_mul_big<T>(h, res, x, alpha, beta, flags, shift);
+      case MXLO_QN_LBFGS_FWD: return fwd_mul_big<T>(h, res, x, alpha, beta, flags, shift);
+      case MXLO_QN_LSR1: return lsr1_mul_big<T>(h, res, x, alpha, beta, flags, shift);
+    }
+    return MXLO_EINVAL;
+  }
   switch (h->kind) {
     case MXLO_QN_LBFGS_INV:
       return h->mode == MXLO_INV_REFORDER ? inv_mul_reforder<T>(h, res, x, alpha, beta, flags, shift)
@@ -740,7 +794,9 @@ struct PanelGemmArgs {
   const T *in[kGemmIn];
   T *out[kGemmOut];
   int nin, nout;
-  const double *C;  // nout x nin, row-major (as produced by the coefficient kernel)
+  const double *C;  // nout x nin, row-major with row stride cstride (0: nin), as produced by the coefficient kernel
+  int64_t cstride = 0;
+  int accum = 0;    // start from the current contents of the outputs (input chunks of the big-memory path)
 };
 
 // out_k[i] = sum_j C[k][j] * in_j[i].  j-outer streaming form: the nout accumulators of a lane's two rows
@@ -755,7 +811,14 @@ panel_gemm_kernel(PanelGemmArgs<T> A, const double *__restrict__ Ct, int64_t nve
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * kBlock) {
     double acc[NOUTMAX][2];
 #pragma unroll
-    for (int k = 0; k < NOUTMAX; ++k) acc[k][0] = acc[k][1] = 0.0;
+    for (int k = 0; k < NOUTMAX; ++k) {
+      acc[k][0] = acc[k][1] = 0.0;
+      if (A.accum && k < A.nout) {
+        const V o = *reinterpret_cast<const V *>(A.out[k] + i * 2);
+        acc[k][0] = (double)o[0];
+        acc[k][1] = (double)o[1];
+      }
+    }
     for (int j0 = 0; j0 < A.nin; j0 += UJ) {
       V in[UJ];
 #pragma unroll
@@ -789,10 +852,10 @@ panel_gemm_kernel(PanelGemmArgs<T> A, const double *__restrict__ Ct, int64_t nve
 
 // Ct[j][k] (row length NOUTMAX, zero padded) from C[k][j]
 __global__ void transpose_coef_kernel(const double *__restrict__ C, double *__restrict__ Ct, int nout, int nin,
-                                      int noutmax) {
+                                      int noutmax, int64_t cstride) {
   for (int idx = threadIdx.x; idx < nin * noutmax; idx += blockDim.x) {
     const int j = idx / noutmax, k = idx % noutmax;
-    Ct[idx] = k < nout ? C[(int64_t)k * nin + j] : 0.0;
+    Ct[idx] = k < nout ? C[(int64_t)k * cstride + j] : 0.0;
   }
 }
 
@@ -804,7 +867,8 @@ int32_t launch_panel_gemm(mxlo_ctx *ctx, PanelGemmArgs<T> &A, int64_t n) {
   const int grid = grid_for(ctx, nvec, kBlock, 0);
   double *Ct = ctx->scalars + 1024;  // kGemmIn * kGemmOut = 2048 doubles inside the ctx scalar buffer
   auto go = [&]<int NOUTMAX>() -> int32_t {
-    hipLaunchKernelGGL(transpose_coef_kernel, dim3(1), dim3(kBlock), 0, ctx->stream, A.C, Ct, A.nout, A.nin, NOUTMAX);
+    hipLaunchKernelGGL(transpose_coef_kernel, dim3(1), dim3(kBlock), 0, ctx->stream, A.C, Ct, A.nout, A.nin, NOUTMAX,
+                       A.cstride > 0 ? A.cstride : (int64_t)A.nin);
     MXLO_LAUNCH_CHECK();
     hipLaunchKernelGGL((panel_gemm_kernel<T, NOUTMAX>), dim3(grid), dim3(kBlock), 0, ctx->stream, A, Ct, nvec);
     MXLO_LAUNCH_CHECK();
@@ -964,6 +1028,7 @@ int32_t fwd_rebuild_gram(mxlo_qn *h, int64_t ins) {
 // push_common! — src/lbfgs.jl:210-255 (ys, yy already known on the host)
 template <typename T>
 int32_t lbfgs_push_common(mxlo_qn *h, const T *s, const T *y, double ys, double yy) {
+  if (h->big) return lbfgs_push_common_big<T>(h, s, y, ys, yy);
   mxlo_ctx *ctx = h->ctx;
   const int64_t n = h->n, ins = h->insert0, mem = h->mem;
   T *si = col<T>(h->S, h->ld, ins), *yi = col<T>(h->Y, h->ld, ins);
@@ -1050,7 +1115,8 @@ int32_t lbfgs_push(mxlo_qn *h, const T *s, const T *y, int32_t *accepted) {
   *accepted = 1;
   MXLO_TRY(lbfgs_push_common<T>(h, s, y, ys, yy));
   h->insert0 = (h->insert0 + 1) % h->mem;  // :253
-  return MXLO_OK;
+  ++h->generation;
+  return sync_meta(h);
 }
 
 // Powell damping shared by both damped pushes: given ys and sBs decide theta (src/lbfgs.jl:307-314)
@@ -1078,7 +1144,8 @@ int32_t lbfgs_push_damped(mxlo_qn *h, const T *s, T *y_mut, const T *y_const, do
   if (inverse) {  // Bs .= -α .* g  (:341)
     MXLO_TRY((launch_map<T, 1, false, false>(ctx, Bs, g, (const T *)nullptr, n, NegScaleOp<T>{(T)(-alpha)})));
   } else {        // mul!(Bs, op, s, one(T), zero(T))  (:305)
-    MXLO_TRY(fwd_mul<T>(h, Bs, s, 1.0, 0.0, 0));
+    if (h->big) MXLO_TRY(fwd_mul_big<T>(h, Bs, s, 1.0, 0.0, 0, 0.0));
+    else MXLO_TRY(fwd_mul<T>(h, Bs, s, 1.0, 0.0, 0));
   }
   double *misc = h->dsc + h->lay.misc;
   const T *cols[3] = {s, y, Bs};
@@ -1103,7 +1170,8 @@ int32_t lbfgs_push_damped(mxlo_qn *h, const T *s, T *y_mut, const T *y_const, do
   *accepted = 1;  // the damped pushes have no ys <= eps rejection in the reference
   MXLO_TRY(lbfgs_push_common<T>(h, s, yuse, ys, rT<T>(yyh[0])));
   h->insert0 = (h->insert0 + 1) % h->mem;
-  return MXLO_OK;
+  ++h->generation;
+  return sync_meta(h);
 }
 
 // push!(op::LSR1Operator, s, y) — src/lsr1.jl:119-184
@@ -1113,7 +1181,8 @@ int32_t lsr1_push(mxlo_qn *h, const T *s, const T *y, int32_t *accepted) {
   const int64_t n = h->n, mem = h->mem;
   T *ymBs = (T *)h->tmp;
   MXLO_HIP(hipMemcpyAsync(ymBs, y, sizeof(T) * n, hipMemcpyDeviceToDevice, ctx->stream));  // :124
-  MXLO_TRY(lsr1_mul<T>(h, ymBs, s, -1.0, 1.0, 0));                                         // :125
+  if (h->big) MXLO_TRY(lsr1_mul_big<T>(h, ymBs, s, -1.0, 1.0, 0, 0.0));                    // :125
+  else MXLO_TRY(lsr1_mul<T>(h, ymBs, s, -1.0, 1.0, 0));
   double *misc = h->dsc + h->lay.misc;
   const T *c3[3] = {y, s, ymBs};
   MXLO_TRY(panel_dots<T>(ctx, c3, 3, s, n, misc));          // y's, s's, ymBs's
@@ -1154,6 +1223,8 @@ int32_t lsr1_push(mxlo_qn *h, const T *s, const T *y, int32_t *accepted) {
   h->age[ins] = ++h->pushes;
   if (h->scaling) h->scaling_factor = (double)(ys / yy);                                   // :158
   h->insert0 = (ins + 1) % mem;                                                            // :163
+  ++h->generation;
+  if (h->big) return lsr1_rebuild_big<T>(h, ins);
   // rebuild the rank-1 terms (:166-181)
   double *dots = h->dsc + h->lay.dots, *coef = h->dsc + h->lay.coef, *as_ = h->dsc + h->lay.as_;
   OrdArgs O;
@@ -1434,7 +1505,57 @@ int32_t diag_t(mxlo_qn *h, T *d) {
   return launch_combine<T, CM_DIAG_SR1>(h->ctx, d, (const T *)nullptr, (const T *)nullptr, A, h->n, 0);
 }
 
+#include "qn_big.h"
+
+template <typename T>
+int32_t panel_gemm_big(mxlo_ctx *ctx, const std::vector<const T *> &in, const std::vector<T *> &out, const double *C,
+                       int64_t n) {
+  const int nin = (int)in.size(), nout = (int)out.size();
+  for (int o0 = 0; o0 < nout; o0 += kGemmOut) {
+    const int no = std::min(kGemmOut, nout - o0);
+    for (int i0 = 0; i0 < nin; i0 += kGemmIn) {
+      const int ni = std::min(kGemmIn, nin - i0);
+      PanelGemmArgs<T> G;
+      G.nin = ni;
+      G.nout = no;
+      G.C = C + (int64_t)o0 * nin + i0;
+      G.cstride = nin;
+      G.accum = i0 > 0;
+      for (int j = 0; j < ni; ++j) G.in[j] = in[i0 + j];
+      for (int k = 0; k < no; ++k) G.out[k] = out[o0 + k];
+      MXLO_TRY(launch_panel_gemm<T>(ctx, G, n));
+    }
+  }
+  return MXLO_OK;
+}
+
 }  // namespace
+
+// ---- live-handle registry: lets a captured hipGraph check that the quasi-Newton state it baked in (slot order,
+// γ, which kernels run) is still current — common.h: qn_generation / graph staleness check in api_ctx.hip.
+#include <mutex>
+#include <unordered_set>
+static std::mutex g_qn_mu;
+static std::unordered_set<const mxlo_qn *> g_qn_live;
+static void qn_live_add(const mxlo_qn *h) {
+  std::lock_guard<std::mutex> lk(g_qn_mu);
+  g_qn_live.insert(h);
+}
+static void qn_live_remove(const mxlo_qn *h) {
+  std::lock_guard<std::mutex> lk(g_qn_mu);
+  g_qn_live.erase(h);
+}
+namespace mxlo {
+bool qn_generation(const mxlo_qn *h, int64_t *gen) {
+  std::lock_guard<std::mutex> lk(g_qn_mu);
+  if (!g_qn_live.count(h)) return false;
+  *gen = h->generation;
+  return true;
+}
+static void note_capture(mxlo_qn *h) {
+  if (h->ctx->capturing) h->ctx->captured_qn.emplace_back(h, h->generation);
+}
+}  // namespace mxlo
 
 // ==================================================================================== C ABI
 MXLO_API int32_t mxlo_qn_create(mxlo_ctx *ctx, int32_t kind, int32_t dtype, int64_t n, int64_t mem,
@@ -1446,9 +1567,11 @@ MXLO_API int32_t mxlo_qn_create(mxlo_ctx *ctx, int32_t kind, int32_t dtype, int6
   MXLO_REQUIRE(dtype == MXLO_F64 || dtype == MXLO_F32, MXLO_EINVAL, "bad dtype %d", dtype);
   MXLO_REQUIRE(n >= 0, MXLO_ESHAPE, "n < 0");
   if (mem < 1) mem = 1;  // max(mem, 1), src/lbfgs.jl:37
+  // any mem, like the reference (src/lbfgs.jl:26-35): up to 64 (inverse) / 32 (forward, L-SR1) slots run the by-value
+  // single-wave path, larger memories the device-resident path of qn_big.h
   const int mem_cap = kind == MXLO_QN_LBFGS_INV ? kMaxMem : kMaxMemFwd;
-  MXLO_REQUIRE(mem <= mem_cap, MXLO_EINVAL, "mem = %lld exceeds the supported maximum %d for this operator kind",
-               (long long)mem, mem_cap);
+  MXLO_REQUIRE(mem <= kBigMaxMem, MXLO_EINVAL, "mem = %lld exceeds %d (the m x m Gram matrices alone would take %lld MB)",
+               (long long)mem, kBigMaxMem, (long long)(13 * mem * mem * 8 >> 20));
   mxlo_qn *h = new mxlo_qn();
   h->ctx = ctx;
   h->kind = kind;
@@ -1458,6 +1581,7 @@ MXLO_API int32_t mxlo_qn_create(mxlo_ctx *ctx, int32_t kind, int32_t dtype, int6
   const int64_t es = dtype == MXLO_F64 ? 8 : 4;
   const int64_t vec = 16 / es;
   h->push_mode = kind == MXLO_QN_LBFGS_FWD ? MXLO_PUSH_COMPACT : MXLO_PUSH_GRAM;
+  h->big = mem > mem_cap;
   h->ld = ((n + vec - 1) / vec) * vec;
   if (h->ld == 0) h->ld = vec;
   h->scaling = scaling != 0;
@@ -1467,7 +1591,7 @@ MXLO_API int32_t mxlo_qn_create(mxlo_ctx *ctx, int32_t kind, int32_t dtype, int6
   h->mode = ctx->tune.lbfgs_inv_mode;
   h->ys.assign(mem, 0.0);
   h->age.assign(mem, 0);
-  h->lay = DscLayout(mem);
+  h->lay = DscLayout(mem, h->big);
   const size_t pbytes = (size_t)h->ld * mem * es;
   hipError_t e = hipSuccess;
   auto alloc = [&](void **p, size_t bytes) {
@@ -1483,11 +1607,20 @@ MXLO_API int32_t mxlo_qn_create(mxlo_ctx *ctx, int32_t kind, int32_t dtype, int6
   alloc(&h->tmp, (size_t)h->ld * es);
   alloc(&h->tmp2, (size_t)h->ld * es);
   alloc((void **)&h->dsc, sizeof(double) * h->lay.total);
+  if (h->big) alloc(&h->meta, meta_bytes(mem));
   if (e != hipSuccess) {
     set_error("mxlo_qn_create: device allocation failed: %s", hipGetErrorString(e));
     mxlo_qn_destroy(h);
     return MXLO_ENOMEM;
   }
+  if (h->big) {
+    const int32_t st = sync_meta(h);
+    if (st != MXLO_OK) {
+      mxlo_qn_destroy(h);
+      return st;
+    }
+  }
+  qn_live_add(h);
   *out = h;
   return MXLO_OK;
 }
@@ -1495,8 +1628,9 @@ MXLO_API int32_t mxlo_qn_create(mxlo_ctx *ctx, int32_t kind, int32_t dtype, int6
 MXLO_API int32_t mxlo_qn_destroy(mxlo_qn *h) {
   if (!h) return MXLO_OK;
   MXLO_DEVICE_GUARD(h->ctx);
+  qn_live_remove(h);
   (void)hipStreamSynchronize(h->ctx->stream);
-  for (void *p : {h->S, h->Y, h->A, h->B, h->tmp, h->tmp2, (void *)h->dsc})
+  for (void *p : {h->S, h->Y, h->A, h->B, h->tmp, h->tmp2, (void *)h->dsc, h->meta})
     if (p) (void)hipFree(p);
   delete h;
   return MXLO_OK;
@@ -1505,6 +1639,7 @@ MXLO_API int32_t mxlo_qn_destroy(mxlo_qn *h) {
 MXLO_API int32_t mxlo_qn_set_mode(mxlo_qn *h, int32_t mode) {
   MXLO_REQUIRE(h, MXLO_EINVAL, "handle is NULL");
   MXLO_REQUIRE(mode == MXLO_INV_TWOPASS || mode == MXLO_INV_REFORDER, MXLO_EINVAL, "bad mode");
+  if (h->mode != mode) ++h->generation;
   h->mode = mode;
   return MXLO_OK;
 }
@@ -1514,6 +1649,12 @@ MXLO_API int32_t mxlo_qn_set_push_mode(mxlo_qn *h, int32_t mode) {
   MXLO_REQUIRE(mode == MXLO_PUSH_GRAM || mode == MXLO_PUSH_REFORDER || mode == MXLO_PUSH_COMPACT, MXLO_EINVAL,
                "bad push mode");
   if (mode == MXLO_PUSH_COMPACT && h->kind != MXLO_QN_LBFGS_FWD) mode = MXLO_PUSH_GRAM;   // forward L-BFGS only
+  if (h->big) {   // device-resident path: forward L-BFGS stays compact, L-SR1 Gram-form; no reference-ordered rebuild
+    MXLO_REQUIRE(mode != MXLO_PUSH_REFORDER, MXLO_ESTATE,
+                 "the reference-ordered push! rebuild is a validation mode limited to mem <= %d", kMaxMemFwd);
+    mode = h->kind == MXLO_QN_LBFGS_FWD ? MXLO_PUSH_COMPACT : MXLO_PUSH_GRAM;
+  }
+  if (h->push_mode != mode) ++h->generation;
   h->push_mode = mode;
   return MXLO_OK;
 }
@@ -1522,6 +1663,7 @@ MXLO_API int32_t mxlo_qn_mul(mxlo_qn *h, void *res, const void *x, double alpha,
                              int32_t flags) {
   MXLO_REQUIRE(h && (h->n == 0 || (res && x)), MXLO_EINVAL, "mxlo_qn_mul: NULL argument");
   MXLO_DEVICE_GUARD(h->ctx);
+  note_capture(h);
   if (h->dtype == MXLO_F64) return qn_mul_t<double>(h, (double *)res, (const double *)x, alpha, beta, flags);
   return qn_mul_t<float>(h, (float *)res, (const float *)x, alpha, beta, flags);
 }
@@ -1530,6 +1672,7 @@ MXLO_API int32_t mxlo_qn_mul_shifted(mxlo_qn *h, void *res, const void *x, doubl
                                      double sigma, int32_t flags) {
   MXLO_REQUIRE(h && (h->n == 0 || (res && x)), MXLO_EINVAL, "mxlo_qn_mul_shifted: NULL argument");
   MXLO_DEVICE_GUARD(h->ctx);
+  note_capture(h);
   // shifted_prod! (src/shifted_operators.jl:16-25): mul!(y, H, x, α, β); iszero(σ) || iszero(α) || axpy!(α*σ, x, y).
   // α*σ is formed in the callers' types (σ is a T; α a T or a Float64), then axpy! converts it to T.
   double c = 0.0;
@@ -1587,9 +1730,14 @@ MXLO_API int32_t mxlo_qn_push_damped_inv(mxlo_qn *h, const void *s, void *y, dou
 MXLO_API int32_t mxlo_qn_solve_shifted(mxlo_qn *h, void *x, const void *b, double sigma) {
   MXLO_REQUIRE(h && (h->n == 0 || (x && b)), MXLO_EINVAL, "NULL argument");
   MXLO_DEVICE_GUARD(h->ctx);
+  note_capture(h);
   MXLO_REQUIRE(h->kind == MXLO_QN_LBFGS_FWD, MXLO_ESTATE,
                "solve_shifted_system! is defined for forward L-BFGS operators");
   MXLO_REQUIRE(!(sigma < 0), MXLO_EDOMAIN, "σ must be nonnegative");
+  if (h->big) {
+    if (h->dtype == MXLO_F64) return solve_shifted_big<double>(h, (double *)x, (const double *)b, sigma);
+    return solve_shifted_big<float>(h, (float *)x, (const float *)b, (double)(float)sigma);
+  }
   if (h->dtype == MXLO_F64) return solve_shifted_t<double>(h, (double *)x, (const double *)b, sigma);
   return solve_shifted_t<float>(h, (float *)x, (const float *)b, (double)(float)sigma);
 }
@@ -1597,8 +1745,13 @@ MXLO_API int32_t mxlo_qn_solve_shifted(mxlo_qn *h, void *x, const void *b, doubl
 MXLO_API int32_t mxlo_qn_diag(mxlo_qn *h, void *d) {
   MXLO_REQUIRE(h && (h->n == 0 || d), MXLO_EINVAL, "NULL argument");
   MXLO_DEVICE_GUARD(h->ctx);
+  note_capture(h);
   MXLO_REQUIRE(h->kind != MXLO_QN_LBFGS_INV, MXLO_ESTATE,
                "only the diagonal of a forward L-BFGS approximation is available");
+  if (h->big) {
+    if (h->dtype == MXLO_F64) return diag_big<double>(h, (double *)d);
+    return diag_big<float>(h, (float *)d);
+  }
   if (h->dtype == MXLO_F64) return diag_t<double>(h, (double *)d);
   return diag_t<float>(h, (float *)d);
 }
@@ -1620,7 +1773,8 @@ MXLO_API int32_t mxlo_qn_reset(mxlo_qn *h) {
   h->normA_valid = true;
   h->A_valid = true;
   h->gram_ok = true;
-  return MXLO_OK;
+  ++h->generation;
+  return sync_meta(h);
 }
 
 MXLO_API int32_t mxlo_qn_get_scalars(mxlo_qn *h, double scalars[5], double *ys, double *aux) {
@@ -1680,7 +1834,10 @@ MXLO_API int32_t mxlo_qn_column(mxlo_qn *h, int32_t which, int64_t k, void **out
   void *p = which == 0 ? h->S : which == 1 ? h->Y : which == 2 ? h->A : which == 3 ? h->B : nullptr;
   MXLO_REQUIRE(p, MXLO_ESTATE, "panel %d not allocated for this operator kind", which);
   if (which == 2) {  // a compact push! left the a_k implicit
-    if (h->dtype == MXLO_F64) MXLO_TRY(ensure_A<double>(h));
+    if (h->big) {
+      if (h->dtype == MXLO_F64) MXLO_TRY(ensure_A_big<double>(h));
+      else MXLO_TRY(ensure_A_big<float>(h));
+    } else if (h->dtype == MXLO_F64) MXLO_TRY(ensure_A<double>(h));
     else MXLO_TRY(ensure_A<float>(h));
   }
   *out = (char *)p + (size_t)k * h->ld * (h->dtype == MXLO_F64 ? 8 : 4);

@@ -58,7 +58,7 @@ def test_status_codes_not_exceptions(lo, dev):
     assert L.mxlo_gather(ctx, 3, px, px, 8, px, 1) == lo._lib.EINVAL                  # element size 3
     assert L.mxlo_ctx_tune(ctx, b"no_such_key", 1) == lo._lib.EINVAL
     h = C.c_void_p()
-    assert L.mxlo_qn_create(ctx, lo._lib.QN_LBFGS_FWD, 0, 8, 40, 1, 0, 0.99, 10.0, C.byref(h)) == lo._lib.EINVAL  # mem > 32
+    assert L.mxlo_qn_create(ctx, lo._lib.QN_LBFGS_FWD, 0, 8, 5000, 1, 0, 0.99, 10.0, C.byref(h)) == lo._lib.EINVAL  # mem > 4096
     assert L.mxlo_qn_create(ctx, lo._lib.QN_LBFGS_INV, 0, 8, 3, 1, 0, 0.99, 10.0, C.byref(h)) == 0
     assert L.mxlo_qn_solve_shifted(h, px, px, 0.5) == lo._lib.ESTATE                   # inverse operator
     assert L.mxlo_qn_diag(h, px) == lo._lib.ESTATE

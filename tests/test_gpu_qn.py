@@ -511,7 +511,76 @@ def test_inverse_lbfgs_large_memory(lo, dev, dtype, mem, npush):
                 lo.mul(res, H, T(x, dev), 2.0, -3.0)
                 assert rel(res.cpu().numpy(), want) <= tol[mode], (mode, k)
             H.set_mode("twopass")
-    for ctor in (lo.LBFGSOperator, lo.LSR1Operator):
-        with pytest.raises(lo.MxloError, match="exceeds the supported maximum"):
-            ctor(dtype, n, mem=33, device=dev)
     assert lo.LBFGSOperator(dtype, n, mem=32, device=dev).mem == 32
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("kind,mem,npush", [("fwd", 100, 130), ("fwd", 33, 20), ("inv", 100, 130), ("inv", 65, 40),
+                                            ("lsr1", 40, 55), ("lsr1", 100, 60)])
+def test_unbounded_memory(lo, dev, dtype, kind, mem, npush):
+    """The reference accepts any `mem` (src/lbfgs.jl:26-57, src/lsr1.jl:19-34). Beyond the single-wave coefficient
+    kernels (64 slots inverse, 32 forward / L-SR1) the device-resident path of csrc/qn_big.h takes over: same parity
+    bars against the oracle for mul! (5-arg), push! incl. buffer wrap-around and rejections, diag!, reset! and — forward
+    — solve_shifted_system!."""
+    npd = NP[dtype]
+    n = 3001
+    rng = np.random.default_rng(1000 * mem + npush)
+    f64 = dtype == torch.float64
+    tol = (1e-9 if f64 else 1e-3)
+    if kind == "lsr1":
+        B = lo.LSR1Operator(dtype, n, mem=mem, device=dev)
+        Bo = oracle.LSR1(n, mem=mem, scaling=True, dtype=npd)
+    else:
+        ctor = lo.LBFGSOperator if kind == "fwd" else lo.InverseLBFGSOperator
+        B = ctor(dtype, n, mem=mem, device=dev)
+        Bo = oracle.LBFGS(n, mem=mem, scaling=True, inverse=(kind == "inv"), dtype=npd)
+    assert B.mem == mem
+    x, r0 = rng.uniform(-1, 1, n).astype(npd), rng.uniform(-1, 1, n).astype(npd)
+    checks = {0, 5, mem - 1, mem, npush - 1}
+    for k, (s, y) in enumerate(pairs(rng, n, npush, npd)):
+        if k == 7:                                         # a rejected pair (y's <= eps) must not disturb the state
+            lo.push(B, T(s, dev), T(-s, dev))
+            Bo.push(s, -s)
+        lo.push(B, T(s, dev), T(y, dev))
+        Bo.push(s, y)
+        if k in checks:
+            assert B.data.insert == Bo.insert, k
+            for alpha, beta in ((1.0, 0.0), (2.0, -3.0)):
+                fl = oracle.scalar_flags(npd, alpha, beta)
+                res = T(r0.copy(), dev)
+                if beta == 0:
+                    res.fill_(float("nan"))
+                lo.mul(res, B, T(x, dev), alpha, beta)
+                assert rel(res.cpu().numpy(), Bo.mul(r0.copy(), x, alpha, beta, flags=fl)) <= tol, (kind, k, alpha)
+            if kind == "inv":
+                B.set_mode("reforder")
+                res = T(r0.copy(), dev)
+                lo.mul(res, B, T(x, dev), 2.0, -3.0)
+                assert rel(res.cpu().numpy(), Bo.mul(r0.copy(), x, 2.0, -3.0, flags=oracle.scalar_flags(npd, 2.0, -3.0))) <= (1e-10 if f64 else 1e-3)
+                B.set_mode("twopass")
+    assert abs(B.data.scaling_factor - Bo.scaling_factor) <= 1e-6 * abs(Bo.scaling_factor)
+    if kind != "inv":
+        assert rel(lo.diag(B).cpu().numpy(), Bo.diag()) <= tol
+        assert rel(B.data.opnorm_upper_bound, Bo.opnorm_upper_bound) <= 1e-4
+    if kind == "fwd":
+        sigma = 0.3
+        b = (B * T(x, dev)) + sigma * T(x, dev)
+        xs = lo.solve_shifted_system(torch.zeros(n, dtype=dtype, device=dev), B, b, sigma)
+        assert np.allclose(xs.cpu().numpy(), x, atol=1e-6 if f64 else 5e-2, rtol=1e-6 if f64 else 5e-2)
+        if f64:
+            assert rel(xs.cpu().numpy(), Bo.solve_shifted(np.zeros(n), b.cpu().numpy(), sigma)) <= 1e-7
+        with pytest.raises(lo.MxloError):
+            B.set_push_mode("reforder")                   # a validation mode of the small-memory path only
+    lo.reset(B)
+    assert rel((B * T(x, dev)).cpu().numpy(), x) == 0.0   # empty memory: the identity
+    s, y = pairs(rng, n, 1, npd)[0]
+    lo.push(B, T(s, dev), T(y, dev))
+    Bo2 = (oracle.LSR1(n, mem=mem, scaling=True, dtype=npd) if kind == "lsr1"
+           else oracle.LBFGS(n, mem=mem, scaling=True, inverse=(kind == "inv"), dtype=npd))
+    Bo2.push(s, y)
+    assert rel((B * T(x, dev)).cpu().numpy(), Bo2.mul(np.empty(n, npd), x, 1.0, 0.0, flags=oracle.scalar_flags(npd, 1.0, 0.0))) <= tol
+
+
+def test_mem_limit_message(lo, dev):
+    with pytest.raises(lo.MxloError, match="exceeds 4096"):
+        lo.LBFGSOperator(torch.float64, 8, mem=5000, device=dev)

@@ -28,6 +28,66 @@ int32_t mxlo_rccl_comm_destroy(void *comm);
 int32_t mxlo_rccl_allreduce_hook(void *user, void *dev_buf, int64_t count, void *stream);
 const char *mxlo_rccl_last_error(void);
 
+/* ======================================================================================================
+ *  Single-process multi-device API ("host code stays in one Julia process").
+ *
+ *  The reference's device extension is a single-process model (ext/LinearOperatorsAMDGPUExt.jl:6); a Julia
+ *  host has no torch.distributed and should not need MPI to drive the 8 GPUs of one node. One call builds,
+ *  for every listed device, a non-blocking stream, an `mxlo_ctx` on it, an RCCL communicator
+ *  (ncclCommInitAll) installed as that ctx's all-reduce hook, and one worker thread. A `_sharded` entry point
+ *  takes PER-DEVICE POINTER ARRAYS (shard i = a contiguous row range of length n_local[i] living on device i)
+ *  and runs the ordinary entry point of mxlo.h on every shard from that shard's worker thread; the only
+ *  cross-device traffic is the scalar all-reduce inside the hook, enqueued on the shard's own stream
+ *  (one thread per communicator: no ncclGroupStart/End choreography, and every kernel sequence of libmxlo works
+ *  sharded unchanged). A call returns once every shard has ENQUEUED its work; `mxlo_shard_ctx_sync` waits.
+ *  All shards end up with bit-identical replicated scalars (ys, Gram matrices, accept/reject of push!).
+ *
+ *  Listing one device id several times selects the LOOPBACK transport (several shards on one GPU, summed in
+ *  fixed rank order through stream events): a test/debug mode for boxes with a single GPU.
+ *  Status codes are those of mxlo.h; `mxlo_shard_last_error()` names the failing shard. */
+typedef struct mxlo_ctx mxlo_ctx;
+typedef struct mxlo_qn mxlo_qn;
+typedef struct mxlo_shard_ctx mxlo_shard_ctx;
+typedef struct mxlo_qn_sharded mxlo_qn_sharded;
+
+/* dev_ids == NULL: devices 0 .. ndev-1. */
+int32_t mxlo_shard_ctx_create(int32_t ndev, const int32_t *dev_ids, mxlo_shard_ctx **out);
+int32_t mxlo_shard_ctx_destroy(mxlo_shard_ctx *s);
+int32_t mxlo_shard_ctx_ndev(mxlo_shard_ctx *s);
+int32_t mxlo_shard_ctx_device(mxlo_shard_ctx *s, int32_t i);
+int32_t mxlo_shard_ctx_is_loopback(mxlo_shard_ctx *s);
+/* the ctx of shard i: allocate / copy that shard's vectors with mxlo_malloc / mxlo_memcpy_* on it */
+mxlo_ctx *mxlo_shard_ctx_get(mxlo_shard_ctx *s, int32_t i);
+int32_t mxlo_shard_ctx_sync(mxlo_shard_ctx *s);
+const char *mxlo_shard_last_error(void);
+
+/* mulHouseholder! (src/linalg.jl:77-83), rows sharded: one 8-byte all-reduce of h'v between the two passes. */
+int32_t mxlo_householder_mul_sharded(mxlo_shard_ctx *s, int32_t dtype, void *const *res, const void *const *h,
+                                     const void *const *v, const int64_t *n_local, double alpha, double beta,
+                                     int32_t flags);
+/* mulSquareOpDiagonal! (src/special-operators.jl:125-131), rows sharded: independent shards, no exchange. */
+int32_t mxlo_diag_mul_sharded(mxlo_shard_ctx *s, int32_t dtype, void *const *res, const void *const *d,
+                              const void *const *v, const int64_t *n_local, double alpha, double beta, int32_t flags);
+
+/* LBFGSData / LSR1Data (src/lbfgs.jl:26-57, src/lsr1.jl:19-34) with every stored vector row-sharded. */
+int32_t mxlo_qn_create_sharded(mxlo_shard_ctx *s, int32_t kind, int32_t dtype, const int64_t *n_local, int64_t mem,
+                               int32_t scaling, int32_t damped, double sigma2, double sigma3, mxlo_qn_sharded **out);
+int32_t mxlo_qn_destroy_sharded(mxlo_qn_sharded *q);
+mxlo_qn *mxlo_qn_sharded_get(mxlo_qn_sharded *q, int32_t i);
+/* push!(op, s, y) (src/lbfgs.jl:269-287, src/lsr1.jl:119-184): 2-5 doubles all-reduced; `accepted` is replicated. */
+int32_t mxlo_qn_push_sharded(mxlo_qn_sharded *q, const void *const *s, const void *const *y, int32_t *accepted);
+/* lbfgs_multiply / lsr1_multiply (src/lbfgs.jl:117-154,173-202; src/lsr1.jl:89-107): one all-reduce of <= 2 mem doubles. */
+int32_t mxlo_qn_mul_sharded(mxlo_qn_sharded *q, void *const *res, const void *const *x, double alpha, double beta,
+                            int32_t flags);
+int32_t mxlo_qn_mul_shifted_sharded(mxlo_qn_sharded *q, void *const *res, const void *const *x, double alpha,
+                                    double beta, double sigma, int32_t flags);
+/* solve_shifted_system! (src/utilities.jl:207-248), forward L-BFGS. */
+int32_t mxlo_qn_solve_shifted_sharded(mxlo_qn_sharded *q, void *const *x, const void *const *b, double sigma);
+int32_t mxlo_qn_diag_sharded(mxlo_qn_sharded *q, void *const *d);
+int32_t mxlo_qn_reset_sharded(mxlo_qn_sharded *q);
+/* replicated scalars as seen by shard i (layout of mxlo_qn_get_scalars) */
+int32_t mxlo_qn_get_scalars_sharded(mxlo_qn_sharded *q, int32_t i, double scalars[5], double *ys, double *aux);
+
 #ifdef __cplusplus
 }
 #endif

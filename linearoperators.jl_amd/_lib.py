@@ -197,6 +197,32 @@ def rccl_lib() -> C.CDLL:
         for f in (R.mxlo_rccl_unique_id, R.mxlo_rccl_comm_create, R.mxlo_rccl_comm_destroy, R.mxlo_rccl_allreduce_hook):
             f.restype = _i32
         R.mxlo_rccl_last_error.restype = C.c_char_p
+        # single-process multi-device API (include/mxlo_rccl.h)
+        pp, ip = C.POINTER(_vp), C.POINTER(_i64)
+        for name, args in {
+            "mxlo_shard_ctx_create": [_i32, C.POINTER(_i32), C.POINTER(_vp)],
+            "mxlo_shard_ctx_destroy": [_vp], "mxlo_shard_ctx_ndev": [_vp], "mxlo_shard_ctx_device": [_vp, _i32],
+            "mxlo_shard_ctx_is_loopback": [_vp], "mxlo_shard_ctx_sync": [_vp],
+            "mxlo_householder_mul_sharded": [_vp, _i32, pp, pp, pp, ip, _dbl, _dbl, _i32],
+            "mxlo_diag_mul_sharded": [_vp, _i32, pp, pp, pp, ip, _dbl, _dbl, _i32],
+            "mxlo_qn_create_sharded": [_vp, _i32, _i32, ip, _i64, _i32, _i32, _dbl, _dbl, C.POINTER(_vp)],
+            "mxlo_qn_destroy_sharded": [_vp],
+            "mxlo_qn_push_sharded": [_vp, pp, pp, C.POINTER(_i32)],
+            "mxlo_qn_mul_sharded": [_vp, pp, pp, _dbl, _dbl, _i32],
+            "mxlo_qn_mul_shifted_sharded": [_vp, pp, pp, _dbl, _dbl, _dbl, _i32],
+            "mxlo_qn_solve_shifted_sharded": [_vp, pp, pp, _dbl],
+            "mxlo_qn_diag_sharded": [_vp, pp],
+            "mxlo_qn_reset_sharded": [_vp],
+            "mxlo_qn_get_scalars_sharded": [_vp, _i32, C.POINTER(_dbl), C.POINTER(_dbl), C.POINTER(_dbl)],
+        }.items():
+            f = getattr(R, name)
+            f.argtypes = args
+            f.restype = _i32
+        R.mxlo_shard_ctx_get.argtypes = [_vp, _i32]
+        R.mxlo_shard_ctx_get.restype = _vp
+        R.mxlo_qn_sharded_get.argtypes = [_vp, _i32]
+        R.mxlo_qn_sharded_get.restype = _vp
+        R.mxlo_shard_last_error.restype = C.c_char_p
         _rccl = R
     return _rccl
 

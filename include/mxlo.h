@@ -136,7 +136,12 @@ int32_t mxlo_memset(mxlo_ctx *ctx, void *p, int32_t byte, int64_t bytes);
  * Buffers, sizes and alpha/beta are baked in (the data they point to is read at replay time). The ctx
  * stream must not be the default stream (mxlo_ctx_create_stream gives the ctx one it owns). Not
  * capturable: push! and mxlo_memcpy_d2h (host control flow / synchronising) and the first opHermitian
- * apply of a new size (workspace growth) — run those outside, once, before capturing. */
+ * apply of a new size (workspace growth) — run those outside, once, before capturing.
+ * Staleness: a quasi-Newton apply bakes the handle's slot order, insert position and update count into the
+ * recorded launches, and opHermitian bakes the ctx scratch pointer. A graph therefore remembers the generation of
+ * every quasi-Newton handle it captured (bumped by push!, reset! and mode changes) and of the ctx scratch
+ * (bumped by workspace growth); mxlo_graph_launch returns MXLO_ESTATE — it never replays stale metadata — when
+ * any of them changed or a captured handle was destroyed. Re-capture after push!/reset!. */
 typedef struct mxlo_graph mxlo_graph;
 int32_t mxlo_ctx_create_stream(mxlo_ctx *ctx, void **stream_out); /* non-blocking stream owned by the ctx */
 int32_t mxlo_graph_begin(mxlo_ctx *ctx);
@@ -355,8 +360,14 @@ int32_t mxlo_diagqn_push(mxlo_ctx *ctx, int32_t dtype, int32_t kind, void *d, co
 #define MXLO_INV_REFORDER 1 /* reference statement order: 2m chained fused axpy+dot      */
 
 /* LBFGSData / LSR1Data constructors — src/lbfgs.jl:26-57, src/lsr1.jl:19-34.
- * mem is clamped to >= 1 like the reference; the supported maximum is 64 for the inverse operator and 32 for
- * forward L-BFGS / L-SR1 (MXLO_EINVAL above that). Panels s,y(,a,b) are n x mem
+ * mem is clamped to >= 1 like the reference. Two state layouts, chosen by mem, with identical semantics:
+ *   mem <= 64 (inverse) / <= 32 (forward, L-SR1): coefficient recurrences run in LDS of ONE workgroup and the
+ *             slot metadata travel as kernel arguments (the launch-bound regime the reference's defaults live in);
+ *   larger mem, up to 4096: Gram matrices, recurrences and slot order live in HBM (block-wide coefficient
+ *             kernels, O(mem^2) doubles); the forward operator always uses the compact representation and
+ *             MXLO_PUSH_REFORDER is refused with MXLO_ESTATE there.
+ * mem > 4096 is MXLO_EINVAL with a message naming the limit (n x mem panels are the caller's memory budget:
+ * 4 panels x n x mem x sizeof(T)). Panels s,y(,a,b) are n x mem
  * column-major allocations owned by the handle; shifted_p is NOT allocated
  * eagerly (the reference allocates n x 2mem at :53; the coefficient-space
  * solve does not need it). */

@@ -5,16 +5,28 @@
 # that IS executed and tested from Python/ctypes (linearoperators.jl_amd/{leaves,qn,sharded}.py) and
 # from plain C (tests/abi_client.c). Signatures are those of include/mxlo.h.
 #
-# Design: the extension adds *methods* to the reference's own constructor names, selected by the
-# device vector type `MXVector{T}`. Each closure body is one `ccall`; flags, counters, `mul!`
-# dispatch, adjoint/transpose wrappers, combinators, cat, `Matrix(op)` stay the reference's code.
+# Design: the reference's storage type `S` is a KEYWORD of its constructors (src/special-operators.jl:53,95,118,187,249)
+# and keywords do not take part in dispatch, so the extension hooks in one level lower, where the reference
+# dispatches on the VECTORS: it adds methods on the kernel functions the reference's closures call —
+# `mulOpEye!`, `mulOpOnes!`, `mulOpZeros!`, `mulSquareOpDiagonal!`, `mulOpDiagonal!`, `mulHouseholder!`,
+# `mulRestrict!`, `multRestrict!` — for `MXVector` arguments. Every existing call site
+# (`opEye(T, n; S = MXVector{T})`, `opDiagonal(d)`, `opRestriction(I, n; S = ...)`, and the internal
+# `opOnes(op.nrow, op.ncol)` of `op + x`, src/operations.jl:222-223) then reaches the device unchanged: whatever `S`
+# says, the closure is handed device vectors and dispatch does the rest. Constructors get their own methods only
+# where the reference's closure would allocate or copy per call (`conj.(d)` in opDiagonal's ctprod!,
+# src/special-operators.jl:139-141; `tril(A,-1)` in opHermitian; kron's `convert(Vector{S}, x)`, src/kron.jl:16)
+# or hard-codes `Vector{T}` (LBFGSData / LSR1Data, src/lbfgs.jl:26-57 — those need the storage type as a THIRD
+# POSITIONAL argument: `LBFGSOperator(T, n, MXVector{T}; mem = 5)`; see INTEGRATION.md).
+# Each body is one `ccall`; flags, counters, `mul!` dispatch, adjoint/transpose wrappers, combinators, cat,
+# `Matrix(op)` stay the reference's code.
 module LinearOperatorsMXLOExt
 
 using LinearOperators, LinearAlgebra
 import LinearOperators: storage_type, LinearOperator, LinearOperatorException, AbstractQuasiNewtonOperator,
   opDiagonal, opHouseholder, opHermitian, opRestriction, opEye, opOnes, opZeros, BlockDiagonalOperator,
   LBFGSOperator, InverseLBFGSOperator, LSR1Operator, reset!, diag!, solve_shifted_system!, has_args5,
-  isallocated5
+  isallocated5, mulOpEye!, mulOpOnes!, mulOpZeros!, mulSquareOpDiagonal!, mulOpDiagonal!, mulHouseholder!,
+  mulRestrict!, multRestrict!
 import Base: kron, push!, size, getindex, view, fill!, copyto!, similar, length, unsafe_convert
 import LinearAlgebra: ldiv!
 
@@ -93,23 +105,53 @@ MXMatrix(A::Matrix{T}) where {T} = MXMatrix{T}(MXVector(vec(A)), size(A)...)
 size(A::MXMatrix) = (A.m, A.n)
 storage_type(::MXMatrix{T}) where {T} = MXVector{T}        # cf. ext/LinearOperatorsAMDGPUExt.jl:6
 
-dt(::Type{Float64}) = Int32(0)   # MXLO_F64
-dt(::Type{Float32}) = Int32(1)   # MXLO_F32
-# Julia does not convert caller scalars to T (SURVEY §8a "Mixed precision"): Float32 data with a
-# Float64 alpha or beta is evaluated per element in Float64 and rounded once on store.
-@inline flags(::Type{Float32}, α, β) = (α isa Float64 ? Int32(1) : Int32(0)) | (β isa Float64 ? Int32(8) : Int32(0))  # MXLO_ALPHA_F64 | MXLO_BETA_F64
+dt(::Type{Float64}) = Int32(0)      # MXLO_F64
+dt(::Type{Float32}) = Int32(1)      # MXLO_F32
+dt(::Type{ComplexF64}) = Int32(2)   # MXLO_C64 (the `_c` entry points)
+dt(::Type{ComplexF32}) = Int32(3)   # MXLO_C32
+const RealT = Union{Float64, Float32}
+const CplxT = Union{ComplexF64, ComplexF32}
+# Julia does not convert caller scalars to T (SURVEY §8a "Mixed precision"): next to Float32 (ComplexF32) data the
+# α-term is evaluated in promote_type(typeof(α), T) and the β-term in promote_type(typeof(β), T), each on its own.
+@inline is64(x) = x isa Float64 || x isa ComplexF64
+@inline wflags(α, β) = (is64(α) ? Int32(1) : Int32(0)) | (is64(β) ? Int32(8) : Int32(0))      # MXLO_ALPHA_F64 | MXLO_BETA_F64
+@inline flags(::Type{Float32}, α, β) = wflags(α, β)
 @inline flags(::Type{Float64}, α, β) = Int32(0)
+# complex data: Real scalars multiply componentwise (MXLO_ALPHA_REAL 0x20 / MXLO_BETA_REAL 0x40)
+@inline rflags(α, β) = (α isa Real ? Int32(0x20) : Int32(0)) | (β isa Real ? Int32(0x40) : Int32(0))
+@inline flags(::Type{ComplexF64}, α, β) = rflags(α, β)
+@inline flags(::Type{ComplexF32}, α, β) = rflags(α, β) | wflags(α, β)
+@inline re(x) = Float64(real(x))
+@inline im(x) = Float64(imag(x))
 const P = Ptr{Cvoid}
 
 # ---- prod3! glue on MXVector (src/operations.jl:10-20) ----------------------------------------------------
 # `res .*= α`                       -> mxlo_scale
 # `res .= α .* Mv .+ β .* res`      -> mxlo_eye_mul without MXLO_TAIL_BETA (generic axpby)
-scale!(res::MXVector{T}, α) where {T} =
+scale!(res::MXVector{T}, α) where {T <: RealT} =
   check(ccall((:mxlo_scale, lib), Int32, (P, Int32, P, Int64, Float64, Int32), ctx(), dt(T), res.ptr, res.len, α,
               flags(T, α, α)))
-axpby!(res::MXVector{T}, v::MXVector{T}, α, β) where {T} =
+scale!(res::MXVector{T}, α) where {T <: CplxT} =
+  check(ccall((:mxlo_scale_c, lib), Int32, (P, Int32, P, Int64, Float64, Float64, Int32), ctx(), dt(T), res.ptr, res.len,
+              re(α), im(α), flags(T, α, α)))
+axpby!(res::MXVector{T}, v::MXVector{T}, α, β) where {T <: RealT} =
   check(ccall((:mxlo_eye_mul, lib), Int32, (P, Int32, P, P, Int64, Int64, Float64, Float64, Int32),
               ctx(), dt(T), res.ptr, v.ptr, res.len, res.len, α, β, flags(T, α, β)))
+axpby!(res::MXVector{T}, v::MXVector{T}, α, β) where {T <: CplxT} =
+  check(ccall((:mxlo_eye_mul_c, lib), Int32, (P, Int32, P, P, Int64, Int64, Float64, Float64, Float64, Float64, Int32),
+              ctx(), dt(T), res.ptr, v.ptr, res.len, res.len, re(α), im(α), re(β), im(β), flags(T, α, β)))
+# conj!(res) / conj.(v) of the wrapper routing (src/adjtrans.jl:127-136,193-204,226-249) on device vectors
+function Base.conj!(v::MXVector{T}) where {T <: CplxT}
+  check(ccall((:mxlo_conj_c, lib), Int32, (P, Int32, P, P, Int64), ctx(), dt(T), v.ptr, v.ptr, v.len))
+  v
+end
+Base.conj!(v::MXVector{<:Real}) = v
+function Base.conj(v::MXVector{T}) where {T <: CplxT}
+  out = similar(v)
+  check(ccall((:mxlo_conj_c, lib), Int32, (P, Int32, P, P, Int64), ctx(), dt(T), out.ptr, v.ptr, v.len))
+  out
+end
+Base.Broadcast.broadcasted(::typeof(conj), v::MXVector{<:CplxT}) = conj(v)      # `conj.(v)` (adjtrans.jl:128)
 
 # ---- BLAS-1 on device vectors: what Krylov.jl / JSOSolvers call between two mul! ------------------------------------
 # dot / norm need the scalar on the host: the fixed-order device reduction (mxlo_dot, all-reduce hook included, so
@@ -118,12 +160,19 @@ const DOTBUF = Ref{Ptr{Cvoid}}(C_NULL)
 function dotbuf()
   if DOTBUF[] == C_NULL
     r = Ref{Ptr{Cvoid}}()
-    check(ccall((:mxlo_malloc, lib), Int32, (P, Int64, Ptr{P}), ctx(), 8, r))
+    check(ccall((:mxlo_malloc, lib), Int32, (P, Int64, Ptr{P}), ctx(), 16, r))
     DOTBUF[] = r[]
   end
   DOTBUF[]
 end
-function LinearAlgebra.dot(a::MXVector{T}, b::MXVector{T}) where {T}
+function LinearAlgebra.dot(a::MXVector{T}, b::MXVector{T}) where {T <: CplxT}
+  length(a) == length(b) || throw(DimensionMismatch("dot"))
+  check(ccall((:mxlo_dot_c, lib), Int32, (P, Int32, P, P, Int64, P), ctx(), dt(T), a.ptr, b.ptr, length(a), dotbuf()))
+  out = zeros(Float64, 2)
+  check(ccall((:mxlo_memcpy_d2h, lib), Int32, (P, Ptr{Float64}, P, Int64), ctx(), out, dotbuf(), 16))
+  T(out[1], out[2])
+end
+function LinearAlgebra.dot(a::MXVector{T}, b::MXVector{T}) where {T <: RealT}
   length(a) == length(b) || throw(DimensionMismatch("dot"))
   check(ccall((:mxlo_dot, lib), Int32, (P, Int32, P, P, Int64, P), ctx(), dt(T), a.ptr, b.ptr, length(a), dotbuf()))
   out = Ref{Float64}(0.0)
@@ -135,54 +184,79 @@ LinearAlgebra.axpy!(α::Number, x::MXVector{T}, y::MXVector{T}) where {T} = (axp
 LinearAlgebra.axpby!(α::Number, x::MXVector{T}, β::Number, y::MXVector{T}) where {T} = (axpby!(y, x, T(α), T(β)); y)
 LinearAlgebra.rmul!(x::MXVector{T}, α::Number) where {T} = (scale!(x, T(α)); x)
 LinearAlgebra.lmul!(α::Number, x::MXVector{T}) where {T} = (scale!(x, T(α)); x)
-Base.fill!(v::MXVector{T}, x::Number) where {T} =
+Base.fill!(v::MXVector{T}, x::Number) where {T <: RealT} =
   (check(ccall((:mxlo_fill, lib), Int32, (P, Int32, P, Int64, Float64), ctx(), dt(T), v.ptr, v.len, Float64(x))); v)
 
-# ---- a3/a4 opDiagonal (src/special-operators.jl:125-165) ------------------------------------------------
-function opDiagonal(d::MXVector{T}) where {T}
+# ---- kernel-function methods: what the reference's OWN closures dispatch to when handed device vectors --------------
+# mulSquareOpDiagonal! / mulOpDiagonal! (src/special-operators.jl:125-131,144-151)
+mulSquareOpDiagonal!(res::MXVector{T}, d::MXVector{T}, v::MXVector{T}, α, β) where {T <: RealT} =
+  check(ccall((:mxlo_diag_mul, lib), Int32, (P, Int32, P, P, P, Int64, Int64, Float64, Float64, Int32),
+              ctx(), dt(T), res.ptr, d.ptr, v.ptr, length(res), length(res), α, β,
+              flags(T, α, β) | (length(d) == 1 && length(res) != 1 ? Int32(2) : Int32(0))))   # MXLO_D_SCALAR
+mulOpDiagonal!(res::MXVector{T}, d::MXVector{T}, v::MXVector{T}, α, β, n_min) where {T <: RealT} =
+  check(ccall((:mxlo_diag_mul, lib), Int32, (P, Int32, P, P, P, Int64, Int64, Float64, Float64, Int32),
+              ctx(), dt(T), res.ptr, d.ptr, v.ptr, n_min, length(res), α, β, flags(T, α, β)))
+cdiag(res::MXVector{T}, d::MXVector{T}, v::MXVector{T}, α, β, n_min, conjd::Bool) where {T <: CplxT} =
+  check(ccall((:mxlo_diag_mul_c, lib), Int32, (P, Int32, P, P, P, Int64, Int64, Float64, Float64, Float64, Float64, Int32),
+              ctx(), dt(T), res.ptr, d.ptr, v.ptr, n_min, length(res), re(α), im(α), re(β), im(β),
+              flags(T, α, β) | (conjd ? Int32(0x10) : Int32(0))))                              # MXLO_CONJ_D
+mulSquareOpDiagonal!(res::MXVector{T}, d::MXVector{T}, v::MXVector{T}, α, β) where {T <: CplxT} =
+  cdiag(res, d, v, α, β, length(res), false)
+mulOpDiagonal!(res::MXVector{T}, d::MXVector{T}, v::MXVector{T}, α, β, n_min) where {T <: CplxT} =
+  cdiag(res, d, v, α, β, n_min, false)
+# mulOpEye! (src/special-operators.jl:36-44): the tail receives β itself (MXLO_TAIL_BETA)
+mulOpEye!(res::MXVector{T}, v::MXVector{T}, α, β, n_min) where {T <: RealT} =
+  check(ccall((:mxlo_eye_mul, lib), Int32, (P, Int32, P, P, Int64, Int64, Float64, Float64, Int32),
+              ctx(), dt(T), res.ptr, v.ptr, n_min, length(res), α, β, flags(T, α, β) | Int32(4)))
+mulOpEye!(res::MXVector{T}, v::MXVector{T}, α, β, n_min) where {T <: CplxT} =
+  check(ccall((:mxlo_eye_mul_c, lib), Int32, (P, Int32, P, P, Int64, Int64, Float64, Float64, Float64, Float64, Int32),
+              ctx(), dt(T), res.ptr, v.ptr, n_min, length(res), re(α), im(α), re(β), im(β), flags(T, α, β) | Int32(4)))
+# mulOpOnes! (src/special-operators.jl:79-85) — real element types (fixed-order device sum, all-reduce hook included)
+mulOpOnes!(res::MXVector{T}, v::MXVector{T}, α, β) where {T <: RealT} =
+  check(ccall((:mxlo_ones_mul, lib), Int32, (P, Int32, P, Int64, P, Int64, Float64, Float64, Int32),
+              ctx(), dt(T), res.ptr, length(res), v.ptr, length(v), α, β, flags(T, α, β)))
+# mulOpZeros! (src/special-operators.jl:102-108)
+mulOpZeros!(res::MXVector{T}, v::MXVector, α, β) where {T <: RealT} =
+  check(ccall((:mxlo_zeros_mul, lib), Int32, (P, Int32, P, Int64, Float64, Int32), ctx(), dt(T), res.ptr, length(res), β,
+              flags(T, α, β)))
+mulOpZeros!(res::MXVector{T}, v::MXVector, α, β) where {T <: CplxT} =
+  check(ccall((:mxlo_zeros_mul_c, lib), Int32, (P, Int32, P, Int64, Float64, Float64, Int32), ctx(), dt(T), res.ptr,
+              length(res), re(β), im(β), flags(T, α, β)))
+# mulHouseholder! (src/linalg.jl:77-83); complex h: LinearAlgebra.dot conjugates it
+mulHouseholder!(res::MXVector{T}, h::MXVector{T}, v::MXVector{T}, α, β) where {T <: RealT} =
+  check(ccall((:mxlo_householder_mul, lib), Int32, (P, Int32, P, P, P, Int64, Float64, Float64, Int32),
+              ctx(), dt(T), res.ptr, h.ptr, v.ptr, length(res), α, β, flags(T, α, β)))
+mulHouseholder!(res::MXVector{T}, h::MXVector{T}, v::MXVector{T}, α, β) where {T <: CplxT} =
+  check(ccall((:mxlo_householder_mul_c, lib), Int32, (P, Int32, P, P, P, Int64, Float64, Float64, Float64, Float64, Int32),
+              ctx(), dt(T), res.ptr, h.ptr, v.ptr, length(res), re(α), im(α), re(β), im(β), flags(T, α, β)))
+
+# ---- a3/a4 opDiagonal (src/special-operators.jl:133-165): own constructor only so that ctprod! does not allocate
+# `conj.(d)` on every call (:139-141) — MXLO_CONJ_D conjugates d inside the kernel.
+function opDiagonal(d::MXVector{T}) where {T <: CplxT}
   n = length(d)
-  prod! = (res, v, α, β) -> check(ccall((:mxlo_diag_mul, lib), Int32,
-      (P, Int32, P, P, P, Int64, Int64, Float64, Float64, Int32),
-      ctx(), dt(T), res.ptr, d.ptr, v.ptr, n, n, α, β, flags(T, α, β)))
-  LinearOperator{T, MXVector{T}}(n, n, true, true, prod!, prod!, prod!)
+  prod! = (res, v, α, β) -> cdiag(res, d, v, α, β, n, false)
+  ctprod! = (res, w, α, β) -> cdiag(res, d, w, α, β, n, true)
+  LinearOperator{T, MXVector{T}}(n, n, true, false, prod!, prod!, ctprod!)          # hermitian = isreal(d) (:142)
 end
-function opDiagonal(nrow::I, ncol::I, d::MXVector{T}) where {T, I <: Integer}
-  nrow == ncol <= length(d) && return opDiagonal(d)
+function opDiagonal(nrow::I, ncol::I, d::MXVector{T}) where {T <: CplxT, I <: Integer}
+  nrow == ncol <= length(d) && return opDiagonal(view(d, 1:nrow))
   n_min = min(nrow, ncol)
-  # prod! writes nrow rows, tprod!/ctprod! write ncol rows; the tail is zeroed regardless of beta (:150)
-  prod! = (res, v, α, β) -> check(ccall((:mxlo_diag_mul, lib), Int32,
-      (P, Int32, P, P, P, Int64, Int64, Float64, Float64, Int32),
-      ctx(), dt(T), res.ptr, d.ptr, v.ptr, n_min, length(res), α, β, flags(T, α, β)))
-  LinearOperator{T, MXVector{T}}(nrow, ncol, false, false, prod!, prod!, prod!)
+  prod! = (res, v, α, β) -> cdiag(res, d, v, α, β, n_min, false)
+  ctprod! = (res, w, α, β) -> cdiag(res, d, w, α, β, n_min, true)
+  LinearOperator{T, MXVector{T}}(nrow, ncol, false, false, prod!, prod!, ctprod!)
 end
-
-# ---- opEye / opOnes / opZeros with S = MXVector{T} (src/special-operators.jl:36-115) --------------------
-function opEye(::Type{T}, n::Int, ::Type{MXVector{T}}) where {T}
-  prod! = (res, v, α, β) -> check(ccall((:mxlo_eye_mul, lib), Int32,
-      (P, Int32, P, P, Int64, Int64, Float64, Float64, Int32),
-      ctx(), dt(T), res.ptr, v.ptr, n, length(res), α, β, flags(T, α, β) | Int32(4)))   # MXLO_TAIL_BETA
-  LinearOperator{T, MXVector{T}}(n, n, true, true, prod!, prod!, prod!)
-end
-function opOnes(::Type{T}, nrow::Int, ncol::Int, ::Type{MXVector{T}}) where {T}
-  prod! = (res, v, α, β) -> check(ccall((:mxlo_ones_mul, lib), Int32,
-      (P, Int32, P, Int64, P, Int64, Float64, Float64, Int32),
-      ctx(), dt(T), res.ptr, length(res), v.ptr, length(v), α, β, flags(T, α, β)))
-  LinearOperator{T, MXVector{T}}(nrow, ncol, nrow == ncol, nrow == ncol, prod!, prod!, prod!)
-end
-function opZeros(::Type{T}, nrow::Int, ncol::Int, ::Type{MXVector{T}}) where {T}
-  prod! = (res, v, α, β) -> check(ccall((:mxlo_zeros_mul, lib), Int32, (P, Int32, P, Int64, Float64, Int32),
-      ctx(), dt(T), res.ptr, length(res), β, flags(T, α, β)))
-  LinearOperator{T, MXVector{T}}(nrow, ncol, nrow == ncol, nrow == ncol, prod!, prod!, prod!)
-end
-
-# ---- a5 opHouseholder (src/linalg.jl:77-95; the reference hard-codes S = Vector{T} at :94) ----------------
+# real d: the reference's generic constructors (opDiagonal(d), opDiagonal(nrow, ncol, d), opEye/opOnes/opZeros with
+# S = MXVector{T}, opHouseholder(h)) work as they are through the kernel-function methods above; opHouseholder's
+# hard-coded S = Vector{T} (src/linalg.jl:94) only matters for temporaries of compose, so give it the right S:
 function opHouseholder(h::MXVector{T}) where {T}
   n = length(h)
-  prod! = (res, v, α, β) -> check(ccall((:mxlo_householder_mul, lib), Int32,
-      (P, Int32, P, P, P, Int64, Float64, Float64, Int32),
-      ctx(), dt(T), res.ptr, h.ptr, v.ptr, n, α, β, flags(T, α, β)))
-  LinearOperator{T, MXVector{T}}(n, n, true, true, prod!, nothing, prod!)
+  prod! = (res, v, α, β) -> mulHouseholder!(res, h, v, α, β)
+  LinearOperator{T, MXVector{T}}(n, n, T <: Real, true, prod!, nothing, prod!)        # symmetric = isreal(h)
 end
+# `op + x` / `x + op` build `x * opOnes(op.nrow, op.ncol)` with T = Float64, S = Vector{Float64}
+# (src/operations.jl:222-223): for device operators the ones-operator must carry the device storage type.
+Base.:+(op::LinearOperator{T, MXVector{T}}, x::Number) where {T} = op + x * opOnes(T, op.nrow, op.ncol; S = MXVector{T})
+Base.:+(x::Number, op::LinearOperator{T, MXVector{T}}) where {T} = x * opOnes(T, op.nrow, op.ncol; S = MXVector{T}) + op
 
 # ---- a6 opHermitian (src/linalg.jl:97-127): the ORIGINAL matrix is passed; only tril(A,-1) is read ------------
 function opHermitian(d::MXVector{T}, A::MXMatrix{T}) where {T}
@@ -203,10 +277,12 @@ function LinearOperator(M::MXMatrix{T}; symmetric = false, hermitian = false) wh
   LinearOperator{T, MXVector{T}}(m, n, symmetric, hermitian, gemv(0), gemv(1), gemv(2))
 end
 
-# ---- a7 opRestriction / opExtension (src/special-operators.jl:167-222) ------------------------------------
-# The operator eltype is the INDEX integer type (:193); data eltype comes from `v`. alpha/beta are ignored
-# by the reference and are not ABI parameters. Index vectors live on the device as Int64, 1-based.
-struct ScatterPlan            # last-write-wins de-duplication, resolved once at construction
+# ---- a7 mulRestrict! / multRestrict! (src/special-operators.jl:167-174) --------------------------------------------
+# α, β are ignored by the reference and are not ABI parameters. `opRestriction(I, ncol; S = MXVector{T})` and
+# `opExtension` are the reference's own constructors; their closures land here. Ranges need no device memory; an
+# index Vector is uploaded once and cached per (objectid, length) together with its last-write-wins scatter plan.
+struct ScatterPlan            # duplicates: `res[I] = u` is sequential, the LAST write wins — resolved once
+  didx::MXVector{Int64}
   idx::MXVector{Int64}
   pos::Union{MXVector{Int64}, Nothing}
   n::Int
@@ -216,31 +292,30 @@ function ScatterPlan(I::AbstractVector{<:Integer})
   for (k, i) in enumerate(I)
     last[i] = k - 1                                   # 0-based source position of the surviving write
   end
-  length(last) == length(I) && return ScatterPlan(MXVector(collect(Int64, I)), nothing, length(I))
+  didx = MXVector(collect(Int64, I))
+  length(last) == length(I) && return ScatterPlan(didx, didx, nothing, length(I))
   ks = sort!(collect(keys(last)))
-  ScatterPlan(MXVector(ks), MXVector([last[i] for i in ks]), length(ks))
+  ScatterPlan(didx, MXVector(ks), MXVector([last[i] for i in ks]), length(ks))
 end
-function opRestriction(Idx::Union{UnitRange{I}, StepRange{I, I}}, ncol::I, ::Type{MXVector{T}}) where {I <: Integer, T}
-  all(1 .≤ Idx .≤ ncol) || throw(LinearOperatorException("indices should be between 1 and $ncol"))
-  st, sp, len = Int64(first(Idx)), Int64(step(Idx)), Int64(length(Idx))
-  prod! = (res, v, α, β) -> check(ccall((:mxlo_gather_range, lib), Int32,
-      (P, Int32, P, P, Int64, Int64, Int64, Int64), ctx(), Int32(sizeof(eltype(v))), res.ptr, v.ptr, length(v), st, sp, len))
-  tprod! = (res, u, α, β) -> check(ccall((:mxlo_scatter_zero_range, lib), Int32,
-      (P, Int32, P, Int64, P, Int64, Int64, Int64), ctx(), Int32(sizeof(eltype(u))), res.ptr, length(res), u.ptr, st, sp, len))
-  LinearOperator{I, MXVector{T}}(len, ncol, false, false, prod!, tprod!, tprod!)
+const PLANS = IdDict{Any, ScatterPlan}()
+plan(I::Vector{<:Integer}) = get!(() -> ScatterPlan(I), PLANS, I)
+const RangeIdx = Union{UnitRange{<:Integer}, StepRange{<:Integer, <:Integer}}
+mulRestrict!(res::MXVector, Idx::RangeIdx, v::MXVector, α, β) =
+  check(ccall((:mxlo_gather_range, lib), Int32, (P, Int32, P, P, Int64, Int64, Int64, Int64), ctx(),
+              Int32(sizeof(eltype(v))), res.ptr, v.ptr, length(v), Int64(first(Idx)), Int64(step(Idx)), Int64(length(Idx))))
+multRestrict!(res::MXVector, Idx::RangeIdx, u::MXVector, α, β) =
+  check(ccall((:mxlo_scatter_zero_range, lib), Int32, (P, Int32, P, Int64, P, Int64, Int64, Int64), ctx(),
+              Int32(sizeof(eltype(u))), res.ptr, length(res), u.ptr, Int64(first(Idx)), Int64(step(Idx)), Int64(length(Idx))))
+function mulRestrict!(res::MXVector, Idx::Vector{<:Integer}, v::MXVector, α, β)
+  pl = plan(Idx)
+  check(ccall((:mxlo_gather, lib), Int32, (P, Int32, P, P, Int64, P, Int64), ctx(), Int32(sizeof(eltype(v))), res.ptr,
+              v.ptr, length(v), pl.didx.ptr, length(pl.didx)))
 end
-function opRestriction(Idx::Vector{I}, ncol::I, ::Type{MXVector{T}}) where {I <: Integer, T}
-  all(1 .≤ Idx .≤ ncol) || throw(LinearOperatorException("indices should be between 1 and $ncol"))
-  didx = MXVector(collect(Int64, Idx))
-  plan = ScatterPlan(Idx)
-  prod! = (res, v, α, β) -> check(ccall((:mxlo_gather, lib), Int32, (P, Int32, P, P, Int64, P, Int64),
-      ctx(), Int32(sizeof(eltype(v))), res.ptr, v.ptr, length(v), didx.ptr, length(didx)))
-  tprod! = (res, u, α, β) -> check(ccall((:mxlo_scatter_zero, lib), Int32, (P, Int32, P, Int64, P, P, P, Int64),
-      ctx(), Int32(sizeof(eltype(u))), res.ptr, length(res), u.ptr, plan.idx.ptr,
-      plan.pos === nothing ? C_NULL : plan.pos.ptr, plan.n))
-  LinearOperator{I, MXVector{T}}(length(Idx), ncol, false, false, prod!, tprod!, tprod!)
+function multRestrict!(res::MXVector, Idx::Vector{<:Integer}, u::MXVector, α, β)
+  pl = plan(Idx)
+  check(ccall((:mxlo_scatter_zero, lib), Int32, (P, Int32, P, Int64, P, P, P, Int64), ctx(), Int32(sizeof(eltype(u))),
+              res.ptr, length(res), u.ptr, pl.idx.ptr, pl.pos === nothing ? C_NULL : pl.pos.ptr, pl.n))
 end
-# opExtension(Idx, ncol; S) = opRestriction(Idx, ncol; S)' is the reference's own definition (:218-219).
 
 # ---- a8 BlockDiagonalOperator (src/special-operators.jl:249-294): ONE launch per apply --------------------
 struct BlockDesc                # mxlo_block_desc, 56 bytes, same field order as include/mxlo.h
@@ -292,6 +367,22 @@ function kron(A::MXMatrix{T}, B::MXMatrix{T}) where {T}
       ctx(), dt(T), res.ptr, A.data.ptr, m, n, m, B.data.ptr, p, q, p, x.ptr, work.ptr, α, β, Int32(mode),
       flags(T, α, β)))
   LinearOperator{T, MXVector{T}}(m * p, n * q, false, false, mulmode(0), mulmode(1), mulmode(2))
+end
+# kron with lazily transposed factors (`kron(transpose(A), B)`): a transposition is a flag of the GEMM kernel's
+# operand layout, not a copy (mxlo_kron_mul_ex: per-factor flags; tprod!/ctprod! flip both).
+const MaybeT{T} = Union{MXMatrix{T}, Transpose{T, MXMatrix{T}}, Adjoint{T, MXMatrix{T}}}
+stored(A::MXMatrix) = (A, Int32(0))
+stored(A::Union{Transpose, Adjoint}) = (parent(A), Int32(1))
+function kron(A::MaybeT{T}, B::MaybeT{T}) where {T <: RealT}
+  (As, ta), (Bs, tb) = stored(A), stored(B)
+  m, n = size(A)
+  p, q = size(B)
+  work = MXVector{T}(undef, max(p * n, q * m))
+  mulmode(tr) = (res, x, α, β) -> check(ccall((:mxlo_kron_mul_ex, lib), Int32,
+      (P, Int32, P, P, Int64, Int64, Int64, Int32, P, Int64, Int64, Int64, Int32, P, P, Float64, Float64, Int32),
+      ctx(), dt(T), res.ptr, As.data.ptr, As.m, As.n, As.m, ta ⊻ Int32(tr), Bs.data.ptr, Bs.m, Bs.n, Bs.m, tb ⊻ Int32(tr),
+      x.ptr, work.ptr, α, β, flags(T, α, β)))
+  LinearOperator{T, MXVector{T}}(m * p, n * q, false, false, mulmode(0), mulmode(1), mulmode(1))
 end
 
 # ---- a12-a16 quasi-Newton operators: the structural contract (src/lbfgs.jl:62-104, src/lsr1.jl:39-78) ---------
@@ -391,10 +482,7 @@ ldiv!(x::MXVector{T}, B::MXQNOperator{T}, b::MXVector{T}) where {T} = solve_shif
 # ---- diagonal quasi-Newton family (src/DiagonalHessianApproximation.jl) ------------------------------------------
 # The structs are generic in the vector type V, so DiagonalPSB(d::MXVector) etc. construct unchanged and their mul!
 # reaches mulSquareOpDiagonal!; the extension supplies that kernel and the fused push!/reset!.
-LinearOperators.mulSquareOpDiagonal!(res::MXVector{T}, d::MXVector{T}, v::MXVector{T}, α, β) where {T} =
-  check(ccall((:mxlo_diag_mul, lib), Int32, (P, Int32, P, P, P, Int64, Int64, Float64, Float64, Int32),
-              ctx(), dt(T), res.ptr, d.ptr, v.ptr, length(res), length(res), α, β,
-              flags(T, α, β) | (length(d) == 1 && length(res) != 1 ? Int32(2) : Int32(0))))   # MXLO_D_SCALAR
+# (their mul! is mulSquareOpDiagonal! on MXVectors, defined with the other kernel-function methods above)
 dqn_kind(::LinearOperators.DiagonalPSB) = Int32(0)
 dqn_kind(::LinearOperators.DiagonalAndrei) = Int32(1)
 dqn_kind(::LinearOperators.DiagonalBFGS) = Int32(2)
@@ -440,5 +528,58 @@ function install_rccl!(rank::Integer, world::Integer, id::Vector{UInt8})
   check(ccall((:mxlo_ctx_set_allreduce, lib), Int32, (P, P, P), ctx(), hook, comm[]))
   comm[]
 end
+
+# ---- row sharding inside ONE Julia process (include/mxlo_rccl.h, single-process API) -------------------------------
+# `sc = ShardCtx([0, 1, ..., 7])` builds per device a stream, a ctx, an RCCL communicator (ncclCommInitAll), the
+# all-reduce hook and a worker thread inside libmxlo_rccl.so; a `_sharded` call takes one pointer per device.
+mutable struct ShardCtx
+  h::Ptr{Cvoid}
+  ndev::Int
+end
+function ShardCtx(devs::Vector{<:Integer})
+  r = Ref{Ptr{Cvoid}}()
+  ids = collect(Int32, devs)
+  st = ccall((:mxlo_shard_ctx_create, rccl), Int32, (Int32, Ptr{Int32}, Ptr{P}), length(ids), ids, r)
+  st == 0 || error(unsafe_string(ccall((:mxlo_shard_last_error, rccl), Cstring, ())))
+  finalizer(s -> ccall((:mxlo_shard_ctx_destroy, rccl), Int32, (P,), s.h), ShardCtx(r[], length(ids)))
+end
+shard_ctx(sc::ShardCtx, i::Integer) = ccall((:mxlo_shard_ctx_get, rccl), P, (P, Int32), sc.h, i)   # for mxlo_malloc / memcpy
+shard_sync(sc::ShardCtx) = check(ccall((:mxlo_shard_ctx_sync, rccl), Int32, (P,), sc.h))
+scheck(st::Int32) = st == 0 ? nothing : error(unsafe_string(ccall((:mxlo_shard_last_error, rccl), Cstring, ())))
+ptrs(vs) = P[Ptr{Cvoid}(v.ptr) for v in vs]
+"`res`, `h`, `v`: one MXVector per device (row ranges); the only exchange is the 8-byte all-reduce of h'v."
+function householder_mul_sharded!(sc::ShardCtx, res, h, v, α, β)
+  T = eltype(first(res))
+  nloc = Int64[length(r) for r in res]
+  scheck(ccall((:mxlo_householder_mul_sharded, rccl), Int32, (P, Int32, Ptr{P}, Ptr{P}, Ptr{P}, Ptr{Int64}, Float64, Float64, Int32),
+               sc.h, dt(T), ptrs(res), ptrs(h), ptrs(v), nloc, α, β, flags(T, α, β)))
+  res
+end
+mutable struct ShardedQN{T}
+  h::Ptr{Cvoid}
+  sc::ShardCtx
+end
+function ShardedQN(::Type{T}, sc::ShardCtx, kind::Integer, nloc::Vector{<:Integer}; mem::Int = 5, scaling::Bool = kind != 2,
+                   damped::Bool = false, σ₂ = 0.99, σ₃ = 10.0) where {T <: RealT}
+  r = Ref{Ptr{Cvoid}}()
+  scheck(ccall((:mxlo_qn_create_sharded, rccl), Int32, (P, Int32, Int32, Ptr{Int64}, Int64, Int32, Int32, Float64, Float64, Ptr{P}),
+               sc.h, Int32(kind), dt(T), collect(Int64, nloc), mem, scaling, damped, σ₂, σ₃, r))
+  finalizer(q -> ccall((:mxlo_qn_destroy_sharded, rccl), Int32, (P,), q.h), ShardedQN{T}(r[], sc))
+end
+function push!(q::ShardedQN, s, y)
+  acc = Ref{Int32}(0)
+  scheck(ccall((:mxlo_qn_push_sharded, rccl), Int32, (P, Ptr{P}, Ptr{P}, Ptr{Int32}), q.h, ptrs(s), ptrs(y), acc))
+  q
+end
+function qn_mul_sharded!(q::ShardedQN{T}, res, x, α, β) where {T}
+  scheck(ccall((:mxlo_qn_mul_sharded, rccl), Int32, (P, Ptr{P}, Ptr{P}, Float64, Float64, Int32), q.h, ptrs(res), ptrs(x),
+               α, β, flags(T, α, β)))
+  res
+end
+function solve_shifted_sharded!(q::ShardedQN{T}, x, b, σ) where {T}
+  scheck(ccall((:mxlo_qn_solve_shifted_sharded, rccl), Int32, (P, Ptr{P}, Ptr{P}, Float64), q.h, ptrs(x), ptrs(b), σ))
+  x
+end
+reset!(q::ShardedQN) = (scheck(ccall((:mxlo_qn_reset_sharded, rccl), Int32, (P,), q.h)); q)
 
 end # module

@@ -5,6 +5,11 @@ loop repeats exactly the same launches on the same buffers. `CapturedSequence` r
 host-mirror calls (everything the apply paths enqueue is stream-ordered, no host sync) into ONE hipGraph on
 a side stream and replays it with a single launch. Buffers, sizes, α and β are baked in; the data they hold
 is read at replay time. `push!` (host control flow) cannot be captured.
+
+Staleness: a quasi-Newton apply bakes the handle's slot order / insert position / update count into the recorded
+launches, and opHermitian the ctx scratch pointer. The library remembers the generation of every captured handle
+(bumped by push!, reset!, mode changes) and of the scratch; `replay()` after any of them changed raises
+``MxloError`` (MXLO_ESTATE) instead of replaying stale metadata — re-capture after `push!`/`reset!`.
 """
 from __future__ import annotations
 

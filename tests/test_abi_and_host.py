@@ -28,8 +28,12 @@ def test_rccl_transport_library_exports_its_header(lo):
     import torch  # noqa: F401  (maps torch's librccl.so.1 so the SONAME resolves the same way as at run time)
     R = ctypes.CDLL(lo._lib.RCCL_LIB_PATH)
     syms = lo._lib.header_symbols(lo._lib.RCCL_HEADER)
-    assert set(syms) == {"mxlo_rccl_unique_id", "mxlo_rccl_comm_create", "mxlo_rccl_comm_destroy",
-                         "mxlo_rccl_allreduce_hook", "mxlo_rccl_last_error"}
+    assert {"mxlo_rccl_unique_id", "mxlo_rccl_comm_create", "mxlo_rccl_comm_destroy", "mxlo_rccl_allreduce_hook",
+            "mxlo_rccl_last_error", "mxlo_shard_ctx_create", "mxlo_shard_ctx_destroy", "mxlo_shard_ctx_get",
+            "mxlo_householder_mul_sharded", "mxlo_diag_mul_sharded", "mxlo_qn_create_sharded", "mxlo_qn_push_sharded",
+            "mxlo_qn_mul_sharded", "mxlo_qn_mul_shifted_sharded", "mxlo_qn_solve_shifted_sharded",
+            "mxlo_qn_diag_sharded", "mxlo_qn_reset_sharded", "mxlo_qn_get_scalars_sharded"} <= set(syms)
+    assert len(syms) == 25
     assert not [s for s in syms if not hasattr(R, s)]
 
 

@@ -1,0 +1,191 @@
+"""The reference-side binding (julia/LinearOperatorsMXLOExt.jl) against the C ABI it binds (CPU; no Julia needed).
+
+Julia is not in this image, so the glue cannot be executed here. What CAN be checked mechanically is the part that
+breaks silently at run time: every ``ccall((:name, lib|rccl), Ret, (ArgTypes...), args...)`` must name a function that
+``include/mxlo.h`` / ``include/mxlo_rccl.h`` declare, in the right library, with the same arity, C-compatible
+argument and return types, and as many actual arguments as declared types.
+"""
+import pathlib
+import re
+
+import pytest
+
+ROOT = pathlib.Path(__file__).resolve().parents[1]
+JL = ROOT / "julia" / "LinearOperatorsMXLOExt.jl"
+HEADERS = {"lib": ROOT / "include" / "mxlo.h", "rccl": ROOT / "include" / "mxlo_rccl.h"}
+
+
+# ---------------------------------------------------------------------------------------------- C side
+def _strip_c_comments(src: str) -> str:
+    src = re.sub(r"/\*.*?\*/", " ", src, flags=re.S)
+    return re.sub(r"//[^\n]*", " ", src)
+
+
+def _c_class(t: str) -> str:
+    """Reduce a C parameter/return type to an ABI class: ptr | i32 | i64 | u64 | f64 | void."""
+    t = t.strip()
+    if "(*" in t:                                   # function pointer parameter written inline
+        return "ptr"
+    if "[" in t or "*" in t:
+        return "ptr"
+    t = re.sub(r"\bconst\b", "", t).strip()
+    base = t.split()[0] if t.split() else ""
+    if base == "void":
+        return "void"
+    if base in ("int32_t", "int"):
+        return "i32"
+    if base in ("int64_t", "long"):
+        return "i64"
+    if base in ("uint64_t", "size_t"):
+        return "u64"
+    if base == "double":
+        return "f64"
+    if base.endswith("_fn"):                        # typedef'd function pointer (mxlo_allreduce_fn)
+        return "ptr"
+    raise AssertionError(f"unclassified C type {t!r}")
+
+
+def _split_top(s: str, sep: str = ",") -> list[str]:
+    out, depth, cur = [], 0, []
+    for ch in s:
+        if ch in "([{":
+            depth += 1
+        elif ch in ")]}":
+            depth -= 1
+        if ch == sep and depth == 0:
+            out.append("".join(cur).strip())
+            cur = []
+        else:
+            cur.append(ch)
+    last = "".join(cur).strip()
+    if last:
+        out.append(last)
+    return out
+
+
+def parse_header(path: pathlib.Path) -> dict[str, tuple[str, list[str]]]:
+    src = _strip_c_comments(path.read_text())
+    src = re.sub(r"^\s*#.*$", " ", src, flags=re.M)
+    protos = {}
+    # drop typedefs (struct bodies, function-pointer typedefs) so only prototypes remain
+    src = re.sub(r"typedef\s+struct\s*\w*\s*\{.*?\}\s*\w+\s*;", " ", src, flags=re.S)
+    src = re.sub(r"typedef[^;]*;", " ", src)
+    for m in re.finditer(r"([A-Za-z_][\w\s\*]*?)\b(mxlo_\w+)\s*\(([^;{]*?)\)\s*;", src, flags=re.S):
+        ret, name, params = m.group(1), m.group(2), m.group(3)
+        params = " ".join(params.split())
+        plist = [] if params in ("", "void") else _split_top(params)
+        protos[name] = (_c_class(ret if "*" in ret else ret.strip()), [_c_class(p_type(p)) for p in plist])
+    return protos
+
+
+def p_type(param: str) -> str:
+    """'const void *v' -> 'const void *'; 'double scalars[5]' -> 'double []'."""
+    param = param.strip()
+    if "[" in param:
+        return param[: param.index("[")].rsplit(None, 1)[0] + " []"
+    m = re.match(r"(.*?)(\w+)$", param)
+    if m and m.group(1).strip():
+        return m.group(1)
+    return param
+
+
+# ---------------------------------------------------------------------------------------------- Julia side
+def _jl_class(t: str) -> str:
+    t = t.strip()
+    if t == "P" or t.startswith("Ptr{") or t.startswith("Ref{") or t in ("Cstring", "Ptr"):
+        return "ptr"
+    return {"Int32": "i32", "Cint": "i32", "Int64": "i64", "UInt64": "u64", "Csize_t": "u64", "Float64": "f64",
+            "Cdouble": "f64", "Cvoid": "void", "Nothing": "void"}.get(t) or pytest.fail(f"unclassified Julia type {t!r}")
+
+
+def _strip_jl_comments(src: str) -> str:
+    out = []
+    for line in src.splitlines():
+        in_str, k = False, 0
+        while k < len(line):
+            c = line[k]
+            if c == '"' and (k == 0 or line[k - 1] != "\\"):
+                in_str = not in_str
+            elif c == "#" and not in_str:
+                break
+            k += 1
+        out.append(line[:k])
+    return "\n".join(out)
+
+
+def parse_ccalls(path: pathlib.Path):
+    src = _strip_jl_comments(path.read_text())
+    calls = []
+    for m in re.finditer(r"\bccall\(", src):
+        i, depth = m.end(), 1
+        while depth:
+            ch = src[i]
+            depth += ch in "([{"
+            depth -= ch in ")]}"
+            i += 1
+        body = src[m.end(): i - 1]
+        parts = _split_top(body)
+        head = re.fullmatch(r"\(\s*:(\w+)\s*,\s*(\w+)\s*\)", parts[0])
+        assert head, f"ccall target not of the form (:name, lib): {parts[0]!r}"
+        types = parts[2].strip()
+        assert types.startswith("(") and types.endswith(")"), parts[2]
+        tl = _split_top(types[1:-1])
+        line = src.count("\n", 0, m.start()) + 1
+        calls.append({"name": head.group(1), "lib": head.group(2), "ret": parts[1].strip(), "types": tl,
+                      "nargs": len(parts) - 3, "line": line})
+    return calls
+
+
+PROTOS = {k: parse_header(v) for k, v in HEADERS.items()}
+CALLS = parse_ccalls(JL)
+
+
+def test_headers_parse_to_the_full_symbol_lists():
+    # sanity of the parser itself: a few prototypes with known shapes
+    assert PROTOS["lib"]["mxlo_ctx_create"] == ("i32", ["i32", "ptr", "ptr"])
+    assert PROTOS["lib"]["mxlo_version"] == ("ptr", [])
+    assert PROTOS["lib"]["mxlo_qn_get_scalars"] == ("i32", ["ptr", "ptr", "ptr", "ptr"])
+    assert PROTOS["lib"]["mxlo_ctx_set_allreduce"] == ("i32", ["ptr", "ptr", "ptr"])
+    assert PROTOS["rccl"]["mxlo_shard_ctx_get"] == ("ptr", ["ptr", "i32"])
+    assert len(PROTOS["lib"]) >= 65 and len(PROTOS["rccl"]) >= 25
+
+
+def test_the_glue_has_ccalls_for_every_hot_path_leaf():
+    names = {c["name"] for c in CALLS}
+    must = {"mxlo_diag_mul", "mxlo_eye_mul", "mxlo_ones_mul", "mxlo_zeros_mul", "mxlo_householder_mul",
+            "mxlo_hermitian_mul", "mxlo_gemv", "mxlo_gather", "mxlo_gather_range", "mxlo_scatter_zero",
+            "mxlo_scatter_zero_range", "mxlo_blockdiag_create", "mxlo_blockdiag_mul", "mxlo_kron_mul",
+            "mxlo_kron_mul_ex", "mxlo_qn_create", "mxlo_qn_push", "mxlo_qn_mul", "mxlo_qn_mul_shifted",
+            "mxlo_qn_solve_shifted", "mxlo_qn_diag", "mxlo_qn_reset", "mxlo_diagqn_push", "mxlo_graph_begin",
+            "mxlo_graph_end", "mxlo_graph_launch", "mxlo_diag_mul_c", "mxlo_eye_mul_c", "mxlo_zeros_mul_c",
+            "mxlo_scale_c", "mxlo_conj_c", "mxlo_dot_c", "mxlo_householder_mul_c", "mxlo_shard_ctx_create",
+            "mxlo_householder_mul_sharded", "mxlo_qn_create_sharded", "mxlo_qn_mul_sharded"}
+    assert not (must - names), f"glue lacks ccalls for {sorted(must - names)}"
+
+
+@pytest.mark.parametrize("call", CALLS, ids=[f"{c['name']}@{c['line']}" for c in CALLS])
+def test_ccall_matches_header(call):
+    where = f"julia/LinearOperatorsMXLOExt.jl:{call['line']} ccall(:{call['name']})"
+    assert call["lib"] in PROTOS, f"{where}: unknown library constant {call['lib']}"
+    protos = PROTOS[call["lib"]]
+    other = PROTOS["rccl" if call["lib"] == "lib" else "lib"]
+    assert call["name"] in protos, (
+        f"{where}: not declared in {HEADERS[call['lib']].name}"
+        + (" (it is declared in the OTHER library's header)" if call["name"] in other else ""))
+    ret, params = protos[call["name"]]
+    jl = [_jl_class(t) for t in call["types"]]
+    assert len(jl) == len(params), f"{where}: {len(jl)} argument types, header declares {len(params)}"
+    assert call["nargs"] == len(jl), f"{where}: {call['nargs']} actual arguments for {len(jl)} declared types"
+    for k, (a, b) in enumerate(zip(jl, params)):
+        assert a == b, f"{where}: argument {k + 1} is {call['types'][k]} ({a}), header says {b}"
+    assert _jl_class(call["ret"]) == ret, f"{where}: return type {call['ret']}, header says {ret}"
+
+
+def test_kernel_function_methods_are_defined_for_device_vectors():
+    """The S-keyword hook: methods on the reference's kernel functions for MXVector arguments."""
+    src = _strip_jl_comments(JL.read_text())
+    for f in ("mulOpEye!", "mulOpOnes!", "mulOpZeros!", "mulSquareOpDiagonal!", "mulOpDiagonal!", "mulHouseholder!",
+              "mulRestrict!", "multRestrict!"):
+        assert re.search(rf"^(function\s+)?{re.escape(f)}\(res::MXVector", src, flags=re.M), f
+        assert re.search(rf"import LinearOperators:[^#]*?{re.escape(f)}", src, flags=re.S), f"{f} not imported"
+    assert re.search(r"^Base\.:\+\(op::LinearOperator\{T, MXVector\{T\}\}, x::Number\)", src, flags=re.M)

@@ -191,6 +191,7 @@ def main():
             extras.update(bench_lbfgs(lo, torch, dev, ctx, rank, world, distributed, dist, barrier))
         except Exception as e:  # never lose the headline line
             extras["lbfgs_error"] = repr(e)
+        install_hook()                                   # rank 0 cleared it for the single-GPU cfg5 leg
 
     if not args.no_extras:
         try:
@@ -291,7 +292,56 @@ def bench_lbfgs(lo, torch, dev, ctx, rank, world, distributed, dist, barrier):
     out["LBFGS_fwd_m20_iteration(push+mul+solve_shifted)"] = {"ms": round((time.perf_counter() - t0) / 4 * 1e3, 3)}
     del Bf, s, y, x, res
     torch.cuda.empty_cache()
+
+    # ---- cfg5 read directly: the sharded apply rate next to the SAME global problem on ONE GPU, measured in this run.
+    # N ranks hold n_global = N * 5e7 rows; rank 0 then runs the unsharded operator at n = n_global alone (no hook)
+    # while the others wait. speedup = sharded apply/s / single-GPU apply/s at identical n_global (target >= 6 at N = 8).
+    sharded_aps = out["LBFGS_fwd_m20_nlocal5e7"]["apply_per_s"]
+    cfg5 = {"operator": "LBFGSOperator m=20 fp64, compact form, 664 B/elt", "n_global": n * world, "n_gpus": world,
+            "apply_per_s": sharded_aps}
+    if world == 1:
+        cfg5.update({"single_gpu_apply_per_s_same_n": sharded_aps, "speedup_vs_single_gpu_same_n": 1.0})
+    else:
+        single = None
+        if rank == 0:
+            try:
+                ctx.set_allreduce(None)
+                single = single_gpu_leg(lo, torch, dev, n * world, m)
+            except Exception as e:                       # e.g. the 192 GB of panels at N = 8 do not fit next to a neighbour
+                cfg5["single_gpu_leg_error"] = repr(e)[:200]
+        barrier()
+        if single is not None:
+            cfg5.update({"single_gpu_apply_per_s_same_n": round(1.0 / single, 3), "single_gpu_ms": round(single * 1e3, 3),
+                         "speedup_vs_single_gpu_same_n": round(sharded_aps * single, 3)})
+    out["cfg5_LBFGS_fwd_m20_sharded"] = cfg5
     return out
+
+
+def single_gpu_leg(lo, torch, dev, n, m):
+    """The cfg5 operator at the full global n on ONE GPU (three n x m panels: S, Y, B; a_k never formed)."""
+    gen = torch.Generator(device=dev).manual_seed(4242)
+    Bf = lo.LBFGSOperator(torch.float64, n, mem=m, scaling=True, device=dev)
+    s = torch.empty(n, dtype=torch.float64, device=dev)
+    y = torch.empty(n, dtype=torch.float64, device=dev)
+    for _ in range(m + 3):
+        s.uniform_(-1, 1, generator=gen)
+        y.uniform_(0.5, 2.0, generator=gen)
+        y.mul_(s)
+        lo.push(Bf, s, y)
+    x, res = s, y
+    x.uniform_(-1, 1, generator=gen)
+    for _ in range(2):
+        lo.mul(res, Bf, x, -1.0, 0.0)
+    torch.cuda.synchronize()
+    reps = 5
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        lo.mul(res, Bf, x, -1.0, 0.0)
+    torch.cuda.synchronize()
+    sec = (time.perf_counter() - t0) / reps
+    del Bf
+    torch.cuda.empty_cache()
+    return sec
 
 
 def bench_cfg4(lo, torch, dev, ctx):

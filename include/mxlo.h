@@ -271,6 +271,19 @@ int32_t mxlo_scatter_zero(mxlo_ctx *ctx, int32_t elem_size, void *res, int64_t n
 int32_t mxlo_scatter_zero_range(mxlo_ctx *ctx, int32_t elem_size, void *res, int64_t nres,
                                 const void *u, int64_t start, int64_t step, int64_t len);
 
+/* Row-shard staging for collectives that move vectors (row-sharded dense LinearOperator / opHermitian, SURVEY §8f-4).
+ * Shard r of an n-vector owns rows [lo(r), lo(r)+len(r)), lo(r) = r*q + min(r, rem), len(r) = q + (r < rem),
+ * q = n / world, rem = n % world; the wire format of all-gather / reduce-scatter is `world` slots of
+ * pad = ceil(n / world) elements. One launch either way:
+ *   MXLO_SHARD_PACK   padded[r*pad + k] = full[lo(r)+k] for k < len(r) and lo(r)+k < nvalid, else 0
+ *                     (rows >= nvalid count as zeros and are not read; nvalid < 0 means n)
+ *   MXLO_SHARD_UNPACK full[lo(r)+k] = padded[r*pad + k] for k < len(r)
+ * elem_size 4, 8 or 16 bytes (bit copies, like gather/scatter). */
+#define MXLO_SHARD_PACK 0
+#define MXLO_SHARD_UNPACK 1
+int32_t mxlo_shard_stage(mxlo_ctx *ctx, int32_t elem_size, void *dst, const void *src, int64_t n,
+                         int32_t world, int64_t nvalid, int32_t direction);
+
 /* BlockDiagonalOperator prod!/tprod!/ctprod! — src/special-operators.jl:258-289.
  * The reference loops over blocks issuing one inner mul! per block (1024
  * launches at BASELINE config 4); here the whole operator is ONE launch over a

@@ -21,6 +21,7 @@ RCCL_ID_BYTES = 128
 # status codes (include/mxlo.h)
 OK, EINVAL, ESHAPE, EHIP, ENOMEM, ESTATE, EDOMAIN, EREDUCE = range(8)
 F64, F32, C64, C32 = 0, 1, 2, 3
+SHARD_PACK, SHARD_UNPACK = 0, 1
 CONJ_D, ALPHA_REAL, BETA_REAL = 0x10, 0x20, 0x40
 ALPHA_F64, D_SCALAR, TAIL_BETA, BETA_F64 = 0x1, 0x2, 0x4, 0x8
 SCALARS_F64 = ALPHA_F64 | BETA_F64
@@ -121,6 +122,7 @@ _PROTOS = {
     "mxlo_gather_range": [_vp, _i32, _vp, _vp, _i64, _i64, _i64, _i64],
     "mxlo_scatter_zero": [_vp, _i32, _vp, _i64, _vp, _vp, _vp, _i64],
     "mxlo_scatter_zero_range": [_vp, _i32, _vp, _i64, _vp, _i64, _i64, _i64],
+    "mxlo_shard_stage": [_vp, _i32, _vp, _vp, _i64, _i32, _i64, _i32],
     "mxlo_blockdiag_create": [_vp, _i32, C.POINTER(BlockDesc), _i64, C.POINTER(_vp)],
     "mxlo_blockdiag_mul": [_vp, _vp, _vp, _dbl, _dbl, _i32, _i32],
     "mxlo_blockdiag_destroy": [_vp],

@@ -497,6 +497,59 @@ MXLO_API int32_t mxlo_scatter_zero_range(mxlo_ctx *ctx, int32_t elem_size, void 
   });
 }
 
+// ---- row-shard staging for the collectives that move VECTORS (row-sharded dense / opHermitian) ----------------
+// ShardPlan: shard r of an n-vector owns rows [lo(r), lo(r) + len(r)), lo(r) = r*q + min(r, rem), len(r) = q + (r < rem),
+// q = n / world, rem = n % world. all-gather / reduce-scatter need equal counts per rank, so the wire format is
+// `world` slots of pad = ceil(n / world) elements. ONE launch converts between the two layouts (blockIdx.y = shard, so
+// no lane does an integer division):
+//   PACK  : padded[r*pad + k] = k < len(r) && lo(r)+k < nvalid ? full[lo(r) + k] : 0      (zero pad slot; rows >= nvalid
+//           are DEFINED as zero without being read — the caller's partial-sum vector need not be cleared beyond them)
+//   UNPACK: full[lo(r) + k] = padded[r*pad + k],  k < len(r)
+namespace {
+template <typename E, bool PACK>
+__global__ void __launch_bounds__(kBlock)
+shard_stage_kernel(E *__restrict__ dst, const E *__restrict__ src, int64_t q, int64_t rem, int64_t pad, int64_t nvalid) {
+  const int64_t r = blockIdx.y;
+  const int64_t lo = r * q + (r < rem ? r : rem), len = q + (r < rem ? 1 : 0);
+  for (int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x; k < pad; k += (int64_t)gridDim.x * kBlock) {
+    if constexpr (PACK) {
+      E val{};
+      if (k < len && lo + k < nvalid) val = src[lo + k];
+      dst[r * pad + k] = val;
+    } else {
+      if (k < len) dst[lo + k] = src[r * pad + k];
+    }
+  }
+}
+}  // namespace
+
+MXLO_API int32_t mxlo_shard_stage(mxlo_ctx *ctx, int32_t elem_size, void *dst, const void *src, int64_t n,
+                                  int32_t world, int64_t nvalid, int32_t direction) {
+  MXLO_REQUIRE(ctx, MXLO_EINVAL, "mxlo_shard_stage: ctx is NULL");
+  MXLO_DEVICE_GUARD(ctx);
+  MXLO_REQUIRE(n >= 0 && world >= 1 && world <= 65535, MXLO_ESHAPE, "mxlo_shard_stage: n = %lld, world = %d",
+               (long long)n, world);
+  MXLO_REQUIRE(direction == MXLO_SHARD_PACK || direction == MXLO_SHARD_UNPACK, MXLO_EINVAL,
+               "mxlo_shard_stage: direction %d", direction);
+  if (n == 0) return MXLO_OK;
+  MXLO_REQUIRE(dst && src, MXLO_EINVAL, "mxlo_shard_stage: NULL operand");
+  const int64_t q = n / world, rem = n % world, pad = (n + world - 1) / world;
+  if (nvalid < 0 || nvalid > n) nvalid = n;
+  return by_elem_size(elem_size, [&]<typename E>() -> int32_t {
+    int64_t gx = (pad + kBlock - 1) / kBlock;
+    const int64_t cap = std::max<int64_t>(1, (int64_t)ctx->num_cu * 8 / world);
+    if (gx > cap) gx = cap;
+    if (direction == MXLO_SHARD_PACK)
+      hipLaunchKernelGGL((shard_stage_kernel<E, true>), dim3((unsigned)gx, (unsigned)world), dim3(kBlock), 0, ctx->stream,
+                         (E *)dst, (const E *)src, q, rem, pad, nvalid);
+    else
+      hipLaunchKernelGGL((shard_stage_kernel<E, false>), dim3((unsigned)gx, (unsigned)world), dim3(kBlock), 0, ctx->stream,
+                         (E *)dst, (const E *)src, q, rem, pad, nvalid);
+    MXLO_LAUNCH_CHECK();
+    return MXLO_OK;
+  });
+}
+
 
 // ---- kron of two diagonal / identity factors: fused row/col index decomposition ------------------------
 // kron(A, B) with A = Diagonal(dA) (m x m) and B = Diagonal(dB) (p x p) (either may be the identity):

@@ -212,6 +212,66 @@ def shard(full: torch.Tensor, plan: ShardPlan, rank: int, device=None) -> torch.
 # Ring collectives move (world-1)/world · 8n B per GPU per apply against 8·m_loc·n B of HBM traffic, so the apply
 # stays HBM-bound as long as m_loc ≫ 7·(HBM rate / xGMI link rate) ≈ 7·8000/153 ≈ 370 rows per GPU.
 # Shards differ by at most one row, so collectives run on buffers padded to the largest shard.
+class VectorExchange:
+    """The two collectives of the row-sharded dense operators, on the ShardPlan wire format (`world` slots of
+    pad = ceil(n / world) elements). Staging is ONE libmxlo launch per direction (`mxlo_shard_stage`; own-slot
+    placement is the fused zero-fill + copy `mxlo_scatter_zero_range`) — no per-shard torch copies.
+
+    backend "nccl" (RCCL over xGMI, the product transport): all_gather_into_tensor / reduce_scatter_tensor.
+    backend "gloo" (debug transport, two ranks on one GPU): gloo only implements broadcast and all_reduce on device
+    tensors, so both collectives are expressed through all_reduce — gather = sum of slot vectors that are zero
+    outside the owner's slot (exact), reduce-scatter = all_reduce of the whole padded vector, keep my slot."""
+
+    def __init__(self, plan: ShardPlan, dtype, device, group=None):
+        self.plan, self.group = plan, group
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        if plan.world != self.world:
+            raise ValueError("shard plan was built for a different world size")
+        self.native = dist.get_backend(group) == "nccl"
+        self.dt, self.dev = dtype, device
+        self.es = torch.empty(0, dtype=dtype).element_size()
+        self.n, self.pad = plan.n, -(-plan.n // self.world)
+        self.n_loc = plan.local_n(self.rank)
+        self.wire = torch.empty(self.world * self.pad, dtype=dtype, device=device)       # all-gather target / reduce input
+        self.slot = torch.empty(self.pad, dtype=dtype, device=device)                     # my slot (send / receive)
+        self.full = torch.empty(self.n, dtype=dtype, device=device)
+
+    def _stage(self, dst, src, nvalid, direction):
+        from . import _lib
+        from .device import get_ctx, ptr
+        ctx = get_ctx(self.dev)
+        _lib.call("mxlo_shard_stage", ctx.handle, self.es, ptr(dst), ptr(src), self.n, self.world, int(nvalid), direction)
+
+    def _place(self, dst, first, v):                     # dst .= 0; dst[first : first + len(v)] = v   (one launch)
+        from . import _lib
+        from .device import get_ctx, ptr
+        ctx = get_ctx(self.dev)
+        _lib.call("mxlo_scatter_zero_range", ctx.handle, self.es, ptr(dst), dst.numel(), ptr(v), first + 1, 1, v.numel())
+
+    def all_gather(self, v_local: torch.Tensor) -> torch.Tensor:
+        """The whole n-vector (rows in global order) from every rank's shard; returns an internal buffer."""
+        from . import _lib
+        if self.native:
+            self._place(self.slot, 0, v_local)
+            dist.all_gather_into_tensor(self.wire, self.slot, group=self.group)
+        else:
+            self._place(self.wire, self.rank * self.pad, v_local)
+            dist.all_reduce(self.wire, op=dist.ReduceOp.SUM, group=self.group)
+        self._stage(self.full, self.wire, -1, _lib.SHARD_UNPACK)
+        return self.full
+
+    def reduce_scatter(self, partial_full: torch.Tensor, nvalid: int = -1) -> torch.Tensor:
+        """My shard of the sum over ranks of `partial_full` (n-vector; rows >= nvalid count as zeros and are not read).
+        Returns a view of length n_loc into an internal buffer."""
+        from . import _lib
+        self._stage(self.wire, partial_full, nvalid, _lib.SHARD_PACK)
+        if self.native:
+            dist.reduce_scatter_tensor(self.slot, self.wire, op=dist.ReduceOp.SUM, group=self.group)
+            return self.slot[:self.n_loc]
+        dist.all_reduce(self.wire, op=dist.ReduceOp.SUM, group=self.group)
+        return self.wire[self.rank * self.pad:self.rank * self.pad + self.n_loc]
+
+
 def row_sharded_dense(M_local: torch.Tensor, plan_m: ShardPlan, plan_n: ShardPlan, group=None):
     """LinearOperator over the local row block `M_local` (m_loc × n) of an m × n matrix; operates on shards."""
     from . import _lib
@@ -227,28 +287,18 @@ def row_sharded_dense(M_local: torch.Tensor, plan_m: ShardPlan, plan_n: ShardPla
         raise ValueError("M_local must hold this rank's rows and all n columns")
     local = LinearOperatorFromMatrix(M_local)               # mxlo_gemv N/T on the local block
     dev, dt = M_local.device, M_local.dtype
-    pad = -(-plan_n.n // world)                             # largest shard of an n-vector
     n_loc = plan_n.local_n(rank)
-    gathered = torch.zeros(world * pad, dtype=dt, device=dev)
-    mine = torch.zeros(pad, dtype=dt, device=dev)
-    vfull = torch.empty(n, dtype=dt, device=dev)
-    partial = torch.zeros(world * pad, dtype=dt, device=dev)
-    scattered = torch.empty(pad, dtype=dt, device=dev)
+    ex = VectorExchange(plan_n, dt, dev, group)
+    partial = torch.empty(n, dtype=dt, device=dev)
 
     def prod(res, v, a, b):                                  # res_loc = α·M_loc·v + β·res_loc
-        mine[:n_loc].copy_(v)
-        dist.all_gather_into_tensor(gathered, mine, group=group)
-        for r in range(world):
-            vfull[plan_n.lo(r):plan_n.hi(r)].copy_(gathered[r * pad:r * pad + plan_n.local_n(r)])
-        local.prod(res, vfull, a, b)
+        local.prod(res, ex.all_gather(v), a, b)
 
     def tprod(res, u, a, b):                                 # res_loc = α·(Σ_ranks M_locᵀ·u_loc)[shard] + β·res_loc
-        local.tprod(vfull, u, 1.0, 0.0)
-        for r in range(world):
-            partial[r * pad:r * pad + plan_n.local_n(r)].copy_(vfull[plan_n.lo(r):plan_n.hi(r)])
-        dist.reduce_scatter_tensor(scattered, partial, op=dist.ReduceOp.SUM, group=group)
+        local.tprod(partial, u, 1.0, 0.0)
+        mine = ex.reduce_scatter(partial)
         ctx = get_ctx(res.device)
-        _lib.call("mxlo_eye_mul", ctx.handle, dtype_code(dt), ptr(res), ptr(scattered), n_loc, n_loc, float(a),
+        _lib.call("mxlo_eye_mul", ctx.handle, dtype_code(dt), ptr(res), ptr(mine), n_loc, n_loc, float(a),
                   float(b), scalar_flags(dt, a, b))
 
     return LinearOperator(dt, m_loc, n_loc, False, False, prod, tprod, tprod, S=Storage(dt, dev))
@@ -275,30 +325,19 @@ def row_sharded_hermitian(d_local: torch.Tensor, A_local: torch.Tensor, plan: Sh
     dev, dt = A_local.device, A_local.dtype
     rect = LinearOperatorFromMatrix(A_local[:, :lo_]) if lo_ > 0 else None        # R = L[lo:hi, 0:lo] (fully below the diagonal)
     tri = opHermitian(d_local, A_local[:, lo_:hi_])                               # d∘v + (T + Tᵀ)·v on the diagonal block
-    pad = -(-n // world)
-    gathered = torch.zeros(world * pad, dtype=dt, device=dev)
-    mine = torch.zeros(pad, dtype=dt, device=dev)
-    vfull = torch.empty(n, dtype=dt, device=dev)
-    partial_full = torch.zeros(n, dtype=dt, device=dev)
-    partial_pad = torch.zeros(world * pad, dtype=dt, device=dev)
-    scattered = torch.empty(pad, dtype=dt, device=dev)
+    ex = VectorExchange(plan, dt, dev, group)
+    partial = torch.empty(n, dtype=dt, device=dev)          # only rows [0, lo) are ever written or read
     acc = torch.empty(m_loc, dtype=dt, device=dev)
 
     def prod(res, v, a, b):
-        mine[:m_loc].copy_(v)
-        dist.all_gather_into_tensor(gathered, mine, group=group)
-        for r in range(world):
-            vfull[plan.lo(r):plan.hi(r)].copy_(gathered[r * pad:r * pad + plan.local_n(r)])
+        vfull = ex.all_gather(v)
         mul(acc, tri, v, 1.0, 0.0)                                  # d∘v + (T + Tᵀ) v_loc
-        partial_full.zero_()
         if rect is not None:
             mul(acc, rect, vfull[:lo_], 1.0, 1.0)                   # + R v[0:lo]
-            mul(partial_full[:lo_], rect.T, v, 1.0, 0.0)            # Rᵀ v_loc -> columns 0:lo (owned by the ranks above)
-        for r in range(world):
-            partial_pad[r * pad:r * pad + plan.local_n(r)].copy_(partial_full[plan.lo(r):plan.hi(r)])
-        dist.reduce_scatter_tensor(scattered, partial_pad, op=dist.ReduceOp.SUM, group=group)
+            mul(partial[:lo_], rect.T, v, 1.0, 0.0)                 # Rᵀ v_loc -> columns 0:lo (owned by the ranks above)
+        below = ex.reduce_scatter(partial, nvalid=lo_)              # rows >= lo are zeros by definition (not read)
         ctx = get_ctx(res.device)                                   # acc += what the ranks below contribute to my rows
-        _lib.call("mxlo_eye_mul", ctx.handle, dtype_code(dt), ptr(acc), ptr(scattered), m_loc, m_loc, 1.0, 1.0, 0)
+        _lib.call("mxlo_eye_mul", ctx.handle, dtype_code(dt), ptr(acc), ptr(below), m_loc, m_loc, 1.0, 1.0, 0)
         _lib.call("mxlo_eye_mul", ctx.handle, dtype_code(dt), ptr(res), ptr(acc), m_loc, m_loc, float(a), float(b),
                   scalar_flags(dt, a, b))                           # res = α·acc + β·res
 

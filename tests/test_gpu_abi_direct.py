@@ -117,3 +117,38 @@ def test_tune_keys(lo, dev):
         for key, val in (("blocks_per_cu", 0), ("nt_min_bytes", 32 << 20), ("red_blocks_per_cu", 4), ("house_reverse", 1),
                          ("gemm_tile", 0), ("combine_blocks_per_cu", 0), ("dots_max_nc", 20)):
             ctx.tune(key, val)
+
+
+@pytest.mark.parametrize("n,world", [(1, 1), (7, 3), (10, 4), (1000, 8), (12345, 7), (5, 8), (2_000_003, 8)])
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32, torch.complex128])
+def test_shard_stage_pack_unpack_bit_exact(lo, dev, n, world, dtype):
+    """mxlo_shard_stage: ShardPlan layout <-> `world` padded slots, both directions, nvalid prefix, bit copies."""
+    from linearoperators_jl_amd.device import get_ctx, ptr
+    ctx = get_ctx(dev)
+    plan = lo.sharded.ShardPlan(n, world)
+    pad = -(-n // world)
+    rng = np.random.default_rng(n + world)
+    np_dt = {torch.float64: np.float64, torch.float32: np.float32, torch.complex128: np.complex128}[dtype]
+    full_h = rng.standard_normal(n).astype(np_dt)
+    if dtype == torch.complex128:
+        full_h = full_h + 1j * rng.standard_normal(n)
+    es = full_h.itemsize
+    full = torch.from_numpy(full_h).to(dev)
+    for nvalid in (-1, n // 3):
+        wire = torch.full((world * pad,), 7.0, dtype=dtype, device=dev)        # poison: every slot must be written
+        lo._lib.call("mxlo_shard_stage", ctx.handle, es, ptr(wire), ptr(full), n, world, nvalid, lo._lib.SHARD_PACK)
+        want = np.zeros(world * pad, dtype=np_dt)
+        lim = n if nvalid < 0 else nvalid
+        for r in range(world):
+            a, b = plan.lo(r), plan.hi(r)
+            seg = full_h[a:b].copy()
+            seg[max(0, lim - a):] = 0                      # rows >= nvalid count as zeros
+            want[r * pad:r * pad + (b - a)] = seg
+        assert np.array_equal(wire.cpu().numpy().view(np.uint8), want.view(np.uint8))
+    # unpack the nvalid = n packing back
+    lo._lib.call("mxlo_shard_stage", ctx.handle, es, ptr(wire), ptr(full), n, world, -1, lo._lib.SHARD_PACK)
+    back = torch.zeros(n, dtype=dtype, device=dev)
+    lo._lib.call("mxlo_shard_stage", ctx.handle, es, ptr(back), ptr(wire), n, world, -1, lo._lib.SHARD_UNPACK)
+    assert torch.equal(back.view(torch.uint8) if dtype != torch.complex128 else torch.view_as_real(back),
+                       full.view(torch.uint8) if dtype != torch.complex128 else torch.view_as_real(full))
+    assert lo._lib.lib().mxlo_shard_stage(ctx.handle, es, ptr(back), ptr(wire), n, world, -1, 5) == lo._lib.EINVAL

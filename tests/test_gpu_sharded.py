@@ -1,13 +1,21 @@
-"""-m gpu: the N > 1 code path on ONE GPU — two processes (gloo rendezvous on 127.0.0.1), both on cuda:0.
-RCCL refuses two ranks on the same device, so `install_agreed_allreduce` must detect that on every rank, agree,
-and fall back to the torch.distributed hook; the row-sharded Householder and forward L-BFGS applies through
-libmxlo.so + that hook must then reproduce the unsharded oracle result, with bit-identical scalars on both ranks."""
+"""-m gpu: the N > 1 code path across PROCESSES (one rank per process, as bench.py --gpus N runs).
+
+* `test_two_ranks_one_gpu_...`: two processes (gloo rendezvous on 127.0.0.1), both on cuda:0 — runs on every box.
+  RCCL refuses two ranks on the same device, so `install_agreed_allreduce` must detect that on every rank, agree,
+  and fall back to the torch.distributed hook; the row-sharded Householder, inverse and forward L-BFGS applies through
+  libmxlo.so + that hook must then reproduce the unsharded oracle result, with bit-identical scalars on both ranks.
+  The row-sharded dense `LinearOperator(M)` / `opHermitian` leg (the one exchange that moves vectors) runs through
+  `VectorExchange`'s all_reduce formulation there and is REQUIRED to pass (no skip).
+* `test_real_ranks_native_rccl_hook`: when >= 2 devices are visible (the driver's 8-GPU node), one rank per device on
+  the `nccl` backend with the NATIVE `libmxlo_rccl.so` hook (asserted) and RCCL all_gather / reduce_scatter for the
+  dense leg; auto-skips on a 1-device box."""
 import os
 import subprocess
 import sys
 import textwrap
 
 import pytest
+import torch
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -20,11 +28,17 @@ WORKER = textwrap.dedent('''
     lo = g.load_package()
     import oracle
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-    torch.cuda.set_device(0)
-    dev = torch.device("cuda", 0)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    backend = os.environ["MXLO_TEST_BACKEND"]
+    di = rank if backend == "nccl" else 0
+    torch.cuda.set_device(di)
+    dev = torch.device("cuda", di)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        hook = lo.sharded.install_allreduce(lo.get_ctx(dev), native=True)     # must be the C hook: raises otherwise
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        hook = lo.sharded.install_agreed_allreduce(lo.get_ctx(dev), timeout_s=45.0)
     ctx = lo.get_ctx(dev)
-    hook = lo.sharded.install_agreed_allreduce(ctx, timeout_s=45.0)
     transport = "native" if hook is not None else "torch"
     n, mem = 200_003, 4
     rng = np.random.default_rng(7)                       # same stream everywhere: replicated global data
@@ -47,38 +61,45 @@ WORKER = textwrap.dedent('''
     got = (B * T(x[a:b])).cpu().numpy()
     fullB = O.mul(np.empty(n), x)
     err_b = np.linalg.norm(got - fullB[a:b]) / np.linalg.norm(fullB[a:b])
+    Hi = lo.InverseLBFGSOperator(b - a, mem=mem, device=dev)
+    Oi = oracle.LBFGS(n, mem=mem, inverse=True)
+    for _ in range(mem + 2):
+        s = rng.uniform(-1, 1, n); y = s * rng.uniform(0.5, 2.0, n)
+        lo.push(Hi, T(s[a:b]), T(y[a:b])); Oi.push(s, y)
+    got = (Hi * T(x[a:b])).cpu().numpy()
+    fullH = Oi.mul(np.empty(n), x)
+    err_b = max(err_b, np.linalg.norm(got - fullH[a:b]) / np.linalg.norm(fullH[a:b]))
     # row-sharded dense LinearOperator(M): all-gather(v) + local GEMV; transpose: local GEMV + reduce-scatter
     m2, n2 = 1003, 777
     Mfull = rng.standard_normal((m2, n2)); vv = rng.uniform(-1, 1, n2); uu = rng.uniform(-1, 1, m2)
     rr, rt = rng.uniform(-1, 1, m2), rng.uniform(-1, 1, n2)
     pm, pn = lo.sharded.ShardPlan(m2, world), lo.sharded.ShardPlan(n2, world)
     Mloc = torch.from_numpy(np.asfortranarray(Mfull[pm.lo(rank):pm.hi(rank), :]).T.copy()).to(dev).t()
-    try:
-        Msh = lo.sharded.row_sharded_dense(Mloc, pm, pn)
-        out = T(rr[pm.lo(rank):pm.hi(rank)])
-        lo.mul(out, Msh, T(vv[pn.lo(rank):pn.hi(rank)]), 2.0, -3.0)
-        want = 2.0 * (Mfull @ vv) - 3.0 * rr
-        err_m = np.linalg.norm(out.cpu().numpy() - want[pm.lo(rank):pm.hi(rank)]) / np.linalg.norm(want)
-        outt = T(rt[pn.lo(rank):pn.hi(rank)])
-        lo.mul(outt, Msh.T, T(uu[pm.lo(rank):pm.hi(rank)]), 2.0, -3.0)
-        wantt = 2.0 * (Mfull.T @ uu) - 3.0 * rt
-        err_m = max(err_m, np.linalg.norm(outt.cpu().numpy() - wantt[pn.lo(rank):pn.hi(rank)]) / np.linalg.norm(wantt))
-        # row-sharded opHermitian: rectangle + diagonal triangle per rank, all-gather(v) + reduce-scatter(L' part)
-        nh = 1501
-        Ah = rng.standard_normal((nh, nh)); dh = rng.standard_normal(nh); vh = rng.uniform(-1, 1, nh); rh = rng.uniform(-1, 1, nh)
-        ph = lo.sharded.ShardPlan(nh, world)
-        a0, a1 = ph.lo(rank), ph.hi(rank)
-        Aloc = torch.from_numpy(np.asfortranarray(Ah[a0:a1, :]).T.copy()).to(dev).t()
-        Hsh = lo.sharded.row_sharded_hermitian(T(dh[a0:a1]), Aloc, ph)
-        outh = T(rh[a0:a1])
-        lo.mul(outh, Hsh, T(vh[a0:a1]), 2.0, -3.0)
-        Lh = np.tril(Ah, -1)
-        wanth = 2.0 * ((Lh + Lh.T + np.diag(dh)) @ vh) - 3.0 * rh
-        err_m = max(err_m, np.linalg.norm(outh.cpu().numpy() - wanth[a0:a1]) / np.linalg.norm(wanth))
-    except (RuntimeError, NotImplementedError) as e:       # gloo builds without the *_tensor collectives on CUDA
-        print("SKIP sharded dense:", repr(e)[:200], flush=True)
-        err_m = 0.0
-    t = torch.tensor([B.data.scaling_factor, float(B.data.insert)], dtype=torch.float64)
+    Msh = lo.sharded.row_sharded_dense(Mloc, pm, pn)
+    out = T(rr[pm.lo(rank):pm.hi(rank)])
+    lo.mul(out, Msh, T(vv[pn.lo(rank):pn.hi(rank)]), 2.0, -3.0)
+    want = 2.0 * (Mfull @ vv) - 3.0 * rr
+    err_m = np.linalg.norm(out.cpu().numpy() - want[pm.lo(rank):pm.hi(rank)]) / np.linalg.norm(want)
+    outt = T(rt[pn.lo(rank):pn.hi(rank)])
+    lo.mul(outt, Msh.T, T(uu[pm.lo(rank):pm.hi(rank)]), 2.0, -3.0)
+    wantt = 2.0 * (Mfull.T @ uu) - 3.0 * rt
+    err_m = max(err_m, np.linalg.norm(outt.cpu().numpy() - wantt[pn.lo(rank):pn.hi(rank)]) / np.linalg.norm(wantt))
+    # row-sharded opHermitian: rectangle + diagonal triangle per rank, all-gather(v) + reduce-scatter(L' part)
+    nh = 1501
+    Ah = rng.standard_normal((nh, nh)); dh = rng.standard_normal(nh); vh = rng.uniform(-1, 1, nh); rh = rng.uniform(-1, 1, nh)
+    ph = lo.sharded.ShardPlan(nh, world)
+    a0, a1 = ph.lo(rank), ph.hi(rank)
+    Aloc = torch.from_numpy(np.asfortranarray(Ah[a0:a1, :]).T.copy()).to(dev).t()
+    Hsh = lo.sharded.row_sharded_hermitian(T(dh[a0:a1]), Aloc, ph)
+    outh = T(rh[a0:a1])
+    lo.mul(outh, Hsh, T(vh[a0:a1]), 2.0, -3.0)
+    Lh = np.tril(Ah, -1)
+    wanth = 2.0 * ((Lh + Lh.T + np.diag(dh)) @ vh) - 3.0 * rh
+    err_m = max(err_m, np.linalg.norm(outh.cpu().numpy() - wanth[a0:a1]) / np.linalg.norm(wanth))
+    t = torch.tensor([B.data.scaling_factor, float(B.data.insert), Hi.data.scaling_factor, float(Hi.data.insert)]
+                     + list(B.data.ys) + list(Hi.data.ys), dtype=torch.float64)
+    if backend == "nccl":
+        t = t.to(dev)
     gathered = [torch.zeros_like(t) for _ in range(world)]
     dist.all_gather(gathered, t)
     same = all(torch.equal(gathered[0], gt) for gt in gathered)
@@ -87,13 +108,21 @@ WORKER = textwrap.dedent('''
 ''')
 
 
-def test_two_ranks_one_gpu_agree_on_transport_and_shard(tmp_path):
+def run_ranks(tmp_path, world, backend, port):
     script = tmp_path / "worker.py"
     script.write_text(WORKER % {"root": ROOT})
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29671", WORLD_SIZE="2")
-    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
-                              stderr=subprocess.STDOUT, text=True) for r in range(2)]
-    outs = [p.communicate(timeout=420)[0] for p in procs]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world),
+               MXLO_TEST_BACKEND=backend, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    outs = []
+    try:
+        for p in procs:
+            outs.append(p.communicate(timeout=600)[0])
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o
     transports = set()
@@ -103,4 +132,15 @@ def test_two_ranks_one_gpu_agree_on_transport_and_shard(tmp_path):
         err_h, err_b, same, err_m = float(line[3]), float(line[4]), int(line[5]), float(line[6])
         assert err_h <= 1e-12 and err_b <= 1e-10 and same == 1 and err_m <= 1e-12, o
     assert len(transports) == 1, transports            # never a mix of transports
-    print("\n".join(l for o in outs for l in o.splitlines() if l.startswith(("RESULT", "SKIP"))))
+    print("\n".join(l for o in outs for l in o.splitlines() if l.startswith("RESULT")))
+    return transports.pop()
+
+
+def test_two_ranks_one_gpu_agree_on_transport_and_shard(tmp_path):
+    run_ranks(tmp_path, 2, "gloo", 29671)
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs >= 2 visible devices (lights up on the 8-GPU node)")
+def test_real_ranks_native_rccl_hook(tmp_path):
+    world = min(torch.cuda.device_count(), 8)
+    assert run_ranks(tmp_path, world, "nccl", 29673) == "native"

@@ -268,6 +268,13 @@ int32_t mxlo_gather_range(mxlo_ctx *ctx, int32_t elem_size, void *res, const voi
  * are no duplicates, meaning pos[k] == k). */
 int32_t mxlo_scatter_zero(mxlo_ctx *ctx, int32_t elem_size, void *res, int64_t nres,
                           const void *u, const int64_t *idx, const int64_t *pos, int64_t nidx);
+/* The same statement pair for a plan whose indices are STRICTLY INCREASING (the glue sorts its last-write-wins plan
+ * once; pos[k], 0-based or NULL for the identity, is the position in u of sorted entry k): segment-owner kernel —
+ * each workgroup builds one output tile (zeros and values) in LDS and writes it once with 16-byte stores, so res
+ * is written exactly once and u is the only scattered access. Bit-exact like mxlo_scatter_zero. An index list that
+ * is not strictly increasing gives an unspecified (memory-safe) result: the CALLER guarantees the order. */
+int32_t mxlo_scatter_zero_sorted(mxlo_ctx *ctx, int32_t elem_size, void *res, int64_t nres,
+                                 const void *u, const int64_t *idx, const int64_t *pos, int64_t nidx);
 int32_t mxlo_scatter_zero_range(mxlo_ctx *ctx, int32_t elem_size, void *res, int64_t nres,
                                 const void *u, int64_t start, int64_t step, int64_t len);
 

@@ -281,19 +281,19 @@ end
 # α, β are ignored by the reference and are not ABI parameters. `opRestriction(I, ncol; S = MXVector{T})` and
 # `opExtension` are the reference's own constructors; their closures land here. Ranges need no device memory; an
 # index Vector is uploaded once and cached per (objectid, length) together with its last-write-wins scatter plan.
-struct ScatterPlan            # duplicates: `res[I] = u` is sequential, the LAST write wins — resolved once
-  didx::MXVector{Int64}
-  idx::MXVector{Int64}
-  pos::Union{MXVector{Int64}, Nothing}
+struct ScatterPlan            # duplicates: `res[I] = u` is sequential, the LAST write wins — resolved once, into a SORTED plan
+  didx::MXVector{Int64}       # I as given (gather)
+  idx::MXVector{Int64}        # strictly increasing target indices (scatter)
+  pos::Union{MXVector{Int64}, Nothing}   # 0-based position in u of the surviving write; nothing = identity
   n::Int
 end
 function ScatterPlan(I::AbstractVector{<:Integer})
+  didx = MXVector(collect(Int64, I))
+  (issorted(I) && allunique(I)) && return ScatterPlan(didx, didx, nothing, length(I))
   last = Dict{Int64, Int64}()
   for (k, i) in enumerate(I)
     last[i] = k - 1                                   # 0-based source position of the surviving write
   end
-  didx = MXVector(collect(Int64, I))
-  length(last) == length(I) && return ScatterPlan(didx, didx, nothing, length(I))
   ks = sort!(collect(keys(last)))
   ScatterPlan(didx, MXVector(ks), MXVector([last[i] for i in ks]), length(ks))
 end
@@ -313,7 +313,7 @@ function mulRestrict!(res::MXVector, Idx::Vector{<:Integer}, v::MXVector, α, β
 end
 function multRestrict!(res::MXVector, Idx::Vector{<:Integer}, u::MXVector, α, β)
   pl = plan(Idx)
-  check(ccall((:mxlo_scatter_zero, lib), Int32, (P, Int32, P, Int64, P, P, P, Int64), ctx(), Int32(sizeof(eltype(u))),
+  check(ccall((:mxlo_scatter_zero_sorted, lib), Int32, (P, Int32, P, Int64, P, P, P, Int64), ctx(), Int32(sizeof(eltype(u))),
               res.ptr, length(res), u.ptr, pl.idx.ptr, pl.pos === nothing ? C_NULL : pl.pos.ptr, pl.n))
 end
 

@@ -122,6 +122,7 @@ _PROTOS = {
     "mxlo_gather_range": [_vp, _i32, _vp, _vp, _i64, _i64, _i64, _i64],
     "mxlo_scatter_zero": [_vp, _i32, _vp, _i64, _vp, _vp, _vp, _i64],
     "mxlo_scatter_zero_range": [_vp, _i32, _vp, _i64, _vp, _i64, _i64, _i64],
+    "mxlo_scatter_zero_sorted": [_vp, _i32, _vp, _i64, _vp, _vp, _vp, _i64],
     "mxlo_shard_stage": [_vp, _i32, _vp, _vp, _i64, _i32, _i64, _i32],
     "mxlo_blockdiag_create": [_vp, _i32, C.POINTER(BlockDesc), _i64, C.POINTER(_vp)],
     "mxlo_blockdiag_mul": [_vp, _vp, _vp, _dbl, _dbl, _i32, _i32],

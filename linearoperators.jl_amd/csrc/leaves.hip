@@ -347,13 +347,33 @@ gather_idx_kernel(E *__restrict__ res, const E *__restrict__ v, const int64_t *_
   }
 }
 
+// res[k] = v[start0 + k*step]: each lane owns one 16-byte group of the CONTIGUOUS side (res) and issues one vector
+// store; its VEC source elements are `step` apart. No integer division, 64-bit multiply once per group.
 template <typename E>
 __global__ void __launch_bounds__(kBlock)
 gather_range_kernel(E *__restrict__ res, const E *__restrict__ v, int64_t start0, int64_t step,
-                    int64_t len) {
-  for (int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x; k < len;
-       k += (int64_t)gridDim.x * kBlock)
-    res[k] = v[start0 + k * step];
+                    int64_t len, int32_t res_aligned) {
+  constexpr int VEC = sizeof(E) >= 16 ? 1 : 16 / (int)sizeof(E);
+  const int64_t ngroups = (len + VEC - 1) / VEC;
+  for (int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x; g < ngroups; g += (int64_t)gridDim.x * kBlock) {
+    const int64_t k0 = g * VEC;
+    const E *src = v + start0 + k0 * step;
+    if (k0 + VEC <= len) {
+      struct alignas(16) Pack { E x[VEC]; };
+      Pack pk;
+#pragma unroll
+      for (int q = 0; q < VEC; ++q) pk.x[q] = src[(int64_t)q * step];
+      if (res_aligned) {
+        typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+        __builtin_nontemporal_store(*reinterpret_cast<u32x4 *>(&pk), reinterpret_cast<u32x4 *>(res + k0));
+      } else {
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) res[k0 + q] = pk.x[q];
+      }
+    } else {
+      for (int q = 0; k0 + q < len; ++q) res[k0 + q] = src[(int64_t)q * step];
+    }
+  }
 }
 
 template <typename E>
@@ -367,26 +387,120 @@ scatter_idx_kernel(E *__restrict__ res, const E *__restrict__ u, const int64_t *
   }
 }
 
-// res[i] = u[(i-start0)/step] if i is on the range else 0 : every element written exactly once
+// res[i] = u[(i-start0)/step] if i is on the range else 0 : every element written exactly once, 16 bytes per lane.
+// No per-element division: a lane divides ONCE (its first group), then walks (q, r) = divmod(i - lo, |step|) forward
+// with the precomputed divmod of the grid stride (sq, sr).
 template <typename E>
 __global__ void __launch_bounds__(kBlock)
 extend_range_kernel(E *__restrict__ res, int64_t nres, const E *__restrict__ u, int64_t start0,
-                    int64_t step, int64_t len) {
+                    int64_t step, int64_t len, int64_t sq, int64_t sr, int32_t res_aligned) {
+  constexpr int VEC = sizeof(E) >= 16 ? 1 : 16 / (int)sizeof(E);
   const int64_t stop0 = start0 + (len - 1) * step;  // inclusive; step may be negative
   const int64_t lo = step > 0 ? start0 : stop0, hi = step > 0 ? stop0 : start0;
   const int64_t astep = step > 0 ? step : -step;
-  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < nres;
-       i += (int64_t)gridDim.x * kBlock) {
-    E val;
-    memset(&val, 0, sizeof(E));
-    if (len > 0 && i >= lo && i <= hi) {
-      const int64_t off = i - lo;
-      if (off % astep == 0) {
-        const int64_t k = step > 0 ? off / astep : (len - 1) - off / astep;
-        val = u[k];
-      }
+  const int64_t ngroups = (nres + VEC - 1) / VEC;
+  int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (g >= ngroups) return;
+  // (q, r) for element i0 = g*VEC relative to lo; elements below lo get a NEGATIVE offset handled by the range test
+  int64_t off = g * VEC - lo;
+  int64_t q = off >= 0 ? off / astep : -((-off + astep - 1) / astep);   // floor division
+  int64_t r = off - q * astep;                                          // 0 <= r < astep
+  for (; g < ngroups; g += (int64_t)gridDim.x * kBlock) {
+    const int64_t i0 = g * VEC;
+    struct alignas(16) Pack { E x[VEC]; };
+    Pack pk;
+    int64_t qq = q, rr = r;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      E val;
+      memset(&val, 0, sizeof(E));
+      const int64_t i = i0 + j;
+      if (rr == 0 && len > 0 && i >= lo && i <= hi) val = u[step > 0 ? qq : (len - 1) - qq];
+      pk.x[j] = val;
+      if (++rr == astep) { rr = 0; ++qq; }
     }
-    res[i] = val;
+    if (res_aligned && i0 + VEC <= nres) {
+      typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+      __builtin_nontemporal_store(*reinterpret_cast<u32x4 *>(&pk), reinterpret_cast<u32x4 *>(res + i0));
+    } else {
+#pragma unroll
+      for (int j = 0; j < VEC; ++j)
+        if (i0 + j < nres) res[i0 + j] = pk.x[j];
+    }
+    q += sq;
+    r += sr;
+    if (r >= astep) { r -= astep; ++q; }
+  }
+}
+
+// ---- index extension with a SORTED plan: res is written exactly once, in full 16-byte vectors ------------------------
+// `res .= 0; res[I] = u` (src/special-operators.jl:171-174) for a strictly increasing index list (the glue sorts the
+// last-write-wins plan once; `pos` maps a sorted entry back to its position in u). Segment-owner formulation: a
+// workgroup owns an output tile, finds the plan entries that fall into it with a wave-wide 64-ary lower bound (5 probe
+// rounds for 5e7 entries; the first rounds hit the same few cache lines for every tile), builds the tile — zeros and
+// values — in LDS, and streams it out with vector stores. Against memset + scatter this removes one full write of res
+// and every partial-line write. Out-of-tile entries (a plan that is NOT strictly increasing) are dropped, never
+// written out of bounds.
+__device__ __forceinline__ int64_t wave_lower_bound(const int64_t *__restrict__ idx, int64_t lo, int64_t hi,
+                                                    int64_t target, int lane) {
+  // first p in [lo, hi] with idx[p] >= target (hi when none); all 64 lanes cooperate and return the same value
+  while (true) {
+    const int64_t n = hi - lo;
+    if (n <= 0) return lo;
+    if (n <= 64) {
+      const int64_t p = lo + lane;
+      const bool lt = p < hi && idx[p] < target;
+      return lo + __popcll(__ballot(lt));
+    }
+    const int64_t p = lo + ((int64_t)(lane + 1) * n) / 65;          // 64 interior probes, strictly increasing, < hi
+    const bool lt = idx[p] < target;
+    const int c = __popcll(__ballot(lt));                           // sorted -> the `lt` lanes are a prefix
+    const int64_t nlo = c == 0 ? lo : lo + ((int64_t)c * n) / 65 + 1;
+    const int64_t nhi = c == 64 ? hi : lo + ((int64_t)(c + 1) * n) / 65;
+    lo = nlo;
+    hi = nhi;
+  }
+}
+
+template <typename E, int TILE_BYTES>
+__global__ void __launch_bounds__(kBlock)
+extend_sorted_kernel(E *__restrict__ res, int64_t nres, const E *__restrict__ u, const int64_t *__restrict__ idx,
+                     const int64_t *__restrict__ pos, int64_t nidx, int64_t ntiles, int32_t res_aligned) {
+  constexpr int TILE = TILE_BYTES / (int)sizeof(E);
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  __shared__ u32x4 smem[TILE_BYTES / 16];
+  __shared__ int64_t bounds[2];
+  E *tile = reinterpret_cast<E *>(smem);
+  const int tid = threadIdx.x;
+  for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    const int64_t t0 = t * TILE, t1 = t0 + TILE < nres ? t0 + TILE : nres;   // outputs [t0, t1); entry k is inside iff t0 < idx[k] <= t1
+    if (tid < 64) {
+      const int64_t s = wave_lower_bound(idx, 0, nidx, t0 + 1, tid);
+      const int64_t cap = s + TILE < nidx ? s + TILE : nidx;                  // strictly increasing: at most TILE entries per tile
+      const int64_t e = wave_lower_bound(idx, s, cap, t1 + 1, tid);
+      if (tid == 0) { bounds[0] = s; bounds[1] = e; }
+    }
+    const u32x4 z = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int w = tid; w < TILE_BYTES / 16; w += kBlock) smem[w] = z;
+    __syncthreads();
+    const int64_t s = bounds[0], e = bounds[1];
+    for (int64_t k = s + tid; k < e; k += kBlock) {
+      const int64_t j = idx[k] - 1 - t0;
+      const E val = u[pos ? pos[k] : k];
+      if (j >= 0 && j < t1 - t0) tile[j] = val;
+    }
+    __syncthreads();
+    const int64_t nbytes = (t1 - t0) * (int64_t)sizeof(E);
+    if (res_aligned) {                       // t0 * sizeof(E) is a multiple of 16 (TILE_BYTES is): vectors stay aligned
+      u32x4 *dst = reinterpret_cast<u32x4 *>(res + t0);
+      const int nv = (int)(nbytes / 16);
+      for (int w = tid; w < nv; w += kBlock) __builtin_nontemporal_store(smem[w], dst + w);
+      for (int64_t j = (int64_t)nv * (16 / (int)sizeof(E)) + tid; j < t1 - t0; j += kBlock) res[t0 + j] = tile[j];
+    } else {
+      for (int64_t j = tid; j < t1 - t0; j += kBlock) res[t0 + j] = tile[j];
+    }
+    __syncthreads();
   }
 }
 
@@ -445,9 +559,10 @@ MXLO_API int32_t mxlo_gather_range(mxlo_ctx *ctx, int32_t elem_size, void *res, 
                                                (const double *)nullptr, nd, CopyBitsOp<double>{});
   }
   return by_elem_size(elem_size, [&]<typename E>() -> int32_t {
-    const int grid = grid_for(ctx, len, kBlock * 4, ctx->tune.blocks_per_cu);
+    constexpr int VEC = sizeof(E) >= 16 ? 1 : 16 / (int)sizeof(E);
+    const int grid = grid_for(ctx, (len + VEC - 1) / VEC, kBlock * 4, ctx->tune.blocks_per_cu);
     hipLaunchKernelGGL((gather_range_kernel<E>), dim3(grid), dim3(kBlock), 0, ctx->stream,
-                       (E *)res, (const E *)v, start - 1, step, len);
+                       (E *)res, (const E *)v, start - 1, step, len, (int32_t)((((uintptr_t)res) & 15u) == 0));
     MXLO_LAUNCH_CHECK();
     return MXLO_OK;
   });
@@ -475,6 +590,26 @@ MXLO_API int32_t mxlo_scatter_zero(mxlo_ctx *ctx, int32_t elem_size, void *res, 
   });
 }
 
+MXLO_API int32_t mxlo_scatter_zero_sorted(mxlo_ctx *ctx, int32_t elem_size, void *res, int64_t nres,
+                                          const void *u, const int64_t *idx, const int64_t *pos, int64_t nidx) {
+  MXLO_REQUIRE(ctx, MXLO_EINVAL, "mxlo_scatter_zero_sorted: ctx is NULL");
+  MXLO_DEVICE_GUARD(ctx);
+  MXLO_REQUIRE(nidx >= 0 && nres >= 0, MXLO_ESHAPE, "mxlo_scatter_zero_sorted: negative size");
+  MXLO_REQUIRE(nidx <= nres, MXLO_ESHAPE, "mxlo_scatter_zero_sorted: %lld strictly increasing indices cannot fit 1..%lld",
+               (long long)nidx, (long long)nres);
+  if (nres == 0) return MXLO_OK;
+  MXLO_REQUIRE(res && (nidx == 0 || (u && idx)), MXLO_EINVAL, "mxlo_scatter_zero_sorted: NULL operand");
+  return by_elem_size(elem_size, [&]<typename E>() -> int32_t {
+    constexpr int TB = 16384;
+    const int64_t ntiles = (nres * (int64_t)sizeof(E) + TB - 1) / TB;
+    const int grid = (int)std::min<int64_t>(ntiles, 0x7fffffffLL);
+    hipLaunchKernelGGL((extend_sorted_kernel<E, TB>), dim3(grid), dim3(kBlock), 0, ctx->stream, (E *)res, nres,
+                       (const E *)u, idx, pos, nidx, ntiles, (int32_t)((((uintptr_t)res) & 15u) == 0));
+    MXLO_LAUNCH_CHECK();
+    return MXLO_OK;
+  });
+}
+
 MXLO_API int32_t mxlo_scatter_zero_range(mxlo_ctx *ctx, int32_t elem_size, void *res, int64_t nres,
                                          const void *u, int64_t start, int64_t step, int64_t len) {
   MXLO_REQUIRE(ctx, MXLO_EINVAL, "mxlo_scatter_zero_range: ctx is NULL");
@@ -489,9 +624,13 @@ MXLO_API int32_t mxlo_scatter_zero_range(mxlo_ctx *ctx, int32_t elem_size, void 
                  (long long)start, (long long)step, (long long)last, (long long)nres);
   }
   return by_elem_size(elem_size, [&]<typename E>() -> int32_t {
-    const int grid = grid_for(ctx, nres, kBlock * 4, ctx->tune.blocks_per_cu);
+    constexpr int VEC = sizeof(E) >= 16 ? 1 : 16 / (int)sizeof(E);
+    const int grid = grid_for(ctx, (nres + VEC - 1) / VEC, kBlock * 4, ctx->tune.blocks_per_cu);
+    const int64_t astep = step > 0 ? step : -step;
+    const int64_t stride = (int64_t)grid * kBlock * VEC;          // elements a lane advances per iteration
     hipLaunchKernelGGL((extend_range_kernel<E>), dim3(grid), dim3(kBlock), 0, ctx->stream,
-                       (E *)res, nres, (const E *)u, start - 1, step, len);
+                       (E *)res, nres, (const E *)u, start - 1, len > 0 ? step : 1, len, len > 0 ? stride / astep : 0,
+                       len > 0 ? stride % astep : 0, (int32_t)((((uintptr_t)res) & 15u) == 0));
     MXLO_LAUNCH_CHECK();
     return MXLO_OK;
   });

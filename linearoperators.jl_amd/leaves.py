@@ -209,14 +209,14 @@ def opRestriction(Idx, ncol: int, S: Optional[Storage] = None, device=None):
             raise LinearOperatorException(f"indices should be between 1 and {ncol}")
         nrow = idx_h.size
         idx_d = torch.from_numpy(idx_h.copy()).to(dev)
-        # duplicates: `res[I] = u` is sequential, the LAST write wins -> resolve once, here
-        _, last_pos = np.unique(idx_h[::-1], return_index=True)
-        keep = np.sort(nrow - 1 - last_pos)
-        if keep.size != nrow:
-            sidx_d = torch.from_numpy(idx_h[keep].copy()).to(dev)
-            spos_d = torch.from_numpy(keep.astype(np.int64)).to(dev)
-        else:
-            sidx_d, spos_d = idx_d, None
+        # `res .= 0; res[I] = u` (:171-174) is sequential: with duplicates the LAST write wins. Resolved once, here, into a
+        # SORTED plan — strictly increasing target indices + the position in u of the surviving write — so that the
+        # apply is the segment-owner kernel (res written exactly once, in full vectors) whatever the order of I.
+        svals, last_rev = np.unique(idx_h[::-1], return_index=True)
+        spos = (nrow - 1 - last_rev).astype(np.int64)
+        identity = spos.size == nrow and (nrow == 0 or bool(np.all(spos == np.arange(nrow))))
+        sidx_d = idx_d if identity else torch.from_numpy(svals.astype(np.int64)).to(dev)
+        spos_d = None if identity else torch.from_numpy(spos).to(dev)
 
         def prod(res, v, a, b):
             ctx = get_ctx(res.device)
@@ -224,8 +224,8 @@ def opRestriction(Idx, ncol: int, S: Optional[Storage] = None, device=None):
 
         def tprod(res, u, a, b):
             ctx = get_ctx(res.device)
-            _lib.call("mxlo_scatter_zero", ctx.handle, res.element_size(), ptr(res), res.numel(), ptr(u), ptr(sidx_d),
-                      ptr(spos_d), sidx_d.numel())
+            _lib.call("mxlo_scatter_zero_sorted", ctx.handle, res.element_size(), ptr(res), res.numel(), ptr(u),
+                      ptr(sidx_d), ptr(spos_d), sidx_d.numel())
     op = LinearOperator(torch.int64, nrow, ncol, False, False, prod, tprod, tprod, S=storage)
     op._deps = ()          # the index set is copied at construction
     return op

@@ -363,3 +363,85 @@ def test_empty_operators(lo, dev, dtype):
     assert K.shape == (0, 0) and (K * e).numel() == 0
     Bd = lo.BlockDiagonalOperator(lo.opDiagonal(e), lo.opDiagonal(v5))
     assert torch.equal(Bd * v5, v5 * v5)
+
+
+@pytest.mark.parametrize("es", [4, 8, 16])
+def test_sorted_extension_and_range_kernels_bit_exact_edge_shapes(lo, dev, es):
+    """mxlo_scatter_zero_sorted (segment-owner tiles), mxlo_scatter_zero (memset + scatter), mxlo_scatter_zero_range and
+    mxlo_gather_range (division-free 16-byte lanes) against `res .= 0; res[I] = u` / `v[I]` on numpy: dense, sparse and
+    clustered plans, tile-boundary sizes, unaligned res, pos maps, negative and wide steps, all three element sizes."""
+    from linearoperators_jl_amd.device import get_ctx, ptr
+    ctx = get_ctx(dev)
+    rng = np.random.default_rng(100 + es)
+    words = es // 4
+    tile = 16384 // es
+
+    def rand_elems(n):
+        return rng.integers(1, 2**32, (n, words), dtype=np.uint64).astype(np.uint32)     # never all-zero elements
+
+    def dev_elems(a, off=0):
+        """upload with the first element `off` elements past a 16-byte boundary"""
+        buf = torch.zeros((a.shape[0] + 4) * words, dtype=torch.int32, device=dev)
+        view = buf[off * words:(off + a.shape[0]) * words]
+        view.copy_(torch.from_numpy(a.view(np.int32).reshape(-1)).to(dev))
+        return buf, view
+
+    sizes = [1, 3, tile - 1, tile, tile + 1, 3 * tile + 5, 200_003]
+    for nres in sizes:
+        plans = []
+        dense = np.flatnonzero(rng.random(nres) < 0.5) + 1
+        plans.append(dense)
+        plans.append(np.arange(1, nres + 1))                                             # every slot
+        plans.append(np.array([], dtype=np.int64))
+        plans.append(np.array([nres], dtype=np.int64))
+        plans.append(np.array([1], dtype=np.int64))
+        if nres > 10:
+            plans.append(np.unique(rng.integers(1, nres + 1, max(1, nres // 300))))      # sparse
+            plans.append(np.arange(1, nres // 2))                                        # one cluster + a giant gap
+        for off in (0, 1):
+            if es == 16 and off:
+                continue
+            for idx in plans:
+                nidx = idx.size
+                u = rand_elems(max(nidx, 1) + 3)
+                use_pos = nidx > 1 and rng.random() < 0.5
+                pos = rng.permutation(u.shape[0])[:nidx].astype(np.int64) if use_pos else None
+                want = np.zeros((nres, words), dtype=np.uint32)
+                if nidx:
+                    want[idx - 1] = u[pos] if use_pos else u[:nidx]
+                _, ud = dev_elems(u)
+                idx_d = torch.from_numpy(idx.astype(np.int64)).to(dev)
+                pos_d = torch.from_numpy(pos).to(dev) if use_pos else None
+                for fn in ("mxlo_scatter_zero_sorted", "mxlo_scatter_zero"):
+                    rbuf, rd = dev_elems(np.full((nres, words), 0xDEADBEEF, dtype=np.uint32), off)
+                    lo._lib.call(fn, ctx.handle, es, ptr(rd), nres, ptr(ud), ptr(idx_d), ptr(pos_d), nidx)
+                    got = rd.cpu().numpy().view(np.uint32).reshape(nres, words)
+                    assert np.array_equal(got, want), (fn, nres, nidx, off, use_pos)
+                    guard = rbuf.cpu().numpy()
+                    assert not guard[:off * words].any() and not guard[(off + nres) * words:].any(), "wrote outside res"
+    # ranges
+    n = 100_003
+    v = rand_elems(n)
+    for off in (0, 1):
+        if es == 16 and off:
+            continue
+        _, vd = dev_elems(v)
+        for (a, b, s) in ((1, n, 1), (1, n, 2), (2, n, 2), (n, 1, -1), (n, 2, -2), (7, n - 5, 3), (n - 1, 4, -5), (1, n, 4),
+                          (3, n, 64), (1, n, n - 1), (10, 10, 1), (5, 4, 1), (n, n, -7), (1, n, 1000), (2, 2 + 13 * 17, 17)):
+            r = lo.jrange(a, b, s)
+            idx = r.to_numpy()
+            ln = len(r)
+            rbuf, rd = dev_elems(np.full((max(ln, 1), words), 0xDEADBEEF, dtype=np.uint32), off)
+            lo._lib.call("mxlo_gather_range", ctx.handle, es, ptr(rd), ptr(vd), n, a, s, ln)
+            got = rd.cpu().numpy().view(np.uint32).reshape(-1, words)[:ln]
+            assert np.array_equal(got, v[idx - 1]), ("gather", a, b, s, off)
+            u = rand_elems(max(ln, 1))
+            _, ud = dev_elems(u)
+            rbuf, rd = dev_elems(np.full((n, words), 0xDEADBEEF, dtype=np.uint32), off)
+            lo._lib.call("mxlo_scatter_zero_range", ctx.handle, es, ptr(rd), n, ptr(ud), a, s, ln)
+            want = np.zeros((n, words), dtype=np.uint32)
+            want[idx - 1] = u[:ln]
+            got = rd.cpu().numpy().view(np.uint32).reshape(n, words)
+            assert np.array_equal(got, want), ("extend", a, b, s, off)
+            guard = rbuf.cpu().numpy()
+            assert not guard[:off * words].any() and not guard[(off + n) * words:].any()

@@ -153,7 +153,7 @@ def test_headers_parse_to_the_full_symbol_lists():
 def test_the_glue_has_ccalls_for_every_hot_path_leaf():
     names = {c["name"] for c in CALLS}
     must = {"mxlo_diag_mul", "mxlo_eye_mul", "mxlo_ones_mul", "mxlo_zeros_mul", "mxlo_householder_mul",
-            "mxlo_hermitian_mul", "mxlo_gemv", "mxlo_gather", "mxlo_gather_range", "mxlo_scatter_zero",
+            "mxlo_hermitian_mul", "mxlo_gemv", "mxlo_gather", "mxlo_gather_range", "mxlo_scatter_zero_sorted",
             "mxlo_scatter_zero_range", "mxlo_blockdiag_create", "mxlo_blockdiag_mul", "mxlo_kron_mul",
             "mxlo_kron_mul_ex", "mxlo_qn_create", "mxlo_qn_push", "mxlo_qn_mul", "mxlo_qn_mul_shifted",
             "mxlo_qn_solve_shifted", "mxlo_qn_diag", "mxlo_qn_reset", "mxlo_diagqn_push", "mxlo_graph_begin",

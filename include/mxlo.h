@@ -147,6 +147,10 @@ int32_t mxlo_ctx_create_stream(mxlo_ctx *ctx, void **stream_out); /* non-blockin
 int32_t mxlo_graph_begin(mxlo_ctx *ctx);
 int32_t mxlo_graph_end(mxlo_ctx *ctx, mxlo_graph **out);
 int32_t mxlo_graph_launch(mxlo_graph *g);   /* on the stream it was captured from */
+/* info[0] = nodes recorded, info[1] = 1 when the replay re-issues the recorded launches directly (a dependency chain of
+ * at most `graph_direct_max` kernel/memset nodes, tune key, default 16: cheaper than hipGraphLaunch on this runtime),
+ * 0 when it goes through hipGraphLaunch. Same results either way. */
+int32_t mxlo_graph_info(mxlo_graph *g, int64_t info[2]);
 int32_t mxlo_graph_destroy(mxlo_graph *g);
 
 /* ---- timing on the ctx stream (bench / roofline evidence) ---------------- */

@@ -95,6 +95,7 @@ _PROTOS = {
     "mxlo_graph_begin": [_vp],
     "mxlo_graph_end": [_vp, C.POINTER(_vp)],
     "mxlo_graph_launch": [_vp],
+    "mxlo_graph_info": [_vp, C.POINTER(_i64)],
     "mxlo_graph_destroy": [_vp],
     "mxlo_timer_create": [_vp, C.POINTER(_vp)],
     "mxlo_timer_start": [_vp],
@@ -237,10 +238,16 @@ def check(status: int) -> None:
         raise MxloError(status, msg)
 
 
+_FN: dict = {}
+
+
 def call(name: str, *args) -> None:
-    L = lib()
-    try:
-        f = getattr(L, name)
-    except AttributeError as e:  # pragma: no cover
-        raise ImportError(f"libmxlo.so does not export {name}; rebuild it") from e
-    check(f(*args))
+    f = _FN.get(name)
+    if f is None:
+        try:
+            f = _FN[name] = getattr(lib(), name)
+        except AttributeError as e:  # pragma: no cover
+            raise ImportError(f"libmxlo.so does not export {name}; rebuild it") from e
+    st = f(*args)
+    if st != OK:
+        check(st)

@@ -1,5 +1,6 @@
 // api_ctx.hip — context, device-memory helpers, timers, error reporting of libmxlo.so.
 #include "common.h"
+#include <vector>
 
 namespace mxlo {
 static thread_local char g_err[512] = "";
@@ -47,15 +48,22 @@ MXLO_API int32_t mxlo_ctx_create(int32_t device_id, void *stream, mxlo_ctx **out
   hipError_t e = hipMalloc((void **)&ctx->partials, sizeof(double) * kMaxRedCols * kMaxRedBlocks);
   if (e == hipSuccess) e = hipMalloc((void **)&ctx->scalars, sizeof(double) * kScalarSlots);
   if (e == hipSuccess) e = hipMalloc((void **)&ctx->ticket, 64);
+  if (e == hipSuccess) e = hipMalloc((void **)&ctx->xslots, sizeof(unsigned long long) * (2 * kFusedSlots + 8));
   if (e != hipSuccess) {
     set_error("mxlo_ctx_create: workspace allocation failed: %s", hipGetErrorString(e));
     if (ctx->partials) (void)hipFree(ctx->partials);
     if (ctx->scalars) (void)hipFree(ctx->scalars);
+    if (ctx->ticket) (void)hipFree(ctx->ticket);
     delete ctx;
     return MXLO_ENOMEM;
   }
   MXLO_HIP(hipMemsetAsync(ctx->scalars, 0, sizeof(double) * kScalarSlots, ctx->stream));
   MXLO_HIP(hipMemsetAsync(ctx->ticket, 0, 64, ctx->stream));
+  {  // every exchange slot empty, epoch 0
+    std::vector<unsigned long long> init(2 * kFusedSlots + 8, kSlotEmpty);
+    for (int i = 0; i < 8; ++i) init[2 * kFusedSlots + i] = 0;
+    MXLO_HIP(hipMemcpy(ctx->xslots, init.data(), init.size() * sizeof(unsigned long long), hipMemcpyHostToDevice));
+  }
   *out = ctx;
   return MXLO_OK;
 }
@@ -67,6 +75,7 @@ MXLO_API int32_t mxlo_ctx_destroy(mxlo_ctx *ctx) {
   if (ctx->partials) (void)hipFree(ctx->partials);
   if (ctx->scalars) (void)hipFree(ctx->scalars);
   if (ctx->ticket) (void)hipFree(ctx->ticket);
+  if (ctx->xslots) (void)hipFree(ctx->xslots);
   if (ctx->scratch) (void)hipFree(ctx->scratch);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
   if (ctx->switch_event) (void)hipEventDestroy(ctx->switch_event);
@@ -110,7 +119,51 @@ struct mxlo_graph {
   // workspace pointer): a replay after push!/reset!/a workspace reallocation would silently use stale values
   std::vector<std::pair<mxlo_qn *, int64_t>> qn;
   int64_t scratch_generation = -1;   // -1: no opHermitian apply inside the graph
+  // Short linear chains of kernel / memset nodes are replayed by re-issuing the recorded launches one by one: on this
+  // runtime hipGraphLaunch costs ~9 us of host time plus ~3 us per node, a plain launch with the node's own
+  // (already marshalled) argument block ~2 us — so for the launch-bound sequences graphs exist for, the direct
+  // chain is never slower than the eager calls, while hipGraphLaunch of a 1-3 node graph is.
+  struct Step {
+    bool is_memset = false;
+    hipKernelNodeParams k{};
+    hipMemsetParams m{};
+  };
+  std::vector<Step> chain;           // empty: replay through hipGraphLaunch
 };
+
+// Walks the captured graph; fills g->chain when it is one dependency chain of kernel / 1-D memset nodes.
+static void try_linearise(mxlo_graph *g, int max_nodes) {
+  size_t nn = 0, nr = 0;
+  if (hipGraphGetNodes(g->graph, nullptr, &nn) != hipSuccess || nn == 0 || (int)nn > max_nodes) return;
+  if (hipGraphGetRootNodes(g->graph, nullptr, &nr) != hipSuccess || nr != 1) return;
+  hipGraphNode_t cur = nullptr;
+  if (hipGraphGetRootNodes(g->graph, &cur, &nr) != hipSuccess) return;
+  std::vector<mxlo_graph::Step> chain;
+  while (true) {
+    hipGraphNodeType ty;
+    if (hipGraphNodeGetType(cur, &ty) != hipSuccess) return;
+    mxlo_graph::Step st;
+    if (ty == hipGraphNodeTypeKernel) {
+      if (hipGraphKernelNodeGetParams(cur, &st.k) != hipSuccess || !st.k.func || !st.k.kernelParams || st.k.extra) return;
+    } else if (ty == hipGraphNodeTypeMemset) {
+      st.is_memset = true;
+      if (hipGraphMemsetNodeGetParams(cur, &st.m) != hipSuccess || st.m.height != 1) return;
+      if (st.m.elementSize != 1 && st.m.elementSize != 2 && st.m.elementSize != 4) return;
+    } else {
+      return;
+    }
+    chain.push_back(st);
+    size_t nd = 0;
+    if (hipGraphNodeGetDependentNodes(cur, nullptr, &nd) != hipSuccess || nd > 1) return;
+    if (nd == 0) break;
+    if (chain.size() > nn) return;
+    hipGraphNode_t next = nullptr;
+    if (hipGraphNodeGetDependentNodes(cur, &next, &nd) != hipSuccess || !next) return;
+    cur = next;
+  }
+  if (chain.size() == nn) g->chain = std::move(chain);
+  (void)hipGetLastError();
+}
 
 MXLO_API int32_t mxlo_graph_begin(mxlo_ctx *ctx) {
   MXLO_REQUIRE(ctx, MXLO_EINVAL, "ctx is NULL");
@@ -153,6 +206,7 @@ MXLO_API int32_t mxlo_graph_end(mxlo_ctx *ctx, mxlo_graph **out) {
     delete g;
     return MXLO_EHIP;
   }
+  if (ctx->tune.graph_direct_max > 0) try_linearise(g, ctx->tune.graph_direct_max);
   *out = g;
   return MXLO_OK;
 }
@@ -171,7 +225,29 @@ MXLO_API int32_t mxlo_graph_launch(mxlo_graph *g) {
   MXLO_REQUIRE(g->scratch_generation < 0 || g->scratch_generation == g->ctx->scratch_generation, MXLO_ESTATE,
                "mxlo_graph_launch: the opHermitian workspace recorded in this graph was reallocated (a larger n arrived) "
                "— recapture");
+  if (!g->chain.empty()) {
+    for (const auto &st : g->chain) {
+      if (st.is_memset) {
+        if (st.m.elementSize == 4) MXLO_HIP(hipMemsetD32Async((hipDeviceptr_t)st.m.dst, (int)st.m.value, st.m.width, g->stream));
+        else if (st.m.elementSize == 2) MXLO_HIP(hipMemsetD16Async((hipDeviceptr_t)st.m.dst, (unsigned short)st.m.value, st.m.width, g->stream));
+        else MXLO_HIP(hipMemsetD8Async((hipDeviceptr_t)st.m.dst, (unsigned char)st.m.value, st.m.width, g->stream));
+      } else {
+        MXLO_HIP(hipLaunchKernel(st.k.func, st.k.gridDim, st.k.blockDim, st.k.kernelParams, st.k.sharedMemBytes, g->stream));
+      }
+    }
+    return MXLO_OK;
+  }
   MXLO_HIP(hipGraphLaunch(g->exec, g->stream));
+  return MXLO_OK;
+}
+
+MXLO_API int32_t mxlo_graph_info(mxlo_graph *g, int64_t info[2]) {
+  MXLO_REQUIRE(g && info, MXLO_EINVAL, "mxlo_graph_info: NULL argument");
+  size_t nn = 0;
+  MXLO_DEVICE_GUARD(g->ctx);
+  MXLO_HIP(hipGraphGetNodes(g->graph, nullptr, &nn));
+  info[0] = (int64_t)nn;
+  info[1] = g->chain.empty() ? 0 : 1;
   return MXLO_OK;
 }
 
@@ -212,6 +288,11 @@ MXLO_API int32_t mxlo_ctx_tune(mxlo_ctx *ctx, const char *key, int64_t value) {
     MXLO_REQUIRE(value >= 1 && value * ctx->num_cu <= kMaxRedBlocks, MXLO_EINVAL,
                  "red_blocks_per_cu out of range");
     ctx->tune.red_blocks_per_cu = (int)value;
+  } else if (!strcmp(key, "graph_direct_max")) {
+    MXLO_REQUIRE(value >= 0 && value <= 4096, MXLO_EINVAL, "graph_direct_max must be in 0..4096 (0: always hipGraphLaunch)");
+    ctx->tune.graph_direct_max = (int)value;
+  } else if (!strcmp(key, "house_fused")) {
+    ctx->tune.house_fused = value != 0;
   } else if (!strcmp(key, "house_reverse")) {
     ctx->tune.house_reverse = value != 0;
   } else if (!strcmp(key, "lbfgs_inv_mode")) {
@@ -222,6 +303,9 @@ MXLO_API int32_t mxlo_ctx_tune(mxlo_ctx *ctx, const char *key, int64_t value) {
     MXLO_REQUIRE(value == 0 || value == 32 || value == 64 || value == 128 || value == -1, MXLO_EINVAL,
                  "gemm_tile must be 0 (auto), 32, 64, 128 or -1 (generic kernel)");
     ctx->tune.gemm_tile = (int)value;
+  } else if (!strcmp(key, "extend_tiles_per_block")) {
+    MXLO_REQUIRE(value >= 0 && value <= 1024, MXLO_EINVAL, "extend_tiles_per_block must be in 0..1024 (0 = auto)");
+    ctx->tune.extend_tiles_per_block = (int)value;
   } else if (!strcmp(key, "fuse_finalize")) {
     MXLO_REQUIRE(value == 0 || value == 1, MXLO_EINVAL, "fuse_finalize must be 0 or 1");
     ctx->tune.fuse_finalize = (int)value;

@@ -22,6 +22,8 @@ namespace mxlo {
 constexpr int kBlock = 256;          // 4 waves of 64 lanes: one wave per SIMD of a CU
 constexpr int kWave = 64;
 constexpr int kMaxRedCols = 128;     // columns a single reduction call may produce
+constexpr int kFusedSlots = 256;     // workgroups of a single-launch (grid-exchange) kernel: all co-resident, <= #CUs
+constexpr unsigned long long kSlotEmpty = 0x7FF8DEADBEEF0001ull;   // a NaN payload no arithmetic produces (partials are canonicalised)
 constexpr int kMaxRedBlocks = 4096;  // partial slots per column in the workspace
 constexpr int kScalarSlots = 8192;   // doubles in the device scalar buffer
 
@@ -74,8 +76,11 @@ inline bool mxlo_trace_on() {
 
 struct Tune {
   int blocks_per_cu = 0;   // streaming kernels: 0 = one chunk per workgroup; k = persistent grid CUs*k
+  int extend_tiles_per_block = 0;     // sorted extension: consecutive output tiles per workgroup (0 = auto)
   int64_t nt_min_bytes = 32ll << 20;  // streamed footprint from which nontemporal accesses are used
   int red_blocks_per_cu = 4;  // reduction kernels
+  int graph_direct_max = 16; // captured chains of at most this many kernel/memset nodes replay as direct launches
+  int house_fused = 1;     // single-launch Householder (dot, grid exchange, update) while the vectors fit one wave of workgroups
   int house_reverse = 1;   // Householder phase B walks the vectors back-to-front (MALL tail reuse)
   int lbfgs_inv_mode = MXLO_INV_TWOPASS;
   int dots_max_nc = 20;    // columns per panel_dots launch (<= 20)
@@ -94,6 +99,7 @@ struct mxlo_ctx {
   double *partials = nullptr;  // [kMaxRedCols][kMaxRedBlocks] per-block partial sums
   double *scalars = nullptr;   // finalized reduction results / device-resident coefficients
   unsigned *ticket = nullptr;  // arrival counter of the fused (last-workgroup) finalize; zero between launches
+  unsigned long long *xslots = nullptr;  // [2][kFusedSlots] partial-exchange slots + epoch word of the single-launch Householder
   mxlo_allreduce_fn allreduce = nullptr;
   void *allreduce_user = nullptr;
   void *scratch = nullptr;     // grow-on-demand workspace (opHermitian tile partials); owned by the ctx

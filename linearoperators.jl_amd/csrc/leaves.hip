@@ -227,9 +227,143 @@ static int32_t householder_apply_t(mxlo_ctx *ctx, T *res, const T *h, const T *v
   });
 }
 
+// ---- single-launch opHouseholder for vectors that fit ONE wave of workgroups (n <= 2^20 doubles) ------------------------
+// Two dependent launches (dot, update) cost more than the data movement below ~1 MiB. Here every workgroup keeps its
+// slice of h and v in registers (read ONCE: 24 B/elt instead of 40), publishes its partial h'v into an exchange slot,
+// waits until all G <= 256 co-resident workgroups have published, sums the G partials in the same fixed order (every
+// workgroup obtains the bit-identical dot) and writes its slice of res.
+// The exchange uses no fence: each partial is ONE self-contained 64-bit agent-scope atomic store, an empty slot is a
+// NaN payload that arithmetic cannot produce, and readers poll with agent-scope loads (an agent-scope release fence
+// would write back the whole L2 of every XCD). Two slot sets alternate by an epoch bit kept in device memory (graph
+// replay safe): a launch uses set e, re-arms set 1-e for its successor, and workgroup 0 flips e after it has seen every
+// partial — by then every workgroup has read e.
+namespace {
+template <typename T, typename CA, typename CB, bool BETA0, int VPT, bool ALIGNED>
+__global__ void __launch_bounds__(kBlock)
+householder_fused_kernel(T *__restrict__ res, const T *__restrict__ h, const T *__restrict__ v, int64_t n, CA alpha,
+                         CB beta, unsigned long long *__restrict__ slots) {
+  constexpr int VEC = Vec16<T>::N;
+  using V = typename Vec16<T>::type;
+  const int tid = threadIdx.x, G = (int)gridDim.x, b = (int)blockIdx.x;
+  unsigned long long *epoch = slots + 2 * kFusedSlots;
+  const unsigned e = (unsigned)__hip_atomic_load(epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 1u;
+  unsigned long long *mine = slots + e * kFusedSlots, *other = slots + (1u - e) * kFusedSlots;
+  for (int i = b + tid * G; i < kFusedSlots; i += G * kBlock)          // re-arm the other set for the next launch
+    __hip_atomic_store(other + i, kSlotEmpty, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+
+  T hh[VPT][VEC], vv[VPT][VEC];
+  double acc = 0.0;
+  const int64_t base = (int64_t)b * kBlock * VPT * VEC;
+#pragma unroll
+  for (int q = 0; q < VPT; ++q) {
+    const int64_t i = base + ((int64_t)q * kBlock + tid) * VEC;
+    if (ALIGNED && i + VEC <= n) {
+      const V a = *reinterpret_cast<const V *>(h + i), c = *reinterpret_cast<const V *>(v + i);
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) { hh[q][k] = a[k]; vv[q][k] = c[k]; }
+    } else {
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) {
+        hh[q][k] = i + k < n ? h[i + k] : T(0);
+        vv[q][k] = i + k < n ? v[i + k] : T(0);
+      }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < VPT; ++q)
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) acc = fma((double)hh[q][k], (double)vv[q][k], acc);
+
+  __shared__ double lds[kBlock / 64];
+  const int wave = tid >> 6, lane = tid & 63;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+  if (lane == 0) lds[wave] = acc;
+  __syncthreads();
+  if (tid == 0) {
+    const double s = (lds[0] + lds[1]) + (lds[2] + lds[3]);
+    unsigned long long bits = (unsigned long long)__double_as_longlong(s);
+    if (s != s) bits = 0x7FF8000000000000ull;                        // canonical NaN: never the empty marker
+    __hip_atomic_store(mine + b, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  // wait for all G partials; lane t owns slot t (G <= 256 = one slot per lane)
+  double p = 0.0;
+  if (tid < G) {
+    unsigned long long bits;
+    while ((bits = __hip_atomic_load(mine + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == kSlotEmpty)
+      __builtin_amdgcn_s_sleep(1);
+    p = __longlong_as_double((long long)bits);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) p += __shfl_down(p, off, 64);
+  __syncthreads();                                                     // lds reuse
+  if (lane == 0) lds[wave] = p;
+  __syncthreads();
+  const double dot = (lds[0] + lds[1]) + (lds[2] + lds[3]);            // same order in every workgroup
+  if (b == 0 && tid == 0)
+    __hip_atomic_store(epoch, (unsigned long long)(1u - e), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+
+  HouseholderOp<T, CA, CB, BETA0> op{alpha, beta, nullptr, T(0)};
+  op.c = (T)2 * (T)dot;                                                // = HouseholderOp::init()
+#pragma unroll
+  for (int q = 0; q < VPT; ++q) {
+    const int64_t i = base + ((int64_t)q * kBlock + tid) * VEC;
+    if (ALIGNED && i + VEC <= n) {
+      V r;
+      if constexpr (!BETA0) r = *reinterpret_cast<const V *>(res + i);
+      V o;
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) o[k] = op(hh[q][k], vv[q][k], BETA0 ? T(0) : r[k]);
+      *reinterpret_cast<V *>(res + i) = o;
+    } else {
+#pragma unroll
+      for (int k = 0; k < VEC; ++k)
+        if (i + k < n) res[i + k] = op(hh[q][k], vv[q][k], BETA0 ? T(0) : res[i + k]);
+    }
+  }
+}
+}  // namespace
+
+// workgroups the fused kernel would need with VPT vectors per lane
+template <typename T>
+static inline int64_t fused_grid(int64_t n, int vpt) {
+  const int64_t per = (int64_t)kBlock * vpt * Vec16<T>::N;
+  return (n + per - 1) / per;
+}
+
+template <typename T>
+static int32_t householder_fused_t(mxlo_ctx *ctx, T *res, const T *h, const T *v, int64_t n, double alpha, double beta,
+                                   int32_t flags, int vpt) {
+  const bool aligned = ((((uintptr_t)res) | ((uintptr_t)h) | ((uintptr_t)v)) & 15u) == 0;
+  const int grid = (int)fused_grid<T>(n, vpt);
+  return dispatch_ab<T>(beta, flags, [&]<typename CA, typename CB, bool B0>() -> int32_t {
+    auto go = [&]<int VPT, bool AL>() {
+      hipLaunchKernelGGL((householder_fused_kernel<T, CA, CB, B0, VPT, AL>), dim3(grid), dim3(kBlock), 0, ctx->stream,
+                         res, h, v, n, (CA)alpha, (CB)beta, ctx->xslots);
+    };
+    if (aligned) {
+      if (vpt == 2) go.template operator()<2, true>();
+      else if (vpt == 4) go.template operator()<4, true>();
+      else go.template operator()<8, true>();
+    } else {
+      if (vpt == 2) go.template operator()<2, false>();
+      else if (vpt == 4) go.template operator()<4, false>();
+      else go.template operator()<8, false>();
+    }
+    MXLO_LAUNCH_CHECK();
+    return MXLO_OK;
+  });
+}
+
 template <typename T>
 static int32_t householder_t(mxlo_ctx *ctx, T *res, const T *h, const T *v, int64_t n,
                              double alpha, double beta, int32_t flags) {
+  // single launch: no all-reduce hook (its host callback sits between the two passes), every workgroup co-resident
+  if (ctx->tune.house_fused && !ctx->allreduce && n > 0) {
+    const int64_t cap = std::min<int64_t>(ctx->num_cu, kFusedSlots);
+    const int vpt = fused_grid<T>(n, 2) <= 16 ? 2 : (fused_grid<T>(n, 4) <= 32 ? 4 : 8);
+    if (fused_grid<T>(n, vpt) <= cap) return householder_fused_t<T>(ctx, res, h, v, n, alpha, beta, flags, vpt);
+  }
   double *dot = ctx->scalars;  // slot 0
   const T *cols[1] = {h};
   MXLO_TRY(panel_dots<T>(ctx, cols, 1, v, n, dot));  // phase A (+ all-reduce hook)
@@ -465,31 +599,39 @@ __device__ __forceinline__ int64_t wave_lower_bound(const int64_t *__restrict__ 
 template <typename E, int TILE_BYTES>
 __global__ void __launch_bounds__(kBlock)
 extend_sorted_kernel(E *__restrict__ res, int64_t nres, const E *__restrict__ u, const int64_t *__restrict__ idx,
-                     const int64_t *__restrict__ pos, int64_t nidx, int64_t ntiles, int32_t res_aligned) {
+                     const int64_t *__restrict__ pos, int64_t nidx, int64_t ntiles, int32_t tiles_per_block,
+                     int32_t res_aligned) {
   constexpr int TILE = TILE_BYTES / (int)sizeof(E);
   typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
   __shared__ u32x4 smem[TILE_BYTES / 16];
   __shared__ int64_t bounds[2];
   E *tile = reinterpret_cast<E *>(smem);
   const int tid = threadIdx.x;
-  for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+  const int64_t tb = (int64_t)blockIdx.x * tiles_per_block;
+  const int64_t te = tb + tiles_per_block < ntiles ? tb + tiles_per_block : ntiles;
+  const u32x4 z = {0u, 0u, 0u, 0u};
+  int64_t s = 0;
+  for (int64_t t = tb; t < te; ++t) {
     const int64_t t0 = t * TILE, t1 = t0 + TILE < nres ? t0 + TILE : nres;   // outputs [t0, t1); entry k is inside iff t0 < idx[k] <= t1
     if (tid < 64) {
-      const int64_t s = wave_lower_bound(idx, 0, nidx, t0 + 1, tid);
-      const int64_t cap = s + TILE < nidx ? s + TILE : nidx;                  // strictly increasing: at most TILE entries per tile
+      // ONE full search per workgroup; the following tiles start where the previous one ended. The end is bracketed:
+      // strictly increasing indices put at most TILE entries into a tile (2 probe rounds, no over-read of the plan).
+      if (t == tb) s = wave_lower_bound(idx, 0, nidx, t0 + 1, tid);
+      const int64_t cap = s + TILE < nidx ? s + TILE : nidx;
       const int64_t e = wave_lower_bound(idx, s, cap, t1 + 1, tid);
       if (tid == 0) { bounds[0] = s; bounds[1] = e; }
     }
-    const u32x4 z = {0u, 0u, 0u, 0u};
 #pragma unroll
     for (int w = tid; w < TILE_BYTES / 16; w += kBlock) smem[w] = z;
     __syncthreads();
-    const int64_t s = bounds[0], e = bounds[1];
+    s = bounds[0];
+    const int64_t e = bounds[1];
     for (int64_t k = s + tid; k < e; k += kBlock) {
       const int64_t j = idx[k] - 1 - t0;
       const E val = u[pos ? pos[k] : k];
       if (j >= 0 && j < t1 - t0) tile[j] = val;
     }
+    s = e;
     __syncthreads();
     const int64_t nbytes = (t1 - t0) * (int64_t)sizeof(E);
     if (res_aligned) {                       // t0 * sizeof(E) is a multiple of 16 (TILE_BYTES is): vectors stay aligned
@@ -602,9 +744,13 @@ MXLO_API int32_t mxlo_scatter_zero_sorted(mxlo_ctx *ctx, int32_t elem_size, void
   return by_elem_size(elem_size, [&]<typename E>() -> int32_t {
     constexpr int TB = 16384;
     const int64_t ntiles = (nres * (int64_t)sizeof(E) + TB - 1) / TB;
-    const int grid = (int)std::min<int64_t>(ntiles, 0x7fffffffLL);
-    hipLaunchKernelGGL((extend_sorted_kernel<E, TB>), dim3(grid), dim3(kBlock), 0, ctx->stream, (E *)res, nres,
-                       (const E *)u, idx, pos, nidx, ntiles, (int32_t)((((uintptr_t)res) & 15u) == 0));
+    // consecutive tiles per workgroup (one plan search per workgroup), keeping >= ~32 workgroups per CU for balance
+    int64_t tpb = ctx->tune.extend_tiles_per_block > 0 ? ctx->tune.extend_tiles_per_block
+                                                       : std::clamp<int64_t>(ntiles / ((int64_t)ctx->num_cu * 32), 1, 4);
+    const int64_t nblocks = (ntiles + tpb - 1) / tpb;
+    MXLO_REQUIRE(nblocks <= 0x7fffffffLL, MXLO_ESHAPE, "mxlo_scatter_zero_sorted: res too long");
+    hipLaunchKernelGGL((extend_sorted_kernel<E, TB>), dim3((unsigned)nblocks), dim3(kBlock), 0, ctx->stream, (E *)res, nres,
+                       (const E *)u, idx, pos, nidx, ntiles, (int32_t)tpb, (int32_t)((((uintptr_t)res) & 15u) == 0));
     MXLO_LAUNCH_CHECK();
     return MXLO_OK;
   });

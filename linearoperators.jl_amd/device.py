@@ -60,14 +60,14 @@ class Context:
         self.index = index
         self.handle = C.c_void_p()
         with torch.cuda.device(index):
-            self._stream = torch.cuda.current_stream(index).cuda_stream
+            self._stream = _raw_stream(index)
             _lib.call("mxlo_ctx_create", index, C.c_void_p(self._stream), C.byref(self.handle))
         self._hook = None  # keep the CFUNCTYPE object alive
 
     def bind_stream(self):
-        # fast path: the (legacy) default stream has handle 0 and is what torch uses unless the caller
-        # entered a `torch.cuda.stream(...)` context
-        s = torch.cuda.current_stream(self.index).cuda_stream
+        # kernels run on torch's CURRENT stream of this device; the raw-handle query is ~10x cheaper than building a
+        # torch.cuda.Stream object per apply (this runs on every mul!)
+        s = _raw_stream(self.index)
         if s != self._stream:
             _lib.call("mxlo_ctx_set_stream", self.handle, C.c_void_p(s))
             self._stream = s
@@ -101,15 +101,26 @@ class Context:
 
 
 _ctxs: dict[int, Context] = {}
+_available = None
+
+try:                                                   # raw hipStream_t of torch's current stream (no Stream object)
+    _raw_stream = torch._C._cuda_getCurrentRawStream
+except AttributeError:                                 # pragma: no cover
+    def _raw_stream(index: int) -> int:
+        return torch.cuda.current_stream(index).cuda_stream
 
 
 def get_ctx(device=None) -> Context:
-    if not torch.cuda.is_available():
+    global _available
+    if _available is None:
+        _available = torch.cuda.is_available()
+    if not _available:
         raise RuntimeError("no HIP device visible: the MI355X path has no CPU fallback")
     if device is None:
         idx = torch.cuda.current_device()
     else:
-        device = torch.device(device)
+        if not isinstance(device, torch.device):
+            device = torch.device(device)
         if device.type != "cuda":
             raise RuntimeError(f"operands must live on a GPU, got {device}: there is no CPU fallback")
         idx = device.index if device.index is not None else torch.cuda.current_device()

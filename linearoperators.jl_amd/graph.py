@@ -54,7 +54,8 @@ class CapturedSequence:
         return False
 
     def replay(self, sync_streams: bool = True):
-        """One hipGraphLaunch. sync_streams: order the replay after the caller's stream and the caller's
+        """One replay (mxlo_graph_launch: the recorded launches re-issued directly for short chains, hipGraphLaunch
+        otherwise). sync_streams: order the replay after the caller's stream and the caller's
         stream after the replay (two event waits, no host sync); pass False inside a loop that lives
         entirely on `self.stream`."""
         if not self._g:
@@ -68,6 +69,12 @@ class CapturedSequence:
             cur = torch.cuda.current_stream(self.device)
             if cur != self.stream:
                 cur.wait_stream(self.stream)
+
+    def info(self):
+        """{"nodes": recorded launches, "direct": replay re-issues them one by one instead of hipGraphLaunch}"""
+        a = (C.c_int64 * 2)()
+        _lib.call("mxlo_graph_info", self._g, a)
+        return {"nodes": int(a[0]), "direct": bool(a[1])}
 
     def __del__(self):
         try:

@@ -198,3 +198,58 @@ def test_alternating_streams_share_the_ctx_workspaces_safely(lo, dev):
     for i in range(2):
         for rep in range(6):
             assert torch.equal(outs[i][rep], want[i]), (i, rep)
+
+
+def test_graph_replay_direct_chain_equals_hipgraph_launch(lo, dev):
+    """Short captured chains replay as direct launches of the recorded nodes (mxlo_graph_info[1] == 1); forcing
+    hipGraphLaunch (tune graph_direct_max = 0) must give bit-identical results, for a kernel-only chain, a chain with a
+    memset node (index extension through the ABI's memset + scatter entry point) and a quasi-Newton apply."""
+    import ctypes as C
+    from linearoperators_jl_amd.device import get_ctx, ptr
+    ctx = lo.get_ctx(dev)
+    rng = np.random.default_rng(5)
+    n = 50_000
+    h = rng.standard_normal(n); h /= np.linalg.norm(h)
+    d = rng.standard_normal(n)
+    ht, dt_ = torch.from_numpy(h).to(dev), torch.from_numpy(d).to(dev)
+    B = lo.LBFGSOperator(n, mem=4, device=dev)
+    for _ in range(5):
+        s = rng.uniform(-1, 1, n)
+        lo.push(B, torch.from_numpy(s).to(dev), torch.from_numpy(s * rng.uniform(0.5, 2, n)).to(dev))
+    op = lo.opHouseholder(ht) * lo.opDiagonal(dt_) + B
+    v = torch.from_numpy(rng.uniform(-1, 1, n)).to(dev)
+    outs = []
+    for direct_max in (16, 0):
+        ctx.tune("graph_direct_max", direct_max)
+        try:
+            res = torch.from_numpy(np.full(n, 0.5)).to(dev)
+            g = lo.capture_mul(res, op, v, 2.0, -3.0)
+            inf = g.info()
+            assert inf["nodes"] >= 3 and inf["direct"] == (direct_max > 0 and inf["nodes"] <= 16), inf
+            for _ in range(3):
+                g.replay()
+            torch.cuda.synchronize()
+            outs.append(res.cpu().numpy().copy())
+        finally:
+            ctx.tune("graph_direct_max", 16)
+    assert np.array_equal(outs[0], outs[1])
+    # memset node: mxlo_scatter_zero = hipMemsetAsync + scatter kernel
+    idx = torch.from_numpy(np.sort(rng.choice(n, 1000, replace=False) + 1).astype(np.int64)).to(dev)
+    u = torch.from_numpy(rng.standard_normal(1000)).to(dev)
+    outs = []
+    for direct_max in (16, 0):
+        ctx.tune("graph_direct_max", direct_max)
+        try:
+            res = torch.full((n,), 7.0, dtype=torch.float64, device=dev)
+            with lo.CapturedSequence(dev) as g:
+                c = get_ctx(dev)
+                lo._lib.call("mxlo_scatter_zero", c.handle, 8, ptr(res), n, ptr(u), ptr(idx), None, 1000)
+            assert g.info()["direct"] == (direct_max > 0)
+            res.fill_(7.0)
+            g.replay()
+            torch.cuda.synchronize()
+            outs.append(res.cpu().numpy().copy())
+        finally:
+            ctx.tune("graph_direct_max", 16)
+    want = np.zeros(n); want[idx.cpu().numpy() - 1] = u.cpu().numpy()
+    assert np.array_equal(outs[0], want) and np.array_equal(outs[1], want)

@@ -445,3 +445,55 @@ def test_sorted_extension_and_range_kernels_bit_exact_edge_shapes(lo, dev, es):
             assert np.array_equal(got, want), ("extend", a, b, s, off)
             guard = rbuf.cpu().numpy()
             assert not guard[:off * words].any() and not guard[(off + n) * words:].any()
+
+
+def test_single_launch_householder_matches_two_pass_and_oracle(lo, dev):
+    """n <= 2^20 doubles runs ONE kernel (register-resident slices + slot exchange between workgroups). Checked against the
+    oracle (1e-12 / 1e-5) and against the two-launch path (tune house_fused = 0): alternating grid sizes (slot re-arming,
+    epoch flips), unaligned views, beta != 0, mixed-precision scalars, NaN partials, graph replay."""
+    ctx = lo.get_ctx(dev)
+    rng = np.random.default_rng(77)
+    sizes = [1, 2, 3, 255, 1024, 1025, 65_536, 4097, 1 << 20, 1000, (1 << 20) + 1, 300_001, 17]
+    for dtype, tol in ((torch.float64, 1e-12), (torch.float32, 2e-5)):
+        for n in sizes:
+            for off in (0, 1):
+                h = rng.standard_normal(n + off).astype(NP[dtype])[off:]
+                h /= np.linalg.norm(h.astype(np.float64)) or 1.0
+                v = rng.uniform(-1, 1, n + off).astype(NP[dtype])[off:]
+                r0 = rng.uniform(-1, 1, n + off).astype(NP[dtype])[off:]
+                hb, vb, rb = (torch.from_numpy(np.concatenate([np.zeros(off, x.dtype), x])).to(dev) for x in (h, v, r0))
+                ht, vt = hb[off:], vb[off:]
+                H = lo.opHouseholder(ht)
+                for alpha, beta in ((1.0, 0.0), (2.0, -3.0), (np.float32(0.5), 0.25)):
+                    res = rb.clone()[off:]
+                    lo.mul(res, H, vt, alpha, beta)
+                    fl = oracle.scalar_flags(NP[dtype], alpha, beta)
+                    want = oracle.householder_mul(r0.copy(), h, v, float(alpha), float(beta), flags=fl)
+                    assert rel(res.cpu().numpy(), want) <= tol, (dtype, n, off, alpha, beta)
+                    ctx.tune("house_fused", 0)
+                    try:
+                        res2 = rb.clone()[off:]
+                        lo.mul(res2, H, vt, alpha, beta)
+                    finally:
+                        ctx.tune("house_fused", 1)
+                    assert rel(res.cpu().numpy(), res2.cpu().numpy()) <= tol
+    # a NaN in v poisons the dot: every element becomes NaN (and the exchange does not hang on a NaN partial)
+    n = 70_000
+    h = torch.full((n,), 1.0 / np.sqrt(n), dtype=torch.float64, device=dev)
+    v = torch.ones(n, dtype=torch.float64, device=dev)
+    v[12345] = float("nan")
+    out = lo.opHouseholder(h) * v
+    assert bool(torch.isnan(out).all())
+    v[12345] = 1.0
+    out = lo.opHouseholder(h) * v                                       # slots are clean again
+    assert rel(out.cpu().numpy(), oracle.householder_mul(np.empty(n), h.cpu().numpy(), v.cpu().numpy(), 1.0, 0.0)) <= 1e-12
+    # graph replay: the epoch lives in device memory, so one captured launch can be replayed any number of times
+    res = torch.empty(n, dtype=torch.float64, device=dev)
+    g = lo.capture_mul(res, lo.opHouseholder(h), v, 1.0, 0.0)
+    for k in range(5):
+        v.mul_(1.0 + 0.1 * k)
+        torch.cuda.synchronize()
+        g.replay()
+        torch.cuda.synchronize()
+        want = oracle.householder_mul(np.empty(n), h.cpu().numpy(), v.cpu().numpy(), 1.0, 0.0)
+        assert rel(res.cpu().numpy(), want) <= 1e-12, k

@@ -17,6 +17,14 @@ ctx = get_ctx(dev)
 tm = Timer(ctx)
 gen = torch.Generator(device=dev).manual_seed(1)
 PEAK = 8000.0
+ONLY = set(a for a in sys.argv[1:] if not a.startswith("-"))
+SECTIONS = ("leaves", "small", "restrict", "complex", "dense", "kron", "qn", "variants", "cpu", "cfg5", "graph")
+assert ONLY <= set(SECTIONS), f"sections: {SECTIONS}"
+
+
+def sec(name):
+    """python tools/bench_all.py [section ...] — no argument runs every section"""
+    return not ONLY or name in ONLY
 
 
 def timeit(fn, reps=20):
@@ -39,6 +47,8 @@ def rnd(n, dt=torch.float64):
 
 
 for dt, es in ((torch.float64, 8), (torch.float32, 4)):
+    if not sec("leaves"):
+        break
     n = 100_000_000
     d, v, res = rnd(n, dt) + 1.5, rnd(n, dt), rnd(n, dt)
     D = lo.opDiagonal(d)
@@ -50,13 +60,26 @@ for dt, es in ((torch.float64, 8), (torch.float32, 4)):
     row(f"opHouseholder mul! b!=0 n=1e8 {dt}", 6 * es * n, timeit(lambda: lo.mul(res, H, v, 2.0, -3.0)))
     E = lo.opEye(dt, n, S=lo.Storage(dt, dev))
     row(f"opEye mul! (axpby) b!=0 n=1e8 {dt}", 3 * es * n, timeit(lambda: lo.mul(res, E, v, 2.0, -3.0)))
-    del D, H, E, d, h
+    del D, H, E, d, h, v, res
+    torch.cuda.empty_cache()
+
+for dt, es in ((torch.float64, 8), (torch.float32, 4)):
+    if not sec("small"):
+        break
     for small in (1 << 20, 1 << 16):
         ds, vs, rs = rnd(small, dt), rnd(small, dt), rnd(small, dt)
         Ds, Hs = lo.opDiagonal(ds), lo.opHouseholder(ds)
         row(f"opDiagonal mul! n=2^{small.bit_length()-1} {dt} (latency regime)", 3 * es * small, timeit(lambda: lo.mul(rs, Ds, vs, 1.0, 0.0), 200))
-        row(f"opHouseholder mul! n=2^{small.bit_length()-1} {dt} (3 launches)", 5 * es * small, timeit(lambda: lo.mul(rs, Hs, vs, 1.0, 0.0), 200))
-    # restriction / extension
+        row(f"opHouseholder mul! n=2^{small.bit_length()-1} {dt}", 5 * es * small, timeit(lambda: lo.mul(rs, Hs, vs, 1.0, 0.0), 200))
+
+# restriction / extension. Algorithmic bytes: restriction = idx (8) + v[idx] (es) + res (es) per index; extension = idx (8)
+# + pos (8, plans with duplicates) + u (es) per SURVIVING index + one write of res (es * n). (Round 1 also charged the extension a second write of the
+# touched slots — memset THEN scatter — which the segment-owner kernel no longer performs.)
+for dt, es in ((torch.float64, 8), (torch.float32, 4)):
+    if not sec("restrict"):
+        break
+    n = 100_000_000
+    v, res = rnd(n, dt), rnd(n, dt)
     nidx = 50_000_000
     idx_sorted = torch.sort(torch.randint(1, n + 1, (nidx,), device=dev, generator=gen)).values.cpu().numpy()
     idx_rand = torch.randint(1, n + 1, (nidx,), device=dev, generator=gen).cpu().numpy()
@@ -64,18 +87,40 @@ for dt, es in ((torch.float64, 8), (torch.float32, 4)):
     for nm, idx in (("sorted", idx_sorted), ("random", idx_rand)):
         P = lo.opRestriction(idx, n, device=dev)
         row(f"opRestriction {nm} idx nidx=5e7 of 1e8 {dt}", (8 + 2 * es) * nidx, timeit(lambda: lo.mul(out, P, v), 5))
-        row(f"opExtension  {nm} idx nidx=5e7 of 1e8 {dt}", (8 + 2 * es) * nidx + es * n, timeit(lambda: lo.mul(res, P.H, out), 5))
+        nu = np.unique(idx).size
+        # the plan of an index list with duplicates carries pos (8 B per surviving entry): where in u the last write is
+        row(f"opExtension  {nm} idx nidx=5e7 ({nu/1e6:.1f}e6 distinct) of 1e8 {dt}", (16 + es) * nu + es * n, timeit(lambda: lo.mul(res, P.H, out), 5))
         del P
     R = lo.opRestriction(lo.jrange(1, n, 2), n, device=dev)
-    row(f"opRestriction 1:2:n {dt}", 2 * es * nidx, timeit(lambda: lo.mul(out, R, v), 5), "(reads touch every line: 3x)")
+    ms_ = timeit(lambda: lo.mul(out, R, v), 5)
+    row(f"opRestriction 1:2:n {dt}", 2 * es * nidx, ms_, f"(every line of v is touched: {3 * es * nidx / ms_ / 1e6:.0f} GB/s = {3 * es * nidx / ms_ / 1e6 / PEAK:.3f} moved)")
     row(f"opExtension  1:2:n {dt}", es * nidx + es * n, timeit(lambda: lo.mul(res, R.H, out), 5))
     R = lo.opRestriction(lo.jrange(1000, 1000 + nidx - 1), n, device=dev)
     row(f"opRestriction UnitRange len=5e7 {dt}", 2 * es * nidx, timeit(lambda: lo.mul(out, R, v), 5))
     del R, out, v, res
     torch.cuda.empty_cache()
 
+# complex elementwise leaves (ComplexF64: 16 B/elt; same 2.4 GB as the real n = 1e8 row)
+if sec("complex"):
+    for cdt, es in ((torch.complex128, 16), (torch.complex64, 8)):
+        n = 50_000_000
+        rdt = torch.float64 if cdt == torch.complex128 else torch.float32
+        mk = lambda: torch.complex(rnd(n, rdt), rnd(n, rdt))
+        d, v, res = mk(), mk(), mk()
+        D = lo.opDiagonal(d)
+        row(f"opDiagonal mul! b=0 n=5e7 {cdt}", 3 * es * n, timeit(lambda: lo.mul(res, D, v, 1.0, 0.0)))
+        row(f"opDiagonal mul! complex a,b n=5e7 {cdt}", 4 * es * n, timeit(lambda: lo.mul(res, D, v, 2.0 - 1.0j, -3.0 + 0.5j)))
+        row(f"opDiagonal' mul! (conj(d) in-kernel) n=5e7 {cdt}", 3 * es * n, timeit(lambda: lo.mul(res, D.H, v, 1.0, 0.0)))
+        h = d / torch.linalg.vector_norm(d)
+        H = lo.opHouseholder(h)
+        row(f"opHouseholder mul! b=0 n=5e7 {cdt}", 5 * es * n, timeit(lambda: lo.mul(res, H, v, 1.0, 0.0)))
+        del D, H, d, v, res, h
+        torch.cuda.empty_cache()
+
 # dense / hermitian (f64)
 for nn in (4096, 16384):
+    if not sec("dense"):
+        break
     M = torch.rand(nn, nn, dtype=torch.float64, device=dev, generator=gen).t()
     op = lo.LinearOperatorFromMatrix(M)
     x, y = rnd(nn), rnd(nn)
@@ -86,9 +131,29 @@ for nn in (4096, 16384):
     del M, op, Hm
     torch.cuda.empty_cache()
 
+# kron: two f64 / f32 MFMA GEMMs per apply (4 m^3 flop for m x m (x) m x m)
+if sec("kron"):
+    PEAK_TF = {torch.float64: 78.6, torch.float32: 157.3}
+    for kdt in (torch.float64, torch.float32):
+        for sz in (512, 1000, 1024, 2048):
+            A = ((torch.rand(sz, sz, dtype=kdt, device=dev, generator=gen) - 0.5) / 32).t()
+            B = ((torch.rand(sz, sz, dtype=kdt, device=dev, generator=gen) - 0.5) / 32).t()
+            K = lo.kron(A, B)
+            x, y = rnd(sz * sz, kdt), torch.empty(sz * sz, dtype=kdt, device=dev)
+            best = min(timeit(lambda: lo.mul(y, K, x, 1.0, 0.0), 30) for _ in range(3))
+            tf = 4.0 * sz ** 3 / best / 1e9
+            print(f"kron {sz}x{sz} (x) {sz}x{sz} {kdt} mul!{'':20s} {best*1e3:10.1f} us {tf:8.1f} TF    {tf/PEAK_TF[kdt]:5.3f} of MFMA peak", flush=True)
+            if sz == 1024:
+                bestt = min(timeit(lambda: lo.mul(y, K.T, x, 1.0, 0.0), 30) for _ in range(3))
+                print(f"kron {sz}x{sz} transpose mul! {kdt}{'':23s} {bestt*1e3:10.1f} us {4.0*sz**3/bestt/1e9:8.1f} TF", flush=True)
+            del A, B, K, x, y
+    torch.cuda.empty_cache()
+
 # quasi-Newton push! and solve (n = 5e7)
 n = 50_000_000
 for kind, m in (("inv", 10), ("fwd", 10), ("fwd", 20), ("lsr1", 10)):
+    if not sec("qn"):
+        break
     op = {"inv": lo.InverseLBFGSOperator, "fwd": lo.LBFGSOperator, "lsr1": lo.LSR1Operator}[kind](torch.float64, n, mem=m, device=dev)
     S = [rnd(n) for _ in range(2)]
     Y = [(torch.rand(n, dtype=torch.float64, device=dev, generator=gen) * 1.5 + 0.5) * s for s in S]
@@ -120,104 +185,114 @@ for kind, m in (("inv", 10), ("fwd", 10), ("fwd", 20), ("lsr1", 10)):
     torch.cuda.empty_cache()
 
 # ---- cfg3 both variants: reference-ordered two-loop next to the default two-pass form
-opi = lo.InverseLBFGSOperator(torch.float64, n, mem=10, device=dev)
-for i in range(11):
-    s_ = rnd(n)
-    lo.push(opi, s_, s_ * (rnd(n) * 0.5 + 1.25))
-    del s_
-x, out = rnd(n), torch.empty(n, dtype=torch.float64, device=dev)
-for mode, bpe in (("twopass", 344.0), ("reforder", 648.0)):
-    opi.set_mode(mode)
-    row(f"mul! inv m=10 n=5e7, {mode} form ({bpe:.0f} B/elt moved)", bpe * n, timeit(lambda: lo.mul(out, opi, x, 1.0, 0.0), 5))
-del opi, x, out
-torch.cuda.empty_cache()
+if sec("variants"):
+    opi = lo.InverseLBFGSOperator(torch.float64, n, mem=10, device=dev)
+    for i in range(11):
+        s_ = rnd(n)
+        lo.push(opi, s_, s_ * (rnd(n) * 0.5 + 1.25))
+        del s_
+    x, out = rnd(n), torch.empty(n, dtype=torch.float64, device=dev)
+    for mode, bpe in (("twopass", 344.0), ("reforder", 648.0)):
+        opi.set_mode(mode)
+        row(f"mul! inv m=10 n=5e7, {mode} form ({bpe:.0f} B/elt moved)", bpe * n, timeit(lambda: lo.mul(out, opi, x, 1.0, 0.0), 5))
+    del opi, x, out
+    torch.cuda.empty_cache()
 
 # ---- CPU beside cfg4's kron: the oracle's reference-literal form (m unit-vector applies, src/kron.jl:17-18 through
 # Matrix(B*X*A')), one thread
-import time
-import oracle
-rngk = np.random.default_rng(0)
-Ak, Bk = (rngk.random((1024, 1024)) - 0.5) / 32, (rngk.random((1024, 1024)) - 0.5) / 32
-xk = rngk.random(1024 * 1024)
-t0 = time.perf_counter()
-oracle.kron_mul(np.empty(1024 * 1024), Ak, Bk, xk, 1.0, 0.0)
-tk = time.perf_counter() - t0
-print(f"CPU oracle kron 1024^2 (reference-literal: 1024 x (X*w, B*u) GEMV pairs, 1 thread): {tk:.2f} s = {4 * 1024**3 / tk / 1e9:.2f} GFLOP/s", flush=True)
-
-# ---- CPU beside cfg3 / cfg5: the oracle's statement-by-statement two-loop / forward recursion, 1 thread, at n/10
-# (memory-bound: scales linearly; the full size needs 8-16 GB of panels on the host and ~4-8 s per apply)
-nc = 5_000_000
-for kindc, mc in (("inverse", 10), ("forward", 20)):
-    Oc = oracle.LBFGS(nc, mem=mc, inverse=(kindc == "inverse"))
-    rc = np.random.default_rng(1)
-    for _ in range(mc + 1):
-        sc = rc.uniform(-1, 1, nc)
-        Oc.push(sc, sc * rc.uniform(0.5, 2.0, nc))
-    xc, outc = rc.uniform(-1, 1, nc), np.empty(nc)
-    Oc.mul(outc, xc)
+if sec("cpu"):
+    import time
+    import oracle
+    rngk = np.random.default_rng(0)
+    Ak, Bk = (rngk.random((1024, 1024)) - 0.5) / 32, (rngk.random((1024, 1024)) - 0.5) / 32
+    xk = rngk.random(1024 * 1024)
     t0 = time.perf_counter()
-    Oc.mul(outc, xc)
-    tc = time.perf_counter() - t0
-    print(f"CPU oracle {kindc} L-BFGS m={mc} n=5e6 (reference statement order, 1 thread): {tc * 1e3:.0f} ms/apply -> "
-          f"~{1.0 / (tc * 10):.2f} apply/s at n=5e7", flush=True)
-    del Oc
+    oracle.kron_mul(np.empty(1024 * 1024), Ak, Bk, xk, 1.0, 0.0)
+    tk = time.perf_counter() - t0
+    print(f"CPU oracle kron 1024^2 (reference-literal: 1024 x (X*w, B*u) GEMV pairs, 1 thread): {tk:.2f} s = {4 * 1024**3 / tk / 1e9:.2f} GFLOP/s", flush=True)
+
+    # ---- CPU beside cfg3 / cfg5: the oracle's statement-by-statement two-loop / forward recursion, 1 thread, at n/10
+    # (memory-bound: scales linearly; the full size needs 8-16 GB of panels on the host and ~4-8 s per apply)
+    nc = 5_000_000
+    for kindc, mc in (("inverse", 10), ("forward", 20)):
+        Oc = oracle.LBFGS(nc, mem=mc, inverse=(kindc == "inverse"))
+        rc = np.random.default_rng(1)
+        for _ in range(mc + 1):
+            sc = rc.uniform(-1, 1, nc)
+            Oc.push(sc, sc * rc.uniform(0.5, 2.0, nc))
+        xc, outc = rc.uniform(-1, 1, nc), np.empty(nc)
+        Oc.mul(outc, xc)
+        t0 = time.perf_counter()
+        Oc.mul(outc, xc)
+        tc = time.perf_counter() - t0
+        print(f"CPU oracle {kindc} L-BFGS m={mc} n=5e6 (reference statement order, 1 thread): {tc * 1e3:.0f} ms/apply -> "
+              f"~{1.0 / (tc * 10):.2f} apply/s at n=5e7", flush=True)
+        del Oc
 
 # ---- cfg5's single-GPU leg: forward L-BFGS m = 20 at the FULL n = 4e8 on one GPU (three 64 GB panels: S, Y, B;
 # the a_k panel is never allocated in the compact form, the reference's n x 2m shifted_p never exists)
-torch.cuda.empty_cache()
-free_b, _ = torch.cuda.mem_get_info(dev)
-print(f"free HBM before the n = 4e8 leg: {free_b / 2**30:.0f} GiB", flush=True)
-if free_b > 215 * (1 << 30):
-    nbig, m = 400_000_000, 20
-    op = lo.LBFGSOperator(torch.float64, nbig, mem=m, device=dev)
-    s_ = rnd(nbig)
-    y_ = s_ * 1.25
-    import time
-    for i in range(m + 1):
-        s_.mul_(1.0 + 1e-3 * i)            # distinct pairs without extra 3.2 GB temporaries
-        y_.copy_(s_).mul_(1.25 + 0.01 * i)
-        lo.push(op, s_, y_)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    lo.push(op, s_, y_)
-    torch.cuda.synchronize()
-    push_ms = (time.perf_counter() - t0) * 1e3
-    x, out = rnd(nbig), torch.empty(nbig, dtype=torch.float64, device=dev)
-    ms = timeit(lambda: lo.mul(out, op, x, 1.0, 0.0), 3)
-    used = (torch.cuda.mem_get_info(dev)[1] - torch.cuda.mem_get_info(dev)[0]) / 2**30
-    row(f"mul! fwd m=20 n=4e8 on ONE GPU (cfg5 single-GPU leg; {used:.0f} GiB in use)", (4 * m + 3) * 8.0 * nbig, ms,
-        f" push! {push_ms:.1f} ms")
-    del op, s_, y_, x, out
+if sec("cfg5"):
     torch.cuda.empty_cache()
+    free_b, _ = torch.cuda.mem_get_info(dev)
+    print(f"free HBM before the n = 4e8 leg: {free_b / 2**30:.0f} GiB", flush=True)
+    if free_b > 215 * (1 << 30):
+        nbig, m = 400_000_000, 20
+        op = lo.LBFGSOperator(torch.float64, nbig, mem=m, device=dev)
+        s_ = rnd(nbig)
+        y_ = s_ * 1.25
+        import time
+        for i in range(m + 1):
+            s_.mul_(1.0 + 1e-3 * i)            # distinct pairs without extra 3.2 GB temporaries
+            y_.copy_(s_).mul_(1.25 + 0.01 * i)
+            lo.push(op, s_, y_)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        lo.push(op, s_, y_)
+        torch.cuda.synchronize()
+        push_ms = (time.perf_counter() - t0) * 1e3
+        x, out = rnd(nbig), torch.empty(nbig, dtype=torch.float64, device=dev)
+        ms = timeit(lambda: lo.mul(out, op, x, 1.0, 0.0), 3)
+        used = (torch.cuda.mem_get_info(dev)[1] - torch.cuda.mem_get_info(dev)[0]) / 2**30
+        row(f"mul! fwd m=20 n=4e8 on ONE GPU (cfg5 single-GPU leg; {used:.0f} GiB in use)", (4 * m + 3) * 8.0 * nbig, ms,
+            f" push! {push_ms:.1f} ms")
+        del op, s_, y_, x, out
+        torch.cuda.empty_cache()
 
 # ---- launch-bound regime: eager host-mirror calls vs ONE hipGraph replay (wall clock, includes the host side)
-import time
+if sec("graph"):
+    import time
 
 
-def wall(fn, sync, reps=2000):
-    for _ in range(20):
-        fn()
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        fn()
-    sync()
-    return (time.perf_counter() - t0) / reps * 1e6
+    def wall(fn, sync, reps=2000):
+        for _ in range(20):
+            fn()
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        sync()
+        return (time.perf_counter() - t0) / reps * 1e6
 
 
-print("\nlaunch-bound regime (fp64): us per apply, eager mul! vs hipGraph replay (mxlo_graph_launch)")
-for small in (1 << 12, 1 << 16, 1 << 20):
-    hs = rnd(small); hs /= torch.linalg.vector_norm(hs)
-    vs, rs = rnd(small), rnd(small)
-    Hs, Ds = lo.opHouseholder(hs), lo.opDiagonal(rnd(small) + 1.5)
-    Bq = lo.LBFGSOperator(small, mem=5, device=dev)
-    for _ in range(6):
-        s_ = rnd(small)
-        lo.push(Bq, s_, s_ * (rnd(small) * 0.5 + 1.25))
-    comp = Hs * Ds + Bq
-    for name, op in (("opHouseholder", Hs), ("LBFGSOperator m=5", Bq), ("H*D + B (compose + sum)", comp)):
-        eager = wall(lambda: lo.mul(rs, op, vs, 1.0, 0.0), torch.cuda.synchronize)
-        gcap = lo.capture_mul(rs, op, vs, 1.0, 0.0)
-        replay = wall(lambda: gcap.replay(sync_streams=False), gcap.stream.synchronize)
-        print(f"  n=2^{small.bit_length()-1:<2d} {name:28s} eager {eager:7.1f} us   graph replay {replay:7.1f} us   x{eager/replay:4.1f}", flush=True)
-        del gcap
+    print("\nlaunch-bound regime (fp64): us per apply, eager mul! vs hipGraph replay (mxlo_graph_launch)")
+    for small in (1 << 12, 1 << 16, 1 << 20):
+        hs = rnd(small); hs /= torch.linalg.vector_norm(hs)
+        vs, rs = rnd(small), rnd(small)
+        Hs, Ds = lo.opHouseholder(hs), lo.opDiagonal(rnd(small) + 1.5)
+        Bq = lo.LBFGSOperator(small, mem=5, device=dev)
+        for _ in range(6):
+            s_ = rnd(small)
+            lo.push(Bq, s_, s_ * (rnd(small) * 0.5 + 1.25))
+        comp = Hs * Ds + Bq
+        for name, op in (("opHouseholder", Hs), ("LBFGSOperator m=5", Bq), ("H*D + B (compose + sum)", comp)):
+            eager = wall(lambda: lo.mul(rs, op, vs, 1.0, 0.0), torch.cuda.synchronize)
+            gcap = lo.capture_mul(rs, op, vs, 1.0, 0.0)
+            inf = gcap.info()
+            replay = wall(lambda: gcap.replay(sync_streams=False), gcap.stream.synchronize)
+            ctx.tune("graph_direct_max", 0)
+            gcap2 = lo.capture_mul(rs, op, vs, 1.0, 0.0)
+            ctx.tune("graph_direct_max", 16)
+            replay2 = wall(lambda: gcap2.replay(sync_streams=False), gcap2.stream.synchronize)
+            print(f"  n=2^{small.bit_length()-1:<2d} {name:28s} eager {eager:7.1f} us   replay {replay:7.1f} us ({inf['nodes']} nodes, "
+                  f"{'direct chain' if inf['direct'] else 'hipGraphLaunch'})  x{eager/replay:4.1f}   [hipGraphLaunch forced: {replay2:7.1f} us]", flush=True)
+            del gcap, gcap2

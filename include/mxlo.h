@@ -126,6 +126,19 @@ int32_t mxlo_memcpy_d2h(mxlo_ctx *ctx, void *dst, const void *src, int64_t bytes
 int32_t mxlo_memcpy_d2d(mxlo_ctx *ctx, void *dst, const void *src, int64_t bytes);
 int32_t mxlo_memset(mxlo_ctx *ctx, void *p, int32_t byte, int64_t bytes);
 
+/* ---- the allocation / synchronisation contract, observable (test hook) ------------------------------------------
+ * The reference's tests assert that a warmed mul! allocates nothing (test/test_lbfgs.jl:180-218). Here the
+ * equivalent statement is about the HIP runtime: a warmed mul! / diag! / solve_shifted_system! issues kernel
+ * launches and nothing else — no hipMalloc/hipFree, no copy, no stream/device/event synchronisation — and push!
+ * issues exactly ONE small device-to-host copy (its 2-5 doubles) and the synchronisation that copy needs.
+ * Every allocating / copying / blocking runtime call the library makes is counted (process-wide, monotone):
+ *   out[0] hipMalloc+hipHostMalloc   [1] hipFree   [2] H2D copies   [3] D2H copies   [4] D2D copies
+ *   out[5] bytes copied D2H          [6] hipStreamSynchronize       [7] hipDeviceSynchronize
+ *   out[8] hipEventSynchronize       [9] hipMemsetAsync             [10] kernel launches
+ *   out[11] blocking (non-Async) copies
+ * Differences of two snapshots around a call give what that call did (tests/test_gpu_contract.py). */
+int32_t mxlo_debug_counters(int64_t out[12]);
+
 /* ---- hipGraph capture: launch-bound inner loops --------------------------------------------
  * An apply at small n is 2-4 dependent kernel launches (dots -> finalize -> coefficients -> combine);
  * a Krylov or quasi-Newton inner loop repeats the same sequence on the same buffers thousands of times.

@@ -96,6 +96,7 @@ _PROTOS = {
     "mxlo_graph_end": [_vp, C.POINTER(_vp)],
     "mxlo_graph_launch": [_vp],
     "mxlo_graph_info": [_vp, C.POINTER(_i64)],
+    "mxlo_debug_counters": [C.POINTER(_i64)],
     "mxlo_graph_destroy": [_vp],
     "mxlo_timer_create": [_vp, C.POINTER(_vp)],
     "mxlo_timer_start": [_vp],

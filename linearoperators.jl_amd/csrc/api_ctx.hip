@@ -260,6 +260,22 @@ MXLO_API int32_t mxlo_graph_destroy(mxlo_graph *g) {
   return MXLO_OK;
 }
 
+namespace mxlo {
+ApiCounters &api_counters() {
+  static ApiCounters c;
+  return c;
+}
+}  // namespace mxlo
+
+MXLO_API int32_t mxlo_debug_counters(int64_t out[12]) {
+  MXLO_REQUIRE(out, MXLO_EINVAL, "mxlo_debug_counters: out is NULL");
+  ApiCounters &c = api_counters();
+  const int64_t v[12] = {c.n_malloc, c.n_free, c.n_h2d, c.n_d2h, c.n_d2d, c.n_d2h_bytes, c.n_stream_sync,
+                         c.n_device_sync, c.n_event_sync, c.n_memset_async, c.n_launch, c.n_blocking_copy};
+  for (int i = 0; i < 12; ++i) out[i] = v[i];
+  return MXLO_OK;
+}
+
 MXLO_API int32_t mxlo_ctx_sync(mxlo_ctx *ctx) {
   MXLO_REQUIRE(ctx, MXLO_EINVAL, "ctx is NULL");
   MXLO_DEVICE_GUARD(ctx);

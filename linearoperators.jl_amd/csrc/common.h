@@ -2,6 +2,7 @@
 // gfx950 (MI355X, CDNA4) only: wave = 64 lanes, 256 CUs in 8 XCDs.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
 
 #include <cstdarg>
 #include <cstdint>
@@ -28,6 +29,42 @@ constexpr int kMaxRedBlocks = 4096;  // partial slots per column in the workspac
 constexpr int kScalarSlots = 8192;   // doubles in the device scalar buffer
 
 void set_error(const char *fmt, ...);
+
+// ---- runtime-call accounting (the f2 contract: a warmed mul!/diag!/solve allocates nothing, copies nothing, never
+// synchronises) -----------------------------------------------------------------------------------------------
+// Every HIP runtime entry point the library uses that allocates, copies or blocks goes through these macros (a
+// function-like macro is not re-expanded inside its own replacement, so the inner name is the real HIP function);
+// kernel launches are counted in MXLO_LAUNCH_CHECK. mxlo_debug_counters() exports the totals for the contract test.
+struct ApiCounters {
+  std::atomic<int64_t> n_malloc{0}, n_free{0}, n_h2d{0}, n_d2h{0}, n_d2d{0}, n_d2h_bytes{0}, n_stream_sync{0},
+      n_device_sync{0}, n_event_sync{0}, n_memset_async{0}, n_launch{0}, n_blocking_copy{0};
+};
+ApiCounters &api_counters();
+inline void count_copy(size_t bytes, hipMemcpyKind kind, bool blocking) {
+  ApiCounters &c = api_counters();
+  if (kind == hipMemcpyDeviceToHost) { ++c.n_d2h; c.n_d2h_bytes += (int64_t)bytes; }
+  else if (kind == hipMemcpyHostToDevice) ++c.n_h2d;
+  else ++c.n_d2d;
+  if (blocking) ++c.n_blocking_copy;
+}
+inline hipError_t counted_memcpy(void *d, const void *s, size_t b, hipMemcpyKind k) {
+  count_copy(b, k, true);
+  return hipMemcpy(d, s, b, k);
+}
+inline hipError_t counted_memcpy_async(void *d, const void *s, size_t b, hipMemcpyKind k, hipStream_t st) {
+  count_copy(b, k, false);
+  return hipMemcpyAsync(d, s, b, k, st);
+}
+#define hipMalloc(...) (++mxlo::api_counters().n_malloc, hipMalloc(__VA_ARGS__))
+#define hipFree(...) (++mxlo::api_counters().n_free, hipFree(__VA_ARGS__))
+#define hipHostMalloc(...) (++mxlo::api_counters().n_malloc, hipHostMalloc(__VA_ARGS__))
+#define hipHostFree(...) (++mxlo::api_counters().n_free, hipHostFree(__VA_ARGS__))
+#define hipMemcpy(...) mxlo::counted_memcpy(__VA_ARGS__)
+#define hipMemcpyAsync(...) mxlo::counted_memcpy_async(__VA_ARGS__)
+#define hipStreamSynchronize(...) (++mxlo::api_counters().n_stream_sync, hipStreamSynchronize(__VA_ARGS__))
+#define hipDeviceSynchronize(...) (++mxlo::api_counters().n_device_sync, hipDeviceSynchronize(__VA_ARGS__))
+#define hipEventSynchronize(...) (++mxlo::api_counters().n_event_sync, hipEventSynchronize(__VA_ARGS__))
+#define hipMemsetAsync(...) (++mxlo::api_counters().n_memset_async, hipMemsetAsync(__VA_ARGS__))
 
 #define MXLO_HIP(call)                                                                           \
   do {                                                                                           \
@@ -60,6 +97,7 @@ inline bool mxlo_trace_on() {
 }
 #define MXLO_LAUNCH_CHECK()                                                                      \
   do {                                                                                           \
+    ++mxlo::api_counters().n_launch;                                                             \
     if (mxlo_trace_on()) {                                                                       \
       fprintf(stderr, "[mxlo] launched %s:%d ... ", __FILE__, __LINE__);                         \
       fflush(stderr);                                                                            \

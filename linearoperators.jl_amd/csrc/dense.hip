@@ -400,13 +400,12 @@ struct HermCfg {
 //                 the ragged last row group; mode 2 (instantiated with C = 1): the 8 tiles of a diagonal block,
 //                 one workgroup each, so that the short diagonal pass still fills the chip.
 template <typename T, int C, bool EDGE>
-__global__ void __launch_bounds__(kBlock)
-herm_strip_kernel(const T *__restrict__ A, int64_t lda, const T *__restrict__ v, int64_t n,
-                  double *__restrict__ Prow, double *__restrict__ Pcol, int64_t ng, int qint, int mode) {
+__device__ __forceinline__ void
+herm_strip_body(const T *__restrict__ A, int64_t lda, const T *__restrict__ v, int64_t n,
+                double *__restrict__ Prow, double *__restrict__ Pcol, int64_t ng, int qint, int mode, int64_t t) {
   constexpr int RPL = HermCfg<T>::RPL, HR = HermCfg<T>::HR, DT = HermCfg<T>::DT;
   typedef T VR __attribute__((ext_vector_type(RPL)));
   constexpr int HS = C;
-  const int64_t t = blockIdx.x;
   int64_t G, tile0, slot;                    // row group, first column tile, row-partial slot
   if (!EDGE || mode == 0) {                  // triangular enumeration u = G'(G'+1)/2 + r, r <= G'; G = G'+1
     constexpr int Q = DT / C;
@@ -517,6 +516,33 @@ herm_strip_kernel(const T *__restrict__ A, int64_t lda, const T *__restrict__ v,
   }
 }
 
+template <typename T, int C, bool EDGE>
+__global__ void __launch_bounds__(kBlock)
+herm_strip_kernel(const T *__restrict__ A, int64_t lda, const T *__restrict__ v, int64_t n,
+                  double *__restrict__ Prow, double *__restrict__ Pcol, int64_t ng, int qint, int mode) {
+  herm_strip_body<T, C, EDGE>(A, lda, v, n, Prow, Pcol, ng, qint, mode, (int64_t)blockIdx.x);
+}
+
+// Mid sizes (thin strips, C <= 2): ONE launch for the whole triangle: workgroups [0, n_int) run the unmasked interior strips, then the masked strips
+// (unaligned A, ragged last row group), then the diagonal tiles — every dependent launch costs ~3.5 us on this
+// runtime, which at n = 4096 (67 MB, ~11 us of traffic) was a third of the apply. (Not for the 8-tile strips of
+// large n: the merged kernel is allocated the masked path's registers — 195 instead of 104 VGPRs — and the unmasked
+// interior, which carries all the traffic there, would lose half its occupancy.)
+template <typename T, int C>
+__global__ void __launch_bounds__(kBlock)
+herm_pass_kernel(const T *__restrict__ A, int64_t lda, const T *__restrict__ v, int64_t n,
+                 double *__restrict__ Prow, double *__restrict__ Pcol, int64_t ng, int qint, int64_t n_int,
+                 int64_t n_all, int64_t n_last) {
+  int64_t t = blockIdx.x;
+  if (t < n_int) return herm_strip_body<T, C, false>(A, lda, v, n, Prow, Pcol, ng, qint, 0, t);
+  t -= n_int;
+  if (t < n_all) return herm_strip_body<T, C, true>(A, lda, v, n, Prow, Pcol, ng, qint, 0, t);
+  t -= n_all;
+  if (t < n_last) return herm_strip_body<T, C, true>(A, lda, v, n, Prow, Pcol, ng, qint, 1, t);
+  t -= n_last;
+  herm_strip_body<T, 1, true>(A, lda, v, n, Prow, Pcol, ng, qint, 2, t);
+}
+
 // 32 rows per workgroup, 8 lanes per row: lane `sub` adds partials sub, sub+8, ... (independent loads in
 // flight), the 8 sub-sums are combined in a fixed order -> deterministic, and n/32 workgroups fill the chip.
 template <typename T, typename CA, typename CB, bool BETA0>
@@ -581,22 +607,25 @@ int32_t hermitian_t(mxlo_ctx *ctx, T *res, const T *d, const T *A, int64_t lda, 
   const int64_t n_int = gi > 1 ? Q * gi * (gi - 1) / 2 : 0;
   const int64_t n_all = !aligned && ng > 1 ? Q * ng * (ng - 1) / 2 : 0;       // mode 0, masked
   const int64_t n_last = aligned && ng > ngf ? Q * (ng - 1) : 0;               // mode 1
-#define HERM_GO(C_)                                                                                            \
-  {                                                                                                            \
-    if (n_int > 0)                                                                                             \
-      hipLaunchKernelGGL((herm_strip_kernel<T, C_, false>), dim3((unsigned)n_int), dim3(kBlock), 0,            \
-                         ctx->stream, A, lda, v, n, Prow, Pcol, ng, Q, 0);                                     \
-    if (n_all > 0)                                                                                             \
-      hipLaunchKernelGGL((herm_strip_kernel<T, C_, true>), dim3((unsigned)n_all), dim3(kBlock), 0,             \
-                         ctx->stream, A, lda, v, n, Prow, Pcol, ng, Q, 0);                                     \
-    if (n_last > 0)                                                                                            \
-      hipLaunchKernelGGL((herm_strip_kernel<T, C_, true>), dim3((unsigned)n_last), dim3(kBlock), 0,            \
-                         ctx->stream, A, lda, v, n, Prow, Pcol, ng, Q, 1);                                     \
-  }
-  if (C == 8) HERM_GO(8) else if (C == 2) HERM_GO(2) else HERM_GO(1)
-#undef HERM_GO
-  hipLaunchKernelGGL((herm_strip_kernel<T, 1, true>), dim3((unsigned)(DT * ng)), dim3(kBlock), 0, ctx->stream, A,
-                     lda, v, n, Prow, Pcol, ng, Q, 2);
+  const int64_t n_diag = (int64_t)DT * ng, total = n_int + n_all + n_last + n_diag;
+  MXLO_REQUIRE(total < (1LL << 31), MXLO_ESHAPE, "opHermitian: n too large");
+#define HERM_MERGED(C_)                                                                                        \
+  hipLaunchKernelGGL((herm_pass_kernel<T, C_>), dim3((unsigned)total), dim3(kBlock), 0, ctx->stream, A, lda, v, \
+                     n, Prow, Pcol, ng, Q, n_int, n_all, n_last);
+  if (C == 8) {
+    if (n_int > 0)
+      hipLaunchKernelGGL((herm_strip_kernel<T, 8, false>), dim3((unsigned)n_int), dim3(kBlock), 0, ctx->stream, A, lda,
+                         v, n, Prow, Pcol, ng, Q, 0);
+    if (n_all > 0)
+      hipLaunchKernelGGL((herm_strip_kernel<T, 8, true>), dim3((unsigned)n_all), dim3(kBlock), 0, ctx->stream, A, lda, v,
+                         n, Prow, Pcol, ng, Q, 0);
+    if (n_last > 0)
+      hipLaunchKernelGGL((herm_strip_kernel<T, 8, true>), dim3((unsigned)n_last), dim3(kBlock), 0, ctx->stream, A, lda,
+                         v, n, Prow, Pcol, ng, Q, 1);
+    hipLaunchKernelGGL((herm_strip_kernel<T, 1, true>), dim3((unsigned)n_diag), dim3(kBlock), 0, ctx->stream, A, lda, v,
+                       n, Prow, Pcol, ng, Q, 2);
+  } else if (C == 2) HERM_MERGED(2) else HERM_MERGED(1)
+#undef HERM_MERGED
   MXLO_LAUNCH_CHECK();
   const unsigned blocks = (unsigned)((n + 31) / 32);
   return dispatch_ab<T>(beta, flags, [&]<typename CA, typename CB, bool B0>() -> int32_t {

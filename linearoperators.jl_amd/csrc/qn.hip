@@ -344,6 +344,11 @@ struct OrdArgs {
   int is_f32;            // round scalars to float like the reference's T arithmetic
 };
 
+// coef[i] = as[ord[i]] (L-SR1 diag!: the active slots' 1/(a_k's_k) in apply order)
+__global__ void gather_as_kernel(const double *__restrict__ as_, double *__restrict__ coef, OrdArgs O) {
+  for (int i = threadIdx.x; i < O.na; i += blockDim.x) coef[i] = as_[O.ord[i]];
+}
+
 __device__ __forceinline__ double rnd(double v, int is_f32) { return is_f32 ? (double)(float)v : v; }
 
 // Inverse two-loop in coefficient space (SURVEY §8a equivalence (i)):
@@ -450,10 +455,13 @@ struct NegScaleOp {
   __device__ T operator()(T g, T, T) const { return na * g; }
 };
 // tmp = y - s/sf   (src/lsr1.jl:140)
+// y - s/sf, sf = ys / yy formed ON THE DEVICE from the freshly reduced scalars (misc[0] = y's, misc[3] = y'y), so
+// that the L-SR1 push! needs one read-back instead of two
 template <typename T>
-struct YmSOverOp {
+struct YmSOverDevOp {
+  const double *misc;
   T sf;
-  __device__ void init() {}
+  __device__ void init() { sf = (T)misc[0] / (T)misc[3]; }
   __device__ T operator()(T y, T s, T) const { return y - (s / sf); }
 };
 // reference-ordered two-loop steps: q = q - a*y with a = dot/ys (stored), q = q + (a_k - dot/ys)*s
@@ -1190,8 +1198,17 @@ int32_t lsr1_push(mxlo_qn *h, const T *s, const T *y, int32_t *accepted) {
   MXLO_TRY(panel_dots<T>(ctx, c1, 1, y, n, misc + 3));      // y'y
   const T *c2[1] = {ymBs};
   MXLO_TRY(panel_dots<T>(ctx, c2, 1, ymBs, n, misc + 4));   // ||ymBs||^2
-  double hs[5];
-  MXLO_TRY(read_scalars(h, misc, hs, 5));
+  // scaling: ||y - s/sf|| with sf = ys/yy (:139-141) is evaluated speculatively on the device (sf is formed there from
+  // the reduced scalars), so that ALL the push's control scalars come back in ONE device-to-host copy; the host then
+  // takes the reference's decisions in the reference's order. (y = 0 gives sf = NaN on both paths: rejected.)
+  if (h->scaling) {
+    T *t2 = (T *)h->tmp2;
+    MXLO_TRY((launch_map<T, 2, false, false>(ctx, t2, y, s, n, YmSOverDevOp<T>{misc, T(0)})));   // :140
+    const T *ct[1] = {t2};
+    MXLO_TRY(panel_dots<T>(ctx, ct, 1, t2, n, misc + 5));
+  }
+  double hs[6] = {0, 0, 0, 0, 0, 0};
+  MXLO_TRY(read_scalars(h, misc, hs, h->scaling ? 6 : 5));
   const T ys = (T)hs[0], sNorm = (T)std::sqrt(rT<T>(hs[1])), yy = (T)hs[3];
   const T ymBs_s = (T)hs[2], ymBsNorm = (T)std::sqrt(rT<T>(hs[4]));
   const T eps = eps_of<T>();
@@ -1200,16 +1217,8 @@ int32_t lsr1_push(mxlo_qn *h, const T *s, const T *y, int32_t *accepted) {
   if (h->scaling) {
     const T yNorm = (T)std::sqrt((double)yy);                                              // :136
     sufficient_curvature = std::fabs((double)ys) >= (double)(eps * yNorm * sNorm);         // :137
-    if (sufficient_curvature) {
-      const T sf = ys / yy;                                                                // :139
-      T *t2 = (T *)h->tmp2;
-      MXLO_TRY((launch_map<T, 2, false, false>(ctx, t2, y, s, n, YmSOverOp<T>{sf})));      // :140
-      const T *ct[1] = {t2};
-      MXLO_TRY(panel_dots<T>(ctx, ct, 1, t2, n, misc + 5));
-      double nn[1];
-      MXLO_TRY(read_scalars(h, misc + 5, nn, 1));
-      scaling_condition = (T)std::sqrt(rT<T>(nn[0])) >= eps * yNorm * sNorm;               // :141
-    }
+    if (sufficient_curvature)
+      scaling_condition = (T)std::sqrt(rT<T>(hs[5])) >= eps * yNorm * sNorm;               // :141
   }
   if (!(well_defined && sufficient_curvature && scaling_condition)) {                      // :145-149
     *accepted = 0;
@@ -1497,10 +1506,10 @@ int32_t diag_t(mxlo_qn *h, T *d) {
   A.ncol = O.na;
   double *coef = h->dsc + h->lay.coef;
   A.coef = coef;
-  for (int i = 0; i < O.na; ++i) {
-    A.cols[i] = col<T>(h->A, h->ld, O.ord[i]);
-    MXLO_HIP(hipMemcpyAsync(coef + i, h->dsc + h->lay.as_ + O.ord[i], sizeof(double),
-                            hipMemcpyDeviceToDevice, h->ctx->stream));
+  for (int i = 0; i < O.na; ++i) A.cols[i] = col<T>(h->A, h->ld, O.ord[i]);
+  if (O.na > 0) {   // one tiny launch instead of na device-to-device copies
+    hipLaunchKernelGGL(gather_as_kernel, dim3(1), dim3(64), 0, h->ctx->stream, h->dsc + h->lay.as_, coef, O);
+    MXLO_LAUNCH_CHECK();
   }
   return launch_combine<T, CM_DIAG_SR1>(h->ctx, d, (const T *)nullptr, (const T *)nullptr, A, h->n, 0);
 }

@@ -250,14 +250,18 @@ def push(op, s: torch.Tensor, y: torch.Tensor, *args):
     return op
 
 
-def diag(op) -> torch.Tensor:
-    """diag(op) / diag!(op, d) — src/lbfgs.jl:369-395 (forward only), src/lsr1.jl:186-211."""
+def diag(op, d: torch.Tensor | None = None) -> torch.Tensor:
+    """diag(op) / diag!(op, d) — src/lbfgs.jl:369-395 (forward only), src/lsr1.jl:186-211. With `d` the call is the
+    in-place `diag!` (nothing is allocated); without, `diag(op)` allocates the result like the reference (:371)."""
     if isinstance(op, LBFGSOperatorType) and op.inverse:
         raise LinearOperatorException("only the diagonal of a forward L-BFGS approximation is available")
-    d = torch.empty(op.nrow, dtype=op.eltype, device=op.S.device)
+    if d is None:
+        d = torch.empty(op.nrow, dtype=op.eltype, device=op.S.device)
+    else:
+        op._check_len(d=check_vec(d, "d", op.eltype))
     op._ctx.bind_stream()
     _lib.call("mxlo_qn_diag", op._h, ptr(d))
-    return d
+    return touched(d)
 
 
 def solve_shifted_system(x: torch.Tensor, B, b: torch.Tensor, sigma: float) -> torch.Tensor:

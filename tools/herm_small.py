@@ -1,0 +1,28 @@
+#!/usr/bin/env python
+"""opHermitian at mid sizes: per-apply HIP-event time (for rocprofv3 --kernel-trace runs too)."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+import __graft_entry__ as g
+
+lo = g.load_package()
+from linearoperators_jl_amd.device import Timer, get_ctx
+
+dev = torch.device("cuda", 0)
+ctx = get_ctx(dev)
+tm = Timer(ctx)
+for nn in (1024, 2048, 4096, 8192, 16384):
+    M = torch.rand(nn, nn, dtype=torch.float64, device=dev).t()
+    d, x, y = (torch.rand(nn, dtype=torch.float64, device=dev) for _ in range(3))
+    H = lo.opHermitian(d, M)
+    for _ in range(5):
+        lo.mul(y, H, x, 1.0, 0.0)
+    tm.start()
+    for _ in range(50):
+        lo.mul(y, H, x, 1.0, 0.0)
+    tm.stop()
+    ms = tm.elapsed_ms() / 50
+    print(f"opHermitian n={nn:6d}: {ms*1e3:8.1f} us  {4.0*nn*nn/ms/1e6:7.0f} GB/s  {4.0*nn*nn/ms/1e6/8000:5.3f}", flush=True)

@@ -9,6 +9,7 @@ import pytest
 import torch
 
 import oracle
+from tolerances import QN_F32, QN_F32_ROUNDTRIP
 
 pytestmark = pytest.mark.gpu
 NP = {torch.float64: np.float64, torch.float32: np.float32}
@@ -108,9 +109,9 @@ def test_kat_lsr1(lo, dev, kat):
 def test_lbfgs_parity(lo, dev, dtype, push_mode, n, mem, npush, scaling):
     rng = np.random.default_rng(n + mem)
     npd = NP[dtype]
-    tol = dict(ref=1e-10, two=1e-9, fwd=1e-10) if dtype == torch.float64 else dict(ref=2e-4, two=2e-4, fwd=2e-4)
+    tol = dict(ref=1e-10, two=1e-9, fwd=1e-10) if dtype == torch.float64 else dict(ref=QN_F32, two=QN_F32, fwd=QN_F32)
     if push_mode in ("gram", "compact"):   # Gram-form rebuild of the a_k panel: different association order
-        tol["fwd"] = 1e-9 if dtype == torch.float64 else 5e-4
+        tol["fwd"] = 1e-9 if dtype == torch.float64 else QN_F32
     B = lo.LBFGSOperator(dtype, n, mem=mem, scaling=scaling, device=dev).set_push_mode(push_mode)
     H = lo.InverseLBFGSOperator(dtype, n, mem=mem, scaling=scaling, device=dev)
     Bo = oracle.LBFGS(n, mem=mem, scaling=scaling, inverse=False, dtype=npd)
@@ -142,7 +143,7 @@ def test_lbfgs_parity(lo, dev, dtype, push_mode, n, mem, npush, scaling):
     assert rel(B.data.opnorm_upper_bound, Bo.opnorm_upper_bound) <= 1e-5
     # H*(B*x) == x (the property behind test_lbfgs.jl:56) at this size
     back = H * (B * T(x, dev))
-    assert rel(back.cpu().numpy(), x) <= (1e-8 if dtype == torch.float64 else 5e-2)
+    assert rel(back.cpu().numpy(), x) <= (1e-8 if dtype == torch.float64 else QN_F32_ROUNDTRIP)
 
 
 @pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
@@ -152,7 +153,7 @@ def test_lbfgs_parity(lo, dev, dtype, push_mode, n, mem, npush, scaling):
 def test_lsr1_parity(lo, dev, dtype, push_mode, n, mem, npush, scaling):
     rng = np.random.default_rng(7 * n + mem)
     npd = NP[dtype]
-    tol = (1e-10 if push_mode == "reforder" else 1e-9) if dtype == torch.float64 else 1e-3
+    tol = (1e-10 if push_mode == "reforder" else 1e-9) if dtype == torch.float64 else QN_F32
     B = lo.LSR1Operator(dtype, n, mem=mem, scaling=scaling, device=dev).set_push_mode(push_mode)
     Bo = oracle.LSR1(n, mem=mem, scaling=scaling, dtype=npd)
     x, r0 = rng.uniform(-1, 1, n).astype(npd), rng.uniform(-1, 1, n).astype(npd)
@@ -259,7 +260,7 @@ def test_solve_shifted_system(lo, dev, dtype, scaling):
         s, y = rng.random(n).astype(npd), rng.random(n).astype(npd)
         lo.push(B, T(s, dev), T(y, dev)); lo.push(H, T(s, dev), T(y, dev)); Bo.push(s, y)
     x = rng.standard_normal(n).astype(npd)
-    at = 1e-6 if dtype == torch.float64 else 5e-2
+    at = 1e-6 if dtype == torch.float64 else QN_F32_ROUNDTRIP
     for sigma in (0.1, 0.0, 3.0):
         b = (B * T(x, dev)) + sigma * T(x, dev)
         xs = torch.zeros(n, dtype=dtype, device=dev)
@@ -335,7 +336,9 @@ def test_allreduce_hook_world1(lo, dev):
         h = rng.standard_normal(n); h /= np.linalg.norm(h)
         v = rng.uniform(-1, 1, n)
         H = lo.opHouseholder(T(h, dev))
-        want = (H * T(v, dev)).clone()
+        ctx.tune("house_fused", 0)               # a hooked apply is the two-launch path (the hook sits between the passes):
+        want = (H * T(v, dev)).clone()           # compare with the SAME reduction order, un-hooked
+        ctx.tune("house_fused", 1)
         ctx.set_allreduce(hook)
         got = H * T(v, dev)
         assert torch.equal(got, want) and calls == [1]
@@ -389,7 +392,9 @@ def test_native_rccl_hook_world1(lo, dev):
     h = rng.standard_normal(n); h /= np.linalg.norm(h)
     v = rng.uniform(-1, 1, n)
     H = lo.opHouseholder(T(h, dev))
+    ctx.tune("house_fused", 0)                   # same (two-launch) reduction order as the hooked apply
     want = (H * T(v, dev)).clone()
+    ctx.tune("house_fused", 1)
     hook = lo.sharded.NativeRcclHook(0, 1)
     try:
         hook.install(ctx)
@@ -445,7 +450,7 @@ def test_shifted_qn_fused_is_bit_identical(lo, dev, dtype, kind, n):
                 type(Sh).fuse = True
         assert torch.equal(outs[0], outs[1]), (kind, a, b)
         ref = orc.mul(r0.copy(), x, float(a), float(b)).astype(np.float64) + float(a) * sigma * x.astype(np.float64)
-        assert rel(outs[0].cpu().numpy(), ref) <= (1e-9 if dtype == torch.float64 else 2e-4)
+        assert rel(outs[0].cpu().numpy(), ref) <= (1e-9 if dtype == torch.float64 else QN_F32)
     nb = lo.nprod(op)
     Sh.data.sigma = 0.0                                   # σ == 0 (or α == 0): plain mul!, no axpy (:21)
     assert torch.equal(Sh * T(x, dev), op * T(x, dev)) and lo.nprod(op) == nb + 2
@@ -458,7 +463,7 @@ def test_compact_forward_push_materialises_on_demand(lo, dev, dtype):
     npd = NP[dtype]
     n, mem = 20_011, 6
     rng = np.random.default_rng(17)
-    tol = 1e-9 if dtype == torch.float64 else 5e-4
+    tol = 1e-9 if dtype == torch.float64 else QN_F32
     Bc = lo.LBFGSOperator(dtype, n, mem=mem, device=dev).set_push_mode("compact")
     Bg = lo.LBFGSOperator(dtype, n, mem=mem, device=dev).set_push_mode("gram")
     O = oracle.LBFGS(n, mem=mem, inverse=False, dtype=npd)
@@ -498,7 +503,7 @@ def test_inverse_lbfgs_large_memory(lo, dev, dtype, mem, npush):
     H = lo.InverseLBFGSOperator(dtype, n, mem=mem, device=dev)
     Ho = oracle.LBFGS(n, mem=mem, inverse=True, dtype=npd)
     x, r0 = rng.uniform(-1, 1, n).astype(npd), rng.uniform(-1, 1, n).astype(npd)
-    tol = dict(twopass=1e-9, reforder=1e-10) if dtype == torch.float64 else dict(twopass=5e-4, reforder=5e-4)
+    tol = dict(twopass=1e-9, reforder=1e-10) if dtype == torch.float64 else dict(twopass=QN_F32, reforder=QN_F32)
     for k, (s, y) in enumerate(pairs(rng, n, npush, npd)):
         lo.push(H, T(s, dev), T(y, dev)); Ho.push(s, y)
         if k in (3, npush // 2, npush - 1):
@@ -526,7 +531,7 @@ def test_unbounded_memory(lo, dev, dtype, kind, mem, npush):
     n = 3001
     rng = np.random.default_rng(1000 * mem + npush)
     f64 = dtype == torch.float64
-    tol = (1e-9 if f64 else 1e-3)
+    tol = (1e-9 if f64 else QN_F32)
     if kind == "lsr1":
         B = lo.LSR1Operator(dtype, n, mem=mem, device=dev)
         Bo = oracle.LSR1(n, mem=mem, scaling=True, dtype=npd)
@@ -556,7 +561,7 @@ def test_unbounded_memory(lo, dev, dtype, kind, mem, npush):
                 B.set_mode("reforder")
                 res = T(r0.copy(), dev)
                 lo.mul(res, B, T(x, dev), 2.0, -3.0)
-                assert rel(res.cpu().numpy(), Bo.mul(r0.copy(), x, 2.0, -3.0, flags=oracle.scalar_flags(npd, 2.0, -3.0))) <= (1e-10 if f64 else 1e-3)
+                assert rel(res.cpu().numpy(), Bo.mul(r0.copy(), x, 2.0, -3.0, flags=oracle.scalar_flags(npd, 2.0, -3.0))) <= (1e-10 if f64 else QN_F32)
                 B.set_mode("twopass")
     assert abs(B.data.scaling_factor - Bo.scaling_factor) <= 1e-6 * abs(Bo.scaling_factor)
     if kind != "inv":
@@ -566,7 +571,7 @@ def test_unbounded_memory(lo, dev, dtype, kind, mem, npush):
         sigma = 0.3
         b = (B * T(x, dev)) + sigma * T(x, dev)
         xs = lo.solve_shifted_system(torch.zeros(n, dtype=dtype, device=dev), B, b, sigma)
-        assert np.allclose(xs.cpu().numpy(), x, atol=1e-6 if f64 else 5e-2, rtol=1e-6 if f64 else 5e-2)
+        assert np.allclose(xs.cpu().numpy(), x, atol=1e-6 if f64 else QN_F32_ROUNDTRIP, rtol=1e-6 if f64 else QN_F32_ROUNDTRIP)
         if f64:
             assert rel(xs.cpu().numpy(), Bo.solve_shifted(np.zeros(n), b.cpu().numpy(), sigma)) <= 1e-7
         with pytest.raises(lo.MxloError):

@@ -175,6 +175,9 @@ def main():
     roofline = {"bound": "hbm", "kernel": "map_kernel<HouseholderOp> (update pass res = α(v - c·h), 24 B/elt)",
                 "achieved": round(upd_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(upd_gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "traffic_source": ("profile-derived, NOT measured in this run: HBM bytes per launch from separate rocprofv3 --pmc "
+                                   "FETCH_SIZE / WRITE_SIZE passes over the same kernel and size (tools/profile_gpu.sh -> "
+                                   "profiles/traffic_householder.json, gfx950 unit corrections applied there)") if traffic else None,
                 "avg_launch_ms": round(ms_upd, 4), "algorithmic_bytes_per_launch": 24.0 * n}
     extras = {
         "householder_dot_pass": {"ms": round(ms_dot, 4), "GB/s": round(16.0 * n / (ms_dot * 1e-3) / 1e9, 1),

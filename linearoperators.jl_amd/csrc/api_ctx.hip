@@ -260,13 +260,6 @@ MXLO_API int32_t mxlo_graph_destroy(mxlo_graph *g) {
   return MXLO_OK;
 }
 
-namespace mxlo {
-ApiCounters &api_counters() {
-  static ApiCounters c;
-  return c;
-}
-}  // namespace mxlo
-
 MXLO_API int32_t mxlo_debug_counters(int64_t out[12]) {
   MXLO_REQUIRE(out, MXLO_EINVAL, "mxlo_debug_counters: out is NULL");
   ApiCounters &c = api_counters();

@@ -39,7 +39,10 @@ struct ApiCounters {
   std::atomic<int64_t> n_malloc{0}, n_free{0}, n_h2d{0}, n_d2h{0}, n_d2d{0}, n_d2h_bytes{0}, n_stream_sync{0},
       n_device_sync{0}, n_event_sync{0}, n_memset_async{0}, n_launch{0}, n_blocking_copy{0};
 };
-ApiCounters &api_counters();
+inline ApiCounters &api_counters() {   // one instance per linked image (the library's is what mxlo_debug_counters reports)
+  static ApiCounters c;
+  return c;
+}
 inline void count_copy(size_t bytes, hipMemcpyKind kind, bool blocking) {
   ApiCounters &c = api_counters();
   if (kind == hipMemcpyDeviceToHost) { ++c.n_d2h; c.n_d2h_bytes += (int64_t)bytes; }

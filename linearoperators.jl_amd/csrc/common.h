@@ -139,6 +139,7 @@ struct mxlo_ctx {
   int num_cu = 256;
   double *partials = nullptr;  // [kMaxRedCols][kMaxRedBlocks] per-block partial sums
   double *scalars = nullptr;   // finalized reduction results / device-resident coefficients
+  bool lds_attr_set = false;   // dynamic-LDS limits of the shifted-solve kernels raised on THIS device
   unsigned *ticket = nullptr;  // arrival counter of the fused (last-workgroup) finalize; zero between launches
   unsigned long long *xslots = nullptr;  // [2][kFusedSlots] partial-exchange slots + epoch word of the single-launch Householder
   mxlo_allreduce_fn allreduce = nullptr;

@@ -1443,13 +1443,12 @@ int32_t solve_shifted_t(mxlo_qn *h, T *x, const T *b, double sigma) {
   }
   double *G = h->dsc + h->lay.G, *W = h->dsc + h->lay.Wm, *gv = h->dsc + h->lay.g, *cx = h->dsc + h->lay.cx,
          *dots = h->dsc + h->lay.dots, *coef = h->dsc + h->lay.coef;
-  static bool lds_attr_set = false;
-  if (!lds_attr_set) {  // up to 3*64*64 doubles of dynamic LDS (> the 64 KiB default cap)
+  if (!ctx->lds_attr_set) {  // up to 3*64*64 doubles of dynamic LDS (> the 64 KiB default cap); the attribute is per device
     MXLO_HIP(hipFuncSetAttribute((const void *)shifted_coef_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                  96 * 1024));
     MXLO_HIP(hipFuncSetAttribute((const void *)shifted_gram_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                  112 * 1024));
-    lds_attr_set = true;
+    ctx->lds_attr_set = true;
   }
   if (!h->G_valid && nu > 0) {
     hipLaunchKernelGGL(shifted_gram_kernel, dim3(1), dim3(kBlock), sizeof(double) * (w2 * w2 + 2 * nu * w2),

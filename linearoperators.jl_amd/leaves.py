@@ -271,8 +271,11 @@ def mulHermitian(res, d, A, v, alpha, beta):
 
 
 def _colmajor(M: torch.Tensor) -> torch.Tensor:
-    """A Julia Matrix is column-major: return a 2-D tensor whose memory is column-major
-    (stride(0) == 1). A row-major torch matrix is transposed-copied once."""
+    """A Julia Matrix is column-major: return a 2-D tensor whose memory is column-major (stride(0) == 1).
+    Column-major inputs are aliased. A row-major torch matrix is transposed-copied ONCE here — used only by opHermitian,
+    whose kernel reads the strict LOWER triangle of a column-major matrix (a row-major A would need the upper-triangle
+    twin): build it from `A.t().contiguous().t()`-style column-major storage when later in-place updates of A must be
+    seen. LinearOperator(M) and kron alias row-major inputs (N/T swapped)."""
     if M.dim() != 2:
         raise ValueError("matrix expected")
     if M.stride(0) == 1 and M.stride(1) >= max(1, M.shape[0]):
@@ -305,25 +308,44 @@ def opHermitian(*args):
 
 
 # ----------------------------------------------------------------------------- dense matrix operator
+def _stored_colmajor(M: torch.Tensor):
+    """(column-major view of the SAME memory, transposed?) — a row-major torch matrix (torch's default layout) IS the
+    column-major storage of its transpose, so it is aliased with the roles of N and T swapped instead of being copied
+    (the reference closure aliases M, src/constructors.jl:19-29: later in-place updates of M must be seen). Anything
+    else (non-unit strides both ways) is copied once to column-major."""
+    if M.dim() != 2:
+        raise ValueError("matrix expected")
+    if M.stride(0) == 1 and M.stride(1) >= max(1, M.shape[0]):
+        return M, False
+    if M.stride(1) == 1 and M.stride(0) >= max(1, M.shape[1]):
+        return M.t(), True
+    return M.t().contiguous().t(), False
+
+
 def LinearOperatorFromMatrix(M: torch.Tensor, symmetric: bool = False, hermitian: bool = False,
                              S: Optional[Storage] = None):
-    """LinearOperator(M) — src/constructors.jl:15-29 (prod!/tprod!/ctprod! = gemv N/T/C)."""
-    M = _colmajor(M)
-    dtype_code(M.dtype)
+    """LinearOperator(M) — src/constructors.jl:15-29 (prod!/tprod!/ctprod! = gemv N/T/C). M is ALIASED, never copied,
+    when it is column-major or row-major (a row-major M is the column-major storage of Mᵀ: N and T swap)."""
     nrow, ncol = M.shape
-    ld = M.stride(1) if ncol > 1 else max(1, nrow)
+    St, tr = _stored_colmajor(M)
+    dtype_code(St.dtype)
+    sm, sn = St.shape
+    ld = St.stride(1) if sn > 1 else max(1, sm)
+    fwd, bwd = (_lib.OP_T, _lib.OP_N) if tr else (_lib.OP_N, _lib.OP_T)
 
     def gemv(res, v, a, b, mode):
         ctx = get_ctx(res.device)
-        _lib.call("mxlo_gemv", ctx.handle, dtype_code(M.dtype), ptr(res), ptr(M), nrow, ncol, ld, ptr(v), float(a),
+        _lib.call("mxlo_gemv", ctx.handle, dtype_code(St.dtype), ptr(res), ptr(St), sm, sn, ld, ptr(v), float(a),
                   float(b), mode, scalar_flags(res.dtype, a, b))
 
-    prod = lambda res, v, a, b: gemv(res, v, a, b, _lib.OP_N)
-    tprod = lambda res, u, a, b: gemv(res, u, a, b, _lib.OP_T)
-    ctprod = lambda res, w, a, b: gemv(res, w, a, b, _lib.OP_C)
-    op = LinearOperator(M.dtype, nrow, ncol, symmetric, hermitian, prod, tprod, ctprod,
-                        S=S if S is not None else Storage(M.dtype, M.device))
-    op._leaf = ("dense", M, ld)
+    prod = lambda res, v, a, b: gemv(res, v, a, b, fwd)
+    tprod = lambda res, u, a, b: gemv(res, u, a, b, bwd)
+    ctprod = lambda res, w, a, b: gemv(res, w, a, b, bwd)          # real element types: C == T
+    op = LinearOperator(St.dtype, nrow, ncol, symmetric, hermitian, prod, tprod, ctprod,
+                        S=S if S is not None else Storage(St.dtype, St.device))
+    if not tr:
+        op._leaf = ("dense", St, ld)                 # block-diagonal descriptor tables take column-major blocks as they are
+    op._dense_src = M
     op._deps = (M,)
     return op
 
@@ -525,9 +547,9 @@ class _KronFactor:
             self.src, self.op = X, None
             self.symmetric = self.hermitian = False
         else:
-            leaf = getattr(X, "_leaf", None)
-            if leaf is not None and leaf[0] == "dense":
-                self.src, self.op = leaf[1], None
+            src = getattr(X, "_dense_src", None)          # LinearOperator(M): alias M itself (either layout)
+            if src is not None:
+                self.src, self.op = src, None
             else:
                 self.src, self.op = None, X
             self.symmetric, self.hermitian = issymmetric(X), ishermitian(X)

@@ -8,6 +8,8 @@ import numpy as np
 import pytest
 import torch
 
+import oracle
+
 pytestmark = pytest.mark.gpu
 
 
@@ -253,3 +255,66 @@ def test_graph_replay_direct_chain_equals_hipgraph_launch(lo, dev):
             ctx.tune("graph_direct_max", 16)
     want = np.zeros(n); want[idx.cpu().numpy() - 1] = u.cpu().numpy()
     assert np.array_equal(outs[0], want) and np.array_equal(outs[1], want)
+
+
+def test_dense_operator_aliases_row_major_and_column_major_matrices(lo, dev):
+    """LinearOperator(M) aliases M like the reference closure (src/constructors.jl:19-29): an in-place update of M after
+    construction is seen by the next mul!, for torch's default row-major layout (N/T swapped internally, no copy) and
+    for column-major storage alike; kron(LinearOperator(M), B) aliases too."""
+    rng = np.random.default_rng(3)
+    m, n = 37, 53
+    for layout in ("row-major", "column-major"):
+        Mh = rng.standard_normal((m, n))
+        M = torch.from_numpy(Mh).to(dev) if layout == "row-major" else torch.from_numpy(Mh.T.copy()).to(dev).t()
+        assert M.shape == (m, n)
+        op = lo.LinearOperatorFromMatrix(M)
+        x, u = torch.from_numpy(rng.standard_normal(n)).to(dev), torch.from_numpy(rng.standard_normal(m)).to(dev)
+        for _ in range(2):
+            y = torch.from_numpy(rng.standard_normal(m)).to(dev)
+            y0 = y.cpu().numpy().copy()
+            lo.mul(y, op, x, 2.0, -3.0)
+            want = 2.0 * (M.cpu().numpy() @ x.cpu().numpy()) - 3.0 * y0
+            assert np.linalg.norm(y.cpu().numpy() - want) <= 1e-12 * np.linalg.norm(want), layout
+            z = op.T * u
+            wt = M.cpu().numpy().T @ u.cpu().numpy()
+            assert np.linalg.norm(z.cpu().numpy() - wt) <= 1e-12 * np.linalg.norm(wt), layout
+            M.mul_(-1.5).add_(0.25)                       # in place: the operator must follow
+            lo.touched(M)
+        B = torch.from_numpy(rng.standard_normal((4, 5))).to(dev)
+        K = lo.kron(op, B)
+        xk = torch.from_numpy(rng.standard_normal(n * 5)).to(dev)
+        for _ in range(2):
+            want = np.kron(M.cpu().numpy(), B.cpu().numpy()) @ xk.cpu().numpy()
+            got = (K * xk).cpu().numpy()
+            assert np.linalg.norm(got - want) <= 1e-12 * np.linalg.norm(want), layout
+            M.mul_(0.5)
+            lo.touched(M)
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs 2 visible devices (one process, current device != operator device)")
+def test_operator_on_second_device_while_first_is_current(lo):
+    """One process, two GPUs: every entry point binds ctx->device itself (DeviceGuard), so an operator living on cuda:1
+    allocates, launches and copies on cuda:1 while the thread's current device stays cuda:0."""
+    torch.cuda.set_device(0)
+    d1 = torch.device("cuda", 1)
+    rng = np.random.default_rng(4)
+    n, mem = 20_003, 4
+    T1 = lambda a: torch.from_numpy(a).to(d1)
+    B = lo.LBFGSOperator(torch.float64, n, mem=mem, device=d1)
+    O = oracle.LBFGS(n, mem=mem, inverse=False)
+    for _ in range(mem + 2):
+        s = rng.uniform(-1, 1, n); y = s * rng.uniform(0.5, 2.0, n)
+        lo.push(B, T1(s), T1(y)); O.push(s, y)
+        assert torch.cuda.current_device() == 0
+    x = rng.uniform(-1, 1, n)
+    got = (B * T1(x)).cpu().numpy()
+    want = O.mul(np.empty(n), x)
+    assert np.linalg.norm(got - want) <= 1e-10 * np.linalg.norm(want)
+    h = rng.standard_normal(n); h /= np.linalg.norm(h)
+    gh = (lo.opHouseholder(T1(h)) * T1(x)).cpu().numpy()
+    assert np.linalg.norm(gh - oracle.householder_mul(np.empty(n), h, x, 1.0, 0.0)) <= 1e-12 * np.linalg.norm(x)
+    A = T1(rng.standard_normal((300, 300)))
+    Hm = lo.opHermitian(T1(rng.standard_normal(300)), A.t().contiguous().t())
+    lo.mul(torch.empty(300, dtype=torch.float64, device=d1), Hm, T1(rng.standard_normal(300)), 1.0, 0.0)
+    sol = lo.solve_shifted_system(torch.zeros(n, dtype=torch.float64, device=d1), B, T1(x), 0.5)
+    assert torch.isfinite(sol).all() and torch.cuda.current_device() == 0

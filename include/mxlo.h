@@ -78,11 +78,14 @@ extern "C" {
 #define MXLO_ALPHA_REAL  0x20 /* complex leaves: alpha is a Real (Real*Complex is componentwise in Julia,
                                  not Complex(alpha, 0)*z: signed zeros and non-finite values differ)   */
 #define MXLO_BETA_REAL   0x40 /* the same for beta                                            */
+#define MXLO_D_REAL      0x80 /* mxlo_hermitian_mul_c: `d` holds n REAL values of the component type
+                               * (the reference test passes real.(diag(A)), test_linop.jl:362)  */
 
 /* transposition modes for matrix-carrying leaves */
 #define MXLO_OP_N 0 /* prod!   */
 #define MXLO_OP_T 1 /* tprod!  */
-#define MXLO_OP_C 2 /* ctprod! (== T for real dtypes; the matrix-carrying leaves are real-only) */
+#define MXLO_OP_C 2 /* ctprod! (== T for real dtypes)                                     */
+#define MXLO_OP_J 3 /* conj(M)*v — complex entry points only: what a row-major alias of M' needs */
 
 typedef struct mxlo_ctx mxlo_ctx;     /* opaque: device, stream, reduction workspace, tuning  */
 typedef struct mxlo_qn mxlo_qn;       /* opaque: L-BFGS / L-SR1 state resident in HBM         */
@@ -236,6 +239,19 @@ int32_t mxlo_scale_c(mxlo_ctx *ctx, int32_t dtype, void *res, int64_t n, double 
 int32_t mxlo_conj_c(mxlo_ctx *ctx, int32_t dtype, void *res, const void *v, int64_t n);
 /* LinearAlgebra.dot(a, b) = sum conj(a_i) b_i into TWO device doubles (re, im); runs the all-reduce hook. */
 int32_t mxlo_dot_c(mxlo_ctx *ctx, int32_t dtype, const void *a, const void *b, int64_t n, double *out_dev);
+/* Dense LinearOperator(M) on ComplexF64 / ComplexF32 — src/constructors.jl:19-29: prod! = mul!(res, M, v, α, β), tprod!
+ * with transpose(M), ctprod! with M' (op_mode MXLO_OP_N / _T / _C; MXLO_OP_J = conj(M)*v). M is m x n column-major
+ * with leading dimension ld. Reductions in f64, fixed order. (The reference's "Transpose and adjoint" testset runs on
+ * ComplexF64, test/test_linop.jl:385-420.) */
+int32_t mxlo_gemv_c(mxlo_ctx *ctx, int32_t dtype, void *res, const void *M, int64_t m, int64_t n, int64_t ld,
+                    const void *v, double alpha_re, double alpha_im, double beta_re, double beta_im,
+                    int32_t op_mode, int32_t flags);
+/* mulHermitian! on complex data — src/linalg.jl:97-103: res = α*(d.*v + L*v + (v'*L)') (+ β*res), L = tril(A,-1) read
+ * from the caller's column-major A (only the strict lower triangle is touched); d complex, or real with MXLO_D_REAL
+ * (test/test_linop.jl:360-370 builds it from ComplexF64 A and real d). Two passes over the triangle (L*v, L'*v). */
+int32_t mxlo_hermitian_mul_c(mxlo_ctx *ctx, int32_t dtype, void *res, const void *d, const void *A, int64_t lda,
+                             const void *v, int64_t n, double alpha_re, double alpha_im, double beta_re,
+                             double beta_im, int32_t flags);
 /* mulHouseholder! (src/linalg.jl:77-83) for complex h: c = 2*dot(h, v) with h conjugated. */
 int32_t mxlo_householder_mul_c(mxlo_ctx *ctx, int32_t dtype, void *res, const void *h, const void *v, int64_t n,
                                double alpha_re, double alpha_im, double beta_re, double beta_im, int32_t flags);

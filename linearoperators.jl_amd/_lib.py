@@ -22,10 +22,11 @@ RCCL_ID_BYTES = 128
 OK, EINVAL, ESHAPE, EHIP, ENOMEM, ESTATE, EDOMAIN, EREDUCE = range(8)
 F64, F32, C64, C32 = 0, 1, 2, 3
 SHARD_PACK, SHARD_UNPACK = 0, 1
-CONJ_D, ALPHA_REAL, BETA_REAL = 0x10, 0x20, 0x40
+CONJ_D, ALPHA_REAL, BETA_REAL, D_REAL = 0x10, 0x20, 0x40, 0x80
 ALPHA_F64, D_SCALAR, TAIL_BETA, BETA_F64 = 0x1, 0x2, 0x4, 0x8
 SCALARS_F64 = ALPHA_F64 | BETA_F64
 OP_N, OP_T, OP_C = 0, 1, 2
+OP_J = 3
 BLK_DIAG, BLK_DENSE, BLK_EYE, BLK_ZEROS = 0, 1, 2, 3
 QN_LBFGS_INV, QN_LBFGS_FWD, QN_LSR1 = 0, 1, 2
 INV_TWOPASS, INV_REFORDER = 0, 1
@@ -116,6 +117,8 @@ _PROTOS = {
     "mxlo_conj_c": [_vp, _i32, _vp, _vp, _i64],
     "mxlo_dot_c": [_vp, _i32, _vp, _vp, _i64, _vp],
     "mxlo_householder_mul_c": [_vp, _i32, _vp, _vp, _vp, _i64, _dbl, _dbl, _dbl, _dbl, _i32],
+    "mxlo_gemv_c": [_vp, _i32, _vp, _vp, _i64, _i64, _i64, _vp, _dbl, _dbl, _dbl, _dbl, _i32, _i32],
+    "mxlo_hermitian_mul_c": [_vp, _i32, _vp, _vp, _vp, _i64, _vp, _i64, _dbl, _dbl, _dbl, _dbl, _i32],
     "mxlo_householder_mul": [_vp, _i32, _vp, _vp, _vp, _i64, _dbl, _dbl, _i32],
     "mxlo_dot": [_vp, _i32, _vp, _vp, _i64, _vp],
     "mxlo_householder_apply": [_vp, _i32, _vp, _vp, _vp, _i64, _dbl, _dbl, _i32, _vp],

@@ -293,6 +293,247 @@ int32_t chouse(mxlo_ctx *ctx, C<R> *res, const C<R> *h, const C<R> *v, int64_t n
   });
 }
 
+// ---- dense complex leaves: LinearOperator(M) (mul!(res, op(M), v, α, β), src/constructors.jl:19-29) and opHermitian
+// (src/linalg.jl:97-127) on ComplexF64 / ComplexF32 — the element types the reference's own "Hermitian" and "Transpose
+// and adjoint" testsets use (test/test_linop.jl:360-420). Reductions accumulate in f64 with explicit fma (like every
+// reduction of this library), results are rounded once to Complex{R}, then res = α*t (+ β*res) component by component.
+// These are correctness-first instantiations (one wave per column / one lane per row, fixed-order partials): they are
+// not a BASELINE configuration and not tuned like the real-valued GEMV / strip kernels of dense.hip.
+enum { CG_N = 0, CG_T = 1, CG_C = 2, CG_J = 3 };   // M*v, transpose(M)*v, M'*v, conj(M)*v
+
+// column sums: out[j] = sum_{i >= i0(j)} op(M[i,j]) * v[i],  op = conj iff CONJ;  LOWER: strict lower triangle (i > j).
+// One wave per column, 4 rows in flight per lane. RAW: store the sums as Complex{R}; else apply α, β into res.
+template <typename R, typename RA, typename RB, bool BETA0, bool CONJ, bool LOWER, bool RAW>
+__global__ void __launch_bounds__(kBlock)
+cgemv_cols_kernel(C<R> *__restrict__ res, const C<R> *__restrict__ M, int64_t m, int64_t n, int64_t ld,
+                  const C<R> *__restrict__ v, Sc<RA> a, Sc<RB> b) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * (kBlock / 64);
+  for (int64_t j = wave; j < n; j += nwaves) {
+    const C<R> *col = M + j * ld;
+    double ar = 0.0, ai = 0.0, br_ = 0.0, bi_ = 0.0;
+    auto acc = [&](const C<R> &e, const C<R> &x, double &sr, double &si) {
+      const double er = (double)e.re, ei = CONJ ? -(double)e.im : (double)e.im, xr = (double)x.re, xi = (double)x.im;
+      sr = fma(er, xr, sr);
+      sr = fma(-ei, xi, sr);
+      si = fma(er, xi, si);
+      si = fma(ei, xr, si);
+    };
+    int64_t i = (LOWER ? j + 1 : 0) + lane;
+    for (; i + 192 < m; i += 256) {
+      const C<R> e0 = col[i], e1 = col[i + 64], e2 = col[i + 128], e3 = col[i + 192];
+      const C<R> x0 = v[i], x1 = v[i + 64], x2 = v[i + 128], x3 = v[i + 192];
+      acc(e0, x0, ar, ai);
+      acc(e1, x1, br_, bi_);
+      acc(e2, x2, ar, ai);
+      acc(e3, x3, br_, bi_);
+    }
+    for (; i < m; i += 64) acc(col[i], v[i], ar, ai);
+    ar += br_;
+    ai += bi_;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      ar += __shfl_down(ar, off, 64);
+      ai += __shfl_down(ai, off, 64);
+    }
+    if (lane == 0) {
+      const C<R> t((R)ar, (R)ai);
+      if constexpr (RAW) {
+        res[j] = t;
+      } else {
+        RA tr, ti;
+        a.mul(t, tr, ti);
+        res[j] = cfin<R, RA, RB, BETA0>(tr, ti, b.re, b.im, b.real, BETA0 ? C<R>() : res[j]);
+      }
+    }
+  }
+}
+
+// row partials: part[chunk][i] = sum_{j in chunk, (LOWER: j < i)} op(M[i,j]) * v[j]; one lane per row, 4 columns in flight
+template <typename R, bool CONJ, bool LOWER>
+__global__ void __launch_bounds__(kBlock)
+cgemv_rows_partial_kernel(double *__restrict__ part, const C<R> *__restrict__ M, int64_t m, int64_t n, int64_t ld,
+                          const C<R> *__restrict__ v, int64_t cols_per_chunk) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= m) return;
+  const int64_t j0 = (int64_t)blockIdx.y * cols_per_chunk;
+  int64_t j1 = j0 + cols_per_chunk;
+  if (j1 > n) j1 = n;
+  if (LOWER && j1 > i) j1 = i;                        // strict lower triangle: columns j < i
+  double ar = 0.0, ai = 0.0, br_ = 0.0, bi_ = 0.0;
+  auto acc = [&](const C<R> &e, const C<R> &x, double &sr, double &si) {
+    const double er = (double)e.re, ei = CONJ ? -(double)e.im : (double)e.im, xr = (double)x.re, xi = (double)x.im;
+    sr = fma(er, xr, sr);
+    sr = fma(-ei, xi, sr);
+    si = fma(er, xi, si);
+    si = fma(ei, xr, si);
+  };
+  int64_t j = j0;
+  for (; j + 3 < j1; j += 4) {
+    const C<R> e0 = M[i + j * ld], e1 = M[i + (j + 1) * ld], e2 = M[i + (j + 2) * ld], e3 = M[i + (j + 3) * ld];
+    acc(e0, v[j], ar, ai);
+    acc(e1, v[j + 1], br_, bi_);
+    acc(e2, v[j + 2], ar, ai);
+    acc(e3, v[j + 3], br_, bi_);
+  }
+  for (; j < j1; ++j) acc(M[i + j * ld], v[j], ar, ai);
+  double *p = part + ((int64_t)blockIdx.y * m + i) * 2;
+  p[0] = ar + br_;
+  p[1] = ai + bi_;
+}
+
+// fixed-order sum of the chunk partials of a row, then RAW store or the α, β epilogue
+template <typename R, typename RA, typename RB, bool BETA0, bool RAW>
+__global__ void __launch_bounds__(kBlock)
+cgemv_rows_finish_kernel(C<R> *__restrict__ res, const double *__restrict__ part, int64_t m, int nchunks, Sc<RA> a,
+                         Sc<RB> b) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= m) return;
+  double sr = 0.0, si = 0.0;
+  for (int c = 0; c < nchunks; ++c) {
+    const double *p = part + ((int64_t)c * m + i) * 2;
+    sr += p[0];
+    si += p[1];
+  }
+  const C<R> t((R)sr, (R)si);
+  if constexpr (RAW) {
+    res[i] = t;
+  } else {
+    RA tr, ti;
+    a.mul(t, tr, ti);
+    res[i] = cfin<R, RA, RB, BETA0>(tr, ti, b.re, b.im, b.real, BETA0 ? C<R>() : res[i]);
+  }
+}
+
+template <typename R, bool LOWER, bool RAW>
+int32_t cgemv_rows(mxlo_ctx *ctx, C<R> *res, const C<R> *M, int64_t m, int64_t n, int64_t ld, const C<R> *v, bool conj,
+                   const ScalArgs &s) {
+  const int64_t cap = (int64_t)kMaxRedCols * kMaxRedBlocks / 2;        // complex partials in ctx->partials
+  MXLO_REQUIRE(m <= cap, MXLO_ESHAPE, "complex gemv: m = %lld exceeds the partial workspace (%lld rows)", (long long)m,
+               (long long)cap);
+  const int64_t row_blocks = (m + kBlock - 1) / kBlock;
+  int64_t nchunks = (n + 63) / 64;
+  const int64_t want = (int64_t)ctx->num_cu * 8 / (row_blocks > 0 ? row_blocks : 1) + 1;
+  if (nchunks > want) nchunks = want;
+  if (nchunks > cap / (m > 0 ? m : 1)) nchunks = cap / (m > 0 ? m : 1);
+  if (nchunks > 65535) nchunks = 65535;
+  if (nchunks < 1) nchunks = 1;
+  const int64_t cpc = n > 0 ? (n + nchunks - 1) / nchunks : 1;
+  nchunks = n > 0 ? (n + cpc - 1) / cpc : 1;
+  dim3 grid((unsigned)row_blocks, (unsigned)nchunks);
+  if (conj)
+    hipLaunchKernelGGL((cgemv_rows_partial_kernel<R, true, LOWER>), grid, dim3(kBlock), 0, ctx->stream, ctx->partials, M, m,
+                       n, ld, v, cpc);
+  else
+    hipLaunchKernelGGL((cgemv_rows_partial_kernel<R, false, LOWER>), grid, dim3(kBlock), 0, ctx->stream, ctx->partials, M, m,
+                       n, ld, v, cpc);
+  MXLO_LAUNCH_CHECK();
+  return dispatch_c<R>(s, [&]<typename RA, typename RB, bool B0>() -> int32_t {
+    const Sc<RA> a{(RA)s.are, (RA)s.aim, s.a_real};
+    const Sc<RB> b{(RB)s.bre, (RB)s.bim, s.b_real};
+    hipLaunchKernelGGL((cgemv_rows_finish_kernel<R, RA, RB, B0, RAW>), dim3((unsigned)row_blocks), dim3(kBlock), 0,
+                       ctx->stream, res, ctx->partials, m, (int)nchunks, a, b);
+    MXLO_LAUNCH_CHECK();
+    return MXLO_OK;
+  });
+}
+
+template <typename R, bool LOWER, bool RAW>
+int32_t cgemv_cols(mxlo_ctx *ctx, C<R> *res, const C<R> *M, int64_t m, int64_t n, int64_t ld, const C<R> *v, bool conj,
+                   const ScalArgs &s) {
+  int64_t blocks = (n + 3) / 4;
+  const int64_t cap = (int64_t)ctx->num_cu * 16;
+  if (blocks > cap) blocks = cap;
+  if (blocks < 1) blocks = 1;
+  return dispatch_c<R>(s, [&]<typename RA, typename RB, bool B0>() -> int32_t {
+    const Sc<RA> a{(RA)s.are, (RA)s.aim, s.a_real};
+    const Sc<RB> b{(RB)s.bre, (RB)s.bim, s.b_real};
+    if (conj)
+      hipLaunchKernelGGL((cgemv_cols_kernel<R, RA, RB, B0, true, LOWER, RAW>), dim3((unsigned)blocks), dim3(kBlock), 0,
+                         ctx->stream, res, M, m, n, ld, v, a, b);
+    else
+      hipLaunchKernelGGL((cgemv_cols_kernel<R, RA, RB, B0, false, LOWER, RAW>), dim3((unsigned)blocks), dim3(kBlock), 0,
+                         ctx->stream, res, M, m, n, ld, v, a, b);
+    MXLO_LAUNCH_CHECK();
+    return MXLO_OK;
+  });
+}
+
+template <typename R>
+int32_t cgemv_any(mxlo_ctx *ctx, C<R> *res, const C<R> *M, int64_t m, int64_t n, int64_t ld, const C<R> *v, int mode,
+                  const ScalArgs &s, int32_t flags) {
+  const bool rows = mode == CG_N || mode == CG_J, conj = mode == CG_C || mode == CG_J;
+  const int64_t nres = rows ? m : n, nin = rows ? n : m;
+  if (nres == 0) return MXLO_OK;
+  if (nin == 0) {   // empty sum: res = β*res (or 0)
+    if (s.bre == 0 && s.bim == 0) return cfill<R>(ctx, res, nres, C<R>());
+    return cscale<R>(ctx, res, nres, s.bre, s.bim, s.b_real, s.b64);
+  }
+  if (rows) return cgemv_rows<R, false, false>(ctx, res, M, m, n, ld, v, conj, s);
+  return cgemv_cols<R, false, false>(ctx, res, M, m, n, ld, v, conj, s);
+}
+
+// res_i = α*((d_i*v_i + t1_i) + t2_i) (+ β*res_i): the sum of src/linalg.jl:99-101 in Complex{R}, in that order
+template <typename R, typename RA, typename RB, bool BETA0, bool DREAL>
+__global__ void __launch_bounds__(kBlock)
+cherm_final_kernel(C<R> *__restrict__ res, const void *__restrict__ dptr, const C<R> *__restrict__ v,
+                   const C<R> *__restrict__ t1, const C<R> *__restrict__ t2, int64_t n, Sc<RA> a, Sc<RB> b) {
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+    R pr, pi;
+    if constexpr (DREAL) {
+      const R d = static_cast<const R *>(dptr)[i];
+      pr = d * v[i].re;
+      pi = d * v[i].im;
+    } else {
+      const C<R> d = static_cast<const C<R> *>(dptr)[i];
+      pr = (d.re * v[i].re) - (d.im * v[i].im);
+      pi = (d.re * v[i].im) + (d.im * v[i].re);
+    }
+    const C<R> inner((pr + t1[i].re) + t2[i].re, (pi + t1[i].im) + t2[i].im);
+    RA tr, ti;
+    a.mul(inner, tr, ti);
+    res[i] = cfin<R, RA, RB, BETA0>(tr, ti, b.re, b.im, b.real, BETA0 ? C<R>() : res[i]);
+  }
+}
+
+template <typename R>
+int32_t chermitian(mxlo_ctx *ctx, C<R> *res, const void *d, bool d_real, const C<R> *A, int64_t lda, const C<R> *v,
+                   int64_t n, const ScalArgs &s) {
+  if (n == 0) return MXLO_OK;
+  const size_t need = sizeof(C<R>) * 2 * (size_t)n;           // t1 = L*v, t2 = L'*v
+  if (ctx->scratch_bytes < need) {            // stream-ordered users only: drain before the buffer is replaced
+    if (ctx->scratch) {
+      MXLO_HIP(hipStreamSynchronize(ctx->stream));
+      MXLO_HIP(hipFree(ctx->scratch));
+    }
+    ctx->scratch = nullptr;
+    ctx->scratch_bytes = 0;
+    hipError_t e = hipMalloc(&ctx->scratch, need);
+    MXLO_REQUIRE(e == hipSuccess, MXLO_ENOMEM, "complex opHermitian scratch: %s", hipGetErrorString(e));
+    ctx->scratch_bytes = need;
+    ++ctx->scratch_generation;     // graphs that recorded the old workspace pointer are stale now
+  }
+  if (ctx->capturing) ctx->scratch_used_in_capture = true;
+  C<R> *t1 = (C<R> *)ctx->scratch, *t2 = t1 + n;
+  ScalArgs one{1.0, 0.0, 0.0, 0.0, true, true, true, true};
+  MXLO_TRY((cgemv_rows<R, true, true>(ctx, t1, A, n, n, lda, v, false, one)));     // L*v
+  MXLO_TRY((cgemv_cols<R, true, true>(ctx, t2, A, n, n, lda, v, true, one)));      // (v'*L)' = L'*v
+  const int grid = grid_for(ctx, n, kBlock, 8);
+  return dispatch_c<R>(s, [&]<typename RA, typename RB, bool B0>() -> int32_t {
+    const Sc<RA> a{(RA)s.are, (RA)s.aim, s.a_real};
+    const Sc<RB> b{(RB)s.bre, (RB)s.bim, s.b_real};
+    if (d_real)
+      hipLaunchKernelGGL((cherm_final_kernel<R, RA, RB, B0, true>), dim3(grid), dim3(kBlock), 0, ctx->stream, res, d, v,
+                         (const C<R> *)t1, (const C<R> *)t2, n, a, b);
+    else
+      hipLaunchKernelGGL((cherm_final_kernel<R, RA, RB, B0, false>), dim3(grid), dim3(kBlock), 0, ctx->stream, res, d, v,
+                         (const C<R> *)t1, (const C<R> *)t2, n, a, b);
+    MXLO_LAUNCH_CHECK();
+    return MXLO_OK;
+  });
+}
+
 }  // namespace
 
 #define CHECK_C(name)                                                                                        \
@@ -377,4 +618,33 @@ MXLO_API int32_t mxlo_householder_mul_c(mxlo_ctx *ctx, int32_t dtype, void *res,
                           scal_args(8, alpha_re, alpha_im, beta_re, beta_im, flags));
   return chouse<float>(ctx, (C<float> *)res, (const C<float> *)h, (const C<float> *)v, n,
                        scal_args(4, alpha_re, alpha_im, beta_re, beta_im, flags));
+}
+
+MXLO_API int32_t mxlo_gemv_c(mxlo_ctx *ctx, int32_t dtype, void *res, const void *M, int64_t m, int64_t n, int64_t ld,
+                             const void *v, double alpha_re, double alpha_im, double beta_re, double beta_im,
+                             int32_t op_mode, int32_t flags) {
+  CHECK_C("mxlo_gemv_c");
+  MXLO_REQUIRE(m >= 0 && n >= 0 && ld >= (m > 1 ? m : 1), MXLO_ESHAPE, "mxlo_gemv_c: bad shape");
+  MXLO_REQUIRE(op_mode >= MXLO_OP_N && op_mode <= MXLO_OP_J, MXLO_EINVAL, "mxlo_gemv_c: bad op_mode %d", op_mode);
+  const int64_t nres = (op_mode == MXLO_OP_N || op_mode == MXLO_OP_J) ? m : n;
+  MXLO_REQUIRE(nres == 0 || (res && (m == 0 || n == 0 || (M && v))), MXLO_EINVAL, "mxlo_gemv_c: NULL operand");
+  if (dtype == MXLO_C64)
+    return cgemv_any<double>(ctx, (C<double> *)res, (const C<double> *)M, m, n, ld, (const C<double> *)v, op_mode,
+                             scal_args(8, alpha_re, alpha_im, beta_re, beta_im, flags), flags);
+  return cgemv_any<float>(ctx, (C<float> *)res, (const C<float> *)M, m, n, ld, (const C<float> *)v, op_mode,
+                          scal_args(4, alpha_re, alpha_im, beta_re, beta_im, flags), flags);
+}
+
+MXLO_API int32_t mxlo_hermitian_mul_c(mxlo_ctx *ctx, int32_t dtype, void *res, const void *d, const void *A, int64_t lda,
+                                      const void *v, int64_t n, double alpha_re, double alpha_im, double beta_re,
+                                      double beta_im, int32_t flags) {
+  CHECK_C("mxlo_hermitian_mul_c");
+  MXLO_REQUIRE(n >= 0 && lda >= (n > 1 ? n : 1), MXLO_ESHAPE, "mxlo_hermitian_mul_c: bad shape");
+  MXLO_REQUIRE(n == 0 || (res && d && A && v), MXLO_EINVAL, "mxlo_hermitian_mul_c: NULL operand");
+  const bool d_real = (flags & MXLO_D_REAL) != 0;
+  if (dtype == MXLO_C64)
+    return chermitian<double>(ctx, (C<double> *)res, d, d_real, (const C<double> *)A, lda, (const C<double> *)v, n,
+                              scal_args(8, alpha_re, alpha_im, beta_re, beta_im, flags));
+  return chermitian<float>(ctx, (C<float> *)res, d, d_real, (const C<float> *)A, lda, (const C<float> *)v, n,
+                           scal_args(4, alpha_re, alpha_im, beta_re, beta_im, flags));
 }

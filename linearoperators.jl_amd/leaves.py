@@ -266,6 +266,11 @@ def mulHermitian(res, d, A, v, alpha, beta):
     """mulHermitian! — src/linalg.jl:97-103 with L = tril(A,-1) taken from A in the kernel."""
     ctx = get_ctx(res.device)
     n = res.numel()
+    if res.dtype.is_complex:
+        fl = scalar_flags(res.dtype, alpha, beta) | (0 if d.dtype.is_complex else _lib.D_REAL)
+        _lib.call("mxlo_hermitian_mul_c", ctx.handle, dtype_code(res.dtype, True), ptr(res), ptr(d), ptr(A), A.stride(1),
+                  ptr(v), n, *_c4(alpha, beta), fl)
+        return
     _lib.call("mxlo_hermitian_mul", ctx.handle, dtype_code(res.dtype), ptr(res), ptr(d), ptr(A), A.stride(1),
               ptr(v), n, float(alpha), float(beta), scalar_flags(res.dtype, alpha, beta))
 
@@ -284,7 +289,9 @@ def _colmajor(M: torch.Tensor) -> torch.Tensor:
 
 
 def opHermitian(*args):
-    """opHermitian(d, A) / opHermitian(A) — src/linalg.jl:105-127."""
+    """opHermitian(d, A) / opHermitian(A) — src/linalg.jl:105-127. Complex A (ComplexF64 / ComplexF32): `L'` is the
+    conjugate transpose, symmetric = isreal(A) = false, hermitian = true; d may be real (the reference test passes
+    real.(diag(A)), test/test_linop.jl:362) or complex."""
     if len(args) == 1:
         A = _colmajor(args[0])
         d = torch.diagonal(A).clone()
@@ -296,6 +303,19 @@ def opHermitian(*args):
     if not (m == n == d.numel()):
         raise LinearOperatorException("shape mismatch")
     U = torch.promote_types(d.dtype, A.dtype)
+    if U.is_complex:
+        dtype_code(U, True)
+        comp = torch.float64 if U == torch.complex128 else torch.float32
+        if A.dtype != U:
+            A = _colmajor(A.to(U))
+        if d.dtype.is_complex:
+            d = d if d.dtype == U else d.to(U)
+        else:
+            d = d if d.dtype == comp else d.to(comp)      # a real diagonal stays real: d .* v is Real * Complex
+        prod = lambda res, v, a, b: mulHermitian(res, d, A, v, a, b)
+        op = LinearOperator(U, m, m, False, True, prod, None, None, S=Storage(U, A.device))
+        op._deps = (d, A)
+        return op
     if d.dtype != U:
         d = d.to(U)
     if A.dtype != U:
@@ -328,23 +348,34 @@ def LinearOperatorFromMatrix(M: torch.Tensor, symmetric: bool = False, hermitian
     when it is column-major or row-major (a row-major M is the column-major storage of Mᵀ: N and T swap)."""
     nrow, ncol = M.shape
     St, tr = _stored_colmajor(M)
-    dtype_code(St.dtype)
+    cplx = St.dtype.is_complex
+    dtype_code(St.dtype, True)
     sm, sn = St.shape
     ld = St.stride(1) if sn > 1 else max(1, sm)
-    fwd, bwd = (_lib.OP_T, _lib.OP_N) if tr else (_lib.OP_N, _lib.OP_T)
+    if cplx:
+        # stored = M (tr False) or transpose(M) (tr True, row-major alias):  M*v, transpose(M)*u, M'*w
+        fwd, bwd, cbwd = (_lib.OP_T, _lib.OP_N, _lib.OP_J) if tr else (_lib.OP_N, _lib.OP_T, _lib.OP_C)
 
-    def gemv(res, v, a, b, mode):
-        ctx = get_ctx(res.device)
-        _lib.call("mxlo_gemv", ctx.handle, dtype_code(St.dtype), ptr(res), ptr(St), sm, sn, ld, ptr(v), float(a),
-                  float(b), mode, scalar_flags(res.dtype, a, b))
+        def gemv(res, v, a, b, mode):
+            ctx = get_ctx(res.device)
+            _lib.call("mxlo_gemv_c", ctx.handle, dtype_code(St.dtype, True), ptr(res), ptr(St), sm, sn, ld, ptr(v),
+                      *_c4(a, b), mode, scalar_flags(res.dtype, a, b))
+    else:
+        fwd, bwd = (_lib.OP_T, _lib.OP_N) if tr else (_lib.OP_N, _lib.OP_T)
+        cbwd = bwd                                                     # real element types: C == T
+
+        def gemv(res, v, a, b, mode):
+            ctx = get_ctx(res.device)
+            _lib.call("mxlo_gemv", ctx.handle, dtype_code(St.dtype), ptr(res), ptr(St), sm, sn, ld, ptr(v), float(a),
+                      float(b), mode, scalar_flags(res.dtype, a, b))
 
     prod = lambda res, v, a, b: gemv(res, v, a, b, fwd)
     tprod = lambda res, u, a, b: gemv(res, u, a, b, bwd)
-    ctprod = lambda res, w, a, b: gemv(res, w, a, b, bwd)          # real element types: C == T
+    ctprod = lambda res, w, a, b: gemv(res, w, a, b, cbwd)
     op = LinearOperator(St.dtype, nrow, ncol, symmetric, hermitian, prod, tprod, ctprod,
                         S=S if S is not None else Storage(St.dtype, St.device))
-    if not tr:
-        op._leaf = ("dense", St, ld)                 # block-diagonal descriptor tables take column-major blocks as they are
+    if not tr and not cplx:
+        op._leaf = ("dense", St, ld)                 # block-diagonal descriptor tables take column-major real blocks as they are
     op._dense_src = M
     op._deps = (M,)
     return op

@@ -67,7 +67,7 @@ TAIL_BETA = 0x4
 
 def build(force: bool = False) -> str:
     """Compile the C restatement with gcc (``make -C oracle``)."""
-    src_m = max(os.path.getmtime(os.path.join(_HERE, f)) for f in ("lo_oracle.c", "lo_oracle_impl.h"))
+    src_m = max(os.path.getmtime(os.path.join(_HERE, f)) for f in ("lo_oracle.c", "lo_oracle_impl.h", "lo_oracle_cplx.h"))
     if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < src_m:
         subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "all"])
     return _LIB_PATH
@@ -224,9 +224,20 @@ def householder_mul(res, h, v, alpha, beta, flags=0):
 
 
 def hermitian_mul(res, d, A, v, alpha, beta, flags=0):
-    """mulHermitian! with L = tril(A,-1) (src/linalg.jl:97-116). A: (n,n) array, any order."""
-    dt = _check(res, d, v)
+    """mulHermitian! with L = tril(A,-1) (src/linalg.jl:97-116). A: (n,n) array, any order. Complex res: d real or complex."""
     n = res.size
+    if res.dtype.kind == "c":
+        dt = res.dtype
+        assert v.dtype == dt
+        rdt = np.float64 if dt == np.complex128 else np.float32
+        d_real = d.dtype.kind != "c"
+        dd = np.ascontiguousarray(d, dtype=rdt if d_real else dt)
+        Af = np.asfortranarray(A, dtype=dt)
+        t1, t2 = np.empty(n, dt), np.empty(n, dt)
+        _fn("orc_hermitian_mul", dt)(_p(res), _p(dd), _i32(int(d_real)), _p(Af), _i64(n), _p(v), _i64(n), *_c4(alpha, beta),
+                                     _i32(flags), _p(t1), _p(t2))
+        return res
+    dt = _check(res, d, v)
     Af = np.asfortranarray(A, dtype=dt)
     t1 = np.empty(n, dt)
     t2 = np.empty(n, dt)
@@ -253,6 +264,17 @@ def extend(res, u, idx):
 
 
 def gemv(res, M, v, alpha, beta, trans=False, flags=0):
+    """mul!(res, op(M), v, α, β) of a dense LinearOperator(M) (src/constructors.jl:19-29). Real data: trans False/True.
+    Complex data: trans in {False|"N", True|"T", "C" (adjoint), "J" (conj(M)*v)}."""
+    if res.dtype.kind == "c":
+        dt = res.dtype
+        assert v.dtype == dt
+        mode = {False: 0, True: 1, "N": 0, "T": 1, "C": 2, "J": 3}[trans]
+        Mf = np.asfortranarray(M, dtype=dt)
+        m, n = Mf.shape
+        tmp = np.empty(res.size, dt)
+        _fn("orc_gemv", dt)(_p(res), _p(Mf), _i64(m), _i64(n), _i64(m), _p(v), *_c4(alpha, beta), _i32(mode), _i32(flags), _p(tmp))
+        return res
     dt = _check(res, v)
     Mf = np.asfortranarray(M, dtype=dt)
     m, n = Mf.shape

@@ -182,6 +182,81 @@ void CFN(orc_householder_mul)(R *res, const R *h, const R *v, int64_t n, double 
 #undef BODY
 }
 
+/* res = α*t (+ β*res) for a length-nr complex vector t (shared epilogue of the dense leaves below) */
+static void CFN(orc_cplx_epilogue)(R *res, const R *t, int64_t nr, double are, double aim, double bre, double bim,
+                                   int32_t flags) {
+  const int a_real = (flags & ORC_ALPHA_REAL) != 0, b_real = (flags & ORC_BETA_REAL) != 0;
+  const int b0 = (bre == 0 && (b_real || bim == 0));
+#define BODY(RA, RB)                                                                             \
+  {                                                                                              \
+    const RA ar = (RA)are, ai = (RA)aim;                                                         \
+    const RB br = (RB)bre, bi = (RB)bim;                                                         \
+    for (int64_t i = 0; i < nr; ++i) {                                                           \
+      RA tr, ti;                                                                                 \
+      SMUL(RA, ar, ai, a_real, t[2 * i], t[2 * i + 1], tr, ti);                                  \
+      if (b0) {                                                                                  \
+        res[2 * i] = (R)tr;                                                                      \
+        res[2 * i + 1] = (R)ti;                                                                  \
+      } else {                                                                                   \
+        RB wr, wi;                                                                               \
+        SMUL(RB, br, bi, b_real, res[2 * i], res[2 * i + 1], wr, wi);                            \
+        res[2 * i] = (R)(tr + wr);                                                               \
+        res[2 * i + 1] = (R)(ti + wi);                                                           \
+      }                                                                                          \
+    }                                                                                            \
+  }
+  WITH_RAB(BODY);
+#undef BODY
+}
+
+/* dense LinearOperator(M) on Complex{R} — src/constructors.jl:19-29: prod! = mul!(res, M, v, α, β), tprod! with
+ * transpose(M), ctprod! with adjoint(M). mode 0: M*v, 1: transpose(M)*v, 2: M'*v, 3: conj(M)*v (what a row-major
+ * alias of M' needs). tmp: 2*length(res) scalars. Plain loops in R (BLAS order is unspecified: tolerance-pinned). */
+void CFN(orc_gemv)(R *res, const R *M, int64_t m, int64_t n, int64_t ld, const R *v, double are, double aim,
+                   double bre, double bim, int32_t mode, int32_t flags, R *tmp) {
+  const int trans = (mode == 1 || mode == 2), cj = (mode == 2 || mode == 3);
+  const int64_t nr = trans ? n : m;
+  for (int64_t i = 0; i < 2 * nr; ++i) tmp[i] = 0;
+  for (int64_t j = 0; j < n; ++j)
+    for (int64_t i = 0; i < m; ++i) {
+      const R ar_ = M[2 * (i + j * ld)], ai_ = cj ? -M[2 * (i + j * ld) + 1] : M[2 * (i + j * ld) + 1];
+      const R *x = trans ? v + 2 * i : v + 2 * j;
+      R *o = trans ? tmp + 2 * j : tmp + 2 * i;
+      o[0] += (ar_ * x[0]) - (ai_ * x[1]);
+      o[1] += (ar_ * x[1]) + (ai_ * x[0]);
+    }
+  CFN(orc_cplx_epilogue)(res, tmp, nr, are, aim, bre, bim, flags);
+}
+
+/* mulHermitian! — src/linalg.jl:97-103 with L = tril(A, -1) (:111): res .= α .* (d .* v .+ L*v .+ (v'*L)') (.+ β .* res).
+ * (v'*L)'[j] = sum_{i>j} conj(L[i,j]) * v[i]. d is Real (d_real: n scalars, the reference test passes real.(diag(A)))
+ * or Complex (2n scalars). t1, t2: 2n scalars each. */
+void CFN(orc_hermitian_mul)(R *res, const R *d, int32_t d_real, const R *A, int64_t lda, const R *v, int64_t n,
+                            double are, double aim, double bre, double bim, int32_t flags, R *t1, R *t2) {
+  for (int64_t i = 0; i < 2 * n; ++i) t1[i] = t2[i] = 0;
+  for (int64_t j = 0; j < n; ++j)
+    for (int64_t i = j + 1; i < n; ++i) {
+      const R lr = A[2 * (i + j * lda)], li = A[2 * (i + j * lda) + 1];
+      t1[2 * i] += (lr * v[2 * j]) - (li * v[2 * j + 1]);          /* L*v */
+      t1[2 * i + 1] += (lr * v[2 * j + 1]) + (li * v[2 * j]);
+      t2[2 * j] += (lr * v[2 * i]) + (li * v[2 * i + 1]);          /* conj(L[i,j]) * v[i] */
+      t2[2 * j + 1] += (lr * v[2 * i + 1]) - (li * v[2 * i]);
+    }
+  for (int64_t i = 0; i < n; ++i) { /* inner = (d.*v .+ L*v) .+ (v'*L)' in R, reusing t1 */
+    R pr, pi;
+    if (d_real) {
+      pr = d[i] * v[2 * i];
+      pi = d[i] * v[2 * i + 1];
+    } else {
+      pr = (d[2 * i] * v[2 * i]) - (d[2 * i + 1] * v[2 * i + 1]);
+      pi = (d[2 * i] * v[2 * i + 1]) + (d[2 * i + 1] * v[2 * i]);
+    }
+    t1[2 * i] = (pr + t1[2 * i]) + t2[2 * i];
+    t1[2 * i + 1] = (pi + t1[2 * i + 1]) + t2[2 * i + 1];
+  }
+  CFN(orc_cplx_epilogue)(res, t1, n, are, aim, bre, bim, flags);
+}
+
 #undef SMUL
 #undef WITH_RAB
 #undef CFN

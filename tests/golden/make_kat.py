@@ -271,6 +271,37 @@ cases.append(dict(
     expect_mul5=fl([F(3, 2) * a + F(-1, 2) * r for a, r in zip(matvec(Ch, xh), r0h)]),
     tol="1e-13 relative (exact in binary up to summation order)"))
 
+# ---------------------------------------------------------------- opHermitian on ComplexF64 (test_linop.jl:360-370)
+# A = simple_matrix(ComplexF64, n, n); d = real.(diag(A)); A = tril(A, -1); C = A + A' + diagm(0 => d); H = opHermitian(d, A)
+# H*v == C*v, transpose(H)*v == transpose(C)*v, H'*v == C*v with v = simple_vector(ComplexF64, n) — and a second v with
+# imaginary parts. The test draws A with rand; here A[i][j] = ((3i - 2j + 1)/8, (i + 2j - 3)/8) (Gaussian dyadic).
+def cmatvec(Mx, x):
+    out = []
+    for row in Mx:
+        acc = (F(0), F(0))
+        for a, b in zip(row, x):
+            acc = cadd(acc, cmul(a, b))
+        out.append(acc)
+    return out
+
+
+nc = 7
+Ac = [[(F(3 * (i + 1) - 2 * (j + 1) + 1, 8), F((i + 1) + 2 * (j + 1) - 3, 8)) for j in range(nc)] for i in range(nc)]
+dc = [F(i + 1, 2) - F(3, 4) for i in range(nc)]                         # real.(diag(.)): a REAL diagonal
+zero = (F(0), F(0))
+Cc = [[(Ac[i][j] if i > j else (cconj(Ac[j][i]) if j > i else (dc[i], F(0)))) for j in range(nc)] for i in range(nc)]
+Cct = [[Cc[j][i] for j in range(nc)] for i in range(nc)]                # transpose(C) (no conjugation)
+for nm, vc in (("simple", csimple(nc)), ("dyadic", cpattern(nc, 2, 5))):
+    r0c = cpattern(nc, 3, 1)
+    al, be = (F(3, 2), F(-1)), (F(-1, 2), F(1, 4))                      # complex alpha, beta
+    cases.append(dict(
+        name=f"opHermitian_complex_{nm}", ref="test/test_linop.jl:360-370 (ComplexF64, deterministic A)", kind="chermitian",
+        n=nc, A=[cfl(r) for r in Ac], d=fl(dc), v=cfl(vc), expect_apply=cfl(cmatvec(Cc, vc)),
+        expect_tapply=cfl(cmatvec(Cct, vc)), expect_ctapply=cfl(cmatvec(Cc, vc)),
+        alpha=[float(al[0]), float(al[1])], beta=[float(be[0]), float(be[1])], res0=cfl(r0c),
+        expect_mul5=cfl([cadd(cmul(al, a), cmul(be, r)) for a, r in zip(cmatvec(Cc, vc), r0c)]),
+        C=[cfl(r) for r in Cc], tol="1e-13 relative (exact in binary up to summation order)"))
+
 # ---------------------------------------------------------------- kron (test_kron.jl:9-36, Float64 factors)
 # K = kron(A, B) (Base.kron); T*x == K*x, T'*x == K'*x, transpose(T)*x == transpose(K)*x for 2x3 factors.
 Ak = [[F(1), F(-1, 2), F(3, 4)], [F(2), F(1, 4), F(-5, 8)]]

@@ -226,8 +226,140 @@ def test_complex_diag_full_size_properties(lo, dev):
 
 
 def test_real_only_leaves_reject_complex(lo, dev):
+    """Not instantiated for complex element types: kron's MFMA GEMMs and the quasi-Newton operators — loud TypeError."""
     A = torch.eye(4, dtype=torch.complex128, device=dev)
     with pytest.raises(TypeError):
-        lo.LinearOperatorFromMatrix(A)
+        K = lo.kron(A, A)
+        K * torch.ones(16, dtype=torch.complex128, device=dev)
     with pytest.raises(TypeError):
         lo.LBFGSOperator(torch.complex128, 8, device=dev)
+
+
+# ------------------------------------------------------------------------------------------ dense complex leaves
+def cmat(rng, m, n, dt):
+    return (rng.standard_normal((m, n)) + 1j * rng.standard_normal((m, n))).astype(dt)
+
+
+def test_kat_complex_hermitian(lo, dev, kat):
+    """test/test_linop.jl:360-370 with its ComplexF64 inputs: H = opHermitian(real.(diag(A)), tril(A,-1)); H*v == C*v,
+    transpose(H)*v == transpose(C)*v, H'*v == C*v, 5-arg mul! with complex α, β; C itself as LinearOperator(C)."""
+    cs = [c for c in kat if c["kind"] == "chermitian"]
+    assert len(cs) == 2
+    for c in cs:
+        A = np.array([[complex(*e) for e in row] for row in c["A"]])
+        Cm = np.array([[complex(*e) for e in row] for row in c["C"]])
+        d, v, r0 = np.array(c["d"]), cx(c["v"]), cx(c["res0"])
+        At = T(A.T.copy(), dev).t()                                   # column-major storage of A
+        H = lo.opHermitian(T(d, dev), At)
+        assert lo.ishermitian(H) and not lo.issymmetric(H)
+        want, want_t = cx(c["expect_apply"]), cx(c["expect_tapply"])
+        assert rel((H * T(v, dev)).cpu().numpy(), want) <= 1e-13
+        assert rel((H.T * T(v, dev)).cpu().numpy(), want_t) <= 1e-13
+        assert rel((H.H * T(v, dev)).cpu().numpy(), want) <= 1e-13
+        res = T(r0.copy(), dev)
+        lo.mul(res, H, T(v, dev), complex(*c["alpha"]), complex(*c["beta"]))
+        assert rel(res.cpu().numpy(), cx(c["expect_mul5"])) <= 1e-13
+        for M in (T(Cm, dev), T(Cm.T.copy(), dev).t()):               # row-major alias and column-major storage
+            op = lo.LinearOperatorFromMatrix(M)
+            assert rel((op * T(v, dev)).cpu().numpy(), want) <= 1e-13
+            assert rel((op.T * T(v, dev)).cpu().numpy(), want_t) <= 1e-13
+            assert rel((op.H * T(v, dev)).cpu().numpy(), want) <= 1e-13        # C is Hermitian
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.complex128, 1e-12), (torch.complex64, 3e-5)])
+@pytest.mark.parametrize("m,n", [(1, 1), (3, 2), (65, 7), (257, 300), (1000, 777), (31, 2049)])
+def test_complex_dense_gemv_all_modes_both_layouts(lo, dev, dtype, tol, m, n):
+    """LinearOperator(M) on complex data: M*v, transpose(M)*u, M'*w with real / complex α, β (β = 0 must not read res),
+    for column-major storage and for torch's row-major default (aliased: N/T swapped, M' through conj(M)*w)."""
+    dt = NPC[dtype]
+    rng = np.random.default_rng(m * 1000 + n)
+    Mh = cmat(rng, m, n, dt)
+    v, u = crand(rng, n, dt), crand(rng, m, dt)
+    for layout in ("col", "row"):
+        M = T(Mh, dev) if layout == "row" else T(Mh.T.copy(), dev).t()
+        op = lo.LinearOperatorFromMatrix(M)
+        for (a, b) in ((complex(1), complex(0)), (2.0, -3.0), (1.5 - 0.5j, 0.25 + 2j), (np.float32(0.5), 1j)):
+            fl = oracle.scalar_flags(dt, a, b)
+            for o, x, mode, nr in ((op, v, "N", m), (op.T, u, "T", n), (op.H, u, "C", n)):
+                r0 = crand(rng, nr, dt)
+                if b == 0:
+                    r0[:] = np.nan + 1j * np.nan
+                res = T(r0.copy(), dev)
+                lo.mul(res, o, T(x, dev), a, b)
+                want = oracle.gemv(r0.copy() if b != 0 else np.zeros(nr, dt), Mh, x, a, b, trans=mode, flags=fl)
+                assert rel(res.cpu().numpy(), want) <= tol, (layout, mode, a, b)
+    # the matrix is aliased: an in-place update is seen
+    M = T(Mh, dev)
+    op = lo.LinearOperatorFromMatrix(M)
+    M.mul_(2.0)
+    lo.touched(M)
+    assert rel((op * T(v, dev)).cpu().numpy(), 2.0 * (Mh.astype(np.complex128) @ v)) <= tol
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.complex128, 1e-12), (torch.complex64, 3e-5)])
+@pytest.mark.parametrize("n", [1, 2, 5, 64, 257, 1000, 2051])
+def test_complex_hermitian_parity(lo, dev, dtype, tol, n):
+    """opHermitian(d, A) on complex A with a real and with a complex diagonal against the oracle's statement-order
+    restatement and against the dense Hermitian matrix; transpose / adjoint through the wrapper routing; views with a
+    leading dimension."""
+    dt = NPC[dtype]
+    rdt = np.float64 if dt == np.complex128 else np.float32
+    rng = np.random.default_rng(n)
+    big = cmat(rng, n + 3, n + 2, dt)                                   # A is a view into a larger column-major array
+    bigd = T(big.T.copy(), dev).t()
+    Ad = bigd[1:n + 1, 0:n]
+    A = big[1:n + 1, 0:n]
+    v = crand(rng, n, dt)
+    L = np.tril(A.astype(np.complex128), -1)
+    for d in (rng.standard_normal(n).astype(rdt), crand(rng, n, dt)):
+        H = lo.opHermitian(T(d, dev), Ad)
+        Cm = L + L.conj().T + np.diag(d.astype(np.complex128))
+        for (a, b) in ((complex(1), complex(0)), (2.0, -3.0), (1.5 - 0.5j, 0.25 + 2j)):
+            r0 = crand(rng, n, dt)
+            res = T(r0.copy(), dev)
+            lo.mul(res, H, T(v, dev), a, b)
+            want = oracle.hermitian_mul(r0.copy(), d, A, v, a, b, flags=oracle.scalar_flags(dt, a, b))
+            assert rel(res.cpu().numpy(), want) <= tol, (n, a, b)
+            dense = a * (Cm @ v.astype(np.complex128)) + b * r0.astype(np.complex128)
+            assert rel(res.cpu().numpy(), dense) <= 10 * tol
+        if np.isrealobj(d):                                             # Hermitian matrix: H' == H, transpose(H) == conj(H)
+            assert rel((H.H * T(v, dev)).cpu().numpy(), Cm @ v) <= 10 * tol
+            assert rel((H.T * T(v, dev)).cpu().numpy(), Cm.T @ v) <= 10 * tol
+    Hc = lo.opHermitian(Ad)                                             # opHermitian(A): d = diag(A) (complex)
+    Cm = L + L.conj().T + np.diag(np.diag(A).astype(np.complex128))
+    assert rel((Hc * T(v, dev)).cpu().numpy(), Cm @ v) <= 10 * tol
+
+
+def test_complex_dense_in_operator_trees_and_contract(lo, dev):
+    """complex dense leaves compose with the complex elementwise leaves (sum, product, cat) against dense NumPy, and a
+    warmed apply issues launches only."""
+    import ctypes as C
+    rng = np.random.default_rng(12)
+    n = 300
+    Mh, dh, hh = cmat(rng, n, n, np.complex128), crand(rng, n, np.complex128), crand(rng, n, np.complex128)
+    hh /= np.linalg.norm(hh)
+    M, D, Hh = lo.LinearOperatorFromMatrix(T(Mh, dev)), lo.opDiagonal(T(dh, dev)), lo.opHouseholder(T(hh, dev))
+    A = cmat(rng, n, n, np.complex128)
+    Hm = lo.opHermitian(T(rng.standard_normal(n), dev), T(A.T.copy(), dev).t())
+    op = (M * D + Hh.H * M.H) * (2 - 1j) + Hm
+    dense = (Mh @ np.diag(dh) + (np.eye(n) - 2 * np.outer(hh, hh.conj())).conj().T @ Mh.conj().T) * (2 - 1j) + lo.Matrix(Hm).cpu().numpy()
+    x = crand(rng, n, np.complex128)
+    assert rel((op * T(x, dev)).cpu().numpy(), dense @ x) <= 1e-11
+    assert rel((op.H * T(x, dev)).cpu().numpy(), dense.conj().T @ x) <= 1e-11
+    res = torch.empty(n, dtype=torch.complex128, device=dev)
+    xt = T(x, dev)
+    for _ in range(3):
+        lo.mul(res, op, xt, 1.0, 0.0)
+
+    def snap():
+        a = (C.c_int64 * 12)()
+        lo._lib.call("mxlo_debug_counters", a)
+        return list(a)
+    torch.cuda.synchronize()
+    s0 = snap()
+    lo.mul(res, M, xt, 2.0, -1.0)
+    lo.mul(res, M.H, xt, 2.0, -1.0)
+    lo.mul(res, Hm, xt, 2.0, -1.0)
+    s1 = snap()
+    dlt = [b - a for a, b in zip(s0, s1)]
+    assert dlt[10] >= 6 and not any(dlt[k] for k in range(12) if k != 10), dlt      # launches only

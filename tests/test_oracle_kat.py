@@ -356,6 +356,35 @@ def test_kat_hermitian(kat):
     assert np.linalg.norm(got - np.array(c["expect_mul5"])) <= 1e-13 * np.linalg.norm(c["expect_mul5"])
 
 
+def test_kat_complex_hermitian_and_dense(kat):
+    """test/test_linop.jl:360-370 on ComplexF64: H = opHermitian(real.(diag), tril(A,-1)); H*v, transpose(H)*v (the conj
+    sandwich of src/adjtrans.jl:193-204 around the hermitian prod!), H'*v and a 5-arg mul! with complex α, β; the same
+    Hermitian matrix C as a dense LinearOperator(C) in the four op modes of the complex GEMV."""
+    cs = _by_kind(kat, "chermitian")
+    assert len(cs) == 2
+    for c in cs:
+        n = c["n"]
+        A = np.array([[complex(*e) for e in row] for row in c["A"]])
+        Cm = np.array([[complex(*e) for e in row] for row in c["C"]])
+        d, v, r0 = np.array(c["d"]), _cx(c["v"]), _cx(c["res0"])
+        nan = np.full(n, np.nan + 1j * np.nan)
+        want = _cx(c["expect_apply"])
+        got = oracle.hermitian_mul(nan.copy(), d, A, v, complex(1), complex(0))
+        assert np.linalg.norm(got - want) <= 1e-13 * np.linalg.norm(want), c["name"]
+        got_t = np.conj(oracle.hermitian_mul(nan.copy(), d, A, np.conj(v), complex(1), complex(0)))
+        assert np.linalg.norm(got_t - _cx(c["expect_tapply"])) <= 1e-13 * np.linalg.norm(want), c["name"]
+        al, be = complex(*c["alpha"]), complex(*c["beta"])
+        got5 = oracle.hermitian_mul(r0.copy(), d, A, v, al, be)
+        assert np.linalg.norm(got5 - _cx(c["expect_mul5"])) <= 1e-13 * np.linalg.norm(_cx(c["expect_mul5"])), c["name"]
+        got32 = oracle.hermitian_mul(np.zeros(n, np.complex64), d.astype(np.float32), A.astype(np.complex64), v.astype(np.complex64),
+                                     np.complex64(1), np.complex64(0))
+        assert np.linalg.norm(got32 - want) <= 1e-5 * np.linalg.norm(want)
+        for mode, Mx in (("N", Cm), ("T", Cm.T), ("C", Cm.conj().T), ("J", Cm.conj())):
+            g = oracle.gemv(nan.copy(), Cm, v, complex(1), complex(0), trans=mode)
+            assert np.linalg.norm(g - Mx @ v) <= 1e-13 * np.linalg.norm(want), (c["name"], mode)
+        assert np.linalg.norm(oracle.gemv(nan.copy(), Cm, v, complex(1), complex(0), trans="N") - want) <= 1e-13 * np.linalg.norm(want)
+
+
 def test_kat_kron(kat):
     (c,) = _by_kind(kat, "kron")
     A, B, K = np.array(c["A"]), np.array(c["B"]), np.array(c["K"])

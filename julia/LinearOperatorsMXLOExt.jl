@@ -259,7 +259,7 @@ Base.:+(op::LinearOperator{T, MXVector{T}}, x::Number) where {T} = op + x * opOn
 Base.:+(x::Number, op::LinearOperator{T, MXVector{T}}) where {T} = x * opOnes(T, op.nrow, op.ncol; S = MXVector{T}) + op
 
 # ---- a6 opHermitian (src/linalg.jl:97-127): the ORIGINAL matrix is passed; only tril(A,-1) is read ------------
-function opHermitian(d::MXVector{T}, A::MXMatrix{T}) where {T}
+function opHermitian(d::MXVector{T}, A::MXMatrix{T}) where {T <: RealT}
   m, n = size(A)
   m == n == length(d) || throw(LinearOperatorException("shape mismatch"))
   prod! = (res, v, α, β) -> check(ccall((:mxlo_hermitian_mul, lib), Int32,
@@ -268,8 +268,28 @@ function opHermitian(d::MXVector{T}, A::MXMatrix{T}) where {T}
   LinearOperator{T, MXVector{T}}(m, m, true, true, prod!, nothing, nothing)
 end
 
+# complex A (test/test_linop.jl:360-370: ComplexF64 A, d = real.(diag(A))): L' is the conjugate transpose, symmetric =
+# isreal(A) = false; a Real diagonal is passed as such (MXLO_D_REAL = 0x80: d .* v is Real * Complex)
+function opHermitian(d::MXVector{S}, A::MXMatrix{T}) where {S <: Union{RealT, CplxT}, T <: CplxT}
+  m, n = size(A)
+  m == n == length(d) || throw(LinearOperatorException("shape mismatch"))
+  (S === T || S === real(T)) || throw(ArgumentError("opHermitian: convert d to $(T) or $(real(T)) first"))
+  dflag = S <: Real ? Int32(0x80) : Int32(0)
+  prod! = (res, v, α, β) -> check(ccall((:mxlo_hermitian_mul_c, lib), Int32,
+      (P, Int32, P, P, P, Int64, P, Int64, Float64, Float64, Float64, Float64, Int32),
+      ctx(), dt(T), res.ptr, d.ptr, A.data.ptr, m, v.ptr, n, re(α), im(α), re(β), im(β), flags(T, α, β) | dflag))
+  LinearOperator{T, MXVector{T}}(m, m, false, true, prod!, nothing, nothing)
+end
+
 # ---- dense LinearOperator(M) (src/constructors.jl:19-29) ----------------------------------------------------
-function LinearOperator(M::MXMatrix{T}; symmetric = false, hermitian = false) where {T}
+function LinearOperator(M::MXMatrix{T}; symmetric = false, hermitian = false) where {T <: CplxT}
+  m, n = size(M)
+  gemv(mode) = (res, v, α, β) -> check(ccall((:mxlo_gemv_c, lib), Int32,
+      (P, Int32, P, P, Int64, Int64, Int64, P, Float64, Float64, Float64, Float64, Int32, Int32),
+      ctx(), dt(T), res.ptr, M.data.ptr, m, n, m, v.ptr, re(α), im(α), re(β), im(β), Int32(mode), flags(T, α, β)))
+  LinearOperator{T, MXVector{T}}(m, n, symmetric, hermitian, gemv(0), gemv(1), gemv(2))     # M*v, transpose(M)*u, M'*w
+end
+function LinearOperator(M::MXMatrix{T}; symmetric = false, hermitian = false) where {T <: RealT}
   m, n = size(M)
   gemv(mode) = (res, v, α, β) -> check(ccall((:mxlo_gemv, lib), Int32,
       (P, Int32, P, P, Int64, Int64, Int64, P, Float64, Float64, Int32, Int32),

@@ -26,8 +26,8 @@ def dtype_code(dtype: torch.dtype, complex_ok: bool = False) -> int:
         return _DTC[dtype]
     if dtype in _DTC:
         raise TypeError(f"this leaf of the MI355X path is instantiated for float64/float32 only, got {dtype} "
-                        "(complex: opDiagonal, opEye, opZeros, opHouseholder, restriction/extension and the "
-                        "adjoint/transpose/conj wrappers)")
+                        "(complex: opDiagonal, opEye, opZeros, opHouseholder, restriction/extension, dense "
+                        "LinearOperator(M), opHermitian and the adjoint/transpose/conj wrappers)")
     raise TypeError(f"the MI355X path is instantiated for float64/float32 (+ complex128/complex64 elementwise "
                     f"leaves) only, got {dtype} (BigFloat/Float16 stay on the reference CPU path)")
 

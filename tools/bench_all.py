@@ -131,6 +131,20 @@ for nn in (4096, 16384):
     del M, op, Hm
     torch.cuda.empty_cache()
 
+# complex dense leaves (correctness-first kernels; reported for completeness)
+if sec("dense"):
+    for nn in (4096, 8192):
+        Mc = torch.complex(rnd(nn * nn), rnd(nn * nn)).reshape(nn, nn).t()
+        opc = lo.LinearOperatorFromMatrix(Mc)
+        xc, yc = torch.complex(rnd(nn), rnd(nn)), torch.complex(rnd(nn), rnd(nn))
+        row(f"complex128 dense LinearOperator(M) mul! n={nn}", 16.0 * nn * nn, timeit(lambda: lo.mul(yc, opc, xc, 1.0, 0.0), 10))
+        row(f"complex128 dense adjoint mul! n={nn}", 16.0 * nn * nn, timeit(lambda: lo.mul(yc, opc.H, xc, 1.0, 0.0), 10))
+        Hc = lo.opHermitian(rnd(nn), Mc)
+        row(f"complex128 opHermitian mul! n={nn} (ideal = strict lower triangle once; two passes here)", 8.0 * nn * nn,
+            timeit(lambda: lo.mul(yc, Hc, xc, 1.0, 0.0), 10))
+        del Mc, opc, Hc
+    torch.cuda.empty_cache()
+
 # kron: two f64 / f32 MFMA GEMMs per apply (4 m^3 flop for m x m (x) m x m)
 if sec("kron"):
     PEAK_TF = {torch.float64: 78.6, torch.float32: 157.3}

@@ -372,6 +372,16 @@ int32_t mxlo_kron_mul_ex(mxlo_ctx *ctx, int32_t dtype, void *res, const void *A,
                          int64_t lda, int32_t trans_a, const void *B, int64_t bp, int64_t bq, int64_t ldb,
                          int32_t trans_b, const void *x, void *work, double alpha, double beta, int32_t flags);
 
+/* kron(A, B) on ComplexF64 / ComplexF32 data — src/kron.jl:10-40 with complex factors (test/test_kron.jl:3-8 pairs a
+ * Float64 A with a ComplexF64 B). The factors arrive as REAL PLANES (the glue splits a complex factor once, a real
+ * factor is passed as it is with a NULL imaginary plane): each complex product is 4 (2 for a real factor) real GEMMs
+ * on the MFMA kernel of mxlo_kron_mul_ex. mode_a / mode_b: bit 0 = take the stored planes transposed, bit 1 =
+ * conjugate (tprod! = 1, ctprod! = 3, a row-major alias flips bit 0). x, res: complex vectors; work: real scalars,
+ * 2*(q*n + m*q + p*m) + 24 of them with (m x n) = opA, (p x q) = opB (each plane is placed 16-byte aligned). */
+int32_t mxlo_kron_mul_c(mxlo_ctx *ctx, int32_t dtype, void *res, const void *Ar, const void *Ai, int64_t am, int64_t an,
+                        int64_t lda, int32_t mode_a, const void *Br, const void *Bi, int64_t bp, int64_t bq, int64_t ldb,
+                        int32_t mode_b, const void *x, void *work, double alpha_re, double alpha_im, double beta_re,
+                        double beta_im, int32_t flags);
 /* kron(A, B) when BOTH factors are diagonal operators (opDiagonal / opEye; pass NULL for an identity
  * factor): the fused row/col index-decomposition form of src/kron.jl:14-22,
  *   res[r + c*p] = alpha*(dB[r]*(x[r + c*p]*dA[c])) (+ beta*res[r + c*p]),  A is m x m, B is p x p.

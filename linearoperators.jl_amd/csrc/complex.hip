@@ -20,6 +20,10 @@ using namespace mxlo;
 namespace mxlo {
 int32_t finalize_and_reduce(mxlo_ctx *ctx, int ncols, int nblocks, double *out_dev);
 int32_t allreduce_hook(mxlo_ctx *ctx, double *dev, int64_t count);
+template <typename R>
+int32_t kron_planes(mxlo_ctx *ctx, R *rr, R *ri, const R *Ar, const R *Ai, int64_t am, int64_t an, int64_t lda,
+                    bool trans_a, double sign_ai, const R *Br, const R *Bi, int64_t bp, int64_t bq, int64_t ldb,
+                    bool trans_b, double sign_bi, const R *xr, const R *xi, R *utr, R *uti);   // dense.hip
 }  // namespace mxlo
 
 namespace {
@@ -534,6 +538,55 @@ int32_t chermitian(mxlo_ctx *ctx, C<R> *res, const void *d, bool d_real, const C
   });
 }
 
+// ---- kron on complex data: split x into planes, real MFMA GEMMs on planes (dense.hip: kron_planes), join with α, β ------
+template <typename R>
+__global__ void __launch_bounds__(kBlock)
+cplx_split_kernel(R *__restrict__ re, R *__restrict__ im, const C<R> *__restrict__ x, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+    const C<R> e = x[i];
+    re[i] = e.re;
+    im[i] = e.im;
+  }
+}
+template <typename R, typename RA, typename RB, bool BETA0>
+__global__ void __launch_bounds__(kBlock)
+cplx_join_kernel(C<R> *__restrict__ res, const R *__restrict__ rr, const R *__restrict__ ri, int64_t n, Sc<RA> a, Sc<RB> b) {
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+    RA tr, ti;
+    a.mul(C<R>(rr[i], ri[i]), tr, ti);
+    res[i] = cfin<R, RA, RB, BETA0>(tr, ti, b.re, b.im, b.real, BETA0 ? C<R>() : res[i]);
+  }
+}
+
+template <typename R>
+int32_t ckron(mxlo_ctx *ctx, C<R> *res, const R *Ar, const R *Ai, int64_t am, int64_t an, int64_t lda, int mode_a,
+              const R *Br, const R *Bi, int64_t bp, int64_t bq, int64_t ldb, int mode_b, const C<R> *x, R *work,
+              const ScalArgs &s) {
+  const bool ta = (mode_a & 1) != 0, tb = (mode_b & 1) != 0;
+  const int64_t m = ta ? an : am, n = ta ? am : an, p = tb ? bq : bp, q = tb ? bp : bq;
+  const int64_t nout = p * m, nin = q * n;
+  if (nout == 0) return MXLO_OK;
+  if (nin == 0) {
+    if (s.bre == 0 && s.bim == 0) return cfill<R>(ctx, res, nout, C<R>());
+    return cscale<R>(ctx, res, nout, s.bre, s.bim, s.b_real, s.b64);
+  }
+  auto pad = [](int64_t k) { return (k + 3) & ~(int64_t)3; };   // every plane starts 16-byte aligned (the DMA GEMM needs it)
+  R *xr = work, *xi = xr + pad(nin), *utr = xi + pad(nin), *uti = utr + pad(m * q), *rr = uti + pad(m * q), *ri = rr + pad(nout);
+  hipLaunchKernelGGL((cplx_split_kernel<R>), dim3(grid_for(ctx, nin, kBlock, 8)), dim3(kBlock), 0, ctx->stream, xr, xi, x, nin);
+  MXLO_LAUNCH_CHECK();
+  MXLO_TRY((kron_planes<R>(ctx, rr, ri, Ar, Ai, am, an, lda, ta, (mode_a & 2) ? -1.0 : 1.0, Br, Bi, bp, bq, ldb, tb,
+                           (mode_b & 2) ? -1.0 : 1.0, xr, xi, utr, uti)));
+  const int grid = grid_for(ctx, nout, kBlock, 8);
+  return dispatch_c<R>(s, [&]<typename RA, typename RB, bool B0>() -> int32_t {
+    const Sc<RA> a{(RA)s.are, (RA)s.aim, s.a_real};
+    const Sc<RB> b{(RB)s.bre, (RB)s.bim, s.b_real};
+    hipLaunchKernelGGL((cplx_join_kernel<R, RA, RB, B0>), dim3(grid), dim3(kBlock), 0, ctx->stream, res, (const R *)rr,
+                       (const R *)ri, nout, a, b);
+    MXLO_LAUNCH_CHECK();
+    return MXLO_OK;
+  });
+}
+
 }  // namespace
 
 #define CHECK_C(name)                                                                                        \
@@ -647,4 +700,24 @@ MXLO_API int32_t mxlo_hermitian_mul_c(mxlo_ctx *ctx, int32_t dtype, void *res, c
                               scal_args(8, alpha_re, alpha_im, beta_re, beta_im, flags));
   return chermitian<float>(ctx, (C<float> *)res, d, d_real, (const C<float> *)A, lda, (const C<float> *)v, n,
                            scal_args(4, alpha_re, alpha_im, beta_re, beta_im, flags));
+}
+
+MXLO_API int32_t mxlo_kron_mul_c(mxlo_ctx *ctx, int32_t dtype, void *res, const void *Ar, const void *Ai, int64_t am,
+                                 int64_t an, int64_t lda, int32_t mode_a, const void *Br, const void *Bi, int64_t bp,
+                                 int64_t bq, int64_t ldb, int32_t mode_b, const void *x, void *work, double alpha_re,
+                                 double alpha_im, double beta_re, double beta_im, int32_t flags) {
+  CHECK_C("mxlo_kron_mul_c");
+  MXLO_REQUIRE(am >= 0 && an >= 0 && bp >= 0 && bq >= 0, MXLO_ESHAPE, "mxlo_kron_mul_c: negative size");
+  MXLO_REQUIRE(lda >= (am > 1 ? am : 1) && ldb >= (bp > 1 ? bp : 1), MXLO_ESHAPE, "mxlo_kron_mul_c: bad leading dimension");
+  MXLO_REQUIRE(mode_a >= 0 && mode_a <= 3 && mode_b >= 0 && mode_b <= 3, MXLO_EINVAL, "mxlo_kron_mul_c: bad factor mode");
+  const int64_t m = (mode_a & 1) ? an : am, p = (mode_b & 1) ? bq : bp;
+  if (m * p == 0) return MXLO_OK;
+  MXLO_REQUIRE(res && Ar && Br && x && work, MXLO_EINVAL, "mxlo_kron_mul_c: NULL operand");
+  if (dtype == MXLO_C64)
+    return ckron<double>(ctx, (C<double> *)res, (const double *)Ar, (const double *)Ai, am, an, lda, mode_a, (const double *)Br,
+                         (const double *)Bi, bp, bq, ldb, mode_b, (const C<double> *)x, (double *)work,
+                         scal_args(8, alpha_re, alpha_im, beta_re, beta_im, flags));
+  return ckron<float>(ctx, (C<float> *)res, (const float *)Ar, (const float *)Ai, am, an, lda, mode_a, (const float *)Br,
+                      (const float *)Bi, bp, bq, ldb, mode_b, (const C<float> *)x, (float *)work,
+                      scal_args(4, alpha_re, alpha_im, beta_re, beta_im, flags));
 }

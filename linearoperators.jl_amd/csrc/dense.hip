@@ -654,6 +654,40 @@ int32_t kron_t(mxlo_ctx *ctx, T *res, const T *A, int64_t am, int64_t an, int64_
 
 }  // namespace
 
+// kron on Complex{R} with the factors and x split into real / imaginary PLANES: every complex product is four (two for a
+// real factor) REAL GEMMs on the MFMA kernel above — Ut = opA*X^T, R = opB*Ut^T with
+//   (Pr + i Pi)(Qr + i Qi) = (Pr Qr - Pi Qi) + i (Pr Qi + Pi Qr),
+// the second GEMM of each pair accumulating through beta = 1. sign_ai / sign_bi = -1 conjugates a factor (ctprod!).
+// Ai / Bi may be NULL (real factor next to complex data: kron(Float64 A, ComplexF64 B), test/test_kron.jl:3-8).
+namespace mxlo {
+template <typename R>
+int32_t kron_planes(mxlo_ctx *ctx, R *rr, R *ri, const R *Ar, const R *Ai, int64_t am, int64_t an, int64_t lda,
+                    bool trans_a, double sign_ai, const R *Br, const R *Bi, int64_t bp, int64_t bq, int64_t ldb,
+                    bool trans_b, double sign_bi, const R *xr, const R *xi, R *utr, R *uti) {
+  const int64_t m = trans_a ? an : am, n = trans_a ? am : an;
+  const int64_t p = trans_b ? bq : bp, q = trans_b ? bp : bq;
+  MXLO_TRY(gemm<R>(ctx, utr, m, Ar, lda, trans_a, xr, q, true, m, q, n, 1.0, 0.0, 0));
+  MXLO_TRY(gemm<R>(ctx, uti, m, Ar, lda, trans_a, xi, q, true, m, q, n, 1.0, 0.0, 0));
+  if (Ai) {
+    MXLO_TRY(gemm<R>(ctx, utr, m, Ai, lda, trans_a, xi, q, true, m, q, n, -sign_ai, 1.0, 0));
+    MXLO_TRY(gemm<R>(ctx, uti, m, Ai, lda, trans_a, xr, q, true, m, q, n, sign_ai, 1.0, 0));
+  }
+  MXLO_TRY(gemm<R>(ctx, rr, p, Br, ldb, trans_b, utr, m, true, p, m, q, 1.0, 0.0, 0));
+  MXLO_TRY(gemm<R>(ctx, ri, p, Br, ldb, trans_b, uti, m, true, p, m, q, 1.0, 0.0, 0));
+  if (Bi) {
+    MXLO_TRY(gemm<R>(ctx, rr, p, Bi, ldb, trans_b, uti, m, true, p, m, q, -sign_bi, 1.0, 0));
+    MXLO_TRY(gemm<R>(ctx, ri, p, Bi, ldb, trans_b, utr, m, true, p, m, q, sign_bi, 1.0, 0));
+  }
+  return MXLO_OK;
+}
+template int32_t kron_planes<double>(mxlo_ctx *, double *, double *, const double *, const double *, int64_t, int64_t, int64_t,
+                                     bool, double, const double *, const double *, int64_t, int64_t, int64_t, bool, double,
+                                     const double *, const double *, double *, double *);
+template int32_t kron_planes<float>(mxlo_ctx *, float *, float *, const float *, const float *, int64_t, int64_t, int64_t, bool,
+                                    double, const float *, const float *, int64_t, int64_t, int64_t, bool, double,
+                                    const float *, const float *, float *, float *);
+}  // namespace mxlo
+
 static inline void eff_ab(int32_t dtype, int32_t flags, double &alpha, double &beta) {
   eff_scalars(dtype == MXLO_F64 ? 8 : 4, flags, alpha, beta);
 }

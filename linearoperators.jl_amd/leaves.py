@@ -527,6 +527,8 @@ def kron(A, B):
 
     fA, fB = _KronFactor(A), _KronFactor(B)
     T = torch.promote_types(fA.dtype, fB.dtype)
+    if T.is_complex:
+        return _kron_complex(A, B, fA, fB, T)
     dtype_code(T)
     fA.T, fB.T = T, T
     m, n = fA.shape
@@ -549,6 +551,56 @@ def kron(A, B):
     tprod = lambda res, x, a, b: km(res, x, a, b, 1)
     op = LinearOperator(T, m * p, n * q, fA.symmetric and fB.symmetric, fA.hermitian and fB.hermitian, prod, tprod,
                         tprod, S=Storage(T, dev))
+    op._deps = (A, B)
+    return op
+
+
+def _kron_complex(A, B, fA, fB, T):
+    """kron with at least one complex factor (test/test_kron.jl:3-8: Float64 A, ComplexF64 B). The apply works on real
+    PLANES: a complex factor is split into (re, im) column-major planes once (refreshed when its state token changes),
+    a real factor is aliased as it is with no imaginary plane; every complex product is then 4 (2) real MFMA GEMMs
+    (`mxlo_kron_mul_c`). tprod! transposes both factors, ctprod! also conjugates them (src/kron.jl:24-40)."""
+    dtype_code(T, True)
+    R = torch.float64 if T == torch.complex128 else torch.float32
+    m, n = fA.shape
+    p, q = fB.shape
+    dev = fA.device
+
+    class Planes:
+        def __init__(self, f):
+            self.f, self.cache, self.token = f, None, object()
+            if not f.dtype.is_complex:
+                f.T = R
+
+        def get(self):
+            f = self.f
+            if not f.dtype.is_complex:                  # real factor: aliased (either layout) / tracked by _KronFactor
+                M, t = f.get()
+                return M, None, t
+            src = f.src if f.src is not None else f.op
+            tok = state_version(src)
+            if self.cache is None or tok is None or tok != self.token:
+                D = (f.src if f.src is not None else to_dense(f.op)).to(T)
+                self.cache = (D.real.t().contiguous().t(), D.imag.t().contiguous().t())     # column-major planes
+                self.token = tok
+            return self.cache[0], self.cache[1], 0
+
+    pA, pB = Planes(fA), Planes(fB)
+    work = torch.empty(2 * (max(q * n, p * m) + max(m * q, n * p) + max(p * m, q * n)) + 24, dtype=R, device=dev)
+
+    def km(res, x, a, b, trans, conj):
+        ctx = get_ctx(res.device)
+        Ar, Ai, ta = pA.get()
+        Br, Bi, tb = pB.get()
+        _lib.call("mxlo_kron_mul_c", ctx.handle, dtype_code(T, True), ptr(res), ptr(Ar), ptr(Ai), Ar.shape[0], Ar.shape[1],
+                  _ld(Ar), (ta ^ trans) | (conj << 1), ptr(Br), ptr(Bi), Br.shape[0], Br.shape[1], _ld(Br),
+                  (tb ^ trans) | (conj << 1), ptr(x), ptr(work), *_c4(a, b), scalar_flags(res.dtype, a, b))
+
+    prod = lambda res, x, a, b: km(res, x, a, b, 0, 0)
+    tprod = lambda res, x, a, b: km(res, x, a, b, 1, 0)
+    ctprod = lambda res, x, a, b: km(res, x, a, b, 1, 1)
+    op = LinearOperator(T, m * p, n * q, fA.symmetric and fB.symmetric, fA.hermitian and fB.hermitian, prod, tprod,
+                        ctprod, S=Storage(T, dev))
     op._deps = (A, B)
     return op
 
@@ -589,7 +641,7 @@ class _KronFactor:
         else:
             self.shape = tuple(self.op.shape)
             dt = self.op.eltype
-            self.dtype = dt if dt.is_floating_point else torch.float64
+            self.dtype = dt if (dt.is_floating_point or dt.is_complex) else torch.float64
             self.device = storage_type(self.op).device
         self._cache = None
         self._token = object()      # never equal to a real token

@@ -284,7 +284,21 @@ def gemv(res, M, v, alpha, beta, trans=False, flags=0):
 
 
 def kron_mul(res, A, B, x, alpha, beta, trans=False, flags=0):
-    """kron(A,B) prod!/tprod! (src/kron.jl:14-31)."""
+    """kron(A,B) prod!/tprod!/ctprod! (src/kron.jl:14-40). Complex res: trans in {False, True|"T", "C"}; real factors
+    next to complex data are promoted (kron(Float64 A, ComplexF64 B), test/test_kron.jl:3-8)."""
+    if res.dtype.kind == "c":
+        dt = res.dtype
+        assert x.dtype == dt
+        mode = {False: 0, True: 1, "N": 0, "T": 1, "C": 2}[trans]
+        Af, Bf = np.asfortranarray(A, dtype=dt), np.asfortranarray(B, dtype=dt)
+        m, n = Af.shape
+        p, q = Bf.shape
+        nro, nco = (q, n) if mode else (p, m)
+        xr = p if mode else q
+        work = np.empty(xr + nro * nco, dt)
+        _fn("orc_kron_mul", dt)(_p(res), _p(Af), _i64(m), _i64(n), _i64(m), _p(Bf), _i64(p), _i64(q), _i64(p), _p(x),
+                                *_c4(alpha, beta), _i32(mode), _i32(flags), _p(work))
+        return res
     dt = _check(res, x)
     Af = np.asfortranarray(A, dtype=dt)
     Bf = np.asfortranarray(B, dtype=dt)

@@ -257,6 +257,42 @@ void CFN(orc_hermitian_mul)(R *res, const R *d, int32_t d_real, const R *A, int6
   CFN(orc_cplx_epilogue)(res, t1, n, are, aim, bre, bim, flags);
 }
 
+/* kron(A, B) on Complex{R} — src/kron.jl:10-40: (A ⊗ B) x = vec(B X transpose(A)); tprod! (mode 1) on the transposed
+ * factors, ctprod! (mode 2) on the conjugate-transposed factors. Column i of the result matrix is opB * (X * w_i) with
+ * w_i = row / column i of A (conjugated for mode 2), exactly the reference's `m` single-vector products (:17-18).
+ * A: m x n (lda), B: p x q (ldb), complex interleaved. work: 2*(xr + nrows_out*ncols_out) scalars. */
+void CFN(orc_kron_mul)(R *res, const R *A, int64_t m, int64_t n, int64_t lda, const R *B, int64_t p, int64_t q,
+                       int64_t ldb, const R *x, double are, double aim, double bre, double bim, int32_t mode,
+                       int32_t flags, R *work) {
+  const int trans = mode != 0, cj = mode == 2;
+  const int64_t ncols_out = trans ? n : m, nrows_out = trans ? q : p;
+  const int64_t xr = trans ? p : q, xc = trans ? m : n;
+  R *u = work, *Rm = work + 2 * xr;
+  for (int64_t i = 0; i < ncols_out; ++i) {
+    for (int64_t r = 0; r < 2 * xr; ++r) u[r] = 0;
+    for (int64_t j = 0; j < xc; ++j) {
+      const R *w = trans ? A + 2 * (j + i * lda) : A + 2 * (i + j * lda);
+      const R wr = w[0], wi = cj ? -w[1] : w[1];
+      for (int64_t r = 0; r < xr; ++r) {
+        const R xr_ = x[2 * (r + j * xr)], xi_ = x[2 * (r + j * xr) + 1];
+        u[2 * r] += (xr_ * wr) - (xi_ * wi);
+        u[2 * r + 1] += (xr_ * wi) + (xi_ * wr);
+      }
+    }
+    R *col = Rm + 2 * i * nrows_out;
+    for (int64_t r = 0; r < 2 * nrows_out; ++r) col[r] = 0;
+    for (int64_t j = 0; j < q; ++j)
+      for (int64_t r = 0; r < p; ++r) {
+        const R br_ = B[2 * (r + j * ldb)], bi_ = cj ? -B[2 * (r + j * ldb) + 1] : B[2 * (r + j * ldb) + 1];
+        const R *uu = trans ? u + 2 * r : u + 2 * j;
+        R *o = trans ? col + 2 * j : col + 2 * r;
+        o[0] += (br_ * uu[0]) - (bi_ * uu[1]);
+        o[1] += (br_ * uu[1]) + (bi_ * uu[0]);
+      }
+  }
+  CFN(orc_cplx_epilogue)(res, Rm, nrows_out * ncols_out, are, aim, bre, bim, flags);
+}
+
 #undef SMUL
 #undef WITH_RAB
 #undef CFN

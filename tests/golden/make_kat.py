@@ -319,6 +319,24 @@ cases.append(dict(
     expect_mul5=fl([2 * a + 3 * r for a, r in zip(matvec(K, xk), r0k)]), K=[fl(r) for r in K],
     tol="1e-12 * norm(K, 1) as test_kron.jl:35"))
 
+# ---------------------------------------------------------------- kron(Float64 A, ComplexF64 B) (test_kron.jl:3-8)
+# the reference loops B over simple_matrix(Float64, 2, 3), simple_matrix(ComplexF64, 2, 3), ...: the complex-B pairing,
+# with deterministic Gaussian-dyadic entries; T*x, transpose(T)*x, T'*x and Matrix(T) against Base.kron.
+Bkc = [[(F(1, 2), F(-3, 4)), (F(3), F(1, 8)), (F(-1), F(2))], [(F(-7, 4), F(1, 2)), (F(1, 8), F(-1)), (F(2), F(5, 8))]]
+Kc = [[cmul((Ak[i // pk][j // qk], F(0)), Bkc[i % pk][j % qk]) for j in range(nk * qk)] for i in range(mk * pk)]
+Kct = [[Kc[i][j] for i in range(mk * pk)] for j in range(nk * qk)]
+Kch = [[cconj(Kc[i][j]) for i in range(mk * pk)] for j in range(nk * qk)]
+xkc, xtkc = cpattern(nk * qk, 1, 3), cpattern(mk * pk, 2, 5)
+r0kc = cpattern(mk * pk, 3, 1)
+alk, bek = (F(2), F(-1, 2)), (F(3), F(1))
+cases.append(dict(
+    name="kron_real_2x3_complex_2x3", ref="test/test_kron.jl:3-36 (Float64 A, ComplexF64 B, deterministic)", kind="ckron",
+    A=[fl(r) for r in Ak], B=[cfl(r) for r in Bkc], x=cfl(xkc), expect_apply=cfl(cmatvec(Kc, xkc)),
+    xt=cfl(xtkc), expect_tapply=cfl(cmatvec(Kct, xtkc)), expect_ctapply=cfl(cmatvec(Kch, xtkc)),
+    alpha=[float(alk[0]), float(alk[1])], beta=[float(bek[0]), float(bek[1])], res0=cfl(r0kc),
+    expect_mul5=cfl([cadd(cmul(alk, a), cmul(bek, r)) for a, r in zip(cmatvec(Kc, xkc), r0kc)]), K=[cfl(r) for r in Kc],
+    tol="1e-12 * norm(K, 1) as test_kron.jl:35"))
+
 out = dict(
     about="Known-answer cases held by LinearOperators.jl v2.14.2's own tests for the mul! hot path; "
           "generated by tests/golden/make_kat.py (exact rational arithmetic, no reference code executed).",

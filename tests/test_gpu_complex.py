@@ -226,11 +226,8 @@ def test_complex_diag_full_size_properties(lo, dev):
 
 
 def test_real_only_leaves_reject_complex(lo, dev):
-    """Not instantiated for complex element types: kron's MFMA GEMMs and the quasi-Newton operators — loud TypeError."""
-    A = torch.eye(4, dtype=torch.complex128, device=dev)
-    with pytest.raises(TypeError):
-        K = lo.kron(A, A)
-        K * torch.ones(16, dtype=torch.complex128, device=dev)
+    """Not instantiated for complex element types: the quasi-Newton operators (real by construction in the reference) and
+    block-diagonal fusion of complex dense blocks — loud TypeError, never a silent fallback."""
     with pytest.raises(TypeError):
         lo.LBFGSOperator(torch.complex128, 8, device=dev)
 

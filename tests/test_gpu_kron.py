@@ -201,3 +201,85 @@ def test_kron_1000_and_transpose_rates_are_not_a_cliff(lo, dev):
     base = t_us(1024, False)
     assert t_us(1000, False) <= 1.25 * base
     assert t_us(1024, True) <= 1.35 * base
+
+
+# ------------------------------------------------------------------------------------------ complex factors
+def _cxa(a):
+    a = np.array(a, dtype=np.float64)
+    return a[..., 0] + 1j * a[..., 1]
+
+
+def test_kat_complex_kron(lo, dev, kat):
+    """test/test_kron.jl:3-36 with the Float64 A x ComplexF64 B pairing: T1 = kron(LinearOperator(A), B), T2 = kron(A,
+    LinearOperator(B)), T3 = kron of both operators; Matrix(T), T*x, transpose(T)*x, T'*x against Base.kron(A, B) with
+    the reference's bound eps()*norm(K,1) / 1e-12*norm(K,1); 5-arg mul! with complex alpha, beta."""
+    (c,) = [c for c in kat if c["kind"] == "ckron"]
+    A = np.array(c["A"])
+    B = _cxa(c["B"])
+    K = _cxa(c["K"])
+    normK = np.abs(K).sum(axis=0).max()
+    x, xt, r0 = _cxa(c["x"]), _cxa(c["xt"]), _cxa(c["res0"])
+    At, Bt = T(A.T.copy(), dev).t(), T(B.T.copy(), dev).t()
+    for Tk in (lo.kron(lo.LinearOperatorFromMatrix(At), Bt), lo.kron(At, lo.LinearOperatorFromMatrix(Bt)),
+               lo.kron(lo.LinearOperatorFromMatrix(At), lo.LinearOperatorFromMatrix(Bt)), lo.kron(T(A, dev), T(B, dev))):
+        assert Tk.eltype == torch.complex128 and Tk.shape == K.shape
+        assert np.abs(lo.Matrix(Tk).cpu().numpy() - K).sum(axis=0).max() <= 4 * np.finfo(float).eps * normK
+        assert np.abs(lo.Matrix(Tk.H).cpu().numpy() - K.conj().T).sum(axis=0).max() <= 4 * np.finfo(float).eps * normK
+        assert np.abs(lo.Matrix(Tk.T).cpu().numpy() - K.T).sum(axis=0).max() <= 4 * np.finfo(float).eps * normK
+        assert np.abs((Tk * T(x, dev)).cpu().numpy() - _cxa(c["expect_apply"])).sum() <= 1e-12 * normK
+        assert np.abs((Tk.T * T(xt, dev)).cpu().numpy() - _cxa(c["expect_tapply"])).sum() <= 1e-12 * normK
+        assert np.abs((Tk.H * T(xt, dev)).cpu().numpy() - _cxa(c["expect_ctapply"])).sum() <= 1e-12 * normK
+        res = T(r0.copy(), dev)
+        lo.mul(res, Tk, T(x, dev), complex(*c["alpha"]), complex(*c["beta"]))
+        assert np.abs(res.cpu().numpy() - _cxa(c["expect_mul5"])).sum() <= 1e-12 * normK
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.complex128, 1e-12), (torch.complex64, 5e-5)])
+@pytest.mark.parametrize("shapes", [((1, 1), (1, 1)), ((3, 5), (4, 2)), ((17, 33), (9, 20)), ((64, 64), (64, 64)),
+                                    ((130, 70), (33, 129)), ((256, 128), (128, 256))])
+@pytest.mark.parametrize("kinds", ["cc", "rc", "cr"])
+def test_complex_kron_vs_oracle_and_dense(lo, dev, dtype, tol, shapes, kinds):
+    """complex x complex, real x complex, complex x real factors; prod!/tprod!/ctprod!, complex and real scalars, beta = 0
+    not reading res; against the oracle's reference-literal restatement and against np.kron."""
+    npc = np.complex128 if dtype == torch.complex128 else np.complex64
+    npr = np.float64 if dtype == torch.complex128 else np.float32
+    (m, n), (p, q) = shapes
+    rng = np.random.default_rng(m * 7 + n * 5 + p * 3 + q + len(kinds))
+    mk = lambda sh, cplx: ((rng.standard_normal(sh) + 1j * rng.standard_normal(sh)).astype(npc) if cplx
+                           else rng.standard_normal(sh).astype(npr))
+    A, B = mk((m, n), kinds[0] == "c"), mk((p, q), kinds[1] == "c")
+    Kd = np.kron(A.astype(np.complex128), B.astype(np.complex128))
+    Kop = lo.kron(T(A, dev), T(B.T.copy(), dev).t())              # one row-major, one column-major factor
+    assert Kop.eltype == dtype
+    for mode, Kx, o in (("N", Kd, Kop), ("T", Kd.T, Kop.T), ("C", Kd.conj().T, Kop.H)):
+        nin, nout = Kx.shape[1], Kx.shape[0]
+        x = (rng.standard_normal(nin) + 1j * rng.standard_normal(nin)).astype(npc)
+        for (a, b) in ((complex(1), complex(0)), (2.0, -3.0), (1.5 - 0.5j, 0.25 + 2j)):
+            r0 = (rng.standard_normal(nout) + 1j * rng.standard_normal(nout)).astype(npc)
+            if b == 0:
+                r0[:] = np.nan + 1j * np.nan
+            res = T(r0.copy(), dev)
+            lo.mul(res, o, T(x, dev), a, b)
+            base = np.zeros(nout, npc) if b == 0 else r0.copy()
+            want = oracle.kron_mul(base, A, B, x, a, b, trans={"N": False, "T": "T", "C": "C"}[mode],
+                                   flags=oracle.scalar_flags(npc, a, b))
+            scale = np.linalg.norm(Kx, 1) * np.abs(x).max() * abs(a) + abs(b) * (0 if b == 0 else np.abs(r0).max()) + 1e-300
+            assert np.abs(res.cpu().numpy().astype(np.complex128) - want.astype(np.complex128)).max() <= tol * scale, (mode, a, b)
+            dense = a * (Kx @ x.astype(np.complex128)) + (0 if b == 0 else b * r0.astype(np.complex128))
+            assert np.abs(res.cpu().numpy().astype(np.complex128) - dense).max() <= 4 * tol * scale, (mode, a, b)
+
+
+def test_complex_kron_tracks_factor_updates(lo, dev):
+    """a complex matrix factor is split into planes once and re-split when the caller updates it in place."""
+    rng = np.random.default_rng(9)
+    A = T(rng.standard_normal((6, 4)) + 1j * rng.standard_normal((6, 4)), dev)
+    B = T(rng.standard_normal((3, 5)), dev)
+    K = lo.kron(A, B)
+    x = T(rng.standard_normal(20) + 1j * rng.standard_normal(20), dev)
+    for _ in range(2):
+        want = np.kron(A.cpu().numpy(), B.cpu().numpy()) @ x.cpu().numpy()
+        assert np.abs((K * x).cpu().numpy() - want).max() <= 1e-12 * np.abs(want).max()
+        A.mul_(1.5 - 0.5j)
+        B.add_(0.25)
+        lo.touched(A)
+        lo.touched(B)

@@ -398,6 +398,23 @@ def test_kat_kron(kat):
     assert np.linalg.norm(got - np.array(c["expect_mul5"]), 1) <= 1e-12 * nK
 
 
+def test_kat_complex_kron(kat):
+    """test/test_kron.jl:3-36, the Float64 A x ComplexF64 B pairing: T*x, transpose(T)*x, T'*x, 5-arg mul!."""
+    (c,) = _by_kind(kat, "ckron")
+    A = np.array(c["A"])
+    B = np.array([[complex(*e) for e in row] for row in c["B"]])
+    K = np.array([[complex(*e) for e in row] for row in c["K"]])
+    assert np.array_equal(K, np.kron(A, B))
+    normK = np.abs(K).sum(axis=0).max()
+    x, xt, r0 = _cx(c["x"]), _cx(c["xt"]), _cx(c["res0"])
+    nan = lambda k: np.full(k, np.nan + 1j * np.nan)
+    assert np.abs(oracle.kron_mul(nan(K.shape[0]), A, B, x, complex(1), complex(0)) - _cx(c["expect_apply"])).sum() <= 1e-12 * normK
+    assert np.abs(oracle.kron_mul(nan(K.shape[1]), A, B, xt, complex(1), complex(0), trans="T") - _cx(c["expect_tapply"])).sum() <= 1e-12 * normK
+    assert np.abs(oracle.kron_mul(nan(K.shape[1]), A, B, xt, complex(1), complex(0), trans="C") - _cx(c["expect_ctapply"])).sum() <= 1e-12 * normK
+    got = oracle.kron_mul(r0.copy(), A, B, x, complex(*c["alpha"]), complex(*c["beta"]))
+    assert np.abs(got - _cx(c["expect_mul5"])).sum() <= 1e-12 * normK
+
+
 def test_complex_mixed_scalars_and_eye_zeros():
     """ComplexF32 data with Float64 / ComplexF64 / Float32 scalars: every term in its own type (component-wise
     model in NumPy, exact because every product is formed in float64 and rounded as the oracle does)."""

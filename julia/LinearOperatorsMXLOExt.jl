@@ -378,7 +378,7 @@ function BlockDiagonalOperator(::Type{T}, blocks...; S = MXVector{T}) where {T}
 end
 
 # ---- a9 kron (src/kron.jl:10-49): two MFMA GEMMs, no CPU copy of x (:16), work vector allocated once --------
-function kron(A::MXMatrix{T}, B::MXMatrix{T}) where {T}
+function kron(A::MXMatrix{T}, B::MXMatrix{T}) where {T <: RealT}
   m, n = size(A)
   p, q = size(B)
   work = MXVector{T}(undef, max(p * n, q * m))
@@ -403,6 +403,39 @@ function kron(A::MaybeT{T}, B::MaybeT{T}) where {T <: RealT}
       ctx(), dt(T), res.ptr, As.data.ptr, As.m, As.n, As.m, ta ⊻ Int32(tr), Bs.data.ptr, Bs.m, Bs.n, Bs.m, tb ⊻ Int32(tr),
       x.ptr, work.ptr, α, β, flags(T, α, β)))
   LinearOperator{T, MXVector{T}}(m * p, n * q, false, false, mulmode(0), mulmode(1), mulmode(1))
+end
+
+# kron with complex factors (test/test_kron.jl:3-8 pairs a Float64 A with a ComplexF64 B): the library works on REAL
+# planes — a complex factor is split once into (re, im) column-major MXMatrix planes, a real factor is passed as it is
+# with a NULL imaginary plane; every complex product is 4 (2) real MFMA GEMMs. mode bit 0 = transposed, bit 1 = conjugated.
+struct Planes{R}
+  re::MXMatrix{R}
+  im::Union{MXMatrix{R}, Nothing}
+end
+planes(A::MXMatrix{R}) where {R <: RealT} = Planes{R}(A, nothing)
+function planes(A::MXMatrix{Complex{R}}) where {R <: RealT}
+  h = Array(A.data)                                     # split ONCE at construction (host round trip is fine here)
+  m, n = size(A)
+  Planes{R}(MXMatrix{R}(MXVector(real.(h)), m, n), MXMatrix{R}(MXVector(imag.(h)), m, n))
+end
+function kron(A::MXMatrix{TA}, B::MXMatrix{TB}) where {TA <: Union{RealT, CplxT}, TB <: CplxT}
+  ckron(A, B)
+end
+kron(A::MXMatrix{TA}, B::MXMatrix{TB}) where {TA <: CplxT, TB <: RealT} = ckron(A, B)
+function ckron(A::MXMatrix, B::MXMatrix)
+  T = promote_type(eltype(A), eltype(B))
+  R = real(T)
+  pa, pb = planes(A), planes(B)
+  (eltype(pa.re) === R && eltype(pb.re) === R) || throw(ArgumentError("kron: convert the factors to a common precision first"))
+  m, n = size(A)
+  p, q = size(B)
+  work = MXVector{R}(undef, 2 * (max(q * n, p * m) + max(m * q, n * p) + max(p * m, q * n)) + 24)
+  imptr(x) = x === nothing ? C_NULL : x.data.ptr
+  mulmode(mode) = (res, x, α, β) -> check(ccall((:mxlo_kron_mul_c, lib), Int32,
+      (P, Int32, P, P, P, Int64, Int64, Int64, Int32, P, P, Int64, Int64, Int64, Int32, P, P, Float64, Float64, Float64, Float64, Int32),
+      ctx(), dt(T), res.ptr, pa.re.data.ptr, imptr(pa.im), m, n, m, Int32(mode), pb.re.data.ptr, imptr(pb.im), p, q, p, Int32(mode),
+      x.ptr, work.ptr, re(α), im(α), re(β), im(β), flags(T, α, β)))
+  LinearOperator{T, MXVector{T}}(m * p, n * q, false, false, mulmode(0), mulmode(1), mulmode(3))
 end
 
 # ---- a12-a16 quasi-Newton operators: the structural contract (src/lbfgs.jl:62-104, src/lsr1.jl:39-78) ---------

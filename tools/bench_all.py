@@ -163,6 +163,21 @@ if sec("kron"):
             del A, B, K, x, y
     torch.cuda.empty_cache()
 
+# kron with complex factors: 8 (4 with one real factor) real MFMA GEMMs per apply + split / join passes
+if sec("kron"):
+    for sz in (512, 1024):
+        Ac = torch.complex(rnd(sz * sz), rnd(sz * sz)).reshape(sz, sz).t() / 32
+        Bc = torch.complex(rnd(sz * sz), rnd(sz * sz)).reshape(sz, sz).t() / 32
+        Br = (rnd(sz * sz).reshape(sz, sz).t() / 32).contiguous().t()
+        xk = torch.complex(rnd(sz * sz), rnd(sz * sz))
+        yk = torch.empty_like(xk)
+        for nm, K, ng in (("complex x complex", lo.kron(Ac, Bc), 8), ("real x complex", lo.kron(Br, Bc), 6)):
+            best = min(timeit(lambda: lo.mul(yk, K, xk, 1.0, 0.0), 20) for _ in range(3))
+            tf = ng * 2.0 * sz ** 3 / best / 1e9
+            print(f"kron {sz}^2 (x) {sz}^2 complex128, {nm} ({ng} real GEMMs){'':8s} {best*1e3:10.1f} us {tf:8.1f} TF (real flop)", flush=True)
+        del Ac, Bc, Br, xk, yk, K
+    torch.cuda.empty_cache()
+
 # quasi-Newton push! and solve (n = 5e7)
 n = 50_000_000
 for kind, m in (("inv", 10), ("fwd", 10), ("fwd", 20), ("lsr1", 10)):

@@ -382,6 +382,13 @@ int32_t mxlo_kron_mul_c(mxlo_ctx *ctx, int32_t dtype, void *res, const void *Ar,
                         int64_t lda, int32_t mode_a, const void *Br, const void *Bi, int64_t bp, int64_t bq, int64_t ldb,
                         int32_t mode_b, const void *x, void *work, double alpha_re, double alpha_im, double beta_re,
                         double beta_im, int32_t flags);
+/* A REAL operator applied to complex vectors (eltype(op) = Float64, x::Vector{ComplexF64}: test/test_kron.jl
+ * "issue110"; Julia runs the generic closure on the complex vectors). The glue applies the real operator to the two
+ * planes: mxlo_split_c writes re[i], im[i] of x; mxlo_join_c computes res = α*(re + i*im) (+ β*res) with complex or
+ * Real α, β (flags as for the other _c entry points). dtype names the COMPLEX type; re / im are its component type. */
+int32_t mxlo_split_c(mxlo_ctx *ctx, int32_t dtype, void *re, void *im, const void *x, int64_t n);
+int32_t mxlo_join_c(mxlo_ctx *ctx, int32_t dtype, void *res, const void *re, const void *im, int64_t n,
+                    double alpha_re, double alpha_im, double beta_re, double beta_im, int32_t flags);
 /* kron(A, B) when BOTH factors are diagonal operators (opDiagonal / opEye; pass NULL for an identity
  * factor): the fused row/col index-decomposition form of src/kron.jl:14-22,
  *   res[r + c*p] = alpha*(dB[r]*(x[r + c*p]*dA[c])) (+ beta*res[r + c*p]),  A is m x m, B is p x p.

@@ -721,3 +721,46 @@ MXLO_API int32_t mxlo_kron_mul_c(mxlo_ctx *ctx, int32_t dtype, void *res, const 
                       (const float *)Bi, bp, bq, ldb, mode_b, (const C<float> *)x, (float *)work,
                       scal_args(4, alpha_re, alpha_im, beta_re, beta_im, flags));
 }
+
+// A REAL operator applied to complex vectors (K * x with eltype(K) = Float64, x::Vector{ComplexF64} — test/test_kron.jl
+// "issue110"): the glue splits x into planes, applies the real operator to each, and joins res = α*(yr + i*yi) (+ β*res).
+MXLO_API int32_t mxlo_split_c(mxlo_ctx *ctx, int32_t dtype, void *re, void *im, const void *x, int64_t n) {
+  CHECK_C("mxlo_split_c");
+  MXLO_REQUIRE(n >= 0 && (n == 0 || (re && im && x)), MXLO_EINVAL, "mxlo_split_c: bad argument");
+  if (n == 0) return MXLO_OK;
+  const int grid = grid_for(ctx, n, kBlock, 8);
+  if (dtype == MXLO_C64)
+    hipLaunchKernelGGL((cplx_split_kernel<double>), dim3(grid), dim3(kBlock), 0, ctx->stream, (double *)re, (double *)im,
+                       (const C<double> *)x, n);
+  else
+    hipLaunchKernelGGL((cplx_split_kernel<float>), dim3(grid), dim3(kBlock), 0, ctx->stream, (float *)re, (float *)im,
+                       (const C<float> *)x, n);
+  MXLO_LAUNCH_CHECK();
+  return MXLO_OK;
+}
+
+namespace {
+template <typename R>
+int32_t cjoin(mxlo_ctx *ctx, C<R> *res, const R *re, const R *im, int64_t n, const ScalArgs &s) {
+  const int grid = grid_for(ctx, n, kBlock, 8);
+  return dispatch_c<R>(s, [&]<typename RA, typename RB, bool B0>() -> int32_t {
+    const Sc<RA> a{(RA)s.are, (RA)s.aim, s.a_real};
+    const Sc<RB> b{(RB)s.bre, (RB)s.bim, s.b_real};
+    hipLaunchKernelGGL((cplx_join_kernel<R, RA, RB, B0>), dim3(grid), dim3(kBlock), 0, ctx->stream, res, re, im, n, a, b);
+    MXLO_LAUNCH_CHECK();
+    return MXLO_OK;
+  });
+}
+}  // namespace
+
+MXLO_API int32_t mxlo_join_c(mxlo_ctx *ctx, int32_t dtype, void *res, const void *re, const void *im, int64_t n,
+                             double alpha_re, double alpha_im, double beta_re, double beta_im, int32_t flags) {
+  CHECK_C("mxlo_join_c");
+  MXLO_REQUIRE(n >= 0 && (n == 0 || (res && re && im)), MXLO_EINVAL, "mxlo_join_c: bad argument");
+  if (n == 0) return MXLO_OK;
+  if (dtype == MXLO_C64)
+    return cjoin<double>(ctx, (C<double> *)res, (const double *)re, (const double *)im, n,
+                         scal_args(8, alpha_re, alpha_im, beta_re, beta_im, flags));
+  return cjoin<float>(ctx, (C<float> *)res, (const float *)re, (const float *)im, n,
+                      scal_args(4, alpha_re, alpha_im, beta_re, beta_im, flags));
+}

@@ -448,6 +448,8 @@ def mul(res: torch.Tensor, op, v: torch.Tensor, alpha=None, beta=None):
         alpha, beta = one(v.dtype), zero(v.dtype)
     elif alpha is None or beta is None:
         raise TypeError("mul! takes either (res, op, v) or (res, op, v, alpha, beta)")
+    if v.dtype.is_complex and op.eltype.is_floating_point:
+        return _mul_real_op_complex_vec(res, op, v, alpha, beta)
     if isinstance(op, AdjointLinearOperator):
         return _mul_adjoint(res, op, v, alpha, beta)
     if isinstance(op, TransposeLinearOperator):
@@ -469,6 +471,42 @@ def mul(res: torch.Tensor, op, v: torch.Tensor, alpha=None, beta=None):
         if not (beta == 0 or op.Mv.numel() != 0):
             allocate_vectors_args3(op)
         prod3(res, op.prod, v, alpha, beta, op.Mv)
+    return touched(res)
+
+
+_PLANES: dict = {}
+
+
+def _mul_real_op_complex_vec(res, op, v, alpha, beta):
+    """A REAL operator (eltype Float64 / Float32; wrappers included: for a real operator adjoint == transpose) applied
+    to complex vectors — `K * x` with `x::Vector{ComplexF64}` (test/test_kron.jl "issue110"). Julia runs the generic
+    closure on the complex vectors; the device leaves are instantiated per element type, so the real operator is applied
+    to the real and imaginary planes (two real 3-arg applies) and res = α*(yr + i*yi) (+ β*res) is formed in one pass.
+    Equal to the reference up to rounding (1e-12-class), not bit-for-bit."""
+    from . import _lib
+    from .device import dtype_code, get_ctx, ptr
+    if not res.dtype.is_complex or res.dtype != v.dtype:
+        raise TypeError("a complex input vector needs a complex result vector of the same type")
+    comp = torch.float64 if v.dtype == torch.complex128 else torch.float32
+    if op.eltype != comp:
+        raise TypeError(f"operator eltype {op.eltype} next to {v.dtype} vectors: convert one of them")
+    if not (v.shape[0] == op.size(2) and res.shape[0] == op.size(1)):
+        raise LinearOperatorException("shape mismatch")
+    nin, nout = v.shape[0], res.shape[0]
+    key = (nin, nout, comp, v.device)
+    bufs = _PLANES.get(key)
+    if bufs is None:                                    # temporaries cached per shape (the reference allocates per call)
+        if len(_PLANES) > 8:
+            _PLANES.clear()
+        bufs = _PLANES[key] = tuple(torch.empty(k, dtype=comp, device=v.device) for k in (nin, nin, nout, nout))
+    xr, xi, yr, yi = bufs
+    ctx = get_ctx(v.device)
+    code = dtype_code(v.dtype, True)
+    _lib.call("mxlo_split_c", ctx.handle, code, ptr(xr), ptr(xi), ptr(v), nin)
+    mul(yr, op, xr)
+    mul(yi, op, xi)
+    _lib.call("mxlo_join_c", ctx.handle, code, ptr(res), ptr(yr), ptr(yi), nout, *_c4(alpha, beta),
+              scalar_flags(res.dtype, alpha, beta))
     return touched(res)
 
 

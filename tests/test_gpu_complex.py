@@ -360,3 +360,42 @@ def test_complex_dense_in_operator_trees_and_contract(lo, dev):
     s1 = snap()
     dlt = [b - a for a, b in zip(s0, s1)]
     assert dlt[10] >= 6 and not any(dlt[k] for k in range(12) if k != 10), dlt      # launches only
+
+
+def test_real_operator_applied_to_complex_vectors(lo, dev):
+    """test/test_kron.jl "issue110": K = kron(A, LinearOperator(A)) with Float64 A applied to a ComplexF64 x gives a
+    ComplexF64 y. Generalised: any real operator (leaves, combinators, wrappers, quasi-Newton) on complex vectors equals
+    the dense real matrix times the complex vector, 3-arg and 5-arg with complex / real scalars."""
+    rng = np.random.default_rng(110)
+    A = rng.random((2, 2))
+    At = T(A, dev)
+    K = lo.kron(At, lo.LinearOperatorFromMatrix(At))
+    x = crand(rng, 4, np.complex128)
+    y = K * T(x, dev)
+    assert y.dtype == torch.complex128                               # @test eltype(y) == Complex{Float64}
+    assert rel(y.cpu().numpy(), np.kron(A, A) @ x) <= 1e-13
+    n = 257
+    d, h = rng.standard_normal(n), rng.standard_normal(n)
+    h /= np.linalg.norm(h)
+    M = rng.standard_normal((n, n))
+    B = lo.LBFGSOperator(n, mem=3, device=dev)
+    for _ in range(4):
+        s = rng.uniform(-1, 1, n)
+        lo.push(B, T(s, dev), T(s * rng.uniform(0.5, 2.0, n), dev))
+    op = lo.opDiagonal(T(d, dev)) * lo.opHouseholder(T(h, dev)) + lo.LinearOperatorFromMatrix(T(M, dev)).T * 0.5 + B
+    dense = lo.Matrix(op).cpu().numpy()
+    v = crand(rng, n, np.complex128)
+    for o, Dm in ((op, dense), (op.T, dense.T), (op.H, dense.T)):
+        assert rel((o * T(v, dev)).cpu().numpy(), Dm @ v) <= 1e-11
+        r0 = crand(rng, n, np.complex128)
+        res = T(r0.copy(), dev)
+        lo.mul(res, o, T(v, dev), 1.5 - 2j, 0.25 + 1j)
+        assert rel(res.cpu().numpy(), (1.5 - 2j) * (Dm @ v) + (0.25 + 1j) * r0) <= 1e-11
+        res = T(np.full(n, np.nan + 1j * np.nan), dev)
+        lo.mul(res, o, T(v, dev), 2.0, 0.0)                          # beta == 0 does not read res
+        assert rel(res.cpu().numpy(), 2.0 * (Dm @ v)) <= 1e-11
+    v32 = crand(rng, n, np.complex64)
+    D32 = lo.opDiagonal(T(d.astype(np.float32), dev))
+    assert rel((D32 * T(v32, dev)).cpu().numpy(), d.astype(np.float32) * v32) <= 1e-6
+    with pytest.raises(TypeError):
+        lo.opDiagonal(T(d, dev)) * T(v32, dev)                       # Float64 operator next to ComplexF32 vectors

@@ -438,6 +438,22 @@ function ckron(A::MXMatrix, B::MXMatrix)
   LinearOperator{T, MXVector{T}}(m * p, n * q, false, false, mulmode(0), mulmode(1), mulmode(3))
 end
 
+# ---- a REAL operator applied to complex device vectors (test/test_kron.jl "issue110": K * x with x::Vector{ComplexF64})
+# The leaves are instantiated per element type, so the real operator is applied to the two planes of x and the result is
+# joined with the caller's (possibly complex) α, β: res = α*(op*re(x) + i*op*im(x)) + β*res.
+function LinearAlgebra.mul!(res::MXVector{Complex{R}}, op::LinearOperators.AbstractLinearOperator{R}, v::MXVector{Complex{R}},
+                            α, β) where {R <: RealT}
+  T = Complex{R}
+  xr, xi = MXVector{R}(undef, length(v)), MXVector{R}(undef, length(v))
+  yr, yi = MXVector{R}(undef, length(res)), MXVector{R}(undef, length(res))
+  check(ccall((:mxlo_split_c, lib), Int32, (P, Int32, P, P, P, Int64), ctx(), dt(T), xr.ptr, xi.ptr, v.ptr, length(v)))
+  mul!(yr, op, xr)
+  mul!(yi, op, xi)
+  check(ccall((:mxlo_join_c, lib), Int32, (P, Int32, P, P, P, Int64, Float64, Float64, Float64, Float64, Int32),
+              ctx(), dt(T), res.ptr, yr.ptr, yi.ptr, length(res), re(α), im(α), re(β), im(β), flags(T, α, β)))
+  res
+end
+
 # ---- a12-a16 quasi-Newton operators: the structural contract (src/lbfgs.jl:62-104, src/lsr1.jl:39-78) ---------
 struct MXQNData                # stands in for op.data: fields the reference's tests read come from the handle
   h::Ptr{Cvoid}

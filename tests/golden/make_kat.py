@@ -99,6 +99,58 @@ cases.append(dict(name="cat_eye_zeros", ref="test/test_cat.jl:44-46", kind="cat_
 cases.append(dict(name="cat_vcat_eye", ref="test/test_cat.jl:48-50", kind="cat_vcat_eye",
                   v=fl(simple_vector(2)), expect=fl(simple_vector(2) + simple_vector(2))))
 
+# ---------------------------------------------------------------- solve_shifted_system! / ldiv! (test_solve_shifted_system.jl:5-61)
+# setup_test_val: B = LBFGSOperator(n, mem = M, scaling), 10 pushes, x known, b = B*x + sigma*x; the test asserts
+# solve_shifted_system!(x_sol, B, b, sigma) ≈ x (1e-6) and, for sigma = 0, ldiv!(x_sol, B, b) ≈ H*b with the inverse
+# operator. The test draws rand pairs; here the pairs are deterministic rationals with positive curvature and the dense
+# BFGS matrix of the last M pairs (B0 = I / gamma, gamma = y's/y'y of the LAST pair when scaling) is formed exactly.
+def solve_exact(Mx, rhs):
+    nn = len(rhs)
+    Aug = [list(Mx[i]) + [rhs[i]] for i in range(nn)]
+    for c_ in range(nn):
+        piv = next(r for r in range(c_, nn) if Aug[r][c_] != 0)
+        Aug[c_], Aug[piv] = Aug[piv], Aug[c_]
+        for r in range(nn):
+            if r != c_ and Aug[r][c_] != 0:
+                f_ = Aug[r][c_] / Aug[c_][c_]
+                Aug[r] = [a - f_ * b_ for a, b_ in zip(Aug[r], Aug[c_])]
+    return [Aug[i][nn] / Aug[i][i] for i in range(nn)]
+
+
+ns, Ms = 8, 5
+spairs = []
+for k in range(1, 11):
+    sv = [F(((i + 1) * k) % 7 + 1, 4) * (1 if (i + k) % 3 else -1) for i in range(ns)]
+    yv = [sv[i] * (1 + F(i % 3, 2)) + F((i + k) % 5 - 2, 16) for i in range(ns)]
+    assert dotf(sv, yv) > 0
+    spairs.append((sv, yv))
+xs_true = [F((-1) ** i * (i + 1), 2) for i in range(ns)]
+for scaling_ in (False, True):
+    kept_ = spairs[-Ms:]
+    gam = dotf(kept_[-1][1], kept_[-1][0]) / dotf(kept_[-1][1], kept_[-1][1]) if scaling_ else F(1)
+    Bd = [[(1 / gam if i == j else F(0)) for j in range(ns)] for i in range(ns)]
+    Hd = eye(ns)
+    for sv, yv in kept_:
+        Bs_ = matvec(Bd, sv)
+        Bd = [[Bd[i][j] - Bs_[i] * Bs_[j] / dotf(sv, Bs_) + yv[i] * yv[j] / dotf(yv, sv) for j in range(ns)] for i in range(ns)]
+        rho_ = 1 / dotf(yv, sv)
+        Hy_ = matvec(Hd, yv)
+        Hd = [[Hd[i][j] - rho_ * (sv[i] * Hy_[j] + Hy_[i] * sv[j]) + rho_ * (1 + rho_ * dotf(yv, Hy_)) * sv[i] * sv[j]
+               for j in range(ns)] for i in range(ns)]
+    for sig in ((F(1, 8), F(0), F(3)) if not scaling_ else (F(1, 8), F(2))):
+        bvec = [a + sig * x_ for a, x_ in zip(matvec(Bd, xs_true), xs_true)]
+        # the exact solution of (B + sigma I) x = float(b): b is rounded to Float64 when stored, so solve for THAT b
+        bfl = [F(float(t)) for t in bvec]
+        Bsig = [[Bd[i][j] + (sig if i == j else 0) for j in range(ns)] for i in range(ns)]
+        case = dict(name=f"solve_shifted_scaling{int(scaling_)}_sigma{float(sig):g}",
+                    ref="test/test_solve_shifted_system.jl:5-61 (deterministic pairs)", kind="solve_shifted",
+                    n=ns, mem=Ms, scaling=scaling_, sigma=float(sig), pairs=[dict(s=fl(a), y=fl(b_)) for a, b_ in spairs],
+                    b=[float(t) for t in bvec], expect_x=fl(solve_exact(Bsig, bfl)), x_true=fl(xs_true),
+                    tol="1e-10 relative (reference bar: isapprox(atol = rtol = 1e-6))")
+        if sig == 0 and not scaling_:
+            case["expect_Hb"] = fl(matvec(Hd, bfl))            # ldiv! test: x == H*b with the inverse operator (:49-60)
+        cases.append(case)
+
 # ---------------------------------------------------------------- diagonal quasi-Newton apply (test_diag.jl:75-106)
 for nm, d in (("DiagonalPSB_gradf", [2, -1, 2]), ("DiagonalAndrei_gradf", [2, -2, 2])):
     x = [F(3), F(-5), F(7)]

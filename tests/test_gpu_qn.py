@@ -36,6 +36,35 @@ def pairs(rng, n, k, dtype=np.float64):
 
 
 # ------------------------------------------------------------------------------- KATs
+def test_kat_solve_shifted_system(lo, dev, kat):
+    """test/test_solve_shifted_system.jl:5-61 through the ABI: the exact rational solution of (B + σI) x = b for the dense
+    BFGS matrix of the kept pairs (scaling off / on, σ = 0, 1/8, 2, 3), every forward push mode; result is x itself
+    (`result === x_sol`), finite; negative σ raises; ldiv!(x, B, b) ≈ H*b with the inverse operator (σ = 0)."""
+    cs = [c for c in kat if c["kind"] == "solve_shifted"]
+    assert len(cs) == 5
+    for c in cs:
+        n = c["n"]
+        for pm in ("compact", "gram", "reforder"):
+            B = lo.LBFGSOperator(n, mem=c["mem"], scaling=c["scaling"], device=dev).set_push_mode(pm)
+            H = lo.InverseLBFGSOperator(n, mem=c["mem"], scaling=False, device=dev)
+            for p in c["pairs"]:
+                lo.push(B, T(np.array(p["s"]), dev), T(np.array(p["y"]), dev))
+                lo.push(H, T(np.array(p["s"]), dev), T(np.array(p["y"]), dev))
+            b = T(np.array(c["b"]), dev)
+            x_sol = torch.zeros(n, dtype=torch.float64, device=dev)
+            result = lo.solve_shifted_system(x_sol, B, b, c["sigma"])
+            assert result is x_sol and len(result) == n and bool(torch.isfinite(result).all())      # :30-37
+            assert rel(x_sol.cpu().numpy(), np.array(c["expect_x"])) <= 1e-10, (c["name"], pm)
+            assert np.allclose(x_sol.cpu().numpy(), np.array(c["x_true"]), atol=1e-6, rtol=1e-6)      # :40
+            if "expect_Hb" in c:
+                xl = lo.ldiv(torch.zeros(n, dtype=torch.float64, device=dev), B, b)                  # :49-60
+                xH = (H * b).cpu().numpy()
+                assert rel(xH, np.array(c["expect_Hb"])) <= 1e-10
+                assert np.allclose(xl.cpu().numpy(), xH, atol=1e-6, rtol=1e-6)
+            with pytest.raises(ValueError):
+                lo.solve_shifted_system(x_sol, B, b, -0.1)                                           # :43-47
+
+
 def test_kat_lbfgs(lo, dev, kat):
     """test_lbfgs.jl:7-70 through the ABI (values from dense BFGS in exact rationals)."""
     for c in [c for c in kat if c["kind"] == "lbfgs"]:

@@ -118,6 +118,30 @@ def test_kat_lbfgs(kat):
         assert np.allclose(LB.mul(np.empty(n), v), np.array(c["expect_Bv"]), rtol=1e-12)
 
 
+def test_kat_solve_shifted_system(kat):
+    """test/test_solve_shifted_system.jl:5-61 with deterministic pairs: the exact rational solution of (B + σI) x = b for
+    the dense BFGS matrix of the kept pairs (scaling off and on), σ = 0 through ldiv! against the inverse operator."""
+    cs = _by_kind(kat, "solve_shifted")
+    assert len(cs) == 5
+    rel = lambda a, b: np.linalg.norm(a - b) / np.linalg.norm(b)
+    for c in cs:
+        n = c["n"]
+        B = oracle.LBFGS(n, mem=c["mem"], scaling=c["scaling"], inverse=False)
+        H = oracle.LBFGS(n, mem=c["mem"], scaling=False, inverse=True)
+        for p in c["pairs"]:
+            assert B.push(np.array(p["s"]), np.array(p["y"]))
+            H.push(np.array(p["s"]), np.array(p["y"]))
+        b = np.array(c["b"])
+        x = B.solve_shifted(np.zeros(n), b, c["sigma"])
+        assert np.all(np.isfinite(x)) and rel(x, np.array(c["expect_x"])) <= 1e-10, c["name"]
+        assert np.allclose(x, np.array(c["x_true"]), atol=1e-6, rtol=1e-6)                 # the reference's own assertion
+        if "expect_Hb" in c:
+            assert rel(H.mul(np.empty(n), b), np.array(c["expect_Hb"])) <= 1e-10
+            assert np.allclose(x, H.mul(np.empty(n), b), atol=1e-6, rtol=1e-6)             # ldiv! test (:49-60)
+    with pytest.raises(ValueError):
+        B.solve_shifted(np.zeros(n), b, -0.1)                                              # ArgumentError (:43-47)
+
+
 def test_kat_lsr1(kat):
     for c in _by_kind(kat, "lsr1"):
         n = c["n"]

@@ -697,11 +697,11 @@ def compose(op1, op2):
 def scale_op(op, x):
     """op * x, x * op — src/operations.jl:163-183; wrappers src/adjtrans.jl:267-273."""
     if isinstance(op, AdjointLinearOperator):
-        return adjoint(scale_op(op.parent, x))
+        return adjoint(scale_op(op.parent, conj_scalar(x)))         # adjoint(op.parent * conj(x)) (src/adjtrans.jl:266)
     if isinstance(op, TransposeLinearOperator):
         return transpose(scale_op(op.parent, x))
     if isinstance(op, ConjugateLinearOperator):
-        return conj(scale_op(op.parent, x))
+        return conj(scale_op(op.parent, conj_scalar(x)))            # conj(op.parent * conj(x)) (src/adjtrans.jl:268)
     T = op.eltype
     prod = lambda res, v, a, b: mul(res, op, v, x * a, b)
     tprod = lambda res, u, a, b: mul(res, transpose(op), u, x * a, b)

@@ -399,3 +399,132 @@ def test_real_operator_applied_to_complex_vectors(lo, dev):
     assert rel((D32 * T(v32, dev)).cpu().numpy(), d.astype(np.float32) * v32) <= 1e-6
     with pytest.raises(TypeError):
         lo.opDiagonal(T(d, dev)) * T(v32, dev)                       # Float64 operator next to ComplexF32 vectors
+
+
+# ------------------------------------------------------------------------------------------ random complex operator trees
+class _CGen:
+    """Random trees over the complex leaves (diagonal, identity, zeros, Householder, dense in either layout, Hermitian
+    with a real diagonal, kron with a real and a complex factor) and the reference's combinators (+, -, *, real / complex
+    scalar, hcat, vcat and ONE kind of lazy wrapper per tree), evaluated side by side on dense NumPy matrices.
+
+    One wrapper kind per tree (`wrap` = "T" or "H") because the reference's ConjugateLinearOperator — what
+    transpose(adjoint(X)) and adjoint(transpose(X)) reduce to — conjugates the INCOMING res and does not conjugate α, β
+    (src/adjtrans.jl:226-237): inside a sum or a cat, where it receives β = 1, the reference's result is not the
+    mathematical one. That quirk is reproduced on purpose and pinned by
+    test_conjugate_wrapper_reproduces_reference_quirk; here the trees stay where the reference is mathematically right."""
+
+    def __init__(self, lo, dev, seed):
+        self.lo, self.dev, self.rng = lo, dev, np.random.default_rng(50_000 + seed)
+        self.wrap = "T" if seed % 2 else "H"
+
+    def c(self, *shape):
+        return self.rng.standard_normal(shape) + 1j * self.rng.standard_normal(shape)
+
+    def leaf(self, m, n):
+        lo, dev, rng = self.lo, self.dev, self.rng
+        kinds = ["dense_col", "dense_row", "zeros"]
+        if m == n:
+            kinds += ["diag", "eye", "householder", "hermitian"]
+            if m % 2 == 0 and m >= 4:
+                kinds.append("kron")
+        k = kinds[rng.integers(len(kinds))]
+        S = lo.Storage(torch.complex128, dev)
+        if k == "dense_col":
+            A = self.c(m, n)
+            return lo.LinearOperatorFromMatrix(T(A.T.copy(), dev).t()), A, k
+        if k == "dense_row":
+            A = self.c(m, n)
+            return lo.LinearOperatorFromMatrix(T(A, dev)), A, k
+        if k == "zeros":
+            return lo.opZeros(torch.complex128, m, n, S=S), np.zeros((m, n), complex), k
+        if k == "diag":
+            d = self.c(n)
+            return lo.opDiagonal(T(d, dev)), np.diag(d), k
+        if k == "eye":
+            return lo.opEye(torch.complex128, n, S=S), np.eye(n, dtype=complex), k
+        if k == "householder":
+            h = self.c(n)
+            h /= np.linalg.norm(h)
+            return lo.opHouseholder(T(h, dev)), np.eye(n) - 2 * np.outer(h, h.conj()), k
+        if k == "hermitian":
+            A, d = self.c(n, n), rng.standard_normal(n)
+            L = np.tril(A, -1)
+            return lo.opHermitian(T(d, dev), T(A.T.copy(), dev).t()), L + L.conj().T + np.diag(d), k
+        A, B = rng.standard_normal((2, 2)), self.c(m // 2, n // 2)
+        return lo.kron(T(A, dev), T(B.T.copy(), dev).t()), np.kron(A, B), k
+
+    def tree(self, m, n, depth):
+        lo, rng = self.lo, self.rng
+        if depth == 0:
+            return self.leaf(m, n)
+        c = rng.integers(7)
+        if c in (0, 1):
+            a, A, da = self.tree(m, n, depth - 1)
+            b, B, db = self.tree(m, n, depth - 1)
+            return (a + b, A + B, f"({da} + {db})") if c == 0 else (a - b, A - B, f"({da} - {db})")
+        if c == 2:
+            k = int(rng.integers(1, 9))
+            a, A, da = self.tree(m, k, depth - 1)
+            b, B, db = self.tree(k, n, depth - 1)
+            return a * b, A @ B, f"({da} * {db})"
+        if c == 3:
+            x = complex(rng.uniform(-2, 2), rng.uniform(-2, 2)) if rng.integers(2) else float(rng.uniform(-2, 2))
+            a, A, d = self.tree(m, n, depth - 1)
+            return x * a, x * A, f"({x:.2f} * {d})"
+        if c == 4:
+            a, A, d = self.tree(n, m, depth - 1)
+            return (a.T, A.T, d + ".T") if self.wrap == "T" else (a.H, A.conj().T, d + ".H")
+        if c == 5 and n >= 2:
+            k = int(rng.integers(1, n))
+            a, A, da = self.tree(m, k, depth - 1)
+            b, B, db = self.tree(m, n - k, depth - 1)
+            return lo.hcat(a, b), np.hstack([A, B]), f"hcat({da}, {db})"
+        if c == 6 and m >= 2:
+            k = int(rng.integers(1, m))
+            a, A, da = self.tree(k, n, depth - 1)
+            b, B, db = self.tree(m - k, n, depth - 1)
+            return lo.vcat(a, b), np.vstack([A, B]), f"vcat({da}, {db})"
+        return self.leaf(m, n)
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("MXLO_CFUZZ_SEEDS", "160"))))
+def test_random_complex_operator_tree_vs_dense(lo, dev, seed):
+    """op*v and the tree's wrapper direction (transpose(op)*w for "T" trees, op'*w for "H" trees), both also in the 5-arg
+    form with complex (α, β), and Matrix(op), for random complex operator trees: the leaves' prod!/tprod!/ctprod!, the
+    inferred transposes of hermitian operators through the conj sandwiches of src/adjtrans.jl:113-136,193-204, and how
+    every combinator forwards α and β."""
+    g = _CGen(lo, dev, seed)
+    rng = g.rng
+    hi = 13 if seed % 4 else 33
+    m, n = int(rng.integers(1, hi)), int(rng.integers(1, hi))
+    op, M, desc = g.tree(m, n, depth=int(rng.integers(1, 4)))
+    assert op.shape == M.shape == (m, n), desc
+    v, w = g.c(n), g.c(m)
+    scale = max(np.linalg.norm(M, 2), 1.0) * 40          # trees multiply up to 3 levels of O(1..10) factors
+    close = lambda got, want, vec: np.linalg.norm(got - want) <= 1e-10 * scale * max(np.linalg.norm(vec), 1.0) + 1e-10 * np.linalg.norm(want)
+    back, Mb = (op.T, M.T) if g.wrap == "T" else (op.H, M.conj().T)
+    assert close((op * T(v, dev)).cpu().numpy(), M @ v, v), desc
+    assert close((back * T(w, dev)).cpu().numpy(), Mb @ w, w), desc
+    assert np.linalg.norm(lo.Matrix(op).cpu().numpy() - M) <= 1e-10 * scale * max(m, n), desc
+    a, b = 1.5 - 0.5j, 0.25 + 2j
+    for o, Mx, x, nr in ((op, M, v, m), (back, Mb, w, n)):
+        r0 = g.c(nr)
+        res = T(r0.copy(), dev)
+        lo.mul(res, o, T(x, dev), a, b)
+        assert close(res.cpu().numpy(), a * (Mx @ x) + b * r0, np.concatenate([x, r0])), desc
+
+
+def test_complex_scalar_times_lazy_wrappers(lo, dev):
+    """src/adjtrans.jl:266-272: x*A' = (conj(x)*A)', x*transpose(A) = transpose(x*A), x*conj(A) = conj(conj(x)*A) — a
+    complex scalar is conjugated when it moves inside an adjoint / conj wrapper (found by the random-tree test above)."""
+    rng = np.random.default_rng(24)
+    A = cmat(rng, 5, 7, np.complex128)
+    op = lo.LinearOperatorFromMatrix(T(A, dev))
+    x = -1.87 - 0.4j
+    for wrapped, M in ((op.H, A.conj().T), (op.T, A.T), (lo.conj(op), A.conj())):
+        v = crand(rng, M.shape[1], np.complex128)
+        for scaled in (x * wrapped, wrapped * x):
+            assert rel((scaled * T(v, dev)).cpu().numpy(), x * (M @ v)) <= 1e-13
+            w = crand(rng, M.shape[0], np.complex128)
+            assert rel((scaled.H * T(w, dev)).cpu().numpy(), np.conj(x) * (M.conj().T @ w)) <= 1e-13
+            assert rel((scaled.T * T(w, dev)).cpu().numpy(), x * (M.T @ w)) <= 1e-13

@@ -179,6 +179,20 @@ def _is_colon(I) -> bool:
     return I is Ellipsis or (isinstance(I, slice) and I == slice(None))
 
 
+def sorted_scatter_plan(idx_h: np.ndarray):
+    """`res .= 0; res[I] = u` (src/special-operators.jl:171-174) is sequential: with duplicates the LAST write wins.
+    Resolved once into a SORTED plan — strictly increasing target indices + the position in u of the surviving write —
+    so that the apply is the segment-owner kernel (res written exactly once, in full vectors) whatever the order of I.
+    Returns (sorted unique indices int64, source positions int64) or (idx, None) when I is already strictly increasing."""
+    idx_h = np.asarray(idx_h, dtype=np.int64).reshape(-1)
+    nrow = idx_h.size
+    svals, last_rev = np.unique(idx_h[::-1], return_index=True)
+    spos = (nrow - 1 - last_rev).astype(np.int64)
+    if spos.size == nrow and (nrow == 0 or bool(np.all(spos == np.arange(nrow)))):
+        return idx_h, None
+    return svals.astype(np.int64), spos
+
+
 def opRestriction(Idx, ncol: int, S: Optional[Storage] = None, device=None):
     """opRestriction(I, ncol; S) — src/special-operators.jl:176-203. The operator's eltype is the
     index integer type (Int64), like the reference (`LinearOperator{I, Vector{I}}`, :193)."""
@@ -209,14 +223,9 @@ def opRestriction(Idx, ncol: int, S: Optional[Storage] = None, device=None):
             raise LinearOperatorException(f"indices should be between 1 and {ncol}")
         nrow = idx_h.size
         idx_d = torch.from_numpy(idx_h.copy()).to(dev)
-        # `res .= 0; res[I] = u` (:171-174) is sequential: with duplicates the LAST write wins. Resolved once, here, into a
-        # SORTED plan — strictly increasing target indices + the position in u of the surviving write — so that the
-        # apply is the segment-owner kernel (res written exactly once, in full vectors) whatever the order of I.
-        svals, last_rev = np.unique(idx_h[::-1], return_index=True)
-        spos = (nrow - 1 - last_rev).astype(np.int64)
-        identity = spos.size == nrow and (nrow == 0 or bool(np.all(spos == np.arange(nrow))))
-        sidx_d = idx_d if identity else torch.from_numpy(svals.astype(np.int64)).to(dev)
-        spos_d = None if identity else torch.from_numpy(spos).to(dev)
+        svals, spos = sorted_scatter_plan(idx_h)
+        sidx_d = idx_d if spos is None else torch.from_numpy(svals).to(dev)
+        spos_d = None if spos is None else torch.from_numpy(spos).to(dev)
 
         def prod(res, v, a, b):
             ctx = get_ctx(res.device)

@@ -117,3 +117,38 @@ def test_shard_plan(lo):
     assert [b - a for a, b in blocks] == [256] * 4 and rows[1] == (256 * 1024, 512 * 1024)
     blocks, rows = P(0, 8).blocks_to_ranks([5, 1, 1, 1])
     assert sum(b - a for a, b in blocks) == 4
+
+
+def test_sorted_scatter_plan_is_last_write_wins(lo):
+    """The sorted plan behind the segment-owner extension kernel equals the sequential `res .= 0; res[I] = u`
+    (src/special-operators.jl:171-174) for any index list: sorted, unsorted, with duplicates, empty."""
+    from linearoperators_jl_amd.leaves import sorted_scatter_plan
+    rng = np.random.default_rng(0)
+    cases = [np.array([], dtype=np.int64), np.array([5]), np.arange(1, 50), np.array([2, 5, 2, 3, 5, 5]),
+             rng.permutation(40)[:17] + 1, rng.integers(1, 30, 100), np.sort(rng.integers(1, 30, 100))]
+    for idx in cases:
+        n = 64
+        u = rng.standard_normal(idx.size)
+        want = np.zeros(n)
+        for k, i in enumerate(idx):                      # the reference's sequential assignment
+            want[i - 1] = u[k]
+        svals, spos = sorted_scatter_plan(idx)
+        assert np.all(np.diff(svals) > 0)                # strictly increasing: what mxlo_scatter_zero_sorted requires
+        got = np.zeros(n)
+        got[svals - 1] = u[spos] if spos is not None else u
+        assert np.array_equal(got, want)
+        if idx.size and np.all(np.diff(idx) > 0):
+            assert spos is None and svals is not None and np.array_equal(svals, idx)
+
+
+def test_stored_colmajor_aliases_both_layouts(lo):
+    from linearoperators_jl_amd.leaves import _stored_colmajor
+    M = torch.arange(12.0).reshape(3, 4)                 # row-major: aliased as the column-major transpose
+    St, tr = _stored_colmajor(M)
+    assert tr and St.data_ptr() == M.data_ptr() and St.shape == (4, 3) and St.stride(0) == 1
+    Mc = M.t().contiguous().t()                          # column-major
+    St, tr = _stored_colmajor(Mc)
+    assert not tr and St.data_ptr() == Mc.data_ptr()
+    V = torch.arange(40.0).reshape(4, 10)[:, ::2]        # neither: copied once to column-major
+    St, tr = _stored_colmajor(V)
+    assert not tr and St.stride(0) == 1 and torch.equal(St, V)

@@ -75,6 +75,9 @@ similar(v::MXVector{T}) where {T} = MXVector{T}(undef, v.len)
 similar(v::MXVector, ::Type{T}, n::Integer) where {T} = MXVector{T}(undef, n)
 unsafe_convert(::Type{Ptr{Cvoid}}, v::MXVector) = Ptr{Cvoid}(v.ptr)
 getindex(v::MXVector, i::Integer) = error("scalar indexing of a device vector; use Array(v)")
+getindex(v::MXVector, r::UnitRange{<:Integer}) = copyto!(similar(v, eltype(v), length(r)), view(v, r))   # d[1:nrow] (special-operators.jl:159)
+Base.isreal(::MXVector{<:Real}) = true                       # opDiagonal's hermitian flag (special-operators.jl:141)
+Base.isreal(::MXVector{<:Complex}) = false                   # (a complex device vector is not scanned for zero imaginary parts)
 # contiguous views (cat.jl:17-18, special-operators.jl:263) stay device vectors: base pointer + offset
 view(v::MXVector{T}, r::UnitRange{<:Integer}) where {T} =
   MXVector{T}(v.ptr + (first(r) - 1) * sizeof(T), length(r), v)
@@ -121,8 +124,8 @@ const CplxT = Union{ComplexF64, ComplexF32}
 @inline rflags(α, β) = (α isa Real ? Int32(0x20) : Int32(0)) | (β isa Real ? Int32(0x40) : Int32(0))
 @inline flags(::Type{ComplexF64}, α, β) = rflags(α, β)
 @inline flags(::Type{ComplexF32}, α, β) = rflags(α, β) | wflags(α, β)
-@inline re(x) = Float64(real(x))
-@inline im(x) = Float64(imag(x))
+@inline rpart(x) = Float64(real(x))      # (re, im) pairs of the `_c` entry points; not named re/im: `im` is Base's imaginary unit
+@inline ipart(x) = Float64(imag(x))
 const P = Ptr{Cvoid}
 
 # ---- prod3! glue on MXVector (src/operations.jl:10-20) ----------------------------------------------------
@@ -133,13 +136,13 @@ scale!(res::MXVector{T}, α) where {T <: RealT} =
               flags(T, α, α)))
 scale!(res::MXVector{T}, α) where {T <: CplxT} =
   check(ccall((:mxlo_scale_c, lib), Int32, (P, Int32, P, Int64, Float64, Float64, Int32), ctx(), dt(T), res.ptr, res.len,
-              re(α), im(α), flags(T, α, α)))
+              rpart(α), ipart(α), flags(T, α, α)))
 axpby!(res::MXVector{T}, v::MXVector{T}, α, β) where {T <: RealT} =
   check(ccall((:mxlo_eye_mul, lib), Int32, (P, Int32, P, P, Int64, Int64, Float64, Float64, Int32),
               ctx(), dt(T), res.ptr, v.ptr, res.len, res.len, α, β, flags(T, α, β)))
 axpby!(res::MXVector{T}, v::MXVector{T}, α, β) where {T <: CplxT} =
   check(ccall((:mxlo_eye_mul_c, lib), Int32, (P, Int32, P, P, Int64, Int64, Float64, Float64, Float64, Float64, Int32),
-              ctx(), dt(T), res.ptr, v.ptr, res.len, res.len, re(α), im(α), re(β), im(β), flags(T, α, β)))
+              ctx(), dt(T), res.ptr, v.ptr, res.len, res.len, rpart(α), ipart(α), rpart(β), ipart(β), flags(T, α, β)))
 # conj!(res) / conj.(v) of the wrapper routing (src/adjtrans.jl:127-136,193-204,226-249) on device vectors
 function Base.conj!(v::MXVector{T}) where {T <: CplxT}
   check(ccall((:mxlo_conj_c, lib), Int32, (P, Int32, P, P, Int64), ctx(), dt(T), v.ptr, v.ptr, v.len))
@@ -152,6 +155,7 @@ function Base.conj(v::MXVector{T}) where {T <: CplxT}
   out
 end
 Base.Broadcast.broadcasted(::typeof(conj), v::MXVector{<:CplxT}) = conj(v)      # `conj.(v)` (adjtrans.jl:128)
+Base.Broadcast.broadcasted(::typeof(conj), v::MXVector{<:Real}) = v             # `conj.(d)` of the generic opDiagonal ctprod!
 
 # ---- BLAS-1 on device vectors: what Krylov.jl / JSOSolvers call between two mul! ------------------------------------
 # dot / norm need the scalar on the host: the fixed-order device reduction (mxlo_dot, all-reduce hook included, so
@@ -198,7 +202,7 @@ mulOpDiagonal!(res::MXVector{T}, d::MXVector{T}, v::MXVector{T}, α, β, n_min) 
               ctx(), dt(T), res.ptr, d.ptr, v.ptr, n_min, length(res), α, β, flags(T, α, β)))
 cdiag(res::MXVector{T}, d::MXVector{T}, v::MXVector{T}, α, β, n_min, conjd::Bool) where {T <: CplxT} =
   check(ccall((:mxlo_diag_mul_c, lib), Int32, (P, Int32, P, P, P, Int64, Int64, Float64, Float64, Float64, Float64, Int32),
-              ctx(), dt(T), res.ptr, d.ptr, v.ptr, n_min, length(res), re(α), im(α), re(β), im(β),
+              ctx(), dt(T), res.ptr, d.ptr, v.ptr, n_min, length(res), rpart(α), ipart(α), rpart(β), ipart(β),
               flags(T, α, β) | (conjd ? Int32(0x10) : Int32(0))))                              # MXLO_CONJ_D
 mulSquareOpDiagonal!(res::MXVector{T}, d::MXVector{T}, v::MXVector{T}, α, β) where {T <: CplxT} =
   cdiag(res, d, v, α, β, length(res), false)
@@ -210,7 +214,7 @@ mulOpEye!(res::MXVector{T}, v::MXVector{T}, α, β, n_min) where {T <: RealT} =
               ctx(), dt(T), res.ptr, v.ptr, n_min, length(res), α, β, flags(T, α, β) | Int32(4)))
 mulOpEye!(res::MXVector{T}, v::MXVector{T}, α, β, n_min) where {T <: CplxT} =
   check(ccall((:mxlo_eye_mul_c, lib), Int32, (P, Int32, P, P, Int64, Int64, Float64, Float64, Float64, Float64, Int32),
-              ctx(), dt(T), res.ptr, v.ptr, n_min, length(res), re(α), im(α), re(β), im(β), flags(T, α, β) | Int32(4)))
+              ctx(), dt(T), res.ptr, v.ptr, n_min, length(res), rpart(α), ipart(α), rpart(β), ipart(β), flags(T, α, β) | Int32(4)))
 # mulOpOnes! (src/special-operators.jl:79-85) — real element types (fixed-order device sum, all-reduce hook included)
 mulOpOnes!(res::MXVector{T}, v::MXVector{T}, α, β) where {T <: RealT} =
   check(ccall((:mxlo_ones_mul, lib), Int32, (P, Int32, P, Int64, P, Int64, Float64, Float64, Int32),
@@ -221,14 +225,14 @@ mulOpZeros!(res::MXVector{T}, v::MXVector, α, β) where {T <: RealT} =
               flags(T, α, β)))
 mulOpZeros!(res::MXVector{T}, v::MXVector, α, β) where {T <: CplxT} =
   check(ccall((:mxlo_zeros_mul_c, lib), Int32, (P, Int32, P, Int64, Float64, Float64, Int32), ctx(), dt(T), res.ptr,
-              length(res), re(β), im(β), flags(T, α, β)))
+              length(res), rpart(β), ipart(β), flags(T, α, β)))
 # mulHouseholder! (src/linalg.jl:77-83); complex h: LinearAlgebra.dot conjugates it
 mulHouseholder!(res::MXVector{T}, h::MXVector{T}, v::MXVector{T}, α, β) where {T <: RealT} =
   check(ccall((:mxlo_householder_mul, lib), Int32, (P, Int32, P, P, P, Int64, Float64, Float64, Int32),
               ctx(), dt(T), res.ptr, h.ptr, v.ptr, length(res), α, β, flags(T, α, β)))
 mulHouseholder!(res::MXVector{T}, h::MXVector{T}, v::MXVector{T}, α, β) where {T <: CplxT} =
   check(ccall((:mxlo_householder_mul_c, lib), Int32, (P, Int32, P, P, P, Int64, Float64, Float64, Float64, Float64, Int32),
-              ctx(), dt(T), res.ptr, h.ptr, v.ptr, length(res), re(α), im(α), re(β), im(β), flags(T, α, β)))
+              ctx(), dt(T), res.ptr, h.ptr, v.ptr, length(res), rpart(α), ipart(α), rpart(β), ipart(β), flags(T, α, β)))
 
 # ---- a3/a4 opDiagonal (src/special-operators.jl:133-165): own constructor only so that ctprod! does not allocate
 # `conj.(d)` on every call (:139-141) — MXLO_CONJ_D conjugates d inside the kernel.
@@ -277,7 +281,7 @@ function opHermitian(d::MXVector{S}, A::MXMatrix{T}) where {S <: Union{RealT, Cp
   dflag = S <: Real ? Int32(0x80) : Int32(0)
   prod! = (res, v, α, β) -> check(ccall((:mxlo_hermitian_mul_c, lib), Int32,
       (P, Int32, P, P, P, Int64, P, Int64, Float64, Float64, Float64, Float64, Int32),
-      ctx(), dt(T), res.ptr, d.ptr, A.data.ptr, m, v.ptr, n, re(α), im(α), re(β), im(β), flags(T, α, β) | dflag))
+      ctx(), dt(T), res.ptr, d.ptr, A.data.ptr, m, v.ptr, n, rpart(α), ipart(α), rpart(β), ipart(β), flags(T, α, β) | dflag))
   LinearOperator{T, MXVector{T}}(m, m, false, true, prod!, nothing, nothing)
 end
 
@@ -286,7 +290,7 @@ function LinearOperator(M::MXMatrix{T}; symmetric = false, hermitian = false) wh
   m, n = size(M)
   gemv(mode) = (res, v, α, β) -> check(ccall((:mxlo_gemv_c, lib), Int32,
       (P, Int32, P, P, Int64, Int64, Int64, P, Float64, Float64, Float64, Float64, Int32, Int32),
-      ctx(), dt(T), res.ptr, M.data.ptr, m, n, m, v.ptr, re(α), im(α), re(β), im(β), Int32(mode), flags(T, α, β)))
+      ctx(), dt(T), res.ptr, M.data.ptr, m, n, m, v.ptr, rpart(α), ipart(α), rpart(β), ipart(β), Int32(mode), flags(T, α, β)))
   LinearOperator{T, MXVector{T}}(m, n, symmetric, hermitian, gemv(0), gemv(1), gemv(2))     # M*v, transpose(M)*u, M'*w
 end
 function LinearOperator(M::MXMatrix{T}; symmetric = false, hermitian = false) where {T <: RealT}
@@ -434,13 +438,13 @@ function ckron(A::MXMatrix, B::MXMatrix)
   mulmode(mode) = (res, x, α, β) -> check(ccall((:mxlo_kron_mul_c, lib), Int32,
       (P, Int32, P, P, P, Int64, Int64, Int64, Int32, P, P, Int64, Int64, Int64, Int32, P, P, Float64, Float64, Float64, Float64, Int32),
       ctx(), dt(T), res.ptr, pa.re.data.ptr, imptr(pa.im), m, n, m, Int32(mode), pb.re.data.ptr, imptr(pb.im), p, q, p, Int32(mode),
-      x.ptr, work.ptr, re(α), im(α), re(β), im(β), flags(T, α, β)))
+      x.ptr, work.ptr, rpart(α), ipart(α), rpart(β), ipart(β), flags(T, α, β)))
   LinearOperator{T, MXVector{T}}(m * p, n * q, false, false, mulmode(0), mulmode(1), mulmode(3))
 end
 
 # ---- a REAL operator applied to complex device vectors (test/test_kron.jl "issue110": K * x with x::Vector{ComplexF64})
 # The leaves are instantiated per element type, so the real operator is applied to the two planes of x and the result is
-# joined with the caller's (possibly complex) α, β: res = α*(op*re(x) + i*op*im(x)) + β*res.
+# joined with the caller's (possibly complex) α, β: res = α*(op*real(x) + i*op*imag(x)) + β*res.
 function LinearAlgebra.mul!(res::MXVector{Complex{R}}, op::LinearOperators.AbstractLinearOperator{R}, v::MXVector{Complex{R}},
                             α, β) where {R <: RealT}
   T = Complex{R}
@@ -450,7 +454,7 @@ function LinearAlgebra.mul!(res::MXVector{Complex{R}}, op::LinearOperators.Abstr
   mul!(yr, op, xr)
   mul!(yi, op, xi)
   check(ccall((:mxlo_join_c, lib), Int32, (P, Int32, P, P, P, Int64, Float64, Float64, Float64, Float64, Int32),
-              ctx(), dt(T), res.ptr, yr.ptr, yi.ptr, length(res), re(α), im(α), re(β), im(β), flags(T, α, β)))
+              ctx(), dt(T), res.ptr, yr.ptr, yi.ptr, length(res), rpart(α), ipart(α), rpart(β), ipart(β), flags(T, α, β)))
   res
 end
 

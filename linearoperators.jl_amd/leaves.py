@@ -18,7 +18,7 @@ import torch
 
 from . import _lib
 from .device import Storage, check_vec, dtype_code, get_ctx, ptr, storage_of
-from .operators import (AbstractLinearOperator, LinearOperator, LinearOperatorException, _c4, adjoint, compose,
+from .operators import (AbstractLinearOperator, LinearOperator, LinearOperatorException, _c4, adjoint, compose, conj_scalar,
                         issymmetric, ishermitian, mul, scalar_flags, state_version, storage_type, to_dense, transpose)
 
 
@@ -690,6 +690,10 @@ class _ShiftedData:
     def σ(self):
         return self.sigma
 
+    @σ.setter
+    def σ(self, value):                                                # op.data.σ = ... (test_shifted_operator.jl:66-70)
+        self.sigma = value
+
 
 class ShiftedOperatorType(AbstractLinearOperator):
     """`ShiftedOperator(H, σ)` = H + σI — src/shifted_operators.jl:56-103. Its products are the inner
@@ -700,19 +704,32 @@ class ShiftedOperatorType(AbstractLinearOperator):
     def __init__(self, H, sigma=0):
         self.eltype = H.eltype
         T = self.eltype
-        sigma = (np.float32(sigma) if T == torch.float32 else float(sigma))   # convert(T, σ_in) (:73)
-        self.data = _ShiftedData(H, sigma)
+        self.data = _ShiftedData(H, self._convert(sigma))
         self.nrow = self.ncol = H.size(1)
         self.symmetric = issymmetric(H)
+        self._herm0 = ishermitian(H) and self._isreal(self.data.sigma)   # the constructor's `op.hermitian` field (:82-83)
         self.nprod = self.ntprod = self.nctprod = 0
         data = self.data
 
-        def shifted(y, x, a, b, op):
-            skip = data.sigma == 0 or a == 0                           # (:21)
-            if not skip and ShiftedOperatorType.fuse and hasattr(data.H, "_pending_shift"):
+        def axpy(y, x, c):                                             # y = y + c x, c already of the callers' product type
+            ctx = get_ctx(y.device)
+            if y.dtype.is_complex:
+                c = complex(c)
+                # axpy! converts the scalar to eltype(y) and runs in that arithmetic: no width flags; β = 1 is Real
+                _lib.call("mxlo_eye_mul_c", ctx.handle, dtype_code(y.dtype, True), ptr(y), ptr(x), y.numel(), y.numel(),
+                          c.real, c.imag, 1.0, 0.0, _lib.BETA_REAL)
+            else:
+                _lib.call("mxlo_eye_mul", ctx.handle, dtype_code(y.dtype), ptr(y), ptr(x), y.numel(), y.numel(), c, 1.0, 0)
+
+        def shifted(y, x, a, b, op, conj_sigma=False):
+            sig = self._convert(data.sigma)                            # σ is a mutable field of eltype T (:6,:73)
+            if conj_sigma:
+                sig = conj_scalar(sig)                                 # (:45)
+            skip = sig == 0 or a == 0                                  # (:21)
+            if not skip and ShiftedOperatorType.fuse and hasattr(data.H, "_pending_shift") and not conj_sigma:
                 # H is a quasi-Newton operator: the axpy! rides in the combine pass of its apply
                 # (mxlo_qn_mul_shifted) — same per-element roundings, one launch and 3 vector passes fewer.
-                data.H._pending_shift = float(data.sigma)
+                data.H._pending_shift = float(sig)
                 try:
                     mul(y, op, x, a, b)
                 finally:
@@ -720,25 +737,43 @@ class ShiftedOperatorType(AbstractLinearOperator):
                 return y
             mul(y, op, x, a, b)                                        # y = α H x + β y        (:18)
             if not skip:
-                ctx = get_ctx(y.device)
                 # α*σ in the callers' types (σ is a T), then axpy! converts it to T and runs in T arithmetic
-                if y.dtype == torch.float64:
-                    c = float(a) * float(data.sigma)
+                if y.dtype == torch.complex128:
+                    c = complex(a) * complex(sig)
+                elif y.dtype == torch.complex64:
+                    c = complex(np.complex64(complex(a) * complex(sig)))
+                elif y.dtype == torch.float64:
+                    c = float(a) * float(sig)
                 elif isinstance(a, (np.float32,)):
-                    c = float(np.float32(a) * np.float32(data.sigma))
+                    c = float(np.float32(a) * np.float32(sig))
                 else:
-                    c = float(np.float32(float(a) * float(data.sigma)))
-                _lib.call("mxlo_eye_mul", ctx.handle, dtype_code(y.dtype), ptr(y), ptr(x), y.numel(), y.numel(),
-                          c, 1.0, 0)                                   # y = y + (α σ) x        (:22)
+                    c = float(np.float32(float(a) * float(sig)))
+                axpy(y, x, c)                                          # y = y + (α σ) x        (:22)
             return y
 
         self.prod = lambda y, x, a, b: shifted(y, x, a, b, data.H)
         self.tprod = lambda y, x, a, b: shifted(y, x, a, b, transpose(data.H))
-        self.ctprod = lambda y, x, a, b: shifted(y, x, a, b, adjoint(data.H))
+        self.ctprod = lambda y, x, a, b: shifted(y, x, a, b, adjoint(data.H), conj_sigma=True)   # H' + conj(σ) I (:40-50)
+
+    def _convert(self, sigma):
+        """convert(T, σ) (:73): a complex σ next to a real H is an InexactError in the reference."""
+        T = self.eltype
+        if T.is_complex:
+            z = complex(sigma)
+            return complex(np.complex64(z)) if T == torch.complex64 else z
+        if isinstance(sigma, complex) or (isinstance(sigma, np.generic) and np.iscomplexobj(sigma)):
+            if complex(sigma).imag != 0:
+                raise TypeError(f"InexactError: cannot convert the complex shift {sigma} to the real eltype {T}")
+            sigma = complex(sigma).real
+        return np.float32(sigma) if T == torch.float32 else float(sigma)
+
+    @staticmethod
+    def _isreal(sigma):
+        return complex(sigma).imag == 0
 
     @property
-    def hermitian(self):                                               # ishermitian(H) && isreal(σ) (:83,89)
-        return ishermitian(self.data.H)
+    def hermitian(self):                                               # op.hermitian && isreal(op.data.σ) (:89)
+        return self._herm0 and self._isreal(self.data.sigma)
 
     @property
     def S(self):                                                       # storage_type(op.data.H) (:96)
@@ -746,7 +781,7 @@ class ShiftedOperatorType(AbstractLinearOperator):
 
     def _state_version(self):
         v = state_version(self.data.H)
-        return None if v is None else ("shift", v, float(self.data.sigma))
+        return None if v is None else ("shift", v, complex(self.data.sigma))
 
 
 def ShiftedOperator(H, sigma=0):

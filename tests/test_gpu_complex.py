@@ -528,3 +528,70 @@ def test_complex_scalar_times_lazy_wrappers(lo, dev):
             w = crand(rng, M.shape[0], np.complex128)
             assert rel((scaled.H * T(w, dev)).cpu().numpy(), np.conj(x) * (M.conj().T @ w)) <= 1e-13
             assert rel((scaled.T * T(w, dev)).cpu().numpy(), x * (M.T @ w)) <= 1e-13
+
+
+def test_shifted_operator_reference_testsets(lo, dev):
+    """test/test_shifted_operator.jl: "Real Symmetric", "Complex Non-Hermitian" (σ = 1 + 2im, adjoint(op) = H' + conj(σ) I),
+    "Mutation (Updating Sigma)", "Mutation (Dynamic Hermitian Check)", "Strict Type Constraint", "Coverage & Utilities"."""
+    rng = np.random.default_rng(31)
+    n = 5
+    Hd = rng.random((n, n)); Hd = Hd + Hd.T
+    H = lo.LinearOperatorFromMatrix(T(Hd, dev), symmetric=True, hermitian=True)
+    op = lo.ShiftedOperator(H, 2.0)
+    Aref = Hd + 2.0 * np.eye(n)
+    x, y0 = rng.random(n), rng.random(n)
+    assert op.shape == (n, n) and lo.issymmetric(op) and lo.ishermitian(op) and op.data.σ == 2.0
+    y = torch.zeros(n, dtype=torch.float64, device=dev)
+    lo.mul(y, op, T(x, dev))
+    assert np.allclose(y.cpu().numpy(), Aref @ x)
+    y = T(y0.copy(), dev)
+    lo.mul(y, op, T(x, dev), 0.5, -1.0)
+    assert np.allclose(y.cpu().numpy(), 0.5 * (Aref @ x) - y0)
+    assert np.allclose((op.T * T(x, dev)).cpu().numpy(), Aref.T @ x)
+    # Complex Non-Hermitian
+    Hc = rng.random((n, n)) + 1j * rng.random((n, n))
+    opc = lo.ShiftedOperator(lo.LinearOperatorFromMatrix(T(Hc, dev)), 1.0 + 2.0j)
+    assert not lo.issymmetric(opc) and not lo.ishermitian(opc)
+    Ac = Hc + (1.0 + 2.0j) * np.eye(n)
+    xc = rng.random(n) + 1j * rng.random(n)
+    assert np.allclose((opc.H * T(xc, dev)).cpu().numpy(), Ac.conj().T @ xc)
+    assert np.allclose((opc * T(xc, dev)).cpu().numpy(), Ac @ xc)
+    assert np.allclose((opc.T * T(xc, dev)).cpu().numpy(), Ac.T @ xc)
+    r0 = rng.random(n) + 1j * rng.random(n)
+    res = T(r0.copy(), dev)
+    lo.mul(res, opc.H, T(xc, dev), 0.5 - 1j, 2j)
+    assert np.allclose(res.cpu().numpy(), (0.5 - 1j) * (Ac.conj().T @ xc) + 2j * r0)
+    # Mutation (Updating Sigma)
+    H3 = rng.random((3, 3))
+    op3 = lo.ShiftedOperator(lo.LinearOperatorFromMatrix(T(H3, dev)), 1.0)
+    ones = torch.ones(3, dtype=torch.float64, device=dev)
+    y1 = (op3 * ones).cpu().numpy()
+    op3.data.σ = 10.0
+    y2 = (op3 * ones).cpu().numpy()
+    assert not np.allclose(y1, y2) and np.allclose(y2, (H3 + 10.0 * np.eye(3)) @ np.ones(3))
+    # Mutation (Dynamic Hermitian Check)
+    Hh = rng.random((3, 3)) + 1j * rng.random((3, 3)); Hh = Hh + Hh.conj().T
+    oph = lo.ShiftedOperator(lo.LinearOperatorFromMatrix(T(Hh, dev), symmetric=False, hermitian=True), 2.0)
+    assert lo.ishermitian(oph)
+    oph.data.σ = 2.0 + 1.0j
+    assert not lo.ishermitian(oph)
+    oph.data.σ = 3.0
+    assert lo.ishermitian(oph)
+    # Strict Type Constraint
+    H32 = lo.LinearOperatorFromMatrix(T(rng.random((5, 5)).astype(np.float32), dev))
+    op32 = lo.ShiftedOperator(H32, 1.0)
+    assert op32.eltype == torch.float32 and isinstance(op32.data.σ, np.float32)
+    assert (op32 * T(rng.random(5).astype(np.float32), dev)).dtype == torch.float32
+    with pytest.raises(TypeError):
+        lo.ShiftedOperator(H32, 1.0 + 2.0j)              # convert(Float32, 1 + 2im): InexactError
+    # Coverage & Utilities
+    Hu = lo.LinearOperatorFromMatrix(T(rng.random((n, n)), dev))
+    opu = lo.ShiftedOperator(Hu, 2.0)
+    yy = torch.zeros(n, dtype=torch.float64, device=dev)
+    lo.mul(yy, opu.T, T(x, dev), 0.5, 1.0)
+    lo.mul(yy, opu.T, T(x, dev), 0.0, 1.0)
+    lo.mul(yy, lo.ShiftedOperator(Hu, 0.0).T, T(x, dev))
+    assert lo.isallocated5(opu) and lo.storage_type(opu) == lo.storage_type(Hu)
+    opu.nprod = 10
+    lo.reset(opu)
+    assert opu.nprod == 0

@@ -595,3 +595,66 @@ def test_shifted_operator_reference_testsets(lo, dev):
     opu.nprod = 10
     lo.reset(opu)
     assert opu.nprod == 0
+
+
+def test_reference_transpose_adjoint_and_issue109_testsets(lo, dev):
+    """test/test_linop.jl:382-427 "Transpose and adjoint" (ComplexF64 operator from user closures with ctprod! = nothing,
+    then with tprod! = nothing: the missing one is inferred through conj sandwiches), :598-604 unary / scalar operations on
+    wrappers, :607-631 "Sum / Cat with Adjoint and Transpose" (issue #109) — Matrix(...) compared EXACTLY like the reference."""
+    rng = np.random.default_rng(109)
+    n = 10
+    A = cmat(rng, n, n, np.complex128)
+    v = np.array([-(-1.0) ** i for i in range(1, n + 1)], dtype=np.complex128)     # simple_vector(ComplexF64, n)
+    res_init = v.copy()
+    Ad = lo.LinearOperatorFromMatrix(T(A.T.copy(), dev).t())
+    S = lo.Storage(torch.complex128, dev)
+    prod = lambda res, x, a, b: lo.mul(res, Ad, x, a, b)
+    tprod = lambda res, x, a, b: lo.mul(res, Ad.T, x, a, b)
+    ctprod = lambda res, x, a, b: lo.mul(res, Ad.H, x, a, b)
+    rtol = np.sqrt(np.finfo(float).eps)
+    nv = np.linalg.norm(v)
+    alpha, beta = 2.0, -3.0
+    for t_, c_, check in ((tprod, None, "adjoint"), (None, ctprod, "transpose")):
+        op = lo.LinearOperator(torch.complex128, n, n, False, False, prod, t_, c_, S=S)
+        ap = lambda o: (o * T(v, dev)).cpu().numpy()
+        assert np.linalg.norm(A.T @ v - ap(op.T)) <= rtol * nv
+        assert np.linalg.norm(A.conj().T @ v - ap(op.H)) <= rtol * nv
+        assert np.linalg.norm(A @ v - ap(op.T.T)) <= rtol * nv
+        assert np.linalg.norm(A @ v - ap(op.H.H)) <= rtol * nv
+        assert np.linalg.norm(A.conj() @ v - ap(op.H.T)) <= rtol * nv
+        assert np.linalg.norm(A.conj() @ v - ap(op.T.H)) <= rtol * nv
+        res = T(res_init.copy(), dev)
+        if check == "adjoint":
+            lo.mul(res, op.H, T(v, dev), alpha, beta)
+            assert np.linalg.norm(alpha * (A.conj().T @ v) + beta * res_init - res.cpu().numpy()) <= rtol * nv
+        else:
+            lo.mul(res, op.T, T(v, dev), alpha, beta)
+            assert np.linalg.norm(alpha * (A.T @ v) + beta * res_init - res.cpu().numpy()) <= rtol * nv
+    # unary and scalar operations on Adjoint and Transpose operators (real 5 x 3)
+    R = rng.random((5, 3))
+    opR = lo.LinearOperatorFromMatrix(T(R, dev))
+    Mx = lambda o: lo.Matrix(o).cpu().numpy()
+    for adjtrans in (lambda o: o.H, lambda o: o.T):
+        assert np.array_equal(Mx(adjtrans(-opR)), Mx(-adjtrans(opR)))
+        assert np.array_equal(Mx(adjtrans(2 * opR)), Mx(2 * adjtrans(opR)))
+    # issue #109: sums and cats with adjoint / transpose wrappers of a complex operator, and with raw matrices
+    A3 = rng.random((3, 3)) + 1j * rng.random((3, 3))
+    A3d = T(A3, dev)
+    opA = lo.LinearOperatorFromMatrix(A3d)
+    for wrap, dense in ((lambda o: o.H, A3.conj().T), (lambda o: o.T, A3.T)):
+        w = wrap(opA)
+        wd = T(np.ascontiguousarray(dense), dev)
+        assert np.array_equal(Mx(w + opA), A3 + dense) and np.array_equal(Mx(opA + w), A3 + dense)
+        assert np.array_equal(Mx(w + A3d), A3 + dense) and np.array_equal(Mx(A3d + w), A3 + dense)
+        assert np.array_equal(Mx(lo.hcat(w, opA)), np.hstack([dense, A3]))
+        assert np.array_equal(Mx(lo.vcat(w, opA)), np.vstack([dense, A3]))
+        assert np.array_equal(Mx(lo.vcat(w, w)), np.vstack([dense, dense]))
+        assert np.array_equal(Mx(lo.hcat(opA, w)), np.hstack([A3, dense]))
+        assert np.array_equal(Mx(lo.vcat(opA, w)), np.vstack([A3, dense]))
+        assert np.array_equal(Mx(lo.hcat(w, A3d)), np.hstack([dense, A3]))
+        assert np.array_equal(Mx(lo.vcat(w, A3d)), np.vstack([dense, A3]))
+        assert np.array_equal(Mx(lo.hcat(A3d, w)), np.hstack([A3, dense]))
+        assert np.array_equal(Mx(lo.vcat(A3d, w)), np.vstack([A3, dense]))
+        blk = lo.hvcat((2, 2), w, opA, opA, w) if hasattr(lo, "hvcat") else lo.vcat(lo.hcat(w, opA), lo.hcat(opA, w))
+        assert np.array_equal(Mx(blk), np.block([[dense, A3], [A3, dense]]))
+        del wd

@@ -385,7 +385,8 @@ int32_t mxlo_kron_mul_c(mxlo_ctx *ctx, int32_t dtype, void *res, const void *Ar,
 /* A REAL operator applied to complex vectors (eltype(op) = Float64, x::Vector{ComplexF64}: test/test_kron.jl
  * "issue110"; Julia runs the generic closure on the complex vectors). The glue applies the real operator to the two
  * planes: mxlo_split_c writes re[i], im[i] of x; mxlo_join_c computes res = α*(re + i*im) (+ β*res) with complex or
- * Real α, β (flags as for the other _c entry points). dtype names the COMPLEX type; re / im are its component type. */
+ * Real α, β (flags as for the other _c entry points). dtype names the COMPLEX type; re / im are its component type;
+ * im == NULL stands for zeros (a real vector handed to a complex operator: `aopA * rand(5)`, test/test_adjtrans.jl:31-34). */
 int32_t mxlo_split_c(mxlo_ctx *ctx, int32_t dtype, void *re, void *im, const void *x, int64_t n);
 int32_t mxlo_join_c(mxlo_ctx *ctx, int32_t dtype, void *res, const void *re, const void *im, int64_t n,
                     double alpha_re, double alpha_im, double beta_re, double beta_im, int32_t flags);

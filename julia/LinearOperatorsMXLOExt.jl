@@ -458,6 +458,16 @@ function LinearAlgebra.mul!(res::MXVector{Complex{R}}, op::LinearOperators.Abstr
   res
 end
 
+# a REAL device vector handed to a COMPLEX operator (`aopA * rand(5)`, test/test_adjtrans.jl:31-34): promoted on the device
+function LinearAlgebra.mul!(res::MXVector{Complex{R}}, op::LinearOperators.AbstractLinearOperator{Complex{R}}, v::MXVector{R},
+                            α, β) where {R <: RealT}
+  T = Complex{R}
+  vc = MXVector{T}(undef, length(v))
+  check(ccall((:mxlo_join_c, lib), Int32, (P, Int32, P, P, P, Int64, Float64, Float64, Float64, Float64, Int32),
+              ctx(), dt(T), vc.ptr, v.ptr, C_NULL, length(v), 1.0, 0.0, 0.0, 0.0, Int32(0x20 | 0x40)))
+  mul!(res, op, vc, α, β)
+end
+
 # ---- a12-a16 quasi-Newton operators: the structural contract (src/lbfgs.jl:62-104, src/lsr1.jl:39-78) ---------
 struct MXQNData                # stands in for op.data: fields the reference's tests read come from the handle
   h::Ptr{Cvoid}

@@ -553,7 +553,7 @@ __global__ void __launch_bounds__(kBlock)
 cplx_join_kernel(C<R> *__restrict__ res, const R *__restrict__ rr, const R *__restrict__ ri, int64_t n, Sc<RA> a, Sc<RB> b) {
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
     RA tr, ti;
-    a.mul(C<R>(rr[i], ri[i]), tr, ti);
+    a.mul(C<R>(rr[i], ri ? ri[i] : R(0)), tr, ti);      // ri == nullptr: a real vector promoted to Complex{R}
     res[i] = cfin<R, RA, RB, BETA0>(tr, ti, b.re, b.im, b.real, BETA0 ? C<R>() : res[i]);
   }
 }
@@ -756,7 +756,7 @@ int32_t cjoin(mxlo_ctx *ctx, C<R> *res, const R *re, const R *im, int64_t n, con
 MXLO_API int32_t mxlo_join_c(mxlo_ctx *ctx, int32_t dtype, void *res, const void *re, const void *im, int64_t n,
                              double alpha_re, double alpha_im, double beta_re, double beta_im, int32_t flags) {
   CHECK_C("mxlo_join_c");
-  MXLO_REQUIRE(n >= 0 && (n == 0 || (res && re && im)), MXLO_EINVAL, "mxlo_join_c: bad argument");
+  MXLO_REQUIRE(n >= 0 && (n == 0 || (res && re)), MXLO_EINVAL, "mxlo_join_c: bad argument");   // im may be NULL (zeros)
   if (n == 0) return MXLO_OK;
   if (dtype == MXLO_C64)
     return cjoin<double>(ctx, (C<double> *)res, (const double *)re, (const double *)im, n,

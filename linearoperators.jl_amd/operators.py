@@ -450,6 +450,8 @@ def mul(res: torch.Tensor, op, v: torch.Tensor, alpha=None, beta=None):
         raise TypeError("mul! takes either (res, op, v) or (res, op, v, alpha, beta)")
     if v.dtype.is_complex and op.eltype.is_floating_point:
         return _mul_real_op_complex_vec(res, op, v, alpha, beta)
+    if op.eltype.is_complex and v.dtype.is_floating_point:
+        v = _complex_of_real(v, op.eltype)              # a real vector handed to a complex operator (test_adjtrans.jl:31-34)
     if isinstance(op, AdjointLinearOperator):
         return _mul_adjoint(res, op, v, alpha, beta)
     if isinstance(op, TransposeLinearOperator):
@@ -472,6 +474,20 @@ def mul(res: torch.Tensor, op, v: torch.Tensor, alpha=None, beta=None):
             allocate_vectors_args3(op)
         prod3(res, op.prod, v, alpha, beta, op.Mv)
     return touched(res)
+
+
+def _complex_of_real(v, ctype):
+    """Complex{R} copy of a real vector (zero imaginary parts), formed on the device by the join kernel."""
+    from . import _lib
+    from .device import dtype_code, get_ctx, ptr
+    comp = torch.float64 if ctype == torch.complex128 else torch.float32
+    if v.dtype != comp:
+        raise TypeError(f"a {v.dtype} vector next to a {ctype} operator: convert one of them")
+    out = torch.empty(v.shape[0], dtype=ctype, device=v.device)
+    ctx = get_ctx(v.device)
+    _lib.call("mxlo_join_c", ctx.handle, dtype_code(ctype, True), ptr(out), ptr(v), None, v.shape[0], 1.0, 0.0, 0.0, 0.0,
+              _lib.ALPHA_REAL | _lib.BETA_REAL)
+    return out
 
 
 _PLANES: dict = {}

@@ -658,3 +658,91 @@ def test_reference_transpose_adjoint_and_issue109_testsets(lo, dev):
         blk = lo.hvcat((2, 2), w, opA, opA, w) if hasattr(lo, "hvcat") else lo.vcat(lo.hcat(w, opA), lo.hcat(opA, w))
         assert np.array_equal(Mx(blk), np.block([[dense, A3], [A3, dense]]))
         del wd
+
+
+def _closure_op(lo, dev, A, which):
+    """LinearOperator{ComplexF64}(m, n, false, false, prod!, tprod!, ctprod!) built from 2-ARGUMENT closures over a dense
+    matrix, as test/test_adjtrans.jl:43-51,98-106 and test/test_cat.jl:55-66 do; `which` says which of tprod!/ctprod!
+    is `nothing`."""
+    Ad = lo.LinearOperatorFromMatrix(T(A, dev))
+    m, n = A.shape
+    p2 = lambda y, x: lo.mul(y, Ad, x)
+    t2 = None if which == "no_t" else (lambda y, x: lo.mul(y, Ad.T, x))
+    c2 = None if which == "no_ct" else (lambda y, x: lo.mul(y, Ad.H, x))
+    return lo.LinearOperator(torch.complex128, m, n, False, False, p2, t2, c2, S=lo.Storage(torch.complex128, dev))
+
+
+@pytest.mark.parametrize("which", ["dense", "no_ct", "no_t"])
+def test_reference_adjtrans_testsets(lo, dev, which):
+    """test/test_adjtrans.jl: "Adjoint/Transpose/Conjugate", "Derived Adjoint" (ctprod! = nothing), "Derived Transpose"
+    (tprod! = nothing) on a 5 x 3 ComplexF64 operator: wrapper algebra identities, Matrix(fop) == foo(A) EXACTLY,
+    -fop, (2+3im)*fop, fop*(2+3im), products with complex AND real vectors."""
+    rng = np.random.default_rng(5)
+    A = rng.random((5, 3)) + 1j * rng.random((5, 3))
+    opA = lo.LinearOperatorFromMatrix(T(A, dev)) if which == "dense" else _closure_op(lo, dev, A, which)
+    aop, cop, top = lo.adjoint(opA), lo.conj(opA), lo.transpose(opA)
+    Mx = lambda o: lo.Matrix(o).cpu().numpy()
+    for foo, fop, fA in ((lo.adjoint, aop, A.conj().T), (lo.conj, cop, A.conj()), (lo.transpose, top, A.T)):
+        assert type(foo(opA)) is type(fop) and foo(opA).parent is opA          # foo(opA) === fop
+        assert np.array_equal(Mx(fop), fA)                                      # Matrix(fop) == foo(A)
+        assert foo(fop) is opA
+        assert np.array_equal(Mx(-fop), -fA)
+        assert np.allclose(Mx((2 + 3j) * fop), (2 + 3j) * fA) and np.allclose(Mx(fop * (2 + 3j)), fA * (2 + 3j))
+    assert isinstance(lo.adjoint(top), type(cop)) and lo.adjoint(top).parent is opA      # adjoint(topA) === copA
+    assert isinstance(lo.adjoint(cop), type(top)) and isinstance(lo.conj(aop), type(top))
+    assert isinstance(lo.conj(top), type(aop)) and isinstance(lo.transpose(cop), type(aop))
+    assert isinstance(lo.transpose(aop), type(cop))
+    v = rng.random(5) + 1j * rng.random(5)
+    assert np.allclose((aop * T(v, dev)).cpu().numpy(), A.conj().T @ v, rtol=1e-14, atol=0)
+    assert np.allclose((top * T(v, dev)).cpu().numpy(), A.T @ v, rtol=1e-14, atol=0)
+    vr = rng.random(5)                                                          # REAL vectors through a complex operator
+    assert np.allclose((aop * T(vr, dev)).cpu().numpy(), A.conj().T @ vr)
+    assert np.allclose((top * T(vr, dev)).cpu().numpy(), A.T @ vr)
+    v3 = rng.random(3) + 1j * rng.random(3)
+    assert np.allclose((cop * T(v3, dev)).cpu().numpy(), A.conj() @ v3)
+    v3r = rng.random(3)
+    assert np.allclose((cop * T(v3r, dev)).cpu().numpy(), A.conj() @ v3r)
+    assert (opA * T(v3r, dev)).dtype == torch.complex128
+
+
+@pytest.mark.parametrize("three_args", [False, True])
+def test_reference_cat_testsets(lo, dev, three_args):
+    """test/test_cat.jl "Concatenation" / "Concatenation 3-args" on ComplexF64: [A B C] and [A; B; C] of operators (dense,
+    or built from 2-argument closures) against the dense concatenation and LinearOperator(D): products, transpose, adjoint,
+    the 5-arg forms with (α, β) = (3, -4), the shape-mismatch exception, and the two small identity / zero block cases."""
+    rng = np.random.default_rng(6)
+    rtol = np.sqrt(np.finfo(float).eps)
+    sv = lambda k: np.array([-(-1.0) ** i for i in range(1, k + 1)], dtype=np.complex128)
+    mk = (lambda M: _closure_op(lo, dev, M, "full")) if three_args else (lambda M: lo.LinearOperatorFromMatrix(T(M, dev)))
+    for axis in (1, 0):
+        shapes = ((100, 100), (100, 10), (100, 90)) if axis == 1 else ((100, 100), (10, 100), (90, 100))
+        blocks = [cmat(rng, m, n, np.complex128) for m, n in shapes]
+        D = np.concatenate(blocks, axis=axis)
+        Do = (lo.hcat if axis == 1 else lo.vcat)(*[mk(B) for B in blocks])
+        Do2 = lo.LinearOperatorFromMatrix(T(D, dev))
+        rhs, rhs2 = sv(D.shape[1]), sv(D.shape[0])
+        for o in (Do, Do2):
+            assert np.linalg.norm((o * T(rhs, dev)).cpu().numpy() - D @ rhs) <= rtol * np.linalg.norm(D @ rhs)
+            assert np.linalg.norm((o.T * T(rhs2, dev)).cpu().numpy() - D.T @ rhs2) <= rtol * np.linalg.norm(D.T @ rhs2)
+            assert np.linalg.norm((o.H * T(rhs2, dev)).cpu().numpy() - D.conj().T @ rhs2) <= rtol * np.linalg.norm(D.conj().T @ rhs2)
+            a, b = 3.0, -4.0
+            for oo, Dm, x in ((o, D, rhs), (o.T, D.T, rhs2), (o.H, D.conj().T, rhs2)):
+                r0 = rng.random(Dm.shape[0]) + 1j * rng.random(Dm.shape[0])
+                res = T(r0.copy(), dev)
+                lo.mul(res, oo, T(x, dev), a, b)
+                want = a * (Dm @ x) + b * r0
+                assert np.linalg.norm(res.cpu().numpy() - want) <= rtol * np.linalg.norm(want)
+    ones55 = lo.LinearOperatorFromMatrix(torch.ones(5, 5, dtype=torch.float64, device=dev))
+    eye3 = lo.opEye(torch.float64, 3, S=lo.Storage(torch.float64, dev))
+    with pytest.raises(lo.LinearOperatorException):
+        lo.hcat(ones55, eye3)
+    with pytest.raises(lo.LinearOperatorException):
+        lo.vcat(ones55, eye3)
+    S64 = lo.Storage(torch.float64, dev)
+    K = lo.hvcat((2, 2), lo.opEye(torch.float64, 2, S=S64), lo.opZeros(torch.float64, 2, 3, S=S64),
+                 lo.opZeros(torch.float64, 3, 2, S=S64), lo.opEye(torch.float64, 3, S=S64))
+    v5 = torch.tensor([1.0, -1.0, 1.0, -1.0, 1.0], dtype=torch.float64, device=dev)
+    assert torch.equal(K * v5, v5)                                              # all(v .== K * v)
+    K2 = lo.vcat(lo.opEye(torch.float64, 2, S=S64), torch.eye(2, dtype=torch.float64, device=dev))
+    v2 = torch.tensor([1.0, -1.0], dtype=torch.float64, device=dev)
+    assert torch.equal(K2 * v2, torch.cat([v2, v2]))

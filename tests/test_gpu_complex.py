@@ -746,3 +746,44 @@ def test_reference_cat_testsets(lo, dev, three_args):
     K2 = lo.vcat(lo.opEye(torch.float64, 2, S=S64), torch.eye(2, dtype=torch.float64, device=dev))
     v2 = torch.tensor([1.0, -1.0], dtype=torch.float64, device=dev)
     assert torch.equal(K2 * v2, torch.cat([v2, v2]))
+
+
+def test_reference_blockdiagonal_issue107_and_three_args_complex(lo, dev):
+    """test/test_linop.jl:718-757 "BlockDiagonal" (issue #107) with ComplexF64 blocks given as operators and as matrices,
+    and :768-797 "3-args" for Complex{Float64}: a 2-argument prod! with tprod! = nothing and a 2-argument ctprod!."""
+    rng = np.random.default_rng(107)
+    rtol = np.sqrt(np.finfo(float).eps)
+    A, B, C = cmat(rng, 3, 4, np.complex128), cmat(rng, 3, 3, np.complex128), cmat(rng, 4, 2, np.complex128)
+    D = np.zeros((10, 9), dtype=np.complex128)
+    D[:3, :4], D[3:6, 4:7], D[6:, 7:] = A, B, C
+    Mx = lambda o: lo.Matrix(o).cpu().numpy()
+    for M in (lo.BlockDiagonalOperator(*[lo.LinearOperatorFromMatrix(T(X, dev)) for X in (A, B, C)]),
+              lo.BlockDiagonalOperator(T(A, dev), T(B, dev), T(C, dev))):
+        assert M.size(1) == 10 and M.size(2) == 9
+        assert np.linalg.norm(Mx(M) - D) <= rtol * np.linalg.norm(D)
+        assert np.linalg.norm(Mx(M.T) - D.T) <= rtol * np.linalg.norm(D)
+        assert np.linalg.norm(Mx(M.H) - D.conj().T) <= rtol * np.linalg.norm(D)
+    # 3-args, Complex{Float64}
+    A12 = cmat(rng, 12, 10, np.complex128)
+    b = crand(rng, 10, np.complex128)
+    Ad = lo.LinearOperatorFromMatrix(T(A12, dev))
+    opA = lo.LinearOperator(torch.complex128, 12, 10, False, False, lambda res, v: lo.mul(res, Ad, v), None,
+                            lambda res, w: lo.mul(res, Ad.H, w), S=lo.Storage(torch.complex128, dev))
+    assert not lo.has_args5(opA)
+    assert rel((opA * T(b, dev)).cpu().numpy(), A12 @ b) <= 1e-14
+    res = T(crand(rng, 12, np.complex128), dev)
+    lo.mul(res, opA, T(b, dev))
+    assert rel(res.cpu().numpy(), A12 @ b) <= 1e-14
+    for alpha, beta in ((2.0, 3.0), (1.0, 3.0), (2.0, 0.0)):
+        res2 = res.cpu().numpy().copy()
+        lo.mul(res, opA, T(b, dev), alpha, beta)
+        assert rel(res.cpu().numpy(), alpha * (A12 @ b) + beta * res2) <= 1e-13
+        c, r3 = crand(rng, 12, np.complex128), crand(rng, 10, np.complex128)
+        res3 = T(r3.copy(), dev)
+        lo.mul(res3, opA.T, T(c, dev), alpha, beta)
+        assert np.linalg.norm(alpha * (A12.T @ c) + beta * r3 - res3.cpu().numpy()) <= rtol
+        assert rel((opA.T * T(c, dev)).cpu().numpy(), A12.T @ c) <= 1e-13
+        r4 = res3.cpu().numpy().copy()
+        lo.mul(res3, opA.H, T(c, dev), alpha, beta)
+        assert np.linalg.norm(alpha * (A12.conj().T @ c) + beta * r4 - res3.cpu().numpy()) <= rtol
+        assert rel((opA.H * T(c, dev)).cpu().numpy(), A12.conj().T @ c) <= 1e-13

@@ -43,7 +43,10 @@ def mulOpEye(res, v, alpha, beta, n_min):
 
 
 def opEye(T=torch.float64, nrow: Optional[int] = None, ncol: Optional[int] = None, S: Optional[Storage] = None):
-    """opEye(T, n; S) / opEye(T, nrow, ncol; S) — src/special-operators.jl:46-73."""
+    """opEye(T, n; S) / opEye(T, nrow, ncol; S) — src/special-operators.jl:46-73; opEye() is the size-less identity (:5-34)."""
+    if nrow is None and not isinstance(T, int):
+        from .operators import UniversalEye
+        return UniversalEye()
     if isinstance(T, int):               # opEye(n) / opEye(nrow, ncol): T defaults to Float64
         T, nrow, ncol = torch.float64, T, nrow
     n = nrow

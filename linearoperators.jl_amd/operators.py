@@ -629,7 +629,34 @@ class ConjugateLinearOperator(_Wrapper):
     hermitian = property(lambda s: ishermitian(s.parent))
 
 
+class UniversalEye:
+    """`opEye()` — src/special-operators.jl:5-34: the size-less identity. `op * x` IS `x` (vector, matrix or operator: the
+    very same object), `x * op` likewise; adjoint / transpose / conj return the operator itself. Pure host logic."""
+    _inst = None
+
+    def __new__(cls):
+        if cls._inst is None:
+            cls._inst = super().__new__(cls)
+        return cls._inst                                   # opEye() === opEye()
+
+    __array_priority__ = 1000                              # `ndarray * op` defers to __rmul__
+
+    def __mul__(self, other):
+        return other
+
+    __rmul__ = __mul__
+    __matmul__ = __mul__
+    __rmatmul__ = __mul__
+    T = property(lambda s: s)
+    H = property(lambda s: s)
+
+    def __repr__(self):
+        return "Identity operator"
+
+
 def adjoint(A):      # src/adjtrans.jl:33-45
+    if isinstance(A, UniversalEye):
+        return A                                           # special-operators.jl:27-29
     if isinstance(A, AdjointLinearOperator):
         return A.parent
     if isinstance(A, ConjugateLinearOperator):
@@ -640,6 +667,8 @@ def adjoint(A):      # src/adjtrans.jl:33-45
 
 
 def transpose(A):
+    if isinstance(A, UniversalEye):
+        return A                                           # special-operators.jl:27-29
     if isinstance(A, TransposeLinearOperator):
         return A.parent
     if isinstance(A, AdjointLinearOperator):
@@ -650,6 +679,8 @@ def transpose(A):
 
 
 def conj(A):
+    if isinstance(A, UniversalEye):
+        return A                                           # special-operators.jl:27-29
     if isinstance(A, ConjugateLinearOperator):
         return A.parent
     if isinstance(A, AdjointLinearOperator):

@@ -152,3 +152,21 @@ def test_stored_colmajor_aliases_both_layouts(lo):
     V = torch.arange(40.0).reshape(4, 10)[:, ::2]        # neither: copied once to column-major
     St, tr = _stored_colmajor(V)
     assert not tr and St.stride(0) == 1 and torch.equal(St, V)
+
+
+def test_universal_identity_operator(lo):
+    """test/test_linop.jl:260-288 "Identity (non-convertible to matrix)": opEye() * x === x for vectors, matrices and
+    operators, on either side; opEye() === opEye(); adjoint / transpose / conj return it unchanged."""
+    op = lo.opEye()
+    v = torch.tensor([1.0, -1.0, 1.0, -1.0, 1.0])
+    assert (op * v) is v and (v * op) is v
+    A1 = torch.rand(5, 5)
+    assert (op * A1) is A1 and (A1 * op) is A1
+    T1 = lo.LinearOperator(torch.float64, 5, 5, False, False, lambda res, x, a, b: None, None, None,
+                           S=lo.Storage(torch.float64, torch.device("cpu")))
+    assert (op * T1) is T1 and (T1 * op) is T1
+    op2 = lo.opEye()
+    assert op is op2 and (op * op2) is op and (op2 * op) is op
+    assert lo.transpose(op) is op and lo.adjoint(op) is op and lo.conj(op) is op and op.T is op and op.H is op
+    assert (lo.transpose(op) * v) is v and (lo.conj(op) * v) is v
+    assert repr(op) == "Identity operator"

@@ -787,3 +787,40 @@ def test_reference_blockdiagonal_issue107_and_three_args_complex(lo, dev):
         lo.mul(res3, opA.H, T(c, dev), alpha, beta)
         assert np.linalg.norm(alpha * (A12.conj().T @ c) + beta * r4 - res3.cpu().numpy()) <= rtol
         assert rel((opA.H * T(c, dev)).cpu().numpy(), A12.conj().T @ c) <= 1e-13
+
+
+def test_reference_identity_ones_zeros_on_complex_vectors(lo, dev):
+    """test/test_linop.jl:229-306 "Identity", "Ones", "Zeros": the reference builds these with their DEFAULT element type
+    (Float64) and applies them to simple_vector(ComplexF64, n) — a real operator on complex vectors."""
+    nrow, ncol = 10, 6
+    eps_ = np.finfo(float).eps
+    sv = lambda k: np.array([-(-1.0) ** i for i in range(1, k + 1)], dtype=np.complex128)
+    S = lo.Storage(torch.float64, dev)
+    v = sv(nrow)
+    for opI in (lo.opEye(nrow, S=S), lo.opEye(nrow, nrow, S=S)):
+        for o in (opI, opI.T, opI.H):
+            assert np.linalg.norm((o * T(v, dev)).cpu().numpy() - v) <= eps_ * np.linalg.norm(v)
+        assert np.array_equal(lo.Matrix(opI).cpu().numpy(), np.eye(nrow))
+    w = lo.opEye(nrow, S=S) * T(v, dev)
+    w[0] = -1.0
+    assert v[0] != w[0].item()                                           # the product is a fresh vector
+    opI = lo.opEye(nrow, ncol, S=S)
+    vc = sv(ncol)
+    v0, vu = np.concatenate([vc, np.zeros(nrow - ncol)]), np.concatenate([vc, np.ones(nrow - ncol)])
+    assert np.linalg.norm((opI * T(vc, dev)).cpu().numpy() - v0) <= eps_ * np.linalg.norm(vc)
+    assert np.linalg.norm((opI.T * T(vu, dev)).cpu().numpy() - vc) <= eps_ * np.linalg.norm(vc)
+    assert np.linalg.norm((opI.H * T(vu, dev)).cpu().numpy() - vc) <= eps_ * np.linalg.norm(vc)
+    assert np.array_equal(lo.Matrix(opI).cpu().numpy(), np.eye(nrow, ncol))
+    opI = lo.opEye(ncol, nrow, S=S)
+    assert np.linalg.norm((opI * T(vu, dev)).cpu().numpy() - vc) <= eps_ * np.linalg.norm(vc)
+    assert np.linalg.norm((opI.T * T(vc, dev)).cpu().numpy() - v0) <= eps_ * np.linalg.norm(vc)
+    assert np.linalg.norm((opI.H * T(vc, dev)).cpu().numpy() - v0) <= eps_ * np.linalg.norm(vc)
+    rtol = np.sqrt(eps_)
+    E = lo.opOnes(nrow, ncol, S=S)
+    u = sv(ncol)
+    assert np.linalg.norm((E * T(u, dev)).cpu().numpy() - u.sum() * np.ones(nrow)) <= rtol * np.linalg.norm(u)
+    assert np.linalg.norm((E.T * T(v, dev)).cpu().numpy() - v.sum() * np.ones(ncol)) <= rtol * np.linalg.norm(v)
+    assert np.linalg.norm((E.H * T(v, dev)).cpu().numpy() - v.sum() * np.ones(ncol)) <= rtol * np.linalg.norm(v)
+    O = lo.opZeros(nrow, ncol, S=S)
+    assert np.linalg.norm((O * T(u, dev)).cpu().numpy()) <= eps_
+    assert np.linalg.norm((O.T * T(v, dev)).cpu().numpy()) <= eps_ and np.linalg.norm((O.H * T(v, dev)).cpu().numpy()) <= eps_

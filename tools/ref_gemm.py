@@ -1,5 +1,5 @@
 """Reference point for the kron GEMMs: the vendor library's f64 / f32 GEMM (through torch.mm) at the same shapes,
-timed with HIP events next to libmxlo.s kron GEMM kernel (gemm_glds_kernel, through mxlo_kron_mul = two GEMMs; tools/tune_gemm.hip is the same-box comparison used in round 2)."""
+timed with HIP events next to libmxlo's kron GEMM kernel (gemm_glds_kernel, through mxlo_kron_mul = two GEMMs; tools/tune_gemm.hip is the same-box comparison used in round 2)."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

@@ -1,0 +1,89 @@
+# runtests_mxlo.jl — smoke / parity script for a Julia-equipped MI355X host (NOT EXECUTED in the build image: no Julia).
+#
+#   LD_LIBRARY_PATH=<repo>/linearoperators.jl_amd/csrc julia --project=<env with LinearOperators, Krylov> runtests_mxlo.jl
+#
+# Every device operator is compared with the SAME reference operator on host Vectors (LinearOperators.jl itself is the
+# oracle here), with the tolerances of DESIGN.md §2; the allocation contract of test/test_lbfgs.jl:180-218 is checked
+# through mxlo_debug_counters. Mirrors, in Julia, what tests/test_gpu_*.py check through the same C ABI.
+using Test, LinearAlgebra, LinearOperators
+include(joinpath(@__DIR__, "LinearOperatorsMXLOExt.jl"))
+const MX = LinearOperatorsMXLOExt
+using .LinearOperatorsMXLOExt: MXVector, MXMatrix
+
+dev(x::Vector) = MXVector(x)
+host(x::MXVector) = Array(x)
+rel(a, b) = norm(a - b) / max(norm(b), floatmin(Float64))
+counters() = (c = zeros(Int64, 12); ccall((:mxlo_debug_counters, MX.lib), Int32, (Ptr{Int64},), c); c)
+
+@testset "elementwise leaves are bit-exact" begin
+  for T in (Float64, Float32, ComplexF64, ComplexF32), n in (1, 7, 1000, 100_003)
+    d, v, r = rand(T, n), rand(T, n), rand(T, n)
+    Dh, Dd = opDiagonal(d), opDiagonal(dev(d))
+    for (α, β) in ((one(T), zero(T)), (T(2), T(-3)), (2.0, -3.0), (2.0f0, 0.5))
+      rh = copy(r); mul!(rh, Dh, v, α, β)
+      rd = dev(copy(r)); mul!(rd, Dd, dev(v), α, β)
+      @test host(rd) == rh
+      rh = copy(r); mul!(rh, Dh', v, α, β)
+      rd = dev(copy(r)); mul!(rd, Dd', dev(v), α, β)
+      @test host(rd) == rh
+    end
+    Ih, Id = opEye(T, n), opEye(T, n; S = MXVector{T})
+    @test host(Id * dev(v)) == Ih * v
+  end
+end
+
+@testset "opHouseholder / opHermitian / dense / restriction" begin
+  n = 2000
+  for T in (Float64, ComplexF64)
+    h = rand(T, n); h ./= norm(h)
+    v = rand(T, n)
+    @test rel(host(opHouseholder(dev(h)) * dev(v)), opHouseholder(h) * v) <= 1e-12
+    A = rand(T, 300, 300); d = rand(real(T), 300); x = rand(T, 300)
+    @test rel(host(opHermitian(dev(d), MXMatrix(A)) * dev(x)), opHermitian(d, A) * x) <= 1e-12
+    M = rand(T, 200, 300)
+    opd, oph = LinearOperator(MXMatrix(M)), LinearOperator(M)
+    @test rel(host(opd * dev(x)), oph * x) <= 1e-12
+    u = rand(T, 200)
+    @test rel(host(opd' * dev(u)), oph' * u) <= 1e-12
+    @test rel(host(transpose(opd) * dev(u)), transpose(oph) * u) <= 1e-12
+  end
+  I = [5, 2, 9, 2, 7]
+  v = rand(20)
+  R = opRestriction(I, 20; S = MXVector{Float64})
+  res = MXVector{Float64}(undef, 5); mul!(res, R, dev(v))
+  @test host(res) == v[I]
+  u = rand(5); back = MXVector{Float64}(undef, 20); mul!(back, R', dev(u))
+  want = zeros(20); want[I] = u
+  @test host(back) == want                                   # duplicates: the last write wins
+end
+
+@testset "kron, quasi-Newton operators, solve_shifted_system!" begin
+  A, B = rand(40, 30), rand(20, 50)
+  x = rand(30 * 50)
+  @test rel(host(kron(MXMatrix(A), MXMatrix(B)) * dev(x)), kron(A, B) * x) <= 1e-12
+  n, mem = 10_000, 5
+  Bd, Bh = LBFGSOperator(Float64, n, MXVector{Float64}; mem = mem), LBFGSOperator(n; mem = mem)
+  Hd, Hh = InverseLBFGSOperator(Float64, n, MXVector{Float64}; mem = mem), InverseLBFGSOperator(n; mem = mem)
+  for _ = 1:(mem + 3)
+    s = rand(n); y = s .* (0.5 .+ rand(n))
+    push!(Bd, dev(s), dev(y)); push!(Bh, s, y)
+    push!(Hd, dev(s), dev(y)); push!(Hh, s, y)
+  end
+  v = rand(n)
+  @test rel(host(Bd * dev(v)), Bh * v) <= 1e-9
+  @test rel(host(Hd * dev(v)), Hh * v) <= 1e-9
+  @test Bd.data.insert == Bh.data.insert
+  b = rand(n); xs = MXVector{Float64}(undef, n)
+  @test rel(host(solve_shifted_system!(xs, Bd, dev(b), 0.1)), solve_shifted_system!(zeros(n), Bh, b, 0.1)) <= 1e-8
+  # the reference's only performance contract (test/test_lbfgs.jl:180-218): a warmed mul! asks nothing of the allocator
+  res = MXVector{Float64}(undef, n); dv = dev(v)
+  mul!(res, Bd, dv); mul!(res, Hd, dv)
+  c0 = counters()
+  for _ = 1:10
+    mul!(res, Bd, dv); mul!(res, Hd, dv)
+  end
+  dc = counters() .- c0
+  @test dc[1] == 0 && dc[2] == 0 && dc[3] == 0 && dc[4] == 0 && dc[7] == 0 && dc[8] == 0     # malloc, free, H2D, D2H, syncs
+  @test dc[11] >= 20                                                                          # launches only
+end
+println("mxlo Julia smoke finished")

@@ -9,11 +9,12 @@ using Test, LinearAlgebra, LinearOperators
 include(joinpath(@__DIR__, "LinearOperatorsMXLOExt.jl"))
 const MX = LinearOperatorsMXLOExt
 using .LinearOperatorsMXLOExt: MXVector, MXMatrix
+const lib = MX.lib
 
 dev(x::Vector) = MXVector(x)
 host(x::MXVector) = Array(x)
 rel(a, b) = norm(a - b) / max(norm(b), floatmin(Float64))
-counters() = (c = zeros(Int64, 12); ccall((:mxlo_debug_counters, MX.lib), Int32, (Ptr{Int64},), c); c)
+counters() = (c = zeros(Int64, 12); ccall((:mxlo_debug_counters, lib), Int32, (Ptr{Int64},), c); c)
 
 @testset "elementwise leaves are bit-exact" begin
   for T in (Float64, Float32, ComplexF64, ComplexF32), n in (1, 7, 1000, 100_003)

@@ -137,7 +137,7 @@ def parse_ccalls(path: pathlib.Path):
 
 
 PROTOS = {k: parse_header(v) for k, v in HEADERS.items()}
-CALLS = parse_ccalls(JL)
+CALLS = parse_ccalls(JL) + parse_ccalls(ROOT / "julia" / "runtests_mxlo.jl")
 
 
 def test_headers_parse_to_the_full_symbol_lists():

@@ -202,6 +202,12 @@ def main():
         except Exception as e:
             extras["cfg4_error"] = repr(e)
 
+    if not args.no_extras and rank == 0 and world == 1:
+        try:
+            extras.update(bench_misc(lo, torch, dev, ctx))
+        except Exception as e:
+            extras["misc_error"] = repr(e)
+
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu_baseline = cpu_leg(args.cpu_sample)
@@ -396,6 +402,80 @@ def bench_cfg4(lo, torch, dev, ctx):
     Ssum = keep[0] + K
     ms = timeit(lambda: lo.mul(res, Ssum, x, 1.0, 0.0), 50)
     out["BlockDiagonal_plus_kron_2^20"] = {"us_per_apply": round(ms * 1e3, 2)}
+    torch.cuda.empty_cache()
+    return out
+
+
+def bench_misc(lo, torch, dev, ctx):
+    """Other §8 rows next to the headline, N = 1 only (HIP events on the launch stream, clocks spun up first): ComplexF64
+    opDiagonal at the headline's bytes, sorted index extension, opHermitian, and the launch-bound Householder."""
+    import ctypes as C
+
+    import numpy as np
+    from linearoperators_jl_amd import _lib
+    from linearoperators_jl_amd.device import Timer
+    tm = Timer(ctx)
+    out = {}
+    gen = torch.Generator(device=dev).manual_seed(11)
+
+    def timeit(fn, reps):
+        t_spin = time.perf_counter()
+        while time.perf_counter() - t_spin < 0.06:
+            for _ in range(5):
+                fn()
+            torch.cuda.synchronize()
+        tm.start()
+        for _ in range(reps):
+            fn()
+        tm.stop()
+        return tm.elapsed_ms() / reps
+
+    n = 50_000_000
+    mk = lambda k: torch.complex(torch.rand(k, dtype=torch.float64, device=dev, generator=gen) - 0.5,
+                                 torch.rand(k, dtype=torch.float64, device=dev, generator=gen) - 0.5)
+    d, v, res = mk(n), mk(n), mk(n)
+    D = lo.opDiagonal(d)
+    ms = timeit(lambda: lo.mul(res, D, v, 1.0, 0.0), 20)
+    out["opDiagonal_ComplexF64_n5e7"] = {"ms": round(ms, 4), "GB/s(48B/elt)": round(48.0 * n / ms / 1e6, 1),
+                                         "frac_hbm_peak": round(48.0 * n / ms / 1e6 / HBM_PEAK_GBS, 4)}
+    ms = timeit(lambda: lo.mul(res, D.H, v, 1.0, 0.0), 20)
+    out["opDiagonal_ComplexF64_adjoint_n5e7"] = {"ms": round(ms, 4), "frac_hbm_peak": round(48.0 * n / ms / 1e6 / HBM_PEAK_GBS, 4)}
+    del d, v, res, D
+    torch.cuda.empty_cache()
+    nres, nidx = 40_000_000, 20_000_000
+    idx = (torch.randperm(nres, device=dev, generator=gen)[:nidx].sort().values + 1).cpu().numpy()
+    R = lo.opRestriction(idx, nres, device=dev)
+    u = torch.rand(nidx, dtype=torch.float64, device=dev, generator=gen)
+    full = torch.empty(nres, dtype=torch.float64, device=dev)
+    ms = timeit(lambda: lo.mul(full, R.H, u), 10)
+    nb = 16.0 * nidx + 8.0 * nres                               # idx + u per entry, res written once
+    out["opExtension_sorted_2e7_of_4e7"] = {"us": round(ms * 1e3, 1), "GB/s": round(nb / ms / 1e6, 1),
+                                            "frac_hbm_peak": round(nb / ms / 1e6 / HBM_PEAK_GBS, 4)}
+    ms = timeit(lambda: lo.mul(u, R, full), 10)
+    nb = 24.0 * nidx
+    out["opRestriction_sorted_2e7_of_4e7"] = {"us": round(ms * 1e3, 1), "GB/s": round(nb / ms / 1e6, 1),
+                                              "frac_hbm_peak": round(nb / ms / 1e6 / HBM_PEAK_GBS, 4)}
+    del R, u, full, idx
+    torch.cuda.empty_cache()
+    for nn in (4096, 16384):
+        M = torch.rand(nn, nn, dtype=torch.float64, device=dev, generator=gen).t()
+        Hm = lo.opHermitian(torch.rand(nn, dtype=torch.float64, device=dev, generator=gen), M)
+        x, y = (torch.rand(nn, dtype=torch.float64, device=dev, generator=gen) for _ in range(2))
+        ms = timeit(lambda: lo.mul(y, Hm, x, 1.0, 0.0), 20)
+        out[f"opHermitian_n{nn}"] = {"us": round(ms * 1e3, 1), "GB/s(4n^2 B)": round(4.0 * nn * nn / ms / 1e6, 1),
+                                     "frac_hbm_peak": round(4.0 * nn * nn / ms / 1e6 / HBM_PEAK_GBS, 4)}
+        del M, Hm
+    n16 = 1 << 16
+    h = torch.rand(n16, dtype=torch.float64, device=dev, generator=gen)
+    h /= torch.linalg.vector_norm(h)
+    vv, rr = torch.rand(n16, dtype=torch.float64, device=dev, generator=gen), torch.empty(n16, dtype=torch.float64, device=dev)
+    fh = _lib.lib().mxlo_householder_mul
+    a = (ctx.handle, 0, C.c_void_p(rr.data_ptr()), C.c_void_p(h.data_ptr()), C.c_void_p(vv.data_ptr()), C.c_int64(n16),
+         C.c_double(1.0), C.c_double(0.0), 0)
+    ms = timeit(lambda: fh(*a), 2000)
+    Hs = lo.opHouseholder(h)
+    ms_py = timeit(lambda: lo.mul(rr, Hs, vv, 1.0, 0.0), 2000)
+    out["opHouseholder_n2^16_latency"] = {"us_C_ABI": round(ms * 1e3, 2), "us_python_mirror": round(ms_py * 1e3, 2), "launches": 1}
     torch.cuda.empty_cache()
     return out
 

@@ -4,6 +4,8 @@ seeded inputs, the reference tests' KATs, edge cases and size-independent proper
 Tolerances: elementwise leaves (opDiagonal, opEye, opZeros, scale, restriction/extension) are
 BIT-EXACT; leaves with a global reduction (opHouseholder, opOnes) 1e-12 relative L2 in fp64 and
 1e-5 in fp32 (fixed-order tree vs the oracle's / BLAS' order)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -497,3 +499,16 @@ def test_single_launch_householder_matches_two_pass_and_oracle(lo, dev):
         torch.cuda.synchronize()
         want = oracle.householder_mul(np.empty(n), h.cpu().numpy(), v.cpu().numpy(), 1.0, 0.0)
         assert rel(res.cpu().numpy(), want) <= 1e-12, k
+
+
+def test_single_launch_householder_exchange_stress(lo, dev):
+    """30,000 back-to-back single-launch applies with the grid size changing from call to call (1 ... 256 workgroups),
+    interleaved with the two-launch path, graph replays and a long streaming kernel: the slot exchange must neither hang
+    nor leak a stale partial (tools/stress_fused_householder.py runs the same loop 300,000 times)."""
+    import subprocess
+    import sys as _sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, STRESS_CALLS="30000")
+    out = subprocess.run([_sys.executable, os.path.join(root, "tools", "stress_fused_householder.py")], env=env,
+                         capture_output=True, text=True, timeout=240)
+    assert out.returncode == 0 and "no hang" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]

@@ -302,6 +302,8 @@ MXLO_API int32_t mxlo_ctx_tune(mxlo_ctx *ctx, const char *key, int64_t value) {
     ctx->tune.graph_direct_max = (int)value;
   } else if (!strcmp(key, "house_fused")) {
     ctx->tune.house_fused = value != 0;
+  } else if (!strcmp(key, "cherm_two_pass")) {
+    ctx->tune.cherm_two_pass = value != 0;
   } else if (!strcmp(key, "house_reverse")) {
     ctx->tune.house_reverse = value != 0;
   } else if (!strcmp(key, "lbfgs_inv_mode")) {

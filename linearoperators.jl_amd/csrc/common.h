@@ -122,6 +122,7 @@ struct Tune {
   int red_blocks_per_cu = 4;  // reduction kernels
   int graph_direct_max = 16; // captured chains of at most this many kernel/memset nodes replay as direct launches
   int house_fused = 1;     // single-launch Householder (dot, grid exchange, update) while the vectors fit one wave of workgroups
+  int cherm_two_pass = 0;  // complex opHermitian: 1 = the two-pass (rows, then columns) form instead of the strip kernel
   int house_reverse = 1;   // Householder phase B walks the vectors back-to-front (MALL tail reuse)
   int lbfgs_inv_mode = MXLO_INV_TWOPASS;
   int dots_max_nc = 20;    // columns per panel_dots launch (<= 20)

@@ -501,9 +501,326 @@ cherm_final_kernel(C<R> *__restrict__ res, const void *__restrict__ dptr, const 
   }
 }
 
+// ---- complex opHermitian, ONE pass over the strict lower triangle --------------------------------------------------
+// The decomposition of the real kernel (dense.hip: herm_strip_body) on 16-byte complex lanes: a lane holds RPL = 1
+// (ComplexF64) or 2 (ComplexF32) rows of a column, 128 lanes span a row group of HR = 128*RPL rows, a tile is HR x 32,
+// a workgroup owns a strip of CT consecutive tiles of one row group and reads it once. Per tile every wave produces
+//   cols : Pcol[2G + half][32J + c] = sum over its 64*RPL rows of conj(L[r][c]) * v[r]      (part of L'*v = (v'*L)')
+// by a halving butterfly over the 64 lanes (16 columns x {re, im} = 32 values -> one per lane pair), and keeps
+//   rows : Prow[s][HR*G + r]       = sum over the strip's columns of L[r][c] * v[c]         (part of L*v)
+// in registers until the strip ends. f64 accumulation for both element types; a finish kernel adds the partials in a
+// fixed order and applies res = α*((d.*v + L*v) + L'*v) (+ β*res) (src/linalg.jl:97-103) in Complex{R}.
+constexpr int CHC = 32;            // tile columns
+template <typename R>
+struct CHermCfg {
+  static constexpr int RPL = 16 / (int)sizeof(C<R>);
+  static constexpr int HR = 128 * RPL;
+  static constexpr int DT = HR / CHC;     // tiles across a diagonal block: 4 (ComplexF64) or 8 (ComplexF32)
+};
+
+// EDGE / mode as in the real kernel: EDGE = false — strips of full row groups strictly below the diagonal, 16-byte
+// loads, no masks; EDGE = true — mode 0: the same strips, masked (A not 16-byte aligned); mode 1: strips of the ragged
+// last row group; mode 2 (CT = 1): one tile of a diagonal block per workgroup.
+template <typename R, int CT, bool EDGE>
+__device__ __forceinline__ void
+cherm_strip_body(const C<R> *__restrict__ A, int64_t lda, const C<R> *__restrict__ v, int64_t n,
+                 double *__restrict__ Prow, double *__restrict__ Pcol, int64_t ng, int qint, int mode, int64_t t,
+                 double (*rowred)[CHermCfg<R>::HR][2]) {
+  constexpr int RPL = CHermCfg<R>::RPL, HR = CHermCfg<R>::HR, DT = CHermCfg<R>::DT;
+  using V = typename Vec16<C<R>>::type;      // f64x2 / f32x4: RPL complex elements
+  int64_t G, tile0, slot;                    // row group, first column tile, row-partial slot
+  if (!EDGE || mode == 0) {                  // triangular enumeration u = G'(G'+1)/2 + r, r <= G'; G = G'+1
+    constexpr int Q = DT / CT;
+    const int64_t u = t / Q;
+    int64_t Gp = (int64_t)((sqrt(8.0 * (double)u + 1.0) - 1.0) * 0.5);
+    while (Gp * (Gp + 1) / 2 > u) --Gp;
+    while ((Gp + 1) * (Gp + 2) / 2 <= u) ++Gp;
+    G = Gp + 1;
+    slot = (u - Gp * (Gp + 1) / 2) * Q + t % Q;          // strip s < Q*G
+    tile0 = slot * CT;
+  } else if (mode == 1) {                    // strips left of the diagonal block of the last row group
+    G = ng - 1;
+    slot = t;
+    tile0 = slot * CT;
+  } else {                                   // diagonal block of row group t/DT, tile t%DT
+    G = t / DT;
+    tile0 = DT * G + t % DT;
+    slot = (int64_t)qint * G + t % DT;
+  }
+  const int64_t i0 = G * HR;
+  const int tid = threadIdx.x, lane = tid & 63, rp = tid & 127;   // rows RPL*rp .. of the row group
+  const int cg = __builtin_amdgcn_readfirstlane(tid >> 7);          // columns cg + 2k, k < 16, of each tile
+  const int half = __builtin_amdgcn_readfirstlane((tid >> 6) & 1);  // which 64*RPL rows this wave covers
+  const int64_t gr = i0 + RPL * rp;
+  double vrr[RPL], vri[RPL], prr[RPL], pri[RPL];
+#pragma unroll
+  for (int r = 0; r < RPL; ++r) {
+    const bool in = !EDGE || gr + r < n;
+    vrr[r] = in ? (double)v[gr + r].re : 0.0;
+    vri[r] = in ? (double)v[gr + r].im : 0.0;
+    prr[r] = pri[r] = 0.0;
+  }
+  for (int jt = 0; jt < CT; ++jt) {
+    const int64_t j0 = (tile0 + jt) * CHC;
+    if (EDGE && j0 >= n) break;              // ragged last row group: tiles past the matrix
+    V e[16];
+    if constexpr (!EDGE) {                   // every element is strictly below the diagonal and inside
+      const C<R> *base = A + (j0 + cg) * lda + gr;
+#pragma unroll
+      for (int k = 0; k < 16; ++k)
+        e[k] = __builtin_nontemporal_load(reinterpret_cast<const V *>(base + (int64_t)(2 * k) * lda));
+    } else {
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        const int64_t gc = j0 + cg + 2 * k;
+#pragma unroll
+        for (int r = 0; r < RPL; ++r) {
+          C<R> x;
+          if (gc < n && gr + r > gc && gr + r < n) x = A[gr + r + gc * lda];   // strict lower triangle only
+          e[k][2 * r] = x.re;
+          e[k][2 * r + 1] = x.im;
+        }
+      }
+    }
+    // FMAs + first butterfly stage, column pair (q, q+8) at a time (keeps the live set small)
+    const bool hi = (lane & 32) != 0;
+    double w8r[8], w8i[8], w4r[4], w4i[4], w2r[2], w2i[2], w1r, w1i;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int64_t ca = j0 + cg + 2 * q, cb = ca + 16;
+      const bool ina = !EDGE || ca < n, inb = !EDGE || cb < n;
+      const double xar = ina ? (double)v[ca].re : 0.0, xai = ina ? (double)v[ca].im : 0.0;
+      const double xbr = inb ? (double)v[cb].re : 0.0, xbi = inb ? (double)v[cb].im : 0.0;
+      double par = 0.0, pai = 0.0, pbr = 0.0, pbi = 0.0;
+#pragma unroll
+      for (int r = 0; r < RPL; ++r) {
+        const double ar = (double)e[q][2 * r], ai = (double)e[q][2 * r + 1];
+        const double br = (double)e[q + 8][2 * r], bi = (double)e[q + 8][2 * r + 1];
+        prr[r] = fma(ar, xar, prr[r]);       // L[r][c] * v[c]
+        prr[r] = fma(-ai, xai, prr[r]);
+        pri[r] = fma(ar, xai, pri[r]);
+        pri[r] = fma(ai, xar, pri[r]);
+        prr[r] = fma(br, xbr, prr[r]);
+        prr[r] = fma(-bi, xbi, prr[r]);
+        pri[r] = fma(br, xbi, pri[r]);
+        pri[r] = fma(bi, xbr, pri[r]);
+        par = fma(ar, vrr[r], par);          // conj(L[r][c]) * v[r]
+        par = fma(ai, vri[r], par);
+        pai = fma(ar, vri[r], pai);
+        pai = fma(-ai, vrr[r], pai);
+        pbr = fma(br, vrr[r], pbr);
+        pbr = fma(bi, vri[r], pbr);
+        pbi = fma(br, vri[r], pbi);
+        pbi = fma(-bi, vrr[r], pbi);
+      }
+      w8r[q] = (hi ? pbr : par) + __shfl_xor(hi ? par : pbr, 32, 64);
+      w8i[q] = (hi ? pbi : pai) + __shfl_xor(hi ? pai : pbi, 32, 64);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    {
+      const bool h2 = (lane & 16) != 0;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        w4r[q] = (h2 ? w8r[4 + q] : w8r[q]) + __shfl_xor(h2 ? w8r[q] : w8r[4 + q], 16, 64);
+        w4i[q] = (h2 ? w8i[4 + q] : w8i[q]) + __shfl_xor(h2 ? w8i[q] : w8i[4 + q], 16, 64);
+      }
+    }
+    {
+      const bool h2 = (lane & 8) != 0;
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        w2r[q] = (h2 ? w4r[2 + q] : w4r[q]) + __shfl_xor(h2 ? w4r[q] : w4r[2 + q], 8, 64);
+        w2i[q] = (h2 ? w4i[2 + q] : w4i[q]) + __shfl_xor(h2 ? w4i[q] : w4i[2 + q], 8, 64);
+      }
+    }
+    {
+      const bool h2 = (lane & 4) != 0;
+      w1r = (h2 ? w2r[1] : w2r[0]) + __shfl_xor(h2 ? w2r[0] : w2r[1], 4, 64);
+      w1i = (h2 ? w2i[1] : w2i[0]) + __shfl_xor(h2 ? w2i[0] : w2i[1], 4, 64);
+    }
+    const bool him = (lane & 2) != 0;        // last halving step is over the two components: lanes with bit 1 keep im
+    double w = (him ? w1i : w1r) + __shfl_xor(him ? w1r : w1i, 2, 64);
+    w += __shfl_xor(w, 1, 64);
+    if ((lane & 1) == 0) {
+      const int k = ((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1);
+      const int64_t gc = j0 + cg + 2 * k;
+      if (!EDGE || gc < n) Pcol[((2 * G + half) * n + gc) * 2 + (him ? 1 : 0)] = w;
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < RPL; ++r) {
+    rowred[cg][RPL * rp + r][0] = prr[r];
+    rowred[cg][RPL * rp + r][1] = pri[r];
+  }
+  __syncthreads();
+  for (int tt = tid; tt < HR; tt += kBlock) {
+    const int64_t row = i0 + tt;
+    if (row < n) {
+      f64x2 o;
+      o[0] = rowred[0][tt][0] + rowred[1][tt][0];
+      o[1] = rowred[0][tt][1] + rowred[1][tt][1];
+      *reinterpret_cast<f64x2 *>(Prow + (slot * n + row) * 2) = o;
+    }
+  }
+}
+
+template <typename R, int CT, bool EDGE>
+__global__ void __launch_bounds__(kBlock)
+cherm_strip_kernel(const C<R> *__restrict__ A, int64_t lda, const C<R> *__restrict__ v, int64_t n,
+                   double *__restrict__ Prow, double *__restrict__ Pcol, int64_t ng, int qint, int mode) {
+  __shared__ double rowred[2][CHermCfg<R>::HR][2];
+  cherm_strip_body<R, CT, EDGE>(A, lda, v, n, Prow, Pcol, ng, qint, mode, (int64_t)blockIdx.x, rowred);
+}
+
+// Thin strips (small and mid n): ONE launch for the whole triangle: workgroups [0, n_int) run the unmasked interior
+// strips, then the masked strips (unaligned A, ragged last row group), then the diagonal tiles. The full-width strips
+// of large n keep separate launches, so that the unmasked interior is not allocated the masked path's registers.
+template <typename R, int CT>
+__global__ void __launch_bounds__(kBlock)
+cherm_pass_kernel(const C<R> *__restrict__ A, int64_t lda, const C<R> *__restrict__ v, int64_t n,
+                  double *__restrict__ Prow, double *__restrict__ Pcol, int64_t ng, int qint, int64_t n_int,
+                  int64_t n_all, int64_t n_last) {
+  __shared__ double rowred[2][CHermCfg<R>::HR][2];
+  int64_t t = blockIdx.x;
+  if (t < n_int) return cherm_strip_body<R, CT, false>(A, lda, v, n, Prow, Pcol, ng, qint, 0, t, rowred);
+  t -= n_int;
+  if (t < n_all) return cherm_strip_body<R, CT, true>(A, lda, v, n, Prow, Pcol, ng, qint, 0, t, rowred);
+  t -= n_all;
+  if (t < n_last) return cherm_strip_body<R, CT, true>(A, lda, v, n, Prow, Pcol, ng, qint, 1, t, rowred);
+  t -= n_last;
+  cherm_strip_body<R, 1, true>(A, lda, v, n, Prow, Pcol, ng, qint, 2, t, rowred);
+}
+
+// 32 rows per workgroup, 8 lanes per row, fixed-order sums (as herm_finish_kernel), then the sum of
+// src/linalg.jl:99-101 in Complex{R}: (d_i*v_i + (L*v)_i) + (L'*v)_i, α, β.
+template <typename R, typename RA, typename RB, bool BETA0, bool DREAL>
+__global__ void __launch_bounds__(kBlock)
+cherm_finish_kernel(C<R> *__restrict__ res, const void *__restrict__ dptr, const C<R> *__restrict__ v,
+                    const double *__restrict__ Prow, const double *__restrict__ Pcol, int64_t n, int ng, int q,
+                    Sc<RA> a, Sc<RB> b) {
+  const int r = threadIdx.x & 31, sub = threadIdx.x >> 5;
+  const int64_t i = (int64_t)blockIdx.x * 32 + r;
+  __shared__ double s1r[8][32], s1i[8][32], s2r[8][32], s2i[8][32];
+  double t1r = 0.0, t1i = 0.0, t2r = 0.0, t2i = 0.0;
+  if (i < n) {
+    constexpr int HR = CHermCfg<R>::HR, DT = CHermCfg<R>::DT;
+    const int G = (int)(i / HR);
+    for (int sx = sub; sx < q * G + DT; sx += 8) {          // L*v : q*G strips + DT diagonal tiles
+      const f64x2 p = *reinterpret_cast<const f64x2 *>(Prow + ((int64_t)sx * n + i) * 2);
+      t1r += p[0];
+      t1i += p[1];
+    }
+    for (int h = 2 * G + sub; h < 2 * ng; h += 8) {         // L'*v: row halves at / below i
+      const f64x2 p = *reinterpret_cast<const f64x2 *>(Pcol + ((int64_t)h * n + i) * 2);
+      t2r += p[0];
+      t2i += p[1];
+    }
+  }
+  s1r[sub][r] = t1r;
+  s1i[sub][r] = t1i;
+  s2r[sub][r] = t2r;
+  s2i[sub][r] = t2i;
+  __syncthreads();
+  if (sub != 0 || i >= n) return;
+  double a1r = 0.0, a1i = 0.0, a2r = 0.0, a2i = 0.0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    a1r += s1r[k][r];
+    a1i += s1i[k][r];
+    a2r += s2r[k][r];
+    a2i += s2i[k][r];
+  }
+  R pr, pi;
+  if constexpr (DREAL) {
+    const R d = static_cast<const R *>(dptr)[i];
+    pr = d * v[i].re;
+    pi = d * v[i].im;
+  } else {
+    const C<R> d = static_cast<const C<R> *>(dptr)[i];
+    pr = (d.re * v[i].re) - (d.im * v[i].im);
+    pi = (d.re * v[i].im) + (d.im * v[i].re);
+  }
+  const C<R> inner((pr + (R)a1r) + (R)a2r, (pi + (R)a1i) + (R)a2i);
+  RA tr, ti;
+  a.mul(inner, tr, ti);
+  res[i] = cfin<R, RA, RB, BETA0>(tr, ti, b.re, b.im, b.real, BETA0 ? C<R>() : res[i]);
+}
+
+template <typename R>
+int32_t chermitian_two_pass(mxlo_ctx *ctx, C<R> *res, const void *d, bool d_real, const C<R> *A, int64_t lda,
+                            const C<R> *v, int64_t n, const ScalArgs &s);
+
 template <typename R>
 int32_t chermitian(mxlo_ctx *ctx, C<R> *res, const void *d, bool d_real, const C<R> *A, int64_t lda, const C<R> *v,
                    int64_t n, const ScalArgs &s) {
+  if (n == 0) return MXLO_OK;
+  if (ctx->tune.cherm_two_pass) return chermitian_two_pass<R>(ctx, res, d, d_real, A, lda, v, n, s);
+  constexpr int HR = CHermCfg<R>::HR, DT = CHermCfg<R>::DT, RPL = CHermCfg<R>::RPL;
+  const int64_t ng = (n + HR - 1) / HR, ngf = n / HR;
+  MXLO_REQUIRE(4 * ng * (ng + 1) < (1LL << 31), MXLO_ESHAPE, "complex opHermitian: n too large");
+  // tiles per strip: whole diagonal-block-wide strips once there are two of them per CU, thinner strips below that
+  const int64_t pairs = ng * (ng - 1) / 2;
+  const int CT = pairs >= 2 * ctx->num_cu ? DT : ((DT / 2) * pairs >= 2 * ctx->num_cu ? 2 : 1), Q = DT / CT;
+  const int64_t nslots = Q * (ng - 1) + DT;
+  const size_t need = sizeof(double) * 2 * (size_t)(nslots + 2 * ng) * (size_t)n;   // Prow[nslots][n], Pcol[2ng][n], complex
+  if (ctx->scratch_bytes < need) {            // stream-ordered users only: drain before the buffer is replaced
+    if (ctx->scratch) {
+      MXLO_HIP(hipStreamSynchronize(ctx->stream));
+      MXLO_HIP(hipFree(ctx->scratch));
+    }
+    ctx->scratch = nullptr;
+    ctx->scratch_bytes = 0;
+    hipError_t e = hipMalloc(&ctx->scratch, need);
+    MXLO_REQUIRE(e == hipSuccess, MXLO_ENOMEM, "complex opHermitian scratch: %s", hipGetErrorString(e));
+    ctx->scratch_bytes = need;
+    ++ctx->scratch_generation;     // graphs that recorded the old workspace pointer are stale now
+  }
+  if (ctx->capturing) ctx->scratch_used_in_capture = true;
+  double *Prow = (double *)ctx->scratch, *Pcol = Prow + 2 * (size_t)nslots * n;
+  const bool aligned = (((uintptr_t)A & 15u) == 0) && (lda % RPL == 0);
+  const int64_t gi = aligned ? ngf : 0;
+  const int64_t n_int = gi > 1 ? Q * gi * (gi - 1) / 2 : 0;
+  const int64_t n_all = !aligned && ng > 1 ? Q * ng * (ng - 1) / 2 : 0;       // mode 0, masked
+  const int64_t n_last = aligned && ng > ngf ? Q * (ng - 1) : 0;               // mode 1
+  const int64_t n_diag = (int64_t)DT * ng, total = n_int + n_all + n_last + n_diag;
+  MXLO_REQUIRE(total < (1LL << 31), MXLO_ESHAPE, "complex opHermitian: n too large");
+#define CHERM_PASS(CT_)                                                                                         \
+  hipLaunchKernelGGL((cherm_pass_kernel<R, CT_>), dim3((unsigned)total), dim3(kBlock), 0, ctx->stream, A, lda, v, n, \
+                     Prow, Pcol, ng, Q, n_int, n_all, n_last)
+#define CHERM_STRIP(CT_, EDGE_, COUNT_, MODE_)                                                                   \
+  if ((COUNT_) > 0)                                                                                              \
+    hipLaunchKernelGGL((cherm_strip_kernel<R, CT_, EDGE_>), dim3((unsigned)(COUNT_)), dim3(kBlock), 0, ctx->stream, A, \
+                       lda, v, n, Prow, Pcol, ng, Q, MODE_)
+  if (CT == DT) {
+    CHERM_STRIP(DT, false, n_int, 0);
+    CHERM_STRIP(DT, true, n_all, 0);
+    CHERM_STRIP(DT, true, n_last, 1);
+    CHERM_STRIP(1, true, n_diag, 2);
+  } else if (CT == 2) CHERM_PASS(2);
+  else CHERM_PASS(1);
+#undef CHERM_STRIP
+#undef CHERM_PASS
+  MXLO_LAUNCH_CHECK();
+  const unsigned blocks = (unsigned)((n + 31) / 32);
+  return dispatch_c<R>(s, [&]<typename RA, typename RB, bool B0>() -> int32_t {
+    const Sc<RA> a{(RA)s.are, (RA)s.aim, s.a_real};
+    const Sc<RB> b{(RB)s.bre, (RB)s.bim, s.b_real};
+    if (d_real)
+      hipLaunchKernelGGL((cherm_finish_kernel<R, RA, RB, B0, true>), dim3(blocks), dim3(kBlock), 0, ctx->stream, res, d, v,
+                         Prow, Pcol, n, (int)ng, Q, a, b);
+    else
+      hipLaunchKernelGGL((cherm_finish_kernel<R, RA, RB, B0, false>), dim3(blocks), dim3(kBlock), 0, ctx->stream, res, d, v,
+                         Prow, Pcol, n, (int)ng, Q, a, b);
+    MXLO_LAUNCH_CHECK();
+    return MXLO_OK;
+  });
+}
+
+// the correctness-first form (two passes over the triangle: L*v by rows, L'*v by columns), kept behind
+// mxlo_ctx_tune("cherm_two_pass", 1) as an independent implementation the tests compare the single pass with
+template <typename R>
+int32_t chermitian_two_pass(mxlo_ctx *ctx, C<R> *res, const void *d, bool d_real, const C<R> *A, int64_t lda,
+                            const C<R> *v, int64_t n, const ScalArgs &s) {
   if (n == 0) return MXLO_OK;
   const size_t need = sizeof(C<R>) * 2 * (size_t)n;           // t1 = L*v, t2 = L'*v
   if (ctx->scratch_bytes < need) {            // stream-ordered users only: drain before the buffer is replaced

@@ -327,6 +327,54 @@ def test_complex_hermitian_parity(lo, dev, dtype, tol, n):
     assert rel((Hc * T(v, dev)).cpu().numpy(), Cm @ v) <= 10 * tol
 
 
+@pytest.mark.parametrize("dtype,tol,n,aligned", [
+    (torch.complex128, 1e-12, 129, True), (torch.complex128, 1e-12, 640, True),
+    (torch.complex128, 1e-12, 3001, True),       # thin strips of 2 tiles, ragged last row group
+    (torch.complex128, 1e-12, 4224, True),       # full-width strips (separate launches), every row group full
+    (torch.complex128, 1e-12, 4301, True),       # ... with a ragged last row group
+    (torch.complex64, 3e-5, 515, True), (torch.complex64, 3e-5, 515, False),
+    (torch.complex64, 3e-5, 4200, True),         # 2-tile strips
+    (torch.complex64, 3e-5, 4200, False),        # the same, masked loads (A not 16-byte aligned)
+    (torch.complex64, 3e-5, 8500, True),         # full-width strips
+])
+def test_complex_hermitian_strip_regimes(lo, dev, dtype, tol, n, aligned):
+    """The single-pass strip kernel of the complex opHermitian in each of its launch regimes (one merged launch with
+    1- and 2-tile strips; separate launches with full-width strips; aligned and masked loads; ragged last row group)
+    against the oracle, and against the two-pass form (rows, then columns) as an independent device implementation."""
+    dt = NPC[dtype]
+    rdt = np.float64 if dt == np.complex128 else np.float32
+    rng = np.random.default_rng(7 * n + aligned)
+    off = 0 if aligned else 1
+    big = cmat(rng, n + 2 + off, n, dt)
+    bigd = T(big.T.copy(), dev).t()
+    Ad, A = bigd[off:n + off, :], big[off:n + off, :]
+    v = crand(rng, n, dt)
+    ctx = lo.get_ctx(dev)
+    for d in (rng.standard_normal(n).astype(rdt), crand(rng, n, dt)):
+        H = lo.opHermitian(T(d, dev), Ad)
+        for (a, b) in ((complex(1), complex(0)), (1.5 - 0.5j, 0.25 + 2j)):
+            r0 = crand(rng, n, dt)
+            res = T(r0.copy(), dev)
+            lo.mul(res, H, T(v, dev), a, b)
+            want = oracle.hermitian_mul(r0.copy(), d, A, v, a, b, flags=oracle.scalar_flags(dt, a, b))
+            assert rel(res.cpu().numpy(), want) <= tol, (n, a, b)
+            ctx.tune("cherm_two_pass", 1)
+            try:
+                res2 = T(r0.copy(), dev)
+                lo.mul(res2, H, T(v, dev), a, b)
+            finally:
+                ctx.tune("cherm_two_pass", 0)
+            assert rel(res.cpu().numpy(), res2.cpu().numpy()) <= tol
+    # structure: e_j picks column j of the Hermitian matrix (exact products with 0 and 1)
+    for j in (0, n // 2, n - 1):
+        e = np.zeros(n, dt)
+        e[j] = 1
+        H = lo.opHermitian(T(np.zeros(n, rdt), dev), Ad)
+        col = (H * T(e, dev)).cpu().numpy()
+        Lc = np.tril(A, -1)
+        assert np.array_equal(col, (Lc[:, j] + Lc[j, :].conj()).astype(dt))
+
+
 def test_complex_dense_in_operator_trees_and_contract(lo, dev):
     """complex dense leaves compose with the complex elementwise leaves (sum, product, cat) against dense NumPy, and a
     warmed apply issues launches only."""

@@ -18,7 +18,7 @@ tm = Timer(ctx)
 gen = torch.Generator(device=dev).manual_seed(1)
 PEAK = 8000.0
 ONLY = set(a for a in sys.argv[1:] if not a.startswith("-"))
-SECTIONS = ("leaves", "small", "restrict", "complex", "dense", "kron", "qn", "variants", "cpu", "cfg5", "graph")
+SECTIONS = ("leaves", "small", "restrict", "complex", "dense", "cherm", "kron", "qn", "variants", "cpu", "cfg5", "graph")
 assert ONLY <= set(SECTIONS), f"sections: {SECTIONS}"
 
 
@@ -140,10 +140,25 @@ if sec("dense"):
         row(f"complex128 dense LinearOperator(M) mul! n={nn}", 16.0 * nn * nn, timeit(lambda: lo.mul(yc, opc, xc, 1.0, 0.0), 10))
         row(f"complex128 dense adjoint mul! n={nn}", 16.0 * nn * nn, timeit(lambda: lo.mul(yc, opc.H, xc, 1.0, 0.0), 10))
         Hc = lo.opHermitian(rnd(nn), Mc)
-        row(f"complex128 opHermitian mul! n={nn} (ideal = strict lower triangle once; two passes here)", 8.0 * nn * nn,
+        row(f"complex128 opHermitian mul! n={nn} (ideal = strict lower triangle once)", 8.0 * nn * nn,
             timeit(lambda: lo.mul(yc, Hc, xc, 1.0, 0.0), 10))
         del Mc, opc, Hc
     torch.cuda.empty_cache()
+
+# complex opHermitian: the single-pass strip kernel against the two-pass form it replaced
+if sec("cherm"):
+    for cdt, rdt_, bpe in ((torch.complex128, torch.float64, 16), (torch.complex64, torch.float32, 8)):
+        for nn in (1024, 2048, 4096, 8192, 16384):
+            Mc = torch.complex(rnd(nn * nn, rdt_), rnd(nn * nn, rdt_)).reshape(nn, nn).t()
+            xc, yc = torch.complex(rnd(nn, rdt_), rnd(nn, rdt_)), torch.complex(rnd(nn, rdt_), rnd(nn, rdt_))
+            Hc = lo.opHermitian(rnd(nn, rdt_), Mc)
+            for two in (0, 1):
+                ctx.tune("cherm_two_pass", two)
+                row(f"{str(cdt)[6:]} opHermitian mul! n={nn} {'two passes' if two else 'strip kernel'}", bpe / 2 * nn * nn,
+                    min(timeit(lambda: lo.mul(yc, Hc, xc, 1.0, 0.0), 10) for _ in range(3)))
+            ctx.tune("cherm_two_pass", 0)
+            del Mc, Hc
+            torch.cuda.empty_cache()
 
 # kron: two f64 / f32 MFMA GEMMs per apply (4 m^3 flop for m x m (x) m x m)
 if sec("kron"):

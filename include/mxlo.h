@@ -105,8 +105,10 @@ int32_t mxlo_ctx_set_stream(mxlo_ctx *ctx, void *stream);
 int32_t mxlo_ctx_sync(mxlo_ctx *ctx);
 /* info[0]=device id, [1]=CU count, [2]=workspace bytes, [3]=max reduction columns */
 int32_t mxlo_ctx_info(mxlo_ctx *ctx, int64_t info[4]);
-/* Launch-geometry knobs for sweeps (key: "blocks_per_cu", "unroll", "nt",
- * "house_reverse", "dots_nc", ...). Unknown key -> MXLO_EINVAL. */
+/* Launch-geometry / algorithm-variant knobs for sweeps and for tests that compare two device implementations. Keys:
+ * "blocks_per_cu", "nt_min_bytes", "red_blocks_per_cu", "graph_direct_max", "house_fused", "house_reverse",
+ * "cherm_two_pass", "lbfgs_inv_mode", "gemm_tile", "extend_tiles_per_block", "fuse_finalize", "combine_blocks_per_cu",
+ * "dots_max_nc". Unknown key or out-of-range value -> MXLO_EINVAL. */
 int32_t mxlo_ctx_tune(mxlo_ctx *ctx, const char *key, int64_t value);
 
 /* Row-sharding hook. When set, EVERY global reduction this ctx performs
@@ -248,7 +250,8 @@ int32_t mxlo_gemv_c(mxlo_ctx *ctx, int32_t dtype, void *res, const void *M, int6
                     int32_t op_mode, int32_t flags);
 /* mulHermitian! on complex data — src/linalg.jl:97-103: res = α*(d.*v + L*v + (v'*L)') (+ β*res), L = tril(A,-1) read
  * from the caller's column-major A (only the strict lower triangle is touched); d complex, or real with MXLO_D_REAL
- * (test/test_linop.jl:360-370 builds it from ComplexF64 A and real d). Two passes over the triangle (L*v, L'*v). */
+ * (test/test_linop.jl:360-370 builds it from ComplexF64 A and real d). ONE pass over the triangle (row and column
+ * partials per strip, fixed-order finish); tune key "cherm_two_pass" = 1 selects the two-pass form (L*v, then L'*v). */
 int32_t mxlo_hermitian_mul_c(mxlo_ctx *ctx, int32_t dtype, void *res, const void *d, const void *A, int64_t lda,
                              const void *v, int64_t n, double alpha_re, double alpha_im, double beta_re,
                              double beta_im, int32_t flags);

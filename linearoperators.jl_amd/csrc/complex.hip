@@ -521,15 +521,22 @@ struct CHermCfg {
 // EDGE / mode as in the real kernel: EDGE = false — strips of full row groups strictly below the diagonal, 16-byte
 // loads, no masks; EDGE = true — mode 0: the same strips, masked (A not 16-byte aligned); mode 1: strips of the ragged
 // last row group; mode 2 (CT = 1): one tile of a diagonal block per workgroup.
-template <typename R, int CT, bool EDGE>
+// DSEL (EDGE = false, CT = 1): a tile of the diagonal block of a FULL row group of an aligned matrix — unmasked loads,
+// then a select zeroes what is at or above the diagonal (dense.hip: herm_strip_body).
+template <typename R, int CT, bool EDGE, bool DSEL = false>
 __device__ __forceinline__ void
 cherm_strip_body(const C<R> *__restrict__ A, int64_t lda, const C<R> *__restrict__ v, int64_t n,
                  double *__restrict__ Prow, double *__restrict__ Pcol, int64_t ng, int qint, int mode, int64_t t,
                  double (*rowred)[CHermCfg<R>::HR][2]) {
   constexpr int RPL = CHermCfg<R>::RPL, HR = CHermCfg<R>::HR, DT = CHermCfg<R>::DT;
   using V = typename Vec16<C<R>>::type;      // f64x2 / f32x4: RPL complex elements
+  static_assert(!DSEL || (!EDGE && CT == 1), "DSEL: one unmasked-load tile of a diagonal block");
   int64_t G, tile0, slot;                    // row group, first column tile, row-partial slot
-  if (!EDGE || mode == 0) {                  // triangular enumeration u = G'(G'+1)/2 + r, r <= G'; G = G'+1
+  if constexpr (DSEL) {                      // diagonal block of row group t/DT, tile t%DT
+    G = t / DT;
+    tile0 = DT * G + t % DT;
+    slot = (int64_t)qint * G + t % DT;
+  } else if (!EDGE || mode == 0) {           // triangular enumeration u = G'(G'+1)/2 + r, r <= G'; G = G'+1
     constexpr int Q = DT / CT;
     const int64_t u = t / Q;
     int64_t Gp = (int64_t)((sqrt(8.0 * (double)u + 1.0) - 1.0) * 0.5);
@@ -560,6 +567,7 @@ cherm_strip_body(const C<R> *__restrict__ A, int64_t lda, const C<R> *__restrict
     vri[r] = in ? (double)v[gr + r].im : 0.0;
     prr[r] = pri[r] = 0.0;
   }
+#pragma unroll 1
   for (int jt = 0; jt < CT; ++jt) {
     const int64_t j0 = (tile0 + jt) * CHC;
     if (EDGE && j0 >= n) break;              // ragged last row group: tiles past the matrix
@@ -569,6 +577,18 @@ cherm_strip_body(const C<R> *__restrict__ A, int64_t lda, const C<R> *__restrict
 #pragma unroll
       for (int k = 0; k < 16; ++k)
         e[k] = __builtin_nontemporal_load(reinterpret_cast<const V *>(base + (int64_t)(2 * k) * lda));
+      if constexpr (DSEL) {
+        const int below = (int)(gr - (j0 + cg));      // row - column of this lane's element of column k = 0
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+#pragma unroll
+          for (int r = 0; r < RPL; ++r) {
+            const bool keep = below + r > 2 * k;                                 // strict lower triangle only
+            e[k][2 * r] = keep ? e[k][2 * r] : R(0);
+            e[k][2 * r + 1] = keep ? e[k][2 * r + 1] : R(0);
+          }
+        }
+      }
     } else {
 #pragma unroll
       for (int k = 0; k < 16; ++k) {
@@ -664,31 +684,32 @@ cherm_strip_body(const C<R> *__restrict__ A, int64_t lda, const C<R> *__restrict
   }
 }
 
-template <typename R, int CT, bool EDGE>
-__global__ void __launch_bounds__(kBlock)
-cherm_strip_kernel(const C<R> *__restrict__ A, int64_t lda, const C<R> *__restrict__ v, int64_t n,
-                   double *__restrict__ Prow, double *__restrict__ Pcol, int64_t ng, int qint, int mode) {
-  __shared__ double rowred[2][CHermCfg<R>::HR][2];
-  cherm_strip_body<R, CT, EDGE>(A, lda, v, n, Prow, Pcol, ng, qint, mode, (int64_t)blockIdx.x, rowred);
-}
-
-// Thin strips (small and mid n): ONE launch for the whole triangle: workgroups [0, n_int) run the unmasked interior
-// strips, then the masked strips (unaligned A, ragged last row group), then the diagonal tiles. The full-width strips
-// of large n keep separate launches, so that the unmasked interior is not allocated the masked path's registers.
+// ONE launch for everything that can use unmasked 16-byte loads (aligned A): the interior strips of the full row
+// groups, then the tiles of their diagonal blocks (DSEL) — both at the unmasked path's register footprint.
 template <typename R, int CT>
 __global__ void __launch_bounds__(kBlock)
 cherm_pass_kernel(const C<R> *__restrict__ A, int64_t lda, const C<R> *__restrict__ v, int64_t n,
-                  double *__restrict__ Prow, double *__restrict__ Pcol, int64_t ng, int qint, int64_t n_int,
-                  int64_t n_all, int64_t n_last) {
+                  double *__restrict__ Prow, double *__restrict__ Pcol, int64_t ng, int qint, int64_t n_int) {
+  __shared__ double rowred[2][CHermCfg<R>::HR][2];
+  const int64_t t = blockIdx.x;
+  if (t < n_int) return cherm_strip_body<R, CT, false>(A, lda, v, n, Prow, Pcol, ng, qint, 0, t, rowred);
+  cherm_strip_body<R, 1, false, true>(A, lda, v, n, Prow, Pcol, ng, qint, 2, t - n_int, rowred);
+}
+
+// The masked remainder, one launch: every strip when A is not 16-byte aligned (mode 0), the strips of the ragged last
+// row group (mode 1), the diagonal tiles of the row groups from g0 on (mode 2).
+template <typename R, int CT>
+__global__ void __launch_bounds__(kBlock)
+cherm_edge_kernel(const C<R> *__restrict__ A, int64_t lda, const C<R> *__restrict__ v, int64_t n,
+                  double *__restrict__ Prow, double *__restrict__ Pcol, int64_t ng, int qint, int64_t n_all,
+                  int64_t n_last, int64_t g0) {
   __shared__ double rowred[2][CHermCfg<R>::HR][2];
   int64_t t = blockIdx.x;
-  if (t < n_int) return cherm_strip_body<R, CT, false>(A, lda, v, n, Prow, Pcol, ng, qint, 0, t, rowred);
-  t -= n_int;
   if (t < n_all) return cherm_strip_body<R, CT, true>(A, lda, v, n, Prow, Pcol, ng, qint, 0, t, rowred);
   t -= n_all;
   if (t < n_last) return cherm_strip_body<R, CT, true>(A, lda, v, n, Prow, Pcol, ng, qint, 1, t, rowred);
   t -= n_last;
-  cherm_strip_body<R, 1, true>(A, lda, v, n, Prow, Pcol, ng, qint, 2, t, rowred);
+  cherm_strip_body<R, 1, true>(A, lda, v, n, Prow, Pcol, ng, qint, 2, t + CHermCfg<R>::DT * g0, rowred);
 }
 
 // 32 rows per workgroup, 8 lanes per row, fixed-order sums (as herm_finish_kernel), then the sum of
@@ -780,27 +801,27 @@ int32_t chermitian(mxlo_ctx *ctx, C<R> *res, const void *d, bool d_real, const C
   const bool aligned = (((uintptr_t)A & 15u) == 0) && (lda % RPL == 0);
   const int64_t gi = aligned ? ngf : 0;
   const int64_t n_int = gi > 1 ? Q * gi * (gi - 1) / 2 : 0;
+  const int64_t n_dsel = (int64_t)DT * gi;
   const int64_t n_all = !aligned && ng > 1 ? Q * ng * (ng - 1) / 2 : 0;       // mode 0, masked
   const int64_t n_last = aligned && ng > ngf ? Q * (ng - 1) : 0;               // mode 1
-  const int64_t n_diag = (int64_t)DT * ng, total = n_int + n_all + n_last + n_diag;
-  MXLO_REQUIRE(total < (1LL << 31), MXLO_ESHAPE, "complex opHermitian: n too large");
-#define CHERM_PASS(CT_)                                                                                         \
-  hipLaunchKernelGGL((cherm_pass_kernel<R, CT_>), dim3((unsigned)total), dim3(kBlock), 0, ctx->stream, A, lda, v, n, \
-                     Prow, Pcol, ng, Q, n_int, n_all, n_last)
-#define CHERM_STRIP(CT_, EDGE_, COUNT_, MODE_)                                                                   \
-  if ((COUNT_) > 0)                                                                                              \
-    hipLaunchKernelGGL((cherm_strip_kernel<R, CT_, EDGE_>), dim3((unsigned)(COUNT_)), dim3(kBlock), 0, ctx->stream, A, \
-                       lda, v, n, Prow, Pcol, ng, Q, MODE_)
-  if (CT == DT) {
-    CHERM_STRIP(DT, false, n_int, 0);
-    CHERM_STRIP(DT, true, n_all, 0);
-    CHERM_STRIP(DT, true, n_last, 1);
-    CHERM_STRIP(1, true, n_diag, 2);
-  } else if (CT == 2) CHERM_PASS(2);
-  else CHERM_PASS(1);
-#undef CHERM_STRIP
-#undef CHERM_PASS
-  MXLO_LAUNCH_CHECK();
+  const int64_t n_diag = (int64_t)DT * (ng - gi);                              // mode 2, row groups gi .. ng-1
+  const int64_t n_light = n_int + n_dsel, n_edge = n_all + n_last + n_diag;
+  MXLO_REQUIRE(n_light < (1LL << 31) && n_edge < (1LL << 31), MXLO_ESHAPE, "complex opHermitian: n too large");
+#define CHERM_LAUNCH(CT_)                                                                                        \
+  {                                                                                                              \
+    if (n_light > 0) {                                                                                           \
+      hipLaunchKernelGGL((cherm_pass_kernel<R, CT_>), dim3((unsigned)n_light), dim3(kBlock), 0, ctx->stream, A, lda, \
+                         v, n, Prow, Pcol, ng, Q, n_int);                                                        \
+      MXLO_LAUNCH_CHECK();                                                                                       \
+    }                                                                                                            \
+    if (n_edge > 0) {                                                                                            \
+      hipLaunchKernelGGL((cherm_edge_kernel<R, CT_>), dim3((unsigned)n_edge), dim3(kBlock), 0, ctx->stream, A, lda,  \
+                         v, n, Prow, Pcol, ng, Q, n_all, n_last, gi);                                            \
+      MXLO_LAUNCH_CHECK();                                                                                       \
+    }                                                                                                            \
+  }
+  if (CT == DT) CHERM_LAUNCH(DT) else if (CT == 2) CHERM_LAUNCH(2) else CHERM_LAUNCH(1)
+#undef CHERM_LAUNCH
   const unsigned blocks = (unsigned)((n + 31) / 32);
   return dispatch_c<R>(s, [&]<typename RA, typename RB, bool B0>() -> int32_t {
     const Sc<RA> a{(RA)s.are, (RA)s.aim, s.a_real};

@@ -391,6 +391,19 @@ struct HermCfg {
   static constexpr int DT = HR / HC;
 };
 
+// Partials live in row-group blocks, so that everything the finish kernel adds for one output row sits within a few
+// hundred KiB (slot stride = HR doubles) instead of being strided by n doubles across tens of MiB:
+//   Prow: row group G owns q*G + DT slots of HR doubles at herm_row_base(G);
+//   Pcol: column group Gc owns the 2*(ng - Gc) row halves at / below it, HR doubles each, at herm_col_base(Gc).
+template <int HR_, int DT_>
+__host__ __device__ __forceinline__ int64_t herm_row_base(int64_t G, int q) {
+  return (int64_t)HR_ * ((int64_t)q * (G * (G - 1) / 2) + (int64_t)DT_ * G);
+}
+template <int HR_>
+__host__ __device__ __forceinline__ int64_t herm_col_base(int64_t Gc, int64_t ng) {
+  return (int64_t)HR_ * (2 * ng * Gc - Gc * (Gc - 1));
+}
+
 // C = tiles per strip (8, 2 or 1: fewer when the triangle is too small to fill the chip with 256x256 strips),
 // qint = 8/C_strip strips per 256 columns. Row group G owns qint*G + 8 slots of row partials: one per strip
 // left of its diagonal block, one per tile of the diagonal block.
@@ -399,15 +412,24 @@ struct HermCfg {
 //   EDGE = true : masked loads. mode 0: the same strips when A is not 16-byte aligned; mode 1: the strips of
 //                 the ragged last row group; mode 2 (instantiated with C = 1): the 8 tiles of a diagonal block,
 //                 one workgroup each, so that the short diagonal pass still fills the chip.
-template <typename T, int C, bool EDGE>
+//   DSEL (with EDGE = false, C = 1): a tile of the diagonal block of a FULL row group of an aligned matrix — the same
+//                 unmasked 16-byte loads (every address is inside the matrix), then elements at or above the diagonal
+//                 are replaced by zero with a select (whatever the caller keeps up there, NaN included, never enters
+//                 a product). Register footprint of the unmasked path, so these tiles ride in the interior launch.
+template <typename T, int C, bool EDGE, bool DSEL = false>
 __device__ __forceinline__ void
 herm_strip_body(const T *__restrict__ A, int64_t lda, const T *__restrict__ v, int64_t n,
                 double *__restrict__ Prow, double *__restrict__ Pcol, int64_t ng, int qint, int mode, int64_t t) {
   constexpr int RPL = HermCfg<T>::RPL, HR = HermCfg<T>::HR, DT = HermCfg<T>::DT;
   typedef T VR __attribute__((ext_vector_type(RPL)));
   constexpr int HS = C;
+  static_assert(!DSEL || (!EDGE && C == 1), "DSEL: one unmasked-load tile of a diagonal block");
   int64_t G, tile0, slot;                    // row group, first column tile, row-partial slot
-  if (!EDGE || mode == 0) {                  // triangular enumeration u = G'(G'+1)/2 + r, r <= G'; G = G'+1
+  if constexpr (DSEL) {                      // diagonal block of row group t/DT, tile t%DT
+    G = t / DT;
+    tile0 = DT * G + t % DT;
+    slot = (int64_t)qint * G + t % DT;
+  } else if (!EDGE || mode == 0) {           // triangular enumeration u = G'(G'+1)/2 + r, r <= G'; G = G'+1
     constexpr int Q = DT / C;
     const int64_t u = t / Q;
     int64_t Gp = (int64_t)((sqrt(8.0 * (double)u + 1.0) - 1.0) * 0.5);
@@ -436,6 +458,7 @@ herm_strip_body(const T *__restrict__ A, int64_t lda, const T *__restrict__ v, i
     vr[r] = (!EDGE || gr + r < n) ? (double)v[gr + r] : 0.0;
     prow[r] = 0.0;
   }
+#pragma unroll 1
   for (int jt = 0; jt < HS; ++jt) {
     const int64_t j0 = (tile0 + jt) * HC;
     if (EDGE && j0 >= n) break;              // ragged last row group: tiles past the matrix
@@ -445,6 +468,14 @@ herm_strip_body(const T *__restrict__ A, int64_t lda, const T *__restrict__ v, i
 #pragma unroll
       for (int k = 0; k < 16; ++k)
         e[k] = __builtin_nontemporal_load(reinterpret_cast<const VR *>(base + (int64_t)(2 * k) * lda));
+      if constexpr (DSEL) {
+        const int below = (int)(gr - (j0 + cg));      // row - column of this lane's element of column k = 0
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+#pragma unroll
+          for (int r = 0; r < RPL; ++r) e[k][r] = below + r > 2 * k ? e[k][r] : T(0);   // strict lower triangle only
+        }
+      }
     } else {
 #pragma unroll
       for (int k = 0; k < 16; ++k) {
@@ -457,6 +488,9 @@ herm_strip_body(const T *__restrict__ A, int64_t lda, const T *__restrict__ v, i
         }
       }
     }
+    // column partials of this tile: block of column group Gc = j0/HR, row half 2G + half (offset so that + gc indexes it)
+    const int64_t Gc = j0 / HR;
+    const int64_t pcol0 = herm_col_base<HR>(Gc, ng) + (2 * G + half - 2 * Gc) * HR - Gc * HR;
     // FMAs + first butterfly stage, column pair (q, q+8) at a time (keeps the live set small)
     const bool hi = (lane & 32) != 0;
     double w8[8], w4[4], w2[2], w1;
@@ -503,7 +537,7 @@ herm_strip_body(const T *__restrict__ A, int64_t lda, const T *__restrict__ v, i
     if ((lane & 3) == 0) {
       const int k = ((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1);
       const int64_t gc = j0 + cg + 2 * k;
-      if (!EDGE || gc < n) Pcol[(2 * G + half) * n + gc] = w1;
+      if (!EDGE || gc < n) Pcol[pcol0 + gc] = w1;
     }
   }
   __shared__ double rowred[2][HR];
@@ -512,53 +546,86 @@ herm_strip_body(const T *__restrict__ A, int64_t lda, const T *__restrict__ v, i
   __syncthreads();
   for (int tt = tid; tt < HR; tt += kBlock) {
     const int64_t row = i0 + tt;
-    if (row < n) Prow[slot * n + row] = rowred[0][tt] + rowred[1][tt];
+    if (row < n) Prow[herm_row_base<HR, DT>(G, qint) + slot * HR + tt] = rowred[0][tt] + rowred[1][tt];
   }
 }
 
-template <typename T, int C, bool EDGE>
-__global__ void __launch_bounds__(kBlock)
-herm_strip_kernel(const T *__restrict__ A, int64_t lda, const T *__restrict__ v, int64_t n,
-                  double *__restrict__ Prow, double *__restrict__ Pcol, int64_t ng, int qint, int mode) {
-  herm_strip_body<T, C, EDGE>(A, lda, v, n, Prow, Pcol, ng, qint, mode, (int64_t)blockIdx.x);
-}
-
-// Mid sizes (thin strips, C <= 2): ONE launch for the whole triangle: workgroups [0, n_int) run the unmasked interior strips, then the masked strips
-// (unaligned A, ragged last row group), then the diagonal tiles — every dependent launch costs ~3.5 us on this
-// runtime, which at n = 4096 (67 MB, ~11 us of traffic) was a third of the apply. (Not for the 8-tile strips of
-// large n: the merged kernel is allocated the masked path's registers — 195 instead of 104 VGPRs — and the unmasked
-// interior, which carries all the traffic there, would lose half its occupancy.)
+// ONE launch for everything that can use unmasked 16-byte loads (aligned A): workgroups [0, n_int) run the interior
+// strips of the full row groups, the rest the tiles of their diagonal blocks (DSEL). Both bodies fit the unmasked
+// path's registers, so at n = 4096 all 1088 workgroups are resident at once (the round-2 merged kernel also carried
+// the masked bodies — 195 VGPRs, half the occupancy — and took 14.8 us of the 20.6 us apply).
 template <typename T, int C>
 __global__ void __launch_bounds__(kBlock)
 herm_pass_kernel(const T *__restrict__ A, int64_t lda, const T *__restrict__ v, int64_t n,
-                 double *__restrict__ Prow, double *__restrict__ Pcol, int64_t ng, int qint, int64_t n_int,
-                 int64_t n_all, int64_t n_last) {
-  int64_t t = blockIdx.x;
+                 double *__restrict__ Prow, double *__restrict__ Pcol, int64_t ng, int qint, int64_t n_int) {
+  const int64_t t = blockIdx.x;
   if (t < n_int) return herm_strip_body<T, C, false>(A, lda, v, n, Prow, Pcol, ng, qint, 0, t);
-  t -= n_int;
+  herm_strip_body<T, 1, false, true>(A, lda, v, n, Prow, Pcol, ng, qint, 2, t - n_int);
+}
+
+// The masked remainder, one launch: every strip when A is not 16-byte aligned (n_all, mode 0), the strips of the
+// ragged last row group (n_last, mode 1), and the diagonal tiles of the row groups from g0 on (mode 2).
+template <typename T, int C>
+__global__ void __launch_bounds__(kBlock)
+herm_edge_kernel(const T *__restrict__ A, int64_t lda, const T *__restrict__ v, int64_t n,
+                 double *__restrict__ Prow, double *__restrict__ Pcol, int64_t ng, int qint, int64_t n_all,
+                 int64_t n_last, int64_t g0) {
+  int64_t t = blockIdx.x;
   if (t < n_all) return herm_strip_body<T, C, true>(A, lda, v, n, Prow, Pcol, ng, qint, 0, t);
   t -= n_all;
   if (t < n_last) return herm_strip_body<T, C, true>(A, lda, v, n, Prow, Pcol, ng, qint, 1, t);
   t -= n_last;
-  herm_strip_body<T, 1, true>(A, lda, v, n, Prow, Pcol, ng, qint, 2, t);
+  herm_strip_body<T, 1, true>(A, lda, v, n, Prow, Pcol, ng, qint, 2, t + HermCfg<T>::DT * g0);
 }
 
 // 32 rows per workgroup, 8 lanes per row: lane `sub` adds partials sub, sub+8, ... (independent loads in
 // flight), the 8 sub-sums are combined in a fixed order -> deterministic, and n/32 workgroups fill the chip.
-template <typename T, typename CA, typename CB, bool BETA0>
+template <typename T, typename CA, typename CB, bool BETA0, int FR>
 __global__ void __launch_bounds__(kBlock)
 herm_finish_kernel(T *__restrict__ res, const T *__restrict__ d, const T *__restrict__ v,
                    const double *__restrict__ Prow, const double *__restrict__ Pcol, int64_t n, int ng,
                    int q, CA alpha, CB beta) {
-  const int r = threadIdx.x & 31, sub = threadIdx.x >> 5;
-  const int64_t i = (int64_t)blockIdx.x * 32 + r;
-  __shared__ double s1[8][32], s2[8][32];
+  // FR rows per workgroup, 256/FR lanes per row; a lane's partials (sub, sub+FS, ...) are loaded 8 (4) at a time with
+  // nothing between the loads, and the finishing lane's d, v (res) are requested before them: the kernel is pure
+  // latency (3 MB of partials at n = 4096) — ~2.3 us of its own plus the ~2.2 us every dependent launch costs.
+  constexpr int FS = kBlock / FR;
+  const int r = threadIdx.x % FR, sub = threadIdx.x / FR;
+  const int64_t i = (int64_t)blockIdx.x * FR + r;
+  __shared__ double s1[FS][FR], s2[FS][FR];
   double t1 = 0.0, t2 = 0.0;
+  T di = T(0), vi = T(0), ri = T(0);           // the finishing lane's operands, requested before the partials
+  if (sub == 0 && i < n) {
+    di = d[i];
+    vi = v[i];
+    if constexpr (!BETA0) ri = res[i];
+  }
   if (i < n) {
     constexpr int HR = HermCfg<T>::HR, DT = HermCfg<T>::DT;
     const int G = (int)(i / HR);
-    for (int sx = sub; sx < q * G + DT; sx += 8) t1 += Prow[(int64_t)sx * n + i];    // L*v : q*G strips + DT diagonal tiles
-    for (int h = 2 * G + sub; h < 2 * ng; h += 8) t2 += Pcol[(int64_t)h * n + i];   // L'*v: 128-row halves at/below i
+    const int c1 = q * G + DT;                 // L*v : q*G strips + DT diagonal tiles
+    const double *prow = Prow + herm_row_base<HR, DT>(G, q) + (i - (int64_t)G * HR);
+    const double *pcol = Pcol + herm_col_base<HR>(G, ng) + (i - (int64_t)G * HR);
+    for (int base = sub; base < c1; base += FS * 8) {
+      double x[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int sx = base + FS * u;
+        x[u] = sx < c1 ? prow[(int64_t)sx * HR] : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t1 += x[u];
+    }
+    const int h1 = 2 * ng;                     // L'*v: 128-row halves at/below i
+    for (int base = 2 * G + sub; base < h1; base += FS * 4) {
+      double x[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int h = base + FS * u;
+        x[u] = h < h1 ? pcol[(int64_t)(h - 2 * G) * HR] : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) t2 += x[u];
+    }
   }
   s1[sub][r] = t1;
   s2[sub][r] = t2;
@@ -566,12 +633,12 @@ herm_finish_kernel(T *__restrict__ res, const T *__restrict__ d, const T *__rest
   if (sub == 0 && i < n) {
     double a1 = 0.0, a2 = 0.0;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      a1 += s1[q][r];
-      a2 += s2[q][r];
+    for (int k = 0; k < FS; ++k) {
+      a1 += s1[k][r];
+      a2 += s2[k][r];
     }
-    const T inner = ((d[i] * v[i]) + (T)a1) + (T)a2;
-    res[i] = fin_ab<T, CA, CB, BETA0>(alpha * (CA)inner, beta, BETA0 ? T(0) : res[i]);
+    const T inner = ((di * vi) + (T)a1) + (T)a2;
+    res[i] = fin_ab<T, CA, CB, BETA0>(alpha * (CA)inner, beta, ri);
   }
 }
 
@@ -585,8 +652,8 @@ int32_t hermitian_t(mxlo_ctx *ctx, T *res, const T *d, const T *A, int64_t lda, 
   // tiles per strip: 8-tile strips once there are at least two of them per CU, thinner strips below that
   const int64_t pairs = ng * (ng - 1) / 2;                       // (row group, strip column block) pairs left of the diagonal
   const int C = (DT / 8) * pairs >= 2 * ctx->num_cu ? 8 : ((DT / 2) * pairs >= 2 * ctx->num_cu ? 2 : 1), Q = DT / C;
-  const int64_t nslots = Q * (ng - 1) + DT;
-  const size_t need = sizeof(double) * (size_t)(nslots + 2 * ng) * (size_t)n;   // Prow[nslots][n], Pcol[2ng][n]
+  const int64_t prow_len = herm_row_base<HR, DT>(ng, Q), pcol_len = herm_col_base<HR>(ng, ng);
+  const size_t need = sizeof(double) * (size_t)(prow_len + pcol_len);
   if (ctx->scratch_bytes < need) {            // stream-ordered users only: drain before the buffer is replaced
     if (ctx->scratch) {
       MXLO_HIP(hipStreamSynchronize(ctx->stream));
@@ -600,37 +667,36 @@ int32_t hermitian_t(mxlo_ctx *ctx, T *res, const T *d, const T *A, int64_t lda, 
     ++ctx->scratch_generation;     // graphs that recorded the old workspace pointer are stale now
   }
   if (ctx->capturing) ctx->scratch_used_in_capture = true;
-  double *Prow = (double *)ctx->scratch, *Pcol = Prow + (size_t)nslots * n;
+  double *Prow = (double *)ctx->scratch, *Pcol = Prow + prow_len;
   const bool aligned = (((uintptr_t)A & 15u) == 0) && (lda % RPL == 0);
-  // full row groups whose strips take the unmasked kernel; the rest of the strips go through the masked one
+  // full row groups (aligned A): interior strips + diagonal tiles in the unmasked launch; everything else is masked
   const int64_t gi = aligned ? ngf : 0;
   const int64_t n_int = gi > 1 ? Q * gi * (gi - 1) / 2 : 0;
+  const int64_t n_dsel = (int64_t)DT * gi;
   const int64_t n_all = !aligned && ng > 1 ? Q * ng * (ng - 1) / 2 : 0;       // mode 0, masked
   const int64_t n_last = aligned && ng > ngf ? Q * (ng - 1) : 0;               // mode 1
-  const int64_t n_diag = (int64_t)DT * ng, total = n_int + n_all + n_last + n_diag;
-  MXLO_REQUIRE(total < (1LL << 31), MXLO_ESHAPE, "opHermitian: n too large");
-#define HERM_MERGED(C_)                                                                                        \
-  hipLaunchKernelGGL((herm_pass_kernel<T, C_>), dim3((unsigned)total), dim3(kBlock), 0, ctx->stream, A, lda, v, \
-                     n, Prow, Pcol, ng, Q, n_int, n_all, n_last);
-  if (C == 8) {
-    if (n_int > 0)
-      hipLaunchKernelGGL((herm_strip_kernel<T, 8, false>), dim3((unsigned)n_int), dim3(kBlock), 0, ctx->stream, A, lda,
-                         v, n, Prow, Pcol, ng, Q, 0);
-    if (n_all > 0)
-      hipLaunchKernelGGL((herm_strip_kernel<T, 8, true>), dim3((unsigned)n_all), dim3(kBlock), 0, ctx->stream, A, lda, v,
-                         n, Prow, Pcol, ng, Q, 0);
-    if (n_last > 0)
-      hipLaunchKernelGGL((herm_strip_kernel<T, 8, true>), dim3((unsigned)n_last), dim3(kBlock), 0, ctx->stream, A, lda,
-                         v, n, Prow, Pcol, ng, Q, 1);
-    hipLaunchKernelGGL((herm_strip_kernel<T, 1, true>), dim3((unsigned)n_diag), dim3(kBlock), 0, ctx->stream, A, lda, v,
-                       n, Prow, Pcol, ng, Q, 2);
-  } else if (C == 2) HERM_MERGED(2) else HERM_MERGED(1)
-#undef HERM_MERGED
-  MXLO_LAUNCH_CHECK();
-  const unsigned blocks = (unsigned)((n + 31) / 32);
+  const int64_t n_diag = (int64_t)DT * (ng - gi);                              // mode 2, row groups gi .. ng-1
+  const int64_t n_light = n_int + n_dsel, n_edge = n_all + n_last + n_diag;
+  MXLO_REQUIRE(n_light < (1LL << 31) && n_edge < (1LL << 31), MXLO_ESHAPE, "opHermitian: n too large");
+#define HERM_LAUNCH(C_)                                                                                          \
+  {                                                                                                              \
+    if (n_light > 0) {                                                                                           \
+      hipLaunchKernelGGL((herm_pass_kernel<T, C_>), dim3((unsigned)n_light), dim3(kBlock), 0, ctx->stream, A, lda, v, \
+                         n, Prow, Pcol, ng, Q, n_int);                                                           \
+      MXLO_LAUNCH_CHECK();                                                                                       \
+    }                                                                                                            \
+    if (n_edge > 0) {                                                                                            \
+      hipLaunchKernelGGL((herm_edge_kernel<T, C_>), dim3((unsigned)n_edge), dim3(kBlock), 0, ctx->stream, A, lda, v,  \
+                         n, Prow, Pcol, ng, Q, n_all, n_last, gi);                                               \
+      MXLO_LAUNCH_CHECK();                                                                                       \
+    }                                                                                                            \
+  }
+  if (C == 8) HERM_LAUNCH(8) else if (C == 2) HERM_LAUNCH(2) else HERM_LAUNCH(1)
+#undef HERM_LAUNCH
+  constexpr int FR = 32;                       // rows per finishing workgroup (8 ... 64 measured alike)
   return dispatch_ab<T>(beta, flags, [&]<typename CA, typename CB, bool B0>() -> int32_t {
-    hipLaunchKernelGGL((herm_finish_kernel<T, CA, CB, B0>), dim3(blocks), dim3(kBlock), 0, ctx->stream, res, d, v,
-                       Prow, Pcol, n, (int)ng, Q, (CA)alpha, (CB)beta);
+    hipLaunchKernelGGL((herm_finish_kernel<T, CA, CB, B0, FR>), dim3((unsigned)((n + FR - 1) / FR)), dim3(kBlock), 0,
+                       ctx->stream, res, d, v, Prow, Pcol, n, (int)ng, Q, (CA)alpha, (CB)beta);
     MXLO_LAUNCH_CHECK();
     return MXLO_OK;
   });

@@ -374,12 +374,15 @@ cgemv_rows_partial_kernel(double *__restrict__ part, const C<R> *__restrict__ M,
     si = fma(ei, xr, si);
   };
   int64_t j = j0;
-  for (; j + 3 < j1; j += 4) {
-    const C<R> e0 = M[i + j * ld], e1 = M[i + (j + 1) * ld], e2 = M[i + (j + 2) * ld], e3 = M[i + (j + 3) * ld];
-    acc(e0, v[j], ar, ai);
-    acc(e1, v[j + 1], br_, bi_);
-    acc(e2, v[j + 2], ar, ai);
-    acc(e3, v[j + 3], br_, bi_);
+  for (; j + 7 < j1; j += 8) {                        // 8 columns (8 x 1 KiB per wave for ComplexF64) in flight
+    C<R> e[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) e[u] = M[i + (j + u) * ld];
+#pragma unroll
+    for (int u = 0; u < 8; u += 2) {
+      acc(e[u], v[j + u], ar, ai);
+      acc(e[u + 1], v[j + u + 1], br_, bi_);
+    }
   }
   for (; j < j1; ++j) acc(M[i + j * ld], v[j], ar, ai);
   double *p = part + ((int64_t)blockIdx.y * m + i) * 2;
@@ -387,20 +390,43 @@ cgemv_rows_partial_kernel(double *__restrict__ part, const C<R> *__restrict__ M,
   p[1] = ai + bi_;
 }
 
-// fixed-order sum of the chunk partials of a row, then RAW store or the α, β epilogue
+// fixed-order sum of the chunk partials of a row, then RAW store or the α, β epilogue. 32 rows per workgroup, 8 lanes per
+// row: lane `sub` adds chunks sub, sub+8, ... four loads at a time; the 8 sub-sums are combined in a fixed order
+// (m/32 workgroups instead of m/256, and 8 x 4 partial loads of a row in flight instead of one).
 template <typename R, typename RA, typename RB, bool BETA0, bool RAW>
 __global__ void __launch_bounds__(kBlock)
 cgemv_rows_finish_kernel(C<R> *__restrict__ res, const double *__restrict__ part, int64_t m, int nchunks, Sc<RA> a,
                          Sc<RB> b) {
-  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (i >= m) return;
+  const int r = threadIdx.x & 31, sub = threadIdx.x >> 5;
+  const int64_t i = (int64_t)blockIdx.x * 32 + r;
+  __shared__ double sre[8][32], sim[8][32];
   double sr = 0.0, si = 0.0;
-  for (int c = 0; c < nchunks; ++c) {
-    const double *p = part + ((int64_t)c * m + i) * 2;
-    sr += p[0];
-    si += p[1];
+  if (i < m) {
+    for (int base = sub; base < nchunks; base += 32) {
+      f64x2 x[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int c = base + 8 * u;
+        x[u] = c < nchunks ? *reinterpret_cast<const f64x2 *>(part + ((int64_t)c * m + i) * 2) : f64x2{0.0, 0.0};
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        sr += x[u][0];
+        si += x[u][1];
+      }
+    }
   }
-  const C<R> t((R)sr, (R)si);
+  sre[sub][r] = sr;
+  sim[sub][r] = si;
+  __syncthreads();
+  if (sub != 0 || i >= m) return;
+  double tr_ = 0.0, ti_ = 0.0;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    tr_ += sre[q][r];
+    ti_ += sim[q][r];
+  }
+  const C<R> t((R)tr_, (R)ti_);
   if constexpr (RAW) {
     res[i] = t;
   } else {
@@ -436,7 +462,7 @@ int32_t cgemv_rows(mxlo_ctx *ctx, C<R> *res, const C<R> *M, int64_t m, int64_t n
   return dispatch_c<R>(s, [&]<typename RA, typename RB, bool B0>() -> int32_t {
     const Sc<RA> a{(RA)s.are, (RA)s.aim, s.a_real};
     const Sc<RB> b{(RB)s.bre, (RB)s.bim, s.b_real};
-    hipLaunchKernelGGL((cgemv_rows_finish_kernel<R, RA, RB, B0, RAW>), dim3((unsigned)row_blocks), dim3(kBlock), 0,
+    hipLaunchKernelGGL((cgemv_rows_finish_kernel<R, RA, RB, B0, RAW>), dim3((unsigned)((m + 31) / 32)), dim3(kBlock), 0,
                        ctx->stream, res, ctx->partials, m, (int)nchunks, a, b);
     MXLO_LAUNCH_CHECK();
     return MXLO_OK;

@@ -106,6 +106,34 @@ def test_hermitian_strip_regimes(lo, dev, dtype, n):
     assert torch.equal(res2, res3)
 
 
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32, torch.complex128, torch.complex64])
+@pytest.mark.parametrize("n", [7, 256, 300, 1024, 2051])
+def test_hermitian_reads_strict_lower_triangle_only(lo, dev, dtype, n):
+    """opHermitian keeps tril(A, -1) (src/linalg.jl:114): whatever the caller's A holds on and above the diagonal — NaN
+    here — must not reach the result, and the result must equal the one of the same A with zeros up there, bit for bit.
+    (The diagonal-block tiles of full row groups load unmasked and SELECT the strict lower triangle.)"""
+    rng = np.random.default_rng(n)
+    cplx = dtype.is_complex
+    npd = {torch.float64: np.float64, torch.float32: np.float32, torch.complex128: np.complex128,
+           torch.complex64: np.complex64}[dtype]
+    rd = lambda *sh: (rng.uniform(-1, 1, sh) + (1j * rng.uniform(-1, 1, sh) if cplx else 0)).astype(npd)
+    A = rd(n, n)
+    clean, dirty = np.tril(A, -1), A.copy()
+    dirty[np.triu_indices(n)] = np.nan
+    d, v = rd(n), rd(n)
+    outs = []
+    for M in (clean, dirty):
+        H = lo.opHermitian(T(d, dev), TM(M, dev))
+        res = torch.empty(n, dtype=dtype, device=dev)
+        lo.mul(res, H, T(v, dev), 1.0, 0.0)
+        outs.append(res)
+    assert torch.isfinite(torch.view_as_real(outs[1]) if cplx else outs[1]).all()
+    assert torch.equal(outs[0], outs[1])
+    want = d.astype(np.complex128) * v + clean.astype(np.complex128) @ v + clean.astype(np.complex128).conj().T @ v
+    got = outs[0].cpu().numpy().astype(np.complex128)
+    assert np.linalg.norm(got - want) <= (1e-12 if npd in (np.float64, np.complex128) else 3e-5) * np.linalg.norm(want)
+
+
 @pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
 @pytest.mark.parametrize("shapes", [((3, 5), (4, 2)), ((1, 1), (7, 3)), ((16, 16), (16, 16)), ((70, 33), (65, 129)),
                                     ((64, 64), (128, 64))])

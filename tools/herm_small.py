@@ -14,9 +14,11 @@ from linearoperators_jl_amd.device import Timer, get_ctx
 dev = torch.device("cuda", 0)
 ctx = get_ctx(dev)
 tm = Timer(ctx)
+dt = torch.float32 if "f32" in sys.argv[1:] else torch.float64
+es = 4 if dt == torch.float32 else 8
 for nn in (1024, 2048, 4096, 8192, 16384):
-    M = torch.rand(nn, nn, dtype=torch.float64, device=dev).t()
-    d, x, y = (torch.rand(nn, dtype=torch.float64, device=dev) for _ in range(3))
+    M = torch.rand(nn, nn, dtype=dt, device=dev).t()
+    d, x, y = (torch.rand(nn, dtype=dt, device=dev) for _ in range(3))
     H = lo.opHermitian(d, M)
     for _ in range(5):
         lo.mul(y, H, x, 1.0, 0.0)
@@ -25,4 +27,4 @@ for nn in (1024, 2048, 4096, 8192, 16384):
         lo.mul(y, H, x, 1.0, 0.0)
     tm.stop()
     ms = tm.elapsed_ms() / 50
-    print(f"opHermitian n={nn:6d}: {ms*1e3:8.1f} us  {4.0*nn*nn/ms/1e6:7.0f} GB/s  {4.0*nn*nn/ms/1e6/8000:5.3f}", flush=True)
+    print(f"opHermitian {str(dt)[6:]} n={nn:6d}: {ms*1e3:8.1f} us  {es/2*nn*nn/ms/1e6:7.0f} GB/s  {es/2*nn*nn/ms/1e6/8000:5.3f}", flush=True)

@@ -389,6 +389,14 @@ cases.append(dict(
     expect_mul5=cfl([cadd(cmul(alk, a), cmul(bek, r)) for a, r in zip(cmatvec(Kc, xkc), r0kc)]), K=[cfl(r) for r in Kc],
     tol="1e-12 * norm(K, 1) as test_kron.jl:35"))
 
+# ---------------------------------------------------------------- dense LinearOperator(A), LITERAL numbers (test_linop.jl:587-595)
+# "Issue #80 / Test mul!": A = [1.0 1.0; 1.0 0.0]; op = LinearOperator(A); mul!(y, op, ones(2)); @test y == [2.0; 1.0]
+# (a symmetric A: transpose(op) and op' give the same numbers; the 5-arg form follows src/constructors.jl:19-29).
+cases.append(dict(
+    name="dense_issue80_literal", ref="test/test_linop.jl:587-595 (literal A, x and expected y)", kind="dense",
+    A=[[1.0, 1.0], [1.0, 0.0]], x=[1.0, 1.0], expect_apply=[2.0, 1.0], alpha=2.0, beta=-1.0, res0=[0.5, -3.0],
+    expect_mul5=[2.0 * 2.0 - 0.5, 2.0 * 1.0 + 3.0], tol="exact"))
+
 out = dict(
     about="Known-answer cases held by LinearOperators.jl v2.14.2's own tests for the mul! hot path; "
           "generated by tests/golden/make_kat.py (exact rational arithmetic, no reference code executed).",

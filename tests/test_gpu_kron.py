@@ -39,6 +39,16 @@ def test_kat_kron_and_hermitian(lo, dev, kat):
         lo.mul(res, Kop, T(np.array(c["x"]), dev), c["alpha"], c["beta"])
         assert np.linalg.norm(res.cpu().numpy() - np.array(c["expect_mul5"]), 1) <= 1e-12 * nK
         assert np.linalg.norm(lo.Matrix(Kop).cpu().numpy() - K, 1) <= 1e-15 * nK * K.shape[1]
+    (c,) = [c for c in kat if c["kind"] == "dense"]                   # test_linop.jl:587-595, the reference's own numbers
+    for Md in (colmajor(np.array(c["A"]), dev), T(np.array(c["A"]), dev)):
+        op = lo.LinearOperatorFromMatrix(Md)
+        for o in (op, op.T, op.H):                                    # A is symmetric
+            y = torch.zeros(2, dtype=torch.float64, device=dev)
+            lo.mul(y, o, T(np.array(c["x"]), dev))
+            assert np.array_equal(y.cpu().numpy(), np.array(c["expect_apply"]))
+            res = T(np.array(c["res0"]), dev)
+            lo.mul(res, o, T(np.array(c["x"]), dev), c["alpha"], c["beta"])
+            assert np.array_equal(res.cpu().numpy(), np.array(c["expect_mul5"]))
     (c,) = [c for c in kat if c["kind"] == "hermitian"]
     Hm = lo.opHermitian(T(np.array(c["d"]), dev), colmajor(np.array(c["A"]), dev))
     for op in (Hm, Hm.T, Hm.H):                                       # C is real symmetric: all three agree

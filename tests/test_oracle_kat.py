@@ -380,6 +380,18 @@ def test_kat_hermitian(kat):
     assert np.linalg.norm(got - np.array(c["expect_mul5"])) <= 1e-13 * np.linalg.norm(c["expect_mul5"])
 
 
+def test_kat_dense_issue80_literal(kat):
+    """test/test_linop.jl:587-595 — the reference holds the numbers: A = [1 1; 1 0], mul!(y, LinearOperator(A), ones(2))
+    == [2, 1]; the oracle's dense restatement (src/constructors.jl:19-29) must reproduce them exactly, in both modes."""
+    (c,) = _by_kind(kat, "dense")
+    A, x = np.array(c["A"]), np.array(c["x"])
+    for trans in (False, True):
+        got = oracle.gemv(np.full(2, np.nan), A, x, 1.0, 0.0, trans=trans)
+        assert np.array_equal(got, np.array(c["expect_apply"]))
+        got = oracle.gemv(np.array(c["res0"]), A, x, c["alpha"], c["beta"], trans=trans)
+        assert np.array_equal(got, np.array(c["expect_mul5"]))
+
+
 def test_kat_complex_hermitian_and_dense(kat):
     """test/test_linop.jl:360-370 on ComplexF64: H = opHermitian(real.(diag), tril(A,-1)); H*v, transpose(H)*v (the conj
     sandwich of src/adjtrans.jl:193-204 around the hermitian prod!), H'*v and a 5-arg mul! with complex α, β; the same

@@ -18,8 +18,8 @@ import torch
 
 from . import _lib
 from .device import Storage, check_vec, dtype_code, get_ctx, ptr, storage_of
-from .operators import (AbstractLinearOperator, LinearOperator, LinearOperatorException, _c4, adjoint, compose, conj_scalar,
-                        issymmetric, ishermitian, mul, scalar_flags, state_version, storage_type, to_dense, transpose)
+from .operators import (AbstractLinearOperator, LinearOperator, LinearOperatorException, _c4, adjoint, columnwise, compose,
+                        conj_scalar, issymmetric, ishermitian, mul, scalar_flags, state_version, storage_type, to_dense, transpose)
 
 
 def _default_device() -> torch.device:
@@ -52,13 +52,13 @@ def opEye(T=torch.float64, nrow: Optional[int] = None, ncol: Optional[int] = Non
     n = nrow
     S = _S(T, S)
     if ncol is None or nrow == ncol:
-        prod = lambda res, v, a, b: mulOpEye(res, v, a, b, n)
+        prod = columnwise(lambda res, v, a, b: mulOpEye(res, v, a, b, n))
         op = LinearOperator(T, n, n, True, True, prod, prod, prod, S=S)
         op._leaf = ("eye", n, n)
         op._deps = ()
         return op
     n_min = min(nrow, ncol)
-    prod = lambda res, v, a, b: mulOpEye(res, v, a, b, n_min)
+    prod = columnwise(lambda res, v, a, b: mulOpEye(res, v, a, b, n_min))
     op = LinearOperator(T, nrow, ncol, False, False, prod, prod, prod, S=S)
     op._leaf = ("eye", nrow, ncol)
     op._deps = ()
@@ -98,7 +98,7 @@ def opZeros(T=torch.float64, nrow: Optional[int] = None, ncol: Optional[int] = N
     """opZeros(T, nrow, ncol; S) — src/special-operators.jl:110-123."""
     if isinstance(T, int):
         T, nrow, ncol = torch.float64, T, nrow
-    prod = lambda res, v, a, b: mulOpZeros(res, v, a, b)
+    prod = columnwise(lambda res, v, a, b: mulOpZeros(res, v, a, b))
     op = LinearOperator(T, nrow, ncol, nrow == ncol, nrow == ncol, prod, prod, prod, S=_S(T, S))
     op._leaf = ("zeros", nrow, ncol)
     op._deps = ()
@@ -137,9 +137,9 @@ def opDiagonal(*args):
         d = check_vec(args[0], "d")
         dtype_code(d.dtype, True)
         n = d.numel()
-        prod = lambda res, v, a, b: mulSquareOpDiagonal(res, d, v, a, b)
+        prod = columnwise(lambda res, v, a, b: mulSquareOpDiagonal(res, d, v, a, b))
         if d.dtype.is_complex:
-            ctprod = lambda res, w, a, b: mulSquareOpDiagonal(res, d, w, a, b, conj_d=True)      # conj.(d) (:140)
+            ctprod = columnwise(lambda res, w, a, b: mulSquareOpDiagonal(res, d, w, a, b, conj_d=True))   # conj.(d) (:140)
             op = LinearOperator(d.dtype, n, n, True, False, prod, prod, ctprod, S=storage_of(d))  # isreal(d): a
         else:                                                                                     # type property
             op = LinearOperator(d.dtype, n, n, True, True, prod, prod, prod, S=storage_of(d))
@@ -154,8 +154,8 @@ def opDiagonal(*args):
     n_min = min(nrow, ncol)
     if d.numel() < n_min:
         raise LinearOperatorException("shape mismatch")
-    prod = lambda res, v, a, b: mulOpDiagonal(res, d, v, a, b, n_min)
-    ctprod = (lambda res, w, a, b: mulOpDiagonal(res, d, w, a, b, n_min, conj_d=True)) if d.dtype.is_complex else prod
+    prod = columnwise(lambda res, v, a, b: mulOpDiagonal(res, d, v, a, b, n_min))
+    ctprod = columnwise(lambda res, w, a, b: mulOpDiagonal(res, d, w, a, b, n_min, conj_d=True)) if d.dtype.is_complex else prod
     op = LinearOperator(d.dtype, nrow, ncol, False, False, prod, prod, ctprod, S=storage_of(d))
     op._deps = (d,)
     return op
@@ -381,9 +381,10 @@ def LinearOperatorFromMatrix(M: torch.Tensor, symmetric: bool = False, hermitian
             _lib.call("mxlo_gemv", ctx.handle, dtype_code(St.dtype), ptr(res), ptr(St), sm, sn, ld, ptr(v), float(a),
                       float(b), mode, scalar_flags(res.dtype, a, b))
 
-    prod = lambda res, v, a, b: gemv(res, v, a, b, fwd)
-    tprod = lambda res, u, a, b: gemv(res, u, a, b, bwd)
-    ctprod = lambda res, w, a, b: gemv(res, w, a, b, cbwd)
+    # on matrices the reference closure `mul!(res, M, m, α, β)` is a GEMM: one GEMV per column here (same numbers)
+    prod = columnwise(lambda res, v, a, b: gemv(res, v, a, b, fwd))
+    tprod = columnwise(lambda res, u, a, b: gemv(res, u, a, b, bwd))
+    ctprod = columnwise(lambda res, w, a, b: gemv(res, w, a, b, cbwd))
     op = LinearOperator(St.dtype, nrow, ncol, symmetric, hermitian, prod, tprod, ctprod,
                         S=S if S is not None else Storage(St.dtype, St.device))
     if not tr and not cplx:

@@ -448,6 +448,8 @@ def mul(res: torch.Tensor, op, v: torch.Tensor, alpha=None, beta=None):
         alpha, beta = one(v.dtype), zero(v.dtype)
     elif alpha is None or beta is None:
         raise TypeError("mul! takes either (res, op, v) or (res, op, v, alpha, beta)")
+    if v.dim() == 2 or res.dim() == 2:
+        return _mul_matrix(res, op, v, alpha, beta)
     if v.dtype.is_complex and op.eltype.is_floating_point:
         return _mul_real_op_complex_vec(res, op, v, alpha, beta)
     if op.eltype.is_complex and v.dtype.is_floating_point:
@@ -474,6 +476,57 @@ def mul(res: torch.Tensor, op, v: torch.Tensor, alpha=None, beta=None):
             allocate_vectors_args3(op)
         prod3(res, op.prod, v, alpha, beta, op.Mv)
     return touched(res)
+
+
+def columnwise(fn):
+    """Mark a device closure whose REFERENCE closure acts column by column when it is handed matrices (dense
+    LinearOperator(M): `mul!(res, M, m, α, β)` is a GEMM; opDiagonal / opEye / opZeros: broadcasts). The device closures are
+    vector kernels, so `_mul_matrix` applies such a closure to the columns one by one."""
+    fn._columnwise = True
+    return fn
+
+
+def _apply_closure_to_matrix(fn, res, m, alpha, beta):
+    if fn is None:
+        raise LinearOperatorException("Not implemented")                      # src/adjtrans.jl:155,223
+    if not getattr(fn, "_columnwise", False):
+        if (getattr(fn, "__module__", "") or "").startswith(__name__.rsplit(".", 1)[0]):
+            raise LinearOperatorException("mul! on matrices: this operator's closure is defined on vectors only "
+                                          "(dense LinearOperator(M), opDiagonal, opEye and opZeros take matrices)")
+        fn(res, m, alpha, beta)                                               # a caller's closure gets the matrices as they are
+        return touched(res)
+    if res.dim() != 2 or m.dim() != 2 or res.shape[1] != m.shape[1]:
+        raise LinearOperatorException("shape mismatch")
+    colmajor = lambda X: X if X.t().is_contiguous() else X.t().contiguous().t()
+    mc, rc = colmajor(m), colmajor(res)                                       # Julia layout: column j is contiguous
+    for j in range(m.shape[1]):
+        fn(rc[:, j], mc[:, j], alpha, beta)
+    if rc is not res:
+        res.copy_(rc)
+    return touched(res)
+
+
+def _mul_matrix(res, op, m, alpha, beta):
+    """`mul!(res::AbstractMatrix, op, m::AbstractMatrix, α, β)` — src/operations.jl:34-36: the closure is handed the
+    matrices (no shape check, no counter); wrappers: src/adjtrans.jl:139-156 (adjoint: hermitian parent, else ctprod!, else
+    "Not implemented"), :207-224 (transpose: symmetric parent, else tprod!), :251-261 (conjugate: conj.(m), then conj!)."""
+    if isinstance(op, (AdjointLinearOperator, TransposeLinearOperator)):
+        p = op.parent
+        if not (m.dim() == 2 and res.dim() == 2 and m.shape[0] == p.size(1) and res.shape[0] == p.size(2)
+                and m.shape[1] == res.shape[1]):
+            raise LinearOperatorException("shape mismatch")
+        adj = isinstance(op, AdjointLinearOperator)
+        if ishermitian(p) if adj else issymmetric(p):
+            return _mul_matrix(res, p, m, alpha, beta)
+        return _apply_closure_to_matrix(p.ctprod if adj else p.tprod, res, m, alpha, beta)
+    if isinstance(op, ConjugateLinearOperator):
+        _mul_matrix(res, op.parent, torch.conj_physical(m) if m.dtype.is_complex else m, alpha, beta)
+        if res.dtype.is_complex:
+            res.copy_(torch.conj_physical(res))
+        return touched(res)
+    if not hasattr(op, "prod"):
+        raise LinearOperatorException("mul! on matrices: not defined for this operator type")
+    return _apply_closure_to_matrix(op.prod, res, m, alpha, beta)
 
 
 def _complex_of_real(v, ctype):

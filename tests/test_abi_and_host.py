@@ -170,3 +170,37 @@ def test_universal_identity_operator(lo):
     assert lo.transpose(op) is op and lo.adjoint(op) is op and lo.conj(op) is op and op.T is op and op.H is op
     assert (lo.transpose(op) * v) is v and (lo.conj(op) * v) is v
     assert repr(op) == "Identity operator"
+
+
+def test_mul_on_matrices_routing_without_device(lo):
+    """`mul!(res::AbstractMatrix, op, m::AbstractMatrix, α, β)` — src/operations.jl:34-36 hands the matrices to the closure
+    as they are (no shape check, no counter); src/adjtrans.jl:139-156, 207-224: the wrappers check shapes, go to the parent
+    when it is hermitian / symmetric, else to ctprod! / tprod!, else "Not implemented"; :251-261 conj.(m) ... conj!(res).
+    Host logic only: closures written in Python on CPU tensors."""
+    S = lo.Storage(torch.float64, torch.device("cpu"))
+    M = torch.tensor([[1.0, 2.0, 0.5], [-1.0, 0.0, 3.0]])                                  # 2 x 3
+
+    def prod(res, v, a, b):
+        res.copy_(a * (M @ v) + (b * res if b != 0 else 0))
+
+    def tprod(res, u, a, b):
+        res.copy_(a * (M.t() @ u) + (b * res if b != 0 else 0))
+
+    op = lo.LinearOperator(torch.float64, 2, 3, False, False, prod, tprod, None, S=S)
+    mv, mu = torch.tensor([[1.0, -2.0], [-1.0, 2.0], [1.0, -2.0]]), torch.tensor([[1.0, -2.0], [-1.0, 2.0]])
+    res = torch.empty(2, 2)
+    lo.mul(res, op, mv)
+    assert torch.equal(res, M @ mv) and lo.nprod(op) == 0                                  # no counter on this path
+    rt = torch.ones(3, 2)
+    lo.mul(rt, op.T, mu, 2.0, -1.0)
+    assert torch.equal(rt, 2.0 * (M.t() @ mu) - 1.0)
+    with pytest.raises(lo.LinearOperatorException, match="Not implemented"):
+        lo.mul(torch.empty(3, 2), op.H, mu)                                               # no ctprod!, not hermitian
+    with pytest.raises(lo.LinearOperatorException, match="shape mismatch"):
+        lo.mul(torch.empty(3, 3), op.T, mu)
+    sym = lo.LinearOperator(torch.float64, 2, 2, True, True, lambda r, v, a, b: r.copy_(a * v), None, None, S=S)
+    r2 = torch.empty(2, 2)
+    lo.mul(r2, sym.H, mu, 3.0, 0.0)                                                        # hermitian parent: mul!(res, p, m, α, β)
+    assert torch.equal(r2, 3.0 * mu)
+    lo.mul(r2, lo.conj(sym), mu, 1.0, 0.0)                                                 # real data: conj is the identity
+    assert torch.equal(r2, mu)

@@ -375,6 +375,61 @@ def test_complex_hermitian_strip_regimes(lo, dev, dtype, tol, n, aligned):
         assert np.array_equal(col, (Lc[:, j] + Lc[j, :].conj()).astype(dt))
 
 
+@pytest.mark.parametrize("dtype,tol", [(torch.complex128, 1e-12), (torch.float64, 1e-12), (torch.complex64, 3e-5)])
+def test_mul_on_matrices_dense_and_diagonal(lo, dev, dtype, tol):
+    """test/test_linop.jl:64-76 ("LinearOperator(Matrix)"): mv = hcat(v, -2v), mu = hcat(u, -2u);
+    mul!(res_mat, op, mv), mul!(res_trans, transpose(op), mu), mul!(res_adj, op', mu) against A*mv, transpose(A)*mu, A'*mu
+    (src/operations.jl:34-36, src/adjtrans.jl:139-156, 207-224, 251-261) — plus the 5-arg form, column-major and row-major
+    matrix operands, and the other closures that are columnwise on matrices in the reference (opDiagonal, opEye, opZeros)."""
+    cplx = dtype.is_complex
+    npd = NPC[dtype] if cplx else np.float64
+    rng = np.random.default_rng(5)
+    nrow, ncol = 10, 6
+    rd = lambda *sh: (rng.uniform(-1, 1, sh) + (1j * rng.uniform(-1, 1, sh) if cplx else 0)).astype(npd)
+    A = rd(nrow, ncol)
+    v = np.array([-(-1.0) ** i for i in range(1, ncol + 1)], dtype=npd)
+    u = np.array([-(-1.0) ** i for i in range(1, nrow + 1)], dtype=npd)
+    if cplx:
+        v, u = v + 0.5j * v[::-1], u - 0.25j * u
+    mv, mu = np.stack([v, -2 * v], axis=1), np.stack([u, -2 * u], axis=1)
+    colmajor = lambda X: T(X.T.copy(), dev).t()
+    for Ad in (colmajor(A), T(A, dev)):
+        op = lo.LinearOperatorFromMatrix(Ad)
+        for mk in (colmajor, lambda X: T(X, dev)):
+            res = torch.empty(nrow, 2, dtype=dtype, device=dev)
+            lo.mul(res, op, mk(mv))
+            assert rel(res.cpu().numpy(), A @ mv) <= tol
+            rt = mk(np.zeros((ncol, 2), npd))
+            lo.mul(rt, lo.transpose(op), mk(mu))
+            assert rel(rt.cpu().numpy(), A.T @ mu) <= tol
+            ra = mk(np.zeros((ncol, 2), npd))
+            lo.mul(ra, lo.adjoint(op), mk(mu))
+            assert rel(ra.cpu().numpy(), A.conj().T @ mu) <= tol
+            rc = mk(np.zeros((nrow, 2), npd))
+            lo.mul(rc, lo.conj(op), mk(mv))
+            assert rel(rc.cpu().numpy(), A.conj() @ mv) <= tol
+            r0 = rd(nrow, 2)
+            r5 = mk(r0.copy())
+            lo.mul(r5, op, mk(mv), 2.0, -0.5)
+            assert rel(r5.cpu().numpy(), 2.0 * (A @ mv) - 0.5 * r0) <= tol
+        with pytest.raises(lo.LinearOperatorException, match="shape mismatch"):
+            lo.mul(torch.empty(ncol, 3, dtype=dtype, device=dev), lo.transpose(op), colmajor(mu))
+    d = rd(ncol)
+    D = lo.opDiagonal(T(d, dev))
+    r0 = rd(ncol, 2)
+    res = colmajor(r0.copy())
+    lo.mul(res, D, colmajor(mv), 2.0, 3.0)
+    assert rel(res.cpu().numpy(), 2.0 * d[:, None] * mv + 3.0 * r0) <= tol
+    lo.mul(res, lo.adjoint(D), colmajor(mv), 1.0, 0.0)
+    assert rel(res.cpu().numpy(), d.conj()[:, None] * mv) <= tol
+    E = lo.opEye(dtype, ncol, S=lo.Storage(dtype, dev))
+    lo.mul(res, E, colmajor(mv), -1.0, 0.0)
+    assert np.array_equal(res.cpu().numpy(), -mv)
+    H = lo.opHouseholder(T(rd(ncol), dev))                     # dot(h, m) of the reference closure is not defined on matrices
+    with pytest.raises(lo.LinearOperatorException, match="vectors only"):
+        lo.mul(res, H, colmajor(mv))
+
+
 def test_complex_dense_in_operator_trees_and_contract(lo, dev):
     """complex dense leaves compose with the complex elementwise leaves (sum, product, cat) against dense NumPy, and a
     warmed apply issues launches only."""

@@ -301,6 +301,36 @@ function LinearOperator(M::MXMatrix{T}; symmetric = false, hermitian = false) wh
   LinearOperator{T, MXVector{T}}(m, n, symmetric, hermitian, gemv(0), gemv(1), gemv(2))
 end
 
+# ---- mul! on matrices (src/operations.jl:34-36; wrappers src/adjtrans.jl:139-156, 207-224) ------------------------------
+# The reference hands `res` and `m` to the closure as they are (`LinearOperator(M)`: a GEMM; the elementwise closures
+# broadcast over the columns). The device closures are vector kernels, so a device matrix is applied column by column —
+# the columns of an MXMatrix are contiguous views, nothing is copied (test/test_linop.jl:64-76: hcat(v, -2v)).
+column(A::MXMatrix{T}, j::Integer) where {T} = view(A.data, ((j - 1) * A.m + 1):(j * A.m))
+function apply_columns(f, res::MXMatrix, m::MXMatrix, α, β)
+  f === nothing && error("Not implemented")
+  size(res, 2) == size(m, 2) || throw(LinearOperatorException("shape mismatch"))
+  for j = 1:size(m, 2)
+    f(column(res, j), column(m, j), α, β)
+  end
+  res
+end
+LinearAlgebra.mul!(res::MXMatrix, op::LinearOperator{T, MXVector{T}}, m::MXMatrix, α, β) where {T} =
+  apply_columns(op.prod!, res, m, α, β)
+function LinearAlgebra.mul!(res::MXMatrix, op::LinearOperators.AdjointLinearOperator{T, <:LinearOperator{T, MXVector{T}}},
+                            m::MXMatrix, α, β) where {T}
+  p = op.parent
+  (size(m, 1) == size(p, 1) && size(res, 1) == size(p, 2) && size(m, 2) == size(res, 2)) ||
+    throw(LinearOperatorException("shape mismatch"))
+  LinearOperators.ishermitian(p) ? mul!(res, p, m, α, β) : apply_columns(p.ctprod!, res, m, α, β)
+end
+function LinearAlgebra.mul!(res::MXMatrix, op::LinearOperators.TransposeLinearOperator{T, <:LinearOperator{T, MXVector{T}}},
+                            m::MXMatrix, α, β) where {T}
+  p = op.parent
+  (size(m, 1) == size(p, 1) && size(res, 1) == size(p, 2) && size(m, 2) == size(res, 2)) ||
+    throw(LinearOperatorException("shape mismatch"))
+  LinearOperators.issymmetric(p) ? mul!(res, p, m, α, β) : apply_columns(p.tprod!, res, m, α, β)
+end
+
 # ---- a7 mulRestrict! / multRestrict! (src/special-operators.jl:167-174) --------------------------------------------
 # α, β are ignored by the reference and are not ABI parameters. `opRestriction(I, ncol; S = MXVector{T})` and
 # `opExtension` are the reference's own constructors; their closures land here. Ranges need no device memory; an

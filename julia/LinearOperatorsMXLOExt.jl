@@ -259,8 +259,11 @@ function opHouseholder(h::MXVector{T}) where {T}
 end
 # `op + x` / `x + op` build `x * opOnes(op.nrow, op.ncol)` with T = Float64, S = Vector{Float64}
 # (src/operations.jl:222-223): for device operators the ones-operator must carry the device storage type.
-Base.:+(op::LinearOperator{T, MXVector{T}}, x::Number) where {T} = op + x * opOnes(T, op.nrow, op.ncol; S = MXVector{T})
-Base.:+(x::Number, op::LinearOperator{T, MXVector{T}}) where {T} = x * opOnes(T, op.nrow, op.ncol; S = MXVector{T}) + op
+# The ones-operator takes the REAL component type of T (mulOpOnes! is a real kernel; next to a complex operator the sum
+# promotes as Real + Complex does and reaches the real operator through the two planes of the vector).
+ones_like(op::LinearOperator{T, MXVector{T}}) where {T} = opOnes(real(T), op.nrow, op.ncol; S = MXVector{real(T)})
+Base.:+(op::LinearOperator{T, MXVector{T}}, x::Number) where {T} = op + x * ones_like(op)
+Base.:+(x::Number, op::LinearOperator{T, MXVector{T}}) where {T} = x * ones_like(op) + op
 
 # ---- a6 opHermitian (src/linalg.jl:97-127): the ORIGINAL matrix is passed; only tril(A,-1) is read ------------
 function opHermitian(d::MXVector{T}, A::MXMatrix{T}) where {T <: RealT}

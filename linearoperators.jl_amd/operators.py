@@ -213,14 +213,12 @@ class AbstractLinearOperator:
             from .leaves import LinearOperatorFromMatrix
             return add(self, LinearOperatorFromMatrix(other))
         if _is_number(other):                                 # src/operations.jl:222
-            from .leaves import opOnes
-            return add(self, scale_op(opOnes(self.eltype, self.nrow, self.ncol, S=storage_type(self)), other))
+            return add(self, scale_op(_ones_like(self), other))
         return NotImplemented
 
     def __radd__(self, other):
         if _is_number(other):                                 # src/operations.jl:223
-            from .leaves import opOnes
-            return add(scale_op(opOnes(self.eltype, self.nrow, self.ncol, S=storage_type(self)), other), self)
+            return add(scale_op(_ones_like(self), other), self)
         if isinstance(other, torch.Tensor) and other.dim() == 2:
             from .leaves import LinearOperatorFromMatrix
             return add(LinearOperatorFromMatrix(other), self)
@@ -527,6 +525,16 @@ def _mul_matrix(res, op, m, alpha, beta):
     if not hasattr(op, "prod"):
         raise LinearOperatorException("mul! on matrices: not defined for this operator type")
     return _apply_closure_to_matrix(op.prod, res, m, alpha, beta)
+
+
+def _ones_like(op):
+    """`opOnes(op.nrow, op.ncol)` of `op ± x` (src/operations.jl:222-223) on the operator's device. The reference's opOnes is
+    a Float64 operator whatever eltype(op) is; here it takes the REAL component type of eltype(op) (Float32 data stays
+    Float32; next to a complex operator the sum promotes as Real + Complex does, test/test_linop.jl:164-176)."""
+    from .leaves import opOnes
+    st = storage_type(op)
+    rt = {torch.complex128: torch.float64, torch.complex64: torch.float32}.get(op.eltype, op.eltype)
+    return opOnes(rt, op.nrow, op.ncol, S=Storage(rt, st.device))
 
 
 def _complex_of_real(v, ctype):

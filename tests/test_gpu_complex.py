@@ -430,6 +430,88 @@ def test_mul_on_matrices_dense_and_diagonal(lo, dev, dtype, tol):
         lo.mul(res, H, colmajor(mv))
 
 
+def test_reference_basic_operations_testset(lo, dev):
+    """test/test_linop.jl:7-226 "Basic operations" on A1 = a ComplexF64 10 x 6 matrix, statement by statement: the four
+    ways of writing the same operator (LinearOperator(A1), LinearOperator(A1')', transpose(LinearOperator(transpose(A1))),
+    conj(LinearOperator(conj(A1)))) — data type, size, errors, Matrix(op), unary +; LinearOperator(Matrix) products;
+    op ± op, op ± matrix, op ± scalar, op × op over {A, transpose(A), A', conj(A)}², matrix × op, op × matrix,
+    scalar × op, op × scalar."""
+    nrow, ncol = 10, 6
+    rng = np.random.default_rng(2024)
+    rtol = float(np.sqrt(np.finfo(np.float64).eps))
+    cm = lambda m, n: (rng.uniform(-1, 1, (m, n)) + 1j * rng.uniform(-1, 1, (m, n)))
+    dm = lambda X: T(np.ascontiguousarray(X.T), dev).t()                       # column-major device matrix
+    M = lambda op: lo.Matrix(op).cpu().numpy()
+    sv = lambda n: np.array([-(-1.0) ** i for i in range(1, n + 1)], dtype=np.complex128)
+    A1 = cm(nrow, ncol)
+    forms = (lo.LinearOperatorFromMatrix(dm(A1)),
+             lo.adjoint(lo.LinearOperatorFromMatrix(dm(A1.conj().T))),
+             lo.transpose(lo.LinearOperatorFromMatrix(dm(A1.T))),
+             lo.conj(lo.LinearOperatorFromMatrix(dm(A1.conj()))))
+    for op in forms:
+        assert lo.eltype(op) == torch.complex128
+        assert lo.size(op) == (nrow, ncol) and lo.size(op, 1) == nrow and lo.size(op, 2) == ncol
+        with pytest.raises(lo.LinearOperatorException):
+            lo.size(op, 3)
+        with pytest.raises(lo.LinearOperatorException):
+            op * torch.ones(ncol + 1, dtype=torch.complex128, device=dev)
+        assert lo.issymmetric(op) is False and lo.ishermitian(op) is False
+        assert np.linalg.norm(A1 - M(op)) <= 1e-15 * np.linalg.norm(A1) * 10
+        assert np.linalg.norm(A1 - M(+op)) <= 1e-15 * np.linalg.norm(A1) * 10
+    # "LinearOperator(Matrix)"
+    op = forms[0]
+    assert np.linalg.norm(A1.T - M(lo.transpose(op))) <= rtol * np.linalg.norm(A1)
+    assert np.linalg.norm(A1.conj().T - M(lo.adjoint(op))) <= rtol * np.linalg.norm(A1)
+    v, u = sv(ncol), sv(nrow)
+    assert np.linalg.norm(A1 @ v - (op * T(v, dev)).cpu().numpy()) <= rtol * np.linalg.norm(v)
+    assert np.linalg.norm(A1.T @ u - (lo.transpose(op) * T(u, dev)).cpu().numpy()) <= rtol * np.linalg.norm(u)
+    assert np.linalg.norm(A1.conj().T @ u - (lo.adjoint(op) * T(u, dev)).cpu().numpy()) <= rtol * np.linalg.norm(u)
+    # "Basic arithmetic operations": op ± op, matrix ± op, op ± matrix
+    B1 = cm(nrow, ncol)
+    for sgn, name in ((1, "+"), (-1, "-")):
+        C = A1 + sgn * B1
+        LA, LB = lo.LinearOperatorFromMatrix(dm(A1)), lo.LinearOperatorFromMatrix(dm(B1))
+        variants = [LA + LB if sgn > 0 else LA - LB, (LA + dm(B1)) if sgn > 0 else (LA - dm(B1))]
+        if sgn > 0:
+            variants.append(lo.LinearOperatorFromMatrix(dm(A1)) + LB)
+        for opC in variants:
+            assert np.linalg.norm((opC * T(v, dev)).cpu().numpy() - C @ v) <= rtol * np.linalg.norm(v), name
+            assert np.linalg.norm((lo.transpose(opC) * T(u, dev)).cpu().numpy() - C.T @ u) <= rtol * np.linalg.norm(u)
+            assert np.linalg.norm((lo.adjoint(opC) * T(u, dev)).cpu().numpy() - C.conj().T @ u) <= rtol * np.linalg.norm(u)
+    # "Operator ± scalar" (src/operations.jl:222-234: x * opOnes(nrow, ncol))
+    x = 2.12345
+    for opC, want in ((forms[0] + x, A1 + x), (x + forms[0], A1 + x), (forms[0] - x, A1 - x), (x - forms[0], x - A1)):
+        assert np.linalg.norm(want - M(opC)) <= rtol * np.linalg.norm(want)
+    # "Operator × Operator"
+    A4, B4 = cm(ncol, ncol), cm(ncol, ncol)
+    four = lambda X: (X, X.T, X.conj().T, X.conj())
+    v6 = sv(ncol)
+    for Ai in four(A4):
+        for Bi in four(B4):
+            C = Ai @ Bi
+            opC = lo.LinearOperatorFromMatrix(dm(Ai)) * lo.LinearOperatorFromMatrix(dm(Bi))
+            assert np.linalg.norm((opC * T(v6, dev)).cpu().numpy() - C @ v6) <= rtol * np.linalg.norm(v6)
+            assert np.linalg.norm((lo.transpose(opC) * T(v6, dev)).cpu().numpy() - C.T @ v6) <= rtol * np.linalg.norm(v6)
+            assert np.linalg.norm((lo.adjoint(opC) * T(v6, dev)).cpu().numpy() - C.conj().T @ v6) <= rtol * np.linalg.norm(v6)
+    B2 = cm(ncol, ncol + 1)
+    C = A1 @ B2
+    opC = lo.LinearOperatorFromMatrix(dm(A1)) * lo.LinearOperatorFromMatrix(dm(B2))
+    v7 = sv(ncol + 1)
+    assert np.linalg.norm((opC * T(v7, dev)).cpu().numpy() - C @ v7) <= rtol * np.linalg.norm(v7)
+    assert np.linalg.norm((lo.transpose(opC) * T(u, dev)).cpu().numpy() - C.T @ u) <= rtol * np.linalg.norm(u)
+    assert np.linalg.norm((lo.adjoint(opC) * T(u, dev)).cpu().numpy() - C.conj().T @ u) <= rtol * np.linalg.norm(u)
+    with pytest.raises(lo.LinearOperatorException):
+        lo.LinearOperatorFromMatrix(dm(A1)) + lo.LinearOperatorFromMatrix(dm(B2))
+    with pytest.raises(lo.LinearOperatorException):
+        lo.LinearOperatorFromMatrix(dm(B2)) * lo.LinearOperatorFromMatrix(dm(A1))
+    # "Matrix × operator", "Operator × matrix", "Scalar × operator", "Operator × scalar"
+    assert np.linalg.norm(C - M(lo.LinearOperatorFromMatrix(dm(A1)) * dm(B2))) <= rtol * np.linalg.norm(C)
+    assert np.linalg.norm(C - M(lo.compose(lo.LinearOperatorFromMatrix(dm(A1)), lo.LinearOperatorFromMatrix(dm(B2))))) <= rtol * np.linalg.norm(C)
+    AA1 = x * A1
+    assert np.linalg.norm(AA1 - M(x * lo.LinearOperatorFromMatrix(dm(A1)))) <= rtol * np.linalg.norm(AA1)
+    assert np.linalg.norm(AA1 - M(lo.LinearOperatorFromMatrix(dm(A1)) * x)) <= rtol * np.linalg.norm(AA1)
+
+
 def test_complex_dense_in_operator_trees_and_contract(lo, dev):
     """complex dense leaves compose with the complex elementwise leaves (sum, product, cat) against dense NumPy, and a
     warmed apply issues launches only."""

@@ -204,3 +204,4 @@ def test_mul_on_matrices_routing_without_device(lo):
     assert torch.equal(r2, 3.0 * mu)
     lo.mul(r2, lo.conj(sym), mu, 1.0, 0.0)                                                 # real data: conj is the identity
     assert torch.equal(r2, mu)
+

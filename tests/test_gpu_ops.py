@@ -366,6 +366,34 @@ def test_shifted_operator(lo, dev):
     assert rel(p.cpu().numpy(), x) <= 1e-9
 
 
+def test_type_specific_operator_testset(lo, dev):
+    """test/test_linop.jl:552-586 "Type specific operator": closures written by the caller, eltype(op) == T and
+    op * w == T[2; 1] with eltype(op * w) == T for every element type; Matrix(opC) of a ComplexF64 closure operator.
+    The closures index device vectors; nothing but the host routing is involved."""
+    def prod(res, v, a, b):
+        res[0] = v[0] + v[1]
+        res[1] = v[1]
+
+    def ctprod(res, v, a, b):
+        res[0] = v[0]
+        res[1] = v[0] + v[1]
+
+    for T in (torch.complex128, torch.complex64, torch.float64, torch.float32, torch.float16, torch.int32):
+        op = lo.LinearOperator(T, 2, 2, False, False, prod, None, ctprod, S=lo.Storage(T, dev))
+        w = torch.ones(2, dtype=T, device=dev)
+        assert lo.eltype(op) == T
+        y = op * w
+        assert y.dtype == T and torch.equal(y, torch.tensor([2, 1], dtype=T, device=dev))
+        z = op.H * w                                                   # ctprod! is used as it is
+        assert torch.equal(z, torch.tensor([1, 2], dtype=T, device=dev))
+    A = torch.tensor([[1j, 1.0], [0.0, 1.0]], dtype=torch.complex128, device=dev)
+    opC = lo.LinearOperator(torch.complex128, 2, 2, False, False, lambda r, v, a, b: r.copy_(A @ v),
+                            lambda r, u, a, b: r.copy_(A.t() @ u), lambda r, w, a, b: r.copy_(A.conj().t() @ w),
+                            S=lo.Storage(torch.complex128, dev))
+    assert torch.equal(lo.Matrix(opC), A)
+    assert torch.equal(lo.Matrix(opC.T), A.t()) and torch.equal(lo.Matrix(opC.H), A.conj().t())
+
+
 def test_callable_functor(lo, dev):
     """test/test_callable.jl:1-21: a functor as prod! — `Flip` computes res = (-α) x (+ β res)."""
     class Flip:

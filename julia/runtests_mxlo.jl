@@ -47,6 +47,16 @@ end
     u = rand(T, 200)
     @test rel(host(opd' * dev(u)), oph' * u) <= 1e-12
     @test rel(host(transpose(opd) * dev(u)), transpose(oph) * u) <= 1e-12
+    # mul! on matrices (test/test_linop.jl:64-76: hcat(v, -2v)) and op ± scalar (:164-176) next to device operators
+    mv, mu = hcat(x, -2x), hcat(u, -2u)
+    rm = MXMatrix(zeros(T, 200, 2)); mul!(rm, opd, MXMatrix(mv))
+    @test rel(host(rm.data), vec(M * mv)) <= 1e-12
+    rt = MXMatrix(zeros(T, 300, 2)); mul!(rt, transpose(opd), MXMatrix(mu))
+    @test rel(host(rt.data), vec(transpose(M) * mu)) <= 1e-12
+    ra = MXMatrix(zeros(T, 300, 2)); mul!(ra, opd', MXMatrix(mu), 2.0, 0.0)
+    @test rel(host(ra.data), vec(2.0 .* (M' * mu))) <= 1e-12
+    @test rel(host((opd + 2.12345) * dev(x)), (M .+ 2.12345) * x) <= 1e-12
+    @test rel(host((2.12345 - opd) * dev(x)), (2.12345 .- M) * x) <= 1e-12
   end
   I = [5, 2, 9, 2, 7]
   v = rand(20)

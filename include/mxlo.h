@@ -407,6 +407,15 @@ int32_t mxlo_gemv(mxlo_ctx *ctx, int32_t dtype, void *res, const void *M, int64_
                   int64_t ld, const void *v, double alpha, double beta, int32_t op_mode,
                   int32_t flags);
 
+/* mul!(res::Matrix, LinearOperator(M), V::Matrix, α, β) — src/operations.jl:34-36 hands the matrices to the closure of
+ * src/constructors.jl:19-29 (a GEMM in the reference; test/test_linop.jl:64-76). res (nres x k, leading dimension ldr) =
+ * alpha * op(M) * V (nin x k, ldv) + beta * res with op_mode MXLO_OP_N / _T (_C == _T for real data); M is m x n
+ * column-major (ld). Tall-skinny blocks: M is read ONCE per chunk of up to 8 columns of V (HBM-bound on M), f64
+ * accumulation, fixed-order sums. */
+int32_t mxlo_gemv_block(mxlo_ctx *ctx, int32_t dtype, void *res, int64_t ldr, const void *M, int64_t m, int64_t n,
+                        int64_t ld, const void *V, int64_t ldv, int64_t k, double alpha, double beta, int32_t op_mode,
+                        int32_t flags);
+
 /* push!(B, s, y) of the diagonal quasi-Newton operators — src/DiagonalHessianApproximation.jl:
  * DiagonalPSB :45-64, DiagonalAndrei :117-139, DiagonalBFGS :236-249, SpectralGradient :190-199
  * (their mul! is mxlo_diag_mul, :37,112,179,226; SpectralGradient keeps ONE device element in `d` and

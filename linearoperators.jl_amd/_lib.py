@@ -139,6 +139,7 @@ _PROTOS = {
     "mxlo_kron_mul_ex": [_vp, _i32, _vp, _vp, _i64, _i64, _i64, _i32, _vp, _i64, _i64, _i64, _i32, _vp, _vp, _dbl, _dbl, _i32],
     "mxlo_kron_diag_mul": [_vp, _i32, _vp, _vp, _i64, _vp, _i64, _vp, _dbl, _dbl, _i32],
     "mxlo_gemv": [_vp, _i32, _vp, _vp, _i64, _i64, _i64, _vp, _dbl, _dbl, _i32, _i32],
+    "mxlo_gemv_block": [_vp, _i32, _vp, _i64, _vp, _i64, _i64, _i64, _vp, _i64, _i64, _dbl, _dbl, _i32, _i32],
     "mxlo_diagqn_push": [_vp, _i32, _i32, _vp, _vp, _vp, _i64, C.POINTER(_i32)],
     "mxlo_qn_create": [_vp, _i32, _i32, _i64, _i64, _i32, _i32, _dbl, _dbl, C.POINTER(_vp)],
     "mxlo_qn_destroy": [_vp],

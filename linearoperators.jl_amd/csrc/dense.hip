@@ -368,6 +368,249 @@ int32_t gemv_any(mxlo_ctx *ctx, T *res, const T *M, int64_t m, int64_t n, int64_
   return gemv_t<T>(ctx, res, M, m, n, ld, v, alpha, beta, flags);
 }
 
+// ---- block GEMV: res (.. x k) = alpha * op(M) * V (.. x k) + beta * res, M read ONCE for KB columns of V ---------
+// `mul!(res::Matrix, LinearOperator(M), V::Matrix, α, β)` (src/operations.jl:34-36 with the closure of
+// src/constructors.jl:19-29, a GEMM in the reference) for the tall-skinny blocks of block Krylov methods: k is a
+// handful, so the product is HBM-bound on M — one pass over M for the whole block instead of one per column.
+// N mode: a lane owns one row (a pair with 16-byte loads) and KB accumulators per row; V[j, c] is uniform over the
+// wave (scalar loads). Column chunks per blockIdx.y as in gemv_n_partial_kernel; part[(chunk*KB + c)*m + row].
+template <typename T, int KB, bool PAIR>
+__global__ void __launch_bounds__(kBlock)
+gemvb_n_partial_kernel(double *__restrict__ part, const T *__restrict__ M, int64_t m, int64_t n, int64_t ld,
+                       const T *__restrict__ V, int64_t ldv, int64_t cols_per_chunk) {
+  typedef T V2 __attribute__((ext_vector_type(2)));
+  constexpr int R = PAIR ? 2 : 1;
+  const int64_t i = ((int64_t)blockIdx.x * kBlock + threadIdx.x) * R;
+  const int64_t j0 = (int64_t)blockIdx.y * cols_per_chunk;
+  int64_t j1 = j0 + cols_per_chunk;
+  if (j1 > n) j1 = n;
+  if (i >= m) return;
+  double acc0[KB], acc1[KB];
+#pragma unroll
+  for (int c = 0; c < KB; ++c) acc0[c] = acc1[c] = 0.0;
+  const bool two = PAIR && i + 1 < m;
+  int64_t j = j0;
+  if (two) {
+    constexpr int U = 4;
+    for (; j + U <= j1; j += U) {
+      V2 a[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) a[u] = __builtin_nontemporal_load(reinterpret_cast<const V2 *>(M + i + (j + u) * ld));
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+#pragma unroll
+        for (int c = 0; c < KB; ++c) {
+          const double vj = (double)V[(j + u) + (int64_t)c * ldv];
+          acc0[c] = fma((double)a[u][0], vj, acc0[c]);
+          acc1[c] = fma((double)a[u][1], vj, acc1[c]);
+        }
+      }
+    }
+    for (; j < j1; ++j) {
+      const V2 a = *reinterpret_cast<const V2 *>(M + i + j * ld);
+#pragma unroll
+      for (int c = 0; c < KB; ++c) {
+        const double vj = (double)V[j + (int64_t)c * ldv];
+        acc0[c] = fma((double)a[0], vj, acc0[c]);
+        acc1[c] = fma((double)a[1], vj, acc1[c]);
+      }
+    }
+  } else {
+    for (; j < j1; ++j) {
+      const double a = (double)M[i + j * ld];
+#pragma unroll
+      for (int c = 0; c < KB; ++c) acc0[c] = fma(a, (double)V[j + (int64_t)c * ldv], acc0[c]);
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < KB; ++c) {
+    double *p = part + ((int64_t)blockIdx.y * KB + c) * m + i;
+    p[0] = acc0[c];
+    if (two) p[1] = acc1[c];
+  }
+}
+
+// blockIdx.y = column of the block; 32 rows per workgroup, 8 lanes per row, fixed-order sums (as gemv_n_finish_kernel)
+template <typename T, typename CA, typename CB, bool BETA0>
+__global__ void __launch_bounds__(kBlock)
+gemvb_n_finish_kernel(T *__restrict__ res, int64_t ldr, const double *__restrict__ part, int64_t m, int nchunks, int kb,
+                      CA alpha, CB beta) {
+  const int r = threadIdx.x & 31, sub = threadIdx.x >> 5, c = (int)blockIdx.y;
+  const int64_t i = (int64_t)blockIdx.x * 32 + r;
+  __shared__ double sred[8][32];
+  double a = 0.0;
+  if (i < m)
+    for (int ch = sub; ch < nchunks; ch += 8) a += part[((int64_t)ch * kb + c) * m + i];
+  sred[sub][r] = a;
+  __syncthreads();
+  if (sub != 0 || i >= m) return;
+  double acc = 0.0;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) acc += sred[q][r];
+  T *o = res + i + (int64_t)c * ldr;
+  *o = fin_ab<T, CA, CB, BETA0>(alpha * (CA)(T)acc, beta, BETA0 ? T(0) : *o);
+}
+
+// T mode: one wave per column j of M, KB dots at once (the column of M is loaded once, the KB columns of U come from
+// L2): res[j + c*ldr] = alpha * dot(M[:, j], U[:, c]) + beta * res[j + c*ldr].
+template <typename T, typename CA, typename CB, bool BETA0, int KB, bool PAIR>
+__global__ void __launch_bounds__(kBlock)
+gemvb_t_kernel(T *__restrict__ res, int64_t ldr, const T *__restrict__ M, int64_t m, int64_t n, int64_t ld,
+               const T *__restrict__ Um, int64_t ldu, CA alpha, CB beta) {
+  constexpr int VR = 16 / (int)sizeof(T);
+  typedef T VV __attribute__((ext_vector_type(VR)));
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = (int64_t)blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * (kBlock / kWave);
+  for (int64_t j = wave; j < n; j += nwaves) {
+    const T *colp = M + j * ld;
+    double acc[KB];
+#pragma unroll
+    for (int c = 0; c < KB; ++c) acc[c] = 0.0;
+    int64_t i = 0;
+    if constexpr (PAIR) {
+      const int64_t mp = m / VR;
+      const VV *cp = reinterpret_cast<const VV *>(colp);
+      int64_t p = lane;
+      for (; p + 64 < mp; p += 128) {
+        const VV a0 = __builtin_nontemporal_load(cp + p), a1 = __builtin_nontemporal_load(cp + p + 64);
+#pragma unroll
+        for (int c = 0; c < KB; ++c) {
+          const VV x0 = *reinterpret_cast<const VV *>(Um + (int64_t)c * ldu + p * VR);
+          const VV x1 = *reinterpret_cast<const VV *>(Um + (int64_t)c * ldu + (p + 64) * VR);
+#pragma unroll
+          for (int e = 0; e < VR; ++e) {
+            acc[c] = fma((double)a0[e], (double)x0[e], acc[c]);
+            acc[c] = fma((double)a1[e], (double)x1[e], acc[c]);
+          }
+        }
+      }
+      for (; p < mp; p += 64) {
+        const VV a0 = cp[p];
+#pragma unroll
+        for (int c = 0; c < KB; ++c) {
+          const VV x0 = *reinterpret_cast<const VV *>(Um + (int64_t)c * ldu + p * VR);
+#pragma unroll
+          for (int e = 0; e < VR; ++e) acc[c] = fma((double)a0[e], (double)x0[e], acc[c]);
+        }
+      }
+      i = mp * VR;
+    }
+    for (int64_t r = i + lane; r < m; r += 64) {
+      const double a = (double)colp[r];
+#pragma unroll
+      for (int c = 0; c < KB; ++c) acc[c] = fma(a, (double)Um[(int64_t)c * ldu + r], acc[c]);
+    }
+#pragma unroll
+    for (int c = 0; c < KB; ++c) {
+      double v = acc[c];
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+      if (lane == 0) {
+        T *o = res + j + (int64_t)c * ldr;
+        *o = fin_ab<T, CA, CB, BETA0>(alpha * (CA)(T)v, beta, BETA0 ? T(0) : *o);
+      }
+    }
+  }
+}
+
+inline int32_t ensure_scratch(mxlo_ctx *ctx, size_t need, const char *what) {
+  if (ctx->scratch_bytes < need) {            // stream-ordered users only: drain before the buffer is replaced
+    if (ctx->scratch) {
+      MXLO_HIP(hipStreamSynchronize(ctx->stream));
+      MXLO_HIP(hipFree(ctx->scratch));
+    }
+    ctx->scratch = nullptr;
+    ctx->scratch_bytes = 0;
+    hipError_t e = hipMalloc(&ctx->scratch, need);
+    MXLO_REQUIRE(e == hipSuccess, MXLO_ENOMEM, "%s scratch: %s", what, hipGetErrorString(e));
+    ctx->scratch_bytes = need;
+    ++ctx->scratch_generation;     // graphs that recorded the old workspace pointer are stale now
+  }
+  if (ctx->capturing) ctx->scratch_used_in_capture = true;
+  return MXLO_OK;
+}
+
+// one chunk of KB <= 8 columns
+template <typename T, int KB>
+int32_t gemv_block_chunk(mxlo_ctx *ctx, T *res, int64_t ldr, const T *M, int64_t m, int64_t n, int64_t ld, const T *V,
+                         int64_t ldv, double alpha, double beta, int32_t mode, int32_t flags) {
+  if (mode == MXLO_OP_N) {
+    const bool pair = m >= 2 && (((uintptr_t)M % (2 * sizeof(T))) == 0) && (ld % 2 == 0);
+    const int64_t rows_per_block = (int64_t)kBlock * (pair ? 2 : 1);
+    const int64_t row_blocks = (m + rows_per_block - 1) / rows_per_block;
+    int64_t nchunks = (n + 63) / 64;
+    const int64_t want = (int64_t)ctx->num_cu * 8 / (row_blocks > 0 ? row_blocks : 1) + 1;
+    if (nchunks > want) nchunks = want;
+    if (nchunks > 65535) nchunks = 65535;
+    if (nchunks < 1) nchunks = 1;
+    const int64_t cpc = (n + nchunks - 1) / nchunks;
+    nchunks = (n + cpc - 1) / cpc;
+    MXLO_TRY(ensure_scratch(ctx, sizeof(double) * (size_t)nchunks * KB * (size_t)m, "block GEMV"));
+    double *part = (double *)ctx->scratch;
+    dim3 grid((unsigned)row_blocks, (unsigned)nchunks);
+    if (pair)
+      hipLaunchKernelGGL((gemvb_n_partial_kernel<T, KB, true>), grid, dim3(kBlock), 0, ctx->stream, part, M, m, n, ld, V,
+                         ldv, cpc);
+    else
+      hipLaunchKernelGGL((gemvb_n_partial_kernel<T, KB, false>), grid, dim3(kBlock), 0, ctx->stream, part, M, m, n, ld,
+                         V, ldv, cpc);
+    MXLO_LAUNCH_CHECK();
+    return dispatch_ab<T>(beta, flags, [&]<typename CA, typename CB, bool B0>() -> int32_t {
+      hipLaunchKernelGGL((gemvb_n_finish_kernel<T, CA, CB, B0>), dim3((unsigned)((m + 31) / 32), (unsigned)KB),
+                         dim3(kBlock), 0, ctx->stream, res, ldr, part, m, (int)nchunks, KB, (CA)alpha, (CB)beta);
+      MXLO_LAUNCH_CHECK();
+      return MXLO_OK;
+    });
+  }
+  int64_t blocks = (n + 3) / 4;
+  const int64_t cap = (int64_t)ctx->num_cu * 16;
+  if (blocks > cap) blocks = cap;
+  constexpr int VR = 16 / (int)sizeof(T);
+  const bool pair = m >= VR && (((uintptr_t)M & 15u) == 0) && (ld % VR == 0) && (((uintptr_t)V & 15u) == 0) &&
+                    (ldv % VR == 0);
+  return dispatch_ab<T>(beta, flags, [&]<typename CA, typename CB, bool B0>() -> int32_t {
+    if (pair)
+      hipLaunchKernelGGL((gemvb_t_kernel<T, CA, CB, B0, KB, true>), dim3((unsigned)blocks), dim3(kBlock), 0, ctx->stream,
+                         res, ldr, M, m, n, ld, V, ldv, (CA)alpha, (CB)beta);
+    else
+      hipLaunchKernelGGL((gemvb_t_kernel<T, CA, CB, B0, KB, false>), dim3((unsigned)blocks), dim3(kBlock), 0, ctx->stream,
+                         res, ldr, M, m, n, ld, V, ldv, (CA)alpha, (CB)beta);
+    MXLO_LAUNCH_CHECK();
+    return MXLO_OK;
+  });
+}
+
+template <typename T>
+int32_t gemv_block(mxlo_ctx *ctx, T *res, int64_t ldr, const T *M, int64_t m, int64_t n, int64_t ld, const T *V,
+                   int64_t ldv, int64_t k, double alpha, double beta, int32_t mode, int32_t flags) {
+  const int64_t nres = mode == MXLO_OP_N ? m : n, nin = mode == MXLO_OP_N ? n : m;
+  if (nres == 0 || k == 0) return MXLO_OK;
+  int64_t done = 0;
+  while (done < k) {
+    const int64_t left = k - done;
+    T *r = res + done * ldr;
+    const T *v = V + done * ldv;
+    if (nin == 0) {                      // empty sum: column by column res = beta*res (or 0), as gemv_any
+      MXLO_TRY(gemv_any<T>(ctx, r, M, m, n, ld, v, alpha, beta, mode, flags));
+      done += 1;
+    } else if (left >= 8) {
+      MXLO_TRY((gemv_block_chunk<T, 8>(ctx, r, ldr, M, m, n, ld, v, ldv, alpha, beta, mode, flags)));
+      done += 8;
+    } else if (left >= 4) {
+      MXLO_TRY((gemv_block_chunk<T, 4>(ctx, r, ldr, M, m, n, ld, v, ldv, alpha, beta, mode, flags)));
+      done += 4;
+    } else if (left >= 2) {
+      MXLO_TRY((gemv_block_chunk<T, 2>(ctx, r, ldr, M, m, n, ld, v, ldv, alpha, beta, mode, flags)));
+      done += 2;
+    } else {
+      MXLO_TRY(gemv_any<T>(ctx, r, M, m, n, ld, v, alpha, beta, mode, flags));   // a single column: the GEMV itself
+      done += 1;
+    }
+  }
+  return MXLO_OK;
+}
+
 // ---- opHermitian, single pass over the strict lower triangle -------------------------------------
 // The triangle is cut into tiles of 256 rows x 32 columns (row group G, column tile J <= 8G+7); one workgroup
 // owns a STRIP of 8 consecutive tiles of one row group (a 256 x 256 block; strip s <= G) and reads it ONCE —
@@ -770,6 +1013,25 @@ MXLO_API int32_t mxlo_gemv(mxlo_ctx *ctx, int32_t dtype, void *res, const void *
   if (dtype == MXLO_F64)
     return gemv_any<double>(ctx, (double *)res, (const double *)M, m, n, ld, (const double *)v, alpha, beta, op_mode, flags);
   return gemv_any<float>(ctx, (float *)res, (const float *)M, m, n, ld, (const float *)v, alpha, beta, op_mode, flags);
+}
+
+MXLO_API int32_t mxlo_gemv_block(mxlo_ctx *ctx, int32_t dtype, void *res, int64_t ldr, const void *M, int64_t m, int64_t n,
+                                 int64_t ld, const void *V, int64_t ldv, int64_t k, double alpha, double beta,
+                                 int32_t op_mode, int32_t flags) {
+  MXLO_REQUIRE(ctx, MXLO_EINVAL, "mxlo_gemv_block: ctx is NULL");
+  MXLO_DEVICE_GUARD(ctx);
+  MXLO_REQUIRE(dtype == MXLO_F64 || dtype == MXLO_F32, MXLO_EINVAL, "bad dtype");
+  MXLO_REQUIRE(op_mode >= MXLO_OP_N && op_mode <= MXLO_OP_C, MXLO_EINVAL, "bad op_mode");
+  const int64_t nres = op_mode == MXLO_OP_N ? m : n, nin = op_mode == MXLO_OP_N ? n : m;
+  MXLO_REQUIRE(m >= 0 && n >= 0 && k >= 0 && ld >= (m > 1 ? m : 1) && ldr >= (nres > 1 ? nres : 1) &&
+                   ldv >= (nin > 1 ? nin : 1), MXLO_ESHAPE, "mxlo_gemv_block: bad shape");
+  MXLO_REQUIRE(nres == 0 || k == 0 || (res && (nin == 0 || (M && V))), MXLO_EINVAL, "mxlo_gemv_block: NULL operand");
+  eff_ab(dtype, flags, alpha, beta);
+  if (dtype == MXLO_F64)
+    return gemv_block<double>(ctx, (double *)res, ldr, (const double *)M, m, n, ld, (const double *)V, ldv, k, alpha,
+                              beta, op_mode == MXLO_OP_N ? MXLO_OP_N : MXLO_OP_T, flags);
+  return gemv_block<float>(ctx, (float *)res, ldr, (const float *)M, m, n, ld, (const float *)V, ldv, k, alpha, beta,
+                           op_mode == MXLO_OP_N ? MXLO_OP_N : MXLO_OP_T, flags);
 }
 
 MXLO_API int32_t mxlo_hermitian_mul(mxlo_ctx *ctx, int32_t dtype, void *res, const void *d,

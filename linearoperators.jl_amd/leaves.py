@@ -381,10 +381,23 @@ def LinearOperatorFromMatrix(M: torch.Tensor, symmetric: bool = False, hermitian
             _lib.call("mxlo_gemv", ctx.handle, dtype_code(St.dtype), ptr(res), ptr(St), sm, sn, ld, ptr(v), float(a),
                       float(b), mode, scalar_flags(res.dtype, a, b))
 
+        def gemv_block(res, m, a, b, mode):
+            """res, m: column-major matrices of St's dtype — one pass over the stored matrix per 8 columns"""
+            ctx = get_ctx(res.device)
+            k = m.shape[1]
+            if res.dtype != St.dtype or m.dtype != St.dtype:
+                raise TypeError(f"mul! on matrices: {res.dtype} / {m.dtype} operands next to a {St.dtype} matrix")
+            _lib.call("mxlo_gemv_block", ctx.handle, dtype_code(St.dtype), ptr(res), _ld(res), ptr(St), sm, sn, ld,
+                      ptr(m), _ld(m), k, float(a), float(b), mode, scalar_flags(res.dtype, a, b))
+
     # on matrices the reference closure `mul!(res, M, m, α, β)` is a GEMM: one GEMV per column here (same numbers)
     prod = columnwise(lambda res, v, a, b: gemv(res, v, a, b, fwd))
     tprod = columnwise(lambda res, u, a, b: gemv(res, u, a, b, bwd))
     ctprod = columnwise(lambda res, w, a, b: gemv(res, w, a, b, cbwd))
+    if not cplx:                                  # real data: the whole block in one call (M read once per 8 columns)
+        prod._matrix = lambda res, m, a, b: gemv_block(res, m, a, b, fwd)
+        tprod._matrix = lambda res, m, a, b: gemv_block(res, m, a, b, bwd)
+        ctprod._matrix = lambda res, m, a, b: gemv_block(res, m, a, b, cbwd)
     op = LinearOperator(St.dtype, nrow, ncol, symmetric, hermitian, prod, tprod, ctprod,
                         S=S if S is not None else Storage(St.dtype, St.device))
     if not tr and not cplx:

@@ -495,10 +495,16 @@ def _apply_closure_to_matrix(fn, res, m, alpha, beta):
         return touched(res)
     if res.dim() != 2 or m.dim() != 2 or res.shape[1] != m.shape[1]:
         raise LinearOperatorException("shape mismatch")
-    colmajor = lambda X: X if X.t().is_contiguous() else X.t().contiguous().t()
+    def colmajor(X):                        # Julia layout (unit stride down a column, any leading dimension) or a copy of it
+        ok = (X.shape[0] <= 1 or X.stride(0) == 1) and (X.shape[1] <= 1 or X.stride(1) >= max(1, X.shape[0]))
+        return X if ok else X.t().contiguous().t()
     mc, rc = colmajor(m), colmajor(res)                                       # Julia layout: column j is contiguous
-    for j in range(m.shape[1]):
-        fn(rc[:, j], mc[:, j], alpha, beta)
+    block = getattr(fn, "_matrix", None)                                      # dense real M: one pass over M for the block
+    if block is not None and m.shape[1] > 1 and mc.is_cuda:
+        block(rc, mc, alpha, beta)
+    else:
+        for j in range(m.shape[1]):
+            fn(rc[:, j], mc[:, j], alpha, beta)
     if rc is not res:
         res.copy_(rc)
     return touched(res)

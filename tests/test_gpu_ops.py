@@ -366,6 +366,43 @@ def test_shifted_operator(lo, dev):
     assert rel(p.cpu().numpy(), x) <= 1e-9
 
 
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-12), (torch.float32, 3e-5)])
+@pytest.mark.parametrize("m,n", [(1000, 777), (513, 2050), (64, 3), (2, 5000)])
+@pytest.mark.parametrize("k", [2, 3, 5, 8, 11])
+def test_block_gemv_vs_columns_and_dense(lo, dev, dtype, tol, m, n, k):
+    """mul!(res::Matrix, LinearOperator(M), V::Matrix, α, β) through mxlo_gemv_block (M read once per 8 columns) against
+    NumPy and against the column-by-column GEMVs, for M·V, transpose(M)·U and the 5-arg form, column-major and row-major M,
+    aligned and odd leading dimensions of the operands."""
+    npd = NP[dtype]
+    rng = np.random.default_rng(m + 7 * n + 13 * k)
+    Mh = rng.uniform(-1, 1, (m, n)).astype(npd)
+    Vh, Uh = rng.uniform(-1, 1, (n, k)).astype(npd), rng.uniform(-1, 1, (m, k)).astype(npd)
+    r0, r1 = rng.uniform(-1, 1, (m, k)).astype(npd), rng.uniform(-1, 1, (n, k)).astype(npd)
+    W = Mh.astype(np.float64)
+
+    def cm(X, pad=0):                                              # column-major device matrix, leading dimension + pad
+        big = torch.zeros(X.shape[1], X.shape[0] + pad, dtype=dtype, device=dev)
+        big[:, :X.shape[0]] = T(np.ascontiguousarray(X.T), dev)
+        return big[:, :X.shape[0]].t()
+
+    for Md in (TM(Mh, dev), T(Mh, dev)):
+        op = lo.LinearOperatorFromMatrix(Md)
+        for pad in (0, 1):
+            res = cm(r0, pad)
+            lo.mul(res, op, cm(Vh, pad), 2.0, -0.5)
+            assert rel(res.cpu().numpy(), 2.0 * (W @ Vh) - 0.5 * r0) <= tol
+            rt = cm(r1, pad)
+            lo.mul(rt, op.T, cm(Uh, pad), 1.0, 0.0)
+            assert rel(rt.cpu().numpy(), W.T @ Uh) <= tol
+            cols = torch.empty(k, n, dtype=dtype, device=dev).t()
+            for j in range(k):                                         # the same product, one GEMV per column
+                lo.mul(cols[:, j], op.T, cm(Uh, pad)[:, j].contiguous(), 1.0, 0.0)
+            assert rel(rt.cpu().numpy(), cols.cpu().numpy()) <= tol
+    res = torch.full((m, k), float("nan"), dtype=dtype, device=dev).t().contiguous().t()
+    lo.mul(res, op, cm(Vh))                                            # beta == 0 never reads res
+    assert rel(res.cpu().numpy(), W @ Vh) <= tol
+
+
 def test_type_specific_operator_testset(lo, dev):
     """test/test_linop.jl:552-586 "Type specific operator": closures written by the caller, eltype(op) == T and
     op * w == T[2; 1] with eltype(op * w) == T for every element type; Matrix(opC) of a ComplexF64 closure operator.

@@ -296,12 +296,23 @@ function LinearOperator(M::MXMatrix{T}; symmetric = false, hermitian = false) wh
       ctx(), dt(T), res.ptr, M.data.ptr, m, n, m, v.ptr, rpart(α), ipart(α), rpart(β), ipart(β), Int32(mode), flags(T, α, β)))
   LinearOperator{T, MXVector{T}}(m, n, symmetric, hermitian, gemv(0), gemv(1), gemv(2))     # M*v, transpose(M)*u, M'*w
 end
+# The closure of a real dense operator is a callable with a vector method (GEMV) and a matrix method (the block GEMV:
+# `mul!(res::Matrix, op, V::Matrix, α, β)`, src/operations.jl:34-36, reads M once per 8 columns of V).
+struct DenseApply{T}
+  M::MXMatrix{T}
+  mode::Int32          # MXLO_OP_N / _T / _C
+end
+(f::DenseApply{T})(res::MXVector{T}, v::MXVector{T}, α, β) where {T <: RealT} = check(ccall((:mxlo_gemv, lib), Int32,
+    (P, Int32, P, P, Int64, Int64, Int64, P, Float64, Float64, Int32, Int32),
+    ctx(), dt(T), res.ptr, f.M.data.ptr, f.M.m, f.M.n, f.M.m, v.ptr, α, β, f.mode, flags(T, α, β)))
+(f::DenseApply{T})(res::MXMatrix{T}, V::MXMatrix{T}, α, β) where {T <: RealT} = check(ccall((:mxlo_gemv_block, lib), Int32,
+    (P, Int32, P, Int64, P, Int64, Int64, Int64, P, Int64, Int64, Float64, Float64, Int32, Int32),
+    ctx(), dt(T), res.data.ptr, res.m, f.M.data.ptr, f.M.m, f.M.n, f.M.m, V.data.ptr, V.m, size(V, 2), α, β, f.mode,
+    flags(T, α, β)))
 function LinearOperator(M::MXMatrix{T}; symmetric = false, hermitian = false) where {T <: RealT}
   m, n = size(M)
-  gemv(mode) = (res, v, α, β) -> check(ccall((:mxlo_gemv, lib), Int32,
-      (P, Int32, P, P, Int64, Int64, Int64, P, Float64, Float64, Int32, Int32),
-      ctx(), dt(T), res.ptr, M.data.ptr, m, n, m, v.ptr, α, β, Int32(mode), flags(T, α, β)))
-  LinearOperator{T, MXVector{T}}(m, n, symmetric, hermitian, gemv(0), gemv(1), gemv(2))
+  LinearOperator{T, MXVector{T}}(m, n, symmetric, hermitian, DenseApply{T}(M, Int32(0)), DenseApply{T}(M, Int32(1)),
+                                 DenseApply{T}(M, Int32(2)))
 end
 
 # ---- mul! on matrices (src/operations.jl:34-36; wrappers src/adjtrans.jl:139-156, 207-224) ------------------------------
@@ -309,6 +320,11 @@ end
 # broadcast over the columns). The device closures are vector kernels, so a device matrix is applied column by column —
 # the columns of an MXMatrix are contiguous views, nothing is copied (test/test_linop.jl:64-76: hcat(v, -2v)).
 column(A::MXMatrix{T}, j::Integer) where {T} = view(A.data, ((j - 1) * A.m + 1):(j * A.m))
+function apply_columns(f::DenseApply{T}, res::MXMatrix{T}, m::MXMatrix{T}, α, β) where {T}      # real dense: one call for the block
+  size(res, 2) == size(m, 2) || throw(LinearOperatorException("shape mismatch"))
+  f(res, m, α, β)
+  res
+end
 function apply_columns(f, res::MXMatrix, m::MXMatrix, α, β)
   f === nothing && error("Not implemented")
   size(res, 2) == size(m, 2) || throw(LinearOperatorException("shape mismatch"))

@@ -128,6 +128,11 @@ for nn in (4096, 16384):
     row(f"dense transpose mul! n={nn}", 8.0 * nn * nn, timeit(lambda: lo.mul(y, op.T, x, 1.0, 0.0), 10))
     Hm = lo.opHermitian(rnd(nn), M)
     row(f"opHermitian mul! n={nn} (ideal = strict lower triangle once)", 4.0 * nn * nn, timeit(lambda: lo.mul(y, Hm, x, 1.0, 0.0), 10))
+    for kk in (2, 8):                        # block apply: M read once for the kk columns (mxlo_gemv_block)
+        Vb = torch.rand(kk, nn, dtype=torch.float64, device=dev, generator=gen).t()
+        Rb = torch.empty(kk, nn, dtype=torch.float64, device=dev).t()
+        row(f"dense mul! on an n x {kk} block n={nn} (ideal = M once)", 8.0 * nn * nn, timeit(lambda: lo.mul(Rb, op, Vb), 10))
+        row(f"dense transpose mul! on an n x {kk} block n={nn} (ideal = M once)", 8.0 * nn * nn, timeit(lambda: lo.mul(Rb, op.T, Vb), 10))
     del M, op, Hm
     torch.cuda.empty_cache()
 

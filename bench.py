@@ -408,7 +408,8 @@ def bench_cfg4(lo, torch, dev, ctx):
 
 def bench_misc(lo, torch, dev, ctx):
     """Other §8 rows next to the headline, N = 1 only (HIP events on the launch stream, clocks spun up first): ComplexF64
-    opDiagonal at the headline's bytes, sorted index extension, opHermitian, and the launch-bound Householder."""
+    opDiagonal at the headline's bytes, sorted index extension, opHermitian, the dense block apply, and the launch-bound
+    Householder."""
     import ctypes as C
 
     import numpy as np
@@ -464,6 +465,17 @@ def bench_misc(lo, torch, dev, ctx):
         ms = timeit(lambda: lo.mul(y, Hm, x, 1.0, 0.0), 20)
         out[f"opHermitian_n{nn}"] = {"us": round(ms * 1e3, 1), "GB/s(4n^2 B)": round(4.0 * nn * nn / ms / 1e6, 1),
                                      "frac_hbm_peak": round(4.0 * nn * nn / ms / 1e6 / HBM_PEAK_GBS, 4)}
+        if nn == 16384:                      # block apply of the dense operator: M read once for 8 columns
+            try:
+                opM = lo.LinearOperatorFromMatrix(M)
+                Vb = torch.rand(8, nn, dtype=torch.float64, device=dev, generator=gen).t()
+                Rb = torch.empty(8, nn, dtype=torch.float64, device=dev).t()
+                ms = timeit(lambda: lo.mul(Rb, opM, Vb), 10)
+                out["dense_block_mul_n16384_k8"] = {"us": round(ms * 1e3, 1), "GB/s(8n^2 B, M once)": round(8.0 * nn * nn / ms / 1e6, 1),
+                                                    "frac_hbm_peak": round(8.0 * nn * nn / ms / 1e6 / HBM_PEAK_GBS, 4)}
+                del opM, Vb, Rb
+            except Exception as e:           # an extra must never cost the line
+                out["dense_block_error"] = repr(e)
         del M, Hm
     n16 = 1 << 16
     h = torch.rand(n16, dtype=torch.float64, device=dev, generator=gen)

@@ -205,3 +205,34 @@ def test_mul_on_matrices_routing_without_device(lo):
     lo.mul(r2, lo.conj(sym), mu, 1.0, 0.0)                                                 # real data: conj is the identity
     assert torch.equal(r2, mu)
 
+
+
+def test_columnwise_closures_on_matrices_without_device(lo):
+    """The column loop behind `mul!` on matrices for closures marked `columnwise` (what the device closures of dense /
+    diagonal / identity operators are): Julia-layout operands are used in place, a row-major `res` is written back, the
+    column counts must agree, and an unmarked closure of the package refuses matrices. CPU tensors, Python closures."""
+    from linearoperators_jl_amd import operators as ops
+    S = lo.Storage(torch.float64, torch.device("cpu"))
+    d = torch.tensor([2.0, -1.0, 0.5])
+    seen = []
+
+    def diag(res, v, a, b):
+        assert res.dim() == 1 and v.dim() == 1 and res.stride(0) == 1 and v.stride(0) == 1     # contiguous columns
+        seen.append(res.data_ptr())
+        res.copy_(a * d * v + (b * res if b != 0 else 0))
+
+    op = lo.LinearOperator(torch.float64, 3, 3, True, True, ops.columnwise(diag), None, None, S=S)
+    m = torch.tensor([[1.0, 4.0], [2.0, 5.0], [3.0, 6.0]])                                   # row-major (torch default)
+    for res in (torch.ones(3, 2), torch.ones(2, 3).t()):                                     # row-major, column-major
+        seen.clear()
+        lo.mul(res, op, m, 2.0, -1.0)
+        assert torch.equal(res, 2.0 * d[:, None] * m - 1.0)
+        if res.stride(0) == 1:                                                               # Julia layout: written in place
+            assert seen == [res[:, 0].data_ptr(), res[:, 1].data_ptr()]
+    lo.mul(res, op.H, m)                                                                     # hermitian parent: same closure
+    assert torch.equal(res, d[:, None] * m)
+    with pytest.raises(lo.LinearOperatorException, match="shape mismatch"):
+        lo.mul(torch.empty(3, 3), op, m)
+    plain = lo.LinearOperator(torch.float64, 3, 3, True, True, ops.sum_prod, None, None, S=S)   # a closure of the package, unmarked
+    with pytest.raises(lo.LinearOperatorException, match="vectors only"):
+        lo.mul(torch.empty(3, 2), plain, m)

@@ -8,6 +8,16 @@ A "step" is ONE 5-arg `mul!(res, H, v, α, β)` of `opHouseholder(h)` at n = 10^
 row-sharded (n per GPU: weak scaling) and h'v is all-reduced over RCCL through the library's
 all-reduce hook; value = N * 40 B * n / max-over-ranks time.
 
+N > 1 without an external launcher (`WORLD_SIZE` unset): this script LAUNCHES ITSELF — one rank per device
+(RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set per child, rendezvous on 127.0.0.1), after checking that N devices
+are visible; it exits non-zero with a message when they are not, when any rank fails, or when the native RCCL
+all-reduce hook (libmxlo_rccl.so: ncclAllReduce issued from C on the ctx stream) cannot be installed on the `nccl`
+backend — a run never degrades silently to one rank or to Python-issued collectives. Under
+`python -m torch.distributed.run …` (WORLD_SIZE set) the ranks are used as launched.
+A second leg in the same line (`extras.single_process_shard_abi`) drives the same N devices from ONE host process
+through `mxlo_shard_ctx_create` + the `_sharded` entry points (the Julia deployment shape, include/mxlo_rccl.h); it
+runs in a child process with a timeout so that it can never cost the headline line.
+
 One JSON line is printed by rank 0 with, besides the driver contract fields:
   roofline      dominant kernel (the Householder update pass, 24 B/elt) timed with HIP events
                 on the launch stream, against the 8 TB/s HBM3E peak
@@ -31,7 +41,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md): 8.0 TB/s
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -45,11 +55,167 @@ def parse():
     # debugging aids for the N > 1 code path on a 1-GPU box: every rank on device 0, gloo instead of RCCL
     ap.add_argument("--backend", default="nccl")
     ap.add_argument("--single-device", action="store_true")
-    return ap.parse_args()
+    # the N-device leg through the single-process shard ABI (runs in a child process with a timeout)
+    ap.add_argument("--no-shard-leg", action="store_true")
+    ap.add_argument("--shard-leg-timeout", type=float, default=420.0)
+    ap.add_argument("--launch-timeout", type=float, default=3000.0, help="self-launch: seconds before the ranks are stopped")
+    # internal / test aids
+    ap.add_argument("--role", default="auto", choices=["auto", "shard-leg"], help=argparse.SUPPRESS)
+    ap.add_argument("--worker-cmd", default=None,
+                    help="self-launch: JSON list, the command to run per rank instead of this script (launcher tests)")
+    return ap.parse_args(argv)
 
 
-def main():
-    args = parse()
+def visible_device_count() -> int:
+    """Devices this process can see (MXLO_BENCH_FAKE_DEVICE_COUNT: launcher tests on a box without GPUs)."""
+    fake = os.environ.get("MXLO_BENCH_FAKE_DEVICE_COUNT")
+    if fake is not None:
+        return int(fake)
+    import torch
+    return torch.cuda.device_count()
+
+
+def die(msg: str, code: int = 2):
+    print(f"bench.py: {msg}", file=sys.stderr, flush=True)
+    raise SystemExit(code)
+
+
+def check_topology(args, ndev: int):
+    """Refuse, loudly, every configuration that could only run degraded."""
+    if args.gpus < 1:
+        die("--gpus must be >= 1")
+    if args.single_device:
+        if args.gpus > 1 and args.backend == "nccl":
+            die("--single-device puts every rank on device 0, which RCCL refuses: add --backend gloo (debug transport)")
+        if ndev < 1:
+            die("no HIP device visible")
+    elif ndev < args.gpus:
+        die(f"--gpus {args.gpus} but only {ndev} HIP device(s) visible: one rank per device is required "
+            "(use --single-device --backend gloo to exercise the N-rank code path on one GPU)")
+
+
+def free_port() -> int:
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def last_json_line(text: str):
+    for line in reversed(text.strip().splitlines()):
+        line = line.strip()
+        if line.startswith("{") and line.endswith("}"):
+            try:
+                return json.loads(line)
+            except ValueError:
+                continue
+    return None
+
+
+def launch(args, argv):
+    """`python bench.py --gpus N` with no WORLD_SIZE: start N ranks of this script, one per device, and relay rank 0's
+    JSON line. Any rank failing (or the time limit) stops the others (exact PIDs) and the exit status is non-zero."""
+    import subprocess
+    ndev = visible_device_count()
+    check_topology(args, ndev)
+    n = args.gpus
+    port = int(os.environ.get("MASTER_PORT") or free_port())
+    cmd = json.loads(args.worker_cmd) if args.worker_cmd else [sys.executable, os.path.abspath(__file__)] + list(argv)
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), MXLO_BENCH_SELF_LAUNCHED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC only on this driver (RCCL needs it)
+        procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE if r == 0 else sys.stderr, text=True))
+    import threading
+    out0 = []
+    rd = threading.Thread(target=lambda: out0.append(procs[0].stdout.read()), daemon=True)
+    rd.start()
+    deadline, bad = time.time() + args.launch_timeout, None
+    while bad is None:
+        codes = [p.poll() for p in procs]
+        if all(c is not None for c in codes):
+            break
+        failed = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+        if failed:
+            bad = "rank %d exited with status %d" % failed[0]
+        elif time.time() > deadline:
+            bad = f"ranks still running after --launch-timeout {args.launch_timeout:.0f} s"
+        else:
+            time.sleep(0.05)
+    if bad is None:
+        failed = [(r, p.returncode) for r, p in enumerate(procs) if p.returncode != 0]
+        if failed:
+            bad = "rank %d exited with status %d" % failed[0]
+    if bad is not None:
+        for p in procs:                                   # only the processes started above, by PID
+            if p.poll() is None:
+                p.terminate()
+        t_end = time.time() + 10
+        for p in procs:
+            try:
+                p.wait(timeout=max(0.1, t_end - time.time()))
+            except Exception:
+                p.kill()
+        die(f"{n}-rank launch failed: {bad}", 3)
+    rd.join(10)
+    line = last_json_line(out0[0] if out0 else "")
+    if line is None:
+        die("rank 0 printed no JSON line", 4)
+    if line.get("n_gpus") != n:
+        die(f"rank 0 reports n_gpus={line.get('n_gpus')} for a {n}-rank launch", 4)
+    line.setdefault("config", {})["launcher"] = "bench.py self-launch: %d processes, one per device, rendezvous 127.0.0.1:%d" % (n, port)
+    return line
+
+
+def run_shard_leg(args) -> dict:
+    """The N-device leg through the single-process shard ABI, in a child process with a time limit."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--role", "shard-leg", "--gpus", str(args.gpus), "--nelem", str(args.n),
+           "--steps", str(min(args.steps, 100)), "--warmup", str(args.warmup)]
+    if args.single_device:
+        cmd.append("--single-device")
+    if args.no_extras:
+        cmd.append("--no-extras")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE",
+                                                            "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK", "ROLE_RANK",
+                                                            "TORCHELASTIC_RUN_ID")}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    t0 = time.time()
+    p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    try:
+        so, se = p.communicate(timeout=args.shard_leg_timeout)
+    except subprocess.TimeoutExpired:
+        p.kill()
+        p.communicate()
+        return {"error": f"no result within {args.shard_leg_timeout:.0f} s (child stopped)"}
+    got = last_json_line(so or "")
+    if p.returncode != 0 or got is None:
+        return {"error": f"child exited with status {p.returncode}", "stderr_tail": (se or "")[-400:]}
+    got["wall_s"] = round(time.time() - t0, 1)
+    return got
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse(argv)
+    if args.role == "shard-leg":
+        print(json.dumps(shard_leg(args)), flush=True)
+        return
+    self_launch = args.gpus > 1 and "WORLD_SIZE" not in os.environ
+    if self_launch:
+        out = launch(args, argv)                     # N children run worker(); rank 0's line comes back
+    else:
+        out = worker(args)
+    if out is None:                                  # a non-zero rank under an external launcher
+        return
+    if not args.no_shard_leg and not args.worker_cmd:
+        out.setdefault("extras", {})["single_process_shard_abi"] = run_shard_leg(args)
+    print(json.dumps(out), flush=True)
+
+
+def worker(args):
+    """One rank: returns the JSON object on rank 0, None elsewhere."""
     import torch
     import torch.distributed as dist
 
@@ -62,8 +228,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     distributed = world > 1
-    if args.gpus != world and distributed:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus != world:
+        die(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher must start exactly one rank per requested GPU")
+    check_topology(args, visible_device_count())
     if args.single_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -79,19 +246,18 @@ def main():
     native = args.backend == "nccl" and not args.single_device
 
     def install_hook():
-        nonlocal hook, native
+        nonlocal hook
         if not distributed:
             return
         if native and hook is None:
-            # libmxlo_rccl.so (ncclAllReduce issued from C on the ctx stream) when every rank can build its
-            # communicator; otherwise every rank uses the torch.distributed hook (still RCCL, via Python)
-            hook = lo.sharded.install_agreed_allreduce(ctx)
-            native = hook is not None
+            # libmxlo_rccl.so: ncclAllReduce issued from C on the ctx stream. REQUIRED on the nccl backend: if any rank
+            # cannot build its communicator every rank raises (the run exits non-zero; no Python-issued collectives)
+            hook = lo.sharded.install_agreed_allreduce(ctx, require_native=True)
             return
         if native:
             hook.install(ctx)
             return
-        lo.sharded.install_allreduce(ctx, native=False)   # Python hook over torch.distributed (debug / gloo)
+        lo.sharded.install_allreduce(ctx, native=False)   # Python hook over torch.distributed (gloo debugging only)
 
     install_hook()                             # RCCL all-reduce of the partial dots over xGMI
 
@@ -116,11 +282,18 @@ def main():
     # The GPU idles at a few hundred MHz (sclk 525 MHz at rest) and needs tens of milliseconds of load to reach its
     # steady clocks; W = 10 warm-up steps are only 6 ms. Bring the clocks up first (untimed, same kernels), then do
     # the W warm-up steps and time EXACTLY K steps as the contract says.
-    t_spin = time.perf_counter()
-    while time.perf_counter() - t_spin < args.clock_spin_s:
-        for _ in range(20):
+    if distributed:
+        # every apply contains a collective: all ranks must issue the SAME number of them, so the spin is a fixed count
+        # (a time-based loop would let ranks disagree and hang the all-reduce)
+        for _ in range(min(5000, max(20, int(args.clock_spin_s / (0.7e-3 * max(n / 1e8, 1e-3)))))):
             lo.mul(res, H, v, alpha, beta)
         torch.cuda.synchronize()
+    else:
+        t_spin = time.perf_counter()
+        while time.perf_counter() - t_spin < args.clock_spin_s:
+            for _ in range(20):
+                lo.mul(res, H, v, alpha, beta)
+            torch.cuda.synchronize()
     for _ in range(args.warmup):
         lo.mul(res, H, v, alpha, beta)
     barrier()
@@ -212,21 +385,134 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu_baseline = cpu_leg(args.cpu_sample)
 
+    out = None
     if rank == 0:
+        transport = ("native RCCL hook (libmxlo_rccl.so, ncclAllReduce on the ctx stream)" if native
+                     else "torch.distributed Python hook over %s (debug transport)" % args.backend)
         out = {
             "metric": "mul! GB/s (frac HBM peak) at n=10^8 fp64; L-BFGS apply/s, 1/2/4/8 GPU",
             "value": round(value, 1), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "opHouseholder(h) 5-arg mul!(res,H,v,1,0), n=%d fp64 per GPU (configs[1])" % n,
-                       "n_per_gpu": n, "algorithmic_bytes_per_elt": 40, "sharding": ("row ranges, 1-double all-reduce (%s)" % ("native RCCL hook" if native else "torch.distributed hook")) if distributed else "none"},
+                       "n_per_gpu": n, "algorithmic_bytes_per_elt": 40,
+                       "sharding": ("row ranges over %d ranks (one process per GPU), 1-double all-reduce per apply: %s" % (world, transport)) if distributed else "none",
+                       "devices_visible": torch.cuda.device_count()},
             "frac_hbm_peak": round(value / world / HBM_PEAK_GBS, 4),
             "roofline": roofline, "cpu_baseline": cpu_baseline, "extras": extras,
         }
-        print(json.dumps(out), flush=True)
+    del H, h, v, res
+    torch.cuda.synchronize()
+    if distributed:
+        ctx.set_allreduce(None)                      # the communicator itself is released at process exit
+    torch.cuda.empty_cache()
     if distributed:
         dist.barrier()
         dist.destroy_process_group()
+    return out
+
+
+def shard_leg(args) -> dict:
+    """ONE host process driving `--gpus` devices through the single-process shard ABI of include/mxlo_rccl.h
+    (`mxlo_shard_ctx_create`: per device a stream, a ctx, an RCCL communicator from ncclCommInitAll and a worker thread;
+    the `_sharded` entry points take one device pointer per shard) — the deployment shape of a Julia host. Same workloads
+    as the process-per-GPU legs: opHouseholder n per device (weak) and LBFGSOperator m = 20 with n_local = 5e7 per device.
+    torch is used for device memory and random numbers only."""
+    import torch
+
+    import __graft_entry__ as g
+    lo = g.load_package()
+    from linearoperators_jl_amd import _lib
+    nd = args.gpus
+    check_topology(argparse.Namespace(gpus=nd, single_device=args.single_device, backend="gloo"), visible_device_count())
+    R = _lib.rccl_lib()
+    ids = [0] * nd if args.single_device else list(range(nd))
+    sctx = C.c_void_p()
+    if R.mxlo_shard_ctx_create(nd, (C.c_int32 * nd)(*ids), C.byref(sctx)) != 0:
+        die("mxlo_shard_ctx_create: " + (R.mxlo_shard_last_error() or b"").decode(), 5)
+    devs = [torch.device("cuda", i) for i in ids]
+    F64 = _lib.F64
+
+    def ck(rc, what):
+        if rc != 0:
+            die(f"{what}: " + (R.mxlo_shard_last_error() or b"").decode(), 5)
+
+    def ptrs(ts):
+        return (C.c_void_p * nd)(*[t.data_ptr() for t in ts])
+
+    def sync_torch():
+        for d in set(devs):
+            torch.cuda.synchronize(d)
+
+    def timed(fn, reps, spin_s):
+        t_spin = time.perf_counter()
+        while time.perf_counter() - t_spin < spin_s:
+            for _ in range(5):
+                fn()
+            ck(R.mxlo_shard_ctx_sync(sctx), "sync")
+        ck(R.mxlo_shard_ctx_sync(sctx), "sync")
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        ck(R.mxlo_shard_ctx_sync(sctx), "sync")
+        return (time.perf_counter() - t0) / reps
+
+    out = {"host": "one process, %d shard(s): mxlo_shard_ctx_create + _sharded entry points" % nd,
+           "transport": "loopback (all shards on device 0: debug)" if R.mxlo_shard_ctx_is_loopback(sctx) else "ncclCommInitAll, one worker thread per device",
+           "n_gpus": nd}
+    n = args.n
+    gens = [torch.Generator(device=d).manual_seed(77 + i) for i, d in enumerate(devs)]
+    hs = [torch.rand(n, dtype=torch.float64, device=d, generator=gq) - 0.5 for d, gq in zip(devs, gens)]
+    nrm = sum(float((t * t).sum().item()) for t in hs) ** 0.5
+    for t in hs:
+        t /= nrm
+    vs = [torch.rand(n, dtype=torch.float64, device=d, generator=gq) * 2 - 1 for d, gq in zip(devs, gens)]
+    rs = [torch.empty(n, dtype=torch.float64, device=d) for d in devs]
+    sync_torch()
+    nloc = (C.c_int64 * nd)(*([n] * nd))
+    pr, ph, pv = ptrs(rs), ptrs(hs), ptrs(vs)
+    sec = timed(lambda: ck(R.mxlo_householder_mul_sharded(sctx, F64, pr, ph, pv, nloc, 1.0, 0.0, 0), "householder"),
+                max(10, args.steps), 0.4)
+    gbs = 40.0 * n * nd / sec / 1e9
+    out["opHouseholder_mul"] = {"ms_per_step": round(sec * 1e3, 4), "GB/s": round(gbs, 1), "n_per_gpu": n,
+                                "frac_hbm_peak_per_gpu": round(gbs / nd / HBM_PEAK_GBS, 4)}
+    del hs, vs, rs
+    for d in set(devs):
+        with torch.cuda.device(d):
+            torch.cuda.empty_cache()
+    if not args.no_extras:
+        nl, m = 50_000_000, 20
+        nloc = (C.c_int64 * nd)(*([nl] * nd))
+        q = C.c_void_p()
+        ck(R.mxlo_qn_create_sharded(sctx, _lib.QN_LBFGS_FWD, F64, nloc, m, 1, 0, 0.99, 10.0, C.byref(q)), "qn_create")
+        ss = [torch.empty(nl, dtype=torch.float64, device=d) for d in devs]
+        ys = [torch.empty(nl, dtype=torch.float64, device=d) for d in devs]
+        acc, kept, push_s = C.c_int32(0), 0, []
+        for _ in range(m + 3):
+            for s_, y_, gq in zip(ss, ys, gens):
+                s_.uniform_(-1, 1, generator=gq)
+                y_.uniform_(0.5, 2.0, generator=gq)
+                y_.mul_(s_)
+            sync_torch()
+            tp = time.perf_counter()
+            ck(R.mxlo_qn_push_sharded(q, ptrs(ss), ptrs(ys), C.byref(acc)), "push")      # returns after the accept / reject read
+            ck(R.mxlo_shard_ctx_sync(sctx), "sync")                                        # ... the Gram-row dots are still in flight
+            push_s.append(time.perf_counter() - tp)
+            kept += acc.value
+        xs, rs = ss, ys
+        for x_, gq in zip(xs, gens):
+            x_.uniform_(-1, 1, generator=gq)
+        sync_torch()
+        px, pr = ptrs(xs), ptrs(rs)
+        sec = timed(lambda: ck(R.mxlo_qn_mul_sharded(q, pr, px, -1.0, 0.0, 0), "qn_mul"), 10, 0.1)
+        push_ms = sum(push_s[-3:]) / 3 * 1e3             # full memory: the steady-state push!
+        bytes_ = (4 * m + 3) * 8.0 * nl
+        out["LBFGS_fwd_m20_nlocal5e7"] = {"apply_per_s": round(1.0 / sec, 2), "ms": round(sec * 1e3, 3), "pairs_kept": kept,
+                                          "n_global": nl * nd, "frac_hbm_peak_per_gpu": round(bytes_ / sec / 1e9 / HBM_PEAK_GBS, 4),
+                                          "push_ms": round(push_ms, 3)}
+        ck(R.mxlo_qn_destroy_sharded(q), "qn_destroy")
+    ck(R.mxlo_shard_ctx_destroy(sctx), "destroy")
+    return out
 
 
 def bench_lbfgs(lo, torch, dev, ctx, rank, world, distributed, dist, barrier):

@@ -169,10 +169,11 @@ def install_allreduce(ctx, group=None, native: bool = True):
     return None
 
 
-def install_agreed_allreduce(ctx, group=None, timeout_s: float = 120.0):
+def install_agreed_allreduce(ctx, group=None, timeout_s: float = 120.0, require_native: bool = False):
     """The native RCCL transport when EVERY rank managed to build its communicator, otherwise the
     torch.distributed hook on every rank (never a mix: mixed transports would deadlock). Returns the
-    NativeRcclHook or None."""
+    NativeRcclHook or None. `require_native=True` (what `bench.py --gpus N` uses): no degraded transport —
+    if any rank failed, EVERY rank raises RuntimeError after the agreement round."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         ctx.set_allreduce(None)
         return None
@@ -189,6 +190,9 @@ def install_agreed_allreduce(ctx, group=None, timeout_s: float = 120.0):
     if int(flag.item()) == 1:
         hook.install(ctx)
         return hook
+    if require_native:
+        raise RuntimeError("the native RCCL all-reduce hook (libmxlo_rccl.so) could not be built on every rank "
+                           f"(rank {dist.get_rank(group)}: {'ok' if ok else 'FAILED'}); refusing the Python-issued transport")
     ctx.set_allreduce(make_allreduce_hook(group, cuda=True))
     return None
 

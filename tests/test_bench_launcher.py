@@ -1,0 +1,110 @@
+"""CPU: `python bench.py --gpus N` must really start N ranks (one per device) or fail loudly — VERDICT r2 weak #1.
+
+The launcher is exercised with a stub worker (`--worker-cmd`) and a faked device count
+(`MXLO_BENCH_FAKE_DEVICE_COUNT`), so no GPU, no torch.distributed and no libmxlo call is involved: what is checked is
+the process topology (N processes, ranks 0..N-1, one LOCAL_RANK each, a common MASTER_ADDR/PORT on 127.0.0.1), that
+rank 0's JSON line is relayed exactly once, and every refusal path (too few devices, a failing rank, a rank-0 line that
+reports the wrong n_gpus, RCCL with all ranks on one device)."""
+import json
+import os
+import subprocess
+import sys
+import textwrap
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+STUB = textwrap.dedent('''
+    import json, os, sys, time
+    out = sys.argv[1]
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    rec = {k: os.environ.get(k) for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT",
+                                          "HSA_ENABLE_IPC_MODE_LEGACY")}
+    rec["pid"] = os.getpid()
+    with open(os.path.join(out, "rank%d.json" % rank), "w") as f:
+        json.dump(rec, f)
+    mode = sys.argv[2]
+    if mode == "fail" and rank == 1:
+        sys.exit(7)
+    if mode == "fail" and rank != 1:
+        time.sleep(60)                       # must be stopped by the launcher, not run to completion
+    if rank == 0:
+        print("some log line on stdout")
+        print(json.dumps({"metric": "stub", "value": 1.0, "n_gpus": world if mode != "lie" else 1, "extras": {}}))
+''')
+
+
+def run(args, env_extra, timeout=120):
+    env = dict(os.environ, **env_extra)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    return subprocess.run([sys.executable, BENCH] + args, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                          text=True, timeout=timeout)
+
+
+def stub_cmd(tmp_path, mode):
+    stub = tmp_path / "stub_worker.py"
+    stub.write_text(STUB)
+    return json.dumps([sys.executable, str(stub), str(tmp_path), mode])
+
+
+@pytest.mark.parametrize("n", [2, 4])
+def test_self_launch_starts_one_rank_per_device(tmp_path, n):
+    p = run(["--gpus", str(n), "--worker-cmd", stub_cmd(tmp_path, "ok")], {"MXLO_BENCH_FAKE_DEVICE_COUNT": str(n)})
+    assert p.returncode == 0, p.stderr
+    recs = [json.load(open(tmp_path / f"rank{r}.json")) for r in range(n)]
+    assert [int(r["RANK"]) for r in recs] == list(range(n))
+    assert [int(r["LOCAL_RANK"]) for r in recs] == list(range(n))            # one device per rank
+    assert {r["WORLD_SIZE"] for r in recs} == {str(n)} and {r["LOCAL_WORLD_SIZE"] for r in recs} == {str(n)}
+    assert {r["MASTER_ADDR"] for r in recs} == {"127.0.0.1"} and len({r["MASTER_PORT"] for r in recs}) == 1
+    assert {r["HSA_ENABLE_IPC_MODE_LEGACY"] for r in recs} == {"0"}
+    assert len({r["pid"] for r in recs}) == n                                # N distinct processes
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1                                                   # ONE JSON line, rank 0's
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == n and "self-launch: %d processes" % n in out["config"]["launcher"]
+
+
+def test_too_few_devices_is_a_loud_failure(tmp_path):
+    p = run(["--gpus", "2", "--worker-cmd", stub_cmd(tmp_path, "ok")], {"MXLO_BENCH_FAKE_DEVICE_COUNT": "1"})
+    assert p.returncode != 0
+    assert "only 1 HIP device(s) visible" in p.stderr and "--gpus 2" in p.stderr
+    assert not list(tmp_path.glob("rank*.json"))                             # nothing was started
+    assert not [ln for ln in p.stdout.splitlines() if ln.strip().startswith("{")]
+
+
+def test_rccl_with_all_ranks_on_one_device_is_refused(tmp_path):
+    p = run(["--gpus", "2", "--single-device", "--worker-cmd", stub_cmd(tmp_path, "ok")], {"MXLO_BENCH_FAKE_DEVICE_COUNT": "1"})
+    assert p.returncode != 0 and "--backend gloo" in p.stderr
+    p = run(["--gpus", "2", "--single-device", "--backend", "gloo", "--worker-cmd", stub_cmd(tmp_path, "ok")],
+            {"MXLO_BENCH_FAKE_DEVICE_COUNT": "1"})
+    assert p.returncode == 0, p.stderr                                       # the debugging shape still launches 2 ranks
+    assert len(list(tmp_path.glob("rank*.json"))) == 2
+
+
+def test_a_failing_rank_stops_the_others_and_fails_the_run(tmp_path):
+    import time
+    t0 = time.time()
+    p = run(["--gpus", "3", "--worker-cmd", stub_cmd(tmp_path, "fail")], {"MXLO_BENCH_FAKE_DEVICE_COUNT": "3"})
+    assert p.returncode != 0 and "rank 1 exited with status 7" in p.stderr
+    assert time.time() - t0 < 40                                             # ranks 0 and 2 were terminated, not awaited
+    assert not [ln for ln in p.stdout.splitlines() if ln.strip().startswith("{")]
+    for r in (0, 2):
+        pid = json.load(open(tmp_path / f"rank{r}.json"))["pid"]
+        assert not os.path.exists(f"/proc/{pid}") or open(f"/proc/{pid}/stat").read().split()[2] == "Z"
+
+
+def test_rank0_reporting_the_wrong_world_is_rejected(tmp_path):
+    p = run(["--gpus", "2", "--worker-cmd", stub_cmd(tmp_path, "lie")], {"MXLO_BENCH_FAKE_DEVICE_COUNT": "2"})
+    assert p.returncode != 0 and "n_gpus=1" in p.stderr
+
+
+def test_worker_refuses_a_world_that_differs_from_gpus():
+    # what the old bench did silently: --gpus 8 with no launcher => one rank. Now an external launcher that starts the
+    # wrong number of ranks is an error in the worker itself (checked before any device is touched)
+    env = {"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0", "MXLO_BENCH_FAKE_DEVICE_COUNT": "8"}
+    p = subprocess.run([sys.executable, BENCH, "--gpus", "4"], env=dict(os.environ, **env), stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, text=True, timeout=300)
+    assert p.returncode != 0 and "--gpus 4 but WORLD_SIZE=2" in p.stderr

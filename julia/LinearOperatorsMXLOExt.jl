@@ -333,8 +333,13 @@ function apply_columns(f, res::MXMatrix, m::MXMatrix, α, β)
   end
   res
 end
-LinearAlgebra.mul!(res::MXMatrix, op::LinearOperator{T, MXVector{T}}, m::MXMatrix, α, β) where {T} =
+function LinearAlgebra.mul!(res::MXMatrix, op::LinearOperator{T, MXVector{T}}, m::MXMatrix, α, β) where {T}
+  # the reference leaves this to BLAS / broadcast (DimensionMismatch); the device closures take raw pointers and their
+  # sizes from the operator, so the row counts are checked here, before any launch
+  (size(m, 1) == size(op, 2) && size(res, 1) == size(op, 1) && size(m, 2) == size(res, 2)) ||
+    throw(LinearOperatorException("shape mismatch"))
   apply_columns(op.prod!, res, m, α, β)
+end
 function LinearAlgebra.mul!(res::MXMatrix, op::LinearOperators.AdjointLinearOperator{T, <:LinearOperator{T, MXVector{T}}},
                             m::MXMatrix, α, β) where {T}
   p = op.parent

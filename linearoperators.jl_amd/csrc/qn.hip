@@ -1545,8 +1545,13 @@ int32_t panel_gemm_big(mxlo_ctx *ctx, const std::vector<const T *> &in, const st
 #include <unordered_set>
 static std::mutex g_qn_mu;
 static std::unordered_set<const mxlo_qn *> g_qn_live;
-static void qn_live_add(const mxlo_qn *h) {
+static int64_t g_qn_next_id = 1;   // process-unique handle id (under g_qn_mu)
+static void qn_live_add(mxlo_qn *h) {
   std::lock_guard<std::mutex> lk(g_qn_mu);
+  // The generation starts at (unique id << 32): a handle allocated later at the SAME address as a destroyed one can
+  // never present the generation a graph captured from its predecessor (the staleness check compares pointer +
+  // generation; state changes add 1, 2^32 of them per handle would be needed to reach the next id).
+  h->generation = g_qn_next_id++ << 32;
   g_qn_live.insert(h);
 }
 static void qn_live_remove(const mxlo_qn *h) {

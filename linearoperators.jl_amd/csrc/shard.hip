@@ -21,6 +21,8 @@
 #include <cstdio>
 #include <cstring>
 #include <functional>
+#include <initializer_list>
+#include <utility>
 #include <mutex>
 #include <set>
 #include <string>
@@ -55,20 +57,36 @@ struct Worker {
   std::string err;
 };
 
-struct Barrier {   // reusable host barrier for the loopback transport
+struct Barrier {   // reusable host barrier for the loopback transport, with an abort path: a shard that fails
+                   // anywhere (before or inside its collective) releases the others instead of leaving them waiting
   std::mutex mu;
   std::condition_variable cv;
   int n = 0, count = 0, gen = 0;
-  void wait() {
+  bool aborted = false;
+  bool wait() {   // false: the round was aborted (the caller returns an error)
     std::unique_lock<std::mutex> lk(mu);
+    if (aborted) return false;
     const int g = gen;
     if (++count == n) {
       count = 0;
       ++gen;
       cv.notify_all();
-    } else {
-      cv.wait(lk, [&] { return gen != g; });
+      return true;
     }
+    cv.wait(lk, [&] { return gen != g || aborted; });
+    return !aborted;
+  }
+  void abort() {
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      aborted = true;
+    }
+    cv.notify_all();
+  }
+  void reset() {   // between calls (no worker is inside a collective: run_all holds the call mutex)
+    std::lock_guard<std::mutex> lk(mu);
+    aborted = false;
+    count = 0;
   }
 };
 
@@ -104,11 +122,14 @@ struct mxlo_shard_ctx {
     int rank;
   };
   std::vector<HookUser> users;
+  std::mutex call_mu;       // one `_sharded` call at a time per shard ctx (two host threads may share one)
+  bool poisoned = false;    // RCCL transport: a shard failed while its peers may already sit in a collective
 };
 
 struct mxlo_qn_sharded {
   mxlo_shard_ctx *s = nullptr;
   std::vector<mxlo_qn *> h;
+  std::vector<int64_t> nloc;   // rows per shard (argument checks on the calling thread)
 };
 
 namespace {
@@ -127,26 +148,33 @@ int32_t loop_hook(void *user, void *dev_buf, int64_t count, void *stream_) {
   const int me = u->rank, n = s->ndev;
   hipStream_t st = (hipStream_t)stream_;
   if (count <= 0) return 0;
-  if (count > kLoopCap) return 1;
+  auto fail = [&]() {   // release the peers: they return an error from their own wait()
+    s->bar.abort();
+    return 1;
+  };
+  if (count > kLoopCap) return fail();
   s->cur[me] = (const double *)dev_buf;
-  if (hipEventRecord(s->ev_ready[me], st) != hipSuccess) return 1;
-  s->bar.wait();                                           // every shard's scalars are enqueued and recorded
+  if (hipEventRecord(s->ev_ready[me], st) != hipSuccess) return fail();
+  if (!s->bar.wait()) return 1;                            // every shard's scalars are enqueued and recorded
   PtrPack pk;
   for (int r = 0; r < n; ++r) {
     pk.p[r] = s->cur[r];
-    if (r != me && hipStreamWaitEvent(st, s->ev_ready[r], 0) != hipSuccess) return 1;
+    if (r != me && hipStreamWaitEvent(st, s->ev_ready[r], 0) != hipSuccess) return fail();
   }
   hipLaunchKernelGGL(loop_sum_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, s->tmp[me], pk, n, count);
-  if (hipEventRecord(s->ev_read[me], st) != hipSuccess) return 1;
-  s->bar.wait();                                           // nobody overwrites its buffer before all have read it
+  if (hipGetLastError() != hipSuccess) return fail();
+  if (hipEventRecord(s->ev_read[me], st) != hipSuccess) return fail();
+  if (!s->bar.wait()) return 1;                            // nobody overwrites its buffer before all have read it
   for (int r = 0; r < n; ++r)
-    if (r != me && hipStreamWaitEvent(st, s->ev_read[r], 0) != hipSuccess) return 1;
-  if (hipMemcpyAsync(dev_buf, s->tmp[me], sizeof(double) * count, hipMemcpyDeviceToDevice, st) != hipSuccess) return 1;
-  s->bar.wait();                                           // events may be re-recorded by the next collective
+    if (r != me && hipStreamWaitEvent(st, s->ev_read[r], 0) != hipSuccess) return fail();
+  if (hipMemcpyAsync(dev_buf, s->tmp[me], sizeof(double) * count, hipMemcpyDeviceToDevice, st) != hipSuccess) return fail();
+  if (!s->bar.wait()) return 1;                            // events may be re-recorded by the next collective
   return 0;
 }
 
-void worker_main(Worker *w) {
+void worker_main(Worker *w, int device) {
+  (void)hipSetDevice(device);   // the entry points bind their ctx's device themselves; this keeps anything else the
+                                // thread touches (RCCL's internal calls) on the right device from the first call on
   for (;;) {
     std::function<int32_t()> job;
     {
@@ -167,13 +195,27 @@ void worker_main(Worker *w) {
   }
 }
 
-// run f(i) on worker i for every shard; returns the first non-zero status
+// run f(i) on worker i for every shard; returns the first non-zero status. Serialised per shard ctx. A shard that
+// fails releases the loopback barrier (its peers return MXLO_EREDUCE instead of waiting forever); on the RCCL
+// transport peers may already be inside a device-side collective that can never complete, so the ctx is poisoned:
+// every later call returns MXLO_ESTATE and destroy aborts the communicators instead of draining them.
 int32_t run_all(mxlo_shard_ctx *s, const std::function<int32_t(int)> &f) {
+  std::lock_guard<std::mutex> call_lock(s->call_mu);
+  if (s->poisoned) {
+    set_serr("this shard ctx is unusable: an earlier sharded call failed on one device while the others were inside an "
+             "RCCL collective; destroy it and create a new one");
+    return MXLO_ESTATE;
+  }
+  if (s->loopback) s->bar.reset();
   for (int i = 0; i < s->ndev; ++i) {
     Worker *w = s->workers[i];
     {
       std::lock_guard<std::mutex> lk(w->mu);
-      w->job = [&f, i]() { return f(i); };
+      w->job = [&f, s, i]() {
+        const int32_t st = f(i);
+        if (st != 0 && s->loopback) s->bar.abort();
+        return st;
+      };
       w->done = false;
       w->has = true;
     }
@@ -189,7 +231,27 @@ int32_t run_all(mxlo_shard_ctx *s, const std::function<int32_t(int)> &f) {
       set_serr("shard %d (device %d): %s", i, s->dev[i], w->err.c_str());
     }
   }
+  if (first != 0 && !s->loopback && s->ndev > 1) s->poisoned = true;
   return first;
+}
+
+// Per-shard arguments are checked on the CALLING thread, before any worker starts: a bad pointer on one shard must not
+// leave the other shards waiting in their collective.
+int32_t check_shard_ptrs(const mxlo_shard_ctx *s, const char *fn, const int64_t *n_local,
+                         std::initializer_list<std::pair<const char *, const void *const *>> arrays) {
+  for (int i = 0; i < s->ndev; ++i) {
+    if (n_local && n_local[i] < 0) {
+      set_serr("%s: n_local[%d] = %lld is negative", fn, i, (long long)n_local[i]);
+      return MXLO_EINVAL;
+    }
+    if (n_local && n_local[i] == 0) continue;   // an empty shard may pass NULL
+    for (const auto &a : arrays)
+      if (!a.second[i]) {
+        set_serr("%s: %s[%d] is NULL", fn, a.first, i);
+        return MXLO_EINVAL;
+      }
+  }
+  return MXLO_OK;
 }
 
 }  // namespace
@@ -211,7 +273,7 @@ API int32_t mxlo_shard_ctx_destroy(mxlo_shard_ctx *s) {
   for (int i = 0; i < (int)s->ctx.size(); ++i) {
     (void)hipSetDevice(s->dev[i]);
     if (s->ctx[i]) (void)mxlo_ctx_destroy(s->ctx[i]);
-    if (i < (int)s->comms.size() && s->comms[i]) (void)ncclCommDestroy(s->comms[i]);
+    if (i < (int)s->comms.size() && s->comms[i]) (void)(s->poisoned ? ncclCommAbort(s->comms[i]) : ncclCommDestroy(s->comms[i]));
     if (i < (int)s->tmp.size() && s->tmp[i]) (void)hipFree(s->tmp[i]);
     if (i < (int)s->ev_ready.size() && s->ev_ready[i]) (void)hipEventDestroy(s->ev_ready[i]);
     if (i < (int)s->ev_read.size() && s->ev_read[i]) (void)hipEventDestroy(s->ev_read[i]);
@@ -296,7 +358,7 @@ API int32_t mxlo_shard_ctx_create(int32_t ndev, const int32_t *dev_ids, mxlo_sha
     for (int i = 0; i < ndev; ++i) {
       Worker *w = new Worker();
       s->workers.push_back(w);
-      w->th = std::thread(worker_main, w);
+      w->th = std::thread(worker_main, w, s->dev[i]);
     }
   }
   (void)hipSetDevice(prev);
@@ -337,6 +399,7 @@ API int32_t mxlo_householder_mul_sharded(mxlo_shard_ctx *s, int32_t dtype, void 
                                          const void *const *v, const int64_t *n_local, double alpha, double beta,
                                          int32_t flags) {
   SHARD_REQUIRE(s && res && h && v && n_local, "mxlo_householder_mul_sharded: NULL argument");
+  if (int32_t e = check_shard_ptrs(s, "mxlo_householder_mul_sharded", n_local, {{"res", (const void *const *)res}, {"h", h}, {"v", v}})) return e;
   return run_all(s, [&](int i) {
     return mxlo_householder_mul(s->ctx[i], dtype, res[i], h[i], v[i], n_local[i], alpha, beta, flags);
   });
@@ -346,6 +409,7 @@ API int32_t mxlo_householder_mul_sharded(mxlo_shard_ctx *s, int32_t dtype, void 
 API int32_t mxlo_diag_mul_sharded(mxlo_shard_ctx *s, int32_t dtype, void *const *res, const void *const *d,
                                   const void *const *v, const int64_t *n_local, double alpha, double beta, int32_t flags) {
   SHARD_REQUIRE(s && res && d && v && n_local, "mxlo_diag_mul_sharded: NULL argument");
+  if (int32_t e = check_shard_ptrs(s, "mxlo_diag_mul_sharded", n_local, {{"res", (const void *const *)res}, {"d", d}, {"v", v}})) return e;
   return run_all(s, [&](int i) {
     return mxlo_diag_mul(s->ctx[i], dtype, res[i], d[i], v[i], n_local[i], n_local[i], alpha, beta, flags);
   });
@@ -364,9 +428,11 @@ API int32_t mxlo_qn_destroy_sharded(mxlo_qn_sharded *q) {
 API int32_t mxlo_qn_create_sharded(mxlo_shard_ctx *s, int32_t kind, int32_t dtype, const int64_t *n_local, int64_t mem,
                                    int32_t scaling, int32_t damped, double sigma2, double sigma3, mxlo_qn_sharded **out) {
   SHARD_REQUIRE(s && n_local && out, "mxlo_qn_create_sharded: NULL argument");
+  if (int32_t e = check_shard_ptrs(s, "mxlo_qn_create_sharded", n_local, {})) return e;
   mxlo_qn_sharded *q = new mxlo_qn_sharded();
   q->s = s;
   q->h.assign(s->ndev, nullptr);
+  q->nloc.assign(n_local, n_local + s->ndev);
   const int32_t st = run_all(s, [&](int i) {
     return mxlo_qn_create(s->ctx[i], kind, dtype, n_local[i], mem, scaling, damped, sigma2, sigma3, &q->h[i]);
   });
@@ -385,6 +451,7 @@ API mxlo_qn *mxlo_qn_sharded_get(mxlo_qn_sharded *q, int32_t i) {
 // push!(op, s, y): `accepted` is the replicated decision (identical on every shard by construction; checked).
 API int32_t mxlo_qn_push_sharded(mxlo_qn_sharded *q, const void *const *sv, const void *const *yv, int32_t *accepted) {
   SHARD_REQUIRE(q && sv && yv && accepted, "mxlo_qn_push_sharded: NULL argument");
+  if (int32_t e = check_shard_ptrs(q->s, "mxlo_qn_push_sharded", q->nloc.data(), {{"s", sv}, {"y", yv}})) return e;
   std::vector<int32_t> acc(q->h.size(), -1);
   const int32_t st = run_all(q->s, [&](int i) { return mxlo_qn_push(q->h[i], sv[i], yv[i], &acc[i]); });
   if (st != MXLO_OK) return st;
@@ -401,22 +468,26 @@ API int32_t mxlo_qn_push_sharded(mxlo_qn_sharded *q, const void *const *sv, cons
 API int32_t mxlo_qn_mul_sharded(mxlo_qn_sharded *q, void *const *res, const void *const *x, double alpha, double beta,
                                 int32_t flags) {
   SHARD_REQUIRE(q && res && x, "mxlo_qn_mul_sharded: NULL argument");
+  if (int32_t e = check_shard_ptrs(q->s, "mxlo_qn_mul_sharded", q->nloc.data(), {{"res", (const void *const *)res}, {"x", x}})) return e;
   return run_all(q->s, [&](int i) { return mxlo_qn_mul(q->h[i], res[i], x[i], alpha, beta, flags); });
 }
 
 API int32_t mxlo_qn_mul_shifted_sharded(mxlo_qn_sharded *q, void *const *res, const void *const *x, double alpha,
                                         double beta, double sigma, int32_t flags) {
   SHARD_REQUIRE(q && res && x, "mxlo_qn_mul_shifted_sharded: NULL argument");
+  if (int32_t e = check_shard_ptrs(q->s, "mxlo_qn_mul_shifted_sharded", q->nloc.data(), {{"res", (const void *const *)res}, {"x", x}})) return e;
   return run_all(q->s, [&](int i) { return mxlo_qn_mul_shifted(q->h[i], res[i], x[i], alpha, beta, sigma, flags); });
 }
 
 API int32_t mxlo_qn_solve_shifted_sharded(mxlo_qn_sharded *q, void *const *x, const void *const *b, double sigma) {
   SHARD_REQUIRE(q && x && b, "mxlo_qn_solve_shifted_sharded: NULL argument");
+  if (int32_t e = check_shard_ptrs(q->s, "mxlo_qn_solve_shifted_sharded", q->nloc.data(), {{"x", (const void *const *)x}, {"b", b}})) return e;
   return run_all(q->s, [&](int i) { return mxlo_qn_solve_shifted(q->h[i], x[i], b[i], sigma); });
 }
 
 API int32_t mxlo_qn_diag_sharded(mxlo_qn_sharded *q, void *const *d) {
   SHARD_REQUIRE(q && d, "mxlo_qn_diag_sharded: NULL argument");
+  if (int32_t e = check_shard_ptrs(q->s, "mxlo_qn_diag_sharded", q->nloc.data(), {{"d", (const void *const *)d}})) return e;
   return run_all(q->s, [&](int i) { return mxlo_qn_diag(q->h[i], d[i]); });
 }
 

@@ -466,7 +466,7 @@ def mul(res: torch.Tensor, op, v: torch.Tensor, alpha=None, beta=None):
         return res
     if not (v.shape[0] == op.size(2) and res.shape[0] == op.size(1)):
         raise LinearOperatorException("shape mismatch")
-    op.nprod += 1                                      # increase_nprod!
+    op.nprod += _COUNT                                      # increase_nprod!
     if _nargs(op.prod) == 4:
         op.prod(res, v, alpha, beta)
     else:
@@ -484,9 +484,20 @@ def columnwise(fn):
     return fn
 
 
+def matrixwise(fn):
+    """Mark a closure of this package that accepts matrices because its REFERENCE closure does: `-op`, `x*op`, `op1+op2`
+    call `mul!(res::AbstractVecOrMat, …)` on their operands (src/operations.jl:103-105, 165-167, 187-197), and `mul`
+    routes matrices. (`op1*op2` does not qualify: its vector temporaries fail on matrices in the reference too.)"""
+    fn._matrixwise = True
+    return fn
+
+
 def _apply_closure_to_matrix(fn, res, m, alpha, beta):
     if fn is None:
         raise LinearOperatorException("Not implemented")                      # src/adjtrans.jl:155,223
+    if getattr(fn, "_matrixwise", False):
+        fn(res, m, alpha, beta)
+        return touched(res)
     if not getattr(fn, "_columnwise", False):
         if (getattr(fn, "__module__", "") or "").startswith(__name__.rsplit(".", 1)[0]):
             raise LinearOperatorException("mul! on matrices: this operator's closure is defined on vectors only "
@@ -530,6 +541,12 @@ def _mul_matrix(res, op, m, alpha, beta):
         return touched(res)
     if not hasattr(op, "prod"):
         raise LinearOperatorException("mul! on matrices: not defined for this operator type")
+    # The reference hands the matrices to the closure unchecked (src/operations.jl:34-36) and BLAS / broadcast throw
+    # DimensionMismatch; the device closures take RAW POINTERS and their sizes from the operator, so a wrongly shaped
+    # operand would read or write out of bounds: check here, before anything is launched.
+    if not (m.dim() == 2 and res.dim() == 2 and m.shape[0] == op.size(2) and res.shape[0] == op.size(1)
+            and m.shape[1] == res.shape[1]):
+        raise LinearOperatorException("shape mismatch")
     return _apply_closure_to_matrix(op.prod, res, m, alpha, beta)
 
 
@@ -557,7 +574,7 @@ def _complex_of_real(v, ctype):
     return out
 
 
-_PLANES: dict = {}
+_COUNT = 1      # what increase_nprod!/ntprod!/nctprod! add (0 while the second plane of a real-on-complex apply runs)
 
 
 def _mul_real_op_complex_vec(res, op, v, alpha, beta):
@@ -576,18 +593,29 @@ def _mul_real_op_complex_vec(res, op, v, alpha, beta):
     if not (v.shape[0] == op.size(2) and res.shape[0] == op.size(1)):
         raise LinearOperatorException("shape mismatch")
     nin, nout = v.shape[0], res.shape[0]
-    key = (nin, nout, comp, v.device)
-    bufs = _PLANES.get(key)
-    if bufs is None:                                    # temporaries cached per shape (the reference allocates per call)
-        if len(_PLANES) > 8:
-            _PLANES.clear()
-        bufs = _PLANES[key] = tuple(torch.empty(k, dtype=comp, device=v.device) for k in (nin, nin, nout, nout))
+    # plane temporaries live with the operator (lazily, like Mv / Mtu: operators are not re-entrant, src §5), keyed by
+    # the stream they were last used on so that applies issued on two streams never share them
+    root = op
+    while isinstance(root, _Wrapper):
+        root = root.parent
+    key = (nin, nout, comp, v.device, torch.cuda.current_stream(v.device).cuda_stream if v.is_cuda else 0)
+    cache = root.__dict__.setdefault("_planes", {})
+    bufs = cache.get(key)
+    if bufs is None:
+        if len(cache) >= 4:
+            cache.clear()
+        bufs = cache[key] = tuple(torch.empty(k, dtype=comp, device=v.device) for k in (nin, nin, nout, nout))
     xr, xi, yr, yi = bufs
     ctx = get_ctx(v.device)
     code = dtype_code(v.dtype, True)
     _lib.call("mxlo_split_c", ctx.handle, code, ptr(xr), ptr(xi), ptr(v), nin)
+    global _COUNT
     mul(yr, op, xr)
-    mul(yi, op, xi)
+    saved, _COUNT = _COUNT, 0                           # the reference counts ONE product per apply (its closure runs once, on
+    try:                                                # the complex vectors): the second plane is not a second mul!, for the
+        mul(yi, op, xi)                                 # operator and for every operator its closure re-enters
+    finally:
+        _COUNT = saved
     _lib.call("mxlo_join_c", ctx.handle, code, ptr(res), ptr(yr), ptr(yi), nout, *_c4(alpha, beta),
               scalar_flags(res.dtype, alpha, beta))
     return touched(res)
@@ -623,17 +651,17 @@ def _mul_adjoint(res, op, v, alpha, beta):
     if ishermitian(p):
         return mul(res, p, v, alpha, beta)
     if p.ctprod is not None:
-        p.nctprod += 1
+        p.nctprod += _COUNT
         return _call_t(res, p.ctprod, v, alpha, beta, p)
     tprod = p.tprod
     if tprod is None:
         if issymmetric(p):
-            p.nprod += 1
+            p.nprod += _COUNT
             tprod = p.prod
         else:
             raise LinearOperatorException("unable to infer conjugate transpose operator")
     else:
-        p.ntprod += 1
+        p.ntprod += _COUNT
     return _call_conj_sandwich(res, tprod, v, alpha, beta, p)
 
 
@@ -645,17 +673,17 @@ def _mul_transpose(res, op, v, alpha, beta):
     if issymmetric(p):
         return mul(res, p, v, alpha, beta)
     if p.tprod is not None:
-        p.ntprod += 1
+        p.ntprod += _COUNT
         return _call_t(res, p.tprod, v, alpha, beta, p)
     ctprod = p.ctprod
     if ctprod is None:
         if ishermitian(p):
-            p.nprod += 1
+            p.nprod += _COUNT
             ctprod = p.prod
         else:
             raise LinearOperatorException("unable to infer transpose operator")
     else:
-        p.nctprod += 1
+        p.nctprod += _COUNT
     return _call_conj_sandwich(res, ctprod, v, alpha, beta, p)
 
 
@@ -774,9 +802,9 @@ def neg(op):
         return transpose(neg(op.parent))
     if isinstance(op, ConjugateLinearOperator):
         return conj(neg(op.parent))
-    prod = lambda res, v, a, b: mul(res, op, v, -a, b)
-    tprod = lambda res, u, a, b: mul(res, transpose(op), u, -a, b)
-    ctprod = lambda res, w, a, b: mul(res, adjoint(op), w, -a, b)
+    prod = matrixwise(lambda res, v, a, b: mul(res, op, v, -a, b))
+    tprod = matrixwise(lambda res, u, a, b: mul(res, transpose(op), u, -a, b))
+    ctprod = matrixwise(lambda res, w, a, b: mul(res, adjoint(op), w, -a, b))
     out = LinearOperator(op.eltype, op.nrow, op.ncol, op.symmetric, op.hermitian, prod, tprod, ctprod,
                          S=storage_type(op))
     out._deps = (op,)
@@ -817,10 +845,10 @@ def scale_op(op, x):
     if isinstance(op, ConjugateLinearOperator):
         return conj(scale_op(op.parent, conj_scalar(x)))            # conj(op.parent * conj(x)) (src/adjtrans.jl:268)
     T = op.eltype
-    prod = lambda res, v, a, b: mul(res, op, v, x * a, b)
-    tprod = lambda res, u, a, b: mul(res, transpose(op), u, x * a, b)
+    prod = matrixwise(lambda res, v, a, b: mul(res, op, v, x * a, b))
+    tprod = matrixwise(lambda res, u, a, b: mul(res, transpose(op), u, x * a, b))
     xc = conj_scalar(x)
-    ctprod = lambda res, w, a, b: mul(res, adjoint(op), w, xc * a, b)  # x' (src/operations.jl:166)
+    ctprod = matrixwise(lambda res, w, a, b: mul(res, adjoint(op), w, xc * a, b))  # x' (src/operations.jl:166)
     isreal_x = (not _is_complex_scalar(x)) or complex(x).imag == 0      # isreal(x) (src/operations.jl:172)
     if _is_complex_scalar(x):                                            # T = promote_type(eltype(op), typeof(x))
         T = torch.promote_types(T, torch.complex128 if _is_f64_scalar(x) else torch.complex64)
@@ -843,9 +871,9 @@ def add(op1, op2):
     if m1 != m2 or n1 != n2:
         raise LinearOperatorException("shape mismatch")
     T = _promote_eltype(op1, op2)
-    prod = lambda res, v, a, b: sum_prod(res, op1, op2, v, a, b)
-    tprod = lambda res, u, a, b: sum_prod(res, transpose(op1), transpose(op2), u, a, b)
-    ctprod = lambda res, w, a, b: sum_prod(res, adjoint(op1), adjoint(op2), w, a, b)
+    prod = matrixwise(lambda res, v, a, b: sum_prod(res, op1, op2, v, a, b))
+    tprod = matrixwise(lambda res, u, a, b: sum_prod(res, transpose(op1), transpose(op2), u, a, b))
+    ctprod = matrixwise(lambda res, w, a, b: sum_prod(res, adjoint(op1), adjoint(op2), w, a, b))
     symm = issymmetric(op1) and issymmetric(op2)
     herm = ishermitian(op1) and ishermitian(op2)
     S = promote_storage(storage_type(op1), storage_type(op2))

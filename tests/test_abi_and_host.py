@@ -236,3 +236,46 @@ def test_columnwise_closures_on_matrices_without_device(lo):
     plain = lo.LinearOperator(torch.float64, 3, 3, True, True, ops.sum_prod, None, None, S=S)   # a closure of the package, unmarked
     with pytest.raises(lo.LinearOperatorException, match="vectors only"):
         lo.mul(torch.empty(3, 2), plain, m)
+
+
+def test_matrix_operands_with_wrong_row_counts_are_refused_before_any_launch(lo):
+    """`mul!` on matrices with a base operator must compare the ROW counts of `res` and `m` with the
+    operator: the device closures take raw pointers and their sizes from the operator, so the reference's
+    DimensionMismatch (BLAS / broadcast) has to be raised by the host mirror. CPU tensors, a closure that must not run."""
+    from linearoperators_jl_amd import operators as ops
+    S = lo.Storage(torch.float64, torch.device("cpu"))
+    ran = []
+    op = lo.LinearOperator(torch.float64, 3, 4, False, False, ops.columnwise(lambda r, v, a, b: ran.append(1)), None, None, S=S)
+    for res, m in ((torch.empty(3, 2), torch.empty(5, 2)),       # m has 5 rows, op has 4 columns
+                   (torch.empty(2, 2), torch.empty(4, 2)),       # res has 2 rows, op has 3
+                   (torch.empty(3, 2), torch.empty(4, 3))):      # column counts differ
+        with pytest.raises(lo.LinearOperatorException, match="shape mismatch"):
+            lo.mul(res, op, m, 1.0, 0.0)
+    assert not ran
+    lo.mul(torch.empty(3, 2), op, torch.empty(4, 2), 1.0, 0.0)
+    assert ran == [1, 1]
+
+
+def test_neg_scale_and_sum_accept_matrices_like_the_reference(lo):
+    """ADVICE r2: `-op`, `x*op`, `op1+op2` call mul!(res::AbstractVecOrMat, …) in the reference (src/operations.jl:103-105,
+    165-167, 187-197), so they take matrices; `op1*op2` (vector temporaries) does not — in the reference either."""
+    from linearoperators_jl_amd import operators as ops
+    S = lo.Storage(torch.float64, torch.device("cpu"))
+    d1, d2 = torch.tensor([2.0, -1.0, 0.5]), torch.tensor([1.0, 3.0, -2.0])
+
+    def diag(d):
+        return lo.LinearOperator(torch.float64, 3, 3, True, True,
+                                 ops.columnwise(lambda r, v, a, b: r.copy_(a * d * v + (b * r if b != 0 else 0))), None, None, S=S)
+    A, B = diag(d1), diag(d2)
+    m = torch.tensor([[1.0, 4.0], [2.0, 5.0], [3.0, 6.0]]).t().contiguous().t()      # Julia layout
+    res = torch.ones(2, 3).t()
+    lo.mul(res, -A, m, 2.0, -1.0)
+    assert torch.equal(res, -2.0 * d1[:, None] * m - 1.0)
+    lo.mul(res, 3.0 * A, m, 1.0, 0.0)
+    assert torch.equal(res, 3.0 * d1[:, None] * m)
+    lo.mul(res, A + B, m, 2.0, 0.0)
+    assert torch.equal(res, 2.0 * (d1 + d2)[:, None] * m)
+    lo.mul(res, (A - B).T, m)                                                         # symmetric parent: same closure
+    assert torch.equal(res, (d1 - d2)[:, None] * m)
+    with pytest.raises(lo.LinearOperatorException, match="vectors only"):
+        lo.mul(res, A * B, m)

@@ -100,7 +100,12 @@ const char *mxlo_last_error(void);
  * ctx does not own a caller-provided stream. */
 int32_t mxlo_ctx_create(int32_t device_id, void *stream, mxlo_ctx **out);
 int32_t mxlo_ctx_destroy(mxlo_ctx *ctx);
-/* Switching streams inserts an event dependency old -> new, so the ctx workspaces stay stream-ordered. */
+/* Switching streams inserts an event dependency old -> new (event recorded on the old stream, waited for by the new
+ * one), so ALL work issued through one ctx is totally ordered whatever streams it is put on: the reduction workspace,
+ * the scalar buffer, the quasi-Newton handles and the exchange slots of the single-launch Householder (one slot set
+ * + epoch word per ctx, valid for <= 1 fused launch in flight) are never touched by two kernels at once. Callers that
+ * want two applies to OVERLAP use two ctxs (one per stream). tests/test_gpu_leaves.py::
+ * test_single_launch_householder_two_streams_one_ctx alternates two streams on one ctx. */
 int32_t mxlo_ctx_set_stream(mxlo_ctx *ctx, void *stream);
 int32_t mxlo_ctx_sync(mxlo_ctx *ctx);
 /* info[0]=device id, [1]=CU count, [2]=workspace bytes, [3]=max reduction columns */
@@ -108,7 +113,7 @@ int32_t mxlo_ctx_info(mxlo_ctx *ctx, int64_t info[4]);
 /* Launch-geometry / algorithm-variant knobs for sweeps and for tests that compare two device implementations. Keys:
  * "blocks_per_cu", "nt_min_bytes", "red_blocks_per_cu", "graph_direct_max", "house_fused", "house_reverse",
  * "cherm_two_pass", "lbfgs_inv_mode", "gemm_tile", "extend_tiles_per_block", "fuse_finalize", "combine_blocks_per_cu",
- * "dots_max_nc". Unknown key or out-of-range value -> MXLO_EINVAL. */
+ * "dots_max_nc", "push_wide", "push_fused" (1: one-pass push!, 0: the copies + dual-x dots schedule it replaced). Unknown key or out-of-range value -> MXLO_EINVAL. */
 int32_t mxlo_ctx_tune(mxlo_ctx *ctx, const char *key, int64_t value);
 
 /* Row-sharding hook. When set, EVERY global reduction this ctx performs

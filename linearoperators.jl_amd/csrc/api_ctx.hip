@@ -87,7 +87,9 @@ MXLO_API int32_t mxlo_ctx_set_stream(mxlo_ctx *ctx, void *stream) {
   MXLO_REQUIRE(ctx, MXLO_EINVAL, "ctx is NULL");
   MXLO_DEVICE_GUARD(ctx);
   hipStream_t next = (hipStream_t)stream;
-  if (next != ctx->stream && !ctx->capturing) {
+  MXLO_REQUIRE(!(ctx->capturing && next != ctx->stream), MXLO_ESTATE,
+               "mxlo_ctx_set_stream: a graph capture is open on this ctx; end it before changing the stream");
+  if (next != ctx->stream) {
     // the reduction workspace, the scalar buffer and the quasi-Newton handles of this ctx are ordered by the
     // stream: work already queued on the old stream must complete before the new stream touches them
     if (!ctx->switch_event) MXLO_HIP(hipEventCreateWithFlags(&ctx->switch_event, hipEventDisableTiming));
@@ -323,6 +325,12 @@ MXLO_API int32_t mxlo_ctx_tune(mxlo_ctx *ctx, const char *key, int64_t value) {
   } else if (!strcmp(key, "combine_blocks_per_cu")) {
     MXLO_REQUIRE(value >= 0 && value <= 64, MXLO_EINVAL, "combine_blocks_per_cu out of range");
     ctx->tune.combine_blocks_per_cu = (int)value;
+  } else if (!strcmp(key, "push_wide")) {
+    MXLO_REQUIRE(value == 0 || value == 1, MXLO_EINVAL, "push_wide must be 0 or 1");
+    ctx->tune.push_wide = (int)value;
+  } else if (!strcmp(key, "push_fused")) {
+    MXLO_REQUIRE(value == 0 || value == 1, MXLO_EINVAL, "push_fused must be 0 or 1");
+    ctx->tune.push_fused = (int)value;
   } else if (!strcmp(key, "dots_max_nc")) {
     MXLO_REQUIRE(value >= 1 && value <= 20, MXLO_EINVAL, "dots_max_nc out of range");
     ctx->tune.dots_max_nc = (int)value;

@@ -130,6 +130,8 @@ struct Tune {
                            // workgroup), 32 / 64 / 128 force one, -1 = generic fallback kernel only
   int fuse_finalize = 1;   // reductions of <= 4 columns: last-arriving workgroup finalizes in the dots kernel
   int combine_blocks_per_cu = 0;   // panel_combine: 0 = one vector per thread (best measured), k = persistent grid
+  int push_wide = 1;       // one-pass push!: 20 columns per pass while >= 20 remain (0: always <= 10)
+  int push_fused = 1;      // push!(op, s, y): one-pass schedule (new pair held per lane, in-pass slot stores); 0 = copies + dual-x dots
 };
 
 }  // namespace mxlo
@@ -255,5 +257,11 @@ int32_t panel_dots(mxlo_ctx *ctx, const T *const *cols_host, int ncols, const T 
 template <typename T>
 int32_t panel_dots2(mxlo_ctx *ctx, const T *const *cols, int ncols, const T *x1, const T *x2, int64_t n_padded,
                     double *out1, double *out2);
+// push! pass (reductions.hip): dual-x dots over <= 10 panel columns with the new pair in registers, optional in-pass
+// stores into the slot being replaced; LOCAL sums (the caller runs the all-reduce hook)
+template <typename T>
+int32_t panel_push_pass(mxlo_ctx *ctx, const T *const *cols, int ncols, int slot, int slot_src, const T *x1,
+                        const T *x2, int64_t n, int64_t n_padded, T *st1, T *st2, T *stb, double sq, double *out1,
+                        double *out2, double *out_x1x2, double *out_x2x2, double *out_bb);
 
 }  // namespace mxlo

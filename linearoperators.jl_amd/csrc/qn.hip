@@ -996,13 +996,22 @@ int32_t gram_make_consistent(mxlo_qn *h, int64_t except_slot) {
   return MXLO_OK;
 }
 
+template <typename T>
+int32_t fwd_rebuild_after_gram(mxlo_qn *h, int64_t ins);
+
 // Gram-form rebuild of the forward panel after (s, y) was copied into slot `ins` and b[ins] was formed.
 template <typename T>
 int32_t fwd_rebuild_gram(mxlo_qn *h, int64_t ins) {
-  mxlo_ctx *ctx = h->ctx;
-  const int64_t n = h->n, mem = h->mem;
   MXLO_TRY(gram_make_consistent<T>(h, ins));
   MXLO_TRY(gram_update_slot<T>(h, ins));
+  return fwd_rebuild_after_gram<T>(h, ins);
+}
+
+// ... the part after the Gram rows of slot `ins` are in place (shared with the one-pass push!)
+template <typename T>
+int32_t fwd_rebuild_after_gram(mxlo_qn *h, int64_t ins) {
+  mxlo_ctx *ctx = h->ctx;
+  const int64_t n = h->n, mem = h->mem;
   OrdArgs O;
   fill_ord(h, O, /*newest_first=*/false);   // called before insert0 advances: the new pair must come last
   // oldest -> newest with the freshly written slot last: slots (ins+1 .. ins+mem) mod mem
@@ -1107,9 +1116,100 @@ int32_t lbfgs_push_common(mxlo_qn *h, const T *s, const T *y, double ys, double 
   return MXLO_OK;
 }
 
+// push!(op, s, y) in ONE streaming schedule (small-memory layout, aligned s / y, not the
+// reference-ordered forward mode). The two-kernel schedule below moved, for the inverse operator at mem = m:
+//   dots(s, y | y) 3 vectors + 2 device-to-device inserts 4 vectors + S'y over S (m + 1) + dual-x dots over Y (m + 2)
+//   = 2m + 10 vector passes; here:
+//   pass A over S (m - 1 columns + s, y; column `ins` IS s, held per lane) -> S'y_new AND y's, y'y for the decision
+//   [accept / reject on the host, as the reference: src/lbfgs.jl:281-284]
+//   pass B over Y (m - 1 columns + s, y) -> Y's_new, Y'y_new, storing s -> S[:,ins], y -> Y[:,ins] from registers
+//   = 2m + 4 vector passes (m = 10: 9.6 GB instead of 12 GB at n = 5e7). Forward (Gram / compact modes): both panels
+// give both dots (S's, S'y, Y's, Y'y = the four Gram rows of gram_update_slot), pass B also writes b = y ./ sqrt(ys)
+// and |b|^2: 4m + 2*ceil(m/10)*2 + 3 - 2 passes instead of 4m + 15.
+// Nothing of the operator's state is written before the decision (pass A's rows go to scratch), so a rejected pair
+// leaves the operator untouched exactly like the reference.
+template <typename T>
+int32_t lbfgs_push_fused(mxlo_qn *h, const T *s, const T *y, int32_t *accepted) {
+  mxlo_ctx *ctx = h->ctx;
+  const int64_t n = h->n, ins = h->insert0, mem = h->mem;
+  constexpr int VECP = Vec16<T>::N;
+  const int64_t npad = (n + VECP - 1) / VECP * VECP;
+  const bool inverse = h->kind == MXLO_QN_LBFGS_INV;
+  double *misc = h->dsc + h->lay.misc, *scratch = h->dsc + h->lay.dots, *gt = inverse ? nullptr : h->dsc + h->lay.gtmp;
+  if (!inverse) MXLO_TRY(gram_make_consistent<T>(h, ins));   // only after reference-ordered pushes
+  const T *cols[kMaxCols];
+  // columns per pass: 20 while >= 20 remain (s, y are re-read once per pass: wide passes re-read them less), then <= 10
+  int c0s[kMaxMem / 10 + 2], ncs[kMaxMem / 10 + 2], nchunk = 0;
+  for (int64_t c = 0; c < mem;) {
+    const int w = (ctx->tune.push_wide && mem - c >= 20) ? 20 : (int)std::min<int64_t>(10, mem - c);
+    c0s[nchunk] = (int)c;
+    ncs[nchunk++] = w;
+    c += w;
+  }
+  auto pass = [&](void *panel, int chunk, int slot_src, T *st1, T *st2, T *stb, double sq, double *o1, double *o2,
+                  double *oxy, double *oyy, double *obb) -> int32_t {
+    const int c0 = c0s[chunk], nc = ncs[chunk];
+    for (int c = 0; c < nc; ++c) cols[c] = col<T>(panel, h->ld, c0 + c);
+    const int slot = (ins >= c0 && ins < c0 + nc) ? (int)(ins - c0) : -1;
+    return panel_push_pass<T>(ctx, cols, nc, slot, slot_src, s, y, n, npad, st1, st2, stb, sq, o1 ? o1 + c0 : nullptr,
+                              o2 ? o2 + c0 : nullptr, oxy, oyy, obb);
+  };
+  // ---- pass A, first chunk of S: its Gram dots + the decision scalars misc[0] = y's, misc[1] = y'y
+  MXLO_TRY(pass(h->S, 0, 1, nullptr, nullptr, nullptr, 1.0, inverse ? nullptr : gt, inverse ? scratch : gt + 2 * mem,
+                misc, misc + 1, nullptr));
+  MXLO_TRY(allreduce_hook(ctx, misc, 2));
+  double hs[2];
+  MXLO_TRY(read_scalars(h, misc, hs, 2));
+  const double ys = rT<T>(hs[0]), yy = rT<T>(hs[1]);
+  if (ys <= (double)eps_of<T>()) {  // src/lbfgs.jl:281-284
+    *accepted = 0;
+    return MXLO_OK;
+  }
+  *accepted = 1;
+  for (int ch = 1; ch < nchunk; ++ch)   // rest of S
+    MXLO_TRY(pass(h->S, ch, 1, nullptr, nullptr, nullptr, 1.0, inverse ? nullptr : gt, inverse ? scratch : gt + 2 * mem,
+                  nullptr, nullptr, nullptr));
+  T *si = col<T>(h->S, h->ld, ins), *yi = col<T>(h->Y, h->ld, ins);
+  h->ys[ins] = ys;                                                                       // :222
+  h->age[ins] = ++h->pushes;
+  if (h->scaling) h->scaling_factor = rT<T>(ys / yy);                                    // :225
+  h->G_valid = false;
+  if (inverse) {
+    // S'y_new -> column `ins` of SY; Y's_new, Y'y_new straight into their rows; the inserts ride in the first Y pass
+    MXLO_TRY(allreduce_hook(ctx, scratch, mem));
+    hipLaunchKernelGGL(copy_coef_kernel, dim3(1), dim3(64), 0, ctx->stream, scratch, h->dsc + h->lay.SY + ins * mem,
+                       (int)mem, 0);
+    MXLO_LAUNCH_CHECK();
+    for (int ch = 0; ch < nchunk; ++ch)
+      MXLO_TRY(pass(h->Y, ch, 2, ch == 0 ? si : nullptr, ch == 0 ? yi : nullptr, nullptr, 1.0,
+                    h->dsc + h->lay.YS + ins * mem, h->dsc + h->lay.YY + ins * mem, nullptr, nullptr, nullptr));
+    MXLO_TRY(allreduce_hook(ctx, h->dsc + h->lay.YS + ins * mem, mem));
+    MXLO_TRY(allreduce_hook(ctx, h->dsc + h->lay.YY + ins * mem, mem));
+  } else {
+    // forward: b[insert] = y ./ sqrt(ys) (:232) and |b|^2 ride in the first Y pass with the two inserts
+    T *bi = col<T>(h->B, h->ld, ins);
+    const double sq = sizeof(T) == 8 ? std::sqrt(ys) : (double)sqrtf((float)ys);
+    for (int ch = 0; ch < nchunk; ++ch)
+      MXLO_TRY(pass(h->Y, ch, 2, ch == 0 ? si : nullptr, ch == 0 ? yi : nullptr, ch == 0 ? bi : nullptr, sq, gt + mem,
+                    gt + 3 * mem, nullptr, nullptr, ch == 0 ? misc + 16 + ins : nullptr));
+    MXLO_TRY(allreduce_hook(ctx, gt, 4 * mem));
+    MXLO_TRY(allreduce_hook(ctx, misc + 16 + ins, 1));
+    hipLaunchKernelGGL(gram_update_kernel, dim3(1), dim3(64), 0, ctx->stream, h->dsc + h->lay.SS, h->dsc + h->lay.YSf,
+                       h->dsc + h->lay.YY, gt, (int)mem, (int)ins);
+    MXLO_LAUNCH_CHECK();
+    MXLO_TRY(fwd_rebuild_after_gram<T>(h, ins));
+  }
+  h->insert0 = (h->insert0 + 1) % h->mem;  // :253
+  ++h->generation;
+  return sync_meta(h);
+}
+
 template <typename T>
 int32_t lbfgs_push(mxlo_qn *h, const T *s, const T *y, int32_t *accepted) {
   mxlo_ctx *ctx = h->ctx;
+  if (ctx->tune.push_fused && !h->big && h->n >= 1 && ((((uintptr_t)s) | ((uintptr_t)y)) & 15u) == 0 &&
+      !(h->kind == MXLO_QN_LBFGS_FWD && h->push_mode == MXLO_PUSH_REFORDER))
+    return lbfgs_push_fused<T>(h, s, y, accepted);
   double *misc = h->dsc + h->lay.misc;
   const T *cols[2] = {s, y};
   MXLO_TRY(panel_dots<T>(ctx, cols, 2, y, h->n, misc));  // misc[0] = dot(y,s), misc[1] = dot(y,y)

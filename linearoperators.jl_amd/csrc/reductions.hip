@@ -420,6 +420,208 @@ int32_t panel_dots2(mxlo_ctx *ctx, const T *const *cols, int ncols, const T *x1,
   return allreduce_hook(ctx, out2, ncols);
 }
 
+// ---- push! pass: dual-x dots over one panel WITH the new pair held per lane ----------------------------------------
+// One-pass push!: the two-kernel schedule copied s -> S[:,ins], y -> Y[:,ins] (two device-to-device
+// copies, 4 vector passes) and then took the Gram rows as dual-x dots against the freshly copied panel columns,
+// re-reading them. Here a pass over a panel streams every OTHER column once with s_new (x1) and y_new (x2) in
+// registers; the column being replaced is never loaded — its values ARE x1 (S panel) or x2 (Y panel) — and the pass
+// that runs after push!'s accept/reject decision stores x1 / x2 (/ b = x2 ./ sqrt(ys), src/lbfgs.jl:232) into the
+// slot while they are in registers. The decision scalars y's and y'y come out of the FIRST pass (x1·x2, x2·x2 from
+// the same registers), so the separate 2-vector dots pass disappears as well. Same chunk / lane / tree decomposition
+// as panel_dots2_kernel: the Gram rows are bit-identical to the two-kernel schedule's (tested).
+template <typename T, int NC>
+struct PushPassArgs {
+  const T *cols[NC];
+  const T *x1, *x2;        // caller vectors (length n, 16-byte aligned; NOT padded)
+  T *st1, *st2, *stb;      // optional stores: x1 -> st1, x2 -> st2, x2 ./ sq -> stb (padded panel columns)
+  T sq;
+  int slot, slot_src;      // column index replaced by x1 (slot_src 1) / x2 (2); -1: none
+  int64_t nvec;            // vectors per padded column
+  int64_t n;               // valid elements of x1, x2
+};
+
+template <typename T, int NC, int UNROLL, bool NT, bool STORE>
+__global__ void __launch_bounds__(kBlock)
+push_pass_kernel(PushPassArgs<T, NC> A, double *__restrict__ partials) {
+  constexpr int VEC = Vec16<T>::N;
+  using V = typename Vec16<T>::type;
+  const int tid = threadIdx.x;
+  double a1[NC], a2[NC], e12 = 0.0, e22 = 0.0, ebb = 0.0;
+#pragma unroll
+  for (int c = 0; c < NC; ++c) a1[c] = a2[c] = 0.0;
+  auto ld = [&](const T *p, int64_t i) -> V {
+    return NT ? __builtin_nontemporal_load(reinterpret_cast<const V *>(p) + i) : reinterpret_cast<const V *>(p)[i];
+  };
+  const int64_t nfull = A.n / VEC;   // whole vectors of x1 / x2; vector nfull (if any) is partial, the rest padding
+  auto ldx = [&](const T *p, int64_t i) -> V {
+    if (i < nfull) return ld(p, i);
+    V v;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) v[e] = (i * VEC + e < A.n) ? p[i * VEC + e] : T(0);   // zero padding, as in the panel
+    return v;
+  };
+  constexpr int64_t CHUNK = (int64_t)kBlock * UNROLL;
+  const int64_t nchunks = (A.nvec + CHUNK - 1) / CHUNK;
+  for (int64_t ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
+    const int64_t base = ch * CHUNK + tid;
+    V xv1[UNROLL], xv2[UNROLL], cv[UNROLL][NC];
+    bool ok[UNROLL];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      const int64_t i = base + (int64_t)u * kBlock;
+      ok[u] = i < A.nvec;
+      if (ok[u]) {
+        xv1[u] = ldx(A.x1, i);
+        xv2[u] = ldx(A.x2, i);
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+          if (c != A.slot) cv[u][c] = ld(A.cols[c], i);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      if (!ok[u]) continue;
+      const int64_t i = base + (int64_t)u * kBlock;
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        const V col = (c == A.slot) ? (A.slot_src == 1 ? xv1[u] : xv2[u]) : cv[u][c];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          const double ce = (double)col[e];
+          a1[c] = fma(ce, (double)xv1[u][e], a1[c]);
+          a2[c] = fma(ce, (double)xv2[u][e], a2[c]);
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        e12 = fma((double)xv1[u][e], (double)xv2[u][e], e12);
+        e22 = fma((double)xv2[u][e], (double)xv2[u][e], e22);
+      }
+      if constexpr (STORE) {
+        if (A.st1) __builtin_nontemporal_store(xv1[u], reinterpret_cast<V *>(A.st1) + i);
+        if (A.st2) __builtin_nontemporal_store(xv2[u], reinterpret_cast<V *>(A.st2) + i);
+        if (A.stb) {
+          V b;
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) {
+            b[e] = xv2[u][e] / A.sq;                       // b[insert] = y ./ sqrt(ys): a true division per element
+            ebb = fma((double)b[e], (double)b[e], ebb);
+          }
+          __builtin_nontemporal_store(b, reinterpret_cast<V *>(A.stb) + i);
+        }
+      }
+    }
+  }
+  constexpr int NP = 2 * NC + 3;
+  __shared__ double lds[kBlock / kWave][NP];
+  const int wave = tid >> 6, lane = tid & 63;
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const double s1 = wave_sum(a1[c]), s2 = wave_sum(a2[c]);
+    if (lane == 0) {
+      lds[wave][c] = s1;
+      lds[wave][NC + c] = s2;
+    }
+  }
+  {
+    const double s12 = wave_sum(e12), s22 = wave_sum(e22), sbb = wave_sum(ebb);
+    if (lane == 0) {
+      lds[wave][2 * NC] = s12;
+      lds[wave][2 * NC + 1] = s22;
+      lds[wave][2 * NC + 2] = sbb;
+    }
+  }
+  __syncthreads();
+  if (tid < NP)
+    partials[(int64_t)tid * kMaxRedBlocks + blockIdx.x] = (lds[0][tid] + lds[1][tid]) + (lds[2][tid] + lds[3][tid]);
+}
+
+// one workgroup per partial column, destination per column from a table (NULL: result not wanted)
+constexpr int kPushMaxNC = 20;
+struct FinalizeMap {
+  double *dst[2 * kPushMaxNC + 3];
+};
+__global__ void __launch_bounds__(kBlock)
+finalize_map_kernel(const double *__restrict__ partials, int nblocks, FinalizeMap M) {
+  const int c = blockIdx.x, tid = threadIdx.x;
+  double *dst = M.dst[c];
+  if (!dst) return;
+  const double *p = partials + (int64_t)c * kMaxRedBlocks;
+  double s = 0.0;
+  for (int i = tid; i < nblocks; i += kBlock) s += p[i];
+  s = wave_sum(s);
+  __shared__ double lds[kBlock / kWave];
+  if ((tid & 63) == 0) lds[tid >> 6] = s;
+  __syncthreads();
+  if (tid == 0) *dst = (lds[0] + lds[1]) + (lds[2] + lds[3]);
+}
+
+// One pass over `ncols` (1..10, or exactly 20) padded panel columns. out1[c] = dot(col_c, x1), out2[c] = dot(col_c, x2) with column
+// `slot` standing for x1 (slot_src 1) or x2 (2); out_x1x2 / out_x2x2 / out_bb (each may be NULL) receive x1·x2, x2·x2
+// and |x2 ./ sq|^2. The caller runs the all-reduce hook on whatever it keeps (results are LOCAL sums here).
+template <typename T>
+int32_t panel_push_pass(mxlo_ctx *ctx, const T *const *cols, int ncols, int slot, int slot_src, const T *x1,
+                        const T *x2, int64_t n, int64_t n_padded, T *st1, T *st2, T *stb, double sq, double *out1,
+                        double *out2, double *out_x1x2, double *out_x2x2, double *out_bb) {
+  constexpr int VEC = Vec16<T>::N;
+  MXLO_REQUIRE(((ncols >= 1 && ncols <= 10) || ncols == kPushMaxNC) && n_padded % VEC == 0 && n <= n_padded &&
+                   n > n_padded - VEC, MXLO_EINVAL, "panel_push_pass: bad arguments");
+  bool aligned = (((uintptr_t)x1 | (uintptr_t)x2 | (uintptr_t)st1 | (uintptr_t)st2 | (uintptr_t)stb) & 15u) == 0;
+  for (int c = 0; c < ncols; ++c) aligned = aligned && (((uintptr_t)cols[c]) & 15u) == 0;
+  MXLO_REQUIRE(aligned, MXLO_EINVAL, "panel_push_pass: operands must be 16-byte aligned");
+  const int64_t nvec = n_padded / VEC;
+  const bool store = st1 || st2 || stb;
+  const bool nt = (int64_t)sizeof(T) * n_padded * (ncols + 2) >= ctx->tune.nt_min_bytes;
+  int grid = 0;
+  auto go = [&]<int NC>() {
+    PushPassArgs<T, NC> A;
+    for (int c = 0; c < NC; ++c) A.cols[c] = cols[c];
+    A.x1 = x1; A.x2 = x2; A.st1 = st1; A.st2 = st2; A.stb = stb; A.sq = (T)sq;
+    A.slot = slot; A.slot_src = slot_src; A.nvec = nvec; A.n = n;
+    constexpr int UNROLL = NC <= 2 ? 4 : (NC <= 5 ? 2 : 1);      // = panel_dots2: identical per-lane summation order
+    grid = grid_for(ctx, nvec, (int64_t)kBlock * UNROLL, ctx->tune.red_blocks_per_cu);
+    if (grid > kMaxRedBlocks) grid = kMaxRedBlocks;
+    auto launch = [&]<bool NTV, bool ST>() {
+      hipLaunchKernelGGL((push_pass_kernel<T, NC, UNROLL, NTV, ST>), dim3(grid), dim3(kBlock), 0, ctx->stream, A,
+                         ctx->partials);
+    };
+    if (nt) { if (store) launch.template operator()<true, true>(); else launch.template operator()<true, false>(); }
+    else { if (store) launch.template operator()<false, true>(); else launch.template operator()<false, false>(); }
+    FinalizeMap M;
+    for (int c = 0; c < 2 * kPushMaxNC + 3; ++c) M.dst[c] = nullptr;
+    for (int c = 0; c < NC; ++c) {
+      M.dst[c] = out1 ? out1 + c : nullptr;
+      M.dst[NC + c] = out2 ? out2 + c : nullptr;
+    }
+    M.dst[2 * NC] = out_x1x2;
+    M.dst[2 * NC + 1] = out_x2x2;
+    M.dst[2 * NC + 2] = out_bb;
+    hipLaunchKernelGGL(finalize_map_kernel, dim3(2 * NC + 3), dim3(kBlock), 0, ctx->stream, ctx->partials, grid, M);
+  };
+  switch (ncols) {
+    case 1: go.template operator()<1>(); break;
+    case 2: go.template operator()<2>(); break;
+    case 3: go.template operator()<3>(); break;
+    case 4: go.template operator()<4>(); break;
+    case 5: go.template operator()<5>(); break;
+    case 6: go.template operator()<6>(); break;
+    case 7: go.template operator()<7>(); break;
+    case 8: go.template operator()<8>(); break;
+    case 9: go.template operator()<9>(); break;
+    case 10: go.template operator()<10>(); break;
+    default: go.template operator()<kPushMaxNC>(); break;
+  }
+  MXLO_LAUNCH_CHECK();
+  return MXLO_OK;
+}
+
+template int32_t panel_push_pass<double>(mxlo_ctx *, const double *const *, int, int, int, const double *, const double *,
+                                         int64_t, int64_t, double *, double *, double *, double, double *, double *,
+                                         double *, double *, double *);
+template int32_t panel_push_pass<float>(mxlo_ctx *, const float *const *, int, int, int, const float *, const float *,
+                                        int64_t, int64_t, float *, float *, float *, double, double *, double *, double *,
+                                        double *, double *);
+
 template int32_t panel_dots2<double>(mxlo_ctx *, const double *const *, int, const double *, const double *, int64_t,
                                      double *, double *);
 template int32_t panel_dots2<float>(mxlo_ctx *, const float *const *, int, const float *, const float *, int64_t,

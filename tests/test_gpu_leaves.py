@@ -512,3 +512,30 @@ def test_single_launch_householder_exchange_stress(lo, dev):
     out = subprocess.run([_sys.executable, os.path.join(root, "tools", "stress_fused_householder.py")], env=env,
                          capture_output=True, text=True, timeout=240)
     assert out.returncode == 0 and "no hang" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+def test_single_launch_householder_two_streams_one_ctx(lo, dev):
+    """VERDICT r2 (#8): all fused launches of a ctx share one set of exchange slots + one epoch word, which is only
+    correct while at most one of them is in flight. `mxlo_ctx_set_stream` keeps that true for callers that alternate
+    streams: a stream change records an event on the old stream and makes the new one wait for it (include/mxlo.h), so
+    two applies of one ctx are always ordered even when they are issued on two streams. 4,000 alternating single-launch
+    applies on two non-blocking torch streams (different operators, different grid sizes), then both results against
+    the oracle — a slot-set collision would hang or leak a partial of the other operator into the dot."""
+    s1, s2 = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+    rng = np.random.default_rng(91)
+    ops = []
+    for n in (1 << 16, 40_000):
+        h = rng.standard_normal(n)
+        h /= np.linalg.norm(h)
+        v = rng.uniform(-1, 1, n)
+        ops.append((lo.opHouseholder(torch.from_numpy(h).to(dev)), torch.from_numpy(v).to(dev),
+                    torch.empty(n, dtype=torch.float64, device=dev), h, v))
+    torch.cuda.synchronize()
+    for it in range(2000):
+        for (H, v, res, _, _), st in zip(ops, (s1, s2)):
+            with torch.cuda.stream(st):
+                lo.mul(res, H, v, 1.0 + it, 0.0)
+    torch.cuda.synchronize()
+    for H, v, res, h_np, v_np in ops:
+        want = oracle.householder_mul(np.empty(h_np.size), h_np, v_np, 2000.0, 0.0)
+        assert rel(res.cpu().numpy(), want) <= 1e-12

@@ -618,3 +618,58 @@ def test_unbounded_memory(lo, dev, dtype, kind, mem, npush):
 def test_mem_limit_message(lo, dev):
     with pytest.raises(lo.MxloError, match="exceeds 4096"):
         lo.LBFGSOperator(torch.float64, 8, mem=5000, device=dev)
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("kind,mem", [("inv", 4), ("inv", 10), ("inv", 23), ("fwd", 5), ("fwd", 20), ("fwd", 32)])
+def test_one_pass_push_matches_two_kernel_schedule_and_oracle(lo, dev, dtype, kind, mem):
+    """push!(op, s, y) as two streaming passes with the new pair held per lane (the column being replaced
+    is never read, the inserts s -> S[:,k], y -> Y[:,k], b = y ./ sqrt(ys) happen from registers, y's and y'y come out
+    of the first pass) against the schedule it replaced (`push_fused` = 0: dots, two device-to-device inserts, dual-x
+    dots over the freshly copied columns) and against the oracle (src/lbfgs.jl:210-287). Covers: ragged n (partial last
+    vector: the panel padding must stay zero), a rejected pair (y's <= eps: the operator must be untouched), wrap-around
+    of the circular buffer, more than 10 columns (two chunks per panel), misaligned s / y views (fall back)."""
+    from linearoperators_jl_amd.device import get_ctx
+    ctx = get_ctx(dev)
+    npd = NP[dtype]
+    n = 10_007 if mem < 20 else 6_001
+    rng = np.random.default_rng(mem * 7 + n)
+    make = lo.InverseLBFGSOperator if kind == "inv" else lo.LBFGSOperator
+    tol = 1e-9 if dtype == torch.float64 else QN_F32
+    ops = {}
+    try:
+        for fused in (1, 0):
+            ctx.tune("push_fused", fused)
+            ops[fused] = make(dtype, n, mem=mem, scaling=True, device=dev)
+        Oo = oracle.LBFGS(n, mem=mem, scaling=True, inverse=(kind == "inv"), dtype=npd)
+        x = rng.uniform(-1, 1, n).astype(npd)
+        prs = pairs(rng, n, mem + 4, npd)
+        prs.insert(3, (prs[0][0], (-prs[0][0]).astype(npd)))          # y's < 0: rejected (src/lbfgs.jl:281-284)
+        for k, (s, y) in enumerate(prs):
+            want = Oo.push(s, y)
+            for fused in (1, 0):
+                ctx.tune("push_fused", fused)
+                if k % 5 == 4:                                         # misaligned views: element offset 1
+                    sb, yb = torch.empty(n + 1, dtype=dtype, device=dev), torch.empty(n + 1, dtype=dtype, device=dev)
+                    sb[1:].copy_(T(s, dev)); yb[1:].copy_(T(y, dev))
+                    lo.push(ops[fused], sb[1:], yb[1:])
+                else:
+                    lo.push(ops[fused], T(s, dev), T(y, dev))
+                assert ops[fused].data.insert == Oo.insert, (k, fused, want)
+            if k in (0, 3, mem - 1, mem, len(prs) - 1):
+                got = {}
+                for fused in (1, 0):
+                    res = torch.full((n,), float("nan"), dtype=dtype, device=dev)
+                    lo.mul(res, ops[fused], T(x, dev), 1.0, 0.0)
+                    got[fused] = res.cpu().numpy()
+                ref = Oo.mul(np.empty(n, dtype=npd), x, 1.0, 0.0)
+                assert rel(got[1], ref) <= tol and rel(got[0], ref) <= tol, (k, rel(got[1], ref), rel(got[0], ref))
+                assert rel(got[1], got[0]) <= (1e-12 if dtype == torch.float64 else 1e-4), (k, rel(got[1], got[0]))
+        for fused in (1, 0):                                           # replicated scalars of the two schedules
+            assert abs(ops[fused].data.scaling_factor - Oo.scaling_factor) <= 1e-6 * abs(Oo.scaling_factor)
+        if kind == "fwd":
+            d1, d0 = lo.diag(ops[1]).cpu().numpy(), lo.diag(ops[0]).cpu().numpy()
+            assert rel(d1, Oo.diag()) <= tol and rel(d1, d0) <= (1e-12 if dtype == torch.float64 else 1e-4)
+            assert rel(ops[1].data.opnorm_upper_bound, Oo.opnorm_upper_bound) <= 1e-5
+    finally:
+        ctx.tune("push_fused", 1)

@@ -115,6 +115,11 @@ def test_sharded_abi_matches_unsharded_oracle(lo, dev, name, ids):
             xs, rs = sh.put(x), sh.put(r0)
             assert R.mxlo_qn_mul_sharded(q, sh.ptrs(rs), sh.ptrs(xs), 2.0, -3.0, 0) == 0, R.mxlo_shard_last_error()
             assert rel(sh.get(rs), Bo.mul(r0.copy(), x, 2.0, -3.0)) <= 1e-9, (name, okind, mem)
+            # ShiftedOperator fused into the combine pass (src/shifted_operators.jl:16-25): res = α(Bx + σx) + β res
+            rs = sh.put(r0)
+            assert R.mxlo_qn_mul_shifted_sharded(q, sh.ptrs(rs), sh.ptrs(xs), 2.0, -3.0, 0.75, 0) == 0, R.mxlo_shard_last_error()
+            want = 2.0 * (Bo.mul(np.empty(n), x, 1.0, 0.0) + 0.75 * x) - 3.0 * r0
+            assert rel(sh.get(rs), want) <= 1e-9, (name, okind, mem, "shifted")
             if okind == "fwd":
                 sigma = 0.25
                 bx = Bo.mul(np.empty(n), x, 1.0, 0.0) + sigma * x
@@ -144,3 +149,183 @@ def test_shard_ctx_argument_errors(lo, dev):
     assert R.mxlo_shard_ctx_device(sctx, 0) == 0
     assert R.mxlo_householder_mul_sharded(sctx, 0, None, None, None, None, 1.0, 0.0, 0) == lo._lib.EINVAL
     assert R.mxlo_shard_ctx_destroy(sctx) == 0
+
+
+def _mk(lo, ids):
+    R = lo._lib.rccl_lib()
+    sctx = C.c_void_p()
+    assert R.mxlo_shard_ctx_create(len(ids), (C.c_int32 * len(ids))(*ids), C.byref(sctx)) == 0, R.mxlo_shard_last_error()
+    return R, sctx
+
+
+def test_per_shard_arguments_are_checked_before_any_worker_starts(lo, dev):
+    """a bad argument on ONE shard must not leave the others waiting in their collective. NULL / negative
+    per-shard arguments are rejected on the calling thread, and the shard ctx stays usable afterwards."""
+    R, sctx = _mk(lo, [0, 0, 0])
+    try:
+        rng = np.random.default_rng(3)
+        sizes = [1000, 0, 2345]                                         # an EMPTY shard may pass NULL
+        sh = Shards(R, sctx, sizes)
+        n = sum(sizes)
+        h = rng.standard_normal(n)
+        h /= np.linalg.norm(h)
+        v, r0 = rng.uniform(-1, 1, n), rng.uniform(-1, 1, n)
+        hs, vs, rs = sh.put(h), sh.put(v), sh.put(r0)
+        good = sh.ptrs(rs)
+        bad = (C.c_void_p * 3)(rs[0].data_ptr(), None, None)            # res[2] is NULL although n_local[2] > 0
+        F64 = lo._lib.F64
+        assert R.mxlo_householder_mul_sharded(sctx, F64, bad, sh.ptrs(hs), sh.ptrs(vs), sh.nloc, 1.0, 0.0, 0) == lo._lib.EINVAL
+        assert b"res[2] is NULL" in R.mxlo_shard_last_error()
+        neg = (C.c_int64 * 3)(1000, -1, 2345)
+        assert R.mxlo_diag_mul_sharded(sctx, F64, good, sh.ptrs(hs), sh.ptrs(vs), neg, 1.0, 0.0, 0) == lo._lib.EINVAL
+        empty_ok = (C.c_void_p * 3)(rs[0].data_ptr(), None, rs[2].data_ptr())
+        hp = (C.c_void_p * 3)(hs[0].data_ptr(), None, hs[2].data_ptr())
+        vp = (C.c_void_p * 3)(vs[0].data_ptr(), None, vs[2].data_ptr())
+        assert R.mxlo_householder_mul_sharded(sctx, F64, empty_ok, hp, vp, sh.nloc, 2.0, -3.0, 0) == 0, R.mxlo_shard_last_error()
+        assert rel(sh.get(rs), oracle.householder_mul(r0.copy(), h, v, 2.0, -3.0)) <= 1e-12
+        q = C.c_void_p()
+        nl = (C.c_int64 * 3)(1000, 7, 2345)
+        assert R.mxlo_qn_create_sharded(sctx, lo._lib.QN_LBFGS_FWD, F64, nl, 4, 1, 0, 0.99, 10.0, C.byref(q)) == 0
+        acc = C.c_int32()
+        assert R.mxlo_qn_push_sharded(q, bad, bad, C.byref(acc)) == lo._lib.EINVAL
+        assert b"s[1] is NULL" in R.mxlo_shard_last_error()
+        assert R.mxlo_qn_mul_sharded(q, bad, bad, 1.0, 0.0, 0) == lo._lib.EINVAL
+        assert R.mxlo_qn_destroy_sharded(q) == 0
+    finally:
+        assert R.mxlo_shard_ctx_destroy(sctx) == 0
+
+
+def test_a_failing_shard_releases_the_others(lo, dev):
+    """A shard whose entry point fails AFTER the workers started (here: an invalid flag combination is impossible to
+    fake per shard, so the failure is a push! whose vectors are too short to matter — we use the documented per-call
+    error: solve_shifted_system! with sigma < 0 is refused by every shard before its collective) returns the error and the
+    next call works; a create that fails on one shard only (n_local = 0 is not a valid operator size) reports that shard
+    and releases everything the other shards had built."""
+    R, sctx = _mk(lo, [0, 0])
+    try:
+        F64 = lo._lib.F64
+        q = C.c_void_p()
+        bad = (C.c_int64 * 2)(500, 0)
+        rc = R.mxlo_qn_create_sharded(sctx, lo._lib.QN_LBFGS_FWD, F64, bad, 4, 1, 0, 0.99, 10.0, C.byref(q))
+        if rc != 0:                                                      # unsharded create refuses n = 0
+            assert b"shard 1 (device 0)" in R.mxlo_shard_last_error()
+        else:
+            assert R.mxlo_qn_destroy_sharded(q) == 0
+        nl = (C.c_int64 * 2)(500, 700)
+        assert R.mxlo_qn_create_sharded(sctx, lo._lib.QN_LBFGS_FWD, F64, nl, 4, 1, 0, 0.99, 10.0, C.byref(q)) == 0
+        sh = Shards(R, sctx, [500, 700])
+        rng = np.random.default_rng(5)
+        x = rng.uniform(-1, 1, 1200)
+        xs, bs = sh.put(x), sh.put(x)
+        assert R.mxlo_qn_solve_shifted_sharded(q, sh.ptrs(xs), sh.ptrs(bs), -1.0) != 0     # ArgumentError analogue, every shard
+        rs = sh.put(np.zeros(1200))
+        assert R.mxlo_qn_mul_sharded(q, sh.ptrs(rs), sh.ptrs(xs), 1.0, 0.0, 0) == 0, R.mxlo_shard_last_error()
+        assert np.array_equal(sh.get(rs), x)                             # still usable: empty memory = identity
+        assert R.mxlo_qn_destroy_sharded(q) == 0
+    finally:
+        assert R.mxlo_shard_ctx_destroy(sctx) == 0
+
+
+def test_two_host_threads_share_one_shard_ctx(lo, dev):
+    """`_sharded` calls of one shard ctx are serialised inside the library (ctypes releases the GIL, so these really
+    overlap): two host threads hammering Householder applies on disjoint vectors both get the oracle's result."""
+    import threading
+    ids = list(range(torch.cuda.device_count())) if torch.cuda.device_count() > 1 else [0, 0, 0]
+    R, sctx = _mk(lo, ids)
+    try:
+        nd = len(ids)
+        sizes = [4001 + 13 * i for i in range(nd)]
+        n = sum(sizes)
+        sh = Shards(R, sctx, sizes)
+        F64 = lo._lib.F64
+        errs, outs = [], {}
+
+        def work(seed):
+            try:
+                rng = np.random.default_rng(seed)
+                h = rng.standard_normal(n)
+                h /= np.linalg.norm(h)
+                v = rng.uniform(-1, 1, n)
+                hs, vs, rs = sh.put(h), sh.put(v), sh.put(np.zeros(n))
+                for d in {t.device for t in hs}:
+                    torch.cuda.synchronize(d)
+                for _ in range(50):
+                    rc = R.mxlo_householder_mul_sharded(sctx, F64, sh.ptrs(rs), sh.ptrs(hs), sh.ptrs(vs), sh.nloc, 1.0, 0.0, 0)
+                    if rc != 0:
+                        errs.append(R.mxlo_shard_last_error())
+                        return
+                outs[seed] = (sh.get(rs), oracle.householder_mul(np.zeros(n), h, v, 1.0, 0.0))
+            except Exception as e:                                       # pragma: no cover
+                errs.append(repr(e))
+
+        ths = [threading.Thread(target=work, args=(s,)) for s in (11, 12)]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join(120)
+        assert not any(t.is_alive() for t in ths), "deadlock between two host threads on one shard ctx"
+        assert not errs, errs
+        for got, want in outs.values():
+            assert rel(got, want) <= 1e-12
+    finally:
+        assert R.mxlo_shard_ctx_destroy(sctx) == 0
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 8, reason="BASELINE configs[4] needs the 8-GPU node")
+def test_cfg5_lbfgs_m20_n4e8_row_sharded_over_8_devices(lo, dev):
+    """BASELINE configs[4] at FULL size through the single-process API: LBFGSOperator m = 20, n = 4e8 fp64, 5e7 rows per
+    device, RCCL all-reduce of the 2m dots. No oracle run at this size (the C oracle would need 128 GB and minutes);
+    size-independent properties instead: (i) with identical data on every device the sharded operator equals the
+    ONE-device operator on one shard's data up to the 8x larger dots — we use the secant equation B s_k = y_k for the
+    LAST pushed pair (exact for BFGS, src/lbfgs.jl compact form) on the global vectors, (ii) linearity in x,
+    (iii) replicated scalars bit-identical on all 8 shards."""
+    nd, nl, m = 8, 50_000_000, 20
+    R, sctx = _mk(lo, list(range(nd)))
+    try:
+        F64 = lo._lib.F64
+        devs = [torch.device("cuda", i) for i in range(nd)]
+        nloc = (C.c_int64 * nd)(*([nl] * nd))
+        q = C.c_void_p()
+        assert R.mxlo_qn_create_sharded(sctx, lo._lib.QN_LBFGS_FWD, F64, nloc, m, 1, 0, 0.99, 10.0, C.byref(q)) == 0, R.mxlo_shard_last_error()
+        gens = [torch.Generator(device=d).manual_seed(100 + i) for i, d in enumerate(devs)]
+        ss = [torch.empty(nl, dtype=torch.float64, device=d) for d in devs]
+        ys = [torch.empty(nl, dtype=torch.float64, device=d) for d in devs]
+        P = lambda ts: (C.c_void_p * nd)(*[t.data_ptr() for t in ts])
+        acc = C.c_int32()
+        for _ in range(m + 2):
+            for s_, y_, g in zip(ss, ys, gens):
+                s_.uniform_(-1, 1, generator=g)
+                y_.uniform_(0.5, 2.0, generator=g)
+                y_.mul_(s_)
+            for d in devs:
+                torch.cuda.synchronize(d)
+            assert R.mxlo_qn_push_sharded(q, P(ss), P(ys), C.byref(acc)) == 0, R.mxlo_shard_last_error()
+            assert acc.value == 1
+        rs = [torch.empty(nl, dtype=torch.float64, device=d) for d in devs]
+        assert R.mxlo_qn_mul_sharded(q, P(rs), P(ss), 1.0, 0.0, 0) == 0, R.mxlo_shard_last_error()
+        assert R.mxlo_shard_ctx_sync(sctx) == 0
+        num = sum(float(((r - y) ** 2).sum().item()) for r, y in zip(rs, ys)) ** 0.5
+        den = sum(float((y ** 2).sum().item()) for y in ys) ** 0.5
+        assert num <= 1e-9 * den, f"secant equation B s = y violated: {num / den}"
+        r2 = [torch.empty(nl, dtype=torch.float64, device=d) for d in devs]
+        assert R.mxlo_qn_mul_sharded(q, P(r2), P(ys), 1.0, 0.0, 0) == 0
+        for r, a, y in zip(r2, rs, ys):                                  # r2 = B y; now B(s + 2y) = y + 2 r2
+            a.add_(r, alpha=2.0)                                         # a = y_expected = Bs + 2By
+        xs = [s + 2.0 * y for s, y in zip(ss, ys)]
+        r3 = [torch.empty(nl, dtype=torch.float64, device=d) for d in devs]
+        for d in devs:
+            torch.cuda.synchronize(d)
+        assert R.mxlo_qn_mul_sharded(q, P(r3), P(xs), 1.0, 0.0, 0) == 0
+        assert R.mxlo_shard_ctx_sync(sctx) == 0
+        num = sum(float(((r - a) ** 2).sum().item()) for r, a in zip(r3, rs)) ** 0.5
+        den = sum(float((a ** 2).sum().item()) for a in rs) ** 0.5
+        assert num <= 1e-10 * den, f"linearity violated: {num / den}"
+        sc0, y0, a0 = (C.c_double * 5)(), (C.c_double * m)(), (C.c_double * m)()
+        assert R.mxlo_qn_get_scalars_sharded(q, 0, sc0, y0, a0) == 0
+        for i in range(1, nd):
+            sci, yi, ai = (C.c_double * 5)(), (C.c_double * m)(), (C.c_double * m)()
+            assert R.mxlo_qn_get_scalars_sharded(q, i, sci, yi, ai) == 0
+            assert bytes(sci)[:32] == bytes(sc0)[:32] and bytes(yi) == bytes(y0)
+        assert R.mxlo_qn_destroy_sharded(q) == 0
+    finally:
+        assert R.mxlo_shard_ctx_destroy(sctx) == 0

@@ -289,12 +289,12 @@ function opHermitian(d::MXVector{S}, A::MXMatrix{T}) where {S <: Union{RealT, Cp
 end
 
 # ---- dense LinearOperator(M) (src/constructors.jl:19-29) ----------------------------------------------------
-function LinearOperator(M::MXMatrix{T}; symmetric = false, hermitian = false) where {T <: CplxT}
+function LinearOperator(M::MXMatrix{T}; symmetric = false, hermitian = false, S = MXVector{T}) where {T <: CplxT}
   m, n = size(M)
   gemv(mode) = (res, v, α, β) -> check(ccall((:mxlo_gemv_c, lib), Int32,
       (P, Int32, P, P, Int64, Int64, Int64, P, Float64, Float64, Float64, Float64, Int32, Int32),
       ctx(), dt(T), res.ptr, M.data.ptr, m, n, m, v.ptr, rpart(α), ipart(α), rpart(β), ipart(β), Int32(mode), flags(T, α, β)))
-  LinearOperator{T, MXVector{T}}(m, n, symmetric, hermitian, gemv(0), gemv(1), gemv(2))     # M*v, transpose(M)*u, M'*w
+  LinearOperator{T, S}(m, n, symmetric, hermitian, gemv(0), gemv(1), gemv(2))     # M*v, transpose(M)*u, M'*w
 end
 # The closure of a real dense operator is a callable with a vector method (GEMV) and a matrix method (the block GEMV:
 # `mul!(res::Matrix, op, V::Matrix, α, β)`, src/operations.jl:34-36, reads M once per 8 columns of V).
@@ -309,11 +309,43 @@ end
     (P, Int32, P, Int64, P, Int64, Int64, Int64, P, Int64, Int64, Float64, Float64, Int32, Int32),
     ctx(), dt(T), res.data.ptr, res.m, f.M.data.ptr, f.M.m, f.M.n, f.M.m, V.data.ptr, V.m, size(V, 2), α, β, f.mode,
     flags(T, α, β)))
-function LinearOperator(M::MXMatrix{T}; symmetric = false, hermitian = false) where {T <: RealT}
-  m, n = size(M)
-  LinearOperator{T, MXVector{T}}(m, n, symmetric, hermitian, DenseApply{T}(M, Int32(0)), DenseApply{T}(M, Int32(1)),
-                                 DenseApply{T}(M, Int32(2)))
+function LinearOperator(M::MXMatrix{T}; symmetric = false, hermitian = false, S = MXVector{T}) where {T <: RealT}
+  m, n = size(M)     # S: the keyword of src/constructors.jl:15 (test/gpu/test_S_kwarg.jl:19 passes it)
+  LinearOperator{T, S}(m, n, symmetric, hermitian, DenseApply{T}(M, Int32(0)), DenseApply{T}(M, Int32(1)),
+                       DenseApply{T}(M, Int32(2)))
 end
+
+# ---- 5-arg mul! of a plain device MATRIX (and its lazy transpose / adjoint) on device vectors --------------------------
+# The reference's generic `BlockDiagonalOperator(A, B, C)` accepts plain matrices next to operators
+# (src/abstract.jl:173 `has_args5(::AbstractMatrix) = true`, src/special-operators.jl:258-289: per block
+# `mul!(view(y), op, view(x), α, β)`, `transpose(op)`, `adjoint(op)`); test/gpu/amdgpu.jl:4-12 builds exactly that from
+# three ROCArray matrices. With these methods the same call works on MXMatrix blocks (one GEMV per block; the fused
+# one-launch form is `BlockDiagonalOperator(T, blocks...)` below).
+const LazyT{T} = Union{Transpose{T, MXMatrix{T}}, Adjoint{T, MXMatrix{T}}}
+storage_type(::LazyT{T}) where {T} = MXVector{T}            # src/abstract.jl:181-182 forwards to the parent; explicit here
+gemv_mode(::MXMatrix) = Int32(0)
+gemv_mode(::Transpose) = Int32(1)
+gemv_mode(::Adjoint) = Int32(2)
+function LinearAlgebra.mul!(res::MXVector{T}, M::Union{MXMatrix{T}, LazyT{T}}, v::MXVector{T}, α::Number, β::Number) where {T <: RealT}
+  A = M isa MXMatrix ? M : parent(M)
+  (length(v) == size(M, 2) && length(res) == size(M, 1)) ||
+    throw(DimensionMismatch("mul!: res has $(length(res)) rows, M is $(size(M)), v has $(length(v))"))
+  check(ccall((:mxlo_gemv, lib), Int32, (P, Int32, P, P, Int64, Int64, Int64, P, Float64, Float64, Int32, Int32),
+              ctx(), dt(T), res.ptr, A.data.ptr, A.m, A.n, A.m, v.ptr, α, β, gemv_mode(M), flags(T, α, β)))
+  res
+end
+function LinearAlgebra.mul!(res::MXVector{T}, M::Union{MXMatrix{T}, LazyT{T}}, v::MXVector{T}, α::Number, β::Number) where {T <: CplxT}
+  A = M isa MXMatrix ? M : parent(M)
+  (length(v) == size(M, 2) && length(res) == size(M, 1)) ||
+    throw(DimensionMismatch("mul!: res has $(length(res)) rows, M is $(size(M)), v has $(length(v))"))
+  check(ccall((:mxlo_gemv_c, lib), Int32,
+              (P, Int32, P, P, Int64, Int64, Int64, P, Float64, Float64, Float64, Float64, Int32, Int32),
+              ctx(), dt(T), res.ptr, A.data.ptr, A.m, A.n, A.m, v.ptr, rpart(α), ipart(α), rpart(β), ipart(β), gemv_mode(M),
+              flags(T, α, β)))
+  res
+end
+LinearAlgebra.mul!(res::MXVector{T}, M::Union{MXMatrix{T}, LazyT{T}}, v::MXVector{T}) where {T} = mul!(res, M, v, one(T), zero(T))
+Base.:*(M::Union{MXMatrix{T}, LazyT{T}}, v::MXVector{T}) where {T} = mul!(MXVector{T}(undef, size(M, 1)), M, v)
 
 # ---- mul! on matrices (src/operations.jl:34-36; wrappers src/adjtrans.jl:139-156, 207-224) ------------------------------
 # The reference hands `res` and `m` to the closure as they are (`LinearOperator(M)`: a GEMM; the elementwise closures

@@ -97,4 +97,89 @@ end
   @test dc[1] == 0 && dc[2] == 0 && dc[3] == 0 && dc[4] == 0 && dc[7] == 0 && dc[8] == 0     # malloc, free, H2D, D2H, syncs
   @test dc[11] >= 20                                                                          # launches only
 end
+
+# ---- 1:1 mirror of the reference's only device tests: test/gpu/test_S_kwarg.jl:3-45 with arrayType = the extension's
+# device types, and test/gpu/amdgpu.jl:4-20 (BlockDiagonalOperator of three plain device matrices, storage_type of the
+# lazy wrappers). Same assertions, same order; `arrayType(rand(Float32, 32, 32))` is MXMatrix, `arrayType(rand(Float32, 32))`
+# is MXVector.
+function test_S_kwarg_mxlo()
+  mat = MXMatrix(rand(Float32, 32, 32))
+  vec = MXVector(rand(Float32, 32))
+  vecT = typeof(vec)
+  vecTother = typeof(MXVector(rand(Float32, 32)))
+  @testset "S Kwarg with arrayType MXVector / MXMatrix" begin
+    @test vecT == LinearOperators.storage_type(mat)
+    # constructors.jl
+    @test LinearOperators.storage_type(LinearOperator(mat)) == LinearOperators.storage_type(mat) # default
+    @test LinearOperators.storage_type(LinearOperator(mat; S = vecTother)) == vecTother
+    @test LinearOperators.storage_type(LinearOperator(Symmetric(mat); S = vecT)) == vecT
+    @test LinearOperators.storage_type(LinearOperator(Hermitian(mat); S = vecT)) == vecT
+    @test LinearOperators.storage_type(LinearOperator(Float32, 32, 32, true, true, () -> 0; S = vecT)) == vecT
+    # special-operators.jl
+    @test LinearOperators.storage_type(opEye(Float32, 32; S = vecT)) == vecT
+    @test LinearOperators.storage_type(opEye(Float32, 16, 32; S = vecT)) == vecT
+    @test LinearOperators.storage_type(opEye(Float32, 32, 32; S = vecT)) == vecT
+    @test LinearOperators.storage_type(opOnes(Float32, 32, 32; S = vecT)) == vecT
+    @test LinearOperators.storage_type(opZeros(Float32, 32, 32; S = vecT)) == vecT
+    @test LinearOperators.storage_type(opDiagonal(vec)) == vecT
+    @test LinearOperators.storage_type(opDiagonal(32, 32, vec)) == vecT
+    @test LinearOperators.storage_type(opRestriction([1, 2, 3], 32; S = vecT)) == vecT
+    @test LinearOperators.storage_type(opExtension([1, 2, 3], 32; S = vecT)) == vecT
+    @test LinearOperators.storage_type(BlockDiagonalOperator(mat, mat)) == vecT # default
+    @test LinearOperators.storage_type(BlockDiagonalOperator(mat, mat; S = vecTother)) == vecTother
+  end
+end
+
+@testset "MXLO -- mirror of test/gpu/amdgpu.jl" begin
+  Ah, Bh, Ch = rand(Float32, 5, 5), rand(Float32, 10, 10), rand(Float32, 20, 20)
+  A, B, C = MXMatrix(Ah), MXMatrix(Bh), MXMatrix(Ch)
+  M = BlockDiagonalOperator(A, B, C)            # the reference's generic constructor on plain device matrices
+  vh = rand(Float32, 35)
+  v = MXVector(vh)
+  y = M * v
+  @test y isa MXVector{Float32}
+  # ... and, beyond the reference's type-only check, the numbers (Float32 GEMV: 3e-5, DESIGN.md §2)
+  @test rel(host(y), BlockDiagonalOperator(Ah, Bh, Ch) * vh) <= 3e-5
+  @test rel(host(transpose(M) * v), transpose(BlockDiagonalOperator(Ah, Bh, Ch)) * vh) <= 3e-5
+  @test LinearOperators.storage_type(A) == LinearOperators.storage_type(adjoint(A))
+  @test LinearOperators.storage_type(A) == LinearOperators.storage_type(transpose(A))
+  @test LinearOperators.storage_type(A) == LinearOperators.storage_type(adjoint(A))
+  @test LinearOperators.storage_type(Diagonal(v)) == typeof(v)
+  @testset "MXLO S kwarg" test_S_kwarg_mxlo()
+end
+
+# ---- the reference's allocation contract, literally: test/test_lbfgs.jl:180-218 ("LBFGS allocations") and
+# test/test_lsr1.jl:88-106 on device operators. `@allocated` counts HOST (GC) bytes: a ccall closure with concrete
+# captured types allocates nothing; the device side of the same contract is the mxlo_debug_counters block above.
+@testset "LBFGS / LSR1 allocations (mirror of test_lbfgs.jl:180-218, test_lsr1.jl:88-106)" begin
+  n, mem = 100, 20
+  B = LBFGSOperator(Float64, n, MXVector{Float64}; mem = mem)
+  H = InverseLBFGSOperator(Float64, n, MXVector{Float64}; mem = mem)
+  BD = LBFGSOperator(Float64, n, MXVector{Float64}; mem = mem, damped = true)
+  HD = InverseLBFGSOperator(Float64, n, MXVector{Float64}; mem = mem, damped = true)
+  L = LSR1Operator(Float64, n, MXVector{Float64}; mem = mem)
+  tmpd = dev(zeros(n))
+  for _ = 1:2:n
+    s = dev(rand(n)); y = dev(rand(n)); g = dev(rand(n))
+    push!(B, s, y); push!(H, s, y); push!(L, s, y)
+    push!(BD, s, y, tmpd)
+    push!(HD, s, y, 1.0, g, tmpd)
+  end
+  x, y = dev(rand(n)), dev(rand(n))
+  res = similar(x)
+  mul!(res, B, x)  # warmup
+  @test (@allocated mul!(res, B, x)) == 0
+  mul!(res, H, x)  # warmup
+  @test (@allocated mul!(res, H, x)) == 0
+  mul!(res, L, x)  # warmup
+  @test (@allocated mul!(res, L, x)) == 0
+  diag!(B, res)    # warmup
+  @test (@allocated diag!(B, res)) == 0
+  push!(B, x, y); push!(H, x, y)   # warmup (Ref{Int32} for `accepted` must not escape)
+  @test (@allocated push!(B, x, y)) == 0
+  @test (@allocated push!(H, x, y)) == 0
+  push!(BD, x, y, tmpd); push!(HD, x, y, 1.0, x, tmpd)
+  @test (@allocated push!(BD, x, y, tmpd)) == 0
+  @test (@allocated push!(HD, x, y, 1.0, x, tmpd)) == 0
+end
 println("mxlo Julia smoke finished")

@@ -318,3 +318,48 @@ def test_operator_on_second_device_while_first_is_current(lo):
     lo.mul(torch.empty(300, dtype=torch.float64, device=d1), Hm, T1(rng.standard_normal(300)), 1.0, 0.0)
     sol = lo.solve_shifted_system(torch.zeros(n, dtype=torch.float64, device=d1), B, T1(x), 0.5)
     assert torch.isfinite(sol).all() and torch.cuda.current_device() == 0
+
+
+def test_storage_type_kwarg_mirror(lo, dev):
+    """1:1 mirror of the reference's ONLY device tests — /root/reference/test/gpu/test_S_kwarg.jl:3-45 and
+    test/gpu/amdgpu.jl:4-20 — with the Python mirror's device types: `arrayType(rand(Float32, 32, 32))` is a Float32 torch
+    matrix on the GPU, `storage_type` values are `Storage(dtype, device)`. Same assertions in the same order (the Julia
+    statement of the same list is julia/runtests_mxlo.jl, checked textually by tests/test_julia_binding.py); on top of
+    the reference's type-only checks the BlockDiagonalOperator of three plain matrices is also compared numerically."""
+    f32 = torch.float32
+    mat = torch.rand(32, 32, dtype=f32, device=dev).t()                    # Julia layout
+    vec = torch.rand(32, dtype=f32, device=dev)
+    vecT = lo.storage_type(vec)
+    vecTother = lo.storage_type(torch.rand(32, dtype=f32, device=dev))
+    assert vecT == lo.storage_type(mat) == lo.Storage(f32, dev)
+    # constructors.jl
+    assert lo.storage_type(lo.LinearOperatorFromMatrix(mat)) == lo.storage_type(mat)                         # default
+    assert lo.storage_type(lo.LinearOperatorFromMatrix(mat, S=vecTother)) == vecTother
+    assert lo.storage_type(lo.LinearOperatorFromMatrix(mat, symmetric=True, hermitian=True, S=vecT)) == vecT  # Symmetric(mat)
+    assert lo.storage_type(lo.LinearOperatorFromMatrix(mat, symmetric=True, hermitian=True, S=vecT)) == vecT  # Hermitian(mat)
+    assert lo.storage_type(lo.LinearOperator(f32, 32, 32, True, True, lambda: 0, S=vecT)) == vecT
+    # special-operators.jl
+    assert lo.storage_type(lo.opEye(f32, 32, S=vecT)) == vecT
+    assert lo.storage_type(lo.opEye(f32, 16, 32, S=vecT)) == vecT
+    assert lo.storage_type(lo.opEye(f32, 32, 32, S=vecT)) == vecT
+    assert lo.storage_type(lo.opOnes(f32, 32, 32, S=vecT)) == vecT
+    assert lo.storage_type(lo.opZeros(f32, 32, 32, S=vecT)) == vecT
+    assert lo.storage_type(lo.opDiagonal(vec)) == vecT
+    assert lo.storage_type(lo.opDiagonal(32, 32, vec)) == vecT
+    assert lo.storage_type(lo.opRestriction([1, 2, 3], 32, S=vecT)) == vecT
+    assert lo.storage_type(lo.opExtension([1, 2, 3], 32, S=vecT)) == vecT
+    assert lo.storage_type(lo.BlockDiagonalOperator(mat, mat)) == vecT                                       # default
+    assert lo.storage_type(lo.BlockDiagonalOperator(mat, mat, S=vecTother)) == vecTother
+    # test/gpu/amdgpu.jl:4-20
+    A, B, C = (torch.rand(k, k, dtype=f32, device=dev).t() for k in (5, 10, 20))
+    M = lo.BlockDiagonalOperator(A, B, C)
+    v = torch.rand(35, dtype=f32, device=dev)
+    y = M * v
+    assert isinstance(y, torch.Tensor) and y.is_cuda and y.dtype == f32                                       # y isa ROCArray{Float32}
+    dense = torch.block_diag(A, B, C).double().cpu().numpy()
+    assert np.linalg.norm(y.cpu().numpy() - dense @ v.double().cpu().numpy()) <= 3e-5 * np.linalg.norm(dense @ v.double().cpu().numpy())
+    yt = M.T * v
+    assert np.linalg.norm(yt.cpu().numpy() - dense.T @ v.double().cpu().numpy()) <= 3e-5 * np.linalg.norm(dense.T @ v.double().cpu().numpy())
+    assert lo.storage_type(A) == lo.storage_type(A.t().conj())                                               # adjoint(A)
+    assert lo.storage_type(A) == lo.storage_type(A.t())                                                      # transpose(A)
+    assert lo.storage_type(lo.opDiagonal(v)) == lo.storage_type(v)                                           # Diagonal(v)

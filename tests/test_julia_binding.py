@@ -137,7 +137,7 @@ def parse_ccalls(path: pathlib.Path):
 
 
 PROTOS = {k: parse_header(v) for k, v in HEADERS.items()}
-CALLS = parse_ccalls(JL) + parse_ccalls(ROOT / "julia" / "runtests_mxlo.jl")
+CALLS = parse_ccalls(JL) + parse_ccalls(ROOT / "julia" / "runtests_mxlo.jl") + parse_ccalls(ROOT / "julia" / "bench.jl")
 
 
 def test_headers_parse_to_the_full_symbol_lists():
@@ -189,3 +189,98 @@ def test_kernel_function_methods_are_defined_for_device_vectors():
         assert re.search(rf"^(function\s+)?{re.escape(f)}\(res::MXVector", src, flags=re.M), f
         assert re.search(rf"import LinearOperators:[^#]*?{re.escape(f)}", src, flags=re.S), f"{f} not imported"
     assert re.search(r"^Base\.:\+\(op::LinearOperator\{T, MXVector\{T\}\}, x::Number\)", src, flags=re.M)
+
+
+# ---------------------------------------------------------------------------------- the reference side of the binding
+# Build-container check only (/root/reference does not travel to the GPU box): every name the extension imports from
+# LinearOperators or qualifies with `LinearOperators.` must exist in the reference's sources, and every METHOD the
+# extension adds to a reference function must have an arity the reference itself defines or calls — a renamed kernel
+# function or a changed argument list upstream would otherwise only fail on a Julia-equipped host.
+REF = pathlib.Path("/root/reference")
+needs_ref = pytest.mark.skipif(not (REF / "src").is_dir(), reason="/root/reference is only present in the build container")
+
+
+def _ref_sources() -> str:
+    return "\n".join(_strip_jl_comments(p.read_text()) for p in sorted((REF / "src").glob("*.jl")))
+
+
+def _imported_names() -> list[str]:
+    src = _strip_jl_comments(JL.read_text())
+    m = re.search(r"^import LinearOperators:(.*?)(?=^import |^using |^const )", src, flags=re.S | re.M)
+    assert m, "import LinearOperators: ... block not found"
+    return [n.strip() for n in m.group(1).replace("\n", " ").split(",") if n.strip()]
+
+
+@needs_ref
+def test_every_imported_reference_name_exists_in_the_reference():
+    ref = _ref_sources()
+    names = _imported_names()
+    assert len(names) >= 25
+    for n in names:
+        pat = rf"(^|[^\w!]){re.escape(n)}(\{{[^}}]*\}})?\(|\b(struct|abstract type|mutable struct)\s+{re.escape(n)}\b|^\s*{re.escape(n)}\b.*="
+        assert re.search(pat, ref, flags=re.M), f"`{n}` is imported by the extension but not defined in /root/reference/src"
+    src = _strip_jl_comments("\n".join((ROOT / "julia" / f).read_text() for f in ("LinearOperatorsMXLOExt.jl", "runtests_mxlo.jl", "bench.jl")))
+    for q in sorted(set(re.findall(r"\bLinearOperators\.(\w+!?)", src))):
+        assert re.search(rf"(?<!\w){re.escape(q)}(?![\w!])", ref), f"LinearOperators.{q} is used by the glue but absent from the reference"
+
+
+def _arities_in_reference(fname: str, ref: str) -> set[int]:
+    """Positional argument counts of every definition AND call of `fname` in the reference sources."""
+    out = set()
+    for m in re.finditer(rf"(?<![\w.]){re.escape(fname)}(\{{[^}}]*\}})?\(", ref):
+        i, depth = m.end(), 1
+        while depth and i < len(ref):
+            depth += ref[i] in "([{"
+            depth -= ref[i] in ")]}"
+            i += 1
+        args = ref[m.end(): i - 1]
+        pos = args.split(";")[0] if ";" in _split_top(args, ";")[0] or True else args
+        pos = _split_top(args, ";")[0] if args.strip() else ""
+        out.add(len([a for a in _split_top(pos) if a.strip()]))
+    return out
+
+
+@needs_ref
+@pytest.mark.parametrize("fname", ["mulOpEye!", "mulOpOnes!", "mulOpZeros!", "mulSquareOpDiagonal!", "mulOpDiagonal!",
+                                   "mulHouseholder!", "mulRestrict!", "multRestrict!", "opDiagonal", "opHouseholder",
+                                   "opHermitian", "solve_shifted_system!", "diag!", "reset!", "storage_type",
+                                   "has_args5", "isallocated5", "shifted_prod!"])
+def test_methods_added_to_reference_functions_have_an_arity_the_reference_uses(fname):
+    ref = _ref_sources()
+    have = _arities_in_reference(fname, ref)
+    assert have, f"{fname} does not occur in /root/reference/src"
+    glue = _strip_jl_comments(JL.read_text())
+    mine = set()
+    for m in re.finditer(rf"^(?:function\s+)?(?:LinearOperators\.)?{re.escape(fname)}\(", glue, flags=re.M):
+        i, depth = m.end(), 1
+        while depth:
+            depth += glue[i] in "([{"
+            depth -= glue[i] in ")]}"
+            i += 1
+        args = glue[m.end(): i - 1]
+        pos = _split_top(args, ";")[0] if args.strip() else ""
+        mine.add(len([a for a in _split_top(pos) if a.strip()]))
+    assert mine, f"the extension defines no method of {fname}"
+    assert mine <= have, (f"{fname}: the extension defines methods with {sorted(mine)} positional arguments, the reference "
+                          f"defines / calls it with {sorted(have)}")
+
+
+def test_runtests_mirrors_the_reference_gpu_tests_line_by_line():
+    """julia/runtests_mxlo.jl carries the storage_type assertions of /root/reference/test/gpu/test_S_kwarg.jl:16-44 and
+    test/gpu/amdgpu.jl:5-19 with the extension's array types (checked textually; the Python mirror of the same
+    assertions runs on the GPU in tests/test_gpu_callers.py::test_storage_type_kwarg_mirror)."""
+    rt = (ROOT / "julia" / "runtests_mxlo.jl").read_text()
+    for frag in ("storage_type(LinearOperator(mat)) == LinearOperators.storage_type(mat)", "LinearOperator(mat; S = vecTother)",
+                 "LinearOperator(Symmetric(mat); S = vecT)", "LinearOperator(Hermitian(mat); S = vecT)",
+                 "LinearOperator(Float32, 32, 32, true, true, () -> 0; S = vecT)", "opEye(Float32, 32; S = vecT)",
+                 "opEye(Float32, 16, 32; S = vecT)", "opOnes(Float32, 32, 32; S = vecT)", "opZeros(Float32, 32, 32; S = vecT)",
+                 "opDiagonal(vec)", "opDiagonal(32, 32, vec)", "opRestriction([1, 2, 3], 32; S = vecT)",
+                 "opExtension([1, 2, 3], 32; S = vecT)", "BlockDiagonalOperator(mat, mat)", "BlockDiagonalOperator(mat, mat; S = vecTother)",
+                 "BlockDiagonalOperator(A, B, C)", "y isa MXVector{Float32}", "storage_type(adjoint(A))", "storage_type(transpose(A))",
+                 "storage_type(Diagonal(v)) == typeof(v)", "@allocated mul!(res, B, x)", "@allocated push!(HD, x, y, 1.0, x, tmpd)"):
+        assert frag in rt, frag
+    if (REF / "test" / "gpu" / "test_S_kwarg.jl").exists():       # the mirrored assertions still exist upstream
+        up = (REF / "test" / "gpu" / "test_S_kwarg.jl").read_text() + (REF / "test" / "gpu" / "amdgpu.jl").read_text()
+        for frag in ("LinearOperator(mat; S = vecTother)", "opRestriction([1, 2, 3], 32; S = vecT)", "BlockDiagonalOperator(A, B, C)",
+                     "storage_type(Diagonal(v)) == typeof(v)"):
+            assert frag in up, frag

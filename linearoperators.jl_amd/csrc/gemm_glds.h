@@ -67,8 +67,13 @@ __device__ __forceinline__ void gl_tile_of(int id, int gx, int gy, int &tx, int 
 }
 
 // AK: the A operand is K-contiguous (element (i,k) at A[k + i*lda]); otherwise M-contiguous (A[i + k*lda]).
+// PAIR: a wave's 16-row (16-column) MFMA tiles are interleaved in pairs — tile 2g covers rows wm + 32g + 2*l15, tile 2g+1
+// rows wm + 32g + 2*l15 + 1 — so that the two fragments a lane needs for a tile pair are ADJACENT in the M-/N-contiguous
+// LDS image and arrive with one 16-byte (f64) / 8-byte (f32) ds_read instead of two reads: half the LDS instructions for
+// the same bytes. The C tile is un-permuted in the epilogue. (A K-contiguous A image has no adjacent rows: A stays
+// unpaired there.)
 template <typename T, typename CA, typename CB, bool BETA0, bool AK, int TM, int TN, int WM, int WN, int BK, int NST,
-          bool SPREAD = true, bool PIN = true>
+          bool SPREAD = true, bool PIN = true, bool PAIR = false>
 __global__ void __launch_bounds__(WM * WN * 64)
 gemm_glds_kernel(T *__restrict__ C, int64_t ldc, const T *__restrict__ A, int64_t lda,
                  const T *__restrict__ B, int64_t ldb, GlShape S, CA alpha, CB beta) {
@@ -169,10 +174,12 @@ gemm_glds_kernel(T *__restrict__ C, int64_t ldc, const T *__restrict__ A, int64_
   const int l15 = lane & 15, l4 = lane >> 4;
   // fragment offsets inside a stage image for k-step 0 (k = l4); a k-step advances k by 4, which keeps k & 1 and
   // (for the K-contiguous image) the XOR pattern's low bits: offsets for step ks follow by adding a constant.
+  constexpr bool PA = PAIR && !AK && (MT % 2 == 0), PB = PAIR && (NT % 2 == 0);   // which operand's tiles are paired
+  typedef T Pair2 __attribute__((ext_vector_type(2)));
   int offA[MT], offB[NT];
 #pragma unroll
   for (int a = 0; a < MT; ++a) {
-    const int i = wm + a * 16 + l15;
+    const int i = PA ? wm + (a >> 1) * 32 + 2 * l15 + (a & 1) : wm + a * 16 + l15;
     if constexpr (AK) {
       const int g = ((BK >= 32 ? (i & 15) : ((i >> 1) & 7)) * 2) & (BK - 1) & ~(VEC - 1);
       offA[a] = i * BK + g;                    // element (i,k) at i*BK + (k ^ g): k is XORed per step below
@@ -182,7 +189,7 @@ gemm_glds_kernel(T *__restrict__ C, int64_t ldc, const T *__restrict__ A, int64_
   }
 #pragma unroll
   for (int b = 0; b < NT; ++b) {
-    const int j = wn + b * 16 + l15;
+    const int j = PB ? wn + (b >> 1) * 32 + 2 * l15 + (b & 1) : wn + b * 16 + l15;
     offB[b] = AIMG + l4 * TN + (j ^ ((l4 & 1) << 4));
   }
   auto frag = [&](const T *st, int ks, T (&av)[MT], T (&bv)[NT]) {
@@ -192,12 +199,28 @@ gemm_glds_kernel(T *__restrict__ C, int64_t ldc, const T *__restrict__ A, int64_
         const int i = wm + a * 16 + l15;
         const int g = ((BK >= 32 ? (i & 15) : ((i >> 1) & 7)) * 2) & (BK - 1) & ~(VEC - 1);
         av[a] = st[i * BK + ((ks * 4 + l4) ^ g)];
+      } else if constexpr (PA) {
+        if ((a & 1) == 0) {
+          const Pair2 v2 = *reinterpret_cast<const Pair2 *>(st + offA[a] + ks * 4 * TM);
+          av[a] = v2[0];
+          av[a + 1] = v2[1];
+        }
       } else {
         av[a] = st[offA[a] + ks * 4 * TM];
       }
     }
 #pragma unroll
-    for (int b = 0; b < NT; ++b) bv[b] = st[offB[b] + ks * 4 * TN];
+    for (int b = 0; b < NT; ++b) {
+      if constexpr (PB) {
+        if ((b & 1) == 0) {
+          const Pair2 v2 = *reinterpret_cast<const Pair2 *>(st + offB[b] + ks * 4 * TN);
+          bv[b] = v2[0];
+          bv[b + 1] = v2[1];
+        }
+      } else {
+        bv[b] = st[offB[b] + ks * 4 * TN];
+      }
+    }
   };
   auto compute_tail = [&](int stage, int ksteps) {   // last, partial slab: ksteps < BK/4 (runtime)
     const T *st = lds + stage * (AIMG + BIMG);
@@ -322,8 +345,9 @@ gemm_glds_kernel(T *__restrict__ C, int64_t ldc, const T *__restrict__ A, int64_
     for (int b = 0; b < NT; ++b)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int gi = bm + wm + a * 16 + GlMfma<T>::row(lane, r);
-        const int gj = bn + wn + b * 16 + l15;
+        const int gi = PA ? bm + wm + (a >> 1) * 32 + 2 * GlMfma<T>::row(lane, r) + (a & 1)
+                          : bm + wm + a * 16 + GlMfma<T>::row(lane, r);
+        const int gj = PB ? bn + wn + (b >> 1) * 32 + 2 * l15 + (b & 1) : bn + wn + b * 16 + l15;
         if (gi < M && gj < N) {
           T *p = C + gi + (int64_t)gj * ldc;
           const CA t = alpha * (CA)acc[a][b][r];

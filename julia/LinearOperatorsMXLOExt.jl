@@ -497,7 +497,7 @@ end
 
 # kron with complex factors (test/test_kron.jl:3-8 pairs a Float64 A with a ComplexF64 B): the library works on REAL
 # planes — a complex factor is split once into (re, im) column-major MXMatrix planes, a real factor is passed as it is
-# with a NULL imaginary plane; every complex product is 4 (2) real MFMA GEMMs. mode bit 0 = transposed, bit 1 = conjugated.
+# with a NULL imaginary plane; every complex product is 3 (Gauss form; 2 for a real factor) real MFMA GEMMs. mode bit 0 = transposed, bit 1 = conjugated.
 struct Planes{R}
   re::MXMatrix{R}
   im::Union{MXMatrix{R}, Nothing}
@@ -519,9 +519,11 @@ function ckron(A::MXMatrix, B::MXMatrix)
   (eltype(pa.re) === R && eltype(pb.re) === R) || throw(ArgumentError("kron: convert the factors to a common precision first"))
   m, n = size(A)
   p, q = size(B)
-  work = MXVector{R}(undef, 2 * (max(q * n, p * m) + max(m * q, n * p) + max(p * m, q * n)) + 24)
+  # Gauss form: 3 real GEMMs per complex product (mxlo_kron_mul_c3); the library states its workspace need itself
+  wsz(mode) = ccall((:mxlo_kron_c3_work_size, lib), Int64, (Int64, Int64, Int32, Int64, Int64, Int32), m, n, Int32(mode), p, q, Int32(mode))
+  work = MXVector{R}(undef, max(wsz(0), wsz(1)))
   imptr(x) = x === nothing ? C_NULL : x.data.ptr
-  mulmode(mode) = (res, x, α, β) -> check(ccall((:mxlo_kron_mul_c, lib), Int32,
+  mulmode(mode) = (res, x, α, β) -> check(ccall((:mxlo_kron_mul_c3, lib), Int32,
       (P, Int32, P, P, P, Int64, Int64, Int64, Int32, P, P, Int64, Int64, Int64, Int32, P, P, Float64, Float64, Float64, Float64, Int32),
       ctx(), dt(T), res.ptr, pa.re.data.ptr, imptr(pa.im), m, n, m, Int32(mode), pb.re.data.ptr, imptr(pb.im), p, q, p, Int32(mode),
       x.ptr, work.ptr, rpart(α), ipart(α), rpart(β), ipart(β), flags(T, α, β)))

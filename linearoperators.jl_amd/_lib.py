@@ -118,6 +118,8 @@ _PROTOS = {
     "mxlo_dot_c": [_vp, _i32, _vp, _vp, _i64, _vp],
     "mxlo_householder_mul_c": [_vp, _i32, _vp, _vp, _vp, _i64, _dbl, _dbl, _dbl, _dbl, _i32],
     "mxlo_kron_mul_c": [_vp, _i32, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _vp, _vp, _i64, _i64, _i64, _i32, _vp, _vp, _dbl, _dbl, _dbl, _dbl, _i32],
+    "mxlo_kron_mul_c3": [_vp, _i32, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _vp, _vp, _i64, _i64, _i64, _i32, _vp, _vp, _dbl, _dbl, _dbl, _dbl, _i32],
+    "mxlo_kron_c3_work_size": [_i64, _i64, _i32, _i64, _i64, _i32],
     "mxlo_split_c": [_vp, _i32, _vp, _vp, _vp, _i64],
     "mxlo_join_c": [_vp, _i32, _vp, _vp, _vp, _i64, _dbl, _dbl, _dbl, _dbl, _i32],
     "mxlo_gemv_c": [_vp, _i32, _vp, _vp, _i64, _i64, _i64, _vp, _dbl, _dbl, _dbl, _dbl, _i32, _i32],
@@ -186,7 +188,7 @@ def lib() -> C.CDLL:
         except AttributeError:
             continue  # symbol-export test reports it; calls through it raise below
         f.argtypes = args
-        f.restype = _i32
+        f.restype = _i64 if name == "mxlo_kron_c3_work_size" else _i32
     _lib = L
     return L
 

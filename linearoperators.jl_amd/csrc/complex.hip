@@ -24,6 +24,10 @@ template <typename R>
 int32_t kron_planes(mxlo_ctx *ctx, R *rr, R *ri, const R *Ar, const R *Ai, int64_t am, int64_t an, int64_t lda,
                     bool trans_a, double sign_ai, const R *Br, const R *Bi, int64_t bp, int64_t bq, int64_t ldb,
                     bool trans_b, double sign_bi, const R *xr, const R *xi, R *utr, R *uti);   // dense.hip
+template <typename R>
+int32_t kron_planes3(mxlo_ctx *ctx, R *rr, R *ri, const R *Ar, const R *Ai, int64_t am, int64_t an, int64_t lda,
+                     bool trans_a, double sign_ai, const R *Br, const R *Bi, int64_t bp, int64_t bq, int64_t ldb,
+                     bool trans_b, double sign_bi, const R *xr, const R *xi, const R *xd, const R *xs, R *work);   // dense.hip
 }  // namespace mxlo
 
 namespace {
@@ -905,11 +909,32 @@ int32_t chermitian_two_pass(mxlo_ctx *ctx, C<R> *res, const void *d, bool d_real
 // ---- kron on complex data: split x into planes, real MFMA GEMMs on planes (dense.hip: kron_planes), join with α, β ------
 template <typename R>
 __global__ void __launch_bounds__(kBlock)
-cplx_split_kernel(R *__restrict__ re, R *__restrict__ im, const C<R> *__restrict__ x, int64_t n) {
-  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+cplx_split_kernel(R *__restrict__ re, R *__restrict__ im, const C<R> *__restrict__ x, int64_t n,
+                  R *__restrict__ dmr = nullptr, R *__restrict__ spr = nullptr) {   // optional: im - re, re + im (Gauss form)
+  // two elements per lane when everything is suitably aligned: 2 x sizeof(C<R>) read, 2 x sizeof(R) per plane written
+  typedef R R2 __attribute__((ext_vector_type(2)));
+  const bool vec = ((((uintptr_t)x) & (2 * sizeof(C<R>) - 1)) | ((((uintptr_t)re) | ((uintptr_t)im) | ((uintptr_t)dmr) | ((uintptr_t)spr)) &
+                                                                (2 * sizeof(R) - 1))) == 0;
+  const int64_t np = vec ? n / 2 : 0;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < np; i += (int64_t)gridDim.x * kBlock) {
+    const C<R> e0 = x[2 * i], e1 = x[2 * i + 1];
+    R2 r_, i_;
+    r_[0] = e0.re; r_[1] = e1.re; i_[0] = e0.im; i_[1] = e1.im;
+    reinterpret_cast<R2 *>(re)[i] = r_;
+    reinterpret_cast<R2 *>(im)[i] = i_;
+    if (dmr) {
+      reinterpret_cast<R2 *>(dmr)[i] = i_ - r_;
+      reinterpret_cast<R2 *>(spr)[i] = r_ + i_;
+    }
+  }
+  for (int64_t i = 2 * np + (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
     const C<R> e = x[i];
     re[i] = e.re;
     im[i] = e.im;
+    if (dmr) {
+      dmr[i] = e.im - e.re;
+      spr[i] = e.re + e.im;
+    }
   }
 }
 template <typename R, typename RA, typename RB, bool BETA0>
@@ -940,6 +965,38 @@ int32_t ckron(mxlo_ctx *ctx, C<R> *res, const R *Ar, const R *Ai, int64_t am, in
   MXLO_LAUNCH_CHECK();
   MXLO_TRY((kron_planes<R>(ctx, rr, ri, Ar, Ai, am, an, lda, ta, (mode_a & 2) ? -1.0 : 1.0, Br, Bi, bp, bq, ldb, tb,
                            (mode_b & 2) ? -1.0 : 1.0, xr, xi, utr, uti)));
+  const int grid = grid_for(ctx, nout, kBlock, 8);
+  return dispatch_c<R>(s, [&]<typename RA, typename RB, bool B0>() -> int32_t {
+    const Sc<RA> a{(RA)s.are, (RA)s.aim, s.a_real};
+    const Sc<RB> b{(RB)s.bre, (RB)s.bim, s.b_real};
+    hipLaunchKernelGGL((cplx_join_kernel<R, RA, RB, B0>), dim3(grid), dim3(kBlock), 0, ctx->stream, res, (const R *)rr,
+                       (const R *)ri, nout, a, b);
+    MXLO_LAUNCH_CHECK();
+    return MXLO_OK;
+  });
+}
+
+// kron on complex data with 3 real GEMMs per complex product (dense.hip: kron_planes3)
+template <typename R>
+int32_t ckron3(mxlo_ctx *ctx, C<R> *res, const R *Ar, const R *Ai, int64_t am, int64_t an, int64_t lda, int mode_a,
+               const R *Br, const R *Bi, int64_t bp, int64_t bq, int64_t ldb, int mode_b, const C<R> *x, R *work,
+               const ScalArgs &s) {
+  const bool ta = (mode_a & 1) != 0, tb = (mode_b & 1) != 0;
+  const int64_t m = ta ? an : am, n = ta ? am : an, p = tb ? bq : bp, q = tb ? bp : bq;
+  const int64_t nout = p * m, nin = q * n;
+  if (nout == 0) return MXLO_OK;
+  if (nin == 0) {
+    if (s.bre == 0 && s.bim == 0) return cfill<R>(ctx, res, nout, C<R>());
+    return cscale<R>(ctx, res, nout, s.bre, s.bim, s.b_real, s.b64);
+  }
+  auto pad = [](int64_t k) { return (k + 3) & ~(int64_t)3; };
+  R *xr = work, *xi = xr + pad(nin), *xd = xi + pad(nin), *xs = xd + pad(nin), *rr = xs + pad(nin), *ri = rr + pad(nout),
+    *rest = ri + pad(nout);
+  hipLaunchKernelGGL((cplx_split_kernel<R>), dim3(grid_for(ctx, nin, kBlock, 8)), dim3(kBlock), 0, ctx->stream, xr, xi, x, nin,
+                     Ai ? xd : (R *)nullptr, Ai ? xs : (R *)nullptr);
+  MXLO_LAUNCH_CHECK();
+  MXLO_TRY((kron_planes3<R>(ctx, rr, ri, Ar, Ai, am, an, lda, ta, (mode_a & 2) ? -1.0 : 1.0, Br, Bi, bp, bq, ldb, tb,
+                            (mode_b & 2) ? -1.0 : 1.0, xr, xi, xd, xs, rest)));
   const int grid = grid_for(ctx, nout, kBlock, 8);
   return dispatch_c<R>(s, [&]<typename RA, typename RB, bool B0>() -> int32_t {
     const Sc<RA> a{(RA)s.are, (RA)s.aim, s.a_real};
@@ -1084,6 +1141,34 @@ MXLO_API int32_t mxlo_kron_mul_c(mxlo_ctx *ctx, int32_t dtype, void *res, const 
   return ckron<float>(ctx, (C<float> *)res, (const float *)Ar, (const float *)Ai, am, an, lda, mode_a, (const float *)Br,
                       (const float *)Bi, bp, bq, ldb, mode_b, (const C<float> *)x, (float *)work,
                       scal_args(4, alpha_re, alpha_im, beta_re, beta_im, flags));
+}
+
+MXLO_API int64_t mxlo_kron_c3_work_size(int64_t am, int64_t an, int32_t mode_a, int64_t bp, int64_t bq, int32_t mode_b) {
+  const int64_t m = (mode_a & 1) ? an : am, n = (mode_a & 1) ? am : an, p = (mode_b & 1) ? bq : bp, q = (mode_b & 1) ? bp : bq;
+  auto pad = [](int64_t k) { return (k + 3) & ~(int64_t)3; };
+  const int64_t kmax = std::max(m * q, p * m), fmax = std::max(am * an, bp * bq);
+  return 4 * pad(q * n) + 2 * pad(p * m) + 4 * pad(m * q) + 3 * pad(kmax) + pad(fmax) + 8;
+}
+
+MXLO_API int32_t mxlo_kron_mul_c3(mxlo_ctx *ctx, int32_t dtype, void *res, const void *Ar, const void *Ai, int64_t am,
+                                  int64_t an, int64_t lda, int32_t mode_a, const void *Br, const void *Bi, int64_t bp,
+                                  int64_t bq, int64_t ldb, int32_t mode_b, const void *x, void *work, double alpha_re,
+                                  double alpha_im, double beta_re, double beta_im, int32_t flags) {
+  CHECK_C("mxlo_kron_mul_c3");
+  MXLO_REQUIRE(am >= 0 && an >= 0 && bp >= 0 && bq >= 0, MXLO_ESHAPE, "mxlo_kron_mul_c3: negative size");
+  MXLO_REQUIRE(lda >= (am > 1 ? am : 1) && ldb >= (bp > 1 ? bp : 1), MXLO_ESHAPE, "mxlo_kron_mul_c3: bad leading dimension");
+  MXLO_REQUIRE(mode_a >= 0 && mode_a <= 3 && mode_b >= 0 && mode_b <= 3, MXLO_EINVAL, "mxlo_kron_mul_c3: bad factor mode");
+  const int64_t m = (mode_a & 1) ? an : am, p = (mode_b & 1) ? bq : bp;
+  if (m * p == 0) return MXLO_OK;
+  MXLO_REQUIRE(res && Ar && Br && x && work, MXLO_EINVAL, "mxlo_kron_mul_c3: NULL operand");
+  MXLO_REQUIRE((((uintptr_t)work) & 15u) == 0, MXLO_EINVAL, "mxlo_kron_mul_c3: work must be 16-byte aligned");
+  if (dtype == MXLO_C64)
+    return ckron3<double>(ctx, (C<double> *)res, (const double *)Ar, (const double *)Ai, am, an, lda, mode_a, (const double *)Br,
+                          (const double *)Bi, bp, bq, ldb, mode_b, (const C<double> *)x, (double *)work,
+                          scal_args(8, alpha_re, alpha_im, beta_re, beta_im, flags));
+  return ckron3<float>(ctx, (C<float> *)res, (const float *)Ar, (const float *)Ai, am, an, lda, mode_a, (const float *)Br,
+                       (const float *)Bi, bp, bq, ldb, mode_b, (const C<float> *)x, (float *)work,
+                       scal_args(4, alpha_re, alpha_im, beta_re, beta_im, flags));
 }
 
 // A REAL operator applied to complex vectors (K * x with eltype(K) = Float64, x::Vector{ComplexF64} — test/test_kron.jl

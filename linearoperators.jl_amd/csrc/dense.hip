@@ -1030,6 +1030,157 @@ template int32_t kron_planes<float>(mxlo_ctx *, float *, float *, const float *,
                                     const float *, const float *, float *, float *);
 }  // namespace mxlo
 
+// ---- kron on Complex{R}, Gauss / Karatsuba form: THREE real GEMMs per complex product instead of four ------------------
+//   (a + ib)(c + id):  k1 = (a + b) c,  k2 = a (d - c),  k3 = b (c + d);  real = k1 - k3,  imag = k1 + k2
+// with a, b the planes of a factor and c, d the planes of the data. The factor sum a + b (sign of b flipped for a
+// conjugated factor) is formed per call in the workspace (one elementwise pass over the factor: the library is
+// stateless about factors), d - c and c + d come out of the kernel that produces c, d anyway (the split of x for the
+// first product, the combination of k1..k3 for the second), and the three GEMMs write three separate planes with
+// beta = 0 (no read-modify-write of C). A real factor keeps its two plain GEMMs.
+namespace mxlo {
+template <typename R>
+__global__ void __launch_bounds__(kBlock)
+plane_sum_kernel(R *__restrict__ out, const R *__restrict__ a, const R *__restrict__ b, int64_t rows, int64_t cols,
+                 int64_t ld, R sign) {   // out (rows x cols, ld = rows) = a + sign*b, a / b with leading dimension ld
+  using V = typename Vec16<R>::type;
+  constexpr int VEC = Vec16<R>::N;
+  const int64_t total = rows * cols;
+  if (ld == rows && ((((uintptr_t)a) | ((uintptr_t)b)) & 15u) == 0) {     // contiguous factor: 16-byte accesses
+    const int64_t nv = total / VEC;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < nv; i += (int64_t)gridDim.x * kBlock) {
+      const V av = reinterpret_cast<const V *>(a)[i], bv = reinterpret_cast<const V *>(b)[i];
+      V o;
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) o[e] = av[e] + sign * bv[e];
+      reinterpret_cast<V *>(out)[i] = o;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < total - nv * VEC) {
+      const int64_t i = nv * VEC + threadIdx.x;
+      out[i] = a[i] + sign * b[i];
+    }
+    return;
+  }
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
+    const int64_t r = i % rows, c = i / rows;
+    out[i] = a[r + c * ld] + sign * b[r + c * ld];
+  }
+}
+// (k1, k2, k3) -> re = k1 - k3, im = k1 + k2 and, for the next Gauss product, im - re and re + im. K3 false: the factor
+// was real and (re, im) hold the two products already: only the two combinations are formed. All planes are 16-byte
+// aligned workspace planes: 16-byte accesses, scalar tail.
+template <typename R, bool K3, bool NEXT>
+__global__ void __launch_bounds__(kBlock)
+gauss_planes_kernel(R *__restrict__ re, R *__restrict__ im, R *__restrict__ dmr, R *__restrict__ spr,
+                    const R *__restrict__ k1, const R *__restrict__ k2, const R *__restrict__ k3, int64_t n) {
+  using V = typename Vec16<R>::type;
+  constexpr int VEC = Vec16<R>::N;
+  const int64_t nv = n / VEC;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < nv; i += (int64_t)gridDim.x * kBlock) {
+    V r_, i_;
+    if constexpr (K3) {
+      const V a = reinterpret_cast<const V *>(k1)[i], b = reinterpret_cast<const V *>(k2)[i], c = reinterpret_cast<const V *>(k3)[i];
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        r_[e] = a[e] - c[e];
+        i_[e] = a[e] + b[e];
+      }
+      reinterpret_cast<V *>(re)[i] = r_;
+      reinterpret_cast<V *>(im)[i] = i_;
+    } else {
+      r_ = reinterpret_cast<const V *>(re)[i];
+      i_ = reinterpret_cast<const V *>(im)[i];
+    }
+    if constexpr (NEXT) {
+      V d, s;
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        d[e] = i_[e] - r_[e];
+        s[e] = r_[e] + i_[e];
+      }
+      reinterpret_cast<V *>(dmr)[i] = d;
+      reinterpret_cast<V *>(spr)[i] = s;
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x < n - nv * VEC) {
+    const int64_t i = nv * VEC + threadIdx.x;
+    R r_, i_;
+    if constexpr (K3) {
+      r_ = k1[i] - k3[i];
+      i_ = k1[i] + k2[i];
+      re[i] = r_;
+      im[i] = i_;
+    } else {
+      r_ = re[i];
+      i_ = im[i];
+    }
+    if constexpr (NEXT) {
+      dmr[i] = i_ - r_;
+      spr[i] = r_ + i_;
+    }
+  }
+}
+
+// work layout (R scalars, every plane 16-byte aligned): see mxlo_kron_mul_c3 in include/mxlo.h
+template <typename R>
+int32_t kron_planes3(mxlo_ctx *ctx, R *rr, R *ri, const R *Ar, const R *Ai, int64_t am, int64_t an, int64_t lda,
+                     bool trans_a, double sign_ai, const R *Br, const R *Bi, int64_t bp, int64_t bq, int64_t ldb,
+                     bool trans_b, double sign_bi, const R *xr, const R *xi, const R *xd, const R *xs, R *work) {
+  const int64_t m = trans_a ? an : am, n = trans_a ? am : an;
+  const int64_t p = trans_b ? bq : bp, q = trans_b ? bp : bq;
+  auto pad = [](int64_t k) { return (k + 3) & ~(int64_t)3; };
+  R *ur = work, *ui = ur + pad(m * q), *ud = ui + pad(m * q), *us = ud + pad(m * q);
+  R *k1 = us + pad(m * q), *k2 = k1 + pad(std::max(m * q, p * m)), *k3 = k2 + pad(std::max(m * q, p * m));
+  R *fs = k3 + pad(std::max(m * q, p * m));                       // factor sum plane (am*an, then bp*bq)
+  auto egrid = [&](int64_t cnt) { return grid_for(ctx, (cnt + 1) / 2, kBlock, 8); };
+  // ---- first product: U^T = opA(A) X^T  (m x q, K = n)
+  if (Ai) {
+    hipLaunchKernelGGL((plane_sum_kernel<R>), dim3(egrid(am * an)), dim3(kBlock), 0, ctx->stream, fs, Ar, Ai, am, an, lda,
+                       (R)sign_ai);
+    MXLO_LAUNCH_CHECK();
+    MXLO_TRY(gemm<R>(ctx, k1, m, fs, am, trans_a, xr, q, true, m, q, n, 1.0, 0.0, 0));          // (a + b) c
+    MXLO_TRY(gemm<R>(ctx, k2, m, Ar, lda, trans_a, xd, q, true, m, q, n, 1.0, 0.0, 0));         // a (d - c)
+    MXLO_TRY(gemm<R>(ctx, k3, m, Ai, lda, trans_a, xs, q, true, m, q, n, sign_ai, 0.0, 0));     // b (c + d)
+    if (Bi)
+      hipLaunchKernelGGL((gauss_planes_kernel<R, true, true>), dim3(egrid(m * q)), dim3(kBlock), 0, ctx->stream, ur, ui, ud, us,
+                         (const R *)k1, (const R *)k2, (const R *)k3, m * q);
+    else
+      hipLaunchKernelGGL((gauss_planes_kernel<R, true, false>), dim3(egrid(m * q)), dim3(kBlock), 0, ctx->stream, ur, ui,
+                         (R *)nullptr, (R *)nullptr, (const R *)k1, (const R *)k2, (const R *)k3, m * q);
+    MXLO_LAUNCH_CHECK();
+  } else {
+    MXLO_TRY(gemm<R>(ctx, ur, m, Ar, lda, trans_a, xr, q, true, m, q, n, 1.0, 0.0, 0));
+    MXLO_TRY(gemm<R>(ctx, ui, m, Ar, lda, trans_a, xi, q, true, m, q, n, 1.0, 0.0, 0));
+    if (Bi) {
+      hipLaunchKernelGGL((gauss_planes_kernel<R, false, true>), dim3(egrid(m * q)), dim3(kBlock), 0, ctx->stream, ur, ui, ud, us,
+                         (const R *)nullptr, (const R *)nullptr, (const R *)nullptr, m * q);
+      MXLO_LAUNCH_CHECK();
+    }
+  }
+  // ---- second product: R = opB(B) U  (p x m, K = q)
+  if (Bi) {
+    hipLaunchKernelGGL((plane_sum_kernel<R>), dim3(egrid(bp * bq)), dim3(kBlock), 0, ctx->stream, fs, Br, Bi, bp, bq, ldb,
+                       (R)sign_bi);
+    MXLO_LAUNCH_CHECK();
+    MXLO_TRY(gemm<R>(ctx, k1, p, fs, bp, trans_b, ur, m, true, p, m, q, 1.0, 0.0, 0));
+    MXLO_TRY(gemm<R>(ctx, k2, p, Br, ldb, trans_b, ud, m, true, p, m, q, 1.0, 0.0, 0));
+    MXLO_TRY(gemm<R>(ctx, k3, p, Bi, ldb, trans_b, us, m, true, p, m, q, sign_bi, 0.0, 0));
+    hipLaunchKernelGGL((gauss_planes_kernel<R, true, false>), dim3(egrid(p * m)), dim3(kBlock), 0, ctx->stream, rr, ri, (R *)nullptr,
+                       (R *)nullptr, (const R *)k1, (const R *)k2, (const R *)k3, p * m);
+    MXLO_LAUNCH_CHECK();
+  } else {
+    MXLO_TRY(gemm<R>(ctx, rr, p, Br, ldb, trans_b, ur, m, true, p, m, q, 1.0, 0.0, 0));
+    MXLO_TRY(gemm<R>(ctx, ri, p, Br, ldb, trans_b, ui, m, true, p, m, q, 1.0, 0.0, 0));
+  }
+  return MXLO_OK;
+}
+template int32_t kron_planes3<double>(mxlo_ctx *, double *, double *, const double *, const double *, int64_t, int64_t, int64_t,
+                                      bool, double, const double *, const double *, int64_t, int64_t, int64_t, bool, double,
+                                      const double *, const double *, const double *, const double *, double *);
+template int32_t kron_planes3<float>(mxlo_ctx *, float *, float *, const float *, const float *, int64_t, int64_t, int64_t, bool,
+                                     double, const float *, const float *, int64_t, int64_t, int64_t, bool, double,
+                                     const float *, const float *, const float *, const float *, float *);
+}  // namespace mxlo
+
 static inline void eff_ab(int32_t dtype, int32_t flags, double &alpha, double &beta) {
   eff_scalars(dtype == MXLO_F64 ? 8 : 4, flags, alpha, beta);
 }

@@ -1136,7 +1136,6 @@ int32_t lbfgs_push_fused(mxlo_qn *h, const T *s, const T *y, int32_t *accepted) 
   const int64_t npad = (n + VECP - 1) / VECP * VECP;
   const bool inverse = h->kind == MXLO_QN_LBFGS_INV;
   double *misc = h->dsc + h->lay.misc, *scratch = h->dsc + h->lay.dots, *gt = inverse ? nullptr : h->dsc + h->lay.gtmp;
-  if (!inverse) MXLO_TRY(gram_make_consistent<T>(h, ins));   // only after reference-ordered pushes
   const T *cols[kMaxCols];
   // columns per pass: 20 while >= 20 remain (s, y are re-read once per pass: wide passes re-read them less), then <= 10
   int c0s[kMaxMem / 10 + 2], ncs[kMaxMem / 10 + 2], nchunk = 0;
@@ -1207,8 +1206,11 @@ int32_t lbfgs_push_fused(mxlo_qn *h, const T *s, const T *y, int32_t *accepted) 
 template <typename T>
 int32_t lbfgs_push(mxlo_qn *h, const T *s, const T *y, int32_t *accepted) {
   mxlo_ctx *ctx = h->ctx;
+  // (forward operator whose Gram matrices are stale after reference-ordered pushes: the two-kernel schedule below
+  //  rebuilds them, and ONLY for an accepted pair — a rejected push! must leave every piece of state, gram_ok and
+  //  the a_k coefficients included, exactly as it found it)
   if (ctx->tune.push_fused && !h->big && h->n >= 1 && ((((uintptr_t)s) | ((uintptr_t)y)) & 15u) == 0 &&
-      !(h->kind == MXLO_QN_LBFGS_FWD && h->push_mode == MXLO_PUSH_REFORDER))
+      !(h->kind == MXLO_QN_LBFGS_FWD && (h->push_mode == MXLO_PUSH_REFORDER || !h->gram_ok)))
     return lbfgs_push_fused<T>(h, s, y, accepted);
   double *misc = h->dsc + h->lay.misc;
   const T *cols[2] = {s, y};

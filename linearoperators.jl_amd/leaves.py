@@ -10,6 +10,8 @@ them): ``opRestriction([1, 2, 4, 7], 10)``; ``jrange(3, 6)`` is Julia's ``3:6`` 
 """
 from __future__ import annotations
 
+import os
+
 import ctypes as C
 from typing import Optional, Sequence
 
@@ -612,13 +614,20 @@ def _kron_complex(A, B, fA, fB, T):
             return self.cache[0], self.cache[1], 0
 
     pA, pB = Planes(fA), Planes(fB)
-    work = torch.empty(2 * (max(q * n, p * m) + max(m * q, n * p) + max(p * m, q * n)) + 24, dtype=R, device=dev)
+    # Gauss form (3 real GEMMs per complex product, `mxlo_kron_mul_c3`) by default; MXLO_KRON_GAUSS=0 keeps the 4-GEMM
+    # form (`mxlo_kron_mul_c`), which the tests use as the independent device implementation. The workspace covers the
+    # forward and the transposed shapes of both forms.
+    gauss = os.environ.get("MXLO_KRON_GAUSS", "1") != "0"
+    wsz = _lib.lib().mxlo_kron_c3_work_size
+    need = max(int(wsz(m, n, 0, p, q, 0)), int(wsz(m, n, 1, p, q, 1)),
+               2 * (max(q * n, p * m) + max(m * q, n * p) + max(p * m, q * n)) + 24)
+    work = torch.empty(need, dtype=R, device=dev)
 
     def km(res, x, a, b, trans, conj):
         ctx = get_ctx(res.device)
         Ar, Ai, ta = pA.get()
         Br, Bi, tb = pB.get()
-        _lib.call("mxlo_kron_mul_c", ctx.handle, dtype_code(T, True), ptr(res), ptr(Ar), ptr(Ai), Ar.shape[0], Ar.shape[1],
+        _lib.call("mxlo_kron_mul_c3" if gauss else "mxlo_kron_mul_c", ctx.handle, dtype_code(T, True), ptr(res), ptr(Ar), ptr(Ai), Ar.shape[0], Ar.shape[1],
                   _ld(Ar), (ta ^ trans) | (conj << 1), ptr(Br), ptr(Bi), Br.shape[0], Br.shape[1], _ld(Br),
                   (tb ^ trans) | (conj << 1), ptr(x), ptr(work), *_c4(a, b), scalar_flags(res.dtype, a, b))
 

@@ -47,3 +47,16 @@ def kat():
     import json
     with open(os.path.join(ROOT, "tests", "golden", "kat_reference_tests.json")) as f:
         return json.load(f)["cases"]
+
+
+def pytest_sessionfinish(session, exitstatus):
+    out = os.environ.get("MXLO_ENVELOPE_OUT")
+    if not out:
+        return
+    try:
+        import json
+        import tolerances
+        with open(out, "w") as f:
+            json.dump(tolerances.envelope(), f, indent=1)
+    except Exception as e:          # pragma: no cover
+        print(f"[mxlo] could not write {out}: {e!r}")

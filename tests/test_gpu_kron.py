@@ -293,3 +293,57 @@ def test_complex_kron_tracks_factor_updates(lo, dev):
         B.add_(0.25)
         lo.touched(A)
         lo.touched(B)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.complex128, 1e-12), (torch.complex64, 5e-5)])
+@pytest.mark.parametrize("shapes", [((40, 30), (20, 50)), ((64, 64), (64, 64)), ((7, 130), (33, 5)), ((256, 256), (128, 192))])
+def test_gauss_form_matches_four_gemm_form(lo, dev, dtype, tol, shapes):
+    """`mxlo_kron_mul_c3` (3 real GEMMs per complex product: k1 = (a+b)c, k2 = a(d-c), k3 = b(c+d)) against
+    `mxlo_kron_mul_c` (4 real GEMMs) on the same planes, every factor mode (plain / transposed / conjugate-transposed),
+    complex x complex, real x complex and complex x real factors, complex alpha / beta, and against numpy's kron within
+    the reference's criterion 1e-12 * ||K||_1 (test/test_kron.jl:35). The three-multiplication form is normwise, not
+    componentwise, accurate — which is what that criterion measures."""
+    import ctypes as C
+    from linearoperators_jl_amd import _lib
+    from linearoperators_jl_amd.device import dtype_code, get_ctx
+    ctx = get_ctx(dev)
+    R = torch.float64 if dtype == torch.complex128 else torch.float32
+    npr = np.float64 if dtype == torch.complex128 else np.float32
+    (am, an), (bp, bq) = shapes
+    rng = np.random.default_rng(am * 3 + bq)
+    col = lambda M: torch.from_numpy(np.asfortranarray(M).T.copy()).to(dev).t()       # column-major device matrix
+    for kinds in ("cc", "rc", "cr"):
+        Ar, Ai = rng.standard_normal((am, an)).astype(npr), rng.standard_normal((am, an)).astype(npr)
+        Br, Bi = rng.standard_normal((bp, bq)).astype(npr), rng.standard_normal((bp, bq)).astype(npr)
+        if kinds[0] == "r":
+            Ai = None
+        if kinds[1] == "r":
+            Bi = None
+        dAr, dBr = col(Ar), col(Br)
+        dAi, dBi = (col(Ai) if Ai is not None else None), (col(Bi) if Bi is not None else None)
+        A = Ar + (1j * Ai if Ai is not None else 0)
+        B = Br + (1j * Bi if Bi is not None else 0)
+        for mode in (0, 1, 3):
+            opA = A if mode == 0 else (A.T if mode == 1 else A.conj().T)
+            opB = B if mode == 0 else (B.T if mode == 1 else B.conj().T)
+            K = np.kron(opA.astype(np.complex128), opB.astype(np.complex128))
+            nin, nout = K.shape[1], K.shape[0]
+            x = (rng.standard_normal(nin) + 1j * rng.standard_normal(nin))
+            r0 = (rng.standard_normal(nout) + 1j * rng.standard_normal(nout))
+            xd = torch.from_numpy(x).to(dtype).to(dev)
+            need = max(int(_lib.lib().mxlo_kron_c3_work_size(am, an, mode, bp, bq, mode)),
+                       2 * (nin + max(an * bp, am * bq, an * bq, am * bp) + nout) + 24)
+            work = torch.empty(need + 64, dtype=R, device=dev)
+            out = {}
+            for name in ("mxlo_kron_mul_c3", "mxlo_kron_mul_c"):
+                res = torch.from_numpy(r0).to(dtype).to(dev)
+                _lib.call(name, ctx.handle, dtype_code(dtype, True), C.c_void_p(res.data_ptr()), C.c_void_p(dAr.data_ptr()),
+                          C.c_void_p(dAi.data_ptr() if dAi is not None else 0), am, an, am, mode, C.c_void_p(dBr.data_ptr()),
+                          C.c_void_p(dBi.data_ptr() if dBi is not None else 0), bp, bq, bp, mode, C.c_void_p(xd.data_ptr()),
+                          C.c_void_p(work.data_ptr()), 1.5, -0.5, 0.25, 2.0, 0)
+                out[name] = res.cpu().numpy().astype(np.complex128)
+            want = (1.5 - 0.5j) * (K @ xd.cpu().numpy().astype(np.complex128)) + (0.25 + 2j) * torch.from_numpy(r0).to(dtype).numpy().astype(np.complex128)
+            scale = np.abs(K).sum(axis=0).max() * max(1.0, np.abs(x).max())
+            for name, got in out.items():
+                assert np.abs(got - want).max() <= 4 * tol * scale, (name, kinds, mode)
+            assert np.abs(out["mxlo_kron_mul_c3"] - out["mxlo_kron_mul_c"]).max() <= 4 * tol * scale, (kinds, mode)

@@ -7,7 +7,9 @@ import pytest
 import torch
 
 import oracle
-from tolerances import QN_F32, QN_F32_SOLVE
+from tolerances import QN_F32_FUZZ_LBFGS, QN_F32_FUZZ_LSR1, QN_F32_SOLVE, observe
+
+QN_F32 = QN_F32_FUZZ_LSR1      # the pinned ill-conditioned sequence is an L-SR1 one
 
 pytestmark = pytest.mark.gpu
 
@@ -32,7 +34,7 @@ def test_random_operation_sequences_fp32(lo, dev, seed):
     """The same state machine on Float32 data (Float64 scalars from the caller: Julia's mixed-precision rule)."""
     if seed == ILL_CONDITIONED_F32_SEED:
         pytest.skip("pinned by name below: test_fp32_lsr1_ill_conditioned_sequence")
-    run_sequence(lo, dev, seed, torch.float32, QN_F32, QN_F32_SOLVE)
+    run_sequence(lo, dev, seed, torch.float32, QN_F32_FUZZ_LSR1 if seed % 3 == 2 else QN_F32_FUZZ_LBFGS, QN_F32_SOLVE)
 
 
 ILL_CONDITIONED_F32_SEED = 1154
@@ -96,6 +98,7 @@ def run_sequence(lo, dev, seed, dtype, tol, tol_solve, shadow=None):
             want64 = O64.mul(r0.astype(np.float64), x.astype(np.float64), a, b)
             shadow.append((tag, err / scale, np.linalg.norm(want - want64) / scale))
         else:
+            observe(f"fuzz {kind} mul!", err / scale, dtype == torch.float32)
             assert err <= tol * scale, (tag, kind, n, mem)
         assert op.data.insert == O.insert
 
@@ -122,11 +125,14 @@ def run_sequence(lo, dev, seed, dtype, tol, tol_solve, shadow=None):
             op.set_push_mode(["gram", "reforder", "compact"][rng.integers(3)])
         elif c == 8 and kind != "inv":
             got, want = lo.diag(op).cpu().numpy().astype(np.float64), O.diag().astype(np.float64)
+            if O64 is None:
+                observe(f"fuzz {kind} diag!", np.linalg.norm(got - want) / (np.linalg.norm(want) + 1e-300), dtype == torch.float32)
             assert O64 is not None or np.linalg.norm(got - want) <= tol * (np.linalg.norm(want) + 1e-300), ("diag", kind, n, mem)
         elif c == 9 and kind == "fwd":
             bvec, sig = rng.uniform(-1, 1, n).astype(npd), npd(rng.uniform(0, 2))
             got = lo.solve_shifted_system(torch.zeros(n, dtype=dtype, device=dev), op, T(bvec, dev), sig).cpu().numpy().astype(np.float64)
             want = O.solve_shifted(np.zeros(n, npd), bvec, sig).astype(np.float64)
+            observe("fuzz fwd solve_shifted_system!", np.linalg.norm(got - want) / (np.linalg.norm(want) + 1e-300), dtype == torch.float32 and O64 is None)
             assert np.linalg.norm(got - want) <= tol_solve * (np.linalg.norm(want) + 1e-300), ("solve_shifted", n, mem)
         elif c == 10:
             sig = float(rng.uniform(-1, 1))
@@ -134,5 +140,7 @@ def run_sequence(lo, dev, seed, dtype, tol, tol_solve, shadow=None):
             got = (lo.ShiftedOperator(op, sig) * T(x, dev)).cpu().numpy().astype(np.float64)
             Bx = O.mul(np.empty(n, npd), x).astype(np.float64)
             want = Bx + sig * x.astype(np.float64)
+            if O64 is None:
+                observe(f"fuzz {kind} shifted mul!", np.linalg.norm(got - want) / (np.linalg.norm(Bx) + abs(sig) * np.linalg.norm(x) + 1e-300), dtype == torch.float32)
             assert O64 is not None or np.linalg.norm(got - want) <= tol * (np.linalg.norm(Bx) + abs(sig) * np.linalg.norm(x) + 1e-300)
         check(f"step {step} op {c}")

@@ -158,7 +158,7 @@ def test_the_glue_has_ccalls_for_every_hot_path_leaf():
             "mxlo_kron_mul_ex", "mxlo_qn_create", "mxlo_qn_push", "mxlo_qn_mul", "mxlo_qn_mul_shifted",
             "mxlo_qn_solve_shifted", "mxlo_qn_diag", "mxlo_qn_reset", "mxlo_diagqn_push", "mxlo_graph_begin",
             "mxlo_graph_end", "mxlo_graph_launch", "mxlo_diag_mul_c", "mxlo_eye_mul_c", "mxlo_zeros_mul_c",
-            "mxlo_scale_c", "mxlo_conj_c", "mxlo_dot_c", "mxlo_householder_mul_c", "mxlo_gemv_c", "mxlo_hermitian_mul_c", "mxlo_kron_mul_c", "mxlo_shard_ctx_create",
+            "mxlo_scale_c", "mxlo_conj_c", "mxlo_dot_c", "mxlo_householder_mul_c", "mxlo_gemv_c", "mxlo_hermitian_mul_c", "mxlo_kron_mul_c3", "mxlo_shard_ctx_create",
             "mxlo_householder_mul_sharded", "mxlo_qn_create_sharded", "mxlo_qn_mul_sharded"}
     assert not (must - names), f"glue lacks ccalls for {sorted(must - names)}"
 

@@ -1,11 +1,43 @@
 """The stated tolerances of DESIGN.md §2 that more than one test file uses (relative L2 norms).
 
-Float32 quasi-Newton operators: ONE number for every apply path (forward compact / Gram / reference order, inverse
-two-pass / reference order, L-SR1, diag!, the fused shifted apply). The recurrences behind an apply amplify
-eps(Float32) = 6e-8 by the conditioning of the stored pairs; on the seeded well-conditioned pairs of the parity tests
-the observed error is 1e-6 .. 2e-4, and over 4010 random operation sequences (tests/test_gpu_qn_fuzz.py) 4009 stay
-below QN_F32 — the one that does not is pinned by name there, together with the evidence that the Float32 REFERENCE
-itself is that far from the exact operator on that sequence."""
-QN_F32 = 2e-3            # mul! / diag! of LBFGSOperator, InverseLBFGSOperator, LSR1Operator on Float32 data
-QN_F32_SOLVE = 2e-2      # solve_shifted_system! in coefficient space vs the oracle's recursion (src/utilities.jl:207-248)
-QN_F32_ROUNDTRIP = 5e-2  # B * solve(B, b) ≈ b, the reference's own kind of check (test/test_solve_shifted_system.jl)
+Float32 quasi-Newton operators. Round 3 set these bounds from the OBSERVED envelope (profiles/r03_qn_f32_envelope.json:
+every Float32 comparison of tests/test_gpu_qn.py and of 4010 random operation sequences of tests/test_gpu_qn_fuzz.py,
+MXLO_QNFUZZ32_SEEDS=4010, reports its error through `observe` below) instead of one loose number:
+
+  path                                                        observed max     bound
+  seeded parity tests, every operator / push mode / apply mode   1.5e-6        QN_F32            = 2e-5
+  fuzz: LBFGSOperator / InverseLBFGSOperator mul!, diag!, shifted 9.3e-7       QN_F32_FUZZ_LBFGS = 2e-5
+  fuzz: LSR1Operator mul! (diag! 4.3e-5, shifted 1.3e-4)          1.4e-3        QN_F32_FUZZ_LSR1  = 2e-3
+  solve_shifted_system! vs the oracle's recursion                 3.7e-5        QN_F32_SOLVE      = 2e-4
+  round trips  H*(B*x) ~ x,  solve(B + sI, (B + sI) x) ~ x        3.1e-7        QN_F32_ROUNDTRIP  = 1e-3
+
+The L-SR1 rows are a conditioning effect, not an accumulation one (every dot accumulates in Float64): the SR1
+denominators (y_k - B_k s_k)'s_k of random sequences with n close to mem nearly cancel, and Float32 rounding of ANY
+evaluation order then moves the operator by 1e-4 .. 1e-3. The one sequence out of 4010 that leaves even that bound
+(seed 1154, 1.6e-2) is pinned by name in tests/test_gpu_qn_fuzz.py together with the evidence that the Float32
+REFERENCE restatement itself is that far from the exact operator there."""
+QN_F32 = 2e-5            # seeded parity tests: mul! / diag! / fused shifted apply of all three operators on Float32 data
+QN_F32_FUZZ_LBFGS = 2e-5 # random operation sequences, LBFGSOperator / InverseLBFGSOperator
+QN_F32_FUZZ_LSR1 = 2e-3  # random operation sequences, LSR1Operator (conditioning of the SR1 denominators)
+QN_F32_SOLVE = 2e-4      # solve_shifted_system! in coefficient space vs the oracle's recursion (src/utilities.jl:207-248)
+QN_F32_ROUNDTRIP = 1e-3  # B * solve(B, b) ≈ b, the reference's own kind of check (test/test_solve_shifted_system.jl)
+
+# ---- observed envelope: every Float32 quasi-Newton comparison reports its relative error here; with
+# MXLO_ENVELOPE_OUT=<file> in the environment conftest.py writes the per-path maxima at the end of the session
+# (profiles/r03_qn_f32_envelope.json is such a run over MXLO_QNFUZZ32_SEEDS=4010). The bounds above are set from it.
+_ENVELOPE: dict = {}
+
+
+def observe(path: str, err, is_f32: bool = True):
+    """Record `err` (a relative error) under `path` when the comparison is a Float32 one; returns err unchanged."""
+    if is_f32:
+        e = float(err)
+        if e == e and e > _ENVELOPE.get(path, (0.0, 0))[0]:
+            _ENVELOPE[path] = (e, _ENVELOPE.get(path, (0.0, 0))[1] + 1)
+        else:
+            _ENVELOPE[path] = (_ENVELOPE.get(path, (0.0, 0))[0], _ENVELOPE.get(path, (0.0, 0))[1] + 1)
+    return err
+
+
+def envelope() -> dict:
+    return {k: {"max_rel_err": v[0], "comparisons": v[1]} for k, v in sorted(_ENVELOPE.items())}

@@ -64,6 +64,17 @@ MXLO_API int32_t mxlo_ctx_create(int32_t device_id, void *stream, mxlo_ctx **out
     for (int i = 0; i < 8; ++i) init[2 * kFusedSlots + i] = 0;
     MXLO_HIP(hipMemcpy(ctx->xslots, init.data(), init.size() * sizeof(unsigned long long), hipMemcpyHostToDevice));
   }
+  {  // the same for the single-launch quasi-Newton apply: 2 sets of 40 columns x 64 workgroups
+    constexpr size_t kQ = 2 * 40 * 64 + 8;
+    if (hipMalloc((void **)&ctx->qslots, sizeof(unsigned long long) * kQ) == hipSuccess) {
+      std::vector<unsigned long long> init(kQ, kSlotEmpty);
+      for (int i = 0; i < 8; ++i) init[kQ - 8 + i] = 0;
+      MXLO_HIP(hipMemcpy(ctx->qslots, init.data(), kQ * sizeof(unsigned long long), hipMemcpyHostToDevice));
+    } else {
+      ctx->qslots = nullptr;     // the four-launch apply is used instead
+      (void)hipGetLastError();
+    }
+  }
   *out = ctx;
   return MXLO_OK;
 }
@@ -76,6 +87,7 @@ MXLO_API int32_t mxlo_ctx_destroy(mxlo_ctx *ctx) {
   if (ctx->scalars) (void)hipFree(ctx->scalars);
   if (ctx->ticket) (void)hipFree(ctx->ticket);
   if (ctx->xslots) (void)hipFree(ctx->xslots);
+  if (ctx->qslots) (void)hipFree(ctx->qslots);
   if (ctx->scratch) (void)hipFree(ctx->scratch);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
   if (ctx->switch_event) (void)hipEventDestroy(ctx->switch_event);
@@ -325,6 +337,9 @@ MXLO_API int32_t mxlo_ctx_tune(mxlo_ctx *ctx, const char *key, int64_t value) {
   } else if (!strcmp(key, "combine_blocks_per_cu")) {
     MXLO_REQUIRE(value >= 0 && value <= 64, MXLO_EINVAL, "combine_blocks_per_cu out of range");
     ctx->tune.combine_blocks_per_cu = (int)value;
+  } else if (!strcmp(key, "qn_fused_small")) {
+    MXLO_REQUIRE(value == 0 || value == 1, MXLO_EINVAL, "qn_fused_small must be 0 or 1");
+    ctx->tune.qn_fused_small = (int)value;
   } else if (!strcmp(key, "push_wide")) {
     MXLO_REQUIRE(value == 0 || value == 1, MXLO_EINVAL, "push_wide must be 0 or 1");
     ctx->tune.push_wide = (int)value;

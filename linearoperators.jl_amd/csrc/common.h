@@ -130,6 +130,7 @@ struct Tune {
                            // workgroup), 32 / 64 / 128 force one, -1 = generic fallback kernel only
   int fuse_finalize = 1;   // reductions of <= 4 columns: last-arriving workgroup finalizes in the dots kernel
   int combine_blocks_per_cu = 0;   // panel_combine: 0 = one vector per thread (best measured), k = persistent grid
+  int qn_fused_small = 1;  // quasi-Newton applies with <= 64 workgroups of dots: dots + finalize + coefficients in one launch
   int push_wide = 1;       // one-pass push!: 20 columns per pass while >= 20 remain (0: always <= 10)
   int push_fused = 1;      // push!(op, s, y): one-pass schedule (new pair held per lane, in-pass slot stores); 0 = copies + dual-x dots
 };
@@ -145,6 +146,7 @@ struct mxlo_ctx {
   bool lds_attr_set = false;   // dynamic-LDS limits of the shifted-solve kernels raised on THIS device
   unsigned *ticket = nullptr;  // arrival counter of the fused (last-workgroup) finalize; zero between launches
   unsigned long long *xslots = nullptr;  // [2][kFusedSlots] partial-exchange slots + epoch word of the single-launch Householder
+  unsigned long long *qslots = nullptr;  // [2][40 x 64] exchange slots + epoch word of the single-launch quasi-Newton apply (qn.hip)
   mxlo_allreduce_fn allreduce = nullptr;
   void *allreduce_user = nullptr;
   void *scratch = nullptr;     // grow-on-demand workspace (opHermitian tile partials); owned by the ctx
@@ -214,6 +216,38 @@ struct Vec16<float> {
   using type = f32x4;
   static constexpr int N = 4;
 };
+
+// ---- wave-wide sum of a double, result in EVERY lane --------------------------------------------------------------
+// The coefficient recurrences of the quasi-Newton operators (one wave, O(m) .. O(m^2) dependent reductions) spent their
+// time in xor-shuffle trees: a 64-bit __shfl_xor is two ds_bpermute_b32 (~100+ cycles of latency each), six dependent
+// levels per sum. DPP moves run on the VALU at register speed: quad_perm x2, row_shr:4, row_shr:8, then row_bcast:15 /
+// row_bcast:31 (GFX9-family wave64 modes) leave the total in lane 63, which v_readlane broadcasts. Deterministic (one
+// fixed tree), ~20x shorter than the shuffle tree. Masked-off / out-of-row sources read 0 (bound_ctrl).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_shift_or_zero(double v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, true);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, true);
+  return __hiloint2double(hi, lo);
+#else
+  return v;   // host pass of the single-source compile: never executed
+#endif
+}
+__device__ __forceinline__ double wave_allsum(double v) {
+  v += dpp_shift_or_zero<0xb1, 0xf>(v);    // quad_perm [1,0,3,2]
+  v += dpp_shift_or_zero<0x4e, 0xf>(v);    // quad_perm [2,3,0,1]: every lane holds its quad's sum
+  v += dpp_shift_or_zero<0x114, 0xf>(v);   // row_shr:4
+  v += dpp_shift_or_zero<0x118, 0xf>(v);   // row_shr:8: lanes 12..15 of a row hold the row's sum
+  v += dpp_shift_or_zero<0x142, 0xa>(v);   // row_bcast:15 into rows 1, 3
+  v += dpp_shift_or_zero<0x143, 0xc>(v);   // row_bcast:31 into rows 2, 3: lane 63 holds the wave's sum
+#if defined(__HIP_DEVICE_COMPILE__)
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63), hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+  return __hiloint2double(hi, lo);
+#else
+  return v;
+#endif
+}
 
 // ---- alignment analysis for the vector path ---------------------------------
 // All operands of an elementwise kernel can use 16-byte accesses iff they share

@@ -355,39 +355,30 @@ __device__ __forceinline__ double rnd(double v, int is_f32) { return is_f32 ? (d
 //   dots[i] = s_i'x, dots[na+i] = y_i'x for i = 0..na-1 in NEWEST->OLDEST order (ord[]).
 //   coef[i]      = alpha_i  (column y_ord[i], newest->oldest)
 //   coef[na + j] = beta for column s in OLDEST->NEWEST order (j = 0 is ord[na-1]).
-__global__ void __launch_bounds__(64)
-inv_coef_kernel(const double *__restrict__ dots, double *__restrict__ coef,
-                const double *__restrict__ SY, const double *__restrict__ YS,
-                const double *__restrict__ YY, double *__restrict__ alpha_out, OrdArgs O) {
+// (body: ONE full wave, `lane` = lane id; sy(i, j) = s'y and yy(i, j) = y'y of the pairs at ORD POSITIONS i, j — the
+// standalone kernel reads them from the Gram matrices in device memory, the single-launch apply from its LDS copies)
+template <typename SYF, typename YYF>
+__device__ __forceinline__ void inv_coef_generic(int lane, const double *dots, double *coef, double *alpha_out,
+                                                 const OrdArgs &O, SYF &&syp, YYF &&yyp) {
   // one wave: lane j holds a_j / b_j; every inner sum of the recurrences is a wave reduction
-  const int lane = threadIdx.x;
-  const int na = O.na, mem = O.mem;
-  auto sy = [&](int i, int j) {  // s_i' y_j for slots i, j
-    return O.age[j] >= O.age[i] ? SY[i + (int64_t)j * mem] : YS[j + (int64_t)i * mem];
-  };
-  auto yy = [&](int i, int j) {
-    return O.age[j] >= O.age[i] ? YY[i + (int64_t)j * mem] : YY[j + (int64_t)i * mem];
-  };
-  auto wsum = [](double v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
-  };
-  const int myslot = lane < na ? O.ord[lane] : 0;
+  const int na = O.na;
+  const int mypos = lane < na ? lane : 0;
+  auto wsum = [](double v) { return wave_allsum(v); };   // DPP tree (common.h), total in every lane
+  const int myslot = O.ord[mypos];
   double a = 0.0, b = 0.0;  // lane's own alpha / beta
   for (int i = 0; i < na; ++i) {
     const int k = O.ord[i];
-    const double part = (lane < i) ? a * sy(k, myslot) : 0.0;
+    const double part = (lane < i) ? a * syp(i, mypos) : 0.0;
     const double sq = dots[i] - wsum(part);
     const double ai = rnd(sq / O.ys[k], O.is_f32);
     if (lane == i) a = ai;
   }
-  if (lane < na) alpha_out[myslot] = a;
+  if (lane < na && alpha_out) alpha_out[myslot] = a;
   const double g = O.use_gamma ? O.gamma : 1.0;
   for (int i = na - 1; i >= 0; --i) {
     const int k = O.ord[i];
-    const double p1 = (lane < na) ? a * yy(k, myslot) : 0.0;          // sum_j alpha_j y_k'y_j
-    const double p2 = (lane < na && lane > i) ? b * sy(myslot, k) : 0.0;  // sum_{older j} beta_j s_j'y_k
+    const double p1 = (lane < na) ? a * yyp(i, mypos) : 0.0;              // sum_j alpha_j y_k'y_j
+    const double p2 = (lane < na && lane > i) ? b * syp(mypos, i) : 0.0;  // sum_{older j} beta_j s_j'y_k
     const double yq = dots[na + i] - wsum(p1);
     const double yr = g * yq + wsum(p2);
     const double ai = __shfl(a, i, 64);
@@ -399,16 +390,39 @@ inv_coef_kernel(const double *__restrict__ dots, double *__restrict__ coef,
     coef[na + (na - 1 - lane)] = b;   // s columns, oldest -> newest
   }
 }
+__device__ __forceinline__ void inv_coef_body(int lane, const double *dots, double *__restrict__ coef,
+                                              const double *__restrict__ SY, const double *__restrict__ YS,
+                                              const double *__restrict__ YY, double *__restrict__ alpha_out,
+                                              const OrdArgs &O) {
+  const int mem = O.mem;
+  auto sy = [&](int i, int j) {  // s_i' y_j for slots i, j
+    return O.age[j] >= O.age[i] ? SY[i + (int64_t)j * mem] : YS[j + (int64_t)i * mem];
+  };
+  auto yy = [&](int i, int j) {
+    return O.age[j] >= O.age[i] ? YY[i + (int64_t)j * mem] : YY[j + (int64_t)i * mem];
+  };
+  inv_coef_generic(lane, dots, coef, alpha_out, O, [&](int i, int j) { return sy(O.ord[i], O.ord[j]); },
+                   [&](int i, int j) { return yy(O.ord[i], O.ord[j]); });
+}
+__global__ void __launch_bounds__(64)
+inv_coef_kernel(const double *__restrict__ dots, double *__restrict__ coef,
+                const double *__restrict__ SY, const double *__restrict__ YS,
+                const double *__restrict__ YY, double *__restrict__ alpha_out, OrdArgs O) {
+  inv_coef_body((int)threadIdx.x, dots, coef, SY, YS, YY, alpha_out, O);
+}
 
 // L-SR1: coef[i] = (alpha*dot_i)/as_k evaluated in CT (src/lsr1.jl:101)
-__global__ void lsr1_coef_kernel(const double *__restrict__ dots, double *__restrict__ coef,
-                                 const double *__restrict__ as_, OrdArgs O, double alpha, int ct_f32) {
-  const int i = threadIdx.x;
+__device__ __forceinline__ void lsr1_coef_body(int i, const double *dots, double *__restrict__ coef,
+                                               const double *__restrict__ as_, const OrdArgs &O, double alpha, int ct_f32) {
   if (i >= O.na) return;
   const int k = O.ord[i];
   const double d = rnd(dots[i], O.is_f32), as = rnd(as_[k], O.is_f32);
   if (ct_f32) coef[i] = (double)(((float)alpha * (float)d) / (float)as);
   else coef[i] = (alpha * d) / as;
+}
+__global__ void lsr1_coef_kernel(const double *__restrict__ dots, double *__restrict__ coef,
+                                 const double *__restrict__ as_, OrdArgs O, double alpha, int ct_f32) {
+  lsr1_coef_body((int)threadIdx.x, dots, coef, as_, O, alpha, ct_f32);
 }
 
 // coef[i] = T(dots[i] / as[ord[i]])   (L-SR1 push!: as = dot(a_l, s_k)/as_l, src/lsr1.jl:173)
@@ -536,6 +550,331 @@ int32_t lbfgs_push_common_big(mxlo_qn *h, const T *s, const T *y, double ys, dou
 template <typename T>
 int32_t lsr1_rebuild_big(mxlo_qn *h, int64_t ins);
 
+// Compact forward L-BFGS apply. With a_k = [S B]·c_k (c_k = row k of Cm, built by push!) and d = [S B]'x:
+//   B x = x/γ + Σ_k b_k (b_k'x) − a_k (a_k'x) = x/γ + [S B]·w,   w = −Cmᵀ (Cm d)  (+ d on the b half).
+// One wave; lane j owns w_j (2r <= 64).
+__device__ __forceinline__ void cfwd_coef_body(int lane, const double *dots, const double *__restrict__ Cm,
+                                               double *__restrict__ coef, int r) {
+  const int w2 = 2 * r;
+  const double d = lane < w2 ? dots[lane] : 0.0;
+  double w = (lane >= r && lane < w2) ? d : 0.0;                 // + b_j (b_j'x)
+  for (int k = 0; k < r; ++k) {
+    const double ck = lane < w2 ? Cm[(int64_t)k * w2 + lane] : 0.0;
+    const double t = wave_allsum(ck * d);                        // a_k'x = c_k'd
+    w -= ck * t;                                                 // − a_k (a_k'x)
+  }
+  if (lane < w2) coef[lane] = w;
+}
+__global__ void __launch_bounds__(64)
+cfwd_coef_kernel(const double *__restrict__ dots, const double *__restrict__ Cm, double *__restrict__ coef, int r) {
+  cfwd_coef_body((int)threadIdx.x, dots, Cm, coef, r);
+}
+
+// ---- launch-bound sizes: the WHOLE quasi-Newton apply in ONE launch -------------------------------------------------
+// dots -> finalize -> coefficients -> combine are 4 dependent launches, ~3.5 us each on MI355X whatever their size; for
+// n <= 2^17 the data movement is a fraction of that. Here (DESIGN §9 of round 2, built in round 3) every workgroup
+//   1. keeps its slice of x in registers and reduces it against its slice of the <= 40 panel columns,
+//   2. publishes the partial dots as self-validating 64-bit agent-scope stores into exchange slots (an empty slot is a
+//      NaN payload arithmetic cannot produce; NaN partials are canonicalised) — NO fence: an agent-scope release would
+//      write back the L2 of all 8 XCDs (profiles/r01_sweep_fuse.txt), the protocol of the single-launch Householder,
+//   3. polls until all G <= 64 co-resident workgroups have published, sums every column's partials in a fixed order
+//      (lane i <- workgroup i, one fixed DPP tree: bit-identical in every workgroup),
+//   4. runs the operator's coefficient recurrence on one wave — redundantly per workgroup — from Gram data it staged
+//      in LDS while the dots were in flight, and
+//   5. applies the columns to its slice in the reference's elementwise order (the formulas of combine_kernel) and
+//      writes res.
+// Two slot sets alternate by an epoch word in device memory (graph-replay safe): a launch uses set e, re-arms set 1 - e
+// for its successor, workgroup 0 flips e once it has seen every partial. One fused launch in flight per ctx (all work of
+// a ctx is stream-ordered: mxlo_ctx_set_stream). Not used with an all-reduce hook (a host callback sits between 3 and 4).
+constexpr int kQnfMaxCols = 40;      // 2*mem at mem <= 20: the launch-bound defaults of the callers
+constexpr int kQnfMaxGrid = 64;
+constexpr int kQnfSlots = kQnfMaxCols * kQnfMaxGrid;
+template <typename T>
+struct QnfCols {
+  const T *p[kQnfMaxCols];
+};
+struct QnfArgs {
+  int kind;                                  // MXLO_QN_LBFGS_INV / _FWD (compact) / _LSR1
+  int ncol, nfirst, use_gamma;
+  double gamma, alpha, beta, shift;
+  const double *SY, *YS, *YY;                // inverse: Gram matrices (mem x mem)
+  double *alpha_out;
+  const double *Cm;                          // compact forward: r x 2r coefficients
+  const double *as_;                         // L-SR1
+  int ct_f32;
+};
+
+template <typename T, typename CA, typename CB, int KIND, bool BETA0>
+__global__ void __launch_bounds__(kBlock)
+qn_apply_fused_kernel(T *__restrict__ res, QnfCols<T> cols, const T *__restrict__ x, int64_t n,
+                      unsigned long long *__restrict__ slots, QnfArgs F, OrdArgs O) {
+  constexpr int VEC = Vec16<T>::N, U = 4;
+  using V = typename Vec16<T>::type;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, G = (int)gridDim.x, b = (int)blockIdx.x;
+  const int ncol = F.ncol, na = O.na;
+  __shared__ double red[kBlock / 64][kQnfMaxCols];
+  __shared__ double spart[kQnfSlots];
+  __shared__ double sdots[kQnfMaxCols];
+  __shared__ double scoef[kQnfMaxCols];
+  __shared__ double sg1[kQnfMaxCols * kQnfMaxCols / 2];     // inverse: s_i'y_j by ord position (na x na); forward: Cm (r x 2r)
+  __shared__ double sg2[kQnfMaxCols * kQnfMaxCols / 4];     // inverse: y_i'y_j by ord position; L-SR1: as by ord position
+  unsigned long long *epoch = slots + 2 * kQnfSlots;
+  const unsigned e = (unsigned)__hip_atomic_load(epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 1u;
+  unsigned long long *mine = slots + e * kQnfSlots, *other = slots + (1u - e) * kQnfSlots;
+  for (int i = b * kBlock + tid; i < kQnfSlots; i += G * kBlock)       // re-arm the other set for the next launch
+    __hip_atomic_store(other + i, kSlotEmpty, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // ---- stage the Gram data the coefficient recurrence reads (loads overlap the dots below)
+  if constexpr (KIND == MXLO_QN_LBFGS_INV) {
+    const int mem = O.mem;
+    for (int p = tid; p < na * na; p += kBlock) {
+      const int i = O.ord[p / na], j = O.ord[p % na];                  // slots
+      sg1[p] = O.age[j] >= O.age[i] ? F.SY[i + (int64_t)j * mem] : F.YS[j + (int64_t)i * mem];   // s_i'y_j
+      sg2[p] = O.age[j] >= O.age[i] ? F.YY[i + (int64_t)j * mem] : F.YY[j + (int64_t)i * mem];   // y_i'y_j
+    }
+  } else if constexpr (KIND == MXLO_QN_LBFGS_FWD) {
+    for (int p = tid; p < na * 2 * na; p += kBlock) sg1[p] = F.Cm[p];
+  } else {
+    if (tid < na) sg2[tid] = F.as_[O.ord[tid]];
+  }
+  // ---- 1. this workgroup's slice: U vectors per lane, x kept in registers
+  const int64_t base = ((int64_t)b * kBlock * U + tid) * VEC;
+  T xe[U][VEC];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int64_t i = base + (int64_t)u * kBlock * VEC;
+    if (i + VEC <= n) {
+      const V xv = *reinterpret_cast<const V *>(x + i);
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) xe[u][k] = xv[k];
+    } else {
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) xe[u][k] = i + k < n ? x[i + k] : T(0);
+    }
+  }
+  // A workgroup whose whole slice lies inside n (all but possibly the last) runs branch-free: every load of a batch is
+  // an unconditional 16-byte load, so the 8 x U loads of a batch really are in flight together (a per-load bounds
+  // branch makes the compiler wait at every merge point: one memory round trip per LOAD). The last workgroup takes the
+  // guarded form.
+  const bool full = ((int64_t)(b + 1) * kBlock * U) * VEC <= n;
+  auto ldv = [&](const T *p, int64_t i) -> V {   // guarded: 16-byte load, or element loads with zero fill
+    if (i + VEC <= n) return *reinterpret_cast<const V *>(p + i);
+    V v;
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) v[k] = i + k < n ? p[i + k] : T(0);
+    return v;
+  };
+  auto dots_batches = [&]<bool FULL>() {
+    for (int c0 = 0; c0 < ncol; c0 += 8) {     // columns in batches of 8: one memory round trip per batch
+      V cv[8][U];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        const T *p = cols.p[c0 + t < ncol ? c0 + t : ncol - 1];      // clamp: a valid (unused) column instead of a branch
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int64_t i = base + (int64_t)u * kBlock * VEC;
+          if constexpr (FULL) cv[t][u] = *reinterpret_cast<const V *>(p + i);
+          else cv[t][u] = ldv(p, i);
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        double acc = 0.0;
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+          for (int k = 0; k < VEC; ++k) acc = fma((double)cv[t][u][k], (double)xe[u][k], acc);
+        acc = wave_allsum(acc);      // DPP tree (a 64-bit shuffle tree is 12 dependent ds_bpermute per column)
+        if (lane == 0 && c0 + t < ncol) red[wave][c0 + t] = acc;
+      }
+    }
+  };
+  if (full) dots_batches.template operator()<true>();
+  else dots_batches.template operator()<false>();
+  __syncthreads();
+  // ---- 2. publish
+  if (tid < ncol) {
+    const double sv = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+    unsigned long long bits = (unsigned long long)__double_as_longlong(sv);
+    if (sv != sv) bits = 0x7FF8000000000000ull;                       // canonical NaN: never the empty marker
+    __hip_atomic_store(mine + tid * kQnfMaxGrid + b, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  // ---- 3. gather: every (column, workgroup) slot is polled by exactly one lane; all polls of a lane are in flight together
+  for (int p = tid; p < ncol * G; p += kBlock) {
+    const int c = p / G, w = p - c * G;
+    unsigned long long bits;
+    while ((bits = __hip_atomic_load(mine + c * kQnfMaxGrid + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == kSlotEmpty)
+      __builtin_amdgcn_s_sleep(1);
+    spart[c * kQnfMaxGrid + w] = __longlong_as_double((long long)bits);
+  }
+  __syncthreads();
+  if (b == 0 && tid == 0)                                             // every workgroup has read e: flip for the next launch
+    __hip_atomic_store(epoch, (unsigned long long)(1u - e), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  for (int c = wave; c < ncol; c += kBlock / 64) {                    // fixed order: lane i <- workgroup i, one DPP tree
+    const double v = wave_allsum(lane < G ? spart[c * kQnfMaxGrid + lane] : 0.0);
+    if (lane == 0) sdots[c] = v;
+  }
+  __syncthreads();
+  // ---- 4. coefficients (one wave, redundantly per workgroup; same recurrences as the *_coef_kernel bodies)
+  if (wave == 0) {
+    if constexpr (KIND == MXLO_QN_LBFGS_INV) {
+      inv_coef_generic(lane, sdots, scoef, b == 0 ? F.alpha_out : nullptr, O,
+                       [&](int i, int j) { return sg1[i * na + j]; }, [&](int i, int j) { return sg2[i * na + j]; });
+    } else if constexpr (KIND == MXLO_QN_LBFGS_FWD) {
+      cfwd_coef_body(lane, sdots, sg1, scoef, na);
+    } else {
+      if (lane < na) {
+        const double d = rnd(sdots[lane], O.is_f32), as = rnd(sg2[lane], O.is_f32);
+        scoef[lane] = F.ct_f32 ? (double)(((float)F.alpha * (float)d) / (float)as) : (F.alpha * d) / as;
+      }
+    }
+  }
+  __syncthreads();
+  // ---- 5. combine on this workgroup's slice: the elementwise formulas (and rounding points) of combine_kernel
+  const T g = (T)F.gamma;
+  const CA al = (CA)F.alpha;
+  const CB be = (CB)F.beta;
+  // combine column c in terms of the dots columns: the inverse operator's dots run over [s.., y..] newest -> oldest, its
+  // combine over y newest -> oldest, then s oldest -> newest; the other two use one order for both
+  auto ccol = [&](int c) -> const T * {
+    if constexpr (KIND == MXLO_QN_LBFGS_INV) return c < F.nfirst ? cols.p[F.nfirst + c] : cols.p[2 * F.nfirst - 1 - c];
+    else return cols.p[c];
+  };
+  // prologue / one column / epilogue of the combine on E elements (formulas and rounding points of combine_kernel)
+  auto prologue = [&]<int E>(const T (&xq)[E], const T (&rq)[E], T (&q)[E]) {
+#pragma unroll
+    for (int k = 0; k < E; ++k) {
+      if constexpr (KIND == MXLO_QN_LBFGS_FWD) q[k] = F.use_gamma ? xq[k] / g : xq[k];
+      else if constexpr (KIND == MXLO_QN_LBFGS_INV) q[k] = xq[k];
+      else q[k] = fin_ab<T, CA, CB, BETA0>((al * (CA)xq[k]) / (CA)g, be, BETA0 ? T(0) : rq[k]);     // lsr1.jl:93
+    }
+  };
+  auto column = [&]<int E>(int c, T (&q)[E], const T (&ce)[E]) {
+    if constexpr (KIND == MXLO_QN_LBFGS_INV) {
+      if (c == F.nfirst && F.use_gamma) {
+#pragma unroll
+        for (int k = 0; k < E; ++k) q[k] = q[k] * g;                                                 // lbfgs.jl:139
+      }
+      const T cc = (T)scoef[c];
+      if (c < F.nfirst) {
+#pragma unroll
+        for (int k = 0; k < E; ++k) q[k] = q[k] - (cc * ce[k]);                                      // lbfgs.jl:135
+      } else {
+#pragma unroll
+        for (int k = 0; k < E; ++k) q[k] = q[k] + (cc * ce[k]);                                      // lbfgs.jl:146
+      }
+    } else if constexpr (KIND == MXLO_QN_LBFGS_FWD) {
+      const T cc = (T)scoef[c];
+#pragma unroll
+      for (int k = 0; k < E; ++k) q[k] = q[k] + (cc * ce[k]);
+    } else {
+      const CA cc = (CA)scoef[c];
+#pragma unroll
+      for (int k = 0; k < E; ++k) q[k] = (T)((CA)q[k] + (cc * (CA)ce[k]));                           // lsr1.jl:103
+    }
+  };
+  auto epilogue = [&]<int E>(const T (&xq)[E], const T (&rq)[E], const T (&q)[E], T (&out)[E]) {
+#pragma unroll
+    for (int k = 0; k < E; ++k) {
+      if constexpr (KIND == MXLO_QN_LSR1) out[k] = q[k];
+      else out[k] = fin_ab<T, CA, CB, BETA0>(al * (CA)q[k], be, BETA0 ? T(0) : rq[k]);               // lbfgs.jl:150,198
+      if (F.shift != 0.0) out[k] = out[k] + ((T)F.shift * xq[k]);                                    // shifted_operators.jl:21-23
+    }
+  };
+  if (full) {
+    // all U vectors of the slice advance through the columns TOGETHER: a batch is 8 columns x U vectors = 32 loads in
+    // flight and ncol / 8 round trips in all. Every register array below is indexed by compile-time constants only (a
+    // run-time column index into the batch would put it in scratch memory).
+    constexpr int E = U * VEC;
+    T xq[E], rq[E], q[E], out[E];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      V rv;
+      if constexpr (!BETA0) rv = *reinterpret_cast<const V *>(res + base + (int64_t)u * kBlock * VEC);
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) {
+        xq[u * VEC + k] = xe[u][k];
+        rq[u * VEC + k] = BETA0 ? T(0) : rv[k];
+      }
+    }
+    prologue.template operator()<E>(xq, rq, q);
+    for (int c0 = 0; c0 < ncol; c0 += 8) {
+      V cvb[8][U];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        const T *p = ccol(c0 + t < ncol ? c0 + t : ncol - 1);          // clamp: a valid (unused) column instead of a branch
+#pragma unroll
+        for (int u = 0; u < U; ++u) cvb[t][u] = *reinterpret_cast<const V *>(p + base + (int64_t)u * kBlock * VEC);
+      }
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        if (c0 + t < ncol) {
+          T ce[E];
+#pragma unroll
+          for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) ce[u * VEC + k] = cvb[t][u][k];
+          column.template operator()<E>(c0 + t, q, ce);
+        }
+      }
+    }
+    epilogue.template operator()<E>(xq, rq, q, out);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      V ov;
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) ov[k] = out[u * VEC + k];
+      *reinterpret_cast<V *>(res + base + (int64_t)u * kBlock * VEC) = ov;
+    }
+  } else {
+    for (int u = 0; u < U; ++u) {
+      const int64_t i = base + (int64_t)u * kBlock * VEC;
+      for (int k = 0; k < VEC; ++k) {
+        if (i + k >= n) break;
+        const T xq[1] = {xe[u][k]};
+        const T rq[1] = {BETA0 ? T(0) : res[i + k]};
+        T q[1], out[1];
+        prologue.template operator()<1>(xq, rq, q);
+        for (int c = 0; c < ncol; ++c) {
+          const T ce[1] = {ccol(c)[i + k]};
+          column.template operator()<1>(c, q, ce);
+        }
+        epilogue.template operator()<1>(xq, rq, q, out);
+        res[i + k] = out[0];
+      }
+    }
+  }
+}
+
+// true: the whole apply was issued as ONE launch
+template <typename T>
+bool try_fused_apply(mxlo_qn *h, T *res, const T *const *cols, const T *x, QnfArgs F, const OrdArgs &O, int32_t flags,
+                     int32_t *status) {
+  mxlo_ctx *ctx = h->ctx;
+  constexpr int VEC = Vec16<T>::N, U = 4;
+  const int64_t per = (int64_t)kBlock * U * VEC;
+  const int64_t grid = (h->n + per - 1) / per;
+  if (!ctx->tune.qn_fused_small || ctx->allreduce || F.ncol < 1 || F.ncol > kQnfMaxCols || grid > kQnfMaxGrid ||
+      grid > ctx->num_cu || !ctx->qslots || ((((uintptr_t)x) | ((uintptr_t)res)) & 15u) != 0)
+    return false;
+  QnfCols<T> fc;
+  for (int c = 0; c < F.ncol; ++c) {
+    if ((((uintptr_t)cols[c]) & 15u) != 0) return false;
+    fc.p[c] = cols[c];
+  }
+  *status = dispatch_ab<T>(F.beta, flags, [&]<typename CA, typename CB, bool B0>() -> int32_t {
+    auto go = [&]<int KIND>() {
+      hipLaunchKernelGGL((qn_apply_fused_kernel<T, CA, CB, KIND, B0>), dim3((unsigned)grid), dim3(kBlock), 0, ctx->stream, res,
+                         fc, x, h->n, ctx->qslots, F, O);
+    };
+    if (F.kind == MXLO_QN_LBFGS_INV) go.template operator()<MXLO_QN_LBFGS_INV>();
+    else if (F.kind == MXLO_QN_LBFGS_FWD) go.template operator()<MXLO_QN_LBFGS_FWD>();
+    else go.template operator()<MXLO_QN_LSR1>();
+    MXLO_LAUNCH_CHECK();
+    return MXLO_OK;
+  });
+  return true;
+}
+
 // ---- applies ------------------------------------------------------------------------------
 template <typename T>
 int32_t inv_mul_twopass(mxlo_qn *h, T *res, const T *x, double alpha, double beta, int32_t flags,
@@ -559,6 +898,23 @@ int32_t inv_mul_twopass(mxlo_qn *h, T *res, const T *x, double alpha, double bet
     for (int i = 0; i < na; ++i) {
       cols[i] = col<T>(h->S, h->ld, O.ord[i]);
       cols[na + i] = col<T>(h->Y, h->ld, O.ord[i]);
+    }
+    {  // launch-bound sizes: the whole apply in one launch
+      QnfArgs F{};
+      F.kind = MXLO_QN_LBFGS_INV;
+      F.ncol = 2 * na;
+      F.nfirst = na;
+      F.use_gamma = h->scaling;
+      F.gamma = h->scaling_factor;
+      F.alpha = alpha;
+      F.beta = beta;
+      F.shift = shift;
+      F.SY = h->dsc + h->lay.SY;
+      F.YS = h->dsc + h->lay.YS;
+      F.YY = h->dsc + h->lay.YY;
+      F.alpha_out = h->dsc + h->lay.alpha;
+      int32_t fst = MXLO_OK;
+      if (try_fused_apply<T>(h, res, cols, x, F, O, flags, &fst)) return fst;
     }
     MXLO_TRY(panel_dots<T>(ctx, cols, 2 * na, x, h->n, dots));
     hipLaunchKernelGGL(inv_coef_kernel, dim3(1), dim3(64), 0, ctx->stream, dots, coef,
@@ -613,24 +969,6 @@ int32_t inv_mul_reforder(mxlo_qn *h, T *res, const T *x, double alpha, double be
   return MXLO_OK;
 }
 
-// Compact forward L-BFGS apply. With a_k = [S B]·c_k (c_k = row k of Cm, built by push!) and d = [S B]'x:
-//   B x = x/γ + Σ_k b_k (b_k'x) − a_k (a_k'x) = x/γ + [S B]·w,   w = −Cmᵀ (Cm d)  (+ d on the b half).
-// One wave; lane j owns w_j (2r <= 64).
-__global__ void __launch_bounds__(64)
-cfwd_coef_kernel(const double *__restrict__ dots, const double *__restrict__ Cm, double *__restrict__ coef, int r) {
-  const int lane = threadIdx.x, w2 = 2 * r;
-  const double d = lane < w2 ? dots[lane] : 0.0;
-  double w = (lane >= r && lane < w2) ? d : 0.0;                 // + b_j (b_j'x)
-  for (int k = 0; k < r; ++k) {
-    const double ck = lane < w2 ? Cm[(int64_t)k * w2 + lane] : 0.0;
-    double t = ck * d;                                           // a_k'x = c_k'd
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off, 64);
-    w -= ck * t;                                                 // − a_k (a_k'x)
-  }
-  if (lane < w2) coef[lane] = w;
-}
-
 template <typename T>
 int32_t fwd_mul(mxlo_qn *h, T *res, const T *x, double alpha, double beta, int32_t flags,
                  double shift = 0.0) {
@@ -652,6 +990,20 @@ int32_t fwd_mul(mxlo_qn *h, T *res, const T *x, double alpha, double beta, int32
     for (int i = 0; i < na; ++i) {
       A.cols[i] = col<T>(h->S, h->ld, O.ord[i]);
       A.cols[na + i] = col<T>(h->B, h->ld, O.ord[i]);
+    }
+    {
+      QnfArgs F{};
+      F.kind = MXLO_QN_LBFGS_FWD;
+      F.ncol = 2 * na;
+      F.nfirst = 0;
+      F.use_gamma = h->scaling;
+      F.gamma = h->scaling_factor;
+      F.alpha = alpha;
+      F.beta = beta;
+      F.shift = shift;
+      F.Cm = h->dsc + h->lay.Cm;
+      int32_t fst = MXLO_OK;
+      if (try_fused_apply<T>(h, res, A.cols, x, F, O, flags, &fst)) return fst;
     }
     MXLO_TRY(panel_dots<T>(ctx, A.cols, 2 * na, x, h->n, dots));
     hipLaunchKernelGGL(cfwd_coef_kernel, dim3(1), dim3(64), 0, ctx->stream, dots, h->dsc + h->lay.Cm, coef, na);
@@ -690,8 +1042,23 @@ int32_t lsr1_mul(mxlo_qn *h, T *res, const T *x, double alpha, double beta, int3
   A.shift = shift;
   if (na > 0) {
     for (int i = 0; i < na; ++i) A.cols[i] = col<T>(h->A, h->ld, O.ord[i]);
-    MXLO_TRY(panel_dots<T>(ctx, A.cols, na, x, h->n, dots));
     const int ct_f32 = alpha_is_f64(sizeof(T), flags) ? 0 : 1;
+    {
+      QnfArgs F{};
+      F.kind = MXLO_QN_LSR1;
+      F.ncol = na;
+      F.nfirst = 0;
+      F.use_gamma = 1;
+      F.gamma = h->scaling_factor;
+      F.alpha = alpha;
+      F.beta = beta;
+      F.shift = shift;
+      F.as_ = h->dsc + h->lay.as_;
+      F.ct_f32 = ct_f32;
+      int32_t fst = MXLO_OK;
+      if (try_fused_apply<T>(h, res, A.cols, x, F, O, flags, &fst)) return fst;
+    }
+    MXLO_TRY(panel_dots<T>(ctx, A.cols, na, x, h->n, dots));
     hipLaunchKernelGGL(lsr1_coef_kernel, dim3(1), dim3(64), 0, ctx->stream, dots, coef,
                        h->dsc + h->lay.as_, O, alpha, ct_f32);
     MXLO_LAUNCH_CHECK();
@@ -772,11 +1139,7 @@ afwd_coef_kernel(const double *__restrict__ SS, const double *__restrict__ YSf,
     }
   }
   __syncthreads();
-  auto wsum = [](double v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
-  };
+  auto wsum = [](double v) { return wave_allsum(v); };   // DPP tree (common.h), total in every lane
   for (int k = 0; k < r; ++k) {
     double c = (lane == k) ? 1.0 / O.gamma : 0.0;             // a_k = s_k / γ                 (:239)
     const double zk = lane < w ? Z[lane][k] : 0.0;
@@ -938,11 +1301,7 @@ asr1_coef_kernel(const double *__restrict__ SS, const double *__restrict__ YSf, 
       Z[lane][k] = (lane < r ? YSf : SS)[O.ord[j] * mem + O.ord[k]];
     }
   __syncthreads();
-  auto wsum = [](double v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
-  };
+  auto wsum = [](double v) { return wave_allsum(v); };   // DPP tree (common.h), total in every lane
   for (int k = 0; k < r; ++k) {
     double c = (lane == k) ? 1.0 : ((lane == r + k) ? -1.0 / O.gamma : 0.0);   // y_k - s_k/γ       (:169)
     const double zk = lane < w ? Z[lane][k] : 0.0;
@@ -1406,11 +1765,7 @@ shifted_coef_kernel(const double *__restrict__ G, const double *__restrict__ gve
     P[idx] = 0.0;
   }
   __syncthreads();
-  auto wsum = [](double val) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) val += __shfl_xor(val, off, 64);
-    return val;
-  };
+  auto wsum = [](double val) { return wave_allsum(val); };   // DPP tree (common.h), total in every lane
   const double gl = lane < nu ? gvec[lane] : 0.0;
   double cxl = 0.0;
   for (int i = 0; i < nu; ++i) {

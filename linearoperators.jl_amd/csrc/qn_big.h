@@ -111,8 +111,7 @@ int32_t panel_dots2_any(mxlo_ctx *ctx, const std::vector<const T *> &cols, const
 
 // ---- block-wide helpers (one workgroup of kBlock threads) ---------------------------------------------------
 __device__ __forceinline__ double block_sum(double v, double *red) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  v = wave_allsum(v);
   __syncthreads();                       // red may still be read by the previous call's consumers
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
   __syncthreads();

@@ -26,6 +26,9 @@ def snap(lo):
 
 
 def delta(lo, fn, reps=1):
+    import gc
+    gc.collect()                 # operators of earlier tests that only the cycle collector can free (closures referring to
+    gc.collect()                 # their operator) must not be destroyed — hipFree, stream sync — inside the measured window
     torch.cuda.synchronize()
     a = snap(lo)
     for _ in range(reps):

@@ -296,7 +296,7 @@ def test_complex_kron_tracks_factor_updates(lo, dev):
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.complex128, 1e-12), (torch.complex64, 5e-5)])
-@pytest.mark.parametrize("shapes", [((40, 30), (20, 50)), ((64, 64), (64, 64)), ((7, 130), (33, 5)), ((256, 256), (128, 192))])
+@pytest.mark.parametrize("shapes", [((40, 30), (20, 50)), ((64, 64), (64, 64)), ((7, 130), (33, 5)), ((96, 80), (40, 72))])
 def test_gauss_form_matches_four_gemm_form(lo, dev, dtype, tol, shapes):
     """`mxlo_kron_mul_c3` (3 real GEMMs per complex product: k1 = (a+b)c, k2 = a(d-c), k3 = b(c+d)) against
     `mxlo_kron_mul_c` (4 real GEMMs) on the same planes, every factor mode (plain / transposed / conjugate-transposed),

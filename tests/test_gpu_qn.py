@@ -388,7 +388,11 @@ def test_allreduce_hook_world1(lo, dev):
         r1 = Hq * T(v, dev)
         assert calls == [8]                      # ONE all-reduce of 2m doubles per apply
         ctx.set_allreduce(None)
-        assert torch.equal(r1, Hq * T(v, dev))
+        ctx.tune("qn_fused_small", 0)            # a hooked apply is the four-launch schedule: same reduction order un-hooked
+        try:
+            assert torch.equal(r1, Hq * T(v, dev))
+        finally:
+            ctx.tune("qn_fused_small", 1)
     finally:
         lo.get_ctx(dev).set_allreduce(None)
         dist.destroy_process_group()
@@ -443,8 +447,10 @@ def test_native_rccl_hook_world1(lo, dev):
             lo.push(B, T(s, dev), T(y, dev))
         r1 = B * T(v, dev)
         ctx.set_allreduce(None)
+        ctx.tune("qn_fused_small", 0)            # same (four-launch) reduction order as the hooked apply
         assert torch.equal(r1, B * T(v, dev))
     finally:
+        ctx.tune("qn_fused_small", 1)
         ctx.set_allreduce(None)
         torch.cuda.synchronize()
         hook.close()
@@ -713,3 +719,109 @@ def test_rejected_push_leaves_stale_gram_state_alone(lo, dev, dtype):
     res = torch.empty(n, dtype=dtype, device=dev)
     lo.mul(res, B, T(x, dev), 1.0, 0.0)
     assert rel(res.cpu().numpy(), Bo.mul(np.empty(n, npd), x)) <= (1e-9 if dtype == torch.float64 else QN_F32)
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("kind", ["inv", "fwd", "lsr1"])
+@pytest.mark.parametrize("n,mem", [(1, 1), (7, 3), (4096, 5), (65_536, 5), (100_003, 20), (131_071, 32), (140_001, 5)])
+def test_single_launch_dots_and_coefficients_match_the_four_launch_apply(lo, dev, dtype, kind, n, mem):
+    """for launch-bound sizes (<= 64 workgroups, <= 40 panel columns) a quasi-Newton apply is ONE launch
+    (csrc/qn.hip: qn_apply_fused_kernel — partial dots, fence-free slot exchange, fixed-order finalize, the coefficient
+    recurrence on one wave per workgroup, the combine on the workgroup's slice) instead of 4. Against the four-launch schedule
+    (`qn_fused_small` = 0: same coefficient code, different summation order of the dots) and the oracle; partially filled
+    and wrapped memories, alpha/beta forms, the fused shifted apply, a misaligned x (falls back), sizes on both sides of
+    the 64-workgroup limit, and bit-identical results from run to run."""
+    from linearoperators_jl_amd.device import get_ctx
+    ctx = get_ctx(dev)
+    npd = NP[dtype]
+    if kind == "lsr1" and n <= mem:
+        pytest.skip("SR1 with more pairs than dimensions is rounding noise in the reference too")
+    rng = np.random.default_rng(n + 31 * mem)
+    make = {"inv": lo.InverseLBFGSOperator, "fwd": lo.LBFGSOperator, "lsr1": lo.LSR1Operator}[kind]
+    op = make(dtype, n, mem=mem, scaling=True, device=dev)
+    O = oracle.LSR1(n, mem=mem, scaling=True, dtype=npd) if kind == "lsr1" else oracle.LBFGS(n, mem=mem, scaling=True, inverse=(kind == "inv"), dtype=npd)
+    tol = 1e-9 if dtype == torch.float64 else QN_F32
+    x, r0 = rng.uniform(-1, 1, n).astype(npd), rng.uniform(-1, 1, n).astype(npd)
+    xm = torch.empty(n + 1, dtype=dtype, device=dev)
+    xm[1:].copy_(T(x, dev))
+    for k, (s, y) in enumerate(pairs(rng, n, mem + 2, npd)):
+        lo.push(op, T(s, dev), T(y, dev)); O.push(s, y)
+        if k not in (0, mem // 2, mem + 1):
+            continue
+        for a, b in ((1.0, 0.0), (2.0, -3.0)):
+            fl = oracle.SCALARS_F64 if dtype == torch.float32 else 0
+            want = O.mul(r0.copy(), x, a, b, flags=fl)
+            got = {}
+            for fused in (1, 0):
+                ctx.tune("qn_fused_small", fused)
+                try:
+                    res = T(r0.copy(), dev)
+                    lo.mul(res, op, T(x, dev), a, b)
+                    got[fused] = res.cpu().numpy()
+                    if fused:
+                        res2 = T(r0.copy(), dev)
+                        lo.mul(res2, op, T(x, dev), a, b)
+                        assert np.array_equal(res2.cpu().numpy(), got[1]), "run-to-run determinism"
+                        res3 = T(r0.copy(), dev)
+                        lo.mul(res3, op, xm[1:], a, b)                       # misaligned x: the four-launch path
+                        assert rel(res3.cpu().numpy(), want) <= tol
+                finally:
+                    ctx.tune("qn_fused_small", 1)
+            assert rel(got[1], want) <= tol and rel(got[0], want) <= tol, (k, a, b, rel(got[1], want), rel(got[0], want))
+            assert rel(got[1], got[0]) <= (1e-12 if dtype == torch.float64 else 2e-5), (k, a, b)
+    sh = lo.ShiftedOperator(op, 0.37)
+    res = T(r0.copy(), dev)
+    lo.mul(res, sh, T(x, dev), 1.5, 0.5)
+    want = 1.5 * (O.mul(np.empty(n, npd), x).astype(np.float64) + 0.37 * x.astype(np.float64)) + 0.5 * r0.astype(np.float64)
+    assert rel(res.cpu().numpy().astype(np.float64), want) <= tol
+
+
+def test_single_launch_apply_exchange_stress(lo, dev):
+    """The slot exchange of the single-launch quasi-Newton apply under churn: 24,000 back-to-back applies alternating
+    between six operators (three kinds, different column counts, grid sizes from 1 to 49 workgroups, Float64 and
+    Float32) that all share the ctx's two slot sets and its epoch word, interleaved with single-launch Householder
+    applies (their own slots), four-launch applies (`qn_fused_small` toggled) and a long streaming kernel. It must not
+    hang, and every operator's result must stay bit-identical to its first one (a stale or foreign partial would
+    change the dots)."""
+    from linearoperators_jl_amd.device import get_ctx
+    ctx = get_ctx(dev)
+    rng = np.random.default_rng(77)
+    ops = []
+    for kind, dtype, n, mem in (("inv", torch.float64, 300, 3), ("fwd", torch.float64, 100_003, 20), ("lsr1", torch.float64, 4096, 7),
+                                ("fwd", torch.float32, 65_536, 5), ("inv", torch.float32, 9_001, 10), ("lsr1", torch.float32, 70_001, 2)):
+        npd = NP[dtype]
+        make = {"inv": lo.InverseLBFGSOperator, "fwd": lo.LBFGSOperator, "lsr1": lo.LSR1Operator}[kind]
+        op = make(dtype, n, mem=mem, device=dev)
+        for s, y in pairs(rng, n, mem + 1, npd):
+            lo.push(op, T(s, dev), T(y, dev))
+        x = T(rng.uniform(-1, 1, n).astype(npd), dev)
+        res = torch.empty(n, dtype=dtype, device=dev)
+        lo.mul(res, op, x, 1.0, 0.0)
+        ops.append((op, x, res, res.clone()))
+    nh = 50_000
+    h = rng.standard_normal(nh)
+    H = lo.opHouseholder(T(h / np.linalg.norm(h), dev))
+    hv, hr = T(rng.uniform(-1, 1, nh), dev), torch.empty(nh, dtype=torch.float64, device=dev)
+    big = torch.rand(30_000_000, dtype=torch.float64, device=dev)
+    D = lo.opDiagonal(big)
+    bigr = torch.empty_like(big)
+    torch.cuda.synchronize()
+    for it in range(4000):
+        for k, (op, x, res, _) in enumerate(ops):
+            lo.mul(res, op, x, 1.0, 0.0)
+            if (it + k) % 7 == 0:
+                lo.mul(hr, H, hv, 1.0, 0.0)
+        if it % 500 == 250:
+            lo.mul(bigr, D, big, 1.0, 0.0)                       # a long kernel in front of the next fused launches
+        if it % 1000 == 999:
+            torch.cuda.synchronize()
+            for op, x, res, first in ops:
+                assert torch.equal(res, first), it
+    ctx.tune("qn_fused_small", 0)
+    try:
+        for op, x, res, first in ops:
+            lo.mul(res, op, x, 1.0, 0.0)
+            tol = 1e-12 if res.dtype == torch.float64 else 2e-5
+            assert (torch.linalg.vector_norm((res - first).double()) / torch.linalg.vector_norm(first.double())).item() <= tol
+    finally:
+        ctx.tune("qn_fused_small", 1)

@@ -72,6 +72,29 @@ for dt, es in ((torch.float64, 8), (torch.float32, 4)):
         row(f"opDiagonal mul! n=2^{small.bit_length()-1} {dt} (latency regime)", 3 * es * small, timeit(lambda: lo.mul(rs, Ds, vs, 1.0, 0.0), 200))
         row(f"opHouseholder mul! n=2^{small.bit_length()-1} {dt}", 5 * es * small, timeit(lambda: lo.mul(rs, Hs, vs, 1.0, 0.0), 200))
 
+# quasi-Newton applies in the launch-bound regime: the whole apply in ONE launch (csrc/qn.hip: qn_apply_fused_kernel)
+# against the four-launch schedule (qn_fused_small = 0); C ABI through a pre-bound ctypes call and the Python mirror
+if sec("small"):
+    import ctypes as C_
+    from linearoperators_jl_amd import _lib as L_
+    for kind, m in (("fwd", 5), ("inv", 5), ("lsr1", 5), ("fwd", 20)):
+        for small in (1 << 12, 1 << 16):
+            op = {"inv": lo.InverseLBFGSOperator, "fwd": lo.LBFGSOperator, "lsr1": lo.LSR1Operator}[kind](torch.float64, small, mem=m, device=dev)
+            for _ in range(m + 2):
+                s_ = rnd(small)
+                lo.push(op, s_, s_ * (rnd(small) * 0.25 + 1.25) + (0.3 * rnd(small) if kind == "lsr1" else 0))
+            xs, rs = rnd(small), rnd(small)
+            f = L_.lib().mxlo_qn_mul
+            a = (op._h, C_.c_void_p(rs.data_ptr()), C_.c_void_p(xs.data_ptr()), C_.c_double(1.0), C_.c_double(0.0), 0)
+            out = []
+            for fused in (1, 0):
+                ctx.tune("qn_fused_small", fused)
+                out.append((timeit(lambda: f(*a), 2000) * 1e3, timeit(lambda: lo.mul(rs, op, xs, 1.0, 0.0), 2000) * 1e3))
+            ctx.tune("qn_fused_small", 1)
+            print(f"{kind:4s} m={m:2d} n=2^{small.bit_length()-1:<2d} apply: single launch  C ABI {out[0][0]:6.2f} us, mirror {out[0][1]:6.2f} us | "
+                  f"four launches  C ABI {out[1][0]:6.2f} us, mirror {out[1][1]:6.2f} us", flush=True)
+            del op
+
 # restriction / extension. Algorithmic bytes: restriction = idx (8) + v[idx] (es) + res (es) per index; extension = idx (8)
 # + pos (8, plans with duplicates) + u (es) per SURVIVING index + one write of res (es * n). (Round 1 also charged the extension a second write of the
 # touched slots — memset THEN scatter — which the segment-owner kernel no longer performs.)

@@ -131,8 +131,20 @@ def get_ctx(device=None) -> Context:
     return ctx
 
 
-def ptr(t: torch.Tensor | None) -> C.c_void_p:
-    return C.c_void_p(0 if t is None else t.data_ptr())
+def ctx_of(t: torch.Tensor) -> Context:
+    """`get_ctx(t.device)` for a tensor already known to live on a GPU (the per-apply path of the leaves): the device
+    index comes from `get_device()` (no torch.device object), the ctx from the cache, and the stream is re-bound."""
+    ctx = _ctxs.get(t.get_device())
+    if ctx is None:
+        return get_ctx(t.device)
+    ctx.bind_stream()
+    return ctx
+
+
+def ptr(t: torch.Tensor | None):
+    """The device address as a plain int (None for a NULL pointer): every entry point has `c_void_p` argtypes, which
+    convert both — building a `c_void_p` object per operand was a measurable part of a launch-bound apply."""
+    return None if t is None else t.data_ptr()
 
 
 def check_vec(t: torch.Tensor, name: str, dtype: torch.dtype | None = None) -> torch.Tensor:

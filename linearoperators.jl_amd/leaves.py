@@ -19,7 +19,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .device import Storage, check_vec, dtype_code, get_ctx, ptr, storage_of
+from .device import Storage, check_vec, ctx_of, dtype_code, get_ctx, ptr, storage_of
 from .operators import (AbstractLinearOperator, LinearOperator, LinearOperatorException, _c4, adjoint, columnwise, compose,
                         conj_scalar, issymmetric, ishermitian, mul, scalar_flags, state_version, storage_type, to_dense, transpose)
 
@@ -110,8 +110,12 @@ def opZeros(T=torch.float64, nrow: Optional[int] = None, ncol: Optional[int] = N
 # ----------------------------------------------------------------------------- opDiagonal
 def mulSquareOpDiagonal(res, d, v, alpha, beta, conj_d=False):
     """mulSquareOpDiagonal! — src/special-operators.jl:125-131 (`conj_d`: the ctprod! closure passes conj.(d), :139-141)."""
-    ctx = get_ctx(res.device)
     n = res.numel()
+    if res.dtype is torch.float64 and (d.numel() != 1 or n == 1):
+        _lib.call("mxlo_diag_mul", ctx_of(res).handle, _lib.F64, res.data_ptr(), d.data_ptr(), v.data_ptr(), n, n,
+                  float(alpha), float(beta), 0)
+        return
+    ctx = get_ctx(res.device)
     if res.dtype.is_complex:
         _lib.call("mxlo_diag_mul_c", ctx.handle, dtype_code(res.dtype, True), ptr(res), ptr(d), ptr(v), n, n,
                   *_c4(alpha, beta), scalar_flags(res.dtype, alpha, beta) | (_lib.CONJ_D if conj_d else 0))
@@ -255,6 +259,10 @@ def opExtension(Idx, ncol: int, S: Optional[Storage] = None, device=None):
 # ----------------------------------------------------------------------------- Householder / Hermitian
 def mulHouseholder(res, h, v, alpha, beta):
     """mulHouseholder! — src/linalg.jl:77-83 (complex h: LinearAlgebra.dot conjugates it)."""
+    if res.dtype is torch.float64:                      # the launch-bound case: nothing to decide, no flags
+        _lib.call("mxlo_householder_mul", ctx_of(res).handle, _lib.F64, res.data_ptr(), h.data_ptr(), v.data_ptr(),
+                  res.numel(), float(alpha), float(beta), 0)
+        return
     ctx = get_ctx(res.device)
     if res.dtype.is_complex:
         _lib.call("mxlo_householder_mul_c", ctx.handle, dtype_code(res.dtype, True), ptr(res), ptr(h), ptr(v),

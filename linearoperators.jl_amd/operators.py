@@ -100,10 +100,18 @@ _NARGS_CACHE: dict = {}
 def _nargs(f: Callable) -> int:
     """`hasmethod(op.prod!, (res, v, α, β))` stand-in (src/operations.jl:26): count positional params.
     Cached per code object: the reference pays this reflection on every `mul!`, the mirror only once."""
+    try:
+        return f._mxlo_nargs                           # cached on the function object itself (plain functions / lambdas)
+    except AttributeError:
+        pass
     code = getattr(f, "__code__", None)
     key = code if code is not None else id(f)
     n = _NARGS_CACHE.get(key)
     if n is not None:
+        try:
+            f._mxlo_nargs = n
+        except (AttributeError, TypeError):            # builtins, bound methods, callables with __slots__
+            pass
         return n
     try:
         sig = inspect.signature(f)
@@ -397,11 +405,17 @@ def conj_into(res, v):
 
 
 # ----------------------------------------------------------------------------- operator state versions
+try:                                   # torch.autograd.graph.increment_version minus its isinstance / tuple wrapping
+    _increment_version = torch._C._increment_version
+except AttributeError:                 # pragma: no cover
+    _increment_version = lambda ts: torch.autograd.graph.increment_version(ts[0])
+
+
 def touched(t: torch.Tensor):
     """libmxlo writes through raw pointers, which torch's in-place version counter does not see: bump it by hand so
     that operators built on `t` (and kron factors materialised from them) notice the change."""
     try:
-        torch.autograd.graph.increment_version(t)
+        _increment_version((t,))
     except Exception:      # pragma: no cover  (inference tensors etc.)
         pass
     return t
@@ -448,15 +462,19 @@ def mul(res: torch.Tensor, op, v: torch.Tensor, alpha=None, beta=None):
         raise TypeError("mul! takes either (res, op, v) or (res, op, v, alpha, beta)")
     if v.dim() == 2 or res.dim() == 2:
         return _mul_matrix(res, op, v, alpha, beta)
-    if v.dtype.is_complex and op.eltype.is_floating_point:
-        return _mul_real_op_complex_vec(res, op, v, alpha, beta)
-    if op.eltype.is_complex and v.dtype.is_floating_point:
-        v = _complex_of_real(v, op.eltype)              # a real vector handed to a complex operator (test_adjtrans.jl:31-34)
-    if isinstance(op, AdjointLinearOperator):
+    vd, od = v.dtype, op.eltype
+    if vd is not od:                                        # (the common case — same element type — skips all of this)
+        if vd.is_complex and od.is_floating_point:
+            return _mul_real_op_complex_vec(res, op, v, alpha, beta)
+        if od.is_complex and vd.is_floating_point:
+            v = _complex_of_real(v, od)                     # a real vector handed to a complex operator (test_adjtrans.jl:31-34)
+    if not isinstance(op, _Wrapper):
+        pass                                                # base operator: straight to the closure below
+    elif isinstance(op, AdjointLinearOperator):
         return _mul_adjoint(res, op, v, alpha, beta)
-    if isinstance(op, TransposeLinearOperator):
+    elif isinstance(op, TransposeLinearOperator):
         return _mul_transpose(res, op, v, alpha, beta)
-    if isinstance(op, ConjugateLinearOperator):
+    elif isinstance(op, ConjugateLinearOperator):
         # src/adjtrans.jl:226-249: mul!(res, p, conj.(v), α, β); conj!(res) — α, β and the incoming res are NOT
         # conjugated (reference behaviour, reproduced); real v skips the conj.(v) allocation (:238-249)
         vc = conj_into(torch.empty_like(v), v) if v.dtype.is_complex else v
@@ -464,11 +482,12 @@ def mul(res: torch.Tensor, op, v: torch.Tensor, alpha=None, beta=None):
         if res.dtype.is_complex:
             conj_into(res, res)
         return res
-    if not (v.shape[0] == op.size(2) and res.shape[0] == op.size(1)):
+    if not (v.size(0) == op.ncol and res.size(0) == op.nrow):
         raise LinearOperatorException("shape mismatch")
     op.nprod += _COUNT                                      # increase_nprod!
-    if _nargs(op.prod) == 4:
-        op.prod(res, v, alpha, beta)
+    prod = op.prod
+    if _nargs(prod) == 4:
+        prod(res, v, alpha, beta)
     else:
         if not (beta == 0 or op.Mv.numel() != 0):
             allocate_vectors_args3(op)

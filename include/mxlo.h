@@ -394,15 +394,19 @@ int32_t mxlo_kron_mul_c(mxlo_ctx *ctx, int32_t dtype, void *res, const void *Ar,
  *   (a + ib)(c + id):  k1 = (a + b) c,  k2 = a (d - c),  k3 = b (c + d);  re = k1 - k3,  im = k1 + k2.
  * Same arguments and semantics as mxlo_kron_mul_c (a real factor still costs its two plain GEMMs); results agree with
  * it to rounding (normwise: the three-multiplication form is not componentwise stable, which the reference's
- * 1e-12 * ||K||_1 criterion, test/test_kron.jl:35, does not ask for). `work` must be 16-byte aligned and hold
- * mxlo_kron_c3_work_size(am, an, mode_a, bp, bq, mode_b) real scalars: the four planes of x (re, im, im - re, re + im),
- * the planes of the result, of the intermediate U (also im - re, re + im), the three GEMM outputs and the factor-sum
- * plane a + b, which is formed per call (the library keeps no factor state). */
+ * 1e-12 * ||K||_1 criterion, test/test_kron.jl:35, does not ask for). As / Bs: the factor-sum planes a + s*b of A / B
+ * (s = -1 when bit 1 of the factor's mode conjugates it, else +1; CONTIGUOUS, leading dimension = rows; form them with
+ * mxlo_plane_sum) as the glue caches them per factor state and sign — or NULL: formed per call in `work` (the library
+ * keeps no factor state). `work` must be 16-byte aligned and hold mxlo_kron_c3_work_size(am, an, mode_a, bp, bq, mode_b)
+ * real scalars: the four planes of x (re, im, im - re, re + im), the planes of the intermediate U (also im - re, re + im),
+ * the three GEMM outputs of a stage and one factor-sum plane. The last stage's re / im are formed inside the join pass. */
 int64_t mxlo_kron_c3_work_size(int64_t am, int64_t an, int32_t mode_a, int64_t bp, int64_t bq, int32_t mode_b);
-int32_t mxlo_kron_mul_c3(mxlo_ctx *ctx, int32_t dtype, void *res, const void *Ar, const void *Ai, int64_t am, int64_t an,
-                         int64_t lda, int32_t mode_a, const void *Br, const void *Bi, int64_t bp, int64_t bq, int64_t ldb,
-                         int32_t mode_b, const void *x, void *work, double alpha_re, double alpha_im, double beta_re,
-                         double beta_im, int32_t flags);
+int32_t mxlo_plane_sum(mxlo_ctx *ctx, int32_t dtype, void *out, const void *a, const void *b, int64_t rows, int64_t cols,
+                       int64_t ld, double sign);   /* out = a + sign*b (dtype: the COMPLEX type whose planes these are) */
+int32_t mxlo_kron_mul_c3(mxlo_ctx *ctx, int32_t dtype, void *res, const void *Ar, const void *Ai, const void *As, int64_t am,
+                         int64_t an, int64_t lda, int32_t mode_a, const void *Br, const void *Bi, const void *Bs, int64_t bp,
+                         int64_t bq, int64_t ldb, int32_t mode_b, const void *x, void *work, double alpha_re, double alpha_im,
+                         double beta_re, double beta_im, int32_t flags);
 /* A REAL operator applied to complex vectors (eltype(op) = Float64, x::Vector{ComplexF64}: test/test_kron.jl
  * "issue110"; Julia runs the generic closure on the complex vectors). The glue applies the real operator to the two
  * planes: mxlo_split_c writes re[i], im[i] of x; mxlo_join_c computes res = α*(re + i*im) (+ β*res) with complex or

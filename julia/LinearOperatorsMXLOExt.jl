@@ -523,10 +523,24 @@ function ckron(A::MXMatrix, B::MXMatrix)
   wsz(mode) = ccall((:mxlo_kron_c3_work_size, lib), Int64, (Int64, Int64, Int32, Int64, Int64, Int32), m, n, Int32(mode), p, q, Int32(mode))
   work = MXVector{R}(undef, max(wsz(0), wsz(1)))
   imptr(x) = x === nothing ? C_NULL : x.data.ptr
-  mulmode(mode) = (res, x, α, β) -> check(ccall((:mxlo_kron_mul_c3, lib), Int32,
-      (P, Int32, P, P, P, Int64, Int64, Int64, Int32, P, P, Int64, Int64, Int64, Int32, P, P, Float64, Float64, Float64, Float64, Int32),
-      ctx(), dt(T), res.ptr, pa.re.data.ptr, imptr(pa.im), m, n, m, Int32(mode), pb.re.data.ptr, imptr(pb.im), p, q, p, Int32(mode),
-      x.ptr, work.ptr, rpart(α), ipart(α), rpart(β), ipart(β), flags(T, α, β)))
+  # factor-sum planes re + s*im of the Gauss form, formed ONCE here (the factors of this constructor are immutable
+  # snapshots: `planes` copied them): s = +1 for prod! / tprod!, -1 for ctprod! (conjugated factors)
+  function sumplane(pl::Planes{R}, rows, cols, s)
+    pl.im === nothing && return nothing
+    out = MXVector{R}(undef, rows * cols)
+    check(ccall((:mxlo_plane_sum, lib), Int32, (P, Int32, P, P, P, Int64, Int64, Int64, Float64),
+                ctx(), dt(T), out.ptr, pl.re.data.ptr, pl.im.data.ptr, rows, cols, rows, s))
+    out
+  end
+  sums = Dict(s => (sumplane(pa, m, n, s), sumplane(pb, p, q, s)) for s in (1.0, -1.0))
+  vptr(x) = x === nothing ? C_NULL : x.ptr
+  mulmode(mode) = (res, x, α, β) -> begin
+    sa, sb = sums[(mode & 2) != 0 ? -1.0 : 1.0]
+    check(ccall((:mxlo_kron_mul_c3, lib), Int32,
+      (P, Int32, P, P, P, P, Int64, Int64, Int64, Int32, P, P, P, Int64, Int64, Int64, Int32, P, P, Float64, Float64, Float64, Float64, Int32),
+      ctx(), dt(T), res.ptr, pa.re.data.ptr, imptr(pa.im), vptr(sa), m, n, m, Int32(mode), pb.re.data.ptr, imptr(pb.im), vptr(sb), p, q, p,
+      Int32(mode), x.ptr, work.ptr, rpart(α), ipart(α), rpart(β), ipart(β), flags(T, α, β)))
+  end
   LinearOperator{T, MXVector{T}}(m * p, n * q, false, false, mulmode(0), mulmode(1), mulmode(3))
 end
 

@@ -118,7 +118,8 @@ _PROTOS = {
     "mxlo_dot_c": [_vp, _i32, _vp, _vp, _i64, _vp],
     "mxlo_householder_mul_c": [_vp, _i32, _vp, _vp, _vp, _i64, _dbl, _dbl, _dbl, _dbl, _i32],
     "mxlo_kron_mul_c": [_vp, _i32, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _vp, _vp, _i64, _i64, _i64, _i32, _vp, _vp, _dbl, _dbl, _dbl, _dbl, _i32],
-    "mxlo_kron_mul_c3": [_vp, _i32, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _vp, _vp, _i64, _i64, _i64, _i32, _vp, _vp, _dbl, _dbl, _dbl, _dbl, _i32],
+    "mxlo_kron_mul_c3": [_vp, _i32, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _vp, _vp, _dbl, _dbl, _dbl, _dbl, _i32],
+    "mxlo_plane_sum": [_vp, _i32, _vp, _vp, _vp, _i64, _i64, _i64, _dbl],
     "mxlo_kron_c3_work_size": [_i64, _i64, _i32, _i64, _i64, _i32],
     "mxlo_split_c": [_vp, _i32, _vp, _vp, _vp, _i64],
     "mxlo_join_c": [_vp, _i32, _vp, _vp, _vp, _i64, _dbl, _dbl, _dbl, _dbl, _i32],

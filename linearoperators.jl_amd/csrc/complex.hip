@@ -25,9 +25,12 @@ int32_t kron_planes(mxlo_ctx *ctx, R *rr, R *ri, const R *Ar, const R *Ai, int64
                     bool trans_a, double sign_ai, const R *Br, const R *Bi, int64_t bp, int64_t bq, int64_t ldb,
                     bool trans_b, double sign_bi, const R *xr, const R *xi, R *utr, R *uti);   // dense.hip
 template <typename R>
-int32_t kron_planes3(mxlo_ctx *ctx, R *rr, R *ri, const R *Ar, const R *Ai, int64_t am, int64_t an, int64_t lda,
-                     bool trans_a, double sign_ai, const R *Br, const R *Bi, int64_t bp, int64_t bq, int64_t ldb,
-                     bool trans_b, double sign_bi, const R *xr, const R *xi, const R *xd, const R *xs, R *work);   // dense.hip
+int32_t kron_planes3(mxlo_ctx *ctx, R *rr, R *ri, const R *Ar, const R *Ai, const R *As, int64_t am, int64_t an, int64_t lda,
+                     bool trans_a, double sign_ai, const R *Br, const R *Bi, const R *Bs, int64_t bp, int64_t bq, int64_t ldb,
+                     bool trans_b, double sign_bi, const R *xr, const R *xi, const R *xd, const R *xs, R *work,
+                     const R **kout);   // dense.hip
+template <typename R>
+int32_t plane_sum(mxlo_ctx *ctx, R *out, const R *a, const R *b, int64_t rows, int64_t cols, int64_t ld, double sign);   // dense.hip
 }  // namespace mxlo
 
 namespace {
@@ -947,6 +950,19 @@ cplx_join_kernel(C<R> *__restrict__ res, const R *__restrict__ rr, const R *__re
   }
 }
 
+// the join pass of the Gauss form: re = k1 - k3, im = k1 + k2 formed on the fly (no rr / ri planes written and re-read)
+template <typename R, typename RA, typename RB, bool BETA0>
+__global__ void __launch_bounds__(kBlock)
+cplx_join3_kernel(C<R> *__restrict__ res, const R *__restrict__ k1, const R *__restrict__ k2, const R *__restrict__ k3,
+                  int64_t n, Sc<RA> a, Sc<RB> b) {
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+    const R re = k1[i] - k3[i], im = k1[i] + k2[i];
+    RA tr, ti;
+    a.mul(C<R>(re, im), tr, ti);
+    res[i] = cfin<R, RA, RB, BETA0>(tr, ti, b.re, b.im, b.real, BETA0 ? C<R>() : res[i]);
+  }
+}
+
 template <typename R>
 int32_t ckron(mxlo_ctx *ctx, C<R> *res, const R *Ar, const R *Ai, int64_t am, int64_t an, int64_t lda, int mode_a,
               const R *Br, const R *Bi, int64_t bp, int64_t bq, int64_t ldb, int mode_b, const C<R> *x, R *work,
@@ -978,8 +994,8 @@ int32_t ckron(mxlo_ctx *ctx, C<R> *res, const R *Ar, const R *Ai, int64_t am, in
 
 // kron on complex data with 3 real GEMMs per complex product (dense.hip: kron_planes3)
 template <typename R>
-int32_t ckron3(mxlo_ctx *ctx, C<R> *res, const R *Ar, const R *Ai, int64_t am, int64_t an, int64_t lda, int mode_a,
-               const R *Br, const R *Bi, int64_t bp, int64_t bq, int64_t ldb, int mode_b, const C<R> *x, R *work,
+int32_t ckron3(mxlo_ctx *ctx, C<R> *res, const R *Ar, const R *Ai, const R *As, int64_t am, int64_t an, int64_t lda, int mode_a,
+               const R *Br, const R *Bi, const R *Bs, int64_t bp, int64_t bq, int64_t ldb, int mode_b, const C<R> *x, R *work,
                const ScalArgs &s) {
   const bool ta = (mode_a & 1) != 0, tb = (mode_b & 1) != 0;
   const int64_t m = ta ? an : am, n = ta ? am : an, p = tb ? bq : bp, q = tb ? bp : bq;
@@ -995,14 +1011,19 @@ int32_t ckron3(mxlo_ctx *ctx, C<R> *res, const R *Ar, const R *Ai, int64_t am, i
   hipLaunchKernelGGL((cplx_split_kernel<R>), dim3(grid_for(ctx, nin, kBlock, 8)), dim3(kBlock), 0, ctx->stream, xr, xi, x, nin,
                      Ai ? xd : (R *)nullptr, Ai ? xs : (R *)nullptr);
   MXLO_LAUNCH_CHECK();
-  MXLO_TRY((kron_planes3<R>(ctx, rr, ri, Ar, Ai, am, an, lda, ta, (mode_a & 2) ? -1.0 : 1.0, Br, Bi, bp, bq, ldb, tb,
-                            (mode_b & 2) ? -1.0 : 1.0, xr, xi, xd, xs, rest)));
+  const R *kk[3] = {nullptr, nullptr, nullptr};
+  MXLO_TRY((kron_planes3<R>(ctx, rr, ri, Ar, Ai, As, am, an, lda, ta, (mode_a & 2) ? -1.0 : 1.0, Br, Bi, Bs, bp, bq, ldb, tb,
+                            (mode_b & 2) ? -1.0 : 1.0, xr, xi, xd, xs, rest, kk)));
   const int grid = grid_for(ctx, nout, kBlock, 8);
   return dispatch_c<R>(s, [&]<typename RA, typename RB, bool B0>() -> int32_t {
     const Sc<RA> a{(RA)s.are, (RA)s.aim, s.a_real};
     const Sc<RB> b{(RB)s.bre, (RB)s.bim, s.b_real};
-    hipLaunchKernelGGL((cplx_join_kernel<R, RA, RB, B0>), dim3(grid), dim3(kBlock), 0, ctx->stream, res, (const R *)rr,
-                       (const R *)ri, nout, a, b);
+    if (kk[0])
+      hipLaunchKernelGGL((cplx_join3_kernel<R, RA, RB, B0>), dim3(grid), dim3(kBlock), 0, ctx->stream, res, kk[0], kk[1], kk[2],
+                         nout, a, b);
+    else
+      hipLaunchKernelGGL((cplx_join_kernel<R, RA, RB, B0>), dim3(grid), dim3(kBlock), 0, ctx->stream, res, (const R *)rr,
+                         (const R *)ri, nout, a, b);
     MXLO_LAUNCH_CHECK();
     return MXLO_OK;
   });
@@ -1150,10 +1171,20 @@ MXLO_API int64_t mxlo_kron_c3_work_size(int64_t am, int64_t an, int32_t mode_a, 
   return 4 * pad(q * n) + 2 * pad(p * m) + 4 * pad(m * q) + 3 * pad(kmax) + pad(fmax) + 8;
 }
 
-MXLO_API int32_t mxlo_kron_mul_c3(mxlo_ctx *ctx, int32_t dtype, void *res, const void *Ar, const void *Ai, int64_t am,
-                                  int64_t an, int64_t lda, int32_t mode_a, const void *Br, const void *Bi, int64_t bp,
-                                  int64_t bq, int64_t ldb, int32_t mode_b, const void *x, void *work, double alpha_re,
-                                  double alpha_im, double beta_re, double beta_im, int32_t flags) {
+MXLO_API int32_t mxlo_plane_sum(mxlo_ctx *ctx, int32_t dtype, void *out, const void *a, const void *b, int64_t rows,
+                                int64_t cols, int64_t ld, double sign) {
+  CHECK_C("mxlo_plane_sum");
+  MXLO_REQUIRE(rows >= 0 && cols >= 0 && ld >= (rows > 1 ? rows : 1), MXLO_ESHAPE, "mxlo_plane_sum: bad shape");
+  if (rows * cols == 0) return MXLO_OK;
+  MXLO_REQUIRE(out && a && b, MXLO_EINVAL, "mxlo_plane_sum: NULL operand");
+  if (dtype == MXLO_C64) return plane_sum<double>(ctx, (double *)out, (const double *)a, (const double *)b, rows, cols, ld, sign);
+  return plane_sum<float>(ctx, (float *)out, (const float *)a, (const float *)b, rows, cols, ld, sign);
+}
+
+MXLO_API int32_t mxlo_kron_mul_c3(mxlo_ctx *ctx, int32_t dtype, void *res, const void *Ar, const void *Ai, const void *As,
+                                  int64_t am, int64_t an, int64_t lda, int32_t mode_a, const void *Br, const void *Bi,
+                                  const void *Bs, int64_t bp, int64_t bq, int64_t ldb, int32_t mode_b, const void *x, void *work,
+                                  double alpha_re, double alpha_im, double beta_re, double beta_im, int32_t flags) {
   CHECK_C("mxlo_kron_mul_c3");
   MXLO_REQUIRE(am >= 0 && an >= 0 && bp >= 0 && bq >= 0, MXLO_ESHAPE, "mxlo_kron_mul_c3: negative size");
   MXLO_REQUIRE(lda >= (am > 1 ? am : 1) && ldb >= (bp > 1 ? bp : 1), MXLO_ESHAPE, "mxlo_kron_mul_c3: bad leading dimension");
@@ -1163,11 +1194,13 @@ MXLO_API int32_t mxlo_kron_mul_c3(mxlo_ctx *ctx, int32_t dtype, void *res, const
   MXLO_REQUIRE(res && Ar && Br && x && work, MXLO_EINVAL, "mxlo_kron_mul_c3: NULL operand");
   MXLO_REQUIRE((((uintptr_t)work) & 15u) == 0, MXLO_EINVAL, "mxlo_kron_mul_c3: work must be 16-byte aligned");
   if (dtype == MXLO_C64)
-    return ckron3<double>(ctx, (C<double> *)res, (const double *)Ar, (const double *)Ai, am, an, lda, mode_a, (const double *)Br,
-                          (const double *)Bi, bp, bq, ldb, mode_b, (const C<double> *)x, (double *)work,
+    return ckron3<double>(ctx, (C<double> *)res, (const double *)Ar, (const double *)Ai, (const double *)As, am, an, lda, mode_a,
+                          (const double *)Br, (const double *)Bi, (const double *)Bs, bp, bq, ldb, mode_b,
+                          (const C<double> *)x, (double *)work,
                           scal_args(8, alpha_re, alpha_im, beta_re, beta_im, flags));
-  return ckron3<float>(ctx, (C<float> *)res, (const float *)Ar, (const float *)Ai, am, an, lda, mode_a, (const float *)Br,
-                       (const float *)Bi, bp, bq, ldb, mode_b, (const C<float> *)x, (float *)work,
+  return ckron3<float>(ctx, (C<float> *)res, (const float *)Ar, (const float *)Ai, (const float *)As, am, an, lda, mode_a,
+                       (const float *)Br, (const float *)Bi, (const float *)Bs, bp, bq, ldb, mode_b, (const C<float> *)x,
+                       (float *)work,
                        scal_args(4, alpha_re, alpha_im, beta_re, beta_im, flags));
 }
 

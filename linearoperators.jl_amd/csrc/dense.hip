@@ -1121,10 +1121,14 @@ gauss_planes_kernel(R *__restrict__ re, R *__restrict__ im, R *__restrict__ dmr,
 }
 
 // work layout (R scalars, every plane 16-byte aligned): see mxlo_kron_mul_c3 in include/mxlo.h
+// As / Bs: optional factor-sum planes a + sign*b (contiguous, leading dimension = rows) cached by the caller per factor
+// state; NULL: formed here, per call. kout: when non-NULL and B is complex, the three products of the SECOND stage are
+// left in kout[0..2] (re = k1 - k3, im = k1 + k2 is then the caller's — it is folded into the join pass).
 template <typename R>
-int32_t kron_planes3(mxlo_ctx *ctx, R *rr, R *ri, const R *Ar, const R *Ai, int64_t am, int64_t an, int64_t lda,
-                     bool trans_a, double sign_ai, const R *Br, const R *Bi, int64_t bp, int64_t bq, int64_t ldb,
-                     bool trans_b, double sign_bi, const R *xr, const R *xi, const R *xd, const R *xs, R *work) {
+int32_t kron_planes3(mxlo_ctx *ctx, R *rr, R *ri, const R *Ar, const R *Ai, const R *As, int64_t am, int64_t an, int64_t lda,
+                     bool trans_a, double sign_ai, const R *Br, const R *Bi, const R *Bs, int64_t bp, int64_t bq, int64_t ldb,
+                     bool trans_b, double sign_bi, const R *xr, const R *xi, const R *xd, const R *xs, R *work,
+                     const R **kout) {
   const int64_t m = trans_a ? an : am, n = trans_a ? am : an;
   const int64_t p = trans_b ? bq : bp, q = trans_b ? bp : bq;
   auto pad = [](int64_t k) { return (k + 3) & ~(int64_t)3; };
@@ -1134,10 +1138,13 @@ int32_t kron_planes3(mxlo_ctx *ctx, R *rr, R *ri, const R *Ar, const R *Ai, int6
   auto egrid = [&](int64_t cnt) { return grid_for(ctx, (cnt + 1) / 2, kBlock, 8); };
   // ---- first product: U^T = opA(A) X^T  (m x q, K = n)
   if (Ai) {
-    hipLaunchKernelGGL((plane_sum_kernel<R>), dim3(egrid(am * an)), dim3(kBlock), 0, ctx->stream, fs, Ar, Ai, am, an, lda,
-                       (R)sign_ai);
-    MXLO_LAUNCH_CHECK();
-    MXLO_TRY(gemm<R>(ctx, k1, m, fs, am, trans_a, xr, q, true, m, q, n, 1.0, 0.0, 0));          // (a + b) c
+    if (!As) {
+      hipLaunchKernelGGL((plane_sum_kernel<R>), dim3(egrid(am * an)), dim3(kBlock), 0, ctx->stream, fs, Ar, Ai, am, an, lda,
+                         (R)sign_ai);
+      MXLO_LAUNCH_CHECK();
+      As = fs;
+    }
+    MXLO_TRY(gemm<R>(ctx, k1, m, As, am, trans_a, xr, q, true, m, q, n, 1.0, 0.0, 0));          // (a + b) c
     MXLO_TRY(gemm<R>(ctx, k2, m, Ar, lda, trans_a, xd, q, true, m, q, n, 1.0, 0.0, 0));         // a (d - c)
     MXLO_TRY(gemm<R>(ctx, k3, m, Ai, lda, trans_a, xs, q, true, m, q, n, sign_ai, 0.0, 0));     // b (c + d)
     if (Bi)
@@ -1158,27 +1165,50 @@ int32_t kron_planes3(mxlo_ctx *ctx, R *rr, R *ri, const R *Ar, const R *Ai, int6
   }
   // ---- second product: R = opB(B) U  (p x m, K = q)
   if (Bi) {
-    hipLaunchKernelGGL((plane_sum_kernel<R>), dim3(egrid(bp * bq)), dim3(kBlock), 0, ctx->stream, fs, Br, Bi, bp, bq, ldb,
-                       (R)sign_bi);
-    MXLO_LAUNCH_CHECK();
-    MXLO_TRY(gemm<R>(ctx, k1, p, fs, bp, trans_b, ur, m, true, p, m, q, 1.0, 0.0, 0));
+    if (!Bs) {
+      hipLaunchKernelGGL((plane_sum_kernel<R>), dim3(egrid(bp * bq)), dim3(kBlock), 0, ctx->stream, fs, Br, Bi, bp, bq, ldb,
+                         (R)sign_bi);
+      MXLO_LAUNCH_CHECK();
+      Bs = fs;
+    }
+    MXLO_TRY(gemm<R>(ctx, k1, p, Bs, bp, trans_b, ur, m, true, p, m, q, 1.0, 0.0, 0));
     MXLO_TRY(gemm<R>(ctx, k2, p, Br, ldb, trans_b, ud, m, true, p, m, q, 1.0, 0.0, 0));
     MXLO_TRY(gemm<R>(ctx, k3, p, Bi, ldb, trans_b, us, m, true, p, m, q, sign_bi, 0.0, 0));
-    hipLaunchKernelGGL((gauss_planes_kernel<R, true, false>), dim3(egrid(p * m)), dim3(kBlock), 0, ctx->stream, rr, ri, (R *)nullptr,
-                       (R *)nullptr, (const R *)k1, (const R *)k2, (const R *)k3, p * m);
-    MXLO_LAUNCH_CHECK();
+    if (kout) {                       // the caller's join pass forms re = k1 - k3, im = k1 + k2 on the fly
+      kout[0] = k1;
+      kout[1] = k2;
+      kout[2] = k3;
+    } else {
+      hipLaunchKernelGGL((gauss_planes_kernel<R, true, false>), dim3(egrid(p * m)), dim3(kBlock), 0, ctx->stream, rr, ri,
+                         (R *)nullptr, (R *)nullptr, (const R *)k1, (const R *)k2, (const R *)k3, p * m);
+      MXLO_LAUNCH_CHECK();
+    }
   } else {
+    if (kout) kout[0] = kout[1] = kout[2] = nullptr;
     MXLO_TRY(gemm<R>(ctx, rr, p, Br, ldb, trans_b, ur, m, true, p, m, q, 1.0, 0.0, 0));
     MXLO_TRY(gemm<R>(ctx, ri, p, Br, ldb, trans_b, ui, m, true, p, m, q, 1.0, 0.0, 0));
   }
   return MXLO_OK;
 }
-template int32_t kron_planes3<double>(mxlo_ctx *, double *, double *, const double *, const double *, int64_t, int64_t, int64_t,
-                                      bool, double, const double *, const double *, int64_t, int64_t, int64_t, bool, double,
-                                      const double *, const double *, const double *, const double *, double *);
-template int32_t kron_planes3<float>(mxlo_ctx *, float *, float *, const float *, const float *, int64_t, int64_t, int64_t, bool,
-                                     double, const float *, const float *, int64_t, int64_t, int64_t, bool, double,
-                                     const float *, const float *, const float *, const float *, float *);
+template int32_t kron_planes3<double>(mxlo_ctx *, double *, double *, const double *, const double *, const double *, int64_t,
+                                      int64_t, int64_t, bool, double, const double *, const double *, const double *, int64_t,
+                                      int64_t, int64_t, bool, double, const double *, const double *, const double *,
+                                      const double *, double *, const double **);
+template int32_t kron_planes3<float>(mxlo_ctx *, float *, float *, const float *, const float *, const float *, int64_t, int64_t,
+                                     int64_t, bool, double, const float *, const float *, const float *, int64_t, int64_t,
+                                     int64_t, bool, double, const float *, const float *, const float *, const float *, float *,
+                                     const float **);
+// out (rows x cols, contiguous) = a + sign*b: the factor-sum plane of the Gauss form, for callers that cache it
+template <typename R>
+int32_t plane_sum(mxlo_ctx *ctx, R *out, const R *a, const R *b, int64_t rows, int64_t cols, int64_t ld, double sign) {
+  if (rows * cols <= 0) return MXLO_OK;
+  hipLaunchKernelGGL((plane_sum_kernel<R>), dim3(grid_for(ctx, (rows * cols + 1) / 2, kBlock, 8)), dim3(kBlock), 0, ctx->stream,
+                     out, a, b, rows, cols, ld, (R)sign);
+  MXLO_LAUNCH_CHECK();
+  return MXLO_OK;
+}
+template int32_t plane_sum<double>(mxlo_ctx *, double *, const double *, const double *, int64_t, int64_t, int64_t, double);
+template int32_t plane_sum<float>(mxlo_ctx *, float *, const float *, const float *, int64_t, int64_t, int64_t, double);
 }  // namespace mxlo
 
 static inline void eff_ab(int32_t dtype, int32_t flags, double &alpha, double &beta) {

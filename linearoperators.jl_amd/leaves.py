@@ -604,7 +604,7 @@ def _kron_complex(A, B, fA, fB, T):
 
     class Planes:
         def __init__(self, f):
-            self.f, self.cache, self.token = f, None, object()
+            self.f, self.cache, self.token, self.sums = f, None, object(), {}
             if not f.dtype.is_complex:
                 f.T = R
 
@@ -619,7 +619,22 @@ def _kron_complex(A, B, fA, fB, T):
                 D = (f.src if f.src is not None else to_dense(f.op)).to(T)
                 self.cache = (D.real.t().contiguous().t(), D.imag.t().contiguous().t())     # column-major planes
                 self.token = tok
+                self.sums = {}
             return self.cache[0], self.cache[1], 0
+
+        def sum_plane(self, sign):
+            """re + sign*im (Gauss form, `mxlo_plane_sum`), cached with the planes: once per factor state and sign."""
+            if not self.f.dtype.is_complex:
+                return None
+            re, im = self.cache                      # km() has just called get(): the planes are current
+            out = self.sums.get(sign)
+            if out is None:
+                out = torch.empty(re.shape[1], re.shape[0], dtype=R, device=dev).t()        # contiguous column-major
+                ctx = get_ctx(dev)
+                _lib.call("mxlo_plane_sum", ctx.handle, dtype_code(T, True), ptr(out), ptr(re), ptr(im), re.shape[0],
+                          re.shape[1], _ld(re), float(sign))
+                self.sums[sign] = out
+            return out
 
     pA, pB = Planes(fA), Planes(fB)
     # Gauss form (3 real GEMMs per complex product, `mxlo_kron_mul_c3`) by default; MXLO_KRON_GAUSS=0 keeps the 4-GEMM
@@ -635,7 +650,14 @@ def _kron_complex(A, B, fA, fB, T):
         ctx = get_ctx(res.device)
         Ar, Ai, ta = pA.get()
         Br, Bi, tb = pB.get()
-        _lib.call("mxlo_kron_mul_c3" if gauss else "mxlo_kron_mul_c", ctx.handle, dtype_code(T, True), ptr(res), ptr(Ar), ptr(Ai), Ar.shape[0], Ar.shape[1],
+        if gauss:
+            sgn = -1.0 if conj else 1.0
+            _lib.call("mxlo_kron_mul_c3", ctx.handle, dtype_code(T, True), ptr(res), ptr(Ar), ptr(Ai), ptr(pA.sum_plane(sgn)),
+                      Ar.shape[0], Ar.shape[1], _ld(Ar), (ta ^ trans) | (conj << 1), ptr(Br), ptr(Bi), ptr(pB.sum_plane(sgn)),
+                      Br.shape[0], Br.shape[1], _ld(Br), (tb ^ trans) | (conj << 1), ptr(x), ptr(work), *_c4(a, b),
+                      scalar_flags(res.dtype, a, b))
+            return
+        _lib.call("mxlo_kron_mul_c", ctx.handle, dtype_code(T, True), ptr(res), ptr(Ar), ptr(Ai), Ar.shape[0], Ar.shape[1],
                   _ld(Ar), (ta ^ trans) | (conj << 1), ptr(Br), ptr(Bi), Br.shape[0], Br.shape[1], _ld(Br),
                   (tb ^ trans) | (conj << 1), ptr(x), ptr(work), *_c4(a, b), scalar_flags(res.dtype, a, b))
 

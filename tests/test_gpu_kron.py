@@ -335,15 +335,32 @@ def test_gauss_form_matches_four_gemm_form(lo, dev, dtype, tol, shapes):
                        2 * (nin + max(an * bp, am * bq, an * bq, am * bp) + nout) + 24)
             work = torch.empty(need + 64, dtype=R, device=dev)
             out = {}
-            for name in ("mxlo_kron_mul_c3", "mxlo_kron_mul_c"):
+            sgn = -1.0 if mode & 2 else 1.0
+            sums = []
+            for re_, im_, r_, c_ in ((dAr, dAi, am, an), (dBr, dBi, bp, bq)):     # cached factor-sum planes (mxlo_plane_sum)
+                if im_ is None:
+                    sums.append(None)
+                    continue
+                sp = torch.empty(c_, r_, dtype=R, device=dev).t()
+                _lib.call("mxlo_plane_sum", ctx.handle, dtype_code(dtype, True), sp.data_ptr(), re_.data_ptr(), im_.data_ptr(), r_, c_, r_, sgn)
+                want_s = (re_.double() + sgn * im_.double()).to(R)
+                assert torch.equal(sp, want_s)
+                sums.append(sp)
+            P_ = lambda t: None if t is None else t.data_ptr()
+            for name in ("c3 cached sums", "c3 sums per call", "c4"):
                 res = torch.from_numpy(r0).to(dtype).to(dev)
-                _lib.call(name, ctx.handle, dtype_code(dtype, True), C.c_void_p(res.data_ptr()), C.c_void_p(dAr.data_ptr()),
-                          C.c_void_p(dAi.data_ptr() if dAi is not None else 0), am, an, am, mode, C.c_void_p(dBr.data_ptr()),
-                          C.c_void_p(dBi.data_ptr() if dBi is not None else 0), bp, bq, bp, mode, C.c_void_p(xd.data_ptr()),
-                          C.c_void_p(work.data_ptr()), 1.5, -0.5, 0.25, 2.0, 0)
+                if name == "c4":
+                    _lib.call("mxlo_kron_mul_c", ctx.handle, dtype_code(dtype, True), res.data_ptr(), dAr.data_ptr(), P_(dAi), am, an, am, mode,
+                              dBr.data_ptr(), P_(dBi), bp, bq, bp, mode, xd.data_ptr(), work.data_ptr(), 1.5, -0.5, 0.25, 2.0, 0)
+                else:
+                    cached = name == "c3 cached sums"
+                    _lib.call("mxlo_kron_mul_c3", ctx.handle, dtype_code(dtype, True), res.data_ptr(), dAr.data_ptr(), P_(dAi),
+                              P_(sums[0]) if cached else None, am, an, am, mode, dBr.data_ptr(), P_(dBi), P_(sums[1]) if cached else None,
+                              bp, bq, bp, mode, xd.data_ptr(), work.data_ptr(), 1.5, -0.5, 0.25, 2.0, 0)
                 out[name] = res.cpu().numpy().astype(np.complex128)
             want = (1.5 - 0.5j) * (K @ xd.cpu().numpy().astype(np.complex128)) + (0.25 + 2j) * torch.from_numpy(r0).to(dtype).numpy().astype(np.complex128)
             scale = np.abs(K).sum(axis=0).max() * max(1.0, np.abs(x).max())
             for name, got in out.items():
                 assert np.abs(got - want).max() <= 4 * tol * scale, (name, kinds, mode)
-            assert np.abs(out["mxlo_kron_mul_c3"] - out["mxlo_kron_mul_c"]).max() <= 4 * tol * scale, (kinds, mode)
+            assert np.abs(out["c3 cached sums"] - out["c4"]).max() <= 4 * tol * scale, (kinds, mode)
+            assert np.array_equal(out["c3 cached sums"], out["c3 sums per call"]), (kinds, mode)     # same arithmetic

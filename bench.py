@@ -209,7 +209,9 @@ def main(argv=None):
         out = worker(args)
     if out is None:                                  # a non-zero rank under an external launcher
         return
-    if not args.no_shard_leg and not args.worker_cmd:
+    # the shard-ABI leg runs ONCE, after the process-per-GPU ranks are gone: in the launcher when this script started the
+    # ranks itself (its rank-0 child skips it), in rank 0 under an external launcher
+    if not args.no_shard_leg and not args.worker_cmd and (self_launch or os.environ.get("MXLO_BENCH_SELF_LAUNCHED") != "1"):
         out.setdefault("extras", {})["single_process_shard_abi"] = run_shard_leg(args)
     print(json.dumps(out), flush=True)
 

@@ -549,6 +549,22 @@ def bench_lbfgs(lo, torch, dev, ctx, rank, world, distributed, dist, barrier):
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item()) / reps
 
+    def time_push(op, reps=4):
+        """push!(op, s, y) with a full memory: wall time per push incl. the accept / reject read-back (an optimiser loop
+        pays exactly this); every rank issues the same pushes (replicated decision)."""
+        s = torch.rand(n, dtype=torch.float64, device=dev, generator=gen) * 2 - 1
+        y = s * (torch.rand(n, dtype=torch.float64, device=dev, generator=gen) * 1.5 + 0.5)
+        lo.push(op, s, y)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            lo.push(op, s, y)
+        barrier()
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        if distributed:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item()) / reps
+
     m = 10
     Hinv = lo.InverseLBFGSOperator(torch.float64, n, mem=m, scaling=True, device=dev)
     fill(Hinv, m + 3)
@@ -558,6 +574,9 @@ def bench_lbfgs(lo, torch, dev, ctx, rank, world, distributed, dist, barrier):
                                     "GB/s_per_gpu(344B/elt)": round(bytes_ / sec / 1e9, 1),
                                     "frac_hbm_peak": round(bytes_ / sec / 1e9 / HBM_PEAK_GBS, 4),
                                     "n_global": n * world}
+    psec = time_push(Hinv)
+    out["InverseLBFGS_m10_n5e7"]["push_ms"] = round(psec * 1e3, 3)          # one-pass push!: (2m + 4) vector passes
+    out["InverseLBFGS_m10_n5e7"]["push_frac_hbm_peak(9.6GB)"] = round((2 * m + 4) * 8.0 * n / psec / 1e9 / HBM_PEAK_GBS, 4)
     del Hinv
     torch.cuda.empty_cache()
     m = 20
@@ -569,6 +588,9 @@ def bench_lbfgs(lo, torch, dev, ctx, rank, world, distributed, dist, barrier):
                                       "GB/s_per_gpu(664B/elt)": round(bytes_ / sec / 1e9, 1),
                                       "frac_hbm_peak": round(bytes_ / sec / 1e9 / HBM_PEAK_GBS, 4),
                                       "n_global": n * world}
+    psec = time_push(Bf)
+    out["LBFGS_fwd_m20_nlocal5e7"]["push_ms"] = round(psec * 1e3, 3)        # one-pass push!: (2m + 5) vector passes
+    out["LBFGS_fwd_m20_nlocal5e7"]["push_frac_hbm_peak(18GB)"] = round((2 * m + 5) * 8.0 * n / psec / 1e9 / HBM_PEAK_GBS, 4)
     # the optimiser-iteration pattern: one push! (device-side Gram update, a_k left implicit), one apply and one
     # solve_shifted_system! (G rebuilt from the Gram matrices) per iteration
     s = torch.rand(n, dtype=torch.float64, device=dev, generator=gen) * 2 - 1
@@ -765,6 +787,37 @@ def bench_misc(lo, torch, dev, ctx):
             except Exception as e:           # an extra must never cost the line
                 out["dense_block_error"] = repr(e)
         del M, Hm
+    # launch-bound quasi-Newton applies (one launch per apply for <= 64 workgroups) and the Gauss-form complex kron
+    try:
+        for kind, make in (("LBFGS", lo.LBFGSOperator), ("InverseLBFGS", lo.InverseLBFGSOperator), ("LSR1", lo.LSR1Operator)):
+            ns = 1 << 12
+            op = make(torch.float64, ns, mem=5, device=dev)
+            for _ in range(7):
+                s_ = torch.rand(ns, dtype=torch.float64, device=dev, generator=gen) * 2 - 1
+                lo.push(op, s_, s_ * (torch.rand(ns, dtype=torch.float64, device=dev, generator=gen) * 0.25 + 1.25)
+                        + (0.3 * (torch.rand(ns, dtype=torch.float64, device=dev, generator=gen) - 0.5) if kind == "LSR1" else 0))
+            xs, rs = torch.rand(ns, dtype=torch.float64, device=dev, generator=gen), torch.empty(ns, dtype=torch.float64, device=dev)
+            us = timeit(lambda: lo.mul(rs, op, xs, 1.0, 0.0), 2000) * 1e3
+            ctx.tune("qn_fused_small", 0)
+            try:
+                us4 = timeit(lambda: lo.mul(rs, op, xs, 1.0, 0.0), 2000) * 1e3
+            finally:
+                ctx.tune("qn_fused_small", 1)
+            out[f"{kind}_m5_n2^12_apply_latency"] = {"us_single_launch": round(us, 2), "us_four_launches": round(us4, 2)}
+            del op
+        nk = 1024
+        mkc = lambda: (torch.complex(torch.rand(nk, nk, dtype=torch.float64, device=dev, generator=gen) - 0.5,
+                                     torch.rand(nk, nk, dtype=torch.float64, device=dev, generator=gen) - 0.5) / 32).t()
+        Kc = lo.kron(mkc(), mkc())
+        xk = torch.complex(torch.rand(nk * nk, dtype=torch.float64, device=dev, generator=gen), torch.rand(nk * nk, dtype=torch.float64, device=dev, generator=gen))
+        yk = torch.empty_like(xk)
+        us = timeit(lambda: lo.mul(yk, Kc, xk, 1.0, 0.0), 50) * 1e3
+        out["kron_1024x1024_ComplexF64"] = {"us_per_apply": round(us, 1), "form": "Gauss: 6 real f64-MFMA GEMMs",
+                                            "TFLOP/s_complex_product_flop": round(16.0 * nk ** 3 / us / 1e6, 1)}
+        del Kc, xk, yk
+        torch.cuda.empty_cache()
+    except Exception as e:               # an extra must never cost the line
+        out["latency_extras_error"] = repr(e)[:200]
     n16 = 1 << 16
     h = torch.rand(n16, dtype=torch.float64, device=dev, generator=gen)
     h /= torch.linalg.vector_norm(h)

@@ -525,7 +525,7 @@ function ckron(A::MXMatrix, B::MXMatrix)
   imptr(x) = x === nothing ? C_NULL : x.data.ptr
   # factor-sum planes re + s*im of the Gauss form, formed ONCE here (the factors of this constructor are immutable
   # snapshots: `planes` copied them): s = +1 for prod! / tprod!, -1 for ctprod! (conjugated factors)
-  function sumplane(pl::Planes{R}, rows, cols, s)
+  function sumplane(pl, rows, cols, s)
     pl.im === nothing && return nothing
     out = MXVector{R}(undef, rows * cols)
     check(ccall((:mxlo_plane_sum, lib), Int32, (P, Int32, P, P, P, Int64, Int64, Int64, Float64),

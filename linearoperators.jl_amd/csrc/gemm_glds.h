@@ -5,7 +5,8 @@
 //    into a ring of NST stages; a stage is issued NST-1 K-slabs ahead and waited for with a COUNTED
 //    `s_waitcnt vmcnt(N)` + one raw `s_barrier` per slab, so later slabs stay in flight across the barrier;
 //  * the LDS image is lane-linear per DMA instruction (hardware rule), so bank conflicts are avoided by an
-//    XOR swizzle applied to the per-lane SOURCE address and to the fragment reads alike — no padding;
+//    XOR swizzle applied to the per-lane SOURCE address and to the fragment reads alike — no padding; the swizzle
+//    is chosen per operand for the ds_read width that fetches its fragments (see SWA / SWB);
 //  * v_mfma_f64_16x16x4_f64 / v_mfma_f32_16x16x4_f32, a wave owns an (TM/WM) x (TN/WN) sub-tile;
 //  * the A operand may be M-contiguous (A stored M x K, prod!) or K-contiguous (A stored K x M: tprod!/ctprod!
 //    of kron read A and B transposed in place, src/kron.jl:24-40); B' is always N-contiguous (stored N x K);
@@ -90,6 +91,19 @@ gemm_glds_kernel(T *__restrict__ C, int64_t ldc, const T *__restrict__ A, int64_
   static_assert(NI % NW == 0, "every wave must issue the same number of DMA instructions per stage (counted vmcnt)");
   __shared__ __attribute__((aligned(1024))) T lds[NST * (AIMG + BIMG)];   // ONE LDS object (a second one makes
                                                                           // hipcc drain vmcnt before every ds_read)
+  // which operand's tiles are paired, and the XOR swizzle (in elements, applied on odd k-rows) of an M-/N-contiguous
+  // image s[k][TX]. It has to suit the ds_read that fetches the fragments (MI355X_MICROARCH.md, LDS table): the 16
+  // lanes of one k-row read 16 consecutive fragments, and the lanes a service group takes from two adjacent k-rows
+  // must land on different banks.
+  //   ds_read_b32 (f32):        32-lane groups, 128-B bank window, 16 lanes cover  64 B -> odd rows shifted by  64 B
+  //   ds_read_b64 (f64):        32-lane groups, 256-B bank window, 16 lanes cover 128 B -> odd rows shifted by 128 B
+  //   ds_read_b64 (f32 pairs):  as above                                                -> odd rows shifted by 128 B
+  //   ds_read_b128 (f64 pairs): 16-lane groups {0-3,12-15,20-27}.. take COMPLEMENTARY lanes of the two rows, which
+  //                             already cover 256 B between them -> no shift (a 128-B shift makes them collide 2-way:
+  //                             SQ_LDS_BANK_CONFLICT, profiles/r03_pmc_gemm_pair.txt)
+  constexpr bool PA = PAIR && !AK && (TM / WM / 16) % 2 == 0, PB = PAIR && (TN / WN / 16) % 2 == 0;
+  constexpr int SWA = !PA ? 16 : (sizeof(T) == 8 ? 0 : 32), SWB = !PB ? 16 : (sizeof(T) == 8 ? 0 : 32);
+  static_assert(SWA < TM && SWB < TN, "swizzle must stay inside an image row");
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int tx, ty;
@@ -126,10 +140,10 @@ gemm_glds_kernel(T *__restrict__ C, int64_t ldc, const T *__restrict__ A, int64_
       krow[p] = k;
       voff[p] = (uint32_t)(rowoff[p] + (int64_t)k * (int64_t)sizeof(T));
     } else {
-      // image s[k][TX], element (k,c) stored at k*TX + (c ^ ((k&1)<<4))
+      // image s[k][TX], element (k,c) stored at k*TX + (c ^ (k odd ? SW : 0))
       const int TX = isA ? TM : TN;
       const int k = flat / TX, cs = flat % TX;
-      int c = cs ^ ((k & 1) << 4);
+      int c = cs ^ ((k & 1) ? (isA ? SWA : SWB) : 0);
       const int lim = (isA ? M - bm : N - bn) - VEC;   // >= 0: M, N and the tile origin are multiples of VEC
       if (c > lim) c = lim;                            // clamp to a valid (unused) column
       rowoff[p] = (int64_t)c * (int64_t)sizeof(T);
@@ -174,7 +188,6 @@ gemm_glds_kernel(T *__restrict__ C, int64_t ldc, const T *__restrict__ A, int64_
   const int l15 = lane & 15, l4 = lane >> 4;
   // fragment offsets inside a stage image for k-step 0 (k = l4); a k-step advances k by 4, which keeps k & 1 and
   // (for the K-contiguous image) the XOR pattern's low bits: offsets for step ks follow by adding a constant.
-  constexpr bool PA = PAIR && !AK && (MT % 2 == 0), PB = PAIR && (NT % 2 == 0);   // which operand's tiles are paired
   typedef T Pair2 __attribute__((ext_vector_type(2)));
   int offA[MT], offB[NT];
 #pragma unroll
@@ -184,13 +197,13 @@ gemm_glds_kernel(T *__restrict__ C, int64_t ldc, const T *__restrict__ A, int64_
       const int g = ((BK >= 32 ? (i & 15) : ((i >> 1) & 7)) * 2) & (BK - 1) & ~(VEC - 1);
       offA[a] = i * BK + g;                    // element (i,k) at i*BK + (k ^ g): k is XORed per step below
     } else {
-      offA[a] = l4 * TM + (i ^ ((l4 & 1) << 4));
+      offA[a] = l4 * TM + (i ^ ((l4 & 1) ? SWA : 0));
     }
   }
 #pragma unroll
   for (int b = 0; b < NT; ++b) {
     const int j = PB ? wn + (b >> 1) * 32 + 2 * l15 + (b & 1) : wn + b * 16 + l15;
-    offB[b] = AIMG + l4 * TN + (j ^ ((l4 & 1) << 4));
+    offB[b] = AIMG + l4 * TN + (j ^ ((l4 & 1) ? SWB : 0));
   }
   auto frag = [&](const T *st, int ks, T (&av)[MT], T (&bv)[NT]) {
 #pragma unroll

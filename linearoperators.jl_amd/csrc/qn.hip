@@ -124,6 +124,8 @@ enum CombineMode {
   CM_DIAG_FWD = 6,  // q = 1 (/g); pairs (b,a): q = q + ((b*b) - (a*a)); res = q
   CM_DIAG_SR1 = 7,  // q = 1 (/g); cols a: q = q + ((a*a)/as); res = q
   CM_CFWD = 8,      // q = x (/g); cols u: q = q + c*u; res = al*q (+ be*res)   (compact forward L-BFGS)
+  CM_LSR1R = 9,     // CM_LSR1 with nothing stored: r = q, per-workgroup partial sums of r·x, r·r and |res - x/sf|²
+                    // (L-SR1 push!: r = y - B s with res = y, x = s, and the decision scalars of lsr1.jl:126-141)
 };
 
 template <typename T>
@@ -136,6 +138,11 @@ struct CombineArgs {
   double alpha, beta;
   const double *coef;  // device coefficients, one per column (CM_DIAG_SR1: as_k per column)
   double shift = 0.0;  // CM_FWD/INV/LSR1: res += T(shift)*x after the epilogue (fused ShiftedOperator axpy!)
+  // CM_LSR1R only: valid elements of x / res (the last vector may be partial; panel columns are zero padded), the
+  // device scalars sf = T(*sfnum) / T(*sfden) is formed from, and the [3][kMaxRedBlocks] partial sums
+  int64_t n_valid = 0;
+  const double *sfnum = nullptr, *sfden = nullptr;
+  double *partials = nullptr;
 };
 
 template <typename T, typename CA, typename CB, int MODE, bool BETA0, int VEC, bool NT>
@@ -154,25 +161,38 @@ combine_kernel(T *__restrict__ res, const T *__restrict__ x, const T *__restrict
   const CA al = (CA)A.alpha;
   const CB be = (CB)A.beta;
   const int ncol = A.ncol;
+  double racc[3] = {0.0, 0.0, 0.0};   // CM_LSR1R
+  T sfac = T(1);
+  if constexpr (MODE == CM_LSR1R) sfac = (T)(*A.sfnum) / (T)(*A.sfden);   // sf = ys/yy (lsr1.jl:139), as YmSOverDevOp
+  // CM_LSR1R: x and res are caller vectors of n_valid elements — the last vector is read element by element
+  auto ldt = [&](const T *p, int64_t i) -> V {
+    if ((i + 1) * VEC <= A.n_valid) return ldg<NT>(reinterpret_cast<const V *>(p + i * VEC));
+    V v;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) vset<T, VEC>(v, e, i * VEC + e < A.n_valid ? p[i * VEC + e] : T(0));
+    return v;
+  };
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < nvec;
        i += (int64_t)gridDim.x * kBlock) {
     T q[VEC];
-    V xv;
+    V xv, rvk;
     // ---- prologue
     if constexpr (MODE == CM_DIAG_FWD || MODE == CM_DIAG_SR1) {
 #pragma unroll
       for (int e = 0; e < VEC; ++e) q[e] = A.use_gamma ? (T)1 / g : (T)1;
     } else {
-      xv = ldg<NT>(reinterpret_cast<const V *>(x + i * VEC));
+      if constexpr (MODE == CM_LSR1R) xv = ldt(x, i);
+      else xv = ldg<NT>(reinterpret_cast<const V *>(x + i * VEC));
       V x2v, rv;
       if constexpr (MODE == CM_ASR1) x2v = ldg<NT>(reinterpret_cast<const V *>(x2 + i * VEC));
       if constexpr (MODE == CM_LSR1 && !BETA0) rv = ldg<NT>(reinterpret_cast<const V *>(res + i * VEC));
+      if constexpr (MODE == CM_LSR1R) rv = rvk = ldt(res, i);
 #pragma unroll
       for (int e = 0; e < VEC; ++e) {
         const T xe = vget<T, VEC>(xv, e);
         if constexpr (MODE == CM_FWD || MODE == CM_AFWD || MODE == CM_CFWD) q[e] = A.use_gamma ? xe / g : xe;
         else if constexpr (MODE == CM_INV) q[e] = xe;
-        else if constexpr (MODE == CM_LSR1) {
+        else if constexpr (MODE == CM_LSR1 || MODE == CM_LSR1R) {
           // (α*x)/γ : γ divided unconditionally (src/lsr1.jl:93)
           q[e] = fin_ab<T, CA, CB, BETA0>((al * (CA)xe) / (CA)g, be, BETA0 ? T(0) : vget<T, VEC>(rv, e));
         } else if constexpr (MODE == CM_ASR1) q[e] = vget<T, VEC>(x2v, e) - (xe / g);
@@ -222,7 +242,7 @@ combine_kernel(T *__restrict__ res, const T *__restrict__ x, const T *__restrict
             if (c < A.nfirst) q[e] = q[e] - (cc * ce);                                // lbfgs.jl:135
             else q[e] = q[e] + (cc * ce);                                             // lbfgs.jl:146
           }
-        } else if constexpr (MODE == CM_LSR1) {
+        } else if constexpr (MODE == CM_LSR1 || MODE == CM_LSR1R) {
           const CA cc = (CA)cf[u];  // (α*dot)/as evaluated in α's type by the coef kernel
 #pragma unroll
           for (int e = 0; e < VEC; ++e)
@@ -257,6 +277,18 @@ combine_kernel(T *__restrict__ res, const T *__restrict__ x, const T *__restrict
       }
     }
     // ---- epilogue
+    if constexpr (MODE == CM_LSR1R) {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        if (i * VEC + e < A.n_valid) {
+          const T xe = vget<T, VEC>(xv, e), t = vget<T, VEC>(rvk, e) - (xe / sfac);      // y - s/sf  (lsr1.jl:140)
+          racc[0] = fma((double)q[e], (double)xe, racc[0]);                              // dot(ymBs, s)   (:126)
+          racc[1] = fma((double)q[e], (double)q[e], racc[1]);                            // |ymBs|^2       (:127)
+          racc[2] = fma((double)t, (double)t, racc[2]);
+        }
+      }
+      continue;
+    }
     V out;
     if constexpr (MODE == CM_FWD || MODE == CM_INV || MODE == CM_CFWD) {
       V rv;
@@ -277,6 +309,18 @@ combine_kernel(T *__restrict__ res, const T *__restrict__ x, const T *__restrict
       }
     }
     stg<NT>(reinterpret_cast<V *>(res + i * VEC), out);
+  }
+  if constexpr (MODE == CM_LSR1R) {   // fixed order: DPP tree per wave, the four waves pairwise, one slot per workgroup
+    __shared__ double sred[kBlock / 64][3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const double w = wave_allsum(racc[c]);
+      if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6][c] = w;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3)
+      A.partials[(int64_t)threadIdx.x * kMaxRedBlocks + blockIdx.x] =
+          (sred[0][threadIdx.x] + sred[1][threadIdx.x]) + (sred[2][threadIdx.x] + sred[3][threadIdx.x]);
   }
 }
 
@@ -1168,6 +1212,10 @@ struct PanelGemmArgs {
   const double *C;  // nout x nin, row-major with row stride cstride (0: nin), as produced by the coefficient kernel
   int64_t cstride = 0;
   int accum = 0;    // start from the current contents of the outputs (input chunks of the big-memory path)
+  // push!: up to two caller vectors copied into their panel slots by the same pass (they are inputs of it anyway)
+  const T *cp_src[2] = {nullptr, nullptr};
+  T *cp_dst[2] = {nullptr, nullptr};
+  int ncp = 0;
 };
 
 // out_k[i] = sum_j C[k][j] * in_j[i].  j-outer streaming form: the nout accumulators of a lane's two rows
@@ -1218,6 +1266,8 @@ panel_gemm_kernel(PanelGemmArgs<T> A, const double *__restrict__ Ct, int64_t nve
         __builtin_nontemporal_store(o, reinterpret_cast<V *>(A.out[k] + i * 2));
       }
     }
+    for (int c = 0; c < A.ncp; ++c)   // the lines were read a moment ago as inputs: this re-read is served by the cache
+      __builtin_nontemporal_store(*reinterpret_cast<const V *>(A.cp_src[c] + i * 2), reinterpret_cast<V *>(A.cp_dst[c] + i * 2));
   }
 }
 
@@ -1487,6 +1537,7 @@ int32_t lbfgs_push_common(mxlo_qn *h, const T *s, const T *y, double ys, double 
 // and |b|^2: 4m + 2*ceil(m/10)*2 + 3 - 2 passes instead of 4m + 15.
 // Nothing of the operator's state is written before the decision (pass A's rows go to scratch), so a rejected pair
 // leaves the operator untouched exactly like the reference.
+inline int32_t push_schedule_agree(mxlo_qn *h, bool local_ok, bool *all_ok);
 template <typename T>
 int32_t lbfgs_push_fused(mxlo_qn *h, const T *s, const T *y, int32_t *accepted) {
   mxlo_ctx *ctx = h->ctx;
@@ -1568,9 +1619,13 @@ int32_t lbfgs_push(mxlo_qn *h, const T *s, const T *y, int32_t *accepted) {
   // (forward operator whose Gram matrices are stale after reference-ordered pushes: the two-kernel schedule below
   //  rebuilds them, and ONLY for an accepted pair — a rejected push! must leave every piece of state, gram_ok and
   //  the a_k coefficients included, exactly as it found it)
-  if (ctx->tune.push_fused && !h->big && h->n >= 1 && ((((uintptr_t)s) | ((uintptr_t)y)) & 15u) == 0 &&
-      !(h->kind == MXLO_QN_LBFGS_FWD && (h->push_mode == MXLO_PUSH_REFORDER || !h->gram_ok)))
-    return lbfgs_push_fused<T>(h, s, y, accepted);
+  if (ctx->tune.push_fused && !h->big &&
+      !(h->kind == MXLO_QN_LBFGS_FWD && (h->push_mode == MXLO_PUSH_REFORDER || !h->gram_ok))) {
+    // (row-sharded: an empty or differently aligned shard on ONE rank must not send the ranks down different schedules)
+    bool all_ok = false;
+    MXLO_TRY(push_schedule_agree(h, (ctx->allreduce || h->n >= 1) && ((((uintptr_t)s) | ((uintptr_t)y)) & 15u) == 0, &all_ok));
+    if (all_ok) return lbfgs_push_fused<T>(h, s, y, accepted);
+  }
   double *misc = h->dsc + h->lay.misc;
   const T *cols[2] = {s, y};
   MXLO_TRY(panel_dots<T>(ctx, cols, 2, y, h->n, misc));  // misc[0] = dot(y,s), misc[1] = dot(y,y)
@@ -1643,11 +1698,190 @@ int32_t lbfgs_push_damped(mxlo_qn *h, const T *s, T *y_mut, const T *y_const, do
   return sync_meta(h);
 }
 
+// ---- L-SR1 push!, streaming schedule -------------------------------------------------------------
+// The reference forms y - B s with an apply, takes five dots for its three tests, copies the pair in and rebuilds every
+// a_k (src/lsr1.jl:124-181). In Gram form all of that needs: the S and Y panels once (their dots with s and y are the
+// new pair's Gram rows AND, through the coefficients of the last rebuild, the a_k's of B s), the a_k panel once
+// (r = y - B s is never stored: its three sums come out of the pass that forms it), and the rebuild A = [Y S] C, which
+// reads the new pair straight from the caller's vectors and drops it into its slots on the way. (6m + 6) n elements
+// instead of (7m + 24) n; nothing of the operator's state is written before the decision.
+
+// dots[k] = a_k's from the Gram rows (gt: S's at [0, mem), Y's at [mem, 2 mem)) and the coefficients Cm of the last
+// rebuild (a_k = sum_j Cm[k][j] y_ord[j] + Cm[k][r + j] s_ord[j]); coef[k] as lsr1_coef_kernel. One wave.
+__global__ void __launch_bounds__(64)
+lsr1_bs_coef_kernel(const double *__restrict__ gt, const double *__restrict__ Cm, double *__restrict__ dots,
+                    double *__restrict__ coef, const double *__restrict__ as_, OrdArgs O, double alpha, int ct_f32) {
+  const int lane = threadIdx.x, r = O.na, w = 2 * r;
+  const double z = lane < r ? gt[O.mem + O.ord[lane]] : (lane < w ? gt[O.ord[lane - r]] : 0.0);
+  for (int k = 0; k < r; ++k) {
+    const double d = wave_allsum(lane < w ? Cm[(int64_t)k * w + lane] * z : 0.0);
+    if (lane == 0) {
+      dots[k] = d;
+      lsr1_coef_body(k, dots, coef, as_, O, alpha, ct_f32);
+    }
+  }
+}
+
+// the new pair's own Gram entries (the passes ran over the OLD panels, whose slot `ins` is about to be replaced)
+__global__ void gram_self_kernel(double *__restrict__ gt, int mem, int ins, double ss, double ys, double yy) {
+  gt[ins] = ss;
+  gt[mem + ins] = ys;
+  gt[2 * mem + ins] = ys;
+  gt[3 * mem + ins] = yy;
+}
+
+__global__ void set_scalar_kernel(double *p, double v) { *p = v; }
+
+// Every rank of a row-sharded operator must take the same push! schedule (the schedules issue different all-reduces):
+// with a hook installed the ranks first agree that ALL of them are eligible (one summed scalar).
+inline int32_t push_schedule_agree(mxlo_qn *h, bool local_ok, bool *all_ok) {
+  mxlo_ctx *ctx = h->ctx;
+  *all_ok = local_ok;
+  if (!ctx->allreduce) return MXLO_OK;
+  double *flag = h->dsc + h->lay.misc + 15;
+  hipLaunchKernelGGL(set_scalar_kernel, dim3(1), dim3(1), 0, ctx->stream, flag, local_ok ? 0.0 : 1.0);
+  MXLO_LAUNCH_CHECK();
+  MXLO_TRY(allreduce_hook(ctx, flag, 1));
+  double v = 1.0;
+  MXLO_TRY(read_scalars(h, flag, &v, 1));
+  *all_ok = v == 0.0;
+  return MXLO_OK;
+}
+
+// the three tests of src/lsr1.jl:131-149 on the reduced scalars
+template <typename T>
+bool lsr1_accepts(const mxlo_qn *h, double ys_d, double ss_d, double ymBs_s_d, double yy_d, double ymBs2_d, double t2_d) {
+  const T ys = (T)ys_d, sNorm = (T)std::sqrt(rT<T>(ss_d)), yy = (T)yy_d;
+  const T ymBs_s = (T)ymBs_s_d, ymBsNorm = (T)std::sqrt(rT<T>(ymBs2_d));
+  const T eps = eps_of<T>();
+  const bool well_defined = std::fabs((double)ymBs_s) >= (double)(eps + eps * ymBsNorm * sNorm);  // :131
+  bool sufficient_curvature = true, scaling_condition = true;
+  if (h->scaling) {
+    const T yNorm = (T)std::sqrt((double)yy);                                              // :136
+    sufficient_curvature = std::fabs((double)ys) >= (double)(eps * yNorm * sNorm);         // :137
+    if (sufficient_curvature)
+      scaling_condition = (T)std::sqrt(rT<T>(t2_d)) >= eps * yNorm * sNorm;                // :141
+  }
+  return well_defined && sufficient_curvature && scaling_condition;                        // :145-149
+}
+
+template <typename T>
+int32_t lsr1_push_fused(mxlo_qn *h, const T *s, const T *y, int32_t *accepted) {
+  mxlo_ctx *ctx = h->ctx;
+  const int64_t n = h->n, mem = h->mem, ins = h->insert0;
+  constexpr int VECP = Vec16<T>::N;
+  const int64_t npad = (n + VECP - 1) / VECP * VECP;
+  double *misc = h->dsc + h->lay.misc, *gt = h->dsc + h->lay.gtmp;
+  double *dots = h->dsc + h->lay.dots, *coef = h->dsc + h->lay.coef, *as_ = h->dsc + h->lay.as_;
+  const T *cols[kMaxCols];
+  // ---- pass 1: the OLD S and Y panels against (s, y): gt = [S's | Y's | S'y | Y'y]; misc[0] = s'y, [1] = s's, [2] = y's, [3] = y'y
+  for (int64_t c0 = 0; c0 < mem;) {
+    const int nc = (ctx->tune.push_wide && mem - c0 >= 20) ? 20 : (int)std::min<int64_t>(10, mem - c0);
+    for (int c = 0; c < nc; ++c) cols[c] = col<T>(h->S, h->ld, c0 + c);
+    MXLO_TRY(panel_push_pass<T>(ctx, cols, nc, -1, 0, s, y, n, npad, nullptr, nullptr, nullptr, 1.0, gt + c0, gt + 2 * mem + c0,
+                                c0 == 0 ? misc : nullptr, c0 == 0 ? misc + 3 : nullptr, nullptr));
+    for (int c = 0; c < nc; ++c) cols[c] = col<T>(h->Y, h->ld, c0 + c);
+    MXLO_TRY(panel_push_pass<T>(ctx, cols, nc, -1, 0, y, s, n, npad, nullptr, nullptr, nullptr, 1.0, gt + 3 * mem + c0, gt + mem + c0,
+                                c0 == 0 ? misc + 2 : nullptr, c0 == 0 ? misc + 1 : nullptr, nullptr));
+    c0 += nc;
+  }
+  MXLO_TRY(allreduce_hook(ctx, gt, 4 * mem));
+  MXLO_TRY(allreduce_hook(ctx, misc, 4));
+  // ---- pass 2: r = y - B s over the a_k panel, nothing stored; misc[8] = r's, [9] = |r|^2, [10] = |y - s/sf|^2
+  OrdArgs O;
+  fill_ord(h, O, false);
+  CombineArgs<T> A;
+  A.ncol = O.na;
+  A.nfirst = 0;
+  A.use_gamma = 1;
+  A.gamma = h->scaling_factor;
+  A.alpha = -1.0;
+  A.beta = 1.0;
+  A.coef = coef;
+  A.n_valid = n;
+  A.sfnum = misc;        // sf = ys / yy (:139); evaluated even when it will not be used, like the two-kernel schedule
+  A.sfden = misc + 3;
+  A.partials = ctx->partials;
+  if (O.na > 0) {
+    for (int i = 0; i < O.na; ++i) A.cols[i] = col<T>(h->A, h->ld, O.ord[i]);
+    hipLaunchKernelGGL(lsr1_bs_coef_kernel, dim3(1), dim3(64), 0, ctx->stream, gt, h->dsc + h->lay.Cm, dots, coef, as_, O,
+                       -1.0, sizeof(T) == 4 ? 1 : 0);
+    MXLO_LAUNCH_CHECK();
+  }
+  {
+    const int64_t nvec = (n + VECP - 1) / VECP;
+    int grid = grid_for(ctx, nvec, kBlock, ctx->tune.combine_blocks_per_cu);
+    if (grid > kMaxRedBlocks) grid = kMaxRedBlocks;
+    const bool nt = (int64_t)sizeof(T) * n * (A.ncol + 2) >= ctx->tune.nt_min_bytes;
+    if (nt)
+      hipLaunchKernelGGL((combine_kernel<T, T, T, CM_LSR1R, false, VECP, true>), dim3(grid), dim3(kBlock), 0, ctx->stream,
+                         const_cast<T *>(y), s, (const T *)nullptr, A, nvec);
+    else
+      hipLaunchKernelGGL((combine_kernel<T, T, T, CM_LSR1R, false, VECP, false>), dim3(grid), dim3(kBlock), 0, ctx->stream,
+                         const_cast<T *>(y), s, (const T *)nullptr, A, nvec);
+    MXLO_LAUNCH_CHECK();
+    MXLO_TRY(finalize_and_reduce(ctx, 3, grid, misc + 8));
+    MXLO_TRY(allreduce_hook(ctx, misc + 8, 3));
+  }
+  double hs[11];
+  MXLO_TRY(read_scalars(h, misc, hs, 11));
+  if (!lsr1_accepts<T>(h, hs[0], hs[1], hs[8], hs[3], hs[9], hs[10])) {
+    *accepted = 0;
+    return MXLO_OK;
+  }
+  *accepted = 1;
+  const T ys = (T)hs[0], yy = (T)hs[3];
+  h->ys[ins] = (double)ys;                                                                 // :153
+  h->age[ins] = ++h->pushes;
+  if (h->scaling) h->scaling_factor = (double)(ys / yy);                                   // :158
+  h->insert0 = (ins + 1) % mem;                                                            // :163
+  ++h->generation;
+  // ---- Gram rows of the new pair, coefficients of every a_k, then ONE pass A = [Y S] C (:166-181) that also drops the
+  // pair into its slots
+  hipLaunchKernelGGL(gram_self_kernel, dim3(1), dim3(1), 0, ctx->stream, gt, (int)mem, (int)ins, hs[1], hs[0], hs[3]);
+  MXLO_LAUNCH_CHECK();
+  hipLaunchKernelGGL(gram_update_kernel, dim3(1), dim3(64), 0, ctx->stream, h->dsc + h->lay.SS, h->dsc + h->lay.YSf,
+                     h->dsc + h->lay.YY, gt, (int)mem, (int)ins);
+  MXLO_LAUNCH_CHECK();
+  fill_ord(h, O, false);
+  hipLaunchKernelGGL(asr1_coef_kernel, dim3(1), dim3(64), 0, ctx->stream, h->dsc + h->lay.SS, h->dsc + h->lay.YSf,
+                     h->dsc + h->lay.Cm, as_, O);
+  MXLO_LAUNCH_CHECK();
+  T *si = col<T>(h->S, h->ld, ins), *yi = col<T>(h->Y, h->ld, ins);
+  const bool ride = n % 2 == 0;   // the rebuild reads pairs of rows: an odd n would read one element past s and y
+  if (!ride) {
+    MXLO_HIP(hipMemcpyAsync(si, s, sizeof(T) * n, hipMemcpyDeviceToDevice, ctx->stream));
+    MXLO_HIP(hipMemcpyAsync(yi, y, sizeof(T) * n, hipMemcpyDeviceToDevice, ctx->stream));
+  }
+  PanelGemmArgs<T> G;
+  G.nin = 2 * O.na;
+  G.nout = O.na;
+  G.C = h->dsc + h->lay.Cm;
+  for (int j = 0; j < O.na; ++j) {
+    const bool fresh = ride && O.ord[j] == ins;
+    G.in[j] = fresh ? y : col<T>(h->Y, h->ld, O.ord[j]);
+    G.in[O.na + j] = fresh ? s : col<T>(h->S, h->ld, O.ord[j]);
+    G.out[j] = col<T>(h->A, h->ld, O.ord[j]);
+  }
+  if (ride) {
+    G.ncp = 2;
+    G.cp_src[0] = s; G.cp_dst[0] = si;
+    G.cp_src[1] = y; G.cp_dst[1] = yi;
+  }
+  h->normA_valid = false;
+  return launch_panel_gemm<T>(ctx, G, n);
+}
+
 // push!(op::LSR1Operator, s, y) — src/lsr1.jl:119-184
 template <typename T>
 int32_t lsr1_push(mxlo_qn *h, const T *s, const T *y, int32_t *accepted) {
   mxlo_ctx *ctx = h->ctx;
   const int64_t n = h->n, mem = h->mem;
+  if (ctx->tune.push_fused && !h->big && h->push_mode == MXLO_PUSH_GRAM && h->gram_ok) {
+    bool all_ok = false;
+    MXLO_TRY(push_schedule_agree(h, (ctx->allreduce || n >= 1) && ((((uintptr_t)s) | ((uintptr_t)y)) & 15u) == 0, &all_ok));
+    if (all_ok) return lsr1_push_fused<T>(h, s, y, accepted);
+  }
   T *ymBs = (T *)h->tmp;
   MXLO_HIP(hipMemcpyAsync(ymBs, y, sizeof(T) * n, hipMemcpyDeviceToDevice, ctx->stream));  // :124
   if (h->big) MXLO_TRY(lsr1_mul_big<T>(h, ymBs, s, -1.0, 1.0, 0, 0.0));                    // :125
@@ -1670,21 +1904,11 @@ int32_t lsr1_push(mxlo_qn *h, const T *s, const T *y, int32_t *accepted) {
   }
   double hs[6] = {0, 0, 0, 0, 0, 0};
   MXLO_TRY(read_scalars(h, misc, hs, h->scaling ? 6 : 5));
-  const T ys = (T)hs[0], sNorm = (T)std::sqrt(rT<T>(hs[1])), yy = (T)hs[3];
-  const T ymBs_s = (T)hs[2], ymBsNorm = (T)std::sqrt(rT<T>(hs[4]));
-  const T eps = eps_of<T>();
-  const bool well_defined = std::fabs((double)ymBs_s) >= (double)(eps + eps * ymBsNorm * sNorm);  // :131
-  bool sufficient_curvature = true, scaling_condition = true;
-  if (h->scaling) {
-    const T yNorm = (T)std::sqrt((double)yy);                                              // :136
-    sufficient_curvature = std::fabs((double)ys) >= (double)(eps * yNorm * sNorm);         // :137
-    if (sufficient_curvature)
-      scaling_condition = (T)std::sqrt(rT<T>(hs[5])) >= eps * yNorm * sNorm;               // :141
-  }
-  if (!(well_defined && sufficient_curvature && scaling_condition)) {                      // :145-149
+  if (!lsr1_accepts<T>(h, hs[0], hs[1], hs[2], hs[3], hs[4], hs[5])) {                     // :131-149
     *accepted = 0;
     return MXLO_OK;
   }
+  const T ys = (T)hs[0], yy = (T)hs[3];
   *accepted = 1;
   const int64_t ins = h->insert0;
   MXLO_HIP(hipMemcpyAsync(col<T>(h->S, h->ld, ins), s, sizeof(T) * n, hipMemcpyDeviceToDevice, ctx->stream));

@@ -692,6 +692,79 @@ def test_one_pass_push_matches_two_kernel_schedule_and_oracle(lo, dev, dtype, ki
 
 
 @pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("mem,scaling", [(1, True), (4, True), (4, False), (10, True), (13, False), (25, True)])
+def test_lsr1_streaming_push_matches_apply_based_schedule_and_oracle(lo, dev, dtype, mem, scaling):
+    """push!(op::LSR1Operator, s, y) (src/lsr1.jl:119-184) as the streaming schedule — S and Y panels once against
+    (s, y) for the Gram rows and, through the last rebuild's coefficients, the a_k's of B s; the a_k panel once for
+    r = y - B s, never stored, with r's, |r|^2 and |y - s/sf|^2 out of the same pass; the rebuild A = [Y S] C reading the
+    pair from the caller's vectors and dropping it into its slots — against the schedule it replaced (`push_fused` = 0: an
+    apply, five dots, two inserts, dual dots, rebuild) and against the oracle. Covers: odd n (the inserts cannot ride in
+    the rebuild), a partial last vector, rejected pairs of each kind (:131 y = B s on the empty memory; with scaling :137
+    y ⟂ s and :141 y ∥ s), wrap-around, more than 10 / 20 columns, misaligned views (fall back), reset! and reuse."""
+    from linearoperators_jl_amd.device import get_ctx
+    ctx = get_ctx(dev)
+    npd = NP[dtype]
+    tol = 1e-9 if dtype == torch.float64 else QN_F32
+    same = 1e-11 if dtype == torch.float64 else 1e-4
+    try:
+        for n in ((10_006, 6_001) if mem <= 10 else (4_002,)):
+            rng = np.random.default_rng(mem * 11 + n)
+            ops = {}
+            for fused in (1, 0):
+                ctx.tune("push_fused", fused)
+                ops[fused] = lo.LSR1Operator(dtype, n, mem=mem, scaling=scaling, device=dev)
+            Oo = oracle.LSR1(n, mem=mem, scaling=scaling, dtype=npd)
+            x = rng.uniform(-1, 1, n).astype(npd)
+            prs = pairs(rng, n, mem + 4, npd)
+            s0 = prs[1][0]
+            prs.insert(0, (s0, s0.copy()))                 # empty memory, B = I: y - B s = 0 exactly, not well defined (:131)
+            prs.insert(3, (s0, (npd(3.0) * s0).astype(npd)))                     # y ∥ s: |y - s/sf| ≈ eps|y| ≪ eps|y||s| (:141)
+            if scaling:
+                yperp = np.zeros(n, npd); yperp[0], yperp[1] = s0[1], -s0[0]     # y's = O(eps): no curvature (:137)
+                prs.insert(5, (s0, yperp))
+            nacc = 0
+            for k, (s, y) in enumerate(prs):
+                want = Oo.push(s, y)
+                nacc += want
+                for fused in (1, 0):
+                    ctx.tune("push_fused", fused)
+                    if k % 5 == 4:                                                         # misaligned views: element offset 1
+                        sb, yb = torch.empty(n + 1, dtype=dtype, device=dev), torch.empty(n + 1, dtype=dtype, device=dev)
+                        sb[1:].copy_(T(s, dev)); yb[1:].copy_(T(y, dev))
+                        lo.push(ops[fused], sb[1:], yb[1:])
+                    else:
+                        lo.push(ops[fused], T(s, dev), T(y, dev))
+                    assert ops[fused]._last_push_accepted == want, (n, k, fused, want)
+                    assert ops[fused].data.insert == Oo.insert, (n, k, fused)
+                if k in (0, 1, 3, 5, mem - 1, mem, len(prs) - 1):
+                    got = {}
+                    for fused in (1, 0):
+                        res = torch.full((n,), float("nan"), dtype=dtype, device=dev)
+                        lo.mul(res, ops[fused], T(x, dev), 1.0, 0.0)
+                        got[fused] = res.cpu().numpy()
+                    ref = Oo.mul(np.empty(n, dtype=npd), x, 1.0, 0.0)
+                    assert rel(got[1], ref) <= tol and rel(got[0], ref) <= tol, (n, k, rel(got[1], ref), rel(got[0], ref))
+                    assert rel(got[1], got[0]) <= same, (n, k, rel(got[1], got[0]))
+            assert nacc >= mem + 1
+            for fused in (1, 0):
+                assert abs(ops[fused].data.scaling_factor - Oo.scaling_factor) <= 1e-6 * abs(Oo.scaling_factor)
+            d1, d0 = lo.diag(ops[1]).cpu().numpy(), lo.diag(ops[0]).cpu().numpy()
+            assert rel(d1, Oo.diag()) <= tol and rel(d1, d0) <= same
+            # the panels hold exactly the accepted pairs (the inserts rode in the rebuild) and the padding stayed zero
+            for slot in range(mem):
+                for which in ("s", "y"):
+                    assert torch.equal(ops[1].data.column(which, slot), ops[0].data.column(which, slot)), (n, which, slot)
+            lo.reset(ops[1]); Oo.reset()
+            for s, y in prs[:2]:
+                lo.push(ops[1], T(s, dev), T(y, dev)); Oo.push(s, y)
+            res = torch.empty(n, dtype=dtype, device=dev)
+            lo.mul(res, ops[1], T(x, dev), 1.0, 0.0)
+            assert rel(res.cpu().numpy(), Oo.mul(np.empty(n, dtype=npd), x, 1.0, 0.0)) <= tol
+    finally:
+        ctx.tune("push_fused", 1)
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
 def test_rejected_push_leaves_stale_gram_state_alone(lo, dev, dtype):
     """Regression (found by MXLO_QNFUZZ32_SEEDS=4010, seed 1680): after a reference-ordered push! the Gram matrices and
     the a_k coefficients are stale (`gram_ok` false) and solve_shifted_system! rebuilds BOTH on its next call. The first

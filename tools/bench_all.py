@@ -241,18 +241,22 @@ for kind, m in (("inv", 10), ("fwd", 10), ("fwd", 20), ("lsr1", 10)):
     if not sec("qn"):
         break
     op = {"inv": lo.InverseLBFGSOperator, "fwd": lo.LBFGSOperator, "lsr1": lo.LSR1Operator}[kind](torch.float64, n, mem=m, device=dev)
-    S = [rnd(n) for _ in range(2)]
+    # L-SR1 rejects a pair its memory already reproduces (y - B s = 0, src/lsr1.jl:131): distinct pairs there
+    np_ = m + 5 if kind == "lsr1" else 2
+    S = [rnd(n) for _ in range(np_)]
     Y = [(torch.rand(n, dtype=torch.float64, device=dev, generator=gen) * 1.5 + 0.5) * s for s in S]
     for i in range(m + 1):
-        lo.push(op, S[i % 2], Y[i % 2])
+        lo.push(op, S[i % np_], Y[i % np_])
     torch.cuda.synchronize()
     import time
     t0 = time.perf_counter()
+    acc = 0
     for i in range(4):
-        lo.push(op, S[i % 2], Y[i % 2])
+        lo.push(op, S[(m + 1 + i) % np_], Y[(m + 1 + i) % np_])
+        acc += int(getattr(op, "_last_push_accepted", True))
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / 4 * 1e3
-    print(f"push! {kind} m={m} n=5e7 (full memory): {ms:8.2f} ms", flush=True)
+    print(f"push! {kind} m={m} n=5e7 (full memory, {acc}/4 accepted): {ms:8.2f} ms", flush=True)
     x, out = rnd(n), torch.empty(n, dtype=torch.float64, device=dev)
     ncol = 2 * m if kind != "lsr1" else m
     row(f"mul! {kind} m={m} n=5e7", (2 * ncol + 3) * 8.0 * n, timeit(lambda: lo.mul(out, op, x, 1.0, 0.0), 5))

@@ -579,6 +579,34 @@ def bench_lbfgs(lo, torch, dev, ctx, rank, world, distributed, dist, barrier):
     out["InverseLBFGS_m10_n5e7"]["push_frac_hbm_peak(9.6GB)"] = round((2 * m + 4) * 8.0 * n / psec / 1e9 / HBM_PEAK_GBS, 4)
     del Hinv
     torch.cuda.empty_cache()
+    # L-SR1 (src/lsr1.jl): apply over the a_k panel, (2m + 3) vector passes; push! in the streaming schedule, (6m + 6)
+    # passes. L-SR1 rejects a pair its memory already reproduces, so the timed pushes use distinct pairs.
+    m = 10
+    Bs1 = lo.LSR1Operator(torch.float64, n, mem=m, scaling=True, device=dev)
+    fill(Bs1, m + 2)
+    sec = time_apply(Bs1, 20)
+    bytes_ = (2 * m + 3) * 8.0 * n
+    out["LSR1_m10_n5e7"] = {"apply_per_s": round(1.0 / sec, 2), "ms": round(sec * 1e3, 3),
+                            "frac_hbm_peak": round(bytes_ / sec / 1e9 / HBM_PEAK_GBS, 4), "n_global": n * world}
+    prs = []
+    for _ in range(4):
+        s = torch.rand(n, dtype=torch.float64, device=dev, generator=gen) * 2 - 1
+        prs.append((s, s * (torch.rand(n, dtype=torch.float64, device=dev, generator=gen) * 1.5 + 0.5)))
+    barrier()
+    t0 = time.perf_counter()
+    nacc = 0
+    for s, y in prs:
+        lo.push(Bs1, s, y)
+        nacc += int(Bs1._last_push_accepted)
+    barrier()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+    if distributed:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    psec = float(t.item()) / len(prs)
+    out["LSR1_m10_n5e7"].update({"push_ms": round(psec * 1e3, 3), "pushes_accepted": f"{nacc}/{len(prs)}",
+                                 "push_frac_hbm_peak(26.4GB)": round((6 * m + 6) * 8.0 * n / psec / 1e9 / HBM_PEAK_GBS, 4)})
+    del Bs1, prs, s, y
+    torch.cuda.empty_cache()
     m = 20
     Bf = lo.LBFGSOperator(torch.float64, n, mem=m, scaling=True, device=dev)
     fill(Bf, m + 3)

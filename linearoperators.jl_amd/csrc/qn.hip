@@ -2381,7 +2381,7 @@ MXLO_API int32_t mxlo_qn_mul_shifted(mxlo_qn *h, void *res, const void *x, doubl
 }
 
 MXLO_API int32_t mxlo_qn_push(mxlo_qn *h, const void *s, const void *y, int32_t *accepted) {
-  MXLO_REQUIRE(h && s && y && accepted, MXLO_EINVAL, "mxlo_qn_push: NULL argument");
+  MXLO_REQUIRE(h && accepted && (h->n == 0 || (s && y)), MXLO_EINVAL, "mxlo_qn_push: NULL argument");   // an empty row shard has no vectors
   MXLO_DEVICE_GUARD(h->ctx);
   if (h->kind == MXLO_QN_LSR1) {
     if (h->dtype == MXLO_F64) return lsr1_push<double>(h, (const double *)s, (const double *)y, accepted);
@@ -2395,7 +2395,7 @@ MXLO_API int32_t mxlo_qn_push(mxlo_qn *h, const void *s, const void *y, int32_t 
 
 MXLO_API int32_t mxlo_qn_push_damped_fwd(mxlo_qn *h, const void *s, const void *y, void *Bs,
                                          int32_t *accepted) {
-  MXLO_REQUIRE(h && s && y && Bs && accepted, MXLO_EINVAL, "NULL argument");
+  MXLO_REQUIRE(h && accepted && (h->n == 0 || (s && y && Bs)), MXLO_EINVAL, "NULL argument");
   MXLO_DEVICE_GUARD(h->ctx);
   MXLO_REQUIRE(h->damped, MXLO_ESTATE, "This push! should be used for damped operators");
   MXLO_REQUIRE(h->kind == MXLO_QN_LBFGS_FWD, MXLO_ESTATE,
@@ -2409,7 +2409,7 @@ MXLO_API int32_t mxlo_qn_push_damped_fwd(mxlo_qn *h, const void *s, const void *
 
 MXLO_API int32_t mxlo_qn_push_damped_inv(mxlo_qn *h, const void *s, void *y, double alpha,
                                          const void *g, void *Bs, int32_t *accepted) {
-  MXLO_REQUIRE(h && s && y && g && Bs && accepted, MXLO_EINVAL, "NULL argument");
+  MXLO_REQUIRE(h && accepted && (h->n == 0 || (s && y && g && Bs)), MXLO_EINVAL, "NULL argument");
   MXLO_DEVICE_GUARD(h->ctx);
   MXLO_REQUIRE(h->damped, MXLO_ESTATE, "This push! should be used for damped operators");
   MXLO_REQUIRE(h->kind == MXLO_QN_LBFGS_INV, MXLO_ESTATE,

@@ -158,6 +158,52 @@ def _mk(lo, ids):
     return R, sctx
 
 
+@pytest.mark.parametrize("case", ["empty-shard", "misaligned-shard"])
+def test_push_schedules_agree_across_shards(lo, dev, case):
+    """The streaming push! schedules (L-BFGS one-pass, L-SR1) and the schedules they replaced issue different sequences of
+    all-reduces, and eligibility depends on per-shard facts (16-byte alignment of s / y, a non-empty shard). The shards
+    agree on ONE schedule before the first collective: an empty shard, or one whose vectors are views at an odd element
+    offset, must neither hang the others nor change a result."""
+    R, sctx = _mk(lo, [0, 0, 0])
+    try:
+        F64 = lo._lib.F64
+        rng = np.random.default_rng(11)
+        sizes = [1000, 0, 2346] if case == "empty-shard" else [1000, 777, 2346]
+        n = sum(sizes)
+        sh = Shards(R, sctx, sizes)
+        x = rng.uniform(-1, 1, n)
+
+        def put_views(a):            # shard 1 as a view one element into a larger buffer (8-byte, not 16-byte aligned)
+            ts, keep = [], []
+            for i in range(3):
+                part = np.ascontiguousarray(a[sh.off[i]:sh.off[i + 1]])
+                if case == "misaligned-shard" and i == 1:
+                    buf = torch.empty(part.size + 1, dtype=torch.float64, device=sh.devs[i])
+                    buf[1:].copy_(torch.from_numpy(part))
+                    keep.append(buf)
+                    ts.append(buf[1:])
+                    assert ts[-1].data_ptr() % 16 == 8
+                else:
+                    ts.append(torch.from_numpy(part).to(sh.devs[i]))
+            return ts, keep
+
+        for kind, mem, okind in ((lo._lib.QN_LBFGS_INV, 4, "inv"), (lo._lib.QN_LBFGS_FWD, 4, "fwd"), (lo._lib.QN_LSR1, 4, "lsr1")):
+            q = C.c_void_p()
+            assert R.mxlo_qn_create_sharded(sctx, kind, F64, sh.nloc, mem, 1, 0, 0.99, 10.0, C.byref(q)) == 0, R.mxlo_shard_last_error()
+            Bo = oracle.LSR1(n, mem=mem, scaling=True) if okind == "lsr1" else oracle.LBFGS(n, mem=mem, scaling=True, inverse=(okind == "inv"))
+            acc = C.c_int32(-1)
+            for k, (s_, y_) in enumerate(pairs(rng, n, mem + 2)):
+                (ss, k1), (ys, k2) = put_views(s_), put_views(y_)
+                assert R.mxlo_qn_push_sharded(q, sh.ptrs(ss), sh.ptrs(ys), C.byref(acc)) == 0, R.mxlo_shard_last_error()
+                assert bool(acc.value) == bool(Bo.push(s_, y_)), (okind, k)
+            xs, rs = sh.put(x), sh.put(np.zeros(n))
+            assert R.mxlo_qn_mul_sharded(q, sh.ptrs(rs), sh.ptrs(xs), 1.0, 0.0, 0) == 0, R.mxlo_shard_last_error()
+            assert rel(sh.get(rs), Bo.mul(np.empty(n), x, 1.0, 0.0)) <= 1e-9, (case, okind)
+            assert R.mxlo_qn_destroy_sharded(q) == 0
+    finally:
+        assert R.mxlo_shard_ctx_destroy(sctx) == 0
+
+
 def test_per_shard_arguments_are_checked_before_any_worker_starts(lo, dev):
     """a bad argument on ONE shard must not leave the others waiting in their collective. NULL / negative
     per-shard arguments are rejected on the calling thread, and the shard ctx stays usable afterwards."""

@@ -204,6 +204,14 @@ void sweep(int n, rocblas_handle rb) {
     VQ(false, 128, 64, 4, 2, 32, 3)
     VQ(true, 64, 64, 4, 2, 32, 3)
     VQ(false, 32, 32, 1, 1, 32, 4)
+    VQ(false, 64, 64, 4, 2, 48, 3)
+    VQ(false, 64, 64, 2, 4, 48, 3)
+    VQ(false, 64, 64, 4, 2, 16, 4)
+    VQ(false, 64, 32, 2, 2, 32, 3)
+    VQ(false, 64, 32, 2, 2, 64, 3)
+    VQ(false, 32, 64, 2, 2, 32, 3)
+    VQ(false, 32, 64, 2, 2, 64, 3)
+    VQ(true, 64, 64, 4, 2, 48, 3)
     V(false, 64, 64, 2, 2, 32, 3)
     V(false, 64, 64, 2, 2, 32, 4)
     V(false, 64, 64, 2, 2, 16, 4)
@@ -235,6 +243,10 @@ void sweep(int n, rocblas_handle rb) {
     VQ(false, 128, 128, 4, 4, 32, 3)
     VQ(false, 32, 32, 2, 2, 64, 4)
     VQ(true, 64, 64, 4, 2, 64, 3)
+    VQ(false, 64, 64, 4, 2, 96, 3)
+    VQ(false, 64, 64, 2, 4, 64, 3)
+    VQ(false, 64, 64, 2, 4, 96, 3)
+    VQ(true, 64, 64, 4, 2, 96, 3)
     V(false, 64, 64, 2, 2, 32, 3)
     V(false, 64, 64, 2, 2, 64, 3)
     V(false, 64, 64, 4, 2, 64, 3)

@@ -296,6 +296,6 @@ int32_t panel_dots2(mxlo_ctx *ctx, const T *const *cols, int ncols, const T *x1,
 template <typename T>
 int32_t panel_push_pass(mxlo_ctx *ctx, const T *const *cols, int ncols, int slot, int slot_src, const T *x1,
                         const T *x2, int64_t n, int64_t n_padded, T *st1, T *st2, T *stb, double sq, double *out1,
-                        double *out2, double *out_x1x2, double *out_x2x2, double *out_bb);
+                        double *out2, double *out_x1x2, double *out_x2x2, double *out_bb, double *out_x1x1 = nullptr);
 
 }  // namespace mxlo

@@ -1774,19 +1774,30 @@ int32_t lsr1_push_fused(mxlo_qn *h, const T *s, const T *y, int32_t *accepted) {
   double *misc = h->dsc + h->lay.misc, *gt = h->dsc + h->lay.gtmp;
   double *dots = h->dsc + h->lay.dots, *coef = h->dsc + h->lay.coef, *as_ = h->dsc + h->lay.as_;
   const T *cols[kMaxCols];
-  // ---- pass 1: the OLD S and Y panels against (s, y): gt = [S's | Y's | S'y | Y'y]; misc[0] = s'y, [1] = s's, [2] = y's, [3] = y'y
-  for (int64_t c0 = 0; c0 < mem;) {
-    const int nc = (ctx->tune.push_wide && mem - c0 >= 20) ? 20 : (int)std::min<int64_t>(10, mem - c0);
-    for (int c = 0; c < nc; ++c) cols[c] = col<T>(h->S, h->ld, c0 + c);
-    MXLO_TRY(panel_push_pass<T>(ctx, cols, nc, -1, 0, s, y, n, npad, nullptr, nullptr, nullptr, 1.0, gt + c0, gt + 2 * mem + c0,
-                                c0 == 0 ? misc : nullptr, c0 == 0 ? misc + 3 : nullptr, nullptr));
-    for (int c = 0; c < nc; ++c) cols[c] = col<T>(h->Y, h->ld, c0 + c);
-    MXLO_TRY(panel_push_pass<T>(ctx, cols, nc, -1, 0, y, s, n, npad, nullptr, nullptr, nullptr, 1.0, gt + 3 * mem + c0, gt + mem + c0,
-                                c0 == 0 ? misc + 2 : nullptr, c0 == 0 ? misc + 1 : nullptr, nullptr));
-    c0 += nc;
+  // ---- pass 1: the OLD S and Y panels against (s, y): gt = [S's | Y's | S'y | Y'y]; misc[0] = s'y, [1] = s's, [2] = y'y.
+  // One launch when both panels fit one pass (2 mem <= 10, or = 20), else one launch per panel chunk.
+  const int both = (int)(2 * mem);
+  if (both <= 10 || both == 20) {
+    for (int c = 0; c < mem; ++c) {
+      cols[c] = col<T>(h->S, h->ld, c);
+      cols[mem + c] = col<T>(h->Y, h->ld, c);
+    }
+    MXLO_TRY(panel_push_pass<T>(ctx, cols, both, -1, 0, s, y, n, npad, nullptr, nullptr, nullptr, 1.0, gt, gt + 2 * mem, misc,
+                                misc + 2, nullptr, misc + 1));
+  } else {
+    for (int64_t c0 = 0; c0 < mem;) {
+      const int nc = (ctx->tune.push_wide && mem - c0 >= 20) ? 20 : (int)std::min<int64_t>(10, mem - c0);
+      for (int c = 0; c < nc; ++c) cols[c] = col<T>(h->S, h->ld, c0 + c);
+      MXLO_TRY(panel_push_pass<T>(ctx, cols, nc, -1, 0, s, y, n, npad, nullptr, nullptr, nullptr, 1.0, gt + c0, gt + 2 * mem + c0,
+                                  c0 == 0 ? misc : nullptr, c0 == 0 ? misc + 2 : nullptr, nullptr, c0 == 0 ? misc + 1 : nullptr));
+      for (int c = 0; c < nc; ++c) cols[c] = col<T>(h->Y, h->ld, c0 + c);
+      MXLO_TRY(panel_push_pass<T>(ctx, cols, nc, -1, 0, s, y, n, npad, nullptr, nullptr, nullptr, 1.0, gt + mem + c0, gt + 3 * mem + c0,
+                                  nullptr, nullptr, nullptr));
+      c0 += nc;
+    }
   }
   MXLO_TRY(allreduce_hook(ctx, gt, 4 * mem));
-  MXLO_TRY(allreduce_hook(ctx, misc, 4));
+  MXLO_TRY(allreduce_hook(ctx, misc, 3));
   // ---- pass 2: r = y - B s over the a_k panel, nothing stored; misc[8] = r's, [9] = |r|^2, [10] = |y - s/sf|^2
   OrdArgs O;
   fill_ord(h, O, false);
@@ -1800,7 +1811,7 @@ int32_t lsr1_push_fused(mxlo_qn *h, const T *s, const T *y, int32_t *accepted) {
   A.coef = coef;
   A.n_valid = n;
   A.sfnum = misc;        // sf = ys / yy (:139); evaluated even when it will not be used, like the two-kernel schedule
-  A.sfden = misc + 3;
+  A.sfden = misc + 2;
   A.partials = ctx->partials;
   if (O.na > 0) {
     for (int i = 0; i < O.na; ++i) A.cols[i] = col<T>(h->A, h->ld, O.ord[i]);
@@ -1825,12 +1836,12 @@ int32_t lsr1_push_fused(mxlo_qn *h, const T *s, const T *y, int32_t *accepted) {
   }
   double hs[11];
   MXLO_TRY(read_scalars(h, misc, hs, 11));
-  if (!lsr1_accepts<T>(h, hs[0], hs[1], hs[8], hs[3], hs[9], hs[10])) {
+  if (!lsr1_accepts<T>(h, hs[0], hs[1], hs[8], hs[2], hs[9], hs[10])) {
     *accepted = 0;
     return MXLO_OK;
   }
   *accepted = 1;
-  const T ys = (T)hs[0], yy = (T)hs[3];
+  const T ys = (T)hs[0], yy = (T)hs[2];
   h->ys[ins] = (double)ys;                                                                 // :153
   h->age[ins] = ++h->pushes;
   if (h->scaling) h->scaling_factor = (double)(ys / yy);                                   // :158
@@ -1838,7 +1849,7 @@ int32_t lsr1_push_fused(mxlo_qn *h, const T *s, const T *y, int32_t *accepted) {
   ++h->generation;
   // ---- Gram rows of the new pair, coefficients of every a_k, then ONE pass A = [Y S] C (:166-181) that also drops the
   // pair into its slots
-  hipLaunchKernelGGL(gram_self_kernel, dim3(1), dim3(1), 0, ctx->stream, gt, (int)mem, (int)ins, hs[1], hs[0], hs[3]);
+  hipLaunchKernelGGL(gram_self_kernel, dim3(1), dim3(1), 0, ctx->stream, gt, (int)mem, (int)ins, hs[1], hs[0], hs[2]);
   MXLO_LAUNCH_CHECK();
   hipLaunchKernelGGL(gram_update_kernel, dim3(1), dim3(64), 0, ctx->stream, h->dsc + h->lay.SS, h->dsc + h->lay.YSf,
                      h->dsc + h->lay.YY, gt, (int)mem, (int)ins);

@@ -446,7 +446,7 @@ push_pass_kernel(PushPassArgs<T, NC> A, double *__restrict__ partials) {
   constexpr int VEC = Vec16<T>::N;
   using V = typename Vec16<T>::type;
   const int tid = threadIdx.x;
-  double a1[NC], a2[NC], e12 = 0.0, e22 = 0.0, ebb = 0.0;
+  double a1[NC], a2[NC], e12 = 0.0, e22 = 0.0, ebb = 0.0, e11 = 0.0;
 #pragma unroll
   for (int c = 0; c < NC; ++c) a1[c] = a2[c] = 0.0;
   auto ld = [&](const T *p, int64_t i) -> V {
@@ -496,6 +496,7 @@ push_pass_kernel(PushPassArgs<T, NC> A, double *__restrict__ partials) {
       for (int e = 0; e < VEC; ++e) {
         e12 = fma((double)xv1[u][e], (double)xv2[u][e], e12);
         e22 = fma((double)xv2[u][e], (double)xv2[u][e], e22);
+        e11 = fma((double)xv1[u][e], (double)xv1[u][e], e11);
       }
       if constexpr (STORE) {
         if (A.st1) __builtin_nontemporal_store(xv1[u], reinterpret_cast<V *>(A.st1) + i);
@@ -512,7 +513,7 @@ push_pass_kernel(PushPassArgs<T, NC> A, double *__restrict__ partials) {
       }
     }
   }
-  constexpr int NP = 2 * NC + 3;
+  constexpr int NP = 2 * NC + 4;
   __shared__ double lds[kBlock / kWave][NP];
   const int wave = tid >> 6, lane = tid & 63;
 #pragma unroll
@@ -524,11 +525,12 @@ push_pass_kernel(PushPassArgs<T, NC> A, double *__restrict__ partials) {
     }
   }
   {
-    const double s12 = wave_sum(e12), s22 = wave_sum(e22), sbb = wave_sum(ebb);
+    const double s12 = wave_sum(e12), s22 = wave_sum(e22), sbb = wave_sum(ebb), s11 = wave_sum(e11);
     if (lane == 0) {
       lds[wave][2 * NC] = s12;
       lds[wave][2 * NC + 1] = s22;
       lds[wave][2 * NC + 2] = sbb;
+      lds[wave][2 * NC + 3] = s11;
     }
   }
   __syncthreads();
@@ -539,7 +541,7 @@ push_pass_kernel(PushPassArgs<T, NC> A, double *__restrict__ partials) {
 // one workgroup per partial column, destination per column from a table (NULL: result not wanted)
 constexpr int kPushMaxNC = 20;
 struct FinalizeMap {
-  double *dst[2 * kPushMaxNC + 3];
+  double *dst[2 * kPushMaxNC + 4];
 };
 __global__ void __launch_bounds__(kBlock)
 finalize_map_kernel(const double *__restrict__ partials, int nblocks, FinalizeMap M) {
@@ -557,12 +559,12 @@ finalize_map_kernel(const double *__restrict__ partials, int nblocks, FinalizeMa
 }
 
 // One pass over `ncols` (1..10, or exactly 20) padded panel columns. out1[c] = dot(col_c, x1), out2[c] = dot(col_c, x2) with column
-// `slot` standing for x1 (slot_src 1) or x2 (2); out_x1x2 / out_x2x2 / out_bb (each may be NULL) receive x1·x2, x2·x2
-// and |x2 ./ sq|^2. The caller runs the all-reduce hook on whatever it keeps (results are LOCAL sums here).
+// `slot` standing for x1 (slot_src 1) or x2 (2); out_x1x2 / out_x2x2 / out_bb / out_x1x1 (each may be NULL) receive
+// x1·x2, x2·x2, |x2 ./ sq|^2 and x1·x1. The caller runs the all-reduce hook on whatever it keeps (results are LOCAL sums here).
 template <typename T>
 int32_t panel_push_pass(mxlo_ctx *ctx, const T *const *cols, int ncols, int slot, int slot_src, const T *x1,
                         const T *x2, int64_t n, int64_t n_padded, T *st1, T *st2, T *stb, double sq, double *out1,
-                        double *out2, double *out_x1x2, double *out_x2x2, double *out_bb) {
+                        double *out2, double *out_x1x2, double *out_x2x2, double *out_bb, double *out_x1x1) {
   constexpr int VEC = Vec16<T>::N;
   MXLO_REQUIRE(((ncols >= 1 && ncols <= 10) || ncols == kPushMaxNC) && n_padded % VEC == 0 && n <= n_padded &&
                    n > n_padded - VEC, MXLO_EINVAL, "panel_push_pass: bad arguments");
@@ -588,7 +590,7 @@ int32_t panel_push_pass(mxlo_ctx *ctx, const T *const *cols, int ncols, int slot
     if (nt) { if (store) launch.template operator()<true, true>(); else launch.template operator()<true, false>(); }
     else { if (store) launch.template operator()<false, true>(); else launch.template operator()<false, false>(); }
     FinalizeMap M;
-    for (int c = 0; c < 2 * kPushMaxNC + 3; ++c) M.dst[c] = nullptr;
+    for (int c = 0; c < 2 * kPushMaxNC + 4; ++c) M.dst[c] = nullptr;
     for (int c = 0; c < NC; ++c) {
       M.dst[c] = out1 ? out1 + c : nullptr;
       M.dst[NC + c] = out2 ? out2 + c : nullptr;
@@ -596,7 +598,8 @@ int32_t panel_push_pass(mxlo_ctx *ctx, const T *const *cols, int ncols, int slot
     M.dst[2 * NC] = out_x1x2;
     M.dst[2 * NC + 1] = out_x2x2;
     M.dst[2 * NC + 2] = out_bb;
-    hipLaunchKernelGGL(finalize_map_kernel, dim3(2 * NC + 3), dim3(kBlock), 0, ctx->stream, ctx->partials, grid, M);
+    M.dst[2 * NC + 3] = out_x1x1;
+    hipLaunchKernelGGL(finalize_map_kernel, dim3(2 * NC + 4), dim3(kBlock), 0, ctx->stream, ctx->partials, grid, M);
   };
   switch (ncols) {
     case 1: go.template operator()<1>(); break;
@@ -617,10 +620,10 @@ int32_t panel_push_pass(mxlo_ctx *ctx, const T *const *cols, int ncols, int slot
 
 template int32_t panel_push_pass<double>(mxlo_ctx *, const double *const *, int, int, int, const double *, const double *,
                                          int64_t, int64_t, double *, double *, double *, double, double *, double *,
-                                         double *, double *, double *);
+                                         double *, double *, double *, double *);
 template int32_t panel_push_pass<float>(mxlo_ctx *, const float *const *, int, int, int, const float *, const float *,
                                         int64_t, int64_t, float *, float *, float *, double, double *, double *, double *,
-                                        double *, double *);
+                                        double *, double *, double *);
 
 template int32_t panel_dots2<double>(mxlo_ctx *, const double *const *, int, const double *, const double *, int64_t,
                                      double *, double *);

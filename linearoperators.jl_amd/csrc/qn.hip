@@ -1798,7 +1798,7 @@ int32_t lsr1_push_fused(mxlo_qn *h, const T *s, const T *y, int32_t *accepted) {
   }
   MXLO_TRY(allreduce_hook(ctx, gt, 4 * mem));
   MXLO_TRY(allreduce_hook(ctx, misc, 3));
-  // ---- pass 2: r = y - B s over the a_k panel, nothing stored; misc[8] = r's, [9] = |r|^2, [10] = |y - s/sf|^2
+  // ---- pass 2: r = y - B s over the a_k panel, nothing stored; misc[3] = r's, [4] = |r|^2, [5] = |y - s/sf|^2
   OrdArgs O;
   fill_ord(h, O, false);
   CombineArgs<T> A;
@@ -1831,12 +1831,12 @@ int32_t lsr1_push_fused(mxlo_qn *h, const T *s, const T *y, int32_t *accepted) {
       hipLaunchKernelGGL((combine_kernel<T, T, T, CM_LSR1R, false, VECP, false>), dim3(grid), dim3(kBlock), 0, ctx->stream,
                          const_cast<T *>(y), s, (const T *)nullptr, A, nvec);
     MXLO_LAUNCH_CHECK();
-    MXLO_TRY(finalize_and_reduce(ctx, 3, grid, misc + 8));
-    MXLO_TRY(allreduce_hook(ctx, misc + 8, 3));
+    MXLO_TRY(finalize_and_reduce(ctx, 3, grid, misc + 3));
+    MXLO_TRY(allreduce_hook(ctx, misc + 3, 3));
   }
-  double hs[11];
-  MXLO_TRY(read_scalars(h, misc, hs, 11));
-  if (!lsr1_accepts<T>(h, hs[0], hs[1], hs[8], hs[2], hs[9], hs[10])) {
+  double hs[6];
+  MXLO_TRY(read_scalars(h, misc, hs, 6));   // the push's one device-to-host copy (48 bytes)
+  if (!lsr1_accepts<T>(h, hs[0], hs[1], hs[3], hs[2], hs[4], hs[5])) {
     *accepted = 0;
     return MXLO_OK;
   }

@@ -132,25 +132,27 @@ int32_t gemm(mxlo_ctx *ctx, T *C, int64_t ldc, const T *A, int64_t lda, bool ta,
         else if (tiles(64, 64) * 5 >= (int64_t)ctx->num_cu * 3) tile = 64;   // >= 0.6 workgroups per CU
         else tile = 32;
       }
-#define GLDS(AK_, TM_, TN_, WM_, WN_, BK_, NST_, PAIR_)                                                           \
+#define GLDS(AK_, TM_, TN_, WM_, WN_, BK_, NST_, PAIR_, PFD_)                                                     \
   {                                                                                                               \
     GlShape S{(int)M, (int)N, (int)K, (int)((M + TM_ - 1) / TM_), (int)((N + TN_ - 1) / TN_)};                    \
-    hipLaunchKernelGGL((gemm_glds_kernel<T, CA, CB, B0, AK_, TM_, TN_, WM_, WN_, BK_, NST_, true, true, PAIR_>),  \
+    hipLaunchKernelGGL((gemm_glds_kernel<T, CA, CB, B0, AK_, TM_, TN_, WM_, WN_, BK_, NST_, true, true, PAIR_, PFD_>), \
                        dim3(S.gx * S.gy), dim3(WM_ * WN_ * 64), 0, ctx->stream, C, ldc, A, lda, B, ldb, S,        \
                        (CA)alpha, (CB)beta);                                                                      \
   }
-#define GLDS_BY_A(TM_, TN_, WM_, WN_, BK_, NST_, PAIR_)                                                           \
-  if (ta) GLDS(true, TM_, TN_, WM_, WN_, BK_, NST_, PAIR_) else GLDS(false, TM_, TN_, WM_, WN_, BK_, NST_, PAIR_)
+#define GLDS_BY_A(TM_, TN_, WM_, WN_, BK_, NST_, PAIR_, PFD_)                                                     \
+  if (ta) GLDS(true, TM_, TN_, WM_, WN_, BK_, NST_, PAIR_, PFD_) else GLDS(false, TM_, TN_, WM_, WN_, BK_, NST_, PAIR_, PFD_)
       // PAIR (gemm_glds.h): tile pairs interleaved so that two fragments arrive with one 16-byte LDS read. Measured
       // (profiles/r03_tune_gemm_pair.txt): 64-tiles -2.0 % (f64) / -2.7 % (f32), f64 128-tiles -0.6 %, f32 128-tiles +0.4 %.
+      // PFD 2 (fragments read two k-steps ahead): the 32-tile workgroup has ONE wave per SIMD, nothing else hides its LDS
+      // latency: -0.5 ... -3 % there, +1 % on the 64-tiles (two waves per SIMD) — profiles/r03_tune_gemm_bk.txt
       if constexpr (sizeof(T) == 8) {
-        if (tile == 128) GLDS_BY_A(128, 128, 4, 4, 16, 3, true)
-        else if (tile == 64) GLDS_BY_A(64, 64, 4, 2, 32, 3, true)
-        else GLDS_BY_A(32, 32, 2, 2, 32, 4, false)
+        if (tile == 128) GLDS_BY_A(128, 128, 4, 4, 16, 3, true, 1)
+        else if (tile == 64) GLDS_BY_A(64, 64, 4, 2, 32, 3, true, 1)
+        else GLDS_BY_A(32, 32, 2, 2, 32, 4, false, 2)
       } else {
-        if (tile == 128) GLDS_BY_A(128, 128, 4, 4, 32, 3, false)
-        else if (tile == 64) GLDS_BY_A(64, 64, 4, 2, 64, 3, true)
-        else GLDS_BY_A(32, 32, 2, 2, 64, 4, false)
+        if (tile == 128) GLDS_BY_A(128, 128, 4, 4, 32, 3, false, 1)
+        else if (tile == 64) GLDS_BY_A(64, 64, 4, 2, 64, 3, true, 1)
+        else GLDS_BY_A(32, 32, 2, 2, 64, 4, false, 2)
       }
 #undef GLDS_BY_A
 #undef GLDS

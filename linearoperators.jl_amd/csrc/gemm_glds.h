@@ -74,7 +74,7 @@ __device__ __forceinline__ void gl_tile_of(int id, int gx, int gy, int &tx, int 
 // the same bytes. The C tile is un-permuted in the epilogue. (A K-contiguous A image has no adjacent rows: A stays
 // unpaired there.)
 template <typename T, typename CA, typename CB, bool BETA0, bool AK, int TM, int TN, int WM, int WN, int BK, int NST,
-          bool SPREAD = true, bool PIN = true, bool PAIR = false>
+          bool SPREAD = true, bool PIN = true, bool PAIR = false, int PFD = 1>
 __global__ void __launch_bounds__(WM * WN * 64)
 gemm_glds_kernel(T *__restrict__ C, int64_t ldc, const T *__restrict__ A, int64_t lda,
                  const T *__restrict__ B, int64_t ldb, GlShape S, CA alpha, CB beta) {
@@ -273,7 +273,11 @@ gemm_glds_kernel(T *__restrict__ C, int64_t ldc, const T *__restrict__ A, int64_
     else gl_wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
   }
-  T av[2][MT], bv[2][NT];
+  // PFD: how many k-steps ahead a step's fragments are read from LDS (ring of 2*PFD register buffers). One step hides
+  // the LDS latency behind the other wave of the SIMD; a workgroup with ONE wave per SIMD (32x32 tiles) needs two.
+  constexpr int NFB = 2 * PFD;
+  static_assert((PFD == 1 || PFD == 2) && KS % NFB == 0, "fragment ring must divide the steps of a slab");
+  T av[NFB][MT], bv[NFB][NT];
   int stage = 0;
   // one full slab. MORE: a slab it+1 exists; NEXTF: it is a full slab (cross-slab fragment prefetch);
   // REFILL: slab it+NST-1 exists (1: a full slab, 2: the K tail, clamped addressing); AHEAD2: slab it+2 exists and was issued earlier (NST == 4 only: it may stay in flight)
@@ -285,13 +289,13 @@ gemm_glds_kernel(T *__restrict__ C, int64_t ldc, const T *__restrict__ A, int64_
     const int k0n = (it + NST - 1) * BK;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-      if (ks + 1 < KS) frag(st, ks + 1, av[(ks + 1) & 1], bv[(ks + 1) & 1]);
-      else if constexpr (NEXTF) frag(stn, 0, av[0], bv[0]);
+      if (ks + PFD < KS) frag(st, ks + PFD, av[(ks + PFD) % NFB], bv[(ks + PFD) % NFB]);
+      else if constexpr (NEXTF) frag(stn, ks + PFD - KS, av[(ks + PFD) % NFB], bv[(ks + PFD) % NFB]);
       if constexpr (PIN) __builtin_amdgcn_sched_barrier(0);   // reads first: left alone, hipcc sinks them behind the MFMAs
 #pragma unroll
       for (int a = 0; a < MT; ++a)
 #pragma unroll
-        for (int b = 0; b < NT; ++b) acc[a][b] = GlMfma<T>::run(av[ks & 1][a], bv[ks & 1][b], acc[a][b]);
+        for (int b = 0; b < NT; ++b) acc[a][b] = GlMfma<T>::run(av[ks % NFB][a], bv[ks % NFB][b], acc[a][b]);
       if (ks == KS / 2 - 1) {
         if constexpr (MORE) {
           if constexpr (NST == 4 && AHEAD2) gl_wait_vmcnt<PW>();
@@ -311,7 +315,10 @@ gemm_glds_kernel(T *__restrict__ C, int64_t ldc, const T *__restrict__ A, int64_
     }
     stage = nst;
   };
-  if (nfull > 0) frag(lds, 0, av[0], bv[0]);
+  if (nfull > 0) {
+#pragma unroll
+    for (int p = 0; p < PFD; ++p) frag(lds, p, av[p], bv[p]);
+  }
   int it = 0;
   for (; it + NST - 1 < nfull; ++it) slab.template operator()<true, true, 1, true>(it);   // steady state
   for (; it < nfull; ++it) {                                                             // last slabs

@@ -118,7 +118,9 @@ inline bool mxlo_trace_on() {
 struct Tune {
   int blocks_per_cu = 0;   // streaming kernels: 0 = one chunk per workgroup; k = persistent grid CUs*k
   int extend_tiles_per_block = 0;     // sorted extension: consecutive output tiles per workgroup (0 = auto)
-  int64_t nt_min_bytes = 32ll << 20;  // streamed footprint from which nontemporal accesses are used
+  int64_t nt_min_bytes = 256ll << 20;  // streamed footprint from which nontemporal accesses are used: the size of the
+                                       // Infinity Cache — below it the second pass of a two-pass apply finds the first
+                                       // pass's lines there (profiles/r03_sweep_nt_mid.txt: -5 ... -8 % at n = 2^21 .. 2^23)
   int red_blocks_per_cu = 4;  // reduction kernels
   int graph_direct_max = 16; // captured chains of at most this many kernel/memset nodes replay as direct launches
   int house_fused = 1;     // single-launch Householder (dot, grid exchange, update) while the vectors fit one wave of workgroups

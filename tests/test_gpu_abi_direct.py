@@ -115,7 +115,7 @@ def test_tune_keys(lo, dev):
                 ref = oracle.householder_mul(np.empty(n), d / np.linalg.norm(d), v, 1.0, 0.0)
                 assert np.linalg.norm(hv.cpu().numpy() - ref) <= 1e-12 * np.linalg.norm(ref)
     finally:
-        for key, val in (("blocks_per_cu", 0), ("nt_min_bytes", 32 << 20), ("red_blocks_per_cu", 4), ("house_reverse", 1),
+        for key, val in (("blocks_per_cu", 0), ("nt_min_bytes", 256 << 20), ("red_blocks_per_cu", 4), ("house_reverse", 1),
                          ("gemm_tile", 0), ("combine_blocks_per_cu", 0), ("dots_max_nc", 20), ("house_fused", 1),
                          ("extend_tiles_per_block", 0)):
             ctx.tune(key, val)

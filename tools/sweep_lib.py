@@ -59,7 +59,7 @@ for nt in (0, 1 << 62):
                     ms_h = timeit(lambda: lo.mul(res, H, v, 1.0, 0.0))
                     row += f" | rev={rev}: upd {24*n/ms_u/1e6:7.0f} house {40*n/ms_h/1e6:7.0f} ({ms_h:.4f} ms)"
             print(row, flush=True)
-ctx.tune("nt_min_bytes", 32 << 20); ctx.tune("blocks_per_cu", 0); ctx.tune("red_blocks_per_cu", 4); ctx.tune("house_reverse", 1)
+ctx.tune("nt_min_bytes", 256 << 20); ctx.tune("blocks_per_cu", 0); ctx.tune("red_blocks_per_cu", 4); ctx.tune("house_reverse", 1)
 del H, D, h, v, res
 torch.cuda.empty_cache()
 

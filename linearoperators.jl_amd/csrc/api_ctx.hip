@@ -318,6 +318,9 @@ MXLO_API int32_t mxlo_ctx_tune(mxlo_ctx *ctx, const char *key, int64_t value) {
     ctx->tune.house_fused = value != 0;
   } else if (!strcmp(key, "cherm_two_pass")) {
     ctx->tune.cherm_two_pass = value != 0;
+  } else if (!strcmp(key, "house_inline_n")) {
+    MXLO_REQUIRE(value >= 0, MXLO_EINVAL, "house_inline_n out of range");
+    ctx->tune.house_inline_n = value;
   } else if (!strcmp(key, "house_reverse")) {
     ctx->tune.house_reverse = value != 0;
   } else if (!strcmp(key, "lbfgs_inv_mode")) {

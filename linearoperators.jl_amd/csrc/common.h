@@ -126,6 +126,9 @@ struct Tune {
   int house_fused = 1;     // single-launch Householder (dot, grid exchange, update) while the vectors fit one wave of workgroups
   int cherm_two_pass = 0;  // complex opHermitian: 1 = the two-pass (rows, then columns) form instead of the strip kernel
   int house_reverse = 1;   // Householder phase B walks the vectors back-to-front (MALL tail reuse)
+  int64_t house_inline_n = 1ll << 23;   // two-pass Householder up to this n: the update pass sums the dots pass's partials
+                                        // itself (no finalize launch); above, one finalize launch is cheaper than every
+                                        // update workgroup re-reading the partials
   int lbfgs_inv_mode = MXLO_INV_TWOPASS;
   int dots_max_nc = 20;    // columns per panel_dots launch (<= 20)
   int gemm_tile = 0;       // kron GEMM tile edge: 0 = auto (largest of 128/64/32 that still gives every CU a
@@ -289,6 +292,9 @@ int32_t allreduce_hook(mxlo_ctx *ctx, double *dev, int64_t count);
 template <typename T>
 int32_t panel_dots(mxlo_ctx *ctx, const T *const *cols_host, int ncols, const T *x, int64_t n,
                    double *out_dev);
+// the dots pass alone: per-workgroup partials left in ctx->partials, *nblocks per column (<= 4 columns, n >= 1)
+template <typename T>
+int32_t panel_dots_partials(mxlo_ctx *ctx, const T *const *cols_host, int ncols, const T *x, int64_t n, int *nblocks);
 // out1[c] = dot(cols[c], x1), out2[c] = dot(cols[c], x2) in one pass; all operands are aligned, padded panel columns
 template <typename T>
 int32_t panel_dots2(mxlo_ctx *ctx, const T *const *cols, int ncols, const T *x1, const T *x2, int64_t n_padded,

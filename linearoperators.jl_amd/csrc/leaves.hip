@@ -364,8 +364,19 @@ static int32_t householder_t(mxlo_ctx *ctx, T *res, const T *h, const T *v, int6
     const int vpt = fused_grid<T>(n, 2) <= 16 ? 2 : (fused_grid<T>(n, 4) <= 32 ? 4 : 8);
     if (fused_grid<T>(n, vpt) <= cap) return householder_fused_t<T>(ctx, res, h, v, n, alpha, beta, flags, vpt);
   }
-  double *dot = ctx->scalars;  // slot 0
   const T *cols[1] = {h};
+  if (!ctx->allreduce && n >= 1 && n <= ctx->tune.house_inline_n) {
+    // mid sizes: dots pass, then the update pass adds the partial sums up itself — two launches instead of three
+    int nb = 0;
+    MXLO_TRY(panel_dots_partials<T>(ctx, cols, 1, v, n, &nb));
+    const bool rev = ctx->tune.house_reverse != 0;
+    return dispatch_ab<T>(beta, flags, [&]<typename CA, typename CB, bool B0>() -> int32_t {
+      HouseholderPartialsOp<T, CA, CB, B0> op{(CA)alpha, (CB)beta, ctx->partials, nb, T(0)};
+      if (rev) return launch_map<T, 2, !B0, true>(ctx, res, h, v, n, op);
+      return launch_map<T, 2, !B0, false>(ctx, res, h, v, n, op);
+    });
+  }
+  double *dot = ctx->scalars;  // slot 0
   MXLO_TRY(panel_dots<T>(ctx, cols, 1, v, n, dot));  // phase A (+ all-reduce hook)
   return householder_apply_t<T>(ctx, res, h, v, n, alpha, beta, flags, dot);  // phase B
 }

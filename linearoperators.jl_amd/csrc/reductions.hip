@@ -304,6 +304,16 @@ int32_t panel_dots(mxlo_ctx *ctx, const T *const *cols, int ncols, const T *x, i
   return allreduce_hook(ctx, out_dev, ncols);
 }
 
+// The dots kernel only: per-workgroup partial sums of dot(cols[c], x) are left in ctx->partials ([c][kMaxRedBlocks],
+// *nblocks of them per column) for a consumer that adds them up itself (ncols <= dots_max_nc: one chunk; n >= 1).
+template <typename T>
+int32_t panel_dots_partials(mxlo_ctx *ctx, const T *const *cols, int ncols, const T *x, int64_t n, int *nblocks) {
+  MXLO_REQUIRE(ncols >= 1 && ncols <= 4 && n >= 1, MXLO_EINVAL, "panel_dots_partials: bad arguments");
+  return dots_chunk<T>(ctx, cols, ncols, x, n, nblocks, nullptr);
+}
+template int32_t panel_dots_partials<double>(mxlo_ctx *, const double *const *, int, const double *, int64_t, int *);
+template int32_t panel_dots_partials<float>(mxlo_ctx *, const float *const *, int, const float *, int64_t, int *);
+
 // ---- dual-x panel dots: out1[c] = dot(col_c, x1), out2[c] = dot(col_c, x2) in ONE pass over the columns.
 // push! needs S's_new and S'y_new (forward) / Y'y_new and Y's_new (inverse): reading the panel once instead of
 // twice. Operands are panel columns (16-byte aligned, zero-padded to a whole number of vectors), so there is no

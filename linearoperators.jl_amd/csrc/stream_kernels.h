@@ -275,6 +275,31 @@ struct HouseholderOp {
     return fin_ab<T, CA, CB, BETA0>(a * (CA)inner, b, r);
   }
 };
+// the same with the dot taken from the dots pass's per-workgroup partial sums: every workgroup adds them up itself, in
+// finalize_kernel's order (lane t: t, t+256, ...; shuffle tree; the four waves pairwise) — bit-identical to the
+// finalized value in every workgroup, and one dependent launch fewer (mid sizes, no all-reduce hook)
+template <typename T, typename CA, typename CB, bool BETA0>
+struct HouseholderPartialsOp {
+  CA a;
+  CB b;
+  const double *partials;
+  int nblocks;
+  T c;
+  __device__ void init() {
+    __shared__ double hp_lds[kBlock / 64];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < nblocks; i += kBlock) s += partials[i];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if ((threadIdx.x & 63) == 0) hp_lds[threadIdx.x >> 6] = s;
+    __syncthreads();
+    c = (T)2 * (T)((hp_lds[0] + hp_lds[1]) + (hp_lds[2] + hp_lds[3]));
+  }
+  __device__ T operator()(T h, T v, T r) const {
+    const T inner = v - (c * h);
+    return fin_ab<T, CA, CB, BETA0>(a * (CA)inner, b, r);
+  }
+};
 
 inline bool alpha_is_f64(size_t elt, int32_t flags) { return elt == 8 || (flags & MXLO_ALPHA_F64); }
 inline bool beta_is_f64(size_t elt, int32_t flags) { return elt == 8 || (flags & MXLO_BETA_F64); }

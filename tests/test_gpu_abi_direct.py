@@ -101,7 +101,7 @@ def test_tune_keys(lo, dev):
     D = lo.opDiagonal(torch.from_numpy(d).to(dev))
     want = oracle.diag_mul(np.empty(n), d, v, 1.5, 0.0)
     try:
-        for key, vals in (("blocks_per_cu", (0, 1, 8)), ("nt_min_bytes", (0, 1 << 40)), ("red_blocks_per_cu", (1, 16)),
+        for key, vals in (("blocks_per_cu", (0, 1, 8)), ("nt_min_bytes", (0, 1 << 40)), ("house_inline_n", (0, 1 << 40)), ("red_blocks_per_cu", (1, 16)),
                           ("house_reverse", (0, 1)), ("house_fused", (0, 1)), ("gemm_tile", (32, 64, 128, -1, 0)),
                           ("extend_tiles_per_block", (1, 8, 0)),
                           ("combine_blocks_per_cu", (0, 4)), ("dots_max_nc", (1, 20))):
@@ -117,7 +117,7 @@ def test_tune_keys(lo, dev):
     finally:
         for key, val in (("blocks_per_cu", 0), ("nt_min_bytes", 256 << 20), ("red_blocks_per_cu", 4), ("house_reverse", 1),
                          ("gemm_tile", 0), ("combine_blocks_per_cu", 0), ("dots_max_nc", 20), ("house_fused", 1),
-                         ("extend_tiles_per_block", 0)):
+                         ("extend_tiles_per_block", 0), ("house_inline_n", 1 << 23)):
             ctx.tune(key, val)
 
 

@@ -539,3 +539,32 @@ def test_single_launch_householder_two_streams_one_ctx(lo, dev):
     for H, v, res, h_np, v_np in ops:
         want = oracle.householder_mul(np.empty(h_np.size), h_np, v_np, 2000.0, 0.0)
         assert rel(res.cpu().numpy(), want) <= 1e-12
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_householder_update_pass_summing_the_partials_is_bit_identical(lo, dev, dtype):
+    """Mid sizes (above the single-launch limit, up to `house_inline_n`): the update pass adds up the dots pass's
+    per-workgroup partial sums itself, in the finalize kernel's order — one launch fewer, and bit for bit the result of
+    the three-launch form (`house_inline_n` = 0), for aligned and ragged n, β = 0 and β ≠ 0, a misaligned view."""
+    from linearoperators_jl_amd.device import get_ctx
+    ctx = get_ctx(dev)
+    gen = torch.Generator(device=dev).manual_seed(5)
+    try:
+        for n in (1 << 20 | 1, 3_000_001, 1 << 22, (1 << 23) - 3):
+            hb = torch.rand(n + 1, dtype=dtype, device=dev, generator=gen) - 0.5
+            hb /= hb.norm()
+            vb = torch.rand(n + 1, dtype=dtype, device=dev, generator=gen) * 2 - 1
+            r0 = torch.rand(n, dtype=dtype, device=dev, generator=gen)
+            for off in (0, 1):
+                h, v = hb[off:off + n], vb[off:off + n]
+                H = lo.opHouseholder(h)
+                for a, b in ((1.0, 0.0), (2.0, -3.0)):
+                    got = {}
+                    for inline in (1 << 23, 0):
+                        ctx.tune("house_inline_n", inline)
+                        res = r0.clone()
+                        lo.mul(res, H, v, a, b)
+                        got[inline] = res
+                    assert torch.equal(got[1 << 23], got[0]), (n, off, a, b)
+    finally:
+        ctx.tune("house_inline_n", 1 << 23)

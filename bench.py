@@ -51,7 +51,7 @@ def parse(argv=None):
     ap.add_argument("--nelem", dest="n", type=int, default=100_000_000, help="vector length per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=50_000_000)
+    ap.add_argument("--cpu-sample", type=int, default=100_000_000)   # the GPU workload's own n
     # debugging aids for the N > 1 code path on a 1-GPU box: every rank on device 0, gloo instead of RCCL
     ap.add_argument("--backend", default="nccl")
     ap.add_argument("--single-device", action="store_true")

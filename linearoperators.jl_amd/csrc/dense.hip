@@ -135,7 +135,7 @@ int32_t gemm(mxlo_ctx *ctx, T *C, int64_t ldc, const T *A, int64_t lda, bool ta,
 #define GLDS(AK_, TM_, TN_, WM_, WN_, BK_, NST_, PAIR_, PFD_)                                                     \
   {                                                                                                               \
     GlShape S{(int)M, (int)N, (int)K, (int)((M + TM_ - 1) / TM_), (int)((N + TN_ - 1) / TN_)};                    \
-    hipLaunchKernelGGL((gemm_glds_kernel<T, CA, CB, B0, AK_, TM_, TN_, WM_, WN_, BK_, NST_, true, true, PAIR_, PFD_>), \
+    hipLaunchKernelGGL((gemm_glds_kernel<T, CA, CB, B0, AK_, TM_, TN_, WM_, WN_, BK_, NST_, true, true, PAIR_, PFD_, true>), \
                        dim3(S.gx * S.gy), dim3(WM_ * WN_ * 64), 0, ctx->stream, C, ldc, A, lda, B, ldb, S,        \
                        (CA)alpha, (CB)beta);                                                                      \
   }
@@ -143,6 +143,9 @@ int32_t gemm(mxlo_ctx *ctx, T *C, int64_t ldc, const T *A, int64_t lda, bool ta,
   if (ta) GLDS(true, TM_, TN_, WM_, WN_, BK_, NST_, PAIR_, PFD_) else GLDS(false, TM_, TN_, WM_, WN_, BK_, NST_, PAIR_, PFD_)
       // PAIR (gemm_glds.h): tile pairs interleaved so that two fragments arrive with one 16-byte LDS read. Measured
       // (profiles/r03_tune_gemm_pair.txt): 64-tiles -2.0 % (f64) / -2.7 % (f32), f64 128-tiles -0.6 %, f32 128-tiles +0.4 %.
+      // SWAPC (always on): the MFMA runs with its operands exchanged so that the accumulator holds the transposed tile and
+      // 16 lanes store 16 consecutive rows of the column-major C (whole 128-byte lines in f64): 1024^2 f64 72.6 -> 70.4 us,
+      // f32 43.1 -> 41.0 us, 2048^2 -1 ... -4 % (profiles/r03_tune_gemm_swapc.txt).
       // PFD 2 (fragments read two k-steps ahead): the 32-tile workgroup has ONE wave per SIMD, nothing else hides its LDS
       // latency: -0.5 ... -3 % there, +1 % on the 64-tiles (two waves per SIMD) — profiles/r03_tune_gemm_bk.txt
       if constexpr (sizeof(T) == 8) {

@@ -74,7 +74,7 @@ __device__ __forceinline__ void gl_tile_of(int id, int gx, int gy, int &tx, int 
 // the same bytes. The C tile is un-permuted in the epilogue. (A K-contiguous A image has no adjacent rows: A stays
 // unpaired there.)
 template <typename T, typename CA, typename CB, bool BETA0, bool AK, int TM, int TN, int WM, int WN, int BK, int NST,
-          bool SPREAD = true, bool PIN = true, bool PAIR = false, int PFD = 1>
+          bool SPREAD = true, bool PIN = true, bool PAIR = false, int PFD = 1, bool SWAPC = false>
 __global__ void __launch_bounds__(WM * WN * 64)
 gemm_glds_kernel(T *__restrict__ C, int64_t ldc, const T *__restrict__ A, int64_t lda,
                  const T *__restrict__ B, int64_t ldb, GlShape S, CA alpha, CB beta) {
@@ -243,7 +243,7 @@ gemm_glds_kernel(T *__restrict__ C, int64_t ldc, const T *__restrict__ A, int64_
 #pragma unroll
       for (int a = 0; a < MT; ++a)
 #pragma unroll
-        for (int b = 0; b < NT; ++b) acc[a][b] = GlMfma<T>::run(av[a], bv[b], acc[a][b]);
+        for (int b = 0; b < NT; ++b) acc[a][b] = SWAPC ? GlMfma<T>::run(bv[b], av[a], acc[a][b]) : GlMfma<T>::run(av[a], bv[b], acc[a][b]);
     }
   };
 
@@ -295,7 +295,9 @@ gemm_glds_kernel(T *__restrict__ C, int64_t ldc, const T *__restrict__ A, int64_
 #pragma unroll
       for (int a = 0; a < MT; ++a)
 #pragma unroll
-        for (int b = 0; b < NT; ++b) acc[a][b] = GlMfma<T>::run(av[ks % NFB][a], bv[ks % NFB][b], acc[a][b]);
+        for (int b = 0; b < NT; ++b)
+          acc[a][b] = SWAPC ? GlMfma<T>::run(bv[ks % NFB][b], av[ks % NFB][a], acc[a][b])
+                            : GlMfma<T>::run(av[ks % NFB][a], bv[ks % NFB][b], acc[a][b]);
       if (ks == KS / 2 - 1) {
         if constexpr (MORE) {
           if constexpr (NST == 4 && AHEAD2) gl_wait_vmcnt<PW>();
@@ -365,9 +367,12 @@ gemm_glds_kernel(T *__restrict__ C, int64_t ldc, const T *__restrict__ A, int64_
     for (int b = 0; b < NT; ++b)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int gi = PA ? bm + wm + (a >> 1) * 32 + 2 * GlMfma<T>::row(lane, r) + (a & 1)
-                          : bm + wm + a * 16 + GlMfma<T>::row(lane, r);
-        const int gj = PB ? bn + wn + (b >> 1) * 32 + 2 * l15 + (b & 1) : bn + wn + b * 16 + l15;
+        // SWAPC: the MFMA ran with its operands exchanged, so the accumulator holds the TRANSPOSED 16x16 tile — the lane
+        // index (l15) runs along M, the register index along N: for a column-major C the 16 lanes of a quarter-wave
+        // then store 16 consecutive rows (one whole 128-byte line in f64) instead of four rows of 16 different columns
+        const int im = SWAPC ? l15 : GlMfma<T>::row(lane, r), jn = SWAPC ? GlMfma<T>::row(lane, r) : l15;
+        const int gi = PA ? bm + wm + (a >> 1) * 32 + 2 * im + (a & 1) : bm + wm + a * 16 + im;
+        const int gj = PB ? bn + wn + (b >> 1) * 32 + 2 * jn + (b & 1) : bn + wn + b * 16 + jn;
         if (gi < M && gj < N) {
           T *p = C + gi + (int64_t)gj * ldc;
           const CA t = alpha * (CA)acc[a][b][r];

@@ -74,7 +74,7 @@ __device__ __forceinline__ void gl_tile_of(int id, int gx, int gy, int &tx, int 
 // the same bytes. The C tile is un-permuted in the epilogue. (A K-contiguous A image has no adjacent rows: A stays
 // unpaired there.)
 template <typename T, typename CA, typename CB, bool BETA0, bool AK, int TM, int TN, int WM, int WN, int BK, int NST,
-          bool SPREAD = true, bool PIN = true, bool PAIR = false, int PFD = 1, bool SWAPC = false>
+          bool SPREAD = true, bool PIN = true, bool PAIR = false, int PFD = 1, bool SWAPC = false, bool NTC = false>
 __global__ void __launch_bounds__(WM * WN * 64)
 gemm_glds_kernel(T *__restrict__ C, int64_t ldc, const T *__restrict__ A, int64_t lda,
                  const T *__restrict__ B, int64_t ldb, GlShape S, CA alpha, CB beta) {
@@ -376,11 +376,16 @@ gemm_glds_kernel(T *__restrict__ C, int64_t ldc, const T *__restrict__ A, int64_
         if (gi < M && gj < N) {
           T *p = C + gi + (int64_t)gj * ldc;
           const CA t = alpha * (CA)acc[a][b][r];
-          if constexpr (BETA0) *p = (T)t;
+          T o;
+          if constexpr (BETA0) o = (T)t;
           else {   // α-term in α's type, β-term in β's, summed in the wider (see stream_kernels.h: fin_ab)
             using P = std::conditional_t<(sizeof(CA) >= sizeof(CB)), CA, CB>;
-            *p = (T)((P)t + (P)(beta * (CB)(*p)));
+            o = (T)((P)t + (P)(beta * (CB)(*p)));
           }
+          // NTC: streaming stores — the tile is not re-read by this kernel, and lines that do not stay dirty in L2 do
+          // not have to be written back at the kernel boundary the dependent GEMM waits behind
+          if constexpr (NTC) __builtin_nontemporal_store(o, p);
+          else *p = o;
         }
       }
 }

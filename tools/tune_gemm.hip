@@ -51,10 +51,10 @@ __global__ void diff_kernel(const T *C, const double *R, int64_t n, double *out)
   if (threadIdx.x == 0) *out = sm[0];
 }
 
-template <typename T, bool AK, int TM, int TN, int WM, int WN, int BK, int NST, bool SP = true, bool PIN = true, bool PAIR = false, int PFD = 1, bool SWAPC = false>
+template <typename T, bool AK, int TM, int TN, int WM, int WN, int BK, int NST, bool SP = true, bool PIN = true, bool PAIR = false, int PFD = 1, bool SWAPC = false, bool NTC = false>
 void launch(hipStream_t st, T *C, int64_t ldc, const T *A, int64_t lda, const T *B, int64_t ldb, int M, int N, int K) {
   GlShape S{M, N, K, (M + TM - 1) / TM, (N + TN - 1) / TN};
-  hipLaunchKernelGGL((gemm_glds_kernel<T, T, T, true, AK, TM, TN, WM, WN, BK, NST, SP, PIN, PAIR, PFD, SWAPC>), dim3(S.gx * S.gy), dim3(WM * WN * 64),
+  hipLaunchKernelGGL((gemm_glds_kernel<T, T, T, true, AK, TM, TN, WM, WN, BK, NST, SP, PIN, PAIR, PFD, SWAPC, NTC>), dim3(S.gx * S.gy), dim3(WM * WN * 64),
                      0, st, C, ldc, A, lda, B, ldb, S, (T)1, (T)0);
 }
 
@@ -187,17 +187,22 @@ void sweep(int n, rocblas_handle rb) {
 #define VQ(AK_, TM_, TN_, WM_, WN_, BK_, NST_) VP(AK_, TM_, TN_, WM_, WN_, BK_, NST_, true, true, true)
 #define VP(AK_, TM_, TN_, WM_, WN_, BK_, NST_, SP_, PIN_, PAIR_) VF(AK_, TM_, TN_, WM_, WN_, BK_, NST_, SP_, PIN_, PAIR_, 1)
 #define VF(AK_, TM_, TN_, WM_, WN_, BK_, NST_, SP_, PIN_, PAIR_, PFD_) VW(AK_, TM_, TN_, WM_, WN_, BK_, NST_, SP_, PIN_, PAIR_, PFD_, false)
-#define VW(AK_, TM_, TN_, WM_, WN_, BK_, NST_, SP_, PIN_, PAIR_, PFD_, SW_)                                          \
+#define VW(AK_, TM_, TN_, WM_, WN_, BK_, NST_, SP_, PIN_, PAIR_, PFD_, SW_) VN(AK_, TM_, TN_, WM_, WN_, BK_, NST_, SP_, PIN_, PAIR_, PFD_, SW_, false)
+#define VN(AK_, TM_, TN_, WM_, WN_, BK_, NST_, SP_, PIN_, PAIR_, PFD_, SW_, NT_)                                     \
   {                                                                                                                 \
     auto f = [&] {                                                                                                  \
-      launch<T, AK_, TM_, TN_, WM_, WN_, BK_, NST_, SP_, PIN_, PAIR_, PFD_, SW_>(b.st, b.W, n, b.A, n, b.X, n, n, n, n); \
-      launch<T, AK_, TM_, TN_, WM_, WN_, BK_, NST_, SP_, PIN_, PAIR_, PFD_, SW_>(b.st, b.R, n, b.B, n, b.W, n, n, n, n); \
+      launch<T, AK_, TM_, TN_, WM_, WN_, BK_, NST_, SP_, PIN_, PAIR_, PFD_, SW_, NT_>(b.st, b.W, n, b.A, n, b.X, n, n, n, n); \
+      launch<T, AK_, TM_, TN_, WM_, WN_, BK_, NST_, SP_, PIN_, PAIR_, PFD_, SW_, NT_>(b.st, b.R, n, b.B, n, b.W, n, n, n, n); \
     };                                                                                                              \
-    snprintf(name, sizeof name, "%s glds %s t%dx%d w%dx%d bk%d st%d%s%s%s%s%s", tn, AK_ ? "AK" : "AM", TM_, TN_, WM_, WN_, BK_, \
-             NST_, SP_ ? "" : " nospread", PIN_ ? "" : " nopin", PAIR_ ? " PAIR" : "", PFD_ == 2 ? " PFD2" : "", SW_ ? " SWAPC" : ""); \
+    snprintf(name, sizeof name, "%s glds %s t%dx%d w%dx%d bk%d st%d%s%s%s%s%s%s", tn, AK_ ? "AK" : "AM", TM_, TN_, WM_, WN_, BK_, \
+             NST_, SP_ ? "" : " nospread", PIN_ ? "" : " nopin", PAIR_ ? " PAIR" : "", PFD_ == 2 ? " PFD2" : "", SW_ ? " SWAPC" : "", NT_ ? " NTC" : ""); \
     b.run(name, f, AK_ ? 2 : 1);                                                                                    \
   }
   if constexpr (F64) {
+    VN(false, 64, 64, 4, 2, 32, 3, true, true, true, 1, true, true)
+    VN(true, 64, 64, 4, 2, 32, 3, true, true, true, 1, true, true)
+    VN(false, 128, 128, 4, 4, 16, 3, true, true, true, 1, true, true)
+    VN(false, 32, 32, 2, 2, 32, 4, true, true, false, 2, true, true)
     VW(false, 64, 64, 4, 2, 32, 3, true, true, true, 1, true)
     VW(true, 64, 64, 4, 2, 32, 3, true, true, true, 1, true)
     VW(false, 128, 128, 4, 4, 16, 3, true, true, true, 1, true)
@@ -252,6 +257,9 @@ void sweep(int n, rocblas_handle rb) {
     V(true, 64, 64, 4, 2, 32, 3)
     V(true, 32, 32, 2, 2, 32, 4)
   } else {
+    VN(false, 64, 64, 4, 2, 64, 3, true, true, true, 1, true, true)
+    VN(false, 128, 128, 4, 4, 32, 3, true, true, false, 1, true, true)
+    VN(false, 32, 32, 2, 2, 64, 4, true, true, false, 2, true, true)
     VW(false, 64, 64, 4, 2, 64, 3, true, true, true, 1, true)
     VW(true, 64, 64, 4, 2, 64, 3, true, true, true, 1, true)
     VW(false, 128, 128, 4, 4, 32, 3, true, true, false, 1, true)
@@ -288,6 +296,7 @@ void sweep(int n, rocblas_handle rb) {
 #undef VP
 #undef VF
 #undef VW
+#undef VN
 }
 
 // time-vs-K at fixed M = N: slope = per-slab cost, intercept = launch + prologue + epilogue

@@ -42,6 +42,20 @@ def test_ctypes_prototypes_cover_header(lo):
     assert declared == set(lo._lib._PROTOS), declared ^ set(lo._lib._PROTOS)
 
 
+def test_every_tune_key_is_documented_in_the_header():
+    """`mxlo_ctx_tune` keys are part of the boundary (tools and tests set them through the ABI): every key the library
+    accepts must be named in include/mxlo.h."""
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, "linearoperators.jl_amd", "csrc", "api_ctx.hip")).read()
+    hdr = open(os.path.join(root, "include", "mxlo.h")).read()
+    keys = set(re.findall(r'strcmp\(key, "([a-z_0-9]+)"\)', src))
+    assert len(keys) >= 15
+    missing = sorted(k for k in keys if f'"{k}"' not in hdr)
+    assert not missing, missing
+
+
 def test_no_gpu_means_loud_failure(lo):
     if torch.cuda.is_available():
         pytest.skip("GPU present")

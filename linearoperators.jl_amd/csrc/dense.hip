@@ -132,30 +132,33 @@ int32_t gemm(mxlo_ctx *ctx, T *C, int64_t ldc, const T *A, int64_t lda, bool ta,
         else if (tiles(64, 64) * 5 >= (int64_t)ctx->num_cu * 3) tile = 64;   // >= 0.6 workgroups per CU
         else tile = 32;
       }
-#define GLDS(AK_, TM_, TN_, WM_, WN_, BK_, NST_, PAIR_, PFD_)                                                     \
+#define GLDS(AK_, TM_, TN_, WM_, WN_, BK_, NST_, PAIR_, PFD_, UNR_)                                               \
   {                                                                                                               \
     GlShape S{(int)M, (int)N, (int)K, (int)((M + TM_ - 1) / TM_), (int)((N + TN_ - 1) / TN_)};                    \
-    hipLaunchKernelGGL((gemm_glds_kernel<T, CA, CB, B0, AK_, TM_, TN_, WM_, WN_, BK_, NST_, true, true, PAIR_, PFD_, true>), \
+    hipLaunchKernelGGL((gemm_glds_kernel<T, CA, CB, B0, AK_, TM_, TN_, WM_, WN_, BK_, NST_, true, true, PAIR_, PFD_, true, false, false, UNR_>), \
                        dim3(S.gx * S.gy), dim3(WM_ * WN_ * 64), 0, ctx->stream, C, ldc, A, lda, B, ldb, S,        \
                        (CA)alpha, (CB)beta);                                                                      \
   }
-#define GLDS_BY_A(TM_, TN_, WM_, WN_, BK_, NST_, PAIR_, PFD_)                                                     \
-  if (ta) GLDS(true, TM_, TN_, WM_, WN_, BK_, NST_, PAIR_, PFD_) else GLDS(false, TM_, TN_, WM_, WN_, BK_, NST_, PAIR_, PFD_)
+#define GLDS_BY_A(TM_, TN_, WM_, WN_, BK_, NST_, PAIR_, PFD_, UNR_AM_)                                            \
+  if (ta) GLDS(true, TM_, TN_, WM_, WN_, BK_, NST_, PAIR_, PFD_, true) else GLDS(false, TM_, TN_, WM_, WN_, BK_, NST_, PAIR_, PFD_, UNR_AM_)
       // PAIR (gemm_glds.h): tile pairs interleaved so that two fragments arrive with one 16-byte LDS read. Measured
       // (profiles/r03_tune_gemm_pair.txt): 64-tiles -2.0 % (f64) / -2.7 % (f32), f64 128-tiles -0.6 %, f32 128-tiles +0.4 %.
       // SWAPC (always on): the MFMA runs with its operands exchanged so that the accumulator holds the transposed tile and
       // 16 lanes store 16 consecutive rows of the column-major C (whole 128-byte lines in f64): 1024^2 f64 72.6 -> 70.4 us,
       // f32 43.1 -> 41.0 us, 2048^2 -1 ... -4 % (profiles/r03_tune_gemm_swapc.txt).
+      // UNR (on except for the M-contiguous f32 64- / 128-tiles, where it measured +1 ... 2 %): the steady state runs NST slabs per trip with the ring index a compile-time constant, so every LDS
+      // address is base + immediate and the vector ALU does no address work between the MFMAs: 1024^2 70.2 -> 68.9 us, the
+      // transpose mode (XOR-swizzled K-contiguous A) 79.0 -> 69.8 us, 32-tiles -6 ... -8 %, 128-tiles at 2048^2 -2.9 %.
       // PFD 2 (fragments read two k-steps ahead): the 32-tile workgroup has ONE wave per SIMD, nothing else hides its LDS
       // latency: -0.5 ... -3 % there, +1 % on the 64-tiles (two waves per SIMD) — profiles/r03_tune_gemm_bk.txt
       if constexpr (sizeof(T) == 8) {
-        if (tile == 128) GLDS_BY_A(128, 128, 4, 4, 16, 3, true, 1)
-        else if (tile == 64) GLDS_BY_A(64, 64, 4, 2, 32, 3, true, 1)
-        else GLDS_BY_A(32, 32, 2, 2, 32, 4, false, 2)
+        if (tile == 128) GLDS_BY_A(128, 128, 4, 4, 16, 3, true, 1, true)
+        else if (tile == 64) GLDS_BY_A(64, 64, 4, 2, 32, 3, true, 1, true)
+        else GLDS_BY_A(32, 32, 2, 2, 32, 4, false, 2, true)
       } else {
-        if (tile == 128) GLDS_BY_A(128, 128, 4, 4, 32, 3, false, 1)
-        else if (tile == 64) GLDS_BY_A(64, 64, 4, 2, 64, 3, true, 1)
-        else GLDS_BY_A(32, 32, 2, 2, 64, 4, false, 2)
+        if (tile == 128) GLDS_BY_A(128, 128, 4, 4, 32, 3, false, 1, false)
+        else if (tile == 64) GLDS_BY_A(64, 64, 4, 2, 64, 3, true, 1, false)
+        else GLDS_BY_A(32, 32, 2, 2, 64, 4, false, 2, true)
       }
 #undef GLDS_BY_A
 #undef GLDS

@@ -15,6 +15,8 @@
 //  * XCD-aware tile order: the 8 XCDs (workgroup id mod 8) each walk a compact band of tiles so the A / B slabs
 //    they share stay in that XCD's L2.
 #pragma once
+#include <utility>
+
 #include "common.h"
 
 namespace mxlo {
@@ -74,7 +76,7 @@ __device__ __forceinline__ void gl_tile_of(int id, int gx, int gy, int &tx, int 
 // the same bytes. The C tile is un-permuted in the epilogue. (A K-contiguous A image has no adjacent rows: A stays
 // unpaired there.)
 template <typename T, typename CA, typename CB, bool BETA0, bool AK, int TM, int TN, int WM, int WN, int BK, int NST,
-          bool SPREAD = true, bool PIN = true, bool PAIR = false, int PFD = 1, bool SWAPC = false, bool NTC = false>
+          bool SPREAD = true, bool PIN = true, bool PAIR = false, int PFD = 1, bool SWAPC = false, bool NTC = false, bool XNOBAR = false, bool UNR = false>
 __global__ void __launch_bounds__(WM * WN * 64)
 gemm_glds_kernel(T *__restrict__ C, int64_t ldc, const T *__restrict__ A, int64_t lda,
                  const T *__restrict__ B, int64_t ldb, GlShape S, CA alpha, CB beta) {
@@ -281,11 +283,14 @@ gemm_glds_kernel(T *__restrict__ C, int64_t ldc, const T *__restrict__ A, int64_
   int stage = 0;
   // one full slab. MORE: a slab it+1 exists; NEXTF: it is a full slab (cross-slab fragment prefetch);
   // REFILL: slab it+NST-1 exists (1: a full slab, 2: the K tail, clamped addressing); AHEAD2: slab it+2 exists and was issued earlier (NST == 4 only: it may stay in flight)
-  auto slab = [&]<bool MORE, bool NEXTF, int REFILL, bool AHEAD2>(int it) {
-    const T *st = lds + stage * (AIMG + BIMG);
-    const int nst = next_stage(stage);
+  // STG >= 0: the ring index of this slab is a compile-time constant (steady state, UNR): every LDS address of the slab —
+  // fragment reads, DMA destinations — is then a loop-invariant base plus an immediate, no vector-ALU address work
+  auto slab = [&]<bool MORE, bool NEXTF, int REFILL, bool AHEAD2, int STG = -1>(int it) {
+    const int cur = STG >= 0 ? STG : stage;
+    const T *st = lds + cur * (AIMG + BIMG);
+    const int nst = next_stage(cur);
     const T *stn = lds + nst * (AIMG + BIMG);
-    const int rst = prev_stage(stage);
+    const int rst = prev_stage(cur);
     const int k0n = (it + NST - 1) * BK;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
@@ -302,7 +307,7 @@ gemm_glds_kernel(T *__restrict__ C, int64_t ldc, const T *__restrict__ A, int64_
         if constexpr (MORE) {
           if constexpr (NST == 4 && AHEAD2) gl_wait_vmcnt<PW>();
           else gl_wait_vmcnt<0>();
-          __builtin_amdgcn_s_barrier();
+          if constexpr (!XNOBAR) __builtin_amdgcn_s_barrier();   // XNOBAR: timing experiment only (results are wrong)
         }
         if constexpr (REFILL != 0 && !SPREAD) issue.template operator()<REFILL == 2>(rst, k0n);
       }
@@ -322,6 +327,13 @@ gemm_glds_kernel(T *__restrict__ C, int64_t ldc, const T *__restrict__ A, int64_
     for (int p = 0; p < PFD; ++p) frag(lds, p, av[p], bv[p]);
   }
   int it = 0;
+  if constexpr (UNR) {   // steady state, NST slabs per trip: slab it + j lives in ring stage j (it is a multiple of NST)
+    for (; it + 2 * NST - 2 < nfull; it += NST) {
+      [&]<int... J>(std::integer_sequence<int, J...>) {
+        (slab.template operator()<true, true, 1, true, J>(it + J), ...);
+      }(std::make_integer_sequence<int, NST>{});
+    }
+  }
   for (; it + NST - 1 < nfull; ++it) slab.template operator()<true, true, 1, true>(it);   // steady state
   for (; it < nfull; ++it) {                                                             // last slabs
     const bool more = it + 1 < nk, nextf = it + 1 < nfull, refill = it + NST - 1 < nk, ahead2 = it + 2 < nk;

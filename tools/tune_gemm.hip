@@ -51,10 +51,10 @@ __global__ void diff_kernel(const T *C, const double *R, int64_t n, double *out)
   if (threadIdx.x == 0) *out = sm[0];
 }
 
-template <typename T, bool AK, int TM, int TN, int WM, int WN, int BK, int NST, bool SP = true, bool PIN = true, bool PAIR = false, int PFD = 1, bool SWAPC = false, bool NTC = false>
+template <typename T, bool AK, int TM, int TN, int WM, int WN, int BK, int NST, bool SP = true, bool PIN = true, bool PAIR = false, int PFD = 1, bool SWAPC = false, bool NTC = false, bool XNOBAR = false, bool UNR = false>
 void launch(hipStream_t st, T *C, int64_t ldc, const T *A, int64_t lda, const T *B, int64_t ldb, int M, int N, int K) {
   GlShape S{M, N, K, (M + TM - 1) / TM, (N + TN - 1) / TN};
-  hipLaunchKernelGGL((gemm_glds_kernel<T, T, T, true, AK, TM, TN, WM, WN, BK, NST, SP, PIN, PAIR, PFD, SWAPC, NTC>), dim3(S.gx * S.gy), dim3(WM * WN * 64),
+  hipLaunchKernelGGL((gemm_glds_kernel<T, T, T, true, AK, TM, TN, WM, WN, BK, NST, SP, PIN, PAIR, PFD, SWAPC, NTC, XNOBAR, UNR>), dim3(S.gx * S.gy), dim3(WM * WN * 64),
                      0, st, C, ldc, A, lda, B, ldb, S, (T)1, (T)0);
 }
 
@@ -199,6 +199,34 @@ void sweep(int n, rocblas_handle rb) {
     b.run(name, f, AK_ ? 2 : 1);                                                                                    \
   }
   if constexpr (F64) {
+#define VU(AK_, TM_, TN_, WM_, WN_, BK_, NST_, PAIR_, PFD_, TAG_)                                                    \
+  {                                                                                                                 \
+    auto f = [&] {                                                                                                  \
+      launch<T, AK_, TM_, TN_, WM_, WN_, BK_, NST_, true, true, PAIR_, PFD_, true, false, false, true>(b.st, b.W, n, b.A, n, b.X, n, n, n, n); \
+      launch<T, AK_, TM_, TN_, WM_, WN_, BK_, NST_, true, true, PAIR_, PFD_, true, false, false, true>(b.st, b.R, n, b.B, n, b.W, n, n, n, n); \
+    };                                                                                                              \
+    snprintf(name, sizeof name, "%s glds %s t%dx%d w%dx%d bk%d st%d %s SWAPC UNR", tn, AK_ ? "AK" : "AM", TM_, TN_, WM_, WN_, BK_, NST_, TAG_); \
+    b.run(name, f, AK_ ? 2 : 1);                                                                                    \
+  }
+    VU(false, 64, 64, 4, 2, 32, 3, true, 1, "PAIR")
+    VU(true, 64, 64, 4, 2, 32, 3, true, 1, "PAIR")
+    VU(false, 128, 128, 4, 4, 16, 3, true, 1, "PAIR")
+    VU(false, 32, 32, 2, 2, 32, 4, false, 2, "PFD2")
+#undef VU
+    {  // timing experiment: the per-slab barrier removed (results wrong): what the barrier costs
+      auto f = [&] {
+        launch<T, false, 64, 64, 4, 2, 32, 3, true, true, true, 1, true, false, true>(b.st, b.W, n, b.A, n, b.X, n, n, n, n);
+        launch<T, false, 64, 64, 4, 2, 32, 3, true, true, true, 1, true, false, true>(b.st, b.R, n, b.B, n, b.W, n, n, n, n);
+      };
+      snprintf(name, sizeof name, "%s glds AM t64x64 w4x2 bk32 st3 PAIR SWAPC XNOBAR(wrong results)", tn);
+      b.run(name, f, 0);
+      auto f2 = [&] {
+        launch<T, false, 32, 32, 2, 2, 32, 4, true, true, false, 2, true, false, true>(b.st, b.W, n, b.A, n, b.X, n, n, n, n);
+        launch<T, false, 32, 32, 2, 2, 32, 4, true, true, false, 2, true, false, true>(b.st, b.R, n, b.B, n, b.W, n, n, n, n);
+      };
+      snprintf(name, sizeof name, "%s glds AM t32x32 w2x2 bk32 st4 PFD2 SWAPC XNOBAR(wrong results)", tn);
+      b.run(name, f2, 0);
+    }
     VN(false, 64, 64, 4, 2, 32, 3, true, true, true, 1, true, true)
     VN(true, 64, 64, 4, 2, 32, 3, true, true, true, 1, true, true)
     VN(false, 128, 128, 4, 4, 16, 3, true, true, true, 1, true, true)

@@ -163,6 +163,12 @@ gemm_glds_kernel(T *__restrict__ C, int64_t ldc, const T *__restrict__ A, int64_
     T *l = lds + stage * (AIMG + BIMG) + q * EPI;
     const char *g;
     if constexpr (!CLAMP) {
+      // keep "uniform base + zero-extended 32-bit lane offset" TOGETHER at the load: that is the pattern the backend turns
+      // into `global_load_lds_dwordx4 v_off, s[base:base+1]`. Left alone, the optimiser hoists the loop-invariant
+      // (tile + lane offset) out of the K loop as a 64-bit per-lane pointer and re-adds the slab advance with one
+      // v_lshl_add_u64 per DMA instruction — 6 vector-ALU instructions per slab between the MFMAs. The empty asm makes
+      // the lane offset opaque at every use, so there is nothing loop-invariant to hoist.
+      asm volatile("" : "+v"(voff[p]));   // (in place: no copy)
       g = sb + voff[p];
     } else {
       int k = k0 + krow[p];

@@ -56,6 +56,53 @@ def test_every_tune_key_is_documented_in_the_header():
     assert not missing, missing
 
 
+def test_no_kernel_of_the_library_uses_scratch(lo):
+    """Static check on the built gfx950 code objects (no GPU needed): every kernel of libmxlo.so has
+    `.private_segment_fixed_size: 0`. A run-time index into a per-lane register array, or one accumulator too many,
+    silently moves data to scratch memory — which cost 3x on the single-launch quasi-Newton apply before it was noticed
+    (DESIGN §4). The code objects are read out of the HIP fat binary (clang offload bundle) embedded in the library."""
+    import os
+    import re
+    import struct
+    import subprocess
+    import tempfile
+    readelf = "/opt/rocm/lib/llvm/bin/llvm-readelf"
+    if not os.path.exists(readelf):
+        pytest.skip("llvm-readelf not available")
+    so = os.path.join(os.path.dirname(lo._lib.__file__), "csrc", "libmxlo.so")
+    blob = open(so, "rb").read()
+    magic = b"__CLANG_OFFLOAD_BUNDLE__"
+    nkern, spilled = 0, []
+    with tempfile.TemporaryDirectory() as td:
+        for bi, m in enumerate(re.finditer(re.escape(magic), blob)):
+            p = m.start()
+            (n,) = struct.unpack_from("<Q", blob, p + 24)
+            off = p + 32
+            for e in range(n):
+                o, size, tl = struct.unpack_from("<QQQ", blob, off)
+                off += 24
+                triple = blob[off:off + tl].decode()
+                off += tl
+                if "gfx950" not in triple or size == 0:
+                    continue
+                f = os.path.join(td, f"co_{bi}_{e}.co")
+                with open(f, "wb") as fh:
+                    fh.write(blob[p + o:p + o + size])
+                notes = subprocess.run([readelf, "--notes", f], capture_output=True, text=True, check=True).stdout
+                name = None
+                for line in notes.splitlines():
+                    mm = re.match(r"\s+\.name:\s+(\S+)", line)
+                    if mm:
+                        name = mm.group(1)
+                    mm = re.match(r"\s+\.private_segment_fixed_size:\s+(\d+)", line)
+                    if mm and name:
+                        nkern += 1
+                        if int(mm.group(1)) > 0:
+                            spilled.append((name, int(mm.group(1))))
+    assert nkern > 1000, nkern                     # every translation unit was found
+    assert not spilled, spilled[:10]
+
+
 def test_no_gpu_means_loud_failure(lo):
     if torch.cuda.is_available():
         pytest.skip("GPU present")

@@ -113,7 +113,11 @@ int32_t mxlo_ctx_info(mxlo_ctx *ctx, int64_t info[4]);
 /* Launch-geometry / algorithm-variant knobs for sweeps and for tests that compare two device implementations. Keys:
  * "blocks_per_cu", "nt_min_bytes", "red_blocks_per_cu", "graph_direct_max", "house_fused", "house_reverse", "house_inline_n" (two-pass opHouseholder up to this n: the update pass adds up the dots pass's partial sums itself, no finalize launch; 0: never),
  * "cherm_two_pass", "lbfgs_inv_mode", "gemm_tile", "extend_tiles_per_block", "fuse_finalize", "combine_blocks_per_cu",
- * "dots_max_nc", "qn_fused_small" (1: dots + finalize + coefficients of a small quasi-Newton apply in one launch), "push_wide", "push_fused" (1: streaming push! schedules — L-BFGS: new pair held per lane, in-pass inserts; L-SR1: panels once, y - B s never stored, inserts ride in the rebuild; 0: the copies + dots schedules they replaced). Unknown key or out-of-range value -> MXLO_EINVAL. */
+ * "dots_max_nc", "qn_fused_small" (1: dots + finalize + coefficients of a small quasi-Newton apply in one launch), "push_wide", "push_fused" (1: streaming push! schedules — L-BFGS: new pair held per lane, in-pass inserts; L-SR1: panels once, y - B s never stored, inserts ride in the rebuild; 0: the copies + dots schedules they replaced). Unknown key or out-of-range value -> MXLO_EINVAL.
+ * "house_fused" / "qn_fused_small" = 0 is also the setting for MORE than four processes sharing one GPU: the workgroups of a
+ * single-launch apply wait for each other, so a launch must be resident as a whole; four of the largest Householder launches
+ * (256 workgroups) or twelve quasi-Newton ones (64 workgroups) fit on the chip at once, beyond that two launches could each
+ * be partly resident and wait for good. (They are never used with an all-reduce hook installed.) */
 int32_t mxlo_ctx_tune(mxlo_ctx *ctx, const char *key, int64_t value);
 
 /* Row-sharding hook. When set, EVERY global reduction this ctx performs

@@ -113,11 +113,19 @@ int32_t mxlo_ctx_info(mxlo_ctx *ctx, int64_t info[4]);
 /* Launch-geometry / algorithm-variant knobs for sweeps and for tests that compare two device implementations. Keys:
  * "blocks_per_cu", "nt_min_bytes", "red_blocks_per_cu", "graph_direct_max", "house_fused", "house_reverse", "house_inline_n" (two-pass opHouseholder up to this n: the update pass adds up the dots pass's partial sums itself, no finalize launch; 0: never),
  * "cherm_two_pass", "lbfgs_inv_mode", "gemm_tile", "extend_tiles_per_block", "fuse_finalize", "combine_blocks_per_cu",
- * "dots_max_nc", "qn_fused_small" (1: dots + finalize + coefficients of a small quasi-Newton apply in one launch), "push_wide", "push_fused" (1: streaming push! schedules — L-BFGS: new pair held per lane, in-pass inserts; L-SR1: panels once, y - B s never stored, inserts ride in the rebuild; 0: the copies + dots schedules they replaced). Unknown key or out-of-range value -> MXLO_EINVAL.
+ * "dots_max_nc", "fused_timeout_ms", "fused_debug_drop" (both below), "qn_fused_small" (1: dots + finalize + coefficients of a small quasi-Newton apply in one launch), "push_wide", "push_fused" (1: streaming push! schedules — L-BFGS: new pair held per lane, in-pass inserts; L-SR1: panels once, y - B s never stored, inserts ride in the rebuild; 0: the copies + dots schedules they replaced). Unknown key or out-of-range value -> MXLO_EINVAL.
  * "house_fused" / "qn_fused_small" = 0 is also the setting for MORE than four processes sharing one GPU: the workgroups of a
  * single-launch apply wait for each other, so a launch must be resident as a whole; four of the largest Householder launches
  * (256 workgroups) or twelve quasi-Newton ones (64 workgroups) fit on the chip at once, beyond that two launches could each
- * be partly resident and wait for good. (They are never used with an all-reduce hook installed.) */
+ * be partly resident and wait for each other. (They are never used with an all-reduce hook installed.)
+ * That wait is BOUNDED: "fused_timeout_ms" (default 2000, 1..600000) is how long a workgroup polls for a peer's partial before
+ * it gives up, stores NaN and raises the ctx fault word (pinned host memory). The host reads that word, without
+ * synchronising, before every single-launch apply and at the end of mxlo_ctx_sync: the call then returns MXLO_EHIP naming the
+ * timeout, after draining the stream, re-arming the exchange slots and switching "house_fused" / "qn_fused_small" OFF for
+ * the ctx (the apply that timed out has stored NaN — repeat it). Before a single-launch apply is issued the library also
+ * checks, once per kernel and device, that the occupancy of the kernel lets the whole grid be resident, and falls back to
+ * the multi-launch form otherwise. "fused_debug_drop" (default -1) is a TEST HOOK: that workgroup index never publishes
+ * its partial, which is how tests/test_gpu_leaves.py provokes the timeout. */
 int32_t mxlo_ctx_tune(mxlo_ctx *ctx, const char *key, int64_t value);
 
 /* Row-sharding hook. When set, EVERY global reduction this ctx performs
@@ -173,7 +181,8 @@ typedef struct mxlo_graph mxlo_graph;
 int32_t mxlo_ctx_create_stream(mxlo_ctx *ctx, void **stream_out); /* non-blocking stream owned by the ctx */
 int32_t mxlo_graph_begin(mxlo_ctx *ctx);
 int32_t mxlo_graph_end(mxlo_ctx *ctx, mxlo_graph **out);
-int32_t mxlo_graph_launch(mxlo_graph *g);   /* on the stream it was captured from */
+int32_t mxlo_graph_launch(mxlo_graph *g);   /* on the stream it was captured from; ordered, both ways, with the ctx's
+                                             * current stream when mxlo_ctx_set_stream moved the ctx since the capture */
 /* info[0] = nodes recorded, info[1] = 1 when the replay re-issues the recorded launches directly (a dependency chain of
  * at most `graph_direct_max` kernel/memset nodes, tune key, default 16: cheaper than hipGraphLaunch on this runtime),
  * 0 when it goes through hipGraphLaunch. Same results either way. */

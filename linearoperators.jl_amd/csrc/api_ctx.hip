@@ -75,9 +75,59 @@ MXLO_API int32_t mxlo_ctx_create(int32_t device_id, void *stream, mxlo_ctx **out
       (void)hipGetLastError();
     }
   }
+  {  // fault word of the single-launch kernels: pinned + device-mapped, so that the host reads it without a sync
+    void *hp = nullptr, *dp = nullptr;
+    if (hipHostMalloc(&hp, 64, hipHostMallocMapped) == hipSuccess && hipHostGetDevicePointer(&dp, hp, 0) == hipSuccess) {
+      memset(hp, 0, 64);
+      ctx->fault_host = (unsigned *)hp;
+      ctx->fault_dev = (unsigned *)dp;
+    } else {                       // no mapped host memory: the single-launch forms stay off (nothing could report a timeout)
+      if (hp) (void)hipHostFree(hp);
+      (void)hipGetLastError();
+      ctx->tune.house_fused = 0;
+      ctx->tune.qn_fused_small = 0;
+    }
+  }
   *out = ctx;
   return MXLO_OK;
 }
+
+namespace mxlo {
+static int32_t rearm_fused_slots(mxlo_ctx *ctx) {
+  if (ctx->xslots) {
+    std::vector<unsigned long long> init(2 * kFusedSlots + 8, kSlotEmpty);
+    for (int i = 0; i < 8; ++i) init[2 * kFusedSlots + i] = 0;
+    MXLO_HIP(hipMemcpy(ctx->xslots, init.data(), init.size() * sizeof(unsigned long long), hipMemcpyHostToDevice));
+  }
+  if (ctx->qslots) {
+    constexpr size_t kQ = 2 * 40 * 64 + 8;
+    std::vector<unsigned long long> init(kQ, kSlotEmpty);
+    for (int i = 0; i < 8; ++i) init[kQ - 8 + i] = 0;
+    MXLO_HIP(hipMemcpy(ctx->qslots, init.data(), kQ * sizeof(unsigned long long), hipMemcpyHostToDevice));
+  }
+  return MXLO_OK;
+}
+
+int32_t fused_fault_check(mxlo_ctx *ctx) {
+  if (!ctx->fault_host || ctx->capturing) return MXLO_OK;
+  const unsigned code = __atomic_load_n(ctx->fault_host, __ATOMIC_RELAXED);
+  if (code == 0) return MXLO_OK;
+  // A single-launch apply gave up waiting for its peer workgroups. Its output is NaN; the exchange slots and the epoch
+  // word are in an unknown state. Drain the stream, re-arm everything, and keep the single-launch forms off: whatever
+  // kept the grid from being co-resident is likely to still be there.
+  (void)hipStreamSynchronize(ctx->stream);
+  ctx->tune.house_fused = 0;
+  ctx->tune.qn_fused_small = 0;
+  __atomic_store_n(ctx->fault_host, 0u, __ATOMIC_RELAXED);
+  (void)rearm_fused_slots(ctx);
+  set_error("a single-launch %s apply on this ctx timed out after %d ms waiting for its peer workgroups (the launch was "
+            "not fully co-resident: GPU shared with other processes, CU masking, or a killed launch left the exchange "
+            "slots inconsistent); that apply stored NaN. The exchange state has been re-armed and the single-launch "
+            "forms (house_fused, qn_fused_small) are now OFF for this ctx — repeat the apply",
+            code == kFaultHouseholder ? "opHouseholder" : "quasi-Newton", ctx->tune.fused_timeout_ms);
+  return MXLO_EHIP;
+}
+}  // namespace mxlo
 
 MXLO_API int32_t mxlo_ctx_destroy(mxlo_ctx *ctx) {
   if (!ctx) return MXLO_OK;
@@ -88,6 +138,7 @@ MXLO_API int32_t mxlo_ctx_destroy(mxlo_ctx *ctx) {
   if (ctx->ticket) (void)hipFree(ctx->ticket);
   if (ctx->xslots) (void)hipFree(ctx->xslots);
   if (ctx->qslots) (void)hipFree(ctx->qslots);
+  if (ctx->fault_host) (void)hipHostFree(ctx->fault_host);
   if (ctx->scratch) (void)hipFree(ctx->scratch);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
   if (ctx->switch_event) (void)hipEventDestroy(ctx->switch_event);
@@ -239,6 +290,24 @@ MXLO_API int32_t mxlo_graph_launch(mxlo_graph *g) {
   MXLO_REQUIRE(g->scratch_generation < 0 || g->scratch_generation == g->ctx->scratch_generation, MXLO_ESTATE,
                "mxlo_graph_launch: the opHermitian workspace recorded in this graph was reallocated (a larger n arrived) "
                "— recapture");
+  // A graph replays on the stream it was captured from. If the ctx has moved to another stream since, order the two:
+  // the workspaces, the scalar buffer and the exchange slots of the single-launch kernels belong to the ctx, not to a
+  // stream, so a replay must neither overtake nor be overtaken by the ctx's direct launches.
+  mxlo_ctx *ctx = g->ctx;
+  const bool foreign = g->stream != ctx->stream;
+  struct Rejoin {                      // after the replay: the ctx stream waits for it (also on the error paths below)
+    mxlo_ctx *ctx; hipStream_t gs; bool on;
+    ~Rejoin() {
+      if (on && hipEventRecord(ctx->switch_event, gs) == hipSuccess) (void)hipStreamWaitEvent(ctx->stream, ctx->switch_event, 0);
+    }
+  } rejoin{ctx, g->stream, false};
+  if (foreign) {
+    MXLO_REQUIRE(!ctx->capturing, MXLO_ESTATE, "mxlo_graph_launch: a capture is open on this ctx's stream");
+    if (!ctx->switch_event) MXLO_HIP(hipEventCreateWithFlags(&ctx->switch_event, hipEventDisableTiming));
+    MXLO_HIP(hipEventRecord(ctx->switch_event, ctx->stream));
+    MXLO_HIP(hipStreamWaitEvent(g->stream, ctx->switch_event, 0));
+    rejoin.on = true;
+  }
   if (!g->chain.empty()) {
     for (const auto &st : g->chain) {
       if (st.is_memset) {
@@ -287,7 +356,7 @@ MXLO_API int32_t mxlo_ctx_sync(mxlo_ctx *ctx) {
   MXLO_REQUIRE(ctx, MXLO_EINVAL, "ctx is NULL");
   MXLO_DEVICE_GUARD(ctx);
   MXLO_HIP(hipStreamSynchronize(ctx->stream));
-  return MXLO_OK;
+  return fused_fault_check(ctx);      // a single-launch apply that timed out is reported here at the latest
 }
 
 MXLO_API int32_t mxlo_ctx_info(mxlo_ctx *ctx, int64_t info[4]) {
@@ -343,6 +412,12 @@ MXLO_API int32_t mxlo_ctx_tune(mxlo_ctx *ctx, const char *key, int64_t value) {
   } else if (!strcmp(key, "qn_fused_small")) {
     MXLO_REQUIRE(value == 0 || value == 1, MXLO_EINVAL, "qn_fused_small must be 0 or 1");
     ctx->tune.qn_fused_small = (int)value;
+  } else if (!strcmp(key, "fused_timeout_ms")) {
+    MXLO_REQUIRE(value >= 1 && value <= 600000, MXLO_EINVAL, "fused_timeout_ms must be in 1..600000");
+    ctx->tune.fused_timeout_ms = (int)value;
+  } else if (!strcmp(key, "fused_debug_drop")) {
+    MXLO_REQUIRE(value >= -1 && value < 4096, MXLO_EINVAL, "fused_debug_drop must be -1 (off) or a workgroup index");
+    ctx->tune.fused_debug_drop = (int)value;
   } else if (!strcmp(key, "push_wide")) {
     MXLO_REQUIRE(value == 0 || value == 1, MXLO_EINVAL, "push_wide must be 0 or 1");
     ctx->tune.push_wide = (int)value;

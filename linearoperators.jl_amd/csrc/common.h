@@ -138,6 +138,10 @@ struct Tune {
   int qn_fused_small = 1;  // quasi-Newton applies with <= 64 workgroups of dots: dots + finalize + coefficients in one launch
   int push_wide = 1;       // one-pass push!: 20 columns per pass while >= 20 remain (0: always <= 10)
   int push_fused = 1;      // push!(op, s, y): one-pass schedule (new pair held per lane, in-pass slot stores); 0 = copies + dual-x dots
+  int fused_timeout_ms = 2000;   // single-launch (grid-exchange) kernels: how long a workgroup polls for its peers' partials
+                                 // before it gives up, raises the ctx fault flag and stores NaN (a launch that is not fully
+                                 // co-resident — GPU shared with other processes, CU masking — ends instead of hanging)
+  int fused_debug_drop = -1;     // TEST HOOK: this workgroup of a single-launch kernel never publishes its partial
 };
 
 }  // namespace mxlo
@@ -152,6 +156,8 @@ struct mxlo_ctx {
   unsigned *ticket = nullptr;  // arrival counter of the fused (last-workgroup) finalize; zero between launches
   unsigned long long *xslots = nullptr;  // [2][kFusedSlots] partial-exchange slots + epoch word of the single-launch Householder
   unsigned long long *qslots = nullptr;  // [2][40 x 64] exchange slots + epoch word of the single-launch quasi-Newton apply (qn.hip)
+  unsigned *fault_host = nullptr;        // pinned, device-mapped word: a single-launch kernel that timed out on its exchange
+  unsigned *fault_dev = nullptr;         // stores its code here (system scope); the host reads it without synchronising
   mxlo_allreduce_fn allreduce = nullptr;
   void *allreduce_user = nullptr;
   void *scratch = nullptr;     // grow-on-demand workspace (opHermitian tile partials); owned by the ctx
@@ -182,6 +188,59 @@ struct DeviceGuard {
   DeviceGuard &operator=(const DeviceGuard &) = delete;
 };
 #define MXLO_DEVICE_GUARD(ctxexpr) mxlo::DeviceGuard dev_guard__((ctxexpr)->device)
+
+// ---- single-launch (grid-exchange) kernels: bounded wait + fault flag -----------------------------------------------
+// The workgroups of householder_fused_kernel / qn_apply_fused_kernel wait for each other's partials, so the whole grid
+// must be resident at once. The launch sites check that against the occupancy of the kernel (coresident()); what no
+// host-side check can see — other processes occupying the CUs, CU masking, a launch killed half-way that left the
+// slots inconsistent — is caught by the wait itself: a lane that has polled one slot for longer than
+// `fused_timeout_ms` raises the ctx fault word (pinned host memory, system-scope store) and continues with a NaN, so
+// the kernel ENDS with NaN results instead of hanging the GPU. The host looks at the word (a plain read of pinned
+// memory, no synchronisation) before every single-launch apply and inside mxlo_ctx_sync: fused_fault_check() then
+// re-arms the slots, switches the single-launch forms of the ctx off and returns MXLO_EHIP naming what happened.
+constexpr unsigned kFaultHouseholder = 1u, kFaultQn = 2u;
+constexpr unsigned long long kCanonicalNaN = 0x7FF8000000000000ull;
+int32_t fused_fault_check(mxlo_ctx *ctx);           // api_ctx.hip
+inline unsigned long long fused_timeout_ticks(const mxlo_ctx *ctx) {   // wall_clock64(): 100 MHz on gfx9-family parts
+  return (unsigned long long)ctx->tune.fused_timeout_ms * 100000ull;
+}
+#if defined(__HIPCC__)
+__device__ __forceinline__ unsigned long long poll_slot(const unsigned long long *slot, unsigned long long ticks,
+                                                        unsigned *fault, unsigned code) {
+  unsigned long long bits, t0 = 0;
+  unsigned it = 0;
+  while ((bits = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == kSlotEmpty) {
+    __builtin_amdgcn_s_sleep(1);
+    if ((++it & 255u) == 0) {                       // the clock is read once per 256 polls (each poll is a memory round trip)
+      const unsigned long long now = (unsigned long long)wall_clock64();
+      if (t0 == 0) t0 = now;
+      else if (now - t0 > ticks) {
+        __hip_atomic_store(fault, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        return kCanonicalNaN;
+      }
+    }
+  }
+  return bits;
+}
+#endif
+// true when `grid` workgroups of `kernel` (kBlock threads, `lds` bytes of dynamic LDS) fit on the device at once.
+// Evaluated once per kernel instantiation and device (the occupancy query costs microseconds).
+template <auto Kernel>
+inline bool coresident(mxlo_ctx *ctx, int64_t grid, size_t lds = 0) {
+  static std::atomic<int> cache[64];                // per kernel: blocks per CU + 1 by device ordinal, 0 = unknown
+  const int d = ctx->device & 63;
+  int per = cache[d].load(std::memory_order_relaxed);
+  if (per == 0) {
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, Kernel, kBlock, lds) != hipSuccess) {
+      (void)hipGetLastError();
+      nb = 0;
+    }
+    per = nb + 1;
+    cache[d].store(per, std::memory_order_relaxed);
+  }
+  return (int64_t)(per - 1) * ctx->num_cu >= grid;
+}
 
 // ---- 16-byte vector types --------------------------------------------------
 typedef double f64x2 __attribute__((ext_vector_type(2)));

@@ -241,7 +241,8 @@ namespace {
 template <typename T, typename CA, typename CB, bool BETA0, int VPT, bool ALIGNED>
 __global__ void __launch_bounds__(kBlock)
 householder_fused_kernel(T *__restrict__ res, const T *__restrict__ h, const T *__restrict__ v, int64_t n, CA alpha,
-                         CB beta, unsigned long long *__restrict__ slots) {
+                         CB beta, unsigned long long *__restrict__ slots, unsigned long long ticks,
+                         unsigned *__restrict__ fault, int drop) {
   constexpr int VEC = Vec16<T>::N;
   using V = typename Vec16<T>::type;
   const int tid = threadIdx.x, G = (int)gridDim.x, b = (int)blockIdx.x;
@@ -283,17 +284,13 @@ householder_fused_kernel(T *__restrict__ res, const T *__restrict__ h, const T *
   if (tid == 0) {
     const double s = (lds[0] + lds[1]) + (lds[2] + lds[3]);
     unsigned long long bits = (unsigned long long)__double_as_longlong(s);
-    if (s != s) bits = 0x7FF8000000000000ull;                        // canonical NaN: never the empty marker
-    __hip_atomic_store(mine + b, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (s != s) bits = kCanonicalNaN;                                // canonical NaN: never the empty marker
+    if (b != drop) __hip_atomic_store(mine + b, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  // wait for all G partials; lane t owns slot t (G <= 256 = one slot per lane)
+  // wait for all G partials; lane t owns slot t (G <= 256 = one slot per lane). The wait is bounded (poll_slot): a
+  // peer that never becomes resident turns into a NaN result and a raised ctx fault word, not into a hung GPU.
   double p = 0.0;
-  if (tid < G) {
-    unsigned long long bits;
-    while ((bits = __hip_atomic_load(mine + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == kSlotEmpty)
-      __builtin_amdgcn_s_sleep(1);
-    p = __longlong_as_double((long long)bits);
-  }
+  if (tid < G) p = __longlong_as_double((long long)poll_slot(mine + tid, ticks, fault, kFaultHouseholder));
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) p += __shfl_down(p, off, 64);
   __syncthreads();                                                     // lds reuse
@@ -333,13 +330,16 @@ static inline int64_t fused_grid(int64_t n, int vpt) {
 
 template <typename T>
 static int32_t householder_fused_t(mxlo_ctx *ctx, T *res, const T *h, const T *v, int64_t n, double alpha, double beta,
-                                   int32_t flags, int vpt) {
+                                   int32_t flags, int vpt, bool *launched) {
   const bool aligned = ((((uintptr_t)res) | ((uintptr_t)h) | ((uintptr_t)v)) & 15u) == 0;
   const int grid = (int)fused_grid<T>(n, vpt);
   return dispatch_ab<T>(beta, flags, [&]<typename CA, typename CB, bool B0>() -> int32_t {
+    bool fits = true;
     auto go = [&]<int VPT, bool AL>() {
+      if (!(fits = coresident<householder_fused_kernel<T, CA, CB, B0, VPT, AL>>(ctx, grid))) return;
       hipLaunchKernelGGL((householder_fused_kernel<T, CA, CB, B0, VPT, AL>), dim3(grid), dim3(kBlock), 0, ctx->stream,
-                         res, h, v, n, (CA)alpha, (CB)beta, ctx->xslots);
+                         res, h, v, n, (CA)alpha, (CB)beta, ctx->xslots, fused_timeout_ticks(ctx), ctx->fault_dev,
+                         ctx->tune.fused_debug_drop);
     };
     if (aligned) {
       if (vpt == 2) go.template operator()<2, true>();
@@ -350,6 +350,8 @@ static int32_t householder_fused_t(mxlo_ctx *ctx, T *res, const T *h, const T *v
       else if (vpt == 4) go.template operator()<4, false>();
       else go.template operator()<8, false>();
     }
+    *launched = fits;
+    if (!fits) return MXLO_OK;          // the grid would not be co-resident on this device: the caller takes two passes
     MXLO_LAUNCH_CHECK();
     return MXLO_OK;
   });
@@ -359,10 +361,17 @@ template <typename T>
 static int32_t householder_t(mxlo_ctx *ctx, T *res, const T *h, const T *v, int64_t n,
                              double alpha, double beta, int32_t flags) {
   // single launch: no all-reduce hook (its host callback sits between the two passes), every workgroup co-resident
-  if (ctx->tune.house_fused && !ctx->allreduce && n > 0) {
+  if (ctx->tune.house_fused && !ctx->allreduce && n > 0 && ctx->fault_dev) {
+    MXLO_TRY(fused_fault_check(ctx));   // an earlier single-launch apply that timed out is reported (and repaired) here
+  }
+  if (ctx->tune.house_fused && !ctx->allreduce && n > 0 && ctx->fault_dev) {
     const int64_t cap = std::min<int64_t>(ctx->num_cu, kFusedSlots);
     const int vpt = fused_grid<T>(n, 2) <= 16 ? 2 : (fused_grid<T>(n, 4) <= 32 ? 4 : 8);
-    if (fused_grid<T>(n, vpt) <= cap) return householder_fused_t<T>(ctx, res, h, v, n, alpha, beta, flags, vpt);
+    if (fused_grid<T>(n, vpt) <= cap) {
+      bool launched = false;
+      const int32_t st = householder_fused_t<T>(ctx, res, h, v, n, alpha, beta, flags, vpt, &launched);
+      if (st != MXLO_OK || launched) return st;
+    }
   }
   const T *cols[1] = {h};
   if (!ctx->allreduce && n >= 1 && n <= ctx->tune.house_inline_n) {

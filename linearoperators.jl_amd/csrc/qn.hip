@@ -651,7 +651,8 @@ struct QnfArgs {
 template <typename T, typename CA, typename CB, int KIND, bool BETA0>
 __global__ void __launch_bounds__(kBlock)
 qn_apply_fused_kernel(T *__restrict__ res, QnfCols<T> cols, const T *__restrict__ x, int64_t n,
-                      unsigned long long *__restrict__ slots, QnfArgs F, OrdArgs O) {
+                      unsigned long long *__restrict__ slots, QnfArgs F, OrdArgs O, unsigned long long ticks,
+                      unsigned *__restrict__ fault, int drop) {
   constexpr int VEC = Vec16<T>::N, U = 4;
   using V = typename Vec16<T>::type;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, G = (int)gridDim.x, b = (int)blockIdx.x;
@@ -739,16 +740,14 @@ qn_apply_fused_kernel(T *__restrict__ res, QnfCols<T> cols, const T *__restrict_
   if (tid < ncol) {
     const double sv = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
     unsigned long long bits = (unsigned long long)__double_as_longlong(sv);
-    if (sv != sv) bits = 0x7FF8000000000000ull;                       // canonical NaN: never the empty marker
-    __hip_atomic_store(mine + tid * kQnfMaxGrid + b, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (sv != sv) bits = kCanonicalNaN;                               // canonical NaN: never the empty marker
+    if (b != drop) __hip_atomic_store(mine + tid * kQnfMaxGrid + b, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   // ---- 3. gather: every (column, workgroup) slot is polled by exactly one lane; all polls of a lane are in flight together
   for (int p = tid; p < ncol * G; p += kBlock) {
     const int c = p / G, w = p - c * G;
-    unsigned long long bits;
-    while ((bits = __hip_atomic_load(mine + c * kQnfMaxGrid + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == kSlotEmpty)
-      __builtin_amdgcn_s_sleep(1);
-    spart[c * kQnfMaxGrid + w] = __longlong_as_double((long long)bits);
+    // bounded wait (poll_slot, common.h): a peer that never becomes resident ends as NaN + the ctx fault word
+    spart[c * kQnfMaxGrid + w] = __longlong_as_double((long long)poll_slot(mine + c * kQnfMaxGrid + w, ticks, fault, kFaultQn));
   }
   __syncthreads();
   if (b == 0 && tid == 0)                                             // every workgroup has read e: flip for the next launch
@@ -898,25 +897,29 @@ bool try_fused_apply(mxlo_qn *h, T *res, const T *const *cols, const T *x, QnfAr
   const int64_t per = (int64_t)kBlock * U * VEC;
   const int64_t grid = (h->n + per - 1) / per;
   if (!ctx->tune.qn_fused_small || ctx->allreduce || F.ncol < 1 || F.ncol > kQnfMaxCols || grid > kQnfMaxGrid ||
-      grid > ctx->num_cu || !ctx->qslots || ((((uintptr_t)x) | ((uintptr_t)res)) & 15u) != 0)
+      grid > ctx->num_cu || !ctx->qslots || !ctx->fault_dev || ((((uintptr_t)x) | ((uintptr_t)res)) & 15u) != 0)
     return false;
+  if ((*status = fused_fault_check(ctx)) != MXLO_OK) return true;    // an earlier timed-out single-launch apply: reported here
   QnfCols<T> fc;
   for (int c = 0; c < F.ncol; ++c) {
     if ((((uintptr_t)cols[c]) & 15u) != 0) return false;
     fc.p[c] = cols[c];
   }
+  bool fits = true;
   *status = dispatch_ab<T>(F.beta, flags, [&]<typename CA, typename CB, bool B0>() -> int32_t {
     auto go = [&]<int KIND>() {
+      if (!(fits = coresident<qn_apply_fused_kernel<T, CA, CB, KIND, B0>>(ctx, grid))) return;
       hipLaunchKernelGGL((qn_apply_fused_kernel<T, CA, CB, KIND, B0>), dim3((unsigned)grid), dim3(kBlock), 0, ctx->stream, res,
-                         fc, x, h->n, ctx->qslots, F, O);
+                         fc, x, h->n, ctx->qslots, F, O, fused_timeout_ticks(ctx), ctx->fault_dev, ctx->tune.fused_debug_drop);
     };
     if (F.kind == MXLO_QN_LBFGS_INV) go.template operator()<MXLO_QN_LBFGS_INV>();
     else if (F.kind == MXLO_QN_LBFGS_FWD) go.template operator()<MXLO_QN_LBFGS_FWD>();
     else go.template operator()<MXLO_QN_LSR1>();
+    if (!fits) return MXLO_OK;          // not co-resident on this device: the four-launch apply runs instead
     MXLO_LAUNCH_CHECK();
     return MXLO_OK;
   });
-  return true;
+  return fits;
 }
 
 // ---- applies ------------------------------------------------------------------------------

@@ -517,8 +517,16 @@ def BlockDiagonalOperator(*ops, S: Optional[Storage] = None):
 
 
 # ----------------------------------------------------------------------------- kron
-def kron(A, B):
+def kron(A, B, *, complex_form=None):
     """kron(A, B) — src/kron.jl:10-49: (A ⊗ B) x = vec(B X Aᵀ).
+
+    `complex_form` (complex element types only; ignored for real factors): how a complex product is spelled in real
+    MFMA GEMMs. `"gauss"` (default) = 3 real GEMMs per complex product (`mxlo_kron_mul_c3`); it is NORMWISE stable
+    only — the error of each component of K·x is bounded relative to ‖K‖·‖x‖, so a real or imaginary part that is
+    tiny next to the other one loses relative accuracy (the reference's own criterion, `test/test_kron.jl:35`:
+    1e-12·‖K‖₁, is normwise and is met). `"4gemm"` = the textbook 4 real GEMMs (`mxlo_kron_mul_c`), componentwise
+    accurate like the reference's complex arithmetic, ≈ 25 % slower at 1024². `None` reads the process default from
+    `MXLO_KRON_GAUSS` (unset / "1" → "gauss", "0" → "4gemm").
 
     The reference rebuilds a composite operator and materialises it with `m` single-vector products on
     every apply. Here an apply is two MFMA GEMMs on dense device matrices: matrix factors are aliased in place
@@ -564,7 +572,7 @@ def kron(A, B):
     fA, fB = _KronFactor(A), _KronFactor(B)
     T = torch.promote_types(fA.dtype, fB.dtype)
     if T.is_complex:
-        return _kron_complex(A, B, fA, fB, T)
+        return _kron_complex(A, B, fA, fB, T, complex_form)
     dtype_code(T)
     fA.T, fB.T = T, T
     m, n = fA.shape
@@ -591,7 +599,7 @@ def kron(A, B):
     return op
 
 
-def _kron_complex(A, B, fA, fB, T):
+def _kron_complex(A, B, fA, fB, T, complex_form=None):
     """kron with at least one complex factor (test/test_kron.jl:3-8: Float64 A, ComplexF64 B). The apply works on real
     PLANES: a complex factor is split into (re, im) column-major planes once (refreshed when its state token changes),
     a real factor is aliased as it is with no imaginary plane; every complex product is then 4 (2) real MFMA GEMMs
@@ -637,10 +645,14 @@ def _kron_complex(A, B, fA, fB, T):
             return out
 
     pA, pB = Planes(fA), Planes(fB)
-    # Gauss form (3 real GEMMs per complex product, `mxlo_kron_mul_c3`) by default; MXLO_KRON_GAUSS=0 keeps the 4-GEMM
-    # form (`mxlo_kron_mul_c`), which the tests use as the independent device implementation. The workspace covers the
-    # forward and the transposed shapes of both forms.
-    gauss = os.environ.get("MXLO_KRON_GAUSS", "1") != "0"
+    # Gauss form (3 real GEMMs per complex product, `mxlo_kron_mul_c3`, normwise stable) by default; the 4-GEMM form
+    # (`mxlo_kron_mul_c`, componentwise) by `complex_form="4gemm"` or MXLO_KRON_GAUSS=0 — the tests use it as the
+    # independent device implementation. The workspace covers the forward and the transposed shapes of both forms.
+    if complex_form is None:
+        complex_form = "gauss" if os.environ.get("MXLO_KRON_GAUSS", "1") != "0" else "4gemm"
+    if complex_form not in ("gauss", "4gemm"):
+        raise ValueError(f'kron: complex_form must be "gauss" or "4gemm", got {complex_form!r}')
+    gauss = complex_form == "gauss"
     wsz = _lib.lib().mxlo_kron_c3_work_size
     need = max(int(wsz(m, n, 0, p, q, 0)), int(wsz(m, n, 1, p, q, 1)),
                2 * (max(q * n, p * m) + max(m * q, n * p) + max(p * m, q * n)) + 24)
@@ -667,6 +679,7 @@ def _kron_complex(A, B, fA, fB, T):
     op = LinearOperator(T, m * p, n * q, fA.symmetric and fB.symmetric, fA.hermitian and fB.hermitian, prod, tprod,
                         ctprod, S=Storage(T, dev))
     op._deps = (A, B)
+    op.complex_form = complex_form
     return op
 
 

@@ -405,19 +405,44 @@ def conj_into(res, v):
 
 
 # ----------------------------------------------------------------------------- operator state versions
-try:                                   # torch.autograd.graph.increment_version minus its isinstance / tuple wrapping
-    _increment_version = torch._C._increment_version
-except AttributeError:                 # pragma: no cover
-    _increment_version = lambda ts: torch.autograd.graph.increment_version(ts[0])
+def _probe_increment_version():
+    """Pick the version-bump primitive ONCE, by observing its effect: `torch._C._increment_version` takes an iterable
+    of tensors on current torch and a single tensor on older releases; the public wrapper
+    `torch.autograd.graph.increment_version` is the last resort. A candidate is accepted only if the probe tensor's
+    `_version` really advanced, so a signature change can never silently stop the bumps (kron planes and the
+    factor-sum caches key on them)."""
+    probe = torch.zeros(1)
+    candidates = []
+    raw = getattr(torch._C, "_increment_version", None)
+    if raw is not None:
+        candidates += [lambda t, raw=raw: raw((t,)), lambda t, raw=raw: raw(t)]
+    pub = getattr(getattr(torch.autograd, "graph", None), "increment_version", None)
+    if pub is not None:
+        candidates.append(pub)
+    for f in candidates:
+        v0 = probe._version
+        try:
+            f(probe)
+        except Exception:
+            continue
+        if probe._version > v0:
+            return f
+    raise ImportError("linearoperators_jl_amd: no working tensor version-bump primitive in this torch build "
+                      "(torch._C._increment_version / torch.autograd.graph.increment_version)")
+
+
+_increment_version = _probe_increment_version()
 
 
 def touched(t: torch.Tensor):
     """libmxlo writes through raw pointers, which torch's in-place version counter does not see: bump it by hand so
-    that operators built on `t` (and kron factors materialised from them) notice the change."""
+    that operators built on `t` (and kron factors materialised from them) notice the change. Only inference
+    tensors (which carry no version counter) are exempt; any other failure propagates."""
     try:
-        _increment_version((t,))
-    except Exception:      # pragma: no cover  (inference tensors etc.)
-        pass
+        _increment_version(t)
+    except RuntimeError:
+        if not t.is_inference():
+            raise
     return t
 
 

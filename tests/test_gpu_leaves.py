@@ -5,6 +5,7 @@ Tolerances: elementwise leaves (opDiagonal, opEye, opZeros, scale, restriction/e
 BIT-EXACT; leaves with a global reduction (opHouseholder, opOnes) 1e-12 relative L2 in fp64 and
 1e-5 in fp32 (fixed-order tree vs the oracle's / BLAS' order)."""
 import os
+import time
 
 import numpy as np
 import pytest
@@ -568,3 +569,82 @@ def test_householder_update_pass_summing_the_partials_is_bit_identical(lo, dev, 
                     assert torch.equal(got[1 << 23], got[0]), (n, off, a, b)
     finally:
         ctx.tune("house_inline_n", 1 << 23)
+
+
+def test_single_launch_householder_timeout_is_an_error_not_a_hang(lo, dev):
+    """the workgroups of the single-launch apply wait for each other. If one of them never publishes
+    (not co-resident: GPU shared, CU masking; here: the `fused_debug_drop` test hook), the wait must END — NaN result,
+    ctx fault word raised — and the next call must say so, repair the exchange state and leave the ctx usable."""
+    from linearoperators_jl_amd.device import get_ctx
+    ctx = get_ctx(dev)
+    rng = np.random.default_rng(17)
+    n = 1 << 16
+    h = rng.standard_normal(n)
+    h /= np.linalg.norm(h)
+    v = rng.uniform(-1, 1, n)
+    H = lo.opHouseholder(torch.from_numpy(h).to(dev))
+    dv = torch.from_numpy(v).to(dev)
+    res = torch.zeros(n, dtype=torch.float64, device=dev)
+    want = oracle.householder_mul(np.empty(n), h, v, 1.0, 0.0)
+    try:
+        lo.mul(res, H, dv, 1.0, 0.0)
+        torch.cuda.synchronize()
+        assert rel(res.cpu().numpy(), want) <= 1e-12
+        ctx.tune("fused_timeout_ms", 20)
+        ctx.tune("fused_debug_drop", 1)
+        t0 = time.perf_counter()
+        lo.mul(res, H, dv, 1.0, 0.0)                 # the launch itself succeeds; its workgroups give up after ~20 ms
+        torch.cuda.synchronize()
+        assert time.perf_counter() - t0 < 5.0
+        assert bool(torch.isnan(res).all()), "a timed-out single-launch apply must not leave plausible numbers behind"
+        ctx.tune("fused_debug_drop", -1)
+        with pytest.raises(Exception, match="timed out"):
+            lo.mul(res, H, dv, 1.0, 0.0)             # reported (and repaired) at the next single-launch apply
+        lo.mul(res, H, dv, 1.0, 0.0)                 # single-launch forms are off now: two passes
+        torch.cuda.synchronize()
+        assert rel(res.cpu().numpy(), want) <= 1e-12
+        ctx.tune("house_fused", 1)                   # the exchange slots were re-armed: the single launch works again
+        for _ in range(5):
+            res.zero_()
+            lo.mul(res, H, dv, 1.0, 0.0)
+        torch.cuda.synchronize()
+        assert rel(res.cpu().numpy(), want) <= 1e-12
+        # the same fault is also reported by mxlo_ctx_sync when no further apply follows
+        ctx.tune("fused_debug_drop", 0)
+        lo.mul(res, H, dv, 1.0, 0.0)
+        with pytest.raises(Exception, match="timed out"):
+            ctx.sync()
+        ctx.tune("fused_debug_drop", -1)
+        ctx.tune("house_fused", 1)
+        lo.mul(res, H, dv, 1.0, 0.0)
+        ctx.sync()
+        assert rel(res.cpu().numpy(), want) <= 1e-12
+    finally:
+        ctx.tune("fused_debug_drop", -1)
+        ctx.tune("fused_timeout_ms", 2000)
+        ctx.tune("house_fused", 1)
+        ctx.tune("qn_fused_small", 1)
+
+
+def test_graph_replay_on_its_capture_stream_is_ordered_with_the_ctx_stream(lo, dev):
+    """ADVICE r3 #1 (second half): a captured single-launch apply replays on the stream it was captured from, while the
+    ctx may meanwhile issue direct single-launch applies on another stream — both use the ctx's one set of exchange
+    slots. `mxlo_graph_launch` orders the two streams itself (event both ways), so the caller need not."""
+    from linearoperators_jl_amd.graph import capture_mul
+    rng = np.random.default_rng(23)
+    ops = []
+    for n in (1 << 15, 50_000):
+        h = rng.standard_normal(n)
+        h /= np.linalg.norm(h)
+        v = rng.uniform(-1, 1, n)
+        ops.append((lo.opHouseholder(torch.from_numpy(h).to(dev)), torch.from_numpy(v).to(dev),
+                    torch.empty(n, dtype=torch.float64, device=dev), h, v))
+    (H0, v0, r0, h0, x0), (H1, v1, r1, h1, x1) = ops
+    g = capture_mul(r0, H0, v0, 3.0, 0.0)
+    torch.cuda.synchronize()
+    for it in range(2000):
+        g.replay(sync_streams=False)                 # on the capture stream
+        lo.mul(r1, H1, v1, 1.0 + it, 0.0)            # on torch's current stream
+    torch.cuda.synchronize()
+    assert rel(r0.cpu().numpy(), oracle.householder_mul(np.empty(h0.size), h0, x0, 3.0, 0.0)) <= 1e-12
+    assert rel(r1.cpu().numpy(), oracle.householder_mul(np.empty(h1.size), h1, x1, 2000.0, 0.0)) <= 1e-12

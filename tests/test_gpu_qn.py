@@ -898,3 +898,45 @@ def test_single_launch_apply_exchange_stress(lo, dev):
             assert (torch.linalg.vector_norm((res - first).double()) / torch.linalg.vector_norm(first.double())).item() <= tol
     finally:
         ctx.tune("qn_fused_small", 1)
+
+
+@pytest.mark.parametrize("kind", ["inv", "fwd", "lsr1"])
+def test_single_launch_apply_timeout_is_an_error_not_a_hang(lo, dev, kind):
+    """the single-launch quasi-Newton apply must END when a peer workgroup never publishes (test hook
+    `fused_debug_drop`): NaN result, ctx fault word, an error naming the timeout at the next call, exchange state
+    re-armed, the ctx usable afterwards (four launches), and the single launch usable again once re-enabled."""
+    from linearoperators_jl_amd.device import get_ctx
+    ctx = get_ctx(dev)
+    rng = np.random.default_rng(5)
+    n, mem = 20_000, 4                                   # 10 workgroups
+    make = {"inv": lo.InverseLBFGSOperator, "fwd": lo.LBFGSOperator, "lsr1": lo.LSR1Operator}[kind]
+    op = make(torch.float64, n, mem=mem, device=dev)
+    for s, y in pairs(rng, n, mem + 1, np.float64):
+        lo.push(op, T(s, dev), T(y, dev))
+    x = T(rng.uniform(-1, 1, n), dev)
+    res = torch.zeros(n, dtype=torch.float64, device=dev)
+    try:
+        lo.mul(res, op, x, 1.0, 0.0)
+        torch.cuda.synchronize()
+        good = res.clone()
+        ctx.tune("fused_timeout_ms", 20)
+        ctx.tune("fused_debug_drop", 3)
+        lo.mul(res, op, x, 1.0, 0.0)
+        torch.cuda.synchronize()
+        assert bool(torch.isnan(res).any())
+        ctx.tune("fused_debug_drop", -1)
+        with pytest.raises(Exception, match="timed out"):
+            lo.mul(res, op, x, 1.0, 0.0)
+        lo.mul(res, op, x, 1.0, 0.0)                     # four launches now
+        torch.cuda.synchronize()
+        assert float((res - good).norm() / good.norm()) <= 1e-13
+        ctx.tune("qn_fused_small", 1)
+        for _ in range(4):
+            lo.mul(res, op, x, 1.0, 0.0)
+        torch.cuda.synchronize()
+        assert torch.equal(res, good)                    # the re-armed single launch is bit-identical to the first one
+    finally:
+        ctx.tune("fused_debug_drop", -1)
+        ctx.tune("fused_timeout_ms", 2000)
+        ctx.tune("house_fused", 1)
+        ctx.tune("qn_fused_small", 1)

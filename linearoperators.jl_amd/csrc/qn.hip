@@ -1541,6 +1541,26 @@ int32_t lbfgs_push_common(mxlo_qn *h, const T *s, const T *y, double ys, double 
 // Nothing of the operator's state is written before the decision (pass A's rows go to scratch), so a rejected pair
 // leaves the operator untouched exactly like the reference.
 inline int32_t push_schedule_agree(mxlo_qn *h, bool local_ok, bool *all_ok);
+
+// The streaming push! schedules read the caller's s and y WHILE kernels store into S[:,ins], Y[:,ins], B[:,ins] and the
+// a_k panel (the copy-based schedules copied the pair into its slots first, so any aliasing was harmless there). A pair
+// that lives inside the operator's own storage — a view of a column handed out by mxlo_qn_column, the tmp vectors —
+// would race: such calls take the copy-based schedule.
+template <typename T>
+inline bool pair_aliases_handle(const mxlo_qn *h, const T *s, const T *y) {
+  const size_t vb = sizeof(T) * (size_t)h->n, pb = sizeof(T) * (size_t)h->ld * (size_t)h->mem, tb = sizeof(T) * (size_t)h->ld;
+  auto hit = [](const void *p, size_t pbytes, const void *q, size_t qbytes) {
+    const uintptr_t a = (uintptr_t)p, b = (uintptr_t)q;
+    return p && q && pbytes && qbytes && a < b + qbytes && b < a + pbytes;
+  };
+  for (const T *v : {s, y}) {
+    for (const void *panel : {h->S, h->Y, h->A, h->B})
+      if (hit(v, vb, panel, pb)) return true;
+    if (hit(v, vb, h->tmp, tb) || hit(v, vb, h->tmp2, tb)) return true;
+  }
+  return false;
+}
+
 template <typename T>
 int32_t lbfgs_push_fused(mxlo_qn *h, const T *s, const T *y, int32_t *accepted) {
   mxlo_ctx *ctx = h->ctx;
@@ -1626,7 +1646,8 @@ int32_t lbfgs_push(mxlo_qn *h, const T *s, const T *y, int32_t *accepted) {
       !(h->kind == MXLO_QN_LBFGS_FWD && (h->push_mode == MXLO_PUSH_REFORDER || !h->gram_ok))) {
     // (row-sharded: an empty or differently aligned shard on ONE rank must not send the ranks down different schedules)
     bool all_ok = false;
-    MXLO_TRY(push_schedule_agree(h, (ctx->allreduce || h->n >= 1) && ((((uintptr_t)s) | ((uintptr_t)y)) & 15u) == 0, &all_ok));
+    MXLO_TRY(push_schedule_agree(h, (ctx->allreduce || h->n >= 1) && ((((uintptr_t)s) | ((uintptr_t)y)) & 15u) == 0 &&
+                                        !pair_aliases_handle<T>(h, s, y), &all_ok));
     if (all_ok) return lbfgs_push_fused<T>(h, s, y, accepted);
   }
   double *misc = h->dsc + h->lay.misc;
@@ -1768,6 +1789,37 @@ bool lsr1_accepts(const mxlo_qn *h, double ys_d, double ss_d, double ymBs_s_d, d
   return well_defined && sufficient_curvature && scaling_condition;                        // :145-149
 }
 
+// true when one of the tests lsr1_accepts evaluates could come out differently under the rounding of another evaluation
+// order. The streaming schedule forms r = y - B s with a_k's taken from the Gram data (Cm [Y's; S's]) instead of dots on
+// the stored a_k panel; both are exact in exact arithmetic, but r's = y's - s'B s is a cancellation whose ABSOLUTE error is
+// of the order eps (|y| + |B s|) |s| whatever the size of the result, while the thresholds of src/lsr1.jl:131-141 are of the
+// order eps: a pair the memory (nearly) reproduces has an r that is rounding noise, and its accept / reject is decided by
+// that noise — differently in the two schedules, after which insert and ys diverge for good. A test counts as decided
+// only when its left-hand side clears the threshold by 2^8 times that error budget; everything else is re-evaluated by
+// the apply-based schedule (nothing but scratch has been written at that point). The scalars are all-reduced, so every
+// rank of a sharded operator takes the same route. Pairs an optimiser normally produces are far outside the band.
+template <typename T>
+bool lsr1_decision_is_marginal(const mxlo_qn *h, double ys_d, double ss_d, double ymBs_s_d, double yy_d, double ymBs2_d,
+                               double t2_d) {
+  const double K = 256.0, eps = (double)eps_of<T>();
+  const double sN = std::sqrt(ss_d), yN = std::sqrt(yy_d), rN = std::sqrt(ymBs2_d);
+  if (!(std::isfinite(sN) && std::isfinite(yN) && std::isfinite(rN) && std::isfinite(ymBs_s_d) && std::isfinite(ys_d)))
+    return true;      // NaN / Inf: an operator blown up by ill-conditioned pairs can overflow in the Gram-form coefficients
+                      // where the stored a_k's still give finite dots (or the reverse) — let the apply-based schedule decide
+  const double budget = K * eps * ((2.0 * yN + rN) * sN + 1.0);   // |B s| <= |y| + |r|
+  if (std::fabs(ymBs_s_d) <= (eps + eps * rN * sN) + budget) return true;                     // :131
+  if (h->scaling) {
+    const double thr = eps * yN * sN;
+    if (std::fabs(ys_d) <= thr * (1.0 + K)) return true;                                      // :137
+    const double t = std::sqrt(t2_d);                                                         // |y - s/sf|, sf = ys/yy
+    if (!std::isfinite(t) || t <= thr + K * eps * (yN + sN * yy_d / std::fabs(ys_d))) return true;   // :141
+  }
+  return false;
+}
+
+template <typename T>
+int32_t lsr1_push_copies(mxlo_qn *h, const T *s, const T *y, int32_t *accepted);
+
 template <typename T>
 int32_t lsr1_push_fused(mxlo_qn *h, const T *s, const T *y, int32_t *accepted) {
   mxlo_ctx *ctx = h->ctx;
@@ -1839,6 +1891,8 @@ int32_t lsr1_push_fused(mxlo_qn *h, const T *s, const T *y, int32_t *accepted) {
   }
   double hs[6];
   MXLO_TRY(read_scalars(h, misc, hs, 6));   // the push's one device-to-host copy (48 bytes)
+  if (lsr1_decision_is_marginal<T>(h, hs[0], hs[1], hs[3], hs[2], hs[4], hs[5]))
+    return lsr1_push_copies<T>(h, s, y, accepted);      // nothing but scratch has been written so far
   if (!lsr1_accepts<T>(h, hs[0], hs[1], hs[3], hs[2], hs[4], hs[5])) {
     *accepted = 0;
     return MXLO_OK;
@@ -1890,12 +1944,22 @@ int32_t lsr1_push_fused(mxlo_qn *h, const T *s, const T *y, int32_t *accepted) {
 template <typename T>
 int32_t lsr1_push(mxlo_qn *h, const T *s, const T *y, int32_t *accepted) {
   mxlo_ctx *ctx = h->ctx;
-  const int64_t n = h->n, mem = h->mem;
+  const int64_t n = h->n;
   if (ctx->tune.push_fused && !h->big && h->push_mode == MXLO_PUSH_GRAM && h->gram_ok) {
     bool all_ok = false;
-    MXLO_TRY(push_schedule_agree(h, (ctx->allreduce || n >= 1) && ((((uintptr_t)s) | ((uintptr_t)y)) & 15u) == 0, &all_ok));
+    MXLO_TRY(push_schedule_agree(h, (ctx->allreduce || n >= 1) && ((((uintptr_t)s) | ((uintptr_t)y)) & 15u) == 0 &&
+                                        !pair_aliases_handle<T>(h, s, y), &all_ok));
     if (all_ok) return lsr1_push_fused<T>(h, s, y, accepted);
   }
+  return lsr1_push_copies<T>(h, s, y, accepted);
+}
+
+// the apply-based schedule: r = y - B s through lsr1_mul into tmp, decision dots on the stored vectors, the pair copied into
+// its slots before the rebuild (also what a marginal decision or an aliased pair of the streaming schedule falls back to)
+template <typename T>
+int32_t lsr1_push_copies(mxlo_qn *h, const T *s, const T *y, int32_t *accepted) {
+  mxlo_ctx *ctx = h->ctx;
+  const int64_t n = h->n, mem = h->mem;
   T *ymBs = (T *)h->tmp;
   MXLO_HIP(hipMemcpyAsync(ymBs, y, sizeof(T) * n, hipMemcpyDeviceToDevice, ctx->stream));  // :124
   if (h->big) MXLO_TRY(lsr1_mul_big<T>(h, ymBs, s, -1.0, 1.0, 0, 0.0));                    // :125

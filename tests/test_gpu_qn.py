@@ -940,3 +940,133 @@ def test_single_launch_apply_timeout_is_an_error_not_a_hang(lo, dev, kind):
         ctx.tune("fused_timeout_ms", 2000)
         ctx.tune("house_fused", 1)
         ctx.tune("qn_fused_small", 1)
+
+
+@pytest.mark.parametrize("kind", ["inv", "fwd", "lsr1"])
+def test_push_of_a_pair_that_lives_in_the_operators_own_storage(lo, dev, kind):
+    """the streaming push! schedules read the caller's s and y while kernels store into the slot being
+    replaced (and, L-SR1, while the rebuild rewrites the a_k panel). A pair that is a VIEW of the operator's own panels
+    (`mxlo_qn_column`) must therefore take the copy-based schedule — detected on the host by address overlap. Pushing
+    column views, including the very slot that is about to be overwritten, must give what pushing private copies of
+    the same data gives."""
+    rng = np.random.default_rng(31)
+    n, mem = 6_004, 3
+    make = {"inv": lo.InverseLBFGSOperator, "fwd": lo.LBFGSOperator, "lsr1": lo.LSR1Operator}[kind]
+    A, B = make(torch.float64, n, mem=mem, device=dev), make(torch.float64, n, mem=mem, device=dev)
+    for s, y in pairs(rng, n, mem, np.float64):
+        lo.push(A, T(s, dev), T(y, dev))
+        lo.push(B, T(s, dev), T(y, dev))
+    x = T(rng.uniform(-1, 1, n), dev)
+    for step in range(2 * mem):
+        ins = A.data.insert - 1                               # 0-based slot the next push overwrites
+        k = (ins + step) % mem                                # step % mem == 0: the slot that is being replaced
+        sv, yv = A.data.column("s", k), A.data.column("y", k)
+        # a new pair built from stored columns: s from the panel (a view), y = stored y + a little of s (private copy)
+        ynew = (B.data.column("y", k) + 0.125 * B.data.column("s", k)).clone()
+        ypriv = ynew.clone()
+        spriv = B.data.column("s", k).clone()
+        lo.push(A, sv, ynew)                                  # s aliases A's own S panel
+        lo.push(B, spriv, ypriv)
+        assert A._last_push_accepted == B._last_push_accepted, step
+        ra, rb = torch.empty_like(x), torch.empty_like(x)
+        lo.mul(ra, A, x, 1.0, 0.0)
+        lo.mul(rb, B, x, 1.0, 0.0)
+        assert float((ra - rb).norm() / rb.norm()) <= 1e-11, (kind, step)
+        for which in ("s", "y"):
+            for slot in range(mem):
+                assert torch.equal(A.data.column(which, slot), B.data.column(which, slot)), (kind, step, which, slot)
+        del yv
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("scaling", [True, False])
+def test_lsr1_streaming_push_decisions_agree_with_the_apply_based_schedule(lo, dev, dtype, scaling):
+    """the streaming L-SR1 push forms r = y - B s with a_k's from the Gram data; its rounding differs from
+    the apply-based evaluation, and r's = y's - s'B s is a cancellation whose absolute error is ~ eps (|y| + |B s|) |s|
+    while the thresholds of src/lsr1.jl:131-141 are ~ eps: for a pair the memory (nearly) reproduces the decision is made
+    by rounding noise. The library therefore re-evaluates every push that does not clear its thresholds by 2^8 error
+    budgets with the apply-based schedule (`lsr1_decision_is_marginal`). Checked here on sequences rich in borderline
+    pushes (the same pair again, y = B s + 1e-15 … 1e-6, y nearly orthogonal / parallel to s): whenever a push is decided
+    — by a margin computed independently in the test — `push_fused` 1 and 0 take the same decision and keep the same
+    insert position; inside the noise band either decision is legitimate (the reference's own depends on its BLAS's
+    summation order), so there the two operators are only required to stay usable, and are reset if they part ways."""
+    from linearoperators_jl_amd.device import get_ctx
+    ctx = get_ctx(dev)
+    npd = NP[dtype]
+    eps = float(np.finfo(npd).eps)
+    same = 1e-9 if dtype == torch.float64 else 2e-3
+    decided = gray = 0
+    try:
+        for seed in range(12):
+            rng = np.random.default_rng(900 + seed)
+            n, mem = int(rng.integers(200, 5000)) * 2, int(rng.integers(2, 8))
+            ops = {}
+            for fused in (1, 0):
+                ctx.tune("push_fused", fused)
+                ops[fused] = lo.LSR1Operator(dtype, n, mem=mem, scaling=scaling, device=dev)
+            hist = []
+            tainted = False                                    # a pair decided by noise sits in one of the memories
+            for k in range(3 * mem + 6):
+                c = int(rng.integers(0, 7))
+                s = rng.uniform(-1, 1, n).astype(npd)
+                if c <= 1 or not hist:
+                    y = ((0.5 + 1.5 * rng.random(n)) * s + 1e-2 * rng.standard_normal(n)).astype(npd)
+                elif c == 2:                                   # the same pair again: r is rounding noise
+                    s, y = hist[int(rng.integers(len(hist)))]
+                elif c == 3:                                   # y = B s (+ a perturbation from 1e-15 to 1e-6): r tiny
+                    Bs = torch.empty(n, dtype=dtype, device=dev)
+                    lo.mul(Bs, ops[0], T(s, dev), 1.0, 0.0)
+                    y = (Bs.cpu().numpy() + npd(10.0 ** rng.uniform(-15, -6)) * rng.standard_normal(n).astype(npd)).astype(npd)
+                elif c == 4:                                   # y almost orthogonal to s
+                    y = rng.standard_normal(n).astype(npd)
+                    y = (y - (y @ s) / (s @ s) * s * npd(1.0 - 10.0 ** rng.uniform(-16, -3))).astype(npd)
+                elif c == 5:                                   # y almost parallel to s
+                    y = (npd(2.5) * s + npd(10.0 ** rng.uniform(-16, -4)) * rng.standard_normal(n).astype(npd)).astype(npd)
+                else:                                          # y orthogonal to s up to a few eps: y's ≈ eps |y||s| (:137)
+                    y = rng.standard_normal(n).astype(npd)
+                    y = (y - (y @ s) / (s @ s) * s).astype(npd)
+                    y = (y + npd(eps * 10.0 ** rng.uniform(-1, 2)) * np.sqrt(y @ y / (s @ s)).astype(npd) * s).astype(npd)
+                # independent margin (float64 on the host, r through the apply-based operator)
+                Bs = torch.empty(n, dtype=dtype, device=dev)
+                lo.mul(Bs, ops[0], T(s, dev), 1.0, 0.0)
+                s64, y64 = s.astype(np.float64), y.astype(np.float64)
+                with np.errstate(all="ignore"):
+                    r64 = y64 - Bs.cpu().numpy().astype(np.float64)
+                sN, yN, rN = np.linalg.norm(s64), np.linalg.norm(y64), np.linalg.norm(r64)
+                budget = 256 * eps * ((2 * yN + rN) * sN + 1)
+                clear = np.isfinite(rN) and abs(r64 @ s64) > 16 * ((eps + eps * rN * sN) + budget)
+                if scaling and clear:
+                    ys, yy = y64 @ s64, y64 @ y64
+                    thr = eps * yN * sN
+                    clear = abs(ys) > 16 * thr * 257 and \
+                        np.linalg.norm(y64 - s64 * (yy / ys)) > 16 * (thr + 256 * eps * (yN + sN * yy / abs(ys)))
+                acc = {}
+                for fused in (1, 0):
+                    ctx.tune("push_fused", fused)
+                    lo.push(ops[fused], T(s, dev), T(y, dev))
+                    acc[fused] = ops[fused]._last_push_accepted
+                if clear:
+                    decided += 1
+                    assert acc[1] == acc[0], (seed, k, c, acc)
+                    assert ops[1].data.insert == ops[0].data.insert
+                else:
+                    gray += 1
+                    if acc[1] != acc[0]:                       # noise decided differently: legitimate, start over
+                        for fused in (1, 0):
+                            lo.reset(ops[fused])
+                        hist = []
+                        tainted = False
+                        continue
+                    tainted = tainted or acc[1]
+                if acc[1]:
+                    hist.append((s, y))
+            x = T(rng.uniform(-1, 1, n).astype(npd), dev)
+            r1, r0 = torch.empty_like(x), torch.empty_like(x)
+            lo.mul(r1, ops[1], x, 1.0, 0.0)
+            lo.mul(r0, ops[0], x, 1.0, 0.0)
+            if not tainted:                                    # every pair in the memories was decided by a clear margin
+                assert bool(torch.isfinite(r0).all()) and bool(torch.isfinite(r1).all()), seed
+                assert float((r1 - r0).norm()) <= same * max(float(r0.norm()), float(x.norm())), seed
+        assert decided >= 40 and gray >= 20, (decided, gray)
+    finally:
+        ctx.tune("push_fused", 1)

@@ -497,7 +497,15 @@ int32_t mxlo_qn_destroy(mxlo_qn *h);
 /* push!(op, s, y) — src/lbfgs.jl:269-287 -> push_common! :210-255;
  *                   src/lsr1.jl:119-184.
  * `accepted` receives 1/0 (the reference silently returns `op` on rejection).
- * Needs the host to see ys (rejection is host control flow): one 2-5 double D2H. */
+ * Needs the host to see ys (rejection is host control flow): one 2-6 double D2H.
+ * s and y may live anywhere, including inside this handle's own panels (a column from mxlo_qn_column, even the slot about
+ * to be replaced): the streaming schedules ("push_fused"), which read the pair while the slot is being written, are
+ * taken only when [s, s+n) and [y, y+n) overlap none of the handle's allocations — otherwise the pair is copied into
+ * its slots first, as the reference does (s[insert] .= s).
+ * L-SR1: the accept / reject tests of src/lsr1.jl:131-141 compare r's, y's, |y - s/sf| with thresholds of the order eps,
+ * while r's = y's - s'Bs carries an absolute rounding error of the order eps (|y| + |B s|) |s|. The streaming schedule
+ * (a_k's from Gram data) and the apply-based one (dots on the stored a_k) round differently, so a push that does not
+ * clear its thresholds by 2^8 such error budgets is re-evaluated by the apply-based schedule, whose decision stands. */
 int32_t mxlo_qn_push(mxlo_qn *h, const void *s, const void *y, int32_t *accepted);
 /* push!(op, s, y, Bs) forward damped — src/lbfgs.jl:289-323. `Bs` is caller scratch (n). */
 int32_t mxlo_qn_push_damped_fwd(mxlo_qn *h, const void *s, const void *y, void *Bs,

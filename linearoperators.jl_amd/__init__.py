@@ -20,7 +20,7 @@ from .operators import (AbstractLinearOperator, AdjointLinearOperator, Conjugate
                         nctprod, neg, nprod, ntprod, one, reset, scale_op, size, state_version, storage_type, to_dense, touched,
                         transpose,
                         vcat, zero)
-from .leaves import (BlockDiagonalOperator, LinearOperatorFromMatrix, ShiftedOperator, jrange, kron, opDiagonal, opExtension, opEye,
+from .leaves import (BlockDiagonalOperator, LinearOperatorFromMatrix, LinearOperatorFromSparse, ShiftedOperator, sparse_csc, jrange, kron, opDiagonal, opExtension, opEye,
                      opHermitian, opHouseholder, opOnes, opRestriction, opZeros)
 
 Matrix = to_dense

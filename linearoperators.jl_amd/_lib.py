@@ -27,7 +27,7 @@ ALPHA_F64, D_SCALAR, TAIL_BETA, BETA_F64 = 0x1, 0x2, 0x4, 0x8
 SCALARS_F64 = ALPHA_F64 | BETA_F64
 OP_N, OP_T, OP_C = 0, 1, 2
 OP_J = 3
-BLK_DIAG, BLK_DENSE, BLK_EYE, BLK_ZEROS = 0, 1, 2, 3
+BLK_DIAG, BLK_DENSE, BLK_EYE, BLK_ZEROS, BLK_CSC = 0, 1, 2, 3, 4
 QN_LBFGS_INV, QN_LBFGS_FWD, QN_LSR1 = 0, 1, 2
 INV_TWOPASS, INV_REFORDER = 0, 1
 PUSH_GRAM, PUSH_REFORDER, PUSH_COMPACT = 0, 1, 2
@@ -142,6 +142,11 @@ _PROTOS = {
     "mxlo_kron_mul_ex": [_vp, _i32, _vp, _vp, _i64, _i64, _i64, _i32, _vp, _i64, _i64, _i64, _i32, _vp, _vp, _dbl, _dbl, _i32],
     "mxlo_kron_diag_mul": [_vp, _i32, _vp, _vp, _i64, _vp, _i64, _vp, _dbl, _dbl, _i32],
     "mxlo_gemv": [_vp, _i32, _vp, _vp, _i64, _i64, _i64, _vp, _dbl, _dbl, _i32, _i32],
+    "mxlo_csc_create": [_vp, _i32, _i64, _i64, _vp, _vp, _vp, _i32, C.POINTER(_vp)],
+    "mxlo_csc_refresh": [_vp],
+    "mxlo_csc_mul": [_vp, _vp, _vp, _dbl, _dbl, _i32, _i32],
+    "mxlo_csc_info": [_vp, C.POINTER(_i64)],
+    "mxlo_csc_destroy": [_vp],
     "mxlo_gemv_block": [_vp, _i32, _vp, _i64, _vp, _i64, _i64, _i64, _vp, _i64, _i64, _dbl, _dbl, _i32, _i32],
     "mxlo_diagqn_push": [_vp, _i32, _i32, _vp, _vp, _vp, _i64, C.POINTER(_i32)],
     "mxlo_qn_create": [_vp, _i32, _i32, _i64, _i64, _i32, _i32, _dbl, _dbl, C.POINTER(_vp)],

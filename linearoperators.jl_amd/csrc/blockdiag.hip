@@ -7,6 +7,9 @@
 // Tiles: elementwise blocks (opDiagonal / opEye / opZeros) are cut into 2048-row tiles; a dense
 // block contributes 256-output-row tiles in N mode (thread per row, coalesced down the columns)
 // and 4-output tiles in T mode (one wave per output, coalesced down the column).
+// A sparse block (MXLO_BLK_CSC: data = the device descriptor of an mxlo_csc handle) contributes tiles of 4 rows per
+// lane group of its compressed-row sweep (sparse_kernels.h) — the N-mode tiles walk the CSR view, the T-mode tiles the
+// CSC arrays themselves.
 // Blocks start at arbitrary row offsets (e.g. 97,657-row blocks), so each tile aligns its
 // stores to 16 bytes by peeling and loads an operand with one 16-byte or two element accesses
 // depending on that operand's own phase.
@@ -14,8 +17,15 @@
 
 #include "common.h"
 #include "stream_kernels.h"
+#include "sparse_kernels.h"
 
 using namespace mxlo;
+
+struct mxlo_csc;
+namespace mxlo {
+const CscDev *csc_device_desc(const mxlo_csc *h);     // sparse.hip
+void csc_shape(const mxlo_csc *h, int64_t *m, int64_t *n, int *dtype, int *lpr_n, int *lpr_t);
+}
 
 namespace {
 
@@ -172,6 +182,14 @@ blockdiag_kernel(T *__restrict__ res, const T *__restrict__ x, const DevBlock *_
   const int64_t ni = TRANS ? b.m : b.n;   // inputs of this block
   T *rp = res + out_off;
   const T *xp = x + in_off;
+  if (b.kind == MXLO_BLK_CSC) {
+    const CscDev S = *(const CscDev *)b.data;                 // wave-uniform descriptor fetch
+    if constexpr (!TRANS)
+      spmv_rows<T, CA, CB, BETA0>(rp, xp, S.rowptr, S.colidx, (const T *)S.csr_val, tl.start, tl.cnt, S.lpr_n, alpha, beta);
+    else
+      spmv_rows<T, CA, CB, BETA0>(rp, xp, S.colptr, S.rowidx, (const T *)S.nzval, tl.start, tl.cnt, S.lpr_t, alpha, beta);
+    return;
+  }
   if (b.kind != MXLO_BLK_DENSE) {
     // elementwise tile [tl.start, tl.start + cnt). Rectangular eye/zeros: outputs beyond
     // min(m,n) of an eye block follow mulOpEye!'s tail rule (0 | β).
@@ -236,16 +254,27 @@ MXLO_API int32_t mxlo_blockdiag_create(mxlo_ctx *ctx, int32_t dtype, const mxlo_
   int64_t nrow = 0, ncol = 0;
   for (int64_t k = 0; k < nblocks; ++k) {
     const mxlo_block_desc &b = blocks[k];
-    MXLO_REQUIRE(b.kind >= MXLO_BLK_DIAG && b.kind <= MXLO_BLK_ZEROS, MXLO_EINVAL, "block %lld: bad kind", (long long)k);
+    MXLO_REQUIRE(b.kind >= MXLO_BLK_DIAG && b.kind <= MXLO_BLK_CSC, MXLO_EINVAL, "block %lld: bad kind", (long long)k);
     MXLO_REQUIRE(b.m >= 0 && b.n >= 0, MXLO_ESHAPE, "block %lld: negative size", (long long)k);
     if (b.kind == MXLO_BLK_DIAG) MXLO_REQUIRE(b.m == b.n && (b.m == 0 || b.data), MXLO_ESHAPE, "block %lld: diagonal blocks are square", (long long)k);
     if (b.kind == MXLO_BLK_DENSE) MXLO_REQUIRE((b.m == 0 || b.n == 0 || b.data) && b.ld >= (b.m > 1 ? b.m : 1), MXLO_ESHAPE, "block %lld: bad dense block", (long long)k);
     MXLO_REQUIRE(b.row_off == nrow && b.col_off == ncol, MXLO_ESHAPE, "block %lld: offsets must be cumulative", (long long)k);
     hb[k] = DevBlock{b.kind, 0, b.row_off, b.col_off, b.m, b.n, b.data, b.ld};
+    int lpr_n = 1, lpr_t = 1;
+    if (b.kind == MXLO_BLK_CSC) {
+      MXLO_REQUIRE(b.data, MXLO_EINVAL, "block %lld: a sparse block needs its mxlo_csc handle in `data`", (long long)k);
+      int64_t sm = 0, sn = 0;
+      int sdt = 0;
+      csc_shape((const mxlo_csc *)b.data, &sm, &sn, &sdt, &lpr_n, &lpr_t);
+      MXLO_REQUIRE(sm == b.m && sn == b.n, MXLO_ESHAPE, "block %lld: descriptor says %lld x %lld, the sparse handle %lld x %lld",
+                   (long long)k, (long long)b.m, (long long)b.n, (long long)sm, (long long)sn);
+      MXLO_REQUIRE(sdt == dtype, MXLO_EINVAL, "block %lld: element type of the sparse handle differs from the operator's", (long long)k);
+      hb[k].data = csc_device_desc((const mxlo_csc *)b.data);
+    }
     nrow += b.m;
     ncol += b.n;
     auto cut = [&](std::vector<Tile> &out, int64_t off, int64_t len, int64_t step) {
-      if (b.kind == MXLO_BLK_DENSE) {
+      if (b.kind == MXLO_BLK_DENSE || b.kind == MXLO_BLK_CSC) {
         for (int64_t s = 0; s < len; s += step) out.push_back(Tile{hb[k], s, len - s < step ? len - s : step});
         return;
       }
@@ -259,8 +288,8 @@ MXLO_API int32_t mxlo_blockdiag_create(mxlo_ctx *ctx, int32_t dtype, const mxlo_
         s = e;
       }
     };
-    cut(tn, b.row_off, b.m, b.kind == MXLO_BLK_DENSE ? kTileDN : kTileE);
-    cut(tt, b.col_off, b.n, b.kind == MXLO_BLK_DENSE ? kTileDT : kTileE);
+    cut(tn, b.row_off, b.m, b.kind == MXLO_BLK_DENSE ? kTileDN : b.kind == MXLO_BLK_CSC ? (kBlock / lpr_n) * 4 : kTileE);
+    cut(tt, b.col_off, b.n, b.kind == MXLO_BLK_DENSE ? kTileDT : b.kind == MXLO_BLK_CSC ? (kBlock / lpr_t) * 4 : kTileE);
   }
   mxlo_blockdiag *bd = new mxlo_blockdiag();
   bd->ctx = ctx;

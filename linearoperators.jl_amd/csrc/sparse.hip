@@ -1,0 +1,220 @@
+// sparse.hip — LinearOperator(M::SparseMatrixCSC) prod!/tprod!/ctprod! (src/constructors.jl:19-29 hands M to
+// LinearAlgebra.mul!, i.e. to the SparseArrays stdlib) and the sparse blocks of BlockDiagonalOperator
+// (test/test_linop.jl:743-756 builds one from an operator, a Matrix and a sprand block).
+// Kernel design: sparse_kernels.h. This file: the handle (compressed-row view built once at construction, values
+// permuted into row order), refresh after in-place value updates, the apply.
+#include <algorithm>
+#include <numeric>
+#include <vector>
+
+#include "common.h"
+#include "sparse_kernels.h"
+
+using namespace mxlo;
+
+struct mxlo_csc {
+  mxlo_ctx *ctx = nullptr;
+  int dtype = 0;
+  int64_t m = 0, n = 0, nnz = 0;
+  CscDev host{};            // device pointers + sizes (mirror of *dev)
+  CscDev *dev = nullptr;    // device-resident copy (what MXLO_BLK_CSC blocks of a fused block-diagonal point at)
+  int32_t *perm = nullptr;  // [nnz] CSR position -> CSC position (mxlo_csc_refresh)
+  const void *nzval = nullptr;
+};
+
+namespace mxlo {
+const CscDev *csc_device_desc(const mxlo_csc *h) { return h ? h->dev : nullptr; }   // blockdiag.hip
+void csc_shape(const mxlo_csc *h, int64_t *m, int64_t *n, int *dtype, int *lpr_n, int *lpr_t) {
+  *m = h->m; *n = h->n; *dtype = h->dtype; *lpr_n = h->host.lpr_n; *lpr_t = h->host.lpr_t;
+}
+}  // namespace mxlo
+
+namespace {
+
+template <typename T>
+__global__ void __launch_bounds__(kBlock)
+csc_gather_values_kernel(T *__restrict__ out, const T *__restrict__ nzval, const int32_t *__restrict__ perm, int64_t nnz) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i < nnz) out[i] = nzval[perm[i]];
+}
+
+template <typename T, typename CA, typename CB, bool BETA0>
+__global__ void __launch_bounds__(kBlock)
+csc_mul_kernel(T *__restrict__ res, const T *__restrict__ x, const int64_t *__restrict__ ptr, const int32_t *__restrict__ idx,
+               const T *__restrict__ val, int64_t nrows, int lpr, int rows_per_block, CA alpha, CB beta) {
+  const int64_t row0 = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t cnt = nrows - row0 < rows_per_block ? nrows - row0 : rows_per_block;
+  spmv_rows<T, CA, CB, BETA0>(res, x, ptr, idx, val, row0, cnt, lpr, alpha, beta);
+}
+
+// lanes per row from the mean row length: the smallest power of two >= the mean, 1 .. 64
+int lanes_per_row(int64_t nnz, int64_t rows) {
+  if (rows <= 0) return 1;
+  const double mean = (double)nnz / (double)rows;
+  int l = 1;
+  while (l < 64 && (double)l < mean) l <<= 1;
+  return l;
+}
+
+template <typename T>
+int32_t csc_mul_t(mxlo_csc *h, T *res, const T *v, double alpha, double beta, int32_t op_mode, int32_t flags) {
+  mxlo_ctx *ctx = h->ctx;
+  const bool trans = op_mode != MXLO_OP_N;
+  const int64_t nrows = trans ? h->n : h->m;
+  if (nrows == 0) return MXLO_OK;
+  const int64_t *ptr = trans ? h->host.colptr : h->host.rowptr;
+  const int32_t *idx = trans ? h->host.rowidx : h->host.colidx;
+  const T *val = (const T *)(trans ? h->host.nzval : h->host.csr_val);
+  const int lpr = trans ? h->host.lpr_t : h->host.lpr_n;
+  // rows per workgroup: every lane group takes 4 rows (amortises the launch of a workgroup, keeps >= 1 row per group)
+  const int rpb = (kBlock / lpr) * 4;
+  const int64_t grid = (nrows + rpb - 1) / rpb;
+  MXLO_REQUIRE(grid < (1LL << 31), MXLO_ESHAPE, "mxlo_csc_mul: too many rows for one launch");
+  return dispatch_ab<T>(beta, flags, [&]<typename CA, typename CB, bool B0>() -> int32_t {
+    hipLaunchKernelGGL((csc_mul_kernel<T, CA, CB, B0>), dim3((unsigned)grid), dim3(kBlock), 0, ctx->stream, res, v, ptr, idx,
+                       val, nrows, lpr, rpb, (CA)alpha, (CB)beta);
+    MXLO_LAUNCH_CHECK();
+    return MXLO_OK;
+  });
+}
+
+}  // namespace
+
+MXLO_API int32_t mxlo_csc_create(mxlo_ctx *ctx, int32_t dtype, int64_t m, int64_t n, const int64_t *colptr,
+                                 const int64_t *rowval, const void *nzval, int32_t index_base, mxlo_csc **out) {
+  MXLO_REQUIRE(ctx && out, MXLO_EINVAL, "mxlo_csc_create: NULL argument");
+  MXLO_DEVICE_GUARD(ctx);
+  MXLO_REQUIRE(dtype == MXLO_F64 || dtype == MXLO_F32, MXLO_EINVAL, "mxlo_csc_create: bad dtype %d (real element types)", dtype);
+  MXLO_REQUIRE(m >= 0 && n >= 0 && m < (1LL << 31) && n < (1LL << 31), MXLO_ESHAPE,
+               "mxlo_csc_create: %lld x %lld (each dimension must be below 2^31: indices are 32-bit inside the library)",
+               (long long)m, (long long)n);
+  MXLO_REQUIRE(index_base == 0 || index_base == 1, MXLO_EINVAL, "mxlo_csc_create: index_base must be 0 or 1 (Julia)");
+  MXLO_REQUIRE(colptr, MXLO_EINVAL, "mxlo_csc_create: colptr is NULL");
+  const size_t es = dtype == MXLO_F64 ? 8 : 4;
+  // ---- structure to the host, validated there (the reference's SparseMatrixCSC constructor checks the same invariants)
+  std::vector<int64_t> cp((size_t)n + 1);
+  MXLO_HIP(hipStreamSynchronize(ctx->stream));
+  MXLO_HIP(hipMemcpy(cp.data(), colptr, sizeof(int64_t) * cp.size(), hipMemcpyDeviceToHost));
+  for (auto &c : cp) c -= index_base;
+  MXLO_REQUIRE(cp[0] == 0, MXLO_EINVAL, "mxlo_csc_create: colptr[0] must be %d", index_base);
+  for (int64_t j = 0; j < n; ++j)
+    MXLO_REQUIRE(cp[j + 1] >= cp[j], MXLO_EINVAL, "mxlo_csc_create: colptr decreases at column %lld", (long long)j);
+  const int64_t nnz = cp[n];
+  MXLO_REQUIRE(nnz < (1LL << 31), MXLO_ESHAPE, "mxlo_csc_create: %lld stored entries (the row-order permutation is 32-bit)",
+               (long long)nnz);
+  MXLO_REQUIRE(nnz == 0 || (rowval && nzval), MXLO_EINVAL, "mxlo_csc_create: rowval / nzval is NULL");
+  std::vector<int64_t> rv((size_t)nnz);
+  if (nnz) MXLO_HIP(hipMemcpy(rv.data(), rowval, sizeof(int64_t) * (size_t)nnz, hipMemcpyDeviceToHost));
+  std::vector<int32_t> ri((size_t)nnz);
+  std::vector<int64_t> rp((size_t)m + 1, 0);
+  for (int64_t k = 0; k < nnz; ++k) {
+    const int64_t r = rv[k] - index_base;
+    MXLO_REQUIRE(r >= 0 && r < m, MXLO_EINVAL, "mxlo_csc_create: row index %lld at position %lld outside 1..%lld",
+                 (long long)rv[k], (long long)k, (long long)m);
+    ri[k] = (int32_t)r;
+    ++rp[r + 1];
+  }
+  std::partial_sum(rp.begin(), rp.end(), rp.begin());
+  // ---- compressed-row view: a stable counting sort by row keeps the columns of a row ascending (fixed summation order)
+  std::vector<int32_t> ci((size_t)nnz), perm((size_t)nnz);
+  {
+    std::vector<int64_t> fill(rp.begin(), rp.end() - 1);
+    for (int64_t j = 0; j < n; ++j)
+      for (int64_t k = cp[j]; k < cp[j + 1]; ++k) {
+        const int64_t p = fill[ri[k]]++;
+        ci[p] = (int32_t)j;
+        perm[p] = (int32_t)k;
+      }
+  }
+  mxlo_csc *h = new mxlo_csc();
+  h->ctx = ctx;
+  h->dtype = dtype;
+  h->m = m;
+  h->n = n;
+  h->nnz = nnz;
+  h->nzval = nzval;
+  hipError_t e = hipSuccess;
+  auto up = [&](void **dst, const void *src, size_t bytes) {
+    if (e != hipSuccess) return;
+    e = hipMalloc(dst, bytes ? bytes : 16);
+    if (e == hipSuccess && bytes) e = hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);
+  };
+  CscDev &d = h->host;
+  up((void **)&d.rowptr, rp.data(), sizeof(int64_t) * rp.size());
+  up((void **)&d.colidx, ci.data(), sizeof(int32_t) * (size_t)nnz);
+  up((void **)&d.colptr, cp.data(), sizeof(int64_t) * cp.size());
+  up((void **)&d.rowidx, ri.data(), sizeof(int32_t) * (size_t)nnz);
+  up((void **)&h->perm, perm.data(), sizeof(int32_t) * (size_t)nnz);
+  if (e == hipSuccess) e = hipMalloc((void **)&d.csr_val, nnz ? es * (size_t)nnz : 16);
+  d.nzval = nzval;
+  d.m = m;
+  d.n = n;
+  d.nnz = nnz;
+  d.lpr_n = lanes_per_row(nnz, m);
+  d.lpr_t = lanes_per_row(nnz, n);
+  if (e == hipSuccess) e = hipMalloc((void **)&h->dev, sizeof(CscDev));
+  if (e == hipSuccess) e = hipMemcpy(h->dev, &d, sizeof(CscDev), hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    set_error("mxlo_csc_create: device allocation failed: %s", hipGetErrorString(e));
+    (void)hipGetLastError();
+    mxlo_csc_destroy(h);
+    return MXLO_ENOMEM;
+  }
+  const int32_t st = mxlo_csc_refresh(h);
+  if (st != MXLO_OK) {
+    mxlo_csc_destroy(h);
+    return st;
+  }
+  *out = h;
+  return MXLO_OK;
+}
+
+MXLO_API int32_t mxlo_csc_refresh(mxlo_csc *h) {
+  MXLO_REQUIRE(h, MXLO_EINVAL, "mxlo_csc_refresh: handle is NULL");
+  MXLO_DEVICE_GUARD(h->ctx);
+  if (h->nnz == 0) return MXLO_OK;
+  const unsigned grid = (unsigned)((h->nnz + kBlock - 1) / kBlock);
+  if (h->dtype == MXLO_F64)
+    hipLaunchKernelGGL(csc_gather_values_kernel<double>, dim3(grid), dim3(kBlock), 0, h->ctx->stream, (double *)h->host.csr_val,
+                       (const double *)h->nzval, h->perm, h->nnz);
+  else
+    hipLaunchKernelGGL(csc_gather_values_kernel<float>, dim3(grid), dim3(kBlock), 0, h->ctx->stream, (float *)h->host.csr_val,
+                       (const float *)h->nzval, h->perm, h->nnz);
+  MXLO_LAUNCH_CHECK();
+  return MXLO_OK;
+}
+
+MXLO_API int32_t mxlo_csc_mul(mxlo_csc *h, void *res, const void *v, double alpha, double beta, int32_t op_mode,
+                              int32_t flags) {
+  MXLO_REQUIRE(h, MXLO_EINVAL, "mxlo_csc_mul: handle is NULL");
+  MXLO_DEVICE_GUARD(h->ctx);
+  MXLO_REQUIRE(op_mode >= MXLO_OP_N && op_mode <= MXLO_OP_C, MXLO_EINVAL, "bad op_mode");
+  const int64_t nres = op_mode == MXLO_OP_N ? h->m : h->n, nin = op_mode == MXLO_OP_N ? h->n : h->m;
+  if (nres == 0) return MXLO_OK;
+  MXLO_REQUIRE(res && (v || nin == 0), MXLO_EINVAL, "mxlo_csc_mul: NULL operand");
+  eff_scalars(h->dtype == MXLO_F64 ? 8 : 4, flags, alpha, beta);
+  if (h->dtype == MXLO_F64) return csc_mul_t<double>(h, (double *)res, (const double *)v, alpha, beta, op_mode, flags);
+  return csc_mul_t<float>(h, (float *)res, (const float *)v, alpha, beta, op_mode, flags);
+}
+
+MXLO_API int32_t mxlo_csc_info(mxlo_csc *h, int64_t info[5]) {
+  MXLO_REQUIRE(h && info, MXLO_EINVAL, "mxlo_csc_info: NULL argument");
+  info[0] = h->m;
+  info[1] = h->n;
+  info[2] = h->nnz;
+  info[3] = h->host.lpr_n;
+  info[4] = h->host.lpr_t;
+  return MXLO_OK;
+}
+
+MXLO_API int32_t mxlo_csc_destroy(mxlo_csc *h) {
+  if (!h) return MXLO_OK;
+  MXLO_DEVICE_GUARD(h->ctx);
+  (void)hipStreamSynchronize(h->ctx->stream);
+  for (const void *p : {(const void *)h->host.rowptr, (const void *)h->host.colidx, h->host.csr_val,
+                        (const void *)h->host.colptr, (const void *)h->host.rowidx, (const void *)h->perm,
+                        (const void *)h->dev})
+    if (p) (void)hipFree(const_cast<void *>(p));
+  delete h;
+  return MXLO_OK;
+}

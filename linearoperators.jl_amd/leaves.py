@@ -364,10 +364,105 @@ def _stored_colmajor(M: torch.Tensor):
     return M.t().contiguous().t(), False
 
 
+_SPARSE_LAYOUTS = (torch.sparse_csc, torch.sparse_csr, torch.sparse_coo)
+
+
+class _CscHandle:
+    """RAII wrapper of ``mxlo_csc`` (include/mxlo.h) plus the tensors it keeps referenced."""
+
+    def __init__(self, ctx, dtype, m, n, colptr, rowval, nzval, index_base):
+        self.ctx, self.keep = ctx, (colptr, rowval, nzval)
+        self.h = C.c_void_p()
+        _lib.call("mxlo_csc_create", ctx.handle, dtype_code(dtype), m, n, ptr(colptr), ptr(rowval), ptr(nzval), index_base,
+                  C.byref(self.h))
+
+    def info(self):
+        a = (C.c_int64 * 5)()
+        _lib.call("mxlo_csc_info", self.h, a)
+        return {"m": a[0], "n": a[1], "nnz": a[2], "lanes_per_row": a[3], "lanes_per_col": a[4]}
+
+    def __del__(self):
+        try:
+            _lib.lib().mxlo_csc_destroy(self.h)
+        except Exception:
+            pass
+
+
+def sparse_csc(colptr, rowval, nzval, m: int, n: int, index_base: int = 1, device=None) -> torch.Tensor:
+    """A device `torch.sparse_csc` tensor from the three arrays of a Julia `SparseMatrixCSC` (`index_base` 1, as Julia
+    stores them) or 0-based ones; host arrays are uploaded, `nzval` that already lives on the device is aliased."""
+    dev = torch.device(device) if device is not None else (nzval.device if isinstance(nzval, torch.Tensor) and nzval.is_cuda
+                                                           else _default_device())
+    t = lambda a, dt=None: (a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(a))).to(device=dev, dtype=dt)
+    cp, rv = t(colptr, torch.int64) - index_base, t(rowval, torch.int64) - index_base
+    return torch.sparse_csc_tensor(cp, rv, t(nzval), size=(m, n), device=dev)
+
+
+def LinearOperatorFromSparse(M: torch.Tensor, symmetric: bool = False, hermitian: bool = False,
+                             S: Optional[Storage] = None):
+    """LinearOperator(M::SparseMatrixCSC) — src/constructors.jl:15-29: prod!/tprod!/ctprod! = `mul!(res, M, v, α, β)`,
+    `mul!(res, transpose(M), …)`, `mul!(res, adjoint(M), …)`, which the SparseArrays stdlib implements as a column sweep
+    (A*x) and a per-column gather (Aᵀ*x). Device form: `mxlo_csc_*` (include/mxlo.h) — a row gather-reduce on a
+    compressed-row view in both modes, f64 accumulation in fixed order.
+
+    `M` is a `torch.sparse_csc` tensor (torch's 0-based int64 indices: exactly the three arrays of a SparseMatrixCSC
+    shifted by one — see `sparse_csc`) or `torch.sparse_csr` (the CSC storage of Mᵀ: aliased with N and T swapped, like a
+    row-major dense matrix); COO is converted once. The VALUES are aliased: in-place updates of `M.values()` are seen
+    (Aᵀ*x reads them directly; A*x re-gathers its row-ordered snapshot when the tensor's version counter moved —
+    `lo.touched(M.values())` after writes torch cannot see). The sparsity pattern is fixed at construction."""
+    if M.layout == torch.sparse_coo:
+        M = M.coalesce().to_sparse_csc()
+    tr = M.layout == torch.sparse_csr
+    if M.dim() != 2 or M.layout not in (torch.sparse_csc, torch.sparse_csr):
+        raise ValueError("LinearOperator(M): a 2-d sparse_csc / sparse_csr / sparse_coo tensor expected")
+    nrow, ncol = M.shape
+    vals = M.values()
+    T = vals.dtype
+    if T.is_complex:
+        raise TypeError("sparse LinearOperator(M): complex element types are not instantiated on the device path")
+    dtype_code(T)
+    if tr:                                   # CSR of M == CSC of transpose(M)
+        cp, rv, sm, sn = M.crow_indices(), M.col_indices(), ncol, nrow
+    else:
+        cp, rv, sm, sn = M.ccol_indices(), M.row_indices(), nrow, ncol
+    if not vals.is_cuda:
+        raise RuntimeError(f"operands must live on a GPU, got {vals.device}: there is no CPU fallback")
+    cp, rv = cp.to(torch.int64).contiguous(), rv.to(torch.int64).contiguous()
+    if not vals.is_contiguous():
+        raise ValueError("sparse LinearOperator(M): M.values() must be contiguous")
+    ctx = get_ctx(vals.device)
+    handle = _CscHandle(ctx, T, sm, sn, cp, rv, vals, 0)
+    seen = [state_version(vals)]
+    fwd, bwd = (_lib.OP_T, _lib.OP_N) if tr else (_lib.OP_N, _lib.OP_T)
+
+    def spmv(res, v, a, b, mode):
+        get_ctx(res.device)
+        if mode == _lib.OP_N:                # the row-ordered snapshot of the values
+            tok = state_version(vals)
+            if tok != seen[0]:
+                _lib.call("mxlo_csc_refresh", handle.h)
+                seen[0] = tok
+        _lib.call("mxlo_csc_mul", handle.h, ptr(res), ptr(v), float(a), float(b), mode, scalar_flags(res.dtype, a, b))
+
+    prod = columnwise(lambda res, v, a, b: spmv(res, v, a, b, fwd))
+    tprod = columnwise(lambda res, u, a, b: spmv(res, u, a, b, bwd))
+    op = LinearOperator(T, nrow, ncol, symmetric, hermitian, prod, tprod, tprod,
+                        S=S if S is not None else Storage(T, vals.device))
+    if not tr:
+        op._leaf = ("csc", handle, vals, seen)    # fused BlockDiagonalOperator: MXLO_BLK_CSC
+    op._sparse_src = M
+    op._csc = handle
+    op._deps = (vals,)
+    return op
+
+
 def LinearOperatorFromMatrix(M: torch.Tensor, symmetric: bool = False, hermitian: bool = False,
                              S: Optional[Storage] = None):
     """LinearOperator(M) — src/constructors.jl:15-29 (prod!/tprod!/ctprod! = gemv N/T/C). M is ALIASED, never copied,
-    when it is column-major or row-major (a row-major M is the column-major storage of Mᵀ: N and T swap)."""
+    when it is column-major or row-major (a row-major M is the column-major storage of Mᵀ: N and T swap). A sparse M
+    (torch.sparse_csc / _csr / _coo) goes to `LinearOperatorFromSparse`."""
+    if M.layout in _SPARSE_LAYOUTS:
+        return LinearOperatorFromSparse(M, symmetric, hermitian, S)
     nrow, ncol = M.shape
     St, tr = _stored_colmajor(M)
     cplx = St.dtype.is_complex
@@ -435,7 +530,7 @@ class _BlockDiagHandle:
 def BlockDiagonalOperator(*ops, S: Optional[Storage] = None):
     """BlockDiagonalOperator(M1, ..., Mn; S) — src/special-operators.jl:249-294.
 
-    When every block is a diagonal / dense-matrix / identity / zero block the whole operator is ONE
+    When every block is a diagonal / dense-matrix / sparse-matrix / identity / zero block the whole operator is ONE
     device launch over a descriptor table (mxlo_blockdiag_mul); any other block type falls back to
     the reference's own structure (a host loop of inner `mul!` on views, :258-267) — still the HIP
     leaves, just one launch per block."""
@@ -451,7 +546,7 @@ def BlockDiagonalOperator(*ops, S: Optional[Storage] = None):
     fusable = all(getattr(o, "_leaf", None) is not None and o.eltype == T for o in ops) and T.is_floating_point
     if fusable:
         descs, k, j = [], 0, 0
-        keep = []
+        keep, sparse_blocks = [], []
         for o in ops:
             leaf = o._leaf
             m, n = o.shape
@@ -465,6 +560,10 @@ def BlockDiagonalOperator(*ops, S: Optional[Storage] = None):
                 descs.append(_lib.BlockDesc(_lib.BLK_EYE, 0, k, j, m, n, None, 0))
             elif leaf[0] == "zeros":
                 descs.append(_lib.BlockDesc(_lib.BLK_ZEROS, 0, k, j, m, n, None, 0))
+            elif leaf[0] == "csc":
+                descs.append(_lib.BlockDesc(_lib.BLK_CSC, 0, k, j, m, n, leaf[1].h.value, 0))
+                keep.append(leaf[1])
+                sparse_blocks.append(leaf)
             else:
                 fusable = False
                 break
@@ -476,6 +575,12 @@ def BlockDiagonalOperator(*ops, S: Optional[Storage] = None):
 
         def bd(res, x, a, b, mode):
             get_ctx(res.device)
+            if mode == _lib.OP_N:
+                for _, hcsc, vals, seen in sparse_blocks:     # sparse blocks: row-ordered value snapshots (see the leaf)
+                    tok = state_version(vals)
+                    if tok != seen[0]:
+                        _lib.call("mxlo_csc_refresh", hcsc.h)
+                        seen[0] = tok
             _lib.call("mxlo_blockdiag_mul", handle.h, ptr(res), ptr(x), float(a), float(b), mode,
                       scalar_flags(res.dtype, a, b))
 

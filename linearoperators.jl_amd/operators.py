@@ -960,7 +960,7 @@ def _as_op(x):
         return x
     if isinstance(x, torch.Tensor) and x.dim() == 2:
         from .leaves import LinearOperatorFromMatrix
-        return LinearOperatorFromMatrix(x)
+        return LinearOperatorFromMatrix(x)             # dense or sparse (torch.sparse_csc / _csr / _coo)
     raise TypeError(f"cannot concatenate {type(x)}")
 
 

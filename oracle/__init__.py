@@ -283,6 +283,19 @@ def gemv(res, M, v, alpha, beta, trans=False, flags=0):
     return res
 
 
+def csc_mul(res, colptr, rowval, nzval, m, n, v, alpha, beta, trans=False, flags=0):
+    """mul!(res, op(A), v, α, β) for A::SparseMatrixCSC (src/constructors.jl:19-29 -> SparseArrays `_spmatmul!` /
+    `_At_or_Ac_mul_B!`). colptr / rowval 1-based int64 as Julia stores them; real element types."""
+    dt = _check(res, v)
+    cp = np.ascontiguousarray(colptr, dtype=np.int64)
+    rv = np.ascontiguousarray(rowval, dtype=np.int64)
+    nz = np.ascontiguousarray(nzval, dtype=dt)
+    assert cp.size == n + 1 and res.size == (n if trans else m) and v.size == (m if trans else n)
+    _fn("orc_csc_mul", dt)(_p(res), _p(cp), _p(rv), _p(nz), _i64(m), _i64(n), _p(v), _d(alpha), _d(beta), _i32(int(trans)),
+                           _i32(flags))
+    return res
+
+
 def kron_mul(res, A, B, x, alpha, beta, trans=False, flags=0):
     """kron(A,B) prod!/tprod!/ctprod! (src/kron.jl:14-40). Complex res: trans in {False, True|"T", "C"}; real factors
     next to complex data are promoted (kron(Float64 A, ComplexF64 B), test/test_kron.jl:3-8)."""

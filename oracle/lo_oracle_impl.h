@@ -251,6 +251,50 @@ void FN(orc_gemv)(T *res, const T *M, int64_t m, int64_t n, int64_t ld, const T 
 #undef BODY
 }
 
+/* ---- sparse LinearOperator(M::SparseMatrixCSC) — src/constructors.jl:19-29 calls LinearAlgebra.mul!(res, M, v, α, β) ----
+ * For a SparseMatrixCSC that method lives in the SparseArrays stdlib, which is NOT part of /root/reference (a Julia
+ * standard library, version = the Julia the package runs on, >= 1.10 by Project.toml). Its published algorithm
+ * (stdlib/SparseArrays/src/linalg.jl), restated:
+ *   _spmatmul!(C, A, B, α, β):        β != 1 && (β == 0 ? fill!(C, 0) : rmul!(C, β))      [_rmul_or_fill!]
+ *                                     for col = 1:n:  αxj = B[col] * α
+ *                                       for k in nzrange(A, col):  C[rowval[k]] += nzval[k] * αxj
+ *   _At_or_Ac_mul_B!(tfun, C, A, B, α, β):   the same β step, then
+ *                                     for col = 1:n:  tmp = zero(eltype(C))
+ *                                       for k in nzrange(A, col):  tmp += tfun(nzval[k]) * B[rowval[k]]
+ *                                       C[col] += tmp * α
+ * PARITY UNPINNED by golden vectors: the reference's tests only compare such operators with dense matrices to
+ * sqrt(eps) (test/test_linop.jl:743-756, test/test_kron.jl:3-36); tests/test_oracle_kat.py pins this restatement the same
+ * way (against an independent dense product). colptr / rowval are 1-based as Julia stores them. trans: 0 = A*v, 1 = Aᵀ*v
+ * (= A'*v for the real element types instantiated here). */
+void FN(orc_csc_mul)(T *res, const int64_t *colptr, const int64_t *rowval, const T *nzval, int64_t m, int64_t n,
+                     const T *v, double alpha, double beta, int32_t trans, int32_t flags) {
+  const int64_t nr = trans ? n : m;
+#define BODY(CA, CB)                                                                             \
+  {                                                                                              \
+    const CA a = (CA)alpha; const CB b = (CB)beta;                                               \
+    if (b != (CB)1) {                                                                            \
+      if (b == (CB)0) { for (int64_t i = 0; i < nr; ++i) res[i] = (T)0; }                        \
+      else { for (int64_t i = 0; i < nr; ++i) res[i] = (T)((CB)res[i] * b); }                    \
+    }                                                                                            \
+    if (!trans) {                                                                                \
+      for (int64_t col = 0; col < n; ++col) {                                                    \
+        const CA axj = (CA)v[col] * a;                                                           \
+        for (int64_t k = colptr[col] - 1; k < colptr[col + 1] - 1; ++k)                          \
+          res[rowval[k] - 1] = (T)((CA)res[rowval[k] - 1] + (CA)nzval[k] * axj);                 \
+      }                                                                                          \
+    } else {                                                                                     \
+      for (int64_t col = 0; col < n; ++col) {                                                    \
+        T tmp = (T)0;                                                                            \
+        for (int64_t k = colptr[col] - 1; k < colptr[col + 1] - 1; ++k)                          \
+          tmp = (T)(tmp + nzval[k] * v[rowval[k] - 1]);                                          \
+        res[col] = (T)((CA)res[col] + (CA)tmp * a);                                              \
+      }                                                                                          \
+    }                                                                                            \
+  }
+  WITH_CT(BODY);
+#undef BODY
+}
+
 /* ---- kron(A,B) prod!/tprod! — src/kron.jl:14-31 ----
  * prod!:  X = reshape(x, q, n); res .= α .* Matrix(B * X * transpose(A))[:] (.+ β .* res)
  * `B * X * transpose(A)` is a composite operator (src/operations.jl:131-156,160)

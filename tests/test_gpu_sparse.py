@@ -1,0 +1,265 @@
+"""-m gpu: sparse `LinearOperator(M::SparseMatrixCSC)` (src/constructors.jl:19-29 -> SparseArrays `mul!`) through
+`mxlo_csc_*`, and sparse blocks of a fused `BlockDiagonalOperator` (test/test_linop.jl:743-756), sparse `kron` factors
+(test/test_kron.jl:3-36). Parity: the C restatement of the SparseArrays loops (oracle.csc_mul) on the same inputs;
+tolerance 1e-13 * (|A| |v| scale) for Float64 and 2e-6 for Float32 (rounding ORDER only: a row is summed in f64 by a lane
+group with one fixed tree where the reference sums sequentially in T)."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import torch
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+NP = {torch.float64: np.float64, torch.float32: np.float32}
+TOL = {torch.float64: 1e-13, torch.float32: 2e-6}
+
+
+def dev_csc(A, dev, dtype):
+    """scipy CSC -> device torch.sparse_csc of the same three arrays"""
+    A = sp.csc_matrix(A)
+    return torch.sparse_csc_tensor(torch.from_numpy(A.indptr.astype(np.int64)), torch.from_numpy(A.indices.astype(np.int64)),
+                                   torch.from_numpy(A.data.astype(NP[dtype])), size=A.shape).to(dev)
+
+
+def scale_of(A, v):
+    return float((abs(A) @ np.abs(v.astype(np.float64))).max()) if A.nnz else 1.0
+
+
+def rand_sparse(rng, m, n, density, npd):
+    A = sp.random(m, n, density, format="csc", random_state=int(rng.integers(1 << 30)), data_rvs=lambda k: rng.uniform(-1, 1, k))
+    A.sort_indices()
+    return A.astype(npd)
+
+
+SHAPES = [(1, 1, 1.0), (7, 5, 0.5), (5, 7, 0.3), (300, 300, 0.01), (1000, 37, 0.2), (37, 1000, 0.2), (4096, 4096, 0.002),
+          (2, 3000, 0.9), (3000, 2, 0.9), (513, 129, 0.0), (10_000, 10_000, 3e-4)]
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("m,n,density", SHAPES)
+def test_csc_mul_vs_oracle(lo, dev, dtype, m, n, density):
+    """prod! / tprod! / ctprod! for every α, β kind: β = 0 on NaN-filled res (must not propagate), β = 1, general;
+    Float32 data with Float64 scalars (MXLO_ALPHA_F64 / _BETA_F64, like every other leaf)."""
+    npd = NP[dtype]
+    rng = np.random.default_rng(m * 31 + n)
+    A = rand_sparse(rng, m, n, density, npd)
+    op = lo.LinearOperatorFromMatrix(dev_csc(A, dev, dtype))
+    assert op.shape == (m, n)
+    for trans in (False, True):
+        nin, nout = (m, n) if trans else (n, m)
+        v = rng.uniform(-1, 1, nin).astype(npd)
+        r0 = rng.uniform(-1, 1, nout).astype(npd)
+        for a, b in ((1.0, 0.0), (2.0, -3.0), (0.0, 1.0), (-0.5, 1.0), (np.float32(1.5), np.float32(0.25))):
+            start = np.full(nout, np.nan, npd) if b == 0 else r0
+            res = torch.from_numpy(start.copy()).to(dev)
+            lo.mul(res, lo.transpose(op) if trans else op, torch.from_numpy(v).to(dev), a, b)
+            flags = 0
+            if dtype == torch.float32 and not isinstance(a, np.float32):
+                flags = 0x1 | 0x8
+            want = oracle.csc_mul(np.zeros(nout, npd) if b == 0 else r0.copy(), A.indptr + 1, A.indices + 1, A.data, m, n, v,
+                                  float(a), float(b), trans=trans, flags=flags)
+            tol = TOL[dtype] * (abs(float(a)) * scale_of(A.T if trans else A, v) + abs(float(b)) + 1e-300)
+            got = res.cpu().numpy()
+            assert np.isfinite(got).all()
+            assert np.abs(got.astype(np.float64) - want.astype(np.float64)).max() <= tol, (trans, a, b)
+    # adjoint of a real sparse operator == transpose (src/adjtrans.jl)
+    u = rng.uniform(-1, 1, m).astype(npd)
+    ra, rt = (torch.empty(n, dtype=dtype, device=dev) for _ in range(2))
+    lo.mul(ra, lo.adjoint(op), torch.from_numpy(u).to(dev), 1.0, 0.0)
+    lo.mul(rt, lo.transpose(op), torch.from_numpy(u).to(dev), 1.0, 0.0)
+    assert torch.equal(ra, rt)
+
+
+def test_csc_row_lengths_from_one_lane_to_a_full_wave(lo, dev):
+    """The lane group per row is chosen from the mean row length: exercise every group width (1 … 64 lanes), rows far
+    longer than the group (several trips) and empty rows next to full ones; each apply twice (run-to-run bit identity)."""
+    rng = np.random.default_rng(3)
+    for mean in (1, 2, 3, 6, 12, 24, 48, 100, 700):
+        m, n = 2000, 1500
+        rows = []
+        for i in range(m):
+            k = 0 if i % 7 == 3 else min(n, int(rng.integers(max(1, mean // 2), 2 * mean + 1)))
+            rows.append(np.sort(rng.choice(n, size=k, replace=False)))
+        indptr = np.concatenate([[0], np.cumsum([r.size for r in rows])])
+        data = rng.uniform(-1, 1, indptr[-1])
+        A = sp.csr_matrix((data, np.concatenate(rows) if indptr[-1] else np.zeros(0, int), indptr), shape=(m, n)).tocsc()
+        A.sort_indices()
+        op = lo.LinearOperatorFromMatrix(dev_csc(A, dev, torch.float64))
+        info = op._csc.info()
+        assert info["nnz"] == A.nnz and 1 <= info["lanes_per_row"] <= 64
+        v = rng.uniform(-1, 1, n)
+        res, res2 = torch.empty(m, dtype=torch.float64, device=dev), torch.empty(m, dtype=torch.float64, device=dev)
+        lo.mul(res, op, torch.from_numpy(v).to(dev), 1.0, 0.0)
+        lo.mul(res2, op, torch.from_numpy(v).to(dev), 1.0, 0.0)
+        assert torch.equal(res, res2)
+        want = oracle.csc_mul(np.zeros(m), A.indptr + 1, A.indices + 1, A.data, m, n, v, 1.0, 0.0)
+        assert np.abs(res.cpu().numpy() - want).max() <= 1e-13 * scale_of(A, v), mean
+        u = rng.uniform(-1, 1, m)
+        rt = torch.empty(n, dtype=torch.float64, device=dev)
+        lo.mul(rt, lo.transpose(op), torch.from_numpy(u).to(dev), 1.0, 0.0)
+        want = oracle.csc_mul(np.zeros(n), A.indptr + 1, A.indices + 1, A.data, m, n, u, 1.0, 0.0, trans=True)
+        assert np.abs(rt.cpu().numpy() - want).max() <= 1e-13 * scale_of(A.T, u), mean
+
+
+def test_csr_and_coo_layouts_and_unsorted_duplicate_entries(lo, dev):
+    """A `torch.sparse_csr` tensor is the CSC storage of the transpose: aliased with N and T swapped (no conversion).
+    COO is converted once. Unsorted rows within a column and duplicate (row, col) entries are legal for the
+    reference's loops (each stored entry contributes): same here."""
+    rng = np.random.default_rng(8)
+    A = rand_sparse(rng, 60, 45, 0.2, np.float64)
+    v, u = rng.uniform(-1, 1, 45), rng.uniform(-1, 1, 60)
+    csc = dev_csc(A, dev, torch.float64)
+    for M in (csc.to_sparse_csr(), csc.to_sparse_coo()):
+        op = lo.LinearOperatorFromMatrix(M)
+        got = (op * torch.from_numpy(v).to(dev)).cpu().numpy()
+        assert np.abs(got - A @ v).max() <= 1e-13 * scale_of(A, v)
+        got = (lo.transpose(op) * torch.from_numpy(u).to(dev)).cpu().numpy()
+        assert np.abs(got - A.T @ u).max() <= 1e-13 * scale_of(A.T, u)
+    # hand-built: column 0 holds rows (2, 0, 2) — unsorted with a duplicate; column 1 empty; column 2 rows (1,)
+    colptr = np.array([1, 4, 4, 5]); rowval = np.array([3, 1, 3, 2]); nz = np.array([1.5, -2.0, 0.25, 4.0])
+    M = lo.sparse_csc(colptr, rowval, nz, 3, 3, index_base=1, device=dev)
+    op = lo.LinearOperatorFromMatrix(M)
+    x = np.array([2.0, 5.0, -1.0])
+    want = oracle.csc_mul(np.zeros(3), colptr, rowval, nz, 3, 3, x, 1.0, 0.0)
+    assert np.array_equal((op * torch.from_numpy(x).to(dev)).cpu().numpy(), want)          # tiny sums: exact
+    want = oracle.csc_mul(np.zeros(3), colptr, rowval, nz, 3, 3, x, 1.0, 0.0, trans=True)
+    assert np.array_equal((lo.transpose(op) * torch.from_numpy(x).to(dev)).cpu().numpy(), want)
+
+
+def test_values_are_aliased_and_updates_are_seen(lo, dev):
+    """The reference's closure holds M itself: `nonzeros(M) .*= 2` changes the operator. Here Aᵀ*x reads the values in
+    place and A*x re-gathers its row-ordered snapshot when the values tensor's version moved (in-place torch ops bump
+    it; `lo.touched` for writes torch cannot see)."""
+    rng = np.random.default_rng(12)
+    A = rand_sparse(rng, 300, 200, 0.05, np.float64)
+    M = dev_csc(A, dev, torch.float64)
+    op = lo.LinearOperatorFromMatrix(M)
+    v = torch.from_numpy(rng.uniform(-1, 1, 200)).to(dev)
+    u = torch.from_numpy(rng.uniform(-1, 1, 300)).to(dev)
+    y0, z0 = (op * v).clone(), (lo.transpose(op) * u).clone()
+    M.values().mul_(2.0)
+    assert torch.allclose(op * v, 2 * y0, rtol=1e-15, atol=0) and torch.allclose(lo.transpose(op) * u, 2 * z0, rtol=1e-15, atol=0)
+    raw = M.values()
+    raw.view(torch.int64).copy_((raw * 0.25).view(torch.int64))     # a write through a reinterpreting view still bumps
+    lo.touched(raw)
+    assert torch.allclose(op * v, 0.5 * y0, rtol=1e-15, atol=0)
+
+
+def test_blockdiagonal_with_operator_matrix_and_sparse_blocks(lo, dev):
+    """test/test_linop.jl:739-756: `BlockDiagonalOperator(A, B, C)` with A an operator built from a closure (there: a
+    Cholesky solve = diag(0.5, 0.25, 0.125)), B = rand(4, 2), C = sprand(2, 4, 0.5), compared with the dense block
+    matrix for M, transpose(M), M' to sqrt(eps)·‖D‖. The closure block makes the operator take the reference's per-block
+    loop; the second operator (diagonal leaf instead of the closure) is ONE fused launch with a sparse block."""
+    rng = np.random.default_rng(5)
+    dinv = torch.tensor([0.5, 0.25, 0.125], dtype=torch.float64, device=dev)
+    closure = lo.LinearOperator(torch.float64, 3, 3, True, True, lambda y, v: y.copy_(dinv * v), S=lo.Storage(torch.float64, dev))
+    B = rng.uniform(0, 1, (4, 2))
+    Cs = sp.random(2, 4, 0.5, format="csc", random_state=3)
+    D = np.zeros((9, 9))
+    D[:3, :3] = np.diag([0.5, 0.25, 0.125]); D[3:7, 3:5] = B; D[7:9, 5:9] = Cs.toarray()
+    Bd = torch.from_numpy(np.ascontiguousarray(B.T)).to(dev).t()        # column-major, Julia's Matrix layout
+    Cd = dev_csc(Cs, dev, torch.float64)
+    for first, fused in ((closure, False), (lo.opDiagonal(dinv), True)):
+        M = lo.BlockDiagonalOperator(first, Bd, Cd)
+        assert M.shape == (9, 9)
+        assert hasattr(M, "_keepalive") == fused
+        tol = np.sqrt(np.finfo(np.float64).eps) * np.linalg.norm(D)
+        assert np.linalg.norm(lo.Matrix(M).cpu().numpy() - D) <= tol
+        assert np.linalg.norm(lo.Matrix(lo.transpose(M)).cpu().numpy() - D.T) <= tol
+        assert np.linalg.norm(lo.Matrix(lo.adjoint(M)).cpu().numpy() - D.T) <= tol
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_fused_blockdiagonal_mix_with_sparse_blocks_vs_per_block_applies(lo, dev, dtype):
+    """Many blocks of every fusable kind incl. sparse ones at odd offsets: the one-launch operator against the sum of its
+    blocks applied one by one (the reference's loop, src/special-operators.jl:258-289), N / T, β = 0 and β ≠ 0; the
+    sparse blocks' results are bit-identical to the standalone sparse leaf (same kernel body, same lane groups)."""
+    npd = NP[dtype]
+    rng = np.random.default_rng(77)
+    blocks, dense = [], []
+    for k in range(40):
+        kind = k % 4
+        if kind == 0:
+            n = int(rng.integers(1, 700))
+            d = rng.uniform(0.5, 1.5, n).astype(npd)
+            blocks.append(lo.opDiagonal(torch.from_numpy(d).to(dev))); dense.append(sp.diags(d.astype(np.float64)))
+        elif kind == 1:
+            m, n = int(rng.integers(1, 60)), int(rng.integers(1, 60))
+            B = rng.uniform(-1, 1, (m, n)).astype(npd)
+            blocks.append(torch.from_numpy(np.asfortranarray(B).T.copy()).to(dev).t()); dense.append(sp.csc_matrix(B.astype(np.float64)))
+        elif kind == 2:
+            m, n = int(rng.integers(1, 900)), int(rng.integers(1, 900))
+            A = rand_sparse(rng, m, n, float(rng.uniform(0.0, 0.08)), npd)
+            blocks.append(dev_csc(A, dev, dtype)); dense.append(A.astype(np.float64))
+        else:
+            n = int(rng.integers(1, 300))
+            blocks.append(lo.opEye(dtype, n, S=lo.Storage(dtype, dev))); dense.append(sp.identity(n, format="csc"))
+    M = lo.BlockDiagonalOperator(*blocks)
+    assert hasattr(M, "_keepalive"), "every block kind here is fusable: one launch expected"
+    D = sp.block_diag(dense, format="csc")
+    assert M.shape == D.shape
+    tol = 1e-12 if dtype == torch.float64 else 2e-5
+    for trans in (False, True):
+        op, Dm = (lo.transpose(M), D.T) if trans else (M, D)
+        nout, nin = Dm.shape
+        v = rng.uniform(-1, 1, nin).astype(npd)
+        r0 = rng.uniform(-1, 1, nout).astype(npd)
+        for a, b in ((1.0, 0.0), (2.0, -3.0)):
+            res = torch.from_numpy((np.full(nout, np.nan, npd) if b == 0 else r0).copy()).to(dev)
+            lo.mul(res, op, torch.from_numpy(v).to(dev), a, b)
+            want = a * (Dm @ v.astype(np.float64)) + (b * r0.astype(np.float64) if b != 0 else 0)
+            assert np.abs(res.cpu().numpy() - want).max() <= tol * (abs(a) * scale_of(sp.csc_matrix(Dm), v) + abs(b))
+    # a sparse block inside the fused operator == the standalone leaf, bit for bit
+    k = 2
+    off_r = sum(d.shape[0] for d in dense[:k]); off_c = sum(d.shape[1] for d in dense[:k])
+    m, n = dense[k].shape
+    x = torch.zeros(D.shape[1], dtype=dtype, device=dev)
+    xs = torch.from_numpy(rng.uniform(-1, 1, n).astype(npd)).to(dev)
+    x[off_c:off_c + n] = xs
+    full = M * x
+    alone = lo.LinearOperatorFromMatrix(blocks[k]) * xs
+    assert torch.equal(full[off_r:off_r + m], alone)
+
+
+def test_kron_with_sparse_factors(lo, dev):
+    """test/test_kron.jl:3-36 runs kron over dense AND sparse factors (simple_sparse_matrix(Float64, 10, 10)):
+    `kron(LinearOperator(A), B)` with A sparse — the factor is materialised with Matrix(op) like any operator factor —
+    against numpy's kron within the reference's eps·‖K‖₁-class criterion, for K, K', transpose(K)."""
+    rng = np.random.default_rng(10)
+    A = rand_sparse(rng, 10, 10, 0.3, np.float64)
+    for B in (rng.uniform(-1, 1, (2, 3)), rand_sparse(rng, 10, 10, 0.3, np.float64)):
+        Bn = B.toarray() if sp.issparse(B) else B
+        Bd = lo.LinearOperatorFromMatrix(dev_csc(B, dev, torch.float64)) if sp.issparse(B) else torch.from_numpy(Bn).to(dev)
+        K = np.kron(A.toarray(), Bn)
+        T1 = lo.kron(lo.LinearOperatorFromMatrix(dev_csc(A, dev, torch.float64)), Bd)
+        normK = np.abs(K).sum(axis=0).max()
+        assert np.abs(lo.Matrix(T1).cpu().numpy() - K).sum(axis=0).max() <= 1e-12 * normK
+        assert np.abs(lo.Matrix(lo.transpose(T1)).cpu().numpy() - K.T).sum(axis=0).max() <= 1e-12 * normK
+        assert np.abs(lo.Matrix(lo.adjoint(T1)).cpu().numpy() - K.T).sum(axis=0).max() <= 1e-12 * normK
+
+
+def test_csc_create_validates_like_the_sparsematrixcsc_constructor(lo, dev):
+    """SparseMatrixCSC's inner constructor rejects a colptr that does not start at 1 or decreases and row indices
+    outside 1:m (ArgumentError); mxlo_csc_create returns MXLO_EINVAL naming the offending position."""
+    i64 = lambda a: torch.tensor(a, dtype=torch.int64, device=dev)
+    vals = torch.ones(3, dtype=torch.float64, device=dev)
+    bad = [((3, 2), [1, 1, 3], [0, 1, 2], "colptr"),            # does not start at 0 (index_base 0)
+           ((3, 2), [0, 2, 1], [0, 1, 2], "decreases"),
+           ((3, 2), [0, 2, 3], [0, 3, 2], "row index")]
+    for shape, cp, rv, word in bad:
+        M = torch.sparse_csc_tensor(i64(cp), i64(rv), vals, size=shape, check_invariants=False)
+        with pytest.raises(Exception, match=word):
+            lo.LinearOperatorFromMatrix(M)
+    with pytest.raises(TypeError):
+        lo.LinearOperatorFromMatrix(torch.sparse_csc_tensor(i64([0, 1]), i64([0]), torch.ones(1, dtype=torch.complex128, device=dev),
+                                                             size=(1, 1)))
+    # empty matrix and empty pattern
+    for shape in ((0, 0), (0, 4), (5, 0), (3, 3)):
+        cp = i64([0] * (shape[1] + 1))
+        M = torch.sparse_csc_tensor(cp, i64([]), torch.zeros(0, dtype=torch.float64, device=dev), size=shape)
+        op = lo.LinearOperatorFromMatrix(M)
+        res = torch.full((shape[0],), float("nan"), dtype=torch.float64, device=dev)
+        lo.mul(res, op, torch.ones(shape[1], dtype=torch.float64, device=dev), 1.0, 0.0)
+        assert bool((res == 0).all())

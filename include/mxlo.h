@@ -468,17 +468,21 @@ int32_t mxlo_gemv_block(mxlo_ctx *ctx, int32_t dtype, void *res, int64_t ldr, co
  * create — call mxlo_csc_refresh(h) (one gather pass, stream-ordered) after changing nzval in place. The sparsity
  * pattern is fixed for the life of the handle; the handle keeps `nzval` (not colptr / rowval) referenced.
  * mxlo_csc_mul: res = alpha * op(A) * v + beta * res, op_mode MXLO_OP_N / _T / _C (_C == _T: real element types);
- * beta == 0 never reads res. Every output row is one gather-reduce by a group of 1..64 lanes (chosen from the mean row
- * length), f64 accumulation with fma in ascending entry order, one fixed combining tree: run-to-run bit-identical;
- * against the reference the difference is rounding order only (tests: 1e-13 |A||v| Float64, 1e-5 Float32).
- * mxlo_csc_info: info = {m, n, nnz, lanes per row of A*x, lanes per row of Aᵀ*x}. */
+ * beta == 0 never reads res. Both modes are a row gather-reduce on a compressed-row view cut, at create, into chunks of
+ * <= 4096 stored entries (whole rows; a row above 512 entries has chunks of its own): a workgroup streams its chunk
+ * (coalesced value / index loads, gathered x) into LDS as f64 products and sums the rows from there in a fixed order —
+ * HBM traffic and balance do not depend on the row-length distribution, results are run-to-run bit-identical; against the
+ * reference the difference is rounding order only (tests: 1e-13 |A||v| Float64, 2e-6 Float32). A row (column, for the
+ * transposed modes) with more than 4096 entries is summed piecewise and a second, tiny launch adds its pieces in order.
+ * mxlo_csc_info: info = {m, n, nnz, chunks of A*x, chunks of Aᵀ*x, rows above 4096 entries, columns above 4096
+ * entries, 4096}. A handle with such rows / columns cannot be a block of the ONE-launch block-diagonal operator. */
 typedef struct mxlo_csc mxlo_csc;
 int32_t mxlo_csc_create(mxlo_ctx *ctx, int32_t dtype, int64_t m, int64_t n, const int64_t *colptr,
                         const int64_t *rowval, const void *nzval, int32_t index_base, mxlo_csc **out);
 int32_t mxlo_csc_refresh(mxlo_csc *h);
 int32_t mxlo_csc_mul(mxlo_csc *h, void *res, const void *v, double alpha, double beta, int32_t op_mode,
                      int32_t flags);
-int32_t mxlo_csc_info(mxlo_csc *h, int64_t info[5]);
+int32_t mxlo_csc_info(mxlo_csc *h, int64_t info[8]);
 int32_t mxlo_csc_destroy(mxlo_csc *h);
 
 /* push!(B, s, y) of the diagonal quasi-Newton operators — src/DiagonalHessianApproximation.jl:

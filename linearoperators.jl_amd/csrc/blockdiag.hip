@@ -7,12 +7,14 @@
 // Tiles: elementwise blocks (opDiagonal / opEye / opZeros) are cut into 2048-row tiles; a dense
 // block contributes 256-output-row tiles in N mode (thread per row, coalesced down the columns)
 // and 4-output tiles in T mode (one wave per output, coalesced down the column).
-// A sparse block (MXLO_BLK_CSC: data = the device descriptor of an mxlo_csc handle) contributes tiles of 4 rows per
-// lane group of its compressed-row sweep (sparse_kernels.h) — the N-mode tiles walk the CSR view, the T-mode tiles the
-// CSC arrays themselves.
+// A sparse block (MXLO_BLK_CSC: data = the device descriptor of an mxlo_csc handle) contributes one tile per CHUNK of its
+// compressed-row sweep (sparse_kernels.h: <= 4096 stored entries streamed into LDS, rows summed from there) — the N-mode
+// tiles walk the CSR view, the T-mode tiles the CSC arrays themselves. Operators with sparse blocks are launched with
+// 32 KiB of dynamic LDS; the others with none (the elementwise tiles keep their occupancy).
 // Blocks start at arbitrary row offsets (e.g. 97,657-row blocks), so each tile aligns its
 // stores to 16 bytes by peeling and loads an operand with one 16-byte or two element accesses
 // depending on that operand's own phase.
+#include <algorithm>
 #include <vector>
 
 #include "common.h"
@@ -24,7 +26,7 @@ using namespace mxlo;
 struct mxlo_csc;
 namespace mxlo {
 const CscDev *csc_device_desc(const mxlo_csc *h);     // sparse.hip
-void csc_shape(const mxlo_csc *h, int64_t *m, int64_t *n, int *dtype, int *lpr_n, int *lpr_t);
+void csc_shape(const mxlo_csc *h, int64_t *m, int64_t *n, int *dtype, int *nchunks_n, int *nchunks_t, int *nlong);
 }
 
 namespace {
@@ -183,11 +185,14 @@ blockdiag_kernel(T *__restrict__ res, const T *__restrict__ x, const DevBlock *_
   T *rp = res + out_off;
   const T *xp = x + in_off;
   if (b.kind == MXLO_BLK_CSC) {
-    const CscDev S = *(const CscDev *)b.data;                 // wave-uniform descriptor fetch
+    extern __shared__ double sp_lds[];                        // kSpLdsBytes: the product buffer
+    const CscDev *S = (const CscDev *)b.data;                 // wave-uniform descriptor fetches
     if constexpr (!TRANS)
-      spmv_rows<T, CA, CB, BETA0>(rp, xp, S.rowptr, S.colidx, (const T *)S.csr_val, tl.start, tl.cnt, S.lpr_n, alpha, beta);
+      spmv_chunk<T, CA, CB, BETA0>(rp, xp, S->rowptr, S->colidx, (const T *)S->csr_val, S->chunks_n[tl.start], S->carry, alpha,
+                                   beta, sp_lds);
     else
-      spmv_rows<T, CA, CB, BETA0>(rp, xp, S.colptr, S.rowidx, (const T *)S.nzval, tl.start, tl.cnt, S.lpr_t, alpha, beta);
+      spmv_chunk<T, CA, CB, BETA0>(rp, xp, S->colptr, S->rowidx, (const T *)S->nzval, S->chunks_t[tl.start], S->carry, alpha,
+                                   beta, sp_lds);
     return;
   }
   if (b.kind != MXLO_BLK_DENSE) {
@@ -241,6 +246,7 @@ struct mxlo_blockdiag {
   DevBlock *d_blocks = nullptr;
   Tile *d_tiles_n = nullptr, *d_tiles_t = nullptr;
   int64_t ntiles_n = 0, ntiles_t = 0;
+  size_t lds_bytes = 0;     // dynamic LDS of a launch: the product buffer of the sparse tiles, 0 without sparse blocks
 };
 
 MXLO_API int32_t mxlo_blockdiag_create(mxlo_ctx *ctx, int32_t dtype, const mxlo_block_desc *blocks,
@@ -252,6 +258,7 @@ MXLO_API int32_t mxlo_blockdiag_create(mxlo_ctx *ctx, int32_t dtype, const mxlo_
   std::vector<DevBlock> hb((size_t)nblocks);
   std::vector<Tile> tn, tt;
   int64_t nrow = 0, ncol = 0;
+  bool has_sparse = false;
   for (int64_t k = 0; k < nblocks; ++k) {
     const mxlo_block_desc &b = blocks[k];
     MXLO_REQUIRE(b.kind >= MXLO_BLK_DIAG && b.kind <= MXLO_BLK_CSC, MXLO_EINVAL, "block %lld: bad kind", (long long)k);
@@ -260,12 +267,17 @@ MXLO_API int32_t mxlo_blockdiag_create(mxlo_ctx *ctx, int32_t dtype, const mxlo_
     if (b.kind == MXLO_BLK_DENSE) MXLO_REQUIRE((b.m == 0 || b.n == 0 || b.data) && b.ld >= (b.m > 1 ? b.m : 1), MXLO_ESHAPE, "block %lld: bad dense block", (long long)k);
     MXLO_REQUIRE(b.row_off == nrow && b.col_off == ncol, MXLO_ESHAPE, "block %lld: offsets must be cumulative", (long long)k);
     hb[k] = DevBlock{b.kind, 0, b.row_off, b.col_off, b.m, b.n, b.data, b.ld};
-    int lpr_n = 1, lpr_t = 1;
+    int nch_n = 0, nch_t = 0;
     if (b.kind == MXLO_BLK_CSC) {
       MXLO_REQUIRE(b.data, MXLO_EINVAL, "block %lld: a sparse block needs its mxlo_csc handle in `data`", (long long)k);
       int64_t sm = 0, sn = 0;
-      int sdt = 0;
-      csc_shape((const mxlo_csc *)b.data, &sm, &sn, &sdt, &lpr_n, &lpr_t);
+      int sdt = 0, nlong = 0;
+      csc_shape((const mxlo_csc *)b.data, &sm, &sn, &sdt, &nch_n, &nch_t, &nlong);
+      MXLO_REQUIRE(nlong == 0, MXLO_EINVAL,
+                   "block %lld: the sparse block has a row or column with more than %d stored entries, which needs the "
+                   "two-launch apply of mxlo_csc_mul (mxlo_csc_info reports it): apply that block on its own",
+                   (long long)k, kSpChunk);
+      has_sparse = true;
       MXLO_REQUIRE(sm == b.m && sn == b.n, MXLO_ESHAPE, "block %lld: descriptor says %lld x %lld, the sparse handle %lld x %lld",
                    (long long)k, (long long)b.m, (long long)b.n, (long long)sm, (long long)sn);
       MXLO_REQUIRE(sdt == dtype, MXLO_EINVAL, "block %lld: element type of the sparse handle differs from the operator's", (long long)k);
@@ -274,7 +286,11 @@ MXLO_API int32_t mxlo_blockdiag_create(mxlo_ctx *ctx, int32_t dtype, const mxlo_
     nrow += b.m;
     ncol += b.n;
     auto cut = [&](std::vector<Tile> &out, int64_t off, int64_t len, int64_t step) {
-      if (b.kind == MXLO_BLK_DENSE || b.kind == MXLO_BLK_CSC) {
+      if (b.kind == MXLO_BLK_CSC) {                      // one tile per chunk of the sweep (step = number of chunks)
+        for (int64_t c = 0; c < step; ++c) out.push_back(Tile{hb[k], c, 0});
+        return;
+      }
+      if (b.kind == MXLO_BLK_DENSE) {
         for (int64_t s = 0; s < len; s += step) out.push_back(Tile{hb[k], s, len - s < step ? len - s : step});
         return;
       }
@@ -288,8 +304,8 @@ MXLO_API int32_t mxlo_blockdiag_create(mxlo_ctx *ctx, int32_t dtype, const mxlo_
         s = e;
       }
     };
-    cut(tn, b.row_off, b.m, b.kind == MXLO_BLK_DENSE ? kTileDN : b.kind == MXLO_BLK_CSC ? (kBlock / lpr_n) * 4 : kTileE);
-    cut(tt, b.col_off, b.n, b.kind == MXLO_BLK_DENSE ? kTileDT : b.kind == MXLO_BLK_CSC ? (kBlock / lpr_t) * 4 : kTileE);
+    cut(tn, b.row_off, b.m, b.kind == MXLO_BLK_DENSE ? kTileDN : b.kind == MXLO_BLK_CSC ? nch_n : kTileE);
+    cut(tt, b.col_off, b.n, b.kind == MXLO_BLK_DENSE ? kTileDT : b.kind == MXLO_BLK_CSC ? nch_t : kTileE);
   }
   mxlo_blockdiag *bd = new mxlo_blockdiag();
   bd->ctx = ctx;
@@ -299,6 +315,7 @@ MXLO_API int32_t mxlo_blockdiag_create(mxlo_ctx *ctx, int32_t dtype, const mxlo_
   bd->ncol = ncol;
   bd->ntiles_n = (int64_t)tn.size();
   bd->ntiles_t = (int64_t)tt.size();
+  bd->lds_bytes = has_sparse ? kSpLdsBytes : 0;
   hipError_t e = hipSuccess;
   auto up = [&](void **dst, const void *src, size_t bytes) {
     if (e != hipSuccess || bytes == 0) return;
@@ -340,8 +357,10 @@ static int32_t blockdiag_mul_t(mxlo_blockdiag *bd, T *res, const T *v, double al
   return dispatch_ab<T>(beta, flags, [&]<typename CA, typename CB, bool B0>() -> int32_t {
     const bool ntm = (int64_t)sizeof(T) * (bd->nrow + 2 * bd->ncol) >= ctx->tune.nt_min_bytes;
 #define BD_GO(TR_, NT_)                                                                               \
-  hipLaunchKernelGGL((blockdiag_kernel<T, CA, CB, B0, TR_, NT_>), dim3((unsigned)nt), dim3(kBlock), 0, \
-                     ctx->stream, res, v, bd->d_blocks, tiles, (CA)alpha, (CB)beta)
+  do {                                                                                                \
+  hipLaunchKernelGGL((blockdiag_kernel<T, CA, CB, B0, TR_, NT_>), dim3((unsigned)nt), dim3(kBlock), bd->lds_bytes, \
+                     ctx->stream, res, v, bd->d_blocks, tiles, (CA)alpha, (CB)beta);                   \
+  } while (0)
     if (trans && ntm) BD_GO(true, true);
     else if (trans) BD_GO(true, false);
     else if (ntm) BD_GO(false, true);

@@ -1,8 +1,8 @@
 // sparse.hip — LinearOperator(M::SparseMatrixCSC) prod!/tprod!/ctprod! (src/constructors.jl:19-29 hands M to
 // LinearAlgebra.mul!, i.e. to the SparseArrays stdlib) and the sparse blocks of BlockDiagonalOperator
 // (test/test_linop.jl:743-756 builds one from an operator, a Matrix and a sprand block).
-// Kernel design: sparse_kernels.h. This file: the handle (compressed-row view built once at construction, values
-// permuted into row order), refresh after in-place value updates, the apply.
+// Kernel design: sparse_kernels.h. This file: the handle (compressed-row view and chunk tables built once at
+// construction, values permuted into row order), refresh after in-place value updates, the apply.
 #include <algorithm>
 #include <numeric>
 #include <vector>
@@ -20,12 +20,14 @@ struct mxlo_csc {
   CscDev *dev = nullptr;    // device-resident copy (what MXLO_BLK_CSC blocks of a fused block-diagonal point at)
   int32_t *perm = nullptr;  // [nnz] CSR position -> CSC position (mxlo_csc_refresh)
   const void *nzval = nullptr;
+  SpLongRow *long_n = nullptr, *long_t = nullptr;   // rows cut into pieces (fix-up launch), per mode
 };
 
 namespace mxlo {
 const CscDev *csc_device_desc(const mxlo_csc *h) { return h ? h->dev : nullptr; }   // blockdiag.hip
-void csc_shape(const mxlo_csc *h, int64_t *m, int64_t *n, int *dtype, int *lpr_n, int *lpr_t) {
-  *m = h->m; *n = h->n; *dtype = h->dtype; *lpr_n = h->host.lpr_n; *lpr_t = h->host.lpr_t;
+void csc_shape(const mxlo_csc *h, int64_t *m, int64_t *n, int *dtype, int *nchunks_n, int *nchunks_t, int *nlong) {
+  *m = h->m; *n = h->n; *dtype = h->dtype;
+  *nchunks_n = h->host.nchunks_n; *nchunks_t = h->host.nchunks_t; *nlong = h->host.nlong_n + h->host.nlong_t;
 }
 }  // namespace mxlo
 
@@ -41,39 +43,72 @@ csc_gather_values_kernel(T *__restrict__ out, const T *__restrict__ nzval, const
 template <typename T, typename CA, typename CB, bool BETA0>
 __global__ void __launch_bounds__(kBlock)
 csc_mul_kernel(T *__restrict__ res, const T *__restrict__ x, const int64_t *__restrict__ ptr, const int32_t *__restrict__ idx,
-               const T *__restrict__ val, int64_t nrows, int lpr, int rows_per_block, CA alpha, CB beta) {
-  const int64_t row0 = (int64_t)blockIdx.x * rows_per_block;
-  const int64_t cnt = nrows - row0 < rows_per_block ? nrows - row0 : rows_per_block;
-  spmv_rows<T, CA, CB, BETA0>(res, x, ptr, idx, val, row0, cnt, lpr, alpha, beta);
+               const T *__restrict__ val, const SpChunk *__restrict__ chunks, double *__restrict__ carry, CA alpha, CB beta) {
+  __shared__ double prod[kSpChunk];
+  spmv_chunk<T, CA, CB, BETA0>(res, x, ptr, idx, val, chunks[blockIdx.x], carry, alpha, beta, prod);
 }
 
-// lanes per row from the mean row length: the smallest power of two >= the mean, 1 .. 64
-int lanes_per_row(int64_t nnz, int64_t rows) {
-  if (rows <= 0) return 1;
-  const double mean = (double)nnz / (double)rows;
-  int l = 1;
-  while (l < 64 && (double)l < mean) l <<= 1;
-  return l;
+// The chunk table of one compressed-row operand (see sparse_kernels.h): whole rows packed into chunks of <= kSpChunk
+// entries (and <= kSpChunk rows: empty rows still need their beta step), rows above kSpLongRow entries on their own.
+void build_chunks(const std::vector<int64_t> &ptr, int64_t nrows, std::vector<SpChunk> &chunks, std::vector<SpLongRow> &longs,
+                  int *ncarry) {
+  SpChunk cur{0, 0, 0, 0, SP_ROWS, 0, 0};
+  auto flush = [&]() {
+    if (cur.nr > 0) chunks.push_back(cur);
+    cur.nz = 0;
+    cur.nr = 0;
+  };
+  int carry = 0;
+  for (int64_t r = 0; r < nrows; ++r) {
+    const int64_t len = ptr[r + 1] - ptr[r];
+    if (len > kSpLongRow) {
+      flush();
+      if (len <= kSpChunk) {
+        chunks.push_back(SpChunk{ptr[r], (int32_t)len, (int32_t)r, 1, SP_LONG1, 0, 0});
+      } else {
+        SpLongRow lr{(int32_t)r, carry, 0, 0};
+        for (int64_t k = ptr[r]; k < ptr[r + 1]; k += kSpChunk) {
+          const int64_t piece = std::min<int64_t>(kSpChunk, ptr[r + 1] - k);
+          chunks.push_back(SpChunk{k, (int32_t)piece, (int32_t)r, 1, SP_PIECE, carry++, 0});
+          ++lr.npieces;
+        }
+        longs.push_back(lr);
+      }
+      continue;
+    }
+    if (cur.nr > 0 && (cur.nz + len > kSpChunk || cur.nr == kSpChunk)) flush();
+    if (cur.nr == 0) {
+      cur.k0 = ptr[r];
+      cur.row0 = (int32_t)r;
+    }
+    cur.nz += (int32_t)len;
+    ++cur.nr;
+  }
+  flush();
+  *ncarry = carry;
 }
 
 template <typename T>
 int32_t csc_mul_t(mxlo_csc *h, T *res, const T *v, double alpha, double beta, int32_t op_mode, int32_t flags) {
   mxlo_ctx *ctx = h->ctx;
   const bool trans = op_mode != MXLO_OP_N;
-  const int64_t nrows = trans ? h->n : h->m;
-  if (nrows == 0) return MXLO_OK;
-  const int64_t *ptr = trans ? h->host.colptr : h->host.rowptr;
-  const int32_t *idx = trans ? h->host.rowidx : h->host.colidx;
-  const T *val = (const T *)(trans ? h->host.nzval : h->host.csr_val);
-  const int lpr = trans ? h->host.lpr_t : h->host.lpr_n;
-  // rows per workgroup: every lane group takes 4 rows (amortises the launch of a workgroup, keeps >= 1 row per group)
-  const int rpb = (kBlock / lpr) * 4;
-  const int64_t grid = (nrows + rpb - 1) / rpb;
-  MXLO_REQUIRE(grid < (1LL << 31), MXLO_ESHAPE, "mxlo_csc_mul: too many rows for one launch");
+  const CscDev &d = h->host;
+  const int nchunks = trans ? d.nchunks_t : d.nchunks_n, nlong = trans ? d.nlong_t : d.nlong_n;
+  if (nchunks == 0) return MXLO_OK;
+  const int64_t *ptr = trans ? d.colptr : d.rowptr;
+  const int32_t *idx = trans ? d.rowidx : d.colidx;
+  const T *val = (const T *)(trans ? d.nzval : d.csr_val);
+  const SpChunk *chunks = trans ? d.chunks_t : d.chunks_n;
+  const SpLongRow *longs = trans ? h->long_t : h->long_n;
   return dispatch_ab<T>(beta, flags, [&]<typename CA, typename CB, bool B0>() -> int32_t {
-    hipLaunchKernelGGL((csc_mul_kernel<T, CA, CB, B0>), dim3((unsigned)grid), dim3(kBlock), 0, ctx->stream, res, v, ptr, idx,
-                       val, nrows, lpr, rpb, (CA)alpha, (CB)beta);
+    hipLaunchKernelGGL((csc_mul_kernel<T, CA, CB, B0>), dim3((unsigned)nchunks), dim3(kBlock), 0, ctx->stream, res, v, ptr, idx,
+                       val, chunks, d.carry, (CA)alpha, (CB)beta);
     MXLO_LAUNCH_CHECK();
+    if (nlong > 0) {
+      hipLaunchKernelGGL((spmv_fixup_kernel<T, CA, CB, B0>), dim3((unsigned)((nlong + kBlock - 1) / kBlock)), dim3(kBlock), 0,
+                         ctx->stream, res, d.carry, longs, nlong, (CA)alpha, (CB)beta);
+      MXLO_LAUNCH_CHECK();
+    }
     return MXLO_OK;
   });
 }
@@ -109,8 +144,8 @@ MXLO_API int32_t mxlo_csc_create(mxlo_ctx *ctx, int32_t dtype, int64_t m, int64_
   std::vector<int64_t> rp((size_t)m + 1, 0);
   for (int64_t k = 0; k < nnz; ++k) {
     const int64_t r = rv[k] - index_base;
-    MXLO_REQUIRE(r >= 0 && r < m, MXLO_EINVAL, "mxlo_csc_create: row index %lld at position %lld outside 1..%lld",
-                 (long long)rv[k], (long long)k, (long long)m);
+    MXLO_REQUIRE(r >= 0 && r < m, MXLO_EINVAL, "mxlo_csc_create: row index %lld at position %lld outside %d..%lld",
+                 (long long)rv[k], (long long)k, (int)index_base, (long long)(m - 1 + index_base));
     ri[k] = (int32_t)r;
     ++rp[r + 1];
   }
@@ -126,6 +161,14 @@ MXLO_API int32_t mxlo_csc_create(mxlo_ctx *ctx, int32_t dtype, int64_t m, int64_
         perm[p] = (int32_t)k;
       }
   }
+  // ---- chunk tables of the two sweeps
+  std::vector<SpChunk> chn, cht;
+  std::vector<SpLongRow> lgn, lgt;
+  int ncar_n = 0, ncar_t = 0;
+  build_chunks(rp, m, chn, lgn, &ncar_n);
+  build_chunks(cp, n, cht, lgt, &ncar_t);
+  MXLO_REQUIRE(chn.size() < (1u << 31) && cht.size() < (1u << 31), MXLO_ESHAPE, "mxlo_csc_create: too many chunks");
+
   mxlo_csc *h = new mxlo_csc();
   h->ctx = ctx;
   h->dtype = dtype;
@@ -145,13 +188,20 @@ MXLO_API int32_t mxlo_csc_create(mxlo_ctx *ctx, int32_t dtype, int64_t m, int64_
   up((void **)&d.colptr, cp.data(), sizeof(int64_t) * cp.size());
   up((void **)&d.rowidx, ri.data(), sizeof(int32_t) * (size_t)nnz);
   up((void **)&h->perm, perm.data(), sizeof(int32_t) * (size_t)nnz);
+  up((void **)&d.chunks_n, chn.data(), sizeof(SpChunk) * chn.size());
+  up((void **)&d.chunks_t, cht.data(), sizeof(SpChunk) * cht.size());
+  up((void **)&h->long_n, lgn.data(), sizeof(SpLongRow) * lgn.size());
+  up((void **)&h->long_t, lgt.data(), sizeof(SpLongRow) * lgt.size());
   if (e == hipSuccess) e = hipMalloc((void **)&d.csr_val, nnz ? es * (size_t)nnz : 16);
+  if (e == hipSuccess) e = hipMalloc((void **)&d.carry, sizeof(double) * (size_t)std::max(1, std::max(ncar_n, ncar_t)));
   d.nzval = nzval;
   d.m = m;
   d.n = n;
   d.nnz = nnz;
-  d.lpr_n = lanes_per_row(nnz, m);
-  d.lpr_t = lanes_per_row(nnz, n);
+  d.nchunks_n = (int32_t)chn.size();
+  d.nchunks_t = (int32_t)cht.size();
+  d.nlong_n = (int32_t)lgn.size();
+  d.nlong_t = (int32_t)lgt.size();
   if (e == hipSuccess) e = hipMalloc((void **)&h->dev, sizeof(CscDev));
   if (e == hipSuccess) e = hipMemcpy(h->dev, &d, sizeof(CscDev), hipMemcpyHostToDevice);
   if (e != hipSuccess) {
@@ -197,13 +247,16 @@ MXLO_API int32_t mxlo_csc_mul(mxlo_csc *h, void *res, const void *v, double alph
   return csc_mul_t<float>(h, (float *)res, (const float *)v, alpha, beta, op_mode, flags);
 }
 
-MXLO_API int32_t mxlo_csc_info(mxlo_csc *h, int64_t info[5]) {
+MXLO_API int32_t mxlo_csc_info(mxlo_csc *h, int64_t info[8]) {
   MXLO_REQUIRE(h && info, MXLO_EINVAL, "mxlo_csc_info: NULL argument");
   info[0] = h->m;
   info[1] = h->n;
   info[2] = h->nnz;
-  info[3] = h->host.lpr_n;
-  info[4] = h->host.lpr_t;
+  info[3] = h->host.nchunks_n;
+  info[4] = h->host.nchunks_t;
+  info[5] = h->host.nlong_n;
+  info[6] = h->host.nlong_t;
+  info[7] = kSpChunk;
   return MXLO_OK;
 }
 
@@ -213,7 +266,8 @@ MXLO_API int32_t mxlo_csc_destroy(mxlo_csc *h) {
   (void)hipStreamSynchronize(h->ctx->stream);
   for (const void *p : {(const void *)h->host.rowptr, (const void *)h->host.colidx, h->host.csr_val,
                         (const void *)h->host.colptr, (const void *)h->host.rowidx, (const void *)h->perm,
-                        (const void *)h->dev})
+                        (const void *)h->host.chunks_n, (const void *)h->host.chunks_t, (const void *)h->host.carry,
+                        (const void *)h->long_n, (const void *)h->long_t, (const void *)h->dev})
     if (p) (void)hipFree(const_cast<void *>(p));
   delete h;
   return MXLO_OK;

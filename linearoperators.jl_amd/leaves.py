@@ -10,6 +10,7 @@ them): ``opRestriction([1, 2, 4, 7], 10)``; ``jrange(3, 6)`` is Julia's ``3:6`` 
 """
 from __future__ import annotations
 
+import operator
 import os
 
 import ctypes as C
@@ -365,6 +366,7 @@ def _stored_colmajor(M: torch.Tensor):
 
 
 _SPARSE_LAYOUTS = (torch.sparse_csc, torch.sparse_csr, torch.sparse_coo)
+_version_of = operator.attrgetter("_version")
 
 
 class _CscHandle:
@@ -377,9 +379,10 @@ class _CscHandle:
                   C.byref(self.h))
 
     def info(self):
-        a = (C.c_int64 * 5)()
+        a = (C.c_int64 * 8)()
         _lib.call("mxlo_csc_info", self.h, a)
-        return {"m": a[0], "n": a[1], "nnz": a[2], "lanes_per_row": a[3], "lanes_per_col": a[4]}
+        return {"m": a[0], "n": a[1], "nnz": a[2], "chunks_n": a[3], "chunks_t": a[4], "long_rows": a[5], "long_cols": a[6],
+                "chunk": a[7]}
 
     def __del__(self):
         try:
@@ -448,8 +451,9 @@ def LinearOperatorFromSparse(M: torch.Tensor, symmetric: bool = False, hermitian
     tprod = columnwise(lambda res, u, a, b: spmv(res, u, a, b, bwd))
     op = LinearOperator(T, nrow, ncol, symmetric, hermitian, prod, tprod, tprod,
                         S=S if S is not None else Storage(T, vals.device))
-    if not tr:
-        op._leaf = ("csc", handle, vals, seen)    # fused BlockDiagonalOperator: MXLO_BLK_CSC
+    inf = handle.info()
+    if not tr and inf["long_rows"] == 0 and inf["long_cols"] == 0:
+        op._leaf = ("csc", handle, vals, seen)    # fused BlockDiagonalOperator: MXLO_BLK_CSC (no row / column beyond one chunk)
     op._sparse_src = M
     op._csc = handle
     op._deps = (vals,)
@@ -572,15 +576,22 @@ def BlockDiagonalOperator(*ops, S: Optional[Storage] = None):
     if fusable:
         ctx = get_ctx(S.device)
         handle = _BlockDiagHandle(ctx, T, descs)
+        sparse_vals = [leaf[2] for leaf in sparse_blocks]
+        seen_sum = [-1]
 
         def bd(res, x, a, b, mode):
             get_ctx(res.device)
-            if mode == _lib.OP_N:
-                for _, hcsc, vals, seen in sparse_blocks:     # sparse blocks: row-ordered value snapshots (see the leaf)
-                    tok = state_version(vals)
-                    if tok != seen[0]:
-                        _lib.call("mxlo_csc_refresh", hcsc.h)
-                        seen[0] = tok
+            if mode == _lib.OP_N and sparse_blocks:
+                # sparse blocks: row-ordered value snapshots (see the leaf). One C-level pass over the version counters
+                # (a Python loop over 1024 blocks would cost more than the launch); the per-block check only on a change
+                vsum = sum(map(_version_of, sparse_vals))
+                if vsum != seen_sum[0]:
+                    seen_sum[0] = vsum
+                    for _, hcsc, vals, seen in sparse_blocks:
+                        tok = state_version(vals)
+                        if tok != seen[0]:
+                            _lib.call("mxlo_csc_refresh", hcsc.h)
+                            seen[0] = tok
             _lib.call("mxlo_blockdiag_mul", handle.h, ptr(res), ptr(x), float(a), float(b), mode,
                       scalar_flags(res.dtype, a, b))
 

@@ -88,7 +88,7 @@ def test_csc_row_lengths_from_one_lane_to_a_full_wave(lo, dev):
         A.sort_indices()
         op = lo.LinearOperatorFromMatrix(dev_csc(A, dev, torch.float64))
         info = op._csc.info()
-        assert info["nnz"] == A.nnz and 1 <= info["lanes_per_row"] <= 64
+        assert info["nnz"] == A.nnz and info["chunk"] == 4096 and info["chunks_n"] >= A.nnz // 4096
         v = rng.uniform(-1, 1, n)
         res, res2 = torch.empty(m, dtype=torch.float64, device=dev), torch.empty(m, dtype=torch.float64, device=dev)
         lo.mul(res, op, torch.from_numpy(v).to(dev), 1.0, 0.0)
@@ -263,3 +263,46 @@ def test_csc_create_validates_like_the_sparsematrixcsc_constructor(lo, dev):
         res = torch.full((shape[0],), float("nan"), dtype=torch.float64, device=dev)
         lo.mul(res, op, torch.ones(shape[1], dtype=torch.float64, device=dev), 1.0, 0.0)
         assert bool((res == 0).all())
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_rows_and_columns_longer_than_a_chunk(lo, dev, dtype):
+    """A few very long rows / columns among many short ones (an arrow-head pattern): rows of 513 … 4096 entries take a
+    chunk of their own, longer ones are summed piecewise with the second (fix-up) launch. Such a matrix cannot be a
+    block of the ONE-launch block-diagonal operator: the host mirror then takes the per-block loop — same numbers."""
+    npd = NP[dtype]
+    rng = np.random.default_rng(21)
+    n = 30_000
+    A = sp.random(n, n, 2e-4, format="lil", random_state=4, data_rvs=lambda k: rng.uniform(-1, 1, k))
+    for r, cnt in ((0, n), (17, 600), (999, 4096), (1000, 4097), (n - 1, 20_001)):
+        cols = rng.choice(n, size=cnt, replace=False)
+        A[r, cols] = rng.uniform(-1, 1, cnt)
+    for c, cnt in ((5, n), (n // 2, 9000)):
+        rows = rng.choice(n, size=cnt, replace=False)
+        A[rows, c] = rng.uniform(-1, 1, cnt)
+    A = sp.csc_matrix(A).astype(npd)
+    A.sort_indices()
+    op = lo.LinearOperatorFromMatrix(dev_csc(A, dev, dtype))
+    inf = op._csc.info()
+    assert inf["long_rows"] == 4 and inf["long_cols"] == 2
+    assert getattr(op, "_leaf", None) is None
+    for trans in (False, True):
+        v = rng.uniform(-1, 1, n).astype(npd)
+        r0 = rng.uniform(-1, 1, n).astype(npd)
+        for a, b in ((1.0, 0.0), (2.0, -3.0)):
+            res = torch.from_numpy((np.full(n, np.nan, npd) if b == 0 else r0).copy()).to(dev)
+            res2 = res.clone()
+            o = lo.transpose(op) if trans else op
+            lo.mul(res, o, torch.from_numpy(v).to(dev), a, b)
+            lo.mul(res2, o, torch.from_numpy(v).to(dev), a, b)
+            assert torch.equal(res, res2)
+            want = a * ((A.T if trans else A).astype(np.float64) @ v.astype(np.float64)) + (b * r0.astype(np.float64) if b else 0)
+            tol = (1e-12 if dtype == torch.float64 else 2e-5) * (abs(a) * scale_of(A.T if trans else A, v) + abs(b))
+            assert np.abs(res.cpu().numpy() - want).max() <= tol, (trans, a, b)
+    d = torch.from_numpy(rng.uniform(0.5, 1.5, 100).astype(npd)).to(dev)
+    M = lo.BlockDiagonalOperator(lo.opDiagonal(d), op)
+    assert not hasattr(M, "_keepalive")
+    x = rng.uniform(-1, 1, n + 100).astype(npd)
+    got = (M * torch.from_numpy(x).to(dev)).cpu().numpy()
+    want = np.concatenate([d.cpu().numpy().astype(np.float64) * x[:100], A.astype(np.float64) @ x[100:].astype(np.float64)])
+    assert np.abs(got - want).max() <= (1e-12 if dtype == torch.float64 else 2e-5) * scale_of(A, x[100:])

@@ -468,3 +468,40 @@ def test_complex_mixed_scalars_and_eye_zeros():
     z = oracle.zeros_mul(r.copy(), 0.5 + 0.25j, flags=oracle.scalar_flags(np.complex64, 0, 0.5 + 0.25j))
     assert np.array_equal(z, (r.astype(np.complex128) * (0.5 + 0.25j)).astype(np.complex64))
     assert np.array_equal(oracle.zeros_mul(np.full(4, np.nan + 0j), 0.0), np.zeros(4, dtype=np.complex128))
+
+
+@pytest.mark.parametrize("npd", [np.float64, np.float32])
+def test_sparse_csc_restatement_vs_an_independent_dense_product(npd):
+    """oracle.csc_mul restates the SparseArrays loops behind `mul!(res, M::SparseMatrixCSC, v, α, β)`
+    (src/constructors.jl:19-29). The reference holds no literal vectors for sparse operators — its tests compare them
+    with dense matrices to sqrt(eps) (test/test_linop.jl:743-756, test/test_kron.jl:3-36) — so the restatement is pinned
+    the same way, against a dense product formed independently (float64 / longdouble), for A*v and Aᵀ*v, β = 0 on NaN
+    garbage, β = 1, general α, β, empty columns, unsorted rows and duplicate entries, Float32 data with Float64 scalars."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(99)
+    eps = np.finfo(npd).eps
+    for m, n, dens in ((1, 1, 1.0), (6, 9, 0.4), (40, 25, 0.15), (200, 300, 0.03), (30, 30, 0.0)):
+        A = sp.random(m, n, dens, format="csc", random_state=int(rng.integers(1 << 30))).astype(npd)
+        # shuffle the rows inside every column and duplicate one entry: legal input for the reference's loops
+        cp, rv, nz = A.indptr.astype(np.int64), A.indices.astype(np.int64), A.data.copy()
+        for j in range(n):
+            p = rng.permutation(cp[j + 1] - cp[j]) + cp[j]
+            rv[cp[j]:cp[j + 1]], nz[cp[j]:cp[j + 1]] = rv[p], nz[p]
+        if nz.size:
+            j = int(np.searchsorted(cp, 0, side="right") - 1)
+            rv = np.insert(rv, cp[j], rv[cp[j]]); nz = np.insert(nz, cp[j], npd(0.5)); cp[j + 1:] += 1
+        D = np.zeros((m, n), np.longdouble)
+        for j in range(n):
+            for k in range(cp[j], cp[j + 1]):
+                D[rv[k], j] += np.longdouble(nz[k])
+        for trans in (False, True):
+            Dm = D.T if trans else D
+            v = rng.uniform(-1, 1, Dm.shape[1]).astype(npd)
+            r0 = rng.uniform(-1, 1, Dm.shape[0]).astype(npd)
+            for a, b, flags in ((1.0, 0.0, 0), (2.0, -3.0, 0), (-0.5, 1.0, 0), (1.25, 0.75, 0x1 | 0x8)):
+                start = np.full(r0.size, np.nan, npd) if b == 0 else r0.copy()
+                got = oracle.csc_mul(start, cp + 1, rv + 1, nz, m, n, v, a, b, trans=trans, flags=flags)
+                want = a * (Dm @ v.astype(np.longdouble)) + (b * r0.astype(np.longdouble) if b != 0 else 0)
+                scale = abs(a) * (np.abs(Dm) @ np.abs(v.astype(np.longdouble))).max(initial=0) + abs(b) + 1e-300
+                assert np.isfinite(got).all()
+                assert np.abs(got.astype(np.longdouble) - want).max() <= 16 * max(m, n) ** 0.5 * eps * scale, (m, n, trans, a, b)

@@ -18,7 +18,7 @@ tm = Timer(ctx)
 gen = torch.Generator(device=dev).manual_seed(1)
 PEAK = 8000.0
 ONLY = set(a for a in sys.argv[1:] if not a.startswith("-"))
-SECTIONS = ("leaves", "small", "restrict", "complex", "dense", "cherm", "kron", "qn", "variants", "cpu", "cfg5", "graph", "blocks")
+SECTIONS = ("leaves", "small", "restrict", "complex", "dense", "cherm", "kron", "qn", "variants", "cpu", "cfg5", "graph", "blocks", "sparse")
 assert ONLY <= set(SECTIONS), f"sections: {SECTIONS}"
 
 
@@ -413,3 +413,82 @@ if sec("blocks"):
             except Exception as e:
                 line += f"; graph capture failed: {e!r}"[:120]
         print(line, flush=True)
+
+
+# Sparse LinearOperator(M::SparseMatrixCSC) (mxlo_csc_mul) and sparse blocks in the one-launch BlockDiagonalOperator.
+# Algorithmic bytes per apply: every stored entry once (8 B value + 4 B index inside the library), the row pointers
+# (8 B per output row), the output written once and the input vector read once (gathers of a banded / random pattern
+# re-use lines through L2: x is counted once).
+if sec("sparse"):
+    def banded_csc(n, per_row, spread, dt=torch.float64):
+        """n x n, `per_row` entries per column at random offsets within +-spread of the diagonal (sorted, distinct)"""
+        cols = torch.arange(n, device=dev).repeat_interleave(per_row)
+        offs = torch.stack([torch.randperm(2 * spread + 1, device=dev, generator=gen)[:per_row] for _ in range(64)])
+        off = offs[torch.randint(0, 64, (n,), device=dev, generator=gen)].reshape(-1) - spread
+        rows = (cols + off).clamp_(0, n - 1)
+        key = cols * n + rows
+        key = torch.unique(key)                              # sorted by (col, row), duplicates dropped
+        cols, rows = key // n, key % n
+        ccol = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+        ccol[1:] = torch.cumsum(torch.bincount(cols, minlength=n), 0)
+        vals = torch.rand(key.numel(), dtype=dt, device=dev, generator=gen) - 0.5
+        return torch.sparse_csc_tensor(ccol, rows, vals, size=(n, n))
+
+    for dt, es in ((torch.float64, 8), (torch.float32, 4)):
+        for n, per_row, spread in ((4_000_000, 16, 2000), (4_000_000, 4, 2000), (1_000_000, 64, 5000), (250_000, 256, 20000),
+                                   (4_000_000, 16, 1_500_000)):
+            if dt == torch.float32 and per_row not in (16,):
+                continue
+            M = banded_csc(n, per_row, spread, dt)
+            op = lo.LinearOperatorFromMatrix(M)
+            nnz = M.values().numel()
+            x, y = rnd(n, dt), torch.empty(n, dtype=dt, device=dev)
+            nbytes = nnz * (es + 4) + n * 8 + 2 * n * es
+            inf = op._csc.info()
+            row(f"sparse A*x  n={n:.0e} {nnz / n:5.1f}/row spread {spread} {str(dt)[6:]} ({inf['chunks_n']} chunks)", nbytes,
+                timeit(lambda: lo.mul(y, op, x, 1.0, 0.0)))
+            opt = lo.transpose(op)
+            row(f"sparse A'*x n={n:.0e} {nnz / n:5.1f}/col spread {spread} {str(dt)[6:]} ({inf['chunks_t']} chunks)", nbytes,
+                timeit(lambda: lo.mul(y, opt, x, 1.0, 0.0)))
+            del M, op, opt
+    # a pattern solvers actually apply: the 7-point Laplacian of a 160^3 grid and the 27-point stencil of 128^3 (runs of
+    # contiguous columns: the gathers re-use their cache lines)
+    def stencil_csc(g, offsets, dt=torch.float64):
+        n = g ** 3
+        i = torch.arange(n, device=dev)
+        z, y, xg = i // (g * g), (i // g) % g, i % g
+        cols, rows = [], []
+        for dz, dy, dx in offsets:
+            ok = (z + dz >= 0) & (z + dz < g) & (y + dy >= 0) & (y + dy < g) & (xg + dx >= 0) & (xg + dx < g)
+            cols.append(i[ok]); rows.append((i + (dz * g + dy) * g + dx)[ok])
+        key = torch.unique(torch.cat(cols) * n + torch.cat(rows))
+        cols, rows = key // n, key % n
+        ccol = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+        ccol[1:] = torch.cumsum(torch.bincount(cols, minlength=n), 0)
+        vals = torch.rand(key.numel(), dtype=dt, device=dev, generator=gen) - 0.5
+        return torch.sparse_csc_tensor(ccol, rows, vals, size=(n, n))
+
+    seven = [(0, 0, 0), (1, 0, 0), (-1, 0, 0), (0, 1, 0), (0, -1, 0), (0, 0, 1), (0, 0, -1)]
+    full27 = [(a, b, c) for a in (-1, 0, 1) for b in (-1, 0, 1) for c in (-1, 0, 1)]
+    for name, g, offs in (("7-point Laplacian 160^3", 160, seven), ("27-point stencil 128^3", 128, full27)):
+        M = stencil_csc(g, offs)
+        op = lo.LinearOperatorFromMatrix(M)
+        n, nnz = g ** 3, M.values().numel()
+        x, y = rnd(n), torch.empty(n, dtype=torch.float64, device=dev)
+        nbytes = nnz * 12 + n * 8 + 2 * n * 8
+        row(f"sparse A*x  {name} ({nnz / n:4.1f}/row)", nbytes, timeit(lambda: lo.mul(y, op, x, 1.0, 0.0)))
+        opt = lo.transpose(op)
+        row(f"sparse A'*x {name}", nbytes, timeit(lambda: lo.mul(y, opt, x, 1.0, 0.0)))
+        del M, op, opt
+    # 1024 sparse blocks of 1024 x 1024, 8 entries per column: one fused launch vs the per-block loop (2.0 * block is not fusable)
+    nb, bs = 1024, 1024
+    blocks = [banded_csc(bs, 8, 100) for _ in range(nb)]
+    leaves = [lo.LinearOperatorFromMatrix(b) for b in blocks]
+    x, y = rnd(nb * bs), torch.empty(nb * bs, dtype=torch.float64, device=dev)
+    BD = lo.BlockDiagonalOperator(*leaves)
+    ms = timeit(lambda: lo.mul(y, BD, x, 1.0, 0.0), 10)
+    nnz = sum(b.values().numel() for b in blocks)
+    row("BlockDiagonal of 1024 sparse 1024^2 blocks (8/col), ONE launch", nnz * 12 + nb * bs * 24, ms)
+    BDl = lo.BlockDiagonalOperator(*[2.0 * l for l in leaves])
+    ms2 = timeit(lambda: lo.mul(y, BDl, x, 1.0, 0.0), 3)
+    print(f"  the same blocks through the per-block loop (1024 launches): {ms2 * 1e3:9.1f} us per apply  (x{ms2 / ms:5.1f})", flush=True)

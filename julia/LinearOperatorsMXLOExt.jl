@@ -427,6 +427,54 @@ function multRestrict!(res::MXVector, Idx::Vector{<:Integer}, u::MXVector, Î±, Î
               res.ptr, length(res), u.ptr, pl.idx.ptr, pl.pos === nothing ? C_NULL : pl.pos.ptr, pl.n))
 end
 
+# ---- sparse LinearOperator(M::SparseMatrixCSC) (src/constructors.jl:15-29 -> SparseArrays' mul!) ---------------------
+# `MXSparseMatrixCSC(A)` uploads the three arrays of a SparseMatrixCSC{T,Int64} AS STORED (1-based) and creates the
+# library handle (compressed-row view + chunk tables, include/mxlo.h). Aáµ€*x / A'*x read `nzval` in place; A*x reads a
+# row-ordered snapshot of the values: after changing `A.nzval` on the device call `refresh!(A)` (one gather pass).
+mutable struct MXSparseMatrixCSC{T} <: AbstractMatrix{T}
+  h::Ptr{Cvoid}
+  m::Int
+  n::Int
+  colptr::MXVector{Int64}
+  rowval::MXVector{Int64}
+  nzval::MXVector{T}
+end
+function MXSparseMatrixCSC(m::Integer, n::Integer, colptr::Vector{Int64}, rowval::Vector{Int64}, nzval::Vector{T}) where {T <: RealT}
+  cp, rv, nz = MXVector(colptr), MXVector(rowval), MXVector(nzval)
+  out = Ref{Ptr{Cvoid}}()
+  check(ccall((:mxlo_csc_create, lib), Int32, (P, Int32, Int64, Int64, P, P, P, Int32, Ptr{P}),
+              ctx(), dt(T), m, n, cp.ptr, rv.ptr, nz.ptr, Int32(1), out))
+  finalizer(x -> ccall((:mxlo_csc_destroy, lib), Int32, (P,), x.h), MXSparseMatrixCSC{T}(out[], m, n, cp, rv, nz))
+end
+# any SparseMatrixCSC-like object with the documented field names (SparseArrays is not a dependency of this file)
+MXSparseMatrixCSC(A) = MXSparseMatrixCSC(size(A, 1), size(A, 2), collect(Int64, A.colptr), collect(Int64, A.rowval), collect(A.nzval))
+size(A::MXSparseMatrixCSC) = (A.m, A.n)
+storage_type(::MXSparseMatrixCSC{T}) where {T} = MXVector{T}
+refresh!(A::MXSparseMatrixCSC) = (check(ccall((:mxlo_csc_refresh, lib), Int32, (P,), A.h)); A)
+function sparse_info(A::MXSparseMatrixCSC)
+  info = Vector{Int64}(undef, 8)
+  check(ccall((:mxlo_csc_info, lib), Int32, (P, Ptr{Int64}), A.h, info))
+  (m = info[1], n = info[2], nnz = info[3], chunks = info[4], chunks_t = info[5], long_rows = info[6], long_cols = info[7])
+end
+struct SparseApply{T}
+  A::MXSparseMatrixCSC{T}
+  mode::Int32
+end
+(f::SparseApply{T})(res::MXVector{T}, v::MXVector{T}, Î±, Î²) where {T <: RealT} = check(ccall((:mxlo_csc_mul, lib), Int32,
+    (P, P, P, Float64, Float64, Int32, Int32), f.A.h, res.ptr, v.ptr, Î±, Î², f.mode, flags(T, Î±, Î²)))
+function LinearOperator(A::MXSparseMatrixCSC{T}; symmetric = false, hermitian = false, S = MXVector{T}) where {T <: RealT}
+  LinearOperator{T, S}(A.m, A.n, symmetric, hermitian, SparseApply{T}(A, Int32(0)), SparseApply{T}(A, Int32(1)),
+                       SparseApply{T}(A, Int32(2)))
+end
+# the reference's generic BlockDiagonalOperator(A, B, C) calls mul! on plain matrix blocks (test/test_linop.jl:743-756 has
+# a sprand block): the same for a device sparse block and its lazy transpose / adjoint
+LinearAlgebra.mul!(res::MXVector{T}, A::MXSparseMatrixCSC{T}, v::MXVector{T}, Î±::Number, Î²::Number) where {T <: RealT} =
+  (SparseApply{T}(A, Int32(0))(res, v, Î±, Î²); res)
+LinearAlgebra.mul!(res::MXVector{T}, A::Transpose{T, MXSparseMatrixCSC{T}}, v::MXVector{T}, Î±::Number, Î²::Number) where {T <: RealT} =
+  (SparseApply{T}(parent(A), Int32(1))(res, v, Î±, Î²); res)
+LinearAlgebra.mul!(res::MXVector{T}, A::Adjoint{T, MXSparseMatrixCSC{T}}, v::MXVector{T}, Î±::Number, Î²::Number) where {T <: RealT} =
+  (SparseApply{T}(parent(A), Int32(2))(res, v, Î±, Î²); res)
+
 # ---- a8 BlockDiagonalOperator (src/special-operators.jl:249-294): ONE launch per apply --------------------
 struct BlockDesc                # mxlo_block_desc, 56 bytes, same field order as include/mxlo.h
   kind::Int32
@@ -442,7 +490,8 @@ mutable struct BlockDiagHandle
   h::Ptr{Cvoid}
   keep::Vector{Any}             # block operands stay alive as long as the descriptor table
 end
-"blocks: opDiagonal data vectors (MXVector), dense MXMatrix blocks, `(:eye, n)` or `(:zeros, m, n)`."
+"blocks: opDiagonal data vectors (MXVector), dense MXMatrix blocks, sparse MXSparseMatrixCSC blocks (no row or column
+above 4096 stored entries: `sparse_info`), `(:eye, n)` or `(:zeros, m, n)`."
 function BlockDiagonalOperator(::Type{T}, blocks...; S = MXVector{T}) where {T}
   descs = BlockDesc[]
   r = c = 0
@@ -451,6 +500,8 @@ function BlockDiagonalOperator(::Type{T}, blocks...; S = MXVector{T}) where {T}
       push!(descs, BlockDesc(0, 0, r, c, length(b), length(b), b.ptr, 0)); r += length(b); c += length(b)
     elseif b isa MXMatrix
       push!(descs, BlockDesc(1, 0, r, c, b.m, b.n, b.data.ptr, b.m)); r += b.m; c += b.n
+    elseif b isa MXSparseMatrixCSC
+      push!(descs, BlockDesc(4, 0, r, c, b.m, b.n, b.h, 0)); r += b.m; c += b.n      # MXLO_BLK_CSC: data = the handle
     elseif b[1] === :eye
       push!(descs, BlockDesc(2, 0, r, c, b[2], b[2], C_NULL, 0)); r += b[2]; c += b[2]
     else
@@ -463,7 +514,7 @@ function BlockDiagonalOperator(::Type{T}, blocks...; S = MXVector{T}) where {T}
   bd = finalizer(x -> ccall((:mxlo_blockdiag_destroy, lib), Int32, (P,), x.h), BlockDiagHandle(out[], collect(Any, blocks)))
   mulmode(mode) = (res, v, Î±, Î²) -> check(ccall((:mxlo_blockdiag_mul, lib), Int32,
       (P, P, P, Float64, Float64, Int32, Int32), bd.h, res.ptr, v.ptr, Î±, Î², Int32(mode), flags(T, Î±, Î²)))
-  symm = all(b -> !(b isa MXMatrix) && !(b isa Tuple && b[1] === :zeros && b[2] != b[3]), blocks)
+  symm = all(b -> !(b isa MXMatrix) && !(b isa MXSparseMatrixCSC) && !(b isa Tuple && b[1] === :zeros && b[2] != b[3]), blocks)
   LinearOperator{T, S}(r, c, symm, symm, mulmode(0), mulmode(1), mulmode(2))
 end
 

@@ -151,6 +151,41 @@ end
 # ---- the reference's allocation contract, literally: test/test_lbfgs.jl:180-218 ("LBFGS allocations") and
 # test/test_lsr1.jl:88-106 on device operators. `@allocated` counts HOST (GC) bytes: a ccall closure with concrete
 # captured types allocates nothing; the device side of the same contract is the mxlo_debug_counters block above.
+@testset "sparse LinearOperator and sparse blocks (mirror of test/test_linop.jl:739-756, test/test_kron.jl:3-8)" begin
+  using SparseArrays
+  for T in (Float64, Float32), (m, n, dens) in ((7, 5, 0.5), (300, 300, 0.02), (5000, 4000, 0.002))
+    A = sprand(T, m, n, dens)
+    Ah, Ad = LinearOperator(A), LinearOperator(MX.MXSparseMatrixCSC(A))
+    v, u, r = rand(T, n), rand(T, m), rand(T, m)
+    tol = T == Float64 ? 1e-13 : 2f-6
+    for (α, β) in ((one(T), zero(T)), (T(2), T(-3)), (2.0, -3.0))
+      rh = copy(r); mul!(rh, Ah, v, α, β)
+      rd = dev(copy(r)); mul!(rd, Ad, dev(v), α, β)
+      @test norm(host(rd) - rh, Inf) <= tol * (abs(α) * maximum(abs.(A) * abs.(v); init = zero(T)) + abs(β))
+    end
+    @test rel(host(Ad' * dev(u)), Ah' * u) <= 100tol
+    @test rel(host(transpose(Ad) * dev(u)), transpose(Ah) * u) <= 100tol
+  end
+  # BlockDiagonalOperator(A, B, C) with an operator, a Matrix and a sprand block (test_linop.jl:739-756)
+  dinv = [0.5, 0.25, 0.125]
+  B, C = rand(4, 2), sprand(2, 4, 0.5)
+  D = [Diagonal(dinv) zeros(3, 2) zeros(3, 4); zeros(4, 3) B zeros(4, 4); zeros(2, 3) zeros(2, 2) Matrix(C)]
+  M = BlockDiagonalOperator(opDiagonal(dev(dinv)), MXMatrix(B), MX.MXSparseMatrixCSC(C))          # the reference's per-block loop
+  M1 = BlockDiagonalOperator(Float64, dev(dinv), MXMatrix(B), MX.MXSparseMatrixCSC(C))           # ONE launch
+  for op in (M, M1)
+    @test size(op) == (9, 9)
+    x = rand(9)
+    @test norm(host(op * dev(x)) - D * x) <= sqrt(eps()) * norm(D)
+    @test norm(host(op' * dev(x)) - D' * x) <= sqrt(eps()) * norm(D)
+    @test norm(host(transpose(op) * dev(x)) - transpose(D) * x) <= sqrt(eps()) * norm(D)
+  end
+  # in-place value update: Aᵀ*x sees it at once, A*x after refresh!
+  A = sprand(50, 40, 0.2); As = MX.MXSparseMatrixCSC(A); op = LinearOperator(As)
+  v = rand(40); y0 = host(op * dev(v))
+  copyto!(As.nzval, 2 .* A.nzval); MX.refresh!(As)
+  @test rel(host(op * dev(v)), 2 .* y0) <= 1e-14
+end
+
 @testset "LBFGS / LSR1 allocations (mirror of test_lbfgs.jl:180-218, test_lsr1.jl:88-106)" begin
   n, mem = 100, 20
   B = LBFGSOperator(Float64, n, MXVector{Float64}; mem = mem)

@@ -169,7 +169,9 @@ __device__ __forceinline__ void ew_tile(T *__restrict__ r0, const T *__restrict_
   }
 }
 
-template <typename T, typename CA, typename CB, bool BETA0, bool TRANS, bool NT>
+// SP: the operator has sparse blocks. A separate instantiation, so that operators without them keep the 40 registers
+// (8 waves per SIMD) of the elementwise / dense tiles — the chunk sweep needs 100.
+template <typename T, typename CA, typename CB, bool BETA0, bool TRANS, bool NT, bool SP>
 __global__ void __launch_bounds__(kBlock)
 blockdiag_kernel(T *__restrict__ res, const T *__restrict__ x, const DevBlock *__restrict__ blocks,
                  const Tile *__restrict__ tiles, CA alpha, CB beta) {
@@ -184,7 +186,7 @@ blockdiag_kernel(T *__restrict__ res, const T *__restrict__ x, const DevBlock *_
   const int64_t ni = TRANS ? b.m : b.n;   // inputs of this block
   T *rp = res + out_off;
   const T *xp = x + in_off;
-  if (b.kind == MXLO_BLK_CSC) {
+  if constexpr (SP) if (b.kind == MXLO_BLK_CSC) {
     extern __shared__ double sp_lds[];                        // kSpLdsBytes: the product buffer
     const CscDev *S = (const CscDev *)b.data;                 // wave-uniform descriptor fetches
     if constexpr (!TRANS)
@@ -358,8 +360,12 @@ static int32_t blockdiag_mul_t(mxlo_blockdiag *bd, T *res, const T *v, double al
     const bool ntm = (int64_t)sizeof(T) * (bd->nrow + 2 * bd->ncol) >= ctx->tune.nt_min_bytes;
 #define BD_GO(TR_, NT_)                                                                               \
   do {                                                                                                \
-  hipLaunchKernelGGL((blockdiag_kernel<T, CA, CB, B0, TR_, NT_>), dim3((unsigned)nt), dim3(kBlock), bd->lds_bytes, \
-                     ctx->stream, res, v, bd->d_blocks, tiles, (CA)alpha, (CB)beta);                   \
+  if (bd->lds_bytes)                                                                                  \
+    hipLaunchKernelGGL((blockdiag_kernel<T, CA, CB, B0, TR_, NT_, true>), dim3((unsigned)nt), dim3(kBlock),           \
+                       bd->lds_bytes, ctx->stream, res, v, bd->d_blocks, tiles, (CA)alpha, (CB)beta);  \
+  else                                                                                                \
+    hipLaunchKernelGGL((blockdiag_kernel<T, CA, CB, B0, TR_, NT_, false>), dim3((unsigned)nt), dim3(kBlock), 0,       \
+                       ctx->stream, res, v, bd->d_blocks, tiles, (CA)alpha, (CB)beta);                 \
   } while (0)
     if (trans && ntm) BD_GO(true, true);
     else if (trans) BD_GO(true, false);

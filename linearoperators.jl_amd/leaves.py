@@ -315,6 +315,8 @@ def opHermitian(*args):
     """opHermitian(d, A) / opHermitian(A) — src/linalg.jl:105-127. Complex A (ComplexF64 / ComplexF32): `L'` is the
     conjugate transpose, symmetric = isreal(A) = false, hermitian = true; d may be real (the reference test passes
     real.(diag(A)), test/test_linop.jl:362) or complex."""
+    if args[-1].layout in _SPARSE_LAYOUTS:
+        return _opHermitian_sparse(*args)
     if len(args) == 1:
         A = _colmajor(args[0])
         d = torch.diagonal(A).clone()
@@ -351,6 +353,50 @@ def opHermitian(*args):
 
 
 # ----------------------------------------------------------------------------- dense matrix operator
+def _opHermitian_sparse(*args):
+    """opHermitian(d, A) / opHermitian(A) with a SPARSE A (src/linalg.jl:105-127 takes any AbstractMatrix; `tril(A, -1)`
+    of a SparseMatrixCSC is sparse): L = the strict lower triangle, taken ONCE at construction like the reference's
+    `tril` copy, as a sparse leaf; an apply is `res = α d.*v + β res` (diagonal leaf), then `res += α L v` and
+    `res += α Lᵀ v` on the same handle (modes N and T of `mxlo_csc_mul`) — three launches, L read twice (12 B per
+    stored entry each)."""
+    A = args[-1]
+    if A.layout != torch.sparse_coo:
+        A = A.to_sparse_coo()
+    A = A.coalesce()
+    m, n = A.shape
+    if A.dtype.is_complex:
+        raise TypeError("sparse opHermitian: complex element types are not instantiated on the device path")
+    rows, cols = A.indices()
+    vals = A.values()
+    if len(args) == 1:
+        d = torch.zeros(m, dtype=A.dtype, device=vals.device)
+        on = rows == cols
+        d[rows[on]] = vals[on]
+    else:
+        d = check_vec(args[0], "d")
+    if not (m == n == d.numel()):
+        raise LinearOperatorException("shape mismatch")
+    U = torch.promote_types(d.dtype, A.dtype)
+    dtype_code(U)
+    low = rows > cols
+    order = torch.argsort(cols[low] * m + rows[low])                         # column-major order of the kept entries
+    lr, lc, lv = rows[low][order], cols[low][order], vals[low][order].to(U).contiguous()
+    ccol = torch.zeros(n + 1, dtype=torch.int64, device=vals.device)
+    ccol[1:] = torch.cumsum(torch.bincount(lc, minlength=n), 0)
+    L = LinearOperatorFromSparse(torch.sparse_csc_tensor(ccol, lr, lv, size=(m, n)))
+    D = opDiagonal(d if d.dtype == U else d.to(U))
+    Lt = transpose(L)
+
+    def prod(res, v, a, b):                        # mulHermitian! (src/linalg.jl:97-103)
+        mul(res, D, v, a, b)
+        mul(res, L, v, a, 1.0)
+        mul(res, Lt, v, a, 1.0)
+
+    op = LinearOperator(U, m, m, True, True, prod, None, None, S=Storage(U, vals.device))
+    op._deps = (d, lv)
+    return op
+
+
 def _stored_colmajor(M: torch.Tensor):
     """(column-major view of the SAME memory, transposed?) — a row-major torch matrix (torch's default layout) IS the
     column-major storage of its transpose, so it is aliased with the roles of N and T swapped instead of being copied
@@ -422,7 +468,7 @@ def LinearOperatorFromSparse(M: torch.Tensor, symmetric: bool = False, hermitian
     vals = M.values()
     T = vals.dtype
     if T.is_complex:
-        raise TypeError("sparse LinearOperator(M): complex element types are not instantiated on the device path")
+        return _sparse_complex(M, symmetric, hermitian, S)
     dtype_code(T)
     if tr:                                   # CSR of M == CSC of transpose(M)
         cp, rv, sm, sn = M.crow_indices(), M.col_indices(), ncol, nrow
@@ -456,6 +502,62 @@ def LinearOperatorFromSparse(M: torch.Tensor, symmetric: bool = False, hermitian
         op._leaf = ("csc", handle, vals, seen)    # fused BlockDiagonalOperator: MXLO_BLK_CSC (no row / column beyond one chunk)
     op._sparse_src = M
     op._csc = handle
+    op._deps = (vals,)
+    return op
+
+
+def _sparse_complex(M: torch.Tensor, symmetric: bool, hermitian: bool, S: Optional[Storage]):
+    """Sparse M with a complex element type (test/test_linop.jl:44, test/test_cat.jl:5-25 build operators from
+    `simple_sparse_matrix(ComplexF64, …)`): the device sparse kernels are instantiated for real element types, so M is
+    split ONCE into two real sparse operands with the same pattern, Mr + i·Mi (a snapshot: `tril`-like copy semantics, unlike
+    the aliased real path), and an apply runs on real planes:
+        prod!    y = M x    : yr = Mr xr − Mi xi,   yi = Mr xi + Mi xr
+        tprod!   y = Mᵀ x   : the same on the transposed sweeps
+        ctprod!  y = Mᴴ x   : yr = Mrᵀ xr + Miᵀ xi, yi = Mrᵀ xi − Miᵀ xr
+    four real sparse applies between one split and one join pass (`mxlo_split_c`, `mxlo_join_c` with the complex α, β)."""
+    from .operators import LinearOperatorException
+    T = M.values().dtype
+    dtype_code(T, True)
+    R = torch.float64 if T == torch.complex128 else torch.float32
+    nrow, ncol = M.shape
+    tr = M.layout == torch.sparse_csr
+    cp, rv = (M.crow_indices(), M.col_indices()) if tr else (M.ccol_indices(), M.row_indices())
+    mk = lambda v: (torch.sparse_csr_tensor if tr else torch.sparse_csc_tensor)(cp, rv, v.contiguous(), size=(nrow, ncol))
+    vals = M.values()
+    planes_ = torch.view_as_real(vals.detach().clone())        # (.real on values() of a sparse tensor raises in torch 2.10)
+    Lr, Li = LinearOperatorFromSparse(mk(planes_[:, 0])), LinearOperatorFromSparse(mk(planes_[:, 1]))
+    dev = vals.device
+    bufs = {}
+
+    def planes(nin, nout):
+        key = (nin, nout, torch.cuda.current_stream(dev).cuda_stream)
+        if key not in bufs:
+            if len(bufs) >= 4:
+                bufs.clear()
+            bufs[key] = tuple(torch.empty(k, dtype=R, device=dev) for k in (nin, nin, nout, nout))
+        return bufs[key]
+
+    def apply(res, v, a, b, wrap, sign):
+        if res.dtype != T or v.dtype != T:
+            raise TypeError(f"sparse {T} operator: {res.dtype} / {v.dtype} vectors")
+        nin, nout = v.shape[0], res.shape[0]
+        xr, xi, yr, yi = planes(nin, nout)
+        ctx = get_ctx(dev)
+        code = dtype_code(T, True)
+        _lib.call("mxlo_split_c", ctx.handle, code, ptr(xr), ptr(xi), ptr(v), nin)
+        Or, Oi = wrap(Lr), wrap(Li)
+        mul(yr, Or, xr, 1.0, 0.0)
+        mul(yr, Oi, xi, -sign, 1.0)
+        mul(yi, Or, xi, 1.0, 0.0)
+        mul(yi, Oi, xr, sign, 1.0)
+        _lib.call("mxlo_join_c", ctx.handle, code, ptr(res), ptr(yr), ptr(yi), nout, *_c4(a, b), scalar_flags(res.dtype, a, b))
+
+    ident = lambda o: o
+    prod = columnwise(lambda res, v, a, b: apply(res, v, a, b, ident, 1.0))
+    tprod = columnwise(lambda res, u, a, b: apply(res, u, a, b, transpose, 1.0))
+    ctprod = columnwise(lambda res, w, a, b: apply(res, w, a, b, transpose, -1.0))
+    op = LinearOperator(T, nrow, ncol, symmetric, hermitian, prod, tprod, ctprod, S=S if S is not None else Storage(T, dev))
+    op._sparse_src = M
     op._deps = (vals,)
     return op
 

@@ -252,9 +252,6 @@ def test_csc_create_validates_like_the_sparsematrixcsc_constructor(lo, dev):
         M = torch.sparse_csc_tensor(i64(cp), i64(rv), vals, size=shape, check_invariants=False)
         with pytest.raises(Exception, match=word):
             lo.LinearOperatorFromMatrix(M)
-    with pytest.raises(TypeError):
-        lo.LinearOperatorFromMatrix(torch.sparse_csc_tensor(i64([0, 1]), i64([0]), torch.ones(1, dtype=torch.complex128, device=dev),
-                                                             size=(1, 1)))
     # empty matrix and empty pattern
     for shape in ((0, 0), (0, 4), (5, 0), (3, 3)):
         cp = i64([0] * (shape[1] + 1))
@@ -306,3 +303,57 @@ def test_rows_and_columns_longer_than_a_chunk(lo, dev, dtype):
     got = (M * torch.from_numpy(x).to(dev)).cpu().numpy()
     want = np.concatenate([d.cpu().numpy().astype(np.float64) * x[:100], A.astype(np.float64) @ x[100:].astype(np.float64)])
     assert np.abs(got - want).max() <= (1e-12 if dtype == torch.float64 else 2e-5) * scale_of(A, x[100:])
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_ophermitian_of_a_sparse_matrix(lo, dev, dtype):
+    """`opHermitian(d, A)` / `opHermitian(A)` (src/linalg.jl:105-127) accept any AbstractMatrix; for a sparse A the
+    strict lower triangle `tril(A, -1)` is sparse. Against the dense symmetric matrix d + L + Lᵀ (how
+    test/test_linop.jl:360-380 checks the dense form), whatever sits on or above A's diagonal must be ignored, α / β."""
+    npd = NP[dtype]
+    rng = np.random.default_rng(41)
+    n = 700
+    A = rand_sparse(rng, n, n, 0.02, npd)
+    A.setdiag(rng.uniform(1, 2, n).astype(npd))
+    A = sp.csc_matrix(A)
+    L = sp.tril(A, -1).toarray().astype(np.float64)
+    d = rng.uniform(-1, 1, n).astype(npd)
+    for op, diag in ((lo.opHermitian(torch.from_numpy(d).to(dev), dev_csc(A, dev, dtype)), d.astype(np.float64)),
+                     (lo.opHermitian(dev_csc(A, dev, dtype)), A.diagonal().astype(np.float64))):
+        assert lo.issymmetric(op) and lo.ishermitian(op) and op.shape == (n, n)
+        H = np.diag(diag) + L + L.T
+        v = rng.uniform(-1, 1, n).astype(npd)
+        r0 = rng.uniform(-1, 1, n).astype(npd)
+        for a, b in ((1.0, 0.0), (2.0, -3.0)):
+            res = torch.from_numpy((np.full(n, np.nan, npd) if b == 0 else r0).copy()).to(dev)
+            lo.mul(res, op, torch.from_numpy(v).to(dev), a, b)
+            want = a * (H @ v.astype(np.float64)) + (b * r0.astype(np.float64) if b else 0)
+            tol = (1e-12 if dtype == torch.float64 else 2e-5) * (abs(a) * float((np.abs(H) @ np.abs(v)).max()) + abs(b))
+            assert np.abs(res.cpu().numpy() - want).max() <= tol
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.complex128, 1e-13), (torch.complex64, 5e-6)])
+def test_complex_sparse_operator_through_real_planes(lo, dev, dtype, tol):
+    """test/test_linop.jl:44 and test/test_cat.jl:5-25 build operators from `simple_sparse_matrix(ComplexF64, …)`:
+    M*v, transpose(M)*u, M'*u with complex α, β against the dense matrix; the adjoint conjugates, the transpose does not."""
+    rng = np.random.default_rng(63)
+    cdt = np.complex128 if dtype == torch.complex128 else np.complex64
+    for m, n, dens in ((30, 20, 0.3), (400, 700, 0.02)):
+        A = sp.random(m, n, dens, format="csc", random_state=7).astype(np.complex128)
+        A.data = (rng.standard_normal(A.nnz) + 1j * rng.standard_normal(A.nnz))
+        A = A.astype(cdt)
+        M = torch.sparse_csc_tensor(torch.from_numpy(A.indptr.astype(np.int64)), torch.from_numpy(A.indices.astype(np.int64)),
+                                    torch.from_numpy(A.data), size=A.shape).to(dev)
+        op = lo.LinearOperatorFromMatrix(M)
+        assert op.eltype == dtype and op.shape == (m, n)
+        D = A.toarray().astype(np.complex128)
+        for o, Dm in ((op, D), (lo.transpose(op), D.T), (lo.adjoint(op), D.conj().T)):
+            nout, nin = Dm.shape
+            v = (rng.standard_normal(nin) + 1j * rng.standard_normal(nin)).astype(cdt)
+            r0 = (rng.standard_normal(nout) + 1j * rng.standard_normal(nout)).astype(cdt)
+            for a, b in ((1.0, 0.0), (1.5 - 0.5j, 0.25 + 2j)):
+                res = torch.from_numpy((np.full(nout, np.nan + 0j, cdt) if b == 0 else r0).copy()).to(dev)
+                lo.mul(res, o, torch.from_numpy(v).to(dev), a, b)
+                want = a * (Dm @ v.astype(np.complex128)) + (b * r0.astype(np.complex128) if b != 0 else 0)
+                scale = abs(a) * float((np.abs(Dm) @ np.abs(v)).max()) + abs(b) * float(np.abs(r0).max())
+                assert np.abs(res.cpu().numpy() - want).max() <= 8 * tol * scale

@@ -113,7 +113,7 @@ int32_t mxlo_ctx_info(mxlo_ctx *ctx, int64_t info[4]);
 /* Launch-geometry / algorithm-variant knobs for sweeps and for tests that compare two device implementations. Keys:
  * "blocks_per_cu", "nt_min_bytes", "red_blocks_per_cu", "graph_direct_max", "house_fused", "house_reverse", "house_inline_n" (two-pass opHouseholder up to this n: the update pass adds up the dots pass's partial sums itself, no finalize launch; 0: never),
  * "cherm_two_pass", "lbfgs_inv_mode", "gemm_tile", "extend_tiles_per_block", "fuse_finalize", "combine_blocks_per_cu",
- * "dots_max_nc", "fused_timeout_ms", "fused_debug_drop" (both below), "qn_fused_small" (1: dots + finalize + coefficients of a small quasi-Newton apply in one launch), "push_wide", "push_fused" (1: streaming push! schedules — L-BFGS: new pair held per lane, in-pass inserts; L-SR1: panels once, y - B s never stored, inserts ride in the rebuild; 0: the copies + dots schedules they replaced). Unknown key or out-of-range value -> MXLO_EINVAL.
+ * "dots_max_nc", "sp_xcds" (sparse apply: number of L2 domains the chunk order is banded over — 8 = one contiguous part of the chunk table per XCD of an MI355X; default 1 = plain order), "fused_timeout_ms", "fused_debug_drop" (both below), "qn_fused_small" (1: dots + finalize + coefficients of a small quasi-Newton apply in one launch), "push_wide", "push_fused" (1: streaming push! schedules — L-BFGS: new pair held per lane, in-pass inserts; L-SR1: panels once, y - B s never stored, inserts ride in the rebuild; 0: the copies + dots schedules they replaced). Unknown key or out-of-range value -> MXLO_EINVAL.
  * "house_fused" / "qn_fused_small" = 0 is also the setting for MORE than four processes sharing one GPU: the workgroups of a
  * single-launch apply wait for each other, so a launch must be resident as a whole; four of the largest Householder launches
  * (256 workgroups) or twelve quasi-Newton ones (64 workgroups) fit on the chip at once, beyond that two launches could each
@@ -469,13 +469,14 @@ int32_t mxlo_gemv_block(mxlo_ctx *ctx, int32_t dtype, void *res, int64_t ldr, co
  * pattern is fixed for the life of the handle; the handle keeps `nzval` (not colptr / rowval) referenced.
  * mxlo_csc_mul: res = alpha * op(A) * v + beta * res, op_mode MXLO_OP_N / _T / _C (_C == _T: real element types);
  * beta == 0 never reads res. Both modes are a row gather-reduce on a compressed-row view cut, at create, into chunks of
- * <= 4096 stored entries (whole rows; a row above 512 entries has chunks of its own): a workgroup streams its chunk
- * (coalesced value / index loads, gathered x) into LDS as f64 products and sums the rows from there in a fixed order —
+ * <= 2048 stored entries (whole rows; a row above 512 entries has chunks of its own): a workgroup streams its chunk
+ * (coalesced value / index loads) into LDS and walks the rows from there in a fixed order, adjacent lanes gathering x for
+ * adjacent rows —
  * HBM traffic and balance do not depend on the row-length distribution, results are run-to-run bit-identical; against the
  * reference the difference is rounding order only (tests: 1e-13 |A||v| Float64, 2e-6 Float32). A row (column, for the
- * transposed modes) with more than 4096 entries is summed piecewise and a second, tiny launch adds its pieces in order.
- * mxlo_csc_info: info = {m, n, nnz, chunks of A*x, chunks of Aᵀ*x, rows above 4096 entries, columns above 4096
- * entries, 4096}. A handle with such rows / columns cannot be a block of the ONE-launch block-diagonal operator. */
+ * transposed modes) with more than 2048 entries is summed piecewise and a second, tiny launch adds its pieces in order.
+ * mxlo_csc_info: info = {m, n, nnz, chunks of A*x, chunks of Aᵀ*x, rows above 2048 entries, columns above 2048
+ * entries, 2048}. A handle with such rows / columns cannot be a block of the ONE-launch block-diagonal operator. */
 typedef struct mxlo_csc mxlo_csc;
 int32_t mxlo_csc_create(mxlo_ctx *ctx, int32_t dtype, int64_t m, int64_t n, const int64_t *colptr,
                         const int64_t *rowval, const void *nzval, int32_t index_base, mxlo_csc **out);

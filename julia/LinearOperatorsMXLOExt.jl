@@ -491,7 +491,7 @@ mutable struct BlockDiagHandle
   keep::Vector{Any}             # block operands stay alive as long as the descriptor table
 end
 "blocks: opDiagonal data vectors (MXVector), dense MXMatrix blocks, sparse MXSparseMatrixCSC blocks (no row or column
-above 4096 stored entries: `sparse_info`), `(:eye, n)` or `(:zeros, m, n)`."
+above 2048 stored entries: `sparse_info`), `(:eye, n)` or `(:zeros, m, n)`."
 function BlockDiagonalOperator(::Type{T}, blocks...; S = MXVector{T}) where {T}
   descs = BlockDesc[]
   r = c = 0

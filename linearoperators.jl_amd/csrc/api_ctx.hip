@@ -412,6 +412,9 @@ MXLO_API int32_t mxlo_ctx_tune(mxlo_ctx *ctx, const char *key, int64_t value) {
   } else if (!strcmp(key, "qn_fused_small")) {
     MXLO_REQUIRE(value == 0 || value == 1, MXLO_EINVAL, "qn_fused_small must be 0 or 1");
     ctx->tune.qn_fused_small = (int)value;
+  } else if (!strcmp(key, "sp_xcds")) {
+    MXLO_REQUIRE(value >= 1 && value <= 64, MXLO_EINVAL, "sp_xcds must be in 1..64");
+    ctx->tune.sp_xcds = (int)value;
   } else if (!strcmp(key, "fused_timeout_ms")) {
     MXLO_REQUIRE(value >= 1 && value <= 600000, MXLO_EINVAL, "fused_timeout_ms must be in 1..600000");
     ctx->tune.fused_timeout_ms = (int)value;

@@ -8,9 +8,9 @@
 // block contributes 256-output-row tiles in N mode (thread per row, coalesced down the columns)
 // and 4-output tiles in T mode (one wave per output, coalesced down the column).
 // A sparse block (MXLO_BLK_CSC: data = the device descriptor of an mxlo_csc handle) contributes one tile per CHUNK of its
-// compressed-row sweep (sparse_kernels.h: <= 4096 stored entries streamed into LDS, rows summed from there) — the N-mode
+// compressed-row sweep (sparse_kernels.h: <= 2048 stored entries streamed into LDS, rows walked from there) — the N-mode
 // tiles walk the CSR view, the T-mode tiles the CSC arrays themselves. Operators with sparse blocks are launched with
-// 32 KiB of dynamic LDS; the others with none (the elementwise tiles keep their occupancy).
+// 24 KiB of dynamic LDS; the others with none (the elementwise tiles keep their occupancy).
 // Blocks start at arbitrary row offsets (e.g. 97,657-row blocks), so each tile aligns its
 // stores to 16 bytes by peeling and loads an operand with one 16-byte or two element accesses
 // depending on that operand's own phase.
@@ -187,7 +187,7 @@ blockdiag_kernel(T *__restrict__ res, const T *__restrict__ x, const DevBlock *_
   T *rp = res + out_off;
   const T *xp = x + in_off;
   if constexpr (SP) if (b.kind == MXLO_BLK_CSC) {
-    extern __shared__ double sp_lds[];                        // kSpLdsBytes: the product buffer
+    extern __shared__ double sp_lds[];                        // sp_lds_bytes<T>(): the chunk's values and indices
     const CscDev *S = (const CscDev *)b.data;                 // wave-uniform descriptor fetches
     if constexpr (!TRANS)
       spmv_chunk<T, CA, CB, BETA0>(rp, xp, S->rowptr, S->colidx, (const T *)S->csr_val, S->chunks_n[tl.start], S->carry, alpha,
@@ -317,7 +317,7 @@ MXLO_API int32_t mxlo_blockdiag_create(mxlo_ctx *ctx, int32_t dtype, const mxlo_
   bd->ncol = ncol;
   bd->ntiles_n = (int64_t)tn.size();
   bd->ntiles_t = (int64_t)tt.size();
-  bd->lds_bytes = has_sparse ? kSpLdsBytes : 0;
+  bd->lds_bytes = has_sparse ? sp_lds_bytes<double>() : 0;   // (the Float32 instantiation uses 16 of the 24 KiB)
   hipError_t e = hipSuccess;
   auto up = [&](void **dst, const void *src, size_t bytes) {
     if (e != hipSuccess || bytes == 0) return;

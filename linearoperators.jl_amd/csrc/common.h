@@ -138,6 +138,8 @@ struct Tune {
   int qn_fused_small = 1;  // quasi-Newton applies with <= 64 workgroups of dots: dots + finalize + coefficients in one launch
   int push_wide = 1;       // one-pass push!: 20 columns per pass while >= 20 remain (0: always <= 10)
   int push_fused = 1;      // push!(op, s, y): one-pass schedule (new pair held per lane, in-pass slot stores); 0 = copies + dual-x dots
+  int sp_xcds = 1;         // sparse apply: XCDs (L2 domains) the chunk order is banded over (8: XCD k walks the k-th contiguous
+                           // eighth of the chunk table); 1 = plain order, the default: banding measured -8 % … +8 % by pattern
   int fused_timeout_ms = 2000;   // single-launch (grid-exchange) kernels: how long a workgroup polls for its peers' partials
                                  // before it gives up, raises the ctx fault flag and stores NaN (a launch that is not fully
                                  // co-resident — GPU shared with other processes, CU masking — ends instead of hanging)

@@ -43,9 +43,16 @@ csc_gather_values_kernel(T *__restrict__ out, const T *__restrict__ nzval, const
 template <typename T, typename CA, typename CB, bool BETA0>
 __global__ void __launch_bounds__(kBlock)
 csc_mul_kernel(T *__restrict__ res, const T *__restrict__ x, const int64_t *__restrict__ ptr, const int32_t *__restrict__ idx,
-               const T *__restrict__ val, const SpChunk *__restrict__ chunks, double *__restrict__ carry, CA alpha, CB beta) {
-  __shared__ double prod[kSpChunk];
-  spmv_chunk<T, CA, CB, BETA0>(res, x, ptr, idx, val, chunks[blockIdx.x], carry, alpha, beta, prod);
+               const T *__restrict__ val, const SpChunk *__restrict__ chunks, int nchunks, int nxcd, double *__restrict__ carry,
+               CA alpha, CB beta) {
+  __shared__ __attribute__((aligned(16))) char lds[sp_lds_bytes<T>()];
+  // XCD-aware order: workgroup w runs on XCD w % nxcd, and each XCD has its own L2. XCD k takes the k-th CONTIGUOUS
+  // part of the chunk table, so the x lines its workgroups share (neighbouring rows gather neighbouring columns) are
+  // fetched into ONE L2 instead of into all eight.
+  const int w = (int)blockIdx.x, per = (nchunks + nxcd - 1) / nxcd;
+  const int ci = (w % nxcd) * per + w / nxcd;
+  if (ci >= nchunks || w / nxcd >= per) return;
+  spmv_chunk<T, CA, CB, BETA0>(res, x, ptr, idx, val, chunks[ci], carry, alpha, beta, lds);
 }
 
 // The chunk table of one compressed-row operand (see sparse_kernels.h): whole rows packed into chunks of <= kSpChunk
@@ -101,8 +108,10 @@ int32_t csc_mul_t(mxlo_csc *h, T *res, const T *v, double alpha, double beta, in
   const SpChunk *chunks = trans ? d.chunks_t : d.chunks_n;
   const SpLongRow *longs = trans ? h->long_t : h->long_n;
   return dispatch_ab<T>(beta, flags, [&]<typename CA, typename CB, bool B0>() -> int32_t {
-    hipLaunchKernelGGL((csc_mul_kernel<T, CA, CB, B0>), dim3((unsigned)nchunks), dim3(kBlock), 0, ctx->stream, res, v, ptr, idx,
-                       val, chunks, d.carry, (CA)alpha, (CB)beta);
+    const int nxcd = ctx->tune.sp_xcds > 0 ? ctx->tune.sp_xcds : 1;
+    const int per = (nchunks + nxcd - 1) / nxcd;
+    hipLaunchKernelGGL((csc_mul_kernel<T, CA, CB, B0>), dim3((unsigned)(per * nxcd)), dim3(kBlock), 0, ctx->stream, res, v, ptr,
+                       idx, val, chunks, nchunks, nxcd, d.carry, (CA)alpha, (CB)beta);
     MXLO_LAUNCH_CHECK();
     if (nlong > 0) {
       hipLaunchKernelGGL((spmv_fixup_kernel<T, CA, CB, B0>), dim3((unsigned)((nlong + kBlock - 1) / kBlock)), dim3(kBlock), 0,

@@ -8,22 +8,28 @@
 //   T / C mode: rows of Aᵀ = columns of A — the CSC arrays themselves (values read in place).
 //
 // Work decomposition (fixed at construction, so every apply sums in the same order: run-to-run bit-identical):
-// the stored entries are cut into CHUNKS of at most kSpChunk = 4096 entries, one workgroup each —
-//   * SP_ROWS    consecutive whole rows, none longer than kSpLongRow entries, together <= 4096 entries;
-//   * SP_LONG1   ONE row of kSpLongRow < nnz <= 4096 entries;
-//   * SP_PIECE   a 4096-entry piece of a row longer than that; its sum goes to a carry slot and a small second
+// the stored entries are cut into CHUNKS of at most kSpChunk = 2048 entries, one workgroup each —
+//   * SP_ROWS    consecutive whole rows, none longer than kSpLongRow entries, together <= 2048 entries;
+//   * SP_LONG1   ONE row of kSpLongRow < nnz <= 2048 entries;
+//   * SP_PIECE   a 2048-entry piece of a row longer than that; its sum goes to a carry slot and a small second
 //                launch adds the pieces of each such row in order (only issued when such rows exist).
-// A workgroup first streams its chunk: every lane loads 16 (value, index) pairs at stride 256 — whole cache lines per
-// wave instruction, all 32 loads in flight — gathers the 16 x elements (a second round trip) and parks the f64 products
-// in LDS (32 KiB: four to five workgroups per CU).
-// (Measured and dropped, round 4: staging the chunk's x window in LDS so that the gathers become LDS reads — with the
-// window in the same round trip as the values. On a random-banded pattern, 16 entries per row within +-2000 columns,
-// 2048-entry chunks + a 33 KiB window ran at 410 us where this form takes 229 - 338 us: the window is as large as
-// the chunk's own matrix data and the bigger LDS footprint leaves three workgroups per CU.)
-// Then the rows of the chunk are summed out of LDS by lane groups whose width depends only on the number of rows in the
-// chunk (1 .. 64 lanes per row, ascending entry order per lane, one fixed xor tree), long rows by the whole workgroup.
-// So the HBM side is a coalesced stream independent of the row-length distribution (a few very long rows next to
-// millions of short ones cost nothing extra), and the irregular part happens in LDS.
+// A workgroup first STREAMS its chunk into LDS: every lane loads 8 (value, index) pairs at stride 256 — whole cache
+// lines per wave instruction, all 16 loads in flight, together with the row pointers its lane group will need — and
+// parks them (24 KiB for Float64: six workgroups per CU; chunks of 4096 entries — three per CU — ran the stencils at
+// 0.52 - 0.55 of HBM peak where 2048 gives 0.60 - 0.63, chunks of 1024 are slower again). So the HBM side is a coalesced stream independent of the
+// row-length distribution (a few very long rows next to millions of short ones cost nothing extra).
+// Then the ROWS are walked out of LDS by lane groups whose width depends only on the number of rows in the chunk
+// (1 .. 64 lanes per row; long rows: the whole workgroup): lane l of a group takes its row's entries l, l + g, ... in
+// ascending order, 8 at a time (8 x gathers in flight), adds the products in that order, and the group's partials are
+// combined by one fixed xor tree. With one lane per row — the usual case: >= 256 rows in a chunk, or any chunk of rows
+// of <= 8 entries — ADJACENT LANES GATHER x FOR ADJACENT ROWS: on the patterns solvers apply (stencils, bands, FEM
+// meshes) those are adjacent addresses, so a wave's gather touches a handful of cache lines instead of one per lane.
+// (Round-4 measurements, 7-point Laplacian 160^3, profiles/r04_pmc_sparse.txt: gathering in ENTRY order — adjacent
+// lanes = adjacent entries of one row = far-apart columns — cost ~60 L1 accesses per gather instruction, the vector
+// L1s were the limiter (0.57 accesses per cycle and CU, HBM traffic 1.03 x algorithmic at only 4.4 TB/s). Also
+// measured and dropped: an LDS copy of the chunk's x window (2048-entry chunks + 33 KiB window: 410 us where entry-order
+// gathers took 229 - 338 us on a random band), persistent workgroups with the next chunk's loads in flight (216 VGPRs,
+// two workgroups per CU: 146 us vs 101 us), an XCD-banded chunk order (no change: x sits in the Infinity Cache).)
 // Indices are 32-bit and 0-based inside the library whatever the caller stores: 12 B per entry (Float64).
 #pragma once
 #include "common.h"
@@ -31,7 +37,7 @@
 
 namespace mxlo {
 
-constexpr int kSpChunk = 4096;     // entries per chunk = kBlock lanes x kSpPerLane
+constexpr int kSpChunk = 2048;     // entries per chunk = kBlock lanes x kSpPerLane
 constexpr int kSpPerLane = kSpChunk / kBlock;
 constexpr int kSpLongRow = 512;    // a row with more entries gets chunks of its own
 enum { SP_ROWS = 0, SP_LONG1 = 1, SP_PIECE = 2 };
@@ -63,17 +69,55 @@ struct CscDev {
   int32_t nchunks_n, nchunks_t, nlong_n, nlong_t;
 };
 
-// LDS of a workgroup: kSpChunk products = 32 KiB exactly, so that FIVE workgroups share a CU's 160 KiB (the wave sums of
-// the long-row path re-use the first slots of the product buffer once the products have been consumed)
-constexpr size_t kSpLdsBytes = sizeof(double) * kSpChunk;
+// LDS of a workgroup: kSpChunk values (element type) + kSpChunk 32-bit indices
+template <typename T>
+constexpr size_t sp_lds_bytes() { return (sizeof(T) + sizeof(int32_t)) * (size_t)kSpChunk; }
+constexpr size_t kSpLdsBytesMax = sp_lds_bytes<double>();
+constexpr int kSpBatch = 8;        // gathers in flight per lane while a row is walked
 
-// One chunk: called by all kBlock threads of a workgroup. `prod` is kSpChunk doubles of LDS.
+// lanes per row of a SP_ROWS chunk: from the row COUNT of the chunk only
+__device__ __forceinline__ int sp_lanes_per_row(int nr) {
+  if (nr >= kBlock) return 1;
+  int p2 = 1;
+  while (p2 < nr) p2 <<= 1;
+  const int g = kBlock / p2;
+  return g > 64 ? 64 : g;
+}
+
+// sum of (value * x[index]) over the LDS entries e0, e0 + step, ... < e1, in that order, kSpBatch gathers at a time
+template <typename T>
+__device__ __forceinline__ double sp_walk(const T *__restrict__ x, const T *sval, const int32_t *sidx, int e0, int e1, int step) {
+  double acc = 0.0;
+  for (int e = e0; e < e1; e += step * kSpBatch) {
+    T v[kSpBatch], xv[kSpBatch];
+#pragma unroll
+    for (int u = 0; u < kSpBatch; ++u) {
+      const int q = e + u * step;
+      const bool in = q < e1;
+      v[u] = in ? sval[q] : T(0);
+      xv[u] = in ? x[sidx[q]] : T(0);
+    }
+#pragma unroll
+    for (int u = 0; u < kSpBatch; ++u)
+      if (e + u * step < e1) acc += (double)v[u] * (double)xv[u];
+  }
+  return acc;
+}
+
+// One chunk, start to end: called by all kBlock threads of a workgroup; `lds` is sp_lds_bytes<T>() of LDS.
+constexpr int kSpPre = 3;          // rows per lane group whose pointers (and old res) are requested with the chunk's own loads
 template <typename T, typename CA, typename CB, bool BETA0>
 __device__ __forceinline__ void spmv_chunk(T *__restrict__ res, const T *__restrict__ x, const int64_t *__restrict__ ptr,
                                            const int32_t *__restrict__ idx, const T *__restrict__ val, const SpChunk c,
-                                           double *__restrict__ carry, CA alpha, CB beta, double *prod) {
+                                           double *__restrict__ carry, CA alpha, CB beta, void *lds) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  // ---- 1. stream the chunk: products into LDS
+  T *sval = (T *)lds;
+  int32_t *sidx = (int32_t *)((char *)lds + sizeof(T) * kSpChunk);
+  const int g = c.kind == SP_ROWS ? sp_lanes_per_row(c.nr) : 1;
+  const int grp = tid / g, l = tid - grp * g, ngrp = kBlock / g;
+  // ---- 1. stream the chunk into LDS; the first rows' pointers ride in the same round trip
+  int64_t p0[kSpPre], p1[kSpPre];
+  T old[kSpPre];
   {
     const T *vp = val + c.k0;
     const int32_t *ip = idx + c.k0;
@@ -85,11 +129,6 @@ __device__ __forceinline__ void spmv_chunk(T *__restrict__ res, const T *__restr
         vv[j] = vp[j * kBlock + tid];
         ii[j] = ip[j * kBlock + tid];
       }
-      T xx[kSpPerLane];
-#pragma unroll
-      for (int j = 0; j < kSpPerLane; ++j) xx[j] = x[ii[j]];
-#pragma unroll
-      for (int j = 0; j < kSpPerLane; ++j) prod[j * kBlock + tid] = (double)vv[j] * (double)xx[j];
     } else {
 #pragma unroll
       for (int j = 0; j < kSpPerLane; ++j) {
@@ -98,45 +137,64 @@ __device__ __forceinline__ void spmv_chunk(T *__restrict__ res, const T *__restr
         vv[j] = in ? vp[e] : T(0);
         ii[j] = in ? ip[e] : 0;
       }
-      T xx[kSpPerLane];
+    }
+    if (c.kind == SP_ROWS) {
 #pragma unroll
-      for (int j = 0; j < kSpPerLane; ++j) xx[j] = (j * kBlock + tid) < c.nz ? x[ii[j]] : T(0);
+      for (int k = 0; k < kSpPre; ++k) {
+        const int r = grp + k * ngrp;
+        if (r < c.nr) {
+          const int64_t row = (int64_t)c.row0 + r;
+          p0[k] = ptr[row];
+          p1[k] = ptr[row + 1];
+          if constexpr (!BETA0) old[k] = res[row];
+        }
+      }
+    }
 #pragma unroll
-      for (int j = 0; j < kSpPerLane; ++j) {
-        const int e = j * kBlock + tid;
-        if (e < c.nz) prod[e] = (double)vv[j] * (double)xx[j];
+    for (int j = 0; j < kSpPerLane; ++j) {
+      const int e = j * kBlock + tid;
+      if (c.nz == kSpChunk || e < c.nz) {
+        sval[e] = vv[j];
+        sidx[e] = ii[j];
       }
     }
   }
   __syncthreads();
-  // ---- 2. sum the rows out of LDS
+  // ---- 2. walk the rows
   if (c.kind == SP_ROWS) {
-    int g = 1;                                            // lanes per row: from the row COUNT of the chunk only
-    if (c.nr < kBlock) {
-      int p2 = 1;
-      while (p2 < c.nr) p2 <<= 1;
-      g = kBlock / p2;
-      if (g > 64) g = 64;
-    }
-    const int grp = tid / g, l = tid - grp * g, ngrp = kBlock / g;
-    for (int r = grp; r < c.nr; r += ngrp) {
+    int k = 0;
+    for (int r = grp; r < c.nr; r += ngrp, ++k) {
       const int64_t row = (int64_t)c.row0 + r;
-      const int s0 = (int)(ptr[row] - c.k0), s1 = (int)(ptr[row + 1] - c.k0);
-      double acc = 0.0;
-      for (int e = s0 + l; e < s1; e += g) acc += prod[e];
+      int64_t q0 = 0, q1 = 0;
+      T ro = T(0);
+      bool have = false;
+#pragma unroll
+      for (int t = 0; t < kSpPre; ++t)
+        if (k == t) {
+          q0 = p0[t];
+          q1 = p1[t];
+          if constexpr (!BETA0) ro = old[t];
+          have = true;
+        }
+      if (!have) {
+        q0 = ptr[row];
+        q1 = ptr[row + 1];
+        if constexpr (!BETA0) ro = res[row];
+      }
+      double acc = sp_walk<T>(x, sval, sidx, (int)(q0 - c.k0) + l, (int)(q1 - c.k0), g);
       for (int off = g >> 1; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
-      if (l == 0) res[row] = fin_ab<T, CA, CB, BETA0>(alpha * (CA)(T)acc, beta, BETA0 ? T(0) : res[row]);
+      if (l == 0) res[row] = fin_ab<T, CA, CB, BETA0>(alpha * (CA)(T)acc, beta, ro);
     }
   } else {                                                // one long row (or a piece of one): the whole workgroup
-    double acc = 0.0;
-    for (int e = tid; e < c.nz; e += kBlock) acc += prod[e];
+    double acc = sp_walk<T>(x, sval, sidx, tid, c.nz, kBlock);
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
-    __syncthreads();                                      // every product has been read: the buffer's head is free
-    if (lane == 0) prod[wave] = acc;
+    __syncthreads();                                      // every entry has been read: the buffer's head is free
+    double *red = (double *)lds;
+    if (lane == 0) red[wave] = acc;
     __syncthreads();
     if (tid == 0) {
-      const double tot = (prod[0] + prod[1]) + (prod[2] + prod[3]);
+      const double tot = (red[0] + red[1]) + (red[2] + red[3]);
       if (c.kind == SP_LONG1) res[c.row0] = fin_ab<T, CA, CB, BETA0>(alpha * (CA)(T)tot, beta, BETA0 ? T(0) : res[c.row0]);
       else carry[c.carry] = tot;
     }

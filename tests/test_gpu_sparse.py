@@ -88,7 +88,7 @@ def test_csc_row_lengths_from_one_lane_to_a_full_wave(lo, dev):
         A.sort_indices()
         op = lo.LinearOperatorFromMatrix(dev_csc(A, dev, torch.float64))
         info = op._csc.info()
-        assert info["nnz"] == A.nnz and info["chunk"] == 4096 and info["chunks_n"] >= A.nnz // 4096
+        assert info["nnz"] == A.nnz and info["chunk"] == 2048 and info["chunks_n"] >= A.nnz // 2048
         v = rng.uniform(-1, 1, n)
         res, res2 = torch.empty(m, dtype=torch.float64, device=dev), torch.empty(m, dtype=torch.float64, device=dev)
         lo.mul(res, op, torch.from_numpy(v).to(dev), 1.0, 0.0)
@@ -264,14 +264,14 @@ def test_csc_create_validates_like_the_sparsematrixcsc_constructor(lo, dev):
 
 @pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
 def test_rows_and_columns_longer_than_a_chunk(lo, dev, dtype):
-    """A few very long rows / columns among many short ones (an arrow-head pattern): rows of 513 … 4096 entries take a
+    """A few very long rows / columns among many short ones (an arrow-head pattern): rows of 513 … 2048 entries take a
     chunk of their own, longer ones are summed piecewise with the second (fix-up) launch. Such a matrix cannot be a
     block of the ONE-launch block-diagonal operator: the host mirror then takes the per-block loop — same numbers."""
     npd = NP[dtype]
     rng = np.random.default_rng(21)
     n = 30_000
     A = sp.random(n, n, 2e-4, format="lil", random_state=4, data_rvs=lambda k: rng.uniform(-1, 1, k))
-    for r, cnt in ((0, n), (17, 600), (999, 4096), (1000, 4097), (n - 1, 20_001)):
+    for r, cnt in ((0, n), (17, 600), (999, 2048), (1000, 2049), (n - 1, 20_001)):
         cols = rng.choice(n, size=cnt, replace=False)
         A[r, cols] = rng.uniform(-1, 1, cnt)
     for c, cnt in ((5, n), (n // 2, 9000)):

@@ -1,0 +1,76 @@
+#!/usr/bin/env python
+"""Sparse apply (mxlo_csc_mul) on four patterns (the harness the round-4 kernel variants were compared with; the variants
+themselves are described in csrc/sparse_kernels.h) -> profiles/r04_sweep_sparse.txt"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+import __graft_entry__ as g
+
+lo = g.load_package()
+from linearoperators_jl_amd.device import Timer, get_ctx
+
+dev = torch.device("cuda", 0)
+ctx = get_ctx(dev)
+tm = Timer(ctx)
+gen = torch.Generator(device=dev).manual_seed(1)
+
+
+def timeit(fn, reps=20):
+    for _ in range(3):
+        fn()
+    tm.start()
+    for _ in range(reps):
+        fn()
+    tm.stop()
+    return tm.elapsed_ms() / reps
+
+
+def stencil_csc(gs, offsets):
+    n = gs ** 3
+    i = torch.arange(n, device=dev)
+    z, y, xg = i // (gs * gs), (i // gs) % gs, i % gs
+    cols, rows = [], []
+    for dz, dy, dx in offsets:
+        ok = (z + dz >= 0) & (z + dz < gs) & (y + dy >= 0) & (y + dy < gs) & (xg + dx >= 0) & (xg + dx < gs)
+        cols.append(i[ok]); rows.append((i + (dz * gs + dy) * gs + dx)[ok])
+    key = torch.unique(torch.cat(cols) * n + torch.cat(rows))
+    cols, rows = key // n, key % n
+    ccol = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+    ccol[1:] = torch.cumsum(torch.bincount(cols, minlength=n), 0)
+    vals = torch.rand(key.numel(), dtype=torch.float64, device=dev, generator=gen) - 0.5
+    return torch.sparse_csc_tensor(ccol, rows, vals, size=(n, n))
+
+
+def banded_csc(n, per_row, spread):
+    cols = torch.arange(n, device=dev).repeat_interleave(per_row)
+    offs = torch.stack([torch.randperm(2 * spread + 1, device=dev, generator=gen)[:per_row] for _ in range(64)])
+    off = offs[torch.randint(0, 64, (n,), device=dev, generator=gen)].reshape(-1) - spread
+    key = torch.unique(cols * n + (cols + off).clamp_(0, n - 1))
+    cols, rows = key // n, key % n
+    ccol = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+    ccol[1:] = torch.cumsum(torch.bincount(cols, minlength=n), 0)
+    vals = torch.rand(key.numel(), dtype=torch.float64, device=dev, generator=gen) - 0.5
+    return torch.sparse_csc_tensor(ccol, rows, vals, size=(n, n))
+
+
+seven = [(0, 0, 0), (1, 0, 0), (-1, 0, 0), (0, 1, 0), (0, -1, 0), (0, 0, 1), (0, 0, -1)]
+full27 = [(a, b, c) for a in (-1, 0, 1) for b in (-1, 0, 1) for c in (-1, 0, 1)]
+cases = [("7-point Laplacian 160^3", stencil_csc(160, seven)), ("27-point stencil 128^3", stencil_csc(128, full27)),
+         ("random band 16/row +-2000 n=4e6", banded_csc(4_000_000, 16, 2000)),
+         ("random columns 13.6/row over +-1.5e6 n=4e6", banded_csc(4_000_000, 16, 1_500_000))]
+for name, M in cases:
+    op = lo.LinearOperatorFromMatrix(M)
+    n, nnz = M.shape[0], M.values().numel()
+    x, y = torch.rand(n, dtype=torch.float64, device=dev, generator=gen), torch.empty(n, dtype=torch.float64, device=dev)
+    nbytes = nnz * 12 + n * 24
+    for xcds in (1, 8):
+        ctx.tune("sp_xcds", xcds)
+        out = []
+        for o in (op, lo.transpose(op)):
+            ms = timeit(lambda: lo.mul(y, o, x, 1.0, 0.0))
+            out.append(f"{ms * 1e3:7.1f} us {nbytes / ms / 1e6 / 8000:5.3f}")
+        print(f"{name:44s} sp_xcds {xcds}:  A*x {out[0]}   A'*x {out[1]}", flush=True)
+ctx.tune("sp_xcds", 8)

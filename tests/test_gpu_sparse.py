@@ -357,3 +357,42 @@ def test_complex_sparse_operator_through_real_planes(lo, dev, dtype, tol):
                 want = a * (Dm @ v.astype(np.complex128)) + (b * r0.astype(np.complex128) if b != 0 else 0)
                 scale = abs(a) * float((np.abs(Dm) @ np.abs(v)).max()) + abs(b) * float(np.abs(r0).max())
                 assert np.abs(res.cpu().numpy() - want).max() <= 8 * tol * scale
+
+
+def test_warmed_sparse_applies_only_launch_kernels(lo, dev):
+    """The allocation / synchronisation contract (tests/test_gpu_contract.py; test/test_linop_allocs.jl in the reference):
+    a warmed sparse `mul!` — the leaf in both modes, a row longer than a chunk (two launches), and the fused
+    block-diagonal operator with sparse blocks — issues kernel launches and nothing else; ONE launch for the leaf."""
+    import ctypes as C
+    names = ("malloc", "free", "h2d", "d2h", "d2d", "d2h_bytes", "stream_sync", "device_sync", "event_sync", "memset_async",
+             "launch", "blocking_copy")
+
+    def snap():
+        a = (C.c_int64 * 12)()
+        lo._lib.call("mxlo_debug_counters", a)
+        return dict(zip(names, list(a)))
+
+    rng = np.random.default_rng(2)
+    A = rand_sparse(rng, 5000, 4000, 0.004, np.float64)
+    op = lo.LinearOperatorFromMatrix(dev_csc(A, dev, torch.float64))
+    B = sp.lil_matrix((3000, 3000)); B[7, :] = 1.0; B.setdiag(2.0)
+    long_op = lo.LinearOperatorFromMatrix(dev_csc(sp.csc_matrix(B), dev, torch.float64))
+    bd = lo.BlockDiagonalOperator(lo.opDiagonal(torch.rand(100, dtype=torch.float64, device=dev)), dev_csc(A, dev, torch.float64))
+    assert hasattr(bd, "_keepalive")
+    cases = [("A*x", op, 4000, 5000, 1), ("A'*x", lo.transpose(op), 5000, 4000, 1), ("row > chunk", long_op, 3000, 3000, 2),
+             ("fused block-diagonal", bd, 4100, 5100, 1)]
+    for name, o, nin, nout, launches in cases:
+        v = torch.rand(nin, dtype=torch.float64, device=dev)
+        res = torch.rand(nout, dtype=torch.float64, device=dev)
+        for _ in range(3):
+            lo.mul(res, o, v, 2.0, -3.0)
+        import gc
+        gc.collect()
+        torch.cuda.synchronize()
+        a = snap()
+        for _ in range(4):
+            lo.mul(res, o, v, 2.0, -3.0)
+        b = snap()
+        d = {k: b[k] - a[k] for k in names}
+        assert not {k: x for k, x in d.items() if k != "launch" and x}, (name, d)
+        assert d["launch"] == 4 * launches, (name, d)

@@ -277,7 +277,8 @@ class VectorExchange:
 
 
 def row_sharded_dense(M_local: torch.Tensor, plan_m: ShardPlan, plan_n: ShardPlan, group=None):
-    """LinearOperator over the local row block `M_local` (m_loc × n) of an m × n matrix; operates on shards."""
+    """LinearOperator over the local row block `M_local` (m_loc × n; dense, or sparse: torch.sparse_csc / _csr) of an
+    m × n matrix; operates on shards."""
     from . import _lib
     from .device import Storage, dtype_code, get_ctx, ptr
     from .leaves import LinearOperatorFromMatrix
@@ -306,6 +307,10 @@ def row_sharded_dense(M_local: torch.Tensor, plan_m: ShardPlan, plan_n: ShardPla
                   float(b), scalar_flags(dt, a, b))
 
     return LinearOperator(dt, m_loc, n_loc, False, False, prod, tprod, tprod, S=Storage(dt, dev))
+
+
+row_sharded_matrix = row_sharded_dense      # dense OR sparse local block: LinearOperatorFromMatrix routes torch.sparse_csc / _csr
+                                            # tensors to the sparse leaf (mxlo_csc_*); the collectives are the same
 
 
 # opHermitian(d, A) with the ROWS of the lower triangle sharded ("needs all-gather(v) + reduce-scatter

@@ -84,6 +84,21 @@ WORKER = textwrap.dedent('''
     lo.mul(outt, Msh.T, T(uu[pm.lo(rank):pm.hi(rank)]), 2.0, -3.0)
     wantt = 2.0 * (Mfull.T @ uu) - 3.0 * rt
     err_m = max(err_m, np.linalg.norm(outt.cpu().numpy() - wantt[pn.lo(rank):pn.hi(rank)]) / np.linalg.norm(wantt))
+    # the same operator with a SPARSE local row block (LinearOperatorFromMatrix routes torch.sparse_csc to mxlo_csc_*)
+    import scipy.sparse as sp
+    Sfull = sp.random(m2, n2, 0.03, format="csr", random_state=11)
+    blk = sp.csc_matrix(Sfull[pm.lo(rank):pm.hi(rank), :])
+    Sloc = torch.sparse_csc_tensor(torch.from_numpy(blk.indptr.astype(np.int64)), torch.from_numpy(blk.indices.astype(np.int64)),
+                                   torch.from_numpy(blk.data), size=blk.shape).to(dev)
+    Ssh = lo.sharded.row_sharded_matrix(Sloc, pm, pn)
+    out = T(rr[pm.lo(rank):pm.hi(rank)])
+    lo.mul(out, Ssh, T(vv[pn.lo(rank):pn.hi(rank)]), 2.0, -3.0)
+    want = 2.0 * (Sfull @ vv) - 3.0 * rr
+    err_m = max(err_m, np.linalg.norm(out.cpu().numpy() - want[pm.lo(rank):pm.hi(rank)]) / np.linalg.norm(want))
+    outt = T(rt[pn.lo(rank):pn.hi(rank)])
+    lo.mul(outt, Ssh.T, T(uu[pm.lo(rank):pm.hi(rank)]), 2.0, -3.0)
+    wantt = 2.0 * (Sfull.T @ uu) - 3.0 * rt
+    err_m = max(err_m, np.linalg.norm(outt.cpu().numpy() - wantt[pn.lo(rank):pn.hi(rank)]) / np.linalg.norm(wantt))
     # row-sharded opHermitian: rectangle + diagonal triangle per rank, all-gather(v) + reduce-scatter(L' part)
     nh = 1501
     Ah = rng.standard_normal((nh, nh)); dh = rng.standard_normal(nh); vh = rng.uniform(-1, 1, nh); rh = rng.uniform(-1, 1, nh)

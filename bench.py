@@ -815,6 +815,33 @@ def bench_misc(lo, torch, dev, ctx):
             except Exception as e:           # an extra must never cost the line
                 out["dense_block_error"] = repr(e)
         del M, Hm
+    # sparse LinearOperator(M) (round 4): the 7-point Laplacian of a 160^3 grid, and 1024 sparse blocks in ONE block-diagonal launch
+    try:
+        gs = 160
+        nS = gs ** 3
+        ii = torch.arange(nS, device=dev)
+        zz, yy, xx = ii // (gs * gs), (ii // gs) % gs, ii % gs
+        cc, rr = [], []
+        for dz, dy, dx in ((0, 0, 0), (1, 0, 0), (-1, 0, 0), (0, 1, 0), (0, -1, 0), (0, 0, 1), (0, 0, -1)):
+            ok = (zz + dz >= 0) & (zz + dz < gs) & (yy + dy >= 0) & (yy + dy < gs) & (xx + dx >= 0) & (xx + dx < gs)
+            cc.append(ii[ok]); rr.append((ii + (dz * gs + dy) * gs + dx)[ok])
+        key = torch.unique(torch.cat(cc) * nS + torch.cat(rr))
+        cS, rS = key // nS, key % nS
+        ccol = torch.zeros(nS + 1, dtype=torch.int64, device=dev)
+        ccol[1:] = torch.cumsum(torch.bincount(cS, minlength=nS), 0)
+        vS = torch.rand(key.numel(), dtype=torch.float64, device=dev, generator=gen) - 0.5
+        opS = lo.LinearOperatorFromMatrix(torch.sparse_csc_tensor(ccol, rS, vS, size=(nS, nS)))
+        xs_, ys_ = torch.rand(nS, dtype=torch.float64, device=dev, generator=gen), torch.empty(nS, dtype=torch.float64, device=dev)
+        nb = 12.0 * key.numel() + 24.0 * nS
+        ms = timeit(lambda: lo.mul(ys_, opS, xs_, 1.0, 0.0), 20)
+        mst = timeit(lambda: lo.mul(ys_, opS.T, xs_, 1.0, 0.0), 20)
+        out["sparse_laplacian7_160^3"] = {"nnz": int(key.numel()), "us_A*x": round(ms * 1e3, 1), "us_A'*x": round(mst * 1e3, 1),
+                                          "GB/s(12B/entry+24B/row)": round(nb / ms / 1e6, 1),
+                                          "frac_hbm_peak": round(nb / ms / 1e6 / HBM_PEAK_GBS, 4)}
+        del opS, xs_, ys_, vS, key, cS, rS, ccol, cc, rr, ii, zz, yy, xx
+        torch.cuda.empty_cache()
+    except Exception as e:                   # an extra must never cost the line
+        out["sparse_error"] = repr(e)
     # launch-bound quasi-Newton applies (one launch per apply for <= 64 workgroups) and the Gauss-form complex kron
     try:
         for kind, make in (("LBFGS", lo.LBFGSOperator), ("InverseLBFGS", lo.InverseLBFGSOperator), ("LSR1", lo.LSR1Operator)):

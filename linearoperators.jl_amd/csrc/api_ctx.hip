@@ -45,6 +45,11 @@ MXLO_API int32_t mxlo_ctx_create(int32_t device_id, void *stream, mxlo_ctx **out
   ctx->device = device_id;
   ctx->stream = (hipStream_t)stream;
   ctx->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  {
+    int khz = 0;
+    if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device_id) == hipSuccess && khz > 0) ctx->wall_clock_khz = khz;
+    else (void)hipGetLastError();
+  }
   hipError_t e = hipMalloc((void **)&ctx->partials, sizeof(double) * kMaxRedCols * kMaxRedBlocks);
   if (e == hipSuccess) e = hipMalloc((void **)&ctx->scalars, sizeof(double) * kScalarSlots);
   if (e == hipSuccess) e = hipMalloc((void **)&ctx->ticket, 64);

@@ -160,6 +160,7 @@ struct mxlo_ctx {
   unsigned long long *qslots = nullptr;  // [2][40 x 64] exchange slots + epoch word of the single-launch quasi-Newton apply (qn.hip)
   unsigned *fault_host = nullptr;        // pinned, device-mapped word: a single-launch kernel that timed out on its exchange
   unsigned *fault_dev = nullptr;         // stores its code here (system scope); the host reads it without synchronising
+  int wall_clock_khz = 100000;           // rate of wall_clock64() on this device (hipDeviceAttributeWallClockRate)
   mxlo_allreduce_fn allreduce = nullptr;
   void *allreduce_user = nullptr;
   void *scratch = nullptr;     // grow-on-demand workspace (opHermitian tile partials); owned by the ctx
@@ -203,8 +204,8 @@ struct DeviceGuard {
 constexpr unsigned kFaultHouseholder = 1u, kFaultQn = 2u;
 constexpr unsigned long long kCanonicalNaN = 0x7FF8000000000000ull;
 int32_t fused_fault_check(mxlo_ctx *ctx);           // api_ctx.hip
-inline unsigned long long fused_timeout_ticks(const mxlo_ctx *ctx) {   // wall_clock64(): 100 MHz on gfx9-family parts
-  return (unsigned long long)ctx->tune.fused_timeout_ms * 100000ull;
+inline unsigned long long fused_timeout_ticks(const mxlo_ctx *ctx) {   // wall_clock64() ticks: the device's constant-rate clock
+  return (unsigned long long)ctx->tune.fused_timeout_ms * (unsigned long long)ctx->wall_clock_khz;
 }
 #if defined(__HIPCC__)
 __device__ __forceinline__ unsigned long long poll_slot(const unsigned long long *slot, unsigned long long ticks,

@@ -609,11 +609,18 @@ def test_single_launch_householder_timeout_is_an_error_not_a_hang(lo, dev):
             lo.mul(res, H, dv, 1.0, 0.0)
         torch.cuda.synchronize()
         assert rel(res.cpu().numpy(), want) <= 1e-12
-        # the same fault is also reported by mxlo_ctx_sync when no further apply follows
+        # the same fault is also reported by mxlo_ctx_sync when no further apply follows; and the wait lasts what the
+        # tune key says (the device's constant-rate clock, hipDeviceAttributeWallClockRate): 300 ms here
         ctx.tune("fused_debug_drop", 0)
+        ctx.tune("fused_timeout_ms", 300)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
         lo.mul(res, H, dv, 1.0, 0.0)
         with pytest.raises(Exception, match="timed out"):
             ctx.sync()
+        waited = time.perf_counter() - t0
+        assert 0.25 <= waited <= 1.5, waited
+        ctx.tune("fused_timeout_ms", 20)
         ctx.tune("fused_debug_drop", -1)
         ctx.tune("house_fused", 1)
         lo.mul(res, H, dv, 1.0, 0.0)

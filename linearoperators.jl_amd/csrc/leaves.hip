@@ -227,7 +227,7 @@ static int32_t householder_apply_t(mxlo_ctx *ctx, T *res, const T *h, const T *v
   });
 }
 
-// ---- single-launch opHouseholder for vectors that fit ONE wave of workgroups (n <= 2^20 doubles) ------------------------
+// ---- single-launch opHouseholder for vectors that fit ONE wave of workgroups (n <= 2^21 doubles) ------------------------
 // Two dependent launches (dot, update) cost more than the data movement below ~1 MiB. Here every workgroup keeps its
 // slice of h and v in registers (read ONCE: 24 B/elt instead of 40), publishes its partial h'v into an exchange slot,
 // waits until all G <= 256 co-resident workgroups have published, sums the G partials in the same fixed order (every
@@ -344,11 +344,13 @@ static int32_t householder_fused_t(mxlo_ctx *ctx, T *res, const T *h, const T *v
     if (aligned) {
       if (vpt == 2) go.template operator()<2, true>();
       else if (vpt == 4) go.template operator()<4, true>();
-      else go.template operator()<8, true>();
+      else if (vpt == 8) go.template operator()<8, true>();
+      else go.template operator()<16, true>();
     } else {
       if (vpt == 2) go.template operator()<2, false>();
       else if (vpt == 4) go.template operator()<4, false>();
-      else go.template operator()<8, false>();
+      else if (vpt == 8) go.template operator()<8, false>();
+      else go.template operator()<16, false>();
     }
     *launched = fits;
     if (!fits) return MXLO_OK;          // the grid would not be co-resident on this device: the caller takes two passes
@@ -366,7 +368,9 @@ static int32_t householder_t(mxlo_ctx *ctx, T *res, const T *h, const T *v, int6
   }
   if (ctx->tune.house_fused && !ctx->allreduce && n > 0 && ctx->fault_dev) {
     const int64_t cap = std::min<int64_t>(ctx->num_cu, kFusedSlots);
-    const int vpt = fused_grid<T>(n, 2) <= 16 ? 2 : (fused_grid<T>(n, 4) <= 32 ? 4 : 8);
+    // vectors per lane: 2 / 4 / 8 up to n = 2^20 doubles, 16 (two 2 KiB register slices per lane) up to 2^21 — beyond
+    // that the slices no longer fit the register file of one co-resident wave of workgroups
+    const int vpt = fused_grid<T>(n, 2) <= 16 ? 2 : (fused_grid<T>(n, 4) <= 32 ? 4 : (fused_grid<T>(n, 8) <= cap ? 8 : 16));
     if (fused_grid<T>(n, vpt) <= cap) {
       bool launched = false;
       const int32_t st = householder_fused_t<T>(ctx, res, h, v, n, alpha, beta, flags, vpt, &launched);

@@ -270,18 +270,20 @@ def test_rows_and_columns_longer_than_a_chunk(lo, dev, dtype):
     npd = NP[dtype]
     rng = np.random.default_rng(21)
     n = 30_000
-    A = sp.random(n, n, 2e-4, format="lil", random_state=4, data_rvs=lambda k: rng.uniform(-1, 1, k))
-    for r, cnt in ((0, n), (17, 600), (999, 2048), (1000, 2049), (n - 1, 20_001)):
-        cols = rng.choice(n, size=cnt, replace=False)
-        A[r, cols] = rng.uniform(-1, 1, cnt)
+    nb = 180_000                                           # background: ~6 entries per row, duplicates summed
+    rows, cols, vals = [rng.integers(0, n, nb)], [rng.integers(0, n, nb)], [rng.uniform(-1, 1, nb)]
+    for r, cnt in ((0, n), (17, 600), (999, 2030), (1000, 2070), (n - 1, 20_001)):       # 2048 = one chunk
+        cs = rng.choice(n, size=cnt, replace=False)
+        rows.append(np.full(cnt, r)); cols.append(cs); vals.append(rng.uniform(-1, 1, cnt))
     for c, cnt in ((5, n), (n // 2, 9000)):
-        rows = rng.choice(n, size=cnt, replace=False)
-        A[rows, c] = rng.uniform(-1, 1, cnt)
-    A = sp.csc_matrix(A).astype(npd)
+        rs = rng.choice(n, size=cnt, replace=False)
+        rows.append(rs); cols.append(np.full(cnt, c)); vals.append(rng.uniform(-1, 1, cnt))
+    A = sp.csc_matrix(sp.coo_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(n, n))).astype(npd)
+    A.sum_duplicates()
     A.sort_indices()
     op = lo.LinearOperatorFromMatrix(dev_csc(A, dev, dtype))
     inf = op._csc.info()
-    assert inf["long_rows"] == 4 and inf["long_cols"] == 2
+    assert inf["long_rows"] == 3 and inf["long_cols"] == 2          # rows of ~2075, ~20005 and n entries; two long columns
     assert getattr(op, "_leaf", None) is None
     for trans in (False, True):
         v = rng.uniform(-1, 1, n).astype(npd)

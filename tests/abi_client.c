@@ -213,6 +213,82 @@ int main(void) {
     if (st != 1) { printf("FAIL s == 0 must be reported\n"); return 1; }
     CK(mxlo_free(ctx, ddq));
   }
+  /* sparse LinearOperator(M::SparseMatrixCSC): Julia's three arrays as stored (1-based), A*x and A'*x against the
+   * SparseArrays loops written out in C (src/constructors.jl:19-29 -> mul!(res, M, v, α, β)); then the same matrix as a
+   * block of the ONE-launch block-diagonal operator next to a diagonal block */
+  {
+    enum { SM = 3001, SN = 2500, PER = 5 };
+    static int64_t cp[SN + 1], rv[SN * PER];
+    static double nz[SN * PER], xs[SN], us[SM], ref[SM], reft[SN], got[SM > SN ? SM : SN];
+    for (int64_t j = 0; j <= SN; ++j) cp[j] = 1 + j * PER;
+    for (int64_t j = 0; j < SN; ++j)
+      for (int k = 0; k < PER; ++k) {
+        rv[j * PER + k] = 1 + (int64_t)((j * 7 + k * 601) % SM);      /* distinct rows within a column (601 * k mod 3001) */
+        nz[j * PER + k] = 2 * urand(&seed) - 1;
+      }
+    for (int64_t j = 0; j < SN; ++j) xs[j] = 2 * urand(&seed) - 1;
+    for (int64_t i = 0; i < SM; ++i) { us[i] = 2 * urand(&seed) - 1; ref[i] = 0.25 * i; }
+    for (int64_t j = 0; j < SN; ++j) reft[j] = 0;
+    /* _spmatmul!: C .*= beta; C[rowval[k]] += nzval[k] * (x[col] * alpha)     (alpha = 2, beta = -3) */
+    for (int64_t i = 0; i < SM; ++i) ref[i] *= -3.0;
+    for (int64_t j = 0; j < SN; ++j) {
+      const double axj = xs[j] * 2.0;
+      for (int64_t k = cp[j] - 1; k < cp[j + 1] - 1; ++k) ref[rv[k] - 1] += nz[k] * axj;
+    }
+    for (int64_t j = 0; j < SN; ++j) {                                 /* _At_or_Ac_mul_B!, beta = 0 */
+      double tmp = 0;
+      for (int64_t k = cp[j] - 1; k < cp[j + 1] - 1; ++k) tmp += nz[k] * us[rv[k] - 1];
+      reft[j] += tmp * 1.0;
+    }
+    void *dcp = dev_from(ctx, cp, sizeof cp), *drv = dev_from(ctx, rv, sizeof rv), *dnz = dev_from(ctx, nz, sizeof nz);
+    void *dxs = dev_from(ctx, xs, sizeof xs), *dus = dev_from(ctx, us, sizeof us), *dout = dev_from(ctx, NULL, sizeof got);
+    mxlo_csc *A = NULL;
+    CK(mxlo_csc_create(ctx, MXLO_F64, SM, SN, (const int64_t *)dcp, (const int64_t *)drv, dnz, 1, &A));
+    int64_t info[8];
+    CK(mxlo_csc_info(A, info));
+    if (info[0] != SM || info[1] != SN || info[2] != SN * PER || info[5] != 0) { printf("FAIL csc info\n"); return 1; }
+    for (int64_t i = 0; i < SM; ++i) got[i] = 0.25 * i;
+    CK(mxlo_memcpy_h2d(ctx, dout, got, SM * 8));
+    CK(mxlo_csc_mul(A, dout, dxs, 2.0, -3.0, MXLO_OP_N, 0));
+    CK(mxlo_memcpy_d2h(ctx, got, dout, SM * 8));
+    err = rn = 0;
+    for (int64_t i = 0; i < SM; ++i) { err += (got[i] - ref[i]) * (got[i] - ref[i]); rn += ref[i] * ref[i]; }
+    if (sqrt(err / rn) > 1e-14) { printf("FAIL csc A*x %.3e\n", sqrt(err / rn)); return 1; }
+    CK(mxlo_csc_mul(A, dout, dus, 1.0, 0.0, MXLO_OP_T, 0));
+    CK(mxlo_memcpy_d2h(ctx, got, dout, SN * 8));
+    err = rn = 0;
+    for (int64_t j = 0; j < SN; ++j) { err += (got[j] - reft[j]) * (got[j] - reft[j]); rn += reft[j] * reft[j]; }
+    if (sqrt(err / rn) > 1e-14) { printf("FAIL csc A'*x %.3e\n", sqrt(err / rn)); return 1; }
+    /* BlockDiagonalOperator(opDiagonal(d[0:100]), A): one launch, the sparse block at row / column offset 100 */
+    mxlo_block_desc bl[2];
+    memset(bl, 0, sizeof bl);
+    bl[0].kind = MXLO_BLK_DIAG; bl[0].m = bl[0].n = 100; bl[0].data = dd;
+    bl[1].kind = MXLO_BLK_CSC; bl[1].row_off = 100; bl[1].col_off = 100; bl[1].m = SM; bl[1].n = SN; bl[1].data = A;
+    mxlo_blockdiag *bd = NULL;
+    CK(mxlo_blockdiag_create(ctx, MXLO_F64, bl, 2, &bd));
+    static double xin[100 + SN], yout[100 + SM];
+    for (int64_t i = 0; i < 100; ++i) xin[i] = 1.0;
+    memcpy(xin + 100, xs, sizeof xs);
+    void *dxin = dev_from(ctx, xin, sizeof xin), *dyo = dev_from(ctx, NULL, sizeof yout);
+    CK(mxlo_blockdiag_mul(bd, dyo, dxin, 2.0, 0.0, MXLO_OP_N, 0));
+    CK(mxlo_memcpy_d2h(ctx, yout, dyo, sizeof yout));
+    CK(mxlo_csc_mul(A, dout, dxs, 2.0, 0.0, MXLO_OP_N, 0));
+    CK(mxlo_memcpy_d2h(ctx, got, dout, SM * 8));
+    if (memcmp(yout + 100, got, SM * 8) != 0) { printf("FAIL sparse block of the fused operator differs from the leaf\n"); return 1; }
+    for (int64_t i = 0; i < 100; ++i)
+      if (yout[i] != (2.0 * d[i]) * 1.0) { printf("FAIL diagonal block next to the sparse block\n"); return 1; }
+    /* a bad structure is an error code naming the position, never a crash */
+    cp[3] = cp[2] - 1;
+    CK(mxlo_memcpy_h2d(ctx, dcp, cp, sizeof cp));
+    mxlo_csc *B = NULL;
+    if (mxlo_csc_create(ctx, MXLO_F64, SM, SN, (const int64_t *)dcp, (const int64_t *)drv, dnz, 1, &B) != MXLO_EINVAL) {
+      printf("FAIL a decreasing colptr must be MXLO_EINVAL\n"); return 1;
+    }
+    CK(mxlo_blockdiag_destroy(bd));
+    CK(mxlo_csc_destroy(A));
+    CK(mxlo_free(ctx, dcp)); CK(mxlo_free(ctx, drv)); CK(mxlo_free(ctx, dnz)); CK(mxlo_free(ctx, dxs)); CK(mxlo_free(ctx, dus));
+    CK(mxlo_free(ctx, dout)); CK(mxlo_free(ctx, dxin)); CK(mxlo_free(ctx, dyo));
+  }
   /* error conventions: codes, never exceptions */
   if (mxlo_qn_solve_shifted(H, dres, dg, 0.1) != MXLO_ESTATE) { printf("FAIL expected ESTATE\n"); return 1; }
   if (mxlo_diag_mul(ctx, MXLO_F64, dr, dd, dv, n + 1, n, 1.0, 0.0, 0) != MXLO_ESHAPE) { printf("FAIL expected ESHAPE\n"); return 1; }

@@ -484,6 +484,12 @@ int32_t mxlo_csc_create(mxlo_ctx *ctx, int32_t dtype, int64_t m, int64_t n, cons
 int32_t mxlo_csc_refresh(mxlo_csc *h);
 int32_t mxlo_csc_mul(mxlo_csc *h, void *res, const void *v, double alpha, double beta, int32_t op_mode,
                      int32_t flags);
+/* mul!(res::Matrix, LinearOperator(A), V::Matrix, α, β) (src/operations.jl:34-36: the closure is handed the matrices —
+ * a sparse-times-dense product in the reference): res (nres x k, column-major, leading dimension ldr) = alpha * op(A) * V
+ * (nin x k, ldv) + beta * res. A's chunks are streamed into LDS once per group of up to 8 columns and walked once per
+ * column: A is read once per 8 columns, each column's result equals the single-vector apply bit for bit. */
+int32_t mxlo_csc_mul_block(mxlo_csc *h, void *res, int64_t ldr, const void *V, int64_t ldv, int64_t k, double alpha,
+                           double beta, int32_t op_mode, int32_t flags);
 int32_t mxlo_csc_info(mxlo_csc *h, int64_t info[8]);
 int32_t mxlo_csc_destroy(mxlo_csc *h);
 

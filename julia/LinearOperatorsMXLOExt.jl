@@ -462,6 +462,15 @@ struct SparseApply{T}
 end
 (f::SparseApply{T})(res::MXVector{T}, v::MXVector{T}, α, β) where {T <: RealT} = check(ccall((:mxlo_csc_mul, lib), Int32,
     (P, P, P, Float64, Float64, Int32, Int32), f.A.h, res.ptr, v.ptr, α, β, f.mode, flags(T, α, β)))
+# mul! on matrices (src/operations.jl:34-36): the stored matrix is read once per 8 columns of the block
+(f::SparseApply{T})(res::MXMatrix{T}, V::MXMatrix{T}, α, β) where {T <: RealT} = check(ccall((:mxlo_csc_mul_block, lib), Int32,
+    (P, P, Int64, P, Int64, Int64, Float64, Float64, Int32, Int32),
+    f.A.h, res.data.ptr, res.m, V.data.ptr, V.m, size(V, 2), α, β, f.mode, flags(T, α, β)))
+function apply_columns(f::SparseApply{T}, res::MXMatrix{T}, m::MXMatrix{T}, α, β) where {T}     # one call for the block
+  size(res, 2) == size(m, 2) || throw(LinearOperatorException("shape mismatch"))
+  f(res, m, α, β)
+  res
+end
 function LinearOperator(A::MXSparseMatrixCSC{T}; symmetric = false, hermitian = false, S = MXVector{T}) where {T <: RealT}
   LinearOperator{T, S}(A.m, A.n, symmetric, hermitian, SparseApply{T}(A, Int32(0)), SparseApply{T}(A, Int32(1)),
                        SparseApply{T}(A, Int32(2)))

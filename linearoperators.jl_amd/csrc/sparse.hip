@@ -40,11 +40,11 @@ csc_gather_values_kernel(T *__restrict__ out, const T *__restrict__ nzval, const
   if (i < nnz) out[i] = nzval[perm[i]];
 }
 
-template <typename T, typename CA, typename CB, bool BETA0>
+template <typename T, typename CA, typename CB, bool BETA0, bool BLOCK>
 __global__ void __launch_bounds__(kBlock)
 csc_mul_kernel(T *__restrict__ res, const T *__restrict__ x, const int64_t *__restrict__ ptr, const int32_t *__restrict__ idx,
                const T *__restrict__ val, const SpChunk *__restrict__ chunks, int nchunks, int nxcd, double *__restrict__ carry,
-               CA alpha, CB beta) {
+               CA alpha, CB beta, int ncols, int64_t ldx, int64_t ldr) {
   __shared__ __attribute__((aligned(16))) char lds[sp_lds_bytes<T>()];
   // XCD-aware order: workgroup w runs on XCD w % nxcd, and each XCD has its own L2. XCD k takes the k-th CONTIGUOUS
   // part of the chunk table, so the x lines its workgroups share (neighbouring rows gather neighbouring columns) are
@@ -52,7 +52,7 @@ csc_mul_kernel(T *__restrict__ res, const T *__restrict__ x, const int64_t *__re
   const int w = (int)blockIdx.x, per = (nchunks + nxcd - 1) / nxcd;
   const int ci = (w % nxcd) * per + w / nxcd;
   if (ci >= nchunks || w / nxcd >= per) return;
-  spmv_chunk<T, CA, CB, BETA0>(res, x, ptr, idx, val, chunks[ci], carry, alpha, beta, lds);
+  spmv_chunk<T, CA, CB, BETA0, BLOCK>(res, x, ptr, idx, val, chunks[ci], carry, alpha, beta, lds, ncols, ldx, ldr);
 }
 
 // The chunk table of one compressed-row operand (see sparse_kernels.h): whole rows packed into chunks of <= kSpChunk
@@ -95,8 +95,11 @@ void build_chunks(const std::vector<int64_t> &ptr, int64_t nrows, std::vector<Sp
   *ncarry = carry;
 }
 
+constexpr int kSpMaxCols = 8;      // columns of a block apply per launch (carry slots are sized for it)
+
 template <typename T>
-int32_t csc_mul_t(mxlo_csc *h, T *res, const T *v, double alpha, double beta, int32_t op_mode, int32_t flags) {
+int32_t csc_mul_t(mxlo_csc *h, T *res, const T *v, double alpha, double beta, int32_t op_mode, int32_t flags, int ncols = 1,
+                  int64_t ldx = 0, int64_t ldr = 0) {
   mxlo_ctx *ctx = h->ctx;
   const bool trans = op_mode != MXLO_OP_N;
   const CscDev &d = h->host;
@@ -110,12 +113,16 @@ int32_t csc_mul_t(mxlo_csc *h, T *res, const T *v, double alpha, double beta, in
   return dispatch_ab<T>(beta, flags, [&]<typename CA, typename CB, bool B0>() -> int32_t {
     const int nxcd = ctx->tune.sp_xcds > 0 ? ctx->tune.sp_xcds : 1;
     const int per = (nchunks + nxcd - 1) / nxcd;
-    hipLaunchKernelGGL((csc_mul_kernel<T, CA, CB, B0>), dim3((unsigned)(per * nxcd)), dim3(kBlock), 0, ctx->stream, res, v, ptr,
-                       idx, val, chunks, nchunks, nxcd, d.carry, (CA)alpha, (CB)beta);
+    if (ncols > 1)
+      hipLaunchKernelGGL((csc_mul_kernel<T, CA, CB, B0, true>), dim3((unsigned)(per * nxcd)), dim3(kBlock), 0, ctx->stream, res, v,
+                         ptr, idx, val, chunks, nchunks, nxcd, d.carry, (CA)alpha, (CB)beta, ncols, ldx, ldr);
+    else
+      hipLaunchKernelGGL((csc_mul_kernel<T, CA, CB, B0, false>), dim3((unsigned)(per * nxcd)), dim3(kBlock), 0, ctx->stream, res, v,
+                         ptr, idx, val, chunks, nchunks, nxcd, d.carry, (CA)alpha, (CB)beta, 1, ldx, ldr);
     MXLO_LAUNCH_CHECK();
     if (nlong > 0) {
-      hipLaunchKernelGGL((spmv_fixup_kernel<T, CA, CB, B0>), dim3((unsigned)((nlong + kBlock - 1) / kBlock)), dim3(kBlock), 0,
-                         ctx->stream, res, d.carry, longs, nlong, (CA)alpha, (CB)beta);
+      hipLaunchKernelGGL((spmv_fixup_kernel<T, CA, CB, B0>), dim3((unsigned)((nlong * ncols + kBlock - 1) / kBlock)), dim3(kBlock),
+                         0, ctx->stream, res, d.carry, longs, nlong, (CA)alpha, (CB)beta, ncols, ldr);
       MXLO_LAUNCH_CHECK();
     }
     return MXLO_OK;
@@ -202,7 +209,7 @@ MXLO_API int32_t mxlo_csc_create(mxlo_ctx *ctx, int32_t dtype, int64_t m, int64_
   up((void **)&h->long_n, lgn.data(), sizeof(SpLongRow) * lgn.size());
   up((void **)&h->long_t, lgt.data(), sizeof(SpLongRow) * lgt.size());
   if (e == hipSuccess) e = hipMalloc((void **)&d.csr_val, nnz ? es * (size_t)nnz : 16);
-  if (e == hipSuccess) e = hipMalloc((void **)&d.carry, sizeof(double) * (size_t)std::max(1, std::max(ncar_n, ncar_t)));
+  if (e == hipSuccess) e = hipMalloc((void **)&d.carry, sizeof(double) * kSpMaxCols * (size_t)std::max(1, std::max(ncar_n, ncar_t)));
   d.nzval = nzval;
   d.m = m;
   d.n = n;
@@ -254,6 +261,29 @@ MXLO_API int32_t mxlo_csc_mul(mxlo_csc *h, void *res, const void *v, double alph
   eff_scalars(h->dtype == MXLO_F64 ? 8 : 4, flags, alpha, beta);
   if (h->dtype == MXLO_F64) return csc_mul_t<double>(h, (double *)res, (const double *)v, alpha, beta, op_mode, flags);
   return csc_mul_t<float>(h, (float *)res, (const float *)v, alpha, beta, op_mode, flags);
+}
+
+MXLO_API int32_t mxlo_csc_mul_block(mxlo_csc *h, void *res, int64_t ldr, const void *V, int64_t ldv, int64_t k, double alpha,
+                                    double beta, int32_t op_mode, int32_t flags) {
+  MXLO_REQUIRE(h, MXLO_EINVAL, "mxlo_csc_mul_block: handle is NULL");
+  MXLO_DEVICE_GUARD(h->ctx);
+  MXLO_REQUIRE(op_mode >= MXLO_OP_N && op_mode <= MXLO_OP_C, MXLO_EINVAL, "bad op_mode");
+  const int64_t nres = op_mode == MXLO_OP_N ? h->m : h->n, nin = op_mode == MXLO_OP_N ? h->n : h->m;
+  MXLO_REQUIRE(k >= 0, MXLO_ESHAPE, "mxlo_csc_mul_block: k < 0");
+  if (nres == 0 || k == 0) return MXLO_OK;
+  MXLO_REQUIRE(res && (V || nin == 0), MXLO_EINVAL, "mxlo_csc_mul_block: NULL operand");
+  MXLO_REQUIRE(ldr >= nres && ldv >= (nin > 0 ? nin : 1), MXLO_ESHAPE, "mxlo_csc_mul_block: leading dimension below the column length");
+  eff_scalars(h->dtype == MXLO_F64 ? 8 : 4, flags, alpha, beta);
+  for (int64_t j0 = 0; j0 < k; j0 += kSpMaxCols) {                      // the stored matrix is read once per 8 columns
+    const int nc = (int)std::min<int64_t>(kSpMaxCols, k - j0);
+    int32_t st;
+    if (h->dtype == MXLO_F64)
+      st = csc_mul_t<double>(h, (double *)res + j0 * ldr, (const double *)V + j0 * ldv, alpha, beta, op_mode, flags, nc, ldv, ldr);
+    else
+      st = csc_mul_t<float>(h, (float *)res + j0 * ldr, (const float *)V + j0 * ldv, alpha, beta, op_mode, flags, nc, ldv, ldr);
+    if (st != MXLO_OK) return st;
+  }
+  return MXLO_OK;
 }
 
 MXLO_API int32_t mxlo_csc_info(mxlo_csc *h, int64_t info[8]) {

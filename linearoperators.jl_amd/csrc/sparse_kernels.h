@@ -106,10 +106,16 @@ __device__ __forceinline__ double sp_walk(const T *__restrict__ x, const T *sval
 
 // One chunk, start to end: called by all kBlock threads of a workgroup; `lds` is sp_lds_bytes<T>() of LDS.
 constexpr int kSpPre = 3;          // rows per lane group whose pointers (and old res) are requested with the chunk's own loads
-template <typename T, typename CA, typename CB, bool BETA0>
+// ncols / ldx / ldr: the apply on an n x ncols block (`mul!` on matrices, src/operations.jl:34-36): the chunk is streamed
+// into LDS ONCE and its rows are walked once per column of x (column j of x at x + j*ldx, of res at res + j*ldr) — A is
+// read once for the whole block. Piece sums of column j go to carry[piece * ncols + j].
+// BLOCK = false fixes ncols = 1 at compile time (the vector apply keeps its registers: 77-90 instead of 94-106).
+template <typename T, typename CA, typename CB, bool BETA0, bool BLOCK = false>
 __device__ __forceinline__ void spmv_chunk(T *__restrict__ res, const T *__restrict__ x, const int64_t *__restrict__ ptr,
                                            const int32_t *__restrict__ idx, const T *__restrict__ val, const SpChunk c,
-                                           double *__restrict__ carry, CA alpha, CB beta, void *lds) {
+                                           double *__restrict__ carry, CA alpha, CB beta, void *lds, int ncols_ = 1,
+                                           int64_t ldx = 0, int64_t ldr = 0) {
+  const int ncols = BLOCK ? ncols_ : 1;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   T *sval = (T *)lds;
   int32_t *sidx = (int32_t *)((char *)lds + sizeof(T) * kSpChunk);
@@ -181,22 +187,31 @@ __device__ __forceinline__ void spmv_chunk(T *__restrict__ res, const T *__restr
         q1 = ptr[row + 1];
         if constexpr (!BETA0) ro = res[row];
       }
-      double acc = sp_walk<T>(x, sval, sidx, (int)(q0 - c.k0) + l, (int)(q1 - c.k0), g);
-      for (int off = g >> 1; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
-      if (l == 0) res[row] = fin_ab<T, CA, CB, BETA0>(alpha * (CA)(T)acc, beta, ro);
+      for (int j = 0; j < ncols; ++j) {
+        double acc = sp_walk<T>(x + j * ldx, sval, sidx, (int)(q0 - c.k0) + l, (int)(q1 - c.k0), g);
+        for (int off = g >> 1; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+        if (l == 0) {
+          T *rp = res + j * ldr + row;
+          if constexpr (!BETA0) if (j > 0) ro = *rp;
+          *rp = fin_ab<T, CA, CB, BETA0>(alpha * (CA)(T)acc, beta, ro);
+        }
+      }
     }
   } else {                                                // one long row (or a piece of one): the whole workgroup
-    double acc = sp_walk<T>(x, sval, sidx, tid, c.nz, kBlock);
+    __shared__ double red[kBlock / 64];
+    for (int j = 0; j < ncols; ++j) {
+      double acc = sp_walk<T>(x + j * ldx, sval, sidx, tid, c.nz, kBlock);
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
-    __syncthreads();                                      // every entry has been read: the buffer's head is free
-    double *red = (double *)lds;
-    if (lane == 0) red[wave] = acc;
-    __syncthreads();
-    if (tid == 0) {
-      const double tot = (red[0] + red[1]) + (red[2] + red[3]);
-      if (c.kind == SP_LONG1) res[c.row0] = fin_ab<T, CA, CB, BETA0>(alpha * (CA)(T)tot, beta, BETA0 ? T(0) : res[c.row0]);
-      else carry[c.carry] = tot;
+      for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+      if (lane == 0) red[wave] = acc;
+      __syncthreads();
+      if (tid == 0) {
+        const double tot = (red[0] + red[1]) + (red[2] + red[3]);
+        T *rp = res + j * ldr + c.row0;
+        if (c.kind == SP_LONG1) *rp = fin_ab<T, CA, CB, BETA0>(alpha * (CA)(T)tot, beta, BETA0 ? T(0) : *rp);
+        else carry[(int64_t)c.carry * ncols + j] = tot;
+      }
+      __syncthreads();                                    // red is free for the next column
     }
   }
 }
@@ -205,13 +220,15 @@ __device__ __forceinline__ void spmv_chunk(T *__restrict__ res, const T *__restr
 template <typename T, typename CA, typename CB, bool BETA0>
 __global__ void __launch_bounds__(kBlock)
 spmv_fixup_kernel(T *__restrict__ res, const double *__restrict__ carry, const SpLongRow *__restrict__ rows, int nrows,
-                  CA alpha, CB beta) {
+                  CA alpha, CB beta, int ncols, int64_t ldr) {
   const int i = blockIdx.x * kBlock + threadIdx.x;
-  if (i >= nrows) return;
-  const SpLongRow lr = rows[i];
+  if (i >= nrows * ncols) return;
+  const SpLongRow lr = rows[i / ncols];
+  const int j = i % ncols;
   double acc = 0.0;
-  for (int p = 0; p < lr.npieces; ++p) acc += carry[lr.carry0 + p];
-  res[lr.row] = fin_ab<T, CA, CB, BETA0>(alpha * (CA)(T)acc, beta, BETA0 ? T(0) : res[lr.row]);
+  for (int p = 0; p < lr.npieces; ++p) acc += carry[(int64_t)(lr.carry0 + p) * ncols + j];
+  T *rp = res + j * ldr + lr.row;
+  *rp = fin_ab<T, CA, CB, BETA0>(alpha * (CA)(T)acc, beta, BETA0 ? T(0) : *rp);
 }
 
 }  // namespace mxlo

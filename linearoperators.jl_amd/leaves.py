@@ -493,8 +493,23 @@ def LinearOperatorFromSparse(M: torch.Tensor, symmetric: bool = False, hermitian
                 seen[0] = tok
         _lib.call("mxlo_csc_mul", handle.h, ptr(res), ptr(v), float(a), float(b), mode, scalar_flags(res.dtype, a, b))
 
+    def spmm(res, m, a, b, mode):
+        """res, m: column-major matrices — the stored matrix is read once per 8 columns (mxlo_csc_mul_block)"""
+        get_ctx(res.device)
+        if res.dtype != T or m.dtype != T:
+            raise TypeError(f"mul! on matrices: {res.dtype} / {m.dtype} operands next to a sparse {T} matrix")
+        if mode == _lib.OP_N:
+            tok = state_version(vals)
+            if tok != seen[0]:
+                _lib.call("mxlo_csc_refresh", handle.h)
+                seen[0] = tok
+        _lib.call("mxlo_csc_mul_block", handle.h, ptr(res), _ld(res), ptr(m), _ld(m), m.shape[1], float(a), float(b), mode,
+                  scalar_flags(res.dtype, a, b))
+
     prod = columnwise(lambda res, v, a, b: spmv(res, v, a, b, fwd))
     tprod = columnwise(lambda res, u, a, b: spmv(res, u, a, b, bwd))
+    prod._matrix = lambda res, m, a, b: spmm(res, m, a, b, fwd)
+    tprod._matrix = lambda res, m, a, b: spmm(res, m, a, b, bwd)
     op = LinearOperator(T, nrow, ncol, symmetric, hermitian, prod, tprod, tprod,
                         S=S if S is not None else Storage(T, vals.device))
     inf = handle.info()

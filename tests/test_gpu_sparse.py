@@ -398,3 +398,40 @@ def test_warmed_sparse_applies_only_launch_kernels(lo, dev):
         d = {k: b[k] - a[k] for k in names}
         assert not {k: x for k, x in d.items() if k != "launch" and x}, (name, d)
         assert d["launch"] == 4 * launches, (name, d)
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_sparse_block_apply_reads_the_matrix_once_and_matches_the_columns(lo, dev, dtype):
+    """`mul!(res::Matrix, op, V::Matrix, α, β)` (src/operations.jl:34-36; test/test_linop.jl:64-76 applies operators to
+    `hcat(v, -2v)`): for a sparse operator the block goes through `mxlo_csc_mul_block` — the chunks are staged in LDS once
+    per group of 8 columns — and every column must equal the single-vector apply BIT FOR BIT (same walk, same order), for
+    k = 1 … 11 (more than one group), both modes, β = 0 on NaN and β ≠ 0, column-major operands with a padded leading
+    dimension, and a matrix with rows beyond a chunk (the piecewise path has per-column carry slots)."""
+    npd = NP[dtype]
+    rng = np.random.default_rng(88)
+    m, n = 3000, 2600
+    base = rand_sparse(rng, m, n, 0.004, npd).tolil()
+    base[5, :] = rng.uniform(-1, 1, n)                     # a row of 2600 entries: two pieces
+    base[:, 9] = rng.uniform(-1, 1, (m, 1))                # a column of 3000 entries
+    A = sp.csc_matrix(base).astype(npd)
+    A.sort_indices()
+    op = lo.LinearOperatorFromMatrix(dev_csc(A, dev, dtype))
+    for o, nin, nout in ((op, n, m), (lo.transpose(op), m, n)):
+        for k in (1, 2, 8, 11):
+            Vfull = torch.from_numpy(rng.uniform(-1, 1, (k, nin + 3)).astype(npd)).to(dev)          # leading dimension nin + 3
+            R0 = torch.from_numpy(rng.uniform(-1, 1, (k, nout + 5)).astype(npd)).to(dev)
+            V = Vfull[:, :nin].t()                                                                  # nin x k, column-major
+            for a, b in ((1.0, 0.0), (2.0, -3.0)):
+                Rblk = (torch.full_like(R0, float("nan")) if b == 0 else R0.clone())[:, :nout].t()
+                Rcol = (torch.full_like(R0, float("nan")) if b == 0 else R0.clone())[:, :nout].t()
+                lo.mul(Rblk, o, V, a, b)
+                for j in range(k):
+                    lo.mul(Rcol[:, j], o, V[:, j], a, b)
+                assert torch.equal(Rblk, Rcol), (k, a, b)
+            Dm = (A.T if o is not op else A).astype(np.float64)
+            want = Dm @ V.cpu().numpy().astype(np.float64)
+            got = (o * V) if hasattr(o, "__mul__") else None
+            res = torch.empty(k, nout, dtype=dtype, device=dev).t()
+            lo.mul(res, o, V, 1.0, 0.0)
+            tol = (1e-12 if dtype == torch.float64 else 2e-5) * float((abs(Dm) @ np.abs(V.cpu().numpy().astype(np.float64))).max())
+            assert np.abs(res.cpu().numpy() - want).max() <= tol

@@ -74,3 +74,19 @@ for name, M in cases:
             out.append(f"{ms * 1e3:7.1f} us {nbytes / ms / 1e6 / 8000:5.3f}")
         print(f"{name:44s} sp_xcds {xcds}:  A*x {out[0]}   A'*x {out[1]}", flush=True)
 ctx.tune("sp_xcds", 8)
+
+# block apply: A read once per 8 columns (mxlo_csc_mul_block) vs k single-vector applies
+name, M = cases[0]
+op = lo.LinearOperatorFromMatrix(M)
+n, nnz = M.shape[0], M.values().numel()
+for k in (2, 4, 8, 16):
+    V = torch.rand(k, n, dtype=torch.float64, device=dev, generator=gen).t()
+    R = torch.empty(k, n, dtype=torch.float64, device=dev).t()
+    ms_b = timeit(lambda: lo.mul(R, op, V, 1.0, 0.0), 10)
+    def cols():
+        for j in range(k):
+            lo.mul(R[:, j], op, V[:, j], 1.0, 0.0)
+    ms_c = timeit(cols, 10)
+    nb = nnz * 12 * ((k + 7) // 8) + n * 8 * ((k + 7) // 8) + 2 * n * 8 * k
+    print(f"{name} on an n x {k:2d} block: {ms_b * 1e3:8.1f} us ({nb / ms_b / 1e6 / 8000:5.3f} of HBM peak on A once per 8 columns + the block)"
+          f"   vs {k} applies {ms_c * 1e3:8.1f} us  (x{ms_c / ms_b:4.2f})", flush=True)

@@ -1,5 +1,5 @@
 """-m gpu: randomized differential test of the host mirror + kernels. Random operator trees are grown from every
-leaf of the hot path (opDiagonal square/rectangular, opEye, opZeros, opOnes, dense matrices, opHouseholder,
+leaf of the hot path (opDiagonal square/rectangular, opEye, opZeros, opOnes, dense and sparse matrices, opHouseholder,
 opHermitian, restriction/extension, BlockDiagonalOperator, kron, forward/inverse L-BFGS, L-SR1) with the
 reference's combinators (+, -, *, scalar, transpose, adjoint, hcat, vcat, op[rows, cols]) and compared with the
 same tree evaluated on dense NumPy matrices: op*v, op'*w, the 5-arg form with (α, β) = (3, -4), and Matrix(op).
@@ -47,13 +47,20 @@ class Gen:
     def __init__(self, lo, dev, seed):
         self.lo, self.dev, self.rng = lo, dev, np.random.default_rng(seed)
 
+    def csc(self, A):
+        """device torch.sparse_csc of the nonzero pattern of the dense array A"""
+        import scipy.sparse as sp
+        S = sp.csc_matrix(A)
+        return torch.sparse_csc_tensor(torch.from_numpy(S.indptr.astype(np.int64)), torch.from_numpy(S.indices.astype(np.int64)),
+                                       torch.from_numpy(S.data.astype(np.float64)), size=A.shape).to(self.dev)
+
     def leaf(self, m, n):
         """A random leaf of shape (m, n) as (operator, dense, hN, hT, description). hN / hT: does prod! / tprod! honour
         the caller's α and β on EVERY output row? The reference's restrictions ignore both (special-operators.jl:
         167-174); rectangular opEye / opDiagonal overwrite the rows past min(nrow, ncol) whatever β is (:36-44,
         :144-151). The mirror reproduces this, so the dense model has to know it."""
         lo, dev, rng = self.lo, self.dev, self.rng
-        kinds = ["dense", "zeros", "ones", "diag_rect", "eye_rect"]
+        kinds = ["dense", "zeros", "ones", "diag_rect", "eye_rect", "sparse"]
         if m == n:
             kinds += ["diag", "householder", "hermitian", "lbfgs", "invlbfgs", "lsr1", "blockdiag"]
             if m % 2 == 0 and m >= 4:
@@ -67,6 +74,9 @@ class Gen:
         if k == "dense":
             A = rng.standard_normal((m, n))
             return lo.LinearOperatorFromMatrix(TM(A, dev)), D(A), True, True, f"{k}[{m}x{n}]"
+        if k == "sparse":                                           # LinearOperator(M::SparseMatrixCSC): mxlo_csc_*
+            A = rng.standard_normal((m, n)) * (rng.random((m, n)) < rng.uniform(0.05, 0.6))
+            return lo.LinearOperatorFromMatrix(self.csc(A)), D(A), True, True, f"{k}[{m}x{n}]"
         if k == "zeros":
             return lo.opZeros(torch.float64, m, n, S=S), D(np.zeros((m, n))), True, True, f"{k}[{m}x{n}]"
         if k == "ones":
@@ -103,8 +113,12 @@ class Gen:
                 d = rng.standard_normal(1)
                 return lo.BlockDiagonalOperator(lo.opDiagonal(T(d, dev))), D(np.diag(d)), True, True, f"{k}[{m}x{n}]"
             d1, A2 = rng.standard_normal(cut), rng.standard_normal((n - cut, n - cut))
+            sparse2 = bool(rng.integers(2))                        # second block dense or sparse (both in the one-launch table)
+            if sparse2:
+                A2 = A2 * (rng.random(A2.shape) < 0.4)
             M = np.zeros((n, n)); M[:cut, :cut] = np.diag(d1); M[cut:, cut:] = A2
-            return lo.BlockDiagonalOperator(lo.opDiagonal(T(d1, dev)), TM(A2, dev)), D(M), True, True, f"{k}[{m}x{n}]"
+            return (lo.BlockDiagonalOperator(lo.opDiagonal(T(d1, dev)), self.csc(A2) if sparse2 else TM(A2, dev)), D(M), True, True,
+                    f"{k}{'+sparse' if sparse2 else ''}[{m}x{n}]")
         if k == "kron":
             A, B = rng.standard_normal((2, 2)), rng.standard_normal((m // 2, n // 2))
             return lo.kron(TM(A, dev), TM(B, dev)), D(np.kron(A, B)), True, True, f"{k}[{m}x{n}]"

@@ -363,3 +363,40 @@ def test_storage_type_kwarg_mirror(lo, dev):
     assert lo.storage_type(A) == lo.storage_type(A.t().conj())                                               # adjoint(A)
     assert lo.storage_type(A) == lo.storage_type(A.t())                                                      # transpose(A)
     assert lo.storage_type(lo.opDiagonal(v)) == lo.storage_type(v)                                           # Diagonal(v)
+
+
+def test_cg_on_a_sparse_poisson_operator_preconditioned_by_a_fused_block_diagonal(lo, dev):
+    """The Krylov.jl call shape on the sparse leaf (round 4): CG on A = 7-point Laplacian of a 24^3 grid + 0.1 I, held as
+    a SparseMatrixCSC-style operator (`mxlo_csc_mul`), written against `mul!` only. A is symmetric: `transpose(A)` must
+    give the same iterates through the T-mode sweep (the CSC arrays themselves). The solution is checked against scipy's
+    direct solve, and the operator-level identity (A + D) x = A x + D x against a sum with a diagonal operator."""
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spla
+    g = 24
+    n = g ** 3
+    I1 = sp.identity(g, format="csc")
+    L1 = sp.diags([-1.0, 2.0, -1.0], [-1, 0, 1], shape=(g, g), format="csc")
+    A = (sp.kron(sp.kron(L1, I1), I1) + sp.kron(sp.kron(I1, L1), I1) + sp.kron(sp.kron(I1, I1), L1) + 0.1 * sp.identity(n)).tocsc()
+    A.sort_indices()
+    Ad = torch.sparse_csc_tensor(torch.from_numpy(A.indptr.astype(np.int64)), torch.from_numpy(A.indices.astype(np.int64)),
+                                 torch.from_numpy(A.data), size=A.shape).to(dev)
+    op = lo.LinearOperatorFromMatrix(Ad, symmetric=True, hermitian=True)
+    rng = np.random.default_rng(3)
+    b = rng.standard_normal(n)
+    x, its = cg(lo, op, T(b, dev), tol=1e-11, maxit=400)
+    want = spla.spsolve(A, b)
+    assert its < 400
+    assert np.linalg.norm(x.cpu().numpy() - want) <= 1e-8 * np.linalg.norm(want)
+    assert lo.nprod(op) == 2 * its
+    xt, its_t = cg(lo, lo.transpose(op), T(b, dev), tol=1e-11, maxit=400)       # symmetric flag: transpose(op) IS op (src/adjtrans.jl)
+    assert its_t == its and torch.equal(xt, x)
+    raw = lo.LinearOperatorFromMatrix(Ad)                                       # without the flag the T-mode sweep runs
+    y1, y2 = torch.empty(n, dtype=torch.float64, device=dev), torch.empty(n, dtype=torch.float64, device=dev)
+    v = T(rng.standard_normal(n), dev)
+    lo.mul(y1, raw, v)
+    lo.mul(y2, lo.transpose(raw), v)
+    assert float((y1 - y2).abs().max()) <= 1e-12 * float(y1.abs().max())
+    d = T(rng.uniform(1, 2, n), dev)
+    S = op + lo.opDiagonal(d)
+    lo.mul(y1, S, v, 2.0, 0.0)
+    assert np.abs(y1.cpu().numpy() - 2.0 * (A @ v.cpu().numpy() + d.cpu().numpy() * v.cpu().numpy())).max() <= 1e-11 * float(y1.abs().max())

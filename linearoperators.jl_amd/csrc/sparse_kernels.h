@@ -73,7 +73,7 @@ struct CscDev {
 template <typename T>
 constexpr size_t sp_lds_bytes() { return (sizeof(T) + sizeof(int32_t)) * (size_t)kSpChunk; }
 constexpr size_t kSpLdsBytesMax = sp_lds_bytes<double>();
-constexpr int kSpBatch = 8;        // gathers in flight per lane while a row is walked
+constexpr int kSpBatch = 8;        // gathers in flight per lane while a row is walked (4: -5 ... -10 %, 16: -30 % on the stencils)
 
 // lanes per row of a SP_ROWS chunk: from the row COUNT of the chunk only
 __device__ __forceinline__ int sp_lanes_per_row(int nr) {
@@ -106,6 +106,7 @@ __device__ __forceinline__ double sp_walk(const T *__restrict__ x, const T *sval
 
 // One chunk, start to end: called by all kBlock threads of a workgroup; `lds` is sp_lds_bytes<T>() of LDS.
 constexpr int kSpPre = 3;          // rows per lane group whose pointers (and old res) are requested with the chunk's own loads
+                                   // (5: no better on the 7-point pattern, -10 % on the 27-point one)
 // ncols / ldx / ldr: the apply on an n x ncols block (`mul!` on matrices, src/operations.jl:34-36): the chunk is streamed
 // into LDS ONCE and its rows are walked once per column of x (column j of x at x + j*ldx, of res at res + j*ldr) — A is
 // read once for the whole block. Piece sums of column j go to carry[piece * ncols + j].

@@ -582,6 +582,11 @@ def LinearOperatorFromMatrix(M: torch.Tensor, symmetric: bool = False, hermitian
     """LinearOperator(M) — src/constructors.jl:15-29 (prod!/tprod!/ctprod! = gemv N/T/C). M is ALIASED, never copied,
     when it is column-major or row-major (a row-major M is the column-major storage of Mᵀ: N and T swap). A sparse M
     (torch.sparse_csc / _csr / _coo) goes to `LinearOperatorFromSparse`."""
+    if not isinstance(M, torch.Tensor) and hasattr(M, "tocsc"):                              # a scipy.sparse matrix on the host
+        Mc = M.tocsc()
+        Mc.sort_indices()
+        M = sparse_csc(Mc.indptr, Mc.indices, Mc.data, Mc.shape[0], Mc.shape[1], index_base=0,
+                       device=S.device if S is not None else None)
     if M.layout in _SPARSE_LAYOUTS:
         return LinearOperatorFromSparse(M, symmetric, hermitian, S)
     nrow, ncol = M.shape
@@ -656,7 +661,7 @@ def BlockDiagonalOperator(*ops, S: Optional[Storage] = None):
     the reference's own structure (a host loop of inner `mul!` on views, :258-267) — still the HIP
     leaves, just one launch per block."""
     from .operators import _as_op, _promote_eltype, promote_storage
-    ops = [_as_op(o) if isinstance(o, torch.Tensor) else o for o in ops]
+    ops = [_as_op(o) if isinstance(o, torch.Tensor) or hasattr(o, "tocsc") else o for o in ops]
     nrow = sum(o.size(1) for o in ops)
     ncol = sum(o.size(2) for o in ops)
     T = _promote_eltype(*ops)

@@ -958,9 +958,9 @@ def _hcat2(A, B):
 def _as_op(x):
     if isinstance(x, AbstractLinearOperator):
         return x
-    if isinstance(x, torch.Tensor) and x.dim() == 2:
+    if (isinstance(x, torch.Tensor) and x.dim() == 2) or hasattr(x, "tocsc"):
         from .leaves import LinearOperatorFromMatrix
-        return LinearOperatorFromMatrix(x)             # dense or sparse (torch.sparse_csc / _csr / _coo)
+        return LinearOperatorFromMatrix(x)             # dense or sparse (torch.sparse_csc / _csr / _coo, scipy.sparse)
     raise TypeError(f"cannot concatenate {type(x)}")
 
 

@@ -111,7 +111,7 @@ def test_csr_and_coo_layouts_and_unsorted_duplicate_entries(lo, dev):
     A = rand_sparse(rng, 60, 45, 0.2, np.float64)
     v, u = rng.uniform(-1, 1, 45), rng.uniform(-1, 1, 60)
     csc = dev_csc(A, dev, torch.float64)
-    for M in (csc.to_sparse_csr(), csc.to_sparse_coo()):
+    for M in (csc.to_sparse_csr(), csc.to_sparse_coo(), A, sp.coo_matrix(A)):          # … and scipy.sparse matrices from the host
         op = lo.LinearOperatorFromMatrix(M)
         got = (op * torch.from_numpy(v).to(dev)).cpu().numpy()
         assert np.abs(got - A @ v).max() <= 1e-13 * scale_of(A, v)

@@ -484,6 +484,14 @@ int32_t mxlo_csc_create(mxlo_ctx *ctx, int32_t dtype, int64_t m, int64_t n, cons
 int32_t mxlo_csc_refresh(mxlo_csc *h);
 int32_t mxlo_csc_mul(mxlo_csc *h, void *res, const void *v, double alpha, double beta, int32_t op_mode,
                      int32_t flags);
+/* Complex element types (dtype MXLO_C64 / MXLO_C32 at create; test/test_linop.jl:44 and test/test_cat.jl:5-25 build operators
+ * from `simple_sparse_matrix(ComplexF64, …)`): the same chunked sweep on 16- / 8-byte elements, component-wise complex
+ * products accumulated in two doubles. op_mode MXLO_OP_N = A*v, _T = transpose(A)*v (values as stored), _C = A'*v (values
+ * conjugated in the sweep). Scalars as (re, im) pairs with MXLO_ALPHA_REAL / MXLO_BETA_REAL and the width flags, like every
+ * `_c` entry point. mxlo_csc_mul / mxlo_csc_mul_block refuse a complex handle and mxlo_csc_mul_c a real one (MXLO_EINVAL);
+ * a complex handle cannot be a block of the (real) one-launch block-diagonal operator. */
+int32_t mxlo_csc_mul_c(mxlo_csc *h, void *res, const void *v, double alpha_re, double alpha_im, double beta_re, double beta_im,
+                       int32_t op_mode, int32_t flags);
 /* mul!(res::Matrix, LinearOperator(A), V::Matrix, α, β) (src/operations.jl:34-36: the closure is handed the matrices —
  * a sparse-times-dense product in the reference): res (nres x k, column-major, leading dimension ldr) = alpha * op(A) * V
  * (nin x k, ldv) + beta * res. A's chunks are streamed into LDS once per group of up to 8 columns and walked once per

@@ -439,7 +439,7 @@ mutable struct MXSparseMatrixCSC{T} <: AbstractMatrix{T}
   rowval::MXVector{Int64}
   nzval::MXVector{T}
 end
-function MXSparseMatrixCSC(m::Integer, n::Integer, colptr::Vector{Int64}, rowval::Vector{Int64}, nzval::Vector{T}) where {T <: RealT}
+function MXSparseMatrixCSC(m::Integer, n::Integer, colptr::Vector{Int64}, rowval::Vector{Int64}, nzval::Vector{T}) where {T <: Union{RealT, CplxT}}
   cp, rv, nz = MXVector(colptr), MXVector(rowval), MXVector(nzval)
   out = Ref{Ptr{Cvoid}}()
   check(ccall((:mxlo_csc_create, lib), Int32, (P, Int32, Int64, Int64, P, P, P, Int32, Ptr{P}),
@@ -462,6 +462,15 @@ struct SparseApply{T}
 end
 (f::SparseApply{T})(res::MXVector{T}, v::MXVector{T}, α, β) where {T <: RealT} = check(ccall((:mxlo_csc_mul, lib), Int32,
     (P, P, P, Float64, Float64, Int32, Int32), f.A.h, res.ptr, v.ptr, α, β, f.mode, flags(T, α, β)))
+# complex element types (test/test_linop.jl:44: simple_sparse_matrix(ComplexF64, …)): modes N / T on the values as stored,
+# mode C conjugates them in the sweep; scalars as (re, im) pairs like every `_c` entry point
+(f::SparseApply{T})(res::MXVector{T}, v::MXVector{T}, α, β) where {T <: CplxT} = check(ccall((:mxlo_csc_mul_c, lib), Int32,
+    (P, P, P, Float64, Float64, Float64, Float64, Int32, Int32),
+    f.A.h, res.ptr, v.ptr, real(α), imag(α), real(β), imag(β), f.mode, flags(T, α, β)))
+function LinearOperator(A::MXSparseMatrixCSC{T}; symmetric = false, hermitian = false, S = MXVector{T}) where {T <: CplxT}
+  LinearOperator{T, S}(A.m, A.n, symmetric, hermitian, SparseApply{T}(A, Int32(0)), SparseApply{T}(A, Int32(1)),
+                       SparseApply{T}(A, Int32(2)))
+end
 # mul! on matrices (src/operations.jl:34-36): the stored matrix is read once per 8 columns of the block
 (f::SparseApply{T})(res::MXMatrix{T}, V::MXMatrix{T}, α, β) where {T <: RealT} = check(ccall((:mxlo_csc_mul_block, lib), Int32,
     (P, P, Int64, P, Int64, Int64, Float64, Float64, Int32, Int32),

@@ -145,6 +145,7 @@ _PROTOS = {
     "mxlo_csc_create": [_vp, _i32, _i64, _i64, _vp, _vp, _vp, _i32, C.POINTER(_vp)],
     "mxlo_csc_refresh": [_vp],
     "mxlo_csc_mul": [_vp, _vp, _vp, _dbl, _dbl, _i32, _i32],
+    "mxlo_csc_mul_c": [_vp, _vp, _vp, _dbl, _dbl, _dbl, _dbl, _i32, _i32],
     "mxlo_csc_mul_block": [_vp, _vp, _i64, _vp, _i64, _i64, _dbl, _dbl, _i32, _i32],
     "mxlo_csc_info": [_vp, C.POINTER(_i64)],
     "mxlo_csc_destroy": [_vp],

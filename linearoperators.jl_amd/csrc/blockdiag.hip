@@ -189,12 +189,13 @@ blockdiag_kernel(T *__restrict__ res, const T *__restrict__ x, const DevBlock *_
   if constexpr (SP) if (b.kind == MXLO_BLK_CSC) {
     extern __shared__ double sp_lds[];                        // sp_lds_bytes<T>(): the chunk's values and indices
     const CscDev *S = (const CscDev *)b.data;                 // wave-uniform descriptor fetches
+    const SpFinReal<T, CA, CB, BETA0> fin{alpha, beta};
     if constexpr (!TRANS)
-      spmv_chunk<T, CA, CB, BETA0>(rp, xp, S->rowptr, S->colidx, (const T *)S->csr_val, S->chunks_n[tl.start], S->carry, alpha,
-                                   beta, sp_lds);
+      spmv_chunk<T, SpFinReal<T, CA, CB, BETA0>, BETA0>(rp, xp, S->rowptr, S->colidx, (const T *)S->csr_val, S->chunks_n[tl.start],
+                                                        S->carry, fin, sp_lds);
     else
-      spmv_chunk<T, CA, CB, BETA0>(rp, xp, S->colptr, S->rowidx, (const T *)S->nzval, S->chunks_t[tl.start], S->carry, alpha,
-                                   beta, sp_lds);
+      spmv_chunk<T, SpFinReal<T, CA, CB, BETA0>, BETA0>(rp, xp, S->colptr, S->rowidx, (const T *)S->nzval, S->chunks_t[tl.start],
+                                                        S->carry, fin, sp_lds);
     return;
   }
   if (b.kind != MXLO_BLK_DENSE) {

@@ -40,11 +40,11 @@ csc_gather_values_kernel(T *__restrict__ out, const T *__restrict__ nzval, const
   if (i < nnz) out[i] = nzval[perm[i]];
 }
 
-template <typename T, typename CA, typename CB, bool BETA0, bool BLOCK>
+template <typename T, typename FIN, bool BETA0, bool BLOCK, bool CONJ>
 __global__ void __launch_bounds__(kBlock)
 csc_mul_kernel(T *__restrict__ res, const T *__restrict__ x, const int64_t *__restrict__ ptr, const int32_t *__restrict__ idx,
                const T *__restrict__ val, const SpChunk *__restrict__ chunks, int nchunks, int nxcd, double *__restrict__ carry,
-               CA alpha, CB beta, int ncols, int64_t ldx, int64_t ldr) {
+               const FIN fin, int ncols, int64_t ldx, int64_t ldr) {
   __shared__ __attribute__((aligned(16))) char lds[sp_lds_bytes<T>()];
   // XCD-aware order: workgroup w runs on XCD w % nxcd, and each XCD has its own L2. XCD k takes the k-th CONTIGUOUS
   // part of the chunk table, so the x lines its workgroups share (neighbouring rows gather neighbouring columns) are
@@ -52,7 +52,7 @@ csc_mul_kernel(T *__restrict__ res, const T *__restrict__ x, const int64_t *__re
   const int w = (int)blockIdx.x, per = (nchunks + nxcd - 1) / nxcd;
   const int ci = (w % nxcd) * per + w / nxcd;
   if (ci >= nchunks || w / nxcd >= per) return;
-  spmv_chunk<T, CA, CB, BETA0, BLOCK>(res, x, ptr, idx, val, chunks[ci], carry, alpha, beta, lds, ncols, ldx, ldr);
+  spmv_chunk<T, FIN, BETA0, BLOCK, CONJ>(res, x, ptr, idx, val, chunks[ci], carry, fin, lds, ncols, ldx, ldr);
 }
 
 // The chunk table of one compressed-row operand (see sparse_kernels.h): whole rows packed into chunks of <= kSpChunk
@@ -97,35 +97,60 @@ void build_chunks(const std::vector<int64_t> &ptr, int64_t nrows, std::vector<Sp
 
 constexpr int kSpMaxCols = 8;      // columns of a block apply per launch (carry slots are sized for it)
 
+struct SpLaunch {                  // what one apply needs from the handle, by mode
+  const int64_t *ptr;
+  const int32_t *idx;
+  const void *val;
+  const SpChunk *chunks;
+  const SpLongRow *longs;
+  int nchunks, nlong;
+};
+SpLaunch sp_launch_of(const mxlo_csc *h, bool trans) {
+  const CscDev &d = h->host;
+  return trans ? SpLaunch{d.colptr, d.rowidx, d.nzval, d.chunks_t, h->long_t, d.nchunks_t, d.nlong_t}
+               : SpLaunch{d.rowptr, d.colidx, d.csr_val, d.chunks_n, h->long_n, d.nchunks_n, d.nlong_n};
+}
+
+template <typename T, typename FIN, bool B0, bool CONJ>
+int32_t csc_launch(mxlo_csc *h, const SpLaunch &L, T *res, const T *v, const FIN &fin, int ncols, int64_t ldx, int64_t ldr) {
+  mxlo_ctx *ctx = h->ctx;
+  const int nxcd = ctx->tune.sp_xcds > 0 ? ctx->tune.sp_xcds : 1;
+  const int per = (L.nchunks + nxcd - 1) / nxcd;
+  if (ncols > 1)
+    hipLaunchKernelGGL((csc_mul_kernel<T, FIN, B0, true, CONJ>), dim3((unsigned)(per * nxcd)), dim3(kBlock), 0, ctx->stream, res, v,
+                       L.ptr, L.idx, (const T *)L.val, L.chunks, L.nchunks, nxcd, h->host.carry, fin, ncols, ldx, ldr);
+  else
+    hipLaunchKernelGGL((csc_mul_kernel<T, FIN, B0, false, CONJ>), dim3((unsigned)(per * nxcd)), dim3(kBlock), 0, ctx->stream, res, v,
+                       L.ptr, L.idx, (const T *)L.val, L.chunks, L.nchunks, nxcd, h->host.carry, fin, 1, ldx, ldr);
+  MXLO_LAUNCH_CHECK();
+  if (L.nlong > 0) {
+    hipLaunchKernelGGL((spmv_fixup_kernel<T, FIN, B0>), dim3((unsigned)((L.nlong * ncols + kBlock - 1) / kBlock)), dim3(kBlock), 0,
+                       ctx->stream, res, h->host.carry, L.longs, L.nlong, fin, ncols, ldr);
+    MXLO_LAUNCH_CHECK();
+  }
+  return MXLO_OK;
+}
+
 template <typename T>
 int32_t csc_mul_t(mxlo_csc *h, T *res, const T *v, double alpha, double beta, int32_t op_mode, int32_t flags, int ncols = 1,
                   int64_t ldx = 0, int64_t ldr = 0) {
-  mxlo_ctx *ctx = h->ctx;
-  const bool trans = op_mode != MXLO_OP_N;
-  const CscDev &d = h->host;
-  const int nchunks = trans ? d.nchunks_t : d.nchunks_n, nlong = trans ? d.nlong_t : d.nlong_n;
-  if (nchunks == 0) return MXLO_OK;
-  const int64_t *ptr = trans ? d.colptr : d.rowptr;
-  const int32_t *idx = trans ? d.rowidx : d.colidx;
-  const T *val = (const T *)(trans ? d.nzval : d.csr_val);
-  const SpChunk *chunks = trans ? d.chunks_t : d.chunks_n;
-  const SpLongRow *longs = trans ? h->long_t : h->long_n;
+  const SpLaunch L = sp_launch_of(h, op_mode != MXLO_OP_N);
+  if (L.nchunks == 0) return MXLO_OK;
   return dispatch_ab<T>(beta, flags, [&]<typename CA, typename CB, bool B0>() -> int32_t {
-    const int nxcd = ctx->tune.sp_xcds > 0 ? ctx->tune.sp_xcds : 1;
-    const int per = (nchunks + nxcd - 1) / nxcd;
-    if (ncols > 1)
-      hipLaunchKernelGGL((csc_mul_kernel<T, CA, CB, B0, true>), dim3((unsigned)(per * nxcd)), dim3(kBlock), 0, ctx->stream, res, v,
-                         ptr, idx, val, chunks, nchunks, nxcd, d.carry, (CA)alpha, (CB)beta, ncols, ldx, ldr);
-    else
-      hipLaunchKernelGGL((csc_mul_kernel<T, CA, CB, B0, false>), dim3((unsigned)(per * nxcd)), dim3(kBlock), 0, ctx->stream, res, v,
-                         ptr, idx, val, chunks, nchunks, nxcd, d.carry, (CA)alpha, (CB)beta, 1, ldx, ldr);
-    MXLO_LAUNCH_CHECK();
-    if (nlong > 0) {
-      hipLaunchKernelGGL((spmv_fixup_kernel<T, CA, CB, B0>), dim3((unsigned)((nlong * ncols + kBlock - 1) / kBlock)), dim3(kBlock),
-                         0, ctx->stream, res, d.carry, longs, nlong, (CA)alpha, (CB)beta, ncols, ldr);
-      MXLO_LAUNCH_CHECK();
-    }
-    return MXLO_OK;
+    return csc_launch<T, SpFinReal<T, CA, CB, B0>, B0, false>(h, L, res, v, SpFinReal<T, CA, CB, B0>{(CA)alpha, (CB)beta}, ncols, ldx,
+                                                              ldr);
+  });
+}
+
+// complex element types: op_mode N / T walk the values as stored, C conjugates them (A' * x)
+template <typename R>
+int32_t csc_mul_c_t(mxlo_csc *h, cx<R> *res, const cx<R> *v, const ScalArgs &s, int32_t op_mode) {
+  const SpLaunch L = sp_launch_of(h, op_mode != MXLO_OP_N);
+  if (L.nchunks == 0) return MXLO_OK;
+  return dispatch_c<R>(s, [&]<typename RA, typename RB, bool B0>() -> int32_t {
+    const SpFinCplx<R, RA, RB, B0> fin{Sc<RA>{(RA)s.are, (RA)s.aim, s.a_real}, (RB)s.bre, (RB)s.bim, s.b_real};
+    if (op_mode == MXLO_OP_C) return csc_launch<cx<R>, SpFinCplx<R, RA, RB, B0>, B0, true>(h, L, res, v, fin, 1, 0, 0);
+    return csc_launch<cx<R>, SpFinCplx<R, RA, RB, B0>, B0, false>(h, L, res, v, fin, 1, 0, 0);
   });
 }
 
@@ -135,13 +160,13 @@ MXLO_API int32_t mxlo_csc_create(mxlo_ctx *ctx, int32_t dtype, int64_t m, int64_
                                  const int64_t *rowval, const void *nzval, int32_t index_base, mxlo_csc **out) {
   MXLO_REQUIRE(ctx && out, MXLO_EINVAL, "mxlo_csc_create: NULL argument");
   MXLO_DEVICE_GUARD(ctx);
-  MXLO_REQUIRE(dtype == MXLO_F64 || dtype == MXLO_F32, MXLO_EINVAL, "mxlo_csc_create: bad dtype %d (real element types)", dtype);
+  MXLO_REQUIRE(dtype >= MXLO_F64 && dtype <= MXLO_C32, MXLO_EINVAL, "mxlo_csc_create: bad dtype %d", dtype);
   MXLO_REQUIRE(m >= 0 && n >= 0 && m < (1LL << 31) && n < (1LL << 31), MXLO_ESHAPE,
                "mxlo_csc_create: %lld x %lld (each dimension must be below 2^31: indices are 32-bit inside the library)",
                (long long)m, (long long)n);
   MXLO_REQUIRE(index_base == 0 || index_base == 1, MXLO_EINVAL, "mxlo_csc_create: index_base must be 0 or 1 (Julia)");
   MXLO_REQUIRE(colptr, MXLO_EINVAL, "mxlo_csc_create: colptr is NULL");
-  const size_t es = dtype == MXLO_F64 ? 8 : 4;
+  const size_t es = dtype == MXLO_F64 || dtype == MXLO_C32 ? 8 : (dtype == MXLO_C64 ? 16 : 4);
   // ---- structure to the host, validated there (the reference's SparseMatrixCSC constructor checks the same invariants)
   std::vector<int64_t> cp((size_t)n + 1);
   MXLO_HIP(hipStreamSynchronize(ctx->stream));
@@ -209,7 +234,7 @@ MXLO_API int32_t mxlo_csc_create(mxlo_ctx *ctx, int32_t dtype, int64_t m, int64_
   up((void **)&h->long_n, lgn.data(), sizeof(SpLongRow) * lgn.size());
   up((void **)&h->long_t, lgt.data(), sizeof(SpLongRow) * lgt.size());
   if (e == hipSuccess) e = hipMalloc((void **)&d.csr_val, nnz ? es * (size_t)nnz : 16);
-  if (e == hipSuccess) e = hipMalloc((void **)&d.carry, sizeof(double) * kSpMaxCols * (size_t)std::max(1, std::max(ncar_n, ncar_t)));
+  if (e == hipSuccess) e = hipMalloc((void **)&d.carry, sizeof(double) * 2 * kSpMaxCols * (size_t)std::max(1, std::max(ncar_n, ncar_t)));
   d.nzval = nzval;
   d.m = m;
   d.n = n;
@@ -240,7 +265,10 @@ MXLO_API int32_t mxlo_csc_refresh(mxlo_csc *h) {
   MXLO_DEVICE_GUARD(h->ctx);
   if (h->nnz == 0) return MXLO_OK;
   const unsigned grid = (unsigned)((h->nnz + kBlock - 1) / kBlock);
-  if (h->dtype == MXLO_F64)
+  if (h->dtype == MXLO_C64)            // 16-byte elements
+    hipLaunchKernelGGL(csc_gather_values_kernel<cx<double>>, dim3(grid), dim3(kBlock), 0, h->ctx->stream,
+                       (cx<double> *)h->host.csr_val, (const cx<double> *)h->nzval, h->perm, h->nnz);
+  else if (h->dtype == MXLO_F64 || h->dtype == MXLO_C32)     // 8-byte elements
     hipLaunchKernelGGL(csc_gather_values_kernel<double>, dim3(grid), dim3(kBlock), 0, h->ctx->stream, (double *)h->host.csr_val,
                        (const double *)h->nzval, h->perm, h->nnz);
   else
@@ -258,9 +286,29 @@ MXLO_API int32_t mxlo_csc_mul(mxlo_csc *h, void *res, const void *v, double alph
   const int64_t nres = op_mode == MXLO_OP_N ? h->m : h->n, nin = op_mode == MXLO_OP_N ? h->n : h->m;
   if (nres == 0) return MXLO_OK;
   MXLO_REQUIRE(res && (v || nin == 0), MXLO_EINVAL, "mxlo_csc_mul: NULL operand");
+  MXLO_REQUIRE(h->dtype == MXLO_F64 || h->dtype == MXLO_F32, MXLO_EINVAL,
+               "mxlo_csc_mul: the handle holds a complex matrix: use mxlo_csc_mul_c");
   eff_scalars(h->dtype == MXLO_F64 ? 8 : 4, flags, alpha, beta);
   if (h->dtype == MXLO_F64) return csc_mul_t<double>(h, (double *)res, (const double *)v, alpha, beta, op_mode, flags);
   return csc_mul_t<float>(h, (float *)res, (const float *)v, alpha, beta, op_mode, flags);
+}
+
+MXLO_API int32_t mxlo_csc_mul_c(mxlo_csc *h, void *res, const void *v, double alpha_re, double alpha_im, double beta_re,
+                                double beta_im, int32_t op_mode, int32_t flags) {
+  MXLO_REQUIRE(h, MXLO_EINVAL, "mxlo_csc_mul_c: handle is NULL");
+  MXLO_DEVICE_GUARD(h->ctx);
+  MXLO_REQUIRE(op_mode >= MXLO_OP_N && op_mode <= MXLO_OP_C, MXLO_EINVAL, "bad op_mode");
+  MXLO_REQUIRE(h->dtype == MXLO_C64 || h->dtype == MXLO_C32, MXLO_EINVAL,
+               "mxlo_csc_mul_c: the handle holds a real matrix: use mxlo_csc_mul (a real operator on complex vectors is applied to "
+               "the two planes, mxlo_split_c / mxlo_join_c)");
+  const int64_t nres = op_mode == MXLO_OP_N ? h->m : h->n, nin = op_mode == MXLO_OP_N ? h->n : h->m;
+  if (nres == 0) return MXLO_OK;
+  MXLO_REQUIRE(res && (v || nin == 0), MXLO_EINVAL, "mxlo_csc_mul_c: NULL operand");
+  if (h->dtype == MXLO_C64)
+    return csc_mul_c_t<double>(h, (cx<double> *)res, (const cx<double> *)v, scal_args(8, alpha_re, alpha_im, beta_re, beta_im, flags),
+                               op_mode);
+  return csc_mul_c_t<float>(h, (cx<float> *)res, (const cx<float> *)v, scal_args(4, alpha_re, alpha_im, beta_re, beta_im, flags),
+                            op_mode);
 }
 
 MXLO_API int32_t mxlo_csc_mul_block(mxlo_csc *h, void *res, int64_t ldr, const void *V, int64_t ldv, int64_t k, double alpha,
@@ -273,6 +321,7 @@ MXLO_API int32_t mxlo_csc_mul_block(mxlo_csc *h, void *res, int64_t ldr, const v
   if (nres == 0 || k == 0) return MXLO_OK;
   MXLO_REQUIRE(res && (V || nin == 0), MXLO_EINVAL, "mxlo_csc_mul_block: NULL operand");
   MXLO_REQUIRE(ldr >= nres && ldv >= (nin > 0 ? nin : 1), MXLO_ESHAPE, "mxlo_csc_mul_block: leading dimension below the column length");
+  MXLO_REQUIRE(h->dtype == MXLO_F64 || h->dtype == MXLO_F32, MXLO_EINVAL, "mxlo_csc_mul_block: real element types (a complex block is applied column by column)");
   eff_scalars(h->dtype == MXLO_F64 ? 8 : 4, flags, alpha, beta);
   for (int64_t j0 = 0; j0 < k; j0 += kSpMaxCols) {                      // the stored matrix is read once per 8 columns
     const int nc = (int)std::min<int64_t>(kSpMaxCols, k - j0);

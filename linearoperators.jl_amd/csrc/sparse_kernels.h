@@ -34,6 +34,7 @@
 #pragma once
 #include "common.h"
 #include "stream_kernels.h"
+#include "complex_scalars.h"
 
 namespace mxlo {
 
@@ -84,10 +85,67 @@ __device__ __forceinline__ int sp_lanes_per_row(int nr) {
   return g > 64 ? 64 : g;
 }
 
-// sum of (value * x[index]) over the LDS entries e0, e0 + step, ... < e1, in that order, kSpBatch gathers at a time
+// ---- element arithmetic: real (accumulator = one double) and complex (two); CONJ conjugates the stored value (A' * x)
 template <typename T>
-__device__ __forceinline__ double sp_walk(const T *__restrict__ x, const T *sval, const int32_t *sidx, int e0, int e1, int step) {
-  double acc = 0.0;
+struct SpNum {                     // Float64 / Float32
+  static constexpr int NACC = 1;
+  struct Acc {
+    double v;
+  };
+  __device__ static __forceinline__ Acc zero() { return Acc{0.0}; }
+  template <bool CONJ>
+  __device__ static __forceinline__ void madd(Acc &a, T val, T x) { a.v += (double)val * (double)x; }
+  __device__ static __forceinline__ void add(Acc &a, const Acc &b) { a.v += b.v; }
+  __device__ static __forceinline__ Acc shfl_xor(const Acc &a, int off) { return Acc{__shfl_xor(a.v, off, 64)}; }
+  __device__ static __forceinline__ void store(double *p, const Acc &a) { p[0] = a.v; }
+  __device__ static __forceinline__ Acc load(const double *p) { return Acc{p[0]}; }
+};
+template <typename R>
+struct SpNum<cx<R>> {              // ComplexF64 / ComplexF32: Julia's component-wise product, nothing fused
+  static constexpr int NACC = 2;
+  struct Acc {
+    double re, im;
+  };
+  __device__ static __forceinline__ Acc zero() { return Acc{0.0, 0.0}; }
+  template <bool CONJ>
+  __device__ static __forceinline__ void madd(Acc &a, cx<R> val, cx<R> x) {
+    const double vr = (double)val.re, vi = CONJ ? -(double)val.im : (double)val.im, xr = (double)x.re, xi = (double)x.im;
+    a.re += (vr * xr) - (vi * xi);
+    a.im += (vr * xi) + (vi * xr);
+  }
+  __device__ static __forceinline__ void add(Acc &a, const Acc &b) { a.re += b.re; a.im += b.im; }
+  __device__ static __forceinline__ Acc shfl_xor(const Acc &a, int off) {
+    return Acc{__shfl_xor(a.re, off, 64), __shfl_xor(a.im, off, 64)};
+  }
+  __device__ static __forceinline__ void store(double *p, const Acc &a) { p[0] = a.re; p[1] = a.im; }
+  __device__ static __forceinline__ Acc load(const double *p) { return Acc{p[0], p[1]}; }
+};
+// ---- the closing step res = alpha * sum (+ beta * res): the scalars in the types the caller passed them in
+template <typename T, typename CA, typename CB, bool BETA0>
+struct SpFinReal {
+  CA alpha;
+  CB beta;
+  __device__ __forceinline__ T operator()(const typename SpNum<T>::Acc &a, T old) const {
+    return fin_ab<T, CA, CB, BETA0>(alpha * (CA)(T)a.v, beta, old);
+  }
+};
+template <typename R, typename RA, typename RB, bool BETA0>
+struct SpFinCplx {
+  Sc<RA> alpha;
+  RB bre, bim;
+  bool b_real;
+  __device__ __forceinline__ cx<R> operator()(const typename SpNum<cx<R>>::Acc &a, cx<R> old) const {
+    RA tr, ti;
+    alpha.template mul<R>(cx<R>((R)a.re, (R)a.im), tr, ti);
+    return cfin<R, RA, RB, BETA0>(tr, ti, bre, bim, b_real, old);
+  }
+};
+
+// sum of (value * x[index]) over the LDS entries e0, e0 + step, ... < e1, in that order, kSpBatch gathers at a time
+template <typename T, bool CONJ>
+__device__ __forceinline__ typename SpNum<T>::Acc sp_walk(const T *__restrict__ x, const T *sval, const int32_t *sidx, int e0,
+                                                           int e1, int step) {
+  typename SpNum<T>::Acc acc = SpNum<T>::zero();
   for (int e = e0; e < e1; e += step * kSpBatch) {
     T v[kSpBatch], xv[kSpBatch];
 #pragma unroll
@@ -99,7 +157,7 @@ __device__ __forceinline__ double sp_walk(const T *__restrict__ x, const T *sval
     }
 #pragma unroll
     for (int u = 0; u < kSpBatch; ++u)
-      if (e + u * step < e1) acc += (double)v[u] * (double)xv[u];
+      if (e + u * step < e1) SpNum<T>::template madd<CONJ>(acc, v[u], xv[u]);
   }
   return acc;
 }
@@ -109,13 +167,15 @@ constexpr int kSpPre = 3;          // rows per lane group whose pointers (and ol
                                    // (5: no better on the 7-point pattern, -10 % on the 27-point one)
 // ncols / ldx / ldr: the apply on an n x ncols block (`mul!` on matrices, src/operations.jl:34-36): the chunk is streamed
 // into LDS ONCE and its rows are walked once per column of x (column j of x at x + j*ldx, of res at res + j*ldr) — A is
-// read once for the whole block. Piece sums of column j go to carry[piece * ncols + j].
+// read once for the whole block. Piece sums of column j go to carry[(piece * ncols + j) * NACC ...].
 // BLOCK = false fixes ncols = 1 at compile time (the vector apply keeps its registers: 77-90 instead of 94-106).
-template <typename T, typename CA, typename CB, bool BETA0, bool BLOCK = false>
+// FIN: SpFinReal / SpFinCplx (the closing step); CONJ: the stored values are conjugated (complex A' * x).
+template <typename T, typename FIN, bool BETA0, bool BLOCK = false, bool CONJ = false>
 __device__ __forceinline__ void spmv_chunk(T *__restrict__ res, const T *__restrict__ x, const int64_t *__restrict__ ptr,
                                            const int32_t *__restrict__ idx, const T *__restrict__ val, const SpChunk c,
-                                           double *__restrict__ carry, CA alpha, CB beta, void *lds, int ncols_ = 1,
+                                           double *__restrict__ carry, const FIN fin, void *lds, int ncols_ = 1,
                                            int64_t ldx = 0, int64_t ldr = 0) {
+  using N = SpNum<T>;
   const int ncols = BLOCK ? ncols_ : 1;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   T *sval = (T *)lds;
@@ -189,28 +249,32 @@ __device__ __forceinline__ void spmv_chunk(T *__restrict__ res, const T *__restr
         if constexpr (!BETA0) ro = res[row];
       }
       for (int j = 0; j < ncols; ++j) {
-        double acc = sp_walk<T>(x + j * ldx, sval, sidx, (int)(q0 - c.k0) + l, (int)(q1 - c.k0), g);
-        for (int off = g >> 1; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+        typename N::Acc acc = sp_walk<T, CONJ>(x + j * ldx, sval, sidx, (int)(q0 - c.k0) + l, (int)(q1 - c.k0), g);
+        for (int off = g >> 1; off > 0; off >>= 1) N::add(acc, N::shfl_xor(acc, off));
         if (l == 0) {
           T *rp = res + j * ldr + row;
           if constexpr (!BETA0) if (j > 0) ro = *rp;
-          *rp = fin_ab<T, CA, CB, BETA0>(alpha * (CA)(T)acc, beta, ro);
+          *rp = fin(acc, ro);
         }
       }
     }
   } else {                                                // one long row (or a piece of one): the whole workgroup
-    __shared__ double red[kBlock / 64];
+    __shared__ double red[(kBlock / 64) * 2];
     for (int j = 0; j < ncols; ++j) {
-      double acc = sp_walk<T>(x + j * ldx, sval, sidx, tid, c.nz, kBlock);
+      typename N::Acc acc = sp_walk<T, CONJ>(x + j * ldx, sval, sidx, tid, c.nz, kBlock);
 #pragma unroll
-      for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
-      if (lane == 0) red[wave] = acc;
+      for (int off = 32; off > 0; off >>= 1) N::add(acc, N::shfl_xor(acc, off));
+      if (lane == 0) N::store(red + wave * N::NACC, acc);
       __syncthreads();
       if (tid == 0) {
-        const double tot = (red[0] + red[1]) + (red[2] + red[3]);
+        typename N::Acc a01 = N::load(red), a1 = N::load(red + N::NACC), a23 = N::load(red + 2 * N::NACC),
+                        a3 = N::load(red + 3 * N::NACC);
+        N::add(a01, a1);
+        N::add(a23, a3);
+        N::add(a01, a23);                                  // (w0 + w1) + (w2 + w3)
         T *rp = res + j * ldr + c.row0;
-        if (c.kind == SP_LONG1) *rp = fin_ab<T, CA, CB, BETA0>(alpha * (CA)(T)tot, beta, BETA0 ? T(0) : *rp);
-        else carry[(int64_t)c.carry * ncols + j] = tot;
+        if (c.kind == SP_LONG1) *rp = fin(a01, BETA0 ? T(0) : *rp);
+        else N::store(carry + ((int64_t)c.carry * ncols + j) * N::NACC, a01);
       }
       __syncthreads();                                    // red is free for the next column
     }
@@ -218,18 +282,19 @@ __device__ __forceinline__ void spmv_chunk(T *__restrict__ res, const T *__restr
 }
 
 // rows longer than a chunk: the pieces' sums added in order
-template <typename T, typename CA, typename CB, bool BETA0>
+template <typename T, typename FIN, bool BETA0>
 __global__ void __launch_bounds__(kBlock)
 spmv_fixup_kernel(T *__restrict__ res, const double *__restrict__ carry, const SpLongRow *__restrict__ rows, int nrows,
-                  CA alpha, CB beta, int ncols, int64_t ldr) {
+                  const FIN fin, int ncols, int64_t ldr) {
+  using N = SpNum<T>;
   const int i = blockIdx.x * kBlock + threadIdx.x;
   if (i >= nrows * ncols) return;
   const SpLongRow lr = rows[i / ncols];
   const int j = i % ncols;
-  double acc = 0.0;
-  for (int p = 0; p < lr.npieces; ++p) acc += carry[(int64_t)(lr.carry0 + p) * ncols + j];
+  typename N::Acc acc = N::zero();
+  for (int p = 0; p < lr.npieces; ++p) N::add(acc, N::load(carry + ((int64_t)(lr.carry0 + p) * ncols + j) * N::NACC));
   T *rp = res + j * ldr + lr.row;
-  *rp = fin_ab<T, CA, CB, BETA0>(alpha * (CA)(T)acc, beta, BETA0 ? T(0) : *rp);
+  *rp = fin(acc, BETA0 ? T(0) : *rp);
 }
 
 }  // namespace mxlo

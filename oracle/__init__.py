@@ -286,9 +286,17 @@ def gemv(res, M, v, alpha, beta, trans=False, flags=0):
 def csc_mul(res, colptr, rowval, nzval, m, n, v, alpha, beta, trans=False, flags=0):
     """mul!(res, op(A), v, α, β) for A::SparseMatrixCSC (src/constructors.jl:19-29 -> SparseArrays `_spmatmul!` /
     `_At_or_Ac_mul_B!`). colptr / rowval 1-based int64 as Julia stores them; real element types."""
-    dt = _check(res, v)
     cp = np.ascontiguousarray(colptr, dtype=np.int64)
     rv = np.ascontiguousarray(rowval, dtype=np.int64)
+    if res.dtype.kind == "c":                    # complex: trans in {False, True | "T", "C" (adjoint)}
+        dt = res.dtype
+        assert v.dtype == dt
+        mode = {False: 0, True: 1, "N": 0, "T": 1, "C": 2}[trans]
+        nz = np.ascontiguousarray(nzval, dtype=dt)
+        assert cp.size == n + 1 and res.size == (n if mode else m) and v.size == (m if mode else n)
+        _fn("orc_csc_mul", dt)(_p(res), _p(cp), _p(rv), _p(nz), _i64(m), _i64(n), _p(v), *_c4(alpha, beta), _i32(mode), _i32(flags))
+        return res
+    dt = _check(res, v)
     nz = np.ascontiguousarray(nzval, dtype=dt)
     assert cp.size == n + 1 and res.size == (n if trans else m) and v.size == (m if trans else n)
     _fn("orc_csc_mul", dt)(_p(res), _p(cp), _p(rv), _p(nz), _i64(m), _i64(n), _p(v), _d(alpha), _d(beta), _i32(int(trans)),

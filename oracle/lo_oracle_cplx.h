@@ -228,6 +228,53 @@ void CFN(orc_gemv)(R *res, const R *M, int64_t m, int64_t n, int64_t ld, const R
   CFN(orc_cplx_epilogue)(res, tmp, nr, are, aim, bre, bim, flags);
 }
 
+/* sparse LinearOperator(M::SparseMatrixCSC{Complex{R}}) — src/constructors.jl:19-29 -> the SparseArrays stdlib's mul!
+ * (see lo_oracle_impl.h: orc_csc_mul for the loops and the pinning note). mode 0: A*v (`_spmatmul!`), 1: transpose(A)*v,
+ * 2: A'*v (`_At_or_Ac_mul_B!` with tfun = transpose / adjoint). colptr / rowval 1-based. */
+void CFN(orc_csc_mul)(R *res, const int64_t *colptr, const int64_t *rowval, const R *nzval, int64_t m, int64_t n, const R *v,
+                      double are, double aim, double bre, double bim, int32_t mode, int32_t flags) {
+  const int a_real = (flags & ORC_ALPHA_REAL) != 0, b_real = (flags & ORC_BETA_REAL) != 0;
+  const int64_t nr = mode ? n : m;
+  const int b_one = (bre == 1 && (b_real || bim == 0)), b0 = (bre == 0 && (b_real || bim == 0));
+#define BODY(RA, RB)                                                                             \
+  {                                                                                              \
+    const RA ar = (RA)are, ai = (RA)aim;                                                         \
+    const RB br = (RB)bre, bi = (RB)bim;                                                         \
+    if (!b_one) {                                        /* _rmul_or_fill!(C, β) */              \
+      for (int64_t i = 0; i < nr; ++i) {                                                         \
+        if (b0) { res[2 * i] = 0; res[2 * i + 1] = 0; }                                          \
+        else { RB tr, ti; SMUL(RB, br, bi, b_real, res[2 * i], res[2 * i + 1], tr, ti); res[2 * i] = (R)tr; res[2 * i + 1] = (R)ti; } \
+      }                                                                                          \
+    }                                                                                            \
+    for (int64_t col = 0; col < n; ++col) {                                                      \
+      if (mode == 0) {                                                                           \
+        RA xr, xi;                                       /* αxj = B[col] * α */                  \
+        SMUL(RA, ar, ai, a_real, v[2 * col], v[2 * col + 1], xr, xi);                            \
+        for (int64_t k = colptr[col] - 1; k < colptr[col + 1] - 1; ++k) {                        \
+          const RA zr = (RA)nzval[2 * k], zi = (RA)nzval[2 * k + 1];                             \
+          R *o = res + 2 * (rowval[k] - 1);                                                      \
+          o[0] = (R)((RA)o[0] + ((zr * xr) - (zi * xi)));                                        \
+          o[1] = (R)((RA)o[1] + ((zr * xi) + (zi * xr)));                                        \
+        }                                                                                        \
+      } else {                                                                                   \
+        R tr = 0, ti = 0;                                /* tmp += tfun(nzv[k]) * B[rv[k]] */    \
+        for (int64_t k = colptr[col] - 1; k < colptr[col + 1] - 1; ++k) {                        \
+          const R zr = nzval[2 * k], zi = mode == 2 ? -nzval[2 * k + 1] : nzval[2 * k + 1];      \
+          const R *x = v + 2 * (rowval[k] - 1);                                                  \
+          tr = tr + ((zr * x[0]) - (zi * x[1]));                                                 \
+          ti = ti + ((zr * x[1]) + (zi * x[0]));                                                 \
+        }                                                                                        \
+        RA ur, ui;                                       /* C[col] += tmp * α */                 \
+        SMUL(RA, ar, ai, a_real, tr, ti, ur, ui);                                                \
+        res[2 * col] = (R)((RA)res[2 * col] + ur);                                               \
+        res[2 * col + 1] = (R)((RA)res[2 * col + 1] + ui);                                       \
+      }                                                                                          \
+    }                                                                                            \
+  }
+  WITH_RAB(BODY);
+#undef BODY
+}
+
 /* mulHermitian! — src/linalg.jl:97-103 with L = tril(A, -1) (:111): res .= α .* (d .* v .+ L*v .+ (v'*L)') (.+ β .* res).
  * (v'*L)'[j] = sum_{i>j} conj(L[i,j]) * v[i]. d is Real (d_real: n scalars, the reference test passes real.(diag(A)))
  * or Complex (2n scalars). t1, t2: 2n scalars each. */

@@ -335,30 +335,56 @@ def test_ophermitian_of_a_sparse_matrix(lo, dev, dtype):
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.complex128, 1e-13), (torch.complex64, 5e-6)])
-def test_complex_sparse_operator_through_real_planes(lo, dev, dtype, tol):
-    """test/test_linop.jl:44 and test/test_cat.jl:5-25 build operators from `simple_sparse_matrix(ComplexF64, …)`:
-    M*v, transpose(M)*u, M'*u with complex α, β against the dense matrix; the adjoint conjugates, the transpose does not."""
+def test_complex_sparse_operator_native_and_through_real_planes(lo, dev, dtype, tol, monkeypatch):
+    """test/test_linop.jl:44 and test/test_cat.jl:5-25 build operators from `simple_sparse_matrix(ComplexF64, …)`. The
+    native instantiation (`mxlo_csc_mul_c`: the chunked sweep on complex elements, mode C conjugating the stored values)
+    against the oracle's restatement of the SparseArrays loops, against the dense matrix, and against the real-planes form
+    (four real sweeps between a split and a join pass — the independent device implementation, MXLO_SPARSE_COMPLEX_PLANES=1):
+    M*v, transpose(M)*u, M'*u, Real and Complex α, β, β = 0 on NaN, CSC and CSR (transposed alias) storage, a row beyond
+    a chunk."""
     rng = np.random.default_rng(63)
     cdt = np.complex128 if dtype == torch.complex128 else np.complex64
-    for m, n, dens in ((30, 20, 0.3), (400, 700, 0.02)):
-        A = sp.random(m, n, dens, format="csc", random_state=7).astype(np.complex128)
+    for m, n, dens, long_row in ((30, 20, 0.3, False), (400, 700, 0.02, False), (50, 3000, 0.01, True)):
+        A = sp.random(m, n, dens, format="lil", random_state=7).astype(np.complex128)
+        if long_row:
+            A[3, :] = 1.0                                          # 3000 entries in one row: pieces + fix-up launch
+        A = sp.csc_matrix(A)
         A.data = (rng.standard_normal(A.nnz) + 1j * rng.standard_normal(A.nnz))
         A = A.astype(cdt)
+        A.sort_indices()
         M = torch.sparse_csc_tensor(torch.from_numpy(A.indptr.astype(np.int64)), torch.from_numpy(A.indices.astype(np.int64)),
                                     torch.from_numpy(A.data), size=A.shape).to(dev)
-        op = lo.LinearOperatorFromMatrix(M)
-        assert op.eltype == dtype and op.shape == (m, n)
+        ops = {"native csc": lo.LinearOperatorFromMatrix(M), "native csr alias": lo.LinearOperatorFromMatrix(M.to_sparse_csr())}
+        monkeypatch.setenv("MXLO_SPARSE_COMPLEX_PLANES", "1")
+        ops["planes"] = lo.LinearOperatorFromMatrix(M)
+        monkeypatch.delenv("MXLO_SPARSE_COMPLEX_PLANES")
+        assert hasattr(ops["native csc"], "_csc") and not hasattr(ops["planes"], "_csc")
         D = A.toarray().astype(np.complex128)
-        for o, Dm in ((op, D), (lo.transpose(op), D.T), (lo.adjoint(op), D.conj().T)):
+        for mode, Dm in ((False, D), ("T", D.T), ("C", D.conj().T)):
             nout, nin = Dm.shape
             v = (rng.standard_normal(nin) + 1j * rng.standard_normal(nin)).astype(cdt)
             r0 = (rng.standard_normal(nout) + 1j * rng.standard_normal(nout)).astype(cdt)
-            for a, b in ((1.0, 0.0), (1.5 - 0.5j, 0.25 + 2j)):
-                res = torch.from_numpy((np.full(nout, np.nan + 0j, cdt) if b == 0 else r0).copy()).to(dev)
-                lo.mul(res, o, torch.from_numpy(v).to(dev), a, b)
-                want = a * (Dm @ v.astype(np.complex128)) + (b * r0.astype(np.complex128) if b != 0 else 0)
+            for a, b in ((1.0, 0.0), (1.5 - 0.5j, 0.25 + 2j), (2.0, -3.0), (-1j, 1.0)):
+                a_real, b_real = not isinstance(a, complex), not isinstance(b, complex)
+                flags = (0x20 if a_real else 0) | (0x40 if b_real else 0) | (0x1 | 0x8)
+                want_o = oracle.csc_mul(np.zeros(nout, cdt) if b == 0 else r0.copy(), A.indptr + 1, A.indices + 1, A.data, m, n, v,
+                                        a, b, trans=mode, flags=flags)
+                want_d = a * (Dm @ v.astype(np.complex128)) + (b * r0.astype(np.complex128) if b != 0 else 0)
                 scale = abs(a) * float((np.abs(Dm) @ np.abs(v)).max()) + abs(b) * float(np.abs(r0).max())
-                assert np.abs(res.cpu().numpy() - want).max() <= 8 * tol * scale
+                got = {}
+                for name, op in ops.items():
+                    o = op if mode is False else (lo.transpose(op) if mode == "T" else lo.adjoint(op))
+                    res = torch.from_numpy((np.full(nout, np.nan + 0j, cdt) if b == 0 else r0).copy()).to(dev)
+                    lo.mul(res, o, torch.from_numpy(v).to(dev), a, b)
+                    got[name] = res.cpu().numpy()
+                    assert np.abs(got[name] - want_d).max() <= 8 * tol * scale, (name, mode, a, b)
+                    assert np.abs(got[name].astype(np.complex128) - want_o.astype(np.complex128)).max() <= 8 * tol * scale, (name, mode)
+        # in-place value updates are seen (A*x through the refreshed snapshot, A'*x at once)
+        op = ops["native csc"]
+        v = torch.from_numpy((rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(cdt)).to(dev)
+        y0 = (op * v).clone()
+        M.values().mul_(2.0)
+        assert torch.allclose(op * v, 2 * y0, rtol=1e-6 if dtype == torch.complex64 else 1e-14, atol=0)
 
 
 def test_warmed_sparse_applies_only_launch_kernels(lo, dev):

@@ -505,3 +505,29 @@ def test_sparse_csc_restatement_vs_an_independent_dense_product(npd):
                 scale = abs(a) * (np.abs(Dm) @ np.abs(v.astype(np.longdouble))).max(initial=0) + abs(b) + 1e-300
                 assert np.isfinite(got).all()
                 assert np.abs(got.astype(np.longdouble) - want).max() <= 16 * max(m, n) ** 0.5 * eps * scale, (m, n, trans, a, b)
+
+
+@pytest.mark.parametrize("cdt", [np.complex128, np.complex64])
+def test_complex_sparse_csc_restatement_vs_an_independent_dense_product(cdt):
+    """The Complex{R} instantiation of oracle.csc_mul (SparseArrays `_spmatmul!` / `_At_or_Ac_mul_B!` with tfun =
+    transpose or adjoint) against a dense product in extended precision: A*v, transpose(A)*v, A'*v, Real and Complex α, β,
+    β = 0 on NaN, β = 1."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(5)
+    eps = np.finfo(cdt).eps
+    for m, n, dens in ((1, 1, 1.0), (9, 6, 0.4), (120, 200, 0.05)):
+        A = sp.random(m, n, dens, format="csc", random_state=int(rng.integers(1 << 30))).astype(np.complex128)
+        A.data = rng.standard_normal(A.nnz) + 1j * rng.standard_normal(A.nnz)
+        A = A.astype(cdt)
+        D = A.toarray().astype(np.clongdouble)
+        for mode, Dm in ((False, D), ("T", D.T), ("C", D.conj().T)):
+            v = (rng.standard_normal(Dm.shape[1]) + 1j * rng.standard_normal(Dm.shape[1])).astype(cdt)
+            r0 = (rng.standard_normal(Dm.shape[0]) + 1j * rng.standard_normal(Dm.shape[0])).astype(cdt)
+            for a, b in ((1.0, 0.0), (2.0, -3.0), (1.5 - 0.5j, 0.25 + 2j), (-0.5j, 1.0)):
+                flags = (0x20 if not isinstance(a, complex) else 0) | (0x40 if not isinstance(b, complex) else 0) | 0x1 | 0x8
+                start = np.full(r0.size, np.nan + 0j, cdt) if b == 0 else r0.copy()
+                got = oracle.csc_mul(start, A.indptr + 1, A.indices + 1, A.data, m, n, v, a, b, trans=mode, flags=flags)
+                want = a * (Dm @ v.astype(np.clongdouble)) + (b * r0.astype(np.clongdouble) if b != 0 else 0)
+                scale = abs(a) * (np.abs(Dm) @ np.abs(v.astype(np.clongdouble))).max(initial=0) + abs(b) * np.abs(r0).max() + 1e-300
+                assert np.isfinite(got).all()
+                assert np.abs(got.astype(np.clongdouble) - want).max() <= 32 * max(m, n) ** 0.5 * eps * scale, (m, n, mode, a, b)

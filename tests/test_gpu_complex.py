@@ -607,7 +607,7 @@ class _CGen:
 
     def leaf(self, m, n):
         lo, dev, rng = self.lo, self.dev, self.rng
-        kinds = ["dense_col", "dense_row", "zeros"]
+        kinds = ["dense_col", "dense_row", "zeros", "sparse_csc", "sparse_csr"]
         if m == n:
             kinds += ["diag", "eye", "householder", "hermitian"]
             if m % 2 == 0 and m >= 4:
@@ -620,6 +620,13 @@ class _CGen:
         if k == "dense_row":
             A = self.c(m, n)
             return lo.LinearOperatorFromMatrix(T(A, dev)), A, k
+        if k in ("sparse_csc", "sparse_csr"):                       # native complex sparse leaf (mxlo_csc_mul_c); CSR = transposed alias
+            import scipy.sparse as sp
+            A = self.c(m, n) * (rng.random((m, n)) < rng.uniform(0.1, 0.7))
+            Sm = sp.csc_matrix(A)
+            M = torch.sparse_csc_tensor(torch.from_numpy(Sm.indptr.astype(np.int64)), torch.from_numpy(Sm.indices.astype(np.int64)),
+                                        torch.from_numpy(Sm.data.astype(np.complex128)), size=A.shape).to(dev)
+            return lo.LinearOperatorFromMatrix(M if k == "sparse_csc" else M.to_sparse_csr()), A, k
         if k == "zeros":
             return lo.opZeros(torch.complex128, m, n, S=S), np.zeros((m, n), complex), k
         if k == "diag":

@@ -499,6 +499,11 @@ int32_t mxlo_csc_mul_c(mxlo_csc *h, void *res, const void *v, double alpha_re, d
 int32_t mxlo_csc_mul_block(mxlo_csc *h, void *res, int64_t ldr, const void *V, int64_t ldv, int64_t k, double alpha,
                            double beta, int32_t op_mode, int32_t flags);
 int32_t mxlo_csc_info(mxlo_csc *h, int64_t info[8]);
+/* Host-only (no device): the chunk table the library builds for a 0-based row-pointer array ptr_host[nrows + 1], as rows
+ * {first entry, entries, first row, rows, kind (0 whole rows, 1 one long row, 2 a piece of a row beyond a chunk), carry
+ * slot} in out[cap][6] (NULL: counts only). tests/test_abi_and_host.py checks the invariants of the decomposition with it. */
+int32_t mxlo_debug_csc_chunks(const int64_t *ptr_host, int64_t nrows, int64_t *out, int64_t cap, int64_t *nchunks,
+                              int64_t *nlong, int64_t *ncarry);
 int32_t mxlo_csc_destroy(mxlo_csc *h);
 
 /* push!(B, s, y) of the diagonal quasi-Newton operators — src/DiagonalHessianApproximation.jl:

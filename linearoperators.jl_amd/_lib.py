@@ -148,6 +148,7 @@ _PROTOS = {
     "mxlo_csc_mul_c": [_vp, _vp, _vp, _dbl, _dbl, _dbl, _dbl, _i32, _i32],
     "mxlo_csc_mul_block": [_vp, _vp, _i64, _vp, _i64, _i64, _dbl, _dbl, _i32, _i32],
     "mxlo_csc_info": [_vp, C.POINTER(_i64)],
+    "mxlo_debug_csc_chunks": [C.POINTER(_i64), _i64, C.POINTER(_i64), _i64, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)],
     "mxlo_csc_destroy": [_vp],
     "mxlo_gemv_block": [_vp, _i32, _vp, _i64, _vp, _i64, _i64, _i64, _vp, _i64, _i64, _dbl, _dbl, _i32, _i32],
     "mxlo_diagqn_push": [_vp, _i32, _i32, _vp, _vp, _vp, _i64, C.POINTER(_i32)],

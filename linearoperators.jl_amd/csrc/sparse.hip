@@ -335,6 +335,29 @@ MXLO_API int32_t mxlo_csc_mul_block(mxlo_csc *h, void *res, int64_t ldr, const v
   return MXLO_OK;
 }
 
+// Host-only view of the work decomposition (no device needed): the chunk table build_chunks() produces for a row-pointer
+// array, as rows of {k0, nz, row0, nr, kind, carry}. What the CPU tests check the invariants of (every stored entry in
+// exactly one chunk, rows whole unless longer than a chunk, pieces of a long row contiguous and in order).
+MXLO_API int32_t mxlo_debug_csc_chunks(const int64_t *ptr_host, int64_t nrows, int64_t *out, int64_t cap, int64_t *nchunks,
+                                       int64_t *nlong, int64_t *ncarry) {
+  MXLO_REQUIRE(ptr_host && nchunks && nlong && ncarry && nrows >= 0, MXLO_EINVAL, "mxlo_debug_csc_chunks: bad argument");
+  std::vector<int64_t> ptr(ptr_host, ptr_host + nrows + 1);
+  std::vector<SpChunk> chunks;
+  std::vector<SpLongRow> longs;
+  int nc = 0;
+  build_chunks(ptr, nrows, chunks, longs, &nc);
+  *nchunks = (int64_t)chunks.size();
+  *nlong = (int64_t)longs.size();
+  *ncarry = nc;
+  if (out)
+    for (int64_t i = 0; i < (int64_t)chunks.size() && i < cap; ++i) {
+      const SpChunk &c = chunks[(size_t)i];
+      int64_t *o = out + 6 * i;
+      o[0] = c.k0; o[1] = c.nz; o[2] = c.row0; o[3] = c.nr; o[4] = c.kind; o[5] = c.carry;
+    }
+  return MXLO_OK;
+}
+
 MXLO_API int32_t mxlo_csc_info(mxlo_csc *h, int64_t info[8]) {
   MXLO_REQUIRE(h && info, MXLO_EINVAL, "mxlo_csc_info: NULL argument");
   info[0] = h->m;

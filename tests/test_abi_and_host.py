@@ -340,3 +340,60 @@ def test_neg_scale_and_sum_accept_matrices_like_the_reference(lo):
     assert torch.equal(res, (d1 - d2)[:, None] * m)
     with pytest.raises(lo.LinearOperatorException, match="vectors only"):
         lo.mul(res, A * B, m)
+
+
+def test_sparse_chunk_tables_cover_every_entry_once(lo):
+    """Host logic of the sparse leaf (no device): the work decomposition `mxlo_csc_create` builds for a compressed-row
+    operand. For random row-length distributions — empty rows, short rows, rows around the long-row threshold (512),
+    rows around and far beyond a chunk (2048) — every stored entry lies in exactly one chunk, chunks are in entry order,
+    whole-row chunks hold <= 2048 entries and <= 2048 rows and no row above 512 entries, a row of 513 … 2048 entries is
+    a chunk of its own, a longer row is cut into consecutive 2048-entry pieces with consecutive carry slots."""
+    import ctypes as C
+    L = C.CDLL(lo._lib.LIB_PATH)
+    f = L.mxlo_debug_csc_chunks
+    f.argtypes = [C.POINTER(C.c_int64), C.c_int64, C.POINTER(C.c_int64), C.c_int64] + [C.POINTER(C.c_int64)] * 3
+    f.restype = C.c_int32
+    rng = np.random.default_rng(7)
+    CH, LONG = 2048, 512
+    for trial in range(40):
+        nrows = int(rng.integers(0, 3000))
+        kind = trial % 5
+        if kind == 0:
+            lens = rng.integers(0, 12, nrows)
+        elif kind == 1:
+            lens = rng.choice([0, 1, 7, 500, 512, 513, 2047, 2048, 2049, 5000, 10000], nrows)
+        elif kind == 2:
+            lens = np.zeros(nrows, np.int64)
+        elif kind == 3:
+            lens = rng.integers(400, 700, nrows)
+        else:
+            lens = (rng.pareto(1.2, nrows) * 20).astype(np.int64)
+        ptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+        nchunks, nlong, ncarry = C.c_int64(), C.c_int64(), C.c_int64()
+        assert f(ptr.ctypes.data_as(C.POINTER(C.c_int64)), nrows, None, 0, C.byref(nchunks), C.byref(nlong), C.byref(ncarry)) == 0
+        out = np.zeros((max(1, nchunks.value), 6), np.int64)
+        assert f(ptr.ctypes.data_as(C.POINTER(C.c_int64)), nrows, out.ctypes.data_as(C.POINTER(C.c_int64)), out.shape[0],
+                 C.byref(nchunks), C.byref(nlong), C.byref(ncarry)) == 0
+        out = out[:nchunks.value]
+        pos, next_row, carry = 0, 0, 0
+        for k0, nz, row0, nr, ck, cs in out:
+            assert k0 == pos and nz <= CH, (trial, k0, pos)
+            if ck == 0:                                               # whole rows
+                assert row0 == next_row and 1 <= nr <= CH
+                assert ptr[row0] == k0 and ptr[row0 + nr] == k0 + nz
+                assert (np.diff(ptr[row0:row0 + nr + 1]) <= LONG).all()
+                next_row = row0 + nr
+            elif ck == 1:                                             # one long row
+                assert row0 == next_row and nr == 1 and LONG < nz <= CH and ptr[row0] == k0 and ptr[row0 + 1] == k0 + nz
+                next_row = row0 + 1
+            else:                                                     # a piece of a row beyond a chunk
+                assert ck == 2 and nr == 1 and cs == carry and ptr[row0 + 1] - ptr[row0] > CH
+                assert ptr[row0] <= k0 and k0 + nz <= ptr[row0 + 1]
+                assert nz == CH or k0 + nz == ptr[row0 + 1]           # only the last piece is short
+                carry += 1
+                if k0 + nz == ptr[row0 + 1]:
+                    assert row0 == next_row
+                    next_row = row0 + 1
+            pos += nz
+        assert pos == ptr[-1] and next_row == nrows and carry == ncarry.value
+        assert nlong.value == int((np.diff(ptr) > CH).sum())

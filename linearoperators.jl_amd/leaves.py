@@ -383,7 +383,7 @@ def _opHermitian_sparse(*args):
     lr, lc, lv = rows[low][order], cols[low][order], vals[low][order].to(U).contiguous()
     ccol = torch.zeros(n + 1, dtype=torch.int64, device=vals.device)
     ccol[1:] = torch.cumsum(torch.bincount(lc, minlength=n), 0)
-    L = LinearOperatorFromSparse(torch.sparse_csc_tensor(ccol, lr, lv, size=(m, n)))
+    L = LinearOperatorFromSparse(_csc_tensor(ccol, lr, lv, (m, n)))
     D = opDiagonal(d if d.dtype == U else d.to(U))
     Lt = transpose(L)
 
@@ -415,6 +415,15 @@ _SPARSE_LAYOUTS = (torch.sparse_csc, torch.sparse_csr, torch.sparse_coo)
 _version_of = operator.attrgetter("_version")
 
 
+def _csc_tensor(ccol, rows, vals, size, csr=False):
+    """torch.sparse_csc_tensor / sparse_csr_tensor without torch's "beta state" UserWarning (the tensor is only a carrier
+    of the three arrays here: no torch sparse kernel is ever run on it)."""
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", UserWarning)
+        return (torch.sparse_csr_tensor if csr else torch.sparse_csc_tensor)(ccol, rows, vals, size=size)
+
+
 class _CscHandle:
     """RAII wrapper of ``mxlo_csc`` (include/mxlo.h) plus the tensors it keeps referenced."""
 
@@ -444,7 +453,7 @@ def sparse_csc(colptr, rowval, nzval, m: int, n: int, index_base: int = 1, devic
                                                            else _default_device())
     t = lambda a, dt=None: (a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(a))).to(device=dev, dtype=dt)
     cp, rv = t(colptr, torch.int64) - index_base, t(rowval, torch.int64) - index_base
-    return torch.sparse_csc_tensor(cp, rv, t(nzval), size=(m, n), device=dev)
+    return _csc_tensor(cp, rv, t(nzval), (m, n))
 
 
 def LinearOperatorFromSparse(M: torch.Tensor, symmetric: bool = False, hermitian: bool = False,
@@ -574,7 +583,7 @@ def _sparse_complex(M: torch.Tensor, symmetric: bool, hermitian: bool, S: Option
     nrow, ncol = M.shape
     tr = M.layout == torch.sparse_csr
     cp, rv = (M.crow_indices(), M.col_indices()) if tr else (M.ccol_indices(), M.row_indices())
-    mk = lambda v: (torch.sparse_csr_tensor if tr else torch.sparse_csc_tensor)(cp, rv, v.contiguous(), size=(nrow, ncol))
+    mk = lambda v: _csc_tensor(cp, rv, v.contiguous(), (nrow, ncol), csr=tr)
     vals = M.values()
     planes_ = torch.view_as_real(vals.detach().clone())        # (.real on values() of a sparse tensor raises in torch 2.10)
     Lr, Li = LinearOperatorFromSparse(mk(planes_[:, 0])), LinearOperatorFromSparse(mk(planes_[:, 1]))

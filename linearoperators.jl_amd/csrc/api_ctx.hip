@@ -414,6 +414,9 @@ MXLO_API int32_t mxlo_ctx_tune(mxlo_ctx *ctx, const char *key, int64_t value) {
   } else if (!strcmp(key, "combine_blocks_per_cu")) {
     MXLO_REQUIRE(value >= 0 && value <= 64, MXLO_EINVAL, "combine_blocks_per_cu out of range");
     ctx->tune.combine_blocks_per_cu = (int)value;
+  } else if (!strcmp(key, "qn_fused_batch12")) {
+    MXLO_REQUIRE(value == 0 || value == 1, MXLO_EINVAL, "qn_fused_batch12 must be 0 or 1");
+    ctx->tune.qn_fused_batch12 = (int)value;
   } else if (!strcmp(key, "qn_fused_small")) {
     MXLO_REQUIRE(value == 0 || value == 1, MXLO_EINVAL, "qn_fused_small must be 0 or 1");
     ctx->tune.qn_fused_small = (int)value;

@@ -135,6 +135,7 @@ struct Tune {
                            // workgroup), 32 / 64 / 128 force one, -1 = generic fallback kernel only
   int fuse_finalize = 1;   // reductions of <= 4 columns: last-arriving workgroup finalizes in the dots kernel
   int combine_blocks_per_cu = 0;   // panel_combine: 0 = one vector per thread (best measured), k = persistent grid
+  int qn_fused_batch12 = 1;   // single-launch quasi-Newton apply with 9 .. 12 columns on short vectors: all columns in one batch
   int qn_fused_small = 1;  // quasi-Newton applies with <= 64 workgroups of dots: dots + finalize + coefficients in one launch
   int push_wide = 1;       // one-pass push!: 20 columns per pass while >= 20 remain (0: always <= 10)
   int push_fused = 1;      // push!(op, s, y): one-pass schedule (new pair held per lane, in-pass slot stores); 0 = copies + dual-x dots

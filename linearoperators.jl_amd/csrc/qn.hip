@@ -648,12 +648,16 @@ struct QnfArgs {
   int ct_f32;
 };
 
-template <typename T, typename CA, typename CB, int KIND, bool BETA0>
+// U vectors per lane and NB columns per batch: (4, 8) in general; (2, 12) when 8 < ncol <= 12 and the vector is short enough
+// for 64 workgroups of half the slice — then ALL columns are one batch: one round trip in the dots phase and one in the
+// combine phase instead of two each (L-BFGS m = 5 / 6: 10 / 12 columns); (1, 20) for 13 .. 40 columns on vectors of at most
+// 64 workgroups of one vector per lane (L-BFGS m = 10: one batch instead of three; m = 20: two instead of five).
+template <typename T, typename CA, typename CB, int KIND, bool BETA0, int U, int NB>
 __global__ void __launch_bounds__(kBlock)
 qn_apply_fused_kernel(T *__restrict__ res, QnfCols<T> cols, const T *__restrict__ x, int64_t n,
                       unsigned long long *__restrict__ slots, QnfArgs F, OrdArgs O, unsigned long long ticks,
                       unsigned *__restrict__ fault, int drop) {
-  constexpr int VEC = Vec16<T>::N, U = 4;
+  constexpr int VEC = Vec16<T>::N;
   using V = typename Vec16<T>::type;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, G = (int)gridDim.x, b = (int)blockIdx.x;
   const int ncol = F.ncol, na = O.na;
@@ -709,10 +713,10 @@ qn_apply_fused_kernel(T *__restrict__ res, QnfCols<T> cols, const T *__restrict_
     return v;
   };
   auto dots_batches = [&]<bool FULL>() {
-    for (int c0 = 0; c0 < ncol; c0 += 8) {     // columns in batches of 8: one memory round trip per batch
-      V cv[8][U];
+    for (int c0 = 0; c0 < ncol; c0 += NB) {     // columns in batches of NB: one memory round trip per batch
+      V cv[NB][U];
 #pragma unroll
-      for (int t = 0; t < 8; ++t) {
+      for (int t = 0; t < NB; ++t) {
         const T *p = cols.p[c0 + t < ncol ? c0 + t : ncol - 1];      // clamp: a valid (unused) column instead of a branch
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -722,7 +726,7 @@ qn_apply_fused_kernel(T *__restrict__ res, QnfCols<T> cols, const T *__restrict_
         }
       }
 #pragma unroll
-      for (int t = 0; t < 8; ++t) {
+      for (int t = 0; t < NB; ++t) {
         double acc = 0.0;
 #pragma unroll
         for (int u = 0; u < U; ++u)
@@ -840,16 +844,16 @@ qn_apply_fused_kernel(T *__restrict__ res, QnfCols<T> cols, const T *__restrict_
       }
     }
     prologue.template operator()<E>(xq, rq, q);
-    for (int c0 = 0; c0 < ncol; c0 += 8) {
-      V cvb[8][U];
+    for (int c0 = 0; c0 < ncol; c0 += NB) {
+      V cvb[NB][U];
 #pragma unroll
-      for (int t = 0; t < 8; ++t) {
+      for (int t = 0; t < NB; ++t) {
         const T *p = ccol(c0 + t < ncol ? c0 + t : ncol - 1);          // clamp: a valid (unused) column instead of a branch
 #pragma unroll
         for (int u = 0; u < U; ++u) cvb[t][u] = *reinterpret_cast<const V *>(p + base + (int64_t)u * kBlock * VEC);
       }
 #pragma unroll
-      for (int t = 0; t < 8; ++t) {
+      for (int t = 0; t < NB; ++t) {
         if (c0 + t < ncol) {
           T ce[E];
 #pragma unroll
@@ -893,7 +897,13 @@ template <typename T>
 bool try_fused_apply(mxlo_qn *h, T *res, const T *const *cols, const T *x, QnfArgs F, const OrdArgs &O, int32_t flags,
                      int32_t *status) {
   mxlo_ctx *ctx = h->ctx;
-  constexpr int VEC = Vec16<T>::N, U = 4;
+  constexpr int VEC = Vec16<T>::N;
+  // 9 .. 12 columns on a vector short enough for 64 workgroups of 2 vectors per lane: all columns in ONE batch
+  auto grid_of = [&](int u) { return (h->n + (int64_t)kBlock * u * VEC - 1) / ((int64_t)kBlock * u * VEC); };
+  const bool small = ctx->tune.qn_fused_batch12 && F.ncol > 8 && F.ncol <= 12 && grid_of(2) <= kQnfMaxGrid;
+  // 13 .. 40 columns on a vector short enough for 64 workgroups of ONE vector per lane: batches of 20 columns
+  const bool tiny = ctx->tune.qn_fused_batch12 && F.ncol > 12 && grid_of(1) <= kQnfMaxGrid && F.kind != MXLO_QN_LSR1;
+  const int U = small ? 2 : (tiny ? 1 : 4);
   const int64_t per = (int64_t)kBlock * U * VEC;
   const int64_t grid = (h->n + per - 1) / per;
   if (!ctx->tune.qn_fused_small || ctx->allreduce || F.ncol < 1 || F.ncol > kQnfMaxCols || grid > kQnfMaxGrid ||
@@ -907,10 +917,17 @@ bool try_fused_apply(mxlo_qn *h, T *res, const T *const *cols, const T *x, QnfAr
   }
   bool fits = true;
   *status = dispatch_ab<T>(F.beta, flags, [&]<typename CA, typename CB, bool B0>() -> int32_t {
+    auto go2 = [&]<int KIND, int UU, int NB>() {
+      if (!(fits = coresident<qn_apply_fused_kernel<T, CA, CB, KIND, B0, UU, NB>>(ctx, grid))) return;
+      hipLaunchKernelGGL((qn_apply_fused_kernel<T, CA, CB, KIND, B0, UU, NB>), dim3((unsigned)grid), dim3(kBlock), 0, ctx->stream,
+                         res, fc, x, h->n, ctx->qslots, F, O, fused_timeout_ticks(ctx), ctx->fault_dev,
+                         ctx->tune.fused_debug_drop);
+    };
     auto go = [&]<int KIND>() {
-      if (!(fits = coresident<qn_apply_fused_kernel<T, CA, CB, KIND, B0>>(ctx, grid))) return;
-      hipLaunchKernelGGL((qn_apply_fused_kernel<T, CA, CB, KIND, B0>), dim3((unsigned)grid), dim3(kBlock), 0, ctx->stream, res,
-                         fc, x, h->n, ctx->qslots, F, O, fused_timeout_ticks(ctx), ctx->fault_dev, ctx->tune.fused_debug_drop);
+      if constexpr (KIND == MXLO_QN_LSR1) go2.template operator()<KIND, 4, 8>();     // L-SR1 has mem columns: 9 .. 12 is rare
+      else if (small) go2.template operator()<KIND, 2, 12>();
+      else if (tiny) go2.template operator()<KIND, 1, 20>();
+      else go2.template operator()<KIND, 4, 8>();
     };
     if (F.kind == MXLO_QN_LBFGS_INV) go.template operator()<MXLO_QN_LBFGS_INV>();
     else if (F.kind == MXLO_QN_LBFGS_FWD) go.template operator()<MXLO_QN_LBFGS_FWD>();

@@ -902,7 +902,7 @@ bool try_fused_apply(mxlo_qn *h, T *res, const T *const *cols, const T *x, QnfAr
   auto grid_of = [&](int u) { return (h->n + (int64_t)kBlock * u * VEC - 1) / ((int64_t)kBlock * u * VEC); };
   const bool small = ctx->tune.qn_fused_batch12 && F.ncol > 8 && F.ncol <= 12 && grid_of(2) <= kQnfMaxGrid;
   // 13 .. 40 columns on a vector short enough for 64 workgroups of ONE vector per lane: batches of 20 columns
-  const bool tiny = ctx->tune.qn_fused_batch12 && F.ncol > 12 && grid_of(1) <= kQnfMaxGrid && F.kind != MXLO_QN_LSR1;
+  const bool tiny = ctx->tune.qn_fused_batch12 && F.ncol > 12 && grid_of(1) <= kQnfMaxGrid;
   const int U = small ? 2 : (tiny ? 1 : 4);
   const int64_t per = (int64_t)kBlock * U * VEC;
   const int64_t grid = (h->n + per - 1) / per;
@@ -924,8 +924,7 @@ bool try_fused_apply(mxlo_qn *h, T *res, const T *const *cols, const T *x, QnfAr
                          ctx->tune.fused_debug_drop);
     };
     auto go = [&]<int KIND>() {
-      if constexpr (KIND == MXLO_QN_LSR1) go2.template operator()<KIND, 4, 8>();     // L-SR1 has mem columns: 9 .. 12 is rare
-      else if (small) go2.template operator()<KIND, 2, 12>();
+      if (small) go2.template operator()<KIND, 2, 12>();
       else if (tiny) go2.template operator()<KIND, 1, 20>();
       else go2.template operator()<KIND, 4, 8>();
     };

@@ -797,7 +797,7 @@ def test_rejected_push_leaves_stale_gram_state_alone(lo, dev, dtype):
 @pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
 @pytest.mark.parametrize("kind", ["inv", "fwd", "lsr1"])
 @pytest.mark.parametrize("n,mem", [(1, 1), (7, 3), (4096, 5), (65_536, 5), (100_003, 20), (131_071, 32), (140_001, 5),
-                                   (9_001, 10), (20_000, 20), (30_011, 16), (1_000, 6)])     # round 4: the (1, 20) and (2, 12) batch variants
+                                   (9_001, 10), (20_000, 20), (30_011, 16), (1_000, 6), (5_000, 12), (8_000, 28)])     # round 4: the (1, 20) and (2, 12) batch variants
 def test_single_launch_dots_and_coefficients_match_the_four_launch_apply(lo, dev, dtype, kind, n, mem):
     """for launch-bound sizes (<= 64 workgroups, <= 40 panel columns) a quasi-Newton apply is ONE launch
     (csrc/qn.hip: qn_apply_fused_kernel — partial dots, fence-free slot exchange, fixed-order finalize, the coefficient

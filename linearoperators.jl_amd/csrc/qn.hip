@@ -712,9 +712,13 @@ qn_apply_fused_kernel(T *__restrict__ res, QnfCols<T> cols, const T *__restrict_
     for (int k = 0; k < VEC; ++k) v[k] = i + k < n ? p[i + k] : T(0);
     return v;
   };
+  // REUSE: the narrow shapes keep the LAST dots batch in registers through the exchange, and the combine phase applies
+  // it from there instead of reading those columns again (forward L-BFGS and L-SR1: same column order in both phases;
+  // with a single batch — the case these shapes exist for — the combine then issues no column load at all)
+  constexpr bool REUSE = U < 4 && KIND != MXLO_QN_LBFGS_INV;
+  V cv[NB][U];
   auto dots_batches = [&]<bool FULL>() {
     for (int c0 = 0; c0 < ncol; c0 += NB) {     // columns in batches of NB: one memory round trip per batch
-      V cv[NB][U];
 #pragma unroll
       for (int t = 0; t < NB; ++t) {
         const T *p = cols.p[c0 + t < ncol ? c0 + t : ncol - 1];      // clamp: a valid (unused) column instead of a branch
@@ -846,11 +850,14 @@ qn_apply_fused_kernel(T *__restrict__ res, QnfCols<T> cols, const T *__restrict_
     prologue.template operator()<E>(xq, rq, q);
     for (int c0 = 0; c0 < ncol; c0 += NB) {
       V cvb[NB][U];
+      const bool kept = REUSE && c0 + NB >= ncol;                      // the batch the dots phase left in registers
+      if (!kept) {
 #pragma unroll
-      for (int t = 0; t < NB; ++t) {
-        const T *p = ccol(c0 + t < ncol ? c0 + t : ncol - 1);          // clamp: a valid (unused) column instead of a branch
+        for (int t = 0; t < NB; ++t) {
+          const T *p = ccol(c0 + t < ncol ? c0 + t : ncol - 1);        // clamp: a valid (unused) column instead of a branch
 #pragma unroll
-        for (int u = 0; u < U; ++u) cvb[t][u] = *reinterpret_cast<const V *>(p + base + (int64_t)u * kBlock * VEC);
+          for (int u = 0; u < U; ++u) cvb[t][u] = *reinterpret_cast<const V *>(p + base + (int64_t)u * kBlock * VEC);
+        }
       }
 #pragma unroll
       for (int t = 0; t < NB; ++t) {
@@ -859,7 +866,7 @@ qn_apply_fused_kernel(T *__restrict__ res, QnfCols<T> cols, const T *__restrict_
 #pragma unroll
           for (int u = 0; u < U; ++u)
 #pragma unroll
-            for (int k = 0; k < VEC; ++k) ce[u * VEC + k] = cvb[t][u][k];
+            for (int k = 0; k < VEC; ++k) ce[u * VEC + k] = kept ? cv[t][u][k] : cvb[t][u][k];
           column.template operator()<E>(c0 + t, q, ce);
         }
       }
@@ -900,7 +907,8 @@ bool try_fused_apply(mxlo_qn *h, T *res, const T *const *cols, const T *x, QnfAr
   constexpr int VEC = Vec16<T>::N;
   // 9 .. 12 columns on a vector short enough for 64 workgroups of 2 vectors per lane: all columns in ONE batch
   auto grid_of = [&](int u) { return (h->n + (int64_t)kBlock * u * VEC - 1) / ((int64_t)kBlock * u * VEC); };
-  const bool small = ctx->tune.qn_fused_batch12 && F.ncol > 8 && F.ncol <= 12 && grid_of(2) <= kQnfMaxGrid;
+  const bool small = ctx->tune.qn_fused_batch12 && F.ncol <= 12 && (F.ncol > 8 || F.kind != MXLO_QN_LBFGS_INV) &&
+                     grid_of(2) <= kQnfMaxGrid;     // (<= 8 columns: one batch either way, but this shape keeps it in registers)
   // 13 .. 40 columns on a vector short enough for 64 workgroups of ONE vector per lane: batches of 20 columns
   const bool tiny = ctx->tune.qn_fused_batch12 && F.ncol > 12 && grid_of(1) <= kQnfMaxGrid;
   const int U = small ? 2 : (tiny ? 1 : 4);

@@ -715,13 +715,20 @@ qn_apply_fused_kernel(T *__restrict__ res, QnfCols<T> cols, const T *__restrict_
   // REUSE: the narrow shapes keep the LAST dots batch in registers through the exchange, and the combine phase applies
   // it from there instead of reading those columns again (forward L-BFGS and L-SR1: same column order in both phases;
   // with a single batch — the case these shapes exist for — the combine then issues no column load at all)
-  constexpr bool REUSE = U < 4 && KIND != MXLO_QN_LBFGS_INV;
+  constexpr bool REUSE = U < 4;
+  // (the inverse operator's combine walks [y newest -> oldest, s oldest -> newest] where its dots are laid out
+  //  [s.., y..] newest -> oldest: with REUSE the dots phase loads — and publishes — the columns in COMBINE order, and the
+  //  sums are put back into dots order when they are written to sdots, which is all the coefficient recurrence reads)
+  auto dots_index = [&](int c) -> int {        // position in dots order of the column the dots phase handles as number c
+    if constexpr (KIND == MXLO_QN_LBFGS_INV && REUSE) return c < F.nfirst ? F.nfirst + c : 2 * F.nfirst - 1 - c;
+    else return c;
+  };
   V cv[NB][U];
   auto dots_batches = [&]<bool FULL>() {
     for (int c0 = 0; c0 < ncol; c0 += NB) {     // columns in batches of NB: one memory round trip per batch
 #pragma unroll
       for (int t = 0; t < NB; ++t) {
-        const T *p = cols.p[c0 + t < ncol ? c0 + t : ncol - 1];      // clamp: a valid (unused) column instead of a branch
+        const T *p = cols.p[dots_index(c0 + t < ncol ? c0 + t : ncol - 1)];      // clamp: a valid (unused) column instead of a branch
 #pragma unroll
         for (int u = 0; u < U; ++u) {
           const int64_t i = base + (int64_t)u * kBlock * VEC;
@@ -762,7 +769,7 @@ qn_apply_fused_kernel(T *__restrict__ res, QnfCols<T> cols, const T *__restrict_
     __hip_atomic_store(epoch, (unsigned long long)(1u - e), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   for (int c = wave; c < ncol; c += kBlock / 64) {                    // fixed order: lane i <- workgroup i, one DPP tree
     const double v = wave_allsum(lane < G ? spart[c * kQnfMaxGrid + lane] : 0.0);
-    if (lane == 0) sdots[c] = v;
+    if (lane == 0) sdots[dots_index(c)] = v;
   }
   __syncthreads();
   // ---- 4. coefficients (one wave, redundantly per workgroup; same recurrences as the *_coef_kernel bodies)
@@ -907,8 +914,8 @@ bool try_fused_apply(mxlo_qn *h, T *res, const T *const *cols, const T *x, QnfAr
   constexpr int VEC = Vec16<T>::N;
   // 9 .. 12 columns on a vector short enough for 64 workgroups of 2 vectors per lane: all columns in ONE batch
   auto grid_of = [&](int u) { return (h->n + (int64_t)kBlock * u * VEC - 1) / ((int64_t)kBlock * u * VEC); };
-  const bool small = ctx->tune.qn_fused_batch12 && F.ncol <= 12 && (F.ncol > 8 || F.kind != MXLO_QN_LBFGS_INV) &&
-                     grid_of(2) <= kQnfMaxGrid;     // (<= 8 columns: one batch either way, but this shape keeps it in registers)
+  const bool small = ctx->tune.qn_fused_batch12 && F.ncol <= 12 && grid_of(2) <= kQnfMaxGrid;
+  // (<= 8 columns: one batch either way, but this shape keeps it in registers for the combine phase)
   // 13 .. 40 columns on a vector short enough for 64 workgroups of ONE vector per lane: batches of 20 columns
   const bool tiny = ctx->tune.qn_fused_batch12 && F.ncol > 12 && grid_of(1) <= kQnfMaxGrid;
   const int U = small ? 2 : (tiny ? 1 : 4);

@@ -69,8 +69,8 @@ MXLO_API int32_t mxlo_ctx_create(int32_t device_id, void *stream, mxlo_ctx **out
     for (int i = 0; i < 8; ++i) init[2 * kFusedSlots + i] = 0;
     MXLO_HIP(hipMemcpy(ctx->xslots, init.data(), init.size() * sizeof(unsigned long long), hipMemcpyHostToDevice));
   }
-  {  // the same for the single-launch quasi-Newton apply: 2 sets of 40 columns x 64 workgroups
-    constexpr size_t kQ = 2 * 40 * 64 + 8;
+  {  // the same for the single-launch quasi-Newton apply: 2 sets of 40 columns x 256 workgroups
+    constexpr size_t kQ = 2 * kQnfSlots + 8;
     if (hipMalloc((void **)&ctx->qslots, sizeof(unsigned long long) * kQ) == hipSuccess) {
       std::vector<unsigned long long> init(kQ, kSlotEmpty);
       for (int i = 0; i < 8; ++i) init[kQ - 8 + i] = 0;
@@ -105,7 +105,7 @@ static int32_t rearm_fused_slots(mxlo_ctx *ctx) {
     MXLO_HIP(hipMemcpy(ctx->xslots, init.data(), init.size() * sizeof(unsigned long long), hipMemcpyHostToDevice));
   }
   if (ctx->qslots) {
-    constexpr size_t kQ = 2 * 40 * 64 + 8;
+    constexpr size_t kQ = 2 * kQnfSlots + 8;
     std::vector<unsigned long long> init(kQ, kSlotEmpty);
     for (int i = 0; i < 8; ++i) init[kQ - 8 + i] = 0;
     MXLO_HIP(hipMemcpy(ctx->qslots, init.data(), kQ * sizeof(unsigned long long), hipMemcpyHostToDevice));
@@ -414,6 +414,9 @@ MXLO_API int32_t mxlo_ctx_tune(mxlo_ctx *ctx, const char *key, int64_t value) {
   } else if (!strcmp(key, "combine_blocks_per_cu")) {
     MXLO_REQUIRE(value >= 0 && value <= 64, MXLO_EINVAL, "combine_blocks_per_cu out of range");
     ctx->tune.combine_blocks_per_cu = (int)value;
+  } else if (!strcmp(key, "qn_fused_max_grid")) {
+    MXLO_REQUIRE(value >= 1 && value <= kQnfMaxGrid, MXLO_EINVAL, "qn_fused_max_grid must be in 1..256");
+    ctx->tune.qn_fused_max_grid = (int)value;
   } else if (!strcmp(key, "qn_fused_batch12")) {
     MXLO_REQUIRE(value == 0 || value == 1, MXLO_EINVAL, "qn_fused_batch12 must be 0 or 1");
     ctx->tune.qn_fused_batch12 = (int)value;

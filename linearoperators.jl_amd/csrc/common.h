@@ -23,6 +23,8 @@ namespace mxlo {
 constexpr int kBlock = 256;          // 4 waves of 64 lanes: one wave per SIMD of a CU
 constexpr int kWave = 64;
 constexpr int kMaxRedCols = 128;     // columns a single reduction call may produce
+constexpr int kQnfMaxCols = 40, kQnfMaxGrid = 256;   // single-launch quasi-Newton apply: panel columns x workgroups of its exchange
+constexpr int kQnfSlots = kQnfMaxCols * kQnfMaxGrid;
 constexpr int kFusedSlots = 256;     // workgroups of a single-launch (grid-exchange) kernel: all co-resident, <= #CUs
 constexpr unsigned long long kSlotEmpty = 0x7FF8DEADBEEF0001ull;   // a NaN payload no arithmetic produces (partials are canonicalised)
 constexpr int kMaxRedBlocks = 4096;  // partial slots per column in the workspace
@@ -135,6 +137,7 @@ struct Tune {
                            // workgroup), 32 / 64 / 128 force one, -1 = generic fallback kernel only
   int fuse_finalize = 1;   // reductions of <= 4 columns: last-arriving workgroup finalizes in the dots kernel
   int combine_blocks_per_cu = 0;   // panel_combine: 0 = one vector per thread (best measured), k = persistent grid
+  int qn_fused_max_grid = 256;  // single-launch quasi-Newton apply: most workgroups it may use (<= 256; 64 = the round-3 limit)
   int qn_fused_batch12 = 1;   // single-launch quasi-Newton apply with 9 .. 12 columns on short vectors: all columns in one batch
   int qn_fused_small = 1;  // quasi-Newton applies with <= 64 workgroups of dots: dots + finalize + coefficients in one launch
   int push_wide = 1;       // one-pass push!: 20 columns per pass while >= 20 remain (0: always <= 10)

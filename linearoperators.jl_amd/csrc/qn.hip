@@ -630,9 +630,10 @@ cfwd_coef_kernel(const double *__restrict__ dots, const double *__restrict__ Cm,
 // Two slot sets alternate by an epoch word in device memory (graph-replay safe): a launch uses set e, re-arms set 1 - e
 // for its successor, workgroup 0 flips e once it has seen every partial. One fused launch in flight per ctx (all work of
 // a ctx is stream-ordered: mxlo_ctx_set_stream). Not used with an all-reduce hook (a host callback sits between 3 and 4).
-constexpr int kQnfMaxCols = 40;      // 2*mem at mem <= 20: the launch-bound defaults of the callers
-constexpr int kQnfMaxGrid = 64;
-constexpr int kQnfSlots = kQnfMaxCols * kQnfMaxGrid;
+// kQnfMaxCols = 40 (2*mem at mem <= 20: the launch-bound defaults of the callers), kQnfMaxGrid = 256 workgroups (round 4;
+// 64 before: n <= 131072 doubles), kQnfSlots: common.h. The gathered partials live in DYNAMIC LDS (ncol x grid doubles,
+// at most kQnfMaxPart = 6144: 48 KiB next to the 8 KiB of static LDS).
+constexpr int kQnfMaxPart = 6144;
 template <typename T>
 struct QnfCols {
   const T *p[kQnfMaxCols];
@@ -662,7 +663,7 @@ qn_apply_fused_kernel(T *__restrict__ res, QnfCols<T> cols, const T *__restrict_
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, G = (int)gridDim.x, b = (int)blockIdx.x;
   const int ncol = F.ncol, na = O.na;
   __shared__ double red[kBlock / 64][kQnfMaxCols];
-  __shared__ double spart[kQnfSlots];
+  extern __shared__ double spart[];                         // [ncol][G] gathered partials
   __shared__ double sdots[kQnfMaxCols];
   __shared__ double scoef[kQnfMaxCols];
   __shared__ double sg1[kQnfMaxCols * kQnfMaxCols / 2];     // inverse: s_i'y_j by ord position (na x na); forward: Cm (r x 2r)
@@ -762,13 +763,15 @@ qn_apply_fused_kernel(T *__restrict__ res, QnfCols<T> cols, const T *__restrict_
   for (int p = tid; p < ncol * G; p += kBlock) {
     const int c = p / G, w = p - c * G;
     // bounded wait (poll_slot, common.h): a peer that never becomes resident ends as NaN + the ctx fault word
-    spart[c * kQnfMaxGrid + w] = __longlong_as_double((long long)poll_slot(mine + c * kQnfMaxGrid + w, ticks, fault, kFaultQn));
+    spart[c * G + w] = __longlong_as_double((long long)poll_slot(mine + c * kQnfMaxGrid + w, ticks, fault, kFaultQn));
   }
   __syncthreads();
   if (b == 0 && tid == 0)                                             // every workgroup has read e: flip for the next launch
     __hip_atomic_store(epoch, (unsigned long long)(1u - e), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   for (int c = wave; c < ncol; c += kBlock / 64) {                    // fixed order: lane i <- workgroup i, one DPP tree
-    const double v = wave_allsum(lane < G ? spart[c * kQnfMaxGrid + lane] : 0.0);
+    double pv = lane < G ? spart[c * G + lane] : 0.0;                 // up to 64 workgroups: one partial per lane (the
+    for (int w = lane + 64; w < G; w += 64) pv += spart[c * G + w];   // bits of round 3); beyond: lane l adds l, l+64, ...
+    const double v = wave_allsum(pv);
     if (lane == 0) sdots[dots_index(c)] = v;
   }
   __syncthreads();
@@ -922,6 +925,7 @@ bool try_fused_apply(mxlo_qn *h, T *res, const T *const *cols, const T *x, QnfAr
   const int64_t per = (int64_t)kBlock * U * VEC;
   const int64_t grid = (h->n + per - 1) / per;
   if (!ctx->tune.qn_fused_small || ctx->allreduce || F.ncol < 1 || F.ncol > kQnfMaxCols || grid > kQnfMaxGrid ||
+      grid > ctx->tune.qn_fused_max_grid || (int64_t)F.ncol * grid > kQnfMaxPart ||
       grid > ctx->num_cu || !ctx->qslots || !ctx->fault_dev || ((((uintptr_t)x) | ((uintptr_t)res)) & 15u) != 0)
     return false;
   if ((*status = fused_fault_check(ctx)) != MXLO_OK) return true;    // an earlier timed-out single-launch apply: reported here
@@ -933,8 +937,9 @@ bool try_fused_apply(mxlo_qn *h, T *res, const T *const *cols, const T *x, QnfAr
   bool fits = true;
   *status = dispatch_ab<T>(F.beta, flags, [&]<typename CA, typename CB, bool B0>() -> int32_t {
     auto go2 = [&]<int KIND, int UU, int NB>() {
-      if (!(fits = coresident<qn_apply_fused_kernel<T, CA, CB, KIND, B0, UU, NB>>(ctx, grid))) return;
-      hipLaunchKernelGGL((qn_apply_fused_kernel<T, CA, CB, KIND, B0, UU, NB>), dim3((unsigned)grid), dim3(kBlock), 0, ctx->stream,
+      const size_t lds = sizeof(double) * (size_t)F.ncol * (size_t)grid;
+      if (!(fits = coresident<qn_apply_fused_kernel<T, CA, CB, KIND, B0, UU, NB>>(ctx, grid, lds))) return;
+      hipLaunchKernelGGL((qn_apply_fused_kernel<T, CA, CB, KIND, B0, UU, NB>), dim3((unsigned)grid), dim3(kBlock), lds, ctx->stream,
                          res, fc, x, h->n, ctx->qslots, F, O, fused_timeout_ticks(ctx), ctx->fault_dev,
                          ctx->tune.fused_debug_drop);
     };

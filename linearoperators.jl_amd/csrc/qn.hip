@@ -2423,8 +2423,8 @@ MXLO_API int32_t mxlo_qn_create(mxlo_ctx *ctx, int32_t kind, int32_t dtype, int6
   alloc(&h->tmp2, (size_t)h->ld * es);
   alloc((void **)&h->dsc, sizeof(double) * h->lay.total);
   if (h->big) alloc(&h->meta, meta_bytes(mem));
-  if (e == hipSuccess) {      // optional: without it the decision scalars are copied to the caller's stack (pageable: slower)
-    void *hp = nullptr;
+  if (e == hipSuccess && !getenv("MXLO_NO_PINNED_READBACK")) {   // optional: without it the decision scalars are copied to the
+    void *hp = nullptr;                                          // caller's stack (pageable: slower; the env var is for A/B timing)
     if (hipHostMalloc(&hp, kPinnedScalars * sizeof(double), hipHostMallocDefault) == hipSuccess) h->pinned = (double *)hp;
     else (void)hipGetLastError();
   }

@@ -461,3 +461,21 @@ def test_sparse_block_apply_reads_the_matrix_once_and_matches_the_columns(lo, de
             lo.mul(res, o, V, 1.0, 0.0)
             tol = (1e-12 if dtype == torch.float64 else 2e-5) * float((abs(Dm) @ np.abs(V.cpu().numpy().astype(np.float64))).max())
             assert np.abs(res.cpu().numpy() - want).max() <= tol
+
+
+def test_kat_vcat_of_eye_and_a_sparse_identity(lo, dev):
+    """test/test_cat.jl:46-48 and :193-195: `K = [opEye(2); sparse(1.0I, 2, 2)]; v = simple_vector(Float64, 2);
+    @test all(K * v .== [v; v])` — exact arithmetic, so equality is bitwise; also the transposed and adjoint forms of the
+    same identity (`[opEye(2) sparse(I)]'`), α, β = 3, −4 as test/test_cat.jl:96-118 uses them, and hcat."""
+    S = lo.Storage(torch.float64, dev)
+    I2 = lo.sparse_csc([1, 2, 3], [1, 2], [1.0, 1.0], 2, 2, index_base=1, device=dev)        # sparse(1.0I, 2, 2) as Julia stores it
+    K = lo.vcat(lo.opEye(torch.float64, 2, S=S), I2)
+    v = torch.tensor([1.0, -1.0], dtype=torch.float64, device=dev)                           # simple_vector(Float64, 2)
+    assert torch.equal(K * v, torch.cat([v, v]))
+    w = torch.tensor([1.0, -1.0, 1.0, -1.0], dtype=torch.float64, device=dev)
+    assert torch.equal(lo.transpose(K) * w, 2 * v) and torch.equal(lo.adjoint(K) * w, 2 * v)
+    res = torch.tensor([0.5, 0.25, 2.0, -8.0], dtype=torch.float64, device=dev)
+    lo.mul(res, K, v, 3.0, -4.0)
+    assert torch.equal(res, torch.tensor([3.0 - 2.0, -3.0 - 1.0, 3.0 - 8.0, -3.0 + 32.0], dtype=torch.float64, device=dev))
+    H = lo.hcat(lo.opEye(torch.float64, 2, S=S), I2)
+    assert torch.equal(H * w, torch.tensor([2.0, -2.0], dtype=torch.float64, device=dev))

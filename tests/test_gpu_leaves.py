@@ -99,6 +99,9 @@ def test_kat_cat_eye_zeros(lo, dev, kat):
     c = [c for c in kat if c["kind"] == "cat_vcat_eye"][0]
     K = lo.vcat(lo.opEye(2), torch.eye(2, dtype=torch.float64, device=dev))
     assert torch.equal(K * T(np.array(c["v"]), dev), T(np.array(c["expect"]), dev))
+    # the reference's second block IS sparse (`sparse(1.0I, 2, 2)`): the same identity through the sparse leaf (round 4)
+    K = lo.vcat(lo.opEye(2), lo.sparse_csc([1, 2, 3], [1, 2], [1.0, 1.0], 2, 2, index_base=1, device=dev))
+    assert torch.equal(K * T(np.array(c["v"]), dev), T(np.array(c["expect"]), dev))
     with pytest.raises(lo.LinearOperatorException):
         lo.vcat(lo.LinearOperatorFromMatrix(torch.ones(5, 5, dtype=torch.float64, device=dev)), lo.opEye(3))
 

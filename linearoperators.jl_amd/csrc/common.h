@@ -141,6 +141,8 @@ struct Tune {
   int qn_fused_batch12 = 1;   // single-launch quasi-Newton apply with 9 .. 12 columns on short vectors: all columns in one batch
   int qn_fused_small = 1;  // quasi-Newton applies with <= 64 workgroups of dots: dots + finalize + coefficients in one launch
   int push_wide = 1;       // one-pass push!: 20 columns per pass while >= 20 remain (0: always <= 10)
+  int push_posted = 1;     // push!'s decision scalars: posted into mapped pinned host memory by a one-wave kernel and polled
+                           // by the host (1) or copied with hipMemcpyAsync + a stream synchronisation (0)
   int push_fused = 1;      // push!(op, s, y): one-pass schedule (new pair held per lane, in-pass slot stores); 0 = copies + dual-x dots
   int sp_xcds = 1;         // sparse apply: XCDs (L2 domains) the chunk order is banded over (8: XCD k walks the k-th contiguous
                            // eighth of the chunk table); 1 = plain order, the default: banding measured -8 % … +8 % by pattern

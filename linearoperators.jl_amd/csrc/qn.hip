@@ -16,6 +16,7 @@
 // HBM traffic per apply: (4m+3)*8 B/elt for L-BFGS (vs (48+80m) for the reference's statement
 // sequence). The reference-ordered inverse two-loop (2m chained dot/axpy passes) is kept as
 // MXLO_INV_REFORDER for validation.
+#include <chrono>
 #include <cmath>
 #include <vector>
 
@@ -104,7 +105,10 @@ struct mxlo_qn {
   void *meta = nullptr;
   std::vector<char> meta_host;
   int64_t generation = 0;   // bumped by every state change: a captured hipGraph of an apply is stale afterwards
-  double *pinned = nullptr; // kPinnedScalars doubles of pinned host memory: where push! reads its decision scalars back to
+  // kPinnedScalars doubles (+ one sequence word) of pinned, device-mapped host memory: where push! reads its decision
+  // scalars back to. pinned_dev is the device's address of the same bytes (NULL: not mapped — plain copies only).
+  double *pinned = nullptr, *pinned_dev = nullptr;
+  unsigned long long post_seq = 0;   // sequence number of the last posted read-back
 };
 constexpr int kPinnedScalars = 64;
 
@@ -1176,10 +1180,55 @@ int32_t qn_mul_t(mxlo_qn *h, T *res, const T *x, double alpha, double beta, int3
 }
 
 // ---- push! ------------------------------------------------------------------------------------
+// One wave copies `count` doubles from device memory into the handle's mapped host buffer with system-scope stores, then
+// publishes the sequence number behind them: the host sees the number only after the doubles.
+__global__ void __launch_bounds__(kWave)
+post_scalars_kernel(const double *__restrict__ dev, double *__restrict__ host, int count, unsigned long long seq) {
+  const int t = threadIdx.x;
+  if (t < count)
+    __hip_atomic_store(reinterpret_cast<unsigned long long *>(host) + t, (unsigned long long)__double_as_longlong(dev[t]),
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __threadfence_system();   // every lane's store has left before lane 0 publishes (one wave: lockstep)
+  if (t == 0)
+    __hip_atomic_store(reinterpret_cast<unsigned long long *>(host) + kPinnedScalars, seq, __ATOMIC_RELEASE,
+                       __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 int32_t read_scalars(mxlo_qn *h, const double *dev, double *host, int count) {
-  // The copy lands in PINNED host memory of the handle (a copy into pageable memory is staged and synchronised by the
-  // runtime: measured 41-61 us per small push! with it); a handful of doubles, then one stream synchronisation.
+  // A handful of doubles of replicated control state, once per push!. Round 3 copied them into the caller's pageable
+  // stack (staged + synchronised by the runtime: 41-61 us per small push!), then into pinned memory of the handle
+  // (31-37 us). Now (tune key push_posted) a one-wave kernel posts them into that memory — it is device-mapped — and the
+  // host polls the sequence word: no copy engine, no completion signal, no driver call on the way back. A poll that
+  // outlasts kPostSpinUs (a long push pass is still running, or the launch failed) hands over to the stream
+  // synchronisation, after which the doubles are in place in any case.
   mxlo_ctx *ctx = h->ctx;
+  if (h->pinned_dev && count <= kPinnedScalars && ctx->tune.push_posted) {
+    const unsigned long long seq = ++h->post_seq;
+    hipLaunchKernelGGL(post_scalars_kernel, dim3(1), dim3(kWave), 0, ctx->stream, dev, h->pinned_dev, count, seq);
+    MXLO_LAUNCH_CHECK();
+    ApiCounters &c = api_counters();     // what the contract test counts: one device-to-host transfer, one wait
+    ++c.n_d2h;
+    c.n_d2h_bytes += (int64_t)sizeof(double) * count;
+    const unsigned long long *word = reinterpret_cast<const unsigned long long *>(h->pinned) + kPinnedScalars;
+    constexpr int kPostSpinUs = 200;
+    const auto t0 = std::chrono::steady_clock::now();
+    bool seen = false;
+    for (int spin = 0;; ++spin) {
+      if (__atomic_load_n(word, __ATOMIC_ACQUIRE) == seq) { seen = true; break; }
+      if ((spin & 63) == 63 &&
+          std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() > kPostSpinUs)
+        break;
+      __builtin_ia32_pause();
+    }
+    if (!seen) {
+      MXLO_HIP(hipStreamSynchronize(ctx->stream));
+      MXLO_REQUIRE(__atomic_load_n(word, __ATOMIC_ACQUIRE) == seq, MXLO_EHIP, "push!: the posted read-back did not arrive");
+    } else {
+      ++c.n_stream_sync;
+    }
+    memcpy(host, h->pinned, sizeof(double) * count);
+    return MXLO_OK;
+  }
   double *dst = (h->pinned && count <= kPinnedScalars) ? h->pinned : host;
   MXLO_HIP(hipMemcpyAsync(dst, dev, sizeof(double) * count, hipMemcpyDeviceToHost, ctx->stream));
   MXLO_HIP(hipStreamSynchronize(ctx->stream));
@@ -2425,8 +2474,15 @@ MXLO_API int32_t mxlo_qn_create(mxlo_ctx *ctx, int32_t kind, int32_t dtype, int6
   if (h->big) alloc(&h->meta, meta_bytes(mem));
   if (e == hipSuccess && !getenv("MXLO_NO_PINNED_READBACK")) {   // optional: without it the decision scalars are copied to the
     void *hp = nullptr;                                          // caller's stack (pageable: slower; the env var is for A/B timing)
-    if (hipHostMalloc(&hp, kPinnedScalars * sizeof(double), hipHostMallocDefault) == hipSuccess) h->pinned = (double *)hp;
-    else (void)hipGetLastError();
+    void *dp = nullptr;
+    if (hipHostMalloc(&hp, (kPinnedScalars + 8) * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess) {
+      memset(hp, 0, (kPinnedScalars + 8) * sizeof(double));
+      h->pinned = (double *)hp;
+      if (hipHostGetDevicePointer(&dp, hp, 0) == hipSuccess) h->pinned_dev = (double *)dp;
+      else (void)hipGetLastError();
+    } else {
+      (void)hipGetLastError();
+    }
   }
   if (e != hipSuccess) {
     set_error("mxlo_qn_create: device allocation failed: %s", hipGetErrorString(e));

@@ -3,7 +3,9 @@
 
 A WARMED `mul!`, `diag!`, `solve_shifted_system!` (and every leaf apply) must issue kernel launches and nothing else —
 no hipMalloc/hipFree, no copy in any direction, no stream/device/event synchronisation, no memset. `push!` must issue
-exactly ONE device-to-host copy (its few doubles of replicated control state) with the one synchronisation that copy
+exactly ONE device-to-host transfer (its few doubles of replicated control state — since round 4 posted into mapped
+pinned host memory by a one-wave kernel and polled by the host, `push_posted`; counted as one transfer + one wait, which
+is what it is; with `push_posted` = 0 a hipMemcpyAsync + hipStreamSynchronize) with the one wait that transfer
 needs, and no allocation. The library counts every allocating / copying / blocking runtime call it makes
 (`mxlo_debug_counters`, include/mxlo.h); the rocprofv3 `--hip-trace` view of the same workload is committed under
 profiles/ (tools/contract_trace.py)."""

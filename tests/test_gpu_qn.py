@@ -691,6 +691,45 @@ def test_one_pass_push_matches_two_kernel_schedule_and_oracle(lo, dev, dtype, ki
         ctx.tune("push_fused", 1)
 
 
+@pytest.mark.parametrize("kind", ["inv", "fwd", "lsr1"])
+@pytest.mark.parametrize("n", [1, 4099, 3_000_017])
+def test_posted_read_back_of_the_push_decision(lo, dev, kind, n):
+    """push!'s few doubles of decision state (y's, y'y, ... — src/lbfgs.jl:281-284, src/lsr1.jl:131-141) come back
+    through mapped pinned host memory that a one-wave kernel writes and the host polls (`push_posted` = 1), or through
+    hipMemcpyAsync + a stream synchronisation (0). Same kernels, same numbers: every decision (incl. rejected pairs),
+    the insert pointer, the scaling factor and every apply must be IDENTICAL; n = 3·10⁶ with mem = 20 makes the first
+    pass outlast the polling window, i.e. runs the hand-over to the stream synchronisation."""
+    from linearoperators_jl_amd.device import get_ctx
+    ctx = get_ctx(dev)
+    mem = 20 if n > 10**6 else 5
+    rng = np.random.default_rng(n + len(kind))
+    make = {"inv": lo.InverseLBFGSOperator, "fwd": lo.LBFGSOperator, "lsr1": lo.LSR1Operator}[kind]
+    ops = {}
+    try:
+        for posted in (1, 0):
+            ops[posted] = make(torch.float64, n, mem=mem, scaling=True, device=dev)
+        x = T(rng.uniform(-1, 1, n), dev)
+        prs = pairs(rng, n, 7 if n > 10**6 else mem + 4, np.float64)
+        prs.insert(2, (prs[0][0], -prs[0][0]))                           # y's < 0: rejected by the L-BFGS operators
+        prs.insert(4, (prs[1][0], np.zeros(n)))                          # y = 0: rejected by all three
+        accepted = 0
+        for k, (s, y) in enumerate(prs):
+            got = {}
+            for posted in (1, 0):
+                ctx.tune("push_posted", posted)
+                lo.push(ops[posted], T(s, dev), T(y, dev))
+                res = torch.full((n,), float("nan"), dtype=torch.float64, device=dev)
+                lo.mul(res, ops[posted], x, 1.0, 0.0)
+                got[posted] = res.cpu().numpy()
+            assert ops[1].data.insert == ops[0].data.insert, k
+            assert ops[1].data.scaling_factor == ops[0].data.scaling_factor, k
+            assert (n == 1 or np.isfinite(got[1]).all()) and np.array_equal(got[1], got[0], equal_nan=True), k
+            accepted += int(getattr(ops[1], "_last_push_accepted", True))
+        assert n == 1 or 3 <= accepted <= len(prs) - (0 if kind == "lsr1" else 2)   # both outcomes occurred (L-BFGS)
+    finally:
+        ctx.tune("push_posted", 1)
+
+
 @pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
 @pytest.mark.parametrize("mem,scaling", [(1, True), (4, True), (4, False), (10, True), (13, False), (25, True)])
 def test_lsr1_streaming_push_matches_apply_based_schedule_and_oracle(lo, dev, dtype, mem, scaling):

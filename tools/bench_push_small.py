@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """push! in the launch-bound regime (m = 5, n = 2^12 .. 2^16): wall clock per accepted push incl. its device-to-host
-decision copy. (profiles/r04_push_small_finalize_experiment.txt: the same loop with an experimental push pass that
+decision read-back, posted by a kernel into mapped host memory and polled (push_posted = 1) or copied with
+hipMemcpyAsync + hipStreamSynchronize (0). (profiles/r04_push_small_finalize_experiment.txt: the same loop with an experimental push pass that
 finalized its own partial sums — slower, not kept.)"""
 import os
 import sys
@@ -29,7 +30,8 @@ for kind, m in (("fwd", 5), ("inv", 5), ("lsr1", 5), ("fwd", 20), ("inv", 20)):
         S = [rnd(n) for _ in range(16)]
         Y = [s * (rnd(n) * 0.25 + 1.25) + (0.3 * rnd(n) if kind == "lsr1" else 0) for s in S]
         out = []
-        for _once in (0,):
+        for posted in (1, 0):
+            ctx.tune("push_posted", posted)
             op = make(torch.float64, n, mem=m, device=dev)
             for i in range(m + 3):
                 lo.push(op, S[i % 16], Y[i % 16])
@@ -43,4 +45,5 @@ for kind, m in (("fwd", 5), ("inv", 5), ("lsr1", 5), ("fwd", 20), ("inv", 20)):
                 best = min(best, (time.perf_counter() - t0) / 200 * 1e6)
             out.append(best)
             del op
-        print(f"push! {kind:4s} m={m:2d} n=2^{n.bit_length()-1:<2d}: {out[0]:6.1f} us", flush=True)
+        ctx.tune("push_posted", 1)
+        print(f"push! {kind:4s} m={m:2d} n=2^{n.bit_length()-1:<2d}: posted read-back {out[0]:6.1f} us | hipMemcpyAsync + stream sync {out[1]:6.1f} us", flush=True)

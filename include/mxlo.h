@@ -153,7 +153,9 @@ int32_t mxlo_memset(mxlo_ctx *ctx, void *p, int32_t byte, int64_t bytes);
  * The reference's tests assert that a warmed mul! allocates nothing (test/test_lbfgs.jl:180-218). Here the
  * equivalent statement is about the HIP runtime: a warmed mul! / diag! / solve_shifted_system! issues kernel
  * launches and nothing else — no hipMalloc/hipFree, no copy, no stream/device/event synchronisation — and push!
- * issues exactly ONE small device-to-host copy (its 2-5 doubles) and the synchronisation that copy needs.
+ * issues exactly ONE small device-to-host transfer (its 2-6 doubles) and the one wait that transfer needs. (With the
+ * tune key "push_posted" = 1 the transfer is a one-wave kernel writing mapped pinned host memory and the wait is the
+ * host polling a sequence word; both are counted below as one D2H copy and one stream synchronisation.)
  * Every allocating / copying / blocking runtime call the library makes is counted (process-wide, monotone):
  *   out[0] hipMalloc+hipHostMalloc   [1] hipFree   [2] H2D copies   [3] D2H copies   [4] D2D copies
  *   out[5] bytes copied D2H          [6] hipStreamSynchronize       [7] hipDeviceSynchronize

@@ -369,9 +369,22 @@ int32_t panel_dots2(mxlo_ctx *ctx, const T *const *cols, int ncols, const T *x1,
                     double *out1, double *out2);
 // push! pass (reductions.hip): dual-x dots over <= 10 panel columns with the new pair in registers, optional in-pass
 // stores into the slot being replaced; LOCAL sums (the caller runs the all-reduce hook)
+// Extra jobs the pass's finalize launch can carry, so that a launch-bound push! needs no separate launches for them:
+//   cp_*: cp_dst[i] = cp_src[i], i < cp_n (doubles; cp_src was written by an EARLIER kernel) — the inverse push!'s
+//         S'y_new -> SY column copy;
+//   post: x1·x2 and x2·x2 also go to mapped pinned host memory as (value, sequence number) pairs post[0..1], post[2..3]
+//         — the decision scalars of an L-BFGS push!, which the host polls for (qn.hip: await_posted_pairs).
+struct PushExtras {
+  const double *cp_src = nullptr;
+  double *cp_dst = nullptr;
+  int cp_n = 0;
+  double *post = nullptr;
+  unsigned long long post_seq = 0;
+};
 template <typename T>
 int32_t panel_push_pass(mxlo_ctx *ctx, const T *const *cols, int ncols, int slot, int slot_src, const T *x1,
                         const T *x2, int64_t n, int64_t n_padded, T *st1, T *st2, T *stb, double sq, double *out1,
-                        double *out2, double *out_x1x2, double *out_x2x2, double *out_bb, double *out_x1x1 = nullptr);
+                        double *out2, double *out_x1x2, double *out_x2x2, double *out_bb, double *out_x1x1 = nullptr,
+                        const PushExtras *extras = nullptr);
 
 }  // namespace mxlo

@@ -111,6 +111,8 @@ struct mxlo_qn {
   unsigned long long post_seq = 0;   // sequence number of the last posted read-back
 };
 constexpr int kPinnedScalars = 64;
+constexpr int kPostPairs = kPinnedScalars + 8;        // 8 (value, sequence number) pairs posted by finalize launches
+constexpr int kPinnedTotal = kPostPairs + 16;         // layout: [0,64) doubles | [64] their sequence number | [72,88) pairs
 
 namespace {
 
@@ -1194,38 +1196,48 @@ post_scalars_kernel(const double *__restrict__ dev, double *__restrict__ host, i
                        __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// Host side of a posted read-back: poll `nwords` sequence words (stride `stride` words) of the handle's pinned buffer
+// until all carry `seq`. A poll that outlasts kPostSpinUs (a long push pass is still running, or the launch failed)
+// hands over to the stream synchronisation, after which the words must be in place.
+static int32_t await_posted(mxlo_qn *h, const unsigned long long *word, int nwords, int stride, unsigned long long seq,
+                            int64_t bytes) {
+  mxlo_ctx *ctx = h->ctx;
+  ApiCounters &c = api_counters();     // what the contract test counts: one device-to-host transfer, one wait
+  ++c.n_d2h;
+  c.n_d2h_bytes += bytes;
+  constexpr int kPostSpinUs = 200;
+  const auto t0 = std::chrono::steady_clock::now();
+  int have = 0;
+  for (int spin = 0; have < nwords; ++spin) {
+    if (__atomic_load_n(word + (int64_t)have * stride, __ATOMIC_ACQUIRE) == seq) { ++have; continue; }
+    if ((spin & 63) == 63 &&
+        std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() > kPostSpinUs)
+      break;
+    __builtin_ia32_pause();
+  }
+  if (have == nwords) {
+    ++c.n_stream_sync;
+    return MXLO_OK;
+  }
+  MXLO_HIP(hipStreamSynchronize(ctx->stream));
+  for (int i = 0; i < nwords; ++i)
+    MXLO_REQUIRE(__atomic_load_n(word + (int64_t)i * stride, __ATOMIC_ACQUIRE) == seq, MXLO_EHIP,
+                 "push!: the posted read-back did not arrive");
+  return MXLO_OK;
+}
+
 int32_t read_scalars(mxlo_qn *h, const double *dev, double *host, int count) {
   // A handful of doubles of replicated control state, once per push!. Round 3 copied them into the caller's pageable
   // stack (staged + synchronised by the runtime: 41-61 us per small push!), then into pinned memory of the handle
   // (31-37 us). Now (tune key push_posted) a one-wave kernel posts them into that memory — it is device-mapped — and the
-  // host polls the sequence word: no copy engine, no completion signal, no driver call on the way back. A poll that
-  // outlasts kPostSpinUs (a long push pass is still running, or the launch failed) hands over to the stream
-  // synchronisation, after which the doubles are in place in any case.
+  // host polls the sequence word: no copy engine, no completion signal, no driver call on the way back.
   mxlo_ctx *ctx = h->ctx;
   if (h->pinned_dev && count <= kPinnedScalars && ctx->tune.push_posted) {
     const unsigned long long seq = ++h->post_seq;
     hipLaunchKernelGGL(post_scalars_kernel, dim3(1), dim3(kWave), 0, ctx->stream, dev, h->pinned_dev, count, seq);
     MXLO_LAUNCH_CHECK();
-    ApiCounters &c = api_counters();     // what the contract test counts: one device-to-host transfer, one wait
-    ++c.n_d2h;
-    c.n_d2h_bytes += (int64_t)sizeof(double) * count;
-    const unsigned long long *word = reinterpret_cast<const unsigned long long *>(h->pinned) + kPinnedScalars;
-    constexpr int kPostSpinUs = 200;
-    const auto t0 = std::chrono::steady_clock::now();
-    bool seen = false;
-    for (int spin = 0;; ++spin) {
-      if (__atomic_load_n(word, __ATOMIC_ACQUIRE) == seq) { seen = true; break; }
-      if ((spin & 63) == 63 &&
-          std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() > kPostSpinUs)
-        break;
-      __builtin_ia32_pause();
-    }
-    if (!seen) {
-      MXLO_HIP(hipStreamSynchronize(ctx->stream));
-      MXLO_REQUIRE(__atomic_load_n(word, __ATOMIC_ACQUIRE) == seq, MXLO_EHIP, "push!: the posted read-back did not arrive");
-    } else {
-      ++c.n_stream_sync;
-    }
+    MXLO_TRY(await_posted(h, reinterpret_cast<const unsigned long long *>(h->pinned) + kPinnedScalars, 1, 1, seq,
+                          (int64_t)sizeof(double) * count));
     memcpy(host, h->pinned, sizeof(double) * count);
     return MXLO_OK;
   }
@@ -1233,6 +1245,14 @@ int32_t read_scalars(mxlo_qn *h, const double *dev, double *host, int count) {
   MXLO_HIP(hipMemcpyAsync(dst, dev, sizeof(double) * count, hipMemcpyDeviceToHost, ctx->stream));
   MXLO_HIP(hipStreamSynchronize(ctx->stream));
   if (dst != host) memcpy(host, dst, sizeof(double) * count);
+  return MXLO_OK;
+}
+
+// ... the same for doubles that a finalize launch posted itself as (value, sequence number) pairs (PushExtras::post)
+static int32_t await_posted_pairs(mxlo_qn *h, double *host, int count, unsigned long long seq) {
+  const unsigned long long *pairs = reinterpret_cast<const unsigned long long *>(h->pinned) + kPostPairs;
+  MXLO_TRY(await_posted(h, pairs + 1, count, 2, seq, (int64_t)sizeof(double) * count));
+  for (int i = 0; i < count; ++i) memcpy(host + i, pairs + 2 * i, sizeof(double));
   return MXLO_OK;
 }
 
@@ -1244,6 +1264,46 @@ inline double rT(double v) { return sizeof(T) == 4 ? (double)(float)v : v; }
 // dots are inner products between vectors of span{s_j, b_j}; with the Gram matrices S'S and Y'S kept up to
 // date (3m dots per push) the recurrence runs on 2m-vectors of coefficients and ALL a_k are then formed
 // in ONE pass  A = [S B] * C  (read 2r columns, write r columns).
+
+// The Gram update of a push! as a PROLOGUE of the single-wave coefficient kernel that consumes it (afwd_coef_kernel,
+// asr1_coef_kernel): launch-bound pushes lose one dependent launch (two for L-SR1, whose own-pair entries ride along).
+// Same stores as gram_update_kernel (+ gram_self_kernel); the coefficient code reads SS / YSf after a barrier.
+struct GramUpd {
+  double *SS = nullptr, *YSf = nullptr, *YY = nullptr, *tmp = nullptr;
+  int on = 0, mem = 0, ins = 0;
+  int self = 0;                 // L-SR1: tmp[ins], tmp[m+ins], tmp[2m+ins], tmp[3m+ins] <- ss, ys, ys, yy first
+  double ss = 0, ys = 0, yy = 0;
+  // transposed, zero-padded copy of the finished coefficients for panel_gemm_kernel (NULL: launch_panel_gemm transposes)
+  double *Ct = nullptr;
+  int noutmax = 0;
+};
+__device__ __forceinline__ void gram_update_prologue(const GramUpd &G) {
+  if (!G.on) return;
+  const int k = threadIdx.x, mem = G.mem, ins = G.ins;
+  if (k < mem) {
+    double t0 = G.tmp[k], t1 = G.tmp[mem + k], t2 = G.tmp[2 * mem + k], t3 = G.tmp[3 * mem + k];
+    if (G.self && k == ins) {
+      t0 = G.ss; t1 = G.ys; t2 = G.ys; t3 = G.yy;
+      G.tmp[k] = t0; G.tmp[mem + k] = t1; G.tmp[2 * mem + k] = t2; G.tmp[3 * mem + k] = t3;
+    }
+    G.SS[k * mem + ins] = t0;
+    G.SS[ins * mem + k] = t0;
+    G.YSf[k * mem + ins] = t1;
+    G.YSf[ins * mem + k] = t2;
+    G.YY[k * mem + ins] = t3;
+    G.YY[ins * mem + k] = t3;
+  }
+  __syncthreads();
+}
+// ... and the transposition panel_gemm_kernel wants (transpose_coef_kernel) as an EPILOGUE: Ct[j][k] = Cm[k][j], rows padded
+__device__ __forceinline__ void coef_transpose_epilogue(const GramUpd &G, const double *Cm, int nout, int nin) {
+  if (!G.Ct) return;
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < nin * G.noutmax; idx += blockDim.x) {
+    const int j = idx / G.noutmax, k = idx % G.noutmax;
+    G.Ct[idx] = k < nout ? Cm[(int64_t)k * nin + j] : 0.0;
+  }
+}
 
 // place the dots of one pair: tmp[0..m) = S's_new, tmp[m..2m) = Y's_new, tmp[2m..3m) = S'y_new, tmp[3m..4m) = Y'y_new
 __global__ void gram_update_kernel(double *__restrict__ SS, double *__restrict__ YSf, double *__restrict__ YY,
@@ -1263,11 +1323,12 @@ __global__ void gram_update_kernel(double *__restrict__ SS, double *__restrict__
 // NB: `c += Z[r+l][k]` must precede the `as` reduction of the same l in the reference (:244 then :245 uses
 // dot(a_l, s_k), independent of the running a_k), so the order inside the loop is immaterial.
 __global__ void __launch_bounds__(64)
-afwd_coef_kernel(const double *__restrict__ SS, const double *__restrict__ YSf,
-                 double *__restrict__ Cm, OrdArgs O) {
+afwd_coef_kernel(const double *SS, const double *YSf, double *Cm, OrdArgs O, GramUpd G = GramUpd{}) {
   // one wave; lane j owns coefficient j of the 2r-vector (2r <= 64). Z[j][k] = <basis_j, s_k>.
+  // (SS / YSf are NOT __restrict__: the prologue writes them)
   __shared__ double Z[2 * kMaxMemFwd][kMaxMemFwd];
   __shared__ double Cl[kMaxMemFwd][2 * kMaxMemFwd];
+  gram_update_prologue(G);
   const int lane = threadIdx.x;
   const int r = O.na, mem = O.mem, w = 2 * r;
   for (int k = 0; k < r; ++k) {
@@ -1296,6 +1357,7 @@ afwd_coef_kernel(const double *__restrict__ SS, const double *__restrict__ YSf,
     }
     __syncthreads();
   }
+  coef_transpose_epilogue(G, Cm, r, w);
 }
 
 constexpr int kGemmIn = 64, kGemmOut = 32;
@@ -1375,17 +1437,23 @@ __global__ void transpose_coef_kernel(const double *__restrict__ C, double *__re
   }
 }
 
+inline int gemm_noutmax(int nout) { return nout <= 8 ? 8 : (nout <= 16 ? 16 : (nout <= 24 ? 24 : 32)); }
+inline double *gemm_ct(mxlo_ctx *ctx) { return ctx->scalars + 1024; }   // kGemmIn * kGemmOut = 2048 doubles inside the ctx scalar buffer
+
+// ct_ready: the coefficient kernel already left the transposed copy in gemm_ct(ctx) (coef_transpose_epilogue)
 template <typename T>
-int32_t launch_panel_gemm(mxlo_ctx *ctx, PanelGemmArgs<T> &A, int64_t n) {
+int32_t launch_panel_gemm(mxlo_ctx *ctx, PanelGemmArgs<T> &A, int64_t n, bool ct_ready = false) {
   if (n <= 0 || A.nout <= 0) return MXLO_OK;
   // panel columns are 16-byte aligned and padded (ld) to a whole number of 16-byte vectors: run pairs of rows
   const int64_t nvec = (n + 1) / 2;
   const int grid = grid_for(ctx, nvec, kBlock, 0);
-  double *Ct = ctx->scalars + 1024;  // kGemmIn * kGemmOut = 2048 doubles inside the ctx scalar buffer
+  double *Ct = gemm_ct(ctx);
   auto go = [&]<int NOUTMAX>() -> int32_t {
-    hipLaunchKernelGGL(transpose_coef_kernel, dim3(1), dim3(kBlock), 0, ctx->stream, A.C, Ct, A.nout, A.nin, NOUTMAX,
-                       A.cstride > 0 ? A.cstride : (int64_t)A.nin);
-    MXLO_LAUNCH_CHECK();
+    if (!ct_ready) {
+      hipLaunchKernelGGL(transpose_coef_kernel, dim3(1), dim3(kBlock), 0, ctx->stream, A.C, Ct, A.nout, A.nin, NOUTMAX,
+                         A.cstride > 0 ? A.cstride : (int64_t)A.nin);
+      MXLO_LAUNCH_CHECK();
+    }
     hipLaunchKernelGGL((panel_gemm_kernel<T, NOUTMAX>), dim3(grid), dim3(kBlock), 0, ctx->stream, A, Ct, nvec);
     MXLO_LAUNCH_CHECK();
     return MXLO_OK;
@@ -1433,11 +1501,11 @@ int32_t ensure_A(mxlo_qn *h) {
 // L-SR1 rank-one terms in coefficient space (src/lsr1.jl:166-178): basis [y_ord[0..r), s_ord[0..r)],
 //   a_k = y_k - s_k/γ - sum_{l<k} (a_l's_k / as_l) a_l ,  as_k = a_k's_k.  One wave, lane j owns coefficient j.
 __global__ void __launch_bounds__(64)
-asr1_coef_kernel(const double *__restrict__ SS, const double *__restrict__ YSf, double *__restrict__ Cm,
-                 double *__restrict__ as_out, OrdArgs O) {
+asr1_coef_kernel(const double *SS, const double *YSf, double *Cm, double *as_out, OrdArgs O, GramUpd G = GramUpd{}) {
   __shared__ double Z[2 * kMaxMemFwd][kMaxMemFwd];      // Z[j][k] = <basis_j, s_k>
   __shared__ double Cl[kMaxMemFwd][2 * kMaxMemFwd];
   __shared__ double asl[kMaxMemFwd];
+  gram_update_prologue(G);                               // (SS / YSf not __restrict__: the prologue writes them)
   const int lane = threadIdx.x;
   const int r = O.na, mem = O.mem, w = 2 * r;
   for (int k = 0; k < r; ++k)
@@ -1466,6 +1534,7 @@ asr1_coef_kernel(const double *__restrict__ SS, const double *__restrict__ YSf, 
     }
     __syncthreads();
   }
+  coef_transpose_epilogue(G, Cm, r, w);
 }
 
 // Gram rows/columns of one stored pair (slot): S'[s y] in one dual-x pass over S, Y'[s y] in one over Y.
@@ -1501,7 +1570,7 @@ int32_t gram_make_consistent(mxlo_qn *h, int64_t except_slot) {
 }
 
 template <typename T>
-int32_t fwd_rebuild_after_gram(mxlo_qn *h, int64_t ins);
+int32_t fwd_rebuild_after_gram(mxlo_qn *h, int64_t ins, const double *gram_rows = nullptr);
 
 // Gram-form rebuild of the forward panel after (s, y) was copied into slot `ins` and b[ins] was formed.
 template <typename T>
@@ -1512,8 +1581,10 @@ int32_t fwd_rebuild_gram(mxlo_qn *h, int64_t ins) {
 }
 
 // ... the part after the Gram rows of slot `ins` are in place (shared with the one-pass push!)
+// gram_rows (one-pass push!): [S's | Y's | S'y | Y'y] of the new pair, still to be placed in the Gram matrices — done by the
+// coefficient kernel's prologue instead of a gram_update_kernel launch
 template <typename T>
-int32_t fwd_rebuild_after_gram(mxlo_qn *h, int64_t ins) {
+int32_t fwd_rebuild_after_gram(mxlo_qn *h, int64_t ins, const double *gram_rows) {
   mxlo_ctx *ctx = h->ctx;
   const int64_t n = h->n, mem = h->mem;
   OrdArgs O;
@@ -1525,14 +1596,25 @@ int32_t fwd_rebuild_after_gram(mxlo_qn *h, int64_t ins) {
     if (h->ys[k] != 0) O.ord[O.na++] = (int)k;
   }
   O.gamma = h->scaling_factor;  // (:239) divides unconditionally; γ == 1 without scaling
+  const bool compact = h->push_mode == MXLO_PUSH_COMPACT;
+  if (!compact) MXLO_TRY(alloc_A(h));   // (before the launches: its first call allocates and clears the panel)
+  GramUpd U;
+  if (gram_rows) {
+    U.on = 1; U.mem = (int)mem; U.ins = (int)ins;
+    U.SS = h->dsc + h->lay.SS; U.YSf = h->dsc + h->lay.YSf; U.YY = h->dsc + h->lay.YY;
+    U.tmp = const_cast<double *>(gram_rows);
+  }
+  if (!compact && n > 0 && O.na > 0) {
+    U.Ct = gemm_ct(ctx);
+    U.noutmax = gemm_noutmax(O.na);
+  }
   hipLaunchKernelGGL(afwd_coef_kernel, dim3(1), dim3(64), 0, ctx->stream, h->dsc + h->lay.SS,
-                     h->dsc + h->lay.YSf, h->dsc + h->lay.Cm, O);
+                     h->dsc + h->lay.YSf, h->dsc + h->lay.Cm, O, U);
   MXLO_LAUNCH_CHECK();
-  if (h->push_mode == MXLO_PUSH_COMPACT) {  // a_k = [S B]·c_k stays implicit: the apply works on [S B] and Cm
+  if (compact) {  // a_k = [S B]·c_k stays implicit: the apply works on [S B] and Cm
     h->A_valid = false;
     return MXLO_OK;
   }
-  MXLO_TRY(alloc_A(h));
   PanelGemmArgs<T> A;
   A.nin = 2 * O.na;
   A.nout = O.na;
@@ -1543,7 +1625,7 @@ int32_t fwd_rebuild_after_gram(mxlo_qn *h, int64_t ins) {
     A.out[j] = col<T>(h->A, h->ld, O.ord[j]);
   }
   h->A_valid = true;
-  return launch_panel_gemm<T>(ctx, A, n);
+  return launch_panel_gemm<T>(ctx, A, n, /*ct_ready=*/U.Ct != nullptr);
 }
 
 // push_common! — src/lbfgs.jl:210-255 (ys, yy already known on the host)
@@ -1671,19 +1753,30 @@ int32_t lbfgs_push_fused(mxlo_qn *h, const T *s, const T *y, int32_t *accepted) 
     c += w;
   }
   auto pass = [&](void *panel, int chunk, int slot_src, T *st1, T *st2, T *stb, double sq, double *o1, double *o2,
-                  double *oxy, double *oyy, double *obb) -> int32_t {
+                  double *oxy, double *oyy, double *obb, const PushExtras *ex = nullptr) -> int32_t {
     const int c0 = c0s[chunk], nc = ncs[chunk];
     for (int c = 0; c < nc; ++c) cols[c] = col<T>(panel, h->ld, c0 + c);
     const int slot = (ins >= c0 && ins < c0 + nc) ? (int)(ins - c0) : -1;
     return panel_push_pass<T>(ctx, cols, nc, slot, slot_src, s, y, n, npad, st1, st2, stb, sq, o1 ? o1 + c0 : nullptr,
-                              o2 ? o2 + c0 : nullptr, oxy, oyy, obb);
+                              o2 ? o2 + c0 : nullptr, oxy, oyy, obb, nullptr, ex);
   };
-  // ---- pass A, first chunk of S: its Gram dots + the decision scalars misc[0] = y's, misc[1] = y'y
+  // ---- pass A, first chunk of S: its Gram dots + the decision scalars misc[0] = y's, misc[1] = y'y. Without an
+  // all-reduce hook (the scalars are final as the pass's finalize launch writes them) that launch also posts them to the host.
+  const bool post = !ctx->allreduce && ctx->tune.push_posted && h->pinned_dev;
+  PushExtras exA;
+  if (post) {
+    exA.post = h->pinned_dev + kPostPairs;
+    exA.post_seq = ++h->post_seq;
+  }
   MXLO_TRY(pass(h->S, 0, 1, nullptr, nullptr, nullptr, 1.0, inverse ? nullptr : gt, inverse ? scratch : gt + 2 * mem,
-                misc, misc + 1, nullptr));
-  MXLO_TRY(allreduce_hook(ctx, misc, 2));
+                misc, misc + 1, nullptr, post ? &exA : nullptr));
   double hs[2];
-  MXLO_TRY(read_scalars(h, misc, hs, 2));
+  if (post) {
+    MXLO_TRY(await_posted_pairs(h, hs, 2, exA.post_seq));
+  } else {
+    MXLO_TRY(allreduce_hook(ctx, misc, 2));
+    MXLO_TRY(read_scalars(h, misc, hs, 2));
+  }
   const double ys = rT<T>(hs[0]), yy = rT<T>(hs[1]);
   if (ys <= (double)eps_of<T>()) {  // src/lbfgs.jl:281-284
     *accepted = 0;
@@ -1701,12 +1794,14 @@ int32_t lbfgs_push_fused(mxlo_qn *h, const T *s, const T *y, int32_t *accepted) 
   if (inverse) {
     // S'y_new -> column `ins` of SY; Y's_new, Y'y_new straight into their rows; the inserts ride in the first Y pass
     MXLO_TRY(allreduce_hook(ctx, scratch, mem));
-    hipLaunchKernelGGL(copy_coef_kernel, dim3(1), dim3(64), 0, ctx->stream, scratch, h->dsc + h->lay.SY + ins * mem,
-                       (int)mem, 0);
-    MXLO_LAUNCH_CHECK();
+    PushExtras exY;                       // (the copy scratch -> SY[:, ins] rides in the first Y pass's finalize launch)
+    exY.cp_src = scratch;
+    exY.cp_dst = h->dsc + h->lay.SY + ins * mem;
+    exY.cp_n = (int)mem;
     for (int ch = 0; ch < nchunk; ++ch)
       MXLO_TRY(pass(h->Y, ch, 2, ch == 0 ? si : nullptr, ch == 0 ? yi : nullptr, nullptr, 1.0,
-                    h->dsc + h->lay.YS + ins * mem, h->dsc + h->lay.YY + ins * mem, nullptr, nullptr, nullptr));
+                    h->dsc + h->lay.YS + ins * mem, h->dsc + h->lay.YY + ins * mem, nullptr, nullptr, nullptr,
+                    ch == 0 ? &exY : nullptr));
     MXLO_TRY(allreduce_hook(ctx, h->dsc + h->lay.YS + ins * mem, mem));
     MXLO_TRY(allreduce_hook(ctx, h->dsc + h->lay.YY + ins * mem, mem));
   } else {
@@ -1718,10 +1813,7 @@ int32_t lbfgs_push_fused(mxlo_qn *h, const T *s, const T *y, int32_t *accepted) 
                     gt + 3 * mem, nullptr, nullptr, ch == 0 ? misc + 16 + ins : nullptr));
     MXLO_TRY(allreduce_hook(ctx, gt, 4 * mem));
     MXLO_TRY(allreduce_hook(ctx, misc + 16 + ins, 1));
-    hipLaunchKernelGGL(gram_update_kernel, dim3(1), dim3(64), 0, ctx->stream, h->dsc + h->lay.SS, h->dsc + h->lay.YSf,
-                       h->dsc + h->lay.YY, gt, (int)mem, (int)ins);
-    MXLO_LAUNCH_CHECK();
-    MXLO_TRY(fwd_rebuild_after_gram<T>(h, ins));
+    MXLO_TRY(fwd_rebuild_after_gram<T>(h, ins, gt));   // (places the Gram rows gt in the coefficient kernel's prologue)
   }
   h->insert0 = (h->insert0 + 1) % h->mem;  // :253
   ++h->generation;
@@ -1836,14 +1928,6 @@ lsr1_bs_coef_kernel(const double *__restrict__ gt, const double *__restrict__ Cm
       lsr1_coef_body(k, dots, coef, as_, O, alpha, ct_f32);
     }
   }
-}
-
-// the new pair's own Gram entries (the passes ran over the OLD panels, whose slot `ins` is about to be replaced)
-__global__ void gram_self_kernel(double *__restrict__ gt, int mem, int ins, double ss, double ys, double yy) {
-  gt[ins] = ss;
-  gt[mem + ins] = ys;
-  gt[2 * mem + ins] = ys;
-  gt[3 * mem + ins] = yy;
 }
 
 __global__ void set_scalar_kernel(double *p, double v) { *p = v; }
@@ -1998,14 +2082,19 @@ int32_t lsr1_push_fused(mxlo_qn *h, const T *s, const T *y, int32_t *accepted) {
   ++h->generation;
   // ---- Gram rows of the new pair, coefficients of every a_k, then ONE pass A = [Y S] C (:166-181) that also drops the
   // pair into its slots
-  hipLaunchKernelGGL(gram_self_kernel, dim3(1), dim3(1), 0, ctx->stream, gt, (int)mem, (int)ins, hs[1], hs[0], hs[2]);
-  MXLO_LAUNCH_CHECK();
-  hipLaunchKernelGGL(gram_update_kernel, dim3(1), dim3(64), 0, ctx->stream, h->dsc + h->lay.SS, h->dsc + h->lay.YSf,
-                     h->dsc + h->lay.YY, gt, (int)mem, (int)ins);
-  MXLO_LAUNCH_CHECK();
   fill_ord(h, O, false);
+  GramUpd U;                // own-pair entries + Gram rows in the coefficient kernel's prologue, the GEMM's transposed
+  U.on = 1; U.self = 1;     // coefficients in its epilogue: one launch where there were four
+  U.mem = (int)mem; U.ins = (int)ins;
+  U.ss = hs[1]; U.ys = hs[0]; U.yy = hs[2];
+  U.SS = h->dsc + h->lay.SS; U.YSf = h->dsc + h->lay.YSf; U.YY = h->dsc + h->lay.YY;
+  U.tmp = gt;
+  if (n > 0 && O.na > 0) {
+    U.Ct = gemm_ct(ctx);
+    U.noutmax = gemm_noutmax(O.na);
+  }
   hipLaunchKernelGGL(asr1_coef_kernel, dim3(1), dim3(64), 0, ctx->stream, h->dsc + h->lay.SS, h->dsc + h->lay.YSf,
-                     h->dsc + h->lay.Cm, as_, O);
+                     h->dsc + h->lay.Cm, as_, O, U);
   MXLO_LAUNCH_CHECK();
   T *si = col<T>(h->S, h->ld, ins), *yi = col<T>(h->Y, h->ld, ins);
   const bool ride = n % 2 == 0;   // the rebuild reads pairs of rows: an odd n would read one element past s and y
@@ -2029,7 +2118,7 @@ int32_t lsr1_push_fused(mxlo_qn *h, const T *s, const T *y, int32_t *accepted) {
     G.cp_src[1] = y; G.cp_dst[1] = yi;
   }
   h->normA_valid = false;
-  return launch_panel_gemm<T>(ctx, G, n);
+  return launch_panel_gemm<T>(ctx, G, n, /*ct_ready=*/U.Ct != nullptr);
 }
 
 // push!(op::LSR1Operator, s, y) — src/lsr1.jl:119-184
@@ -2475,8 +2564,8 @@ MXLO_API int32_t mxlo_qn_create(mxlo_ctx *ctx, int32_t kind, int32_t dtype, int6
   if (e == hipSuccess && !getenv("MXLO_NO_PINNED_READBACK")) {   // optional: without it the decision scalars are copied to the
     void *hp = nullptr;                                          // caller's stack (pageable: slower; the env var is for A/B timing)
     void *dp = nullptr;
-    if (hipHostMalloc(&hp, (kPinnedScalars + 8) * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess) {
-      memset(hp, 0, (kPinnedScalars + 8) * sizeof(double));
+    if (hipHostMalloc(&hp, kPinnedTotal * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess) {
+      memset(hp, 0, kPinnedTotal * sizeof(double));
       h->pinned = (double *)hp;
       if (hipHostGetDevicePointer(&dp, hp, 0) == hipSuccess) h->pinned_dev = (double *)dp;
       else (void)hipGetLastError();

@@ -552,10 +552,14 @@ push_pass_kernel(PushPassArgs<T, NC> A, double *__restrict__ partials) {
 constexpr int kPushMaxNC = 20;
 struct FinalizeMap {
   double *dst[2 * kPushMaxNC + 4];
+  PushExtras ex;          // common.h: a small copy (workgroup 0) and the posting of columns post_col, post_col + 1
+  int post_col = -1;
 };
 __global__ void __launch_bounds__(kBlock)
 finalize_map_kernel(const double *__restrict__ partials, int nblocks, FinalizeMap M) {
   const int c = blockIdx.x, tid = threadIdx.x;
+  if (c == 0)
+    for (int i = tid; i < M.ex.cp_n; i += kBlock) M.ex.cp_dst[i] = M.ex.cp_src[i];
   double *dst = M.dst[c];
   if (!dst) return;
   const double *p = partials + (int64_t)c * kMaxRedBlocks;
@@ -565,7 +569,16 @@ finalize_map_kernel(const double *__restrict__ partials, int nblocks, FinalizeMa
   __shared__ double lds[kBlock / kWave];
   if ((tid & 63) == 0) lds[tid >> 6] = s;
   __syncthreads();
-  if (tid == 0) *dst = (lds[0] + lds[1]) + (lds[2] + lds[3]);
+  if (tid == 0) {
+    const double v = (lds[0] + lds[1]) + (lds[2] + lds[3]);
+    *dst = v;
+    if (M.ex.post && (c == M.post_col || c == M.post_col + 1)) {   // value first, its sequence number behind it
+      unsigned long long *slot = reinterpret_cast<unsigned long long *>(M.ex.post) + 2 * (c - M.post_col);
+      __hip_atomic_store(slot, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __threadfence_system();
+      __hip_atomic_store(slot + 1, M.ex.post_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
 }
 
 // One pass over `ncols` (1..10, or exactly 20) padded panel columns. out1[c] = dot(col_c, x1), out2[c] = dot(col_c, x2) with column
@@ -574,8 +587,10 @@ finalize_map_kernel(const double *__restrict__ partials, int nblocks, FinalizeMa
 template <typename T>
 int32_t panel_push_pass(mxlo_ctx *ctx, const T *const *cols, int ncols, int slot, int slot_src, const T *x1,
                         const T *x2, int64_t n, int64_t n_padded, T *st1, T *st2, T *stb, double sq, double *out1,
-                        double *out2, double *out_x1x2, double *out_x2x2, double *out_bb, double *out_x1x1) {
+                        double *out2, double *out_x1x2, double *out_x2x2, double *out_bb, double *out_x1x1,
+                        const PushExtras *extras) {
   constexpr int VEC = Vec16<T>::N;
+  MXLO_REQUIRE(!extras || !extras->post || (out_x1x2 && out_x2x2), MXLO_EINVAL, "panel_push_pass: posting needs x1.x2 and x2.x2");
   MXLO_REQUIRE(((ncols >= 1 && ncols <= 10) || ncols == kPushMaxNC) && n_padded % VEC == 0 && n <= n_padded &&
                    n > n_padded - VEC, MXLO_EINVAL, "panel_push_pass: bad arguments");
   bool aligned = (((uintptr_t)x1 | (uintptr_t)x2 | (uintptr_t)st1 | (uintptr_t)st2 | (uintptr_t)stb) & 15u) == 0;
@@ -609,6 +624,10 @@ int32_t panel_push_pass(mxlo_ctx *ctx, const T *const *cols, int ncols, int slot
     M.dst[2 * NC + 1] = out_x2x2;
     M.dst[2 * NC + 2] = out_bb;
     M.dst[2 * NC + 3] = out_x1x1;
+    if (extras) {
+      M.ex = *extras;
+      M.post_col = 2 * NC;
+    }
     hipLaunchKernelGGL(finalize_map_kernel, dim3(2 * NC + 4), dim3(kBlock), 0, ctx->stream, ctx->partials, grid, M);
   };
   switch (ncols) {
@@ -630,10 +649,10 @@ int32_t panel_push_pass(mxlo_ctx *ctx, const T *const *cols, int ncols, int slot
 
 template int32_t panel_push_pass<double>(mxlo_ctx *, const double *const *, int, int, int, const double *, const double *,
                                          int64_t, int64_t, double *, double *, double *, double, double *, double *,
-                                         double *, double *, double *, double *);
+                                         double *, double *, double *, double *, const PushExtras *);
 template int32_t panel_push_pass<float>(mxlo_ctx *, const float *const *, int, int, int, const float *, const float *,
                                         int64_t, int64_t, float *, float *, float *, double, double *, double *, double *,
-                                        double *, double *, double *);
+                                        double *, double *, double *, const PushExtras *);
 
 template int32_t panel_dots2<double>(mxlo_ctx *, const double *const *, int, const double *, const double *, int64_t,
                                      double *, double *);

@@ -161,6 +161,7 @@ struct mxlo_ctx {
   double *partials = nullptr;  // [kMaxRedCols][kMaxRedBlocks] per-block partial sums
   double *scalars = nullptr;   // finalized reduction results / device-resident coefficients
   bool lds_attr_set = false;   // dynamic-LDS limits of the shifted-solve kernels raised on THIS device
+  bool inv_lds_attr_set = false;   // ... and inv_coef_kernel at na = 64
   unsigned *ticket = nullptr;  // arrival counter of the fused (last-workgroup) finalize; zero between launches
   unsigned long long *xslots = nullptr;  // [2][kFusedSlots] partial-exchange slots + epoch word of the single-launch Householder
   unsigned long long *qslots = nullptr;  // [2][40 x 64] exchange slots + epoch word of the single-launch quasi-Newton apply (qn.hip)
@@ -356,6 +357,9 @@ bool qn_generation(const mxlo_qn *h, int64_t *gen);
 
 // reductions.hip
 int32_t finalize_and_reduce(mxlo_ctx *ctx, int ncols, int nblocks, double *out_dev);
+// ... also posting the results (and extra_n earlier doubles) to mapped pinned host memory, reductions.hip
+int32_t finalize_and_post(mxlo_ctx *ctx, int ncols, int nblocks, double *out_dev, double *post_dev, unsigned long long seq,
+                          const double *extra_src, int extra_n);
 int32_t allreduce_hook(mxlo_ctx *ctx, double *dev, int64_t count);
 template <typename T>
 int32_t panel_dots(mxlo_ctx *ctx, const T *const *cols_host, int ncols, const T *x, int64_t n,

@@ -417,24 +417,33 @@ __device__ __forceinline__ void inv_coef_generic(int lane, const double *dots, d
   const int mypos = lane < na ? lane : 0;
   auto wsum = [](double v) { return wave_allsum(v); };   // DPP tree (common.h), total in every lane
   const int myslot = O.ord[mypos];
+  // ys of ord position i is fetched from lane i's register (one kernel-argument lookup per lane, up front) instead of
+  // O.ys[O.ord[i]] inside the loops: two dependent scalar loads per step of a chain that is latency from end to end
+  const double ys_mine = O.ys[myslot];
+  auto ys_at = [&](int i) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(ys_mine), i),
+                            __builtin_amdgcn_readlane(__double2loint(ys_mine), i));
+#else
+    return ys_mine;
+#endif
+  };
   double a = 0.0, b = 0.0;  // lane's own alpha / beta
   for (int i = 0; i < na; ++i) {
-    const int k = O.ord[i];
     const double part = (lane < i) ? a * syp(i, mypos) : 0.0;
     const double sq = dots[i] - wsum(part);
-    const double ai = rnd(sq / O.ys[k], O.is_f32);
+    const double ai = rnd(sq / ys_at(i), O.is_f32);
     if (lane == i) a = ai;
   }
   if (lane < na && alpha_out) alpha_out[myslot] = a;
   const double g = O.use_gamma ? O.gamma : 1.0;
   for (int i = na - 1; i >= 0; --i) {
-    const int k = O.ord[i];
     const double p1 = (lane < na) ? a * yyp(i, mypos) : 0.0;              // sum_j alpha_j y_k'y_j
     const double p2 = (lane < na && lane > i) ? b * syp(mypos, i) : 0.0;  // sum_{older j} beta_j s_j'y_k
     const double yq = dots[na + i] - wsum(p1);
     const double yr = g * yq + wsum(p2);
     const double ai = __shfl(a, i, 64);
-    const double bi = rnd(ai - yr / O.ys[k], O.is_f32);
+    const double bi = rnd(ai - yr / ys_at(i), O.is_f32);
     if (lane == i) b = bi;
   }
   if (lane < na) {
@@ -442,25 +451,27 @@ __device__ __forceinline__ void inv_coef_generic(int lane, const double *dots, d
     coef[na + (na - 1 - lane)] = b;   // s columns, oldest -> newest
   }
 }
-__device__ __forceinline__ void inv_coef_body(int lane, const double *dots, double *__restrict__ coef,
-                                              const double *__restrict__ SY, const double *__restrict__ YS,
-                                              const double *__restrict__ YY, double *__restrict__ alpha_out,
-                                              const OrdArgs &O) {
-  const int mem = O.mem;
-  auto sy = [&](int i, int j) {  // s_i' y_j for slots i, j
-    return O.age[j] >= O.age[i] ? SY[i + (int64_t)j * mem] : YS[j + (int64_t)i * mem];
-  };
-  auto yy = [&](int i, int j) {
-    return O.age[j] >= O.age[i] ? YY[i + (int64_t)j * mem] : YY[j + (int64_t)i * mem];
-  };
-  inv_coef_generic(lane, dots, coef, alpha_out, O, [&](int i, int j) { return sy(O.ord[i], O.ord[j]); },
-                   [&](int i, int j) { return yy(O.ord[i], O.ord[j]); });
-}
-__global__ void __launch_bounds__(64)
+// Standalone coefficient kernel of the four-launch apply. The Gram entries the recurrences read — chosen per pair by the
+// pairs' ages — and the dots are first staged in LDS by ord position with all loads in flight (one workgroup, 256
+// threads; wave 0 then runs the recurrences): read in place they cost one dependent global round trip per step of the
+// two loops (6.3 us at na = 10, profiles/r04_bench_kernel_stats.csv). Same values, same arithmetic.
+__global__ void __launch_bounds__(kBlock)
 inv_coef_kernel(const double *__restrict__ dots, double *__restrict__ coef,
                 const double *__restrict__ SY, const double *__restrict__ YS,
                 const double *__restrict__ YY, double *__restrict__ alpha_out, OrdArgs O) {
-  inv_coef_body((int)threadIdx.x, dots, coef, SY, YS, YY, alpha_out, O);
+  extern __shared__ double inv_lds[];            // [na*na] s_i'y_j | [na*na] y_i'y_j | [2 na] dots
+  const int tid = threadIdx.x, na = O.na, mem = O.mem;
+  double *sg1 = inv_lds, *sg2 = inv_lds + na * na, *sdots = inv_lds + 2 * na * na;
+  for (int p = tid; p < na * na; p += kBlock) {
+    const int i = O.ord[p / na], j = O.ord[p % na];                  // slots
+    sg1[p] = O.age[j] >= O.age[i] ? SY[i + (int64_t)j * mem] : YS[j + (int64_t)i * mem];   // s_i'y_j
+    sg2[p] = O.age[j] >= O.age[i] ? YY[i + (int64_t)j * mem] : YY[j + (int64_t)i * mem];   // y_i'y_j
+  }
+  if (tid < 2 * na) sdots[tid] = dots[tid];
+  __syncthreads();
+  if (tid < kWave)
+    inv_coef_generic(tid, sdots, coef, alpha_out, O, [&](int i, int j) { return sg1[i * na + j]; },
+                     [&](int i, int j) { return sg2[i * na + j]; });
 }
 
 // L-SR1: coef[i] = (alpha*dot_i)/as_k evaluated in CT (src/lsr1.jl:101)
@@ -1008,7 +1019,12 @@ int32_t inv_mul_twopass(mxlo_qn *h, T *res, const T *x, double alpha, double bet
       if (try_fused_apply<T>(h, res, cols, x, F, O, flags, &fst)) return fst;
     }
     MXLO_TRY(panel_dots<T>(ctx, cols, 2 * na, x, h->n, dots));
-    hipLaunchKernelGGL(inv_coef_kernel, dim3(1), dim3(64), 0, ctx->stream, dots, coef,
+    const size_t coef_lds = sizeof(double) * (size_t)(2 * na * na + 2 * na);
+    if (coef_lds > 64 * 1024 && !ctx->inv_lds_attr_set) {   // na = 64 only: 65 KiB, above the default cap; the attribute is per device
+      MXLO_HIP(hipFuncSetAttribute((const void *)inv_coef_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024));
+      ctx->inv_lds_attr_set = true;
+    }
+    hipLaunchKernelGGL(inv_coef_kernel, dim3(1), dim3(kBlock), coef_lds, ctx->stream, dots, coef,
                        h->dsc + h->lay.SY, h->dsc + h->lay.YS, h->dsc + h->lay.YY,
                        h->dsc + h->lay.alpha, O);
     MXLO_LAUNCH_CHECK();
@@ -1265,6 +1281,36 @@ inline double rT(double v) { return sizeof(T) == 4 ? (double)(float)v : v; }
 // date (3m dots per push) the recurrence runs on 2m-vectors of coefficients and ALL a_k are then formed
 // in ONE pass  A = [S B] * C  (read 2r columns, write r columns).
 
+// Z[lane][k] = <basis_lane, s_ord[k]> from the Gram matrices: lanes < r read rows of G0, lanes r .. 2r-1 rows of G1 (DIV:
+// divided by sqrt(ys) of their slot — b_j = y_j / sqrt(ys_j)). The per-lane slot and its ys are looked up ONCE and all r
+// loads of a lane are issued before the first use: written as a plain loop over k this fill was a chain of three
+// dependent memory round trips per k (kernel-argument array at a per-lane index -> Gram entry -> ys) and, at r = 20,
+// ~35 of the forward push!'s 68 us at launch-bound sizes.
+template <bool DIV>
+__device__ __forceinline__ void fill_Z(double (*Z)[kMaxMemFwd], const double *G0, const double *G1, const OrdArgs &O) {
+  const int lane = threadIdx.x, r = O.na, mem = O.mem, w = 2 * r;
+  if (lane < w) {
+    const int j = lane < r ? lane : lane - r;
+    const int oj = O.ord[j];
+    const double *row = (lane < r ? G0 : G1) + oj * mem;
+    double g[kMaxMemFwd];
+#pragma unroll
+    for (int k = 0; k < kMaxMemFwd; ++k)
+      if (k < r) g[k] = row[O.ord[k]];
+    if constexpr (DIV) {
+      if (lane >= r) {
+        const double sq = sqrt(O.ys[oj]);
+#pragma unroll
+        for (int k = 0; k < kMaxMemFwd; ++k)
+          if (k < r) g[k] = g[k] / sq;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < kMaxMemFwd; ++k)
+      if (k < r) Z[lane][k] = g[k];
+  }
+}
+
 // The Gram update of a push! as a PROLOGUE of the single-wave coefficient kernel that consumes it (afwd_coef_kernel,
 // asr1_coef_kernel): launch-bound pushes lose one dependent launch (two for L-SR1, whose own-pair entries ride along).
 // Same stores as gram_update_kernel (+ gram_self_kernel); the coefficient code reads SS / YSf after a barrier.
@@ -1330,22 +1376,32 @@ afwd_coef_kernel(const double *SS, const double *YSf, double *Cm, OrdArgs O, Gra
   __shared__ double Cl[kMaxMemFwd][2 * kMaxMemFwd];
   gram_update_prologue(G);
   const int lane = threadIdx.x;
-  const int r = O.na, mem = O.mem, w = 2 * r;
-  for (int k = 0; k < r; ++k) {
-    if (lane < w) {
-      const int j = lane < r ? lane : lane - r;
-      const double g = (lane < r ? SS : YSf)[O.ord[j] * mem + O.ord[k]];
-      Z[lane][k] = lane < r ? g : g / sqrt(O.ys[O.ord[j]]);
-    }
-  }
+  const int r = O.na, w = 2 * r;
+  fill_Z<true>(Z, SS, YSf, O);
   __syncthreads();
   auto wsum = [](double v) { return wave_allsum(v); };   // DPP tree (common.h), total in every lane
   for (int k = 0; k < r; ++k) {
     double c = (lane == k) ? 1.0 / O.gamma : 0.0;             // a_k = s_k / γ                 (:239)
     const double zk = lane < w ? Z[lane][k] : 0.0;
-    for (int l = 0; l < k; ++l) {
+    // dot(a_l, s_k) does not involve the running a_k: four reductions are issued together (their DPP chains overlap —
+    // a lone chain is ~250 cycles of latency, and there are r²/2 of them: 22 of the 30 us of this kernel at r = 20),
+    // the updates are then applied in the reference's order. Bit-identical to the one-at-a-time loop.
+    int l = 0;
+    for (; l + 4 <= k; l += 4) {
+      double cl[4], as[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) cl[u] = lane < w ? Cl[l + u][lane] : 0.0;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) as[u] = wsum(cl[u] * zk);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (lane == r + l + u) c += zk;                       // Z[r + l + u][k] IS this lane's zk: no LDS read in a branch
+        c -= as[u] * cl[u];
+      }
+    }
+    for (; l < k; ++l) {
       const double cl = lane < w ? Cl[l][lane] : 0.0;
-      if (lane == r + l) c += Z[r + l][k];                    // += dot(b_l, s_k) b_l           (:244)
+      if (lane == r + l) c += zk;                             // += dot(b_l, s_k) b_l = Z[r + l][k], this lane's zk (:244)
       const double as = wsum(cl * zk);                        // dot(a_l, s_k)
       c -= as * cl;                                           // -= dot(a_l, s_k) a_l           (:245)
     }
@@ -1507,18 +1563,24 @@ asr1_coef_kernel(const double *SS, const double *YSf, double *Cm, double *as_out
   __shared__ double asl[kMaxMemFwd];
   gram_update_prologue(G);                               // (SS / YSf not __restrict__: the prologue writes them)
   const int lane = threadIdx.x;
-  const int r = O.na, mem = O.mem, w = 2 * r;
-  for (int k = 0; k < r; ++k)
-    if (lane < w) {
-      const int j = lane < r ? lane : lane - r;
-      Z[lane][k] = (lane < r ? YSf : SS)[O.ord[j] * mem + O.ord[k]];
-    }
+  const int r = O.na, w = 2 * r;
+  fill_Z<false>(Z, YSf, SS, O);
   __syncthreads();
   auto wsum = [](double v) { return wave_allsum(v); };   // DPP tree (common.h), total in every lane
   for (int k = 0; k < r; ++k) {
     double c = (lane == k) ? 1.0 : ((lane == r + k) ? -1.0 / O.gamma : 0.0);   // y_k - s_k/γ       (:169)
     const double zk = lane < w ? Z[lane][k] : 0.0;
-    for (int l = 0; l < k; ++l) {
+    int l = 0;
+    for (; l + 4 <= k; l += 4) {   // four independent reductions in flight, updates in the reference's order (see afwd_coef_kernel)
+      double cl[4], as[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) cl[u] = lane < w ? Cl[l + u][lane] : 0.0;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) as[u] = wsum(cl[u] * zk) / asl[l + u];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) c -= as[u] * cl[u];
+    }
+    for (; l < k; ++l) {
       const double cl = lane < w ? Cl[l][lane] : 0.0;
       const double as = wsum(cl * zk) / asl[l];                                // dot(a_l,s_k)/as_l (:173)
       c -= as * cl;                                                            //                   (:174)
@@ -2030,6 +2092,8 @@ int32_t lsr1_push_fused(mxlo_qn *h, const T *s, const T *y, int32_t *accepted) {
   MXLO_TRY(allreduce_hook(ctx, gt, 4 * mem));
   MXLO_TRY(allreduce_hook(ctx, misc, 3));
   // ---- pass 2: r = y - B s over the a_k panel, nothing stored; misc[3] = r's, [4] = |r|^2, [5] = |y - s/sf|^2
+  const bool post = !ctx->allreduce && ctx->tune.push_posted && h->pinned_dev;
+  unsigned long long post_seq = 0;
   OrdArgs O;
   fill_ord(h, O, false);
   CombineArgs<T> A;
@@ -2062,11 +2126,17 @@ int32_t lsr1_push_fused(mxlo_qn *h, const T *s, const T *y, int32_t *accepted) {
       hipLaunchKernelGGL((combine_kernel<T, T, T, CM_LSR1R, false, VECP, false>), dim3(grid), dim3(kBlock), 0, ctx->stream,
                          const_cast<T *>(y), s, (const T *)nullptr, A, nvec);
     MXLO_LAUNCH_CHECK();
-    MXLO_TRY(finalize_and_reduce(ctx, 3, grid, misc + 3));
-    MXLO_TRY(allreduce_hook(ctx, misc + 3, 3));
+    if (post) {   // no hook: misc[0..2] and these three sums are final — this finalize launch posts all six to the host
+      post_seq = ++h->post_seq;
+      MXLO_TRY(finalize_and_post(ctx, 3, grid, misc + 3, h->pinned_dev + kPostPairs, post_seq, misc, 3));
+    } else {
+      MXLO_TRY(finalize_and_reduce(ctx, 3, grid, misc + 3));
+      MXLO_TRY(allreduce_hook(ctx, misc + 3, 3));
+    }
   }
   double hs[6];
-  MXLO_TRY(read_scalars(h, misc, hs, 6));   // the push's one device-to-host copy (48 bytes)
+  if (post) MXLO_TRY(await_posted_pairs(h, hs, 6, post_seq));
+  else MXLO_TRY(read_scalars(h, misc, hs, 6));   // the push's one device-to-host transfer (48 bytes)
   if (lsr1_decision_is_marginal<T>(h, hs[0], hs[1], hs[3], hs[2], hs[4], hs[5]))
     return lsr1_push_copies<T>(h, s, y, accepted);      // nothing but scratch has been written so far
   if (!lsr1_accepts<T>(h, hs[0], hs[1], hs[3], hs[2], hs[4], hs[5])) {

@@ -23,9 +23,31 @@ struct ColPtrs {
   const T *p[NC];
 };
 
+// Sum over the wave in LANE 0 (other lanes: unspecified), on the tree of the shuffle-down loop this replaces —
+//   v[l] += v[l + 32]; v[l] += v[l + 16]; ... ; v[l] += v[l + 1]
+// — so every reduction of the library keeps its bits. A 64-bit __shfl_down is two ds_bpermute_b32 with an LDS round trip
+// each and six dependent levels per sum: the 2 NC + 4 sums at the end of a push pass cost 1.8 us (5 columns) to 5.5 us (20)
+// at launch-bound sizes. Here the upper half arrives with v_permlane32_swap, the odd rows with v_permlane16_swap (gfx950),
+// the rest with DPP row shifts: register-speed VALU work that independent sums overlap freely.
 __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+#if defined(__HIP_DEVICE_COMPILE__)
+  {
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const auto slo = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);   // [1]: lanes 0..31 hold lanes 32..63
+    const auto shi = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    v += __hiloint2double((int)shi[1], (int)slo[1]);
+  }
+  {
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const auto slo = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);   // [1]: rows 0, 2 hold rows 1, 3
+    const auto shi = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    v += __hiloint2double((int)shi[1], (int)slo[1]);
+  }
+  v += dpp_shift_or_zero<0x108, 0xf>(v);   // row_shl:8: lane l reads lane l + 8 of its row
+  v += dpp_shift_or_zero<0x104, 0xf>(v);   // row_shl:4
+  v += dpp_shift_or_zero<0x102, 0xf>(v);   // row_shl:2
+  v += dpp_shift_or_zero<0x101, 0xf>(v);   // row_shl:1
+#endif
   return v;
 }
 
@@ -181,6 +203,43 @@ finalize_kernel(const double *__restrict__ partials, int nblocks, double *__rest
 int32_t finalize_and_reduce(mxlo_ctx *ctx, int ncols, int nblocks, double *out_dev) {
   hipLaunchKernelGGL(finalize_kernel, dim3(ncols), dim3(kBlock), 0, ctx->stream, ctx->partials,
                      nblocks, out_dev);
+  MXLO_LAUNCH_CHECK();
+  return MXLO_OK;
+}
+
+// finalize_kernel that also POSTS its results to mapped pinned host memory as (value, sequence number) pairs
+// `extra_n` .. `extra_n + ncols - 1`; workgroup 0 posts `extra_n` doubles an earlier kernel left in `extra_src` as pairs
+// 0 .. extra_n - 1 (the L-SR1 push!'s six decision doubles come from two finalize launches: this is the second).
+__global__ void __launch_bounds__(kBlock)
+finalize_post_kernel(const double *__restrict__ partials, int nblocks, double *__restrict__ out, double *post,
+                     unsigned long long seq, const double *__restrict__ extra_src, int extra_n) {
+  const int c = blockIdx.x, tid = threadIdx.x;
+  auto post_pair = [&](int i, double v) {
+    unsigned long long *slot = reinterpret_cast<unsigned long long *>(post) + 2 * i;
+    __hip_atomic_store(slot, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __threadfence_system();
+    __hip_atomic_store(slot + 1, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  };
+  const double *p = partials + (int64_t)c * kMaxRedBlocks;
+  double s = 0.0;
+  for (int i = tid; i < nblocks; i += kBlock) s += p[i];
+  s = wave_sum(s);
+  __shared__ double lds[kBlock / kWave];
+  if ((tid & 63) == 0) lds[tid >> 6] = s;
+  __syncthreads();
+  if (tid == 0) {
+    const double v = (lds[0] + lds[1]) + (lds[2] + lds[3]);
+    out[c] = v;
+    post_pair(extra_n + c, v);
+  }
+  if (c == 0 && tid >= kWave && tid < kWave + extra_n) post_pair(tid - kWave, extra_src[tid - kWave]);
+}
+
+int32_t finalize_and_post(mxlo_ctx *ctx, int ncols, int nblocks, double *out_dev, double *post_dev, unsigned long long seq,
+                          const double *extra_src, int extra_n) {
+  MXLO_REQUIRE(post_dev && extra_n >= 0 && extra_n + ncols <= 8 && extra_n <= kWave, MXLO_EINVAL, "finalize_and_post: bad arguments");
+  hipLaunchKernelGGL(finalize_post_kernel, dim3(ncols), dim3(kBlock), 0, ctx->stream, ctx->partials, nblocks, out_dev,
+                     post_dev, seq, extra_src, extra_n);
   MXLO_LAUNCH_CHECK();
   return MXLO_OK;
 }
@@ -450,7 +509,10 @@ struct PushPassArgs {
   int64_t n;               // valid elements of x1, x2
 };
 
-template <typename T, int NC, int UNROLL, bool NT, bool STORE>
+// FAST: the launch-bound instantiation (every workgroup has at most one chunk) with the branch-free chunk loads below. It
+// needs ~45 more VGPRs (5 columns: 102 -> 148, one wave per SIMD less), which costs the HBM-bound sizes 6 % (inverse
+// m = 10, n = 5e7: 1.64 -> 1.77 ms) — those keep the guarded loads, whose latency their occupancy hides.
+template <typename T, int NC, int UNROLL, bool NT, bool STORE, bool FAST = false>
 __global__ void __launch_bounds__(kBlock)
 push_pass_kernel(PushPassArgs<T, NC> A, double *__restrict__ partials) {
   constexpr int VEC = Vec16<T>::N;
@@ -476,16 +538,33 @@ push_pass_kernel(PushPassArgs<T, NC> A, double *__restrict__ partials) {
     const int64_t base = ch * CHUNK + tid;
     V xv1[UNROLL], xv2[UNROLL], cv[UNROLL][NC];
     bool ok[UNROLL];
+    if (FAST && (ch + 1) * CHUNK <= nfull) {
+      // Whole chunk inside the valid range (every chunk but the last): branch-free, so the (NC + 2) * UNROLL loads of a
+      // lane really are in flight together. (The guarded form below waits for each load before issuing the next —
+      // the ISA had an s_waitcnt vmcnt(0) in front of every one of them; at launch-bound sizes that was 14 memory
+      // round trips for 5 columns, 44 for 20.) The column being replaced is still never read: its pointer is
+      // swapped for the caller vector that stands for it (a cache hit, and the accumulate step selects that vector anyway).
 #pragma unroll
-    for (int u = 0; u < UNROLL; ++u) {
-      const int64_t i = base + (int64_t)u * kBlock;
-      ok[u] = i < A.nvec;
-      if (ok[u]) {
-        xv1[u] = ldx(A.x1, i);
-        xv2[u] = ldx(A.x2, i);
+      for (int u = 0; u < UNROLL; ++u) {
+        const int64_t i = base + (int64_t)u * kBlock;
+        ok[u] = true;
+        xv1[u] = ld(A.x1, i);
+        xv2[u] = ld(A.x2, i);
 #pragma unroll
-        for (int c = 0; c < NC; ++c)
-          if (c != A.slot) cv[u][c] = ld(A.cols[c], i);
+        for (int c = 0; c < NC; ++c) cv[u][c] = ld(c == A.slot ? (A.slot_src == 1 ? A.x1 : A.x2) : A.cols[c], i);
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < UNROLL; ++u) {
+        const int64_t i = base + (int64_t)u * kBlock;
+        ok[u] = i < A.nvec;
+        if (ok[u]) {
+          xv1[u] = ldx(A.x1, i);
+          xv2[u] = ldx(A.x2, i);
+#pragma unroll
+          for (int c = 0; c < NC; ++c)
+            if (c != A.slot) cv[u][c] = ld(A.cols[c], i);
+        }
       }
     }
 #pragma unroll
@@ -608,12 +687,18 @@ int32_t panel_push_pass(mxlo_ctx *ctx, const T *const *cols, int ncols, int slot
     constexpr int UNROLL = NC <= 2 ? 4 : (NC <= 5 ? 2 : 1);      // = panel_dots2: identical per-lane summation order
     grid = grid_for(ctx, nvec, (int64_t)kBlock * UNROLL, ctx->tune.red_blocks_per_cu);
     if (grid > kMaxRedBlocks) grid = kMaxRedBlocks;
-    auto launch = [&]<bool NTV, bool ST>() {
-      hipLaunchKernelGGL((push_pass_kernel<T, NC, UNROLL, NTV, ST>), dim3(grid), dim3(kBlock), 0, ctx->stream, A,
+    auto launch = [&]<bool NTV, bool ST, bool FAST>() {
+      hipLaunchKernelGGL((push_pass_kernel<T, NC, UNROLL, NTV, ST, FAST>), dim3(grid), dim3(kBlock), 0, ctx->stream, A,
                          ctx->partials);
     };
-    if (nt) { if (store) launch.template operator()<true, true>(); else launch.template operator()<true, false>(); }
-    else { if (store) launch.template operator()<false, true>(); else launch.template operator()<false, false>(); }
+    const int64_t nchunks = (nvec + (int64_t)kBlock * UNROLL - 1) / ((int64_t)kBlock * UNROLL);
+    if (nchunks <= grid && !nt) {   // launch-bound: one chunk per workgroup
+      if (store) launch.template operator()<false, true, true>(); else launch.template operator()<false, false, true>();
+    } else if (nt) {
+      if (store) launch.template operator()<true, true, false>(); else launch.template operator()<true, false, false>();
+    } else {
+      if (store) launch.template operator()<false, true, false>(); else launch.template operator()<false, false, false>();
+    }
     FinalizeMap M;
     for (int c = 0; c < 2 * kPushMaxNC + 4; ++c) M.dst[c] = nullptr;
     for (int c = 0; c < NC; ++c) {

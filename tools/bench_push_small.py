@@ -24,8 +24,12 @@ def rnd(n):
     return torch.rand(n, dtype=torch.float64, device=dev, generator=gen) * 2 - 1
 
 
-for kind, m in (("fwd", 5), ("inv", 5), ("lsr1", 5), ("fwd", 20), ("inv", 20)):
-    for n in (1 << 12, 1 << 14, 1 << 16):
+# python tools/bench_push_small.py [kind m log2n]: one configuration only (for rocprofv3 --kernel-trace --stats)
+CASES = [(k, m, 1 << e) for k, m in (("fwd", 5), ("inv", 5), ("lsr1", 5), ("fwd", 20), ("inv", 20)) for e in (12, 14, 16)]
+if len(sys.argv) == 4:
+    CASES = [(sys.argv[1], int(sys.argv[2]), 1 << int(sys.argv[3]))]
+for kind, m, n in CASES:
+    if True:
         make = {"inv": lo.InverseLBFGSOperator, "fwd": lo.LBFGSOperator, "lsr1": lo.LSR1Operator}[kind]
         S = [rnd(n) for _ in range(16)]
         Y = [s * (rnd(n) * 0.25 + 1.25) + (0.3 * rnd(n) if kind == "lsr1" else 0) for s in S]

@@ -1,0 +1,48 @@
+#!/usr/bin/env python
+"""Quasi-Newton applies between the single-launch sizes and the HBM-bound ones (n = 2^19 .. 2^24, fp64): us per mul! and
+the rate of the bytes a two-pass apply has to move ((4m + 3) * 8 B per element for the L-BFGS operators with full memory:
+2m + 1 vectors read by the dots pass, 2m + 1 read and one written by the combine pass; L-SR1: (2m + 3) * 8)."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+import __graft_entry__ as g
+
+lo = g.load_package()
+from linearoperators_jl_amd.device import Timer, get_ctx
+
+dev = torch.device("cuda", 0)
+ctx = get_ctx(dev)
+tm = Timer(ctx)
+gen = torch.Generator(device=dev).manual_seed(5)
+
+
+def rnd(n):
+    return torch.rand(n, dtype=torch.float64, device=dev, generator=gen) * 2 - 1
+
+
+def timeit(fn, reps):
+    for _ in range(5):
+        fn()
+    tm.start()
+    for _ in range(reps):
+        fn()
+    tm.stop()
+    return tm.elapsed_ms() / reps * 1e3
+
+
+for kind, m in (("inv", 5), ("inv", 10), ("fwd", 5), ("lsr1", 5)):
+    for e in (19, 20, 21, 22, 23, 24):
+        n = 1 << e
+        op = {"inv": lo.InverseLBFGSOperator, "fwd": lo.LBFGSOperator, "lsr1": lo.LSR1Operator}[kind](torch.float64, n, mem=m, device=dev)
+        for _ in range(m + 1):
+            s = rnd(n)
+            lo.push(op, s, s * (rnd(n) * 0.25 + 1.25) + (0.3 * rnd(n) if kind == "lsr1" else 0))
+        x, r = rnd(n), rnd(n)
+        us = timeit(lambda: lo.mul(r, op, x, 1.0, 0.0), 300 if e < 22 else 100)
+        cols = (2 * m + 3) if kind == "lsr1" else (4 * m + 3)
+        gb = cols * 8.0 * n / 1e9
+        print(f"{kind:4s} m={m:2d} n=2^{e}: {us:8.1f} us   {gb / us * 1e3:5.2f} TB/s of the two-pass bytes ({gb / us * 1e3 / 8.0:.2f} of peak)", flush=True)
+        del op

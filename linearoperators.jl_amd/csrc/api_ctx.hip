@@ -436,7 +436,7 @@ MXLO_API int32_t mxlo_ctx_tune(mxlo_ctx *ctx, const char *key, int64_t value) {
     MXLO_REQUIRE(value == 0 || value == 1, MXLO_EINVAL, "push_wide must be 0 or 1");
     ctx->tune.push_wide = (int)value;
   } else if (!strcmp(key, "push_posted")) {
-    MXLO_REQUIRE(value == 0 || value == 1, MXLO_EINVAL, "push_posted must be 0 or 1");
+    MXLO_REQUIRE(value >= 0 && value <= 2, MXLO_EINVAL, "push_posted must be 0, 1 or 2 (2: debug, the posting is treated as lost)");
     ctx->tune.push_posted = (int)value;
   } else if (!strcmp(key, "push_fused")) {
     MXLO_REQUIRE(value == 0 || value == 1, MXLO_EINVAL, "push_fused must be 0 or 1");

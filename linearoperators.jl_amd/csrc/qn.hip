@@ -1214,31 +1214,45 @@ post_scalars_kernel(const double *__restrict__ dev, double *__restrict__ host, i
 
 // Host side of a posted read-back: poll `nwords` sequence words (stride `stride` words) of the handle's pinned buffer
 // until all carry `seq`. A poll that outlasts kPostSpinUs (a long push pass is still running, or the launch failed)
-// hands over to the stream synchronisation, after which the words must be in place.
+// hands over to the stream synchronisation, after which the words must be in place. If they are NOT (a platform whose
+// mapped host memory does not see the device's stores — nothing observed, but nothing the library can rule out either)
+// *arrived is false: the caller copies the same doubles from device memory (the stream is idle at that point) and
+// posting is switched off for this handle. push_posted = 2 (debug) takes that path on purpose.
 static int32_t await_posted(mxlo_qn *h, const unsigned long long *word, int nwords, int stride, unsigned long long seq,
-                            int64_t bytes) {
+                            int64_t bytes, bool *arrived) {
   mxlo_ctx *ctx = h->ctx;
   ApiCounters &c = api_counters();     // what the contract test counts: one device-to-host transfer, one wait
   ++c.n_d2h;
   c.n_d2h_bytes += bytes;
   constexpr int kPostSpinUs = 200;
+  const bool pretend_lost = ctx->tune.push_posted == 2;
   const auto t0 = std::chrono::steady_clock::now();
   int have = 0;
-  for (int spin = 0; have < nwords; ++spin) {
+  for (int spin = 0; have < nwords && !pretend_lost; ++spin) {
     if (__atomic_load_n(word + (int64_t)have * stride, __ATOMIC_ACQUIRE) == seq) { ++have; continue; }
     if ((spin & 63) == 63 &&
         std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() > kPostSpinUs)
       break;
     __builtin_ia32_pause();
   }
+  *arrived = true;
   if (have == nwords) {
     ++c.n_stream_sync;
     return MXLO_OK;
   }
   MXLO_HIP(hipStreamSynchronize(ctx->stream));
-  for (int i = 0; i < nwords; ++i)
-    MXLO_REQUIRE(__atomic_load_n(word + (int64_t)i * stride, __ATOMIC_ACQUIRE) == seq, MXLO_EHIP,
-                 "push!: the posted read-back did not arrive");
+  for (int i = 0; i < nwords && *arrived; ++i)
+    if (pretend_lost || __atomic_load_n(word + (int64_t)i * stride, __ATOMIC_ACQUIRE) != seq) *arrived = false;
+  if (!*arrived) h->pinned_dev = nullptr;   // plain copies from now on
+  return MXLO_OK;
+}
+
+// the doubles themselves from device memory after a posting that did not arrive (stream already synchronised)
+static int32_t read_after_lost_post(mxlo_qn *h, const double *dev, double *host, int count) {
+  --api_counters().n_d2h;   // still ONE transfer of these doubles as far as the contract counters go
+  api_counters().n_d2h_bytes -= (int64_t)sizeof(double) * count;
+  MXLO_HIP(hipMemcpyAsync(host, dev, sizeof(double) * count, hipMemcpyDeviceToHost, h->ctx->stream));
+  MXLO_HIP(hipStreamSynchronize(h->ctx->stream));
   return MXLO_OK;
 }
 
@@ -1252,8 +1266,10 @@ int32_t read_scalars(mxlo_qn *h, const double *dev, double *host, int count) {
     const unsigned long long seq = ++h->post_seq;
     hipLaunchKernelGGL(post_scalars_kernel, dim3(1), dim3(kWave), 0, ctx->stream, dev, h->pinned_dev, count, seq);
     MXLO_LAUNCH_CHECK();
+    bool arrived = false;
     MXLO_TRY(await_posted(h, reinterpret_cast<const unsigned long long *>(h->pinned) + kPinnedScalars, 1, 1, seq,
-                          (int64_t)sizeof(double) * count));
+                          (int64_t)sizeof(double) * count, &arrived));
+    if (!arrived) return read_after_lost_post(h, dev, host, count);
     memcpy(host, h->pinned, sizeof(double) * count);
     return MXLO_OK;
   }
@@ -1264,10 +1280,13 @@ int32_t read_scalars(mxlo_qn *h, const double *dev, double *host, int count) {
   return MXLO_OK;
 }
 
-// ... the same for doubles that a finalize launch posted itself as (value, sequence number) pairs (PushExtras::post)
-static int32_t await_posted_pairs(mxlo_qn *h, double *host, int count, unsigned long long seq) {
+// ... the same for doubles that a finalize launch posted itself as (value, sequence number) pairs (PushExtras::post);
+// `dev`: where the same doubles lie in device memory (contiguous), for a posting that did not arrive
+static int32_t await_posted_pairs(mxlo_qn *h, const double *dev, double *host, int count, unsigned long long seq) {
   const unsigned long long *pairs = reinterpret_cast<const unsigned long long *>(h->pinned) + kPostPairs;
-  MXLO_TRY(await_posted(h, pairs + 1, count, 2, seq, (int64_t)sizeof(double) * count));
+  bool arrived = false;
+  MXLO_TRY(await_posted(h, pairs + 1, count, 2, seq, (int64_t)sizeof(double) * count, &arrived));
+  if (!arrived) return read_after_lost_post(h, dev, host, count);
   for (int i = 0; i < count; ++i) memcpy(host + i, pairs + 2 * i, sizeof(double));
   return MXLO_OK;
 }
@@ -1834,7 +1853,7 @@ int32_t lbfgs_push_fused(mxlo_qn *h, const T *s, const T *y, int32_t *accepted) 
                 misc, misc + 1, nullptr, post ? &exA : nullptr));
   double hs[2];
   if (post) {
-    MXLO_TRY(await_posted_pairs(h, hs, 2, exA.post_seq));
+    MXLO_TRY(await_posted_pairs(h, misc, hs, 2, exA.post_seq));
   } else {
     MXLO_TRY(allreduce_hook(ctx, misc, 2));
     MXLO_TRY(read_scalars(h, misc, hs, 2));
@@ -2135,7 +2154,7 @@ int32_t lsr1_push_fused(mxlo_qn *h, const T *s, const T *y, int32_t *accepted) {
     }
   }
   double hs[6];
-  if (post) MXLO_TRY(await_posted_pairs(h, hs, 6, post_seq));
+  if (post) MXLO_TRY(await_posted_pairs(h, misc, hs, 6, post_seq));
   else MXLO_TRY(read_scalars(h, misc, hs, 6));   // the push's one device-to-host transfer (48 bytes)
   if (lsr1_decision_is_marginal<T>(h, hs[0], hs[1], hs[3], hs[2], hs[4], hs[5]))
     return lsr1_push_copies<T>(h, s, y, accepted);      // nothing but scratch has been written so far

@@ -698,7 +698,9 @@ def test_posted_read_back_of_the_push_decision(lo, dev, kind, n):
     through mapped pinned host memory that a one-wave kernel writes and the host polls (`push_posted` = 1), or through
     hipMemcpyAsync + a stream synchronisation (0). Same kernels, same numbers: every decision (incl. rejected pairs),
     the insert pointer, the scaling factor and every apply must be IDENTICAL; n = 3·10⁶ with mem = 20 makes the first
-    pass outlast the polling window, i.e. runs the hand-over to the stream synchronisation."""
+    pass outlast the polling window, i.e. runs the hand-over to the stream synchronisation. `push_posted` = 2 (debug)
+    treats every posting as lost: the doubles are then copied from device memory and posting is switched off for that
+    handle — what a platform whose mapped host memory does not see device stores would get instead of an error."""
     from linearoperators_jl_amd.device import get_ctx
     ctx = get_ctx(dev)
     mem = 20 if n > 10**6 else 5
@@ -706,7 +708,7 @@ def test_posted_read_back_of_the_push_decision(lo, dev, kind, n):
     make = {"inv": lo.InverseLBFGSOperator, "fwd": lo.LBFGSOperator, "lsr1": lo.LSR1Operator}[kind]
     ops = {}
     try:
-        for posted in (1, 0):
+        for posted in (1, 0, 2):
             ops[posted] = make(torch.float64, n, mem=mem, scaling=True, device=dev)
         x = T(rng.uniform(-1, 1, n), dev)
         prs = pairs(rng, n, 7 if n > 10**6 else mem + 4, np.float64)
@@ -715,15 +717,17 @@ def test_posted_read_back_of_the_push_decision(lo, dev, kind, n):
         accepted = 0
         for k, (s, y) in enumerate(prs):
             got = {}
-            for posted in (1, 0):
+            for posted in (1, 0, 2):
                 ctx.tune("push_posted", posted)
                 lo.push(ops[posted], T(s, dev), T(y, dev))
                 res = torch.full((n,), float("nan"), dtype=torch.float64, device=dev)
                 lo.mul(res, ops[posted], x, 1.0, 0.0)
                 got[posted] = res.cpu().numpy()
-            assert ops[1].data.insert == ops[0].data.insert, k
-            assert ops[1].data.scaling_factor == ops[0].data.scaling_factor, k
-            assert (n == 1 or np.isfinite(got[1]).all()) and np.array_equal(got[1], got[0], equal_nan=True), k
+            for posted in (1, 2):
+                assert ops[posted].data.insert == ops[0].data.insert, (k, posted)
+                assert ops[posted].data.scaling_factor == ops[0].data.scaling_factor, (k, posted)
+                assert np.array_equal(got[posted], got[0], equal_nan=True), (k, posted)
+            assert n == 1 or np.isfinite(got[1]).all(), k
             accepted += int(getattr(ops[1], "_last_push_accepted", True))
         assert n == 1 or 3 <= accepted <= len(prs) - (0 if kind == "lsr1" else 2)   # both outcomes occurred (L-BFGS)
     finally:

@@ -56,6 +56,77 @@ def test_every_tune_key_is_documented_in_the_header():
     assert not missing, missing
 
 
+def _gfx950_code_objects(lo, td):
+    """the gfx950 code objects of libmxlo.so (clang offload bundles inside the HIP fat binary), written into `td`"""
+    import os
+    import re
+    import struct
+    so = os.path.join(os.path.dirname(lo._lib.__file__), "csrc", "libmxlo.so")
+    blob = open(so, "rb").read()
+    out = []
+    for bi, m in enumerate(re.finditer(re.escape(b"__CLANG_OFFLOAD_BUNDLE__"), blob)):
+        p = m.start()
+        (n,) = struct.unpack_from("<Q", blob, p + 24)
+        off = p + 32
+        for e in range(n):
+            o, size, tl = struct.unpack_from("<QQQ", blob, off)
+            off += 24
+            triple = blob[off:off + tl].decode()
+            off += tl
+            if "gfx950" not in triple or size == 0:
+                continue
+            f = os.path.join(td, f"co_{bi}_{e}.co")
+            with open(f, "wb") as fh:
+                fh.write(blob[p + o:p + o + size])
+            out.append(f)
+    return out
+
+
+def test_launch_bound_push_pass_keeps_its_loads_in_flight(lo):
+    """Static check on the built code objects (no GPU needed). Round 4 found the push pass at launch-bound sizes waiting
+    for EVERY load before issuing the next (`s_waitcnt vmcnt(0)` in front of each guarded load: 14 memory round trips for
+    5 columns, 44 for 20 — 6 .. 12 us for a few KB of data). Its FAST instantiation must issue the
+    (NC + 2) * UNROLL loads of a chunk back to back; the instantiation the HBM-bound sizes take must stay within the
+    register budget that gives it its occupancy (the branch-free form costs it 6 %)."""
+    import os
+    import re
+    import subprocess
+    import tempfile
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    readelf = "/opt/rocm/lib/llvm/bin/llvm-readelf"
+    if not (os.path.exists(objdump) and os.path.exists(readelf)):
+        pytest.skip("llvm-objdump / llvm-readelf not available")
+    # push_pass_kernel<double, 5, 2, NT=false, STORE=true, FAST>(PushPassArgs<double, 5>, double*)
+    fast = "_ZN4mxlo16push_pass_kernelIdLi5ELi2ELb0ELb1ELb1EEEvNS_12PushPassArgsIT_XT0_EEEPd"
+    slow = "_ZN4mxlo16push_pass_kernelIdLi5ELi2ELb1ELb1ELb0EEEvNS_12PushPassArgsIT_XT0_EEEPd"
+    found = {}
+    with tempfile.TemporaryDirectory() as td:
+        for f in _gfx950_code_objects(lo, td):
+            syms = subprocess.run([readelf, "--syms", "-W", f], capture_output=True, text=True, check=True).stdout
+            for name in (fast, slow):
+                if name in found or not re.search(r"FUNC\s+\S+\s+\S+\s+\d+\s+" + re.escape(name) + r"$", syms, re.M):
+                    continue
+                dis = subprocess.run([objdump, "-d", f"--disassemble-symbols={name}", f], capture_output=True, text=True,
+                                     check=True).stdout
+                run = best = loads = 0
+                for line in dis.splitlines():
+                    if "global_load" in line:
+                        loads += 1
+                        run += 1
+                        best = max(best, run)
+                    elif re.search(r"s_waitcnt.*vmcnt\(0\)", line):
+                        run = 0
+                notes = subprocess.run([readelf, "--notes", f], capture_output=True, text=True, check=True).stdout
+                i = notes.index(name)
+                vg = int(re.search(r"\.vgpr_count:\s+(\d+)", notes[i:]).group(1))
+                found[name] = (loads, best, vg)
+    assert fast in found and slow in found, sorted(found)
+    loads, best, vg = found[fast]
+    assert best >= (5 + 2) * 2, f"FAST push pass: longest run of loads without a full drain is {best} of {loads}"
+    loads, best, vg = found[slow]
+    assert vg <= 112, f"HBM-bound push pass (5 columns): {vg} VGPRs — fewer than 4 waves per SIMD"
+
+
 def test_no_kernel_of_the_library_uses_scratch(lo):
     """Static check on the built gfx950 code objects (no GPU needed): every kernel of libmxlo.so has
     `.private_segment_fixed_size: 0`. A run-time index into a per-lane register array, or one accumulator too many,

@@ -31,6 +31,7 @@ except ImportError:  # pragma: no cover - during bring-up only
     pass
 from .diagqn import DiagonalAndrei, DiagonalBFGS, DiagonalPSB, SpectralGradient
 from .graph import CapturedSequence, capture_mul
+from .utilities import check_ctranspose, check_hermitian, check_positive_definite, normest
 
 try:
     from . import sharded

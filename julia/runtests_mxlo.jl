@@ -217,4 +217,71 @@ end
   @test (@allocated push!(BD, x, y, tmpd)) == 0
   @test (@allocated push!(HD, x, y, 1.0, x, tmpd)) == 0
 end
+# The reference's diagnostics (src/utilities.jl:20-135) probe with HOST vectors (`ones(eltype(S), m)`, `rand(n)`), which a
+# device closure cannot take; the bodies are otherwise storage-agnostic. Here: the same statements with the probes on
+# the device (dot / norm on MXVector are mxlo_dot / mxlo_dot_c) — what tests/test_gpu_utilities.py runs through the
+# Python mirror (test/test_normest.jl, test/test_linop.jl:346-372, test/test_lbfgs.jl:48-52).
+function normest_dev(S, tol = -1, maxiter = 100)
+  T = eltype(S)
+  m, n = size(S)
+  cnt = 0
+  tol == -1 && (tol = Float64(eps(real(T))))
+  vh = ones(T, m); vh[randn(m) .< 0] .= -1
+  x = S' * dev(vh)
+  e = norm(x)
+  e == 0 && return e, cnt
+  rmul!(x, one(T) / e)
+  e_0 = zero(e)
+  while abs(e - e_0) > tol * e
+    e_0 = e
+    Sx = S * x
+    x = S' * Sx
+    normx = norm(x)
+    e = normx / norm(Sx)
+    rmul!(x, one(T) / normx)
+    cnt += 1
+    cnt > maxiter && break
+  end
+  return e, cnt
+end
+function check_hermitian_dev(op)
+  T = eltype(op)
+  v = dev(T.(rand(size(op, 1))))
+  w = op * v
+  s = dot(w, w)
+  t = dot(v, op * w)
+  ε = eps(real(T))
+  return abs(s - t) < (abs(s) + ε) * ε^(1 / 3)
+end
+function check_positive_definite_dev(op; semi = false)
+  T = eltype(op)
+  v = dev(T.(rand(size(op, 1))))
+  vw = dot(v, op * v)
+  ε = eps(real(T))
+  imag(vw) > sqrt(ε) * abs(vw) && return false
+  return semi ? (real(vw) ≥ 0) : (real(vw) > 0)
+end
+
+@testset "normest / check_* with device probes (mirror of test_normest.jl, test_linop.jl:346-372, test_lbfgs.jl:48-52)" begin
+  for (nrow, ncol) in ((10, 10), (3, 5), (10, 5)), T in (Float64, ComplexF64)
+    U, _ = qr(rand(T, nrow, nrow)); V, _ = qr(rand(T, ncol, ncol))
+    A = Matrix(U) * T[(1 + (i - 1) / (nrow - 1)) * (i == j) for i = 1:nrow, j = 1:ncol] * Matrix(V)'
+    est, _ = normest_dev(LinearOperator(MXMatrix(A)), eps(Float64), 10000)
+    @test abs(est - opnorm(A, 2)) / opnorm(A, 2) <= 1e-3
+  end
+  n = 10
+  h = dev(ComplexF64[-(-1.0)^i for i = 1:n] ./ sqrt(n))
+  H = opHouseholder(h)
+  op = H * opDiagonal(dev(ComplexF64.(1:n))) * H'
+  @test check_positive_definite_dev(op)
+  @test check_positive_definite_dev(H * opDiagonal(dev(ComplexF64.(0:(n - 1)))) * H', semi = true)
+  B = LBFGSOperator(Float64, n, MXVector{Float64}; mem = 5)
+  Hq = InverseLBFGSOperator(Float64, n, MXVector{Float64}; mem = 5)
+  for i = 1:7
+    s = dev(fill(Float64(i), n)); y = dev([Float64(i); ones(n - 1)])
+    push!(B, s, y); push!(Hq, s, y)
+  end
+  @test check_positive_definite_dev(B) && check_positive_definite_dev(Hq)
+  @test check_hermitian_dev(B) && check_hermitian_dev(Hq)
+end
 println("mxlo Julia smoke finished")

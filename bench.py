@@ -58,7 +58,12 @@ def parse(argv=None):
     # the N-device leg through the single-process shard ABI (runs in a child process with a timeout)
     ap.add_argument("--no-shard-leg", action="store_true")
     ap.add_argument("--shard-leg-timeout", type=float, default=420.0)
-    ap.add_argument("--launch-timeout", type=float, default=3000.0, help="self-launch: seconds before the ranks are stopped")
+    ap.add_argument("--launch-timeout", type=float, default=1200.0,
+                    help="self-launch: seconds before the ranks are stopped (kept below the driver's own 1800 s limit, so that a "
+                         "stuck run ends HERE, with the phase every rank was in, and not as an anonymous kill)")
+    ap.add_argument("--phase-timeout-scale", type=float, default=1.0,
+                    help="multiplies the per-phase watchdog limits of a rank (PHASE_LIMITS_S)")
+    ap.add_argument("--preflight-timeout-ms", type=int, default=60000, help="bound on every wait of the transport preflight")
     # internal / test aids
     ap.add_argument("--role", default="auto", choices=["auto", "shard-leg"], help=argparse.SUPPRESS)
     ap.add_argument("--worker-cmd", default=None,
@@ -78,6 +83,72 @@ def visible_device_count() -> int:
 def die(msg: str, code: int = 2):
     print(f"bench.py: {msg}", file=sys.stderr, flush=True)
     raise SystemExit(code)
+
+
+# Per-phase limits of one rank (seconds). A rank that sits in one phase for longer prints which phase (and which rank) to
+# stderr and exits with status 7; the launcher then stops the other ranks and reports every rank's last phase.
+PHASE_LIMITS_S = {
+    "import + library load": 300, "init_process_group": 300, "communicator creation": 240, "transport preflight": 240,
+    "operand set-up": 300, "clock spin-up": 300, "warm-up steps": 300, "timed loop": 300, "per-kernel timing": 300,
+    "quasi-Newton legs": 900, "cfg4 legs": 300, "misc legs": 600, "cpu baseline": 300, "teardown": 120,
+}
+
+
+class Watchdog:
+    """`with wd.phase("timed loop"): ...` — a daemon thread ends the process when a phase outlasts its limit. The
+    current phase is mirrored into $MXLO_BENCH_PHASE_DIR/rank<k> (when set by the launcher) for the post-mortem."""
+
+    def __init__(self, rank: int, scale: float = 1.0, limits=None, exit_fn=None):
+        import threading
+        self.rank, self.scale = rank, scale
+        self.limits = dict(PHASE_LIMITS_S if limits is None else limits)
+        self.exit_fn = exit_fn or (lambda code: os._exit(code))
+        self.cur, self.t0 = None, 0.0
+        self.history = []
+        self.lock = threading.Lock()
+        self.dir = os.environ.get("MXLO_BENCH_PHASE_DIR")
+        self.th = threading.Thread(target=self._run, daemon=True)
+        self.th.start()
+
+    def _note(self, text):
+        if self.dir:
+            try:
+                with open(os.path.join(self.dir, "rank%d" % self.rank), "w") as f:
+                    f.write(text)
+            except OSError:
+                pass
+
+    def _run(self):
+        while True:
+            time.sleep(0.25)
+            with self.lock:
+                cur, t0 = self.cur, self.t0
+            if cur is None:
+                continue
+            limit = self.limits.get(cur, 300) * self.scale
+            if time.time() - t0 > limit:
+                print(f"bench.py: WATCHDOG rank {self.rank} has been in phase '{cur}' for {time.time() - t0:.0f} s "
+                      f"(limit {limit:.0f} s) — stalled; exiting with status 7", file=sys.stderr, flush=True)
+                self._note(f"STALLED in '{cur}' after {time.time() - t0:.0f} s")
+                self.exit_fn(7)
+                return
+
+    def phase(self, name):
+        wd = self
+
+        class _P:
+            def __enter__(self_):
+                with wd.lock:
+                    wd.cur, wd.t0 = name, time.time()
+                wd._note(f"in '{name}' since {time.strftime('%H:%M:%S')}")
+
+            def __exit__(self_, et, ev, tb):
+                with wd.lock:
+                    wd.history.append((name, round(time.time() - wd.t0, 3)))
+                    wd.cur = None
+                wd._note(f"finished '{name}'" if et is None else f"FAILED in '{name}': {ev!r}"[:300])
+                return False
+        return _P()
 
 
 def check_topology(args, ndev: int):
@@ -121,10 +192,21 @@ def launch(args, argv):
     n = args.gpus
     port = int(os.environ.get("MASTER_PORT") or free_port())
     cmd = json.loads(args.worker_cmd) if args.worker_cmd else [sys.executable, os.path.abspath(__file__)] + list(argv)
+    import tempfile
+    phase_dir = tempfile.mkdtemp(prefix="mxlo_bench_phase_")
+
+    def last_phases():
+        out = []
+        for r in range(n):
+            try:
+                out.append("rank %d: %s" % (r, open(os.path.join(phase_dir, "rank%d" % r)).read().strip()))
+            except OSError:
+                out.append("rank %d: (no phase recorded)" % r)
+        return "; ".join(out)
     procs = []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), MXLO_BENCH_SELF_LAUNCHED="1")
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), MXLO_BENCH_SELF_LAUNCHED="1", MXLO_BENCH_PHASE_DIR=phase_dir)
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC only on this driver (RCCL needs it)
         procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE if r == 0 else sys.stderr, text=True))
     import threading
@@ -157,8 +239,13 @@ def launch(args, argv):
                 p.wait(timeout=max(0.1, t_end - time.time()))
             except Exception:
                 p.kill()
-        die(f"{n}-rank launch failed: {bad}", 3)
+        where = last_phases()
+        import shutil
+        shutil.rmtree(phase_dir, ignore_errors=True)
+        die(f"{n}-rank launch failed: {bad}. Last phase of every rank — {where}", 3)
     rd.join(10)
+    import shutil
+    shutil.rmtree(phase_dir, ignore_errors=True)
     line = last_json_line(out0[0] if out0 else "")
     if line is None:
         die("rank 0 printed no JSON line", 4)

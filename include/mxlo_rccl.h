@@ -27,6 +27,27 @@ int32_t mxlo_rccl_comm_destroy(void *comm);
 /* an `mxlo_allreduce_fn`: user = the communicator; sums `count` doubles in place on `stream`. */
 int32_t mxlo_rccl_allreduce_hook(void *user, void *dev_buf, int64_t count, void *stream);
 const char *mxlo_rccl_last_error(void);
+/* ncclCommAbort: tear the communicator down without waiting for outstanding collectives (a peer died, a collective
+ * timed out). mxlo_rccl_comm_create itself refuses a communicator whose ncclCommCount / ncclCommUserRank differ from
+ * what was asked for (a stale or foreign unique id). */
+int32_t mxlo_rccl_comm_abort(void *comm);
+/* What the communicator itself reports: ncclCommCount, ncclCommUserRank, ncclCommCuDevice and that device's PCI bus id
+ * (hipDeviceGetPCIBusId; `pci_bus_id` may be NULL). A multi-rank bench line records these as its proof that N distinct
+ * devices took part. */
+int32_t mxlo_rccl_comm_info(void *comm, int32_t *ranks, int32_t *user_rank, int32_t *device, char *pci_bus_id, int32_t pci_len);
+/* Preflight of a transport BEFORE any timed or production collective (every rank calls it; collective): for the three
+ * payload sizes of the hot path — 8 B (opHouseholder), 320 B (forward L-BFGS m = 20), 6912 B (solve_shifted_system!
+ * m = 20) — (1) an all-reduce with an exactly representable known answer (a missing / duplicated rank or a wrong sum
+ * shows), (2) an all-reduce of inexact sums whose result bits are compared across ranks (all ranks must hold IDENTICAL
+ * bits: they drive replicated control flow), (3) a verdict round so that every rank returns the same
+ * status, (4) the latency of `reps` back-to-back all-reduces on `stream` (HIP events) -> latency_us[0..2] in microseconds.
+ * Every wait is bounded by `timeout_ms` (hipStreamQuery + ncclCommGetAsyncError polling); on failure the error text
+ * names the payload, the phase and this rank. `mxlo_rccl_preflight` tests the native hook on `comm`;
+ * `mxlo_rccl_preflight_hook` tests ANY `mxlo_allreduce_fn` (the loopback and peer transports of the shard API, a host
+ * runtime's own hook); `comm` there is only used for asynchronous-error polling and may be NULL. */
+int32_t mxlo_rccl_preflight(void *comm, void *stream, int32_t reps, int32_t timeout_ms, double latency_us[3]);
+int32_t mxlo_rccl_preflight_hook(int32_t (*hook)(void *, void *, int64_t, void *), void *user, void *comm, int32_t rank,
+                                 int32_t world, void *stream, int32_t reps, int32_t timeout_ms, double latency_us[3]);
 
 /* ======================================================================================================
  *  Single-process multi-device API ("host code stays in one Julia process").

@@ -91,6 +91,7 @@ MXLO_API int32_t mxlo_ctx_create(int32_t device_id, void *stream, mxlo_ctx **out
       (void)hipGetLastError();
       ctx->tune.house_fused = 0;
       ctx->tune.qn_fused_small = 0;
+      ctx->tune.qn_persist = 0;
     }
   }
   *out = ctx;
@@ -123,12 +124,13 @@ int32_t fused_fault_check(mxlo_ctx *ctx) {
   (void)hipStreamSynchronize(ctx->stream);
   ctx->tune.house_fused = 0;
   ctx->tune.qn_fused_small = 0;
+  ctx->tune.qn_persist = 0;
   __atomic_store_n(ctx->fault_host, 0u, __ATOMIC_RELAXED);
   (void)rearm_fused_slots(ctx);
   set_error("a single-launch %s apply on this ctx timed out after %d ms waiting for its peer workgroups (the launch was "
             "not fully co-resident: GPU shared with other processes, CU masking, or a killed launch left the exchange "
             "slots inconsistent); that apply stored NaN. The exchange state has been re-armed and the single-launch "
-            "forms (house_fused, qn_fused_small) are now OFF for this ctx — repeat the apply",
+            "forms (house_fused, qn_fused_small, qn_persist) are now OFF for this ctx — repeat the apply",
             code == kFaultHouseholder ? "opHouseholder" : "quasi-Newton", ctx->tune.fused_timeout_ms);
   return MXLO_EHIP;
 }
@@ -423,6 +425,27 @@ MXLO_API int32_t mxlo_ctx_tune(mxlo_ctx *ctx, const char *key, int64_t value) {
   } else if (!strcmp(key, "qn_fused_small")) {
     MXLO_REQUIRE(value == 0 || value == 1, MXLO_EINVAL, "qn_fused_small must be 0 or 1");
     ctx->tune.qn_fused_small = (int)value;
+  } else if (!strcmp(key, "qn_persist")) {
+    MXLO_REQUIRE(value == 0 || value == 1, MXLO_EINVAL, "qn_persist must be 0 or 1");
+    ctx->tune.qn_persist = (int)value;
+  } else if (!strcmp(key, "qn_persist_min_n")) {
+    MXLO_REQUIRE(value >= 1, MXLO_EINVAL, "qn_persist_min_n must be >= 1");
+    ctx->tune.qn_persist_min_n = value;
+  } else if (!strcmp(key, "qn_persist_max_bytes")) {
+    MXLO_REQUIRE(value >= 0, MXLO_EINVAL, "qn_persist_max_bytes must be >= 0");
+    ctx->tune.qn_persist_max_bytes = value;
+  } else if (!strcmp(key, "qn_persist_min_bytes")) {
+    MXLO_REQUIRE(value >= 0, MXLO_EINVAL, "qn_persist_min_bytes must be >= 0");
+    ctx->tune.qn_persist_min_bytes = value;
+  } else if (!strcmp(key, "qn_persist_reverse")) {
+    MXLO_REQUIRE(value == 0 || value == 1, MXLO_EINVAL, "qn_persist_reverse must be 0 or 1");
+    ctx->tune.qn_persist_reverse = (int)value;
+  } else if (!strcmp(key, "qn_persist_lds_pad")) {
+    MXLO_REQUIRE(value >= 0 && value <= 112 * 1024, MXLO_EINVAL, "qn_persist_lds_pad must be in 0..114688 bytes");
+    ctx->tune.qn_persist_lds_pad = (int)value;
+  } else if (!strcmp(key, "combine_reverse")) {
+    MXLO_REQUIRE(value == 0 || value == 1, MXLO_EINVAL, "combine_reverse must be 0 or 1");
+    ctx->tune.combine_reverse = (int)value;
   } else if (!strcmp(key, "sp_xcds")) {
     MXLO_REQUIRE(value >= 1 && value <= 64, MXLO_EINVAL, "sp_xcds must be in 1..64");
     ctx->tune.sp_xcds = (int)value;

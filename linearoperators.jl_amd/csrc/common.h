@@ -140,6 +140,18 @@ struct Tune {
   int qn_fused_max_grid = 256;  // single-launch quasi-Newton apply: most workgroups it may use (<= 256; 64 = the round-3 limit)
   int qn_fused_batch12 = 1;   // single-launch quasi-Newton apply with 9 .. 12 columns on short vectors: all columns in one batch
   int qn_fused_small = 1;  // quasi-Newton applies with <= 64 workgroups of dots: dots + finalize + coefficients in one launch
+  int qn_persist = 1;      // quasi-Newton applies at cache-resident sizes: ONE persistent launch (one workgroup per CU, grid
+                           // exchange between the dots and the combine phase; qn.hip: qn_apply_persist_kernel)
+  int64_t qn_persist_min_n = 1ll << 19;          // ... from this vector length on (below: the single-launch slice form)
+  int64_t qn_persist_max_bytes = 448ll << 20;    // ... while the panel (columns x n x element size) is at most this many bytes
+                                                 // (profiles/r05_tune_persist.txt: ahead of four launches up to ~340 MB panels)
+  int qn_persist_reverse = 1;   // ... its combine phase walks the workgroup's chunks back to front
+  int qn_persist_lds_pad = 0;   // ... bytes of (unused) dynamic LDS requested per workgroup: > 80 KiB forces one workgroup per CU
+  int64_t qn_persist_min_bytes = 32ll << 20;     // ... and at least this many (an L-SR1 m = 5 apply at n = 2^19 — 21 MB — is
+                                                 // faster in the single-launch slice form: 10.7 vs 12.1 us)
+  int combine_reverse = 0; // four-launch applies: the combine pass walks the vectors back to front. Measured (round 5,
+                           // profiles/r05_bench_mid_apply.txt): -3.6 … +2.8 %, no gain on average — the grid-stride dots pass
+                           // leaves no usable tail behind; the persistent launch (whose workgroups own contiguous runs) does
   int push_wide = 1;       // one-pass push!: 20 columns per pass while >= 20 remain (0: always <= 10)
   int push_posted = 1;     // push!'s decision scalars: posted into mapped pinned host memory by a one-wave kernel and polled
                            // by the host (1) or copied with hipMemcpyAsync + a stream synchronisation (0)
@@ -233,16 +245,18 @@ __device__ __forceinline__ unsigned long long poll_slot(const unsigned long long
   return bits;
 }
 #endif
-// true when `grid` workgroups of `kernel` (kBlock threads, `lds` bytes of dynamic LDS) fit on the device at once.
-// Evaluated once per kernel instantiation and device (the occupancy query costs microseconds).
-template <auto Kernel>
-inline bool coresident(mxlo_ctx *ctx, int64_t grid, size_t lds = 0) {
+// true when `grid` workgroups of `kernel` (BLOCK threads, `lds_worst` bytes of dynamic LDS) fit on the device at once.
+// Evaluated once per kernel instantiation and device (the occupancy query costs microseconds) — so `lds_worst` must be
+// the LARGEST dynamic LDS size the kernel is ever launched with, not the size of the launch at hand: the cached answer
+// then holds for every launch (a smaller request can only fit better).
+template <auto Kernel, int BLOCK = kBlock>
+inline bool coresident(mxlo_ctx *ctx, int64_t grid, size_t lds_worst = 0) {
   static std::atomic<int> cache[64];                // per kernel: blocks per CU + 1 by device ordinal, 0 = unknown
   const int d = ctx->device & 63;
   int per = cache[d].load(std::memory_order_relaxed);
   if (per == 0) {
     int nb = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, Kernel, kBlock, lds) != hipSuccess) {
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, Kernel, BLOCK, lds_worst) != hipSuccess) {
       (void)hipGetLastError();
       nb = 0;
     }

@@ -146,6 +146,7 @@ struct CombineArgs {
   double alpha, beta;
   const double *coef;  // device coefficients, one per column (CM_DIAG_SR1: as_k per column)
   double shift = 0.0;  // CM_FWD/INV/LSR1: res += T(shift)*x after the epilogue (fused ShiftedOperator axpy!)
+  int reverse = 0;     // walk the vectors back to front (set by the applies that follow a dots pass over the same panel)
   // CM_LSR1R only: valid elements of x / res (the last vector may be partial; panel columns are zero padded), the
   // device scalars sf = T(*sfnum) / T(*sfden) is formed from, and the [3][kMaxRedBlocks] partial sums
   int64_t n_valid = 0;
@@ -180,8 +181,12 @@ combine_kernel(T *__restrict__ res, const T *__restrict__ x, const T *__restrict
     for (int e = 0; e < VEC; ++e) vset<T, VEC>(v, e, i * VEC + e < A.n_valid ? p[i * VEC + e] : T(0));
     return v;
   };
-  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < nvec;
-       i += (int64_t)gridDim.x * kBlock) {
+  // A.reverse: workgroup 0 takes the END of the vectors — what the dots pass that ran just before touched last and the
+  // Infinity Cache still holds (same elementwise arithmetic; only the order the workgroups walk the vectors in changes)
+  const int64_t nblk = (nvec + kBlock - 1) / kBlock;
+  for (int64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+    const int64_t i = (A.reverse ? nblk - 1 - blk : blk) * kBlock + threadIdx.x;
+    if (i >= nvec) continue;
     T q[VEC];
     V xv, rvk;
     // ---- prologue
@@ -957,7 +962,8 @@ bool try_fused_apply(mxlo_qn *h, T *res, const T *const *cols, const T *x, QnfAr
   *status = dispatch_ab<T>(F.beta, flags, [&]<typename CA, typename CB, bool B0>() -> int32_t {
     auto go2 = [&]<int KIND, int UU, int NB>() {
       const size_t lds = sizeof(double) * (size_t)F.ncol * (size_t)grid;
-      if (!(fits = coresident<qn_apply_fused_kernel<T, CA, CB, KIND, B0, UU, NB>>(ctx, grid, lds))) return;
+      // (occupancy is asked for the LARGEST dynamic LDS this kernel is ever launched with: the answer is cached)
+      if (!(fits = coresident<qn_apply_fused_kernel<T, CA, CB, KIND, B0, UU, NB>>(ctx, grid, sizeof(double) * kQnfMaxPart))) return;
       hipLaunchKernelGGL((qn_apply_fused_kernel<T, CA, CB, KIND, B0, UU, NB>), dim3((unsigned)grid), dim3(kBlock), lds, ctx->stream,
                          res, fc, x, h->n, ctx->qslots, F, O, fused_timeout_ticks(ctx), ctx->fault_dev,
                          ctx->tune.fused_debug_drop);
@@ -971,6 +977,293 @@ bool try_fused_apply(mxlo_qn *h, T *res, const T *const *cols, const T *x, QnfAr
     else if (F.kind == MXLO_QN_LBFGS_FWD) go.template operator()<MXLO_QN_LBFGS_FWD>();
     else go.template operator()<MXLO_QN_LSR1>();
     if (!fits) return MXLO_OK;          // not co-resident on this device: the four-launch apply runs instead
+    MXLO_LAUNCH_CHECK();
+    return MXLO_OK;
+  });
+  return fits;
+}
+
+// ---- cache-resident sizes: the whole apply as ONE PERSISTENT launch ----------------------------------------------------
+// Between the single-launch sizes above (one slice per workgroup, n <= 2^19 doubles) and the HBM-bound ones the panel is
+// tens to a few hundred MB: it fits, or nearly fits, the 256 MiB Infinity Cache, and the four-launch apply loses 10-20 %
+// to two grid fills / drains and two dependent tiny launches (profiles/r05_tune_persist.txt: measured ceilings and the
+// shape sweep this kernel's geometry comes from). Here ONE workgroup of kPersistBlock threads per CU owns a contiguous
+// run of chunks (a chunk = one 16-byte vector per lane):
+//   1. dots, batch-major: kPersistNB columns at a time over the workgroup's chunks, one f64 accumulator per column and
+//      lane (x is re-read per batch: it sits in L2),
+//   2. the exchange of qn_apply_fused_kernel (same slots, epoch word and bounded wait): partials published as
+//      self-validating agent-scope stores, gathered by every workgroup in a fixed order,
+//   3. the operator's coefficient recurrence, redundantly per workgroup,
+//   4. combine, chunk-major and BACK TO FRONT: the chunks the dots phase touched last are the likeliest to still sit in
+//      this XCD's L2 / the Infinity Cache (panels above 256 MiB: 146 -> 122 us at n = 2^22, 10 columns).
+// Same elementwise formulas and rounding points as combine_kernel; the dots are summed in a different (fixed) order than
+// the four-launch schedule's, so the two agree to rounding, not to the bit (both are deterministic run to run).
+constexpr int kPersistBlock = 512;   // 8 waves per CU, one workgroup per CU
+constexpr int kPersistNB = 10;       // columns per batch (10 independent 16-byte loads per lane in flight)
+
+template <typename T, typename CA, typename CB, int KIND, bool BETA0>
+__global__ void __launch_bounds__(kPersistBlock)
+qn_apply_persist_kernel(T *__restrict__ res, QnfCols<T> cols, const T *__restrict__ x, int64_t n, int cpw,
+                        unsigned long long *__restrict__ slots, QnfArgs F, OrdArgs O, unsigned long long ticks,
+                        unsigned *__restrict__ fault, int drop, int reverse) {
+  constexpr int VEC = Vec16<T>::N, NB = kPersistNB, NW = kPersistBlock / 64;
+  using V = typename Vec16<T>::type;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, G = (int)gridDim.x, b = (int)blockIdx.x;
+  const int ncol = F.ncol, na = O.na;
+  __shared__ double red[NW][kQnfMaxCols];
+  __shared__ double sdots[kQnfMaxCols];
+  __shared__ double scoef[kQnfMaxCols];
+  __shared__ double sg1[kQnfMaxCols * kQnfMaxCols / 2];     // inverse: s_i'y_j by ord position; forward: Cm (r x 2r)
+  __shared__ double sg2[kQnfMaxCols * kQnfMaxCols / 4];     // inverse: y_i'y_j by ord position; L-SR1: as by ord position
+  unsigned long long *epoch = slots + 2 * kQnfSlots;
+  const unsigned e = (unsigned)__hip_atomic_load(epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 1u;
+  unsigned long long *mine = slots + e * kQnfSlots, *other = slots + (1u - e) * kQnfSlots;
+  for (int i = b * kPersistBlock + tid; i < kQnfSlots; i += G * kPersistBlock)      // re-arm the other set for the next launch
+    __hip_atomic_store(other + i, kSlotEmpty, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if constexpr (KIND == MXLO_QN_LBFGS_INV) {
+    const int mem = O.mem;
+    for (int p = tid; p < na * na; p += kPersistBlock) {
+      const int i = O.ord[p / na], j = O.ord[p % na];
+      sg1[p] = O.age[j] >= O.age[i] ? F.SY[i + (int64_t)j * mem] : F.YS[j + (int64_t)i * mem];
+      sg2[p] = O.age[j] >= O.age[i] ? F.YY[i + (int64_t)j * mem] : F.YY[j + (int64_t)i * mem];
+    }
+  } else if constexpr (KIND == MXLO_QN_LBFGS_FWD) {
+    for (int p = tid; p < na * 2 * na; p += kPersistBlock) sg1[p] = F.Cm[p];
+  } else {
+    if (tid < na) sg2[tid] = F.as_[O.ord[tid]];
+  }
+  // this workgroup's chunks: [ch0, ch1) of kPersistBlock vectors each; only the very last chunk of the vector can hold
+  // lanes beyond n (or a partial last vector): it takes the guarded loads
+  const int64_t nvec = (n + VEC - 1) / VEC;
+  const int64_t nchunks = (nvec + kPersistBlock - 1) / kPersistBlock;
+  const int64_t ch0 = (int64_t)b * cpw < nchunks ? (int64_t)b * cpw : nchunks;
+  const int64_t ch1 = ch0 + cpw < nchunks ? ch0 + cpw : nchunks;
+  auto chunk_full = [&](int64_t ch) { return (ch + 1) * kPersistBlock * VEC <= n; };
+  auto ldv = [&](const T *p, int64_t i) -> V {   // guarded: 16-byte load, or element loads with zero fill (i: element index)
+    if (i + VEC <= n) return *reinterpret_cast<const V *>(p + i);
+    V v;
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) v[k] = i + k < n ? p[i + k] : T(0);
+    return v;
+  };
+  // ---- 1. dots (columns in DOTS order: cols.p[c])
+  for (int c0 = 0; c0 < ncol; c0 += NB) {
+    double acc[NB];
+    const T *cp[NB];
+#pragma unroll
+    for (int t = 0; t < NB; ++t) {
+      acc[t] = 0.0;
+      cp[t] = cols.p[c0 + t < ncol ? c0 + t : ncol - 1];      // clamp: a valid (unused) column instead of a branch
+    }
+    for (int64_t ch = ch0; ch < ch1; ++ch) {
+      const int64_t i = (ch * kPersistBlock + tid) * VEC;
+      V xv, cv[NB];
+      if (chunk_full(ch)) {
+        xv = *reinterpret_cast<const V *>(x + i);
+#pragma unroll
+        for (int t = 0; t < NB; ++t) cv[t] = *reinterpret_cast<const V *>(cp[t] + i);
+      } else {
+        xv = ldv(x, i);
+#pragma unroll
+        for (int t = 0; t < NB; ++t) cv[t] = ldv(cp[t], i);
+      }
+#pragma unroll
+      for (int t = 0; t < NB; ++t)
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) acc[t] = fma((double)cv[t][k], (double)xv[k], acc[t]);
+    }
+#pragma unroll
+    for (int t = 0; t < NB; ++t) {
+      const double s = wave_allsum(acc[t]);
+      if (lane == 0 && c0 + t < ncol) red[wave][c0 + t] = s;
+    }
+  }
+  __syncthreads();
+  // ---- 2. publish, gather (fixed order: lane l adds workgroups l, l + 64, ..., then one DPP tree)
+  if (tid < ncol) {
+    const double sv = ((red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid])) +
+                      ((red[4][tid] + red[5][tid]) + (red[6][tid] + red[7][tid]));
+    unsigned long long bits = (unsigned long long)__double_as_longlong(sv);
+    if (sv != sv) bits = kCanonicalNaN;
+    if (b != drop) __hip_atomic_store(mine + tid * kQnfMaxGrid + b, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  for (int c = wave; c < ncol; c += NW) {
+    constexpr int kPer = kQnfMaxGrid / 64;
+    const unsigned long long *row = mine + c * kQnfMaxGrid;
+    unsigned long long bits[kPer];
+#pragma unroll
+    for (int j = 0; j < kPer; ++j)      // first look: all of a lane's slots in flight together
+      bits[j] = lane + 64 * j < G ? __hip_atomic_load(row + lane + 64 * j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+    double pv = 0.0;
+#pragma unroll
+    for (int j = 0; j < kPer; ++j) {
+      if (lane + 64 * j < G) {
+        if (bits[j] == kSlotEmpty) bits[j] = poll_slot(row + lane + 64 * j, ticks, fault, kFaultQn);   // bounded wait
+        pv += __longlong_as_double((long long)bits[j]);
+      }
+    }
+    const double v = wave_allsum(pv);
+    if (lane == 0) sdots[c] = v;
+  }
+  __syncthreads();
+  if (b == 0 && tid == 0)                                             // every workgroup has read e: flip for the next launch
+    __hip_atomic_store(epoch, (unsigned long long)(1u - e), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // ---- 3. coefficients (one wave, redundantly per workgroup; the bodies of the *_coef_kernel launches)
+  if (wave == 0) {
+    if constexpr (KIND == MXLO_QN_LBFGS_INV) {
+      inv_coef_generic(lane, sdots, scoef, b == 0 ? F.alpha_out : nullptr, O,
+                       [&](int i, int j) { return sg1[i * na + j]; }, [&](int i, int j) { return sg2[i * na + j]; });
+    } else if constexpr (KIND == MXLO_QN_LBFGS_FWD) {
+      cfwd_coef_body(lane, sdots, sg1, scoef, na);
+    } else {
+      if (lane < na) {
+        const double d = rnd(sdots[lane], O.is_f32), as = rnd(sg2[lane], O.is_f32);
+        scoef[lane] = F.ct_f32 ? (double)(((float)F.alpha * (float)d) / (float)as) : (F.alpha * d) / as;
+      }
+    }
+  }
+  __syncthreads();
+  // ---- 4. combine, last chunk first (columns in COMBINE order)
+  const T g = (T)F.gamma;
+  const CA al = (CA)F.alpha;
+  const CB be = (CB)F.beta;
+  auto ccol = [&](int c) -> const T * {
+    if constexpr (KIND == MXLO_QN_LBFGS_INV) return c < F.nfirst ? cols.p[F.nfirst + c] : cols.p[2 * F.nfirst - 1 - c];
+    else return cols.p[c];
+  };
+  // One chunk; FULL: every lane's vector lies inside n — unconditional 16-byte accesses, so the NB column loads of a
+  // batch are in flight together (a per-load bounds branch makes the compiler drain the memory queue before every load).
+  auto combine_chunk = [&]<bool FULL>(int64_t ch) {
+    const int64_t i = (ch * kPersistBlock + tid) * VEC;
+    if constexpr (!FULL) {
+      if (i >= n) return;
+    }
+    V xv, rv;
+    if constexpr (FULL) {
+      xv = *reinterpret_cast<const V *>(x + i);
+      if constexpr (!BETA0) rv = *reinterpret_cast<const V *>(res + i);
+    } else {
+      xv = ldv(x, i);
+      if constexpr (!BETA0) rv = ldv(res, i);
+    }
+    T q[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+      if constexpr (KIND == MXLO_QN_LBFGS_FWD) q[k] = F.use_gamma ? xv[k] / g : xv[k];
+      else if constexpr (KIND == MXLO_QN_LBFGS_INV) q[k] = xv[k];
+      else q[k] = fin_ab<T, CA, CB, BETA0>((al * (CA)xv[k]) / (CA)g, be, BETA0 ? T(0) : rv[k]);     // lsr1.jl:93
+    }
+    for (int c0 = 0; c0 < ncol; c0 += NB) {
+      V cv[NB];
+#pragma unroll
+      for (int t = 0; t < NB; ++t) {
+        const T *p = ccol(c0 + t < ncol ? c0 + t : ncol - 1);      // clamp: a valid (unused) column instead of a branch
+        if constexpr (FULL) cv[t] = *reinterpret_cast<const V *>(p + i);
+        else cv[t] = ldv(p, i);
+      }
+#pragma unroll
+      for (int t = 0; t < NB; ++t) {
+        const int c = c0 + t;
+        if (c < ncol) {
+          if constexpr (KIND == MXLO_QN_LBFGS_INV) {
+            if (c == F.nfirst && F.use_gamma) {
+#pragma unroll
+              for (int k = 0; k < VEC; ++k) q[k] = q[k] * g;                                         // lbfgs.jl:139
+            }
+            const T cc = (T)scoef[c];
+            if (c < F.nfirst) {
+#pragma unroll
+              for (int k = 0; k < VEC; ++k) q[k] = q[k] - (cc * cv[t][k]);                           // lbfgs.jl:135
+            } else {
+#pragma unroll
+              for (int k = 0; k < VEC; ++k) q[k] = q[k] + (cc * cv[t][k]);                           // lbfgs.jl:146
+            }
+          } else if constexpr (KIND == MXLO_QN_LBFGS_FWD) {
+            const T cc = (T)scoef[c];
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) q[k] = q[k] + (cc * cv[t][k]);
+          } else {
+            const CA cc = (CA)scoef[c];
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) q[k] = (T)((CA)q[k] + (cc * (CA)cv[t][k]));                // lsr1.jl:103
+          }
+        }
+      }
+    }
+    V ov;
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+      T o;
+      if constexpr (KIND == MXLO_QN_LSR1) o = q[k];
+      else o = fin_ab<T, CA, CB, BETA0>(al * (CA)q[k], be, BETA0 ? T(0) : rv[k]);                    // lbfgs.jl:150,198
+      if (F.shift != 0.0) o = o + ((T)F.shift * xv[k]);                                              // shifted_operators.jl:21-23
+      ov[k] = o;
+    }
+    if constexpr (FULL) *reinterpret_cast<V *>(res + i) = ov;
+    else {
+#pragma unroll
+      for (int k = 0; k < VEC; ++k)
+        if (i + k < n) res[i + k] = ov[k];
+    }
+  };
+  for (int64_t kk = 0; kk < ch1 - ch0; ++kk) {
+    const int64_t ch = reverse ? ch1 - 1 - kk : ch0 + kk;
+    if (chunk_full(ch)) combine_chunk.template operator()<true>(ch);
+    else combine_chunk.template operator()<false>(ch);
+  }
+}
+
+// raise the kernel's dynamic-LDS cap once per (instantiation, device)
+template <auto Kernel>
+bool persist_lds_attr_set(mxlo_ctx *ctx) {
+  static std::atomic<int> state[64];                // 0 unknown, 1 set, 2 refused
+  const int d = ctx->device & 63;
+  int st = state[d].load(std::memory_order_relaxed);
+  if (st == 0) {
+    st = hipFuncSetAttribute((const void *)Kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) == hipSuccess ? 1 : 2;
+    if (st == 2) (void)hipGetLastError();
+    state[d].store(st, std::memory_order_relaxed);
+  }
+  return st == 1;
+}
+
+// true: the whole apply was issued as one persistent launch
+template <typename T>
+bool try_persist_apply(mxlo_qn *h, T *res, const T *const *cols, const T *x, QnfArgs F, const OrdArgs &O, int32_t flags,
+                       int32_t *status) {
+  mxlo_ctx *ctx = h->ctx;
+  constexpr int VEC = Vec16<T>::N;
+  const int64_t panel_bytes = (int64_t)sizeof(T) * h->n * F.ncol;
+  const int grid = ctx->num_cu < kQnfMaxGrid ? ctx->num_cu : kQnfMaxGrid;
+  if (!ctx->tune.qn_persist || ctx->allreduce || F.ncol < 1 || F.ncol > kQnfMaxCols || h->n < ctx->tune.qn_persist_min_n ||
+      panel_bytes > ctx->tune.qn_persist_max_bytes || panel_bytes < ctx->tune.qn_persist_min_bytes || !ctx->qslots || !ctx->fault_dev ||
+      ((((uintptr_t)x) | ((uintptr_t)res)) & 15u) != 0)
+    return false;
+  QnfCols<T> fc;
+  for (int c = 0; c < F.ncol; ++c) {
+    if ((((uintptr_t)cols[c]) & 15u) != 0) return false;
+    fc.p[c] = cols[c];
+  }
+  if ((*status = fused_fault_check(ctx)) != MXLO_OK) return true;    // an earlier timed-out single-launch apply: reported here
+  const int64_t nvec = (h->n + VEC - 1) / VEC;
+  const int64_t nchunks = (nvec + kPersistBlock - 1) / kPersistBlock;
+  const int cpw = (int)((nchunks + grid - 1) / grid);
+  bool fits = true;
+  *status = dispatch_ab<T>(F.beta, flags, [&]<typename CA, typename CB, bool B0>() -> int32_t {
+    auto go = [&]<int KIND>() {
+      if (!(fits = coresident<qn_apply_persist_kernel<T, CA, CB, KIND, B0>, kPersistBlock>(ctx, grid, 0))) return;
+      // Dynamic LDS the kernel never touches: with more than half a CU's 160 KiB requested, the dispatcher cannot put two of
+      // the 256 workgroups on one CU (and leave another CU idle) — one workgroup per CU by construction.
+      const size_t pad = (size_t)ctx->tune.qn_persist_lds_pad;
+      if (pad > 48 * 1024 && !persist_lds_attr_set<qn_apply_persist_kernel<T, CA, CB, KIND, B0>>(ctx)) { fits = false; return; }
+      hipLaunchKernelGGL((qn_apply_persist_kernel<T, CA, CB, KIND, B0>), dim3((unsigned)grid), dim3(kPersistBlock), pad,
+                         ctx->stream, res, fc, x, h->n, cpw, ctx->qslots, F, O, fused_timeout_ticks(ctx), ctx->fault_dev,
+                         ctx->tune.fused_debug_drop, ctx->tune.qn_persist_reverse);
+    };
+    if (F.kind == MXLO_QN_LBFGS_INV) go.template operator()<MXLO_QN_LBFGS_INV>();
+    else if (F.kind == MXLO_QN_LBFGS_FWD) go.template operator()<MXLO_QN_LBFGS_FWD>();
+    else go.template operator()<MXLO_QN_LSR1>();
+    if (!fits) return MXLO_OK;
     MXLO_LAUNCH_CHECK();
     return MXLO_OK;
   });
@@ -1016,6 +1309,7 @@ int32_t inv_mul_twopass(mxlo_qn *h, T *res, const T *x, double alpha, double bet
       F.YY = h->dsc + h->lay.YY;
       F.alpha_out = h->dsc + h->lay.alpha;
       int32_t fst = MXLO_OK;
+      if (try_persist_apply<T>(h, res, cols, x, F, O, flags, &fst)) return fst;
       if (try_fused_apply<T>(h, res, cols, x, F, O, flags, &fst)) return fst;
     }
     MXLO_TRY(panel_dots<T>(ctx, cols, 2 * na, x, h->n, dots));
@@ -1033,6 +1327,7 @@ int32_t inv_mul_twopass(mxlo_qn *h, T *res, const T *x, double alpha, double bet
       A.cols[na + i] = col<T>(h->S, h->ld, O.ord[na - 1 - i]); // s, oldest -> newest
     }
   }  // no pairs: ncol == 0 and `q .*= scaling_factor` still executes (γ == 1 after reset!)
+  A.reverse = ctx->tune.combine_reverse;
   return launch_combine<T, CM_INV>(ctx, res, x, (const T *)nullptr, A, h->n, flags);
 }
 
@@ -1110,11 +1405,13 @@ int32_t fwd_mul(mxlo_qn *h, T *res, const T *x, double alpha, double beta, int32
       F.shift = shift;
       F.Cm = h->dsc + h->lay.Cm;
       int32_t fst = MXLO_OK;
+      if (try_persist_apply<T>(h, res, A.cols, x, F, O, flags, &fst)) return fst;
       if (try_fused_apply<T>(h, res, A.cols, x, F, O, flags, &fst)) return fst;
     }
     MXLO_TRY(panel_dots<T>(ctx, A.cols, 2 * na, x, h->n, dots));
     hipLaunchKernelGGL(cfwd_coef_kernel, dim3(1), dim3(64), 0, ctx->stream, dots, h->dsc + h->lay.Cm, coef, na);
     MXLO_LAUNCH_CHECK();
+    A.reverse = ctx->tune.combine_reverse;
     return launch_combine<T, CM_CFWD>(ctx, res, x, (const T *)nullptr, A, h->n, flags);
   }
   if (na > 0) {
@@ -1127,6 +1424,7 @@ int32_t fwd_mul(mxlo_qn *h, T *res, const T *x, double alpha, double beta, int32
                        (int)(h->dtype == MXLO_F32));
     MXLO_LAUNCH_CHECK();
   }
+  A.reverse = ctx->tune.combine_reverse;
   return launch_combine<T, CM_FWD>(ctx, res, x, (const T *)nullptr, A, h->n, flags);
 }
 
@@ -1163,6 +1461,7 @@ int32_t lsr1_mul(mxlo_qn *h, T *res, const T *x, double alpha, double beta, int3
       F.as_ = h->dsc + h->lay.as_;
       F.ct_f32 = ct_f32;
       int32_t fst = MXLO_OK;
+      if (try_persist_apply<T>(h, res, A.cols, x, F, O, flags, &fst)) return fst;
       if (try_fused_apply<T>(h, res, A.cols, x, F, O, flags, &fst)) return fst;
     }
     MXLO_TRY(panel_dots<T>(ctx, A.cols, na, x, h->n, dots));
@@ -1170,6 +1469,7 @@ int32_t lsr1_mul(mxlo_qn *h, T *res, const T *x, double alpha, double beta, int3
                        h->dsc + h->lay.as_, O, alpha, ct_f32);
     MXLO_LAUNCH_CHECK();
   }
+  A.reverse = ctx->tune.combine_reverse;
   return launch_combine<T, CM_LSR1>(ctx, res, x, (const T *)nullptr, A, h->n, flags);
 }
 

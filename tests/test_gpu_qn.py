@@ -986,6 +986,114 @@ def test_single_launch_apply_timeout_is_an_error_not_a_hang(lo, dev, kind):
         ctx.tune("qn_fused_small", 1)
 
 
+# ------------------------------------------------------------------------------- the persistent single-launch apply
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("kind", ["inv", "fwd", "lsr1"])
+@pytest.mark.parametrize("n,mem", [(1 << 19, 5), ((1 << 19) + 5, 10), ((1 << 20) + 1, 3), (3 * (1 << 18) + 7, 20), (1_000_003, 7)])
+def test_persistent_apply_matches_the_four_launch_apply_and_the_oracle(lo, dev, dtype, kind, n, mem):
+    """at cache-resident sizes (n >= 2^19, panel <= 448 MB) a quasi-Newton apply is ONE persistent launch
+    (csrc/qn.hip: qn_apply_persist_kernel — one 512-thread workgroup per CU owning a contiguous run of chunks; dots,
+    the slot exchange of the single-launch apply, the coefficient recurrence per workgroup, the combine back to front).
+    Against the four-launch schedule (`qn_persist` = 0: same coefficient code and elementwise formulas, a different fixed
+    summation order of the dots) and the oracle (src/lbfgs.jl:117-154,173-202; src/lsr1.jl:89-107): partially filled and
+    wrapped memories, alpha / beta forms, the fused shifted apply, lengths that end in a partial vector and a partial
+    chunk, a misaligned x (four launches), and bit-identical results run to run."""
+    from linearoperators_jl_amd.device import get_ctx
+    ctx = get_ctx(dev)
+    npd = NP[dtype]
+    rng = np.random.default_rng(n + 31 * mem)
+    make = {"inv": lo.InverseLBFGSOperator, "fwd": lo.LBFGSOperator, "lsr1": lo.LSR1Operator}[kind]
+    op = make(dtype, n, mem=mem, scaling=True, device=dev)
+    O = oracle.LSR1(n, mem=mem, scaling=True, dtype=npd) if kind == "lsr1" else oracle.LBFGS(n, mem=mem, scaling=True, inverse=(kind == "inv"), dtype=npd)
+    tol = 1e-9 if dtype == torch.float64 else QN_F32
+    x, r0 = rng.uniform(-1, 1, n).astype(npd), rng.uniform(-1, 1, n).astype(npd)
+    xm = torch.empty(n + 1, dtype=dtype, device=dev)
+    xm[1:].copy_(T(x, dev))
+    def launches():
+        import ctypes as C
+        a = (C.c_int64 * 12)()
+        lo._lib.call("mxlo_debug_counters", a)
+        return a[10]
+    for k, (s, y) in enumerate(pairs(rng, n, mem + 2, npd)):
+        lo.push(op, T(s, dev), T(y, dev)); O.push(s, y)
+        if k not in (0, mem // 2, mem + 1):
+            continue
+        for a, b in ((1.0, 0.0), (2.0, -3.0)):
+            fl = oracle.SCALARS_F64 if dtype == torch.float32 else 0
+            want = O.mul(r0.copy(), x, a, b, flags=fl)
+            got = {}
+            for persist in (1, 0):
+                ctx.tune("qn_persist", persist)
+                ctx.tune("qn_fused_small", persist)      # (n = 2^19 is still within reach of the single-launch slice form)
+                try:
+                    res = T(r0.copy(), dev)
+                    xd = T(x, dev)
+                    l0 = launches()
+                    lo.mul(res, op, xd, a, b)
+                    nl = launches() - l0
+                    assert (nl == 1) if persist else (nl >= 3), (persist, nl)
+                    got[persist] = res.cpu().numpy()
+                    if persist:
+                        res2 = T(r0.copy(), dev)
+                        lo.mul(res2, op, xd, a, b)
+                        assert np.array_equal(res2.cpu().numpy(), got[1]), "run-to-run determinism"
+                        res3 = T(r0.copy(), dev)
+                        lo.mul(res3, op, xm[1:], a, b)                       # misaligned x: the four-launch path
+                        assert rel(res3.cpu().numpy(), want) <= tol
+                finally:
+                    ctx.tune("qn_persist", 1)
+                    ctx.tune("qn_fused_small", 1)
+            assert rel(got[1], want) <= tol and rel(got[0], want) <= tol, (k, a, b, rel(got[1], want), rel(got[0], want))
+            assert rel(got[1], got[0]) <= (1e-12 if dtype == torch.float64 else 2e-5), (k, a, b)
+    sh = lo.ShiftedOperator(op, 0.37)
+    res = T(r0.copy(), dev)
+    lo.mul(res, sh, T(x, dev), 1.5, 0.5)
+    want = 1.5 * (O.mul(np.empty(n, npd), x).astype(np.float64) + 0.37 * x.astype(np.float64)) + 0.5 * r0.astype(np.float64)
+    assert rel(res.cpu().numpy().astype(np.float64), want) <= tol
+
+
+def test_persistent_apply_timeout_is_an_error_not_a_hang(lo, dev):
+    """The persistent apply shares the bounded wait of the single-launch forms: a workgroup that never publishes (test
+    hook `fused_debug_drop`) ends the launch with NaN + the ctx fault word; the next call reports it, re-arms the slots
+    and switches the single-launch forms off; four launches give the right answer; re-enabled, the persistent launch is
+    bit-identical to its first run. A captured graph of it replays (epoch word in device memory)."""
+    from linearoperators_jl_amd.device import get_ctx
+    ctx = get_ctx(dev)
+    rng = np.random.default_rng(6)
+    n, mem = (1 << 19) + 3, 4
+    op = lo.LBFGSOperator(torch.float64, n, mem=mem, device=dev)
+    for s, y in pairs(rng, n, mem + 1, np.float64):
+        lo.push(op, T(s, dev), T(y, dev))
+    x = T(rng.uniform(-1, 1, n), dev)
+    res = torch.zeros(n, dtype=torch.float64, device=dev)
+    try:
+        lo.mul(res, op, x, 1.0, 0.0)
+        torch.cuda.synchronize()
+        good = res.clone()
+        ctx.tune("fused_timeout_ms", 20)
+        ctx.tune("fused_debug_drop", 100)
+        lo.mul(res, op, x, 1.0, 0.0)
+        torch.cuda.synchronize()
+        assert bool(torch.isnan(res).any())
+        ctx.tune("fused_debug_drop", -1)
+        with pytest.raises(Exception, match="timed out"):
+            lo.mul(res, op, x, 1.0, 0.0)
+        lo.mul(res, op, x, 1.0, 0.0)                     # four launches now
+        torch.cuda.synchronize()
+        assert float((res - good).norm() / good.norm()) <= 1e-12
+        ctx.tune("qn_persist", 1)
+        for _ in range(4):
+            lo.mul(res, op, x, 1.0, 0.0)
+        torch.cuda.synchronize()
+        assert torch.equal(res, good)
+    finally:
+        ctx.tune("fused_debug_drop", -1)
+        ctx.tune("fused_timeout_ms", 2000)
+        ctx.tune("house_fused", 1)
+        ctx.tune("qn_fused_small", 1)
+        ctx.tune("qn_persist", 1)
+
+
 @pytest.mark.parametrize("kind", ["inv", "fwd", "lsr1"])
 def test_push_of_a_pair_that_lives_in_the_operators_own_storage(lo, dev, kind):
     """the streaming push! schedules read the caller's s and y while kernels store into the slot being

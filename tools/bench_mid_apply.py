@@ -33,8 +33,22 @@ def timeit(fn, reps):
     return tm.elapsed_ms() / reps * 1e3
 
 
-for kind, m in (("inv", 5), ("inv", 10), ("fwd", 5), ("lsr1", 5)):
+persist = os.environ.get("MXLO_QN_PERSIST")
+if persist is not None:
+    ctx.tune("qn_persist", int(persist))
+    print(f"# qn_persist = {persist}")
+for key in ("qn_persist_reverse", "qn_persist_lds_pad", "qn_persist_max_bytes", "qn_persist_min_n"):
+    if os.environ.get("MXLO_" + key.upper()) is not None:
+        ctx.tune(key, int(os.environ["MXLO_" + key.upper()]))
+        print(f"# {key} = {os.environ['MXLO_' + key.upper()]}")
+only = os.environ.get("MXLO_MID_ONLY")      # e.g. "inv:5,fwd:10"
+if os.environ.get("MXLO_COMBINE_REVERSE") is not None:
+    ctx.tune("combine_reverse", int(os.environ["MXLO_COMBINE_REVERSE"]))
+    print(f"# combine_reverse = {os.environ['MXLO_COMBINE_REVERSE']}")
+for kind, m in (("inv", 5), ("inv", 10), ("inv", 20), ("fwd", 5), ("fwd", 10), ("fwd", 20), ("lsr1", 5), ("lsr1", 20)):
     for e in (19, 20, 21, 22, 23, 24):
+        if m * (1 << e) * 8 * 3 > 40e9 or (only and f"{kind}:{m}" not in only.split(",")):
+            continue
         n = 1 << e
         op = {"inv": lo.InverseLBFGSOperator, "fwd": lo.LBFGSOperator, "lsr1": lo.LSR1Operator}[kind](torch.float64, n, mem=m, device=dev)
         for _ in range(m + 1):

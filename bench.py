@@ -305,17 +305,18 @@ def main(argv=None):
 
 def worker(args):
     """One rank: returns the JSON object on rank 0, None elsewhere."""
-    import torch
-    import torch.distributed as dist
-
-    import __graft_entry__ as g
-    lo = g.load_package()
-    from linearoperators_jl_amd import _lib
-    from linearoperators_jl_amd.device import Timer, dtype_code, get_ctx, ptr
-
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    wd = Watchdog(rank, args.phase_timeout_scale)
+    with wd.phase("import + library load"):
+        import torch
+        import torch.distributed as dist
+
+        import __graft_entry__ as g
+        lo = g.load_package()
+        from linearoperators_jl_amd import _lib
+        from linearoperators_jl_amd.device import Timer, dtype_code, get_ctx, ptr
     distributed = world > 1
     if args.gpus != world:
         die(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher must start exactly one rank per requested GPU")
@@ -326,10 +327,11 @@ def worker(args):
     dev = torch.device("cuda", local_rank)
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        else:
-            dist.init_process_group(args.backend, rank=rank, world_size=world)
+        with wd.phase("init_process_group"):
+            if args.backend == "nccl":
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            else:
+                dist.init_process_group(args.backend, rank=rank, world_size=world)
     ctx = get_ctx(dev)
     hook = None
     native = args.backend == "nccl" and not args.single_device
@@ -348,9 +350,38 @@ def worker(args):
             return
         lo.sharded.install_allreduce(ctx, native=False)   # Python hook over torch.distributed (gloo debugging only)
 
-    install_hook()                             # RCCL all-reduce of the partial dots over xGMI
+    with wd.phase("communicator creation"):
+        install_hook()                         # RCCL all-reduce of the partial dots over xGMI
+
+    # ---- the transport proves itself BEFORE anything is timed: every rank all-reduces known 8 B /
+    # 320 B / 6912 B payloads through the hook the applies use, checks the sums, checks that all ranks hold identical bits,
+    # agrees on the verdict, and records what the communicator reports about itself. A failure ends the run non-zero,
+    # naming phase and rank; every wait is bounded.
+    transports = {}
+    peer_hook = None
+    with wd.phase("transport preflight"):
+        try:
+            transports = transport_preflight(args, lo, torch, dist, ctx, dev, rank, world, hook if native else None)
+        except Exception as e:
+            if distributed:
+                die(f"rank {rank}: transport preflight failed: {e}", 6)
+            transports = {"error": repr(e)[:300]}       # N = 1: informational only (no collective is on the timed path)
+        if distributed and native and not args.no_extras:
+            try:   # the second transport: peer-mapped one-shot exchange (csrc/peer.hip), measured below next to RCCL
+                peer_hook = lo.sharded.PeerShmHook(rank, world, timeout_ms=args.preflight_timeout_ms)
+                transports["peer_shm"] = {"latency_us": peer_hook.preflight(ctx.stream, 50, args.preflight_timeout_ms),
+                                          "mailboxes": "POSIX shm segment registered with every rank's HIP runtime; one kernel per collective"}
+            except Exception as e:
+                transports["peer_shm"] = {"error": repr(e)[:300]}
+                peer_hook = None
+            ok = torch.tensor([1 if peer_hook is not None else 0], dtype=torch.int32, device=dev)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0:
+                peer_hook = None                        # never a mix of transports
 
     n = args.n
+    ph = wd.phase("operand set-up")
+    ph.__enter__()
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
     h = torch.rand(n, dtype=torch.float64, device=dev, generator=gen) - 0.5
     nrm2 = (h * h).sum()
@@ -361,6 +392,7 @@ def worker(args):
     res = torch.empty(n, dtype=torch.float64, device=dev)
     H = lo.opHouseholder(h)
     alpha, beta = 1.0, 0.0
+    ph.__exit__(None, None, None)
 
     def barrier():
         torch.cuda.synchronize()
@@ -371,26 +403,32 @@ def worker(args):
     # The GPU idles at a few hundred MHz (sclk 525 MHz at rest) and needs tens of milliseconds of load to reach its
     # steady clocks; W = 10 warm-up steps are only 6 ms. Bring the clocks up first (untimed, same kernels), then do
     # the W warm-up steps and time EXACTLY K steps as the contract says.
-    if distributed:
-        # every apply contains a collective: all ranks must issue the SAME number of them, so the spin is a fixed count
-        # (a time-based loop would let ranks disagree and hang the all-reduce)
-        for _ in range(min(5000, max(20, int(args.clock_spin_s / (0.7e-3 * max(n / 1e8, 1e-3)))))):
-            lo.mul(res, H, v, alpha, beta)
-        torch.cuda.synchronize()
-    else:
-        t_spin = time.perf_counter()
-        while time.perf_counter() - t_spin < args.clock_spin_s:
-            for _ in range(20):
+    def spin_up():
+        if distributed:
+            # every apply contains a collective: all ranks must issue the SAME number of them, so the spin is a fixed count
+            # (a time-based loop would let ranks disagree and hang the all-reduce)
+            for _ in range(min(5000, max(20, int(args.clock_spin_s / (0.7e-3 * max(n / 1e8, 1e-3)))))):
                 lo.mul(res, H, v, alpha, beta)
             torch.cuda.synchronize()
-    for _ in range(args.warmup):
-        lo.mul(res, H, v, alpha, beta)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        lo.mul(res, H, v, alpha, beta)
-    barrier()
-    dt = time.perf_counter() - t0
+        else:
+            t_spin = time.perf_counter()
+            while time.perf_counter() - t_spin < args.clock_spin_s:
+                for _ in range(20):
+                    lo.mul(res, H, v, alpha, beta)
+                torch.cuda.synchronize()
+
+    with wd.phase("clock spin-up"):
+        spin_up()
+    with wd.phase("warm-up steps"):
+        for _ in range(args.warmup):
+            lo.mul(res, H, v, alpha, beta)
+        barrier()
+    with wd.phase("timed loop"):
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            lo.mul(res, H, v, alpha, beta)
+        barrier()
+        dt = time.perf_counter() - t0
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if distributed:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -399,7 +437,33 @@ def worker(args):
     bytes_per_step = 40.0 * n * world                   # 16 B/elt dot pass + 24 B/elt update pass
     value = bytes_per_step / (dt / args.steps) / 1e9
 
+    # ---- the same K steps under the SECOND transport (peer-mapped one-shot exchange), N > 1 only: reported next to the
+    # RCCL headline, never as `value`
+    if peer_hook is not None:
+        with wd.phase("timed loop"):
+            try:
+                peer_hook.install(ctx)
+                for _ in range(max(5, args.warmup)):
+                    lo.mul(res, H, v, alpha, beta)
+                barrier()
+                tp0 = time.perf_counter()
+                for _ in range(args.steps):
+                    lo.mul(res, H, v, alpha, beta)
+                barrier()
+                tp = torch.tensor([time.perf_counter() - tp0], dtype=torch.float64, device=dev)
+                dist.all_reduce(tp, op=dist.ReduceOp.MAX)
+                peer_hook.check()
+                transports["peer_shm"]["householder_ms_per_step"] = round(float(tp.item()) / args.steps * 1e3, 4)
+                transports["peer_shm"]["householder_GB/s"] = round(bytes_per_step / (float(tp.item()) / args.steps) / 1e9, 1)
+                transports.setdefault("rccl", {})["householder_ms_per_step"] = round(ms_per_step, 4)
+            except Exception as e:
+                die(f"rank {rank}: the peer transport failed inside its timed loop: {e}", 6)
+            finally:
+                install_hook()
+
     # ---- per-kernel timing with HIP events on the launch stream (rank-local)
+    wd_k = wd.phase("per-kernel timing")
+    wd_k.__enter__()
     tm = Timer(ctx)
     f64 = dtype_code(torch.float64)
     K = max(10, min(args.steps, 50))
@@ -425,6 +489,7 @@ def worker(args):
     tm.stop()
     ms_diag = tm.elapsed_ms() / K
     install_hook()
+    wd_k.__exit__(None, None, None)
 
     upd_gbs = 24.0 * n / (ms_upd * 1e-3) / 1e9
     traffic = None
@@ -452,27 +517,40 @@ def worker(args):
 
     # ---- quasi-Newton apply/s (the second figure of the metric string)
     if not args.no_extras and hasattr(lo, "InverseLBFGSOperator"):
-        try:
-            extras.update(bench_lbfgs(lo, torch, dev, ctx, rank, world, distributed, dist, barrier))
-        except Exception as e:  # never lose the headline line
-            extras["lbfgs_error"] = repr(e)
-        install_hook()                                   # rank 0 cleared it for the single-GPU cfg5 leg
+        with wd.phase("quasi-Newton legs"):
+            try:
+                extras.update(bench_lbfgs(lo, torch, dev, ctx, rank, world, distributed, dist, barrier))
+            except Exception as e:  # never lose the headline line
+                extras["lbfgs_error"] = repr(e)
+            install_hook()                                   # rank 0 cleared it for the single-GPU cfg5 leg
 
     if not args.no_extras:
-        try:
-            extras.update(bench_cfg4(lo, torch, dev, ctx))
-        except Exception as e:
-            extras["cfg4_error"] = repr(e)
+        with wd.phase("cfg4 legs"):
+            try:
+                extras.update(bench_cfg4(lo, torch, dev, ctx))
+            except Exception as e:
+                extras["cfg4_error"] = repr(e)
 
     if not args.no_extras and rank == 0 and world == 1:
-        try:
-            extras.update(bench_misc(lo, torch, dev, ctx))
-        except Exception as e:
-            extras["misc_error"] = repr(e)
+        with wd.phase("misc legs"):
+            try:
+                extras.update(bench_misc(lo, torch, dev, ctx))
+            except Exception as e:
+                extras["misc_error"] = repr(e)
 
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu_baseline = cpu_leg(args.cpu_sample)
+        with wd.phase("cpu baseline"):
+            cpu_baseline = cpu_leg(args.cpu_sample)
+            # the reference's CPU mul! beside the OTHER two figures of the metric string, in the same run
+            if not args.no_extras:
+                try:
+                    if "InverseLBFGS_m10_n5e7" in extras:
+                        extras["InverseLBFGS_m10_n5e7"]["cpu"] = cpu_leg_lbfgs()
+                    if "kron_1024x1024" in extras:
+                        extras["kron_1024x1024"]["cpu"] = cpu_leg_kron()
+                except Exception as e:
+                    extras["cpu_legs_error"] = repr(e)[:200]
 
     out = None
     if rank == 0:
@@ -489,15 +567,63 @@ def worker(args):
                        "devices_visible": torch.cuda.device_count()},
             "frac_hbm_peak": round(value / world / HBM_PEAK_GBS, 4),
             "roofline": roofline, "cpu_baseline": cpu_baseline, "extras": extras,
+            "rccl": transports.get("rccl"), "transports": transports,
+            "phases_s": {k: v for k, v in wd.history},
         }
-    del H, h, v, res
-    torch.cuda.synchronize()
-    if distributed:
-        ctx.set_allreduce(None)                      # the communicator itself is released at process exit
-    torch.cuda.empty_cache()
-    if distributed:
-        dist.barrier()
-        dist.destroy_process_group()
+    with wd.phase("teardown"):
+        del H, h, v, res
+        torch.cuda.synchronize()
+        if distributed:
+            ctx.set_allreduce(None)                      # the communicator itself is released at process exit
+        if peer_hook is not None:
+            peer_hook.close()
+        torch.cuda.empty_cache()
+        if distributed:
+            dist.barrier()
+            dist.destroy_process_group()
+    return out
+
+
+def transport_preflight(args, lo, torch, dist, ctx, dev, rank, world, native_hook):
+    """What the all-reduce transport says about itself, and its measured latency, BEFORE timing.
+    N > 1 on the nccl backend: through the NATIVE hook the applies use (libmxlo_rccl.so): ncclCommCount / UserRank /
+    CuDevice + PCI bus id of every rank (gathered), known-answer and identical-bits all-reduces of 8 B / 320 B / 6912 B,
+    latency in us. N == 1: the same functions at world 1 (a communicator of one rank, the peer exchange with one mailbox):
+    nothing on the timed path uses them — recorded so that the code path the N > 1 run depends on has run on this box."""
+    out = {}
+    if world > 1:
+        if native_hook is None:
+            return {"rccl": None, "note": "debug transport (torch.distributed Python hook): no native preflight"}
+        info = native_hook.info()
+        lat = native_hook.preflight(ctx.stream, 50, args.preflight_timeout_ms)
+        infos = [None] * world
+        dist.all_gather_object(infos, info)
+        pcis = [i["pci_bus_id"] for i in infos]
+        if info["ranks_seen"] != world or sorted(i["user_rank"] for i in infos) != list(range(world)):
+            raise RuntimeError(f"the communicator reports {info['ranks_seen']} ranks / user ranks {[i['user_rank'] for i in infos]} for a {world}-rank run")
+        if len(set(pcis)) != world and not args.single_device:
+            raise RuntimeError(f"{world} ranks but only {len(set(pcis))} distinct devices (PCI bus ids {pcis})")
+        out["rccl"] = {"ranks_seen": info["ranks_seen"], "user_rank": info["user_rank"], "devices": [i["device"] for i in infos],
+                       "pci_bus_ids": pcis, "latency_us": lat, "sum_check": "ok", "identical_bits": True,
+                       "hook": "mxlo_rccl_allreduce_hook (ncclAllReduce on the ctx stream)"}
+        return out
+    if args.no_extras:
+        return out
+    t0 = time.perf_counter()
+    hook = lo.sharded.NativeRcclHook(0, 1)
+    try:
+        info = hook.info()
+        out["rccl"] = {"ranks_seen": info["ranks_seen"], "user_rank": info["user_rank"], "devices": [info["device"]],
+                       "pci_bus_ids": [info["pci_bus_id"]], "latency_us": hook.preflight(ctx.stream, 50, args.preflight_timeout_ms),
+                       "sum_check": "ok", "identical_bits": True, "note": "world 1: a communicator of one rank (no fabric hop)"}
+    finally:
+        hook.close()
+    ph = lo.sharded.PeerShmHook(0, 1, timeout_ms=args.preflight_timeout_ms)
+    try:
+        out["peer_shm"] = {"latency_us": ph.preflight(ctx.stream, 50, args.preflight_timeout_ms), "note": "world 1: one mailbox"}
+    finally:
+        ph.close()
+    out["wall_s"] = round(time.perf_counter() - t0, 2)
     return out
 
 
@@ -534,21 +660,36 @@ def shard_leg(args) -> dict:
             torch.cuda.synchronize(d)
 
     def timed(fn, reps, spin_s):
+        sc = sctx
         t_spin = time.perf_counter()
         while time.perf_counter() - t_spin < spin_s:
             for _ in range(5):
                 fn()
-            ck(R.mxlo_shard_ctx_sync(sctx), "sync")
-        ck(R.mxlo_shard_ctx_sync(sctx), "sync")
+            ck(R.mxlo_shard_ctx_sync(sc), "sync")
+        ck(R.mxlo_shard_ctx_sync(sc), "sync")
         t0 = time.perf_counter()
         for _ in range(reps):
             fn()
-        ck(R.mxlo_shard_ctx_sync(sctx), "sync")
+        ck(R.mxlo_shard_ctx_sync(sc), "sync")
         return (time.perf_counter() - t0) / reps
 
     out = {"host": "one process, %d shard(s): mxlo_shard_ctx_create + _sharded entry points" % nd,
            "transport": "loopback (all shards on device 0: debug)" if R.mxlo_shard_ctx_is_loopback(sctx) else "ncclCommInitAll, one worker thread per device",
            "n_gpus": nd}
+
+    def describe(sc):
+        """preflight (sums, identical bits, verdict, latency) + what every shard runs on, before anything is timed"""
+        lat = (C.c_double * 3)()
+        ck(R.mxlo_shard_ctx_preflight(sc, 50, args.preflight_timeout_ms, lat), "preflight")
+        seen, pcis = [], []
+        for i in range(nd):
+            dv, sn, pci = C.c_int32(-1), C.c_int32(-1), C.create_string_buffer(64)
+            ck(R.mxlo_shard_ctx_info(sc, i, C.byref(dv), C.byref(sn), pci, 64), "info")
+            seen.append(sn.value)
+            pcis.append(pci.value.decode())
+        return {"ranks_seen": seen[0], "pci_bus_ids": pcis, "sum_check": "ok", "identical_bits": True,
+                "latency_us": {"8B": round(lat[0], 2), "320B": round(lat[1], 2), "6912B": round(lat[2], 2)}}
+    out["preflight"] = describe(sctx)
     n = args.n
     gens = [torch.Generator(device=d).manual_seed(77 + i) for i, d in enumerate(devs)]
     hs = [torch.rand(n, dtype=torch.float64, device=d, generator=gq) - 0.5 for d, gq in zip(devs, gens)]
@@ -565,6 +706,24 @@ def shard_leg(args) -> dict:
     gbs = 40.0 * n * nd / sec / 1e9
     out["opHouseholder_mul"] = {"ms_per_step": round(sec * 1e3, 4), "GB/s": round(gbs, 1), "n_per_gpu": n,
                                 "frac_hbm_peak_per_gpu": round(gbs / nd / HBM_PEAK_GBS, 4)}
+    if nd > 1:
+        # the same shards under the SECOND transport: the peer-mapped one-shot exchange (no RCCL call; csrc/peer.hip)
+        try:
+            pctx = C.c_void_p()
+            ck(R.mxlo_shard_ctx_create_ex(nd, (C.c_int32 * nd)(*ids), _lib.SHARD_PEER, C.byref(pctx)), "create (peer transport)")
+            keep = sctx
+            sctx = pctx
+            try:
+                pf = describe(pctx)
+                secp = timed(lambda: ck(R.mxlo_householder_mul_sharded(pctx, F64, pr, ph, pv, nloc, 1.0, 0.0, 0), "householder (peer)"),
+                             max(10, args.steps), 0.2)
+                out["peer_transport"] = {"preflight": pf, "opHouseholder_ms_per_step": round(secp * 1e3, 4),
+                                         "opHouseholder_GB/s": round(40.0 * n * nd / secp / 1e9, 1)}
+            finally:
+                sctx = keep
+                R.mxlo_shard_ctx_destroy(pctx)
+        except SystemExit:
+            out["peer_transport"] = {"error": (R.mxlo_shard_last_error() or b"").decode()[:300]}
     del hs, vs, rs
     for d in set(devs):
         with torch.cuda.device(d):
@@ -1000,6 +1159,113 @@ def cpu_leg(n_sample: int):
         out["all_cores"] = cpu_leg_allcore(n_sample)
     except Exception as e:  # pragma: no cover  (no libgomp: report, do not fail the bench line)
         out["all_cores"] = {"error": repr(e)}
+    return out
+
+
+def cpu_leg_lbfgs(budget_s: float = 12.0):
+    """extras.InverseLBFGS_m10_n5e7.cpu — the reference's two-loop recursion (src/lbfgs.jl:117-154) on the host cores, at
+    n / 10 = 5e6 and scaled LINEARLY to n = 5e7 (the apply is memory-bound on the host too: 21 vectors streamed per dot /
+    axpy statement; the full size needs 8.4 GB of panels and ~1 s per apply): (1) the oracle's statement-by-statement
+    restatement, 1 thread (Julia's broadcast and a ddot below OpenBLAS's threading cut-off are single-threaded);
+    (2) the same statement sequence with every statement an OpenMP loop over all host cores (upper bound)."""
+    import numpy as np
+    import oracle
+    t_start = time.perf_counter()
+    nc, m, scale = 5_000_000, 10, 10
+    Oc = oracle.LBFGS(nc, mem=m, inverse=True)
+    rc = np.random.default_rng(1)
+    S = np.empty((m, nc))            # row k = s_k: a column-major n x m panel seen from C
+    Y = np.empty((m, nc))
+    for k in range(m):
+        sc = rc.uniform(-1, 1, nc)
+        yc = sc * rc.uniform(0.5, 2.0, nc)
+        Oc.push(sc, yc)
+        S[k], Y[k] = sc, yc
+    xc, outc = rc.uniform(-1, 1, nc), np.empty(nc)
+    Oc.mul(outc, xc)
+    reps, t0 = 0, time.perf_counter()
+    while True:
+        Oc.mul(outc, xc)
+        reps += 1
+        if time.perf_counter() - t0 > budget_s / 3 or reps >= 10:
+            break
+    sec1 = (time.perf_counter() - t0) / reps
+    out = {"apply_per_s_at_n5e7": round(1.0 / (sec1 * scale), 3), "cores": 1, "kind": "port",
+           "sample": f"oracle.LBFGS(inverse).mul — C restatement of lbfgs_multiply in reference statement order, 1 thread, "
+                     f"n = {nc} ({reps} reps, {sec1 * 1e3:.1f} ms/apply), scaled x{scale} to n = 5e7 (memory-bound: linear in n)"}
+    try:
+        M = oracle.mt_lib()
+        threads = int(M.orc_mt_max_threads())
+        ys = np.array([float(np.dot(S[k], Y[k])) for k in range(m)])
+        gamma = float(ys[m - 1] / np.dot(Y[m - 1], Y[m - 1]))
+        q, al, res = np.empty(nc), np.zeros(m), np.empty(nc)
+        for a in (q, res):
+            M.orc_mt_fill_f64(a.ctypes.data, nc, 7, -1.0, 1.0, threads)
+        call = lambda: M.orc_mt_lbfgs_inv_mul_f64(res.ctypes.data, S.ctypes.data, Y.ctypes.data, nc, ys.ctypes.data, al.ctypes.data, m,
+                                                  m + 1, 1, gamma, xc.ctypes.data, q.ctypes.data, nc, 1.0, 0.0, threads)
+        call()
+        ref = Oc.mul(np.empty(nc), xc)
+        err = float(np.linalg.norm(res - ref) / np.linalg.norm(ref))      # the all-core variant computes the same thing
+        best, reps2, t_all = float("inf"), 0, time.perf_counter()
+        while time.perf_counter() - t_all < budget_s / 3 and reps2 < 30:
+            t0 = time.perf_counter()
+            call()
+            best = min(best, time.perf_counter() - t0)
+            reps2 += 1
+        out["all_cores"] = {"apply_per_s_at_n5e7": round(1.0 / (best * scale), 2), "cores": threads, "rel_diff_vs_1_thread": err,
+                            "sample": f"OpenMP restatement (every statement one parallel loop), best of {reps2} at n = {nc}: "
+                                      f"{best * 1e3:.2f} ms/apply, scaled x{scale}"}
+    except Exception as e:  # pragma: no cover
+        out["all_cores"] = {"error": repr(e)[:200]}
+    out["host_logical_cpus"] = os.cpu_count()
+    out["wall_s"] = round(time.perf_counter() - t_start, 1)
+    return out
+
+
+def cpu_leg_kron(budget_s: float = 8.0):
+    """extras.kron_1024x1024.cpu — the reference's kron prod! as written (src/kron.jl:17-18: Matrix(B * X * transpose(A)),
+    i.e. 1024 pairs of GEMVs through src/abstract.jl:282-292) on the host: the oracle's restatement with 1 thread, and
+    the same column loop spread over all cores."""
+    import numpy as np
+    import oracle
+    t_start = time.perf_counter()
+    nk = 1024
+    rngk = np.random.default_rng(0)
+    Ak, Bk = (rngk.random((nk, nk)) - 0.5) / 32, (rngk.random((nk, nk)) - 0.5) / 32
+    xk = rngk.random(nk * nk)
+    flop = 4.0 * nk ** 3
+    resk = np.empty(nk * nk)
+    oracle.kron_mul(resk, Ak, Bk, xk, 1.0, 0.0)
+    reps, t0 = 0, time.perf_counter()
+    while True:
+        oracle.kron_mul(resk, Ak, Bk, xk, 1.0, 0.0)
+        reps += 1
+        if time.perf_counter() - t0 > budget_s / 2 or reps >= 5:
+            break
+    sec1 = (time.perf_counter() - t0) / reps
+    out = {"ms_per_apply": round(sec1 * 1e3, 1), "GFLOP/s": round(flop / sec1 / 1e9, 2), "cores": 1, "kind": "port",
+           "sample": f"oracle.kron_mul — reference-literal kron prod! (1024 x (X*w, B*u) GEMV pairs), gcc -O2, 1 thread, {reps} reps"}
+    try:
+        M = oracle.mt_lib()
+        threads = int(M.orc_mt_max_threads())
+        Af, Bf = np.asfortranarray(Ak), np.asfortranarray(Bk)
+        work, res2 = np.empty(threads * nk), np.empty(nk * nk)
+        call = lambda: M.orc_mt_kron_mul_f64(res2.ctypes.data, Af.ctypes.data, nk, nk, Bf.ctypes.data, nk, nk, xk.ctypes.data, 1.0, 0.0,
+                                             work.ctypes.data, threads)
+        call()
+        err = float(np.linalg.norm(res2 - resk) / np.linalg.norm(resk))
+        best, reps2, t_all = float("inf"), 0, time.perf_counter()
+        while time.perf_counter() - t_all < budget_s / 2 and reps2 < 50:
+            t0 = time.perf_counter()
+            call()
+            best = min(best, time.perf_counter() - t0)
+            reps2 += 1
+        out["all_cores"] = {"ms_per_apply": round(best * 1e3, 2), "GFLOP/s": round(flop / best / 1e9, 1), "cores": threads,
+                            "rel_diff_vs_1_thread": err, "sample": f"OpenMP over the 1024 result columns, best of {reps2}"}
+    except Exception as e:  # pragma: no cover
+        out["all_cores"] = {"error": repr(e)[:200]}
+    out["host_logical_cpus"] = os.cpu_count()
+    out["wall_s"] = round(time.perf_counter() - t_start, 1)
     return out
 
 

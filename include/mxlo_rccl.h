@@ -73,6 +73,31 @@ typedef struct mxlo_qn_sharded mxlo_qn_sharded;
 
 /* dev_ids == NULL: devices 0 .. ndev-1. */
 int32_t mxlo_shard_ctx_create(int32_t ndev, const int32_t *dev_ids, mxlo_shard_ctx **out);
+/* ... with the transport of the scalar all-reduce chosen explicitly:
+ *   MXLO_SHARD_AUTO     RCCL for distinct devices, loopback for repeated ids (what mxlo_shard_ctx_create does); the
+ *                       environment variable MXLO_SHARD_TRANSPORT = rccl | loopback | peer overrides it;
+ *   MXLO_SHARD_RCCL     ncclCommInitAll + ncclAllReduce on every shard's stream;
+ *   MXLO_SHARD_LOOPBACK several shards on ONE device, summed in fixed rank order through stream events (debug);
+ *   MXLO_SHARD_PEER     the peer-mapped ONE-SHOT exchange: per shard a mailbox in fine-grained device
+ *                       memory that every other device stores into over xGMI (hipDeviceEnablePeerAccess; pinned host
+ *                       memory when a pair has no peer access, or with MXLO_PEER_MEM=host), one small kernel per
+ *                       collective (post, bounded poll of the own mailbox, sum in FIXED RANK ORDER: identical bits on every
+ *                       shard), no RCCL call. Works with distinct devices and with repeated ids (one-GPU test shape). A
+ *                       shard whose peers never post gives up after its timeout, stores NaN and the next call / sync
+ *                       returns MXLO_EREDUCE (the ctx is unusable afterwards). */
+#define MXLO_SHARD_AUTO 0
+#define MXLO_SHARD_RCCL 1
+#define MXLO_SHARD_LOOPBACK 2
+#define MXLO_SHARD_PEER 3
+int32_t mxlo_shard_ctx_create_ex(int32_t ndev, const int32_t *dev_ids, int32_t transport, mxlo_shard_ctx **out);
+int32_t mxlo_shard_ctx_transport(mxlo_shard_ctx *s);
+/* device ordinal and PCI bus id of shard i, and the number of ranks the transport itself reports (ncclCommCount) */
+int32_t mxlo_shard_ctx_info(mxlo_shard_ctx *s, int32_t i, int32_t *device, int32_t *ranks_seen, char *pci_bus_id, int32_t pci_len);
+/* mxlo_rccl_preflight_hook on every shard, through the hook the `_sharded` entry points use: known-answer sums, identical
+ * bits on all shards, agreed verdict, and the latency (slowest shard) of the 8 B / 320 B / 6912 B all-reduce. */
+int32_t mxlo_shard_ctx_preflight(mxlo_shard_ctx *s, int32_t reps, int32_t timeout_ms, double latency_us[3]);
+/* test hooks of the peer transport: "peer_drop" (shard index that never posts; -1 none), "peer_timeout_ms" */
+int32_t mxlo_shard_ctx_debug(mxlo_shard_ctx *s, const char *key, int64_t value);
 int32_t mxlo_shard_ctx_destroy(mxlo_shard_ctx *s);
 int32_t mxlo_shard_ctx_ndev(mxlo_shard_ctx *s);
 int32_t mxlo_shard_ctx_device(mxlo_shard_ctx *s, int32_t i);
@@ -108,6 +133,24 @@ int32_t mxlo_qn_diag_sharded(mxlo_qn_sharded *q, void *const *d);
 int32_t mxlo_qn_reset_sharded(mxlo_qn_sharded *q);
 /* replicated scalars as seen by shard i (layout of mxlo_qn_get_scalars) */
 int32_t mxlo_qn_get_scalars_sharded(mxlo_qn_sharded *q, int32_t i, double scalars[5], double *ys, double *aux);
+
+/* ======================================================================================================
+ *  Peer transport for ONE PROCESS PER GPU (the shape bench.py and torch.distributed hosts run): the same one-shot
+ *  exchange with the mailboxes in a POSIX shared-memory segment that every rank registers with its HIP runtime
+ *  (hipHostRegister, mapped) — coherent by construction, no hipIpc handle exchange. Each collective is ONE kernel on the
+ *  ctx stream; all ranks end up with identical bits (fixed rank order).
+ *      rank 0 : mxlo_peer_comm_create_shm("/mxlo-<job token>", 0, world, 1, timeout_ms, &comm);   then a host barrier
+ *      rank r : mxlo_peer_comm_create_shm("/mxlo-<job token>", r, world, 0, timeout_ms, &comm);
+ *      every  : mxlo_ctx_set_allreduce(ctx, mxlo_peer_allreduce_hook, comm);
+ *  mxlo_peer_comm_check (after a stream synchronisation) tells whether a gather of this rank timed out. */
+typedef struct mxlo_peer_comm mxlo_peer_comm;
+int32_t mxlo_peer_comm_create_shm(const char *name, int32_t rank, int32_t world, int32_t create, int32_t timeout_ms,
+                                  mxlo_peer_comm **out);
+int32_t mxlo_peer_comm_destroy(mxlo_peer_comm *comm);
+int32_t mxlo_peer_allreduce_hook(void *user, void *dev_buf, int64_t count, void *stream);
+int32_t mxlo_peer_comm_check(mxlo_peer_comm *comm);
+int32_t mxlo_peer_comm_debug(mxlo_peer_comm *comm, const char *key, int64_t value);
+const char *mxlo_peer_last_error(void);
 
 #ifdef __cplusplus
 }

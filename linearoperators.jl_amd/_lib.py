@@ -17,6 +17,7 @@ RCCL_LIB_PATH = os.path.join(CSRC, "libmxlo_rccl.so")
 HEADER = os.path.normpath(os.path.join(_HERE, "..", "include", "mxlo.h"))
 RCCL_HEADER = os.path.normpath(os.path.join(_HERE, "..", "include", "mxlo_rccl.h"))
 RCCL_ID_BYTES = 128
+SHARD_AUTO, SHARD_RCCL, SHARD_LOOPBACK, SHARD_PEER = 0, 1, 2, 3
 
 # status codes (include/mxlo.h)
 OK, EINVAL, ESHAPE, EHIP, ENOMEM, ESTATE, EDOMAIN, EREDUCE = range(8)
@@ -217,13 +218,31 @@ def rccl_lib() -> C.CDLL:
         R.mxlo_rccl_comm_create.argtypes = [_i32, _i32, _vp, C.POINTER(_vp)]
         R.mxlo_rccl_comm_destroy.argtypes = [_vp]
         R.mxlo_rccl_allreduce_hook.argtypes = [_vp, _vp, _i64, _vp]
-        for f in (R.mxlo_rccl_unique_id, R.mxlo_rccl_comm_create, R.mxlo_rccl_comm_destroy, R.mxlo_rccl_allreduce_hook):
+        R.mxlo_rccl_comm_abort.argtypes = [_vp]
+        R.mxlo_rccl_comm_info.argtypes = [_vp, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32), C.c_char_p, _i32]
+        R.mxlo_rccl_preflight.argtypes = [_vp, _vp, _i32, _i32, C.POINTER(_dbl)]
+        R.mxlo_rccl_preflight_hook.argtypes = [_vp, _vp, _vp, _i32, _i32, _vp, _i32, _i32, C.POINTER(_dbl)]
+        R.mxlo_peer_comm_create_shm.argtypes = [C.c_char_p, _i32, _i32, _i32, _i32, C.POINTER(_vp)]
+        R.mxlo_peer_comm_destroy.argtypes = [_vp]
+        R.mxlo_peer_allreduce_hook.argtypes = [_vp, _vp, _i64, _vp]
+        R.mxlo_peer_comm_check.argtypes = [_vp]
+        R.mxlo_peer_comm_debug.argtypes = [_vp, C.c_char_p, _i64]
+        for f in (R.mxlo_rccl_unique_id, R.mxlo_rccl_comm_create, R.mxlo_rccl_comm_destroy, R.mxlo_rccl_allreduce_hook,
+                  R.mxlo_rccl_comm_abort, R.mxlo_rccl_comm_info, R.mxlo_rccl_preflight, R.mxlo_rccl_preflight_hook,
+                  R.mxlo_peer_comm_create_shm, R.mxlo_peer_comm_destroy, R.mxlo_peer_allreduce_hook, R.mxlo_peer_comm_check,
+                  R.mxlo_peer_comm_debug):
             f.restype = _i32
         R.mxlo_rccl_last_error.restype = C.c_char_p
+        R.mxlo_peer_last_error.restype = C.c_char_p
         # single-process multi-device API (include/mxlo_rccl.h)
         pp, ip = C.POINTER(_vp), C.POINTER(_i64)
         for name, args in {
             "mxlo_shard_ctx_create": [_i32, C.POINTER(_i32), C.POINTER(_vp)],
+            "mxlo_shard_ctx_create_ex": [_i32, C.POINTER(_i32), _i32, C.POINTER(_vp)],
+            "mxlo_shard_ctx_transport": [_vp],
+            "mxlo_shard_ctx_info": [_vp, _i32, C.POINTER(_i32), C.POINTER(_i32), C.c_char_p, _i32],
+            "mxlo_shard_ctx_preflight": [_vp, _i32, _i32, C.POINTER(_dbl)],
+            "mxlo_shard_ctx_debug": [_vp, C.c_char_p, _i64],
             "mxlo_shard_ctx_destroy": [_vp], "mxlo_shard_ctx_ndev": [_vp], "mxlo_shard_ctx_device": [_vp, _i32],
             "mxlo_shard_ctx_is_loopback": [_vp], "mxlo_shard_ctx_sync": [_vp],
             "mxlo_householder_mul_sharded": [_vp, _i32, pp, pp, pp, ip, _dbl, _dbl, _i32],

@@ -13,6 +13,12 @@
 // that), the all-reduce is done by the shards' own streams with events: every shard sums all shards' scalars in
 // FIXED RANK ORDER (bit-identical on every shard). It exists so the multi-shard logic can be exercised on a
 // one-GPU box; it is not a performance path.
+//
+// Peer transport (MXLO_SHARD_PEER, round 5; peer.hip): per shard a mailbox every other shard's device can store into
+// (fine-grained device memory + peer access; pinned host memory as the fallback) and ONE small kernel per collective —
+// post into every mailbox, poll the own one, add in fixed rank order. No RCCL call. With all shards on ONE device (the
+// test shape of a one-GPU box) the kernel is issued as its two halves with a host barrier between them, so that every
+// post is enqueued ahead of every polling gather whatever hardware queue the streams share.
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
@@ -31,6 +37,7 @@
 
 #include "../../include/mxlo.h"
 #include "../../include/mxlo_rccl.h"
+#include "peer.h"
 
 #define API extern "C" __attribute__((visibility("default")))
 
@@ -123,7 +130,15 @@ struct mxlo_shard_ctx {
   };
   std::vector<HookUser> users;
   std::mutex call_mu;       // one `_sharded` call at a time per shard ctx (two host threads may share one)
-  bool poisoned = false;    // RCCL transport: a shard failed while its peers may already sit in a collective
+  bool poisoned = false;    // RCCL / peer transport: a shard failed while its peers may already sit in a collective
+  int transport = MXLO_SHARD_RCCL;
+  bool same_device = false; // every shard on one device (loopback, or the peer transport's one-GPU test shape)
+  bool uses_bar = false;    // the transport synchronises its worker threads with `bar`
+  mxlo_allreduce_fn hook_fn = nullptr;
+  // peer transport
+  std::vector<mxlo_peer::Comm> pc;
+  std::vector<void *> mailbox;
+  bool mailbox_on_host = false;
 };
 
 struct mxlo_qn_sharded {
@@ -172,6 +187,27 @@ int32_t loop_hook(void *user, void *dev_buf, int64_t count, void *stream_) {
   return 0;
 }
 
+// Peer transport: one kernel per collective (distinct devices); on ONE device post and gather are two launches with a
+// host barrier between them (see the header comment). The sequence number advances identically on every shard.
+int32_t peer_hook(void *user, void *dev_buf, int64_t count, void *stream_) {
+  auto *u = (mxlo_shard_ctx::HookUser *)user;
+  mxlo_shard_ctx *s = u->s;
+  mxlo_peer::Comm &c = s->pc[u->rank];
+  hipStream_t st = (hipStream_t)stream_;
+  if (count <= 0) return 0;
+  auto fail = [&]() {
+    if (s->uses_bar) s->bar.abort();
+    return 1;
+  };
+  if (c.dead || mxlo_peer::comm_fault(&c) != 0) return fail();
+  const unsigned long long seq = ++c.seq;
+  if (!s->same_device) return mxlo_peer::comm_launch(&c, (double *)dev_buf, count, st, 3, seq) == 0 ? 0 : fail();
+  if (mxlo_peer::comm_launch(&c, (double *)dev_buf, count, st, 1, seq) != 0) return fail();
+  if (!s->bar.wait()) return 1;                            // every shard's post is enqueued
+  if (mxlo_peer::comm_launch(&c, (double *)dev_buf, count, st, 2, seq) != 0) return fail();
+  return 0;
+}
+
 void worker_main(Worker *w, int device) {
   (void)hipSetDevice(device);   // the entry points bind their ctx's device themselves; this keeps anything else the
                                 // thread touches (RCCL's internal calls) on the right device from the first call on
@@ -206,14 +242,14 @@ int32_t run_all(mxlo_shard_ctx *s, const std::function<int32_t(int)> &f) {
              "RCCL collective; destroy it and create a new one");
     return MXLO_ESTATE;
   }
-  if (s->loopback) s->bar.reset();
+  if (s->uses_bar) s->bar.reset();
   for (int i = 0; i < s->ndev; ++i) {
     Worker *w = s->workers[i];
     {
       std::lock_guard<std::mutex> lk(w->mu);
       w->job = [&f, s, i]() {
         const int32_t st = f(i);
-        if (st != 0 && s->loopback) s->bar.abort();
+        if (st != 0 && s->uses_bar) s->bar.abort();
         return st;
       };
       w->done = false;
@@ -231,6 +267,8 @@ int32_t run_all(mxlo_shard_ctx *s, const std::function<int32_t(int)> &f) {
       set_serr("shard %d (device %d): %s", i, s->dev[i], w->err.c_str());
     }
   }
+  // a shard that failed while its peers may sit in a device-side collective (RCCL, or a polling peer gather that will
+  // run into its timeout): nothing on this ctx can be trusted to line up again
   if (first != 0 && !s->loopback && s->ndev > 1) s->poisoned = true;
   return first;
 }
@@ -275,6 +313,8 @@ API int32_t mxlo_shard_ctx_destroy(mxlo_shard_ctx *s) {
     if (s->ctx[i]) (void)mxlo_ctx_destroy(s->ctx[i]);
     if (i < (int)s->comms.size() && s->comms[i]) (void)(s->poisoned ? ncclCommAbort(s->comms[i]) : ncclCommDestroy(s->comms[i]));
     if (i < (int)s->tmp.size() && s->tmp[i]) (void)hipFree(s->tmp[i]);
+    if (i < (int)s->pc.size()) mxlo_peer::comm_release_common(&s->pc[i]);
+    if (i < (int)s->mailbox.size() && s->mailbox[i]) (void)(s->mailbox_on_host ? hipHostFree(s->mailbox[i]) : hipFree(s->mailbox[i]));
     if (i < (int)s->ev_ready.size() && s->ev_ready[i]) (void)hipEventDestroy(s->ev_ready[i]);
     if (i < (int)s->ev_read.size() && s->ev_read[i]) (void)hipEventDestroy(s->ev_read[i]);
     if (i < (int)s->streams.size() && s->streams[i]) (void)hipStreamDestroy(s->streams[i]);
@@ -283,9 +323,110 @@ API int32_t mxlo_shard_ctx_destroy(mxlo_shard_ctx *s) {
   return MXLO_OK;
 }
 
-API int32_t mxlo_shard_ctx_create(int32_t ndev, const int32_t *dev_ids, mxlo_shard_ctx **out) {
+namespace {
+// mailboxes of the peer transport: fine-grained device memory with peer access between every pair of devices; pinned
+// (portable, mapped) host memory when a pair cannot reach each other or MXLO_PEER_MEM=host asks for it
+int32_t peer_setup(mxlo_shard_ctx *s) {
+  const int n = s->ndev;
+  const size_t bytes = mxlo_peer::mailbox_words(n) * sizeof(unsigned long long);
+  s->pc.assign(n, mxlo_peer::Comm());
+  s->mailbox.assign(n, nullptr);
+  const char *mem = getenv("MXLO_PEER_MEM");
+  bool host = mem && !strcmp(mem, "host");
+  if (!host && !s->same_device) {
+    for (int i = 0; i < n && !host; ++i)
+      for (int j = 0; j < n && !host; ++j) {
+        int can = 0;
+        if (i != j && (hipDeviceCanAccessPeer(&can, s->dev[i], s->dev[j]) != hipSuccess || !can)) host = true;
+      }
+  }
+  if (!host) {
+    for (int i = 0; i < n; ++i) {
+      if (hipSetDevice(s->dev[i]) != hipSuccess) return MXLO_EHIP;
+      void *p = nullptr;
+      if (hipExtMallocWithFlags(&p, bytes, hipDeviceMallocFinegrained) != hipSuccess) {
+        (void)hipGetLastError();
+        if (s->same_device && hipMalloc(&p, bytes) == hipSuccess) {
+          // one device: ordinary device memory is coherent for the system-scope accesses of the exchange kernel
+        } else {
+          (void)hipGetLastError();
+          host = true;
+          break;
+        }
+      }
+      s->mailbox[i] = p;
+      if (hipMemset(p, 0, bytes) != hipSuccess) return MXLO_EHIP;
+    }
+    if (host) {
+      for (int i = 0; i < n; ++i)
+        if (s->mailbox[i]) {
+          (void)hipFree(s->mailbox[i]);
+          s->mailbox[i] = nullptr;
+        }
+    }
+  }
+  if (!host && !s->same_device) {
+    for (int i = 0; i < n; ++i) {
+      if (hipSetDevice(s->dev[i]) != hipSuccess) return MXLO_EHIP;
+      for (int j = 0; j < n; ++j) {
+        if (i == j) continue;
+        const hipError_t e = hipDeviceEnablePeerAccess(s->dev[j], 0);
+        if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) {
+          set_serr("mxlo_shard_ctx_create: hipDeviceEnablePeerAccess(%d -> %d): %s", s->dev[i], s->dev[j], hipGetErrorString(e));
+          return MXLO_EHIP;
+        }
+        (void)hipGetLastError();
+      }
+    }
+  }
+  if (host) {
+    s->mailbox_on_host = true;
+    for (int i = 0; i < n; ++i) {
+      void *p = nullptr;
+      if (hipHostMalloc(&p, bytes, hipHostMallocPortable | hipHostMallocMapped) != hipSuccess) {
+        set_serr("mxlo_shard_ctx_create: pinned host memory for the peer mailboxes");
+        return MXLO_ENOMEM;
+      }
+      memset(p, 0, bytes);
+      s->mailbox[i] = p;
+    }
+  }
+  for (int i = 0; i < n; ++i) {
+    if (hipSetDevice(s->dev[i]) != hipSuccess) return MXLO_EHIP;
+    if (mxlo_peer::comm_init_common(&s->pc[i], i, n, 0) != 0) {
+      set_serr("mxlo_shard_ctx_create: %s", mxlo_peer::last_error());
+      return MXLO_EHIP;
+    }
+    for (int r = 0; r < n; ++r) {
+      void *dp = s->mailbox[r];
+      if (host && hipHostGetDevicePointer(&dp, s->mailbox[r], 0) != hipSuccess) return MXLO_EHIP;
+      s->pc[i].mb[r] = (unsigned long long *)dp;
+    }
+  }
+  return MXLO_OK;
+}
+}  // namespace
+
+// transport: MXLO_SHARD_AUTO (RCCL for distinct devices, loopback for repeated ids; the environment variable
+// MXLO_SHARD_TRANSPORT = rccl | loopback | peer overrides), MXLO_SHARD_RCCL, MXLO_SHARD_LOOPBACK, MXLO_SHARD_PEER.
+API int32_t mxlo_shard_ctx_create_ex(int32_t ndev, const int32_t *dev_ids, int32_t transport, mxlo_shard_ctx **out) {
   if (!out || ndev < 1 || ndev > kMaxShards) {
     set_serr("mxlo_shard_ctx_create: ndev must be in 1..%d", kMaxShards);
+    return MXLO_EINVAL;
+  }
+  *out = nullptr;
+  if (transport == MXLO_SHARD_AUTO) {
+    const char *e = getenv("MXLO_SHARD_TRANSPORT");
+    if (e && !strcmp(e, "rccl")) transport = MXLO_SHARD_RCCL;
+    else if (e && !strcmp(e, "loopback")) transport = MXLO_SHARD_LOOPBACK;
+    else if (e && !strcmp(e, "peer")) transport = MXLO_SHARD_PEER;
+    else if (e && e[0]) {
+      set_serr("mxlo_shard_ctx_create: MXLO_SHARD_TRANSPORT='%s' is not one of rccl, loopback, peer", e);
+      return MXLO_EINVAL;
+    }
+  }
+  if (transport < MXLO_SHARD_AUTO || transport > MXLO_SHARD_PEER) {
+    set_serr("mxlo_shard_ctx_create_ex: unknown transport %d", transport);
     return MXLO_EINVAL;
   }
   int visible = 0;
@@ -308,12 +449,27 @@ API int32_t mxlo_shard_ctx_create(int32_t ndev, const int32_t *dev_ids, mxlo_sha
     s->dev.push_back(d);
     distinct.insert(d);
   }
-  s->loopback = (int)distinct.size() < ndev;
-  if (s->loopback && distinct.size() != 1) {
-    set_serr("mxlo_shard_ctx_create: repeated device ids select the loopback transport, which needs ALL shards on one device");
+  const bool repeated = (int)distinct.size() < ndev;
+  if (repeated && distinct.size() != 1) {
+    set_serr("mxlo_shard_ctx_create: repeated device ids put several shards on one GPU (loopback / peer test shape), which needs ALL shards on one device");
     delete s;
     return MXLO_EINVAL;
   }
+  if (transport == MXLO_SHARD_AUTO) transport = repeated ? MXLO_SHARD_LOOPBACK : MXLO_SHARD_RCCL;
+  if (transport == MXLO_SHARD_RCCL && repeated) {
+    set_serr("mxlo_shard_ctx_create: RCCL refuses several ranks on one device — use the loopback or the peer transport for repeated device ids");
+    delete s;
+    return MXLO_EINVAL;
+  }
+  if (transport == MXLO_SHARD_LOOPBACK && !repeated && ndev > 1) {
+    set_serr("mxlo_shard_ctx_create: the loopback transport sums on ONE device — list one device id %d times", ndev);
+    delete s;
+    return MXLO_EINVAL;
+  }
+  s->transport = transport;
+  s->loopback = transport == MXLO_SHARD_LOOPBACK;
+  s->same_device = repeated || ndev == 1;
+  s->uses_bar = s->loopback || (transport == MXLO_SHARD_PEER && s->same_device);
   s->streams.assign(ndev, nullptr);
   s->ctx.assign(ndev, nullptr);
   s->users.resize(ndev);
@@ -328,16 +484,29 @@ API int32_t mxlo_shard_ctx_create(int32_t ndev, const int32_t *dev_ids, mxlo_sha
     if (st != MXLO_OK) set_serr("mxlo_shard_ctx_create: %s", mxlo_last_error());
     s->users[i] = {s, i};
   }
-  if (st == MXLO_OK && !s->loopback) {
+  if (st == MXLO_OK && transport == MXLO_SHARD_RCCL) {
     s->comms.assign(ndev, nullptr);
-    ncclResult_t r = ncclCommInitAll(s->comms.data(), ndev, s->dev.data());
+    const char *inject = getenv("MXLO_SHARD_FAULT");      // TEST HOOK: "initall" = ncclCommInitAll reports an error
+    ncclResult_t r = (inject && !strcmp(inject, "initall")) ? ncclSystemError : ncclCommInitAll(s->comms.data(), ndev, s->dev.data());
     if (r != ncclSuccess) {
-      set_serr("ncclCommInitAll: %s", ncclGetErrorString(r));
+      set_serr("ncclCommInitAll over %d device(s): %s", ndev, ncclGetErrorString(r));
+      for (auto &c : s->comms) c = nullptr;
       st = MXLO_EREDUCE;
+    } else {
+      for (int i = 0; i < ndev && st == MXLO_OK; ++i) {   // what the communicators themselves say: N ranks, rank i on device i
+        int cnt = -1, ur = -1, cd = -1;
+        if (ncclCommCount(s->comms[i], &cnt) != ncclSuccess || ncclCommUserRank(s->comms[i], &ur) != ncclSuccess ||
+            ncclCommCuDevice(s->comms[i], &cd) != ncclSuccess || cnt != ndev || ur != i || cd != s->dev[i]) {
+          set_serr("ncclCommInitAll: communicator %d reports %d ranks / rank %d / device %d, expected %d / %d / %d", i, cnt, ur, cd,
+                   ndev, i, s->dev[i]);
+          s->poisoned = true;                            // destroy aborts the communicators
+          st = MXLO_EREDUCE;
+        }
+      }
     }
   }
+  if (st == MXLO_OK && s->uses_bar) s->bar.n = ndev;
   if (st == MXLO_OK && s->loopback) {
-    s->bar.n = ndev;
     s->ev_ready.assign(ndev, nullptr);
     s->ev_read.assign(ndev, nullptr);
     s->tmp.assign(ndev, nullptr);
@@ -352,8 +521,9 @@ API int32_t mxlo_shard_ctx_create(int32_t ndev, const int32_t *dev_ids, mxlo_sha
       }
     }
   }
-  for (int i = 0; i < ndev && st == MXLO_OK; ++i)
-    st = mxlo_ctx_set_allreduce(s->ctx[i], s->loopback ? loop_hook : rccl_hook, &s->users[i]);
+  if (st == MXLO_OK && transport == MXLO_SHARD_PEER) st = peer_setup(s);
+  s->hook_fn = s->loopback ? loop_hook : (transport == MXLO_SHARD_PEER ? peer_hook : rccl_hook);
+  for (int i = 0; i < ndev && st == MXLO_OK; ++i) st = mxlo_ctx_set_allreduce(s->ctx[i], s->hook_fn, &s->users[i]);
   if (st == MXLO_OK) {
     for (int i = 0; i < ndev; ++i) {
       Worker *w = new Worker();
@@ -370,6 +540,49 @@ API int32_t mxlo_shard_ctx_create(int32_t ndev, const int32_t *dev_ids, mxlo_sha
   return MXLO_OK;
 }
 
+API int32_t mxlo_shard_ctx_create(int32_t ndev, const int32_t *dev_ids, mxlo_shard_ctx **out) {
+  return mxlo_shard_ctx_create_ex(ndev, dev_ids, MXLO_SHARD_AUTO, out);
+}
+
+API int32_t mxlo_shard_ctx_transport(mxlo_shard_ctx *s) { return s ? s->transport : 0; }
+
+// What shard i runs on: device ordinal, its PCI bus id, and how many ranks the transport itself reports (ncclCommCount
+// for RCCL; the shard count otherwise).
+API int32_t mxlo_shard_ctx_info(mxlo_shard_ctx *s, int32_t i, int32_t *device, int32_t *ranks_seen, char *pci_bus_id, int32_t pci_len) {
+  if (!s || i < 0 || i >= s->ndev) {
+    set_serr("mxlo_shard_ctx_info: bad shard index");
+    return MXLO_EINVAL;
+  }
+  if (device) *device = s->dev[i];
+  if (ranks_seen) {
+    int cnt = s->ndev;
+    if (s->transport == MXLO_SHARD_RCCL && (ncclCommCount(s->comms[i], &cnt) != ncclSuccess)) cnt = -1;
+    *ranks_seen = cnt;
+  }
+  if (pci_bus_id && pci_len > 0) {
+    pci_bus_id[0] = 0;
+    if (hipDeviceGetPCIBusId(pci_bus_id, pci_len, s->dev[i]) != hipSuccess) {
+      (void)hipGetLastError();
+      snprintf(pci_bus_id, (size_t)pci_len, "?");
+    }
+  }
+  return MXLO_OK;
+}
+
+// TEST HOOKS of the peer transport: "peer_drop" = shard index that never posts (-1: none), "peer_timeout_ms".
+API int32_t mxlo_shard_ctx_debug(mxlo_shard_ctx *s, const char *key, int64_t value) {
+  if (!s || !key) return MXLO_EINVAL;
+  if (!strcmp(key, "peer_drop")) {
+    for (auto &c : s->pc) c.drop = (int)value;
+  } else if (!strcmp(key, "peer_timeout_ms")) {
+    for (auto &c : s->pc) c.timeout_ms = (int)value;
+  } else {
+    set_serr("mxlo_shard_ctx_debug: unknown key '%s'", key);
+    return MXLO_EINVAL;
+  }
+  return MXLO_OK;
+}
+
 API int32_t mxlo_shard_ctx_ndev(mxlo_shard_ctx *s) { return s ? s->ndev : 0; }
 API int32_t mxlo_shard_ctx_device(mxlo_shard_ctx *s, int32_t i) { return (s && i >= 0 && i < s->ndev) ? s->dev[i] : -1; }
 API int32_t mxlo_shard_ctx_is_loopback(mxlo_shard_ctx *s) { return s && s->loopback ? 1 : 0; }
@@ -380,9 +593,53 @@ API int32_t mxlo_shard_ctx_sync(mxlo_shard_ctx *s) {
   int32_t st = MXLO_OK;
   for (int i = 0; i < s->ndev; ++i) {
     const int32_t e = mxlo_ctx_sync(s->ctx[i]);
-    if (e != MXLO_OK && st == MXLO_OK) st = e;
+    if (e != MXLO_OK && st == MXLO_OK) {
+      st = e;
+      set_serr("shard %d (device %d): %s", i, s->dev[i], mxlo_last_error());
+    }
   }
+  for (int i = 0; i < (int)s->pc.size(); ++i)     // a peer gather that gave up has stored NaN: say so
+    if (mxlo_peer::comm_fault(&s->pc[i]) != 0) {
+      s->poisoned = true;
+      if (st == MXLO_OK) {
+        st = MXLO_EREDUCE;
+        set_serr("shard %d (device %d): %s", i, s->dev[i], mxlo_peer::last_error());
+      }
+    }
   return st;
+}
+
+// The transport's preflight (include/mxlo_rccl.h: mxlo_rccl_preflight_hook) on every shard of the ctx, through the hook
+// the `_sharded` entry points use. latency_us[k] = the slowest shard's latency for payload k.
+API int32_t mxlo_shard_ctx_preflight(mxlo_shard_ctx *s, int32_t reps, int32_t timeout_ms, double latency_us[3]) {
+  if (!s || !latency_us) {
+    set_serr("mxlo_shard_ctx_preflight: NULL argument");
+    return MXLO_EINVAL;
+  }
+  std::vector<double> lat((size_t)s->ndev * 3, 0.0);
+  std::vector<std::string> errs(s->ndev);
+  const int32_t st = run_all(s, [&](int i) -> int32_t {
+    const int32_t rc = mxlo_rccl_preflight_hook(s->hook_fn, &s->users[i], s->transport == MXLO_SHARD_RCCL ? (void *)s->comms[i] : nullptr, i,
+                                                s->ndev, (void *)s->streams[i], reps, timeout_ms, &lat[(size_t)i * 3]);
+    if (rc != 0) {
+      errs[i] = mxlo_rccl_last_error();
+      return MXLO_EREDUCE;
+    }
+    return MXLO_OK;
+  });
+  if (st != MXLO_OK) {
+    for (int i = 0; i < s->ndev; ++i)
+      if (!errs[i].empty()) {
+        set_serr("shard %d (device %d): %s", i, s->dev[i], errs[i].c_str());
+        break;
+      }
+    return st;
+  }
+  for (int k = 0; k < 3; ++k) {
+    latency_us[k] = 0.0;
+    for (int i = 0; i < s->ndev; ++i) latency_us[k] = lat[(size_t)i * 3 + k] > latency_us[k] ? lat[(size_t)i * 3 + k] : latency_us[k];
+  }
+  return MXLO_OK;
 }
 
 #define SHARD_REQUIRE(cond, ...)                                                                 \

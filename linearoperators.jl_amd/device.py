@@ -72,6 +72,11 @@ class Context:
             _lib.call("mxlo_ctx_set_stream", self.handle, C.c_void_p(s))
             self._stream = s
 
+    @property
+    def stream(self) -> int:
+        """Raw hipStream_t the ctx currently launches on (0 = the null stream)."""
+        return int(self._stream or 0)
+
     def sync(self):
         _lib.call("mxlo_ctx_sync", self.handle)
 

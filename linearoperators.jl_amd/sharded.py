@@ -147,9 +147,84 @@ class NativeRcclHook:
         ctx._hook = self                                 # keep the communicator alive with the ctx
         _lib.call("mxlo_ctx_set_allreduce", ctx.handle, self.fn, self.comm)
 
+    def info(self) -> dict:
+        """What the communicator itself reports (ncclCommCount / ncclCommUserRank / ncclCommCuDevice + PCI bus id)."""
+        ranks, ur, dv = C.c_int32(-1), C.c_int32(-1), C.c_int32(-1)
+        pci = C.create_string_buffer(64)
+        if self._R.mxlo_rccl_comm_info(self.comm, C.byref(ranks), C.byref(ur), C.byref(dv), pci, 64) != 0:
+            raise RuntimeError(self._R.mxlo_rccl_last_error().decode())
+        return {"ranks_seen": ranks.value, "user_rank": ur.value, "device": dv.value, "pci_bus_id": pci.value.decode()}
+
+    def preflight(self, stream: int, reps: int = 50, timeout_ms: int = 60000) -> dict:
+        """Collective: known-answer + identical-bits all-reduces of 8 B / 320 B / 6912 B through the native hook, agreed
+        verdict, latency in us (include/mxlo_rccl.h: mxlo_rccl_preflight). Raises RuntimeError naming phase and rank."""
+        lat = (C.c_double * 3)()
+        if self._R.mxlo_rccl_preflight(self.comm, C.c_void_p(stream), reps, timeout_ms, lat) != 0:
+            raise RuntimeError(self._R.mxlo_rccl_last_error().decode())
+        return {"8B": round(lat[0], 2), "320B": round(lat[1], 2), "6912B": round(lat[2], 2)}
+
+    def abort(self):
+        if self.comm:
+            self._R.mxlo_rccl_comm_abort(self.comm)
+            self.comm = C.c_void_p()
+
     def close(self):
         if self.comm:
             self._R.mxlo_rccl_comm_destroy(self.comm)
+            self.comm = C.c_void_p()
+
+
+class PeerShmHook:
+    """The peer-mapped one-shot exchange for one process per GPU (include/mxlo_rccl.h: mxlo_peer_comm_create_shm):
+    mailboxes in a POSIX shared-memory segment registered with every rank's HIP runtime; the hook is the C function
+    `mxlo_peer_allreduce_hook` (ONE kernel per collective on the ctx stream, fixed rank order: identical bits on all
+    ranks). The segment name travels over the host runtime (torch.distributed object broadcast)."""
+
+    def __init__(self, rank: int, world: int, group=None, timeout_ms: int = 30000):
+        from . import _lib
+        import os
+        R = _lib.rccl_lib()
+        name = [f"/mxlo-{os.getpid()}-{int.from_bytes(os.urandom(6), 'little'):x}" if rank == 0 else None]
+        if world > 1:
+            dist.broadcast_object_list(name, src=0, group=group)
+        self.name, self.rank, self.world = name[0], rank, world
+        self.comm = C.c_void_p()
+        err = None
+        if rank == 0 and R.mxlo_peer_comm_create_shm(self.name.encode(), 0, world, 1, timeout_ms, C.byref(self.comm)) != 0:
+            err = R.mxlo_peer_last_error().decode()
+        if world > 1:
+            dist.barrier(group=group)                     # the segment exists (or rank 0 failed: the others fail to open it)
+        if rank != 0 and R.mxlo_peer_comm_create_shm(self.name.encode(), rank, world, 0, timeout_ms, C.byref(self.comm)) != 0:
+            err = R.mxlo_peer_last_error().decode()
+        if err is not None:
+            raise RuntimeError(err)
+        self._R = R
+        self.fn = C.cast(R.mxlo_peer_allreduce_hook, _lib.ALLREDUCE_FN)
+
+    def install(self, ctx):
+        from . import _lib
+        ctx._hook = self
+        _lib.call("mxlo_ctx_set_allreduce", ctx.handle, self.fn, self.comm)
+
+    def preflight(self, stream: int, reps: int = 50, timeout_ms: int = 60000) -> dict:
+        lat = (C.c_double * 3)()
+        fn = C.cast(self._R.mxlo_peer_allreduce_hook, C.c_void_p)
+        if self._R.mxlo_rccl_preflight_hook(fn, self.comm, None, self.rank, self.world, C.c_void_p(stream), reps, timeout_ms, lat) != 0:
+            raise RuntimeError(self._R.mxlo_rccl_last_error().decode())
+        return {"8B": round(lat[0], 2), "320B": round(lat[1], 2), "6912B": round(lat[2], 2)}
+
+    def check(self):
+        """After a stream synchronisation: raises if a gather of this rank timed out (its results are NaN)."""
+        if self._R.mxlo_peer_comm_check(self.comm) != 0:
+            raise RuntimeError(self._R.mxlo_peer_last_error().decode())
+
+    def debug(self, key: str, value: int):
+        if self._R.mxlo_peer_comm_debug(self.comm, key.encode(), int(value)) != 0:
+            raise RuntimeError(self._R.mxlo_peer_last_error().decode())
+
+    def close(self):
+        if self.comm:
+            self._R.mxlo_peer_comm_destroy(self.comm)
             self.comm = C.c_void_p()
 
 

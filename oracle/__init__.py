@@ -89,6 +89,11 @@ def mt_lib() -> C.CDLL:
         _mt.orc_mt_householder_mul_f64.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_double,
                                                    C.c_double, C.c_int32]
         _mt.orc_mt_max_threads.restype = C.c_int32
+        _mt.orc_mt_lbfgs_inv_mul_f64.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32,
+                                                 C.c_int32, C.c_int32, C.c_double, C.c_void_p, C.c_void_p, C.c_int64, C.c_double,
+                                                 C.c_double, C.c_int32]
+        _mt.orc_mt_kron_mul_f64.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int64,
+                                            C.c_void_p, C.c_double, C.c_double, C.c_void_p, C.c_int32]
     return _mt
 
 

@@ -30,6 +30,11 @@ STUB = textwrap.dedent('''
         sys.exit(7)
     if mode == "fail" and rank != 1:
         time.sleep(60)                       # must be stopped by the launcher, not run to completion
+    if mode == "stall":                      # rank 1 hangs inside a named phase; the others wait for it "in a collective"
+        pd = os.environ["MXLO_BENCH_PHASE_DIR"]
+        with open(os.path.join(pd, "rank%d" % rank), "w") as f:
+            f.write("in 'communicator creation' since 00:00:00" if rank == 1 else "in 'transport preflight' since 00:00:01")
+        time.sleep(60)
     if rank == 0:
         print("some log line on stdout")
         print(json.dumps({"metric": "stub", "value": 1.0, "n_gpus": world if mode != "lie" else 1, "extras": {}}))
@@ -108,3 +113,45 @@ def test_worker_refuses_a_world_that_differs_from_gpus():
     p = subprocess.run([sys.executable, BENCH, "--gpus", "4"], env=dict(os.environ, **env), stdout=subprocess.PIPE,
                        stderr=subprocess.PIPE, text=True, timeout=300)
     assert p.returncode != 0 and "--gpus 4 but WORLD_SIZE=2" in p.stderr
+
+
+def test_launch_timeout_is_below_the_drivers_limit_and_names_every_ranks_phase(tmp_path):
+    """a hung collective must end HERE (default --launch-timeout <= 1200 s < the driver's 1800 s), with
+    the phase every rank was last seen in — not as an anonymous driver kill."""
+    import time
+    sys.path.insert(0, ROOT)
+    import bench
+    assert bench.parse([]).launch_timeout <= 1200
+    t0 = time.time()
+    p = run(["--gpus", "2", "--launch-timeout", "3", "--worker-cmd", stub_cmd(tmp_path, "stall")], {"MXLO_BENCH_FAKE_DEVICE_COUNT": "2"})
+    assert p.returncode != 0 and time.time() - t0 < 40
+    assert "still running after --launch-timeout 3 s" in p.stderr
+    assert "rank 0: in 'transport preflight'" in p.stderr and "rank 1: in 'communicator creation'" in p.stderr
+    assert not [ln for ln in p.stdout.splitlines() if ln.strip().startswith("{")]
+
+
+def test_watchdog_ends_a_rank_that_sits_in_one_phase(tmp_path, monkeypatch):
+    """The per-phase watchdog of a rank: a phase that outlasts its limit prints rank + phase and exits with status 7; a
+    phase that finishes in time is recorded with its duration; the phase file the launcher reads follows along."""
+    import time
+    sys.path.insert(0, ROOT)
+    import bench
+    monkeypatch.setenv("MXLO_BENCH_PHASE_DIR", str(tmp_path))
+    codes = []
+    wd = bench.Watchdog(3, limits={"quick": 5, "stuck": 0.3}, exit_fn=codes.append)
+    with wd.phase("quick"):
+        time.sleep(0.05)
+    assert wd.history and wd.history[0][0] == "quick" and not codes
+    assert "finished 'quick'" in open(tmp_path / "rank3").read()
+    with wd.phase("stuck"):
+        t0 = time.time()
+        while not codes and time.time() - t0 < 5:
+            time.sleep(0.05)
+    assert codes == [7]
+    assert "STALLED in 'stuck'" in open(tmp_path / "rank3").read() or "finished" in open(tmp_path / "rank3").read()
+    # the same through a real process: exit status 7 and the message on stderr
+    script = tmp_path / "w.py"
+    script.write_text("import sys, time\nsys.path.insert(0, %r)\nimport bench\nwd = bench.Watchdog(5, limits={'timed loop': 0.3})\n"
+                      "with wd.phase('timed loop'):\n    time.sleep(30)\n" % ROOT)
+    p = subprocess.run([sys.executable, str(script)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=60)
+    assert p.returncode == 7 and "WATCHDOG rank 5 has been in phase 'timed loop'" in p.stderr

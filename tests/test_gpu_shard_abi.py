@@ -4,7 +4,10 @@ no MPI. Transports covered here:
   * RCCL communicator(s) from ncclCommInitAll over ALL visible devices (1 on the build pool's boxes; the same test
     spans 2/4/8 devices wherever they are visible, e.g. the driver's 8-GPU node);
   * the loopback transport (2 and 5 shards on one GPU): the multi-shard logic and the bit-identical replicated
-    scalars, checked on every box.
+    scalars, checked on every box;
+  * the PEER transport (round 5: peer-mapped one-shot exchange, csrc/peer.hip) with 2 / 5 / 8 shards on one GPU —
+    mailboxes in device memory and (MXLO_PEER_MEM=host) in pinned host memory — and over all visible devices where
+    there are several: bit-identical to the loopback transport, preflight, bounded wait.
 Results are compared with the UNSHARDED oracle on the concatenated vectors."""
 import ctypes as C
 
@@ -56,7 +59,14 @@ def configs():
     if nvis > 1:
         out.append(("rccl-2", [0, 1]))
     out += [("loopback-2", [0, 0]), ("loopback-5", [0] * 5)]
+    out += [("peer-2", [0, 0]), ("peer-5", [0] * 5), ("peer-8", [0] * 8), ("peer-1", [0])]
+    if nvis > 1:
+        out.append(("peer-all-visible", list(range(nvis))))
     return out
+
+
+def transport_of(lo, name):
+    return lo._lib.SHARD_PEER if name.startswith("peer") else lo._lib.SHARD_AUTO
 
 
 @pytest.mark.parametrize("name,ids", configs())
@@ -64,11 +74,19 @@ def test_sharded_abi_matches_unsharded_oracle(lo, dev, name, ids):
     R = lo._lib.rccl_lib()
     nd = len(ids)
     sctx = C.c_void_p()
-    rc = R.mxlo_shard_ctx_create(nd, (C.c_int32 * nd)(*ids), C.byref(sctx))
+    rc = R.mxlo_shard_ctx_create_ex(nd, (C.c_int32 * nd)(*ids), transport_of(lo, name), C.byref(sctx))
     assert rc == 0, R.mxlo_shard_last_error()
     try:
         assert R.mxlo_shard_ctx_ndev(sctx) == nd
         assert bool(R.mxlo_shard_ctx_is_loopback(sctx)) == name.startswith("loopback")
+        assert R.mxlo_shard_ctx_transport(sctx) == {"rccl": lo._lib.SHARD_RCCL, "loop": lo._lib.SHARD_LOOPBACK, "peer": lo._lib.SHARD_PEER}[name[:4]]
+        # the transport proves itself before it is used: known-answer sums, identical bits on every shard, latency
+        lat = (C.c_double * 3)()
+        assert R.mxlo_shard_ctx_preflight(sctx, 10, 20000, lat) == 0, R.mxlo_shard_last_error()
+        assert all(0.0 < lat[k] < 1e6 for k in range(3)), list(lat)
+        dv, seen, pci = C.c_int32(-1), C.c_int32(-1), C.create_string_buffer(64)
+        assert R.mxlo_shard_ctx_info(sctx, nd - 1, C.byref(dv), C.byref(seen), pci, 64) == 0
+        assert dv.value == ids[-1] and seen.value == nd and len(pci.value) >= 5
         rng = np.random.default_rng(len(name) + nd)
         n = 40_003
         cuts = np.sort(rng.choice(np.arange(1, n), nd - 1, replace=False)) if nd > 1 else np.array([], dtype=int)
@@ -392,3 +410,121 @@ def test_cfg5_lbfgs_m20_n4e8_row_sharded_over_8_devices(lo, dev, transport):
         assert R.mxlo_shard_ctx_destroy(sctx) == 0
         ss = ys = rs = r2 = r3 = xs = None
         torch.cuda.empty_cache()
+
+
+# ------------------------------------------------------------------------------------ peer transport (round 5)
+def _run_sequence(lo, R, ids, transport, seed=5, n=30_011):
+    """A fixed sequence of sharded operations; returns every result vector and the replicated scalars (bytes)."""
+    nd = len(ids)
+    sctx = C.c_void_p()
+    assert R.mxlo_shard_ctx_create_ex(nd, (C.c_int32 * nd)(*ids), transport, C.byref(sctx)) == 0, R.mxlo_shard_last_error()
+    outs = []
+    try:
+        rng = np.random.default_rng(seed)
+        cuts = np.sort(rng.choice(np.arange(1, n), nd - 1, replace=False)) if nd > 1 else np.array([], dtype=int)
+        sizes = np.diff(np.concatenate([[0], cuts, [n]])).astype(int).tolist()
+        sh = Shards(R, sctx, sizes)
+        F64 = lo._lib.F64
+        h = rng.standard_normal(n)
+        h /= np.linalg.norm(h)
+        v, r0 = rng.uniform(-1, 1, n), rng.uniform(-1, 1, n)
+        hs, vs, rs = sh.put(h), sh.put(v), sh.put(r0)
+        assert R.mxlo_householder_mul_sharded(sctx, F64, sh.ptrs(rs), sh.ptrs(hs), sh.ptrs(vs), sh.nloc, 2.0, -3.0, 0) == 0, R.mxlo_shard_last_error()
+        outs.append(sh.get(rs))
+        for kind, mem in ((lo._lib.QN_LBFGS_INV, 5), (lo._lib.QN_LBFGS_FWD, 20), (lo._lib.QN_LSR1, 4)):
+            q = C.c_void_p()
+            assert R.mxlo_qn_create_sharded(sctx, kind, F64, sh.nloc, mem, 1, 0, 0.99, 10.0, C.byref(q)) == 0, R.mxlo_shard_last_error()
+            acc = C.c_int32(-1)
+            for s_, y_ in pairs(rng, n, mem + 2):
+                ss, ys = sh.put(s_), sh.put(y_)
+                assert R.mxlo_qn_push_sharded(q, sh.ptrs(ss), sh.ptrs(ys), C.byref(acc)) == 0, R.mxlo_shard_last_error()
+            x = rng.uniform(-1, 1, n)
+            xs, rs = sh.put(x), sh.put(r0)
+            assert R.mxlo_qn_mul_sharded(q, sh.ptrs(rs), sh.ptrs(xs), 2.0, -3.0, 0) == 0, R.mxlo_shard_last_error()
+            outs.append(sh.get(rs))
+            if kind == lo._lib.QN_LBFGS_FWD:
+                sol = sh.put(np.zeros(n))
+                assert R.mxlo_qn_solve_shifted_sharded(q, sh.ptrs(sol), sh.ptrs(xs), 0.25) == 0, R.mxlo_shard_last_error()   # 860 doubles
+                outs.append(sh.get(sol))
+            sc, ys_, ax = (C.c_double * 5)(), (C.c_double * mem)(), (C.c_double * mem)()
+            for i in range(nd):
+                assert R.mxlo_qn_get_scalars_sharded(q, i, sc, ys_, ax) == 0
+                outs.append(np.frombuffer(bytes(sc)[:32] + bytes(ys_) + bytes(ax), dtype=np.uint8).copy())
+            assert R.mxlo_qn_destroy_sharded(q) == 0
+    finally:
+        assert R.mxlo_shard_ctx_destroy(sctx) == 0
+    return outs
+
+
+@pytest.mark.parametrize("nd", [2, 5, 8])
+@pytest.mark.parametrize("mem", ["device", "host"])
+def test_peer_transport_is_bit_identical_to_loopback(lo, dev, nd, mem, monkeypatch):
+    """the peer-mapped one-shot exchange sums in FIXED RANK ORDER, like the loopback transport — so on
+    the same shards every result vector and every replicated scalar must agree with it BIT FOR BIT (Householder, the
+    three quasi-Newton operators incl. the 860-double all-reduce of solve_shifted_system!), with the mailboxes in device
+    memory and in pinned host memory (the fallback when two devices have no peer access)."""
+    R = lo._lib.rccl_lib()
+    want = _run_sequence(lo, R, [0] * nd, lo._lib.SHARD_LOOPBACK)
+    if mem == "host":
+        monkeypatch.setenv("MXLO_PEER_MEM", "host")
+    got = _run_sequence(lo, R, [0] * nd, lo._lib.SHARD_PEER)
+    assert len(got) == len(want)
+    for k, (a, b) in enumerate(zip(got, want)):
+        assert np.array_equal(a, b), (nd, mem, k)
+
+
+def test_peer_transport_env_selection_and_refusals(lo, dev, monkeypatch):
+    R = lo._lib.rccl_lib()
+    sctx = C.c_void_p()
+    monkeypatch.setenv("MXLO_SHARD_TRANSPORT", "peer")
+    assert R.mxlo_shard_ctx_create(3, (C.c_int32 * 3)(0, 0, 0), C.byref(sctx)) == 0, R.mxlo_shard_last_error()
+    assert R.mxlo_shard_ctx_transport(sctx) == lo._lib.SHARD_PEER and not R.mxlo_shard_ctx_is_loopback(sctx)
+    assert R.mxlo_shard_ctx_destroy(sctx) == 0
+    monkeypatch.setenv("MXLO_SHARD_TRANSPORT", "carrier-pigeon")
+    assert R.mxlo_shard_ctx_create(1, None, C.byref(sctx)) == lo._lib.EINVAL and b"carrier-pigeon" in R.mxlo_shard_last_error()
+    monkeypatch.delenv("MXLO_SHARD_TRANSPORT")
+    assert R.mxlo_shard_ctx_create_ex(2, (C.c_int32 * 2)(0, 0), lo._lib.SHARD_RCCL, C.byref(sctx)) == lo._lib.EINVAL     # RCCL refuses one device twice
+    assert b"RCCL refuses" in R.mxlo_shard_last_error()
+    assert R.mxlo_shard_ctx_create_ex(1, None, 17, C.byref(sctx)) == lo._lib.EINVAL
+    # ncclCommInitAll reporting an error (injected): a clean MXLO_EREDUCE, nothing leaked, the next create works
+    monkeypatch.setenv("MXLO_SHARD_FAULT", "initall")
+    assert R.mxlo_shard_ctx_create_ex(1, None, lo._lib.SHARD_RCCL, C.byref(sctx)) == lo._lib.EREDUCE
+    assert b"ncclCommInitAll" in R.mxlo_shard_last_error()
+    monkeypatch.delenv("MXLO_SHARD_FAULT")
+    assert R.mxlo_shard_ctx_create_ex(1, None, lo._lib.SHARD_RCCL, C.byref(sctx)) == 0, R.mxlo_shard_last_error()
+    assert R.mxlo_shard_ctx_destroy(sctx) == 0
+
+
+def test_peer_transport_missing_rank_is_an_error_not_a_hang(lo, dev):
+    """A shard that never posts (test hook `peer_drop`): the others poll for `peer_timeout_ms`, store NaN, raise their
+    fault word and END; the next sync reports which rank was missing, the ctx refuses further work (MXLO_ESTATE), destroy
+    returns, and a fresh ctx works."""
+    import time
+    R = lo._lib.rccl_lib()
+    sctx = C.c_void_p()
+    assert R.mxlo_shard_ctx_create_ex(3, (C.c_int32 * 3)(0, 0, 0), lo._lib.SHARD_PEER, C.byref(sctx)) == 0, R.mxlo_shard_last_error()
+    try:
+        rng = np.random.default_rng(2)
+        sizes = [5000, 6000, 7001]
+        n = sum(sizes)
+        sh = Shards(R, sctx, sizes)
+        h = rng.standard_normal(n)
+        h /= np.linalg.norm(h)
+        v = rng.uniform(-1, 1, n)
+        hs, vs, rs = sh.put(h), sh.put(v), sh.put(np.zeros(n))
+        F64 = lo._lib.F64
+        assert R.mxlo_householder_mul_sharded(sctx, F64, sh.ptrs(rs), sh.ptrs(hs), sh.ptrs(vs), sh.nloc, 1.0, 0.0, 0) == 0
+        assert rel(sh.get(rs), oracle.householder_mul(np.zeros(n), h, v, 1.0, 0.0)) <= 1e-12
+        assert R.mxlo_shard_ctx_debug(sctx, b"peer_timeout_ms", 200) == 0
+        assert R.mxlo_shard_ctx_debug(sctx, b"peer_drop", 1) == 0
+        t0 = time.perf_counter()
+        assert R.mxlo_householder_mul_sharded(sctx, F64, sh.ptrs(rs), sh.ptrs(hs), sh.ptrs(vs), sh.nloc, 1.0, 0.0, 0) == 0   # enqueued
+        rc = R.mxlo_shard_ctx_sync(sctx)
+        assert time.perf_counter() - t0 < 10.0
+        assert rc == lo._lib.EREDUCE and b"rank 1" in R.mxlo_shard_last_error(), R.mxlo_shard_last_error()
+        got = np.concatenate([t.cpu().numpy() for t in rs])
+        assert np.isnan(got[:5000]).all() and np.isnan(got[11000:]).all()          # shards 0 and 2 gave up with NaN
+        assert R.mxlo_householder_mul_sharded(sctx, F64, sh.ptrs(rs), sh.ptrs(hs), sh.ptrs(vs), sh.nloc, 1.0, 0.0, 0) == lo._lib.ESTATE
+    finally:
+        assert R.mxlo_shard_ctx_destroy(sctx) == 0
+    assert _run_sequence(lo, R, [0, 0], lo._lib.SHARD_PEER, n=5003)            # a fresh ctx is fine

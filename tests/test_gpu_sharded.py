@@ -32,14 +32,25 @@ WORKER = textwrap.dedent('''
     di = rank if backend == "nccl" else 0
     torch.cuda.set_device(di)
     dev = torch.device("cuda", di)
+    want_peer = os.environ.get("MXLO_TEST_TRANSPORT") == "peer"
     if backend == "nccl":
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        hook = lo.sharded.install_allreduce(lo.get_ctx(dev), native=True)     # must be the C hook: raises otherwise
+        if not want_peer:
+            hook = lo.sharded.install_allreduce(lo.get_ctx(dev), native=True)     # must be the C hook: raises otherwise
+            pf = hook.preflight(lo.get_ctx(dev).stream, reps=20, timeout_ms=30000)   # collective: sums, identical bits, latency
+            inf = hook.info()
+            assert inf["ranks_seen"] == world and inf["user_rank"] == rank and inf["device"] == di, inf
     else:
         dist.init_process_group("gloo", rank=rank, world_size=world)
-        hook = lo.sharded.install_agreed_allreduce(lo.get_ctx(dev), timeout_s=45.0)
+        if not want_peer:
+            hook = lo.sharded.install_agreed_allreduce(lo.get_ctx(dev), timeout_s=45.0)
     ctx = lo.get_ctx(dev)
-    transport = "native" if hook is not None else "torch"
+    if want_peer:     # the peer-mapped one-shot exchange over a POSIX shm segment: ONE kernel per collective, no RCCL
+        hook = lo.sharded.PeerShmHook(rank, world, timeout_ms=20000)
+        hook.install(ctx)
+        pf = hook.preflight(ctx.stream, reps=20, timeout_ms=30000)
+        assert all(0 < pf[k] < 1e6 for k in pf), pf
+    transport = "peer" if want_peer else ("native" if hook is not None else "torch")
     n, mem = 200_003, 4
     rng = np.random.default_rng(7)                       # same stream everywhere: replicated global data
     plan = lo.sharded.ShardPlan(n, world)
@@ -118,16 +129,19 @@ WORKER = textwrap.dedent('''
     gathered = [torch.zeros_like(t) for _ in range(world)]
     dist.all_gather(gathered, t)
     same = all(torch.equal(gathered[0], gt) for gt in gathered)
+    if want_peer:
+        torch.cuda.synchronize()
+        hook.check()
     print("RESULT", rank, transport, err_h, err_b, int(same), err_m, flush=True)
     dist.destroy_process_group()
 ''')
 
 
-def run_ranks(tmp_path, world, backend, port):
+def run_ranks(tmp_path, world, backend, port, transport="auto"):
     script = tmp_path / "worker.py"
     script.write_text(WORKER % {"root": ROOT})
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world),
-               MXLO_TEST_BACKEND=backend, HSA_ENABLE_IPC_MODE_LEGACY="0")
+               MXLO_TEST_BACKEND=backend, MXLO_TEST_TRANSPORT=transport, HSA_ENABLE_IPC_MODE_LEGACY="0")
     procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
     outs = []
@@ -159,3 +173,18 @@ def test_two_ranks_one_gpu_agree_on_transport_and_shard(tmp_path):
 def test_real_ranks_native_rccl_hook(tmp_path):
     world = min(torch.cuda.device_count(), 8)
     assert run_ranks(tmp_path, world, "nccl", 29673) == "native"
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_ranks_on_one_gpu_peer_shm_transport(tmp_path, world):
+    """VERDICT r4 next #2, one process per GPU: the peer-mapped one-shot exchange (csrc/peer.hip) with its mailboxes in a
+    POSIX shared-memory segment — ONE kernel per collective, fixed rank order. 2 and 3 processes on cuda:0 (gloo is only
+    the host runtime that carries the segment name): preflight (known-answer sums, identical bits, verdict), the sharded
+    Householder / L-BFGS applies against the unsharded oracle, bit-identical replicated scalars on all ranks."""
+    assert run_ranks(tmp_path, world, "gloo", 29675 + world, transport="peer") == "peer"
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs >= 2 visible devices (lights up on the 8-GPU node)")
+def test_real_ranks_peer_shm_transport(tmp_path):
+    world = min(torch.cuda.device_count(), 8)
+    assert run_ranks(tmp_path, world, "nccl", 29679, transport="peer") == "peer"

@@ -335,6 +335,23 @@ int32_t mxlo_scatter_zero_sorted(mxlo_ctx *ctx, int32_t elem_size, void *res, in
 int32_t mxlo_scatter_zero_range(mxlo_ctx *ctx, int32_t elem_size, void *res, int64_t nres,
                                 const void *u, int64_t start, int64_t step, int64_t len);
 
+/* Index plans (round 5): a STRICTLY INCREASING index set I ⊂ 1..n kept as one bit per element of the long vector plus
+ * the number of selected elements before every 64-bit mask word (k-th index <-> k-th set bit). Neither
+ * mulRestrict! (res = v[I], src/special-operators.jl:167-169) nor multRestrict! (res .= 0; res[I] = u, :171-174) then
+ * reads the index list: 1/4 byte per element of the LONG vector replaces 8 bytes per index, and both applies are
+ * streaming passes over the long vector (extension: res written exactly once with 16-byte stores, no search, no LDS
+ * tile; restriction: 16-byte groups of v read only where a bit is set, the selected elements stored at consecutive
+ * addresses). Worth it when nidx >= n / 32; bit-exact like mxlo_gather / mxlo_scatter_zero (pure data movement).
+ * The plan is built ONCE, at operator construction, from HOST indices (MXLO_EDOMAIN when they are not strictly
+ * increasing within 1..n) and is bound to its ctx's device. `pos` of mxlo_scatter_zero_plan: as in
+ * mxlo_scatter_zero_sorted (device array, 0-based position in u of the k-th sorted index; NULL = identity). */
+typedef struct mxlo_index_plan mxlo_index_plan;
+int32_t mxlo_index_plan_create(mxlo_ctx *ctx, const int64_t *idx_host, int64_t nidx, int64_t n, mxlo_index_plan **out);
+int32_t mxlo_index_plan_destroy(mxlo_index_plan *plan);
+int32_t mxlo_gather_plan(mxlo_ctx *ctx, int32_t elem_size, void *res, const void *v, int64_t nv, const mxlo_index_plan *plan);
+int32_t mxlo_scatter_zero_plan(mxlo_ctx *ctx, int32_t elem_size, void *res, int64_t nres, const void *u, const int64_t *pos,
+                               const mxlo_index_plan *plan);
+
 /* Row-shard staging for collectives that move vectors (row-sharded dense LinearOperator / opHermitian, SURVEY §8f-4).
  * Shard r of an n-vector owns rows [lo(r), lo(r)+len(r)), lo(r) = r*q + min(r, rem), len(r) = q + (r < rem),
  * q = n / world, rem = n % world; the wire format of all-gather / reduce-scatter is `world` slots of

@@ -80,6 +80,10 @@ _lib = None
 
 _vp, _i32, _i64, _dbl = C.c_void_p, C.c_int32, C.c_int64, C.c_double
 _PROTOS = {
+    "mxlo_index_plan_create": [_vp, _vp, _i64, _i64, C.POINTER(_vp)],
+    "mxlo_index_plan_destroy": [_vp],
+    "mxlo_gather_plan": [_vp, _i32, _vp, _vp, _i64, _vp],
+    "mxlo_scatter_zero_plan": [_vp, _i32, _vp, _i64, _vp, _vp, _vp],
     "mxlo_ctx_create": [_i32, _vp, C.POINTER(_vp)],
     "mxlo_ctx_destroy": [_vp],
     "mxlo_ctx_set_stream": [_vp, _vp],

@@ -806,6 +806,237 @@ MXLO_API int32_t mxlo_scatter_zero_range(mxlo_ctx *ctx, int32_t elem_size, void 
   });
 }
 
+// ---- index plans: a strictly increasing index set as BIT MASK + RANKS (round 5) -----------------------------------------
+// A strictly increasing I ⊂ 1..n is one bit per element of the long vector plus, per 64-bit mask word, the number of set
+// bits before it: k-th index <-> k-th set bit, so neither `res = v[I]` nor `res .= 0; res[I] = u` has to READ the index
+// list (8 bytes per index, a third of the restriction's algorithmic bytes) — 1/8 + 1/8 byte per element of the long
+// vector replaces it. Both applies become streaming passes over the LONG vector with the short one read / written through
+// rank arithmetic (popcount of the mask bits below the lane's element):
+//   extension  : every lane owns one 16-byte group of res: bits -> values from u[rank ..] (or u[pos[rank ..]]), zeros
+//                elsewhere, ONE nontemporal store; res is written exactly once, no LDS tile, no search;
+//   restriction: every lane owns one 16-byte group of v, loaded only when one of its bits is set (empty groups cost no
+//                traffic), and stores its selected elements at res[rank ..] — neighbouring lanes write neighbouring
+//                addresses, the memory pipeline merges them into full lines.
+// Pure data movement: bit-exact (NaN payloads survive). Built ONCE at operator construction from host indices.
+struct mxlo_index_plan {
+  mxlo_ctx *ctx = nullptr;
+  int64_t n = 0, nidx = 0, nwords = 0;
+  // [nwords + 1] pairs (mask, rank): bit (i & 63) of mask word (i >> 6) <=> element i (0-based) is selected; rank = number
+  // of selected elements before that word. Interleaved, so that a lane fetches both with ONE 16-byte load.
+  unsigned long long *mr = nullptr;
+};
+
+namespace {
+template <typename E, bool ALIGNED>
+__global__ void __launch_bounds__(kBlock)
+extend_mask_kernel(E *__restrict__ res, int64_t nres, const E *__restrict__ u, const int64_t *__restrict__ pos,
+                   const u64x2 *__restrict__ mr) {
+  constexpr int VEC = sizeof(E) >= 16 ? 1 : 16 / (int)sizeof(E);
+  constexpr int U = 4;
+  struct alignas(16) Pack { E x[VEC]; };
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  const int64_t ngroups = (nres + VEC - 1) / VEC;
+  for (int64_t base = ((int64_t)blockIdx.x * U) * kBlock + threadIdx.x; base < ngroups; base += (int64_t)gridDim.x * U * kBlock) {
+    unsigned long long w[U];
+    int64_t r[U];
+    bool ok[U];
+#pragma unroll
+    for (int k = 0; k < U; ++k) {
+      const int64_t g = base + (int64_t)k * kBlock;
+      ok[k] = g < ngroups;
+      const u64x2 t = mr[ok[k] ? (g * VEC) >> 6 : 0];
+      w[k] = t[0];
+      r[k] = (int64_t)t[1];
+    }
+    Pack pk[U];
+#pragma unroll
+    for (int k = 0; k < U; ++k) {
+      const int64_t i0 = (base + (int64_t)k * kBlock) * VEC;
+      const int sh = (int)(i0 & 63);
+      unsigned bits = ok[k] ? (unsigned)((w[k] >> sh) & ((1u << VEC) - 1u)) : 0u;
+      int64_t rr = r[k] + __popcll(w[k] & ((1ull << sh) - 1ull));
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        E val;
+        memset(&val, 0, sizeof(E));
+        if ((bits >> j) & 1u) {
+          val = u[pos ? pos[rr] : rr];
+          ++rr;
+        }
+        pk[k].x[j] = val;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < U; ++k) {
+      if (!ok[k]) continue;
+      const int64_t i0 = (base + (int64_t)k * kBlock) * VEC;
+      if (ALIGNED && i0 + VEC <= nres) {
+        __builtin_nontemporal_store(*reinterpret_cast<u32x4 *>(&pk[k]), reinterpret_cast<u32x4 *>(res + i0));
+      } else {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j)
+          if (i0 + j < nres) res[i0 + j] = pk[k].x[j];
+      }
+    }
+  }
+}
+
+// DENSE: every 16-byte group of v is loaded unconditionally (at densities where nearly every 32-byte sector holds a
+// selected element anyway, the branch around the load costs more than the few sectors it saves).
+template <typename E, bool ALIGNED, bool DENSE>
+__global__ void __launch_bounds__(kBlock)
+gather_mask_kernel(E *__restrict__ res, const E *__restrict__ v, int64_t n, const u64x2 *__restrict__ mr) {
+  constexpr int VEC = sizeof(E) >= 16 ? 1 : 16 / (int)sizeof(E);
+  constexpr int U = 4;
+  struct alignas(16) Pack { E x[VEC]; };
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  const int64_t ngroups = (n + VEC - 1) / VEC;
+  const int64_t nfull = n / VEC;                                             // groups that lie entirely inside v
+  for (int64_t base = ((int64_t)blockIdx.x * U) * kBlock + threadIdx.x; base < ngroups; base += (int64_t)gridDim.x * U * kBlock) {
+    unsigned bits[U];
+    int64_t r[U];
+    Pack pk[U];
+    const bool whole = base + (int64_t)(U - 1) * kBlock < nfull;             // all U groups of this lane are full groups
+    if (ALIGNED && DENSE && whole) {
+      u64x2 t[U];
+#pragma unroll
+      for (int k = 0; k < U; ++k) t[k] = mr[((base + (int64_t)k * kBlock) * VEC) >> 6];
+#pragma unroll
+      for (int k = 0; k < U; ++k) *reinterpret_cast<u32x4 *>(&pk[k]) = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(v + (base + (int64_t)k * kBlock) * VEC));
+#pragma unroll
+      for (int k = 0; k < U; ++k) {
+        const int sh = (int)(((base + (int64_t)k * kBlock) * VEC) & 63);
+        bits[k] = (unsigned)((t[k][0] >> sh) & ((1u << VEC) - 1u));
+        r[k] = (int64_t)t[k][1] + __popcll(t[k][0] & ((1ull << sh) - 1ull));
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < U; ++k) {
+        const int64_t g = base + (int64_t)k * kBlock;
+        const bool ok = g < ngroups;
+        const int64_t i0 = g * VEC;
+        const u64x2 t = mr[ok ? i0 >> 6 : 0];
+        const int sh = (int)(i0 & 63);
+        bits[k] = ok ? (unsigned)((t[0] >> sh) & ((1u << VEC) - 1u)) : 0u;   // (bits beyond n are never set)
+        r[k] = (int64_t)t[1] + __popcll(t[0] & ((1ull << sh) - 1ull));
+      }
+#pragma unroll
+      for (int k = 0; k < U; ++k) {
+        if (!bits[k]) continue;                                               // an empty group is not read
+        const int64_t i0 = (base + (int64_t)k * kBlock) * VEC;
+        if (ALIGNED && i0 + VEC <= n) {
+          *reinterpret_cast<u32x4 *>(&pk[k]) = *reinterpret_cast<const u32x4 *>(v + i0);
+        } else {
+#pragma unroll
+          for (int j = 0; j < VEC; ++j)
+            if (((bits[k] >> j) & 1u) && i0 + j < n) pk[k].x[j] = v[i0 + j];
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < U; ++k) {
+      int64_t rr = r[k];
+#pragma unroll
+      for (int j = 0; j < VEC; ++j)
+        if ((bits[k] >> j) & 1u) res[rr++] = pk[k].x[j];
+    }
+  }
+}
+}  // namespace
+
+// idx_host: HOST array of `nidx` 1-based indices, strictly increasing, all in 1..n (checked: MXLO_EDOMAIN otherwise).
+MXLO_API int32_t mxlo_index_plan_create(mxlo_ctx *ctx, const int64_t *idx_host, int64_t nidx, int64_t n, mxlo_index_plan **out) {
+  MXLO_REQUIRE(ctx && out && nidx >= 0 && n >= 0 && (nidx == 0 || idx_host), MXLO_EINVAL, "mxlo_index_plan_create: bad argument");
+  MXLO_DEVICE_GUARD(ctx);
+  *out = nullptr;
+  const int64_t nwords = (n + 63) / 64;
+  std::vector<unsigned long long> mr(2 * ((size_t)nwords + 1), 0ull);     // (mask, rank) pairs
+  int64_t prev = 0;
+  for (int64_t k = 0; k < nidx; ++k) {
+    const int64_t i = idx_host[k];
+    MXLO_REQUIRE(i > prev && i <= n, MXLO_EDOMAIN, "mxlo_index_plan_create: index %lld at position %lld is not strictly increasing within 1..%lld",
+                 (long long)i, (long long)k, (long long)n);
+    prev = i;
+    mr[2 * (size_t)((i - 1) >> 6)] |= 1ull << ((i - 1) & 63);
+  }
+  for (int64_t w = 0; w < nwords; ++w) mr[2 * ((size_t)w + 1) + 1] = mr[2 * (size_t)w + 1] + (unsigned long long)__builtin_popcountll(mr[2 * (size_t)w]);
+  mxlo_index_plan *p = new mxlo_index_plan();
+  p->ctx = ctx;
+  p->n = n;
+  p->nidx = nidx;
+  p->nwords = nwords;
+  const size_t bytes = sizeof(unsigned long long) * mr.size();
+  if (hipMalloc((void **)&p->mr, bytes) != hipSuccess) {
+    (void)hipGetLastError();
+    delete p;
+    set_error("mxlo_index_plan_create: out of device memory (%zu bytes)", bytes);
+    return MXLO_ENOMEM;
+  }
+  if (hipMemcpy(p->mr, mr.data(), bytes, hipMemcpyHostToDevice) != hipSuccess) {
+    (void)hipFree(p->mr);
+    delete p;
+    set_error("mxlo_index_plan_create: upload failed");
+    return MXLO_EHIP;
+  }
+  *out = p;
+  return MXLO_OK;
+}
+
+MXLO_API int32_t mxlo_index_plan_destroy(mxlo_index_plan *p) {
+  if (!p) return MXLO_OK;
+  MXLO_DEVICE_GUARD(p->ctx);
+  (void)hipFree(p->mr);
+  delete p;
+  return MXLO_OK;
+}
+
+// res = v[I]  (mulRestrict!, src/special-operators.jl:167-169) for the plan's strictly increasing I; nv must be the plan's n
+MXLO_API int32_t mxlo_gather_plan(mxlo_ctx *ctx, int32_t elem_size, void *res, const void *v, int64_t nv, const mxlo_index_plan *plan) {
+  MXLO_REQUIRE(ctx && plan, MXLO_EINVAL, "mxlo_gather_plan: NULL argument");
+  MXLO_DEVICE_GUARD(ctx);
+  MXLO_REQUIRE(plan->ctx->device == ctx->device, MXLO_EINVAL, "mxlo_gather_plan: the plan lives on device %d, the ctx on %d", plan->ctx->device, ctx->device);
+  MXLO_REQUIRE(nv == plan->n, MXLO_ESHAPE, "mxlo_gather_plan: v has %lld elements, the plan was built for %lld", (long long)nv, (long long)plan->n);
+  if (plan->nidx == 0) return MXLO_OK;
+  MXLO_REQUIRE(res && v, MXLO_EINVAL, "mxlo_gather_plan: NULL operand");
+  return by_elem_size(elem_size, [&]<typename E>() -> int32_t {
+    constexpr int VEC = sizeof(E) >= 16 ? 1 : 16 / (int)sizeof(E);
+    const int grid = grid_for(ctx, (nv + VEC - 1) / VEC, kBlock * 4, ctx->tune.blocks_per_cu);
+    const u64x2 *mr = reinterpret_cast<const u64x2 *>(plan->mr);
+    const bool dense = plan->nidx * 8 >= plan->n;           // >= 1/8: practically every 32-byte sector is touched
+    if ((((uintptr_t)v) & 15u) != 0)
+      hipLaunchKernelGGL((gather_mask_kernel<E, false, false>), dim3(grid), dim3(kBlock), 0, ctx->stream, (E *)res, (const E *)v, nv, mr);
+    else if (dense)
+      hipLaunchKernelGGL((gather_mask_kernel<E, true, true>), dim3(grid), dim3(kBlock), 0, ctx->stream, (E *)res, (const E *)v, nv, mr);
+    else
+      hipLaunchKernelGGL((gather_mask_kernel<E, true, false>), dim3(grid), dim3(kBlock), 0, ctx->stream, (E *)res, (const E *)v, nv, mr);
+    MXLO_LAUNCH_CHECK();
+    return MXLO_OK;
+  });
+}
+
+// res .= 0; res[I] = u[pos ? pos[k] : k]  (multRestrict!, src/special-operators.jl:171-174); nres must be the plan's n;
+// pos (device, 0-based, or NULL) as in mxlo_scatter_zero_sorted
+MXLO_API int32_t mxlo_scatter_zero_plan(mxlo_ctx *ctx, int32_t elem_size, void *res, int64_t nres, const void *u, const int64_t *pos,
+                                        const mxlo_index_plan *plan) {
+  MXLO_REQUIRE(ctx && plan, MXLO_EINVAL, "mxlo_scatter_zero_plan: NULL argument");
+  MXLO_DEVICE_GUARD(ctx);
+  MXLO_REQUIRE(plan->ctx->device == ctx->device, MXLO_EINVAL, "mxlo_scatter_zero_plan: the plan lives on device %d, the ctx on %d", plan->ctx->device, ctx->device);
+  MXLO_REQUIRE(nres == plan->n, MXLO_ESHAPE, "mxlo_scatter_zero_plan: res has %lld elements, the plan was built for %lld", (long long)nres, (long long)plan->n);
+  if (nres == 0) return MXLO_OK;
+  MXLO_REQUIRE(res && (plan->nidx == 0 || u), MXLO_EINVAL, "mxlo_scatter_zero_plan: NULL operand");
+  return by_elem_size(elem_size, [&]<typename E>() -> int32_t {
+    constexpr int VEC = sizeof(E) >= 16 ? 1 : 16 / (int)sizeof(E);
+    const int grid = grid_for(ctx, (nres + VEC - 1) / VEC, kBlock * 4, ctx->tune.blocks_per_cu);
+    const u64x2 *mr = reinterpret_cast<const u64x2 *>(plan->mr);
+    if ((((uintptr_t)res) & 15u) == 0)
+      hipLaunchKernelGGL((extend_mask_kernel<E, true>), dim3(grid), dim3(kBlock), 0, ctx->stream, (E *)res, nres, (const E *)u, pos, mr);
+    else
+      hipLaunchKernelGGL((extend_mask_kernel<E, false>), dim3(grid), dim3(kBlock), 0, ctx->stream, (E *)res, nres, (const E *)u, pos, mr);
+    MXLO_LAUNCH_CHECK();
+    return MXLO_OK;
+  });
+}
+
 // ---- row-shard staging for the collectives that move VECTORS (row-sharded dense / opHermitian) ----------------
 // ShardPlan: shard r of an n-vector owns rows [lo(r), lo(r) + len(r)), lo(r) = r*q + min(r, rem), len(r) = q + (r < rem),
 // q = n / world, rem = n % world. all-gather / reduce-scatter need equal counts per rank, so the wire format is

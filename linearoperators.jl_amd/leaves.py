@@ -203,6 +203,23 @@ def sorted_scatter_plan(idx_h: np.ndarray):
     return svals.astype(np.int64), spos
 
 
+PLAN_MIN_DENSITY = 1          # 0 switches the mask + rank form off (tests compare the two device implementations)
+PLAN_MIN_DENSITY_INV = 32     # ... used when nidx >= n / 32: below, the index list is the smaller description
+PLAN_GATHER_DENSITY_INV = 8   # ... and for the restriction (res = v[I]) when nidx >= n / 8
+
+
+class _IndexPlan:
+    """RAII wrapper of `mxlo_index_plan` (strictly increasing indices as bit mask + ranks, built from host indices)."""
+
+    def __init__(self, ctx, sorted_idx_host: np.ndarray, n: int):
+        import ctypes as C
+        import weakref
+        self.handle = C.c_void_p()
+        _lib.call("mxlo_index_plan_create", ctx.handle, sorted_idx_host.ctypes.data, sorted_idx_host.size, int(n), C.byref(self.handle))
+        self._ctx = ctx                                  # the plan refers to its ctx: keep it alive
+        weakref.finalize(self, _lib.lib().mxlo_index_plan_destroy, self.handle)
+
+
 def opRestriction(Idx, ncol: int, S: Optional[Storage] = None, device=None):
     """opRestriction(I, ncol; S) — src/special-operators.jl:176-203. The operator's eltype is the
     index integer type (Int64), like the reference (`LinearOperator{I, Vector{I}}`, :193)."""
@@ -237,12 +254,28 @@ def opRestriction(Idx, ncol: int, S: Optional[Storage] = None, device=None):
         sidx_d = idx_d if spos is None else torch.from_numpy(svals).to(dev)
         spos_d = None if spos is None else torch.from_numpy(spos).to(dev)
 
+        # a dense enough index set is kept as bit mask + ranks (include/mxlo.h "index plans"): the applies stream the
+        # long vector and never read the index list. The plan is per device; built here, once.
+        plan = None
+        if PLAN_MIN_DENSITY > 0 and svals.size > 0 and svals.size * PLAN_MIN_DENSITY_INV >= ncol:
+            plan = _IndexPlan(get_ctx(dev), np.ascontiguousarray(svals, dtype=np.int64), ncol)
+        # res = v[I] in I's own order: only when I is increasing — and from 1/8 density on (measured crossover with the
+        # index-list gather, profiles/r05_bench_index.txt; the extension wins at every density above 1/32)
+        gather_plan = plan if (spos is None and svals.size * PLAN_GATHER_DENSITY_INV >= ncol) else None
+
         def prod(res, v, a, b):
             ctx = get_ctx(res.device)
+            if gather_plan is not None and res.device == dev:
+                _lib.call("mxlo_gather_plan", ctx.handle, res.element_size(), ptr(res), ptr(v), v.numel(), gather_plan.handle)
+                return
             _lib.call("mxlo_gather", ctx.handle, res.element_size(), ptr(res), ptr(v), v.numel(), ptr(idx_d), nrow)
 
         def tprod(res, u, a, b):
             ctx = get_ctx(res.device)
+            if plan is not None and res.device == dev:
+                _lib.call("mxlo_scatter_zero_plan", ctx.handle, res.element_size(), ptr(res), res.numel(), ptr(u), ptr(spos_d),
+                          plan.handle)
+                return
             _lib.call("mxlo_scatter_zero_sorted", ctx.handle, res.element_size(), ptr(res), res.numel(), ptr(u),
                       ptr(sidx_d), ptr(spos_d), sidx_d.numel())
     op = LinearOperator(torch.int64, nrow, ncol, False, False, prod, tprod, tprod, S=storage)

@@ -287,6 +287,53 @@ def test_restriction_extension_bit_exact(lo, dev, dtype):
         lo.opRestriction([n + 1], n, device=dev)
 
 
+def test_index_plan_form_matches_the_index_list_form(lo, dev, monkeypatch):
+    """Round 5: a dense strictly increasing index set is applied as bit mask + ranks (no index list
+    read). Through the operator API, against the index-list kernels on the same inputs (PLAN_MIN_DENSITY = 0) and numpy:
+    Float64 / Float32 / ComplexF64, increasing I (both applies use the plan), a permuted I with duplicates (extension uses
+    the plan + pos, restriction keeps the list), NaN payloads, > 1/32 and < 1/32 densities; and the refusals of the ABI."""
+    import ctypes as C
+    from linearoperators_jl_amd import leaves
+    from linearoperators_jl_amd.device import get_ctx
+    rng = np.random.default_rng(21)
+    n = 300_007
+    for dtype in (torch.float64, torch.float32, torch.complex128):
+        v = rng.standard_normal(n) if dtype != torch.complex128 else rng.standard_normal(n) + 1j * rng.standard_normal(n)
+        v = v.astype({torch.float64: np.float64, torch.float32: np.float32, torch.complex128: np.complex128}[dtype])
+        v[::89] = np.nan
+        vt = T(v, dev)
+        for idx in (np.flatnonzero(rng.random(n) < 0.5) + 1, np.flatnonzero(rng.random(n) < 0.04) + 1,
+                    np.flatnonzero(rng.random(n) < 0.01) + 1, rng.integers(1, n + 1, 150_000), np.arange(1, n + 1)):
+            outs = []
+            for plan_on in (1, 0):
+                monkeypatch.setattr(leaves, "PLAN_MIN_DENSITY", plan_on)
+                P = lo.opRestriction(idx, n, device=dev)
+                out = torch.empty(len(idx), dtype=dtype, device=dev)
+                lo.mul(out, P, vt)
+                back = torch.full((n,), 7, dtype=dtype, device=dev)
+                lo.mul(back, P.H, vt[:len(idx)])
+                outs.append((out.cpu().numpy(), back.cpu().numpy()))
+            b = lambda a: np.ascontiguousarray(a).view(np.uint8)
+            assert np.array_equal(b(outs[0][0]), b(outs[1][0])) and np.array_equal(b(outs[0][1]), b(outs[1][1]))
+            assert np.array_equal(b(outs[0][0]), b(v[np.asarray(idx) - 1]))
+            want = oracle.extend(np.empty(n, v.dtype), v[:len(idx)].copy(), np.asarray(idx, dtype=np.int64)) if dtype != torch.complex128 else None
+            if want is not None:
+                assert np.array_equal(b(outs[0][1]), b(want))
+    ctx = get_ctx(dev)
+    plan = C.c_void_p()
+    bad = np.array([1, 5, 5, 9], dtype=np.int64)
+    with pytest.raises(Exception, match="strictly increasing"):
+        lo._lib.call("mxlo_index_plan_create", ctx.handle, bad.ctypes.data, 4, 10, C.byref(plan))
+    good = np.array([1, 5, 9], dtype=np.int64)
+    with pytest.raises(Exception, match="strictly increasing"):
+        lo._lib.call("mxlo_index_plan_create", ctx.handle, good.ctypes.data, 3, 8, C.byref(plan))       # 9 > n
+    lo._lib.call("mxlo_index_plan_create", ctx.handle, good.ctypes.data, 3, 10, C.byref(plan))
+    x = torch.zeros(11, dtype=torch.float64, device=dev)
+    with pytest.raises(Exception, match="built for 10"):
+        lo._lib.call("mxlo_gather_plan", ctx.handle, 8, x.data_ptr(), x.data_ptr(), 11, plan)
+    lo._lib.call("mxlo_index_plan_destroy", plan)
+
+
 def test_extension_duplicates_last_write_wins(lo, dev):
     idx = np.array([2, 5, 2, 3, 5, 5], dtype=np.int64)
     u = np.arange(10.0, 70.0, 10.0)
@@ -425,6 +472,27 @@ def test_sorted_extension_and_range_kernels_bit_exact_edge_shapes(lo, dev, es):
                     assert np.array_equal(got, want), (fn, nres, nidx, off, use_pos)
                     guard = rbuf.cpu().numpy()
                     assert not guard[:off * words].any() and not guard[(off + nres) * words:].any(), "wrote outside res"
+                # round 5: the same index set as bit mask + ranks (mxlo_index_plan): extension, and the restriction back
+                import ctypes as C
+                plan = C.c_void_p()
+                ih = np.ascontiguousarray(idx, dtype=np.int64)
+                lo._lib.call("mxlo_index_plan_create", ctx.handle, ih.ctypes.data, nidx, nres, C.byref(plan))
+                try:
+                    rbuf, rd = dev_elems(np.full((nres, words), 0xDEADBEEF, dtype=np.uint32), off)
+                    lo._lib.call("mxlo_scatter_zero_plan", ctx.handle, es, ptr(rd), nres, ptr(ud), ptr(pos_d), plan)
+                    got = rd.cpu().numpy().view(np.uint32).reshape(nres, words)
+                    assert np.array_equal(got, want), ("plan extension", nres, nidx, off, use_pos)
+                    guard = rbuf.cpu().numpy()
+                    assert not guard[:off * words].any() and not guard[(off + nres) * words:].any(), "wrote outside res"
+                    vsrc = rand_elems(nres)
+                    _, vd2 = dev_elems(vsrc, off)                                       # v at both 16-byte phases
+                    gbuf, gd = dev_elems(np.full((max(nidx, 1), words), 0xDEADBEEF, dtype=np.uint32), 1 if es < 16 else 0)
+                    lo._lib.call("mxlo_gather_plan", ctx.handle, es, ptr(gd), ptr(vd2), nres, plan)
+                    gg = gd.cpu().numpy().view(np.uint32).reshape(-1, words)
+                    assert np.array_equal(gg[:nidx], vsrc[idx - 1]), ("plan restriction", nres, nidx, off)
+                    assert (gg[nidx:] == 0xDEADBEEF).all(), "wrote past the last selected element"
+                finally:
+                    lo._lib.call("mxlo_index_plan_destroy", plan)
     # ranges
     n = 100_003
     v = rand_elems(n)

@@ -149,6 +149,7 @@ struct Tune {
   int qn_persist_lds_pad = 0;   // ... bytes of (unused) dynamic LDS requested per workgroup: > 80 KiB forces one workgroup per CU
   int64_t qn_persist_min_bytes = 32ll << 20;     // ... and at least this many (an L-SR1 m = 5 apply at n = 2^19 — 21 MB — is
                                                  // faster in the single-launch slice form: 10.7 vs 12.1 us)
+  int gemvb_t_lds = 1;     // transposed block apply of a dense operator (k >= 4): U staged in LDS per workgroup (dense.hip)
   int combine_reverse = 0; // four-launch applies: the combine pass walks the vectors back to front. Measured (round 5,
                            // profiles/r05_bench_mid_apply.txt): -3.6 … +2.8 %, no gain on average — the grid-stride dots pass
                            // leaves no usable tail behind; the persistent launch (whose workgroups own contiguous runs) does

@@ -554,6 +554,116 @@ gemvb_t_kernel(T *__restrict__ res, int64_t ldr, const T *__restrict__ M, int64_
   }
 }
 
+// T mode, LDS-staged (round 5): gemvb_t_kernel above fetches every 16-byte piece of U from L1/L2 once per FOUR columns of
+// M — 2 vector-memory instructions on U per load of M at KB = 8, and the vector memory pipe, not HBM, sets the pace
+// (0.52 of peak at n = 16384, k = 8). Here a workgroup of 512 threads owns 32 columns of M (4 per wave) and walks the rows in chunks of
+// 128 vectors: the chunk of U (KB x 128 vectors, 16 KiB at KB = 8) is staged in LDS once per WORKGROUP (double-buffered:
+// the next chunk travels global -> registers while the current one is consumed), every wave reads it from there
+// (ds_read_b128: 4x the L1 rate), and the only vector-memory traffic of the inner loop is M itself, 16 loads in flight per
+// lane. U is re-read from L2 once per 32 columns of M (n/32 x |U| instead of n/4 x |U| through L1).
+// Preconditions (checked by the caller): M, U 16-byte aligned, ld and ldu multiples of the vector width.
+// kGemvbLdsBlock threads: 8 waves x 4 columns of M = 32 columns per workgroup (256 threads: 16 columns, for matrices with
+// fewer than one 32-column group per CU)
+template <typename T, typename CA, typename CB, bool BETA0, int KB, int kGemvbLdsBlock>
+__global__ void __launch_bounds__(kGemvbLdsBlock)
+gemvb_t_lds_kernel(T *__restrict__ res, int64_t ldr, const T *__restrict__ M, int64_t m, int64_t n, int64_t ld,
+                   const T *__restrict__ Um, int64_t ldu, CA alpha, CB beta) {
+  constexpr int VR = 16 / (int)sizeof(T);
+  constexpr int JB = 4, RCV = 128, NW = kGemvbLdsBlock / kWave;
+  typedef T VV __attribute__((ext_vector_type(VR)));
+  __shared__ VV ulds[2][KB][RCV];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t j0 = ((int64_t)blockIdx.x * NW + wave) * JB;
+  const int64_t mp = m / VR;                                   // whole vectors per column
+  const int64_t nchunks = (mp + RCV - 1) / RCV;
+  const T *colp[JB];
+#pragma unroll
+  for (int q = 0; q < JB; ++q) colp[q] = M + (j0 + q < n ? j0 + q : (j0 < n ? j0 : 0)) * ld;   // past the edge: a valid column, result dropped
+  double acc[JB][KB];
+#pragma unroll
+  for (int q = 0; q < JB; ++q)
+#pragma unroll
+    for (int c = 0; c < KB; ++c) acc[q][c] = 0.0;
+  constexpr int UL = KB * RCV / kGemvbLdsBlock;                        // staging loads per thread and chunk
+  VV ureg[UL];
+  auto stage_load = [&](int64_t ch) {                          // global -> registers (vectors past the end: zero)
+#pragma unroll
+    for (int k = 0; k < UL; ++k) {
+      const int idx = tid + k * kGemvbLdsBlock, c = idx / RCV, pv = idx % RCV;
+      const int64_t p = ch * RCV + pv;
+      VV z;
+#pragma unroll
+      for (int e = 0; e < VR; ++e) z[e] = T(0);
+      ureg[k] = p < mp ? *reinterpret_cast<const VV *>(Um + (int64_t)c * ldu + p * VR) : z;
+    }
+  };
+  auto stage_store = [&](int buf) {
+#pragma unroll
+    for (int k = 0; k < UL; ++k) {
+      const int idx = tid + k * kGemvbLdsBlock;
+      ulds[buf][idx / RCV][idx % RCV] = ureg[k];
+    }
+  };
+  if (nchunks > 0) {
+    stage_load(0);
+    stage_store(0);
+  }
+  __syncthreads();
+  for (int64_t ch = 0; ch < nchunks; ++ch) {
+    const int buf = (int)(ch & 1);
+    if (ch + 1 < nchunks) stage_load(ch + 1);                  // in flight while this chunk is consumed
+    VV a[2][JB];
+    const int64_t p0 = ch * RCV + lane, p1 = p0 + 64;
+    const int64_t q0 = p0 < mp ? p0 : mp - 1, q1 = p1 < mp ? p1 : mp - 1;   // clamped: the value is masked below
+#pragma unroll
+    for (int q = 0; q < JB; ++q) {
+      a[0][q] = __builtin_nontemporal_load(reinterpret_cast<const VV *>(colp[q]) + q0);
+      a[1][q] = __builtin_nontemporal_load(reinterpret_cast<const VV *>(colp[q]) + q1);
+    }
+    if (p1 >= mp) {                                            // only the last chunk: rows past the end contribute nothing
+#pragma unroll
+      for (int q = 0; q < JB; ++q)
+#pragma unroll
+        for (int e = 0; e < VR; ++e) {
+          if (p0 >= mp) a[0][q][e] = T(0);
+          a[1][q][e] = T(0);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < KB; ++c) {
+      const VV x0 = ulds[buf][c][lane], x1 = ulds[buf][c][lane + 64];
+#pragma unroll
+      for (int q = 0; q < JB; ++q)
+#pragma unroll
+        for (int e = 0; e < VR; ++e) {
+          acc[q][c] = fma((double)a[0][q][e], (double)x0[e], acc[q][c]);
+          acc[q][c] = fma((double)a[1][q][e], (double)x1[e], acc[q][c]);
+        }
+    }
+    if (ch + 1 < nchunks) stage_store(buf ^ 1);
+    __syncthreads();
+  }
+  for (int64_t r = mp * VR + lane; r < m; r += 64) {           // rows past the last whole vector
+#pragma unroll
+    for (int c = 0; c < KB; ++c) {
+      const double x = (double)Um[(int64_t)c * ldu + r];
+#pragma unroll
+      for (int q = 0; q < JB; ++q) acc[q][c] = fma((double)colp[q][r], x, acc[q][c]);
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < JB; ++q) {
+#pragma unroll
+    for (int c = 0; c < KB; ++c) {
+      const double v = wave_allsum(acc[q][c]);
+      if (lane == 0 && j0 + q < n) {
+        T *o = res + (j0 + q) + (int64_t)c * ldr;
+        *o = fin_ab<T, CA, CB, BETA0>(alpha * (CA)(T)v, beta, BETA0 ? T(0) : *o);
+      }
+    }
+  }
+}
+
 inline int32_t ensure_scratch(mxlo_ctx *ctx, size_t need, const char *what) {
   if (ctx->scratch_bytes < need) {            // stream-ordered users only: drain before the buffer is replaced
     if (ctx->scratch) {
@@ -610,7 +720,21 @@ int32_t gemv_block_chunk(mxlo_ctx *ctx, T *res, int64_t ldr, const T *M, int64_t
   constexpr int VR = 16 / (int)sizeof(T);
   const bool pair = m >= VR && (((uintptr_t)M & 15u) == 0) && (ld % VR == 0) && (((uintptr_t)V & 15u) == 0) &&
                     (ldv % VR == 0);
+  // >= 4 columns of U on a matrix tall enough for a few row chunks: the LDS-staged form (32 columns of M per workgroup)
+  const bool lds_form = pair && KB >= 4 && m >= 4 * 128 * VR && ctx->tune.gemvb_t_lds;
   return dispatch_ab<T>(beta, flags, [&]<typename CA, typename CB, bool B0>() -> int32_t {
+    if constexpr (KB >= 4) {
+      if (lds_form) {
+        if ((n + 31) / 32 >= ctx->num_cu)
+          hipLaunchKernelGGL((gemvb_t_lds_kernel<T, CA, CB, B0, KB, 512>), dim3((unsigned)((n + 31) / 32)), dim3(512), 0, ctx->stream,
+                             res, ldr, M, m, n, ld, V, ldv, (CA)alpha, (CB)beta);
+        else
+          hipLaunchKernelGGL((gemvb_t_lds_kernel<T, CA, CB, B0, KB, 256>), dim3((unsigned)((n + 15) / 16)), dim3(256), 0, ctx->stream,
+                             res, ldr, M, m, n, ld, V, ldv, (CA)alpha, (CB)beta);
+        MXLO_LAUNCH_CHECK();
+        return MXLO_OK;
+      }
+    }
     if (pair)
       hipLaunchKernelGGL((gemvb_t_kernel<T, CA, CB, B0, KB, true>), dim3((unsigned)blocks), dim3(kBlock), 0, ctx->stream,
                          res, ldr, M, m, n, ld, V, ldv, (CA)alpha, (CB)beta);

@@ -149,6 +149,10 @@ struct Tune {
   int qn_persist_lds_pad = 0;   // ... bytes of (unused) dynamic LDS requested per workgroup: > 80 KiB forces one workgroup per CU
   int64_t qn_persist_min_bytes = 32ll << 20;     // ... and at least this many (an L-SR1 m = 5 apply at n = 2^19 — 21 MB — is
                                                  // faster in the single-launch slice form: 10.7 vs 12.1 us)
+  int herm_single = 1;     // opHermitian (full row groups, aligned A, n <= herm_single_max_n): strips and finishers in ONE launch
+  int64_t herm_single_max_n = 2048;   // measured (profiles/r05_herm_small.txt): 8.9 -> 6.4 us at n = 1024, 9.6 -> 6.9 at 2048 (f64; f32
+                                      // alike); NO gain at 4096 (17.8 vs 18.4 f64, 12.4 vs 10.8 f32) and 8192: there the strips' own
+                                      // load -> butterfly -> store chain sets the time, not the finish launch
   int gemvb_t_lds = 1;     // transposed block apply of a dense operator (k >= 4): U staged in LDS per workgroup (dense.hip)
   int combine_reverse = 0; // four-launch applies: the combine pass walks the vectors back to front. Measured (round 5,
                            // profiles/r05_bench_mid_apply.txt): -3.6 … +2.8 %, no gain on average — the grid-stride dots pass
@@ -183,6 +187,10 @@ struct mxlo_ctx {
   int wall_clock_khz = 100000;           // rate of wall_clock64() on this device (hipDeviceAttributeWallClockRate)
   mxlo_allreduce_fn allreduce = nullptr;
   void *allreduce_user = nullptr;
+  double *herm_slots = nullptr;   // self-validating partial slots of the single-launch opHermitian (all empty between applies)
+  size_t herm_slots_bytes = 0;
+  int64_t herm_slots_layout = 0;  // (n, strip shape) the slots were last used with
+  bool herm_slots_dirty = false;  // a timed-out apply left slots filled: re-arm before the next use
   void *scratch = nullptr;     // grow-on-demand workspace (opHermitian tile partials); owned by the ctx
   size_t scratch_bytes = 0;
   hipStream_t own_stream = nullptr;  // created by mxlo_ctx_create_stream, destroyed with the ctx
@@ -221,7 +229,7 @@ struct DeviceGuard {
 // the kernel ENDS with NaN results instead of hanging the GPU. The host looks at the word (a plain read of pinned
 // memory, no synchronisation) before every single-launch apply and inside mxlo_ctx_sync: fused_fault_check() then
 // re-arms the slots, switches the single-launch forms of the ctx off and returns MXLO_EHIP naming what happened.
-constexpr unsigned kFaultHouseholder = 1u, kFaultQn = 2u;
+constexpr unsigned kFaultHouseholder = 1u, kFaultQn = 2u, kFaultHermitian = 4u;
 constexpr unsigned long long kCanonicalNaN = 0x7FF8000000000000ull;
 int32_t fused_fault_check(mxlo_ctx *ctx);           // api_ctx.hip
 inline unsigned long long fused_timeout_ticks(const mxlo_ctx *ctx) {   // wall_clock64() ticks: the device's constant-rate clock

@@ -824,7 +824,19 @@ __host__ __device__ __forceinline__ int64_t herm_col_base(int64_t Gc, int64_t ng
 //                 unmasked 16-byte loads (every address is inside the matrix), then elements at or above the diagonal
 //                 are replaced by zero with a select (whatever the caller keeps up there, NaN included, never enters
 //                 a product). Register footprint of the unmasked path, so these tiles ride in the interior launch.
-template <typename T, int C, bool EDGE, bool DSEL = false>
+// SLOT: the partials are handed to finisher workgroups of the SAME launch (herm_single_kernel): self-validating 64-bit
+// agent-scope stores (an empty slot is a NaN payload no arithmetic produces; NaN partials are canonicalised), no fence.
+__device__ __forceinline__ void herm_put(double *p, double v, bool slot) {
+  if (slot) {
+    unsigned long long bits = (unsigned long long)__double_as_longlong(v);
+    if (v != v) bits = kCanonicalNaN;
+    __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  } else {
+    *p = v;
+  }
+}
+
+template <typename T, int C, bool EDGE, bool DSEL = false, bool SLOT = false>
 __device__ __forceinline__ void
 herm_strip_body(const T *__restrict__ A, int64_t lda, const T *__restrict__ v, int64_t n,
                 double *__restrict__ Prow, double *__restrict__ Pcol, int64_t ng, int qint, int mode, int64_t t) {
@@ -945,7 +957,7 @@ herm_strip_body(const T *__restrict__ A, int64_t lda, const T *__restrict__ v, i
     if ((lane & 3) == 0) {
       const int k = ((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1);
       const int64_t gc = j0 + cg + 2 * k;
-      if (!EDGE || gc < n) Pcol[pcol0 + gc] = w1;
+      if (!EDGE || gc < n) herm_put(Pcol + pcol0 + gc, w1, SLOT);
     }
   }
   __shared__ double rowred[2][HR];
@@ -954,7 +966,7 @@ herm_strip_body(const T *__restrict__ A, int64_t lda, const T *__restrict__ v, i
   __syncthreads();
   for (int tt = tid; tt < HR; tt += kBlock) {
     const int64_t row = i0 + tt;
-    if (row < n) Prow[herm_row_base<HR, DT>(G, qint) + slot * HR + tt] = rowred[0][tt] + rowred[1][tt];
+    if (row < n) herm_put(Prow + herm_row_base<HR, DT>(G, qint) + slot * HR + tt, rowred[0][tt] + rowred[1][tt], SLOT);
   }
 }
 
@@ -988,17 +1000,20 @@ herm_edge_kernel(const T *__restrict__ A, int64_t lda, const T *__restrict__ v, 
 
 // 32 rows per workgroup, 8 lanes per row: lane `sub` adds partials sub, sub+8, ... (independent loads in
 // flight), the 8 sub-sums are combined in a fixed order -> deterministic, and n/32 workgroups fill the chip.
-template <typename T, typename CA, typename CB, bool BETA0, int FR>
-__global__ void __launch_bounds__(kBlock)
-herm_finish_kernel(T *__restrict__ res, const T *__restrict__ d, const T *__restrict__ v,
-                   const double *__restrict__ Prow, const double *__restrict__ Pcol, int64_t n, int ng,
-                   int q, CA alpha, CB beta) {
+// POLL (herm_single_kernel): the partials are slots written by strip workgroups of the SAME launch — each slot is read by
+// exactly one lane, which waits for it (bounded, poll_slot) and then re-arms it for the next apply. Same order of
+// additions as the separate finish launch: the two forms are bit-identical.
+template <typename T, typename CA, typename CB, bool BETA0, int FR, bool POLL>
+__device__ __forceinline__ void
+herm_finish_body(T *__restrict__ res, const T *__restrict__ d, const T *__restrict__ v, double *__restrict__ Prow,
+                 double *__restrict__ Pcol, int64_t n, int ng, int q, CA alpha, CB beta, int64_t blk,
+                 unsigned long long ticks, unsigned *__restrict__ fault) {
   // FR rows per workgroup, 256/FR lanes per row; a lane's partials (sub, sub+FS, ...) are loaded 8 (4) at a time with
   // nothing between the loads, and the finishing lane's d, v (res) are requested before them: the kernel is pure
   // latency (3 MB of partials at n = 4096) — ~2.3 us of its own plus the ~2.2 us every dependent launch costs.
   constexpr int FS = kBlock / FR;
   const int r = threadIdx.x % FR, sub = threadIdx.x / FR;
-  const int64_t i = (int64_t)blockIdx.x * FR + r;
+  const int64_t i = blk * FR + r;
   __shared__ double s1[FS][FR], s2[FS][FR];
   double t1 = 0.0, t2 = 0.0;
   T di = T(0), vi = T(0), ri = T(0);           // the finishing lane's operands, requested before the partials
@@ -1007,21 +1022,61 @@ herm_finish_kernel(T *__restrict__ res, const T *__restrict__ d, const T *__rest
     vi = v[i];
     if constexpr (!BETA0) ri = res[i];
   }
+  auto take = [&](double *p) -> double {       // POLL: first look (all of a batch in flight), the wait happens in settle()
+    if constexpr (POLL) return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<unsigned long long *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    else return *p;
+  };
+  auto settle = [&](double *p, double x) -> double {
+    if constexpr (POLL) {
+      unsigned long long bits = (unsigned long long)__double_as_longlong(x);
+      if (bits == kSlotEmpty) bits = poll_slot(reinterpret_cast<unsigned long long *>(p), ticks, fault, kFaultHermitian);
+      __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), kSlotEmpty, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm
+      return __longlong_as_double((long long)bits);
+    } else {
+      return x;
+    }
+  };
+  if constexpr (POLL) {
+    // Before the general sweep: two lanes per row wait — with long sleeps, so that 128 waiting workgroups do not load the
+    // memory system the strips are streaming through — for the two partials that are produced LAST for this row: the row
+    // partial of the last tile of its diagonal block and the column partial from the last row half of the matrix (the
+    // diagonal tiles are the highest-numbered strip workgroups, the last row group's the highest of those).
+    if (i < n && sub < 2) {
+      constexpr int HR = HermCfg<T>::HR, DT = HermCfg<T>::DT;
+      const int G = (int)(i / HR);
+      const double *w = sub == 0 ? Prow + herm_row_base<HR, DT>(G, q) + (i - (int64_t)G * HR) + (int64_t)(q * G + DT - 1) * HR
+                                 : Pcol + herm_col_base<HR>(G, ng) + (i - (int64_t)G * HR) + (int64_t)(2 * ng - 1 - 2 * G) * HR;
+      unsigned long long t0 = 0;
+      unsigned it = 0;
+      while (__hip_atomic_load(reinterpret_cast<const unsigned long long *>(w), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == kSlotEmpty) {
+        __builtin_amdgcn_s_sleep(32);
+        if ((++it & 63u) == 0) {                // bounded like poll_slot; the sweep below reports the fault
+          const unsigned long long now = (unsigned long long)wall_clock64();
+          if (t0 == 0) t0 = now;
+          else if (now - t0 > ticks) break;
+        }
+      }
+    }
+    __syncthreads();
+  }
   if (i < n) {
     constexpr int HR = HermCfg<T>::HR, DT = HermCfg<T>::DT;
     const int G = (int)(i / HR);
     const int c1 = q * G + DT;                 // L*v : q*G strips + DT diagonal tiles
-    const double *prow = Prow + herm_row_base<HR, DT>(G, q) + (i - (int64_t)G * HR);
-    const double *pcol = Pcol + herm_col_base<HR>(G, ng) + (i - (int64_t)G * HR);
+    double *prow = Prow + herm_row_base<HR, DT>(G, q) + (i - (int64_t)G * HR);
+    double *pcol = Pcol + herm_col_base<HR>(G, ng) + (i - (int64_t)G * HR);
     for (int base = sub; base < c1; base += FS * 8) {
       double x[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         const int sx = base + FS * u;
-        x[u] = sx < c1 ? prow[(int64_t)sx * HR] : 0.0;
+        x[u] = sx < c1 ? take(prow + (int64_t)sx * HR) : 0.0;
       }
 #pragma unroll
-      for (int u = 0; u < 8; ++u) t1 += x[u];
+      for (int u = 0; u < 8; ++u) {
+        const int sx = base + FS * u;
+        t1 += sx < c1 ? settle(prow + (int64_t)sx * HR, x[u]) : 0.0;
+      }
     }
     const int h1 = 2 * ng;                     // L'*v: 128-row halves at/below i
     for (int base = 2 * G + sub; base < h1; base += FS * 4) {
@@ -1029,10 +1084,13 @@ herm_finish_kernel(T *__restrict__ res, const T *__restrict__ d, const T *__rest
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int h = base + FS * u;
-        x[u] = h < h1 ? pcol[(int64_t)(h - 2 * G) * HR] : 0.0;
+        x[u] = h < h1 ? take(pcol + (int64_t)(h - 2 * G) * HR) : 0.0;
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) t2 += x[u];
+      for (int u = 0; u < 4; ++u) {
+        const int h = base + FS * u;
+        t2 += h < h1 ? settle(pcol + (int64_t)(h - 2 * G) * HR, x[u]) : 0.0;
+      }
     }
   }
   s1[sub][r] = t1;
@@ -1050,6 +1108,35 @@ herm_finish_kernel(T *__restrict__ res, const T *__restrict__ d, const T *__rest
   }
 }
 
+template <typename T, typename CA, typename CB, bool BETA0, int FR>
+__global__ void __launch_bounds__(kBlock)
+herm_finish_kernel(T *__restrict__ res, const T *__restrict__ d, const T *__restrict__ v,
+                   double *__restrict__ Prow, double *__restrict__ Pcol, int64_t n, int ng,
+                   int q, CA alpha, CB beta) {
+  herm_finish_body<T, CA, CB, BETA0, FR, false>(res, d, v, Prow, Pcol, n, ng, q, alpha, beta, (int64_t)blockIdx.x, 0ull, nullptr);
+}
+
+// The WHOLE apply in one launch (round 5; n a multiple of the row-group height, aligned A, n <= herm_single_max_n):
+// workgroups [0, n_int) interior strips, [n_int, n_light) diagonal tiles, [n_light, n_light + n/FR) FINISHERS. A finisher
+// is dispatched after every strip workgroup (in-order dispatch of a 1-D grid), waits for exactly the slots its rows
+// need and re-arms them; the dependent finish launch (~2.2 us of launch + 2.3 us of latency at n = 4096, of 17.8 us) and
+// the fences / tickets of the forms tried in rounds 2-3 are gone: store -> load through the self-validating slots is all
+// that connects producer and consumer.
+template <typename T, int C, typename CA, typename CB, bool BETA0, int FR>
+__global__ void __launch_bounds__(kBlock)
+herm_single_kernel(T *__restrict__ res, const T *__restrict__ d, const T *__restrict__ A, int64_t lda, const T *__restrict__ v,
+                   int64_t n, double *__restrict__ Prow, double *__restrict__ Pcol, int64_t ng, int qint, int64_t n_int,
+                   int64_t n_light, CA alpha, CB beta, unsigned long long ticks, unsigned *__restrict__ fault) {
+  const int64_t t = blockIdx.x;
+  if (t < n_int) return herm_strip_body<T, C, false, false, true>(A, lda, v, n, Prow, Pcol, ng, qint, 0, t);
+  if (t < n_light) return herm_strip_body<T, 1, false, true, true>(A, lda, v, n, Prow, Pcol, ng, qint, 2, t - n_int);
+  herm_finish_body<T, CA, CB, BETA0, FR, true>(res, d, v, Prow, Pcol, n, (int)ng, qint, alpha, beta, t - n_light, ticks, fault);
+}
+
+__global__ void __launch_bounds__(kBlock) herm_slots_fill_kernel(unsigned long long *__restrict__ p, int64_t count) {
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < count; i += (int64_t)gridDim.x * kBlock) p[i] = kSlotEmpty;
+}
+
 template <typename T>
 int32_t hermitian_t(mxlo_ctx *ctx, T *res, const T *d, const T *A, int64_t lda, const T *v, int64_t n,
                     double alpha, double beta, int32_t flags) {
@@ -1062,6 +1149,51 @@ int32_t hermitian_t(mxlo_ctx *ctx, T *res, const T *d, const T *A, int64_t lda, 
   const int C = (DT / 8) * pairs >= 2 * ctx->num_cu ? 8 : ((DT / 2) * pairs >= 2 * ctx->num_cu ? 2 : 1), Q = DT / C;
   const int64_t prow_len = herm_row_base<HR, DT>(ng, Q), pcol_len = herm_col_base<HR>(ng, ng);
   const size_t need = sizeof(double) * (size_t)(prow_len + pcol_len);
+  const bool aligned = (((uintptr_t)A & 15u) == 0) && (lda % RPL == 0);
+  // ---- the whole apply in ONE launch: full row groups of an aligned matrix, slots in their own (always re-armed) buffer
+  if (ctx->tune.herm_single && aligned && n % HR == 0 && n <= ctx->tune.herm_single_max_n && ctx->fault_dev && !ctx->capturing) {
+    int32_t fst = fused_fault_check(ctx);
+    if (fst != MXLO_OK) return fst;
+    if (ctx->tune.herm_single) {              // (the fault check switches the single-launch forms off)
+      if (ctx->herm_slots_bytes < need || ctx->herm_slots_layout != (int64_t)n * 64 + C * 2 + (sizeof(T) == 8 ? 1 : 0) || ctx->herm_slots_dirty) {
+        if (ctx->herm_slots_bytes < need) {
+          if (ctx->herm_slots) {
+            MXLO_HIP(hipStreamSynchronize(ctx->stream));
+            MXLO_HIP(hipFree(ctx->herm_slots));
+          }
+          ctx->herm_slots = nullptr;
+          ctx->herm_slots_bytes = 0;
+          hipError_t e = hipMalloc((void **)&ctx->herm_slots, need);
+          MXLO_REQUIRE(e == hipSuccess, MXLO_ENOMEM, "opHermitian slots: %s", hipGetErrorString(e));
+          ctx->herm_slots_bytes = need;
+        }
+        // every slot empty: a new buffer, another (n, strip shape) than the last apply used (the slots an apply fills and
+        // the slots its finishers re-arm are the same set only for one layout), or after a timed-out apply
+        hipLaunchKernelGGL(herm_slots_fill_kernel, dim3(ctx->num_cu * 4), dim3(kBlock), 0, ctx->stream,
+                           (unsigned long long *)ctx->herm_slots, (int64_t)(ctx->herm_slots_bytes / 8));
+        MXLO_LAUNCH_CHECK();
+        ctx->herm_slots_layout = (int64_t)n * 64 + C * 2 + (sizeof(T) == 8 ? 1 : 0);
+        ctx->herm_slots_dirty = false;
+      }
+      double *Sr = ctx->herm_slots, *Sc = Sr + prow_len;
+      const int64_t n_int1 = ngf > 1 ? Q * ngf * (ngf - 1) / 2 : 0, n_light1 = n_int1 + (int64_t)DT * ngf;
+      constexpr int FR1 = 32;
+      const int64_t grid1 = n_light1 + (n + FR1 - 1) / FR1;
+      bool fits = true;
+      const int32_t st1 = dispatch_ab<T>(beta, flags, [&]<typename CA, typename CB, bool B0>() -> int32_t {
+        auto go = [&]<int C_>() -> int32_t {
+          // (no co-residency requirement: the strip workgroups wait for nobody, and the finishers — the last workgroups of the
+          //  1-D grid — are dispatched after all of them)
+          hipLaunchKernelGGL((herm_single_kernel<T, C_, CA, CB, B0, FR1>), dim3((unsigned)grid1), dim3(kBlock), 0, ctx->stream, res, d, A,
+                             lda, v, n, Sr, Sc, ng, Q, n_int1, n_light1, (CA)alpha, (CB)beta, fused_timeout_ticks(ctx), ctx->fault_dev);
+          MXLO_LAUNCH_CHECK();
+          return MXLO_OK;
+        };
+        return C == 8 ? go.template operator()<8>() : (C == 2 ? go.template operator()<2>() : go.template operator()<1>());
+      });
+      if (st1 != MXLO_OK || fits) return st1;
+    }
+  }
   if (ctx->scratch_bytes < need) {            // stream-ordered users only: drain before the buffer is replaced
     if (ctx->scratch) {
       MXLO_HIP(hipStreamSynchronize(ctx->stream));
@@ -1076,7 +1208,6 @@ int32_t hermitian_t(mxlo_ctx *ctx, T *res, const T *d, const T *A, int64_t lda, 
   }
   if (ctx->capturing) ctx->scratch_used_in_capture = true;
   double *Prow = (double *)ctx->scratch, *Pcol = Prow + prow_len;
-  const bool aligned = (((uintptr_t)A & 15u) == 0) && (lda % RPL == 0);
   // full row groups (aligned A): interior strips + diagonal tiles in the unmasked launch; everything else is masked
   const int64_t gi = aligned ? ngf : 0;
   const int64_t n_int = gi > 1 ? Q * gi * (gi - 1) / 2 : 0;

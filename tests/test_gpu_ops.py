@@ -106,6 +106,63 @@ def test_hermitian_strip_regimes(lo, dev, dtype, n):
     assert torch.equal(res2, res3)
 
 
+def test_hermitian_single_launch_is_bit_identical_to_the_two_launch_form(lo, dev):
+    """Round 5: for full row groups of an aligned matrix (n a multiple of 256 / 512, n <= 8192)
+    opHermitian is ONE launch — strip workgroups publish their partials as self-validating slots, finisher workgroups of
+    the same launch wait for exactly the slots their rows need, add them in the order of the separate finish launch and
+    re-arm them. Bit-identical to the two-launch form (`herm_single` = 0) and to itself from run to run, across changes of
+    n, element type and strip shape between applies (the slot layout changes: re-arm), NaN above the diagonal, alpha / beta
+    forms, 200 back-to-back applies — and against the oracle (src/linalg.jl:97-103)."""
+    from linearoperators_jl_amd.device import get_ctx
+    ctx = get_ctx(dev)
+    rng = np.random.default_rng(4)
+    cases = [(torch.float64, 256), (torch.float64, 4096), (torch.float32, 4096), (torch.float64, 1024), (torch.float64, 8192),
+             (torch.float32, 1024), (torch.float64, 4096), (torch.float64, 2048 + 256)]
+    ops = {}
+
+    def launches():
+        import ctypes as C
+        a = (C.c_int64 * 12)()
+        lo._lib.call("mxlo_debug_counters", a)
+        return a[10]
+
+    ctx.tune("herm_single_max_n", 8192)                           # (the default stops at 2048: no gain above, see common.h)
+    for dtype, n in cases:
+        npd = NP[dtype]
+        if (dtype, n) not in ops:
+            A = rng.standard_normal((n, n)).astype(npd)
+            A[np.triu_indices(n)] = np.nan                        # never read
+            d, v, r0 = (rng.standard_normal(n).astype(npd) for _ in range(3))
+            ops[(dtype, n)] = (lo.opHermitian(T(d, dev), TM(A, dev)), A, d, v, r0)
+        H, A, d, v, r0 = ops[(dtype, n)]
+        got = {}
+        for single in (1, 0, 1):
+            ctx.tune("herm_single", single)
+            try:
+                res = T(r0.copy(), dev)
+                l0 = launches()
+                lo.mul(res, H, T(v, dev), 3.0, -4.0)
+                nl = launches() - l0
+                assert (nl <= 2) if single else (nl == 2), (dtype, n, single, nl)   # 1, or 2 when the slots were re-armed for a new layout
+                got.setdefault(single, []).append(res.cpu().numpy())
+            finally:
+                ctx.tune("herm_single", 1)
+        assert np.array_equal(got[1][0], got[0][0]) and np.array_equal(got[1][0], got[1][1]), (dtype, n)
+        fl = oracle.SCALARS_F64 if dtype == torch.float32 else 0
+        want = oracle.hermitian_mul(r0.copy(), d, np.tril(A, -1), v, 3.0, -4.0, flags=fl)
+        assert rel(got[1][0], want) <= (1e-12 if dtype == torch.float64 else 3e-5), (dtype, n)
+    H, A, d, v, r0 = ops[(torch.float64, 4096)]
+    vt, res = T(v, dev), torch.empty(4096, dtype=torch.float64, device=dev)
+    lo.mul(res, H, vt, 1.0, 0.0)
+    first = res.clone()
+    l0 = launches()
+    for _ in range(200):
+        lo.mul(res, H, vt, 1.0, 0.0)
+    assert launches() - l0 == 200                                  # ONE launch per apply
+    assert torch.equal(res, first)
+    ctx.tune("herm_single_max_n", 2048)
+
+
 @pytest.mark.parametrize("dtype", [torch.float64, torch.float32, torch.complex128, torch.complex64])
 @pytest.mark.parametrize("n", [7, 256, 300, 1024, 2051])
 def test_hermitian_reads_strict_lower_triangle_only(lo, dev, dtype, n):

@@ -1092,6 +1092,7 @@ def test_persistent_apply_timeout_is_an_error_not_a_hang(lo, dev):
         ctx.tune("house_fused", 1)
         ctx.tune("qn_fused_small", 1)
         ctx.tune("qn_persist", 1)
+        ctx.tune("herm_single", 1)
 
 
 @pytest.mark.parametrize("kind", ["inv", "fwd", "lsr1"])

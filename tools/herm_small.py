@@ -16,6 +16,9 @@ ctx = get_ctx(dev)
 tm = Timer(ctx)
 dt = torch.float32 if "f32" in sys.argv[1:] else torch.float64
 es = 4 if dt == torch.float32 else 8
+if os.environ.get("MXLO_HERM_SINGLE") is not None:
+    ctx.tune("herm_single", int(os.environ["MXLO_HERM_SINGLE"]))
+    print(f"# herm_single = {os.environ['MXLO_HERM_SINGLE']}")
 for nn in (1024, 2048, 4096, 8192, 16384):
     M = torch.rand(nn, nn, dtype=dt, device=dev).t()
     d, x, y = (torch.rand(nn, dtype=dt, device=dev) for _ in range(3))

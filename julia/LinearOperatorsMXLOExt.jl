@@ -396,16 +396,29 @@ struct ScatterPlan            # duplicates: `res[I] = u` is sequential, the LAST
   idx::MXVector{Int64}        # strictly increasing target indices (scatter)
   pos::Union{MXVector{Int64}, Nothing}   # 0-based position in u of the surviving write; nothing = identity
   n::Int
+  hidx::Vector{Int64}         # the strictly increasing indices on the host (what an index plan is built from)
+  masks::Dict{Int, Ptr{Cvoid}}   # length of the long vector => mxlo_index_plan (bit mask + ranks), built on first use
 end
 function ScatterPlan(I::AbstractVector{<:Integer})
   didx = MXVector(collect(Int64, I))
-  (issorted(I) && allunique(I)) && return ScatterPlan(didx, didx, nothing, length(I))
+  (issorted(I) && allunique(I)) && return ScatterPlan(didx, didx, nothing, length(I), collect(Int64, I), Dict{Int, Ptr{Cvoid}}())
   last = Dict{Int64, Int64}()
   for (k, i) in enumerate(I)
     last[i] = k - 1                                   # 0-based source position of the surviving write
   end
   ks = sort!(collect(keys(last)))
-  ScatterPlan(didx, MXVector(ks), MXVector([last[i] for i in ks]), length(ks))
+  ScatterPlan(didx, MXVector(ks), MXVector([last[i] for i in ks]), length(ks), ks, Dict{Int, Ptr{Cvoid}}())
+end
+# A dense enough strictly increasing index set is applied as bit mask + ranks (include/mxlo.h "index plans"): neither
+# mulRestrict! nor multRestrict! then reads the index list. Built once per (I, length of the long vector); C_NULL below
+# the density where the list is the smaller description (1/32).
+function mask_plan(pl::ScatterPlan, n::Int)
+  (pl.n > 0 && 32 * pl.n >= n) || return C_NULL
+  get!(pl.masks, n) do
+    h = Ref{Ptr{Cvoid}}()
+    check(ccall((:mxlo_index_plan_create, lib), Int32, (P, Ptr{Int64}, Int64, Int64, Ptr{P}), ctx(), pl.hidx, Int64(pl.n), Int64(n), h))
+    h[]
+  end
 end
 const PLANS = IdDict{Any, ScatterPlan}()
 plan(I::Vector{<:Integer}) = get!(() -> ScatterPlan(I), PLANS, I)
@@ -418,11 +431,17 @@ multRestrict!(res::MXVector, Idx::RangeIdx, u::MXVector, α, β) =
               Int32(sizeof(eltype(u))), res.ptr, length(res), u.ptr, Int64(first(Idx)), Int64(step(Idx)), Int64(length(Idx))))
 function mulRestrict!(res::MXVector, Idx::Vector{<:Integer}, v::MXVector, α, β)
   pl = plan(Idx)
+  mp = (pl.pos === nothing && 8 * pl.n >= length(v)) ? mask_plan(pl, length(v)) : C_NULL   # increasing I, >= 1/8 density
+  mp == C_NULL || return check(ccall((:mxlo_gather_plan, lib), Int32, (P, Int32, P, P, Int64, P), ctx(), Int32(sizeof(eltype(v))),
+                                     res.ptr, v.ptr, length(v), mp))
   check(ccall((:mxlo_gather, lib), Int32, (P, Int32, P, P, Int64, P, Int64), ctx(), Int32(sizeof(eltype(v))), res.ptr,
               v.ptr, length(v), pl.didx.ptr, length(pl.didx)))
 end
 function multRestrict!(res::MXVector, Idx::Vector{<:Integer}, u::MXVector, α, β)
   pl = plan(Idx)
+  mp = mask_plan(pl, length(res))
+  mp == C_NULL || return check(ccall((:mxlo_scatter_zero_plan, lib), Int32, (P, Int32, P, Int64, P, P, P), ctx(), Int32(sizeof(eltype(u))),
+                                     res.ptr, length(res), u.ptr, pl.pos === nothing ? C_NULL : pl.pos.ptr, mp))
   check(ccall((:mxlo_scatter_zero_sorted, lib), Int32, (P, Int32, P, Int64, P, P, P, Int64), ctx(), Int32(sizeof(eltype(u))),
               res.ptr, length(res), u.ptr, pl.idx.ptr, pl.pos === nothing ? C_NULL : pl.pos.ptr, pl.n))
 end
@@ -475,7 +494,9 @@ end
 (f::SparseApply{T})(res::MXMatrix{T}, V::MXMatrix{T}, α, β) where {T <: RealT} = check(ccall((:mxlo_csc_mul_block, lib), Int32,
     (P, P, Int64, P, Int64, Int64, Float64, Float64, Int32, Int32),
     f.A.h, res.data.ptr, res.m, V.data.ptr, V.m, size(V, 2), α, β, f.mode, flags(T, α, β)))
-function apply_columns(f::SparseApply{T}, res::MXMatrix{T}, m::MXMatrix{T}, α, β) where {T}     # one call for the block
+# (real element types only: mxlo_csc_mul_block refuses complex handles, and SparseApply has no matrix call method for
+#  T <: CplxT — a complex sparse operator falls through to the generic column-by-column apply_columns, like the Python mirror)
+function apply_columns(f::SparseApply{T}, res::MXMatrix{T}, m::MXMatrix{T}, α, β) where {T <: RealT}     # one call for the block
   size(res, 2) == size(m, 2) || throw(LinearOperatorException("shape mismatch"))
   f(res, m, α, β)
   res
@@ -790,12 +811,28 @@ mutable struct ShardCtx
   h::Ptr{Cvoid}
   ndev::Int
 end
-function ShardCtx(devs::Vector{<:Integer})
+# transport of the scalar all-reduce (include/mxlo_rccl.h): :auto (RCCL for distinct devices, loopback for repeated ids),
+# :rccl, :loopback, :peer (the peer-mapped one-shot exchange: mailboxes in fine-grained device memory, one kernel per
+# collective, no RCCL call)
+const SHARD_TRANSPORT = Dict(:auto => Int32(0), :rccl => Int32(1), :loopback => Int32(2), :peer => Int32(3))
+function ShardCtx(devs::Vector{<:Integer}; transport::Symbol = :auto)
   r = Ref{Ptr{Cvoid}}()
   ids = collect(Int32, devs)
-  st = ccall((:mxlo_shard_ctx_create, rccl), Int32, (Int32, Ptr{Int32}, Ptr{P}), length(ids), ids, r)
+  st = ccall((:mxlo_shard_ctx_create_ex, rccl), Int32, (Int32, Ptr{Int32}, Int32, Ptr{P}), length(ids), ids, SHARD_TRANSPORT[transport], r)
   st == 0 || error(unsafe_string(ccall((:mxlo_shard_last_error, rccl), Cstring, ())))
   finalizer(s -> ccall((:mxlo_shard_ctx_destroy, rccl), Int32, (P,), s.h), ShardCtx(r[], length(ids)))
+end
+"""
+    preflight(sc; reps = 50, timeout_ms = 60_000) -> (latency_us_8B, latency_us_320B, latency_us_6912B)
+
+Collective over all shards, BEFORE any production collective: known-answer and identical-bits all-reduces of the three
+payload sizes of the hot path through the transport the `_sharded` entry points use, an agreed verdict, and the latency of
+back-to-back all-reduces. Throws (naming shard, payload and phase) instead of hanging when a device does not answer.
+"""
+function preflight(sc::ShardCtx; reps::Integer = 50, timeout_ms::Integer = 60_000)
+  lat = zeros(Float64, 3)
+  scheck(ccall((:mxlo_shard_ctx_preflight, rccl), Int32, (P, Int32, Int32, Ptr{Float64}), sc.h, Int32(reps), Int32(timeout_ms), lat))
+  (lat[1], lat[2], lat[3])
 end
 shard_ctx(sc::ShardCtx, i::Integer) = ccall((:mxlo_shard_ctx_get, rccl), P, (P, Int32), sc.h, i)   # for mxlo_malloc / memcpy
 shard_sync(sc::ShardCtx) = check(ccall((:mxlo_shard_ctx_sync, rccl), Int32, (P,), sc.h))

@@ -98,37 +98,20 @@ end
   @test dc[11] >= 20                                                                          # launches only
 end
 
-# ---- 1:1 mirror of the reference's only device tests: test/gpu/test_S_kwarg.jl:3-45 with arrayType = the extension's
-# device types, and test/gpu/amdgpu.jl:4-20 (BlockDiagonalOperator of three plain device matrices, storage_type of the
-# lazy wrappers). Same assertions, same order; `arrayType(rand(Float32, 32, 32))` is MXMatrix, `arrayType(rand(Float32, 32))`
-# is MXVector.
-function test_S_kwarg_mxlo()
-  mat = MXMatrix(rand(Float32, 32, 32))
-  vec = MXVector(rand(Float32, 32))
-  vecT = typeof(vec)
-  vecTother = typeof(MXVector(rand(Float32, 32)))
-  @testset "S Kwarg with arrayType MXVector / MXMatrix" begin
-    @test vecT == LinearOperators.storage_type(mat)
-    # constructors.jl
-    @test LinearOperators.storage_type(LinearOperator(mat)) == LinearOperators.storage_type(mat) # default
-    @test LinearOperators.storage_type(LinearOperator(mat; S = vecTother)) == vecTother
-    @test LinearOperators.storage_type(LinearOperator(Symmetric(mat); S = vecT)) == vecT
-    @test LinearOperators.storage_type(LinearOperator(Hermitian(mat); S = vecT)) == vecT
-    @test LinearOperators.storage_type(LinearOperator(Float32, 32, 32, true, true, () -> 0; S = vecT)) == vecT
-    # special-operators.jl
-    @test LinearOperators.storage_type(opEye(Float32, 32; S = vecT)) == vecT
-    @test LinearOperators.storage_type(opEye(Float32, 16, 32; S = vecT)) == vecT
-    @test LinearOperators.storage_type(opEye(Float32, 32, 32; S = vecT)) == vecT
-    @test LinearOperators.storage_type(opOnes(Float32, 32, 32; S = vecT)) == vecT
-    @test LinearOperators.storage_type(opZeros(Float32, 32, 32; S = vecT)) == vecT
-    @test LinearOperators.storage_type(opDiagonal(vec)) == vecT
-    @test LinearOperators.storage_type(opDiagonal(32, 32, vec)) == vecT
-    @test LinearOperators.storage_type(opRestriction([1, 2, 3], 32; S = vecT)) == vecT
-    @test LinearOperators.storage_type(opExtension([1, 2, 3], 32; S = vecT)) == vecT
-    @test LinearOperators.storage_type(BlockDiagonalOperator(mat, mat)) == vecT # default
-    @test LinearOperators.storage_type(BlockDiagonalOperator(mat, mat; S = vecTother)) == vecTother
-  end
-end
+# ---- the reference's own device test for storage-type propagation, run with the extension's array types exactly the way
+# the reference runs it for JLArrays / CUDA / AMDGPU (test/gpu/jlarrays.jl:1, test/gpu/amdgpu.jl:2): include ITS file and
+# call ITS function — `arrayType(rand(Float32, 32, 32))` is an MXMatrix, `arrayType(rand(Float32, 32))` an MXVector.
+# The assertions it makes (test/gpu/test_S_kwarg.jl:15-43) cover LinearOperator(mat), LinearOperator(mat; S = vecTother),
+# LinearOperator(Symmetric(mat); S = vecT), LinearOperator(Hermitian(mat); S = vecT),
+# LinearOperator(Float32, 32, 32, true, true, () -> 0; S = vecT), opEye(Float32, 32; S = vecT), opEye(Float32, 16, 32; S = vecT),
+# opOnes(Float32, 32, 32; S = vecT), opZeros(Float32, 32, 32; S = vecT), opDiagonal(vec), opDiagonal(32, 32, vec),
+# opRestriction([1, 2, 3], 32; S = vecT), opExtension([1, 2, 3], 32; S = vecT), BlockDiagonalOperator(mat, mat) and
+# BlockDiagonalOperator(mat, mat; S = vecTother); with storage_type(LinearOperator(mat)) == LinearOperators.storage_type(mat)
+# as the default rule.
+mxlo_array(A::AbstractMatrix) = MXMatrix(A)
+mxlo_array(v::AbstractVector) = MXVector(v)
+include(joinpath(pkgdir(LinearOperators), "test", "gpu", "test_S_kwarg.jl"))
+test_S_kwarg(arrayType = mxlo_array)
 
 @testset "MXLO -- mirror of test/gpu/amdgpu.jl" begin
   Ah, Bh, Ch = rand(Float32, 5, 5), rand(Float32, 10, 10), rand(Float32, 20, 20)
@@ -145,8 +128,7 @@ end
   @test LinearOperators.storage_type(A) == LinearOperators.storage_type(transpose(A))
   @test LinearOperators.storage_type(A) == LinearOperators.storage_type(adjoint(A))
   @test LinearOperators.storage_type(Diagonal(v)) == typeof(v)
-  @testset "MXLO S kwarg" test_S_kwarg_mxlo()
-end
+  @testset "MXLO S kwarg" end
 
 # ---- the reference's allocation contract, literally: test/test_lbfgs.jl:180-218 ("LBFGS allocations") and
 # test/test_lsr1.jl:88-106 on device operators. `@allocated` counts HOST (GC) bytes: a ccall closure with concrete

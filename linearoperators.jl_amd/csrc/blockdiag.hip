@@ -27,6 +27,7 @@ struct mxlo_csc;
 namespace mxlo {
 const CscDev *csc_device_desc(const mxlo_csc *h);     // sparse.hip
 void csc_shape(const mxlo_csc *h, int64_t *m, int64_t *n, int *dtype, int *nchunks_n, int *nchunks_t, int *nlong);
+const mxlo_ctx *csc_ctx(const mxlo_csc *h);
 }
 
 namespace {
@@ -276,6 +277,11 @@ MXLO_API int32_t mxlo_blockdiag_create(mxlo_ctx *ctx, int32_t dtype, const mxlo_
       int64_t sm = 0, sn = 0;
       int sdt = 0, nlong = 0;
       csc_shape((const mxlo_csc *)b.data, &sm, &sn, &sdt, &nch_n, &nch_t, &nlong);
+      // the one-launch kernel dereferences the handle's DEVICE descriptor, and mxlo_csc_refresh orders its value gather on
+      // the handle's ctx stream: both only make sense when the handle was built on THIS ctx (same device, same stream order)
+      MXLO_REQUIRE(csc_ctx((const mxlo_csc *)b.data) == ctx, MXLO_EINVAL,
+                   "block %lld: the sparse handle belongs to another mxlo_ctx than the block-diagonal operator (build both on one ctx; "
+                   "refreshes of the handle are ordered on ITS ctx stream)", (long long)k);
       MXLO_REQUIRE(nlong == 0, MXLO_EINVAL,
                    "block %lld: the sparse block has a row or column with more than %d stored entries, which needs the "
                    "two-launch apply of mxlo_csc_mul (mxlo_csc_info reports it): apply that block on its own",

@@ -17,6 +17,7 @@
 // sequence). The reference-ordered inverse two-loop (2m chained dot/axpy passes) is kept as
 // MXLO_INV_REFORDER for validation.
 #include <chrono>
+#include <thread>
 #include <cmath>
 #include <vector>
 
@@ -1533,7 +1534,13 @@ static int32_t await_posted(mxlo_qn *h, const unsigned long long *word, int nwor
     if ((spin & 63) == 63 &&
         std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() > kPostSpinUs)
       break;
+#if defined(__x86_64__) || defined(__i386__)
     __builtin_ia32_pause();
+#elif defined(__aarch64__)
+    __asm__ __volatile__("yield");
+#else
+    std::this_thread::yield();
+#endif
   }
   *arrived = true;
   if (have == nwords) {

@@ -25,6 +25,7 @@ struct mxlo_csc {
 
 namespace mxlo {
 const CscDev *csc_device_desc(const mxlo_csc *h) { return h ? h->dev : nullptr; }   // blockdiag.hip
+const mxlo_ctx *csc_ctx(const mxlo_csc *h) { return h ? h->ctx : nullptr; }
 void csc_shape(const mxlo_csc *h, int64_t *m, int64_t *n, int *dtype, int *nchunks_n, int *nchunks_t, int *nlong) {
   *m = h->m; *n = h->n; *dtype = h->dtype;
   *nchunks_n = h->host.nchunks_n; *nchunks_t = h->host.nchunks_t; *nlong = h->host.nlong_n + h->host.nlong_t;

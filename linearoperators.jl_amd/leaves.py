@@ -348,7 +348,12 @@ def opHermitian(*args):
     """opHermitian(d, A) / opHermitian(A) — src/linalg.jl:105-127. Complex A (ComplexF64 / ComplexF32): `L'` is the
     conjugate transpose, symmetric = isreal(A) = false, hermitian = true; d may be real (the reference test passes
     real.(diag(A)), test/test_linop.jl:362) or complex."""
-    if args[-1].layout in _SPARSE_LAYOUTS:
+    if hasattr(args[-1], "tocsc") and not isinstance(args[-1], torch.Tensor):      # a scipy.sparse matrix, as LinearOperator(M),
+        Mc = args[-1].tocsc()                                                       # cat and BlockDiagonalOperator accept it
+        Mc.sort_indices()
+        dv = args[0].device if len(args) == 2 else None
+        args = (*args[:-1], sparse_csc(Mc.indptr, Mc.indices, Mc.data, Mc.shape[0], Mc.shape[1], index_base=0, device=dv))
+    if getattr(args[-1], "layout", None) in _SPARSE_LAYOUTS:
         return _opHermitian_sparse(*args)
     if len(args) == 1:
         A = _colmajor(args[0])

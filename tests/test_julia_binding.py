@@ -158,7 +158,8 @@ def test_the_glue_has_ccalls_for_every_hot_path_leaf():
             "mxlo_kron_mul_ex", "mxlo_qn_create", "mxlo_qn_push", "mxlo_qn_mul", "mxlo_qn_mul_shifted",
             "mxlo_qn_solve_shifted", "mxlo_qn_diag", "mxlo_qn_reset", "mxlo_diagqn_push", "mxlo_graph_begin",
             "mxlo_graph_end", "mxlo_graph_launch", "mxlo_diag_mul_c", "mxlo_eye_mul_c", "mxlo_zeros_mul_c",
-            "mxlo_scale_c", "mxlo_conj_c", "mxlo_dot_c", "mxlo_householder_mul_c", "mxlo_gemv_c", "mxlo_hermitian_mul_c", "mxlo_kron_mul_c3", "mxlo_shard_ctx_create",
+            "mxlo_scale_c", "mxlo_conj_c", "mxlo_dot_c", "mxlo_householder_mul_c", "mxlo_gemv_c", "mxlo_hermitian_mul_c", "mxlo_kron_mul_c3", "mxlo_shard_ctx_create_ex",
+            "mxlo_shard_ctx_preflight", "mxlo_index_plan_create", "mxlo_gather_plan", "mxlo_scatter_zero_plan",
             "mxlo_householder_mul_sharded", "mxlo_qn_create_sharded", "mxlo_qn_mul_sharded"}
     assert not (must - names), f"glue lacks ccalls for {sorted(must - names)}"
 
@@ -266,21 +267,25 @@ def test_methods_added_to_reference_functions_have_an_arity_the_reference_uses(f
 
 
 def test_runtests_mirrors_the_reference_gpu_tests_line_by_line():
-    """julia/runtests_mxlo.jl carries the storage_type assertions of /root/reference/test/gpu/test_S_kwarg.jl:16-44 and
-    test/gpu/amdgpu.jl:5-19 with the extension's array types (checked textually; the Python mirror of the same
-    assertions runs on the GPU in tests/test_gpu_callers.py::test_storage_type_kwarg_mirror)."""
+    """julia/runtests_mxlo.jl runs the reference's OWN storage-type test (test/gpu/test_S_kwarg.jl) by including that file
+    and calling its `test_S_kwarg(arrayType = …)` with the extension's array types — the pattern of test/gpu/jlarrays.jl:1 /
+    amdgpu.jl:2 (no re-typed assertion list) — and carries the assertions of test/gpu/amdgpu.jl:5-19 and the
+    `@allocated == 0` block with the extension's types (checked textually; the Python mirror of the same assertions runs on
+    the GPU in tests/test_gpu_callers.py::test_storage_type_kwarg_mirror)."""
     rt = (ROOT / "julia" / "runtests_mxlo.jl").read_text()
-    for frag in ("storage_type(LinearOperator(mat)) == LinearOperators.storage_type(mat)", "LinearOperator(mat; S = vecTother)",
-                 "LinearOperator(Symmetric(mat); S = vecT)", "LinearOperator(Hermitian(mat); S = vecT)",
-                 "LinearOperator(Float32, 32, 32, true, true, () -> 0; S = vecT)", "opEye(Float32, 32; S = vecT)",
-                 "opEye(Float32, 16, 32; S = vecT)", "opOnes(Float32, 32, 32; S = vecT)", "opZeros(Float32, 32, 32; S = vecT)",
-                 "opDiagonal(vec)", "opDiagonal(32, 32, vec)", "opRestriction([1, 2, 3], 32; S = vecT)",
-                 "opExtension([1, 2, 3], 32; S = vecT)", "BlockDiagonalOperator(mat, mat)", "BlockDiagonalOperator(mat, mat; S = vecTother)",
-                 "BlockDiagonalOperator(A, B, C)", "y isa MXVector{Float32}", "storage_type(adjoint(A))", "storage_type(transpose(A))",
+    code = "\n".join(ln for ln in rt.splitlines() if not ln.lstrip().startswith("#"))
+    assert 'include(joinpath(pkgdir(LinearOperators), "test", "gpu", "test_S_kwarg.jl"))' in code
+    assert "test_S_kwarg(arrayType = mxlo_array)" in code
+    assert "LinearOperator(mat; S = vecTother)" not in code, "the S-kwarg assertions are the reference's: include its file, do not re-type them"
+    for frag in ("BlockDiagonalOperator(A, B, C)", "y isa MXVector{Float32}", "storage_type(adjoint(A))", "storage_type(transpose(A))",
                  "storage_type(Diagonal(v)) == typeof(v)", "@allocated mul!(res, B, x)", "@allocated push!(HD, x, y, 1.0, x, tmpd)"):
         assert frag in rt, frag
-    if (REF / "test" / "gpu" / "test_S_kwarg.jl").exists():       # the mirrored assertions still exist upstream
-        up = (REF / "test" / "gpu" / "test_S_kwarg.jl").read_text() + (REF / "test" / "gpu" / "amdgpu.jl").read_text()
-        for frag in ("LinearOperator(mat; S = vecTother)", "opRestriction([1, 2, 3], 32; S = vecT)", "BlockDiagonalOperator(A, B, C)",
-                     "storage_type(Diagonal(v)) == typeof(v)"):
+    if (REF / "test" / "gpu" / "test_S_kwarg.jl").exists():       # what the include relies on still exists upstream
+        up = (REF / "test" / "gpu" / "test_S_kwarg.jl").read_text()
+        assert "function test_S_kwarg(; arrayType" in up
+        for frag in ("LinearOperator(mat; S = vecTother)", "opRestriction([1, 2, 3], 32; S = vecT)", "arrayType(rand(Float32, 32, 32))",
+                     "arrayType(rand(Float32, 32))"):
             assert frag in up, frag
+        up2 = (REF / "test" / "gpu" / "amdgpu.jl").read_text()
+        for frag in ("BlockDiagonalOperator(A, B, C)", "storage_type(Diagonal(v)) == typeof(v)"):
+            assert frag in up2, frag

@@ -1014,6 +1014,7 @@ def test_persistent_apply_matches_the_four_launch_apply_and_the_oracle(lo, dev, 
         a = (C.c_int64 * 12)()
         lo._lib.call("mxlo_debug_counters", a)
         return a[10]
+    ctx.tune("qn_persist_min_bytes", 0)          # (default 32 MiB: a two-column panel would take the other forms) — restored below
     for k, (s, y) in enumerate(pairs(rng, n, mem + 2, npd)):
         lo.push(op, T(s, dev), T(y, dev)); O.push(s, y)
         if k not in (0, mem // 2, mem + 1):
@@ -1050,6 +1051,7 @@ def test_persistent_apply_matches_the_four_launch_apply_and_the_oracle(lo, dev, 
     lo.mul(res, sh, T(x, dev), 1.5, 0.5)
     want = 1.5 * (O.mul(np.empty(n, npd), x).astype(np.float64) + 0.37 * x.astype(np.float64)) + 0.5 * r0.astype(np.float64)
     assert rel(res.cpu().numpy().astype(np.float64), want) <= tol
+    ctx.tune("qn_persist_min_bytes", 32 << 20)
 
 
 def test_persistent_apply_timeout_is_an_error_not_a_hang(lo, dev):

@@ -103,16 +103,20 @@ class NativeRcclHook:
     """RCCL communicator owned by libmxlo_rccl.so; the hook is the C function `mxlo_rccl_allreduce_hook`
     itself (ncclAllReduce on the ctx stream) — no Python, no extra stream, nothing synchronises."""
 
-    def __init__(self, rank: int, world: int, group=None, timeout_s: float = 120.0):
+    def __init__(self, rank: int, world: int, group=None, timeout_s: float = 120.0, unique_id: bytes | None = None):
+        """`unique_id`: the 128-byte id when the host runtime has already delivered it (MPI, a file, a test); otherwise
+        rank 0 creates it and it is broadcast over torch.distributed."""
         from . import _lib
         R = _lib.rccl_lib()
         idbuf = torch.zeros(_lib.RCCL_ID_BYTES, dtype=torch.uint8)
-        if rank == 0:
+        if unique_id is not None:
+            idbuf = torch.tensor(list(unique_id[:_lib.RCCL_ID_BYTES].ljust(_lib.RCCL_ID_BYTES, b"\0")), dtype=torch.uint8)
+        elif rank == 0:
             raw = (C.c_ubyte * _lib.RCCL_ID_BYTES)()
             if R.mxlo_rccl_unique_id(raw) != 0:
                 raise RuntimeError(R.mxlo_rccl_last_error().decode())
             idbuf = torch.tensor(list(raw), dtype=torch.uint8)
-        if world > 1:                                   # the 128-byte id travels over the host runtime
+        if world > 1 and unique_id is None:             # the 128-byte id travels over the host runtime
             dev = torch.device("cuda", torch.cuda.current_device())
             backend = dist.get_backend(group)
             t = idbuf.to(dev) if backend == "nccl" else idbuf

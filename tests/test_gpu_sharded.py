@@ -188,3 +188,74 @@ def test_ranks_on_one_gpu_peer_shm_transport(tmp_path, world):
 def test_real_ranks_peer_shm_transport(tmp_path):
     world = min(torch.cuda.device_count(), 8)
     assert run_ranks(tmp_path, world, "nccl", 29679, transport="peer") == "peer"
+
+
+def test_transport_preflight_and_refusal_paths_at_world_1(lo, dev, tmp_path):
+    """what `bench.py --gpus N` runs before it times anything, on the one device every box has.
+    (i) the NATIVE RCCL hook at world 1: the communicator reports 1 rank / rank 0 / this device + a PCI bus id, the preflight
+    (known-answer sums, identical bits, verdict, latency of 8 B / 320 B / 6912 B) passes; (ii) the peer transport over a shm
+    segment at world 1, incl. a second segment of the same name being refused (O_EXCL) and a non-creator that finds no
+    segment; (iii) argument refusals of the C entry points; (iv) ONE RANK MISSING: rank 0 of a 2-rank communicator whose
+    peer never shows up must come back with TimeoutError from `NativeRcclHook(timeout_s=…)` instead of hanging — run in a
+    child process that is killed afterwards (the abandoned bootstrap thread cannot be cancelled)."""
+    import ctypes as C
+    from linearoperators_jl_amd.device import get_ctx
+    ctx = get_ctx(dev)
+    R = lo._lib.rccl_lib()
+    hook = lo.sharded.NativeRcclHook(0, 1)
+    try:
+        inf = hook.info()
+        assert inf["ranks_seen"] == 1 and inf["user_rank"] == 0 and inf["device"] == dev.index and len(inf["pci_bus_id"]) >= 7, inf
+        lat = hook.preflight(ctx.stream, reps=20, timeout_ms=20000)
+        assert set(lat) == {"8B", "320B", "6912B"} and all(0 <= v < 1e6 for v in lat.values()), lat
+    finally:
+        hook.close()
+    ph = lo.sharded.PeerShmHook(0, 1, timeout_ms=5000)
+    try:
+        lat = ph.preflight(ctx.stream, reps=20, timeout_ms=20000)
+        assert all(0 < v < 1e6 for v in lat.values()), lat
+        dup = C.c_void_p()
+        assert R.mxlo_peer_comm_create_shm(ph.name.encode(), 0, 1, 1, 1000, C.byref(dup)) != 0       # the name is taken
+        assert b"O_EXCL" in R.mxlo_peer_last_error() or b"exists" in R.mxlo_peer_last_error().lower()
+    finally:
+        ph.close()
+    none = C.c_void_p()
+    assert R.mxlo_peer_comm_create_shm(b"/mxlo-test-no-such-segment", 1, 2, 0, 1000, C.byref(none)) != 0
+    assert R.mxlo_peer_comm_create_shm(b"no-slash", 0, 1, 1, 1000, C.byref(none)) != 0
+    idb = (C.c_ubyte * lo._lib.RCCL_ID_BYTES)()
+    comm = C.c_void_p()
+    assert R.mxlo_rccl_comm_create(2, 2, idb, C.byref(comm)) != 0 and b"rank 2 not in [0, 2)" in R.mxlo_rccl_last_error()
+    assert R.mxlo_rccl_comm_create(0, 1, None, C.byref(comm)) != 0
+    lat3 = (C.c_double * 3)()
+    assert R.mxlo_rccl_preflight(None, None, 10, 1000, lat3) != 0
+    # (iv) a rank that never joins
+    script = tmp_path / "lonely_rank.py"
+    script.write_text(textwrap.dedent('''
+        import os, sys, time
+        sys.path.insert(0, %r)
+        import torch
+        import __graft_entry__ as g
+        lo = g.load_package()
+        torch.cuda.set_device(0)
+        t0 = time.time()
+        import ctypes as C
+        R = lo._lib.rccl_lib()
+        raw = (C.c_ubyte * lo._lib.RCCL_ID_BYTES)()
+        assert R.mxlo_rccl_unique_id(raw) == 0
+        try:
+            lo.sharded.NativeRcclHook(0, 2, timeout_s=4.0, unique_id=bytes(raw))   # world 2, nobody else: bootstrap waits for rank 1
+            print("UNEXPECTED: returned", flush=True)
+        except TimeoutError as e:
+            print("TIMEOUT-REPORTED after %%.1f s: %%s" %% (time.time() - t0, e), flush=True)
+        except Exception as e:                                       # an immediate refusal is acceptable too
+            print("REFUSED: %%r" %% (e,), flush=True)
+        os._exit(0)
+    ''') % ROOT)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", NCCL_SOCKET_IFNAME="lo")
+    p = subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    try:
+        out = p.communicate(timeout=180)[0]
+    except subprocess.TimeoutExpired:
+        p.kill()
+        raise AssertionError("a 2-rank communicator with one rank missing hung the caller")
+    assert "TIMEOUT-REPORTED" in out or "REFUSED" in out, out

@@ -55,6 +55,10 @@ def parse(argv=None):
     # debugging aids for the N > 1 code path on a 1-GPU box: every rank on device 0, gloo instead of RCCL
     ap.add_argument("--backend", default="nccl")
     ap.add_argument("--single-device", action="store_true")
+    ap.add_argument("--rehearse-distributed", action="store_true",
+                    help="N = 1 only: run the N-rank code path at world 1 — nccl process group of one rank, the NATIVE RCCL hook, "
+                         "transport preflight, the peer transport, every collective of the timed legs — so that the code the "
+                         "driver's multi-GPU run depends on has executed on a one-GPU box (the numbers are those of one GPU)")
     # the N-device leg through the single-process shard ABI (runs in a child process with a timeout)
     ap.add_argument("--no-shard-leg", action="store_true")
     ap.add_argument("--shard-leg-timeout", type=float, default=420.0)
@@ -317,7 +321,9 @@ def worker(args):
         lo = g.load_package()
         from linearoperators_jl_amd import _lib
         from linearoperators_jl_amd.device import Timer, dtype_code, get_ctx, ptr
-    distributed = world > 1
+    distributed = world > 1 or args.rehearse_distributed
+    if args.rehearse_distributed and world != 1:
+        die("--rehearse-distributed is the world-1 rehearsal of the N-rank path: use it with --gpus 1")
     if args.gpus != world:
         die(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher must start exactly one rank per requested GPU")
     check_topology(args, visible_device_count())
@@ -327,6 +333,8 @@ def worker(args):
     dev = torch.device("cuda", local_rank)
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if args.rehearse_distributed:
+            os.environ.setdefault("MASTER_PORT", str(free_port()))
         with wd.phase("init_process_group"):
             if args.backend == "nccl":
                 dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
@@ -343,7 +351,7 @@ def worker(args):
         if native and hook is None:
             # libmxlo_rccl.so: ncclAllReduce issued from C on the ctx stream. REQUIRED on the nccl backend: if any rank
             # cannot build its communicator every rank raises (the run exits non-zero; no Python-issued collectives)
-            hook = lo.sharded.install_agreed_allreduce(ctx, require_native=True)
+            hook = lo.sharded.install_agreed_allreduce(ctx, require_native=True, even_at_world_1=args.rehearse_distributed)
             return
         if native:
             hook.install(ctx)
@@ -568,6 +576,8 @@ def worker(args):
             "frac_hbm_peak": round(value / world / HBM_PEAK_GBS, 4),
             "roofline": roofline, "cpu_baseline": cpu_baseline, "extras": extras,
             "rccl": transports.get("rccl"), "transports": transports,
+            "rehearsal": ("world-1 rehearsal of the N-rank code path (nccl group of one rank, native hook, preflight, peer transport)"
+                          if args.rehearse_distributed else None),
             "phases_s": {k: v for k, v in wd.history},
         }
     with wd.phase("teardown"):
@@ -591,7 +601,7 @@ def transport_preflight(args, lo, torch, dist, ctx, dev, rank, world, native_hoo
     latency in us. N == 1: the same functions at world 1 (a communicator of one rank, the peer exchange with one mailbox):
     nothing on the timed path uses them — recorded so that the code path the N > 1 run depends on has run on this box."""
     out = {}
-    if world > 1:
+    if world > 1 or args.rehearse_distributed:
         if native_hook is None:
             return {"rccl": None, "note": "debug transport (torch.distributed Python hook): no native preflight"}
         info = native_hook.info()

@@ -248,12 +248,14 @@ def install_allreduce(ctx, group=None, native: bool = True):
     return None
 
 
-def install_agreed_allreduce(ctx, group=None, timeout_s: float = 120.0, require_native: bool = False):
+def install_agreed_allreduce(ctx, group=None, timeout_s: float = 120.0, require_native: bool = False,
+                             even_at_world_1: bool = False):
     """The native RCCL transport when EVERY rank managed to build its communicator, otherwise the
     torch.distributed hook on every rank (never a mix: mixed transports would deadlock). Returns the
     NativeRcclHook or None. `require_native=True` (what `bench.py --gpus N` uses): no degraded transport —
-    if any rank failed, EVERY rank raises RuntimeError after the agreement round."""
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if any rank failed, EVERY rank raises RuntimeError after the agreement round. `even_at_world_1`: build and install the
+    communicator for a group of ONE rank too (a rehearsal of the N-rank path on a one-GPU box)."""
+    if not dist.is_initialized() or (dist.get_world_size(group) == 1 and not even_at_world_1):
         ctx.set_allreduce(None)
         return None
     hook, ok = None, 1

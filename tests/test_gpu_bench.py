@@ -1,0 +1,38 @@
+"""-m gpu: bench.py itself. The driver's multi-GPU run is the first time `bench.py --gpus N` meets N devices, so the code
+that run depends on is rehearsed here at world 1: an `nccl` process group of one rank, the NATIVE RCCL all-reduce hook
+installed through the agreement round, the transport preflight (ranks_seen / PCI ids / latency in the JSON), the second
+transport (peer-mapped exchange over shm) with its own timed loop, and every collective the timed legs issue."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_rehearsal_of_the_n_rank_path_at_world_1():
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--rehearse-distributed", "--steps", "5", "--warmup", "2",
+                        "--nelem", "4000000", "--no-cpu-baseline", "--no-shard-leg", "--clock-spin-s", "0.05"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["rehearsal"] and "native RCCL hook" in d["config"]["sharding"]
+    r = d["rccl"]
+    assert r["ranks_seen"] == 1 and r["user_rank"] == 0 and r["sum_check"] == "ok" and r["identical_bits"] is True
+    assert len(r["pci_bus_ids"]) == 1 and set(r["latency_us"]) == {"8B", "320B", "6912B"}
+    ps = d["transports"]["peer_shm"]
+    assert "error" not in ps and ps["householder_ms_per_step"] > 0 and set(ps["latency_us"]) == {"8B", "320B", "6912B"}
+    assert "timed loop" in d["phases_s"] and "transport preflight" in d["phases_s"]
+    assert "lbfgs_error" not in d["extras"] and "cfg4_error" not in d["extras"]
+    # rehearsal with more than one rank is refused (it is the world-1 form of the N-rank path)
+    q = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearse-distributed", "--single-device", "--backend", "gloo",
+                        "--nelem", "100000", "--steps", "2", "--no-extras", "--no-cpu-baseline", "--no-shard-leg"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert q.returncode != 0 and "--rehearse-distributed" in q.stderr

@@ -283,7 +283,8 @@ def test_random_blockdiagonal_vs_dense(lo, dev, seed):
 @pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("MXLO_IDXFUZZ_SEEDS", "80"))))
 def test_random_restriction_extension_bit_exact(lo, dev, seed):
     """opRestriction / opExtension over random UnitRanges, StepRanges (positive and NEGATIVE steps), index vectors with
-    duplicates (last write wins, special-operators.jl:171-174) and scalars; data of 4 and 8 bytes; views at odd offsets.
+    duplicates (last write wins, special-operators.jl:171-174), strictly increasing sets of random density (index plans)
+    and scalars; data of 4 and 8 bytes; views at odd offsets.
     Pure data movement: bit-exact against NumPy indexing."""
     rng = np.random.default_rng(9000 + seed)
     dtype = [torch.float64, torch.float32, torch.int64, torch.int32][seed % 4]
@@ -293,8 +294,12 @@ def test_random_restriction_extension_bit_exact(lo, dev, seed):
     v = base[off:off + ncol]                                   # a view at any 4/8-byte phase
     vh = v.cpu().numpy()
     S = lo.Storage(dtype, dev)
-    kind = rng.integers(4)
-    if kind == 0:
+    kind = rng.integers(5)
+    if kind == 4:                                               # round 5: a strictly increasing set of random density —
+        dens = [0.9, 0.5, 0.2, 0.05][int(rng.integers(4))]      # bit mask + ranks from 1/32 (extension) / 1/8 (restriction)
+        idx0 = np.flatnonzero(rng.random(ncol) < dens)
+        I = (idx0 + 1).tolist()
+    elif kind == 0:
         a = int(rng.integers(1, ncol + 1)); b = int(rng.integers(a, ncol + 1))
         I, idx0 = lo.jrange(a, b), np.arange(a, b + 1) - 1
     elif kind == 1:

@@ -904,8 +904,10 @@ def test_single_launch_apply_exchange_stress(lo, dev):
     ctx = get_ctx(dev)
     rng = np.random.default_rng(77)
     ops = []
+    # (round 5: two operators large enough for the PERSISTENT launch, which shares the slot sets and the epoch word)
     for kind, dtype, n, mem in (("inv", torch.float64, 300, 3), ("fwd", torch.float64, 100_003, 20), ("lsr1", torch.float64, 4096, 7),
-                                ("fwd", torch.float32, 65_536, 5), ("inv", torch.float32, 9_001, 10), ("lsr1", torch.float32, 70_001, 2)):
+                                ("fwd", torch.float32, 65_536, 5), ("inv", torch.float32, 9_001, 10), ("lsr1", torch.float32, 70_001, 2),
+                                ("inv", torch.float64, (1 << 19) + 5, 5), ("fwd", torch.float32, (1 << 20) + 3, 10)):
         npd = NP[dtype]
         make = {"inv": lo.InverseLBFGSOperator, "fwd": lo.LBFGSOperator, "lsr1": lo.LSR1Operator}[kind]
         op = make(dtype, n, mem=mem, device=dev)
@@ -935,6 +937,7 @@ def test_single_launch_apply_exchange_stress(lo, dev):
             for op, x, res, first in ops:
                 assert torch.equal(res, first), it
     ctx.tune("qn_fused_small", 0)
+    ctx.tune("qn_persist", 0)
     try:
         for op, x, res, first in ops:
             lo.mul(res, op, x, 1.0, 0.0)
@@ -942,6 +945,7 @@ def test_single_launch_apply_exchange_stress(lo, dev):
             assert (torch.linalg.vector_norm((res - first).double()) / torch.linalg.vector_norm(first.double())).item() <= tol
     finally:
         ctx.tune("qn_fused_small", 1)
+        ctx.tune("qn_persist", 1)
 
 
 @pytest.mark.parametrize("kind", ["inv", "fwd", "lsr1"])

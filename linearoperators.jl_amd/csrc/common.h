@@ -146,6 +146,9 @@ struct Tune {
   int64_t qn_persist_max_bytes = 448ll << 20;    // ... while the panel (columns x n x element size) is at most this many bytes
                                                  // (profiles/r05_tune_persist.txt: ahead of four launches up to ~340 MB panels)
   int qn_persist_reverse = 1;   // ... its combine phase walks the workgroup's chunks back to front
+  int qn_persist_prefetch = 0;  // ... x and the first column batch of its first combine chunk are requested before the exchange.
+                                // Measured (profiles/r05_bench_mid_apply.txt, last block): 1.5 us SLOWER at n = 2^19 .. 2^20 (the polls of
+                                // the exchange return in order behind the 11 prefetch loads), neutral above — off
   int qn_persist_lds_pad = 0;   // ... bytes of (unused) dynamic LDS requested per workgroup: > 80 KiB forces one workgroup per CU
   int64_t qn_persist_min_bytes = 32ll << 20;     // ... and at least this many (an L-SR1 m = 5 apply at n = 2^19 — 21 MB — is
                                                  // faster in the single-launch slice form: 10.7 vs 12.1 us)

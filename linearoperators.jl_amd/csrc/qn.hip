@@ -1006,7 +1006,7 @@ template <typename T, typename CA, typename CB, int KIND, bool BETA0>
 __global__ void __launch_bounds__(kPersistBlock)
 qn_apply_persist_kernel(T *__restrict__ res, QnfCols<T> cols, const T *__restrict__ x, int64_t n, int cpw,
                         unsigned long long *__restrict__ slots, QnfArgs F, OrdArgs O, unsigned long long ticks,
-                        unsigned *__restrict__ fault, int drop, int reverse) {
+                        unsigned *__restrict__ fault, int drop, int reverse, int prefetch) {
   constexpr int VEC = Vec16<T>::N, NB = kPersistNB, NW = kPersistBlock / 64;
   using V = typename Vec16<T>::type;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, G = (int)gridDim.x, b = (int)blockIdx.x;
@@ -1080,6 +1080,24 @@ qn_apply_persist_kernel(T *__restrict__ res, QnfCols<T> cols, const T *__restric
     }
   }
   __syncthreads();
+  // combine column c in terms of the dots columns
+  auto ccol = [&](int c) -> const T * {
+    if constexpr (KIND == MXLO_QN_LBFGS_INV) return c < F.nfirst ? cols.p[F.nfirst + c] : cols.p[2 * F.nfirst - 1 - c];
+    else return cols.p[c];
+  };
+  // PREFETCH across the exchange (tune key qn_persist_prefetch, OFF by default): x and the first batch of columns of the
+  // chunk the combine phase takes first are requested NOW — they need no coefficient — and travel while the partials are
+  // exchanged and the recurrence runs. Measured: no gain — 1.5 us slower at n = 2^19 .. 2^20 (loads return in order, so the
+  // first poll of the exchange waits behind the 11 prefetch loads), neutral above (profiles/r05_bench_mid_apply.txt).
+  const int64_t chp = reverse ? ch1 - 1 : ch0;
+  const bool pre = prefetch && ch1 > ch0 && chunk_full(chp);
+  V pxv, pcv[NB];
+  if (pre) {
+    const int64_t ip = (chp * kPersistBlock + tid) * VEC;
+    pxv = *reinterpret_cast<const V *>(x + ip);
+#pragma unroll
+    for (int t = 0; t < NB; ++t) pcv[t] = *reinterpret_cast<const V *>(ccol(t < ncol ? t : ncol - 1) + ip);
+  }
   // ---- 2. publish, gather (fixed order: lane l adds workgroups l, l + 64, ..., then one DPP tree)
   if (tid < ncol) {
     const double sv = ((red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid])) +
@@ -1128,20 +1146,18 @@ qn_apply_persist_kernel(T *__restrict__ res, QnfCols<T> cols, const T *__restric
   const T g = (T)F.gamma;
   const CA al = (CA)F.alpha;
   const CB be = (CB)F.beta;
-  auto ccol = [&](int c) -> const T * {
-    if constexpr (KIND == MXLO_QN_LBFGS_INV) return c < F.nfirst ? cols.p[F.nfirst + c] : cols.p[2 * F.nfirst - 1 - c];
-    else return cols.p[c];
-  };
   // One chunk; FULL: every lane's vector lies inside n — unconditional 16-byte accesses, so the NB column loads of a
   // batch are in flight together (a per-load bounds branch makes the compiler drain the memory queue before every load).
-  auto combine_chunk = [&]<bool FULL>(int64_t ch) {
+  // PRE (a FULL chunk): x and the first batch of columns are the registers prefetched across the exchange.
+  auto combine_chunk = [&]<bool FULL, bool PRE = false>(int64_t ch) {
     const int64_t i = (ch * kPersistBlock + tid) * VEC;
     if constexpr (!FULL) {
       if (i >= n) return;
     }
     V xv, rv;
     if constexpr (FULL) {
-      xv = *reinterpret_cast<const V *>(x + i);
+      if constexpr (PRE) xv = pxv;
+      else xv = *reinterpret_cast<const V *>(x + i);
       if constexpr (!BETA0) rv = *reinterpret_cast<const V *>(res + i);
     } else {
       xv = ldv(x, i);
@@ -1159,7 +1175,8 @@ qn_apply_persist_kernel(T *__restrict__ res, QnfCols<T> cols, const T *__restric
 #pragma unroll
       for (int t = 0; t < NB; ++t) {
         const T *p = ccol(c0 + t < ncol ? c0 + t : ncol - 1);      // clamp: a valid (unused) column instead of a branch
-        if constexpr (FULL) cv[t] = *reinterpret_cast<const V *>(p + i);
+        if constexpr (PRE) cv[t] = c0 == 0 ? pcv[t] : *reinterpret_cast<const V *>(p + i);
+        else if constexpr (FULL) cv[t] = *reinterpret_cast<const V *>(p + i);
         else cv[t] = ldv(p, i);
       }
 #pragma unroll
@@ -1209,7 +1226,8 @@ qn_apply_persist_kernel(T *__restrict__ res, QnfCols<T> cols, const T *__restric
   };
   for (int64_t kk = 0; kk < ch1 - ch0; ++kk) {
     const int64_t ch = reverse ? ch1 - 1 - kk : ch0 + kk;
-    if (chunk_full(ch)) combine_chunk.template operator()<true>(ch);
+    if (kk == 0 && pre) combine_chunk.template operator()<true, true>(ch);
+    else if (chunk_full(ch)) combine_chunk.template operator()<true>(ch);
     else combine_chunk.template operator()<false>(ch);
   }
 }
@@ -1259,7 +1277,7 @@ bool try_persist_apply(mxlo_qn *h, T *res, const T *const *cols, const T *x, Qnf
       if (pad > 48 * 1024 && !persist_lds_attr_set<qn_apply_persist_kernel<T, CA, CB, KIND, B0>>(ctx)) { fits = false; return; }
       hipLaunchKernelGGL((qn_apply_persist_kernel<T, CA, CB, KIND, B0>), dim3((unsigned)grid), dim3(kPersistBlock), pad,
                          ctx->stream, res, fc, x, h->n, cpw, ctx->qslots, F, O, fused_timeout_ticks(ctx), ctx->fault_dev,
-                         ctx->tune.fused_debug_drop, ctx->tune.qn_persist_reverse);
+                         ctx->tune.fused_debug_drop, ctx->tune.qn_persist_reverse, ctx->tune.qn_persist_prefetch);
     };
     if (F.kind == MXLO_QN_LBFGS_INV) go.template operator()<MXLO_QN_LBFGS_INV>();
     else if (F.kind == MXLO_QN_LBFGS_FWD) go.template operator()<MXLO_QN_LBFGS_FWD>();

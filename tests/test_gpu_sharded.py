@@ -241,7 +241,10 @@ def test_transport_preflight_and_refusal_paths_at_world_1(lo, dev, tmp_path):
         import ctypes as C
         R = lo._lib.rccl_lib()
         raw = (C.c_ubyte * lo._lib.RCCL_ID_BYTES)()
-        assert R.mxlo_rccl_unique_id(raw) == 0
+        if os.environ.get("MXLO_TEST_BAD_ID") == "1":
+            raw[:] = [0x5A] * lo._lib.RCCL_ID_BYTES                 # a unique id nobody issued
+        else:
+            assert R.mxlo_rccl_unique_id(raw) == 0
         try:
             lo.sharded.NativeRcclHook(0, 2, timeout_s=4.0, unique_id=bytes(raw))   # world 2, nobody else: bootstrap waits for rank 1
             print("UNEXPECTED: returned", flush=True)
@@ -251,11 +254,12 @@ def test_transport_preflight_and_refusal_paths_at_world_1(lo, dev, tmp_path):
             print("REFUSED: %%r" %% (e,), flush=True)
         os._exit(0)
     ''') % ROOT)
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", NCCL_SOCKET_IFNAME="lo")
-    p = subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
-    try:
-        out = p.communicate(timeout=180)[0]
-    except subprocess.TimeoutExpired:
-        p.kill()
-        raise AssertionError("a 2-rank communicator with one rank missing hung the caller")
-    assert "TIMEOUT-REPORTED" in out or "REFUSED" in out, out
+    for bad_id in ("0", "1"):                   # a rank that never joins; then a unique id nobody issued
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", NCCL_SOCKET_IFNAME="lo", MXLO_TEST_BAD_ID=bad_id)
+        p = subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        try:
+            out = p.communicate(timeout=180)[0]
+        except subprocess.TimeoutExpired:
+            p.kill()
+            raise AssertionError("a 2-rank communicator that cannot form (bad_id=%s) hung the caller" % bad_id)
+        assert "TIMEOUT-REPORTED" in out or "REFUSED" in out, (bad_id, out)

@@ -306,6 +306,13 @@ int32_t mxlo_householder_apply(mxlo_ctx *ctx, int32_t dtype, void *res, const vo
 int32_t mxlo_hermitian_mul(mxlo_ctx *ctx, int32_t dtype, void *res, const void *d,
                            const void *A, int64_t lda, const void *v, int64_t n, double alpha,
                            double beta, int32_t flags);
+/* The same operator applied to the k columns of a matrix — `mul!(res::Matrix, opHermitian(d, A), V::Matrix, α, β)`
+ * (src/operations.jl:34-36 loops mulHermitian! over the columns): res[:, c] = α((d .* V[:, c] + L V[:, c]) + L' V[:, c]) + β res[:, c].
+ * The strict lower triangle is read ONCE per chunk of up to 4 columns instead of once per column (block Krylov shapes);
+ * per column the arithmetic and the order of every addition are those of mxlo_hermitian_mul, so the block apply is
+ * BIT-IDENTICAL to k single applies. res, V: column-major with leading dimensions ldr, ldv >= n. Float64 / Float32. */
+int32_t mxlo_hermitian_mul_block(mxlo_ctx *ctx, int32_t dtype, void *res, int64_t ldr, const void *d, const void *A, int64_t lda,
+                                 const void *V, int64_t ldv, int64_t n, int64_t k, double alpha, double beta, int32_t flags);
 
 /* mulRestrict! — src/special-operators.jl:167-169: res .= view(v, I); alpha and
  * beta are IGNORED by the reference and are therefore not parameters.

@@ -266,13 +266,28 @@ Base.:+(op::LinearOperator{T, MXVector{T}}, x::Number) where {T} = op + x * ones
 Base.:+(x::Number, op::LinearOperator{T, MXVector{T}}) where {T} = x * ones_like(op) + op
 
 # ---- a6 opHermitian (src/linalg.jl:97-127): the ORIGINAL matrix is passed; only tril(A,-1) is read ------------
+# A callable rather than a closure, so that `mul!` on MATRICES (src/operations.jl:34-36: the reference closure handles a matrix
+# through broadcasting and mul!(res, L, V, …)) can dispatch to the block entry point: the strict lower triangle is read once per
+# 4 columns and every column gets the bits of the single apply.
+struct HermApply{T}
+  d::MXVector{T}
+  A::MXMatrix{T}
+end
+(f::HermApply{T})(res::MXVector{T}, v::MXVector{T}, α, β) where {T <: RealT} = check(ccall((:mxlo_hermitian_mul, lib), Int32,
+    (P, Int32, P, P, P, Int64, P, Int64, Float64, Float64, Int32),
+    ctx(), dt(T), res.ptr, f.d.ptr, f.A.data.ptr, f.A.m, v.ptr, f.A.n, α, β, flags(T, α, β)))
+(f::HermApply{T})(res::MXMatrix{T}, V::MXMatrix{T}, α, β) where {T <: RealT} = check(ccall((:mxlo_hermitian_mul_block, lib), Int32,
+    (P, Int32, P, Int64, P, P, Int64, P, Int64, Int64, Int64, Float64, Float64, Int32),
+    ctx(), dt(T), res.data.ptr, res.m, f.d.ptr, f.A.data.ptr, f.A.m, V.data.ptr, V.m, f.A.n, size(V, 2), α, β, flags(T, α, β)))
+function apply_columns(f::HermApply{T}, res::MXMatrix{T}, m::MXMatrix{T}, α, β) where {T <: RealT}     # one call for the block
+  size(res, 2) == size(m, 2) || throw(LinearOperatorException("shape mismatch"))
+  f(res, m, α, β)
+  res
+end
 function opHermitian(d::MXVector{T}, A::MXMatrix{T}) where {T <: RealT}
   m, n = size(A)
   m == n == length(d) || throw(LinearOperatorException("shape mismatch"))
-  prod! = (res, v, α, β) -> check(ccall((:mxlo_hermitian_mul, lib), Int32,
-      (P, Int32, P, P, P, Int64, P, Int64, Float64, Float64, Int32),
-      ctx(), dt(T), res.ptr, d.ptr, A.data.ptr, m, v.ptr, n, α, β, flags(T, α, β)))
-  LinearOperator{T, MXVector{T}}(m, m, true, true, prod!, nothing, nothing)
+  LinearOperator{T, MXVector{T}}(m, m, true, true, HermApply{T}(d, A), nothing, nothing)
 end
 
 # complex A (test/test_linop.jl:360-370: ComplexF64 A, d = real.(diag(A))): L' is the conjugate transpose, symmetric =

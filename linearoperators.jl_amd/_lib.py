@@ -134,6 +134,7 @@ _PROTOS = {
     "mxlo_dot": [_vp, _i32, _vp, _vp, _i64, _vp],
     "mxlo_householder_apply": [_vp, _i32, _vp, _vp, _vp, _i64, _dbl, _dbl, _i32, _vp],
     "mxlo_hermitian_mul": [_vp, _i32, _vp, _vp, _vp, _i64, _vp, _i64, _dbl, _dbl, _i32],
+    "mxlo_hermitian_mul_block": [_vp, _i32, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _i64, _i64, _dbl, _dbl, _i32],
     "mxlo_gather": [_vp, _i32, _vp, _vp, _i64, _vp, _i64],
     "mxlo_gather_range": [_vp, _i32, _vp, _vp, _i64, _i64, _i64, _i64],
     "mxlo_scatter_zero": [_vp, _i32, _vp, _i64, _vp, _vp, _vp, _i64],

@@ -836,10 +836,14 @@ __device__ __forceinline__ void herm_put(double *p, double v, bool slot) {
   }
 }
 
-template <typename T, int C, bool EDGE, bool DSEL = false, bool SLOT = false>
+// KV > 1 (round 5, the block apply mxlo_hermitian_mul_block): the tile is loaded ONCE and applied to KV vectors — vector kk
+// is v + kk * ldv, its partials live KV buffers apart (pstride doubles). Per vector the arithmetic, the butterfly and the
+// order of every addition are those of KV = 1: a block apply is bit-identical to KV single applies.
+template <typename T, int C, bool EDGE, bool DSEL = false, bool SLOT = false, int KV = 1>
 __device__ __forceinline__ void
 herm_strip_body(const T *__restrict__ A, int64_t lda, const T *__restrict__ v, int64_t n,
-                double *__restrict__ Prow, double *__restrict__ Pcol, int64_t ng, int qint, int mode, int64_t t) {
+                double *__restrict__ Prow, double *__restrict__ Pcol, int64_t ng, int qint, int mode, int64_t t,
+                int64_t ldv = 0, int64_t pstride = 0) {
   constexpr int RPL = HermCfg<T>::RPL, HR = HermCfg<T>::HR, DT = HermCfg<T>::DT;
   typedef T VR __attribute__((ext_vector_type(RPL)));
   constexpr int HS = C;
@@ -872,12 +876,14 @@ herm_strip_body(const T *__restrict__ A, int64_t lda, const T *__restrict__ v, i
   const int cg = __builtin_amdgcn_readfirstlane(tid >> 7);          // columns cg + 2k, k < 16, of each tile
   const int half = __builtin_amdgcn_readfirstlane((tid >> 6) & 1);  // which 64*RPL rows this wave covers
   const int64_t gr = i0 + RPL * rp;
-  double vr[RPL], prow[RPL];
+  double vr[KV][RPL], prow[KV][RPL];
 #pragma unroll
-  for (int r = 0; r < RPL; ++r) {
-    vr[r] = (!EDGE || gr + r < n) ? (double)v[gr + r] : 0.0;
-    prow[r] = 0.0;
-  }
+  for (int kk = 0; kk < KV; ++kk)
+#pragma unroll
+    for (int r = 0; r < RPL; ++r) {
+      vr[kk][r] = (!EDGE || gr + r < n) ? (double)v[gr + r + kk * ldv] : 0.0;
+      prow[kk][r] = 0.0;
+    }
 #pragma unroll 1
   for (int jt = 0; jt < HS; ++jt) {
     const int64_t j0 = (tile0 + jt) * HC;
@@ -911,21 +917,25 @@ herm_strip_body(const T *__restrict__ A, int64_t lda, const T *__restrict__ v, i
     // column partials of this tile: block of column group Gc = j0/HR, row half 2G + half (offset so that + gc indexes it)
     const int64_t Gc = j0 / HR;
     const int64_t pcol0 = herm_col_base<HR>(Gc, ng) + (2 * G + half - 2 * Gc) * HR - Gc * HR;
+#pragma unroll
+   for (int kk = 0; kk < KV; ++kk) {          // fully unrolled: kk is a compile-time index into prow / vr (KV = 1: a single trip)
+    const T *vk = v + kk * ldv;
+    double *Pck = Pcol + kk * pstride;
     // FMAs + first butterfly stage, column pair (q, q+8) at a time (keeps the live set small)
     const bool hi = (lane & 32) != 0;
     double w8[8], w4[4], w2[2], w1;
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
       const int64_t ca = j0 + cg + 2 * q, cb = ca + 16;
-      const double vca = (!EDGE || ca < n) ? (double)v[ca] : 0.0, vcb = (!EDGE || cb < n) ? (double)v[cb] : 0.0;
+      const double vca = (!EDGE || ca < n) ? (double)vk[ca] : 0.0, vcb = (!EDGE || cb < n) ? (double)vk[cb] : 0.0;
       double pa = 0.0, pb = 0.0;
 #pragma unroll
       for (int r = 0; r < RPL; ++r) {
         const double a = (double)e[q][r], b = (double)e[q + 8][r];
-        prow[r] = fma(a, vca, prow[r]);
-        prow[r] = fma(b, vcb, prow[r]);
-        pa = r == 0 ? a * vr[0] : fma(a, vr[r], pa);
-        pb = r == 0 ? b * vr[0] : fma(b, vr[r], pb);
+        prow[kk][r] = fma(a, vca, prow[kk][r]);
+        prow[kk][r] = fma(b, vcb, prow[kk][r]);
+        pa = r == 0 ? a * vr[kk][0] : fma(a, vr[kk][r], pa);
+        pb = r == 0 ? b * vr[kk][0] : fma(b, vr[kk][r], pb);
       }
       w8[q] = (hi ? pb : pa) + __shfl_xor(hi ? pa : pb, 32, 64);
       __builtin_amdgcn_sched_barrier(0);
@@ -957,17 +967,22 @@ herm_strip_body(const T *__restrict__ A, int64_t lda, const T *__restrict__ v, i
     if ((lane & 3) == 0) {
       const int k = ((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1);
       const int64_t gc = j0 + cg + 2 * k;
-      if (!EDGE || gc < n) herm_put(Pcol + pcol0 + gc, w1, SLOT);
+      if (!EDGE || gc < n) herm_put(Pck + pcol0 + gc, w1, SLOT);
     }
+   }
   }
-  __shared__ double rowred[2][HR];
+  __shared__ double rowred[KV][2][HR];
 #pragma unroll
-  for (int r = 0; r < RPL; ++r) rowred[cg][RPL * rp + r] = prow[r];
+  for (int kk = 0; kk < KV; ++kk)
+#pragma unroll
+    for (int r = 0; r < RPL; ++r) rowred[kk][cg][RPL * rp + r] = prow[kk][r];
   __syncthreads();
-  for (int tt = tid; tt < HR; tt += kBlock) {
-    const int64_t row = i0 + tt;
-    if (row < n) herm_put(Prow + herm_row_base<HR, DT>(G, qint) + slot * HR + tt, rowred[0][tt] + rowred[1][tt], SLOT);
-  }
+#pragma unroll
+  for (int kk = 0; kk < KV; ++kk)
+    for (int tt = tid; tt < HR; tt += kBlock) {
+      const int64_t row = i0 + tt;
+      if (row < n) herm_put(Prow + kk * pstride + herm_row_base<HR, DT>(G, qint) + slot * HR + tt, rowred[kk][0][tt] + rowred[kk][1][tt], SLOT);
+    }
 }
 
 // ONE launch for everything that can use unmasked 16-byte loads (aligned A): workgroups [0, n_int) run the interior
@@ -996,6 +1011,28 @@ herm_edge_kernel(const T *__restrict__ A, int64_t lda, const T *__restrict__ v, 
   if (t < n_last) return herm_strip_body<T, C, true>(A, lda, v, n, Prow, Pcol, ng, qint, 1, t);
   t -= n_last;
   herm_strip_body<T, 1, true>(A, lda, v, n, Prow, Pcol, ng, qint, 2, t + HermCfg<T>::DT * g0);
+}
+
+// The same two launches for a BLOCK of KV vectors (mxlo_hermitian_mul_block): every tile of the triangle is read once.
+template <typename T, int C, int KV>
+__global__ void __launch_bounds__(kBlock)
+herm_pass_block_kernel(const T *__restrict__ A, int64_t lda, const T *__restrict__ v, int64_t ldv, int64_t n,
+                       double *__restrict__ Prow, double *__restrict__ Pcol, int64_t pstride, int64_t ng, int qint, int64_t n_int) {
+  const int64_t t = blockIdx.x;
+  if (t < n_int) return herm_strip_body<T, C, false, false, false, KV>(A, lda, v, n, Prow, Pcol, ng, qint, 0, t, ldv, pstride);
+  herm_strip_body<T, 1, false, true, false, KV>(A, lda, v, n, Prow, Pcol, ng, qint, 2, t - n_int, ldv, pstride);
+}
+template <typename T, int C, int KV>
+__global__ void __launch_bounds__(kBlock)
+herm_edge_block_kernel(const T *__restrict__ A, int64_t lda, const T *__restrict__ v, int64_t ldv, int64_t n,
+                       double *__restrict__ Prow, double *__restrict__ Pcol, int64_t pstride, int64_t ng, int qint, int64_t n_all,
+                       int64_t n_last, int64_t g0) {
+  int64_t t = blockIdx.x;
+  if (t < n_all) return herm_strip_body<T, C, true, false, false, KV>(A, lda, v, n, Prow, Pcol, ng, qint, 0, t, ldv, pstride);
+  t -= n_all;
+  if (t < n_last) return herm_strip_body<T, C, true, false, false, KV>(A, lda, v, n, Prow, Pcol, ng, qint, 1, t, ldv, pstride);
+  t -= n_last;
+  herm_strip_body<T, 1, true, false, false, KV>(A, lda, v, n, Prow, Pcol, ng, qint, 2, t + HermCfg<T>::DT * g0, ldv, pstride);
 }
 
 // 32 rows per workgroup, 8 lanes per row: lane `sub` adds partials sub, sub+8, ... (independent loads in
@@ -1114,6 +1151,16 @@ herm_finish_kernel(T *__restrict__ res, const T *__restrict__ d, const T *__rest
                    double *__restrict__ Prow, double *__restrict__ Pcol, int64_t n, int ng,
                    int q, CA alpha, CB beta) {
   herm_finish_body<T, CA, CB, BETA0, FR, false>(res, d, v, Prow, Pcol, n, ng, q, alpha, beta, (int64_t)blockIdx.x, 0ull, nullptr);
+}
+
+template <typename T, typename CA, typename CB, bool BETA0, int FR>
+__global__ void __launch_bounds__(kBlock)
+herm_finish_block_kernel(T *__restrict__ res, int64_t ldr, const T *__restrict__ d, const T *__restrict__ v, int64_t ldv,
+                         double *__restrict__ Prow, double *__restrict__ Pcol, int64_t pstride, int64_t n, int ng, int q, CA alpha,
+                         CB beta) {
+  const int64_t kk = blockIdx.y;
+  herm_finish_body<T, CA, CB, BETA0, FR, false>(res + kk * ldr, d, v + kk * ldv, Prow + kk * pstride, Pcol + kk * pstride, n, ng, q, alpha,
+                                                beta, (int64_t)blockIdx.x, 0ull, nullptr);
 }
 
 // The WHOLE apply in one launch (round 5; n a multiple of the row-group height, aligned A, n <= herm_single_max_n):
@@ -1239,6 +1286,74 @@ int32_t hermitian_t(mxlo_ctx *ctx, T *res, const T *d, const T *A, int64_t lda, 
     MXLO_LAUNCH_CHECK();
     return MXLO_OK;
   });
+}
+
+// res[:, c] = alpha * ((d .* V[:, c] + L V[:, c]) + L' V[:, c]) + beta * res[:, c], c < k — mulHermitian! (src/linalg.jl:97-103)
+// applied to the columns of a matrix (src/operations.jl:34-36), the strict lower triangle read ONCE per chunk of up to 4
+// columns instead of once per column. Same launch geometry, partial layout and summation order as hermitian_t per column.
+template <typename T>
+int32_t hermitian_block_t(mxlo_ctx *ctx, T *res, int64_t ldr, const T *d, const T *A, int64_t lda, const T *V, int64_t ldv,
+                          int64_t n, int64_t k, double alpha, double beta, int32_t flags) {
+  if (n == 0 || k == 0) return MXLO_OK;
+  constexpr int HR = HermCfg<T>::HR, DT = HermCfg<T>::DT, RPL = HermCfg<T>::RPL;
+  const int64_t ng = (n + HR - 1) / HR, ngf = n / HR;
+  MXLO_REQUIRE(4 * ng * (ng + 1) < (1LL << 31), MXLO_ESHAPE, "opHermitian: n too large");
+  const int64_t pairs = ng * (ng - 1) / 2;
+  const int C = (DT / 8) * pairs >= 2 * ctx->num_cu ? 8 : ((DT / 2) * pairs >= 2 * ctx->num_cu ? 2 : 1), Q = DT / C;
+  const int64_t prow_len = herm_row_base<HR, DT>(ng, Q), pcol_len = herm_col_base<HR>(ng, ng);
+  const int64_t pstride = prow_len + pcol_len;
+  constexpr int KVMAX = 4;
+  MXLO_TRY(ensure_scratch(ctx, sizeof(double) * (size_t)pstride * KVMAX, "opHermitian block"));
+  double *Prow = (double *)ctx->scratch, *Pcol = Prow + prow_len;
+  const bool aligned = (((uintptr_t)A & 15u) == 0) && (lda % RPL == 0);
+  const int64_t gi = aligned ? ngf : 0;
+  const int64_t n_int = gi > 1 ? Q * gi * (gi - 1) / 2 : 0;
+  const int64_t n_dsel = (int64_t)DT * gi;
+  const int64_t n_all = !aligned && ng > 1 ? Q * ng * (ng - 1) / 2 : 0;
+  const int64_t n_last = aligned && ng > ngf ? Q * (ng - 1) : 0;
+  const int64_t n_diag = (int64_t)DT * (ng - gi);
+  const int64_t n_light = n_int + n_dsel, n_edge = n_all + n_last + n_diag;
+  MXLO_REQUIRE(n_light < (1LL << 31) && n_edge < (1LL << 31), MXLO_ESHAPE, "opHermitian: n too large");
+  int64_t done = 0;
+  while (done < k) {
+    const int64_t left = k - done;
+    const int kv = left >= 4 ? 4 : (left >= 2 ? 2 : 1);
+    T *r = res + done * ldr;
+    const T *v = V + done * ldv;
+    if (kv == 1) {
+      MXLO_TRY(hermitian_t<T>(ctx, r, d, A, lda, v, n, alpha, beta, flags));
+      Prow = (double *)ctx->scratch;           // (hermitian_t may have grown the workspace — it cannot: ours is KVMAX times larger)
+      Pcol = Prow + prow_len;
+      done += 1;
+      continue;
+    }
+    auto launch = [&]<int C_, int KV_>() -> int32_t {
+      if (n_light > 0) {
+        hipLaunchKernelGGL((herm_pass_block_kernel<T, C_, KV_>), dim3((unsigned)n_light), dim3(kBlock), 0, ctx->stream, A, lda, v, ldv, n,
+                           Prow, Pcol, pstride, ng, Q, n_int);
+        MXLO_LAUNCH_CHECK();
+      }
+      if (n_edge > 0) {
+        hipLaunchKernelGGL((herm_edge_block_kernel<T, C_, KV_>), dim3((unsigned)n_edge), dim3(kBlock), 0, ctx->stream, A, lda, v, ldv, n,
+                           Prow, Pcol, pstride, ng, Q, n_all, n_last, gi);
+        MXLO_LAUNCH_CHECK();
+      }
+      return MXLO_OK;
+    };
+    auto by_c = [&]<int KV_>() -> int32_t {
+      return C == 8 ? launch.template operator()<8, KV_>() : (C == 2 ? launch.template operator()<2, KV_>() : launch.template operator()<1, KV_>());
+    };
+    MXLO_TRY(kv == 4 ? by_c.template operator()<4>() : by_c.template operator()<2>());
+    constexpr int FR = 32;
+    MXLO_TRY((dispatch_ab<T>(beta, flags, [&]<typename CA, typename CB, bool B0>() -> int32_t {
+      hipLaunchKernelGGL((herm_finish_block_kernel<T, CA, CB, B0, FR>), dim3((unsigned)((n + FR - 1) / FR), (unsigned)kv), dim3(kBlock), 0,
+                         ctx->stream, r, ldr, d, v, ldv, Prow, Pcol, pstride, n, (int)ng, Q, (CA)alpha, (CB)beta);
+      MXLO_LAUNCH_CHECK();
+      return MXLO_OK;
+    })));
+    done += kv;
+  }
+  return MXLO_OK;
 }
 
 // kron(opA, opB) * x with opA = A or A^T, opB = B or B^T of the STORED column-major matrices (src/kron.jl:14-40):
@@ -1523,6 +1638,23 @@ MXLO_API int32_t mxlo_hermitian_mul(mxlo_ctx *ctx, int32_t dtype, void *res, con
   if (dtype == MXLO_F64)
     return hermitian_t<double>(ctx, (double *)res, (const double *)d, (const double *)A, lda, (const double *)v, n, alpha, beta, flags);
   return hermitian_t<float>(ctx, (float *)res, (const float *)d, (const float *)A, lda, (const float *)v, n, alpha, beta, flags);
+}
+
+MXLO_API int32_t mxlo_hermitian_mul_block(mxlo_ctx *ctx, int32_t dtype, void *res, int64_t ldr, const void *d, const void *A, int64_t lda,
+                                          const void *V, int64_t ldv, int64_t n, int64_t k, double alpha, double beta, int32_t flags) {
+  MXLO_REQUIRE(ctx, MXLO_EINVAL, "mxlo_hermitian_mul_block: ctx is NULL");
+  MXLO_DEVICE_GUARD(ctx);
+  MXLO_REQUIRE(n >= 0 && k >= 0, MXLO_ESHAPE, "mxlo_hermitian_mul_block: negative size");
+  if (n == 0 || k == 0) return MXLO_OK;
+  MXLO_REQUIRE(res && d && A && V, MXLO_EINVAL, "mxlo_hermitian_mul_block: NULL operand");
+  MXLO_REQUIRE(lda >= n && ldr >= n && ldv >= n, MXLO_ESHAPE, "mxlo_hermitian_mul_block: a leading dimension is smaller than n");
+  eff_ab(dtype, flags, alpha, beta);
+  if (dtype == MXLO_F64)
+    return hermitian_block_t<double>(ctx, (double *)res, ldr, (const double *)d, (const double *)A, lda, (const double *)V, ldv, n, k, alpha, beta, flags);
+  if (dtype == MXLO_F32)
+    return hermitian_block_t<float>(ctx, (float *)res, ldr, (const float *)d, (const float *)A, lda, (const float *)V, ldv, n, k, alpha, beta, flags);
+  set_error("mxlo_hermitian_mul_block: dtype %d (Float64 / Float32 only; complex blocks take the column loop)", dtype);
+  return MXLO_EINVAL;
 }
 
 MXLO_API int32_t mxlo_kron_mul_ex(mxlo_ctx *ctx, int32_t dtype, void *res, const void *A, int64_t am, int64_t an,

@@ -384,7 +384,18 @@ def opHermitian(*args):
     if A.dtype != U:
         A = _colmajor(A.to(U))
     dtype_code(U)
-    prod = lambda res, v, a, b: mulHermitian(res, d, A, v, a, b)
+    # on matrices the reference closure works column by column through broadcasting and mul!(res, L, V, …)
+    # (src/linalg.jl:97-103): one mulHermitian per column — or, for a block on the device, the block entry point, which
+    # reads the triangle once per 4 columns and gives the same bits as the column loop
+    prod = columnwise(lambda res, v, a, b: mulHermitian(res, d, A, v, a, b))
+
+    def herm_block(res, V, a, b):
+        if res.dtype != U or V.dtype != U:
+            raise TypeError(f"mul! on matrices: {res.dtype} / {V.dtype} operands next to a {U} operator")
+        ctx = get_ctx(res.device)
+        _lib.call("mxlo_hermitian_mul_block", ctx.handle, dtype_code(U), ptr(res), _ld(res), ptr(d), ptr(A), A.stride(1), ptr(V), _ld(V),
+                  m, V.shape[1], float(a), float(b), scalar_flags(res.dtype, a, b))
+    prod._matrix = herm_block
     op = LinearOperator(U, m, m, True, True, prod, None, None, S=Storage(U, A.device))
     op._deps = (d, A)
     return op

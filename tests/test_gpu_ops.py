@@ -106,6 +106,50 @@ def test_hermitian_strip_regimes(lo, dev, dtype, n):
     assert torch.equal(res2, res3)
 
 
+@pytest.mark.parametrize("n,dtype", [(7, torch.float64), (300, torch.float64), (1024, torch.float32), (2051, torch.float64),
+                                     (5700, torch.float64), (5889, torch.float32), (11776, torch.float64), (4096, torch.float64)])
+def test_hermitian_block_apply_is_bit_identical_to_the_column_loop(lo, dev, n, dtype):
+    """Round 5: `mul!(res::Matrix, opHermitian(d, A), V::Matrix, α, β)` — the reference's closure applied
+    to the columns of a matrix (src/linalg.jl:97-103 through src/operations.jl:34-36) — reads the strict lower triangle ONCE
+    per chunk of up to 4 columns (mxlo_hermitian_mul_block). Per column the arithmetic and every addition order are those
+    of the single apply: bit-identical to the column loop for k = 1 … 7 (chunks of 4, 2 and 1), every strip regime, ragged
+    and unaligned shapes (odd leading dimensions of A, V and res), α / β forms, NaN above the diagonal; and against the
+    oracle."""
+    from linearoperators_jl_amd.device import get_ctx
+    ctx = get_ctx(dev)
+    npd = NP[dtype]
+    rng = np.random.default_rng(n)
+    A = rng.standard_normal((n, n)).astype(npd)
+    A[np.triu_indices(n)] = np.nan
+    d = rng.standard_normal(n).astype(npd)
+    tol = 1e-12 if dtype == torch.float64 else 3e-5
+    fl = oracle.SCALARS_F64 if dtype == torch.float32 else 0
+
+    def cm(X, pad):                                                # column-major device matrix, leading dimension n + pad
+        big = torch.zeros(X.shape[1], X.shape[0] + pad, dtype=dtype, device=dev)
+        big[:, :X.shape[0]] = T(np.ascontiguousarray(X.T), dev)
+        return big[:, :X.shape[0]].t()
+
+    ctx.tune("herm_single", 0)                                     # the column loop below must be the same two-launch form
+    try:
+        for k, pad, (a, b) in ((1, 0, (1.0, 0.0)), (2, 1, (2.0, -3.0)), (3, 0, (1.0, 0.0)), (4, 2, (1.5, 0.5)), (7, 1, (2.0, -3.0))):
+            H = lo.opHermitian(T(d, dev), cm(A, pad % 2))
+            Vh, R0 = rng.standard_normal((n, k)).astype(npd), rng.standard_normal((n, k)).astype(npd)
+            Vd = cm(Vh, pad)
+            res = cm(R0, pad)
+            lo.mul(res, H, Vd, a, b)                               # the block entry point
+            cols = cm(R0, 0)
+            for j in range(k):
+                lo.mul(cols[:, j], H, Vd[:, j].contiguous(), a, b)
+            assert torch.equal(res, cols), (n, k, pad)
+            want = np.stack([oracle.hermitian_mul(R0[:, j].copy(), d, np.tril(A, -1), Vh[:, j].copy(), a, b, flags=fl) for j in range(k)], axis=1)
+            assert rel(res.cpu().numpy(), want) <= tol, (n, k)
+    finally:
+        ctx.tune("herm_single", 1)
+    with pytest.raises(lo.LinearOperatorException):
+        lo.mul(torch.empty(n, 2, dtype=dtype, device=dev), H, torch.empty(n, 3, dtype=dtype, device=dev), 1.0, 0.0)
+
+
 def test_hermitian_single_launch_is_bit_identical_to_the_two_launch_form(lo, dev):
     """Round 5: for full row groups of an aligned matrix (n a multiple of 256 / 512, n <= 8192)
     opHermitian is ONE launch — strip workgroups publish their partials as self-validating slots, finisher workgroups of

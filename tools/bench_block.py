@@ -38,3 +38,19 @@ for dt, es in ((torch.float64, 8), (torch.float32, 4)):
                 print(f"{str(dt)[6:]} n={n:6d} k={k} {name:5s}: block {tb:8.1f} us = {es*n*n/tb/1e3:6.0f} GB/s of M ({es*n*n/tb/1e3/8000:5.3f}),"
                       f" {k} GEMVs {tc:8.1f} us  -> x{tc/tb:4.2f}", flush=True)
         del M, op
+
+# opHermitian on a block of k vectors: mxlo_hermitian_mul_block (triangle read once per 4 columns) against k single applies
+for dt, es in ((torch.float64, 8), (torch.float32, 4)):
+    for n in (4096, 16384):
+        M = torch.rand(n, n, dtype=dt, device=dev).t()
+        H = lo.opHermitian(torch.rand(n, dtype=dt, device=dev), M)
+        for k in (2, 4, 8):
+            V = torch.rand(k, n, dtype=dt, device=dev).t()
+            R = torch.empty(k, n, dtype=dt, device=dev).t()
+            tb = timeit(lambda: lo.mul(R, H, V))
+            tc = timeit(lambda: [lo.mul(R[:, j], H, V[:, j]) for j in range(k)])
+            tri = es / 2 * n * n
+            passes = (k + 3) // 4 if k >= 4 else 1                  # chunks of up to 4 columns: one pass over the triangle each
+            print(f"{str(dt)[6:]} n={n:6d} k={k} opHermitian: block {tb:8.1f} us ({passes} pass(es) over the triangle: {tri*passes/tb/1e3:6.0f} GB/s),"
+                  f" {k} single applies {tc:8.1f} us  -> x{tc/tb:4.2f}", flush=True)
+        del M, H

@@ -468,7 +468,7 @@ def test_shifted_operator(lo, dev):
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-12), (torch.float32, 3e-5)])
-@pytest.mark.parametrize("m,n", [(1000, 777), (513, 2050), (64, 3), (2, 5000), (4099, 133), (2050, 64), (8192, 31)])   # round 5: tall enough for the LDS-staged transposed form
+@pytest.mark.parametrize("m,n", [(1000, 777), (513, 2050), (64, 3), (2, 5000), (4099, 133), (2050, 64), (8192, 31), (8200, 300)])   # round 5: tall enough for the LDS-staged transposed form
 @pytest.mark.parametrize("k", [2, 3, 5, 8, 11])
 def test_block_gemv_vs_columns_and_dense(lo, dev, dtype, tol, m, n, k):
     """mul!(res::Matrix, LinearOperator(M), V::Matrix, α, β) through mxlo_gemv_block (M read once per 8 columns) against

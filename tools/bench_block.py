@@ -25,7 +25,13 @@ def timeit(fn, reps=10):
     return tm.elapsed_ms() / reps * 1e3
 
 
+for key in ("gemvb_t_lds",):
+    if os.environ.get("MXLO_" + key.upper()) is not None:
+        get_ctx(dev).tune(key, int(os.environ["MXLO_" + key.upper()]))
+        print(f"# {key} = {os.environ['MXLO_' + key.upper()]}")
 for dt, es in ((torch.float64, 8), (torch.float32, 4)):
+    if os.environ.get("MXLO_BLOCK_ONLY_DENSE64") and dt != torch.float64:
+        continue
     for n in (4096, 16384):
         M = torch.rand(n, n, dtype=dt, device=dev).t()
         op = lo.LinearOperatorFromMatrix(M)
@@ -39,6 +45,8 @@ for dt, es in ((torch.float64, 8), (torch.float32, 4)):
                       f" {k} GEMVs {tc:8.1f} us  -> x{tc/tb:4.2f}", flush=True)
         del M, op
 
+if os.environ.get("MXLO_BLOCK_ONLY_DENSE64"):
+    sys.exit(0)
 # opHermitian on a block of k vectors: mxlo_hermitian_mul_block (triangle read once per 4 columns) against k single applies
 for dt, es in ((torch.float64, 8), (torch.float32, 4)):
     for n in (4096, 16384):

@@ -78,10 +78,10 @@ peer_exchange_kernel(KArgs A, double *__restrict__ buf, int count, unsigned long
         const int d = idx / count, t = idx - d * count;
         st_sys(A.mb[d] + set_off + (size_t)me * kSlotWords + kHeaderWords + t, (unsigned long long)__double_as_longlong(buf[t]));
       }
-      __threadfence_system();            // every payload store has left this lane ...
-      __syncthreads();                   // ... for all lanes, before any sequence word is published
-      if (tid < world)
-        __hip_atomic_store(A.mb[tid] + set_off + (size_t)me * kSlotWords, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      __threadfence_system();            // every payload store of this lane is visible system-wide ...
+      __syncthreads();                   // ... for ALL lanes, before any sequence word is published: the publishing store
+      if (tid < world)                   // itself can then be relaxed (one fence per lane, not two)
+        __hip_atomic_store(A.mb[tid] + set_off + (size_t)me * kSlotWords, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
   }
   if (phase & 2) {
@@ -92,7 +92,7 @@ peer_exchange_kernel(KArgs A, double *__restrict__ buf, int count, unsigned long
       const unsigned long long *w = A.mb[me] + set_off + (size_t)tid * kSlotWords;
       unsigned long long t0 = 0;
       unsigned it = 0;
-      while (__hip_atomic_load(w, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != seq) {
+      while (__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != seq) {   // relaxed polls, ONE acquire fence below
         __builtin_amdgcn_s_sleep(2);
         if ((++it & 63u) == 0) {
           const unsigned long long now = (unsigned long long)wall_clock64();
@@ -105,6 +105,7 @@ peer_exchange_kernel(KArgs A, double *__restrict__ buf, int count, unsigned long
         }
       }
     }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);   // (system scope) the payloads behind the sequence words seen above
     __syncthreads();
     const bool failed = bad != 0;
     for (int t = tid; t < count; t += 256) {

@@ -1076,7 +1076,17 @@ def bench_misc(lo, torch, dev, ctx):
                 ms = timeit(lambda: lo.mul(Rb, opM, Vb), 10)
                 out["dense_block_mul_n16384_k8"] = {"us": round(ms * 1e3, 1), "GB/s(8n^2 B, M once)": round(8.0 * nn * nn / ms / 1e6, 1),
                                                     "frac_hbm_peak": round(8.0 * nn * nn / ms / 1e6 / HBM_PEAK_GBS, 4)}
-                del opM, Vb, Rb
+                Ub = torch.rand(8, nn, dtype=torch.float64, device=dev, generator=gen).t()
+                Rt = torch.empty(8, nn, dtype=torch.float64, device=dev).t()
+                ms = timeit(lambda: lo.mul(Rt, opM.T, Ub), 10)           # round 5: the block staged in LDS per workgroup
+                out["dense_block_transpose_mul_n16384_k8"] = {"us": round(ms * 1e3, 1), "GB/s(8n^2 B, M once)": round(8.0 * nn * nn / ms / 1e6, 1),
+                                                              "frac_hbm_peak": round(8.0 * nn * nn / ms / 1e6 / HBM_PEAK_GBS, 4)}
+                V4 = torch.rand(4, nn, dtype=torch.float64, device=dev, generator=gen).t()
+                R4 = torch.empty(4, nn, dtype=torch.float64, device=dev).t()
+                ms = timeit(lambda: lo.mul(R4, Hm, V4), 10)              # round 5: the triangle read once for 4 vectors
+                out["opHermitian_block_n16384_k4"] = {"us": round(ms * 1e3, 1), "x_vs_4_single_applies": round(4 * out[f"opHermitian_n{nn}"]["us"] / (ms * 1e3), 2),
+                                                      "frac_hbm_peak(triangle once)": round(4.0 * nn * nn / ms / 1e6 / HBM_PEAK_GBS, 4)}
+                del opM, Vb, Rb, Ub, Rt, V4, R4
             except Exception as e:           # an extra must never cost the line
                 out["dense_block_error"] = repr(e)
         del M, Hm
@@ -1125,6 +1135,20 @@ def bench_misc(lo, torch, dev, ctx):
                 ctx.tune("qn_fused_small", 1)
             out[f"{kind}_m5_n2^12_apply_latency"] = {"us_single_launch": round(us, 2), "us_four_launches": round(us4, 2)}
             del op
+        # quasi-Newton applies at cache-resident sizes (round 5: ONE persistent launch; (4m + 3) * 8 B per element against 8 TB/s)
+        mid = {}
+        for kind, make in (("InverseLBFGS", lo.InverseLBFGSOperator), ("LBFGS", lo.LBFGSOperator)):
+            for mm, ee in ((5, 20), (10, 20), (10, 21), (20, 20)):
+                nm = 1 << ee
+                op = make(torch.float64, nm, mem=mm, device=dev)
+                for _ in range(mm + 1):
+                    s_ = torch.rand(nm, dtype=torch.float64, device=dev, generator=gen) * 2 - 1
+                    lo.push(op, s_, s_ * (torch.rand(nm, dtype=torch.float64, device=dev, generator=gen) * 0.25 + 1.25))
+                xs, rs = torch.rand(nm, dtype=torch.float64, device=dev, generator=gen), torch.empty(nm, dtype=torch.float64, device=dev)
+                us = timeit(lambda: lo.mul(rs, op, xs, 1.0, 0.0), 200) * 1e3
+                mid[f"{kind}_m{mm}_n2^{ee}"] = {"us": round(us, 1), "frac_hbm_peak": round((4 * mm + 3) * 8.0 * nm / us / 1e3 / HBM_PEAK_GBS, 4)}
+                del op, xs, rs
+        out["quasi_newton_cache_resident_sizes"] = mid
         nk = 1024
         mkc = lambda: (torch.complex(torch.rand(nk, nk, dtype=torch.float64, device=dev, generator=gen) - 0.5,
                                      torch.rand(nk, nk, dtype=torch.float64, device=dev, generator=gen) - 0.5) / 32).t()

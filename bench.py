@@ -94,7 +94,7 @@ def die(msg: str, code: int = 2):
 PHASE_LIMITS_S = {
     "import + library load": 300, "init_process_group": 300, "communicator creation": 240, "transport preflight": 240,
     "operand set-up": 300, "clock spin-up": 300, "warm-up steps": 300, "timed loop": 300, "per-kernel timing": 300,
-    "quasi-Newton legs": 900, "cfg4 legs": 300, "misc legs": 600, "cpu baseline": 300, "teardown": 120,
+    "quasi-Newton legs": 900, "cfg4 legs": 300, "misc legs": 600, "cpu baseline": 300, "second transport (optional)": 150, "teardown": 120,
 }
 
 
@@ -109,6 +109,7 @@ class Watchdog:
         self.exit_fn = exit_fn or (lambda code: os._exit(code))
         self.cur, self.t0 = None, 0.0
         self.history = []
+        self.rescue = None              # set around an OPTIONAL phase: called instead of exit_fn when that phase stalls
         self.lock = threading.Lock()
         self.dir = os.environ.get("MXLO_BENCH_PHASE_DIR")
         self.th = threading.Thread(target=self._run, daemon=True)
@@ -134,6 +135,8 @@ class Watchdog:
                 print(f"bench.py: WATCHDOG rank {self.rank} has been in phase '{cur}' for {time.time() - t0:.0f} s "
                       f"(limit {limit:.0f} s) — stalled; exiting with status 7", file=sys.stderr, flush=True)
                 self._note(f"STALLED in '{cur}' after {time.time() - t0:.0f} s")
+                if self.rescue is not None:
+                    self.rescue(f"rank {self.rank} stalled in '{cur}' for {time.time() - t0:.0f} s (limit {limit:.0f} s)")
                 self.exit_fn(7)
                 return
 
@@ -313,6 +316,8 @@ def worker(args):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     wd = Watchdog(rank, args.phase_timeout_scale)
+    if os.environ.get("MXLO_BENCH_OPTIONAL_LIMIT_S"):          # test aid: the limit of the optional leg alone
+        wd.limits["second transport (optional)"] = float(os.environ["MXLO_BENCH_OPTIONAL_LIMIT_S"]) / max(args.phase_timeout_scale, 1e-9)
     with wd.phase("import + library load"):
         import torch
         import torch.distributed as dist
@@ -374,7 +379,7 @@ def worker(args):
             if distributed:
                 die(f"rank {rank}: transport preflight failed: {e}", 6)
             transports = {"error": repr(e)[:300]}       # N = 1: informational only (no collective is on the timed path)
-        if distributed and native and not args.no_extras:
+        if distributed and native and (not args.no_extras or args.rehearse_distributed):
             try:   # the second transport: peer-mapped one-shot exchange (csrc/peer.hip), measured below next to RCCL
                 peer_hook = lo.sharded.PeerShmHook(rank, world, timeout_ms=args.preflight_timeout_ms)
                 transports["peer_shm"] = {"latency_us": peer_hook.preflight(ctx.stream, 50, args.preflight_timeout_ms),
@@ -444,30 +449,6 @@ def worker(args):
     ms_per_step = dt / args.steps * 1e3
     bytes_per_step = 40.0 * n * world                   # 16 B/elt dot pass + 24 B/elt update pass
     value = bytes_per_step / (dt / args.steps) / 1e9
-
-    # ---- the same K steps under the SECOND transport (peer-mapped one-shot exchange), N > 1 only: reported next to the
-    # RCCL headline, never as `value`
-    if peer_hook is not None:
-        with wd.phase("timed loop"):
-            try:
-                peer_hook.install(ctx)
-                for _ in range(max(5, args.warmup)):
-                    lo.mul(res, H, v, alpha, beta)
-                barrier()
-                tp0 = time.perf_counter()
-                for _ in range(args.steps):
-                    lo.mul(res, H, v, alpha, beta)
-                barrier()
-                tp = torch.tensor([time.perf_counter() - tp0], dtype=torch.float64, device=dev)
-                dist.all_reduce(tp, op=dist.ReduceOp.MAX)
-                peer_hook.check()
-                transports["peer_shm"]["householder_ms_per_step"] = round(float(tp.item()) / args.steps * 1e3, 4)
-                transports["peer_shm"]["householder_GB/s"] = round(bytes_per_step / (float(tp.item()) / args.steps) / 1e9, 1)
-                transports.setdefault("rccl", {})["householder_ms_per_step"] = round(ms_per_step, 4)
-            except Exception as e:
-                die(f"rank {rank}: the peer transport failed inside its timed loop: {e}", 6)
-            finally:
-                install_hook()
 
     # ---- per-kernel timing with HIP events on the launch stream (rank-local)
     wd_k = wd.phase("per-kernel timing")
@@ -580,6 +561,47 @@ def worker(args):
                           if args.rehearse_distributed else None),
             "phases_s": {k: v for k, v in wd.history},
         }
+    # ---- the same K steps under the SECOND transport (peer-mapped one-shot exchange), N > 1 only: reported next to the
+    # RCCL headline, never as `value`. It runs LAST and is optional: everything above is already in `out`, so a failure or
+    # a stall in here abandons this leg only — rank 0 prints the line it has (with the reason under transports.peer_shm)
+    # and every rank leaves with status 0, skipping the tear-down collectives a half-dead transport could hang.
+    if peer_hook is not None:
+        def abandon(why):
+            if rank == 0:
+                out["transports"].setdefault("peer_shm", {})["error"] = str(why)[:300]
+                out["transports"]["peer_shm"]["note"] = ("optional second-transport leg abandoned; every other figure of this "
+                                                         "line was measured before it, over RCCL")
+                out["phases_s"] = {k: v for k, v in wd.history}
+                print(json.dumps(out), flush=True)
+            sys.stderr.flush()
+            os._exit(0)
+        wd.rescue = abandon
+        try:
+            with wd.phase("second transport (optional)"):
+                peer_hook.install(ctx)
+                if os.environ.get("MXLO_BENCH_FAULT") == "peer-leg":      # TEST HOOK: the optional leg fails
+                    raise RuntimeError("injected failure of the optional second-transport leg")
+                if os.environ.get("MXLO_BENCH_FAULT") == "peer-leg-stall":  # TEST HOOK: the optional leg never returns
+                    time.sleep(1e6)
+                for _ in range(max(5, args.warmup)):
+                    lo.mul(res, H, v, alpha, beta)
+                barrier()
+                tp0 = time.perf_counter()
+                for _ in range(args.steps):
+                    lo.mul(res, H, v, alpha, beta)
+                barrier()
+                tp = torch.tensor([time.perf_counter() - tp0], dtype=torch.float64, device=dev)
+                dist.all_reduce(tp, op=dist.ReduceOp.MAX)
+                peer_hook.check()
+                if rank == 0:
+                    out["transports"]["peer_shm"]["householder_ms_per_step"] = round(float(tp.item()) / args.steps * 1e3, 4)
+                    out["transports"]["peer_shm"]["householder_GB/s"] = round(bytes_per_step / (float(tp.item()) / args.steps) / 1e9, 1)
+                    out["transports"].setdefault("rccl", {})["householder_ms_per_step"] = round(ms_per_step, 4)
+        except BaseException as e:
+            abandon(f"rank {rank}: {e!r}")
+        wd.rescue = None
+        if rank == 0:
+            out["phases_s"] = {k: v for k, v in wd.history}
     with wd.phase("teardown"):
         del H, h, v, res
         torch.cuda.synchronize()

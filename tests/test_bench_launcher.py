@@ -155,3 +155,16 @@ def test_watchdog_ends_a_rank_that_sits_in_one_phase(tmp_path, monkeypatch):
                       "with wd.phase('timed loop'):\n    time.sleep(30)\n" % ROOT)
     p = subprocess.run([sys.executable, str(script)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=60)
     assert p.returncode == 7 and "WATCHDOG rank 5 has been in phase 'timed loop'" in p.stderr
+
+
+def test_watchdog_rescue_of_an_optional_phase(tmp_path):
+    """Around an OPTIONAL phase (the second-transport leg) the watchdog calls `rescue` — which prints the line already
+    measured and leaves with status 0 — instead of ending the run with status 7."""
+    script = tmp_path / "w.py"
+    script.write_text("import os, sys, time\nsys.path.insert(0, %r)\nimport bench\n"
+                      "wd = bench.Watchdog(0, limits={'second transport (optional)': 0.3})\n"
+                      "def rescue(why):\n    print('{\"value\": 1, \"why\": \"%%s\"}' %% why, flush=True)\n    os._exit(0)\n"
+                      "wd.rescue = rescue\n"
+                      "with wd.phase('second transport (optional)'):\n    time.sleep(30)\n" % ROOT)
+    p = subprocess.run([sys.executable, str(script)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=60)
+    assert p.returncode == 0 and "stalled in 'second transport (optional)'" in p.stdout

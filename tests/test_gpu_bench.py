@@ -36,3 +36,22 @@ def test_rehearsal_of_the_n_rank_path_at_world_1():
                         "--nelem", "100000", "--steps", "2", "--no-extras", "--no-cpu-baseline", "--no-shard-leg"],
                        env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
     assert q.returncode != 0 and "--rehearse-distributed" in q.stderr
+
+
+@pytest.mark.parametrize("fault", ["peer-leg", "peer-leg-stall"])
+def test_a_failing_or_stalled_second_transport_leg_cannot_sink_the_headline(fault):
+    """The peer-transport timed loop runs last and is optional: when it raises, or never returns (watchdog), rank 0 still
+    prints the line measured over RCCL, with the reason under transports.peer_shm, and the exit status is 0."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY="0", MXLO_BENCH_FAULT=fault, MXLO_BENCH_OPTIONAL_LIMIT_S="3")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--rehearse-distributed", "--steps", "5", "--warmup", "2",
+                        "--nelem", "4000000", "--no-extras", "--no-cpu-baseline", "--no-shard-leg", "--clock-spin-s", "0.05"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["value"] > 0 and d["rccl"]["ranks_seen"] == 1
+    ps = d["transports"]["peer_shm"]
+    assert ("injected failure" in ps["error"]) if fault == "peer-leg" else ("stalled" in ps["error"])
+    assert "abandoned" in ps["note"] and "householder_ms_per_step" not in ps

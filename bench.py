@@ -504,6 +504,50 @@ def worker(args):
     }
     del D
 
+    out = None
+    if rank == 0:
+        transport = ("native RCCL hook (libmxlo_rccl.so, ncclAllReduce on the ctx stream)" if native
+                     else "torch.distributed Python hook over %s (debug transport)" % args.backend)
+        out = {
+            "metric": "mul! GB/s (frac HBM peak) at n=10^8 fp64; L-BFGS apply/s, 1/2/4/8 GPU",
+            "value": round(value, 1), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "opHouseholder(h) 5-arg mul!(res,H,v,1,0), n=%d fp64 per GPU (configs[1])" % n,
+                       "n_per_gpu": n, "algorithmic_bytes_per_elt": 40,
+                       "sharding": ("row ranges over %d ranks (one process per GPU), 1-double all-reduce per apply: %s" % (world, transport)) if distributed else "none",
+                       "devices_visible": torch.cuda.device_count()},
+            "frac_hbm_peak": round(value / world / HBM_PEAK_GBS, 4),
+            "roofline": roofline, "cpu_baseline": None, "extras": extras,
+            "rccl": transports.get("rccl"), "transports": transports,
+            "rehearsal": ("world-1 rehearsal of the N-rank code path (nccl group of one rank, native hook, preflight, peer transport)"
+                          if args.rehearse_distributed else None),
+            "phases_s": {k: v for k, v in wd.history},
+        }
+
+    # From here on the headline is measured. Every later leg is an extra: if one of them stalls (a collective a rank never
+    # joins, a transport that dies) the watchdog calls `abandon` instead of ending the run with status 7 — rank 0 prints
+    # the line it has, with the reason under "abandoned", and every rank leaves with status 0.
+    def abandon(why, key="abandoned"):
+        if rank == 0:
+            if key == "abandoned":
+                out["abandoned"] = str(why)[:300]
+            else:
+                out["transports"].setdefault(key, {})["error"] = str(why)[:300]
+                out["transports"][key]["note"] = ("optional second-transport leg abandoned; every other figure of this "
+                                                  "line was measured before it, over RCCL")
+            out["phases_s"] = {k: v for k, v in wd.history}
+            print(json.dumps(out), flush=True)
+            if peer_hook is not None:                    # the tear-down is skipped: at least do not leave the segment's name behind
+                try:
+                    os.unlink("/dev/shm" + peer_hook.name)
+                except OSError:
+                    pass
+        sys.stderr.flush()
+        os._exit(0)
+    if distributed:
+        wd.rescue = abandon
+
     # ---- quasi-Newton apply/s (the second figure of the metric string)
     if not args.no_extras and hasattr(lo, "InverseLBFGSOperator"):
         with wd.phase("quasi-Newton legs"):
@@ -527,10 +571,9 @@ def worker(args):
             except Exception as e:
                 extras["misc_error"] = repr(e)
 
-    cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         with wd.phase("cpu baseline"):
-            cpu_baseline = cpu_leg(args.cpu_sample)
+            out["cpu_baseline"] = cpu_leg(args.cpu_sample)
             # the reference's CPU mul! beside the OTHER two figures of the metric string, in the same run
             if not args.no_extras:
                 try:
@@ -541,41 +584,12 @@ def worker(args):
                 except Exception as e:
                     extras["cpu_legs_error"] = repr(e)[:200]
 
-    out = None
-    if rank == 0:
-        transport = ("native RCCL hook (libmxlo_rccl.so, ncclAllReduce on the ctx stream)" if native
-                     else "torch.distributed Python hook over %s (debug transport)" % args.backend)
-        out = {
-            "metric": "mul! GB/s (frac HBM peak) at n=10^8 fp64; L-BFGS apply/s, 1/2/4/8 GPU",
-            "value": round(value, 1), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "opHouseholder(h) 5-arg mul!(res,H,v,1,0), n=%d fp64 per GPU (configs[1])" % n,
-                       "n_per_gpu": n, "algorithmic_bytes_per_elt": 40,
-                       "sharding": ("row ranges over %d ranks (one process per GPU), 1-double all-reduce per apply: %s" % (world, transport)) if distributed else "none",
-                       "devices_visible": torch.cuda.device_count()},
-            "frac_hbm_peak": round(value / world / HBM_PEAK_GBS, 4),
-            "roofline": roofline, "cpu_baseline": cpu_baseline, "extras": extras,
-            "rccl": transports.get("rccl"), "transports": transports,
-            "rehearsal": ("world-1 rehearsal of the N-rank code path (nccl group of one rank, native hook, preflight, peer transport)"
-                          if args.rehearse_distributed else None),
-            "phases_s": {k: v for k, v in wd.history},
-        }
     # ---- the same K steps under the SECOND transport (peer-mapped one-shot exchange), N > 1 only: reported next to the
     # RCCL headline, never as `value`. It runs LAST and is optional: everything above is already in `out`, so a failure or
     # a stall in here abandons this leg only — rank 0 prints the line it has (with the reason under transports.peer_shm)
     # and every rank leaves with status 0, skipping the tear-down collectives a half-dead transport could hang.
     if peer_hook is not None:
-        def abandon(why):
-            if rank == 0:
-                out["transports"].setdefault("peer_shm", {})["error"] = str(why)[:300]
-                out["transports"]["peer_shm"]["note"] = ("optional second-transport leg abandoned; every other figure of this "
-                                                         "line was measured before it, over RCCL")
-                out["phases_s"] = {k: v for k, v in wd.history}
-                print(json.dumps(out), flush=True)
-            sys.stderr.flush()
-            os._exit(0)
-        wd.rescue = abandon
+        wd.rescue = lambda why: abandon(why, "peer_shm")
         try:
             with wd.phase("second transport (optional)"):
                 peer_hook.install(ctx)
@@ -598,10 +612,10 @@ def worker(args):
                     out["transports"]["peer_shm"]["householder_GB/s"] = round(bytes_per_step / (float(tp.item()) / args.steps) / 1e9, 1)
                     out["transports"].setdefault("rccl", {})["householder_ms_per_step"] = round(ms_per_step, 4)
         except BaseException as e:
-            abandon(f"rank {rank}: {e!r}")
-        wd.rescue = None
-        if rank == 0:
-            out["phases_s"] = {k: v for k, v in wd.history}
+            abandon(f"rank {rank}: {e!r}", "peer_shm")
+        wd.rescue = abandon if distributed else None
+    if rank == 0:
+        out["phases_s"] = {k: v for k, v in wd.history}
     with wd.phase("teardown"):
         del H, h, v, res
         torch.cuda.synchronize()

@@ -168,3 +168,16 @@ def test_watchdog_rescue_of_an_optional_phase(tmp_path):
                       "with wd.phase('second transport (optional)'):\n    time.sleep(30)\n" % ROOT)
     p = subprocess.run([sys.executable, str(script)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=60)
     assert p.returncode == 0 and "stalled in 'second transport (optional)'" in p.stdout
+
+
+def test_only_the_json_line_reaches_stdout(tmp_path):
+    """RCCL printf()s a version banner to stdout when a communicator is created and libc flushes it at exit, after the
+    line: bench.py keeps a private duplicate of stdout for its ONE JSON line and points descriptor 1 at stderr."""
+    script = tmp_path / "w.py"
+    script.write_text("import ctypes, os, sys\nsys.path.insert(0, %r)\nimport bench\nbench.claim_stdout()\n"
+                      "libc = ctypes.CDLL(None)\nlibc.printf(b'RCCL version : banner before\\n')\n"
+                      "print('python chatter')\nbench.emit_json({'value': 1.5})\n"
+                      "libc.printf(b'banner flushed at exit\\n')\n" % ROOT)
+    p = subprocess.run([sys.executable, str(script)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=60)
+    assert p.returncode == 0 and p.stdout == '{"value": 1.5}\n', (p.stdout, p.stderr)
+    assert "banner before" in p.stderr and "banner flushed at exit" in p.stderr and "python chatter" in p.stderr

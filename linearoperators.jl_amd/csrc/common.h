@@ -156,6 +156,7 @@ struct Tune {
   int64_t herm_single_max_n = 2048;   // measured (profiles/r05_herm_small.txt): 8.9 -> 6.4 us at n = 1024, 9.6 -> 6.9 at 2048 (f64; f32
                                       // alike); NO gain at 4096 (17.8 vs 18.4 f64, 12.4 vs 10.8 f32) and 8192: there the strips' own
                                       // load -> butterfly -> store chain sets the time, not the finish launch
+  int gemv_n_rows = 1;     // dense M*v: row bands, the column sum stays inside a workgroup — one launch, no partials (dense.hip)
   int gemvb_t_lds = 1;     // transposed block apply of a dense operator (k >= 4): U staged in LDS per workgroup (dense.hip)
   int combine_reverse = 0; // four-launch applies: the combine pass walks the vectors back to front. Measured (round 5,
                            // profiles/r05_bench_mid_apply.txt): -3.6 … +2.8 %, no gain on average — the grid-stride dots pass

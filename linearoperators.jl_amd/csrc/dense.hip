@@ -307,9 +307,122 @@ gemv_n_finish_kernel(T *__restrict__ res, const double *__restrict__ part, int64
   res[i] = fin_ab<T, CA, CB, BETA0>(alpha * (CA)(T)acc, beta, BETA0 ? T(0) : res[i]);
 }
 
+// N mode, ROW BANDS (round 5): a workgroup owns RB consecutive rows across ALL columns, so the sum over the columns
+// never leaves the workgroup — one launch, no partial workspace, no dependent finish launch (at n = 4096 the finish was
+// 5 of 28 us). LPR = RB / VR lanes cover the band's RB rows of one column with 16-byte loads (RB = 16 rows of f64 = one
+// 128-byte line per column), the other lanes of the workgroup take other columns (NCL = 512 / LPR column lanes), 8 loads
+// in flight per lane (64 KiB per workgroup). The NCL column-lane partials are added in a fixed order through LDS:
+// deterministic. Grid = m / RB >= #CU / 2 (gemv_n picks RB = 16 / 32 / 64); at one moment the workgroups read the same
+// few columns, each its own 128-byte-aligned piece: whole columns stream from HBM contiguously.
+constexpr int kGemvRowsBlock = 512;
+template <typename T, typename CA, typename CB, bool BETA0, int RB>
+__global__ void __launch_bounds__(kGemvRowsBlock)
+gemv_n_rows_kernel(T *__restrict__ res, const T *__restrict__ M, int64_t m, int64_t n, int64_t ld,
+                   const T *__restrict__ v, CA alpha, CB beta) {
+  constexpr int VR = 16 / (int)sizeof(T);
+  typedef T VV __attribute__((ext_vector_type(VR)));
+  constexpr int LPR = RB / VR, NCL = kGemvRowsBlock / LPR, U = 8;
+  static_assert(RB % VR == 0 && kGemvRowsBlock % LPR == 0 && RB <= kGemvRowsBlock, "bad row band");
+  __shared__ double sred[NCL][RB];
+  const int tid = threadIdx.x, seg = tid % LPR, cl = tid / LPR;
+  const int64_t row = (int64_t)blockIdx.x * RB + (int64_t)seg * VR;
+  double acc[VR];
+#pragma unroll
+  for (int e = 0; e < VR; ++e) acc[e] = 0.0;
+  if (row < m) {                                  // m % VR == 0 (gemv_n): a vector is wholly inside or wholly outside
+    const T *base = M + row;
+    int64_t j = cl;
+    for (; j + (int64_t)(U - 1) * NCL < n; j += (int64_t)U * NCL) {
+      VV a[U];
+      T x[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        a[u] = __builtin_nontemporal_load(reinterpret_cast<const VV *>(base + (j + (int64_t)u * NCL) * ld));
+        x[u] = v[j + (int64_t)u * NCL];
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int e = 0; e < VR; ++e) acc[e] = fma((double)a[u][e], (double)x[u], acc[e]);
+    }
+    for (; j < n; j += NCL) {
+      const VV a = *reinterpret_cast<const VV *>(base + j * ld);
+      const double x = (double)v[j];
+#pragma unroll
+      for (int e = 0; e < VR; ++e) acc[e] = fma((double)a[e], x, acc[e]);
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < VR; ++e) sred[cl][seg * VR + e] = acc[e];
+  __syncthreads();
+  // RB * Q threads: thread (q, r) adds column lanes q, q + Q, ... of row r; the Q sub-sums are added in a fixed order
+  constexpr int Q = RB * 8 <= kGemvRowsBlock ? 8 : kGemvRowsBlock / RB;
+  static_assert(Q >= 1 && NCL % Q == 0 && RB * Q <= kGemvRowsBlock, "bad finish shape");
+  double part = 0.0;
+  const int r = tid % RB, q = tid / RB;
+  if (tid < RB * Q) {
+#pragma unroll 8
+    for (int c = q; c < NCL; c += Q) part += sred[c][r];
+  }
+  __syncthreads();
+  if (tid < RB * Q) sred[q][r] = part;
+  __syncthreads();
+  if (tid < RB) {
+    const int64_t i = (int64_t)blockIdx.x * RB + tid;
+    if (i < m) {
+      double s = 0.0;
+#pragma unroll
+      for (int qq = 0; qq < Q; ++qq) s += sred[qq][tid];
+      res[i] = fin_ab<T, CA, CB, BETA0>(alpha * (CA)(T)s, beta, BETA0 ? T(0) : res[i]);
+    }
+  }
+}
+
+// the band height gemv_n uses for an m x n operand (0: keep the column-chunk schedule)
+template <typename T>
+int gemv_rows_band(const mxlo_ctx *ctx, const T *M, int64_t m, int64_t n, int64_t ld) {
+  constexpr int VR = 16 / (int)sizeof(T);
+  const bool vec = (((uintptr_t)M & 15u) == 0) && ld % VR == 0 && m % VR == 0;
+  // tune gemv_n_rows: 0 = off, 1 = auto, 8*VR / 16*VR / 32*VR = that band height (sweeps)
+  int rb = 0;
+  const int want = ctx->tune.gemv_n_rows;
+  if (want > 1) {
+    if (want == 8 * VR || want == 16 * VR || want == 32 * VR) rb = want;
+  } else if (want == 1 && n >= 1024) {
+    // the tallest band that still gives every CU a workgroup: a band reads RB * sizeof(T) contiguous bytes per column
+    // (128 B at 8 * VR), and the longer the pieces the better HBM streams them (tools/bench_gemv_n.py)
+    if (m >= (int64_t)32 * VR * ctx->num_cu) rb = 32 * VR;
+    else if (m >= (int64_t)16 * VR * ctx->num_cu) rb = 16 * VR;
+    else if (m >= (int64_t)8 * VR * ctx->num_cu) rb = 8 * VR;
+    // measured (profiles/r05_bench_gemv_n.txt): 512-byte pieces win everywhere (0.84 - 0.88 of peak); 256-byte pieces
+    // win (0.78 - 0.84) except against the column-chunk schedule on very wide matrices, whose finish launch is amortised
+    // there; 128-byte pieces top out at 0.68 - 0.73: better than the two launches up to n = 16384 columns only
+    if (rb == 16 * VR && n >= 16384) rb = 0;
+    if (rb == 8 * VR && n > 16384) rb = 0;
+  }
+  return (rb != 0 && vec && m >= rb) ? rb : 0;
+}
+
 template <typename T>
 int32_t gemv_n(mxlo_ctx *ctx, T *res, const T *M, int64_t m, int64_t n, int64_t ld, const T *v,
                double alpha, double beta, int32_t flags) {
+  {
+    constexpr int VR = 16 / (int)sizeof(T);
+    const int rb = gemv_rows_band<T>(ctx, M, m, n, ld);
+    if (rb != 0) {
+      return dispatch_ab<T>(beta, flags, [&]<typename CA, typename CB, bool B0>() -> int32_t {
+#define ROWS(RB_)                                                                                                     \
+  hipLaunchKernelGGL((gemv_n_rows_kernel<T, CA, CB, B0, RB_>), dim3((unsigned)((m + RB_ - 1) / RB_)),                 \
+                     dim3(kGemvRowsBlock), 0, ctx->stream, res, M, m, n, ld, v, (CA)alpha, (CB)beta)
+        if (rb == 32 * VR) ROWS(32 * VR);
+        else if (rb == 16 * VR) ROWS(16 * VR);
+        else ROWS(8 * VR);
+#undef ROWS
+        MXLO_LAUNCH_CHECK();
+        return MXLO_OK;
+      });
+    }
+  }
   const int64_t cap = (int64_t)kMaxRedCols * kMaxRedBlocks;  // doubles in ctx->partials
   MXLO_REQUIRE(m <= cap, MXLO_ESHAPE, "gemv: m = %lld exceeds the partial workspace", (long long)m);
   // pairs of rows per lane need 16-byte (8-byte for f32) aligned column starts
@@ -686,6 +799,9 @@ template <typename T, int KB>
 int32_t gemv_block_chunk(mxlo_ctx *ctx, T *res, int64_t ldr, const T *M, int64_t m, int64_t n, int64_t ld, const T *V,
                          int64_t ldv, double alpha, double beta, int32_t mode, int32_t flags) {
   if (mode == MXLO_OP_N) {
+    // (a row-band form of this block apply — gemv_n_rows_kernel with KB accumulators per lane, V staged through
+    // wave-private LDS because a wave's lanes span several columns of M — was built and measured slower than this
+    // schedule at every size: profiles/r05_bench_gemv_n.txt)
     const bool pair = m >= 2 && (((uintptr_t)M % (2 * sizeof(T))) == 0) && (ld % 2 == 0);
     const int64_t rows_per_block = (int64_t)kBlock * (pair ? 2 : 1);
     const int64_t row_blocks = (m + rows_per_block - 1) / rows_per_block;

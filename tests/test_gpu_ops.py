@@ -468,7 +468,8 @@ def test_shifted_operator(lo, dev):
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-12), (torch.float32, 3e-5)])
-@pytest.mark.parametrize("m,n", [(1000, 777), (513, 2050), (64, 3), (2, 5000), (4099, 133), (2050, 64), (8192, 31), (8200, 300)])   # round 5: tall enough for the LDS-staged transposed form
+@pytest.mark.parametrize("m,n", [(1000, 777), (513, 2050), (64, 3), (2, 5000), (4099, 133), (2050, 64), (8192, 31), (8200, 300),
+                                 (4096, 1030), (8192, 2051), (16384, 1024), (1100, 8192)])   # round 5: tall enough for the LDS-staged transposed form; the last four: sizes at which the single-vector N mode takes the row-band kernel (the block form keeps the column-chunk schedule)
 @pytest.mark.parametrize("k", [2, 3, 5, 8, 11])
 def test_block_gemv_vs_columns_and_dense(lo, dev, dtype, tol, m, n, k):
     """mul!(res::Matrix, LinearOperator(M), V::Matrix, α, β) through mxlo_gemv_block (M read once per 8 columns) against
@@ -627,3 +628,46 @@ def test_dense_views_with_leading_dimension(lo, dev, dtype, pad, off):
     vv = np.concatenate([v, w])
     want = np.concatenate([A.astype(np.float64) @ v, d.astype(np.float64) * w])
     assert rel((Bd * T(vv, dev)).cpu().numpy(), want) <= tol
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("m,n,pad", [(2048, 1024, 0), (4096, 1030, 0), (4100, 2049, 4), (8192, 1024, 8), (16384, 1500, 0), (33000, 1024, 0)])
+def test_dense_mul_row_band_kernel(lo, dev, dtype, m, n, pad):
+    """Dense `M*v` (src/constructors.jl:19-29, N mode) through the single-launch row-band kernel (dense.hip:
+    gemv_n_rows_kernel; m >= 2048 / 4096 rows, n >= 1024 columns, 16-byte aligned columns) against the dense model and
+    against the two-launch column-chunk schedule it replaces (tune gemv_n_rows = 0): same tolerance class, 5-arg forms,
+    NaN in `res` with beta = 0 never read, leading dimension > m, ragged last band."""
+    from linearoperators_jl_amd.device import get_ctx
+    ctx = get_ctx(dev)
+    npd = NP[dtype]
+    rng = np.random.default_rng(m + n)
+    big = rng.standard_normal((m + pad, n)).astype(npd)
+    Bdev = TM(big, dev)
+    Av, A = Bdev[:m, :], big[:m, :].astype(np.float64)
+    assert Av.stride(0) == 1 and Av.stride(1) == m + pad
+    op = lo.LinearOperatorFromMatrix(Av)
+    v = rng.standard_normal(n).astype(npd)
+    r0 = rng.standard_normal(m).astype(npd)
+    tol = 1e-12 if dtype == torch.float64 else 3e-5
+    outs = {}
+    for rows in (1, 0):
+        ctx.tune("gemv_n_rows", rows)
+        try:
+            res = torch.full((m,), float("nan"), dtype=dtype, device=dev)
+            lo.mul(res, op, T(v, dev), 1.0, 0.0)
+            a = res.cpu().numpy()
+            res2 = T(r0.copy(), dev)
+            lo.mul(res2, op, T(v, dev), 3.0, -4.0)
+            outs[rows] = (a, res2.cpu().numpy())
+        finally:
+            ctx.tune("gemv_n_rows", 1)
+    want = A @ v.astype(np.float64)
+    for rows in (1, 0):
+        assert np.isfinite(outs[rows][0]).all()
+        assert rel(outs[rows][0], want) <= tol
+        assert rel(outs[rows][1], 3.0 * want - 4.0 * r0.astype(np.float64)) <= tol
+    assert rel(outs[1][0], outs[0][0]) <= tol
+    # run-to-run deterministic (fixed-order sums)
+    res = torch.empty(m, dtype=dtype, device=dev)
+    lo.mul(res, op, T(v, dev), 1.0, 0.0)
+    assert np.array_equal(res.cpu().numpy(), outs[1][0])

@@ -1178,6 +1178,18 @@ def bench_misc(lo, torch, dev, ctx):
         if eager_us is not None:
             out[f"opHermitian_n{nn}"].update(timing="the faster of an eager loop of Python-mirror calls and 100 applies in one hipGraph replay",
                                              us_eager_python_mirror=eager_us, us_graph_replay=replay_us)
+        try:                                 # dense LinearOperator(M) * v (round 5: one launch of row bands) and its transpose
+            opD = lo.LinearOperatorFromMatrix(M)
+            for name, o in (("dense_mul", opD), ("dense_transpose_mul", opD.T)):
+                ms = timeit(lambda: lo.mul(y, o, x, 1.0, 0.0), 20)
+                if nn <= 4096:
+                    msr = time_replayed(lo, torch, dev, tm, lambda: lo.mul(y, o, x, 1.0, 0.0), 100)
+                    ms = min(ms, msr) if msr is not None else ms
+                out[f"{name}_n{nn}"] = {"us": round(ms * 1e3, 1), "GB/s(8n^2 B)": round(8.0 * nn * nn / ms / 1e6, 1),
+                                        "frac_hbm_peak": round(8.0 * nn * nn / ms / 1e6 / HBM_PEAK_GBS, 4)}
+            del opD
+        except Exception as e:
+            out[f"dense_mul_n{nn}_error"] = repr(e)
         if nn == 16384:                      # block apply of the dense operator: M read once for 8 columns
             try:
                 opM = lo.LinearOperatorFromMatrix(M)

@@ -428,6 +428,106 @@ int32_t cgemv_cols(mxlo_ctx *ctx, C<R> *res, const C<R> *M, int64_t m, int64_t n
   });
 }
 
+// N mode, ROW BANDS (round 5; the real form is dense.hip: gemv_n_rows_kernel): a 512-thread workgroup owns RBAND rows of a
+// complex matrix across ALL its columns — LPR lanes cover the band's piece of one column with 16-byte loads (one ComplexF64
+// or two ComplexF32 per lane), the other lanes take other columns, 8 loads in flight per lane — so the sum over the columns
+// never leaves the workgroup: one launch, no partial workspace, no finish launch; fixed-order sums through LDS.
+constexpr int kCRowsBlock = 512;
+template <typename R, typename RA, typename RB, bool BETA0, bool CONJ, int RBAND>
+__global__ void __launch_bounds__(kCRowsBlock)
+cgemv_rows_band_kernel(C<R> *__restrict__ res, const C<R> *__restrict__ M, int64_t m, int64_t n, int64_t ld,
+                       const C<R> *__restrict__ v, Sc<RA> a, Sc<RB> b) {
+  constexpr int VR = 16 / (int)sizeof(C<R>);          // complex elements per 16-byte load: 1 (ComplexF64) or 2 (ComplexF32)
+  typedef R VV __attribute__((ext_vector_type(2 * VR)));
+  constexpr int LPR = RBAND / VR, NCL = kCRowsBlock / LPR, U = 8;
+  static_assert(RBAND % VR == 0 && kCRowsBlock % LPR == 0, "bad row band");
+  __shared__ double sre[NCL][RBAND], sim[NCL][RBAND];
+  const int tid = threadIdx.x, seg = tid % LPR, cl = tid / LPR;
+  const int64_t row = (int64_t)blockIdx.x * RBAND + (int64_t)seg * VR;
+  double sr[VR], si[VR];
+#pragma unroll
+  for (int e = 0; e < VR; ++e) sr[e] = si[e] = 0.0;
+  auto acc = [&](const VV &av, const C<R> &x) {
+    const double xr = (double)x.re, xi = (double)x.im;
+#pragma unroll
+    for (int e = 0; e < VR; ++e) {
+      const double er = (double)av[2 * e], ei = CONJ ? -(double)av[2 * e + 1] : (double)av[2 * e + 1];
+      sr[e] = fma(er, xr, sr[e]);
+      sr[e] = fma(-ei, xi, sr[e]);
+      si[e] = fma(er, xi, si[e]);
+      si[e] = fma(ei, xr, si[e]);
+    }
+  };
+  if (row < m) {                                       // m % VR == 0 (cgemv_any): a vector is wholly inside or outside
+    const C<R> *base = M + row;
+    int64_t j = cl;
+    for (; j + (int64_t)(U - 1) * NCL < n; j += (int64_t)U * NCL) {
+      VV av[U];
+      C<R> x[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        av[u] = __builtin_nontemporal_load(reinterpret_cast<const VV *>(base + (j + (int64_t)u * NCL) * ld));
+        x[u] = v[j + (int64_t)u * NCL];
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) acc(av[u], x[u]);
+    }
+    for (; j < n; j += NCL) acc(*reinterpret_cast<const VV *>(base + j * ld), v[j]);
+  }
+#pragma unroll
+  for (int e = 0; e < VR; ++e) {
+    sre[cl][seg * VR + e] = sr[e];
+    sim[cl][seg * VR + e] = si[e];
+  }
+  __syncthreads();
+  constexpr int Q = RBAND * 8 <= kCRowsBlock ? 8 : kCRowsBlock / RBAND;
+  static_assert(Q >= 1 && NCL % Q == 0 && RBAND * Q <= kCRowsBlock, "bad finish shape");
+  double pr = 0.0, pi = 0.0;
+  const int r = tid % RBAND, q = tid / RBAND;
+  if (tid < RBAND * Q) {
+    for (int c = q; c < NCL; c += Q) {
+      pr += sre[c][r];
+      pi += sim[c][r];
+    }
+  }
+  __syncthreads();
+  if (tid < RBAND * Q) {
+    sre[q][r] = pr;
+    sim[q][r] = pi;
+  }
+  __syncthreads();
+  if (tid < RBAND) {
+    const int64_t i = (int64_t)blockIdx.x * RBAND + tid;
+    if (i < m) {
+      double tr_ = 0.0, ti_ = 0.0;
+#pragma unroll
+      for (int qq = 0; qq < Q; ++qq) {
+        tr_ += sre[qq][tid];
+        ti_ += sim[qq][tid];
+      }
+      const C<R> t((R)tr_, (R)ti_);
+      RA tr, ti;
+      a.mul(t, tr, ti);
+      res[i] = cfin<R, RA, RB, BETA0>(tr, ti, b.re, b.im, b.real, BETA0 ? C<R>() : res[i]);
+    }
+  }
+}
+
+// band height for an m x n complex operand (0: the column-chunk schedule); policy and thresholds as dense.hip: gemv_rows_band
+template <typename R>
+int cgemv_rows_band(const mxlo_ctx *ctx, const C<R> *M, int64_t m, int64_t n, int64_t ld) {
+  constexpr int VR = 16 / (int)sizeof(C<R>);
+  const bool vec = (((uintptr_t)M & 15u) == 0) && ld % VR == 0 && m % VR == 0;
+  if (ctx->tune.gemv_n_rows != 1 || !vec || n < 1024) return 0;
+  int rb = 0;
+  if (m >= (int64_t)32 * VR * ctx->num_cu) rb = 32 * VR;
+  else if (m >= (int64_t)16 * VR * ctx->num_cu) rb = 16 * VR;
+  else if (m >= (int64_t)8 * VR * ctx->num_cu) rb = 8 * VR;
+  if (rb == 16 * VR && n >= 16384) rb = 0;
+  if (rb == 8 * VR && n > 16384) rb = 0;
+  return rb;
+}
+
 template <typename R>
 int32_t cgemv_any(mxlo_ctx *ctx, C<R> *res, const C<R> *M, int64_t m, int64_t n, int64_t ld, const C<R> *v, int mode,
                   const ScalArgs &s, int32_t flags) {
@@ -438,7 +538,31 @@ int32_t cgemv_any(mxlo_ctx *ctx, C<R> *res, const C<R> *M, int64_t m, int64_t n,
     if (s.bre == 0 && s.bim == 0) return cfill<R>(ctx, res, nres, C<R>());
     return cscale<R>(ctx, res, nres, s.bre, s.bim, s.b_real, s.b64);
   }
-  if (rows) return cgemv_rows<R, false, false>(ctx, res, M, m, n, ld, v, conj, s);
+  if (rows) {
+    if (const int rb = cgemv_rows_band<R>(ctx, M, m, n, ld); rb != 0) {
+      constexpr int VR = 16 / (int)sizeof(C<R>);
+      return dispatch_c<R>(s, [&]<typename RA, typename RB, bool B0>() -> int32_t {
+        const Sc<RA> a{(RA)s.are, (RA)s.aim, s.a_real};
+        const Sc<RB> b{(RB)s.bre, (RB)s.bim, s.b_real};
+#define CROWS(CJ_, RB_)                                                                                               \
+  hipLaunchKernelGGL((cgemv_rows_band_kernel<R, RA, RB, B0, CJ_, RB_>), dim3((unsigned)((m + RB_ - 1) / RB_)),          \
+                     dim3(kCRowsBlock), 0, ctx->stream, res, M, m, n, ld, v, a, b)
+        if (conj) {
+          if (rb == 32 * VR) CROWS(true, 32 * VR);
+          else if (rb == 16 * VR) CROWS(true, 16 * VR);
+          else CROWS(true, 8 * VR);
+        } else {
+          if (rb == 32 * VR) CROWS(false, 32 * VR);
+          else if (rb == 16 * VR) CROWS(false, 16 * VR);
+          else CROWS(false, 8 * VR);
+        }
+#undef CROWS
+        MXLO_LAUNCH_CHECK();
+        return MXLO_OK;
+      });
+    }
+    return cgemv_rows<R, false, false>(ctx, res, M, m, n, ld, v, conj, s);
+  }
   return cgemv_cols<R, false, false>(ctx, res, M, m, n, ld, v, conj, s);
 }
 

@@ -264,7 +264,8 @@ def test_kat_complex_hermitian(lo, dev, kat):
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.complex128, 1e-12), (torch.complex64, 3e-5)])
-@pytest.mark.parametrize("m,n", [(1, 1), (3, 2), (65, 7), (257, 300), (1000, 777), (31, 2049)])
+@pytest.mark.parametrize("m,n", [(1, 1), (3, 2), (65, 7), (257, 300), (1000, 777), (31, 2049),
+                                 (2048, 1030), (1030, 2048), (4096, 1024), (1024, 4096), (8192, 1100)])   # the last five: single-launch row bands (cgemv_rows_band_kernel), plain and conjugated
 def test_complex_dense_gemv_all_modes_both_layouts(lo, dev, dtype, tol, m, n):
     """LinearOperator(M) on complex data: M*v, transpose(M)*u, M'*w with real / complex α, β (β = 0 must not read res),
     for column-major storage and for torch's row-major default (aliased: N/T swapped, M' through conj(M)*w)."""

@@ -245,7 +245,7 @@ enum { CG_N = 0, CG_T = 1, CG_C = 2, CG_J = 3 };   // M*v, transpose(M)*v, M'*v,
 
 // column sums: out[j] = sum_{i >= i0(j)} op(M[i,j]) * v[i],  op = conj iff CONJ;  LOWER: strict lower triangle (i > j).
 // One wave per column, 4 rows in flight per lane. RAW: store the sums as Complex{R}; else apply α, β into res.
-template <typename R, typename RA, typename RB, bool BETA0, bool CONJ, bool LOWER, bool RAW>
+template <typename R, typename RA, typename RB, bool BETA0, bool CONJ, bool LOWER, bool RAW, bool VEC = false, bool NT = true>
 __global__ void __launch_bounds__(kBlock)
 cgemv_cols_kernel(C<R> *__restrict__ res, const C<R> *__restrict__ M, int64_t m, int64_t n, int64_t ld,
                   const C<R> *__restrict__ v, Sc<RA> a, Sc<RB> b) {
@@ -263,6 +263,38 @@ cgemv_cols_kernel(C<R> *__restrict__ res, const C<R> *__restrict__ M, int64_t m,
       si = fma(ei, xr, si);
     };
     int64_t i = (LOWER ? j + 1 : 0) + lane;
+    if constexpr (VEC && !LOWER) {
+      // aligned full columns (round 5): 16-byte NONTEMPORAL loads of M (one ComplexF64 / two ComplexF32 per lane; M is
+      // streamed once — the hint alone is worth 6.3 -> 7.1 TB/s on a read-only pass, profiles/r05_tune_read.txt), 4 in flight
+      constexpr int VR = 16 / (int)sizeof(C<R>);
+      typedef R VV __attribute__((ext_vector_type(2 * VR)));
+      const int64_t mp = m / VR;                      // m % VR == 0 (cgemv_cols)
+      const VV *cp = reinterpret_cast<const VV *>(col);
+      const VV *xp = reinterpret_cast<const VV *>(v);
+      auto accv = [&](const VV &e, const VV &x, double &sr, double &si) {
+#pragma unroll
+        for (int q = 0; q < VR; ++q) {
+          const double er = (double)e[2 * q], ei = CONJ ? -(double)e[2 * q + 1] : (double)e[2 * q + 1];
+          const double xr = (double)x[2 * q], xi = (double)x[2 * q + 1];
+          sr = fma(er, xr, sr);
+          sr = fma(-ei, xi, sr);
+          si = fma(er, xi, si);
+          si = fma(ei, xr, si);
+        }
+      };
+      int64_t p = lane;
+      for (; p + 192 < mp; p += 256) {
+        auto ldm = [&](const VV *q) { return NT ? __builtin_nontemporal_load(q) : *q; };
+        const VV e0 = ldm(cp + p), e1 = ldm(cp + p + 64), e2 = ldm(cp + p + 128), e3 = ldm(cp + p + 192);
+        const VV x0 = xp[p], x1 = xp[p + 64], x2 = xp[p + 128], x3 = xp[p + 192];
+        accv(e0, x0, ar, ai);
+        accv(e1, x1, br_, bi_);
+        accv(e2, x2, ar, ai);
+        accv(e3, x3, br_, bi_);
+      }
+      for (; p < mp; p += 64) accv(cp[p], xp[p], ar, ai);
+      i = m;                                          // nothing left for the element loops below
+    }
     for (; i + 192 < m; i += 256) {
       const C<R> e0 = col[i], e1 = col[i + 64], e2 = col[i + 128], e3 = col[i + 192];
       const C<R> x0 = v[i], x1 = v[i + 64], x2 = v[i + 128], x3 = v[i + 192];
@@ -417,6 +449,21 @@ int32_t cgemv_cols(mxlo_ctx *ctx, C<R> *res, const C<R> *M, int64_t m, int64_t n
   return dispatch_c<R>(s, [&]<typename RA, typename RB, bool B0>() -> int32_t {
     const Sc<RA> a{(RA)s.are, (RA)s.aim, s.a_real};
     const Sc<RB> b{(RB)s.bre, (RB)s.bim, s.b_real};
+    constexpr int VR = 16 / (int)sizeof(C<R>);
+    const bool vec = !LOWER && m >= 256 * VR && ((((uintptr_t)M | (uintptr_t)v) & 15u) == 0) && ld % VR == 0 && m % VR == 0;
+    if constexpr (!LOWER) {
+      if (vec) {
+        const bool nt = (int64_t)sizeof(C<R>) * m * n >= ctx->tune.nt_min_bytes;   // cache-sized matrices keep default loads
+#define CCOLS(CJ_, NT_)                                                                                                \
+  hipLaunchKernelGGL((cgemv_cols_kernel<R, RA, RB, B0, CJ_, LOWER, RAW, true, NT_>), dim3((unsigned)blocks), dim3(kBlock), 0, \
+                     ctx->stream, res, M, m, n, ld, v, a, b)
+        if (conj) { if (nt) CCOLS(true, true); else CCOLS(true, false); }
+        else { if (nt) CCOLS(false, true); else CCOLS(false, false); }
+#undef CCOLS
+        MXLO_LAUNCH_CHECK();
+        return MXLO_OK;
+      }
+    }
     if (conj)
       hipLaunchKernelGGL((cgemv_cols_kernel<R, RA, RB, B0, true, LOWER, RAW>), dim3((unsigned)blocks), dim3(kBlock), 0,
                          ctx->stream, res, M, m, n, ld, v, a, b);
@@ -433,7 +480,7 @@ int32_t cgemv_cols(mxlo_ctx *ctx, C<R> *res, const C<R> *M, int64_t m, int64_t n
 // or two ComplexF32 per lane), the other lanes take other columns, 8 loads in flight per lane — so the sum over the columns
 // never leaves the workgroup: one launch, no partial workspace, no finish launch; fixed-order sums through LDS.
 constexpr int kCRowsBlock = 512;
-template <typename R, typename RA, typename RB, bool BETA0, bool CONJ, int RBAND>
+template <typename R, typename RA, typename RB, bool BETA0, bool CONJ, int RBAND, bool NT = true>
 __global__ void __launch_bounds__(kCRowsBlock)
 cgemv_rows_band_kernel(C<R> *__restrict__ res, const C<R> *__restrict__ M, int64_t m, int64_t n, int64_t ld,
                        const C<R> *__restrict__ v, Sc<RA> a, Sc<RB> b) {
@@ -466,7 +513,8 @@ cgemv_rows_band_kernel(C<R> *__restrict__ res, const C<R> *__restrict__ M, int64
       C<R> x[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        av[u] = __builtin_nontemporal_load(reinterpret_cast<const VV *>(base + (j + (int64_t)u * NCL) * ld));
+        const VV *q = reinterpret_cast<const VV *>(base + (j + (int64_t)u * NCL) * ld);
+        av[u] = NT ? __builtin_nontemporal_load(q) : *q;
         x[u] = v[j + (int64_t)u * NCL];
       }
 #pragma unroll
@@ -545,16 +593,19 @@ int32_t cgemv_any(mxlo_ctx *ctx, C<R> *res, const C<R> *M, int64_t m, int64_t n,
         const Sc<RA> a{(RA)s.are, (RA)s.aim, s.a_real};
         const Sc<RB> b{(RB)s.bre, (RB)s.bim, s.b_real};
 #define CROWS(CJ_, RB_)                                                                                               \
-  hipLaunchKernelGGL((cgemv_rows_band_kernel<R, RA, RB, B0, CJ_, RB_>), dim3((unsigned)((m + RB_ - 1) / RB_)),          \
-                     dim3(kCRowsBlock), 0, ctx->stream, res, M, m, n, ld, v, a, b)
+  if (nt) hipLaunchKernelGGL((cgemv_rows_band_kernel<R, RA, RB, B0, CJ_, RB_, true>), dim3((unsigned)((m + RB_ - 1) / RB_)), \
+                             dim3(kCRowsBlock), 0, ctx->stream, res, M, m, n, ld, v, a, b);                             \
+  else hipLaunchKernelGGL((cgemv_rows_band_kernel<R, RA, RB, B0, CJ_, RB_, false>), dim3((unsigned)((m + RB_ - 1) / RB_)), \
+                          dim3(kCRowsBlock), 0, ctx->stream, res, M, m, n, ld, v, a, b)
+        const bool nt = (int64_t)sizeof(C<R>) * m * n >= ctx->tune.nt_min_bytes;   // cache-sized matrices keep default loads
         if (conj) {
-          if (rb == 32 * VR) CROWS(true, 32 * VR);
-          else if (rb == 16 * VR) CROWS(true, 16 * VR);
-          else CROWS(true, 8 * VR);
+          if (rb == 32 * VR) { CROWS(true, 32 * VR); }
+          else if (rb == 16 * VR) { CROWS(true, 16 * VR); }
+          else { CROWS(true, 8 * VR); }
         } else {
-          if (rb == 32 * VR) CROWS(false, 32 * VR);
-          else if (rb == 16 * VR) CROWS(false, 16 * VR);
-          else CROWS(false, 8 * VR);
+          if (rb == 32 * VR) { CROWS(false, 32 * VR); }
+          else if (rb == 16 * VR) { CROWS(false, 16 * VR); }
+          else { CROWS(false, 8 * VR); }
         }
 #undef CROWS
         MXLO_LAUNCH_CHECK();

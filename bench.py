@@ -46,6 +46,8 @@ def parse(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--settle-max-s", type=float, default=8.0,
+                    help="N = 1: upper bound on the untimed spin-up that waits for the step time to settle")
     ap.add_argument("--clock-spin-s", type=float, default=0.5,
                     help="untimed seconds of the same kernels before the warm-up steps, to reach steady GPU clocks")
     ap.add_argument("--nelem", dest="n", type=int, default=100_000_000, help="vector length per GPU")
@@ -450,11 +452,23 @@ def worker(args):
                 lo.mul(res, H, v, alpha, beta)
             torch.cuda.synchronize()
         else:
+            # ... and until the step time has SETTLED (bounded): a bench started right after another process released tens
+            # of GB (the driver runs it after the test suite) shares HBM with the driver's scrubbing of the freed memory for
+            # the first seconds — measured: 6306 / 6445 GB/s in the first run after pytest against 6690-6750 in every later
+            # one. Batches of 20 untimed applies until the last three agree within 1.5 % (at most --settle-max-s seconds).
             t_spin = time.perf_counter()
-            while time.perf_counter() - t_spin < args.clock_spin_s:
+            recent = []
+            while True:
+                tb = time.perf_counter()
                 for _ in range(20):
                     lo.mul(res, H, v, alpha, beta)
                 torch.cuda.synchronize()
+                recent = (recent + [time.perf_counter() - tb])[-3:]
+                if os.environ.get("MXLO_BENCH_DEBUG_SETTLE"):
+                    print("settle: t=%.2f s batch=%.3f ms/apply" % (time.perf_counter() - t_spin, recent[-1] / 20 * 1e3), file=sys.stderr, flush=True)
+                el = time.perf_counter() - t_spin
+                if el >= args.clock_spin_s and ((len(recent) == 3 and max(recent) <= 1.015 * min(recent)) or el >= args.settle_max_s):
+                    break
 
     with wd.phase("clock spin-up"):
         spin_up()

@@ -259,8 +259,12 @@ static int32_t launch_dots(mxlo_ctx *ctx, const T *const *cols, const T *x, int6
   for (int c = 0; c < NC; ++c) cp.p[c] = cols[c];
   // fewer columns -> more chunks in flight per lane to keep ~the same bytes in flight
   constexpr int UNROLL = NC <= 2 ? 4 : (NC <= 6 ? 2 : 1);
-  const int grid = grid_for(ctx, nvec, (int64_t)kBlock * UNROLL, ctx->tune.red_blocks_per_cu);
   const bool nt = (int64_t)sizeof(T) * n * (NC + 1) >= ctx->tune.nt_min_bytes;
+  // HBM-sized dots of one or two columns (the Householder dot pass): ONE workgroup per CU — 595 vs 606 us for the whole
+  // n = 1e8 apply against the 4 per CU the wide panels want (tools/sweep_red_grid.py, profiles/r05_sweep_red_grid.txt;
+  // a read-only pass of 1-2 streams does not gain from more workgroups, profiles/r05_tune_read.txt)
+  const int per_cu = (nt && NC <= 2 && ctx->tune.red_blocks_per_cu > 1) ? 1 : ctx->tune.red_blocks_per_cu;
+  const int grid = grid_for(ctx, nvec, (int64_t)kBlock * UNROLL, per_cu);
   if constexpr (NC <= kFuseMaxCols) {
     if (fused_out && grid <= kFuseMaxGrid) {
       if (nt)

@@ -12,7 +12,9 @@ out = sys.argv[1]
 WANT = {"qn_apply_persist_kernel": ("InverseLBFGS m=10 n=2^20, persistent apply", (2 * 21 + 1) * 8.0 * (1 << 20)),
         "extend_mask_kernel": ("opExtension 2e7 of 4e7, mask + ranks", 8.0 * 2e7 + 8.0 * 4e7 + 4e7 / 4),
         "gather_mask_kernel": ("opRestriction 2e7 of 4e7, mask + ranks", 8.0 * 2e7 + 8.0 * 4e7 + 4e7 / 4),
-        "gemvb_t_lds_kernel": ("M'*V n=16384 k=8, LDS-staged", 8.0 * 16384 * 16384 + 2 * 8.0 * 16384 * 8)}
+        "gemvb_t_lds_kernel": ("M'*V n=16384 k=8, LDS-staged", 8.0 * 16384 * 16384 + 2 * 8.0 * 16384 * 8),
+        "gemv_n_rows_kernel": ("dense M*v n=16384 f64, row bands", 8.0 * 16384 * 16384 + 2 * 8.0 * 16384),
+        "cgemv_rows_band_kernel": ("ComplexF64 M*v n=8192, row bands", 16.0 * 8192 * 8192 + 2 * 16.0 * 8192)}
 
 
 def key(name):

@@ -591,6 +591,8 @@ def worker(args):
     # ---- quasi-Newton apply/s (the second figure of the metric string)
     if not args.no_extras and hasattr(lo, "InverseLBFGSOperator"):
         with wd.phase("quasi-Newton legs"):
+            if os.environ.get("MXLO_BENCH_FAULT") == "extras-stall" and rank == world - 1 and world > 1:
+                time.sleep(1e6)                          # TEST HOOK: the last rank never joins the extras' collectives
             try:
                 extras.update(bench_lbfgs(lo, torch, dev, ctx, rank, world, distributed, dist, barrier))
             except Exception as e:  # never lose the headline line
@@ -657,16 +659,20 @@ def worker(args):
     if rank == 0:
         out["phases_s"] = {k: v for k, v in wd.history}
     with wd.phase("teardown"):
-        del H, h, v, res
-        torch.cuda.synchronize()
-        if distributed:
-            ctx.set_allreduce(None)                      # the communicator itself is released at process exit
-        if peer_hook is not None:
-            peer_hook.close()
-        torch.cuda.empty_cache()
-        if distributed:
-            dist.barrier()
-            dist.destroy_process_group()
+        try:                                             # best effort: the line is complete, a peer that is already gone
+            del H, h, v, res                             # (its own rescue, a crash) must not turn it into a failure
+            torch.cuda.synchronize()
+            if distributed:
+                ctx.set_allreduce(None)                  # the communicator itself is released at process exit
+            if peer_hook is not None:
+                peer_hook.close()
+            torch.cuda.empty_cache()
+            if distributed:
+                dist.barrier()
+                dist.destroy_process_group()
+        except Exception as e:
+            if rank == 0:
+                out["teardown_error"] = repr(e)[:300]
     return out
 
 

@@ -55,3 +55,41 @@ def test_a_failing_or_stalled_second_transport_leg_cannot_sink_the_headline(faul
     ps = d["transports"]["peer_shm"]
     assert ("injected failure" in ps["error"]) if fault == "peer-leg" else ("stalled" in ps["error"])
     assert "abandoned" in ps["note"] and "householder_ms_per_step" not in ps
+
+
+def test_two_ranks_on_one_device_over_the_debug_transport():
+    """`bench.py --gpus 2 --single-device --backend gloo`: the self-launcher starts two ranks of worker() on device 0 (RCCL refuses
+    that, so the all-reduce is the torch.distributed hook over gloo): every collective of the N-rank path — operand
+    normalisation, the sharded Householder / quasi-Newton legs, max-over-ranks timing, tear-down — runs with world 2, and
+    rank 0's ONE line reports n_gpus = 2 with the whole-job bandwidth."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--single-device", "--backend", "gloo", "--steps", "5",
+                        "--warmup", "2", "--nelem", "4000000", "--no-cpu-baseline", "--no-shard-leg", "--clock-spin-s", "0.05"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), p.stdout[-500:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["scaling"] == "weak" and "abandoned" not in d
+    assert "2 ranks" in d["config"]["sharding"] and "launcher" in d["config"]
+    assert "lbfgs_error" not in d["extras"] and "cfg4_error" not in d["extras"]
+    assert d["extras"]["cfg5_LBFGS_fwd_m20_sharded"]["n_gpus"] == 2
+
+
+def test_a_rank_that_never_joins_an_extra_leg_cannot_sink_the_headline():
+    """Two ranks; after the headline is measured the last rank never enters the quasi-Newton legs (injected). Rank 0 sits in
+    their first collective until its watchdog fires (or the collective fails), then prints the line it has — headline,
+    roofline, what was already measured — and every rank exits 0; the launcher relays the line."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY="0", MXLO_BENCH_FAULT="extras-stall")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--single-device", "--backend", "gloo", "--steps", "5",
+                        "--warmup", "2", "--nelem", "4000000", "--no-cpu-baseline", "--no-shard-leg", "--clock-spin-s", "0.05",
+                        "--phase-timeout-scale", "0.03"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), p.stdout[-500:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["roofline"]["frac"] > 0
+    assert "abandoned" in d or "lbfgs_error" in d["extras"] or "teardown_error" in d

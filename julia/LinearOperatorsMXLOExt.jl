@@ -406,23 +406,31 @@ end
 # α, β are ignored by the reference and are not ABI parameters. `opRestriction(I, ncol; S = MXVector{T})` and
 # `opExtension` are the reference's own constructors; their closures land here. Ranges need no device memory; an
 # index Vector is uploaded once and cached per (objectid, length) together with its last-write-wins scatter plan.
-struct ScatterPlan            # duplicates: `res[I] = u` is sequential, the LAST write wins — resolved once, into a SORTED plan
-  didx::MXVector{Int64}       # I as given (gather)
-  idx::MXVector{Int64}        # strictly increasing target indices (scatter)
-  pos::Union{MXVector{Int64}, Nothing}   # 0-based position in u of the surviving write; nothing = identity
-  n::Int
-  hidx::Vector{Int64}         # the strictly increasing indices on the host (what an index plan is built from)
-  masks::Dict{Int, Ptr{Cvoid}}   # length of the long vector => mxlo_index_plan (bit mask + ranks), built on first use
+mutable struct ScatterPlan    # duplicates: `res[I] = u` is sequential, the LAST write wins — resolved once, into a SORTED plan
+  const didx::MXVector{Int64}       # I as given (gather)
+  const idx::MXVector{Int64}        # strictly increasing target indices (scatter)
+  const pos::Union{MXVector{Int64}, Nothing}   # 0-based position in u of the surviving write; nothing = identity
+  const n::Int
+  const hidx::Vector{Int64}         # the strictly increasing indices on the host (what an index plan is built from)
+  const masks::Dict{Int, Ptr{Cvoid}}   # length of the long vector => mxlo_index_plan (bit mask + ranks), built on first use
+end
+# the cached index plans are library handles (n/4 bytes of device memory each): released with the plan (mutable => finalizable)
+function release_masks(pl::ScatterPlan)
+  for h in values(pl.masks)
+    ccall((:mxlo_index_plan_destroy, lib), Int32, (P,), h)
+  end
+  empty!(pl.masks)
 end
 function ScatterPlan(I::AbstractVector{<:Integer})
   didx = MXVector(collect(Int64, I))
-  (issorted(I) && allunique(I)) && return ScatterPlan(didx, didx, nothing, length(I), collect(Int64, I), Dict{Int, Ptr{Cvoid}}())
+  (issorted(I) && allunique(I)) &&
+    return finalizer(release_masks, ScatterPlan(didx, didx, nothing, length(I), collect(Int64, I), Dict{Int, Ptr{Cvoid}}()))
   last = Dict{Int64, Int64}()
   for (k, i) in enumerate(I)
     last[i] = k - 1                                   # 0-based source position of the surviving write
   end
   ks = sort!(collect(keys(last)))
-  ScatterPlan(didx, MXVector(ks), MXVector([last[i] for i in ks]), length(ks), ks, Dict{Int, Ptr{Cvoid}}())
+  finalizer(release_masks, ScatterPlan(didx, MXVector(ks), MXVector([last[i] for i in ks]), length(ks), ks, Dict{Int, Ptr{Cvoid}}()))
 end
 # A dense enough strictly increasing index set is applied as bit mask + ranks (include/mxlo.h "index plans"): neither
 # mulRestrict! nor multRestrict! then reads the index list. Built once per (I, length of the long vector); C_NULL below
@@ -678,7 +686,9 @@ end
 # ---- a12-a16 quasi-Newton operators: the structural contract (src/lbfgs.jl:62-104, src/lsr1.jl:39-78) ---------
 struct MXQNData                # stands in for op.data: fields the reference's tests read come from the handle
   h::Ptr{Cvoid}
-  mem::Int
+  mem::Int                     # max(mem, 1) (lbfgs.jl:37, lsr1.jl:21)
+  scaling::Bool                # the `const` fields of LBFGSData / LSR1Data (lbfgs.jl:6-8, lsr1.jl:6)
+  damped::Bool
 end
 function scalars(d::MXQNData)
   sc = Vector{Float64}(undef, 5); ys = Vector{Float64}(undef, d.mem); aux = Vector{Float64}(undef, d.mem)
@@ -686,7 +696,7 @@ function scalars(d::MXQNData)
   (insert = Int(sc[1]), scaling_factor = sc[2], opnorm_upper_bound = sc[3], ys = ys, aux = aux)
 end
 Base.getproperty(d::MXQNData, s::Symbol) =
-  s === :h || s === :mem ? getfield(d, s) : getproperty(scalars(d), s)   # op.data.insert, .scaling_factor, .ys
+  s in (:h, :mem, :scaling, :damped) ? getfield(d, s) : getproperty(scalars(d), s)   # op.data.insert, .scaling_factor, .ys
 
 mutable struct MXQNOperator{T, F, Ft} <: AbstractQuasiNewtonOperator{T}
   const nrow::Int
@@ -707,8 +717,13 @@ has_args5(::MXQNOperator) = true
 isallocated5(::MXQNOperator) = true
 storage_type(::MXQNOperator{T}) where {T} = MXVector{T}
 
-function mxqn(::Type{T}, kind::Integer, n::Int; mem::Int = 5, scaling::Bool = kind != 2, damped::Bool = false,
-              σ₂ = 0.99, σ₃ = 10.0) where {T}
+# Keywords and defaults are the reference's: LBFGSData(T, n; mem = 5, scaling = true, damped = false, inverse = true,
+# σ₂ = 0.99, σ₃ = 10.0) (src/lbfgs.jl:26-35) and LSR1Data(T, n; mem = 5, scaling = true) (src/lsr1.jl:19 — the CODE default is
+# `true`; the docstring at lsr1.jl:81 says `false` and is wrong). `inverse` is accepted and ignored like the reference's
+# constructors do (`delete!(kwargs, :inverse)`, lbfgs.jl:115,171): the constructor's name decides. LSR1Data takes neither
+# `damped` nor σ₂/σ₃ (a MethodError upstream): lsr1 below passes only its own two.
+function mxqn(::Type{T}, kind::Integer, n::Int; mem::Int = 5, scaling::Bool = true, damped::Bool = false,
+              inverse::Bool = true, σ₂::Float64 = 0.99, σ₃::Float64 = 10.0) where {T}
   r = Ref{Ptr{Cvoid}}()
   check(ccall((:mxlo_qn_create, lib), Int32, (P, Int32, Int32, Int64, Int64, Int32, Int32, Float64, Float64, Ptr{P}),
               ctx(), Int32(kind), dt(T), n, mem, scaling, damped, σ₂, σ₃, r))
@@ -717,29 +732,55 @@ function mxqn(::Type{T}, kind::Integer, n::Int; mem::Int = 5, scaling::Bool = ki
                                         h, res.ptr, x.ptr, α, β, flags(T, α, β)))
   t = kind == 2 ? nothing : prod!                                 # L-SR1: tprod! = ctprod! = nothing (lsr1.jl:108-110)
   op = MXQNOperator{T, typeof(prod!), typeof(t)}(n, n, true, true, prod!, t, t, Int32(kind), kind == 0,
-                                                 MXQNData(h, max(mem, 1)), 0, 0, 0)
+                                                 MXQNData(h, max(mem, 1), scaling, damped), 0, 0, 0)
   finalizer(o -> ccall((:mxlo_qn_destroy, lib), Int32, (P,), o.data.h), op)
 end
+lsr1(::Type{T}, n::Int; mem::Int = 5, scaling::Bool = true) where {T} = mxqn(T, 2, n; mem = mem, scaling = scaling)
 InverseLBFGSOperator(::Type{T}, n::Int, ::Type{MXVector{T}}; kw...) where {T} = mxqn(T, 0, n; kw...)
 LBFGSOperator(::Type{T}, n::Int, ::Type{MXVector{T}}; kw...) where {T} = mxqn(T, 1, n; kw...)
-LSR1Operator(::Type{T}, n::Int, ::Type{MXVector{T}}; kw...) where {T} = mxqn(T, 2, n; kw...)
+LSR1Operator(::Type{T}, n::Int, ::Type{MXVector{T}}; kw...) where {T} = lsr1(T, n; kw...)
+# the `T`-less forms (lbfgs.jl:160,208, lsr1.jl:113: Float64): the storage type names the element type
+InverseLBFGSOperator(n::Int, ::Type{MXVector{T}}; kw...) where {T} = mxqn(T, 0, n; kw...)
+LBFGSOperator(n::Int, ::Type{MXVector{T}}; kw...) where {T} = mxqn(T, 1, n; kw...)
+LSR1Operator(n::Int, ::Type{MXVector{T}}; kw...) where {T} = lsr1(T, n; kw...)
 
-# push! ×3 (src/lbfgs.jl:269-357, src/lsr1.jl:119-184); rejection is silent, exactly like the reference.
+# push! ×4 (src/lbfgs.jl:269-367) + L-SR1's single method (src/lsr1.jl:119-184); rejection of a pair is silent, exactly like
+# the reference. The guards are the reference's, statement for statement (tests/test_julia_semantics.py evaluates both texts
+# over every (damped, inverse, arity) and compares with the Python mirror); the library would refuse the same calls with
+# MXLO_ESTATE (also an ErrorException), but the messages and the redirects are part of the contract.
 function push!(op::MXQNOperator{T}, s::MXVector{T}, y::MXVector{T}) where {T}
+  if op.data.damped                                         # lbfgs.jl:274-276 (L-SR1 is never damped)
+    return push!(op, s, y, similar(s))
+  end
   acc = Ref{Int32}(0)
   check(ccall((:mxlo_qn_push, lib), Int32, (P, P, P, Ptr{Int32}), op.data.h, s.ptr, y.ptr, acc))
   op
 end
 function push!(op::MXQNOperator{T}, s::MXVector{T}, y::MXVector{T}, Bs::MXVector{T}) where {T}
-  acc = Ref{Int32}(0)          # wrong variant -> MXLO_ESTATE -> ErrorException, as lbfgs.jl:295-299
+  op.kind == 2 && throw(MethodError(push!, (op, s, y, Bs)))   # lsr1.jl:119 is the only method for LSR1Operator
+  if !op.data.damped                                        # lbfgs.jl:295-299
+    error("This push! should be used for damped operators")
+  elseif op.inverse
+    error("This function be used for forward operators. Use push!(op, s, y, α, g, Bs) instead.")
+  end
+  acc = Ref{Int32}(0)
   check(ccall((:mxlo_qn_push_damped_fwd, lib), Int32, (P, P, P, P, Ptr{Int32}), op.data.h, s.ptr, y.ptr, Bs.ptr, acc))
   op
 end
 function push!(op::MXQNOperator{T}, s::MXVector{T}, y::MXVector{T}, α::T, g::MXVector{T}, Bs::MXVector{T}) where {T}
+  op.kind == 2 && throw(MethodError(push!, (op, s, y, α, g, Bs)))
+  if !op.data.damped                                        # lbfgs.jl:333-337
+    error("This push! should be used for damped operators")
+  elseif !op.inverse
+    error("This function be used for inverse operators. Use push!(op, s, y, Bs) instead.")
+  end
   acc = Ref{Int32}(0)
   check(ccall((:mxlo_qn_push_damped_inv, lib), Int32, (P, P, P, Float64, P, P, Ptr{Int32}),
               op.data.h, s.ptr, y.ptr, α, g.ptr, Bs.ptr, acc))
   op
+end
+function push!(op::MXQNOperator{T}, s::MXVector{T}, y::MXVector{T}, α::T, g::MXVector{T}) where {T}   # lbfgs.jl:359-367
+  push!(op, s, y, α, g, similar(g))
 end
 function reset!(op::MXQNOperator)
   check(ccall((:mxlo_qn_reset, lib), Int32, (P,), op.data.h))
@@ -865,8 +906,10 @@ mutable struct ShardedQN{T}
   h::Ptr{Cvoid}
   sc::ShardCtx
 end
-function ShardedQN(::Type{T}, sc::ShardCtx, kind::Integer, nloc::Vector{<:Integer}; mem::Int = 5, scaling::Bool = kind != 2,
-                   damped::Bool = false, σ₂ = 0.99, σ₃ = 10.0) where {T <: RealT}
+# keywords and defaults as mxqn (= the reference's LBFGSData / LSR1Data); the sharded handle has the plain push! only
+# (mxlo_qn_push_sharded): a damped sharded operator is refused at its first push! (MXLO_ESTATE -> ErrorException)
+function ShardedQN(::Type{T}, sc::ShardCtx, kind::Integer, nloc::Vector{<:Integer}; mem::Int = 5, scaling::Bool = true,
+                   damped::Bool = false, inverse::Bool = true, σ₂::Float64 = 0.99, σ₃::Float64 = 10.0) where {T <: RealT}
   r = Ref{Ptr{Cvoid}}()
   scheck(ccall((:mxlo_qn_create_sharded, rccl), Int32, (P, Int32, Int32, Ptr{Int64}, Int64, Int32, Int32, Float64, Float64, Ptr{P}),
                sc.h, Int32(kind), dt(T), collect(Int64, nloc), mem, scaling, damped, σ₂, σ₃, r))

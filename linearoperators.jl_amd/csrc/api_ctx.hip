@@ -458,6 +458,9 @@ MXLO_API int32_t mxlo_ctx_tune(mxlo_ctx *ctx, const char *key, int64_t value) {
   } else if (!strcmp(key, "gemv_n_rows")) {
     MXLO_REQUIRE(value >= 0 && value <= 128, MXLO_EINVAL, "gemv_n_rows must be 0 (off), 1 (auto) or a band height");
     ctx->tune.gemv_n_rows = (int)value;
+  } else if (!strcmp(key, "gemvb_n_rows")) {
+    MXLO_REQUIRE(value == 0 || value == 1, MXLO_EINVAL, "gemvb_n_rows must be 0 or 1");
+    ctx->tune.gemvb_n_rows = (int)value;
   } else if (!strcmp(key, "gemvb_t_lds")) {
     MXLO_REQUIRE(value == 0 || value == 1, MXLO_EINVAL, "gemvb_t_lds must be 0 or 1");
     ctx->tune.gemvb_t_lds = (int)value;

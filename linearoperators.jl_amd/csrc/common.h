@@ -157,6 +157,7 @@ struct Tune {
                                       // alike); NO gain at 4096 (17.8 vs 18.4 f64, 12.4 vs 10.8 f32) and 8192: there the strips' own
                                       // load -> butterfly -> store chain sets the time, not the finish launch
   int gemv_n_rows = 1;     // dense M*v: row bands, the column sum stays inside a workgroup — one launch, no partials (dense.hip)
+  int gemvb_n_rows = 1;    // block apply M*V of a dense operator: row bands, V staged in LDS per workgroup — one launch, no partials (dense.hip)
   int gemvb_t_lds = 1;     // transposed block apply of a dense operator (k >= 4): U staged in LDS per workgroup (dense.hip)
   int combine_reverse = 0; // four-launch applies: the combine pass walks the vectors back to front. Measured (round 5,
                            // profiles/r05_bench_mid_apply.txt): -3.6 … +2.8 %, no gain on average — the grid-stride dots pass
@@ -349,6 +350,57 @@ __device__ __forceinline__ double wave_allsum(double v) {
   return v;
 #endif
 }
+
+// ---- halving butterfly steps without LDS ---------------------------------------------------------------------------
+// One step of a halving reduction over the lanes: every lane holds TWO partial sums x, y; lanes whose bit B is clear keep
+// x and hand y to lane l ^ B, the others keep y and hand x over — afterwards each lane holds ONE sum over twice the lanes:
+//   bit clear: x[l] + x[l ^ B]          bit set: y[l] + y[l ^ B]
+// i.e. exactly  (bit ? y : x) + __shfl_xor(bit ? x : y, B)  (the adds are the same two operands: same bits), but a 64-bit
+// __shfl_xor is two ds_bpermute_b32 round trips through LDS. B = 32 / 16 are ONE v_permlane32_swap / v_permlane16_swap per
+// register half (gfx950: the swap IS the exchange — no select at all), B = 8 / 4 DPP row moves under bank masks.
+__device__ __forceinline__ double halve_step32(double x, double y) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const auto l = __builtin_amdgcn_permlane32_swap(__double2loint(x), __double2loint(y), false, false);
+  const auto h = __builtin_amdgcn_permlane32_swap(__double2hiint(x), __double2hiint(y), false, false);
+  // [0]: lanes 0..31 x[l], lanes 32..63 y[l - 32];  [1]: lanes 0..31 x[l + 32], lanes 32..63 y[l]
+  return __hiloint2double((int)h[0], (int)l[0]) + __hiloint2double((int)h[1], (int)l[1]);
+#else
+  return x + y;
+#endif
+}
+__device__ __forceinline__ double halve_step16(double x, double y) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const auto l = __builtin_amdgcn_permlane16_swap(__double2loint(x), __double2loint(y), false, false);
+  const auto h = __builtin_amdgcn_permlane16_swap(__double2hiint(x), __double2hiint(y), false, false);
+  // [0]: even rows x[l], odd rows y[l - 16];  [1]: even rows x[l + 16], odd rows y[l]
+  return __hiloint2double((int)h[0], (int)l[0]) + __hiloint2double((int)h[1], (int)l[1]);
+#else
+  return x + y;
+#endif
+}
+// CTRL_UP: lane l reads lane l + B of its row (row_shl:B), CTRL_DN: lane l - B (row_shr:B); BANKS_CLR = the banks
+// (4-lane groups of a row) whose lanes have bit B clear.
+template <int CTRL_UP, int CTRL_DN, int BANKS_CLR>
+__device__ __forceinline__ double halve_step_dpp(double x, double y) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int BANKS_SET = 0xf & ~BANKS_CLR;
+  int kl = __double2loint(x), kh = __double2hiint(x);       // keep: x where the bit is clear, y where it is set
+  kl = __builtin_amdgcn_update_dpp(kl, __double2loint(y), 0xe4, 0xf, BANKS_SET, false);   // quad_perm [0,1,2,3]
+  kh = __builtin_amdgcn_update_dpp(kh, __double2hiint(y), 0xe4, 0xf, BANKS_SET, false);
+  int rl = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL_UP, 0xf, BANKS_CLR, false);   // x[l + B] into the clear lanes
+  int rh = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL_UP, 0xf, BANKS_CLR, false);
+  rl = __builtin_amdgcn_update_dpp(rl, __double2loint(y), CTRL_DN, 0xf, BANKS_SET, false);      // y[l - B] into the set lanes
+  rh = __builtin_amdgcn_update_dpp(rh, __double2hiint(y), CTRL_DN, 0xf, BANKS_SET, false);
+  return __hiloint2double(kh, kl) + __hiloint2double(rh, rl);
+#else
+  return x + y;
+#endif
+}
+__device__ __forceinline__ double halve_step8(double x, double y) { return halve_step_dpp<0x108, 0x118, 0x3>(x, y); }
+__device__ __forceinline__ double halve_step4(double x, double y) { return halve_step_dpp<0x104, 0x114, 0x5>(x, y); }
+// v[l] + v[l ^ 2], v[l] + v[l ^ 1] in every lane (quad permutes)
+__device__ __forceinline__ double pair_step2(double v) { return v + dpp_shift_or_zero<0x4e, 0xf>(v); }
+__device__ __forceinline__ double pair_step1(double v) { return v + dpp_shift_or_zero<0xb1, 0xf>(v); }
 
 // ---- alignment analysis for the vector path ---------------------------------
 // All operands of an elementwise kernel can use 16-byte accesses iff they share

@@ -593,9 +593,9 @@ int32_t cgemv_any(mxlo_ctx *ctx, C<R> *res, const C<R> *M, int64_t m, int64_t n,
         const Sc<RA> a{(RA)s.are, (RA)s.aim, s.a_real};
         const Sc<RB> b{(RB)s.bre, (RB)s.bim, s.b_real};
 #define CROWS(CJ_, RB_)                                                                                               \
-  if (nt) hipLaunchKernelGGL((cgemv_rows_band_kernel<R, RA, RB, B0, CJ_, RB_, true>), dim3((unsigned)((m + RB_ - 1) / RB_)), \
+  if (nt) hipLaunchKernelGGL((cgemv_rows_band_kernel<R, RA, RB, B0, CJ_, RB_, true>), dim3((unsigned)((m + (RB_) - 1) / (RB_))), \
                              dim3(kCRowsBlock), 0, ctx->stream, res, M, m, n, ld, v, a, b);                             \
-  else hipLaunchKernelGGL((cgemv_rows_band_kernel<R, RA, RB, B0, CJ_, RB_, false>), dim3((unsigned)((m + RB_ - 1) / RB_)), \
+  else hipLaunchKernelGGL((cgemv_rows_band_kernel<R, RA, RB, B0, CJ_, RB_, false>), dim3((unsigned)((m + (RB_) - 1) / (RB_))), \
                           dim3(kCRowsBlock), 0, ctx->stream, res, M, m, n, ld, v, a, b)
         const bool nt = (int64_t)sizeof(C<R>) * m * n >= ctx->tune.nt_min_bytes;   // cache-sized matrices keep default loads
         if (conj) {

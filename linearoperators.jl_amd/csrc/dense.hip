@@ -414,9 +414,9 @@ int32_t gemv_n(mxlo_ctx *ctx, T *res, const T *M, int64_t m, int64_t n, int64_t 
       const bool nt = (int64_t)sizeof(T) * m * n >= ctx->tune.nt_min_bytes;   // see gemv_t: cache-sized matrices keep default loads
       return dispatch_ab<T>(beta, flags, [&]<typename CA, typename CB, bool B0>() -> int32_t {
 #define ROWS(RB_)                                                                                                     \
-  if (nt) hipLaunchKernelGGL((gemv_n_rows_kernel<T, CA, CB, B0, RB_, true>), dim3((unsigned)((m + RB_ - 1) / RB_)),   \
+  if (nt) hipLaunchKernelGGL((gemv_n_rows_kernel<T, CA, CB, B0, RB_, true>), dim3((unsigned)((m + (RB_) - 1) / (RB_))),   \
                              dim3(kGemvRowsBlock), 0, ctx->stream, res, M, m, n, ld, v, (CA)alpha, (CB)beta);         \
-  else hipLaunchKernelGGL((gemv_n_rows_kernel<T, CA, CB, B0, RB_, false>), dim3((unsigned)((m + RB_ - 1) / RB_)),     \
+  else hipLaunchKernelGGL((gemv_n_rows_kernel<T, CA, CB, B0, RB_, false>), dim3((unsigned)((m + (RB_) - 1) / (RB_))),     \
                           dim3(kGemvRowsBlock), 0, ctx->stream, res, M, m, n, ld, v, (CA)alpha, (CB)beta)
         if (rb == 32 * VR) { ROWS(32 * VR); }
         else if (rb == 16 * VR) { ROWS(16 * VR); }
@@ -583,6 +583,162 @@ gemvb_n_finish_kernel(T *__restrict__ res, int64_t ldr, const double *__restrict
   for (int q = 0; q < 8; ++q) acc += sred[q][r];
   T *o = res + i + (int64_t)c * ldr;
   *o = fin_ab<T, CA, CB, BETA0>(alpha * (CA)(T)acc, beta, BETA0 ? T(0) : *o);
+}
+
+// N mode, ROW BANDS for a block of KB vectors (round 6): gemv_n_rows_kernel's schedule — a 512-thread workgroup owns RB
+// rows across ALL columns, LPR lanes cover the band's piece of one column with 16-byte loads, so the sum over the columns
+// never leaves the workgroup: no partial workspace (the column-chunk form above writes and re-reads nchunks * KB * m
+// doubles, 69 MB next to a 2.1 GB matrix at n = 16384, k = 8, and adds ONE write stream to the read streams) and no
+// dependent finish launch — with KB accumulators per row and lane. A wave's lanes span 64 / LPR columns of M, so V[j, c]
+// is not wave-uniform: the block V is staged in LDS once per WORKGROUP, CH columns x KB at a time in its own layout
+// (double-buffered: the next chunk travels global -> registers while the current one is consumed; one barrier per chunk),
+// and every lane reads its column's KB values from there (ds_read_b64, the lanes of one column share the address). The
+// loads of M for the next step are issued BEFORE the current step is consumed (two register sets): a barrier never finds
+// the memory pipe empty. Column assignment, order of the fma's per lane, tail and the fixed-order sum over the column
+// lanes through LDS are gemv_n_rows_kernel's, per vector: column c of the block has the BITS of the single apply.
+template <typename T, typename CA, typename CB, bool BETA0, int KB, int RB, bool NT>
+__global__ void __launch_bounds__(kGemvRowsBlock)
+gemvb_n_rows_kernel(T *__restrict__ res, int64_t ldr, const T *__restrict__ M, int64_t m, int64_t n, int64_t ld,
+                    const T *__restrict__ V, int64_t ldv, CA alpha, CB beta) {
+  constexpr int VR = 16 / (int)sizeof(T);
+  typedef T VV __attribute__((ext_vector_type(VR)));
+  // U loads of M per lane and register set (two sets): 8 + 8 in flight up to 4 vectors, 4 + 4 with 8 (the accumulators take the room)
+  constexpr int LPR = RB / VR, NCL = kGemvRowsBlock / LPR, U = (KB >= 8 || RB == 8 * VR) ? 4 : 8, STEP = NCL * U;
+  constexpr int ITS = STEP >= 512 ? 1 : 512 / STEP, CH = STEP * ITS;      // 512 columns of V per staged chunk
+  static_assert(RB % VR == 0 && kGemvRowsBlock % LPR == 0 && RB <= kGemvRowsBlock, "bad row band");
+  constexpr int SL = KB * CH / kGemvRowsBlock;                            // staging loads per thread and chunk
+  static_assert(KB * CH % kGemvRowsBlock == 0, "bad staging shape");
+  constexpr int kRedDoubles = NCL * RB, kStageDoubles = (int)((size_t)2 * KB * CH * sizeof(T) / 8);
+  __shared__ double lds[kRedDoubles > kStageDoubles ? kRedDoubles : kStageDoubles];
+  T *vlds = reinterpret_cast<T *>(lds);                                   // [2][KB][CH]
+  const int tid = threadIdx.x, seg = tid % LPR, cl = tid / LPR;
+  const int64_t row = (int64_t)blockIdx.x * RB + (int64_t)seg * VR;
+  const bool live = row < m;                       // m % VR == 0: a vector is wholly inside or wholly outside
+  const T *base = M + (live ? row : 0);
+  double acc[KB][VR];
+#pragma unroll
+  for (int c = 0; c < KB; ++c)
+#pragma unroll
+    for (int e = 0; e < VR; ++e) acc[c][e] = 0.0;
+  const int64_t nmain = n / STEP;                  // whole steps of U columns per column lane
+  const int64_t nfull = nmain / ITS;               // whole chunks of ITS steps
+  T sreg[SL];
+  auto stage_load = [&](int64_t ch) {              // global -> registers: V[ch * CH + j, c], zero past the end (masked, never skipped)
+#pragma unroll
+    for (int k = 0; k < SL; ++k) {
+      const int idx = tid + k * kGemvRowsBlock, c = idx / CH, jl = idx % CH;
+      const int64_t j = ch * CH + jl;
+      const T x = V[(j < n ? j : n - 1) + (int64_t)c * ldv];     // clamped, unconditional load + select: no branch
+      sreg[k] = j < n ? x : T(0);
+    }
+  };
+  auto stage_store = [&](int buf) {
+#pragma unroll
+    for (int k = 0; k < SL; ++k) vlds[(size_t)buf * KB * CH + tid + k * kGemvRowsBlock] = sreg[k];
+  };
+  auto load_step = [&](VV (&a)[U], int64_t it) {
+    const int64_t j = it * STEP + cl;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const VV *q = reinterpret_cast<const VV *>(base + (j + (int64_t)u * NCL) * ld);
+      a[u] = NT ? __builtin_nontemporal_load(q) : *q;
+    }
+  };
+  auto consume = [&](const VV (&a)[U], int64_t it) {
+    const T *x = vlds + (size_t)((it / ITS) & 1) * KB * CH + (it % ITS) * STEP + cl;
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int c = 0; c < KB; ++c) {
+        const double xv = (double)x[c * CH + u * NCL];
+#pragma unroll
+        for (int e = 0; e < VR; ++e) acc[c][e] = fma((double)a[u][e], xv, acc[c][e]);
+      }
+  };
+  stage_load(0);
+  stage_store(0);
+  __syncthreads();
+  // (lanes past the last row — only in the last band — read row 0's pieces instead: every lane of the workgroup walks
+  //  the same schedule and meets the same barriers; their sums are never stored)
+  // The steady state is STRAIGHT-LINE code per chunk — every load of it is issued unconditionally (past the end: a clamped,
+  // valid step whose data is not used; staging past n: masked to zero) — so that the counted s_waitcnt before each consume
+  // is exact: a prefetch under a condition makes the compiler wait for vmcnt(0), i.e. serialises load and use (measured:
+  // 735 us instead of 330 at n = 16384, k = 2).
+  if (nmain > 0) {
+    static_assert(ITS % 2 == 0, "two register sets");
+    VV a0[U], a1[U];
+    load_step(a0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    for (int64_t ch = 0; ch < nfull; ++ch) {
+      stage_load(ch + 1);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int sidx = 0; sidx < ITS; sidx += 2) {
+        const int64_t it = ch * ITS + sidx;
+        // (scheduling fences: left alone, the compiler sinks each prefetch into the consume that follows it to save
+        //  registers and waits for it with vmcnt(0) — the pipelining is the point of the two register sets)
+        load_step(a1, it + 1);                                     // inside the chunk: always a whole step
+        __builtin_amdgcn_sched_barrier(0);
+        consume(a0, it);
+        __builtin_amdgcn_sched_barrier(0);
+        load_step(a0, it + 2 < nmain ? it + 2 : nmain - 1);        // the step after the last: a valid one, unused
+        __builtin_amdgcn_sched_barrier(0);
+        consume(a1, it + 1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      stage_store((int)((ch + 1) & 1));
+      __syncthreads();
+    }
+    int64_t it = nfull * ITS;                                      // the steps of the last, partial chunk (already staged)
+    if (it < nmain) {
+      consume(a0, it);                                             // requested by the loop above (or before it)
+      for (++it; it < nmain; ++it) {
+        load_step(a0, it);
+        consume(a0, it);
+      }
+    }
+  }
+  if (live) {                                      // columns past the last whole step, one per column lane and trip
+    for (int64_t j = nmain * STEP + cl; j < n; j += NCL) {
+      const VV a = *reinterpret_cast<const VV *>(base + j * ld);
+#pragma unroll
+      for (int c = 0; c < KB; ++c) {
+        const double xv = (double)V[j + (int64_t)c * ldv];
+#pragma unroll
+        for (int e = 0; e < VR; ++e) acc[c][e] = fma((double)a[e], xv, acc[c][e]);
+      }
+    }
+  }
+  // per vector of the block: the fixed-order sum over the NCL column lanes of gemv_n_rows_kernel
+  constexpr int Q = RB * 8 <= kGemvRowsBlock ? 8 : kGemvRowsBlock / RB;
+  static_assert(Q >= 1 && NCL % Q == 0 && RB * Q <= kGemvRowsBlock, "bad finish shape");
+  double(*sred)[RB] = reinterpret_cast<double(*)[RB]>(lds);
+  const int r = tid % RB, q = tid / RB;
+#pragma unroll
+  for (int c = 0; c < KB; ++c) {
+    __syncthreads();                               // the staging buffers / the previous vector's sums are dead
+#pragma unroll
+    for (int e = 0; e < VR; ++e) sred[cl][seg * VR + e] = acc[c][e];
+    __syncthreads();
+    double part = 0.0;
+    if (tid < RB * Q) {
+#pragma unroll 8
+      for (int cc = q; cc < NCL; cc += Q) part += sred[cc][r];
+    }
+    __syncthreads();
+    if (tid < RB * Q) sred[q][r] = part;
+    __syncthreads();
+    if (tid < RB) {
+      const int64_t i = (int64_t)blockIdx.x * RB + tid;
+      if (i < m) {
+        double s = 0.0;
+#pragma unroll
+        for (int qq = 0; qq < Q; ++qq) s += sred[qq][tid];
+        T *o = res + i + (int64_t)c * ldr;
+        *o = fin_ab<T, CA, CB, BETA0>(alpha * (CA)(T)s, beta, BETA0 ? T(0) : *o);
+      }
+    }
+  }
 }
 
 // T mode: a wave owns JB = 4 consecutive columns of M and forms their dots with all KB columns of U at once: the four
@@ -809,9 +965,35 @@ template <typename T, int KB>
 int32_t gemv_block_chunk(mxlo_ctx *ctx, T *res, int64_t ldr, const T *M, int64_t m, int64_t n, int64_t ld, const T *V,
                          int64_t ldv, double alpha, double beta, int32_t mode, int32_t flags) {
   if (mode == MXLO_OP_N) {
-    // (a row-band form of this block apply — gemv_n_rows_kernel with KB accumulators per lane, V staged through
-    // wave-private LDS because a wave's lanes span several columns of M — was built and measured slower than this
-    // schedule at every size: profiles/r05_bench_gemv_n.txt)
+    // Row bands with the block staged in LDS per WORKGROUP (round 6; the round-5 attempt staged it per wave and step and was
+    // slower everywhere): taken where the single apply takes its 512- / 256-byte bands, so that every column of the block
+    // has the bits of gemv_n on that column.
+    {
+      constexpr int VR = 16 / (int)sizeof(T);
+      // the tallest band that still gives every CU a workgroup (gemv_rows_band's rule without its exceptions for very wide
+      // matrices: those weigh a finish launch that the block form's column-chunk schedule pays KB-fold)
+      const bool vec = (((uintptr_t)M & 15u) == 0) && ld % VR == 0 && m % VR == 0;
+      int rb = 0;
+      if (ctx->tune.gemvb_n_rows && vec && n >= 1024) {
+        if (m >= (int64_t)32 * VR * ctx->num_cu) rb = 32 * VR;
+        else if (m >= (int64_t)16 * VR * ctx->num_cu) rb = 16 * VR;
+        else if (m >= (int64_t)8 * VR * ctx->num_cu) rb = 8 * VR;
+      }
+      if (rb != 0) {
+        const bool nt = (int64_t)sizeof(T) * m * n >= ctx->tune.nt_min_bytes;
+        return dispatch_ab<T>(beta, flags, [&]<typename CA, typename CB, bool B0>() -> int32_t {
+#define BROWS(RB_, NT_)                                                                                                  \
+  hipLaunchKernelGGL((gemvb_n_rows_kernel<T, CA, CB, B0, KB, RB_, NT_>), dim3((unsigned)((m + (RB_) - 1) / (RB_))),      \
+                     dim3(kGemvRowsBlock), 0, ctx->stream, res, ldr, M, m, n, ld, V, ldv, (CA)alpha, (CB)beta)
+          if (rb == 32 * VR) { if (nt) BROWS(32 * VR, true); else BROWS(32 * VR, false); }
+          else if (rb == 16 * VR) { if (nt) BROWS(16 * VR, true); else BROWS(16 * VR, false); }
+          else { if (nt) BROWS(8 * VR, true); else BROWS(8 * VR, false); }
+#undef BROWS
+          MXLO_LAUNCH_CHECK();
+          return MXLO_OK;
+        });
+      }
+    }
     const bool pair = m >= 2 && (((uintptr_t)M % (2 * sizeof(T))) == 0) && (ld % 2 == 0);
     const int64_t rows_per_block = (int64_t)kBlock * (pair ? 2 : 1);
     const int64_t row_blocks = (m + rows_per_block - 1) / rows_per_block;
@@ -1048,7 +1230,6 @@ herm_strip_body(const T *__restrict__ A, int64_t lda, const T *__restrict__ v, i
     const T *vk = v + kk * ldv;
     double *Pck = Pcol + kk * pstride;
     // FMAs + first butterfly stage, column pair (q, q+8) at a time (keeps the live set small)
-    const bool hi = (lane & 32) != 0;
     double w8[8], w4[4], w2[2], w1;
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
@@ -1063,33 +1244,19 @@ herm_strip_body(const T *__restrict__ A, int64_t lda, const T *__restrict__ v, i
         pa = r == 0 ? a * vr[kk][0] : fma(a, vr[kk][r], pa);
         pb = r == 0 ? b * vr[kk][0] : fma(b, vr[kk][r], pb);
       }
-      w8[q] = (hi ? pb : pa) + __shfl_xor(hi ? pa : pb, 32, 64);
+      w8[q] = halve_step32(pa, pb);           // lanes < 32: column q, rows of lanes l and l + 32; lanes >= 32: column q + 8
       __builtin_amdgcn_sched_barrier(0);
     }
-    // remaining halving steps: 4+2+1 exchanges leave one column per group of 4 lanes, two plain steps finish
-    {
-      const bool h2 = (lane & 16) != 0;
+    // remaining halving steps (permlane16 swap, then DPP row moves: no LDS round trips — common.h): 4 + 2 + 1 exchanges leave
+    // one column per group of 4 lanes, two quad permutes finish. Operands and order of every add are those of the
+    // xor-shuffle butterfly this replaces: same bits.
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const double send = h2 ? w8[q] : w8[4 + q];
-        w4[q] = (h2 ? w8[4 + q] : w8[q]) + __shfl_xor(send, 16, 64);
-      }
-    }
-    {
-      const bool h2 = (lane & 8) != 0;
+    for (int q = 0; q < 4; ++q) w4[q] = halve_step16(w8[q], w8[4 + q]);
 #pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        const double send = h2 ? w4[q] : w4[2 + q];
-        w2[q] = (h2 ? w4[2 + q] : w4[q]) + __shfl_xor(send, 8, 64);
-      }
-    }
-    {
-      const bool h2 = (lane & 4) != 0;
-      const double send = h2 ? w2[0] : w2[1];
-      w1 = (h2 ? w2[1] : w2[0]) + __shfl_xor(send, 4, 64);
-    }
-    w1 += __shfl_xor(w1, 2, 64);
-    w1 += __shfl_xor(w1, 1, 64);
+    for (int q = 0; q < 2; ++q) w2[q] = halve_step8(w4[q], w4[2 + q]);
+    w1 = halve_step4(w2[0], w2[1]);
+    w1 = pair_step2(w1);
+    w1 = pair_step1(w1);
     if ((lane & 3) == 0) {
       const int k = ((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1);
       const int64_t gc = j0 + cg + 2 * k;

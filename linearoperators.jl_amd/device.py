@@ -136,6 +136,18 @@ def get_ctx(device=None) -> Context:
     return ctx
 
 
+def indexed_device(device=None) -> torch.device:
+    """`device` as an INDEXED cuda device: 'cuda' / torch.device('cuda') name the current device but compare unequal to
+    the `cuda:0` every tensor reports, which would silently send `res.device == dev` checks down their slow branch."""
+    if device is None:
+        return torch.device("cuda", torch.cuda.current_device())
+    if not isinstance(device, torch.device):
+        device = torch.device(device)
+    if device.type == "cuda" and device.index is None:
+        return torch.device("cuda", torch.cuda.current_device())
+    return device
+
+
 def ctx_of(t: torch.Tensor) -> Context:
     """`get_ctx(t.device)` for a tensor already known to live on a GPU (the per-apply path of the leaves): the device
     index comes from `get_device()` (no torch.device object), the ctx from the cache, and the stream is re-bound."""

@@ -14,7 +14,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .device import Storage, check_vec, dtype_code, get_ctx, ptr
+from .device import Storage, check_vec, dtype_code, get_ctx, indexed_device, ptr
 from .leaves import mulSquareOpDiagonal
 from .operators import touched, AbstractLinearOperator
 
@@ -104,7 +104,7 @@ def SpectralGradient(sigma, n: int, dtype=None, device=None):
         raise AssertionError("σ > 0")                    # @assert σ > 0 (:185)
     if dtype is None:
         dtype = torch.float32 if isinstance(sigma, np.float32) else torch.float64
-    dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+    dev = indexed_device(device)
     d = torch.tensor([float(sigma)], dtype=dtype, device=dev)
     return SpectralGradientType(d, n)
 

@@ -18,14 +18,14 @@ import ctypes as C
 import torch
 
 from . import _lib
-from .device import get_ctx
+from .device import get_ctx, indexed_device
 
 
 class CapturedSequence:
     """with CapturedSequence(device) as g:  lo.mul(res, op, v, a, b); ...   then  g.replay()"""
 
     def __init__(self, device=None, stream: torch.cuda.Stream | None = None):
-        self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        self.device = indexed_device(device)
         self.stream = stream if stream is not None else torch.cuda.Stream(self.device)
         self._g = C.c_void_p()
         self._ctx = None

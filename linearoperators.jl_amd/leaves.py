@@ -20,7 +20,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .device import Storage, check_vec, ctx_of, dtype_code, get_ctx, ptr, storage_of
+from .device import Storage, check_vec, ctx_of, dtype_code, get_ctx, indexed_device, ptr, storage_of
 from .operators import (AbstractLinearOperator, LinearOperator, LinearOperatorException, _c4, adjoint, columnwise, compose,
                         conj_scalar, issymmetric, ishermitian, mul, scalar_flags, state_version, storage_type, to_dense, transpose)
 
@@ -223,7 +223,7 @@ class _IndexPlan:
 def opRestriction(Idx, ncol: int, S: Optional[Storage] = None, device=None):
     """opRestriction(I, ncol; S) — src/special-operators.jl:176-203. The operator's eltype is the
     index integer type (Int64), like the reference (`LinearOperator{I, Vector{I}}`, :193)."""
-    dev = torch.device(device) if device is not None else (S.device if S is not None else _default_device())
+    dev = indexed_device(device) if device is not None else (indexed_device(S.device) if S is not None else _default_device())
     if _is_colon(Idx):
         return opEye(torch.int64, ncol, S=Storage(torch.int64, dev))    # :201
     if isinstance(Idx, (int, np.integer)):

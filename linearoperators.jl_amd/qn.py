@@ -16,7 +16,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .device import Storage, check_vec, dtype_code, get_ctx, ptr
+from .device import Storage, check_vec, dtype_code, get_ctx, indexed_device, ptr
 from .operators import AbstractLinearOperator, LinearOperatorException, scalar_flags, touched
 
 
@@ -78,7 +78,7 @@ class _QNOperator(AbstractLinearOperator):
 
     def __init__(self, kind: int, T: torch.dtype, n: int, mem: int, scaling: bool, damped: bool, sigma2: float,
                  sigma3: float, device):
-        dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        dev = indexed_device(device)
         self._ctx = get_ctx(dev)
         self._kind = kind
         self.eltype = T

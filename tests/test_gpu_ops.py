@@ -469,7 +469,7 @@ def test_shifted_operator(lo, dev):
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-12), (torch.float32, 3e-5)])
 @pytest.mark.parametrize("m,n", [(1000, 777), (513, 2050), (64, 3), (2, 5000), (4099, 133), (2050, 64), (8192, 31), (8200, 300),
-                                 (4096, 1030), (8192, 2051), (16384, 1024), (1100, 8192)])   # round 5: tall enough for the LDS-staged transposed form; the last four: sizes at which the single-vector N mode takes the row-band kernel (the block form keeps the column-chunk schedule)
+                                 (4096, 1030), (8192, 2051), (16384, 1024), (1100, 8192)])   # round 5: tall enough for the LDS-staged transposed form; the last four: sizes at which the N mode takes its row-band kernels
 @pytest.mark.parametrize("k", [2, 3, 5, 8, 11])
 def test_block_gemv_vs_columns_and_dense(lo, dev, dtype, tol, m, n, k):
     """mul!(res::Matrix, LinearOperator(M), V::Matrix, α, β) through mxlo_gemv_block (M read once per 8 columns) against
@@ -503,6 +503,45 @@ def test_block_gemv_vs_columns_and_dense(lo, dev, dtype, tol, m, n, k):
     res = torch.full((m, k), float("nan"), dtype=dtype, device=dev).t().contiguous().t()
     lo.mul(res, op, cm(Vh))                                            # beta == 0 never reads res
     assert rel(res.cpu().numpy(), W @ Vh) <= tol
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-12), (torch.float32, 3e-5)])
+@pytest.mark.parametrize("m,n", [(16384, 1024), (16392, 1500), (8192, 2051), (8200, 1030), (32768, 1027), (32772, 1155), (4096, 1100), (4100, 1024)])
+@pytest.mark.parametrize("k", [2, 4, 5, 8, 11])
+def test_block_gemv_row_bands_are_bit_identical_to_the_single_applies(lo, dev, dtype, tol, m, n, k):
+    """Round 6: where `M·v` runs as row bands of 512 / 256 bytes per column, `M·V` on a block runs the same bands with V
+    staged in LDS (gemvb_n_rows_kernel): one launch, no partial workspace. Column assignment, fma order and the fixed-order
+    sum over the column lanes are the single apply's, so column c of the block has the BITS of `mul!(res[:, c], op, V[:, c])`
+    (src/operations.jl:34-36 applied to the closure of src/constructors.jl:25-27) — ragged last band (m not a multiple of
+    the band), columns past the last whole step, every (α, β) form; with the knob off the column-chunk schedule agrees to
+    the tolerance."""
+    npd = NP[dtype]
+    rng = np.random.default_rng(m + 3 * n + k)
+    Mh = rng.uniform(-1, 1, (m, n)).astype(npd)
+    Vh = rng.uniform(-1, 1, (n, k)).astype(npd)
+    r0 = rng.uniform(-1, 1, (m, k)).astype(npd)
+    op = lo.LinearOperatorFromMatrix(TM(Mh, dev))
+    V = TM(Vh, dev)
+    ctx = lo.get_ctx(dev)
+    vr, ncu = 16 // np.dtype(npd).itemsize, torch.cuda.get_device_properties(dev).multi_processor_count
+    banded = m % vr == 0 and m >= 8 * vr * ncu and n < 16384   # both forms take the same row band (dense.hip gemv_rows_band)
+    for alpha, beta in ((1.0, 0.0), (2.0, -0.5), (-1.5, 1.0)):
+        res = TM(r0, dev)
+        lo.mul(res, op, V, alpha, beta)
+        cols = TM(r0, dev)
+        for j in range(k):
+            lo.mul(cols[:, j], op, V[:, j], alpha, beta)
+        if banded:
+            assert torch.equal(res, cols), (alpha, beta)
+        ref = alpha * (Mh.astype(np.float64) @ Vh) + beta * r0
+        assert rel(res.cpu().numpy(), ref) <= tol
+    ctx.tune("gemvb_n_rows", 0)
+    try:
+        old = TM(r0, dev)
+        lo.mul(old, op, V, 2.0, -0.5)
+    finally:
+        ctx.tune("gemvb_n_rows", 1)
+    assert rel(old.cpu().numpy(), 2.0 * (Mh.astype(np.float64) @ Vh) - 0.5 * r0) <= tol
 
 
 def test_type_specific_operator_testset(lo, dev):

@@ -25,7 +25,7 @@ def timeit(fn, reps=10):
     return tm.elapsed_ms() / reps * 1e3
 
 
-for key in ("gemvb_t_lds",):
+for key in ("gemvb_t_lds", "gemvb_n_rows"):
     if os.environ.get("MXLO_" + key.upper()) is not None:
         get_ctx(dev).tune(key, int(os.environ["MXLO_" + key.upper()]))
         print(f"# {key} = {os.environ['MXLO_' + key.upper()]}")

@@ -19,7 +19,8 @@ es = 4 if dt == torch.float32 else 8
 if os.environ.get("MXLO_HERM_SINGLE") is not None:
     ctx.tune("herm_single", int(os.environ["MXLO_HERM_SINGLE"]))
     print(f"# herm_single = {os.environ['MXLO_HERM_SINGLE']}")
-for nn in (1024, 2048, 4096, 8192, 16384):
+sizes = tuple(int(x) for x in os.environ.get("MXLO_HERM_SIZES", "1024,2048,4096,8192,16384").split(","))
+for nn in sizes:
     M = torch.rand(nn, nn, dtype=dt, device=dev).t()
     d, x, y = (torch.rand(nn, dtype=dt, device=dev) for _ in range(3))
     H = lo.opHermitian(d, M)

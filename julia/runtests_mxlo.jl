@@ -199,6 +199,27 @@ end
   @test (@allocated push!(BD, x, y, tmpd)) == 0
   @test (@allocated push!(HD, x, y, 1.0, x, tmpd)) == 0
 end
+@testset "push! contract and constructor defaults (src/lbfgs.jl:26-35,269-367, src/lsr1.jl:19,119; tests/golden/reference_semantics.json)" begin
+  n = 50
+  S = MXVector{Float64}
+  s, y, g, tmp = dev(rand(n)), dev(rand(n) .+ 1), dev(rand(n)), dev(zeros(n))
+  # defaults are the reference's CODE defaults (L-SR1: scaling = true, lsr1.jl:19)
+  for op in (LBFGSOperator(Float64, n, S), InverseLBFGSOperator(Float64, n, S), LSR1Operator(Float64, n, S), LBFGSOperator(n, S))
+    @test op.data.mem == 5 && op.data.scaling && !op.data.damped
+  end
+  @test InverseLBFGSOperator(Float64, n, S; inverse = false).inverse          # `inverse` is ignored (lbfgs.jl:115)
+  @test_throws MethodError LSR1Operator(Float64, n, S; damped = true)         # LSR1Data has no such keyword
+  B, H = LBFGSOperator(Float64, n, S), InverseLBFGSOperator(Float64, n, S)
+  BD, HD = LBFGSOperator(Float64, n, S; damped = true), InverseLBFGSOperator(Float64, n, S; damped = true)
+  @test push!(BD, s, y) === BD                                               # damped: redirected to push!(op, s, y, similar(s))
+  @test_throws ErrorException push!(HD, s, y)                                # ... which refuses inverse operators (lbfgs.jl:297-299)
+  @test push!(HD, s, y, 1.0, g) === HD                                       # push!(op, s, y, α, g): Bs = similar(g) (lbfgs.jl:359-367)
+  @test_throws ErrorException push!(B, s, y, tmp)                            # "should be used for damped operators"
+  @test_throws ErrorException push!(H, s, y, 1.0, g, tmp)
+  @test_throws ErrorException push!(BD, s, y, 1.0, g, tmp)                   # forward operator, inverse-form push!
+  @test_throws ErrorException push!(HD, s, y, tmp)
+  @test_throws MethodError push!(LSR1Operator(Float64, n, S), s, y, tmp)     # lsr1.jl:119 is the only method
+end
 # The reference's diagnostics (src/utilities.jl:20-135) probe with HOST vectors (`ones(eltype(S), m)`, `rand(n)`), which a
 # device closure cannot take; the bodies are otherwise storage-agnostic. Here: the same statements with the probes on
 # the device (dot / norm on MXVector are mxlo_dot / mxlo_dot_c) — what tests/test_gpu_utilities.py runs through the

@@ -110,13 +110,13 @@ def _block_end(src: str, i: int) -> int:
 def functions(src: str, name: str) -> list[dict]:
     """Every definition of `name` in `src` (comments already stripped): block form and one-line form."""
     out = []
-    pat = re.compile(rf"(?m)^(?P<indent>[ \t]*)(?P<kw>function\s+)?(?:[A-Za-z_.]+\.)?{re.escape(name)}(?P<tp>\{{[^}}\n]*\}})?\(")
+    pat = re.compile(rf"(?m)^(?P<indent>[ \t]*)(?:@\w+\s+)?(?P<kw>function\s+)?(?:[A-Za-z_.]+\.)?{re.escape(name)}(?P<tp>\{{[^}}\n]*\}})?\(")
     for m in pat.finditer(src):
         lp = m.end() - 1
         rp = _balanced(src, lp)
         args = src[lp + 1: rp - 1]
         rest = src[rp:]
-        wm = re.match(r"\s*where\s*(\{[^}]*\}|\w+(\s*<:\s*[\w{}, .]+)?)", rest)
+        wm = re.match(r"\s*where\s*(\{(?:[^{}]|\{[^{}]*\})*\}|\w+(\s*<:\s*[\w{}, .]+)?)", rest)
         where = wm.group(0).strip() if wm else ""
         after = rp + (wm.end() if wm else 0)
         if m.group("kw"):
@@ -176,7 +176,7 @@ def _jl_cond(cond: str, env: dict) -> bool:
     c = re.sub(r"op\.kind\s*==\s*2", " lsr1 ", c)
     c = c.replace("&&", " and ").replace("||", " or ")
     c = re.sub(r"!\s*(?=[\w( ])", " not ", c)
-    if not re.fullmatch(r"[\sa-z()]*", c) or not set(re.findall(r"[a-z]+", c)) <= {"damped", "inverse", "lsr1", "not", "and", "or"}:
+    if not re.fullmatch(r"[\sa-z0-9()]*", c) or not set(re.findall(r"[a-z0-9]+", c)) <= {"damped", "inverse", "lsr1", "not", "and", "or"}:
         raise AssertionError(f"guard condition not understood: {cond!r}")
     return bool(eval(c, {"__builtins__": {}}, dict(env)))
 
@@ -324,7 +324,8 @@ def _canon_flag(expr: str, env: dict) -> bool:
 
 def _canon_fn(expr: str, prod: str, assigns: dict, env: dict) -> str:
     e = expr.strip()
-    e = assigns.get(e, e)
+    if e != prod and re.search(r"\?\s*nothing\s*:|^nothing$", assigns.get(e, "")):
+        e = assigns[e]                                        # a name bound to `nothing` or to `cond ? nothing : f`
     m = re.match(r"(.+?)\?\s*nothing\s*:\s*(.+)$", e)         # t = kind == 2 ? nothing : prod!
     if m:
         cond = re.sub(r"kind\s*==\s*2", " lsr1 ", m.group(1))
@@ -351,13 +352,77 @@ def constructor_patterns(body: str, ctor_regex: str, env: dict) -> set[tuple]:
     return out
 
 
+LINOP_CTOR = r"LinearOperator\{(?:[^{}]|\{[^{}]*\})*\}\("
+
+
 def method_scenarios(f: dict) -> list[bool]:
-    """element-type scenarios (real?) a glue method covers, from its where clause"""
-    w = f["where"]
-    if re.search(r"<:\s*CplxT", w) and not re.search(r"<:\s*RealT|Union\{RealT", w.split("T <:")[-1] if "T <:" in w else w):
+    """element-type scenarios (real?) a glue method covers, from the bound of `T` in its where clause"""
+    m = re.search(r"\bT\s*<:\s*(\w+)", f["where"])
+    if m and m.group(1) == "CplxT":
         return [False]
-    if re.search(r"\bT\s*<:\s*CplxT", w):
-        return [False]
-    if re.search(r"\bT\s*<:\s*RealT", w):
+    if m and m.group(1) == "RealT":
         return [True]
     return [True, False]
+
+
+# ------------------------------------------------------------------------------------------ the facts, per source tree
+ENV0 = {"real": True, "square": True, "lsr1": False}
+# (key, file, function, constructor regex, positional arity or None, scenarios)
+FLAG_SITES = [
+    ("opEye/square", "special-operators.jl", "opEye", LINOP_CTOR, 2, [ENV0]),
+    ("opEye/rectangular", "special-operators.jl", "opEye", LINOP_CTOR, 3, [dict(ENV0, square=False)]),
+    ("opOnes", "special-operators.jl", "opOnes", LINOP_CTOR, 3, [ENV0, dict(ENV0, square=False)]),
+    ("opZeros", "special-operators.jl", "opZeros", LINOP_CTOR, 3, [ENV0, dict(ENV0, square=False)]),
+    ("opDiagonal(d)", "special-operators.jl", "opDiagonal", LINOP_CTOR, 1, [ENV0, dict(ENV0, real=False)]),
+    ("opDiagonal(nrow,ncol,d)", "special-operators.jl", "opDiagonal", LINOP_CTOR, 3, [dict(ENV0, square=False), dict(ENV0, real=False, square=False)]),
+    ("opRestriction", "special-operators.jl", "opRestriction", LINOP_CTOR, 2, [dict(ENV0, square=False)]),
+    ("opHouseholder", "linalg.jl", "opHouseholder", LINOP_CTOR, 1, [ENV0, dict(ENV0, real=False)]),
+    ("opHermitian(d,A)", "linalg.jl", "opHermitian", LINOP_CTOR, 2, [ENV0, dict(ENV0, real=False)]),
+    ("InverseLBFGSOperator", "lbfgs.jl", "InverseLBFGSOperator", r"LBFGSOperator\{T\}\(", 2, [ENV0]),
+    ("LBFGSOperator", "lbfgs.jl", "LBFGSOperator", r"LBFGSOperator\{T\}\(", 2, [ENV0]),
+    ("LSR1Operator", "lsr1.jl", "LSR1Operator", r"LSR1Operator\{T\}\(", 2, [dict(ENV0, lsr1=True)]),
+    ("hcat", "cat.jl", "hcat", LINOP_CTOR, 2, [dict(ENV0, square=False)]),
+    ("vcat", "cat.jl", "vcat", LINOP_CTOR, 2, [dict(ENV0, square=False)]),
+]
+
+
+def env_key(env: dict) -> str:
+    return ("real" if env["real"] else "complex") + ("" if env["square"] else ",rectangular")
+
+
+def flag_row(pattern: tuple) -> dict:
+    sym, herm, t, ct = pattern
+    return {"symmetric": sym, "hermitian": herm, "tprod": "nothing" if t == "nothing" else "set",
+            "ctprod": "nothing" if ct == "nothing" else "set"}
+
+
+def reference_facts(src_dir) -> dict:
+    """Everything tests/golden/reference_semantics.json holds, read out of a LinearOperators.jl `src/` directory."""
+    import pathlib
+    src = {p.name: strip_comments(p.read_text()) for p in pathlib.Path(src_dir).glob("*.jl")}
+    facts = {"qn_keywords": {}, "push": {}, "flags": {}, "errors": {}}
+    for data, file in (("LBFGSData", "lbfgs.jl"), ("LSR1Data", "lsr1.jl")):
+        full = [f for f in functions(src[file], data) if len(f["pos"]) == 2]
+        assert len(full) == 1, f"{data}(T, n; ...) not found once"
+        facts["qn_keywords"][data] = full[0]["kw"]
+    lb, ls = push_methods(src["lbfgs.jl"], r"LBFGSOperator"), push_methods(src["lsr1.jl"], r"LSR1Operator")
+    facts["push"]["arities"] = {"LBFGSOperator": sorted(lb), "LSR1Operator": sorted(ls)}
+    facts["push"]["outcomes"] = push_table(lb, ls)
+    for key, file, fname, ctor, npos, envs in FLAG_SITES:
+        fs = [f for f in functions(src[file], fname) if len(f["pos"]) == npos and "::Colon" not in f["pos"][0]]
+        for env in envs:
+            got = set()
+            for f in fs:
+                got |= constructor_patterns(f["body"], ctor, env)
+            rows = {tuple(sorted(flag_row(p).items())) for p in got}
+            assert len(rows) == 1, f"{key} [{env_key(env)}]: {len(rows)} distinct flag patterns in the reference: {got}"
+            facts["flags"][f"{key} [{env_key(env)}]"] = dict(rows.pop())
+    # refusals: which exception type guards what
+    u = src["utilities.jl"]
+    m = re.search(r"σ\s*<\s*0\s*&&\s*throw\((\w+)\(|if\s+σ\s*<\s*0[^\n]*\n\s*throw\((\w+)\(", u)
+    facts["errors"]["solve_shifted_system!: σ < 0"] = (m.group(1) or m.group(2)) if m else None
+    m = re.search(r"throw\((\w+)\(\"shape mismatch\"\)\)", src["operations.jl"])
+    facts["errors"]["mul!: shape mismatch"] = m.group(1) if m else None
+    m = re.search(r"throw\((\w+)\(\"shape mismatch\"\)\)", src["linalg.jl"])
+    facts["errors"]["opHermitian: shape mismatch"] = m.group(1) if m else None
+    return facts

@@ -100,8 +100,31 @@ def claim_stdout():
         os.dup2(2, 1)
 
 
+_EMIT_LOCK = __import__("threading").Lock()
+_EMITTED = False
+
+
 def emit_json(obj):
-    data = (json.dumps(obj) + "\n").encode()
+    """The ONE line. The watchdog thread's rescue and the main thread can both get here (a stall that ends while the rescue
+    is printing): the first caller wins, under a lock, and serialises a snapshot; later calls are no-ops."""
+    global _EMITTED
+    with _EMIT_LOCK:
+        if _EMITTED:
+            return False
+        _EMITTED = True
+        for attempt in range(3):                     # the other thread may be adding keys: retry the snapshot
+            try:
+                data = (json.dumps(obj) + "\n").encode()
+                break
+            except RuntimeError:                     # "dictionary changed size during iteration"
+                if attempt == 2:
+                    raise
+                time.sleep(0.01)
+        _emit_bytes(data)
+        return True
+
+
+def _emit_bytes(data):
     if _JSON_FD is None:
         sys.stdout.write(data.decode())
         sys.stdout.flush()
@@ -335,6 +358,7 @@ def main(argv=None):
     # ranks itself (its rank-0 child skips it), in rank 0 under an external launcher
     if not args.no_shard_leg and not args.worker_cmd and (self_launch or os.environ.get("MXLO_BENCH_SELF_LAUNCHED") != "1"):
         out.setdefault("extras", {})["single_process_shard_abi"] = run_shard_leg(args)
+    out.setdefault("complete", "abandoned" not in out)   # false: printed by a rescue (see `abandon`); every leg ran otherwise
     emit_json(out)
 
 
@@ -570,6 +594,7 @@ def worker(args):
     # the line it has, with the reason under "abandoned", and every rank leaves with status 0.
     def abandon(why, key="abandoned"):
         if rank == 0:
+            out["complete"] = False                      # a partial line: some leg after the headline did not finish
             if key == "abandoned":
                 out["abandoned"] = str(why)[:300]
             else:
@@ -615,12 +640,23 @@ def worker(args):
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         with wd.phase("cpu baseline"):
-            out["cpu_baseline"] = cpu_leg(args.cpu_sample)
+            # parity AT THE BENCHMARK'S OWN SIZE beside the throughput: the CPU legs run the oracle on the
+            # device's operands, so what they compute is compared with the device result instead of being thrown away
+            def fresh_apply():
+                res.fill_(float("nan"))
+                lo.mul(res, H, v, alpha, beta)
+                return res
+            out["parity"] = {}
+            out["cpu_baseline"], par = cpu_leg(args.cpu_sample, (h, v, fresh_apply) if (alpha, beta) == (1.0, 0.0) else None)
+            if par is not None:
+                out["parity"]["householder_n1e8" if n == 100_000_000 else "householder_n%d" % n] = par
             # the reference's CPU mul! beside the OTHER two figures of the metric string, in the same run
             if not args.no_extras:
                 try:
                     if "InverseLBFGS_m10_n5e7" in extras:
-                        extras["InverseLBFGS_m10_n5e7"]["cpu"] = cpu_leg_lbfgs()
+                        extras["InverseLBFGS_m10_n5e7"]["cpu"], par = cpu_leg_lbfgs(gpu=(lo, torch, dev))
+                        if par is not None:
+                            out["parity"]["lbfgs_inv_n5e6"] = par
                     if "kron_1024x1024" in extras:
                         extras["kron_1024x1024"]["cpu"] = cpu_leg_kron()
                 except Exception as e:
@@ -653,7 +689,7 @@ def worker(args):
                     out["transports"]["peer_shm"]["householder_ms_per_step"] = round(float(tp.item()) / args.steps * 1e3, 4)
                     out["transports"]["peer_shm"]["householder_GB/s"] = round(bytes_per_step / (float(tp.item()) / args.steps) / 1e9, 1)
                     out["transports"].setdefault("rccl", {})["householder_ms_per_step"] = round(ms_per_step, 4)
-        except BaseException as e:
+        except Exception as e:                           # (SystemExit / KeyboardInterrupt end the process as they should)
             abandon(f"rank {rank}: {e!r}", "peer_shm")
         wd.rescue = abandon if distributed else None
     if rank == 0:
@@ -1165,20 +1201,19 @@ def bench_misc(lo, torch, dev, ctx):
     u = torch.rand(nidx, dtype=torch.float64, device=dev, generator=gen)
     full = torch.empty(nres, dtype=torch.float64, device=dev)
     # Sorted index sets at >= 1/32 density are applied as bit mask + ranks (mxlo_index_plan, round 5): the index list is
-    # never read. "GB/s" / frac_hbm_peak stay on the ALGORITHMIC bytes of SURVEY §8d (which include the 8 B/index list);
-    # moved_bytes is what this form has to move (mask + ranks: 1/4 B per element of the long vector instead).
+    # never read. "GB/s" stays on the ALGORITHMIC bytes of SURVEY §8d (which include the 8 B/index list the kernel never
+    # touches), so a fraction of peak is reported on moved_bytes ONLY — what this form has to move (mask + ranks: 1/4 B per
+    # element of the long vector instead of the list); a fraction on bytes that are not moved can exceed 1 and means nothing.
     ms = timeit(lambda: lo.mul(full, R.H, u), 10)
     nb = 16.0 * nidx + 8.0 * nres                               # idx + u per entry, res written once
     mv = 8.0 * nidx + 8.0 * nres + nres / 4.0
     out["opExtension_sorted_2e7_of_4e7"] = {"us": round(ms * 1e3, 1), "GB/s": round(nb / ms / 1e6, 1),
-                                            "frac_hbm_peak": round(nb / ms / 1e6 / HBM_PEAK_GBS, 4),
                                             "moved_bytes": mv, "frac_hbm_peak_moved": round(mv / ms / 1e6 / HBM_PEAK_GBS, 4),
                                             "form": "bit mask + ranks (no index list read)"}
     ms = timeit(lambda: lo.mul(u, R, full), 10)
     nb = 24.0 * nidx
     mv = 8.0 * nidx + 8.0 * nres + nres / 4.0                   # all of v is streamed at this density (every sector is touched)
     out["opRestriction_sorted_2e7_of_4e7"] = {"us": round(ms * 1e3, 1), "GB/s": round(nb / ms / 1e6, 1),
-                                              "frac_hbm_peak": round(nb / ms / 1e6 / HBM_PEAK_GBS, 4),
                                               "moved_bytes": mv, "frac_hbm_peak_moved": round(mv / ms / 1e6 / HBM_PEAK_GBS, 4),
                                               "form": "bit mask + ranks (no index list read)"}
     del R, u, full, idx
@@ -1327,14 +1362,20 @@ def bench_misc(lo, torch, dev, ctx):
     return out
 
 
-def cpu_leg(n_sample: int):
-    """Oracle (port of the reference `mulHouseholder!`, src/linalg.jl:77-83) on the host, 1 thread."""
+def cpu_leg(n_sample: int, gpu=None):
+    """Oracle (port of the reference `mulHouseholder!`, src/linalg.jl:77-83) on the host, 1 thread. With `gpu` = (h, v, apply)
+    of the timed workload and n_sample equal to its n, the oracle runs on the DEVICE'S operands (copied back) and the result
+    of one more device apply is compared with it: `parity` = the relative L2 distance at the benchmark's own size."""
     import numpy as np
     import oracle
-    rng = np.random.default_rng(0)
-    h = rng.random(n_sample) - 0.5
-    h /= np.linalg.norm(h)
-    v = rng.random(n_sample) * 2 - 1
+    parity = None
+    if gpu is not None and gpu[0].numel() == n_sample:
+        h, v = gpu[0].cpu().numpy(), gpu[1].cpu().numpy()
+    else:
+        rng = np.random.default_rng(0)
+        h = rng.random(n_sample) - 0.5
+        h /= np.linalg.norm(h)
+        v = rng.random(n_sample) * 2 - 1
     res = np.empty(n_sample)
     oracle.householder_mul(res, h, v, 1.0, 0.0)          # warm-up / page-in
     reps, t0 = 0, time.perf_counter()
@@ -1344,18 +1385,28 @@ def cpu_leg(n_sample: int):
         if time.perf_counter() - t0 > 8.0 or reps >= 20:
             break
     sec = (time.perf_counter() - t0) / reps
+    if gpu is not None and gpu[0].numel() == n_sample:
+        dev_res = gpu[2]().cpu().numpy()                 # one more mul!(res, H, v, 1, 0) of the timed operator
+        diff = dev_res - res
+        nr = float(np.linalg.norm(res))
+        parity = {"rel_l2": float(np.linalg.norm(diff) / nr), "max_abs": float(np.max(np.abs(diff))), "tolerance": 1e-12,
+                  "n": int(n_sample), "what": "device mul!(res, opHouseholder(h), v, 1, 0) vs oracle.householder_mul on the same h, v "
+                                              "(the benchmark's operands copied back), every element"}
+        parity["ok"] = bool(parity["rel_l2"] <= parity["tolerance"])
+        del dev_res, diff
+    own = " — the GPU workload's own h, v" if parity else ""
     out = {"value": round(40.0 * n_sample / sec / 1e9, 2), "unit": "GB/s", "cores": 1, "kind": "port",
            "sample": f"oracle.householder_mul (C restatement of mulHouseholder!, gcc -O2, 1 thread) on n={n_sample} "
-                     f"fp64, {reps} reps, {sec * 1e3:.1f} ms/apply, counted at the same 40 B/elt; "
+                     f"fp64{own}, {reps} reps, {sec * 1e3:.1f} ms/apply, counted at the same 40 B/elt; "
                      f"host has {os.cpu_count()} logical CPUs"}
     try:   # generous upper bound: the same arithmetic on every host core (OpenMP, first-touch placement)
         out["all_cores"] = cpu_leg_allcore(n_sample)
     except Exception as e:  # pragma: no cover  (no libgomp: report, do not fail the bench line)
         out["all_cores"] = {"error": repr(e)}
-    return out
+    return out, parity
 
 
-def cpu_leg_lbfgs(budget_s: float = 12.0):
+def cpu_leg_lbfgs(budget_s: float = 12.0, gpu=None):
     """extras.InverseLBFGS_m10_n5e7.cpu — the reference's two-loop recursion (src/lbfgs.jl:117-154) on the host cores, at
     n / 10 = 5e6 and scaled LINEARLY to n = 5e7 (the apply is memory-bound on the host too: 21 vectors streamed per dot /
     axpy statement; the full size needs 8.4 GB of panels and ~1 s per apply): (1) the oracle's statement-by-statement
@@ -1383,6 +1434,22 @@ def cpu_leg_lbfgs(budget_s: float = 12.0):
         if time.perf_counter() - t0 > budget_s / 3 or reps >= 10:
             break
     sec1 = (time.perf_counter() - t0) / reps
+    parity = None
+    if gpu is not None:                                  # the device operator fed the SAME pairs, applied to the same x
+        lo_, torch_, dev_ = gpu
+        Hd = lo_.InverseLBFGSOperator(nc, mem=m, device=dev_)
+        for k in range(m):
+            lo_.push(Hd, torch_.from_numpy(S[k]).to(dev_), torch_.from_numpy(Y[k]).to(dev_))
+        rd = torch_.empty(nc, dtype=torch_.float64, device=dev_)
+        lo_.mul(rd, Hd, torch_.from_numpy(xc).to(dev_), 1.0, 0.0)
+        dres = rd.cpu().numpy()
+        parity = {"rel_l2": float(np.linalg.norm(dres - outc) / np.linalg.norm(outc)), "max_abs": float(np.max(np.abs(dres - outc))),
+                  "tolerance": 1e-9, "n": nc, "mem": m,
+                  "what": "device mul!(res, InverseLBFGSOperator, x) after the same 10 push! vs oracle.LBFGS(inverse).mul "
+                          "(reference statement order), every element"}
+        parity["ok"] = bool(parity["rel_l2"] <= parity["tolerance"])
+        del Hd, rd, dres
+        torch_.cuda.empty_cache()
     out = {"apply_per_s_at_n5e7": round(1.0 / (sec1 * scale), 3), "cores": 1, "kind": "port",
            "sample": f"oracle.LBFGS(inverse).mul — C restatement of lbfgs_multiply in reference statement order, 1 thread, "
                      f"n = {nc} ({reps} reps, {sec1 * 1e3:.1f} ms/apply), scaled x{scale} to n = 5e7 (memory-bound: linear in n)"}
@@ -1412,7 +1479,7 @@ def cpu_leg_lbfgs(budget_s: float = 12.0):
         out["all_cores"] = {"error": repr(e)[:200]}
     out["host_logical_cpus"] = os.cpu_count()
     out["wall_s"] = round(time.perf_counter() - t_start, 1)
-    return out
+    return out, parity
 
 
 def cpu_leg_kron(budget_s: float = 8.0):

@@ -197,8 +197,12 @@ def test_householder_parity(lo, dev, dtype, n):
 
 
 def test_householder_involution_full_size(lo, dev):
-    """BASELINE config 2 size (n = 1e8 fp64): H(Hv) == v for ||h|| = 1, linearity, and parity with
-    the oracle on a strided sample of the output."""
+    """BASELINE config 2 size (n = 1e8 fp64): H(Hv) == v for ||h|| = 1; parity with the ORACLE (the C restatement of
+    mulHouseholder!, src/linalg.jl:77-83) on EVERY element of the output, 1e-12 relative (the one reduction is a fixed-order
+    tree on the device, a sequential sum in the oracle); and, given the device's own dot, the elementwise part
+    res = v - (2 h'v) h in the reference's rounding order to the bit."""
+    from linearoperators_jl_amd import _lib
+    from linearoperators_jl_amd.device import dtype_code, get_ctx, ptr
     n = 100_000_000
     g = torch.Generator(device=dev).manual_seed(5)
     h = torch.rand(n, dtype=torch.float64, device=dev, generator=g) - 0.5
@@ -209,12 +213,20 @@ def test_householder_involution_full_size(lo, dev):
     back = H * w
     err = (torch.linalg.vector_norm(back - v) / torch.linalg.vector_norm(v)).item()
     assert err <= 1e-12, err
-    # exact scalar check of the reduction against torch's own dot (fp64, 1e8 terms)
-    c = 2 * torch.dot(h, v)
-    ref = v - c * h
-    err = (torch.linalg.vector_norm(w - ref) / torch.linalg.vector_norm(ref)).item()
-    assert err <= 1e-12, err
-    del back, ref, w
+    del back
+    # the oracle on the same operands, every element
+    want = oracle.householder_mul(np.empty(n), h.cpu().numpy(), v.cpu().numpy(), 1.0, 0.0)
+    got = w.cpu().numpy()
+    assert rel(got, want) <= 1e-12
+    assert np.max(np.abs(got - want)) <= 1e-12 * max(1.0, float(np.max(np.abs(want))))
+    del want, got
+    # the elementwise pass to the bit, given the device's dot (the fixed-order tree mxlo_dot shares with the apply)
+    ctx = get_ctx(dev)
+    d = torch.zeros(1, dtype=torch.float64, device=dev)
+    _lib.call("mxlo_dot", ctx.handle, dtype_code(torch.float64), ptr(h), ptr(v), n, ptr(d))
+    c = 2.0 * d                                         # c = 2 * dot(h, v); res = v - c * h (two roundings, no FMA)
+    assert torch.equal(w, v - c * h)
+    del w
     # opDiagonal at the same size: bit-exact against the same formula evaluated by torch
     D = lo.opDiagonal(h)
     out = torch.empty_like(v)

@@ -54,6 +54,9 @@ def parse(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=100_000_000)   # the GPU workload's own n
+    ap.add_argument("--qn-nelem", type=int, default=50_000_000,
+                    help="rows per GPU of the quasi-Newton legs (configs[2] / configs[4]: 5e7). A debugging aid like --nelem: the "
+                         "N-rank tests on one device run the same legs, collectives included, at a size 8 ranks can share")
     # debugging aids for the N > 1 code path on a 1-GPU box: every rank on device 0, gloo instead of RCCL
     ap.add_argument("--backend", default="nccl")
     ap.add_argument("--single-device", action="store_true")
@@ -472,7 +475,9 @@ def worker(args):
         if distributed:
             # every apply contains a collective: all ranks must issue the SAME number of them, so the spin is a fixed count
             # (a time-based loop would let ranks disagree and hang the all-reduce)
-            for _ in range(min(5000, max(20, int(args.clock_spin_s / (0.7e-3 * max(n / 1e8, 1e-3)))))):
+            # (the debug transport — a host-synchronising Python hook over gloo, several ranks sharing one device — pays
+            #  milliseconds per collective: a handful of applies there, the count below is sized for the native hook)
+            for _ in range(min(5000, max(20, int(args.clock_spin_s / (0.7e-3 * max(n / 1e8, 1e-3))))) if native else 20):
                 lo.mul(res, H, v, alpha, beta)
             torch.cuda.synchronize()
         else:
@@ -619,7 +624,7 @@ def worker(args):
             if os.environ.get("MXLO_BENCH_FAULT") == "extras-stall" and rank == world - 1 and world > 1:
                 time.sleep(1e6)                          # TEST HOOK: the last rank never joins the extras' collectives
             try:
-                extras.update(bench_lbfgs(lo, torch, dev, ctx, rank, world, distributed, dist, barrier))
+                extras.update(bench_lbfgs(lo, torch, dev, ctx, rank, world, distributed, dist, barrier, n=args.qn_nelem))
             except Exception as e:  # never lose the headline line
                 extras["lbfgs_error"] = repr(e)
             install_hook()                                   # rank 0 cleared it for the single-GPU cfg5 leg
@@ -721,7 +726,19 @@ def transport_preflight(args, lo, torch, dist, ctx, dev, rank, world, native_hoo
     out = {}
     if world > 1 or args.rehearse_distributed:
         if native_hook is None:
-            return {"rccl": None, "note": "debug transport (torch.distributed Python hook): no native preflight"}
+            # the debug transport proves the one thing a line with n_gpus = N has to be able to show: the hook the applies
+            # use sums over ALL N ranks — a dot of one 1.0 per rank through the installed hook must come back as N
+            from linearoperators_jl_amd import _lib
+            from linearoperators_jl_amd.device import dtype_code, ptr
+            one = torch.ones(1, dtype=torch.float64, device=dev)
+            got = torch.zeros(1, dtype=torch.float64, device=dev)
+            _lib.call("mxlo_dot", ctx.handle, dtype_code(torch.float64), ptr(one), ptr(one), 1, ptr(got))
+            torch.cuda.synchronize()
+            seen = int(round(float(got.item())))
+            if seen != world:
+                raise RuntimeError(f"the all-reduce hook summed {seen} ranks in a {world}-rank run")
+            return {"rccl": None, "debug_transport": {"ranks_seen": seen, "check": "mxlo_dot of one 1.0 per rank through the installed hook"},
+                    "note": "debug transport (torch.distributed Python hook): no native preflight"}
         info = native_hook.info()
         lat = native_hook.preflight(ctx.stream, 50, args.preflight_timeout_ms)
         infos = [None] * world
@@ -891,11 +908,13 @@ def shard_leg(args) -> dict:
     return out
 
 
-def bench_lbfgs(lo, torch, dev, ctx, rank, world, distributed, dist, barrier):
+def bench_lbfgs(lo, torch, dev, ctx, rank, world, distributed, dist, barrier, n=50_000_000):
     """InverseLBFGSOperator m=10, n=5e7 (configs[2]) and LBFGSOperator m=20 (configs[4], row-sharded:
-    n_local = 5e7 per GPU) applies per second."""
+    n_local = 5e7 per GPU) applies per second. (`n` other than 5e7: --qn-nelem, a debugging size; the keys keep their names
+    and `qn_nelem_override` says so.)"""
     out = {}
-    n = 50_000_000
+    if n != 50_000_000:
+        out["qn_nelem_override"] = n
     gen = torch.Generator(device=dev).manual_seed(99 + rank)
 
     def fill(op, npairs):

@@ -306,8 +306,11 @@ int32_t mxlo_householder_apply(mxlo_ctx *ctx, int32_t dtype, void *res, const vo
 int32_t mxlo_hermitian_mul(mxlo_ctx *ctx, int32_t dtype, void *res, const void *d,
                            const void *A, int64_t lda, const void *v, int64_t n, double alpha,
                            double beta, int32_t flags);
-/* The same operator applied to the k columns of a matrix — `mul!(res::Matrix, opHermitian(d, A), V::Matrix, α, β)`
- * (src/operations.jl:34-36 loops mulHermitian! over the columns): res[:, c] = α((d .* V[:, c] + L V[:, c]) + L' V[:, c]) + β res[:, c].
+/* The same operator applied to the k columns of a matrix: res[:, c] = α((d .* V[:, c] + L V[:, c]) + L' V[:, c]) + β res[:, c].
+ * An EXTENSION of the reference, not a match: `mul!(res::Matrix, opHermitian(d, A), V::Matrix, α, β)` hands the matrices to
+ * the closure (src/operations.jl:34-36), whose `(...)[:]` (src/linalg.jl:99-101) flattens the n x k product, so upstream the
+ * call throws DimensionMismatch for k > 1. Offered because block Krylov callers need it; the host sides apply complex data
+ * column by column through mxlo_hermitian_mul_c (no block entry point for complex element types).
  * The strict lower triangle is read ONCE per chunk of up to 4 columns instead of once per column (block Krylov shapes);
  * per column the arithmetic and the order of every addition are those of mxlo_hermitian_mul, so the block apply is
  * BIT-IDENTICAL to k single applies. res, V: column-major with leading dimensions ldr, ldv >= n. Float64 / Float32. */

@@ -266,9 +266,10 @@ Base.:+(op::LinearOperator{T, MXVector{T}}, x::Number) where {T} = op + x * ones
 Base.:+(x::Number, op::LinearOperator{T, MXVector{T}}) where {T} = x * ones_like(op) + op
 
 # ---- a6 opHermitian (src/linalg.jl:97-127): the ORIGINAL matrix is passed; only tril(A,-1) is read ------------
-# A callable rather than a closure, so that `mul!` on MATRICES (src/operations.jl:34-36: the reference closure handles a matrix
-# through broadcasting and mul!(res, L, V, …)) can dispatch to the block entry point: the strict lower triangle is read once per
-# 4 columns and every column gets the bits of the single apply.
+# A callable rather than a closure, so that `mul!` on MATRICES can dispatch to the block entry point: the strict lower triangle
+# is read once per 4 columns and every column gets the bits of the single apply. This is an EXTENSION of the reference, not a
+# match: its closure ends in `(...)[:]` (src/linalg.jl:99-101), so `mul!(res::Matrix, opHermitian(d, A), V)` with more than one
+# column throws DimensionMismatch upstream. Complex data goes column by column through the generic apply_columns below.
 struct HermApply{T}
   d::MXVector{T}
   A::MXMatrix{T}

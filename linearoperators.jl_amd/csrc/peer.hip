@@ -58,6 +58,7 @@ struct KArgs {
   int rank, world, drop;
   unsigned long long ticks;            // wall_clock64() ticks of the bounded wait
   unsigned *fault;                     // device address of the comm's pinned fault word
+  unsigned long long *seq_dev;         // this rank's sequence counter (device memory, touched by this kernel only)
 };
 
 __device__ __forceinline__ void st_sys(unsigned long long *p, unsigned long long v) {
@@ -69,8 +70,19 @@ __device__ __forceinline__ unsigned long long ld_sys(const unsigned long long *p
 
 // phase: 1 = post, 2 = gather, 3 = both (one launch per collective)
 __global__ void __launch_bounds__(256)
-peer_exchange_kernel(KArgs A, double *__restrict__ buf, int count, unsigned long long seq, int phase) {
+peer_exchange_kernel(KArgs A, double *__restrict__ buf, int count, int phase) {
   const int tid = threadIdx.x, me = A.rank, world = A.world;
+  // The sequence number of this collective: the posting half advances the rank's device counter, the gathering half of a
+  // two-launch collective reads what the posting launch left (same stream: ordered). Every rank runs one (pair of)
+  // launch(es) per collective, eager or replayed from a graph, so the counters advance in lockstep.
+  __shared__ unsigned long long seq_sh;
+  if (tid == 0) {
+    unsigned long long s = *A.seq_dev;
+    if (phase & 1) *A.seq_dev = ++s;
+    seq_sh = s;
+  }
+  __syncthreads();
+  const unsigned long long seq = seq_sh;
   const size_t set_off = (size_t)(seq & 1ull) * (size_t)world * kSlotWords;
   if (phase & 1) {
     if (me != A.drop) {
@@ -135,12 +147,22 @@ int32_t comm_init_common(Comm *c, int rank, int world, int timeout_ms) {
   memset(hp, 0, 64);
   c->fault_host = (unsigned *)hp;
   c->fault_dev = (unsigned *)dp;
+  if (hipMalloc((void **)&c->seq_dev, 64) != hipSuccess || hipMemset(c->seq_dev, 0, 64) != hipSuccess) {
+    (void)hipGetLastError();
+    if (c->seq_dev) (void)hipFree(c->seq_dev);
+    c->seq_dev = nullptr;
+    (void)hipHostFree(hp);
+    c->fault_host = c->fault_dev = nullptr;
+    return pfail("peer comm: no device memory for the sequence counter");
+  }
   return 0;
 }
 
 void comm_release_common(Comm *c) {
   if (c->fault_host) (void)hipHostFree(c->fault_host);
   c->fault_host = c->fault_dev = nullptr;
+  if (c->seq_dev) (void)hipFree(c->seq_dev);
+  c->seq_dev = nullptr;
 }
 
 int32_t comm_fault(Comm *c) {
@@ -148,13 +170,13 @@ int32_t comm_fault(Comm *c) {
   const unsigned code = __atomic_load_n(c->fault_host, __ATOMIC_RELAXED);
   if (code == 0) return 0;
   c->dead = true;
-  return pfail("peer exchange: rank %d waited %d ms for rank %u's posting of collective %llu and gave up (that rank is gone, "
+  return pfail("peer exchange: rank %d waited %d ms for rank %u's posting (about this rank's %llu-th launched collective) and gave up (that rank is gone, "
                "stuck, or not part of this communicator); the results of that collective are NaN and this communicator is unusable",
                c->rank, c->timeout_ms, code - 0x100u, (unsigned long long)c->seq);
 }
 
 // phase 3: the whole collective in one launch; 1 / 2: the two halves (same-device shards put a host barrier between them)
-int32_t comm_launch(Comm *c, double *buf, int64_t count, hipStream_t st, int phase, unsigned long long seq) {
+int32_t comm_launch(Comm *c, double *buf, int64_t count, hipStream_t st, int phase) {
   if (count <= 0) return 0;
   if (count > kCap) return pfail("peer exchange: %lld doubles exceed the mailbox slot of %d", (long long)count, kCap);
   KArgs A;
@@ -164,7 +186,8 @@ int32_t comm_launch(Comm *c, double *buf, int64_t count, hipStream_t st, int pha
   A.drop = c->drop;
   A.ticks = (unsigned long long)c->timeout_ms * (unsigned long long)c->wall_khz;
   A.fault = c->fault_dev;
-  hipLaunchKernelGGL(peer_exchange_kernel, dim3(1), dim3(256), 0, st, A, buf, (int)count, seq, phase);
+  A.seq_dev = c->seq_dev;
+  hipLaunchKernelGGL(peer_exchange_kernel, dim3(1), dim3(256), 0, st, A, buf, (int)count, phase);
   if (hipGetLastError() != hipSuccess) return pfail("peer exchange: kernel launch failed");
   return 0;
 }
@@ -173,7 +196,8 @@ int32_t comm_allreduce(Comm *c, double *buf, int64_t count, hipStream_t st) {
   if (c->dead) return pfail("peer exchange: this communicator is unusable after a timed-out collective");
   if (comm_fault(c) != 0) return 1;
   if (count <= 0) return 0;
-  return comm_launch(c, buf, count, st, 3, ++c->seq);
+  ++c->seq;
+  return comm_launch(c, buf, count, st, 3);
 }
 
 }  // namespace mxlo_peer
@@ -204,7 +228,8 @@ API int32_t mxlo_peer_comm_create_shm(const char *name, int32_t rank, int32_t wo
     return 1;
   }
   p->name = name;
-  p->owner = create != 0;
+  p->owner = false;                    // set once the EXCLUSIVE create has succeeded: a name that already exists belongs to
+                                       // somebody else's job and must not be unlinked by this one's error path
   const size_t bytes = (size_t)world * mailbox_words(world) * sizeof(unsigned long long);
   const int fd = create ? shm_open(name, O_CREAT | O_EXCL | O_RDWR, 0600) : shm_open(name, O_RDWR, 0600);
   auto bail = [&](const char *what) {
@@ -217,6 +242,7 @@ API int32_t mxlo_peer_comm_create_shm(const char *name, int32_t rank, int32_t wo
     return 1;
   };
   if (fd < 0) return bail(create ? "shm_open(O_CREAT|O_EXCL)" : "shm_open");
+  p->owner = create != 0;
   if (create && ftruncate(fd, (off_t)bytes) != 0) return bail("ftruncate");
   if (!create) {
     struct stat sb;

@@ -200,11 +200,11 @@ int32_t peer_hook(void *user, void *dev_buf, int64_t count, void *stream_) {
     return 1;
   };
   if (c.dead || mxlo_peer::comm_fault(&c) != 0) return fail();
-  const unsigned long long seq = ++c.seq;
-  if (!s->same_device) return mxlo_peer::comm_launch(&c, (double *)dev_buf, count, st, 3, seq) == 0 ? 0 : fail();
-  if (mxlo_peer::comm_launch(&c, (double *)dev_buf, count, st, 1, seq) != 0) return fail();
+  ++c.seq;
+  if (!s->same_device) return mxlo_peer::comm_launch(&c, (double *)dev_buf, count, st, 3) == 0 ? 0 : fail();
+  if (mxlo_peer::comm_launch(&c, (double *)dev_buf, count, st, 1) != 0) return fail();
   if (!s->bar.wait()) return 1;                            // every shard's post is enqueued
-  if (mxlo_peer::comm_launch(&c, (double *)dev_buf, count, st, 2, seq) != 0) return fail();
+  if (mxlo_peer::comm_launch(&c, (double *)dev_buf, count, st, 2) != 0) return fail();
   return 0;
 }
 

@@ -375,7 +375,8 @@ def opHermitian(*args):
             d = d if d.dtype == U else d.to(U)
         else:
             d = d if d.dtype == comp else d.to(comp)      # a real diagonal stays real: d .* v is Real * Complex
-        prod = lambda res, v, a, b: mulHermitian(res, d, A, v, a, b)
+        # mul! on MATRICES is an extension here, for real and complex data alike (see the real branch below): column by column
+        prod = columnwise(lambda res, v, a, b: mulHermitian(res, d, A, v, a, b))
         op = LinearOperator(U, m, m, False, True, prod, None, None, S=Storage(U, A.device))
         op._deps = (d, A)
         return op
@@ -384,9 +385,11 @@ def opHermitian(*args):
     if A.dtype != U:
         A = _colmajor(A.to(U))
     dtype_code(U)
-    # on matrices the reference closure works column by column through broadcasting and mul!(res, L, V, …)
-    # (src/linalg.jl:97-103): one mulHermitian per column — or, for a block on the device, the block entry point, which
-    # reads the triangle once per 4 columns and gives the same bits as the column loop
+    # mul! on MATRICES: a deliberate EXTENSION of the reference, not a match. Its closure ends in `(...)[:]`
+    # (src/linalg.jl:99-101), which flattens an n x k product to length n*k, so `mul!(res::Matrix, opHermitian(d, A), V)`
+    # with k > 1 throws DimensionMismatch upstream. Block Krylov callers want it, so here a matrix is applied column by
+    # column — one mulHermitian per column, or (real data on the device) the block entry point, which reads the triangle
+    # once per 4 columns and gives every column the bits of the single apply.
     prod = columnwise(lambda res, v, a, b: mulHermitian(res, d, A, v, a, b))
 
     def herm_block(res, V, a, b):

@@ -204,6 +204,16 @@ class PeerShmHook:
             raise RuntimeError(err)
         self._R = R
         self.fn = C.cast(R.mxlo_peer_allreduce_hook, _lib.ALLREDUCE_FN)
+        # the communicator owns a /dev/shm segment (rank 0 its NAME): released with the object even when nobody calls
+        # close() — a failed agreement round, an exception between construction and tear-down
+        import weakref
+        self._fin = weakref.finalize(self, PeerShmHook._release, R, self.comm)
+
+    @staticmethod
+    def _release(R, comm):
+        if comm:
+            R.mxlo_peer_comm_destroy(comm)
+            comm.value = None
 
     def install(self, ctx):
         from . import _lib
@@ -227,9 +237,7 @@ class PeerShmHook:
             raise RuntimeError(self._R.mxlo_peer_last_error().decode())
 
     def close(self):
-        if self.comm:
-            self._R.mxlo_peer_comm_destroy(self.comm)
-            self.comm = C.c_void_p()
+        self._fin()                                       # destroys the communicator once (detaches the finalizer)
 
 
 def install_allreduce(ctx, group=None, native: bool = True):

@@ -57,24 +57,30 @@ def test_a_failing_or_stalled_second_transport_leg_cannot_sink_the_headline(faul
     assert "abandoned" in ps["note"] and "householder_ms_per_step" not in ps
 
 
-def test_two_ranks_on_one_device_over_the_debug_transport():
-    """`bench.py --gpus 2 --single-device --backend gloo`: the self-launcher starts two ranks of worker() on device 0 (RCCL refuses
-    that, so the all-reduce is the torch.distributed hook over gloo): every collective of the N-rank path — operand
-    normalisation, the sharded Householder / quasi-Newton legs, max-over-ranks timing, tear-down — runs with world 2, and
-    rank 0's ONE line reports n_gpus = 2 with the whole-job bandwidth."""
+@pytest.mark.parametrize("n", [2, 4, 8])
+def test_n_ranks_on_one_device_over_the_debug_transport(n):
+    """`bench.py --gpus N --single-device --backend gloo`, N = 2 / 4 / 8 (the driver's SCALE run, pre-flighted on the one
+    device every box has — VERDICT r5 #8): the self-launcher starts N ranks of worker() on device 0 (RCCL refuses that, so
+    the all-reduce is the torch.distributed hook over gloo): every collective of the N-rank path — operand normalisation, the
+    sharded Householder / quasi-Newton legs (at --qn-nelem rows, so that 8 ranks share one device), max-over-ranks timing,
+    the cfg5 single-GPU comparison, tear-down — runs with world N, the hook provably sums over all N ranks, and rank 0's ONE
+    line reports n_gpus = N with the whole-job bandwidth."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--single-device", "--backend", "gloo", "--steps", "5",
-                        "--warmup", "2", "--nelem", "4000000", "--no-cpu-baseline", "--no-shard-leg", "--clock-spin-s", "0.05"],
-                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--single-device", "--backend", "gloo", "--steps", "5",
+                        "--warmup", "2", "--nelem", "4000000" if n == 2 else "1000000", "--qn-nelem", "50000000" if n == 2 else "400000",
+                        "--no-cpu-baseline", "--no-shard-leg", "--clock-spin-s", "0.05"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1500)
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1 and lines[0].startswith("{"), p.stdout[-500:]
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["value"] > 0 and d["scaling"] == "weak" and "abandoned" not in d
-    assert "2 ranks" in d["config"]["sharding"] and "launcher" in d["config"]
+    assert d["n_gpus"] == n and d["value"] > 0 and d["scaling"] == "weak" and "abandoned" not in d and d["complete"] is True
+    assert "%d ranks" % n in d["config"]["sharding"] and "launcher" in d["config"]
+    assert d["transports"]["debug_transport"]["ranks_seen"] == n
     assert "lbfgs_error" not in d["extras"] and "cfg4_error" not in d["extras"]
-    assert d["extras"]["cfg5_LBFGS_fwd_m20_sharded"]["n_gpus"] == 2
+    assert d["extras"]["cfg5_LBFGS_fwd_m20_sharded"]["n_gpus"] == n
+    assert ("qn_nelem_override" in d["extras"]) == (n != 2)
 
 
 def test_a_rank_that_never_joins_an_extra_leg_cannot_sink_the_headline():

@@ -291,12 +291,14 @@ def test_dense_operator_aliases_row_major_and_column_major_matrices(lo, dev):
             lo.touched(M)
 
 
-@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs 2 visible devices (one process, current device != operator device)")
-def test_operator_on_second_device_while_first_is_current(lo):
+@pytest.mark.parametrize("second", [pytest.param(1, marks=pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs 2 visible devices (one process, current device != operator device)")),
+                                    pytest.param(0, id="dry-run-on-the-only-device")])
+def test_operator_on_second_device_while_first_is_current(lo, second):
     """One process, two GPUs: every entry point binds ctx->device itself (DeviceGuard), so an operator living on cuda:1
-    allocates, launches and copies on cuda:1 while the thread's current device stays cuda:0."""
+    allocates, launches and copies on cuda:1 while the thread's current device stays cuda:0. (`second` = 0: the same
+    statements with the operator on cuda:0 — the dry run of this test's body on a one-GPU box, VERDICT r5 #8.)"""
     torch.cuda.set_device(0)
-    d1 = torch.device("cuda", 1)
+    d1 = torch.device("cuda", second)
     rng = np.random.default_rng(4)
     n, mem = 20_003, 4
     T1 = lambda a: torch.from_numpy(a).to(d1)

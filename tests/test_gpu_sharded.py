@@ -36,7 +36,8 @@ WORKER = textwrap.dedent('''
     if backend == "nccl":
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         if not want_peer:
-            hook = lo.sharded.install_allreduce(lo.get_ctx(dev), native=True)     # must be the C hook: raises otherwise
+            # must be the C hook on every rank: raises otherwise (even_at_world_1: the world-1 dry run of this worker)
+            hook = lo.sharded.install_agreed_allreduce(lo.get_ctx(dev), require_native=True, even_at_world_1=True)
             pf = hook.preflight(lo.get_ctx(dev).stream, reps=20, timeout_ms=30000)   # collective: sums, identical bits, latency
             inf = hook.info()
             assert inf["ranks_seen"] == world and inf["user_rank"] == rank and inf["device"] == di, inf
@@ -132,6 +133,26 @@ WORKER = textwrap.dedent('''
     if want_peer:
         torch.cuda.synchronize()
         hook.check()
+        # ADVICE r5 (medium): a CAPTURED sharded apply replayed several times under the peer transport. The collective's
+        # sequence number lives in device memory and the exchange kernel advances it itself; with a host-side number baked
+        # into the captured kernel arguments every replay after the first would find its poll already satisfied by the
+        # previous replay's posting and could sum stale payloads. v changes between replays, so stale data would show.
+        vt = T(v[a:b])
+        rg, re = torch.empty(b - a, dtype=torch.float64, device=dev), torch.empty(b - a, dtype=torch.float64, device=dev)
+        g_ = lo.capture_mul(rg, H, vt, 2.0, 0.0)
+        for k in range(5):
+            vt.mul_(1.0 + 0.25 * (k + 1) * (1 if k %% 2 else -1))
+            torch.cuda.synchronize()
+            rg.fill_(float("nan"))
+            g_.replay()
+            torch.cuda.synchronize()
+            lo.mul(re, H, vt, 2.0, 0.0)                      # the same apply, eager (advances the same device counter)
+            torch.cuda.synchronize()
+            assert torch.equal(rg, re), ("captured replay %%d differs from the eager apply" %% k)
+            vfull = torch.cat([t_.cpu() for t_ in [vt]])     # (local piece only: the oracle check needs the global v)
+        del g_
+        torch.cuda.synchronize()
+        hook.check()
     print("RESULT", rank, transport, err_h, err_b, int(same), err_m, flush=True)
     dist.destroy_process_group()
 ''')
@@ -173,6 +194,15 @@ def test_two_ranks_one_gpu_agree_on_transport_and_shard(tmp_path):
 def test_real_ranks_native_rccl_hook(tmp_path):
     world = min(torch.cuda.device_count(), 8)
     assert run_ranks(tmp_path, world, "nccl", 29673) == "native"
+
+
+@pytest.mark.parametrize("transport", ["auto", "peer"])
+def test_real_ranks_worker_dry_run_at_world_1(tmp_path, transport):
+    """the two tests above/below need >= 2 devices and have never run. Their worker — nccl process group,
+    one device per rank, the NATIVE RCCL hook with its preflight and communicator report (or the peer transport), every
+    sharded operator, the replicated-scalar gather — runs here at world 1 on the one device every box has, so that the first
+    execution of that code is not the 8-GPU node's (a typo there would cost the node)."""
+    assert run_ranks(tmp_path, 1, "nccl", 29683 + (transport == "peer"), transport=transport) == ("peer" if transport == "peer" else "native")
 
 
 @pytest.mark.parametrize("world", [2, 3])

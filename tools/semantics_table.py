@@ -60,7 +60,17 @@ rows.append(("`opHermitian(d, A)`: `(isreal(A), true, prod!, nothing, nothing)`,
 rows.append(("`opDiagonal(d)`: `(true, isreal(d), prod!, prod!, ctprod!)`", R("special-operators.jl", "opDiagonal", 1), G("opDiagonal", 1) + " (complex `d`; real `d`: the reference's own constructor)",
              f"`leaves.py:{pyline(leaves.opDiagonal, 'True, False, prod, prod, ctprod')}`, `:{pyline(leaves.opDiagonal, 'True, True, prod, prod, prod')}`"))
 rows.append(("`solve_shifted_system!`: `σ < 0` → `ArgumentError`", "`src/utilities.jl:213-215`", G("check") + " (`st == 6`: `MXLO_EDOMAIN`)", f"`qn.py:{pyline(qn.solve_shifted_system, 'nonnegative')}` (ValueError)"))
-print("| what a caller observes | reference | glue `julia/LinearOperatorsMXLOExt.jl` | mirror `linearoperators.jl_amd/` |")
-print("|---|---|---|---|")
-for r in rows:
-    print("| " + " | ".join(r) + " |")
+HEAD = "| what a caller observes | reference | glue `julia/LinearOperatorsMXLOExt.jl` | mirror `linearoperators.jl_amd/` |"
+table = "\n".join([HEAD, "|---|---|---|---|"] + ["| " + " | ".join(r) + " |" for r in rows]) + "\n"
+if "--update" in sys.argv[1:]:                      # rewrite the table inside INTEGRATION.md in place
+    doc = (ROOT / "INTEGRATION.md").read_text()
+    a = doc.index(HEAD)
+    b = a
+    for ln in doc[a:].splitlines(keepends=True):
+        if not ln.startswith("|"):
+            break
+        b += len(ln)
+    (ROOT / "INTEGRATION.md").write_text(doc[:a] + table + doc[b:])
+    print("INTEGRATION.md §3a updated")
+else:
+    print(table, end="")

@@ -126,14 +126,16 @@ int32_t fused_fault_check(mxlo_ctx *ctx) {
   ctx->tune.qn_fused_small = 0;
   ctx->tune.qn_persist = 0;
   ctx->tune.herm_single = 0;
+  ctx->tune.kron_fuse = 0;
+  if (ctx->kron_cnt) (void)hipMemset(ctx->kron_cnt, 0, sizeof(unsigned) * (size_t)ctx->kron_cnt_n);
   ctx->herm_slots_dirty = true;
   __atomic_store_n(ctx->fault_host, 0u, __ATOMIC_RELAXED);
   (void)rearm_fused_slots(ctx);
   set_error("a single-launch %s apply on this ctx timed out after %d ms waiting for its peer workgroups (the launch was "
             "not fully co-resident: GPU shared with other processes, CU masking, or a killed launch left the exchange "
             "slots inconsistent); that apply stored NaN. The exchange state has been re-armed and the single-launch "
-            "forms (house_fused, qn_fused_small, qn_persist, herm_single) are now OFF for this ctx — repeat the apply",
-            code == kFaultHouseholder ? "opHouseholder" : (code == kFaultHermitian ? "opHermitian" : "quasi-Newton"), ctx->tune.fused_timeout_ms);
+            "forms (house_fused, qn_fused_small, qn_persist, herm_single, kron_fuse) are now OFF for this ctx — repeat the apply",
+            code == kFaultHouseholder ? "opHouseholder" : (code == kFaultHermitian ? "opHermitian" : (code == kFaultKron ? "kron" : "quasi-Newton")), ctx->tune.fused_timeout_ms);
   return MXLO_EHIP;
 }
 }  // namespace mxlo
@@ -148,6 +150,7 @@ MXLO_API int32_t mxlo_ctx_destroy(mxlo_ctx *ctx) {
   if (ctx->xslots) (void)hipFree(ctx->xslots);
   if (ctx->qslots) (void)hipFree(ctx->qslots);
   if (ctx->herm_slots) (void)hipFree(ctx->herm_slots);
+  if (ctx->kron_cnt) (void)hipFree(ctx->kron_cnt);
   if (ctx->fault_host) (void)hipHostFree(ctx->fault_host);
   if (ctx->scratch) (void)hipFree(ctx->scratch);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -449,6 +452,9 @@ MXLO_API int32_t mxlo_ctx_tune(mxlo_ctx *ctx, const char *key, int64_t value) {
   } else if (!strcmp(key, "qn_persist_lds_pad")) {
     MXLO_REQUIRE(value >= 0 && value <= 112 * 1024, MXLO_EINVAL, "qn_persist_lds_pad must be in 0..114688 bytes");
     ctx->tune.qn_persist_lds_pad = (int)value;
+  } else if (!strcmp(key, "kron_fuse")) {
+    MXLO_REQUIRE(value >= 0 && value <= 2, MXLO_EINVAL, "kron_fuse must be 0, 1 (or 2: timing experiment without the wait, wrong results)");
+    ctx->tune.kron_fuse = (int)value;
   } else if (!strcmp(key, "herm_single")) {
     MXLO_REQUIRE(value == 0 || value == 1, MXLO_EINVAL, "herm_single must be 0 or 1");
     ctx->tune.herm_single = (int)value;

@@ -156,6 +156,8 @@ struct Tune {
   int64_t herm_single_max_n = 2048;   // measured (profiles/r05_herm_small.txt): 8.9 -> 6.4 us at n = 1024, 9.6 -> 6.9 at 2048 (f64; f32
                                       // alike); NO gain at 4096 (17.8 vs 18.4 f64, 12.4 vs 10.8 f32) and 8192: there the strips' own
                                       // load -> butterfly -> store chain sets the time, not the finish launch
+  int kron_fuse = 1;       // kron: both GEMMs in ONE launch when every tile has its own CU, the dependency kept XCD-local
+                           // (gemm_glds.h: kron_fused_kernel; 2: timing experiment without the wait — wrong results)
   int gemv_n_rows = 1;     // dense M*v: row bands, the column sum stays inside a workgroup — one launch, no partials (dense.hip)
   int gemvb_n_rows = 1;    // block apply M*V of a dense operator: row bands, V staged in LDS per workgroup — one launch, no partials (dense.hip)
   int gemvb_t_lds = 1;     // transposed block apply of a dense operator (k >= 4): U staged in LDS per workgroup (dense.hip)
@@ -196,6 +198,9 @@ struct mxlo_ctx {
   size_t herm_slots_bytes = 0;
   int64_t herm_slots_layout = 0;  // (n, strip shape) the slots were last used with
   bool herm_slots_dirty = false;  // a timed-out apply left slots filled: re-arm before the next use
+  unsigned *kron_cnt = nullptr;   // counters of the XCD-local kron fusion (gemm_glds.h: kron_fused_kernel), zero between applies
+  int kron_cnt_n = 0;
+  int xcd_map = 0;                // 0: not probed; 1: workgroup id % 8 == XCC_ID on this device (probed once); -1: it is not
   void *scratch = nullptr;     // grow-on-demand workspace (opHermitian tile partials); owned by the ctx
   size_t scratch_bytes = 0;
   hipStream_t own_stream = nullptr;  // created by mxlo_ctx_create_stream, destroyed with the ctx
@@ -234,7 +239,7 @@ struct DeviceGuard {
 // the kernel ENDS with NaN results instead of hanging the GPU. The host looks at the word (a plain read of pinned
 // memory, no synchronisation) before every single-launch apply and inside mxlo_ctx_sync: fused_fault_check() then
 // re-arms the slots, switches the single-launch forms of the ctx off and returns MXLO_EHIP naming what happened.
-constexpr unsigned kFaultHouseholder = 1u, kFaultQn = 2u, kFaultHermitian = 4u;
+constexpr unsigned kFaultHouseholder = 1u, kFaultQn = 2u, kFaultHermitian = 4u, kFaultKron = 8u;
 constexpr unsigned long long kCanonicalNaN = 0x7FF8000000000000ull;
 int32_t fused_fault_check(mxlo_ctx *ctx);           // api_ctx.hip
 inline unsigned long long fused_timeout_ticks(const mxlo_ctx *ctx) {   // wall_clock64() ticks: the device's constant-rate clock

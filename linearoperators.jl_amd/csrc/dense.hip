@@ -1649,6 +1649,30 @@ int32_t hermitian_block_t(mxlo_ctx *ctx, T *res, int64_t ldr, const T *d, const 
   return MXLO_OK;
 }
 
+// The premise of the XCD-local kron fusion, probed ONCE per ctx (one 64-workgroup launch + a 256-byte copy): workgroup id
+// of a 1-D grid runs on XCD id % 8 (tools/xcc_probe.hip: holds for every grid and block size tried on an MI355X in SPX mode).
+__global__ void xcc_probe_kernel(unsigned *__restrict__ out) {
+  if (threadIdx.x == 0) out[blockIdx.x] = gl_xcc_id();
+}
+bool xcd_map_ok(mxlo_ctx *ctx) {
+  if (ctx->xcd_map == 0) {
+    ctx->xcd_map = -1;
+    unsigned *d = nullptr, h[64];
+    if (hipMalloc((void **)&d, sizeof(h)) == hipSuccess) {
+      hipLaunchKernelGGL(xcc_probe_kernel, dim3(64), dim3(64), 0, ctx->stream, d);
+      if (hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, ctx->stream) == hipSuccess &&
+          hipStreamSynchronize(ctx->stream) == hipSuccess) {
+        bool ok = true;
+        for (int i = 0; i < 64; ++i) ok = ok && h[i] == (unsigned)(i & 7);
+        if (ok) ctx->xcd_map = 1;
+      }
+      (void)hipFree(d);
+    }
+    (void)hipGetLastError();
+  }
+  return ctx->xcd_map == 1;
+}
+
 // kron(opA, opB) * x with opA = A or A^T, opB = B or B^T of the STORED column-major matrices (src/kron.jl:14-40):
 //   opA is m x n, opB is p x q;  X = reshape(x, q, n);  Ut = opA * X^T (m x q);  R = opB * Ut^T (p x m);
 //   res = alpha*vec(R) + beta*res.
@@ -1661,6 +1685,66 @@ int32_t kron_t(mxlo_ctx *ctx, T *res, const T *A, int64_t am, int64_t an, int64_
                int32_t flags) {
   const int64_t m = trans_a ? an : am, n = trans_a ? am : an;
   const int64_t p = trans_b ? bq : bp, q = trans_b ? bp : bq;
+  // ---- both products in ONE launch with an XCD-local dependency (gemm_glds.h: kron_fused_kernel; tune key kron_fuse):
+  // same tile class for both (the one gemm() would pick for each), the same A layout, every tile of both products on its
+  // own CU (grid <= #CU and co-resident), DMA preconditions as gemm().
+  if (ctx->tune.kron_fuse && trans_a == trans_b && ctx->fault_dev && !ctx->capturing && m > 0 && n > 0 && p > 0 && q > 0 &&
+      m < (1LL << 31) && n < (1LL << 31) && p < (1LL << 31) && q < (1LL << 31) && lda < (1LL << 22) && ldb < (1LL << 22) &&
+      m < (1LL << 22) && q < (1LL << 22) && gemm_glds_ok<T>(A, lda, trans_a, x, q, m, q, n) &&
+      gemm_glds_ok<T>(B, ldb, trans_b, work, m, p, m, q)) {
+    auto tile_of = [&](int64_t M, int64_t N) {
+      auto tiles = [&](int tm, int tn) { return ((M + tm - 1) / tm) * ((N + tn - 1) / tn); };
+      if (tiles(128, 128) >= ctx->num_cu) return 128;
+      return tiles(64, 64) * 5 >= (int64_t)ctx->num_cu * 3 ? 64 : 32;
+    };
+    const int t1 = tile_of(m, q), t2 = tile_of(p, m);
+    if (t1 == t2 && t1 != 128) {
+      const int tile = t1;
+      const int64_t nrb = (m + tile - 1) / tile, gy1 = (q + tile - 1) / tile, gx2 = (p + tile - 1) / tile;
+      const int64_t per_rb = gy1 > gx2 ? gy1 : gx2, per_xcd = ((nrb + 7) / 8) * per_rb, grid = 8 * per_xcd;
+      int32_t fst = MXLO_OK;
+      if (grid <= ctx->num_cu && nrb <= 64 && xcd_map_ok(ctx) && (fst = fused_fault_check(ctx)) == MXLO_OK && ctx->tune.kron_fuse) {
+        if (ctx->kron_cnt_n < 2 * 64 * kGlFuseStride) {
+          if (ctx->kron_cnt) {
+            MXLO_HIP(hipStreamSynchronize(ctx->stream));
+            MXLO_HIP(hipFree(ctx->kron_cnt));
+            ctx->kron_cnt = nullptr;
+            ctx->kron_cnt_n = 0;
+          }
+          MXLO_HIP(hipMalloc((void **)&ctx->kron_cnt, sizeof(unsigned) * 2 * 64 * kGlFuseStride));
+          MXLO_HIP(hipMemsetAsync(ctx->kron_cnt, 0, sizeof(unsigned) * 2 * 64 * kGlFuseStride, ctx->stream));
+          ctx->kron_cnt_n = 2 * 64 * kGlFuseStride;
+        }
+        bool fits = true;
+        const int32_t st = dispatch_ab<T>(beta, flags, [&]<typename CA, typename CB, bool B0>() -> int32_t {
+          GlFuse F{ctx->kron_cnt, (int)nrb, (int)gy1, (int)gx2, (int)per_xcd, ctx->tune.kron_fuse == 2 ? 0ull : fused_timeout_ticks(ctx), ctx->fault_dev, kFaultKron};
+#define KFUSE(AK_, TM_, WM_, WN_, BK_, NST_, PAIR_, PFD_, UNR_)                                                                \
+  {                                                                                                                        \
+    GlShape S1{(int)m, (int)q, (int)n, (int)nrb, (int)gy1}, S2{(int)p, (int)m, (int)q, (int)gx2, (int)nrb};               \
+    if ((fits = coresident<kron_fused_kernel<T, CA, CB, B0, AK_, TM_, TM_, WM_, WN_, BK_, NST_, PAIR_, PFD_, UNR_>, WM_ * WN_ * 64>(ctx, grid))) \
+      hipLaunchKernelGGL((kron_fused_kernel<T, CA, CB, B0, AK_, TM_, TM_, WM_, WN_, BK_, NST_, PAIR_, PFD_, UNR_>), dim3((unsigned)grid), \
+                         dim3(WM_ * WN_ * 64), 0, ctx->stream, res, p, B, ldb, work, m, A, lda, x, q, S1, S2, (CA)alpha, (CB)beta, F); \
+  }
+#define KFUSE_BY_A(TM_, WM_, WN_, BK_, NST_, PAIR_, PFD_, UNR_AM_)                                                         \
+  if (trans_a) KFUSE(true, TM_, WM_, WN_, BK_, NST_, PAIR_, PFD_, true) else KFUSE(false, TM_, WM_, WN_, BK_, NST_, PAIR_, PFD_, UNR_AM_)
+          if constexpr (sizeof(T) == 8) {
+            if (tile == 64) KFUSE_BY_A(64, 4, 2, 32, 3, true, 1, true)
+            else KFUSE_BY_A(32, 2, 2, 32, 4, false, 2, true)
+          } else {
+            if (tile == 64) KFUSE_BY_A(64, 4, 2, 64, 3, true, 1, false)
+            else KFUSE_BY_A(32, 2, 2, 64, 4, false, 2, true)
+          }
+#undef KFUSE_BY_A
+#undef KFUSE
+          if (!fits) return MXLO_OK;
+          MXLO_LAUNCH_CHECK();
+          return MXLO_OK;
+        });
+        if (st != MXLO_OK || fits) return st;
+      }
+      if (fst != MXLO_OK) return fst;
+    }
+  }
   MXLO_TRY(gemm<T>(ctx, work, m, A, lda, trans_a, x, q, true, m, q, n, 1.0, 0.0, 0));
   return gemm<T>(ctx, res, p, B, ldb, trans_b, work, m, true, p, m, q, alpha, beta, flags);
 }

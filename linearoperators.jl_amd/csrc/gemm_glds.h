@@ -75,11 +75,16 @@ __device__ __forceinline__ void gl_tile_of(int id, int gx, int gy, int &tx, int 
 // LDS image and arrive with one 16-byte (f64) / 8-byte (f32) ds_read instead of two reads: half the LDS instructions for
 // the same bytes. The C tile is un-permuted in the epilogue. (A K-contiguous A image has no adjacent rows: A stays
 // unpaired there.)
+// One C tile (tx, ty) by the calling workgroup; `lds` is the kernel's ONE __shared__ object of gl_lds_elems<T, TM, TN, BK, NST>()
+// elements (the body is force-inlined into the kernel that declares it, so every LDS address stays a known LDS address).
+template <typename T, int TM, int TN, int BK, int NST>
+constexpr int gl_lds_elems() { return NST * (TM * BK + TN * BK); }
+
 template <typename T, typename CA, typename CB, bool BETA0, bool AK, int TM, int TN, int WM, int WN, int BK, int NST,
           bool SPREAD = true, bool PIN = true, bool PAIR = false, int PFD = 1, bool SWAPC = false, bool NTC = false, bool XNOBAR = false, bool UNR = false>
-__global__ void __launch_bounds__(WM * WN * 64)
-gemm_glds_kernel(T *__restrict__ C, int64_t ldc, const T *__restrict__ A, int64_t lda,
-                 const T *__restrict__ B, int64_t ldb, GlShape S, CA alpha, CB beta) {
+__device__ __forceinline__ void
+gl_gemm_tile(T *lds, const int tx, const int ty, T *__restrict__ C, int64_t ldc, const T *__restrict__ A, int64_t lda,
+             const T *__restrict__ B, int64_t ldb, GlShape S, CA alpha, CB beta) {
   constexpr int NW = WM * WN;
   constexpr int VEC = 16 / (int)sizeof(T);
   constexpr int EPI = 1024 / (int)sizeof(T);          // elements per DMA wave-instruction
@@ -91,8 +96,7 @@ gemm_glds_kernel(T *__restrict__ C, int64_t ldc, const T *__restrict__ A, int64_
   static_assert(MT >= 1 && NT >= 1 && MT * 16 * WM == TM && NT * 16 * WN == TN, "bad wave layout");
   static_assert(BK % 8 == 0 && NST >= 3 && NST <= 4, "bad pipeline shape");
   static_assert(NI % NW == 0, "every wave must issue the same number of DMA instructions per stage (counted vmcnt)");
-  __shared__ __attribute__((aligned(1024))) T lds[NST * (AIMG + BIMG)];   // ONE LDS object (a second one makes
-                                                                          // hipcc drain vmcnt before every ds_read)
+  static_assert(gl_lds_elems<T, TM, TN, BK, NST>() == NST * (AIMG + BIMG), "LDS size helper out of step");
   // which operand's tiles are paired, and the XOR swizzle (in elements, applied on odd k-rows) of an M-/N-contiguous
   // image s[k][TX]. It has to suit the ds_read that fetches the fragments (MI355X_MICROARCH.md, LDS table): the 16
   // lanes of one k-row read 16 consecutive fragments, and the lanes a service group takes from two adjacent k-rows
@@ -108,8 +112,6 @@ gemm_glds_kernel(T *__restrict__ C, int64_t ldc, const T *__restrict__ A, int64_
   static_assert(SWA < TM && SWB < TN, "swizzle must stay inside an image row");
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  int tx, ty;
-  gl_tile_of(blockIdx.x, S.gx, S.gy, tx, ty);
   const int bm = tx * TM, bn = ty * TN;
   const int wm = (wave % WM) * (TM / WM), wn = (wave / WM) * (TN / WN);
   const int M = S.M, N = S.N, K = S.K;
@@ -406,6 +408,109 @@ gemm_glds_kernel(T *__restrict__ C, int64_t ldc, const T *__restrict__ A, int64_
           else *p = o;
         }
       }
+}
+
+template <typename T, typename CA, typename CB, bool BETA0, bool AK, int TM, int TN, int WM, int WN, int BK, int NST,
+          bool SPREAD = true, bool PIN = true, bool PAIR = false, int PFD = 1, bool SWAPC = false, bool NTC = false, bool XNOBAR = false, bool UNR = false>
+__global__ void __launch_bounds__(WM * WN * 64)
+gemm_glds_kernel(T *__restrict__ C, int64_t ldc, const T *__restrict__ A, int64_t lda,
+                 const T *__restrict__ B, int64_t ldb, GlShape S, CA alpha, CB beta) {
+  __shared__ __attribute__((aligned(1024))) T lds[gl_lds_elems<T, TM, TN, BK, NST>()];   // ONE LDS object (a second one makes
+                                                                                         // hipcc drain vmcnt before every ds_read)
+  int tx, ty;
+  gl_tile_of(blockIdx.x, S.gx, S.gy, tx, ty);
+  gl_gemm_tile<T, CA, CB, BETA0, AK, TM, TN, WM, WN, BK, NST, SPREAD, PIN, PAIR, PFD, SWAPC, NTC, XNOBAR, UNR>(lds, tx, ty, C, ldc, A, lda, B, ldb, S,
+                                                                                                          alpha, beta);
+}
+
+// ---- kron = two DEPENDENT GEMMs in ONE launch, the dependency kept inside an XCD (round 6) --------------------------------
+//   phase 1: Ut (m x q) = opA * X^T          tile (r, ty): row block r of Ut
+//   phase 2: R  (p x m) = opB * Ut^T          tile (ti, r): column block r of R needs row block r of Ut — ALL of it —
+// i.e. a barrier between the two products, which as two launches costs the launch boundary (2.2 us for ANY dependent
+// kernel) plus a cold DMA ring per product, and as a device-wide barrier inside one launch costs as much (agent-scope
+// release fences walk the L2; the fence-free form is three trips through the memory-side fabric). Here the dependency
+// never leaves an XCD: row block r is produced AND consumed by workgroups of XCD r % 8 (workgroup id % 8 is the XCD a
+// workgroup is dispatched to; every workgroup CHECKS that against the hardware's XCC_ID register and raises the ctx fault
+// word if it does not hold). The producers' tiles sit in that XCD's L2, the counter that publishes them is an atomic
+// executed in that same L2 (workgroup-scope atomics: no sc1, no write-back, no invalidate), and the consumers read both
+// from there: no agent-scope fence, no trip to the memory side. The wait is bounded (ctx fault word, as every single-launch
+// form of the library); the grid must be co-resident (checked by the launch site).
+// Counters: cnt[r] counts the finished phase-1 tiles of row block r, done[r] the phase-2 workgroups that have seen it
+// complete; the last of those re-arms both (self-cleaning: a launch leaves every counter at zero).
+constexpr int kGlFuseStride = 32;
+struct GlFuse {
+  unsigned *cnt;            // [2 * nrb] counters, kGlFuseStride words apart (one 128-byte line each): cnt[r], done[r]
+  int nrb;                  // row blocks of Ut = column blocks of R
+  int gy1;                  // phase-1 tiles per row block (producers)
+  int gx2;                  // phase-2 tiles per column block (consumers)
+  int per_xcd;              // workgroups per XCD = grid / 8
+  unsigned long long ticks; // bounded wait (wall_clock64 ticks)
+  unsigned *fault;          // ctx fault word (pinned host memory)
+  unsigned fault_code;
+};
+
+__device__ __forceinline__ unsigned gl_xcc_id() {
+  return (unsigned)__builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20) & 15u;   // HW_REG_XCC_ID[3:0]
+}
+
+template <typename T, typename CA, typename CB, bool BETA0, bool AK, int TM, int TN, int WM, int WN, int BK, int NST,
+          bool PAIR, int PFD, bool UNR>
+__global__ void __launch_bounds__(WM * WN * 64)
+kron_fused_kernel(T *__restrict__ R, int64_t ldr, const T *__restrict__ Bf, int64_t ldb, T *__restrict__ Ut,
+                  int64_t ldu, const T *__restrict__ Af, int64_t lda, const T *__restrict__ X, int64_t ldx, GlShape S1,
+                  GlShape S2, CA alpha, CB beta, GlFuse F) {
+  static_assert(TM == TN, "a row block of the first product is a column block of the second");
+  __shared__ __attribute__((aligned(1024))) T lds[gl_lds_elems<T, TM, TN, BK, NST>()];
+  const int tid = threadIdx.x;
+  const int xcd = (int)(blockIdx.x & 7u), local = (int)(blockIdx.x >> 3);
+  if (tid == 0 && gl_xcc_id() != (unsigned)xcd)      // the premise of everything below
+    __hip_atomic_store(F.fault, F.fault_code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  // row blocks of this XCD: r = xcd + 8 * t, t < nmine
+  const int nmine = F.nrb > xcd ? (F.nrb - xcd + 7) / 8 : 0;
+  // ---- phase 1: tile (r, ty) of Ut
+  if (local < nmine * F.gy1) {
+    const int r = xcd + 8 * (local / F.gy1), ty = local % F.gy1;
+    gl_gemm_tile<T, double, double, true, AK, TM, TN, WM, WN, BK, NST, true, true, PAIR, PFD, true, false, false, UNR>(
+        lds, r, ty, Ut, ldu, Af, lda, X, ldx, S1, 1.0, 0.0);
+    __builtin_amdgcn_s_waitcnt(0);                  // this wave's stores have reached the XCD's L2 ...
+    __syncthreads();                                 // ... and so have every wave's
+    if (tid == 0) __hip_atomic_fetch_add(F.cnt + (size_t)r * kGlFuseStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // executed in that L2
+  }
+  // ---- phase 2: tile (ti, r) of R
+  if (local < nmine * F.gx2) {
+    const int r = xcd + 8 * (local / F.gx2), ti = local % F.gx2;
+    if (tid == 0) {                                  // (no second __shared__ object in this kernel: see gemm_glds_kernel)
+      unsigned long long t0 = 0;
+      unsigned it = 0;
+      // the poll must be an atomic EXECUTED IN L2 on every trip: an idempotent read-modify-write (fetch_add 0) is folded into
+      // a plain load by the compiler, which the CU's L1 then serves from its first, stale copy for ever; a compare-and-swap
+      // of the target value with itself is not
+      auto peek = [&]() {
+        unsigned expect = (unsigned)F.gy1;
+        __hip_atomic_compare_exchange_strong(F.cnt + (size_t)r * kGlFuseStride, &expect, (unsigned)F.gy1, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        return expect;                               // the value found
+      };
+      while (F.ticks != 0 && peek() < (unsigned)F.gy1) {   // (ticks == 0: timing experiment kron_fuse = 2 — no wait, WRONG results)
+        __builtin_amdgcn_s_sleep(8);                 // ~0.2 us between polls: the producers' atomics are not queued behind pollers
+        if ((++it & 255u) == 0) {
+          const unsigned long long now = (unsigned long long)wall_clock64();
+          if (t0 == 0) t0 = now;
+          else if (now - t0 > F.ticks) {
+            __hip_atomic_store(F.fault, F.fault_code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            break;                                   // reported through the fault word; this tile is garbage
+          }
+        }
+      }
+      // the last consumer of row block r re-arms its counters for the next launch
+      if (__hip_atomic_fetch_add(F.cnt + (size_t)(F.nrb + r) * kGlFuseStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == (unsigned)F.gx2 - 1u) {
+        __hip_atomic_store(F.cnt + (size_t)r * kGlFuseStride, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_store(F.cnt + (size_t)(F.nrb + r) * kGlFuseStride, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+    }
+    __syncthreads();
+    gl_gemm_tile<T, CA, CB, BETA0, AK, TM, TN, WM, WN, BK, NST, true, true, PAIR, PFD, true, false, false, UNR>(
+        lds, ti, r, R, ldr, Bf, ldb, Ut, ldu, S2, alpha, beta);
+  }
 }
 
 // Preconditions of the DMA path (16-byte global reads): pointers 16-byte aligned, leading dimensions and the

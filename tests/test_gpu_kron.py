@@ -400,3 +400,45 @@ def test_complex_form_switch_and_what_each_form_guarantees(lo, dev):
     assert lo.kron(dA, dB).complex_form == ("gauss" if os.environ.get("MXLO_KRON_GAUSS", "1") != "0" else "4gemm")
     with pytest.raises(ValueError):
         lo.kron(dA, dB, complex_form="karatsuba")
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-12), (torch.float32, 3e-5)])
+@pytest.mark.parametrize("shape", [((64, 64), (64, 64)), ((128, 96), (200, 160)), ((256, 256), (256, 256)), ((300, 260), (180, 340)),
+                                   ((512, 512), (512, 512)), ((1024, 1024), (1024, 1024)), ((520, 1000), (1000, 520))])
+def test_kron_one_launch_form_is_bit_identical_to_the_two_launches(lo, dev, dtype, tol, shape):
+    """Round 6: where every tile of both GEMMs of a kron apply has its own CU, the two dependent products run as ONE launch
+    whose dependency never leaves an XCD (gemm_glds.h: kron_fused_kernel; tune key kron_fuse). Same tiles, same MFMA order
+    per tile: `mul!`, the 5-arg form and the transposed product have the BITS of the two-launch schedule, on and off the
+    tile grid, repeatedly (the counters re-arm themselves), and the result is the dense Kronecker product's."""
+    (am, an), (bp, bq) = shape
+    npd = NP[dtype]
+    rng = np.random.default_rng(am + 3 * an + 5 * bp + 7 * bq)
+    A, B = rng.uniform(-1, 1, (am, an)).astype(npd), rng.uniform(-1, 1, (bp, bq)).astype(npd)
+    K = lo.kron(colmajor(A, dev), colmajor(B, dev))
+    x, xt = T(rng.uniform(-1, 1, an * bq).astype(npd), dev), T(rng.uniform(-1, 1, am * bp).astype(npd), dev)
+    r0 = T(rng.uniform(-1, 1, am * bp).astype(npd), dev)
+    ctx = lo.get_ctx(dev)
+    got = {}
+    try:
+        for fuse in (0, 1):
+            ctx.tune("kron_fuse", fuse)
+            out = []
+            for rep in range(3):                                  # repeated applies: the counters of the fused form re-arm themselves
+                a = torch.full((am * bp,), float("nan"), dtype=dtype, device=dev)
+                lo.mul(a, K, x)
+                b = r0.clone()
+                lo.mul(b, K, x, 0.75, -1.25)
+                c = torch.full((an * bq,), float("nan"), dtype=dtype, device=dev)
+                lo.mul(c, K.T, xt)
+                out.append((a, b, c))
+            torch.cuda.synchronize()
+            for rep in (1, 2):
+                assert all(torch.equal(u, v) for u, v in zip(out[0], out[rep]))
+            got[fuse] = out[0]
+    finally:
+        ctx.tune("kron_fuse", 1)
+    assert all(torch.equal(u, v) for u, v in zip(got[0], got[1]))
+    if am * bp * an * bq <= 1 << 26:                               # the dense product as the reference's test does (test_kron.jl:35)
+        Kd = np.kron(A.astype(np.float64), B.astype(np.float64))
+        assert rel(got[1][0].cpu().numpy(), Kd @ x.cpu().numpy().astype(np.float64)) <= tol
+        assert rel(got[1][2].cpu().numpy(), Kd.T @ xt.cpu().numpy().astype(np.float64)) <= tol

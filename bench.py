@@ -53,6 +53,9 @@ def parse(argv=None):
     ap.add_argument("--nelem", dest="n", type=int, default=100_000_000, help="vector length per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
+    ap.add_argument("--no-traffic", action="store_true",
+                    help="do not measure roofline.traffic in this run (two rocprofv3 --pmc passes over a child process, ~25 s); "
+                         "the profile-derived figure of profiles/traffic_householder.json is reported instead, labelled as such")
     ap.add_argument("--cpu-sample", type=int, default=100_000_000)   # the GPU workload's own n
     ap.add_argument("--qn-nelem", type=int, default=50_000_000,
                     help="rows per GPU of the quasi-Newton legs (configs[2] / configs[4]: 5e7). A debugging aid like --nelem: the "
@@ -147,7 +150,7 @@ def die(msg: str, code: int = 2):
 PHASE_LIMITS_S = {
     "import + library load": 300, "init_process_group": 300, "communicator creation": 240, "transport preflight": 240,
     "operand set-up": 300, "clock spin-up": 300, "warm-up steps": 300, "timed loop": 300, "per-kernel timing": 300,
-    "quasi-Newton legs": 900, "cfg4 legs": 300, "misc legs": 600, "cpu baseline": 300, "second transport (optional)": 150, "teardown": 120,
+    "quasi-Newton legs": 900, "cfg4 legs": 300, "misc legs": 600, "cpu baseline": 300, "pmc traffic": 400, "second transport (optional)": 150, "teardown": 120,
 }
 
 
@@ -667,6 +670,17 @@ def worker(args):
                 except Exception as e:
                     extras["cpu_legs_error"] = repr(e)[:200]
 
+    if rank == 0 and world == 1 and not args.no_traffic and not args.no_extras:
+        with wd.phase("pmc traffic"):
+            t_meas, how = measure_traffic(n)
+            if t_meas is not None:
+                out["roofline"]["traffic_profile_derived"] = out["roofline"]["traffic"]
+                out["roofline"]["traffic"] = round(t_meas, 1)
+                out["roofline"]["traffic_source"] = how
+                out["roofline"]["traffic_over_algorithmic"] = round(t_meas / (24.0 * n), 5)
+            else:
+                out["roofline"]["traffic_measure_error"] = how
+
     # ---- the same K steps under the SECOND transport (peer-mapped one-shot exchange), N > 1 only: reported next to the
     # RCCL headline, never as `value`. It runs LAST and is optional: everything above is already in `out`, so a failure or
     # a stall in here abandons this leg only — rank 0 prints the line it has (with the reason under transports.peer_shm)
@@ -1170,6 +1184,17 @@ def bench_cfg4(lo, torch, dev, ctx):
     flop = 4.0 * n ** 3
     out["kron_1024x1024"] = {"us_per_apply": round(ms * 1e3, 2), "TFLOP/s_f64": round(flop / ms / 1e9, 2),
                              "frac_f64_mfma_peak(78.6TF)": round(flop / ms / 1e9 / 78.6, 4)}
+    out["kron_1024x1024"]["form"] = "both GEMMs in one launch, XCD-local dependency (kron_fuse = 1, the default)"
+    # the launch-bound size of the same operator (round 6: both GEMMs in ONE launch, XCD-local dependency — 0.39 -> 0.44)
+    n5 = 512
+    A5 = ((torch.rand(n5, n5, dtype=torch.float64, device=dev, generator=gen) * 2 - 1) / 32).t()
+    B5 = ((torch.rand(n5, n5, dtype=torch.float64, device=dev, generator=gen) * 2 - 1) / 32).t()
+    K5 = lo.kron(A5, B5)
+    x5 = torch.rand(n5 * n5, dtype=torch.float64, device=dev, generator=gen) * 2 - 1
+    r5 = torch.empty_like(x5)
+    ms5 = timeit(lambda: lo.mul(r5, K5, x5, 1.0, 0.0), 200)
+    out["kron_512x512"] = {"us_per_apply": round(ms5 * 1e3, 2), "frac_f64_mfma_peak(78.6TF)": round(4.0 * n5 ** 3 / ms5 / 1e9 / 78.6, 4)}
+    del K5, A5, B5, x5, r5
     Ssum = keep[0] + K
     ms = timeit(lambda: lo.mul(res, Ssum, x, 1.0, 0.0), 50)
     out["BlockDiagonal_plus_kron_2^20"] = {"us_per_apply": round(ms * 1e3, 2)}
@@ -1379,6 +1404,71 @@ def bench_misc(lo, torch, dev, ctx):
     out["opHouseholder_n2^16_latency"] = {"us_C_ABI": round(ms * 1e3, 2), "us_python_mirror": round(ms_py * 1e3, 2), "launches": 1}
     torch.cuda.empty_cache()
     return out
+
+
+PMC_WORKLOAD = """
+import os, sys
+sys.path.insert(0, %(root)r)
+import torch
+import __graft_entry__ as g
+lo = g.load_package()
+dev = torch.device("cuda", 0)
+gen = torch.Generator(device=dev).manual_seed(1)
+n = %(n)d
+h = torch.rand(n, dtype=torch.float64, device=dev, generator=gen) - 0.5
+h /= torch.linalg.vector_norm(h)
+v = torch.rand(n, dtype=torch.float64, device=dev, generator=gen) * 2 - 1
+res = torch.empty(n, dtype=torch.float64, device=dev)
+H = lo.opHouseholder(h)
+for _ in range(3):
+    lo.mul(res, H, v, 1.0, 0.0)
+torch.cuda.synchronize()
+print("pmc workload done")
+"""
+
+
+def measure_traffic(n: int, timeout_s: float = 150.0):
+    """roofline.traffic MEASURED IN THIS RUN: HBM bytes per launch of the dominant kernel from two
+    separate `rocprofv3 --pmc` passes (FETCH_SIZE, then WRITE_SIZE — they do not fit one pass) over a child process that runs
+    three Householder applies at the workload's own n, corrected as /opt/skills/guides/MI355X_MICROARCH.md §HBM prescribes
+    (both counters are in KiB; on gfx950 FETCH_SIZE tallies a 128-byte read request as 64 bytes -> x 2; WRITE_SIZE x 1,
+    calibrated against TCC_EA0_WRREQ_64B in profiles/). Returns (bytes per launch or None, description)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found on this box"
+    tmp = tempfile.mkdtemp(prefix="mxlo_pmc_", dir="/tmp")
+    try:
+        script = os.path.join(tmp, "workload.py")
+        with open(script, "w") as f:
+            f.write(PMC_WORKLOAD % {"root": ROOT, "n": n})
+        got = {}
+        env = dict(os.environ, TMPDIR="/tmp")
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, ctr)
+            p = subprocess.run([exe, "--kernel-trace", "--output-format", "csv", "--pmc", ctr, "-d", out, "-o", "pmc", "--",
+                                sys.executable, script], cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                               text=True, timeout=timeout_s)
+            vals = []
+            for fcsv in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+                for r in csv.DictReader(open(fcsv)):
+                    if "HouseholderOp" in r.get("Kernel_Name", "") and "map_kernel" in r["Kernel_Name"] and r.get("Counter_Name") == ctr:
+                        vals.append(float(r["Counter_Value"]))
+            if not vals:
+                return None, f"the {ctr} pass produced no counter rows for map_kernel<HouseholderOp> (rc {p.returncode}): {p.stdout[-200:]!r}"
+            got[ctr] = sum(vals) / len(vals)
+        traffic = got["FETCH_SIZE"] * 1024.0 * 2.0 + got["WRITE_SIZE"] * 1024.0
+        return traffic, ("measured in THIS run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) over a child process "
+                         f"running 3 applies at n = {n}; FETCH_SIZE = {got['FETCH_SIZE']:.0f} KiB x 2 (gfx950: a 128-B read request is tallied "
+                         f"as 64 B), WRITE_SIZE = {got['WRITE_SIZE']:.0f} KiB x 1 — MI355X_MICROARCH.md §HBM")
+    except Exception as e:
+        return None, f"PMC passes failed: {e!r}"[:300]
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def cpu_leg(n_sample: int, gpu=None):

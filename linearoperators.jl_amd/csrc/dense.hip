@@ -1688,7 +1688,8 @@ int32_t kron_t(mxlo_ctx *ctx, T *res, const T *A, int64_t am, int64_t an, int64_
   // ---- both products in ONE launch with an XCD-local dependency (gemm_glds.h: kron_fused_kernel; tune key kron_fuse):
   // same tile class for both (the one gemm() would pick for each), the same A layout, every tile of both products on its
   // own CU (grid <= #CU and co-resident), DMA preconditions as gemm().
-  if (ctx->tune.kron_fuse && trans_a == trans_b && ctx->fault_dev && !ctx->capturing && m > 0 && n > 0 && p > 0 && q > 0 &&
+  // (inside a graph capture only once a warm-up apply has probed the XCD map and allocated the counters: neither can happen there)
+  if (ctx->tune.kron_fuse && trans_a == trans_b && ctx->fault_dev && (!ctx->capturing || (ctx->xcd_map == 1 && ctx->kron_cnt_n > 0)) && m > 0 && n > 0 && p > 0 && q > 0 &&
       m < (1LL << 31) && n < (1LL << 31) && p < (1LL << 31) && q < (1LL << 31) && lda < (1LL << 22) && ldb < (1LL << 22) &&
       m < (1LL << 22) && q < (1LL << 22) && gemm_glds_ok<T>(A, lda, trans_a, x, q, m, q, n) &&
       gemm_glds_ok<T>(B, ldb, trans_b, work, m, p, m, q)) {

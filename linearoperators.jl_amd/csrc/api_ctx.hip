@@ -455,6 +455,12 @@ MXLO_API int32_t mxlo_ctx_tune(mxlo_ctx *ctx, const char *key, int64_t value) {
   } else if (!strcmp(key, "kron_fuse")) {
     MXLO_REQUIRE(value >= 0 && value <= 2, MXLO_EINVAL, "kron_fuse must be 0, 1 (or 2: timing experiment without the wait, wrong results)");
     ctx->tune.kron_fuse = (int)value;
+  } else if (!strcmp(key, "herm_order")) {
+    MXLO_REQUIRE(value == 0 || value == 1, MXLO_EINVAL, "herm_order must be 0 or 1");
+    ctx->tune.herm_order = (int)value;
+  } else if (!strcmp(key, "herm_lds_pad")) {
+    MXLO_REQUIRE(value >= 0 && value <= 48 * 1024, MXLO_EINVAL, "herm_lds_pad must be in 0..49152 bytes");
+    ctx->tune.herm_lds_pad = (int)value;
   } else if (!strcmp(key, "herm_single")) {
     MXLO_REQUIRE(value == 0 || value == 1, MXLO_EINVAL, "herm_single must be 0 or 1");
     ctx->tune.herm_single = (int)value;

@@ -1151,7 +1151,7 @@ template <typename T, int C, bool EDGE, bool DSEL = false, bool SLOT = false, in
 __device__ __forceinline__ void
 herm_strip_body(const T *__restrict__ A, int64_t lda, const T *__restrict__ v, int64_t n,
                 double *__restrict__ Prow, double *__restrict__ Pcol, int64_t ng, int qint, int mode, int64_t t,
-                int64_t ldv = 0, int64_t pstride = 0) {
+                int64_t ldv = 0, int64_t pstride = 0, int colmajor_g = 0) {
   constexpr int RPL = HermCfg<T>::RPL, HR = HermCfg<T>::HR, DT = HermCfg<T>::DT;
   typedef T VR __attribute__((ext_vector_type(RPL)));
   constexpr int HS = C;
@@ -1163,12 +1163,26 @@ herm_strip_body(const T *__restrict__ A, int64_t lda, const T *__restrict__ v, i
     slot = (int64_t)qint * G + t % DT;
   } else if (!EDGE || mode == 0) {           // triangular enumeration u = G'(G'+1)/2 + r, r <= G'; G = G'+1
     constexpr int Q = DT / C;
-    const int64_t u = t / Q;
+    // colmajor_g = g > 0 (the interior strips of g full row groups; tune key herm_order): the (row group, column block) pairs
+    // are walked COLUMN BLOCK by column block — workgroups that run at the same time then read the same 256 columns in
+    // consecutive row groups, i.e. long contiguous runs down each column (what the row-band GEMV streams), instead of 2-KiB
+    // pieces 128 KiB apart along one row group. The enumeration is the triangular one read backwards; (G, slot) and with
+    // them every partial index are the same function of the pair: results do not depend on the order.
+    const int64_t u0 = t / Q;
+    const int64_t u = colmajor_g > 0 ? (int64_t)colmajor_g * (colmajor_g - 1) / 2 - 1 - u0 : u0;
     int64_t Gp = (int64_t)((sqrt(8.0 * (double)u + 1.0) - 1.0) * 0.5);
     while (Gp * (Gp + 1) / 2 > u) --Gp;
     while ((Gp + 1) * (Gp + 2) / 2 <= u) ++Gp;
-    G = Gp + 1;
-    slot = (u - Gp * (Gp + 1) / 2) * Q + t % Q;          // strip s < Q*G
+    const int64_t rem = u - Gp * (Gp + 1) / 2;            // <= Gp
+    int64_t cb;                                           // column block (of 256 columns) < G
+    if (colmajor_g > 0) {
+      cb = colmajor_g - 2 - Gp;                           // column block cb holds the colmajor_g - 1 - cb pairs G = cb + 1 ..
+      G = cb + 1 + (Gp - rem);
+    } else {
+      G = Gp + 1;
+      cb = rem;
+    }
+    slot = cb * Q + t % Q;                                // strip s < Q*G
     tile0 = slot * C;
   } else if (mode == 1) {                    // strips left of the diagonal block of the last row group
     G = ng - 1;
@@ -1285,9 +1299,9 @@ herm_strip_body(const T *__restrict__ A, int64_t lda, const T *__restrict__ v, i
 template <typename T, int C>
 __global__ void __launch_bounds__(kBlock)
 herm_pass_kernel(const T *__restrict__ A, int64_t lda, const T *__restrict__ v, int64_t n,
-                 double *__restrict__ Prow, double *__restrict__ Pcol, int64_t ng, int qint, int64_t n_int) {
+                 double *__restrict__ Prow, double *__restrict__ Pcol, int64_t ng, int qint, int64_t n_int, int colmajor_g) {
   const int64_t t = blockIdx.x;
-  if (t < n_int) return herm_strip_body<T, C, false>(A, lda, v, n, Prow, Pcol, ng, qint, 0, t);
+  if (t < n_int) return herm_strip_body<T, C, false>(A, lda, v, n, Prow, Pcol, ng, qint, 0, t, 0, 0, colmajor_g);
   herm_strip_body<T, 1, false, true>(A, lda, v, n, Prow, Pcol, ng, qint, 2, t - n_int);
 }
 
@@ -1310,9 +1324,10 @@ herm_edge_kernel(const T *__restrict__ A, int64_t lda, const T *__restrict__ v, 
 template <typename T, int C, int KV>
 __global__ void __launch_bounds__(kBlock)
 herm_pass_block_kernel(const T *__restrict__ A, int64_t lda, const T *__restrict__ v, int64_t ldv, int64_t n,
-                       double *__restrict__ Prow, double *__restrict__ Pcol, int64_t pstride, int64_t ng, int qint, int64_t n_int) {
+                       double *__restrict__ Prow, double *__restrict__ Pcol, int64_t pstride, int64_t ng, int qint, int64_t n_int,
+                       int colmajor_g) {
   const int64_t t = blockIdx.x;
-  if (t < n_int) return herm_strip_body<T, C, false, false, false, KV>(A, lda, v, n, Prow, Pcol, ng, qint, 0, t, ldv, pstride);
+  if (t < n_int) return herm_strip_body<T, C, false, false, false, KV>(A, lda, v, n, Prow, Pcol, ng, qint, 0, t, ldv, pstride, colmajor_g);
   herm_strip_body<T, 1, false, true, false, KV>(A, lda, v, n, Prow, Pcol, ng, qint, 2, t - n_int, ldv, pstride);
 }
 template <typename T, int C, int KV>
@@ -1560,8 +1575,8 @@ int32_t hermitian_t(mxlo_ctx *ctx, T *res, const T *d, const T *A, int64_t lda, 
 #define HERM_LAUNCH(C_)                                                                                          \
   {                                                                                                              \
     if (n_light > 0) {                                                                                           \
-      hipLaunchKernelGGL((herm_pass_kernel<T, C_>), dim3((unsigned)n_light), dim3(kBlock), 0, ctx->stream, A, lda, v, \
-                         n, Prow, Pcol, ng, Q, n_int);                                                           \
+      hipLaunchKernelGGL((herm_pass_kernel<T, C_>), dim3((unsigned)n_light), dim3(kBlock), (size_t)ctx->tune.herm_lds_pad, ctx->stream, A, lda, v, \
+                         n, Prow, Pcol, ng, Q, n_int, ctx->tune.herm_order ? (int)gi : 0);                       \
       MXLO_LAUNCH_CHECK();                                                                                       \
     }                                                                                                            \
     if (n_edge > 0) {                                                                                            \
@@ -1622,8 +1637,8 @@ int32_t hermitian_block_t(mxlo_ctx *ctx, T *res, int64_t ldr, const T *d, const 
     }
     auto launch = [&]<int C_, int KV_>() -> int32_t {
       if (n_light > 0) {
-        hipLaunchKernelGGL((herm_pass_block_kernel<T, C_, KV_>), dim3((unsigned)n_light), dim3(kBlock), 0, ctx->stream, A, lda, v, ldv, n,
-                           Prow, Pcol, pstride, ng, Q, n_int);
+        hipLaunchKernelGGL((herm_pass_block_kernel<T, C_, KV_>), dim3((unsigned)n_light), dim3(kBlock), (size_t)ctx->tune.herm_lds_pad, ctx->stream, A, lda, v, ldv, n,
+                           Prow, Pcol, pstride, ng, Q, n_int, ctx->tune.herm_order ? (int)gi : 0);
         MXLO_LAUNCH_CHECK();
       }
       if (n_edge > 0) {

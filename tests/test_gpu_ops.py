@@ -150,6 +150,33 @@ def test_hermitian_block_apply_is_bit_identical_to_the_column_loop(lo, dev, n, d
         lo.mul(torch.empty(n, 2, dtype=dtype, device=dev), H, torch.empty(n, 3, dtype=dtype, device=dev), 1.0, 0.0)
 
 
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("n", [2304, 4096, 5000])
+def test_hermitian_strip_order_does_not_change_a_bit(lo, dev, dtype, n):
+    """Round 6: the interior strips of opHermitian are walked column block by column block (tune key herm_order = 1, the
+    default: workgroups that run together read contiguous runs down the same columns — n = 4096 f64 17.7 -> 16.2 us) instead
+    of row group by row group (0). Every partial lands in the same slot and is added in the same order: single applies and
+    block applies are bit-identical under both orders."""
+    g = torch.Generator(device="cpu").manual_seed(n)
+    M = (torch.rand(n, n, dtype=dtype, generator=g) - 0.5).to(dev).t()
+    d, x = ((torch.rand(n, dtype=dtype, generator=g) - 0.5).to(dev) for _ in range(2))
+    V = (torch.rand(4, n, dtype=dtype, generator=g) - 0.5).to(dev).t()
+    H = lo.opHermitian(d, M)
+    ctx = lo.get_ctx(dev)
+    got = {}
+    try:
+        for order in (0, 1):
+            ctx.tune("herm_order", order)
+            r = torch.empty(n, dtype=dtype, device=dev)
+            lo.mul(r, H, x, 0.7, 0.0)
+            R = torch.empty(4, n, dtype=dtype, device=dev).t()
+            lo.mul(R, H, V, 1.0, 0.0)
+            got[order] = (r, R)
+    finally:
+        ctx.tune("herm_order", 1)
+    assert torch.equal(got[0][0], got[1][0]) and torch.equal(got[0][1], got[1][1])
+
+
 def test_hermitian_single_launch_is_bit_identical_to_the_two_launch_form(lo, dev):
     """Round 5: for full row groups of an aligned matrix (n a multiple of 256 / 512, n <= 8192)
     opHermitian is ONE launch — strip workgroups publish their partials as self-validating slots, finisher workgroups of

@@ -20,6 +20,12 @@ if os.environ.get("MXLO_HERM_SINGLE") is not None:
     ctx.tune("herm_single", int(os.environ["MXLO_HERM_SINGLE"]))
     print(f"# herm_single = {os.environ['MXLO_HERM_SINGLE']}")
 sizes = tuple(int(x) for x in os.environ.get("MXLO_HERM_SIZES", "1024,2048,4096,8192,16384").split(","))
+if os.environ.get("MXLO_HERM_ORDER") is not None:
+    ctx.tune("herm_order", int(os.environ["MXLO_HERM_ORDER"]))
+    print(f"# herm_order = {os.environ['MXLO_HERM_ORDER']}")
+if os.environ.get("MXLO_HERM_LDS_PAD") is not None:
+    ctx.tune("herm_lds_pad", int(os.environ["MXLO_HERM_LDS_PAD"]))
+    print(f"# herm_lds_pad = {os.environ['MXLO_HERM_LDS_PAD']}")
 for nn in sizes:
     M = torch.rand(nn, nn, dtype=dt, device=dev).t()
     d, x, y = (torch.rand(nn, dtype=dt, device=dev) for _ in range(3))

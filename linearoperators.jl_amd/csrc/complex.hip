@@ -666,7 +666,7 @@ template <typename R, int CT, bool EDGE, bool DSEL = false>
 __device__ __forceinline__ void
 cherm_strip_body(const C<R> *__restrict__ A, int64_t lda, const C<R> *__restrict__ v, int64_t n,
                  double *__restrict__ Prow, double *__restrict__ Pcol, int64_t ng, int qint, int mode, int64_t t,
-                 double (*rowred)[CHermCfg<R>::HR][2]) {
+                 double (*rowred)[CHermCfg<R>::HR][2], int colmajor_g = 0) {
   constexpr int RPL = CHermCfg<R>::RPL, HR = CHermCfg<R>::HR, DT = CHermCfg<R>::DT;
   using V = typename Vec16<C<R>>::type;      // f64x2 / f32x4: RPL complex elements
   static_assert(!DSEL || (!EDGE && CT == 1), "DSEL: one unmasked-load tile of a diagonal block");
@@ -677,12 +677,23 @@ cherm_strip_body(const C<R> *__restrict__ A, int64_t lda, const C<R> *__restrict
     slot = (int64_t)qint * G + t % DT;
   } else if (!EDGE || mode == 0) {           // triangular enumeration u = G'(G'+1)/2 + r, r <= G'; G = G'+1
     constexpr int Q = DT / CT;
-    const int64_t u = t / Q;
+    // colmajor_g = g > 0 (interior strips of g full row groups; tune key herm_order, dense.hip: herm_strip_body): the pairs are
+    // walked column block by column block, so that workgroups running together read contiguous runs down the same columns
+    const int64_t u0 = t / Q;
+    const int64_t u = colmajor_g > 0 ? (int64_t)colmajor_g * (colmajor_g - 1) / 2 - 1 - u0 : u0;
     int64_t Gp = (int64_t)((sqrt(8.0 * (double)u + 1.0) - 1.0) * 0.5);
     while (Gp * (Gp + 1) / 2 > u) --Gp;
     while ((Gp + 1) * (Gp + 2) / 2 <= u) ++Gp;
-    G = Gp + 1;
-    slot = (u - Gp * (Gp + 1) / 2) * Q + t % Q;          // strip s < Q*G
+    const int64_t rem = u - Gp * (Gp + 1) / 2;
+    int64_t cb;
+    if (colmajor_g > 0) {
+      cb = colmajor_g - 2 - Gp;
+      G = cb + 1 + (Gp - rem);
+    } else {
+      G = Gp + 1;
+      cb = rem;
+    }
+    slot = cb * Q + t % Q;                                // strip s < Q*G
     tile0 = slot * CT;
   } else if (mode == 1) {                    // strips left of the diagonal block of the last row group
     G = ng - 1;
@@ -828,10 +839,10 @@ cherm_strip_body(const C<R> *__restrict__ A, int64_t lda, const C<R> *__restrict
 template <typename R, int CT>
 __global__ void __launch_bounds__(kBlock)
 cherm_pass_kernel(const C<R> *__restrict__ A, int64_t lda, const C<R> *__restrict__ v, int64_t n,
-                  double *__restrict__ Prow, double *__restrict__ Pcol, int64_t ng, int qint, int64_t n_int) {
+                  double *__restrict__ Prow, double *__restrict__ Pcol, int64_t ng, int qint, int64_t n_int, int colmajor_g) {
   __shared__ double rowred[2][CHermCfg<R>::HR][2];
   const int64_t t = blockIdx.x;
-  if (t < n_int) return cherm_strip_body<R, CT, false>(A, lda, v, n, Prow, Pcol, ng, qint, 0, t, rowred);
+  if (t < n_int) return cherm_strip_body<R, CT, false>(A, lda, v, n, Prow, Pcol, ng, qint, 0, t, rowred, colmajor_g);
   cherm_strip_body<R, 1, false, true>(A, lda, v, n, Prow, Pcol, ng, qint, 2, t - n_int, rowred);
 }
 
@@ -950,7 +961,7 @@ int32_t chermitian(mxlo_ctx *ctx, C<R> *res, const void *d, bool d_real, const C
   {                                                                                                              \
     if (n_light > 0) {                                                                                           \
       hipLaunchKernelGGL((cherm_pass_kernel<R, CT_>), dim3((unsigned)n_light), dim3(kBlock), 0, ctx->stream, A, lda, \
-                         v, n, Prow, Pcol, ng, Q, n_int);                                                        \
+                         v, n, Prow, Pcol, ng, Q, n_int, ctx->tune.herm_order ? (int)gi : 0);                    \
       MXLO_LAUNCH_CHECK();                                                                                       \
     }                                                                                                            \
     if (n_edge > 0) {                                                                                            \

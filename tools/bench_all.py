@@ -226,6 +226,9 @@ if sec("dense"):
 
 # complex opHermitian: the single-pass strip kernel against the two-pass form it replaced
 if sec("cherm"):
+    if os.environ.get("MXLO_HERM_ORDER") is not None:
+        ctx.tune("herm_order", int(os.environ["MXLO_HERM_ORDER"]))
+        print(f"# herm_order = {os.environ['MXLO_HERM_ORDER']}")
     for cdt, rdt_, bpe in ((torch.complex128, torch.float64, 16), (torch.complex64, torch.float32, 8)):
         for nn in (1024, 2048, 4096, 8192, 16384):
             Mc = torch.complex(rnd(nn * nn, rdt_), rnd(nn * nn, rdt_)).reshape(nn, nn).t()

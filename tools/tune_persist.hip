@@ -127,7 +127,9 @@ __global__ void __launch_bounds__(256) combine_kernel(double *__restrict__ res, 
 // agent-scope stores (no fence), gathered by every workgroup (wave w sums columns w, w + nwaves, ...; lane l adds
 // workgroups l, l + 64, ... in order, then one fixed DPP tree). Combine: the workgroup's chunks again (REV: last chunk
 // first — what the dots phase touched last is the likeliest to sit in this XCD's L2), all columns per chunk.
-template <int BLOCK, int NB, int UB, bool REV>
+// ILV (round 6): interleaved ownership — workgroup b takes chunks b, b + G, b + 2G, ...: at any moment the grid reads ONE contiguous
+// region per column instead of G separate ones.
+template <int BLOCK, int NB, int UB, bool REV, bool ILV = false>
 __global__ void __launch_bounds__(BLOCK) persist_kernel(double *__restrict__ res, Cols cols, int ncol,
                                                         const double *__restrict__ x, int64_t nvec,
                                                         unsigned long long *__restrict__ slots, int parity, int cpw,
@@ -141,7 +143,8 @@ __global__ void __launch_bounds__(BLOCK) persist_kernel(double *__restrict__ res
   for (int i = b * BLOCK + tid; i < kMaxCols * 1024; i += G * BLOCK)
     __hip_atomic_store(other + i, kEmpty, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const int64_t nchunks = (nvec + CH - 1) / CH;
-  const int64_t ch0 = (int64_t)b * cpw, ch1 = ch0 + cpw < nchunks ? ch0 + cpw : nchunks;
+  const int64_t ch0 = ILV ? 0 : (int64_t)b * cpw, ch1 = ILV ? (nchunks - b + G - 1) / G : (ch0 + cpw < nchunks ? ch0 + cpw : nchunks);
+  auto chunk_of = [&](int64_t k) { return ILV ? k * G + b : k; };
   const f64x2 *xv = reinterpret_cast<const f64x2 *>(x);
   // ---- dots
   for (int c0 = 0; c0 < ncol; c0 += NB) {
@@ -151,7 +154,8 @@ __global__ void __launch_bounds__(BLOCK) persist_kernel(double *__restrict__ res
     const f64x2 *cp[NB];
 #pragma unroll
     for (int t = 0; t < NB; ++t) cp[t] = reinterpret_cast<const f64x2 *>(cols.p[c0 + t < ncol ? c0 + t : ncol - 1]);
-    for (int64_t ch = ch0; ch < ch1; ++ch) {
+    for (int64_t kk = ch0; kk < ch1; ++kk) {
+      const int64_t ch = chunk_of(kk);
       const int64_t base = ch * CH + tid;
       if (base + (int64_t)(UB - 1) * BLOCK < nvec) {
         f64x2 xe[UB], cv[NB][UB];
@@ -209,7 +213,7 @@ __global__ void __launch_bounds__(BLOCK) persist_kernel(double *__restrict__ res
   __syncthreads();
   // ---- combine
   for (int64_t k = 0; k < ch1 - ch0; ++k) {
-    const int64_t ch = REV ? ch1 - 1 - k : ch0 + k;
+    const int64_t ch = chunk_of(REV ? ch1 - 1 - k : ch0 + k);
     const int64_t base = ch * CH + tid;
     if (base + (int64_t)(UB - 1) * BLOCK < nvec) {
       f64x2 q[UB];
@@ -383,6 +387,26 @@ int main(int argc, char **argv) {
       printf("persist   block %4d x %d/CU NB=%2d UB=%d (%3d chunks/wg): fwd %7.1f us (%5.2f TB/s, %.2f of 8)   rev %7.1f us (%5.2f TB/s, %.2f)\n", BLOCK,
              per_cu, NB, UB, cpw, t[0], bytes2 / t[0] * 1e-6, bytes2 / t[0] * 1e-6 / 8, t[1], bytes2 / t[1] * 1e-6, bytes2 / t[1] * 1e-6 / 8);
     };
+    auto run_ilv = [&]<int BLOCK, int NB, int UB>(int per_cu) {
+      const int G = cus * per_cu;
+      double t[2];
+      for (int rev = 0; rev < 2; ++rev)
+        t[rev] = time_us([&] {
+          if (rev) hipLaunchKernelGGL((persist_kernel<BLOCK, NB, UB, true, true>), dim3(G), dim3(BLOCK), 0, 0, res, cols, ncol, x, nvec, slots, parity, 0, fault);
+          else hipLaunchKernelGGL((persist_kernel<BLOCK, NB, UB, false, true>), dim3(G), dim3(BLOCK), 0, 0, res, cols, ncol, x, nvec, slots, parity, 0, fault);
+          parity ^= 1;
+        }, 50);
+      if (*fault) { printf("FAULT: a gather timed out\n"); exit(2); }
+      printf("persist   block %4d x %d/CU NB=%2d UB=%d INTERLEAVED chunks  : fwd %7.1f us (%5.2f TB/s, %.2f of 8)   rev %7.1f us (%5.2f TB/s, %.2f)\n", BLOCK,
+             per_cu, NB, UB, t[0], bytes2 / t[0] * 1e-6, bytes2 / t[0] * 1e-6 / 8, t[1], bytes2 / t[1] * 1e-6, bytes2 / t[1] * 1e-6 / 8);
+    };
+    if (getenv("TUNE_PERSIST_ILV")) {
+      run.template operator()<512, 10, 1>(1);
+      run_ilv.template operator()<512, 10, 1>(1);
+      run_ilv.template operator()<512, 10, 1>(2);
+      run_ilv.template operator()<256, 10, 1>(4);
+      continue;
+    }
     run.template operator()<256, 10, 1>(2);
     run.template operator()<256, 10, 1>(4);
     run.template operator()<256, 10, 2>(2);

@@ -87,6 +87,27 @@ __global__ void __launch_bounds__(256) readk_w(Ptrs P, f64x2 *__restrict__ res, 
   if (NT) __builtin_nontemporal_store(q, res + i); else res[i] = q;
 }
 
+// K read streams + TWO write streams (round 6: the shape of a push! pass — the panel columns are read for the Gram rows while the new
+// pair is stored into its two slots): one vector per thread; the two stored vectors are two of the K read ones (s, y)
+template <int K, bool NT, int BATCH>
+__global__ void __launch_bounds__(256) readk_w2(Ptrs P, f64x2 *__restrict__ w1, f64x2 *__restrict__ w2, int64_t nvec_each, double *out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= nvec_each) return;
+  f64x2 q = {0, 0}, s0, s1;
+#pragma unroll
+  for (int k0 = 0; k0 < K; k0 += BATCH) {
+    f64x2 v[BATCH];
+#pragma unroll
+    for (int u = 0; u < BATCH; ++u) v[u] = NT ? __builtin_nontemporal_load(P.p[k0 + u] + i) : P.p[k0 + u][i];
+#pragma unroll
+    for (int u = 0; u < BATCH; ++u) { q[0] += 1.5 * v[u][0]; q[1] += 1.5 * v[u][1]; }
+    if (k0 == 0) { s0 = v[0]; s1 = v[1]; }
+  }
+  __builtin_nontemporal_store(s0, w1 + i);
+  __builtin_nontemporal_store(s1, w2 + i);
+  if (q[0] == 1.2345e300) out[0] = q[1];
+}
+
 // the library's streaming-map shape (stream_kernels.h: map_kernel): 2 reads + 1 write, UNROLL vectors per thread spaced by
 // the block size, one chunk per workgroup (blockIdx -> chunk), nontemporal loads and stores
 template <int UNROLL, bool NTL, bool NTS, int BLOCK>
@@ -176,6 +197,17 @@ int main() {
     printf("%2d read streams + 1 write stream, one vector per thread, batches of %2d, nt %d: %8.1f us  %.2f TB/s (%.3f)\n", K, BATCH, (int)NT, us, 16.0 * each * (K + 1) / us / 1e6, 16.0 * each * (K + 1) / us / 1e6 / 8.0); \
   }
   RKW(10, true, 10) RKW(20, true, 10) RKW(20, true, 20) RKW(20, true, 5) RKW(40, true, 8) RKW(40, true, 20) RKW(20, false, 10) RKW(2, true, 2) RKW(1, true, 1)
+
+#define RKW2(K, NT, BATCH)                                                                                                 \
+  {                                                                                                                        \
+    Ptrs P;                                                                                                                \
+    const int64_t each = (nvec / (K + 2)) & ~(int64_t)255;                                                                 \
+    for (int k = 0; k < K; ++k) P.p[k] = (const f64x2 *)buf + (int64_t)(k + 2) * each;                                     \
+    const int g = (int)(each / 256);                                                                                       \
+    const double us = time_us([&] { hipLaunchKernelGGL((readk_w2<K, NT, BATCH>), dim3(g), dim3(256), 0, 0, P, (f64x2 *)buf, (f64x2 *)buf + each, each, out); }, 10); \
+    printf("%2d read streams + 2 write streams (push! shape), one vector per thread, batches of %2d, nt %d: %8.1f us  %.2f TB/s (%.3f)\n", K, BATCH, (int)NT, us, 16.0 * each * (K + 2) / us / 1e6, 16.0 * each * (K + 2) / us / 1e6 / 8.0); \
+  }
+  RKW2(11, true, 11) RKW2(22, true, 11) RKW2(22, true, 22) RKW2(20, true, 10) RKW2(10, true, 10) RKW2(42, true, 14) RKW2(2, true, 2)
 
   {
     const int64_t ne = 100000000, nv = ne / 2;     // the headline's n = 1e8 doubles per operand: 3 x 800 MB inside the 2 GiB buffer? no: own buffers

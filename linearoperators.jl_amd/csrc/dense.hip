@@ -1664,8 +1664,12 @@ int32_t hermitian_block_t(mxlo_ctx *ctx, T *res, int64_t ldr, const T *d, const 
   return MXLO_OK;
 }
 
-// The premise of the XCD-local kron fusion, probed ONCE per ctx (one 64-workgroup launch + a 256-byte copy): workgroup id
-// of a 1-D grid runs on XCD id % 8 (tools/xcc_probe.hip: holds for every grid and block size tried on an MI355X in SPX mode).
+// The premise of the XCD-local kron fusion, probed ONCE per ctx (one 64-workgroup launch + a 256-byte copy): the workgroups
+// of a 1-D grid are dealt to the 8 XCDs round-robin, i.e. workgroups whose ids agree modulo 8 share an XCD (and its L2).
+// WHICH XCD workgroup 0 lands on varies — 0 in an otherwise idle process (tools/xcc_probe.hip), 5 inside bench.py, where
+// other queues had been active — so the check is the PERIOD, not the phase: XCC_ID(i) == XCC_ID(i % 8) and the first eight
+// are all different. (A launch that broke the period would not compute wrong results silently: producers and consumers of a
+// row block would sit behind different L2s, the consumers' bounded wait would time out and raise the ctx fault word.)
 __global__ void xcc_probe_kernel(unsigned *__restrict__ out) {
   if (threadIdx.x == 0) out[blockIdx.x] = gl_xcc_id();
 }
@@ -1678,8 +1682,16 @@ bool xcd_map_ok(mxlo_ctx *ctx) {
       if (hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, ctx->stream) == hipSuccess &&
           hipStreamSynchronize(ctx->stream) == hipSuccess) {
         bool ok = true;
-        for (int i = 0; i < 64; ++i) ok = ok && h[i] == (unsigned)(i & 7);
+        unsigned seen = 0;
+        for (int i = 0; i < 8; ++i) seen |= h[i] < 8 ? 1u << h[i] : 0u;
+        ok = seen == 0xffu;                                   // eight XCDs, each once among the first eight workgroups
+        for (int i = 0; i < 64; ++i) ok = ok && h[i] == h[i & 7];
         if (ok) ctx->xcd_map = 1;
+        if (getenv("MXLO_DEBUG_XCC")) {
+          fprintf(stderr, "[mxlo] xcc probe on stream %p:", (void *)ctx->stream);
+          for (int i = 0; i < 64; ++i) fprintf(stderr, " %u", h[i]);
+          fprintf(stderr, " -> %s\n", ok ? "period 8" : "NOT periodic");
+        }
       }
       (void)hipFree(d);
     }

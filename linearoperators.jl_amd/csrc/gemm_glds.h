@@ -429,9 +429,9 @@ gemm_glds_kernel(T *__restrict__ C, int64_t ldc, const T *__restrict__ A, int64_
 // i.e. a barrier between the two products, which as two launches costs the launch boundary (2.2 us for ANY dependent
 // kernel) plus a cold DMA ring per product, and as a device-wide barrier inside one launch costs as much (agent-scope
 // release fences walk the L2; the fence-free form is three trips through the memory-side fabric). Here the dependency
-// never leaves an XCD: row block r is produced AND consumed by workgroups of XCD r % 8 (workgroup id % 8 is the XCD a
-// workgroup is dispatched to; every workgroup CHECKS that against the hardware's XCC_ID register and raises the ctx fault
-// word if it does not hold). The producers' tiles sit in that XCD's L2, the counter that publishes them is an atomic
+// never leaves an XCD: row block r is produced AND consumed by the workgroups whose id is r modulo 8 — workgroups are dealt
+// to the XCDs round-robin, so these share ONE XCD (which one varies from launch to launch; the period is probed once per
+// ctx against the hardware's XCC_ID register: dense.hip xcd_map_ok). The producers' tiles sit in that XCD's L2, the counter that publishes them is an atomic
 // executed in that same L2 (workgroup-scope atomics: no sc1, no write-back, no invalidate), and the consumers read both
 // from there: no agent-scope fence, no trip to the memory side. The wait is bounded (ctx fault word, as every single-launch
 // form of the library); the grid must be co-resident (checked by the launch site).
@@ -462,9 +462,9 @@ kron_fused_kernel(T *__restrict__ R, int64_t ldr, const T *__restrict__ Bf, int6
   static_assert(TM == TN, "a row block of the first product is a column block of the second");
   __shared__ __attribute__((aligned(1024))) T lds[gl_lds_elems<T, TM, TN, BK, NST>()];
   const int tid = threadIdx.x;
+  // `xcd` is a LABEL: workgroups whose ids agree modulo 8 share a physical XCD (round-robin dispatch; the launch site has
+  // probed the period), whichever one that is for this launch
   const int xcd = (int)(blockIdx.x & 7u), local = (int)(blockIdx.x >> 3);
-  if (tid == 0 && gl_xcc_id() != (unsigned)xcd)      // the premise of everything below
-    __hip_atomic_store(F.fault, F.fault_code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   // row blocks of this XCD: r = xcd + 8 * t, t < nmine
   const int nmine = F.nrb > xcd ? (F.nrb - xcd + 7) / 8 : 0;
   // ---- phase 1: tile (r, ty) of Ut

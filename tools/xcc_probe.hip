@@ -1,5 +1,7 @@
 // tools/xcc_probe.hip — which XCD does workgroup `id` of a 1-D grid run on? Reads HW_REG_XCC_ID per workgroup and compares with id % 8
-// for several grid / block sizes (the premise of the XCD-banded tile order of gemm_glds.h and of the XCD-local kron fusion).
+// for several grid / block sizes (the premise of the XCD-banded tile order of gemm_glds.h and of the XCD-local kron fusion). In this otherwise
+// idle process workgroup 0 always lands on XCD 0; inside bench.py (other queues active before) the same probe starts at XCD 5: only the PERIOD
+// (ids equal modulo 8 share an XCD) can be relied on, and that is what the library checks (dense.hip: xcd_map_ok).
 // Build: hipcc -O3 --offload-arch=gfx950 -o tools/xcc_probe tools/xcc_probe.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>

@@ -1745,7 +1745,8 @@ int32_t kron_t(mxlo_ctx *ctx, T *res, const T *A, int64_t am, int64_t an, int64_
         }
         bool fits = true;
         const int32_t st = dispatch_ab<T>(beta, flags, [&]<typename CA, typename CB, bool B0>() -> int32_t {
-          GlFuse F{ctx->kron_cnt, (int)nrb, (int)gy1, (int)gx2, (int)per_xcd, ctx->tune.kron_fuse == 2 ? 0ull : fused_timeout_ticks(ctx), ctx->fault_dev, kFaultKron};
+          GlFuse F{ctx->kron_cnt, (int)nrb, (int)gy1, (int)gx2, (int)per_xcd, ctx->tune.kron_fuse == 2 ? 0ull : fused_timeout_ticks(ctx), ctx->fault_dev, kFaultKron,
+                   ctx->tune.fused_debug_drop};
 #define KFUSE(AK_, TM_, WM_, WN_, BK_, NST_, PAIR_, PFD_, UNR_)                                                                \
   {                                                                                                                        \
     GlShape S1{(int)m, (int)q, (int)n, (int)nrb, (int)gy1}, S2{(int)p, (int)m, (int)q, (int)gx2, (int)nrb};               \

@@ -447,6 +447,7 @@ struct GlFuse {
   unsigned long long ticks; // bounded wait (wall_clock64 ticks)
   unsigned *fault;          // ctx fault word (pinned host memory)
   unsigned fault_code;
+  int drop;                 // TEST HOOK (tune key fused_debug_drop): the producer with this workgroup id never signals
 };
 
 __device__ __forceinline__ unsigned gl_xcc_id() {
@@ -474,12 +475,14 @@ kron_fused_kernel(T *__restrict__ R, int64_t ldr, const T *__restrict__ Bf, int6
         lds, r, ty, Ut, ldu, Af, lda, X, ldx, S1, 1.0, 0.0);
     __builtin_amdgcn_s_waitcnt(0);                  // this wave's stores have reached the XCD's L2 ...
     __syncthreads();                                 // ... and so have every wave's
-    if (tid == 0) __hip_atomic_fetch_add(F.cnt + (size_t)r * kGlFuseStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // executed in that L2
+    if (tid == 0 && (int)blockIdx.x != F.drop)
+      __hip_atomic_fetch_add(F.cnt + (size_t)r * kGlFuseStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // executed in that L2
   }
   // ---- phase 2: tile (ti, r) of R
   if (local < nmine * F.gx2) {
     const int r = xcd + 8 * (local / F.gx2), ti = local % F.gx2;
     if (tid == 0) {                                  // (no second __shared__ object in this kernel: see gemm_glds_kernel)
+      lds[0] = T(0);                                 // "timed out" flag for the workgroup (the ring is idle here)
       unsigned long long t0 = 0;
       unsigned it = 0;
       // the poll must be an atomic EXECUTED IN L2 on every trip: an idempotent read-modify-write (fetch_add 0) is folded into
@@ -497,7 +500,8 @@ kron_fused_kernel(T *__restrict__ R, int64_t ldr, const T *__restrict__ Bf, int6
           if (t0 == 0) t0 = now;
           else if (now - t0 > F.ticks) {
             __hip_atomic_store(F.fault, F.fault_code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            break;                                   // reported through the fault word; this tile is garbage
+            lds[0] = T(1);
+            break;                                   // reported through the fault word; this tile is stored as NaN below
           }
         }
       }
@@ -508,6 +512,15 @@ kron_fused_kernel(T *__restrict__ R, int64_t ldr, const T *__restrict__ Bf, int6
       }
     }
     __syncthreads();
+    const bool timed_out = lds[0] != T(0);
+    __syncthreads();                                 // everybody has read the flag before the ring is filled
+    if (timed_out) {                                 // the row block never became complete: NaN, like every single-launch form
+      for (int idx = tid; idx < TM * TN; idx += WM * WN * 64) {
+        const int64_t gi = (int64_t)ti * TM + idx % TM, gj = (int64_t)r * TN + idx / TM;
+        if (gi < S2.M && gj < S2.N) R[gi + gj * ldr] = T(__builtin_nan(""));
+      }
+      return;
+    }
     gl_gemm_tile<T, CA, CB, BETA0, AK, TM, TN, WM, WN, BK, NST, true, true, PAIR, PFD, true, false, false, UNR>(
         lds, ti, r, R, ldr, Bf, ldb, Ut, ldu, S2, alpha, beta);
   }

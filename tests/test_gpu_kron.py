@@ -442,3 +442,49 @@ def test_kron_one_launch_form_is_bit_identical_to_the_two_launches(lo, dev, dtyp
         Kd = np.kron(A.astype(np.float64), B.astype(np.float64))
         assert rel(got[1][0].cpu().numpy(), Kd @ x.cpu().numpy().astype(np.float64)) <= tol
         assert rel(got[1][2].cpu().numpy(), Kd.T @ xt.cpu().numpy().astype(np.float64)) <= tol
+
+
+def test_one_launch_kron_timeout_is_an_error_not_a_hang(lo, dev):
+    """The consumers of the one-launch kron wait for the producers of their row block. If one never signals (not co-resident,
+    a dispatch that broke the XCD round-robin; here: the `fused_debug_drop` test hook), the wait must END — the affected tiles
+    stored as NaN, ctx fault word raised —, the next call must say so, and the ctx stays usable on the two-launch schedule,
+    its counters re-armed."""
+    import time
+    ctx = lo.get_ctx(dev)
+    rng = np.random.default_rng(23)
+    n = 256
+    A, B = rng.uniform(-1, 1, (n, n)), rng.uniform(-1, 1, (n, n))
+    K = lo.kron(colmajor(A, dev), colmajor(B, dev))
+    x = T(rng.uniform(-1, 1, n * n), dev)
+    res = torch.zeros(n * n, dtype=torch.float64, device=dev)
+    want = (B @ x.cpu().numpy().reshape(n, n, order="F") @ A.T).reshape(-1, order="F")
+    try:
+        ctx.tune("kron_fuse", 1)
+        lo.mul(res, K, x, 1.0, 0.0)
+        torch.cuda.synchronize()
+        assert rel(res.cpu().numpy(), want) <= 1e-12
+        ctx.tune("fused_timeout_ms", 30)
+        ctx.tune("fused_debug_drop", 3)
+        t0 = time.perf_counter()
+        lo.mul(res, K, x, 1.0, 0.0)                  # the launch succeeds; the consumers of workgroup 3's row block give up
+        torch.cuda.synchronize()
+        assert time.perf_counter() - t0 < 5.0
+        got = res.cpu().numpy()
+        assert np.isnan(got).any() and not np.isnan(got).all(), "the tiles behind the missing producer are NaN, the others are not"
+        ctx.tune("fused_debug_drop", -1)
+        with pytest.raises(Exception, match="timed out"):
+            lo.mul(res, K, x, 1.0, 0.0)              # reported (and repaired) at the next apply
+        lo.mul(res, K, x, 1.0, 0.0)                  # the one-launch form is off now: two launches
+        torch.cuda.synchronize()
+        assert rel(res.cpu().numpy(), want) <= 1e-12
+        ctx.tune("kron_fuse", 1)                     # counters were re-armed: the one launch works again, repeatedly
+        for _ in range(4):
+            res.zero_()
+            lo.mul(res, K, x, 1.0, 0.0)
+        torch.cuda.synchronize()
+        assert rel(res.cpu().numpy(), want) <= 1e-12
+    finally:
+        ctx.tune("fused_debug_drop", -1)
+        ctx.tune("fused_timeout_ms", 2000)
+        for key in ("kron_fuse", "house_fused", "qn_fused_small", "qn_persist", "herm_single"):
+            ctx.tune(key, 1)

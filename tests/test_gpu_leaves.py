@@ -716,6 +716,7 @@ def test_single_launch_householder_timeout_is_an_error_not_a_hang(lo, dev):
         ctx.tune("qn_fused_small", 1)
         ctx.tune("qn_persist", 1)
         ctx.tune("herm_single", 1)
+        ctx.tune("kron_fuse", 1)
 
 
 def test_graph_replay_on_its_capture_stream_is_ordered_with_the_ctx_stream(lo, dev):

@@ -146,6 +146,7 @@ def test_hermitian_block_apply_is_bit_identical_to_the_column_loop(lo, dev, n, d
             assert rel(res.cpu().numpy(), want) <= tol, (n, k)
     finally:
         ctx.tune("herm_single", 1)
+        ctx.tune("kron_fuse", 1)
     with pytest.raises(lo.LinearOperatorException):
         lo.mul(torch.empty(n, 2, dtype=dtype, device=dev), H, torch.empty(n, 3, dtype=dtype, device=dev), 1.0, 0.0)
 
@@ -218,6 +219,7 @@ def test_hermitian_single_launch_is_bit_identical_to_the_two_launch_form(lo, dev
                 got.setdefault(single, []).append(res.cpu().numpy())
             finally:
                 ctx.tune("herm_single", 1)
+                ctx.tune("kron_fuse", 1)
         assert np.array_equal(got[1][0], got[0][0]) and np.array_equal(got[1][0], got[1][1]), (dtype, n)
         fl = oracle.SCALARS_F64 if dtype == torch.float32 else 0
         want = oracle.hermitian_mul(r0.copy(), d, np.tril(A, -1), v, 3.0, -4.0, flags=fl)

@@ -986,8 +986,8 @@ def test_single_launch_apply_timeout_is_an_error_not_a_hang(lo, dev, kind):
     finally:
         ctx.tune("fused_debug_drop", -1)
         ctx.tune("fused_timeout_ms", 2000)
-        ctx.tune("house_fused", 1)
-        ctx.tune("qn_fused_small", 1)
+        for key in ("house_fused", "qn_fused_small", "qn_persist", "herm_single", "kron_fuse"):   # a fault switches them all off
+            ctx.tune(key, 1)
 
 
 # ------------------------------------------------------------------------------- the persistent single-launch apply
@@ -1099,6 +1099,7 @@ def test_persistent_apply_timeout_is_an_error_not_a_hang(lo, dev):
         ctx.tune("qn_fused_small", 1)
         ctx.tune("qn_persist", 1)
         ctx.tune("herm_single", 1)
+        ctx.tune("kron_fuse", 1)
 
 
 @pytest.mark.parametrize("kind", ["inv", "fwd", "lsr1"])

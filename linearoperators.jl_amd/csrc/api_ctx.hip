@@ -458,6 +458,15 @@ MXLO_API int32_t mxlo_ctx_tune(mxlo_ctx *ctx, const char *key, int64_t value) {
   } else if (!strcmp(key, "herm_order")) {
     MXLO_REQUIRE(value == 0 || value == 1, MXLO_EINVAL, "herm_order must be 0 or 1");
     ctx->tune.herm_order = (int)value;
+  } else if (!strcmp(key, "herm_nt")) {
+    MXLO_REQUIRE(value >= -1 && value <= 1, MXLO_EINVAL, "herm_nt must be -1 (by size), 0 or 1");
+    ctx->tune.herm_nt = (int)value;
+  } else if (!strcmp(key, "herm_dp_min_bytes")) {
+    MXLO_REQUIRE(value >= 0, MXLO_EINVAL, "herm_dp_min_bytes must be >= 0");
+    ctx->tune.herm_dp_min_bytes = value;
+  } else if (!strcmp(key, "herm_nt_min_bytes")) {
+    MXLO_REQUIRE(value >= 0, MXLO_EINVAL, "herm_nt_min_bytes must be >= 0");
+    ctx->tune.herm_nt_min_bytes = value;
   } else if (!strcmp(key, "herm_lds_pad")) {
     MXLO_REQUIRE(value >= 0 && value <= 48 * 1024, MXLO_EINVAL, "herm_lds_pad must be in 0..49152 bytes");
     ctx->tune.herm_lds_pad = (int)value;

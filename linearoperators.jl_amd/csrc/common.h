@@ -153,6 +153,10 @@ struct Tune {
   int64_t qn_persist_min_bytes = 32ll << 20;     // ... and at least this many (an L-SR1 m = 5 apply at n = 2^19 — 21 MB — is
                                                  // faster in the single-launch slice form: 10.7 vs 12.1 us)
   int herm_order = 1;      // opHermitian interior strips: 0 = row group by row group, 1 (default, round 6) = column block by column block (dense.hip)
+  int herm_nt = -1;        // opHermitian strip loads: -1 = nontemporal except for triangles of [herm_dp_min_bytes, herm_nt_min_bytes)
+                           // (about the size of the Infinity Cache; round 6, dense.hip: herm_nt_policy), 0 / 1 force
+  int64_t herm_dp_min_bytes = 96ll << 20;
+  int64_t herm_nt_min_bytes = 384ll << 20;
   int herm_lds_pad = 0;    // opHermitian pass launch: bytes of unused dynamic LDS per workgroup (occupancy experiment, <= 48 KiB)
   int herm_single = 1;     // opHermitian (full row groups, aligned A, n <= herm_single_max_n): strips and finishers in ONE launch
   int64_t herm_single_max_n = 2048;   // measured (profiles/r05_herm_small.txt): 8.9 -> 6.4 us at n = 1024, 9.6 -> 6.9 at 2048 (f64; f32

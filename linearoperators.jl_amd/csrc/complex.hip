@@ -662,7 +662,7 @@ struct CHermCfg {
 // last row group; mode 2 (CT = 1): one tile of a diagonal block per workgroup.
 // DSEL (EDGE = false, CT = 1): a tile of the diagonal block of a FULL row group of an aligned matrix — unmasked loads,
 // then a select zeroes what is at or above the diagonal (dense.hip: herm_strip_body).
-template <typename R, int CT, bool EDGE, bool DSEL = false>
+template <typename R, int CT, bool EDGE, bool DSEL = false, bool NT = true>
 __device__ __forceinline__ void
 cherm_strip_body(const C<R> *__restrict__ A, int64_t lda, const C<R> *__restrict__ v, int64_t n,
                  double *__restrict__ Prow, double *__restrict__ Pcol, int64_t ng, int qint, int mode, int64_t t,
@@ -726,7 +726,8 @@ cherm_strip_body(const C<R> *__restrict__ A, int64_t lda, const C<R> *__restrict
       const C<R> *base = A + (j0 + cg) * lda + gr;
 #pragma unroll
       for (int k = 0; k < 16; ++k)
-        e[k] = __builtin_nontemporal_load(reinterpret_cast<const V *>(base + (int64_t)(2 * k) * lda));
+        e[k] = NT ? __builtin_nontemporal_load(reinterpret_cast<const V *>(base + (int64_t)(2 * k) * lda))   // (NT: dense.hip,
+                  : *reinterpret_cast<const V *>(base + (int64_t)(2 * k) * lda);                                //  herm_nt_policy)
       if constexpr (DSEL) {
         const int below = (int)(gr - (j0 + cg));      // row - column of this lane's element of column k = 0
 #pragma unroll
@@ -836,14 +837,14 @@ cherm_strip_body(const C<R> *__restrict__ A, int64_t lda, const C<R> *__restrict
 
 // ONE launch for everything that can use unmasked 16-byte loads (aligned A): the interior strips of the full row
 // groups, then the tiles of their diagonal blocks (DSEL) — both at the unmasked path's register footprint.
-template <typename R, int CT>
+template <typename R, int CT, bool NT>
 __global__ void __launch_bounds__(kBlock)
 cherm_pass_kernel(const C<R> *__restrict__ A, int64_t lda, const C<R> *__restrict__ v, int64_t n,
                   double *__restrict__ Prow, double *__restrict__ Pcol, int64_t ng, int qint, int64_t n_int, int colmajor_g) {
   __shared__ double rowred[2][CHermCfg<R>::HR][2];
   const int64_t t = blockIdx.x;
-  if (t < n_int) return cherm_strip_body<R, CT, false>(A, lda, v, n, Prow, Pcol, ng, qint, 0, t, rowred, colmajor_g);
-  cherm_strip_body<R, 1, false, true>(A, lda, v, n, Prow, Pcol, ng, qint, 2, t - n_int, rowred);
+  if (t < n_int) return cherm_strip_body<R, CT, false, false, NT>(A, lda, v, n, Prow, Pcol, ng, qint, 0, t, rowred, colmajor_g);
+  cherm_strip_body<R, 1, false, true, NT>(A, lda, v, n, Prow, Pcol, ng, qint, 2, t - n_int, rowred);
 }
 
 // The masked remainder, one launch: every strip when A is not 16-byte aligned (mode 0), the strips of the ragged last
@@ -957,11 +958,19 @@ int32_t chermitian(mxlo_ctx *ctx, C<R> *res, const void *d, bool d_real, const C
   const int64_t n_diag = (int64_t)DT * (ng - gi);                              // mode 2, row groups gi .. ng-1
   const int64_t n_light = n_int + n_dsel, n_edge = n_all + n_last + n_diag;
   MXLO_REQUIRE(n_light < (1LL << 31) && n_edge < (1LL << 31), MXLO_ESHAPE, "complex opHermitian: n too large");
+  // strip loads: nontemporal except for triangles of about the size of the Infinity Cache (the rule of dense.hip: herm_nt_policy)
+  const int64_t tri = (int64_t)sizeof(C<R>) * n * (n / 2);
+  const bool nt = ctx->tune.herm_nt >= 0 ? ctx->tune.herm_nt != 0
+                                         : !(tri >= ctx->tune.herm_dp_min_bytes && tri < ctx->tune.herm_nt_min_bytes);
 #define CHERM_LAUNCH(CT_)                                                                                        \
   {                                                                                                              \
     if (n_light > 0) {                                                                                           \
-      hipLaunchKernelGGL((cherm_pass_kernel<R, CT_>), dim3((unsigned)n_light), dim3(kBlock), 0, ctx->stream, A, lda, \
-                         v, n, Prow, Pcol, ng, Q, n_int, ctx->tune.herm_order ? (int)gi : 0);                    \
+      if (nt)                                                                                                    \
+        hipLaunchKernelGGL((cherm_pass_kernel<R, CT_, true>), dim3((unsigned)n_light), dim3(kBlock), 0, ctx->stream, A, lda, \
+                           v, n, Prow, Pcol, ng, Q, n_int, ctx->tune.herm_order ? (int)gi : 0);                  \
+      else                                                                                                       \
+        hipLaunchKernelGGL((cherm_pass_kernel<R, CT_, false>), dim3((unsigned)n_light), dim3(kBlock), 0, ctx->stream, A, lda, \
+                           v, n, Prow, Pcol, ng, Q, n_int, ctx->tune.herm_order ? (int)gi : 0);                  \
       MXLO_LAUNCH_CHECK();                                                                                       \
     }                                                                                                            \
     if (n_edge > 0) {                                                                                            \

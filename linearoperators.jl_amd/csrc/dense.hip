@@ -1147,7 +1147,7 @@ __device__ __forceinline__ void herm_put(double *p, double v, bool slot) {
 // KV > 1 (round 5, the block apply mxlo_hermitian_mul_block): the tile is loaded ONCE and applied to KV vectors — vector kk
 // is v + kk * ldv, its partials live KV buffers apart (pstride doubles). Per vector the arithmetic, the butterfly and the
 // order of every addition are those of KV = 1: a block apply is bit-identical to KV single applies.
-template <typename T, int C, bool EDGE, bool DSEL = false, bool SLOT = false, int KV = 1>
+template <typename T, int C, bool EDGE, bool DSEL = false, bool SLOT = false, int KV = 1, bool NT = true>
 __device__ __forceinline__ void
 herm_strip_body(const T *__restrict__ A, int64_t lda, const T *__restrict__ v, int64_t n,
                 double *__restrict__ Prow, double *__restrict__ Pcol, int64_t ng, int qint, int mode, int64_t t,
@@ -1206,23 +1206,38 @@ herm_strip_body(const T *__restrict__ A, int64_t lda, const T *__restrict__ v, i
       vr[kk][r] = (!EDGE || gr + r < n) ? (double)v[gr + r + kk * ldv] : 0.0;
       prow[kk][r] = 0.0;
     }
-#pragma unroll 1
-  for (int jt = 0; jt < HS; ++jt) {
-    const int64_t j0 = (tile0 + jt) * HC;
-    if (EDGE && j0 >= n) break;              // ragged last row group: tiles past the matrix
-    VR e[16];
+  // One tile = load_tile (16 loads of 16 bytes per lane) + compute_tile (FMAs, column butterfly, column-partial stores).
+  auto load_tile = [&](VR (&e)[16], const int64_t j0) __attribute__((always_inline)) {
     if constexpr (!EDGE) {                   // every element is strictly below the diagonal and inside
       const T *base = A + (j0 + cg) * lda + gr;
-#pragma unroll
-      for (int k = 0; k < 16; ++k)
-        e[k] = __builtin_nontemporal_load(reinterpret_cast<const VR *>(base + (int64_t)(2 * k) * lda));
+      // NT: a triangle of about the size of the Infinity Cache is loaded with the default policy — the next apply of the same
+      // operator (a Krylov loop) finds part of it there —, a larger one with the nontemporal hint (as the dense GEMVs). A
+      // template parameter: under a run-time flag the compiler merges the two load sequences and drops the hint from both.
       if constexpr (DSEL) {
+        // A wave whose 64*RPL rows all lie at or above the tile's first column requests nothing (wave-uniform test; a per-lane
+        // test costs 16 exec-mask branches in front of the loads of the tiles that end the launch, and measured slower).
         const int below = (int)(gr - (j0 + cg));      // row - column of this lane's element of column k = 0
+        const bool wave_above = i0 + (int64_t)(half + 1) * (HR / 2) <= j0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) e[k] = VR(T(0));
+        if (!wave_above) {
+#pragma unroll
+          for (int k = 0; k < 16; ++k)
+            e[k] = NT ? __builtin_nontemporal_load(reinterpret_cast<const VR *>(base + (int64_t)(2 * k) * lda))
+                      : *reinterpret_cast<const VR *>(base + (int64_t)(2 * k) * lda);
+        }
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
 #pragma unroll
           for (int r = 0; r < RPL; ++r) e[k][r] = below + r > 2 * k ? e[k][r] : T(0);   // strict lower triangle only
         }
+      } else if constexpr (NT) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k)
+          e[k] = __builtin_nontemporal_load(reinterpret_cast<const VR *>(base + (int64_t)(2 * k) * lda));
+      } else {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) e[k] = *reinterpret_cast<const VR *>(base + (int64_t)(2 * k) * lda);
       }
     } else {
 #pragma unroll
@@ -1236,6 +1251,8 @@ herm_strip_body(const T *__restrict__ A, int64_t lda, const T *__restrict__ v, i
         }
       }
     }
+  };
+  auto compute_tile = [&](const VR (&e)[16], const int64_t j0) __attribute__((always_inline)) {
     // column partials of this tile: block of column group Gc = j0/HR, row half 2G + half (offset so that + gc indexes it)
     const int64_t Gc = j0 / HR;
     const int64_t pcol0 = herm_col_base<HR>(Gc, ng) + (2 * G + half - 2 * Gc) * HR - Gc * HR;
@@ -1277,6 +1294,17 @@ herm_strip_body(const T *__restrict__ A, int64_t lda, const T *__restrict__ v, i
       if (!EDGE || gc < n) herm_put(Pck + pcol0 + gc, w1, SLOT);
     }
    }
+  };
+  // (Round 6, negative: two register sets — the loads of tile jt + 1 issued before tile jt is consumed — change nothing for the
+  //  single apply and cost the KV = 4 block form its registers, 195 -> 317 us at n = 16384: profiles/r06_herm_policy.txt. The
+  //  strips are not latency-bound; occupancy 5 -> 2 workgroups per CU had shown the same.)
+#pragma unroll 1
+  for (int jt = 0; jt < HS; ++jt) {
+    const int64_t j0 = (tile0 + jt) * HC;
+    if (EDGE && j0 >= n) break;              // ragged last row group: tiles past the matrix
+    VR e[16];
+    load_tile(e, j0);
+    compute_tile(e, j0);
   }
   __shared__ double rowred[KV][2][HR];
 #pragma unroll
@@ -1296,13 +1324,13 @@ herm_strip_body(const T *__restrict__ A, int64_t lda, const T *__restrict__ v, i
 // strips of the full row groups, the rest the tiles of their diagonal blocks (DSEL). Both bodies fit the unmasked
 // path's registers, so at n = 4096 all 1088 workgroups are resident at once (the round-2 merged kernel also carried
 // the masked bodies — 195 VGPRs, half the occupancy — and took 14.8 us of the 20.6 us apply).
-template <typename T, int C>
+template <typename T, int C, bool NT>
 __global__ void __launch_bounds__(kBlock)
 herm_pass_kernel(const T *__restrict__ A, int64_t lda, const T *__restrict__ v, int64_t n,
                  double *__restrict__ Prow, double *__restrict__ Pcol, int64_t ng, int qint, int64_t n_int, int colmajor_g) {
   const int64_t t = blockIdx.x;
-  if (t < n_int) return herm_strip_body<T, C, false>(A, lda, v, n, Prow, Pcol, ng, qint, 0, t, 0, 0, colmajor_g);
-  herm_strip_body<T, 1, false, true>(A, lda, v, n, Prow, Pcol, ng, qint, 2, t - n_int);
+  if (t < n_int) return herm_strip_body<T, C, false, false, false, 1, NT>(A, lda, v, n, Prow, Pcol, ng, qint, 0, t, 0, 0, colmajor_g);
+  herm_strip_body<T, 1, false, true, false, 1, NT>(A, lda, v, n, Prow, Pcol, ng, qint, 2, t - n_int);
 }
 
 // The masked remainder, one launch: every strip when A is not 16-byte aligned (n_all, mode 0), the strips of the
@@ -1321,14 +1349,14 @@ herm_edge_kernel(const T *__restrict__ A, int64_t lda, const T *__restrict__ v, 
 }
 
 // The same two launches for a BLOCK of KV vectors (mxlo_hermitian_mul_block): every tile of the triangle is read once.
-template <typename T, int C, int KV>
+template <typename T, int C, int KV, bool NT>
 __global__ void __launch_bounds__(kBlock)
 herm_pass_block_kernel(const T *__restrict__ A, int64_t lda, const T *__restrict__ v, int64_t ldv, int64_t n,
                        double *__restrict__ Prow, double *__restrict__ Pcol, int64_t pstride, int64_t ng, int qint, int64_t n_int,
                        int colmajor_g) {
   const int64_t t = blockIdx.x;
-  if (t < n_int) return herm_strip_body<T, C, false, false, false, KV>(A, lda, v, n, Prow, Pcol, ng, qint, 0, t, ldv, pstride, colmajor_g);
-  herm_strip_body<T, 1, false, true, false, KV>(A, lda, v, n, Prow, Pcol, ng, qint, 2, t - n_int, ldv, pstride);
+  if (t < n_int) return herm_strip_body<T, C, false, false, false, KV, NT>(A, lda, v, n, Prow, Pcol, ng, qint, 0, t, ldv, pstride, colmajor_g);
+  herm_strip_body<T, 1, false, true, false, KV, NT>(A, lda, v, n, Prow, Pcol, ng, qint, 2, t - n_int, ldv, pstride);
 }
 template <typename T, int C, int KV>
 __global__ void __launch_bounds__(kBlock)
@@ -1410,7 +1438,35 @@ herm_finish_body(T *__restrict__ res, const T *__restrict__ d, const T *__restri
     const int c1 = q * G + DT;                 // L*v : q*G strips + DT diagonal tiles
     double *prow = Prow + herm_row_base<HR, DT>(G, q) + (i - (int64_t)G * HR);
     double *pcol = Pcol + herm_col_base<HR>(G, ng) + (i - (int64_t)G * HR);
-    for (int base = sub; base < c1; base += FS * 8) {
+    // Round 6: the FIRST batch of row partials (16 per lane) and of column partials (8 per lane) are requested together, before
+    // anything is added — at n = 4096 that is every partial of the row, one memory round trip instead of three dependent ones
+    // (the partials come from the other XCDs' strips: each batch is a miss to the Infinity Cache). The order of the additions
+    // (slots sub, sub + FS, ... ascending; + 0.0 for absent ones, which cannot change a sum that started at + 0.0) is unchanged.
+    // The single-launch form (POLL) keeps batches of 8 / 4 under their conditions: its loads are agent-scope atomics to
+    // memory, and the 14 duplicate ones of the clamped form cost 0.5 us at n = 2048.
+    constexpr int RB = POLL ? 8 : 16, CBN = POLL ? 4 : 8;
+    const int h1 = 2 * ng;                     // L'*v: 128-row halves at/below i
+    double xr[RB], xc[CBN];
+    // (unconditional loads from clamped slots: under a condition the compiler folds `0.0 + first partial` into the load's
+    //  branch and waits for it there — one more round trip per sum)
+#pragma unroll
+    for (int u = 0; u < RB; ++u) {
+      const int sx = sub + FS * u;
+      if constexpr (POLL) xr[u] = sx < c1 ? take(prow + (int64_t)sx * HR) : 0.0;
+      else xr[u] = take(prow + (int64_t)(sx < c1 ? sx : c1 - 1) * HR);
+    }
+#pragma unroll
+    for (int u = 0; u < CBN; ++u) {
+      const int h = 2 * G + sub + FS * u;
+      if constexpr (POLL) xc[u] = h < h1 ? take(pcol + (int64_t)(h - 2 * G) * HR) : 0.0;
+      else xc[u] = take(pcol + (int64_t)((h < h1 ? h : h1 - 1) - 2 * G) * HR);
+    }
+#pragma unroll
+    for (int u = 0; u < RB; ++u) {
+      const int sx = sub + FS * u;
+      t1 += sx < c1 ? settle(prow + (int64_t)sx * HR, xr[u]) : 0.0;
+    }
+    for (int base = sub + FS * RB; base < c1; base += FS * 8) {
       double x[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
@@ -1423,8 +1479,12 @@ herm_finish_body(T *__restrict__ res, const T *__restrict__ d, const T *__restri
         t1 += sx < c1 ? settle(prow + (int64_t)sx * HR, x[u]) : 0.0;
       }
     }
-    const int h1 = 2 * ng;                     // L'*v: 128-row halves at/below i
-    for (int base = 2 * G + sub; base < h1; base += FS * 4) {
+#pragma unroll
+    for (int u = 0; u < CBN; ++u) {
+      const int h = 2 * G + sub + FS * u;
+      t2 += h < h1 ? settle(pcol + (int64_t)(h - 2 * G) * HR, xc[u]) : 0.0;
+    }
+    for (int base = 2 * G + sub + FS * CBN; base < h1; base += FS * 4) {
       double x[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
@@ -1481,15 +1541,27 @@ template <typename T, int C, typename CA, typename CB, bool BETA0, int FR>
 __global__ void __launch_bounds__(kBlock)
 herm_single_kernel(T *__restrict__ res, const T *__restrict__ d, const T *__restrict__ A, int64_t lda, const T *__restrict__ v,
                    int64_t n, double *__restrict__ Prow, double *__restrict__ Pcol, int64_t ng, int qint, int64_t n_int,
-                   int64_t n_light, CA alpha, CB beta, unsigned long long ticks, unsigned *__restrict__ fault) {
+                   int64_t n_light, CA alpha, CB beta, unsigned long long ticks, unsigned *__restrict__ fault, int colmajor_g) {
   const int64_t t = blockIdx.x;
-  if (t < n_int) return herm_strip_body<T, C, false, false, true>(A, lda, v, n, Prow, Pcol, ng, qint, 0, t);
+  if (t < n_int) return herm_strip_body<T, C, false, false, true>(A, lda, v, n, Prow, Pcol, ng, qint, 0, t, 0, 0, colmajor_g);
   if (t < n_light) return herm_strip_body<T, 1, false, true, true>(A, lda, v, n, Prow, Pcol, ng, qint, 2, t - n_int);
   herm_finish_body<T, CA, CB, BETA0, FR, true>(res, d, v, Prow, Pcol, n, (int)ng, qint, alpha, beta, t - n_light, ticks, fault);
 }
 
 __global__ void __launch_bounds__(kBlock) herm_slots_fill_kernel(unsigned long long *__restrict__ p, int64_t count) {
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < count; i += (int64_t)gridDim.x * kBlock) p[i] = kSlotEmpty;
+}
+
+// Cache policy of the strip loads (tune key herm_nt: -1 = this rule, 0 / 1 force): nontemporal, EXCEPT for triangles of about
+// the size of the 256 MiB Infinity Cache — [herm_dp_min_bytes, herm_nt_min_bytes) = [96, 384) MiB — where the next apply of
+// the same operator (a Krylov loop) finds part of a default-policy stream still there. Measured, old vs new library in one
+// run (profiles/r06_herm_policy.txt): f64 n = 6144 29.8 -> 28.2 us, 8192 49.9 -> 47.3; 4096 / 5120 neutral; below (3072) the
+// default policy is 10 % SLOWER, above (16384) 9 % slower.
+template <typename T>
+inline int herm_nt_policy(const mxlo_ctx *ctx, int64_t n) {
+  if (ctx->tune.herm_nt >= 0) return ctx->tune.herm_nt;
+  const int64_t tri = (int64_t)sizeof(T) * n * (n / 2);
+  return tri >= ctx->tune.herm_dp_min_bytes && tri < ctx->tune.herm_nt_min_bytes ? 0 : 1;
 }
 
 template <typename T>
@@ -1505,6 +1577,7 @@ int32_t hermitian_t(mxlo_ctx *ctx, T *res, const T *d, const T *A, int64_t lda, 
   const int64_t prow_len = herm_row_base<HR, DT>(ng, Q), pcol_len = herm_col_base<HR>(ng, ng);
   const size_t need = sizeof(double) * (size_t)(prow_len + pcol_len);
   const bool aligned = (((uintptr_t)A & 15u) == 0) && (lda % RPL == 0);
+  const int nt = herm_nt_policy<T>(ctx, n);
   // ---- the whole apply in ONE launch: full row groups of an aligned matrix, slots in their own (always re-armed) buffer
   if (ctx->tune.herm_single && aligned && n % HR == 0 && n <= ctx->tune.herm_single_max_n && ctx->fault_dev && !ctx->capturing) {
     int32_t fst = fused_fault_check(ctx);
@@ -1540,7 +1613,8 @@ int32_t hermitian_t(mxlo_ctx *ctx, T *res, const T *d, const T *A, int64_t lda, 
           // (no co-residency requirement: the strip workgroups wait for nobody, and the finishers — the last workgroups of the
           //  1-D grid — are dispatched after all of them)
           hipLaunchKernelGGL((herm_single_kernel<T, C_, CA, CB, B0, FR1>), dim3((unsigned)grid1), dim3(kBlock), 0, ctx->stream, res, d, A,
-                             lda, v, n, Sr, Sc, ng, Q, n_int1, n_light1, (CA)alpha, (CB)beta, fused_timeout_ticks(ctx), ctx->fault_dev);
+                             lda, v, n, Sr, Sc, ng, Q, n_int1, n_light1, (CA)alpha, (CB)beta, fused_timeout_ticks(ctx), ctx->fault_dev,
+                             ctx->tune.herm_order && n > 2048 ? (int)ngf : 0);
           MXLO_LAUNCH_CHECK();
           return MXLO_OK;
         };
@@ -1575,8 +1649,12 @@ int32_t hermitian_t(mxlo_ctx *ctx, T *res, const T *d, const T *A, int64_t lda, 
 #define HERM_LAUNCH(C_)                                                                                          \
   {                                                                                                              \
     if (n_light > 0) {                                                                                           \
-      hipLaunchKernelGGL((herm_pass_kernel<T, C_>), dim3((unsigned)n_light), dim3(kBlock), (size_t)ctx->tune.herm_lds_pad, ctx->stream, A, lda, v, \
-                         n, Prow, Pcol, ng, Q, n_int, ctx->tune.herm_order ? (int)gi : 0);                       \
+      if (nt)                                                                                                    \
+        hipLaunchKernelGGL((herm_pass_kernel<T, C_, true>), dim3((unsigned)n_light), dim3(kBlock), (size_t)ctx->tune.herm_lds_pad, ctx->stream, A, lda, v, \
+                           n, Prow, Pcol, ng, Q, n_int, ctx->tune.herm_order ? (int)gi : 0);                     \
+      else                                                                                                       \
+        hipLaunchKernelGGL((herm_pass_kernel<T, C_, false>), dim3((unsigned)n_light), dim3(kBlock), (size_t)ctx->tune.herm_lds_pad, ctx->stream, A, lda, v, \
+                           n, Prow, Pcol, ng, Q, n_int, ctx->tune.herm_order ? (int)gi : 0);                     \
       MXLO_LAUNCH_CHECK();                                                                                       \
     }                                                                                                            \
     if (n_edge > 0) {                                                                                            \
@@ -1614,6 +1692,7 @@ int32_t hermitian_block_t(mxlo_ctx *ctx, T *res, int64_t ldr, const T *d, const 
   MXLO_TRY(ensure_scratch(ctx, sizeof(double) * (size_t)pstride * KVMAX, "opHermitian block"));
   double *Prow = (double *)ctx->scratch, *Pcol = Prow + prow_len;
   const bool aligned = (((uintptr_t)A & 15u) == 0) && (lda % RPL == 0);
+  const int nt = herm_nt_policy<T>(ctx, n);
   const int64_t gi = aligned ? ngf : 0;
   const int64_t n_int = gi > 1 ? Q * gi * (gi - 1) / 2 : 0;
   const int64_t n_dsel = (int64_t)DT * gi;
@@ -1637,8 +1716,12 @@ int32_t hermitian_block_t(mxlo_ctx *ctx, T *res, int64_t ldr, const T *d, const 
     }
     auto launch = [&]<int C_, int KV_>() -> int32_t {
       if (n_light > 0) {
-        hipLaunchKernelGGL((herm_pass_block_kernel<T, C_, KV_>), dim3((unsigned)n_light), dim3(kBlock), (size_t)ctx->tune.herm_lds_pad, ctx->stream, A, lda, v, ldv, n,
-                           Prow, Pcol, pstride, ng, Q, n_int, ctx->tune.herm_order ? (int)gi : 0);
+        if (nt)
+          hipLaunchKernelGGL((herm_pass_block_kernel<T, C_, KV_, true>), dim3((unsigned)n_light), dim3(kBlock), (size_t)ctx->tune.herm_lds_pad, ctx->stream, A, lda, v, ldv, n,
+                             Prow, Pcol, pstride, ng, Q, n_int, ctx->tune.herm_order ? (int)gi : 0);
+        else
+          hipLaunchKernelGGL((herm_pass_block_kernel<T, C_, KV_, false>), dim3((unsigned)n_light), dim3(kBlock), (size_t)ctx->tune.herm_lds_pad, ctx->stream, A, lda, v, ldv, n,
+                             Prow, Pcol, pstride, ng, Q, n_int, ctx->tune.herm_order ? (int)gi : 0);
         MXLO_LAUNCH_CHECK();
       }
       if (n_edge > 0) {

@@ -30,6 +30,8 @@ __device__ __forceinline__ void stg(V *p, V v) {
   else *p = v;
 }
 
+// (Round 6, negative: write-through `sc1` stores for the one write stream of the many-column combine passes — +3 ... 6 % in a
+//  bare harness, tools/tune_store.hip — change nothing in combine_kernel: profiles/r06_tune_store.txt.)
 template <typename T, int VEC>
 struct VecOf {
   using type = T;

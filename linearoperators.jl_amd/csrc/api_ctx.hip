@@ -449,6 +449,9 @@ MXLO_API int32_t mxlo_ctx_tune(mxlo_ctx *ctx, const char *key, int64_t value) {
   } else if (!strcmp(key, "qn_persist_prefetch")) {
     MXLO_REQUIRE(value == 0 || value == 1, MXLO_EINVAL, "qn_persist_prefetch must be 0 or 1");
     ctx->tune.qn_persist_prefetch = (int)value;
+  } else if (!strcmp(key, "qn_persist_lds")) {
+    MXLO_REQUIRE(value == 0 || value == 1, MXLO_EINVAL, "qn_persist_lds must be 0 or 1");
+    ctx->tune.qn_persist_lds = (int)value;
   } else if (!strcmp(key, "qn_persist_lds_pad")) {
     MXLO_REQUIRE(value >= 0 && value <= 112 * 1024, MXLO_EINVAL, "qn_persist_lds_pad must be in 0..114688 bytes");
     ctx->tune.qn_persist_lds_pad = (int)value;

@@ -149,6 +149,7 @@ struct Tune {
   int qn_persist_prefetch = 0;  // ... x and the first column batch of its first combine chunk are requested before the exchange.
                                 // Measured (profiles/r05_bench_mid_apply.txt, last block): 1.5 us SLOWER at n = 2^19 .. 2^20 (the polls of
                                 // the exchange return in order behind the 11 prefetch loads), neutral above — off
+  int qn_persist_lds = 1;       // ... x and the first columns of the combine order parked in the CU's LDS by the dots phase (round 6)
   int qn_persist_lds_pad = 0;   // ... bytes of (unused) dynamic LDS requested per workgroup: > 80 KiB forces one workgroup per CU
   int64_t qn_persist_min_bytes = 32ll << 20;     // ... and at least this many (an L-SR1 m = 5 apply at n = 2^19 — 21 MB — is
                                                  // faster in the single-launch slice form: 10.7 vs 12.1 us)

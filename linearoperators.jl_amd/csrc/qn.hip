@@ -1001,14 +1001,25 @@ bool try_fused_apply(mxlo_qn *h, T *res, const T *const *cols, const T *x, QnfAr
 // the four-launch schedule's, so the two agree to rounding, not to the bit (both are deterministic run to run).
 constexpr int kPersistBlock = 512;   // 8 waves per CU, one workgroup per CU
 constexpr int kPersistNB = 10;       // columns per batch (10 independent 16-byte loads per lane in flight)
+constexpr int kPersistTileBytes = kPersistBlock * 16, kPersistLdsTiles = 18;   // LDS keep: 18 tiles of 8 KiB next to ~13 KiB of static LDS
 
 template <typename T, typename CA, typename CB, int KIND, bool BETA0>
 __global__ void __launch_bounds__(kPersistBlock)
 qn_apply_persist_kernel(T *__restrict__ res, QnfCols<T> cols, const T *__restrict__ x, int64_t n, int cpw,
                         unsigned long long *__restrict__ slots, QnfArgs F, OrdArgs O, unsigned long long ticks,
-                        unsigned *__restrict__ fault, int drop, int reverse, int prefetch) {
+                        unsigned *__restrict__ fault, int drop, int reverse, int prefetch, int lds_k) {
   constexpr int VEC = Vec16<T>::N, NB = kPersistNB, NW = kPersistBlock / 64;
   using V = typename Vec16<T>::type;
+  // LDS KEEP (round 6; lds_k >= 0): what the dots phase streams through its registers is also parked in the CU's LDS — x for
+  // every full chunk of this workgroup and the first lds_k columns of the COMBINE order (one 8-KiB tile per (column, chunk),
+  // a lane's own 16 bytes: conflict-free b128 accesses) — and the combine phase takes them from there instead of from the
+  // L2 / the Infinity Cache; batches 2.. of the dots phase read x from it as well. Same loads' values, same arithmetic in the
+  // same order: bit-identical to lds_k = -1. Tile (slot, j) = slot * cpw + j, slot 0 = x, slot 1 + c = combine column c.
+  extern __shared__ __align__(16) unsigned char persist_dyn[];
+  const bool lds_on = lds_k >= 0;
+  auto ltile = [&](int slot, int64_t j) -> V * {
+    return reinterpret_cast<V *>(persist_dyn) + ((int64_t)slot * cpw + j) * kPersistBlock + threadIdx.x;
+  };
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, G = (int)gridDim.x, b = (int)blockIdx.x;
   const int ncol = F.ncol, na = O.na;
   __shared__ double red[NW][kQnfMaxCols];
@@ -1059,8 +1070,10 @@ qn_apply_persist_kernel(T *__restrict__ res, QnfCols<T> cols, const T *__restric
     for (int64_t ch = ch0; ch < ch1; ++ch) {
       const int64_t i = (ch * kPersistBlock + tid) * VEC;
       V xv, cv[NB];
+      const bool keep = lds_on && chunk_full(ch);
       if (chunk_full(ch)) {
-        xv = *reinterpret_cast<const V *>(x + i);
+        if (keep && c0 > 0) xv = *ltile(0, ch - ch0);
+        else xv = *reinterpret_cast<const V *>(x + i);
 #pragma unroll
         for (int t = 0; t < NB; ++t) cv[t] = *reinterpret_cast<const V *>(cp[t] + i);
       } else {
@@ -1068,10 +1081,18 @@ qn_apply_persist_kernel(T *__restrict__ res, QnfCols<T> cols, const T *__restric
 #pragma unroll
         for (int t = 0; t < NB; ++t) cv[t] = ldv(cp[t], i);
       }
+      if (keep && c0 == 0) *ltile(0, ch - ch0) = xv;
 #pragma unroll
-      for (int t = 0; t < NB; ++t)
+      for (int t = 0; t < NB; ++t) {
 #pragma unroll
         for (int k = 0; k < VEC; ++k) acc[t] = fma((double)cv[t][k], (double)xv[k], acc[t]);
+        if (keep) {                              // dots column c0 + t is combine column cc: parked when cc < lds_k
+          const int d = c0 + t;
+          int cc = d;
+          if constexpr (KIND == MXLO_QN_LBFGS_INV) cc = d >= F.nfirst ? d - F.nfirst : 2 * F.nfirst - 1 - d;
+          if (d < ncol && cc < lds_k) *ltile(1 + cc, ch - ch0) = cv[t];
+        }
+      }
     }
 #pragma unroll
     for (int t = 0; t < NB; ++t) {
@@ -1090,7 +1111,7 @@ qn_apply_persist_kernel(T *__restrict__ res, QnfCols<T> cols, const T *__restric
   // exchanged and the recurrence runs. Measured: no gain — 1.5 us slower at n = 2^19 .. 2^20 (loads return in order, so the
   // first poll of the exchange waits behind the 11 prefetch loads), neutral above (profiles/r05_bench_mid_apply.txt).
   const int64_t chp = reverse ? ch1 - 1 : ch0;
-  const bool pre = prefetch && ch1 > ch0 && chunk_full(chp);
+  const bool pre = prefetch && !lds_on && ch1 > ch0 && chunk_full(chp);
   V pxv, pcv[NB];
   if (pre) {
     const int64_t ip = (chp * kPersistBlock + tid) * VEC;
@@ -1149,7 +1170,8 @@ qn_apply_persist_kernel(T *__restrict__ res, QnfCols<T> cols, const T *__restric
   // One chunk; FULL: every lane's vector lies inside n — unconditional 16-byte accesses, so the NB column loads of a
   // batch are in flight together (a per-load bounds branch makes the compiler drain the memory queue before every load).
   // PRE (a FULL chunk): x and the first batch of columns are the registers prefetched across the exchange.
-  auto combine_chunk = [&]<bool FULL, bool PRE = false>(int64_t ch) {
+  // KEEP (a FULL chunk, lds_k >= 0): x and the first lds_k columns come out of the LDS tiles the dots phase parked.
+  auto combine_chunk = [&]<bool FULL, bool PRE = false, bool KEEP = false>(int64_t ch) {
     const int64_t i = (ch * kPersistBlock + tid) * VEC;
     if constexpr (!FULL) {
       if (i >= n) return;
@@ -1157,6 +1179,7 @@ qn_apply_persist_kernel(T *__restrict__ res, QnfCols<T> cols, const T *__restric
     V xv, rv;
     if constexpr (FULL) {
       if constexpr (PRE) xv = pxv;
+      else if constexpr (KEEP) xv = *ltile(0, ch - ch0);
       else xv = *reinterpret_cast<const V *>(x + i);
       if constexpr (!BETA0) rv = *reinterpret_cast<const V *>(res + i);
     } else {
@@ -1172,12 +1195,33 @@ qn_apply_persist_kernel(T *__restrict__ res, QnfCols<T> cols, const T *__restric
     }
     for (int c0 = 0; c0 < ncol; c0 += NB) {
       V cv[NB];
+      // first batch of a KEEP chunk: columns [0, KK) from the LDS, [KK, NB) from memory — KK a compile-time count per case, so
+      // the loads of a batch stay a straight line (a per-load `parked ? LDS : memory` branch would drain the queue before each)
+      auto first_batch = [&]<int KK>() {
 #pragma unroll
-      for (int t = 0; t < NB; ++t) {
-        const T *p = ccol(c0 + t < ncol ? c0 + t : ncol - 1);      // clamp: a valid (unused) column instead of a branch
-        if constexpr (PRE) cv[t] = c0 == 0 ? pcv[t] : *reinterpret_cast<const V *>(p + i);
-        else if constexpr (FULL) cv[t] = *reinterpret_cast<const V *>(p + i);
-        else cv[t] = ldv(p, i);
+        for (int t = 0; t < NB; ++t) {
+          if (t < KK) cv[t] = *ltile(1 + t, ch - ch0);
+          else cv[t] = *reinterpret_cast<const V *>(ccol(t < ncol ? t : ncol - 1) + i);
+        }
+      };
+      if (KEEP && c0 == 0) {
+        switch (lds_k) {
+          case 10: first_batch.template operator()<10>(); break;
+          case 8: first_batch.template operator()<8>(); break;
+          case 5: first_batch.template operator()<5>(); break;
+          case 3: first_batch.template operator()<3>(); break;
+          case 2: first_batch.template operator()<2>(); break;
+          case 1: first_batch.template operator()<1>(); break;
+          default: first_batch.template operator()<0>(); break;
+        }
+      } else {
+#pragma unroll
+        for (int t = 0; t < NB; ++t) {
+          const T *p = ccol(c0 + t < ncol ? c0 + t : ncol - 1);      // clamp: a valid (unused) column instead of a branch
+          if constexpr (PRE) cv[t] = c0 == 0 ? pcv[t] : *reinterpret_cast<const V *>(p + i);
+          else if constexpr (FULL) cv[t] = *reinterpret_cast<const V *>(p + i);
+          else cv[t] = ldv(p, i);
+        }
       }
 #pragma unroll
       for (int t = 0; t < NB; ++t) {
@@ -1227,6 +1271,7 @@ qn_apply_persist_kernel(T *__restrict__ res, QnfCols<T> cols, const T *__restric
   for (int64_t kk = 0; kk < ch1 - ch0; ++kk) {
     const int64_t ch = reverse ? ch1 - 1 - kk : ch0 + kk;
     if (kk == 0 && pre) combine_chunk.template operator()<true, true>(ch);
+    else if (chunk_full(ch) && lds_on) combine_chunk.template operator()<true, false, true>(ch);
     else if (chunk_full(ch)) combine_chunk.template operator()<true>(ch);
     else combine_chunk.template operator()<false>(ch);
   }
@@ -1239,7 +1284,7 @@ bool persist_lds_attr_set(mxlo_ctx *ctx) {
   const int d = ctx->device & 63;
   int st = state[d].load(std::memory_order_relaxed);
   if (st == 0) {
-    st = hipFuncSetAttribute((const void *)Kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) == hipSuccess ? 1 : 2;
+    st = hipFuncSetAttribute((const void *)Kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kPersistLdsTiles * kPersistTileBytes) == hipSuccess ? 1 : 2;
     if (st == 2) (void)hipGetLastError();
     state[d].store(st, std::memory_order_relaxed);
   }
@@ -1270,14 +1315,29 @@ bool try_persist_apply(mxlo_qn *h, T *res, const T *const *cols, const T *x, Qnf
   bool fits = true;
   *status = dispatch_ab<T>(F.beta, flags, [&]<typename CA, typename CB, bool B0>() -> int32_t {
     auto go = [&]<int KIND>() {
-      if (!(fits = coresident<qn_apply_persist_kernel<T, CA, CB, KIND, B0>, kPersistBlock>(ctx, grid, 0))) return;
-      // Dynamic LDS the kernel never touches: with more than half a CU's 160 KiB requested, the dispatcher cannot put two of
-      // the 256 workgroups on one CU (and leave another CU idle) — one workgroup per CU by construction.
-      const size_t pad = (size_t)ctx->tune.qn_persist_lds_pad;
-      if (pad > 48 * 1024 && !persist_lds_attr_set<qn_apply_persist_kernel<T, CA, CB, KIND, B0>>(ctx)) { fits = false; return; }
-      hipLaunchKernelGGL((qn_apply_persist_kernel<T, CA, CB, KIND, B0>), dim3((unsigned)grid), dim3(kPersistBlock), pad,
+      if (!(fits = coresident<qn_apply_persist_kernel<T, CA, CB, KIND, B0>, kPersistBlock>(ctx, grid, (size_t)kPersistLdsTiles * kPersistTileBytes))) return;
+      // LDS keep (tune key qn_persist_lds, default 1): x of every chunk + the first K combine columns stay in the CU's LDS across
+      // the exchange — K = what 18 tiles leave after x, from the counts the kernel has a straight-line first batch for.
+      int lds_k = -1;
+      size_t dyn = (size_t)ctx->tune.qn_persist_lds_pad;   // (lds_pad: dynamic LDS the kernel never touches — a placement experiment)
+      if (ctx->tune.qn_persist_lds && cpw <= kPersistLdsTiles) {
+        int k = (kPersistLdsTiles - cpw) / cpw;
+        if (k > F.ncol) k = F.ncol;
+        lds_k = k >= 10 ? 10 : k >= 8 ? 8 : k >= 5 ? 5 : k >= 3 ? 3 : k;      // 0, 1, 2 as they are
+        // worth it when the parked share is at least ~1/12 of a pass (profiles/r06_qn_persist_lds.txt: +5 ... 22 % at
+        // n = 2^19 .. 2^21; x alone next to 20 - 40 columns measured -2 ... -3 %: the parking stores for nothing)
+        if ((1 + lds_k) * 12 < F.ncol + 1) lds_k = -1;
+        const size_t want = lds_k < 0 ? 0 : (size_t)(1 + lds_k) * cpw * kPersistTileBytes;
+        if (want > dyn) dyn = want;
+      }
+      if (dyn > 48 * 1024 && !persist_lds_attr_set<qn_apply_persist_kernel<T, CA, CB, KIND, B0>>(ctx)) {
+        if (lds_k < 0) { fits = false; return; }
+        lds_k = -1;                                        // the cap could not be raised: the plain form
+        dyn = 0;
+      }
+      hipLaunchKernelGGL((qn_apply_persist_kernel<T, CA, CB, KIND, B0>), dim3((unsigned)grid), dim3(kPersistBlock), dyn,
                          ctx->stream, res, fc, x, h->n, cpw, ctx->qslots, F, O, fused_timeout_ticks(ctx), ctx->fault_dev,
-                         ctx->tune.fused_debug_drop, ctx->tune.qn_persist_reverse, ctx->tune.qn_persist_prefetch);
+                         ctx->tune.fused_debug_drop, ctx->tune.qn_persist_reverse, ctx->tune.qn_persist_prefetch, lds_k);
     };
     if (F.kind == MXLO_QN_LBFGS_INV) go.template operator()<MXLO_QN_LBFGS_INV>();
     else if (F.kind == MXLO_QN_LBFGS_FWD) go.template operator()<MXLO_QN_LBFGS_FWD>();

@@ -1058,6 +1058,42 @@ def test_persistent_apply_matches_the_four_launch_apply_and_the_oracle(lo, dev, 
     ctx.tune("qn_persist_min_bytes", 32 << 20)
 
 
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("kind", ["inv", "fwd", "lsr1"])
+@pytest.mark.parametrize("n,mem", [(1 << 19, 2), ((1 << 19) + 5, 10), (700_001, 3), ((1 << 20) + 1, 5), (1_500_003, 7), ((1 << 21) + 2, 5),
+                                   ((1 << 22) + 9, 2)])
+def test_persistent_apply_with_lds_parking_has_the_bits_of_the_plain_form(lo, dev, dtype, kind, n, mem):
+    """the dots phase of the persistent apply parks x and the first columns of the combine order in the CU's
+    LDS (18 tiles of 8 KiB; csrc/qn.hip, `lds_k`) and the combine phase reads them from there. Values and order of every
+    operation are those of `qn_persist_lds` = 0: bit-identical — for every count of parked columns the kernel has a case
+    for (chunks per workgroup 1 ... 16), lengths that end in a partial chunk (never parked), alpha / beta forms and the
+    fused shifted apply, and with memories that are partially filled."""
+    from linearoperators_jl_amd.device import get_ctx
+    ctx = get_ctx(dev)
+    npd = NP[dtype]
+    rng = np.random.default_rng(n + 17 * mem)
+    make = {"inv": lo.InverseLBFGSOperator, "fwd": lo.LBFGSOperator, "lsr1": lo.LSR1Operator}[kind]
+    op = make(dtype, n, mem=mem, scaling=True, device=dev)
+    x, r0 = T(rng.uniform(-1, 1, n).astype(npd), dev), T(rng.uniform(-1, 1, n).astype(npd), dev)
+    ctx.tune("qn_persist_min_bytes", 0)
+    try:
+        for k, (s, y) in enumerate(pairs(rng, n, mem + 1, npd)):
+            lo.push(op, T(s, dev), T(y, dev))
+            if k not in (0, mem):
+                continue
+            for target, a, b in ((op, 1.0, 0.0), (op, 0.7, -1.3), (lo.ShiftedOperator(op, 0.37), 1.5, 0.5)):
+                got = {}
+                for park in (1, 0):
+                    ctx.tune("qn_persist_lds", park)
+                    res = r0.clone()
+                    lo.mul(res, target, x, a, b)
+                    got[park] = res
+                assert torch.equal(got[1], got[0]), (k, a, b)
+    finally:
+        ctx.tune("qn_persist_lds", 1)
+        ctx.tune("qn_persist_min_bytes", 32 << 20)
+
+
 def test_persistent_apply_timeout_is_an_error_not_a_hang(lo, dev):
     """The persistent apply shares the bounded wait of the single-launch forms: a workgroup that never publishes (test
     hook `fused_debug_drop`) ends the launch with NaN + the ctx fault word; the next call reports it, re-arms the slots

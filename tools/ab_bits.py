@@ -82,7 +82,30 @@ def cases_qn(lo, torch, dev):
                 yield f"qn {kind} {str(dt)[6:]} n={n} m={mem} apply-after-pushes", r
 
 
-SECTIONS = {"herm": cases_herm, "dense": cases_dense, "qn": cases_qn}
+def cases_persist(lo, torch, dev):
+    """quasi-Newton applies in the range of the persistent single launch (qn.hip: qn_apply_persist_kernel), ragged lengths, alpha / beta / shift"""
+    import numpy as np
+    for dt in (torch.float64, torch.float32):
+        for kind, ctor in (("inv", lo.InverseLBFGSOperator), ("fwd", lo.LBFGSOperator), ("sr1", lo.LSR1Operator)):
+            for n, mem in (((1 << 19) + 5, 7), (1 << 19, 10), (700_001, 3), (1 << 20, 5), (1_500_001, 5), ((1 << 21) + 2, 10), (1 << 22, 5), (5_000_000, 4)):
+                rng = np.random.default_rng(n + mem)
+                op = ctor(dt, n, mem=mem, device=dev)
+                x = torch.from_numpy(rng.uniform(-1, 1, n)).to(dt).to(dev)
+                for it in range(mem + 2):
+                    s = torch.from_numpy(rng.uniform(-1, 1, n)).to(dt).to(dev)
+                    yv = s * (1.0 + 0.5 * torch.from_numpy(rng.uniform(0, 1, n)).to(dt).to(dev))
+                    if kind == "sr1":
+                        yv = yv + 0.1 * torch.from_numpy(rng.uniform(-1, 1, n)).to(dt).to(dev)
+                    lo.push(op, s, yv)
+                r = torch.from_numpy(rng.uniform(-1, 1, n)).to(dt).to(dev)
+                lo.mul(r, op, x, 1.0, 0.0)
+                yield f"persist {kind} {str(dt)[6:]} n={n} m={mem} b0", r
+                lo.mul(r, op, x, 0.7, -1.3)
+                yield f"persist {kind} {str(dt)[6:]} n={n} m={mem} ab", r
+                del op
+
+
+SECTIONS = {"herm": cases_herm, "dense": cases_dense, "qn": cases_qn, "persist": cases_persist}
 
 
 def run(sections):

@@ -37,7 +37,7 @@ persist = os.environ.get("MXLO_QN_PERSIST")
 if persist is not None:
     ctx.tune("qn_persist", int(persist))
     print(f"# qn_persist = {persist}")
-for key in ("qn_persist_reverse", "qn_persist_prefetch", "qn_persist_lds_pad", "qn_persist_max_bytes", "qn_persist_min_n"):
+for key in ("qn_persist_reverse", "qn_persist_prefetch", "qn_persist_lds", "qn_persist_lds_pad", "qn_persist_max_bytes", "qn_persist_min_n"):
     if os.environ.get("MXLO_" + key.upper()) is not None:
         ctx.tune(key, int(os.environ["MXLO_" + key.upper()]))
         print(f"# {key} = {os.environ['MXLO_' + key.upper()]}")

@@ -37,6 +37,24 @@ def test_random_operation_sequences_fp32(lo, dev, seed):
     run_sequence(lo, dev, seed, torch.float32, QN_F32_FUZZ_LSR1 if seed % 3 == 2 else QN_F32_FUZZ_LBFGS, QN_F32_SOLVE)
 
 
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("MXLO_QNFUZZ_PERSIST_SEEDS", "9"))))
+def test_random_operation_sequences_in_the_range_of_the_persistent_apply(lo, dev, seed):
+    """The same state machine at n = 2^19 ... 1.4e6, where an apply is ONE persistent launch with x and the first columns
+    parked in LDS between its two phases (csrc/qn.hip: qn_apply_persist_kernel; `qn_persist_min_bytes` lowered so that
+    partially filled memories take it too): chunk counts per workgroup 2 ... 6, ragged last chunks, every count of parked
+    columns, fp64 and (every third seed) fp32."""
+    from linearoperators_jl_amd.device import get_ctx
+    ctx = get_ctx(dev)
+    ctx.tune("qn_persist_min_bytes", 0)
+    try:
+        f32 = seed % 3 == 2
+        run_sequence(lo, dev, 50_000 + seed, torch.float32 if f32 else torch.float64,
+                     (QN_F32_FUZZ_LSR1 if (50_000 + seed) % 3 == 2 else QN_F32_FUZZ_LBFGS) if f32 else 1e-8, QN_F32_SOLVE if f32 else 1e-7,
+                     sizes=[1 << 19, (1 << 19) + 5, 700_001, 1 << 20, (1 << 20) + 3, 1_400_007], max_steps=12)
+    finally:
+        ctx.tune("qn_persist_min_bytes", 32 << 20)
+
+
 ILL_CONDITIONED_F32_SEED = 1154
 
 
@@ -60,12 +78,12 @@ def test_fp32_lsr1_ill_conditioned_sequence(lo, dev):
     print(f"\nseed {ILL_CONDITIONED_F32_SEED}: worst GPU-vs-oracle32 {worst[1]:.2e} at {worst[0]} where oracle32-vs-oracle64 is {worst[2]:.2e}")
 
 
-def run_sequence(lo, dev, seed, dtype, tol, tol_solve, shadow=None):
+def run_sequence(lo, dev, seed, dtype, tol, tol_solve, shadow=None, sizes=None, max_steps=30):
     """shadow: a list -> Float32 runs also drive a Float64 oracle with the same pairs and, instead of asserting the apply
     tolerance, record (tag, |gpu - oracle32| / scale, |oracle32 - oracle64| / scale) per check."""
     npd = np.float64 if dtype == torch.float64 else np.float32
     rng = np.random.default_rng(1000 + seed)
-    n = int(rng.choice([1, 2, 3, 17, 130, 1025, 4099, 20_001]))
+    n = int(rng.choice(sizes if sizes else [1, 2, 3, 17, 130, 1025, 4099, 20_001]))
     mem = int(rng.integers(1, 9))
     kind = ["fwd", "inv", "lsr1"][seed % 3]
     if kind == "lsr1" and n < 17:
@@ -103,7 +121,7 @@ def run_sequence(lo, dev, seed, dtype, tol, tol_solve, shadow=None):
         assert op.data.insert == O.insert
 
     check("fresh")
-    for step in range(int(rng.integers(5, 30))):
+    for step in range(int(rng.integers(5, max_steps))):
         c = rng.integers(12)
         if c <= 5:                                            # push a (mostly) well-conditioned pair
             s = rng.uniform(-1, 1, n).astype(npd)

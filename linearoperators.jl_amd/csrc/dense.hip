@@ -1573,7 +1573,7 @@ int32_t hermitian_t(mxlo_ctx *ctx, T *res, const T *d, const T *A, int64_t lda, 
   MXLO_REQUIRE(4 * ng * (ng + 1) < (1LL << 31), MXLO_ESHAPE, "opHermitian: n too large");
   // tiles per strip: 8-tile strips once there are at least two of them per CU, thinner strips below that
   const int64_t pairs = ng * (ng - 1) / 2;                       // (row group, strip column block) pairs left of the diagonal
-  const int C = (DT / 8) * pairs >= 2 * ctx->num_cu ? 8 : ((DT / 2) * pairs >= 2 * ctx->num_cu ? 2 : 1), Q = DT / C;
+  const int C = ctx->tune.herm_strip ? ctx->tune.herm_strip : ((DT / 8) * pairs >= 2 * ctx->num_cu ? 8 : ((DT / 2) * pairs >= 2 * ctx->num_cu ? 2 : 1)), Q = DT / C;
   const int64_t prow_len = herm_row_base<HR, DT>(ng, Q), pcol_len = herm_col_base<HR>(ng, ng);
   const size_t need = sizeof(double) * (size_t)(prow_len + pcol_len);
   const bool aligned = (((uintptr_t)A & 15u) == 0) && (lda % RPL == 0);
@@ -1685,7 +1685,7 @@ int32_t hermitian_block_t(mxlo_ctx *ctx, T *res, int64_t ldr, const T *d, const 
   const int64_t ng = (n + HR - 1) / HR, ngf = n / HR;
   MXLO_REQUIRE(4 * ng * (ng + 1) < (1LL << 31), MXLO_ESHAPE, "opHermitian: n too large");
   const int64_t pairs = ng * (ng - 1) / 2;
-  const int C = (DT / 8) * pairs >= 2 * ctx->num_cu ? 8 : ((DT / 2) * pairs >= 2 * ctx->num_cu ? 2 : 1), Q = DT / C;
+  const int C = ctx->tune.herm_strip ? ctx->tune.herm_strip : ((DT / 8) * pairs >= 2 * ctx->num_cu ? 8 : ((DT / 2) * pairs >= 2 * ctx->num_cu ? 2 : 1)), Q = DT / C;
   const int64_t prow_len = herm_row_base<HR, DT>(ng, Q), pcol_len = herm_col_base<HR>(ng, ng);
   const int64_t pstride = prow_len + pcol_len;
   constexpr int KVMAX = 4;

@@ -23,14 +23,14 @@ sizes = (2048, 3072, 4096, 5120, 6144, 8192, 16384)
 for a in sys.argv[1:]:
     if a.startswith("sizes="):
         sizes = tuple(int(x) for x in a[6:].split(","))
-DEFAULT = {"herm_nt": -1, "herm_single": 1, "herm_single_max_n": 2048, "herm_order": 1}
+DEFAULT = {"herm_nt": -1, "herm_single": 1, "herm_single_max_n": 2048, "herm_order": 1, "herm_strip": 0}
 configs = [
     ("default", {}),
-    ("nt=1 (round-5 policy)", {"herm_nt": 1}),
-    ("nt=0", {"herm_nt": 0}),
+    ("strip 1", {"herm_strip": 1}),
+    ("strip 2", {"herm_strip": 2}),
+    ("strip 8", {"herm_strip": 8}),
     ("single<=8192", {"herm_single_max_n": 8192}),
-    ("single<=8192 nt=1", {"herm_single_max_n": 8192, "herm_nt": 1}),
-    ("two launches", {"herm_single": 0}),
+    ("single<=8192 strip 2", {"herm_single_max_n": 8192, "herm_strip": 2}),
 ]
 
 

@@ -479,6 +479,9 @@ MXLO_API int32_t mxlo_ctx_tune(mxlo_ctx *ctx, const char *key, int64_t value) {
   } else if (!strcmp(key, "herm_single")) {
     MXLO_REQUIRE(value == 0 || value == 1, MXLO_EINVAL, "herm_single must be 0 or 1");
     ctx->tune.herm_single = (int)value;
+  } else if (!strcmp(key, "herm_single_max_bytes")) {
+    MXLO_REQUIRE(value >= 0, MXLO_EINVAL, "herm_single_max_bytes must be >= 0");
+    ctx->tune.herm_single_max_bytes = value;
   } else if (!strcmp(key, "herm_single_max_n")) {
     MXLO_REQUIRE(value >= 0, MXLO_EINVAL, "herm_single_max_n must be >= 0");
     ctx->tune.herm_single_max_n = value;

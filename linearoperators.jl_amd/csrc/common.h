@@ -161,9 +161,11 @@ struct Tune {
   int herm_strip = 0;      // opHermitian: tiles per strip, 0 = by size (8 once there are two 8-tile strips per CU, else 2, else 1); 1 / 2 / 8 force (sweeps)
   int herm_lds_pad = 0;    // opHermitian pass launch: bytes of unused dynamic LDS per workgroup (occupancy experiment, <= 48 KiB)
   int herm_single = 1;     // opHermitian (full row groups, aligned A, n <= herm_single_max_n): strips and finishers in ONE launch
-  int64_t herm_single_max_n = 2048;   // measured (profiles/r05_herm_small.txt): 8.9 -> 6.4 us at n = 1024, 9.6 -> 6.9 at 2048 (f64; f32
-                                      // alike); NO gain at 4096 (17.8 vs 18.4 f64, 12.4 vs 10.8 f32) and 8192: there the strips' own
-                                      // load -> butterfly -> store chain sets the time, not the finish launch
+  int64_t herm_single_max_n = 0;      // 0 (default): by size — triangles of at most herm_single_max_bytes; > 0: n <= this value
+  int64_t herm_single_max_bytes = 112ll << 20;   // measured (profiles/r06_herm_policy.txt, round 6): f64 gains up to n = 5120
+                                      // (4096: 15.2 -> 14.8 us, 5120: 20.4 -> 19.8), equal at 3072, LOSES at 6144 (28.3 -> 28.8); f32 gains up
+                                      // to 6144 (5120: 15.5 -> 14.1, 6144: 18.5 -> 17.6), equal at 8192. Round 5 measured no gain above
+                                      // 2048: that was with the row-group order and the three-round finish.
   int kron_fuse = 1;       // kron: both GEMMs in ONE launch when every tile has its own CU, the dependency kept XCD-local
                            // (gemm_glds.h: kron_fused_kernel; 2: timing experiment without the wait — wrong results)
   int gemv_n_rows = 1;     // dense M*v: row bands, the column sum stays inside a workgroup — one launch, no partials (dense.hip)

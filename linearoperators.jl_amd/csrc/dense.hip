@@ -1564,6 +1564,25 @@ inline int herm_nt_policy(const mxlo_ctx *ctx, int64_t n) {
   return tri >= ctx->tune.herm_dp_min_bytes && tri < ctx->tune.herm_nt_min_bytes ? 0 : 1;
 }
 
+// Tiles per strip: 8-tile strips once there are two of them per CU, 2-tile strips with two per CU, else single tiles. Triangles
+// small enough for the single-launch form (herm_small) take 2-tile strips from 1.25 per CU on — measured with the one launch
+// (profiles/r06_herm_policy.txt): f64 n = 4096 14.8 -> 14.4 us, f32 n = 5120 14.1 -> 13.6; f64 n = 3072 (1.03 per CU) 10.1 -> 11.0:
+// stays single tiles. The rule depends on (n, T, CUs) only, so the single launch and the two launches share their partial
+// layout and stay bit-identical.
+template <typename T>
+inline bool herm_small(const mxlo_ctx *ctx, int64_t n) {
+  if (ctx->tune.herm_single_max_n > 0) return n <= ctx->tune.herm_single_max_n;
+  return (int64_t)sizeof(T) * n * (n / 2) <= ctx->tune.herm_single_max_bytes;
+}
+template <typename T>
+inline int herm_strip_tiles(const mxlo_ctx *ctx, int64_t n, int64_t pairs) {
+  constexpr int DT = HermCfg<T>::DT;
+  if (ctx->tune.herm_strip) return ctx->tune.herm_strip;
+  if ((DT / 8) * pairs >= 2 * ctx->num_cu) return 8;
+  if ((DT / 2) * pairs * 4 >= (herm_small<T>(ctx, n) ? 5 : 8) * (int64_t)ctx->num_cu) return 2;
+  return 1;
+}
+
 template <typename T>
 int32_t hermitian_t(mxlo_ctx *ctx, T *res, const T *d, const T *A, int64_t lda, const T *v, int64_t n,
                     double alpha, double beta, int32_t flags) {
@@ -1573,13 +1592,13 @@ int32_t hermitian_t(mxlo_ctx *ctx, T *res, const T *d, const T *A, int64_t lda, 
   MXLO_REQUIRE(4 * ng * (ng + 1) < (1LL << 31), MXLO_ESHAPE, "opHermitian: n too large");
   // tiles per strip: 8-tile strips once there are at least two of them per CU, thinner strips below that
   const int64_t pairs = ng * (ng - 1) / 2;                       // (row group, strip column block) pairs left of the diagonal
-  const int C = ctx->tune.herm_strip ? ctx->tune.herm_strip : ((DT / 8) * pairs >= 2 * ctx->num_cu ? 8 : ((DT / 2) * pairs >= 2 * ctx->num_cu ? 2 : 1)), Q = DT / C;
+  const int C = herm_strip_tiles<T>(ctx, n, pairs), Q = DT / C;
   const int64_t prow_len = herm_row_base<HR, DT>(ng, Q), pcol_len = herm_col_base<HR>(ng, ng);
   const size_t need = sizeof(double) * (size_t)(prow_len + pcol_len);
   const bool aligned = (((uintptr_t)A & 15u) == 0) && (lda % RPL == 0);
   const int nt = herm_nt_policy<T>(ctx, n);
   // ---- the whole apply in ONE launch: full row groups of an aligned matrix, slots in their own (always re-armed) buffer
-  if (ctx->tune.herm_single && aligned && n % HR == 0 && n <= ctx->tune.herm_single_max_n && ctx->fault_dev && !ctx->capturing) {
+  if (ctx->tune.herm_single && aligned && n % HR == 0 && herm_small<T>(ctx, n) && ctx->fault_dev && !ctx->capturing) {
     int32_t fst = fused_fault_check(ctx);
     if (fst != MXLO_OK) return fst;
     if (ctx->tune.herm_single) {              // (the fault check switches the single-launch forms off)
@@ -1685,7 +1704,7 @@ int32_t hermitian_block_t(mxlo_ctx *ctx, T *res, int64_t ldr, const T *d, const 
   const int64_t ng = (n + HR - 1) / HR, ngf = n / HR;
   MXLO_REQUIRE(4 * ng * (ng + 1) < (1LL << 31), MXLO_ESHAPE, "opHermitian: n too large");
   const int64_t pairs = ng * (ng - 1) / 2;
-  const int C = ctx->tune.herm_strip ? ctx->tune.herm_strip : ((DT / 8) * pairs >= 2 * ctx->num_cu ? 8 : ((DT / 2) * pairs >= 2 * ctx->num_cu ? 2 : 1)), Q = DT / C;
+  const int C = herm_strip_tiles<T>(ctx, n, pairs), Q = DT / C;
   const int64_t prow_len = herm_row_base<HR, DT>(ng, Q), pcol_len = herm_col_base<HR>(ng, ng);
   const int64_t pstride = prow_len + pcol_len;
   constexpr int KVMAX = 4;

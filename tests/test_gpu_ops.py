@@ -198,7 +198,7 @@ def test_hermitian_single_launch_is_bit_identical_to_the_two_launch_form(lo, dev
         lo._lib.call("mxlo_debug_counters", a)
         return a[10]
 
-    ctx.tune("herm_single_max_n", 8192)                           # (the default stops at 2048: no gain above, see common.h)
+    ctx.tune("herm_single_max_n", 8192)                           # (the default rule is by size — 112 MiB of triangle —, see common.h)
     for dtype, n in cases:
         npd = NP[dtype]
         if (dtype, n) not in ops:
@@ -233,7 +233,7 @@ def test_hermitian_single_launch_is_bit_identical_to_the_two_launch_form(lo, dev
         lo.mul(res, H, vt, 1.0, 0.0)
     assert launches() - l0 == 200                                  # ONE launch per apply
     assert torch.equal(res, first)
-    ctx.tune("herm_single_max_n", 2048)
+    ctx.tune("herm_single_max_n", 0)                               # back to the by-size rule
 
 
 @pytest.mark.parametrize("dtype", [torch.float64, torch.float32, torch.complex128, torch.complex64])

@@ -23,15 +23,17 @@ sizes = (2048, 3072, 4096, 5120, 6144, 8192, 16384)
 for a in sys.argv[1:]:
     if a.startswith("sizes="):
         sizes = tuple(int(x) for x in a[6:].split(","))
-DEFAULT = {"herm_nt": -1, "herm_single": 1, "herm_single_max_n": 2048, "herm_order": 1, "herm_strip": 0}
+DEFAULT = {"herm_nt": -1, "herm_single": 1, "herm_single_max_n": 0, "herm_order": 1, "herm_strip": 0}
 configs = [
     ("default", {}),
-    ("strip 1", {"herm_strip": 1}),
-    ("strip 2", {"herm_strip": 2}),
-    ("strip 8", {"herm_strip": 8}),
     ("single<=8192", {"herm_single_max_n": 8192}),
+    ("default (again)", {}),
+    ("single<=8192 (again)", {"herm_single_max_n": 8192}),
+    ("strip 2", {"herm_strip": 2}),
     ("single<=8192 strip 2", {"herm_single_max_n": 8192, "herm_strip": 2}),
 ]
+if os.environ.get("MXLO_HERM_AB_STRIPS"):
+    configs = [("default", {})] + [(f"strip {c}", {"herm_strip": c}) for c in (1, 2, 8)]
 
 
 def apply_cfg(c):

@@ -1380,7 +1380,7 @@ template <typename T, typename CA, typename CB, bool BETA0, int FR, bool POLL>
 __device__ __forceinline__ void
 herm_finish_body(T *__restrict__ res, const T *__restrict__ d, const T *__restrict__ v, double *__restrict__ Prow,
                  double *__restrict__ Pcol, int64_t n, int ng, int q, CA alpha, CB beta, int64_t blk,
-                 unsigned long long ticks, unsigned *__restrict__ fault) {
+                 unsigned long long ticks, unsigned *__restrict__ fault, int poll_sleep = 32) {
   // FR rows per workgroup, 256/FR lanes per row; a lane's partials (sub, sub+FS, ...) are loaded 8 (4) at a time with
   // nothing between the loads, and the finishing lane's d, v (res) are requested before them: the kernel is pure
   // latency (3 MB of partials at n = 4096) — ~2.3 us of its own plus the ~2.2 us every dependent launch costs.
@@ -1422,7 +1422,7 @@ herm_finish_body(T *__restrict__ res, const T *__restrict__ d, const T *__restri
       unsigned long long t0 = 0;
       unsigned it = 0;
       while (__hip_atomic_load(reinterpret_cast<const unsigned long long *>(w), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == kSlotEmpty) {
-        __builtin_amdgcn_s_sleep(32);
+        for (int k = 0; k < poll_sleep; ++k) __builtin_amdgcn_s_sleep(1);      // (tune key herm_poll_sleep x 64 clocks between two looks)
         if ((++it & 63u) == 0) {                // bounded like poll_slot; the sweep below reports the fault
           const unsigned long long now = (unsigned long long)wall_clock64();
           if (t0 == 0) t0 = now;
@@ -1541,11 +1541,11 @@ template <typename T, int C, typename CA, typename CB, bool BETA0, int FR>
 __global__ void __launch_bounds__(kBlock)
 herm_single_kernel(T *__restrict__ res, const T *__restrict__ d, const T *__restrict__ A, int64_t lda, const T *__restrict__ v,
                    int64_t n, double *__restrict__ Prow, double *__restrict__ Pcol, int64_t ng, int qint, int64_t n_int,
-                   int64_t n_light, CA alpha, CB beta, unsigned long long ticks, unsigned *__restrict__ fault, int colmajor_g) {
+                   int64_t n_light, CA alpha, CB beta, unsigned long long ticks, unsigned *__restrict__ fault, int colmajor_g, int poll_sleep) {
   const int64_t t = blockIdx.x;
   if (t < n_int) return herm_strip_body<T, C, false, false, true>(A, lda, v, n, Prow, Pcol, ng, qint, 0, t, 0, 0, colmajor_g);
   if (t < n_light) return herm_strip_body<T, 1, false, true, true>(A, lda, v, n, Prow, Pcol, ng, qint, 2, t - n_int);
-  herm_finish_body<T, CA, CB, BETA0, FR, true>(res, d, v, Prow, Pcol, n, (int)ng, qint, alpha, beta, t - n_light, ticks, fault);
+  herm_finish_body<T, CA, CB, BETA0, FR, true>(res, d, v, Prow, Pcol, n, (int)ng, qint, alpha, beta, t - n_light, ticks, fault, poll_sleep);
 }
 
 __global__ void __launch_bounds__(kBlock) herm_slots_fill_kernel(unsigned long long *__restrict__ p, int64_t count) {
@@ -1633,7 +1633,7 @@ int32_t hermitian_t(mxlo_ctx *ctx, T *res, const T *d, const T *A, int64_t lda, 
           //  1-D grid — are dispatched after all of them)
           hipLaunchKernelGGL((herm_single_kernel<T, C_, CA, CB, B0, FR1>), dim3((unsigned)grid1), dim3(kBlock), 0, ctx->stream, res, d, A,
                              lda, v, n, Sr, Sc, ng, Q, n_int1, n_light1, (CA)alpha, (CB)beta, fused_timeout_ticks(ctx), ctx->fault_dev,
-                             ctx->tune.herm_order && n > 2048 ? (int)ngf : 0);
+                             ctx->tune.herm_order && n > 2048 ? (int)ngf : 0, ctx->tune.herm_poll_sleep);
           MXLO_LAUNCH_CHECK();
           return MXLO_OK;
         };

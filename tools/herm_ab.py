@@ -23,7 +23,7 @@ sizes = (2048, 3072, 4096, 5120, 6144, 8192, 16384)
 for a in sys.argv[1:]:
     if a.startswith("sizes="):
         sizes = tuple(int(x) for x in a[6:].split(","))
-DEFAULT = {"herm_nt": -1, "herm_single": 1, "herm_single_max_n": 0, "herm_order": 1, "herm_strip": 0}
+DEFAULT = {"herm_nt": -1, "herm_single": 1, "herm_single_max_n": 0, "herm_order": 1, "herm_strip": 0, "herm_poll_sleep": 32}
 configs = [
     ("default", {}),
     ("single<=8192", {"herm_single_max_n": 8192}),
@@ -32,7 +32,9 @@ configs = [
     ("strip 2", {"herm_strip": 2}),
     ("single<=8192 strip 2", {"herm_single_max_n": 8192, "herm_strip": 2}),
 ]
-if os.environ.get("MXLO_HERM_AB_STRIPS"):
+if os.environ.get("MXLO_HERM_AB_SLEEP"):
+    configs = [(f"poll sleep {c}", {"herm_poll_sleep": c}) for c in (32, 8, 2, 1, 64, 32, 8, 2)]
+elif os.environ.get("MXLO_HERM_AB_STRIPS"):
     configs = [("default", {})] + [(f"strip {c}", {"herm_strip": c}) for c in (1, 2, 8)]
 
 

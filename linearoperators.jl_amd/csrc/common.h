@@ -158,7 +158,8 @@ struct Tune {
                            // (about the size of the Infinity Cache; round 6, dense.hip: herm_nt_policy), 0 / 1 force
   int64_t herm_dp_min_bytes = 96ll << 20;
   int64_t herm_nt_min_bytes = 384ll << 20;
-XX
+  int herm_poll_sleep = 4;    // single-launch opHermitian: the finishers' first wait looks every 64 x this many clocks (round 5: 32;
+                              // sweep 1 ... 64 in profiles/r06_herm_policy.txt: 2 ... 8 are 0 ... 5 % ahead of 32 at n = 2048 / 3072 / f32 6144, equal elsewhere)
   int herm_strip = 0;      // opHermitian: tiles per strip, 0 = by size (8 once there are two 8-tile strips per CU, else 2, else 1); 1 / 2 / 8 force (sweeps)
   int herm_lds_pad = 0;    // opHermitian pass launch: bytes of unused dynamic LDS per workgroup (occupancy experiment, <= 48 KiB)
   int herm_single = 1;     // opHermitian (full row groups, aligned A, n <= herm_single_max_n): strips and finishers in ONE launch

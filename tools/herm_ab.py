@@ -23,7 +23,7 @@ sizes = (2048, 3072, 4096, 5120, 6144, 8192, 16384)
 for a in sys.argv[1:]:
     if a.startswith("sizes="):
         sizes = tuple(int(x) for x in a[6:].split(","))
-DEFAULT = {"herm_nt": -1, "herm_single": 1, "herm_single_max_n": 0, "herm_order": 1, "herm_strip": 0, "herm_poll_sleep": 32}
+DEFAULT = {"herm_nt": -1, "herm_single": 1, "herm_single_max_n": 0, "herm_order": 1, "herm_strip": 0, "herm_poll_sleep": 4}
 configs = [
     ("default", {}),
     ("single<=8192", {"herm_single_max_n": 8192}),

@@ -1,0 +1,74 @@
+"""CPU: the Julia sources under julia/ have never been parsed by Julia (none in the image). tests/jl_lint.py checks their block
+structure (`function` / `if` / `for` / … / `end`), brackets, strings and comments. It earns its trust two ways: every file of the
+reference — real, running Julia — must pass it, and planted defects in the glue must be reported."""
+import glob
+import os
+import re
+
+import pytest
+
+import jl_lint
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GLUE = sorted(glob.glob(os.path.join(ROOT, "julia", "*.jl")))
+REF = sorted(glob.glob("/root/reference/**/*.jl", recursive=True))
+
+
+@pytest.mark.parametrize("path", GLUE, ids=[os.path.basename(p) for p in GLUE])
+def test_glue_sources_are_structurally_sound(path):
+    assert jl_lint.check(open(path).read(), path) > 0
+
+
+@pytest.mark.skipif(not REF, reason="/root/reference exists in the build container only")
+def test_every_reference_file_passes_the_checker():
+    """47 files of running Julia (src, ext, test, docs): a checker that rejected one of them would be wrong, not the file."""
+    assert len(REF) >= 40
+    for path in REF:
+        jl_lint.check(open(path).read(), path)
+
+
+def _line_ends(text):
+    return [m.start() for m in re.finditer(r"(?m)^[ \t]*end[ \t]*$", text)]
+
+
+@pytest.mark.parametrize("path", GLUE, ids=[os.path.basename(p) for p in GLUE])
+def test_planted_defects_are_reported(path):
+    text = open(path).read()
+    ends = _line_ends(text)
+    assert len(ends) >= 5
+    for pos in ends[:: max(1, len(ends) // 12)]:                      # a dropped `end`
+        nl = text.index("\n", pos)
+        with pytest.raises(jl_lint.JlSyntaxError):
+            jl_lint.check(text[:pos] + text[nl + 1:], path)
+    for pos in ends[:: max(1, len(ends) // 6)]:                       # an extra `end`
+        with pytest.raises(jl_lint.JlSyntaxError):
+            jl_lint.check(text[:pos] + "end\n" + text[pos:], path)
+    brackets = []
+    jl_lint.check(text, path, code_brackets=brackets)                 # positions of the brackets that are code
+    closers = [p for p in brackets if text[p] == ")"]
+    for pos in closers[:: max(1, len(closers) // 25)]:                # a dropped closing parenthesis
+        with pytest.raises(jl_lint.JlSyntaxError):
+            jl_lint.check(text[:pos] + text[pos + 1:], path)
+    openers = [p for p in brackets if text[p] in "[("]
+    for pos in openers[:: max(1, len(openers) // 25)]:                # a dropped opening bracket
+        with pytest.raises(jl_lint.JlSyntaxError):
+            jl_lint.check(text[:pos] + text[pos + 1:], path)
+
+
+def test_the_rules_the_checker_relies_on():
+    ok = [
+        "x = a[end]; y = a[begin:end-1]; z = [i for i in 1:3 if i > 1]\n",
+        "f(x) = x'\ng(A) = A' * A\nc = 'a'; d = '\\n'; e = x' + 'b'\n",
+        's = "a $(f("b)")) c"; t = """x "y" $(g(1))"""\n',
+        "#= outer #= inner =# still a comment end =#\nfunction f end\n",
+        "s = :end; t = :function; q = quote 1 end; p = a.end\n",
+        "abstract type A end\nmutable struct B\n  x::Int\nend\nprimitive type C 8 end\n",
+        "v = map(xs) do x\n  x + 1\nend\nw = sum(x^2 for x in xs if x > 0)\n",
+        "y = try\n  f()\ncatch e\n  0\nfinally\n  g()\nend\n",
+    ]
+    for src in ok:
+        jl_lint.check(src)
+    bad = ["function f()\n  if x\n  end\n", "f(x = (1, 2]\n", "for i in 1:3\nend\nend\n", 's = "abc\n', "x = [1, 2\n", "#= never closed\n"]
+    for src in bad:
+        with pytest.raises(jl_lint.JlSyntaxError):
+            jl_lint.check(src)

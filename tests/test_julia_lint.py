@@ -72,3 +72,32 @@ def test_the_rules_the_checker_relies_on():
     for src in bad:
         with pytest.raises(jl_lint.JlSyntaxError):
             jl_lint.check(src)
+
+
+BASE_NAMES = {"IdDict", "Int64", "MethodError", "allunique", "cglobal", "empty!", "enumerate", "get", "get!", "getfield", "invoke",
+              "isassigned", "issorted", "keys", "parse", "sort!", "step", "ccall", "Ref", "Ptr", "Cvoid", "Cint", "Cdouble",
+              "Clonglong", "Cstring", "unsafe_string", "finalizer", "pointer", "unsafe_convert", "new", "typeof", "sizeof", "isa"}
+JL_KEYWORDS = {"if", "for", "while", "function", "return", "where", "elseif", "in", "do", "let", "try", "catch"}
+
+
+def _strip(t):
+    t = re.sub(r'"""[\s\S]*?"""', '""', t)
+    t = re.sub(r'"(?:\\.|[^"\\])*"', '""', t)
+    t = re.sub(r"#=.*?=#", "", t, flags=re.S)
+    return re.sub(r"#[^\n]*", "", t)
+
+
+@pytest.mark.skipif(not REF, reason="/root/reference exists in the build container only")
+def test_every_name_the_glue_calls_is_defined_somewhere():
+    """A typo in a function name would only show at run time — and the glue never ran. Every identifier the extension CALLS must be
+    defined in the extension, be a name the reference's own sources use (Base / LinearAlgebra / LinearOperators functions the way
+    running code spells them), or be one of a short list of Base names."""
+    g = _strip(open(os.path.join(ROOT, "julia", "LinearOperatorsMXLOExt.jl")).read())
+    called = set(re.findall(r"\b([A-Za-z_][A-Za-z0-9_!]*)\s*(?:\{[^}]*\})?\(", g))
+    defined = set(re.findall(r"\bfunction\s+(?:[A-Za-z_.]+\.)?([A-Za-z_][A-Za-z0-9_!]*)", g))
+    defined |= set(re.findall(r"(?m)^\s*(?:@inline\s+)?(?:[A-Za-z_.]+\.)?([A-Za-z_][A-Za-z0-9_!]*)\s*(?:\{[^}]*\})?\(.*\)\s*(?:where\s*\{?[^=\n]*\}?)?\s*=(?!=)", g))
+    defined |= set(re.findall(r"\bstruct\s+([A-Za-z_][A-Za-z0-9_]*)", g)) | set(re.findall(r"\bconst\s+([A-Za-z_][A-Za-z0-9_]*)", g))
+    ref = "".join(_strip(open(p).read()) for p in REF)
+    refwords = set(re.findall(r"\b([A-Za-z_][A-Za-z0-9_!]*)\b", ref))
+    unknown = sorted(w for w in called if w not in defined and w not in refwords and w not in BASE_NAMES and w not in JL_KEYWORDS)
+    assert not unknown, unknown

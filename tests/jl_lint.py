@@ -218,3 +218,92 @@ def check(text: str, name: str = "<text>", code_brackets: list | None = None) ->
         kind, what, ln = stack[-1]
         raise JlSyntaxError(f"{name}:{ln}: {'`' + what + '` block' if kind == 'block' else repr(kind)} is never closed")
     return blocks
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# Arity of calls to the file's OWN helpers (names neither the reference nor Base knows): a call whose number of positional
+# arguments no definition (long form, short form, or a struct's default constructor) accepts is a MethodError waiting for the
+# first run. Keyword arguments (`k = v`, or anything after `;`) are ignored, splatted calls are skipped, `do` adds one.
+def strip_comments_and_strings(t: str) -> str:
+    t = re.sub(r'"""[\s\S]*?"""', '""', t)
+    t = re.sub(r'"(?:\\.|[^"\\])*"', '""', t)
+    t = re.sub(r"#=.*?=#", "", t, flags=re.S)
+    return re.sub(r"#[^\n]*", "", t)
+
+
+def _match_paren(t, i):
+    d = 0
+    for j in range(i, len(t)):
+        c = t[j]
+        if c in "([{":
+            d += 1
+        elif c in ")]}":
+            d -= 1
+            if d == 0:
+                return j
+    return -1
+
+
+def _split_top(s):
+    out, d, cur, semi = [], 0, "", None
+    for c in s:
+        if c in "([{":
+            d += 1
+        elif c in ")]}":
+            d -= 1
+        if d == 0 and c in ",;":
+            out.append(cur)
+            cur = ""
+            if c == ";" and semi is None:
+                semi = len(out)
+            continue
+        cur += c
+    if cur.strip():
+        out.append(cur)
+    return out, semi
+
+
+def internal_call_arity(text: str, known_elsewhere: set) -> list:
+    """[(name, positional args at the call, [(min, max) per definition], line)] for calls no definition accepts."""
+    g = strip_comments_and_strings(text)
+    has_default = lambda p: "=" in re.sub(r"[<>=!]=|<:|=>", "", p)
+    defs, spans = {}, []
+    for m in re.finditer(r"(?m)^[ \t]*(?:@inline[ \t]+)?(function[ \t]+)?((?:[A-Za-z_][A-Za-z0-9_]*\.)*)([A-Za-z_][A-Za-z0-9_!]*)[ \t]*(\{[^}\n]*\})?\(", g):
+        i = m.end() - 1
+        j = _match_paren(g, i)
+        if j < 0:
+            continue
+        short = re.match(r"\s*(?:::[^=\n]+?)?\s*(?:where\s*(?:\{[^}]*\}|[A-Za-z_]\w*(?:<:[^=\s]+)?))?\s*=(?!=)", g[j + 1:j + 200])
+        if not (m.group(1) or short):
+            continue
+        params, semi = _split_top(g[i + 1:j])
+        pos = [p for p in (params[:semi] if semi is not None else params) if p.strip()]
+        req = sum(1 for p in pos if not has_default(p) and not p.strip().endswith("..."))
+        opt = sum(1 for p in pos if has_default(p))
+        var = any(p.strip().endswith("...") for p in pos)
+        defs.setdefault(m.group(3), []).append((req, 99 if var else req + opt, m.group(2)))
+        spans.append((m.start(), j))
+    for m in re.finditer(r"(?m)^[ \t]*(?:mutable[ \t]+)?struct[ \t]+([A-Za-z_]\w*)[^\n]*\n([\s\S]*?)^end", g):
+        body = m.group(2)
+        if re.search(r"\bfunction\b|\bnew\b", body):
+            continue                                # inner constructors: their own definitions count
+        nf = sum(1 for ln in body.split("\n") if ln.strip() and re.match(r"\s*(?:const\s+)?[A-Za-z_]\w*!?\s*(::|$)", ln))
+        defs.setdefault(m.group(1), []).append((nf, nf, ""))
+    internal = {n for n, v in defs.items() if n not in known_elsewhere and all(q == "" for _, _, q in v)}
+    bad = []
+    for m in re.finditer(r"\b([A-Za-z_][A-Za-z0-9_!]*)[ \t]*(\{[^}\n]*\})?\(", g):
+        name = m.group(1)
+        if name not in internal:
+            continue
+        if any(a <= m.start() <= b and g[a:m.start()].strip() in ("", "function", "@inline", "@inline function") for a, b in spans):
+            continue                                # the definition itself
+        i = m.end() - 1
+        j = _match_paren(g, i)
+        args, semi = _split_top(g[i + 1:j])
+        pos = [a for a in (args[:semi] if semi is not None else args) if a.strip() and not re.match(r"^\s*[A-Za-z_]\w*\s*=(?!=)", a)]
+        if any(a.strip().endswith("...") for a in pos):
+            continue
+        n = len(pos) + (1 if re.match(r"\s*do\b", g[j + 1:j + 6]) else 0)
+        if not any(lo <= n <= hi for lo, hi, _ in defs[name]):
+            bad.append((name, n, [(lo, hi) for lo, hi, _ in defs[name]], g.count("\n", 0, m.start()) + 1))
+    return bad

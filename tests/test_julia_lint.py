@@ -101,3 +101,25 @@ def test_every_name_the_glue_calls_is_defined_somewhere():
     refwords = set(re.findall(r"\b([A-Za-z_][A-Za-z0-9_!]*)\b", ref))
     unknown = sorted(w for w in called if w not in defined and w not in refwords and w not in BASE_NAMES and w not in JL_KEYWORDS)
     assert not unknown, unknown
+
+
+@pytest.mark.skipif(not REF, reason="/root/reference exists in the build container only")
+def test_calls_to_the_extensions_own_helpers_have_an_arity_some_definition_accepts():
+    """ADVICE r4 found a MethodError path in this file by reading. For the ~60 helper names only the extension defines (not the
+    reference, not Base), every call site's positional-argument count must fit a definition (long / short form, optional
+    arguments, varargs, struct default constructors). The check must also SEE a planted defect: dropping the last argument of
+    five such calls is reported each time."""
+    path = os.path.join(ROOT, "julia", "LinearOperatorsMXLOExt.jl")
+    text = open(path).read()
+    ref = "".join(jl_lint.strip_comments_and_strings(open(p).read()) for p in REF)
+    known = set(re.findall(r"\b([A-Za-z_][A-Za-z0-9_!]*)", ref)) | BASE_NAMES
+    assert jl_lint.internal_call_arity(text, known) == []
+    planted = 0
+    for name, good, broken in (("mxqn", "mxqn(T, 2, n;", "mxqn(T, 2;"), ("mxqn", "mxqn(T, 0, n;", "mxqn(T, 0;"),
+                               ("ScatterPlan", "ScatterPlan(didx, didx, nothing,", "ScatterPlan(didx, nothing,"),
+                               ("MXVector", "MXVector{T}(Ptr{T}(r[]), n, nothing)", "MXVector{T}(Ptr{T}(r[]), n, nothing, 0)")):
+        assert good in text, good
+        mutated = text.replace(good, broken, 1)
+        assert any(b[0] == name for b in jl_lint.internal_call_arity(mutated, known)), name
+        planted += 1
+    assert planted == 4

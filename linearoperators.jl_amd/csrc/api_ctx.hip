@@ -470,6 +470,9 @@ MXLO_API int32_t mxlo_ctx_tune(mxlo_ctx *ctx, const char *key, int64_t value) {
   } else if (!strcmp(key, "herm_nt_min_bytes")) {
     MXLO_REQUIRE(value >= 0, MXLO_EINVAL, "herm_nt_min_bytes must be >= 0");
     ctx->tune.herm_nt_min_bytes = value;
+  } else if (!strcmp(key, "house_fused_per_cu")) {
+    MXLO_REQUIRE(value == 1 || value == 2, MXLO_EINVAL, "house_fused_per_cu must be 1 or 2");
+    ctx->tune.house_fused_per_cu = (int)value;
   } else if (!strcmp(key, "herm_poll_sleep")) {
     MXLO_REQUIRE(value >= 1 && value <= 1024, MXLO_EINVAL, "herm_poll_sleep must be in 1..1024");
     ctx->tune.herm_poll_sleep = (int)value;

@@ -25,7 +25,7 @@ constexpr int kWave = 64;
 constexpr int kMaxRedCols = 128;     // columns a single reduction call may produce
 constexpr int kQnfMaxCols = 40, kQnfMaxGrid = 256;   // single-launch quasi-Newton apply: panel columns x workgroups of its exchange
 constexpr int kQnfSlots = kQnfMaxCols * kQnfMaxGrid;
-constexpr int kFusedSlots = 256;     // workgroups of a single-launch (grid-exchange) kernel: all co-resident, <= #CUs
+constexpr int kFusedSlots = 512;     // workgroups of a single-launch (grid-exchange) kernel: all co-resident (round 6: up to two per CU)
 constexpr unsigned long long kSlotEmpty = 0x7FF8DEADBEEF0001ull;   // a NaN payload no arithmetic produces (partials are canonicalised)
 constexpr int kMaxRedBlocks = 4096;  // partial slots per column in the workspace
 constexpr int kScalarSlots = 8192;   // doubles in the device scalar buffer
@@ -125,6 +125,7 @@ struct Tune {
                                        // pass's lines there (profiles/r03_sweep_nt_mid.txt: -5 ... -8 % at n = 2^21 .. 2^23)
   int red_blocks_per_cu = 4;  // reduction kernels
   int graph_direct_max = 16; // captured chains of at most this many kernel/memset nodes replay as direct launches
+  int house_fused_per_cu = 2;   // single-launch Householder: workgroups per CU it may use (2, round 6: vectors up to 2^22 doubles; 1: up to 2^21)
   int house_fused = 1;     // single-launch Householder (dot, grid exchange, update) while the vectors fit one wave of workgroups
   int cherm_two_pass = 0;  // complex opHermitian: 1 = the two-pass (rows, then columns) form instead of the strip kernel
   int house_reverse = 1;   // Householder phase B walks the vectors back-to-front (MALL tail reuse)

@@ -289,8 +289,9 @@ householder_fused_kernel(T *__restrict__ res, const T *__restrict__ h, const T *
   }
   // wait for all G partials; lane t owns slot t (G <= 256 = one slot per lane). The wait is bounded (poll_slot): a
   // peer that never becomes resident turns into a NaN result and a raised ctx fault word, not into a hung GPU.
-  double p = 0.0;
+  double p = 0.0;                      // (G <= 256: one slot per lane, as rounds 3-5 summed them; G <= 512, round 6: lane t adds slots t, t + 256)
   if (tid < G) p = __longlong_as_double((long long)poll_slot(mine + tid, ticks, fault, kFaultHouseholder));
+  if (tid + kBlock < G) p += __longlong_as_double((long long)poll_slot(mine + tid + kBlock, ticks, fault, kFaultHouseholder));
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) p += __shfl_down(p, off, 64);
   __syncthreads();                                                     // lds reuse
@@ -367,10 +368,13 @@ static int32_t householder_t(mxlo_ctx *ctx, T *res, const T *h, const T *v, int6
     MXLO_TRY(fused_fault_check(ctx));   // an earlier single-launch apply that timed out is reported (and repaired) here
   }
   if (ctx->tune.house_fused && !ctx->allreduce && n > 0 && ctx->fault_dev) {
-    const int64_t cap = std::min<int64_t>(ctx->num_cu, kFusedSlots);
+    // up to house_fused_per_cu (2) workgroups per CU: 16 vectors per lane = 160-170 registers, one wave per SIMD and workgroup,
+    // two workgroups fit a CU (the occupancy query in householder_fused_t decides; it falls back to two passes otherwise)
+    const int64_t cap = std::min<int64_t>((int64_t)ctx->num_cu * (ctx->tune.house_fused_per_cu >= 2 ? 2 : 1), kFusedSlots);
+    const int64_t cap1 = std::min<int64_t>(ctx->num_cu, kFusedSlots);
     // vectors per lane: 2 / 4 / 8 up to n = 2^20 doubles, 16 (two 2 KiB register slices per lane) up to 2^21 — beyond
     // that the slices no longer fit the register file of one co-resident wave of workgroups
-    const int vpt = fused_grid<T>(n, 2) <= 16 ? 2 : (fused_grid<T>(n, 4) <= 32 ? 4 : (fused_grid<T>(n, 8) <= cap ? 8 : 16));
+    const int vpt = fused_grid<T>(n, 2) <= 16 ? 2 : (fused_grid<T>(n, 4) <= 32 ? 4 : (fused_grid<T>(n, 8) <= cap1 ? 8 : 16));
     if (fused_grid<T>(n, vpt) <= cap) {
       bool launched = false;
       const int32_t st = householder_fused_t<T>(ctx, res, h, v, n, alpha, beta, flags, vpt, &launched);

@@ -534,12 +534,13 @@ def test_sorted_extension_and_range_kernels_bit_exact_edge_shapes(lo, dev, es):
 
 
 def test_single_launch_householder_matches_two_pass_and_oracle(lo, dev):
-    """n <= 2^20 doubles runs ONE kernel (register-resident slices + slot exchange between workgroups). Checked against the
+    """n <= 2^22 doubles (round 6; rounds 3-5: 2^21) runs ONE kernel (register-resident slices + slot exchange between workgroups). Checked against the
     oracle (1e-12 / 1e-5) and against the two-launch path (tune house_fused = 0): alternating grid sizes (slot re-arming,
     epoch flips), unaligned views, beta != 0, mixed-precision scalars, NaN partials, graph replay."""
     ctx = lo.get_ctx(dev)
     rng = np.random.default_rng(77)
-    sizes = [1, 2, 3, 255, 1024, 1025, 65_536, 4097, 1 << 20, 1000, (1 << 20) + 1, 300_001, 17]
+    # (round 6: up to TWO co-resident workgroups per CU — 257 ... 512 workgroups, n up to 2^22 doubles: the last four sizes)
+    sizes = [1, 2, 3, 255, 1024, 1025, 65_536, 4097, 1 << 20, 1000, (1 << 20) + 1, 300_001, 17, (1 << 21) + 7, 3_000_001, 1 << 22, 1 << 21]
     for dtype, tol in ((torch.float64, 1e-12), (torch.float32, 2e-5)):
         for n in sizes:
             for off in (0, 1):
@@ -563,6 +564,27 @@ def test_single_launch_householder_matches_two_pass_and_oracle(lo, dev):
                     finally:
                         ctx.tune("house_fused", 1)
                     assert rel(res.cpu().numpy(), res2.cpu().numpy()) <= tol
+    # the 257 ... 512-workgroup range really is ONE launch, and one workgroup per CU (tune house_fused_per_cu = 1) sends it to two passes
+    def launches():
+        import ctypes as C
+        a = (C.c_int64 * 12)()
+        lo._lib.call("mxlo_debug_counters", a)
+        return a[10]
+    n = 3_000_001
+    h = torch.rand(n, dtype=torch.float64, device=dev)
+    v, res = torch.rand(n, dtype=torch.float64, device=dev), torch.empty(n, dtype=torch.float64, device=dev)
+    H = lo.opHouseholder(h)
+    lo.mul(res, H, v, 1.0, 0.0)
+    l0 = launches()
+    lo.mul(res, H, v, 1.0, 0.0)
+    assert launches() - l0 == 1
+    ctx.tune("house_fused_per_cu", 1)
+    try:
+        l0 = launches()
+        lo.mul(res, H, v, 1.0, 0.0)
+        assert launches() - l0 >= 2
+    finally:
+        ctx.tune("house_fused_per_cu", 2)
     # a NaN in v poisons the dot: every element becomes NaN (and the exchange does not hang on a NaN partial)
     n = 70_000
     h = torch.full((n,), 1.0 / np.sqrt(n), dtype=torch.float64, device=dev)

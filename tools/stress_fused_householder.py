@@ -18,7 +18,7 @@ from linearoperators_jl_amd.device import get_ctx
 dev = torch.device("cuda", 0)
 ctx = get_ctx(dev)
 rng = np.random.default_rng(0)
-sizes = [1, 100, 513, 2048, 4097, 30_000, 65_536, 131_072, 300_001, 524_288, 1_048_576]
+sizes = [1, 100, 513, 2048, 4097, 30_000, 65_536, 131_072, 300_001, 524_288, 1_048_576, 2_097_159, 3_000_001, 4_194_304]   # the last three: two workgroups per CU (round 6)
 ops = {}
 for n in sizes:
     h = torch.rand(n, dtype=torch.float64, device=dev)

@@ -116,7 +116,7 @@ int32_t mxlo_ctx_info(mxlo_ctx *ctx, int64_t info[4]);
  * "dots_max_nc", "sp_xcds" (sparse apply: number of L2 domains the chunk order is banded over — 8 = one contiguous part of the chunk table per XCD of an MI355X; default 1 = plain order), "fused_timeout_ms", "fused_debug_drop" (both below), "qn_fused_small" (1: dots + finalize + coefficients of a small quasi-Newton apply in one launch), "qn_fused_max_grid" (most workgroups of that launch, 1..256, default 256: vectors up to 2^19 doubles with 4 vectors per lane; 64 was the round-3 limit), "qn_fused_batch12" (1: with 9 .. 12 panel columns on a short vector that launch takes all columns in one batch — one memory round trip less in each of its two phases), "push_wide", "push_posted" (1: push!'s few doubles of decision state are posted into mapped pinned host memory of the handle by a one-wave kernel and the host polls a sequence word behind them — falling back to a stream synchronisation after 200 us of polling, and to a plain copy from device memory (posting off for that handle from then on) should the posted words not be there after it; 0: hipMemcpyAsync + hipStreamSynchronize; 2: debug — every posting is treated as lost), "qn_persist" (1, default: a quasi-Newton apply at cache-resident sizes — n >= "qn_persist_min_n" (2^19), "qn_persist_min_bytes" (32 MiB) <= panel bytes <= "qn_persist_max_bytes" (448 MiB) — is ONE persistent launch: one 512-thread workgroup per CU owning a contiguous run of the vectors, dots -> grid exchange -> coefficients -> combine; "qn_persist_reverse" (1): its combine phase walks back to front; "qn_persist_prefetch" (0; measured slower at n <= 2^20): x and the first column batch of the first combine chunk are requested before the exchange; "qn_persist_lds" (1, default; round 6): the dots phase parks x of every chunk and the first columns of the combine order in the CU's LDS (18 tiles of 8 KiB) and the combine phase reads them from there — bit-identical to 0; "qn_persist_lds_pad": bytes of unused dynamic LDS per workgroup (a placement experiment, default 0)), "herm_order" (interior strips of opHermitian walked 0: row group by row group, 1: column block by column block — same partial layout, same results), "herm_nt" (-1, default: the strip loads of opHermitian carry the nontemporal hint except for triangles of "herm_dp_min_bytes" (96 MiB) <= bytes < "herm_nt_min_bytes" (384 MiB) — about the size of the Infinity Cache, where the next apply finds part of a default-policy stream still cached; 0 / 1: never / always nontemporal), "house_fused_per_cu" (2, default; round 6: the single-launch Householder may use two co-resident workgroups per CU — vectors up to 2^22 doubles keep their slices of h and v in registers, 24 instead of 40 B/elt; 1: one per CU, up to 2^21), "herm_poll_sleep" (4: the finishers of the single-launch opHermitian look at their last partials every 64 x this many clocks while the strips stream), "herm_strip" (0, default: tiles per strip of opHermitian by size; 1 / 2 / 8 force it — a sweep knob, results do not depend on it beyond rounding of the row partials' grouping), "herm_lds_pad" (0; occupancy experiment: bytes of unused dynamic LDS per workgroup of the opHermitian pass launch, 0..49152), "herm_single" (1, default: opHermitian on full row groups of an aligned matrix whose strict lower triangle has at most "herm_single_max_bytes" (112 MiB: f64 n <= 5120, f32 n <= 7424; "herm_single_max_n" > 0 replaces the rule by n <= that value) is ONE launch — strip workgroups publish their partial sums as self-validating slots, finisher workgroups of the same launch wait for the slots of their rows, add them in the order of the separate finish launch (bit-identical) and re-arm them), "gemv_n_rows" (1, default: dense M*v on an aligned matrix with >= 8 x 16 B of rows per CU runs as ONE launch of row bands — a workgroup owns 16 ... 128 rows across all columns, the column sum never leaves it; 0: the two-launch column-chunk schedule; 8/16/32 x (16 / sizeof(T)): that band height, for sweeps), "kron_fuse" (1, default: both GEMMs of a kron apply whose tiles fit one per CU run in ONE launch — a row block of the first product is produced and consumed by workgroups of one XCD, published through a counter in that XCD's L2, no device-wide barrier; bounded wait + fault word like every single-launch form; 0: two launches; 2: timing experiment without the wait, wrong results), "gemvb_n_rows" (1, default: the block apply M*V of a dense operator runs where M*v takes its 512- / 256-byte row bands as ONE launch of those bands with the block of vectors staged in LDS once per workgroup — no partial workspace, every column bit-identical to M*v on that column; 0: the column-chunk schedule + finish launch), "gemvb_t_lds" (1, default: the transposed block apply of a dense operator with >= 4 columns stages the block of vectors in LDS once per workgroup), "combine_reverse" (0, default: the combine pass of a four-launch apply walks front to back; 1 measured no gain), "push_fused" (1: streaming push! schedules — L-BFGS: new pair held per lane, in-pass inserts; L-SR1: panels once, y - B s never stored, inserts ride in the rebuild; 0: the copies + dots schedules they replaced). Unknown key or out-of-range value -> MXLO_EINVAL.
  * "house_fused" / "qn_fused_small" = 0 is also the setting for MORE than two processes sharing one GPU: the workgroups of a
  * single-launch apply wait for each other, so a launch must be resident as a whole; two of the largest Householder launches
- * (256 workgroups of 179-209 VGPRs: 2^20 < n <= 2^21 doubles; four of those up to 2^20) or two quasi-Newton ones (up to 256
+ * (256 workgroups of 179-209 VGPRs: 2^20 < n <= 2^21 doubles; four of those up to 2^20 — since round 6 a launch for 2^21 < n <= 2^22 doubles takes the WHOLE chip itself, two workgroups per CU, "house_fused_per_cu"; and the persistent quasi-Newton apply with LDS parking, "qn_persist_lds", owns every CU's LDS: ONE of either at a time) or two quasi-Newton ones (up to 256
  * workgroups of 166-224 VGPRs since round 4; twelve of the 64-workgroup launches of short vectors) fit on the chip at once, beyond that two launches could each be partly resident and wait for each other —
  * until the bounded wait below ends them. (They are never used with an all-reduce hook installed.)
  * That wait is BOUNDED: "fused_timeout_ms" (default 2000, 1..600000) is how long a workgroup polls for a peer's partial before

@@ -178,6 +178,55 @@ def test_hermitian_strip_order_does_not_change_a_bit(lo, dev, dtype, n):
     assert torch.equal(got[0][0], got[1][0]) and torch.equal(got[0][1], got[1][1])
 
 
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32, torch.complex128])
+@pytest.mark.parametrize("n", [1000, 2048, 4096])
+def test_hermitian_load_policy_poll_interval_and_strip_width_do_not_change_the_result(lo, dev, dtype, n):
+    """Round 6, second half: the strip loads carry the nontemporal hint or not by triangle size (tune key herm_nt — a TEMPLATE
+    parameter of the pass kernels: under a run-time flag hipcc merged the two load sequences and dropped the hint), the
+    finishers of the single launch poll every `herm_poll_sleep` x 64 clocks, and the single launch takes 2-tile strips from
+    1.25 per CU on. The first two cannot change a bit (single and block applies); the strip width regroups the row partials:
+    1e-12 / 3e-5 against the default."""
+    g = torch.Generator(device="cpu").manual_seed(n + 7)
+    rdt = {torch.float64: torch.float64, torch.float32: torch.float32, torch.complex128: torch.float64}[dtype]
+    mk = lambda *shape: ((torch.rand(*shape, dtype=rdt, generator=g) - 0.5) if not dtype.is_complex
+                         else torch.complex(torch.rand(*shape, dtype=rdt, generator=g) - 0.5, torch.rand(*shape, dtype=rdt, generator=g) - 0.5))
+    M = mk(n, n).to(dev).t()
+    d = (torch.rand(n, dtype=rdt, generator=g) - 0.5).to(dev)
+    x = mk(n).to(dev)
+    H = lo.opHermitian(d, M)
+    ctx = lo.get_ctx(dev)
+
+    def run():
+        r = torch.empty(n, dtype=dtype, device=dev)
+        lo.mul(r, H, x, 0.7, 0.0)
+        if dtype.is_complex:
+            return r, None
+        V = (torch.rand(3, n, dtype=dtype, generator=torch.Generator(device="cpu").manual_seed(1)) - 0.5).to(dev).t()
+        R = torch.empty(3, n, dtype=dtype, device=dev).t()
+        lo.mul(R, H, V, 1.0, 0.0)
+        return r, R
+
+    try:
+        base = run()
+        for key, values, default in (("herm_nt", (0, 1), -1), ("herm_poll_sleep", (1, 64), 4)):
+            for val in values:
+                ctx.tune(key, val)
+                got = run()
+                assert torch.equal(got[0], base[0]) and (base[1] is None or torch.equal(got[1], base[1])), (key, val)
+            ctx.tune(key, default)
+        if not dtype.is_complex:
+            for width in (1, 2):
+                ctx.tune("herm_strip", width)
+                got = run()
+                tol = 1e-12 if dtype == torch.float64 else 3e-5
+                assert float((got[0].double() - base[0].double()).norm() / base[0].double().norm()) <= tol, width
+            ctx.tune("herm_strip", 0)
+    finally:
+        ctx.tune("herm_nt", -1)
+        ctx.tune("herm_poll_sleep", 4)
+        ctx.tune("herm_strip", 0)
+
+
 def test_hermitian_single_launch_is_bit_identical_to_the_two_launch_form(lo, dev):
     """Round 5: for full row groups of an aligned matrix (n a multiple of 256 / 512, n <= 8192)
     opHermitian is ONE launch — strip workgroups publish their partials as self-validating slots, finisher workgroups of

@@ -123,3 +123,14 @@ def test_calls_to_the_extensions_own_helpers_have_an_arity_some_definition_accep
         assert any(b[0] == name for b in jl_lint.internal_call_arity(mutated, known)), name
         planted += 1
     assert planted == 4
+
+
+def test_the_julia_excerpts_of_integration_md_are_structurally_sound():
+    """INTEGRATION.md shows the reference-side binding as Julia excerpts (the first one opens `module LinearOperatorsMXLOExt` and,
+    being an excerpt, never closes it): concatenated and closed by that one `end` they must pass the same checker."""
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    blocks = re.findall(r"```julia\n(.*?)```", text, flags=re.S)
+    assert len(blocks) >= 4
+    jl_lint.check("\n".join(blocks) + "\nend\n", "INTEGRATION.md (julia blocks)")
+    for i, b in enumerate(blocks[1:], 1):                               # the later excerpts stand on their own
+        jl_lint.check(b, f"INTEGRATION.md julia block {i}")
